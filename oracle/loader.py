@@ -1,0 +1,173 @@
+"""oracle/loader.py -- TEST INFRASTRUCTURE ONLY.
+
+ctypes access to (a) oracle/build/liboracle.so, our C restatement of the
+reference's hot path, and (b) oracle/_ref/libwmixref.so + ref_mix_driver, the
+real reference compiled from /root/reference by oracle/Makefile (present only
+where it was prebuilt).  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module; the product (wmix_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_DIR = os.path.join(HERE, "_ref")
+PORT_SO = os.path.join(HERE, "build", "liboracle.so")
+REF_SO = os.path.join(REF_DIR, "libwmixref.so")
+REF_MIX = os.path.join(REF_DIR, "ref_mix_driver")
+
+_i16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+
+
+def build_port():
+    subprocess.check_call(["make", "-s", "-C", HERE, "port"])
+
+
+def build_ref():
+    subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def have_ref_mix():
+    return os.path.exists(REF_MIX) and os.access(REF_MIX, os.X_OK)
+
+
+_port = None
+_ref = None
+
+
+def port():
+    """Our C restatement (built on demand: plain gcc, a few seconds)."""
+    global _port
+    if _port is None:
+        build_port()
+        _port = C.CDLL(PORT_SO)
+    return _port
+
+
+def ref():
+    """The real reference wrappers, pinned to the generic-C AEC kernels."""
+    global _ref
+    if _ref is None:
+        lib = C.CDLL(REF_SO)
+        assert lib.ref_pin_generic_c() == 1
+        _ref = lib
+    return _ref
+
+
+# ---------------------------------------------------------------- G.711
+def _g711(lib, name, src, out_dtype, n_arg):
+    fn = getattr(lib, name)
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    src = np.ascontiguousarray(src)
+    out = np.zeros(src.size, dtype=out_dtype)
+    r = fn(src.ctypes.data, out.ctypes.data, n_arg, 0)
+    return out, r
+
+
+def g711_encode(lib, law, pcm):
+    """law 'a'|'u'; pcm int16 -> uint8 codes via PCM2G711x(in,out,bytes,0)."""
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    return _g711(lib, "PCM2G711" + law, pcm, np.uint8, pcm.size * 2)
+
+
+def g711_decode(lib, law, codes):
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    return _g711(lib, "G711%s2PCM" % law, codes, np.int16, codes.size)
+
+
+# ---------------------------------------------------------------- wrappers (whole-run drivers)
+def run_ns(lib, chn, freq, pcm, frames_per_call, prefix="ref"):
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    out = np.empty_like(pcm)
+    n_calls = pcm.size // (frames_per_call * chn)
+    fn = getattr(lib, prefix + "_run_ns")
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_int, _i16p, _i16p, C.c_int, C.c_int]
+    rc = fn(chn, freq, pcm, out, frames_per_call, n_calls)
+    assert rc == 0, rc
+    return out
+
+
+def run_agc(lib, chn, freq, value, pcm, frames_per_call, prefix="ref"):
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    out = np.empty_like(pcm)
+    n_calls = pcm.size // (frames_per_call * chn)
+    fn = getattr(lib, prefix + "_run_agc")
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_int, C.c_int, _i16p, _i16p, C.c_int, C.c_int]
+    rc = fn(chn, freq, value, pcm, out, frames_per_call, n_calls)
+    assert rc == 0, rc
+    return out
+
+
+def run_vad(lib, chn, freq, interval_ms, pcm, frames_per_call, prefix="ref"):
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    out = np.empty_like(pcm)
+    n_calls = pcm.size // (frames_per_call * chn)
+    fn = getattr(lib, prefix + "_run_vad")
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_int, C.c_int, _i16p, _i16p, C.c_int, C.c_int]
+    rc = fn(chn, freq, interval_ms, pcm, out, frames_per_call, n_calls)
+    assert rc == 0, rc
+    return out
+
+
+def run_aec(lib, chn, freq, interval_ms, far, near, frames_per_call, delay_ms=0, prefix="ref"):
+    far = np.ascontiguousarray(far, dtype=np.int16)
+    near = np.ascontiguousarray(near, dtype=np.int16)
+    out = np.empty_like(near)
+    n_calls = near.size // (frames_per_call * chn)
+    fn = getattr(lib, prefix + "_run_aec")
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_int, C.c_int, _i16p, _i16p, _i16p, C.c_int, C.c_int, C.c_int]
+    rc = fn(chn, freq, interval_ms, far, near, out, frames_per_call, n_calls, delay_ms)
+    assert rc == 0, rc
+    return out
+
+
+def run_chain(lib, chn, freq, agc_value, stages, far, near, frames_per_call, prefix="ref"):
+    """stages bitmask: 1 NS, 2 AEC, 4 AGC, 8 VAD (daemon order, src/wmix.c:613-709)."""
+    far = np.ascontiguousarray(far, dtype=np.int16)
+    near = np.ascontiguousarray(near, dtype=np.int16)
+    out = np.empty_like(near)
+    n_calls = near.size // (frames_per_call * chn)
+    fn = getattr(lib, prefix + "_run_chain")
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint, _i16p, _i16p, _i16p, C.c_int, C.c_int]
+    rc = fn(chn, freq, agc_value, stages, far, near, out, frames_per_call, n_calls)
+    assert rc == 0, rc
+    return out
+
+
+# ---------------------------------------------------------------- reference mixer (executable)
+def ref_mix(*args, stdin=b""):
+    return subprocess.run([REF_MIX] + [str(a) for a in args], input=stdin, stdout=subprocess.PIPE, check=True).stdout
+
+
+# ---------------------------------------------------------------- shared synthetic inputs
+def fnv1a64(b):
+    h = 0xCBF29CE484222325
+    for x in bytes(b):
+        h = ((h ^ x) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def lcg_noise(seed, n, amp):
+    """32-bit LCG x=x*1664525+1013904223; sample=((x>>16)%(2A+1))-A."""
+    x = np.empty(n, dtype=np.uint64)
+    s = seed & 0xFFFFFFFF
+    # vectorised LCG via jump-ahead would be overkill: do it in chunks with python ints only for small n
+    a, c, m = 1664525, 1013904223, 0xFFFFFFFF
+    out = np.empty(n, dtype=np.int64)
+    for i in range(n):
+        s = (s * a + c) & m
+        out[i] = ((s >> 16) % (2 * amp + 1)) - amp
+    return out.astype(np.int16)

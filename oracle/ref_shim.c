@@ -1,0 +1,103 @@
+/* oracle/ref_shim.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Our own glue compiled INTO oracle/_ref/libwmixref.so next to the unmodified
+ * reference sources.  It contains no reference code; it
+ *   (1) pins WebRTC's run-time kernel selection to the generic C path
+ *       (cpu_features.cc:71-72 exports the two function
+ *       pointers; aec_core.c:1451-1455 and aec_rdft.c:574-577 consult them), and
+ *   (2) offers whole-run drivers so a Python test can push a [frames x pkt]
+ *       buffer through the reference wrappers (src/webrtc.h:32-61) in one call.
+ */
+#include <stdint.h>
+#include <stdbool.h>
+#include <stdlib.h>
+#include <string.h>
+#include "webrtc.h"
+
+extern int (*WebRtc_GetCPUInfo)(int);
+extern int (*WebRtc_GetCPUInfoNoASM)(int);
+
+__attribute__((constructor)) static void ref_pin_ctor(void) { WebRtc_GetCPUInfo = WebRtc_GetCPUInfoNoASM; }
+
+int ref_pin_generic_c(void)
+{
+    WebRtc_GetCPUInfo = WebRtc_GetCPUInfoNoASM;
+    return WebRtc_GetCPUInfo(0) == 0 && WebRtc_GetCPUInfo(1) == 0;
+}
+
+static bool g_dbg = false;
+
+/* Each driver: `n_calls` wrapper calls of `frames_per_call` frames (a frame =
+ * chn int16).  in/out are contiguous; out may alias in. Returns 0 or the first
+ * error code. */
+int ref_run_ns(int chn, int freq, const int16_t *in, int16_t *out, int frames_per_call, int n_calls)
+{
+    void *h = ns_init(chn, freq, &g_dbg);
+    if (!h) return -100;
+    size_t step = (size_t)frames_per_call * chn;
+    if (out != in) memcpy(out, in, step * n_calls * sizeof(int16_t));
+    for (int i = 0; i < n_calls; i++) ns_process(h, out + i * step, out + i * step, frames_per_call);
+    ns_release(h);
+    return 0;
+}
+
+int ref_run_agc(int chn, int freq, int value, const int16_t *in, int16_t *out, int frames_per_call, int n_calls)
+{
+    void *h = agc_init(chn, freq, 10, value, &g_dbg);
+    if (!h) return -100;
+    size_t step = (size_t)frames_per_call * chn;
+    if (out != in) memcpy(out, in, step * n_calls * sizeof(int16_t));
+    int rc = 0;
+    for (int i = 0; i < n_calls && rc == 0; i++) rc = agc_process(h, out + i * step, out + i * step, frames_per_call);
+    agc_release(h);
+    return rc;
+}
+
+int ref_run_vad(int chn, int freq, int interval_ms, const int16_t *in, int16_t *out, int frames_per_call, int n_calls)
+{
+    void *h = vad_init(chn, freq, interval_ms, &g_dbg);
+    if (!h) return -100;
+    size_t step = (size_t)frames_per_call * chn;
+    if (out != in) memcpy(out, in, step * n_calls * sizeof(int16_t));
+    for (int i = 0; i < n_calls; i++) vad_process(h, out + i * step, frames_per_call);
+    vad_release(h);
+    return 0;
+}
+
+int ref_run_aec(int chn, int freq, int interval_ms, const int16_t *far, const int16_t *near, int16_t *out,
+                int frames_per_call, int n_calls, int delay_ms)
+{
+    void *h = aec_init(chn, freq, interval_ms, &g_dbg);
+    if (!h) return -100;
+    size_t step = (size_t)frames_per_call * chn;
+    int rc = 0;
+    for (int i = 0; i < n_calls && rc == 0; i++)
+        rc = aec_process2(h, (int16_t *)far + i * step, (int16_t *)near + i * step, out + i * step, frames_per_call, delay_ms);
+    aec_release(h);
+    return rc;
+}
+
+/* The daemon's record chain (src/wmix.c:613-709): NS -> AEC -> AGC -> VAD, all in place. */
+int ref_run_chain(int chn, int freq, int agc_value, unsigned stages, const int16_t *far, const int16_t *near,
+                  int16_t *out, int frames_per_call, int n_calls)
+{
+    void *ns = (stages & 1) ? ns_init(chn, freq, &g_dbg) : NULL;
+    void *aec = (stages & 2) ? aec_init(chn, freq, 10, &g_dbg) : NULL;
+    void *agc = (stages & 4) ? agc_init(chn, freq, 10, agc_value, &g_dbg) : NULL;
+    void *vad = (stages & 8) ? vad_init(chn, freq, 10, &g_dbg) : NULL;
+    size_t step = (size_t)frames_per_call * chn;
+    int rc = 0;
+    memcpy(out, near, step * n_calls * sizeof(int16_t));
+    for (int i = 0; i < n_calls && rc == 0; i++) {
+        int16_t *p = out + i * step;
+        if (ns) ns_process(ns, p, p, frames_per_call);
+        if (aec) rc = aec_process2(aec, (int16_t *)far + i * step, p, p, frames_per_call, 0);
+        if (agc && rc == 0) rc = agc_process(agc, p, p, frames_per_call);
+        if (vad && rc == 0) vad_process(vad, p, frames_per_call);
+    }
+    if (ns) ns_release(ns);
+    if (aec) aec_release(aec);
+    if (agc) agc_release(agc);
+    if (vad) vad_release(vad);
+    return rc;
+}
