@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the wmix DSP hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+A "step" is one pass of the hot path over one batch of synthetic 10 ms frames that
+is already resident in HBM.  Streams shard across ranks with no data-path
+collective except the one RCCL broadcast of the shared AEC far-end frame
+(SURVEY.md section 8e), so scaling is weak: every rank owns the full per-GPU batch.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying
+`roofline` (dominant kernel, HIP-event timed) and `cpu_baseline` (the oracle
+timed on this box's host cores, rank 0 / N=1 only, bounded sample).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+# ----------------------------------------------------------------------------- workloads
+class G711Workload:
+    """configs[0]-style plumbing case scaled up: mu-law encode + decode round trip of
+    80-sample (10 ms @ 8 kHz) frames.  Algorithmic bytes per frame = 160 + 80 (encode)
+    + 80 + 160 (decode) = 480 B."""
+    name = "g711_ulaw_roundtrip_8k"
+    dtype = "u8"
+    frame_samples = 80
+    bytes_per_frame = 480.0
+    dominant_kernel = "g711_encode_kernel<1>"
+    dominant_bytes_per_frame = 240.0  # encode: 160 B in + 80 B out
+
+    def __init__(self, dev, n_streams, rank):
+        from wmix_amd import g711, synth
+        self.g711 = g711
+        self.n_frames = n_streams  # one 10 ms frame per stream per step
+        pcm = synth.lcg_noise(1000 + rank * 7919 + np.arange(64, dtype=np.uint64), self.n_frames * 80 // 64, 20000)
+        self.pcm = torch.from_numpy(pcm.reshape(-1)).to(dev)
+        self.code = torch.empty(self.pcm.numel(), dtype=torch.uint8, device=dev)
+        self.back = torch.empty_like(self.pcm)
+        self.ev = []
+
+    def step(self, timed):
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self.g711.encode("u", self.pcm, self.code)
+        if timed:
+            e1.record()
+            self.ev.append((e0, e1))
+        self.g711.decode("u", self.code, self.back)
+
+    def dominant_ms(self):
+        return float(np.mean([a.elapsed_time(b) for a, b in self.ev])) if self.ev else None
+
+    def config(self):
+        return {"workload": self.name, "frames_per_step_per_gpu": self.n_frames, "frame": "80 x int16 (10 ms @ 8 kHz mono)"}
+
+    def cpu_baseline(self, budget_s):
+        from oracle import loader
+        port = loader.port()
+        n = 80 * 20000
+        pcm = np.ascontiguousarray(self.pcm[:n].cpu().numpy())
+        code = np.zeros(n, np.uint8)
+        back = np.zeros(n, np.int16)
+        enc, dec = port.orc_PCM2G711u, port.orc_G711u2PCM
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < budget_s:
+            enc(C.c_void_p(pcm.ctypes.data), C.c_void_p(code.ctypes.data), n * 2, 0)
+            dec(C.c_void_p(code.ctypes.data), C.c_void_p(back.ctypes.data), n, 0)
+            reps += 1
+        dt = time.perf_counter() - t0
+        return {"value": reps * 20000 / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+                "sample": "%d x 20000 frames of 80 samples through oracle/orc_g711.c (-O2), 1 thread" % reps}
+
+
+WORKLOADS = {"g711": (G711Workload, 1 << 20)}
+DEFAULT_WORKLOAD = "g711"
+
+
+# ----------------------------------------------------------------------------- driver
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
+    ap.add_argument("--streams", type=int, default=0, help="streams (frames per step) per GPU; 0 = workload default")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    from wmix_amd import _lib
+    _lib.lib()  # no fallback: raises when the HIP library is missing
+
+    cls, default_streams = WORKLOADS[args.workload]
+    wl = cls(dev, args.streams or default_streams, rank)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        wl.step(False)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step(True)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    frames_total = wl.n_frames * args.steps * world
+    value = frames_total / elapsed
+    dom_ms = wl.dominant_ms()
+    roofline = None
+    if dom_ms:
+        achieved = wl.dominant_bytes_per_frame * wl.n_frames / (dom_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": wl.dominant_kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "avg_launch_ms": round(dom_ms, 5),
+                    "algorithmic_bytes_per_launch": wl.dominant_bytes_per_frame * wl.n_frames}
+    out = {
+        "metric": "10 ms frames/s", "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
+        "config": wl.config(), "roofline": roofline,
+        "whole_step_hbm_frac": round(value / world * wl.bytes_per_frame / 1e9 / HBM_PEAK_GBS, 5),
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = wl.cpu_baseline(args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,54 @@
+/* wmix_amd.h -- C ABI of libwmix_amd.so: the MI355X (gfx950) implementation of
+ * wmix's per-frame DSP hot path.
+ *
+ * Two layers are exported:
+ *
+ *  (1) the REFERENCE'S OWN signatures, unchanged, so the wmix daemon links
+ *      against libwmix_amd.so instead of src/webrtc.c + libwebrtc{vad,aec,ns,agc}
+ *      + src/g711codec.c (+ the two arithmetic functions of src/wmix.c).  They take
+ *      HOST pointers exactly like the reference and are thin adapters over a
+ *      batch of one stream (H2D copy, one launch, D2H copy).  Declared in
+ *      include/wmix_compat.h.
+ *
+ *  (2) the BATCHED entry points below (prefix wmx_): many independent 10 ms
+ *      streams per launch, PCM and state resident in HBM.  Plain pointers and
+ *      sizes only; `stream` is a hipStream_t passed as void* (NULL = default
+ *      stream).  All d_* pointers are DEVICE pointers.  Every function returns 0
+ *      on success, a negative value on failure (-(int)hipError_t for HIP errors,
+ *      WMX_E* otherwise); wmx_last_error() describes the last failure on the
+ *      calling thread.  There is NO CPU fallback: without a usable HIP device the
+ *      calls fail.
+ */
+#ifndef WMIX_AMD_H
+#define WMIX_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WMX_EINVAL (-10001) /* bad argument (unsupported freq / chn / size) */
+#define WMX_ENODEV (-10002) /* no HIP device */
+#define WMX_ESTATE (-10003) /* wrong handle kind */
+
+const char *wmx_last_error(void);
+int wmx_device_count(void);
+/* library/ABI version: major*10000 + minor*100 + patch */
+int wmx_version(void);
+
+/* ------------------------------------------------------------------ G.711
+ * Replaces g711{a,u}_encode / g711{a,u}_decode (src/g711codec.h:30-34,
+ * src/g711codec.c:82-216) for device-resident buffers.  law: 0 = A-law, 1 = mu-law.
+ * Bit-exact with the reference including its 16-bit-domain segment table and the
+ * negative A-law path. */
+#define WMX_LAW_A 0
+#define WMX_LAW_U 1
+int wmx_g711_encode(int law, const int16_t *d_pcm, uint8_t *d_code, size_t n_samples, void *stream);
+int wmx_g711_decode(int law, const uint8_t *d_code, int16_t *d_pcm, size_t n_codes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WMIX_AMD_H */

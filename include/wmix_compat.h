@@ -1,0 +1,34 @@
+/* wmix_compat.h -- the reference's own C signatures, exported unchanged by
+ * libwmix_amd.so (drop-in boundary).  A maintainer of wmix keeps
+ * including src/webrtc.h, src/g711codec.h and src/wmix.h; this header exists so
+ * that OUR tests and tools can bind the same symbols without the reference tree.
+ *
+ * HOST pointers, reference semantics (in==out aliasing allowed, int16
+ * interleaved, frameNum counted in frames of `chn` samples).
+ */
+#ifndef WMIX_COMPAT_H
+#define WMIX_COMPAT_H
+
+#include <stdbool.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- src/g711codec.h:24-34 (+ linear2alaw/linear2ulaw, exported by src/g711codec.c:82,120) */
+int PCM2G711a(char *InAudioData, char *OutAudioData, int DataLen, int reserve);
+int PCM2G711u(char *InAudioData, char *OutAudioData, int DataLen, int reserve);
+int G711a2PCM(char *InAudioData, char *OutAudioData, int DataLen, int reserve);
+int G711u2PCM(char *InAudioData, char *OutAudioData, int DataLen, int reserve);
+int g711a_decode(short amp[], const unsigned char g711a_data[], int g711a_bytes);
+int g711u_decode(short amp[], const unsigned char g711u_data[], int g711u_bytes);
+int g711a_encode(unsigned char g711_data[], const short amp[], int len);
+int g711u_encode(unsigned char g711_data[], const short amp[], int len);
+unsigned char linear2alaw(int pcm_val);
+unsigned char linear2ulaw(int pcm_val);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WMIX_COMPAT_H */

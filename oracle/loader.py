@@ -152,22 +152,9 @@ def ref_mix(*args, stdin=b""):
     return subprocess.run([REF_MIX] + [str(a) for a in args], input=stdin, stdout=subprocess.PIPE, check=True).stdout
 
 
-# ---------------------------------------------------------------- shared synthetic inputs
+# ---------------------------------------------------------------- hashing for golden files
 def fnv1a64(b):
     h = 0xCBF29CE484222325
     for x in bytes(b):
         h = ((h ^ x) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
     return h
-
-
-def lcg_noise(seed, n, amp):
-    """32-bit LCG x=x*1664525+1013904223; sample=((x>>16)%(2A+1))-A."""
-    x = np.empty(n, dtype=np.uint64)
-    s = seed & 0xFFFFFFFF
-    # vectorised LCG via jump-ahead would be overkill: do it in chunks with python ints only for small n
-    a, c, m = 1664525, 1013904223, 0xFFFFFFFF
-    out = np.empty(n, dtype=np.int64)
-    for i in range(n):
-        s = (s * a + c) & m
-        out[i] = ((s >> 16) % (2 * amp + 1)) - amp
-    return out.astype(np.int16)

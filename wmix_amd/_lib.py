@@ -1,0 +1,72 @@
+"""ctypes binding of libwmix_amd.so (the only compute path; no fallback)."""
+import ctypes as C
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libwmix_amd.so")
+INCLUDE_DIR = os.path.join(os.path.dirname(HERE), "include")
+
+_lib = None
+
+
+class WmxError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libwmix_amd.so.  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise WmxError(
+                "libwmix_amd.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C wmix_amd/csrc` (there is no CPU fallback)")
+        _lib = C.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().wmx_last_error().decode(errors="replace")
+        raise WmxError("%s failed (rc=%d): %s" % (what or "wmx call", rc, msg))
+
+
+def declared_symbols():
+    """Every function name declared in include/*.h (used by the ABI test)."""
+    names = []
+    for fn in sorted(os.listdir(INCLUDE_DIR)):
+        if not fn.endswith(".h"):
+            continue
+        src = open(os.path.join(INCLUDE_DIR, fn)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        src = re.sub(r"//[^\n]*", "", src)
+        src = re.sub(r"^\s*#.*$", "", src, flags=re.M)
+        for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}()]*\)\s*;", src):
+            names.append(m.group(1))
+    return sorted(set(names))
+
+
+def _declare(L):
+    vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
+    L.wmx_last_error.restype = C.c_char_p
+    L.wmx_last_error.argtypes = []
+    L.wmx_device_count.restype = i
+    L.wmx_version.restype = i
+    for name in ("wmx_g711_encode", "wmx_g711_decode"):
+        f = getattr(L, name)
+        f.restype = i
+        f.argtypes = [i, vp, vp, sz, vp]
+    for name in ("PCM2G711a", "PCM2G711u", "G711a2PCM", "G711u2PCM"):
+        f = getattr(L, name)
+        f.restype = i
+        f.argtypes = [vp, vp, i, i]
+    for name in ("g711a_encode", "g711u_encode", "g711a_decode", "g711u_decode"):
+        f = getattr(L, name)
+        f.restype = i
+        f.argtypes = [vp, vp, i]
+    for name in ("linear2alaw", "linear2ulaw"):
+        f = getattr(L, name)
+        f.restype = C.c_ubyte
+        f.argtypes = [i]

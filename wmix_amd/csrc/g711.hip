@@ -1,0 +1,189 @@
+// g711.hip -- G.711 A-law / mu-law companding on gfx950.
+//
+// Replaces linear2alaw / linear2ulaw / alaw2linear / ulaw2linear and the
+// g711x_encode / g711x_decode / PCM2G711x / G711x2PCM loops of the reference
+// (src/g711codec.c:28-308).  The arithmetic is the reference's 16-bit-domain Sun
+// variant (segment ends 0xFF..0x7FFF, no 13/14-bit prescale; negative A-law input
+// is mapped with -pcm-8 and may stay negative: SURVEY.md section 0 quirk 6); the segment
+// search is a count-leading-zeros instead of the table walk.
+//
+// Roofline: pure HBM streaming, 3 B per sample each way (2 B PCM + 1 B code).
+// One lane handles 8 samples: one 16-byte PCM access and one 8-byte code access
+// per lane, so every wave instruction moves 1 KiB / 512 B fully coalesced.
+#include "wmx_internal.h"
+
+namespace {
+
+__device__ __forceinline__ int seg_of(int v) {
+    // first i with v <= (0x100<<i)-1, i in 0..7, else 8 (src/g711codec.c:12-22)
+    if (v <= 0xFF) return 0;
+    int s = 24 - __clz(v);  // bit_length(v) - 8
+    return s > 8 ? 8 : s;
+}
+
+__device__ __forceinline__ unsigned enc_alaw(int pcm) {
+    // src/g711codec.c:82-114
+    unsigned mask = 0xD5;
+    if (pcm < 0) {
+        mask = 0x55;
+        pcm = -pcm - 8;
+    }
+    int seg = seg_of(pcm);
+    if (seg >= 8) return 0x7F ^ mask;
+    unsigned a = (unsigned)seg << 4;
+    a |= (unsigned)(pcm >> (seg < 2 ? 4 : seg + 3)) & 0xF;
+    return (a ^ mask) & 0xFF;
+}
+
+__device__ __forceinline__ unsigned enc_ulaw(int pcm) {
+    // src/g711codec.c:120-152
+    unsigned mask;
+    if (pcm < 0) {
+        pcm = 0x84 - pcm;
+        mask = 0x7F;
+    } else {
+        pcm += 0x84;
+        mask = 0xFF;
+    }
+    int seg = seg_of(pcm);
+    if (seg >= 8) return 0x7F ^ mask;
+    unsigned u = ((unsigned)seg << 4) | ((unsigned)(pcm >> (seg + 3)) & 0xF);
+    return (u ^ mask) & 0xFF;
+}
+
+__device__ __forceinline__ int dec_alaw(unsigned a) {
+    // src/g711codec.c:28-51
+    a ^= 0x55;
+    int t = (int)(a & 0xF) << 4;
+    int seg = (int)(a & 0x70) >> 4;
+    if (seg == 0)
+        t += 8;
+    else
+        t = (t + 0x108) << (seg - 1);
+    return (a & 0x80) ? t : -t;
+}
+
+__device__ __forceinline__ int dec_ulaw(unsigned u) {
+    // src/g711codec.c:62-76
+    u = ~u & 0xFF;
+    int t = ((int)(u & 0xF) << 3) + 0x84;
+    t <<= (u & 0x70) >> 4;
+    return (u & 0x80) ? (0x84 - t) : (t - 0x84);
+}
+
+template <int LAW>
+__device__ __forceinline__ unsigned enc1(int pcm) {
+    return LAW == WMX_LAW_A ? enc_alaw(pcm) : enc_ulaw(pcm);
+}
+template <int LAW>
+__device__ __forceinline__ int dec1(unsigned c) {
+    return LAW == WMX_LAW_A ? dec_alaw(c) : dec_ulaw(c);
+}
+
+// n8 = number of full 8-sample groups; `aligned` says both pointers allow the
+// wide accesses (16 B PCM / 8 B code).  The tail (< 8 samples) and the unaligned
+// case run through the scalar loop at the end.
+template <int LAW>
+__global__ __launch_bounds__(256) void g711_encode_kernel(const int16_t *__restrict__ pcm,
+                                                          uint8_t *__restrict__ code, size_t n, int aligned) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+    size_t done = 0;
+    if (aligned) {
+        const size_t n8 = n / 8;
+        const uint4 *src = reinterpret_cast<const uint4 *>(pcm);
+        uint2 *dst = reinterpret_cast<uint2 *>(code);
+        for (size_t i = tid; i < n8; i += nthreads) {
+            uint4 v = src[i];
+            unsigned w[4] = {v.x, v.y, v.z, v.w};
+            unsigned c[8];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                c[2 * k] = enc1<LAW>((int)(int16_t)(w[k] & 0xFFFF));
+                c[2 * k + 1] = enc1<LAW>((int)(int16_t)(w[k] >> 16));
+            }
+            uint2 o;
+            o.x = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
+            o.y = c[4] | (c[5] << 8) | (c[6] << 16) | (c[7] << 24);
+            dst[i] = o;
+        }
+        done = n8 * 8;
+    }
+    for (size_t i = done + tid; i < n; i += nthreads) code[i] = (uint8_t)enc1<LAW>((int)pcm[i]);
+}
+
+template <int LAW>
+__global__ __launch_bounds__(256) void g711_decode_kernel(const uint8_t *__restrict__ code,
+                                                          int16_t *__restrict__ pcm, size_t n, int aligned) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+    size_t done = 0;
+    if (aligned) {
+        const size_t n8 = n / 8;
+        const uint2 *src = reinterpret_cast<const uint2 *>(code);
+        uint4 *dst = reinterpret_cast<uint4 *>(pcm);
+        for (size_t i = tid; i < n8; i += nthreads) {
+            uint2 v = src[i];
+            unsigned w[2] = {v.x, v.y};
+            unsigned p[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                unsigned lo = (w[k / 2] >> (16 * (k & 1))) & 0xFF;
+                unsigned hi = (w[k / 2] >> (16 * (k & 1) + 8)) & 0xFF;
+                p[k] = ((unsigned)dec1<LAW>(lo) & 0xFFFF) | ((unsigned)dec1<LAW>(hi) << 16);
+            }
+            dst[i] = make_uint4(p[0], p[1], p[2], p[3]);
+        }
+        done = n8 * 8;
+    }
+    for (size_t i = done + tid; i < n; i += nthreads) pcm[i] = (int16_t)dec1<LAW>(code[i]);
+}
+
+inline bool ok16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline bool ok8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int wmx_g711_encode(int law, const int16_t *d_pcm, uint8_t *d_code, size_t n, void *stream) {
+    if (law != WMX_LAW_A && law != WMX_LAW_U) {
+        wmx::set_error("wmx_g711_encode: law must be 0 (A) or 1 (mu), got %d", law);
+        return WMX_EINVAL;
+    }
+    if (n == 0) return 0;
+    if (!d_pcm || !d_code) {
+        wmx::set_error("wmx_g711_encode: null buffer");
+        return WMX_EINVAL;
+    }
+    const int aligned = ok16(d_pcm) && ok8(d_code);
+    const unsigned block = 256, grid = wmx::stream_grid((n + 7) / 8, block);
+    if (law == WMX_LAW_A)
+        hipLaunchKernelGGL(g711_encode_kernel<WMX_LAW_A>, dim3(grid), dim3(block), 0, wmx::as_stream(stream), d_pcm, d_code, n, aligned);
+    else
+        hipLaunchKernelGGL(g711_encode_kernel<WMX_LAW_U>, dim3(grid), dim3(block), 0, wmx::as_stream(stream), d_pcm, d_code, n, aligned);
+    WMX_LAUNCH_CHECK();
+    return 0;
+}
+
+int wmx_g711_decode(int law, const uint8_t *d_code, int16_t *d_pcm, size_t n, void *stream) {
+    if (law != WMX_LAW_A && law != WMX_LAW_U) {
+        wmx::set_error("wmx_g711_decode: law must be 0 (A) or 1 (mu), got %d", law);
+        return WMX_EINVAL;
+    }
+    if (n == 0) return 0;
+    if (!d_pcm || !d_code) {
+        wmx::set_error("wmx_g711_decode: null buffer");
+        return WMX_EINVAL;
+    }
+    const int aligned = ok16(d_pcm) && ok8(d_code);
+    const unsigned block = 256, grid = wmx::stream_grid((n + 7) / 8, block);
+    if (law == WMX_LAW_A)
+        hipLaunchKernelGGL(g711_decode_kernel<WMX_LAW_A>, dim3(grid), dim3(block), 0, wmx::as_stream(stream), d_code, d_pcm, n, aligned);
+    else
+        hipLaunchKernelGGL(g711_decode_kernel<WMX_LAW_U>, dim3(grid), dim3(block), 0, wmx::as_stream(stream), d_code, d_pcm, n, aligned);
+    WMX_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,39 @@
+// wmx_core.hip -- error plumbing and device queries for libwmix_amd.so.
+#include "wmx_internal.h"
+
+namespace wmx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    set_error("HIP error %d (%s) at %s:%d in %s", (int)e, hipGetErrorString(e), file, line, what);
+    (void)hipGetLastError();  // clear the sticky per-thread error
+    return e == hipErrorNoDevice ? WMX_ENODEV : -(int)e;
+}
+
+}  // namespace wmx
+
+extern "C" {
+
+const char *wmx_last_error(void) { return wmx::g_err; }
+
+int wmx_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        wmx::hip_fail(e, "hipGetDeviceCount", __FILE__, __LINE__);
+        return 0;
+    }
+    return n;
+}
+
+int wmx_version(void) { return 100; }
+
+}  // extern "C"

@@ -1,0 +1,34 @@
+// wmx_internal.h -- shared host-side helpers for libwmix_amd.so (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include "../../include/wmix_amd.h"
+
+namespace wmx {
+
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Grid size for a grid-stride, HBM-bound kernel: enough workgroups to fill
+// 256 CUs x 8 (guide: Guideline 11), never more than the work needs.
+inline unsigned stream_grid(size_t work_items, unsigned block) {
+    size_t need = (work_items + block - 1) / block;
+    size_t cap = 256u * 8u;
+    if (need < 1) need = 1;
+    return (unsigned)(need < cap ? need : cap);
+}
+
+}  // namespace wmx
+
+#define WMX_HIP(expr)                                                         \
+    do {                                                                      \
+        hipError_t _e = (expr);                                               \
+        if (_e != hipSuccess) return wmx::hip_fail(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+#define WMX_LAUNCH_CHECK() WMX_HIP(hipGetLastError())
