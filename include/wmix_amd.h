@@ -48,6 +48,33 @@ int wmx_version(void);
 int wmx_g711_encode(int law, const int16_t *d_pcm, uint8_t *d_code, size_t n_samples, void *stream);
 int wmx_g711_decode(int law, const uint8_t *d_code, int16_t *d_pcm, size_t n_codes, void *stream);
 
+/* ------------------------------------------------------------------ NS (float noise suppressor)
+ * Batched form of ns_init / ns_process / ns_release (src/webrtc.h:47-51, src/webrtc.c:560-661):
+ * n_streams independent streams, each with the state WebRtcNs_Create/Init/set_policy(2) would
+ * give it.  freq in {8000,16000,32000}, chn in {1,2}; anything else -> WMX_EINVAL (ns_init
+ * returns NULL there).  A packet is 10 ms = freq/100 frames of chn interleaved int16.
+ *
+ * wmx_ns_process runs n_packets consecutive packets of every stream in one launch.  Packet p of
+ * stream s starts at d_in + s*stream_stride + p*packet_stride (strides in int16 elements), same
+ * for d_out; d_out may alias d_in (the daemon always processes in place).  Reference quirks are
+ * kept: the right channel of a 2-channel stream is treated as a high band, and at 32 kHz only the
+ * first 160 frames of each packet are processed, the rest of the output packet is zero
+ * (SURVEY.md section 0 quirks 2-3).
+ *
+ * wmx_ns_set_ordered(h, 1) (default) adds every spectral/time sum in the reference's index order:
+ * bit-exact with the CPU path.  0 lets the wave add in parallel: <= 1 LSB at the output. */
+typedef struct wmx_ns wmx_ns;
+int wmx_ns_create(wmx_ns **out, int n_streams, int chn, int freq);
+int wmx_ns_destroy(wmx_ns *h);
+int wmx_ns_set_ordered(wmx_ns *h, int ordered);
+int wmx_ns_packet_samples(const wmx_ns *h); /* int16 elements per packet = freq/100*chn */
+int wmx_ns_process(wmx_ns *h, const int16_t *d_in, int16_t *d_out, int n_packets, long stream_stride,
+                   long packet_stride, void *stream);
+/* debugging / tests: copy one stream's state block (layout: wmix_amd/csrc/ns_layout.h) and its
+ * 3 x 1000 histogram counters to host memory (either pointer may be NULL). */
+int wmx_ns_state_words(const wmx_ns *h);
+int wmx_ns_export_state(const wmx_ns *h, int stream_index, float *host_words, unsigned short *host_hist);
+
 #ifdef __cplusplus
 }
 #endif

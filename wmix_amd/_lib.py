@@ -58,6 +58,20 @@ def _declare(L):
         f = getattr(L, name)
         f.restype = i
         f.argtypes = [i, vp, vp, sz, vp]
+    L.wmx_ns_create.restype = i
+    L.wmx_ns_create.argtypes = [C.POINTER(vp), i, i, i]
+    L.wmx_ns_destroy.restype = i
+    L.wmx_ns_destroy.argtypes = [vp]
+    L.wmx_ns_set_ordered.restype = i
+    L.wmx_ns_set_ordered.argtypes = [vp, i]
+    L.wmx_ns_packet_samples.restype = i
+    L.wmx_ns_packet_samples.argtypes = [vp]
+    L.wmx_ns_state_words.restype = i
+    L.wmx_ns_state_words.argtypes = [vp]
+    L.wmx_ns_export_state.restype = i
+    L.wmx_ns_export_state.argtypes = [vp, i, vp, vp]
+    L.wmx_ns_process.restype = i
+    L.wmx_ns_process.argtypes = [vp, vp, vp, i, C.c_long, C.c_long, vp]
     for name in ("PCM2G711a", "PCM2G711u", "G711a2PCM", "G711u2PCM"):
         f = getattr(L, name)
         f.restype = i

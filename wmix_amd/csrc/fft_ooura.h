@@ -1,0 +1,338 @@
+// fft_ooura.h -- the reference's split-radix real FFT, re-expressed for one wavefront.
+//
+// The float paths of the reference transform with Ooura's rdft (NS: n = 128 | 256,
+// W:common_audio/fft4g.c:324-361; AEC: the n = 128 specialisation with frozen tables,
+// W:modules/audio_processing/aec/aec_rdft.c:32-563).  NS and AEC feed the spectra back
+// into threshold decisions, so we keep the reference's exact dataflow graph: every
+// output element is produced by the same float operations in the same order, hence
+// bit-identical results (compiled with -ffp-contract=off).  What changes is WHO computes
+// what: the n/2 complex points live in LDS and each lane of the wave evaluates one
+// radix-4 butterfly (or one conjugate pair of the real split) per pass.
+//
+//   pass 1      : fft4g.c:1002-1104 cft1st   (stride 1), bit reversal (fft4g.c:693-790)
+//                 fused into its gather
+//   passes 2..  : fft4g.c:1107-1231 cftmdl   (stride 4, 16)
+//   closing pass: fft4g.c:913-948 / 963-998  (radix-4 when 4*stride == n/2, else radix-2;
+//                 the inverse uses cftbsub's conjugating form)
+//   real split  : fft4g.c:1234-1284 rftfsub / rftbsub
+//
+// Host side: FftTables is filled by fft_tables_ooura() (makewt/makect, fft4g.c:642-690,
+// same libm calls as the reference) or fft_tables_aec128() (frozen rdft_w).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstring>
+
+namespace wmx {
+
+struct FftTables {
+    float w2;           // w[2]: twiddle of the "block 1" special butterfly
+    float pad[3];
+    float W1[32][2];    // per radix-4 block index b >= 2 (b < n/8)
+    float W2[32][2];
+    float W3[32][2];
+    float c[64];        // real-split table, n/4 entries (+ c[n/4] unused)
+};
+static_assert(sizeof(FftTables) == (4 + 64 * 3 + 64) * 4, "FftTables layout");
+constexpr int kFftTableWords = sizeof(FftTables) / 4;
+
+// ---------------------------------------------------------------- host: table builders
+inline int host_bitrev(int q, int bits) {
+    int r = 0;
+    for (int b = 0; b < bits; b++)
+        if (q & (1 << b)) r |= 1 << (bits - 1 - b);
+    return r;
+}
+
+inline void host_expand_twiddles(const float *w, int n, FftTables *t) {
+    volatile float tmp;  // force float rounding of every product (no host FMA contraction)
+    t->w2 = w[2];
+    for (int b = 2; b < n / 8; b++) {
+        int k1 = 2 * (b >> 1), k2 = 2 * k1;
+        float wk2r = w[k1], wk2i = w[k1 + 1], wk1r, wk1i, two;
+        if ((b & 1) == 0) {
+            wk1r = w[k2];
+            wk1i = w[k2 + 1];
+            two = 2 * wk2i;
+            t->W2[b][0] = wk2r;
+            t->W2[b][1] = wk2i;
+        } else {
+            wk1r = w[k2 + 2];
+            wk1i = w[k2 + 3];
+            two = 2 * wk2r;
+            t->W2[b][0] = -wk2i;
+            t->W2[b][1] = wk2r;
+        }
+        tmp = two * wk1i;
+        t->W3[b][0] = wk1r - tmp;
+        tmp = two * wk1r;
+        t->W3[b][1] = tmp - wk1i;
+        t->W1[b][0] = wk1r;
+        t->W1[b][1] = wk1i;
+    }
+}
+
+// fft4g.c:642-690 makewt(n/4) + makect(n/4)
+inline void fft_tables_ooura(int n, FftTables *t) {
+    std::memset(t, 0, sizeof(*t));
+    float w[64];
+    const int nw = n >> 2, nwh = nw >> 1;
+    {
+        float delta = (float)atan(1.0f) / nwh;
+        w[0] = 1;
+        w[1] = 0;
+        w[nwh] = (float)cos(delta * nwh);
+        w[nwh + 1] = w[nwh];
+        for (int j = 2; j < nwh; j += 2) {
+            float x = (float)cos(delta * j), y = (float)sin(delta * j);
+            w[j] = x;
+            w[j + 1] = y;
+            w[nw - j] = y;
+            w[nw - j + 1] = x;
+        }
+        int bits = 0;
+        while ((1 << bits) < nwh) bits++;
+        for (int q = 0; q < nwh; q++) {  // bitrv2(nw, w): permute the nw/2 complex entries
+            int r = host_bitrev(q, bits);
+            if (r > q) {
+                float a = w[2 * q], b = w[2 * q + 1];
+                w[2 * q] = w[2 * r];
+                w[2 * q + 1] = w[2 * r + 1];
+                w[2 * r] = a;
+                w[2 * r + 1] = b;
+            }
+        }
+    }
+    {
+        const int nc = n >> 2, nch = nc >> 1;
+        float delta = (float)atan(1.0f) / nch;
+        t->c[0] = (float)cos(delta * nch);
+        t->c[nch] = 0.5f * t->c[0];
+        for (int j = 1; j < nch; j++) {
+            t->c[j] = 0.5f * (float)cos(delta * j);
+            t->c[nc - j] = 0.5f * (float)sin(delta * j);
+        }
+    }
+    host_expand_twiddles(w, n, t);
+}
+
+// aec_rdft.c:32-49: frozen rdft_w[64] (IEEE-754 bit patterns; 8 entries differ by 1 ulp
+// from what makewt/makect(128) give with today's libm, so the table is data).
+inline void fft_tables_aec128(FftTables *t) {
+    static const unsigned kW[64] = {
+        0x3f800000, 0x00000000, 0x3f3504f3, 0x3f3504f3, 0x3f6c835f, 0x3ec3ef16, 0x3ec3ef16, 0x3f6c835f,
+        0x3f7b14be, 0x3e47c5c2, 0x3f0e39da, 0x3f54db31, 0x3f54db31, 0x3f0e39da, 0x3e47c5c2, 0x3f7b14be,
+        0x3f7ec46d, 0x3dc8bd36, 0x3f22679a, 0x3f45e403, 0x3f61c598, 0x3ef15aea, 0x3e94a031, 0x3f74fa0b,
+        0x3f74fa0b, 0x3e94a031, 0x3ef15aea, 0x3f61c598, 0x3f45e403, 0x3f22679a, 0x3dc8bd36, 0x3f7ec46d,
+        0x3f3504f3, 0x3effb10f, 0x3efec46d, 0x3efd3aac, 0x3efb14be, 0x3ef853f8, 0x3ef4fa0b, 0x3ef10908,
+        0x3eec835f, 0x3ee76bd7, 0x3ee1c598, 0x3edb941a, 0x3ed4db31, 0x3ecd9f02, 0x3ec5e403, 0x3ebdaefa,
+        0x3eb504f3, 0x3eabeb4a, 0x3ea2679a, 0x3e987fc0, 0x3e8e39da, 0x3e839c3d, 0x3e715aea, 0x3e5ae880,
+        0x3e43ef16, 0x3e2c7cd4, 0x3e14a031, 0x3df8cfcd, 0x3dc7c5c2, 0x3d964083, 0x3d48bd36, 0x3cc8fb30,
+    };
+    std::memset(t, 0, sizeof(*t));
+    float w[64];
+    std::memcpy(w, kW, sizeof(w));
+    std::memcpy(t->c, w + 32, 32 * sizeof(float));
+    host_expand_twiddles(w, 128, t);
+}
+
+// ---------------------------------------------------------------- device: one wave, data in LDS
+// `a` points to n floats in LDS owned by this wave (packed complex, reference layout);
+// `T` points to the FftTables copy in LDS.  Every lane of the wave must call.  The callers
+// bracket these with __syncthreads() (one wave per workgroup: a cheap fence that stops the
+// compiler from moving LDS reads across other lanes' writes).
+
+__device__ __forceinline__ int dev_bitrev(int q, int bits) { return (int)(__brev((unsigned)q) >> (32 - bits)); }
+
+// One full radix-4 butterfly on complex points p0 + {0,1,2,3}*hc with inputs already in
+// registers.  b = block index (twiddle class).  INV_CLOSE selects cftbsub's closing form.
+struct Cx { float r, i; };
+
+__device__ __forceinline__ void bfly4_store(float *a, int p0, int hc, int b, const FftTables *T, Cx A, Cx B, Cx C, Cx D) {
+    const int p1 = p0 + hc, p2 = p1 + hc, p3 = p2 + hc;
+    const float x0r = A.r + B.r, x0i = A.i + B.i, x1r = A.r - B.r, x1i = A.i - B.i;
+    const float x2r = C.r + D.r, x2i = C.i + D.i, x3r = C.r - D.r, x3i = C.i - D.i;
+    float2 o0, o1, o2, o3;
+    o0.x = x0r + x2r;
+    o0.y = x0i + x2i;
+    if (b == 0) {
+        o2.x = x0r - x2r;
+        o2.y = x0i - x2i;
+        o1.x = x1r - x3i;
+        o1.y = x1i + x3r;
+        o3.x = x1r + x3i;
+        o3.y = x1i - x3r;
+    } else if (b == 1) {
+        const float w = T->w2;
+        o2.x = x2i - x0i;
+        o2.y = x0r - x2r;
+        float tr = x1r - x3i, ti = x1i + x3r;
+        o1.x = w * (tr - ti);
+        o1.y = w * (tr + ti);
+        tr = x3i + x1r;
+        ti = x3r - x1i;
+        o3.x = w * (ti - tr);
+        o3.y = w * (ti + tr);
+    } else {
+        const float w1r = T->W1[b][0], w1i = T->W1[b][1], w2r = T->W2[b][0], w2i = T->W2[b][1];
+        const float w3r = T->W3[b][0], w3i = T->W3[b][1];
+        float tr = x0r - x2r, ti = x0i - x2i;
+        o2.x = w2r * tr - w2i * ti;
+        o2.y = w2r * ti + w2i * tr;
+        tr = x1r - x3i;
+        ti = x1i + x3r;
+        o1.x = w1r * tr - w1i * ti;
+        o1.y = w1r * ti + w1i * tr;
+        tr = x1r + x3i;
+        ti = x1i - x3r;
+        o3.x = w3r * tr - w3i * ti;
+        o3.y = w3r * ti + w3i * tr;
+    }
+    *reinterpret_cast<float2 *>(a + 2 * p0) = o0;
+    *reinterpret_cast<float2 *>(a + 2 * p1) = o1;
+    *reinterpret_cast<float2 *>(a + 2 * p2) = o2;
+    *reinterpret_cast<float2 *>(a + 2 * p3) = o3;
+}
+
+__device__ __forceinline__ Cx ld_cx(const float *a, int p) {
+    float2 v = *reinterpret_cast<const float2 *>(a + 2 * p);
+    return Cx{v.x, v.y};
+}
+
+// The complex passes (bitrv2 + cftfsub / cftbsub) for NC = n/2 complex points.
+template <int NC, bool INVERSE>
+__device__ __forceinline__ void fft_complex_passes(float *a, const FftTables *T, int lane) {
+    constexpr int BITS = (NC == 128) ? 7 : 6;
+    constexpr int NB = NC / 4;  // butterflies per radix-4 pass
+    // pass 1: stride 1, gathering from bit-reversed positions.  rev(4g + j) over BITS bits =
+    // rev(g) over BITS-2 bits + {0, NC/2, NC/4, 3NC/4}[j].
+    {
+        Cx A, B, C, D;
+        const bool act = lane < NB;
+        if (act) {
+            const int r0 = dev_bitrev(lane, BITS - 2);
+            A = ld_cx(a, r0);
+            B = ld_cx(a, r0 + NC / 2);
+            C = ld_cx(a, r0 + NC / 4);
+            D = ld_cx(a, r0 + 3 * NC / 4);
+        }
+        __syncthreads();
+        if (act) bfly4_store(a, 4 * lane, 1, lane, T, A, B, C, D);
+        __syncthreads();
+    }
+    // twiddled passes with stride 4, 16 while 4*hc < NC
+#pragma unroll
+    for (int hc = 4; hc * 4 < NC; hc *= 4) {
+        if (lane < NB) {
+            const int b = lane / hc, j = lane % hc, p0 = b * 4 * hc + j;
+            bfly4_store(a, p0, hc, b, T, ld_cx(a, p0), ld_cx(a, p0 + hc), ld_cx(a, p0 + 2 * hc), ld_cx(a, p0 + 3 * hc));
+        }
+        __syncthreads();
+    }
+    constexpr int HC = (NC == 128) ? 64 : 16;  // stride of the closing pass
+    if constexpr (HC * 4 == NC) {
+        // closing radix-4 without twiddles (fft4g.c:913-934 / 963-984)
+        if (lane < HC) {
+            const int p0 = lane, p1 = p0 + HC, p2 = p1 + HC, p3 = p2 + HC;
+            const Cx A = ld_cx(a, p0), B = ld_cx(a, p1), C = ld_cx(a, p2), D = ld_cx(a, p3);
+            const float x0r = A.r + B.r, x1r = A.r - B.r, x2r = C.r + D.r, x2i = C.i + D.i, x3r = C.r - D.r,
+                        x3i = C.i - D.i;
+            float2 o0, o1, o2, o3;
+            if constexpr (!INVERSE) {
+                const float x0i = A.i + B.i, x1i = A.i - B.i;
+                o0 = make_float2(x0r + x2r, x0i + x2i);
+                o2 = make_float2(x0r - x2r, x0i - x2i);
+                o1 = make_float2(x1r - x3i, x1i + x3r);
+                o3 = make_float2(x1r + x3i, x1i - x3r);
+            } else {
+                const float x0i = -A.i - B.i, x1i = -A.i + B.i;
+                o0 = make_float2(x0r + x2r, x0i - x2i);
+                o2 = make_float2(x0r - x2r, x0i + x2i);
+                o1 = make_float2(x1r - x3i, x1i - x3r);
+                o3 = make_float2(x1r + x3i, x1i + x3r);
+            }
+            *reinterpret_cast<float2 *>(a + 2 * p0) = o0;
+            *reinterpret_cast<float2 *>(a + 2 * p1) = o1;
+            *reinterpret_cast<float2 *>(a + 2 * p2) = o2;
+            *reinterpret_cast<float2 *>(a + 2 * p3) = o3;
+        }
+    } else {
+        // closing radix-2 (fft4g.c:936-947 / 986-997), HC == NC/2
+        if (lane < HC) {
+            const int p0 = lane, p1 = lane + HC;
+            const Cx A = ld_cx(a, p0), B = ld_cx(a, p1);
+            float2 o0, o1;
+            if constexpr (!INVERSE) {
+                o0 = make_float2(A.r + B.r, A.i + B.i);
+                o1 = make_float2(A.r - B.r, A.i - B.i);
+            } else {
+                o0 = make_float2(A.r + B.r, -A.i - B.i);
+                o1 = make_float2(A.r - B.r, -A.i + B.i);
+            }
+            *reinterpret_cast<float2 *>(a + 2 * p0) = o0;
+            *reinterpret_cast<float2 *>(a + 2 * p1) = o1;
+        }
+    }
+    __syncthreads();
+}
+
+// fft4g.c:1234-1284 rftfsub / rftbsub: conjugate pairs (q, NC - q), q = 1 .. NC/2 - 1.
+template <int NC, bool INVERSE>
+__device__ __forceinline__ void fft_real_split(float *a, const FftTables *T, int lane) {
+    constexpr int NQ = NC / 2;  // table length n/4
+    if (lane >= 1 && lane < NQ) {
+        const int j = 2 * lane, k = 2 * NC - j;
+        const float wkr = 0.5f - T->c[NQ - lane], wki = T->c[lane];
+        const float aj = a[j], aj1 = a[j + 1], ak = a[k], ak1 = a[k + 1];
+        const float xr = aj - ak, xi = aj1 + ak1;
+        if constexpr (!INVERSE) {
+            const float yr = wkr * xr - wki * xi, yi = wkr * xi + wki * xr;
+            a[j] = aj - yr;
+            a[j + 1] = aj1 - yi;
+            a[k] = ak + yr;
+            a[k + 1] = ak1 - yi;
+        } else {
+            const float yr = wkr * xr + wki * xi, yi = wkr * xi - wki * xr;
+            a[j] = aj - yr;
+            a[j + 1] = yi - aj1;
+            a[k] = ak + yr;
+            a[k + 1] = yi - ak1;
+        }
+    }
+    if constexpr (INVERSE) {
+        if (lane == 0) {
+            a[1] = -a[1];
+            a[NC + 1] = -a[NC + 1];
+        }
+    }
+    __syncthreads();
+}
+
+// WebRtc_rdft(n, +1, a) / aec_rdft_forward_128(a).  n = 2*NC.
+template <int NC>
+__device__ __forceinline__ void rdft_forward(float *a, const FftTables *T, int lane) {
+    fft_complex_passes<NC, false>(a, T, lane);
+    fft_real_split<NC, false>(a, T, lane);
+    if (lane == 0) {
+        const float a0 = a[0], a1 = a[1];
+        a[0] = a0 + a1;
+        a[1] = a0 - a1;
+    }
+    __syncthreads();
+}
+
+// WebRtc_rdft(n, -1, a) / aec_rdft_inverse_128(a); unnormalised like the reference.
+template <int NC>
+__device__ __forceinline__ void rdft_inverse(float *a, const FftTables *T, int lane) {
+    if (lane == 0) {
+        const float a0 = a[0], a1 = a[1];
+        const float h = 0.5f * (a0 - a1);
+        a[1] = h;
+        a[0] = a0 - h;
+    }
+    __syncthreads();
+    fft_real_split<NC, true>(a, T, lane);
+    fft_complex_passes<NC, true>(a, T, lane);
+}
+
+}  // namespace wmx

@@ -1,0 +1,889 @@
+// ns.hip -- batched float noise suppressor for gfx950: one wavefront per stream.
+//
+// Replaces, for many independent streams per launch, what wmix's ns_process() does per
+// 10 ms packet (src/webrtc.c:612-644): WebRtcNs_Analyze(in[0]) followed by
+// WebRtcNs_Process(in, chn, out) of the vendored float NS
+// (W:modules/audio_processing/ns/ns_core.c:1043-1181 AnalyzeCore, :1183-1415 ProcessCore,
+// policy 2 set by ns_init, src/webrtc.c:532,577).
+//
+// Mapping.  A stream's spectrum has 65 (8 kHz) or 129 (16/32 kHz) bins; lane k of the
+// wave owns bins k, k+64 (and lane 0 bin 128).  Per-bin state is read from / written to
+// HBM exactly once per frame with 256-byte coalesced accesses; the three Ooura FFT
+// work arrays, the reduction staging and the FFT tables live in LDS (about 5 KB per wave).
+// All per-stream scalars and control flow (start-up phases, zero-energy early-out,
+// histogram windows) are wave-uniform, so streams in different states never diverge
+// inside a wave.
+//
+// Because wmix always hands the SAME frame to Analyze and Process, analyzeBuf == dataBuf
+// and magnPrevAnalyze == magnPrevProcess at all times (both start at zero and receive
+// identical updates, ns_core.c:1069,1228 and :1180,1298), so one window+FFT serves both
+// halves and one copy of each is kept in the state.  `noise`, `speechProb` and
+// `parametricNoise` are only consumed inside the frame that produces them and are not
+// state here.
+//
+// Numerics.  Same float expressions as the reference, -ffp-contract=off, the reference's
+// double-precision libm calls (log/exp/tanh/pow/sqrt) evaluated in double.  Sums over
+// bins/samples are where a parallel machine wants a different order: with ORDERED=true the
+// kernel adds in the reference's index order (bit-exact against the CPU path); with
+// ORDERED=false each lane adds its own elements and the wave combines them by a butterfly
+// (differences of a few ulp in the sums, <= 1 LSB at the output).
+#include <cmath>
+#include <vector>
+#include "wmx_internal.h"
+#include "fft_ooura.h"
+#include "ns_layout.h"
+
+namespace wmx {
+namespace {
+
+constexpr int kStartupShort = 50;   // defines.h:22
+constexpr int kStartupLong = 200;   // defines.h:21
+constexpr int kHistBins = 1000;     // defines.h:45
+constexpr int kUpdateWindow = 500;  // ns_core.c:188
+constexpr int kStartBand = 5;       // ns_core.c:1045
+
+template <int L>
+struct NsShared {
+    FftTables tab;                 // Ooura tables for n = L
+    float window[L];               // hybrid Hanning window (windows_private.h:64,94)
+    float logi[NsLayout<L>::MP];   // (float)log((float)i)
+    float fa[L];                   // FFT work array
+    float r0[L], r1[NsLayout<L>::MP], r2[NsLayout<L>::MP], r3[NsLayout<L>::MP], r4[NsLayout<L>::MP];
+};
+
+__device__ __forceinline__ float sat16f(float v) { return v > 32767.f ? 32767.f : (v < -32768.f ? -32768.f : v); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// sum of x[lo..hi) ; all lanes get the result.
+template <bool ORDERED>
+__device__ __forceinline__ float sum_range(const float *x, int lo, int hi, int lane) {
+    if constexpr (ORDERED) {
+        float acc = 0.f;
+        for (int i = lo; i < hi; i++) acc += x[i];
+        return acc;
+    } else {
+        float acc = 0.f;
+        for (int i = lo + lane; i < hi; i += 64) acc += x[i];
+        return wave_sum(acc);
+    }
+}
+
+template <int L, bool ORDERED>
+__device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short *__restrict__ hist,
+                         const int16_t *in, int16_t *out, const int chn, const int pkg, const int lane) {
+    using Y = NsLayout<L>;
+    constexpr int M = Y::M, B = Y::B, SLOTS = Y::SLOTS, NT = L / 64, NC = L / 2;
+    int *sti = reinterpret_cast<int *>(st);
+
+    // ---- load the packet (channel 0 = low band, channel 1 = "high band") and
+    //      slide the analysis buffer (UpdateBuffer, ns_core.c:855-873).  All loads before stores.
+    float buf[NT], hb[NT], synt[NT];
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+        const int i = lane + 64 * k;
+        buf[k] = (i < L - B) ? st[Y::IN_BUF + i + B] : (float)in[(i - (L - B)) * chn];
+        synt[k] = st[Y::SYNT_BUF + i];
+        hb[k] = 0.f;
+        if (chn == 2) hb[k] = (i < L - B) ? st[Y::HB_BUF + i + B] : (float)in[(i - (L - B)) * chn + 1];
+    }
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+        const int i = lane + 64 * k;
+        st[Y::IN_BUF + i] = buf[k];
+        if (chn == 2) st[Y::HB_BUF + i] = hb[k];
+    }
+    // window + energy (ns_core.c:1071-1072 / 1241-1242)
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+        const int i = lane + 64 * k;
+        const float w = sh.window[i] * buf[k];
+        sh.fa[i] = w;
+        sh.r0[i] = w * w;
+    }
+    __syncthreads();
+    const float energy1 = sum_range<ORDERED>(sh.r0, 0, L, lane);
+    __syncthreads();
+
+    float outv[NT];  // low-band output samples for i < B
+    float hb_gain = 1.f;
+    const bool zero_frame = (energy1 == 0.0f);
+
+    if (!zero_frame) {
+        // ===================================================== Analyze (ns_core.c:1085-1180)
+        const int block_ind = sti[Y::S_BLOCK_IND] + 1;
+        sti[Y::S_BLOCK_IND] = block_ind;
+        const int update_flag = sti[Y::S_UPDATE_FLAG];
+        const bool startup = block_ind < kStartupShort;
+
+        rdft_forward<NC>(sh.fa, &sh.tab, lane);
+
+        float re[SLOTS], im[SLOTS], magn[SLOTS], lmagn[SLOTS], noise[SLOTS], prev_est[SLOTS];
+        float snr_prior[SLOTS], snr_post[SLOTS], sprob[SLOTS], noise_prev[SLOTS], pause[SLOTS], par_noise[SLOTS];
+#pragma unroll
+        for (int s = 0; s < SLOTS; s++) {
+            const int b = lane + 64 * s;
+            re[s] = im[s] = magn[s] = lmagn[s] = 0.f;
+            if (b < M) {
+                // FFT() ns_core.c:886-911
+                if (b == 0) {
+                    re[s] = sh.fa[0];
+                    magn[s] = fabsf(re[s]) + 1.f;
+                } else if (b == M - 1) {
+                    re[s] = sh.fa[1];
+                    magn[s] = fabsf(re[s]) + 1.f;
+                } else {
+                    re[s] = sh.fa[2 * b];
+                    im[s] = sh.fa[2 * b + 1];
+                    magn[s] = sqrtf(re[s] * re[s] + im[s] * im[s]) + 1.f;
+                }
+                lmagn[s] = (float)log((double)magn[s]);
+                pause[s] = st[Y::MAGN_AVG_PAUSE + b];
+                sh.r0[b] = re[s] * re[s] + im[s] * im[s];
+                sh.r1[b] = magn[s];
+                sh.r2[b] = lmagn[s];
+                sh.r3[b] = sh.logi[b] * lmagn[s];
+                sh.r4[b] = pause[s];
+            }
+        }
+        __syncthreads();
+        // ordered reductions over the bins (ns_core.c:1089-1101, :540, :608)
+        float signal_energy, sum_magn, sum_log_magn = 0.f, sum_log_i_log_magn = 0.f, flat_num, avg_pause;
+        if constexpr (ORDERED) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f;
+            for (int i = 0; i < M; i++) {
+                a0 += sh.r0[i];
+                a1 += sh.r1[i];
+                a5 += sh.r4[i];
+                if (i >= 1) a4 += sh.r2[i];
+                if (startup && i >= kStartBand) {
+                    a2 += sh.r2[i];
+                    a3 += sh.r3[i];
+                }
+            }
+            signal_energy = a0;
+            sum_magn = a1;
+            sum_log_magn = a2;
+            sum_log_i_log_magn = a3;
+            flat_num = a4;
+            avg_pause = a5;
+        } else {
+            signal_energy = sum_range<false>(sh.r0, 0, M, lane);
+            sum_magn = sum_range<false>(sh.r1, 0, M, lane);
+            flat_num = sum_range<false>(sh.r2, 1, M, lane);
+            avg_pause = sum_range<false>(sh.r4, 0, M, lane);
+            if (startup) {
+                sum_log_magn = sum_range<false>(sh.r2, kStartBand, M, lane);
+                sum_log_i_log_magn = sum_range<false>(sh.r3, kStartBand, M, lane);
+            }
+        }
+        const float magn0 = sh.r1[0];
+        __syncthreads();
+        signal_energy = signal_energy / ((float)M);
+
+        // ---- NoiseEstimation (ns_core.c:217-285)
+        int updates = sti[Y::S_UPDATES];
+        if (updates < kStartupLong) updates++;
+        sti[Y::S_UPDATES] = updates;
+        float quant[SLOTS];
+#pragma unroll
+        for (int s = 0; s < SLOTS; s++) {
+            const int b = lane + 64 * s;
+            quant[s] = (b < M) ? st[Y::QUANTILE + b] : 0.f;
+        }
+        float last_lq[SLOTS];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int cnt = sti[Y::S_COUNTER + q];
+            const float cnt1 = (float)(cnt + 1), cntf = (float)cnt;
+            const bool wrap = cnt >= kStartupLong;
+#pragma unroll
+            for (int s = 0; s < SLOTS; s++) {
+                const int b = lane + 64 * s;
+                if (b < M) {
+                    float dens = st[Y::DENSITY + q * Y::MP + b];
+                    float lq = st[Y::LQUANTILE + q * Y::MP + b];
+                    float delta;
+                    if (dens > 1.0f)
+                        delta = 40.f * 1.f / dens;
+                    else
+                        delta = 40.f;
+                    if (lmagn[s] > lq)
+                        lq += 0.25f * delta / cnt1;
+                    else
+                        lq -= (1.f - 0.25f) * delta / cnt1;
+                    if (fabsf(lmagn[s] - lq) < 0.01f) {
+                        dens = (cntf * dens + 1.f / (2.f * 0.01f)) / cnt1;
+                        st[Y::DENSITY + q * Y::MP + b] = dens;
+                    }
+                    st[Y::LQUANTILE + q * Y::MP + b] = lq;
+                    last_lq[s] = lq;
+                    if (wrap && updates >= kStartupLong) quant[s] = (float)exp((double)lq);
+                }
+            }
+            sti[Y::S_COUNTER + q] = wrap ? 1 : cnt + 1;
+        }
+#pragma unroll
+        for (int s = 0; s < SLOTS; s++) {
+            const int b = lane + 64 * s;
+            if (b < M) {
+                if (updates < kStartupLong) quant[s] = (float)exp((double)last_lq[s]);
+                st[Y::QUANTILE + b] = quant[s];
+                noise[s] = quant[s];
+            }
+        }
+
+        // ---- start-up white/pink parametric noise model (ns_core.c:1108-1160)
+        const float overdrive = 1.1f, denoise_bound = 0.125f;  // policy 2, ns_core.c:1030-1033
+        if (startup) {
+            float white = st[Y::S_WHITE] + sum_magn / ((float)M) * overdrive;
+            st[Y::S_WHITE] = white;
+            const float sum_log_i = sh.logi[Y::MP - 2], sum_log_i_sq = sh.logi[Y::MP - 1];
+            float t1 = sum_log_i_sq * ((float)(M - kStartBand));
+            t1 -= (sum_log_i * sum_log_i);
+            float t2 = (sum_log_i_sq * sum_log_magn - sum_log_i * sum_log_i_log_magn);
+            float t3 = t2 / t1;
+            if (t3 < 0.f) t3 = 0.f;
+            const float pink_num = st[Y::S_PINK_NUM] + t3;
+            st[Y::S_PINK_NUM] = pink_num;
+            t2 = (sum_log_i * sum_log_magn);
+            t2 -= ((float)(M - kStartBand)) * sum_log_i_log_magn;
+            t3 = t2 / t1;
+            if (t3 < 0.f) t3 = 0.f;
+            if (t3 > 1.f) t3 = 1.f;
+            const float pink_exp = st[Y::S_PINK_EXP] + t3;
+            st[Y::S_PINK_EXP] = pink_exp;
+            float pnum = 0.0f, pexp = 0.0f;
+            if (pink_exp > 0.f) {
+                pnum = (float)exp((double)(pink_num / (float)(block_ind + 1)));
+                pnum *= (float)(block_ind + 1);
+                pexp = pink_exp / (float)(block_ind + 1);
+            }
+#pragma unroll
+            for (int s = 0; s < SLOTS; s++) {
+                const int b = lane + 64 * s;
+                par_noise[s] = 0.f;
+                if (b < M) {
+                    if (pink_exp == 0.f) {
+                        par_noise[s] = white;
+                    } else {
+                        const float band = (float)(b < kStartBand ? kStartBand : b);
+                        par_noise[s] = (float)((double)pnum / pow((double)band, (double)pexp));
+                    }
+                    noise[s] *= (float)(block_ind);
+                    const float t = par_noise[s] * (float)(kStartupShort - block_ind);
+                    noise[s] += (t / (float)(block_ind + 1));
+                    noise[s] /= (float)kStartupShort;
+                }
+            }
+        }
+        // normalisation of the spectral-difference feature (ns_core.c:1163-1167)
+        float feat_norm = st[Y::S_FEAT_NORM];
+        if (block_ind < kStartupLong) {
+            feat_norm *= (float)block_ind;
+            feat_norm += signal_energy;
+            feat_norm /= (float)(block_ind + 1);
+        }
+
+        // ---- ComputeSnr (ns_core.c:566-588); prev_est is reused by the Wiener filter (:996)
+#pragma unroll
+        for (int s = 0; s < SLOTS; s++) {
+            const int b = lane + 64 * s;
+            if (b < M) {
+                noise_prev[s] = st[Y::NOISE_PREV + b];
+                prev_est[s] = st[Y::MAGN_PREV + b] / (noise_prev[s] + 0.0001f) * st[Y::SMOOTH + b];
+                snr_post[s] = 0.f;
+                if (magn[s] > noise[s]) snr_post[s] = magn[s] / (noise[s] + 0.0001f) - 1.f;
+                snr_prior[s] = 0.98f * prev_est[s] + (1.f - 0.98f) * snr_post[s];
+            }
+        }
+
+        // ---- FeatureUpdate: spectral flatness (ns_core.c:523-556), difference (:595-634)
+        float feat_flat = st[Y::S_FEAT_FLAT];
+        {
+            float den = sum_magn;
+            den -= magn0;
+            den = den / (float)M;
+            const float num = flat_num / (float)M;
+            const float tmp = (float)exp((double)num) / den;
+            feat_flat += 0.3f * (tmp - feat_flat);
+        }
+        avg_pause = avg_pause / ((float)M);
+        const float avg_magn = sum_magn / ((float)M);
+#pragma unroll
+        for (int s = 0; s < SLOTS; s++) {
+            const int b = lane + 64 * s;
+            if (b < M) {
+                const float dm = magn[s] - avg_magn, dp = pause[s] - avg_pause;
+                sh.r0[b] = dm * dp;
+                sh.r1[b] = dp * dp;
+                sh.r2[b] = dm * dm;
+            }
+        }
+        __syncthreads();
+        float cov, var_pause, var_magn;
+        if constexpr (ORDERED) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+            for (int i = 0; i < M; i++) {
+                a0 += sh.r0[i];
+                a1 += sh.r1[i];
+                a2 += sh.r2[i];
+            }
+            cov = a0;
+            var_pause = a1;
+            var_magn = a2;
+        } else {
+            cov = sum_range<false>(sh.r0, 0, M, lane);
+            var_pause = sum_range<false>(sh.r1, 0, M, lane);
+            var_magn = sum_range<false>(sh.r2, 0, M, lane);
+        }
+        __syncthreads();
+        cov = cov / ((float)M);
+        var_pause = var_pause / ((float)M);
+        var_magn = var_magn / ((float)M);
+        float feat_acc = st[Y::S_FEAT_ACC] + signal_energy;
+        float feat_diff = st[Y::S_FEAT_DIFF];
+        {
+            float d = var_magn - (cov * cov) / (var_pause + 0.0001f);
+            d = d / (feat_norm + 0.0001f);
+            feat_diff += 0.3f * (d - feat_diff);
+        }
+        float feat_lrt = st[Y::S_FEAT_LRT];
+        float thr_lrt = st[Y::S_THR_LRT], thr_flat = st[Y::S_THR_FLAT], thr_diff = st[Y::S_THR_DIFF];
+        float w_lrt = st[Y::S_W_LRT], w_flat = st[Y::S_W_FLAT], w_diff = st[Y::S_W_DIFF];
+        // histograms + threshold extraction every 500 blocks (ns_core.c:293-518, :765-790)
+        if (update_flag >= 1) {
+            const int countdown = sti[Y::S_COUNTDOWN] - 1;
+            if (countdown > 0) {
+                if (lane == 0) {
+                    if ((feat_lrt < kHistBins * 0.1f) && (feat_lrt >= 0.0f)) hist[(int)(feat_lrt / 0.1f)]++;
+                    if ((feat_flat < kHistBins * 0.05f) && (feat_flat >= 0.0f)) hist[kHistBins + (int)(feat_flat / 0.05f)]++;
+                    if ((feat_diff < kHistBins * 0.1f) && (feat_diff >= 0.0f)) hist[2 * kHistBins + (int)(feat_diff / 0.1f)]++;
+                }
+                sti[Y::S_COUNTDOWN] = countdown;
+            } else {
+                // every lane walks the three histograms in order (uniform loads, runs once per 5 s)
+                float avg = 0.0f, avg_compl = 0.0f, avg_sq = 0.0f;
+                int num = 0;
+                for (int i = 0; i < kHistBins; i++) {
+                    const float mid = ((float)i + 0.5f) * 0.1f;
+                    const int h = hist[i];
+                    if (mid <= 1.f) {
+                        avg += h * mid;
+                        num += h;
+                    }
+                    avg_sq += h * mid * mid;
+                    avg_compl += h * mid;
+                }
+                if (num > 0) avg = avg / ((float)num);
+                avg_compl = avg_compl / ((float)kUpdateWindow);
+                avg_sq = avg_sq / ((float)kUpdateWindow);
+                const float fluct = avg_sq - avg * avg_compl;
+                if (fluct < 0.05f) {
+                    thr_lrt = 1.f;
+                } else {
+                    thr_lrt = 1.2f * avg;
+                    if (thr_lrt < 0.2f) thr_lrt = 0.2f;
+                    if (thr_lrt > 1.f) thr_lrt = 1.f;
+                }
+                int w1[2], w2[2];
+                float p1[2], p2[2];
+#pragma unroll
+                for (int f = 0; f < 2; f++) {
+                    const float bin = f == 0 ? 0.05f : 0.1f;
+                    int max1 = 0, max2 = 0;
+                    w1[f] = w2[f] = 0;
+                    p1[f] = p2[f] = 0.0f;
+                    for (int i = 0; i < kHistBins; i++) {
+                        const float mid = ((float)i + 0.5f) * bin;
+                        const int h = hist[(f + 1) * kHistBins + i];
+                        if (h > max1) {
+                            max2 = max1;
+                            w2[f] = w1[f];
+                            p2[f] = p1[f];
+                            max1 = h;
+                            w1[f] = h;
+                            p1[f] = mid;
+                        } else if (h > max2) {
+                            max2 = h;
+                            w2[f] = h;
+                            p2[f] = mid;
+                        }
+                    }
+                }
+                const int thres_weight = 150;  // (int)(0.3 * 500)
+                int use_flat = 1, use_diff = 1;
+                if ((fabsf(p2[0] - p1[0]) < 2 * 0.05f) && (w2[0] > 0.5f * w1[0])) {
+                    w1[0] += w2[0];
+                    p1[0] = 0.5f * (p1[0] + p2[0]);
+                }
+                if (w1[0] < thres_weight || p1[0] < 0.6f) use_flat = 0;
+                if (use_flat == 1) {
+                    thr_flat = 0.9f * p1[0];
+                    if (thr_flat < 0.1f) thr_flat = 0.1f;
+                    if (thr_flat > 0.95f) thr_flat = 0.95f;
+                }
+                if ((fabsf(p2[1] - p1[1]) < 2 * 0.1f) && (w2[1] > 0.5f * w1[1])) {
+                    w1[1] += w2[1];
+                    p1[1] = 0.5f * (p1[1] + p2[1]);
+                }
+                thr_diff = 1.2f * p1[1];
+                if (w1[1] < thres_weight) use_diff = 0;
+                if (thr_diff < 0.16f) thr_diff = 0.16f;
+                if (thr_diff > 1.f) thr_diff = 1.f;
+                if (fluct < 0.05f) use_diff = 0;
+                const float fsum = (float)(1 + use_flat + use_diff);
+                w_lrt = 1.f / fsum;
+                w_flat = ((float)use_flat) / fsum;
+                w_diff = ((float)use_diff) / fsum;
+                __syncthreads();
+                for (int i = lane; i < 3 * kHistBins; i += 64) hist[i] = 0;
+                sti[Y::S_COUNTDOWN] = kUpdateWindow;
+                if (update_flag == 1) {
+                    sti[Y::S_UPDATE_FLAG] = 0;
+                } else {
+                    feat_acc = feat_acc / ((float)kUpdateWindow);
+                    feat_norm = 0.5f * (feat_acc + feat_norm);
+                    feat_acc = 0.f;
+                }
+                st[Y::S_THR_LRT] = thr_lrt;
+                st[Y::S_THR_FLAT] = thr_flat;
+                st[Y::S_THR_DIFF] = thr_diff;
+                st[Y::S_W_LRT] = w_lrt;
+                st[Y::S_W_FLAT] = w_flat;
+                st[Y::S_W_DIFF] = w_diff;
+            }
+        }
+        st[Y::S_FEAT_FLAT] = feat_flat;
+        st[Y::S_FEAT_DIFF] = feat_diff;
+        st[Y::S_FEAT_NORM] = feat_norm;
+        st[Y::S_FEAT_ACC] = feat_acc;
+
+        // ---- SpeechNoiseProb (ns_core.c:642-749)
+        float llrt[SLOTS];
+#pragma unroll
+        for (int s = 0; s < SLOTS; s++) {
+            const int b = lane + 64 * s;
+            if (b < M) {
+                const float t1 = 1.f + 2.f * snr_prior[s];
+                const float t2 = 2.f * snr_prior[s] / (t1 + 0.0001f);
+                const float bessel = (snr_post[s] + 1.f) * t2;
+                float v = st[Y::LOG_LRT + b];
+                v += 0.5f * (bessel - (float)log((double)t1) - v);
+                st[Y::LOG_LRT + b] = v;
+                llrt[s] = v;
+                sh.r0[b] = v;
+            }
+        }
+        __syncthreads();
+        float ksum = sum_range<ORDERED>(sh.r0, 0, M, lane);
+        __syncthreads();
+        ksum = ksum / (float)(M);
+        feat_lrt = ksum;
+        st[Y::S_FEAT_LRT] = feat_lrt;
+        float prior = st[Y::S_PRIOR];
+        {
+            float width = 4.0f;
+            if (ksum < thr_lrt) width = 2.f * 4.0f;
+            const float ind0 = 0.5f * ((float)tanh((double)(width * (ksum - thr_lrt))) + 1.f);
+            width = 4.0f;
+            if (feat_flat > thr_flat) width = 2.f * 4.0f;
+            const float ind1 = 0.5f * ((float)tanh((double)((float)1 * width * (thr_flat - feat_flat))) + 1.f);
+            width = 4.0f;
+            if (feat_diff < thr_diff) width = 2.f * 4.0f;
+            const float ind2 = 0.5f * ((float)tanh((double)(width * (feat_diff - thr_diff))) + 1.f);
+            const float ind = w_lrt * ind0 + w_flat * ind1 + w_diff * ind2;
+            prior += 0.1f * (ind - prior);
+            if (prior > 1.f) prior = 1.f;
+            if (prior < 0.01f) prior = 0.01f;
+            st[Y::S_PRIOR] = prior;
+        }
+        const float gain_prior = (1.f - prior) / (prior + 0.0001f);
+#pragma unroll
+        for (int s = 0; s < SLOTS; s++) {
+            const int b = lane + 64 * s;
+            sprob[s] = 0.f;
+            if (b < M) {
+                float inv = (float)exp((double)(-llrt[s]));
+                inv = gain_prior * inv;
+                sprob[s] = 1.f / (1.f + inv);
+                sh.r1[b] = sprob[s];
+            }
+        }
+        __syncthreads();
+        // ---- UpdateNoiseEstimate (ns_core.c:800-846): bin i starts from the gamma chosen at bin i-1
+#pragma unroll
+        for (int s = 0; s < SLOTS; s++) {
+            const int b = lane + 64 * s;
+            if (b < M) {
+                const float ps = sprob[s], pn = 1.f - ps;
+                float gamma_old = 0.9f;
+                if (b > 0 && sh.r1[b - 1] > 0.2f) gamma_old = 0.99f;
+                const float tmp = gamma_old * noise_prev[s] + (1.f - gamma_old) * (pn * magn[s] + ps * noise_prev[s]);
+                float gamma = 0.9f;
+                if (ps > 0.2f) gamma = 0.99f;
+                if (ps < 0.2f) {
+                    pause[s] += 0.05f * (magn[s] - pause[s]);
+                    st[Y::MAGN_AVG_PAUSE + b] = pause[s];
+                }
+                float nz;
+                if (gamma == gamma_old) {
+                    nz = tmp;
+                } else {
+                    nz = gamma * noise_prev[s] + (1.f - gamma) * (pn * magn[s] + ps * noise_prev[s]);
+                    if (tmp < nz) nz = tmp;
+                }
+                noise[s] = nz;
+            }
+        }
+        __syncthreads();
+
+        // ===================================================== Process (ns_core.c:1275-1359)
+#pragma unroll
+        for (int s = 0; s < SLOTS; s++) {
+            const int b = lane + 64 * s;
+            if (b < M) {
+                float init_est = 0.f;
+                if (startup) {
+                    init_est = st[Y::INIT_MAGN + b] + magn[s];
+                    st[Y::INIT_MAGN + b] = init_est;
+                }
+                // ComputeDdBasedWienerFilter (ns_core.c:985-1007) + flooring / start-up blend (:1285-1315)
+                float cur = 0.f;
+                if (magn[s] > noise[s]) cur = magn[s] / (noise[s] + 0.0001f) - 1.f;
+                const float snr = 0.98f * prev_est[s] + (1.f - 0.98f) * cur;
+                float f = snr / (overdrive + snr);
+                if (f < denoise_bound) f = denoise_bound;
+                if (f > 1.f) f = 1.f;
+                if (startup) {
+                    float ft = (init_est - overdrive * par_noise[s]);
+                    ft /= (init_est + 0.0001f);
+                    if (ft < denoise_bound) ft = denoise_bound;
+                    if (ft > 1.f) ft = 1.f;
+                    f *= (float)(block_ind);
+                    ft *= (float)(kStartupShort - block_ind);
+                    f += ft;
+                    f /= (float)(kStartupShort);
+                }
+                st[Y::SMOOTH + b] = f;
+                st[Y::MAGN_PREV + b] = magn[s];
+                st[Y::NOISE_PREV + b] = noise[s];
+                re[s] *= f;
+                im[s] *= f;
+                sh.r2[b] = f;      // for the high-band gain
+                sh.r3[b] = magn[s];
+                // IFFT packing (ns_core.c:934-939)
+                if (b == 0)
+                    sh.fa[0] = re[s];
+                else if (b == M - 1)
+                    sh.fa[1] = re[s];
+                else {
+                    sh.fa[2 * b] = re[s];
+                    sh.fa[2 * b + 1] = im[s];
+                }
+            }
+        }
+        __syncthreads();
+        rdft_inverse<NC>(sh.fa, &sh.tab, lane);
+        float td[NT];
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+            const int i = lane + 64 * k;
+            td[k] = sh.fa[i] * (2.f / L);
+            sh.r0[i] = td[k] * td[k];
+        }
+        __syncthreads();
+        float factor = 1.f;
+        if (block_ind > kStartupLong) {  // gainmap == 1 for policy 2
+            const float energy2 = sum_range<ORDERED>(sh.r0, 0, L, lane);
+            float gain = sqrtf(energy2 / (energy1 + 1.f));
+            float factor1 = 1.f, factor2 = 1.f;
+            if (gain > 0.5f) {
+                factor1 = 1.f + 1.3f * (gain - 0.5f);
+                if (gain * factor1 > 1.f) factor1 = 1.f / gain;
+            }
+            if (gain < 0.5f) {
+                if (gain <= denoise_bound) gain = denoise_bound;
+                factor2 = 1.f - 0.3f * (0.5f - gain);
+            }
+            factor = prior * factor1 + (1.f - prior) * factor2;
+        }
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+            const int i = lane + 64 * k;
+            const float w = sh.window[i] * td[k];
+            synt[k] += factor * w;
+        }
+        // ---- high band: time-domain gain (ns_core.c:1362-1414), only when chn == 2
+        if (chn == 2) {
+            constexpr int D = M / 4;
+            float avg_prob = sum_range<ORDERED>(sh.r1, M - D - 1, M - 1, lane);
+            avg_prob = avg_prob / ((float)D);
+            // magnPrevAnalyze == magnPrevProcess here, so sumMagnProcess / sumMagnAnalyze is x / x
+            const float sm = sum_range<ORDERED>(sh.r3, 0, M, lane);
+            avg_prob *= sm / sm;
+            float avg_gain = sum_range<ORDERED>(sh.r2, M - D - 1, M - 1, lane);
+            avg_gain = avg_gain / ((float)D);
+            const float t = 2.f * avg_prob - 1.f;
+            const float gain_mod = 0.5f * (1.f + (float)tanh((double)(1.0f * t)));
+            float g = 0.5f * gain_mod + 0.5f * avg_gain;
+            if (avg_prob >= 0.5f) g = 0.25f * gain_mod + 0.75f * avg_gain;
+            g = g * 1.0f;
+            if (g < denoise_bound) g = denoise_bound;
+            if (g > 1.f) g = 1.f;
+            hb_gain = g;
+        }
+        __syncthreads();
+    }
+
+    // ---- read out the finished segment, slide the synthesis buffer (ns_core.c:1245-1251 / 1347-1359)
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+        const int i = lane + 64 * k;
+        outv[k] = sat16f(synt[k]);
+        if (i >= B) st[Y::SYNT_BUF + i - B] = synt[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+        const int i = lane + 64 * k;
+        if (i >= L - B) st[Y::SYNT_BUF + i] = 0.f;
+    }
+    // HB output: the OLDEST block of the (already slid) high-band buffer, times the gain
+    // (zero-energy frames pass it through unscaled, ns_core.c:1255-1265).  Stage through LDS
+    // because sample j of the output sits in buffer slot j.
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+        const int i = lane + 64 * k;
+        sh.r0[i] = outv[k];
+        if (chn == 2) sh.fa[i] = zero_frame ? sat16f(hb[k]) : sat16f(hb_gain * hb[k]);
+    }
+    __syncthreads();
+    // interleave + (int16_t) cast (src/webrtc.c:640-642).  Samples beyond the core's block
+    // length (32 kHz: 160..319) are the wrapper's calloc zeros.
+    for (int i = lane; i < pkg; i += 64) {
+        const float lo = (i < B) ? sh.r0[i] : 0.f;
+        out[i * chn] = (int16_t)lo;
+        if (chn == 2) out[i * chn + 1] = (int16_t)((i < B) ? sh.fa[i] : 0.f);
+    }
+    __syncthreads();
+}
+
+template <int L, bool ORDERED>
+__global__ __launch_bounds__(64) void ns_kernel(float *__restrict__ state, unsigned short *__restrict__ hists,
+                                                const float *__restrict__ consts, const int16_t *in, int16_t *out,
+                                                int n_streams, int n_packets, long stream_stride, long packet_stride,
+                                                int chn, int pkg) {
+    using Y = NsLayout<L>;
+    __shared__ NsShared<L> sh;
+    const int lane = threadIdx.x;
+    // constants: FftTables | window[L] | logi[MP]
+    {
+        float *dst = reinterpret_cast<float *>(&sh);
+        constexpr int NCONST = kFftTableWords + L + Y::MP;
+        for (int i = lane; i < NCONST; i += 64) dst[i] = consts[i];
+    }
+    __syncthreads();
+    for (int sidx = blockIdx.x; sidx < n_streams; sidx += gridDim.x) {
+        float *st = state + (size_t)sidx * Y::WORDS;
+        unsigned short *hist = hists + (size_t)sidx * 3 * kHistBins;
+        for (int p = 0; p < n_packets; p++) {
+            const size_t off = (size_t)sidx * stream_stride + (size_t)p * packet_stride;
+            ns_frame<L, ORDERED>(sh, st, hist, in + off, out + off, chn, pkg, lane);
+        }
+    }
+}
+
+}  // namespace
+}  // namespace wmx
+
+// ------------------------------------------------------------------------------------ host
+struct wmx_ns {
+    int n_streams, chn, freq, L, pkg, ordered;
+    float *d_state;
+    unsigned short *d_hist;
+    float *d_consts;
+    size_t words;
+};
+
+namespace {
+
+template <int L>
+void build_ns_template(std::vector<float> &st, std::vector<float> &consts) {
+    using Y = wmx::NsLayout<L>;
+    st.assign(Y::WORDS, 0.f);
+    int *sti = reinterpret_cast<int *>(st.data());
+    // WebRtcNs_InitCore ns_core.c:74-214
+    for (int q = 0; q < 3; q++)
+        for (int b = 0; b < Y::M; b++) {
+            st[Y::LQUANTILE + q * Y::MP + b] = 8.f;
+            st[Y::DENSITY + q * Y::MP + b] = 0.3f;
+        }
+    for (int q = 0; q < 3; q++) sti[Y::S_COUNTER + q] = (int)floor((float)(200 * (q + 1)) / (float)3);
+    for (int b = 0; b < Y::M; b++) {
+        st[Y::SMOOTH + b] = 1.f;
+        st[Y::LOG_LRT + b] = 0.5f;
+    }
+    sti[Y::S_UPDATES] = 0;
+    sti[Y::S_BLOCK_IND] = -1;
+    sti[Y::S_UPDATE_FLAG] = 2;
+    sti[Y::S_COUNTDOWN] = 500;
+    st[Y::S_PRIOR] = 0.5f;
+    st[Y::S_FEAT_FLAT] = 0.5f;
+    st[Y::S_FEAT_LRT] = 0.5f;
+    st[Y::S_FEAT_DIFF] = 0.5f;
+    st[Y::S_THR_LRT] = 0.5f;
+    st[Y::S_THR_FLAT] = 0.5f;
+    st[Y::S_THR_DIFF] = 0.5f;
+    st[Y::S_W_LRT] = 1.f;
+    // constants block: FftTables | window | log table (+ the two data-independent start-up sums)
+    consts.assign(wmx::kFftTableWords + L + Y::MP, 0.f);
+    wmx::FftTables tab;
+    wmx::fft_tables_ooura(L, &tab);
+    std::memcpy(consts.data(), &tab, sizeof(tab));
+    float *win = consts.data() + wmx::kFftTableWords;
+    const int ramp = (L == 128) ? 48 : 96;
+    const double half_pi = 1.5707963267948966;
+    for (int i = 0; i < L; i++) {
+        // windows_private.h:64,94: 8-decimal literals of a sine ramp / flat top / mirrored ramp
+        double v = (i < ramp) ? sin(half_pi * i / ramp) : (i < L - ramp ? 1.0 : sin(half_pi * (L - i) / ramp));
+        win[i] = (float)(floor(v * 1e8 + 0.5) / 1e8);
+    }
+    float *logi = win + L;
+    volatile float acc1 = 0.0f, acc2 = 0.0f;
+    for (int i = 0; i < Y::M; i++) {
+        float li = (i == 0) ? 0.f : (float)log((double)(float)i);  // ns_core.c:1093
+        logi[i] = li;
+        if (i >= 5) {
+            acc1 = acc1 + li;
+            volatile float sq = li * li;
+            acc2 = acc2 + sq;
+        }
+    }
+    logi[Y::MP - 2] = acc1;  // sum_log_i        (ns_core.c:1094)
+    logi[Y::MP - 1] = acc2;  // sum_log_i_square (ns_core.c:1095)
+}
+
+__global__ void ns_fill_state(float *state, const float *tmpl, int words, int n_streams) {
+    const size_t total = (size_t)words * n_streams;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        state[i] = tmpl[i % words];
+}
+
+}  // namespace
+
+extern "C" {
+
+int wmx_ns_create(wmx_ns **out, int n_streams, int chn, int freq) {
+    if (!out) return WMX_EINVAL;
+    *out = nullptr;
+    // ns_init: freq <= 32000 and a multiple of 8000 (src/webrtc.c:563-564); in[2]/out[2] => chn <= 2
+    if (freq > 32000 || freq % 8000 != 0 || freq <= 0 || chn < 1 || chn > 2 || n_streams < 1) {
+        wmx::set_error("wmx_ns_create: unsupported n_streams=%d chn=%d freq=%d", n_streams, chn, freq);
+        return WMX_EINVAL;
+    }
+    wmx_ns *h = new wmx_ns();
+    h->n_streams = n_streams;
+    h->chn = chn;
+    h->freq = freq;
+    h->L = (freq == 8000) ? 128 : 256;
+    h->pkg = freq / 1000 * 10;
+    h->ordered = 1;
+    std::vector<float> st, consts;
+    if (h->L == 128)
+        build_ns_template<128>(st, consts);
+    else
+        build_ns_template<256>(st, consts);
+    h->words = st.size();
+    float *d_tmpl = nullptr;
+    hipError_t e;
+#define NS_TRY(x)                                                  \
+    if ((e = (x)) != hipSuccess) {                                 \
+        int rc = wmx::hip_fail(e, #x, __FILE__, __LINE__);         \
+        wmx_ns_destroy(h);                                         \
+        if (d_tmpl) (void)hipFree(d_tmpl);                         \
+        return rc;                                                 \
+    }
+    NS_TRY(hipMalloc(&h->d_state, h->words * sizeof(float) * (size_t)n_streams));
+    NS_TRY(hipMalloc(&h->d_hist, (size_t)n_streams * 3 * 1000 * sizeof(unsigned short)));
+    NS_TRY(hipMalloc(&h->d_consts, consts.size() * sizeof(float)));
+    NS_TRY(hipMalloc(&d_tmpl, st.size() * sizeof(float)));
+    NS_TRY(hipMemcpy(h->d_consts, consts.data(), consts.size() * sizeof(float), hipMemcpyHostToDevice));
+    NS_TRY(hipMemcpy(d_tmpl, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
+    NS_TRY(hipMemset(h->d_hist, 0, (size_t)n_streams * 3 * 1000 * sizeof(unsigned short)));
+    hipLaunchKernelGGL(ns_fill_state, dim3(1024), dim3(256), 0, nullptr, h->d_state, d_tmpl, (int)h->words, n_streams);
+    NS_TRY(hipGetLastError());
+    NS_TRY(hipDeviceSynchronize());
+    (void)hipFree(d_tmpl);
+    d_tmpl = nullptr;
+#undef NS_TRY
+    *out = h;
+    return 0;
+}
+
+int wmx_ns_destroy(wmx_ns *h) {
+    if (!h) return 0;
+    if (h->d_state) (void)hipFree(h->d_state);
+    if (h->d_hist) (void)hipFree(h->d_hist);
+    if (h->d_consts) (void)hipFree(h->d_consts);
+    delete h;
+    return 0;
+}
+
+int wmx_ns_set_ordered(wmx_ns *h, int ordered) {
+    if (!h) return WMX_EINVAL;
+    h->ordered = ordered ? 1 : 0;
+    return 0;
+}
+
+int wmx_ns_packet_samples(const wmx_ns *h) { return h ? h->pkg * h->chn : WMX_EINVAL; }
+int wmx_ns_state_words(const wmx_ns *h) { return h ? (int)h->words : WMX_EINVAL; }
+
+int wmx_ns_export_state(const wmx_ns *h, int stream_index, float *host_words, unsigned short *host_hist) {
+    if (!h || stream_index < 0 || stream_index >= h->n_streams) return WMX_EINVAL;
+    WMX_HIP(hipDeviceSynchronize());
+    if (host_words)
+        WMX_HIP(hipMemcpy(host_words, h->d_state + (size_t)stream_index * h->words, h->words * sizeof(float), hipMemcpyDeviceToHost));
+    if (host_hist)
+        WMX_HIP(hipMemcpy(host_hist, h->d_hist + (size_t)stream_index * 3000, 3000 * sizeof(unsigned short), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int wmx_ns_process(wmx_ns *h, const int16_t *d_in, int16_t *d_out, int n_packets, long stream_stride,
+                   long packet_stride, void *stream) {
+    if (!h || !d_in || !d_out || n_packets < 0) {
+        wmx::set_error("wmx_ns_process: bad argument");
+        return WMX_EINVAL;
+    }
+    if (n_packets == 0) return 0;
+    const int per_pkt = h->pkg * h->chn;
+    if (packet_stride < per_pkt || (h->n_streams > 1 && stream_stride < per_pkt)) {
+        // a packet must not overlap its neighbours; streams may be packet- or stream-major
+        wmx::set_error("wmx_ns_process: strides (%ld, %ld) smaller than a packet (%d samples)", stream_stride, packet_stride, per_pkt);
+        return WMX_EINVAL;
+    }
+    const unsigned grid = (unsigned)h->n_streams;
+    hipStream_t s = wmx::as_stream(stream);
+#define NS_LAUNCH(LL, ORD)                                                                                          \
+    hipLaunchKernelGGL((wmx::ns_kernel<LL, ORD>), dim3(grid), dim3(64), 0, s, h->d_state, h->d_hist, h->d_consts, d_in, \
+                       d_out, h->n_streams, n_packets, stream_stride, packet_stride, h->chn, h->pkg)
+    if (h->L == 128) {
+        if (h->ordered)
+            NS_LAUNCH(128, true);
+        else
+            NS_LAUNCH(128, false);
+    } else {
+        if (h->ordered)
+            NS_LAUNCH(256, true);
+        else
+            NS_LAUNCH(256, false);
+    }
+#undef NS_LAUNCH
+    WMX_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"
