@@ -28,6 +28,11 @@ int g711u_encode(unsigned char g711_data[], const short amp[], int len);
 unsigned char linear2alaw(int pcm_val);
 unsigned char linear2ulaw(int pcm_val);
 
+/* ---- src/webrtc.h:47-51 (NS) */
+void *ns_init(int chn, int freq, bool *debug);
+void ns_process(void *fp, int16_t *frame, int16_t *frameOut, int frameNum);
+void ns_release(void *fp);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,106 @@
+"""GPU parity: wmix_amd/csrc/ns.hip through the C ABI vs the oracle and the golden vectors.
+ordered mode: bit-exact.  parallel-sum mode: max |d| <= 1 LSB and RMS error <= 1e-3 of full scale
+(the tolerance BASELINE.json's north_star states for the float NS path)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import loader as L
+
+sys.path.insert(0, GOLDEN)
+from make_ns_golden import NS_CASES, ns_case_input  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(GOLDEN, "ns_golden.npz"))
+
+
+def run_gpu(cuda, chn, freq, x_streams, ordered=True, packets_per_launch=64, packet_major=False):
+    """x_streams: int16 [S, n_frames*pkt*chn] -> same shape, through NsBatch."""
+    import torch
+    from wmix_amd.ns import NsBatch
+    S = x_streams.shape[0]
+    per = freq // 100 * chn
+    nf = x_streams.shape[1] // per
+    nb = NsBatch(S, chn, freq, ordered=ordered)
+    if packet_major:
+        d = torch.from_numpy(np.ascontiguousarray(x_streams.reshape(S, nf, per).transpose(1, 0, 2))).to(cuda)
+        for f in range(0, nf, packets_per_launch):
+            nb.process_packet_major(d[f:f + packets_per_launch])
+        out = d.cpu().numpy().transpose(1, 0, 2).reshape(S, -1)
+    else:
+        d = torch.from_numpy(np.ascontiguousarray(x_streams.reshape(S, nf, per))).to(cuda)
+        for f in range(0, nf, packets_per_launch):
+            nb.process(d[:, f:f + packets_per_launch])
+        out = d.cpu().numpy().reshape(S, -1)
+    nb.close()
+    return out
+
+
+@pytest.mark.parametrize("chn,freq,nf", NS_CASES)
+def test_golden_synthetic_bit_exact(cuda, chn, freq, nf):
+    x = ns_case_input(chn, freq, nf)
+    got = run_gpu(cuda, chn, freq, x[None, :])
+    assert np.array_equal(got[0], G["synth_%dx%d" % (chn, freq)])
+
+
+@pytest.mark.parametrize("name,chn,freq", [("speech_1x8000", 1, 8000), ("speech_2x16000", 2, 16000)])
+def test_golden_speech_bit_exact(cuda, name, chn, freq):
+    got = run_gpu(cuda, chn, freq, G[name + "_in"][None, :], packets_per_launch=7)
+    assert np.array_equal(got[0], G[name + "_out"])
+
+
+@pytest.mark.parametrize("chn,freq", [(1, 16000), (1, 8000), (2, 16000)])
+def test_many_streams_long_run_vs_oracle(cuda, oracle_port, chn, freq):
+    """64 independent streams, 1100 frames (crosses block 50/200/500/1000), one stream with silence gaps."""
+    S, nf = 64, 1100
+    x = np.stack([ns_case_input(chn, freq, nf, seed=1000 + 31 * s) for s in range(S)])
+    x[5].reshape(nf, -1)[300:420] = 0
+    want = np.stack([L.run_ns(oracle_port, chn, freq, x[s], freq // 100, prefix="orc") for s in range(S)])
+    got = run_gpu(cuda, chn, freq, x, packets_per_launch=100, packet_major=(chn == 1))
+    assert np.array_equal(got, want)
+    fast = run_gpu(cuda, chn, freq, x, ordered=False, packets_per_launch=100)
+    d = fast.astype(np.int32) - want.astype(np.int32)
+    assert np.abs(d).max() <= 1, "parallel-sum mode must stay within 1 LSB"
+    assert np.sqrt((d.astype(np.float64) ** 2).mean()) / 32768.0 <= 1e-3
+
+
+def test_reference_host_signatures(wmx, oracle_port):
+    """ns_init / ns_process / ns_release over HOST buffers, in place, 20 ms calls (src/webrtc.h:47-51)."""
+    assert wmx.ns_init(1, 44100, None) is None
+    assert wmx.ns_init(1, 48000, None) is None
+    for chn, freq in ((1, 8000), (2, 16000)):
+        x = ns_case_input(chn, freq, 120, seed=5)
+        want = L.run_ns(oracle_port, chn, freq, x, freq // 100, prefix="orc")
+        h = wmx.ns_init(chn, freq, None)
+        assert h
+        buf = x.copy()
+        step = 2 * (freq // 100) * chn  # WMIX_FRAME_NUM: 20 ms per call
+        for off in range(0, buf.size, step):
+            p = C.c_void_p(buf.ctypes.data + 2 * off)
+            wmx.ns_process(h, p, p, 2 * (freq // 100))
+        wmx.ns_release(h)
+        assert np.array_equal(buf, want)
+
+
+def test_full_size_batch_properties(cuda):
+    """configs[1] size (4096 streams): identical streams give identical outputs wherever they sit in the
+    batch, and a stream's output does not depend on its neighbours."""
+    import torch
+    from wmix_amd.ns import NsBatch
+    S, nf, pkt = 4096, 60, 160
+    base = np.stack([ns_case_input(1, 16000, nf, seed=77 + s) for s in range(4)])
+    idx = np.arange(S) % 4
+    d = torch.from_numpy(base[idx].reshape(S, nf, pkt)).to(cuda)
+    nb = NsBatch(S, 1, 16000)
+    nb.process(d)
+    out = d.cpu().numpy()
+    nb.close()
+    for k in range(4):
+        same = out[idx == k]
+        assert (same == same[0]).all()
+    small = run_gpu(cuda, 1, 16000, base)
+    assert np.array_equal(out[:4].reshape(4, -1), small)

@@ -72,6 +72,12 @@ def _declare(L):
     L.wmx_ns_export_state.argtypes = [vp, i, vp, vp]
     L.wmx_ns_process.restype = i
     L.wmx_ns_process.argtypes = [vp, vp, vp, i, C.c_long, C.c_long, vp]
+    L.ns_init.restype = vp
+    L.ns_init.argtypes = [i, i, vp]
+    L.ns_process.restype = None
+    L.ns_process.argtypes = [vp, vp, vp, i]
+    L.ns_release.restype = None
+    L.ns_release.argtypes = [vp]
     for name in ("PCM2G711a", "PCM2G711u", "G711a2PCM", "G711u2PCM"):
         f = getattr(L, name)
         f.restype = i
