@@ -75,6 +75,38 @@ int wmx_ns_process(wmx_ns *h, const int16_t *d_in, int16_t *d_out, int n_packets
 int wmx_ns_state_words(const wmx_ns *h);
 int wmx_ns_export_state(const wmx_ns *h, int stream_index, float *host_words, unsigned short *host_hist);
 
+/* ------------------------------------------------------------------ VAD (voice-activity gate)
+ * Batched form of vad_init / vad_process / vad_release (src/webrtc.h:32-36, src/webrtc.c:40-164):
+ * WebRtcVad mode 3 decides speech/no-speech per packet; a per-stream `reduce` in [0,4] moves one
+ * step per decision and the packet is shifted right by it, in place.  Packet = intervalMs worth of
+ * frames (20 ms only when freq <= 16000 and interval_ms % 20 == 0, else 10 ms).
+ *
+ * One "call" = one vad_process() invocation covering packets_per_call packets; the reference
+ * analyses and attenuates only packet 0 of a call and so do we.  Call c of
+ * stream s starts at d_pcm + s*stream_stride + c*call_stride (int16 elements).  Integer path:
+ * bit-exact. */
+typedef struct wmx_vad wmx_vad;
+int wmx_vad_create(wmx_vad **out, int n_streams, int chn, int freq, int interval_ms);
+int wmx_vad_destroy(wmx_vad *h);
+int wmx_vad_packet_samples(const wmx_vad *h); /* int16 elements per packet = freq/1000*intervalMs*chn */
+int wmx_vad_process(wmx_vad *h, int16_t *d_pcm, int packets_per_call, int n_calls, long stream_stride,
+                    long call_stride, void *stream);
+
+/* ------------------------------------------------------------------ AGC (legacy fixed-point, adaptive digital)
+ * Batched form of agc_init / agc_process / agc_addition / agc_release (src/webrtc.h:55-60,
+ * src/webrtc.c:694-860): target 0 dBFS, compression gain `value` dB, limiter off.  Channels are
+ * averaged to mono, processed as one band and duplicated back.  Packet = 10 ms (5 ms at 32 kHz,
+ * SURVEY.md section 0 quirk 4).  `value` outside the reference's gain-table range makes create/set_gain
+ * fail with WMX_EINVAL (agc_init returns NULL there).  Integer path: bit-exact. */
+typedef struct wmx_agc wmx_agc;
+int wmx_agc_create(wmx_agc **out, int n_streams, int chn, int freq, int interval_ms, int value);
+int wmx_agc_destroy(wmx_agc *h);
+int wmx_agc_set_gain(wmx_agc *h, int value); /* agc_addition for every stream of the batch */
+int wmx_agc_packet_samples(const wmx_agc *h);
+int wmx_agc_gain_table(const wmx_agc *h, int32_t *host_table32); /* the 32 Q16 gains in use (tests) */
+int wmx_agc_process(wmx_agc *h, const int16_t *d_in, int16_t *d_out, int n_packets, long stream_stride,
+                    long packet_stride, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,6 +33,17 @@ void *ns_init(int chn, int freq, bool *debug);
 void ns_process(void *fp, int16_t *frame, int16_t *frameOut, int frameNum);
 void ns_release(void *fp);
 
+/* ---- src/webrtc.h:32-36 (VAD) */
+void *vad_init(int chn, int freq, int intervalMs, bool *debug);
+void vad_process(void *fp, int16_t *frame, int frameNum);
+void vad_release(void *fp);
+
+/* ---- src/webrtc.h:55-60 (AGC) */
+void *agc_init(int chn, int freq, int intervalMs, int value, bool *debug);
+int agc_process(void *fp, int16_t *frame, int16_t *frameOut, int frameNum);
+void agc_addition(void *fp, uint8_t value);
+void agc_release(void *fp);
+
 #ifdef __cplusplus
 }
 #endif

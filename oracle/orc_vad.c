@@ -57,7 +57,7 @@ static uint32_t band_energy(const int16_t *v, int len, int *scale)
 }
 
 /* vad_sp.c:27-54 */
-static void downsample2(const int16_t *in, int16_t *out, int32_t *st, int in_len)
+void orc_vad_downsample(const int16_t *in, int16_t *out, int32_t *st, int in_len)
 {
     int32_t s1 = st[0], s2 = st[1];
     for (int n = 0; n < (in_len >> 1); n++) {
@@ -430,12 +430,12 @@ int orc_vad_core_process(orc_vad_core *s, int fs, const int16_t *frame, int fram
     const int16_t *p = frame;
     int len = frame_len;
     if (fs == 32000) {
-        downsample2(p, wb, &s->ds_state[2], len);
+        orc_vad_downsample(p, wb, &s->ds_state[2], len);
         len /= 2;
         p = wb;
     }
     if (fs >= 16000) {
-        downsample2(p, nb, &s->ds_state[0], len);
+        orc_vad_downsample(p, nb, &s->ds_state[0], len);
         len /= 2;
         p = nb;
     }

@@ -20,6 +20,7 @@ typedef struct { /* Vad_Struct, src/webrtc.c:18-27 */
 int orc_norm_w32(int32_t a);
 int orc_norm_u32(uint32_t a);
 int32_t orc_div_w32_w16(int32_t num, int16_t den);
+void orc_vad_downsample(const int16_t *in, int16_t *out, int32_t *st, int in_len);
 void orc_vad_core_init(orc_vad_core *s);
 int orc_vad_core_process(orc_vad_core *s, int fs, const int16_t *frame, int frame_len);
 int16_t orc_vad_features(orc_vad_core *s, const int16_t *in, int len, int16_t *f);

@@ -1,0 +1,156 @@
+"""CPU: oracle/orc_vad.c and oracle/orc_agc.c against (a) the known-answer values of the upstream
+gtest files vendored in the reference tarball, (b) golden outputs of the real reference
+(tests/golden/vadagc_golden.npz) and (c) oracle/_ref on longer runs when present.  Bit-exact."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import loader as L
+
+sys.path.insert(0, GOLDEN)
+from make_vadagc_golden import AGC_CASES, VAD_CASES, agc_input, agc_pkg, vad_input, vad_pkg  # noqa: E402
+
+G = np.load(os.path.join(GOLDEN, "vadagc_golden.npz"))
+
+
+class VadCore(C.Structure):  # mirrors orc_vad_core (oracle/orc_vad.h)
+    _fields_ = [("ds_state", C.c_int32 * 4), ("noise_means", C.c_int16 * 12), ("speech_means", C.c_int16 * 12),
+                ("noise_stds", C.c_int16 * 12), ("speech_stds", C.c_int16 * 12), ("frame_counter", C.c_int32),
+                ("over_hang", C.c_int16), ("num_of_speech", C.c_int16), ("index_vector", C.c_int16 * 96),
+                ("low_value_vector", C.c_int16 * 96), ("mean_value", C.c_int16 * 6), ("upper_state", C.c_int16 * 5),
+                ("lower_state", C.c_int16 * 5), ("hp_filter_state", C.c_int16 * 4)]
+
+
+def test_kat_filterbank(oracle_port):
+    """W:common_audio/vad/vad_filterbank_unittest.cc:26-86 (one instance, lengths 80/160/240 in sequence)."""
+    p = oracle_port
+    p.orc_vad_features.restype = C.c_int16
+    ref_feat = {80: [1213, 759, 587, 462, 434, 272], 160: [1479, 1385, 1291, 1200, 1103, 1099],
+                240: [1732, 1692, 1681, 1629, 1436, 1436]}
+    ref_energy = {80: 48, 160: 11, 240: 11}
+    speech = (np.arange(240, dtype=np.int64) ** 2).astype(np.int16)  # wraps like the C test
+    feat = (C.c_int16 * 6)()
+    core = VadCore()
+    p.orc_vad_core_init(C.byref(core))
+    for n in (80, 160, 240):
+        e = p.orc_vad_features(C.byref(core), speech.ctypes.data_as(C.c_void_p), n, feat)
+        assert (e, list(feat)) == (ref_energy[n], ref_feat[n])
+    core = VadCore()
+    p.orc_vad_core_init(C.byref(core))
+    zeros = np.zeros(240, np.int16)
+    for n in (80, 160, 240):
+        assert p.orc_vad_features(C.byref(core), zeros.ctypes.data_as(C.c_void_p), n, feat) == 0
+        assert list(feat) == [368, 368, 272, 176, 176, 176]
+    ones = np.ones(240, np.int16)
+    for n in (80, 160, 240):
+        core = VadCore()
+        p.orc_vad_core_init(C.byref(core))
+        assert p.orc_vad_features(C.byref(core), ones.ctypes.data_as(C.c_void_p), n, feat) == 0
+        assert list(feat) == [368, 368, 272, 176, 176, 176]
+
+
+def test_kat_gmm(oracle_port):
+    """W:common_audio/vad/vad_gmm_unittest.cc:20-41."""
+    p = oracle_port
+    p.orc_vad_gauss.restype = C.c_int32
+    p.orc_vad_gauss.argtypes = [C.c_int16, C.c_int16, C.c_int16, C.POINTER(C.c_int16)]
+    d = C.c_int16(0)
+    assert (p.orc_vad_gauss(0, 0, 128, C.byref(d)), d.value) == (1048576, 0)
+    assert (p.orc_vad_gauss(16, 128, 128, C.byref(d)), d.value) == (1048576, 0)
+    assert (p.orc_vad_gauss(-16, -128, 128, C.byref(d)), d.value) == (1048576, 0)
+    assert (p.orc_vad_gauss(59, 0, 128, C.byref(d)), d.value) == (1024, 7552)
+    assert (p.orc_vad_gauss(75, 128, 128, C.byref(d)), d.value) == (1024, 7552)
+    assert (p.orc_vad_gauss(-75, -128, 128, C.byref(d)), d.value) == (1024, -7552)
+    assert (p.orc_vad_gauss(105, 0, 128, C.byref(d)), d.value) == (0, 13440)
+
+
+def test_kat_downsampling_and_find_minimum(oracle_port):
+    """W:common_audio/vad/vad_sp_unittest.cc:22-72."""
+    p = oracle_port
+    state = (C.c_int32 * 2)(0, 0)
+    zeros = np.zeros(960, np.int16)
+    out = np.ones(480, np.int16)
+    p.orc_vad_downsample(zeros.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), state, 960)
+    assert list(state) == [0, 0] and not out.any()
+    data = (np.arange(960, dtype=np.int64) ** 2).astype(np.int16)
+    p.orc_vad_downsample(data.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), state, 960)
+    assert list(state) == [207, 2270]
+    p.orc_vad_find_min.restype = C.c_int16
+    ref = [1600, 720, 509, 512, 532, 552, 570, 588, 606, 624, 642, 659, 675, 691, 707, 723,
+           1600, 544, 502, 522, 542, 561, 579, 597, 615, 633, 651, 667, 683, 699, 715, 731]
+    core = VadCore()
+    p.orc_vad_core_init(C.byref(core))
+    for i in range(16):
+        for ch in range(6):
+            assert p.orc_vad_find_min(C.byref(core), C.c_int16(500 * (i + 1)), ch) == ref[i]
+            assert p.orc_vad_find_min(C.byref(core), C.c_int16(12000), ch) == ref[i + 16]
+        core.frame_counter += 1
+
+
+def test_kat_core_zeros(oracle_port):
+    """W:common_audio/vad/vad_core_unittest.cc:63-81: all zeros in gives VAD = 0 for every valid rate/length
+    (the i*i part of that test runs in mode 0; wmix's mode 3 is covered by the goldens instead)."""
+    p = oracle_port
+    core = VadCore()
+    p.orc_vad_core_init(C.byref(core))
+    for ms in (10, 20, 30):
+        for fs in (8000, 16000, 32000):
+            n = fs // 1000 * ms
+            z = np.zeros(n, np.int16)
+            assert p.orc_vad_core_process(C.byref(core), fs, z.ctypes.data_as(C.c_void_p), n) == 0
+    assert p.orc_vad_core_process(C.byref(core), 8000, np.zeros(81, np.int16).ctypes.data_as(C.c_void_p), 81) == -1
+    assert p.orc_vad_core_process(C.byref(core), 44100, np.zeros(441, np.int16).ctypes.data_as(C.c_void_p), 441) == -1
+
+
+def test_kat_spl(oracle_port):
+    """signal_processing_unittest.cc: NormW32/NormU32 inline tests (:170-190) and Sqrt(:413)."""
+    p = oracle_port
+    assert [p.orc_norm_w32(v) for v in (0, -1, -2147483648, 2147483647, 111121)] == [0, 31, 0, 0, 14]
+    assert [p.orc_norm_u32(v) for v in (0, 0xFFFFFFFF, 111121)] == [0, 0, 15]
+    assert p.orc_spl_sqrt(1134567892) == 33700  # signal_processing_unittest.cc:139-148
+
+
+@pytest.mark.parametrize("chn,freq,ims,k", VAD_CASES)
+def test_vad_golden(oracle_port, chn, freq, ims, k):
+    x = vad_input(chn, freq, ims, k)
+    got = L.run_vad(oracle_port, chn, freq, ims, x, k * vad_pkg(freq, ims), prefix="orc")
+    want = G["vad_%dx%d_%dms_k%d" % (chn, freq, ims, k)]
+    assert np.array_equal(got, want)
+    assert (got != x).any() and (got == x).any()  # the gate both closes and opens on this input
+
+
+@pytest.mark.parametrize("chn,freq,value", AGC_CASES)
+def test_agc_golden(oracle_port, chn, freq, value):
+    x = agc_input(chn, freq)
+    got = L.run_agc(oracle_port, chn, freq, value, x, agc_pkg(freq), prefix="orc")
+    assert np.array_equal(got, G["agc_%dx%d_v%d" % (chn, freq, value)])
+
+
+def test_speech_goldens(oracle_port):
+    sp = G["speech_in"]
+    assert np.array_equal(L.run_vad(oracle_port, 1, 8000, 20, sp, 160, prefix="orc"), G["speech_vad_20ms"])
+    assert np.array_equal(L.run_agc(oracle_port, 1, 8000, 5, sp, 80, prefix="orc"), G["speech_agc_v5"])
+
+
+def test_agc_rejects_out_of_range_gain_and_rates(oracle_port):
+    oracle_port.orc_agc_init.restype = C.c_void_p
+    assert oracle_port.orc_agc_init(1, 16000, 10, 192) is None  # diffGain >= 128 -> set_config fails -> NULL
+    assert oracle_port.orc_agc_init(1, 16000, 10, -3) is None
+    assert oracle_port.orc_agc_init(1, 44100, 10, 5) is None
+    oracle_port.orc_vad_init.restype = C.c_void_p
+    assert oracle_port.orc_vad_init(1, 48000, 10) is None
+
+
+def test_against_real_reference_long(oracle_port, oracle_ref):
+    for chn, freq, ims, k in ((1, 16000, 10, 1), (2, 8000, 20, 1), (1, 32000, 10, 2)):
+        x = vad_input(chn, freq, ims, k, n_calls=2500, seed=77)
+        n = k * vad_pkg(freq, ims)
+        assert np.array_equal(L.run_vad(oracle_ref, chn, freq, ims, x, n), L.run_vad(oracle_port, chn, freq, ims, x, n, prefix="orc"))
+    for chn, freq, value in ((1, 16000, 5), (2, 32000, 40), (1, 8000, 0)):
+        x = agc_input(chn, freq, n_calls=3000, seed=78)
+        assert np.array_equal(L.run_agc(oracle_ref, chn, freq, value, x, agc_pkg(freq)),
+                              L.run_agc(oracle_port, chn, freq, value, x, agc_pkg(freq), prefix="orc"))

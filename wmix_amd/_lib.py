@@ -72,6 +72,40 @@ def _declare(L):
     L.wmx_ns_export_state.argtypes = [vp, i, vp, vp]
     L.wmx_ns_process.restype = i
     L.wmx_ns_process.argtypes = [vp, vp, vp, i, C.c_long, C.c_long, vp]
+    L.wmx_vad_create.restype = i
+    L.wmx_vad_create.argtypes = [C.POINTER(vp), i, i, i, i]
+    L.wmx_vad_destroy.restype = i
+    L.wmx_vad_destroy.argtypes = [vp]
+    L.wmx_vad_packet_samples.restype = i
+    L.wmx_vad_packet_samples.argtypes = [vp]
+    L.wmx_vad_process.restype = i
+    L.wmx_vad_process.argtypes = [vp, vp, i, i, C.c_long, C.c_long, vp]
+    L.wmx_agc_create.restype = i
+    L.wmx_agc_create.argtypes = [C.POINTER(vp), i, i, i, i, i]
+    L.wmx_agc_destroy.restype = i
+    L.wmx_agc_destroy.argtypes = [vp]
+    L.wmx_agc_set_gain.restype = i
+    L.wmx_agc_set_gain.argtypes = [vp, i]
+    L.wmx_agc_packet_samples.restype = i
+    L.wmx_agc_packet_samples.argtypes = [vp]
+    L.wmx_agc_gain_table.restype = i
+    L.wmx_agc_gain_table.argtypes = [vp, vp]
+    L.wmx_agc_process.restype = i
+    L.wmx_agc_process.argtypes = [vp, vp, vp, i, C.c_long, C.c_long, vp]
+    L.vad_init.restype = vp
+    L.vad_init.argtypes = [i, i, i, vp]
+    L.vad_process.restype = None
+    L.vad_process.argtypes = [vp, vp, i]
+    L.vad_release.restype = None
+    L.vad_release.argtypes = [vp]
+    L.agc_init.restype = vp
+    L.agc_init.argtypes = [i, i, i, i, vp]
+    L.agc_process.restype = i
+    L.agc_process.argtypes = [vp, vp, vp, i]
+    L.agc_addition.restype = None
+    L.agc_addition.argtypes = [vp, C.c_ubyte]
+    L.agc_release.restype = None
+    L.agc_release.argtypes = [vp]
     L.ns_init.restype = vp
     L.ns_init.argtypes = [i, i, vp]
     L.ns_process.restype = None

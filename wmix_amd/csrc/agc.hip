@@ -1,0 +1,545 @@
+// agc.hip -- batched legacy (fixed-point) AGC for gfx950: one LANE per stream.
+//
+// Replaces, for many independent streams per launch, wmix's agc_process() (src/webrtc.c:767-819)
+// over WebRtcAgc_Process in adaptive-digital mode, target 0 dBFS, limiter off
+// (W:modules/audio_processing/agc/legacy/analog_agc.c:1134-1229 -> digital_agc.c:294-604
+// ProcessDigital, :633-771 ProcessVad; WebRtcSpl_DownsampleBy2 resample_by_2.c:70-124;
+// WebRtcSpl_Sqrt spl_sqrt.c).  Everything is a per-stream integer recurrence (ten 1 ms
+// envelope steps, a 4 kHz level detector, a per-sample gain ramp), so 64 streams share a
+// wavefront, state is field-major ([field][stream], one coalesced line per access) and the
+// 32-entry gain table -- identical for every stream of a batch -- sits in LDS.  Bit-exact.
+//
+// WebRtcAgc_ProcessAnalog also runs in the reference (lowLevelSignal == 0) but with
+// inMicLevel = 0 it only moves analog-side bookkeeping that wmix throws away and cannot fail
+// (SURVEY.md section 8 row a15); it has no device counterpart.  The gain table itself is computed on
+// the host by WebRtcAgc_CalculateGainTable's integer recipe (digital_agc.c:61-257).
+#include <cmath>
+#include <vector>
+#include "wmx_internal.h"
+#include "spl_dev.h"
+
+namespace wmx {
+namespace {
+
+enum : int {  // DigitalAgc + AgcVad vadNearend (digital_agc.h:26-53)
+    A32_CAP_SLOW = 0,
+    A32_CAP_FAST = 1,
+    A32_GAIN = 2,
+    A32_DOWN = 3,  // downState[8]
+    A32_VAR_LONG = 11,
+    A32_VAR_SHORT = 12,
+    A32_WORDS = 13,
+    A16_GATE_PREV = 0,
+    A16_HP = 1,
+    A16_COUNTER = 2,
+    A16_LOG_RATIO = 3,
+    A16_MEAN_LONG = 4,
+    A16_STD_LONG = 5,
+    A16_MEAN_SHORT = 6,
+    A16_STD_SHORT = 7,
+    A16_WORDS = 8,
+};
+
+struct AgcRef {
+    int16_t *s16;
+    int32_t *s32;
+    size_t n;
+    __device__ __forceinline__ int16_t &h(int f) const { return s16[(size_t)f * n]; }
+    __device__ __forceinline__ int32_t &w(int f) const { return s32[(size_t)f * n]; }
+};
+
+// resample_by_2.c:70-124: two input samples -> one output sample
+__device__ __forceinline__ int16_t down2_step(int16_t a, int16_t b, int32_t *st) {
+    int32_t in32 = (int32_t)a << 10, diff, t1, t2;
+    diff = wsub(in32, st[1]);
+    t1 = spl_scalediff32(12199, diff, st[0]);
+    st[0] = in32;
+    diff = wsub(t1, st[2]);
+    t2 = spl_scalediff32(37471, diff, st[1]);
+    st[1] = t1;
+    diff = wsub(t2, st[3]);
+    st[3] = spl_scalediff32(60255, diff, st[2]);
+    st[2] = t2;
+    in32 = (int32_t)b << 10;
+    diff = wsub(in32, st[5]);
+    t1 = spl_scalediff32(3284, diff, st[4]);
+    st[4] = in32;
+    diff = wsub(t1, st[6]);
+    t2 = spl_scalediff32(24441, diff, st[5]);
+    st[5] = t1;
+    diff = wsub(t2, st[7]);
+    st[7] = spl_scalediff32(49528, diff, st[6]);
+    st[6] = t2;
+    return sat_w16(wadd(wadd(st[3], st[7]), 1024) >> 11);
+}
+
+// One packet (10*L mono samples) of one stream.  in/out point at the packet's first frame;
+// `chn` interleaved channels are averaged on input and duplicated on output (src/webrtc.c:789-815).
+template <int L>  // samples per millisecond sub-frame: 8 (8 kHz) or 16 (16 / 32 kHz)
+__device__ void agc_packet(const AgcRef &S, const int32_t *__restrict__ gain_table, const int16_t *in, int16_t *out, int chn) {
+    constexpr int L2 = (L == 8) ? 3 : 4;
+    auto load = [&](int i) -> int16_t {
+        if (chn == 1) return in[i];
+        int32_t acc = 0;
+        for (int c = 0; c < chn; c++) acc += in[i * chn + c];
+        return (int16_t)(acc / chn);
+    };
+    // ---- pass 1 over the packet: level detector (ProcessVad) and per-millisecond peak energy
+    int32_t env[10];
+    int32_t nrg = 0;
+    {
+        int32_t ds[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) ds[i] = S.w(A32_DOWN + i);
+        int16_t hp = S.h(A16_HP);
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+            int32_t mx = 0;
+            int16_t x[L];
+#pragma unroll
+            for (int n = 0; n < L; n++) {
+                x[n] = load(k * L + n);
+                const int32_t e = x[n] * x[n];
+                if (e > mx) mx = e;
+            }
+            env[k] = mx;
+            int16_t b2[4];
+            if (L == 16) {
+                int16_t b1[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) b1[j] = (int16_t)(((int32_t)x[2 * j] + (int32_t)x[2 * j + 1]) >> 1);
+#pragma unroll
+                for (int j = 0; j < 4; j++) b2[j] = down2_step(b1[2 * j], b1[2 * j + 1], ds);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) b2[j] = down2_step(x[2 * j], x[2 * j + 1], ds);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int32_t o = b2[j] + hp;
+                const int32_t t = 600 * o;
+                hp = (int16_t)((t >> 10) - b2[j]);
+                nrg = wadd(nrg, (o * o) >> 6);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) S.w(A32_DOWN + i) = ds[i];
+        S.h(A16_HP) = hp;
+    }
+    // ---- ProcessVad statistics (digital_agc.c:685-770)
+    int16_t std_long, std_short, logratio;
+    {
+        const int16_t zeros = nrg == 0 ? 31 : (int16_t)__clz(nrg);
+        const int16_t dB = (int16_t)((15 - zeros) << 11);
+        int16_t counter = S.h(A16_COUNTER);
+        if (counter < 250) counter++;
+        S.h(A16_COUNTER) = counter;
+        int32_t t32 = S.h(A16_MEAN_SHORT) * 15 + dB;
+        const int16_t mean_short = (int16_t)(t32 >> 4);
+        S.h(A16_MEAN_SHORT) = mean_short;
+        t32 = (dB * dB) >> 12;
+        t32 += S.w(A32_VAR_SHORT) * 15;
+        const int32_t var_short = t32 / 16;
+        S.w(A32_VAR_SHORT) = var_short;
+        t32 = mean_short * mean_short;
+        t32 = wsub(wshl(var_short, 12), t32);
+        std_short = (int16_t)spl_sqrt(t32);
+        S.h(A16_STD_SHORT) = std_short;
+        t32 = S.h(A16_MEAN_LONG) * counter + dB;
+        const int16_t mean_long = (int16_t)(t32 / sat_w16((int32_t)counter + 1));
+        S.h(A16_MEAN_LONG) = mean_long;
+        t32 = (dB * dB) >> 12;
+        t32 += S.w(A32_VAR_LONG) * counter;
+        const int32_t var_long = div_w32_w16(t32, sat_w16((int32_t)counter + 1));
+        S.w(A32_VAR_LONG) = var_long;
+        t32 = mean_long * mean_long;
+        t32 = wsub(wshl(var_long, 12), t32);
+        std_long = (int16_t)spl_sqrt(t32);
+        S.h(A16_STD_LONG) = std_long;
+        const int16_t t16 = 3 << 12;
+        t32 = t16 * (int16_t)(dB - mean_long);
+        t32 = div_w32_w16(t32, std_long);
+        const int32_t t32b = (int32_t)S.h(A16_LOG_RATIO) * 53248;
+        t32 += t32b >> 10;
+        logratio = (int16_t)(t32 >> 6);
+        if (logratio > 2048) logratio = 2048;
+        if (logratio < -2048) logratio = -2048;
+        S.h(A16_LOG_RATIO) = logratio;
+    }
+    // ---- decay, envelope followers, gain curve (digital_agc.c:336-460)
+    int16_t decay;
+    if (logratio > 1024)
+        decay = -65;
+    else if (logratio < 0)
+        decay = 0;
+    else
+        decay = (int16_t)(((0 - logratio) * 65) >> 10);
+    if (std_long < 4000)
+        decay = 0;
+    else if (std_long < 8096)
+        decay = (int16_t)(((std_long - 4000) * decay) >> 12);
+    int32_t gains[11];
+    int32_t cap_fast = S.w(A32_CAP_FAST), cap_slow = S.w(A32_CAP_SLOW);
+    gains[0] = S.w(A32_GAIN);
+    int16_t zeros = 0, frac = 0;
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        cap_fast = agc_scalediff32(-1000, cap_fast, cap_fast);
+        if (env[k] > cap_fast) cap_fast = env[k];
+        if (env[k] > cap_slow)
+            cap_slow = agc_scalediff32(500, wsub(env[k], cap_slow), cap_slow);
+        else
+            cap_slow = agc_scalediff32(decay, cap_slow, cap_slow);
+        const int32_t cur = cap_fast > cap_slow ? cap_fast : cap_slow;
+        zeros = (int16_t)norm_u32((uint32_t)cur);
+        if (cur == 0) zeros = 31;
+        int32_t t32 = wshl(cur, zeros) & 0x7FFFFFFF;
+        frac = (int16_t)(t32 >> 19);
+        t32 = wmul(wsub(gain_table[(zeros - 1) & 31], gain_table[zeros & 31]), frac);
+        gains[k + 1] = wadd(gain_table[zeros & 31], t32 >> 12);
+    }
+    S.w(A32_CAP_FAST) = cap_fast;
+    S.w(A32_CAP_SLOW) = cap_slow;
+    // ---- gate (digital_agc.c:462-512)
+    zeros = (int16_t)((zeros << 9) - (frac >> 3));
+    int16_t zeros_fast = (int16_t)norm_u32((uint32_t)cap_fast);
+    if (cap_fast == 0) zeros_fast = 31;
+    {
+        const int32_t t32 = wshl(cap_fast, zeros_fast) & 0x7FFFFFFF;
+        zeros_fast = (int16_t)(zeros_fast << 9);
+        zeros_fast = (int16_t)(zeros_fast - (int16_t)(t32 >> 22));
+    }
+    int16_t gate = (int16_t)(1000 + zeros_fast - zeros - std_short);
+    if (gate < 0) {
+        S.h(A16_GATE_PREV) = 0;
+    } else {
+        const int32_t t32 = S.h(A16_GATE_PREV) * 7;
+        gate = (int16_t)((gate + t32) >> 3);
+        S.h(A16_GATE_PREV) = gate;
+    }
+    const int32_t g0 = gain_table[0];
+    if (gate > 0) {
+        const int16_t gain_adj = gate < 2500 ? (int16_t)((2500 - gate) >> 5) : (int16_t)0;
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+            int32_t t32;
+            if (wsub(gains[k + 1], g0) > 8388608) {
+                t32 = wsub(gains[k + 1], g0) >> 8;
+                t32 = wmul(t32, 178 + gain_adj);
+            } else {
+                t32 = wmul(wsub(gains[k + 1], g0), 178 + gain_adj);
+                t32 >>= 8;
+            }
+            gains[k + 1] = wadd(g0, t32);
+        }
+    }
+    // ---- overflow limiter (digital_agc.c:514-541)
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        int z = 10;
+        if (gains[k + 1] > 47453132) z = 16 - norm_w32(gains[k + 1]);
+        int32_t gain32 = (gains[k + 1] >> z) + 1;
+        gain32 = wmul(gain32, gain32);
+        while (agc_mul32((env[k] >> 12) + 1, gain32) > shift_w32((int32_t)32767, 2 * (1 - z + 10))) {
+            if (gains[k + 1] > 8388607)
+                gains[k + 1] = (gains[k + 1] / 256) * 253;
+            else
+                gains[k + 1] = (gains[k + 1] * 253) / 256;
+            gain32 = (gains[k + 1] >> z) + 1;
+            gain32 = wmul(gain32, gain32);
+        }
+    }
+#pragma unroll
+    for (int k = 1; k < 10; k++)
+        if (gains[k] > gains[k + 1]) gains[k] = gains[k + 1];
+    S.w(A32_GAIN) = gains[10];
+    // ---- pass 2: apply the ramped gain (digital_agc.c:552-603)
+    auto store = [&](int i, int16_t v) {
+        for (int c = 0; c < chn; c++) out[i * chn + c] = v;
+    };
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        const int32_t delta = wshl(wsub(gains[k + 1], gains[k]), 4 - L2);
+        int32_t gain32 = wshl(gains[k], 4);
+        int16_t x[L];
+#pragma unroll
+        for (int n = 0; n < L; n++) x[n] = load(k * L + n);  // all loads of the sub-frame before its stores (in == out)
+#pragma unroll
+        for (int n = 0; n < L; n++) {
+            int16_t y;
+            if (k == 0) {
+                const int32_t o = wmul(x[n], wadd(gain32, 127) >> 7) >> 16;
+                if (o > 4095)
+                    y = 32767;
+                else if (o < -4096)
+                    y = -32768;
+                else
+                    y = (int16_t)(wmul(x[n], gain32 >> 4) >> 16);
+            } else {
+                y = (int16_t)(wmul(x[n], gain32 >> 4) >> 16);
+            }
+            store(k * L + n, y);
+            gain32 = wadd(gain32, delta);
+        }
+    }
+}
+
+template <int L>
+__global__ __launch_bounds__(64) void agc_kernel(int16_t *s16, int32_t *s32, const int32_t *gain_table_g, const int16_t *in,
+                                                 int16_t *out, int n_streams, int n_packets, long stream_stride,
+                                                 long packet_stride, int chn) {
+    __shared__ int32_t gain_table[32];
+    if (threadIdx.x < 32) gain_table[threadIdx.x] = gain_table_g[threadIdx.x];
+    __syncthreads();
+    const int stream = blockIdx.x * 64 + threadIdx.x;
+    if (stream >= n_streams) return;
+    const AgcRef S{s16 + stream, s32 + stream, (size_t)n_streams};
+    for (int p = 0; p < n_packets; p++) {
+        const size_t off = (size_t)stream * stream_stride + (size_t)p * packet_stride;
+        agc_packet<L>(S, gain_table, in + off, out + off, chn);
+    }
+}
+
+__global__ void agc_fill_state(int16_t *s16, int32_t *s32, int n_streams) {
+    // WebRtcAgc_InitDigital digital_agc.c:259-282 + WebRtcAgc_InitVad :606-631
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n_streams; i += (size_t)gridDim.x * blockDim.x) {
+        for (int f = 0; f < A32_WORDS; f++) s32[(size_t)f * n_streams + i] = 0;
+        for (int f = 0; f < A16_WORDS; f++) s16[(size_t)f * n_streams + i] = 0;
+        s32[(size_t)A32_CAP_SLOW * n_streams + i] = 134217728;
+        s32[(size_t)A32_GAIN * n_streams + i] = 65536;
+        s32[(size_t)A32_VAR_LONG * n_streams + i] = 500 << 8;
+        s32[(size_t)A32_VAR_SHORT * n_streams + i] = 500 << 8;
+        s16[(size_t)A16_MEAN_LONG * n_streams + i] = 15 << 10;
+        s16[(size_t)A16_MEAN_SHORT * n_streams + i] = 15 << 10;
+        s16[(size_t)A16_COUNTER * n_streams + i] = 3;
+    }
+}
+
+// ---- host: WebRtcAgc_CalculateGainTable (digital_agc.c:61-257), integer arithmetic only ----
+inline int32_t h_wshl(int32_t a, int s) { return (int32_t)((uint32_t)a << s); }
+inline int32_t h_wmul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
+inline int32_t h_shift(int32_t x, int c) { return c >= 0 ? h_wshl(x, c) : (x >> (-c)); }
+inline int h_norm_w32(int32_t a) {
+    if (a == 0) return 0;
+    if (a < 0) a = ~a;
+    return a == 0 ? 31 : __builtin_clz((uint32_t)a) - 1;
+}
+inline int h_norm_u32(uint32_t a) { return a == 0 ? 0 : __builtin_clz(a); }
+inline int32_t h_div(int32_t num, int16_t den) { return den != 0 ? num / den : 0x7FFFFFFF; }
+
+int host_gain_table(int32_t *table, int16_t comp_db, int16_t target_dbfs, bool limiter, int16_t analog_target) {
+    // kGenFuncTable[i] = round(256 * log2(1 + e^i)) (digital_agc.c:38-56)
+    uint16_t gen[128];
+    for (int i = 0; i < 128; i++) gen[i] = (uint16_t)floor(256.0 * log2(1.0 + exp((double)i)) + 0.5);
+    const uint16_t kLog10 = 54426, kLog10_2 = 49321, kLogE_1 = 23637;
+    const int16_t kCompRatio = 3, constLinApprox = 22817;
+    const int16_t limiterOffset = 0;
+    int32_t t32 = (comp_db - analog_target) * (kCompRatio - 1);
+    int16_t t16 = (int16_t)(analog_target - target_dbfs);
+    t16 = (int16_t)(t16 + (int16_t)((t32 + (kCompRatio >> 1)) / kCompRatio));
+    const int16_t maxGain = t16 > (analog_target - target_dbfs) ? t16 : (int16_t)(analog_target - target_dbfs);
+    t32 = comp_db * (kCompRatio - 1);
+    const int16_t diffGain = (int16_t)((t32 + (kCompRatio >> 1)) / kCompRatio);
+    if (diffGain < 0 || diffGain >= 128) return -1;
+    const int16_t limiterLvlX = (int16_t)(analog_target - limiterOffset);
+    const int16_t limiterIdx = (int16_t)(2 + (int16_t)(((int32_t)limiterLvlX << 13) / (int16_t)(kLog10_2 / 2)));
+    const int32_t limiterLvl = target_dbfs + (int16_t)((limiterOffset + (kCompRatio >> 1)) / kCompRatio);
+    const uint16_t constMaxGain = gen[diffGain];
+    const int32_t den = 20 * (int32_t)constMaxGain;
+    for (int16_t i = 0; i < 32; i++) {
+        t16 = (int16_t)((kCompRatio - 1) * (i - 1));
+        t32 = (int32_t)t16 * kLog10_2 + 1;
+        int32_t inLevel = h_div(t32, kCompRatio);
+        inLevel = ((int32_t)diffGain << 14) - inLevel;
+        const uint32_t absIn = (uint32_t)(inLevel >= 0 ? inLevel : -inLevel);
+        uint16_t intPart = (uint16_t)(absIn >> 14), fracPart = (uint16_t)(absIn & 0x3FFF);
+        const uint16_t tU16 = (uint16_t)(gen[intPart + 1] - gen[intPart]);
+        uint32_t u1 = (uint32_t)tU16 * fracPart, u2;
+        u1 += (uint32_t)gen[intPart] << 14;
+        uint32_t logApprox = u1 >> 8;
+        if (inLevel < 0) {
+            const int zeros = h_norm_u32(absIn);
+            int zerosScale = 0;
+            if (zeros < 15) {
+                u2 = absIn >> (15 - zeros);
+                u2 = u2 * kLogE_1;
+                if (zeros < 9) {
+                    zerosScale = 9 - zeros;
+                    u1 >>= zerosScale;
+                } else {
+                    u2 >>= zeros - 9;
+                }
+            } else {
+                u2 = absIn * kLogE_1;
+                u2 >>= 6;
+            }
+            logApprox = 0;
+            if (u2 < u1) logApprox = (u1 - u2) >> (8 - zerosScale);
+        }
+        int32_t numFIX = h_wshl(maxGain * constMaxGain, 6);
+        numFIX = (int32_t)((uint32_t)numFIX - (uint32_t)h_wmul((int32_t)logApprox, diffGain));
+        int zeros;
+        if (numFIX > (den >> 8))
+            zeros = h_norm_w32(numFIX);
+        else
+            zeros = h_norm_w32(den) + 8;
+        numFIX = h_wshl(numFIX, zeros);
+        const int32_t d = h_shift(den, zeros - 8);
+        if (numFIX < 0)
+            numFIX -= d / 2;
+        else
+            numFIX += d / 2;
+        int32_t y32 = numFIX / d;
+        if (limiter && (i < limiterIdx)) {
+            t32 = (int32_t)(int16_t)(i - 1) * kLog10_2;
+            t32 -= limiterLvl << 14;
+            y32 = h_div(t32 + 10, 20);
+        }
+        if (y32 > 39000) {
+            t32 = (int32_t)((uint32_t)h_wmul(y32 >> 1, kLog10) + 4096u);
+            t32 >>= 13;
+        } else {
+            t32 = (int32_t)((uint32_t)h_wmul(y32, kLog10) + 8192u);
+            t32 >>= 14;
+        }
+        t32 += 16 << 14;
+        if (t32 > 0) {
+            intPart = (uint16_t)(int16_t)(t32 >> 14);
+            fracPart = (uint16_t)(t32 & 0x3FFF);
+            int32_t t2;
+            if ((fracPart >> 13) != 0) {
+                t16 = (int16_t)((2 << 14) - constLinApprox);
+                t2 = (1 << 14) - fracPart;
+                t2 *= t16;
+                t2 >>= 13;
+                t2 = (1 << 14) - t2;
+            } else {
+                t16 = (int16_t)(constLinApprox - (1 << 14));
+                t2 = (fracPart * t16) >> 13;
+            }
+            fracPart = (uint16_t)t2;
+            table[i] = (int32_t)((uint32_t)h_wshl(1, intPart) + (uint32_t)h_shift(fracPart, intPart - 14));
+        } else {
+            table[i] = 0;
+        }
+    }
+    return 0;
+}
+
+// analog_agc.c:438-444 (UpdateAgcThresholds, adaptive-digital mode)
+int16_t analog_target_for(int16_t comp_db) {
+    int16_t t = (int16_t)((5 * comp_db) + 5);
+    t = (int16_t)((int32_t)t / 11);
+    const int16_t a = (int16_t)(4 + t);
+    return a < 4 ? (int16_t)4 : a;
+}
+
+}  // namespace
+}  // namespace wmx
+
+struct wmx_agc {
+    int n_streams, chn, freq, pkg;
+    int16_t *d_s16;
+    int32_t *d_s32;
+    int32_t *d_table;
+    int32_t table[32];
+};
+
+extern "C" {
+
+int wmx_agc_destroy(wmx_agc *h) {
+    if (!h) return 0;
+    if (h->d_s16) (void)hipFree(h->d_s16);
+    if (h->d_s32) (void)hipFree(h->d_s32);
+    if (h->d_table) (void)hipFree(h->d_table);
+    delete h;
+    return 0;
+}
+
+// agc_addition (src/webrtc.c:824-839): WebRtcAgc_set_config with a new compression gain -> new table.
+// Returns WMX_EINVAL and keeps the old table when the reference's set_config would fail.
+int wmx_agc_set_gain(wmx_agc *h, int value) {
+    using namespace wmx;
+    if (!h) return WMX_EINVAL;
+    int32_t t[32];
+    const int16_t comp = (int16_t)value;
+    if (host_gain_table(t, comp, 0, false, analog_target_for(comp)) != 0) {
+        set_error("wmx_agc_set_gain: compression gain %d dB is outside the gain-table range", value);
+        return WMX_EINVAL;
+    }
+    memcpy(h->table, t, sizeof(t));
+    WMX_HIP(hipMemcpy(h->d_table, t, sizeof(t), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int wmx_agc_create(wmx_agc **out, int n_streams, int chn, int freq, int interval_ms, int value) {
+    using namespace wmx;
+    (void)interval_ms;
+    if (!out) return WMX_EINVAL;
+    *out = nullptr;
+    if (freq > 32000 || freq % 8000 != 0 || freq <= 0 || chn < 1 || n_streams < 1) {  // src/webrtc.c:711-712
+        set_error("wmx_agc_create: unsupported n_streams=%d chn=%d freq=%d", n_streams, chn, freq);
+        return WMX_EINVAL;
+    }
+    wmx_agc *h = new wmx_agc();
+    h->n_streams = n_streams;
+    h->chn = chn;
+    h->freq = freq;
+    h->pkg = freq / 1000 * (freq <= 16000 ? 10 : 5);  // 5 ms packets at 32 kHz, src/webrtc.c:724-728
+    hipError_t e;
+#define AGC_TRY(x)                                         \
+    if ((e = (x)) != hipSuccess) {                         \
+        int rc = hip_fail(e, #x, __FILE__, __LINE__);      \
+        wmx_agc_destroy(h);                                \
+        return rc;                                         \
+    }
+    AGC_TRY(hipMalloc(&h->d_s16, (size_t)A16_WORDS * n_streams * sizeof(int16_t)));
+    AGC_TRY(hipMalloc(&h->d_s32, (size_t)A32_WORDS * n_streams * sizeof(int32_t)));
+    AGC_TRY(hipMalloc(&h->d_table, 32 * sizeof(int32_t)));
+    hipLaunchKernelGGL(agc_fill_state, dim3(512), dim3(256), 0, nullptr, h->d_s16, h->d_s32, n_streams);
+    AGC_TRY(hipGetLastError());
+    AGC_TRY(hipDeviceSynchronize());
+#undef AGC_TRY
+    const int rc = wmx_agc_set_gain(h, value);  // agc_init fails (NULL) when set_config fails
+    if (rc != 0) {
+        wmx_agc_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+int wmx_agc_packet_samples(const wmx_agc *h) { return h ? h->pkg * h->chn : WMX_EINVAL; }
+
+int wmx_agc_gain_table(const wmx_agc *h, int32_t *host_table32) {
+    if (!h || !host_table32) return WMX_EINVAL;
+    memcpy(host_table32, h->table, sizeof(h->table));
+    return 0;
+}
+
+int wmx_agc_process(wmx_agc *h, const int16_t *d_in, int16_t *d_out, int n_packets, long stream_stride, long packet_stride,
+                    void *stream) {
+    using namespace wmx;
+    if (!h || !d_in || !d_out || n_packets < 0) {
+        set_error("wmx_agc_process: bad argument");
+        return WMX_EINVAL;
+    }
+    if (n_packets == 0) return 0;
+    const long per_pkt = (long)h->pkg * h->chn;
+    if (packet_stride < per_pkt || (h->n_streams > 1 && stream_stride < per_pkt)) {
+        set_error("wmx_agc_process: strides (%ld, %ld) smaller than a packet (%ld samples)", stream_stride, packet_stride, per_pkt);
+        return WMX_EINVAL;
+    }
+    const dim3 grid((h->n_streams + 63) / 64), block(64);
+    hipStream_t s = as_stream(stream);
+    if (h->freq == 8000)
+        hipLaunchKernelGGL((agc_kernel<8>), grid, block, 0, s, h->d_s16, h->d_s32, h->d_table, d_in, d_out, h->n_streams, n_packets,
+                           stream_stride, packet_stride, h->chn);
+    else
+        hipLaunchKernelGGL((agc_kernel<16>), grid, block, 0, s, h->d_s16, h->d_s32, h->d_table, d_in, d_out, h->n_streams, n_packets,
+                           stream_stride, packet_stride, h->chn);
+    WMX_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -40,9 +40,121 @@ struct NsHandleCompat {
     DevBuf buf;
 };
 
+struct VadHandleCompat {
+    wmx_vad *batch;
+    int chn, freq, pkg;
+    bool *debug;
+    DevBuf buf;
+};
+
+struct AgcHandleCompat {
+    wmx_agc *batch;
+    int chn, freq, pkg;
+    bool *debug;
+    DevBuf buf;
+};
+
 }  // namespace
 
 extern "C" {
+
+// src/webrtc.c:40-82
+void *vad_init(int chn, int freq, int intervalMs, bool *debug) {
+    if (freq > 32000 || freq % 8000 != 0) return NULL;
+    wmx_vad *b = nullptr;
+    if (wmx_vad_create(&b, 1, chn, freq, intervalMs) != 0) {
+        if (debug && *debug) printf("WebRtcVad_Create failed !! (%s)\r\n", wmx_last_error());
+        return NULL;
+    }
+    VadHandleCompat *h = new VadHandleCompat();
+    h->batch = b;
+    h->chn = chn;
+    h->freq = freq;
+    h->pkg = wmx_vad_packet_samples(b) / chn;
+    h->debug = debug;
+    if (debug && *debug) printf("vad_init: chn/%d freq/%d intervalMs/%d pkgFrame/%d\r\n", chn, freq, h->pkg / (freq / 1000), h->pkg);
+    return h;
+}
+
+// src/webrtc.c:91-151: one call = ceil(frameNum / pkgFrame) decisions, all on packet 0
+void vad_process(void *fp, int16_t *frame, int frameNum) {
+    VadHandleCompat *h = static_cast<VadHandleCompat *>(fp);
+    const int packets = (frameNum + h->pkg - 1) / h->pkg;
+    if (packets <= 0) return;
+    const size_t n = (size_t)packets * h->pkg * h->chn, given = (size_t)frameNum * h->chn;
+    bool ok = h->buf.ensure(n);
+    ok = ok && hipMemcpy(h->buf.p, frame, given * sizeof(int16_t), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && wmx_vad_process(h->batch, h->buf.p, packets, 1, 0, (long)n, nullptr) == 0;
+    ok = ok && hipMemcpy(frame, h->buf.p, given * sizeof(int16_t), hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        fprintf(stderr, "wmix_amd: vad_process failed on the GPU: %s\n", wmx_last_error());
+    }
+}
+
+// src/webrtc.c:156-164
+void vad_release(void *fp) {
+    VadHandleCompat *h = static_cast<VadHandleCompat *>(fp);
+    if (!h) return;
+    wmx_vad_destroy(h->batch);
+    if (h->debug && *h->debug) printf("vad_release\r\n");
+    delete h;
+}
+
+// src/webrtc.c:694-753
+void *agc_init(int chn, int freq, int intervalMs, int value, bool *debug) {
+    if (freq > 32000 || freq % 8000 != 0) return NULL;
+    wmx_agc *b = nullptr;
+    if (wmx_agc_create(&b, 1, chn, freq, intervalMs, value) != 0) {
+        if (debug && *debug) printf("WebRtcAgc_set_config failed !! (%s)\r\n", wmx_last_error());
+        return NULL;
+    }
+    AgcHandleCompat *h = new AgcHandleCompat();
+    h->batch = b;
+    h->chn = chn;
+    h->freq = freq;
+    h->pkg = wmx_agc_packet_samples(b) / chn;
+    h->debug = debug;
+    if (debug && *debug)
+        printf("agc_init: chn/%d freq/%d intervalMs/%d pkgFrame/%d x %d\r\n", chn, freq, freq <= 16000 ? 10 : 5, h->pkg, chn);
+    return h;
+}
+
+// src/webrtc.c:767-819: 0 on success, -1 on failure
+int agc_process(void *fp, int16_t *frame, int16_t *frameOut, int frameNum) {
+    AgcHandleCompat *h = static_cast<AgcHandleCompat *>(fp);
+    const int per_pkt = h->pkg * h->chn, total = frameNum * h->chn;
+    const int n_packets = (total + per_pkt - 1) / per_pkt;
+    if (n_packets <= 0) return 0;
+    const size_t n = (size_t)n_packets * per_pkt;
+    bool ok = h->buf.ensure(n);
+    ok = ok && hipMemcpy(h->buf.p, frame, (size_t)total * sizeof(int16_t), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && wmx_agc_process(h->batch, h->buf.p, h->buf.p, n_packets, 0, per_pkt, nullptr) == 0;
+    ok = ok && hipMemcpy(frameOut, h->buf.p, (size_t)total * sizeof(int16_t), hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        if (h->debug && *h->debug) printf("WebRtcAgc_Process failed !!, ret %d \r\n", -1);
+        fprintf(stderr, "wmix_amd: agc_process failed on the GPU: %s\n", wmx_last_error());
+        return -1;
+    }
+    return 0;
+}
+
+// src/webrtc.c:824-839
+void agc_addition(void *fp, uint8_t value) {
+    AgcHandleCompat *h = static_cast<AgcHandleCompat *>(fp);
+    const int ret = wmx_agc_set_gain(h->batch, (int)value);
+    if (ret != 0 && h->debug && *h->debug) printf("WebRtcAgc_set_config failed !!, ret %d \r\n", -1);
+}
+
+// src/webrtc.c:844-860
+void agc_release(void *fp) {
+    AgcHandleCompat *h = static_cast<AgcHandleCompat *>(fp);
+    if (!h) return;
+    wmx_agc_destroy(h->batch);
+    if (h->debug && *h->debug) printf("agc_release\r\n");
+    delete h;
+}
 
 // src/webrtc.c:560-602
 void *ns_init(int chn, int freq, bool *debug) {

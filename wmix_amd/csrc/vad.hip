@@ -1,0 +1,630 @@
+// vad.hip -- batched voice-activity gate for gfx950: one LANE per stream.
+//
+// Replaces, for many independent streams per launch, wmix's vad_process() (src/webrtc.c:91-151)
+// over WebRtcVad_Process in mode 3 (W:common_audio/vad/webrtc_vad.c:71-104, vad_core.c:124-674,
+// vad_filterbank.c:41-333, vad_gmm.c:30-83, vad_sp.c:27-177).  The whole path is a chain of
+// short integer recurrences (all-pass decimators, GMM update, a 16-entry order-statistics
+// filter), so there is nothing to parallelise inside a stream: 64 streams ride one wavefront,
+// per-stream state is laid out field-major ([field][stream]) so every state access of the wave
+// is one 128/256-byte line, and the sub-band signals of the 6-band split tree live in LDS as
+// [sample][lane] int16 (bank-conflict free).  Results are bit-exact with the reference; signed
+// overflow that the reference leaves to two's-complement wrap is spelled out.
+//
+// Kept reference quirks: a call of several packets always analyses packet 0
+// and only packet 0 is attenuated; multi-channel input is mean-downmixed in place and expanded
+// backwards afterwards.
+#include <vector>
+#include "wmx_internal.h"
+#include "spl_dev.h"
+
+namespace wmx {
+namespace {
+
+// ---- field-major state: int16 words and int32 words (VadInstT, vad_core.h:27-56; Vad_Struct.reduce)
+enum : int {
+    V16_NOISE_MEANS = 0,
+    V16_SPEECH_MEANS = 12,
+    V16_NOISE_STDS = 24,
+    V16_SPEECH_STDS = 36,
+    V16_OVER_HANG = 48,
+    V16_NUM_SPEECH = 49,
+    V16_AGE = 50,         // index_vector[96]
+    V16_LOW = 146,        // low_value_vector[96]
+    V16_MEAN_VALUE = 242,
+    V16_UPPER = 248,
+    V16_LOWER = 253,
+    V16_HP = 258,
+    V16_REDUCE = 262,
+    V16_WORDS = 263,
+    V32_DS = 0,  // downsampling_filter_states[4]
+    V32_FRAME_COUNTER = 4,
+    V32_WORDS = 5,
+};
+
+struct VadRef {
+    int16_t *s16;
+    int32_t *s32;
+    size_t n;  // streams (row pitch)
+    __device__ __forceinline__ int16_t &h(int f) const { return s16[(size_t)f * n]; }
+    __device__ __forceinline__ int32_t &w(int f) const { return s32[(size_t)f * n]; }
+};
+
+// LDS int16 buffer private to one lane: element i lives at base[i * 64]
+struct LaneBuf {
+    int16_t *base;
+    __device__ __forceinline__ int16_t &operator[](int i) const { return base[i * 64]; }
+};
+
+__constant__ int16_t kNoiseW[12] = {34, 62, 72, 66, 53, 25, 94, 66, 56, 62, 75, 103};
+__constant__ int16_t kSpeechW[12] = {48, 82, 45, 87, 50, 47, 80, 46, 83, 41, 78, 81};
+__constant__ int16_t kSpecW[6] = {6, 8, 10, 12, 14, 16};
+__constant__ int16_t kMinDiff[6] = {544, 544, 576, 576, 576, 576};
+__constant__ int16_t kMaxSpeech[6] = {11392, 11392, 11520, 11520, 11520, 11520};
+__constant__ int16_t kMaxNoise[6] = {9216, 9088, 8960, 8832, 8704, 8576};
+
+// vad_sp.c:27-54: one output sample of the 2:1 all-pass decimator
+__device__ __forceinline__ int16_t ds2_step(int16_t a, int16_t b, int32_t &s1, int32_t &s2) {
+    const int16_t t1 = (int16_t)((s1 >> 1) + ((5243 * a) >> 14));
+    s1 = (int32_t)a - ((5243 * t1) >> 12);
+    const int16_t t2 = (int16_t)((s2 >> 1) + ((1392 * b) >> 14));
+    s2 = (int32_t)b - ((1392 * t2) >> 12);
+    return (int16_t)(t1 + t2);
+}
+
+// vad_filterbank.c:83-118: one step of the first-order all-pass (state kept as the Q15 32-bit value)
+__device__ __forceinline__ int16_t allpass_step(int16_t x, int16_t coef, int32_t &s32) {
+    const int32_t t32 = wadd(s32, coef * x);
+    const int16_t t16 = (int16_t)(t32 >> 16);
+    s32 = (int32_t)x << 14;
+    s32 = wsub(s32, coef * t16);
+    s32 = wshl(s32, 1);
+    return t16;
+}
+
+// vad_filterbank.c:121-145 for a source that is already in LDS
+__device__ void split_lds(const LaneBuf in, int len, int16_t &up_state, int16_t &lo_state, LaneBuf hp, LaneBuf lp) {
+    const int half = len >> 1;
+    int32_t su = wshl(up_state, 16), sl = wshl(lo_state, 16);
+    for (int i = 0; i < half; i++) {
+        const int16_t h = allpass_step(in[2 * i], 20972, su);
+        const int16_t l = allpass_step(in[2 * i + 1], 5571, sl);
+        hp[i] = (int16_t)(h - l);
+        lp[i] = (int16_t)(l + h);
+    }
+    up_state = (int16_t)(su >> 16);
+    lo_state = (int16_t)(sl >> 16);
+}
+
+// vad_filterbank.c:155-243 (+ energy.c:20-39, get_scaling_square.c:20-47)
+__device__ void log_energy(const LaneBuf v, int n, int16_t offset, int16_t &total, int16_t &out) {
+    const int nbits = size_in_bits((uint32_t)n);
+    int16_t smax = -1;
+    for (int i = 0; i < n; i++) {
+        const int16_t x = v[i];
+        const int16_t sabs = (int16_t)(x > 0 ? x : -x);
+        if (sabs > smax) smax = sabs;
+    }
+    const int t = norm_w32((int32_t)smax * smax);
+    int rsh = (smax == 0) ? 0 : ((t > nbits) ? 0 : nbits - t);
+    uint32_t energy = 0;
+    for (int i = 0; i < n; i++) {
+        const int32_t x = v[i];
+        energy += (uint32_t)((x * x) >> rsh);
+    }
+    if (energy == 0) {
+        out = offset;
+        return;
+    }
+    const int norm = 17 - norm_u32(energy);
+    int16_t log2e = 14336;
+    rsh += norm;
+    if (norm < 0)
+        energy <<= -norm;
+    else
+        energy >>= norm;
+    log2e = (int16_t)(log2e + (int16_t)((energy & 0x3FFF) >> 4));
+    int16_t le = (int16_t)(((24660 * log2e) >> 19) + ((rsh * 24660) >> 9));
+    if (le < 0) le = 0;
+    out = (int16_t)(le + offset);
+    if (total <= 10) {
+        if (rsh >= 0)
+            total = (int16_t)(total + 10 + 1);
+        else
+            total = (int16_t)(total + (int16_t)(energy >> -rsh));
+    }
+}
+
+// vad_gmm.c:30-83
+__device__ int32_t gauss_prob(int16_t input, int16_t mean, int16_t std, int16_t &delta) {
+    int16_t exp_value = 0;
+    int32_t t32 = (int32_t)131072 + (int32_t)(std >> 1);
+    const int16_t inv_std = (int16_t)div_w32_w16(t32, std);
+    int16_t t16 = (int16_t)(inv_std >> 2);
+    const int16_t inv_std2 = (int16_t)((t16 * t16) >> 2);
+    t16 = (int16_t)(input << 3);
+    t16 = (int16_t)(t16 - mean);
+    delta = (int16_t)((inv_std2 * t16) >> 10);
+    t32 = (delta * t16) >> 9;
+    if (t32 < 22005) {
+        t16 = (int16_t)((5909 * t32) >> 12);
+        t16 = (int16_t)-t16;
+        exp_value = (int16_t)(0x0400 | (t16 & 0x03FF));
+        t16 = (int16_t)(t16 ^ (int16_t)0xFFFF);
+        t16 = (int16_t)(t16 >> 10);
+        t16 = (int16_t)(t16 + 1);
+        exp_value = (int16_t)(exp_value >> t16);
+    }
+    return inv_std * exp_value;
+}
+
+// vad_sp.c:59-177, operating directly on the field-major state rows
+__device__ int16_t find_minimum(const VadRef &S, int16_t v, int ch, int32_t frame_counter) {
+    const int a0 = V16_AGE + (ch << 4), l0 = V16_LOW + (ch << 4);
+    for (int i = 0; i < 16; i++) {
+        const int16_t age = S.h(a0 + i);
+        if (age != 100) {
+            S.h(a0 + i) = (int16_t)(age + 1);
+        } else {
+            for (int j = i; j < 15; j++) {
+                S.h(l0 + j) = S.h(l0 + j + 1);
+                S.h(a0 + j) = S.h(a0 + j + 1);
+            }
+            S.h(a0 + 15) = 101;
+            S.h(l0 + 15) = 10000;
+        }
+    }
+    int pos = -1;
+    if (v < S.h(l0 + 15)) {  // sorted ascending: the reference's unrolled binary search == first larger element
+        pos = 0;
+        while (!(v < S.h(l0 + pos))) pos++;
+    }
+    if (pos > -1) {
+        for (int i = 15; i > pos; i--) {
+            S.h(l0 + i) = S.h(l0 + i - 1);
+            S.h(a0 + i) = S.h(a0 + i - 1);
+        }
+        S.h(l0 + pos) = v;
+        S.h(a0 + pos) = 1;
+    }
+    int16_t median = 1600, alpha = 0;
+    if (frame_counter > 2)
+        median = S.h(l0 + 2);
+    else if (frame_counter > 0)
+        median = S.h(l0);
+    const int16_t mean = S.h(V16_MEAN_VALUE + ch);
+    if (frame_counter > 0) alpha = (median < mean) ? 6553 : 32439;
+    int32_t t = (alpha + 1) * mean;
+    t += (32767 - alpha) * median;
+    t += 16384;
+    const int16_t r = (int16_t)(t >> 15);
+    S.h(V16_MEAN_VALUE + ch) = r;
+    return r;
+}
+
+// vad_core.c:108-118 on rows base+c and base+c+6
+__device__ __forceinline__ int32_t weighted_avg(const VadRef &S, int base, int c, int16_t offset, const int16_t *w) {
+    int32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int16_t d = (int16_t)(S.h(base + c + 6 * k) + offset);
+        S.h(base + c + 6 * k) = d;
+        acc += d * w[c + 6 * k];
+    }
+    return acc;
+}
+
+// vad_core.c:124-479 with the mode-3 thresholds of vad_core.c:88-91
+__device__ int16_t gmm_probability(const VadRef &S, const int16_t *feat, int16_t total_power, int idx) {
+    const int16_t oh1 = idx == 0 ? 6 : (idx == 1 ? 3 : 2), oh2 = idx == 0 ? 9 : (idx == 1 ? 5 : 3);
+    const int16_t loc = 94, glob = idx == 1 ? 1050 : 1100;
+    int16_t vadflag = 0;
+    if (total_power > 10) {
+        int16_t dN[12], dS[12], ngpr[12], sgpr[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) ngpr[i] = sgpr[i] = 0;
+        int32_t sum_llr = 0;
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            int32_t h0t = 0, h1t = 0, np0 = 0, sp0 = 0;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int g = c + k * 6;
+                const int32_t npk = kNoiseW[g] * gauss_prob(feat[c], S.h(V16_NOISE_MEANS + g), S.h(V16_NOISE_STDS + g), dN[g]);
+                h0t += npk;
+                const int32_t spk = kSpeechW[g] * gauss_prob(feat[c], S.h(V16_SPEECH_MEANS + g), S.h(V16_SPEECH_STDS + g), dS[g]);
+                h1t += spk;
+                if (k == 0) {
+                    np0 = npk;
+                    sp0 = spk;
+                }
+            }
+            int16_t sh0 = (int16_t)norm_w32(h0t), sh1 = (int16_t)norm_w32(h1t);
+            if (h0t == 0) sh0 = 31;
+            if (h1t == 0) sh1 = 31;
+            const int16_t llr = (int16_t)(sh0 - sh1);
+            sum_llr += (int32_t)(llr * kSpecW[c]);
+            if ((llr * 4) > loc) vadflag = 1;
+            const int16_t h0 = (int16_t)(h0t >> 12);
+            if (h0 > 0) {
+                ngpr[c] = (int16_t)div_w32_w16(wshl((int32_t)(np0 & 0xFFFFF000), 2), h0);
+                ngpr[c + 6] = (int16_t)(16384 - ngpr[c]);
+            } else {
+                ngpr[c] = 16384;
+            }
+            const int16_t h1 = (int16_t)(h1t >> 12);
+            if (h1 > 0) {
+                sgpr[c] = (int16_t)div_w32_w16(wshl((int32_t)(sp0 & 0xFFFFF000), 2), h1);
+                sgpr[c + 6] = (int16_t)(16384 - sgpr[c]);
+            }
+        }
+        vadflag |= (sum_llr >= glob);
+        const int32_t frame_counter = S.w(V32_FRAME_COUNTER);
+        int16_t maxspe = 12800;
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            const int16_t fmin = find_minimum(S, feat[c], c, frame_counter);
+            int32_t ngm = weighted_avg(S, V16_NOISE_MEANS, c, 0, kNoiseW);
+            const int16_t t1 = (int16_t)(ngm >> 6);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int g = c + k * 6;
+                const int16_t nmk = S.h(V16_NOISE_MEANS + g), smk = S.h(V16_SPEECH_MEANS + g);
+                int16_t nsk = S.h(V16_NOISE_STDS + g), ssk = S.h(V16_SPEECH_STDS + g);
+                int16_t nmk2 = nmk, t16;
+                if (!vadflag) {
+                    const int16_t delt = (int16_t)((ngpr[g] * dN[g]) >> 11);
+                    nmk2 = (int16_t)(nmk + (int16_t)((delt * 655) >> 22));
+                }
+                const int16_t ndelt = (int16_t)((fmin << 4) - t1);
+                int16_t nmk3 = (int16_t)(nmk2 + (int16_t)((ndelt * 154) >> 9));
+                t16 = (int16_t)((k + 5) << 7);
+                if (nmk3 < t16) nmk3 = t16;
+                t16 = (int16_t)((72 + k - c) << 7);
+                if (nmk3 > t16) nmk3 = t16;
+                S.h(V16_NOISE_MEANS + g) = nmk3;
+                if (vadflag) {
+                    const int16_t delt = (int16_t)((sgpr[g] * dS[g]) >> 11);
+                    t16 = (int16_t)((delt * 6554) >> 21);
+                    int16_t smk2 = (int16_t)(smk + ((t16 + 1) >> 1));
+                    const int16_t maxmu = (int16_t)(maxspe + 640);
+                    const int16_t minmean = k == 0 ? 640 : 768;
+                    if (smk2 < minmean) smk2 = minmean;
+                    if (smk2 > maxmu) smk2 = maxmu;
+                    S.h(V16_SPEECH_MEANS + g) = smk2;
+                    t16 = (int16_t)((smk + 4) >> 3);
+                    t16 = (int16_t)(feat[c] - t16);
+                    int32_t a = (dS[g] * t16) >> 3;
+                    int32_t b = a - 4096;
+                    t16 = (int16_t)(sgpr[g] >> 2);
+                    a = t16 * b;
+                    b = a >> 4;
+                    if (b > 0) {
+                        t16 = (int16_t)div_w32_w16(b, (int16_t)(ssk * 10));
+                    } else {
+                        t16 = (int16_t)div_w32_w16(-b, (int16_t)(ssk * 10));
+                        t16 = (int16_t)-t16;
+                    }
+                    t16 = (int16_t)(t16 + 128);
+                    ssk = (int16_t)(ssk + (t16 >> 8));
+                    if (ssk < 384) ssk = 384;
+                    S.h(V16_SPEECH_STDS + g) = ssk;
+                } else {
+                    t16 = (int16_t)(feat[c] - (nmk >> 3));
+                    int32_t a = (dN[g] * t16) >> 3;
+                    a -= 4096;
+                    t16 = (int16_t)((ngpr[g] + 2) >> 2);
+                    const int32_t b = t16 * a;
+                    a = b >> 14;
+                    if (a > 0) {
+                        t16 = (int16_t)div_w32_w16(a, nsk);
+                    } else {
+                        t16 = (int16_t)div_w32_w16(-a, nsk);
+                        t16 = (int16_t)-t16;
+                    }
+                    t16 = (int16_t)(t16 + 32);
+                    nsk = (int16_t)(nsk + (t16 >> 6));
+                    if (nsk < 384) nsk = 384;
+                    S.h(V16_NOISE_STDS + g) = nsk;
+                }
+            }
+            ngm = weighted_avg(S, V16_NOISE_MEANS, c, 0, kNoiseW);
+            int32_t sgm = weighted_avg(S, V16_SPEECH_MEANS, c, 0, kSpeechW);
+            const int16_t diff = (int16_t)((int16_t)(sgm >> 9) - (int16_t)(ngm >> 9));
+            if (diff < kMinDiff[c]) {
+                const int16_t t16 = (int16_t)(kMinDiff[c] - diff);
+                const int16_t u1 = (int16_t)((13 * t16) >> 2), u2 = (int16_t)((3 * t16) >> 2);
+                sgm = weighted_avg(S, V16_SPEECH_MEANS, c, u1, kSpeechW);
+                ngm = weighted_avg(S, V16_NOISE_MEANS, c, (int16_t)-u2, kNoiseW);
+            }
+            maxspe = kMaxSpeech[c];
+            int16_t t2 = (int16_t)(sgm >> 7);
+            if (t2 > maxspe) {
+                t2 = (int16_t)(t2 - maxspe);
+#pragma unroll
+                for (int k = 0; k < 2; k++) S.h(V16_SPEECH_MEANS + c + 6 * k) = (int16_t)(S.h(V16_SPEECH_MEANS + c + 6 * k) - t2);
+            }
+            t2 = (int16_t)(ngm >> 7);
+            if (t2 > kMaxNoise[c]) {
+                t2 = (int16_t)(t2 - kMaxNoise[c]);
+#pragma unroll
+                for (int k = 0; k < 2; k++) S.h(V16_NOISE_MEANS + c + 6 * k) = (int16_t)(S.h(V16_NOISE_MEANS + c + 6 * k) - t2);
+            }
+        }
+        S.w(V32_FRAME_COUNTER) = frame_counter + 1;
+    }
+    int16_t over_hang = S.h(V16_OVER_HANG), num_speech = S.h(V16_NUM_SPEECH);
+    if (!vadflag) {
+        if (over_hang > 0) {
+            vadflag = (int16_t)(2 + over_hang);
+            over_hang--;
+        }
+        num_speech = 0;
+    } else {
+        num_speech++;
+        if (num_speech > 6) {
+            num_speech = 6;
+            over_hang = oh2;
+        } else {
+            over_hang = oh1;
+        }
+    }
+    S.h(V16_OVER_HANG) = over_hang;
+    S.h(V16_NUM_SPEECH) = num_speech;
+    return vadflag;
+}
+
+// WebRtcVad_Process (webrtc_vad.c:71-104) on one packet of NB*RATIO samples at fs = 8000*RATIO.
+// RATIO = 1, 2, 4 (vad_core.c:623-674: one or two chained 2:1 decimators in front of the 8 kHz core).
+template <int NB, int RATIO>
+__device__ int vad_packet(const VadRef &S, const int16_t *p, LaneBuf hp120, LaneBuf lp120, LaneBuf hp60, LaneBuf lp60) {
+    // ---- decimation to 8 kHz fused with the first band split (vad_filterbank.c:268-270)
+    {
+        int32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+        if (RATIO >= 2) {
+            d0 = S.w(V32_DS + 0);
+            d1 = S.w(V32_DS + 1);
+        }
+        if (RATIO == 4) {
+            d2 = S.w(V32_DS + 2);
+            d3 = S.w(V32_DS + 3);
+        }
+        int16_t up = S.h(V16_UPPER + 0), lo = S.h(V16_LOWER + 0);
+        int32_t su = wshl(up, 16), sl = wshl(lo, 16);
+        for (int i = 0; i < NB / 2; i++) {
+            int16_t nb[2];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int16_t *q = p + (2 * i + e) * RATIO;
+                if (RATIO == 1) {
+                    nb[e] = q[0];
+                } else if (RATIO == 2) {
+                    nb[e] = ds2_step(q[0], q[1], d0, d1);
+                } else {
+                    const int16_t w0 = ds2_step(q[0], q[1], d2, d3);
+                    const int16_t w1 = ds2_step(q[2], q[3], d2, d3);
+                    nb[e] = ds2_step(w0, w1, d0, d1);
+                }
+            }
+            const int16_t h = allpass_step(nb[0], 20972, su);
+            const int16_t l = allpass_step(nb[1], 5571, sl);
+            hp120[i] = (int16_t)(h - l);
+            lp120[i] = (int16_t)(l + h);
+        }
+        S.h(V16_UPPER + 0) = (int16_t)(su >> 16);
+        S.h(V16_LOWER + 0) = (int16_t)(sl >> 16);
+        if (RATIO >= 2) {
+            S.w(V32_DS + 0) = d0;
+            S.w(V32_DS + 1) = d1;
+        }
+        if (RATIO == 4) {
+            S.w(V32_DS + 2) = d2;
+            S.w(V32_DS + 3) = d3;
+        }
+    }
+    // ---- rest of WebRtcVad_CalculateFeatures (vad_filterbank.c:272-332)
+    int16_t feat[6], total = 0;
+    auto do_split = [&](LaneBuf in, int len, int band, LaneBuf hp, LaneBuf lp) {
+        int16_t up = S.h(V16_UPPER + band), lo = S.h(V16_LOWER + band);
+        split_lds(in, len, up, lo, hp, lp);
+        S.h(V16_UPPER + band) = up;
+        S.h(V16_LOWER + band) = lo;
+    };
+    do_split(hp120, NB / 2, 1, hp60, lp60);
+    log_energy(hp60, NB / 4, 176, total, feat[5]);
+    log_energy(lp60, NB / 4, 176, total, feat[4]);
+    do_split(lp120, NB / 2, 2, hp60, lp60);
+    log_energy(hp60, NB / 4, 176, total, feat[3]);
+    do_split(lp60, NB / 4, 3, hp120, lp120);
+    log_energy(hp120, NB / 8, 272, total, feat[2]);
+    do_split(lp120, NB / 8, 4, hp60, lp60);
+    log_energy(hp60, NB / 16, 368, total, feat[1]);
+    {
+        // HighPassFilter vad_filterbank.c:41-80
+        int16_t s0 = S.h(V16_HP + 0), s1 = S.h(V16_HP + 1), s2 = S.h(V16_HP + 2), s3 = S.h(V16_HP + 3);
+        for (int i = 0; i < NB / 16; i++) {
+            const int16_t x = lp60[i];
+            int32_t t = 6631 * x;
+            t += -13262 * s0;
+            t += 6631 * s1;
+            s1 = s0;
+            s0 = x;
+            t -= -7756 * s2;
+            t -= 5620 * s3;
+            s3 = s2;
+            s2 = (int16_t)(t >> 14);
+            hp120[i] = s2;
+        }
+        S.h(V16_HP + 0) = s0;
+        S.h(V16_HP + 1) = s1;
+        S.h(V16_HP + 2) = s2;
+        S.h(V16_HP + 3) = s3;
+    }
+    log_energy(hp120, NB / 16, 368, total, feat[0]);
+    const int v = gmm_probability(S, feat, total, NB == 80 ? 0 : (NB == 160 ? 1 : 2));
+    return v > 0 ? 1 : v;
+}
+
+template <int NB, int RATIO>
+__global__ __launch_bounds__(64) void vad_kernel(int16_t *s16, int32_t *s32, int16_t *pcm, int n_streams, int packets_per_call,
+                                                 int n_calls, long stream_stride, long call_stride, int chn) {
+    __shared__ int16_t lds[64 * (NB / 2 + NB / 2 + NB / 4 + NB / 4)];
+    const int lane = threadIdx.x;
+    const int stream = blockIdx.x * 64 + lane;
+    if (stream >= n_streams) return;  // lanes are independent: no barriers anywhere in this kernel
+    const VadRef S{s16 + stream, s32 + stream, (size_t)n_streams};
+    const LaneBuf hp120{lds + lane}, lp120{lds + lane + 64 * (NB / 2)}, hp60{lds + lane + 64 * NB},
+        lp60{lds + lane + 64 * (NB + NB / 4)};
+    constexpr int PKG = NB * RATIO;  // frames (mono samples) per packet at the stream's rate
+    for (int call = 0; call < n_calls; call++) {
+        int16_t *frame = pcm + (size_t)stream * stream_stride + (size_t)call * call_stride;
+        const int n_mono = packets_per_call * PKG;
+        if (chn > 1) {  // in-place mean downmix, src/webrtc.c:104-116
+            for (int i = 0; i < n_mono; i++) {
+                int32_t acc = 0;
+                for (int c = 0; c < chn; c++) acc += frame[i * chn + c];
+                frame[i] = (int16_t)(acc / chn);
+            }
+        }
+        int reduce = S.h(V16_REDUCE);
+        for (int it = 0; it < packets_per_call; it++) {
+            const int r = vad_packet<NB, RATIO>(S, frame, hp120, lp120, hp60, lp60);  // always packet 0 (quirk 1)
+            if (r == 0) {
+                if (reduce < 4) reduce += 1;
+            } else {
+                if (reduce > 0) reduce -= 1;
+            }
+            if (it == 0)  // for (cReduce = cLen; cReduce < pkgFrame; ...) only covers anything when cLen == 0
+                for (int i = 0; i < PKG; i++) frame[i] = (int16_t)(frame[i] >> reduce);
+        }
+        S.h(V16_REDUCE) = (int16_t)reduce;
+        if (chn > 1) {  // expand backwards, src/webrtc.c:145-150
+            for (int i = n_mono - 1; i >= 0; i--) {
+                const int16_t v = frame[i];
+                for (int c = chn - 1; c >= 0; c--) frame[i * chn + c] = v;
+            }
+        }
+    }
+}
+
+__global__ void vad_fill_state(int16_t *s16, int32_t *s32, const int16_t *t16, int n_streams) {
+    const size_t total = (size_t)V16_WORDS * n_streams;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        s16[i] = t16[i / n_streams];
+    const size_t total32 = (size_t)V32_WORDS * n_streams;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total32; i += (size_t)gridDim.x * blockDim.x) s32[i] = 0;
+}
+
+}  // namespace
+}  // namespace wmx
+
+struct wmx_vad {
+    int n_streams, chn, freq, interval_ms, pkg;
+    int16_t *d_s16;
+    int32_t *d_s32;
+};
+
+extern "C" {
+
+int wmx_vad_destroy(wmx_vad *h) {
+    if (!h) return 0;
+    if (h->d_s16) (void)hipFree(h->d_s16);
+    if (h->d_s32) (void)hipFree(h->d_s32);
+    delete h;
+    return 0;
+}
+
+int wmx_vad_create(wmx_vad **out, int n_streams, int chn, int freq, int interval_ms) {
+    using namespace wmx;
+    if (!out) return WMX_EINVAL;
+    *out = nullptr;
+    // vad_init: freq <= 32000 and a multiple of 8000 (src/webrtc.c:43-44)
+    if (freq > 32000 || freq % 8000 != 0 || freq <= 0 || chn < 1 || n_streams < 1) {
+        set_error("wmx_vad_create: unsupported n_streams=%d chn=%d freq=%d", n_streams, chn, freq);
+        return WMX_EINVAL;
+    }
+    wmx_vad *h = new wmx_vad();
+    h->n_streams = n_streams;
+    h->chn = chn;
+    h->freq = freq;
+    h->interval_ms = (freq <= 16000 && interval_ms % 20 == 0) ? 20 : 10;  // src/webrtc.c:57-66
+    h->pkg = freq / 1000 * h->interval_ms;
+    // WebRtcVad_InitCore vad_core.c:482-531 (start values vad_core.c:46-57) + reduce = 4 (src/webrtc.c:68)
+    static const int16_t nm[12] = {6738, 4892, 7065, 6715, 6771, 3369, 7646, 3863, 7820, 7266, 5020, 4362};
+    static const int16_t sm[12] = {8306, 10085, 10078, 11823, 11843, 6309, 9473, 9571, 10879, 7581, 8180, 7483};
+    static const int16_t ns[12] = {378, 1064, 493, 582, 688, 593, 474, 697, 475, 688, 421, 455};
+    static const int16_t ss[12] = {555, 505, 567, 524, 585, 1231, 509, 828, 492, 1540, 1079, 850};
+    std::vector<int16_t> t(V16_WORDS, 0);
+    for (int i = 0; i < 12; i++) {
+        t[V16_NOISE_MEANS + i] = nm[i];
+        t[V16_SPEECH_MEANS + i] = sm[i];
+        t[V16_NOISE_STDS + i] = ns[i];
+        t[V16_SPEECH_STDS + i] = ss[i];
+    }
+    for (int i = 0; i < 96; i++) t[V16_LOW + i] = 10000;
+    for (int i = 0; i < 6; i++) t[V16_MEAN_VALUE + i] = 1600;
+    t[V16_REDUCE] = 4;
+    int16_t *d_t = nullptr;
+    hipError_t e;
+#define VAD_TRY(x)                                         \
+    if ((e = (x)) != hipSuccess) {                         \
+        int rc = hip_fail(e, #x, __FILE__, __LINE__);      \
+        wmx_vad_destroy(h);                                \
+        if (d_t) (void)hipFree(d_t);                       \
+        return rc;                                         \
+    }
+    VAD_TRY(hipMalloc(&h->d_s16, (size_t)V16_WORDS * n_streams * sizeof(int16_t)));
+    VAD_TRY(hipMalloc(&h->d_s32, (size_t)V32_WORDS * n_streams * sizeof(int32_t)));
+    VAD_TRY(hipMalloc(&d_t, V16_WORDS * sizeof(int16_t)));
+    VAD_TRY(hipMemcpy(d_t, t.data(), V16_WORDS * sizeof(int16_t), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(vad_fill_state, dim3(512), dim3(256), 0, nullptr, h->d_s16, h->d_s32, d_t, n_streams);
+    VAD_TRY(hipGetLastError());
+    VAD_TRY(hipDeviceSynchronize());
+    (void)hipFree(d_t);
+    d_t = nullptr;
+#undef VAD_TRY
+    *out = h;
+    return 0;
+}
+
+int wmx_vad_packet_samples(const wmx_vad *h) { return h ? h->pkg * h->chn : WMX_EINVAL; }
+
+int wmx_vad_process(wmx_vad *h, int16_t *d_pcm, int packets_per_call, int n_calls, long stream_stride, long call_stride,
+                    void *stream) {
+    using namespace wmx;
+    if (!h || !d_pcm || packets_per_call < 1 || n_calls < 0) {
+        set_error("wmx_vad_process: bad argument");
+        return WMX_EINVAL;
+    }
+    if (n_calls == 0) return 0;
+    const long per_call = (long)packets_per_call * h->pkg * h->chn;
+    if (call_stride < per_call || (h->n_streams > 1 && stream_stride < per_call)) {
+        set_error("wmx_vad_process: strides (%ld, %ld) smaller than a call (%ld samples)", stream_stride, call_stride, per_call);
+        return WMX_EINVAL;
+    }
+    const dim3 grid((h->n_streams + 63) / 64), block(64);
+    hipStream_t s = as_stream(stream);
+    const int nb = h->pkg / (h->freq / 8000);  // packet length at 8 kHz: 80 or 160
+    const int ratio = h->freq / 8000;
+#define VAD_LAUNCH(NB, R)                                                                                                 \
+    hipLaunchKernelGGL((vad_kernel<NB, R>), grid, block, 0, s, h->d_s16, h->d_s32, d_pcm, h->n_streams, packets_per_call, \
+                       n_calls, stream_stride, call_stride, h->chn)
+    if (nb == 80 && ratio == 1)
+        VAD_LAUNCH(80, 1);
+    else if (nb == 80 && ratio == 2)
+        VAD_LAUNCH(80, 2);
+    else if (nb == 80 && ratio == 4)
+        VAD_LAUNCH(80, 4);
+    else if (nb == 160 && ratio == 1)
+        VAD_LAUNCH(160, 1);
+    else if (nb == 160 && ratio == 2)
+        VAD_LAUNCH(160, 2);
+    else {
+        set_error("wmx_vad_process: unsupported packet %d samples at %d Hz", h->pkg, h->freq);
+        return WMX_EINVAL;
+    }
+#undef VAD_LAUNCH
+    WMX_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"
