@@ -107,6 +107,32 @@ int wmx_agc_gain_table(const wmx_agc *h, int32_t *host_table32); /* the 32 Q16 g
 int wmx_agc_process(wmx_agc *h, const int16_t *d_in, int16_t *d_out, int n_packets, long stream_stride,
                     long packet_stride, void *stream);
 
+/* ------------------------------------------------------------------ AEC (float echo canceller)
+ * Batched form of aec_init / aec_setFrameFar / aec_process / aec_process2 / aec_release
+ * (src/webrtc.h:40-45, src/webrtc.c:217-505): n_streams near-end streams cancelled against ONE
+ * shared far-end reference (BASELINE.json configs[2..3]; a batch of one stream is the reference's
+ * per-handle case).  freq in {8000,16000}; packet = 10 ms (20 ms only at 8000 Hz with
+ * interval_ms % 20 == 0).  Only channel 0 of far and near is used; the output is duplicated to
+ * every channel.
+ *
+ * wmx_aec_run processes n_packets consecutive packets: mode bit 1 buffers the far-end packet
+ * (aec_setFrameFar), bit 2 processes the near-end packet (aec_process), 3 does both in the
+ * reference's order (aec_process2).  d_far is the shared far-end (packet p at
+ * d_far + p*far_packet_stride); near/out packet p of stream s at s*stream_stride + p*packet_stride;
+ * d_out may alias d_near.  delay_ms is the reported sound-card delay (the daemon passes 0).
+ * Returns 0, a WMX_E* error, or -1 where the reference wrapper would return non-zero (delay outside
+ * [0,500]: the offending packet is left unwritten and nothing after it runs).
+ * Float path: same operation order as the reference; tests require max |d| <= 1 LSB, and
+ * observe bit-exactness. */
+typedef struct wmx_aec wmx_aec;
+int wmx_aec_create(wmx_aec **out, int n_streams, int chn, int freq, int interval_ms);
+int wmx_aec_destroy(wmx_aec *h);
+int wmx_aec_packet_samples(const wmx_aec *h);
+int wmx_aec_run(wmx_aec *h, int mode, const int16_t *d_far, long far_packet_stride, const int16_t *d_near,
+                int16_t *d_out, int n_packets, long stream_stride, long packet_stride, int delay_ms, void *stream);
+int wmx_aec_state_words(const wmx_aec *h);
+int wmx_aec_export_state(const wmx_aec *h, int stream_index, float *host_words);
+
 #ifdef __cplusplus
 }
 #endif

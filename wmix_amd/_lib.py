@@ -92,6 +92,18 @@ def _declare(L):
     L.wmx_agc_gain_table.argtypes = [vp, vp]
     L.wmx_agc_process.restype = i
     L.wmx_agc_process.argtypes = [vp, vp, vp, i, C.c_long, C.c_long, vp]
+    L.wmx_aec_create.restype = i
+    L.wmx_aec_create.argtypes = [C.POINTER(vp), i, i, i, i]
+    L.wmx_aec_destroy.restype = i
+    L.wmx_aec_destroy.argtypes = [vp]
+    L.wmx_aec_packet_samples.restype = i
+    L.wmx_aec_packet_samples.argtypes = [vp]
+    L.wmx_aec_state_words.restype = i
+    L.wmx_aec_state_words.argtypes = [vp]
+    L.wmx_aec_export_state.restype = i
+    L.wmx_aec_export_state.argtypes = [vp, i, vp]
+    L.wmx_aec_run.restype = i
+    L.wmx_aec_run.argtypes = [vp, i, vp, C.c_long, vp, vp, i, C.c_long, C.c_long, i, vp]
     L.vad_init.restype = vp
     L.vad_init.argtypes = [i, i, i, vp]
     L.vad_process.restype = None

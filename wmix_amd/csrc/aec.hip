@@ -1,0 +1,791 @@
+// aec.hip -- batched float acoustic echo canceller for gfx950: one wavefront per stream.
+//
+// Replaces, for many independent near-end streams per launch that share ONE far-end reference,
+// what wmix's aec_process2() does per packet (src/webrtc.c:410-483): WebRtcAec_BufferFarend +
+// WebRtcAec_Process of the vendored float AEC in its wmix configuration (12-partition PBFDAF
+// NLMS, NLP aggressive, no skew/metrics/delay-logging):
+//   W:modules/audio_processing/aec/echo_cancellation.c:278-409,599-747,821-872
+//   W:modules/audio_processing/aec/aec_core.c:148-547 (FilterFar, ScaleErrorSignal,
+//     FilterAdaptation, OverdriveAndSuppress, PartitionDelay, SmoothedPSD, SubbandCoherence,
+//     ComfortNoise), :911-1351 (NonLinearProcessing, ProcessBlock), :1690-1850 (far buffering,
+//     ProcessFrames), aec_rdft.c (128-point Ooura rdft with frozen tables).
+//
+// Split of work (see aec_ctl.h): the data-independent control plane (start-up/delay state
+// machine, ring-buffer indices, block counters, comfort-noise phases) runs once per packet on
+// the host and arrives as an AecPlan.  Two kernels consume it:
+//   aec_far_kernel   one wave per batch: far-end pre-buffer, the plain and sqrt-Hanning-windowed
+//                    spectra of every new 64-sample far block (2 rdft128 each), the history of
+//                    CONSUMED far spectra and the far power xPow -- all shared by every stream.
+//   aec_near_kernel  one wave per stream: ProcessBlock + NonLinearProcessing.  The stream's whole
+//                    11 KB state block (12x65 complex filter taps, PSDs, rings) is pulled into LDS
+//                    with one contiguous read, all blocks of all packets of the launch run on it,
+//                    and it is written back once: HBM traffic = the algorithmic minimum.
+//                    Lane k owns frequency bin k (lane 0 also bin 64); the 24 constraint FFTs of
+//                    the filter update run four partitions at a time, 16 lanes per transform.
+// Float expressions, their order and the ordered sums follow the reference exactly
+// (-ffp-contract=off); powf/log are evaluated in double and rounded; cosf/sinf of the comfort
+// noise come from the host's libm through the plan.
+#include <cmath>
+#include <cstddef>
+#include <vector>
+#include "wmx_internal.h"
+#include "aec_ctl.h"
+#include "fft_ooura.h"
+
+namespace wmx {
+namespace {
+
+constexpr int BP = 68;  // padded per-bin array length (65 bins)
+// ---- per-stream state block (32-bit words)
+enum : int {
+    AS_W_RE = 0,                 // [12][BP]  wfBuf[0]
+    AS_W_IM = AS_W_RE + 12 * BP, // [12][BP]  wfBuf[1]
+    AS_DPOW = AS_W_IM + 12 * BP,
+    AS_DMIN = AS_DPOW + BP,
+    AS_DINIT = AS_DMIN + BP,
+    AS_SD = AS_DINIT + BP,
+    AS_SE = AS_SD + BP,
+    AS_SX = AS_SE + BP,
+    AS_SDE_RE = AS_SX + BP,
+    AS_SDE_IM = AS_SDE_RE + BP,
+    AS_SXD_RE = AS_SDE_IM + BP,
+    AS_SXD_IM = AS_SXD_RE + BP,
+    AS_DPREV = AS_SXD_IM + BP,   // dBuf[0..63]
+    AS_EPREV = AS_DPREV + 64,    // eBuf[0..63]
+    AS_OUTBUF = AS_EPREV + 64,
+    AS_NEAR_RING = AS_OUTBUF + 64,  // nearFrBuf storage [144]
+    AS_OUT_RING = AS_NEAR_RING + kAecRing,
+    AS_SCAL = AS_OUT_RING + kAecRing,
+    AS_HNLFBMIN = AS_SCAL + 0,
+    AS_HNLFBLOCALMIN = AS_SCAL + 1,
+    AS_HNLXDAVGMIN = AS_SCAL + 2,
+    AS_OVERDRIVE = AS_SCAL + 3,
+    AS_OVERDRIVESM = AS_SCAL + 4,
+    AS_HNLNEWMIN = AS_SCAL + 5,  // ints from here
+    AS_HNLMINCTR = AS_SCAL + 6,
+    AS_DELAYIDX = AS_SCAL + 7,
+    AS_STNEAR = AS_SCAL + 8,
+    AS_ECHOSTATE = AS_SCAL + 9,
+    AS_DIVERGE = AS_SCAL + 10,
+    AS_WORDS = AS_SCAL + 16,
+};
+static_assert(AS_WORDS % 4 == 0, "state block must be a whole number of 16-byte chunks");
+
+// ---- shared (per batch) far-end data
+struct AecFarBufs {
+    float *pre;      // [kAecPreLen] time-domain pre-buffer ring
+    float *ring;     // [kAecFarBlocks][130] plain spectra  (re[65] | im[65])
+    float *ring_w;   // [kAecFarBlocks][130] windowed spectra
+    float *hist;     // [kAecHist][130] consumed plain spectra
+    float *hist_w;   // [kAecHist][130] consumed windowed spectra
+    float *xpow_seq; // [kAecHist][BP]  xPow after each consumed block
+    float *xpow;     // [BP] running xPow
+};
+
+struct AecConsts {  // copied to LDS by both kernels
+    FftTables tab;
+    float hanning[BP], weight[BP], overdrive[BP];
+};
+constexpr int kAecConstWords = sizeof(AecConsts) / 4;
+
+__device__ __forceinline__ float sat16f(float v) { return v > 32767.f ? 32767.f : (v < -32768.f ? -32768.f : v); }
+
+// spectrum of a packed rdft array: bin b of a[] (StoreAsComplex / TimeToFrequency layout rules)
+__device__ __forceinline__ void unpack_bin(const float *a, int b, float &re, float &im) {
+    if (b == 0) {
+        re = a[0];
+        im = 0.f;
+    } else if (b == kAecPart) {
+        re = a[1];
+        im = 0.f;
+    } else {
+        re = a[2 * b];
+        im = a[2 * b + 1];
+    }
+}
+
+// ================================================================== far-end kernel
+__global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F, const float *__restrict__ consts_g, const AecPlan *__restrict__ plans,
+                                                     int n_packets, const int16_t *far_pcm, long far_packet_stride, int chn, float gpow1np) {
+    __shared__ AecConsts K;
+    __shared__ float fa[2][132];
+    const int lane = threadIdx.x;
+    {
+        float *dst = reinterpret_cast<float *>(&K);
+        for (int i = lane; i < kAecConstWords; i += 64) dst[i] = consts_g[i];
+    }
+    __syncthreads();
+    for (int p = 0; p < n_packets; p++) {
+        const AecPlan &pl = plans[p];
+        if (pl.has_far) {
+            // WebRtc_WriteBuffer(far_pre_buf, farend): channel 0 of the far-end packet (src/webrtc.c:430)
+            const int16_t *src = far_pcm + (size_t)p * far_packet_stride;
+            for (int i = lane; i < pl.far_n; i += 64) F.pre[(pl.pre_wr + i) % kAecPreLen] = (float)src[i * chn];
+            __syncthreads();
+            for (int q = 0; q < pl.n_part; q++) {
+                // BufferFarendPartition (aec_core.c:1690-1707): plain and windowed transform of [prev64 | new64]
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int i = lane + 64 * h;
+                    const float v = F.pre[(pl.part[q].pre_rd + i) % kAecPreLen];
+                    fa[0][i] = v;
+                    fa[1][i] = v * (h == 0 ? K.hanning[lane] : K.hanning[kAecPart - lane]);
+                }
+                __syncthreads();
+                rdft_forward<64>(fa[0], &K.tab, lane);
+                rdft_forward<64>(fa[1], &K.tab, lane);
+                float *dst = F.ring + (size_t)pl.part[q].far_slot * 130;
+                float *dstw = F.ring_w + (size_t)pl.part[q].far_slot * 130;
+                for (int b = lane; b < kAecPart1; b += 64) {
+                    float re, im;
+                    unpack_bin(fa[0], b, re, im);
+                    dst[b] = re;
+                    dst[kAecPart1 + b] = im;
+                    unpack_bin(fa[1], b, re, im);
+                    dstw[b] = re;
+                    dstw[kAecPart1 + b] = im;
+                }
+                __syncthreads();
+            }
+        }
+        if (pl.has_near && !pl.passthrough) {
+            for (int k = 0; k < pl.n_blk; k++) {
+                // far block consumed by ProcessBlock k: history entry + xPow (aec_core.c:1209-1216)
+                const float *src = F.ring + (size_t)pl.blk[k].far_slot * 130;
+                const float *srcw = F.ring_w + (size_t)pl.blk[k].far_slot * 130;
+                const int hs = pl.blk[k].hist_n % kAecHist;
+                for (int i = lane; i < 130; i += 64) {
+                    F.hist[hs * 130 + i] = src[i];
+                    F.hist_w[hs * 130 + i] = srcw[i];
+                }
+                for (int b = lane; b < kAecPart1; b += 64) {
+                    const float xr = src[b], xi = src[kAecPart1 + b];
+                    const float far_spectrum = (xr * xr) + (xi * xi);
+                    const float xp = 0.9f * F.xpow[b] + gpow1np * far_spectrum;
+                    F.xpow[b] = xp;
+                    F.xpow_seq[hs * BP + b] = xp;
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+// ================================================================== near-end kernel
+struct AecShared {
+    AecConsts K;
+    float st[AS_WORDS];
+    float fa[4][132];
+    float ef_re[BP], ef_im[BP];
+    float xw_re[BP], xw_im[BP], dw_re[BP], dw_im[BP], ew_re[BP], ew_im[BP];
+    float t0[BP], t1[BP], t2[BP], t3[BP];
+    float cur[64], enew[64];
+};
+
+template <int MULT>  // 1: 8 kHz, 2: 16 kHz
+__device__ void aec_block(AecShared &sh, const AecFarBufs &F, const AecBlkPlan &bp, const int lane) {
+    float *S = sh.st;
+    int *Si = reinterpret_cast<int *>(sh.st);
+    const float mu = MULT == 1 ? 0.6f : 0.5f, err_thr = MULT == 1 ? 2e-6f : 1.5e-6f;  // aec_core.c:1530-1538
+    const float scale = 2.0f / 128;
+    const int n = bp.hist_n;
+    const int g = lane >> 4, gl = lane & 15;
+
+    // ---- near block, d = [prev | cur], df = rdft(d)   (aec_core.c:1177-1195)
+    {
+        const float c = S[AS_NEAR_RING + (bp.near_rd + lane) % kAecRing];
+        sh.cur[lane] = c;
+        sh.fa[0][lane] = S[AS_DPREV + lane];
+        sh.fa[0][64 + lane] = c;
+    }
+    __syncthreads();
+    rdft_forward<64>(sh.fa[0], &sh.K.tab, lane);
+    // ---- near power, noise floor (aec_core.c:1197-1243)
+    for (int b = lane; b < kAecPart1; b += 64) {
+        float re, im;
+        unpack_bin(sh.fa[0], b, re, im);
+        const float ns = re * re + im * im;
+        const float dpow = 0.9f * S[AS_DPOW + b] + 0.1f * ns;
+        S[AS_DPOW + b] = dpow;
+        float dmin = S[AS_DMIN + b];
+        if (bp.flags & kAecFlagNoiseMin) {
+            if (dpow < dmin)
+                dmin = (dpow + 0.1f * (dmin - dpow)) * 1.0002f;
+            else
+                dmin *= 1.0002f;
+            S[AS_DMIN + b] = dmin;
+        }
+        if (bp.flags & kAecFlagNoiseInit) {
+            float dinit = S[AS_DINIT + b];
+            if (dmin > dinit)
+                dinit = 0.999f * dinit + 0.001f * dmin;
+            else
+                dinit = dmin;
+            S[AS_DINIT + b] = dinit;
+        }
+    }
+    // ---- FilterFar (aec_core.c:148-170): y = sum_p X_{n-p} * W_p, partitions in order
+    for (int b = lane; b < kAecPart1; b += 64) {
+        float yr = 0.f, yi = 0.f;
+#pragma unroll
+        for (int p = 0; p < 12; p++) {
+            const float *X = F.hist + (size_t)((n - p + kAecHist) % kAecHist) * 130;
+            const float xr = X[b], xi = X[kAecPart1 + b];
+            const float wr = S[AS_W_RE + p * BP + b], wi = S[AS_W_IM + p * BP + b];
+            yr += xr * wr - xi * wi;
+            yi += xr * wi + xi * wr;
+        }
+        if (b == 0)
+            sh.fa[1][0] = yr;
+        else if (b == kAecPart)
+            sh.fa[1][1] = yr;
+        else {
+            sh.fa[1][2 * b] = yr;
+            sh.fa[1][2 * b + 1] = yi;
+        }
+    }
+    __syncthreads();
+    rdft_inverse<64>(sh.fa[1], &sh.K.tab, lane);
+    // ---- error e = d - y, ef = rdft([0 | e])  (aec_core.c:1286-1309)
+    {
+        const float y = sh.fa[1][64 + lane] * scale;
+        const float e = sh.cur[lane] - y;
+        sh.enew[lane] = e;
+        sh.fa[2][lane] = 0.f;
+        sh.fa[2][64 + lane] = e;
+    }
+    __syncthreads();
+    rdft_forward<64>(sh.fa[2], &sh.K.tab, lane);
+    // ---- ScaleErrorSignal (aec_core.c:172-194)
+    for (int b = lane; b < kAecPart1; b += 64) {
+        float er, ei;
+        unpack_bin(sh.fa[2], b, er, ei);
+        const float xp = F.xpow_seq[(n % kAecHist) * BP + b];
+        er /= (xp + 1e-10f);
+        ei /= (xp + 1e-10f);
+        float abs_ef = sqrtf(er * er + ei * ei);
+        if (abs_ef > err_thr) {
+            abs_ef = err_thr / (abs_ef + 1e-10f);
+            er *= abs_ef;
+            ei *= abs_ef;
+        }
+        er *= mu;
+        ei *= mu;
+        sh.ef_re[b] = er;
+        sh.ef_im[b] = ei;
+    }
+    __syncthreads();
+    // ---- FilterAdaptation (aec_core.c:222-270), four partitions per round
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int p = 4 * r + q;
+            const float *X = F.hist + (size_t)((n - p + kAecHist) % kAecHist) * 130;
+            const float er = sh.ef_re[lane], ei = sh.ef_im[lane];
+            const float xr = X[lane], xi = -X[kAecPart1 + lane];
+            sh.fa[q][2 * lane] = xr * er - xi * ei;
+            sh.fa[q][2 * lane + 1] = xr * ei + xi * er;
+            if (lane == 0) {
+                const float nr = X[kAecPart], ni = -X[kAecPart1 + kAecPart];
+                sh.fa[q][1] = nr * sh.ef_re[kAecPart] - ni * sh.ef_im[kAecPart];
+            }
+        }
+        __syncthreads();
+        rdft_inverse<64, 16>(sh.fa[g], &sh.K.tab, gl);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            sh.fa[q][64 + lane] = 0.f;
+            sh.fa[q][lane] *= scale;
+        }
+        __syncthreads();
+        rdft_forward<64, 16>(sh.fa[g], &sh.K.tab, gl);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int p = 4 * r + q;
+            for (int b = lane; b < kAecPart1; b += 64) {
+                float re, im;
+                unpack_bin(sh.fa[q], b, re, im);
+                S[AS_W_RE + p * BP + b] += re;
+                if (b != 0 && b != kAecPart) S[AS_W_IM + p * BP + b] += im;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ================================================= NonLinearProcessing (aec_core.c:911-1141)
+    constexpr int prefSize = 24 / MULT, minPref = 4 / MULT;
+    const float gc0 = MULT == 1 ? 0.9f : 0.93f, gc1 = MULT == 1 ? 0.1f : 0.07f;  // kNormalSmoothingCoefficients
+    // PartitionDelay (aec_core.c:295-319) every 10*mult blocks
+    int delayIdx = Si[AS_DELAYIDX];
+    if (bp.flags & kAecFlagDelayEst) {
+        if (lane < 12) {
+            float en = 0.f;
+            for (int j = 0; j < kAecPart1; j++) {
+                const float wr = S[AS_W_RE + lane * BP + j], wi = S[AS_W_IM + lane * BP + j];
+                en += wr * wr + wi * wi;
+            }
+            sh.t0[lane] = en;
+        }
+        __syncthreads();
+        float best = 0.f;
+        delayIdx = 0;
+        for (int p = 0; p < 12; p++)
+            if (sh.t0[p] > best) {
+                best = sh.t0[p];
+                delayIdx = p;
+            }
+        __syncthreads();
+        Si[AS_DELAYIDX] = delayIdx;
+    }
+    // xfw = windowed far spectrum consumed delayIdx blocks ago; windowed d and e transforms
+    {
+        const float *Xw = F.hist_w + (size_t)((n - delayIdx + kAecHist) % kAecHist) * 130;
+        for (int b = lane; b < kAecPart1; b += 64) {
+            sh.xw_re[b] = Xw[b];
+            sh.xw_im[b] = Xw[kAecPart1 + b];
+        }
+        const float h0 = sh.K.hanning[lane], h1 = sh.K.hanning[kAecPart - lane];
+        sh.fa[0][lane] = S[AS_DPREV + lane] * h0;
+        sh.fa[0][64 + lane] = sh.cur[lane] * h1;
+        sh.fa[1][lane] = S[AS_EPREV + lane] * h0;
+        sh.fa[1][64 + lane] = sh.enew[lane] * h1;
+    }
+    __syncthreads();
+    rdft_forward<64, 16>(sh.fa[g], &sh.K.tab, gl);  // groups 0 and 1 carry d and e; 2 and 3 idle on scratch
+    // SmoothedPSD (aec_core.c:333-386)
+    for (int b = lane; b < kAecPart1; b += 64) {
+        float dr, di, er, ei;
+        unpack_bin(sh.fa[0], b, dr, di);
+        unpack_bin(sh.fa[1], b, er, ei);
+        const float xr = sh.xw_re[b], xi = sh.xw_im[b];
+        const float sd = gc0 * S[AS_SD + b] + gc1 * (dr * dr + di * di);
+        const float se = gc0 * S[AS_SE + b] + gc1 * (er * er + ei * ei);
+        const float xx = xr * xr + xi * xi;
+        S[AS_SX + b] = gc0 * S[AS_SX + b] + gc1 * (xx > 15.f ? xx : 15.f);
+        S[AS_SD + b] = sd;
+        S[AS_SE + b] = se;
+        S[AS_SDE_RE + b] = gc0 * S[AS_SDE_RE + b] + gc1 * (dr * er + di * ei);
+        S[AS_SDE_IM + b] = gc0 * S[AS_SDE_IM + b] + gc1 * (dr * ei - di * er);
+        S[AS_SXD_RE + b] = gc0 * S[AS_SXD_RE + b] + gc1 * (dr * xr + di * xi);
+        S[AS_SXD_IM + b] = gc0 * S[AS_SXD_IM + b] + gc1 * (dr * xi - di * xr);
+        sh.dw_re[b] = dr;
+        sh.dw_im[b] = di;
+        sh.ew_re[b] = er;
+        sh.ew_im[b] = ei;
+    }
+    __syncthreads();
+    float sdSum = 0.f, seSum = 0.f;
+    for (int i = 0; i < kAecPart1; i++) {
+        sdSum += S[AS_SD + i];
+        seSum += S[AS_SE + i];
+    }
+    const int diverge = ((Si[AS_DIVERGE] ? 1.05f : 1.0f) * seSum > sdSum) ? 1 : 0;
+    const bool reset_filter = seSum > (19.95f * sdSum);
+    __syncthreads();
+    Si[AS_DIVERGE] = diverge;
+    if (reset_filter)
+        for (int i = lane; i < 24 * BP; i += 64) S[AS_W_RE + i] = 0.f;  // memset(wfBuf): both planes are contiguous
+    // coherences (aec_core.c:440-449)
+    for (int b = lane; b < kAecPart1; b += 64) {
+        if (diverge) {
+            sh.ew_re[b] = sh.dw_re[b];
+            sh.ew_im[b] = sh.dw_im[b];
+        }
+        const float sde_r = S[AS_SDE_RE + b], sde_i = S[AS_SDE_IM + b], sxd_r = S[AS_SXD_RE + b], sxd_i = S[AS_SXD_IM + b];
+        sh.t0[b] = (sde_r * sde_r + sde_i * sde_i) / (S[AS_SD + b] * S[AS_SE + b] + 1e-10f);  // cohde
+        sh.t1[b] = (sxd_r * sxd_r + sxd_i * sxd_i) / (S[AS_SX + b] * S[AS_SD + b] + 1e-10f);  // cohxd
+    }
+    __syncthreads();
+    float hNlXdAvg = 0.f, hNlDeAvg = 0.f;
+    for (int i = minPref; i < prefSize + minPref; i++) hNlXdAvg += sh.t1[i];
+    hNlXdAvg /= prefSize;
+    hNlXdAvg = 1 - hNlXdAvg;
+    for (int i = minPref; i < prefSize + minPref; i++) hNlDeAvg += sh.t0[i];
+    hNlDeAvg /= prefSize;
+    float hNlXdAvgMin = S[AS_HNLXDAVGMIN], hNlFbMin = S[AS_HNLFBMIN], hNlFbLocalMin = S[AS_HNLFBLOCALMIN];
+    float overDrive = S[AS_OVERDRIVE], overDriveSm = S[AS_OVERDRIVESM];
+    int stNear = Si[AS_STNEAR], echoState, hNlNewMin = Si[AS_HNLNEWMIN], hNlMinCtr = Si[AS_HNLMINCTR];
+    if (hNlXdAvg < 0.75f && hNlXdAvg < hNlXdAvgMin) hNlXdAvgMin = hNlXdAvg;
+    if (hNlDeAvg > 0.98f && hNlXdAvg > 0.9f)
+        stNear = 1;
+    else if (hNlDeAvg < 0.95f || hNlXdAvg < 0.8f)
+        stNear = 0;
+    // hNl selection (aec_core.c:988-1024); mode: 0 cohde, 1 (1 - cohxd), 2 min of both
+    int mode;
+    float hNlFb, hNlFbLow;
+    if (hNlXdAvgMin == 1) {
+        echoState = 0;
+        overDrive = 5.0f;  // kNormalMinOverDrive[kAecNlpAggressive]
+        if (stNear == 1) {
+            mode = 0;
+            hNlFb = hNlDeAvg;
+            hNlFbLow = hNlDeAvg;
+        } else {
+            mode = 1;
+            hNlFb = hNlXdAvg;
+            hNlFbLow = hNlXdAvg;
+        }
+    } else {
+        if (stNear == 1) {
+            echoState = 0;
+            mode = 0;
+            hNlFb = hNlDeAvg;
+            hNlFbLow = hNlDeAvg;
+        } else {
+            echoState = 1;
+            mode = 2;
+            hNlFb = 0.f;
+            hNlFbLow = 0.f;
+        }
+    }
+    for (int b = lane; b < kAecPart1; b += 64) {
+        const float cde = sh.t0[b], cxd = 1 - sh.t1[b];
+        sh.t2[b] = mode == 0 ? cde : (mode == 1 ? cxd : (cde < cxd ? cde : cxd));  // hNl
+    }
+    __syncthreads();
+    if (mode == 2) {
+        // qsort(hNlPref) + the two order statistics (aec_core.c:1017-1022): rank by counting
+        constexpr int i75 = (int)(0.75f * (prefSize - 1)), i50 = (int)(0.5f * (prefSize - 1));
+        if (lane < prefSize) {
+            const float v = sh.t2[minPref + lane];
+            int rank = 0;
+            for (int i = 0; i < prefSize; i++) {
+                const float u = sh.t2[minPref + i];
+                rank += (u < v || (u == v && i < lane)) ? 1 : 0;
+            }
+            if (rank == i75) sh.t3[0] = v;
+            if (rank == i50) sh.t3[1] = v;
+        }
+        __syncthreads();
+        hNlFb = sh.t3[0];
+        hNlFbLow = sh.t3[1];
+        __syncthreads();
+    }
+    if (hNlFbLow < 0.6f && hNlFbLow < hNlFbLocalMin) {
+        hNlFbLocalMin = hNlFbLow;
+        hNlFbMin = hNlFbLow;
+        hNlNewMin = 1;
+        hNlMinCtr = 0;
+    }
+    {
+        float t = hNlFbLocalMin + 0.0008f / MULT;
+        hNlFbLocalMin = t < 1 ? t : 1;
+        t = hNlXdAvgMin + 0.0006f / MULT;
+        hNlXdAvgMin = t < 1 ? t : 1;
+    }
+    if (hNlNewMin == 1) hNlMinCtr++;
+    if (hNlMinCtr == 2) {
+        hNlNewMin = 0;
+        hNlMinCtr = 0;
+        const float od = -18.4f / ((float)log((double)(hNlFbMin + 1e-10f)) + 1e-10f);  // kTargetSupp[2]
+        overDrive = od > 5.0f ? od : 5.0f;
+    }
+    if (overDrive < overDriveSm)
+        overDriveSm = 0.99f * overDriveSm + 0.01f * overDrive;
+    else
+        overDriveSm = 0.9f * overDriveSm + 0.1f * overDrive;
+    // every lane holds the same scalars; lane 0 publishes them
+    if (lane == 0) {
+        S[AS_HNLXDAVGMIN] = hNlXdAvgMin;
+        S[AS_HNLFBMIN] = hNlFbMin;
+        S[AS_HNLFBLOCALMIN] = hNlFbLocalMin;
+        S[AS_OVERDRIVE] = overDrive;
+        S[AS_OVERDRIVESM] = overDriveSm;
+        Si[AS_STNEAR] = stNear;
+        Si[AS_ECHOSTATE] = echoState;
+        Si[AS_HNLNEWMIN] = hNlNewMin;
+        Si[AS_HNLMINCTR] = hNlMinCtr;
+    }
+    // OverdriveAndSuppress (aec_core.c:272-293) + ComfortNoise (:462-547) + packing for the inverse transform
+    const int noise_off = (bp.flags & kAecFlagNoiseInit) ? AS_DINIT : AS_DMIN;
+    for (int b = lane; b < kAecPart1; b += 64) {
+        float h = sh.t2[b];
+        const float wc = sh.K.weight[b];
+        if (h > hNlFb) h = wc * hNlFb + (1 - wc) * h;
+        h = (float)pow((double)h, (double)(overDriveSm * sh.K.overdrive[b]));
+        float er = sh.ew_re[b] * h, ei = sh.ew_im[b] * h;
+        ei *= -1;
+        float ur = 0.f, ui = 0.f;
+        if (b >= 1) {
+            const float noise = sqrtf(S[noise_off + b]);
+            ur = noise * bp.ucos[b - 1];
+            ui = -noise * bp.usin[b - 1];
+            if (b == kAecPart) ui = 0.f;
+        }
+        const float v = 1 - h * h;
+        const float tmp = sqrtf(v > 0 ? v : 0);
+        er += tmp * ur;
+        ei += tmp * ui;
+        if (b == 0)
+            sh.fa[3][0] = er;
+        else if (b == kAecPart)
+            sh.fa[3][1] = er;
+        else {
+            sh.fa[3][2 * b] = er;
+            sh.fa[3][2 * b + 1] = -ei;
+        }
+    }
+    __syncthreads();
+    rdft_inverse<64>(sh.fa[3], &sh.K.tab, lane);
+    // overlap-add with the sqrt-Hanning window, saturate, queue 64 output samples (aec_core.c:1089-1101, 1341)
+    {
+        float v = sh.fa[3][lane] * scale;
+        v = v * sh.K.hanning[lane] + S[AS_OUTBUF + lane];
+        const float t = sh.fa[3][64 + lane] * scale;
+        S[AS_OUTBUF + lane] = t * sh.K.hanning[kAecPart - lane];
+        S[AS_OUT_RING + (bp.out_wr + lane) % kAecRing] = sat16f(v);
+        S[AS_DPREV + lane] = sh.cur[lane];
+        S[AS_EPREV + lane] = sh.enew[lane];
+    }
+    __syncthreads();
+}
+
+template <int MULT>
+__global__ __launch_bounds__(64) void aec_near_kernel(float *__restrict__ state, AecFarBufs F, const float *__restrict__ consts_g,
+                                                      const AecPlan *__restrict__ plans, int n_packets, const int16_t *near_pcm,
+                                                      int16_t *out_pcm, int n_streams, long stream_stride, long packet_stride, int chn,
+                                                      int pkg) {
+    __shared__ AecShared sh;
+    const int lane = threadIdx.x;
+    {
+        float *dst = reinterpret_cast<float *>(&sh.K);
+        for (int i = lane; i < kAecConstWords; i += 64) dst[i] = consts_g[i];
+    }
+    for (int sidx = blockIdx.x; sidx < n_streams; sidx += gridDim.x) {
+        float4 *g4 = reinterpret_cast<float4 *>(state + (size_t)sidx * AS_WORDS);
+        float4 *s4 = reinterpret_cast<float4 *>(sh.st);
+        __syncthreads();
+        for (int i = lane; i < AS_WORDS / 4; i += 64) s4[i] = g4[i];  // one contiguous 11 KB read
+        __syncthreads();
+        for (int p = 0; p < n_packets; p++) {
+            const AecPlan &pl = plans[p];
+            if (!pl.has_near) continue;
+            const size_t off = (size_t)sidx * stream_stride + (size_t)p * packet_stride;
+            const int16_t *in = near_pcm + off;
+            int16_t *out = out_pcm + off;
+            if (pl.passthrough) {
+                // start-up phase: AEC disabled, out = near (echo_cancellation.c:651-657); left channel to all channels
+                for (int i = lane; i < pkg; i += 64) {
+                    const int16_t v = in[i * chn];
+                    for (int c = 0; c < chn; c++) out[i * chn + c] = v;
+                }
+                continue;
+            }
+            for (int s = 0; s < pl.n_sub; s++) {
+                const AecSubPlan &sp = pl.sub[s];
+                for (int i = lane; i < kAecFrame; i += 64)
+                    sh.st[AS_NEAR_RING + (sp.near_wr + i) % kAecRing] = (float)in[(s * kAecFrame + i) * chn];
+                __syncthreads();
+                for (int k = 0; k < sp.n_blocks; k++) aec_block<MULT>(sh, F, pl.blk[sp.first_blk + k], lane);
+                for (int i = lane; i < kAecFrame; i += 64) {
+                    const int16_t v = (int16_t)sh.st[AS_OUT_RING + (sp.out_rd + i) % kAecRing];
+                    for (int c = 0; c < chn; c++) out[(s * kAecFrame + i) * chn + c] = v;
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        for (int i = lane; i < AS_WORDS / 4; i += 64) g4[i] = s4[i];
+    }
+}
+
+__global__ void aec_fill_state(float *state, const float *tmpl, int words, int n_streams) {
+    const size_t total = (size_t)words * n_streams;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        state[i] = tmpl[i % words];
+}
+
+}  // namespace
+}  // namespace wmx
+
+// ================================================================== host
+struct wmx_aec {
+    int n_streams, chn, freq, pkg;
+    wmx::AecCtl ctl;
+    float *d_state;
+    float *d_consts;
+    float *d_far;  // one allocation carved into AecFarBufs
+    wmx::AecFarBufs far;
+    wmx::AecPlan *d_plans;
+    std::vector<wmx::AecPlan> h_plans;
+    int16_t *d_zero_far;  // a silent far-end packet for near-only calls that need no far data
+};
+
+extern "C" {
+
+int wmx_aec_destroy(wmx_aec *h) {
+    if (!h) return 0;
+    if (h->d_state) (void)hipFree(h->d_state);
+    if (h->d_consts) (void)hipFree(h->d_consts);
+    if (h->d_far) (void)hipFree(h->d_far);
+    if (h->d_plans) (void)hipFree(h->d_plans);
+    delete h;
+    return 0;
+}
+
+int wmx_aec_create(wmx_aec **out, int n_streams, int chn, int freq, int interval_ms) {
+    using namespace wmx;
+    if (!out) return WMX_EINVAL;
+    *out = nullptr;
+    // aec_init: freq <= 16000 and a multiple of 8000 (src/webrtc.c:220-221)
+    if (freq > 16000 || freq % 8000 != 0 || freq <= 0 || chn < 1 || n_streams < 1) {
+        set_error("wmx_aec_create: unsupported n_streams=%d chn=%d freq=%d", n_streams, chn, freq);
+        return WMX_EINVAL;
+    }
+    wmx_aec *h = new wmx_aec();
+    h->n_streams = n_streams;
+    h->chn = chn;
+    h->freq = freq;
+    h->pkg = freq / 1000 * ((freq <= 8000 && interval_ms % 20 == 0) ? 20 : 10);  // src/webrtc.c:239-248
+    h->ctl.init(freq);
+    h->d_state = h->d_consts = h->d_far = nullptr;
+    h->d_plans = nullptr;
+    h->d_zero_far = nullptr;
+    // constants: Ooura tables (frozen rdft_w) + the three curves of aec_core.c:49-103
+    AecConsts K;
+    memset(&K, 0, sizeof(K));
+    fft_tables_aec128(&K.tab);
+    const double pi = 3.14159265358979323846;
+    for (int i = 0; i < 65; i++) {
+        K.hanning[i] = (float)sin(pi * i / 128.0);
+        K.overdrive[i] = (float)(floor((sqrt(i / 64.0) + 1.0) * 1e4 + 0.5) / 1e4);
+        K.weight[i] = i == 0 ? 0.f : (float)(floor((0.3 * sqrt((i - 1) / 63.0) + 0.1) * 1e4 + 0.5) / 1e4);
+    }
+    // initial per-stream state (InitAec aec_core.c:1623-1681)
+    std::vector<float> st(AS_WORDS, 0.f);
+    for (int b = 0; b < 65; b++) {
+        st[AS_DMIN + b] = 1.0e6f;
+        st[AS_SD + b] = 1.f;
+        st[AS_SX + b] = 1.f;
+    }
+    st[AS_HNLFBMIN] = 1.f;
+    st[AS_HNLFBLOCALMIN] = 1.f;
+    st[AS_HNLXDAVGMIN] = 1.f;
+    st[AS_OVERDRIVE] = 2.f;
+    st[AS_OVERDRIVESM] = 2.f;
+    const size_t far_words = (size_t)kAecPreLen + 2 * (size_t)kAecFarBlocks * 130 + 2 * (size_t)kAecHist * 130 + (size_t)kAecHist * BP + BP;
+    float *d_tmpl = nullptr;
+    hipError_t e;
+#define AEC_TRY(x)                                         \
+    if ((e = (x)) != hipSuccess) {                         \
+        int rc = hip_fail(e, #x, __FILE__, __LINE__);      \
+        wmx_aec_destroy(h);                                \
+        if (d_tmpl) (void)hipFree(d_tmpl);                 \
+        return rc;                                         \
+    }
+    AEC_TRY(hipMalloc(&h->d_state, (size_t)AS_WORDS * n_streams * sizeof(float)));
+    AEC_TRY(hipMalloc(&h->d_consts, sizeof(K)));
+    AEC_TRY(hipMalloc(&h->d_far, far_words * sizeof(float)));
+    AEC_TRY(hipMalloc(&h->d_plans, kAecMaxPktPerLaunch * sizeof(AecPlan)));
+    AEC_TRY(hipMalloc(&d_tmpl, AS_WORDS * sizeof(float)));
+    AEC_TRY(hipMemcpy(h->d_consts, &K, sizeof(K), hipMemcpyHostToDevice));
+    AEC_TRY(hipMemcpy(d_tmpl, st.data(), AS_WORDS * sizeof(float), hipMemcpyHostToDevice));
+    AEC_TRY(hipMemset(h->d_far, 0, far_words * sizeof(float)));
+    hipLaunchKernelGGL(aec_fill_state, dim3(1024), dim3(256), 0, nullptr, h->d_state, d_tmpl, (int)AS_WORDS, n_streams);
+    AEC_TRY(hipGetLastError());
+    AEC_TRY(hipDeviceSynchronize());
+    (void)hipFree(d_tmpl);
+    d_tmpl = nullptr;
+#undef AEC_TRY
+    float *p = h->d_far;
+    h->far.pre = p;
+    p += kAecPreLen;
+    h->far.ring = p;
+    p += (size_t)kAecFarBlocks * 130;
+    h->far.ring_w = p;
+    p += (size_t)kAecFarBlocks * 130;
+    h->far.hist = p;
+    p += (size_t)kAecHist * 130;
+    h->far.hist_w = p;
+    p += (size_t)kAecHist * 130;
+    h->far.xpow_seq = p;
+    p += (size_t)kAecHist * BP;
+    h->far.xpow = p;
+    h->h_plans.resize(kAecMaxPktPerLaunch);
+    *out = h;
+    return 0;
+}
+
+int wmx_aec_packet_samples(const wmx_aec *h) { return h ? h->pkg * h->chn : WMX_EINVAL; }
+int wmx_aec_state_words(const wmx_aec *h) { return h ? (int)wmx::AS_WORDS : WMX_EINVAL; }
+
+int wmx_aec_export_state(const wmx_aec *h, int stream_index, float *host_words) {
+    if (!h || !host_words || stream_index < 0 || stream_index >= h->n_streams) return WMX_EINVAL;
+    WMX_HIP(hipDeviceSynchronize());
+    WMX_HIP(hipMemcpy(host_words, h->d_state + (size_t)stream_index * wmx::AS_WORDS, wmx::AS_WORDS * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// mode bit 1: buffer the far-end packet (aec_setFrameFar), bit 2: process the near-end packet (aec_process);
+// 3 = aec_process2.  d_far: the SHARED far-end, packet p at d_far + p*far_packet_stride.
+// Returns 0, WMX_E*, or the reference's -1 when a packet is rejected (bad delay: packets before it are done).
+int wmx_aec_run(wmx_aec *h, int mode, const int16_t *d_far, long far_packet_stride, const int16_t *d_near, int16_t *d_out,
+                int n_packets, long stream_stride, long packet_stride, int delay_ms, void *stream) {
+    using namespace wmx;
+    if (!h || n_packets < 0 || (mode & 3) == 0 || ((mode & 1) && !d_far) || ((mode & 2) && (!d_near || !d_out))) {
+        set_error("wmx_aec_run: bad argument");
+        return WMX_EINVAL;
+    }
+    const long per_pkt = (long)h->pkg * h->chn;
+    if ((mode & 2) && (packet_stride < per_pkt || (h->n_streams > 1 && stream_stride < per_pkt))) {
+        set_error("wmx_aec_run: strides (%ld, %ld) smaller than a packet (%ld samples)", stream_stride, packet_stride, per_pkt);
+        return WMX_EINVAL;
+    }
+    if ((mode & 1) && far_packet_stride < per_pkt && n_packets > 1) {
+        set_error("wmx_aec_run: far stride %ld smaller than a packet (%ld samples)", far_packet_stride, per_pkt);
+        return WMX_EINVAL;
+    }
+    hipStream_t s = as_stream(stream);
+    const float gpow1np = 0.1f * 12;  // gPow[1] * num_partitions (aec_core.c:1212), evaluated in float like the reference
+    int rc_ref = 0;
+    for (int done = 0; done < n_packets && rc_ref == 0;) {
+        int chunk = n_packets - done;
+        if (chunk > kAecMaxPktPerLaunch) chunk = kAecMaxPktPerLaunch;
+        int built = 0;
+        for (; built < chunk; built++) {
+            AecPlan &pl = h->h_plans[built];
+            memset(&pl, 0, offsetof(AecPlan, blk));
+            if (mode & 1) {
+                const int r = h->ctl.buffer_farend(h->pkg, &pl);
+                if (r != 0) {
+                    rc_ref = r;
+                    break;
+                }
+            }
+            if (mode & 2) {
+                const int r = h->ctl.process(h->pkg, delay_ms, &pl);
+                if (r != 0) {  // src/webrtc.c:463-468: the wrapper stops here; nothing of this packet is written
+                    pl.has_near = 0;
+                    rc_ref = r;
+                    built++;
+                    break;
+                }
+            }
+        }
+        if (built > 0) {
+            WMX_HIP(hipMemcpyAsync(h->d_plans, h->h_plans.data(), built * sizeof(AecPlan), hipMemcpyHostToDevice, s));
+            // the plan buffer is reused by the next chunk: the copy above is stream-ordered after the previous kernels
+            hipLaunchKernelGGL(aec_far_kernel, dim3(1), dim3(64), 0, s, h->far, h->d_consts, h->d_plans, built,
+                               d_far ? d_far + (size_t)done * far_packet_stride : nullptr, far_packet_stride, h->chn, gpow1np);
+            WMX_LAUNCH_CHECK();
+            if (mode & 2) {
+                const int16_t *nin = d_near + (size_t)done * packet_stride;
+                int16_t *nout = d_out + (size_t)done * packet_stride;
+                const unsigned grid = (unsigned)h->n_streams;
+                if (h->freq == 8000)
+                    hipLaunchKernelGGL((aec_near_kernel<1>), dim3(grid), dim3(64), 0, s, h->d_state, h->far, h->d_consts, h->d_plans, built, nin,
+                                       nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg);
+                else
+                    hipLaunchKernelGGL((aec_near_kernel<2>), dim3(grid), dim3(64), 0, s, h->d_state, h->far, h->d_consts, h->d_plans, built, nin,
+                                       nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg);
+                WMX_LAUNCH_CHECK();
+            }
+            // h_plans is pageable host memory: hipMemcpyAsync from it returns after the copy is staged,
+            // so it may be rewritten for the next chunk.
+        }
+        done += chunk;
+    }
+    return rc_ref;
+}
+
+}  // extern "C"

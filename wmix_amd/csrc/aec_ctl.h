@@ -1,0 +1,292 @@
+// aec_ctl.h -- host-side control plane of the batched AEC.
+//
+// Everything in the reference's AEC that decides WHERE data goes -- the start-up state machine
+// and delay filter of ProcessNormal / EstBufDelayNormal (W:modules/audio_processing/aec/
+// echo_cancellation.c:599-747, 821-872), the far/near/out ring buffers with their negative
+// read-pointer moves (W:common_audio/ring_buffer.c:25-247; aec_core.c:1690-1717, 1719-1850), the
+// block counters (noiseEstCtr, delayEstCtr, xfBufBlockPos) and the comfort-noise random
+// generator (seed*69069+1, randomization_functions.c:87-112) -- depends only on the call
+// pattern (packet sizes, reported delay), never on the audio.  All streams of a batch are
+// driven in lockstep, so this logic runs ONCE per packet on the host, with indices only, and is
+// handed to the kernels as a small plan; the GPU does the arithmetic (aec.hip).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+namespace wmx {
+
+constexpr int kAecPart = 64, kAecPart1 = 65, kAecFrame = 80;
+constexpr int kAecFarBlocks = 250;   // kBufSizePartitions, aec_core.c:38
+constexpr int kAecPreLen = 128 + 320;  // far_pre_buf: PART_LEN2 + kResamplerBufferSize, echo_cancellation.c:147
+constexpr int kAecRing = kAecFrame + kAecPart;  // nearFrBuf / outFrBuf, aec_core.c:1361,1368
+constexpr int kAecHist = 64;         // consumed-block history kept for the kernels (>= 12 + blocks per launch)
+constexpr int kAecMaxPktPerLaunch = 16;
+
+enum : int { kAecFlagNoiseMin = 1, kAecFlagNoiseInit = 2, kAecFlagDelayEst = 4 };
+
+struct AecBlkPlan {
+    int near_rd;   // near ring position of the block's 64 samples
+    int out_wr;    // out ring position for the block's 64 output samples
+    int hist_n;    // sequence number of the consumed far block (history slot = hist_n % kAecHist)
+    int far_slot;  // far ring slot consumed (plain and windowed rings move together)
+    int flags;
+    int pad[3];
+    float ucos[64], usin[64];  // cosf / sinf of the 64 comfort-noise phases (aec_core.c:482-489), host libm
+};
+struct AecSubPlan {
+    int near_wr;   // near ring position where the 80 new samples go
+    int n_blocks;  // blocks processed in this 80-sample sub-frame
+    int first_blk; // index into blk[]
+    int out_rd;    // out ring position the 80 output samples are read from (after stuffing)
+};
+struct AecPartPlan {
+    int pre_rd;    // far_pre ring position of the partition's 128 samples
+    int far_slot;  // far ring slot written
+};
+struct AecPlan {
+    int has_far;       // BufferFarend part present: write `far_n` samples at pre_wr, then n_part partitions
+    int far_n, pre_wr, n_part;
+    int has_near;      // Process part present
+    int passthrough;   // start-up phase: out = near
+    int n_sub, n_blk;
+    AecSubPlan sub[2];
+    AecPartPlan part[4];
+    AecBlkPlan blk[4];
+};
+
+// index-only ring buffer: same arithmetic as W:common_audio/ring_buffer.c:112-247
+struct RingIdx {
+    int count = 0, rd = 0, wr = 0, diff_wrap = 0;
+    void init(int n) {
+        count = n;
+        rd = wr = 0;
+        diff_wrap = 0;
+    }
+    int avail_read() const { return diff_wrap ? count - rd + wr : wr - rd; }
+    int avail_write() const { return count - avail_read(); }
+    int move_read(int n) {
+        const int fr = avail_write(), readable = avail_read();
+        int pos = rd;
+        if (n > readable) n = readable;
+        if (n < -fr) n = -fr;
+        pos += n;
+        if (pos > count) {
+            pos -= count;
+            diff_wrap = 0;
+        }
+        if (pos < 0) {
+            pos += count;
+            diff_wrap = 1;
+        }
+        rd = pos;
+        return n;
+    }
+    // returns the number of elements written; *pos = first slot (mod count)
+    int write(int n, int *pos) {
+        const int fr = avail_write(), w = fr < n ? fr : n;
+        int left = w;
+        const int margin = count - wr;
+        *pos = wr % count;
+        if (w > margin) {
+            wr = 0;
+            left -= margin;
+            diff_wrap = 1;
+        }
+        wr += left;
+        return w;
+    }
+    int read(int n, int *pos) {
+        const int readable = avail_read(), k = readable < n ? readable : n;
+        *pos = rd % count;
+        move_read(k);
+        return k;
+    }
+};
+
+struct AecCtl {
+    int fs = 0, mult = 1, rate_factor = 1;
+    RingIdx near_fr, out_fr, far_buf, far_pre;
+    int system_delay = 0, core_known_delay = 0;
+    int noise_ctr = 0, delay_est_ctr = 0;
+    uint32_t seed = 777;
+    int hist_n = 0;
+    // Aec wrapper (echo_cancellation_internal.h:17-65)
+    int bufSizeStart = 0, knownDelay = 0, sum = 0, timeForDelayChange = 0, startup_phase = 1, checkBuffSize = 1;
+    short counter = 0, firstVal = 0, checkBufSizeCtr = 0, msInSndCardBuf = 0, filtDelay = -1, lastDelayDiff = 0;
+
+    void init(int freq) {  // WebRtcAec_Init echo_cancellation.c:179-275 + InitAec aec_core.c:1527-1688
+        *this = AecCtl();
+        fs = freq;
+        mult = freq / 8000;
+        rate_factor = freq / 8000;
+        near_fr.init(kAecRing);
+        out_fr.init(kAecRing);
+        far_buf.init(kAecFarBlocks);
+        far_pre.init(kAecPreLen);
+        far_pre.move_read(-kAecPart);  // "Start overlap", echo_cancellation.c:227
+    }
+
+    int move_far_read(int n) {  // aec_core.c:1709-1717 (plain and windowed rings stay in lockstep)
+        const int moved = far_buf.move_read(n);
+        system_delay -= moved * kAecPart;
+        return moved;
+    }
+
+    // WebRtcAec_BufferFarend, echo_cancellation.c:278-339
+    int buffer_farend(int n, AecPlan *pl) {
+        if (n != 80 && n != 160) return -1;
+        pl->has_far = 1;
+        pl->far_n = n;
+        system_delay += n;
+        far_pre.write(n, &pl->pre_wr);
+        pl->n_part = 0;
+        while (far_pre.avail_read() >= 2 * kAecPart) {
+            AecPartPlan &pp = pl->part[pl->n_part++];
+            far_pre.read(2 * kAecPart, &pp.pre_rd);
+            if (far_buf.avail_write() < 1) move_far_read(1);  // BufferFarendPartition aec_core.c:1693-1695
+            far_buf.write(1, &pp.far_slot);
+            far_pre.move_read(-kAecPart);
+        }
+        return 0;
+    }
+
+    void est_buf_delay() {  // echo_cancellation.c:821-872
+        const int nSamp = msInSndCardBuf * 8 * rate_factor;
+        int cur = nSamp - system_delay;
+        cur += kAecFrame * rate_factor;
+        if (cur < kAecPart) cur += move_far_read(1) * kAecPart;
+        filtDelay = filtDelay < 0 ? (short)0 : filtDelay;
+        {
+            const short f = (short)(0.8 * filtDelay + 0.2 * cur);
+            filtDelay = f > 0 ? f : (short)0;
+        }
+        const int diff = filtDelay - knownDelay;
+        if (diff > 224) {
+            if (lastDelayDiff < 96)
+                timeForDelayChange = 0;
+            else
+                timeForDelayChange++;
+        } else if (diff < 96 && knownDelay > 0) {
+            if (lastDelayDiff > 224)
+                timeForDelayChange = 0;
+            else
+                timeForDelayChange++;
+        } else {
+            timeForDelayChange = 0;
+        }
+        lastDelayDiff = (short)diff;
+        if (timeForDelayChange > 25) {
+            const int k = (int)filtDelay - 160;
+            knownDelay = k > 0 ? k : 0;
+        }
+    }
+
+    void plan_block(AecPlan *pl) {  // the index side of ProcessBlock + NonLinearProcessing (aec_core.c:1143-1351, 911-1141)
+        AecBlkPlan &b = pl->blk[pl->n_blk++];
+        near_fr.read(kAecPart, &b.near_rd);
+        far_buf.read(1, &b.far_slot);
+        b.hist_n = hist_n++;
+        b.flags = 0;
+        if (noise_ctr > 50) b.flags |= kAecFlagNoiseMin;
+        if (noise_ctr < 500 * mult) {
+            noise_ctr++;
+            b.flags |= kAecFlagNoiseInit;
+        }
+        delay_est_ctr++;
+        if (delay_est_ctr == 10 * mult) delay_est_ctr = 0;
+        if (delay_est_ctr == 0) b.flags |= kAecFlagDelayEst;
+        // ComfortNoise: 64 uniform numbers -> phases (aec_core.c:476-489), WebRtcSpl_RandUArray
+        const float pi2 = 6.28318530717959f;
+        for (int i = 0; i < kAecPart; i++) {
+            seed = (seed * 69069u + 1u) & 0x7FFFFFFFu;
+            const float r = ((float)(int16_t)(seed >> 16)) / 32768;
+            const float tmp = pi2 * r;
+            b.ucos[i] = cosf(tmp);
+            b.usin[i] = sinf(tmp);
+        }
+        out_fr.write(kAecPart, &b.out_wr);
+    }
+
+    // WebRtcAec_Process -> ProcessNormal (echo_cancellation.c:341-409, 599-747) + ProcessFrames (aec_core.c:1719-1850)
+    int process(int n, int ms_in_snd_card_buf, AecPlan *pl) {
+        int ret = 0;
+        if (n != 80 && n != 160) return -1;
+        short ms = (short)ms_in_snd_card_buf;
+        if (ms < 0) {
+            ms = 0;
+            ret = -1;
+        } else if (ms > 500) {
+            ret = -1;
+        }
+        ms = ms > 500 ? (short)500 : ms;
+        ms = (short)(ms + 10);
+        msInSndCardBuf = ms;
+        pl->has_near = 1;
+        pl->passthrough = 0;
+        pl->n_sub = 0;
+        pl->n_blk = 0;
+        const short nBlocks10ms = (short)(n / (kAecFrame * rate_factor));
+        if (startup_phase) {
+            pl->passthrough = 1;
+            if (checkBuffSize) {
+                checkBufSizeCtr++;
+                if (counter == 0) {
+                    firstVal = msInSndCardBuf;
+                    sum = 0;
+                }
+                const double lim = 0.2 * msInSndCardBuf;
+                if (std::abs(firstVal - msInSndCardBuf) < (lim > 8 ? lim : 8)) {
+                    sum += msInSndCardBuf;
+                    counter++;
+                } else {
+                    counter = 0;
+                }
+                if (counter * nBlocks10ms >= 6) {
+                    const int v = (3 * sum * rate_factor * 8) / (4 * counter * kAecPart);
+                    bufSizeStart = v < 62 ? v : 62;
+                    checkBuffSize = 0;
+                }
+                if (checkBufSizeCtr * nBlocks10ms > 50) {
+                    const int v = (msInSndCardBuf * rate_factor * 3) / 40;
+                    bufSizeStart = v < 62 ? v : 62;
+                    checkBuffSize = 0;
+                }
+            }
+            if (!checkBuffSize) {
+                const int overhead = system_delay / kAecPart - bufSizeStart;
+                if (overhead == 0) {
+                    startup_phase = 0;
+                } else if (overhead > 0) {
+                    move_far_read(overhead);
+                    startup_phase = 0;
+                }
+            }
+            return ret;
+        }
+        est_buf_delay();
+        for (int j = 0; j < n; j += kAecFrame) {
+            AecSubPlan &sp = pl->sub[pl->n_sub++];
+            near_fr.write(kAecFrame, &sp.near_wr);
+            if (system_delay < kAecFrame) move_far_read(-(mult + 1));
+            {
+                const int move = (core_known_delay - knownDelay - 32) / kAecPart;
+                const int moved = far_buf.move_read(move);
+                core_known_delay -= moved * kAecPart;
+            }
+            sp.first_blk = pl->n_blk;
+            sp.n_blocks = 0;
+            while (near_fr.avail_read() >= kAecPart) {
+                plan_block(pl);
+                sp.n_blocks++;
+            }
+            system_delay -= kAecFrame;
+            const int avail = out_fr.avail_read();
+            if (avail < kAecFrame) out_fr.move_read(avail - kAecFrame);
+            out_fr.read(kAecFrame, &sp.out_rd);
+        }
+        return ret;
+    }
+};
+
+}  // namespace wmx

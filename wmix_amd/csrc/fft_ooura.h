@@ -200,8 +200,12 @@ __device__ __forceinline__ Cx ld_cx(const float *a, int p) {
 }
 
 // The complex passes (bitrv2 + cftfsub / cftbsub) for NC = n/2 complex points.
-template <int NC, bool INVERSE>
+// `lane` is the lane index INSIDE the group of GL lanes that owns array `a` (GL = 64: one
+// transform per wave; GL = 16 with NC = 64: four transforms side by side, each group passing
+// its own `a`).  GL >= NC/4 so one pass is one step.
+template <int NC, bool INVERSE, int GL = 64>
 __device__ __forceinline__ void fft_complex_passes(float *a, const FftTables *T, int lane) {
+    static_assert(GL >= NC / 4, "a group must hold one butterfly per lane");
     constexpr int BITS = (NC == 128) ? 7 : 6;
     constexpr int NB = NC / 4;  // butterflies per radix-4 pass
     // pass 1: stride 1, gathering from bit-reversed positions.  rev(4g + j) over BITS bits =
@@ -232,7 +236,7 @@ __device__ __forceinline__ void fft_complex_passes(float *a, const FftTables *T,
     constexpr int HC = (NC == 128) ? 64 : 16;  // stride of the closing pass
     if constexpr (HC * 4 == NC) {
         // closing radix-4 without twiddles (fft4g.c:913-934 / 963-984)
-        if (lane < HC) {
+        if (lane < HC) {  // HC == NC/4 <= GL
             const int p0 = lane, p1 = p0 + HC, p2 = p1 + HC, p3 = p2 + HC;
             const Cx A = ld_cx(a, p0), B = ld_cx(a, p1), C = ld_cx(a, p2), D = ld_cx(a, p3);
             const float x0r = A.r + B.r, x1r = A.r - B.r, x2r = C.r + D.r, x2i = C.i + D.i, x3r = C.r - D.r,
@@ -258,8 +262,8 @@ __device__ __forceinline__ void fft_complex_passes(float *a, const FftTables *T,
         }
     } else {
         // closing radix-2 (fft4g.c:936-947 / 986-997), HC == NC/2
-        if (lane < HC) {
-            const int p0 = lane, p1 = lane + HC;
+        for (int p0 = lane; p0 < HC; p0 += GL) {
+            const int p1 = p0 + HC;
             const Cx A = ld_cx(a, p0), B = ld_cx(a, p1);
             float2 o0, o1;
             if constexpr (!INVERSE) {
@@ -277,12 +281,13 @@ __device__ __forceinline__ void fft_complex_passes(float *a, const FftTables *T,
 }
 
 // fft4g.c:1234-1284 rftfsub / rftbsub: conjugate pairs (q, NC - q), q = 1 .. NC/2 - 1.
-template <int NC, bool INVERSE>
+template <int NC, bool INVERSE, int GL = 64>
 __device__ __forceinline__ void fft_real_split(float *a, const FftTables *T, int lane) {
     constexpr int NQ = NC / 2;  // table length n/4
-    if (lane >= 1 && lane < NQ) {
-        const int j = 2 * lane, k = 2 * NC - j;
-        const float wkr = 0.5f - T->c[NQ - lane], wki = T->c[lane];
+    for (int q = lane; q < NQ; q += GL) {
+        if (q == 0) continue;
+        const int j = 2 * q, k = 2 * NC - j;
+        const float wkr = 0.5f - T->c[NQ - q], wki = T->c[q];
         const float aj = a[j], aj1 = a[j + 1], ak = a[k], ak1 = a[k + 1];
         const float xr = aj - ak, xi = aj1 + ak1;
         if constexpr (!INVERSE) {
@@ -309,10 +314,10 @@ __device__ __forceinline__ void fft_real_split(float *a, const FftTables *T, int
 }
 
 // WebRtc_rdft(n, +1, a) / aec_rdft_forward_128(a).  n = 2*NC.
-template <int NC>
+template <int NC, int GL = 64>
 __device__ __forceinline__ void rdft_forward(float *a, const FftTables *T, int lane) {
-    fft_complex_passes<NC, false>(a, T, lane);
-    fft_real_split<NC, false>(a, T, lane);
+    fft_complex_passes<NC, false, GL>(a, T, lane);
+    fft_real_split<NC, false, GL>(a, T, lane);
     if (lane == 0) {
         const float a0 = a[0], a1 = a[1];
         a[0] = a0 + a1;
@@ -322,7 +327,7 @@ __device__ __forceinline__ void rdft_forward(float *a, const FftTables *T, int l
 }
 
 // WebRtc_rdft(n, -1, a) / aec_rdft_inverse_128(a); unnormalised like the reference.
-template <int NC>
+template <int NC, int GL = 64>
 __device__ __forceinline__ void rdft_inverse(float *a, const FftTables *T, int lane) {
     if (lane == 0) {
         const float a0 = a[0], a1 = a[1];
@@ -331,8 +336,8 @@ __device__ __forceinline__ void rdft_inverse(float *a, const FftTables *T, int l
         a[0] = a0 - h;
     }
     __syncthreads();
-    fft_real_split<NC, true>(a, T, lane);
-    fft_complex_passes<NC, true>(a, T, lane);
+    fft_real_split<NC, true, GL>(a, T, lane);
+    fft_complex_passes<NC, true, GL>(a, T, lane);
 }
 
 }  // namespace wmx
