@@ -28,6 +28,13 @@ int g711u_encode(unsigned char g711_data[], const short amp[], int len);
 unsigned char linear2alaw(int pcm_val);
 unsigned char linear2ulaw(int pcm_val);
 
+/* ---- src/webrtc.h:40-45 (AEC) */
+void *aec_init(int chn, int freq, int intervalMs, bool *debug);
+int aec_setFrameFar(void *fp, int16_t *frameFar, int frameNum);
+int aec_process(void *fp, int16_t *frameNear, int16_t *frameOut, int frameNum, int delayms);
+int aec_process2(void *fp, int16_t *frameFar, int16_t *frameNear, int16_t *frameOut, int frameNum, int delayms);
+void aec_release(void *fp);
+
 /* ---- src/webrtc.h:47-51 (NS) */
 void *ns_init(int chn, int freq, bool *debug);
 void ns_process(void *fp, int16_t *frame, int16_t *frameOut, int frameNum);

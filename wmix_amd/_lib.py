@@ -104,6 +104,16 @@ def _declare(L):
     L.wmx_aec_export_state.argtypes = [vp, i, vp]
     L.wmx_aec_run.restype = i
     L.wmx_aec_run.argtypes = [vp, i, vp, C.c_long, vp, vp, i, C.c_long, C.c_long, i, vp]
+    L.aec_init.restype = vp
+    L.aec_init.argtypes = [i, i, i, vp]
+    L.aec_setFrameFar.restype = i
+    L.aec_setFrameFar.argtypes = [vp, vp, i]
+    L.aec_process.restype = i
+    L.aec_process.argtypes = [vp, vp, vp, i, i]
+    L.aec_process2.restype = i
+    L.aec_process2.argtypes = [vp, vp, vp, vp, i, i]
+    L.aec_release.restype = None
+    L.aec_release.argtypes = [vp]
     L.vad_init.restype = vp
     L.vad_init.argtypes = [i, i, i, vp]
     L.vad_process.restype = None

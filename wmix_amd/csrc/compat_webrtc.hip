@@ -54,9 +54,85 @@ struct AgcHandleCompat {
     DevBuf buf;
 };
 
+struct AecHandleCompat {
+    wmx_aec *batch;
+    int chn, freq, pkg;
+    bool *debug;
+    DevBuf far, near;
+};
+
+// shared body of aec_setFrameFar / aec_process / aec_process2 (src/webrtc.c:286-483)
+int aec_run_host(AecHandleCompat *h, int mode, int16_t *far, int16_t *nearp, int16_t *out, int frameNum, int delayms) {
+    const int per_pkt = h->pkg * h->chn, total = frameNum * h->chn;
+    const int n_packets = (total + per_pkt - 1) / per_pkt;
+    if (n_packets <= 0) return 0;
+    const size_t n = (size_t)n_packets * per_pkt, bytes = (size_t)total * sizeof(int16_t);
+    bool ok = true;
+    if (mode & 1) ok = ok && h->far.ensure(n) && hipMemcpy(h->far.p, far, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    if (mode & 2) ok = ok && h->near.ensure(n) && hipMemcpy(h->near.p, nearp, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    int rc = -1;
+    if (ok) {
+        rc = wmx_aec_run(h->batch, mode, (mode & 1) ? h->far.p : nullptr, per_pkt, (mode & 2) ? h->near.p : nullptr,
+                         (mode & 2) ? h->near.p : nullptr, n_packets, 0, per_pkt, delayms, nullptr);
+        if (rc == 0 || rc == -1) {
+            // rc == -1: the reference returned mid-buffer; packets before the offending one were written
+            if ((mode & 2) && hipMemcpy(out, h->near.p, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = -1;
+        }
+    }
+    if (rc != 0) {
+        (void)hipGetLastError();
+        if (h->debug && *h->debug) printf("WebRtcAecX_Process failed !!, ret %d \r\n", rc);
+    }
+    return rc == 0 ? 0 : -1;
+}
+
 }  // namespace
 
 extern "C" {
+
+// src/webrtc.c:217-274
+void *aec_init(int chn, int freq, int intervalMs, bool *debug) {
+    if (freq > 16000 || freq % 8000 != 0) return NULL;
+    wmx_aec *b = nullptr;
+    if (wmx_aec_create(&b, 1, chn, freq, intervalMs) != 0) {
+        if (debug && *debug) printf("WebRtcAecX_Create failed !! (%s)\r\n", wmx_last_error());
+        return NULL;
+    }
+    AecHandleCompat *h = new AecHandleCompat();
+    h->batch = b;
+    h->chn = chn;
+    h->freq = freq;
+    h->pkg = wmx_aec_packet_samples(b) / chn;
+    h->debug = debug;
+    if (debug && *debug)
+        printf("aec_init: chn/%d freq/%d intervalMs/%d pkgFrame/%d x %d\r\n", chn, freq, h->pkg / (freq / 1000), h->pkg, chn);
+    return h;
+}
+
+// src/webrtc.c:286-323
+int aec_setFrameFar(void *fp, int16_t *frameFar, int frameNum) {
+    return aec_run_host(static_cast<AecHandleCompat *>(fp), 1, frameFar, nullptr, nullptr, frameNum, 0);
+}
+
+// src/webrtc.c:337-395.  Note: when the reference aborts mid-buffer its frameOut keeps whatever the caller had
+// there for the unprocessed packets; with in == out (the daemon's use) that is the unprocessed input, same here.
+int aec_process(void *fp, int16_t *frameNear, int16_t *frameOut, int frameNum, int delayms) {
+    return aec_run_host(static_cast<AecHandleCompat *>(fp), 2, nullptr, frameNear, frameOut, frameNum, delayms);
+}
+
+// src/webrtc.c:410-483
+int aec_process2(void *fp, int16_t *frameFar, int16_t *frameNear, int16_t *frameOut, int frameNum, int delayms) {
+    return aec_run_host(static_cast<AecHandleCompat *>(fp), 3, frameFar, frameNear, frameOut, frameNum, delayms);
+}
+
+// src/webrtc.c:488-505
+void aec_release(void *fp) {
+    AecHandleCompat *h = static_cast<AecHandleCompat *>(fp);
+    if (!h) return;
+    wmx_aec_destroy(h->batch);
+    if (h->debug && *h->debug) printf("aec_release\r\n");
+    delete h;
+}
 
 // src/webrtc.c:40-82
 void *vad_init(int chn, int freq, int intervalMs, bool *debug) {
