@@ -62,7 +62,9 @@ int wmx_g711_decode(int law, const uint8_t *d_code, int16_t *d_pcm, size_t n_cod
  * (SURVEY.md section 0 quirks 2-3).
  *
  * wmx_ns_set_ordered(h, 1) (default) adds every spectral/time sum in the reference's index order:
- * bit-exact with the CPU path.  0 lets the wave add in parallel: <= 1 LSB at the output. */
+ * bit-exact with the CPU path.  0 lets the wave add in parallel (faster, NOT parity-grade: sums
+ * change by an ulp and NS feeds them back into decisions; RMS error stays < 1e-3 of full scale but
+ * individual samples of a few streams can be off by several LSB for a few frames). */
 typedef struct wmx_ns wmx_ns;
 int wmx_ns_create(wmx_ns **out, int n_streams, int chn, int freq);
 int wmx_ns_destroy(wmx_ns *h);

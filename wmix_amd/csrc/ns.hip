@@ -26,7 +26,8 @@
 // bins/samples are where a parallel machine wants a different order: with ORDERED=true the
 // kernel adds in the reference's index order (bit-exact against the CPU path); with
 // ORDERED=false each lane adds its own elements and the wave combines them by a butterfly
-// (differences of a few ulp in the sums, <= 1 LSB at the output).
+// (an ulp of difference in the sums; NS feeds them back into decisions, so this mode is
+// statistically equivalent but not parity-grade -- see tests/test_ns_gpu.py).
 #include <cmath>
 #include <vector>
 #include "wmx_internal.h"
