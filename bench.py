@@ -85,16 +85,169 @@ class G711Workload:
                 "sample": "%d x 20000 frames of 80 samples through oracle/orc_g711.c (-O2), 1 thread" % reps}
 
 
-WORKLOADS = {"g711": (G711Workload, 1 << 20)}
-DEFAULT_WORKLOAD = "g711"
+class _StageTimer:
+    """HIP-event timing of individual launches on torch's current stream (the stream every wmx_* call is given)."""
+
+    def __init__(self):
+        self.ev = {}
+
+    def run(self, name, timed, fn):
+        if not timed:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        self.ev.setdefault(name, []).append((e0, e1))
+        return r
+
+    def mean_ms(self, name):
+        v = self.ev.get(name)
+        return float(np.mean([a.elapsed_time(b) for a, b in v])) if v else None
+
+
+class NsWorkload:
+    """BASELINE.json configs[1]: WebRtcNs_Process, 16 kHz mono, 4096 streams per GPU, one 10 ms packet per stream
+    per step.  Algorithmic bytes per stream-frame = 320 in + 320 out + 2 x 12 200 live state = 25 040 B."""
+    name = "ns_16k_mono"
+    dtype = "f32"
+    bytes_per_frame = 25040.0
+    dominant_kernel = "ns_kernel<256, true>"
+    dominant_bytes_per_frame = 25040.0
+    freq, pkt = 16000, 160
+
+    def __init__(self, dev, n_streams, rank):
+        from wmix_amd import synth
+        from wmix_amd.ns import NsBatch
+        self.n_frames = n_streams
+        self.K = 8
+        base = synth.ns_input(2000 + 7919 * rank, 256, self.K, self.pkt).reshape(256, self.K, self.pkt)
+        reps = (n_streams + 255) // 256
+        x = np.tile(base, (reps, 1, 1))[:n_streams].transpose(1, 0, 2)  # [K, S, pkt] packet-major
+        self.inp = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        self.work = torch.empty_like(self.inp[0:1])
+        self.ns = NsBatch(n_streams, 1, self.freq, ordered=True)
+        self.t = _StageTimer()
+        self.k = 0
+
+    def step(self, timed):
+        k = self.k % self.K
+        self.k += 1
+        self.t.run("ns", timed, lambda: self.ns.process_packet_major(self.inp[k:k + 1], self.work))
+
+    def dominant_ms(self):
+        return self.t.mean_ms("ns")
+
+    def stage_ms(self):
+        return {"ns": self.t.mean_ms("ns")}
+
+    def config(self):
+        return {"workload": self.name, "streams_per_gpu": self.n_frames, "frame": "160 x int16 (10 ms @ 16 kHz mono)",
+                "sum_order": "reference (bit-exact mode)"}
+
+    def cpu_baseline(self, budget_s):
+        from oracle import loader
+        port = loader.port()
+        n = 3000
+        x = np.ascontiguousarray(self.inp[:, 0].cpu().numpy().reshape(-1))
+        x = np.tile(x, n // self.K + 1)[: n * self.pkt]
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < budget_s:
+            loader.run_ns(port, 1, self.freq, x, self.pkt, prefix="orc")
+            reps += 1
+        dt = time.perf_counter() - t0
+        return {"value": reps * n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+                "sample": "%d x %d packets of one 16 kHz stream through oracle/orc_ns.c (-O2), 1 thread" % (reps, n)}
+
+
+class ChainWorkload:
+    """BASELINE.json configs[2]: the daemon's record chain NS -> AEC -> AGC -> VAD (src/wmix.c:613-709), 16 kHz mono,
+    65536 streams per GPU sharing one far-end reference, one 10 ms packet per stream per step.  With N > 1 ranks the
+    far-end packet is broadcast from rank 0 over RCCL every step; streams never talk to each other.
+    Algorithmic bytes per stream-frame = 640 PCM + 2 x (12 200 + 11 700 + 668 + 736) state = 51 248 B (SURVEY 8d);
+    the dominant kernel is the AEC near-end kernel: 320 + 320 + 2 x 11 700 = 24 040 B per stream-frame."""
+    name = "chain_ns_aec_agc_vad_16k_mono"
+    dtype = "f32"
+    bytes_per_frame = 51248.0
+    dominant_kernel = "aec_near_kernel<2>"
+    dominant_bytes_per_frame = 24040.0
+    freq, pkt = 16000, 160
+
+    def __init__(self, dev, n_streams, rank, dist=None):
+        from wmix_amd import synth
+        from wmix_amd.aec import AecBatch
+        from wmix_amd.agc import AgcBatch
+        from wmix_amd.ns import NsBatch
+        from wmix_amd.vad import VadBatch
+        self.n_frames = n_streams
+        self.dist = dist
+        self.K = 8
+        far = synth.far_end(3000, self.K, self.pkt)  # the same far-end on every rank (rank 0's copy is broadcast)
+        base = synth.near_end(3001 + 7919 * rank, 256, self.K, self.pkt, far=far).reshape(256, self.K, self.pkt)
+        reps = (n_streams + 255) // 256
+        x = np.tile(base, (reps, 1, 1))[:n_streams].transpose(1, 0, 2)
+        self.inp = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        self.far_src = torch.from_numpy(far.reshape(self.K, self.pkt).copy()).to(dev)
+        self.far = torch.zeros(1, self.pkt, dtype=torch.int16, device=dev)
+        self.work = torch.empty_like(self.inp[0:1])
+        self.ns = NsBatch(n_streams, 1, self.freq, ordered=True)
+        self.aec = AecBatch(n_streams, 1, self.freq, 10)
+        self.agc = AgcBatch(n_streams, 1, self.freq, 5)  # volumeAgc default 5, src/wmix.c:1596
+        self.vad = VadBatch(n_streams, 1, self.freq, 10)
+        self.rank = rank
+        self.t = _StageTimer()
+        self.k = 0
+
+    def step(self, timed):
+        k = self.k % self.K
+        self.k += 1
+        if self.rank == 0:
+            self.far.copy_(self.far_src[k:k + 1])
+        if self.dist is not None:
+            self.t.run("far_broadcast", timed, lambda: self.dist.broadcast(self.far, src=0))
+        self.t.run("ns", timed, lambda: self.ns.process_packet_major(self.inp[k:k + 1], self.work))
+        self.t.run("aec", timed, lambda: self.aec.process2_packet_major(self.far, self.work))
+        self.t.run("agc", timed, lambda: self.agc.process_packet_major(self.work))
+        self.t.run("vad", timed, lambda: self.vad.process_packet_major(self.work))
+
+    def dominant_ms(self):
+        return self.t.mean_ms("aec")
+
+    def stage_ms(self):
+        return {k: self.t.mean_ms(k) for k in ("far_broadcast", "ns", "aec", "agc", "vad") if self.t.mean_ms(k) is not None}
+
+    def config(self):
+        return {"workload": self.name, "streams_per_gpu": self.n_frames, "frame": "160 x int16 (10 ms @ 16 kHz mono)",
+                "far_end": "shared, RCCL broadcast from rank 0 each step", "sum_order": "reference (bit-exact NS mode)",
+                "aec_launch": "far kernel + near kernel; the near kernel is the timed dominant kernel together with its far kernel"}
+
+    def cpu_baseline(self, budget_s):
+        from oracle import loader
+        port = loader.port()
+        n = 2000
+        far = np.tile(self.far_src.cpu().numpy().reshape(-1), n // self.K + 1)[: n * self.pkt]
+        near = np.tile(np.ascontiguousarray(self.inp[:, 0].cpu().numpy().reshape(-1)), n // self.K + 1)[: n * self.pkt]
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < budget_s:
+            loader.run_chain(port, 1, self.freq, 5, 15, far, near, self.pkt, prefix="orc")
+            reps += 1
+        dt = time.perf_counter() - t0
+        return {"value": reps * n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+                "sample": "%d x %d packets of one 16 kHz stream through the oracle chain (oracle/orc_*.c, -O2), 1 thread" % (reps, n)}
+
+
+WORKLOADS = {"g711": (G711Workload, 1 << 20), "ns": (NsWorkload, 4096), "chain": (ChainWorkload, 65536)}
+DEFAULT_WORKLOAD = "chain"
 
 
 # ----------------------------------------------------------------------------- driver
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=0, help="streams (frames per step) per GPU; 0 = workload default")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -119,7 +272,10 @@ def main():
     _lib.lib()  # no fallback: raises when the HIP library is missing
 
     cls, default_streams = WORKLOADS[args.workload]
-    wl = cls(dev, args.streams or default_streams, rank)
+    if cls is ChainWorkload:
+        wl = cls(dev, args.streams or default_streams, rank, dist)
+    else:
+        wl = cls(dev, args.streams or default_streams, rank)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -155,6 +311,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
         "config": wl.config(), "roofline": roofline,
+        "stage_ms": wl.stage_ms() if hasattr(wl, "stage_ms") else None,
         "whole_step_hbm_frac": round(value / world * wl.bytes_per_frame / 1e9 / HBM_PEAK_GBS, 5),
     }
     if rank == 0:
