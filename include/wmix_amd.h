@@ -135,6 +135,22 @@ int wmx_aec_run(wmx_aec *h, int mode, const int16_t *d_far, long far_packet_stri
 int wmx_aec_state_words(const wmx_aec *h);
 int wmx_aec_export_state(const wmx_aec *h, int stream_index, float *host_words);
 
+/* ------------------------------------------------------------------ resample + mix
+ * Batched forms of wmix_pcm_zoom (src/wmix.c:139-222) and of wmix_load_data + the play thread's drain
+ * (src/wmix.c:1639-1957, 1347-1366).  Strides in int16 elements.  Integer path: bit-exact, including the
+ * dead 2ch->2ch branch of wmix_pcm_zoom (writes 0 bytes) and the order-dependent saturating add. */
+int wmx_pcm_zoom(int inChn, int inFreq, const int16_t *d_in, uint32_t inLen, int outChn, int outFreq, int16_t *d_out,
+                 long in_stride, long out_stride, int n_streams, uint32_t *out_len, void *stream);
+typedef struct wmx_mix wmx_mix;
+int wmx_mix_create(wmx_mix **out, int n_groups, int ring_chn, int ring_freq);
+int wmx_mix_destroy(wmx_mix *m);
+int wmx_mix_set(wmx_mix *m, uint32_t head_off, uint32_t tick, int reduce_mode); /* wmix->head/tick/reduceMode */
+int wmx_mix_ring_bytes(const wmx_mix *m);
+int wmx_mix_load(wmx_mix *m, const int16_t *d_src, uint32_t srcU8Len, int freq, int channels, int sample, int n_src,
+                 long group_stride, long source_stride, int reduce, uint32_t *head, uint32_t *tick, void *stream);
+int wmx_mix_drain(wmx_mix *m, int16_t *d_out, uint32_t bytes, long out_stride, void *stream);
+int wmx_mix_export(const wmx_mix *m, int group, int16_t *host_ring, uint32_t *head_off, uint32_t *tick);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,7 @@
 
 #include <stdbool.h>
 #include <stdint.h>
+#include <sys/types.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -50,6 +51,39 @@ void *agc_init(int chn, int freq, int intervalMs, int value, bool *debug);
 int agc_process(void *fp, int16_t *frame, int16_t *frameOut, int frameNum);
 void agc_addition(void *fp, uint8_t value);
 void agc_release(void *fp);
+
+/* ---- src/wmix.h:40-49, 113-127 (resample + mix).  WMix_Point is src/wmixConf.h:149-156; WMix_Struct_Head
+ * mirrors, field for field, the leading part of WMix_Struct (src/wmixConf.h:176-203) up to `reduceMode`, the
+ * last field wmix_load_data reads -- a daemon passes its own WMix_Struct*. */
+typedef union {
+    int8_t *S8;
+    uint8_t *U8;
+    int16_t *S16;
+    uint16_t *U16;
+    int32_t *S32;
+    uint32_t *U32;
+} WMix_Point;
+typedef struct {
+    void *objAo, *objAi;
+    uint8_t *buff;
+    WMix_Point start, end;
+    WMix_Point head, tail;
+    bool run;
+    uint8_t loopWord, loopWordRecord, loopWordFifo, loopWordRtp;
+    uint32_t tick;
+    uint32_t thread_sys, thread_record, thread_play;
+    bool playRun, recordRun;
+    int shmemRun;
+    key_t msg_key;
+    int msg_fd;
+    uint8_t reduceMode;
+} WMix_Struct_Head;
+WMix_Point wmix_load_data(WMix_Struct_Head *wmix, WMix_Point src, uint32_t srcU8Len, uint16_t freq, uint8_t channels,
+                          uint8_t sample, WMix_Point head, uint8_t reduce, uint32_t *tick);
+uint32_t wmix_len_of_out(uint8_t inChn, uint16_t inFreq, uint32_t inLen, uint8_t outChn, uint16_t outFreq);
+uint32_t wmix_len_of_in(uint8_t inChn, uint16_t inFreq, uint8_t outChn, uint16_t outFreq, uint32_t outLen);
+uint32_t wmix_pcm_zoom(uint8_t inChn, uint16_t inFreq, uint8_t *in, uint32_t inLen, uint8_t outChn, uint16_t outFreq,
+                       uint8_t *out);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,126 @@
+"""GPU parity: wmix_amd/csrc/mix.hip through the C ABI vs the goldens of the real reference mixer arithmetic
+and vs the oracle for other ring formats / many groups.  Integer path: bit-exact."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+sys.path.insert(0, GOLDEN)
+from make_mix_golden import LOAD_CASES, ZOOM_CASES, load_input, zoom_input  # noqa: E402
+from test_mix_oracle import _bind, orc_load, orc_zoom  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(GOLDEN, "mix_golden.npz"))
+
+
+def gpu_load(cuda, ring_chn, ring_freq, freq, chn, rmode, rarg, nsrc, sbytes, start, src, n_groups=1):
+    import torch
+    from wmix_amd.mix import MixBatch
+    mb = MixBatch(n_groups, ring_chn, ring_freq)
+    mb.set(start, 0, rmode)
+    per = sbytes // 2
+    # sources back to back like the reference driver: source s starts at s*per, look-ahead reads the next one
+    d = torch.from_numpy(np.ascontiguousarray(np.tile(src[None, :], (n_groups, 1)))).to(cuda)
+    view = torch.as_strided(d, (n_groups, nsrc, per + chn), (d.stride(0), per, 1))
+    h, t = mb.load(view, sbytes, freq, chn, reduce=rarg)
+    rings = [mb.export(g)[0] for g in range(n_groups)]
+    mb.close()
+    return rings, h, t
+
+
+@pytest.mark.parametrize("i", range(len(ZOOM_CASES)))
+def test_zoom_golden(cuda, wmx, i):
+    import torch
+    from wmix_amd import mix
+    ic, ifr, oc, ofr, n = ZOOM_CASES[i]
+    x = zoom_input(i, n)
+    got = mix.pcm_zoom(ic, ifr, torch.from_numpy(np.tile(x, (3, 1))).to(cuda), oc, ofr).cpu().numpy()
+    assert got.shape[1] == G["zoom_%d" % i].size and all(np.array_equal(got[s], G["zoom_%d" % i]) for s in range(3))
+    assert mix.len_of_out(ic, ifr, n, oc, ofr) == G["lens_%d" % i][0]
+    assert mix.len_of_in(ic, ifr, oc, ofr, n) == G["lens_%d" % i][1]
+    out = np.zeros(n * 8 + 64, np.uint8)  # legacy host signature, src/wmix.h:122-127
+    m = wmx.wmix_pcm_zoom(ic, ifr, x.ctypes.data_as(C.c_void_p), n, oc, ofr, out.ctypes.data_as(C.c_void_p))
+    assert m == G["zoom_%d" % i].size * 2 and np.array_equal(out[:m].view(np.int16), G["zoom_%d" % i])
+
+
+@pytest.mark.parametrize("i", range(len(LOAD_CASES)))
+def test_load_data_golden(cuda, i):
+    freq, chn, rmode, rarg, nsrc, sbytes, start = LOAD_CASES[i]
+    rings, h, t = gpu_load(cuda, 1, 8000, freq, chn, rmode, rarg, nsrc, sbytes, start, load_input(i, nsrc, sbytes), n_groups=3)
+    for r in rings:
+        assert np.array_equal(r, G["ring_%d" % i])
+    assert (t, h) == tuple(G["meta_%d" % i][-1])  # every source of one call ends on the same cursor
+
+
+@pytest.mark.parametrize("ring_chn,ring_freq", [(2, 16000), (1, 16000), (2, 8000)])
+def test_other_ring_formats_vs_oracle(cuda, oracle_port, ring_chn, ring_freq):
+    """ring formats other than the reference's default build can only be pinned by the restatement."""
+    _bind(oracle_port)
+    rng = np.random.default_rng(77)
+    for (freq, chn, rmode, rarg, nsrc, sbytes, start) in ((32000, 2, 1, 1, 3, 1280, 0), (8000, 1, 2, 1, 2, 320, 64), (ring_freq, ring_chn, 1, 1, 4, 640, 0),
+                                                          (11025, 2, 1, 1, 2, 884, ring_chn * 2 * ring_freq - 128)):
+        src = rng.integers(-20000, 20000, size=nsrc * sbytes // 2 + 8, dtype=np.int16)
+        want, meta = orc_load(oracle_port, ring_chn, ring_freq, freq, chn, rmode, rarg, nsrc, sbytes, start, src)
+        rings, h, t = gpu_load(cuda, ring_chn, ring_freq, freq, chn, rmode, rarg, nsrc, sbytes, start, src)
+        assert np.array_equal(rings[0], want) and (t, h) == tuple(meta[-1])
+
+
+def test_legacy_wmix_load_data_signature(wmx):
+    """WMix_Point wmix_load_data(WMix_Struct*, ...) over a host ring (src/wmix.h:40-49), default 1 x 8000 ring."""
+
+    class Point(C.Union):
+        _fields_ = [("U8", C.c_void_p)]
+
+    class Head(C.Structure):  # WMix_Struct_Head (include/wmix_compat.h)
+        _fields_ = [("objAo", C.c_void_p), ("objAi", C.c_void_p), ("buff", C.c_void_p), ("start", Point), ("end", Point), ("head", Point),
+                    ("tail", Point), ("run", C.c_bool), ("loopWord", C.c_uint8), ("loopWordRecord", C.c_uint8), ("loopWordFifo", C.c_uint8),
+                    ("loopWordRtp", C.c_uint8), ("tick", C.c_uint32), ("thread_sys", C.c_uint32), ("thread_record", C.c_uint32),
+                    ("thread_play", C.c_uint32), ("playRun", C.c_bool), ("recordRun", C.c_bool), ("shmemRun", C.c_int), ("msg_key", C.c_int),
+                    ("msg_fd", C.c_int), ("reduceMode", C.c_uint8)]
+
+    wmx.wmix_load_data.restype = Point
+    wmx.wmix_load_data.argtypes = [C.POINTER(Head), Point, C.c_uint32, C.c_uint16, C.c_uint8, C.c_uint8, Point, C.c_uint8, C.POINTER(C.c_uint32)]
+    i = 2
+    freq, chn, rmode, rarg, nsrc, sbytes, start = LOAD_CASES[i]
+    src = load_input(i, nsrc, sbytes)
+    ring = np.zeros(16000 // 2 + 8, np.int16)
+    w = Head()
+    w.start.U8 = ring.ctypes.data
+    w.end.U8 = ring.ctypes.data + 16000
+    w.head.U8 = ring.ctypes.data + start
+    w.run, w.reduceMode, w.tick = True, rmode, 0
+    for s in range(nsrc):
+        tick = C.c_uint32(0)
+        sp, hp = Point(), Point()
+        sp.U8 = src.ctypes.data + s * sbytes
+        hp.U8 = None
+        r = wmx.wmix_load_data(C.byref(w), sp, sbytes, freq, chn, 16, hp, rarg, C.byref(tick))
+        assert (tick.value, r.U8 - ring.ctypes.data) == tuple(G["meta_%d" % i][s])
+    assert np.array_equal(ring[:8000], G["ring_%d" % i])
+
+
+def test_full_size_mix_properties(cuda):
+    """configs[4] size: 32768 sources of 2ch 32 kHz 10 ms mixed 8-way into 4096 groups of a 1 x 8000 ring.
+    Equal inputs give equal rings; draining returns the mixed packet and leaves the ring all zero; a mix of
+    sources that never saturates equals the plain integer sum."""
+    import torch
+    from wmix_amd.mix import MixBatch
+    n_groups, n_src, per = 4096, 8, 640
+    base = np.random.default_rng(5).integers(-3000, 3000, size=(2, n_src, per + 2), dtype=np.int16)
+    d = torch.from_numpy(base[np.arange(n_groups) % 2]).to(cuda)
+    mb = MixBatch(n_groups, 1, 8000)
+    h, t = mb.load(d, per * 2, 32000, 2)
+    assert (h, t) == (3200 + 160, 3200 + 160)
+    r0, r1, r2 = mb.export(0)[0], mb.export(1)[0], mb.export(4094)[0]
+    assert np.array_equal(r0, r2) and not np.array_equal(r0, r1)
+    want = base[0, :, 0:per:8].astype(np.int32).sum(0)  # L channel, every 4th frame, summed over sources
+    assert np.array_equal(r0[1600:1680].astype(np.int32), want)
+    mb.set(3200, 0, 1)
+    out = mb.drain(160).cpu().numpy()
+    assert np.array_equal(out[0], r0[1600:1680]) and np.array_equal(out[1], r1[1600:1680])
+    assert not mb.export(0)[0].any()
+    mb.close()

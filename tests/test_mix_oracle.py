@@ -1,0 +1,106 @@
+"""CPU: oracle/orc_mix.c against golden results of the real wmix_pcm_zoom / wmix_len_of_* / wmix_load_data
+(tests/golden/mix_golden.npz) and against oracle/_ref/ref_mix_driver on fresh inputs when present.  Bit-exact."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import loader as L
+
+sys.path.insert(0, GOLDEN)
+from make_mix_golden import LOAD_CASES, ZOOM_CASES, load_input, zoom_input  # noqa: E402
+
+G = np.load(os.path.join(GOLDEN, "mix_golden.npz"))
+
+
+class Ring(C.Structure):  # orc_mix_ring
+    _fields_ = [("chn", C.c_int), ("freq", C.c_int), ("size", C.c_uint32), ("buff", C.c_void_p), ("head_off", C.c_uint32),
+                ("tick", C.c_uint32), ("reduce_mode", C.c_uint8), ("play_correct", C.c_uint32)]
+
+
+def _bind(p):
+    for n in ("orc_len_of_out", "orc_len_of_in", "orc_pcm_zoom", "orc_load_data"):
+        getattr(p, n).restype = C.c_uint32
+
+
+def orc_zoom(p, ic, ifr, x, oc, ofr):
+    out = np.zeros(x.size * 16 + 64, np.int16)
+    m = p.orc_pcm_zoom(ic, ifr, x.ctypes.data_as(C.c_void_p), x.size * 2, oc, ofr, out.ctypes.data_as(C.c_void_p))
+    return out[: m // 2].copy()
+
+
+def orc_load(p, ring_chn, ring_freq, freq, chn, rmode, rarg, nsrc, sbytes, start, src):
+    size = ring_chn * 2 * ring_freq
+    store = np.zeros(size + 64, np.uint8)
+    r = Ring()
+    p.orc_mix_ring_init(C.byref(r), store.ctypes.data_as(C.c_void_p), ring_chn, ring_freq)
+    r.head_off, r.reduce_mode = start, rmode
+    meta = []
+    for i in range(nsrc):
+        tick = C.c_uint32(0)
+        h = p.orc_load_data(C.byref(r), C.c_void_p(src.ctypes.data + i * sbytes), sbytes, freq, chn, 16, C.c_uint32(0xFFFFFFFF), rarg,
+                            C.byref(tick))
+        meta.append((tick.value, h))
+    return store[:size].view(np.int16).copy(), np.array(meta, np.uint32)
+
+
+@pytest.mark.parametrize("i", range(len(ZOOM_CASES)))
+def test_zoom_and_len_golden(oracle_port, i):
+    _bind(oracle_port)
+    ic, ifr, oc, ofr, n = ZOOM_CASES[i]
+    x = zoom_input(i, n)
+    assert np.array_equal(orc_zoom(oracle_port, ic, ifr, x, oc, ofr), G["zoom_%d" % i])
+    assert oracle_port.orc_len_of_out(ic, ifr, n, oc, ofr) == G["lens_%d" % i][0]
+    assert oracle_port.orc_len_of_in(ic, ifr, oc, ofr, n) == G["lens_%d" % i][1]
+
+
+def test_survey_smoke_values(oracle_port):
+    """zoom(2,32000,2560 B -> 1,8000) = 320 B; (2,32000 -> 2,16000) = 0 B (dead branch);
+    load of 1280 int16 of 2x32k into a fresh 1x8000 ring -> tick 3520, head 3520."""
+    _bind(oracle_port)
+    x = zoom_input(0, 2560)
+    assert orc_zoom(oracle_port, 2, 32000, x, 1, 8000).size * 2 == 320
+    assert orc_zoom(oracle_port, 2, 32000, x, 2, 16000).size == 0
+    src = load_input(0, 1, 2560)
+    _, meta = orc_load(oracle_port, 1, 8000, 32000, 2, 1, 1, 1, 2560, 0, src)
+    assert tuple(meta[0]) == (3520, 3520)
+
+
+@pytest.mark.parametrize("i", range(len(LOAD_CASES)))
+def test_load_data_golden(oracle_port, i):
+    _bind(oracle_port)
+    freq, chn, rmode, rarg, nsrc, sbytes, start = LOAD_CASES[i]
+    ring, meta = orc_load(oracle_port, 1, 8000, freq, chn, rmode, rarg, nsrc, sbytes, start, load_input(i, nsrc, sbytes))
+    assert np.array_equal(ring, G["ring_%d" % i]) and np.array_equal(meta, G["meta_%d" % i])
+
+
+def test_saturation_is_order_dependent(oracle_port):
+    """volumeAdd saturates per step (src/wmix.c:1617-1636): (+30000) + (+30000) + (-30000) != (-30000) + ... order."""
+    _bind(oracle_port)
+    a = np.full(84, 30000, np.int16)
+    b = np.full(84, -30000, np.int16)
+    r1, _ = orc_load(oracle_port, 1, 8000, 8000, 1, 1, 1, 3, 160, 0, np.concatenate([a[:80], a[:80], b]))
+    r2, _ = orc_load(oracle_port, 1, 8000, 8000, 1, 1, 1, 3, 160, 0, np.concatenate([b[:80], a[:80], a]))
+    assert r1[1600] == 32767 - 30000 and r2[1600] == 30000  # head starts 3200 B = 1600 samples ahead (VIEW_PLAY_CORRECT)
+
+
+def test_against_real_reference_fresh_inputs(oracle_port):
+    if not L.have_ref_mix():
+        pytest.skip("oracle/_ref/ref_mix_driver not present")
+    _bind(oracle_port)
+    rng = np.random.default_rng(1234)
+    for (ic, ifr, oc, ofr) in ((2, 32000, 1, 8000), (1, 11025, 2, 44100), (2, 16000, 1, 48000), (1, 48000, 1, 8000)):
+        for n in (4, 90, 1764, 4096):
+            x = rng.integers(-32768, 32768, size=n // 2, dtype=np.int16)
+            want = np.frombuffer(L.ref_mix("zoom", ic, ifr, oc, ofr, stdin=x.tobytes()), dtype=np.int16)
+            assert np.array_equal(orc_zoom(oracle_port, ic, ifr, x, oc, ofr), want)
+    for (freq, chn) in ((8000, 1), (32000, 2), (44100, 1), (5000, 2), (12000, 1)):
+        for (rmode, rarg, nsrc, sbytes, start) in ((1, 1, 5, 1000, 0), (4, 1, 3, 2000, 15000), (2, 2, 2, 400, 8000)):
+            src = rng.integers(-25000, 25000, size=nsrc * sbytes // 2 + 8, dtype=np.int16)
+            b = L.ref_mix("load", freq, chn, rmode, rarg, nsrc, sbytes, start, stdin=src.tobytes())
+            ring, meta = orc_load(oracle_port, 1, 8000, freq, chn, rmode, rarg, nsrc, sbytes, start, src)
+            assert np.array_equal(ring, np.frombuffer(b[:16000], dtype=np.int16))
+            assert np.array_equal(meta, np.frombuffer(b[16000:], dtype=np.uint32).reshape(nsrc, 2))

@@ -104,6 +104,29 @@ def _declare(L):
     L.wmx_aec_export_state.argtypes = [vp, i, vp]
     L.wmx_aec_run.restype = i
     L.wmx_aec_run.argtypes = [vp, i, vp, C.c_long, vp, vp, i, C.c_long, C.c_long, i, vp]
+    u32 = C.c_uint32
+    L.wmx_pcm_zoom.restype = i
+    L.wmx_pcm_zoom.argtypes = [i, i, vp, u32, i, i, vp, C.c_long, C.c_long, i, C.POINTER(u32), vp]
+    L.wmx_mix_create.restype = i
+    L.wmx_mix_create.argtypes = [C.POINTER(vp), i, i, i]
+    L.wmx_mix_destroy.restype = i
+    L.wmx_mix_destroy.argtypes = [vp]
+    L.wmx_mix_set.restype = i
+    L.wmx_mix_set.argtypes = [vp, u32, u32, i]
+    L.wmx_mix_ring_bytes.restype = i
+    L.wmx_mix_ring_bytes.argtypes = [vp]
+    L.wmx_mix_load.restype = i
+    L.wmx_mix_load.argtypes = [vp, vp, u32, i, i, i, i, C.c_long, C.c_long, i, C.POINTER(u32), C.POINTER(u32), vp]
+    L.wmx_mix_drain.restype = i
+    L.wmx_mix_drain.argtypes = [vp, vp, u32, C.c_long, vp]
+    L.wmx_mix_export.restype = i
+    L.wmx_mix_export.argtypes = [vp, i, vp, C.POINTER(u32), C.POINTER(u32)]
+    L.wmix_len_of_out.restype = u32
+    L.wmix_len_of_out.argtypes = [C.c_uint8, C.c_uint16, u32, C.c_uint8, C.c_uint16]
+    L.wmix_len_of_in.restype = u32
+    L.wmix_len_of_in.argtypes = [C.c_uint8, C.c_uint16, C.c_uint8, C.c_uint16, u32]
+    L.wmix_pcm_zoom.restype = u32
+    L.wmix_pcm_zoom.argtypes = [C.c_uint8, C.c_uint16, vp, u32, C.c_uint8, C.c_uint16, vp]
     L.aec_init.restype = vp
     L.aec_init.argtypes = [i, i, i, vp]
     L.aec_setFrameFar.restype = i

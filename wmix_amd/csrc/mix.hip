@@ -1,0 +1,483 @@
+// mix.hip -- wmix's resample + saturating-mix arithmetic, batched for gfx950.
+//
+// Replaces wmix_pcm_zoom / wmix_len_of_out / wmix_len_of_in (src/wmix.c:49-222) and the arithmetic of
+// wmix_load_data + volumeAdd (src/wmix.c:1617-1957) for many independent mix groups per launch.
+//
+// Both reference routines drive their source/destination cursors with a float32 phase accumulator
+// (`divStep += div; if ((int)divStep > 0) ... divStep -= 1.0`, `divCount += divPow; if (divCount >= 1.0)`)
+// that depends only on the two rates and the length, never on the samples.  The host therefore runs the
+// SAME float recurrence once per call and emits a gather schedule (one entry per destination sample);
+// the kernels are pure HBM-streaming gathers: zoom = copy through the schedule, load = gather (+ the
+// reference's linear "repair" fill when up-sampling) / reduce, then volumeAdd (a saturating add) into the
+// group's 1 s ring.  All sources of a group are applied by the same thread in call order, so the
+// order-dependent saturation (src/wmix.c:1617-1636) is reproduced without atomics.  Bit-exact.
+#include <cstddef>
+#include <cstdlib>
+#include <vector>
+#include "wmx_internal.h"
+#include "../../include/wmix_compat.h"
+
+namespace wmx {
+namespace {
+
+// ---------------------------------------------------------------- host: the reference's phase recurrences
+// src/wmix.c:49-91 / 94-136 share one loop; `want_in` selects which counter bounds it.
+uint32_t len_walk(uint8_t inChn, uint16_t inFreq, uint8_t outChn, uint16_t outFreq, uint32_t limit, bool limit_is_in, bool return_in) {
+    uint32_t inCount = 0, outCount = 0;
+    float div, divStep = 0;
+    if (inFreq < outFreq) {
+        div = (float)inFreq / outFreq;
+        while ((limit_is_in ? inCount : outCount) < limit) {
+            outCount += outChn;
+            divStep += div;
+            if ((int)divStep > 0) {
+                inCount += inChn;
+                divStep -= 1.0;
+            }
+        }
+    } else {
+        div = (float)outFreq / inFreq;
+        while ((limit_is_in ? inCount : outCount) < limit) {
+            divStep += div;
+            if ((int)divStep > 0) {
+                outCount += outChn;
+                divStep -= 1.0;
+            }
+            inCount += inChn;
+        }
+    }
+    return return_in ? inCount : outCount;
+}
+
+// wmix_pcm_zoom (src/wmix.c:139-222) as a gather list: out sample i <- in sample idx[i]
+void zoom_schedule(uint8_t inChn, uint16_t inFreq, uint32_t inLen, uint8_t outChn, uint16_t outFreq, std::vector<int32_t> &idx) {
+    idx.clear();
+    const uint8_t mode = (uint8_t)((inChn << 4) | (outChn & 0x0F));
+    const int emit = (mode == 0x11 || mode == 0x21) ? 1 : (mode == 0x12 ? 2 : 0);  // 0x22 is dead code in the reference
+    int32_t ip = 0;  // int16 index; the reference loops while the S16 cursor is below the byte address in + inLen
+    float div, divStep = 0;
+    if (inFreq < outFreq) {
+        div = (float)inFreq / outFreq;
+        while ((uint32_t)ip * 2u < inLen) {
+            for (int e = 0; e < emit; e++) idx.push_back(ip);
+            divStep += div;
+            if ((int)divStep > 0) {
+                ip += inChn;
+                divStep -= 1.0;
+            }
+        }
+    } else {
+        div = (float)outFreq / inFreq;
+        while ((uint32_t)ip * 2u < inLen) {
+            divStep += div;
+            if ((int)divStep > 0) {
+                for (int e = 0; e < emit; e++) idx.push_back(ip);
+                divStep -= 1.0;
+            }
+            ip += inChn;
+        }
+    }
+}
+
+// wmix_load_data's cursor walk (src/wmix.c:1675-1939) as a schedule: destination sample i (relative to the
+// head, in ring samples) <- either source sample `src` or the k-th of n2 linear fill samples between
+// source samples `src - step` and `src` (repairBuff, src/wmix.c:1854-1866).
+struct LoadEntry {
+    int32_t src;   // int16 index into the source buffer
+    int16_t k;     // -1: plain copy, else fill sample index
+    int16_t n2;    // divCount2
+    int32_t step;  // int16 per source frame (for the fill: previous sample = src - step)
+};
+
+bool load_schedule(int ring_chn, int ring_freq, uint32_t srcU8Len, uint16_t freq, uint8_t channels, uint8_t sample,
+                   std::vector<LoadEntry> &sch) {
+    sch.clear();
+    const int32_t freqErr = ring_freq - (int32_t)freq;
+    uint32_t count;
+    int32_t ps = 0;
+    auto put = [&](int32_t s, int k, int n2, int step) { sch.push_back(LoadEntry{s, (int16_t)k, (int16_t)n2, step}); };
+    if (freq == ring_freq && channels == ring_chn && sample == 16) {
+        for (count = 0; count < srcU8Len;) {
+            put(ps, -1, 0, 1);
+            ps++;
+            count += 2;
+            if (ring_chn != 1) {
+                put(ps, -1, 0, 1);
+                ps++;
+                count += 2;
+            }
+        }
+        return true;
+    }
+    if (sample != 16 || (channels != 1 && channels != 2)) return true;  // the reference's empty 8/32-bit branches: nothing is written
+    const int step = channels;
+    float divCount = 0, divPow;
+    if (freqErr < 0) {
+        divPow = (float)(-freqErr) / ring_freq;
+        for (count = 0; count < srcU8Len;) {
+            if (divCount >= 1.0) {
+                ps += step;
+                divCount -= 1.0;
+                count += 2 * step;
+            } else {
+                put(ps, -1, 0, step);
+                if (ring_chn != 1) put(channels == 2 ? ps + 1 : ps, -1, 0, step);
+                ps += step;
+                divCount += divPow;
+                count += 2 * step;
+            }
+        }
+    } else {
+        divPow = (float)freqErr / freq;
+        int rc = 0, n2 = 0, rsrc = 0;
+        for (count = 0; count < srcU8Len;) {
+            if (divCount >= 1.0) {
+                if (n2 > 64 || rc >= n2) return false;  // the reference would run off repairBuff[64]
+                put(rsrc, rc, n2, step);
+                if (ring_chn != 1) put(rsrc, rc, n2, step);
+                divCount -= 1.0;
+                rc += 1;
+            } else {
+                put(ps, -1, 0, step);
+                if (ring_chn != 1) put(channels == 2 ? ps + 1 : ps, -1, 0, step);
+                ps += step;
+                divCount += divPow;
+                count += 2 * step;
+                if (divCount >= 1.0) {
+                    n2 = (int)divCount + 1;
+                    rsrc = ps;
+                    rc = 0;
+                }
+            }
+        }
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------- kernels
+__global__ __launch_bounds__(256) void zoom_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out,
+                                                   const int32_t *__restrict__ idx, uint32_t n_out, long in_stride, long out_stride,
+                                                   int n_streams) {
+    const size_t total = (size_t)n_out * n_streams;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t i = (uint32_t)(t % n_out);
+        const size_t s = t / n_out;
+        out[s * out_stride + i] = in[s * in_stride + idx[i]];
+    }
+}
+
+__device__ __forceinline__ int16_t volume_add(int16_t a, int16_t b) {  // src/wmix.c:1617-1636
+    if (a == 0) return b;
+    if (b == 0) return a;
+    const int32_t s = (int32_t)a + b;
+    return (int16_t)(s < -32768 ? -32768 : (s > 32767 ? 32767 : s));
+}
+
+// one thread = one ring sample of one group; all `n_src` sources are accumulated in order
+__global__ __launch_bounds__(256) void load_kernel(int16_t *__restrict__ rings, uint32_t ring_samples, const int16_t *__restrict__ src,
+                                                   const LoadEntry *__restrict__ sch, uint32_t n_out, uint32_t head_sample, int n_src,
+                                                   long group_stride, long source_stride, int rdce, int n_groups) {
+    const size_t total = (size_t)n_out * n_groups;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t i = (uint32_t)(t % n_out);
+        const size_t g = t / n_out;
+        const LoadEntry e = sch[i];
+        uint32_t pos = head_sample + i;
+        pos -= (pos >= ring_samples) ? ring_samples * (pos / ring_samples) : 0;
+        int16_t *dst = rings + g * (size_t)ring_samples + pos;
+        int16_t acc = *dst;
+        const int16_t *sg = src + g * group_stride;
+        for (int s = 0; s < n_src; s++) {
+            const int16_t *p = sg + (size_t)s * source_stride;
+            int16_t v;
+            if (e.k < 0) {
+                v = p[e.src];
+            } else {
+                // repairBuff[k] = prev + (k+1 times accumulated) step, float adds in the reference's order
+                const int16_t prev = p[e.src - e.step];
+                const float st = (float)((int)p[e.src] - (int)prev) / (float)e.n2;
+                float sum = st;
+                for (int j = 0; j < e.k; j++) sum += st;
+                v = (int16_t)((float)prev + sum);
+            }
+            acc = volume_add(acc, (int16_t)(v / rdce));
+        }
+        *dst = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void drain_kernel(int16_t *__restrict__ rings, uint32_t ring_samples, int16_t *__restrict__ out,
+                                                    uint32_t n, uint32_t head_sample, long out_stride, int n_groups) {
+    const size_t total = (size_t)n * n_groups;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t i = (uint32_t)(t % n);
+        const size_t g = t / n;
+        uint32_t pos = head_sample + i;
+        pos -= (pos >= ring_samples) ? ring_samples * (pos / ring_samples) : 0;
+        int16_t *src = rings + g * (size_t)ring_samples + pos;
+        out[g * out_stride + i] = *src;
+        *src = 0;  // the play thread zeroes what it has read (src/wmix.c:1351-1352)
+    }
+}
+
+struct DevVec {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        WMX_HIP(hipMalloc(&p, bytes));
+        cap = bytes;
+        return 0;
+    }
+    ~DevVec() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+}  // namespace
+}  // namespace wmx
+
+struct wmx_mix {
+    int n_groups, chn, freq;
+    uint32_t ring_bytes, head_off, tick, play_correct;
+    uint8_t reduce_mode;
+    int16_t *d_rings;
+    wmx::DevVec d_sch;
+    std::vector<wmx::LoadEntry> sch;
+};
+
+extern "C" {
+
+// ---- src/wmix.h:113-121: pure index arithmetic, identical loops to the reference
+uint32_t wmix_len_of_out(uint8_t inChn, uint16_t inFreq, uint32_t inLen, uint8_t outChn, uint16_t outFreq) {
+    if (inFreq == outFreq && inChn == outChn) return inLen;
+    return wmx::len_walk(inChn, inFreq, outChn, outFreq, inLen, true, false);
+}
+uint32_t wmix_len_of_in(uint8_t inChn, uint16_t inFreq, uint8_t outChn, uint16_t outFreq, uint32_t outLen) {
+    if (inFreq == outFreq && inChn == outChn) return outLen;
+    return wmx::len_walk(inChn, inFreq, outChn, outFreq, outLen, false, true);
+}
+
+// batched wmix_pcm_zoom: n_streams buffers of the same format and length.  Strides in int16 elements.
+int wmx_pcm_zoom(int inChn, int inFreq, const int16_t *d_in, uint32_t inLen, int outChn, int outFreq, int16_t *d_out, long in_stride,
+                 long out_stride, int n_streams, uint32_t *out_len, void *stream) {
+    using namespace wmx;
+    if (!d_in || !d_out || n_streams < 1 || inChn < 1 || outChn < 1 || inFreq < 1 || outFreq < 1) {
+        set_error("wmx_pcm_zoom: bad argument");
+        return WMX_EINVAL;
+    }
+    hipStream_t s = as_stream(stream);
+    if (inFreq == outFreq && inChn == outChn) {  // memcpy branch, src/wmix.c:154-158
+        if (out_len) *out_len = inLen;
+        if (inLen == 0) return 0;
+        WMX_HIP(hipMemcpy2DAsync(d_out, out_stride * 2, d_in, in_stride * 2, inLen, n_streams, hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
+    static thread_local std::vector<int32_t> idx;
+    static thread_local DevVec d_idx;
+    zoom_schedule((uint8_t)inChn, (uint16_t)inFreq, inLen, (uint8_t)outChn, (uint16_t)outFreq, idx);
+    if (out_len) *out_len = (uint32_t)(idx.size() * 2);
+    if (idx.empty()) return 0;
+    if (d_idx.ensure(idx.size() * sizeof(int32_t))) return WMX_ENODEV;
+    WMX_HIP(hipMemcpyAsync(d_idx.p, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    const unsigned grid = stream_grid(idx.size() * (size_t)n_streams, 256);
+    hipLaunchKernelGGL(zoom_kernel, dim3(grid), dim3(256), 0, s, d_in, d_out, (const int32_t *)d_idx.p, (uint32_t)idx.size(), in_stride,
+                       out_stride, n_streams);
+    WMX_LAUNCH_CHECK();
+    return 0;
+}
+
+// legacy host form, src/wmix.h:122-127
+uint32_t wmix_pcm_zoom(uint8_t inChn, uint16_t inFreq, uint8_t *in, uint32_t inLen, uint8_t outChn, uint16_t outFreq, uint8_t *out) {
+    using namespace wmx;
+    static thread_local DevVec a, b;
+    const uint32_t max_out = wmix_len_of_out(inChn, inFreq, inLen, outChn, outFreq) + 16;
+    uint32_t n = 0;
+    if (inLen == 0) return 0;
+    if (a.ensure(inLen + 16) || b.ensure(max_out)) return 0;
+    if (hipMemcpy(a.p, in, inLen, hipMemcpyHostToDevice) != hipSuccess) return 0;
+    if (wmx_pcm_zoom(inChn, inFreq, (const int16_t *)a.p, inLen, outChn, outFreq, (int16_t *)b.p, 0, 0, 1, &n, nullptr) != 0) return 0;
+    if (n && hipMemcpy(out, b.p, n, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
+}
+
+int wmx_mix_destroy(wmx_mix *m) {
+    if (!m) return 0;
+    if (m->d_rings) (void)hipFree(m->d_rings);
+    delete m;
+    return 0;
+}
+
+// n_groups rings of 1 s each in the ring format (the reference's compile-time WMIX_CHN / WMIX_FREQ)
+int wmx_mix_create(wmx_mix **out, int n_groups, int ring_chn, int ring_freq) {
+    using namespace wmx;
+    if (!out) return WMX_EINVAL;
+    *out = nullptr;
+    if (n_groups < 1 || (ring_chn != 1 && ring_chn != 2) || ring_freq < 1000 || ring_freq > 96000) {
+        set_error("wmx_mix_create: unsupported n_groups=%d chn=%d freq=%d", n_groups, ring_chn, ring_freq);
+        return WMX_EINVAL;
+    }
+    wmx_mix *m = new wmx_mix();
+    m->n_groups = n_groups;
+    m->chn = ring_chn;
+    m->freq = ring_freq;
+    m->ring_bytes = (uint32_t)(ring_chn * 2) * (uint32_t)ring_freq;  // WMIX_BUFF_SIZE, src/wmixConf.h:124
+    m->head_off = 0;
+    m->tick = 0;
+    m->reduce_mode = 1;
+    m->play_correct = (uint32_t)(ring_chn * ring_freq * 16 / 8 / 5);  // PLAT_PLAY_CORRECT, platform/alsa/plat.h:54
+    m->d_rings = nullptr;
+    hipError_t e = hipMalloc(&m->d_rings, (size_t)m->ring_bytes * n_groups);
+    if (e == hipSuccess) e = hipMemset(m->d_rings, 0, (size_t)m->ring_bytes * n_groups);
+    if (e != hipSuccess) {
+        const int rc = hip_fail(e, "hipMalloc/hipMemset(rings)", __FILE__, __LINE__);
+        wmx_mix_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return 0;
+}
+
+int wmx_mix_set(wmx_mix *m, uint32_t head_off, uint32_t tick, int reduce_mode) {
+    if (!m || head_off >= m->ring_bytes || reduce_mode < 1 || reduce_mode > 255) return WMX_EINVAL;
+    m->head_off = head_off;
+    m->tick = tick;
+    m->reduce_mode = (uint8_t)reduce_mode;
+    return 0;
+}
+
+int wmx_mix_ring_bytes(const wmx_mix *m) { return m ? (int)m->ring_bytes : WMX_EINVAL; }
+
+// wmix_load_data for every group: n_src sources per group (source s of group g at d_src + g*group_stride +
+// s*source_stride, int16 elements), all in the same format, all starting from the cursor (*head, *tick) like
+// N task threads that begin together (head == UINT32_MAX is the reference's NULL head); they are added in
+// index order.  On return *head / *tick hold the cursor every one of those sources ends with.
+// NOTE: like the reference (src/wmix.c:1857,1914) the up-sampling fill reads one source frame past
+// srcU8Len; the caller's buffers must make that frame readable.
+int wmx_mix_load(wmx_mix *m, const int16_t *d_src, uint32_t srcU8Len, int freq, int channels, int sample, int n_src, long group_stride,
+                 long source_stride, int reduce, uint32_t *head, uint32_t *tick, void *stream) {
+    using namespace wmx;
+    if (!m || !head || !tick || n_src < 1) {
+        set_error("wmx_mix_load: bad argument");
+        return WMX_EINVAL;
+    }
+    if (!d_src || srcU8Len < 1) return 0;  // reference returns the head unchanged (src/wmix.c:1663-1664)
+    uint32_t head_off = *head, tk = *tick;
+    if (head_off == UINT32_MAX || tk < m->tick) {  // src/wmix.c:1666-1673
+        head_off = m->head_off + m->play_correct;
+        tk = m->tick + m->play_correct;
+        if (head_off >= m->ring_bytes) head_off = 0;
+    }
+    if (!load_schedule(m->chn, m->freq, srcU8Len, (uint16_t)freq, (uint8_t)channels, (uint8_t)sample, m->sch)) {
+        set_error("wmx_mix_load: rate ratio needs more than 64 fill samples (the reference overruns repairBuff here)");
+        return WMX_EINVAL;
+    }
+    const uint32_t n_out = (uint32_t)m->sch.size();
+    const int rdce = (reduce == m->reduce_mode) ? 1 : m->reduce_mode;  // src/wmix.c:1675-1676
+    hipStream_t s = as_stream(stream);
+    if (n_out) {
+        if (m->d_sch.ensure(n_out * sizeof(LoadEntry))) return WMX_ENODEV;
+        WMX_HIP(hipMemcpyAsync(m->d_sch.p, m->sch.data(), n_out * sizeof(LoadEntry), hipMemcpyHostToDevice, s));
+        const unsigned grid = stream_grid((size_t)n_out * m->n_groups, 256);
+        hipLaunchKernelGGL(load_kernel, dim3(grid), dim3(256), 0, s, m->d_rings, m->ring_bytes / 2, d_src, (const LoadEntry *)m->d_sch.p,
+                           n_out, head_off / 2, n_src, group_stride, source_stride, rdce, m->n_groups);
+        WMX_LAUNCH_CHECK();
+    }
+    // cursor bookkeeping, src/wmix.c:1942-1956
+    uint32_t tickAdd = n_out * 2, new_head = head_off + tickAdd;
+    new_head %= m->ring_bytes;
+    if (tk < m->tick) {
+        new_head = m->head_off + tickAdd;
+        tickAdd += m->tick;
+        if (new_head >= m->ring_bytes) new_head -= m->ring_bytes;
+    } else {
+        tickAdd += tk;
+    }
+    *tick = tickAdd;
+    *head = new_head;
+    return 0;
+}
+
+// the play thread's drain (src/wmix.c:1347-1366): read `bytes` at the ring head into d_out (per group), zero what
+// was read, advance head and tick.
+int wmx_mix_drain(wmx_mix *m, int16_t *d_out, uint32_t bytes, long out_stride, void *stream) {
+    using namespace wmx;
+    if (!m || !d_out || (bytes & 1) || bytes > m->ring_bytes) return WMX_EINVAL;
+    if (bytes == 0) return 0;
+    const uint32_t n = bytes / 2;
+    const unsigned grid = stream_grid((size_t)n * m->n_groups, 256);
+    hipLaunchKernelGGL(drain_kernel, dim3(grid), dim3(256), 0, as_stream(stream), m->d_rings, m->ring_bytes / 2, d_out, n, m->head_off / 2,
+                       out_stride, m->n_groups);
+    WMX_LAUNCH_CHECK();
+    m->head_off = (m->head_off + bytes) % m->ring_bytes;
+    m->tick += bytes;
+    return 0;
+}
+
+// legacy host form, src/wmix.h:40-49.  The ring format is the reference's compile-time WMIX_CHN x WMIX_FREQ; the
+// default platform is 1 x 8000 (platform/alsa/plat.h:48-50).  A differently configured daemon sets
+// WMIX_AMD_RING="chn,freq" in the environment.
+WMix_Point wmix_load_data(WMix_Struct_Head *wmix, WMix_Point src, uint32_t srcU8Len, uint16_t freq, uint8_t channels, uint8_t sample,
+                          WMix_Point head, uint8_t reduce, uint32_t *tick) {
+    using namespace wmx;
+    WMix_Point pHead = head;
+    if (!wmix || !wmix->run || !src.U8 || srcU8Len < 1) return pHead;  // src/wmix.c:1663-1664
+    static int ring_chn = 0, ring_freq = 0;
+    if (!ring_chn) {
+        ring_chn = 1;
+        ring_freq = 8000;
+        const char *env = getenv("WMIX_AMD_RING");
+        int c = 0, f = 0;
+        if (env && sscanf(env, "%d,%d", &c, &f) == 2 && (c == 1 || c == 2) && f >= 1000) {
+            ring_chn = c;
+            ring_freq = f;
+        }
+    }
+    const uint32_t size = (uint32_t)(wmix->end.U8 - wmix->start.U8);
+    static thread_local wmx_mix *m = nullptr;
+    static thread_local DevVec d_src;
+    if (!m || m->chn != ring_chn || m->freq != ring_freq) {
+        if (m) wmx_mix_destroy(m);
+        m = nullptr;
+        if (wmx_mix_create(&m, 1, ring_chn, ring_freq) != 0) return pHead;
+    }
+    if (size != m->ring_bytes) {
+        set_error("wmix_load_data: ring of %u bytes does not match WMIX_AMD_RING=%d,%d", size, ring_chn, ring_freq);
+        fprintf(stderr, "wmix_amd: %s\n", wmx_last_error());
+        return pHead;
+    }
+    m->head_off = (uint32_t)(wmix->head.U8 - wmix->start.U8);
+    m->tick = wmix->tick;
+    m->reduce_mode = wmix->reduceMode;
+    uint32_t h = head.U8 ? (uint32_t)(head.U8 - wmix->start.U8) : UINT32_MAX, t = *tick;
+    const size_t src_bytes = (size_t)srcU8Len + 2 * channels;  // + the frame the fill looks ahead to (see wmx_mix_load)
+    bool ok = d_src.ensure(src_bytes) == 0;
+    ok = ok && hipMemcpy(d_src.p, src.U8, src_bytes, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(m->d_rings, wmix->start.U8, size, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && wmx_mix_load(m, (const int16_t *)d_src.p, srcU8Len, freq, channels, sample, 1, 0, 0, reduce, &h, &t, nullptr) == 0;
+    ok = ok && hipMemcpy(wmix->start.U8, m->d_rings, size, hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        fprintf(stderr, "wmix_amd: wmix_load_data failed on the GPU: %s\n", wmx_last_error());
+        return pHead;
+    }
+    *tick = t;
+    pHead.U8 = wmix->start.U8 + h;
+    return pHead;
+}
+
+int wmx_mix_export(const wmx_mix *m, int group, int16_t *host_ring, uint32_t *head_off, uint32_t *tick) {
+    if (!m || group < 0 || group >= m->n_groups) return WMX_EINVAL;
+    if (host_ring) {
+        WMX_HIP(hipDeviceSynchronize());
+        WMX_HIP(hipMemcpy(host_ring, (const uint8_t *)m->d_rings + (size_t)group * m->ring_bytes, m->ring_bytes, hipMemcpyDeviceToHost));
+    }
+    if (head_off) *head_off = m->head_off;
+    if (tick) *tick = m->tick;
+    return 0;
+}
+
+}  // extern "C"
