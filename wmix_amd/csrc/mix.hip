@@ -273,7 +273,10 @@ int wmx_pcm_zoom(int inChn, int inFreq, const int16_t *d_in, uint32_t inLen, int
     if (inFreq == outFreq && inChn == outChn) {  // memcpy branch, src/wmix.c:154-158
         if (out_len) *out_len = inLen;
         if (inLen == 0) return 0;
-        WMX_HIP(hipMemcpy2DAsync(d_out, out_stride * 2, d_in, in_stride * 2, inLen, n_streams, hipMemcpyDeviceToDevice, s));
+        if (n_streams == 1)
+            WMX_HIP(hipMemcpyAsync(d_out, d_in, inLen, hipMemcpyDeviceToDevice, s));
+        else
+            WMX_HIP(hipMemcpy2DAsync(d_out, out_stride * 2, d_in, in_stride * 2, inLen, n_streams, hipMemcpyDeviceToDevice, s));
         return 0;
     }
     static thread_local std::vector<int32_t> idx;
@@ -294,7 +297,8 @@ int wmx_pcm_zoom(int inChn, int inFreq, const int16_t *d_in, uint32_t inLen, int
 uint32_t wmix_pcm_zoom(uint8_t inChn, uint16_t inFreq, uint8_t *in, uint32_t inLen, uint8_t outChn, uint16_t outFreq, uint8_t *out) {
     using namespace wmx;
     static thread_local DevVec a, b;
-    const uint32_t max_out = wmix_len_of_out(inChn, inFreq, inLen, outChn, outFreq) + 16;
+    // capacity bound: every input frame emits at most ceil(outFreq/inFreq)+1 output frames
+    const uint32_t max_out = (inLen / 2 / inChn + 2) * (outFreq / inFreq + 2) * outChn * 2 + 16;
     uint32_t n = 0;
     if (inLen == 0) return 0;
     if (a.ensure(inLen + 16) || b.ensure(max_out)) return 0;

@@ -22,10 +22,9 @@ def pcm_zoom(in_chn, in_freq, pcm, out_chn, out_freq):
     """pcm: int16 CUDA [n_streams, n_in] -> int16 CUDA [n_streams, n_out] (n_out from the reference's own walk)."""
     assert pcm.is_cuda and pcm.dtype == torch.int16 and pcm.dim() == 2 and pcm.stride(1) == 1
     in_len = pcm.shape[1] * 2
-    n_out = len_of_out(in_chn, in_freq, in_len, out_chn, out_freq) // 2
-    if (in_chn, out_chn) == (2, 2) and in_freq != out_freq:
-        n_out = 0  # SURVEY quirk 5: wmix_len_of_out counts samples that wmix_pcm_zoom never writes
-    out = torch.zeros(pcm.shape[0], max(n_out, 1), dtype=torch.int16, device=pcm.device)
+    # capacity: frames * rate ratio (+ slack); wmix_len_of_out is unit-agnostic and does not bound the byte count
+    n_out = (int(np.ceil(pcm.shape[1] / in_chn * max(out_freq / in_freq, 1.0))) + 4) * out_chn
+    out = torch.zeros(pcm.shape[0], n_out, dtype=torch.int16, device=pcm.device)
     got = C.c_uint32(0)
     check(lib().wmx_pcm_zoom(in_chn, in_freq, pcm.data_ptr(), in_len, out_chn, out_freq, out.data_ptr(), pcm.stride(0), out.stride(0),
                              pcm.shape[0], C.byref(got), torch.cuda.current_stream().cuda_stream), "wmx_pcm_zoom")

@@ -1,0 +1,16 @@
+"""Multi-GPU plumbing of the hot path: streams shard by contiguous ranges, state never
+leaves its GPU, and the only exchange is the shared AEC far-end packet, broadcast from the ingest rank."""
+
+
+def stream_range(n_total, rank, world):
+    """Contiguous [lo, hi) of the global stream ids owned by `rank` (remainder spread over the first ranks)."""
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def broadcast_far(far, dist, src=0):
+    """far: the int16 far-end packet tensor (same shape on every rank); rank `src` holds the data."""
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(far, src=src)
+    return far
