@@ -180,6 +180,8 @@ class ChainWorkload:
         from wmix_amd.agc import AgcBatch
         from wmix_amd.ns import NsBatch
         from wmix_amd.vad import VadBatch
+        global broadcast_far
+        from wmix_amd.shard import broadcast_far
         self.n_frames = n_streams
         self.dist = dist
         self.K = 8
@@ -205,7 +207,7 @@ class ChainWorkload:
         if self.rank == 0:
             self.far.copy_(self.far_src[k:k + 1])
         if self.dist is not None:
-            self.t.run("far_broadcast", timed, lambda: self.dist.broadcast(self.far, src=0))
+            self.t.run("far_broadcast", timed, lambda: broadcast_far(self.far, self.dist, src=0))
         self.t.run("ns", timed, lambda: self.ns.process_packet_major(self.inp[k:k + 1], self.work))
         self.t.run("aec", timed, lambda: self.aec.process2_packet_major(self.far, self.work))
         self.t.run("agc", timed, lambda: self.agc.process_packet_major(self.work))

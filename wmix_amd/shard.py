@@ -12,5 +12,7 @@ def stream_range(n_total, rank, world):
 def broadcast_far(far, dist, src=0):
     """far: the int16 far-end packet tensor (same shape on every rank); rank `src` holds the data."""
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.broadcast(far, src=src)
+        # neither RCCL nor gloo has an int16 type: broadcast the same bytes as uint8 (a view, no copy)
+        import torch
+        dist.broadcast(far.view(torch.uint8), src=src)
     return far
