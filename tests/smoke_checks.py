@@ -18,3 +18,39 @@ def run(dev, np, torch):
         back = np.zeros(pcm.size, np.int16)
         getattr(port, "orc_G711%s2PCM" % law)(C.c_void_p(want.ctypes.data), C.c_void_p(back.ctypes.data), want.size, 0)
         assert np.array_equal(g711.decode(law, got).cpu().numpy(), back), "G.711 %s-law decode mismatch" % law
+
+
+def _chain(dev, np, torch):
+    """NS -> AEC -> AGC -> VAD on 4 streams x 40 packets of 16 kHz mono vs the oracle chain."""
+    from oracle import loader
+    from wmix_amd import synth
+    from wmix_amd.aec import AecBatch
+    from wmix_amd.agc import AgcBatch
+    from wmix_amd.ns import NsBatch
+    from wmix_amd.vad import VadBatch
+    port = loader.port()
+    S, n, pkt = 4, 40, 160
+    far = synth.far_end(11, n, pkt)
+    near = synth.near_end(12, S, n, pkt, far=far)
+    want = np.stack([loader.run_chain(port, 1, 16000, 5, 15, far, near[s], pkt, prefix="orc") for s in range(S)])
+    d = torch.from_numpy(near.reshape(S, n, pkt).copy()).to(dev)
+    dfar = torch.from_numpy(far.reshape(n, pkt).copy()).to(dev)
+    ns, aec, agc, vad = NsBatch(S, 1, 16000), AecBatch(S, 1, 16000), AgcBatch(S, 1, 16000, 5), VadBatch(S, 1, 16000)
+    for f in range(0, n, 10):
+        blk = d[:, f:f + 10]
+        ns.process(blk)
+        rc, _ = aec.process2(dfar[f:f + 10], blk)
+        assert rc == 0
+        agc.process(blk)
+        vad.process(blk)
+    got = d.cpu().numpy().reshape(S, -1)
+    diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert diff.max() <= 1, "chain differs from the oracle by %d LSB" % diff.max()
+
+
+_run_g711 = run
+
+
+def run(dev, np, torch):  # noqa: F811
+    _run_g711(dev, np, torch)
+    _chain(dev, np, torch)
