@@ -114,14 +114,14 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F, const float *
         float *dst = reinterpret_cast<float *>(&K);
         for (int i = lane; i < kAecConstWords; i += 64) dst[i] = consts_g[i];
     }
-    __syncthreads();
+    wave_sync();
     for (int p = 0; p < n_packets; p++) {
         const AecPlan &pl = plans[p];
         if (pl.has_far) {
             // WebRtc_WriteBuffer(far_pre_buf, farend): channel 0 of the far-end packet (src/webrtc.c:430)
             const int16_t *src = far_pcm + (size_t)p * far_packet_stride;
             for (int i = lane; i < pl.far_n; i += 64) F.pre[(pl.pre_wr + i) % kAecPreLen] = (float)src[i * chn];
-            __syncthreads();
+            wave_sync();
             for (int q = 0; q < pl.n_part; q++) {
                 // BufferFarendPartition (aec_core.c:1690-1707): plain and windowed transform of [prev64 | new64]
 #pragma unroll
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F, const float *
                     fa[0][i] = v;
                     fa[1][i] = v * (h == 0 ? K.hanning[lane] : K.hanning[kAecPart - lane]);
                 }
-                __syncthreads();
+                wave_sync();
                 rdft_forward<64>(fa[0], &K.tab, lane);
                 rdft_forward<64>(fa[1], &K.tab, lane);
                 float *dst = F.ring + (size_t)pl.part[q].far_slot * 130;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F, const float *
                     dstw[b] = re;
                     dstw[kAecPart1 + b] = im;
                 }
-                __syncthreads();
+                wave_sync();
             }
         }
         if (pl.has_near && !pl.passthrough) {
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F, const float *
                     F.xpow[b] = xp;
                     F.xpow_seq[hs * BP + b] = xp;
                 }
-                __syncthreads();
+                wave_sync();
             }
         }
     }
@@ -198,7 +198,7 @@ __device__ void aec_block(AecShared &sh, const AecFarBufs &F, const AecBlkPlan &
         sh.fa[0][lane] = S[AS_DPREV + lane];
         sh.fa[0][64 + lane] = c;
     }
-    __syncthreads();
+    wave_sync();
     rdft_forward<64>(sh.fa[0], &sh.K.tab, lane);
     // ---- near power, noise floor (aec_core.c:1197-1243)
     for (int b = lane; b < kAecPart1; b += 64) {
@@ -244,7 +244,7 @@ __device__ void aec_block(AecShared &sh, const AecFarBufs &F, const AecBlkPlan &
             sh.fa[1][2 * b + 1] = yi;
         }
     }
-    __syncthreads();
+    wave_sync();
     rdft_inverse<64>(sh.fa[1], &sh.K.tab, lane);
     // ---- error e = d - y, ef = rdft([0 | e])  (aec_core.c:1286-1309)
     {
@@ -254,7 +254,7 @@ __device__ void aec_block(AecShared &sh, const AecFarBufs &F, const AecBlkPlan &
         sh.fa[2][lane] = 0.f;
         sh.fa[2][64 + lane] = e;
     }
-    __syncthreads();
+    wave_sync();
     rdft_forward<64>(sh.fa[2], &sh.K.tab, lane);
     // ---- ScaleErrorSignal (aec_core.c:172-194)
     for (int b = lane; b < kAecPart1; b += 64) {
@@ -274,7 +274,7 @@ __device__ void aec_block(AecShared &sh, const AecFarBufs &F, const AecBlkPlan &
         sh.ef_re[b] = er;
         sh.ef_im[b] = ei;
     }
-    __syncthreads();
+    wave_sync();
     // ---- FilterAdaptation (aec_core.c:222-270), four partitions per round
     for (int r = 0; r < 3; r++) {
 #pragma unroll
@@ -290,14 +290,14 @@ __device__ void aec_block(AecShared &sh, const AecFarBufs &F, const AecBlkPlan &
                 sh.fa[q][1] = nr * sh.ef_re[kAecPart] - ni * sh.ef_im[kAecPart];
             }
         }
-        __syncthreads();
+        wave_sync();
         rdft_inverse<64, 16>(sh.fa[g], &sh.K.tab, gl);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             sh.fa[q][64 + lane] = 0.f;
             sh.fa[q][lane] *= scale;
         }
-        __syncthreads();
+        wave_sync();
         rdft_forward<64, 16>(sh.fa[g], &sh.K.tab, gl);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -309,7 +309,7 @@ __device__ void aec_block(AecShared &sh, const AecFarBufs &F, const AecBlkPlan &
                 if (b != 0 && b != kAecPart) S[AS_W_IM + p * BP + b] += im;
             }
         }
-        __syncthreads();
+        wave_sync();
     }
 
     // ================================================= NonLinearProcessing (aec_core.c:911-1141)
@@ -326,7 +326,7 @@ __device__ void aec_block(AecShared &sh, const AecFarBufs &F, const AecBlkPlan &
             }
             sh.t0[lane] = en;
         }
-        __syncthreads();
+        wave_sync();
         float best = 0.f;
         delayIdx = 0;
         for (int p = 0; p < 12; p++)
@@ -334,7 +334,7 @@ __device__ void aec_block(AecShared &sh, const AecFarBufs &F, const AecBlkPlan &
                 best = sh.t0[p];
                 delayIdx = p;
             }
-        __syncthreads();
+        wave_sync();
         Si[AS_DELAYIDX] = delayIdx;
     }
     // xfw = windowed far spectrum consumed delayIdx blocks ago; windowed d and e transforms
@@ -350,7 +350,7 @@ __device__ void aec_block(AecShared &sh, const AecFarBufs &F, const AecBlkPlan &
         sh.fa[1][lane] = S[AS_EPREV + lane] * h0;
         sh.fa[1][64 + lane] = sh.enew[lane] * h1;
     }
-    __syncthreads();
+    wave_sync();
     rdft_forward<64, 16>(sh.fa[g], &sh.K.tab, gl);  // groups 0 and 1 carry d and e; 2 and 3 idle on scratch
     // SmoothedPSD (aec_core.c:333-386)
     for (int b = lane; b < kAecPart1; b += 64) {
@@ -373,7 +373,7 @@ __device__ void aec_block(AecShared &sh, const AecFarBufs &F, const AecBlkPlan &
         sh.ew_re[b] = er;
         sh.ew_im[b] = ei;
     }
-    __syncthreads();
+    wave_sync();
     float sdSum = 0.f, seSum = 0.f;
     for (int i = 0; i < kAecPart1; i++) {
         sdSum += S[AS_SD + i];
@@ -381,7 +381,7 @@ __device__ void aec_block(AecShared &sh, const AecFarBufs &F, const AecBlkPlan &
     }
     const int diverge = ((Si[AS_DIVERGE] ? 1.05f : 1.0f) * seSum > sdSum) ? 1 : 0;
     const bool reset_filter = seSum > (19.95f * sdSum);
-    __syncthreads();
+    wave_sync();
     Si[AS_DIVERGE] = diverge;
     if (reset_filter)
         for (int i = lane; i < 24 * BP; i += 64) S[AS_W_RE + i] = 0.f;  // memset(wfBuf): both planes are contiguous
@@ -395,7 +395,7 @@ __device__ void aec_block(AecShared &sh, const AecFarBufs &F, const AecBlkPlan &
         sh.t0[b] = (sde_r * sde_r + sde_i * sde_i) / (S[AS_SD + b] * S[AS_SE + b] + 1e-10f);  // cohde
         sh.t1[b] = (sxd_r * sxd_r + sxd_i * sxd_i) / (S[AS_SX + b] * S[AS_SD + b] + 1e-10f);  // cohxd
     }
-    __syncthreads();
+    wave_sync();
     float hNlXdAvg = 0.f, hNlDeAvg = 0.f;
     for (int i = minPref; i < prefSize + minPref; i++) hNlXdAvg += sh.t1[i];
     hNlXdAvg /= prefSize;
@@ -442,7 +442,7 @@ __device__ void aec_block(AecShared &sh, const AecFarBufs &F, const AecBlkPlan &
         const float cde = sh.t0[b], cxd = 1 - sh.t1[b];
         sh.t2[b] = mode == 0 ? cde : (mode == 1 ? cxd : (cde < cxd ? cde : cxd));  // hNl
     }
-    __syncthreads();
+    wave_sync();
     if (mode == 2) {
         // qsort(hNlPref) + the two order statistics (aec_core.c:1017-1022): rank by counting
         constexpr int i75 = (int)(0.75f * (prefSize - 1)), i50 = (int)(0.5f * (prefSize - 1));
@@ -456,10 +456,10 @@ __device__ void aec_block(AecShared &sh, const AecFarBufs &F, const AecBlkPlan &
             if (rank == i75) sh.t3[0] = v;
             if (rank == i50) sh.t3[1] = v;
         }
-        __syncthreads();
+        wave_sync();
         hNlFb = sh.t3[0];
         hNlFbLow = sh.t3[1];
-        __syncthreads();
+        wave_sync();
     }
     if (hNlFbLow < 0.6f && hNlFbLow < hNlFbLocalMin) {
         hNlFbLocalMin = hNlFbLow;
@@ -525,7 +525,7 @@ __device__ void aec_block(AecShared &sh, const AecFarBufs &F, const AecBlkPlan &
             sh.fa[3][2 * b + 1] = -ei;
         }
     }
-    __syncthreads();
+    wave_sync();
     rdft_inverse<64>(sh.fa[3], &sh.K.tab, lane);
     // overlap-add with the sqrt-Hanning window, saturate, queue 64 output samples (aec_core.c:1089-1101, 1341)
     {
@@ -537,7 +537,7 @@ __device__ void aec_block(AecShared &sh, const AecFarBufs &F, const AecBlkPlan &
         S[AS_DPREV + lane] = sh.cur[lane];
         S[AS_EPREV + lane] = sh.enew[lane];
     }
-    __syncthreads();
+    wave_sync();
 }
 
 template <int MULT>
@@ -554,9 +554,9 @@ __global__ __launch_bounds__(64) void aec_near_kernel(float *__restrict__ state,
     for (int sidx = blockIdx.x; sidx < n_streams; sidx += gridDim.x) {
         float4 *g4 = reinterpret_cast<float4 *>(state + (size_t)sidx * AS_WORDS);
         float4 *s4 = reinterpret_cast<float4 *>(sh.st);
-        __syncthreads();
+        wave_sync();
         for (int i = lane; i < AS_WORDS / 4; i += 64) s4[i] = g4[i];  // one contiguous 11 KB read
-        __syncthreads();
+        wave_sync();
         for (int p = 0; p < n_packets; p++) {
             const AecPlan &pl = plans[p];
             if (!pl.has_near) continue;
@@ -575,16 +575,16 @@ __global__ __launch_bounds__(64) void aec_near_kernel(float *__restrict__ state,
                 const AecSubPlan &sp = pl.sub[s];
                 for (int i = lane; i < kAecFrame; i += 64)
                     sh.st[AS_NEAR_RING + (sp.near_wr + i) % kAecRing] = (float)in[(s * kAecFrame + i) * chn];
-                __syncthreads();
+                wave_sync();
                 for (int k = 0; k < sp.n_blocks; k++) aec_block<MULT>(sh, F, pl.blk[sp.first_blk + k], lane);
                 for (int i = lane; i < kAecFrame; i += 64) {
                     const int16_t v = (int16_t)sh.st[AS_OUT_RING + (sp.out_rd + i) % kAecRing];
                     for (int c = 0; c < chn; c++) out[(s * kAecFrame + i) * chn + c] = v;
                 }
-                __syncthreads();
+                wave_sync();
             }
         }
-        __syncthreads();
+        wave_sync();
         for (int i = lane; i < AS_WORDS / 4; i += 64) g4[i] = s4[i];
     }
 }

@@ -139,8 +139,18 @@ inline void fft_tables_aec128(FftTables *t) {
 // ---------------------------------------------------------------- device: one wave, data in LDS
 // `a` points to n floats in LDS owned by this wave (packed complex, reference layout);
 // `T` points to the FftTables copy in LDS.  Every lane of the wave must call.  The callers
-// bracket these with __syncthreads() (one wave per workgroup: a cheap fence that stops the
-// compiler from moving LDS reads across other lanes' writes).
+// bracket these with wave_sync() (one wave per workgroup).
+
+// Hand-off of LDS data between lanes of ONE wavefront.  The kernels that use this header run one wave per
+// workgroup; a wave's LDS instructions are executed in issue order by the hardware, so a ds_read issued after
+// a ds_write of another lane of the same wave already sees the data.  What is needed is only that the COMPILER
+// keeps the order: a wavefront-scope fence (no s_waitcnt vmcnt(0), no s_barrier -- unlike __syncthreads(),
+// which would also drain every outstanding global load/store at each of the ~40 LDS phases of a block).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
 
 __device__ __forceinline__ int dev_bitrev(int q, int bits) { return (int)(__brev((unsigned)q) >> (32 - bits)); }
 
@@ -220,9 +230,9 @@ __device__ __forceinline__ void fft_complex_passes(float *a, const FftTables *T,
             C = ld_cx(a, r0 + NC / 4);
             D = ld_cx(a, r0 + 3 * NC / 4);
         }
-        __syncthreads();
+        wave_sync();
         if (act) bfly4_store(a, 4 * lane, 1, lane, T, A, B, C, D);
-        __syncthreads();
+        wave_sync();
     }
     // twiddled passes with stride 4, 16 while 4*hc < NC
 #pragma unroll
@@ -231,7 +241,7 @@ __device__ __forceinline__ void fft_complex_passes(float *a, const FftTables *T,
             const int b = lane / hc, j = lane % hc, p0 = b * 4 * hc + j;
             bfly4_store(a, p0, hc, b, T, ld_cx(a, p0), ld_cx(a, p0 + hc), ld_cx(a, p0 + 2 * hc), ld_cx(a, p0 + 3 * hc));
         }
-        __syncthreads();
+        wave_sync();
     }
     constexpr int HC = (NC == 128) ? 64 : 16;  // stride of the closing pass
     if constexpr (HC * 4 == NC) {
@@ -277,7 +287,7 @@ __device__ __forceinline__ void fft_complex_passes(float *a, const FftTables *T,
             *reinterpret_cast<float2 *>(a + 2 * p1) = o1;
         }
     }
-    __syncthreads();
+    wave_sync();
 }
 
 // fft4g.c:1234-1284 rftfsub / rftbsub: conjugate pairs (q, NC - q), q = 1 .. NC/2 - 1.
@@ -310,7 +320,7 @@ __device__ __forceinline__ void fft_real_split(float *a, const FftTables *T, int
             a[NC + 1] = -a[NC + 1];
         }
     }
-    __syncthreads();
+    wave_sync();
 }
 
 // WebRtc_rdft(n, +1, a) / aec_rdft_forward_128(a).  n = 2*NC.
@@ -323,7 +333,7 @@ __device__ __forceinline__ void rdft_forward(float *a, const FftTables *T, int l
         a[0] = a0 + a1;
         a[1] = a0 - a1;
     }
-    __syncthreads();
+    wave_sync();
 }
 
 // WebRtc_rdft(n, -1, a) / aec_rdft_inverse_128(a); unnormalised like the reference.
@@ -335,7 +345,7 @@ __device__ __forceinline__ void rdft_inverse(float *a, const FftTables *T, int l
         a[1] = h;
         a[0] = a0 - h;
     }
-    __syncthreads();
+    wave_sync();
     fft_real_split<NC, true, GL>(a, T, lane);
     fft_complex_passes<NC, true, GL>(a, T, lane);
 }

@@ -106,9 +106,9 @@ __device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short
         sh.fa[i] = w;
         sh.r0[i] = w * w;
     }
-    __syncthreads();
+    wave_sync();
     const float energy1 = sum_range<ORDERED>(sh.r0, 0, L, lane);
-    __syncthreads();
+    wave_sync();
 
     float outv[NT];  // low-band output samples for i < B
     float hb_gain = 1.f;
@@ -151,7 +151,7 @@ __device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short
                 sh.r4[b] = pause[s];
             }
         }
-        __syncthreads();
+        wave_sync();
         // ordered reductions over the bins (ns_core.c:1089-1101, :540, :608)
         float signal_energy, sum_magn, sum_log_magn = 0.f, sum_log_i_log_magn = 0.f, flat_num, avg_pause;
         if constexpr (ORDERED) {
@@ -183,7 +183,7 @@ __device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short
             }
         }
         const float magn0 = sh.r1[0];
-        __syncthreads();
+        wave_sync();
         signal_energy = signal_energy / ((float)M);
 
         // ---- NoiseEstimation (ns_core.c:217-285)
@@ -325,7 +325,7 @@ __device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short
                 sh.r2[b] = dm * dm;
             }
         }
-        __syncthreads();
+        wave_sync();
         float cov, var_pause, var_magn;
         if constexpr (ORDERED) {
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
@@ -342,7 +342,7 @@ __device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short
             var_pause = sum_range<false>(sh.r1, 0, M, lane);
             var_magn = sum_range<false>(sh.r2, 0, M, lane);
         }
-        __syncthreads();
+        wave_sync();
         cov = cov / ((float)M);
         var_pause = var_pause / ((float)M);
         var_magn = var_magn / ((float)M);
@@ -441,7 +441,7 @@ __device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short
                 w_lrt = 1.f / fsum;
                 w_flat = ((float)use_flat) / fsum;
                 w_diff = ((float)use_diff) / fsum;
-                __syncthreads();
+                wave_sync();
                 for (int i = lane; i < 3 * kHistBins; i += 64) hist[i] = 0;
                 sti[Y::S_COUNTDOWN] = kUpdateWindow;
                 if (update_flag == 1) {
@@ -480,9 +480,9 @@ __device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short
                 sh.r0[b] = v;
             }
         }
-        __syncthreads();
+        wave_sync();
         float ksum = sum_range<ORDERED>(sh.r0, 0, M, lane);
-        __syncthreads();
+        wave_sync();
         ksum = ksum / (float)(M);
         feat_lrt = ksum;
         st[Y::S_FEAT_LRT] = feat_lrt;
@@ -515,7 +515,7 @@ __device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short
                 sh.r1[b] = sprob[s];
             }
         }
-        __syncthreads();
+        wave_sync();
         // ---- UpdateNoiseEstimate (ns_core.c:800-846): bin i starts from the gamma chosen at bin i-1
 #pragma unroll
         for (int s = 0; s < SLOTS; s++) {
@@ -541,7 +541,7 @@ __device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short
                 noise[s] = nz;
             }
         }
-        __syncthreads();
+        wave_sync();
 
         // ===================================================== Process (ns_core.c:1275-1359)
 #pragma unroll
@@ -588,7 +588,7 @@ __device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
         rdft_inverse<NC>(sh.fa, &sh.tab, lane);
         float td[NT];
 #pragma unroll
@@ -597,7 +597,7 @@ __device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short
             td[k] = sh.fa[i] * (2.f / L);
             sh.r0[i] = td[k] * td[k];
         }
-        __syncthreads();
+        wave_sync();
         float factor = 1.f;
         if (block_ind > kStartupLong) {  // gainmap == 1 for policy 2
             const float energy2 = sum_range<ORDERED>(sh.r0, 0, L, lane);
@@ -638,7 +638,7 @@ __device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short
             if (g > 1.f) g = 1.f;
             hb_gain = g;
         }
-        __syncthreads();
+        wave_sync();
     }
 
     // ---- read out the finished segment, slide the synthesis buffer (ns_core.c:1245-1251 / 1347-1359)
@@ -662,7 +662,7 @@ __device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short
         sh.r0[i] = outv[k];
         if (chn == 2) sh.fa[i] = zero_frame ? sat16f(hb[k]) : sat16f(hb_gain * hb[k]);
     }
-    __syncthreads();
+    wave_sync();
     // interleave + (int16_t) cast (src/webrtc.c:640-642).  Samples beyond the core's block
     // length (32 kHz: 160..319) are the wrapper's calloc zeros.
     for (int i = lane; i < pkg; i += 64) {
@@ -670,11 +670,11 @@ __device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short
         out[i * chn] = (int16_t)lo;
         if (chn == 2) out[i * chn + 1] = (int16_t)((i < B) ? sh.fa[i] : 0.f);
     }
-    __syncthreads();
+    wave_sync();
 }
 
 template <int L, bool ORDERED>
-__global__ __launch_bounds__(64) void ns_kernel(float *__restrict__ state, unsigned short *__restrict__ hists,
+__global__ __launch_bounds__(64, 4) void ns_kernel(float *__restrict__ state, unsigned short *__restrict__ hists,
                                                 const float *__restrict__ consts, const int16_t *in, int16_t *out,
                                                 int n_streams, int n_packets, long stream_stride, long packet_stride,
                                                 int chn, int pkg) {
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(64) void ns_kernel(float *__restrict__ state, unsig
         constexpr int NCONST = kFftTableWords + L + Y::MP;
         for (int i = lane; i < NCONST; i += 64) dst[i] = consts[i];
     }
-    __syncthreads();
+    wave_sync();
     for (int sidx = blockIdx.x; sidx < n_streams; sidx += gridDim.x) {
         float *st = state + (size_t)sidx * Y::WORDS;
         unsigned short *hist = hists + (size_t)sidx * 3 * kHistBins;
