@@ -8,8 +8,10 @@
 //
 // Mapping.  A stream's spectrum has 65 (8 kHz) or 129 (16/32 kHz) bins; lane k of the
 // wave owns bins k, k+64 (and lane 0 bin 128).  Per-bin state is read from / written to
-// HBM exactly once per frame with 256-byte coalesced accesses; the three Ooura FFT
-// work arrays, the reduction staging and the FFT tables live in LDS (about 5 KB per wave).
+// HBM exactly once per frame with 256-byte coalesced accesses; the FFT work array, the frame's
+// per-bin intermediates and the reduction staging live in LDS (8.4 KB per wave), the FFT tables and
+// window once per 4-wave workgroup.  Every phase is a short rolled loop over the lane's 2-3 bins, so
+// the kernel fits 128 VGPRs and runs 4 waves per SIMD (occupancy, not bandwidth, is what bounds it).
 // All per-stream scalars and control flow (start-up phases, zero-energy early-out,
 // histogram windows) are wave-uniform, so streams in different states never diverge
 // inside a wave.
@@ -43,14 +45,23 @@ constexpr int kHistBins = 1000;     // defines.h:45
 constexpr int kUpdateWindow = 500;  // ns_core.c:188
 constexpr int kStartBand = 5;       // ns_core.c:1045
 
+// Block-shared constants (one copy per 4-wave workgroup) and one working set per wave / stream.
 template <int L>
-struct NsShared {
-    FftTables tab;                 // Ooura tables for n = L
-    float window[L];               // hybrid Hanning window (windows_private.h:64,94)
-    float logi[NsLayout<L>::MP];   // (float)log((float)i)
-    float fa[L];                   // FFT work array
-    float r0[L], r1[NsLayout<L>::MP], r2[NsLayout<L>::MP], r3[NsLayout<L>::MP], r4[NsLayout<L>::MP];
+struct NsConstLds {
+    FftTables tab;                // Ooura tables for n = L
+    float window[L];              // hybrid Hanning window (windows_private.h:64,94)
+    float logi[NsLayout<L>::MP];  // (float)log((float)i); [MP-2], [MP-1] hold the two data-independent start-up sums
 };
+template <int L>
+struct alignas(16) NsWaveLds {
+    static constexpr int MP = NsLayout<L>::MP;
+    float fa[L];  // FFT work array / packed spectrum / time-domain output staging
+    // per-bin intermediates of the frame (kept in LDS, not registers: every phase below is a short rolled loop
+    // over the wave's 2-3 bins per lane, which keeps the kernel at <= 128 VGPRs = 4 waves per SIMD)
+    float re[MP], im[MP], magn[MP], lmagn[MP], noise[MP], prev[MP], snrp[MP], snrq[MP], sprob[MP], nprev[MP], pause[MP];
+    float r0[MP], r1[MP], r2[MP];  // staging of terms for the ordered sums; r0..r1 double as a L-float time-domain stage
+};
+static_assert(2 * NsLayout<256>::MP >= 256 && 2 * NsLayout<128>::MP >= 128, "r0..r1 must hold L floats");
 
 __device__ __forceinline__ float sat16f(float v) { return v > 32767.f ? 32767.f : (v < -32768.f ? -32768.f : v); }
 
@@ -60,12 +71,29 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// sum of x[lo..hi) ; all lanes get the result.
+// sum of x[lo..hi); every lane gets the result.  ORDERED: the reference's index order, every lane adds the same
+// LDS-broadcast values (16-byte reads, eight terms in flight); else lane partials + butterfly.
 template <bool ORDERED>
 __device__ __forceinline__ float sum_range(const float *x, int lo, int hi, int lane) {
     if constexpr (ORDERED) {
         float acc = 0.f;
-        for (int i = lo; i < hi; i++) acc += x[i];
+        int i = lo;
+#pragma unroll 1
+        for (; i < hi && (i & 3); i++) acc += x[i];
+#pragma unroll 1
+        for (; i + 8 <= hi; i += 8) {
+            const float4 a = *reinterpret_cast<const float4 *>(x + i), b = *reinterpret_cast<const float4 *>(x + i + 4);
+            acc += a.x;
+            acc += a.y;
+            acc += a.z;
+            acc += a.w;
+            acc += b.x;
+            acc += b.y;
+            acc += b.z;
+            acc += b.w;
+        }
+#pragma unroll 1
+        for (; i < hi; i++) acc += x[i];
         return acc;
     } else {
         float acc = 0.f;
@@ -75,14 +103,15 @@ __device__ __forceinline__ float sum_range(const float *x, int lo, int hi, int l
 }
 
 template <int L, bool ORDERED>
-__device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short *__restrict__ hist,
+__device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restrict__ st, unsigned short *__restrict__ hist,
                          const int16_t *in, int16_t *out, const int chn, const int pkg, const int lane) {
     using Y = NsLayout<L>;
-    constexpr int M = Y::M, B = Y::B, SLOTS = Y::SLOTS, NT = L / 64, NC = L / 2;
+    constexpr int M = Y::M, B = Y::B, NT = L / 64, NC = L / 2;
     int *sti = reinterpret_cast<int *>(st);
+    float *tdst = W.r0;  // L floats spanning r0..r1
 
-    // ---- load the packet (channel 0 = low band, channel 1 = "high band") and
-    //      slide the analysis buffer (UpdateBuffer, ns_core.c:855-873).  All loads before stores.
+    // ---- load the packet (channel 0 = low band, channel 1 = "high band") and slide the analysis
+    //      buffer (UpdateBuffer, ns_core.c:855-873).  All loads before the stores.
     float buf[NT], hb[NT], synt[NT];
 #pragma unroll
     for (int k = 0; k < NT; k++) {
@@ -92,6 +121,7 @@ __device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short
         hb[k] = 0.f;
         if (chn == 2) hb[k] = (i < L - B) ? st[Y::HB_BUF + i + B] : (float)in[(i - (L - B)) * chn + 1];
     }
+    wave_sync();  // other lanes' stores below overwrite what this lane just loaded: keep the compiler from interleaving them
 #pragma unroll
     for (int k = 0; k < NT; k++) {
         const int i = lane + 64 * k;
@@ -102,15 +132,14 @@ __device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short
 #pragma unroll
     for (int k = 0; k < NT; k++) {
         const int i = lane + 64 * k;
-        const float w = sh.window[i] * buf[k];
-        sh.fa[i] = w;
-        sh.r0[i] = w * w;
+        const float w = K.window[i] * buf[k];
+        W.fa[i] = w;
+        tdst[i] = w * w;
     }
     wave_sync();
-    const float energy1 = sum_range<ORDERED>(sh.r0, 0, L, lane);
+    const float energy1 = sum_range<ORDERED>(tdst, 0, L, lane);
     wave_sync();
 
-    float outv[NT];  // low-band output samples for i < B
     float hb_gain = 1.f;
     const bool zero_frame = (energy1 == 0.0f);
 
@@ -120,69 +149,47 @@ __device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short
         sti[Y::S_BLOCK_IND] = block_ind;
         const int update_flag = sti[Y::S_UPDATE_FLAG];
         const bool startup = block_ind < kStartupShort;
+        const float overdrive = 1.1f, denoise_bound = 0.125f;  // policy 2, ns_core.c:1030-1033
 
-        rdft_forward<NC>(sh.fa, &sh.tab, lane);
+        rdft_forward<NC>(W.fa, &K.tab, lane);
 
-        float re[SLOTS], im[SLOTS], magn[SLOTS], lmagn[SLOTS], noise[SLOTS], prev_est[SLOTS];
-        float snr_prior[SLOTS], snr_post[SLOTS], sprob[SLOTS], noise_prev[SLOTS], pause[SLOTS], par_noise[SLOTS];
-#pragma unroll
-        for (int s = 0; s < SLOTS; s++) {
-            const int b = lane + 64 * s;
-            re[s] = im[s] = magn[s] = lmagn[s] = 0.f;
-            if (b < M) {
-                // FFT() ns_core.c:886-911
-                if (b == 0) {
-                    re[s] = sh.fa[0];
-                    magn[s] = fabsf(re[s]) + 1.f;
-                } else if (b == M - 1) {
-                    re[s] = sh.fa[1];
-                    magn[s] = fabsf(re[s]) + 1.f;
-                } else {
-                    re[s] = sh.fa[2 * b];
-                    im[s] = sh.fa[2 * b + 1];
-                    magn[s] = sqrtf(re[s] * re[s] + im[s] * im[s]) + 1.f;
-                }
-                lmagn[s] = (float)log((double)magn[s]);
-                pause[s] = st[Y::MAGN_AVG_PAUSE + b];
-                sh.r0[b] = re[s] * re[s] + im[s] * im[s];
-                sh.r1[b] = magn[s];
-                sh.r2[b] = lmagn[s];
-                sh.r3[b] = sh.logi[b] * lmagn[s];
-                sh.r4[b] = pause[s];
+        // ---- spectrum, magnitude, log-magnitude (FFT() ns_core.c:886-911; :228, :1095)
+#pragma unroll 1
+        for (int b = lane; b < M; b += 64) {
+            float re, im = 0.f, mg;
+            if (b == 0) {
+                re = W.fa[0];
+                mg = fabsf(re) + 1.f;
+            } else if (b == M - 1) {
+                re = W.fa[1];
+                mg = fabsf(re) + 1.f;
+            } else {
+                re = W.fa[2 * b];
+                im = W.fa[2 * b + 1];
+                mg = sqrtf(re * re + im * im) + 1.f;
             }
+            const float lm = (float)log((double)mg);
+            const float pz = st[Y::MAGN_AVG_PAUSE + b];
+            W.re[b] = re;
+            W.im[b] = im;
+            W.magn[b] = mg;
+            W.lmagn[b] = lm;
+            W.pause[b] = pz;
+            W.r0[b] = re * re + im * im;
+            W.r1[b] = K.logi[b] * lm;
         }
         wave_sync();
         // ordered reductions over the bins (ns_core.c:1089-1101, :540, :608)
-        float signal_energy, sum_magn, sum_log_magn = 0.f, sum_log_i_log_magn = 0.f, flat_num, avg_pause;
-        if constexpr (ORDERED) {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f;
-            for (int i = 0; i < M; i++) {
-                a0 += sh.r0[i];
-                a1 += sh.r1[i];
-                a5 += sh.r4[i];
-                if (i >= 1) a4 += sh.r2[i];
-                if (startup && i >= kStartBand) {
-                    a2 += sh.r2[i];
-                    a3 += sh.r3[i];
-                }
-            }
-            signal_energy = a0;
-            sum_magn = a1;
-            sum_log_magn = a2;
-            sum_log_i_log_magn = a3;
-            flat_num = a4;
-            avg_pause = a5;
-        } else {
-            signal_energy = sum_range<false>(sh.r0, 0, M, lane);
-            sum_magn = sum_range<false>(sh.r1, 0, M, lane);
-            flat_num = sum_range<false>(sh.r2, 1, M, lane);
-            avg_pause = sum_range<false>(sh.r4, 0, M, lane);
-            if (startup) {
-                sum_log_magn = sum_range<false>(sh.r2, kStartBand, M, lane);
-                sum_log_i_log_magn = sum_range<false>(sh.r3, kStartBand, M, lane);
-            }
+        float signal_energy = sum_range<ORDERED>(W.r0, 0, M, lane);
+        const float sum_magn = sum_range<ORDERED>(W.magn, 0, M, lane);
+        const float flat_num = sum_range<ORDERED>(W.lmagn, 1, M, lane);
+        float avg_pause = sum_range<ORDERED>(W.pause, 0, M, lane);
+        float sum_log_magn = 0.f, sum_log_i_log_magn = 0.f;
+        if (startup) {
+            sum_log_magn = sum_range<ORDERED>(W.lmagn, kStartBand, M, lane);
+            sum_log_i_log_magn = sum_range<ORDERED>(W.r1, kStartBand, M, lane);
         }
-        const float magn0 = sh.r1[0];
+        const float magn0 = W.magn[0];
         wave_sync();
         signal_energy = signal_energy / ((float)M);
 
@@ -190,60 +197,46 @@ __device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short
         int updates = sti[Y::S_UPDATES];
         if (updates < kStartupLong) updates++;
         sti[Y::S_UPDATES] = updates;
-        float quant[SLOTS];
+        const int cnt0 = sti[Y::S_COUNTER + 0], cnt1 = sti[Y::S_COUNTER + 1], cnt2 = sti[Y::S_COUNTER + 2];
+#pragma unroll 1
+        for (int b = lane; b < M; b += 64) {
+            const float lm = W.lmagn[b];
+            float quant = st[Y::QUANTILE + b], lq = 0.f;
 #pragma unroll
-        for (int s = 0; s < SLOTS; s++) {
-            const int b = lane + 64 * s;
-            quant[s] = (b < M) ? st[Y::QUANTILE + b] : 0.f;
-        }
-        float last_lq[SLOTS];
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-            const int cnt = sti[Y::S_COUNTER + q];
-            const float cnt1 = (float)(cnt + 1), cntf = (float)cnt;
-            const bool wrap = cnt >= kStartupLong;
-#pragma unroll
-            for (int s = 0; s < SLOTS; s++) {
-                const int b = lane + 64 * s;
-                if (b < M) {
-                    float dens = st[Y::DENSITY + q * Y::MP + b];
-                    float lq = st[Y::LQUANTILE + q * Y::MP + b];
-                    float delta;
-                    if (dens > 1.0f)
-                        delta = 40.f * 1.f / dens;
-                    else
-                        delta = 40.f;
-                    if (lmagn[s] > lq)
-                        lq += 0.25f * delta / cnt1;
-                    else
-                        lq -= (1.f - 0.25f) * delta / cnt1;
-                    if (fabsf(lmagn[s] - lq) < 0.01f) {
-                        dens = (cntf * dens + 1.f / (2.f * 0.01f)) / cnt1;
-                        st[Y::DENSITY + q * Y::MP + b] = dens;
-                    }
-                    st[Y::LQUANTILE + q * Y::MP + b] = lq;
-                    last_lq[s] = lq;
-                    if (wrap && updates >= kStartupLong) quant[s] = (float)exp((double)lq);
+            for (int q = 0; q < 3; q++) {
+                const int cnt = q == 0 ? cnt0 : (q == 1 ? cnt1 : cnt2);
+                const float c1 = (float)(cnt + 1), cf = (float)cnt;
+                float dens = st[Y::DENSITY + q * Y::MP + b];
+                lq = st[Y::LQUANTILE + q * Y::MP + b];
+                float delta;
+                if (dens > 1.0f)
+                    delta = 40.f * 1.f / dens;
+                else
+                    delta = 40.f;
+                if (lm > lq)
+                    lq += 0.25f * delta / c1;
+                else
+                    lq -= (1.f - 0.25f) * delta / c1;
+                if (fabsf(lm - lq) < 0.01f) {
+                    dens = (cf * dens + 1.f / (2.f * 0.01f)) / c1;
+                    st[Y::DENSITY + q * Y::MP + b] = dens;
                 }
+                st[Y::LQUANTILE + q * Y::MP + b] = lq;
+                if (cnt >= kStartupLong && updates >= kStartupLong) quant = (float)exp((double)lq);
             }
-            sti[Y::S_COUNTER + q] = wrap ? 1 : cnt + 1;
+            if (updates < kStartupLong) quant = (float)exp((double)lq);  // lq of the last estimator
+            st[Y::QUANTILE + b] = quant;
+            W.noise[b] = quant;
         }
-#pragma unroll
-        for (int s = 0; s < SLOTS; s++) {
-            const int b = lane + 64 * s;
-            if (b < M) {
-                if (updates < kStartupLong) quant[s] = (float)exp((double)last_lq[s]);
-                st[Y::QUANTILE + b] = quant[s];
-                noise[s] = quant[s];
-            }
-        }
+        sti[Y::S_COUNTER + 0] = cnt0 >= kStartupLong ? 1 : cnt0 + 1;
+        sti[Y::S_COUNTER + 1] = cnt1 >= kStartupLong ? 1 : cnt1 + 1;
+        sti[Y::S_COUNTER + 2] = cnt2 >= kStartupLong ? 1 : cnt2 + 1;
 
-        // ---- start-up white/pink parametric noise model (ns_core.c:1108-1160)
-        const float overdrive = 1.1f, denoise_bound = 0.125f;  // policy 2, ns_core.c:1030-1033
+        // ---- start-up white/pink parametric noise model (ns_core.c:1108-1160); parametricNoise kept in r1
         if (startup) {
-            float white = st[Y::S_WHITE] + sum_magn / ((float)M) * overdrive;
+            const float white = st[Y::S_WHITE] + sum_magn / ((float)M) * overdrive;
             st[Y::S_WHITE] = white;
-            const float sum_log_i = sh.logi[Y::MP - 2], sum_log_i_sq = sh.logi[Y::MP - 1];
+            const float sum_log_i = K.logi[Y::MP - 2], sum_log_i_sq = K.logi[Y::MP - 1];
             float t1 = sum_log_i_sq * ((float)(M - kStartBand));
             t1 -= (sum_log_i * sum_log_i);
             float t2 = (sum_log_i_sq * sum_log_magn - sum_log_i * sum_log_i_log_magn);
@@ -264,22 +257,22 @@ __device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short
                 pnum *= (float)(block_ind + 1);
                 pexp = pink_exp / (float)(block_ind + 1);
             }
-#pragma unroll
-            for (int s = 0; s < SLOTS; s++) {
-                const int b = lane + 64 * s;
-                par_noise[s] = 0.f;
-                if (b < M) {
-                    if (pink_exp == 0.f) {
-                        par_noise[s] = white;
-                    } else {
-                        const float band = (float)(b < kStartBand ? kStartBand : b);
-                        par_noise[s] = (float)((double)pnum / pow((double)band, (double)pexp));
-                    }
-                    noise[s] *= (float)(block_ind);
-                    const float t = par_noise[s] * (float)(kStartupShort - block_ind);
-                    noise[s] += (t / (float)(block_ind + 1));
-                    noise[s] /= (float)kStartupShort;
+#pragma unroll 1
+            for (int b = lane; b < M; b += 64) {
+                float pn;
+                if (pink_exp == 0.f) {
+                    pn = white;
+                } else {
+                    const float band = (float)(b < kStartBand ? kStartBand : b);
+                    pn = (float)((double)pnum / pow((double)band, (double)pexp));
                 }
+                W.r1[b] = pn;
+                float nz = W.noise[b];
+                nz *= (float)(block_ind);
+                const float t = pn * (float)(kStartupShort - block_ind);
+                nz += (t / (float)(block_ind + 1));
+                nz /= (float)kStartupShort;
+                W.noise[b] = nz;
             }
         }
         // normalisation of the spectral-difference feature (ns_core.c:1163-1167)
@@ -290,19 +283,27 @@ __device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short
             feat_norm /= (float)(block_ind + 1);
         }
 
-        // ---- ComputeSnr (ns_core.c:566-588); prev_est is reused by the Wiener filter (:996)
-#pragma unroll
-        for (int s = 0; s < SLOTS; s++) {
-            const int b = lane + 64 * s;
-            if (b < M) {
-                noise_prev[s] = st[Y::NOISE_PREV + b];
-                prev_est[s] = st[Y::MAGN_PREV + b] / (noise_prev[s] + 0.0001f) * st[Y::SMOOTH + b];
-                snr_post[s] = 0.f;
-                if (magn[s] > noise[s]) snr_post[s] = magn[s] / (noise[s] + 0.0001f) - 1.f;
-                snr_prior[s] = 0.98f * prev_est[s] + (1.f - 0.98f) * snr_post[s];
-            }
+        // ---- ComputeSnr (ns_core.c:566-588); prev is reused by the Wiener filter (:996).  Same loop: the terms of
+        //      the spectral-difference sums (ns_core.c:612-620), which need avg_pause / avg_magn only.
+        avg_pause = avg_pause / ((float)M);
+        const float avg_magn = sum_magn / ((float)M);
+#pragma unroll 1
+        for (int b = lane; b < M; b += 64) {
+            const float mg = W.magn[b], nz = W.noise[b];
+            const float np = st[Y::NOISE_PREV + b];
+            const float pe = st[Y::MAGN_PREV + b] / (np + 0.0001f) * st[Y::SMOOTH + b];
+            float sq = 0.f;
+            if (mg > nz) sq = mg / (nz + 0.0001f) - 1.f;
+            W.nprev[b] = np;
+            W.prev[b] = pe;
+            W.snrq[b] = sq;
+            W.snrp[b] = 0.98f * pe + (1.f - 0.98f) * sq;
+            const float dm = mg - avg_magn, dp = W.pause[b] - avg_pause;
+            W.r0[b] = dm * dp;
+            W.r2[b] = dp * dp;
+            W.lmagn[b] = dm * dm;  // lmagn is dead from here on
         }
-
+        wave_sync();
         // ---- FeatureUpdate: spectral flatness (ns_core.c:523-556), difference (:595-634)
         float feat_flat = st[Y::S_FEAT_FLAT];
         {
@@ -313,35 +314,9 @@ __device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short
             const float tmp = (float)exp((double)num) / den;
             feat_flat += 0.3f * (tmp - feat_flat);
         }
-        avg_pause = avg_pause / ((float)M);
-        const float avg_magn = sum_magn / ((float)M);
-#pragma unroll
-        for (int s = 0; s < SLOTS; s++) {
-            const int b = lane + 64 * s;
-            if (b < M) {
-                const float dm = magn[s] - avg_magn, dp = pause[s] - avg_pause;
-                sh.r0[b] = dm * dp;
-                sh.r1[b] = dp * dp;
-                sh.r2[b] = dm * dm;
-            }
-        }
-        wave_sync();
-        float cov, var_pause, var_magn;
-        if constexpr (ORDERED) {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-            for (int i = 0; i < M; i++) {
-                a0 += sh.r0[i];
-                a1 += sh.r1[i];
-                a2 += sh.r2[i];
-            }
-            cov = a0;
-            var_pause = a1;
-            var_magn = a2;
-        } else {
-            cov = sum_range<false>(sh.r0, 0, M, lane);
-            var_pause = sum_range<false>(sh.r1, 0, M, lane);
-            var_magn = sum_range<false>(sh.r2, 0, M, lane);
-        }
+        float cov = sum_range<ORDERED>(W.r0, 0, M, lane);
+        float var_pause = sum_range<ORDERED>(W.r2, 0, M, lane);
+        float var_magn = sum_range<ORDERED>(W.lmagn, 0, M, lane);
         wave_sync();
         cov = cov / ((float)M);
         var_pause = var_pause / ((float)M);
@@ -465,24 +440,19 @@ __device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short
         st[Y::S_FEAT_ACC] = feat_acc;
 
         // ---- SpeechNoiseProb (ns_core.c:642-749)
-        float llrt[SLOTS];
-#pragma unroll
-        for (int s = 0; s < SLOTS; s++) {
-            const int b = lane + 64 * s;
-            if (b < M) {
-                const float t1 = 1.f + 2.f * snr_prior[s];
-                const float t2 = 2.f * snr_prior[s] / (t1 + 0.0001f);
-                const float bessel = (snr_post[s] + 1.f) * t2;
-                float v = st[Y::LOG_LRT + b];
-                v += 0.5f * (bessel - (float)log((double)t1) - v);
-                st[Y::LOG_LRT + b] = v;
-                llrt[s] = v;
-                sh.r0[b] = v;
-            }
+#pragma unroll 1
+        for (int b = lane; b < M; b += 64) {
+            const float sp = W.snrp[b];
+            const float t1 = 1.f + 2.f * sp;
+            const float t2 = 2.f * sp / (t1 + 0.0001f);
+            const float bessel = (W.snrq[b] + 1.f) * t2;
+            float v = st[Y::LOG_LRT + b];
+            v += 0.5f * (bessel - (float)log((double)t1) - v);
+            st[Y::LOG_LRT + b] = v;
+            W.r0[b] = v;
         }
         wave_sync();
-        float ksum = sum_range<ORDERED>(sh.r0, 0, M, lane);
-        wave_sync();
+        float ksum = sum_range<ORDERED>(W.r0, 0, M, lane);
         ksum = ksum / (float)(M);
         feat_lrt = ksum;
         st[Y::S_FEAT_LRT] = feat_lrt;
@@ -504,103 +474,84 @@ __device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short
             st[Y::S_PRIOR] = prior;
         }
         const float gain_prior = (1.f - prior) / (prior + 0.0001f);
-#pragma unroll
-        for (int s = 0; s < SLOTS; s++) {
-            const int b = lane + 64 * s;
-            sprob[s] = 0.f;
-            if (b < M) {
-                float inv = (float)exp((double)(-llrt[s]));
-                inv = gain_prior * inv;
-                sprob[s] = 1.f / (1.f + inv);
-                sh.r1[b] = sprob[s];
+#pragma unroll 1
+        for (int b = lane; b < M; b += 64) {
+            float inv = (float)exp((double)(-W.r0[b]));
+            inv = gain_prior * inv;
+            W.sprob[b] = 1.f / (1.f + inv);
+        }
+        wave_sync();
+        // ---- UpdateNoiseEstimate (ns_core.c:800-846): bin i starts from the gamma chosen at bin i-1.
+        //      Then Process: initMagnEst, DD Wiener filter + flooring / start-up blend (ns_core.c:1277-1315), IFFT packing.
+#pragma unroll 1
+        for (int b = lane; b < M; b += 64) {
+            const float ps = W.sprob[b], pn = 1.f - ps, mg = W.magn[b], np = W.nprev[b];
+            float gamma_old = 0.9f;
+            if (b > 0 && W.sprob[b - 1] > 0.2f) gamma_old = 0.99f;
+            const float tmp = gamma_old * np + (1.f - gamma_old) * (pn * mg + ps * np);
+            float gamma = 0.9f;
+            if (ps > 0.2f) gamma = 0.99f;
+            if (ps < 0.2f) {
+                float pz = W.pause[b];
+                pz += 0.05f * (mg - pz);
+                st[Y::MAGN_AVG_PAUSE + b] = pz;
+            }
+            float nz;
+            if (gamma == gamma_old) {
+                nz = tmp;
+            } else {
+                nz = gamma * np + (1.f - gamma) * (pn * mg + ps * np);
+                if (tmp < nz) nz = tmp;
+            }
+            // ---- Process
+            float init_est = 0.f;
+            if (startup) {
+                init_est = st[Y::INIT_MAGN + b] + mg;
+                st[Y::INIT_MAGN + b] = init_est;
+            }
+            float cur = 0.f;
+            if (mg > nz) cur = mg / (nz + 0.0001f) - 1.f;
+            const float snr = 0.98f * W.prev[b] + (1.f - 0.98f) * cur;
+            float f = snr / (overdrive + snr);
+            if (f < denoise_bound) f = denoise_bound;
+            if (f > 1.f) f = 1.f;
+            if (startup) {
+                float ft = (init_est - overdrive * W.r1[b]);
+                ft /= (init_est + 0.0001f);
+                if (ft < denoise_bound) ft = denoise_bound;
+                if (ft > 1.f) ft = 1.f;
+                f *= (float)(block_ind);
+                ft *= (float)(kStartupShort - block_ind);
+                f += ft;
+                f /= (float)(kStartupShort);
+            }
+            st[Y::SMOOTH + b] = f;
+            st[Y::MAGN_PREV + b] = mg;
+            st[Y::NOISE_PREV + b] = nz;
+            W.snrp[b] = f;  // the filter, for the high-band gain
+            const float re = W.re[b] * f, im = W.im[b] * f;
+            if (b == 0)
+                W.fa[0] = re;
+            else if (b == M - 1)
+                W.fa[1] = re;
+            else {
+                W.fa[2 * b] = re;
+                W.fa[2 * b + 1] = im;
             }
         }
         wave_sync();
-        // ---- UpdateNoiseEstimate (ns_core.c:800-846): bin i starts from the gamma chosen at bin i-1
-#pragma unroll
-        for (int s = 0; s < SLOTS; s++) {
-            const int b = lane + 64 * s;
-            if (b < M) {
-                const float ps = sprob[s], pn = 1.f - ps;
-                float gamma_old = 0.9f;
-                if (b > 0 && sh.r1[b - 1] > 0.2f) gamma_old = 0.99f;
-                const float tmp = gamma_old * noise_prev[s] + (1.f - gamma_old) * (pn * magn[s] + ps * noise_prev[s]);
-                float gamma = 0.9f;
-                if (ps > 0.2f) gamma = 0.99f;
-                if (ps < 0.2f) {
-                    pause[s] += 0.05f * (magn[s] - pause[s]);
-                    st[Y::MAGN_AVG_PAUSE + b] = pause[s];
-                }
-                float nz;
-                if (gamma == gamma_old) {
-                    nz = tmp;
-                } else {
-                    nz = gamma * noise_prev[s] + (1.f - gamma) * (pn * magn[s] + ps * noise_prev[s]);
-                    if (tmp < nz) nz = tmp;
-                }
-                noise[s] = nz;
-            }
-        }
-        wave_sync();
-
-        // ===================================================== Process (ns_core.c:1275-1359)
-#pragma unroll
-        for (int s = 0; s < SLOTS; s++) {
-            const int b = lane + 64 * s;
-            if (b < M) {
-                float init_est = 0.f;
-                if (startup) {
-                    init_est = st[Y::INIT_MAGN + b] + magn[s];
-                    st[Y::INIT_MAGN + b] = init_est;
-                }
-                // ComputeDdBasedWienerFilter (ns_core.c:985-1007) + flooring / start-up blend (:1285-1315)
-                float cur = 0.f;
-                if (magn[s] > noise[s]) cur = magn[s] / (noise[s] + 0.0001f) - 1.f;
-                const float snr = 0.98f * prev_est[s] + (1.f - 0.98f) * cur;
-                float f = snr / (overdrive + snr);
-                if (f < denoise_bound) f = denoise_bound;
-                if (f > 1.f) f = 1.f;
-                if (startup) {
-                    float ft = (init_est - overdrive * par_noise[s]);
-                    ft /= (init_est + 0.0001f);
-                    if (ft < denoise_bound) ft = denoise_bound;
-                    if (ft > 1.f) ft = 1.f;
-                    f *= (float)(block_ind);
-                    ft *= (float)(kStartupShort - block_ind);
-                    f += ft;
-                    f /= (float)(kStartupShort);
-                }
-                st[Y::SMOOTH + b] = f;
-                st[Y::MAGN_PREV + b] = magn[s];
-                st[Y::NOISE_PREV + b] = noise[s];
-                re[s] *= f;
-                im[s] *= f;
-                sh.r2[b] = f;      // for the high-band gain
-                sh.r3[b] = magn[s];
-                // IFFT packing (ns_core.c:934-939)
-                if (b == 0)
-                    sh.fa[0] = re[s];
-                else if (b == M - 1)
-                    sh.fa[1] = re[s];
-                else {
-                    sh.fa[2 * b] = re[s];
-                    sh.fa[2 * b + 1] = im[s];
-                }
-            }
-        }
-        wave_sync();
-        rdft_inverse<NC>(sh.fa, &sh.tab, lane);
+        rdft_inverse<NC>(W.fa, &K.tab, lane);
         float td[NT];
 #pragma unroll
         for (int k = 0; k < NT; k++) {
             const int i = lane + 64 * k;
-            td[k] = sh.fa[i] * (2.f / L);
-            sh.r0[i] = td[k] * td[k];
+            td[k] = W.fa[i] * (2.f / L);
+            tdst[i] = td[k] * td[k];
         }
         wave_sync();
         float factor = 1.f;
         if (block_ind > kStartupLong) {  // gainmap == 1 for policy 2
-            const float energy2 = sum_range<ORDERED>(sh.r0, 0, L, lane);
+            const float energy2 = sum_range<ORDERED>(tdst, 0, L, lane);
             float gain = sqrtf(energy2 / (energy1 + 1.f));
             float factor1 = 1.f, factor2 = 1.f;
             if (gain > 0.5f) {
@@ -616,18 +567,17 @@ __device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short
 #pragma unroll
         for (int k = 0; k < NT; k++) {
             const int i = lane + 64 * k;
-            const float w = sh.window[i] * td[k];
+            const float w = K.window[i] * td[k];
             synt[k] += factor * w;
         }
         // ---- high band: time-domain gain (ns_core.c:1362-1414), only when chn == 2
         if (chn == 2) {
             constexpr int D = M / 4;
-            float avg_prob = sum_range<ORDERED>(sh.r1, M - D - 1, M - 1, lane);
+            float avg_prob = sum_range<ORDERED>(W.sprob, M - D - 1, M - 1, lane);
             avg_prob = avg_prob / ((float)D);
             // magnPrevAnalyze == magnPrevProcess here, so sumMagnProcess / sumMagnAnalyze is x / x
-            const float sm = sum_range<ORDERED>(sh.r3, 0, M, lane);
-            avg_prob *= sm / sm;
-            float avg_gain = sum_range<ORDERED>(sh.r2, M - D - 1, M - 1, lane);
+            avg_prob *= sum_magn / sum_magn;
+            float avg_gain = sum_range<ORDERED>(W.snrp, M - D - 1, M - 1, lane);
             avg_gain = avg_gain / ((float)D);
             const float t = 2.f * avg_prob - 1.f;
             const float gain_mod = 0.5f * (1.f + (float)tanh((double)(1.0f * t)));
@@ -645,56 +595,53 @@ __device__ void ns_frame(NsShared<L> &sh, float *__restrict__ st, unsigned short
 #pragma unroll
     for (int k = 0; k < NT; k++) {
         const int i = lane + 64 * k;
-        outv[k] = sat16f(synt[k]);
         if (i >= B) st[Y::SYNT_BUF + i - B] = synt[k];
+        tdst[i] = sat16f(synt[k]);
+        // HB output: the OLDEST block of the (already slid) high-band buffer, times the gain (zero-energy frames pass
+        // it through unscaled, ns_core.c:1255-1265)
+        if (chn == 2) W.fa[i] = zero_frame ? sat16f(hb[k]) : sat16f(hb_gain * hb[k]);
     }
 #pragma unroll
     for (int k = 0; k < NT; k++) {
         const int i = lane + 64 * k;
         if (i >= L - B) st[Y::SYNT_BUF + i] = 0.f;
     }
-    // HB output: the OLDEST block of the (already slid) high-band buffer, times the gain
-    // (zero-energy frames pass it through unscaled, ns_core.c:1255-1265).  Stage through LDS
-    // because sample j of the output sits in buffer slot j.
-#pragma unroll
-    for (int k = 0; k < NT; k++) {
-        const int i = lane + 64 * k;
-        sh.r0[i] = outv[k];
-        if (chn == 2) sh.fa[i] = zero_frame ? sat16f(hb[k]) : sat16f(hb_gain * hb[k]);
-    }
     wave_sync();
-    // interleave + (int16_t) cast (src/webrtc.c:640-642).  Samples beyond the core's block
-    // length (32 kHz: 160..319) are the wrapper's calloc zeros.
+    // interleave + (int16_t) cast (src/webrtc.c:640-642).  Samples beyond the core's block length (32 kHz: 160..319)
+    // are the wrapper's calloc zeros.
     for (int i = lane; i < pkg; i += 64) {
-        const float lo = (i < B) ? sh.r0[i] : 0.f;
+        const float lo = (i < B) ? tdst[i] : 0.f;
         out[i * chn] = (int16_t)lo;
-        if (chn == 2) out[i * chn + 1] = (int16_t)((i < B) ? sh.fa[i] : 0.f);
+        if (chn == 2) out[i * chn + 1] = (int16_t)((i < B) ? W.fa[i] : 0.f);
     }
     wave_sync();
 }
 
+constexpr int kNsWavesPerBlock = 4;
+
 template <int L, bool ORDERED>
-__global__ __launch_bounds__(64, 4) void ns_kernel(float *__restrict__ state, unsigned short *__restrict__ hists,
-                                                const float *__restrict__ consts, const int16_t *in, int16_t *out,
-                                                int n_streams, int n_packets, long stream_stride, long packet_stride,
-                                                int chn, int pkg) {
+__global__ __launch_bounds__(64 * kNsWavesPerBlock, 2) void ns_kernel(float *__restrict__ state, unsigned short *__restrict__ hists,
+                                                                      const float *__restrict__ consts, const int16_t *in, int16_t *out,
+                                                                      int n_streams, int n_packets, long stream_stride,
+                                                                      long packet_stride, int chn, int pkg) {
     using Y = NsLayout<L>;
-    __shared__ NsShared<L> sh;
-    const int lane = threadIdx.x;
+    __shared__ NsConstLds<L> K;
+    __shared__ NsWaveLds<L> Wv[kNsWavesPerBlock];
     // constants: FftTables | window[L] | logi[MP]
     {
-        float *dst = reinterpret_cast<float *>(&sh);
+        float *dst = reinterpret_cast<float *>(&K);
         constexpr int NCONST = kFftTableWords + L + Y::MP;
-        for (int i = lane; i < NCONST; i += 64) dst[i] = consts[i];
+        for (int i = threadIdx.x; i < NCONST; i += blockDim.x) dst[i] = consts[i];
     }
-    wave_sync();
-    for (int sidx = blockIdx.x; sidx < n_streams; sidx += gridDim.x) {
-        float *st = state + (size_t)sidx * Y::WORDS;
-        unsigned short *hist = hists + (size_t)sidx * 3 * kHistBins;
-        for (int p = 0; p < n_packets; p++) {
-            const size_t off = (size_t)sidx * stream_stride + (size_t)p * packet_stride;
-            ns_frame<L, ORDERED>(sh, st, hist, in + off, out + off, chn, pkg, lane);
-        }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sidx = blockIdx.x * kNsWavesPerBlock + wave;  // one stream per wave; no block-level barrier below
+    if (sidx >= n_streams) return;
+    float *st = state + (size_t)sidx * Y::WORDS;
+    unsigned short *hist = hists + (size_t)sidx * 3 * kHistBins;
+    for (int p = 0; p < n_packets; p++) {
+        const size_t off = (size_t)sidx * stream_stride + (size_t)p * packet_stride;
+        ns_frame<L, ORDERED>(K, Wv[wave], st, hist, in + off, out + off, chn, pkg, lane);
     }
 }
 
@@ -866,11 +813,11 @@ int wmx_ns_process(wmx_ns *h, const int16_t *d_in, int16_t *d_out, int n_packets
         wmx::set_error("wmx_ns_process: strides (%ld, %ld) smaller than a packet (%d samples)", stream_stride, packet_stride, per_pkt);
         return WMX_EINVAL;
     }
-    const unsigned grid = (unsigned)h->n_streams;
+    const unsigned grid = (unsigned)((h->n_streams + wmx::kNsWavesPerBlock - 1) / wmx::kNsWavesPerBlock);
     hipStream_t s = wmx::as_stream(stream);
-#define NS_LAUNCH(LL, ORD)                                                                                          \
-    hipLaunchKernelGGL((wmx::ns_kernel<LL, ORD>), dim3(grid), dim3(64), 0, s, h->d_state, h->d_hist, h->d_consts, d_in, \
-                       d_out, h->n_streams, n_packets, stream_stride, packet_stride, h->chn, h->pkg)
+#define NS_LAUNCH(LL, ORD)                                                                                              \
+    hipLaunchKernelGGL((wmx::ns_kernel<LL, ORD>), dim3(grid), dim3(64 * wmx::kNsWavesPerBlock), 0, s, h->d_state, h->d_hist, \
+                       h->d_consts, d_in, d_out, h->n_streams, n_packets, stream_stride, packet_stride, h->chn, h->pkg)
     if (h->L == 128) {
         if (h->ordered)
             NS_LAUNCH(128, true);
