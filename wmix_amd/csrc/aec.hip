@@ -172,94 +172,108 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F, const float *
 }
 
 // ================================================================== near-end kernel
-struct AecShared {
-    AecConsts K;
-    float st[AS_WORDS];
-    float fa[4][132];
+constexpr int kAecWavesPerBlock = 4;
+constexpr int AS_LDS0 = AS_DPOW;               // state words kept in LDS: everything after the filter taps
+constexpr int AS_LDS_WORDS = AS_WORDS - AS_DPOW;
+constexpr int FAS = 132;                        // floats per FFT work row (128 + pad)
+
+struct alignas(16) AecWaveLds {
+    float st[AS_LDS_WORDS];  // per-bin PSDs, time-domain tails, rings, scalars (indexed AS_x - AS_LDS0)
+    float wn[16];            // wfBuf[0][p][64]: the Nyquist column of the filter (the other 64 bins live in registers)
+    float fa[12][FAS];       // FFT work rows: 12 at once in the filter update; rows 4..11 double as NLP scratch
     float ef_re[BP], ef_im[BP];
-    float xw_re[BP], xw_im[BP], dw_re[BP], dw_im[BP], ew_re[BP], ew_im[BP];
-    float t0[BP], t1[BP], t2[BP], t3[BP];
     float cur[64], enew[64];
+};
+#define AEC_ST(x) W.st[(x) - AS_LDS0]
+
+// The adaptive filter: lane k holds bin k of all 12 partitions (wfBuf, aec_core_internal.h:78)
+struct AecTaps {
+    float re[12], im[12];
 };
 
 template <int MULT>  // 1: 8 kHz, 2: 16 kHz
-__device__ void aec_block(AecShared &sh, const AecFarBufs &F, const AecBlkPlan &bp, const int lane) {
-    float *S = sh.st;
-    int *Si = reinterpret_cast<int *>(sh.st);
+__device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, AecTaps &taps, const AecFarBufs &F, const AecBlkPlan &bp,
+                                          const int lane) {
+    int *Si = reinterpret_cast<int *>(W.st) - AS_LDS0;
     const float mu = MULT == 1 ? 0.6f : 0.5f, err_thr = MULT == 1 ? 2e-6f : 1.5e-6f;  // aec_core.c:1530-1538
     const float scale = 2.0f / 128;
     const int n = bp.hist_n;
     const int g = lane >> 4, gl = lane & 15;
+    // NLP scratch rows (free outside the filter update)
+    float *xw = W.fa[4], *dw = W.fa[5], *ew = W.fa[6];  // re at [b], im at [66 + b]
+    float *t0 = W.fa[8], *t1 = W.fa[9], *t2 = W.fa[10], *t3 = W.fa[11];
 
     // ---- near block, d = [prev | cur], df = rdft(d)   (aec_core.c:1177-1195)
     {
-        const float c = S[AS_NEAR_RING + (bp.near_rd + lane) % kAecRing];
-        sh.cur[lane] = c;
-        sh.fa[0][lane] = S[AS_DPREV + lane];
-        sh.fa[0][64 + lane] = c;
+        const float c = AEC_ST(AS_NEAR_RING + (bp.near_rd + lane) % kAecRing);
+        W.cur[lane] = c;
+        W.fa[0][lane] = AEC_ST(AS_DPREV + lane);
+        W.fa[0][64 + lane] = c;
     }
     wave_sync();
-    rdft_forward<64>(sh.fa[0], &sh.K.tab, lane);
+    rdft_forward<64>(W.fa[0], &K.tab, lane);
     // ---- near power, noise floor (aec_core.c:1197-1243)
     for (int b = lane; b < kAecPart1; b += 64) {
         float re, im;
-        unpack_bin(sh.fa[0], b, re, im);
+        unpack_bin(W.fa[0], b, re, im);
         const float ns = re * re + im * im;
-        const float dpow = 0.9f * S[AS_DPOW + b] + 0.1f * ns;
-        S[AS_DPOW + b] = dpow;
-        float dmin = S[AS_DMIN + b];
+        const float dpow = 0.9f * AEC_ST(AS_DPOW + b) + 0.1f * ns;
+        AEC_ST(AS_DPOW + b) = dpow;
+        float dmin = AEC_ST(AS_DMIN + b);
         if (bp.flags & kAecFlagNoiseMin) {
             if (dpow < dmin)
                 dmin = (dpow + 0.1f * (dmin - dpow)) * 1.0002f;
             else
                 dmin *= 1.0002f;
-            S[AS_DMIN + b] = dmin;
+            AEC_ST(AS_DMIN + b) = dmin;
         }
         if (bp.flags & kAecFlagNoiseInit) {
-            float dinit = S[AS_DINIT + b];
+            float dinit = AEC_ST(AS_DINIT + b);
             if (dmin > dinit)
                 dinit = 0.999f * dinit + 0.001f * dmin;
             else
                 dinit = dmin;
-            S[AS_DINIT + b] = dinit;
+            AEC_ST(AS_DINIT + b) = dinit;
         }
     }
-    // ---- FilterFar (aec_core.c:148-170): y = sum_p X_{n-p} * W_p, partitions in order
-    for (int b = lane; b < kAecPart1; b += 64) {
-        float yr = 0.f, yi = 0.f;
+    // ---- FilterFar (aec_core.c:148-170): y = sum_p X_{n-p} * W_p, partitions in order; lane 0 also does bin 64
+    {
+        float yr = 0.f, yi = 0.f, y64 = 0.f;
 #pragma unroll
         for (int p = 0; p < 12; p++) {
             const float *X = F.hist + (size_t)((n - p + kAecHist) % kAecHist) * 130;
-            const float xr = X[b], xi = X[kAecPart1 + b];
-            const float wr = S[AS_W_RE + p * BP + b], wi = S[AS_W_IM + p * BP + b];
-            yr += xr * wr - xi * wi;
-            yi += xr * wi + xi * wr;
+            const float xr = X[lane], xi = X[kAecPart1 + lane];
+            yr += xr * taps.re[p] - xi * taps.im[p];
+            yi += xr * taps.im[p] + xi * taps.re[p];
+            if (lane == 0) {
+                const float nr = X[kAecPart], ni = X[kAecPart1 + kAecPart];  // ni == 0, wfBuf[1][.][64] == 0
+                y64 += nr * W.wn[p] - ni * 0.f;
+            }
         }
-        if (b == 0)
-            sh.fa[1][0] = yr;
-        else if (b == kAecPart)
-            sh.fa[1][1] = yr;
-        else {
-            sh.fa[1][2 * b] = yr;
-            sh.fa[1][2 * b + 1] = yi;
+        if (lane == 0) {
+            W.fa[1][0] = yr;
+            W.fa[1][1] = y64;
+        } else {
+            W.fa[1][2 * lane] = yr;
+            W.fa[1][2 * lane + 1] = yi;
         }
     }
     wave_sync();
-    rdft_inverse<64>(sh.fa[1], &sh.K.tab, lane);
+    rdft_inverse<64>(W.fa[1], &K.tab, lane);
     // ---- error e = d - y, ef = rdft([0 | e])  (aec_core.c:1286-1309)
     {
-        const float y = sh.fa[1][64 + lane] * scale;
-        const float e = sh.cur[lane] - y;
-        sh.enew[lane] = e;
-        sh.fa[2][lane] = 0.f;
-        sh.fa[2][64 + lane] = e;
+        const float y = W.fa[1][64 + lane] * scale;
+        const float e = W.cur[lane] - y;
+        W.enew[lane] = e;
+        W.fa[2][lane] = 0.f;
+        W.fa[2][64 + lane] = e;
     }
     wave_sync();
-    rdft_forward<64>(sh.fa[2], &sh.K.tab, lane);
+    rdft_forward<64>(W.fa[2], &K.tab, lane);
     // ---- ScaleErrorSignal (aec_core.c:172-194)
     for (int b = lane; b < kAecPart1; b += 64) {
         float er, ei;
-        unpack_bin(sh.fa[2], b, er, ei);
+        unpack_bin(W.fa[2], b, er, ei);
         const float xp = F.xpow_seq[(n % kAecHist) * BP + b];
         er /= (xp + 1e-10f);
         ei /= (xp + 1e-10f);
@@ -271,139 +285,151 @@ __device__ void aec_block(AecShared &sh, const AecFarBufs &F, const AecBlkPlan &
         }
         er *= mu;
         ei *= mu;
-        sh.ef_re[b] = er;
-        sh.ef_im[b] = ei;
+        W.ef_re[b] = er;
+        W.ef_im[b] = ei;
     }
     wave_sync();
-    // ---- FilterAdaptation (aec_core.c:222-270), four partitions per round
-    for (int r = 0; r < 3; r++) {
+    // ---- FilterAdaptation (aec_core.c:222-270): all 12 constraint transforms side by side -- 4 groups of 16 lanes,
+    //      3 partitions per group (partition p = 4*r + g lives in row p)
+    {
+        const float er = W.ef_re[lane], ei = W.ef_im[lane];
+        const float e64r = W.ef_re[kAecPart], e64i = W.ef_im[kAecPart];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int p = 4 * r + q;
+        for (int p = 0; p < 12; p++) {
             const float *X = F.hist + (size_t)((n - p + kAecHist) % kAecHist) * 130;
-            const float er = sh.ef_re[lane], ei = sh.ef_im[lane];
             const float xr = X[lane], xi = -X[kAecPart1 + lane];
-            sh.fa[q][2 * lane] = xr * er - xi * ei;
-            sh.fa[q][2 * lane + 1] = xr * ei + xi * er;
-            if (lane == 0) {
+            float v1 = xr * ei + xi * er;
+            if (lane == 0) {  // fft[1] is overwritten with the Nyquist product (aec_core.c:245-248)
                 const float nr = X[kAecPart], ni = -X[kAecPart1 + kAecPart];
-                sh.fa[q][1] = nr * sh.ef_re[kAecPart] - ni * sh.ef_im[kAecPart];
+                v1 = nr * e64r - ni * e64i;
             }
+            W.fa[p][2 * lane] = xr * er - xi * ei;
+            W.fa[p][2 * lane + 1] = v1;
         }
-        wave_sync();
-        rdft_inverse<64, 16>(sh.fa[g], &sh.K.tab, gl);
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            sh.fa[q][64 + lane] = 0.f;
-            sh.fa[q][lane] *= scale;
-        }
-        wave_sync();
-        rdft_forward<64, 16>(sh.fa[g], &sh.K.tab, gl);
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int p = 4 * r + q;
-            for (int b = lane; b < kAecPart1; b += 64) {
-                float re, im;
-                unpack_bin(sh.fa[q], b, re, im);
-                S[AS_W_RE + p * BP + b] += re;
-                if (b != 0 && b != kAecPart) S[AS_W_IM + p * BP + b] += im;
-            }
-        }
-        wave_sync();
     }
+    wave_sync();
+    rdft_inverse<64, 16, 3>(W.fa[g], &K.tab, gl, 4 * FAS);
+#pragma unroll
+    for (int p = 0; p < 12; p++) {
+        W.fa[p][64 + lane] = 0.f;
+        W.fa[p][lane] *= scale;
+    }
+    wave_sync();
+    rdft_forward<64, 16, 3>(W.fa[g], &K.tab, gl, 4 * FAS);
+#pragma unroll
+    for (int p = 0; p < 12; p++) {
+        if (lane == 0) {
+            taps.re[p] += W.fa[p][0];
+            W.wn[p] += W.fa[p][1];
+        } else {
+            taps.re[p] += W.fa[p][2 * lane];
+            taps.im[p] += W.fa[p][2 * lane + 1];
+        }
+    }
+    wave_sync();
 
     // ================================================= NonLinearProcessing (aec_core.c:911-1141)
     constexpr int prefSize = 24 / MULT, minPref = 4 / MULT;
     const float gc0 = MULT == 1 ? 0.9f : 0.93f, gc1 = MULT == 1 ? 0.1f : 0.07f;  // kNormalSmoothingCoefficients
-    // PartitionDelay (aec_core.c:295-319) every 10*mult blocks
+    // PartitionDelay (aec_core.c:295-319) every 10*mult blocks: per-partition ordered energy sums
     int delayIdx = Si[AS_DELAYIDX];
     if (bp.flags & kAecFlagDelayEst) {
+#pragma unroll
+        for (int p = 0; p < 12; p++) {
+            W.fa[p][lane] = taps.re[p] * taps.re[p] + taps.im[p] * taps.im[p];
+            if (lane == 0) W.fa[p][64] = W.wn[p] * W.wn[p] + 0.f * 0.f;
+        }
+        wave_sync();
         if (lane < 12) {
             float en = 0.f;
-            for (int j = 0; j < kAecPart1; j++) {
-                const float wr = S[AS_W_RE + lane * BP + j], wi = S[AS_W_IM + lane * BP + j];
-                en += wr * wr + wi * wi;
-            }
-            sh.t0[lane] = en;
+            for (int j = 0; j < kAecPart1; j++) en += W.fa[lane][j];
+            W.ef_re[BP - 1 - lane] = en;  // 12 spare floats at the tail of the padded rows
         }
         wave_sync();
         float best = 0.f;
         delayIdx = 0;
         for (int p = 0; p < 12; p++)
-            if (sh.t0[p] > best) {
-                best = sh.t0[p];
+            if (W.ef_re[BP - 1 - p] > best) {
+                best = W.ef_re[BP - 1 - p];
                 delayIdx = p;
             }
         wave_sync();
-        Si[AS_DELAYIDX] = delayIdx;
+        if (lane == 0) Si[AS_DELAYIDX] = delayIdx;
     }
     // xfw = windowed far spectrum consumed delayIdx blocks ago; windowed d and e transforms
     {
         const float *Xw = F.hist_w + (size_t)((n - delayIdx + kAecHist) % kAecHist) * 130;
         for (int b = lane; b < kAecPart1; b += 64) {
-            sh.xw_re[b] = Xw[b];
-            sh.xw_im[b] = Xw[kAecPart1 + b];
+            xw[b] = Xw[b];
+            xw[66 + b] = Xw[kAecPart1 + b];
         }
-        const float h0 = sh.K.hanning[lane], h1 = sh.K.hanning[kAecPart - lane];
-        sh.fa[0][lane] = S[AS_DPREV + lane] * h0;
-        sh.fa[0][64 + lane] = sh.cur[lane] * h1;
-        sh.fa[1][lane] = S[AS_EPREV + lane] * h0;
-        sh.fa[1][64 + lane] = sh.enew[lane] * h1;
+        const float h0 = K.hanning[lane], h1 = K.hanning[kAecPart - lane];
+        W.fa[0][lane] = AEC_ST(AS_DPREV + lane) * h0;
+        W.fa[0][64 + lane] = W.cur[lane] * h1;
+        W.fa[1][lane] = AEC_ST(AS_EPREV + lane) * h0;
+        W.fa[1][64 + lane] = W.enew[lane] * h1;
     }
     wave_sync();
-    rdft_forward<64, 16>(sh.fa[g], &sh.K.tab, gl);  // groups 0 and 1 carry d and e; 2 and 3 idle on scratch
+    rdft_forward<64, 16>(W.fa[g], &K.tab, gl);  // groups 0 and 1 carry d and e; 2 and 3 idle on scratch rows
     // SmoothedPSD (aec_core.c:333-386)
     for (int b = lane; b < kAecPart1; b += 64) {
         float dr, di, er, ei;
-        unpack_bin(sh.fa[0], b, dr, di);
-        unpack_bin(sh.fa[1], b, er, ei);
-        const float xr = sh.xw_re[b], xi = sh.xw_im[b];
-        const float sd = gc0 * S[AS_SD + b] + gc1 * (dr * dr + di * di);
-        const float se = gc0 * S[AS_SE + b] + gc1 * (er * er + ei * ei);
+        unpack_bin(W.fa[0], b, dr, di);
+        unpack_bin(W.fa[1], b, er, ei);
+        const float xr = xw[b], xi = xw[66 + b];
+        const float sd = gc0 * AEC_ST(AS_SD + b) + gc1 * (dr * dr + di * di);
+        const float se = gc0 * AEC_ST(AS_SE + b) + gc1 * (er * er + ei * ei);
         const float xx = xr * xr + xi * xi;
-        S[AS_SX + b] = gc0 * S[AS_SX + b] + gc1 * (xx > 15.f ? xx : 15.f);
-        S[AS_SD + b] = sd;
-        S[AS_SE + b] = se;
-        S[AS_SDE_RE + b] = gc0 * S[AS_SDE_RE + b] + gc1 * (dr * er + di * ei);
-        S[AS_SDE_IM + b] = gc0 * S[AS_SDE_IM + b] + gc1 * (dr * ei - di * er);
-        S[AS_SXD_RE + b] = gc0 * S[AS_SXD_RE + b] + gc1 * (dr * xr + di * xi);
-        S[AS_SXD_IM + b] = gc0 * S[AS_SXD_IM + b] + gc1 * (dr * xi - di * xr);
-        sh.dw_re[b] = dr;
-        sh.dw_im[b] = di;
-        sh.ew_re[b] = er;
-        sh.ew_im[b] = ei;
+        AEC_ST(AS_SX + b) = gc0 * AEC_ST(AS_SX + b) + gc1 * (xx > 15.f ? xx : 15.f);
+        AEC_ST(AS_SD + b) = sd;
+        AEC_ST(AS_SE + b) = se;
+        AEC_ST(AS_SDE_RE + b) = gc0 * AEC_ST(AS_SDE_RE + b) + gc1 * (dr * er + di * ei);
+        AEC_ST(AS_SDE_IM + b) = gc0 * AEC_ST(AS_SDE_IM + b) + gc1 * (dr * ei - di * er);
+        AEC_ST(AS_SXD_RE + b) = gc0 * AEC_ST(AS_SXD_RE + b) + gc1 * (dr * xr + di * xi);
+        AEC_ST(AS_SXD_IM + b) = gc0 * AEC_ST(AS_SXD_IM + b) + gc1 * (dr * xi - di * xr);
+        dw[b] = dr;
+        dw[66 + b] = di;
+        ew[b] = er;
+        ew[66 + b] = ei;
     }
     wave_sync();
     float sdSum = 0.f, seSum = 0.f;
     for (int i = 0; i < kAecPart1; i++) {
-        sdSum += S[AS_SD + i];
-        seSum += S[AS_SE + i];
+        sdSum += AEC_ST(AS_SD + i);
+        seSum += AEC_ST(AS_SE + i);
     }
     const int diverge = ((Si[AS_DIVERGE] ? 1.05f : 1.0f) * seSum > sdSum) ? 1 : 0;
     const bool reset_filter = seSum > (19.95f * sdSum);
     wave_sync();
-    Si[AS_DIVERGE] = diverge;
-    if (reset_filter)
-        for (int i = lane; i < 24 * BP; i += 64) S[AS_W_RE + i] = 0.f;  // memset(wfBuf): both planes are contiguous
+    if (lane == 0) Si[AS_DIVERGE] = diverge;
+    if (reset_filter) {  // memset(wfBuf, 0)
+#pragma unroll
+        for (int p = 0; p < 12; p++) {
+            taps.re[p] = 0.f;
+            taps.im[p] = 0.f;
+            if (lane == 0) W.wn[p] = 0.f;
+        }
+    }
     // coherences (aec_core.c:440-449)
     for (int b = lane; b < kAecPart1; b += 64) {
         if (diverge) {
-            sh.ew_re[b] = sh.dw_re[b];
-            sh.ew_im[b] = sh.dw_im[b];
+            ew[b] = dw[b];
+            ew[66 + b] = dw[66 + b];
         }
-        const float sde_r = S[AS_SDE_RE + b], sde_i = S[AS_SDE_IM + b], sxd_r = S[AS_SXD_RE + b], sxd_i = S[AS_SXD_IM + b];
-        sh.t0[b] = (sde_r * sde_r + sde_i * sde_i) / (S[AS_SD + b] * S[AS_SE + b] + 1e-10f);  // cohde
-        sh.t1[b] = (sxd_r * sxd_r + sxd_i * sxd_i) / (S[AS_SX + b] * S[AS_SD + b] + 1e-10f);  // cohxd
+        const float sde_r = AEC_ST(AS_SDE_RE + b), sde_i = AEC_ST(AS_SDE_IM + b), sxd_r = AEC_ST(AS_SXD_RE + b),
+                    sxd_i = AEC_ST(AS_SXD_IM + b);
+        t0[b] = (sde_r * sde_r + sde_i * sde_i) / (AEC_ST(AS_SD + b) * AEC_ST(AS_SE + b) + 1e-10f);  // cohde
+        t1[b] = (sxd_r * sxd_r + sxd_i * sxd_i) / (AEC_ST(AS_SX + b) * AEC_ST(AS_SD + b) + 1e-10f);  // cohxd
     }
     wave_sync();
     float hNlXdAvg = 0.f, hNlDeAvg = 0.f;
-    for (int i = minPref; i < prefSize + minPref; i++) hNlXdAvg += sh.t1[i];
+    for (int i = minPref; i < prefSize + minPref; i++) hNlXdAvg += t1[i];
     hNlXdAvg /= prefSize;
     hNlXdAvg = 1 - hNlXdAvg;
-    for (int i = minPref; i < prefSize + minPref; i++) hNlDeAvg += sh.t0[i];
+    for (int i = minPref; i < prefSize + minPref; i++) hNlDeAvg += t0[i];
     hNlDeAvg /= prefSize;
-    float hNlXdAvgMin = S[AS_HNLXDAVGMIN], hNlFbMin = S[AS_HNLFBMIN], hNlFbLocalMin = S[AS_HNLFBLOCALMIN];
-    float overDrive = S[AS_OVERDRIVE], overDriveSm = S[AS_OVERDRIVESM];
+    float hNlXdAvgMin = AEC_ST(AS_HNLXDAVGMIN), hNlFbMin = AEC_ST(AS_HNLFBMIN), hNlFbLocalMin = AEC_ST(AS_HNLFBLOCALMIN);
+    float overDrive = AEC_ST(AS_OVERDRIVE), overDriveSm = AEC_ST(AS_OVERDRIVESM);
     int stNear = Si[AS_STNEAR], echoState, hNlNewMin = Si[AS_HNLNEWMIN], hNlMinCtr = Si[AS_HNLMINCTR];
     if (hNlXdAvg < 0.75f && hNlXdAvg < hNlXdAvgMin) hNlXdAvgMin = hNlXdAvg;
     if (hNlDeAvg > 0.98f && hNlXdAvg > 0.9f)
@@ -439,26 +465,26 @@ __device__ void aec_block(AecShared &sh, const AecFarBufs &F, const AecBlkPlan &
         }
     }
     for (int b = lane; b < kAecPart1; b += 64) {
-        const float cde = sh.t0[b], cxd = 1 - sh.t1[b];
-        sh.t2[b] = mode == 0 ? cde : (mode == 1 ? cxd : (cde < cxd ? cde : cxd));  // hNl
+        const float cde = t0[b], cxd = 1 - t1[b];
+        t2[b] = mode == 0 ? cde : (mode == 1 ? cxd : (cde < cxd ? cde : cxd));  // hNl
     }
     wave_sync();
     if (mode == 2) {
         // qsort(hNlPref) + the two order statistics (aec_core.c:1017-1022): rank by counting
         constexpr int i75 = (int)(0.75f * (prefSize - 1)), i50 = (int)(0.5f * (prefSize - 1));
         if (lane < prefSize) {
-            const float v = sh.t2[minPref + lane];
+            const float v = t2[minPref + lane];
             int rank = 0;
             for (int i = 0; i < prefSize; i++) {
-                const float u = sh.t2[minPref + i];
+                const float u = t2[minPref + i];
                 rank += (u < v || (u == v && i < lane)) ? 1 : 0;
             }
-            if (rank == i75) sh.t3[0] = v;
-            if (rank == i50) sh.t3[1] = v;
+            if (rank == i75) t3[0] = v;
+            if (rank == i50) t3[1] = v;
         }
         wave_sync();
-        hNlFb = sh.t3[0];
-        hNlFbLow = sh.t3[1];
+        hNlFb = t3[0];
+        hNlFbLow = t3[1];
         wave_sync();
     }
     if (hNlFbLow < 0.6f && hNlFbLow < hNlFbLocalMin) {
@@ -486,11 +512,11 @@ __device__ void aec_block(AecShared &sh, const AecFarBufs &F, const AecBlkPlan &
         overDriveSm = 0.9f * overDriveSm + 0.1f * overDrive;
     // every lane holds the same scalars; lane 0 publishes them
     if (lane == 0) {
-        S[AS_HNLXDAVGMIN] = hNlXdAvgMin;
-        S[AS_HNLFBMIN] = hNlFbMin;
-        S[AS_HNLFBLOCALMIN] = hNlFbLocalMin;
-        S[AS_OVERDRIVE] = overDrive;
-        S[AS_OVERDRIVESM] = overDriveSm;
+        AEC_ST(AS_HNLXDAVGMIN) = hNlXdAvgMin;
+        AEC_ST(AS_HNLFBMIN) = hNlFbMin;
+        AEC_ST(AS_HNLFBLOCALMIN) = hNlFbLocalMin;
+        AEC_ST(AS_OVERDRIVE) = overDrive;
+        AEC_ST(AS_OVERDRIVESM) = overDriveSm;
         Si[AS_STNEAR] = stNear;
         Si[AS_ECHOSTATE] = echoState;
         Si[AS_HNLNEWMIN] = hNlNewMin;
@@ -499,15 +525,15 @@ __device__ void aec_block(AecShared &sh, const AecFarBufs &F, const AecBlkPlan &
     // OverdriveAndSuppress (aec_core.c:272-293) + ComfortNoise (:462-547) + packing for the inverse transform
     const int noise_off = (bp.flags & kAecFlagNoiseInit) ? AS_DINIT : AS_DMIN;
     for (int b = lane; b < kAecPart1; b += 64) {
-        float h = sh.t2[b];
-        const float wc = sh.K.weight[b];
+        float h = t2[b];
+        const float wc = K.weight[b];
         if (h > hNlFb) h = wc * hNlFb + (1 - wc) * h;
-        h = (float)pow((double)h, (double)(overDriveSm * sh.K.overdrive[b]));
-        float er = sh.ew_re[b] * h, ei = sh.ew_im[b] * h;
+        h = (float)pow((double)h, (double)(overDriveSm * K.overdrive[b]));
+        float er = ew[b] * h, ei = ew[66 + b] * h;
         ei *= -1;
         float ur = 0.f, ui = 0.f;
         if (b >= 1) {
-            const float noise = sqrtf(S[noise_off + b]);
+            const float noise = sqrtf(AEC_ST(noise_off + b));
             ur = noise * bp.ucos[b - 1];
             ui = -noise * bp.usin[b - 1];
             if (b == kAecPart) ui = 0.f;
@@ -517,75 +543,100 @@ __device__ void aec_block(AecShared &sh, const AecFarBufs &F, const AecBlkPlan &
         er += tmp * ur;
         ei += tmp * ui;
         if (b == 0)
-            sh.fa[3][0] = er;
+            W.fa[3][0] = er;
         else if (b == kAecPart)
-            sh.fa[3][1] = er;
+            W.fa[3][1] = er;
         else {
-            sh.fa[3][2 * b] = er;
-            sh.fa[3][2 * b + 1] = -ei;
+            W.fa[3][2 * b] = er;
+            W.fa[3][2 * b + 1] = -ei;
         }
     }
     wave_sync();
-    rdft_inverse<64>(sh.fa[3], &sh.K.tab, lane);
+    rdft_inverse<64>(W.fa[3], &K.tab, lane);
     // overlap-add with the sqrt-Hanning window, saturate, queue 64 output samples (aec_core.c:1089-1101, 1341)
     {
-        float v = sh.fa[3][lane] * scale;
-        v = v * sh.K.hanning[lane] + S[AS_OUTBUF + lane];
-        const float t = sh.fa[3][64 + lane] * scale;
-        S[AS_OUTBUF + lane] = t * sh.K.hanning[kAecPart - lane];
-        S[AS_OUT_RING + (bp.out_wr + lane) % kAecRing] = sat16f(v);
-        S[AS_DPREV + lane] = sh.cur[lane];
-        S[AS_EPREV + lane] = sh.enew[lane];
+        float v = W.fa[3][lane] * scale;
+        v = v * K.hanning[lane] + AEC_ST(AS_OUTBUF + lane);
+        const float t = W.fa[3][64 + lane] * scale;
+        AEC_ST(AS_OUTBUF + lane) = t * K.hanning[kAecPart - lane];
+        AEC_ST(AS_OUT_RING + (bp.out_wr + lane) % kAecRing) = sat16f(v);
+        AEC_ST(AS_DPREV + lane) = W.cur[lane];
+        AEC_ST(AS_EPREV + lane) = W.enew[lane];
     }
     wave_sync();
 }
 
 template <int MULT>
-__global__ __launch_bounds__(64) void aec_near_kernel(float *__restrict__ state, AecFarBufs F, const float *__restrict__ consts_g,
-                                                      const AecPlan *__restrict__ plans, int n_packets, const int16_t *near_pcm,
-                                                      int16_t *out_pcm, int n_streams, long stream_stride, long packet_stride, int chn,
-                                                      int pkg) {
-    __shared__ AecShared sh;
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(64 * kAecWavesPerBlock) void aec_near_kernel(float *__restrict__ state, AecFarBufs F,
+                                                                          const float *__restrict__ consts_g,
+                                                                          const AecPlan *__restrict__ plans, int n_packets,
+                                                                          const int16_t *near_pcm, int16_t *out_pcm, int n_streams,
+                                                                          long stream_stride, long packet_stride, int chn, int pkg) {
+    __shared__ AecConsts K;
+    __shared__ AecWaveLds Wv[kAecWavesPerBlock];
     {
-        float *dst = reinterpret_cast<float *>(&sh.K);
-        for (int i = lane; i < kAecConstWords; i += 64) dst[i] = consts_g[i];
+        float *dst = reinterpret_cast<float *>(&K);
+        for (int i = threadIdx.x; i < kAecConstWords; i += blockDim.x) dst[i] = consts_g[i];
     }
-    for (int sidx = blockIdx.x; sidx < n_streams; sidx += gridDim.x) {
-        float4 *g4 = reinterpret_cast<float4 *>(state + (size_t)sidx * AS_WORDS);
-        float4 *s4 = reinterpret_cast<float4 *>(sh.st);
-        wave_sync();
-        for (int i = lane; i < AS_WORDS / 4; i += 64) s4[i] = g4[i];  // one contiguous 11 KB read
-        wave_sync();
-        for (int p = 0; p < n_packets; p++) {
-            const AecPlan &pl = plans[p];
-            if (!pl.has_near) continue;
-            const size_t off = (size_t)sidx * stream_stride + (size_t)p * packet_stride;
-            const int16_t *in = near_pcm + off;
-            int16_t *out = out_pcm + off;
-            if (pl.passthrough) {
-                // start-up phase: AEC disabled, out = near (echo_cancellation.c:651-657); left channel to all channels
-                for (int i = lane; i < pkg; i += 64) {
-                    const int16_t v = in[i * chn];
-                    for (int c = 0; c < chn; c++) out[i * chn + c] = v;
-                }
-                continue;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sidx = blockIdx.x * kAecWavesPerBlock + wave;  // one stream per wave; no block-level barrier below
+    if (sidx >= n_streams) return;
+    AecWaveLds &W = Wv[wave];
+    float *gst = state + (size_t)sidx * AS_WORDS;
+    // ---- state in: filter taps straight into registers (256-byte rows), the rest as one contiguous block into LDS
+    AecTaps taps;
+#pragma unroll
+    for (int p = 0; p < 12; p++) {
+        taps.re[p] = gst[AS_W_RE + p * BP + lane];
+        taps.im[p] = gst[AS_W_IM + p * BP + lane];
+    }
+    if (lane < 12) W.wn[lane] = gst[AS_W_RE + lane * BP + kAecPart];
+    {
+        const float4 *g4 = reinterpret_cast<const float4 *>(gst + AS_LDS0);
+        float4 *s4 = reinterpret_cast<float4 *>(W.st);
+        for (int i = lane; i < AS_LDS_WORDS / 4; i += 64) s4[i] = g4[i];
+    }
+    wave_sync();
+    for (int p = 0; p < n_packets; p++) {
+        const AecPlan &pl = plans[p];
+        if (!pl.has_near) continue;
+        const size_t off = (size_t)sidx * stream_stride + (size_t)p * packet_stride;
+        const int16_t *in = near_pcm + off;
+        int16_t *out = out_pcm + off;
+        if (pl.passthrough) {
+            // start-up phase: AEC disabled, out = near (echo_cancellation.c:651-657); left channel to all channels
+            for (int i = lane; i < pkg; i += 64) {
+                const int16_t v = in[i * chn];
+                for (int c = 0; c < chn; c++) out[i * chn + c] = v;
             }
-            for (int s = 0; s < pl.n_sub; s++) {
-                const AecSubPlan &sp = pl.sub[s];
-                for (int i = lane; i < kAecFrame; i += 64)
-                    sh.st[AS_NEAR_RING + (sp.near_wr + i) % kAecRing] = (float)in[(s * kAecFrame + i) * chn];
-                wave_sync();
-                for (int k = 0; k < sp.n_blocks; k++) aec_block<MULT>(sh, F, pl.blk[sp.first_blk + k], lane);
-                for (int i = lane; i < kAecFrame; i += 64) {
-                    const int16_t v = (int16_t)sh.st[AS_OUT_RING + (sp.out_rd + i) % kAecRing];
-                    for (int c = 0; c < chn; c++) out[(s * kAecFrame + i) * chn + c] = v;
-                }
-                wave_sync();
-            }
+            continue;
         }
-        wave_sync();
-        for (int i = lane; i < AS_WORDS / 4; i += 64) g4[i] = s4[i];
+        for (int s = 0; s < pl.n_sub; s++) {
+            const AecSubPlan &sp = pl.sub[s];
+            for (int i = lane; i < kAecFrame; i += 64)
+                AEC_ST(AS_NEAR_RING + (sp.near_wr + i) % kAecRing) = (float)in[(s * kAecFrame + i) * chn];
+            wave_sync();
+            for (int k = 0; k < sp.n_blocks; k++) aec_block<MULT>(K, W, taps, F, pl.blk[sp.first_blk + k], lane);
+            for (int i = lane; i < kAecFrame; i += 64) {
+                const int16_t v = (int16_t)AEC_ST(AS_OUT_RING + (sp.out_rd + i) % kAecRing);
+                for (int c = 0; c < chn; c++) out[(s * kAecFrame + i) * chn + c] = v;
+            }
+            wave_sync();
+        }
+    }
+    wave_sync();
+    // ---- state out
+#pragma unroll
+    for (int p = 0; p < 12; p++) {
+        gst[AS_W_RE + p * BP + lane] = taps.re[p];
+        gst[AS_W_IM + p * BP + lane] = taps.im[p];
+    }
+    if (lane < 12) gst[AS_W_RE + lane * BP + kAecPart] = W.wn[lane];
+    {
+        float4 *g4 = reinterpret_cast<float4 *>(gst + AS_LDS0);
+        const float4 *s4 = reinterpret_cast<const float4 *>(W.st);
+        for (int i = lane; i < AS_LDS_WORDS / 4; i += 64) g4[i] = s4[i];
     }
 }
 
@@ -771,12 +822,13 @@ int wmx_aec_run(wmx_aec *h, int mode, const int16_t *d_far, long far_packet_stri
             if (mode & 2) {
                 const int16_t *nin = d_near + (size_t)done * packet_stride;
                 int16_t *nout = d_out + (size_t)done * packet_stride;
-                const unsigned grid = (unsigned)h->n_streams;
+                const unsigned grid = (unsigned)((h->n_streams + kAecWavesPerBlock - 1) / kAecWavesPerBlock);
+                const dim3 blk(64 * kAecWavesPerBlock);
                 if (h->freq == 8000)
-                    hipLaunchKernelGGL((aec_near_kernel<1>), dim3(grid), dim3(64), 0, s, h->d_state, h->far, h->d_consts, h->d_plans, built, nin,
+                    hipLaunchKernelGGL((aec_near_kernel<1>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, h->d_plans, built, nin,
                                        nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg);
                 else
-                    hipLaunchKernelGGL((aec_near_kernel<2>), dim3(grid), dim3(64), 0, s, h->d_state, h->far, h->d_consts, h->d_plans, built, nin,
+                    hipLaunchKernelGGL((aec_near_kernel<2>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, h->d_plans, built, nin,
                                        nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg);
                 WMX_LAUNCH_CHECK();
             }
