@@ -30,7 +30,7 @@
 #include <vector>
 #include "wmx_internal.h"
 #include "aec_ctl.h"
-#include "fft_ooura.h"
+#include "fft_regs.h"
 
 namespace wmx {
 namespace {
@@ -173,6 +173,19 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F, const float *
 
 // ================================================================== near-end kernel
 constexpr int kAecWavesPerBlock = 4;
+#ifdef WMX_AEC_PROF  // developer build only (make EXTRA=-DWMX_AEC_PROF): cycles per phase of aec_block, summed over waves
+__device__ unsigned long long g_aec_prof[16];
+#define AEC_PROF(i)                                                              \
+    do {                                                                         \
+        const long long t_now = clock64();                                       \
+        if (lane == 0) W.prof[i] += (unsigned long long)(t_now - t_prev);        \
+        t_prev = clock64();                                                      \
+    } while (0)
+#define AEC_PROF_START long long t_prev = clock64()
+#else
+#define AEC_PROF(i)
+#define AEC_PROF_START
+#endif
 constexpr int AS_LDS0 = AS_DPOW;               // state words kept in LDS: everything after the filter taps
 constexpr int AS_LDS_WORDS = AS_WORDS - AS_DPOW;
 constexpr int FAS = 132;                        // floats per FFT work row (128 + pad)
@@ -183,6 +196,9 @@ struct alignas(16) AecWaveLds {
     float fa[12][FAS];       // FFT work rows: 12 at once in the filter update; rows 4..11 double as NLP scratch
     float ef_re[BP], ef_im[BP];
     float cur[64], enew[64];
+#ifdef WMX_AEC_PROF
+    unsigned long long prof[16];
+#endif
 };
 #define AEC_ST(x) W.st[(x) - AS_LDS0]
 
@@ -190,6 +206,27 @@ struct alignas(16) AecWaveLds {
 struct AecTaps {
     float re[12], im[12];
 };
+
+// One 128-point real transform per 16-lane group, data in registers (fft_regs.h).  `src(p)` supplies complex
+// point p of the time-domain input; the result of the complex passes goes to `row` (natural order), where
+// rdft128_fwd_bin() finishes the real split for whoever reads a bin.
+template <class Src>
+__device__ __forceinline__ void aec_fft_fwd(float *row, const FftTables *T, int gl, Src src) {
+    Cx v[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) v[m] = src(fft64_src_point(gl, m));
+    fft64_regs<false>(v, T, gl);
+#pragma unroll
+    for (int m = 0; m < 4; m++) *reinterpret_cast<float2 *>(row + 2 * (gl + 16 * m)) = make_float2(v[m].r, v[m].i);
+}
+
+// Inverse transform of the packed spectrum in `row`; v[m] = time-domain samples 2p, 2p+1 with p = gl + 16 m
+// (unnormalised, like aec_rdft_inverse_128).
+__device__ __forceinline__ void aec_fft_inv(const float *row, const FftTables *T, int gl, Cx v[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; m++) v[m] = rdft128_inv_point(row, T, fft64_src_point(gl, m));
+    fft64_regs<true>(v, T, gl);
+}
 
 template <int MULT>  // 1: 8 kHz, 2: 16 kHz
 __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, AecTaps &taps, const AecFarBufs &F, const AecBlkPlan &bp,
@@ -202,20 +239,39 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
     // NLP scratch rows (free outside the filter update)
     float *xw = W.fa[4], *dw = W.fa[5], *ew = W.fa[6];  // re at [b], im at [66 + b]
     float *t0 = W.fa[8], *t1 = W.fa[9], *t2 = W.fa[10], *t3 = W.fa[11];
+    AEC_PROF_START;
 
-    // ---- near block, d = [prev | cur], df = rdft(d)   (aec_core.c:1177-1195)
-    {
-        const float c = AEC_ST(AS_NEAR_RING + (bp.near_rd + lane) % kAecRing);
-        W.cur[lane] = c;
-        W.fa[0][lane] = AEC_ST(AS_DPREV + lane);
-        W.fa[0][64 + lane] = c;
+    // ---- near block (aec_core.c:1177-1195).  d = [prev | cur]; its plain transform feeds the near power, its
+    //      windowed transform the coherence estimates of the NLP (aec_core.c:934-949): both now, side by side.
+    W.cur[lane] = AEC_ST(AS_NEAR_RING + (bp.near_rd + lane) % kAecRing);
+    wave_sync();
+    if (g < 2) {
+        const bool win = g == 1;
+        aec_fft_fwd(W.fa[g], &K.tab, gl, [&](int p) {
+            const int i = 2 * (p & 31);
+            float x0, x1, h0 = 1.f, h1 = 1.f;
+            if (p < 32) {
+                x0 = AEC_ST(AS_DPREV + i);
+                x1 = AEC_ST(AS_DPREV + i + 1);
+                if (win) h0 = K.hanning[i], h1 = K.hanning[i + 1];
+            } else {
+                x0 = W.cur[i];
+                x1 = W.cur[i + 1];
+                if (win) h0 = K.hanning[kAecPart - i], h1 = K.hanning[kAecPart - i - 1];
+            }
+            return win ? Cx{x0 * h0, x1 * h1} : Cx{x0, x1};
+        });
     }
     wave_sync();
-    rdft_forward<64>(W.fa[0], &K.tab, lane);
+    AEC_PROF(0);
+    // windowed near spectrum, kept in registers across the filter update (bin = lane; lane 0 also bin 64)
+    float dwr, dwi, dw64 = 0.f, dum;
+    rdft128_fwd_bin(W.fa[1], &K.tab, lane, dwr, dwi);
+    if (lane == 0) rdft128_fwd_bin(W.fa[1], &K.tab, kAecPart, dw64, dum);
     // ---- near power, noise floor (aec_core.c:1197-1243)
     for (int b = lane; b < kAecPart1; b += 64) {
         float re, im;
-        unpack_bin(W.fa[0], b, re, im);
+        rdft128_fwd_bin(W.fa[0], &K.tab, b, re, im);
         const float ns = re * re + im * im;
         const float dpow = 0.9f * AEC_ST(AS_DPOW + b) + 0.1f * ns;
         AEC_ST(AS_DPOW + b) = dpow;
@@ -251,82 +307,121 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
             }
         }
         if (lane == 0) {
-            W.fa[1][0] = yr;
-            W.fa[1][1] = y64;
+            W.fa[2][0] = yr;
+            W.fa[2][1] = y64;
         } else {
-            W.fa[1][2 * lane] = yr;
-            W.fa[1][2 * lane + 1] = yi;
+            W.fa[2][2 * lane] = yr;
+            W.fa[2][2 * lane + 1] = yi;
         }
     }
     wave_sync();
-    rdft_inverse<64>(W.fa[1], &K.tab, lane);
-    // ---- error e = d - y, ef = rdft([0 | e])  (aec_core.c:1286-1309)
-    {
-        const float y = W.fa[1][64 + lane] * scale;
-        const float e = W.cur[lane] - y;
-        W.enew[lane] = e;
-        W.fa[2][lane] = 0.f;
-        W.fa[2][64 + lane] = e;
-    }
-    wave_sync();
-    rdft_forward<64>(W.fa[2], &K.tab, lane);
-    // ---- ScaleErrorSignal (aec_core.c:172-194)
-    for (int b = lane; b < kAecPart1; b += 64) {
-        float er, ei;
-        unpack_bin(W.fa[2], b, er, ei);
-        const float xp = F.xpow_seq[(n % kAecHist) * BP + b];
-        er /= (xp + 1e-10f);
-        ei /= (xp + 1e-10f);
-        float abs_ef = sqrtf(er * er + ei * ei);
-        if (abs_ef > err_thr) {
-            abs_ef = err_thr / (abs_ef + 1e-10f);
-            er *= abs_ef;
-            ei *= abs_ef;
+    AEC_PROF(1);
+    // ---- error e = d - y (aec_core.c:1286-1297): the second half of the inverse transform is points 32..63
+    if (g == 0) {
+        Cx v[4];
+        aec_fft_inv(W.fa[2], &K.tab, gl, v);
+#pragma unroll
+        for (int m = 2; m < 4; m++) {
+            const int i = 2 * (gl + 16 * m - 32);
+            W.enew[i] = W.cur[i] - v[m].r * scale;
+            W.enew[i + 1] = W.cur[i + 1] - v[m].i * scale;
         }
-        er *= mu;
-        ei *= mu;
-        W.ef_re[b] = er;
-        W.ef_im[b] = ei;
     }
     wave_sync();
-    // ---- FilterAdaptation (aec_core.c:222-270): all 12 constraint transforms side by side -- 4 groups of 16 lanes,
-    //      3 partitions per group (partition p = 4*r + g lives in row p)
+    // ---- ef = rdft([0 | e]) (aec_core.c:1299-1309) and the windowed rdft([eprev | e] * w) of the NLP
+    if (g < 2) {
+        const bool win = g == 1;
+        aec_fft_fwd(W.fa[2 + g], &K.tab, gl, [&](int p) {
+            const int i = 2 * (p & 31);
+            if (p < 32) {
+                if (!win) return Cx{0.f, 0.f};
+                return Cx{AEC_ST(AS_EPREV + i) * K.hanning[i], AEC_ST(AS_EPREV + i + 1) * K.hanning[i + 1]};
+            }
+            const float x0 = W.enew[i], x1 = W.enew[i + 1];
+            if (!win) return Cx{x0, x1};
+            return Cx{x0 * K.hanning[kAecPart - i], x1 * K.hanning[kAecPart - i - 1]};
+        });
+    }
+    wave_sync();
+    AEC_PROF(2);
+    float ewr, ewi, ew64 = 0.f;
+    rdft128_fwd_bin(W.fa[3], &K.tab, lane, ewr, ewi);
+    if (lane == 0) rdft128_fwd_bin(W.fa[3], &K.tab, kAecPart, ew64, dum);
+    // ---- ScaleErrorSignal (aec_core.c:172-194); ef stays in registers (bin = lane; lane 0 also bin 64)
+    float efr, efi, ef64r = 0.f, ef64i = 0.f;
     {
-        const float er = W.ef_re[lane], ei = W.ef_im[lane];
-        const float e64r = W.ef_re[kAecPart], e64i = W.ef_im[kAecPart];
+        auto scale_err = [&](int b, float &er, float &ei) {
+            rdft128_fwd_bin(W.fa[2], &K.tab, b, er, ei);
+            const float xp = F.xpow_seq[(n % kAecHist) * BP + b];
+            er /= (xp + 1e-10f);
+            ei /= (xp + 1e-10f);
+            float abs_ef = sqrtf(er * er + ei * ei);
+            if (abs_ef > err_thr) {
+                abs_ef = err_thr / (abs_ef + 1e-10f);
+                er *= abs_ef;
+                ei *= abs_ef;
+            }
+            er *= mu;
+            ei *= mu;
+        };
+        scale_err(lane, efr, efi);
+        if (lane == 0) scale_err(kAecPart, ef64r, ef64i);
+    }
+    wave_sync();  // rows 2, 3 are read; the filter update overwrites all twelve
+    // ---- FilterAdaptation (aec_core.c:222-270): conj(X_{n-p}) * ef -> time domain, zero the second half,
+    //      back to frequency, add to partition p.  Four groups of 16 lanes, three partitions each (p = 4r + g).
+    {
 #pragma unroll
         for (int p = 0; p < 12; p++) {
             const float *X = F.hist + (size_t)((n - p + kAecHist) % kAecHist) * 130;
             const float xr = X[lane], xi = -X[kAecPart1 + lane];
-            float v1 = xr * ei + xi * er;
+            float v1 = xr * efi + xi * efr;
             if (lane == 0) {  // fft[1] is overwritten with the Nyquist product (aec_core.c:245-248)
                 const float nr = X[kAecPart], ni = -X[kAecPart1 + kAecPart];
-                v1 = nr * e64r - ni * e64i;
+                v1 = nr * ef64r - ni * ef64i;
             }
-            W.fa[p][2 * lane] = xr * er - xi * ei;
+            W.fa[p][2 * lane] = xr * efr - xi * efi;
             W.fa[p][2 * lane + 1] = v1;
         }
     }
     wave_sync();
-    rdft_inverse<64, 16, 3>(W.fa[g], &K.tab, gl, 4 * FAS);
+    {
+        Cx v[3][4];
 #pragma unroll
-    for (int p = 0; p < 12; p++) {
-        W.fa[p][64 + lane] = 0.f;
-        W.fa[p][lane] *= scale;
+        for (int r = 0; r < 3; r++) aec_fft_inv(W.fa[4 * r + g], &K.tab, gl, v[r]);
+        // points 0..31 (m = 0, 1) scaled, points 32..63 zeroed; the forward gather wants points
+        // rev4(gl) + {0, 32, 16, 48}: two of them from lane rev4(gl), two zeros
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const Cx a = Cx{row_bitrev(v[r][0].r * scale, lane), row_bitrev(v[r][0].i * scale, lane)};
+            const Cx c = Cx{row_bitrev(v[r][1].r * scale, lane), row_bitrev(v[r][1].i * scale, lane)};
+            v[r][0] = a;
+            v[r][1] = Cx{0.f, 0.f};
+            v[r][2] = c;
+            v[r][3] = Cx{0.f, 0.f};
+            fft64_regs<false>(v[r], &K.tab, gl);
+        }
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+                *reinterpret_cast<float2 *>(W.fa[4 * r + g] + 2 * (gl + 16 * m)) = make_float2(v[r][m].r, v[r][m].i);
     }
     wave_sync();
-    rdft_forward<64, 16, 3>(W.fa[g], &K.tab, gl, 4 * FAS);
 #pragma unroll
     for (int p = 0; p < 12; p++) {
+        float re, im;
+        rdft128_fwd_bin(W.fa[p], &K.tab, lane, re, im);
+        taps.re[p] += re;
         if (lane == 0) {
-            taps.re[p] += W.fa[p][0];
-            W.wn[p] += W.fa[p][1];
+            rdft128_fwd_bin(W.fa[p], &K.tab, kAecPart, re, im);
+            W.wn[p] += re;
         } else {
-            taps.re[p] += W.fa[p][2 * lane];
-            taps.im[p] += W.fa[p][2 * lane + 1];
+            taps.im[p] += im;
         }
     }
     wave_sync();
+    AEC_PROF(3);
 
     // ================================================= NonLinearProcessing (aec_core.c:911-1141)
     constexpr int prefSize = 24 / MULT, minPref = 4 / MULT;
@@ -356,26 +451,29 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
         wave_sync();
         if (lane == 0) Si[AS_DELAYIDX] = delayIdx;
     }
-    // xfw = windowed far spectrum consumed delayIdx blocks ago; windowed d and e transforms
+    AEC_PROF(4);
+    // xfw = windowed far spectrum consumed delayIdx blocks ago; the windowed near / error spectra come back from registers
     {
         const float *Xw = F.hist_w + (size_t)((n - delayIdx + kAecHist) % kAecHist) * 130;
         for (int b = lane; b < kAecPart1; b += 64) {
             xw[b] = Xw[b];
             xw[66 + b] = Xw[kAecPart1 + b];
         }
-        const float h0 = K.hanning[lane], h1 = K.hanning[kAecPart - lane];
-        W.fa[0][lane] = AEC_ST(AS_DPREV + lane) * h0;
-        W.fa[0][64 + lane] = W.cur[lane] * h1;
-        W.fa[1][lane] = AEC_ST(AS_EPREV + lane) * h0;
-        W.fa[1][64 + lane] = W.enew[lane] * h1;
+        dw[lane] = dwr;
+        dw[66 + lane] = dwi;
+        ew[lane] = ewr;
+        ew[66 + lane] = ewi;
+        if (lane == 0) {
+            dw[kAecPart] = dw64;
+            dw[66 + kAecPart] = 0.f;
+            ew[kAecPart] = ew64;
+            ew[66 + kAecPart] = 0.f;
+        }
     }
     wave_sync();
-    rdft_forward<64, 16>(W.fa[g], &K.tab, gl);  // groups 0 and 1 carry d and e; 2 and 3 idle on scratch rows
     // SmoothedPSD (aec_core.c:333-386)
     for (int b = lane; b < kAecPart1; b += 64) {
-        float dr, di, er, ei;
-        unpack_bin(W.fa[0], b, dr, di);
-        unpack_bin(W.fa[1], b, er, ei);
+        const float dr = dw[b], di = dw[66 + b], er = ew[b], ei = ew[66 + b];
         const float xr = xw[b], xi = xw[66 + b];
         const float sd = gc0 * AEC_ST(AS_SD + b) + gc1 * (dr * dr + di * di);
         const float se = gc0 * AEC_ST(AS_SE + b) + gc1 * (er * er + ei * ei);
@@ -387,12 +485,9 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
         AEC_ST(AS_SDE_IM + b) = gc0 * AEC_ST(AS_SDE_IM + b) + gc1 * (dr * ei - di * er);
         AEC_ST(AS_SXD_RE + b) = gc0 * AEC_ST(AS_SXD_RE + b) + gc1 * (dr * xr + di * xi);
         AEC_ST(AS_SXD_IM + b) = gc0 * AEC_ST(AS_SXD_IM + b) + gc1 * (dr * xi - di * xr);
-        dw[b] = dr;
-        dw[66 + b] = di;
-        ew[b] = er;
-        ew[66 + b] = ei;
     }
     wave_sync();
+    AEC_PROF(5);
     float sdSum = 0.f, seSum = 0.f;
     for (int i = 0; i < kAecPart1; i++) {
         sdSum += AEC_ST(AS_SD + i);
@@ -410,6 +505,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
             if (lane == 0) W.wn[p] = 0.f;
         }
     }
+    AEC_PROF(6);
     // coherences (aec_core.c:440-449)
     for (int b = lane; b < kAecPart1; b += 64) {
         if (diverge) {
@@ -522,6 +618,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
         Si[AS_HNLNEWMIN] = hNlNewMin;
         Si[AS_HNLMINCTR] = hNlMinCtr;
     }
+    AEC_PROF(7);
     // OverdriveAndSuppress (aec_core.c:272-293) + ComfortNoise (:462-547) + packing for the inverse transform
     const int noise_off = (bp.flags & kAecFlagNoiseInit) ? AS_DINIT : AS_DMIN;
     for (int b = lane; b < kAecPart1; b += 64) {
@@ -552,18 +649,32 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
         }
     }
     wave_sync();
-    rdft_inverse<64>(W.fa[3], &K.tab, lane);
-    // overlap-add with the sqrt-Hanning window, saturate, queue 64 output samples (aec_core.c:1089-1101, 1341)
-    {
-        float v = W.fa[3][lane] * scale;
-        v = v * K.hanning[lane] + AEC_ST(AS_OUTBUF + lane);
-        const float t = W.fa[3][64 + lane] * scale;
-        AEC_ST(AS_OUTBUF + lane) = t * K.hanning[kAecPart - lane];
-        AEC_ST(AS_OUT_RING + (bp.out_wr + lane) % kAecRing) = sat16f(v);
-        AEC_ST(AS_DPREV + lane) = W.cur[lane];
-        AEC_ST(AS_EPREV + lane) = W.enew[lane];
+    AEC_PROF(8);
+    // inverse transform, overlap-add with the sqrt-Hanning window, saturate, queue 64 output samples
+    // (aec_core.c:1089-1101, 1341): points 0..31 are the first half, 32..63 the new overlap tail
+    if (g == 0) {
+        Cx v[4];
+        aec_fft_inv(W.fa[3], &K.tab, gl, v);
+        float o[4];
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const int i = 2 * (gl + 16 * m);
+            o[2 * m] = sat16f(v[m].r * scale * K.hanning[i] + AEC_ST(AS_OUTBUF + i));
+            o[2 * m + 1] = sat16f(v[m].i * scale * K.hanning[i + 1] + AEC_ST(AS_OUTBUF + i + 1));
+        }
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const int i = 2 * (gl + 16 * m);
+            AEC_ST(AS_OUT_RING + (bp.out_wr + i) % kAecRing) = o[2 * m];
+            AEC_ST(AS_OUT_RING + (bp.out_wr + i + 1) % kAecRing) = o[2 * m + 1];
+            AEC_ST(AS_OUTBUF + i) = v[m + 2].r * scale * K.hanning[kAecPart - i];
+            AEC_ST(AS_OUTBUF + i + 1) = v[m + 2].i * scale * K.hanning[kAecPart - i - 1];
+        }
     }
+    AEC_ST(AS_DPREV + lane) = W.cur[lane];
+    AEC_ST(AS_EPREV + lane) = W.enew[lane];
     wave_sync();
+    AEC_PROF(9);
 }
 
 template <int MULT>
@@ -584,6 +695,10 @@ __global__ __launch_bounds__(64 * kAecWavesPerBlock) void aec_near_kernel(float 
     if (sidx >= n_streams) return;
     AecWaveLds &W = Wv[wave];
     float *gst = state + (size_t)sidx * AS_WORDS;
+#ifdef WMX_AEC_PROF
+    if (lane < 16) W.prof[lane] = 0;
+#endif
+    AEC_PROF_START;
     // ---- state in: filter taps straight into registers (256-byte rows), the rest as one contiguous block into LDS
     AecTaps taps;
 #pragma unroll
@@ -598,6 +713,7 @@ __global__ __launch_bounds__(64 * kAecWavesPerBlock) void aec_near_kernel(float 
         for (int i = lane; i < AS_LDS_WORDS / 4; i += 64) s4[i] = g4[i];
     }
     wave_sync();
+    AEC_PROF(10);
     for (int p = 0; p < n_packets; p++) {
         const AecPlan &pl = plans[p];
         if (!pl.has_near) continue;
@@ -626,6 +742,7 @@ __global__ __launch_bounds__(64 * kAecWavesPerBlock) void aec_near_kernel(float 
         }
     }
     wave_sync();
+    AEC_PROF(11);  // includes the blocks; subtract 0..9
     // ---- state out
 #pragma unroll
     for (int p = 0; p < 12; p++) {
@@ -638,7 +755,22 @@ __global__ __launch_bounds__(64 * kAecWavesPerBlock) void aec_near_kernel(float 
         const float4 *s4 = reinterpret_cast<const float4 *>(W.st);
         for (int i = lane; i < AS_LDS_WORDS / 4; i += 64) g4[i] = s4[i];
     }
+    AEC_PROF(12);
+#ifdef WMX_AEC_PROF
+    if (lane < 13) atomicAdd(&g_aec_prof[lane], W.prof[lane]);
+#endif
 }
+#ifdef WMX_AEC_PROF
+extern "C" int wmx_debug_aec_prof(unsigned long long *out16, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_aec_prof), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(g_aec_prof), z, sizeof(z));
+    }
+    return 0;
+}
+#endif
 
 __global__ void aec_fill_state(float *state, const float *tmpl, int words, int n_streams) {
     const size_t total = (size_t)words * n_streams;

@@ -158,11 +158,10 @@ __device__ __forceinline__ int dev_bitrev(int q, int bits) { return (int)(__brev
 // registers.  b = block index (twiddle class).  INV_CLOSE selects cftbsub's closing form.
 struct Cx { float r, i; };
 
-__device__ __forceinline__ void bfly4_store(float *a, int p0, int hc, int b, const FftTables *T, Cx A, Cx B, Cx C, Cx D) {
-    const int p1 = p0 + hc, p2 = p1 + hc, p3 = p2 + hc;
+__device__ __forceinline__ void bfly4(int b, const FftTables *T, Cx A, Cx B, Cx C, Cx D, float2 &o0, float2 &o1, float2 &o2,
+                                      float2 &o3) {
     const float x0r = A.r + B.r, x0i = A.i + B.i, x1r = A.r - B.r, x1i = A.i - B.i;
     const float x2r = C.r + D.r, x2i = C.i + D.i, x3r = C.r - D.r, x3i = C.i - D.i;
-    float2 o0, o1, o2, o3;
     o0.x = x0r + x2r;
     o0.y = x0i + x2i;
     if (b == 0) {
@@ -198,10 +197,35 @@ __device__ __forceinline__ void bfly4_store(float *a, int p0, int hc, int b, con
         o3.x = w3r * tr - w3i * ti;
         o3.y = w3r * ti + w3i * tr;
     }
+}
+
+__device__ __forceinline__ void bfly4_store(float *a, int p0, int hc, int b, const FftTables *T, Cx A, Cx B, Cx C, Cx D) {
+    const int p1 = p0 + hc, p2 = p1 + hc, p3 = p2 + hc;
+    float2 o0, o1, o2, o3;
+    bfly4(b, T, A, B, C, D, o0, o1, o2, o3);
     *reinterpret_cast<float2 *>(a + 2 * p0) = o0;
     *reinterpret_cast<float2 *>(a + 2 * p1) = o1;
     *reinterpret_cast<float2 *>(a + 2 * p2) = o2;
     *reinterpret_cast<float2 *>(a + 2 * p3) = o3;
+}
+
+// closing radix-4 without twiddles (fft4g.c:913-934 forward / 963-984 conjugating inverse)
+template <bool INVERSE>
+__device__ __forceinline__ void bfly4_close(Cx A, Cx B, Cx C, Cx D, float2 &o0, float2 &o1, float2 &o2, float2 &o3) {
+    const float x0r = A.r + B.r, x1r = A.r - B.r, x2r = C.r + D.r, x2i = C.i + D.i, x3r = C.r - D.r, x3i = C.i - D.i;
+    if constexpr (!INVERSE) {
+        const float x0i = A.i + B.i, x1i = A.i - B.i;
+        o0 = make_float2(x0r + x2r, x0i + x2i);
+        o2 = make_float2(x0r - x2r, x0i - x2i);
+        o1 = make_float2(x1r - x3i, x1i + x3r);
+        o3 = make_float2(x1r + x3i, x1i - x3r);
+    } else {
+        const float x0i = -A.i - B.i, x1i = -A.i + B.i;
+        o0 = make_float2(x0r + x2r, x0i - x2i);
+        o2 = make_float2(x0r - x2r, x0i + x2i);
+        o1 = make_float2(x1r - x3i, x1i - x3r);
+        o3 = make_float2(x1r + x3i, x1i + x3r);
+    }
 }
 
 __device__ __forceinline__ Cx ld_cx(const float *a, int p) {
@@ -258,29 +282,14 @@ __device__ __forceinline__ void fft_complex_passes(float *a, const FftTables *T,
     }
     constexpr int HC = (NC == 128) ? 64 : 16;  // stride of the closing pass
     if constexpr (HC * 4 == NC) {
-        // closing radix-4 without twiddles (fft4g.c:913-934 / 963-984)
         if (lane < HC) {  // HC == NC/4 <= GL
 #pragma unroll
             for (int r = 0; r < REP; r++) {
                 float *ar = a + r * rs;
                 const int p0 = lane, p1 = p0 + HC, p2 = p1 + HC, p3 = p2 + HC;
                 const Cx A = ld_cx(ar, p0), B = ld_cx(ar, p1), C = ld_cx(ar, p2), D = ld_cx(ar, p3);
-                const float x0r = A.r + B.r, x1r = A.r - B.r, x2r = C.r + D.r, x2i = C.i + D.i, x3r = C.r - D.r,
-                            x3i = C.i - D.i;
                 float2 o0, o1, o2, o3;
-                if constexpr (!INVERSE) {
-                    const float x0i = A.i + B.i, x1i = A.i - B.i;
-                    o0 = make_float2(x0r + x2r, x0i + x2i);
-                    o2 = make_float2(x0r - x2r, x0i - x2i);
-                    o1 = make_float2(x1r - x3i, x1i + x3r);
-                    o3 = make_float2(x1r + x3i, x1i - x3r);
-                } else {
-                    const float x0i = -A.i - B.i, x1i = -A.i + B.i;
-                    o0 = make_float2(x0r + x2r, x0i - x2i);
-                    o2 = make_float2(x0r - x2r, x0i + x2i);
-                    o1 = make_float2(x1r - x3i, x1i - x3r);
-                    o3 = make_float2(x1r + x3i, x1i + x3r);
-                }
+                bfly4_close<INVERSE>(A, B, C, D, o0, o1, o2, o3);
                 *reinterpret_cast<float2 *>(ar + 2 * p0) = o0;
                 *reinterpret_cast<float2 *>(ar + 2 * p1) = o1;
                 *reinterpret_cast<float2 *>(ar + 2 * p2) = o2;
