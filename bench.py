@@ -302,10 +302,12 @@ def main():
     value = frames_total / elapsed
     dom_ms = wl.dominant_ms()
     roofline = None
+    traffic, traffic_src = _pmc_traffic(wl.dominant_kernel, wl.n_frames)
     if dom_ms:
         achieved = wl.dominant_bytes_per_frame * wl.n_frames / (dom_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": wl.dominant_kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "traffic_source": traffic_src,
                     "avg_launch_ms": round(dom_ms, 5),
                     "algorithmic_bytes_per_launch": wl.dominant_bytes_per_frame * wl.n_frames}
     out = {
@@ -324,6 +326,30 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _pmc_traffic(kernel, n_frames):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/rNN/chain_hbm_pmc.json,
+    made by profiles/tools/profile_chain.sh: separate FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be read from inside this process, so the
+    figure is the one measured on the same command and stream count when the profile was taken; None if the
+    profile was taken at another size or is absent."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    for path in sorted(glob.glob(os.path.join(here, "profiles", "r*", "chain_hbm_pmc.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            if d.get("n_frames_per_launch") != n_frames:
+                continue
+            base = kernel.split("<")[0]
+            tot = 0
+            for c in ("FETCH_SIZE", "WRITE_SIZE"):
+                hit = [v for k, v in d[c].items() if k.split("<")[0] == base]
+                tot += hit[0]["bytes_per_dispatch_corrected"]
+            return tot, os.path.relpath(path, here)
+        except Exception:
+            continue
+    return None, None
 
 
 if __name__ == "__main__":

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Recipe behind profiles/rNN/chain_*: run on the GPU box as
+#   gpurun -- 'bash profiles/tools/profile_chain.sh r01'
+# Three separate rocprofv3 runs of the same bench command (kernel trace + stats; FETCH_SIZE pass; WRITE_SIZE
+# pass -- PMC passes carry --kernel-trace only, as the pool requires), summarised into gpurun_out/<round>/.
+set -u
+ROUND=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$ROUND
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+CMD="python3 $R/bench.py --no-cpu --steps 16 --warmup 2"
+rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o chain --output-format csv -- $CMD > "$OUT/bench_under_stats.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o chain --output-format csv -- $CMD > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -o chain --output-format csv -- $CMD > /dev/null 2>&1
+cd "$R"
+python3 profiles/tools/summarise.py "$OUT"
+python3 bench.py --steps 40 --warmup 8 > "$OUT/bench_line.json" 2> "$OUT/bench_stderr.log"
+tail -c 1500 "$OUT/bench_line.json"

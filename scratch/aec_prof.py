@@ -13,8 +13,8 @@ buf=(ctypes.c_ulonglong*16)()
 for k in range(nf):
     if k==16: f(buf,1)
     ab.process2(dfar[k:k+1],dn[:,k:k+1]); 
-f(buf,0); v=np.array(buf[:13],dtype=np.float64)
-names=['near fft+pow','filterfar+ifft','err fft+scale','adapt(12 fft x2)','partdelay','xfw+d/e fft+psd','sd/se sums','coh+hNl+scalars','overdrive+cn+ifft','ola+out','state in','(all pkts)','state out']
-tot=v[:10].sum()+v[10]+v[12]+ (v[11]-v[:10].sum())
+f(buf,0); v=np.array(buf[:16],dtype=np.float64)
+names=['near ring+d,dw fft','dpow+filterfar','y ifft+e,ew fft','scale+adapt','partdelay','xfw+psd','sd/se sums','coh+hNl+scalars','overdrive+cn','ifft+ola','state in','(all pkts)','state out','scale_err','pack','24 ffts']
+tot=v[10]+v[12]+v[11]
 for n,x in zip(names,v): print('%-20s %8.1f Mcyc %5.1f%%'%(n,x/1e6,100*x/tot))
-print('pcm io etc', (v[11]-v[:10].sum())/1e6)
+print('pcm io etc', (v[11]-v[:10].sum()-v[13:].sum())/1e6)
