@@ -9,11 +9,12 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$ROUND
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --no-cpu --steps 16 --warmup 2"
+STEPS=40
+CMD="python3 $R/bench.py --no-cpu --steps $STEPS --warmup 8"   # bench.py's defaults
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o chain --output-format csv -- $CMD > "$OUT/bench_under_stats.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o chain --output-format csv -- $CMD > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -o chain --output-format csv -- $CMD > /dev/null 2>&1
 cd "$R"
-python3 profiles/tools/summarise.py "$OUT"
+python3 profiles/tools/summarise.py "$OUT" 65536 $STEPS
 python3 bench.py --steps 40 --warmup 8 > "$OUT/bench_line.json" 2> "$OUT/bench_stderr.log"
 tail -c 1500 "$OUT/bench_line.json"

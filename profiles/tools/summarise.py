@@ -28,6 +28,28 @@ if stats:
         for r in rows:
             w.writerow([kname(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["Percentage"]])
 
+# The bench's timed region is its last `steps` launches of every kernel (the launches before are warm-up and, for the
+# AEC, its start-up packets, which pass the signal through: echo_cancellation.c:651-657): average those separately,
+# that is the figure bench.py's HIP events must agree with.
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+trace = glob.glob(out + "/stats/**/*kernel_trace.csv", recursive=True)
+if trace:
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(trace[0])):
+        per[kname(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r))
+    with open(out + "/chain_timed_region.csv", "w") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "launches_in_timed_region", "avg_ns", "min_ns", "max_ns", "vgpr", "lds_bytes", "scratch_bytes", "workgroup", "grid"])
+        for k, v in per.items():
+            if "_kernel" not in k or len(v) < steps:
+                continue
+            v.sort(key=lambda t: t[0])
+            last = v[-steps:]
+            d = [t[1] for t in last]
+            r = last[-1][2]
+            w.writerow([k, len(d), round(sum(d) / len(d)), min(d), max(d), r["VGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"],
+                        r["Workgroup_Size_X"], r["Grid_Size_X"]])
+
 pmc = {}
 for cname, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     acc = collections.defaultdict(list)

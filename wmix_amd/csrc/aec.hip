@@ -207,6 +207,11 @@ struct AecTaps {
     float re[12], im[12];
 };
 
+__device__ __forceinline__ int opaque_lane(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 // One 128-point real transform per 16-lane group, data in registers (fft_regs.h).  `src(p)` supplies complex
 // point p of the time-domain input; the result of the complex passes goes to `row` (natural order), where
 // rdft128_fwd_bin() finishes the real split for whoever reads a bin.
@@ -230,12 +235,22 @@ __device__ __forceinline__ void aec_fft_inv(const float *row, const FftTables *T
 
 template <int MULT>  // 1: 8 kHz, 2: 16 kHz
 __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, AecTaps &taps, const AecFarBufs &F, const AecBlkPlan &bp,
-                                          const int lane) {
+                                          const int lane_in) {
+    // The lane-derived LDS addresses (gather points, twiddle and window slots) are loop invariant; left alone the
+    // compiler hoists ~100 of them out of the packet loop and pins them in VGPRs for the whole kernel.  Recomputing
+    // them per block costs a few VALU ops and frees the registers.
+    int lane = opaque_lane(lane_in);
     int *Si = reinterpret_cast<int *>(W.st) - AS_LDS0;
     const float mu = MULT == 1 ? 0.6f : 0.5f, err_thr = MULT == 1 ? 2e-6f : 1.5e-6f;  // aec_core.c:1530-1538
     const float scale = 2.0f / 128;
     const int n = bp.hist_n;
-    const int g = lane >> 4, gl = lane & 15;
+    int g = lane >> 4, gl = lane & 15;
+#define AEC_RELANE()              \
+    do {                          \
+        lane = opaque_lane(lane); \
+        g = lane >> 4;            \
+        gl = lane & 15;           \
+    } while (0)
     // NLP scratch rows (free outside the filter update)
     float *xw = W.fa[4], *dw = W.fa[5], *ew = W.fa[6];  // re at [b], im at [66 + b]
     float *t0 = W.fa[8], *t1 = W.fa[9], *t2 = W.fa[10], *t3 = W.fa[11];
@@ -264,6 +279,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
     }
     wave_sync();
     AEC_PROF(0);
+    AEC_RELANE();
     // windowed near spectrum, kept in registers across the filter update (bin = lane; lane 0 also bin 64)
     float dwr, dwi, dw64 = 0.f, dum;
     rdft128_fwd_bin(W.fa[1], &K.tab, lane, dwr, dwi);
@@ -316,6 +332,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
     }
     wave_sync();
     AEC_PROF(1);
+    AEC_RELANE();
     // ---- error e = d - y (aec_core.c:1286-1297): the second half of the inverse transform is points 32..63
     if (g == 0) {
         Cx v[4];
@@ -328,6 +345,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
         }
     }
     wave_sync();
+    AEC_RELANE();
     // ---- ef = rdft([0 | e]) (aec_core.c:1299-1309) and the windowed rdft([eprev | e] * w) of the NLP
     if (g < 2) {
         const bool win = g == 1;
@@ -344,6 +362,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
     }
     wave_sync();
     AEC_PROF(2);
+    AEC_RELANE();
     float ewr, ewi, ew64 = 0.f;
     rdft128_fwd_bin(W.fa[3], &K.tab, lane, ewr, ewi);
     if (lane == 0) rdft128_fwd_bin(W.fa[3], &K.tab, kAecPart, ew64, dum);
@@ -368,6 +387,8 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
         if (lane == 0) scale_err(kAecPart, ef64r, ef64i);
     }
     wave_sync();  // rows 2, 3 are read; the filter update overwrites all twelve
+    AEC_PROF(13);
+    AEC_RELANE();
     // ---- FilterAdaptation (aec_core.c:222-270): conj(X_{n-p}) * ef -> time domain, zero the second half,
     //      back to frequency, add to partition p.  Four groups of 16 lanes, three partitions each (p = 4r + g).
     {
@@ -385,29 +406,32 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
         }
     }
     wave_sync();
+    AEC_PROF(14);
+    AEC_RELANE();
     {
-        Cx v[3][4];
-#pragma unroll
-        for (int r = 0; r < 3; r++) aec_fft_inv(W.fa[4 * r + g], &K.tab, gl, v[r]);
-        // points 0..31 (m = 0, 1) scaled, points 32..63 zeroed; the forward gather wants points
-        // rev4(gl) + {0, 32, 16, 48}: two of them from lane rev4(gl), two zeros
-#pragma unroll
+        // one partition at a time per group: each lane reads its (and its mirror's) points of row 4r + g before any
+        // lane of the group stores to it
+#pragma unroll 1
         for (int r = 0; r < 3; r++) {
-            const Cx a = Cx{row_bitrev(v[r][0].r * scale, lane), row_bitrev(v[r][0].i * scale, lane)};
-            const Cx c = Cx{row_bitrev(v[r][1].r * scale, lane), row_bitrev(v[r][1].i * scale, lane)};
-            v[r][0] = a;
-            v[r][1] = Cx{0.f, 0.f};
-            v[r][2] = c;
-            v[r][3] = Cx{0.f, 0.f};
-            fft64_regs<false>(v[r], &K.tab, gl);
+            float *row = W.fa[4 * r + g];
+            Cx v[4];
+            aec_fft_inv(row, &K.tab, gl, v);
+            // points 0..31 (m = 0, 1) scaled, points 32..63 zeroed; the forward gather wants points
+            // rev4(gl) + {0, 32, 16, 48}: two of them from lane rev4(gl), two zeros
+            const Cx a = Cx{row_bitrev(v[0].r * scale, lane), row_bitrev(v[0].i * scale, lane)};
+            const Cx c = Cx{row_bitrev(v[1].r * scale, lane), row_bitrev(v[1].i * scale, lane)};
+            v[0] = a;
+            v[1] = Cx{0.f, 0.f};
+            v[2] = c;
+            v[3] = Cx{0.f, 0.f};
+            fft64_regs<false>(v, &K.tab, gl);
+#pragma unroll
+            for (int m = 0; m < 4; m++) *reinterpret_cast<float2 *>(row + 2 * (gl + 16 * m)) = make_float2(v[m].r, v[m].i);
         }
-#pragma unroll
-        for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int m = 0; m < 4; m++)
-                *reinterpret_cast<float2 *>(W.fa[4 * r + g] + 2 * (gl + 16 * m)) = make_float2(v[r][m].r, v[r][m].i);
     }
     wave_sync();
+    AEC_PROF(15);
+    AEC_RELANE();
 #pragma unroll
     for (int p = 0; p < 12; p++) {
         float re, im;
@@ -423,6 +447,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
     wave_sync();
     AEC_PROF(3);
 
+    AEC_RELANE();
     // ================================================= NonLinearProcessing (aec_core.c:911-1141)
     constexpr int prefSize = 24 / MULT, minPref = 4 / MULT;
     const float gc0 = MULT == 1 ? 0.9f : 0.93f, gc1 = MULT == 1 ? 0.1f : 0.07f;  // kNormalSmoothingCoefficients
@@ -506,6 +531,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
         }
     }
     AEC_PROF(6);
+    AEC_RELANE();
     // coherences (aec_core.c:440-449)
     for (int b = lane; b < kAecPart1; b += 64) {
         if (diverge) {
@@ -619,6 +645,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
         Si[AS_HNLMINCTR] = hNlMinCtr;
     }
     AEC_PROF(7);
+    AEC_RELANE();
     // OverdriveAndSuppress (aec_core.c:272-293) + ComfortNoise (:462-547) + packing for the inverse transform
     const int noise_off = (bp.flags & kAecFlagNoiseInit) ? AS_DINIT : AS_DMIN;
     for (int b = lane; b < kAecPart1; b += 64) {
@@ -650,6 +677,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
     }
     wave_sync();
     AEC_PROF(8);
+    AEC_RELANE();
     // inverse transform, overlap-add with the sqrt-Hanning window, saturate, queue 64 output samples
     // (aec_core.c:1089-1101, 1341): points 0..31 are the first half, 32..63 the new overlap tail
     if (g == 0) {
@@ -675,10 +703,11 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
     AEC_ST(AS_EPREV + lane) = W.enew[lane];
     wave_sync();
     AEC_PROF(9);
+#undef AEC_RELANE
 }
 
 template <int MULT>
-__global__ __launch_bounds__(64 * kAecWavesPerBlock) void aec_near_kernel(float *__restrict__ state, AecFarBufs F,
+__global__ __launch_bounds__(64 * kAecWavesPerBlock, 3) void aec_near_kernel(float *__restrict__ state, AecFarBufs F,
                                                                           const float *__restrict__ consts_g,
                                                                           const AecPlan *__restrict__ plans, int n_packets,
                                                                           const int16_t *near_pcm, int16_t *out_pcm, int n_streams,
@@ -743,7 +772,8 @@ __global__ __launch_bounds__(64 * kAecWavesPerBlock) void aec_near_kernel(float 
     }
     wave_sync();
     AEC_PROF(11);  // includes the blocks; subtract 0..9
-    // ---- state out
+    // ---- state out (addresses recomputed: keeping the ones of the load alive across the packet loop costs 17 VGPRs)
+    asm volatile("" : "+v"(gst));
 #pragma unroll
     for (int p = 0; p < 12; p++) {
         gst[AS_W_RE + p * BP + lane] = taps.re[p];
@@ -757,7 +787,7 @@ __global__ __launch_bounds__(64 * kAecWavesPerBlock) void aec_near_kernel(float 
     }
     AEC_PROF(12);
 #ifdef WMX_AEC_PROF
-    if (lane < 13) atomicAdd(&g_aec_prof[lane], W.prof[lane]);
+    if (lane < 16) atomicAdd(&g_aec_prof[lane], W.prof[lane]);
 #endif
 }
 #ifdef WMX_AEC_PROF
