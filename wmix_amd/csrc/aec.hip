@@ -719,7 +719,8 @@ __global__ __launch_bounds__(64 * kAecWavesPerBlock, 3) void aec_near_kernel(flo
         for (int i = threadIdx.x; i < kAecConstWords; i += blockDim.x) dst[i] = consts_g[i];
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: state pointers become scalar bases
     const int sidx = blockIdx.x * kAecWavesPerBlock + wave;  // one stream per wave; no block-level barrier below
     if (sidx >= n_streams) return;
     AecWaveLds &W = Wv[wave];

@@ -104,8 +104,13 @@ __device__ __forceinline__ float sum_range(const float *x, int lo, int hi, int l
 
 template <int L, bool ORDERED>
 __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restrict__ st, unsigned short *__restrict__ hist,
-                         const int16_t *in, int16_t *out, const int chn, const int pkg, const int lane) {
+                         const int16_t *in, int16_t *out, const int chn, const int pkg, const int lane_in) {
     using Y = NsLayout<L>;
+    // Lane-derived addresses are loop invariant; left alone the compiler hoists them out of the packet loop and
+    // keeps them in VGPRs for the whole kernel.  Re-deriving them per phase is a few VALU ops and frees the registers.
+    int lane = lane_in;
+#define NS_RELANE() asm volatile("" : "+v"(lane))
+    NS_RELANE();
     constexpr int M = Y::M, B = Y::B, NT = L / 64, NC = L / 2;
     int *sti = reinterpret_cast<int *>(st);
     float *tdst = W.r0;  // L floats spanning r0..r1
@@ -151,8 +156,10 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         const bool startup = block_ind < kStartupShort;
         const float overdrive = 1.1f, denoise_bound = 0.125f;  // policy 2, ns_core.c:1030-1033
 
+        NS_RELANE();
         rdft_forward<NC>(W.fa, &K.tab, lane);
 
+        NS_RELANE();
         // ---- spectrum, magnitude, log-magnitude (FFT() ns_core.c:886-911; :228, :1095)
 #pragma unroll 1
         for (int b = lane; b < M; b += 64) {
@@ -193,6 +200,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         wave_sync();
         signal_energy = signal_energy / ((float)M);
 
+        NS_RELANE();
         // ---- NoiseEstimation (ns_core.c:217-285)
         int updates = sti[Y::S_UPDATES];
         if (updates < kStartupLong) updates++;
@@ -232,6 +240,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         sti[Y::S_COUNTER + 1] = cnt1 >= kStartupLong ? 1 : cnt1 + 1;
         sti[Y::S_COUNTER + 2] = cnt2 >= kStartupLong ? 1 : cnt2 + 1;
 
+        NS_RELANE();
         // ---- start-up white/pink parametric noise model (ns_core.c:1108-1160); parametricNoise kept in r1
         if (startup) {
             const float white = st[Y::S_WHITE] + sum_magn / ((float)M) * overdrive;
@@ -283,6 +292,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             feat_norm /= (float)(block_ind + 1);
         }
 
+        NS_RELANE();
         // ---- ComputeSnr (ns_core.c:566-588); prev is reused by the Wiener filter (:996).  Same loop: the terms of
         //      the spectral-difference sums (ns_core.c:612-620), which need avg_pause / avg_magn only.
         avg_pause = avg_pause / ((float)M);
@@ -439,6 +449,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         st[Y::S_FEAT_NORM] = feat_norm;
         st[Y::S_FEAT_ACC] = feat_acc;
 
+        NS_RELANE();
         // ---- SpeechNoiseProb (ns_core.c:642-749)
 #pragma unroll 1
         for (int b = lane; b < M; b += 64) {
@@ -481,6 +492,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             W.sprob[b] = 1.f / (1.f + inv);
         }
         wave_sync();
+        NS_RELANE();
         // ---- UpdateNoiseEstimate (ns_core.c:800-846): bin i starts from the gamma chosen at bin i-1.
         //      Then Process: initMagnEst, DD Wiener filter + flooring / start-up blend (ns_core.c:1277-1315), IFFT packing.
 #pragma unroll 1
@@ -540,6 +552,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             }
         }
         wave_sync();
+        NS_RELANE();
         rdft_inverse<NC>(W.fa, &K.tab, lane);
         float td[NT];
 #pragma unroll
@@ -591,6 +604,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         wave_sync();
     }
 
+        NS_RELANE();
     // ---- read out the finished segment, slide the synthesis buffer (ns_core.c:1245-1251 / 1347-1359)
 #pragma unroll
     for (int k = 0; k < NT; k++) {
@@ -615,12 +629,13 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         if (chn == 2) out[i * chn + 1] = (int16_t)((i < B) ? W.fa[i] : 0.f);
     }
     wave_sync();
+#undef NS_RELANE
 }
 
 constexpr int kNsWavesPerBlock = 4;
 
 template <int L, bool ORDERED>
-__global__ __launch_bounds__(64 * kNsWavesPerBlock, 2) void ns_kernel(float *__restrict__ state, unsigned short *__restrict__ hists,
+__global__ __launch_bounds__(64 * kNsWavesPerBlock, 4) void ns_kernel(float *__restrict__ state, unsigned short *__restrict__ hists,
                                                                       const float *__restrict__ consts, const int16_t *in, int16_t *out,
                                                                       int n_streams, int n_packets, long stream_stride,
                                                                       long packet_stride, int chn, int pkg) {
@@ -634,7 +649,8 @@ __global__ __launch_bounds__(64 * kNsWavesPerBlock, 2) void ns_kernel(float *__r
         for (int i = threadIdx.x; i < NCONST; i += blockDim.x) dst[i] = consts[i];
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: state pointers become scalar bases
     const int sidx = blockIdx.x * kNsWavesPerBlock + wave;  // one stream per wave; no block-level barrier below
     if (sidx >= n_streams) return;
     float *st = state + (size_t)sidx * Y::WORDS;
