@@ -31,6 +31,7 @@
 #include "wmx_internal.h"
 #include "aec_ctl.h"
 #include "fft_regs.h"
+#include "libm_dev.h"
 
 namespace wmx {
 namespace {
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F, const float *
 }
 
 // ================================================================== near-end kernel
-constexpr int kAecWavesPerBlock = 4;
+constexpr int kAecWavesPerBlock = 8;
 #ifdef WMX_AEC_PROF  // developer build only (make EXTRA=-DWMX_AEC_PROF): cycles per phase of aec_block, summed over waves
 __device__ unsigned long long g_aec_prof[16];
 #define AEC_PROF(i)                                                              \
@@ -192,9 +193,9 @@ constexpr int FAS = 132;                        // floats per FFT work row (128 
 
 struct alignas(16) AecWaveLds {
     float st[AS_LDS_WORDS];  // per-bin PSDs, time-domain tails, rings, scalars (indexed AS_x - AS_LDS0)
-    float wn[16];            // wfBuf[0][p][64]: the Nyquist column of the filter (the other 64 bins live in registers)
-    float fa[12][FAS];       // FFT work rows: 12 at once in the filter update; rows 4..11 double as NLP scratch
-    float ef_re[BP], ef_im[BP];
+    float wn[32];            // [0..11] wfBuf[0][p][64], the Nyquist column of the filter (the other 64 bins live in
+                             // registers); [16..27] partition energies of PartitionDelay
+    float fa[8][FAS];        // work rows: spectra handed to / from the register FFTs; rows 1..7 double as NLP scratch
     float cur[64], enew[64];
 #ifdef WMX_AEC_PROF
     unsigned long long prof[16];
@@ -252,8 +253,8 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
         gl = lane & 15;           \
     } while (0)
     // NLP scratch rows (free outside the filter update)
-    float *xw = W.fa[4], *dw = W.fa[5], *ew = W.fa[6];  // re at [b], im at [66 + b]
-    float *t0 = W.fa[8], *t1 = W.fa[9], *t2 = W.fa[10], *t3 = W.fa[11];
+    float *xw = W.fa[1], *dw = W.fa[2], *ew = W.fa[3];  // re at [b], im at [66 + b]
+    float *t0 = W.fa[4], *t1 = W.fa[5], *t2 = W.fa[6], *t3 = W.fa[7];
     AEC_PROF_START;
 
     // ---- near block (aec_core.c:1177-1195).  d = [prev | cur]; its plain transform feeds the near power, its
@@ -387,13 +388,17 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
         if (lane == 0) scale_err(kAecPart, ef64r, ef64i);
     }
     wave_sync();  // rows 2, 3 are read; the filter update overwrites all twelve
-    AEC_PROF(13);
     AEC_RELANE();
     // ---- FilterAdaptation (aec_core.c:222-270): conj(X_{n-p}) * ef -> time domain, zero the second half,
-    //      back to frequency, add to partition p.  Four groups of 16 lanes, three partitions each (p = 4r + g).
-    {
+    //      back to frequency, add to partition p.  Four groups of 16 lanes; partitions 0..7 first (two per group),
+    //      then 8..11, through the same eight work rows.
 #pragma unroll
-        for (int p = 0; p < 12; p++) {
+    for (int pass = 0; pass < 2; pass++) {
+        const int base = 8 * pass, cnt = pass == 0 ? 8 : 4;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            if (q >= cnt) continue;
+            const int p = base + q;
             const float *X = F.hist + (size_t)((n - p + kAecHist) % kAecHist) * 130;
             const float xr = X[lane], xi = -X[kAecPart1 + lane];
             float v1 = xr * efi + xi * efr;
@@ -401,18 +406,15 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
                 const float nr = X[kAecPart], ni = -X[kAecPart1 + kAecPart];
                 v1 = nr * ef64r - ni * ef64i;
             }
-            W.fa[p][2 * lane] = xr * efr - xi * efi;
-            W.fa[p][2 * lane + 1] = v1;
+            W.fa[q][2 * lane] = xr * efr - xi * efi;
+            W.fa[q][2 * lane + 1] = v1;
         }
-    }
-    wave_sync();
-    AEC_PROF(14);
-    AEC_RELANE();
-    {
+        wave_sync();
+        AEC_RELANE();
         // one partition at a time per group: each lane reads its (and its mirror's) points of row 4r + g before any
         // lane of the group stores to it
 #pragma unroll 1
-        for (int r = 0; r < 3; r++) {
+        for (int r = 0; r < cnt / 4; r++) {
             float *row = W.fa[4 * r + g];
             Cx v[4];
             aec_fft_inv(row, &K.tab, gl, v);
@@ -428,23 +430,24 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
 #pragma unroll
             for (int m = 0; m < 4; m++) *reinterpret_cast<float2 *>(row + 2 * (gl + 16 * m)) = make_float2(v[m].r, v[m].i);
         }
-    }
-    wave_sync();
-    AEC_PROF(15);
-    AEC_RELANE();
+        wave_sync();
+        AEC_RELANE();
 #pragma unroll
-    for (int p = 0; p < 12; p++) {
-        float re, im;
-        rdft128_fwd_bin(W.fa[p], &K.tab, lane, re, im);
-        taps.re[p] += re;
-        if (lane == 0) {
-            rdft128_fwd_bin(W.fa[p], &K.tab, kAecPart, re, im);
-            W.wn[p] += re;
-        } else {
-            taps.im[p] += im;
+        for (int q = 0; q < 8; q++) {
+            if (q >= cnt) continue;
+            const int p = base + q;
+            float re, im;
+            rdft128_fwd_bin(W.fa[q], &K.tab, lane, re, im);
+            taps.re[p] += re;
+            if (lane == 0) {
+                rdft128_fwd_bin(W.fa[q], &K.tab, kAecPart, re, im);
+                W.wn[p] += re;
+            } else {
+                taps.im[p] += im;
+            }
         }
+        wave_sync();
     }
-    wave_sync();
     AEC_PROF(3);
 
     AEC_RELANE();
@@ -454,23 +457,26 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
     // PartitionDelay (aec_core.c:295-319) every 10*mult blocks: per-partition ordered energy sums
     int delayIdx = Si[AS_DELAYIDX];
     if (bp.flags & kAecFlagDelayEst) {
+        // two partitions per work row: [0..64] and [66..130]
 #pragma unroll
         for (int p = 0; p < 12; p++) {
-            W.fa[p][lane] = taps.re[p] * taps.re[p] + taps.im[p] * taps.im[p];
-            if (lane == 0) W.fa[p][64] = W.wn[p] * W.wn[p] + 0.f * 0.f;
+            float *dst = W.fa[p >> 1] + (p & 1) * 66;
+            dst[lane] = taps.re[p] * taps.re[p] + taps.im[p] * taps.im[p];
+            if (lane == 0) dst[64] = W.wn[p] * W.wn[p] + 0.f * 0.f;
         }
         wave_sync();
         if (lane < 12) {
+            const float *src = W.fa[lane >> 1] + (lane & 1) * 66;
             float en = 0.f;
-            for (int j = 0; j < kAecPart1; j++) en += W.fa[lane][j];
-            W.ef_re[BP - 1 - lane] = en;  // 12 spare floats at the tail of the padded rows
+            for (int j = 0; j < kAecPart1; j++) en += src[j];
+            W.wn[16 + lane] = en;
         }
         wave_sync();
         float best = 0.f;
         delayIdx = 0;
         for (int p = 0; p < 12; p++)
-            if (W.ef_re[BP - 1 - p] > best) {
-                best = W.ef_re[BP - 1 - p];
+            if (W.wn[16 + p] > best) {
+                best = W.wn[16 + p];
                 delayIdx = p;
             }
         wave_sync();
@@ -625,7 +631,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
     if (hNlMinCtr == 2) {
         hNlNewMin = 0;
         hNlMinCtr = 0;
-        const float od = -18.4f / ((float)log((double)(hNlFbMin + 1e-10f)) + 1e-10f);  // kTargetSupp[2]
+        const float od = -18.4f / (log_d(hNlFbMin + 1e-10f) + 1e-10f);  // kTargetSupp[2]
         overDrive = od > 5.0f ? od : 5.0f;
     }
     if (overDrive < overDriveSm)
@@ -652,7 +658,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
         float h = t2[b];
         const float wc = K.weight[b];
         if (h > hNlFb) h = wc * hNlFb + (1 - wc) * h;
-        h = (float)pow((double)h, (double)(overDriveSm * K.overdrive[b]));
+        h = pow_d(h, overDriveSm * K.overdrive[b]);
         float er = ew[b] * h, ei = ew[66 + b] * h;
         ei *= -1;
         float ur = 0.f, ui = 0.f;
@@ -667,12 +673,12 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
         er += tmp * ur;
         ei += tmp * ui;
         if (b == 0)
-            W.fa[3][0] = er;
+            W.fa[0][0] = er;
         else if (b == kAecPart)
-            W.fa[3][1] = er;
+            W.fa[0][1] = er;
         else {
-            W.fa[3][2 * b] = er;
-            W.fa[3][2 * b + 1] = -ei;
+            W.fa[0][2 * b] = er;
+            W.fa[0][2 * b + 1] = -ei;
         }
     }
     wave_sync();
@@ -682,7 +688,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
     // (aec_core.c:1089-1101, 1341): points 0..31 are the first half, 32..63 the new overlap tail
     if (g == 0) {
         Cx v[4];
-        aec_fft_inv(W.fa[3], &K.tab, gl, v);
+        aec_fft_inv(W.fa[0], &K.tab, gl, v);
         float o[4];
 #pragma unroll
         for (int m = 0; m < 2; m++) {
@@ -707,7 +713,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
 }
 
 template <int MULT>
-__global__ __launch_bounds__(64 * kAecWavesPerBlock, 3) void aec_near_kernel(float *__restrict__ state, AecFarBufs F,
+__global__ __launch_bounds__(64 * kAecWavesPerBlock, 2) void aec_near_kernel(float *__restrict__ state, AecFarBufs F,
                                                                           const float *__restrict__ consts_g,
                                                                           const AecPlan *__restrict__ plans, int n_packets,
                                                                           const int16_t *near_pcm, int16_t *out_pcm, int n_streams,
