@@ -60,7 +60,21 @@ struct alignas(16) NsWaveLds {
     // over the wave's 2-3 bins per lane, which keeps the kernel at <= 128 VGPRs = 4 waves per SIMD)
     float re[MP], im[MP], magn[MP], lmagn[MP], noise[MP], prev[MP], snrp[MP], snrq[MP], sprob[MP], nprev[MP], pause[MP];
     float r0[MP], r1[MP], r2[MP];  // staging of terms for the ordered sums; r0..r1 double as a L-float time-domain stage
+#ifdef WMX_NS_PROF
+    unsigned long long prof[16];
+#endif
 };
+#ifdef WMX_NS_PROF  // developer build only (make EXTRA=-DWMX_NS_PROF): cycles per phase of ns_frame, summed over waves
+__device__ unsigned long long g_ns_prof[16];
+#define NS_PROF(i)                                                         \
+    do {                                                                   \
+        const long long t_now = clock64();                                 \
+        if (lane == 0) W.prof[i] += (unsigned long long)(t_now - t_prev);  \
+        t_prev = clock64();                                                \
+    } while (0)
+#else
+#define NS_PROF(i)
+#endif
 static_assert(2 * NsLayout<256>::MP >= 256 && 2 * NsLayout<128>::MP >= 128, "r0..r1 must hold L floats");
 
 __device__ __forceinline__ float sat16f(float v) { return v > 32767.f ? 32767.f : (v < -32768.f ? -32768.f : v); }
@@ -102,6 +116,31 @@ __device__ __forceinline__ float sum_range(const float *x, int lo, int hi, int l
     }
 }
 
+// Several ordered sums at once: lane k (k < n) adds the MP4*4 floats at its own pointer in index order, all chains
+// advancing in the same instructions; sum k is then read from lane k.  The arrays are zero outside the reference's
+// summation range (x + 0.0f == x), so every chain runs the same full length.
+template <int MP4>
+__device__ __forceinline__ float sum_lanes(const float *mine) {
+    float acc = 0.f;
+#pragma unroll 1
+    for (int i = 0; i < MP4; i += 2) {
+        const float4 a = *reinterpret_cast<const float4 *>(mine + 4 * i);
+        acc += a.x;
+        acc += a.y;
+        acc += a.z;
+        acc += a.w;
+        if (i + 1 < MP4) {
+            const float4 b = *reinterpret_cast<const float4 *>(mine + 4 * i + 4);
+            acc += b.x;
+            acc += b.y;
+            acc += b.z;
+            acc += b.w;
+        }
+    }
+    return acc;
+}
+__device__ __forceinline__ float lane_value(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
+
 template <int L, bool ORDERED>
 __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restrict__ st, unsigned short *__restrict__ hist,
                          const int16_t *in, int16_t *out, const int chn, const int pkg, const int lane_in) {
@@ -111,6 +150,9 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
     int lane = lane_in;
 #define NS_RELANE() asm volatile("" : "+v"(lane))
     NS_RELANE();
+#ifdef WMX_NS_PROF
+    long long t_prev = clock64();
+#endif
     constexpr int M = Y::M, B = Y::B, NT = L / 64, NC = L / 2;
     int *sti = reinterpret_cast<int *>(st);
     float *tdst = W.r0;  // L floats spanning r0..r1
@@ -144,6 +186,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
     wave_sync();
     const float energy1 = sum_range<ORDERED>(tdst, 0, L, lane);
     wave_sync();
+    NS_PROF(0);
 
     float hb_gain = 1.f;
     const bool zero_frame = (energy1 == 0.0f);
@@ -158,6 +201,8 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
 
         NS_RELANE();
         rdft_forward<NC>(W.fa, &K.tab, lane);
+        if (lane < Y::MP - M) W.r0[M + lane] = 0.f;  // the window-energy stage above spilled into r0's zero tail
+        NS_PROF(1);
 
         NS_RELANE();
         // ---- spectrum, magnitude, log-magnitude (FFT() ns_core.c:886-911; :228, :1095)
@@ -183,21 +228,39 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             W.lmagn[b] = lm;
             W.pause[b] = pz;
             W.r0[b] = re * re + im * im;
-            W.r1[b] = K.logi[b] * lm;
+            W.r1[b] = b >= kStartBand ? K.logi[b] * lm : 0.f;  // terms of the start-up sums (i >= 5, ns_core.c:1092)
+            W.r2[b] = b >= 1 ? lm : 0.f;                       // spectral flatness skips bin 0 (ns_core.c:540)
+            W.snrp[b] = b >= kStartBand ? lm : 0.f;            // snrp is free until ComputeSnr
         }
         wave_sync();
+        NS_PROF(2);
         // ordered reductions over the bins (ns_core.c:1089-1101, :540, :608)
-        float signal_energy = sum_range<ORDERED>(W.r0, 0, M, lane);
-        const float sum_magn = sum_range<ORDERED>(W.magn, 0, M, lane);
-        const float flat_num = sum_range<ORDERED>(W.lmagn, 1, M, lane);
-        float avg_pause = sum_range<ORDERED>(W.pause, 0, M, lane);
-        float sum_log_magn = 0.f, sum_log_i_log_magn = 0.f;
-        if (startup) {
-            sum_log_magn = sum_range<ORDERED>(W.lmagn, kStartBand, M, lane);
-            sum_log_i_log_magn = sum_range<ORDERED>(W.r1, kStartBand, M, lane);
+        float signal_energy, sum_magn, flat_num, avg_pause, sum_log_magn = 0.f, sum_log_i_log_magn = 0.f;
+        if constexpr (ORDERED) {
+            const float *mine =
+                lane == 1 ? W.magn : (lane == 2 ? W.r2 : (lane == 3 ? W.pause : (lane == 4 ? W.snrp : (lane == 5 ? W.r1 : W.r0))));
+            const float acc = sum_lanes<Y::MP / 4>(mine);
+            signal_energy = lane_value(acc, 0);
+            sum_magn = lane_value(acc, 1);
+            flat_num = lane_value(acc, 2);
+            avg_pause = lane_value(acc, 3);
+            if (startup) {
+                sum_log_magn = lane_value(acc, 4);
+                sum_log_i_log_magn = lane_value(acc, 5);
+            }
+        } else {
+            signal_energy = sum_range<ORDERED>(W.r0, 0, M, lane);
+            sum_magn = sum_range<ORDERED>(W.magn, 0, M, lane);
+            flat_num = sum_range<ORDERED>(W.r2, 0, M, lane);
+            avg_pause = sum_range<ORDERED>(W.pause, 0, M, lane);
+            if (startup) {
+                sum_log_magn = sum_range<ORDERED>(W.snrp, 0, M, lane);
+                sum_log_i_log_magn = sum_range<ORDERED>(W.r1, 0, M, lane);
+            }
         }
         const float magn0 = W.magn[0];
         wave_sync();
+        NS_PROF(3);
         signal_energy = signal_energy / ((float)M);
 
         NS_RELANE();
@@ -241,6 +304,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         sti[Y::S_COUNTER + 2] = cnt2 >= kStartupLong ? 1 : cnt2 + 1;
 
         NS_RELANE();
+        NS_PROF(4);
         // ---- start-up white/pink parametric noise model (ns_core.c:1108-1160); parametricNoise kept in r1
         if (startup) {
             const float white = st[Y::S_WHITE] + sum_magn / ((float)M) * overdrive;
@@ -314,6 +378,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             W.lmagn[b] = dm * dm;  // lmagn is dead from here on
         }
         wave_sync();
+        NS_PROF(5);
         // ---- FeatureUpdate: spectral flatness (ns_core.c:523-556), difference (:595-634)
         float feat_flat = st[Y::S_FEAT_FLAT];
         {
@@ -324,10 +389,19 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             const float tmp = (float)exp((double)num) / den;
             feat_flat += 0.3f * (tmp - feat_flat);
         }
-        float cov = sum_range<ORDERED>(W.r0, 0, M, lane);
-        float var_pause = sum_range<ORDERED>(W.r2, 0, M, lane);
-        float var_magn = sum_range<ORDERED>(W.lmagn, 0, M, lane);
+        float cov, var_pause, var_magn;
+        if constexpr (ORDERED) {
+            const float acc = sum_lanes<Y::MP / 4>(lane == 1 ? W.r2 : (lane == 2 ? W.lmagn : W.r0));
+            cov = lane_value(acc, 0);
+            var_pause = lane_value(acc, 1);
+            var_magn = lane_value(acc, 2);
+        } else {
+            cov = sum_range<ORDERED>(W.r0, 0, M, lane);
+            var_pause = sum_range<ORDERED>(W.r2, 0, M, lane);
+            var_magn = sum_range<ORDERED>(W.lmagn, 0, M, lane);
+        }
         wave_sync();
+        NS_PROF(6);
         cov = cov / ((float)M);
         var_pause = var_pause / ((float)M);
         var_magn = var_magn / ((float)M);
@@ -463,6 +537,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             W.r0[b] = v;
         }
         wave_sync();
+        NS_PROF(7);
         float ksum = sum_range<ORDERED>(W.r0, 0, M, lane);
         ksum = ksum / (float)(M);
         feat_lrt = ksum;
@@ -492,6 +567,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             W.sprob[b] = 1.f / (1.f + inv);
         }
         wave_sync();
+        NS_PROF(8);
         NS_RELANE();
         // ---- UpdateNoiseEstimate (ns_core.c:800-846): bin i starts from the gamma chosen at bin i-1.
         //      Then Process: initMagnEst, DD Wiener filter + flooring / start-up blend (ns_core.c:1277-1315), IFFT packing.
@@ -552,8 +628,10 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             }
         }
         wave_sync();
+        NS_PROF(9);
         NS_RELANE();
         rdft_inverse<NC>(W.fa, &K.tab, lane);
+        NS_PROF(10);
         float td[NT];
 #pragma unroll
         for (int k = 0; k < NT; k++) {
@@ -562,6 +640,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             tdst[i] = td[k] * td[k];
         }
         wave_sync();
+        NS_PROF(11);
         float factor = 1.f;
         if (block_ind > kStartupLong) {  // gainmap == 1 for policy 2
             const float energy2 = sum_range<ORDERED>(tdst, 0, L, lane);
@@ -602,6 +681,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             hb_gain = g;
         }
         wave_sync();
+        NS_PROF(12);
     }
 
         NS_RELANE();
@@ -629,6 +709,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         if (chn == 2) out[i * chn + 1] = (int16_t)((i < B) ? W.fa[i] : 0.f);
     }
     wave_sync();
+    NS_PROF(13);
 #undef NS_RELANE
 }
 
@@ -655,11 +736,34 @@ __global__ __launch_bounds__(64 * kNsWavesPerBlock, 4) void ns_kernel(float *__r
     if (sidx >= n_streams) return;
     float *st = state + (size_t)sidx * Y::WORDS;
     unsigned short *hist = hists + (size_t)sidx * 3 * kHistBins;
+    {
+        // the tail [M, MP) of every per-bin array is summed by sum_lanes and must be zero; nothing below writes it
+        float *wb = Wv[wave].re;
+        constexpr int NARR = 14;  // re .. r2
+        if (lane < NARR * (Y::MP - Y::M)) wb[(lane / (Y::MP - Y::M)) * Y::MP + Y::M + lane % (Y::MP - Y::M)] = 0.f;
+    }
+#ifdef WMX_NS_PROF
+    if (lane < 16) Wv[wave].prof[lane] = 0;
+#endif
     for (int p = 0; p < n_packets; p++) {
         const size_t off = (size_t)sidx * stream_stride + (size_t)p * packet_stride;
         ns_frame<L, ORDERED>(K, Wv[wave], st, hist, in + off, out + off, chn, pkg, lane);
     }
+#ifdef WMX_NS_PROF
+    if (lane < 16) atomicAdd(&g_ns_prof[lane], Wv[wave].prof[lane]);
+#endif
 }
+#ifdef WMX_NS_PROF
+extern "C" int wmx_debug_ns_prof(unsigned long long *out16, int reset) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ns_prof), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ns_prof), z, sizeof(z));
+    }
+    return 0;
+}
+#endif
 
 }  // namespace
 }  // namespace wmx
