@@ -252,6 +252,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=0, help="streams (frames per step) per GPU; 0 = workload default")
+    ap.add_argument("--prime", type=int, default=256,
+                    help="untimed steps run before the warm-up so that every stream is past the reference's start-up phases "
+                         "(NS: 200 blocks of noise-model start-up, ns_core.c:1103-1160; AEC: pass-through until the far-end "
+                         "buffer has filled, echo_cancellation.c:651-657); the timed steps then measure the steady state")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -285,7 +289,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(args.prime + args.warmup):
         wl.step(False)
     sync_all()
     t0 = time.perf_counter()
@@ -314,7 +318,7 @@ def main():
         "metric": "10 ms frames/s", "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
-        "config": wl.config(), "roofline": roofline,
+        "config": dict(wl.config(), primed_steps=args.prime), "roofline": roofline,
         "stage_ms": wl.stage_ms() if hasattr(wl, "stage_ms") else None,
         "whole_step_hbm_frac": round(value / world * wl.bytes_per_frame / 1e9 / HBM_PEAK_GBS, 5),
     }
