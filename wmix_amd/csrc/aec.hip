@@ -282,13 +282,13 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
     AEC_PROF(0);
     AEC_RELANE();
     // windowed near spectrum, kept in registers across the filter update (bin = lane; lane 0 also bin 64)
-    float dwr, dwi, dw64 = 0.f, dum;
-    rdft128_fwd_bin(W.fa[1], &K.tab, lane, dwr, dwi);
-    if (lane == 0) rdft128_fwd_bin(W.fa[1], &K.tab, kAecPart, dw64, dum);
+    float dwr, dwi, dw64;
+    rdft128_fwd_bin_lane(W.fa[1], &K.tab, lane, dwr, dwi, dw64);
     // ---- near power, noise floor (aec_core.c:1197-1243)
+    float dfr, dfi, df64;
+    rdft128_fwd_bin_lane(W.fa[0], &K.tab, lane, dfr, dfi, df64);
     for (int b = lane; b < kAecPart1; b += 64) {
-        float re, im;
-        rdft128_fwd_bin(W.fa[0], &K.tab, b, re, im);
+        const float re = b == kAecPart ? df64 : dfr, im = b == kAecPart ? 0.f : dfi;
         const float ns = re * re + im * im;
         const float dpow = 0.9f * AEC_ST(AS_DPOW + b) + 0.1f * ns;
         AEC_ST(AS_DPOW + b) = dpow;
@@ -318,10 +318,8 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
             const float xr = X[lane], xi = X[kAecPart1 + lane];
             yr += xr * taps.re[p] - xi * taps.im[p];
             yi += xr * taps.im[p] + xi * taps.re[p];
-            if (lane == 0) {
-                const float nr = X[kAecPart], ni = X[kAecPart1 + kAecPart];  // ni == 0, wfBuf[1][.][64] == 0
-                y64 += nr * W.wn[p] - ni * 0.f;
-            }
+            const float nr = X[kAecPart], ni = X[kAecPart1 + kAecPart];  // ni == 0, wfBuf[1][.][64] == 0
+            y64 += nr * W.wn[p] - ni * 0.f;                              // used by lane 0 only
         }
         if (lane == 0) {
             W.fa[2][0] = yr;
@@ -364,14 +362,13 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
     wave_sync();
     AEC_PROF(2);
     AEC_RELANE();
-    float ewr, ewi, ew64 = 0.f;
-    rdft128_fwd_bin(W.fa[3], &K.tab, lane, ewr, ewi);
-    if (lane == 0) rdft128_fwd_bin(W.fa[3], &K.tab, kAecPart, ew64, dum);
+    float ewr, ewi, ew64;
+    rdft128_fwd_bin_lane(W.fa[3], &K.tab, lane, ewr, ewi, ew64);
     // ---- ScaleErrorSignal (aec_core.c:172-194); ef stays in registers (bin = lane; lane 0 also bin 64)
     float efr, efi, ef64r = 0.f, ef64i = 0.f;
     {
+        rdft128_fwd_bin_lane(W.fa[2], &K.tab, lane, efr, efi, ef64r);
         auto scale_err = [&](int b, float &er, float &ei) {
-            rdft128_fwd_bin(W.fa[2], &K.tab, b, er, ei);
             const float xp = F.xpow_seq[(n % kAecHist) * BP + b];
             er /= (xp + 1e-10f);
             ei /= (xp + 1e-10f);
@@ -401,11 +398,9 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
             const int p = base + q;
             const float *X = F.hist + (size_t)((n - p + kAecHist) % kAecHist) * 130;
             const float xr = X[lane], xi = -X[kAecPart1 + lane];
-            float v1 = xr * efi + xi * efr;
-            if (lane == 0) {  // fft[1] is overwritten with the Nyquist product (aec_core.c:245-248)
-                const float nr = X[kAecPart], ni = -X[kAecPart1 + kAecPart];
-                v1 = nr * ef64r - ni * ef64i;
-            }
+            // fft[1] is overwritten with the Nyquist product (aec_core.c:245-248): lane 0 only, selected not branched
+            const float nr = X[kAecPart], ni = -X[kAecPart1 + kAecPart];
+            const float v1 = lane == 0 ? nr * ef64r - ni * ef64i : xr * efi + xi * efr;
             W.fa[q][2 * lane] = xr * efr - xi * efi;
             W.fa[q][2 * lane + 1] = v1;
         }
@@ -436,15 +431,11 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
         for (int q = 0; q < 8; q++) {
             if (q >= cnt) continue;
             const int p = base + q;
-            float re, im;
-            rdft128_fwd_bin(W.fa[q], &K.tab, lane, re, im);
+            float re, im, nyq;
+            rdft128_fwd_bin_lane(W.fa[q], &K.tab, lane, re, im, nyq);
             taps.re[p] += re;
-            if (lane == 0) {
-                rdft128_fwd_bin(W.fa[q], &K.tab, kAecPart, re, im);
-                W.wn[p] += re;
-            } else {
-                taps.im[p] += im;
-            }
+            taps.im[p] += im;  // lane 0: im == 0 (wfBuf[1][pos] is never touched, aec_core.c:262-268)
+            if (lane == 0) W.wn[p] += nyq;
         }
         wave_sync();
     }
@@ -713,7 +704,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
 }
 
 template <int MULT>
-__global__ __launch_bounds__(64 * kAecWavesPerBlock, 2) void aec_near_kernel(float *__restrict__ state, AecFarBufs F,
+__global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * kAecWavesPerBlock) void aec_near_kernel(float *__restrict__ state, AecFarBufs F,
                                                                           const float *__restrict__ consts_g,
                                                                           const AecPlan *__restrict__ plans, int n_packets,
                                                                           const int16_t *near_pcm, int16_t *out_pcm, int n_streams,
@@ -780,7 +771,7 @@ __global__ __launch_bounds__(64 * kAecWavesPerBlock, 2) void aec_near_kernel(flo
     wave_sync();
     AEC_PROF(11);  // includes the blocks; subtract 0..9
     // ---- state out (addresses recomputed: keeping the ones of the load alive across the packet loop costs 17 VGPRs)
-    asm volatile("" : "+v"(gst));
+    asm volatile("" : "+s"(gst));
 #pragma unroll
     for (int p = 0; p < 12; p++) {
         gst[AS_W_RE + p * BP + lane] = taps.re[p];

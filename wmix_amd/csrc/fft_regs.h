@@ -98,19 +98,21 @@ __device__ __forceinline__ void fft64_regs(Cx v[4], const FftTables *T, int gl) 
 // from the packed spectrum row a[128] (a[1] fix-up fft4g.c:349-351, rftbsub fft4g.c:1260-1284 incl. its sign
 // flips).
 __device__ __forceinline__ Cx rdft128_inv_point(const float *a, const FftTables *T, int p) {
-    if (p == 0) {
-        const float a0 = a[0], a1 = a[1];
-        const float h = 0.5f * (a0 - a1);
-        return Cx{a0 - h, -h};
-    }
-    if (p == 32) return Cx{a[64], -a[65]};
+    // one straight-line path for every point: the general pair formula is evaluated with q clamped into the
+    // table (p = 0 reads a[128..129], inside the 132-float row, and discards the result), then the two special
+    // points are selected in.  No divergent branches inside a wave.
     const int q = p < 32 ? p : 64 - p;
     const int j = 2 * q, k = 128 - j;
     const float wkr = 0.5f - T->c[32 - q], wki = T->c[q];
     const float aj = a[j], aj1 = a[j + 1], ak = a[k], ak1 = a[k + 1];
     const float xr = aj - ak, xi = aj1 + ak1;
     const float yr = wkr * xr + wki * xi, yi = wkr * xi - wki * xr;
-    return p < 32 ? Cx{aj - yr, yi - aj1} : Cx{ak + yr, yi - ak1};
+    float re = p < 32 ? aj - yr : ak + yr;
+    float im = p < 32 ? yi - aj1 : yi - ak1;
+    const float h = 0.5f * (aj - aj1);  // p == 0: aj = a[0], aj1 = a[1]
+    re = p == 0 ? aj - h : (p == 32 ? aj : re);
+    im = p == 0 ? -h : (p == 32 ? -aj1 : im);
+    return Cx{re, im};
 }
 
 // Output side of rdft(128, +1, a): bin b (0..64) of the spectrum, from the row holding the result of the
@@ -141,6 +143,21 @@ __device__ __forceinline__ void rdft128_fwd_bin(const float *a, const FftTables 
         re = ak + yr;
         im = ak1 - yi;
     }
+}
+
+// rdft128_fwd_bin for bin == lane (0..63), straight-line; `nyq` is bin 64 (real), valid in lane 0 only.
+__device__ __forceinline__ void rdft128_fwd_bin_lane(const float *a, const FftTables *T, int lane, float &re, float &im, float &nyq) {
+    const int q = lane < 32 ? lane : 64 - lane;  // lane 0: q = 0 (reads a[128..129], discarded); lane 32: j == k == 64
+    const int j = 2 * q, k = 128 - j;
+    const float wkr = 0.5f - T->c[32 - q], wki = T->c[q];
+    const float aj = a[j], aj1 = a[j + 1], ak = a[k], ak1 = a[k + 1];
+    const float xr = aj - ak, xi = aj1 + ak1;
+    const float yr = wkr * xr - wki * xi, yi = wkr * xi + wki * xr;
+    const float gre = lane < 32 ? aj - yr : ak + yr;
+    const float gim = lane < 32 ? aj1 - yi : ak1 - yi;
+    re = lane == 0 ? aj + aj1 : (lane == 32 ? aj : gre);
+    im = lane == 0 ? 0.f : (lane == 32 ? aj1 : gim);
+    nyq = aj - aj1;
 }
 
 // value held by lane rev4(gl) of the same row (ds_bpermute: no LDS memory, no barrier)
