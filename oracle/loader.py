@@ -147,6 +147,52 @@ def run_chain(lib, chn, freq, agc_value, stages, far, near, frames_per_call, pre
     return out
 
 
+# ---------------------------------------------------------------- math/fft.c
+MFFT_KINDS = ("FFT", "FFTR", "IFFT", "IFFTR")
+
+
+def mfft(lib, kind, re, im, n, prefix="ref", want="riap"):
+    """One transform of math/fft.c.  kind 0..3 = FFT, FFTR, IFFT, IFFTR; `re` / `im` float32[n] or None (read as
+    zeros, like the reference's NULL); `want` picks the outputs (r, i, a = amplitude, p = phase; the inverses have
+    no a / p).  Returns a dict of float32[n] arrays."""
+    f32 = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)
+    re, im = f32(re), f32(im)
+    ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    out = {k: np.zeros(n, np.float32) for k in want if not (kind >= 2 and k in "ap")}
+    o = lambda k: ptr(out.get(k))
+    if prefix == "orc":
+        fn = lib.orc_mfft
+        fn.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_uint]
+        fn.restype = C.c_int
+        assert fn(kind, ptr(re), ptr(im), o("r"), o("i"), o("a"), o("p"), n) == 0
+    else:
+        fn = getattr(lib, MFFT_KINDS[kind])
+        fn.restype = None
+        if kind < 2:
+            fn.argtypes = [C.c_void_p] * 6 + [C.c_uint]
+            fn(ptr(re), ptr(im), o("r"), o("i"), o("a"), o("p"), n)
+        else:
+            fn.argtypes = [C.c_void_p] * 4 + [C.c_uint]
+            fn(ptr(re), ptr(im), o("r"), o("i"), n)
+    return out
+
+
+def mfft_stream(lib, chunks, st_len, prefix="ref"):
+    """fft_stream over successive chunks; returns (stream, [af per call], [pf per call])."""
+    stream = np.zeros(st_len, np.float32)
+    fn = lib.orc_mfft_stream if prefix == "orc" else lib.fft_stream
+    fn.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p]
+    fn.restype = C.c_int if prefix == "orc" else None
+    afs, pfs = [], []
+    for ch in chunks:
+        ch = np.ascontiguousarray(ch, np.float32)
+        af, pf = np.zeros(st_len, np.float32), np.zeros(st_len, np.float32)
+        fn(ch.ctypes.data, len(ch), stream.ctypes.data, st_len, af.ctypes.data, pf.ctypes.data)
+        afs.append(af)
+        pfs.append(pf)
+    return stream, afs, pfs
+
+
 # ---------------------------------------------------------------- reference mixer (executable)
 def ref_mix(*args, stdin=b""):
     return subprocess.run([REF_MIX] + [str(a) for a in args], input=stdin, stdout=subprocess.PIPE, check=True).stdout
