@@ -151,6 +151,27 @@ int wmx_mix_load(wmx_mix *m, const int16_t *d_src, uint32_t srcU8Len, int freq, 
 int wmx_mix_drain(wmx_mix *m, int16_t *d_out, uint32_t bytes, long out_stride, void *stream);
 int wmx_mix_export(const wmx_mix *m, int group, int16_t *host_ring, uint32_t *head_off, uint32_t *tick);
 
+/* ------------------------------------------------------------------ math/fft.c (stand-alone radix-2 FFT helpers)
+ * Batched form of FFT / FFTR / IFFT / IFFTR (math/fft.h:19-38, math/fft.c:121-398): n_batch independent
+ * transforms of N points per launch, arrays laid out [n_batch][N] float on the device.  kind: 0 FFT, 1 FFTR,
+ * 2 IFFT, 3 IFFTR.  As in the reference any of the arrays may be NULL: a NULL input reads as zeros, a NULL output is
+ * skipped; the inverses have no amplitude / phase outputs (d_out_af / d_out_pf are ignored for kind >= 2); the real
+ * variants never read d_in_im.  N must be a power of two, 2 <= N <= 4096, else WMX_EINVAL.  Bit-exact for
+ * re / im / amplitude (the twiddles are the reference's double cos/sin values, tabulated on the host);
+ * the phase curve is a double atan2 rounded to float. */
+#define WMX_MFFT_FFT 0
+#define WMX_MFFT_FFTR 1
+#define WMX_MFFT_IFFT 2
+#define WMX_MFFT_IFFTR 3
+int wmx_mfft(int kind, int n_batch, unsigned N, const float *d_in_re, const float *d_in_im, float *d_out_re,
+             float *d_out_im, float *d_out_af, float *d_out_pf, void *stream);
+/* Batched fft_stream (math/fft.h:51, math/fft.c:413-424): for every stream, move pool[in_len..2*in_len) to the front,
+ * append the in_len new samples behind it, transform the st_len-point pool and write the amplitude / phase curves
+ * (either may be NULL).  d_in [n_streams][in_len], d_pool [n_streams][st_len] (updated in place), outputs
+ * [n_streams][st_len].  Requires 2*in_len <= st_len (the reference reads past the pool otherwise). */
+int wmx_mfft_stream(int n_streams, const float *d_in, unsigned in_len, float *d_pool, unsigned st_len, float *d_out_af,
+                    float *d_out_pf, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

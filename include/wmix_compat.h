@@ -85,6 +85,14 @@ uint32_t wmix_len_of_in(uint8_t inChn, uint16_t inFreq, uint8_t outChn, uint16_t
 uint32_t wmix_pcm_zoom(uint8_t inChn, uint16_t inFreq, uint8_t *in, uint32_t inLen, uint8_t outChn, uint16_t outFreq,
                        uint8_t *out);
 
+/* ------------------------------------------------------------------ math/fft.h:19-51 (stand-alone FFT helpers;
+ * no callers inside the daemon, kept for link compatibility with tools that use them).  Host arrays. */
+void FFT(float inReal[], float inImag[], float outReal[], float outImag[], float outAF[], float outPF[], unsigned int N);
+void FFTR(float inReal[], float inImag[], float outReal[], float outImag[], float outAF[], float outPF[], unsigned int N);
+void IFFT(float inReal[], float inImag[], float outReal[], float outImag[], unsigned int N);
+void IFFTR(float inReal[], float inImag[], float outReal[], float outImag[], unsigned int N);
+void fft_stream(float in[], unsigned int inLen, float stream[], unsigned int stLen, float outAF[], float outPF[]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,6 +107,10 @@ def _declare(L):
     u32 = C.c_uint32
     L.wmx_pcm_zoom.restype = i
     L.wmx_pcm_zoom.argtypes = [i, i, vp, u32, i, i, vp, C.c_long, C.c_long, i, C.POINTER(u32), vp]
+    L.wmx_mfft.restype = i
+    L.wmx_mfft.argtypes = [i, i, C.c_uint, vp, vp, vp, vp, vp, vp, vp]
+    L.wmx_mfft_stream.restype = i
+    L.wmx_mfft_stream.argtypes = [i, vp, C.c_uint, vp, C.c_uint, vp, vp, vp]
     L.wmx_mix_create.restype = i
     L.wmx_mix_create.argtypes = [C.POINTER(vp), i, i, i]
     L.wmx_mix_destroy.restype = i

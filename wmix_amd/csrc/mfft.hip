@@ -1,0 +1,319 @@
+// mfft.hip -- the reference's stand-alone radix-2 FFT helpers (math/fft.c) batched for gfx950.
+//
+// Replaces FFT / FFTR / IFFT / IFFTR / fft_stream (math/fft.h:19-51, math/fft.c:121-424) for many independent
+// transforms per launch.  The reference is a textbook decimation-in-time radix-2 FFT on float arrays whose
+// twiddles are cos/sin(2.0 * FFT_PI * p / N) evaluated in double at every butterfly (FFT_PI = 3.1415926535897,
+// math/fft.c:21); the products and their sum are double, rounded to float once, the butterfly add/sub are float.
+//
+// Mapping: one wavefront per transform, data in LDS (8 KB for N = 1024), log2(N) passes of N/2 butterflies spread
+// over the 64 lanes, wave-scope fences between passes.  The twiddle table for a size is built once on the host
+// with the reference's own expression and libm (so every entry has the reference's bits) and cached on the device
+// as double2[N/2]; kernels keep the reference's double multiply-add and single rounding.  Bit-exact for re / im /
+// amplitude; the phase curve goes through the device's double atan2 (<= 1 float ulp from glibc's).
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <vector>
+#include "wmx_internal.h"
+#include "fft_ooura.h"  // wave_sync
+#include "../../include/wmix_compat.h"
+
+namespace wmx {
+namespace {
+
+constexpr double kMfftPi = 3.1415926535897;  // math/fft.c:21
+constexpr unsigned kMfftMaxN = 4096;
+
+// ---------------------------------------------------------------- host: twiddle tables, cached per size
+std::mutex g_tw_mutex;
+std::map<unsigned, double2 *> g_tw;  // size n -> device double2[n/2] = (cos, sin)(2.0 * PI * p / n)
+
+int twiddles_for(unsigned n, const double2 **out) {
+    std::lock_guard<std::mutex> lock(g_tw_mutex);
+    auto it = g_tw.find(n);
+    if (it != g_tw.end()) {
+        *out = it->second;
+        return 0;
+    }
+    const unsigned h = n / 2 ? n / 2 : 1;
+    std::vector<double2> t(h);
+    for (unsigned p = 0; p < h; p++) {
+        const int pi = (int)p;
+        t[p].x = cos(2.0 * kMfftPi * pi / n);  // same expression, same libm as math/fft.c:108
+        t[p].y = sin(2.0 * kMfftPi * pi / n);
+    }
+    double2 *d = nullptr;
+    WMX_HIP(hipMalloc(&d, h * sizeof(double2)));
+    WMX_HIP(hipMemcpy(d, t.data(), h * sizeof(double2), hipMemcpyHostToDevice));
+    g_tw[n] = d;
+    *out = d;
+    return 0;
+}
+
+// ---------------------------------------------------------------- device
+// log2(n) radix-2 DIT passes on n complex points in LDS (math/fft.c:81-118 / 256-296)
+template <bool INVERSE>
+__device__ __forceinline__ void dit_passes(float *re, float *im, unsigned n, unsigned m, const double2 *__restrict__ tw, int lane) {
+    for (unsigned l = 1; l <= m; l++) {
+        const unsigned half = 1u << (l - 1), shift = m - l;  // twiddle step 2^(m-l)
+        for (unsigned t = lane; t < n / 2; t += 64) {
+            const unsigned i = t >> (l - 1), j = t & (half - 1);
+            const unsigned r = j + 2 * half * i, q = r + half;
+            const double2 w = tw[j << shift];
+            const float xr = re[q], xi = im[q], ar = re[r], ai = im[r];
+            float tr, ti;
+            if constexpr (!INVERSE) {
+                tr = (float)((double)xr * w.x + (double)xi * w.y);
+                ti = (float)((double)xi * w.x - (double)xr * w.y);
+                re[q] = ar - tr;
+                im[q] = ai - ti;
+                re[r] = ar + tr;
+                im[r] = ai + ti;
+            } else {
+                tr = (float)((double)xr * w.x - (double)xi * w.y);
+                ti = (float)((double)xi * w.x + (double)xr * w.y);
+                re[q] = (ar - tr) / 2;
+                im[q] = (ai - ti) / 2;
+                re[r] = (ar + tr) / 2;
+                im[r] = (ai + ti) / 2;
+            }
+        }
+        wave_sync();
+    }
+}
+
+__device__ __forceinline__ unsigned rev_bits(unsigned i, unsigned m) { return m ? (__brev(i) >> (32 - m)) : 0u; }
+
+__device__ __forceinline__ void emit(unsigned idx, float r, float i, unsigned n, float *o_re, float *o_im, float *o_af, float *o_pf) {
+    if (o_re) o_re[idx] = r;
+    if (o_im) o_im[idx] = i;
+    if (o_af) o_af[idx] = (float)(sqrt((double)(r * r + i * i)) / (double)(n / 2));  // math/fft.c:143-146
+    if (o_pf) o_pf[idx] = (float)atan2((double)i, (double)r);                        // math/fft.c:149-152
+}
+
+// KIND 0 FFT, 1 FFTR, 2 IFFT, 3 IFFTR; STREAM: fft_stream's FIFO update in front of a KIND 0 transform
+template <int KIND, bool STREAM>
+__global__ void mfft_kernel(int n_batch, unsigned n, unsigned m, const double2 *__restrict__ tw_inner, const double2 *__restrict__ tw_n,
+                            const float *in_re, const float *in_im, float *out_re, float *out_im, float *out_af, float *out_pf,
+                            unsigned in_len) {
+    extern __shared__ float lds[];
+    constexpr bool REAL = (KIND == 1 || KIND == 3), INV = (KIND >= 2);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int idx = blockIdx.x * (blockDim.x >> 6) + wave;  // one transform per wave; no block-level barrier
+    if (idx >= n_batch) return;
+    const unsigned nc = REAL ? n / 2 : n, mc = REAL ? m - 1 : m;  // points of the complex transform
+    float *re = lds + (size_t)wave * 2 * n, *im = re + n;
+    const size_t base = (size_t)idx * n;
+    float *o_re = out_re ? out_re + base : nullptr, *o_im = out_im ? out_im + base : nullptr;
+    float *o_af = out_af ? out_af + base : nullptr, *o_pf = out_pf ? out_pf + base : nullptr;
+
+    if constexpr (STREAM) {
+        // fft_stream (math/fft.c:413-424): stream[0..L) = stream[L..2L), stream[L..2L) = in[0..L), then FFT(stream).
+        // `out_re` is the stream pool [n_batch][n] (updated in place), `in_re` the new samples [n_batch][in_len].
+        float *pool = out_re + base;
+        const float *fresh = in_re + (size_t)idx * in_len;
+        float *stage = lds + (size_t)(blockDim.x >> 6) * 2 * n + (size_t)wave * 2 * in_len;  // the pool's new head
+        for (unsigned i = lane; i < 2 * in_len; i += 64) stage[i] = i < in_len ? pool[i + in_len] : fresh[i - in_len];
+        wave_sync();  // every read of pool[in_len..2 in_len) is done before any lane overwrites it
+        for (unsigned i = lane; i < n; i += 64) {
+            float v;
+            if (i < 2 * in_len) {
+                v = stage[i];
+                pool[i] = v;
+            } else {
+                v = pool[i];
+            }
+            re[rev_bits(i, mc)] = v;
+            im[i] = 0.f;
+        }
+        o_re = nullptr;  // the pool is not a spectrum output
+    } else if constexpr (!REAL) {
+        for (unsigned i = lane; i < n; i += 64) {
+            const unsigned j = rev_bits(i, mc);
+            re[j] = in_re ? in_re[base + i] : 0.f;
+            im[j] = in_im ? in_im[base + i] : 0.f;
+        }
+    } else {
+        // y[i] = in[2i] + j in[2i+1]; the imaginary input array is not used by the real variants
+        for (unsigned i = lane; i < nc; i += 64) {
+            const unsigned j = rev_bits(i, mc);
+            re[j] = in_re ? in_re[base + 2 * i] : 0.f;
+            im[j] = in_re ? in_re[base + 2 * i + 1] : 0.f;
+        }
+    }
+    wave_sync();
+    dit_passes<INV>(re, im, nc, mc, tw_inner, lane);
+
+    if constexpr (!REAL) {
+        for (unsigned i = lane; i < n; i += 64) emit(i, re[i], im[i], n, o_re, o_im, INV ? nullptr : o_af, INV ? nullptr : o_pf);
+    } else {
+        // split into the spectra of the even / odd samples and the last butterfly stage (math/fft.c:182-232 / 345-392)
+        const unsigned h = nc;
+        for (unsigned j = lane; j < h; j += 64) {
+            float x1r, x1i, x2r, x2i;
+            if (j == 0) {
+                x1r = re[0];
+                x1i = im[0];
+                x2r = im[0];
+                x2i = -re[0];
+            } else {
+                const float yr = re[j], yi = im[j], zr = re[h - j], zi = im[h - j];
+                x1r = (yr + zr) / 2;
+                x1i = (yi - zi) / 2;
+                x2r = (yi + zi) / 2;
+                x2i = (zr - yr) / 2;
+            }
+            const double2 w = tw_n[j];
+            float xr, xi;
+            if constexpr (!INV) {
+                const float tr = (float)((double)x2r * w.x + (double)x2i * w.y);
+                const float ti = (float)((double)x2i * w.x - (double)x2r * w.y);
+                xr = x1r + tr;
+                xi = x1i + ti;
+            } else {
+                const float tr = (float)((double)x2r * w.x - (double)x2i * w.y);
+                const float ti = (float)((double)x2i * w.x + (double)x2r * w.y);
+                xr = (x1r + tr) / 2;
+                xi = (x1i + ti) / 2;
+            }
+            emit(j, xr, xi, n, o_re, o_im, INV ? nullptr : o_af, INV ? nullptr : o_pf);
+            if (j == 0) {
+                float mr = x1r - x2r, mi = x1i - x2i;
+                if constexpr (INV) {
+                    mr = mr / 2;
+                    mi = mi / 2;
+                }
+                emit(h, mr, mi, n, o_re, o_im, INV ? nullptr : o_af, INV ? nullptr : o_pf);
+            } else {
+                emit(n - j, xr, -xi, n, o_re, o_im, INV ? nullptr : o_af, INV ? nullptr : o_pf);
+            }
+        }
+    }
+}
+
+int check_size(unsigned n, unsigned *m) {
+    if (n < 2 || n > kMfftMaxN || (n & (n - 1))) {
+        set_error("math/fft: N = %u (must be a power of two in [2, %u])", n, kMfftMaxN);
+        return WMX_EINVAL;
+    }
+    unsigned b = 0;
+    while ((1u << (b + 1)) <= n) b++;
+    *m = b;
+    return 0;
+}
+
+unsigned waves_per_block(unsigned n) { return n <= 1024 ? 4u : (n <= 2048 ? 2u : 1u); }
+
+}  // namespace
+}  // namespace wmx
+
+using namespace wmx;
+
+extern "C" int wmx_mfft(int kind, int n_batch, unsigned n, const float *d_in_re, const float *d_in_im, float *d_out_re,
+                        float *d_out_im, float *d_out_af, float *d_out_pf, void *stream) {
+    unsigned m;
+    if (int rc = check_size(n, &m)) return rc;
+    if (kind < 0 || kind > 3 || n_batch < 0) {
+        set_error("wmx_mfft: kind %d / n_batch %d", kind, n_batch);
+        return WMX_EINVAL;
+    }
+    if (n_batch == 0) return 0;
+    const bool real = kind == 1 || kind == 3;
+    const double2 *tw_inner = nullptr, *tw_n = nullptr;
+    if (int rc = twiddles_for(n, &tw_n)) return rc;
+    if (real) {
+        if (int rc = twiddles_for(n / 2, &tw_inner)) return rc;
+    } else {
+        tw_inner = tw_n;
+    }
+    const unsigned wpb = waves_per_block(n);
+    const dim3 grid((unsigned)((n_batch + wpb - 1) / wpb)), block(64 * wpb);
+    const size_t lds = (size_t)wpb * 2 * n * sizeof(float);
+    hipStream_t s = as_stream(stream);
+#define WMX_MFFT_LAUNCH(K) \
+    hipLaunchKernelGGL((mfft_kernel<K, false>), grid, block, lds, s, n_batch, n, m, tw_inner, tw_n, d_in_re, d_in_im, d_out_re, d_out_im, d_out_af, d_out_pf, 0u)
+    switch (kind) {
+        case 0: WMX_MFFT_LAUNCH(0); break;
+        case 1: WMX_MFFT_LAUNCH(1); break;
+        case 2: WMX_MFFT_LAUNCH(2); break;
+        default: WMX_MFFT_LAUNCH(3); break;
+    }
+#undef WMX_MFFT_LAUNCH
+    WMX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int wmx_mfft_stream(int n_streams, const float *d_in, unsigned in_len, float *d_pool, unsigned st_len, float *d_out_af,
+                               float *d_out_pf, void *stream) {
+    unsigned m;
+    if (int rc = check_size(st_len, &m)) return rc;
+    // the reference moves stream[inLen..2*inLen) down and appends inLen new samples behind it (math/fft.c:417-421):
+    // 2*inLen must fit the pool or it reads past it
+    if (n_streams < 0 || !d_in || !d_pool || in_len == 0 || 2 * in_len > st_len) {
+        set_error("wmx_mfft_stream: n_streams %d, in_len %u, st_len %u", n_streams, in_len, st_len);
+        return WMX_EINVAL;
+    }
+    if (n_streams == 0) return 0;
+    const double2 *tw = nullptr;
+    if (int rc = twiddles_for(st_len, &tw)) return rc;
+    const unsigned wpb = waves_per_block(st_len);
+    const dim3 grid((unsigned)((n_streams + wpb - 1) / wpb)), block(64 * wpb);
+    const size_t lds = (size_t)wpb * (2 * st_len + 2 * in_len) * sizeof(float);
+    hipLaunchKernelGGL((mfft_kernel<0, true>), grid, block, lds, as_stream(stream), n_streams, st_len, m, tw, tw, d_in, (const float *)nullptr,
+                       d_pool, (float *)nullptr, d_out_af, d_out_pf, in_len);
+    WMX_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ legacy signatures (math/fft.h:19-51): one transform,
+// host arrays, NULLs as in the reference
+namespace {
+int legacy(int kind, float *in_re, float *in_im, float *out_re, float *out_im, float *out_af, float *out_pf, unsigned n) {
+    unsigned m;
+    if (check_size(n, &m)) return -1;
+    float *d = nullptr;
+    const size_t bytes = (size_t)n * sizeof(float);
+    if (hipMalloc(&d, 6 * bytes) != hipSuccess) return -1;
+    float *d_ir = in_re ? d : nullptr, *d_ii = in_im ? d + n : nullptr;
+    float *d_or = out_re ? d + 2 * n : nullptr, *d_oi = out_im ? d + 3 * n : nullptr;
+    float *d_af = out_af ? d + 4 * n : nullptr, *d_pf = out_pf ? d + 5 * n : nullptr;
+    int rc = 0;
+    if (in_re && hipMemcpy(d_ir, in_re, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = -1;
+    if (in_im && hipMemcpy(d_ii, in_im, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = -1;
+    if (!rc) rc = wmx_mfft(kind, 1, n, d_ir, d_ii, d_or, d_oi, d_af, d_pf, nullptr);
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = -1;
+    float *outs[4] = {out_re, out_im, out_af, out_pf}, *devs[4] = {d_or, d_oi, d_af, d_pf};
+    for (int k = 0; k < 4 && !rc; k++)
+        if (outs[k] && hipMemcpy(outs[k], devs[k], bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = -1;
+    (void)hipFree(d);
+    return rc;
+}
+}  // namespace
+
+extern "C" void FFT(float inReal[], float inImag[], float outReal[], float outImag[], float outAF[], float outPF[], unsigned int N) {
+    legacy(0, inReal, inImag, outReal, outImag, outAF, outPF, N);
+}
+extern "C" void FFTR(float inReal[], float inImag[], float outReal[], float outImag[], float outAF[], float outPF[], unsigned int N) {
+    legacy(1, inReal, inImag, outReal, outImag, outAF, outPF, N);
+}
+extern "C" void IFFT(float inReal[], float inImag[], float outReal[], float outImag[], unsigned int N) {
+    legacy(2, inReal, inImag, outReal, outImag, nullptr, nullptr, N);
+}
+extern "C" void IFFTR(float inReal[], float inImag[], float outReal[], float outImag[], unsigned int N) {
+    legacy(3, inReal, inImag, outReal, outImag, nullptr, nullptr, N);
+}
+extern "C" void fft_stream(float in[], unsigned int inLen, float stream[], unsigned int stLen, float outAF[], float outPF[]) {
+    unsigned m;
+    if (!in || !stream || inLen == 0 || 2 * inLen > stLen || check_size(stLen, &m)) return;
+    float *d = nullptr;
+    const size_t sb = (size_t)stLen * sizeof(float), ib = (size_t)inLen * sizeof(float);
+    if (hipMalloc(&d, 3 * sb + ib) != hipSuccess) return;
+    float *d_pool = d, *d_af = d + stLen, *d_pf = d + 2 * stLen, *d_in = d + 3 * stLen;
+    bool ok = hipMemcpy(d_pool, stream, sb, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d_in, in, ib, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && wmx_mfft_stream(1, d_in, inLen, d_pool, stLen, outAF ? d_af : nullptr, outPF ? d_pf : nullptr, nullptr) == 0;
+    ok = ok && hipDeviceSynchronize() == hipSuccess && hipMemcpy(stream, d_pool, sb, hipMemcpyDeviceToHost) == hipSuccess;
+    if (ok && outAF) ok = hipMemcpy(outAF, d_af, sb, hipMemcpyDeviceToHost) == hipSuccess;
+    if (ok && outPF) ok = hipMemcpy(outPF, d_pf, sb, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+}
