@@ -161,6 +161,51 @@ class NsWorkload:
                 "sample": "%d x %d packets of one 16 kHz stream through oracle/orc_ns.c (-O2), 1 thread" % (reps, n)}
 
 
+class MfftWorkload:
+    """math/fft.c's intended use (fft_stream's 1024-sample pool): one 1024-point real FFT (FFTR) with amplitude curve
+    per stream per step.  Algorithmic bytes per transform = 4 096 in + 4 096 amplitude out = 8 192 B."""
+    name = "mfft_fftr_1024_amplitude"
+    dtype = "f32 data, f64 twiddles"
+    bytes_per_frame = 8192.0
+    dominant_kernel = "mfft_kernel<1, false>"
+    dominant_bytes_per_frame = 8192.0
+    N = 1024
+
+    def __init__(self, dev, n_streams, rank):
+        from wmix_amd import mfft
+        self.mfft = mfft
+        self.n_frames = n_streams
+        g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+        self.x = (torch.randn((n_streams, self.N), generator=g) * 3000).to(dev)
+        self.t = _StageTimer()
+
+    def step(self, timed):
+        self.t.run("fftr", timed, lambda: self.mfft.transform(1, self.x, None, want="a"))
+
+    def dominant_ms(self):
+        return self.t.mean_ms("fftr")
+
+    def stage_ms(self):
+        return {"fftr": self.t.mean_ms("fftr")}
+
+    def config(self):
+        return {"workload": self.name, "transforms_per_step_per_gpu": self.n_frames, "frame": "1024 x float32"}
+
+    def cpu_baseline(self, budget_s):
+        from oracle import loader
+        port = loader.port()
+        x = self.x[0].cpu().numpy()
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < budget_s:
+            for _ in range(200):
+                loader.mfft(port, 1, x, None, self.N, prefix="orc", want="a")
+            reps += 200
+        dt = time.perf_counter() - t0
+        return {"value": reps / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+                "sample": "%d x FFTR(1024) through oracle/orc_mfft.c (-O2), 1 thread" % reps}
+
+
 class ChainWorkload:
     """BASELINE.json configs[2]: the daemon's record chain NS -> AEC -> AGC -> VAD (src/wmix.c:613-709), 16 kHz mono,
     65536 streams per GPU sharing one far-end reference, one 10 ms packet per stream per step.  With N > 1 ranks the
@@ -240,7 +285,8 @@ class ChainWorkload:
                 "sample": "%d x %d packets of one 16 kHz stream through the oracle chain (oracle/orc_*.c, -O2), 1 thread" % (reps, n)}
 
 
-WORKLOADS = {"g711": (G711Workload, 1 << 20), "ns": (NsWorkload, 4096), "chain": (ChainWorkload, 65536)}
+WORKLOADS = {"g711": (G711Workload, 1 << 20), "ns": (NsWorkload, 4096), "chain": (ChainWorkload, 65536),
+             "mfft": (MfftWorkload, 65536)}
 DEFAULT_WORKLOAD = "chain"
 
 

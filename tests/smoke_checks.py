@@ -48,9 +48,23 @@ def _chain(dev, np, torch):
     assert diff.max() <= 1, "chain differs from the oracle by %d LSB" % diff.max()
 
 
+def _mfft(dev, np, torch):
+    """math/fft.c: 8 real 256-point transforms vs the oracle (re / im / amplitude bit-exact)."""
+    from oracle import loader
+    from wmix_amd import mfft
+    port = loader.port()
+    x = (np.random.default_rng(3).standard_normal((8, 256)) * 2000).astype(np.float32)
+    got = mfft.transform(1, torch.from_numpy(x).to(dev), None, want="ria")
+    for b in range(8):
+        want = loader.mfft(port, 1, x[b], None, 256, prefix="orc", want="ria")
+        for k, w in want.items():
+            assert np.array_equal(got[k][b].cpu().numpy().view(np.uint32), w.view(np.uint32)), "math/fft FFTR %s mismatch" % k
+
+
 _run_g711 = run
 
 
 def run(dev, np, torch):  # noqa: F811
     _run_g711(dev, np, torch)
     _chain(dev, np, torch)
+    _mfft(dev, np, torch)
