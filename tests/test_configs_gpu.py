@@ -1,0 +1,107 @@
+"""Parity at the BASELINE.json configurations that are not bench lines:
+configs[3]  NS + AEC, 8 kHz mono, shared far-end (131 072 streams per GPU when the 1 M streams shard over 8 GPUs)
+configs[4]  2-channel 32 kHz NS + AGC, then wmix_load_data's resample to the 8 kHz mono ring with an N-way mix.
+Small cases against the oracle sample for sample; the full sizes through properties plus an oracle spot check."""
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+sys.path.insert(0, GOLDEN)
+from oracle import loader  # noqa: E402
+from test_aec_gpu import check_float_path, gpu_chain  # noqa: E402
+from test_mix_oracle import _bind, orc_load  # noqa: E402
+from wmix_amd import synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config3_ns_aec_8k_vs_oracle(cuda, oracle_port):
+    S, n, pkt = 48, 400, 80
+    far = synth.far_end(31, n, pkt)
+    near = synth.near_end(32, S, n, pkt, far=far)
+    near[5] = 0  # a silent stream takes the zero-energy early-outs
+    got = gpu_chain(cuda, 1, 8000, 3, far, near)
+    for s in range(0, S, 5):
+        want = loader.run_chain(oracle_port, 1, 8000, 5, 3, far, near[s], pkt, prefix="orc")
+        check_float_path(got[s], want)
+
+
+def test_config3_full_size(cuda, oracle_port):
+    """131 072 streams of 8 kHz NS -> AEC in one batch: streams with equal input give equal output wherever they
+    sit, and sampled streams agree with the oracle."""
+    from wmix_amd.aec import AecBatch
+    from wmix_amd.ns import NsBatch
+    S, n, pkt, U = 131072, 24, 80, 64
+    far = synth.far_end(41, n, pkt)
+    uniq = synth.near_end(42, U, n, pkt, far=far).reshape(U, n, pkt)
+    d = torch.from_numpy(uniq).to(cuda).repeat(S // U, 1, 1).contiguous()  # stream s carries input s % U
+    dfar = torch.from_numpy(far.reshape(n, pkt).copy()).to(cuda)
+    ns, aec = NsBatch(S, 1, 8000), AecBatch(S, 1, 8000, 10)
+    for f in range(0, n, 8):
+        ns.process(d[:, f:f + 8])
+        rc, _ = aec.process2(dfar[f:f + 8], d[:, f:f + 8])
+        assert rc == 0
+    first = d[:U]
+    assert torch.equal(d.view(S // U, U, n, pkt), first.expand(S // U, U, n, pkt))
+    got = first.cpu().numpy().reshape(U, -1)
+    for s in (0, 17, 63):
+        want = loader.run_chain(oracle_port, 1, 8000, 5, 3, far, uniq[s].reshape(-1), pkt, prefix="orc")
+        check_float_path(got[s], want)
+    ns.close()
+    aec.close()
+
+
+def _ns_agc_32k_2ch(cuda, src):
+    """src int16 [S, n_pkts, 640] (10 ms of 2 x 32 kHz) -> NS then AGC in place, like the daemon's record chain with
+    AEC and VAD switched off (src/wmix.c:613-709); the AGC works in 5 ms packets at 32 kHz (src/webrtc.c:724-727)."""
+    from wmix_amd.agc import AgcBatch
+    from wmix_amd.ns import NsBatch
+    S, n, per = src.shape
+    d = torch.from_numpy(src).to(cuda)
+    ns, agc = NsBatch(S, 2, 32000), AgcBatch(S, 2, 32000, 5)
+    assert ns.pkt == 640 and agc.pkt == 320
+    ns.process(d)
+    agc.process(d.view(S, 2 * n, 320))
+    ns.close()
+    agc.close()
+    return d
+
+
+def test_config4_ns_agc_resample_mix_vs_oracle(cuda, oracle_port):
+    from wmix_amd.mix import MixBatch
+    _bind(oracle_port)
+    G_, N, n = 3, 4, 30  # mix groups, sources per group, 10 ms packets
+    S, per = G_ * N, 640
+    rng = np.random.default_rng(77)
+    t = np.arange(n * 320)
+    src = np.zeros((S, n * 320, 2), np.int16)
+    for s in range(S):
+        tone = 9000 * np.sin(2 * np.pi * (200 + 37 * s) * t / 32000) * (((t // 3200) + s) % 3 > 0)
+        src[s, :, 0] = np.clip(tone + rng.integers(-1500, 1500, t.size), -32768, 32767)
+        src[s, :, 1] = src[s, :, 0] // 3  # wmix hands the R channel to NS as the "high band" 
+    src = src.reshape(S, n, per)
+    d = _ns_agc_32k_2ch(cuda, src.copy())
+    # oracle: the same two stages per source
+    want_pcm = np.stack([loader.run_chain(oracle_port, 2, 32000, 5, 1 | 4, np.zeros(n * per, np.int16), src[s].reshape(-1), 320, prefix="orc")
+                         for s in range(S)]).reshape(S, n, per)
+    assert np.array_equal(d.cpu().numpy(), want_pcm)
+    # every 10 ms: the N sources of a group are resampled (2 x 32 kHz -> 1 x 8 kHz, L channel, every 4th frame) and
+    # accumulated with saturation into the group's ring in call order; then the play thread drains 10 ms
+    mb = MixBatch(G_, 1, 8000)
+    pad = torch.zeros(S, n, 2, dtype=torch.int16, device=cuda)
+    dsrc = torch.cat([d, pad], 2).view(G_, N, n, per + 2)
+    for k in range(n):
+        mb.set(0, 0, 1)
+        h, tk = mb.load(dsrc[:, :, k].contiguous(), per * 2, 32000, 2)
+        mb.set(3200, 0, 1)
+        out = mb.drain(160).cpu().numpy()
+        for g in range(G_):
+            flat = np.concatenate([want_pcm[g * N + i, k] for i in range(N)] + [np.zeros(2, np.int16)])
+            ring, meta = orc_load(oracle_port, 1, 8000, 32000, 2, 1, 1, N, per * 2, 0, flat)
+            assert np.array_equal(out[g], ring[1600:1680]), (k, g)
+            assert (h, tk) == (int(meta[-1][1]), int(meta[-1][0]))
+    mb.close()
