@@ -158,45 +158,50 @@ __device__ __forceinline__ int dev_bitrev(int q, int bits) { return (int)(__brev
 // registers.  b = block index (twiddle class).  INV_CLOSE selects cftbsub's closing form.
 struct Cx { float r, i; };
 
-__device__ __forceinline__ void bfly4(int b, const FftTables *T, Cx A, Cx B, Cx C, Cx D, float2 &o0, float2 &o1, float2 &o2,
-                                      float2 &o3) {
-    const float x0r = A.r + B.r, x0i = A.i + B.i, x1r = A.r - B.r, x1i = A.i - B.i;
-    const float x2r = C.r + D.r, x2i = C.i + D.i, x3r = C.r - D.r, x3i = C.i - D.i;
-    o0.x = x0r + x2r;
-    o0.y = x0i + x2i;
+// Complex values as 2-element vectors: gfx950 has packed fp32 add / mul (v_pk_add_f32, v_pk_mul_f32: both halves in
+// one VALU issue, each half an ordinary IEEE single operation), which is exactly the (re, im) pairing of a butterfly.
+// Every expression below is the reference's, operand for operand; only the instruction count changes.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f cx(Cx a) { return v2f{a.r, a.i}; }
+__device__ __forceinline__ v2f swap(v2f a) { return __builtin_shufflevector(a, a, 1, 0); }
+// (a.x - b.y, a.y + b.x) = a + i*b      and      (a.x + b.y, a.y - b.x) = a - i*b
+__device__ __forceinline__ v2f add_i(v2f a, v2f b) { return a + v2f{-b.y, b.x}; }
+__device__ __forceinline__ v2f sub_i(v2f a, v2f b) { return a + v2f{b.y, -b.x}; }
+// (wr*t.x - wi*t.y, wr*t.y + wi*t.x): the reference's twiddle product, two packed multiplies and one packed add
+__device__ __forceinline__ v2f cmul_w(float wr, float wi, v2f t) { return v2f{wr, wr} * t + v2f{-wi, wi} * swap(t); }
+
+// in place on v[0..3] = A, B, C, D -> o0, o1, o2, o3
+__device__ __forceinline__ void bfly4_v(int b, const FftTables *T, v2f v[4]) {
+    const v2f x0 = v[0] + v[1], x1 = v[0] - v[1], x2 = v[2] + v[3], x3 = v[2] - v[3];
+    v[0] = x0 + x2;
     if (b == 0) {
-        o2.x = x0r - x2r;
-        o2.y = x0i - x2i;
-        o1.x = x1r - x3i;
-        o1.y = x1i + x3r;
-        o3.x = x1r + x3i;
-        o3.y = x1i - x3r;
+        v[2] = x0 - x2;
+        v[1] = add_i(x1, x3);  // (x1r - x3i, x1i + x3r)
+        v[3] = sub_i(x1, x3);  // (x1r + x3i, x1i - x3r)
     } else if (b == 1) {
         const float w = T->w2;
-        o2.x = x2i - x0i;
-        o2.y = x0r - x2r;
-        float tr = x1r - x3i, ti = x1i + x3r;
-        o1.x = w * (tr - ti);
-        o1.y = w * (tr + ti);
-        tr = x3i + x1r;
-        ti = x3r - x1i;
-        o3.x = w * (ti - tr);
-        o3.y = w * (ti + tr);
+        v[2] = v2f{x2.y - x0.y, x0.x - x2.x};
+        v2f t = add_i(x1, x3);  // tr = x1r - x3i, ti = x1i + x3r
+        v[1] = v2f{w, w} * v2f{t.x - t.y, t.x + t.y};
+        t = v2f{x3.y + x1.x, x3.x - x1.y};
+        v[3] = v2f{w, w} * v2f{t.y - t.x, t.y + t.x};
     } else {
         const float w1r = T->W1[b][0], w1i = T->W1[b][1], w2r = T->W2[b][0], w2i = T->W2[b][1];
         const float w3r = T->W3[b][0], w3i = T->W3[b][1];
-        float tr = x0r - x2r, ti = x0i - x2i;
-        o2.x = w2r * tr - w2i * ti;
-        o2.y = w2r * ti + w2i * tr;
-        tr = x1r - x3i;
-        ti = x1i + x3r;
-        o1.x = w1r * tr - w1i * ti;
-        o1.y = w1r * ti + w1i * tr;
-        tr = x1r + x3i;
-        ti = x1i - x3r;
-        o3.x = w3r * tr - w3i * ti;
-        o3.y = w3r * ti + w3i * tr;
+        v[2] = cmul_w(w2r, w2i, x0 - x2);
+        v[1] = cmul_w(w1r, w1i, add_i(x1, x3));
+        v[3] = cmul_w(w3r, w3i, sub_i(x1, x3));
     }
+}
+
+__device__ __forceinline__ void bfly4(int b, const FftTables *T, Cx A, Cx B, Cx C, Cx D, float2 &o0, float2 &o1, float2 &o2,
+                                      float2 &o3) {
+    v2f v[4] = {cx(A), cx(B), cx(C), cx(D)};
+    bfly4_v(b, T, v);
+    o0 = make_float2(v[0].x, v[0].y);
+    o1 = make_float2(v[1].x, v[1].y);
+    o2 = make_float2(v[2].x, v[2].y);
+    o3 = make_float2(v[3].x, v[3].y);
 }
 
 __device__ __forceinline__ void bfly4_store(float *a, int p0, int hc, int b, const FftTables *T, Cx A, Cx B, Cx C, Cx D) {
@@ -209,23 +214,34 @@ __device__ __forceinline__ void bfly4_store(float *a, int p0, int hc, int b, con
     *reinterpret_cast<float2 *>(a + 2 * p3) = o3;
 }
 
-// closing radix-4 without twiddles (fft4g.c:913-934 forward / 963-984 conjugating inverse)
+// closing radix-4 without twiddles (fft4g.c:913-934 forward / 963-984 conjugating inverse), in place on v[0..3]
+template <bool INVERSE>
+__device__ __forceinline__ void bfly4_close_v(v2f v[4]) {
+    const v2f x2 = v[2] + v[3], x3 = v[2] - v[3];
+    if constexpr (!INVERSE) {
+        const v2f x0 = v[0] + v[1], x1 = v[0] - v[1];
+        v[0] = x0 + x2;
+        v[2] = x0 - x2;
+        v[1] = add_i(x1, x3);  // (x1r - x3i, x1i + x3r)
+        v[3] = sub_i(x1, x3);  // (x1r + x3i, x1i - x3r)
+    } else {
+        // x0r = A.r + B.r, x0i = -A.i - B.i; x1r = A.r - B.r, x1i = -A.i + B.i
+        const v2f na = v2f{v[0].x, -v[0].y};
+        const v2f x0 = na + v2f{v[1].x, -v[1].y}, x1 = na + v2f{-v[1].x, v[1].y};
+        v[0] = x0 + v2f{x2.x, -x2.y};   // (x0r + x2r, x0i - x2i)
+        v[2] = x0 + v2f{-x2.x, x2.y};   // (x0r - x2r, x0i + x2i)
+        v[1] = x1 + v2f{-x3.y, -x3.x};  // (x1r - x3i, x1i - x3r)
+        v[3] = x1 + v2f{x3.y, x3.x};    // (x1r + x3i, x1i + x3r)
+    }
+}
 template <bool INVERSE>
 __device__ __forceinline__ void bfly4_close(Cx A, Cx B, Cx C, Cx D, float2 &o0, float2 &o1, float2 &o2, float2 &o3) {
-    const float x0r = A.r + B.r, x1r = A.r - B.r, x2r = C.r + D.r, x2i = C.i + D.i, x3r = C.r - D.r, x3i = C.i - D.i;
-    if constexpr (!INVERSE) {
-        const float x0i = A.i + B.i, x1i = A.i - B.i;
-        o0 = make_float2(x0r + x2r, x0i + x2i);
-        o2 = make_float2(x0r - x2r, x0i - x2i);
-        o1 = make_float2(x1r - x3i, x1i + x3r);
-        o3 = make_float2(x1r + x3i, x1i - x3r);
-    } else {
-        const float x0i = -A.i - B.i, x1i = -A.i + B.i;
-        o0 = make_float2(x0r + x2r, x0i - x2i);
-        o2 = make_float2(x0r - x2r, x0i + x2i);
-        o1 = make_float2(x1r - x3i, x1i - x3r);
-        o3 = make_float2(x1r + x3i, x1i + x3r);
-    }
+    v2f v[4] = {cx(A), cx(B), cx(C), cx(D)};
+    bfly4_close_v<INVERSE>(v);
+    o0 = make_float2(v[0].x, v[0].y);
+    o1 = make_float2(v[1].x, v[1].y);
+    o2 = make_float2(v[2].x, v[2].y);
+    o3 = make_float2(v[3].x, v[3].y);
 }
 
 __device__ __forceinline__ Cx ld_cx(const float *a, int p) {

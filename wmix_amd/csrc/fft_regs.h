@@ -21,43 +21,43 @@
 
 namespace wmx {
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+template <int CTRL, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_mov(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, BANK_MASK, false));
 }
 
-// value held by lane (l ^ X) of the same 16-lane row.  quad_perm for X = 1, 2; row_ror (lane l receives from
-// l - n mod 16) for X = 8 and, selected by the lane's own bit, for X = 4.
+// Swap lane bit X of the 16-lane row with one element-index bit: lanes whose bit X is clear keep `lo` and receive
+// the partner's `lo` into `hi`; lanes whose bit is set keep `hi` and receive the partner's `hi` into `lo`.
+//   X = 4, 8: row_ror with a bank mask (a DPP bank is 4 lanes, so "bit 2 / bit 3 of the lane" is a set of banks)
+//             writes only the receiving lanes -- two instructions per register pair, no selects.
+//   X = 1, 2: quad_perm fetch of the partner's value, then a select on the lane's own bit.
 template <int X>
-__device__ __forceinline__ float row_xor(float v, bool bit) {
-    if constexpr (X == 1) {
-        return dpp_mov<0xB1>(v);  // quad_perm:[1,0,3,2]
-    } else if constexpr (X == 2) {
-        return dpp_mov<0x4E>(v);  // quad_perm:[2,3,0,1]
+__device__ __forceinline__ void xstage1(float lo, float hi, bool bit, float &nlo, float &nhi) {
+    if constexpr (X == 4) {
+        nlo = dpp_mov<0x124, 0xA>(lo, hi);  // row_ror:4  -> lanes 4-7, 12-15 take hi of lane - 4
+        nhi = dpp_mov<0x12C, 0x5>(hi, lo);  // row_ror:12 -> lanes 0-3, 8-11 take lo of lane + 4
     } else if constexpr (X == 8) {
-        return dpp_mov<0x128>(v);  // row_ror:8
+        nlo = dpp_mov<0x128, 0xC>(lo, hi);  // row_ror:8 -> lanes 8-15 take hi of lane - 8
+        nhi = dpp_mov<0x128, 0x3>(hi, lo);  //           -> lanes 0-7 take lo of lane + 8
     } else {
-        static_assert(X == 4, "row_xor: 1, 2, 4, 8");
-        const float from_minus4 = dpp_mov<0x124>(v), from_plus4 = dpp_mov<0x12C>(v);  // row_ror:4, row_ror:12
-        return bit ? from_minus4 : from_plus4;
+        constexpr int QP = X == 1 ? 0xB1 : 0x4E;  // quad_perm:[1,0,3,2] / [2,3,0,1]
+        const float phi = dpp_mov<QP>(hi, hi), plo = dpp_mov<QP>(lo, lo);
+        nlo = bit ? phi : lo;
+        nhi = bit ? hi : plo;
     }
 }
-
-// swap lane bit X with one element-index bit: the lane whose bit is clear sends `hi` and receives into `hi`,
-// its partner sends `lo` and receives into `lo`
 template <int X>
-__device__ __forceinline__ void xstage(Cx &lo, Cx &hi, bool bit) {
-    const float sr = bit ? lo.r : hi.r, si = bit ? lo.i : hi.i;
-    const float xr = row_xor<X>(sr, bit), xi = row_xor<X>(si, bit);
-    lo.r = bit ? xr : lo.r;
-    lo.i = bit ? xi : lo.i;
-    hi.r = bit ? hi.r : xr;
-    hi.i = bit ? hi.i : xi;
+__device__ __forceinline__ void xstage(v2f &lo, v2f &hi, bool bit) {
+    float lx, hx, ly, hy;
+    xstage1<X>(lo.x, hi.x, bit, lx, hx);
+    xstage1<X>(lo.y, hi.y, bit, ly, hy);
+    lo = v2f{lx, ly};
+    hi = v2f{hx, hy};
 }
 
 // 4x4 transpose between the lane bits (XA, XB) and the element index of v[0..3]
 template <int XA, int XB>
-__device__ __forceinline__ void transpose4(Cx v[4], int gl) {
+__device__ __forceinline__ void transpose4(v2f v[4], int gl) {
     const bool ba = (gl & XA) != 0, bb = (gl & XB) != 0;
     xstage<XA>(v[0], v[1], ba);
     xstage<XA>(v[2], v[3], ba);
@@ -73,25 +73,19 @@ __device__ __forceinline__ int fft64_src_point(int gl, int m) {
 // bitrv2 + cftfsub (forward) / cftbsub (inverse) on 64 complex points.  in: v[m] = point fft64_src_point(gl, m);
 // out: v[m] = point gl + 16 m.
 template <bool INVERSE>
-__device__ __forceinline__ void fft64_regs(Cx v[4], const FftTables *T, int gl) {
-    float2 o0, o1, o2, o3;
-    bfly4(gl, T, v[0], v[1], v[2], v[3], o0, o1, o2, o3);
-    v[0] = Cx{o0.x, o0.y};
-    v[1] = Cx{o1.x, o1.y};
-    v[2] = Cx{o2.x, o2.y};
-    v[3] = Cx{o3.x, o3.y};
+__device__ __forceinline__ void fft64_regs(v2f v[4], const FftTables *T, int gl) {
+    bfly4_v(gl, T, v);
     transpose4<1, 2>(v, gl);
-    bfly4(gl >> 2, T, v[0], v[1], v[2], v[3], o0, o1, o2, o3);
-    v[0] = Cx{o0.x, o0.y};
-    v[1] = Cx{o1.x, o1.y};
-    v[2] = Cx{o2.x, o2.y};
-    v[3] = Cx{o3.x, o3.y};
+    bfly4_v(gl >> 2, T, v);
     transpose4<4, 8>(v, gl);
-    bfly4_close<INVERSE>(v[0], v[1], v[2], v[3], o0, o1, o2, o3);
-    v[0] = Cx{o0.x, o0.y};
-    v[1] = Cx{o1.x, o1.y};
-    v[2] = Cx{o2.x, o2.y};
-    v[3] = Cx{o3.x, o3.y};
+    bfly4_close_v<INVERSE>(v);
+}
+template <bool INVERSE>
+__device__ __forceinline__ void fft64_regs(Cx c[4], const FftTables *T, int gl) {
+    v2f v[4] = {cx(c[0]), cx(c[1]), cx(c[2]), cx(c[3])};
+    fft64_regs<INVERSE>(v, T, gl);
+#pragma unroll
+    for (int m = 0; m < 4; m++) c[m] = Cx{v[m].x, v[m].y};
 }
 
 // Input side of rdft(128, -1, a): point p (0..63) of the complex array the inverse passes start from, computed
