@@ -137,6 +137,20 @@ def test_chain_many_streams_vs_oracle(cuda, oracle_port):
     check_float_path(gpu_chain(cuda, 1, freq, 15, far, near), want)
 
 
+def test_chain_parity_gate_3000_frames(cuda, oracle_port):
+    """SURVEY section 8d parity gate: the full NS -> AEC -> AGC -> VAD chain over a 3 000-frame (30 s) run, 64 streams
+    of a larger batch (256) picked at random, <= 1 LSB and <= 1e-3 RMS against the generic-C oracle.  Crosses every
+    start-up phase (NS 50 / 200 / 500 / 1000 / ... blocks, AEC 1000 noise-init blocks, AGC and VAD hang-overs)."""
+    from wmix_amd import synth
+    S, n, freq = 256, 3000, 16000
+    far = synth.far_end(8001, n, 160)
+    near = synth.near_end(8100, S, n, 160, far=far)
+    got = gpu_chain(cuda, 1, freq, 15, far, near, pkts_per_launch=50)
+    pick = np.random.default_rng(8).choice(S, 64, replace=False)
+    want = np.stack([L.run_chain(oracle_port, 1, freq, 5, 15, far, near[s], 160, prefix="orc") for s in pick])
+    check_float_path(got[pick], want)
+
+
 def test_reference_host_signatures(wmx, oracle_port):
     """aec_init / aec_process2 / aec_setFrameFar + aec_process / aec_release over HOST buffers (src/webrtc.h:40-45)."""
     assert wmx.aec_init(1, 32000, 10, None) is None
