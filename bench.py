@@ -275,13 +275,24 @@ class ChainWorkload:
         n = 2000
         far = np.tile(self.far_src.cpu().numpy().reshape(-1), n // self.K + 1)[: n * self.pkt]
         near = np.tile(np.ascontiguousarray(self.inp[:, 0].cpu().numpy().reshape(-1)), n // self.K + 1)[: n * self.pkt]
-        t0 = time.perf_counter()
-        reps = 0
-        while time.perf_counter() - t0 < budget_s:
-            loader.run_chain(port, 1, self.freq, 5, 15, far, near, self.pkt, prefix="orc")
-            reps += 1
-        dt = time.perf_counter() - t0
-        return {"value": reps * n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+        def timed(lib, prefix, seconds):
+            t0 = time.perf_counter()
+            reps = 0
+            while time.perf_counter() - t0 < seconds:
+                loader.run_chain(lib, 1, self.freq, 5, 15, far, near, self.pkt, prefix=prefix)
+                reps += 1
+            return reps, reps * n / (time.perf_counter() - t0)
+
+        if loader.have_ref():
+            # the real reference (src/webrtc.c over the vendored WebRTC, gcc -O2, generic-C AEC kernels), prebuilt by
+            # oracle/Makefile where /root/reference exists; our restatement timed beside it for comparison
+            reps, v = timed(loader.ref(), "ref", budget_s * 0.7)
+            _, vp = timed(port, "orc", budget_s * 0.3)
+            return {"value": v, "unit": "frames/s", "cores": 1, "kind": "reference", "port_value": vp,
+                    "sample": "%d x %d packets of one 16 kHz stream through the reference chain ns_process -> aec_process2 -> "
+                              "agc_process -> vad_process (oracle/_ref/libwmixref.so, -O2), 1 thread" % (reps, n)}
+        reps, v = timed(port, "orc", budget_s)
+        return {"value": v, "unit": "frames/s", "cores": 1, "kind": "port",
                 "sample": "%d x %d packets of one 16 kHz stream through the oracle chain (oracle/orc_*.c, -O2), 1 thread" % (reps, n)}
 
 
