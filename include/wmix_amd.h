@@ -172,6 +172,25 @@ int wmx_mfft(int kind, int n_batch, unsigned N, const float *d_in_re, const floa
 int wmx_mfft_stream(int n_streams, const float *d_in, unsigned in_len, float *d_pool, unsigned st_len, float *d_out_af,
                     float *d_out_pf, void *stream);
 
+/* ------------------------------------------------------------------ RTP / G.711 packet edge
+ * Egress: for n_streams senders set up like wmix_thread_rtp_send_pcma does (src/wmixTask.c:1058: v = 2, m = 1,
+ * seq = timestamp = ssrc = 0; pt 8 for law WMX_LAW_A, pt 0 for WMX_LAW_U), one call produces one datagram per stream
+ * from that stream's PCM: wmix_pcm_zoom(in_chn, in_freq -> out_chn, out_freq), G.711 encode, timestamp += codes /
+ * out_chn, network-order header (src/rtp.c:35-70, src/rtp.h:37-75), seq += 1 -- the loop body of
+ * src/wmixTask.c:1124-1143 fused into one kernel.  d_pcm rows are pcm_stride int16 apart and in_bytes long; d_packets
+ * rows packet_stride bytes apart; *packet_bytes receives 12 + number of codes.
+ * Ingest (stateless): payload size by payload type as rtp_recv decides it (160 for PCMA / PCMU, else 0;
+ * src/rtp.c:86-95) and G711a2PCM of the payload (src/wmixTask.c:1282): d_pcm rows get 160 int16, d_pcm_bytes[s] = 320
+ * or 0, d_seq_raw[s] = header bytes 2..3 as the reference leaves them (no ntohs).  Optional outputs may be NULL. */
+typedef struct wmx_rtp wmx_rtp;
+int wmx_rtp_create(wmx_rtp **out, int n_streams, int law);
+int wmx_rtp_destroy(wmx_rtp *h);
+int wmx_rtp_egress(wmx_rtp *h, int in_chn, int in_freq, const int16_t *d_pcm, uint32_t in_bytes, long pcm_stride, int out_chn,
+                   int out_freq, uint8_t *d_packets, long packet_stride, uint32_t *packet_bytes, void *stream);
+int wmx_rtp_ingest(int n_streams, const uint8_t *d_packets, long packet_stride, int16_t *d_pcm, long pcm_stride,
+                   uint32_t *d_pcm_bytes, uint16_t *d_seq_raw, void *stream);
+int wmx_rtp_export(wmx_rtp *h, int stream_index, uint16_t *seq, uint32_t *timestamp);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,11 +17,23 @@
  *        bytes from ring start; writes the whole ring (WMIX_BUFF_SIZE bytes) then
  *        per source: uint32 tick, uint32 head offset.
  *   ref_mix_driver consts  -> prints WMIX_CHN WMIX_FREQ WMIX_BUFF_SIZE VIEW_PLAY_CORRECT
+ *   ref_mix_driver rtpsend chn freq <ring.pcm >packets.bin
+ *        the loop body of wmix_thread_rtp_send_pcma (src/wmixTask.c:1124-1143) over stdin cut into chunks of
+ *        wmix_len_of_in(..20 ms..) bytes: wmix_pcm_zoom -> PCM2G711a -> timestamp += n/chn -> rtp_send over UDP
+ *        loopback; what arrives on the wire is written as [uint32 len][bytes] per packet.
+ *   ref_mix_driver rtprecv <packets.bin >pcm.bin
+ *        every [uint32 len][bytes] record is sent to a socket opened with rtp_socket(bind) and taken through
+ *        rtp_recv + G711a2PCM (src/wmixTask.c:1278-1282); writes [uint32 pcm_bytes][pcm][uint16 header seq as stored].
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "wmix.h"
+#include "rtp.h"
+#include "g711codec.h"
+#include <arpa/inet.h>
+#include <sys/socket.h>
+#include <unistd.h>
 
 static unsigned char *slurp(size_t *n)
 {
@@ -40,6 +52,80 @@ int main(int argc, char **argv)
     if (argc < 2) return 2;
     if (!strcmp(argv[1], "consts")) {
         printf("%d %d %d %d\n", WMIX_CHN, WMIX_FREQ, WMIX_BUFF_SIZE, VIEW_PLAY_CORRECT);
+        return 0;
+    }
+    if (!strcmp(argv[1], "rtpsend") && argc == 4) {
+        const int chn = atoi(argv[2]), freq = atoi(argv[3]);
+        size_t n;
+        unsigned char *in = slurp(&n);
+        /* a plain receiving socket on an ephemeral loopback port */
+        int rx = socket(AF_INET, SOCK_DGRAM, 0);
+        struct sockaddr_in a;
+        socklen_t al = sizeof(a);
+        memset(&a, 0, sizeof(a));
+        a.sin_family = AF_INET;
+        a.sin_addr.s_addr = inet_addr("127.0.0.1");
+        if (bind(rx, (struct sockaddr *)&a, sizeof(a)) < 0 || getsockname(rx, (struct sockaddr *)&a, &al) < 0) return 3;
+        SocketStruct *ss = rtp_socket("127.0.0.1", ntohs(a.sin_port), false);
+        if (!ss) return 4;
+        RtpPacket pkt;
+        rtp_header(&pkt, 0, 0, 0, RTP_VESION, RTP_PAYLOAD_TYPE_PCMA, 1, 0, 0, 0);
+        const uint32_t distSize = WMIX_INTERVAL_MS * freq / 1000 * chn * 16 / 8;
+        const uint32_t srcSize = wmix_len_of_in(WMIX_CHN, WMIX_FREQ, chn, freq, distSize);
+        unsigned char *dist = calloc(distSize * 2 + 64, 1);
+        for (size_t off = 0; off + srcSize <= n; off += srcSize) {
+            int ret = wmix_pcm_zoom(WMIX_CHN, WMIX_FREQ, in + off, srcSize, chn, freq, dist);
+            ret = PCM2G711a((char *)dist, (char *)pkt.payload, ret, 0);
+            pkt.rtpHeader.timestamp += ret / chn;
+            ret = rtp_send(ss, &pkt, ret);
+            if (ret < 0) return 5;
+            unsigned char wire[5000];
+            int got = -1;
+            for (int tries = 0; tries < 1000 && got < 0; tries++) {
+                got = recv(rx, wire, sizeof(wire), MSG_DONTWAIT);
+                if (got < 0) usleep(1000);
+            }
+            if (got < 0) return 6;
+            uint32_t g = (uint32_t)got;
+            fwrite(&g, 4, 1, stdout);
+            fwrite(wire, 1, g, stdout);
+        }
+        return 0;
+    }
+    if (!strcmp(argv[1], "rtprecv") && argc == 2) {
+        size_t n;
+        unsigned char *in = slurp(&n);
+        const int port = 20000 + (getpid() % 20000);
+        SocketStruct *ss = rtp_socket("127.0.0.1", port, true);
+        if (!ss) return 4;
+        int tx = socket(AF_INET, SOCK_DGRAM, 0);
+        struct sockaddr_in a;
+        memset(&a, 0, sizeof(a));
+        a.sin_family = AF_INET;
+        a.sin_port = htons(port);
+        a.sin_addr.s_addr = inet_addr("127.0.0.1");
+        for (size_t off = 0; off + 4 <= n;) {
+            uint32_t len;
+            memcpy(&len, in + off, 4);
+            off += 4;
+            if (sendto(tx, in + off, len, 0, (struct sockaddr *)&a, sizeof(a)) < 0) return 5;
+            off += len;
+            RtpPacket pkt;
+            uint32_t retSize = 0;
+            int ret = -1;
+            for (int tries = 0; tries < 1000 && ret <= 0; tries++) {
+                ret = rtp_recv(ss, &pkt, &retSize);
+                if (ret <= 0) usleep(1000);
+            }
+            if (ret <= 0) return 6;
+            unsigned char buff[1024];
+            memset(buff, 0, sizeof(buff));
+            uint32_t pcm = (uint32_t)G711a2PCM((char *)pkt.payload, (char *)buff, retSize, 0);
+            uint16_t seq = pkt.rtpHeader.seq;
+            fwrite(&pcm, 4, 1, stdout);
+            fwrite(buff, 1, pcm > sizeof(buff) ? sizeof(buff) : pcm, stdout);
+            fwrite(&seq, 2, 1, stdout);
+        }
         return 0;
     }
     if (!strcmp(argv[1], "lenout") && argc == 7) {

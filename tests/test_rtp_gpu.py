@@ -1,0 +1,82 @@
+"""RTP / G.711 packet edge on the GPU (wmix_amd/csrc/rtp.hip through the C-ABI): bit-exact against the datagrams of
+the real reference (golden) and against the oracle for batches."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+sys.path.insert(0, GOLDEN)
+from make_rtp_golden import N_PACKETS, SEND_CASES, ring_pcm  # noqa: E402
+from test_rtp_oracle import orc_send  # noqa: E402
+from wmix_amd import rtp  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(GOLDEN, "rtp_golden.npz"))
+
+
+@pytest.mark.parametrize("c", range(len(SEND_CASES)))
+def test_egress_golden(cuda, c):
+    chn, freq = SEND_CASES[c]
+    pcm = ring_pcm(c, N_PACKETS).reshape(N_PACKETS, -1)
+    snd = rtp.RtpSenders(1, "a")
+    for k in range(N_PACKETS):
+        pkt = snd.egress(torch.from_numpy(pcm[k:k + 1].copy()).to(cuda), 1, 8000, chn, freq)
+        assert np.array_equal(pkt.cpu().numpy()[0], G["send_%d" % c][k]), k
+    assert snd.state(0) == (N_PACKETS, N_PACKETS * (G["send_%d" % c].shape[1] - 12) // chn)
+    snd.close()
+
+
+def test_ingest_golden(cuda):
+    pcm, nbytes, seq = rtp.ingest(torch.from_numpy(G["recv_in"].copy()).to(cuda))
+    assert np.array_equal(nbytes.cpu().numpy().astype(np.uint32), G["recv_bytes"])
+    assert np.array_equal(seq.cpu().numpy().view(np.uint16), G["recv_seq"])
+    got = pcm.cpu().numpy()
+    for k in range(len(G["recv_in"])):
+        assert np.array_equal(got[k, : G["recv_bytes"][k] // 2], G["recv_pcm"][k, : G["recv_bytes"][k] // 2]), k
+
+
+@pytest.mark.parametrize("law", [0, 1])
+def test_many_streams_vs_oracle(cuda, oracle_port, law):
+    """4096 senders, 70 000 packets' worth of sequence numbers would take too long: start near the uint16 wrap
+    instead (export/import is not part of the API, so run 3 packets and compare streams against the oracle)."""
+    S, n = 4096, 3
+    base = np.stack([ring_pcm(20 + s, n) for s in range(8)])  # 8 distinct inputs
+    pcm = base[np.arange(S) % 8].reshape(S, n, 160)
+    snd = rtp.RtpSenders(S, "au"[law])
+    d = torch.from_numpy(pcm).to(cuda)
+    for k in range(n):
+        pk = snd.egress(d[:, k].contiguous(), 1, 8000, 1, 8000).cpu().numpy()
+        for s in (0, 1, 7, 4095):
+            want, _ = orc_send(oracle_port, law, 1, 8000, base[s % 8][: 160 * (k + 1)], k + 1)
+            assert np.array_equal(pk[s], want[k]), (k, s)
+    assert snd.state(4095) == (n, 160 * n)
+    snd.close()
+
+
+def test_round_trip_full_size(cuda):
+    """configs-size property: 65 536 streams, egress then ingest returns decode(encode(x)) (G.711 is idempotent after
+    one pass), sequence numbers count up, header bytes are constant."""
+    from wmix_amd import g711
+    S = 65536
+    x = torch.randint(-20000, 20000, (S, 160), dtype=torch.int16, device=cuda)
+    snd = rtp.RtpSenders(S, "a")
+    p0 = snd.egress(x, 1, 8000, 1, 8000).clone()
+    p1 = snd.egress(x, 1, 8000, 1, 8000)
+    assert p0.shape == (S, 172) and bool((p0[:, 0] == 0x80).all()) and bool((p0[:, 1] == 0x88).all())
+    assert bool((p0[:, 3] == 0).all()) and bool((p1[:, 3] == 1).all()) and bool((p1[:, 7] == (320 & 0xFF)).all())
+    pcm, nbytes, _ = rtp.ingest(p1)
+    assert bool((nbytes == 320).all())
+    assert torch.equal(pcm, g711.decode("a", g711.encode("a", x)))
+    snd.close()
+
+
+def test_rejects_bad_arguments(wmx):
+    h = C.c_void_p()
+    assert wmx.wmx_rtp_create(C.byref(h), 0, 0) == -10001
+    assert wmx.wmx_rtp_create(C.byref(h), 4, 5) == -10001
+    assert wmx.wmx_rtp_ingest(1, None, 172, None, 160, None, None, None) == -10001

@@ -111,6 +111,16 @@ def _declare(L):
     L.wmx_mfft.argtypes = [i, i, C.c_uint, vp, vp, vp, vp, vp, vp, vp]
     L.wmx_mfft_stream.restype = i
     L.wmx_mfft_stream.argtypes = [i, vp, C.c_uint, vp, C.c_uint, vp, vp, vp]
+    L.wmx_rtp_create.restype = i
+    L.wmx_rtp_create.argtypes = [C.POINTER(vp), i, i]
+    L.wmx_rtp_destroy.restype = i
+    L.wmx_rtp_destroy.argtypes = [vp]
+    L.wmx_rtp_egress.restype = i
+    L.wmx_rtp_egress.argtypes = [vp, i, i, vp, C.c_uint32, C.c_long, i, i, vp, C.c_long, C.POINTER(C.c_uint32), vp]
+    L.wmx_rtp_ingest.restype = i
+    L.wmx_rtp_ingest.argtypes = [i, vp, C.c_long, vp, C.c_long, vp, vp, vp]
+    L.wmx_rtp_export.restype = i
+    L.wmx_rtp_export.argtypes = [vp, i, C.POINTER(C.c_uint16), C.POINTER(C.c_uint32)]
     L.wmx_mix_create.restype = i
     L.wmx_mix_create.argtypes = [C.POINTER(vp), i, i, i]
     L.wmx_mix_destroy.restype = i

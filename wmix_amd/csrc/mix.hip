@@ -238,6 +238,15 @@ struct DevVec {
 };
 
 }  // namespace
+
+void zoom_gather_list(int inChn, int inFreq, uint32_t inLen, int outChn, int outFreq, std::vector<int32_t> &idx) {
+    if (inChn == outChn && inFreq == outFreq) {
+        idx.resize(inLen / 2);
+        for (size_t i = 0; i < idx.size(); i++) idx[i] = (int32_t)i;
+        return;
+    }
+    zoom_schedule((uint8_t)inChn, (uint16_t)inFreq, inLen, (uint8_t)outChn, (uint16_t)outFreq, idx);
+}
 }  // namespace wmx
 
 struct wmx_mix {

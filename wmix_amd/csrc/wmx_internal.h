@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 #include "../../include/wmix_amd.h"
 
 namespace wmx {
@@ -22,6 +23,10 @@ inline unsigned stream_grid(size_t work_items, unsigned block) {
     if (need < 1) need = 1;
     return (unsigned)(need < cap ? need : cap);
 }
+
+// wmix_pcm_zoom's cursor walk (src/wmix.c:139-222) as a gather list: out int16 i <- in int16 idx[i]; identical formats
+// give the identity (the reference's memcpy branch).  Defined in mix.hip.
+void zoom_gather_list(int inChn, int inFreq, uint32_t inLen, int outChn, int outFreq, std::vector<int32_t> &idx);
 
 }  // namespace wmx
 
