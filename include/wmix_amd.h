@@ -191,6 +191,10 @@ int wmx_rtp_ingest(int n_streams, const uint8_t *d_packets, long packet_stride, 
                    uint32_t *d_pcm_bytes, uint16_t *d_seq_raw, void *stream);
 int wmx_rtp_export(wmx_rtp *h, int stream_index, uint16_t *seq, uint32_t *timestamp);
 
+/* Developer / test hook: the NS kernels' table-driven log (kind 0, x >= 1) and exp (kind 1) evaluated on the host from
+ * the same source (wmix_amd/csrc/libm_dev.h), for sweeping against libm without a GPU. */
+int wmx_debug_ns_libm(int kind, const float *x, float *y, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,52 @@
+"""The NS kernels' table-driven log / exp (wmix_amd/csrc/libm_dev.h), evaluated on the host from the same source
+through wmx_debug_ns_libm, swept against the reference's own expression float(log((double)x)) / float(exp((double)x))
+with glibc (oracle/orc_libm.c).  No GPU needed: the functions are plain IEEE double arithmetic with explicit fma."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def _run(fn, x):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.zeros_like(x)
+    fn(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), C.c_size_t(x.size))
+    return y
+
+
+def _product(wmx, kind, x):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.zeros_like(x)
+    assert wmx.wmx_debug_ns_libm(kind, x.ctypes.data, y.ctypes.data, x.size) == 0
+    return y
+
+
+def test_log_sweep(wmx, oracle_port):
+    """every argument class the NS produces: magn = |X| + 1 in [1, 1e8], 1 + 2 snr; dense next to 1 where log -> 0"""
+    rng = np.random.default_rng(11)
+    x = np.concatenate([
+        1 + rng.random(3_000_000) * 1e-4, 1 + rng.random(3_000_000), np.exp(rng.random(6_000_000) * 18.5),
+        np.float32(1) + np.arange(0, 4096, dtype=np.float32) * np.float32(2 ** -23),  # the first floats above 1
+        2.0 ** np.arange(0, 40), np.array([1.0, 3.0e7, 3.3e38, np.inf, 0.5, 0.0, -1.0, np.nan]),  # last ones: fallback path
+    ]).astype(np.float32)
+    with np.errstate(all="ignore"):
+        got, want = _product(wmx, 0, x), _run(oracle_port.orc_libm_log, x)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_exp_sweep(wmx, oracle_port):
+    """exp(-logLrt), exp(lquantile), exp(flatness): [-120, 90] incl. float-denormal results, overflow, specials"""
+    rng = np.random.default_rng(12)
+    x = np.concatenate([
+        rng.random(6_000_000) * -120, rng.random(4_000_000) * 40 - 10, rng.random(1_000_000) * 2e-3 - 1e-3,
+        np.arange(-110, 95, 0.25), np.array([0.0, -0.0, 88.72, 88.73, 100, 710, -710, -800, np.inf, -np.inf, np.nan]),
+    ]).astype(np.float32)
+    with np.errstate(all="ignore"):
+        got, want = _product(wmx, 1, x), _run(oracle_port.orc_libm_exp, x)
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.array_equal(got.view(np.uint32)[~nan], want.view(np.uint32)[~nan])
+
+
+def test_rejects_bad_arguments(wmx):
+    assert wmx.wmx_debug_ns_libm(5, None, None, 0) == -10001

@@ -16,4 +16,84 @@ __device__ __noinline__ static float exp_d(float x) { return (float)exp((double)
 __device__ __noinline__ static float tanh_d(float x) { return (float)tanh((double)x); }
 __device__ __noinline__ static float pow_d(float x, float y) { return (float)pow((double)x, (double)y); }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Table-driven log / exp for the NS's per-bin calls.  The reference computes float(log((double)x)) and
+// float(exp((double)x)) with glibc (error < 1 ulp of double).  Any double result within ~1 ulp of the true value rounds
+// to the same float except when the true value lies within that ulp of a float rounding boundary (probability ~2^-28
+// per call) -- the same exposure the ocml routines have.  These keep that accuracy class (a few 2^-53 relative) with
+// ~25 fp64 operations instead of ocml's ~100-400 (it carries double-double arithmetic for a 0.5-ulp bound that the
+// final rounding to float throws away):
+//   log(x), x >= 1:  x = 2^e * m, m in [1,2); c = 1 + idx/128 (idx = top 7 mantissa bits), r = m * RN(1/c) - 1 in
+//                    [0, 2^-7); log x = e*ln2 + log c + log1p(r), log1p by its Taylor polynomial to r^9 (r^10/10 <
+//                    2^-73).  idx = 0 has c = 1, log c = 0, so log(1.0f) = 0 exactly and values next to 1 keep full
+//                    relative accuracy.
+//   exp(x):          k = rint(x * 64/ln2), r = x - k*ln2/64 (two-part constant), |r| <= 0.0055;
+//                    e^x = 2^(k>>6) * T[k&63] * (1 + expm1(r)), expm1 by Taylor to r^6 (r^7/5040 < 2^-63).
+// Tables (NsLibmTables, built by the host with the host libm) live in LDS with the other per-block constants.
+struct NsLibmTables {
+    double2 logtab[128];  // (RN(1/c), RN(log c)), c = 1 + i/128
+    double exptab[64];    // 2^(j/64)
+};
+constexpr int kNsLibmWords = sizeof(NsLibmTables) / 4;
+
+inline void ns_libm_tables(NsLibmTables *t) {
+    for (int i = 0; i < 128; i++) {
+        const double c = 1.0 + i / 128.0;
+        t->logtab[i].x = 1.0 / c;
+        t->logtab[i].y = log(c);
+    }
+    for (int j = 0; j < 64; j++) t->exptab[j] = exp2(j / 64.0);
+}
+
+__host__ __device__ __forceinline__ float fast_log_ge1(float x, const NsLibmTables &M) {
+    if (!(x >= 1.0f && x < 3.0e38f)) return (float)log((double)x);  // never taken on the NS's arguments (|X| + 1, 1 + 2 snr)
+    unsigned u;
+    __builtin_memcpy(&u, &x, 4);
+    const int e = (int)(u >> 23) - 127;
+    const unsigned mu = (u & 0x007FFFFFu) | 0x3F800000u;
+    float mf;
+    __builtin_memcpy(&mf, &mu, 4);
+    const double m = (double)mf;
+    const double2 t = M.logtab[(u >> 16) & 0x7F];
+    const double r = fma(m, t.x, -1.0);
+    double p = -1.0 / 9.0 * r + 1.0 / 8.0;  // alternating series, highest term r^9/9
+    p = fma(p, r, -1.0 / 7.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, -1.0 / 5.0);
+    p = fma(p, r, 1.0 / 4.0);
+    p = fma(p, r, -1.0 / 3.0);
+    p = fma(p, r, 1.0 / 2.0);
+    p = fma(-p, r, 1.0);
+    p = p * r;  // log1p(r) = r - r^2/2 + ... + r^9/9
+    const double ed = (double)e;
+    constexpr double kLn2Hi = 0x1.62e42fefa38p-1, kLn2Lo = 0x1.ef35793c7673p-45;  // ln2 split: e * hi is exact for |e| < 2^11
+    return (float)(fma(ed, kLn2Hi, t.y) + fma(ed, kLn2Lo, p));
+}
+
+__host__ __device__ __forceinline__ float fast_exp(float xf, const NsLibmTables &M) {
+    const double x = (double)xf;
+    if (!(x > -700.0 && x < 700.0)) return (float)exp(x);  // overflow / deep underflow / NaN: the library routine
+    constexpr double kInv = 0x1.71547652b82fep+6;                                   // 64 / ln2
+    constexpr double kHi = 0x1.62e42fefa0000p-7, kLo = 0x1.cf79abc9e3b3ap-46;       // ln2 / 64, kHi * k exact for |k| < 2^21
+    const double kd = rint(x * kInv);
+    const int k = (int)kd;
+    double r = fma(-kd, kHi, x);
+    r = fma(-kd, kLo, r);
+    double p = fma(r, 1.0 / 720.0, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = p * r;  // expm1(r)
+    const double t = M.exptab[k & 63];
+    const double y = fma(t, p, t);
+    // scale by 2^(k >> 6): y in [1, 2), |k >> 6| < 1100 / 64, the result is a normal double
+    long long bits;
+    __builtin_memcpy(&bits, &y, 8);
+    bits += (long long)(k >> 6) << 52;
+    double z;
+    __builtin_memcpy(&z, &bits, 8);
+    return (float)z;
+}
+
 }  // namespace wmx

@@ -34,6 +34,7 @@
 #include <vector>
 #include "wmx_internal.h"
 #include "fft_ooura.h"
+#include "libm_dev.h"
 #include "ns_layout.h"
 
 namespace wmx {
@@ -51,6 +52,7 @@ struct NsConstLds {
     FftTables tab;                // Ooura tables for n = L
     float window[L];              // hybrid Hanning window (windows_private.h:64,94)
     float logi[NsLayout<L>::MP];  // (float)log((float)i); [MP-2], [MP-1] hold the two data-independent start-up sums
+    NsLibmTables lm;              // tables of fast_log_ge1 / fast_exp (libm_dev.h)
 };
 template <int L>
 struct alignas(16) NsWaveLds {
@@ -220,7 +222,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
                 im = W.fa[2 * b + 1];
                 mg = sqrtf(re * re + im * im) + 1.f;
             }
-            const float lm = (float)log((double)mg);
+            const float lm = fast_log_ge1(mg, K.lm);
             const float pz = st[Y::MAGN_AVG_PAUSE + b];
             W.re[b] = re;
             W.im[b] = im;
@@ -293,9 +295,9 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
                     st[Y::DENSITY + q * Y::MP + b] = dens;
                 }
                 st[Y::LQUANTILE + q * Y::MP + b] = lq;
-                if (cnt >= kStartupLong && updates >= kStartupLong) quant = (float)exp((double)lq);
+                if (cnt >= kStartupLong && updates >= kStartupLong) quant = fast_exp(lq, K.lm);
             }
-            if (updates < kStartupLong) quant = (float)exp((double)lq);  // lq of the last estimator
+            if (updates < kStartupLong) quant = fast_exp(lq, K.lm);  // lq of the last estimator
             st[Y::QUANTILE + b] = quant;
             W.noise[b] = quant;
         }
@@ -386,7 +388,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             den -= magn0;
             den = den / (float)M;
             const float num = flat_num / (float)M;
-            const float tmp = (float)exp((double)num) / den;
+            const float tmp = fast_exp(num, K.lm) / den;
             feat_flat += 0.3f * (tmp - feat_flat);
         }
         float cov, var_pause, var_magn;
@@ -532,7 +534,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             const float t2 = 2.f * sp / (t1 + 0.0001f);
             const float bessel = (W.snrq[b] + 1.f) * t2;
             float v = st[Y::LOG_LRT + b];
-            v += 0.5f * (bessel - (float)log((double)t1) - v);
+            v += 0.5f * (bessel - fast_log_ge1(t1, K.lm) - v);
             st[Y::LOG_LRT + b] = v;
             W.r0[b] = v;
         }
@@ -546,13 +548,18 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         {
             float width = 4.0f;
             if (ksum < thr_lrt) width = 2.f * 4.0f;
-            const float ind0 = 0.5f * ((float)tanh((double)(width * (ksum - thr_lrt))) + 1.f);
+            const float a0 = width * (ksum - thr_lrt);
             width = 4.0f;
             if (feat_flat > thr_flat) width = 2.f * 4.0f;
-            const float ind1 = 0.5f * ((float)tanh((double)((float)1 * width * (thr_flat - feat_flat))) + 1.f);
+            const float a1 = (float)1 * width * (thr_flat - feat_flat);
             width = 4.0f;
             if (feat_diff < thr_diff) width = 2.f * 4.0f;
-            const float ind2 = 0.5f * ((float)tanh((double)(width * (feat_diff - thr_diff))) + 1.f);
+            const float a2 = width * (feat_diff - thr_diff);
+            // the three indicator tanh's are wave-uniform scalars: evaluate them in lanes 0..2 of one call
+            const float th = (float)tanh((double)(lane == 1 ? a1 : (lane == 2 ? a2 : a0)));
+            const float ind0 = 0.5f * (lane_value(th, 0) + 1.f);
+            const float ind1 = 0.5f * (lane_value(th, 1) + 1.f);
+            const float ind2 = 0.5f * (lane_value(th, 2) + 1.f);
             const float ind = w_lrt * ind0 + w_flat * ind1 + w_diff * ind2;
             prior += 0.1f * (ind - prior);
             if (prior > 1.f) prior = 1.f;
@@ -562,7 +569,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         const float gain_prior = (1.f - prior) / (prior + 0.0001f);
 #pragma unroll 1
         for (int b = lane; b < M; b += 64) {
-            float inv = (float)exp((double)(-W.r0[b]));
+            float inv = fast_exp(-W.r0[b], K.lm);
             inv = gain_prior * inv;
             W.sprob[b] = 1.f / (1.f + inv);
         }
@@ -723,10 +730,10 @@ __global__ __launch_bounds__(64 * kNsWavesPerBlock, 4) void ns_kernel(float *__r
     using Y = NsLayout<L>;
     __shared__ NsConstLds<L> K;
     __shared__ NsWaveLds<L> Wv[kNsWavesPerBlock];
-    // constants: FftTables | window[L] | logi[MP]
+    // constants: FftTables | window[L] | logi[MP] | libm tables (the host builds the same struct)
     {
         float *dst = reinterpret_cast<float *>(&K);
-        constexpr int NCONST = kFftTableWords + L + Y::MP;
+        constexpr int NCONST = sizeof(NsConstLds<L>) / 4;
         for (int i = threadIdx.x; i < NCONST; i += blockDim.x) dst[i] = consts[i];
     }
     __syncthreads();
@@ -808,7 +815,9 @@ void build_ns_template(std::vector<float> &st, std::vector<float> &consts) {
     st[Y::S_THR_DIFF] = 0.5f;
     st[Y::S_W_LRT] = 1.f;
     // constants block: FftTables | window | log table (+ the two data-independent start-up sums)
-    consts.assign(wmx::kFftTableWords + L + Y::MP, 0.f);
+    static_assert(offsetof(wmx::NsConstLds<L>, lm) == (wmx::kFftTableWords + L + Y::MP) * 4, "constants block layout");
+    consts.assign(sizeof(wmx::NsConstLds<L>) / 4, 0.f);
+    wmx::ns_libm_tables(reinterpret_cast<wmx::NsLibmTables *>(consts.data() + wmx::kFftTableWords + L + Y::MP));
     wmx::FftTables tab;
     wmx::fft_tables_ooura(L, &tab);
     std::memcpy(consts.data(), &tab, sizeof(tab));
@@ -955,3 +964,17 @@ int wmx_ns_process(wmx_ns *h, const int16_t *d_in, int16_t *d_out, int n_packets
 }
 
 }  // extern "C"
+
+// Host-side evaluation of the NS's table-driven log / exp (libm_dev.h) -- the same source the kernels compile, run on
+// the CPU so that the `-m "not gpu"` tests can sweep millions of arguments against glibc.  kind 0: log (x >= 1), 1: exp.
+extern "C" int wmx_debug_ns_libm(int kind, const float *x, float *y, size_t n) {
+    static wmx::NsLibmTables tab;
+    static bool init = false;
+    if (!init) {
+        wmx::ns_libm_tables(&tab);
+        init = true;
+    }
+    if (!x || !y || kind < 0 || kind > 1) return WMX_EINVAL;
+    for (size_t i = 0; i < n; i++) y[i] = kind == 0 ? wmx::fast_log_ge1(x[i], tab) : wmx::fast_exp(x[i], tab);
+    return 0;
+}
