@@ -202,6 +202,21 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         const float overdrive = 1.1f, denoise_bound = 0.125f;  // policy 2, ns_core.c:1030-1033
 
         NS_RELANE();
+        // Per-bin state this frame will need, requested from HBM now and consumed several phases later (the FFT, the
+        // spectrum loop and the ordered sums run in between): the loops below then never wait on HBM latency.
+        constexpr int NI = (M + 63) / 64;  // bins per lane: 3 (M = 129) or 2 (M = 65), the last one lane 0 only
+        float pf_quant[NI], pf_dens[NI][3], pf_lq[NI][3];
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int b = lane + 64 * k;
+            const bool ok = b < M;
+            pf_quant[k] = ok ? st[Y::QUANTILE + b] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                pf_dens[k][q] = ok ? st[Y::DENSITY + q * Y::MP + b] : 0.f;
+                pf_lq[k][q] = ok ? st[Y::LQUANTILE + q * Y::MP + b] : 0.f;
+            }
+        }
         rdft_forward<NC>(W.fa, &K.tab, lane);
         if (lane < Y::MP - M) W.r0[M + lane] = 0.f;  // the window-energy stage above spilled into r0's zero tail
         NS_PROF(1);
@@ -271,16 +286,30 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         if (updates < kStartupLong) updates++;
         sti[Y::S_UPDATES] = updates;
         const int cnt0 = sti[Y::S_COUNTER + 0], cnt1 = sti[Y::S_COUNTER + 1], cnt2 = sti[Y::S_COUNTER + 2];
-#pragma unroll 1
-        for (int b = lane; b < M; b += 64) {
+        // second prefetch wave: what ComputeSnr and SpeechNoiseProb read (consumed after the quantile update and the
+        // next ordered sums)
+        float pf_nprev[NI], pf_mprev[NI], pf_smooth[NI], pf_lrt[NI];
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int b = lane + 64 * k;
+            const bool ok = b < M;
+            pf_nprev[k] = ok ? st[Y::NOISE_PREV + b] : 0.f;
+            pf_mprev[k] = ok ? st[Y::MAGN_PREV + b] : 0.f;
+            pf_smooth[k] = ok ? st[Y::SMOOTH + b] : 0.f;
+            pf_lrt[k] = ok ? st[Y::LOG_LRT + b] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int b = lane + 64 * k;
+            if (b >= M) continue;
             const float lm = W.lmagn[b];
-            float quant = st[Y::QUANTILE + b], lq = 0.f;
+            float quant = pf_quant[k], lq = 0.f;
 #pragma unroll
             for (int q = 0; q < 3; q++) {
                 const int cnt = q == 0 ? cnt0 : (q == 1 ? cnt1 : cnt2);
                 const float c1 = (float)(cnt + 1), cf = (float)cnt;
-                float dens = st[Y::DENSITY + q * Y::MP + b];
-                lq = st[Y::LQUANTILE + q * Y::MP + b];
+                float dens = pf_dens[k][q];
+                lq = pf_lq[k][q];
                 float delta;
                 if (dens > 1.0f)
                     delta = 40.f * 1.f / dens;
@@ -363,11 +392,13 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         //      the spectral-difference sums (ns_core.c:612-620), which need avg_pause / avg_magn only.
         avg_pause = avg_pause / ((float)M);
         const float avg_magn = sum_magn / ((float)M);
-#pragma unroll 1
-        for (int b = lane; b < M; b += 64) {
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int b = lane + 64 * k;
+            if (b >= M) continue;
             const float mg = W.magn[b], nz = W.noise[b];
-            const float np = st[Y::NOISE_PREV + b];
-            const float pe = st[Y::MAGN_PREV + b] / (np + 0.0001f) * st[Y::SMOOTH + b];
+            const float np = pf_nprev[k];
+            const float pe = pf_mprev[k] / (np + 0.0001f) * pf_smooth[k];
             float sq = 0.f;
             if (mg > nz) sq = mg / (nz + 0.0001f) - 1.f;
             W.nprev[b] = np;
@@ -527,13 +558,15 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
 
         NS_RELANE();
         // ---- SpeechNoiseProb (ns_core.c:642-749)
-#pragma unroll 1
-        for (int b = lane; b < M; b += 64) {
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int b = lane + 64 * k;
+            if (b >= M) continue;
             const float sp = W.snrp[b];
             const float t1 = 1.f + 2.f * sp;
             const float t2 = 2.f * sp / (t1 + 0.0001f);
             const float bessel = (W.snrq[b] + 1.f) * t2;
-            float v = st[Y::LOG_LRT + b];
+            float v = pf_lrt[k];
             v += 0.5f * (bessel - fast_log_ge1(t1, K.lm) - v);
             st[Y::LOG_LRT + b] = v;
             W.r0[b] = v;
