@@ -161,6 +161,11 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
 
     // ---- load the packet (channel 0 = low band, channel 1 = "high band") and slide the analysis
     //      buffer (UpdateBuffer, ns_core.c:855-873).  All loads before the stores.
+    // the stream's 24 scalar state words in one coalesced load; read back lane by lane (every field is read at most
+    // once per frame, before it is written)
+    const float scv = lane < 24 ? st[Y::SCALARS + lane] : 0.f;
+#define SCF(f) lane_value(scv, Y::f - Y::SCALARS)
+#define SCI(f) __float_as_int(lane_value(scv, Y::f - Y::SCALARS))
     float buf[NT], hb[NT], synt[NT];
 #pragma unroll
     for (int k = 0; k < NT; k++) {
@@ -195,9 +200,9 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
 
     if (!zero_frame) {
         // ===================================================== Analyze (ns_core.c:1085-1180)
-        const int block_ind = sti[Y::S_BLOCK_IND] + 1;
+        const int block_ind = SCI(S_BLOCK_IND) + 1;
         sti[Y::S_BLOCK_IND] = block_ind;
-        const int update_flag = sti[Y::S_UPDATE_FLAG];
+        const int update_flag = SCI(S_UPDATE_FLAG);
         const bool startup = block_ind < kStartupShort;
         const float overdrive = 1.1f, denoise_bound = 0.125f;  // policy 2, ns_core.c:1030-1033
 
@@ -205,11 +210,12 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         // Per-bin state this frame will need, requested from HBM now and consumed several phases later (the FFT, the
         // spectrum loop and the ordered sums run in between): the loops below then never wait on HBM latency.
         constexpr int NI = (M + 63) / 64;  // bins per lane: 3 (M = 129) or 2 (M = 65), the last one lane 0 only
-        float pf_quant[NI], pf_dens[NI][3], pf_lq[NI][3];
+        float pf_quant[NI], pf_dens[NI][3], pf_lq[NI][3], pf_pause[NI];
 #pragma unroll
         for (int k = 0; k < NI; k++) {
             const int b = lane + 64 * k;
             const bool ok = b < M;
+            pf_pause[k] = ok ? st[Y::MAGN_AVG_PAUSE + b] : 0.f;
             pf_quant[k] = ok ? st[Y::QUANTILE + b] : 0.f;
 #pragma unroll
             for (int q = 0; q < 3; q++) {
@@ -223,8 +229,10 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
 
         NS_RELANE();
         // ---- spectrum, magnitude, log-magnitude (FFT() ns_core.c:886-911; :228, :1095)
-#pragma unroll 1
-        for (int b = lane; b < M; b += 64) {
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int b = lane + 64 * k;
+            if (b >= M) continue;
             float re, im = 0.f, mg;
             if (b == 0) {
                 re = W.fa[0];
@@ -238,7 +246,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
                 mg = sqrtf(re * re + im * im) + 1.f;
             }
             const float lm = fast_log_ge1(mg, K.lm);
-            const float pz = st[Y::MAGN_AVG_PAUSE + b];
+            const float pz = pf_pause[k];
             W.re[b] = re;
             W.im[b] = im;
             W.magn[b] = mg;
@@ -282,10 +290,10 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
 
         NS_RELANE();
         // ---- NoiseEstimation (ns_core.c:217-285)
-        int updates = sti[Y::S_UPDATES];
+        int updates = SCI(S_UPDATES);
         if (updates < kStartupLong) updates++;
         sti[Y::S_UPDATES] = updates;
-        const int cnt0 = sti[Y::S_COUNTER + 0], cnt1 = sti[Y::S_COUNTER + 1], cnt2 = sti[Y::S_COUNTER + 2];
+        const int cnt0 = SCI(S_COUNTER + 0), cnt1 = SCI(S_COUNTER + 1), cnt2 = SCI(S_COUNTER + 2);
         // second prefetch wave: what ComputeSnr and SpeechNoiseProb read (consumed after the quantile update and the
         // next ordered sums)
         float pf_nprev[NI], pf_mprev[NI], pf_smooth[NI], pf_lrt[NI];
@@ -338,7 +346,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         NS_PROF(4);
         // ---- start-up white/pink parametric noise model (ns_core.c:1108-1160); parametricNoise kept in r1
         if (startup) {
-            const float white = st[Y::S_WHITE] + sum_magn / ((float)M) * overdrive;
+            const float white = SCF(S_WHITE) + sum_magn / ((float)M) * overdrive;
             st[Y::S_WHITE] = white;
             const float sum_log_i = K.logi[Y::MP - 2], sum_log_i_sq = K.logi[Y::MP - 1];
             float t1 = sum_log_i_sq * ((float)(M - kStartBand));
@@ -346,14 +354,14 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             float t2 = (sum_log_i_sq * sum_log_magn - sum_log_i * sum_log_i_log_magn);
             float t3 = t2 / t1;
             if (t3 < 0.f) t3 = 0.f;
-            const float pink_num = st[Y::S_PINK_NUM] + t3;
+            const float pink_num = SCF(S_PINK_NUM) + t3;
             st[Y::S_PINK_NUM] = pink_num;
             t2 = (sum_log_i * sum_log_magn);
             t2 -= ((float)(M - kStartBand)) * sum_log_i_log_magn;
             t3 = t2 / t1;
             if (t3 < 0.f) t3 = 0.f;
             if (t3 > 1.f) t3 = 1.f;
-            const float pink_exp = st[Y::S_PINK_EXP] + t3;
+            const float pink_exp = SCF(S_PINK_EXP) + t3;
             st[Y::S_PINK_EXP] = pink_exp;
             float pnum = 0.0f, pexp = 0.0f;
             if (pink_exp > 0.f) {
@@ -380,7 +388,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             }
         }
         // normalisation of the spectral-difference feature (ns_core.c:1163-1167)
-        float feat_norm = st[Y::S_FEAT_NORM];
+        float feat_norm = SCF(S_FEAT_NORM);
         if (block_ind < kStartupLong) {
             feat_norm *= (float)block_ind;
             feat_norm += signal_energy;
@@ -413,7 +421,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         wave_sync();
         NS_PROF(5);
         // ---- FeatureUpdate: spectral flatness (ns_core.c:523-556), difference (:595-634)
-        float feat_flat = st[Y::S_FEAT_FLAT];
+        float feat_flat = SCF(S_FEAT_FLAT);
         {
             float den = sum_magn;
             den -= magn0;
@@ -438,19 +446,19 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         cov = cov / ((float)M);
         var_pause = var_pause / ((float)M);
         var_magn = var_magn / ((float)M);
-        float feat_acc = st[Y::S_FEAT_ACC] + signal_energy;
-        float feat_diff = st[Y::S_FEAT_DIFF];
+        float feat_acc = SCF(S_FEAT_ACC) + signal_energy;
+        float feat_diff = SCF(S_FEAT_DIFF);
         {
             float d = var_magn - (cov * cov) / (var_pause + 0.0001f);
             d = d / (feat_norm + 0.0001f);
             feat_diff += 0.3f * (d - feat_diff);
         }
-        float feat_lrt = st[Y::S_FEAT_LRT];
-        float thr_lrt = st[Y::S_THR_LRT], thr_flat = st[Y::S_THR_FLAT], thr_diff = st[Y::S_THR_DIFF];
-        float w_lrt = st[Y::S_W_LRT], w_flat = st[Y::S_W_FLAT], w_diff = st[Y::S_W_DIFF];
+        float feat_lrt = SCF(S_FEAT_LRT);
+        float thr_lrt = SCF(S_THR_LRT), thr_flat = SCF(S_THR_FLAT), thr_diff = SCF(S_THR_DIFF);
+        float w_lrt = SCF(S_W_LRT), w_flat = SCF(S_W_FLAT), w_diff = SCF(S_W_DIFF);
         // histograms + threshold extraction every 500 blocks (ns_core.c:293-518, :765-790)
         if (update_flag >= 1) {
-            const int countdown = sti[Y::S_COUNTDOWN] - 1;
+            const int countdown = SCI(S_COUNTDOWN) - 1;
             if (countdown > 0) {
                 if (lane == 0) {
                     if ((feat_lrt < kHistBins * 0.1f) && (feat_lrt >= 0.0f)) hist[(int)(feat_lrt / 0.1f)]++;
@@ -577,7 +585,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         ksum = ksum / (float)(M);
         feat_lrt = ksum;
         st[Y::S_FEAT_LRT] = feat_lrt;
-        float prior = st[Y::S_PRIOR];
+        float prior = SCF(S_PRIOR);
         {
             float width = 4.0f;
             if (ksum < thr_lrt) width = 2.f * 4.0f;
@@ -751,6 +759,8 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
     wave_sync();
     NS_PROF(13);
 #undef NS_RELANE
+#undef SCF
+#undef SCI
 }
 
 constexpr int kNsWavesPerBlock = 4;
