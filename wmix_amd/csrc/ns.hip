@@ -175,6 +175,23 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         hb[k] = 0.f;
         if (chn == 2) hb[k] = (i < L - B) ? st[Y::HB_BUF + i + B] : (float)in[(i - (L - B)) * chn + 1];
     }
+    // Per-bin state this frame will need, requested from HBM right behind the time-domain buffers (loads return in order) and consumed
+    // several phases later (window, energy sum, FFT, spectrum loop and the ordered sums run in between): the loops below
+    // never wait on HBM latency.  (A zero-energy frame does not use them; it is the rare case.)
+    constexpr int NI = (M + 63) / 64;  // bins per lane: 3 (M = 129) or 2 (M = 65), the last one lane 0 only
+    float pf_quant[NI], pf_dens[NI][3], pf_lq[NI][3], pf_pause[NI];
+#pragma unroll
+    for (int k = 0; k < NI; k++) {
+        const int b = lane + 64 * k;
+        const bool ok = b < M;
+        pf_pause[k] = ok ? st[Y::MAGN_AVG_PAUSE + b] : 0.f;
+        pf_quant[k] = ok ? st[Y::QUANTILE + b] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            pf_dens[k][q] = ok ? st[Y::DENSITY + q * Y::MP + b] : 0.f;
+            pf_lq[k][q] = ok ? st[Y::LQUANTILE + q * Y::MP + b] : 0.f;
+        }
+    }
     wave_sync();  // other lanes' stores below overwrite what this lane just loaded: keep the compiler from interleaving them
 #pragma unroll
     for (int k = 0; k < NT; k++) {
@@ -207,22 +224,6 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         const float overdrive = 1.1f, denoise_bound = 0.125f;  // policy 2, ns_core.c:1030-1033
 
         NS_RELANE();
-        // Per-bin state this frame will need, requested from HBM now and consumed several phases later (the FFT, the
-        // spectrum loop and the ordered sums run in between): the loops below then never wait on HBM latency.
-        constexpr int NI = (M + 63) / 64;  // bins per lane: 3 (M = 129) or 2 (M = 65), the last one lane 0 only
-        float pf_quant[NI], pf_dens[NI][3], pf_lq[NI][3], pf_pause[NI];
-#pragma unroll
-        for (int k = 0; k < NI; k++) {
-            const int b = lane + 64 * k;
-            const bool ok = b < M;
-            pf_pause[k] = ok ? st[Y::MAGN_AVG_PAUSE + b] : 0.f;
-            pf_quant[k] = ok ? st[Y::QUANTILE + b] : 0.f;
-#pragma unroll
-            for (int q = 0; q < 3; q++) {
-                pf_dens[k][q] = ok ? st[Y::DENSITY + q * Y::MP + b] : 0.f;
-                pf_lq[k][q] = ok ? st[Y::LQUANTILE + q * Y::MP + b] : 0.f;
-            }
-        }
         rdft_forward<NC>(W.fa, &K.tab, lane);
         if (lane < Y::MP - M) W.r0[M + lane] = 0.f;  // the window-energy stage above spilled into r0's zero tail
         NS_PROF(1);
