@@ -462,9 +462,12 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             const int countdown = SCI(S_COUNTDOWN) - 1;
             if (countdown > 0) {
                 if (lane == 0) {
-                    if ((feat_lrt < kHistBins * 0.1f) && (feat_lrt >= 0.0f)) hist[(int)(feat_lrt / 0.1f)]++;
-                    if ((feat_flat < kHistBins * 0.05f) && (feat_flat >= 0.0f)) hist[kHistBins + (int)(feat_flat / 0.05f)]++;
-                    if ((feat_diff < kHistBins * 0.1f) && (feat_diff >= 0.0f)) hist[2 * kHistBins + (int)(feat_diff / 0.1f)]++;
+                    // counter++ as a no-return 32-bit atomic on the dword that holds the uint16 (a counter never exceeds
+                    // the 500-frame window, so the low half cannot carry into the high one): nothing waits for HBM
+                    auto bump = [&](int i) { atomicAdd(reinterpret_cast<unsigned *>(hist) + (i >> 1), (i & 1) ? 0x10000u : 1u); };
+                    if ((feat_lrt < kHistBins * 0.1f) && (feat_lrt >= 0.0f)) bump((int)(feat_lrt / 0.1f));
+                    if ((feat_flat < kHistBins * 0.05f) && (feat_flat >= 0.0f)) bump(kHistBins + (int)(feat_flat / 0.05f));
+                    if ((feat_diff < kHistBins * 0.1f) && (feat_diff >= 0.0f)) bump(2 * kHistBins + (int)(feat_diff / 0.1f));
                 }
                 sti[Y::S_COUNTDOWN] = countdown;
             } else {
