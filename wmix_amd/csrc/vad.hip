@@ -472,6 +472,19 @@ __global__ __launch_bounds__(64) void vad_kernel(int16_t *s16, int32_t *s32, int
     const int stream = blockIdx.x * 64 + lane;
     if (stream >= n_streams) return;  // lanes are independent: no barriers anywhere in this kernel
     const VadRef S{s16 + stream, s32 + stream, (size_t)n_streams};
+    // warm L2 with this wave's state rows and PCM lines (wmx_internal.h: touch_line)
+    int sink = 0;
+#pragma unroll 1
+    for (int f = 0; f < V16_WORDS; f++) touch_line(&S.h(f), sink);
+#pragma unroll 1
+    for (int f = 0; f < V32_WORDS; f++) touch_line(&S.w(f), sink);
+    {
+        const int16_t *row = pcm + (size_t)stream * stream_stride;
+        const int n_i16 = packets_per_call * NB * RATIO * chn;
+#pragma unroll 1
+        for (int i = 0; i < n_i16; i += 32) touch_line(row + i, sink);
+    }
+    touch_done(sink);  // one HBM round trip for everything, instead of one per field along the chain
     const LaneBuf hp120{lds + lane}, lp120{lds + lane + 64 * (NB / 2)}, hp60{lds + lane + 64 * NB},
         lp60{lds + lane + 64 * (NB + NB / 4)};
     constexpr int PKG = NB * RATIO;  // frames (mono samples) per packet at the stream's rate

@@ -28,6 +28,20 @@ inline unsigned stream_grid(size_t work_items, unsigned block) {
 // give the identity (the reference's memcpy branch).  Defined in mix.hip.
 void zoom_gather_list(int inChn, int inFreq, uint32_t inLen, int outChn, int outFreq, std::vector<int32_t> &idx);
 
+#ifdef __HIPCC__
+// Lane-per-stream kernels (VAD, AGC) walk their state field by field along a sequential dependency chain, one wave
+// per SIMD: every first touch of a field would expose a full HBM round trip.  touch_line() requests a line up front
+// (result discarded; loads return in order, so ordinary loads behind the touches are still waited for correctly);
+// the chain then runs against L2.
+// The load's result arrives asynchronously, so its destination must be a register the compiler keeps reserved until
+// the wave has waited for every touch: `sink` is threaded through all touches as a read-write operand and pinned by
+// touch_done() at the end of the kernel.
+__device__ __forceinline__ void touch_line(const void *p, int &sink) {
+    asm volatile("global_load_ubyte %0, %1, off" : "+v"(sink) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void touch_done(int &sink) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory"); }
+#endif
+
 }  // namespace wmx
 
 #define WMX_HIP(expr)                                                         \
