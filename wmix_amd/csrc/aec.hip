@@ -711,15 +711,29 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * kAe
                                                                           long stream_stride, long packet_stride, int chn, int pkg) {
     __shared__ AecConsts K;
     __shared__ AecWaveLds Wv[kAecWavesPerBlock];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: state pointers become scalar bases
+    const int sidx = blockIdx.x * kAecWavesPerBlock + wave;  // one stream per wave
+    const bool live = sidx < n_streams;
+    // First thing in flight: this stream's first near-end packet (HBM); the constants (L2) and the state follow, so the
+    // round trips overlap instead of queueing behind the workgroup barrier.
+    int16_t pcm0[2][2] = {{0, 0}, {0, 0}};
+    if (live && n_packets > 0) {
+        const int16_t *in0 = near_pcm + (size_t)sidx * stream_stride;
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int i = lane + 64 * h;
+                if (i < kAecFrame && s * kAecFrame + i < pkg) pcm0[s][h] = in0[(s * kAecFrame + i) * chn];
+            }
+    }
     {
         float *dst = reinterpret_cast<float *>(&K);
         for (int i = threadIdx.x; i < kAecConstWords; i += blockDim.x) dst[i] = consts_g[i];
     }
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: state pointers become scalar bases
-    const int sidx = blockIdx.x * kAecWavesPerBlock + wave;  // one stream per wave; no block-level barrier below
-    if (sidx >= n_streams) return;
+    __syncthreads();  // the only block-level barrier
+    if (!live) return;
     AecWaveLds &W = Wv[wave];
     float *gst = state + (size_t)sidx * AS_WORDS;
 #ifdef WMX_AEC_PROF
@@ -757,8 +771,13 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * kAe
         }
         for (int s = 0; s < pl.n_sub; s++) {
             const AecSubPlan &sp = pl.sub[s];
-            for (int i = lane; i < kAecFrame; i += 64)
-                AEC_ST(AS_NEAR_RING + (sp.near_wr + i) % kAecRing) = (float)in[(s * kAecFrame + i) * chn];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int i = lane + 64 * h;
+                if (i >= kAecFrame) continue;
+                const int16_t v = (p == 0 && s < 2) ? (s == 0 ? pcm0[0][h] : pcm0[1][h]) : in[(s * kAecFrame + i) * chn];
+                AEC_ST(AS_NEAR_RING + (sp.near_wr + i) % kAecRing) = (float)v;
+            }
             wave_sync();
             for (int k = 0; k < sp.n_blocks; k++) aec_block<MULT>(K, W, taps, F, pl.blk[sp.first_blk + k], lane);
             for (int i = lane; i < kAecFrame; i += 64) {
