@@ -194,6 +194,8 @@ int wmx_rtp_export(wmx_rtp *h, int stream_index, uint16_t *seq, uint32_t *timest
 /* Developer / test hook: the NS kernels' table-driven log (kind 0, x >= 1) and exp (kind 1) evaluated on the host from
  * the same source (wmix_amd/csrc/libm_dev.h), for sweeping against libm without a GPU. */
 int wmx_debug_ns_libm(int kind, const float *x, float *y, size_t n);
+/* Same for the AEC kernel's table-driven powf: y[i] = x[i] ^ e[i]. */
+int wmx_debug_pow(const float *x, const float *e, float *y, size_t n);
 
 #ifdef __cplusplus
 }

@@ -13,3 +13,13 @@ void orc_libm_exp(const float *x, float *y, size_t n)
 {
     for (size_t i = 0; i < n; i++) y[i] = (float)exp((double)x[i]);
 }
+/* aec_core.c:278 calls the float routine powf directly */
+void orc_libm_powf(const float *x, const float *e, float *y, size_t n)
+{
+    for (size_t i = 0; i < n; i++) y[i] = powf(x[i], e[i]);
+}
+/* the same power evaluated in double and rounded once: what a correctly rounded powf would return in all but ~2^-29 of cases */
+void orc_libm_pow_d(const float *x, const float *e, float *y, size_t n)
+{
+    for (size_t i = 0; i < n; i++) y[i] = (float)pow((double)x[i], (double)e[i]);
+}

@@ -48,5 +48,27 @@ def test_exp_sweep(wmx, oracle_port):
     assert np.array_equal(got.view(np.uint32)[~nan], want.view(np.uint32)[~nan])
 
 
+def test_pow_sweep(wmx, oracle_port):
+    """The AEC's hNl ^ (overDriveSm * curve): base in (0, 1], exponent in [1, 30].  The table-driven power must equal
+    the double-precision pow rounded to float everywhere; against glibc's powf (which is not correctly rounded) it may
+    differ by one float ulp in a small fraction of arguments -- the same fraction the rounded double pow differs in."""
+    rng = np.random.default_rng(13)
+    n = 6_000_000
+    x = np.concatenate([rng.random(n // 2), 1 - rng.random(n // 2) * 1e-2, np.array([1.0, 0.5, 1e-30, 1e-45, 0.0, 2.0, np.inf, np.nan, -0.5])]).astype(np.float32)
+    e = np.concatenate([1 + rng.random(n) * 29, np.array([5.0, 7.5, 3.0, 2.0, 5.0, 10.0, 2.0, 2.0, 2.0])]).astype(np.float32)
+    got = np.zeros_like(x)
+    assert wmx.wmx_debug_pow(x.ctypes.data, e.ctypes.data, got.ctypes.data, x.size) == 0
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    dbl, flt = np.zeros_like(x), np.zeros_like(x)
+    with np.errstate(all="ignore"):
+        oracle_port.orc_libm_pow_d(p(x), p(e), p(dbl), C.c_size_t(x.size))
+        oracle_port.orc_libm_powf(p(x), p(e), p(flt), C.c_size_t(x.size))
+    ok = ~np.isnan(dbl)
+    assert np.array_equal(np.isnan(got), ~ok)
+    assert np.array_equal(got.view(np.uint32)[ok], dbl.view(np.uint32)[ok])
+    d = np.abs(got.view(np.int32)[ok].astype(np.int64) - flt.view(np.int32)[ok].astype(np.int64))
+    assert d.max() <= 1 and (d != 0).mean() < 2e-3
+
+
 def test_rejects_bad_arguments(wmx):
     assert wmx.wmx_debug_ns_libm(5, None, None, 0) == -10001

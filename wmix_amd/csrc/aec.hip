@@ -208,6 +208,9 @@ struct AecTaps {
     float re[12], im[12];
 };
 
+// out of line for the same reason as libm_dev.h's pow_d: inlined, its fp64 temporaries push the block over 128 VGPRs
+__device__ __noinline__ static float aec_powf(float x, float y, const PowTables *__restrict__ t) { return fast_pow(x, y, t); }
+
 __device__ __forceinline__ int opaque_lane(int x) {
     asm volatile("" : "+v"(x));
     return x;
@@ -235,8 +238,8 @@ __device__ __forceinline__ void aec_fft_inv(const float *row, const FftTables *T
 }
 
 template <int MULT>  // 1: 8 kHz, 2: 16 kHz
-__device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, AecTaps &taps, const AecFarBufs &F, const AecBlkPlan &bp,
-                                          const int lane_in) {
+__device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *__restrict__ powtab, AecWaveLds &W, AecTaps &taps,
+                                          const AecFarBufs &F, const AecBlkPlan &bp, const int lane_in) {
     // The lane-derived LDS addresses (gather points, twiddle and window slots) are loop invariant; left alone the
     // compiler hoists ~100 of them out of the packet loop and pins them in VGPRs for the whole kernel.  Recomputing
     // them per block costs a few VALU ops and frees the registers.
@@ -649,7 +652,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, AecWaveLds &W, Aec
         float h = t2[b];
         const float wc = K.weight[b];
         if (h > hNlFb) h = wc * hNlFb + (1 - wc) * h;
-        h = pow_d(h, overDriveSm * K.overdrive[b]);
+        h = aec_powf(h, overDriveSm * K.overdrive[b], powtab);  // powf (aec_core.c:278) -> libm_dev.h fast_pow
         float er = ew[b] * h, ei = ew[66 + b] * h;
         ei *= -1;
         float ur = 0.f, ui = 0.f;
@@ -734,6 +737,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * kAe
     }
     __syncthreads();  // the only block-level barrier
     if (!live) return;
+    const PowTables *powtab = reinterpret_cast<const PowTables *>(consts_g + kAecConstWords);  // stays in global memory (L1 / L2 hits)
     AecWaveLds &W = Wv[wave];
     float *gst = state + (size_t)sidx * AS_WORDS;
 #ifdef WMX_AEC_PROF
@@ -779,7 +783,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * kAe
                 AEC_ST(AS_NEAR_RING + (sp.near_wr + i) % kAecRing) = (float)v;
             }
             wave_sync();
-            for (int k = 0; k < sp.n_blocks; k++) aec_block<MULT>(K, W, taps, F, pl.blk[sp.first_blk + k], lane);
+            for (int k = 0; k < sp.n_blocks; k++) aec_block<MULT>(K, powtab, W, taps, F, pl.blk[sp.first_blk + k], lane);
             for (int i = lane; i < kAecFrame; i += 64) {
                 const int16_t v = (int16_t)AEC_ST(AS_OUT_RING + (sp.out_rd + i) % kAecRing);
                 for (int c = 0; c < chn; c++) out[(s * kAecFrame + i) * chn + c] = v;
@@ -904,11 +908,17 @@ int wmx_aec_create(wmx_aec **out, int n_streams, int chn, int freq, int interval
         return rc;                                         \
     }
     AEC_TRY(hipMalloc(&h->d_state, (size_t)AS_WORDS * n_streams * sizeof(float)));
-    AEC_TRY(hipMalloc(&h->d_consts, sizeof(K)));
+    AEC_TRY(hipMalloc(&h->d_consts, sizeof(K) + sizeof(PowTables)));  // [AecConsts | PowTables]; only the first part is copied to LDS
     AEC_TRY(hipMalloc(&h->d_far, far_words * sizeof(float)));
     AEC_TRY(hipMalloc(&h->d_plans, kAecMaxPktPerLaunch * sizeof(AecPlan)));
     AEC_TRY(hipMalloc(&d_tmpl, AS_WORDS * sizeof(float)));
     AEC_TRY(hipMemcpy(h->d_consts, &K, sizeof(K), hipMemcpyHostToDevice));
+    {
+        static_assert(sizeof(AecConsts) % 16 == 0, "PowTables behind AecConsts must stay 16-byte aligned");
+        PowTables pt;
+        pow_tables(&pt);
+        AEC_TRY(hipMemcpy(reinterpret_cast<char *>(h->d_consts) + sizeof(K), &pt, sizeof(pt), hipMemcpyHostToDevice));
+    }
     AEC_TRY(hipMemcpy(d_tmpl, st.data(), AS_WORDS * sizeof(float), hipMemcpyHostToDevice));
     AEC_TRY(hipMemset(h->d_far, 0, far_words * sizeof(float)));
     hipLaunchKernelGGL(aec_fill_state, dim3(1024), dim3(256), 0, nullptr, h->d_state, d_tmpl, (int)AS_WORDS, n_streams);
@@ -1020,3 +1030,17 @@ int wmx_aec_run(wmx_aec *h, int mode, const int16_t *d_far, long far_packet_stri
 }
 
 }  // extern "C"
+
+// Host-side evaluation of the AEC's table-driven powf (libm_dev.h), same source as the kernel, for CPU sweeps against
+// glibc's powf (tests/test_libm_tables.py).
+extern "C" int wmx_debug_pow(const float *x, const float *e, float *y, size_t n) {
+    static wmx::PowTables tab;
+    static bool init = false;
+    if (!init) {
+        wmx::pow_tables(&tab);
+        init = true;
+    }
+    if (!x || !e || !y) return WMX_EINVAL;
+    for (size_t i = 0; i < n; i++) y[i] = wmx::fast_pow(x[i], e[i], &tab);
+    return 0;
+}

@@ -96,4 +96,72 @@ __host__ __device__ __forceinline__ float fast_exp(float xf, const NsLibmTables 
     return (float)z;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// powf for the AEC's OverdriveAndSuppress (aec_core.c:278: hNl[i] = powf(hNl[i], overDriveSm * curve[i])), same
+// scheme: x^y = exp(y * log x) with log and exp as above but kept in double end to end (no intermediate rounding), for
+// 0 < x < inf.  The log is the general-argument version: mantissas above sqrt(2) are folded down (c/2 with e + 1) so
+// that arguments next to 1 -- no suppression, the common case -- see no cancellation between e*ln2 and log c.
+// Error ~ y * 2^-53 * |log x| relative, i.e. the result rounds to glibc's float except within ~2^-48 of a rounding
+// boundary; glibc's powf itself is not correctly rounded, and the parity criterion for the AEC is <= 1 LSB.
+struct PowTables {
+    double2 logtab[128];  // (RN(1/c), RN(log c)) for c < sqrt 2, (RN(1/c), RN(log(c/2))) above; c = 1 + i/128
+    double exptab[64];    // 2^(j/64)
+};
+constexpr int kPowFold = 53;  // first i with 1 + i/128 > sqrt(2)
+
+inline void pow_tables(PowTables *t) {
+    for (int i = 0; i < 128; i++) {
+        const double c = 1.0 + i / 128.0;
+        t->logtab[i].x = 1.0 / c;
+        t->logtab[i].y = i < kPowFold ? log(c) : log(c / 2.0);
+    }
+    for (int j = 0; j < 64; j++) t->exptab[j] = exp2(j / 64.0);
+}
+
+__host__ __device__ __forceinline__ float fast_pow(float x, float y, const PowTables *__restrict__ M) {
+    unsigned u;
+    __builtin_memcpy(&u, &x, 4);
+    if (!(u >= 0x00800000u && u < 0x7F800000u)) return (float)pow((double)x, (double)y);  // zero, denormal, negative, inf, NaN
+    const int idx = (u >> 16) & 0x7F;
+    const int e = (int)(u >> 23) - 127 + (idx >= kPowFold ? 1 : 0);
+    const unsigned mu = (u & 0x007FFFFFu) | 0x3F800000u;
+    float mf;
+    __builtin_memcpy(&mf, &mu, 4);
+    const double2 t = M->logtab[idx];
+    const double r = fma((double)mf, t.x, -1.0);
+    double p = -1.0 / 9.0 * r + 1.0 / 8.0;
+    p = fma(p, r, -1.0 / 7.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, -1.0 / 5.0);
+    p = fma(p, r, 1.0 / 4.0);
+    p = fma(p, r, -1.0 / 3.0);
+    p = fma(p, r, 1.0 / 2.0);
+    p = fma(-p, r, 1.0);
+    p = p * r;
+    const double ed = (double)e;
+    constexpr double kLn2Hi = 0x1.62e42fefa38p-1, kLn2Lo = 0x1.ef35793c7673p-45;
+    const double lg = fma(ed, kLn2Hi, t.y) + fma(ed, kLn2Lo, p);
+    const double z = (double)y * lg;
+    if (!(z > -700.0 && z < 700.0)) return (float)exp(z);
+    constexpr double kInv = 0x1.71547652b82fep+6, kHi = 0x1.62e42fefa0000p-7, kLo = 0x1.cf79abc9e3b3ap-46;
+    const double kd = rint(z * kInv);
+    const int k = (int)kd;
+    double rr = fma(-kd, kHi, z);
+    rr = fma(-kd, kLo, rr);
+    double q = fma(rr, 1.0 / 720.0, 1.0 / 120.0);
+    q = fma(q, rr, 1.0 / 24.0);
+    q = fma(q, rr, 1.0 / 6.0);
+    q = fma(q, rr, 0.5);
+    q = fma(q, rr, 1.0);
+    q = q * rr;
+    const double tt = M->exptab[k & 63];
+    const double yv = fma(tt, q, tt);
+    long long bits;
+    __builtin_memcpy(&bits, &yv, 8);
+    bits += (long long)(k >> 6) << 52;
+    double out;
+    __builtin_memcpy(&out, &bits, 8);
+    return (float)out;
+}
+
 }  // namespace wmx
