@@ -513,10 +513,26 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
     }
     wave_sync();
     AEC_PROF(5);
-    float sdSum = 0.f, seSum = 0.f;
-    for (int i = 0; i < kAecPart1; i++) {
-        sdSum += AEC_ST(AS_SD + i);
-        seSum += AEC_ST(AS_SE + i);
+    // the two ordered sums advance side by side: lane 0 adds sd[0..64], lane 1 adds se[0..64] (index order each)
+    float sdSum, seSum;
+    {
+        const float *mine = &AEC_ST(lane == 1 ? AS_SE : AS_SD);
+        float acc = 0.f;
+#pragma unroll 1
+        for (int i = 0; i < kAecPart; i += 8) {
+            const float4 a = *reinterpret_cast<const float4 *>(mine + i), b = *reinterpret_cast<const float4 *>(mine + i + 4);
+            acc += a.x;
+            acc += a.y;
+            acc += a.z;
+            acc += a.w;
+            acc += b.x;
+            acc += b.y;
+            acc += b.z;
+            acc += b.w;
+        }
+        acc += mine[kAecPart];
+        sdSum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 0));
+        seSum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 1));
     }
     const int diverge = ((Si[AS_DIVERGE] ? 1.05f : 1.0f) * seSum > sdSum) ? 1 : 0;
     const bool reset_filter = seSum > (19.95f * sdSum);
