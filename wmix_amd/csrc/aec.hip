@@ -324,26 +324,15 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
             const float nr = X[kAecPart], ni = X[kAecPart1 + kAecPart];  // ni == 0, wfBuf[1][.][64] == 0
             y64 += nr * W.wn[p] - ni * 0.f;                              // used by lane 0 only
         }
-        if (lane == 0) {
-            W.fa[2][0] = yr;
-            W.fa[2][1] = y64;
-        } else {
-            W.fa[2][2 * lane] = yr;
-            W.fa[2][2 * lane + 1] = yi;
-        }
-    }
-    wave_sync();
-    AEC_PROF(1);
-    AEC_RELANE();
-    // ---- error e = d - y (aec_core.c:1286-1297): the second half of the inverse transform is points 32..63
-    if (g == 0) {
-        Cx v[4];
-        aec_fft_inv(W.fa[2], &K.tab, gl, v);
-#pragma unroll
-        for (int m = 2; m < 4; m++) {
-            const int i = 2 * (gl + 16 * m - 32);
-            W.enew[i] = W.cur[i] - v[m].r * scale;
-            W.enew[i + 1] = W.cur[i + 1] - v[m].i * scale;
+        // ---- error e = d - y (aec_core.c:1286-1297): y = second half of the inverse transform of the packed spectrum
+        //      (lane 0 carries (bin 0, bin 64)), one point per lane in registers: lanes 32..63 end up with y[2(l-32)], +1
+        AEC_PROF(1);
+        v2f pt = rdft128_inv_point_lanes(v2f{yr, lane == 0 ? y64 : yi}, &K.tab, lane);
+        pt = fft64_lanes<true>(pt, &K.tab, lane);
+        if (lane >= 32) {
+            const int i = 2 * (lane - 32);
+            W.enew[i] = W.cur[i] - pt.x * scale;
+            W.enew[i + 1] = W.cur[i + 1] - pt.y * scale;
         }
     }
     wave_sync();
@@ -664,6 +653,8 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
     AEC_RELANE();
     // OverdriveAndSuppress (aec_core.c:272-293) + ComfortNoise (:462-547) + packing for the inverse transform
     const int noise_off = (bp.flags & kAecFlagNoiseInit) ? AS_DINIT : AS_DMIN;
+    v2f out_spec = v2f{0.f, 0.f};
+    float out_nyq = 0.f;
     for (int b = lane; b < kAecPart1; b += 64) {
         float h = t2[b];
         const float wc = K.weight[b];
@@ -682,37 +673,32 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
         const float tmp = sqrtf(v > 0 ? v : 0);
         er += tmp * ur;
         ei += tmp * ui;
-        if (b == 0)
-            W.fa[0][0] = er;
-        else if (b == kAecPart)
-            W.fa[0][1] = er;
-        else {
-            W.fa[0][2 * b] = er;
-            W.fa[0][2 * b + 1] = -ei;
-        }
+        // packed spectrum for the inverse transform, kept in registers: bin == lane, lane 0 carries (bin 0, bin 64)
+        if (b == kAecPart)
+            out_nyq = er;
+        else
+            out_spec = v2f{er, -ei};
     }
-    wave_sync();
     AEC_PROF(8);
     AEC_RELANE();
     // inverse transform, overlap-add with the sqrt-Hanning window, saturate, queue 64 output samples
     // (aec_core.c:1089-1101, 1341): points 0..31 are the first half, 32..63 the new overlap tail
-    if (g == 0) {
-        Cx v[4];
-        aec_fft_inv(W.fa[0], &K.tab, gl, v);
-        float o[4];
-#pragma unroll
-        for (int m = 0; m < 2; m++) {
-            const int i = 2 * (gl + 16 * m);
-            o[2 * m] = sat16f(v[m].r * scale * K.hanning[i] + AEC_ST(AS_OUTBUF + i));
-            o[2 * m + 1] = sat16f(v[m].i * scale * K.hanning[i + 1] + AEC_ST(AS_OUTBUF + i + 1));
+    {
+        if (lane == 0) out_spec.y = out_nyq;
+        v2f pt = rdft128_inv_point_lanes(out_spec, &K.tab, lane);
+        pt = fft64_lanes<true>(pt, &K.tab, lane);
+        // lane l holds samples 2l, 2l+1: lanes 0..31 the output half, lanes 32..63 the new overlap tail
+        const int i = 2 * (lane & 31);
+        if (lane < 32) {
+            const float o0 = sat16f(pt.x * scale * K.hanning[i] + AEC_ST(AS_OUTBUF + i));
+            const float o1 = sat16f(pt.y * scale * K.hanning[i + 1] + AEC_ST(AS_OUTBUF + i + 1));
+            AEC_ST(AS_OUT_RING + (bp.out_wr + i) % kAecRing) = o0;
+            AEC_ST(AS_OUT_RING + (bp.out_wr + i + 1) % kAecRing) = o1;
         }
-#pragma unroll
-        for (int m = 0; m < 2; m++) {
-            const int i = 2 * (gl + 16 * m);
-            AEC_ST(AS_OUT_RING + (bp.out_wr + i) % kAecRing) = o[2 * m];
-            AEC_ST(AS_OUT_RING + (bp.out_wr + i + 1) % kAecRing) = o[2 * m + 1];
-            AEC_ST(AS_OUTBUF + i) = v[m + 2].r * scale * K.hanning[kAecPart - i];
-            AEC_ST(AS_OUTBUF + i + 1) = v[m + 2].i * scale * K.hanning[kAecPart - i - 1];
+        wave_sync();  // the tail overwrites outBuf only after every lane has read it
+        if (lane >= 32) {
+            AEC_ST(AS_OUTBUF + i) = pt.x * scale * K.hanning[kAecPart - i];
+            AEC_ST(AS_OUTBUF + i + 1) = pt.y * scale * K.hanning[kAecPart - i - 1];
         }
     }
     AEC_ST(AS_DPREV + lane) = W.cur[lane];

@@ -154,6 +154,87 @@ __device__ __forceinline__ void rdft128_fwd_bin_lane(const float *a, const FftTa
     nyq = aj - aj1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same transform with ONE point per lane (lane l holds point l before and after every pass) for the places
+// where a single transform is on the critical path and the 16-lane form would leave three quarters of the wave
+// idle.  Each lane fetches the four inputs of its butterfly with ds_bpermute (LDS crossbar, no VALU, no memory) and
+// evaluates only its own output j of it:
+//     xa = A (+/-) B, xb = C (+/-) D            (- for odd j)
+//     t  = xa (+/-) xb      for even j,   t = xa (+/-) i*xb   for odd j      (- for j >= 2)
+//     out = t, or W_j[b] * t in a twiddled block, or the reference's special forms in block b == 1
+// which is operand for operand what bfly4 / bfly4_close compute for output j (x +/- y is written fma(+/-1, y, x):
+// the product is exact, one rounding, the same value as the add / subtract).  The conjugating inverse closing pass
+// (fft4g.c:963-984) conjugates A and B on the way in and xb on the way out.
+__device__ __forceinline__ v2f lane_fetch(v2f v, int src_lane) {
+    return v2f{__int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v.x))),
+               __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v.y)))};
+}
+
+// KIND 0: twiddled pass (block class b), 1: closing forward, 2: closing inverse
+template <int KIND>
+__device__ __forceinline__ v2f bfly4_lane(int j, int b, const FftTables *T, v2f A, v2f B, v2f C, v2f D) {
+    const float s1 = (j & 1) ? -1.f : 1.f, s2 = (j & 2) ? -1.f : 1.f;
+    if constexpr (KIND == 2) {
+        A.y = -A.y;
+        B.y = -B.y;
+    }
+    const v2f xa = v2f{fmaf(s1, B.x, A.x), fmaf(s1, B.y, A.y)};
+    const v2f xb = v2f{fmaf(s1, D.x, C.x), fmaf(s1, D.y, C.y)};
+    v2f r;  // what is added to / subtracted from xa
+    if constexpr (KIND == 2)
+        r = (j & 1) ? v2f{-xb.y, -xb.x} : v2f{xb.x, -xb.y};
+    else
+        r = (j & 1) ? v2f{-xb.y, xb.x} : xb;
+    const v2f t = v2f{fmaf(s2, r.x, xa.x), fmaf(s2, r.y, xa.y)};
+    if constexpr (KIND != 0) return t;
+    if (b == 0 || j == 0) return t;
+    if (b == 1) {
+        const float w = T->w2;
+        if (j == 2) return v2f{-t.y, t.x};
+        if (j == 1) return v2f{w, w} * v2f{t.x - t.y, t.x + t.y};
+        return v2f{w, w} * v2f{-t.y - t.x, -t.y + t.x};
+    }
+    const float *wp = j == 1 ? T->W1[b] : (j == 2 ? T->W2[b] : T->W3[b]);
+    return cmul_w(wp[0], wp[1], t);
+}
+
+template <bool INVERSE>
+__device__ __forceinline__ v2f fft64_lanes(v2f pt, const FftTables *T, int lane) {
+    {  // pass 1: butterfly lane>>2 gathers the bit-reversed points rev4(bt) + {0, 32, 16, 48}
+        const int bt = lane >> 2, r0 = dev_bitrev(bt, 4);
+        const v2f A = lane_fetch(pt, r0), B = lane_fetch(pt, r0 + 32), C = lane_fetch(pt, r0 + 16), D = lane_fetch(pt, r0 + 48);
+        pt = bfly4_lane<0>(lane & 3, bt, T, A, B, C, D);
+    }
+    {  // pass 2: stride 4
+        const int base = lane & 0x33;
+        const v2f A = lane_fetch(pt, base), B = lane_fetch(pt, base + 4), C = lane_fetch(pt, base + 8), D = lane_fetch(pt, base + 12);
+        pt = bfly4_lane<0>((lane >> 2) & 3, lane >> 4, T, A, B, C, D);
+    }
+    {  // closing pass: stride 16, no twiddles
+        const int base = lane & 15;
+        const v2f A = lane_fetch(pt, base), B = lane_fetch(pt, base + 16), C = lane_fetch(pt, base + 32), D = lane_fetch(pt, base + 48);
+        pt = bfly4_lane<INVERSE ? 2 : 1>(lane >> 4, 0, T, A, B, C, D);
+    }
+    return pt;
+}
+
+// rdft128_inv_point for point == lane with the packed spectrum in registers: `own` = bin lane (lane 0: (a[0], a[1]) =
+// (bin 0, bin 64), both real), partner = bin 64 - lane fetched from its lane.
+__device__ __forceinline__ v2f rdft128_inv_point_lanes(v2f own, const FftTables *T, int lane) {
+    const v2f other = lane_fetch(own, (64 - lane) & 63);
+    const int q = lane < 32 ? lane : 64 - lane;
+    const float wkr = 0.5f - T->c[32 - q], wki = T->c[q];
+    const v2f aj = lane < 32 ? own : other, ak = lane < 32 ? other : own;  // pair (j = 2q, k = 128 - 2q)
+    const float xr = aj.x - ak.x, xi = aj.y + ak.y;
+    const float yr = wkr * xr + wki * xi, yi = wkr * xi - wki * xr;
+    float re = lane < 32 ? aj.x - yr : ak.x + yr;
+    float im = lane < 32 ? yi - aj.y : yi - ak.y;
+    const float h = 0.5f * (own.x - own.y);  // lane 0: a[0] = own.x, a[1] = own.y
+    re = lane == 0 ? own.x - h : (lane == 32 ? own.x : re);
+    im = lane == 0 ? -h : (lane == 32 ? -own.y : im);
+    return v2f{re, im};
+}
+
 // value held by lane rev4(gl) of the same row (ds_bpermute: no LDS memory, no barrier)
 __device__ __forceinline__ float row_bitrev(float v, int lane) {
     const int src = (lane & ~15) | dev_bitrev(lane & 15, 4);
