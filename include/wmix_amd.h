@@ -191,6 +191,19 @@ int wmx_rtp_ingest(int n_streams, const uint8_t *d_packets, long packet_stride, 
                    uint32_t *d_pcm_bytes, uint16_t *d_seq_raw, void *stream);
 int wmx_rtp_export(wmx_rtp *h, int stream_index, uint16_t *seq, uint32_t *timestamp);
 
+/* ------------------------------------------------------------------ AEC far-end delay FIFO
+ * Batched form of playPkgBuff_add/get and recordPkgBuff_add/get (src/wmix.c:432-526): n_slots packets
+ * (AEC_FIFO_PKG_NUM = AEC_INTERVALMS / WMIX_INTERVAL_MS + 2, src/wmixConf.h:141) of pkg_bytes per stream, resident on
+ * the device.  add: the packets of all streams (rows `stride` bytes apart) go into the slot under the cursor.
+ * get: the packet the reference's index arithmetic selects for `delayms` is copied to d_out (rows `stride` bytes
+ * apart) -- the arithmetic is reproduced as written, see oracle/orc_pkgfifo.c for what it amounts to.  A delay that
+ * makes the reference read in front of its array returns WMX_EINVAL. */
+typedef struct wmx_pkgfifo wmx_pkgfifo;
+int wmx_pkgfifo_create(wmx_pkgfifo **out, int n_streams, int n_slots, int pkg_bytes, int interval_ms, int frame_bytes);
+int wmx_pkgfifo_destroy(wmx_pkgfifo *h);
+int wmx_pkgfifo_add(wmx_pkgfifo *h, const uint8_t *d_pkgs, long stride, void *stream);
+int wmx_pkgfifo_get(wmx_pkgfifo *h, uint8_t *d_out, long stride, int delayms, void *stream);
+
 /* Developer / test hook: the NS kernels' table-driven log (kind 0, x >= 1) and exp (kind 1) evaluated on the host from
  * the same source (wmix_amd/csrc/libm_dev.h), for sweeping against libm without a GPU. */
 int wmx_debug_ns_libm(int kind, const float *x, float *y, size_t n);

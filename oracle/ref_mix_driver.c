@@ -21,6 +21,9 @@
  *        the loop body of wmix_thread_rtp_send_pcma (src/wmixTask.c:1124-1143) over stdin cut into chunks of
  *        wmix_len_of_in(..20 ms..) bytes: wmix_pcm_zoom -> PCM2G711a -> timestamp += n/chn -> rtp_send over UDP
  *        loopback; what arrives on the wire is written as [uint32 len][bytes] per packet.
+ *   ref_mix_driver pkgfifo delayms <ops.bin >out.bin
+ *        stdin = a sequence of WMIX_PKG_SIZE-byte packets; each is pushed with playPkgBuff_add and followed by a
+ *        playPkgBuff_get(buff, delayms) (src/wmix.c:487-526); the WMIX_PKG_SIZE bytes of every get are written out.
  *   ref_mix_driver rtprecv <packets.bin >pcm.bin
  *        every [uint32 len][bytes] record is sent to a socket opened with rtp_socket(bind) and taken through
  *        rtp_recv + G711a2PCM (src/wmixTask.c:1278-1282); writes [uint32 pcm_bytes][pcm][uint16 header seq as stored].
@@ -89,6 +92,19 @@ int main(int argc, char **argv)
             uint32_t g = (uint32_t)got;
             fwrite(&g, 4, 1, stdout);
             fwrite(wire, 1, g, stdout);
+        }
+        return 0;
+    }
+    if (!strcmp(argv[1], "pkgfifo") && argc == 3) {
+        extern void playPkgBuff_add(uint8_t *pkgBuff);
+        extern uint8_t *playPkgBuff_get(uint8_t *buff, int delayms);
+        size_t n;
+        unsigned char *in = slurp(&n);
+        unsigned char buff[WMIX_PKG_SIZE];
+        for (size_t off = 0; off + WMIX_PKG_SIZE <= n; off += WMIX_PKG_SIZE) {
+            playPkgBuff_add(in + off);
+            playPkgBuff_get(buff, atoi(argv[2]));
+            fwrite(buff, 1, WMIX_PKG_SIZE, stdout);
         }
         return 0;
     }

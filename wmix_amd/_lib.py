@@ -125,6 +125,14 @@ def _declare(L):
     L.wmx_debug_pow.argtypes = [vp, vp, vp, C.c_size_t]
     L.wmx_debug_ns_libm.restype = i
     L.wmx_debug_ns_libm.argtypes = [i, vp, vp, C.c_size_t]
+    L.wmx_pkgfifo_create.restype = i
+    L.wmx_pkgfifo_create.argtypes = [C.POINTER(vp), i, i, i, i, i]
+    L.wmx_pkgfifo_destroy.restype = i
+    L.wmx_pkgfifo_destroy.argtypes = [vp]
+    L.wmx_pkgfifo_add.restype = i
+    L.wmx_pkgfifo_add.argtypes = [vp, vp, C.c_long, vp]
+    L.wmx_pkgfifo_get.restype = i
+    L.wmx_pkgfifo_get.argtypes = [vp, vp, C.c_long, i, vp]
     L.wmx_mix_create.restype = i
     L.wmx_mix_create.argtypes = [C.POINTER(vp), i, i, i]
     L.wmx_mix_destroy.restype = i
