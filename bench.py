@@ -251,9 +251,11 @@ class ChainWorkload:
         self.k += 1
         if self.rank == 0:
             self.far.copy_(self.far_src[k:k + 1])
-        if self.dist is not None:
-            self.t.run("far_broadcast", timed, lambda: broadcast_far(self.far, self.dist, src=0))
+        # the far-end broadcast (RCCL, its own stream) runs behind the noise suppressor, which does not need it
+        work = broadcast_far(self.far, self.dist, src=0, async_op=True) if self.dist is not None else None
         self.t.run("ns", timed, lambda: self.ns.process_packet_major(self.inp[k:k + 1], self.work))
+        if work is not None:
+            self.t.run("far_broadcast_wait", timed, work.wait)
         self.t.run("aec", timed, lambda: self.aec.process2_packet_major(self.far, self.work))
         self.t.run("agc", timed, lambda: self.agc.process_packet_major(self.work))
         self.t.run("vad", timed, lambda: self.vad.process_packet_major(self.work))
@@ -262,11 +264,11 @@ class ChainWorkload:
         return self.t.mean_ms("aec")
 
     def stage_ms(self):
-        return {k: self.t.mean_ms(k) for k in ("far_broadcast", "ns", "aec", "agc", "vad") if self.t.mean_ms(k) is not None}
+        return {k: self.t.mean_ms(k) for k in ("far_broadcast_wait", "ns", "aec", "agc", "vad") if self.t.mean_ms(k) is not None}
 
     def config(self):
         return {"workload": self.name, "streams_per_gpu": self.n_frames, "frame": "160 x int16 (10 ms @ 16 kHz mono)",
-                "far_end": "shared, RCCL broadcast from rank 0 each step", "sum_order": "reference (bit-exact NS mode)",
+                "far_end": "shared, RCCL broadcast from rank 0 each step (asynchronous, overlapped with NS)", "sum_order": "reference (bit-exact NS mode)",
                 "aec_launch": "far kernel + near kernel; the near kernel is the timed dominant kernel together with its far kernel"}
 
     def cpu_baseline(self, budget_s):
