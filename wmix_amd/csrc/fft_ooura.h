@@ -249,38 +249,27 @@ __device__ __forceinline__ Cx ld_cx(const float *a, int p) {
     return Cx{v.x, v.y};
 }
 
-// The complex passes (bitrv2 + cftfsub / cftbsub) for NC = n/2 complex points.
-// `lane` is the lane index INSIDE the group of GL lanes that owns array `a` (GL = 64: one
-// transform per wave; GL = 16 with NC = 64: four transforms side by side, each group passing
-// its own `a`).  GL >= NC/4 so one pass is one step.  REP > 1: every lane additionally carries
-// REP independent transforms, stored `rs` floats apart (a, a + rs, ...): the same number of
-// instructions, but REP butterflies in flight per LDS round trip instead of one.
-template <int NC, bool INVERSE, int GL = 64, int REP = 1>
-__device__ __forceinline__ void fft_complex_passes(float *a, const FftTables *T, int lane, int rs = 0) {
-    static_assert(GL >= NC / 4, "a group must hold one butterfly per lane");
+// The complex passes (bitrv2 + cftfsub / cftbsub) for NC = n/2 complex points in LDS, one transform per wave:
+// every pass has NC/4 butterflies, lane k takes butterfly k.
+template <int NC, bool INVERSE>
+__device__ __forceinline__ void fft_complex_passes(float *a, const FftTables *T, int lane) {
+    static_assert(NC / 4 <= 64, "one butterfly per lane");
     constexpr int BITS = (NC == 128) ? 7 : 6;
     constexpr int NB = NC / 4;  // butterflies per radix-4 pass
     // pass 1: stride 1, gathering from bit-reversed positions.  rev(4g + j) over BITS bits =
     // rev(g) over BITS-2 bits + {0, NC/2, NC/4, 3NC/4}[j].
     {
-        Cx A[REP], B[REP], C[REP], D[REP];
+        Cx A{0.f, 0.f}, B = A, C = A, D = A;
         const bool act = lane < NB;
         if (act) {
             const int r0 = dev_bitrev(lane, BITS - 2);
-#pragma unroll
-            for (int r = 0; r < REP; r++) {
-                const float *ar = a + r * rs;
-                A[r] = ld_cx(ar, r0);
-                B[r] = ld_cx(ar, r0 + NC / 2);
-                C[r] = ld_cx(ar, r0 + NC / 4);
-                D[r] = ld_cx(ar, r0 + 3 * NC / 4);
-            }
+            A = ld_cx(a, r0);
+            B = ld_cx(a, r0 + NC / 2);
+            C = ld_cx(a, r0 + NC / 4);
+            D = ld_cx(a, r0 + 3 * NC / 4);
         }
         wave_sync();
-        if (act) {
-#pragma unroll
-            for (int r = 0; r < REP; r++) bfly4_store(a + r * rs, 4 * lane, 1, lane, T, A[r], B[r], C[r], D[r]);
-        }
+        if (act) bfly4_store(a, 4 * lane, 1, lane, T, A, B, C, D);
         wave_sync();
     }
     // twiddled passes with stride 4, 16 while 4*hc < NC
@@ -288,128 +277,100 @@ __device__ __forceinline__ void fft_complex_passes(float *a, const FftTables *T,
     for (int hc = 4; hc * 4 < NC; hc *= 4) {
         if (lane < NB) {
             const int b = lane / hc, j = lane % hc, p0 = b * 4 * hc + j;
-#pragma unroll
-            for (int r = 0; r < REP; r++) {
-                float *ar = a + r * rs;
-                bfly4_store(ar, p0, hc, b, T, ld_cx(ar, p0), ld_cx(ar, p0 + hc), ld_cx(ar, p0 + 2 * hc), ld_cx(ar, p0 + 3 * hc));
-            }
+            bfly4_store(a, p0, hc, b, T, ld_cx(a, p0), ld_cx(a, p0 + hc), ld_cx(a, p0 + 2 * hc), ld_cx(a, p0 + 3 * hc));
         }
         wave_sync();
     }
     constexpr int HC = (NC == 128) ? 64 : 16;  // stride of the closing pass
     if constexpr (HC * 4 == NC) {
-        if (lane < HC) {  // HC == NC/4 <= GL
-#pragma unroll
-            for (int r = 0; r < REP; r++) {
-                float *ar = a + r * rs;
-                const int p0 = lane, p1 = p0 + HC, p2 = p1 + HC, p3 = p2 + HC;
-                const Cx A = ld_cx(ar, p0), B = ld_cx(ar, p1), C = ld_cx(ar, p2), D = ld_cx(ar, p3);
-                float2 o0, o1, o2, o3;
-                bfly4_close<INVERSE>(A, B, C, D, o0, o1, o2, o3);
-                *reinterpret_cast<float2 *>(ar + 2 * p0) = o0;
-                *reinterpret_cast<float2 *>(ar + 2 * p1) = o1;
-                *reinterpret_cast<float2 *>(ar + 2 * p2) = o2;
-                *reinterpret_cast<float2 *>(ar + 2 * p3) = o3;
-            }
+        if (lane < HC) {
+            const int p0 = lane, p1 = p0 + HC, p2 = p1 + HC, p3 = p2 + HC;
+            const Cx A = ld_cx(a, p0), B = ld_cx(a, p1), C = ld_cx(a, p2), D = ld_cx(a, p3);
+            float2 o0, o1, o2, o3;
+            bfly4_close<INVERSE>(A, B, C, D, o0, o1, o2, o3);
+            *reinterpret_cast<float2 *>(a + 2 * p0) = o0;
+            *reinterpret_cast<float2 *>(a + 2 * p1) = o1;
+            *reinterpret_cast<float2 *>(a + 2 * p2) = o2;
+            *reinterpret_cast<float2 *>(a + 2 * p3) = o3;
         }
     } else {
         // closing radix-2 (fft4g.c:936-947 / 986-997), HC == NC/2
-#pragma unroll
-        for (int r = 0; r < REP; r++) {
-            float *ar = a + r * rs;
-            for (int p0 = lane; p0 < HC; p0 += GL) {
-                const int p1 = p0 + HC;
-                const Cx A = ld_cx(ar, p0), B = ld_cx(ar, p1);
-                float2 o0, o1;
-                if constexpr (!INVERSE) {
-                    o0 = make_float2(A.r + B.r, A.i + B.i);
-                    o1 = make_float2(A.r - B.r, A.i - B.i);
-                } else {
-                    o0 = make_float2(A.r + B.r, -A.i - B.i);
-                    o1 = make_float2(A.r - B.r, -A.i + B.i);
-                }
-                *reinterpret_cast<float2 *>(ar + 2 * p0) = o0;
-                *reinterpret_cast<float2 *>(ar + 2 * p1) = o1;
+        for (int p0 = lane; p0 < HC; p0 += 64) {
+            const int p1 = p0 + HC;
+            const Cx A = ld_cx(a, p0), B = ld_cx(a, p1);
+            float2 o0, o1;
+            if constexpr (!INVERSE) {
+                o0 = make_float2(A.r + B.r, A.i + B.i);
+                o1 = make_float2(A.r - B.r, A.i - B.i);
+            } else {
+                o0 = make_float2(A.r + B.r, -A.i - B.i);
+                o1 = make_float2(A.r - B.r, -A.i + B.i);
             }
+            *reinterpret_cast<float2 *>(a + 2 * p0) = o0;
+            *reinterpret_cast<float2 *>(a + 2 * p1) = o1;
         }
     }
     wave_sync();
 }
 
 // fft4g.c:1234-1284 rftfsub / rftbsub: conjugate pairs (q, NC - q), q = 1 .. NC/2 - 1.
-template <int NC, bool INVERSE, int GL = 64, int REP = 1>
-__device__ __forceinline__ void fft_real_split(float *a, const FftTables *T, int lane, int rs = 0) {
+template <int NC, bool INVERSE>
+__device__ __forceinline__ void fft_real_split(float *a, const FftTables *T, int lane) {
     constexpr int NQ = NC / 2;  // table length n/4
-    for (int q = lane; q < NQ; q += GL) {
+    for (int q = lane; q < NQ; q += 64) {
         if (q == 0) continue;
         const int j = 2 * q, k = 2 * NC - j;
         const float wkr = 0.5f - T->c[NQ - q], wki = T->c[q];
-#pragma unroll
-        for (int r = 0; r < REP; r++) {
-            float *ar = a + r * rs;
-            const float aj = ar[j], aj1 = ar[j + 1], ak = ar[k], ak1 = ar[k + 1];
-            const float xr = aj - ak, xi = aj1 + ak1;
-            if constexpr (!INVERSE) {
-                const float yr = wkr * xr - wki * xi, yi = wkr * xi + wki * xr;
-                ar[j] = aj - yr;
-                ar[j + 1] = aj1 - yi;
-                ar[k] = ak + yr;
-                ar[k + 1] = ak1 - yi;
-            } else {
-                const float yr = wkr * xr + wki * xi, yi = wkr * xi - wki * xr;
-                ar[j] = aj - yr;
-                ar[j + 1] = yi - aj1;
-                ar[k] = ak + yr;
-                ar[k + 1] = yi - ak1;
-            }
+        const float aj = a[j], aj1 = a[j + 1], ak = a[k], ak1 = a[k + 1];
+        const float xr = aj - ak, xi = aj1 + ak1;
+        if constexpr (!INVERSE) {
+            const float yr = wkr * xr - wki * xi, yi = wkr * xi + wki * xr;
+            a[j] = aj - yr;
+            a[j + 1] = aj1 - yi;
+            a[k] = ak + yr;
+            a[k + 1] = ak1 - yi;
+        } else {
+            const float yr = wkr * xr + wki * xi, yi = wkr * xi - wki * xr;
+            a[j] = aj - yr;
+            a[j + 1] = yi - aj1;
+            a[k] = ak + yr;
+            a[k + 1] = yi - ak1;
         }
     }
     if constexpr (INVERSE) {
         if (lane == 0) {
-#pragma unroll
-            for (int r = 0; r < REP; r++) {
-                float *ar = a + r * rs;
-                ar[1] = -ar[1];
-                ar[NC + 1] = -ar[NC + 1];
-            }
+            a[1] = -a[1];
+            a[NC + 1] = -a[NC + 1];
         }
     }
     wave_sync();
 }
 
 // WebRtc_rdft(n, +1, a) / aec_rdft_forward_128(a).  n = 2*NC.
-template <int NC, int GL = 64, int REP = 1>
-__device__ __forceinline__ void rdft_forward(float *a, const FftTables *T, int lane, int rs = 0) {
-    fft_complex_passes<NC, false, GL, REP>(a, T, lane, rs);
-    fft_real_split<NC, false, GL, REP>(a, T, lane, rs);
+template <int NC>
+__device__ __forceinline__ void rdft_forward(float *a, const FftTables *T, int lane) {
+    fft_complex_passes<NC, false>(a, T, lane);
+    fft_real_split<NC, false>(a, T, lane);
     if (lane == 0) {
-#pragma unroll
-        for (int r = 0; r < REP; r++) {
-            float *ar = a + r * rs;
-            const float a0 = ar[0], a1 = ar[1];
-            ar[0] = a0 + a1;
-            ar[1] = a0 - a1;
-        }
+        const float a0 = a[0], a1 = a[1];
+        a[0] = a0 + a1;
+        a[1] = a0 - a1;
     }
     wave_sync();
 }
 
 // WebRtc_rdft(n, -1, a) / aec_rdft_inverse_128(a); unnormalised like the reference.
-template <int NC, int GL = 64, int REP = 1>
-__device__ __forceinline__ void rdft_inverse(float *a, const FftTables *T, int lane, int rs = 0) {
+template <int NC>
+__device__ __forceinline__ void rdft_inverse(float *a, const FftTables *T, int lane) {
     if (lane == 0) {
-#pragma unroll
-        for (int r = 0; r < REP; r++) {
-            float *ar = a + r * rs;
-            const float a0 = ar[0], a1 = ar[1];
-            const float h = 0.5f * (a0 - a1);
-            ar[1] = h;
-            ar[0] = a0 - h;
-        }
+        const float a0 = a[0], a1 = a[1];
+        const float h = 0.5f * (a0 - a1);
+        a[1] = h;
+        a[0] = a0 - h;
     }
     wave_sync();
-    fft_real_split<NC, true, GL, REP>(a, T, lane, rs);
-    fft_complex_passes<NC, true, GL, REP>(a, T, lane, rs);
+    fft_real_split<NC, true>(a, T, lane);
+    fft_complex_passes<NC, true>(a, T, lane);
 }
 
 }  // namespace wmx

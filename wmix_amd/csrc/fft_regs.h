@@ -109,37 +109,9 @@ __device__ __forceinline__ Cx rdft128_inv_point(const float *a, const FftTables 
     return Cx{re, im};
 }
 
-// Output side of rdft(128, +1, a): bin b (0..64) of the spectrum, from the row holding the result of the
-// forward complex passes (rftfsub fft4g.c:1234-1257 + the a[0]/a[1] fix-up fft4g.c:340-342), in the
-// StoreAsComplex convention (bin 0 and bin 64 real).
-__device__ __forceinline__ void rdft128_fwd_bin(const float *a, const FftTables *T, int b, float &re, float &im) {
-    if (b == 0 || b == 64) {
-        const float a0 = a[0], a1 = a[1];
-        re = b == 0 ? a0 + a1 : a0 - a1;
-        im = 0.f;
-        return;
-    }
-    if (b == 32) {
-        re = a[64];
-        im = a[65];
-        return;
-    }
-    const int q = b < 32 ? b : 64 - b;
-    const int j = 2 * q, k = 128 - j;
-    const float wkr = 0.5f - T->c[32 - q], wki = T->c[q];
-    const float aj = a[j], aj1 = a[j + 1], ak = a[k], ak1 = a[k + 1];
-    const float xr = aj - ak, xi = aj1 + ak1;
-    const float yr = wkr * xr - wki * xi, yi = wkr * xi + wki * xr;
-    if (b < 32) {
-        re = aj - yr;
-        im = aj1 - yi;
-    } else {
-        re = ak + yr;
-        im = ak1 - yi;
-    }
-}
-
-// rdft128_fwd_bin for bin == lane (0..63), straight-line; `nyq` is bin 64 (real), valid in lane 0 only.
+// Output side of rdft(128, +1, a): bin == lane (0..63) of the spectrum, from the row holding the result of the forward
+// complex passes (rftfsub fft4g.c:1234-1257 + the a[0]/a[1] fix-up fft4g.c:340-342), StoreAsComplex convention (bin 0
+// real).  Straight-line for all lanes; `nyq` is bin 64 (real), valid in lane 0 only.
 __device__ __forceinline__ void rdft128_fwd_bin_lane(const float *a, const FftTables *T, int lane, float &re, float &im, float &nyq) {
     const int q = lane < 32 ? lane : 64 - lane;  // lane 0: q = 0 (reads a[128..129], discarded); lane 32: j == k == 64
     const int j = 2 * q, k = 128 - j;
