@@ -65,6 +65,22 @@ for cname, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         }
         for k, v in acc.items()
     }
+# SQ pass: per-kernel means over the timed region's launches, and each bucket as a fraction of the wave cycles
+sq = collections.defaultdict(lambda: collections.defaultdict(list))
+for path in glob.glob(out + "/pmc_sq/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(path)):
+        sq[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+sq_out = {}
+for k, c in sq.items():
+    if "_kernel" not in k:
+        continue
+    m = {n: sum(v[-steps:]) / len(v[-steps:]) for n, v in c.items()}
+    wc = m.get("SQ_WAVE_CYCLES", 0) or 1
+    sq_out[k] = {"mean": {n: round(x) for n, x in m.items()},
+                 "fraction_of_wave_cycles": {n: round(x / wc, 3) for n, x in m.items() if n not in ("SQ_WAVE_CYCLES", "SQ_WAVES")}}
+if sq_out:
+    json.dump(sq_out, open(out + "/chain_sq_pmc.json", "w"), indent=1)
+
 pmc["n_frames_per_launch"] = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 json.dump(pmc, open(out + "/chain_hbm_pmc.json", "w"), indent=1)
 print(json.dumps({c: {k: v["bytes_per_dispatch_corrected"] for k, v in d.items() if "wmx" in k or "_kernel" in k} for c, d in pmc.items() if isinstance(d, dict)}))
