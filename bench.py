@@ -219,7 +219,7 @@ class ChainWorkload:
     dominant_bytes_per_frame = 24040.0
     freq, pkt = 16000, 160
 
-    def __init__(self, dev, n_streams, rank, dist=None):
+    def __init__(self, dev, n_streams, rank, dist=None, packets=1):
         from wmix_amd import synth
         from wmix_amd.aec import AecBatch
         from wmix_amd.agc import AgcBatch
@@ -227,7 +227,8 @@ class ChainWorkload:
         from wmix_amd.vad import VadBatch
         global broadcast_far
         from wmix_amd.shard import broadcast_far
-        self.n_frames = n_streams
+        self.n_streams = n_streams
+        self.n_frames = n_streams * packets  # 10 ms stream-frames per step
         self.dist = dist
         self.K = 8
         far = synth.far_end(3000, self.K, self.pkt)  # the same far-end on every rank (rank 0's copy is broadcast)
@@ -236,8 +237,10 @@ class ChainWorkload:
         x = np.tile(base, (reps, 1, 1))[:n_streams].transpose(1, 0, 2)
         self.inp = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
         self.far_src = torch.from_numpy(far.reshape(self.K, self.pkt).copy()).to(dev)
-        self.far = torch.zeros(1, self.pkt, dtype=torch.int16, device=dev)
-        self.work = torch.empty_like(self.inp[0:1])
+        self.P = packets  # 10 ms packets per stream per step (1 = one packet per launch; 2 = the daemon's own 20 ms calls)
+        assert self.K % self.P == 0
+        self.far = torch.zeros(self.P, self.pkt, dtype=torch.int16, device=dev)
+        self.work = torch.empty_like(self.inp[0:self.P])
         self.ns = NsBatch(n_streams, 1, self.freq, ordered=True)
         self.aec = AecBatch(n_streams, 1, self.freq, 10)
         self.agc = AgcBatch(n_streams, 1, self.freq, 5)  # volumeAgc default 5, src/wmix.c:1596
@@ -247,13 +250,14 @@ class ChainWorkload:
         self.k = 0
 
     def step(self, timed):
-        k = self.k % self.K
+        P = self.P
+        k = (self.k * P) % self.K
         self.k += 1
         if self.rank == 0:
-            self.far.copy_(self.far_src[k:k + 1])
+            self.far.copy_(self.far_src[k:k + P])
         # the far-end broadcast (RCCL, its own stream) runs behind the noise suppressor, which does not need it
         work = broadcast_far(self.far, self.dist, src=0, async_op=True) if self.dist is not None else None
-        self.t.run("ns", timed, lambda: self.ns.process_packet_major(self.inp[k:k + 1], self.work))
+        self.t.run("ns", timed, lambda: self.ns.process_packet_major(self.inp[k:k + P], self.work))
         if work is not None:
             self.t.run("far_broadcast_wait", timed, work.wait)
         self.t.run("aec", timed, lambda: self.aec.process2_packet_major(self.far, self.work))
@@ -267,7 +271,8 @@ class ChainWorkload:
         return {k: self.t.mean_ms(k) for k in ("far_broadcast_wait", "ns", "aec", "agc", "vad") if self.t.mean_ms(k) is not None}
 
     def config(self):
-        return {"workload": self.name, "streams_per_gpu": self.n_frames, "frame": "160 x int16 (10 ms @ 16 kHz mono)",
+        return {"workload": self.name, "streams_per_gpu": self.n_streams, "packets_per_stream_per_step": self.P,
+                "frame": "160 x int16 (10 ms @ 16 kHz mono)",
                 "far_end": "shared, RCCL broadcast from rank 0 each step (asynchronous, overlapped with NS)", "sum_order": "reference (bit-exact NS mode)",
                 "aec_launch": "far kernel + near kernel; the near kernel is the timed dominant kernel together with its far kernel"}
 
@@ -315,6 +320,9 @@ def main():
                     help="untimed steps run before the warm-up so that every stream is past the reference's start-up phases "
                          "(NS: 200 blocks of noise-model start-up, ns_core.c:1103-1160; AEC: pass-through until the far-end "
                          "buffer has filled, echo_cancellation.c:651-657); the timed steps then measure the steady state")
+    ap.add_argument("--packets-per-step", type=int, default=1, choices=[1, 2, 4, 8],
+                    help="chain workload: 10 ms packets per stream per step / launch (default 1; the daemon itself hands the "
+                         "chain 20 ms = 2 packets per call at 16 kHz, src/wmix.c:613-709)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -345,7 +353,7 @@ def main():
 
     cls, default_streams = WORKLOADS[args.workload]
     if cls is ChainWorkload:
-        wl = cls(dev, args.streams or default_streams, rank, dist)
+        wl = cls(dev, args.streams or default_streams, rank, dist, args.packets_per_step)
     else:
         wl = cls(dev, args.streams or default_streams, rank)
 
