@@ -51,32 +51,57 @@ int twiddles_for(unsigned n, const double2 **out) {
 }
 
 // ---------------------------------------------------------------- device
-// log2(n) radix-2 DIT passes on n complex points in LDS (math/fft.c:81-118 / 256-296)
+// one radix-2 DIT butterfly of the reference (math/fft.c:106-113 / 281-292): t = w * x[q] in double, rounded once;
+// x[q] = x[r] - t, x[r] = x[r] + t (the inverse halves both)
 template <bool INVERSE>
-__device__ __forceinline__ void dit_passes(float *re, float *im, unsigned n, unsigned m, const double2 *__restrict__ tw, int lane) {
-    for (unsigned l = 1; l <= m; l++) {
-        const unsigned half = 1u << (l - 1), shift = m - l;  // twiddle step 2^(m-l)
+__device__ __forceinline__ void dit_bfly(float &ar, float &ai, float &xr, float &xi, double2 w) {
+    float tr, ti;
+    if constexpr (!INVERSE) {
+        tr = (float)((double)xr * w.x + (double)xi * w.y);
+        ti = (float)((double)xi * w.x - (double)xr * w.y);
+        xr = ar - tr;
+        xi = ai - ti;
+        ar = ar + tr;
+        ai = ai + ti;
+    } else {
+        tr = (float)((double)xr * w.x - (double)xi * w.y);
+        ti = (float)((double)xi * w.x + (double)xr * w.y);
+        xr = (ar - tr) / 2;
+        xi = (ai - ti) / 2;
+        ar = (ar + tr) / 2;
+        ai = (ai + ti) / 2;
+    }
+}
+
+// log2(n) radix-2 DIT passes on n complex points in LDS (math/fft.c:81-118 / 256-296).  Two consecutive stages are
+// evaluated on four points held in registers (the same butterflies in the same order, one LDS round trip instead of
+// two); an odd last stage runs alone.  `tw` is the size-n twiddle table in LDS.
+template <bool INVERSE>
+__device__ __forceinline__ void dit_passes(float *re, float *im, unsigned n, unsigned m, const double2 *tw, int lane) {
+    unsigned l = 1;
+    for (; l + 1 <= m; l += 2) {
+        const unsigned half = 1u << (l - 1), s1 = m - l, s2 = m - l - 1;  // twiddle steps 2^(m-l), 2^(m-l-1)
+        for (unsigned t = lane; t < n / 4; t += 64) {
+            const unsigned i = t >> (l - 1), j = t & (half - 1);
+            const unsigned r0 = j + 4 * half * i, r1 = r0 + half, r2 = r1 + half, r3 = r2 + half;
+            float ar = re[r0], ai = im[r0], br = re[r1], bi = im[r1], cr = re[r2], ci = im[r2], dr = re[r3], di = im[r3];
+            const double2 wa = tw[j << s1];
+            dit_bfly<INVERSE>(ar, ai, br, bi, wa);  // stage l:     (r0, r1) and (r2, r3), same twiddle
+            dit_bfly<INVERSE>(cr, ci, dr, di, wa);
+            dit_bfly<INVERSE>(ar, ai, cr, ci, tw[j << s2]);           // stage l + 1: (r0, r2)
+            dit_bfly<INVERSE>(br, bi, dr, di, tw[(j + half) << s2]);  //              (r1, r3)
+            re[r0] = ar, im[r0] = ai, re[r1] = br, im[r1] = bi, re[r2] = cr, im[r2] = ci, re[r3] = dr, im[r3] = di;
+        }
+        wave_sync();
+    }
+    if (l == m) {
+        const unsigned half = 1u << (l - 1);
         for (unsigned t = lane; t < n / 2; t += 64) {
             const unsigned i = t >> (l - 1), j = t & (half - 1);
             const unsigned r = j + 2 * half * i, q = r + half;
-            const double2 w = tw[j << shift];
-            const float xr = re[q], xi = im[q], ar = re[r], ai = im[r];
-            float tr, ti;
-            if constexpr (!INVERSE) {
-                tr = (float)((double)xr * w.x + (double)xi * w.y);
-                ti = (float)((double)xi * w.x - (double)xr * w.y);
-                re[q] = ar - tr;
-                im[q] = ai - ti;
-                re[r] = ar + tr;
-                im[r] = ai + ti;
-            } else {
-                tr = (float)((double)xr * w.x - (double)xi * w.y);
-                ti = (float)((double)xi * w.x + (double)xr * w.y);
-                re[q] = (ar - tr) / 2;
-                im[q] = (ai - ti) / 2;
-                re[r] = (ar + tr) / 2;
-                im[r] = (ai + ti) / 2;
-            }
+            float ar = re[r], ai = im[r], xr = re[q], xi = im[q];
+            dit_bfly<INVERSE>(ar, ai, xr, xi, tw[j]);
+            re[r] = ar, im[r] = ai, re[q] = xr, im[q] = xi;
         }
         wave_sync();
     }
@@ -96,13 +121,17 @@ template <int KIND, bool STREAM>
 __global__ void mfft_kernel(int n_batch, unsigned n, unsigned m, const double2 *__restrict__ tw_inner, const double2 *__restrict__ tw_n,
                             const float *in_re, const float *in_im, float *out_re, float *out_im, float *out_af, float *out_pf,
                             unsigned in_len) {
-    extern __shared__ float lds[];
+    extern __shared__ double2 lds_tw[];  // [nc / 2] twiddles of the complex transform, then the waves' data
     constexpr bool REAL = (KIND == 1 || KIND == 3), INV = (KIND >= 2);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int idx = blockIdx.x * (blockDim.x >> 6) + wave;  // one transform per wave; no block-level barrier
-    if (idx >= n_batch) return;
+    const int idx = blockIdx.x * (blockDim.x >> 6) + wave;  // one transform per wave
     const unsigned nc = REAL ? n / 2 : n, mc = REAL ? m - 1 : m;  // points of the complex transform
+    const unsigned ntw = nc / 2 ? nc / 2 : 1;
+    for (unsigned i = threadIdx.x; i < ntw; i += blockDim.x) lds_tw[i] = tw_inner[i];
+    __syncthreads();  // the only block-level barrier
+    if (idx >= n_batch) return;
+    float *lds = reinterpret_cast<float *>(lds_tw + ntw);
     float *re = lds + (size_t)wave * 2 * n, *im = re + n;
     const size_t base = (size_t)idx * n;
     float *o_re = out_re ? out_re + base : nullptr, *o_im = out_im ? out_im + base : nullptr;
@@ -143,7 +172,7 @@ __global__ void mfft_kernel(int n_batch, unsigned n, unsigned m, const double2 *
         }
     }
     wave_sync();
-    dit_passes<INV>(re, im, nc, mc, tw_inner, lane);
+    dit_passes<INV>(re, im, nc, mc, lds_tw, lane);
 
     if constexpr (!REAL) {
         for (unsigned i = lane; i < n; i += 64) emit(i, re[i], im[i], n, o_re, o_im, INV ? nullptr : o_af, INV ? nullptr : o_pf);
@@ -229,7 +258,7 @@ extern "C" int wmx_mfft(int kind, int n_batch, unsigned n, const float *d_in_re,
     }
     const unsigned wpb = waves_per_block(n);
     const dim3 grid((unsigned)((n_batch + wpb - 1) / wpb)), block(64 * wpb);
-    const size_t lds = (size_t)wpb * 2 * n * sizeof(float);
+    const size_t lds = (size_t)wpb * 2 * n * sizeof(float) + (size_t)((real ? n / 4 : n / 2) ? (real ? n / 4 : n / 2) : 1) * sizeof(double2);
     hipStream_t s = as_stream(stream);
 #define WMX_MFFT_LAUNCH(K) \
     hipLaunchKernelGGL((mfft_kernel<K, false>), grid, block, lds, s, n_batch, n, m, tw_inner, tw_n, d_in_re, d_in_im, d_out_re, d_out_im, d_out_af, d_out_pf, 0u)
@@ -259,7 +288,7 @@ extern "C" int wmx_mfft_stream(int n_streams, const float *d_in, unsigned in_len
     if (int rc = twiddles_for(st_len, &tw)) return rc;
     const unsigned wpb = waves_per_block(st_len);
     const dim3 grid((unsigned)((n_streams + wpb - 1) / wpb)), block(64 * wpb);
-    const size_t lds = (size_t)wpb * (2 * st_len + 2 * in_len) * sizeof(float);
+    const size_t lds = (size_t)wpb * (2 * st_len + 2 * in_len) * sizeof(float) + (size_t)(st_len / 2) * sizeof(double2);
     hipLaunchKernelGGL((mfft_kernel<0, true>), grid, block, lds, as_stream(stream), n_streams, st_len, m, tw, tw, d_in, (const float *)nullptr,
                        d_pool, (float *)nullptr, d_out_af, d_out_pf, in_len);
     WMX_LAUNCH_CHECK();
