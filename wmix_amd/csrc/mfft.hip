@@ -112,7 +112,10 @@ __device__ __forceinline__ unsigned rev_bits(unsigned i, unsigned m) { return m 
 __device__ __forceinline__ void emit(unsigned idx, float r, float i, unsigned n, float *o_re, float *o_im, float *o_af, float *o_pf) {
     if (o_re) o_re[idx] = r;
     if (o_im) o_im[idx] = i;
-    if (o_af) o_af[idx] = (float)(sqrt((double)(r * r + i * i)) / (double)(n / 2));  // math/fft.c:143-146
+    // math/fft.c:143-146: sqrt(double(float sum)) / (N/2), rounded to float once.  N/2 is a power of two, so the quotient
+    // is an exact scaling, and rounding a double square root of a float to float equals the correctly rounded float square
+    // root (53 >= 2*24 + 2 bits): sqrtf(x) * 2^-k is the same float, without the fp64 sqrt and divide.
+    if (o_af) o_af[idx] = sqrtf(r * r + i * i) * (1.0f / (float)(n / 2));
     if (o_pf) o_pf[idx] = (float)atan2((double)i, (double)r);                        // math/fft.c:149-152
 }
 
