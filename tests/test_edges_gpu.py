@@ -1,0 +1,71 @@
+"""Edge cases of the batched API on the GPU: ragged stream counts (not multiples of the 4 / 8 waves per workgroup or the
+64 lanes of the lane-per-stream kernels), empty calls, padded (strided) layouts, launches longer than the per-launch
+plan limit -- all against the oracle, same parity criteria as the main tests."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import loader as L
+from test_aec_gpu import check_float_path, gpu_chain
+from wmix_amd import synth
+from wmix_amd.aec import AecBatch
+from wmix_amd.agc import AgcBatch
+from wmix_amd.ns import NsBatch
+from wmix_amd.vad import VadBatch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("S", [1, 3, 5, 7, 9, 63, 65])
+def test_ragged_stream_counts_full_chain(cuda, oracle_port, S):
+    n, freq = 60, 16000
+    far = synth.far_end(900 + S, n, 160)
+    near = synth.near_end(950 + S, S, n, 160, far=far)
+    got = gpu_chain(cuda, 1, freq, 15, far, near, pkts_per_launch=7)
+    for s in sorted({0, S // 2, S - 1}):
+        want = L.run_chain(oracle_port, 1, freq, 5, 15, far, near[s], 160, prefix="orc")
+        check_float_path(got[s], want)
+
+
+def test_empty_calls_change_nothing(cuda):
+    S = 5
+    x = torch.randint(-3000, 3000, (S, 0, 160), dtype=torch.int16, device=cuda)
+    far = torch.zeros((0, 160), dtype=torch.int16, device=cuda)
+    ns, aec, agc, vad = NsBatch(S, 1, 16000), AecBatch(S, 1, 16000, 10), AgcBatch(S, 1, 16000, 5), VadBatch(S, 1, 16000, 10)
+    before = ns.export_state(0)
+    ns.process(x)
+    rc, _ = aec.process2(far, x)
+    assert rc == 0
+    agc.process(x)
+    vad.process(x)
+    after = ns.export_state(0)
+    # integer fields live in the float block as bit patterns (blockInd = -1 reads as NaN): compare the bits
+    assert np.array_equal(before[0].view(np.uint32), after[0].view(np.uint32)) and np.array_equal(before[1], after[1])
+    for b in (ns, aec, agc, vad):
+        b.close()
+
+
+def test_padded_strides_and_long_launches(cuda, oracle_port):
+    """rows padded to 200 int16 per packet and 37 packets per launch (the AEC plans at most 16 per kernel launch and
+    must chunk); only the 160 live samples of a packet may be touched"""
+    S, n, pkt, pad = 6, 74, 160, 200
+    far = synth.far_end(77, n, pkt)
+    near = synth.near_end(78, S, n, pkt, far=far)
+    buf = torch.full((S, n, pad), 12345, dtype=torch.int16, device=cuda)
+    buf[:, :, :pkt] = torch.from_numpy(near.reshape(S, n, pkt)).to(cuda)
+    dfar = torch.from_numpy(far.reshape(n, pkt).copy()).to(cuda)
+    ns, aec, agc, vad = NsBatch(S, 1, 16000), AecBatch(S, 1, 16000, 10), AgcBatch(S, 1, 16000, 5), VadBatch(S, 1, 16000, 10)
+    for f in range(0, n, 37):
+        view = buf[:, f:f + 37, :pkt]  # strides (n*pad, pad, 1)
+        ns.process(view)
+        rc, _ = aec.process2(dfar[f:f + 37], view)
+        assert rc == 0
+        agc.process(view)
+        vad.process(view)
+    out = buf.cpu().numpy()
+    assert (out[:, :, pkt:] == 12345).all()
+    for s in (0, 5):
+        want = L.run_chain(oracle_port, 1, 16000, 5, 15, far, near[s], pkt, prefix="orc")
+        check_float_path(out[s, :, :pkt].reshape(-1), want)
+    for b in (ns, aec, agc, vad):
+        b.close()

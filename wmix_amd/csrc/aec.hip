@@ -964,8 +964,13 @@ int wmx_aec_export_state(const wmx_aec *h, int stream_index, float *host_words) 
 int wmx_aec_run(wmx_aec *h, int mode, const int16_t *d_far, long far_packet_stride, const int16_t *d_near, int16_t *d_out,
                 int n_packets, long stream_stride, long packet_stride, int delay_ms, void *stream) {
     using namespace wmx;
-    if (!h || n_packets < 0 || (mode & 3) == 0 || ((mode & 1) && !d_far) || ((mode & 2) && (!d_near || !d_out))) {
+    if (!h || n_packets < 0 || (mode & 3) == 0) {
         set_error("wmx_aec_run: bad argument");
+        return WMX_EINVAL;
+    }
+    if (n_packets == 0) return 0;  // frameNum == 0: nothing to do, whatever the pointers are
+    if (((mode & 1) && !d_far) || ((mode & 2) && (!d_near || !d_out))) {
+        set_error("wmx_aec_run: null buffer");
         return WMX_EINVAL;
     }
     const long per_pkt = (long)h->pkg * h->chn;

@@ -520,11 +520,15 @@ int wmx_agc_gain_table(const wmx_agc *h, int32_t *host_table32) {
 int wmx_agc_process(wmx_agc *h, const int16_t *d_in, int16_t *d_out, int n_packets, long stream_stride, long packet_stride,
                     void *stream) {
     using namespace wmx;
-    if (!h || !d_in || !d_out || n_packets < 0) {
+    if (!h || n_packets < 0) {
         set_error("wmx_agc_process: bad argument");
         return WMX_EINVAL;
     }
-    if (n_packets == 0) return 0;
+    if (n_packets == 0) return 0;  // frameNum == 0: nothing to do, whatever the pointers are
+    if (!d_in || !d_out) {
+        set_error("wmx_agc_process: null buffer");
+        return WMX_EINVAL;
+    }
     const long per_pkt = (long)h->pkg * h->chn;
     if (packet_stride < per_pkt || (h->n_streams > 1 && stream_stride < per_pkt)) {
         set_error("wmx_agc_process: strides (%ld, %ld) smaller than a packet (%ld samples)", stream_stride, packet_stride, per_pkt);

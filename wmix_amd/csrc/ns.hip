@@ -978,11 +978,15 @@ int wmx_ns_export_state(const wmx_ns *h, int stream_index, float *host_words, un
 
 int wmx_ns_process(wmx_ns *h, const int16_t *d_in, int16_t *d_out, int n_packets, long stream_stride,
                    long packet_stride, void *stream) {
-    if (!h || !d_in || !d_out || n_packets < 0) {
+    if (!h || n_packets < 0) {
         wmx::set_error("wmx_ns_process: bad argument");
         return WMX_EINVAL;
     }
-    if (n_packets == 0) return 0;
+    if (n_packets == 0) return 0;  // frameNum == 0: the reference's loop does not run, whatever the pointers are
+    if (!d_in || !d_out) {
+        wmx::set_error("wmx_ns_process: null buffer");
+        return WMX_EINVAL;
+    }
     const int per_pkt = h->pkg * h->chn;
     if (packet_stride < per_pkt || (h->n_streams > 1 && stream_stride < per_pkt)) {
         // a packet must not overlap its neighbours; streams may be packet- or stream-major

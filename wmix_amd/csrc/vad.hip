@@ -604,11 +604,15 @@ int wmx_vad_packet_samples(const wmx_vad *h) { return h ? h->pkg * h->chn : WMX_
 int wmx_vad_process(wmx_vad *h, int16_t *d_pcm, int packets_per_call, int n_calls, long stream_stride, long call_stride,
                     void *stream) {
     using namespace wmx;
-    if (!h || !d_pcm || packets_per_call < 1 || n_calls < 0) {
+    if (!h || packets_per_call < 1 || n_calls < 0) {
         set_error("wmx_vad_process: bad argument");
         return WMX_EINVAL;
     }
-    if (n_calls == 0) return 0;
+    if (n_calls == 0) return 0;  // nothing to do, whatever the pointer is
+    if (!d_pcm) {
+        set_error("wmx_vad_process: null buffer");
+        return WMX_EINVAL;
+    }
     const long per_call = (long)packets_per_call * h->pkg * h->chn;
     if (call_stride < per_call || (h->n_streams > 1 && stream_stride < per_call)) {
         set_error("wmx_vad_process: strides (%ld, %ld) smaller than a call (%ld samples)", stream_stride, call_stride, per_call);
