@@ -218,6 +218,7 @@ class ChainWorkload:
     dominant_kernel = "aec_near_kernel<2>"
     dominant_bytes_per_frame = 24040.0
     freq, pkt = 16000, 160
+    with_agc_vad = True
 
     def __init__(self, dev, n_streams, rank, dist=None, packets=1):
         from wmix_amd import synth
@@ -243,8 +244,8 @@ class ChainWorkload:
         self.work = torch.empty_like(self.inp[0:self.P])
         self.ns = NsBatch(n_streams, 1, self.freq, ordered=True)
         self.aec = AecBatch(n_streams, 1, self.freq, 10)
-        self.agc = AgcBatch(n_streams, 1, self.freq, 5)  # volumeAgc default 5, src/wmix.c:1596
-        self.vad = VadBatch(n_streams, 1, self.freq, 10)
+        self.agc = AgcBatch(n_streams, 1, self.freq, 5) if self.with_agc_vad else None  # volumeAgc default 5, src/wmix.c:1596
+        self.vad = VadBatch(n_streams, 1, self.freq, 10) if self.with_agc_vad else None
         self.rank = rank
         self.t = _StageTimer()
         self.k = 0
@@ -261,8 +262,9 @@ class ChainWorkload:
         if work is not None:
             self.t.run("far_broadcast_wait", timed, work.wait)
         self.t.run("aec", timed, lambda: self.aec.process2_packet_major(self.far, self.work))
-        self.t.run("agc", timed, lambda: self.agc.process_packet_major(self.work))
-        self.t.run("vad", timed, lambda: self.vad.process_packet_major(self.work))
+        if self.with_agc_vad:
+            self.t.run("agc", timed, lambda: self.agc.process_packet_major(self.work))
+            self.t.run("vad", timed, lambda: self.vad.process_packet_major(self.work))
 
     def dominant_ms(self):
         return self.t.mean_ms("aec")
@@ -272,7 +274,7 @@ class ChainWorkload:
 
     def config(self):
         return {"workload": self.name, "streams_per_gpu": self.n_streams, "packets_per_stream_per_step": self.P,
-                "frame": "160 x int16 (10 ms @ 16 kHz mono)",
+                "frame": "%d x int16 (10 ms @ %d kHz mono)" % (self.pkt, self.freq // 1000),
                 "far_end": "shared, RCCL broadcast from rank 0 each step (asynchronous, overlapped with NS)", "sum_order": "reference (bit-exact NS mode)",
                 "aec_launch": "far kernel + near kernel; the near kernel is the timed dominant kernel together with its far kernel"}
 
@@ -286,7 +288,7 @@ class ChainWorkload:
             t0 = time.perf_counter()
             reps = 0
             while time.perf_counter() - t0 < seconds:
-                loader.run_chain(lib, 1, self.freq, 5, 15, far, near, self.pkt, prefix=prefix)
+                loader.run_chain(lib, 1, self.freq, 5, 15 if self.with_agc_vad else 3, far, near, self.pkt, prefix=prefix)
                 reps += 1
             return reps, reps * n / (time.perf_counter() - t0)
 
@@ -303,8 +305,20 @@ class ChainWorkload:
                 "sample": "%d x %d packets of one 16 kHz stream through the oracle chain (oracle/orc_*.c, -O2), 1 thread" % (reps, n)}
 
 
+class NsAec8kWorkload(ChainWorkload):
+    """BASELINE.json configs[3]: NS -> AEC, 8 kHz mono, shared far-end, 131 072 streams per GPU (the 1 M streams of the
+    config over 8 GPUs).  Algorithmic bytes per stream-frame = 320 PCM + 2 x (6 000 + 11 700) = 35 720 B; the
+    AEC near-end kernel: 160 + 160 + 2 x 11 700 = 23 720 B."""
+    name = "ns_aec_8k_mono"
+    bytes_per_frame = 35720.0
+    dominant_kernel = "aec_near_kernel<1>"
+    dominant_bytes_per_frame = 23720.0
+    freq, pkt = 8000, 80
+    with_agc_vad = False
+
+
 WORKLOADS = {"g711": (G711Workload, 1 << 20), "ns": (NsWorkload, 4096), "chain": (ChainWorkload, 65536),
-             "mfft": (MfftWorkload, 65536)}
+             "mfft": (MfftWorkload, 65536), "ns_aec_8k": (NsAec8kWorkload, 131072)}
 DEFAULT_WORKLOAD = "chain"
 
 
@@ -352,7 +366,7 @@ def main():
     _lib.lib()  # no fallback: raises when the HIP library is missing
 
     cls, default_streams = WORKLOADS[args.workload]
-    if cls is ChainWorkload:
+    if issubclass(cls, ChainWorkload):
         wl = cls(dev, args.streams or default_streams, rank, dist, args.packets_per_step)
     else:
         wl = cls(dev, args.streams or default_streams, rank)
