@@ -305,6 +305,80 @@ class ChainWorkload:
                 "sample": "%d x %d packets of one 16 kHz stream through the oracle chain (oracle/orc_*.c, -O2), 1 thread" % (reps, n)}
 
 
+class NsAgcMix32kWorkload:
+    """BASELINE.json configs[4]: 2-channel 32 kHz NS + AGC per source, then wmix_load_data's resample to the 8 kHz mono ring
+    with an 8-way saturating mix, 32 768 sources per GPU in 4 096 mix groups, and the play thread's 10 ms drain.
+    Algorithmic bytes per source-frame = 2 560 PCM + 2 x (12 200 + 2 048 + 668) state + 160 x (1 + 1/8) ring = 32 550 B
+    (SURVEY 8d); the NS kernel: 1 280 + 1 280 + 2 x (12 200 + 2 048) = 31 056 B."""
+    name = "ns_agc_32k_2ch_mix8_to_8k"
+    dtype = "f32 (NS), int16/int32 (AGC, mix)"
+    bytes_per_frame = 32550.0
+    dominant_kernel = "ns_kernel<256, true>"
+    dominant_bytes_per_frame = 31056.0
+    N = 8  # sources per mix group
+
+    def __init__(self, dev, n_streams, rank):
+        from wmix_amd.agc import AgcBatch
+        from wmix_amd.mix import MixBatch
+        from wmix_amd.ns import NsBatch
+        S = self.n_frames = n_streams
+        assert S % self.N == 0
+        self.K, per = 4, 640
+        rng = np.random.default_rng(500 + rank)
+        t = np.arange(self.K * 320)
+        base = np.zeros((64, self.K * 320, 2), np.int16)
+        for s in range(64):
+            tone = 6000 * np.sin(2 * np.pi * (150 + 31 * s) * t / 32000)
+            base[s, :, 0] = np.clip(tone + rng.integers(-2000, 2000, t.size), -32768, 32767)
+            base[s, :, 1] = base[s, :, 0] // 3
+        x = np.tile(base.reshape(64, self.K, per), (S // 64 + 1, 1, 1))[:S].transpose(1, 0, 2)
+        self.inp = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        self.flat = torch.zeros(S * per + 2, dtype=torch.int16, device=dev)  # + the mixer's 2-sample look-ahead
+        self.work = self.flat[: S * per].view(1, S, per)
+        self.src = torch.as_strided(self.flat, (S // self.N, self.N, per + 2), (self.N * per, per, 1))
+        self.ns, self.agc = NsBatch(S, 2, 32000, ordered=True), AgcBatch(S, 2, 32000, 5)
+        self.mix = MixBatch(S // self.N, 1, 8000)
+        self.t = _StageTimer()
+        self.k = 0
+
+    def step(self, timed):
+        k = self.k % self.K
+        self.k += 1
+        S = self.n_frames
+        self.t.run("ns", timed, lambda: self.ns.process_packet_major(self.inp[k:k + 1], self.work))
+        self.t.run("agc", timed, lambda: self.agc.process(self.work[0].view(S, 2, 320)))  # 5 ms AGC packets at 32 kHz
+
+        def mix():
+            self.mix.set(0, 0, 1)
+            self.mix.load(self.src, 1280, 32000, 2)
+            self.mix.set(3200, 0, 1)
+            return self.mix.drain(160)
+        self.t.run("mix", timed, mix)
+
+    def dominant_ms(self):
+        return self.t.mean_ms("ns")
+
+    def stage_ms(self):
+        return {k: self.t.mean_ms(k) for k in ("ns", "agc", "mix")}
+
+    def config(self):
+        return {"workload": self.name, "sources_per_gpu": self.n_frames, "mix_groups": self.n_frames // self.N,
+                "frame": "640 x int16 (10 ms @ 32 kHz, 2 channels) -> 80 x int16 (10 ms @ 8 kHz mono) per group"}
+
+    def cpu_baseline(self, budget_s):
+        from oracle import loader
+        port = loader.port()
+        n = 1000
+        x = np.tile(np.ascontiguousarray(self.inp[:, 0].cpu().numpy().reshape(-1)), n // self.K + 1)[: n * 640]
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < budget_s:
+            loader.run_chain(port, 2, 32000, 5, 1 | 4, np.zeros_like(x), x, 320, prefix="orc")
+            reps += 1
+        return {"value": reps * n / (time.perf_counter() - t0), "unit": "frames/s", "cores": 1, "kind": "port",
+                "sample": "%d x %d packets of one 2 x 32 kHz source through NS + AGC of the oracle (mix excluded), 1 thread" % (reps, n)}
+
+
 class NsAec8kWorkload(ChainWorkload):
     """BASELINE.json configs[3]: NS -> AEC, 8 kHz mono, shared far-end, 131 072 streams per GPU (the 1 M streams of the
     config over 8 GPUs).  Algorithmic bytes per stream-frame = 320 PCM + 2 x (6 000 + 11 700) = 35 720 B; the
@@ -318,7 +392,8 @@ class NsAec8kWorkload(ChainWorkload):
 
 
 WORKLOADS = {"g711": (G711Workload, 1 << 20), "ns": (NsWorkload, 4096), "chain": (ChainWorkload, 65536),
-             "mfft": (MfftWorkload, 65536), "ns_aec_8k": (NsAec8kWorkload, 131072)}
+             "mfft": (MfftWorkload, 65536), "ns_aec_8k": (NsAec8kWorkload, 131072),
+             "ns_agc_mix_32k": (NsAgcMix32kWorkload, 32768)}
 DEFAULT_WORKLOAD = "chain"
 
 
