@@ -75,8 +75,9 @@ __device__ __forceinline__ int16_t down2_step(int16_t a, int16_t b, int32_t *st)
 
 // One packet (10*L mono samples) of one stream.  in/out point at the packet's first frame;
 // `chn` interleaved channels are averaged on input and duplicated on output (src/webrtc.c:789-815).
-template <int L>  // samples per millisecond sub-frame: 8 (8 kHz) or 16 (16 / 32 kHz)
-__device__ void agc_packet(const AgcRef &S, const int32_t *__restrict__ gain_table, const int16_t *in, int16_t *out, int chn) {
+template <int L, int CHN>  // L samples per millisecond sub-frame: 8 (8 kHz) or 16 (16 / 32 kHz); CHN interleaved channels
+__device__ void agc_packet(const AgcRef &S, const int32_t *__restrict__ gain_table, const int16_t *in, int16_t *out, int chn_rt) {
+    const int chn = CHN ? CHN : chn_rt;  // CHN = 1, 2: compile-time (the daemon's cases); 0: any count, at run time
     constexpr int L2 = (L == 8) ? 3 : 4;
     auto load = [&](int i) -> int16_t {
         if (chn == 1) return in[i];
@@ -284,10 +285,10 @@ __device__ void agc_packet(const AgcRef &S, const int32_t *__restrict__ gain_tab
     }
 }
 
-template <int L>
+template <int L, int CHN>
 __global__ __launch_bounds__(64) void agc_kernel(int16_t *s16, int32_t *s32, const int32_t *gain_table_g, const int16_t *in,
                                                  int16_t *out, int n_streams, int n_packets, long stream_stride,
-                                                 long packet_stride, int chn) {
+                                                 long packet_stride, int chn_rt) {
     __shared__ int32_t gain_table[32];
     if (threadIdx.x < 32) gain_table[threadIdx.x] = gain_table_g[threadIdx.x];
     __syncthreads();
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(64) void agc_kernel(int16_t *s16, int32_t *s32, con
     const AgcRef S{s16 + stream, s32 + stream, (size_t)n_streams};
     for (int p = 0; p < n_packets; p++) {
         const size_t off = (size_t)stream * stream_stride + (size_t)p * packet_stride;
-        agc_packet<L>(S, gain_table, in + off, out + off, chn);
+        agc_packet<L, CHN>(S, gain_table, in + off, out + off, chn_rt);
     }
 }
 
@@ -536,12 +537,25 @@ int wmx_agc_process(wmx_agc *h, const int16_t *d_in, int16_t *d_out, int n_packe
     }
     const dim3 grid((h->n_streams + 63) / 64), block(64);
     hipStream_t s = as_stream(stream);
-    if (h->freq == 8000)
-        hipLaunchKernelGGL((agc_kernel<8>), grid, block, 0, s, h->d_s16, h->d_s32, h->d_table, d_in, d_out, h->n_streams, n_packets,
-                           stream_stride, packet_stride, h->chn);
-    else
-        hipLaunchKernelGGL((agc_kernel<16>), grid, block, 0, s, h->d_s16, h->d_s32, h->d_table, d_in, d_out, h->n_streams, n_packets,
-                           stream_stride, packet_stride, h->chn);
+#define AGC_LAUNCH(LL, CC)                                                                                                   \
+    hipLaunchKernelGGL((agc_kernel<LL, CC>), grid, block, 0, s, h->d_s16, h->d_s32, h->d_table, d_in, d_out, h->n_streams, n_packets, \
+                       stream_stride, packet_stride, h->chn)
+    if (h->freq == 8000) {
+        if (h->chn == 1)
+            AGC_LAUNCH(8, 1);
+        else if (h->chn == 2)
+            AGC_LAUNCH(8, 2);
+        else
+            AGC_LAUNCH(8, 0);
+    } else {
+        if (h->chn == 1)
+            AGC_LAUNCH(16, 1);
+        else if (h->chn == 2)
+            AGC_LAUNCH(16, 2);
+        else
+            AGC_LAUNCH(16, 0);
+    }
+#undef AGC_LAUNCH
     WMX_LAUNCH_CHECK();
     return 0;
 }
