@@ -112,7 +112,7 @@ class NsWorkload:
     name = "ns_16k_mono"
     dtype = "f32"
     bytes_per_frame = 25040.0
-    dominant_kernel = "ns_kernel<256, true>"
+    dominant_kernel = "ns_kernel<256, true, 1>"
     dominant_bytes_per_frame = 25040.0
     freq, pkt = 16000, 160
 
@@ -313,7 +313,7 @@ class NsAgcMix32kWorkload:
     name = "ns_agc_32k_2ch_mix8_to_8k"
     dtype = "f32 (NS), int16/int32 (AGC, mix)"
     bytes_per_frame = 32550.0
-    dominant_kernel = "ns_kernel<256, true>"
+    dominant_kernel = "ns_kernel<256, true, 2>"
     dominant_bytes_per_frame = 31056.0
     N = 8  # sources per mix group
 

@@ -143,10 +143,11 @@ __device__ __forceinline__ float sum_lanes(const float *mine) {
 }
 __device__ __forceinline__ float lane_value(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
 
-template <int L, bool ORDERED>
+template <int L, bool ORDERED, int CHN>
 __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restrict__ st, unsigned short *__restrict__ hist,
-                         const int16_t *in, int16_t *out, const int chn, const int pkg, const int lane_in) {
+                         const int16_t *in, int16_t *out, const int pkg, const int lane_in) {
     using Y = NsLayout<L>;
+    constexpr int chn = CHN;  // 1 or 2 (ns_init takes nothing else): compile-time, so the mono kernel carries no high band
     // Lane-derived addresses are loop invariant; left alone the compiler hoists them out of the packet loop and
     // keeps them in VGPRs for the whole kernel.  Re-deriving them per phase is a few VALU ops and frees the registers.
     int lane = lane_in;
@@ -769,11 +770,11 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
 
 constexpr int kNsWavesPerBlock = 4;
 
-template <int L, bool ORDERED>
+template <int L, bool ORDERED, int CHN>
 __global__ __launch_bounds__(64 * kNsWavesPerBlock, 4) void ns_kernel(float *__restrict__ state, unsigned short *__restrict__ hists,
                                                                       const float *__restrict__ consts, const int16_t *in, int16_t *out,
                                                                       int n_streams, int n_packets, long stream_stride,
-                                                                      long packet_stride, int chn, int pkg) {
+                                                                      long packet_stride, int pkg) {
     using Y = NsLayout<L>;
     __shared__ NsConstLds<L> K;
     __shared__ NsWaveLds<L> Wv[kNsWavesPerBlock];
@@ -801,7 +802,7 @@ __global__ __launch_bounds__(64 * kNsWavesPerBlock, 4) void ns_kernel(float *__r
 #endif
     for (int p = 0; p < n_packets; p++) {
         const size_t off = (size_t)sidx * stream_stride + (size_t)p * packet_stride;
-        ns_frame<L, ORDERED>(K, Wv[wave], st, hist, in + off, out + off, chn, pkg, lane);
+        ns_frame<L, ORDERED, CHN>(K, Wv[wave], st, hist, in + off, out + off, pkg, lane);
     }
 #ifdef WMX_NS_PROF
     if (lane < 16) atomicAdd(&g_ns_prof[lane], Wv[wave].prof[lane]);
@@ -995,20 +996,28 @@ int wmx_ns_process(wmx_ns *h, const int16_t *d_in, int16_t *d_out, int n_packets
     }
     const unsigned grid = (unsigned)((h->n_streams + wmx::kNsWavesPerBlock - 1) / wmx::kNsWavesPerBlock);
     hipStream_t s = wmx::as_stream(stream);
-#define NS_LAUNCH(LL, ORD)                                                                                              \
-    hipLaunchKernelGGL((wmx::ns_kernel<LL, ORD>), dim3(grid), dim3(64 * wmx::kNsWavesPerBlock), 0, s, h->d_state, h->d_hist, \
-                       h->d_consts, d_in, d_out, h->n_streams, n_packets, stream_stride, packet_stride, h->chn, h->pkg)
+#define NS_LAUNCH(LL, ORD, CC)                                                                                              \
+    hipLaunchKernelGGL((wmx::ns_kernel<LL, ORD, CC>), dim3(grid), dim3(64 * wmx::kNsWavesPerBlock), 0, s, h->d_state, h->d_hist, \
+                       h->d_consts, d_in, d_out, h->n_streams, n_packets, stream_stride, packet_stride, h->pkg)
+#define NS_LAUNCH_ORD(LL, CC) \
+    do {                      \
+        if (h->ordered)       \
+            NS_LAUNCH(LL, true, CC); \
+        else                  \
+            NS_LAUNCH(LL, false, CC); \
+    } while (0)
     if (h->L == 128) {
-        if (h->ordered)
-            NS_LAUNCH(128, true);
+        if (h->chn == 1)
+            NS_LAUNCH_ORD(128, 1);
         else
-            NS_LAUNCH(128, false);
+            NS_LAUNCH_ORD(128, 2);
     } else {
-        if (h->ordered)
-            NS_LAUNCH(256, true);
+        if (h->chn == 1)
+            NS_LAUNCH_ORD(256, 1);
         else
-            NS_LAUNCH(256, false);
+            NS_LAUNCH_ORD(256, 2);
     }
+#undef NS_LAUNCH_ORD
 #undef NS_LAUNCH
     WMX_LAUNCH_CHECK();
     return 0;
