@@ -45,9 +45,14 @@ struct VadRef {
     int16_t *s16;
     int32_t *s32;
     size_t n;  // streams (row pitch)
+    int16_t *minbuf;  // LDS copy of index_vector / low_value_vector (V16_AGE .. V16_MEAN_VALUE), element f at minbuf[f * 64]
     __device__ __forceinline__ int16_t &h(int f) const { return s16[(size_t)f * n]; }
     __device__ __forceinline__ int32_t &w(int f) const { return s32[(size_t)f * n]; }
+    // the 2 x 96 order-statistics entries: WebRtcVad_FindMinimum walks and shifts them element by element
+    // (vad_sp.c:59-177), a long chain of dependent accesses -- from LDS, not from HBM / L2
+    __device__ __forceinline__ int16_t &hm(int f) const { return minbuf[(f - V16_AGE) * 64]; }
 };
+constexpr int kVadMinFields = V16_MEAN_VALUE - V16_AGE;  // 192
 
 // LDS int16 buffer private to one lane: element i lives at base[i * 64]
 struct LaneBuf {
@@ -161,36 +166,36 @@ __device__ int32_t gauss_prob(int16_t input, int16_t mean, int16_t std, int16_t 
 __device__ int16_t find_minimum(const VadRef &S, int16_t v, int ch, int32_t frame_counter) {
     const int a0 = V16_AGE + (ch << 4), l0 = V16_LOW + (ch << 4);
     for (int i = 0; i < 16; i++) {
-        const int16_t age = S.h(a0 + i);
+        const int16_t age = S.hm(a0 + i);
         if (age != 100) {
-            S.h(a0 + i) = (int16_t)(age + 1);
+            S.hm(a0 + i) = (int16_t)(age + 1);
         } else {
             for (int j = i; j < 15; j++) {
-                S.h(l0 + j) = S.h(l0 + j + 1);
-                S.h(a0 + j) = S.h(a0 + j + 1);
+                S.hm(l0 + j) = S.hm(l0 + j + 1);
+                S.hm(a0 + j) = S.hm(a0 + j + 1);
             }
-            S.h(a0 + 15) = 101;
-            S.h(l0 + 15) = 10000;
+            S.hm(a0 + 15) = 101;
+            S.hm(l0 + 15) = 10000;
         }
     }
     int pos = -1;
-    if (v < S.h(l0 + 15)) {  // sorted ascending: the reference's unrolled binary search == first larger element
+    if (v < S.hm(l0 + 15)) {  // sorted ascending: the reference's unrolled binary search == first larger element
         pos = 0;
-        while (!(v < S.h(l0 + pos))) pos++;
+        while (!(v < S.hm(l0 + pos))) pos++;
     }
     if (pos > -1) {
         for (int i = 15; i > pos; i--) {
-            S.h(l0 + i) = S.h(l0 + i - 1);
-            S.h(a0 + i) = S.h(a0 + i - 1);
+            S.hm(l0 + i) = S.hm(l0 + i - 1);
+            S.hm(a0 + i) = S.hm(a0 + i - 1);
         }
-        S.h(l0 + pos) = v;
-        S.h(a0 + pos) = 1;
+        S.hm(l0 + pos) = v;
+        S.hm(a0 + pos) = 1;
     }
     int16_t median = 1600, alpha = 0;
     if (frame_counter > 2)
-        median = S.h(l0 + 2);
+        median = S.hm(l0 + 2);
     else if (frame_counter > 0)
-        median = S.h(l0);
+        median = S.hm(l0);
     const int16_t mean = S.h(V16_MEAN_VALUE + ch);
     if (frame_counter > 0) alpha = (median < mean) ? 6553 : 32439;
     int32_t t = (alpha + 1) * mean;
@@ -468,14 +473,19 @@ template <int NB, int RATIO>
 __global__ __launch_bounds__(64) void vad_kernel(int16_t *s16, int32_t *s32, int16_t *pcm, int n_streams, int packets_per_call,
                                                  int n_calls, long stream_stride, long call_stride, int chn) {
     __shared__ int16_t lds[64 * (NB / 2 + NB / 2 + NB / 4 + NB / 4)];
+    __shared__ int16_t minlds[64 * kVadMinFields];
     const int lane = threadIdx.x;
     const int stream = blockIdx.x * 64 + lane;
     if (stream >= n_streams) return;  // lanes are independent: no barriers anywhere in this kernel
-    const VadRef S{s16 + stream, s32 + stream, (size_t)n_streams};
+    const VadRef S{s16 + stream, s32 + stream, (size_t)n_streams, minlds + lane};
+    // order-statistics state in: 192 coalesced rows, all in flight together
+#pragma unroll 8
+    for (int f = 0; f < kVadMinFields; f++) minlds[f * 64 + lane] = S.h(V16_AGE + f);
     // warm L2 with this wave's state rows and PCM lines (wmx_internal.h: touch_line)
     int sink = 0;
 #pragma unroll 1
-    for (int f = 0; f < V16_WORDS; f++) touch_line(&S.h(f), sink);
+    for (int f = 0; f < V16_WORDS; f++)
+        if (f < V16_AGE || f >= V16_MEAN_VALUE) touch_line(&S.h(f), sink);
 #pragma unroll 1
     for (int f = 0; f < V32_WORDS; f++) touch_line(&S.w(f), sink);
     {
@@ -517,6 +527,8 @@ __global__ __launch_bounds__(64) void vad_kernel(int16_t *s16, int32_t *s32, int
             }
         }
     }
+#pragma unroll 8
+    for (int f = 0; f < kVadMinFields; f++) S.h(V16_AGE + f) = minlds[f * 64 + lane];
 }
 
 __global__ void vad_fill_state(int16_t *s16, int32_t *s32, const int16_t *t16, int n_streams) {
