@@ -25,12 +25,48 @@ __device__ __forceinline__ int dec1(unsigned c) {
     return LAW == WMX_LAW_A ? dec_alaw(c) : dec_ulaw(c);
 }
 
+// Encoding through a table in LDS.  Both laws quantise a magnitude v whose low bits never reach the code:
+//   mu-law: v = |pcm| + 0x84 in [0x84, 32900], code bits = f(v >> 3);   A-law: v = pcm or -pcm - 8 (which may stay
+//   negative) in [-7, 32767], code bits = f(v >> 4)
+// so a 4 KB (mu) / 2 KB (A) byte table indexed by v >> 3 / (v >> 4) + 1 holds every case; each workgroup fills its copy
+// with enc_ulaw / enc_alaw themselves (g711_dev.h, the reference's arithmetic) on one representative per bucket, and
+// the stream loop is sign, magnitude, one LDS byte read, sign mask: about half the VALU work per sample of the
+// segment search, which is what the kernel was short of.
+template <int LAW>
+struct EncTable {
+    static constexpr int kSize = LAW == WMX_LAW_U ? (32900 >> 3) + 1 : (32767 >> 4) + 2;
+    static constexpr unsigned kPosMask = LAW == WMX_LAW_U ? 0xFFu : 0xD5u;
+    __device__ static void fill(uint8_t *t) {
+        for (int i = threadIdx.x; i < kSize; i += blockDim.x) {
+            if (LAW == WMX_LAW_U) {
+                const int v = (i << 3) < 0x84 ? 0x84 : (i << 3);  // buckets below 0x84 >> 3 are never indexed
+                t[i] = (uint8_t)(enc_ulaw(v - 0x84) ^ kPosMask);
+            } else {
+                t[i] = i == 0 ? (uint8_t)(enc_alaw(-7) ^ 0x55u) : (uint8_t)(enc_alaw((i - 1) << 4) ^ kPosMask);
+            }
+        }
+    }
+    __device__ __forceinline__ static unsigned encode(const uint8_t *t, int pcm) {
+        const int sign = pcm >> 31;            // 0 or -1
+        const int mag = (pcm ^ sign) - sign;   // |pcm| (32768 for -32768)
+        int idx;
+        if (LAW == WMX_LAW_U)
+            idx = (mag + 0x84) >> 3;
+        else
+            idx = ((mag + (sign & -8)) >> 4) + 1;  // -pcm - 8 for negative input, arithmetic shift
+        return (unsigned)t[idx] ^ (kPosMask ^ ((unsigned)sign & 0x80u));
+    }
+};
+
 // n8 = number of full 8-sample groups; `aligned` says both pointers allow the
 // wide accesses (16 B PCM / 8 B code).  The tail (< 8 samples) and the unaligned
 // case run through the scalar loop at the end.
 template <int LAW>
 __global__ __launch_bounds__(256) void g711_encode_kernel(const int16_t *__restrict__ pcm,
                                                           uint8_t *__restrict__ code, size_t n, int aligned) {
+    __shared__ uint8_t tab[(EncTable<LAW>::kSize + 15) & ~15];
+    EncTable<LAW>::fill(tab);
+    __syncthreads();
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nthreads = (size_t)gridDim.x * blockDim.x;
     size_t done = 0;
@@ -44,8 +80,8 @@ __global__ __launch_bounds__(256) void g711_encode_kernel(const int16_t *__restr
             unsigned c[8];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                c[2 * k] = enc1<LAW>((int)(int16_t)(w[k] & 0xFFFF));
-                c[2 * k + 1] = enc1<LAW>((int)(int16_t)(w[k] >> 16));
+                c[2 * k] = EncTable<LAW>::encode(tab, (int)(int16_t)(w[k] & 0xFFFF));
+                c[2 * k + 1] = EncTable<LAW>::encode(tab, (int)(int16_t)(w[k] >> 16));
             }
             uint2 o;
             o.x = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
@@ -54,7 +90,7 @@ __global__ __launch_bounds__(256) void g711_encode_kernel(const int16_t *__restr
         }
         done = n8 * 8;
     }
-    for (size_t i = done + tid; i < n; i += nthreads) code[i] = (uint8_t)enc1<LAW>((int)pcm[i]);
+    for (size_t i = done + tid; i < n; i += nthreads) code[i] = (uint8_t)EncTable<LAW>::encode(tab, (int)pcm[i]);
 }
 
 template <int LAW>
