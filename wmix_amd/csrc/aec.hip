@@ -398,15 +398,33 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
         }
         wave_sync();
         AEC_RELANE();
-        // one partition at a time per group: each lane reads its (and its mirror's) points of row 4r + g before any
-        // lane of the group stores to it
-#pragma unroll 1
-        for (int r = 0; r < cnt / 4; r++) {
-            float *row = W.fa[4 * r + g];
-            Cx v[4];
-            aec_fft_inv(row, &K.tab, gl, v);
+        if (pass == 0) {
+            // partitions g and 4 + g of this group as one packed pair (fft_regs.h, Cx2): every lane reads its (and its
+            // mirror's) points of both rows before any lane of the group stores to them
+            float *row0 = W.fa[g], *row1 = W.fa[4 + g];
+            Cx2 v[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) v[m] = rdft128_inv_point_x2(row0, row1, &K.tab, fft64_src_point(gl, m));
+            fft64_regs_x2<true>(v, &K.tab, gl);
             // points 0..31 (m = 0, 1) scaled, points 32..63 zeroed; the forward gather wants points
             // rev4(gl) + {0, 32, 16, 48}: two of them from lane rev4(gl), two zeros
+            const v2f sc = bc(scale), z = bc(0.f);
+            const v2f ar = v[0].r * sc, ai = v[0].i * sc, cr = v[1].r * sc, ci = v[1].i * sc;
+            v[0] = Cx2{v2f{row_bitrev(ar.x, lane), row_bitrev(ar.y, lane)}, v2f{row_bitrev(ai.x, lane), row_bitrev(ai.y, lane)}};
+            v[2] = Cx2{v2f{row_bitrev(cr.x, lane), row_bitrev(cr.y, lane)}, v2f{row_bitrev(ci.x, lane), row_bitrev(ci.y, lane)}};
+            v[1] = Cx2{z, z};
+            v[3] = Cx2{z, z};
+            fft64_regs_x2<false>(v, &K.tab, gl);
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                *reinterpret_cast<float2 *>(row0 + 2 * (gl + 16 * m)) = make_float2(v[m].r.x, v[m].i.x);
+                *reinterpret_cast<float2 *>(row1 + 2 * (gl + 16 * m)) = make_float2(v[m].r.y, v[m].i.y);
+            }
+        } else {
+            // partitions 8 + g: one transform per group
+            float *row = W.fa[g];
+            Cx v[4];
+            aec_fft_inv(row, &K.tab, gl, v);
             const Cx a = Cx{row_bitrev(v[0].r * scale, lane), row_bitrev(v[0].i * scale, lane)};
             const Cx c = Cx{row_bitrev(v[1].r * scale, lane), row_bitrev(v[1].i * scale, lane)};
             v[0] = a;

@@ -127,6 +127,115 @@ __device__ __forceinline__ void rdft128_fwd_bin_lane(const float *a, const FftTa
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// TWO transforms per lane, packed across the transforms: every value is a v2f whose halves belong to transform 0 and
+// transform 1 of the same 16-lane group (real and imaginary parts in separate vectors).  The butterflies then are
+// purely element-wise -- v_pk_add_f32 / v_pk_mul_f32 with the (shared) twiddle broadcast, no swizzles, no sign
+// shuffles -- and cost what one transform costs; only the DPP transposes move each 32-bit half on its own.  Formulas:
+// the scalar ones of the reference (fft4g.c:1002-1231, 913-984), operand for operand.
+struct Cx2 {
+    v2f r, i;
+};
+__device__ __forceinline__ v2f bc(float x) { return v2f{x, x}; }
+
+__device__ __forceinline__ void bfly4_x2(int b, const FftTables *T, Cx2 v[4]) {
+    const v2f x0r = v[0].r + v[1].r, x0i = v[0].i + v[1].i, x1r = v[0].r - v[1].r, x1i = v[0].i - v[1].i;
+    const v2f x2r = v[2].r + v[3].r, x2i = v[2].i + v[3].i, x3r = v[2].r - v[3].r, x3i = v[2].i - v[3].i;
+    v[0].r = x0r + x2r;
+    v[0].i = x0i + x2i;
+    if (b == 0) {
+        v[2].r = x0r - x2r;
+        v[2].i = x0i - x2i;
+        v[1].r = x1r - x3i;
+        v[1].i = x1i + x3r;
+        v[3].r = x1r + x3i;
+        v[3].i = x1i - x3r;
+    } else if (b == 1) {
+        const v2f w = bc(T->w2);
+        v[2].r = x2i - x0i;
+        v[2].i = x0r - x2r;
+        v2f tr = x1r - x3i, ti = x1i + x3r;
+        v[1].r = w * (tr - ti);
+        v[1].i = w * (tr + ti);
+        tr = x3i + x1r;
+        ti = x3r - x1i;
+        v[3].r = w * (ti - tr);
+        v[3].i = w * (ti + tr);
+    } else {
+        const v2f w1r = bc(T->W1[b][0]), w1i = bc(T->W1[b][1]), w2r = bc(T->W2[b][0]), w2i = bc(T->W2[b][1]);
+        const v2f w3r = bc(T->W3[b][0]), w3i = bc(T->W3[b][1]);
+        v2f tr = x0r - x2r, ti = x0i - x2i;
+        v[2].r = w2r * tr - w2i * ti;
+        v[2].i = w2r * ti + w2i * tr;
+        tr = x1r - x3i;
+        ti = x1i + x3r;
+        v[1].r = w1r * tr - w1i * ti;
+        v[1].i = w1r * ti + w1i * tr;
+        tr = x1r + x3i;
+        ti = x1i - x3r;
+        v[3].r = w3r * tr - w3i * ti;
+        v[3].i = w3r * ti + w3i * tr;
+    }
+}
+
+template <bool INVERSE>
+__device__ __forceinline__ void bfly4_close_x2(Cx2 v[4]) {
+    const v2f x0r = v[0].r + v[1].r, x1r = v[0].r - v[1].r, x2r = v[2].r + v[3].r, x2i = v[2].i + v[3].i, x3r = v[2].r - v[3].r,
+              x3i = v[2].i - v[3].i;
+    if constexpr (!INVERSE) {
+        const v2f x0i = v[0].i + v[1].i, x1i = v[0].i - v[1].i;
+        v[0] = Cx2{x0r + x2r, x0i + x2i};
+        v[2] = Cx2{x0r - x2r, x0i - x2i};
+        v[1] = Cx2{x1r - x3i, x1i + x3r};
+        v[3] = Cx2{x1r + x3i, x1i - x3r};
+    } else {
+        const v2f x0i = -v[0].i - v[1].i, x1i = -v[0].i + v[1].i;
+        v[0] = Cx2{x0r + x2r, x0i - x2i};
+        v[2] = Cx2{x0r - x2r, x0i + x2i};
+        v[1] = Cx2{x1r - x3i, x1i - x3r};
+        v[3] = Cx2{x1r + x3i, x1i + x3r};
+    }
+}
+
+template <int XA, int XB>
+__device__ __forceinline__ void transpose4_x2(Cx2 v[4], int gl) {
+    const bool ba = (gl & XA) != 0, bb = (gl & XB) != 0;
+    xstage<XA>(v[0].r, v[1].r, ba);
+    xstage<XA>(v[0].i, v[1].i, ba);
+    xstage<XA>(v[2].r, v[3].r, ba);
+    xstage<XA>(v[2].i, v[3].i, ba);
+    xstage<XB>(v[0].r, v[2].r, bb);
+    xstage<XB>(v[0].i, v[2].i, bb);
+    xstage<XB>(v[1].r, v[3].r, bb);
+    xstage<XB>(v[1].i, v[3].i, bb);
+}
+
+// in: v[m] = point fft64_src_point(gl, m) of both transforms; out: v[m] = point gl + 16 m
+template <bool INVERSE>
+__device__ __forceinline__ void fft64_regs_x2(Cx2 v[4], const FftTables *T, int gl) {
+    bfly4_x2(gl, T, v);
+    transpose4_x2<1, 2>(v, gl);
+    bfly4_x2(gl >> 2, T, v);
+    transpose4_x2<4, 8>(v, gl);
+    bfly4_close_x2<INVERSE>(v);
+}
+
+// rdft128_inv_point for the same point p of two packed spectrum rows a0 / a1 (transform 0 / 1)
+__device__ __forceinline__ Cx2 rdft128_inv_point_x2(const float *a0, const float *a1, const FftTables *T, int p) {
+    const int q = p < 32 ? p : 64 - p;
+    const int j = 2 * q, k = 128 - j;
+    const v2f wkr = bc(0.5f - T->c[32 - q]), wki = bc(T->c[q]);
+    const v2f aj = v2f{a0[j], a1[j]}, aj1 = v2f{a0[j + 1], a1[j + 1]}, ak = v2f{a0[k], a1[k]}, ak1 = v2f{a0[k + 1], a1[k + 1]};
+    const v2f xr = aj - ak, xi = aj1 + ak1;
+    const v2f yr = wkr * xr + wki * xi, yi = wkr * xi - wki * xr;
+    v2f re = p < 32 ? aj - yr : ak + yr;
+    v2f im = p < 32 ? yi - aj1 : yi - ak1;
+    const v2f h = bc(0.5f) * (aj - aj1);  // p == 0: aj = a[0], aj1 = a[1]
+    re = p == 0 ? aj - h : (p == 32 ? aj : re);
+    im = p == 0 ? -h : (p == 32 ? -aj1 : im);
+    return Cx2{re, im};
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // The same transform with ONE point per lane (lane l holds point l before and after every pass) for the places
 // where a single transform is on the critical path and the 16-lane form would leave three quarters of the wave
 // idle.  Each lane fetches the four inputs of its butterfly with ds_bpermute (LDS crossbar, no VALU, no memory) and
