@@ -16,14 +16,16 @@
 //   aec_far_kernel   one wave per batch: far-end pre-buffer, the plain and sqrt-Hanning-windowed
 //                    spectra of every new 64-sample far block (2 rdft128 each), the history of
 //                    CONSUMED far spectra and the far power xPow -- all shared by every stream.
-//   aec_near_kernel  one wave per stream: ProcessBlock + NonLinearProcessing.  The stream's whole
-//                    11 KB state block (12x65 complex filter taps, PSDs, rings) is pulled into LDS
-//                    with one contiguous read, all blocks of all packets of the launch run on it,
-//                    and it is written back once: HBM traffic = the algorithmic minimum.
-//                    Lane k owns frequency bin k (lane 0 also bin 64); the 24 constraint FFTs of
-//                    the filter update run four partitions at a time, 16 lanes per transform.
-// Float expressions, their order and the ordered sums follow the reference exactly
-// (-ffp-contract=off); powf/log are evaluated in double and rounded; cosf/sinf of the comfort
+//   aec_near_kernel  one wave per stream, eight streams per workgroup: ProcessBlock + NonLinearProcessing.  The
+//                    12 x 64-bin filter taps live in registers (lane k = bin k; the Nyquist column in LDS) and go
+//                    straight from / to their 256-byte HBM rows; the other 4.7 KB of state (PSDs, tails, rings,
+//                    scalars) are pulled into LDS with one contiguous read; all blocks of all packets of the launch
+//                    run on that, and everything is written back once: HBM traffic = the algorithmic minimum.
+//                    The transforms run in registers (fft_regs.h): the 24 constraint FFTs of the filter update as
+//                    16-lane groups (partitions 0-7 as packed pairs, then 8-11), the two single inverse transforms
+//                    of a block with one point per lane, the two forward pairs in two 16-lane groups.
+// Float expressions, their order and the ordered sums follow the reference exactly (-ffp-contract=off); powf is the
+// table-driven double-precision evaluation of libm_dev.h, the rare log the library routine; cosf/sinf of the comfort
 // noise come from the host's libm through the plan.
 #include <cmath>
 #include <cstddef>
@@ -376,7 +378,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
         scale_err(lane, efr, efi);
         if (lane == 0) scale_err(kAecPart, ef64r, ef64i);
     }
-    wave_sync();  // rows 2, 3 are read; the filter update overwrites all twelve
+    wave_sync();  // rows 2, 3 are read; the filter update overwrites the work rows
     AEC_RELANE();
     // ---- FilterAdaptation (aec_core.c:222-270): conj(X_{n-p}) * ef -> time domain, zero the second half,
     //      back to frequency, add to partition p.  Four groups of 16 lanes; partitions 0..7 first (two per group),
