@@ -9,9 +9,11 @@
 // Mapping.  A stream's spectrum has 65 (8 kHz) or 129 (16/32 kHz) bins; lane k of the
 // wave owns bins k, k+64 (and lane 0 bin 128).  Per-bin state is read from / written to
 // HBM exactly once per frame with 256-byte coalesced accesses; the FFT work array, the frame's
-// per-bin intermediates and the reduction staging live in LDS (8.4 KB per wave), the FFT tables and
-// window once per 4-wave workgroup.  Every phase is a short rolled loop over the lane's 2-3 bins, so
-// the kernel fits 128 VGPRs and runs 4 waves per SIMD (occupancy, not bandwidth, is what bounds it).
+// per-bin intermediates and the reduction staging live in LDS (8.4 KB per wave), the FFT tables,
+// window and libm tables once per 4-wave workgroup.  The kernel fits 128 VGPRs and runs 4 waves per
+// SIMD; the per-bin state a frame needs is requested from HBM at the start of the frame and consumed
+// phases later (its loops were latency bound before that), the independent ordered sums of a phase
+// advance as parallel lane chains, and what is left is VALU issue.
 // All per-stream scalars and control flow (start-up phases, zero-energy early-out,
 // histogram windows) are wave-uniform, so streams in different states never diverge
 // inside a wave.
@@ -24,7 +26,8 @@
 // state here.
 //
 // Numerics.  Same float expressions as the reference, -ffp-contract=off, the reference's
-// double-precision libm calls (log/exp/tanh/pow/sqrt) evaluated in double.  Sums over
+// double-precision libm calls evaluated in double (log / exp by the table-driven routines of
+// libm_dev.h, same floats as glibc's over every argument class swept; tanh / pow by ocml).  Sums over
 // bins/samples are where a parallel machine wants a different order: with ORDERED=true the
 // kernel adds in the reference's index order (bit-exact against the CPU path); with
 // ORDERED=false each lane adds its own elements and the wave combines them by a butterfly
