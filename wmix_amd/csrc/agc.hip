@@ -7,7 +7,10 @@
 // WebRtcSpl_Sqrt spl_sqrt.c).  Everything is a per-stream integer recurrence (ten 1 ms
 // envelope steps, a 4 kHz level detector, a per-sample gain ramp), so 64 streams share a
 // wavefront, state is field-major ([field][stream], one coalesced line per access) and the
-// 32-entry gain table -- identical for every stream of a batch -- sits in LDS.  Bit-exact.
+// 32-entry gain table -- identical for every stream of a batch -- sits in LDS.  The channel count is
+// a template parameter (1, 2; 0 = any, at run time): with a run-time `for (c < chn)` around every
+// sample access the compiler could not batch the packet's loads and the kernel ran 3x longer.
+// Bit-exact.
 //
 // WebRtcAgc_ProcessAnalog also runs in the reference (lowLevelSignal == 0) but with
 // inMicLevel = 0 it only moves analog-side bookkeeping that wmix throws away and cannot fail

@@ -7,8 +7,12 @@
 // filter), so there is nothing to parallelise inside a stream: 64 streams ride one wavefront,
 // per-stream state is laid out field-major ([field][stream]) so every state access of the wave
 // is one 128/256-byte line, and the sub-band signals of the 6-band split tree live in LDS as
-// [sample][lane] int16 (bank-conflict free).  Results are bit-exact with the reference; signed
-// overflow that the reference leaves to two's-complement wrap is spelled out.
+// [sample][lane] int16 (bank-conflict free).  At one wave per SIMD the kernel's time is the length of
+// one stream's dependency chain, so state is kept off the HBM latency path: the order-statistics
+// vectors (192 of the 263 int16 fields, walked element by element by FindMinimum) are staged in LDS for
+// the launch, and one up-front round trip pulls every other state row and the PCM lines into L2.
+// Results are bit-exact with the reference; signed overflow that the reference leaves to
+// two's-complement wrap is spelled out.
 //
 // Kept reference quirks: a call of several packets always analyses packet 0
 // and only packet 0 is attenuated; multi-channel input is mean-downmixed in place and expanded
