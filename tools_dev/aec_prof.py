@@ -4,6 +4,8 @@ import numpy as np, torch
 from wmix_amd import synth, _lib
 from wmix_amd.aec import AecBatch
 dev=torch.device('cuda:0'); S=int(sys.argv[1]) if len(sys.argv)>1 else 65536
+import os
+if os.environ.get('WMX_TOOL_LIB'): _lib.LIB_PATH=os.environ['WMX_TOOL_LIB']  # profiling build kept beside the product library
 lib=_lib.lib(); f=lib.wmx_debug_aec_prof; f.argtypes=[ctypes.c_void_p,ctypes.c_int]
 ab=AecBatch(S,1,16000,10); nf=24
 far=synth.far_end(5,nf,160); near=synth.near_end(50,64,nf,160,far=far)

@@ -817,16 +817,17 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * kAe
     AEC_PROF(11);  // includes the blocks; subtract 0..9
     // ---- state out (addresses recomputed: keeping the ones of the load alive across the packet loop costs 17 VGPRs)
     asm volatile("" : "+s"(gst));
+    const int ln = opaque_lane(lane);  // same for the lane-derived offsets (otherwise kept alive, or spilled, across the loop)
 #pragma unroll
     for (int p = 0; p < 12; p++) {
-        gst[AS_W_RE + p * BP + lane] = taps.re[p];
-        gst[AS_W_IM + p * BP + lane] = taps.im[p];
+        gst[AS_W_RE + p * BP + ln] = taps.re[p];
+        gst[AS_W_IM + p * BP + ln] = taps.im[p];
     }
-    if (lane < 12) gst[AS_W_RE + lane * BP + kAecPart] = W.wn[lane];
+    if (ln < 12) gst[AS_W_RE + ln * BP + kAecPart] = W.wn[ln];
     {
         float4 *g4 = reinterpret_cast<float4 *>(gst + AS_LDS0);
         const float4 *s4 = reinterpret_cast<const float4 *>(W.st);
-        for (int i = lane; i < AS_LDS_WORDS / 4; i += 64) g4[i] = s4[i];
+        for (int i = ln; i < AS_LDS_WORDS / 4; i += 64) g4[i] = s4[i];
     }
     AEC_PROF(12);
 #ifdef WMX_AEC_PROF

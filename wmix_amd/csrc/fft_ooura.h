@@ -47,6 +47,12 @@ inline int host_bitrev(int q, int bits) {
 inline void host_expand_twiddles(const float *w, int n, FftTables *t) {
     volatile float tmp;  // force float rounding of every product (no host FMA contraction)
     t->w2 = w[2];
+    // blocks 0 and 1 (the reference's twiddle-free / w2-only special butterflies) as table entries for the one
+    // straight-line butterfly of bfly4_v (see there): b = 0 multiplies by 1, b = 1 by i, w2 and -w2
+    t->W1[0][0] = t->W2[0][0] = t->W3[0][0] = 1.f;
+    t->W1[1][0] = w[2];
+    t->W2[1][1] = 1.f;
+    t->W3[1][0] = -w[2];
     for (int b = 2; b < n / 8; b++) {
         int k1 = 2 * (b >> 1), k2 = 2 * k1;
         float wk2r = w[k1], wk2i = w[k1 + 1], wk1r, wk1i, two;
@@ -170,28 +176,30 @@ __device__ __forceinline__ v2f sub_i(v2f a, v2f b) { return a + v2f{b.y, -b.x}; 
 // (wr*t.x - wi*t.y, wr*t.y + wi*t.x): the reference's twiddle product, two packed multiplies and one packed add
 __device__ __forceinline__ v2f cmul_w(float wr, float wi, v2f t) { return v2f{wr, wr} * t + v2f{-wi, wi} * swap(t); }
 
-// in place on v[0..3] = A, B, C, D -> o0, o1, o2, o3
+// in place on v[0..3] = A, B, C, D -> o0, o1, o2, o3.
+// The reference has three butterfly forms: twiddle-free (block 0, fft4g.c:1013-1032 / 1118-1141), the w2-only form of
+// block 1 (fft4g.c:1034-1056 / 1143-1170) and the general one.  Lanes of one wave hold butterflies of all three kinds,
+// so branching on b makes every wave execute all three; instead every lane runs the general form with table entries
+// that reproduce the special forms operand for operand:
+//   b = 0:  W1 = W2 = W3 = 1                        1*t + 0*t' == t
+//   b = 1:  o2 = i*(x0 - x2)                        W2 = i:  (0*tr - 1*ti, 0*ti + 1*tr) == (-ti, tr)
+//           o1 = w2*(tr - ti, tr + ti)              t rotated first (m = 1), then W1 = (w2, 0)
+//           o3 = w2*(-ti - tr, tr - ti)             == -w2*(tr + ti, ti - tr): rotated the other way, W3 = (-w2, 0)
+// with m = 0 outside block 1 (tr - 0*ti == tr).  Products with 0 and 1 and sign changes are exact, so each output is
+// the reference's value (a zero result may carry the other sign; nothing downstream can see that).
 __device__ __forceinline__ void bfly4_v(int b, const FftTables *T, v2f v[4]) {
     const v2f x0 = v[0] + v[1], x1 = v[0] - v[1], x2 = v[2] + v[3], x3 = v[2] - v[3];
     v[0] = x0 + x2;
-    if (b == 0) {
-        v[2] = x0 - x2;
-        v[1] = add_i(x1, x3);  // (x1r - x3i, x1i + x3r)
-        v[3] = sub_i(x1, x3);  // (x1r + x3i, x1i - x3r)
-    } else if (b == 1) {
-        const float w = T->w2;
-        v[2] = v2f{x2.y - x0.y, x0.x - x2.x};
-        v2f t = add_i(x1, x3);  // tr = x1r - x3i, ti = x1i + x3r
-        v[1] = v2f{w, w} * v2f{t.x - t.y, t.x + t.y};
-        t = v2f{x3.y + x1.x, x3.x - x1.y};
-        v[3] = v2f{w, w} * v2f{t.y - t.x, t.y + t.x};
-    } else {
-        const float w1r = T->W1[b][0], w1i = T->W1[b][1], w2r = T->W2[b][0], w2i = T->W2[b][1];
-        const float w3r = T->W3[b][0], w3i = T->W3[b][1];
-        v[2] = cmul_w(w2r, w2i, x0 - x2);
-        v[1] = cmul_w(w1r, w1i, add_i(x1, x3));
-        v[3] = cmul_w(w3r, w3i, sub_i(x1, x3));
-    }
+    const float m = b == 1 ? 1.f : 0.f;
+    const float w1r = T->W1[b][0], w1i = T->W1[b][1], w2r = T->W2[b][0], w2i = T->W2[b][1];
+    const float w3r = T->W3[b][0], w3i = T->W3[b][1];
+    v2f t1 = add_i(x1, x3);  // (x1r - x3i, x1i + x3r)
+    v2f t3 = sub_i(x1, x3);  // (x1r + x3i, x1i - x3r)
+    t1 = t1 + v2f{-m, m} * swap(t1);
+    t3 = t3 + v2f{m, -m} * swap(t3);
+    v[2] = cmul_w(w2r, w2i, x0 - x2);
+    v[1] = cmul_w(w1r, w1i, t1);
+    v[3] = cmul_w(w3r, w3i, t3);
 }
 
 __device__ __forceinline__ void bfly4(int b, const FftTables *T, Cx A, Cx B, Cx C, Cx D, float2 &o0, float2 &o1, float2 &o2,

@@ -21,36 +21,49 @@
 
 namespace wmx {
 
-template <int CTRL, int BANK_MASK = 0xf>
-__device__ __forceinline__ float dpp_mov(float old, float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, BANK_MASK, false));
-}
-
 // Swap lane bit X of the 16-lane row with one element-index bit: lanes whose bit X is clear keep `lo` and receive
-// the partner's `lo` into `hi`; lanes whose bit is set keep `hi` and receive the partner's `hi` into `lo`.
-//   X = 4, 8: row_ror with a bank mask (a DPP bank is 4 lanes, so "bit 2 / bit 3 of the lane" is a set of banks)
-//             writes only the receiving lanes -- two instructions per register pair, no selects.
-//   X = 1, 2: quad_perm fetch of the partner's value, then a select on the lane's own bit.
+// the partner's `lo` into `hi`; lanes whose bit is set keep `hi` and receive the partner's `hi` into `lo`.  The partner
+// is reached with quad_perm (X = 1, 2) or row_ror (X = 4, 8).
+// One exchange = two v_cndmask_b32_dpp: the select reads the partner's value straight through the DPP crossbar on
+// src0 (D = vcc ? src1 : dpp(src0)).  The compiler does not form this instruction from a DPP move + select (its
+// combiner cannot invert the condition to get the fetched value into src0), hence the assembly; `set` / `clr` are
+// the wave masks of the lanes whose bit X is set / clear.  s_mov + s_nop cover the two wait states a DPP read of a
+// freshly written VGPR needs (the hazard recogniser does not look inside inline assembly).
+#define WMX_XSTAGE_ASM(BELOW, ABOVE)                                                                               \
+    asm("s_mov_b64 vcc, %4\n\ts_nop 0\n\t"                                                                        \
+        "v_cndmask_b32_dpp %1, %2, %3, vcc " ABOVE " row_mask:0xf bank_mask:0xf\n\t"                               \
+        "s_mov_b64 vcc, %5\n\t"                                                                                    \
+        "v_cndmask_b32_dpp %0, %3, %2, vcc " BELOW " row_mask:0xf bank_mask:0xf"                                    \
+        : "=&v"(nlo), "=&v"(nhi)                                                                                   \
+        : "v"(lo), "v"(hi), "s"(set), "s"(clr)                                                                     \
+        : "vcc")
 template <int X>
-__device__ __forceinline__ void xstage1(float lo, float hi, bool bit, float &nlo, float &nhi) {
-    if constexpr (X == 4) {
-        nlo = dpp_mov<0x124, 0xA>(lo, hi);  // row_ror:4  -> lanes 4-7, 12-15 take hi of lane - 4
-        nhi = dpp_mov<0x12C, 0x5>(hi, lo);  // row_ror:12 -> lanes 0-3, 8-11 take lo of lane + 4
-    } else if constexpr (X == 8) {
-        nlo = dpp_mov<0x128, 0xC>(lo, hi);  // row_ror:8 -> lanes 8-15 take hi of lane - 8
-        nhi = dpp_mov<0x128, 0x3>(hi, lo);  //           -> lanes 0-7 take lo of lane + 8
-    } else {
-        constexpr int QP = X == 1 ? 0xB1 : 0x4E;  // quad_perm:[1,0,3,2] / [2,3,0,1]
-        const float phi = dpp_mov<QP>(hi, hi), plo = dpp_mov<QP>(lo, lo);
-        nlo = bit ? phi : lo;
-        nhi = bit ? hi : plo;
-    }
+__device__ __forceinline__ void xstage1(float lo, float hi, unsigned long long set, unsigned long long clr, float &nlo, float &nhi) {
+    // nhi = bit ? hi : partner's lo (the partner sits X lanes above);  nlo = bit ? partner's hi (X lanes below) : lo
+    if constexpr (X == 1)
+        WMX_XSTAGE_ASM("quad_perm:[1,0,3,2]", "quad_perm:[1,0,3,2]");
+    else if constexpr (X == 2)
+        WMX_XSTAGE_ASM("quad_perm:[2,3,0,1]", "quad_perm:[2,3,0,1]");
+    else if constexpr (X == 4)
+        WMX_XSTAGE_ASM("row_ror:4", "row_ror:12");  // row_ror:n -- lane i reads lane i - n of its 16-lane row
+    else
+        WMX_XSTAGE_ASM("row_ror:8", "row_ror:8");
+}
+#undef WMX_XSTAGE_ASM
+struct XMask {
+    unsigned long long set, clr;
+};
+__device__ __forceinline__ XMask xmask(int gl, int x) {
+    XMask m;
+    m.set = __builtin_amdgcn_ballot_w64((gl & x) != 0);
+    m.clr = __builtin_amdgcn_ballot_w64((gl & x) == 0);
+    return m;
 }
 template <int X>
-__device__ __forceinline__ void xstage(v2f &lo, v2f &hi, bool bit) {
+__device__ __forceinline__ void xstage(v2f &lo, v2f &hi, XMask bit) {
     float lx, hx, ly, hy;
-    xstage1<X>(lo.x, hi.x, bit, lx, hx);
-    xstage1<X>(lo.y, hi.y, bit, ly, hy);
+    xstage1<X>(lo.x, hi.x, bit.set, bit.clr, lx, hx);
+    xstage1<X>(lo.y, hi.y, bit.set, bit.clr, ly, hy);
     lo = v2f{lx, ly};
     hi = v2f{hx, hy};
 }
@@ -58,7 +71,7 @@ __device__ __forceinline__ void xstage(v2f &lo, v2f &hi, bool bit) {
 // 4x4 transpose between the lane bits (XA, XB) and the element index of v[0..3]
 template <int XA, int XB>
 __device__ __forceinline__ void transpose4(v2f v[4], int gl) {
-    const bool ba = (gl & XA) != 0, bb = (gl & XB) != 0;
+    const XMask ba = xmask(gl, XA), bb = xmask(gl, XB);
     xstage<XA>(v[0], v[1], ba);
     xstage<XA>(v[2], v[3], ba);
     xstage<XB>(v[0], v[2], bb);
@@ -138,43 +151,35 @@ struct Cx2 {
 __device__ __forceinline__ v2f bc(float x) { return v2f{x, x}; }
 
 __device__ __forceinline__ void bfly4_x2(int b, const FftTables *T, Cx2 v[4]) {
+    // the straight-line butterfly of bfly4_v (fft_ooura.h), element-wise on the two packed transforms
     const v2f x0r = v[0].r + v[1].r, x0i = v[0].i + v[1].i, x1r = v[0].r - v[1].r, x1i = v[0].i - v[1].i;
     const v2f x2r = v[2].r + v[3].r, x2i = v[2].i + v[3].i, x3r = v[2].r - v[3].r, x3i = v[2].i - v[3].i;
     v[0].r = x0r + x2r;
     v[0].i = x0i + x2i;
-    if (b == 0) {
-        v[2].r = x0r - x2r;
-        v[2].i = x0i - x2i;
-        v[1].r = x1r - x3i;
-        v[1].i = x1i + x3r;
-        v[3].r = x1r + x3i;
-        v[3].i = x1i - x3r;
-    } else if (b == 1) {
-        const v2f w = bc(T->w2);
-        v[2].r = x2i - x0i;
-        v[2].i = x0r - x2r;
-        v2f tr = x1r - x3i, ti = x1i + x3r;
-        v[1].r = w * (tr - ti);
-        v[1].i = w * (tr + ti);
-        tr = x3i + x1r;
-        ti = x3r - x1i;
-        v[3].r = w * (ti - tr);
-        v[3].i = w * (ti + tr);
-    } else {
-        const v2f w1r = bc(T->W1[b][0]), w1i = bc(T->W1[b][1]), w2r = bc(T->W2[b][0]), w2i = bc(T->W2[b][1]);
-        const v2f w3r = bc(T->W3[b][0]), w3i = bc(T->W3[b][1]);
-        v2f tr = x0r - x2r, ti = x0i - x2i;
-        v[2].r = w2r * tr - w2i * ti;
-        v[2].i = w2r * ti + w2i * tr;
-        tr = x1r - x3i;
-        ti = x1i + x3r;
-        v[1].r = w1r * tr - w1i * ti;
-        v[1].i = w1r * ti + w1i * tr;
-        tr = x1r + x3i;
-        ti = x1i - x3r;
-        v[3].r = w3r * tr - w3i * ti;
-        v[3].i = w3r * ti + w3i * tr;
+    const v2f m = bc(b == 1 ? 1.f : 0.f);
+    const v2f w1r = bc(T->W1[b][0]), w1i = bc(T->W1[b][1]), w2r = bc(T->W2[b][0]), w2i = bc(T->W2[b][1]);
+    const v2f w3r = bc(T->W3[b][0]), w3i = bc(T->W3[b][1]);
+    v2f tr = x0r - x2r, ti = x0i - x2i;
+    v[2].r = w2r * tr - w2i * ti;
+    v[2].i = w2r * ti + w2i * tr;
+    tr = x1r - x3i;
+    ti = x1i + x3r;
+    {
+        const v2f a = tr - m * ti, c = ti + m * tr;
+        tr = a;
+        ti = c;
     }
+    v[1].r = w1r * tr - w1i * ti;
+    v[1].i = w1r * ti + w1i * tr;
+    tr = x1r + x3i;
+    ti = x1i - x3r;
+    {
+        const v2f a = tr + m * ti, c = ti - m * tr;
+        tr = a;
+        ti = c;
+    }
+    v[3].r = w3r * tr - w3i * ti;
+    v[3].i = w3r * ti + w3i * tr;
 }
 
 template <bool INVERSE>
@@ -198,7 +203,7 @@ __device__ __forceinline__ void bfly4_close_x2(Cx2 v[4]) {
 
 template <int XA, int XB>
 __device__ __forceinline__ void transpose4_x2(Cx2 v[4], int gl) {
-    const bool ba = (gl & XA) != 0, bb = (gl & XB) != 0;
+    const XMask ba = xmask(gl, XA), bb = xmask(gl, XB);
     xstage<XA>(v[0].r, v[1].r, ba);
     xstage<XA>(v[0].i, v[1].i, ba);
     xstage<XA>(v[2].r, v[3].r, ba);
@@ -266,16 +271,13 @@ __device__ __forceinline__ v2f bfly4_lane(int j, int b, const FftTables *T, v2f 
         r = (j & 1) ? v2f{-xb.y, -xb.x} : v2f{xb.x, -xb.y};
     else
         r = (j & 1) ? v2f{-xb.y, xb.x} : xb;
-    const v2f t = v2f{fmaf(s2, r.x, xa.x), fmaf(s2, r.y, xa.y)};
+    v2f t = v2f{fmaf(s2, r.x, xa.x), fmaf(s2, r.y, xa.y)};
     if constexpr (KIND != 0) return t;
-    if (b == 0 || j == 0) return t;
-    if (b == 1) {
-        const float w = T->w2;
-        if (j == 2) return v2f{-t.y, t.x};
-        if (j == 1) return v2f{w, w} * v2f{t.x - t.y, t.x + t.y};
-        return v2f{w, w} * v2f{-t.y - t.x, -t.y + t.x};
-    }
-    const float *wp = j == 1 ? T->W1[b] : (j == 2 ? T->W2[b] : T->W3[b]);
+    // twiddle of output j in block b: W_0 = 1; blocks 0 and 1 come out of the table like any other (bfly4_v,
+    // fft_ooura.h), block 1 with its outputs 1 and 3 rotated first
+    const float ms = (b == 1 && (j & 1)) ? (j == 1 ? 1.f : -1.f) : 0.f;
+    t = t + v2f{-ms, ms} * swap(t);
+    const float *wp = j == 1 ? T->W1[b] : (j == 2 ? T->W2[b] : (j == 3 ? T->W3[b] : T->W1[0]));
     return cmul_w(wp[0], wp[1], t);
 }
 
