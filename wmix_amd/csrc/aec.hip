@@ -199,6 +199,7 @@ struct alignas(16) AecWaveLds {
                              // registers); [16..27] partition energies of PartitionDelay
     float fa[8][FAS];        // work rows: spectra handed to / from the register FFTs; rows 1..7 double as NLP scratch
     float cur[64], enew[64];
+    float park[kAecFrame];   // second sub-frame of the launch's first packet, prefetched (the first one parks in fa[])
 #ifdef WMX_AEC_PROF
     unsigned long long prof[16];
 #endif
@@ -229,14 +230,6 @@ __device__ __forceinline__ void aec_fft_fwd(float *row, const FftTables *T, int 
     fft64_regs<false>(v, T, gl);
 #pragma unroll
     for (int m = 0; m < 4; m++) *reinterpret_cast<float2 *>(row + 2 * (gl + 16 * m)) = make_float2(v[m].r, v[m].i);
-}
-
-// Inverse transform of the packed spectrum in `row`; v[m] = time-domain samples 2p, 2p+1 with p = gl + 16 m
-// (unnormalised, like aec_rdft_inverse_128).
-__device__ __forceinline__ void aec_fft_inv(const float *row, const FftTables *T, int gl, Cx v[4]) {
-#pragma unroll
-    for (int m = 0; m < 4; m++) v[m] = rdft128_inv_point(row, T, fft64_src_point(gl, m));
-    fft64_regs<true>(v, T, gl);
 }
 
 template <int MULT>  // 1: 8 kHz, 2: 16 kHz
@@ -287,11 +280,14 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
     AEC_PROF(0);
     AEC_RELANE();
     // windowed near spectrum, kept in registers across the filter update (bin = lane; lane 0 also bin 64)
-    float dwr, dwi, dw64;
-    rdft128_fwd_bin_lane(W.fa[1], &K.tab, lane, dwr, dwi, dw64);
+    float dwr, dwi, dw64, dfr, dfi, df64;
+    {
+        const SplitLane cf = rdft128_fwd_coef(&K.tab, lane);
+        const v2f dwb = rdft128_fwd_bin_u(W.fa[1], cf, lane), dfb = rdft128_fwd_bin_u(W.fa[0], cf, lane);
+        dwr = dwb.x, dwi = dwb.y, dw64 = W.fa[1][0] - W.fa[1][1];  // bin 64 = a[0] - a[1] (used by lane 0)
+        dfr = dfb.x, dfi = dfb.y, df64 = W.fa[0][0] - W.fa[0][1];
+    }
     // ---- near power, noise floor (aec_core.c:1197-1243)
-    float dfr, dfi, df64;
-    rdft128_fwd_bin_lane(W.fa[0], &K.tab, lane, dfr, dfi, df64);
     for (int b = lane; b < kAecPart1; b += 64) {
         const float re = b == kAecPart ? df64 : dfr, im = b == kAecPart ? 0.f : dfi;
         const float ns = re * re + im * im;
@@ -356,12 +352,16 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
     wave_sync();
     AEC_PROF(2);
     AEC_RELANE();
-    float ewr, ewi, ew64;
-    rdft128_fwd_bin_lane(W.fa[3], &K.tab, lane, ewr, ewi, ew64);
-    // ---- ScaleErrorSignal (aec_core.c:172-194); ef stays in registers (bin = lane; lane 0 also bin 64)
-    float efr, efi, ef64r = 0.f, ef64i = 0.f;
+    // ---- ScaleErrorSignal (aec_core.c:172-194); ef stays in registers (bin = lane; lane 0 also bin 64), and so
+    //      does the windowed error spectrum
+    float ewr, ewi, ew64, efr, efi, ef64r, ef64i = 0.f;
     {
-        rdft128_fwd_bin_lane(W.fa[2], &K.tab, lane, efr, efi, ef64r);
+        {
+            const SplitLane cf = rdft128_fwd_coef(&K.tab, lane);
+            const v2f ewb = rdft128_fwd_bin_u(W.fa[3], cf, lane), efb = rdft128_fwd_bin_u(W.fa[2], cf, lane);
+            ewr = ewb.x, ewi = ewb.y, ew64 = W.fa[3][0] - W.fa[3][1];
+            efr = efb.x, efi = efb.y, ef64r = W.fa[2][0] - W.fa[2][1];
+        }
         auto scale_err = [&](int b, float &er, float &ei) {
             const float xp = F.xpow_seq[(n % kAecHist) * BP + b];
             er /= (xp + 1e-10f);
@@ -383,6 +383,8 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
     // ---- FilterAdaptation (aec_core.c:222-270): conj(X_{n-p}) * ef -> time domain, zero the second half,
     //      back to frequency, add to partition p.  Four groups of 16 lanes; partitions 0..7 first (two per group),
     //      then 8..11, through the same eight work rows.
+    const float e64r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ef64r), 0));
+    const float e64i = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ef64i), 0));
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
         const int base = 8 * pass, cnt = pass == 0 ? 8 : 4;
@@ -392,11 +394,15 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
             const int p = base + q;
             const float *X = F.hist + (size_t)((n - p + kAecHist) % kAecHist) * 130;
             const float xr = X[lane], xi = -X[kAecPart1 + lane];
-            // fft[1] is overwritten with the Nyquist product (aec_core.c:245-248): lane 0 only, selected not branched
+            st_pt(W.fa[q], lane, v2f{xr * efr - xi * efi, xr * efi + xi * efr});
+        }
+        wave_sync();
+        // fft[1] is overwritten with the Nyquist product (aec_core.c:245-248): lane j patches partition base + j
+        // (LDS runs a wave's accesses in order, so this lands after lane 0's store above)
+        if (lane < cnt) {
+            const float *X = F.hist + (size_t)((n - (base + lane) + kAecHist) % kAecHist) * 130;
             const float nr = X[kAecPart], ni = -X[kAecPart1 + kAecPart];
-            const float v1 = lane == 0 ? nr * ef64r - ni * ef64i : xr * efi + xi * efr;
-            W.fa[q][2 * lane] = xr * efr - xi * efi;
-            W.fa[q][2 * lane + 1] = v1;
+            W.fa[lane][1] = nr * e64r - ni * e64i;
         }
         wave_sync();
         AEC_RELANE();
@@ -406,7 +412,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
             float *row0 = W.fa[g], *row1 = W.fa[4 + g];
             Cx2 v[4];
 #pragma unroll
-            for (int m = 0; m < 4; m++) v[m] = rdft128_inv_point_x2(row0, row1, &K.tab, fft64_src_point(gl, m));
+            for (int m = 0; m < 4; m++) v[m] = rdft128_inv_point_x2(row0, row1, &K.tab, gl, m);
             fft64_regs_x2<true>(v, &K.tab, gl);
             // points 0..31 (m = 0, 1) scaled, points 32..63 zeroed; the forward gather wants points
             // rev4(gl) + {0, 32, 16, 48}: two of them from lane rev4(gl), two zeros
@@ -426,7 +432,12 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
             // partitions 8 + g: one transform per group
             float *row = W.fa[g];
             Cx v[4];
-            aec_fft_inv(row, &K.tab, gl, v);
+            {
+                const v2f p0 = rdft128_inv_point_m<0>(row, &K.tab, gl), p1 = rdft128_inv_point_m<1>(row, &K.tab, gl);
+                const v2f p2 = rdft128_inv_point_m<2>(row, &K.tab, gl), p3 = rdft128_inv_point_m<3>(row, &K.tab, gl);
+                v[0] = Cx{p0.x, p0.y}, v[1] = Cx{p1.x, p1.y}, v[2] = Cx{p2.x, p2.y}, v[3] = Cx{p3.x, p3.y};
+                fft64_regs<true>(v, &K.tab, gl);
+            }
             const Cx a = Cx{row_bitrev(v[0].r * scale, lane), row_bitrev(v[0].i * scale, lane)};
             const Cx c = Cx{row_bitrev(v[1].r * scale, lane), row_bitrev(v[1].i * scale, lane)};
             v[0] = a;
@@ -439,15 +450,16 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
         }
         wave_sync();
         AEC_RELANE();
+        {
+            const SplitLane cf = rdft128_fwd_coef(&K.tab, lane);
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            if (q >= cnt) continue;
-            const int p = base + q;
-            float re, im, nyq;
-            rdft128_fwd_bin_lane(W.fa[q], &K.tab, lane, re, im, nyq);
-            taps.re[p] += re;
-            taps.im[p] += im;  // lane 0: im == 0 (wfBuf[1][pos] is never touched, aec_core.c:262-268)
-            if (lane == 0) W.wn[p] += nyq;
+            for (int q = 0; q < 8; q++) {
+                if (q >= cnt) continue;
+                const v2f d = rdft128_fwd_bin_u(W.fa[q], cf, lane);
+                taps.re[base + q] += d.x;
+                taps.im[base + q] += d.y;  // lane 0 adds 0 (wfBuf[1][pos] is never touched, aec_core.c:262-268)
+            }
+            if (lane < cnt) W.wn[base + lane] += W.fa[lane][0] - W.fa[lane][1];  // wfBuf[0][pos + 64] += fft[1]: bin 64 = a[0] - a[1]
         }
         wave_sync();
     }
@@ -779,6 +791,16 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * kAe
         float4 *s4 = reinterpret_cast<float4 *>(W.st);
         for (int i = lane; i < AS_LDS_WORDS / 4; i += 64) s4[i] = g4[i];
     }
+    // the prefetched packet leaves the registers (it would stay live, or spilled, across the whole packet loop): the
+    // first sub-frame waits in the still unused work rows, the second in its own row
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int i = lane + 64 * h;
+        if (i < kAecFrame) {
+            W.fa[0][i] = (float)pcm0[0][h];
+            W.park[i] = (float)pcm0[1][h];
+        }
+    }
     wave_sync();
     AEC_PROF(10);
     for (int p = 0; p < n_packets; p++) {
@@ -797,16 +819,17 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * kAe
         }
         for (int s = 0; s < pl.n_sub; s++) {
             const AecSubPlan &sp = pl.sub[s];
+            const int ln = opaque_lane(lane);  // PCM offsets rebuilt per sub-frame, not carried (or spilled) across the blocks
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const int i = lane + 64 * h;
+                const int i = ln + 64 * h;
                 if (i >= kAecFrame) continue;
-                const int16_t v = (p == 0 && s < 2) ? (s == 0 ? pcm0[0][h] : pcm0[1][h]) : in[(s * kAecFrame + i) * chn];
-                AEC_ST(AS_NEAR_RING + (sp.near_wr + i) % kAecRing) = (float)v;
+                const float v = (p == 0 && s < 2) ? (s == 0 ? W.fa[0][i] : W.park[i]) : (float)in[(s * kAecFrame + i) * chn];
+                AEC_ST(AS_NEAR_RING + (sp.near_wr + i) % kAecRing) = v;
             }
             wave_sync();
             for (int k = 0; k < sp.n_blocks; k++) aec_block<MULT>(K, powtab, W, taps, F, pl.blk[sp.first_blk + k], lane);
-            for (int i = lane; i < kAecFrame; i += 64) {
+            for (int i = opaque_lane(lane); i < kAecFrame; i += 64) {
                 const int16_t v = (int16_t)AEC_ST(AS_OUT_RING + (sp.out_rd + i) % kAecRing);
                 for (int c = 0; c < chn; c++) out[(s * kAecFrame + i) * chn + c] = v;
             }

@@ -15,7 +15,7 @@
 // so a transform costs no LDS round trip between passes; four transforms run side by side in a wave, and a
 // lane can carry several (the callers unroll over REP).  The real-data pre/post processing (rftbsub before
 // the inverse passes, rftfsub after the forward ones) is folded into the gather of the consumer:
-// rdft128_inv_point() and rdft128_fwd_bin() evaluate one point / one bin from the packed LDS row.
+// rdft128_inv_point_m() and rdft128_fwd_bin_u() evaluate one point / one bin from the packed LDS row.
 #pragma once
 #include "fft_ooura.h"
 
@@ -99,44 +99,6 @@ __device__ __forceinline__ void fft64_regs(Cx c[4], const FftTables *T, int gl) 
     fft64_regs<INVERSE>(v, T, gl);
 #pragma unroll
     for (int m = 0; m < 4; m++) c[m] = Cx{v[m].x, v[m].y};
-}
-
-// Input side of rdft(128, -1, a): point p (0..63) of the complex array the inverse passes start from, computed
-// from the packed spectrum row a[128] (a[1] fix-up fft4g.c:349-351, rftbsub fft4g.c:1260-1284 incl. its sign
-// flips).
-__device__ __forceinline__ Cx rdft128_inv_point(const float *a, const FftTables *T, int p) {
-    // one straight-line path for every point: the general pair formula is evaluated with q clamped into the
-    // table (p = 0 reads a[128..129], inside the 132-float row, and discards the result), then the two special
-    // points are selected in.  No divergent branches inside a wave.
-    const int q = p < 32 ? p : 64 - p;
-    const int j = 2 * q, k = 128 - j;
-    const float wkr = 0.5f - T->c[32 - q], wki = T->c[q];
-    const float aj = a[j], aj1 = a[j + 1], ak = a[k], ak1 = a[k + 1];
-    const float xr = aj - ak, xi = aj1 + ak1;
-    const float yr = wkr * xr + wki * xi, yi = wkr * xi - wki * xr;
-    float re = p < 32 ? aj - yr : ak + yr;
-    float im = p < 32 ? yi - aj1 : yi - ak1;
-    const float h = 0.5f * (aj - aj1);  // p == 0: aj = a[0], aj1 = a[1]
-    re = p == 0 ? aj - h : (p == 32 ? aj : re);
-    im = p == 0 ? -h : (p == 32 ? -aj1 : im);
-    return Cx{re, im};
-}
-
-// Output side of rdft(128, +1, a): bin == lane (0..63) of the spectrum, from the row holding the result of the forward
-// complex passes (rftfsub fft4g.c:1234-1257 + the a[0]/a[1] fix-up fft4g.c:340-342), StoreAsComplex convention (bin 0
-// real).  Straight-line for all lanes; `nyq` is bin 64 (real), valid in lane 0 only.
-__device__ __forceinline__ void rdft128_fwd_bin_lane(const float *a, const FftTables *T, int lane, float &re, float &im, float &nyq) {
-    const int q = lane < 32 ? lane : 64 - lane;  // lane 0: q = 0 (reads a[128..129], discarded); lane 32: j == k == 64
-    const int j = 2 * q, k = 128 - j;
-    const float wkr = 0.5f - T->c[32 - q], wki = T->c[q];
-    const float aj = a[j], aj1 = a[j + 1], ak = a[k], ak1 = a[k + 1];
-    const float xr = aj - ak, xi = aj1 + ak1;
-    const float yr = wkr * xr - wki * xi, yi = wkr * xi + wki * xr;
-    const float gre = lane < 32 ? aj - yr : ak + yr;
-    const float gim = lane < 32 ? aj1 - yi : ak1 - yi;
-    re = lane == 0 ? aj + aj1 : (lane == 32 ? aj : gre);
-    im = lane == 0 ? 0.f : (lane == 32 ? aj1 : gim);
-    nyq = aj - aj1;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -224,20 +186,75 @@ __device__ __forceinline__ void fft64_regs_x2(Cx2 v[4], const FftTables *T, int 
     bfly4_close_x2<INVERSE>(v);
 }
 
-// rdft128_inv_point for the same point p of two packed spectrum rows a0 / a1 (transform 0 / 1)
-__device__ __forceinline__ Cx2 rdft128_inv_point_x2(const float *a0, const float *a1, const FftTables *T, int p) {
-    const int q = p < 32 ? p : 64 - p;
-    const int j = 2 * q, k = 128 - j;
-    const v2f wkr = bc(0.5f - T->c[32 - q]), wki = bc(T->c[q]);
-    const v2f aj = v2f{a0[j], a1[j]}, aj1 = v2f{a0[j + 1], a1[j + 1]}, ak = v2f{a0[k], a1[k]}, ak1 = v2f{a0[k + 1], a1[k + 1]};
-    const v2f xr = aj - ak, xi = aj1 + ak1;
-    const v2f yr = wkr * xr + wki * xi, yi = wkr * xi - wki * xr;
-    v2f re = p < 32 ? aj - yr : ak + yr;
-    v2f im = p < 32 ? yi - aj1 : yi - ak1;
-    const v2f h = bc(0.5f) * (aj - aj1);  // p == 0: aj = a[0], aj1 = a[1]
-    re = p == 0 ? aj - h : (p == 32 ? aj : re);
-    im = p == 0 ? -h : (p == 32 ? -aj1 : im);
-    return Cx2{re, im};
+// ---------------------------------------------------------------------------------------------------------------
+// Real-split pre/post processing without selects.
+__device__ __forceinline__ v2f ld_pt(const float *row, int p) {
+    const float2 v = *reinterpret_cast<const float2 *>(row + 2 * p);
+    return v2f{v.x, v.y};
+}
+__device__ __forceinline__ void st_pt(float *row, int p, v2f c) { *reinterpret_cast<float2 *>(row + 2 * p) = make_float2(c.x, c.y); }
+
+// rdft128_inv_point without selects: point p = rev4(b) + {0, 32, 16, 48}[M] of the complex array the inverse passes
+// start from.  With own = point p, other = point 64 - p of the packed spectrum, xr = own.r - other.r and
+// xi = own.i + other.i, the reference's two cases (p < 32: own is a[j]; p > 32: own is a[k], fft4g.c:1260-1284) are
+//     re = own.r - (wkr*xr +- wki*xi),    im = (wkr*xi -+ wki*xr) - own.i          (upper signs: p < 32)
+// -- for p > 32 the reference forms xr with the other sign and adds; negating a product or a difference is exact, so
+// these are the same floats.  M fixes the case at compile time (M odd <=> p >= 32); p == 32 (own == other) runs with
+// zero coefficients, p == 0 (the a[1] fix-up, fft4g.c:349-351) is selected in.
+template <int M>
+__device__ __forceinline__ v2f rdft128_inv_point_m(const float *a, const FftTables *T, int b) {
+    constexpr int OFF = M == 0 ? 0 : (M == 1 ? 32 : (M == 2 ? 16 : 48));
+    const int p = dev_bitrev(b, 4) + OFF;
+    const v2f own = ld_pt(a, p), other = ld_pt(a, (64 - p) & 63);
+    const int q = (M & 1) ? 64 - p : p;
+    float wr = 0.5f - T->c[32 - q], wi = T->c[q];
+    if constexpr (M == 1) {
+        wr = b == 0 ? 0.f : wr;  // p == 32: re = a[64], im = -a[65]
+        wi = b == 0 ? 0.f : wi;
+    }
+    const v2f x = own + v2f{-other.x, other.y};
+    const v2f y = (M & 1) ? cmul_w(wr, wi, x) : cmul_w(wr, -wi, x);  // (wr*xr -+ wi*xi, wr*xi +- wi*xr)
+    v2f out = v2f{-y.x, y.y} + v2f{own.x, -own.y};
+    if constexpr (M == 0) {
+        const float h = 0.5f * (own.x - own.y);
+        out = b == 0 ? v2f{own.x - h, -h} : out;
+    }
+    return out;
+}
+
+// the same point of two rows, as a packed pair for fft64_regs_x2
+__device__ __forceinline__ Cx2 rdft128_inv_point_x2(const float *a0, const float *a1, const FftTables *T, int b, int m) {
+    v2f u, w;
+    switch (m) {  // m is a compile-time constant at every call site (unrolled loops)
+        case 0: u = rdft128_inv_point_m<0>(a0, T, b), w = rdft128_inv_point_m<0>(a1, T, b); break;
+        case 1: u = rdft128_inv_point_m<1>(a0, T, b), w = rdft128_inv_point_m<1>(a1, T, b); break;
+        case 2: u = rdft128_inv_point_m<2>(a0, T, b), w = rdft128_inv_point_m<2>(a1, T, b); break;
+        default: u = rdft128_inv_point_m<3>(a0, T, b), w = rdft128_inv_point_m<3>(a1, T, b); break;
+    }
+    return Cx2{v2f{u.x, w.x}, v2f{u.y, w.y}};
+}
+
+// Output side without selects (rftfsub + the a[0]/a[1] fix-up, fft4g.c:340-342,1234-1257): bin == lane of the packed
+// row `a` holding the result of the forward complex passes.  With own = point lane, other = point 64 - lane:
+//     (re, im) = own - (wr*xr - wi*xi, wr*xi + wi*xr),    wr = wkr, wi = +-wki (- for lane > 32)
+// lane 32 runs with wr = wi = 0 (re = a[64], im = a[65]); lane 0 reads itself as `other` and runs with wr = 0,
+// wi = 0.5: re = a[0] - (0 - 0.5*(a[1] + a[1])) = a[0] + a[1], and z = 0 clears its imaginary part (bin 0 is real;
+// a zero of either sign).  Bin 64 = a[0] - a[1] is left to the caller.
+struct SplitLane {
+    float wr, wi, z;
+};
+__device__ __forceinline__ SplitLane rdft128_fwd_coef(const FftTables *T, int lane) {
+    const int q = lane < 32 ? lane : 64 - lane;
+    float wr = 0.5f - T->c[32 - q], wi = T->c[q];
+    wi = lane < 32 ? wi : -wi;
+    wr = (lane & 31) == 0 ? 0.f : wr;
+    wi = lane == 0 ? 0.5f : (lane == 32 ? 0.f : wi);
+    return SplitLane{wr, wi, lane == 0 ? 0.f : 1.f};
+}
+__device__ __forceinline__ v2f rdft128_fwd_bin_u(const float *a, SplitLane s, int lane) {
+    const v2f own = ld_pt(a, lane), other = ld_pt(a, (64 - lane) & 63);
+    const v2f x = own + v2f{-other.x, other.y};
+    return (own - cmul_w(s.wr, s.wi, x)) * v2f{1.f, s.z};
 }
 
 // ---------------------------------------------------------------------------------------------------------------
