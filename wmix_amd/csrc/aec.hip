@@ -211,6 +211,13 @@ struct AecTaps {
     float re[12], im[12];
 };
 
+// wave-uniform read of far-end data (the address must be the same in every lane): through the constant address space it
+// becomes a scalar load -- no VGPR, no vector-memory round trip.  Valid because the far kernel wrote these buffers in an
+// earlier launch.
+__device__ __forceinline__ float uniform_ld(const float *p) {
+    return *reinterpret_cast<const float __attribute__((address_space(4))) *>(reinterpret_cast<size_t>(p));
+}
+
 // out of line for the same reason as libm_dev.h's pow_d: inlined, its fp64 temporaries push the block over 128 VGPRs
 __device__ __noinline__ static float aec_powf(float x, float y, const PowTables *__restrict__ t) { return fast_pow(x, y, t); }
 
@@ -257,6 +264,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
 
     // ---- near block (aec_core.c:1177-1195).  d = [prev | cur]; its plain transform feeds the near power, its
     //      windowed transform the coherence estimates of the NLP (aec_core.c:934-949): both now, side by side.
+    const float xpow_lane = F.xpow_seq[(n % kAecHist) * BP + lane];  // far power of this block (ScaleErrorSignal), requested early
     W.cur[lane] = AEC_ST(AS_NEAR_RING + (bp.near_rd + lane) % kAecRing);
     wave_sync();
     if (g < 2) {
@@ -312,15 +320,23 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
     }
     // ---- FilterFar (aec_core.c:148-170): y = sum_p X_{n-p} * W_p, partitions in order; lane 0 also does bin 64
     {
+        // all 24 far-spectrum values of this lane requested at once (one memory round trip, not one per few partitions);
+        // the Nyquist column is wave-uniform and comes through the scalar path
+        float xr[12], xi[12];
+#pragma unroll
+        for (int p = 0; p < 12; p++) {
+            const float *X = F.hist + (size_t)((n - p + kAecHist) % kAecHist) * 130;
+            xr[p] = X[lane];
+            xi[p] = X[kAecPart1 + lane];
+        }
         float yr = 0.f, yi = 0.f, y64 = 0.f;
 #pragma unroll
         for (int p = 0; p < 12; p++) {
             const float *X = F.hist + (size_t)((n - p + kAecHist) % kAecHist) * 130;
-            const float xr = X[lane], xi = X[kAecPart1 + lane];
-            yr += xr * taps.re[p] - xi * taps.im[p];
-            yi += xr * taps.im[p] + xi * taps.re[p];
-            const float nr = X[kAecPart], ni = X[kAecPart1 + kAecPart];  // ni == 0, wfBuf[1][.][64] == 0
-            y64 += nr * W.wn[p] - ni * 0.f;                              // used by lane 0 only
+            yr += xr[p] * taps.re[p] - xi[p] * taps.im[p];
+            yi += xr[p] * taps.im[p] + xi[p] * taps.re[p];
+            const float nr = uniform_ld(X + kAecPart), ni = uniform_ld(X + kAecPart1 + kAecPart);  // ni == 0, wfBuf[1][.][64] == 0
+            y64 += nr * W.wn[p] - ni * 0.f;                                                    // used by lane 0 only
         }
         // ---- error e = d - y (aec_core.c:1286-1297): y = second half of the inverse transform of the packed spectrum
         //      (lane 0 carries (bin 0, bin 64)), one point per lane in registers: lanes 32..63 end up with y[2(l-32)], +1
@@ -362,8 +378,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
             ewr = ewb.x, ewi = ewb.y, ew64 = W.fa[3][0] - W.fa[3][1];
             efr = efb.x, efi = efb.y, ef64r = W.fa[2][0] - W.fa[2][1];
         }
-        auto scale_err = [&](int b, float &er, float &ei) {
-            const float xp = F.xpow_seq[(n % kAecHist) * BP + b];
+        auto scale_err = [&](float xp, float &er, float &ei) {
             er /= (xp + 1e-10f);
             ei /= (xp + 1e-10f);
             float abs_ef = sqrtf(er * er + ei * ei);
@@ -375,8 +390,8 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
             er *= mu;
             ei *= mu;
         };
-        scale_err(lane, efr, efi);
-        if (lane == 0) scale_err(kAecPart, ef64r, ef64i);
+        scale_err(xpow_lane, efr, efi);
+        if (lane == 0) scale_err(uniform_ld(F.xpow_seq + (n % kAecHist) * BP + kAecPart), ef64r, ef64i);
     }
     wave_sync();  // rows 2, 3 are read; the filter update overwrites the work rows
     AEC_RELANE();
@@ -388,22 +403,31 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
         const int base = 8 * pass, cnt = pass == 0 ? 8 : 4;
+        float nyq_r = 0.f, nyq_i = 0.f;  // Nyquist bin of the far block of partition base + lane (lanes < cnt)
+        if (lane < cnt) {
+            const float *X = F.hist + (size_t)((n - (base + lane) + kAecHist) % kAecHist) * 130;
+            nyq_r = X[kAecPart];
+            nyq_i = -X[kAecPart1 + kAecPart];
+        }
+        {
+            float xr[8], xi[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            if (q >= cnt) continue;
-            const int p = base + q;
-            const float *X = F.hist + (size_t)((n - p + kAecHist) % kAecHist) * 130;
-            const float xr = X[lane], xi = -X[kAecPart1 + lane];
-            st_pt(W.fa[q], lane, v2f{xr * efr - xi * efi, xr * efi + xi * efr});
+            for (int q = 0; q < 8; q++) {
+                if (q >= cnt) continue;
+                const float *X = F.hist + (size_t)((n - (base + q) + kAecHist) % kAecHist) * 130;
+                xr[q] = X[lane];
+                xi[q] = -X[kAecPart1 + lane];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (q >= cnt) continue;
+                st_pt(W.fa[q], lane, v2f{xr[q] * efr - xi[q] * efi, xr[q] * efi + xi[q] * efr});
+            }
         }
         wave_sync();
         // fft[1] is overwritten with the Nyquist product (aec_core.c:245-248): lane j patches partition base + j
         // (LDS runs a wave's accesses in order, so this lands after lane 0's store above)
-        if (lane < cnt) {
-            const float *X = F.hist + (size_t)((n - (base + lane) + kAecHist) % kAecHist) * 130;
-            const float nr = X[kAecPart], ni = -X[kAecPart1 + kAecPart];
-            W.fa[lane][1] = nr * e64r - ni * e64i;
-        }
+        if (lane < cnt) W.fa[lane][1] = nyq_r * e64r - nyq_i * e64i;
         wave_sync();
         AEC_RELANE();
         if (pass == 0) {
@@ -868,6 +892,7 @@ extern "C" int wmx_debug_aec_prof(unsigned long long *out16, int reset) {
     return 0;
 }
 #endif
+
 
 __global__ void aec_fill_state(float *state, const float *tmpl, int words, int n_streams) {
     const size_t total = (size_t)words * n_streams;

@@ -24,32 +24,42 @@ namespace wmx {
 // Swap lane bit X of the 16-lane row with one element-index bit: lanes whose bit X is clear keep `lo` and receive
 // the partner's `lo` into `hi`; lanes whose bit is set keep `hi` and receive the partner's `hi` into `lo`.  The partner
 // is reached with quad_perm (X = 1, 2) or row_ror (X = 4, 8).
-// One exchange = two v_cndmask_b32_dpp: the select reads the partner's value straight through the DPP crossbar on
-// src0 (D = vcc ? src1 : dpp(src0)).  The compiler does not form this instruction from a DPP move + select (its
-// combiner cannot invert the condition to get the fetched value into src0), hence the assembly; `set` / `clr` are
-// the wave masks of the lanes whose bit X is set / clear.  s_mov + s_nop cover the two wait states a DPP read of a
-// freshly written VGPR needs (the hazard recogniser does not look inside inline assembly).
-#define WMX_XSTAGE_ASM(BELOW, ABOVE)                                                                               \
-    asm("s_mov_b64 vcc, %4\n\ts_nop 0\n\t"                                                                        \
-        "v_cndmask_b32_dpp %1, %2, %3, vcc " ABOVE " row_mask:0xf bank_mask:0xf\n\t"                               \
-        "s_mov_b64 vcc, %5\n\t"                                                                                    \
-        "v_cndmask_b32_dpp %0, %3, %2, vcc " BELOW " row_mask:0xf bank_mask:0xf"                                    \
-        : "=&v"(nlo), "=&v"(nhi)                                                                                   \
-        : "v"(lo), "v"(hi), "s"(set), "s"(clr)                                                                     \
-        : "vcc")
+// Measured on gfx950 (tools_dev/ubench/pk_rate.hip, ns of SIMD time per wave64 instruction at 4 waves/SIMD):
+// v_mov_b32_dpp 2.0, v_cndmask_b32_e64 with an SGPR-pair mask 2.1, v_add_f32 1.3, v_pk_add_f32 2.1 -- but any
+// v_cndmask_b32 that takes its mask from VCC (the e32 form the compiler prefers, and the only form that accepts a DPP
+// operand) 9.8.  So: lane bits 2 / 3 move with row_ror under a bank mask (a DPP bank is 4 lanes, so "bit 2 / bit 3 of
+// the lane" is a set of banks; only the receiving lanes are written, no select at all), lane bits 0 / 1 with a
+// quad_perm fetch followed by an SGPR-masked select, spelled in assembly so that it cannot become the VCC form.
+template <int CTRL, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_mov(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, BANK_MASK, false));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_fetch(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// mask ? a : b with the lane mask in an SGPR pair
+__device__ __forceinline__ float sel_sgpr(unsigned long long mask, float a, float b) {
+    float d;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "s"(mask));
+    return d;
+}
 template <int X>
 __device__ __forceinline__ void xstage1(float lo, float hi, unsigned long long set, unsigned long long clr, float &nlo, float &nhi) {
     // nhi = bit ? hi : partner's lo (the partner sits X lanes above);  nlo = bit ? partner's hi (X lanes below) : lo
-    if constexpr (X == 1)
-        WMX_XSTAGE_ASM("quad_perm:[1,0,3,2]", "quad_perm:[1,0,3,2]");
-    else if constexpr (X == 2)
-        WMX_XSTAGE_ASM("quad_perm:[2,3,0,1]", "quad_perm:[2,3,0,1]");
-    else if constexpr (X == 4)
-        WMX_XSTAGE_ASM("row_ror:4", "row_ror:12");  // row_ror:n -- lane i reads lane i - n of its 16-lane row
-    else
-        WMX_XSTAGE_ASM("row_ror:8", "row_ror:8");
+    if constexpr (X == 4) {
+        nlo = dpp_mov<0x124, 0xA>(lo, hi);  // row_ror:4  -> lanes 4-7, 12-15 take hi of lane - 4
+        nhi = dpp_mov<0x12C, 0x5>(hi, lo);  // row_ror:12 -> lanes 0-3, 8-11 take lo of lane + 4
+    } else if constexpr (X == 8) {
+        nlo = dpp_mov<0x128, 0xC>(lo, hi);  // row_ror:8 -> lanes 8-15 take hi of lane - 8
+        nhi = dpp_mov<0x128, 0x3>(hi, lo);  //           -> lanes 0-7 take lo of lane + 8
+    } else {
+        constexpr int QP = X == 1 ? 0xB1 : 0x4E;  // quad_perm:[1,0,3,2] / [2,3,0,1]
+        const float phi = dpp_fetch<QP>(hi), plo = dpp_fetch<QP>(lo);
+        nlo = sel_sgpr(set, phi, lo);
+        nhi = sel_sgpr(set, hi, plo);
+    }
 }
-#undef WMX_XSTAGE_ASM
 struct XMask {
     unsigned long long set, clr;
 };
