@@ -400,9 +400,18 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
     //      then 8..11, through the same eight work rows.
     const float e64r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ef64r), 0));
     const float e64i = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ef64i), 0));
+    // windowed far spectrum of the NLP (bins 0..63 of the block consumed delayIdx blocks ago): requested while the second
+    // half of the filter update runs; PartitionDelay below may still move delayIdx (every 10 * mult blocks)
+    const int delayIdx0 = Si[AS_DELAYIDX];
+    float xwr_pre = 0.f, xwi_pre = 0.f;
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
         const int base = 8 * pass, cnt = pass == 0 ? 8 : 4;
+        if (pass == 1) {
+            const float *Xw = F.hist_w + (size_t)((n - delayIdx0 + kAecHist) % kAecHist) * 130;
+            xwr_pre = Xw[lane];
+            xwi_pre = Xw[kAecPart1 + lane];
+        }
         float nyq_r = 0.f, nyq_i = 0.f;  // Nyquist bin of the far block of partition base + lane (lanes < cnt)
         if (lane < cnt) {
             const float *X = F.hist + (size_t)((n - (base + lane) + kAecHist) % kAecHist) * 130;
@@ -494,7 +503,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
     constexpr int prefSize = 24 / MULT, minPref = 4 / MULT;
     const float gc0 = MULT == 1 ? 0.9f : 0.93f, gc1 = MULT == 1 ? 0.1f : 0.07f;  // kNormalSmoothingCoefficients
     // PartitionDelay (aec_core.c:295-319) every 10*mult blocks: per-partition ordered energy sums
-    int delayIdx = Si[AS_DELAYIDX];
+    int delayIdx = delayIdx0;
     if (bp.flags & kAecFlagDelayEst) {
         // two partitions per work row: [0..64] and [66..130]
 #pragma unroll
@@ -525,9 +534,15 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
     // xfw = windowed far spectrum consumed delayIdx blocks ago; the windowed near / error spectra come back from registers
     {
         const float *Xw = F.hist_w + (size_t)((n - delayIdx + kAecHist) % kAecHist) * 130;
-        for (int b = lane; b < kAecPart1; b += 64) {
-            xw[b] = Xw[b];
-            xw[66 + b] = Xw[kAecPart1 + b];
+        if (delayIdx != delayIdx0) {  // wave-uniform, rare
+            xwr_pre = Xw[lane];
+            xwi_pre = Xw[kAecPart1 + lane];
+        }
+        xw[lane] = xwr_pre;
+        xw[66 + lane] = xwi_pre;
+        if (lane == 0) {
+            xw[kAecPart] = uniform_ld(Xw + kAecPart);
+            xw[66 + kAecPart] = uniform_ld(Xw + kAecPart1 + kAecPart);
         }
         dw[lane] = dwr;
         dw[66 + lane] = dwi;
