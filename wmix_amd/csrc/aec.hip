@@ -828,7 +828,19 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * kAe
     {
         const float4 *g4 = reinterpret_cast<const float4 *>(gst + AS_LDS0);
         float4 *s4 = reinterpret_cast<float4 *>(W.st);
-        for (int i = lane; i < AS_LDS_WORDS / 4; i += 64) s4[i] = g4[i];
+        // all chunks requested before the first one is parked (one HBM round trip, not one per chunk)
+        constexpr int kChunks = (AS_LDS_WORDS / 4 + 63) / 64;
+        float4 c[kChunks];
+#pragma unroll
+        for (int k = 0; k < kChunks; k++) {
+            const int i = lane + 64 * k;
+            c[k] = i < AS_LDS_WORDS / 4 ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < kChunks; k++) {
+            const int i = lane + 64 * k;
+            if (i < AS_LDS_WORDS / 4) s4[i] = c[k];
+        }
     }
     // the prefetched packet leaves the registers (it would stay live, or spilled, across the whole packet loop): the
     // first sub-frame waits in the still unused work rows, the second in its own row
