@@ -800,8 +800,12 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * kAe
         for (int s = 0; s < 2; s++)
 #pragma unroll
             for (int h = 0; h < 2; h++) {
+                // unconditional loads (sample 0 stands in where this lane has nothing to fetch): loads under a branch
+                // are waited for one by one
                 const int i = lane + 64 * h;
-                if (i < kAecFrame && s * kAecFrame + i < pkg) pcm0[s][h] = in0[(s * kAecFrame + i) * chn];
+                const bool want = i < kAecFrame && s * kAecFrame + i < pkg;
+                const int16_t v = in0[want ? (s * kAecFrame + i) * chn : 0];
+                pcm0[s][h] = want ? v : (int16_t)0;
             }
     }
     {
