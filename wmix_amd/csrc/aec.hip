@@ -791,11 +791,17 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * kAe
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: state pointers become scalar bases
     const int sidx = blockIdx.x * kAecWavesPerBlock + wave;  // one stream per wave
     const bool live = sidx < n_streams;
-    // First thing in flight: this stream's first near-end packet (HBM); the constants (L2) and the state follow, so the
-    // round trips overlap instead of queueing behind the workgroup barrier.
-    int16_t pcm0[2][2] = {{0, 0}, {0, 0}};
-    if (live && n_packets > 0) {
-        const int16_t *in0 = near_pcm + (size_t)sidx * stream_stride;
+    // Everything this wave needs from memory is requested up front -- its first near-end packet, the 24 filter rows, the
+    // LDS part of the state, the constants -- and waited for ONCE, at the workgroup barrier; issued phase by phase, each
+    // group costs its own HBM round trip.  (A wave without a stream reads stream 0 and leaves after the barrier.)
+    const int sl = live ? sidx : 0;
+    float *gst = state + (size_t)sl * AS_WORDS;
+    // the constants first (L2 hits): their copy into LDS then waits for them alone, not for the HBM loads behind them
+    static_assert(kAecConstWords <= 64 * kAecWavesPerBlock, "one constant word per thread");
+    const float kc = consts_g[threadIdx.x < kAecConstWords ? threadIdx.x : 0];
+    int16_t pcm0[2][2];
+    {
+        const int16_t *in0 = near_pcm + (size_t)sl * stream_stride;
 #pragma unroll
         for (int s = 0; s < 2; s++)
 #pragma unroll
@@ -808,38 +814,38 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * kAe
                 pcm0[s][h] = want ? v : (int16_t)0;
             }
     }
-    {
-        float *dst = reinterpret_cast<float *>(&K);
-        for (int i = threadIdx.x; i < kAecConstWords; i += blockDim.x) dst[i] = consts_g[i];
-    }
-    __syncthreads();  // the only block-level barrier
-    if (!live) return;
-    const PowTables *powtab = reinterpret_cast<const PowTables *>(consts_g + kAecConstWords);  // stays in global memory (L1 / L2 hits)
-    AecWaveLds &W = Wv[wave];
-    float *gst = state + (size_t)sidx * AS_WORDS;
-#ifdef WMX_AEC_PROF
-    if (lane < 16) W.prof[lane] = 0;
-#endif
-    AEC_PROF_START;
-    // ---- state in: filter taps straight into registers (256-byte rows), the rest as one contiguous block into LDS
+    // filter taps straight into registers (256-byte rows), the rest as one contiguous block, later parked in LDS
     AecTaps taps;
 #pragma unroll
     for (int p = 0; p < 12; p++) {
         taps.re[p] = gst[AS_W_RE + p * BP + lane];
         taps.im[p] = gst[AS_W_IM + p * BP + lane];
     }
-    if (lane < 12) W.wn[lane] = gst[AS_W_RE + lane * BP + kAecPart];
+    const float wn0 = gst[AS_W_RE + (lane < 12 ? lane : 0) * BP + kAecPart];
+    constexpr int kChunks = (AS_LDS_WORDS / 4 + 63) / 64;
+    float4 c[kChunks];
     {
         const float4 *g4 = reinterpret_cast<const float4 *>(gst + AS_LDS0);
-        float4 *s4 = reinterpret_cast<float4 *>(W.st);
-        // all chunks requested before the first one is parked (one HBM round trip, not one per chunk)
-        constexpr int kChunks = (AS_LDS_WORDS / 4 + 63) / 64;
-        float4 c[kChunks];
 #pragma unroll
         for (int k = 0; k < kChunks; k++) {
             const int i = lane + 64 * k;
-            c[k] = i < AS_LDS_WORDS / 4 ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            c[k] = g4[i < AS_LDS_WORDS / 4 ? i : 0];
         }
+    }
+    if (threadIdx.x < kAecConstWords) reinterpret_cast<float *>(&K)[threadIdx.x] = kc;
+    // the only block-level barrier: LDS writes drained, then s_barrier -- spelled out because __syncthreads() would also
+    // wait for every outstanding global load (the state requests above) in all eight waves
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (!live) return;
+    const PowTables *powtab = reinterpret_cast<const PowTables *>(consts_g + kAecConstWords);  // stays in global memory (L1 / L2 hits)
+    AecWaveLds &W = Wv[wave];
+#ifdef WMX_AEC_PROF
+    if (lane < 16) W.prof[lane] = 0;
+#endif
+    AEC_PROF_START;
+    if (lane < 12) W.wn[lane] = wn0;
+    {
+        float4 *s4 = reinterpret_cast<float4 *>(W.st);
 #pragma unroll
         for (int k = 0; k < kChunks; k++) {
             const int i = lane + 64 * k;
