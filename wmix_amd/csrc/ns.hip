@@ -50,6 +50,8 @@ constexpr int kUpdateWindow = 500;  // ns_core.c:188
 constexpr int kStartBand = 5;       // ns_core.c:1045
 
 // Block-shared constants (one copy per 4-wave workgroup) and one working set per wave / stream.
+constexpr int kNsWavesPerBlock = 4;
+
 template <int L>
 struct NsConstLds {
     FftTables tab;                // Ooura tables for n = L
@@ -771,8 +773,6 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
 #undef SCI
 }
 
-constexpr int kNsWavesPerBlock = 4;
-
 template <int L, bool ORDERED, int CHN>
 __global__ __launch_bounds__(64 * kNsWavesPerBlock, 4) void ns_kernel(float *__restrict__ state, unsigned short *__restrict__ hists,
                                                                       const float *__restrict__ consts, const int16_t *in, int16_t *out,
@@ -784,8 +784,19 @@ __global__ __launch_bounds__(64 * kNsWavesPerBlock, 4) void ns_kernel(float *__r
     // constants: FftTables | window[L] | logi[MP] | libm tables (the host builds the same struct)
     {
         float *dst = reinterpret_cast<float *>(&K);
-        constexpr int NCONST = sizeof(NsConstLds<L>) / 4;
-        for (int i = threadIdx.x; i < NCONST; i += blockDim.x) dst[i] = consts[i];
+        constexpr int NCONST = sizeof(NsConstLds<L>) / 4, NIT = (NCONST + 64 * kNsWavesPerBlock - 1) / (64 * kNsWavesPerBlock);
+        // every load requested before the first store (a rolled copy loop waits for each L2 round trip in turn)
+        float c[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; k++) {
+            const int i = threadIdx.x + 64 * kNsWavesPerBlock * k;
+            c[k] = consts[i < NCONST ? i : 0];
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; k++) {
+            const int i = threadIdx.x + 64 * kNsWavesPerBlock * k;
+            if (i < NCONST) dst[i] = c[k];
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
