@@ -12,6 +12,12 @@
 namespace wmx {
 
 __device__ __noinline__ static float log_d(float x) { return (float)log((double)x); }
+// tanh of a promoted float, rounded back (ns_core.c:700,1321); out of line so that its fp64 coefficients are not hoisted
+// out of the callers' packet loops and held (or spilled) there
+__device__ __noinline__ static float tanh_d(float x) { return (float)tanh((double)x); }
+// the start-up pink-noise model (ns_core.c:1111-1153, first 50 blocks only): exp and x / pow(b, e) in double, rounded back
+__device__ __noinline__ static float exp_d(float x) { return (float)exp((double)x); }
+__device__ __noinline__ static float div_pow_d(float num, float base, float e) { return (float)((double)num / pow((double)base, (double)e)); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Table-driven log / exp for the NS's per-bin calls.  The reference computes float(log((double)x)) and

@@ -372,7 +372,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             st[Y::S_PINK_EXP] = pink_exp;
             float pnum = 0.0f, pexp = 0.0f;
             if (pink_exp > 0.f) {
-                pnum = (float)exp((double)(pink_num / (float)(block_ind + 1)));
+                pnum = exp_d(pink_num / (float)(block_ind + 1));
                 pnum *= (float)(block_ind + 1);
                 pexp = pink_exp / (float)(block_ind + 1);
             }
@@ -383,7 +383,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
                     pn = white;
                 } else {
                     const float band = (float)(b < kStartBand ? kStartBand : b);
-                    pn = (float)((double)pnum / pow((double)band, (double)pexp));
+                    pn = div_pow_d(pnum, band, pexp);
                 }
                 W.r1[b] = pn;
                 float nz = W.noise[b];
@@ -607,7 +607,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             if (feat_diff < thr_diff) width = 2.f * 4.0f;
             const float a2 = width * (feat_diff - thr_diff);
             // the three indicator tanh's are wave-uniform scalars: evaluate them in lanes 0..2 of one call
-            const float th = (float)tanh((double)(lane == 1 ? a1 : (lane == 2 ? a2 : a0)));
+            const float th = tanh_d(lane == 1 ? a1 : (lane == 2 ? a2 : a0));
             const float ind0 = 0.5f * (lane_value(th, 0) + 1.f);
             const float ind1 = 0.5f * (lane_value(th, 1) + 1.f);
             const float ind2 = 0.5f * (lane_value(th, 2) + 1.f);
@@ -730,7 +730,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             float avg_gain = sum_range<ORDERED>(W.snrp, M - D - 1, M - 1, lane);
             avg_gain = avg_gain / ((float)D);
             const float t = 2.f * avg_prob - 1.f;
-            const float gain_mod = 0.5f * (1.f + (float)tanh((double)(1.0f * t)));
+            const float gain_mod = 0.5f * (1.f + tanh_d(1.0f * t));
             float g = 0.5f * gain_mod + 0.5f * avg_gain;
             if (avg_prob >= 0.5f) g = 0.25f * gain_mod + 0.75f * avg_gain;
             g = g * 1.0f;
