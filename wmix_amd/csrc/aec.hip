@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F, const float *
 }
 
 // ================================================================== near-end kernel
-constexpr int kAecWavesPerBlock = 8;
+constexpr int kAecWavesPerBlock = 4;
 #ifdef WMX_AEC_PROF  // developer build only (make EXTRA=-DWMX_AEC_PROF): cycles per phase of aec_block, summed over waves
 __device__ unsigned long long g_aec_prof[16];
 #define AEC_PROF(i)                                                              \
@@ -199,7 +199,7 @@ struct alignas(16) AecWaveLds {
                              // registers); [16..27] partition energies of PartitionDelay
     float fa[8][FAS];        // work rows: spectra handed to / from the register FFTs; rows 1..7 double as NLP scratch
     float cur[64], enew[64];
-    float park[kAecFrame];   // second sub-frame of the launch's first packet, prefetched (the first one parks in fa[])
+    int16_t park[kAecFrame];  // second sub-frame of the launch's first packet, prefetched (the first one parks in fa[])
 #ifdef WMX_AEC_PROF
     unsigned long long prof[16];
 #endif
@@ -797,8 +797,13 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * kAe
     const int sl = live ? sidx : 0;
     float *gst = state + (size_t)sl * AS_WORDS;
     // the constants first (L2 hits): their copy into LDS then waits for them alone, not for the HBM loads behind them
-    static_assert(kAecConstWords <= 64 * kAecWavesPerBlock, "one constant word per thread");
-    const float kc = consts_g[threadIdx.x < kAecConstWords ? threadIdx.x : 0];
+    constexpr int kConstIt = (kAecConstWords + 64 * kAecWavesPerBlock - 1) / (64 * kAecWavesPerBlock);
+    float kc[kConstIt];
+#pragma unroll
+    for (int k = 0; k < kConstIt; k++) {
+        const int i = threadIdx.x + 64 * kAecWavesPerBlock * k;
+        kc[k] = consts_g[i < kAecConstWords ? i : 0];
+    }
     int16_t pcm0[2][2];
     {
         const int16_t *in0 = near_pcm + (size_t)sl * stream_stride;
@@ -832,7 +837,11 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * kAe
             c[k] = g4[i < AS_LDS_WORDS / 4 ? i : 0];
         }
     }
-    if (threadIdx.x < kAecConstWords) reinterpret_cast<float *>(&K)[threadIdx.x] = kc;
+#pragma unroll
+    for (int k = 0; k < kConstIt; k++) {
+        const int i = threadIdx.x + 64 * kAecWavesPerBlock * k;
+        if (i < kAecConstWords) reinterpret_cast<float *>(&K)[i] = kc[k];
+    }
     // the only block-level barrier: LDS writes drained, then s_barrier -- spelled out because __syncthreads() would also
     // wait for every outstanding global load (the state requests above) in all eight waves
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -859,7 +868,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * kAe
         const int i = lane + 64 * h;
         if (i < kAecFrame) {
             W.fa[0][i] = (float)pcm0[0][h];
-            W.park[i] = (float)pcm0[1][h];
+            W.park[i] = pcm0[1][h];
         }
     }
     wave_sync();
@@ -885,7 +894,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * kAe
             for (int h = 0; h < 2; h++) {
                 const int i = ln + 64 * h;
                 if (i >= kAecFrame) continue;
-                const float v = (p == 0 && s < 2) ? (s == 0 ? W.fa[0][i] : W.park[i]) : (float)in[(s * kAecFrame + i) * chn];
+                const float v = (p == 0 && s < 2) ? (s == 0 ? W.fa[0][i] : (float)W.park[i]) : (float)in[(s * kAecFrame + i) * chn];
                 AEC_ST(AS_NEAR_RING + (sp.near_wr + i) % kAecRing) = v;
             }
             wave_sync();
