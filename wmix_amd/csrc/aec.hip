@@ -16,7 +16,7 @@
 //   aec_far_kernel   one wave per batch: far-end pre-buffer, the plain and sqrt-Hanning-windowed
 //                    spectra of every new 64-sample far block (2 rdft128 each), the history of
 //                    CONSUMED far spectra and the far power xPow -- all shared by every stream.
-//   aec_near_kernel  one wave per stream, eight streams per workgroup: ProcessBlock + NonLinearProcessing.  The
+//   aec_near_kernel  one wave per stream, four streams per workgroup: ProcessBlock + NonLinearProcessing.  The
 //                    12 x 64-bin filter taps live in registers (lane k = bin k; the Nyquist column in LDS) and go
 //                    straight from / to their 256-byte HBM rows; the other 4.7 KB of state (PSDs, tails, rings,
 //                    scalars) are pulled into LDS with one contiguous read; all blocks of all packets of the launch
@@ -24,6 +24,9 @@
 //                    The transforms run in registers (fft_regs.h): the 24 constraint FFTs of the filter update as
 //                    16-lane groups (partitions 0-7 as packed pairs, then 8-11), the two single inverse transforms
 //                    of a block with one point per lane, the two forward pairs in two 16-lane groups.
+//                    A wave spends more of its life waiting for data than issuing, so every
+//                    global request of a phase goes out in one batch, a phase early where registers allow, and
+//                    wave-uniform far-end data takes the scalar path.
 // Float expressions, their order and the ordered sums follow the reference exactly (-ffp-contract=off); powf is the
 // table-driven double-precision evaluation of libm_dev.h, the rare log the library routine; cosf/sinf of the comfort
 // noise come from the host's libm through the plan.
