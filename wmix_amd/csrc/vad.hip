@@ -45,18 +45,22 @@ enum : int {
     V32_WORDS = 5,
 };
 
+constexpr int kVadMinFields = V16_MEAN_VALUE - V16_AGE;  // 192
+constexpr int kVadRegFields = V16_WORDS - (V16_MEAN_VALUE - V16_AGE);  // 71: everything but the order statistics
 struct VadRef {
-    int16_t *s16;
-    int32_t *s32;
-    size_t n;  // streams (row pitch)
+    // The lane's own copy of the stream's state for the length of the launch: the 71 scalar int16 fields and the five
+    // int32 words in REGISTERS (every index below is a compile-time constant once the channel / Gaussian loops are
+    // unrolled), the order statistics in LDS.  Loaded in one batch at kernel entry, written back once at the end: the
+    // dependency chain of a frame never waits on a state row again (it used to pay an L2 round trip per field).
+    int16_t *r16;     // [kVadRegFields]
+    int32_t *r32;     // [V32_WORDS]
     int16_t *minbuf;  // LDS copy of index_vector / low_value_vector (V16_AGE .. V16_MEAN_VALUE), element f at minbuf[f * 64]
-    __device__ __forceinline__ int16_t &h(int f) const { return s16[(size_t)f * n]; }
-    __device__ __forceinline__ int32_t &w(int f) const { return s32[(size_t)f * n]; }
+    __device__ __forceinline__ int16_t &h(int f) const { return r16[f < V16_AGE ? f : f - (V16_MEAN_VALUE - V16_AGE)]; }
+    __device__ __forceinline__ int32_t &w(int f) const { return r32[f]; }
     // the 2 x 96 order-statistics entries: WebRtcVad_FindMinimum walks and shifts them element by element
     // (vad_sp.c:59-177), a long chain of dependent accesses -- from LDS, not from HBM / L2
     __device__ __forceinline__ int16_t &hm(int f) const { return minbuf[(f - V16_AGE) * 64]; }
 };
-constexpr int kVadMinFields = V16_MEAN_VALUE - V16_AGE;  // 192
 
 // LDS int16 buffer private to one lane: element i lives at base[i * 64]
 struct LaneBuf {
@@ -384,8 +388,26 @@ __device__ int16_t gmm_probability(const VadRef &S, const int16_t *feat, int16_t
 
 // WebRtcVad_Process (webrtc_vad.c:71-104) on one packet of NB*RATIO samples at fs = 8000*RATIO.
 // RATIO = 1, 2, 4 (vad_core.c:623-674: one or two chained 2:1 decimators in front of the 8 kHz core).
-template <int NB, int RATIO>
-__device__ int vad_packet(const VadRef &S, const int16_t *p, LaneBuf hp120, LaneBuf lp120, LaneBuf hp60, LaneBuf lp60) {
+// sample sources of vad_packet: the packet in memory, or the packet already in registers (8 samples per uint4; the
+// index is a compile-time constant there because the decimation loop is fully unrolled for it)
+struct MemSrc {
+    const int16_t *p;
+    static constexpr bool kUnroll = false;
+    __device__ __forceinline__ int16_t operator()(int i) const { return p[i]; }
+};
+template <int NV>
+struct RegSrc {
+    const uint4 *raw;
+    static constexpr bool kUnroll = true;
+    __device__ __forceinline__ int16_t operator()(int i) const {
+        const uint4 v = raw[i >> 3];
+        const unsigned w = ((i >> 1) & 3) == 0 ? v.x : (((i >> 1) & 3) == 1 ? v.y : (((i >> 1) & 3) == 2 ? v.z : v.w));
+        return (int16_t)((i & 1) ? (w >> 16) : (w & 0xffffu));
+    }
+};
+
+template <int NB, int RATIO, class Src>
+__device__ __forceinline__ int vad_packet(const VadRef &S, const Src p, LaneBuf hp120, LaneBuf lp120, LaneBuf hp60, LaneBuf lp60) {
     // ---- decimation to 8 kHz fused with the first band split (vad_filterbank.c:268-270)
     {
         int32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
@@ -399,18 +421,20 @@ __device__ int vad_packet(const VadRef &S, const int16_t *p, LaneBuf hp120, Lane
         }
         int16_t up = S.h(V16_UPPER + 0), lo = S.h(V16_LOWER + 0);
         int32_t su = wshl(up, 16), sl = wshl(lo, 16);
+        constexpr int kUn = Src::kUnroll ? NB / 2 : 1;
+#pragma unroll kUn
         for (int i = 0; i < NB / 2; i++) {
             int16_t nb[2];
 #pragma unroll
             for (int e = 0; e < 2; e++) {
-                const int16_t *q = p + (2 * i + e) * RATIO;
+                const int q = (2 * i + e) * RATIO;
                 if (RATIO == 1) {
-                    nb[e] = q[0];
+                    nb[e] = p(q);
                 } else if (RATIO == 2) {
-                    nb[e] = ds2_step(q[0], q[1], d0, d1);
+                    nb[e] = ds2_step(p(q), p(q + 1), d0, d1);
                 } else {
-                    const int16_t w0 = ds2_step(q[0], q[1], d2, d3);
-                    const int16_t w1 = ds2_step(q[2], q[3], d2, d3);
+                    const int16_t w0 = ds2_step(p(q), p(q + 1), d2, d3);
+                    const int16_t w1 = ds2_step(p(q + 2), p(q + 3), d2, d3);
                     nb[e] = ds2_step(w0, w1, d0, d1);
                 }
             }
@@ -481,18 +505,23 @@ __global__ __launch_bounds__(64) void vad_kernel(int16_t *s16, int32_t *s32, int
     const int lane = threadIdx.x;
     const int stream = blockIdx.x * 64 + lane;
     if (stream >= n_streams) return;  // lanes are independent: no barriers anywhere in this kernel
-    const VadRef S{s16 + stream, s32 + stream, (size_t)n_streams, minlds + lane};
-    // order-statistics state in: 192 coalesced rows, all in flight together
+    int16_t r16[kVadRegFields];
+    int32_t r32[V32_WORDS];
+    const VadRef S{r16, r32, minlds + lane};
+    const int16_t *g16 = s16 + stream;
+    const int32_t *g32 = s32 + stream;
+    // state in: every row requested before the first one is used (coalesced: field-major rows)
+#pragma unroll
+    for (int f = 0; f < V16_AGE; f++) r16[f] = g16[(size_t)f * n_streams];
+#pragma unroll
+    for (int f = V16_MEAN_VALUE; f < V16_WORDS; f++) r16[f - kVadMinFields] = g16[(size_t)f * n_streams];
+#pragma unroll
+    for (int f = 0; f < V32_WORDS; f++) r32[f] = g32[(size_t)f * n_streams];
 #pragma unroll 8
-    for (int f = 0; f < kVadMinFields; f++) minlds[f * 64 + lane] = S.h(V16_AGE + f);
-    // warm L2 with this wave's state rows and PCM lines (wmx_internal.h: touch_line)
+    for (int f = 0; f < kVadMinFields; f++) minlds[f * 64 + lane] = g16[(size_t)(V16_AGE + f) * n_streams];
+    // warm L2 with this wave's PCM lines (wmx_internal.h: touch_line); the register path below fetches them itself
     int sink = 0;
-#pragma unroll 1
-    for (int f = 0; f < V16_WORDS; f++)
-        if (f < V16_AGE || f >= V16_MEAN_VALUE) touch_line(&S.h(f), sink);
-#pragma unroll 1
-    for (int f = 0; f < V32_WORDS; f++) touch_line(&S.w(f), sink);
-    {
+    if (!(NB * RATIO <= 160 && chn == 1 && packets_per_call == 1)) {
         const int16_t *row = pcm + (size_t)stream * stream_stride;
         const int n_i16 = packets_per_call * NB * RATIO * chn;
 #pragma unroll 1
@@ -502,7 +531,40 @@ __global__ __launch_bounds__(64) void vad_kernel(int16_t *s16, int32_t *s32, int
     const LaneBuf hp120{lds + lane}, lp120{lds + lane + 64 * (NB / 2)}, hp60{lds + lane + 64 * NB},
         lp60{lds + lane + 64 * (NB + NB / 4)};
     constexpr int PKG = NB * RATIO;  // frames (mono samples) per packet at the stream's rate
-    for (int call = 0; call < n_calls; call++) {
+    // One mono packet per call with 16-byte aligned rows (the batched chain's case): the lane's packet is fetched as
+    // uint4's in one batch, analysed from registers, attenuated there and written back as uint4's -- instead of ~2 x PKG
+    // dependent two-byte accesses along the chain.
+    constexpr bool kRegPath = PKG <= 160;  // 20 uint4 per lane; longer packets keep the memory path (register budget)
+    constexpr int NV = kRegPath ? PKG / 8 : 1;
+    const bool fast = kRegPath && chn == 1 && packets_per_call == 1 && (stream_stride % 8) == 0 && (call_stride % 8) == 0 &&
+                      (reinterpret_cast<size_t>(pcm) % 16) == 0;
+    bool done = false;
+    if constexpr (kRegPath) {
+        if (fast) {
+        done = true;
+        for (int call = 0; call < n_calls; call++) {
+            uint4 *frame4 = reinterpret_cast<uint4 *>(pcm + (size_t)stream * stream_stride + (size_t)call * call_stride);
+            uint4 raw[NV];
+#pragma unroll
+            for (int j = 0; j < NV; j++) raw[j] = frame4[j];
+            int reduce = S.h(V16_REDUCE);
+            const int r = vad_packet<NB, RATIO>(S, RegSrc<NV>{raw}, hp120, lp120, hp60, lp60);
+            if (r == 0) {
+                if (reduce < 4) reduce += 1;
+            } else {
+                if (reduce > 0) reduce -= 1;
+            }
+            auto att = [&](unsigned w) {  // both int16 halves >> reduce (arithmetic)
+                const int lo = (int)(int16_t)(w & 0xffffu) >> reduce, hi = (int)(int16_t)(w >> 16) >> reduce;
+                return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16);
+            };
+#pragma unroll
+            for (int j = 0; j < NV; j++) frame4[j] = make_uint4(att(raw[j].x), att(raw[j].y), att(raw[j].z), att(raw[j].w));
+            S.h(V16_REDUCE) = (int16_t)reduce;
+        }
+        }
+    }
+    for (int call = 0; call < (done ? 0 : n_calls); call++) {
         int16_t *frame = pcm + (size_t)stream * stream_stride + (size_t)call * call_stride;
         const int n_mono = packets_per_call * PKG;
         if (chn > 1) {  // in-place mean downmix, src/webrtc.c:104-116
@@ -514,7 +576,7 @@ __global__ __launch_bounds__(64) void vad_kernel(int16_t *s16, int32_t *s32, int
         }
         int reduce = S.h(V16_REDUCE);
         for (int it = 0; it < packets_per_call; it++) {
-            const int r = vad_packet<NB, RATIO>(S, frame, hp120, lp120, hp60, lp60);  // always packet 0 (quirk 1)
+            const int r = vad_packet<NB, RATIO>(S, MemSrc{frame}, hp120, lp120, hp60, lp60);  // always packet 0 (quirk 1)
             if (r == 0) {
                 if (reduce < 4) reduce += 1;
             } else {
@@ -531,8 +593,18 @@ __global__ __launch_bounds__(64) void vad_kernel(int16_t *s16, int32_t *s32, int
             }
         }
     }
+    {
+        int16_t *o16 = s16 + stream;
+        int32_t *o32 = s32 + stream;
+#pragma unroll
+        for (int f = 0; f < V16_AGE; f++) o16[(size_t)f * n_streams] = r16[f];
+#pragma unroll
+        for (int f = V16_MEAN_VALUE; f < V16_WORDS; f++) o16[(size_t)f * n_streams] = r16[f - kVadMinFields];
+#pragma unroll
+        for (int f = 0; f < V32_WORDS; f++) o32[(size_t)f * n_streams] = r32[f];
 #pragma unroll 8
-    for (int f = 0; f < kVadMinFields; f++) S.h(V16_AGE + f) = minlds[f * 64 + lane];
+        for (int f = 0; f < kVadMinFields; f++) o16[(size_t)(V16_AGE + f) * n_streams] = minlds[f * 64 + lane];
+    }
 }
 
 __global__ void vad_fill_state(int16_t *s16, int32_t *s32, const int16_t *t16, int n_streams) {
