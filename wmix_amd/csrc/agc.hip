@@ -44,11 +44,15 @@ enum : int {  // DigitalAgc + AgcVad vadNearend (digital_agc.h:26-53)
 };
 
 struct AgcRef {
-    int16_t *s16;
-    int32_t *s32;
-    size_t n;
-    __device__ __forceinline__ int16_t &h(int f) const { return s16[(size_t)f * n]; }
-    __device__ __forceinline__ int32_t &w(int f) const { return s32[(size_t)f * n]; }
+    // the lane's copy of the stream's 21 state words, in registers for the length of the launch (every index is a
+    // compile-time constant): one batch of loads at kernel entry, one batch of stores at the end
+    // (pitch 1); the run-time channel-count fallback keeps its loops rolled and addresses the state rows in memory
+    // (pitch = number of streams)
+    int16_t *r16;  // [A16_WORDS]
+    int32_t *r32;  // [A32_WORDS]
+    size_t pitch;
+    __device__ __forceinline__ int16_t &h(int f) const { return r16[(size_t)f * pitch]; }
+    __device__ __forceinline__ int32_t &w(int f) const { return r32[(size_t)f * pitch]; }
 };
 
 // resample_by_2.c:70-124: two input samples -> one output sample
@@ -297,10 +301,28 @@ __global__ __launch_bounds__(64) void agc_kernel(int16_t *s16, int32_t *s32, con
     __syncthreads();
     const int stream = blockIdx.x * 64 + threadIdx.x;
     if (stream >= n_streams) return;
-    const AgcRef S{s16 + stream, s32 + stream, (size_t)n_streams};
-    for (int p = 0; p < n_packets; p++) {
-        const size_t off = (size_t)stream * stream_stride + (size_t)p * packet_stride;
-        agc_packet<L, CHN>(S, gain_table, in + off, out + off, chn_rt);
+    if constexpr (CHN == 0) {
+        const AgcRef S{s16 + stream, s32 + stream, (size_t)n_streams};
+        for (int p = 0; p < n_packets; p++) {
+            const size_t off = (size_t)stream * stream_stride + (size_t)p * packet_stride;
+            agc_packet<L, CHN>(S, gain_table, in + off, out + off, chn_rt);
+        }
+    } else {
+        int16_t r16[A16_WORDS];
+        int32_t r32[A32_WORDS];
+#pragma unroll
+        for (int f = 0; f < A32_WORDS; f++) r32[f] = s32[(size_t)f * n_streams + stream];
+#pragma unroll
+        for (int f = 0; f < A16_WORDS; f++) r16[f] = s16[(size_t)f * n_streams + stream];
+        const AgcRef S{r16, r32, 1};
+        for (int p = 0; p < n_packets; p++) {
+            const size_t off = (size_t)stream * stream_stride + (size_t)p * packet_stride;
+            agc_packet<L, CHN>(S, gain_table, in + off, out + off, chn_rt);
+        }
+#pragma unroll
+        for (int f = 0; f < A32_WORDS; f++) s32[(size_t)f * n_streams + stream] = r32[f];
+#pragma unroll
+        for (int f = 0; f < A16_WORDS; f++) s16[(size_t)f * n_streams + stream] = r16[f];
     }
 }
 
