@@ -176,10 +176,24 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
 #pragma unroll
     for (int k = 0; k < NT; k++) {
         const int i = lane + 64 * k;
-        buf[k] = (i < L - B) ? st[Y::IN_BUF + i + B] : (float)in[(i - (L - B)) * chn];
+        // No load under a lane-dependent branch (such a load is waited for on the spot, one HBM round trip each): which
+        // of the 64-sample groups hold old samples, new samples or both is a compile-time fact; the mixed group
+        // fetches both with clamped addresses and selects.
+        constexpr int KEEP = L - B;  // samples carried over from the previous frame
+        const bool all_old = 64 * k + 63 < KEEP, all_new = 64 * k >= KEEP;
+        const bool is_old = all_old || (!all_new && i < KEEP);
+        float o = 0.f, oh = 0.f;
+        int16_t n = 0, nh = 0;
+        if (!all_new) o = st[Y::IN_BUF + (is_old ? i + B : 0)];
+        if (!all_old) n = in[(is_old ? 0 : i - KEEP) * chn];
+        buf[k] = is_old ? o : (float)n;
         synt[k] = st[Y::SYNT_BUF + i];
         hb[k] = 0.f;
-        if (chn == 2) hb[k] = (i < L - B) ? st[Y::HB_BUF + i + B] : (float)in[(i - (L - B)) * chn + 1];
+        if (chn == 2) {
+            if (!all_new) oh = st[Y::HB_BUF + (is_old ? i + B : 0)];
+            if (!all_old) nh = in[(is_old ? 0 : i - KEEP) * chn + 1];
+            hb[k] = is_old ? oh : (float)nh;
+        }
     }
     // Per-bin state this frame will need, requested from HBM right behind the time-domain buffers (loads return in order) and consumed
     // several phases later (window, energy sum, FFT, spectrum loop and the ordered sums run in between): the loops below
