@@ -491,19 +491,32 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
                 }
                 sti[Y::S_COUNTDOWN] = countdown;
             } else {
-                // every lane walks the three histograms in order (uniform loads, runs once per 5 s)
+                // The three histograms are walked in bin order (the float sums are order-sensitive), but only their
+                // NON-ZERO bins: an empty bin adds +0 to every sum and can never be a peak (h > max needs h > 0), and 500
+                // samples leave most of the 1000 bins empty.  64 bins per coalesced load, occupied ones found by ballot.
+                auto walk = [&](int which, auto &&visit) {
+                    for (int base = 0; base < kHistBins; base += 64) {
+                        const int i = base + lane;
+                        const int hv = i < kHistBins ? (int)hist[which * kHistBins + i] : 0;
+                        unsigned long long m = __builtin_amdgcn_ballot_w64(hv != 0);
+                        while (m) {
+                            const int j = __builtin_ctzll(m);
+                            m &= m - 1;
+                            visit(base + j, __builtin_amdgcn_readlane(hv, j));
+                        }
+                    }
+                };
                 float avg = 0.0f, avg_compl = 0.0f, avg_sq = 0.0f;
                 int num = 0;
-                for (int i = 0; i < kHistBins; i++) {
+                walk(0, [&](int i, int h) {
                     const float mid = ((float)i + 0.5f) * 0.1f;
-                    const int h = hist[i];
                     if (mid <= 1.f) {
                         avg += h * mid;
                         num += h;
                     }
                     avg_sq += h * mid * mid;
                     avg_compl += h * mid;
-                }
+                });
                 if (num > 0) avg = avg / ((float)num);
                 avg_compl = avg_compl / ((float)kUpdateWindow);
                 avg_sq = avg_sq / ((float)kUpdateWindow);
@@ -523,9 +536,8 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
                     int max1 = 0, max2 = 0;
                     w1[f] = w2[f] = 0;
                     p1[f] = p2[f] = 0.0f;
-                    for (int i = 0; i < kHistBins; i++) {
+                    walk(f + 1, [&](int i, int h) {
                         const float mid = ((float)i + 0.5f) * bin;
-                        const int h = hist[(f + 1) * kHistBins + i];
                         if (h > max1) {
                             max2 = max1;
                             w2[f] = w1[f];
@@ -538,7 +550,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
                             w2[f] = h;
                             p2[f] = mid;
                         }
-                    }
+                    });
                 }
                 const int thres_weight = 150;  // (int)(0.3 * 500)
                 int use_flat = 1, use_diff = 1;
