@@ -836,8 +836,10 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * kAe
         const float4 *g4 = reinterpret_cast<const float4 *>(gst + AS_LDS0);
 #pragma unroll
         for (int k = 0; k < kChunks; k++) {
+            // lanes past the end of the last chunk fetch (and later park) their element of the chunk before once more:
+            // no lane-dependent branch around a load or its store (such a load is issued late and waited for on the spot)
             const int i = lane + 64 * k;
-            c[k] = g4[i < AS_LDS_WORDS / 4 ? i : 0];
+            c[k] = g4[i < AS_LDS_WORDS / 4 ? i : i - 64];
         }
     }
 #pragma unroll
@@ -861,7 +863,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * kAe
 #pragma unroll
         for (int k = 0; k < kChunks; k++) {
             const int i = lane + 64 * k;
-            if (i < AS_LDS_WORDS / 4) s4[i] = c[k];
+            s4[i < AS_LDS_WORDS / 4 ? i : i - 64] = c[k];
         }
     }
     // the prefetched packet leaves the registers (it would stay live, or spilled, across the whole packet loop): the
