@@ -494,21 +494,23 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
                 // The three histograms are walked in bin order (the float sums are order-sensitive), but only their
                 // NON-ZERO bins: an empty bin adds +0 to every sum and can never be a peak (h > max needs h > 0), and 500
                 // samples leave most of the 1000 bins empty.  64 bins per coalesced load, occupied ones found by ballot.
-                auto walk = [&](int which, auto &&visit) {
-                    for (int base = 0; base < kHistBins; base += 64) {
-                        const int i = base + lane;
-                        const int hv = i < kHistBins ? (int)hist[which * kHistBins + i] : 0;
-                        unsigned long long m = __builtin_amdgcn_ballot_w64(hv != 0);
-                        while (m) {
-                            const int j = __builtin_ctzll(m);
-                            m &= m - 1;
-                            visit(base + j, __builtin_amdgcn_readlane(hv, j));
-                        }
-                    }
-                };
+                // (a macro, not a lambda: with the accumulators captured by reference through two lambda levels the
+                // compiler kept them in scratch memory)
+#define NS_WALK(which, ...)                                                                  \
+    for (int base = 0; base < kHistBins; base += 64) {                                       \
+        const int ii = base + lane;                                                          \
+        const int hv = ii < kHistBins ? (int)hist[(which) * kHistBins + ii] : 0;             \
+        unsigned long long m = __builtin_amdgcn_ballot_w64(hv != 0);                         \
+        while (m) {                                                                          \
+            const int j = __builtin_ctzll(m);                                                \
+            m &= m - 1;                                                                      \
+            const int i = base + j, h = __builtin_amdgcn_readlane(hv, j);                    \
+            __VA_ARGS__                                                                      \
+        }                                                                                    \
+    }
                 float avg = 0.0f, avg_compl = 0.0f, avg_sq = 0.0f;
                 int num = 0;
-                walk(0, [&](int i, int h) {
+                NS_WALK(0, {
                     const float mid = ((float)i + 0.5f) * 0.1f;
                     if (mid <= 1.f) {
                         avg += h * mid;
@@ -516,7 +518,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
                     }
                     avg_sq += h * mid * mid;
                     avg_compl += h * mid;
-                });
+                })
                 if (num > 0) avg = avg / ((float)num);
                 avg_compl = avg_compl / ((float)kUpdateWindow);
                 avg_sq = avg_sq / ((float)kUpdateWindow);
@@ -528,48 +530,52 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
                     if (thr_lrt < 0.2f) thr_lrt = 0.2f;
                     if (thr_lrt > 1.f) thr_lrt = 1.f;
                 }
-                int w1[2], w2[2];
-                float p1[2], p2[2];
-#pragma unroll
-                for (int f = 0; f < 2; f++) {
-                    const float bin = f == 0 ? 0.05f : 0.1f;
+                // the two peaks of the flatness / difference histograms
+                int w1a = 0, w2a = 0, w1b = 0, w2b = 0;
+                float p1a = 0.0f, p2a = 0.0f, p1b = 0.0f, p2b = 0.0f;
+                {
                     int max1 = 0, max2 = 0;
-                    w1[f] = w2[f] = 0;
-                    p1[f] = p2[f] = 0.0f;
-                    walk(f + 1, [&](int i, int h) {
-                        const float mid = ((float)i + 0.5f) * bin;
+                    NS_WALK(1, {
+                        const float mid = ((float)i + 0.5f) * 0.05f;
                         if (h > max1) {
-                            max2 = max1;
-                            w2[f] = w1[f];
-                            p2[f] = p1[f];
-                            max1 = h;
-                            w1[f] = h;
-                            p1[f] = mid;
+                            max2 = max1, w2a = w1a, p2a = p1a;
+                            max1 = h, w1a = h, p1a = mid;
                         } else if (h > max2) {
-                            max2 = h;
-                            w2[f] = h;
-                            p2[f] = mid;
+                            max2 = h, w2a = h, p2a = mid;
                         }
-                    });
+                    })
                 }
+                {
+                    int max1 = 0, max2 = 0;
+                    NS_WALK(2, {
+                        const float mid = ((float)i + 0.5f) * 0.1f;
+                        if (h > max1) {
+                            max2 = max1, w2b = w1b, p2b = p1b;
+                            max1 = h, w1b = h, p1b = mid;
+                        } else if (h > max2) {
+                            max2 = h, w2b = h, p2b = mid;
+                        }
+                    })
+                }
+#undef NS_WALK
                 const int thres_weight = 150;  // (int)(0.3 * 500)
                 int use_flat = 1, use_diff = 1;
-                if ((fabsf(p2[0] - p1[0]) < 2 * 0.05f) && (w2[0] > 0.5f * w1[0])) {
-                    w1[0] += w2[0];
-                    p1[0] = 0.5f * (p1[0] + p2[0]);
+                if ((fabsf(p2a - p1a) < 2 * 0.05f) && (w2a > 0.5f * w1a)) {
+                    w1a += w2a;
+                    p1a = 0.5f * (p1a + p2a);
                 }
-                if (w1[0] < thres_weight || p1[0] < 0.6f) use_flat = 0;
+                if (w1a < thres_weight || p1a < 0.6f) use_flat = 0;
                 if (use_flat == 1) {
-                    thr_flat = 0.9f * p1[0];
+                    thr_flat = 0.9f * p1a;
                     if (thr_flat < 0.1f) thr_flat = 0.1f;
                     if (thr_flat > 0.95f) thr_flat = 0.95f;
                 }
-                if ((fabsf(p2[1] - p1[1]) < 2 * 0.1f) && (w2[1] > 0.5f * w1[1])) {
-                    w1[1] += w2[1];
-                    p1[1] = 0.5f * (p1[1] + p2[1]);
+                if ((fabsf(p2b - p1b) < 2 * 0.1f) && (w2b > 0.5f * w1b)) {
+                    w1b += w2b;
+                    p1b = 0.5f * (p1b + p2b);
                 }
-                thr_diff = 1.2f * p1[1];
-                if (w1[1] < thres_weight) use_diff = 0;
+                thr_diff = 1.2f * p1b;
+                if (w1b < thres_weight) use_diff = 0;
                 if (thr_diff < 0.16f) thr_diff = 0.16f;
                 if (thr_diff > 1.f) thr_diff = 1.f;
                 if (fluct < 0.05f) use_diff = 0;
