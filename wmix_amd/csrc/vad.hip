@@ -8,9 +8,12 @@
 // per-stream state is laid out field-major ([field][stream]) so every state access of the wave
 // is one 128/256-byte line, and the sub-band signals of the 6-band split tree live in LDS as
 // [sample][lane] int16 (bank-conflict free).  At one wave per SIMD the kernel's time is the length of
-// one stream's dependency chain, so state is kept off the HBM latency path: the order-statistics
+// one stream's dependency chain, so state is kept off the memory latency path: the order-statistics
 // vectors (192 of the 263 int16 fields, walked element by element by FindMinimum) are staged in LDS for
-// the launch, and one up-front round trip pulls every other state row and the PCM lines into L2.
+// the launch, the other 76 state words live in registers (one batch of loads at entry, one of stores at
+// the end), and a mono single-packet call also fetches its packet as uint4 rows in one batch, analyses
+// and attenuates it in registers and writes it back the same way (other shapes: the packet's lines are
+// pulled into L2 up front and read from memory).
 // Results are bit-exact with the reference; signed overflow that the reference leaves to
 // two's-complement wrap is spelled out.
 //
