@@ -232,6 +232,7 @@ class ChainWorkload:
     dominant_bytes_per_frame = 24040.0
     freq, pkt = 16000, 160
     with_agc_vad = True
+    overlap_tail = os.environ.get("WMIX_BENCH_OVERLAP_TAIL", "0") == "1"  # developer switch, see the comment in __init__
 
     def __init__(self, dev, n_streams, rank, dist=None, packets=1):
         from wmix_amd import synth
@@ -254,7 +255,17 @@ class ChainWorkload:
         self.P = packets  # 10 ms packets per stream per step (1 = one packet per launch; 2 = the daemon's own 20 ms calls)
         assert self.K % self.P == 0
         self.far = torch.zeros(self.P, self.pkt, dtype=torch.int16, device=dev)
-        self.work = torch.empty_like(self.inp[0:self.P])
+        # Two packet buffers for the developer switch WMIX_BENCH_OVERLAP_TAIL=1: AGC and VAD are lane-per-stream chains
+        # that leave most of the GPU idle (one wave per SIMD, issue-bound); on a second, high-priority HIP stream they run
+        # beside step k+1's noise suppressor (per stream the order NS -> AEC -> AGC -> VAD of every packet is unchanged:
+        # events between the two HIP streams).  Measured: 1.42 -> 1.39 ms per step, but VAD then trickles in behind the
+        # NS workgroups that hold all the LDS (0.44 ms instead of 0.07), reaches into the AEC launch and costs it 3 %.
+        # Off by default: the per-kernel timings of the default line stay those of kernels running alone.
+        self.works = [torch.empty_like(self.inp[0:self.P]) for _ in range(2)]
+        self.work = self.works[0]
+        self.side = torch.cuda.Stream(device=dev, priority=-1) if self.overlap_tail else None
+        self.ev_aec = [torch.cuda.Event() for _ in range(2)]
+        self.ev_tail = [None, None]
         self.ns = NsBatch(n_streams, 1, self.freq, ordered=True)
         self.aec = AecBatch(n_streams, 1, self.freq, 10)
         self.agc = AgcBatch(n_streams, 1, self.freq, 5) if self.with_agc_vad else None  # volumeAgc default 5, src/wmix.c:1596
@@ -266,7 +277,12 @@ class ChainWorkload:
     def step(self, timed):
         P = self.P
         k = (self.k * P) % self.K
+        b = self.k & 1
         self.k += 1
+        self.work = self.works[b]
+        main = torch.cuda.current_stream()
+        if self.ev_tail[b] is not None:
+            main.wait_event(self.ev_tail[b])  # the tail of two steps ago has finished with this buffer
         if self.rank == 0:
             self.far.copy_(self.far_src[k:k + P])
         # the far-end broadcast (RCCL, its own stream) runs behind the noise suppressor, which does not need it
@@ -275,7 +291,16 @@ class ChainWorkload:
         if work is not None:
             self.t.run("far_broadcast_wait", timed, work.wait)
         self.t.run("aec", timed, lambda: self.aec.process2_packet_major(self.far, self.work))
-        if self.with_agc_vad:
+        if self.with_agc_vad and self.side is not None:
+            self.ev_aec[b].record(main)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.ev_aec[b])
+                self.t.run("agc", timed, lambda: self.agc.process_packet_major(self.work))
+                self.t.run("vad", timed, lambda: self.vad.process_packet_major(self.work))
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+                self.ev_tail[b] = ev
+        elif self.with_agc_vad:
             self.t.run("agc", timed, lambda: self.agc.process_packet_major(self.work))
             self.t.run("vad", timed, lambda: self.vad.process_packet_major(self.work))
 
