@@ -117,8 +117,15 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F, const float *
     __shared__ float fa[2][132];
     const int lane = threadIdx.x;
     {
+        // one wave, one latency chain: every request of a group goes out before the first result is used
         float *dst = reinterpret_cast<float *>(&K);
-        for (int i = lane; i < kAecConstWords; i += 64) dst[i] = consts_g[i];
+        constexpr int NIT = (kAecConstWords + 63) / 64;
+        float c[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; k++) c[k] = consts_g[lane + 64 * k < kAecConstWords ? lane + 64 * k : 0];
+#pragma unroll
+        for (int k = 0; k < NIT; k++)
+            if (lane + 64 * k < kAecConstWords) dst[lane + 64 * k] = c[k];
     }
     wave_sync();
     for (int p = 0; p < n_packets; p++) {
@@ -155,24 +162,54 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F, const float *
             }
         }
         if (pl.has_near && !pl.passthrough) {
-            for (int k = 0; k < pl.n_blk; k++) {
-                // far block consumed by ProcessBlock k: history entry + xPow (aec_core.c:1209-1216)
+            // far blocks consumed by the ProcessBlock calls of this packet: history entries + xPow
+            // (aec_core.c:1209-1216).  The spectra of all blocks (at most 4) are requested together; xPow is a
+            // recurrence over the blocks and stays in registers between them.
+            float sp[4][3], spw[4][3];  // row elements lane, lane + 64, lane + 128 (the last for lanes 0, 1): the copy
+            float xi_b[4], xr64[4], xi64[4];  // imaginary part of bin `lane`; bin 64 (every lane reads the same two words)
+            float xp0 = F.xpow[lane], xp1 = F.xpow[lane == 0 ? kAecPart : 0];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (k >= pl.n_blk) break;
                 const float *src = F.ring + (size_t)pl.blk[k].far_slot * 130;
                 const float *srcw = F.ring_w + (size_t)pl.blk[k].far_slot * 130;
-                const int hs = pl.blk[k].hist_n % kAecHist;
-                for (int i = lane; i < 130; i += 64) {
-                    F.hist[hs * 130 + i] = src[i];
-                    F.hist_w[hs * 130 + i] = srcw[i];
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const int i = lane + 64 * j < 130 ? lane + 64 * j : 0;
+                    sp[k][j] = src[i];
+                    spw[k][j] = srcw[i];
                 }
-                for (int b = lane; b < kAecPart1; b += 64) {
-                    const float xr = src[b], xi = src[kAecPart1 + b];
-                    const float far_spectrum = (xr * xr) + (xi * xi);
-                    const float xp = 0.9f * F.xpow[b] + gpow1np * far_spectrum;
-                    F.xpow[b] = xp;
-                    F.xpow_seq[hs * BP + b] = xp;
-                }
-                wave_sync();
+                xi_b[k] = src[kAecPart1 + lane];
+                xr64[k] = src[kAecPart];
+                xi64[k] = src[kAecPart1 + kAecPart];
             }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (k >= pl.n_blk) break;
+                const int hs = pl.blk[k].hist_n % kAecHist;
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const int i = lane + 64 * j;
+                    if (i < 130) {
+                        F.hist[hs * 130 + i] = sp[k][j];
+                        F.hist_w[hs * 130 + i] = spw[k][j];
+                    }
+                }
+                {
+                    const float xr = sp[k][0], xi = xi_b[k];
+                    const float far_spectrum = (xr * xr) + (xi * xi);
+                    xp0 = 0.9f * xp0 + gpow1np * far_spectrum;
+                    F.xpow_seq[hs * BP + lane] = xp0;
+                }
+                {
+                    const float far_spectrum = (xr64[k] * xr64[k]) + (xi64[k] * xi64[k]);
+                    xp1 = 0.9f * xp1 + gpow1np * far_spectrum;  // every lane, same value
+                    if (lane == 0) F.xpow_seq[hs * BP + kAecPart] = xp1;
+                }
+            }
+            F.xpow[lane] = xp0;
+            if (lane == 0) F.xpow[kAecPart] = xp1;
+            wave_sync();
         }
     }
 }
