@@ -133,14 +133,32 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F, const float *
         if (pl.has_far) {
             // WebRtc_WriteBuffer(far_pre_buf, farend): channel 0 of the far-end packet (src/webrtc.c:430)
             const int16_t *src = far_pcm + (size_t)p * far_packet_stride;
-            for (int i = lane; i < pl.far_n; i += 64) F.pre[(pl.pre_wr + i) % kAecPreLen] = (float)src[i * chn];
+            {
+                // at most 160 samples (20 ms at 8 kHz): three per lane, fetched together (clamped index, guarded store)
+                int16_t s3[3];
+#pragma unroll
+                for (int j = 0; j < 3; j++) s3[j] = src[(lane + 64 * j < pl.far_n ? lane + 64 * j : 0) * chn];
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                    if (lane + 64 * j < pl.far_n) F.pre[(pl.pre_wr + lane + 64 * j) % kAecPreLen] = (float)s3[j];
+            }
             wave_sync();
-            for (int q = 0; q < pl.n_part; q++) {
+            // the [prev64 | new64] windows of all partitions of this packet (at most 4), requested together
+            float win[4][2];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (q >= pl.n_part) break;
+#pragma unroll
+                for (int h = 0; h < 2; h++) win[q][h] = F.pre[(pl.part[q].pre_rd + lane + 64 * h) % kAecPreLen];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (q >= pl.n_part) break;
                 // BufferFarendPartition (aec_core.c:1690-1707): plain and windowed transform of [prev64 | new64]
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     const int i = lane + 64 * h;
-                    const float v = F.pre[(pl.part[q].pre_rd + i) % kAecPreLen];
+                    const float v = win[q][h];
                     fa[0][i] = v;
                     fa[1][i] = v * (h == 0 ? K.hanning[lane] : K.hanning[kAecPart - lane]);
                 }
