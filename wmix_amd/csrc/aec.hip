@@ -636,7 +636,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
     {
         const float *mine = &AEC_ST(lane == 1 ? AS_SE : AS_SD);
         float acc = 0.f;
-#pragma unroll 1
+#pragma unroll
         for (int i = 0; i < kAecPart; i += 8) {
             const float4 a = *reinterpret_cast<const float4 *>(mine + i), b = *reinterpret_cast<const float4 *>(mine + i + 4);
             acc += a.x;
@@ -678,11 +678,18 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
         t1[b] = (sxd_r * sxd_r + sxd_i * sxd_i) / (AEC_ST(AS_SX + b) * AEC_ST(AS_SD + b) + 1e-10f);  // cohxd
     }
     wave_sync();
-    float hNlXdAvg = 0.f, hNlDeAvg = 0.f;
-    for (int i = minPref; i < prefSize + minPref; i++) hNlXdAvg += t1[i];
+    // the two band averages as parallel lane chains (lane 0: cohxd, lane 1: cohde), index order each
+    float hNlXdAvg, hNlDeAvg;
+    {
+        const float *mine = lane == 1 ? t0 : t1;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = minPref; i < prefSize + minPref; i++) acc += mine[i];
+        hNlXdAvg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 0));
+        hNlDeAvg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 1));
+    }
     hNlXdAvg /= prefSize;
     hNlXdAvg = 1 - hNlXdAvg;
-    for (int i = minPref; i < prefSize + minPref; i++) hNlDeAvg += t0[i];
     hNlDeAvg /= prefSize;
     float hNlXdAvgMin = AEC_ST(AS_HNLXDAVGMIN), hNlFbMin = AEC_ST(AS_HNLFBMIN), hNlFbLocalMin = AEC_ST(AS_HNLFBLOCALMIN);
     float overDrive = AEC_ST(AS_OVERDRIVE), overDriveSm = AEC_ST(AS_OVERDRIVESM);
