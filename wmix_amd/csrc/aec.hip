@@ -448,16 +448,18 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
             er *= mu;
             ei *= mu;
         };
+        // bin 64 (read by every lane from the same LDS words) is scaled by every lane alongside its own bin: two independent
+        // dependency chains in one instruction stream instead of a second, serial pass under `if (lane == 0)`
+        const float xp64 = uniform_ld(F.xpow_seq + (n % kAecHist) * BP + kAecPart);
         scale_err(xpow_lane, efr, efi);
-        if (lane == 0) scale_err(uniform_ld(F.xpow_seq + (n % kAecHist) * BP + kAecPart), ef64r, ef64i);
+        scale_err(xp64, ef64r, ef64i);
     }
     wave_sync();  // rows 2, 3 are read; the filter update overwrites the work rows
     AEC_RELANE();
     // ---- FilterAdaptation (aec_core.c:222-270): conj(X_{n-p}) * ef -> time domain, zero the second half,
     //      back to frequency, add to partition p.  Four groups of 16 lanes; partitions 0..7 first (two per group),
     //      then 8..11, through the same eight work rows.
-    const float e64r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ef64r), 0));
-    const float e64i = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ef64i), 0));
+    const float e64r = ef64r, e64i = ef64i;  // wave-uniform already
     // windowed far spectrum of the NLP (bins 0..63 of the block consumed delayIdx blocks ago): requested while the second
     // half of the filter update runs; PartitionDelay below may still move delayIdx (every 10 * mult blocks)
     const int delayIdx0 = Si[AS_DELAYIDX];
