@@ -616,20 +616,39 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
         }
     }
     wave_sync();
-    // SmoothedPSD (aec_core.c:333-386)
-    for (int b = lane; b < kAecPart1; b += 64) {
-        const float dr = dw[b], di = dw[66 + b], er = ew[b], ei = ew[66 + b];
-        const float xr = xw[b], xi = xw[66 + b];
-        const float sd = gc0 * AEC_ST(AS_SD + b) + gc1 * (dr * dr + di * di);
-        const float se = gc0 * AEC_ST(AS_SE + b) + gc1 * (er * er + ei * ei);
-        const float xx = xr * xr + xi * xi;
-        AEC_ST(AS_SX + b) = gc0 * AEC_ST(AS_SX + b) + gc1 * (xx > 15.f ? xx : 15.f);
-        AEC_ST(AS_SD + b) = sd;
-        AEC_ST(AS_SE + b) = se;
-        AEC_ST(AS_SDE_RE + b) = gc0 * AEC_ST(AS_SDE_RE + b) + gc1 * (dr * er + di * ei);
-        AEC_ST(AS_SDE_IM + b) = gc0 * AEC_ST(AS_SDE_IM + b) + gc1 * (dr * ei - di * er);
-        AEC_ST(AS_SXD_RE + b) = gc0 * AEC_ST(AS_SXD_RE + b) + gc1 * (dr * xr + di * xi);
-        AEC_ST(AS_SXD_IM + b) = gc0 * AEC_ST(AS_SXD_IM + b) + gc1 * (dr * xi - di * xr);
+    // SmoothedPSD (aec_core.c:333-386).  Bin `lane` and bin 64 go through the same straight-line code (every lane forms bin
+    // 64 from the same LDS words, lane 0 stores it): two independent dependency chains for the scheduler to interleave,
+    // instead of a second loop iteration that runs for lane 0 alone.
+    {
+        struct Psd {
+            float sd, se, sx, sde_r, sde_i, sxd_r, sxd_i;
+        };
+        auto psd = [&](int b) {
+            const float dr = dw[b], di = dw[66 + b], er = ew[b], ei = ew[66 + b];
+            const float xr = xw[b], xi = xw[66 + b];
+            Psd r;
+            r.sd = gc0 * AEC_ST(AS_SD + b) + gc1 * (dr * dr + di * di);
+            r.se = gc0 * AEC_ST(AS_SE + b) + gc1 * (er * er + ei * ei);
+            const float xx = xr * xr + xi * xi;
+            r.sx = gc0 * AEC_ST(AS_SX + b) + gc1 * (xx > 15.f ? xx : 15.f);
+            r.sde_r = gc0 * AEC_ST(AS_SDE_RE + b) + gc1 * (dr * er + di * ei);
+            r.sde_i = gc0 * AEC_ST(AS_SDE_IM + b) + gc1 * (dr * ei - di * er);
+            r.sxd_r = gc0 * AEC_ST(AS_SXD_RE + b) + gc1 * (dr * xr + di * xi);
+            r.sxd_i = gc0 * AEC_ST(AS_SXD_IM + b) + gc1 * (dr * xi - di * xr);
+            return r;
+        };
+        auto put = [&](int b, const Psd &r) {
+            AEC_ST(AS_SX + b) = r.sx;
+            AEC_ST(AS_SD + b) = r.sd;
+            AEC_ST(AS_SE + b) = r.se;
+            AEC_ST(AS_SDE_RE + b) = r.sde_r;
+            AEC_ST(AS_SDE_IM + b) = r.sde_i;
+            AEC_ST(AS_SXD_RE + b) = r.sxd_r;
+            AEC_ST(AS_SXD_IM + b) = r.sxd_i;
+        };
+        const Psd a = psd(lane), c = psd(kAecPart);
+        put(lane, a);
+        if (lane == 0) put(kAecPart, c);
     }
     wave_sync();
     AEC_PROF(5);
