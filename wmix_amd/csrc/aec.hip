@@ -353,28 +353,40 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
         dwr = dwb.x, dwi = dwb.y, dw64 = W.fa[1][0] - W.fa[1][1];  // bin 64 = a[0] - a[1] (used by lane 0)
         dfr = dfb.x, dfi = dfb.y, df64 = W.fa[0][0] - W.fa[0][1];
     }
-    // ---- near power, noise floor (aec_core.c:1197-1243)
-    for (int b = lane; b < kAecPart1; b += 64) {
-        const float re = b == kAecPart ? df64 : dfr, im = b == kAecPart ? 0.f : dfi;
-        const float ns = re * re + im * im;
-        const float dpow = 0.9f * AEC_ST(AS_DPOW + b) + 0.1f * ns;
-        AEC_ST(AS_DPOW + b) = dpow;
-        float dmin = AEC_ST(AS_DMIN + b);
-        if (bp.flags & kAecFlagNoiseMin) {
-            if (dpow < dmin)
-                dmin = (dpow + 0.1f * (dmin - dpow)) * 1.0002f;
-            else
-                dmin *= 1.0002f;
-            AEC_ST(AS_DMIN + b) = dmin;
-        }
-        if (bp.flags & kAecFlagNoiseInit) {
-            float dinit = AEC_ST(AS_DINIT + b);
-            if (dmin > dinit)
-                dinit = 0.999f * dinit + 0.001f * dmin;
-            else
-                dinit = dmin;
-            AEC_ST(AS_DINIT + b) = dinit;
-        }
+    // ---- near power, noise floor (aec_core.c:1197-1243); bin `lane` and bin 64 side by side (see SmoothedPSD below)
+    {
+        struct Pw {
+            float dpow, dmin, dinit;
+        };
+        auto power = [&](int b, float re, float im) {
+            Pw r;
+            const float ns = re * re + im * im;
+            r.dpow = 0.9f * AEC_ST(AS_DPOW + b) + 0.1f * ns;
+            r.dmin = AEC_ST(AS_DMIN + b);
+            if (bp.flags & kAecFlagNoiseMin) {
+                if (r.dpow < r.dmin)
+                    r.dmin = (r.dpow + 0.1f * (r.dmin - r.dpow)) * 1.0002f;
+                else
+                    r.dmin *= 1.0002f;
+            }
+            r.dinit = 0.f;
+            if (bp.flags & kAecFlagNoiseInit) {
+                r.dinit = AEC_ST(AS_DINIT + b);
+                if (r.dmin > r.dinit)
+                    r.dinit = 0.999f * r.dinit + 0.001f * r.dmin;
+                else
+                    r.dinit = r.dmin;
+            }
+            return r;
+        };
+        auto put = [&](int b, const Pw &r) {
+            AEC_ST(AS_DPOW + b) = r.dpow;
+            if (bp.flags & kAecFlagNoiseMin) AEC_ST(AS_DMIN + b) = r.dmin;
+            if (bp.flags & kAecFlagNoiseInit) AEC_ST(AS_DINIT + b) = r.dinit;
+        };
+        const Pw a = power(lane, dfr, dfi), c = power(kAecPart, df64, 0.f);
+        put(lane, a);
+        if (lane == 0) put(kAecPart, c);
     }
     // ---- FilterFar (aec_core.c:148-170): y = sum_p X_{n-p} * W_p, partitions in order; lane 0 also does bin 64
     {
@@ -687,16 +699,31 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
     }
     AEC_PROF(6);
     AEC_RELANE();
-    // coherences (aec_core.c:440-449)
-    for (int b = lane; b < kAecPart1; b += 64) {
-        if (diverge) {
-            ew[b] = dw[b];
-            ew[66 + b] = dw[66 + b];
+    // coherences (aec_core.c:440-449), bin `lane` and bin 64 side by side
+    {
+        auto coh = [&](int b, float &cde, float &cxd) {
+            const float sde_r = AEC_ST(AS_SDE_RE + b), sde_i = AEC_ST(AS_SDE_IM + b), sxd_r = AEC_ST(AS_SXD_RE + b),
+                        sxd_i = AEC_ST(AS_SXD_IM + b);
+            cde = (sde_r * sde_r + sde_i * sde_i) / (AEC_ST(AS_SD + b) * AEC_ST(AS_SE + b) + 1e-10f);
+            cxd = (sxd_r * sxd_r + sxd_i * sxd_i) / (AEC_ST(AS_SX + b) * AEC_ST(AS_SD + b) + 1e-10f);
+        };
+        float a0, a1, c0, c1;
+        coh(lane, a0, a1);
+        coh(kAecPart, c0, c1);
+        if (diverge) {  // divergeState: the error spectrum is replaced by the near spectrum (aec_core.c:959-962)
+            ew[lane] = dw[lane];
+            ew[66 + lane] = dw[66 + lane];
         }
-        const float sde_r = AEC_ST(AS_SDE_RE + b), sde_i = AEC_ST(AS_SDE_IM + b), sxd_r = AEC_ST(AS_SXD_RE + b),
-                    sxd_i = AEC_ST(AS_SXD_IM + b);
-        t0[b] = (sde_r * sde_r + sde_i * sde_i) / (AEC_ST(AS_SD + b) * AEC_ST(AS_SE + b) + 1e-10f);  // cohde
-        t1[b] = (sxd_r * sxd_r + sxd_i * sxd_i) / (AEC_ST(AS_SX + b) * AEC_ST(AS_SD + b) + 1e-10f);  // cohxd
+        t0[lane] = a0;
+        t1[lane] = a1;
+        if (lane == 0) {
+            if (diverge) {
+                ew[kAecPart] = dw[kAecPart];
+                ew[66 + kAecPart] = dw[66 + kAecPart];
+            }
+            t0[kAecPart] = c0;
+            t1[kAecPart] = c1;
+        }
     }
     wave_sync();
     // the two band averages as parallel lane chains (lane 0: cohxd, lane 1: cohde), index order each
