@@ -252,22 +252,28 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         // ---- spectrum, magnitude, log-magnitude (FFT() ns_core.c:886-911; :228, :1095)
 #pragma unroll
         for (int k = 0; k < NI; k++) {
-            const int b = lane + 64 * k;
-            if (b >= M) continue;
-            float re, im = 0.f, mg;
-            if (b == 0) {
-                re = W.fa[0];
-                mg = fabsf(re) + 1.f;
-            } else if (b == M - 1) {
+            // No lane-dependent branch around the arithmetic: groups that are full (a compile-time fact) run straight-line,
+            // and in the last group (bin M - 1 alone) every lane evaluates that bin and lane 0 stores it -- the log chains of
+            // the groups then sit in one basic block and overlap, instead of one serial pass for lane 0.
+            const int b0 = lane + 64 * k;
+            const bool ok = (64 * k + 63 < M) || b0 < M;
+            const int b = ok ? b0 : M - 1;
+            float re, im, mg;
+            if (k == NI - 1) {  // only bin M - 1 (Nyquist): real
                 re = W.fa[1];
+                im = 0.f;
                 mg = fabsf(re) + 1.f;
             } else {
-                re = W.fa[2 * b];
-                im = W.fa[2 * b + 1];
-                mg = sqrtf(re * re + im * im) + 1.f;
+                const float a0 = W.fa[2 * b], a1 = W.fa[2 * b + 1];
+                const bool dc = k == 0 && b == 0;  // bin 0 is real; fa[1] holds the Nyquist value
+                re = a0;
+                im = dc ? 0.f : a1;
+                const float g = sqrtf(re * re + im * im) + 1.f;
+                mg = dc ? fabsf(re) + 1.f : g;
             }
             const float lm = fast_log_ge1(mg, K.lm);
             const float pz = pf_pause[k];
+            if (!ok) continue;
             W.re[b] = re;
             W.im[b] = im;
             W.magn[b] = mg;
