@@ -202,14 +202,15 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
     float pf_quant[NI], pf_dens[NI][3], pf_lq[NI][3], pf_pause[NI];
 #pragma unroll
     for (int k = 0; k < NI; k++) {
-        const int b = lane + 64 * k;
-        const bool ok = b < M;
-        pf_pause[k] = ok ? st[Y::MAGN_AVG_PAUSE + b] : 0.f;
-        pf_quant[k] = ok ? st[Y::QUANTILE + b] : 0.f;
+        // unconditional loads: lanes past the last bin fetch bin M - 1 again (same value in every lane of that group), so
+        // nothing below needs a lane test around its arithmetic
+        const int b = lane + 64 * k < M ? lane + 64 * k : M - 1;
+        pf_pause[k] = st[Y::MAGN_AVG_PAUSE + b];
+        pf_quant[k] = st[Y::QUANTILE + b];
 #pragma unroll
         for (int q = 0; q < 3; q++) {
-            pf_dens[k][q] = ok ? st[Y::DENSITY + q * Y::MP + b] : 0.f;
-            pf_lq[k][q] = ok ? st[Y::LQUANTILE + q * Y::MP + b] : 0.f;
+            pf_dens[k][q] = st[Y::DENSITY + q * Y::MP + b];
+            pf_lq[k][q] = st[Y::LQUANTILE + q * Y::MP + b];
         }
     }
     wave_sync();  // other lanes' stores below overwrite what this lane just loaded: keep the compiler from interleaving them
@@ -326,17 +327,17 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         float pf_nprev[NI], pf_mprev[NI], pf_smooth[NI], pf_lrt[NI];
 #pragma unroll
         for (int k = 0; k < NI; k++) {
-            const int b = lane + 64 * k;
-            const bool ok = b < M;
-            pf_nprev[k] = ok ? st[Y::NOISE_PREV + b] : 0.f;
-            pf_mprev[k] = ok ? st[Y::MAGN_PREV + b] : 0.f;
-            pf_smooth[k] = ok ? st[Y::SMOOTH + b] : 0.f;
-            pf_lrt[k] = ok ? st[Y::LOG_LRT + b] : 0.f;
+            const int b = lane + 64 * k < M ? lane + 64 * k : M - 1;
+            pf_nprev[k] = st[Y::NOISE_PREV + b];
+            pf_mprev[k] = st[Y::MAGN_PREV + b];
+            pf_smooth[k] = st[Y::SMOOTH + b];
+            pf_lrt[k] = st[Y::LOG_LRT + b];
         }
 #pragma unroll
         for (int k = 0; k < NI; k++) {
-            const int b = lane + 64 * k;
-            if (b >= M) continue;
+            const int b0 = lane + 64 * k;
+            const bool ok = (64 * k + 63 < M) || b0 < M;  // compile-time true except in the last group (bin M - 1 alone)
+            const int b = ok ? b0 : M - 1;
             const float lm = W.lmagn[b];
             float quant = pf_quant[k], lq = 0.f;
 #pragma unroll
@@ -356,14 +357,16 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
                     lq -= (1.f - 0.25f) * delta / c1;
                 if (fabsf(lm - lq) < 0.01f) {
                     dens = (cf * dens + 1.f / (2.f * 0.01f)) / c1;
-                    st[Y::DENSITY + q * Y::MP + b] = dens;
+                    if (ok) st[Y::DENSITY + q * Y::MP + b] = dens;
                 }
-                st[Y::LQUANTILE + q * Y::MP + b] = lq;
+                if (ok) st[Y::LQUANTILE + q * Y::MP + b] = lq;
                 if (cnt >= kStartupLong && updates >= kStartupLong) quant = fast_exp(lq, K.lm);
             }
             if (updates < kStartupLong) quant = fast_exp(lq, K.lm);  // lq of the last estimator
-            st[Y::QUANTILE + b] = quant;
-            W.noise[b] = quant;
+            if (ok) {
+                st[Y::QUANTILE + b] = quant;
+                W.noise[b] = quant;
+            }
         }
         sti[Y::S_COUNTER + 0] = cnt0 >= kStartupLong ? 1 : cnt0 + 1;
         sti[Y::S_COUNTER + 1] = cnt1 >= kStartupLong ? 1 : cnt1 + 1;
