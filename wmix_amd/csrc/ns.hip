@@ -432,18 +432,20 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         const float avg_magn = sum_magn / ((float)M);
 #pragma unroll
         for (int k = 0; k < NI; k++) {
-            const int b = lane + 64 * k;
-            if (b >= M) continue;
+            const int b0 = lane + 64 * k;
+            const bool ok = (64 * k + 63 < M) || b0 < M;  // see the noise estimation loop
+            const int b = ok ? b0 : M - 1;
             const float mg = W.magn[b], nz = W.noise[b];
             const float np = pf_nprev[k];
             const float pe = pf_mprev[k] / (np + 0.0001f) * pf_smooth[k];
             float sq = 0.f;
             if (mg > nz) sq = mg / (nz + 0.0001f) - 1.f;
+            const float dm = mg - avg_magn, dp = W.pause[b] - avg_pause;
+            if (!ok) continue;
             W.nprev[b] = np;
             W.prev[b] = pe;
             W.snrq[b] = sq;
             W.snrp[b] = 0.98f * pe + (1.f - 0.98f) * sq;
-            const float dm = mg - avg_magn, dp = W.pause[b] - avg_pause;
             W.r0[b] = dm * dp;
             W.r2[b] = dp * dp;
             W.lmagn[b] = dm * dm;  // lmagn is dead from here on
@@ -619,14 +621,16 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         // ---- SpeechNoiseProb (ns_core.c:642-749)
 #pragma unroll
         for (int k = 0; k < NI; k++) {
-            const int b = lane + 64 * k;
-            if (b >= M) continue;
+            const int b0 = lane + 64 * k;
+            const bool ok = (64 * k + 63 < M) || b0 < M;  // see the noise estimation loop
+            const int b = ok ? b0 : M - 1;
             const float sp = W.snrp[b];
             const float t1 = 1.f + 2.f * sp;
             const float t2 = 2.f * sp / (t1 + 0.0001f);
             const float bessel = (W.snrq[b] + 1.f) * t2;
             float v = pf_lrt[k];
             v += 0.5f * (bessel - fast_log_ge1(t1, K.lm) - v);
+            if (!ok) continue;
             st[Y::LOG_LRT + b] = v;
             W.r0[b] = v;
         }
@@ -659,11 +663,15 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             st[Y::S_PRIOR] = prior;
         }
         const float gain_prior = (1.f - prior) / (prior + 0.0001f);
-#pragma unroll 1
-        for (int b = lane; b < M; b += 64) {
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int b0 = lane + 64 * k;
+            const bool ok = (64 * k + 63 < M) || b0 < M;
+            const int b = ok ? b0 : M - 1;
             float inv = fast_exp(-W.r0[b], K.lm);
             inv = gain_prior * inv;
-            W.sprob[b] = 1.f / (1.f + inv);
+            const float spb = 1.f / (1.f + inv);
+            if (ok) W.sprob[b] = spb;
         }
         wave_sync();
         NS_PROF(8);
