@@ -678,8 +678,11 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         NS_RELANE();
         // ---- UpdateNoiseEstimate (ns_core.c:800-846): bin i starts from the gamma chosen at bin i-1.
         //      Then Process: initMagnEst, DD Wiener filter + flooring / start-up blend (ns_core.c:1277-1315), IFFT packing.
-#pragma unroll 1
-        for (int b = lane; b < M; b += 64) {
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int b0 = lane + 64 * k;
+            const bool ok = (64 * k + 63 < M) || b0 < M;  // see the noise estimation loop
+            const int b = ok ? b0 : M - 1;
             const float ps = W.sprob[b], pn = 1.f - ps, mg = W.magn[b], np = W.nprev[b];
             float gamma_old = 0.9f;
             if (b > 0 && W.sprob[b - 1] > 0.2f) gamma_old = 0.99f;
@@ -689,7 +692,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             if (ps < 0.2f) {
                 float pz = W.pause[b];
                 pz += 0.05f * (mg - pz);
-                st[Y::MAGN_AVG_PAUSE + b] = pz;
+                if (ok) st[Y::MAGN_AVG_PAUSE + b] = pz;
             }
             float nz;
             if (gamma == gamma_old) {
@@ -702,7 +705,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             float init_est = 0.f;
             if (startup) {
                 init_est = st[Y::INIT_MAGN + b] + mg;
-                st[Y::INIT_MAGN + b] = init_est;
+                if (ok) st[Y::INIT_MAGN + b] = init_est;
             }
             float cur = 0.f;
             if (mg > nz) cur = mg / (nz + 0.0001f) - 1.f;
@@ -720,11 +723,12 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
                 f += ft;
                 f /= (float)(kStartupShort);
             }
+            const float re = W.re[b] * f, im = W.im[b] * f;
+            if (!ok) continue;
             st[Y::SMOOTH + b] = f;
             st[Y::MAGN_PREV + b] = mg;
             st[Y::NOISE_PREV + b] = nz;
             W.snrp[b] = f;  // the filter, for the high-band gain
-            const float re = W.re[b] * f, im = W.im[b] * f;
             if (b == 0)
                 W.fa[0] = re;
             else if (b == M - 1)
