@@ -101,7 +101,7 @@ __device__ __forceinline__ float sum_range(const float *x, int lo, int hi, int l
         int i = lo;
 #pragma unroll 1
         for (; i < hi && (i & 3); i++) acc += x[i];
-#pragma unroll 1
+#pragma unroll 4
         for (; i + 8 <= hi; i += 8) {
             const float4 a = *reinterpret_cast<const float4 *>(x + i), b = *reinterpret_cast<const float4 *>(x + i + 4);
             acc += a.x;
@@ -129,7 +129,7 @@ __device__ __forceinline__ float sum_range(const float *x, int lo, int hi, int l
 template <int MP4>
 __device__ __forceinline__ float sum_lanes(const float *mine) {
     float acc = 0.f;
-#pragma unroll 1
+#pragma unroll 4
     for (int i = 0; i < MP4; i += 2) {
         const float4 a = *reinterpret_cast<const float4 *>(mine + 4 * i);
         acc += a.x;
