@@ -13,6 +13,10 @@ void orc_libm_exp(const float *x, float *y, size_t n)
 {
     for (size_t i = 0; i < n; i++) y[i] = (float)exp((double)x[i]);
 }
+void orc_libm_tanh(const float *x, float *y, size_t n)
+{
+    for (size_t i = 0; i < n; i++) y[i] = (float)tanh((double)x[i]);
+}
 /* aec_core.c:278 calls the float routine powf directly */
 void orc_libm_powf(const float *x, const float *e, float *y, size_t n)
 {

@@ -48,6 +48,22 @@ def test_exp_sweep(wmx, oracle_port):
     assert np.array_equal(got.view(np.uint32)[~nan], want.view(np.uint32)[~nan])
 
 
+def test_tanh_sweep(wmx, oracle_port):
+    """the three indicator arguments width * (feature - threshold) of ns_core.c:700-731: a few units either side of 0,
+    dense next to 0 (tanh x ~ x) and in the saturating tail; plus the high-band gain argument and specials"""
+    rng = np.random.default_rng(14)
+    x = np.concatenate([
+        rng.random(4_000_000) * 16 - 8, rng.random(2_000_000) * 60 - 30, (rng.random(2_000_000) * 2 - 1) * 1e-2,
+        (rng.random(1_000_000) * 2 - 1) * 1e-6, np.arange(-25, 25, 1 / 64), 10.0 ** np.arange(-40, 3, 0.5),
+        np.array([0.0, -0.0, 0.0054, 0.0055, 19.9, 20.0, 20.1, 88, -88, 1e30, -1e30, np.inf, -np.inf, np.nan]),
+    ]).astype(np.float32)
+    with np.errstate(all="ignore"):
+        got, want = _product(wmx, 2, x), _run(oracle_port.orc_libm_tanh, x)
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.array_equal(got.view(np.uint32)[~nan], want.view(np.uint32)[~nan])
+
+
 def test_pow_sweep(wmx, oracle_port):
     """The AEC's hNl ^ (overDriveSm * curve): base in (0, 1], exponent in [1, 30].  The table-driven power must equal
     the double-precision pow rounded to float everywhere; against glibc's powf (which is not correctly rounded) it may

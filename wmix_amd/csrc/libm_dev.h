@@ -33,9 +33,16 @@ __device__ __noinline__ static float div_pow_d(float num, float base, float e) {
 //   exp(x):          k = rint(x * 64/ln2), r = x - k*ln2/64 (two-part constant), |r| <= 0.0055;
 //                    e^x = 2^(k>>6) * T[k&63] * (1 + expm1(r)), expm1 by Taylor to r^6 (r^7/5040 < 2^-63).
 // Tables (NsLibmTables, built by the host with the host libm) live in LDS with the other per-block constants.
+//   tanh(x):         odd, so for a = |x|:  tanh a = E / (E + 2) with E = expm1(2a) = 2^q * T[j] * (1 + p) - 1 from the
+//                    exp reduction of 2a (k = 64 q + j).  For q = 0 the subtraction would cancel against the rounding
+//                    error of T[j], so E = Tm1[j] + T[j] * p with Tm1[j] = RN(expm1(j ln2/64)) from the host's libm
+//                    (j = 0: E = p, full relative accuracy next to 0); for q >= 1, E >= 1 and the subtraction is
+//                    harmless.  One correctly rounded fp64 division; 2a >= 40 returns 1 (tanh differs from 1 by
+//                    < 2^-56 there).  The NS calls it once per frame (three indicator arguments, ns_core.c:700-731).
 struct NsLibmTables {
     double2 logtab[128];  // (RN(1/c), RN(log c)), c = 1 + i/128
     double exptab[64];    // 2^(j/64)
+    double expm1tab[64];  // 2^(j/64) - 1, rounded from the exact value
 };
 constexpr int kNsLibmWords = sizeof(NsLibmTables) / 4;
 
@@ -45,7 +52,10 @@ inline void ns_libm_tables(NsLibmTables *t) {
         t->logtab[i].x = 1.0 / c;
         t->logtab[i].y = log(c);
     }
-    for (int j = 0; j < 64; j++) t->exptab[j] = exp2(j / 64.0);
+    for (int j = 0; j < 64; j++) {
+        t->exptab[j] = exp2(j / 64.0);
+        t->expm1tab[j] = expm1(j * 0.010830424696249145);  // j * ln2 / 64 (the product is exact enough: 2^-60 relative)
+    }
 }
 
 __host__ __device__ __forceinline__ float fast_log_ge1(float x, const NsLibmTables &M) {
@@ -97,6 +107,41 @@ __host__ __device__ __forceinline__ float fast_exp(float xf, const NsLibmTables 
     double z;
     __builtin_memcpy(&z, &bits, 8);
     return (float)z;
+}
+
+__host__ __device__ __forceinline__ float fast_tanh(float xf, const NsLibmTables &M) {
+    const double a2 = 2.0 * fabs((double)xf);
+    if (!(a2 < 40.0)) {
+        if (a2 != a2) return (float)tanh((double)xf);  // NaN: the library routine
+        return xf < 0.f ? -1.0f : 1.0f;
+    }
+    constexpr double kInv = 0x1.71547652b82fep+6;                              // 64 / ln2
+    constexpr double kHi = 0x1.62e42fefa0000p-7, kLo = 0x1.cf79abc9e3b3ap-46;  // ln2 / 64 in two parts
+    const double kd = rint(a2 * kInv);
+    const int k = (int)kd;  // 0 .. 3694
+    double r = fma(-kd, kHi, a2);
+    r = fma(-kd, kLo, r);
+    double p = fma(r, 1.0 / 720.0, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = p * r;  // expm1(r)
+    const double t = M.exptab[k & 63];
+    double E;
+    if ((k >> 6) == 0) {
+        E = fma(t, p, M.expm1tab[k & 63]);
+    } else {
+        const double y = fma(t, p, t);
+        long long bits;
+        __builtin_memcpy(&bits, &y, 8);
+        bits += (long long)(k >> 6) << 52;
+        double z;
+        __builtin_memcpy(&z, &bits, 8);
+        E = z - 1.0;
+    }
+    const double th = E / (E + 2.0);
+    return copysignf((float)th, xf);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

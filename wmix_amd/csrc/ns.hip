@@ -146,6 +146,8 @@ __device__ __forceinline__ float sum_lanes(const float *mine) {
     }
     return acc;
 }
+// second call site of the 32 kHz path: kept out of line so that its fp64 temporaries do not raise the kernel's pressure
+__device__ __noinline__ static float tanh_call(float x, const NsLibmTables *m) { return fast_tanh(x, *m); }
 __device__ __forceinline__ float lane_value(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
 
 template <int L, bool ORDERED, int CHN>
@@ -652,7 +654,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             if (feat_diff < thr_diff) width = 2.f * 4.0f;
             const float a2 = width * (feat_diff - thr_diff);
             // the three indicator tanh's are wave-uniform scalars: evaluate them in lanes 0..2 of one call
-            const float th = tanh_d(lane == 1 ? a1 : (lane == 2 ? a2 : a0));
+            const float th = fast_tanh(lane == 1 ? a1 : (lane == 2 ? a2 : a0), K.lm);
             const float ind0 = 0.5f * (lane_value(th, 0) + 1.f);
             const float ind1 = 0.5f * (lane_value(th, 1) + 1.f);
             const float ind2 = 0.5f * (lane_value(th, 2) + 1.f);
@@ -783,7 +785,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             float avg_gain = sum_range<ORDERED>(W.snrp, M - D - 1, M - 1, lane);
             avg_gain = avg_gain / ((float)D);
             const float t = 2.f * avg_prob - 1.f;
-            const float gain_mod = 0.5f * (1.f + tanh_d(1.0f * t));
+            const float gain_mod = 0.5f * (1.f + tanh_call(1.0f * t, &K.lm));
             float g = 0.5f * gain_mod + 0.5f * avg_gain;
             if (avg_prob >= 0.5f) g = 0.25f * gain_mod + 0.75f * avg_gain;
             g = g * 1.0f;
@@ -1093,7 +1095,7 @@ int wmx_ns_process(wmx_ns *h, const int16_t *d_in, int16_t *d_out, int n_packets
 }  // extern "C"
 
 // Host-side evaluation of the NS's table-driven log / exp (libm_dev.h) -- the same source the kernels compile, run on
-// the CPU so that the `-m "not gpu"` tests can sweep millions of arguments against glibc.  kind 0: log (x >= 1), 1: exp.
+// the CPU so that the `-m "not gpu"` tests can sweep millions of arguments against glibc.  kind 0: log (x >= 1), 1: exp, 2: tanh.
 extern "C" int wmx_debug_ns_libm(int kind, const float *x, float *y, size_t n) {
     static wmx::NsLibmTables tab;
     static bool init = false;
@@ -1101,7 +1103,8 @@ extern "C" int wmx_debug_ns_libm(int kind, const float *x, float *y, size_t n) {
         wmx::ns_libm_tables(&tab);
         init = true;
     }
-    if (!x || !y || kind < 0 || kind > 1) return WMX_EINVAL;
-    for (size_t i = 0; i < n; i++) y[i] = kind == 0 ? wmx::fast_log_ge1(x[i], tab) : wmx::fast_exp(x[i], tab);
+    if (!x || !y || kind < 0 || kind > 2) return WMX_EINVAL;
+    for (size_t i = 0; i < n; i++)
+        y[i] = kind == 0 ? wmx::fast_log_ge1(x[i], tab) : (kind == 1 ? wmx::fast_exp(x[i], tab) : wmx::fast_tanh(x[i], tab));
     return 0;
 }
