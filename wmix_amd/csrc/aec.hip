@@ -308,12 +308,12 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
     const float mu = MULT == 1 ? 0.6f : 0.5f, err_thr = MULT == 1 ? 2e-6f : 1.5e-6f;  // aec_core.c:1530-1538
     const float scale = 2.0f / 128;
     const int n = bp.hist_n;
-    int g = lane >> 4, gl = lane & 15;
+    int g = fft_group(lane), gl = fft_index(lane);
 #define AEC_RELANE()              \
     do {                          \
         lane = opaque_lane(lane); \
-        g = lane >> 4;            \
-        gl = lane & 15;           \
+        g = fft_group(lane);      \
+        gl = fft_index(lane);     \
     } while (0)
     // NLP scratch rows (free outside the filter update)
     float *xw = W.fa[1], *dw = W.fa[2], *ew = W.fa[3];  // re at [b], im at [66 + b]

@@ -2,14 +2,14 @@
 //
 // Same dataflow graph, same float operations per output element (bfly4 / bfly4_close / the rftfsub-rftbsub
 // pair formulas are shared with fft_ooura.h), hence the same bits; what changes is where the 64 complex
-// points live between the three radix-4 passes.  A group of 16 lanes -- one DPP row -- owns a transform,
-// 4 points per lane:
+// points live between the three radix-4 passes.  A group of 16 lanes (the lanes with the same lane % 4; l = lane / 4
+// below) owns a transform, 4 points per lane:
 //
 //     gather      lane l takes points rev4(l) + {0, 32, 16, 48}        (bit reversal fused, fft4g.c:693-790)
 //     pass 1      butterfly b = l           -> points 4l + e            (cft1st,  fft4g.c:1002-1104)
-//     transpose   lane bits 0-1 <-> e       (DPP quad_perm)            -> points 16(l/4) + l%4 + 4m
+//     transpose   bits 0-1 of l <-> e       (DPP row_ror)              -> points 16(l/4) + l%4 + 4m
 //     pass 2      butterfly b = l/4                                     (cftmdl,  fft4g.c:1107-1231)
-//     transpose   lane bits 2-3 <-> e       (DPP row_ror)              -> points l + 16m
+//     transpose   bits 2-3 of l <-> e       (v_permlane16/32_swap)     -> points l + 16m
 //     pass 3      closing radix-4, no twiddles                          (fft4g.c:913-934 / 963-984)
 //
 // so a transform costs no LDS round trip between passes; four transforms run side by side in a wave, and a
@@ -21,71 +21,62 @@
 
 namespace wmx {
 
-// Swap lane bit X of the 16-lane row with one element-index bit: lanes whose bit X is clear keep `lo` and receive
-// the partner's `lo` into `hi`; lanes whose bit is set keep `hi` and receive the partner's `hi` into `lo`.  The partner
-// is reached with quad_perm (X = 1, 2) or row_ror (X = 4, 8).
-// Measured on gfx950 (tools_dev/ubench/pk_rate.hip, ns of SIMD time per wave64 instruction at 4 waves/SIMD):
-// v_mov_b32_dpp 2.0, v_cndmask_b32_e64 with an SGPR-pair mask 2.1, v_add_f32 1.3, v_pk_add_f32 2.1 -- but any
-// v_cndmask_b32 that takes its mask from VCC (the e32 form the compiler prefers, and the only form that accepts a DPP
-// operand) 9.8.  So: lane bits 2 / 3 move with row_ror under a bank mask (a DPP bank is 4 lanes, so "bit 2 / bit 3 of
-// the lane" is a set of banks; only the receiving lanes are written, no select at all), lane bits 0 / 1 with a
-// quad_perm fetch followed by an SGPR-masked select, spelled in assembly so that it cannot become the VCC form.
+// Which lanes form a transform: the 16 lanes with the same lane % 4 (group g = lane & 3, index inside the transform
+// gl = lane >> 2), not a contiguous DPP row.  Bit k of gl is then lane bit k + 2, and every one of the four lane-bit <->
+// element-bit exchanges of the two transposes has a cheap form on gfx950:
+//     gl bit 0 / 1 = lane bit 2 / 3: the partner is 4 / 8 lanes away in the same DPP row: v_mov_b32_dpp row_ror under a
+//                    bank mask (a DPP bank is 4 lanes, so "bit 2 / bit 3 of the lane" is a set of banks; only the
+//                    receiving lanes are written, no select)
+//     gl bit 2 = lane bit 4: v_permlane16_swap_b32 (odd rows of one register <-> even rows of the other)
+//     gl bit 3 = lane bit 5: v_permlane32_swap_b32 (upper half of one register <-> lower half of the other)
+// -- the two swaps are exactly the exchange a transpose step needs, one instruction for both registers, in place.
+// Measured (tools_dev/ubench/pk_rate.hip, ns of SIMD time per wave64 instruction at 4 waves/SIMD): v_mov_b32 1.35,
+// v_mov_b32_dpp 2.0, v_permlane16_swap 3.6, v_cndmask_b32_e64 with an SGPR-pair mask 2.1, any v_cndmask_b32 with its mask in
+// VCC 9.8, ds_bpermute 10.  Per register pair an exchange costs 5.4 (copy + two DPP moves) or 3.6 (swap); the contiguous-row
+// mapping used before needed a quad_perm fetch + select per register for lane bits 0 / 1 (8.4 per pair).
+__device__ __forceinline__ int fft_group(int lane) { return lane & 3; }
+__device__ __forceinline__ int fft_index(int lane) { return lane >> 2; }
 template <int CTRL, int BANK_MASK = 0xf>
 __device__ __forceinline__ float dpp_mov(float old, float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, BANK_MASK, false));
 }
-template <int CTRL>
-__device__ __forceinline__ float dpp_fetch(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-// mask ? a : b with the lane mask in an SGPR pair
-__device__ __forceinline__ float sel_sgpr(unsigned long long mask, float a, float b) {
-    float d;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "s"(mask));
-    return d;
-}
+// Swap bit X of gl with one element-index bit: lanes whose bit is clear keep `lo` and receive the partner's `lo` into
+// `hi`; lanes whose bit is set keep `hi` and receive the partner's `hi` into `lo`.
 template <int X>
-__device__ __forceinline__ void xstage1(float lo, float hi, unsigned long long set, unsigned long long clr, float &nlo, float &nhi) {
-    // nhi = bit ? hi : partner's lo (the partner sits X lanes above);  nlo = bit ? partner's hi (X lanes below) : lo
-    if constexpr (X == 4) {
-        nlo = dpp_mov<0x124, 0xA>(lo, hi);  // row_ror:4  -> lanes 4-7, 12-15 take hi of lane - 4
-        nhi = dpp_mov<0x12C, 0x5>(hi, lo);  // row_ror:12 -> lanes 0-3, 8-11 take lo of lane + 4
-    } else if constexpr (X == 8) {
-        nlo = dpp_mov<0x128, 0xC>(lo, hi);  // row_ror:8 -> lanes 8-15 take hi of lane - 8
-        nhi = dpp_mov<0x128, 0x3>(hi, lo);  //           -> lanes 0-7 take lo of lane + 8
+__device__ __forceinline__ void xstage1(float &lo, float &hi) {
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    if constexpr (X == 1) {
+        const float nlo = dpp_mov<0x124, 0xA>(lo, hi);  // row_ror:4  -> lanes 4-7, 12-15 take hi of lane - 4
+        const float nhi = dpp_mov<0x12C, 0x5>(hi, lo);  // row_ror:12 -> lanes 0-3, 8-11 take lo of lane + 4
+        lo = nlo, hi = nhi;
+    } else if constexpr (X == 2) {
+        const float nlo = dpp_mov<0x128, 0xC>(lo, hi);  // row_ror:8 -> lanes 8-15 take hi of lane - 8
+        const float nhi = dpp_mov<0x128, 0x3>(hi, lo);  //           -> lanes 0-7 take lo of lane + 8
+        lo = nlo, hi = nhi;
+    } else if constexpr (X == 4) {
+        const v2u r = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+        lo = __uint_as_float(r.x), hi = __uint_as_float(r.y);
     } else {
-        constexpr int QP = X == 1 ? 0xB1 : 0x4E;  // quad_perm:[1,0,3,2] / [2,3,0,1]
-        const float phi = dpp_fetch<QP>(hi), plo = dpp_fetch<QP>(lo);
-        nlo = sel_sgpr(set, phi, lo);
-        nhi = sel_sgpr(set, hi, plo);
+        const v2u r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+        lo = __uint_as_float(r.x), hi = __uint_as_float(r.y);
     }
 }
-struct XMask {
-    unsigned long long set, clr;
-};
-__device__ __forceinline__ XMask xmask(int gl, int x) {
-    XMask m;
-    m.set = __builtin_amdgcn_ballot_w64((gl & x) != 0);
-    m.clr = __builtin_amdgcn_ballot_w64((gl & x) == 0);
-    return m;
-}
 template <int X>
-__device__ __forceinline__ void xstage(v2f &lo, v2f &hi, XMask bit) {
-    float lx, hx, ly, hy;
-    xstage1<X>(lo.x, hi.x, bit.set, bit.clr, lx, hx);
-    xstage1<X>(lo.y, hi.y, bit.set, bit.clr, ly, hy);
+__device__ __forceinline__ void xstage(v2f &lo, v2f &hi) {
+    float lx = lo.x, hx = hi.x, ly = lo.y, hy = hi.y;
+    xstage1<X>(lx, hx);
+    xstage1<X>(ly, hy);
     lo = v2f{lx, ly};
     hi = v2f{hx, hy};
 }
 
-// 4x4 transpose between the lane bits (XA, XB) and the element index of v[0..3]
+// 4x4 transpose between the bits (XA, XB) of gl and the element index of v[0..3]
 template <int XA, int XB>
-__device__ __forceinline__ void transpose4(v2f v[4], int gl) {
-    const XMask ba = xmask(gl, XA), bb = xmask(gl, XB);
-    xstage<XA>(v[0], v[1], ba);
-    xstage<XA>(v[2], v[3], ba);
-    xstage<XB>(v[0], v[2], bb);
-    xstage<XB>(v[1], v[3], bb);
+__device__ __forceinline__ void transpose4(v2f v[4]) {
+    xstage<XA>(v[0], v[1]);
+    xstage<XA>(v[2], v[3]);
+    xstage<XB>(v[0], v[2]);
+    xstage<XB>(v[1], v[3]);
 }
 
 // point that lane gl (0..15) must supply as v[m] to fft64_regs
@@ -98,9 +89,9 @@ __device__ __forceinline__ int fft64_src_point(int gl, int m) {
 template <bool INVERSE>
 __device__ __forceinline__ void fft64_regs(v2f v[4], const FftTables *T, int gl) {
     bfly4_v(gl, T, v);
-    transpose4<1, 2>(v, gl);
+    transpose4<1, 2>(v);
     bfly4_v(gl >> 2, T, v);
-    transpose4<4, 8>(v, gl);
+    transpose4<4, 8>(v);
     bfly4_close_v<INVERSE>(v);
 }
 template <bool INVERSE>
@@ -174,25 +165,24 @@ __device__ __forceinline__ void bfly4_close_x2(Cx2 v[4]) {
 }
 
 template <int XA, int XB>
-__device__ __forceinline__ void transpose4_x2(Cx2 v[4], int gl) {
-    const XMask ba = xmask(gl, XA), bb = xmask(gl, XB);
-    xstage<XA>(v[0].r, v[1].r, ba);
-    xstage<XA>(v[0].i, v[1].i, ba);
-    xstage<XA>(v[2].r, v[3].r, ba);
-    xstage<XA>(v[2].i, v[3].i, ba);
-    xstage<XB>(v[0].r, v[2].r, bb);
-    xstage<XB>(v[0].i, v[2].i, bb);
-    xstage<XB>(v[1].r, v[3].r, bb);
-    xstage<XB>(v[1].i, v[3].i, bb);
+__device__ __forceinline__ void transpose4_x2(Cx2 v[4]) {
+    xstage<XA>(v[0].r, v[1].r);
+    xstage<XA>(v[0].i, v[1].i);
+    xstage<XA>(v[2].r, v[3].r);
+    xstage<XA>(v[2].i, v[3].i);
+    xstage<XB>(v[0].r, v[2].r);
+    xstage<XB>(v[0].i, v[2].i);
+    xstage<XB>(v[1].r, v[3].r);
+    xstage<XB>(v[1].i, v[3].i);
 }
 
 // in: v[m] = point fft64_src_point(gl, m) of both transforms; out: v[m] = point gl + 16 m
 template <bool INVERSE>
 __device__ __forceinline__ void fft64_regs_x2(Cx2 v[4], const FftTables *T, int gl) {
     bfly4_x2(gl, T, v);
-    transpose4_x2<1, 2>(v, gl);
+    transpose4_x2<1, 2>(v);
     bfly4_x2(gl >> 2, T, v);
-    transpose4_x2<4, 8>(v, gl);
+    transpose4_x2<4, 8>(v);
     bfly4_close_x2<INVERSE>(v);
 }
 
@@ -345,9 +335,9 @@ __device__ __forceinline__ v2f rdft128_inv_point_lanes(v2f own, const FftTables 
     return v2f{re, im};
 }
 
-// value held by lane rev4(gl) of the same row (ds_bpermute: no LDS memory, no barrier)
+// value held by the lane with index rev4(gl) of the same transform (ds_bpermute: no LDS memory, no barrier)
 __device__ __forceinline__ float row_bitrev(float v, int lane) {
-    const int src = (lane & ~15) | dev_bitrev(lane & 15, 4);
+    const int src = (dev_bitrev(lane >> 2, 4) << 2) | (lane & 3);
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v)));
 }
 
