@@ -107,6 +107,30 @@ __global__ void k(float *out, long long *cyc, int iters) {
             asm volatile("v_max_f32 %0, %0, %8\n v_max_f32 %1, %1, %8\n v_max_f32 %2, %2, %8\n v_max_f32 %3, %3, %8\n"
                          "v_max_f32 %4, %4, %8\n v_max_f32 %5, %5, %8\n v_max_f32 %6, %6, %8\n v_max_f32 %7, %7, %8"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
+        } else if (MODE == 23) {  // 4 x (v_cmp -> vcc, v_cndmask <- vcc): what the compiler emits for a select
+            asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32 %1, %1, %9, vcc\n v_cmp_lt_f32 vcc, %2, %8\n v_cndmask_b32 %3, %3, %9, vcc\n"
+                         "v_cmp_lt_f32 vcc, %4, %8\n v_cndmask_b32 %5, %5, %9, vcc\n v_cmp_lt_f32 vcc, %6, %8\n v_cndmask_b32 %7, %7, %9, vcc"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(c2) : "vcc");
+        } else if (MODE == 24) {  // the same through an SGPR pair
+            asm volatile("v_cmp_lt_f32_e64 s[20:21], %0, %8\n v_cndmask_b32_e64 %1, %1, %9, s[20:21]\n v_cmp_lt_f32_e64 s[22:23], %2, %8\n v_cndmask_b32_e64 %3, %3, %9, s[22:23]\n"
+                         "v_cmp_lt_f32_e64 s[20:21], %4, %8\n v_cndmask_b32_e64 %5, %5, %9, s[20:21]\n v_cmp_lt_f32_e64 s[22:23], %6, %8\n v_cndmask_b32_e64 %7, %7, %9, s[22:23]"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(c2) : "s20", "s21", "s22", "s23");
+        } else if (MODE == 25) {  // v_cndmask_b32_e64 reading vcc explicitly (VOP3 encoding, mask operand = vcc)
+            asm volatile("v_cndmask_b32_e64 %0, %1, %2, vcc\n v_cndmask_b32_e64 %1, %2, %3, vcc\n v_cndmask_b32_e64 %2, %3, %4, vcc\n v_cndmask_b32_e64 %3, %4, %5, vcc\n"
+                         "v_cndmask_b32_e64 %4, %5, %6, vcc\n v_cndmask_b32_e64 %5, %6, %7, vcc\n v_cndmask_b32_e64 %6, %7, %0, vcc\n v_cndmask_b32_e64 %7, %0, %1, vcc"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "vcc");
+        } else if (MODE == 26) {  // v_div_fmas_f32 (reads vcc implicitly)
+            asm volatile("v_div_fmas_f32 %0, %0, %8, %9\n v_div_fmas_f32 %1, %1, %8, %9\n v_div_fmas_f32 %2, %2, %8, %9\n v_div_fmas_f32 %3, %3, %8, %9\n"
+                         "v_div_fmas_f32 %4, %4, %8, %9\n v_div_fmas_f32 %5, %5, %8, %9\n v_div_fmas_f32 %6, %6, %8, %9\n v_div_fmas_f32 %7, %7, %8, %9"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(c2) : "vcc");
+        } else if (MODE == 27) {  // v_fma_f32 for comparison
+            asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                         "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(c2));
+        } else if (MODE == 28) {  // v_permlane32_swap (gfx950)
+            asm volatile("v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n"
+                         "v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
         } else if (MODE == 8) {  // 8 v_pk_fma
             asm volatile("v_pk_fma_f32 %0, %0, %4, %4\n v_pk_fma_f32 %1, %1, %4, %4\n v_pk_fma_f32 %2, %2, %4, %4\n v_pk_fma_f32 %3, %3, %4, %4\n"
                          "v_pk_fma_f32 %0, %0, %4, %4\n v_pk_fma_f32 %1, %1, %4, %4\n v_pk_fma_f32 %2, %2, %4, %4\n v_pk_fma_f32 %3, %3, %4, %4"
@@ -146,7 +170,8 @@ int main() {
         run<0>("v_add_f32", w); run<2>("v_pk_add_f32", w);
         run<4>("v_cndmask_b32_dpp", w); run<18>("v_cndmask_b32_e64 sgpr", w); run<19>("v_bfi_b32", w); run<20>("v_cmp_lt_f32 vcc", w); run<21>("v_cndmask indep", w); run<22>("v_max_f32", w);
         run<9>("v_mov_b32_dpp quad_perm", w); run<10>("v_mov_b32_dpp ror+bank", w); run<11>("v_add_f32_dpp", w); run<12>("v_cndmask_b32 vcc", w);
-        run<13>("ds_bpermute_b32", w); run<14>("ds_swizzle_b32", w); run<15>("ds_write+read_b64 (8)", w); run<16>("v_mov_b32", w); run<17>("v_permlane16_swap", w);
+        run<13>("ds_bpermute_b32", w); run<14>("ds_swizzle_b32", w); run<15>("ds_write+read_b64 (8)", w); run<16>("v_mov_b32", w); run<17>("v_permlane16_swap", w); run<28>("v_permlane32_swap", w);
+        run<23>("cmp+cndmask via vcc (8)", w); run<24>("cmp+cndmask via sgpr (8)", w); run<25>("v_cndmask_e64 vcc", w); run<26>("v_div_fmas_f32", w); run<27>("v_fma_f32", w);
     }
     return 0;
 }
