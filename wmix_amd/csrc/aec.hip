@@ -279,6 +279,14 @@ __device__ __forceinline__ float uniform_ld(const float *p) {
 // out of line for the same reason as libm_dev.h's pow_d: inlined, its fp64 temporaries push the block over 128 VGPRs
 __device__ __noinline__ static float aec_powf(float x, float y, const PowTables *__restrict__ t) { return fast_pow(x, y, t); }
 
+// (pos + i) % kAecRing for a ring position 0 <= pos < kAecRing and an offset 0 <= i <= kAecRing: one compare and a
+// subtraction instead of the multiply-high / multiply-low pair of a division by a constant (both quarter rate)
+__device__ __forceinline__ int ring_at(int pos, int i) {
+    const int t = pos + i;
+    return t >= kAecRing ? t - kAecRing : t;
+}
+// row `r` of the work rows for a lane-dependent r < 64 (a 24-bit multiply; `W.fa[r]` costs two 64-bit multiply-adds)
+__device__ __forceinline__ float *fa_row(AecWaveLds &W, int r) { return &W.fa[0][0] + __umul24((unsigned)r, (unsigned)FAS); }
 __device__ __forceinline__ int opaque_lane(int x) {
     asm volatile("" : "+v"(x));
     return x;
@@ -323,7 +331,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
     // ---- near block (aec_core.c:1177-1195).  d = [prev | cur]; its plain transform feeds the near power, its
     //      windowed transform the coherence estimates of the NLP (aec_core.c:934-949): both now, side by side.
     const float xpow_lane = F.xpow_seq[(n % kAecHist) * BP + lane];  // far power of this block (ScaleErrorSignal), requested early
-    W.cur[lane] = AEC_ST(AS_NEAR_RING + (bp.near_rd + lane) % kAecRing);
+    W.cur[lane] = AEC_ST(AS_NEAR_RING + ring_at(bp.near_rd, lane));
     wave_sync();
     if (g < 2) {
         const bool win = g == 1;
@@ -508,7 +516,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
         wave_sync();
         // fft[1] is overwritten with the Nyquist product (aec_core.c:245-248): lane j patches partition base + j
         // (LDS runs a wave's accesses in order, so this lands after lane 0's store above)
-        if (lane < cnt) W.fa[lane][1] = nyq_r * e64r - nyq_i * e64i;
+        if (lane < cnt) fa_row(W, lane)[1] = nyq_r * e64r - nyq_i * e64i;
         wave_sync();
         AEC_RELANE();
         if (pass == 0) {
@@ -564,7 +572,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
                 taps.re[base + q] += d.x;
                 taps.im[base + q] += d.y;  // lane 0 adds 0 (wfBuf[1][pos] is never touched, aec_core.c:262-268)
             }
-            if (lane < cnt) W.wn[base + lane] += W.fa[lane][0] - W.fa[lane][1];  // wfBuf[0][pos + 64] += fft[1]: bin 64 = a[0] - a[1]
+            if (lane < cnt) W.wn[base + lane] += fa_row(W, lane)[0] - fa_row(W, lane)[1];  // wfBuf[0][pos + 64] += fft[1]: bin 64 = a[0] - a[1]
         }
         wave_sync();
     }
@@ -876,8 +884,8 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
         if (lane < 32) {
             const float o0 = sat16f(pt.x * scale * K.hanning[i] + AEC_ST(AS_OUTBUF + i));
             const float o1 = sat16f(pt.y * scale * K.hanning[i + 1] + AEC_ST(AS_OUTBUF + i + 1));
-            AEC_ST(AS_OUT_RING + (bp.out_wr + i) % kAecRing) = o0;
-            AEC_ST(AS_OUT_RING + (bp.out_wr + i + 1) % kAecRing) = o1;
+            AEC_ST(AS_OUT_RING + ring_at(bp.out_wr, i)) = o0;
+            AEC_ST(AS_OUT_RING + ring_at(bp.out_wr, i + 1)) = o1;
         }
         wave_sync();  // the tail overwrites outBuf only after every lane has read it
         if (lane >= 32) {
@@ -1010,12 +1018,12 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * kAe
                 const int i = ln + 64 * h;
                 if (i >= kAecFrame) continue;
                 const float v = (p == 0 && s < 2) ? (s == 0 ? W.fa[0][i] : (float)W.park[i]) : (float)in[(s * kAecFrame + i) * chn];
-                AEC_ST(AS_NEAR_RING + (sp.near_wr + i) % kAecRing) = v;
+                AEC_ST(AS_NEAR_RING + ring_at(sp.near_wr, i)) = v;
             }
             wave_sync();
             for (int k = 0; k < sp.n_blocks; k++) aec_block<MULT>(K, powtab, W, taps, F, pl.blk[sp.first_blk + k], lane);
             for (int i = opaque_lane(lane); i < kAecFrame; i += 64) {
-                const int16_t v = (int16_t)AEC_ST(AS_OUT_RING + (sp.out_rd + i) % kAecRing);
+                const int16_t v = (int16_t)AEC_ST(AS_OUT_RING + ring_at(sp.out_rd, i));
                 for (int c = 0; c < chn; c++) out[(s * kAecFrame + i) * chn + c] = v;
             }
             wave_sync();

@@ -187,6 +187,14 @@ __device__ __forceinline__ void fft64_regs_x2(Cx2 v[4], const FftTables *T, int 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// (64 - p) & 63, kept from the optimiser: scaled to a byte offset it would become (p * -8) & 0x1f8 with a full 32-bit
+// multiply (quarter rate) where a subtraction and a shift do
+__device__ __forceinline__ int mirror64(int p) {
+    int q = (64 - p) & 63;
+    asm("" : "+v"(q));
+    return q;
+}
+
 // Real-split pre/post processing without selects.
 __device__ __forceinline__ v2f ld_pt(const float *row, int p) {
     const float2 v = *reinterpret_cast<const float2 *>(row + 2 * p);
@@ -205,7 +213,7 @@ template <int M>
 __device__ __forceinline__ v2f rdft128_inv_point_m(const float *a, const FftTables *T, int b) {
     constexpr int OFF = M == 0 ? 0 : (M == 1 ? 32 : (M == 2 ? 16 : 48));
     const int p = dev_bitrev(b, 4) + OFF;
-    const v2f own = ld_pt(a, p), other = ld_pt(a, (64 - p) & 63);
+    const v2f own = ld_pt(a, p), other = ld_pt(a, mirror64(p));
     const int q = (M & 1) ? 64 - p : p;
     float wr = 0.5f - T->c[32 - q], wi = T->c[q];
     if constexpr (M == 1) {
@@ -252,7 +260,7 @@ __device__ __forceinline__ SplitLane rdft128_fwd_coef(const FftTables *T, int la
     return SplitLane{wr, wi, lane == 0 ? 0.f : 1.f};
 }
 __device__ __forceinline__ v2f rdft128_fwd_bin_u(const float *a, SplitLane s, int lane) {
-    const v2f own = ld_pt(a, lane), other = ld_pt(a, (64 - lane) & 63);
+    const v2f own = ld_pt(a, lane), other = ld_pt(a, mirror64(lane));
     const v2f x = own + v2f{-other.x, other.y};
     return (own - cmul_w(s.wr, s.wi, x)) * v2f{1.f, s.z};
 }
@@ -321,7 +329,7 @@ __device__ __forceinline__ v2f fft64_lanes(v2f pt, const FftTables *T, int lane)
 // rdft128_inv_point for point == lane with the packed spectrum in registers: `own` = bin lane (lane 0: (a[0], a[1]) =
 // (bin 0, bin 64), both real), partner = bin 64 - lane fetched from its lane.
 __device__ __forceinline__ v2f rdft128_inv_point_lanes(v2f own, const FftTables *T, int lane) {
-    const v2f other = lane_fetch(own, (64 - lane) & 63);
+    const v2f other = lane_fetch(own, mirror64(lane));
     const int q = lane < 32 ? lane : 64 - lane;
     const float wkr = 0.5f - T->c[32 - q], wki = T->c[q];
     const v2f aj = lane < 32 ? own : other, ak = lane < 32 ? other : own;  // pair (j = 2q, k = 128 - 2q)
