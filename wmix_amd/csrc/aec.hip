@@ -333,25 +333,65 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
     const float xpow_lane = F.xpow_seq[(n % kAecHist) * BP + lane];  // far power of this block (ScaleErrorSignal), requested early
     W.cur[lane] = AEC_ST(AS_NEAR_RING + ring_at(bp.near_rd, lane));
     wave_sync();
-    if (g < 2) {
-        const bool win = g == 1;
+    AEC_PROF(0);
+    AEC_RELANE();
+    // ---- FilterFar (aec_core.c:148-170): y = sum_p X_{n-p} * W_p, partitions in order; lane 0 also does bin 64
+    {
+        // all 24 far-spectrum values of this lane requested at once (one memory round trip, not one per few partitions);
+        // the Nyquist column is wave-uniform and comes through the scalar path
+        float xr[12], xi[12];
+#pragma unroll
+        for (int p = 0; p < 12; p++) {
+            const float *X = F.hist + (size_t)((n - p + kAecHist) % kAecHist) * 130;
+            xr[p] = X[lane];
+            xi[p] = X[kAecPart1 + lane];
+        }
+        float yr = 0.f, yi = 0.f, y64 = 0.f;
+#pragma unroll
+        for (int p = 0; p < 12; p++) {
+            const float *X = F.hist + (size_t)((n - p + kAecHist) % kAecHist) * 130;
+            yr += xr[p] * taps.re[p] - xi[p] * taps.im[p];
+            yi += xr[p] * taps.im[p] + xi[p] * taps.re[p];
+            const float nr = uniform_ld(X + kAecPart), ni = uniform_ld(X + kAecPart1 + kAecPart);  // ni == 0, wfBuf[1][.][64] == 0
+            y64 += nr * W.wn[p] - ni * 0.f;                                                    // used by lane 0 only
+        }
+        // ---- error e = d - y (aec_core.c:1286-1297): y = second half of the inverse transform of the packed spectrum
+        //      (lane 0 carries (bin 0, bin 64)), one point per lane in registers: lanes 32..63 end up with y[2(l-32)], +1
+        AEC_PROF(1);
+        v2f pt = rdft128_inv_point_lanes(v2f{yr, lane == 0 ? y64 : yi}, &K.tab, lane);
+        pt = fft64_lanes<true>(pt, &K.tab, lane);
+        if (lane >= 32) {
+            const int i = 2 * (lane - 32);
+            W.enew[i] = W.cur[i] - pt.x * scale;
+            W.enew[i + 1] = W.cur[i + 1] - pt.y * scale;
+        }
+    }
+    wave_sync();
+    AEC_RELANE();
+    // ---- four transforms side by side, one per lane group: rdft(d) and rdft(d * w) of the near block [dprev | cur]
+    //      (aec_core.c:1177-1195, 934-949), ef = rdft([0 | e]) (aec_core.c:1299-1309) and the windowed rdft([eprev | e] * w) of
+    //      the NLP.  The reference transforms d before it filters the far end; nothing between the two reads the other's
+    //      result, so the near transforms wait for the error and share its instruction stream.
+    {
+        const bool win = g & 1, err = g >= 2;
         aec_fft_fwd(W.fa[g], &K.tab, gl, [&](int p) {
             const int i = 2 * (p & 31);
-            float x0, x1, h0 = 1.f, h1 = 1.f;
-            if (p < 32) {
-                x0 = AEC_ST(AS_DPREV + i);
-                x1 = AEC_ST(AS_DPREV + i + 1);
-                if (win) h0 = K.hanning[i], h1 = K.hanning[i + 1];
+            float x0, x1, h0, h1;
+            if (p < 32) {  // p is a compile-time property of the point index m (fft64_src_point): no divergence
+                const float *prev = &AEC_ST(err ? AS_EPREV : AS_DPREV);
+                x0 = prev[i], x1 = prev[i + 1];
+                h0 = K.hanning[i], h1 = K.hanning[i + 1];
+                if (g == 2) x0 = 0.f, x1 = 0.f;
             } else {
-                x0 = W.cur[i];
-                x1 = W.cur[i + 1];
-                if (win) h0 = K.hanning[kAecPart - i], h1 = K.hanning[kAecPart - i - 1];
+                const float *now = err ? W.enew : W.cur;
+                x0 = now[i], x1 = now[i + 1];
+                h0 = K.hanning[kAecPart - i], h1 = K.hanning[kAecPart - i - 1];
             }
-            return win ? Cx{x0 * h0, x1 * h1} : Cx{x0, x1};
+            return Cx{win ? x0 * h0 : x0, win ? x1 * h1 : x1};
         });
     }
     wave_sync();
-    AEC_PROF(0);
+    AEC_PROF(2);
     AEC_RELANE();
     // windowed near spectrum, kept in registers across the filter update (bin = lane; lane 0 also bin 64)
     float dwr, dwi, dw64, dfr, dfi, df64;
@@ -396,56 +436,6 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
         put(lane, a);
         if (lane == 0) put(kAecPart, c);
     }
-    // ---- FilterFar (aec_core.c:148-170): y = sum_p X_{n-p} * W_p, partitions in order; lane 0 also does bin 64
-    {
-        // all 24 far-spectrum values of this lane requested at once (one memory round trip, not one per few partitions);
-        // the Nyquist column is wave-uniform and comes through the scalar path
-        float xr[12], xi[12];
-#pragma unroll
-        for (int p = 0; p < 12; p++) {
-            const float *X = F.hist + (size_t)((n - p + kAecHist) % kAecHist) * 130;
-            xr[p] = X[lane];
-            xi[p] = X[kAecPart1 + lane];
-        }
-        float yr = 0.f, yi = 0.f, y64 = 0.f;
-#pragma unroll
-        for (int p = 0; p < 12; p++) {
-            const float *X = F.hist + (size_t)((n - p + kAecHist) % kAecHist) * 130;
-            yr += xr[p] * taps.re[p] - xi[p] * taps.im[p];
-            yi += xr[p] * taps.im[p] + xi[p] * taps.re[p];
-            const float nr = uniform_ld(X + kAecPart), ni = uniform_ld(X + kAecPart1 + kAecPart);  // ni == 0, wfBuf[1][.][64] == 0
-            y64 += nr * W.wn[p] - ni * 0.f;                                                    // used by lane 0 only
-        }
-        // ---- error e = d - y (aec_core.c:1286-1297): y = second half of the inverse transform of the packed spectrum
-        //      (lane 0 carries (bin 0, bin 64)), one point per lane in registers: lanes 32..63 end up with y[2(l-32)], +1
-        AEC_PROF(1);
-        v2f pt = rdft128_inv_point_lanes(v2f{yr, lane == 0 ? y64 : yi}, &K.tab, lane);
-        pt = fft64_lanes<true>(pt, &K.tab, lane);
-        if (lane >= 32) {
-            const int i = 2 * (lane - 32);
-            W.enew[i] = W.cur[i] - pt.x * scale;
-            W.enew[i + 1] = W.cur[i + 1] - pt.y * scale;
-        }
-    }
-    wave_sync();
-    AEC_RELANE();
-    // ---- ef = rdft([0 | e]) (aec_core.c:1299-1309) and the windowed rdft([eprev | e] * w) of the NLP
-    if (g < 2) {
-        const bool win = g == 1;
-        aec_fft_fwd(W.fa[2 + g], &K.tab, gl, [&](int p) {
-            const int i = 2 * (p & 31);
-            if (p < 32) {
-                if (!win) return Cx{0.f, 0.f};
-                return Cx{AEC_ST(AS_EPREV + i) * K.hanning[i], AEC_ST(AS_EPREV + i + 1) * K.hanning[i + 1]};
-            }
-            const float x0 = W.enew[i], x1 = W.enew[i + 1];
-            if (!win) return Cx{x0, x1};
-            return Cx{x0 * K.hanning[kAecPart - i], x1 * K.hanning[kAecPart - i - 1]};
-        });
-    }
-    wave_sync();
-    AEC_PROF(2);
-    AEC_RELANE();
     // ---- ScaleErrorSignal (aec_core.c:172-194); ef stays in registers (bin = lane; lane 0 also bin 64), and so
     //      does the windowed error spectrum
     float ewr, ewi, ew64, efr, efi, ef64r, ef64i = 0.f;
