@@ -131,6 +131,19 @@ __global__ void k(float *out, long long *cyc, int iters) {
             asm volatile("v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n"
                          "v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if (MODE == 29 || MODE == 30 || MODE == 31) {  // 8 v_add_f32 with 1 / 16 / 32 active lanes: does a mostly empty EXEC cost less?
+            asm volatile("s_mov_b64 s[20:21], exec\n s_mov_b64 exec, %9\n"
+                         "v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
+                         "v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n"
+                         "v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
+                         "v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n"
+                         "v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
+                         "v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n"
+                         "v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
+                         "v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n"
+                         "s_mov_b64 exec, s[20:21]"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                         : "v"(c), "s"(MODE == 29 ? 1ull : (MODE == 30 ? 0xffffull : 0xffffffffull)) : "s20", "s21");
         } else if (MODE == 8) {  // 8 v_pk_fma
             asm volatile("v_pk_fma_f32 %0, %0, %4, %4\n v_pk_fma_f32 %1, %1, %4, %4\n v_pk_fma_f32 %2, %2, %4, %4\n v_pk_fma_f32 %3, %3, %4, %4\n"
                          "v_pk_fma_f32 %0, %0, %4, %4\n v_pk_fma_f32 %1, %1, %4, %4\n v_pk_fma_f32 %2, %2, %4, %4\n v_pk_fma_f32 %3, %3, %4, %4"
@@ -160,7 +173,7 @@ void run(const char *name, int waves_per_simd) {
     (void)hipDeviceSynchronize();
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
     long long c; (void)hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
-    const double n_instr = (double)iters * (MODE == 1 ? 4 : 8);
+    const double n_instr = (double)iters * (MODE == 1 ? 4 : (MODE >= 29 && MODE <= 31 ? 34 : 8));
     printf("%-24s %d waves/SIMD: %6.2f ns per instr per wave, %6.3f ns per instr per SIMD (ticks/instr/wave %5.2f)\n", name, waves_per_simd,
            ms * 1e6 / n_instr, ms * 1e6 / n_instr / waves_per_simd, (double)c / n_instr);
     (void)hipFree(out); (void)hipFree(cyc);
@@ -172,6 +185,7 @@ int main() {
         run<9>("v_mov_b32_dpp quad_perm", w); run<10>("v_mov_b32_dpp ror+bank", w); run<11>("v_add_f32_dpp", w); run<12>("v_cndmask_b32 vcc", w);
         run<13>("ds_bpermute_b32", w); run<14>("ds_swizzle_b32", w); run<15>("ds_write+read_b64 (8)", w); run<16>("v_mov_b32", w); run<17>("v_permlane16_swap", w); run<28>("v_permlane32_swap", w);
         run<23>("cmp+cndmask via vcc (8)", w); run<24>("cmp+cndmask via sgpr (8)", w); run<25>("v_cndmask_e64 vcc", w); run<26>("v_div_fmas_f32", w); run<27>("v_fma_f32", w);
+        run<29>("v_add_f32 exec=1 lane", w); run<30>("v_add_f32 exec=16 lanes", w); run<31>("v_add_f32 exec=32 lanes", w);
     }
     return 0;
 }
