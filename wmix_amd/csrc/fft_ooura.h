@@ -171,8 +171,23 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f cx(Cx a) { return v2f{a.r, a.i}; }
 __device__ __forceinline__ v2f swap(v2f a) { return __builtin_shufflevector(a, a, 1, 0); }
 // (a.x - b.y, a.y + b.x) = a + i*b      and      (a.x + b.y, a.y - b.x) = a - i*b
-__device__ __forceinline__ v2f add_i(v2f a, v2f b) { return a + v2f{-b.y, b.x}; }
-__device__ __forceinline__ v2f sub_i(v2f a, v2f b) { return a + v2f{b.y, -b.x}; }
+// One v_pk_add_f32 each: its operand-select bits swap the halves of b, its negation bits apply per half.  (Written as
+// vector code the compiler builds the swapped / negated operand first: an xor and a copy in front of every add.)
+#define WMX_PK_ADD(name, mods)                                                      \
+    __device__ __forceinline__ v2f name(v2f a, v2f b) {                             \
+        v2f d;                                                                      \
+        asm("v_pk_add_f32 %0, %1, %2 " mods : "=v"(d) : "v"(a), "v"(b));           \
+        return d;                                                                   \
+    }
+WMX_PK_ADD(add_i, "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")                  // (a.x - b.y, a.y + b.x)
+WMX_PK_ADD(sub_i, "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")                  // (a.x + b.y, a.y - b.x)
+WMX_PK_ADD(add_swap, "op_sel:[0,1] op_sel_hi:[1,0]")                            // (a.x + b.y, a.y + b.x)
+WMX_PK_ADD(sub_swap, "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]")  // (a.x - b.y, a.y - b.x)
+WMX_PK_ADD(add_conj, "neg_hi:[0,1]")                                            // (a.x + b.x, a.y - b.y)
+WMX_PK_ADD(sub_conj, "neg_lo:[0,1]")                                            // (a.x - b.x, a.y + b.y)
+WMX_PK_ADD(conj_sub, "neg_hi:[1,1]")                                            // (a.x + b.x, -a.y - b.y)
+WMX_PK_ADD(conj_add, "neg_lo:[0,1] neg_hi:[1,0]")                               // (a.x - b.x, -a.y + b.y)
+#undef WMX_PK_ADD
 // (wr*t.x - wi*t.y, wr*t.y + wi*t.x): the reference's twiddle product, two packed multiplies and one packed add
 __device__ __forceinline__ v2f cmul_w(float wr, float wi, v2f t) { return v2f{wr, wr} * t + v2f{-wi, wi} * swap(t); }
 
@@ -234,12 +249,11 @@ __device__ __forceinline__ void bfly4_close_v(v2f v[4]) {
         v[3] = sub_i(x1, x3);  // (x1r + x3i, x1i - x3r)
     } else {
         // x0r = A.r + B.r, x0i = -A.i - B.i; x1r = A.r - B.r, x1i = -A.i + B.i
-        const v2f na = v2f{v[0].x, -v[0].y};
-        const v2f x0 = na + v2f{v[1].x, -v[1].y}, x1 = na + v2f{-v[1].x, v[1].y};
-        v[0] = x0 + v2f{x2.x, -x2.y};   // (x0r + x2r, x0i - x2i)
-        v[2] = x0 + v2f{-x2.x, x2.y};   // (x0r - x2r, x0i + x2i)
-        v[1] = x1 + v2f{-x3.y, -x3.x};  // (x1r - x3i, x1i - x3r)
-        v[3] = x1 + v2f{x3.y, x3.x};    // (x1r + x3i, x1i + x3r)
+        const v2f x0 = conj_sub(v[0], v[1]), x1 = conj_add(v[0], v[1]);
+        v[0] = add_conj(x0, x2);  // (x0r + x2r, x0i - x2i)
+        v[2] = sub_conj(x0, x2);  // (x0r - x2r, x0i + x2i)
+        v[1] = sub_swap(x1, x3);  // (x1r - x3i, x1i - x3r)
+        v[3] = add_swap(x1, x3);  // (x1r + x3i, x1i + x3r)
     }
 }
 template <bool INVERSE>

@@ -222,7 +222,7 @@ __device__ __forceinline__ v2f rdft128_inv_point_m(const float *a, const FftTabl
     }
     const v2f x = own + v2f{-other.x, other.y};
     const v2f y = (M & 1) ? cmul_w(wr, wi, x) : cmul_w(wr, -wi, x);  // (wr*xr -+ wi*xi, wr*xi +- wi*xr)
-    v2f out = v2f{-y.x, y.y} + v2f{own.x, -own.y};
+    v2f out = conj_add(own, y);  // {own.x - y.x, -own.y + y.y}
     if constexpr (M == 0) {
         const float h = 0.5f * (own.x - own.y);
         out = b == 0 ? v2f{own.x - h, -h} : out;
