@@ -283,14 +283,17 @@ class ChainWorkload:
         main = torch.cuda.current_stream()
         if self.ev_tail[b] is not None:
             main.wait_event(self.ev_tail[b])  # the tail of two steps ago has finished with this buffer
-        if self.rank == 0:
+        # one GPU: the far-end packet is read where it lies, like the near-end packets; several GPUs: rank 0's packet goes
+        # through the broadcast buffer, and the broadcast (RCCL, its own stream) runs behind the noise suppressor, which
+        # does not need it
+        far = self.far_src[k:k + P] if self.dist is None else self.far
+        if self.dist is not None and self.rank == 0:
             self.far.copy_(self.far_src[k:k + P])
-        # the far-end broadcast (RCCL, its own stream) runs behind the noise suppressor, which does not need it
         work = broadcast_far(self.far, self.dist, src=0, async_op=True) if self.dist is not None else None
         self.t.run("ns", timed, lambda: self.ns.process_packet_major(self.inp[k:k + P], self.work))
         if work is not None:
             self.t.run("far_broadcast_wait", timed, work.wait)
-        self.t.run("aec", timed, lambda: self.aec.process2_packet_major(self.far, self.work))
+        self.t.run("aec", timed, lambda: self.aec.process2_packet_major(far, self.work))
         if self.with_agc_vad and self.side is not None:
             self.ev_aec[b].record(main)
             with torch.cuda.stream(self.side):
@@ -313,7 +316,8 @@ class ChainWorkload:
     def config(self):
         return {"workload": self.name, "streams_per_gpu": self.n_streams, "packets_per_stream_per_step": self.P,
                 "frame": "%d x int16 (10 ms @ %d kHz mono)" % (self.pkt, self.freq // 1000),
-                "far_end": "shared, RCCL broadcast from rank 0 each step (asynchronous, overlapped with NS)", "sum_order": "reference (bit-exact NS mode)",
+                "far_end": ("shared, RCCL broadcast from rank 0 each step (asynchronous, overlapped with NS)" if self.dist is not None
+                            else "shared, resident in HBM (one GPU: nothing to broadcast)"), "sum_order": "reference (bit-exact NS mode)",
                 "aec_launch": "far kernel + near kernel; the near kernel is the timed dominant kernel together with its far kernel"}
 
     def cpu_baseline(self, budget_s):
