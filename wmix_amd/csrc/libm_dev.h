@@ -19,6 +19,20 @@ __device__ __noinline__ static float tanh_d(float x) { return (float)tanh((doubl
 __device__ __noinline__ static float exp_d(float x) { return (float)exp((double)x); }
 __device__ __noinline__ static float div_pow_d(float num, float base, float e) { return (float)((double)num / pow((double)base, (double)e)); }
 
+// p * r + c for a literal coefficient c.  On the device the coefficient sits in an SGPR pair and the operation is one
+// three-address v_fma_f64; written as plain fma() the compiler keeps every coefficient of a polynomial in a VGPR pair for
+// the whole kernel and spells each Horner step as v_mov_b64 (copy the coefficient) + v_fmac_f64 (accumulate into the
+// copy): twice the VALU work and two dozen registers.  Same single rounding either way.
+__host__ __device__ __forceinline__ double fma_c(double p, double r, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(r), "s"(c));
+    return d;
+#else
+    return fma(p, r, c);
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Table-driven log / exp for the NS's per-bin calls.  The reference computes float(log((double)x)) and
 // float(exp((double)x)) with glibc (error < 1 ulp of double).  Any double result within ~1 ulp of the true value rounds
@@ -70,11 +84,11 @@ __host__ __device__ __forceinline__ float fast_log_ge1(float x, const NsLibmTabl
     const double2 t = M.logtab[(u >> 16) & 0x7F];
     const double r = fma(m, t.x, -1.0);
     double p = -1.0 / 9.0 * r + 1.0 / 8.0;  // alternating series, highest term r^9/9
-    p = fma(p, r, -1.0 / 7.0);
-    p = fma(p, r, 1.0 / 6.0);
-    p = fma(p, r, -1.0 / 5.0);
-    p = fma(p, r, 1.0 / 4.0);
-    p = fma(p, r, -1.0 / 3.0);
+    p = fma_c(p, r, -1.0 / 7.0);
+    p = fma_c(p, r, 1.0 / 6.0);
+    p = fma_c(p, r, -1.0 / 5.0);
+    p = fma_c(p, r, 1.0 / 4.0);
+    p = fma_c(p, r, -1.0 / 3.0);
     p = fma(p, r, 1.0 / 2.0);
     p = fma(-p, r, 1.0);
     p = p * r;  // log1p(r) = r - r^2/2 + ... + r^9/9
@@ -92,9 +106,9 @@ __host__ __device__ __forceinline__ float fast_exp(float xf, const NsLibmTables 
     const int k = (int)kd;
     double r = fma(-kd, kHi, x);
     r = fma(-kd, kLo, r);
-    double p = fma(r, 1.0 / 720.0, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
+    double p = fma_c(r, 1.0 / 720.0, 1.0 / 120.0);
+    p = fma_c(p, r, 1.0 / 24.0);
+    p = fma_c(p, r, 1.0 / 6.0);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = p * r;  // expm1(r)
@@ -121,9 +135,9 @@ __host__ __device__ __forceinline__ float fast_tanh(float xf, const NsLibmTables
     const int k = (int)kd;  // 0 .. 3694
     double r = fma(-kd, kHi, a2);
     r = fma(-kd, kLo, r);
-    double p = fma(r, 1.0 / 720.0, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
+    double p = fma_c(r, 1.0 / 720.0, 1.0 / 120.0);
+    p = fma_c(p, r, 1.0 / 24.0);
+    p = fma_c(p, r, 1.0 / 6.0);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = p * r;  // expm1(r)
@@ -178,11 +192,11 @@ __host__ __device__ __forceinline__ float fast_pow(float x, float y, const PowTa
     const double2 t = M->logtab[idx];
     const double r = fma((double)mf, t.x, -1.0);
     double p = -1.0 / 9.0 * r + 1.0 / 8.0;
-    p = fma(p, r, -1.0 / 7.0);
-    p = fma(p, r, 1.0 / 6.0);
-    p = fma(p, r, -1.0 / 5.0);
-    p = fma(p, r, 1.0 / 4.0);
-    p = fma(p, r, -1.0 / 3.0);
+    p = fma_c(p, r, -1.0 / 7.0);
+    p = fma_c(p, r, 1.0 / 6.0);
+    p = fma_c(p, r, -1.0 / 5.0);
+    p = fma_c(p, r, 1.0 / 4.0);
+    p = fma_c(p, r, -1.0 / 3.0);
     p = fma(p, r, 1.0 / 2.0);
     p = fma(-p, r, 1.0);
     p = p * r;
@@ -196,9 +210,9 @@ __host__ __device__ __forceinline__ float fast_pow(float x, float y, const PowTa
     const int k = (int)kd;
     double rr = fma(-kd, kHi, z);
     rr = fma(-kd, kLo, rr);
-    double q = fma(rr, 1.0 / 720.0, 1.0 / 120.0);
-    q = fma(q, rr, 1.0 / 24.0);
-    q = fma(q, rr, 1.0 / 6.0);
+    double q = fma_c(rr, 1.0 / 720.0, 1.0 / 120.0);
+    q = fma_c(q, rr, 1.0 / 24.0);
+    q = fma_c(q, rr, 1.0 / 6.0);
     q = fma(q, rr, 0.5);
     q = fma(q, rr, 1.0);
     q = q * rr;
