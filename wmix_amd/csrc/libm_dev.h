@@ -19,6 +19,30 @@ __device__ __noinline__ static float tanh_d(float x) { return (float)tanh((doubl
 __device__ __noinline__ static float exp_d(float x) { return (float)exp((double)x); }
 __device__ __noinline__ static float div_pow_d(float num, float base, float e) { return (float)((double)num / pow((double)base, (double)e)); }
 
+// the library routines behind the table-driven ones' guard branches (arguments the NS never produces): out of line on the
+// device for the reason given at the top -- inlined three times each, their coefficients had 32 VGPRs pinned in ns_kernel
+__host__ __device__ __forceinline__ float slow_log(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return log_d(x);
+#else
+    return (float)log((double)x);
+#endif
+}
+__host__ __device__ __forceinline__ float slow_exp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return exp_d(x);
+#else
+    return (float)exp((double)x);
+#endif
+}
+__host__ __device__ __forceinline__ float slow_tanh(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return tanh_d(x);
+#else
+    return (float)tanh((double)x);
+#endif
+}
+
 // p * r + c for a literal coefficient c.  On the device the coefficient sits in an SGPR pair and the operation is one
 // three-address v_fma_f64; written as plain fma() the compiler keeps every coefficient of a polynomial in a VGPR pair for
 // the whole kernel and spells each Horner step as v_mov_b64 (copy the coefficient) + v_fmac_f64 (accumulate into the
@@ -73,7 +97,7 @@ inline void ns_libm_tables(NsLibmTables *t) {
 }
 
 __host__ __device__ __forceinline__ float fast_log_ge1(float x, const NsLibmTables &M) {
-    if (!(x >= 1.0f && x < 3.0e38f)) return (float)log((double)x);  // never taken on the NS's arguments (|X| + 1, 1 + 2 snr)
+    if (!(x >= 1.0f && x < 3.0e38f)) return slow_log(x);  // never taken on the NS's arguments (|X| + 1, 1 + 2 snr)
     unsigned u;
     __builtin_memcpy(&u, &x, 4);
     const int e = (int)(u >> 23) - 127;
@@ -99,7 +123,7 @@ __host__ __device__ __forceinline__ float fast_log_ge1(float x, const NsLibmTabl
 
 __host__ __device__ __forceinline__ float fast_exp(float xf, const NsLibmTables &M) {
     const double x = (double)xf;
-    if (!(x > -700.0 && x < 700.0)) return (float)exp(x);  // overflow / deep underflow / NaN: the library routine
+    if (!(x > -700.0 && x < 700.0)) return slow_exp(xf);  // overflow / deep underflow / NaN: the library routine
     constexpr double kInv = 0x1.71547652b82fep+6;                                   // 64 / ln2
     constexpr double kHi = 0x1.62e42fefa0000p-7, kLo = 0x1.cf79abc9e3b3ap-46;       // ln2 / 64, kHi * k exact for |k| < 2^21
     const double kd = rint(x * kInv);
@@ -126,7 +150,7 @@ __host__ __device__ __forceinline__ float fast_exp(float xf, const NsLibmTables 
 __host__ __device__ __forceinline__ float fast_tanh(float xf, const NsLibmTables &M) {
     const double a2 = 2.0 * fabs((double)xf);
     if (!(a2 < 40.0)) {
-        if (a2 != a2) return (float)tanh((double)xf);  // NaN: the library routine
+        if (a2 != a2) return slow_tanh(xf);  // NaN: the library routine
         return xf < 0.f ? -1.0f : 1.0f;
     }
     constexpr double kInv = 0x1.71547652b82fep+6;                              // 64 / ln2
