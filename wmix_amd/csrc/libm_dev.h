@@ -35,13 +35,6 @@ __host__ __device__ __forceinline__ float slow_exp(float x) {
     return (float)exp((double)x);
 #endif
 }
-__host__ __device__ __forceinline__ float slow_tanh(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return tanh_d(x);
-#else
-    return (float)tanh((double)x);
-#endif
-}
 
 // p * r + c for a literal coefficient c.  On the device the coefficient sits in an SGPR pair and the operation is one
 // three-address v_fma_f64; written as plain fma() the compiler keeps every coefficient of a polynomial in a VGPR pair for
@@ -150,7 +143,7 @@ __host__ __device__ __forceinline__ float fast_exp(float xf, const NsLibmTables 
 __host__ __device__ __forceinline__ float fast_tanh(float xf, const NsLibmTables &M) {
     const double a2 = 2.0 * fabs((double)xf);
     if (!(a2 < 40.0)) {
-        if (a2 != a2) return slow_tanh(xf);  // NaN: the library routine
+        if (a2 != a2) return xf + xf;  // NaN in, (quiet) NaN out, like the library routine
         return xf < 0.f ? -1.0f : 1.0f;
     }
     constexpr double kInv = 0x1.71547652b82fep+6;                              // 64 / ln2
