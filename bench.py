@@ -3,6 +3,9 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
+--gpus N > 1 outside a torchrun environment starts N rank processes of this script itself (one per GPU, RCCL);
+under torchrun (WORLD_SIZE set) --gpus must equal WORLD_SIZE.
+
 A "step" is one pass of the hot path over one batch of synthetic 10 ms frames that
 is already resident in HBM.  Streams shard across ranks with no data-path
 collective except the one RCCL broadcast of the shared AEC far-end frame
@@ -446,6 +449,77 @@ DEFAULT_WORKLOAD = "chain"
 
 
 # ----------------------------------------------------------------------------- driver
+class StubCpuWorkload:
+    """No GPU, no HIP library: exists so that the N > 1 launcher, the rendezvous, the far-end broadcast and the JSON
+    contract can be driven on a CPU-only box over gloo (tests/test_bench_launcher.py).  Never a measurement."""
+    name = "stub_cpu"
+    dtype = "int16"
+    bytes_per_frame = 640.0
+    dominant_kernel = "none"
+    dominant_bytes_per_frame = 640.0
+    needs_gpu = False
+
+    def __init__(self, dev, n_streams, rank, dist=None, packets=1):
+        from wmix_amd.shard import broadcast_far
+        self._bcast = broadcast_far
+        self.n_frames = n_streams
+        self.dist, self.rank = dist, rank
+        self.far = torch.zeros(160, dtype=torch.int16)
+        self.acc = torch.zeros(n_streams, 160, dtype=torch.int32)
+        self.k = 0
+
+    def step(self, timed):
+        self.k += 1
+        if self.rank == 0:
+            self.far.fill_(self.k)
+        self._bcast(self.far, self.dist, src=0)
+        self.acc += self.far.to(torch.int32)[None, :]
+
+    def dominant_ms(self):
+        return None
+
+    def config(self):
+        return {"workload": self.name, "streams_per_gpu": self.n_frames, "far_sum": int(self.acc[0, 0].item())}
+
+    def cpu_baseline(self, budget_s):
+        return None
+
+
+WORKLOADS["stub_cpu"] = (StubCpuWorkload, 4)
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a torchrun environment: start N fresh rank processes of this script (one per GPU)
+    and relay rank 0's JSON line.  The parent has imported torch but made no HIP call (importing torch does not
+    initialise the GPU), and it starts children -- it never replaces itself with another program."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", WMIX_BENCH_LAUNCHED_BY="bench.py")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -464,9 +538,18 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(_launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks\n" % (args.gpus, world))
+        sys.exit(2)
+
+    cls, default_streams = WORKLOADS[args.workload]
+    on_gpu = getattr(cls, "needs_gpu", True)
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -475,30 +558,35 @@ def main():
         one_gpu = os.environ.get("WMIX_BENCH_ONE_GPU_GLOO") == "1"
         if one_gpu:
             local_rank = 0
-        torch.cuda.set_device(local_rank)
-        if one_gpu:
+        if on_gpu:
+            torch.cuda.set_device(local_rank)
+        if one_gpu or not on_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = dist.get_backend()
     else:
         dist = None
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+        if on_gpu:
+            torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0) if on_gpu else torch.device("cpu")
 
-    from wmix_amd import _lib
-    _lib.lib()  # no fallback: raises when the HIP library is missing
+    if on_gpu:
+        from wmix_amd import _lib
+        _lib.lib()  # no fallback: raises when the HIP library is missing
 
-    cls, default_streams = WORKLOADS[args.workload]
-    if issubclass(cls, ChainWorkload):
+    if issubclass(cls, (ChainWorkload, StubCpuWorkload)):
         wl = cls(dev, args.streams or default_streams, rank, dist, args.packets_per_step)
     else:
         wl = cls(dev, args.streams or default_streams, rank)
 
     def sync_all():
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     for _ in range(args.prime + args.warmup):
         wl.step(False)
@@ -508,10 +596,14 @@ def main():
         wl.step(True)
     sync_all()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if dist is not None:
+        # max over ranks is the job's time; every rank's own figure rides along for the record
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank_ms = [float(x.item()) / args.steps * 1e3 for x in every]
+        elapsed = max(float(x.item()) for x in every)
 
     # per-stage breakdown: a few extra steps with every launch bracketed by events, outside the timed region
     for _ in range(min(args.steps, 16)):
@@ -522,7 +614,7 @@ def main():
     value = frames_total / elapsed
     dom_ms = wl.dominant_ms()
     roofline = None
-    traffic, traffic_src = _pmc_traffic(wl.dominant_kernel, wl.n_frames)
+    traffic, traffic_src = _pmc_traffic(wl.dominant_kernel, wl.n_frames, getattr(wl, "pmc_tag", "chain"))
     if dom_ms:
         achieved = wl.dominant_bytes_per_frame * wl.n_frames / (dom_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": wl.dominant_kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
@@ -538,18 +630,27 @@ def main():
         "stage_ms": wl.stage_ms() if hasattr(wl, "stage_ms") else None,
         "stage_ms_source": "up to 16 extra steps after the timed region (inside it only the dominant kernel carries events)",
         "whole_step_hbm_frac": round(value / world * wl.bytes_per_frame / 1e9 / HBM_PEAK_GBS, 5),
+        "per_rank_ms_per_step": [round(x, 5) for x in per_rank_ms],
+        # the size the collective library itself reports (backend nccl = RCCL on ROCm); None on one rank
+        "rccl_ranks": (dist.get_world_size() if dist is not None and backend == "nccl" else None),
+        "dist_backend": backend,
+        "launched_by": os.environ.get("WMIX_BENCH_LAUNCHED_BY", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"),
     }
+    if hasattr(wl, "parity_check"):
+        out["parity_checked"] = wl.parity_check() if rank == 0 else None
     if rank == 0:
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = wl.cpu_baseline(args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 
-def _pmc_traffic(kernel, n_frames):
+def _pmc_traffic(kernel, n_frames, tag="chain"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/rNN/chain_hbm_pmc.json,
     made by profiles/tools/profile_chain.sh: separate FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be read from inside this process, so the
@@ -557,7 +658,7 @@ def _pmc_traffic(kernel, n_frames):
     profile was taken at another size or is absent."""
     import glob
     here = os.path.dirname(os.path.abspath(__file__))
-    for path in sorted(glob.glob(os.path.join(here, "profiles", "r*", "chain_hbm_pmc.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(here, "profiles", "r*", tag + "_hbm_pmc.json")), reverse=True):
         try:
             d = json.load(open(path))
             if d.get("n_frames_per_launch") != n_frames:

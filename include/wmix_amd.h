@@ -35,6 +35,11 @@ extern "C" {
 
 const char *wmx_last_error(void);
 int wmx_device_count(void);
+/* Device affinity: every wmx_* handle records the HIP device that is current on the creating thread and every entry
+ * point that takes the handle runs on that device (and restores the caller's), so a host with one thread per GPU needs
+ * no thread-local hipSetDevice discipline.  Device pointers passed to a call must live on
+ * the handle's device.  Works for any wmx_* handle type; WMX_EINVAL for NULL. */
+int wmx_handle_device(const void *handle);
 /* library/ABI version: major*10000 + minor*100 + patch */
 int wmx_version(void);
 
@@ -52,7 +57,8 @@ int wmx_g711_decode(int law, const uint8_t *d_code, int16_t *d_pcm, size_t n_cod
  * Batched form of ns_init / ns_process / ns_release (src/webrtc.h:47-51, src/webrtc.c:560-661):
  * n_streams independent streams, each with the state WebRtcNs_Create/Init/set_policy(2) would
  * give it.  freq in {8000,16000,32000}, chn in {1,2}; anything else -> WMX_EINVAL (ns_init
- * returns NULL there).  A packet is 10 ms = freq/100 frames of chn interleaved int16.
+ * returns NULL there; 24000 passes the wrapper's `freq % 8000` test but WebRtcNs_Init refuses it, and for VAD / AGC
+ * the reference then hands out a handle whose every process call fails -- here creation fails for all four).  A packet is 10 ms = freq/100 frames of chn interleaved int16.
  *
  * wmx_ns_process runs n_packets consecutive packets of every stream in one launch.  Packet p of
  * stream s starts at d_in + s*stream_stride + p*packet_stride (strides in int16 elements), same
@@ -139,8 +145,10 @@ int wmx_aec_export_state(const wmx_aec *h, int stream_index, float *host_words);
  * Batched forms of wmix_pcm_zoom (src/wmix.c:139-222) and of wmix_load_data + the play thread's drain
  * (src/wmix.c:1639-1957, 1347-1366).  Strides in int16 elements.  Integer path: bit-exact, including the
  * dead 2ch->2ch branch of wmix_pcm_zoom (writes 0 bytes) and the order-dependent saturating add. */
+/* out_capacity: bytes available per output row; a conversion that needs more returns WMX_EINVAL with *out_len = the
+ * bytes it needs (wmix_len_of_out gives the same figure beforehand) and writes nothing. */
 int wmx_pcm_zoom(int inChn, int inFreq, const int16_t *d_in, uint32_t inLen, int outChn, int outFreq, int16_t *d_out,
-                 long in_stride, long out_stride, int n_streams, uint32_t *out_len, void *stream);
+                 uint32_t out_capacity, long in_stride, long out_stride, int n_streams, uint32_t *out_len, void *stream);
 typedef struct wmx_mix wmx_mix;
 int wmx_mix_create(wmx_mix **out, int n_groups, int ring_chn, int ring_freq);
 int wmx_mix_destroy(wmx_mix *m);

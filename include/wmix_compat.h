@@ -85,6 +85,18 @@ uint32_t wmix_len_of_in(uint8_t inChn, uint16_t inFreq, uint8_t outChn, uint16_t
 uint32_t wmix_pcm_zoom(uint8_t inChn, uint16_t inFreq, uint8_t *in, uint32_t inLen, uint8_t outChn, uint16_t outFreq,
                        uint8_t *out);
 
+/* The same four functions under names that cannot collide with the daemon's own definitions.  The reference defines the
+ * wmix.h group inside src/wmix.c, the translation unit of main(); a maintainer who links the unchanged daemon against
+ * libwmix_amd.so weakens those four symbols in wmix.o (`objcopy --weaken-symbol`) and adds the object built from
+ * wmix_amd/csrc/daemon_shim.c, whose strong definitions forward here (proven by
+ * tools_dev/link_daemon.sh). */
+WMix_Point wmx_compat_load_data(WMix_Struct_Head *wmix, WMix_Point src, uint32_t srcU8Len, uint16_t freq, uint8_t channels,
+                                uint8_t sample, WMix_Point head, uint8_t reduce, uint32_t *tick);
+uint32_t wmx_compat_len_of_out(uint8_t inChn, uint16_t inFreq, uint32_t inLen, uint8_t outChn, uint16_t outFreq);
+uint32_t wmx_compat_len_of_in(uint8_t inChn, uint16_t inFreq, uint8_t outChn, uint16_t outFreq, uint32_t outLen);
+uint32_t wmx_compat_pcm_zoom(uint8_t inChn, uint16_t inFreq, uint8_t *in, uint32_t inLen, uint8_t outChn, uint16_t outFreq,
+                             uint8_t *out);
+
 /* ------------------------------------------------------------------ math/fft.h:19-51 (stand-alone FFT helpers;
  * no callers inside the daemon, kept for link compatibility with tools that use them).  Host arrays. */
 void FFT(float inReal[], float inImag[], float outReal[], float outImag[], float outAF[], float outPF[], unsigned int N);

@@ -69,3 +69,23 @@ def test_padded_strides_and_long_launches(cuda, oracle_port):
         check_float_path(out[s, :, :pkt].reshape(-1), want)
     for b in (ns, aec, agc, vad):
         b.close()
+
+
+def test_24khz_is_rejected_everywhere(cuda, wmx):
+    """24000 passes the reference wrappers' `freq % 8000` test, but WebRtcNs_Init refuses it and WebRtcVad / WebRtcAgc
+    fail on every packet (round-1 ADVICE: we used to build a 240-sample packet and process 160 of it)."""
+    import ctypes as C
+    from wmix_amd._lib import WmxError
+    for mk in (lambda: NsBatch(2, 1, 24000), lambda: AgcBatch(2, 1, 24000, 5), lambda: VadBatch(2, 1, 24000, 10),
+               lambda: AecBatch(2, 1, 24000, 10)):
+        with pytest.raises(WmxError):
+            mk()
+    assert not wmx.ns_init(1, 24000, None) and not wmx.agc_init(1, 24000, 10, 5, None)
+    assert not wmx.vad_init(1, 24000, 10, None) and not wmx.aec_init(1, 24000, 10, None)
+
+
+def test_handles_know_their_device(cuda, wmx):
+    ns = NsBatch(1, 1, 8000)
+    assert wmx.wmx_handle_device(ns._h) == torch.cuda.current_device()
+    assert wmx.wmx_handle_device(None) == -10001
+    ns.close()

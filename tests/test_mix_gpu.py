@@ -124,3 +124,102 @@ def test_full_size_mix_properties(cuda):
     assert np.array_equal(out[0], r0[1600:1680]) and np.array_equal(out[1], r1[1600:1680])
     assert not mb.export(0)[0].any()
     mb.close()
+
+
+def _legacy_types(wmx):
+    class Point(C.Union):
+        _fields_ = [("U8", C.c_void_p)]
+
+    class Head(C.Structure):  # WMix_Struct_Head (include/wmix_compat.h)
+        _fields_ = [("objAo", C.c_void_p), ("objAi", C.c_void_p), ("buff", C.c_void_p), ("start", Point), ("end", Point), ("head", Point),
+                    ("tail", Point), ("run", C.c_bool), ("loopWord", C.c_uint8), ("loopWordRecord", C.c_uint8), ("loopWordFifo", C.c_uint8),
+                    ("loopWordRtp", C.c_uint8), ("tick", C.c_uint32), ("thread_sys", C.c_uint32), ("thread_record", C.c_uint32),
+                    ("thread_play", C.c_uint32), ("playRun", C.c_bool), ("recordRun", C.c_bool), ("shmemRun", C.c_int), ("msg_key", C.c_int),
+                    ("msg_fd", C.c_int), ("reduceMode", C.c_uint8)]
+
+    wmx.wmix_load_data.restype = Point
+    wmx.wmix_load_data.argtypes = [C.POINTER(Head), Point, C.c_uint32, C.c_uint16, C.c_uint8, C.c_uint8, Point, C.c_uint8, C.POINTER(C.c_uint32)]
+    return Point, Head
+
+
+def test_legacy_load_data_touches_only_its_span(wmx, oracle_port):
+    """The reference writes ring bytes [head, head + n_out*2) and nothing else while other threads work on the ring
+    (src/wmix.c:1347-1352, 1678-1702).  A second thread keeps rewriting ring samples OUTSIDE the span during many legacy
+    calls (ctypes releases the GIL for the call): none of its writes may be lost or resurrected, and the span itself
+    must equal the oracle's ring, including across the wrap.  Also: the copy branch must not read behind the source."""
+    import threading
+    Point, Head = _legacy_types(wmx)
+    _bind(oracle_port)
+    ring = np.zeros(8000 + 8, np.int16)
+    w = Head()
+    w.start.U8, w.end.U8 = ring.ctypes.data, ring.ctypes.data + 16000
+    start = 16000 - 100  # the span of every call wraps
+    w.head.U8 = ring.ctypes.data + start
+    w.run, w.reduceMode, w.tick = True, 1, 0
+    # source buffer that ends exactly at the end of an allocation guard: the 320 B same-format source sits at the tail
+    rng = np.random.default_rng(3)
+    src = rng.integers(-9000, 9000, size=160, dtype=np.int16)
+    outside = np.r_[100:3000]  # sample indices far from the span [7950, 8000) + [0, 110)
+    stop = threading.Event()
+    writes = [0]
+
+    def player():  # plays the part of wmix_play_thread zeroing / other tasks adding elsewhere in the ring
+        k = 0
+        while not stop.is_set():
+            k += 1
+            ring[outside] = k & 0x7FFF
+            writes[0] = k
+
+    th = threading.Thread(target=player)
+    th.start()
+    try:
+        for _ in range(200):
+            tick = C.c_uint32(0)
+            sp, hp = Point(), Point()
+            sp.U8, hp.U8 = src.ctypes.data, None
+            r = wmx.wmix_load_data(C.byref(w), sp, 320, 8000, 1, 16, hp, 1, C.byref(tick))
+            assert r.U8 is not None
+    finally:
+        stop.set()
+        th.join()
+    # the player's last write is intact everywhere outside the span (a whole-ring write-back would have restored
+    # older values somewhere in these 2 900 samples at some point of 200 calls)
+    assert (ring[outside] == (writes[0] & 0x7FFF)).all()
+    # the span: 200 saturating adds of the same packet at head + PLAY_CORRECT (head == NULL => wmix->head + 3200 B)
+    pos = ((start + 3200) % 16000) // 2
+    want = np.zeros(8000, np.int16)
+    acc = np.zeros(160, np.int32)
+    for _ in range(200):
+        a, b = acc, src.astype(np.int32)
+        acc = np.where(a == 0, b, np.where(b == 0, a, np.clip(a + b, -32768, 32767)))
+    idx = (pos + np.arange(160)) % 8000
+    want[idx] = acc
+    got = ring[:8000].copy()
+    got[outside] = 0
+    assert np.array_equal(got, want)
+
+
+def test_zoom_capacity_is_checked(cuda, wmx):
+    import torch
+    x = torch.zeros(2, 160, dtype=torch.int16, device=cuda)
+    out = torch.full((2, 400), 77, dtype=torch.int16, device=cuda)
+    need = C.c_uint32(0)
+    rc = wmx.wmx_pcm_zoom(1, 8000, x.data_ptr(), 320, 1, 16000, out.data_ptr(), 100, 160, 400, 2, C.byref(need), None)
+    assert rc == -10001 and need.value == 640
+    torch.cuda.synchronize()
+    assert (out == 77).all()
+    rc = wmx.wmx_pcm_zoom(1, 8000, x.data_ptr(), 320, 1, 16000, out.data_ptr(), 640, 160, 400, 2, C.byref(need), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert (out[:, :320] == 0).all() and (out[:, 320:] == 77).all()
+
+
+def test_load_rejects_more_than_one_ring(cuda):
+    import torch
+    from wmix_amd._lib import WmxError
+    from wmix_amd.mix import MixBatch
+    mb = MixBatch(1, 1, 8000)
+    d = torch.zeros(1, 1, 9000, dtype=torch.int16, device=cuda)
+    with pytest.raises(WmxError):
+        mb.load(d, 17000, 8000, 1)
+    mb.close()

@@ -106,7 +106,9 @@ def _declare(L):
     L.wmx_aec_run.argtypes = [vp, i, vp, C.c_long, vp, vp, i, C.c_long, C.c_long, i, vp]
     u32 = C.c_uint32
     L.wmx_pcm_zoom.restype = i
-    L.wmx_pcm_zoom.argtypes = [i, i, vp, u32, i, i, vp, C.c_long, C.c_long, i, C.POINTER(u32), vp]
+    L.wmx_pcm_zoom.argtypes = [i, i, vp, u32, i, i, vp, u32, C.c_long, C.c_long, i, C.POINTER(u32), vp]
+    L.wmx_handle_device.restype = i
+    L.wmx_handle_device.argtypes = [vp]
     L.wmx_mfft.restype = i
     L.wmx_mfft.argtypes = [i, i, C.c_uint, vp, vp, vp, vp, vp, vp, vp]
     L.wmx_mfft_stream.restype = i

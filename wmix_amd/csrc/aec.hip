@@ -1064,6 +1064,7 @@ __global__ void aec_fill_state(float *state, const float *tmpl, int words, int n
 
 // ================================================================== host
 struct wmx_aec {
+    int device;  // the HIP device the state lives on (current device at create); every entry point switches to it
     int n_streams, chn, freq, pkg;
     wmx::AecCtl ctl;
     float *d_state;
@@ -1078,6 +1079,7 @@ struct wmx_aec {
 extern "C" {
 
 int wmx_aec_destroy(wmx_aec *h) {
+    WMX_ON_DEVICE(h);
     if (!h) return 0;
     if (h->d_state) (void)hipFree(h->d_state);
     if (h->d_consts) (void)hipFree(h->d_consts);
@@ -1092,11 +1094,15 @@ int wmx_aec_create(wmx_aec **out, int n_streams, int chn, int freq, int interval
     if (!out) return WMX_EINVAL;
     *out = nullptr;
     // aec_init: freq <= 16000 and a multiple of 8000 (src/webrtc.c:220-221)
-    if (freq > 16000 || freq % 8000 != 0 || freq <= 0 || chn < 1 || n_streams < 1) {
+    if ((freq != 8000 && freq != 16000) || chn < 1 || n_streams < 1) {
         set_error("wmx_aec_create: unsupported n_streams=%d chn=%d freq=%d", n_streams, chn, freq);
         return WMX_EINVAL;
     }
     wmx_aec *h = new wmx_aec();
+    if ((h->device = wmx::current_device()) < 0) {
+        delete h;
+        return WMX_ENODEV;
+    }
     h->n_streams = n_streams;
     h->chn = chn;
     h->freq = freq;
@@ -1180,6 +1186,7 @@ int wmx_aec_packet_samples(const wmx_aec *h) { return h ? h->pkg * h->chn : WMX_
 int wmx_aec_state_words(const wmx_aec *h) { return h ? (int)wmx::AS_WORDS : WMX_EINVAL; }
 
 int wmx_aec_export_state(const wmx_aec *h, int stream_index, float *host_words) {
+    WMX_ON_DEVICE(h);
     if (!h || !host_words || stream_index < 0 || stream_index >= h->n_streams) return WMX_EINVAL;
     WMX_HIP(hipDeviceSynchronize());
     WMX_HIP(hipMemcpy(host_words, h->d_state + (size_t)stream_index * wmx::AS_WORDS, wmx::AS_WORDS * sizeof(float), hipMemcpyDeviceToHost));
@@ -1191,6 +1198,7 @@ int wmx_aec_export_state(const wmx_aec *h, int stream_index, float *host_words) 
 // Returns 0, WMX_E*, or the reference's -1 when a packet is rejected (bad delay: packets before it are done).
 int wmx_aec_run(wmx_aec *h, int mode, const int16_t *d_far, long far_packet_stride, const int16_t *d_near, int16_t *d_out,
                 int n_packets, long stream_stride, long packet_stride, int delay_ms, void *stream) {
+    WMX_ON_DEVICE(h);
     using namespace wmx;
     if (!h || n_packets < 0 || (mode & 3) == 0) {
         set_error("wmx_aec_run: bad argument");

@@ -464,6 +464,7 @@ int16_t analog_target_for(int16_t comp_db) {
 }  // namespace wmx
 
 struct wmx_agc {
+    int device;  // the HIP device the state lives on (current device at create); every entry point switches to it
     int n_streams, chn, freq, pkg;
     int16_t *d_s16;
     int32_t *d_s32;
@@ -474,6 +475,7 @@ struct wmx_agc {
 extern "C" {
 
 int wmx_agc_destroy(wmx_agc *h) {
+    WMX_ON_DEVICE(h);
     if (!h) return 0;
     if (h->d_s16) (void)hipFree(h->d_s16);
     if (h->d_s32) (void)hipFree(h->d_s32);
@@ -485,6 +487,7 @@ int wmx_agc_destroy(wmx_agc *h) {
 // agc_addition (src/webrtc.c:824-839): WebRtcAgc_set_config with a new compression gain -> new table.
 // Returns WMX_EINVAL and keeps the old table when the reference's set_config would fail.
 int wmx_agc_set_gain(wmx_agc *h, int value) {
+    WMX_ON_DEVICE(h);
     using namespace wmx;
     if (!h) return WMX_EINVAL;
     int32_t t[32];
@@ -503,11 +506,15 @@ int wmx_agc_create(wmx_agc **out, int n_streams, int chn, int freq, int interval
     (void)interval_ms;
     if (!out) return WMX_EINVAL;
     *out = nullptr;
-    if (freq > 32000 || freq % 8000 != 0 || freq <= 0 || chn < 1 || n_streams < 1) {  // src/webrtc.c:711-712
+    if ((freq != 8000 && freq != 16000 && freq != 32000) || chn < 1 || n_streams < 1) {  // src/webrtc.c:711-712
         set_error("wmx_agc_create: unsupported n_streams=%d chn=%d freq=%d", n_streams, chn, freq);
         return WMX_EINVAL;
     }
     wmx_agc *h = new wmx_agc();
+    if ((h->device = wmx::current_device()) < 0) {
+        delete h;
+        return WMX_ENODEV;
+    }
     h->n_streams = n_streams;
     h->chn = chn;
     h->freq = freq;
@@ -538,6 +545,7 @@ int wmx_agc_create(wmx_agc **out, int n_streams, int chn, int freq, int interval
 int wmx_agc_packet_samples(const wmx_agc *h) { return h ? h->pkg * h->chn : WMX_EINVAL; }
 
 int wmx_agc_gain_table(const wmx_agc *h, int32_t *host_table32) {
+    WMX_ON_DEVICE(h);
     if (!h || !host_table32) return WMX_EINVAL;
     memcpy(host_table32, h->table, sizeof(h->table));
     return 0;
@@ -545,6 +553,7 @@ int wmx_agc_gain_table(const wmx_agc *h, int32_t *host_table32) {
 
 int wmx_agc_process(wmx_agc *h, const int16_t *d_in, int16_t *d_out, int n_packets, long stream_stride, long packet_stride,
                     void *stream) {
+    WMX_ON_DEVICE(h);
     using namespace wmx;
     if (!h || n_packets < 0) {
         set_error("wmx_agc_process: bad argument");

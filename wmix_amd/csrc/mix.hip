@@ -223,6 +223,9 @@ __global__ __launch_bounds__(256) void drain_kernel(int16_t *__restrict__ rings,
 struct DevVec {
     void *p = nullptr;
     size_t cap = 0;
+    bool leak = false;  // thread_local instances skip hipFree at thread / process end (the runtime may be gone)
+    DevVec() = default;
+    explicit DevVec(bool leak_at_exit) : leak(leak_at_exit) {}
     int ensure(size_t bytes) {
         if (bytes <= cap) return 0;
         if (p) (void)hipFree(p);
@@ -233,7 +236,7 @@ struct DevVec {
         return 0;
     }
     ~DevVec() {
-        if (p) (void)hipFree(p);
+        if (p && !leak) (void)hipFree(p);
     }
 };
 
@@ -250,11 +253,12 @@ void zoom_gather_list(int inChn, int inFreq, uint32_t inLen, int outChn, int out
 }  // namespace wmx
 
 struct wmx_mix {
+    int device;  // the HIP device the state lives on (current device at create); every entry point switches to it
     int n_groups, chn, freq;
     uint32_t ring_bytes, head_off, tick, play_correct;
     uint8_t reduce_mode;
     int16_t *d_rings;
-    wmx::DevVec d_sch;
+    wmx::SchedCache sched;  // load schedules per source format, never rewritten (see SchedCache)
     std::vector<wmx::LoadEntry> sch;
 };
 
@@ -270,9 +274,11 @@ uint32_t wmix_len_of_in(uint8_t inChn, uint16_t inFreq, uint8_t outChn, uint16_t
     return wmx::len_walk(inChn, inFreq, outChn, outFreq, outLen, false, true);
 }
 
-// batched wmix_pcm_zoom: n_streams buffers of the same format and length.  Strides in int16 elements.
-int wmx_pcm_zoom(int inChn, int inFreq, const int16_t *d_in, uint32_t inLen, int outChn, int outFreq, int16_t *d_out, long in_stride,
-                 long out_stride, int n_streams, uint32_t *out_len, void *stream) {
+// batched wmix_pcm_zoom: n_streams buffers of the same format and length.  Strides in int16 elements.  out_capacity =
+// bytes available per output row: a conversion that needs more fails with WMX_EINVAL (and *out_len = what it needs)
+// instead of overrunning the row -- the reference has no such check, its callers size `out` by wmix_len_of_out.
+int wmx_pcm_zoom(int inChn, int inFreq, const int16_t *d_in, uint32_t inLen, int outChn, int outFreq, int16_t *d_out, uint32_t out_capacity,
+                 long in_stride, long out_stride, int n_streams, uint32_t *out_len, void *stream) {
     using namespace wmx;
     if (!d_in || !d_out || n_streams < 1 || inChn < 1 || outChn < 1 || inFreq < 1 || outFreq < 1) {
         set_error("wmx_pcm_zoom: bad argument");
@@ -281,6 +287,10 @@ int wmx_pcm_zoom(int inChn, int inFreq, const int16_t *d_in, uint32_t inLen, int
     hipStream_t s = as_stream(stream);
     if (inFreq == outFreq && inChn == outChn) {  // memcpy branch, src/wmix.c:154-158
         if (out_len) *out_len = inLen;
+        if (inLen > out_capacity) {
+            set_error("wmx_pcm_zoom: %u output bytes per row, capacity %u", inLen, out_capacity);
+            return WMX_EINVAL;
+        }
         if (inLen == 0) return 0;
         if (n_streams == 1)
             WMX_HIP(hipMemcpyAsync(d_out, d_in, inLen, hipMemcpyDeviceToDevice, s));
@@ -288,15 +298,25 @@ int wmx_pcm_zoom(int inChn, int inFreq, const int16_t *d_in, uint32_t inLen, int
             WMX_HIP(hipMemcpy2DAsync(d_out, out_stride * 2, d_in, in_stride * 2, inLen, n_streams, hipMemcpyDeviceToDevice, s));
         return 0;
     }
+    // the gather list depends on the format only: built and uploaded once per format and thread
     static thread_local std::vector<int32_t> idx;
-    static thread_local DevVec d_idx;
-    zoom_schedule((uint8_t)inChn, (uint16_t)inFreq, inLen, (uint8_t)outChn, (uint16_t)outFreq, idx);
-    if (out_len) *out_len = (uint32_t)(idx.size() * 2);
-    if (idx.empty()) return 0;
-    if (d_idx.ensure(idx.size() * sizeof(int32_t))) return WMX_ENODEV;
-    WMX_HIP(hipMemcpyAsync(d_idx.p, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    const unsigned grid = stream_grid(idx.size() * (size_t)n_streams, 256);
-    hipLaunchKernelGGL(zoom_kernel, dim3(grid), dim3(256), 0, s, d_in, d_out, (const int32_t *)d_idx.p, (uint32_t)idx.size(), in_stride,
+    static thread_local SchedCache cache(true);
+    const uint64_t k0 = ((uint64_t)inChn << 56) | ((uint64_t)outChn << 48) | ((uint64_t)(uint32_t)inFreq << 24) | (uint32_t)outFreq;
+    const uint64_t k1 = ((uint64_t)(uint32_t)current_device() << 32) | inLen;
+    const SchedCache::Entry *ent = cache.find(k0, k1);
+    if (!ent) {
+        zoom_schedule((uint8_t)inChn, (uint16_t)inFreq, inLen, (uint8_t)outChn, (uint16_t)outFreq, idx);
+        const int rc = cache.add(k0, k1, idx.data(), idx.size() * sizeof(int32_t), idx.size(), &ent);
+        if (rc) return rc;
+    }
+    if (out_len) *out_len = (uint32_t)(ent->n * 2);
+    if (ent->n * 2 > out_capacity) {
+        set_error("wmx_pcm_zoom: %zu output bytes per row, capacity %u", ent->n * 2, out_capacity);
+        return WMX_EINVAL;
+    }
+    if (ent->n == 0) return 0;
+    const unsigned grid = stream_grid(ent->n * (size_t)n_streams, 256);
+    hipLaunchKernelGGL(zoom_kernel, dim3(grid), dim3(256), 0, s, d_in, d_out, (const int32_t *)ent->p, (uint32_t)ent->n, in_stride,
                        out_stride, n_streams);
     WMX_LAUNCH_CHECK();
     return 0;
@@ -305,19 +325,20 @@ int wmx_pcm_zoom(int inChn, int inFreq, const int16_t *d_in, uint32_t inLen, int
 // legacy host form, src/wmix.h:122-127
 uint32_t wmix_pcm_zoom(uint8_t inChn, uint16_t inFreq, uint8_t *in, uint32_t inLen, uint8_t outChn, uint16_t outFreq, uint8_t *out) {
     using namespace wmx;
-    static thread_local DevVec a, b;
-    // capacity bound: every input frame emits at most ceil(outFreq/inFreq)+1 output frames
-    const uint32_t max_out = (inLen / 2 / inChn + 2) * (outFreq / inFreq + 2) * outChn * 2 + 16;
+    static thread_local DevVec a(true), b(true);
+    if (inLen == 0 || !in || !out || !inFreq || !outFreq || !inChn || !outChn) return 0;
+    const uint32_t need = wmix_len_of_out(inChn, inFreq, inLen, outChn, outFreq);  // what the reference's callers size `out` by
     uint32_t n = 0;
-    if (inLen == 0) return 0;
-    if (a.ensure(inLen + 16) || b.ensure(max_out)) return 0;
+    if (a.ensure(inLen + 16) || b.ensure((size_t)need + 16)) return 0;
     if (hipMemcpy(a.p, in, inLen, hipMemcpyHostToDevice) != hipSuccess) return 0;
-    if (wmx_pcm_zoom(inChn, inFreq, (const int16_t *)a.p, inLen, outChn, outFreq, (int16_t *)b.p, 0, 0, 1, &n, nullptr) != 0) return 0;
+    if (wmx_pcm_zoom(inChn, inFreq, (const int16_t *)a.p, inLen, outChn, outFreq, (int16_t *)b.p, need + 16, 0, 0, 1, &n, nullptr) != 0)
+        return 0;
     if (n && hipMemcpy(out, b.p, n, hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return n;
 }
 
 int wmx_mix_destroy(wmx_mix *m) {
+    WMX_ON_DEVICE(m);
     if (!m) return 0;
     if (m->d_rings) (void)hipFree(m->d_rings);
     delete m;
@@ -334,6 +355,10 @@ int wmx_mix_create(wmx_mix **out, int n_groups, int ring_chn, int ring_freq) {
         return WMX_EINVAL;
     }
     wmx_mix *m = new wmx_mix();
+    if ((m->device = wmx::current_device()) < 0) {
+        delete m;
+        return WMX_ENODEV;
+    }
     m->n_groups = n_groups;
     m->chn = ring_chn;
     m->freq = ring_freq;
@@ -355,6 +380,7 @@ int wmx_mix_create(wmx_mix **out, int n_groups, int ring_chn, int ring_freq) {
 }
 
 int wmx_mix_set(wmx_mix *m, uint32_t head_off, uint32_t tick, int reduce_mode) {
+    WMX_ON_DEVICE(m);
     if (!m || head_off >= m->ring_bytes || reduce_mode < 1 || reduce_mode > 255) return WMX_EINVAL;
     m->head_off = head_off;
     m->tick = tick;
@@ -372,6 +398,7 @@ int wmx_mix_ring_bytes(const wmx_mix *m) { return m ? (int)m->ring_bytes : WMX_E
 // srcU8Len; the caller's buffers must make that frame readable.
 int wmx_mix_load(wmx_mix *m, const int16_t *d_src, uint32_t srcU8Len, int freq, int channels, int sample, int n_src, long group_stride,
                  long source_stride, int reduce, uint32_t *head, uint32_t *tick, void *stream) {
+    WMX_ON_DEVICE(m);
     using namespace wmx;
     if (!m || !head || !tick || n_src < 1) {
         set_error("wmx_mix_load: bad argument");
@@ -384,18 +411,28 @@ int wmx_mix_load(wmx_mix *m, const int16_t *d_src, uint32_t srcU8Len, int freq, 
         tk = m->tick + m->play_correct;
         if (head_off >= m->ring_bytes) head_off = 0;
     }
-    if (!load_schedule(m->chn, m->freq, srcU8Len, (uint16_t)freq, (uint8_t)channels, (uint8_t)sample, m->sch)) {
-        set_error("wmx_mix_load: rate ratio needs more than 64 fill samples (the reference overruns repairBuff here)");
-        return WMX_EINVAL;
+    const uint64_t k0 = ((uint64_t)srcU8Len << 32) | (uint32_t)freq, k1 = ((uint64_t)(uint8_t)channels << 8) | (uint8_t)sample;
+    const SchedCache::Entry *ent = m->sched.find(k0, k1);
+    if (!ent) {
+        if (!load_schedule(m->chn, m->freq, srcU8Len, (uint16_t)freq, (uint8_t)channels, (uint8_t)sample, m->sch)) {
+            set_error("wmx_mix_load: rate ratio needs more than 64 fill samples (the reference overruns repairBuff here)");
+            return WMX_EINVAL;
+        }
+        // More than one ring of output would make two threads of the launch read-modify-write the same ring sample (the
+        // reference adds them one after the other); nothing in the daemon loads more than a few packets per call.
+        if (m->sch.size() > m->ring_bytes / 2) {
+            set_error("wmx_mix_load: %zu output samples do not fit the %u-sample ring in one call", m->sch.size(), m->ring_bytes / 2);
+            return WMX_EINVAL;
+        }
+        const int rc = m->sched.add(k0, k1, m->sch.data(), m->sch.size() * sizeof(LoadEntry), m->sch.size(), &ent);
+        if (rc) return rc;
     }
-    const uint32_t n_out = (uint32_t)m->sch.size();
+    const uint32_t n_out = (uint32_t)ent->n;
     const int rdce = (reduce == m->reduce_mode) ? 1 : m->reduce_mode;  // src/wmix.c:1675-1676
     hipStream_t s = as_stream(stream);
     if (n_out) {
-        if (m->d_sch.ensure(n_out * sizeof(LoadEntry))) return WMX_ENODEV;
-        WMX_HIP(hipMemcpyAsync(m->d_sch.p, m->sch.data(), n_out * sizeof(LoadEntry), hipMemcpyHostToDevice, s));
         const unsigned grid = stream_grid((size_t)n_out * m->n_groups, 256);
-        hipLaunchKernelGGL(load_kernel, dim3(grid), dim3(256), 0, s, m->d_rings, m->ring_bytes / 2, d_src, (const LoadEntry *)m->d_sch.p,
+        hipLaunchKernelGGL(load_kernel, dim3(grid), dim3(256), 0, s, m->d_rings, m->ring_bytes / 2, d_src, (const LoadEntry *)ent->p,
                            n_out, head_off / 2, n_src, group_stride, source_stride, rdce, m->n_groups);
         WMX_LAUNCH_CHECK();
     }
@@ -417,6 +454,7 @@ int wmx_mix_load(wmx_mix *m, const int16_t *d_src, uint32_t srcU8Len, int freq, 
 // the play thread's drain (src/wmix.c:1347-1366): read `bytes` at the ring head into d_out (per group), zero what
 // was read, advance head and tick.
 int wmx_mix_drain(wmx_mix *m, int16_t *d_out, uint32_t bytes, long out_stride, void *stream) {
+    WMX_ON_DEVICE(m);
     using namespace wmx;
     if (!m || !d_out || (bytes & 1) || bytes > m->ring_bytes) return WMX_EINVAL;
     if (bytes == 0) return 0;
@@ -451,7 +489,7 @@ WMix_Point wmix_load_data(WMix_Struct_Head *wmix, WMix_Point src, uint32_t srcU8
     }
     const uint32_t size = (uint32_t)(wmix->end.U8 - wmix->start.U8);
     static thread_local wmx_mix *m = nullptr;
-    static thread_local DevVec d_src;
+    static thread_local DevVec d_src(true);
     if (!m || m->chn != ring_chn || m->freq != ring_freq) {
         if (m) wmx_mix_destroy(m);
         m = nullptr;
@@ -466,12 +504,35 @@ WMix_Point wmix_load_data(WMix_Struct_Head *wmix, WMix_Point src, uint32_t srcU8
     m->tick = wmix->tick;
     m->reduce_mode = wmix->reduceMode;
     uint32_t h = head.U8 ? (uint32_t)(head.U8 - wmix->start.U8) : UINT32_MAX, t = *tick;
-    const size_t src_bytes = (size_t)srcU8Len + 2 * channels;  // + the frame the fill looks ahead to (see wmx_mix_load)
-    bool ok = d_src.ensure(src_bytes) == 0;
+    // The reference touches ring bytes [head, head + n_out*2) only, while other task threads and the play thread work on
+    // the same ring without a lock (src/wmix.c:1347-1352, 1678-1702).  So does this adapter: the span the call will write
+    // is worked out first (same cursor rule and schedule as wmx_mix_load), only that span goes up, and only it comes
+    // back.  Between the two copies the adapter is a read-modify-write like the reference's per-sample `*pHead = ...`,
+    // just longer: it gives no more atomicity than the reference does, and no less outside the span.
+    uint32_t span_off = h;
+    if (span_off == UINT32_MAX || t < m->tick) {  // src/wmix.c:1666-1673, as in wmx_mix_load
+        span_off = m->head_off + m->play_correct;
+        if (span_off >= m->ring_bytes) span_off = 0;
+    }
+    if (span_off >= size || (span_off & 1)) return pHead;
+    if (!load_schedule(m->chn, m->freq, srcU8Len, freq, channels, sample, m->sch) || m->sch.size() > size / 2) {
+        fprintf(stderr, "wmix_amd: wmix_load_data: unsupported rate ratio or more than one ring of output\n");
+        return pHead;
+    }
+    const uint32_t span = (uint32_t)m->sch.size() * 2;
+    const uint32_t first = span < size - span_off ? span : size - span_off, second = span - first;  // split at the wrap
+    // the up-sampling fill interpolates towards the frame behind the last one (src/wmix.c:1857,1914); the copy and
+    // down-sampling branches never read ahead, and neither does the adapter
+    const bool reads_ahead = sample == 16 && (channels == 1 || channels == 2) && (int)freq < m->freq;
+    const size_t src_bytes = (size_t)srcU8Len + (reads_ahead ? 2 * channels : 0);
+    uint8_t *ring = (uint8_t *)m->d_rings;
+    bool ok = d_src.ensure(src_bytes + 8) == 0;
     ok = ok && hipMemcpy(d_src.p, src.U8, src_bytes, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && hipMemcpy(m->d_rings, wmix->start.U8, size, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && (!first || hipMemcpy(ring + span_off, wmix->start.U8 + span_off, first, hipMemcpyHostToDevice) == hipSuccess);
+    ok = ok && (!second || hipMemcpy(ring, wmix->start.U8, second, hipMemcpyHostToDevice) == hipSuccess);
     ok = ok && wmx_mix_load(m, (const int16_t *)d_src.p, srcU8Len, freq, channels, sample, 1, 0, 0, reduce, &h, &t, nullptr) == 0;
-    ok = ok && hipMemcpy(wmix->start.U8, m->d_rings, size, hipMemcpyDeviceToHost) == hipSuccess;
+    ok = ok && (!first || hipMemcpy(wmix->start.U8 + span_off, ring + span_off, first, hipMemcpyDeviceToHost) == hipSuccess);
+    ok = ok && (!second || hipMemcpy(wmix->start.U8, ring, second, hipMemcpyDeviceToHost) == hipSuccess);
     if (!ok) {
         (void)hipGetLastError();
         fprintf(stderr, "wmix_amd: wmix_load_data failed on the GPU: %s\n", wmx_last_error());
@@ -482,7 +543,23 @@ WMix_Point wmix_load_data(WMix_Struct_Head *wmix, WMix_Point src, uint32_t srcU8
     return pHead;
 }
 
+// collision-free names of the legacy group for the daemon link shim (include/wmix_compat.h, daemon_shim.c)
+WMix_Point wmx_compat_load_data(WMix_Struct_Head *wmix, WMix_Point src, uint32_t srcU8Len, uint16_t freq, uint8_t channels, uint8_t sample,
+                                WMix_Point head, uint8_t reduce, uint32_t *tick) {
+    return wmix_load_data(wmix, src, srcU8Len, freq, channels, sample, head, reduce, tick);
+}
+uint32_t wmx_compat_len_of_out(uint8_t inChn, uint16_t inFreq, uint32_t inLen, uint8_t outChn, uint16_t outFreq) {
+    return wmix_len_of_out(inChn, inFreq, inLen, outChn, outFreq);
+}
+uint32_t wmx_compat_len_of_in(uint8_t inChn, uint16_t inFreq, uint8_t outChn, uint16_t outFreq, uint32_t outLen) {
+    return wmix_len_of_in(inChn, inFreq, outChn, outFreq, outLen);
+}
+uint32_t wmx_compat_pcm_zoom(uint8_t inChn, uint16_t inFreq, uint8_t *in, uint32_t inLen, uint8_t outChn, uint16_t outFreq, uint8_t *out) {
+    return wmix_pcm_zoom(inChn, inFreq, in, inLen, outChn, outFreq, out);
+}
+
 int wmx_mix_export(const wmx_mix *m, int group, int16_t *host_ring, uint32_t *head_off, uint32_t *tick) {
+    WMX_ON_DEVICE(m);
     if (!m || group < 0 || group >= m->n_groups) return WMX_EINVAL;
     if (host_ring) {
         WMX_HIP(hipDeviceSynchronize());

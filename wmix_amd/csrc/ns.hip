@@ -894,6 +894,7 @@ extern "C" int wmx_debug_ns_prof(unsigned long long *out16, int reset) {
 
 // ------------------------------------------------------------------------------------ host
 struct wmx_ns {
+    int device;  // the HIP device the state lives on (current device at create); every entry point switches to it
     int n_streams, chn, freq, L, pkg, ordered;
     float *d_state;
     unsigned short *d_hist;
@@ -975,11 +976,15 @@ int wmx_ns_create(wmx_ns **out, int n_streams, int chn, int freq) {
     if (!out) return WMX_EINVAL;
     *out = nullptr;
     // ns_init: freq <= 32000 and a multiple of 8000 (src/webrtc.c:563-564); in[2]/out[2] => chn <= 2
-    if (freq > 32000 || freq % 8000 != 0 || freq <= 0 || chn < 1 || chn > 2 || n_streams < 1) {
+    if ((freq != 8000 && freq != 16000 && freq != 32000) || chn < 1 || chn > 2 || n_streams < 1) {
         wmx::set_error("wmx_ns_create: unsupported n_streams=%d chn=%d freq=%d", n_streams, chn, freq);
         return WMX_EINVAL;
     }
     wmx_ns *h = new wmx_ns();
+    if ((h->device = wmx::current_device()) < 0) {
+        delete h;
+        return WMX_ENODEV;
+    }
     h->n_streams = n_streams;
     h->chn = chn;
     h->freq = freq;
@@ -1019,6 +1024,7 @@ int wmx_ns_create(wmx_ns **out, int n_streams, int chn, int freq) {
 }
 
 int wmx_ns_destroy(wmx_ns *h) {
+    WMX_ON_DEVICE(h);
     if (!h) return 0;
     if (h->d_state) (void)hipFree(h->d_state);
     if (h->d_hist) (void)hipFree(h->d_hist);
@@ -1028,6 +1034,7 @@ int wmx_ns_destroy(wmx_ns *h) {
 }
 
 int wmx_ns_set_ordered(wmx_ns *h, int ordered) {
+    WMX_ON_DEVICE(h);
     if (!h) return WMX_EINVAL;
     h->ordered = ordered ? 1 : 0;
     return 0;
@@ -1037,6 +1044,7 @@ int wmx_ns_packet_samples(const wmx_ns *h) { return h ? h->pkg * h->chn : WMX_EI
 int wmx_ns_state_words(const wmx_ns *h) { return h ? (int)h->words : WMX_EINVAL; }
 
 int wmx_ns_export_state(const wmx_ns *h, int stream_index, float *host_words, unsigned short *host_hist) {
+    WMX_ON_DEVICE(h);
     if (!h || stream_index < 0 || stream_index >= h->n_streams) return WMX_EINVAL;
     WMX_HIP(hipDeviceSynchronize());
     if (host_words)
@@ -1048,6 +1056,7 @@ int wmx_ns_export_state(const wmx_ns *h, int stream_index, float *host_words, un
 
 int wmx_ns_process(wmx_ns *h, const int16_t *d_in, int16_t *d_out, int n_packets, long stream_stride,
                    long packet_stride, void *stream) {
+    WMX_ON_DEVICE(h);
     if (!h || n_packets < 0) {
         wmx::set_error("wmx_ns_process: bad argument");
         return WMX_EINVAL;

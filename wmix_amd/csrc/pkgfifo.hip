@@ -8,6 +8,7 @@
 #include "wmx_internal.h"
 
 struct wmx_pkgfifo {
+    int device;  // the HIP device the state lives on (current device at create); every entry point switches to it
     int n_streams, n_slots, pkg_bytes, interval_ms, frame_bytes, count;
     uint8_t *d_slots;
 };
@@ -38,19 +39,29 @@ int wmx_pkgfifo_create(wmx_pkgfifo **out, int n_streams, int n_slots, int pkg_by
         set_error("wmx_pkgfifo_create: bad geometry");
         return WMX_EINVAL;
     }
-    wmx_pkgfifo *h = new wmx_pkgfifo{n_streams, n_slots, pkg_bytes, interval_ms, frame_bytes, 0, nullptr};
+    wmx_pkgfifo *h = new wmx_pkgfifo{wmx::current_device(), n_streams, n_slots, pkg_bytes, interval_ms, frame_bytes, 0, nullptr};
+    if (h->device < 0) {
+        delete h;
+        return WMX_ENODEV;
+    }
     const size_t bytes = (size_t)n_slots * n_streams * pkg_bytes;
     if (hipMalloc(&h->d_slots, bytes) != hipSuccess) {
         delete h;
         set_error("wmx_pkgfifo_create: no HIP device / out of memory");
         return WMX_ENODEV;
     }
-    WMX_HIP(hipMemset(h->d_slots, 0, bytes));  // the reference's FIFOs are zero-initialised statics
+    const hipError_t e = hipMemset(h->d_slots, 0, bytes);  // the reference's FIFOs are zero-initialised statics
+    if (e != hipSuccess) {
+        const int rc = hip_fail(e, "hipMemset(slots)", __FILE__, __LINE__);
+        wmx_pkgfifo_destroy(h);
+        return rc;
+    }
     *out = h;
     return 0;
 }
 
 int wmx_pkgfifo_destroy(wmx_pkgfifo *h) {
+    WMX_ON_DEVICE(h);
     if (!h) return 0;
     (void)hipFree(h->d_slots);
     delete h;
@@ -58,6 +69,7 @@ int wmx_pkgfifo_destroy(wmx_pkgfifo *h) {
 }
 
 int wmx_pkgfifo_add(wmx_pkgfifo *h, const uint8_t *d_pkgs, long stride, void *stream) {
+    WMX_ON_DEVICE(h);
     if (!h || !d_pkgs || (h->n_streams > 1 && stride < h->pkg_bytes)) {
         set_error("wmx_pkgfifo_add: bad arguments");
         return WMX_EINVAL;
@@ -70,6 +82,7 @@ int wmx_pkgfifo_add(wmx_pkgfifo *h, const uint8_t *d_pkgs, long stride, void *st
 }
 
 int wmx_pkgfifo_get(wmx_pkgfifo *h, uint8_t *d_out, long stride, int delayms, void *stream) {
+    WMX_ON_DEVICE(h);
     if (!h || !d_out || delayms < 0 || (h->n_streams > 1 && stride < h->pkg_bytes)) {
         set_error("wmx_pkgfifo_get: bad arguments");
         return WMX_EINVAL;

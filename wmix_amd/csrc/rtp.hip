@@ -13,14 +13,12 @@
 #include "g711_dev.h"
 
 struct wmx_rtp {
+    int device;  // the HIP device the state lives on (current device at create); every entry point switches to it
     int n_streams, law;
     uint32_t *d_seq;  // per stream: sequence number (low 16 bits significant)
     uint32_t *d_ts;   // per stream: timestamp
-    int32_t *d_idx;   // gather list of the last egress format
-    size_t idx_cap;
+    wmx::SchedCache sched;  // gather list per egress format, never rewritten (see SchedCache)
     std::vector<int32_t> idx;
-    int k_in_chn, k_in_freq, k_out_chn, k_out_freq;
-    uint32_t k_in_bytes;
 };
 
 namespace wmx {
@@ -89,49 +87,52 @@ int wmx_rtp_create(wmx_rtp **out, int n_streams, int law) {
         return WMX_ENODEV;
     }
     wmx_rtp *h = new wmx_rtp();
+    if ((h->device = wmx::current_device()) < 0) {
+        delete h;
+        return WMX_ENODEV;
+    }
     h->n_streams = n_streams;
     h->law = law;
-    h->d_idx = nullptr;
-    h->idx_cap = 0;
-    h->k_in_bytes = 0;
-    h->k_in_chn = h->k_in_freq = h->k_out_chn = h->k_out_freq = -1;
-    WMX_HIP(hipMalloc(&h->d_seq, sizeof(uint32_t) * n_streams));
-    WMX_HIP(hipMalloc(&h->d_ts, sizeof(uint32_t) * n_streams));
-    WMX_HIP(hipMemset(h->d_seq, 0, sizeof(uint32_t) * n_streams));  // rtp_header(..., seq 0, timestamp 0, ssrc 0)
-    WMX_HIP(hipMemset(h->d_ts, 0, sizeof(uint32_t) * n_streams));
+    h->d_seq = h->d_ts = nullptr;
+    hipError_t e = hipMalloc(&h->d_seq, sizeof(uint32_t) * n_streams);
+    if (e == hipSuccess) e = hipMalloc(&h->d_ts, sizeof(uint32_t) * n_streams);
+    if (e == hipSuccess) e = hipMemset(h->d_seq, 0, sizeof(uint32_t) * n_streams);  // rtp_header(..., seq 0, timestamp 0, ssrc 0)
+    if (e == hipSuccess) e = hipMemset(h->d_ts, 0, sizeof(uint32_t) * n_streams);
+    if (e != hipSuccess) {
+        const int rc = hip_fail(e, "wmx_rtp_create: hipMalloc/hipMemset", __FILE__, __LINE__);
+        wmx_rtp_destroy(h);
+        return rc;
+    }
     *out = h;
     return 0;
 }
 
 int wmx_rtp_destroy(wmx_rtp *h) {
+    WMX_ON_DEVICE(h);
     if (!h) return 0;
-    (void)hipFree(h->d_seq);
-    (void)hipFree(h->d_ts);
-    (void)hipFree(h->d_idx);
+    if (h->d_seq) (void)hipFree(h->d_seq);
+    if (h->d_ts) (void)hipFree(h->d_ts);
     delete h;
     return 0;
 }
 
 int wmx_rtp_egress(wmx_rtp *h, int in_chn, int in_freq, const int16_t *d_pcm, uint32_t in_bytes, long pcm_stride, int out_chn,
                    int out_freq, uint8_t *d_packets, long packet_stride, uint32_t *packet_bytes, void *stream) {
+    WMX_ON_DEVICE(h);
     if (!h || !d_pcm || !d_packets || in_chn < 1 || in_chn > 2 || out_chn < 1 || out_chn > 2 || in_freq < 1 || out_freq < 1 ||
         in_bytes == 0 || (h->n_streams > 1 && pcm_stride < (long)(in_bytes / 2))) {
         set_error("wmx_rtp_egress: bad arguments");
         return WMX_EINVAL;
     }
-    if (in_chn != h->k_in_chn || in_freq != h->k_in_freq || out_chn != h->k_out_chn || out_freq != h->k_out_freq || in_bytes != h->k_in_bytes) {
+    const uint64_t k0 = ((uint64_t)in_chn << 56) | ((uint64_t)out_chn << 48) | ((uint64_t)(uint32_t)in_freq << 24) | (uint32_t)out_freq;
+    const SchedCache::Entry *ent = h->sched.find(k0, in_bytes);
+    if (!ent) {
         zoom_gather_list(in_chn, in_freq, in_bytes, out_chn, out_freq, h->idx);
-        if (h->idx.size() > h->idx_cap) {
-            (void)hipFree(h->d_idx);
-            h->d_idx = nullptr;
-            h->idx_cap = 0;
-            WMX_HIP(hipMalloc(&h->d_idx, h->idx.size() * sizeof(int32_t)));
-            h->idx_cap = h->idx.size();
-        }
-        if (!h->idx.empty()) WMX_HIP(hipMemcpy(h->d_idx, h->idx.data(), h->idx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        h->k_in_chn = in_chn, h->k_in_freq = in_freq, h->k_out_chn = out_chn, h->k_out_freq = out_freq, h->k_in_bytes = in_bytes;
+        const int rc = h->sched.add(k0, in_bytes, h->idx.data(), h->idx.size() * sizeof(int32_t), h->idx.size(), &ent);
+        if (rc) return rc;
     }
-    const int n_codes = (int)h->idx.size();  // PCM2G711x returns DataLen / 2 codes
+    const int32_t *d_idx = (const int32_t *)ent->p;
+    const int n_codes = (int)ent->n;  // PCM2G711x returns DataLen / 2 codes
     if (packet_stride < kRtpHeader + n_codes) {
         set_error("wmx_rtp_egress: packet_stride %ld < %d", packet_stride, kRtpHeader + n_codes);
         return WMX_EINVAL;
@@ -140,10 +141,10 @@ int wmx_rtp_egress(wmx_rtp *h, int in_chn, int in_freq, const int16_t *d_pcm, ui
     const dim3 block(256), grid((unsigned)((n_codes + 255) / 256 > 0 ? (n_codes + 255) / 256 : 1), (unsigned)h->n_streams);
     const int pt = h->law == WMX_LAW_A ? 8 : 0;  // RTP_PAYLOAD_TYPE_PCMA / PCMU, src/rtp.h:21-24
     if (h->law == WMX_LAW_A)
-        hipLaunchKernelGGL((rtp_egress_kernel<WMX_LAW_A>), grid, block, 0, as_stream(stream), d_pcm, pcm_stride, h->d_idx, n_codes,
+        hipLaunchKernelGGL((rtp_egress_kernel<WMX_LAW_A>), grid, block, 0, as_stream(stream), d_pcm, pcm_stride, d_idx, n_codes,
                            n_codes / out_chn, h->d_seq, h->d_ts, d_packets, packet_stride, h->n_streams, pt);
     else
-        hipLaunchKernelGGL((rtp_egress_kernel<WMX_LAW_U>), grid, block, 0, as_stream(stream), d_pcm, pcm_stride, h->d_idx, n_codes,
+        hipLaunchKernelGGL((rtp_egress_kernel<WMX_LAW_U>), grid, block, 0, as_stream(stream), d_pcm, pcm_stride, d_idx, n_codes,
                            n_codes / out_chn, h->d_seq, h->d_ts, d_packets, packet_stride, h->n_streams, pt);
     WMX_LAUNCH_CHECK();
     return 0;
@@ -163,6 +164,7 @@ int wmx_rtp_ingest(int n_streams, const uint8_t *d_packets, long packet_stride, 
 }
 
 int wmx_rtp_export(wmx_rtp *h, int stream_index, uint16_t *seq, uint32_t *timestamp) {
+    WMX_ON_DEVICE(h);
     if (!h || stream_index < 0 || stream_index >= h->n_streams) return WMX_EINVAL;
     uint32_t s = 0, t = 0;
     WMX_HIP(hipDeviceSynchronize());

@@ -622,6 +622,7 @@ __global__ void vad_fill_state(int16_t *s16, int32_t *s32, const int16_t *t16, i
 }  // namespace wmx
 
 struct wmx_vad {
+    int device;  // the HIP device the state lives on (current device at create); every entry point switches to it
     int n_streams, chn, freq, interval_ms, pkg;
     int16_t *d_s16;
     int32_t *d_s32;
@@ -630,6 +631,7 @@ struct wmx_vad {
 extern "C" {
 
 int wmx_vad_destroy(wmx_vad *h) {
+    WMX_ON_DEVICE(h);
     if (!h) return 0;
     if (h->d_s16) (void)hipFree(h->d_s16);
     if (h->d_s32) (void)hipFree(h->d_s32);
@@ -642,11 +644,15 @@ int wmx_vad_create(wmx_vad **out, int n_streams, int chn, int freq, int interval
     if (!out) return WMX_EINVAL;
     *out = nullptr;
     // vad_init: freq <= 32000 and a multiple of 8000 (src/webrtc.c:43-44)
-    if (freq > 32000 || freq % 8000 != 0 || freq <= 0 || chn < 1 || n_streams < 1) {
+    if ((freq != 8000 && freq != 16000 && freq != 32000) || chn < 1 || n_streams < 1) {
         set_error("wmx_vad_create: unsupported n_streams=%d chn=%d freq=%d", n_streams, chn, freq);
         return WMX_EINVAL;
     }
     wmx_vad *h = new wmx_vad();
+    if ((h->device = wmx::current_device()) < 0) {
+        delete h;
+        return WMX_ENODEV;
+    }
     h->n_streams = n_streams;
     h->chn = chn;
     h->freq = freq;
@@ -694,6 +700,7 @@ int wmx_vad_packet_samples(const wmx_vad *h) { return h ? h->pkg * h->chn : WMX_
 
 int wmx_vad_process(wmx_vad *h, int16_t *d_pcm, int packets_per_call, int n_calls, long stream_stride, long call_stride,
                     void *stream) {
+    WMX_ON_DEVICE(h);
     using namespace wmx;
     if (!h || packets_per_call < 1 || n_calls < 0) {
         set_error("wmx_vad_process: bad argument");

@@ -18,6 +18,16 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
     return e == hipErrorNoDevice ? WMX_ENODEV : -(int)e;
 }
 
+int current_device() {
+    int d = -1;
+    hipError_t e = hipGetDevice(&d);
+    if (e != hipSuccess) {
+        hip_fail(e, "hipGetDevice", __FILE__, __LINE__);
+        return -1;
+    }
+    return d;
+}
+
 }  // namespace wmx
 
 extern "C" {
@@ -34,6 +44,9 @@ int wmx_device_count(void) {
     return n;
 }
 
-int wmx_version(void) { return 100; }
+int wmx_version(void) { return 200; }
+
+// `int device` is the first member of every wmx_* handle struct
+int wmx_handle_device(const void *handle) { return handle ? *static_cast<const int *>(handle) : WMX_EINVAL; }
 
 }  // extern "C"

@@ -26,8 +26,8 @@ def pcm_zoom(in_chn, in_freq, pcm, out_chn, out_freq):
     n_out = (int(np.ceil(pcm.shape[1] / in_chn * max(out_freq / in_freq, 1.0))) + 4) * out_chn
     out = torch.zeros(pcm.shape[0], n_out, dtype=torch.int16, device=pcm.device)
     got = C.c_uint32(0)
-    check(lib().wmx_pcm_zoom(in_chn, in_freq, pcm.data_ptr(), in_len, out_chn, out_freq, out.data_ptr(), pcm.stride(0), out.stride(0),
-                             pcm.shape[0], C.byref(got), torch.cuda.current_stream().cuda_stream), "wmx_pcm_zoom")
+    check(lib().wmx_pcm_zoom(in_chn, in_freq, pcm.data_ptr(), in_len, out_chn, out_freq, out.data_ptr(), n_out * 2, pcm.stride(0),
+                             out.stride(0), pcm.shape[0], C.byref(got), torch.cuda.current_stream().cuda_stream), "wmx_pcm_zoom")
     return out[:, : got.value // 2]
 
 
