@@ -159,7 +159,7 @@ def test_legacy_load_data_touches_only_its_span(wmx, oracle_port):
     # source buffer that ends exactly at the end of an allocation guard: the 320 B same-format source sits at the tail
     rng = np.random.default_rng(3)
     src = rng.integers(-9000, 9000, size=160, dtype=np.int16)
-    outside = np.r_[100:3000]  # sample indices far from the span [7950, 8000) + [0, 110)
+    outside = np.r_[200:3000]  # sample indices away from the span [7950, 8000) + [0, 110)
     stop = threading.Event()
     writes = [0]
 
@@ -176,8 +176,9 @@ def test_legacy_load_data_touches_only_its_span(wmx, oracle_port):
         for _ in range(200):
             tick = C.c_uint32(0)
             sp, hp = Point(), Point()
-            sp.U8, hp.U8 = src.ctypes.data, None
+            sp.U8, hp.U8 = src.ctypes.data, ring.ctypes.data + start  # an explicit head: the span wraps at the ring end
             r = wmx.wmix_load_data(C.byref(w), sp, 320, 8000, 1, 16, hp, 1, C.byref(tick))
+            assert r.U8 - ring.ctypes.data == (start + 320) % 16000 and tick.value == 320
             assert r.U8 is not None
     finally:
         stop.set()
@@ -185,8 +186,8 @@ def test_legacy_load_data_touches_only_its_span(wmx, oracle_port):
     # the player's last write is intact everywhere outside the span (a whole-ring write-back would have restored
     # older values somewhere in these 2 900 samples at some point of 200 calls)
     assert (ring[outside] == (writes[0] & 0x7FFF)).all()
-    # the span: 200 saturating adds of the same packet at head + PLAY_CORRECT (head == NULL => wmix->head + 3200 B)
-    pos = ((start + 3200) % 16000) // 2
+    # the span: 200 saturating adds of the same packet at the given head
+    pos = start // 2
     want = np.zeros(8000, np.int16)
     acc = np.zeros(160, np.int32)
     for _ in range(200):
