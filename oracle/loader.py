@@ -96,6 +96,19 @@ def run_ns(lib, chn, freq, pcm, frames_per_call, prefix="ref"):
     return out
 
 
+def run_nsx(lib, chn, freq, pcm, frames_per_call, prefix="ref"):
+    """The wrapper built with MAKE_WEBRTC_NSX (src/webrtc.c:512-521): fixed-point noise suppressor."""
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    out = np.empty_like(pcm)
+    n_calls = pcm.size // (frames_per_call * chn)
+    fn = getattr(lib, prefix + "_run_nsx")
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_int, _i16p, _i16p, C.c_int, C.c_int]
+    rc = fn(chn, freq, pcm, out, frames_per_call, n_calls)
+    assert rc == 0, rc
+    return out
+
+
 def run_agc(lib, chn, freq, value, pcm, frames_per_call, prefix="ref"):
     pcm = np.ascontiguousarray(pcm, dtype=np.int16)
     out = np.empty_like(pcm)

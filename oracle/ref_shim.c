@@ -41,6 +41,22 @@ int ref_run_ns(int chn, int freq, const int16_t *in, int16_t *out, int frames_pe
     return 0;
 }
 
+/* the same wrapper built with -DMAKE_WEBRTC_NSX (oracle/Makefile): the reference's fixed-point noise suppressor */
+void *nsx_ns_init(int chn, int freq, bool *debug);
+void nsx_ns_process(void *fp, int16_t *frame, int16_t *frameOut, int frameNum);
+void nsx_ns_release(void *fp);
+
+int ref_run_nsx(int chn, int freq, const int16_t *in, int16_t *out, int frames_per_call, int n_calls)
+{
+    void *h = nsx_ns_init(chn, freq, &g_dbg);
+    if (!h) return -100;
+    size_t step = (size_t)frames_per_call * chn;
+    if (out != in) memcpy(out, in, step * n_calls * sizeof(int16_t));
+    for (int i = 0; i < n_calls; i++) nsx_ns_process(h, out + i * step, out + i * step, frames_per_call);
+    nsx_ns_release(h);
+    return 0;
+}
+
 int ref_run_agc(int chn, int freq, int value, const int16_t *in, int16_t *out, int frames_per_call, int n_calls)
 {
     void *h = agc_init(chn, freq, 10, value, &g_dbg);
