@@ -83,6 +83,21 @@ int wmx_ns_process(wmx_ns *h, const int16_t *d_in, int16_t *d_out, int n_packets
 int wmx_ns_state_words(const wmx_ns *h);
 int wmx_ns_export_state(const wmx_ns *h, int stream_index, float *host_words, unsigned short *host_hist);
 
+/* ------------------------------------------------------------------ NSX (fixed-point noise suppressor)
+ * Batched form of the SAME three wrapper functions when the reference is built with its MAKE_WEBRTC_NSX switch
+ * (src/webrtc.c:512-521: ns_init / ns_process / ns_release over WebRtcNsx_Create / Init / set_policy(2) / Process,
+ * W:modules/audio_processing/ns/nsx_core.c).  Same packet rule, strides, aliasing and quirks as wmx_ns_* (right channel =
+ * high band, second half of a 32 kHz packet zero).  Integer path: bit-exact.  The legacy ns_init picks this
+ * implementation when the environment has WMIX_AMD_NSX=1 (the build-time macro of the reference becomes a run-time
+ * switch). */
+typedef struct wmx_nsx wmx_nsx;
+int wmx_nsx_create(wmx_nsx **out, int n_streams, int chn, int freq);
+int wmx_nsx_destroy(wmx_nsx *h);
+int wmx_nsx_packet_samples(const wmx_nsx *h);
+int wmx_nsx_state_bytes(const wmx_nsx *h); /* per-stream state block in HBM (the 3 x 1000 int16 histograms come on top) */
+int wmx_nsx_process(wmx_nsx *h, const int16_t *d_in, int16_t *d_out, int n_packets, long stream_stride,
+                    long packet_stride, void *stream);
+
 /* ------------------------------------------------------------------ VAD (voice-activity gate)
  * Batched form of vad_init / vad_process / vad_release (src/webrtc.h:32-36, src/webrtc.c:40-164):
  * WebRtcVad mode 3 decides speech/no-speech per packet; a per-stream `reduce` in [0,4] moves one

@@ -72,6 +72,16 @@ def _declare(L):
     L.wmx_ns_export_state.argtypes = [vp, i, vp, vp]
     L.wmx_ns_process.restype = i
     L.wmx_ns_process.argtypes = [vp, vp, vp, i, C.c_long, C.c_long, vp]
+    L.wmx_nsx_create.restype = i
+    L.wmx_nsx_create.argtypes = [C.POINTER(vp), i, i, i]
+    L.wmx_nsx_destroy.restype = i
+    L.wmx_nsx_destroy.argtypes = [vp]
+    L.wmx_nsx_packet_samples.restype = i
+    L.wmx_nsx_packet_samples.argtypes = [vp]
+    L.wmx_nsx_state_bytes.restype = i
+    L.wmx_nsx_state_bytes.argtypes = [vp]
+    L.wmx_nsx_process.restype = i
+    L.wmx_nsx_process.argtypes = [vp, vp, vp, i, C.c_long, C.c_long, vp]
     L.wmx_vad_create.restype = i
     L.wmx_vad_create.argtypes = [C.POINTER(vp), i, i, i, i]
     L.wmx_vad_destroy.restype = i
