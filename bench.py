@@ -77,15 +77,14 @@ class G711Workload:
         code = np.zeros(n, np.uint8)
         back = np.zeros(n, np.int16)
         enc, dec = port.orc_PCM2G711u, port.orc_G711u2PCM
-        t0 = time.perf_counter()
-        reps = 0
-        while time.perf_counter() - t0 < budget_s:
-            enc(C.c_void_p(pcm.ctypes.data), C.c_void_p(code.ctypes.data), n * 2, 0)
-            dec(C.c_void_p(code.ctypes.data), C.c_void_p(back.ctypes.data), n, 0)
-            reps += 1
-        dt = time.perf_counter() - t0
-        return {"value": reps * 20000 / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-                "sample": "%d x 20000 frames of 80 samples through oracle/orc_g711.c (-O2), 1 thread" % reps}
+
+        def one():
+            c, bk = np.zeros(n, np.uint8), np.zeros(n, np.int16)
+            enc(C.c_void_p(pcm.ctypes.data), C.c_void_p(c.ctypes.data), n * 2, 0)
+            dec(C.c_void_p(c.ctypes.data), C.c_void_p(bk.ctypes.data), n, 0)
+        reps, v1, nc, vn = _cpu_rates(one, 20000, budget_s)
+        return {"value": v1, "unit": "frames/s", "cores": 1, "kind": "port", "all_cores_value": vn, "all_cores": nc, "cpu_model": _cpu_model(),
+                "sample": "%d x 20000 frames of 80 samples through oracle/orc_g711.c (-O2), 1 thread; then all %d cores" % (reps, nc)}
 
 
 class _StageTimer:
@@ -167,14 +166,130 @@ class NsWorkload:
         n = 3000
         x = np.ascontiguousarray(self.inp[:, 0].cpu().numpy().reshape(-1))
         x = np.tile(x, n // self.K + 1)[: n * self.pkt]
-        t0 = time.perf_counter()
-        reps = 0
-        while time.perf_counter() - t0 < budget_s:
-            loader.run_ns(port, 1, self.freq, x, self.pkt, prefix="orc")
-            reps += 1
-        dt = time.perf_counter() - t0
-        return {"value": reps * n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-                "sample": "%d x %d packets of one 16 kHz stream through oracle/orc_ns.c (-O2), 1 thread" % (reps, n)}
+        reps, v1, nc, vn = _cpu_rates(lambda: loader.run_ns(port, 1, self.freq, x, self.pkt, prefix="orc"), n, budget_s)
+        return {"value": v1, "unit": "frames/s", "cores": 1, "kind": "port", "all_cores_value": vn, "all_cores": nc, "cpu_model": _cpu_model(),
+                "sample": "%d x %d packets of one 16 kHz stream through oracle/orc_ns.c (-O2), 1 thread; then all %d cores" % (reps, n, nc)}
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_rates(one_call, frames_per_call, budget_s):
+    """Time `one_call()` (one self-contained run of the CPU path over `frames_per_call` stream-frames; a ctypes call, so the
+    GIL is released while it runs) on ONE thread, then on every host core at once (one independent stream per thread --
+    streams never interact).  Returns (reps_1, frames/s on 1 core, n_cores, frames/s on all cores)."""
+    import threading
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < budget_s * 0.4 or reps == 0:
+        one_call()
+        reps += 1
+    v1 = reps * frames_per_call / (time.perf_counter() - t0)
+    n = os.cpu_count() or 1
+    counts = [0] * n
+    stop_at = time.perf_counter() + budget_s * 0.6
+
+    def worker(i):
+        while time.perf_counter() < stop_at or counts[i] == 0:
+            one_call()
+            counts[i] += 1
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(n)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    vn = sum(counts) * frames_per_call / (time.perf_counter() - t0)
+    return reps, v1, n, vn
+
+
+class NsxWorkload:
+    """the fixed-point noise suppressor (the reference's MAKE_WEBRTC_NSX build of ns_process), 16 kHz mono,
+    65 536 streams per GPU, one 10 ms packet per stream per step.  Algorithmic bytes per stream-frame = 320 in + 320 out +
+    2 x 5 516 live state (NoiseSuppressionFixedC's per-frame fields: two 256-sample int16 buffers, seven int16 and four
+    int32 per-bin arrays of 129, ~100 B of scalars; nsx_core.h:23-123) = 11 672 B."""
+    name = "nsx_16k_mono"
+    dtype = "int16/int32 (fixed point)"
+    bytes_per_frame = 11672.0
+    dominant_kernel = "nsx_kernel<256, 1>"
+    dominant_bytes_per_frame = 11672.0
+    pmc_tag = "nsx"
+    freq, pkt = 16000, 160
+
+    def __init__(self, dev, n_streams, rank):
+        from wmix_amd import synth
+        from wmix_amd.nsx import NsxBatch
+        self.n_frames = n_streams
+        self.K = 200
+        base = synth.ns_input(2100 + 7919 * rank, 256, self.K, self.pkt).reshape(256, self.K, self.pkt)
+        self.base = base
+        b = torch.from_numpy(np.ascontiguousarray(base.transpose(1, 0, 2))).to(dev)  # [K, 256, pkt]
+        self.inp = b[:, torch.arange(n_streams, device=dev) % 256]                     # [K, S, pkt] packet-major
+        self.work = torch.empty_like(self.inp[0:1])
+        self.nsx = NsxBatch(n_streams, 1, self.freq)
+        self.t = _StageTimer("nsx")
+        self.k = 0
+        self.sample = [int(i) for i in np.linspace(0, n_streams - 1, 16)]
+        self.rec = []
+
+    def step(self, timed):
+        k = self.k % self.K
+        self.t.run("nsx", timed, lambda: self.nsx.process_packet_major(self.inp[k:k + 1], self.work))
+        if timed is not True:  # outside the timed region: keep what the sampled streams produced, for parity_check()
+            self.rec.append((self.k, self.work[0, self.sample].clone()))
+        self.k += 1
+
+    def dominant_ms(self):
+        return self.t.dominant_ms()
+
+    def stage_ms(self):
+        return {"nsx": self.t.mean_ms("nsx")}
+
+    def config(self):
+        return {"workload": self.name, "streams_per_gpu": self.n_frames, "frame": "160 x int16 (10 ms @ 16 kHz mono)",
+                "input": "noise A=3000 + 3000 sin(0.01 t) gated every 100 frames (SURVEY 8d recipe), 256 distinct streams x %d "
+                         "packets, tiled" % self.K}
+
+    def parity_check(self):
+        """Replays the sampled streams through the oracle for exactly the packets this run fed and compares every packet
+        recorded outside the timed region (the ones behind it depend on every timed step through the state)."""
+        from oracle import loader
+        port = loader.port()
+        worst, n = 0, 0
+        for col, s in enumerate(self.sample):
+            x = np.concatenate([self.base[s % 256, k % self.K] for k in range(self.k)])
+            want = loader.run_nsx(port, 1, self.freq, x, self.pkt, prefix="orc").reshape(self.k, self.pkt)
+            for k, got in self.rec:
+                d = np.abs(got[col].cpu().numpy().astype(np.int32) - want[k].astype(np.int32)).max()
+                worst, n = max(worst, int(d)), n + 1
+        return {"streams": len(self.sample), "packets_compared": n, "max_lsb": worst, "oracle": "oracle/orc_nsx.c (port)",
+                "steps_replayed": self.k}
+
+    def cpu_baseline(self, budget_s):
+        from oracle import loader
+        n = 2000
+        x = np.tile(np.ascontiguousarray(self.base[0].reshape(-1)), n // self.K + 1)[: n * self.pkt]
+        lib, kind, prefix = loader.port(), "port", "orc"
+        if loader.have_ref():
+            try:
+                lib, kind, prefix = loader.ref(), "reference", "ref"
+                getattr(lib, "ref_run_nsx")
+            except Exception:
+                lib, kind, prefix = loader.port(), "port", "orc"
+        reps, v1, nc, vn = _cpu_rates(lambda: loader.run_nsx(lib, 1, self.freq, x, self.pkt, prefix=prefix), n, budget_s)
+        return {"value": v1, "unit": "frames/s", "cores": 1, "kind": kind, "all_cores_value": vn, "all_cores": nc,
+                "cpu_model": _cpu_model(),
+                "sample": "%d x %d packets of one 16 kHz stream through %s, 1 thread; then one stream per thread on all cores"
+                          % (reps, n, "ns_process built with MAKE_WEBRTC_NSX (oracle/_ref/libwmixref.so, -O2)" if kind == "reference"
+                             else "oracle/orc_nsx.c (-O2)")}
 
 
 class MfftWorkload:
@@ -211,15 +326,14 @@ class MfftWorkload:
         from oracle import loader
         port = loader.port()
         x = self.x[0].cpu().numpy()
-        t0 = time.perf_counter()
-        reps = 0
-        while time.perf_counter() - t0 < budget_s:
+
+        def one():
             for _ in range(200):
                 loader.mfft(port, 1, x, None, self.N, prefix="orc", want="a")
-            reps += 200
-        dt = time.perf_counter() - t0
-        return {"value": reps / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-                "sample": "%d x FFTR(1024) through oracle/orc_mfft.c (-O2), 1 thread" % reps}
+        reps, v1, nc, vn = _cpu_rates(one, 200, budget_s)
+        return {"value": v1, "unit": "frames/s", "cores": 1, "kind": "port", "all_cores_value": vn, "all_cores": nc, "cpu_model": _cpu_model(),
+                "sample": "%d x 200 FFTR(1024) through oracle/orc_mfft.c (-O2), 1 thread; then all %d cores (python call overhead "
+                          "included: one ctypes call per transform)" % (reps, nc)}
 
 
 class ChainWorkload:
@@ -248,12 +362,17 @@ class ChainWorkload:
         self.n_streams = n_streams
         self.n_frames = n_streams * packets  # 10 ms stream-frames per step
         self.dist = dist
-        self.K = 8
+        # SURVEY 8d recipe: shared far-end = LCG noise A=8000; near = far delayed 40 samples / 2 + noise A=200 + a
+        # 3000 sin(0.01 t) tone gated on/off every 100 frames.  One full gate period (200 packets) of 256 distinct streams,
+        # tiled over the batch on the device; a default run (256 priming + warm-up + timed + 16 steps) walks through the
+        # tone-on, tone-off and both transitions, so the data-dependent branches (VAD decisions, NS feature updates, AEC
+        # near-state) are not frozen on one 80 ms loop as in round 1.
+        self.K = 200
         far = synth.far_end(3000, self.K, self.pkt)  # the same far-end on every rank (rank 0's copy is broadcast)
         base = synth.near_end(3001 + 7919 * rank, 256, self.K, self.pkt, far=far).reshape(256, self.K, self.pkt)
-        reps = (n_streams + 255) // 256
-        x = np.tile(base, (reps, 1, 1))[:n_streams].transpose(1, 0, 2)
-        self.inp = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        self.base, self.far_host = base, far.reshape(self.K, self.pkt)
+        b = torch.from_numpy(np.ascontiguousarray(base.transpose(1, 0, 2))).to(dev)  # [K, 256, pkt]
+        self.inp = b[:, torch.arange(n_streams, device=dev) % 256]                     # [K, S, pkt] packet-major
         self.far_src = torch.from_numpy(far.reshape(self.K, self.pkt).copy()).to(dev)
         self.P = packets  # 10 ms packets per stream per step (1 = one packet per launch; 2 = the daemon's own 20 ms calls)
         assert self.K % self.P == 0
@@ -276,11 +395,14 @@ class ChainWorkload:
         self.rank = rank
         self.t = _StageTimer("aec")
         self.k = 0
+        self.sample = [int(i) for i in np.linspace(0, n_streams - 1, 16)]
+        self.rec = []
 
     def step(self, timed):
         P = self.P
         k = (self.k * P) % self.K
         b = self.k & 1
+        step_index = self.k
         self.k += 1
         self.work = self.works[b]
         main = torch.cuda.current_stream()
@@ -309,6 +431,9 @@ class ChainWorkload:
         elif self.with_agc_vad:
             self.t.run("agc", timed, lambda: self.agc.process_packet_major(self.work))
             self.t.run("vad", timed, lambda: self.vad.process_packet_major(self.work))
+        if timed is not True and self.side is None:
+            # outside the timed region: keep what the sampled streams produced, for parity_check()
+            self.rec.append((step_index, self.work[:, self.sample].clone()))
 
     def dominant_ms(self):
         return self.t.dominant_ms()
@@ -316,9 +441,30 @@ class ChainWorkload:
     def stage_ms(self):
         return {k: self.t.mean_ms(k) for k in ("far_broadcast_wait", "ns", "aec", "agc", "vad") if self.t.mean_ms(k) is not None}
 
+    def parity_check(self):
+        """Replays 16 sampled streams through the oracle chain for exactly the packets this run fed (priming, warm-up,
+        timed and breakdown steps) and compares every packet recorded outside the timed region; the packets behind the
+        timed region depend on every timed step through the filter / model state.  +-1 LSB is the float path's bar."""
+        from oracle import loader
+        port = loader.port()
+        T, P = self.k, self.P
+        far = np.concatenate([self.far_host[(k * P + p) % self.K] for k in range(T) for p in range(P)])
+        stages = 15 if self.with_agc_vad else 3
+        worst, n, n_off = 0, 0, 0
+        for col, s in enumerate(self.sample):
+            near = np.concatenate([self.base[s % 256, (k * P + p) % self.K] for k in range(T) for p in range(P)])
+            want = loader.run_chain(port, 1, self.freq, 5, stages, far, near, self.pkt, prefix="orc").reshape(T, P, self.pkt)
+            for k, got in self.rec:
+                d = np.abs(got[:, col].cpu().numpy().astype(np.int32) - want[k].astype(np.int32))
+                worst, n, n_off = max(worst, int(d.max())), n + P, n_off + int((d > 0).sum())
+        return {"streams": len(self.sample), "packets_compared": n, "max_lsb": worst, "samples_off_by_one": n_off,
+                "oracle": "oracle/orc_*.c chain (port)", "steps_replayed": T}
+
     def config(self):
         return {"workload": self.name, "streams_per_gpu": self.n_streams, "packets_per_stream_per_step": self.P,
                 "frame": "%d x int16 (10 ms @ %d kHz mono)" % (self.pkt, self.freq // 1000),
+                "input": "SURVEY 8d recipe: far = LCG noise A=8000; near = far delayed 40 / 2 + noise A=200 + 3000 sin(0.01 t) gated "
+                         "every 100 frames; 256 distinct streams x %d packets, tiled" % self.K,
                 "far_end": ("shared, RCCL broadcast from rank 0 each step (asynchronous, overlapped with NS)" if self.dist is not None
                             else "shared, resident in HBM (one GPU: nothing to broadcast)"), "sum_order": "reference (bit-exact NS mode)",
                 "aec_launch": "far kernel + near kernel; the near kernel is the timed dominant kernel together with its far kernel"}
@@ -327,16 +473,10 @@ class ChainWorkload:
         from oracle import loader
         port = loader.port()
         n = 2000
-        far = np.tile(self.far_src.cpu().numpy().reshape(-1), n // self.K + 1)[: n * self.pkt]
-        near = np.tile(np.ascontiguousarray(self.inp[:, 0].cpu().numpy().reshape(-1)), n // self.K + 1)[: n * self.pkt]
-        def timed(lib, prefix, seconds):
-            t0 = time.perf_counter()
-            reps = 0
-            while time.perf_counter() - t0 < seconds:
-                loader.run_chain(lib, 1, self.freq, 5, 15 if self.with_agc_vad else 3, far, near, self.pkt, prefix=prefix)
-                reps += 1
-            return reps, reps * n / (time.perf_counter() - t0)
-
+        far = np.tile(self.far_host.reshape(-1), n // self.K + 1)[: n * self.pkt]
+        near = np.tile(np.ascontiguousarray(self.base[0].reshape(-1)), n // self.K + 1)[: n * self.pkt]
+        stages = 15 if self.with_agc_vad else 3
+        chain = ("ns_process -> aec_process2 -> agc_process -> vad_process" if self.with_agc_vad else "ns_process -> aec_process2")
         ref_lib = None
         if loader.have_ref():
             try:  # a prebuilt library that does not load on this host must not take the benchmark down
@@ -346,14 +486,20 @@ class ChainWorkload:
         if ref_lib is not None:
             # the real reference (src/webrtc.c over the vendored WebRTC, gcc -O2, generic-C AEC kernels), prebuilt by
             # oracle/Makefile where /root/reference exists; our restatement timed beside it for comparison
-            reps, v = timed(ref_lib, "ref", budget_s * 0.7)
-            _, vp = timed(port, "orc", budget_s * 0.3)
-            return {"value": v, "unit": "frames/s", "cores": 1, "kind": "reference", "port_value": vp,
-                    "sample": "%d x %d packets of one 16 kHz stream through the reference chain ns_process -> aec_process2 -> "
-                              "agc_process -> vad_process (oracle/_ref/libwmixref.so, -O2), 1 thread" % (reps, n)}
-        reps, v = timed(port, "orc", budget_s)
-        return {"value": v, "unit": "frames/s", "cores": 1, "kind": "port",
-                "sample": "%d x %d packets of one 16 kHz stream through the oracle chain (oracle/orc_*.c, -O2), 1 thread" % (reps, n)}
+            reps, v1, nc, vn = _cpu_rates(lambda: loader.run_chain(ref_lib, 1, self.freq, 5, stages, far, near, self.pkt, prefix="ref"),
+                                          n, budget_s * 0.75)
+            _, vp, _, _ = _cpu_rates(lambda: loader.run_chain(port, 1, self.freq, 5, stages, far, near, self.pkt, prefix="orc"), n,
+                                     budget_s * 0.25)
+            return {"value": v1, "unit": "frames/s", "cores": 1, "kind": "reference", "all_cores_value": vn, "all_cores": nc,
+                    "cpu_model": _cpu_model(), "port_value": vp,
+                    "sample": "%d x %d packets of one %d kHz stream through the reference chain %s (oracle/_ref/libwmixref.so, "
+                              "-O2), 1 thread; then one stream per thread on all %d cores" % (reps, n, self.freq // 1000, chain, nc)}
+        reps, v1, nc, vn = _cpu_rates(lambda: loader.run_chain(port, 1, self.freq, 5, stages, far, near, self.pkt, prefix="orc"), n,
+                                      budget_s)
+        return {"value": v1, "unit": "frames/s", "cores": 1, "kind": "port", "all_cores_value": vn, "all_cores": nc,
+                "cpu_model": _cpu_model(),
+                "sample": "%d x %d packets of one %d kHz stream through the oracle chain (oracle/orc_*.c, -O2), 1 thread; then one "
+                          "stream per thread on all %d cores" % (reps, n, self.freq // 1000, nc)}
 
 
 class NsAgcMix32kWorkload:
@@ -421,13 +567,11 @@ class NsAgcMix32kWorkload:
         port = loader.port()
         n = 1000
         x = np.tile(np.ascontiguousarray(self.inp[:, 0].cpu().numpy().reshape(-1)), n // self.K + 1)[: n * 640]
-        t0 = time.perf_counter()
-        reps = 0
-        while time.perf_counter() - t0 < budget_s:
-            loader.run_chain(port, 2, 32000, 5, 1 | 4, np.zeros_like(x), x, 320, prefix="orc")
-            reps += 1
-        return {"value": reps * n / (time.perf_counter() - t0), "unit": "frames/s", "cores": 1, "kind": "port",
-                "sample": "%d x %d packets of one 2 x 32 kHz source through NS + AGC of the oracle (mix excluded), 1 thread" % (reps, n)}
+        z = np.zeros_like(x)
+        reps, v1, nc, vn = _cpu_rates(lambda: loader.run_chain(port, 2, 32000, 5, 1 | 4, z, x, 320, prefix="orc"), n, budget_s)
+        return {"value": v1, "unit": "frames/s", "cores": 1, "kind": "port", "all_cores_value": vn, "all_cores": nc, "cpu_model": _cpu_model(),
+                "sample": "%d x %d packets of one 2 x 32 kHz source through NS + AGC of the oracle (mix excluded), 1 thread; then all %d "
+                          "cores" % (reps, n, nc)}
 
 
 class NsAec8kWorkload(ChainWorkload):
@@ -442,7 +586,7 @@ class NsAec8kWorkload(ChainWorkload):
     with_agc_vad = False
 
 
-WORKLOADS = {"g711": (G711Workload, 1 << 20), "ns": (NsWorkload, 4096), "chain": (ChainWorkload, 65536),
+WORKLOADS = {"g711": (G711Workload, 1 << 20), "ns": (NsWorkload, 4096), "nsx": (NsxWorkload, 65536), "chain": (ChainWorkload, 65536),
              "mfft": (MfftWorkload, 65536), "ns_aec_8k": (NsAec8kWorkload, 131072),
              "ns_agc_mix_32k": (NsAgcMix32kWorkload, 32768)}
 DEFAULT_WORKLOAD = "chain"
@@ -523,7 +667,7 @@ def _launch_ranks(n, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=400, help="timed steps (default 400: about half a second of GPU time for the chain)")
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=0, help="streams (frames per step) per GPU; 0 = workload default")

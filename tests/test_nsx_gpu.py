@@ -87,3 +87,24 @@ def test_full_size_batch_properties(cuda, oracle_port):
         same = out[:, idx == k, :]
         assert (same == same[:, :1, :]).all()
         assert np.array_equal(same[:, 0, :], want)
+
+
+def test_reference_host_signatures_with_nsx_switch(wmx, oracle_port, monkeypatch):
+    """ns_init / ns_process / ns_release over HOST buffers pick the fixed-point path when WMIX_AMD_NSX=1 -- the run-time
+    form of the reference's build-time MAKE_WEBRTC_NSX (src/webrtc.c:512-521) -- and the float path otherwise."""
+    for chn, freq in ((1, 8000), (2, 16000), (1, 32000)):
+        x = nsx_case_input(chn, freq, 120, 3000, seed=5)
+        for switch, runner in (("1", L.run_nsx), ("0", L.run_ns)):
+            monkeypatch.setenv("WMIX_AMD_NSX", switch)
+            want = runner(oracle_port, chn, freq, x, freq // 100, prefix="orc")
+            h = wmx.ns_init(chn, freq, None)
+            assert h
+            buf = x.copy()
+            step = 2 * (freq // 100) * chn  # WMIX_FRAME_NUM: 20 ms per call
+            for off in range(0, buf.size, step):
+                p = C.c_void_p(buf.ctypes.data + 2 * off)
+                wmx.ns_process(h, p, p, 2 * (freq // 100))
+            wmx.ns_release(h)
+            assert np.array_equal(buf, want)
+    monkeypatch.setenv("WMIX_AMD_NSX", "1")
+    assert wmx.ns_init(1, 44100, None) is None and wmx.ns_init(1, 24000, None) is None

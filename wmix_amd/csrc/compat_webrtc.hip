@@ -34,7 +34,8 @@ struct DevBuf {
 };
 
 struct NsHandleCompat {
-    wmx_ns *batch;
+    wmx_ns *batch;    // float NS (the reference's default build) ...
+    wmx_nsx *batchx;  // ... or the fixed-point NSX (its MAKE_WEBRTC_NSX build): exactly one is set
     int chn, freq, pkg;
     bool *debug;
     DevBuf buf;
@@ -235,13 +236,19 @@ void agc_release(void *fp) {
 // src/webrtc.c:560-602
 void *ns_init(int chn, int freq, bool *debug) {
     if (freq > 32000 || freq % 8000 != 0) return NULL;
+    // The reference chooses between WebRtcNs_* and WebRtcNsx_* at build time (#define MAKE_WEBRTC_NSX, src/webrtc.c:512-521).
+    // One library serves both builds: WMIX_AMD_NSX=1 in the daemon's environment is that switch.
+    const char *sw = getenv("WMIX_AMD_NSX");
+    const bool fixed = sw && sw[0] == '1';
     wmx_ns *b = nullptr;
-    if (wmx_ns_create(&b, 1, chn, freq) != 0) {
+    wmx_nsx *bx = nullptr;
+    if ((fixed ? wmx_nsx_create(&bx, 1, chn, freq) : wmx_ns_create(&b, 1, chn, freq)) != 0) {
         if (debug && *debug) printf("WebRtcNs_Create failed !! (%s)\r\n", wmx_last_error());
         return NULL;
     }
     NsHandleCompat *h = new NsHandleCompat();
     h->batch = b;
+    h->batchx = bx;
     h->chn = chn;
     h->freq = freq;
     h->pkg = freq / 1000 * 10;
@@ -260,7 +267,8 @@ void ns_process(void *fp, int16_t *frame, int16_t *frameOut, int frameNum) {
     const size_t n = (size_t)n_packets * per_pkt;
     bool ok = h->buf.ensure(n);
     ok = ok && hipMemcpy(h->buf.p, frame, (size_t)total * sizeof(int16_t), hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && wmx_ns_process(h->batch, h->buf.p, h->buf.p, n_packets, 0, per_pkt, nullptr) == 0;
+    ok = ok && (h->batchx ? wmx_nsx_process(h->batchx, h->buf.p, h->buf.p, n_packets, 0, per_pkt, nullptr)
+                          : wmx_ns_process(h->batch, h->buf.p, h->buf.p, n_packets, 0, per_pkt, nullptr)) == 0;
     ok = ok && hipMemcpy(frameOut, h->buf.p, (size_t)total * sizeof(int16_t), hipMemcpyDeviceToHost) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
@@ -272,7 +280,8 @@ void ns_process(void *fp, int16_t *frame, int16_t *frameOut, int frameNum) {
 void ns_release(void *fp) {
     NsHandleCompat *h = static_cast<NsHandleCompat *>(fp);
     if (!h) return;
-    wmx_ns_destroy(h->batch);
+    if (h->batch) wmx_ns_destroy(h->batch);
+    if (h->batchx) wmx_nsx_destroy(h->batchx);
     if (h->debug && *h->debug) printf("ns_release\r\n");
     delete h;
 }
