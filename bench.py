@@ -181,6 +181,19 @@ def _cpu_model():
     return "unknown"
 
 
+def _usable_cores():
+    """Host cores this process may actually use: the scheduler affinity mask, cut down to the cgroup CPU quota (a GPU box
+    hands a 1-GPU job a share of the host, not all of its cores)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def _cpu_rates(one_call, frames_per_call, budget_s):
     """Time `one_call()` (one self-contained run of the CPU path over `frames_per_call` stream-frames; a ctypes call, so the
     GIL is released while it runs) on ONE thread, then on every host core at once (one independent stream per thread --
@@ -192,7 +205,7 @@ def _cpu_rates(one_call, frames_per_call, budget_s):
         one_call()
         reps += 1
     v1 = reps * frames_per_call / (time.perf_counter() - t0)
-    n = os.cpu_count() or 1
+    n = _usable_cores()
     counts = [0] * n
     stop_at = time.perf_counter() + budget_s * 0.6
 

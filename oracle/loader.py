@@ -40,6 +40,24 @@ def have_ref_mix():
 
 _port = None
 _ref = None
+_bound = {}
+_bind_lock = __import__("threading").Lock()
+
+
+def _fn(lib, name, restype, argtypes):
+    """The foreign function with its prototype set ONCE: bench.py's all-core CPU baseline calls the run_* helpers from many
+    threads, and re-assigning argtypes on the shared function object while another thread converts arguments races."""
+    key = (id(lib), name)
+    f = _bound.get(key)
+    if f is None:
+        with _bind_lock:
+            f = _bound.get(key)
+            if f is None:
+                f = getattr(lib, name)
+                f.restype = restype
+                f.argtypes = argtypes
+                _bound[key] = f
+    return f
 
 
 def port():
@@ -88,9 +106,7 @@ def run_ns(lib, chn, freq, pcm, frames_per_call, prefix="ref"):
     pcm = np.ascontiguousarray(pcm, dtype=np.int16)
     out = np.empty_like(pcm)
     n_calls = pcm.size // (frames_per_call * chn)
-    fn = getattr(lib, prefix + "_run_ns")
-    fn.restype = C.c_int
-    fn.argtypes = [C.c_int, C.c_int, _i16p, _i16p, C.c_int, C.c_int]
+    fn = _fn(lib, prefix + "_run_ns", C.c_int, [C.c_int, C.c_int, _i16p, _i16p, C.c_int, C.c_int])
     rc = fn(chn, freq, pcm, out, frames_per_call, n_calls)
     assert rc == 0, rc
     return out
@@ -101,9 +117,7 @@ def run_nsx(lib, chn, freq, pcm, frames_per_call, prefix="ref"):
     pcm = np.ascontiguousarray(pcm, dtype=np.int16)
     out = np.empty_like(pcm)
     n_calls = pcm.size // (frames_per_call * chn)
-    fn = getattr(lib, prefix + "_run_nsx")
-    fn.restype = C.c_int
-    fn.argtypes = [C.c_int, C.c_int, _i16p, _i16p, C.c_int, C.c_int]
+    fn = _fn(lib, prefix + "_run_nsx", C.c_int, [C.c_int, C.c_int, _i16p, _i16p, C.c_int, C.c_int])
     rc = fn(chn, freq, pcm, out, frames_per_call, n_calls)
     assert rc == 0, rc
     return out
@@ -113,9 +127,7 @@ def run_agc(lib, chn, freq, value, pcm, frames_per_call, prefix="ref"):
     pcm = np.ascontiguousarray(pcm, dtype=np.int16)
     out = np.empty_like(pcm)
     n_calls = pcm.size // (frames_per_call * chn)
-    fn = getattr(lib, prefix + "_run_agc")
-    fn.restype = C.c_int
-    fn.argtypes = [C.c_int, C.c_int, C.c_int, _i16p, _i16p, C.c_int, C.c_int]
+    fn = _fn(lib, prefix + "_run_agc", C.c_int, [C.c_int, C.c_int, C.c_int, _i16p, _i16p, C.c_int, C.c_int])
     rc = fn(chn, freq, value, pcm, out, frames_per_call, n_calls)
     assert rc == 0, rc
     return out
@@ -125,9 +137,7 @@ def run_vad(lib, chn, freq, interval_ms, pcm, frames_per_call, prefix="ref"):
     pcm = np.ascontiguousarray(pcm, dtype=np.int16)
     out = np.empty_like(pcm)
     n_calls = pcm.size // (frames_per_call * chn)
-    fn = getattr(lib, prefix + "_run_vad")
-    fn.restype = C.c_int
-    fn.argtypes = [C.c_int, C.c_int, C.c_int, _i16p, _i16p, C.c_int, C.c_int]
+    fn = _fn(lib, prefix + "_run_vad", C.c_int, [C.c_int, C.c_int, C.c_int, _i16p, _i16p, C.c_int, C.c_int])
     rc = fn(chn, freq, interval_ms, pcm, out, frames_per_call, n_calls)
     assert rc == 0, rc
     return out
@@ -138,9 +148,7 @@ def run_aec(lib, chn, freq, interval_ms, far, near, frames_per_call, delay_ms=0,
     near = np.ascontiguousarray(near, dtype=np.int16)
     out = np.empty_like(near)
     n_calls = near.size // (frames_per_call * chn)
-    fn = getattr(lib, prefix + "_run_aec")
-    fn.restype = C.c_int
-    fn.argtypes = [C.c_int, C.c_int, C.c_int, _i16p, _i16p, _i16p, C.c_int, C.c_int, C.c_int]
+    fn = _fn(lib, prefix + "_run_aec", C.c_int, [C.c_int, C.c_int, C.c_int, _i16p, _i16p, _i16p, C.c_int, C.c_int, C.c_int])
     rc = fn(chn, freq, interval_ms, far, near, out, frames_per_call, n_calls, delay_ms)
     assert rc == 0, rc
     return out
@@ -152,9 +160,7 @@ def run_chain(lib, chn, freq, agc_value, stages, far, near, frames_per_call, pre
     near = np.ascontiguousarray(near, dtype=np.int16)
     out = np.empty_like(near)
     n_calls = near.size // (frames_per_call * chn)
-    fn = getattr(lib, prefix + "_run_chain")
-    fn.restype = C.c_int
-    fn.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint, _i16p, _i16p, _i16p, C.c_int, C.c_int]
+    fn = _fn(lib, prefix + "_run_chain", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint, _i16p, _i16p, _i16p, C.c_int, C.c_int])
     rc = fn(chn, freq, agc_value, stages, far, near, out, frames_per_call, n_calls)
     assert rc == 0, rc
     return out
