@@ -154,6 +154,19 @@ def run_aec(lib, chn, freq, interval_ms, far, near, frames_per_call, delay_ms=0,
     return out
 
 
+def run_aecm(lib, chn, freq, interval_ms, far, near, frames_per_call, delay_ms=0, split=0, prefix="ref", expect_rc=0):
+    """The wrapper built with the reference's AECM switch (src/webrtc.c:168-191): fixed-point echo canceller.
+    split=1 drives aec_setFrameFar + aec_process instead of aec_process2."""
+    far = np.ascontiguousarray(far, dtype=np.int16)
+    near = np.ascontiguousarray(near, dtype=np.int16)
+    out = np.zeros_like(near)
+    n_calls = near.size // (frames_per_call * chn)
+    fn = _fn(lib, prefix + "_run_aecm", C.c_int, [C.c_int, C.c_int, C.c_int, _i16p, _i16p, _i16p, C.c_int, C.c_int, C.c_int, C.c_int])
+    rc = fn(chn, freq, interval_ms, far, near, out, frames_per_call, n_calls, delay_ms, split)
+    assert rc == expect_rc, rc
+    return out
+
+
 def run_chain(lib, chn, freq, agc_value, stages, far, near, frames_per_call, prefix="ref"):
     """stages bitmask: 1 NS, 2 AEC, 4 AGC, 8 VAD (daemon order, src/wmix.c:613-709)."""
     far = np.ascontiguousarray(far, dtype=np.int16)

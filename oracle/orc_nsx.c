@@ -136,7 +136,7 @@ static int cfft(int16_t *x, int stages, int inverse)
                 const int j = i + l;
                 const int32_t tr = ((int32_t)wr * x[2 * j] - (int32_t)wi * x[2 * j + 1] + 1) >> 1;
                 const int32_t ti = ((int32_t)wr * x[2 * j + 1] + (int32_t)wi * x[2 * j] + 1) >> 1;
-                const int32_t qr = (int32_t)x[2 * i] << 14, qi = (int32_t)x[2 * i + 1] << 14;
+                const int32_t qr = wshl(x[2 * i], 14), qi = wshl(x[2 * i + 1], 14);
                 x[2 * j] = (int16_t)((qr - tr + round2) >> (shift + 14));
                 x[2 * j + 1] = (int16_t)((qi - ti + round2) >> (shift + 14));
                 x[2 * i] = (int16_t)((qr + tr + round2) >> (shift + 14));

@@ -93,6 +93,33 @@ int ref_run_aec(int chn, int freq, int interval_ms, const int16_t *far, const in
     return rc;
 }
 
+/* the same wrapper built with the reference's AECM switch (oracle/Makefile, oracle/aecm_switch/): WebRtcAecm_* */
+void *aecm_aec_init(int chn, int freq, int intervalMs, bool *debug);
+int aecm_aec_setFrameFar(void *fp, int16_t *frameFar, int frameNum);
+int aecm_aec_process(void *fp, int16_t *frameNear, int16_t *frameOut, int frameNum, int delayms);
+int aecm_aec_process2(void *fp, int16_t *frameFar, int16_t *frameNear, int16_t *frameOut, int frameNum, int delayms);
+void aecm_aec_release(void *fp);
+
+/* split = 0: aec_process2 per call; split = 1: aec_setFrameFar then aec_process (the two-call form, src/webrtc.c:286-395) */
+int ref_run_aecm(int chn, int freq, int interval_ms, const int16_t *far, const int16_t *near, int16_t *out,
+                 int frames_per_call, int n_calls, int delay_ms, int split)
+{
+    void *h = aecm_aec_init(chn, freq, interval_ms, &g_dbg);
+    if (!h) return -100;
+    size_t step = (size_t)frames_per_call * chn;
+    int rc = 0;
+    for (int i = 0; i < n_calls && rc == 0; i++) {
+        if (split) {
+            rc = aecm_aec_setFrameFar(h, (int16_t *)far + i * step, frames_per_call);
+            if (rc == 0) rc = aecm_aec_process(h, (int16_t *)near + i * step, out + i * step, frames_per_call, delay_ms);
+        } else {
+            rc = aecm_aec_process2(h, (int16_t *)far + i * step, (int16_t *)near + i * step, out + i * step, frames_per_call, delay_ms);
+        }
+    }
+    aecm_aec_release(h);
+    return rc;
+}
+
 /* The daemon's record chain (src/wmix.c:613-709): NS -> AEC -> AGC -> VAD, all in place. */
 int ref_run_chain(int chn, int freq, int agc_value, unsigned stages, const int16_t *far, const int16_t *near,
                   int16_t *out, int frames_per_call, int n_calls)
