@@ -156,6 +156,22 @@ int wmx_aec_run(wmx_aec *h, int mode, const int16_t *d_far, long far_packet_stri
 int wmx_aec_state_words(const wmx_aec *h);
 int wmx_aec_export_state(const wmx_aec *h, int stream_index, float *host_words);
 
+/* ------------------------------------------------------------------ AECM (fixed-point echo canceller)
+ * Batched form of the SAME five wrapper functions when the reference is built with its AECM switch (`#undef
+ * MAKE_WEBRTC_AEC`, src/webrtc.c:168-191: WebRtcAecm_Create / Init / BufferFarend / Process, echo mode 3, comfort noise on,
+ * W:modules/audio_processing/aecm/).  Same arguments, modes, strides, aliasing and return values as wmx_aec_*; one shared
+ * far-end per batch.  When the reference returns -1 for a delay outside [0, 500] ms the packet HAS been processed with
+ * the delay clamped (state advances) but its output is not written, as in the wrapper.  Integer path: bit-exact.  At
+ * 8 kHz with 20 ms packets the reference replays an uninitialised buffer (farendOld[1]); it is zero here.
+ * The legacy aec_init picks this implementation when the environment has WMIX_AMD_AECM=1. */
+typedef struct wmx_aecm wmx_aecm;
+int wmx_aecm_create(wmx_aecm **out, int n_streams, int chn, int freq, int interval_ms);
+int wmx_aecm_destroy(wmx_aecm *h);
+int wmx_aecm_packet_samples(const wmx_aecm *h);
+int wmx_aecm_state_bytes(const wmx_aecm *h);
+int wmx_aecm_run(wmx_aecm *h, int mode, const int16_t *d_far, long far_packet_stride, const int16_t *d_near,
+                 int16_t *d_out, int n_packets, long stream_stride, long packet_stride, int delay_ms, void *stream);
+
 /* ------------------------------------------------------------------ resample + mix
  * Batched forms of wmix_pcm_zoom (src/wmix.c:139-222) and of wmix_load_data + the play thread's drain
  * (src/wmix.c:1639-1957, 1347-1366).  Strides in int16 elements.  Integer path: bit-exact, including the

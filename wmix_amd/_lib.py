@@ -82,6 +82,16 @@ def _declare(L):
     L.wmx_nsx_state_bytes.argtypes = [vp]
     L.wmx_nsx_process.restype = i
     L.wmx_nsx_process.argtypes = [vp, vp, vp, i, C.c_long, C.c_long, vp]
+    L.wmx_aecm_create.restype = i
+    L.wmx_aecm_create.argtypes = [C.POINTER(vp), i, i, i, i]
+    L.wmx_aecm_destroy.restype = i
+    L.wmx_aecm_destroy.argtypes = [vp]
+    L.wmx_aecm_packet_samples.restype = i
+    L.wmx_aecm_packet_samples.argtypes = [vp]
+    L.wmx_aecm_state_bytes.restype = i
+    L.wmx_aecm_state_bytes.argtypes = [vp]
+    L.wmx_aecm_run.restype = i
+    L.wmx_aecm_run.argtypes = [vp, i, vp, C.c_long, vp, vp, i, C.c_long, C.c_long, i, vp]
     L.wmx_vad_create.restype = i
     L.wmx_vad_create.argtypes = [C.POINTER(vp), i, i, i, i]
     L.wmx_vad_destroy.restype = i

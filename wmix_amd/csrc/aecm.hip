@@ -1,0 +1,1063 @@
+// aecm.hip -- batched FIXED-POINT echo canceller (AECM) for gfx950: one wavefront per stream.
+//
+// What the reference runs when src/webrtc.c is built with its AECM switch (`#undef MAKE_WEBRTC_AEC`, src/webrtc.c:168-191):
+// aec_setFrameFar / aec_process / aec_process2 over WebRtcAecm_BufferFarend / WebRtcAecm_Process
+// (W:modules/audio_processing/aecm/echo_control_mobile.c), WebRtcAecm_ProcessFrame / ProcessBlock
+// (aecm_core.c:569-664, aecm_core_c.c:280-639: TimeToFrequencyDomain, CalcEnergies, CalcStepSize, UpdateChannel,
+// CalcSuppressionGain, the Wiener / NLP gains, ComfortNoise, InverseFFTAndWindow) and the binary-spectrum delay estimator
+// (W:modules/audio_processing/utility/delay_estimator.c:393-487, delay_estimator_wrapper.c:52-78).
+//
+// Split of the work, as in aec.hip.  The control plane (start-up phase, far-end buffer bookkeeping, 80 -> 64 re-blocking)
+// is data independent and runs on the host (aecm_ctl.h -> AecmPlan).  `aecm_far_kernel` (one wave per batch) does
+// everything that depends on the SHARED far-end only: far ring, re-blocking, the far spectrum |X| with its Q-domain, the
+// binary far spectrum; it appends them to a 256-slot history that replaces the reference's per-handle far_history /
+// binary_far_history (index = absolute block number, the reference's `history_pos - delay`).  `aecm_near_kernel` (one
+// wave per stream, 4 streams per workgroup) does the per-stream part: near spectrum, the delay estimate (100 history
+// comparisons = two per lane, argmin by a wave reduction that keeps the reference's first-minimum rule), channel
+// estimation, gains, comfort noise, inverse transform.  Lane k owns bin k; lane 0 also bin 64.  Every sum is an integer
+// sum (order-free), so the kernel is bit-exact by construction; the FFT is the SPL radix-2 fixed-point transform of
+// spl_fx.h, order 7.  State: 3.4 KB per stream, one contiguous block moved through LDS.
+//
+// One reference quirk is pinned to its well-defined reading: at 8 kHz with 20 ms packets the second 10 ms frame of a
+// packet replays farendOld[1], which WebRtcAecm_Init leaves uninitialised (it clears 160 bytes, not 160 samples,
+// echo_control_mobile.c:211); here it starts as zeros, what a fresh heap gives (tests/golden/make_aecm_golden.py).
+#include <vector>
+#include "wmx_internal.h"
+#include "spl_fx.h"
+#include "aecm_ctl.h"
+#include "fx_tables.h"
+
+namespace wmx {
+namespace {
+
+constexpr int kAecmWavesPerBlock = 4;
+constexpr int kAecmBP = 68;        // 65 bins padded
+constexpr int kAecmMaxDelay = 100;  // MAX_DELAY, aecm_defines.h:26
+
+struct alignas(16) AecmConsts {
+    int16_t sin1024[1024];
+    int16_t sqrt_hanning[66];
+    int16_t cos360[360], sin360[360];
+    int16_t pad[2];
+    uint32_t lcg_a[64], lcg_c[64];  // seed after k+1 steps = lcg_a[k] * seed + lcg_c[k]  (mod 2^31)
+};
+static_assert(sizeof(AecmConsts) % 16 == 0, "AecmConsts is copied in 16-byte pieces");
+
+// shared far-end state of a batch (device memory)
+struct AecmFarBufs {
+    int16_t *ring;      // [kAecmFarRing]           farendBuf
+    int16_t *old;       // [2][80]                  farendOld
+    int16_t *frame;     // [kAecmFrameRing]         farFrameBuf
+    int16_t *x_prev;    // [64]                     xBuf[0..63]
+    int32_t *mean_far;  // [32] + initialised flag  mean_far_spectrum of bins 12..43, far_spectrum_initialized
+    uint16_t *hist;     // [kAecmHist][kAecmBP]     far spectra by absolute block number
+    int32_t *hist_q;    // [kAecmHist]              their Q-domains
+    uint32_t *hist_bin; // [kAecmHist]              binary far spectra
+};
+
+// ---------------------------------------------------------------- per-stream state block (int32 words)
+enum AecmLayout : int {
+    A_D_PREV = 0,                    // int16[64]  dBufNoisy[0..63]
+    A_OUT_BUF = A_D_PREV + 32,       // int16[64]  outBuf
+    A_NEAR_RING = A_OUT_BUF + 32,    // int16[144] nearNoisyFrameBuf
+    A_OUT_RING = A_NEAR_RING + 72,   // int16[144] outFrameBuf
+    A_CH_STORED = A_OUT_RING + 72,   // int16[68]
+    A_CH_ADAPT16 = A_CH_STORED + 34, // int16[68]
+    A_NEAR_FILT = A_CH_ADAPT16 + 34, // int16[68]
+    A_NOISE_LO = A_NEAR_FILT + 34,   // int16[68]  noiseEstTooLowCtr
+    A_NOISE_HI = A_NOISE_LO + 34,    // int16[68]  noiseEstTooHighCtr
+    A_NEAR_LOG = A_NOISE_HI + 34,    // int16[64]  nearLogEnergy        (rings: logical [i] = physical [(head + i) & 63])
+    A_EADAPT_LOG = A_NEAR_LOG + 32,  // int16[64]  echoAdaptLogEnergy
+    A_ESTORED_LOG = A_EADAPT_LOG + 32,  // int16[64] echoStoredLogEnergy
+    A_CH_ADAPT32 = A_ESTORED_LOG + 32,  // int32[68]
+    A_ECHO_FILT = A_CH_ADAPT32 + 68,    // int32[68]
+    A_NOISE_EST = A_ECHO_FILT + 68,     // int32[68]
+    A_MEAN_NEAR = A_NOISE_EST + 68,     // int32[32] mean_near_spectrum of bins 12..43
+    A_MEAN_BITS = A_MEAN_NEAR + 32,     // int32[104] mean_bit_counts
+    A_SCAL = A_MEAN_BITS + 104,         // 34 scalar words
+    A_WORDS = A_SCAL + 34
+};
+static_assert(A_WORDS % 4 == 0, "16-byte state copies");
+enum AecmScalar {
+    M_FIRST_VAD = 0, M_CUR_VAD, M_DFA_Q, M_TOT_COUNT, M_FAR_LOG, M_E_MIN, M_E_MAX, M_E_MAXMIN, M_E_VAD, M_E_MSE, M_VAD_UPD, M_STARTUP,
+    M_MSE_COUNT, M_SUP_GAIN, M_SUP_GAIN_OLD, M_MSE_ADAPT_OLD, M_MSE_STORED_OLD, M_MSE_THR, M_NOISE_CTR, M_SEED, M_NEAR_INIT, M_MIN_PROB,
+    M_LAST_PROB, M_LAST_DELAY, M_LOG_HEAD, M_COUNT
+};
+
+struct alignas(16) AecmWave {
+    int32_t st[A_WORDS];
+    int32_t cx[128];        // FFT work array (packed complex)
+    int16_t td[128];        // time-domain block pair / inverse transform output
+    int32_t dfw[kAecmBP];   // near spectrum (re | im << 16)
+    int32_t efw[kAecmBP];   // filtered spectrum
+    int32_t echo_est[kAecmBP];
+    uint16_t dfa[kAecmBP], xfa[kAecmBP];
+    int16_t hnl[kAecmBP];
+};
+
+__device__ __forceinline__ int32_t add_sat32(int32_t a, int32_t b) {  // spl_inl.h:38-55
+    int32_t s = wadd(a, b);
+    if (a < 0) {
+        if (b < 0 && s >= 0) s = (int32_t)0x80000000;
+    } else if (b > 0 && s < 0) {
+        s = 0x7FFFFFFF;
+    }
+    return s;
+}
+__device__ __forceinline__ int16_t log_energy_q8(uint32_t energy, int q) {  // aecm_core.c:709-721
+    int16_t l = 7 << 7;
+    if (energy > 0) {
+        const int zeros = norm_u32(energy);
+        const int16_t frac = (int16_t)(((energy << zeros) & 0x7FFFFFFF) >> 23);
+        l = (int16_t)(l + ((31 - zeros) << 8) + frac - (q << 8));
+    }
+    return l;
+}
+__device__ __forceinline__ int16_t asym_filt(int16_t old, int16_t in, int step_pos, int step_neg) {  // aecm_core.c:668-690
+    if (old == 32767 || old == -32768) return in;
+    return old > in ? (int16_t)(old - ((old - in) >> step_neg)) : (int16_t)(old + ((in - old) >> step_pos));
+}
+__device__ __forceinline__ void mean_estimator(int32_t v, int factor, int32_t &mean) {  // delay_estimator.c:672-684
+    int32_t d = wsub(v, mean);
+    d = d < 0 ? -((-d) >> factor) : d >> factor;
+    mean = wadd(mean, d);
+}
+
+// TimeToFrequencyDomain + WindowAndFFT (aecm_core_c.c:68-96, 171-278) of the 128 samples in td: leaves the spectrum in
+// spec[] (re | im << 16, imag already sign-flipped like freq_signal) and |X| in mag[]; returns the scaling; *sum = sum |X|
+__device__ int time_to_freq(AecmWave &W, const AecmConsts &K, int lane, int32_t *spec, uint16_t *mag, uint32_t *sum) {
+    int mx = 0;
+    for (int i = lane; i < 128; i += 64) {
+        const int a = W.td[i] < 0 ? -(int)W.td[i] : (int)W.td[i];
+        mx = a > mx ? a : mx;
+    }
+    mx = wave_max(mx);
+    if (mx > 32767) mx = 32767;
+    const int q = norm_w16((int16_t)mx);
+    for (int i = lane; i < 128; i += 64) {
+        const int16_t s = (int16_t)wshl(W.td[i], q);
+        const int16_t w = i < 64 ? K.sqrt_hanning[i] : K.sqrt_hanning[128 - i];
+        W.cx[bitrev<7>(i)] = (int32_t)(uint16_t)(int16_t)((s * w) >> 14);
+    }
+    wave_sync();
+    spl_cfft<7, false>(W.cx, K.sin1024, lane);
+    uint32_t part = 0;
+    for (int b = lane; b < 65; b += 64) {
+        const int32_t x = W.cx[b];
+        const int16_t re = lo16(x);
+        int16_t im = (int16_t)-hi16(x);
+        uint16_t m;
+        if (b == 0 || b == 64) {
+            im = 0;
+            m = (uint16_t)(re >= 0 ? re : -re);
+        } else if (re == 0) {
+            m = (uint16_t)(im >= 0 ? im : -im);
+        } else if (im == 0) {
+            m = (uint16_t)(re >= 0 ? re : -re);
+        } else {
+            const int16_t ar = (int16_t)(re >= 0 ? re : -re), ai = (int16_t)(im >= 0 ? im : -im);
+            m = (uint16_t)sqrt_floor(add_sat32(ar * ar, ai * ai));
+        }
+        spec[b] = pack16(re, im);
+        mag[b] = m;
+        part += m;
+    }
+    *sum = wave_sum(part);
+    wave_sync();
+    return q;
+}
+
+// BinarySpectrumFix (delay_estimator_wrapper.c:52-78): lanes 12..43 own one band each; mean[] holds bands 12..43
+__device__ uint32_t binary_spectrum(const uint16_t *mag, int32_t *mean, int q, int &initialized, int lane) {
+    const bool mine = lane >= 12 && lane <= 43;
+    const int32_t s = mine ? wshl((int32_t)mag[lane], 15 - q) : 0;
+    int32_t m = mine ? mean[lane - 12] : 0;
+    if (!initialized) {
+        if (mine && mag[lane] > 0) m = s >> 1;
+        initialized = wave_any(mine && mag[lane] > 0);
+    }
+    if (mine) {
+        mean_estimator(s, 6, m);
+        mean[lane - 12] = m;
+    }
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(mine && s > m);
+    return (uint32_t)(bal >> 12);
+}
+
+// ---------------------------------------------------------------- far-end kernel: one wave per batch
+__global__ __launch_bounds__(64) void aecm_far_kernel(AecmFarBufs F, const AecmConsts *__restrict__ consts, const AecmPlan *__restrict__ plans,
+                                                     int n_plans, const int16_t *far, long far_stride, int chn) {
+    __shared__ AecmConsts K;
+    __shared__ AecmWave W;
+    const int lane = threadIdx.x;
+    {
+        const int4 *src = reinterpret_cast<const int4 *>(consts);
+        int4 *dst = reinterpret_cast<int4 *>(&K);
+        for (int i = lane; i < (int)(sizeof(AecmConsts) / 16); i += 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    int far_init = uni(F.mean_far[32]);
+    int32_t *mean = &W.st[0];  // 32 thresholds staged in LDS for the launch
+    if (lane < 32) mean[lane] = F.mean_far[lane];
+    wave_sync();
+    for (int p = 0; p < n_plans; p++) {
+        const AecmPlan &pl = plans[p];
+        if (pl.has_far) {
+            const int16_t *src = far + (long)p * far_stride;
+            for (int i = lane; i < pl.far_n; i += 64) {
+                int pos = pl.far_w + i;
+                pos -= pos >= kAecmFarRing ? kAecmFarRing : 0;
+                F.ring[pos] = src[(long)i * chn];  // left channel only, src/webrtc.c:303-309
+            }
+            __threadfence();
+            wave_sync();
+        }
+        if (!pl.has_near || pl.passthrough) continue;
+        for (int f = 0; f < pl.n_frames; f++) {
+            const AecmFramePlan &fp = pl.fr[f];
+            for (int i = lane; i < kAecmFrame; i += 64) {
+                int16_t v;
+                if (fp.far_src >= 0) {
+                    int pos = fp.far_src + i;
+                    pos -= pos >= kAecmFarRing ? kAecmFarRing : 0;
+                    v = F.ring[pos];
+                    F.old[fp.old_slot * kAecmFrame + i] = v;
+                } else {
+                    v = F.old[fp.old_slot * kAecmFrame + i];
+                }
+                int w = fp.ring_w + i;
+                w -= w >= kAecmFrameRing ? kAecmFrameRing : 0;
+                F.frame[w] = v;
+            }
+            __threadfence();
+            wave_sync();
+            for (int b = 0; b < fp.n_blocks; b++) {
+                int r = fp.blk_r[b] + lane;
+                r -= r >= kAecmFrameRing ? kAecmFrameRing : 0;
+                const int16_t nw = F.frame[r];
+                W.td[lane] = F.x_prev[lane];
+                W.td[64 + lane] = nw;
+                wave_sync();
+                uint32_t sum;
+                const int far_q = time_to_freq(W, K, lane, W.dfw, W.xfa, &sum);
+                const int slot = fp.blk_t[b] & (kAecmHist - 1);
+                for (int k = lane; k < 65; k += 64) F.hist[slot * kAecmBP + k] = W.xfa[k];
+                const uint32_t bin = binary_spectrum(W.xfa, mean, far_q, far_init, lane);
+                if (lane == 0) {
+                    F.hist_q[slot] = far_q;
+                    F.hist_bin[slot] = bin;
+                }
+                F.x_prev[lane] = nw;
+                __threadfence();
+                wave_sync();
+            }
+        }
+    }
+    if (lane < 32) F.mean_far[lane] = mean[lane];
+    if (lane == 0) F.mean_far[32] = far_init;
+}
+
+// ---------------------------------------------------------------- one 64-sample block of one stream (ProcessBlock)
+__device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &F, int32_t (&sc)[M_COUNT], int t, int mult, int lane) {
+    int16_t *ch_stored = reinterpret_cast<int16_t *>(&W.st[A_CH_STORED]), *ch_adapt16 = reinterpret_cast<int16_t *>(&W.st[A_CH_ADAPT16]);
+    int16_t *near_filt = reinterpret_cast<int16_t *>(&W.st[A_NEAR_FILT]);
+    int16_t *noise_lo = reinterpret_cast<int16_t *>(&W.st[A_NOISE_LO]), *noise_hi = reinterpret_cast<int16_t *>(&W.st[A_NOISE_HI]);
+    int16_t *near_log = reinterpret_cast<int16_t *>(&W.st[A_NEAR_LOG]), *eadapt_log = reinterpret_cast<int16_t *>(&W.st[A_EADAPT_LOG]);
+    int16_t *estored_log = reinterpret_cast<int16_t *>(&W.st[A_ESTORED_LOG]);
+    int32_t *ch_adapt32 = &W.st[A_CH_ADAPT32], *echo_filt = &W.st[A_ECHO_FILT], *noise_est = &W.st[A_NOISE_EST];
+    int32_t *mean_near = &W.st[A_MEAN_NEAR], *mean_bits = &W.st[A_MEAN_BITS];
+    int16_t *out_buf = reinterpret_cast<int16_t *>(&W.st[A_OUT_BUF]);
+
+    if (sc[M_STARTUP] < 2) sc[M_STARTUP] = ((uint32_t)sc[M_TOT_COUNT] >= 512) + ((uint32_t)sc[M_TOT_COUNT] >= 1024);
+    // near spectrum (W.td holds [previous block | new block])
+    uint32_t dfa_sum;
+    const int zeros_d = time_to_freq(W, K, lane, W.dfw, W.dfa, &dfa_sum);
+    const int dfa_q_old = sc[M_DFA_Q];
+    sc[M_DFA_Q] = zeros_d;
+
+    // delay estimate: BinarySpectrumFix + WebRtc_ProcessBinarySpectrum (robust validation off)
+    int delay;
+    {
+        int near_init = sc[M_NEAR_INIT];
+        const uint32_t near_bin = binary_spectrum(W.dfa, mean_near, zeros_d, near_init, lane);
+        sc[M_NEAR_INIT] = near_init;
+        uint32_t kmin = 0xFFFFFFFFu;
+        int32_t vmax = 0;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int i = lane + 64 * r;
+            if (i < kAecmMaxDelay) {
+                const uint32_t fb = F.hist_bin[(t - i) & (kAecmHist - 1)];  // binary_far_history[i] = the spectrum of i blocks ago
+                const int fbc = __popc(fb);
+                int32_t m = mean_bits[i];
+                if (fbc > 0) mean_estimator(__popc(near_bin ^ fb) << 9, 13 - ((3 * fbc) >> 4), m);
+                mean_bits[i] = m;
+                // first minimum wins (strict < in index order): order by (value, index); values are < 2^15
+                const uint32_t key = ((uint32_t)m << 8) | (uint32_t)i;
+                kmin = key < kmin ? key : kmin;
+                vmax = m > vmax ? m : vmax;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t w = (uint32_t)__shfl_xor((int)kmin, o, 64);
+            kmin = w < kmin ? w : kmin;
+        }
+        kmin = (uint32_t)uni((int)kmin);
+        vmax = wave_max(vmax);
+        int32_t best = (int32_t)(kmin >> 8);
+        int candidate = (int)(kmin & 0xff);
+        if (best >= (32 << 9)) best = 32 << 9, candidate = -1;  // nothing below kMaxBitCountsQ9
+        const int32_t depth = vmax - best;
+        if (sc[M_MIN_PROB] > 8704 && depth > 2816) {
+            int32_t thr = best + 1024;
+            if (thr < 8704) thr = 8704;
+            if (sc[M_MIN_PROB] > thr) sc[M_MIN_PROB] = thr;
+        }
+        sc[M_LAST_PROB]++;
+        if (depth > 1024 && (best < sc[M_MIN_PROB] || best < sc[M_LAST_PROB])) {
+            sc[M_LAST_DELAY] = candidate;
+            if (best < sc[M_LAST_PROB]) sc[M_LAST_PROB] = best;
+        }
+        delay = sc[M_LAST_DELAY];
+        if (delay < 0) delay = 0;  // -2: no estimate yet (aecm_core_c.c:397-400); -1 cannot reach here
+    }
+    // aligned far spectrum (WebRtcAecm_AlignedFarend): the block `delay` blocks ago
+    const int slot = (t - delay) & (kAecmHist - 1);
+    const int zeros_x = F.hist_q[slot];
+    for (int b = lane; b < 65; b += 64) W.xfa[b] = F.hist[slot * kAecmBP + b];
+    wave_sync();
+
+    // ---- CalcEnergies, aecm_core.c:730-851
+    const int head = (sc[M_LOG_HEAD] - 1) & 63;  // the three log histories shift by one: move the ring head instead
+    sc[M_LOG_HEAD] = head;
+    {
+        uint32_t e_far = 0, e_adapt = 0, e_stored = 0;
+        for (int b = lane; b < 65; b += 64) {
+            const uint16_t x = W.xfa[b];
+            const int32_t est = (int32_t)ch_stored[b] * x;
+            W.echo_est[b] = est;
+            e_far += x;
+            e_adapt += (uint32_t)(ch_adapt16[b] * x);
+            e_stored += (uint32_t)est;
+        }
+        e_far = wave_sum(e_far);
+        e_adapt = wave_sum(e_adapt);
+        e_stored = wave_sum(e_stored);
+        const int16_t near0 = log_energy_q8(dfa_sum, zeros_d);
+        int16_t eadapt0 = log_energy_q8(e_adapt, 12 + zeros_x);
+        const int16_t estored0 = log_energy_q8(e_stored, 12 + zeros_x);
+        const int16_t far_log = log_energy_q8(e_far, zeros_x);
+        sc[M_FAR_LOG] = far_log;
+        int16_t e_min = (int16_t)sc[M_E_MIN], e_max = (int16_t)sc[M_E_MAX], e_vad = (int16_t)sc[M_E_VAD];
+        if (far_log > 1025) {
+            int inc_max = 4, dec_max = 11, inc_min = 11, dec_min = 3;
+            if (sc[M_STARTUP] == 0) inc_max = 2, dec_min = 2, inc_min = 8;
+            e_min = asym_filt(e_min, far_log, inc_min, dec_min);
+            e_max = asym_filt(e_max, far_log, inc_max, dec_max);
+            sc[M_E_MAXMIN] = (int16_t)(e_max - e_min);
+            int16_t tv = (int16_t)(2560 - e_min);
+            tv = tv > 0 ? (int16_t)((tv * 230) >> 9) : (int16_t)0;
+            tv = (int16_t)(tv + 230);
+            if ((sc[M_STARTUP] == 0) | (sc[M_VAD_UPD] > 1024)) {
+                e_vad = (int16_t)(e_min + tv);
+            } else if (e_vad > far_log) {
+                e_vad = (int16_t)(e_vad + ((far_log + tv - e_vad) >> 6));
+                sc[M_VAD_UPD] = 0;
+            } else {
+                sc[M_VAD_UPD] = (int16_t)(sc[M_VAD_UPD] + 1);
+            }
+            sc[M_E_MSE] = (int16_t)(e_vad + (1 << 8));
+            sc[M_E_MIN] = e_min;
+            sc[M_E_MAX] = e_max;
+            sc[M_E_VAD] = e_vad;
+        }
+        if (far_log > e_vad) {
+            if ((sc[M_STARTUP] == 0) | (sc[M_E_MAXMIN] > 929)) sc[M_CUR_VAD] = 1;
+        } else {
+            sc[M_CUR_VAD] = 0;
+        }
+        if (sc[M_CUR_VAD] && sc[M_FIRST_VAD]) {
+            sc[M_FIRST_VAD] = 0;
+            if (eadapt0 > near0) {
+                for (int b = lane; b < 65; b += 64) ch_adapt16[b] >>= 3;
+                eadapt0 = (int16_t)(eadapt0 - (3 << 8));
+                sc[M_FIRST_VAD] = 1;
+            }
+        }
+        if (lane == 0) {
+            near_log[head] = near0;
+            eadapt_log[head] = eadapt0;
+            estored_log[head] = estored0;
+        }
+    }
+    wave_sync();
+
+    // ---- CalcStepSize, aecm_core.c:858-891
+    int16_t mu = 1;
+    if (!sc[M_CUR_VAD]) {
+        mu = 0;
+    } else if (sc[M_STARTUP] > 0) {
+        if (sc[M_E_MIN] >= sc[M_E_MAX]) {
+            mu = 10;
+        } else {
+            const int16_t t16 = (int16_t)(sc[M_FAR_LOG] - sc[M_E_MIN]);
+            mu = (int16_t)(10 - 1 - (int16_t)div_w32_w16(t16 * 9, (int16_t)sc[M_E_MAXMIN]));
+        }
+        if (mu < 1) mu = 1;
+    }
+    sc[M_TOT_COUNT] = (int32_t)((uint32_t)sc[M_TOT_COUNT] + 1);
+
+    // ---- UpdateChannel, aecm_core.c:902-1109
+    if (mu) {
+        for (int b = lane; b < 65; b += 64) {
+            const uint16_t x = W.xfa[b], d = W.dfa[b];
+            const int32_t ca = ch_adapt32[b];
+            const int16_t zeros_ch = (int16_t)norm_u32((uint32_t)ca), zeros_far = (int16_t)norm_u32((uint32_t)x);
+            uint32_t u1;
+            int16_t shift_ch_far;
+            if (zeros_ch + zeros_far > 31) {
+                u1 = (uint32_t)ca * x;
+                shift_ch_far = 0;
+            } else {
+                shift_ch_far = (int16_t)(32 - zeros_ch - zeros_far);
+                u1 = (uint32_t)wmul(ca >> shift_ch_far, x);
+            }
+            int16_t zeros_num = (int16_t)norm_u32(u1);
+            const int16_t zeros_dfa = (int16_t)(d ? norm_u32((uint32_t)d) : 32);
+            const int16_t t16 = (int16_t)(zeros_dfa - 2 + zeros_d - 28 - zeros_x + shift_ch_far);
+            int16_t xfa_q, dfa_q;
+            if (zeros_num > t16 + 1) {
+                xfa_q = t16;
+                dfa_q = (int16_t)(zeros_dfa - 2);
+            } else {
+                xfa_q = (int16_t)(zeros_num - 2);
+                dfa_q = (int16_t)(28 + zeros_x - zeros_d - shift_ch_far + xfa_q);
+            }
+            u1 = xfa_q >= 0 ? u1 << xfa_q : u1 >> -xfa_q;
+            const uint32_t u2 = dfa_q >= 0 ? (uint32_t)d << dfa_q : (uint32_t)d >> -dfa_q;
+            const int32_t err = (int32_t)u2 - (int32_t)u1;
+            zeros_num = (int16_t)norm_w32(err);
+            if (err && x > (16 << zeros_x)) {
+                int32_t upd;
+                int16_t shift_num;
+                if (zeros_num + zeros_far > 31) {
+                    upd = err > 0 ? (int32_t)((uint32_t)err * x) : -(int32_t)((uint32_t)(-err) * x);
+                    shift_num = 0;
+                } else {
+                    shift_num = (int16_t)(32 - (zeros_num + zeros_far));
+                    upd = err > 0 ? wmul(err >> shift_num, x) : -wmul(-err >> shift_num, x);
+                }
+                upd = div_w32_w16(upd, (int16_t)(b + 1));
+                const int16_t shift2 = (int16_t)(shift_num + shift_ch_far - xfa_q - mu - ((30 - zeros_far) << 1));
+                upd = norm_w32(upd) < shift2 ? 0x7FFFFFFF : shift_w32(upd, shift2);
+                int32_t nc = add_sat32(ca, upd);
+                if (nc < 0) nc = 0;
+                ch_adapt32[b] = nc;
+                ch_adapt16[b] = (int16_t)(nc >> 16);
+            }
+        }
+        wave_sync();
+    }
+    int store = 0, reset = 0;
+    if ((sc[M_STARTUP] == 0) & (sc[M_CUR_VAD] != 0)) {
+        store = 1;
+    } else {
+        if (sc[M_FAR_LOG] < sc[M_E_MSE])
+            sc[M_MSE_COUNT] = 0;
+        else
+            sc[M_MSE_COUNT] = (int16_t)(sc[M_MSE_COUNT] + 1);
+        if (sc[M_MSE_COUNT] >= 30) {
+            uint32_t ms = 0, ma = 0;
+            if (lane < 20) {
+                const int k = (head + lane) & 63;
+                int32_t d = (int32_t)estored_log[k] - (int32_t)near_log[k];
+                ms = (uint32_t)(d >= 0 ? d : -d);
+                d = (int32_t)eadapt_log[k] - (int32_t)near_log[k];
+                ma = (uint32_t)(d >= 0 ? d : -d);
+            }
+            const int32_t mse_stored = (int32_t)wave_sum(ms), mse_adapt = (int32_t)wave_sum(ma);
+            if (((mse_stored << 5) < (29 * mse_adapt)) & (wshl(sc[M_MSE_STORED_OLD], 5) < wmul(29, sc[M_MSE_ADAPT_OLD]))) {
+                reset = 1;
+            } else if (((29 * mse_stored) > (mse_adapt << 5)) & (mse_adapt < sc[M_MSE_THR]) & (sc[M_MSE_ADAPT_OLD] < sc[M_MSE_THR])) {
+                store = 1;
+                if (sc[M_MSE_THR] == 0x7FFFFFFF) {
+                    sc[M_MSE_THR] = wadd(mse_adapt, sc[M_MSE_ADAPT_OLD]);
+                } else {
+                    const int scaled = wmul(sc[M_MSE_THR], 5) / 8;
+                    sc[M_MSE_THR] = wadd(sc[M_MSE_THR], wmul(mse_adapt - scaled, 205) >> 8);
+                }
+            }
+            sc[M_MSE_COUNT] = 0;
+            sc[M_MSE_STORED_OLD] = mse_stored;
+            sc[M_MSE_ADAPT_OLD] = mse_adapt;
+        }
+    }
+    if (store) {  // StoreAdaptiveChannelC, aecm_core.c:334-362
+        for (int b = lane; b < 65; b += 64) {
+            const int16_t c = ch_adapt16[b];
+            ch_stored[b] = c;
+            W.echo_est[b] = (int32_t)c * W.xfa[b];
+        }
+    } else if (reset) {  // ResetAdaptiveChannelC, :364-380
+        for (int b = lane; b < 65; b += 64) {
+            const int16_t c = ch_stored[b];
+            ch_adapt16[b] = c;
+            ch_adapt32[b] = wshl(c, 16);
+        }
+    }
+
+    // ---- CalcSuppressionGain, aecm_core.c:1118-1185
+    int16_t sup_gain;
+    {
+        int16_t sup = 256;
+        if (!sc[M_CUR_VAD]) {
+            sup = 0;
+        } else {
+            // nearLogEnergy[0] / echoStoredLogEnergy[0] of this block were written by lane 0 above; all lanes read them
+            const int16_t tdiff = (int16_t)(near_log[head] - estored_log[head]);
+            const int16_t dE = (int16_t)(tdiff >= 0 ? tdiff : -tdiff);
+            if (dE < 400) {
+                if (dE < 200)
+                    sup = (int16_t)(3072 - (int16_t)div_w32_w16(1536 * dE + 100, 200));
+                else
+                    sup = (int16_t)(256 + (int16_t)div_w32_w16(1280 * (400 - dE) + 100, 200));
+            } else {
+                sup = 256;
+            }
+        }
+        const int16_t tg = sup > (int16_t)sc[M_SUP_GAIN_OLD] ? sup : (int16_t)sc[M_SUP_GAIN_OLD];
+        sc[M_SUP_GAIN_OLD] = sup;
+        sc[M_SUP_GAIN] = (int16_t)(sc[M_SUP_GAIN] + (int16_t)((tg - sc[M_SUP_GAIN]) >> 4));
+        sup_gain = (int16_t)sc[M_SUP_GAIN];
+    }
+    wave_sync();
+
+    // ---- Wiener filter coefficients, aecm_core_c.c:434-545
+    int pos_count = 0;
+    for (int b = lane; b < 65; b += 64) {
+        int32_t ef = echo_filt[b];
+        ef = wadd(ef, wmul(wsub(W.echo_est[b], ef), 50) >> 8);
+        echo_filt[b] = ef;
+        const int16_t zeros32 = (int16_t)(norm_w32(ef) + 1);
+        int16_t zeros16 = (int16_t)(norm_w16(sup_gain) + 1);
+        uint32_t gained;
+        int16_t res_diff;
+        if (zeros32 + zeros16 > 16) {
+            gained = (uint32_t)ef * (uint16_t)sup_gain;
+            res_diff = (int16_t)(14 - 12 - 8 + (zeros_d - zeros_x));
+        } else {
+            const int16_t tt = (int16_t)(17 - zeros32 - zeros16);
+            res_diff = (int16_t)(14 + tt - 12 - 8 + (zeros_d - zeros_x));
+            gained = zeros32 > tt ? (uint32_t)ef * (uint16_t)(sup_gain >> tt) : (uint32_t)wmul(ef >> tt, sup_gain);
+        }
+        int16_t nf = near_filt[b];
+        const uint16_t d = W.dfa[b];
+        zeros16 = (int16_t)norm_w16(nf);
+        const int16_t dq = (int16_t)(zeros_d - dfa_q_old);
+        int16_t t1, t2, q_diff;
+        if (zeros16 < dq && nf) {
+            t1 = (int16_t)wshl(nf, zeros16);
+            q_diff = (int16_t)(zeros16 - dq);
+            t2 = (int16_t)(d >> -q_diff);
+        } else {
+            t1 = (int16_t)(dq < 0 ? nf >> -dq : wshl(nf, dq));
+            q_diff = 0;
+            t2 = (int16_t)d;
+        }
+        const int32_t nd = (int32_t)(t2 - t1);
+        t2 = (int16_t)(nd >> 4);
+        t2 = (int16_t)(t2 + t1);
+        zeros16 = (int16_t)norm_w16(t2);
+        if ((t2) & (-q_diff > zeros16))
+            nf = 32767;
+        else
+            nf = (int16_t)(q_diff < 0 ? wshl(t2, -q_diff) : t2 >> q_diff);
+        near_filt[b] = nf;
+        int16_t h;
+        if (gained == 0) {
+            h = 16384;
+        } else if (nf == 0) {
+            h = 0;
+        } else {
+            gained += (uint32_t)(nf >> 1);
+            const uint32_t qv = gained / (uint16_t)nf;
+            const int32_t r = (int32_t)(res_diff >= 0 ? qv << res_diff : qv >> -res_diff);
+            if (r > 16384) {
+                h = 0;
+            } else if (r < 0) {
+                h = 16384;
+            } else {
+                h = (int16_t)(16384 - (int16_t)r);
+                if (h < 0) h = 0;
+            }
+        }
+        if (h) pos_count++;
+        if (mult == 2) h = (int16_t)((h * h) >> 14);  // wideband: squared (aecm_core_c.c:549-553)
+        W.hnl[b] = h;
+    }
+    const int num_pos = (int)wave_sum((uint32_t)pos_count);
+    wave_sync();
+    int16_t avg_hnl = 0;
+    if (mult == 2) {  // cap the bands above 24 by the mean of bands 4..24, :555-571
+        uint32_t a = (lane >= 4 && lane <= 24) ? (uint32_t)(int32_t)W.hnl[lane] : 0u;
+        avg_hnl = (int16_t)((int32_t)wave_sum(a) / 21);
+    }
+    const int16_t nlp_gain = (int16_t)(num_pos < 3 ? 0 : 16384);
+    for (int b = lane; b < 65; b += 64) {
+        int16_t h = W.hnl[b];
+        if (mult == 2 && b >= 24 && h > avg_hnl) h = avg_hnl;
+        // nlpFlag is always 1 (aecm_core.c:436; WebRtcAecm_Control is never called by wmix)
+        if (h > 16384)
+            h = 16384;
+        else if (h < 3277)
+            h = 0;
+        if (!(h == 16384 && nlp_gain == 16384)) h = (int16_t)((h * nlp_gain) >> 14);
+        W.hnl[b] = h;
+        const int32_t x = W.dfw[b];
+        W.efw[b] = pack16((int16_t)((lo16(x) * h + 8192) >> 14), (int16_t)((hi16(x) * h + 8192) >> 14));
+    }
+
+    // ---- ComfortNoise, aecm_core_c.c:641-771 (cngMode is AecmTrue, echo_control_mobile.c:223)
+    {
+        const int16_t shift = (int16_t)(15 - zeros_d);
+        int min_track;
+        if (sc[M_NOISE_CTR] < 100) {
+            sc[M_NOISE_CTR]++;
+            min_track = 6;
+        } else {
+            min_track = 9;
+        }
+        // the 64 draws of WebRtcSpl_RandUArray by jump-ahead: draw k = A[k] * seed + C[k] (mod 2^31)
+        const uint32_t seed = (uint32_t)sc[M_SEED];
+        const uint32_t my_draw = (K.lcg_a[lane] * seed + K.lcg_c[lane]) & 0x7FFFFFFFu;
+        sc[M_SEED] = (int32_t)((K.lcg_a[63] * seed + K.lcg_c[63]) & 0x7FFFFFFFu);
+        // bin b uses draw b - 1: lane b takes the draw of the lane below, and lane 0 -- which owns bin 64 in the second
+        // pass -- that of lane 63 (the exchange sits outside the per-bin loop: every lane must take part in it)
+        const uint32_t prev_draw = (uint32_t)__shfl((int)my_draw, (lane + 63) & 63, 64);
+        for (int b = lane; b < 65; b += 64) {
+            const int32_t v = wshl((int32_t)W.dfa[b], shift);
+            int32_t ne = noise_est[b];
+            int16_t lo = noise_lo[b], hi = noise_hi[b];
+            if (v < ne) {
+                lo = 0;
+                if (ne < (1 << min_track)) {
+                    hi++;
+                    if (hi >= 5) {
+                        ne--;
+                        hi = 0;
+                    }
+                } else {
+                    ne -= (ne - v) >> min_track;
+                }
+            } else {
+                hi = 0;
+                if ((ne >> 19) > 0) {
+                    ne >>= 11;
+                    ne = wmul(ne, 2049);
+                } else if ((ne >> 11) > 0) {
+                    ne = wmul(ne, 2049);
+                    ne >>= 11;
+                } else {
+                    lo++;
+                    if (lo >= 5) {
+                        ne += (ne >> 9) + 1;
+                        lo = 0;
+                    }
+                }
+            }
+            int32_t nv = ne >> shift;
+            if (nv > 32767) {
+                nv = 32767;
+                ne = wshl(nv, shift);
+            }
+            noise_est[b] = ne;
+            noise_lo[b] = lo;
+            noise_hi[b] = hi;
+            const int16_t noise = (int16_t)(((int16_t)(16384 - W.hnl[b]) * (int16_t)nv) >> 14);
+            int16_t ur = 0, ui = 0;
+            if (b > 0) {
+                const int16_t idx = (int16_t)((359 * (int16_t)(prev_draw >> 16)) >> 15);
+                ur = (int16_t)((noise * K.cos360[idx]) >> 13);
+                ui = (int16_t)((-noise * K.sin360[idx]) >> 13);
+            }
+            if (b == 64) ui = 0;
+            const int32_t e = W.efw[b];
+            W.efw[b] = pack16(sat_w16((int32_t)lo16(e) + ur), sat_w16((int32_t)hi16(e) + ui));
+        }
+    }
+    wave_sync();
+
+    // ---- InverseFFTAndWindow, aecm_core_c.c:98-169
+    for (int b = lane; b < 65; b += 64) {
+        const int32_t e = W.efw[b];
+        const int16_t re = lo16(e), nim = (int16_t)-hi16(e);
+        W.cx[bitrev<7>(b)] = pack16(re, nim);
+        if (b > 0 && b < 64) W.cx[bitrev<7>(128 - b)] = pack16(re, (int16_t)-nim);
+    }
+    wave_sync();
+    const int out_scale = spl_cfft<7, true>(W.cx, K.sin1024, lane);
+    {
+        const int i = lane;
+        const int16_t a = (int16_t)(((int32_t)lo16(W.cx[i]) * K.sqrt_hanning[i] + 8192) >> 14);
+        int32_t v = shift_w32((int32_t)a, out_scale - zeros_d);
+        const int16_t o = sat_w16(v + out_buf[i]);
+        v = (lo16(W.cx[64 + i]) * K.sqrt_hanning[64 - i]) >> 14;
+        v = shift_w32(v, out_scale - zeros_d);
+        out_buf[i] = sat_w16(v);
+        W.td[i] = W.td[64 + i];  // dBufNoisy slides: the new block becomes the previous one
+        wave_sync();
+        W.td[64 + i] = o;        // the block's output, picked up by the caller
+    }
+    wave_sync();
+}
+
+// One wave per stream, kAecmWavesPerBlock streams per workgroup.
+__global__ __launch_bounds__(64 * kAecmWavesPerBlock) void aecm_near_kernel(int32_t *__restrict__ state, AecmFarBufs F,
+                                                                            const AecmConsts *__restrict__ consts,
+                                                                            const AecmPlan *__restrict__ plans, int n_plans, const int16_t *near,
+                                                                            int16_t *out, int n_streams, long stream_stride, long packet_stride,
+                                                                            int chn, int pkg, int mult) {
+    __shared__ AecmConsts K;
+    __shared__ AecmWave WS[kAecmWavesPerBlock];
+    {
+        const int4 *src = reinterpret_cast<const int4 *>(consts);
+        int4 *dst = reinterpret_cast<int4 *>(&K);
+        for (int i = threadIdx.x; i < (int)(sizeof(AecmConsts) / 16); i += blockDim.x) dst[i] = src[i];
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const long s = (long)blockIdx.x * kAecmWavesPerBlock + wave;
+    AecmWave &W = WS[wave];
+    const bool live = s < n_streams;
+    int32_t *st = state + (live ? s : 0) * (long)A_WORDS;
+    if (live) {
+        const int4 *src = reinterpret_cast<const int4 *>(st);
+        int4 *dst = reinterpret_cast<int4 *>(W.st);
+        for (int i = lane; i < A_WORDS / 4; i += 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (!live) return;
+    int32_t sc[M_COUNT];
+#pragma unroll
+    for (int k = 0; k < M_COUNT; k++) sc[k] = uni(W.st[A_SCAL + k]);
+    int16_t *near_ring = reinterpret_cast<int16_t *>(&W.st[A_NEAR_RING]), *out_ring = reinterpret_cast<int16_t *>(&W.st[A_OUT_RING]);
+    int16_t *d_prev = reinterpret_cast<int16_t *>(&W.st[A_D_PREV]);
+    for (int p = 0; p < n_plans; p++) {
+        const AecmPlan &pl = plans[p];
+        if (!pl.has_near) continue;
+        const int16_t *ip = near + s * stream_stride + (long)p * packet_stride;
+        int16_t *op = out + s * stream_stride + (long)p * packet_stride;
+        if (pl.passthrough) {  // start-up: out = near (echo_control_mobile.c:341-352), left channel to every channel
+            if (pl.discard_out) continue;
+            for (int i = lane; i < pkg; i += 64) {
+                const int16_t v = ip[(long)i * chn];
+                for (int c = 0; c < chn; c++) op[(long)i * chn + c] = v;
+            }
+            continue;
+        }
+        // the whole packet is read before anything is written (in-place calls)
+        int16_t in0[2], in1[2];
+#pragma unroll
+        for (int f = 0; f < 2; f++) {
+            in0[f] = (f < pl.n_frames) ? ip[(long)(f * kAecmFrame + lane) * chn] : (int16_t)0;
+            in1[f] = (f < pl.n_frames && lane < kAecmFrame - 64) ? ip[(long)(f * kAecmFrame + 64 + lane) * chn] : (int16_t)0;
+        }
+#pragma unroll
+        for (int f = 0; f < 2; f++) {
+            if (f >= pl.n_frames) break;
+            const AecmFramePlan &fp = pl.fr[f];
+            {
+                int w = fp.ring_w + lane;
+                w -= w >= kAecmFrameRing ? kAecmFrameRing : 0;
+                near_ring[w] = in0[f];
+                if (lane < kAecmFrame - 64) {
+                    int w2 = fp.ring_w + 64 + lane;
+                    w2 -= w2 >= kAecmFrameRing ? kAecmFrameRing : 0;
+                    near_ring[w2] = in1[f];
+                }
+            }
+            wave_sync();
+            for (int b = 0; b < fp.n_blocks; b++) {
+                int r = fp.blk_r[b] + lane;
+                r -= r >= kAecmFrameRing ? kAecmFrameRing : 0;
+                W.td[lane] = d_prev[lane];
+                W.td[64 + lane] = near_ring[r];
+                wave_sync();
+                aecm_block(W, K, F, sc, fp.blk_t[b], mult, lane);
+                d_prev[lane] = W.td[lane];
+                int ow = fp.blk_out_w[b] + lane;
+                ow -= ow >= kAecmFrameRing ? kAecmFrameRing : 0;
+                out_ring[ow] = W.td[64 + lane];
+                wave_sync();
+            }
+            if (!pl.discard_out)
+                for (int i = lane; i < kAecmFrame; i += 64) {
+                    int r = fp.out_r + i;
+                    r -= r >= kAecmFrameRing ? kAecmFrameRing : 0;
+                    const int16_t v = out_ring[r];
+                    for (int c = 0; c < chn; c++) op[(long)(f * kAecmFrame + i) * chn + c] = v;
+                }
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < M_COUNT; k++) W.st[A_SCAL + k] = sc[k];
+    }
+    wave_sync();
+    {
+        int4 *dst = reinterpret_cast<int4 *>(st);
+        const int4 *src = reinterpret_cast<const int4 *>(W.st);
+        for (int i = lane; i < A_WORDS / 4; i += 64) dst[i] = src[i];
+    }
+}
+
+__global__ void aecm_fill_state(int32_t *state, const int32_t *tmpl, int words, int n_streams) {
+    const size_t total = (size_t)words * n_streams;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        state[i] = tmpl[i % words];
+}
+
+}  // namespace
+}  // namespace wmx
+
+// ------------------------------------------------------------------------------------ host
+struct wmx_aecm {
+    int device;  // the HIP device the state lives on (current device at create); every entry point switches to it
+    int n_streams, chn, freq, pkg;
+    wmx::AecmCtl ctl;
+    int32_t *d_state;
+    wmx::AecmConsts *d_consts;
+    void *d_far;  // one allocation carved into AecmFarBufs
+    wmx::AecmFarBufs far;
+    wmx::AecmPlan *d_plans[2];  // double-buffered: a chunk's plans stay untouched while its kernels may still run
+    hipEvent_t plan_free[2];    // recorded behind the kernels that read d_plans[i]; waited for before it is rewritten
+    bool plan_used[2];
+    int plan_sel;
+    std::vector<wmx::AecmPlan> h_plans;
+};
+
+extern "C" {
+
+int wmx_aecm_destroy(wmx_aecm *h) {
+    WMX_ON_DEVICE(h);
+    if (!h) return 0;
+    if (h->d_state) (void)hipFree(h->d_state);
+    if (h->d_consts) (void)hipFree(h->d_consts);
+    if (h->d_far) (void)hipFree(h->d_far);
+    if (h->d_plans[0]) (void)hipFree(h->d_plans[0]);
+    for (int i = 0; i < 2; i++)
+        if (h->plan_free[i]) (void)hipEventDestroy(h->plan_free[i]);
+    delete h;
+    return 0;
+}
+
+int wmx_aecm_create(wmx_aecm **out, int n_streams, int chn, int freq, int interval_ms) {
+    using namespace wmx;
+    if (!out) return WMX_EINVAL;
+    *out = nullptr;
+    // aec_init (src/webrtc.c:220-221) + WebRtcAecm_Init (echo_control_mobile.c:186-190)
+    if ((freq != 8000 && freq != 16000) || chn < 1 || n_streams < 1) {
+        set_error("wmx_aecm_create: unsupported n_streams=%d chn=%d freq=%d", n_streams, chn, freq);
+        return WMX_EINVAL;
+    }
+    wmx_aecm *h = new wmx_aecm();
+    if ((h->device = current_device()) < 0) {
+        delete h;
+        return WMX_ENODEV;
+    }
+    h->n_streams = n_streams;
+    h->chn = chn;
+    h->freq = freq;
+    h->pkg = freq / 1000 * ((freq <= 8000 && interval_ms % 20 == 0) ? 20 : 10);  // src/webrtc.c:239-248
+    h->ctl.init(freq);
+    h->d_state = nullptr;
+    h->d_consts = nullptr;
+    h->d_far = nullptr;
+    h->d_plans[0] = h->d_plans[1] = nullptr;
+    h->plan_free[0] = h->plan_free[1] = nullptr;
+    h->plan_used[0] = h->plan_used[1] = false;
+    h->plan_sel = 0;
+    h->h_plans.resize(kAecmMaxPktPerLaunch);
+
+    AecmConsts *K = new AecmConsts();
+    memset(K, 0, sizeof(*K));
+    memcpy(K->sin1024, fx_spl_sin1024, sizeof(fx_spl_sin1024));
+    memcpy(K->sqrt_hanning, fx_aecm_sqrt_hanning, sizeof(fx_aecm_sqrt_hanning));
+    memcpy(K->cos360, fx_aecm_cos, sizeof(fx_aecm_cos));
+    memcpy(K->sin360, fx_aecm_sin, sizeof(fx_aecm_sin));
+    {
+        uint32_t a = 1, c = 0;  // x -> 69069 x + 1 composed k + 1 times (randomization_functions.c:92-96)
+        for (int k = 0; k < 64; k++) {
+            a = a * 69069u;
+            c = c * 69069u + 1u;
+            K->lcg_a[k] = a;
+            K->lcg_c[k] = c;
+        }
+    }
+    // initial per-stream state: WebRtcAecm_InitCore aecm_core.c:401-546, WebRtc_InitBinaryDelayEstimator
+    std::vector<int32_t> st(A_WORDS, 0);
+    {
+        int16_t *cs = reinterpret_cast<int16_t *>(&st[A_CH_STORED]), *c16 = reinterpret_cast<int16_t *>(&st[A_CH_ADAPT16]);
+        const int16_t *path = freq == 8000 ? fx_aecm_channel_8k : fx_aecm_channel_16k;
+        for (int i = 0; i < 65; i++) {
+            cs[i] = c16[i] = path[i];
+            st[A_CH_ADAPT32 + i] = (int32_t)((uint32_t)(int32_t)path[i] << 16);
+        }
+        int32_t t32 = 65 * 65;
+        int16_t t16 = 65;
+        int i;
+        for (i = 0; i < (65 >> 1) - 1; i++) {
+            st[A_NOISE_EST + i] = (int32_t)((uint32_t)t32 << 8);
+            t16--;
+            t32 -= (int32_t)((t16 << 1) + 1);
+        }
+        for (; i < 65; i++) st[A_NOISE_EST + i] = (int32_t)((uint32_t)t32 << 8);
+        for (i = 0; i <= kAecmMaxDelay; i++) st[A_MEAN_BITS + i] = 20 << 9;
+        int32_t *sc = &st[A_SCAL];
+        sc[M_FIRST_VAD] = 1;
+        sc[M_E_MIN] = 32767;
+        sc[M_E_MAX] = -32768;
+        sc[M_E_VAD] = 1025;
+        sc[M_SUP_GAIN] = 256;
+        sc[M_SUP_GAIN_OLD] = 256;
+        sc[M_MSE_ADAPT_OLD] = 1000;
+        sc[M_MSE_STORED_OLD] = 1000;
+        sc[M_MSE_THR] = 0x7FFFFFFF;
+        sc[M_SEED] = 666;
+        sc[M_MIN_PROB] = 32 << 9;
+        sc[M_LAST_PROB] = 32 << 9;
+        sc[M_LAST_DELAY] = -2;
+    }
+    const size_t far_bytes = sizeof(int16_t) * (kAecmFarRing + 2 * kAecmFrame + kAecmFrameRing + 64 + 8) + sizeof(int32_t) * (36 + kAecmHist) +
+                             sizeof(uint16_t) * (size_t)kAecmHist * kAecmBP + sizeof(uint32_t) * kAecmHist + 64;
+    int32_t *d_tmpl = nullptr;
+    hipError_t e;
+#define AECM_TRY(x)                                         \
+    if ((e = (x)) != hipSuccess) {                          \
+        const int rc = hip_fail(e, #x, __FILE__, __LINE__); \
+        wmx_aecm_destroy(h);                                \
+        if (d_tmpl) (void)hipFree(d_tmpl);                  \
+        delete K;                                           \
+        return rc;                                          \
+    }
+    AECM_TRY(hipMalloc(&h->d_state, (size_t)A_WORDS * n_streams * sizeof(int32_t)));
+    AECM_TRY(hipMalloc(&h->d_consts, sizeof(AecmConsts)));
+    AECM_TRY(hipMalloc(&h->d_far, far_bytes));
+    AECM_TRY(hipMalloc(&h->d_plans[0], 2 * kAecmMaxPktPerLaunch * sizeof(AecmPlan)));
+    h->d_plans[1] = h->d_plans[0] + kAecmMaxPktPerLaunch;
+    AECM_TRY(hipEventCreateWithFlags(&h->plan_free[0], hipEventDisableTiming));
+    AECM_TRY(hipEventCreateWithFlags(&h->plan_free[1], hipEventDisableTiming));
+    AECM_TRY(hipMalloc(&d_tmpl, A_WORDS * sizeof(int32_t)));
+    AECM_TRY(hipMemcpy(h->d_consts, K, sizeof(AecmConsts), hipMemcpyHostToDevice));
+    AECM_TRY(hipMemcpy(d_tmpl, st.data(), A_WORDS * sizeof(int32_t), hipMemcpyHostToDevice));
+    AECM_TRY(hipMemset(h->d_far, 0, far_bytes));
+    hipLaunchKernelGGL(aecm_fill_state, dim3(1024), dim3(256), 0, nullptr, h->d_state, d_tmpl, (int)A_WORDS, n_streams);
+    AECM_TRY(hipGetLastError());
+    AECM_TRY(hipDeviceSynchronize());
+#undef AECM_TRY
+    (void)hipFree(d_tmpl);
+    delete K;
+    {  // carve the far-end allocation (32-bit arrays first: alignment)
+        char *p = static_cast<char *>(h->d_far);
+        h->far.mean_far = reinterpret_cast<int32_t *>(p);
+        p += sizeof(int32_t) * 36;
+        h->far.hist_q = reinterpret_cast<int32_t *>(p);
+        p += sizeof(int32_t) * kAecmHist;
+        h->far.hist_bin = reinterpret_cast<uint32_t *>(p);
+        p += sizeof(uint32_t) * kAecmHist;
+        h->far.hist = reinterpret_cast<uint16_t *>(p);
+        p += sizeof(uint16_t) * (size_t)kAecmHist * kAecmBP;
+        h->far.ring = reinterpret_cast<int16_t *>(p);
+        p += sizeof(int16_t) * kAecmFarRing;
+        h->far.old = reinterpret_cast<int16_t *>(p);
+        p += sizeof(int16_t) * 2 * kAecmFrame;
+        h->far.frame = reinterpret_cast<int16_t *>(p);
+        p += sizeof(int16_t) * kAecmFrameRing;
+        h->far.x_prev = reinterpret_cast<int16_t *>(p);
+    }
+    *out = h;
+    return 0;
+}
+
+int wmx_aecm_packet_samples(const wmx_aecm *h) { return h ? h->pkg * h->chn : WMX_EINVAL; }
+int wmx_aecm_state_bytes(const wmx_aecm *h) { return h ? (int)wmx::A_WORDS * 4 : WMX_EINVAL; }
+
+// Same contract as wmx_aec_run: mode bit 1 = aec_setFrameFar, bit 2 = aec_process, 3 = aec_process2.
+int wmx_aecm_run(wmx_aecm *h, int mode, const int16_t *d_far, long far_packet_stride, const int16_t *d_near, int16_t *d_out, int n_packets,
+                 long stream_stride, long packet_stride, int delay_ms, void *stream) {
+    WMX_ON_DEVICE(h);
+    using namespace wmx;
+    if (!h || n_packets < 0 || (mode & 3) == 0) {
+        set_error("wmx_aecm_run: bad argument");
+        return WMX_EINVAL;
+    }
+    if (n_packets == 0) return 0;
+    if (((mode & 1) && !d_far) || ((mode & 2) && (!d_near || !d_out))) {
+        set_error("wmx_aecm_run: null buffer");
+        return WMX_EINVAL;
+    }
+    const long per_pkt = (long)h->pkg * h->chn;
+    if ((mode & 2) && (packet_stride < per_pkt || (h->n_streams > 1 && stream_stride < per_pkt))) {
+        set_error("wmx_aecm_run: strides (%ld, %ld) smaller than a packet (%ld samples)", stream_stride, packet_stride, per_pkt);
+        return WMX_EINVAL;
+    }
+    if ((mode & 1) && far_packet_stride < per_pkt && n_packets > 1) {
+        set_error("wmx_aecm_run: far stride %ld smaller than a packet (%ld samples)", far_packet_stride, per_pkt);
+        return WMX_EINVAL;
+    }
+    hipStream_t s = as_stream(stream);
+    int rc_ref = 0;
+    for (int done = 0; done < n_packets && rc_ref == 0;) {
+        int chunk = n_packets - done;
+        if (chunk > kAecmMaxPktPerLaunch) chunk = kAecmMaxPktPerLaunch;
+        int built = 0;
+        for (; built < chunk; built++) {
+            AecmPlan &pl = h->h_plans[built];
+            memset(&pl, 0, sizeof(pl));
+            if (mode & 1) {
+                const int r = h->ctl.buffer_farend(h->pkg, &pl);
+                if (r != 0) {
+                    rc_ref = r;
+                    break;
+                }
+            }
+            if (mode & 2) {
+                const int r = h->ctl.process(h->pkg, delay_ms, &pl);
+                if (r != 0) {
+                    // WebRtcAecm_Process has PROCESSED the packet with the delay clamped (state advances) and returns -1; the
+                    // wmix wrapper then returns without copying its output (src/webrtc.c:382-387).  Same here: the kernel
+                    // runs the packet but leaves the caller's buffer alone; later packets are not touched.
+                    pl.discard_out = 1;
+                    rc_ref = r;
+                    built++;
+                    break;
+                }
+            }
+        }
+        if (built > 0) {
+            const int sel = h->plan_sel;
+            AecmPlan *dp = h->d_plans[sel];
+            h->plan_sel ^= 1;
+            // The device buffer alternates and is rewritten only after the kernels that read it last have finished (they
+            // may run on any user stream); the copy itself is blocking, so the pageable host vector can be reused at once.
+            if (h->plan_used[sel]) WMX_HIP(hipEventSynchronize(h->plan_free[sel]));
+            WMX_HIP(hipMemcpy(dp, h->h_plans.data(), built * sizeof(AecmPlan), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(aecm_far_kernel, dim3(1), dim3(64), 0, s, h->far, h->d_consts, dp, built,
+                               d_far ? d_far + (size_t)done * far_packet_stride : nullptr, far_packet_stride, h->chn);
+            WMX_LAUNCH_CHECK();
+            if (mode & 2) {
+                const unsigned grid = (unsigned)((h->n_streams + kAecmWavesPerBlock - 1) / kAecmWavesPerBlock);
+                hipLaunchKernelGGL(aecm_near_kernel, dim3(grid), dim3(64 * kAecmWavesPerBlock), 0, s, h->d_state, h->far, h->d_consts, dp, built,
+                                   d_near + (size_t)done * packet_stride, d_out + (size_t)done * packet_stride, h->n_streams, stream_stride,
+                                   packet_stride, h->chn, h->pkg, h->freq / 8000);
+                WMX_LAUNCH_CHECK();
+            }
+            WMX_HIP(hipEventRecord(h->plan_free[sel], s));
+            h->plan_used[sel] = true;
+        }
+        done += chunk;
+    }
+    return rc_ref;
+}
+
+}  // extern "C"

@@ -56,7 +56,8 @@ struct AgcHandleCompat {
 };
 
 struct AecHandleCompat {
-    wmx_aec *batch;
+    wmx_aec *batch;    // float AEC (the reference's default build) ...
+    wmx_aecm *batchm;  // ... or the fixed-point AECM (its `#undef MAKE_WEBRTC_AEC` build): exactly one is set
     int chn, freq, pkg;
     bool *debug;
     DevBuf far, near;
@@ -73,8 +74,10 @@ int aec_run_host(AecHandleCompat *h, int mode, int16_t *far, int16_t *nearp, int
     if (mode & 2) ok = ok && h->near.ensure(n) && hipMemcpy(h->near.p, nearp, bytes, hipMemcpyHostToDevice) == hipSuccess;
     int rc = -1;
     if (ok) {
-        rc = wmx_aec_run(h->batch, mode, (mode & 1) ? h->far.p : nullptr, per_pkt, (mode & 2) ? h->near.p : nullptr,
-                         (mode & 2) ? h->near.p : nullptr, n_packets, 0, per_pkt, delayms, nullptr);
+        rc = h->batchm ? wmx_aecm_run(h->batchm, mode, (mode & 1) ? h->far.p : nullptr, per_pkt, (mode & 2) ? h->near.p : nullptr,
+                                      (mode & 2) ? h->near.p : nullptr, n_packets, 0, per_pkt, delayms, nullptr)
+                       : wmx_aec_run(h->batch, mode, (mode & 1) ? h->far.p : nullptr, per_pkt, (mode & 2) ? h->near.p : nullptr,
+                                     (mode & 2) ? h->near.p : nullptr, n_packets, 0, per_pkt, delayms, nullptr);
         if (rc == 0 || rc == -1) {
             // rc == -1: the reference returned mid-buffer; packets before the offending one were written
             if ((mode & 2) && hipMemcpy(out, h->near.p, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = -1;
@@ -94,16 +97,22 @@ extern "C" {
 // src/webrtc.c:217-274
 void *aec_init(int chn, int freq, int intervalMs, bool *debug) {
     if (freq > 16000 || freq % 8000 != 0) return NULL;
+    // The reference chooses between WebRtcAec_* and WebRtcAecm_* by a source edit (`#undef MAKE_WEBRTC_AEC`,
+    // src/webrtc.c:168-191).  One library serves both builds: WMIX_AMD_AECM=1 in the daemon's environment is that switch.
+    const char *sw = getenv("WMIX_AMD_AECM");
+    const bool mobile = sw && sw[0] == '1';
     wmx_aec *b = nullptr;
-    if (wmx_aec_create(&b, 1, chn, freq, intervalMs) != 0) {
+    wmx_aecm *bm = nullptr;
+    if ((mobile ? wmx_aecm_create(&bm, 1, chn, freq, intervalMs) : wmx_aec_create(&b, 1, chn, freq, intervalMs)) != 0) {
         if (debug && *debug) printf("WebRtcAecX_Create failed !! (%s)\r\n", wmx_last_error());
         return NULL;
     }
     AecHandleCompat *h = new AecHandleCompat();
     h->batch = b;
+    h->batchm = bm;
     h->chn = chn;
     h->freq = freq;
-    h->pkg = wmx_aec_packet_samples(b) / chn;
+    h->pkg = (mobile ? wmx_aecm_packet_samples(bm) : wmx_aec_packet_samples(b)) / chn;
     h->debug = debug;
     if (debug && *debug)
         printf("aec_init: chn/%d freq/%d intervalMs/%d pkgFrame/%d x %d\r\n", chn, freq, h->pkg / (freq / 1000), h->pkg, chn);
@@ -130,7 +139,8 @@ int aec_process2(void *fp, int16_t *frameFar, int16_t *frameNear, int16_t *frame
 void aec_release(void *fp) {
     AecHandleCompat *h = static_cast<AecHandleCompat *>(fp);
     if (!h) return;
-    wmx_aec_destroy(h->batch);
+    if (h->batch) wmx_aec_destroy(h->batch);
+    if (h->batchm) wmx_aecm_destroy(h->batchm);
     if (h->debug && *h->debug) printf("aec_release\r\n");
     delete h;
 }
