@@ -305,6 +305,102 @@ class NsxWorkload:
                              else "oracle/orc_nsx.c (-O2)")}
 
 
+class AecmWorkload:
+    """the fixed-point echo canceller (the reference's AECM build of aec_process2), 16 kHz mono, 65 536 near-end
+    streams per GPU against one shared far-end, one 10 ms packet (two 80-sample frames, 2-3 blocks) per stream per step.
+    Algorithmic bytes per stream-frame = 320 in + 320 out + 2 x 3 900 live per-stream state (AecmCore without the far-end
+    history, which is shared: frame rings, dBufNoisy, outBuf, the three channel arrays, echoFilt / nearFilt / noiseEst and
+    its counters, the three 64-entry log-energy histories, near mean spectrum + mean_bit_counts of the delay estimator;
+    aecm_core.h:31-133, delay_estimator.h:24-73) = 8 440 B."""
+    name = "aecm_16k_mono"
+    dtype = "int16/int32 (fixed point)"
+    bytes_per_frame = 8440.0
+    dominant_kernel = "aecm_near_kernel"
+    dominant_bytes_per_frame = 8440.0
+    pmc_tag = "aecm"
+    freq, pkt = 16000, 160
+
+    def __init__(self, dev, n_streams, rank, dist=None, packets=1):
+        from wmix_amd import synth
+        from wmix_amd.aecm import AecmBatch
+        from wmix_amd.shard import broadcast_far
+        self._bcast = broadcast_far
+        self.n_frames = n_streams
+        self.dist, self.rank = dist, rank
+        self.K = 200
+        far = synth.far_end(3000, self.K, self.pkt)
+        base = synth.near_end(3001 + 7919 * rank, 256, self.K, self.pkt, far=far).reshape(256, self.K, self.pkt)
+        self.base, self.far_host = base, far.reshape(self.K, self.pkt)
+        b = torch.from_numpy(np.ascontiguousarray(base.transpose(1, 0, 2))).to(dev)
+        self.inp = b[:, torch.arange(n_streams, device=dev) % 256]
+        self.far_src = torch.from_numpy(self.far_host.copy()).to(dev)
+        self.far = torch.zeros(1, self.pkt, dtype=torch.int16, device=dev)
+        self.work = torch.empty_like(self.inp[0:1])
+        self.aecm = AecmBatch(n_streams, 1, self.freq, 10)
+        self.t = _StageTimer("aecm")
+        self.k = 0
+        self.sample = [int(i) for i in np.linspace(0, n_streams - 1, 16)]
+        self.rec = []
+
+    def step(self, timed):
+        k = self.k % self.K
+        far = self.far_src[k:k + 1]
+        if self.dist is not None:
+            if self.rank == 0:
+                self.far.copy_(far)
+            self._bcast(self.far, self.dist, src=0)
+            far = self.far
+        self.work.copy_(self.inp[k:k + 1])
+        self.t.run("aecm", timed, lambda: self.aecm.process2_packet_major(far, self.work))
+        if timed is not True:
+            self.rec.append((self.k, self.work[0, self.sample].clone()))
+        self.k += 1
+
+    def dominant_ms(self):
+        return self.t.dominant_ms()
+
+    def stage_ms(self):
+        return {"aecm (far + near kernels)": self.t.mean_ms("aecm")}
+
+    def config(self):
+        return {"workload": self.name, "streams_per_gpu": self.n_frames, "frame": "160 x int16 (10 ms @ 16 kHz mono)",
+                "far_end": "shared" + (", RCCL broadcast from rank 0 each step" if self.dist is not None else ", resident in HBM"),
+                "input": "SURVEY 8d recipe (far noise A=8000, near = far delayed 40 / 2 + noise + gated tone), 256 distinct streams x "
+                         "%d packets, tiled; the timed launch includes a copy of the input packet (in-place kernel)" % self.K}
+
+    def parity_check(self):
+        from oracle import loader
+        port = loader.port()
+        far = np.concatenate([self.far_host[k % self.K] for k in range(self.k)])
+        worst, n = 0, 0
+        for col, s in enumerate(self.sample):
+            near = np.concatenate([self.base[s % 256, k % self.K] for k in range(self.k)])
+            want = loader.run_aecm(port, 1, self.freq, 10, far, near, self.pkt, prefix="orc").reshape(self.k, self.pkt)
+            for k, got in self.rec:
+                d = np.abs(got[col].cpu().numpy().astype(np.int32) - want[k].astype(np.int32)).max()
+                worst, n = max(worst, int(d)), n + 1
+        return {"streams": len(self.sample), "packets_compared": n, "max_lsb": worst, "oracle": "oracle/orc_aecm.c (port)",
+                "steps_replayed": self.k}
+
+    def cpu_baseline(self, budget_s):
+        from oracle import loader
+        n = 2000
+        far = np.tile(self.far_host.reshape(-1), n // self.K + 1)[: n * self.pkt]
+        near = np.tile(np.ascontiguousarray(self.base[0].reshape(-1)), n // self.K + 1)[: n * self.pkt]
+        lib, kind, prefix = loader.port(), "port", "orc"
+        if loader.have_ref():
+            try:
+                lib, kind, prefix = loader.ref(), "reference", "ref"
+                getattr(lib, "ref_run_aecm")
+            except Exception:
+                lib, kind, prefix = loader.port(), "port", "orc"
+        reps, v1, nc, vn = _cpu_rates(lambda: loader.run_aecm(lib, 1, self.freq, 10, far, near, self.pkt, prefix=prefix), n, budget_s)
+        return {"value": v1, "unit": "frames/s", "cores": 1, "kind": kind, "all_cores_value": vn, "all_cores": nc, "cpu_model": _cpu_model(),
+                "sample": "%d x %d packets of one 16 kHz stream through %s, 1 thread; then one stream per thread on all %d cores"
+                          % (reps, n, "aec_process2 built with the AECM switch (oracle/_ref/libwmixref.so, -O2)" if kind == "reference"
+                             else "oracle/orc_aecm.c (-O2)", nc)}
+
+
 class MfftWorkload:
     """math/fft.c's intended use (fft_stream's 1024-sample pool): one 1024-point real FFT (FFTR) with amplitude curve
     per stream per step.  Algorithmic bytes per transform = 4 096 in + 4 096 amplitude out = 8 192 B."""
@@ -599,7 +695,7 @@ class NsAec8kWorkload(ChainWorkload):
     with_agc_vad = False
 
 
-WORKLOADS = {"g711": (G711Workload, 1 << 20), "ns": (NsWorkload, 4096), "nsx": (NsxWorkload, 65536), "chain": (ChainWorkload, 65536),
+WORKLOADS = {"g711": (G711Workload, 1 << 20), "ns": (NsWorkload, 4096), "nsx": (NsxWorkload, 65536), "aecm": (AecmWorkload, 65536), "chain": (ChainWorkload, 65536),
              "mfft": (MfftWorkload, 65536), "ns_aec_8k": (NsAec8kWorkload, 131072),
              "ns_agc_mix_32k": (NsAgcMix32kWorkload, 32768)}
 DEFAULT_WORKLOAD = "chain"
@@ -732,7 +828,7 @@ def main():
         from wmix_amd import _lib
         _lib.lib()  # no fallback: raises when the HIP library is missing
 
-    if issubclass(cls, (ChainWorkload, StubCpuWorkload)):
+    if issubclass(cls, (ChainWorkload, StubCpuWorkload, AecmWorkload)):
         wl = cls(dev, args.streams or default_streams, rank, dist, args.packets_per_step)
     else:
         wl = cls(dev, args.streams or default_streams, rank)
