@@ -153,6 +153,15 @@ int wmx_aec_destroy(wmx_aec *h);
 int wmx_aec_packet_samples(const wmx_aec *h);
 int wmx_aec_run(wmx_aec *h, int mode, const int16_t *d_far, long far_packet_stride, const int16_t *d_near,
                 int16_t *d_out, int n_packets, long stream_stride, long packet_stride, int delay_ms, void *stream);
+/* Far-end groups: the reference handle owns its far-end (aec_process2(fp, far, near, ...), src/webrtc.c:410), so a batch
+ * need not share one.  n_far far-ends per batch; host array stream_far[n_streams] gives each stream's far-end in
+ * [0, n_far).  All far-ends are driven in lockstep (same packet count and reported delay per call).  wmx_aec_run_groups
+ * takes far-end g's packet p at d_far + g*far_group_stride + p*far_packet_stride.  wmx_aec_create / wmx_aec_run are the
+ * n_far = 1 forms.  Cost: one far-end wave per group in front of the near kernel; configs with one far-end run unchanged. */
+int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int interval_ms, int n_far, const int32_t *stream_far);
+int wmx_aec_run_groups(wmx_aec *h, int mode, const int16_t *d_far, long far_packet_stride, long far_group_stride,
+                       const int16_t *d_near, int16_t *d_out, int n_packets, long stream_stride, long packet_stride,
+                       int delay_ms, void *stream);
 int wmx_aec_state_words(const wmx_aec *h);
 int wmx_aec_export_state(const wmx_aec *h, int stream_index, float *host_words);
 

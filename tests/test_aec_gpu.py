@@ -12,6 +12,7 @@ import pytest
 
 from conftest import GOLDEN
 from oracle import loader as L
+from wmix_amd import synth
 
 sys.path.insert(0, GOLDEN)
 from make_aec_golden import AEC_CASES, CHAIN_CASES, aec_input, aec_pkg  # noqa: E402
@@ -198,3 +199,33 @@ def test_full_size_batch_properties(cuda):
     assert np.array_equal(out[:8].reshape(8, -1), small)
     for k in range(8):
         assert (out[idx == k] == out[k]).all()
+
+
+def test_far_end_groups_vs_per_handle_oracle(cuda, oracle_port):
+    """The reference handle owns its far-end (aec_process2(fp, far, near, ...), src/webrtc.c:410-483): one batch with 4
+    far-ends x 24 streams (interleaved, so neighbouring waves of a workgroup use different far-ends) must give every stream
+    what a per-handle oracle run with its own far-end gives.  VERDICT r01 item 8."""
+    import torch
+    from wmix_amd.aec import AecBatch
+    n_far, per, n, pkt = 4, 24, 420, 160
+    S = n_far * per
+    fars = np.stack([synth.far_end(7000 + 13 * g, n, pkt, amp=2000 * (g + 1)) for g in range(n_far)])
+    stream_far = np.arange(S) % n_far
+    near = np.stack([synth.near_end(7100 + s, 1, n, pkt, far=fars[stream_far[s]], delay=20 + 7 * (s % 9))[0] for s in range(S)])
+    ab = AecBatch(S, 1, 16000, 10, stream_far=stream_far)
+    d = torch.from_numpy(near.reshape(S, n, pkt).copy()).to(cuda)
+    dfar = torch.from_numpy(fars.reshape(n_far, n, pkt).copy()).to(cuda)
+    for f in range(0, n, 37):
+        rc, _ = ab.process2(dfar[:, f:f + 37], d[:, f:f + 37])
+        assert rc == 0
+    got = d.cpu().numpy().reshape(S, -1)
+    ab.close()
+    for s in list(range(0, S, 5)) + [S - 1]:
+        want = L.run_aec(oracle_port, 1, 16000, 10, fars[stream_far[s]], near[s], pkt, prefix="orc")
+        check_float_path(got[s], want)
+    # and a map is refused when it points outside the groups
+    from wmix_amd._lib import lib
+    import ctypes as C
+    hnd = C.c_void_p()
+    bad = np.array([0, 1, 4], np.int32)
+    assert lib().wmx_aec_create_groups(C.byref(hnd), 3, 1, 16000, 10, 4, bad.ctypes.data) == -10001

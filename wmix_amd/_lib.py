@@ -124,6 +124,10 @@ def _declare(L):
     L.wmx_aec_export_state.argtypes = [vp, i, vp]
     L.wmx_aec_run.restype = i
     L.wmx_aec_run.argtypes = [vp, i, vp, C.c_long, vp, vp, i, C.c_long, C.c_long, i, vp]
+    L.wmx_aec_create_groups.restype = i
+    L.wmx_aec_create_groups.argtypes = [C.POINTER(vp), i, i, i, i, i, vp]
+    L.wmx_aec_run_groups.restype = i
+    L.wmx_aec_run_groups.argtypes = [vp, i, vp, C.c_long, C.c_long, vp, vp, i, C.c_long, C.c_long, i, vp]
     u32 = C.c_uint32
     L.wmx_pcm_zoom.restype = i
     L.wmx_pcm_zoom.argtypes = [i, i, vp, u32, i, i, vp, u32, C.c_long, C.c_long, i, C.POINTER(u32), vp]

@@ -86,7 +86,13 @@ struct AecFarBufs {
     float *hist_w;   // [kAecHist][130] consumed windowed spectra
     float *xpow_seq; // [kAecHist][BP]  xPow after each consumed block
     float *xpow;     // [BP] running xPow
+    size_t group_words;  // floats between the buffers of consecutive far-end groups (all seven live in one slab per group)
 };
+// the buffers of far-end group g (wave-uniform g: pointer arithmetic on scalars)
+__device__ __forceinline__ AecFarBufs far_group(const AecFarBufs &F, int g) {
+    const size_t o = (size_t)g * F.group_words;
+    return AecFarBufs{F.pre + o, F.ring + o, F.ring_w + o, F.hist + o, F.hist_w + o, F.xpow_seq + o, F.xpow + o, F.group_words};
+}
 
 struct AecConsts {  // copied to LDS by both kernels
     FftTables tab;
@@ -111,11 +117,15 @@ __device__ __forceinline__ void unpack_bin(const float *a, int b, float &re, flo
 }
 
 // ================================================================== far-end kernel
-__global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F, const float *__restrict__ consts_g, const AecPlan *__restrict__ plans,
-                                                     int n_packets, const int16_t *far_pcm, long far_packet_stride, int chn, float gpow1np) {
+// grid = number of far-end groups: workgroup g (one wave) serves far-end g, whose packets start at far_pcm + g * far_group_stride
+__global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const float *__restrict__ consts_g, const AecPlan *__restrict__ plans,
+                                                     int n_packets, const int16_t *far_pcm, long far_packet_stride, long far_group_stride,
+                                                     int chn, float gpow1np) {
     __shared__ AecConsts K;
     __shared__ float fa[2][132];
     const int lane = threadIdx.x;
+    const AecFarBufs F = far_group(F_all, (int)blockIdx.x);
+    if (far_pcm) far_pcm += (size_t)blockIdx.x * far_group_stride;
     {
         // one wave, one latency chain: every request of a group goes out before the first result is used
         float *dst = reinterpret_cast<float *>(&K);
@@ -891,11 +901,12 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
 }
 
 template <int MULT>
-__global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * kAecWavesPerBlock) void aec_near_kernel(float *__restrict__ state, AecFarBufs F,
+__global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * kAecWavesPerBlock) void aec_near_kernel(float *__restrict__ state, AecFarBufs F_all,
                                                                           const float *__restrict__ consts_g,
                                                                           const AecPlan *__restrict__ plans, int n_packets,
                                                                           const int16_t *near_pcm, int16_t *out_pcm, int n_streams,
-                                                                          long stream_stride, long packet_stride, int chn, int pkg) {
+                                                                          long stream_stride, long packet_stride, int chn, int pkg,
+                                                                          const int *__restrict__ stream_far) {
     __shared__ AecConsts K;
     __shared__ AecWaveLds Wv[kAecWavesPerBlock];
     const int lane = threadIdx.x & 63;
@@ -906,6 +917,9 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * kAe
     // LDS part of the state, the constants -- and waited for ONCE, at the workgroup barrier; issued phase by phase, each
     // group costs its own HBM round trip.  (A wave without a stream reads stream 0 and leaves after the barrier.)
     const int sl = live ? sidx : 0;
+    // the far-end this stream is cancelled against (one per batch unless the handle was created with far-end groups):
+    // wave-uniform, so the group's buffers are scalar bases like the single far-end's
+    const AecFarBufs F = far_group(F_all, stream_far ? __builtin_amdgcn_readfirstlane(stream_far[sl]) : 0);
     float *gst = state + (size_t)sl * AS_WORDS;
     // the constants first (L2 hits): their copy into LDS then waits for them alone, not for the HBM loads behind them
     constexpr int kConstIt = (kAecConstWords + 64 * kAecWavesPerBlock - 1) / (64 * kAecWavesPerBlock);
@@ -1071,8 +1085,14 @@ struct wmx_aec {
     float *d_consts;
     float *d_far;  // one allocation carved into AecFarBufs
     wmx::AecFarBufs far;
-    wmx::AecPlan *d_plans;
-    std::vector<wmx::AecPlan> h_plans;
+    static constexpr int kPlanBufs = 4;
+    wmx::AecPlan *d_plans;   // kPlanBufs x kAecMaxPktPerLaunch plans, used round robin
+    wmx::AecPlan *h_plans;   // pinned mirror: the asynchronous copy reads it in place, so each slot has its own
+    hipEvent_t plan_free[kPlanBufs];  // recorded behind the kernels that read slot i; waited for before slot i is rewritten
+    bool plan_used[kPlanBufs];
+    int plan_sel;
+    int n_far;               // far-end groups (1 = one shared far-end)
+    int *d_stream_far;       // [n_streams] group of each stream, or nullptr when n_far == 1
     int16_t *d_zero_far;  // a silent far-end packet for near-only calls that need no far data
 };
 
@@ -1085,14 +1105,32 @@ int wmx_aec_destroy(wmx_aec *h) {
     if (h->d_consts) (void)hipFree(h->d_consts);
     if (h->d_far) (void)hipFree(h->d_far);
     if (h->d_plans) (void)hipFree(h->d_plans);
+    if (h->h_plans) (void)hipHostFree(h->h_plans);
+    if (h->d_stream_far) (void)hipFree(h->d_stream_far);
+    for (int i = 0; i < wmx_aec::kPlanBufs; i++)
+        if (h->plan_free[i]) (void)hipEventDestroy(h->plan_free[i]);
     delete h;
     return 0;
 }
 
 int wmx_aec_create(wmx_aec **out, int n_streams, int chn, int freq, int interval_ms) {
+    return wmx_aec_create_groups(out, n_streams, chn, freq, interval_ms, 1, nullptr);
+}
+
+int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int interval_ms, int n_far, const int32_t *stream_far) {
     using namespace wmx;
     if (!out) return WMX_EINVAL;
     *out = nullptr;
+    if (n_far < 1 || (n_far > 1 && !stream_far)) {
+        set_error("wmx_aec_create_groups: n_far=%d needs a stream -> far-end map", n_far);
+        return WMX_EINVAL;
+    }
+    if (n_far > 1)
+        for (int i = 0; i < n_streams; i++)
+            if (stream_far[i] < 0 || stream_far[i] >= n_far) {
+                set_error("wmx_aec_create_groups: stream %d maps to far-end %d of %d", i, stream_far[i], n_far);
+                return WMX_EINVAL;
+            }
     // aec_init: freq <= 16000 and a multiple of 8000 (src/webrtc.c:220-221)
     if ((freq != 8000 && freq != 16000) || chn < 1 || n_streams < 1) {
         set_error("wmx_aec_create: unsupported n_streams=%d chn=%d freq=%d", n_streams, chn, freq);
@@ -1110,6 +1148,11 @@ int wmx_aec_create(wmx_aec **out, int n_streams, int chn, int freq, int interval
     h->ctl.init(freq);
     h->d_state = h->d_consts = h->d_far = nullptr;
     h->d_plans = nullptr;
+    h->h_plans = nullptr;
+    h->d_stream_far = nullptr;
+    h->n_far = n_far;
+    h->plan_sel = 0;
+    for (int i = 0; i < wmx_aec::kPlanBufs; i++) h->plan_free[i] = nullptr, h->plan_used[i] = false;
     h->d_zero_far = nullptr;
     // constants: Ooura tables (frozen rdft_w) + the three curves of aec_core.c:49-103
     AecConsts K;
@@ -1145,8 +1188,14 @@ int wmx_aec_create(wmx_aec **out, int n_streams, int chn, int freq, int interval
     }
     AEC_TRY(hipMalloc(&h->d_state, (size_t)AS_WORDS * n_streams * sizeof(float)));
     AEC_TRY(hipMalloc(&h->d_consts, sizeof(K) + sizeof(PowTables)));  // [AecConsts | PowTables]; only the first part is copied to LDS
-    AEC_TRY(hipMalloc(&h->d_far, far_words * sizeof(float)));
-    AEC_TRY(hipMalloc(&h->d_plans, kAecMaxPktPerLaunch * sizeof(AecPlan)));
+    AEC_TRY(hipMalloc(&h->d_far, far_words * n_far * sizeof(float)));
+    AEC_TRY(hipMalloc(&h->d_plans, wmx_aec::kPlanBufs * kAecMaxPktPerLaunch * sizeof(AecPlan)));
+    AEC_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->h_plans), wmx_aec::kPlanBufs * kAecMaxPktPerLaunch * sizeof(AecPlan), hipHostMallocDefault));
+    for (int i = 0; i < wmx_aec::kPlanBufs; i++) AEC_TRY(hipEventCreateWithFlags(&h->plan_free[i], hipEventDisableTiming));
+    if (n_far > 1) {
+        AEC_TRY(hipMalloc(&h->d_stream_far, sizeof(int) * n_streams));
+        AEC_TRY(hipMemcpy(h->d_stream_far, stream_far, sizeof(int) * n_streams, hipMemcpyHostToDevice));
+    }
     AEC_TRY(hipMalloc(&d_tmpl, AS_WORDS * sizeof(float)));
     AEC_TRY(hipMemcpy(h->d_consts, &K, sizeof(K), hipMemcpyHostToDevice));
     {
@@ -1156,7 +1205,7 @@ int wmx_aec_create(wmx_aec **out, int n_streams, int chn, int freq, int interval
         AEC_TRY(hipMemcpy(reinterpret_cast<char *>(h->d_consts) + sizeof(K), &pt, sizeof(pt), hipMemcpyHostToDevice));
     }
     AEC_TRY(hipMemcpy(d_tmpl, st.data(), AS_WORDS * sizeof(float), hipMemcpyHostToDevice));
-    AEC_TRY(hipMemset(h->d_far, 0, far_words * sizeof(float)));
+    AEC_TRY(hipMemset(h->d_far, 0, far_words * n_far * sizeof(float)));
     hipLaunchKernelGGL(aec_fill_state, dim3(1024), dim3(256), 0, nullptr, h->d_state, d_tmpl, (int)AS_WORDS, n_streams);
     AEC_TRY(hipGetLastError());
     AEC_TRY(hipDeviceSynchronize());
@@ -1177,7 +1226,7 @@ int wmx_aec_create(wmx_aec **out, int n_streams, int chn, int freq, int interval
     h->far.xpow_seq = p;
     p += (size_t)kAecHist * BP;
     h->far.xpow = p;
-    h->h_plans.resize(kAecMaxPktPerLaunch);
+    h->far.group_words = far_words;
     *out = h;
     return 0;
 }
@@ -1198,6 +1247,11 @@ int wmx_aec_export_state(const wmx_aec *h, int stream_index, float *host_words) 
 // Returns 0, WMX_E*, or the reference's -1 when a packet is rejected (bad delay: packets before it are done).
 int wmx_aec_run(wmx_aec *h, int mode, const int16_t *d_far, long far_packet_stride, const int16_t *d_near, int16_t *d_out,
                 int n_packets, long stream_stride, long packet_stride, int delay_ms, void *stream) {
+    return wmx_aec_run_groups(h, mode, d_far, far_packet_stride, 0, d_near, d_out, n_packets, stream_stride, packet_stride, delay_ms, stream);
+}
+
+int wmx_aec_run_groups(wmx_aec *h, int mode, const int16_t *d_far, long far_packet_stride, long far_group_stride, const int16_t *d_near,
+                       int16_t *d_out, int n_packets, long stream_stride, long packet_stride, int delay_ms, void *stream) {
     WMX_ON_DEVICE(h);
     using namespace wmx;
     if (!h || n_packets < 0 || (mode & 3) == 0) {
@@ -1224,9 +1278,15 @@ int wmx_aec_run(wmx_aec *h, int mode, const int16_t *d_far, long far_packet_stri
     for (int done = 0; done < n_packets && rc_ref == 0;) {
         int chunk = n_packets - done;
         if (chunk > kAecMaxPktPerLaunch) chunk = kAecMaxPktPerLaunch;
+        // the next plan slot: its pinned host half and its device half are rewritten only after the kernels that read the
+        // device half last have finished, whatever stream they ran on (round-1 ADVICE: the single buffer was reused blindly)
+        const int sel = h->plan_sel;
+        h->plan_sel = (sel + 1) % wmx_aec::kPlanBufs;
+        if (h->plan_used[sel]) WMX_HIP(hipEventSynchronize(h->plan_free[sel]));
+        AecPlan *hp = h->h_plans + (size_t)sel * kAecMaxPktPerLaunch, *dp = h->d_plans + (size_t)sel * kAecMaxPktPerLaunch;
         int built = 0;
         for (; built < chunk; built++) {
-            AecPlan &pl = h->h_plans[built];
+            AecPlan &pl = hp[built];
             memset(&pl, 0, offsetof(AecPlan, blk));
             if (mode & 1) {
                 const int r = h->ctl.buffer_farend(h->pkg, &pl);
@@ -1246,10 +1306,9 @@ int wmx_aec_run(wmx_aec *h, int mode, const int16_t *d_far, long far_packet_stri
             }
         }
         if (built > 0) {
-            WMX_HIP(hipMemcpyAsync(h->d_plans, h->h_plans.data(), built * sizeof(AecPlan), hipMemcpyHostToDevice, s));
-            // the plan buffer is reused by the next chunk: the copy above is stream-ordered after the previous kernels
-            hipLaunchKernelGGL(aec_far_kernel, dim3(1), dim3(64), 0, s, h->far, h->d_consts, h->d_plans, built,
-                               d_far ? d_far + (size_t)done * far_packet_stride : nullptr, far_packet_stride, h->chn, gpow1np);
+            WMX_HIP(hipMemcpyAsync(dp, hp, built * sizeof(AecPlan), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(aec_far_kernel, dim3((unsigned)h->n_far), dim3(64), 0, s, h->far, h->d_consts, dp, built,
+                               d_far ? d_far + (size_t)done * far_packet_stride : nullptr, far_packet_stride, far_group_stride, h->chn, gpow1np);
             WMX_LAUNCH_CHECK();
             if (mode & 2) {
                 const int16_t *nin = d_near + (size_t)done * packet_stride;
@@ -1257,15 +1316,15 @@ int wmx_aec_run(wmx_aec *h, int mode, const int16_t *d_far, long far_packet_stri
                 const unsigned grid = (unsigned)((h->n_streams + kAecWavesPerBlock - 1) / kAecWavesPerBlock);
                 const dim3 blk(64 * kAecWavesPerBlock);
                 if (h->freq == 8000)
-                    hipLaunchKernelGGL((aec_near_kernel<1>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, h->d_plans, built, nin,
-                                       nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg);
+                    hipLaunchKernelGGL((aec_near_kernel<1>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, built, nin,
+                                       nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg, h->d_stream_far);
                 else
-                    hipLaunchKernelGGL((aec_near_kernel<2>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, h->d_plans, built, nin,
-                                       nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg);
+                    hipLaunchKernelGGL((aec_near_kernel<2>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, built, nin,
+                                       nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg, h->d_stream_far);
                 WMX_LAUNCH_CHECK();
             }
-            // h_plans is pageable host memory: hipMemcpyAsync from it returns after the copy is staged,
-            // so it may be rewritten for the next chunk.
+            WMX_HIP(hipEventRecord(h->plan_free[sel], s));
+            h->plan_used[sel] = true;
         }
         done += chunk;
     }
