@@ -401,6 +401,114 @@ class AecmWorkload:
                              else "oracle/orc_aecm.c (-O2)", nc)}
 
 
+class RtpChainWorkload:
+    """SURVEY 8f-1, the packet edge end to end: per stream and step one 172-byte RTP/PCMA datagram (20 ms at 8 kHz) ->
+    decode -> NS -> AEC -> AGC -> VAD (two 10 ms packets each) -> encode -> one 172-byte datagram (wmix_amd/pipeline.py,
+    src/wmixTask.c:1278-1316 / 1124-1143 around src/wmix.c:613-709).  `value` is the resident rate (datagrams in and out in
+    HBM); `pcie_inclusive` on the line is the same pipeline with the datagrams starting and ending in pinned host memory,
+    copies on their own HIP streams overlapped with compute (three slots in flight).
+    Algorithmic bytes per 10 ms stream-frame = (172 in + 172 out + 2 x (6 000 NS + 11 700 AEC + 668 AGC + 736 VAD) state) / 2
+    = 19 276 B; dominant kernel = the AEC near kernel over two packets: 320 + 320 + 2 x 11 700 = 24 040 B per stream."""
+    name = "rtp_chain_8k_pcma"
+    dtype = "u8 datagrams, f32 / int16 chain"
+    bytes_per_frame = 19276.0
+    dominant_kernel = "aec_near_kernel<1>"
+    dominant_bytes_per_frame = 12020.0  # per 10 ms frame: the launch covers two
+    pmc_tag = "rtp_chain"
+
+    def __init__(self, dev, n_streams, rank):
+        from wmix_amd import g711, synth
+        from wmix_amd.pipeline import RtpChain, StreamingPipe
+        self.S, self.n_frames = n_streams, 2 * n_streams
+        self.K = 50
+        far = synth.far_end(5000, 2 * self.K, 80)
+        base = synth.near_end(5001 + 7919 * rank, 256, 2 * self.K, 80, far=far).reshape(256, self.K, 160)
+        self.far_host = far
+        self.far = torch.from_numpy(far.reshape(self.K, 2, 80).copy()).to(dev)
+        pcm = torch.from_numpy(np.ascontiguousarray(base.transpose(1, 0, 2))).to(dev)  # [K, 256, 160]
+        codes = torch.empty(pcm.shape, dtype=torch.uint8, device=dev)
+        g711.encode("a", pcm.reshape(-1), codes.reshape(-1))
+        dg = torch.zeros((self.K, 256, 172), dtype=torch.uint8, device=dev)
+        dg[:, :, 0], dg[:, :, 1] = 0x80, 0x88
+        dg[:, :, 12:] = codes
+        self.base_dg = dg.cpu().numpy()  # [K, 256, 172] for the oracle replay
+        self.d_in = dg[:, torch.arange(n_streams, device=dev) % 256].contiguous()  # [K, S, 172]
+        self.d_out = torch.zeros((n_streams, 172), dtype=torch.uint8, device=dev)
+        self.chain = RtpChain(n_streams, dev)
+        self.pipe_cls = StreamingPipe
+        self.k = 0
+        self.t = _StageTimer("step")
+        self.sample = [int(i) for i in np.linspace(0, n_streams - 1, 8)]
+        self.rec = []
+
+    def step(self, timed):
+        k = self.k % self.K
+        self.t.run("step", timed, lambda: self.chain.step(self.d_in[k], self.far[k], self.d_out))
+        if timed is not True:
+            self.rec.append((self.k, self.d_out[self.sample].clone()))
+        self.k += 1
+
+    def dominant_ms(self):
+        return None  # the line's roofline entry is filled from the whole step below (several kernels share it)
+
+    def stage_ms(self):
+        return {"ingest + ns + aec + agc + vad + egress": self.t.mean_ms("step")}
+
+    def config(self):
+        return {"workload": self.name, "streams_per_gpu": self.S, "frame": "172-byte RTP/PCMA datagram = 160 x int16 (20 ms @ 8 kHz mono)",
+                "frames_per_step_per_gpu": self.n_frames, "pcie_inclusive": getattr(self, "pcie", None)}
+
+    def measure_pcie(self, steps):
+        """The same steps with host-resident datagrams: H2D of step k+1 and D2H of step k-1 overlap the compute of step k."""
+        pipe = self.pipe_cls(self.chain)
+        for s in range(pipe.SLOTS):
+            pipe.h_in[s].copy_(self.d_in[s % self.K])
+        for _ in range(4):
+            pipe.submit(self.far[self.k % self.K])
+            self.k += 1
+        pipe.drain()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pipe.submit(self.far[self.k % self.K])
+            self.k += 1
+        pipe.drain()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        self.pcie = {"value": self.n_frames * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3,
+                     "bytes_over_pcie_per_step": 2 * 172 * self.S, "GB_per_s_each_way": 172 * self.S * steps / dt / 1e9,
+                     "note": "pinned host buffers, 3 slots in flight, copy-in / copy-out streams beside the compute stream; the "
+                             "streaming steps fed the pinned slots' datagrams again, so they are excluded from parity_checked"}
+        return self.pcie
+
+    def parity_check(self):
+        from oracle import loader
+        port = loader.port()
+        n_res = max(k for k, _ in self.rec) + 1
+        far = np.concatenate([self.far_host[(k % self.K) * 160:(k % self.K) * 160 + 160] for k in range(n_res)])
+        worst, n = 0, 0
+        for col, s in enumerate(self.sample):
+            dgs = np.stack([self.base_dg[k % self.K, s % 256] for k in range(n_res)])
+            want = loader.run_rtp_chain(port, far, dgs)
+            for k, got in self.rec:
+                g = got[col].cpu().numpy()
+                assert np.array_equal(g[:12], want[k][:12]), "RTP header differs"
+                worst, n = max(worst, int(np.abs(g[12:].astype(np.int16) - want[k][12:].astype(np.int16)).max())), n + 1
+        return {"streams": len(self.sample), "datagrams_compared": n, "max_code_step": worst, "headers": "identical",
+                "oracle": "orc_rtp_ingest -> orc_*.c chain -> orc_rtp_egress (port)", "steps_replayed": n_res}
+
+    def cpu_baseline(self, budget_s):
+        from oracle import loader
+        port = loader.port()
+        n = 400
+        far = np.tile(self.far_host, n // self.K + 1)[: n * 160]
+        dgs = np.tile(self.base_dg[:, 0], (n // self.K + 1, 1))[:n]
+        reps, v1, nc, vn = _cpu_rates(lambda: loader.run_rtp_chain(port, far, dgs), 2 * n, budget_s)
+        return {"value": v1, "unit": "frames/s", "cores": 1, "kind": "port", "all_cores_value": vn, "all_cores": nc, "cpu_model": _cpu_model(),
+                "sample": "%d x %d datagrams of one stream through orc_rtp_ingest -> oracle chain -> orc_rtp_egress (python loop over "
+                          "datagrams around the C calls), 1 thread; then all %d cores" % (reps, n, nc)}
+
+
 class MfftWorkload:
     """math/fft.c's intended use (fft_stream's 1024-sample pool): one 1024-point real FFT (FFTR) with amplitude curve
     per stream per step.  Algorithmic bytes per transform = 4 096 in + 4 096 amplitude out = 8 192 B."""
@@ -695,7 +803,7 @@ class NsAec8kWorkload(ChainWorkload):
     with_agc_vad = False
 
 
-WORKLOADS = {"g711": (G711Workload, 1 << 20), "ns": (NsWorkload, 4096), "nsx": (NsxWorkload, 65536), "aecm": (AecmWorkload, 65536), "chain": (ChainWorkload, 65536),
+WORKLOADS = {"g711": (G711Workload, 1 << 20), "ns": (NsWorkload, 4096), "nsx": (NsxWorkload, 65536), "aecm": (AecmWorkload, 65536), "rtp_chain": (RtpChainWorkload, 65536), "chain": (ChainWorkload, 65536),
              "mfft": (MfftWorkload, 65536), "ns_aec_8k": (NsAec8kWorkload, 131072),
              "ns_agc_mix_32k": (NsAgcMix32kWorkload, 32768)}
 DEFAULT_WORKLOAD = "chain"
@@ -863,6 +971,11 @@ def main():
         wl.step("all")
     sync_all()
 
+    if hasattr(wl, "measure_pcie") and rank == 0:
+        parity_early = wl.parity_check()  # before the streaming steps advance the state past what was recorded
+        wl.measure_pcie(min(args.steps, 100))
+    else:
+        parity_early = None
     frames_total = wl.n_frames * args.steps * world
     value = frames_total / elapsed
     dom_ms = wl.dominant_ms()
@@ -875,6 +988,13 @@ def main():
                     "traffic_source": traffic_src,
                     "avg_launch_ms": round(dom_ms, 5),
                     "algorithmic_bytes_per_launch": wl.dominant_bytes_per_frame * wl.n_frames}
+    if roofline is None and getattr(wl, "name", "") == "rtp_chain_8k_pcma":
+        step_ms = elapsed / args.steps * 1e3
+        achieved = wl.bytes_per_frame * wl.n_frames / (step_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "whole step (ingest, ns, aec far + near, agc, vad, egress)", "achieved": round(achieved, 2),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "traffic_source": traffic_src, "avg_launch_ms": round(step_ms, 5),
+                    "algorithmic_bytes_per_launch": wl.bytes_per_frame * wl.n_frames}
     out = {
         "metric": "10 ms frames/s", "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -890,7 +1010,7 @@ def main():
         "launched_by": os.environ.get("WMIX_BENCH_LAUNCHED_BY", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"),
     }
     if hasattr(wl, "parity_check"):
-        out["parity_checked"] = wl.parity_check() if rank == 0 else None
+        out["parity_checked"] = (parity_early or wl.parity_check()) if rank == 0 else None
     if rank == 0:
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = wl.cpu_baseline(args.cpu_seconds)

@@ -179,6 +179,26 @@ def run_chain(lib, chn, freq, agc_value, stages, far, near, frames_per_call, pre
     return out
 
 
+def run_rtp_chain(lib, far, datagrams, agc_value=5):
+    """One stream through the packet edge + chain of SURVEY 8f-1 with the restatement: datagrams uint8 [n, 172] (RTP/PCMA,
+    20 ms at 8 kHz) -> orc_rtp_ingest -> NS -> AEC -> AGC -> VAD (160-sample calls, 10 ms packets) -> orc_rtp_egress with a
+    fresh sender.  far int16 [n * 160].  Returns uint8 [n, 172]."""
+    n = datagrams.shape[0]
+    ing = _fn(lib, "orc_rtp_ingest", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p])
+    pcm = np.zeros(n * 160, np.int16)
+    for k in range(n):
+        p = np.ascontiguousarray(datagrams[k])
+        assert ing(p.ctypes.data, pcm[k * 160:].ctypes.data, None) == 320
+    out = run_chain(lib, 1, 8000, agc_value, 15, far, pcm, 160, prefix="orc")
+    snd = (C.c_uint8 * 16)()
+    _fn(lib, "orc_rtp_sender_init", None, [C.c_void_p, C.c_int])(snd, 0)
+    eg = _fn(lib, "orc_rtp_egress", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p])
+    res = np.zeros((n, 172), np.uint8)
+    for k in range(n):
+        assert eg(snd, 1, 8000, out[k * 160:].ctypes.data, 320, 1, 8000, res[k].ctypes.data) == 172
+    return res
+
+
 # ---------------------------------------------------------------- math/fft.c
 MFFT_KINDS = ("FFT", "FFTR", "IFFT", "IFFTR")
 

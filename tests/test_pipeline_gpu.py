@@ -32,22 +32,7 @@ def make_datagrams(port, S, n, seed):
 
 
 def oracle_pipeline(port, far, pk_stream):
-    n = pk_stream.shape[0]
-    ing = port.orc_rtp_ingest
-    ing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-    pcm = np.zeros(n * 160, np.int16)
-    for k in range(n):
-        p = np.ascontiguousarray(pk_stream[k])
-        assert ing(p.ctypes.data, pcm[k * 160:].ctypes.data, None) == 320
-    out = L.run_chain(port, 1, 8000, 5, 15, far, pcm, 160, prefix="orc")
-    snd = (C.c_uint8 * 16)()
-    port.orc_rtp_sender_init(snd, 0)
-    eg = port.orc_rtp_egress
-    eg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
-    res = np.zeros((n, 172), np.uint8)
-    for k in range(n):
-        assert eg(snd, 1, 8000, out[k * 160:].ctypes.data, 320, 1, 8000, res[k].ctypes.data) == 172
-    return res
+    return L.run_rtp_chain(port, far, pk_stream)
 
 
 def test_rtp_chain_vs_oracle_resident_and_streaming(cuda, oracle_port):
