@@ -1,4 +1,5 @@
-"""Summarise the rocprofv3 outputs of profile_chain.sh into <out>/chain_kernel_stats.csv and chain_hbm_pmc.json.
+"""Summarise the rocprofv3 outputs of profile_chain.sh / profile_workload.sh into <out>/<tag>_kernel_stats.csv,
+<tag>_timed_region.csv, <tag>_hbm_pmc.json and <tag>_sq_pmc.json (tag = argv[4], default "chain").
 
 rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  Per /opt/skills/guides/MI355X_MICROARCH.md (HBM section) gfx950's
 FETCH_SIZE is exactly half of the bytes of wide coalesced reads (128-B requests tallied at 64 B) and has to be
@@ -12,6 +13,7 @@ import re
 import sys
 
 out = sys.argv[1]
+tag = sys.argv[4] if len(sys.argv) > 4 else "chain"
 
 
 def kname(full):
@@ -22,7 +24,7 @@ def kname(full):
 stats = glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True)
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
-    with open(out + "/chain_kernel_stats.csv", "w") as f:
+    with open(out + "/%s_kernel_stats.csv" % tag, "w") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "percent"])
         for r in rows:
@@ -37,7 +39,7 @@ if trace:
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(trace[0])):
         per[kname(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r))
-    with open(out + "/chain_timed_region.csv", "w") as f:
+    with open(out + "/%s_timed_region.csv" % tag, "w") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "launches_in_timed_region", "avg_ns", "min_ns", "max_ns", "vgpr", "lds_bytes", "scratch_bytes", "workgroup", "grid"])
         for k, v in per.items():
@@ -67,7 +69,7 @@ for cname, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     }
 # SQ pass: per-kernel means over the timed region's launches, and each bucket as a fraction of the wave cycles
 sq = collections.defaultdict(lambda: collections.defaultdict(list))
-for path in glob.glob(out + "/pmc_sq/**/*counter_collection.csv", recursive=True):
+for path in glob.glob(out + "/pmc_sq*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(path)):
         sq[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 sq_out = {}
@@ -77,10 +79,16 @@ for k, c in sq.items():
     m = {n: sum(v[-steps:]) / len(v[-steps:]) for n, v in c.items()}
     wc = m.get("SQ_WAVE_CYCLES", 0) or 1
     sq_out[k] = {"mean": {n: round(x) for n, x in m.items()},
-                 "fraction_of_wave_cycles": {n: round(x / wc, 3) for n, x in m.items() if n not in ("SQ_WAVE_CYCLES", "SQ_WAVES")}}
+                 "fraction_of_wave_cycles": {n: round(x / wc, 3) for n, x in m.items()
+                                             if n.startswith(("SQ_WAIT", "SQ_ACTIVE")) and n != "SQ_WAVE_CYCLES"}}
+    if m.get("SQ_LDS_IDX_ACTIVE"):
+        sq_out[k]["lds_bank_conflict_fraction_of_lds_active"] = round(m.get("SQ_LDS_BANK_CONFLICT", 0) / m["SQ_LDS_IDX_ACTIVE"], 3)
+    if m.get("SQ_BUSY_CYCLES") and m.get("SQ_WAVE_CYCLES"):
+        # mean resident waves per SIMD while the kernel ran: wave-cycles / (busy cycles x SIMDs seen by the counter)
+        sq_out[k]["wave_cycles_per_busy_cycle"] = round(m["SQ_WAVE_CYCLES"] / m["SQ_BUSY_CYCLES"], 2)
 if sq_out:
-    json.dump(sq_out, open(out + "/chain_sq_pmc.json", "w"), indent=1)
+    json.dump(sq_out, open(out + "/%s_sq_pmc.json" % tag, "w"), indent=1)
 
 pmc["n_frames_per_launch"] = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
-json.dump(pmc, open(out + "/chain_hbm_pmc.json", "w"), indent=1)
+json.dump(pmc, open(out + "/%s_hbm_pmc.json" % tag, "w"), indent=1)
 print(json.dumps({c: {k: v["bytes_per_dispatch_corrected"] for k, v in d.items() if "wmx" in k or "_kernel" in k} for c, d in pmc.items() if isinstance(d, dict)}))

@@ -298,7 +298,9 @@ __device__ __forceinline__ int ring_at(int pos, int i) {
 // row `r` of the work rows for a lane-dependent r < 64 (a 24-bit multiply; `W.fa[r]` costs two 64-bit multiply-adds)
 __device__ __forceinline__ float *fa_row(AecWaveLds &W, int r) { return &W.fa[0][0] + __umul24((unsigned)r, (unsigned)FAS); }
 __device__ __forceinline__ int opaque_lane(int x) {
+#ifndef WMX_AEC_HOIST  // experiment switch: let the compiler keep lane-derived addresses in VGPRs (needs a lower occupancy)
     asm volatile("" : "+v"(x));
+#endif
     return x;
 }
 
@@ -901,7 +903,10 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
 }
 
 template <int MULT>
-__global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * kAecWavesPerBlock) void aec_near_kernel(float *__restrict__ state, AecFarBufs F_all,
+#ifndef WMX_AEC_WAVES
+#define WMX_AEC_WAVES 4
+#endif
+__global__ __attribute__((amdgpu_waves_per_eu(WMX_AEC_WAVES, WMX_AEC_WAVES))) __launch_bounds__(64 * kAecWavesPerBlock) void aec_near_kernel(float *__restrict__ state, AecFarBufs F_all,
                                                                           const float *__restrict__ consts_g,
                                                                           const AecPlan *__restrict__ plans, int n_packets,
                                                                           const int16_t *near_pcm, int16_t *out_pcm, int n_streams,

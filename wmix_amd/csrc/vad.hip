@@ -176,6 +176,9 @@ __device__ int32_t gauss_prob(int16_t input, int16_t mean, int16_t std, int16_t 
 // vad_sp.c:59-177, operating directly on the field-major state rows
 __device__ int16_t find_minimum(const VadRef &S, int16_t v, int ch, int32_t frame_counter) {
     const int a0 = V16_AGE + (ch << 4), l0 = V16_LOW + (ch << 4);
+#ifdef WMX_VAD_NOFINDMIN  // timing experiment only (wrong results): what the order-statistics walk costs
+    return (int16_t)(v + S.h(V16_MEAN_VALUE + ch));
+#endif
     for (int i = 0; i < 16; i++) {
         const int16_t age = S.hm(a0 + i);
         if (age != 100) {
