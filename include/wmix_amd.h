@@ -252,6 +252,10 @@ int wmx_pkgfifo_destroy(wmx_pkgfifo *h);
 int wmx_pkgfifo_add(wmx_pkgfifo *h, const uint8_t *d_pkgs, long stride, void *stream);
 int wmx_pkgfifo_get(wmx_pkgfifo *h, uint8_t *d_out, long stride, int delayms, void *stream);
 
+/* Developer / test hook: the cross-lane FFT executors of the kernels, stand-alone, one transform per wavefront, in place
+ * (wmix_amd/csrc/fft_debug.hip lists the kinds: Ooura rdft 128 / 256 through the LDS executor, aec_rdft_128 through the LDS,
+ * 16-lane-register and one-point-per-lane executors, the SPL fixed-point real FFT of orders 7 and 8). */
+int wmx_debug_fft(int kind, int n_batch, void *d_data, int32_t *d_aux, void *stream);
 /* Developer / test hook: the NS kernels' table-driven log (kind 0, x >= 1) and exp (kind 1) evaluated on the host from
  * the same source (wmix_amd/csrc/libm_dev.h), for sweeping against libm without a GPU. */
 int wmx_debug_ns_libm(int kind, const float *x, float *y, size_t n);

@@ -147,6 +147,8 @@ def _declare(L):
     L.wmx_rtp_ingest.argtypes = [i, vp, C.c_long, vp, C.c_long, vp, vp, vp]
     L.wmx_rtp_export.restype = i
     L.wmx_rtp_export.argtypes = [vp, i, C.POINTER(C.c_uint16), C.POINTER(C.c_uint32)]
+    L.wmx_debug_fft.restype = i
+    L.wmx_debug_fft.argtypes = [i, i, vp, vp, vp]
     L.wmx_debug_pow.restype = i
     L.wmx_debug_pow.argtypes = [vp, vp, vp, C.c_size_t]
     L.wmx_debug_ns_libm.restype = i
