@@ -37,6 +37,7 @@ class G711Workload:
     80-sample (10 ms @ 8 kHz) frames.  Algorithmic bytes per frame = 160 + 80 (encode)
     + 80 + 160 (decode) = 480 B."""
     name = "g711_ulaw_roundtrip_8k"
+    pmc_tag = "g711"
     dtype = "u8"
     frame_samples = 80
     bytes_per_frame = 480.0
@@ -125,6 +126,7 @@ class NsWorkload:
     """BASELINE.json configs[1]: WebRtcNs_Process, 16 kHz mono, 4096 streams per GPU, one 10 ms packet per stream
     per step.  Algorithmic bytes per stream-frame = 320 in + 320 out + 2 x 12 200 live state = 25 040 B."""
     name = "ns_16k_mono"
+    pmc_tag = "ns"
     dtype = "f32"
     bytes_per_frame = 25040.0
     dominant_kernel = "ns_kernel<256, true, 1>"
@@ -513,6 +515,7 @@ class MfftWorkload:
     """math/fft.c's intended use (fft_stream's 1024-sample pool): one 1024-point real FFT (FFTR) with amplitude curve
     per stream per step.  Algorithmic bytes per transform = 4 096 in + 4 096 amplitude out = 8 192 B."""
     name = "mfft_fftr_1024_amplitude"
+    pmc_tag = "mfft"
     dtype = "f32 data, f64 twiddles"
     bytes_per_frame = 8192.0
     dominant_kernel = "mfft_kernel<1, false>"
@@ -725,6 +728,7 @@ class NsAgcMix32kWorkload:
     Algorithmic bytes per source-frame = 2 560 PCM + 2 x (12 200 + 2 048 + 668) state + 160 x (1 + 1/8) ring = 32 550 B
     (SURVEY 8d); the NS kernel: 1 280 + 1 280 + 2 x (12 200 + 2 048) = 31 056 B."""
     name = "ns_agc_32k_2ch_mix8_to_8k"
+    pmc_tag = "ns_agc_mix_32k"
     dtype = "f32 (NS), int16/int32 (AGC, mix)"
     bytes_per_frame = 32550.0
     dominant_kernel = "ns_kernel<256, true, 2>"
@@ -796,6 +800,7 @@ class NsAec8kWorkload(ChainWorkload):
     config over 8 GPUs).  Algorithmic bytes per stream-frame = 320 PCM + 2 x (6 000 + 11 700) = 35 720 B; the
     AEC near-end kernel: 160 + 160 + 2 x 11 700 = 23 720 B."""
     name = "ns_aec_8k_mono"
+    pmc_tag = "ns_aec_8k"
     bytes_per_frame = 35720.0
     dominant_kernel = "aec_near_kernel<1>"
     dominant_bytes_per_frame = 23720.0
