@@ -25,4 +25,6 @@ rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CY
   -d "$OUT/pmc_sq_lds" -o p --output-format csv -- $CMD > /dev/null 2>&1
 cd "$R"
 python3 profiles/tools/summarise.py "$OUT" "$NFR" $STEPS "$WL"
+# the raw traces are tens of MB per workload and gpurun brings back at most 64 MiB: keep the summaries only
+[ -n "${KEEP_RAW:-}" ] || rm -rf "$OUT"/stats "$OUT"/pmc_*
 ls "$OUT"/*.csv "$OUT"/*.json 2>/dev/null

@@ -81,9 +81,7 @@ struct alignas(16) NsxWave {
     int32_t cx[ANA];     // FFT work array, one packed complex (re | im << 16) per word
     int16_t td[ANA];     // windowed frame, later the time-domain output of the inverse transform (inst->real)
     int32_t spec[BP];    // the frame's spectrum (inst->real / inst->imag), packed like cx
-    uint32_t noise[BP], post[BP], prior[BP], pnear[BP];
-    uint16_t magn[BP], nsp[BP], ftmp[BP], pn16[BP];
-    int16_t lmagn[BP];
+    uint16_t magn[BP], nsp[BP];  // read across lanes (magn[0], nsp[b - 1]); the other per-bin intermediates are registers
 };
 
 __device__ __forceinline__ int16_t log2_q8(const NsxConsts &K, uint32_t v) {  // nsx_core.c:362-370
@@ -181,6 +179,9 @@ __device__ void two_peaks(const int16_t *hist, int lane, uint32_t &pos1, int &w1
     w1 = wa;
 }
 
+// pass r of a per-bin loop: bin b = lane + 64 r (unrolled: r is a compile-time constant in the body)
+#define FOR_BINS(r, b) _Pragma("unroll") for (int r = 0; r < NP; r++) if (const int b = lane + 64 * r; b < BINS)
+
 // ---------------------------------------------------------------- one 10 ms block of one stream (ProcessCore)
 // in0 / out0: low band (channel 0), in1 / out1: the "high band" (channel 1 of a 2-channel stream);
 // element stride CHN.  sc[]: the stream's scalars, wave-uniform registers.
@@ -198,6 +199,14 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
     uint32_t *initm = reinterpret_cast<uint32_t *>(&W.st[Y::INITM]), *pnoise = reinterpret_cast<uint32_t *>(&W.st[Y::PNOISE]);
     int16_t *hb = reinterpret_cast<int16_t *>(&W.st[Y::HB]);
     constexpr int BP = Y::BP;
+    // the frame's per-bin intermediates stay in registers: pass r of a per-bin loop handles bin lane + 64 r (the last
+    // pass is lane 0's Nyquist bin), every loop is unrolled over the passes, so the indices are compile-time constants
+    constexpr int NP = (BINS + 63) / 64;
+    uint32_t t_noise[NP], t_post[NP], t_prior[NP], t_pnear[NP];
+    uint16_t t_ftmp[NP], t_pn16[NP];
+    int16_t t_lmagn[NP];
+#pragma unroll
+    for (int r = 0; r < NP; r++) t_noise[r] = t_post[r] = t_prior[r] = t_pnear[r] = 0, t_ftmp[r] = t_pn16[r] = 0, t_lmagn[r] = 0;
 
     // ---- DataAnalysis, nsx_core.c:1184-1419: shift in the packet, window (AnalysisUpdateC :524-541)
     {
@@ -251,7 +260,7 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
         const bool startup = sc[X_BLOCK_INDEX] < 50;  // the previous block's index: it is advanced below
         uint32_t e_sum = 0, m_sum = 0;
         int32_t sum_log = 0, sum_ilog = 0;
-        for (int b = lane; b < BINS; b += 64) {
+        FOR_BINS(r, b) {
             const int32_t x = W.cx[b];
             int16_t re = lo16(x), im = (int16_t)-hi16(x);
             uint32_t e;
@@ -333,7 +342,7 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
         {
             uint32_t num = 0;
             int any_zero = 0;
-            for (int b = lane; b < BINS; b += 64) {
+            FOR_BINS(r, b) {
                 if (b >= 1) {
                     const uint16_t mg = W.magn[b];
                     if (mg)
@@ -370,23 +379,23 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
         {
             const int tabind = STAGES - norm_data;
             const int16_t logval = (int16_t)(tabind < 0 ? -K.log_table[-tabind] : K.log_table[tabind]);
-            for (int b = lane; b < BINS; b += 64) {
+            FOR_BINS(r, b) {
                 const uint16_t mg = W.magn[b];
                 int16_t lm = logval;
                 if (mg) {
                     lm = (int16_t)((log2_q8(K, mg) * 22713) >> 15);
                     lm = (int16_t)(lm + logval);
                 }
-                W.lmagn[b] = lm;
+                t_lmagn[r] = lm;
             }
             int update_off = -1;
 #pragma unroll
             for (int e = 0; e < 3; e++) {
                 const int16_t counter = (int16_t)sc[X_COUNTER0 + e], count_div = K.counter_div[counter];
                 const int16_t count_prod = (int16_t)(counter * count_div);
-                for (int b = lane; b < BINS; b += 64) {
+                FOR_BINS(r, b) {
                     int16_t q = lq[e * BP + b], dn = dens[e * BP + b];
-                    const int16_t lm = W.lmagn[b];
+                    const int16_t lm = t_lmagn[r];
                     int16_t delta;
                     if (dn > 512)
                         delta = (int16_t)(2621440 >> (14 - norm_w16(dn)));
@@ -419,10 +428,10 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
             if (update_off >= 0) {  // UpdateNoiseEstimate, :303-331 (at most one estimator per block reaches its period)
                 const int16_t *q = lq + update_off * BP;
                 int32_t mx = -32768;
-                for (int b = lane; b < BINS; b += 64) mx = q[b] > mx ? q[b] : mx;
+                FOR_BINS(r, b) mx = q[b] > mx ? q[b] : mx;
                 mx = wave_max(mx);
                 sc[X_QNOISE] = 14 - (int)mul_rsft_round(11819, (int16_t)mx, 21);
-                for (int b = lane; b < BINS; b += 64) {
+                FOR_BINS(r, b) {
                     const int32_t ee = 11819 * q[b];
                     int32_t m = 0x00200000 | (ee & 0x001FFFFF);
                     int16_t sh = (int16_t)(ee >> 21);
@@ -432,9 +441,9 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
                     quant[b] = sat_w16(m);
                 }
             }
-            for (int b = lane; b < BINS; b += 64) {
-                W.noise[b] = (uint32_t)quant[b];
-                W.pn16[b] = (uint16_t)(pnoise[b] >> 11);
+            FOR_BINS(r, b) {
+                t_noise[r] = (uint32_t)quant[b];
+                t_pn16[r] = (uint16_t)(pnoise[b] >> 11);
             }
             q_noise = (int16_t)sc[X_QNOISE];
         }
@@ -453,7 +462,7 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
                 est0 = (uint32_t)sc[X_WHITE];
                 est0_avg = est0 / (uint32_t)(block_index + 1);
             }
-            for (int b = lane; b < BINS; b += 64) {
+            FOR_BINS(r, b) {
                 uint32_t est = est0, est_avg = est0_avg;
                 if (sc[X_PINK_EXP] && b >= 5) {
                     est = 0, est_avg = 0;
@@ -475,14 +484,14 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
                         ft = (uint16_t)(q > 16384 ? 16384 : (q < (uint32_t)denoise_bound ? (uint32_t)denoise_bound : q));
                     }
                 }
-                W.ftmp[b] = ft;
-                uint32_t a = W.noise[b] >> (q_noise - qd);
+                t_ftmp[r] = ft;
+                uint32_t a = t_noise[r] >> (q_noise - qd);
                 uint32_t c = est_avg >> (sc[X_MIN_NORM] - STAGES - qd);
                 int sh = 0;
                 if (a & 0xfc000000) a >>= 6, c >>= 6, sh = 6;
                 a *= (uint32_t)block_index;
                 c *= (uint32_t)(50 - block_index);
-                W.noise[b] = ((a + c) / 50u) << sh;
+                t_noise[r] = ((a + c) / 50u) << sh;
             }
             q_noise = (int16_t)qd;
         }
@@ -495,10 +504,10 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
         const uint32_t sat_max = 1048575;
         {
             const int post_shifts = 6 + q_magn - q_noise, n_shifts = 5 - sc[X_PREV_QMAGN] + sc[X_PREV_QNOISE];
-            for (int b = lane; b < BINS; b += 64) {
+            FOR_BINS(r, b) {
                 uint32_t post = 2048;
                 uint32_t m = (uint32_t)W.magn[b] << 6;
-                const uint32_t nz = post_shifts < 0 ? W.noise[b] >> -post_shifts : W.noise[b] << post_shifts;
+                const uint32_t nz = post_shifts < 0 ? t_noise[r] >> -post_shifts : t_noise[r] << post_shifts;
                 if (m > nz) {
                     m <<= 11;
                     if (nz > 0) {
@@ -516,17 +525,17 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
                 } else {
                     a = sat_max;
                 }
-                W.post[b] = post;
-                W.pnear[b] = a;
+                t_post[r] = post;
+                t_pnear[r] = a;
                 const uint32_t p = a * 2007u + (post - 2048) * 41u + 512;
-                W.prior[b] = 2048 + (p >> 10);
+                t_prior[r] = 2048 + (p >> 10);
             }
         }
 
         // ComputeSpectralDifference, :1091-1181
         {
             int32_t s_p = 0, mx = 0, mn = pause[0];
-            for (int b = lane; b < BINS; b += 64) {
+            FOR_BINS(r, b) {
                 const int32_t p = pause[b];
                 s_p = wadd(s_p, p);
                 mx = p > mx ? p : mx;
@@ -541,7 +550,7 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
             int n_shifts = 10 + STAGES - norm_w32(dev);
             if (n_shifts < 0) n_shifts = 0;
             uint32_t v_m = 0, v_p = 0, cv = 0;
-            for (int b = lane; b < BINS; b += 64) {
+            FOR_BINS(r, b) {
                 const int16_t dm = (int16_t)((int32_t)W.magn[b] - avg_magn);
                 const int32_t dp = wsub(pause[b], avg_pause);
                 v_m += (uint32_t)(dm * dm);
@@ -678,8 +687,8 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
         // SpeechNoiseProb, nsx_core_c.c:26-260
         {
             uint32_t ls = 0;
-            for (int b = lane; b < BINS; b += 64) {
-                const uint32_t post = W.post[b], prior = W.prior[b];
+            FOR_BINS(r, b) {
+                const uint32_t post = t_post[r], prior = t_prior[r];
                 int32_t bessel = (int32_t)post;
                 const int nt = norm_u32(post);
                 const uint32_t num = post << nt;
@@ -731,7 +740,7 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
             const int16_t dprior = (int16_t)(ind16 - (int16_t)sc[X_PRIOR]);
             sc[X_PRIOR] = (int16_t)((int16_t)sc[X_PRIOR] + (int16_t)((1638 * dprior) >> 14));
             const int32_t prior_ns = sc[X_PRIOR];
-            for (int b = lane; b < BINS; b += 64) {
+            FOR_BINS(r, b) {
                 uint16_t ns = 0;
                 const int32_t la = lrt[b];
                 if (prior_ns > 0 && la < 65300) {
@@ -763,8 +772,8 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
         {
             uint32_t mx = 0;
             const int post_shifts = sc[X_PREV_QNOISE] - q_magn, n_shifts = sc[X_PREV_QMAGN] - q_magn;
-            for (int b = lane; b < BINS; b += 64) {
-                const uint16_t mg = W.magn[b], ns = W.nsp[b], pn = W.pn16[b];
+            FOR_BINS(r, b) {
+                const uint16_t mg = W.magn[b], ns = W.nsp[b], pn = t_pn16[r];
                 const uint32_t m = post_shifts < 0 ? (uint32_t)(mg >> -post_shifts) : (uint32_t)mg << post_shifts;
                 int sign;
                 uint32_t d;
@@ -786,7 +795,7 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
                     const uint32_t alt = sign > 0 ? pv + st : pv - st;
                     if (upd > alt) upd = alt;
                 }
-                W.noise[b] = upd;
+                t_noise[r] = upd;
                 mx = upd > mx ? upd : mx;
                 int32_t pz = shift_w32(pause[b], -n_shifts);
                 if (ns > 205) {
@@ -811,9 +820,9 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
         // step 3: Wiener gain from the updated noise, :1947-2013; previous-frame arrays, :2015-2029
         {
             const int n_shifts = sc[X_PREV_QNOISE] + 11 - q_magn;
-            for (int b = lane; b < BINS; b += 64) {
+            FOR_BINS(r, b) {
                 const uint16_t mg = W.magn[b];
-                const uint32_t nu = W.noise[b];
+                const uint32_t nu = t_noise[r];
                 uint32_t cur = 0, m, nz;
                 if (n_shifts < 0) {
                     m = (uint32_t)mg;
@@ -834,13 +843,13 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
                     if (c > 0) a /= c;
                     cur = sat_max < a ? sat_max : a;
                 }
-                const uint32_t prior = W.pnear[b] * 2007u + cur * 41u;
+                const uint32_t prior = t_pnear[r] * 2007u + cur * 41u;
                 const uint32_t den = (uint32_t)overdrive + ((prior + 8192) >> 14);
                 const uint16_t g = (uint16_t)((prior + den / 2) / den);
                 uint16_t fl = g > 16384 ? (uint16_t)16384 : (g < denoise_bound ? (uint16_t)denoise_bound : g);
                 if (block_index < 50) {
                     uint32_t a = (uint32_t)(fl * block_index);
-                    a += (uint32_t)(W.ftmp[b] * (50 - block_index));
+                    a += (uint32_t)(t_ftmp[r] * (50 - block_index));
                     fl = (uint16_t)(a / 50u);
                 }
                 filt[b] = fl;
@@ -853,7 +862,7 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
         wave_sync();
 
         // ---- DataSynthesis, :1421-1499: PrepareSpectrumC :456-474, inverse transform, DenormalizeC :477-488
-        for (int b = lane; b < BINS; b += 64) {
+        FOR_BINS(r, b) {
             const int32_t x = W.spec[b];
             const int16_t f = (int16_t)filt[b];
             const int16_t re = (int16_t)((lo16(x) * f) >> 14), im = (int16_t)((hi16(x) * f) >> 14);
