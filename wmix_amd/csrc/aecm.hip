@@ -35,7 +35,7 @@ constexpr int kAecmBP = 68;        // 65 bins padded
 constexpr int kAecmMaxDelay = 100;  // MAX_DELAY, aecm_defines.h:26
 
 struct alignas(16) AecmConsts {
-    int16_t sin1024[1024];
+    SplTwiddles tw;  // packed twiddle pairs of the SPL FFT (spl_fx.h), both directions
     int16_t sqrt_hanning[66];
     int16_t cos360[360], sin360[360];
     int16_t pad[2];
@@ -82,6 +82,24 @@ enum AecmScalar {
     M_FIRST_VAD = 0, M_CUR_VAD, M_DFA_Q, M_TOT_COUNT, M_FAR_LOG, M_E_MIN, M_E_MAX, M_E_MAXMIN, M_E_VAD, M_E_MSE, M_VAD_UPD, M_STARTUP,
     M_MSE_COUNT, M_SUP_GAIN, M_SUP_GAIN_OLD, M_MSE_ADAPT_OLD, M_MSE_STORED_OLD, M_MSE_THR, M_NOISE_CTR, M_SEED, M_NEAR_INIT, M_MIN_PROB,
     M_LAST_PROB, M_LAST_DELAY, M_LOG_HEAD, M_COUNT
+};
+
+// The stream's scalar state lives in its LDS copy of the state block and is fetched where it is used (one broadcast LDS read
+// + readfirstlane): held in registers for the whole kernel, the 25 values plus the kernel's pointers exceed the SGPR file
+// and every use turns into v_readlane / v_writelane spill traffic (half of the kernel's instructions when measured).
+struct AecmScalRef {
+    int32_t *p;
+    __device__ __forceinline__ operator int32_t() const { return uni(*p); }
+    __device__ __forceinline__ AecmScalRef &operator=(int32_t v) {
+        *p = v;
+        return *this;
+    }
+    __device__ __forceinline__ AecmScalRef &operator=(const AecmScalRef &o) { return *this = (int32_t)o; }
+    __device__ __forceinline__ void operator++(int) { *p = uni(*p) + 1; }
+};
+struct AecmScal {
+    int32_t *base;
+    __device__ __forceinline__ AecmScalRef operator[](int k) const { return AecmScalRef{base + k}; }
 };
 
 struct alignas(16) AecmWave {
@@ -140,7 +158,7 @@ __device__ int time_to_freq(AecmWave &W, const AecmConsts &K, int lane, int32_t 
         W.cx[bitrev<7>(i)] = (int32_t)(uint16_t)(int16_t)((s * w) >> 14);
     }
     wave_sync();
-    spl_cfft<7, false>(W.cx, K.sin1024, lane);
+    spl_cfft<7, false>(W.cx, K.tw, lane);
     uint32_t part = 0;
     for (int b = lane; b < 65; b += 64) {
         const int32_t x = W.cx[b];
@@ -258,7 +276,7 @@ __global__ __launch_bounds__(64) void aecm_far_kernel(AecmFarBufs F, const AecmC
 }
 
 // ---------------------------------------------------------------- one 64-sample block of one stream (ProcessBlock)
-__device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &F, int32_t (&sc)[M_COUNT], int t, int mult, int lane) {
+__device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &F, const AecmScal sc, int t, int mult, int lane) {
     int16_t *ch_stored = reinterpret_cast<int16_t *>(&W.st[A_CH_STORED]), *ch_adapt16 = reinterpret_cast<int16_t *>(&W.st[A_CH_ADAPT16]);
     int16_t *near_filt = reinterpret_cast<int16_t *>(&W.st[A_NEAR_FILT]);
     int16_t *noise_lo = reinterpret_cast<int16_t *>(&W.st[A_NOISE_LO]), *noise_hi = reinterpret_cast<int16_t *>(&W.st[A_NOISE_HI]);
@@ -696,7 +714,7 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
         if (b > 0 && b < 64) W.cx[bitrev<7>(128 - b)] = pack16(re, (int16_t)-nim);
     }
     wave_sync();
-    const int out_scale = spl_cfft<7, true>(W.cx, K.sin1024, lane);
+    const int out_scale = spl_cfft<7, true>(W.cx, K.tw, lane);
     {
         const int i = lane;
         const int16_t a = (int16_t)(((int32_t)lo16(W.cx[i]) * K.sqrt_hanning[i] + 8192) >> 14);
@@ -737,9 +755,7 @@ __global__ __launch_bounds__(64 * kAecmWavesPerBlock) void aecm_near_kernel(int3
     }
     __syncthreads();
     if (!live) return;
-    int32_t sc[M_COUNT];
-#pragma unroll
-    for (int k = 0; k < M_COUNT; k++) sc[k] = uni(W.st[A_SCAL + k]);
+    const AecmScal sc{&W.st[A_SCAL]};
     int16_t *near_ring = reinterpret_cast<int16_t *>(&W.st[A_NEAR_RING]), *out_ring = reinterpret_cast<int16_t *>(&W.st[A_OUT_RING]);
     int16_t *d_prev = reinterpret_cast<int16_t *>(&W.st[A_D_PREV]);
     for (int p = 0; p < n_plans; p++) {
@@ -798,10 +814,6 @@ __global__ __launch_bounds__(64 * kAecmWavesPerBlock) void aecm_near_kernel(int3
                     for (int c = 0; c < chn; c++) op[(long)(f * kAecmFrame + i) * chn + c] = v;
                 }
         }
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < M_COUNT; k++) W.st[A_SCAL + k] = sc[k];
     }
     wave_sync();
     {
@@ -881,7 +893,7 @@ int wmx_aecm_create(wmx_aecm **out, int n_streams, int chn, int freq, int interv
 
     AecmConsts *K = new AecmConsts();
     memset(K, 0, sizeof(*K));
-    memcpy(K->sin1024, fx_spl_sin1024, sizeof(fx_spl_sin1024));
+    spl_twiddles(fx_spl_sin1024, &K->tw);
     memcpy(K->sqrt_hanning, fx_aecm_sqrt_hanning, sizeof(fx_aecm_sqrt_hanning));
     memcpy(K->cos360, fx_aecm_cos, sizeof(fx_aecm_cos));
     memcpy(K->sin360, fx_aecm_sin, sizeof(fx_aecm_sin));

@@ -87,12 +87,12 @@ __global__ __launch_bounds__(64) void dbg_aec_lanes_inv(const FftTables *__restr
 }
 
 template <int ORDER, bool INV>
-__global__ __launch_bounds__(64) void dbg_spl_fft(const int16_t *__restrict__ sin1024, int16_t *data, int32_t *aux, int n_batch) {
+__global__ __launch_bounds__(64) void dbg_spl_fft(const SplTwiddles *__restrict__ tw, int16_t *data, int32_t *aux, int n_batch) {
     constexpr int N = 1 << ORDER;
-    __shared__ int16_t S[1024];
+    __shared__ SplTwiddles S;
     __shared__ int32_t cx[N];
     const int lane = threadIdx.x;
-    for (int i = lane; i < 1024; i += 64) S[i] = sin1024[i];
+    for (int i = lane; i < (int)(sizeof(SplTwiddles) / 4); i += 64) reinterpret_cast<int32_t *>(&S)[i] = reinterpret_cast<const int32_t *>(tw)[i];
     int16_t *x = data + (size_t)blockIdx.x * (N + 2);
     if (!INV) {  // real_fft.c:46-70
         for (int i = lane; i < N; i += 64) cx[bitrev<ORDER>(i)] = (int32_t)(uint16_t)x[i];
@@ -152,9 +152,13 @@ extern "C" int wmx_debug_fft(int kind, int n_batch, void *d_data, int32_t *d_aux
         return 0;
     }
     if ((kind == 9 || kind == 11) && !d_aux) return WMX_EINVAL;
-    int16_t *d_sin = nullptr;
-    WMX_HIP(hipMalloc(&d_sin, sizeof(fx_spl_sin1024)));
-    WMX_HIP(hipMemcpy(d_sin, fx_spl_sin1024, sizeof(fx_spl_sin1024), hipMemcpyHostToDevice));
+    SplTwiddles *d_sin = nullptr;
+    {
+        SplTwiddles h;
+        spl_twiddles(fx_spl_sin1024, &h);
+        WMX_HIP(hipMalloc(&d_sin, sizeof(h)));
+        WMX_HIP(hipMemcpy(d_sin, &h, sizeof(h), hipMemcpyHostToDevice));
+    }
     int16_t *x = static_cast<int16_t *>(d_data);
     const dim3 grid((unsigned)n_batch), blk(64);
     switch (kind) {

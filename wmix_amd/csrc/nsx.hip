@@ -32,7 +32,7 @@ constexpr int kNsxHist = 1000;  // HIST_PAR_EST, nsx_defines.h:45
 
 // ---------------------------------------------------------------- constants (one copy per workgroup in LDS)
 struct alignas(16) NsxConsts {
-    int16_t sin1024[1024];
+    SplTwiddles tw;  // packed twiddle pairs of the SPL FFT (spl_fx.h), both directions
     int16_t window[256];
     int16_t log_frac[256];
     int16_t counter_div[202];
@@ -255,7 +255,7 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
         // NormalizeRealBufferC + real_fft.c:46-70: zero imaginary parts, bit reversal, forward transform
         for (int i = lane; i < ANA; i += 64) W.cx[bitrev<STAGES>(i)] = (int32_t)(uint16_t)(int16_t)wshl(W.td[i], norm_data);
         wave_sync();
-        spl_cfft<STAGES, false>(W.cx, K.sin1024, lane);
+        spl_cfft<STAGES, false>(W.cx, K.tw, lane);
         // spectrum, magnitudes, sums (:1231-1264 / :1266-1328)
         const bool startup = sc[X_BLOCK_INDEX] < 50;  // the previous block's index: it is advanced below
         uint32_t e_sum = 0, m_sum = 0;
@@ -872,7 +872,7 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
             if (b > 0 && b < H) W.cx[bitrev<STAGES>(ANA - b)] = pack16(re, (int16_t) - (int16_t)-im);
         }
         wave_sync();
-        const int out_scale = spl_cfft<STAGES, true>(W.cx, K.sin1024, lane);
+        const int out_scale = spl_cfft<STAGES, true>(W.cx, K.tw, lane);
         for (int i = lane; i < ANA; i += 64) W.td[i] = sat_w16(shift_w32((int32_t)lo16(W.cx[i]), out_scale - norm_data));
         wave_sync();
         int16_t gain = 8192;
@@ -1082,7 +1082,7 @@ int wmx_nsx_create(wmx_nsx **out, int n_streams, int chn, int freq) {
     h->words = (int)st.size();
     NsxConsts *K = new NsxConsts();
     memset(K, 0, sizeof(*K));
-    memcpy(K->sin1024, fx_spl_sin1024, sizeof(fx_spl_sin1024));
+    spl_twiddles(fx_spl_sin1024, &K->tw);
     if (h->ana == 256)
         memcpy(K->window, fx_nsx_window256, sizeof(fx_nsx_window256));
     else

@@ -49,62 +49,104 @@ __device__ __forceinline__ int32_t wave_min(int32_t v) {
 }
 __device__ __forceinline__ int wave_any(int p) { return __builtin_amdgcn_ballot_w64(p != 0) != 0; }
 
-// spl_sqrt_floor.c:48-75: floor(sqrt(value)) for value >= 0, 0 for a negative argument
+// WebRtcSpl_SqrtFloor (spl_sqrt_floor.c:48-75) = floor(sqrt(value)) for value > 0 and 0 otherwise: the reference's 16
+// successive-approximation steps are replaced by the float square root and one correction each way.  float(value) and
+// sqrtf are each good to 2^-24 relative, so the estimate is within 0.01 of the true root (< 46 341): after truncation it
+// is the floor or one off, and the two exact integer comparisons settle it.
 __device__ __forceinline__ int32_t sqrt_floor(int32_t value) {
-    int32_t root = 0;
-#pragma unroll
-    for (int n = 15; n >= 0; n--) {
-        const int32_t t = wshl(root + (1 << n), n);
-        if (value >= t) {
-            value -= t;
-            root |= 2 << n;
-        }
-    }
-    return root >> 1;
+    if (value <= 0) return 0;
+    const uint32_t v = (uint32_t)value;
+    uint32_t r = (uint32_t)__fsqrt_rn((float)v);
+    r -= (r * r > v) ? 1u : 0u;
+    r += ((r + 1) * (r + 1) <= v) ? 1u : 0u;
+    return (int32_t)r;
 }
 __device__ __forceinline__ int16_t lo16(int32_t w) { return (int16_t)(w & 0xffff); }
 __device__ __forceinline__ int16_t hi16(int32_t w) { return (int16_t)(w >> 16); }
 __device__ __forceinline__ int32_t pack16(int16_t lo, int16_t hi) { return (int32_t)((uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16)); }
 
 // ---------------------------------------------------------------- SPL complex FFT across the wave (complex_fft.c mode 1)
-// cx holds N = 1 << STAGES packed complex points in bit-reversed order on entry.  INVERSE: returns the number of
-// one-bit shifts the data-dependent scaling applied (WebRtcSpl_ComplexIFFT's return value).
+// Twiddles as packed int16 pairs, so that a butterfly's two rotated components are one dot-product instruction each on
+// the packed point (re | im << 16):  tr = wr*re - wi*im + 1 = dot2(x, A) + 1,  ti = wr*im + wi*re + 1 = dot2(x, B) + 1
+// with A = (wr, -wi), B = (wi, wr); wr = kSinTable1024[j + 256], wi = -/+ kSinTable1024[j] (forward / inverse).  Entry q
+// is table position j = 4 q (a 256-point transform uses every entry, a 128-point one every second).
+struct SplTwiddles {
+    int32_t a[2][128], b[2][128];  // [0]: forward, [1]: inverse
+};
+inline void spl_twiddles(const int16_t *sin1024, SplTwiddles *t) {
+    for (int d = 0; d < 2; d++)
+        for (int q = 0; q < 128; q++) {
+            const int16_t wr = sin1024[4 * q + 256], wi = (int16_t)(d ? sin1024[4 * q] : -sin1024[4 * q]);
+            t->a[d][q] = (int32_t)((uint32_t)(uint16_t)wr | ((uint32_t)(uint16_t)(int16_t)-wi << 16));
+            t->b[d][q] = (int32_t)((uint32_t)(uint16_t)wi | ((uint32_t)(uint16_t)wr << 16));
+        }
+}
+
+typedef short spl_v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int32_t dot2_i16(int32_t x, int32_t w, int32_t c) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(spl_v2s, x), __builtin_bit_cast(spl_v2s, w), c, false);
+}
+// packed |x| of both int16 halves with -32768 kept as 0x8000, which an UNSIGNED comparison ranks above every other
+// magnitude -- what WebRtcSpl_MaxAbsValueW16's abs() + cap at 32767 needs for the two thresholds it is compared with
+__device__ __forceinline__ uint32_t pk_abs16(int32_t x) {
+    uint32_t n, r;
+    asm("v_pk_sub_i16 %0, 0, %1" : "=v"(n) : "v"(x));
+    asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(n));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// cx holds N = 1 << STAGES packed complex points in bit-reversed order on entry; one radix-2 pass per stage, every output
+// rounded to int16 exactly as the reference does (the stages cannot be merged).  Each lane owns butterfly `lane` (and
+// lane + 64 when N = 256) of every stage.  INVERSE: the stage's extra shift (0..2 bits) comes from the largest |value| of
+// the whole array (complex_fft.c:170-186): found once by a scan before the first stage, afterwards carried along from
+// the values each lane has just produced.  Returns the number of one-bit shifts applied (WebRtcSpl_ComplexIFFT's result).
 template <int STAGES, bool INVERSE>
-__device__ int spl_cfft(int32_t *cx, const int16_t *sin1024, int lane) {
+__device__ int spl_cfft(int32_t *cx, const SplTwiddles &T, int lane) {
     constexpr int N = 1 << STAGES, PER = N / 128 > 0 ? N / 128 : 1;  // butterflies per lane and stage
+    const int32_t *ta = T.a[INVERSE ? 1 : 0], *tb = T.b[INVERSE ? 1 : 0];
     int scale = 0;
-#pragma unroll 1
+    uint32_t mag = 0;  // packed running maximum of |re|, |im| of this lane's values (INVERSE only)
+    if (INVERSE) {
+        for (int i = lane; i < N; i += 64) mag = pk_max_u16(mag, pk_abs16(cx[i]));
+    }
+#pragma unroll 1  // unrolled, the three transforms of the AECM block push its kernel past the 64 KB instruction cache
     for (int s = 0; s < STAGES; s++) {
-        const int l = 1 << s, k = 9 - s;
+        const int l = 1 << s;
         int shift = INVERSE ? 0 : 1;
         int32_t round2 = INVERSE ? 8192 : 16384;
         if (INVERSE) {
-            int32_t mx = 0;
-            for (int i = lane; i < N; i += 64) {
-                const int32_t w = cx[i];
-                int a = lo16(w), b = hi16(w);
-                a = a < 0 ? -a : a;
-                b = b < 0 ? -b : b;
-                mx = a > mx ? a : mx;
-                mx = b > mx ? b : mx;
-            }
-            mx = wave_max(mx);
+            uint32_t m16 = (mag & 0xffffu) > (mag >> 16) ? (mag & 0xffffu) : (mag >> 16);
+            int32_t mx = wave_max((int32_t)m16);
             if (mx > 32767) mx = 32767;
             if (mx > 13573) shift++, scale++, round2 <<= 1;
             if (mx > 27146) shift++, scale++, round2 <<= 1;
+            mag = 0;
         }
 #pragma unroll
         for (int r = 0; r < PER; r++) {
             const int b = lane + 64 * r;
             if (N >= 128 || b < N / 2) {
-                const int m = b & (l - 1), i = ((b >> s) << (s + 1)) + m, j = i + l, j0 = m << k;
-                const int16_t wr = sin1024[j0 + 256], wi = (int16_t)(INVERSE ? sin1024[j0] : -sin1024[j0]);
+                const int m = b & (l - 1), i = 2 * b - m, j = i + l;  // i = (b >> s << (s + 1)) + m
+                const int q = m << (7 - s);                            // table position j0 / 4, j0 = m << (9 - s)
                 const int32_t xi = cx[i], xj = cx[j];
-                const int32_t jr = lo16(xj), ji = hi16(xj);
-                const int32_t tr = (wr * jr - wi * ji + 1) >> 1, ti = (wr * ji + wi * jr + 1) >> 1;
-                const int32_t qr = (int32_t)lo16(xi) << 14, qi = (int32_t)hi16(xi) << 14;
-                cx[j] = pack16((int16_t)((qr - tr + round2) >> (shift + 14)), (int16_t)((qi - ti + round2) >> (shift + 14)));
-                cx[i] = pack16((int16_t)((qr + tr + round2) >> (shift + 14)), (int16_t)((qi + ti + round2) >> (shift + 14)));
+#ifdef WMX_FFT_NODOT
+                const int32_t wa = ta[q], jr = lo16(xj), ji = hi16(xj);
+                const int32_t tr = (lo16(wa) * jr + hi16(wa) * ji + 1) >> 1, ti = (lo16(wa) * ji - hi16(wa) * jr + 1) >> 1;
+#else
+                const int32_t tr = dot2_i16(xj, ta[q], 1) >> 1, ti = dot2_i16(xj, tb[q], 1) >> 1;
+#endif
+                const int32_t qr = (int32_t)((uint32_t)xi << 16) >> 2, qi = (int32_t)((uint32_t)xi & 0xffff0000u) >> 2;  // re << 14, im << 14
+                const int sh = shift + 14;
+                const int32_t o_j = (int32_t)__builtin_amdgcn_perm((uint32_t)((qi - ti + round2) >> sh), (uint32_t)((qr - tr + round2) >> sh), 0x05040100u);
+                const int32_t o_i = (int32_t)__builtin_amdgcn_perm((uint32_t)((qi + ti + round2) >> sh), (uint32_t)((qr + tr + round2) >> sh), 0x05040100u);
+                cx[j] = o_j;
+                cx[i] = o_i;
+                if (INVERSE && s + 1 < STAGES) mag = pk_max_u16(mag, pk_max_u16(pk_abs16(o_i), pk_abs16(o_j)));
             }
         }
         wave_sync();
