@@ -84,24 +84,6 @@ enum AecmScalar {
     M_LAST_PROB, M_LAST_DELAY, M_LOG_HEAD, M_COUNT
 };
 
-// The stream's scalar state lives in its LDS copy of the state block and is fetched where it is used (one broadcast LDS read
-// + readfirstlane): held in registers for the whole kernel, the 25 values plus the kernel's pointers exceed the SGPR file
-// and every use turns into v_readlane / v_writelane spill traffic (half of the kernel's instructions when measured).
-struct AecmScalRef {
-    int32_t *p;
-    __device__ __forceinline__ operator int32_t() const { return uni(*p); }
-    __device__ __forceinline__ AecmScalRef &operator=(int32_t v) {
-        *p = v;
-        return *this;
-    }
-    __device__ __forceinline__ AecmScalRef &operator=(const AecmScalRef &o) { return *this = (int32_t)o; }
-    __device__ __forceinline__ void operator++(int) { *p = uni(*p) + 1; }
-};
-struct AecmScal {
-    int32_t *base;
-    __device__ __forceinline__ AecmScalRef operator[](int k) const { return AecmScalRef{base + k}; }
-};
-
 struct alignas(16) AecmWave {
     int32_t st[A_WORDS];
     int32_t cx[128];        // FFT work array (packed complex)
@@ -276,7 +258,7 @@ __global__ __launch_bounds__(64) void aecm_far_kernel(AecmFarBufs F, const AecmC
 }
 
 // ---------------------------------------------------------------- one 64-sample block of one stream (ProcessBlock)
-__device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &F, const AecmScal sc, int t, int mult, int lane) {
+__device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &F, const LdsScal sc, int t, int mult, int lane) {
     int16_t *ch_stored = reinterpret_cast<int16_t *>(&W.st[A_CH_STORED]), *ch_adapt16 = reinterpret_cast<int16_t *>(&W.st[A_CH_ADAPT16]);
     int16_t *near_filt = reinterpret_cast<int16_t *>(&W.st[A_NEAR_FILT]);
     int16_t *noise_lo = reinterpret_cast<int16_t *>(&W.st[A_NOISE_LO]), *noise_hi = reinterpret_cast<int16_t *>(&W.st[A_NOISE_HI]);
@@ -731,7 +713,10 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
 }
 
 // One wave per stream, kAecmWavesPerBlock streams per workgroup.
-__global__ __launch_bounds__(64 * kAecmWavesPerBlock) void aecm_near_kernel(int32_t *__restrict__ state, AecmFarBufs F,
+#ifndef WMX_AECM_WPE
+#define WMX_AECM_WPE 6  // 0.63 / 0.53 / 0.48 / 0.445 ms at 3 / 4 / 5 / 6 waves per SIMD (LDS allows 6)
+#endif
+__global__ __launch_bounds__(64 * kAecmWavesPerBlock) __attribute__((amdgpu_waves_per_eu(WMX_AECM_WPE, WMX_AECM_WPE))) void aecm_near_kernel(int32_t *__restrict__ state, AecmFarBufs F,
                                                                             const AecmConsts *__restrict__ consts,
                                                                             const AecmPlan *__restrict__ plans, int n_plans, const int16_t *near,
                                                                             int16_t *out, int n_streams, long stream_stride, long packet_stride,
@@ -755,7 +740,7 @@ __global__ __launch_bounds__(64 * kAecmWavesPerBlock) void aecm_near_kernel(int3
     }
     __syncthreads();
     if (!live) return;
-    const AecmScal sc{&W.st[A_SCAL]};
+    const LdsScal sc{&W.st[A_SCAL]};
     int16_t *near_ring = reinterpret_cast<int16_t *>(&W.st[A_NEAR_RING]), *out_ring = reinterpret_cast<int16_t *>(&W.st[A_OUT_RING]);
     int16_t *d_prev = reinterpret_cast<int16_t *>(&W.st[A_D_PREV]);
     for (int p = 0; p < n_plans; p++) {

@@ -27,7 +27,19 @@
 namespace wmx {
 namespace {
 
-constexpr int kNsxWavesPerBlock = 4;
+// Workgroup shape: waves (= streams) per workgroup, and the occupancy the register budget is set for.  Four waves and
+// 32 368 B of LDS per workgroup (16 kHz mono: 7 128 B per stream + 3.8 KB of tables) let five workgroups share a CU's
+// 160 KB -- 5 waves per SIMD; the 8 kHz formats fit 8 workgroups and are register-limited to 6 per SIMD.
+// A workgroup's waves are dealt round-robin to the CU's four SIMDs starting at the same one, so a wave count that is not a
+// multiple of 4 piles the surplus on SIMD 0 and the CU stops accepting workgroups early: 5-, 9- and 10-wave workgroups
+// (sized to fill the LDS with 15 / 18 / 20 waves) all ran at 10 waves per CU, 0.65-0.73 ms against 0.455 ms for 4 x 4.
+#ifndef WMX_NSX_WPB
+#define WMX_NSX_WPB 4
+#endif
+template <int ANA, int CHN>
+struct NsxShape {
+    static constexpr int WPB = WMX_NSX_WPB, WPE = ANA == 256 ? 5 : 6;
+};
 constexpr int kNsxHist = 1000;  // HIST_PAR_EST, nsx_defines.h:45
 
 // ---------------------------------------------------------------- constants (one copy per workgroup in LDS)
@@ -41,17 +53,17 @@ struct alignas(16) NsxConsts {
     int16_t factor2[258];
     int16_t indicator[18];
     int16_t log_table[10];
-    int16_t sum_log_index[66];
-    int16_t sum_sq_log_index[66];
-    int16_t determinant[66];
-    int16_t pad[2];
+    // kSumLogIndex / kSumSquareLogIndex / kDeterminantEstMatrix are only ever read at the start band (5) and, for the
+    // 129-bin format, at 65 (nsx_core.c:1330-1365): five values instead of three tables
+    int16_t sum_log_index_5, sum_log_index_65, sum_sq_log_index_5, sum_sq_log_index_65, determinant_5;
+    int16_t pad[5];
 };
 static_assert(sizeof(NsxConsts) % 16 == 0, "NsxConsts is copied in 16-byte pieces");
 
 // ---------------------------------------------------------------- per-stream state block (int32 words)
 template <int ANA>
 struct NsxLayout {
-    static constexpr int BINS = ANA / 2 + 1, BP = ANA / 2 + 4;
+    static constexpr int BINS = ANA / 2 + 1, BP = ANA / 2 + 2;
     static constexpr int ANA_BUF = 0;                    // int16[ANA]   analysisBuffer
     static constexpr int SYN_BUF = ANA_BUF + ANA / 2;    // int16[ANA]   synthesisBuffer
     static constexpr int FILT = SYN_BUF + ANA / 2;       // uint16[BP]   noiseSupFilter (Q14)
@@ -63,8 +75,8 @@ struct NsxLayout {
     static constexpr int PAUSE = LRT + BP;               // int32[BP]    avgMagnPause
     static constexpr int INITM = PAUSE + BP;             // uint32[BP]   initMagnEst
     static constexpr int PNOISE = INITM + BP;            // uint32[BP]   prevNoiseU32
-    static constexpr int SCAL = PNOISE + BP;             // 34 scalar words
-    static constexpr int HB = SCAL + 34;                 // int16[ANA]   dataBufHBFX[0] (2-channel streams only)
+    static constexpr int SCAL = PNOISE + BP;             // 35 scalar words (X_COUNT used)
+    static constexpr int HB = SCAL + 35;                 // int16[ANA]   dataBufHBFX[0] (2-channel streams only)
     static constexpr int WORDS_MONO = HB, WORDS_2CH = HB + ANA / 2;
     static_assert(WORDS_MONO % 4 == 0 && WORDS_2CH % 4 == 0, "16-byte state copies");
 };
@@ -74,13 +86,17 @@ enum NsxScalar {
     X_BLOCK_INDEX, X_CNT_THR, X_PREV_QNOISE, X_PREV_QMAGN, X_COUNT
 };
 
-template <int ANA>
+template <int ANA, int CHN>
 struct alignas(16) NsxWave {
-    static constexpr int BP = ANA / 2 + 4;
-    int32_t st[NsxLayout<ANA>::WORDS_2CH];
-    int32_t cx[ANA];     // FFT work array, one packed complex (re | im << 16) per word
-    int16_t td[ANA];     // windowed frame, later the time-domain output of the inverse transform (inst->real)
-    int32_t spec[BP];    // the frame's spectrum (inst->real / inst->imag), packed like cx
+    static constexpr int BP = NsxLayout<ANA>::BP;
+    int32_t st[CHN == 2 ? NsxLayout<ANA>::WORDS_2CH : NsxLayout<ANA>::WORDS_MONO];
+    // FFT work array, one packed complex (re | im << 16) per word.  Three tenants, never at the same time: the windowed
+    // frame td[ANA] (int16, in the first half) until the forward transform's bit-reversed load; the transform itself, whose
+    // first ANA/2 + 1 words then stay as the frame's spectrum (inst->real / inst->imag) until the inverse transform's load;
+    // and the inverse transform, whose output becomes td[] again (inst->real).  Each hand-over reads into registers, then
+    // writes after a wave_sync.
+    int32_t cx[ANA];
+    __device__ __forceinline__ int16_t *td() { return reinterpret_cast<int16_t *>(cx); }
     uint16_t magn[BP], nsp[BP];  // read across lanes (magn[0], nsp[b - 1]); the other per-bin intermediates are registers
 };
 
@@ -186,7 +202,7 @@ __device__ void two_peaks(const int16_t *hist, int lane, uint32_t &pos1, int &w1
 // in0 / out0: low band (channel 0), in1 / out1: the "high band" (channel 1 of a 2-channel stream);
 // element stride CHN.  sc[]: the stream's scalars, wave-uniform registers.
 template <int ANA, int CHN>
-__device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_COUNT], int16_t *hist, const int16_t *in, int16_t *out,
+__device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsScal sc, int16_t *hist, const int16_t *in, int16_t *out,
                           int lane, int overdrive, int denoise_bound) {
     using Y = NsxLayout<ANA>;
     constexpr int BINS = Y::BINS, H = ANA / 2, BLOCK = ANA == 256 ? 160 : 80, KEEP = ANA - BLOCK, STAGES = ANA == 256 ? 8 : 7;
@@ -199,6 +215,7 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
     uint32_t *initm = reinterpret_cast<uint32_t *>(&W.st[Y::INITM]), *pnoise = reinterpret_cast<uint32_t *>(&W.st[Y::PNOISE]);
     int16_t *hb = reinterpret_cast<int16_t *>(&W.st[Y::HB]);
     constexpr int BP = Y::BP;
+    int16_t *td = W.td();
     // the frame's per-bin intermediates stay in registers: pass r of a per-bin loop handles bin lane + 64 r (the last
     // pass is lane 0's Nyquist bin), every loop is unrolled over the passes, so the indices are compile-time constants
     constexpr int NP = (BINS + 63) / 64;
@@ -232,13 +249,13 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
         }
         wave_sync();
     }
-    for (int i = lane; i < ANA; i += 64) W.td[i] = (int16_t)mul_rsft_round(K.window[i], ana[i], 14);
+    for (int i = lane; i < ANA; i += 64) td[i] = (int16_t)mul_rsft_round(K.window[i], ana[i], 14);
     wave_sync();
     int scale_energy_in;
-    int32_t energy_in = wave_energy<ANA>(W.td, lane, &scale_energy_in);
+    int32_t energy_in = wave_energy<ANA>(td, lane, &scale_energy_in);
     int mxabs = 0;
     for (int i = lane; i < ANA; i += 64) {
-        const int a = W.td[i] < 0 ? -(int)W.td[i] : (int)W.td[i];
+        const int a = td[i] < 0 ? -(int)td[i] : (int)td[i];
         mxabs = a > mxabs ? a : mxabs;
     }
     mxabs = wave_max(mxabs);
@@ -253,7 +270,14 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
         sc[X_MIN_NORM] -= rs_init;
         if (rs_magn < 0) rs_magn = 0;
         // NormalizeRealBufferC + real_fft.c:46-70: zero imaginary parts, bit reversal, forward transform
-        for (int i = lane; i < ANA; i += 64) W.cx[bitrev<STAGES>(i)] = (int32_t)(uint16_t)(int16_t)wshl(W.td[i], norm_data);
+        {
+            int16_t tv[ANA / 64];
+#pragma unroll
+            for (int r = 0; r < ANA / 64; r++) tv[r] = td[lane + 64 * r];
+            wave_sync();  // td[] lives in cx
+#pragma unroll
+            for (int r = 0; r < ANA / 64; r++) W.cx[bitrev<STAGES>(lane + 64 * r)] = (int32_t)(uint16_t)(int16_t)wshl(tv[r], norm_data);
+        }
         wave_sync();
         spl_cfft<STAGES, false>(W.cx, K.tw, lane);
         // spectrum, magnitudes, sums (:1231-1264 / :1266-1328)
@@ -273,7 +297,7 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
                 e = (uint32_t)(re * re) + (uint32_t)(hi16(x) * hi16(x));
                 mg = (uint16_t)sqrt_floor((int32_t)e);
             }
-            W.spec[b] = pack16(re, im);
+            W.cx[b] = pack16(re, im);  // the spectrum stays in place
             W.magn[b] = mg;
             e_sum += e;
             m_sum += mg;
@@ -295,16 +319,16 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
             uint32_t w = (sum_magn * (uint32_t)overdrive) >> (STAGES + 8);
             w >>= rs_magn;
             sc[X_WHITE] = (int32_t)((uint32_t)sc[X_WHITE] + w);
-            int16_t det = K.determinant[5], sum_i = K.sum_log_index[5], sum_i2 = K.sum_sq_log_index[5];
+            int16_t det = K.determinant_5, sum_i = K.sum_log_index_5, sum_i2 = K.sum_sq_log_index_5;
             if (ANA == 128) {
                 int32_t t = det;
-                t += (K.sum_log_index[65] * sum_i) >> 9;
-                t -= (K.sum_log_index[65] * K.sum_log_index[65]) >> 10;
+                t += (K.sum_log_index_65 * sum_i) >> 9;
+                t -= (K.sum_log_index_65 * K.sum_log_index_65) >> 10;
                 t -= (int32_t)sum_i2 << 4;
-                t -= ((BINS - 5) * K.sum_sq_log_index[65]) >> 2;
+                t -= ((BINS - 5) * K.sum_sq_log_index_65) >> 2;
                 det = (int16_t)t;
-                sum_i = (int16_t)(sum_i - K.sum_log_index[65]);
-                sum_i2 = (int16_t)(sum_i2 - K.sum_sq_log_index[65]);
+                sum_i = (int16_t)(sum_i - K.sum_log_index_65);
+                sum_i2 = (int16_t)(sum_i2 - K.sum_sq_log_index_65);
             }
             int zeros = 16 - norm_w32(sum_log);
             if (zeros < 0) zeros = 0;
@@ -862,8 +886,11 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
         wave_sync();
 
         // ---- DataSynthesis, :1421-1499: PrepareSpectrumC :456-474, inverse transform, DenormalizeC :477-488
+        int32_t t_spec[NP];
+        FOR_BINS(r, b) t_spec[r] = W.cx[b];
+        wave_sync();  // the spectrum lives in cx
         FOR_BINS(r, b) {
-            const int32_t x = W.spec[b];
+            const int32_t x = t_spec[r];
             const int16_t f = (int16_t)filt[b];
             const int16_t re = (int16_t)((lo16(x) * f) >> 14), im = (int16_t)((hi16(x) * f) >> 14);
             // real_fft.c:72-100: the packed spectrum carries -imag; the upper half is its conjugate mirror
@@ -873,12 +900,19 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
         }
         wave_sync();
         const int out_scale = spl_cfft<STAGES, true>(W.cx, K.tw, lane);
-        for (int i = lane; i < ANA; i += 64) W.td[i] = sat_w16(shift_w32((int32_t)lo16(W.cx[i]), out_scale - norm_data));
+        {
+            int16_t tv[ANA / 64];
+#pragma unroll
+            for (int r = 0; r < ANA / 64; r++) tv[r] = sat_w16(shift_w32((int32_t)lo16(W.cx[lane + 64 * r]), out_scale - norm_data));
+            wave_sync();  // td[] lives in cx
+#pragma unroll
+            for (int r = 0; r < ANA / 64; r++) td[lane + 64 * r] = tv[r];
+        }
         wave_sync();
         int16_t gain = 8192;
         if (block_index > 200 && energy_in > 0) {  // gainMap == 1 for policy 2
             int sc_out = 0;
-            int32_t e_out = wave_energy<ANA>(W.td, lane, &sc_out);
+            int32_t e_out = wave_energy<ANA>(td, lane, &sc_out);
             if (sc_out == 0 && !(e_out & 0x7f800000))
                 e_out = shift_w32(e_out, 8 + sc_out - scale_energy_in);
             else  // a negative count is an undefined shift + failed assert in the reference; unity gain here (orc_nsx.c)
@@ -893,7 +927,7 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
         }
         // SynthesisUpdateC, :491-521
         for (int i = lane; i < ANA; i += 64) {
-            const int16_t w = (int16_t)mul_rsft_round(K.window[i], W.td[i], 14);
+            const int16_t w = (int16_t)mul_rsft_round(K.window[i], td[i], 14);
             const int16_t g = sat_w16(mul_rsft_round(w, gain, 13));
             syn[i] = sat_w16((int32_t)syn[i] + g);
         }
@@ -945,24 +979,24 @@ __device__ void nsx_block(NsxWave<ANA> &W, const NsxConsts &K, int32_t (&sc)[X_C
     wave_sync();
 }
 
-// One wave per stream, kNsxWavesPerBlock streams per workgroup, all packets of the launch with the state in LDS.
+// One wave per stream, NsxShape::WPB streams per workgroup, all packets of the launch with the state in LDS.
 template <int ANA, int CHN>
-__global__ __launch_bounds__(64 * kNsxWavesPerBlock) void nsx_kernel(int32_t *__restrict__ state, int16_t *__restrict__ hist,
+__global__ __launch_bounds__((64 * NsxShape<ANA, CHN>::WPB)) __attribute__((amdgpu_waves_per_eu(NsxShape<ANA, CHN>::WPE, NsxShape<ANA, CHN>::WPE))) void nsx_kernel(int32_t *__restrict__ state, int16_t *__restrict__ hist,
                                                                      const NsxConsts *__restrict__ consts, const int16_t *in, int16_t *out,
                                                                      int n_streams, int n_packets, long stream_stride, long packet_stride,
                                                                      int pkg, int overdrive, int denoise_bound) {
     using Y = NsxLayout<ANA>;
-    constexpr int WORDS = CHN == 2 ? Y::WORDS_2CH : Y::WORDS_MONO, BLOCK = ANA == 256 ? 160 : 80;
+    constexpr int WORDS = CHN == 2 ? Y::WORDS_2CH : Y::WORDS_MONO, BLOCK = ANA == 256 ? 160 : 80, WPB = NsxShape<ANA, CHN>::WPB;
     __shared__ NsxConsts K;
-    __shared__ NsxWave<ANA> WS[kNsxWavesPerBlock];
+    __shared__ NsxWave<ANA, CHN> WS[WPB];
     {
         const int4 *src = reinterpret_cast<const int4 *>(consts);
         int4 *dst = reinterpret_cast<int4 *>(&K);
         for (int i = threadIdx.x; i < (int)(sizeof(NsxConsts) / 16); i += blockDim.x) dst[i] = src[i];
     }
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const long s = (long)blockIdx.x * kNsxWavesPerBlock + wave;
-    NsxWave<ANA> &W = WS[wave];
+    const long s = (long)blockIdx.x * WPB + wave;
+    NsxWave<ANA, CHN> &W = WS[wave];
     const bool live = s < n_streams;
     int32_t *st = state + (live ? s : 0) * (long)WORDS;
     if (live) {
@@ -972,9 +1006,7 @@ __global__ __launch_bounds__(64 * kNsxWavesPerBlock) void nsx_kernel(int32_t *__
     }
     __syncthreads();
     if (!live) return;
-    int32_t sc[X_COUNT];
-#pragma unroll
-    for (int k = 0; k < X_COUNT; k++) sc[k] = uni(W.st[Y::SCAL + k]);
+    const LdsScal sc{&W.st[Y::SCAL]};
     int16_t *hs = hist + s * (long)(3 * kNsxHist);
     for (int p = 0; p < n_packets; p++) {
         const int16_t *ip = in + s * stream_stride + (long)p * packet_stride;
@@ -983,10 +1015,6 @@ __global__ __launch_bounds__(64 * kNsxWavesPerBlock) void nsx_kernel(int32_t *__
         // 32 kHz: the wrapper's packet is 320 frames but the core consumes 160; the rest of the output packet is
         // the wrapper's calloc zeros (src/webrtc.c:577 vs nsx_core.c:655)
         for (int i = BLOCK * CHN + lane; i < pkg * CHN; i += 64) op[i] = 0;
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < X_COUNT; k++) W.st[Y::SCAL + k] = sc[k];
     }
     wave_sync();
     {
@@ -1094,9 +1122,9 @@ int wmx_nsx_create(wmx_nsx **out, int n_streams, int chn, int freq) {
     memcpy(K->factor2, fx_nsx_factor2_mode2, sizeof(fx_nsx_factor2_mode2));
     memcpy(K->indicator, fx_nsx_indicator, sizeof(fx_nsx_indicator));
     memcpy(K->log_table, fx_nsx_log_table, sizeof(fx_nsx_log_table));
-    memcpy(K->sum_log_index, fx_nsx_sum_log_index, sizeof(fx_nsx_sum_log_index));
-    memcpy(K->sum_sq_log_index, fx_nsx_sum_sq_log_index, sizeof(fx_nsx_sum_sq_log_index));
-    memcpy(K->determinant, fx_nsx_determinant, sizeof(fx_nsx_determinant));
+    K->sum_log_index_5 = fx_nsx_sum_log_index[5], K->sum_log_index_65 = fx_nsx_sum_log_index[65];
+    K->sum_sq_log_index_5 = fx_nsx_sum_sq_log_index[5], K->sum_sq_log_index_65 = fx_nsx_sum_sq_log_index[65];
+    K->determinant_5 = fx_nsx_determinant[5];
     int32_t *d_tmpl = nullptr;
     hipError_t e;
 #define NSX_TRY(x)                                        \
@@ -1139,11 +1167,11 @@ int wmx_nsx_process(wmx_nsx *h, const int16_t *d_in, int16_t *d_out, int n_packe
         set_error("wmx_nsx_process: null buffer");
         return WMX_EINVAL;
     }
-    const dim3 grid((unsigned)((h->n_streams + kNsxWavesPerBlock - 1) / kNsxWavesPerBlock)), block(64 * kNsxWavesPerBlock);
     hipStream_t s = as_stream(stream);
-#define NSX_LAUNCH(A, C)                                                                                                            \
-    hipLaunchKernelGGL((nsx_kernel<A, C>), grid, block, 0, s, h->d_state, h->d_hist, h->d_consts, d_in, d_out, h->n_streams, n_packets, \
-                       stream_stride, packet_stride, h->pkg, h->overdrive, h->denoise_bound)
+#define NSX_LAUNCH(A, C)                                                                                                    \
+    hipLaunchKernelGGL((nsx_kernel<A, C>), dim3((unsigned)((h->n_streams + NsxShape<A, C>::WPB - 1) / NsxShape<A, C>::WPB)),  \
+                       dim3(64 * NsxShape<A, C>::WPB), 0, s, h->d_state, h->d_hist, h->d_consts, d_in, d_out, h->n_streams, \
+                       n_packets, stream_stride, packet_stride, h->pkg, h->overdrive, h->denoise_bound)
     if (h->ana == 128) {
         if (h->chn == 1)
             NSX_LAUNCH(128, 1);

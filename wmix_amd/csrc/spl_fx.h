@@ -65,21 +65,45 @@ __device__ __forceinline__ int16_t lo16(int32_t w) { return (int16_t)(w & 0xffff
 __device__ __forceinline__ int16_t hi16(int32_t w) { return (int16_t)(w >> 16); }
 __device__ __forceinline__ int32_t pack16(int16_t lo, int16_t hi) { return (int32_t)((uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16)); }
 
+// ---------------------------------------------------------------- a stream's scalar state, resident in LDS
+// The scalars of a stream live in its LDS copy of the state block and are fetched where they are used (one broadcast LDS
+// read + readfirstlane).  Held in registers for the whole kernel, a few dozen of them plus the kernel's pointers exceed the
+// SGPR file and every use turns into v_readlane / v_writelane spill traffic (half of the AECM kernel's instructions when
+// measured).  Every lane stores the same value; reads are wave-uniform.
+struct LdsScalRef {
+    int32_t *p;
+    __device__ __forceinline__ operator int32_t() const { return uni(*p); }
+    __device__ __forceinline__ LdsScalRef &operator=(int32_t v) {
+        *p = v;
+        return *this;
+    }
+    __device__ __forceinline__ LdsScalRef &operator=(const LdsScalRef &o) { return *this = (int32_t)o; }
+    __device__ __forceinline__ void operator++(int) { *p = uni(*p) + 1; }
+    __device__ __forceinline__ void operator--(int) { *p = uni(*p) - 1; }
+    __device__ __forceinline__ void operator+=(int32_t v) { *p = uni(*p) + v; }
+    __device__ __forceinline__ void operator-=(int32_t v) { *p = uni(*p) - v; }
+};
+struct LdsScal {
+    int32_t *base;
+    __device__ __forceinline__ LdsScalRef operator[](int k) const { return LdsScalRef{base + k}; }
+};
+
 // ---------------------------------------------------------------- SPL complex FFT across the wave (complex_fft.c mode 1)
 // Twiddles as packed int16 pairs, so that a butterfly's two rotated components are one dot-product instruction each on
 // the packed point (re | im << 16):  tr = wr*re - wi*im + 1 = dot2(x, A) + 1,  ti = wr*im + wi*re + 1 = dot2(x, B) + 1
 // with A = (wr, -wi), B = (wi, wr); wr = kSinTable1024[j + 256], wi = -/+ kSinTable1024[j] (forward / inverse).  Entry q
-// is table position j = 4 q (a 256-point transform uses every entry, a 128-point one every second).
+// is table position j = 4 q (a 256-point transform uses every entry, a 128-point one every second).  Only the forward
+// pair is stored: with s = kSinTable1024[j] it is A = (wr, s), B = (-s, wr), and the inverse pair A' = (wr, -s),
+// B' = (s, wr) is B and A with their halves exchanged (one v_alignbit each).
 struct SplTwiddles {
-    int32_t a[2][128], b[2][128];  // [0]: forward, [1]: inverse
+    int32_t a[128], b[128];
 };
 inline void spl_twiddles(const int16_t *sin1024, SplTwiddles *t) {
-    for (int d = 0; d < 2; d++)
-        for (int q = 0; q < 128; q++) {
-            const int16_t wr = sin1024[4 * q + 256], wi = (int16_t)(d ? sin1024[4 * q] : -sin1024[4 * q]);
-            t->a[d][q] = (int32_t)((uint32_t)(uint16_t)wr | ((uint32_t)(uint16_t)(int16_t)-wi << 16));
-            t->b[d][q] = (int32_t)((uint32_t)(uint16_t)wi | ((uint32_t)(uint16_t)wr << 16));
-        }
+    for (int q = 0; q < 128; q++) {
+        const int16_t wr = sin1024[4 * q + 256], sn = sin1024[4 * q];
+        t->a[q] = (int32_t)((uint32_t)(uint16_t)wr | ((uint32_t)(uint16_t)sn << 16));
+        t->b[q] = (int32_t)((uint32_t)(uint16_t)(int16_t)-sn | ((uint32_t)(uint16_t)wr << 16));
+    }
 }
 
 typedef short spl_v2s __attribute__((ext_vector_type(2)));
@@ -108,7 +132,6 @@ __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
 template <int STAGES, bool INVERSE>
 __device__ int spl_cfft(int32_t *cx, const SplTwiddles &T, int lane) {
     constexpr int N = 1 << STAGES, PER = N / 128 > 0 ? N / 128 : 1;  // butterflies per lane and stage
-    const int32_t *ta = T.a[INVERSE ? 1 : 0], *tb = T.b[INVERSE ? 1 : 0];
     int scale = 0;
     uint32_t mag = 0;  // packed running maximum of |re|, |im| of this lane's values (INVERSE only)
     if (INVERSE) {
@@ -134,12 +157,10 @@ __device__ int spl_cfft(int32_t *cx, const SplTwiddles &T, int lane) {
                 const int m = b & (l - 1), i = 2 * b - m, j = i + l;  // i = (b >> s << (s + 1)) + m
                 const int q = m << (7 - s);                            // table position j0 / 4, j0 = m << (9 - s)
                 const int32_t xi = cx[i], xj = cx[j];
-#ifdef WMX_FFT_NODOT
-                const int32_t wa = ta[q], jr = lo16(xj), ji = hi16(xj);
-                const int32_t tr = (lo16(wa) * jr + hi16(wa) * ji + 1) >> 1, ti = (lo16(wa) * ji - hi16(wa) * jr + 1) >> 1;
-#else
-                const int32_t tr = dot2_i16(xj, ta[q], 1) >> 1, ti = dot2_i16(xj, tb[q], 1) >> 1;
-#endif
+                const int32_t fa = T.a[q], fb = T.b[q];
+                const int32_t wa = INVERSE ? (int32_t)__builtin_amdgcn_alignbit((uint32_t)fb, (uint32_t)fb, 16) : fa;
+                const int32_t wb = INVERSE ? (int32_t)__builtin_amdgcn_alignbit((uint32_t)fa, (uint32_t)fa, 16) : fb;
+                const int32_t tr = dot2_i16(xj, wa, 1) >> 1, ti = dot2_i16(xj, wb, 1) >> 1;
                 const int32_t qr = (int32_t)((uint32_t)xi << 16) >> 2, qi = (int32_t)((uint32_t)xi & 0xffff0000u) >> 2;  // re << 14, im << 14
                 const int sh = shift + 14;
                 const int32_t o_j = (int32_t)__builtin_amdgcn_perm((uint32_t)((qi - ti + round2) >> sh), (uint32_t)((qr - tr + round2) >> sh), 0x05040100u);
