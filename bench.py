@@ -992,7 +992,9 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "traffic_source": traffic_src,
                     "avg_launch_ms": round(dom_ms, 5),
-                    "algorithmic_bytes_per_launch": wl.dominant_bytes_per_frame * wl.n_frames}
+                    "algorithmic_bytes_per_launch": wl.dominant_bytes_per_frame * wl.n_frames,
+                    # what actually bounds the per-stream DSP kernels: vector-ALU issue (see _pmc_issue)
+                    "valu_issue": _pmc_issue(wl.dominant_kernel, wl.n_frames, getattr(wl, "pmc_tag", "chain"), dom_ms)}
     if roofline is None and getattr(wl, "name", "") == "rtp_chain_8k_pcma":
         step_ms = elapsed / args.steps * 1e3
         achieved = wl.bytes_per_frame * wl.n_frames / (step_ms * 1e-3) / 1e9
@@ -1050,6 +1052,30 @@ def _pmc_traffic(kernel, n_frames, tag="chain"):
         except Exception:
             continue
     return None, None
+
+
+def _pmc_issue(kernel, n_frames, tag, launch_ms):
+    """Vector-ALU issue floor of `kernel` from the committed SQ_INSTS_VALU count (profiles/rNN/<tag>_sq_pmc.json, same
+    command and stream count): a wave64 VALU instruction occupies its SIMD for 4 cycles, the chip has 256 CUs x 4 SIMDs at
+    2.4 GHz (MI355X_MICROARCH.md), so floor = insts x 4 / (1024 x 2.4e9).  `frac` = floor / the launch time measured in
+    this run: how close the kernel is to issuing a vector instruction on every SIMD every cycle.  None without a profile."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    for path in sorted(glob.glob(os.path.join(here, "profiles", "r*", tag + "_sq_pmc.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            hbm = json.load(open(path.replace("_sq_pmc.json", "_hbm_pmc.json")))
+            if hbm.get("n_frames_per_launch") != n_frames:
+                continue
+            base = kernel.split("<")[0]
+            hit = [v for k, v in d.items() if k.split("<")[0] == base]
+            insts = hit[0]["mean"]["SQ_INSTS_VALU"]
+            floor_ms = insts * 4 / (1024 * 2.4e9) * 1e3
+            return {"valu_insts_per_frame": round(insts / n_frames, 1), "floor_ms": round(floor_ms, 5),
+                    "frac": round(floor_ms / launch_ms, 4), "source": os.path.relpath(path, here)}
+        except Exception:
+            continue
+    return None
 
 
 if __name__ == "__main__":
