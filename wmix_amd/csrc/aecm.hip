@@ -74,7 +74,7 @@ enum AecmLayout : int {
     A_NOISE_EST = A_ECHO_FILT + 68,     // int32[68]
     A_MEAN_NEAR = A_NOISE_EST + 68,     // int32[32] mean_near_spectrum of bins 12..43
     A_MEAN_BITS = A_MEAN_NEAR + 32,     // int32[104] mean_bit_counts
-    A_SCAL = A_MEAN_BITS + 104,         // 34 scalar words
+    A_SCAL = A_MEAN_BITS + 104,         // 34 scalar words (M_COUNT used), read in place through LdsScal
     A_WORDS = A_SCAL + 34
 };
 static_assert(A_WORDS % 4 == 0, "16-byte state copies");

@@ -15,8 +15,9 @@
 // (three increments per frame, a full scan every 512 blocks).  The FFT is the reference's own dataflow -- bit reversal,
 // then one radix-2 pass per stage with its per-stage rounding and, in the inverse, its data-dependent shift from the
 // largest |value| of the whole array -- on packed int16 pairs in LDS, two butterflies per lane and stage.
-// Per-stream scalars are wave-uniform (results of wave reductions are moved to SGPRs with readfirstlane), so the
-// start-up phases, the zero-input path and the 512-block threshold update never diverge inside a wave.
+// Per-stream scalars are wave-uniform (read from the LDS state block through readfirstlane where they are used; results
+// of wave reductions likewise), so the start-up phases, the zero-input path and the 512-block threshold update never
+// diverge inside a wave.
 //
 // Integer path: bit-exact against the reference (tests/test_nsx_gpu.py).
 #include <vector>
@@ -200,7 +201,7 @@ __device__ void two_peaks(const int16_t *hist, int lane, uint32_t &pos1, int &w1
 
 // ---------------------------------------------------------------- one 10 ms block of one stream (ProcessCore)
 // in0 / out0: low band (channel 0), in1 / out1: the "high band" (channel 1 of a 2-channel stream);
-// element stride CHN.  sc[]: the stream's scalars, wave-uniform registers.
+// element stride CHN.  sc[]: the stream's scalars in its LDS state block, read wave-uniformly where used (LdsScal, spl_fx.h).
 template <int ANA, int CHN>
 __device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsScal sc, int16_t *hist, const int16_t *in, int16_t *out,
                           int lane, int overdrive, int denoise_bound) {
