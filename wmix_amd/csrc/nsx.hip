@@ -39,7 +39,7 @@ namespace {
 #endif
 template <int ANA, int CHN>
 struct NsxShape {
-    static constexpr int WPB = WMX_NSX_WPB, WPE = ANA == 256 ? 5 : 6;
+    static constexpr int WPB = WMX_NSX_WPB, WPE = ANA == 256 ? (CHN == 1 ? 5 : 4) : 6;  // 16 kHz 2-channel: 34 416 B of LDS, 4 workgroups
 };
 constexpr int kNsxHist = 1000;  // HIST_PAR_EST, nsx_defines.h:45
 
