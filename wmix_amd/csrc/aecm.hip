@@ -140,7 +140,7 @@ __device__ int time_to_freq(AecmWave &W, const AecmConsts &K, int lane, int32_t 
         W.cx[bitrev<7>(i)] = (int32_t)(uint16_t)(int16_t)((s * w) >> 14);
     }
     wave_sync();
-    spl_cfft<7, false>(W.cx, K.tw, lane);
+    spl_cfft<7, false, true>(W.cx, K.tw, lane);
     uint32_t part = 0;
     for (int b = lane; b < 65; b += 64) {
         const int32_t x = W.cx[b];
@@ -298,12 +298,7 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
                 vmax = m > vmax ? m : vmax;
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const uint32_t w = (uint32_t)__shfl_xor((int)kmin, o, 64);
-            kmin = w < kmin ? w : kmin;
-        }
-        kmin = (uint32_t)uni((int)kmin);
+        kmin = wave_umin(kmin);
         vmax = wave_max(vmax);
         int32_t best = (int32_t)(kmin >> 8);
         int candidate = (int)(kmin & 0xff);
@@ -359,7 +354,7 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
             int16_t tv = (int16_t)(2560 - e_min);
             tv = tv > 0 ? (int16_t)((tv * 230) >> 9) : (int16_t)0;
             tv = (int16_t)(tv + 230);
-            if ((sc[M_STARTUP] == 0) | (sc[M_VAD_UPD] > 1024)) {
+            if ((int)(sc[M_STARTUP] == 0) | (int)(sc[M_VAD_UPD] > 1024)) {
                 e_vad = (int16_t)(e_min + tv);
             } else if (e_vad > far_log) {
                 e_vad = (int16_t)(e_vad + ((far_log + tv - e_vad) >> 6));
@@ -373,7 +368,7 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
             sc[M_E_VAD] = e_vad;
         }
         if (far_log > e_vad) {
-            if ((sc[M_STARTUP] == 0) | (sc[M_E_MAXMIN] > 929)) sc[M_CUR_VAD] = 1;
+            if ((int)(sc[M_STARTUP] == 0) | (int)(sc[M_E_MAXMIN] > 929)) sc[M_CUR_VAD] = 1;
         } else {
             sc[M_CUR_VAD] = 0;
         }
@@ -460,7 +455,7 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
         wave_sync();
     }
     int store = 0, reset = 0;
-    if ((sc[M_STARTUP] == 0) & (sc[M_CUR_VAD] != 0)) {
+    if ((int)(sc[M_STARTUP] == 0) & (int)(sc[M_CUR_VAD] != 0)) {
         store = 1;
     } else {
         if (sc[M_FAR_LOG] < sc[M_E_MSE])
@@ -479,7 +474,7 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
             const int32_t mse_stored = (int32_t)wave_sum(ms), mse_adapt = (int32_t)wave_sum(ma);
             if (((mse_stored << 5) < (29 * mse_adapt)) & (wshl(sc[M_MSE_STORED_OLD], 5) < wmul(29, sc[M_MSE_ADAPT_OLD]))) {
                 reset = 1;
-            } else if (((29 * mse_stored) > (mse_adapt << 5)) & (mse_adapt < sc[M_MSE_THR]) & (sc[M_MSE_ADAPT_OLD] < sc[M_MSE_THR])) {
+            } else if ((int)((29 * mse_stored) > (mse_adapt << 5)) & (int)(mse_adapt < sc[M_MSE_THR]) & (int)(sc[M_MSE_ADAPT_OLD] < sc[M_MSE_THR])) {
                 store = 1;
                 if (sc[M_MSE_THR] == 0x7FFFFFFF) {
                     sc[M_MSE_THR] = wadd(mse_adapt, sc[M_MSE_ADAPT_OLD]);
@@ -634,7 +629,7 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
         sc[M_SEED] = (int32_t)((K.lcg_a[63] * seed + K.lcg_c[63]) & 0x7FFFFFFFu);
         // bin b uses draw b - 1: lane b takes the draw of the lane below, and lane 0 -- which owns bin 64 in the second
         // pass -- that of lane 63 (the exchange sits outside the per-bin loop: every lane must take part in it)
-        const uint32_t prev_draw = (uint32_t)__shfl((int)my_draw, (lane + 63) & 63, 64);
+        const uint32_t prev_draw = (uint32_t)dpp_rows<0x13C>((int)my_draw);  // wave_ror:1 -- lane b takes lane b - 1, lane 0 lane 63
         for (int b = lane; b < 65; b += 64) {
             const int32_t v = wshl((int32_t)W.dfa[b], shift);
             int32_t ne = noise_est[b];
@@ -696,7 +691,7 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
         if (b > 0 && b < 64) W.cx[bitrev<7>(128 - b)] = pack16(re, (int16_t)-nim);
     }
     wave_sync();
-    const int out_scale = spl_cfft<7, true>(W.cx, K.tw, lane);
+    const int out_scale = spl_cfft<7, true, true>(W.cx, K.tw, lane);
     {
         const int i = lane;
         const int16_t a = (int16_t)(((int32_t)lo16(W.cx[i]) * K.sqrt_hanning[i] + 8192) >> 14);

@@ -18,34 +18,59 @@ __device__ __forceinline__ int norm_w16(int16_t a) {
 __device__ __forceinline__ int32_t mul_rsft_round(int16_t a, int16_t b, int c) { return ((int32_t)a * b + ((int32_t)1 << (c - 1))) >> c; }
 __device__ __forceinline__ uint32_t div_u32_u16(uint32_t num, uint16_t den) { return den ? num / den : 0xFFFFFFFFu; }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Wave reductions on the DPP path: four in-row steps (lane ^ 1, lane ^ 2, the two mirrors -- after each step the lanes
+// that are combined next already agree, so mirrors serve as the xor 4 / xor 8 exchanges) leave every 16-lane row holding
+// its row's result; the four rows meet in scalar registers.  No LDS-crossbar traffic (`__shfl_xor` = ds_bpermute_b32, six
+// dependent round trips per reduction), and the result is wave-uniform by construction.  Integer sums wrap, max / min are
+// exact: the order of combination does not matter.
+template <int CTRL>
+__device__ __forceinline__ int dpp_rows(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+// (the exchanged value goes into a temporary first: written as `dpp(v) > v ? dpp(v) : v` the compiler evaluates the
+// second DPP move under the comparison's lane mask, where a disabled source lane leaves the destination untouched)
+#define WMX_ROW_REDUCE(v, OP)                                                          \
+    do {                                                                               \
+        decltype(v) o_;                                                                \
+        o_ = (decltype(v))dpp_rows<0xB1>((int)v), v = OP(v, o_);  /* quad_perm [1,0,3,2] */ \
+        o_ = (decltype(v))dpp_rows<0x4E>((int)v), v = OP(v, o_);  /* quad_perm [2,3,0,1] */ \
+        o_ = (decltype(v))dpp_rows<0x141>((int)v), v = OP(v, o_); /* row_half_mirror */     \
+        o_ = (decltype(v))dpp_rows<0x140>((int)v), v = OP(v, o_); /* row_mirror */          \
+    } while (0)
+#define WMX_OP_ADD(a, b) ((a) + (b))
+#define WMX_OP_MAX(a, b) ((b) > (a) ? (b) : (a))
+#define WMX_OP_MIN(a, b) ((b) < (a) ? (b) : (a))
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
-    return (uint32_t)uni((int)v);
+    WMX_ROW_REDUCE(v, WMX_OP_ADD);
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ int32_t wave_max(int32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const int32_t w = __shfl_xor(v, o, 64);
-        v = w > v ? w : v;
-    }
-    return uni(v);
+    WMX_ROW_REDUCE(v, WMX_OP_MAX);
+    const int32_t r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const int32_t r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    const int32_t a = r1 > r0 ? r1 : r0, b = r3 > r2 ? r3 : r2;
+    return b > a ? b : a;
 }
 __device__ __forceinline__ uint32_t wave_umax(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t w = (uint32_t)__shfl_xor((int)v, o, 64);
-        v = w > v ? w : v;
-    }
-    return (uint32_t)uni((int)v);
+    WMX_ROW_REDUCE(v, WMX_OP_MAX);
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    const uint32_t a = r1 > r0 ? r1 : r0, b = r3 > r2 ? r3 : r2;
+    return b > a ? b : a;
+}
+__device__ __forceinline__ uint32_t wave_umin(uint32_t v) {
+    WMX_ROW_REDUCE(v, WMX_OP_MIN);
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    const uint32_t a = r1 < r0 ? r1 : r0, b = r3 < r2 ? r3 : r2;
+    return b < a ? b : a;
 }
 __device__ __forceinline__ int32_t wave_min(int32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const int32_t w = __shfl_xor(v, o, 64);
-        v = w < v ? w : v;
-    }
-    return uni(v);
+    WMX_ROW_REDUCE(v, WMX_OP_MIN);
+    const int32_t r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const int32_t r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    const int32_t a = r1 < r0 ? r1 : r0, b = r3 < r2 ? r3 : r2;
+    return b < a ? b : a;
 }
 __device__ __forceinline__ int wave_any(int p) { return __builtin_amdgcn_ballot_w64(p != 0) != 0; }
 
@@ -95,14 +120,19 @@ struct LdsScal {
 // is table position j = 4 q (a 256-point transform uses every entry, a 128-point one every second).  Only the forward
 // pair is stored: with s = kSinTable1024[j] it is A = (wr, s), B = (-s, wr), and the inverse pair A' = (wr, -s),
 // B' = (s, wr) is B and A with their halves exchanged (one v_alignbit each).
+// One word of padding follows every 32 entries: stage s reads entries m << (7 - s), a stride that is a multiple of the
+// bank count in the early stages -- with the padding the distinct entries of a stage fall into distinct banks.
 struct SplTwiddles {
-    int32_t a[128], b[128];
+    static constexpr int kEntries = 128 + 128 / 32;
+    int32_t a[kEntries], b[kEntries];
+    __host__ __device__ static constexpr int slot(int q) { return q + (q >> 5); }
 };
 inline void spl_twiddles(const int16_t *sin1024, SplTwiddles *t) {
+    for (int i = 0; i < SplTwiddles::kEntries; i++) t->a[i] = t->b[i] = 0;
     for (int q = 0; q < 128; q++) {
         const int16_t wr = sin1024[4 * q + 256], sn = sin1024[4 * q];
-        t->a[q] = (int32_t)((uint32_t)(uint16_t)wr | ((uint32_t)(uint16_t)sn << 16));
-        t->b[q] = (int32_t)((uint32_t)(uint16_t)(int16_t)-sn | ((uint32_t)(uint16_t)wr << 16));
+        t->a[SplTwiddles::slot(q)] = (int32_t)((uint32_t)(uint16_t)wr | ((uint32_t)(uint16_t)sn << 16));
+        t->b[SplTwiddles::slot(q)] = (int32_t)((uint32_t)(uint16_t)(int16_t)-sn | ((uint32_t)(uint16_t)wr << 16));
     }
 }
 
@@ -129,7 +159,7 @@ __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
 // lane + 64 when N = 256) of every stage.  INVERSE: the stage's extra shift (0..2 bits) comes from the largest |value| of
 // the whole array (complex_fft.c:170-186): found once by a scan before the first stage, afterwards carried along from
 // the values each lane has just produced.  Returns the number of one-bit shifts applied (WebRtcSpl_ComplexIFFT's result).
-template <int STAGES, bool INVERSE>
+template <int STAGES, bool INVERSE, bool UNROLL = false>
 __device__ int spl_cfft(int32_t *cx, const SplTwiddles &T, int lane) {
     constexpr int N = 1 << STAGES, PER = N / 128 > 0 ? N / 128 : 1;  // butterflies per lane and stage
     int scale = 0;
@@ -137,7 +167,11 @@ __device__ int spl_cfft(int32_t *cx, const SplTwiddles &T, int lane) {
     if (INVERSE) {
         for (int i = lane; i < N; i += 64) mag = pk_max_u16(mag, pk_abs16(cx[i]));
     }
-#pragma unroll 1  // unrolled, the three transforms of the AECM block push its kernel past the 64 KB instruction cache
+    // UNROLL: the stages as straight-line code (shift counts and strides become immediates).  Worth 6 % to the AECM block
+    // (three 128-point transforms, +6 KB of code) once its kernel had shrunk to 26 KB; at 70 KB the same unrolling pushed it
+    // further past the 64 KB instruction cache and cost 20 %; the 256-point NSX transforms (two butterflies per lane) spill.
+    constexpr int kUnroll = UNROLL ? STAGES : 1;
+#pragma unroll kUnroll
     for (int s = 0; s < STAGES; s++) {
         const int l = 1 << s;
         int shift = INVERSE ? 0 : 1;
@@ -157,7 +191,7 @@ __device__ int spl_cfft(int32_t *cx, const SplTwiddles &T, int lane) {
                 const int m = b & (l - 1), i = 2 * b - m, j = i + l;  // i = (b >> s << (s + 1)) + m
                 const int q = m << (7 - s);                            // table position j0 / 4, j0 = m << (9 - s)
                 const int32_t xi = cx[i], xj = cx[j];
-                const int32_t fa = T.a[q], fb = T.b[q];
+                const int32_t fa = T.a[SplTwiddles::slot(q)], fb = T.b[SplTwiddles::slot(q)];
                 const int32_t wa = INVERSE ? (int32_t)__builtin_amdgcn_alignbit((uint32_t)fb, (uint32_t)fb, 16) : fa;
                 const int32_t wb = INVERSE ? (int32_t)__builtin_amdgcn_alignbit((uint32_t)fa, (uint32_t)fa, 16) : fb;
                 const int32_t tr = dot2_i16(xj, wa, 1) >> 1, ti = dot2_i16(xj, wb, 1) >> 1;
