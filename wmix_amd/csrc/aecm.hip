@@ -140,7 +140,7 @@ __device__ int time_to_freq(AecmWave &W, const AecmConsts &K, int lane, int32_t 
         W.cx[bitrev<7>(i)] = (int32_t)(uint16_t)(int16_t)((s * w) >> 14);
     }
     wave_sync();
-    spl_cfft<7, false, true>(W.cx, K.tw, lane);
+    spl_cfft128<false>(W.cx, K.tw, lane);
     uint32_t part = 0;
     for (int b = lane; b < 65; b += 64) {
         const int32_t x = W.cx[b];
@@ -691,7 +691,7 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
         if (b > 0 && b < 64) W.cx[bitrev<7>(128 - b)] = pack16(re, (int16_t)-nim);
     }
     wave_sync();
-    const int out_scale = spl_cfft<7, true, true>(W.cx, K.tw, lane);
+    const int out_scale = spl_cfft128<true>(W.cx, K.tw, lane);
     {
         const int i = lane;
         const int16_t a = (int16_t)(((int32_t)lo16(W.cx[i]) * K.sqrt_hanning[i] + 8192) >> 14);

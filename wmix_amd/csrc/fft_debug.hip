@@ -97,7 +97,10 @@ __global__ __launch_bounds__(64) void dbg_spl_fft(const SplTwiddles *__restrict_
     if (!INV) {  // real_fft.c:46-70
         for (int i = lane; i < N; i += 64) cx[bitrev<ORDER>(i)] = (int32_t)(uint16_t)x[i];
         wave_sync();
-        spl_cfft<ORDER, false>(cx, S, lane);
+        if constexpr (ORDER == 7)
+            spl_cfft128<false>(cx, S, lane);
+        else
+            spl_cfft<ORDER, false>(cx, S, lane);
         for (int i = lane; i <= N / 2; i += 64) {
             x[2 * i] = lo16(cx[i]);
             x[2 * i + 1] = hi16(cx[i]);
@@ -109,7 +112,11 @@ __global__ __launch_bounds__(64) void dbg_spl_fft(const SplTwiddles *__restrict_
             if (b > 0 && b < N / 2) cx[bitrev<ORDER>(N - b)] = pack16(re, (int16_t)-im);
         }
         wave_sync();
-        const int sc = spl_cfft<ORDER, true>(cx, S, lane);
+        int sc;
+        if constexpr (ORDER == 7)
+            sc = spl_cfft128<true>(cx, S, lane);
+        else
+            sc = spl_cfft<ORDER, true>(cx, S, lane);
         for (int i = lane; i < N; i += 64) x[i] = lo16(cx[i]);
         if (lane == 0) aux[blockIdx.x] = sc;
     }

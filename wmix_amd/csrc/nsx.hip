@@ -30,7 +30,7 @@ namespace {
 
 // Workgroup shape: waves (= streams) per workgroup, and the occupancy the register budget is set for.  Four waves and
 // 32 368 B of LDS per workgroup (16 kHz mono: 7 128 B per stream + 3.8 KB of tables) let five workgroups share a CU's
-// 160 KB -- 5 waves per SIMD; the 8 kHz formats fit 8 workgroups and are register-limited to 6 per SIMD.
+// 160 KB -- 5 waves per SIMD; the 8 kHz formats fit 8 workgroups and are register-limited to 5 per SIMD.
 // A workgroup's waves are dealt round-robin to the CU's four SIMDs starting at the same one, so a wave count that is not a
 // multiple of 4 piles the surplus on SIMD 0 and the CU stops accepting workgroups early: 5-, 9- and 10-wave workgroups
 // (sized to fill the LDS with 15 / 18 / 20 waves) all ran at 10 waves per CU, 0.65-0.73 ms against 0.455 ms for 4 x 4.
@@ -39,7 +39,7 @@ namespace {
 #endif
 template <int ANA, int CHN>
 struct NsxShape {
-    static constexpr int WPB = WMX_NSX_WPB, WPE = ANA == 256 ? (CHN == 1 ? 5 : 4) : 6;  // 16 kHz 2-channel: 34 416 B of LDS, 4 workgroups
+    static constexpr int WPB = WMX_NSX_WPB, WPE = ANA == 256 && CHN == 2 ? 4 : 5;  // 16 kHz 2-channel: 34 KB of LDS, 4 workgroups
 };
 constexpr int kNsxHist = 1000;  // HIST_PAR_EST, nsx_defines.h:45
 
@@ -280,7 +280,10 @@ __device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsSca
             for (int r = 0; r < ANA / 64; r++) W.cx[bitrev<STAGES>(lane + 64 * r)] = (int32_t)(uint16_t)(int16_t)wshl(tv[r], norm_data);
         }
         wave_sync();
-        spl_cfft<STAGES, false>(W.cx, K.tw, lane);
+        if constexpr (STAGES == 7)
+            spl_cfft128<false>(W.cx, K.tw, lane);
+        else
+            spl_cfft<STAGES, false>(W.cx, K.tw, lane);
         // spectrum, magnitudes, sums (:1231-1264 / :1266-1328)
         const bool startup = sc[X_BLOCK_INDEX] < 50;  // the previous block's index: it is advanced below
         uint32_t e_sum = 0, m_sum = 0;
@@ -900,7 +903,11 @@ __device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsSca
             if (b > 0 && b < H) W.cx[bitrev<STAGES>(ANA - b)] = pack16(re, (int16_t) - (int16_t)-im);
         }
         wave_sync();
-        const int out_scale = spl_cfft<STAGES, true>(W.cx, K.tw, lane);
+        int out_scale;
+        if constexpr (STAGES == 7)
+            out_scale = spl_cfft128<true>(W.cx, K.tw, lane);
+        else
+            out_scale = spl_cfft<STAGES, true>(W.cx, K.tw, lane);
         {
             int16_t tv[ANA / 64];
 #pragma unroll

@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <type_traits>
 #include "spl_dev.h"
 #include "fft_ooura.h"  // wave_sync()
 
@@ -208,6 +209,85 @@ __device__ int spl_cfft(int32_t *cx, const SplTwiddles &T, int lane) {
     }
     return scale;
 }
+// ---------------------------------------------------------------- the 128-point transform without LDS between stages
+// Lane L holds the two points of ITS butterfly of the current stage, (u, v) = points (i, i + 2^s) with i = L with a zero
+// bit inserted at position s.  After the butterfly, the pairing of stage s + 1 is a 2 x 2 transpose between the lanes that
+// differ in bit s: the lane with the bit clear keeps its u and takes the partner's u as its new v, the lane with the bit
+// set keeps its v and takes the partner's v as its new u -- one v_permlane32_swap / v_permlane16_swap for lane bits 5 / 4,
+// two bank-masked row rotations for bits 3 / 2, two quad permutes + two selects for bits 1 / 0.  LDS is touched once on the
+// way in (one 8-byte read per lane) and once on the way out; the arithmetic is that of spl_cfft, operation for operation.
+template <int BIT>
+__device__ __forceinline__ void spl_xchg(int32_t &u, int32_t &v, int lane) {
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    if constexpr (BIT == 5) {
+        const v2u r = __builtin_amdgcn_permlane32_swap((unsigned)u, (unsigned)v, false, false);
+        u = (int32_t)r.x, v = (int32_t)r.y;
+    } else if constexpr (BIT == 4) {
+        const v2u r = __builtin_amdgcn_permlane16_swap((unsigned)u, (unsigned)v, false, false);
+        u = (int32_t)r.x, v = (int32_t)r.y;
+    } else if constexpr (BIT == 3) {
+        const int32_t nu = __builtin_amdgcn_update_dpp(u, v, 0x128, 0xf, 0xC, false);  // row_ror:8, lanes 8-15: v of lane - 8
+        const int32_t nv = __builtin_amdgcn_update_dpp(v, u, 0x128, 0xf, 0x3, false);  //            lanes 0-7:  u of lane + 8
+        u = nu, v = nv;
+    } else if constexpr (BIT == 2) {
+        const int32_t nu = __builtin_amdgcn_update_dpp(u, v, 0x124, 0xf, 0xA, false);  // row_ror:4,  lanes 4-7, 12-15: v of lane - 4
+        const int32_t nv = __builtin_amdgcn_update_dpp(v, u, 0x12C, 0xf, 0x5, false);  // row_ror:12, lanes 0-3, 8-11:  u of lane + 4
+        u = nu, v = nv;
+    } else {
+        constexpr int kCtrl = BIT == 1 ? 0x4E : 0xB1;  // quad_perm [2,3,0,1] / [1,0,3,2]
+        const int32_t pu = dpp_rows<kCtrl>(u), pv = dpp_rows<kCtrl>(v);
+        const bool set = (lane >> BIT) & 1;
+        u = set ? pv : u;
+        v = set ? v : pu;
+    }
+}
+
+template <bool INVERSE>
+__device__ int spl_cfft128(int32_t *cx, const SplTwiddles &T, int lane) {
+    int scale = 0;
+    int32_t u, v;
+    {
+        const int2 uv = *reinterpret_cast<const int2 *>(cx + 2 * lane);  // bit-reversed order on entry: stage 0 pairs (2 L, 2 L + 1)
+        u = uv.x, v = uv.y;
+    }
+    uint32_t mag = INVERSE ? pk_max_u16(pk_abs16(u), pk_abs16(v)) : 0u;
+    auto stage = [&](auto S_) {
+        constexpr int s = decltype(S_)::value, l = 1 << s;
+        int shift = INVERSE ? 0 : 1;
+        int32_t round2 = INVERSE ? 8192 : 16384;
+        if (INVERSE) {
+            uint32_t m16 = (mag & 0xffffu) > (mag >> 16) ? (mag & 0xffffu) : (mag >> 16);
+            int32_t mx = wave_max((int32_t)m16);
+            if (mx > 32767) mx = 32767;
+            if (mx > 13573) shift++, scale++, round2 <<= 1;
+            if (mx > 27146) shift++, scale++, round2 <<= 1;
+        }
+        const int q = (lane & (l - 1)) << (7 - s);
+        const int32_t fa = T.a[SplTwiddles::slot(q)], fb = T.b[SplTwiddles::slot(q)];
+        const int32_t wa = INVERSE ? (int32_t)__builtin_amdgcn_alignbit((uint32_t)fb, (uint32_t)fb, 16) : fa;
+        const int32_t wb = INVERSE ? (int32_t)__builtin_amdgcn_alignbit((uint32_t)fa, (uint32_t)fa, 16) : fb;
+        const int32_t tr = dot2_i16(v, wa, 1) >> 1, ti = dot2_i16(v, wb, 1) >> 1;
+        const int32_t qr = (int32_t)((uint32_t)u << 16) >> 2, qi = (int32_t)((uint32_t)u & 0xffff0000u) >> 2;  // re << 14, im << 14
+        const int sh = shift + 14;
+        v = (int32_t)__builtin_amdgcn_perm((uint32_t)((qi - ti + round2) >> sh), (uint32_t)((qr - tr + round2) >> sh), 0x05040100u);
+        u = (int32_t)__builtin_amdgcn_perm((uint32_t)((qi + ti + round2) >> sh), (uint32_t)((qr + tr + round2) >> sh), 0x05040100u);
+        if (INVERSE && s < 6) mag = pk_max_u16(pk_abs16(u), pk_abs16(v));
+        if constexpr (s < 6) spl_xchg<s>(u, v, lane);
+    };
+    stage(std::integral_constant<int, 0>{});
+    stage(std::integral_constant<int, 1>{});
+    stage(std::integral_constant<int, 2>{});
+    stage(std::integral_constant<int, 3>{});
+    stage(std::integral_constant<int, 4>{});
+    stage(std::integral_constant<int, 5>{});
+    stage(std::integral_constant<int, 6>{});
+    wave_sync();  // every lane's read of the input precedes the stores below (also in the compiler's eyes)
+    cx[lane] = u;  // after the last stage lane L holds points L and L + 64
+    cx[lane + 64] = v;
+    wave_sync();
+    return scale;
+}
+
 template <int STAGES>
 __device__ __forceinline__ int bitrev(int i) { return (int)(__brev((unsigned)i) >> (32 - STAGES)); }
 
