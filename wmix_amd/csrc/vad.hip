@@ -65,6 +65,21 @@ struct VadRef {
     __device__ __forceinline__ int16_t &hm(int f) const { return minbuf[(f - V16_AGE) * 64]; }
 };
 
+#ifdef WMX_VAD_PROF  // developer build only (make EXTRA=-DWMX_VAD_PROF): cycles per phase of the kernel, summed over waves
+__device__ unsigned long long g_vad_prof[16];
+__shared__ long long g_t_prev;
+#define VAD_PROF(i)                                                                        \
+    do {                                                                                   \
+        if (threadIdx.x == 0) {                                                            \
+            const long long t_now = clock64();                                             \
+            atomicAdd(&g_vad_prof[i], (unsigned long long)(t_now - g_t_prev));             \
+            g_t_prev = clock64();                                                          \
+        }                                                                                  \
+    } while (0)
+#else
+#define VAD_PROF(i)
+#endif
+
 // LDS int16 buffer private to one lane: element i lives at base[i * 64]
 struct LaneBuf {
     int16_t *base;
@@ -277,11 +292,13 @@ __device__ int16_t gmm_probability(const VadRef &S, const int16_t *feat, int16_t
             }
         }
         vadflag |= (sum_llr >= glob);
+        VAD_PROF(4);  // gaussian probabilities
         const int32_t frame_counter = S.w(V32_FRAME_COUNTER);
         int16_t maxspe = 12800;
 #pragma unroll
         for (int c = 0; c < 6; c++) {
             const int16_t fmin = find_minimum(S, feat[c], c, frame_counter);
+            VAD_PROF(5);  // find_minimum
             int32_t ngm = weighted_avg(S, V16_NOISE_MEANS, c, 0, kNoiseW);
             const int16_t t1 = (int16_t)(ngm >> 6);
 #pragma unroll
@@ -368,6 +385,7 @@ __device__ int16_t gmm_probability(const VadRef &S, const int16_t *feat, int16_t
 #pragma unroll
                 for (int k = 0; k < 2; k++) S.h(V16_NOISE_MEANS + c + 6 * k) = (int16_t)(S.h(V16_NOISE_MEANS + c + 6 * k) - t2);
             }
+            VAD_PROF(6);  // model update
         }
         S.w(V32_FRAME_COUNTER) = frame_counter + 1;
     }
@@ -460,6 +478,7 @@ __device__ __forceinline__ int vad_packet(const VadRef &S, const Src p, LaneBuf 
             S.w(V32_DS + 3) = d3;
         }
     }
+    VAD_PROF(2);  // decimation + first split
     // ---- rest of WebRtcVad_CalculateFeatures (vad_filterbank.c:272-332)
     int16_t feat[6], total = 0;
     auto do_split = [&](LaneBuf in, int len, int band, LaneBuf hp, LaneBuf lp) {
@@ -499,6 +518,7 @@ __device__ __forceinline__ int vad_packet(const VadRef &S, const Src p, LaneBuf 
         S.h(V16_HP + 3) = s3;
     }
     log_energy(hp120, NB / 16, 368, total, feat[0]);
+    VAD_PROF(3);  // remaining splits + log energies
     const int v = gmm_probability(S, feat, total, NB == 80 ? 0 : (NB == 160 ? 1 : 2));
     return v > 0 ? 1 : v;
 }
@@ -516,6 +536,9 @@ __global__ __launch_bounds__(64) void vad_kernel(int16_t *s16, int32_t *s32, int
     const VadRef S{r16, r32, minlds + lane};
     const int16_t *g16 = s16 + stream;
     const int32_t *g32 = s32 + stream;
+#ifdef WMX_VAD_PROF
+    if (threadIdx.x == 0) g_t_prev = clock64();
+#endif
     // state in: every row requested before the first one is used (coalesced: field-major rows)
 #pragma unroll
     for (int f = 0; f < V16_AGE; f++) r16[f] = g16[(size_t)f * n_streams];
@@ -534,6 +557,7 @@ __global__ __launch_bounds__(64) void vad_kernel(int16_t *s16, int32_t *s32, int
         for (int i = 0; i < n_i16; i += 32) touch_line(row + i, sink);
     }
     touch_done(sink);  // one HBM round trip for everything, instead of one per field along the chain
+    VAD_PROF(0);  // state in
     const LaneBuf hp120{lds + lane}, lp120{lds + lane + 64 * (NB / 2)}, hp60{lds + lane + 64 * NB},
         lp60{lds + lane + 64 * (NB + NB / 4)};
     constexpr int PKG = NB * RATIO;  // frames (mono samples) per packet at the stream's rate
@@ -554,6 +578,7 @@ __global__ __launch_bounds__(64) void vad_kernel(int16_t *s16, int32_t *s32, int
 #pragma unroll
             for (int j = 0; j < NV; j++) raw[j] = frame4[j];
             int reduce = S.h(V16_REDUCE);
+            VAD_PROF(1);  // packet in (issue only: the loads are consumed inside the first loop)
             const int r = vad_packet<NB, RATIO>(S, RegSrc<NV>{raw}, hp120, lp120, hp60, lp60);
             if (r == 0) {
                 if (reduce < 4) reduce += 1;
@@ -567,6 +592,7 @@ __global__ __launch_bounds__(64) void vad_kernel(int16_t *s16, int32_t *s32, int
 #pragma unroll
             for (int j = 0; j < NV; j++) frame4[j] = make_uint4(att(raw[j].x), att(raw[j].y), att(raw[j].z), att(raw[j].w));
             S.h(V16_REDUCE) = (int16_t)reduce;
+            VAD_PROF(7);  // hangover + attenuate + packet out
         }
         }
     }
@@ -611,7 +637,19 @@ __global__ __launch_bounds__(64) void vad_kernel(int16_t *s16, int32_t *s32, int
 #pragma unroll 8
         for (int f = 0; f < kVadMinFields; f++) o16[(size_t)(V16_AGE + f) * n_streams] = minlds[f * 64 + lane];
     }
+    VAD_PROF(8);  // state out (issue)
 }
+#ifdef WMX_VAD_PROF
+extern "C" int wmx_debug_vad_prof(unsigned long long *out16, int reset) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_vad_prof), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_vad_prof), z, sizeof(z));
+    }
+    return 0;
+}
+#endif
 
 __global__ void vad_fill_state(int16_t *s16, int32_t *s32, const int16_t *t16, int n_streams) {
     const size_t total = (size_t)V16_WORDS * n_streams;
