@@ -87,9 +87,7 @@ enum AecmScalar {
 struct alignas(16) AecmWave {
     int32_t st[A_WORDS];
     int32_t cx[128];        // FFT work array (packed complex)
-    int16_t td[128];        // time-domain block pair / inverse transform output
-    int32_t dfw[kAecmBP];   // near spectrum (re | im << 16)
-    int32_t efw[kAecmBP];   // filtered spectrum
+    int32_t dfw[kAecmBP];   // near spectrum (re | im << 16); the filtered spectrum overwrites it bin by bin
     int32_t echo_est[kAecmBP];
     uint16_t dfa[kAecmBP], xfa[kAecmBP];
     int16_t hnl[kAecmBP];
@@ -123,22 +121,21 @@ __device__ __forceinline__ void mean_estimator(int32_t v, int factor, int32_t &m
     mean = wadd(mean, d);
 }
 
-// TimeToFrequencyDomain + WindowAndFFT (aecm_core_c.c:68-96, 171-278) of the 128 samples in td: leaves the spectrum in
+// TimeToFrequencyDomain + WindowAndFFT (aecm_core_c.c:68-96, 171-278) of the 128 samples (t0, t1): leaves the spectrum in
 // spec[] (re | im << 16, imag already sign-flipped like freq_signal) and |X| in mag[]; returns the scaling; *sum = sum |X|
-__device__ int time_to_freq(AecmWave &W, const AecmConsts &K, int lane, int32_t *spec, uint16_t *mag, uint32_t *sum) {
-    int mx = 0;
-    for (int i = lane; i < 128; i += 64) {
-        const int a = W.td[i] < 0 ? -(int)W.td[i] : (int)W.td[i];
+__device__ int time_to_freq(AecmWave &W, const AecmConsts &K, int lane, int16_t t0, int16_t t1, int32_t *spec, uint16_t *mag,
+                            uint32_t *sum) {
+    // t0 / t1: samples lane and 64 + lane of the 128-sample block pair (registers: the pair never lives in LDS)
+    int mx = t0 < 0 ? -(int)t0 : (int)t0;
+    {
+        const int a = t1 < 0 ? -(int)t1 : (int)t1;
         mx = a > mx ? a : mx;
     }
     mx = wave_max(mx);
     if (mx > 32767) mx = 32767;
     const int q = norm_w16((int16_t)mx);
-    for (int i = lane; i < 128; i += 64) {
-        const int16_t s = (int16_t)wshl(W.td[i], q);
-        const int16_t w = i < 64 ? K.sqrt_hanning[i] : K.sqrt_hanning[128 - i];
-        W.cx[bitrev<7>(i)] = (int32_t)(uint16_t)(int16_t)((s * w) >> 14);
-    }
+    W.cx[bitrev<7>(lane)] = (int32_t)(uint16_t)(int16_t)(((int16_t)wshl(t0, q) * K.sqrt_hanning[lane]) >> 14);
+    W.cx[bitrev<7>(64 + lane)] = (int32_t)(uint16_t)(int16_t)(((int16_t)wshl(t1, q) * K.sqrt_hanning[64 - lane]) >> 14);
     wave_sync();
     spl_cfft128<false>(W.cx, K.tw, lane);
     uint32_t part = 0;
@@ -235,11 +232,8 @@ __global__ __launch_bounds__(64) void aecm_far_kernel(AecmFarBufs F, const AecmC
                 int r = fp.blk_r[b] + lane;
                 r -= r >= kAecmFrameRing ? kAecmFrameRing : 0;
                 const int16_t nw = F.frame[r];
-                W.td[lane] = F.x_prev[lane];
-                W.td[64 + lane] = nw;
-                wave_sync();
                 uint32_t sum;
-                const int far_q = time_to_freq(W, K, lane, W.dfw, W.xfa, &sum);
+                const int far_q = time_to_freq(W, K, lane, F.x_prev[lane], nw, W.dfw, W.xfa, &sum);
                 const int slot = fp.blk_t[b] & (kAecmHist - 1);
                 for (int k = lane; k < 65; k += 64) F.hist[slot * kAecmBP + k] = W.xfa[k];
                 const uint32_t bin = binary_spectrum(W.xfa, mean, far_q, far_init, lane);
@@ -258,7 +252,10 @@ __global__ __launch_bounds__(64) void aecm_far_kernel(AecmFarBufs F, const AecmC
 }
 
 // ---------------------------------------------------------------- one 64-sample block of one stream (ProcessBlock)
-__device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &F, const LdsScal sc, int t, int mult, int lane) {
+// t_prev / t_new: sample `lane` of the previous and of the new near-end block on entry; on return t_prev is the new block's
+// sample (dBufNoisy slides) and t_new the block's output sample.
+__device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &F, const LdsScal sc, int t, int mult, int lane,
+                           int16_t &t_prev, int16_t &t_new) {
     int16_t *ch_stored = reinterpret_cast<int16_t *>(&W.st[A_CH_STORED]), *ch_adapt16 = reinterpret_cast<int16_t *>(&W.st[A_CH_ADAPT16]);
     int16_t *near_filt = reinterpret_cast<int16_t *>(&W.st[A_NEAR_FILT]);
     int16_t *noise_lo = reinterpret_cast<int16_t *>(&W.st[A_NOISE_LO]), *noise_hi = reinterpret_cast<int16_t *>(&W.st[A_NOISE_HI]);
@@ -269,9 +266,9 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
     int16_t *out_buf = reinterpret_cast<int16_t *>(&W.st[A_OUT_BUF]);
 
     if (sc[M_STARTUP] < 2) sc[M_STARTUP] = ((uint32_t)sc[M_TOT_COUNT] >= 512) + ((uint32_t)sc[M_TOT_COUNT] >= 1024);
-    // near spectrum (W.td holds [previous block | new block])
+    // near spectrum of [previous block | new block]
     uint32_t dfa_sum;
-    const int zeros_d = time_to_freq(W, K, lane, W.dfw, W.dfa, &dfa_sum);
+    const int zeros_d = time_to_freq(W, K, lane, t_prev, t_new, W.dfw, W.dfa, &dfa_sum);
     const int dfa_q_old = sc[M_DFA_Q];
     sc[M_DFA_Q] = zeros_d;
 
@@ -610,7 +607,7 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
         if (!(h == 16384 && nlp_gain == 16384)) h = (int16_t)((h * nlp_gain) >> 14);
         W.hnl[b] = h;
         const int32_t x = W.dfw[b];
-        W.efw[b] = pack16((int16_t)((lo16(x) * h + 8192) >> 14), (int16_t)((hi16(x) * h + 8192) >> 14));
+        W.dfw[b] = pack16((int16_t)((lo16(x) * h + 8192) >> 14), (int16_t)((hi16(x) * h + 8192) >> 14));
     }
 
     // ---- ComfortNoise, aecm_core_c.c:641-771 (cngMode is AecmTrue, echo_control_mobile.c:223)
@@ -677,15 +674,15 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
                 ui = (int16_t)((-noise * K.sin360[idx]) >> 13);
             }
             if (b == 64) ui = 0;
-            const int32_t e = W.efw[b];
-            W.efw[b] = pack16(sat_w16((int32_t)lo16(e) + ur), sat_w16((int32_t)hi16(e) + ui));
+            const int32_t e = W.dfw[b];
+            W.dfw[b] = pack16(sat_w16((int32_t)lo16(e) + ur), sat_w16((int32_t)hi16(e) + ui));
         }
     }
     wave_sync();
 
     // ---- InverseFFTAndWindow, aecm_core_c.c:98-169
     for (int b = lane; b < 65; b += 64) {
-        const int32_t e = W.efw[b];
+        const int32_t e = W.dfw[b];
         const int16_t re = lo16(e), nim = (int16_t)-hi16(e);
         W.cx[bitrev<7>(b)] = pack16(re, nim);
         if (b > 0 && b < 64) W.cx[bitrev<7>(128 - b)] = pack16(re, (int16_t)-nim);
@@ -700,16 +697,15 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
         v = (lo16(W.cx[64 + i]) * K.sqrt_hanning[64 - i]) >> 14;
         v = shift_w32(v, out_scale - zeros_d);
         out_buf[i] = sat_w16(v);
-        W.td[i] = W.td[64 + i];  // dBufNoisy slides: the new block becomes the previous one
-        wave_sync();
-        W.td[64 + i] = o;        // the block's output, picked up by the caller
+        t_prev = t_new;  // dBufNoisy slides: the new block becomes the previous one
+        t_new = o;       // the block's output, picked up by the caller
     }
     wave_sync();
 }
 
 // One wave per stream, kAecmWavesPerBlock streams per workgroup.
 #ifndef WMX_AECM_WPE
-#define WMX_AECM_WPE 6  // 0.63 / 0.53 / 0.48 / 0.445 ms at 3 / 4 / 5 / 6 waves per SIMD (LDS allows 6)
+#define WMX_AECM_WPE 7  // 0.63 / 0.53 / 0.48 / 0.445 ms at 3 / 4 / 5 / 6 waves per SIMD when first measured; 22.6 KB of LDS per workgroup allow 7
 #endif
 __global__ __launch_bounds__(64 * kAecmWavesPerBlock) __attribute__((amdgpu_waves_per_eu(WMX_AECM_WPE, WMX_AECM_WPE))) void aecm_near_kernel(int32_t *__restrict__ state, AecmFarBufs F,
                                                                             const AecmConsts *__restrict__ consts,
@@ -776,14 +772,12 @@ __global__ __launch_bounds__(64 * kAecmWavesPerBlock) __attribute__((amdgpu_wave
             for (int b = 0; b < fp.n_blocks; b++) {
                 int r = fp.blk_r[b] + lane;
                 r -= r >= kAecmFrameRing ? kAecmFrameRing : 0;
-                W.td[lane] = d_prev[lane];
-                W.td[64 + lane] = near_ring[r];
-                wave_sync();
-                aecm_block(W, K, F, sc, fp.blk_t[b], mult, lane);
-                d_prev[lane] = W.td[lane];
+                int16_t t_prev = d_prev[lane], t_new = near_ring[r];
+                aecm_block(W, K, F, sc, fp.blk_t[b], mult, lane, t_prev, t_new);
+                d_prev[lane] = t_prev;
                 int ow = fp.blk_out_w[b] + lane;
                 ow -= ow >= kAecmFrameRing ? kAecmFrameRing : 0;
-                out_ring[ow] = W.td[64 + lane];
+                out_ring[ow] = t_new;
                 wave_sync();
             }
             if (!pl.discard_out)
