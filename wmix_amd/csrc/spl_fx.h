@@ -24,6 +24,9 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 // its row's result; the four rows meet in scalar registers.  No LDS-crossbar traffic (`__shfl_xor` = ds_bpermute_b32, six
 // dependent round trips per reduction), and the result is wave-uniform by construction.  Integer sums wrap, max / min are
 // exact: the order of combination does not matter.
+// For wave-uniform control flow only (every lane on): a lane whose source lane is switched off would read 0.  `old` = 0 is
+// what lets the compiler fold the move into the consuming instruction (v_add_u32_dpp / v_max_i32_dpp ... bound_ctrl:1); with
+// `old` = v it stays a separate v_mov_b32_dpp and the two kernels lose 1-5 %.
 template <int CTRL>
 __device__ __forceinline__ int dpp_rows(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
 // (the exchanged value goes into a temporary first: written as `dpp(v) > v ? dpp(v) : v` the compiler evaluates the
