@@ -119,12 +119,14 @@ class _StageTimer:
         return self._mean(self.ev.get(self.dominant))
 
     def mean_ms(self, name):
-        """Per-stage figure of the breakdown pass: the MEDIAN of its (up to 16) launches -- bracketing every launch with
-        events lets a host-side hiccup between two records show up as one 40 ms "launch" now and then (seen on the
-        ns_agc_mix_32k line: one outlier among 16, on a different stage each run; the timed region has no such gaps)."""
+        """Per-stage figure of the breakdown pass: the mean of its (up to 16) launches without outliers beyond five times
+        their median -- bracketing every launch with events lets a host-side hiccup between two records show up as one
+        40 ms "launch" now and then (seen on the ns_agc_mix_32k line: one among 16, on a different stage each run; the timed
+        region has no such gaps).  A plain median would misreport the AEC, whose launches alternate between two block counts."""
         v = self.ev_all.get(name)
         if v:
-            return float(np.median([a.elapsed_time(b) for a, b in v]))
+            t = np.array([a.elapsed_time(b) for a, b in v])
+            return float(t[t <= 5 * np.median(t)].mean())
         return self._mean(self.ev.get(name))
 
 
@@ -1014,7 +1016,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
         "config": dict(wl.config(), primed_steps=args.prime), "roofline": roofline,
         "stage_ms": wl.stage_ms() if hasattr(wl, "stage_ms") else None,
-        "stage_ms_source": "median over up to 16 extra steps after the timed region (inside it only the dominant kernel carries events)",
+        "stage_ms_source": "mean over up to 16 extra steps after the timed region, outliers beyond 5x the median dropped (inside the timed region only the dominant kernel carries events)",
         "whole_step_hbm_frac": round(value / world * wl.bytes_per_frame / 1e9 / HBM_PEAK_GBS, 5),
         "per_rank_ms_per_step": [round(x, 5) for x in per_rank_ms],
         # the size the collective library itself reports (backend nccl = RCCL on ROCm); None on one rank

@@ -63,9 +63,11 @@ template <int L>
 struct alignas(16) NsWaveLds {
     static constexpr int MP = NsLayout<L>::MP;
     float fa[L];  // FFT work array / packed spectrum / time-domain output staging
-    // per-bin intermediates of the frame (kept in LDS, not registers: every phase below is a short rolled loop
-    // over the wave's 2-3 bins per lane, which keeps the kernel at <= 128 VGPRs = 4 waves per SIMD)
-    float re[MP], im[MP], magn[MP], lmagn[MP], noise[MP], prev[MP], snrp[MP], snrq[MP], sprob[MP], nprev[MP], pause[MP];
+    // per-bin intermediates of the frame that another lane reads (ordered sums walk whole arrays, sprob[b - 1], magn[0]) or
+    // that a rolled loop indexes (noise).  The ones only their own lane touches -- the spectrum, the previous-frame SNR
+    // estimate, the instantaneous SNR -- are registers of ns_frame (t_re / t_im / t_prev / t_snrq, index = the group k of
+    // the unrolled per-bin loops): 5 776 B per stream instead of 8 416, five workgroups per CU instead of four.
+    float magn[MP], lmagn[MP], noise[MP], snrp[MP], sprob[MP], pause[MP];
     float r0[MP], r1[MP], r2[MP];  // staging of terms for the ordered sums; r0..r1 double as a L-float time-domain stage
 #ifdef WMX_NS_PROF
     unsigned long long prof[16];
@@ -237,6 +239,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
 
     float hb_gain = 1.f;
     const bool zero_frame = (energy1 == 0.0f);
+    float t_re[(Y::M + 63) / 64], t_im[(Y::M + 63) / 64], t_prev[(Y::M + 63) / 64], t_snrq[(Y::M + 63) / 64];
 
     if (!zero_frame) {
         // ===================================================== Analyze (ns_core.c:1085-1180)
@@ -276,9 +279,9 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             }
             const float lm = fast_log_ge1(mg, K.lm);
             const float pz = pf_pause[k];
+            t_re[k] = re;
+            t_im[k] = im;
             if (!ok) continue;
-            W.re[b] = re;
-            W.im[b] = im;
             W.magn[b] = mg;
             W.lmagn[b] = lm;
             W.pause[b] = pz;
@@ -443,10 +446,9 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             float sq = 0.f;
             if (mg > nz) sq = mg / (nz + 0.0001f) - 1.f;
             const float dm = mg - avg_magn, dp = W.pause[b] - avg_pause;
+            t_prev[k] = pe;
+            t_snrq[k] = sq;
             if (!ok) continue;
-            W.nprev[b] = np;
-            W.prev[b] = pe;
-            W.snrq[b] = sq;
             W.snrp[b] = 0.98f * pe + (1.f - 0.98f) * sq;
             W.r0[b] = dm * dp;
             W.r2[b] = dp * dp;
@@ -629,7 +631,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             const float sp = W.snrp[b];
             const float t1 = 1.f + 2.f * sp;
             const float t2 = 2.f * sp / (t1 + 0.0001f);
-            const float bessel = (W.snrq[b] + 1.f) * t2;
+            const float bessel = (t_snrq[k] + 1.f) * t2;
             float v = pf_lrt[k];
             v += 0.5f * (bessel - fast_log_ge1(t1, K.lm) - v);
             if (!ok) continue;
@@ -685,7 +687,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             const int b0 = lane + 64 * k;
             const bool ok = (64 * k + 63 < M) || b0 < M;  // see the noise estimation loop
             const int b = ok ? b0 : M - 1;
-            const float ps = W.sprob[b], pn = 1.f - ps, mg = W.magn[b], np = W.nprev[b];
+            const float ps = W.sprob[b], pn = 1.f - ps, mg = W.magn[b], np = pf_nprev[k];
             float gamma_old = 0.9f;
             if (b > 0 && W.sprob[b - 1] > 0.2f) gamma_old = 0.99f;
             const float tmp = gamma_old * np + (1.f - gamma_old) * (pn * mg + ps * np);
@@ -711,7 +713,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             }
             float cur = 0.f;
             if (mg > nz) cur = mg / (nz + 0.0001f) - 1.f;
-            const float snr = 0.98f * W.prev[b] + (1.f - 0.98f) * cur;
+            const float snr = 0.98f * t_prev[k] + (1.f - 0.98f) * cur;
             float f = snr / (overdrive + snr);
             if (f < denoise_bound) f = denoise_bound;
             if (f > 1.f) f = 1.f;
@@ -725,7 +727,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
                 f += ft;
                 f /= (float)(kStartupShort);
             }
-            const float re = W.re[b] * f, im = W.im[b] * f;
+            const float re = t_re[k] * f, im = t_im[k] * f;
             if (!ok) continue;
             st[Y::SMOOTH + b] = f;
             st[Y::MAGN_PREV + b] = mg;
@@ -828,8 +830,17 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
 #undef SCI
 }
 
+// Register budget = the occupancy the LDS allows: 16 kHz / 32 kHz streams (28.8 KB per workgroup) five workgroups per CU, 8 kHz
+// streams (16.7 KB) nine, more than the seven waves per SIMD a 72-register budget gives.  The unordered variants need more registers.
+#ifndef WMX_NS_W128
+#define WMX_NS_W128 7  // 6: 0.409, 7: 0.393, 8: 0.389 ms (131 072 streams; at 8 the 2-channel variant spills)
+#endif
+template <int L, bool ORDERED>
+struct NsOcc {
+    static constexpr int kWaves = !ORDERED ? 4 : (L == 128 ? WMX_NS_W128 : 5);
+};
 template <int L, bool ORDERED, int CHN>
-__global__ __launch_bounds__(64 * kNsWavesPerBlock, 4) void ns_kernel(float *__restrict__ state, unsigned short *__restrict__ hists,
+__global__ __launch_bounds__(64 * kNsWavesPerBlock) __attribute__((amdgpu_waves_per_eu(NsOcc<L, ORDERED>::kWaves, NsOcc<L, ORDERED>::kWaves))) void ns_kernel(float *__restrict__ state, unsigned short *__restrict__ hists,
                                                                       const float *__restrict__ consts, const int16_t *in, int16_t *out,
                                                                       int n_streams, int n_packets, long stream_stride,
                                                                       long packet_stride, int pkg) {
@@ -862,8 +873,8 @@ __global__ __launch_bounds__(64 * kNsWavesPerBlock, 4) void ns_kernel(float *__r
     unsigned short *hist = hists + (size_t)sidx * 3 * kHistBins;
     {
         // the tail [M, MP) of every per-bin array is summed by sum_lanes and must be zero; nothing below writes it
-        float *wb = Wv[wave].re;
-        constexpr int NARR = 14;  // re .. r2
+        float *wb = Wv[wave].magn;
+        constexpr int NARR = 9;  // magn .. r2
         if (lane < NARR * (Y::MP - Y::M)) wb[(lane / (Y::MP - Y::M)) * Y::MP + Y::M + lane % (Y::MP - Y::M)] = 0.f;
     }
 #ifdef WMX_NS_PROF
