@@ -835,9 +835,12 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
 #ifndef WMX_NS_W128
 #define WMX_NS_W128 7  // 6: 0.409, 7: 0.393, 8: 0.389 ms (131 072 streams; at 8 the 2-channel variant spills)
 #endif
+#ifndef WMX_NS_W256
+#define WMX_NS_W256 5
+#endif
 template <int L, bool ORDERED>
 struct NsOcc {
-    static constexpr int kWaves = !ORDERED ? 4 : (L == 128 ? WMX_NS_W128 : 5);
+    static constexpr int kWaves = !ORDERED ? 4 : (L == 128 ? WMX_NS_W128 : WMX_NS_W256);
 };
 template <int L, bool ORDERED, int CHN>
 __global__ __launch_bounds__(64 * kNsWavesPerBlock) __attribute__((amdgpu_waves_per_eu(NsOcc<L, ORDERED>::kWaves, NsOcc<L, ORDERED>::kWaves))) void ns_kernel(float *__restrict__ state, unsigned short *__restrict__ hists,
