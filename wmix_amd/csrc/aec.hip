@@ -118,12 +118,22 @@ __device__ __forceinline__ void unpack_bin(const float *a, int b, float &re, flo
 
 // ================================================================== far-end kernel
 // grid = number of far-end groups: workgroup g (one wave) serves far-end g, whose packets start at far_pcm + g * far_group_stride
-__global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const float *__restrict__ consts_g, const AecPlan *__restrict__ plans,
+// plan_by_value: a one-packet launch hands its plan over as a kernel argument; this kernel, which runs in front of the near
+// kernel in the same stream, stores it into plans[0] for both -- no host-to-device blit between the previous kernel of the
+// stream and this one (4.7 us per step of the chain).  Every far-end group stores the same bytes.
+__global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const float *__restrict__ consts_g, AecPlan *plans,
                                                      int n_packets, const int16_t *far_pcm, long far_packet_stride, long far_group_stride,
-                                                     int chn, float gpow1np) {
+                                                     int chn, float gpow1np, int plan_by_value, const AecPlan plan_value) {
     __shared__ AecConsts K;
     __shared__ float fa[2][132];
     const int lane = threadIdx.x;
+    if (plan_by_value) {
+        const int *src = reinterpret_cast<const int *>(&plan_value);
+        int *dst = reinterpret_cast<int *>(plans);
+        for (int i = lane; i < (int)(sizeof(AecPlan) / 4); i += 64) dst[i] = src[i];
+        __threadfence();
+        wave_sync();
+    }
     const AecFarBufs F = far_group(F_all, (int)blockIdx.x);
     if (far_pcm) far_pcm += (size_t)blockIdx.x * far_group_stride;
     {
@@ -1311,9 +1321,11 @@ int wmx_aec_run_groups(wmx_aec *h, int mode, const int16_t *d_far, long far_pack
             }
         }
         if (built > 0) {
-            WMX_HIP(hipMemcpyAsync(dp, hp, built * sizeof(AecPlan), hipMemcpyHostToDevice, s));
+            const int by_value = built == 1;
+            if (!by_value) WMX_HIP(hipMemcpyAsync(dp, hp, built * sizeof(AecPlan), hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(aec_far_kernel, dim3((unsigned)h->n_far), dim3(64), 0, s, h->far, h->d_consts, dp, built,
-                               d_far ? d_far + (size_t)done * far_packet_stride : nullptr, far_packet_stride, far_group_stride, h->chn, gpow1np);
+                               d_far ? d_far + (size_t)done * far_packet_stride : nullptr, far_packet_stride, far_group_stride, h->chn, gpow1np,
+                               by_value, hp[0]);
             WMX_LAUNCH_CHECK();
             if (mode & 2) {
                 const int16_t *nin = d_near + (size_t)done * packet_stride;

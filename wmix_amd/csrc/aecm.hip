@@ -182,11 +182,21 @@ __device__ uint32_t binary_spectrum(const uint16_t *mag, int32_t *mean, int q, i
 }
 
 // ---------------------------------------------------------------- far-end kernel: one wave per batch
-__global__ __launch_bounds__(64) void aecm_far_kernel(AecmFarBufs F, const AecmConsts *__restrict__ consts, const AecmPlan *__restrict__ plans,
-                                                     int n_plans, const int16_t *far, long far_stride, int chn) {
+// plan_by_value: a one-packet launch hands its plan over as a kernel argument; this kernel, which runs in front of the near
+// kernel in the same stream, stores it into plans[0] for both (no host-to-device copy of the plan in front of the launch).
+__global__ __launch_bounds__(64) void aecm_far_kernel(AecmFarBufs F, const AecmConsts *__restrict__ consts, AecmPlan *plans, int n_plans,
+                                                     const int16_t *far, long far_stride, int chn, int plan_by_value,
+                                                     const AecmPlan plan_value) {
     __shared__ AecmConsts K;
     __shared__ AecmWave W;
     const int lane = threadIdx.x;
+    if (plan_by_value) {
+        const int *src = reinterpret_cast<const int *>(&plan_value);
+        int *dst = reinterpret_cast<int *>(plans);
+        for (int i = lane; i < (int)(sizeof(AecmPlan) / 4); i += 64) dst[i] = src[i];
+        __threadfence();
+        wave_sync();
+    }
     {
         const int4 *src = reinterpret_cast<const int4 *>(consts);
         int4 *dst = reinterpret_cast<int4 *>(&K);
@@ -1027,9 +1037,10 @@ int wmx_aecm_run(wmx_aecm *h, int mode, const int16_t *d_far, long far_packet_st
             // The device buffer alternates and is rewritten only after the kernels that read it last have finished (they
             // may run on any user stream); the copy itself is blocking, so the pageable host vector can be reused at once.
             if (h->plan_used[sel]) WMX_HIP(hipEventSynchronize(h->plan_free[sel]));
-            WMX_HIP(hipMemcpy(dp, h->h_plans.data(), built * sizeof(AecmPlan), hipMemcpyHostToDevice));
+            const int by_value = built == 1;
+            if (!by_value) WMX_HIP(hipMemcpy(dp, h->h_plans.data(), built * sizeof(AecmPlan), hipMemcpyHostToDevice));
             hipLaunchKernelGGL(aecm_far_kernel, dim3(1), dim3(64), 0, s, h->far, h->d_consts, dp, built,
-                               d_far ? d_far + (size_t)done * far_packet_stride : nullptr, far_packet_stride, h->chn);
+                               d_far ? d_far + (size_t)done * far_packet_stride : nullptr, far_packet_stride, h->chn, by_value, h->h_plans[0]);
             WMX_LAUNCH_CHECK();
             if (mode & 2) {
                 const unsigned grid = (unsigned)((h->n_streams + kAecmWavesPerBlock - 1) / kAecmWavesPerBlock);
