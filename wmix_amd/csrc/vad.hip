@@ -20,6 +20,7 @@
 // Kept reference quirks: a call of several packets always analyses packet 0
 // and only packet 0 is attenuated; multi-channel input is mean-downmixed in place and expanded
 // backwards afterwards.
+#include <cstdlib>
 #include <vector>
 #include "wmx_internal.h"
 #include "spl_dev.h"
@@ -430,8 +431,10 @@ struct RegSrc {
     }
 };
 
+// WebRtcVad_CalculateFeatures on one packet: the six band log-energies and the total power indicator
 template <int NB, int RATIO, class Src>
-__device__ __forceinline__ int vad_packet(const VadRef &S, const Src p, LaneBuf hp120, LaneBuf lp120, LaneBuf hp60, LaneBuf lp60) {
+__device__ __forceinline__ void vad_features(const VadRef &S, const Src p, LaneBuf hp120, LaneBuf lp120, LaneBuf hp60, LaneBuf lp60,
+                                             int16_t (&feat)[6], int16_t &total) {
     // ---- decimation to 8 kHz fused with the first band split (vad_filterbank.c:268-270)
     {
         int32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
@@ -480,7 +483,7 @@ __device__ __forceinline__ int vad_packet(const VadRef &S, const Src p, LaneBuf 
     }
     VAD_PROF(2);  // decimation + first split
     // ---- rest of WebRtcVad_CalculateFeatures (vad_filterbank.c:272-332)
-    int16_t feat[6], total = 0;
+    total = 0;
     auto do_split = [&](LaneBuf in, int len, int band, LaneBuf hp, LaneBuf lp) {
         int16_t up = S.h(V16_UPPER + band), lo = S.h(V16_LOWER + band);
         split_lds(in, len, up, lo, hp, lp);
@@ -519,8 +522,361 @@ __device__ __forceinline__ int vad_packet(const VadRef &S, const Src p, LaneBuf 
     }
     log_energy(hp120, NB / 16, 368, total, feat[0]);
     VAD_PROF(3);  // remaining splits + log energies
+}
+
+template <int NB, int RATIO, class Src>
+__device__ __forceinline__ int vad_packet(const VadRef &S, const Src p, LaneBuf hp120, LaneBuf lp120, LaneBuf hp60, LaneBuf lp60) {
+    int16_t feat[6], total;
+    vad_features<NB, RATIO>(S, p, hp120, lp120, hp60, lp60, feat, total);
     const int v = gmm_probability(S, feat, total, NB == 80 ? 0 : (NB == 160 ? 1 : 2));
     return v > 0 ? 1 : v;
+}
+
+// ================================================================== the 10 ms mono packet as a four-wave pipeline
+// vad_kernel above runs a stream in one lane from end to end: 65 536 streams are 1 024 waves, one per SIMD, and the launch
+// lasts as long as one wave's chain of ~9 000 dependent-issue instructions -- 60 % of it the six channels of the GMM
+// (probabilities, order statistics, model update), which do not depend on each other.  Here a workgroup still owns 64
+// streams (lane = stream), but as four waves: wave 3 runs the filter bank and the packet, waves 0..2 two GMM channels each
+// (their state rows are requested while wave 3 is still filtering).  Features and the per-channel log-likelihood ratios
+// cross through LDS at two workgroup barriers; every integer operation of a stream is the one vad_kernel performs.
+struct VadChan {
+    int16_t dN[2], dS[2], ngpr[2], sgpr[2];
+};
+// first channel loop of gmm_probability (vad_core.c:152-232) for channel C
+template <int C>
+__device__ __forceinline__ void gmm_prob_channel(const VadRef &S, int16_t feat_c, VadChan &R, int32_t &llr_w, int &flag) {
+    R.ngpr[0] = R.ngpr[1] = R.sgpr[0] = R.sgpr[1] = 0;
+    int32_t h0t = 0, h1t = 0, np0 = 0, sp0 = 0;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int g = C + k * 6;
+        const int32_t npk = kNoiseW[g] * gauss_prob(feat_c, S.h(V16_NOISE_MEANS + g), S.h(V16_NOISE_STDS + g), R.dN[k]);
+        h0t += npk;
+        const int32_t spk = kSpeechW[g] * gauss_prob(feat_c, S.h(V16_SPEECH_MEANS + g), S.h(V16_SPEECH_STDS + g), R.dS[k]);
+        h1t += spk;
+        if (k == 0) {
+            np0 = npk;
+            sp0 = spk;
+        }
+    }
+    int16_t sh0 = (int16_t)norm_w32(h0t), sh1 = (int16_t)norm_w32(h1t);
+    if (h0t == 0) sh0 = 31;
+    if (h1t == 0) sh1 = 31;
+    const int16_t llr = (int16_t)(sh0 - sh1);
+    llr_w = (int32_t)(llr * kSpecW[C]);
+    flag = (llr * 4) > 94;
+    const int16_t h0 = (int16_t)(h0t >> 12);
+    if (h0 > 0) {
+        R.ngpr[0] = (int16_t)div_w32_w16(wshl((int32_t)(np0 & 0xFFFFF000), 2), h0);
+        R.ngpr[1] = (int16_t)(16384 - R.ngpr[0]);
+    } else {
+        R.ngpr[0] = 16384;
+    }
+    const int16_t h1 = (int16_t)(h1t >> 12);
+    if (h1 > 0) {
+        R.sgpr[0] = (int16_t)div_w32_w16(wshl((int32_t)(sp0 & 0xFFFFF000), 2), h1);
+        R.sgpr[1] = (int16_t)(16384 - R.sgpr[0]);
+    }
+}
+// second channel loop of gmm_probability (vad_core.c:240-440) for channel C
+template <int C>
+__device__ __forceinline__ void gmm_update_channel(const VadRef &S, int16_t feat_c, int vadflag, int32_t frame_counter, const VadChan &R) {
+    const int16_t maxspe_in = C == 0 ? (int16_t)12800 : kMaxSpeech[C == 0 ? 0 : C - 1];
+    const int16_t fmin = find_minimum(S, feat_c, C, frame_counter);
+    int32_t ngm = weighted_avg(S, V16_NOISE_MEANS, C, 0, kNoiseW);
+    const int16_t t1 = (int16_t)(ngm >> 6);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int g = C + k * 6;
+        const int16_t nmk = S.h(V16_NOISE_MEANS + g), smk = S.h(V16_SPEECH_MEANS + g);
+        int16_t nsk = S.h(V16_NOISE_STDS + g), ssk = S.h(V16_SPEECH_STDS + g);
+        int16_t nmk2 = nmk, t16;
+        if (!vadflag) {
+            const int16_t delt = (int16_t)((R.ngpr[k] * R.dN[k]) >> 11);
+            nmk2 = (int16_t)(nmk + (int16_t)((delt * 655) >> 22));
+        }
+        const int16_t ndelt = (int16_t)((fmin << 4) - t1);
+        int16_t nmk3 = (int16_t)(nmk2 + (int16_t)((ndelt * 154) >> 9));
+        t16 = (int16_t)((k + 5) << 7);
+        if (nmk3 < t16) nmk3 = t16;
+        t16 = (int16_t)((72 + k - C) << 7);
+        if (nmk3 > t16) nmk3 = t16;
+        S.h(V16_NOISE_MEANS + g) = nmk3;
+        if (vadflag) {
+            const int16_t delt = (int16_t)((R.sgpr[k] * R.dS[k]) >> 11);
+            t16 = (int16_t)((delt * 6554) >> 21);
+            int16_t smk2 = (int16_t)(smk + ((t16 + 1) >> 1));
+            const int16_t maxmu = (int16_t)(maxspe_in + 640);
+            const int16_t minmean = k == 0 ? 640 : 768;
+            if (smk2 < minmean) smk2 = minmean;
+            if (smk2 > maxmu) smk2 = maxmu;
+            S.h(V16_SPEECH_MEANS + g) = smk2;
+            t16 = (int16_t)((smk + 4) >> 3);
+            t16 = (int16_t)(feat_c - t16);
+            int32_t a = (R.dS[k] * t16) >> 3;
+            int32_t b = a - 4096;
+            t16 = (int16_t)(R.sgpr[k] >> 2);
+            a = t16 * b;
+            b = a >> 4;
+            if (b > 0) {
+                t16 = (int16_t)div_w32_w16(b, (int16_t)(ssk * 10));
+            } else {
+                t16 = (int16_t)div_w32_w16(-b, (int16_t)(ssk * 10));
+                t16 = (int16_t)-t16;
+            }
+            t16 = (int16_t)(t16 + 128);
+            ssk = (int16_t)(ssk + (t16 >> 8));
+            if (ssk < 384) ssk = 384;
+            S.h(V16_SPEECH_STDS + g) = ssk;
+        } else {
+            t16 = (int16_t)(feat_c - (nmk >> 3));
+            int32_t a = (R.dN[k] * t16) >> 3;
+            a -= 4096;
+            t16 = (int16_t)((R.ngpr[k] + 2) >> 2);
+            const int32_t b = t16 * a;
+            a = b >> 14;
+            if (a > 0) {
+                t16 = (int16_t)div_w32_w16(a, nsk);
+            } else {
+                t16 = (int16_t)div_w32_w16(-a, nsk);
+                t16 = (int16_t)-t16;
+            }
+            t16 = (int16_t)(t16 + 32);
+            nsk = (int16_t)(nsk + (t16 >> 6));
+            if (nsk < 384) nsk = 384;
+            S.h(V16_NOISE_STDS + g) = nsk;
+        }
+    }
+    ngm = weighted_avg(S, V16_NOISE_MEANS, C, 0, kNoiseW);
+    int32_t sgm = weighted_avg(S, V16_SPEECH_MEANS, C, 0, kSpeechW);
+    const int16_t diff = (int16_t)((int16_t)(sgm >> 9) - (int16_t)(ngm >> 9));
+    if (diff < kMinDiff[C]) {
+        const int16_t t16 = (int16_t)(kMinDiff[C] - diff);
+        const int16_t u1 = (int16_t)((13 * t16) >> 2), u2 = (int16_t)((3 * t16) >> 2);
+        sgm = weighted_avg(S, V16_SPEECH_MEANS, C, u1, kSpeechW);
+        ngm = weighted_avg(S, V16_NOISE_MEANS, C, (int16_t)-u2, kNoiseW);
+    }
+    const int16_t maxspe = kMaxSpeech[C];
+    int16_t t2 = (int16_t)(sgm >> 7);
+    if (t2 > maxspe) {
+        t2 = (int16_t)(t2 - maxspe);
+#pragma unroll
+        for (int k = 0; k < 2; k++) S.h(V16_SPEECH_MEANS + C + 6 * k) = (int16_t)(S.h(V16_SPEECH_MEANS + C + 6 * k) - t2);
+    }
+    t2 = (int16_t)(ngm >> 7);
+    if (t2 > kMaxNoise[C]) {
+        t2 = (int16_t)(t2 - kMaxNoise[C]);
+#pragma unroll
+        for (int k = 0; k < 2; k++) S.h(V16_NOISE_MEANS + C + 6 * k) = (int16_t)(S.h(V16_NOISE_MEANS + C + 6 * k) - t2);
+    }
+}
+
+// exchange area (int32 [field][lane], aliases the band buffers, which are dead between the filter bank and the next packet)
+enum : int { X_FEAT = 0, X_TOTAL = 6, X_LLR = 7, X_FLAG = 13, X_FIELDS = 19 };
+
+// one pair of GMM channels (C0, C0 + 1) of the workgroup's 64 streams: state in, per packet probabilities -> barrier ->
+// decision + update, state out
+template <int C0>
+__device__ __forceinline__ void vad_pipe_channels(const VadRef &S, int16_t *s16, int32_t *s32, int32_t *xch, int16_t *minlds, int lane,
+                                                  int stream, bool live, int n_streams, int n_calls) {
+    const int16_t *g16 = s16 + stream;
+    // this wave's state rows, all requested before the first one is used
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int g = C0 + j + 6 * k;
+            S.h(V16_NOISE_MEANS + g) = g16[(size_t)(V16_NOISE_MEANS + g) * n_streams];
+            S.h(V16_SPEECH_MEANS + g) = g16[(size_t)(V16_SPEECH_MEANS + g) * n_streams];
+            S.h(V16_NOISE_STDS + g) = g16[(size_t)(V16_NOISE_STDS + g) * n_streams];
+            S.h(V16_SPEECH_STDS + g) = g16[(size_t)(V16_SPEECH_STDS + g) * n_streams];
+        }
+        S.h(V16_MEAN_VALUE + C0 + j) = g16[(size_t)(V16_MEAN_VALUE + C0 + j) * n_streams];
+    }
+    S.w(V32_FRAME_COUNTER) = s32[(size_t)V32_FRAME_COUNTER * n_streams + stream];
+    // index_vector / low_value_vector rows of the two channels (2 x 16 each)
+#pragma unroll 8
+    for (int i = 0; i < 32; i++) {
+        const int fa = V16_AGE + 16 * C0 + i, fl = V16_LOW + 16 * C0 + i;
+        minlds[(fa - V16_AGE) * 64 + lane] = g16[(size_t)fa * n_streams];
+        minlds[(fl - V16_AGE) * 64 + lane] = g16[(size_t)fl * n_streams];
+    }
+    for (int call = 0; call < n_calls; call++) {
+        __syncthreads();  // 1: the packet's features are in xch
+        const int16_t total = (int16_t)xch[X_TOTAL * 64 + lane];
+        const int16_t f0 = (int16_t)xch[(X_FEAT + C0) * 64 + lane], f1 = (int16_t)xch[(X_FEAT + C0 + 1) * 64 + lane];
+        VadChan R0, R1;
+        int32_t l0 = 0, l1 = 0;
+        int g0 = 0, g1 = 0;
+        if (total > 10) {
+            gmm_prob_channel<C0>(S, f0, R0, l0, g0);
+            gmm_prob_channel<C0 + 1>(S, f1, R1, l1, g1);
+        }
+        xch[(X_LLR + C0) * 64 + lane] = l0;
+        xch[(X_LLR + C0 + 1) * 64 + lane] = l1;
+        xch[(X_FLAG + C0) * 64 + lane] = g0;
+        xch[(X_FLAG + C0 + 1) * 64 + lane] = g1;
+        __syncthreads();  // 2: every channel's log-likelihood ratio is in xch
+        if (total > 10) {
+            int32_t sum_llr = 0;
+            int vadflag = 0;
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                sum_llr += xch[(X_LLR + c) * 64 + lane];
+                vadflag |= xch[(X_FLAG + c) * 64 + lane];
+            }
+            vadflag |= (sum_llr >= 1100);
+            const int32_t frame_counter = S.w(V32_FRAME_COUNTER);
+            gmm_update_channel<C0>(S, f0, vadflag, frame_counter, R0);
+            gmm_update_channel<C0 + 1>(S, f1, vadflag, frame_counter, R1);
+            S.w(V32_FRAME_COUNTER) = frame_counter + 1;
+        }
+        __syncthreads();  // 3: xch may be overwritten by the next packet's filter bank
+    }
+    if (!live) return;
+    int16_t *o16 = s16 + stream;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int g = C0 + j + 6 * k;
+            o16[(size_t)(V16_NOISE_MEANS + g) * n_streams] = S.h(V16_NOISE_MEANS + g);
+            o16[(size_t)(V16_SPEECH_MEANS + g) * n_streams] = S.h(V16_SPEECH_MEANS + g);
+            o16[(size_t)(V16_NOISE_STDS + g) * n_streams] = S.h(V16_NOISE_STDS + g);
+            o16[(size_t)(V16_SPEECH_STDS + g) * n_streams] = S.h(V16_SPEECH_STDS + g);
+        }
+        o16[(size_t)(V16_MEAN_VALUE + C0 + j) * n_streams] = S.h(V16_MEAN_VALUE + C0 + j);
+    }
+    if (C0 == 0) s32[(size_t)V32_FRAME_COUNTER * n_streams + stream] = S.w(V32_FRAME_COUNTER);
+#pragma unroll 8
+    for (int i = 0; i < 32; i++) {
+        const int fa = V16_AGE + 16 * C0 + i, fl = V16_LOW + 16 * C0 + i;
+        o16[(size_t)fa * n_streams] = minlds[(fa - V16_AGE) * 64 + lane];
+        o16[(size_t)fl * n_streams] = minlds[(fl - V16_AGE) * 64 + lane];
+    }
+}
+
+// RATIO = 1 (8 kHz) or 2 (16 kHz), one mono 10 ms packet per call, 16-byte aligned rows (what wmx_vad_process checks)
+template <int RATIO>
+__global__ __launch_bounds__(256) void vad_pipe_kernel(int16_t *s16, int32_t *s32, int16_t *pcm, int n_streams, int n_calls,
+                                                       long stream_stride, long call_stride) {
+    constexpr int NB = 80, PKG = NB * RATIO, NV = PKG / 8;
+    __shared__ __attribute__((aligned(16))) int16_t lds[64 * (NB / 2 + NB / 2 + NB / 4 + NB / 4)];
+    __shared__ int16_t minlds[64 * kVadMinFields];
+    int32_t *xch = reinterpret_cast<int32_t *>(lds);
+    static_assert(X_FIELDS * 64 * 4 <= (int)sizeof(lds), "exchange area must fit in the band buffers");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int stream_raw = (int)blockIdx.x * 64 + lane;
+    const bool live = stream_raw < n_streams;
+    const int stream = live ? stream_raw : n_streams - 1;  // a lane without a stream recomputes the last one and stores nothing
+    int16_t r16[kVadRegFields];
+    int32_t r32[V32_WORDS];
+    const VadRef S{r16, r32, minlds + lane};
+    if (wave == 0) {
+        vad_pipe_channels<0>(S, s16, s32, xch, minlds, lane, stream, live, n_streams, n_calls);
+        return;
+    }
+    if (wave == 1) {
+        vad_pipe_channels<2>(S, s16, s32, xch, minlds, lane, stream, live, n_streams, n_calls);
+        return;
+    }
+    if (wave == 2) {
+        vad_pipe_channels<4>(S, s16, s32, xch, minlds, lane, stream, live, n_streams, n_calls);
+        return;
+    }
+    // ---- wave 3: filter bank, hangover, attenuation
+    const int16_t *g16 = s16 + stream;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        S.h(V16_UPPER + i) = g16[(size_t)(V16_UPPER + i) * n_streams];
+        S.h(V16_LOWER + i) = g16[(size_t)(V16_LOWER + i) * n_streams];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) S.h(V16_HP + i) = g16[(size_t)(V16_HP + i) * n_streams];
+    S.h(V16_REDUCE) = g16[(size_t)V16_REDUCE * n_streams];
+    S.h(V16_OVER_HANG) = g16[(size_t)V16_OVER_HANG * n_streams];
+    S.h(V16_NUM_SPEECH) = g16[(size_t)V16_NUM_SPEECH * n_streams];
+#pragma unroll
+    for (int i = 0; i < 4; i++) S.w(V32_DS + i) = s32[(size_t)(V32_DS + i) * n_streams + stream];
+    const LaneBuf hp120{lds + lane}, lp120{lds + lane + 64 * (NB / 2)}, hp60{lds + lane + 64 * NB}, lp60{lds + lane + 64 * (NB + NB / 4)};
+    for (int call = 0; call < n_calls; call++) {
+        uint4 *frame4 = reinterpret_cast<uint4 *>(pcm + (size_t)stream * stream_stride + (size_t)call * call_stride);
+        uint4 raw[NV];
+#pragma unroll
+        for (int j = 0; j < NV; j++) raw[j] = frame4[j];
+        int16_t feat[6], total;
+        vad_features<NB, RATIO>(S, RegSrc<NV>{raw}, hp120, lp120, hp60, lp60, feat, total);
+        // the band buffers are read for the last time above and xch lives in the same bytes: keep the compiler from moving
+        // the stores below in front of those reads (the hardware executes a wave's LDS instructions in order)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int c = 0; c < 6; c++) xch[(X_FEAT + c) * 64 + lane] = feat[c];
+        xch[X_TOTAL * 64 + lane] = total;
+        __syncthreads();  // 1
+        __syncthreads();  // 2
+        int vadflag = 0;
+        if (total > 10) {
+            int32_t sum_llr = 0;
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                sum_llr += xch[(X_LLR + c) * 64 + lane];
+                vadflag |= xch[(X_FLAG + c) * 64 + lane];
+            }
+            vadflag |= (sum_llr >= 1100);
+        }
+        // hangover smoothing (vad_core.c:443-468), mode-3 values of the 10 ms frame length
+        int16_t over_hang = S.h(V16_OVER_HANG), num_speech = S.h(V16_NUM_SPEECH);
+        if (!vadflag) {
+            if (over_hang > 0) {
+                vadflag = 2 + over_hang;
+                over_hang--;
+            }
+            num_speech = 0;
+        } else {
+            num_speech++;
+            if (num_speech > 6) {
+                num_speech = 6;
+                over_hang = 9;
+            } else {
+                over_hang = 6;
+            }
+        }
+        S.h(V16_OVER_HANG) = over_hang;
+        S.h(V16_NUM_SPEECH) = num_speech;
+        int reduce = S.h(V16_REDUCE);
+        if (vadflag == 0) {
+            if (reduce < 4) reduce += 1;
+        } else {
+            if (reduce > 0) reduce -= 1;
+        }
+        S.h(V16_REDUCE) = (int16_t)reduce;
+        auto att = [&](unsigned w) {  // both int16 halves >> reduce (arithmetic)
+            const int lo = (int)(int16_t)(w & 0xffffu) >> reduce, hi = (int)(int16_t)(w >> 16) >> reduce;
+            return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16);
+        };
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < NV; j++) frame4[j] = make_uint4(att(raw[j].x), att(raw[j].y), att(raw[j].z), att(raw[j].w));
+        }
+        __syncthreads();  // 3
+    }
+    if (!live) return;
+    int16_t *o16 = s16 + stream;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        o16[(size_t)(V16_UPPER + i) * n_streams] = S.h(V16_UPPER + i);
+        o16[(size_t)(V16_LOWER + i) * n_streams] = S.h(V16_LOWER + i);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) o16[(size_t)(V16_HP + i) * n_streams] = S.h(V16_HP + i);
+    o16[(size_t)V16_REDUCE * n_streams] = S.h(V16_REDUCE);
+    o16[(size_t)V16_OVER_HANG * n_streams] = S.h(V16_OVER_HANG);
+    o16[(size_t)V16_NUM_SPEECH * n_streams] = S.h(V16_NUM_SPEECH);
+#pragma unroll
+    for (int i = 0; i < 4; i++) s32[(size_t)(V32_DS + i) * n_streams + stream] = S.w(V32_DS + i);
 }
 
 template <int NB, int RATIO>
@@ -761,6 +1117,22 @@ int wmx_vad_process(wmx_vad *h, int16_t *d_pcm, int packets_per_call, int n_call
     hipStream_t s = as_stream(stream);
     const int nb = h->pkg / (h->freq / 8000);  // packet length at 8 kHz: 80 or 160
     const int ratio = h->freq / 8000;
+    // one mono 10 ms packet per call with 16-byte aligned rows -- the batched chain's case -- goes through the four-wave
+    // pipeline; every other shape (20 ms packets, several packets per call, 32 kHz, interleaved channels, odd alignment)
+    // through the one-lane-per-stream kernel
+    const bool pipe = h->chn == 1 && packets_per_call == 1 && h->pkg == 80 * (h->freq / 8000) && h->freq <= 16000 &&
+                      (stream_stride % 8) == 0 && (call_stride % 8) == 0 && (reinterpret_cast<size_t>(d_pcm) % 16) == 0 &&
+                      !getenv("WMIX_AMD_VAD_ONE_LANE");
+    if (pipe) {
+        if (h->freq == 8000)
+            hipLaunchKernelGGL((vad_pipe_kernel<1>), grid, dim3(256), 0, s, h->d_s16, h->d_s32, d_pcm, h->n_streams, n_calls, stream_stride,
+                               call_stride);
+        else
+            hipLaunchKernelGGL((vad_pipe_kernel<2>), grid, dim3(256), 0, s, h->d_s16, h->d_s32, d_pcm, h->n_streams, n_calls, stream_stride,
+                               call_stride);
+        WMX_LAUNCH_CHECK();
+        return 0;
+    }
 #define VAD_LAUNCH(NB, R)                                                                                                 \
     hipLaunchKernelGGL((vad_kernel<NB, R>), grid, block, 0, s, h->d_s16, h->d_s32, d_pcm, h->n_streams, packets_per_call, \
                        n_calls, stream_stride, call_stride, h->chn)
