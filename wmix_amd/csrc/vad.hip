@@ -431,6 +431,10 @@ struct RegSrc {
     }
 };
 
+template <int NB>
+__device__ __forceinline__ void vad_features_rest(const VadRef &S, LaneBuf hp120, LaneBuf lp120, LaneBuf hp60, LaneBuf lp60,
+                                                  int16_t (&feat)[6], int16_t &total);
+
 // WebRtcVad_CalculateFeatures on one packet: the six band log-energies and the total power indicator
 template <int NB, int RATIO, class Src>
 __device__ __forceinline__ void vad_features(const VadRef &S, const Src p, LaneBuf hp120, LaneBuf lp120, LaneBuf hp60, LaneBuf lp60,
@@ -482,7 +486,13 @@ __device__ __forceinline__ void vad_features(const VadRef &S, const Src p, LaneB
         }
     }
     VAD_PROF(2);  // decimation + first split
-    // ---- rest of WebRtcVad_CalculateFeatures (vad_filterbank.c:272-332)
+    vad_features_rest<NB>(S, hp120, lp120, hp60, lp60, feat, total);
+}
+
+// ---- rest of WebRtcVad_CalculateFeatures (vad_filterbank.c:272-332) behind the first band split
+template <int NB>
+__device__ __forceinline__ void vad_features_rest(const VadRef &S, LaneBuf hp120, LaneBuf lp120, LaneBuf hp60, LaneBuf lp60,
+                                                  int16_t (&feat)[6], int16_t &total) {
     total = 0;
     auto do_split = [&](LaneBuf in, int len, int band, LaneBuf hp, LaneBuf lp) {
         int16_t up = S.h(V16_UPPER + band), lo = S.h(V16_LOWER + band);
@@ -671,6 +681,52 @@ __device__ __forceinline__ void gmm_update_channel(const VadRef &S, int16_t feat
     }
 }
 
+// Decimation + first band split of vad_features for the pipeline's filter-bank wave, with the packet passing through the
+// registers eight output samples at a time (the next block's 2 / 4 uint4 are requested while the current one is filtered)
+// instead of 10 / 20 uint4 held at once: the kernel's register count decides how many workgroups share a CU.
+template <int RATIO>
+__device__ __forceinline__ void vad_front_blocked(const VadRef &S, const uint4 *frame4, LaneBuf hp120, LaneBuf lp120) {
+    constexpr int NB = 80, IT = 8, VPB = IT * 2 * RATIO / 8, NBLK = NB / 2 / IT;
+    static_assert(RATIO == 1 || RATIO == 2, "8 or 16 kHz");
+    int32_t d0 = 0, d1 = 0;
+    if (RATIO == 2) {
+        d0 = S.w(V32_DS + 0);
+        d1 = S.w(V32_DS + 1);
+    }
+    int32_t su = wshl(S.h(V16_UPPER + 0), 16), sl = wshl(S.h(V16_LOWER + 0), 16);
+    uint4 cur[VPB], nxt[VPB];
+#pragma unroll
+    for (int j = 0; j < VPB; j++) cur[j] = frame4[j];
+#pragma unroll 1
+    for (int blk = 0; blk < NBLK; blk++) {
+        const int nb = blk + 1 < NBLK ? blk + 1 : blk;  // the last block re-requests itself (no branch around the loads)
+#pragma unroll
+        for (int j = 0; j < VPB; j++) nxt[j] = frame4[nb * VPB + j];
+        const RegSrc<VPB> p{cur};
+#pragma unroll
+        for (int it = 0; it < IT; it++) {
+            int16_t s8[2];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int q = (2 * it + e) * RATIO;
+                s8[e] = RATIO == 1 ? p(q) : ds2_step(p(q), p(q + 1), d0, d1);
+            }
+            const int16_t h = allpass_step(s8[0], 20972, su);
+            const int16_t l = allpass_step(s8[1], 5571, sl);
+            hp120[blk * IT + it] = (int16_t)(h - l);
+            lp120[blk * IT + it] = (int16_t)(l + h);
+        }
+#pragma unroll
+        for (int j = 0; j < VPB; j++) cur[j] = nxt[j];
+    }
+    S.h(V16_UPPER + 0) = (int16_t)(su >> 16);
+    S.h(V16_LOWER + 0) = (int16_t)(sl >> 16);
+    if (RATIO == 2) {
+        S.w(V32_DS + 0) = d0;
+        S.w(V32_DS + 1) = d1;
+    }
+}
+
 // exchange area (int32 [field][lane], aliases the band buffers, which are dead between the filter bank and the next packet)
 enum : int { X_FEAT = 0, X_TOTAL = 6, X_LLR = 7, X_FLAG = 13, X_FIELDS = 19 };
 
@@ -802,11 +858,9 @@ __global__ __launch_bounds__(256) void vad_pipe_kernel(int16_t *s16, int32_t *s3
     const LaneBuf hp120{lds + lane}, lp120{lds + lane + 64 * (NB / 2)}, hp60{lds + lane + 64 * NB}, lp60{lds + lane + 64 * (NB + NB / 4)};
     for (int call = 0; call < n_calls; call++) {
         uint4 *frame4 = reinterpret_cast<uint4 *>(pcm + (size_t)stream * stream_stride + (size_t)call * call_stride);
-        uint4 raw[NV];
-#pragma unroll
-        for (int j = 0; j < NV; j++) raw[j] = frame4[j];
         int16_t feat[6], total;
-        vad_features<NB, RATIO>(S, RegSrc<NV>{raw}, hp120, lp120, hp60, lp60, feat, total);
+        vad_front_blocked<RATIO>(S, frame4, hp120, lp120);
+        vad_features_rest<NB>(S, hp120, lp120, hp60, lp60, feat, total);
         // the band buffers are read for the last time above and xch lives in the same bytes: keep the compiler from moving
         // the stores below in front of those reads (the hardware executes a wave's LDS instructions in order)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -858,8 +912,13 @@ __global__ __launch_bounds__(256) void vad_pipe_kernel(int16_t *s16, int32_t *s3
             return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16);
         };
         if (live) {
+            // the packet is fetched a second time (L2) rather than held in 80 registers across the two barriers: the
+            // kernel's register count decides how many workgroups share a CU
+            uint4 again[NV];
 #pragma unroll
-            for (int j = 0; j < NV; j++) frame4[j] = make_uint4(att(raw[j].x), att(raw[j].y), att(raw[j].z), att(raw[j].w));
+            for (int j = 0; j < NV; j++) again[j] = frame4[j];
+#pragma unroll
+            for (int j = 0; j < NV; j++) frame4[j] = make_uint4(att(again[j].x), att(again[j].y), att(again[j].z), att(again[j].w));
         }
         __syncthreads();  // 3
     }
