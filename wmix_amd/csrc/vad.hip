@@ -814,8 +814,8 @@ __device__ __forceinline__ void vad_pipe_channels(const VadRef &S, int16_t *s16,
 
 // RATIO = 1 (8 kHz) or 2 (16 kHz), one mono 10 ms packet per call, 16-byte aligned rows (what wmx_vad_process checks)
 template <int RATIO>
-__global__ __launch_bounds__(256) void vad_pipe_kernel(int16_t *s16, int32_t *s32, int16_t *pcm, int n_streams, int n_calls,
-                                                       long stream_stride, long call_stride) {
+__global__ __launch_bounds__(256) void vad_pipe_kernel(int16_t *s16, int32_t *s32, int16_t *pcm, int n_streams, int packets_per_call,
+                                                       int n_calls, long stream_stride, long call_stride) {
     constexpr int NB = 80, PKG = NB * RATIO, NV = PKG / 8;
     __shared__ __attribute__((aligned(16))) int16_t lds[64 * (NB / 2 + NB / 2 + NB / 4 + NB / 4)];
     __shared__ int16_t minlds[64 * kVadMinFields];
@@ -830,15 +830,15 @@ __global__ __launch_bounds__(256) void vad_pipe_kernel(int16_t *s16, int32_t *s3
     int32_t r32[V32_WORDS];
     const VadRef S{r16, r32, minlds + lane};
     if (wave == 0) {
-        vad_pipe_channels<0>(S, s16, s32, xch, minlds, lane, stream, live, n_streams, n_calls);
+        vad_pipe_channels<0>(S, s16, s32, xch, minlds, lane, stream, live, n_streams, n_calls * packets_per_call);
         return;
     }
     if (wave == 1) {
-        vad_pipe_channels<2>(S, s16, s32, xch, minlds, lane, stream, live, n_streams, n_calls);
+        vad_pipe_channels<2>(S, s16, s32, xch, minlds, lane, stream, live, n_streams, n_calls * packets_per_call);
         return;
     }
     if (wave == 2) {
-        vad_pipe_channels<4>(S, s16, s32, xch, minlds, lane, stream, live, n_streams, n_calls);
+        vad_pipe_channels<4>(S, s16, s32, xch, minlds, lane, stream, live, n_streams, n_calls * packets_per_call);
         return;
     }
     // ---- wave 3: filter bank, hangover, attenuation
@@ -856,7 +856,10 @@ __global__ __launch_bounds__(256) void vad_pipe_kernel(int16_t *s16, int32_t *s3
 #pragma unroll
     for (int i = 0; i < 4; i++) S.w(V32_DS + i) = s32[(size_t)(V32_DS + i) * n_streams + stream];
     const LaneBuf hp120{lds + lane}, lp120{lds + lane + 64 * (NB / 2)}, hp60{lds + lane + 64 * NB}, lp60{lds + lane + 64 * (NB + NB / 4)};
-    for (int call = 0; call < n_calls; call++) {
+    // A call of several packets analyses its FIRST packet once per packet (the wrapper never advances its pointer)
+    // and attenuates that packet after the first analysis only: the later analyses see the attenuated samples.
+    for (int pass = 0; pass < n_calls * packets_per_call; pass++) {
+        const int call = pass / packets_per_call, it = pass - call * packets_per_call;
         uint4 *frame4 = reinterpret_cast<uint4 *>(pcm + (size_t)stream * stream_stride + (size_t)call * call_stride);
         int16_t feat[6], total;
         vad_front_blocked<RATIO>(S, frame4, hp120, lp120);
@@ -911,7 +914,7 @@ __global__ __launch_bounds__(256) void vad_pipe_kernel(int16_t *s16, int32_t *s3
             const int lo = (int)(int16_t)(w & 0xffffu) >> reduce, hi = (int)(int16_t)(w >> 16) >> reduce;
             return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16);
         };
-        if (live) {
+        if (live && it == 0) {
             // the packet is fetched a second time (L2) rather than held in 80 registers across the two barriers: the
             // kernel's register count decides how many workgroups share a CU
             uint4 again[NV];
@@ -919,6 +922,7 @@ __global__ __launch_bounds__(256) void vad_pipe_kernel(int16_t *s16, int32_t *s3
             for (int j = 0; j < NV; j++) again[j] = frame4[j];
 #pragma unroll
             for (int j = 0; j < NV; j++) frame4[j] = make_uint4(att(again[j].x), att(again[j].y), att(again[j].z), att(again[j].w));
+            if (packets_per_call > 1) __threadfence();  // the next analysis of this call reads what was just stored
         }
         __syncthreads();  // 3
     }
@@ -1176,19 +1180,19 @@ int wmx_vad_process(wmx_vad *h, int16_t *d_pcm, int packets_per_call, int n_call
     hipStream_t s = as_stream(stream);
     const int nb = h->pkg / (h->freq / 8000);  // packet length at 8 kHz: 80 or 160
     const int ratio = h->freq / 8000;
-    // one mono 10 ms packet per call with 16-byte aligned rows -- the batched chain's case -- goes through the four-wave
-    // pipeline; every other shape (20 ms packets, several packets per call, 32 kHz, interleaved channels, odd alignment)
+    // mono 10 ms packets at 8 / 16 kHz with 16-byte aligned rows -- the batched chain's case, one or several packets per call --
+    // go through the four-wave pipeline; every other shape (20 ms packets, 32 kHz, interleaved channels, odd alignment)
     // through the one-lane-per-stream kernel
-    const bool pipe = h->chn == 1 && packets_per_call == 1 && h->pkg == 80 * (h->freq / 8000) && h->freq <= 16000 &&
+    const bool pipe = h->chn == 1 && h->pkg == 80 * (h->freq / 8000) && h->freq <= 16000 &&
                       (stream_stride % 8) == 0 && (call_stride % 8) == 0 && (reinterpret_cast<size_t>(d_pcm) % 16) == 0 &&
                       !getenv("WMIX_AMD_VAD_ONE_LANE");
     if (pipe) {
         if (h->freq == 8000)
-            hipLaunchKernelGGL((vad_pipe_kernel<1>), grid, dim3(256), 0, s, h->d_s16, h->d_s32, d_pcm, h->n_streams, n_calls, stream_stride,
-                               call_stride);
+            hipLaunchKernelGGL((vad_pipe_kernel<1>), grid, dim3(256), 0, s, h->d_s16, h->d_s32, d_pcm, h->n_streams, packets_per_call, n_calls,
+                               stream_stride, call_stride);
         else
-            hipLaunchKernelGGL((vad_pipe_kernel<2>), grid, dim3(256), 0, s, h->d_s16, h->d_s32, d_pcm, h->n_streams, n_calls, stream_stride,
-                               call_stride);
+            hipLaunchKernelGGL((vad_pipe_kernel<2>), grid, dim3(256), 0, s, h->d_s16, h->d_s32, d_pcm, h->n_streams, packets_per_call, n_calls,
+                               stream_stride, call_stride);
         WMX_LAUNCH_CHECK();
         return 0;
     }
