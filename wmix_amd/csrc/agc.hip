@@ -17,6 +17,7 @@
 // (SURVEY.md section 8 row a15); it has no device counterpart.  The gain table itself is computed on
 // the host by WebRtcAgc_CalculateGainTable's integer recipe (digital_agc.c:61-257).
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 #include "wmx_internal.h"
 #include "spl_dev.h"
@@ -80,60 +81,10 @@ __device__ __forceinline__ int16_t down2_step(int16_t a, int16_t b, int32_t *st)
     return sat_w16(wadd(wadd(st[3], st[7]), 1024) >> 11);
 }
 
-// One packet (10*L mono samples) of one stream.  in/out point at the packet's first frame;
-// `chn` interleaved channels are averaged on input and duplicated on output (src/webrtc.c:789-815).
-template <int L, int CHN>  // L samples per millisecond sub-frame: 8 (8 kHz) or 16 (16 / 32 kHz); CHN interleaved channels
-__device__ void agc_packet(const AgcRef &S, const int32_t *__restrict__ gain_table, const int16_t *in, int16_t *out, int chn_rt) {
-    const int chn = CHN ? CHN : chn_rt;  // CHN = 1, 2: compile-time (the daemon's cases); 0: any count, at run time
-    constexpr int L2 = (L == 8) ? 3 : 4;
-    auto load = [&](int i) -> int16_t {
-        if (chn == 1) return in[i];
-        int32_t acc = 0;
-        for (int c = 0; c < chn; c++) acc += in[i * chn + c];
-        return (int16_t)(acc / chn);
-    };
-    // ---- pass 1 over the packet: level detector (ProcessVad) and per-millisecond peak energy
-    int32_t env[10];
-    int32_t nrg = 0;
-    {
-        int32_t ds[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) ds[i] = S.w(A32_DOWN + i);
-        int16_t hp = S.h(A16_HP);
-#pragma unroll
-        for (int k = 0; k < 10; k++) {
-            int32_t mx = 0;
-            int16_t x[L];
-#pragma unroll
-            for (int n = 0; n < L; n++) {
-                x[n] = load(k * L + n);
-                const int32_t e = x[n] * x[n];
-                if (e > mx) mx = e;
-            }
-            env[k] = mx;
-            int16_t b2[4];
-            if (L == 16) {
-                int16_t b1[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) b1[j] = (int16_t)(((int32_t)x[2 * j] + (int32_t)x[2 * j + 1]) >> 1);
-#pragma unroll
-                for (int j = 0; j < 4; j++) b2[j] = down2_step(b1[2 * j], b1[2 * j + 1], ds);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; j++) b2[j] = down2_step(x[2 * j], x[2 * j + 1], ds);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int32_t o = b2[j] + hp;
-                const int32_t t = 600 * o;
-                hp = (int16_t)((t >> 10) - b2[j]);
-                nrg = wadd(nrg, (o * o) >> 6);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; i++) S.w(A32_DOWN + i) = ds[i];
-        S.h(A16_HP) = hp;
-    }
+// Everything between the two passes over a packet: ProcessVad's statistics from the level detector's energy, the envelope
+// followers over the ten per-millisecond peaks, the gain curve, the gate and the overflow limiter -> gains[0..10]
+__device__ __forceinline__ void agc_decide(const AgcRef &S, const int32_t *__restrict__ gain_table, int32_t nrg, const int32_t (&env)[10],
+                                           int32_t (&gains)[11]) {
     // ---- ProcessVad statistics (digital_agc.c:685-770)
     int16_t std_long, std_short, logratio;
     {
@@ -186,7 +137,6 @@ __device__ void agc_packet(const AgcRef &S, const int32_t *__restrict__ gain_tab
         decay = 0;
     else if (std_long < 8096)
         decay = (int16_t)(((std_long - 4000) * decay) >> 12);
-    int32_t gains[11];
     int32_t cap_fast = S.w(A32_CAP_FAST), cap_slow = S.w(A32_CAP_SLOW);
     gains[0] = S.w(A32_GAIN);
     int16_t zeros = 0, frac = 0;
@@ -261,6 +211,74 @@ __device__ void agc_packet(const AgcRef &S, const int32_t *__restrict__ gain_tab
     for (int k = 1; k < 10; k++)
         if (gains[k] > gains[k + 1]) gains[k] = gains[k + 1];
     S.w(A32_GAIN) = gains[10];
+}
+
+// one output sample of pass 2 (digital_agc.c:552-603); the first sub-frame saturates, the others wrap
+__device__ __forceinline__ int16_t agc_apply(int16_t x, int32_t gain32, bool first_subframe) {
+    if (first_subframe) {
+        const int32_t o = wmul(x, wadd(gain32, 127) >> 7) >> 16;
+        if (o > 4095) return 32767;
+        if (o < -4096) return -32768;
+    }
+    return (int16_t)(wmul(x, gain32 >> 4) >> 16);
+}
+
+// One packet (10*L mono samples) of one stream.  in/out point at the packet's first frame;
+// `chn` interleaved channels are averaged on input and duplicated on output (src/webrtc.c:789-815).
+template <int L, int CHN>  // L samples per millisecond sub-frame: 8 (8 kHz) or 16 (16 / 32 kHz); CHN interleaved channels
+__device__ void agc_packet(const AgcRef &S, const int32_t *__restrict__ gain_table, const int16_t *in, int16_t *out, int chn_rt) {
+    const int chn = CHN ? CHN : chn_rt;  // CHN = 1, 2: compile-time (the daemon's cases); 0: any count, at run time
+    constexpr int L2 = (L == 8) ? 3 : 4;
+    auto load = [&](int i) -> int16_t {
+        if (chn == 1) return in[i];
+        int32_t acc = 0;
+        for (int c = 0; c < chn; c++) acc += in[i * chn + c];
+        return (int16_t)(acc / chn);
+    };
+    // ---- pass 1 over the packet: level detector (ProcessVad) and per-millisecond peak energy
+    int32_t env[10];
+    int32_t nrg = 0;
+    {
+        int32_t ds[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) ds[i] = S.w(A32_DOWN + i);
+        int16_t hp = S.h(A16_HP);
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+            int32_t mx = 0;
+            int16_t x[L];
+#pragma unroll
+            for (int n = 0; n < L; n++) {
+                x[n] = load(k * L + n);
+                const int32_t e = x[n] * x[n];
+                if (e > mx) mx = e;
+            }
+            env[k] = mx;
+            int16_t b2[4];
+            if (L == 16) {
+                int16_t b1[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) b1[j] = (int16_t)(((int32_t)x[2 * j] + (int32_t)x[2 * j + 1]) >> 1);
+#pragma unroll
+                for (int j = 0; j < 4; j++) b2[j] = down2_step(b1[2 * j], b1[2 * j + 1], ds);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) b2[j] = down2_step(x[2 * j], x[2 * j + 1], ds);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int32_t o = b2[j] + hp;
+                const int32_t t = 600 * o;
+                hp = (int16_t)((t >> 10) - b2[j]);
+                nrg = wadd(nrg, (o * o) >> 6);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) S.w(A32_DOWN + i) = ds[i];
+        S.h(A16_HP) = hp;
+    }
+    int32_t gains[11];
+    agc_decide(S, gain_table, nrg, env, gains);
     // ---- pass 2: apply the ramped gain (digital_agc.c:552-603)
     auto store = [&](int i, int16_t v) {
         for (int c = 0; c < chn; c++) out[i * chn + c] = v;
@@ -319,6 +337,147 @@ __global__ __launch_bounds__(64) void agc_kernel(int16_t *s16, int32_t *s32, con
             const size_t off = (size_t)stream * stream_stride + (size_t)p * packet_stride;
             agc_packet<L, CHN>(S, gain_table, in + off, out + off, chn_rt);
         }
+#pragma unroll
+        for (int f = 0; f < A32_WORDS; f++) s32[(size_t)f * n_streams + stream] = r32[f];
+#pragma unroll
+        for (int f = 0; f < A16_WORDS; f++) s16[(size_t)f * n_streams + stream] = r16[f];
+    }
+}
+
+// ================================================================== the mono packet as a four-wave pipeline
+// agc_kernel runs a stream in one lane from end to end: 65 536 streams are 1 024 waves, one per SIMD, and the launch lasts as
+// long as one wave's chain of ~3 900 instructions issued one every >= 8 cycles.  Here a workgroup still owns 64 streams
+// (lane = stream), but as four waves: waves 0..2 share the packet's ten 1 ms sub-frames ({0..3}, {4..6}, {7..9}), load them
+// once (two 16-byte loads per sub-frame at 16 kHz), take their peak energies and hand the level detector's input (pair
+// averages at 16 kHz) over through LDS; wave 3, which holds no samples, runs the serial part -- the detector's decimator,
+// ProcessVad's statistics, the envelope followers, gain curve, gate and limiter (agc_decide) -- and publishes the eleven
+// gains; waves 0..2 then apply the gain ramp to the samples they still hold and store them.  Same integer operations per
+// stream as agc_kernel, which stays for interleaved channels and unaligned rows.
+template <int L>
+__global__ __launch_bounds__(256) void agc_pipe_kernel(int16_t *s16, int32_t *s32, const int32_t *gain_table_g, const int16_t *in,
+                                                       int16_t *out, int n_streams, int n_packets, long stream_stride,
+                                                       long packet_stride) {
+    constexpr int L2 = (L == 8) ? 3 : 4, VPS = L / 8;  // uint4 per sub-frame
+    __shared__ int32_t gain_table[32];
+    __shared__ int16_t xdet[80 * 64];  // the detector's 80 input samples of every stream, [sample][lane]
+    __shared__ int32_t xenv[10 * 64];  // per-millisecond peak energies
+    __shared__ int32_t xgain[11 * 64];
+    if (threadIdx.x < 32) gain_table[threadIdx.x] = gain_table_g[threadIdx.x];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int stream_raw = (int)blockIdx.x * 64 + lane;
+    const bool live = stream_raw < n_streams;
+    const int stream = live ? stream_raw : n_streams - 1;  // a lane without a stream recomputes the last one and stores nothing
+    const int k0 = wave == 0 ? 0 : (wave == 1 ? 4 : 7), nk = wave == 0 ? 4 : (wave == 3 ? 0 : 3);  // this wave's sub-frames
+    int16_t r16[A16_WORDS];
+    int32_t r32[A32_WORDS];
+    const AgcRef S{r16, r32, 1};
+    if (wave == 3) {
+#pragma unroll
+        for (int f = 0; f < A32_WORDS; f++) r32[f] = s32[(size_t)f * n_streams + stream];
+#pragma unroll
+        for (int f = 0; f < A16_WORDS; f++) r16[f] = s16[(size_t)f * n_streams + stream];
+    }
+    for (int p = 0; p < n_packets; p++) {
+        const size_t off = (size_t)stream * stream_stride + (size_t)p * packet_stride;
+        const uint4 *in4 = reinterpret_cast<const uint4 *>(in + off);
+        uint4 *out4 = reinterpret_cast<uint4 *>(out + off);
+        auto sample = [](const uint4 (&raw)[VPS], int i) -> int16_t {  // sample i of a sub-frame (compile-time i)
+            const uint4 v = raw[i >> 3];
+            const unsigned w = ((i >> 1) & 3) == 0 ? v.x : (((i >> 1) & 3) == 1 ? v.y : (((i >> 1) & 3) == 2 ? v.z : v.w));
+            return (int16_t)((i & 1) ? (w >> 16) : (w & 0xffffu));
+        };
+        // ---- pass 1, this wave's share: peak energy per sub-frame, the detector's input samples.  One sub-frame in
+        //      registers at a time (the next one requested while this one is reduced); pass 2 fetches them again from L2 --
+        //      held across the barriers, the samples cost the registers that decide how many workgroups share a CU.
+        if (nk) {
+            uint4 cur[VPS], nxt[VPS];
+#pragma unroll
+            for (int j = 0; j < VPS; j++) cur[j] = in4[k0 * VPS + j];
+#pragma unroll 1
+            for (int kk = 0; kk < nk; kk++) {
+                const int kn = kk + 1 < nk ? kk + 1 : kk;
+#pragma unroll
+                for (int j = 0; j < VPS; j++) nxt[j] = in4[(k0 + kn) * VPS + j];
+                int32_t mx = 0;
+#pragma unroll
+                for (int n = 0; n < L; n++) {
+                    const int32_t x = sample(cur, n);
+                    const int32_t e = x * x;
+                    if (e > mx) mx = e;
+                }
+                xenv[(k0 + kk) * 64 + lane] = mx;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int16_t d = L == 16 ? (int16_t)(((int32_t)sample(cur, 2 * j) + (int32_t)sample(cur, 2 * j + 1)) >> 1) : sample(cur, j);
+                    xdet[((k0 + kk) * 8 + j) * 64 + lane] = d;
+                }
+#pragma unroll
+                for (int j = 0; j < VPS; j++) cur[j] = nxt[j];
+            }
+        }
+        __syncthreads();  // 1: peaks and detector input of the whole packet are in LDS
+        if (wave == 3) {
+            int32_t env[10], gains[11], nrg = 0;
+            int32_t ds[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) ds[i] = S.w(A32_DOWN + i);
+            int16_t hp = S.h(A16_HP);
+#pragma unroll 2
+            for (int k = 0; k < 10; k++) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int16_t b2 = down2_step(xdet[(k * 8 + 2 * j) * 64 + lane], xdet[(k * 8 + 2 * j + 1) * 64 + lane], ds);
+                    const int32_t o = b2 + hp;
+                    const int32_t t = 600 * o;
+                    hp = (int16_t)((t >> 10) - b2);
+                    nrg = wadd(nrg, (o * o) >> 6);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) S.w(A32_DOWN + i) = ds[i];
+            S.h(A16_HP) = hp;
+#pragma unroll
+            for (int k = 0; k < 10; k++) env[k] = xenv[k * 64 + lane];
+            agc_decide(S, gain_table, nrg, env, gains);
+#pragma unroll
+            for (int k = 0; k < 11; k++) xgain[k * 64 + lane] = gains[k];
+        }
+        __syncthreads();  // 2: the packet's gains are in LDS
+        // ---- pass 2, this wave's share
+        if (nk) {
+            uint4 cur[VPS], nxt[VPS];
+#pragma unroll
+            for (int j = 0; j < VPS; j++) cur[j] = in4[k0 * VPS + j];
+#pragma unroll 1
+            for (int kk = 0; kk < nk; kk++) {
+                const int k = k0 + kk, kn = kk + 1 < nk ? kk + 1 : kk;
+#pragma unroll
+                for (int j = 0; j < VPS; j++) nxt[j] = in4[(k0 + kn) * VPS + j];  // before this sub-frame's stores (in == out)
+                const int32_t ga = xgain[k * 64 + lane], gb = xgain[(k + 1) * 64 + lane];
+                const int32_t delta = wshl(wsub(gb, ga), 4 - L2);
+                int32_t gain32 = wshl(ga, 4);
+                unsigned yw[L / 2];
+#pragma unroll
+                for (int n = 0; n < L; n++) {
+                    const int16_t y = agc_apply(sample(cur, n), gain32, k == 0);
+                    gain32 = wadd(gain32, delta);
+                    if (n & 1)
+                        yw[n >> 1] |= (unsigned)(uint16_t)y << 16;
+                    else
+                        yw[n >> 1] = (unsigned)(uint16_t)y;
+                }
+                if (live) {
+#pragma unroll
+                    for (int j = 0; j < VPS; j++) out4[k * VPS + j] = make_uint4(yw[4 * j], yw[4 * j + 1], yw[4 * j + 2], yw[4 * j + 3]);
+                }
+#pragma unroll
+                for (int j = 0; j < VPS; j++) cur[j] = nxt[j];
+            }
+        }
+        __syncthreads();  // 3: LDS may be overwritten by the next packet
+    }
+    if (wave == 3 && live) {
 #pragma unroll
         for (int f = 0; f < A32_WORDS; f++) s32[(size_t)f * n_streams + stream] = r32[f];
 #pragma unroll
@@ -571,6 +730,19 @@ int wmx_agc_process(wmx_agc *h, const int16_t *d_in, int16_t *d_out, int n_packe
     }
     const dim3 grid((h->n_streams + 63) / 64), block(64);
     hipStream_t s = as_stream(stream);
+    // mono packets with 16-byte aligned rows -- the batched chain's case -- go through the four-wave pipeline
+    const bool pipe = h->chn == 1 && (stream_stride % 8) == 0 && (packet_stride % 8) == 0 && (reinterpret_cast<size_t>(d_in) % 16) == 0 &&
+                      (reinterpret_cast<size_t>(d_out) % 16) == 0 && !getenv("WMIX_AMD_AGC_ONE_LANE");
+    if (pipe) {
+        if (h->freq == 8000)
+            hipLaunchKernelGGL((agc_pipe_kernel<8>), grid, dim3(256), 0, s, h->d_s16, h->d_s32, h->d_table, d_in, d_out, h->n_streams, n_packets,
+                               stream_stride, packet_stride);
+        else
+            hipLaunchKernelGGL((agc_pipe_kernel<16>), grid, dim3(256), 0, s, h->d_s16, h->d_s32, h->d_table, d_in, d_out, h->n_streams, n_packets,
+                               stream_stride, packet_stride);
+        WMX_LAUNCH_CHECK();
+        return 0;
+    }
 #define AGC_LAUNCH(LL, CC)                                                                                                   \
     hipLaunchKernelGGL((agc_kernel<LL, CC>), grid, block, 0, s, h->d_s16, h->d_s32, h->d_table, d_in, d_out, h->n_streams, n_packets, \
                        stream_stride, packet_stride, h->chn)
