@@ -1,4 +1,5 @@
-// agc.hip -- batched legacy (fixed-point) AGC for gfx950: one LANE per stream.
+// agc.hip -- batched legacy (fixed-point) AGC for gfx950: one LANE per stream (agc_kernel), and for mono packets one lane
+// per stream in four waves that split a packet's work (agc_pipe_kernel, further down).
 //
 // Replaces, for many independent streams per launch, wmix's agc_process() (src/webrtc.c:767-819)
 // over WebRtcAgc_Process in adaptive-digital mode, target 0 dBFS, limiter off

@@ -1,4 +1,5 @@
-// vad.hip -- batched voice-activity gate for gfx950: one LANE per stream.
+// vad.hip -- batched voice-activity gate for gfx950: one LANE per stream (vad_kernel), and for the mono 10 ms packets of the
+// batched chain one lane per stream in FOUR waves that split a packet's work (vad_pipe_kernel, further down).
 //
 // Replaces, for many independent streams per launch, wmix's vad_process() (src/webrtc.c:91-151)
 // over WebRtcVad_Process in mode 3 (W:common_audio/vad/webrtc_vad.c:71-104, vad_core.c:124-674,
@@ -14,6 +15,8 @@
 // the end), and a mono single-packet call also fetches its packet as uint4 rows in one batch, analyses
 // and attenuates it in registers and writes it back the same way (other shapes: the packet's lines are
 // pulled into L2 up front and read from memory).
+// vad_pipe_kernel: the filter bank and the packet in one wave, two GMM channels in each of the other three, features and
+// likelihood ratios through LDS at two workgroup barriers -- four waves per SIMD instead of one, half the time.
 // Results are bit-exact with the reference; signed overflow that the reference leaves to
 // two's-complement wrap is spelled out.
 //
