@@ -169,3 +169,23 @@ def test_full_size_batch_properties(cuda):
     assert np.array_equal(out[:8].reshape(8, -1), small)
     for k in range(8):
         assert (out[idx == k] == out[k]).all()
+
+
+@pytest.mark.parametrize("freq", [8000, 16000])
+@pytest.mark.parametrize("S,k", [(1, 1), (65, 2), (130, 3)])
+def test_pipeline_kernels_equal_the_one_lane_kernels(cuda, monkeypatch, freq, S, k):
+    """The four-wave VAD / AGC pipelines (mono 10 ms packets, aligned rows) against the one-lane-per-stream kernels they
+    replace, on stream counts that leave lanes and workgroups partly empty and on calls of 1, 2 and 3 packets (the
+    wrapper's analyse-packet-0-again quirk); then the AGC out of place."""
+    n_calls = 150
+    xv = np.stack([vad_input(1, freq, 10, k, n_calls=n_calls, seed=900 + 3 * s) for s in range(S)])
+    xa = np.stack([agc_input(1, freq, n_calls=n_calls, seed=950 + 5 * s) for s in range(S)])
+    res = {}
+    for one_lane in ("1", "0"):
+        monkeypatch.setenv("WMIX_AMD_VAD_ONE_LANE", one_lane)
+        monkeypatch.setenv("WMIX_AMD_AGC_ONE_LANE", one_lane)
+        res[one_lane] = (gpu_vad(cuda, 1, freq, 10, k, xv, calls_per_launch=40, packet_major=(S > 1)),
+                         gpu_agc(cuda, 1, freq, 5, xa, packets_per_launch=64, packet_major=(S > 1)),
+                         gpu_agc(cuda, 1, freq, 5, xa, packets_per_launch=7, in_place=False))
+    for a, b in zip(res["1"], res["0"]):
+        assert np.array_equal(a, b)
