@@ -130,7 +130,14 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const flo
     if (plan_by_value) {
         const int *src = reinterpret_cast<const int *>(&plan_value);
         int *dst = reinterpret_cast<int *>(plans);
-        for (int i = lane; i < (int)(sizeof(AecPlan) / 4); i += 64) dst[i] = src[i];
+        // every request before the first store: the argument segment is far away (host memory), one round trip not nine
+        constexpr int NW = (int)(sizeof(AecPlan) / 4), NIT = (NW + 63) / 64;
+        int v[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; k++) v[k] = src[lane + 64 * k < NW ? lane + 64 * k : 0];
+#pragma unroll
+        for (int k = 0; k < NIT; k++)
+            if (lane + 64 * k < NW) dst[lane + 64 * k] = v[k];
         __threadfence();
         wave_sync();
     }
