@@ -189,3 +189,16 @@ def test_pipeline_kernels_equal_the_one_lane_kernels(cuda, monkeypatch, freq, S,
                          gpu_agc(cuda, 1, freq, 5, xa, packets_per_launch=7, in_place=False))
     for a, b in zip(res["1"], res["0"]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("freq", [8000, 32000])
+def test_two_channel_agc_pipeline_equals_the_one_lane_kernel(cuda, monkeypatch, freq):
+    """Interleaved stereo through the AGC pipeline (pair averaged on the way in, result written to both channels)."""
+    S = 70
+    xa = np.stack([agc_input(2, freq, n_calls=120, seed=990 + 5 * s) for s in range(S)])
+    res = {}
+    for one_lane in ("1", "0"):
+        monkeypatch.setenv("WMIX_AMD_AGC_ONE_LANE", one_lane)
+        res[one_lane] = (gpu_agc(cuda, 2, freq, 9, xa, packets_per_launch=50), gpu_agc(cuda, 2, freq, 9, xa, packets_per_launch=3, in_place=False))
+    for a, b in zip(res["1"], res["0"]):
+        assert np.array_equal(a, b)

@@ -353,12 +353,13 @@ __global__ __launch_bounds__(64) void agc_kernel(int16_t *s16, int32_t *s32, con
 // averages at 16 kHz) over through LDS; wave 3, which holds no samples, runs the serial part -- the detector's decimator,
 // ProcessVad's statistics, the envelope followers, gain curve, gate and limiter (agc_decide) -- and publishes the eleven
 // gains; waves 0..2 then apply the gain ramp to the samples they still hold and store them.  Same integer operations per
-// stream as agc_kernel, which stays for interleaved channels and unaligned rows.
-template <int L>
+// stream as agc_kernel, which stays for more than two channels and unaligned rows.  CHN = 2: the interleaved pair is averaged
+// on the way in and the result written to both channels (src/webrtc.c:789-815), like agc_packet's load / store.
+template <int L, int CHN>
 __global__ __launch_bounds__(256) void agc_pipe_kernel(int16_t *s16, int32_t *s32, const int32_t *gain_table_g, const int16_t *in,
                                                        int16_t *out, int n_streams, int n_packets, long stream_stride,
                                                        long packet_stride) {
-    constexpr int L2 = (L == 8) ? 3 : 4, VPS = L / 8;  // uint4 per sub-frame
+    constexpr int L2 = (L == 8) ? 3 : 4, VPS = L * CHN / 8;  // uint4 per sub-frame
     __shared__ int32_t gain_table[32];
     __shared__ int16_t xdet[80 * 64];  // the detector's 80 input samples of every stream, [sample][lane]
     __shared__ int32_t xenv[10 * 64];  // per-millisecond peak energies
@@ -383,10 +384,17 @@ __global__ __launch_bounds__(256) void agc_pipe_kernel(int16_t *s16, int32_t *s3
         const size_t off = (size_t)stream * stream_stride + (size_t)p * packet_stride;
         const uint4 *in4 = reinterpret_cast<const uint4 *>(in + off);
         uint4 *out4 = reinterpret_cast<uint4 *>(out + off);
-        auto sample = [](const uint4 (&raw)[VPS], int i) -> int16_t {  // sample i of a sub-frame (compile-time i)
-            const uint4 v = raw[i >> 3];
-            const unsigned w = ((i >> 1) & 3) == 0 ? v.x : (((i >> 1) & 3) == 1 ? v.y : (((i >> 1) & 3) == 2 ? v.z : v.w));
-            return (int16_t)((i & 1) ? (w >> 16) : (w & 0xffffu));
+        auto sample = [](const uint4 (&raw)[VPS], int i) -> int16_t {  // mono sample i of a sub-frame (compile-time i)
+            if constexpr (CHN == 1) {
+                const uint4 v = raw[i >> 3];
+                const unsigned w = ((i >> 1) & 3) == 0 ? v.x : (((i >> 1) & 3) == 1 ? v.y : (((i >> 1) & 3) == 2 ? v.z : v.w));
+                return (int16_t)((i & 1) ? (w >> 16) : (w & 0xffffu));
+            } else {  // frame i = one word: left | right << 16
+                const uint4 v = raw[i >> 2];
+                const unsigned w = (i & 3) == 0 ? v.x : ((i & 3) == 1 ? v.y : ((i & 3) == 2 ? v.z : v.w));
+                const int32_t acc = (int32_t)(int16_t)(w & 0xffffu) + (int32_t)(int16_t)(w >> 16);
+                return (int16_t)(acc / 2);
+            }
         };
         // ---- pass 1, this wave's share: peak energy per sub-frame, the detector's input samples.  One sub-frame in
         //      registers at a time (the next one requested while this one is reduced); pass 2 fetches them again from L2 --
@@ -458,12 +466,14 @@ __global__ __launch_bounds__(256) void agc_pipe_kernel(int16_t *s16, int32_t *s3
                 const int32_t ga = xgain[k * 64 + lane], gb = xgain[(k + 1) * 64 + lane];
                 const int32_t delta = wshl(wsub(gb, ga), 4 - L2);
                 int32_t gain32 = wshl(ga, 4);
-                unsigned yw[L / 2];
+                unsigned yw[L * CHN / 2];
 #pragma unroll
                 for (int n = 0; n < L; n++) {
                     const int16_t y = agc_apply(sample(cur, n), gain32, k == 0);
                     gain32 = wadd(gain32, delta);
-                    if (n & 1)
+                    if (CHN == 2)
+                        yw[n] = (unsigned)(uint16_t)y | ((unsigned)(uint16_t)y << 16);
+                    else if (n & 1)
                         yw[n >> 1] |= (unsigned)(uint16_t)y << 16;
                     else
                         yw[n >> 1] = (unsigned)(uint16_t)y;
@@ -731,16 +741,25 @@ int wmx_agc_process(wmx_agc *h, const int16_t *d_in, int16_t *d_out, int n_packe
     }
     const dim3 grid((h->n_streams + 63) / 64), block(64);
     hipStream_t s = as_stream(stream);
-    // mono packets with 16-byte aligned rows -- the batched chain's case -- go through the four-wave pipeline
-    const bool pipe = h->chn == 1 && (stream_stride % 8) == 0 && (packet_stride % 8) == 0 && (reinterpret_cast<size_t>(d_in) % 16) == 0 &&
+    // one- and two-channel packets with 16-byte aligned rows -- the batched chains' cases -- go through the four-wave pipeline
+    const bool pipe = h->chn <= 2 && (stream_stride % 8) == 0 && (packet_stride % 8) == 0 && (reinterpret_cast<size_t>(d_in) % 16) == 0 &&
                       (reinterpret_cast<size_t>(d_out) % 16) == 0 && !getenv("WMIX_AMD_AGC_ONE_LANE");
     if (pipe) {
-        if (h->freq == 8000)
-            hipLaunchKernelGGL((agc_pipe_kernel<8>), grid, dim3(256), 0, s, h->d_s16, h->d_s32, h->d_table, d_in, d_out, h->n_streams, n_packets,
-                               stream_stride, packet_stride);
-        else
-            hipLaunchKernelGGL((agc_pipe_kernel<16>), grid, dim3(256), 0, s, h->d_s16, h->d_s32, h->d_table, d_in, d_out, h->n_streams, n_packets,
-                               stream_stride, packet_stride);
+#define AGC_PIPE(LL, CC)                                                                                                          \
+    hipLaunchKernelGGL((agc_pipe_kernel<LL, CC>), grid, dim3(256), 0, s, h->d_s16, h->d_s32, h->d_table, d_in, d_out, h->n_streams, \
+                       n_packets, stream_stride, packet_stride)
+        if (h->freq == 8000) {
+            if (h->chn == 1)
+                AGC_PIPE(8, 1);
+            else
+                AGC_PIPE(8, 2);
+        } else {
+            if (h->chn == 1)
+                AGC_PIPE(16, 1);
+            else
+                AGC_PIPE(16, 2);
+        }
+#undef AGC_PIPE
         WMX_LAUNCH_CHECK();
         return 0;
     }
