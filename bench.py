@@ -577,14 +577,10 @@ class ChainWorkload:
     dominant_bytes_per_frame = 24040.0
     freq, pkt = 16000, 160
     with_agc_vad = True
-    overlap_tail = os.environ.get("WMIX_BENCH_OVERLAP_TAIL", "0") == "1"  # developer switch, see the comment in __init__
 
     def __init__(self, dev, n_streams, rank, dist=None, packets=1):
         from wmix_amd import synth
-        from wmix_amd.aec import AecBatch
-        from wmix_amd.agc import AgcBatch
-        from wmix_amd.ns import NsBatch
-        from wmix_amd.vad import VadBatch
+        from wmix_amd.chain import AEC, AGC, NS, VAD, ChainBatch
         global broadcast_far
         from wmix_amd.shard import broadcast_far
         self.n_streams = n_streams
@@ -602,72 +598,81 @@ class ChainWorkload:
         b = torch.from_numpy(np.ascontiguousarray(base.transpose(1, 0, 2))).to(dev)  # [K, 256, pkt]
         self.inp = b[:, torch.arange(n_streams, device=dev) % 256]                     # [K, S, pkt] packet-major
         self.far_src = torch.from_numpy(far.reshape(self.K, self.pkt).copy()).to(dev)
+        if dist is not None and rank != 0:
+            self.far_src.zero_()  # only rank 0 has the far-end; the others hear it through the broadcast alone
         self.P = packets  # 10 ms packets per stream per step (1 = one packet per launch; 2 = the daemon's own 20 ms calls)
         assert self.K % self.P == 0
-        self.far = torch.zeros(self.P, self.pkt, dtype=torch.int16, device=dev)
-        # Two packet buffers for the developer switch WMIX_BENCH_OVERLAP_TAIL=1: AGC and VAD are lane-per-stream chains
-        # that leave most of the GPU idle (one wave per SIMD, issue-bound); on a second, high-priority HIP stream they run
-        # beside step k+1's noise suppressor (per stream the order NS -> AEC -> AGC -> VAD of every packet is unchanged:
-        # events between the two HIP streams).  Measured: 1.42 -> 1.39 ms per step, but VAD then trickles in behind the
-        # NS workgroups that hold all the LDS (0.44 ms instead of 0.07), reaches into the AEC launch and costs it 3 %.
-        # Off by default: the per-kernel timings of the default line stay those of kernels running alone.
-        self.works = [torch.empty_like(self.inp[0:self.P]) for _ in range(2)]
-        self.work = self.works[0]
-        self.side = torch.cuda.Stream(device=dev, priority=-1) if self.overlap_tail else None
-        self.ev_aec = [torch.cuda.Event() for _ in range(2)]
-        self.ev_tail = [None, None]
-        self.ns = NsBatch(n_streams, 1, self.freq, ordered=True)
-        self.aec = AecBatch(n_streams, 1, self.freq, 10)
-        self.agc = AgcBatch(n_streams, 1, self.freq, 5) if self.with_agc_vad else None  # volumeAgc default 5, src/wmix.c:1596
-        self.vad = VadBatch(n_streams, 1, self.freq, 10) if self.with_agc_vad else None
+        # several GPUs: two far-end receive buffers; the packet of step k + 1 is broadcast while step k computes (the daemon
+        # itself hands the AEC a far-end that is 400 ms old, src/wmix.c:651-657: it is known long before it is needed)
+        self.far = [torch.zeros(self.P, self.pkt, dtype=torch.int16, device=dev) for _ in range(2)]
+        self.far_work = [None, None]
+        self.work = torch.empty_like(self.inp[0:self.P])
+        # the four stages behind ONE C call per step (wmx_chain_process, the heartbeat of src/wmix.c:613-709)
+        self.chain = ChainBatch(n_streams, 1, self.freq, 10, 5,  # volumeAgc default 5, src/wmix.c:1596
+                                (NS | AEC | AGC | VAD) if self.with_agc_vad else (NS | AEC))
         self.rank = rank
         self.t = _StageTimer("aec")
         self.k = 0
+        self.near_ms, self.far_ms, self.aec_launches = 0.0, 0.0, 0
         self.sample = [int(i) for i in np.linspace(0, n_streams - 1, 16)]
         self.rec = []
+
+    def _far_for(self, step_index):
+        """The far-end packets of a step.  One GPU: read where they lie.  Several: rank 0's packets arrive through the
+        broadcast buffer of that step's parity, requested one step ahead."""
+        P = self.P
+        k = (step_index * P) % self.K
+        if self.dist is None:
+            return self.far_src[k:k + P]
+        b = step_index & 1
+        if self.far_work[b] is None:  # first step: nothing was requested ahead
+            self._request_far(step_index)
+        w, self.far_work[b] = self.far_work[b], None
+        if w is not True:
+            w.wait()
+        self._request_far(step_index + 1)
+        return self.far[b]
+
+    def _request_far(self, step_index):
+        b = step_index & 1
+        k = (step_index * self.P) % self.K
+        if self.rank == 0:
+            self.far[b].copy_(self.far_src[k:k + self.P])
+        self.far_work[b] = broadcast_far(self.far[b], self.dist, src=0, async_op=True) or True
+
+    def timed_region(self, on):
+        """Inside the timed region the library itself records HIP events around the AEC's kernels, on the launch stream
+        (wmx_aec_set_timing): the dominant kernel's own duration, far kernel excluded."""
+        self.chain.set_aec_timing(on)
+        if not on:
+            n, f, r = self.chain.aec_timing()
+            self.aec_launches, self.far_ms, self.near_ms = self.aec_launches + n, self.far_ms + f, self.near_ms + r
 
     def step(self, timed):
         P = self.P
         k = (self.k * P) % self.K
-        b = self.k & 1
         step_index = self.k
         self.k += 1
-        self.work = self.works[b]
-        main = torch.cuda.current_stream()
-        if self.ev_tail[b] is not None:
-            main.wait_event(self.ev_tail[b])  # the tail of two steps ago has finished with this buffer
-        # one GPU: the far-end packet is read where it lies, like the near-end packets; several GPUs: rank 0's packet goes
-        # through the broadcast buffer, and the broadcast (RCCL, its own stream) runs behind the noise suppressor, which
-        # does not need it
-        far = self.far_src[k:k + P] if self.dist is None else self.far
-        if self.dist is not None and self.rank == 0:
-            self.far.copy_(self.far_src[k:k + P])
-        work = broadcast_far(self.far, self.dist, src=0, async_op=True) if self.dist is not None else None
-        self.t.run("ns", timed, lambda: self.ns.process_packet_major(self.inp[k:k + P], self.work))
-        if work is not None:
-            self.t.run("far_broadcast_wait", timed, work.wait)
-        self.t.run("aec", timed, lambda: self.aec.process2_packet_major(far, self.work))
-        if self.with_agc_vad and self.side is not None:
-            self.ev_aec[b].record(main)
-            with torch.cuda.stream(self.side):
-                self.side.wait_event(self.ev_aec[b])
-                self.t.run("agc", timed, lambda: self.agc.process_packet_major(self.work))
-                self.t.run("vad", timed, lambda: self.vad.process_packet_major(self.work))
-                ev = torch.cuda.Event()
-                ev.record(self.side)
-                self.ev_tail[b] = ev
-        elif self.with_agc_vad:
-            self.t.run("agc", timed, lambda: self.agc.process_packet_major(self.work))
-            self.t.run("vad", timed, lambda: self.vad.process_packet_major(self.work))
-        if timed is not True and self.side is None:
+        far = self._far_for(step_index)
+        if timed == "all":
+            for name, fn in self.chain.stage_calls_packet_major(far, self.inp[k:k + P], self.work):
+                self.t.run(name, timed, fn)
+        else:
+            rc, _, _ = self.chain.process_packet_major(far, self.inp[k:k + P], out=self.work)
+            assert rc == 0
+        if timed is not True:
             # outside the timed region: keep what the sampled streams produced, for parity_check()
             self.rec.append((step_index, self.work[:, self.sample].clone()))
 
     def dominant_ms(self):
-        return self.t.dominant_ms()
+        return self.near_ms / self.aec_launches if self.aec_launches else None
 
     def stage_ms(self):
-        return {k: self.t.mean_ms(k) for k in ("far_broadcast_wait", "ns", "aec", "agc", "vad") if self.t.mean_ms(k) is not None}
+        d = {k: self.t.mean_ms(k) for k in ("ns", "aec", "agc", "vad") if self.t.mean_ms(k) is not None}
+        if self.aec_launches:
+            d["aec_far_kernel (timed region)"] = self.far_ms / self.aec_launches
+            d["aec_near_kernel (timed region)"] = self.near_ms / self.aec_launches
+        return d
 
     def parity_check(self):
         """Replays 16 sampled streams through the oracle chain for exactly the packets this run fed (priming, warm-up,
@@ -693,9 +698,12 @@ class ChainWorkload:
                 "frame": "%d x int16 (10 ms @ %d kHz mono)" % (self.pkt, self.freq // 1000),
                 "input": "SURVEY 8d recipe: far = LCG noise A=8000; near = far delayed 40 / 2 + noise A=200 + 3000 sin(0.01 t) gated "
                          "every 100 frames; 256 distinct streams x %d packets, tiled" % self.K,
-                "far_end": ("shared, RCCL broadcast from rank 0 each step (asynchronous, overlapped with NS)" if self.dist is not None
-                            else "shared, resident in HBM (one GPU: nothing to broadcast)"), "sum_order": "reference (bit-exact NS mode)",
-                "aec_launch": "far kernel + near kernel; the near kernel is the timed dominant kernel together with its far kernel"}
+                "far_end": ("shared, RCCL broadcast from rank 0 each step (the packet of step k + 1 travels while step k computes)"
+                            if self.dist is not None else "shared, resident in HBM (one GPU: nothing to broadcast)"),
+                "sum_order": "reference (bit-exact NS mode)",
+                "host_calls_per_step": "one: wmx_chain_process (NS, AEC far + near, AGC, VAD launched back to back by the C library)",
+                "aec_launch": "far kernel + near kernel; roofline = the near kernel alone, timed by HIP events the library records "
+                              "on the launch stream around it (wmx_aec_set_timing)"}
 
     def cpu_baseline(self, budget_s):
         from oracle import loader
@@ -835,6 +843,8 @@ class StubCpuWorkload:
 
     def __init__(self, dev, n_streams, rank, dist=None, packets=1):
         from wmix_amd.shard import broadcast_far
+        if os.environ.get("WMIX_STUB_FAIL_RANK") == str(rank):  # tests: one rank dies after the rendezvous
+            sys.exit(7)
         self._bcast = broadcast_far
         self.n_frames = n_streams
         self.dist, self.rank = dist, rank
@@ -883,14 +893,39 @@ def _launch_ranks(n, argv):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", WMIX_BENCH_LAUNCHED_BY="bench.py")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # Poll every rank: when one dies (bad device index, library missing on that rank) the others would sit in the rendezvous
+    # or in a barrier until the collective's own timeout -- end them, and say which rank failed with what code.
+    limit = float(os.environ.get("WMIX_BENCH_LAUNCH_TIMEOUT_S", "3000"))
+    t_end = time.monotonic() + limit
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad or all(rc is not None for rc in rcs):
+            failed = bad or None
+            break
+        if time.monotonic() > t_end:
+            failed = [(-1, "timeout after %.0f s" % limit)]
+            break
+        time.sleep(0.05)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.monotonic() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    out0 = procs[0].stdout.read() if procs[0].stdout else b""
     sys.stdout.write(out0.decode(errors="replace"))
     sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)
-        return 1
+    if failed:
+        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s; the other ranks were stopped\n" % failed)
+        bad_codes = [rc for _, rc in failed if isinstance(rc, int)]
+        return bad_codes[0] if bad_codes and 0 < bad_codes[0] < 256 else 1
     return 0
 
 
@@ -908,6 +943,9 @@ def main():
     ap.add_argument("--packets-per-step", type=int, default=1, choices=[1, 2, 4, 8],
                     help="chain workload: 10 ms packets per stream per step / launch (default 1; the daemon itself hands the "
                          "chain 20 ms = 2 packets per call at 16 kHz, src/wmix.c:613-709)")
+    ap.add_argument("--spinup", type=int, default=64,
+                    help="untimed steps queued directly in front of the timed ones, with no synchronisation in between: the timed "
+                         "region starts on a busy device at its working clock (a 20-step region then reads like a 1000-step one)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -971,12 +1009,30 @@ def main():
     import gc
     gc.collect()
     gc.disable()
+    # The barrier + synchronize above (and the one below) bracket the region as the contract asks, but they also leave the
+    # device empty and clocked down: a short region started cold measures the ramp, not the path (round 2: 20 steps read 13 %
+    # slower than 1 000).  So `--spinup` untimed steps are queued first, WITHOUT a synchronisation behind them, and the K timed
+    # steps are bracketed by two HIP events recorded in the launch stream: ms_per_step is the device time between them --
+    # exactly K steps, on a device that is already busy.  The host's wall clock over the same K steps is reported beside it.
+    on_events = on_gpu
+    for _ in range(args.spinup if on_gpu else 0):
+        wl.step(False)
+    if hasattr(wl, "timed_region"):
+        wl.timed_region(True)
+    if on_events:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         wl.step(True)
+    if on_events:
+        ev1.record()
     sync_all()
-    elapsed = time.perf_counter() - t0
+    host_elapsed = time.perf_counter() - t0
     gc.enable()
+    elapsed = ev0.elapsed_time(ev1) * 1e-3 if on_events else host_elapsed
+    if hasattr(wl, "timed_region"):
+        wl.timed_region(False)
     per_rank_ms = [elapsed / args.steps * 1e3]
     if dist is not None:
         # max over ranks is the job's time; every rank's own figure rides along for the record
@@ -1020,6 +1076,9 @@ def main():
     out = {
         "metric": "10 ms frames/s", "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "timed_by": ("HIP events recorded in the launch stream around the K timed steps (max over ranks), %d untimed spin-up steps "
+                     "queued in front; barrier + synchronize on both sides of spin-up + region" % args.spinup) if on_gpu else "host clock",
+        "host_wall_ms_per_step": host_elapsed / args.steps * 1e3,
         "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
         "config": dict(wl.config(), primed_steps=args.prime), "roofline": roofline,
         "stage_ms": wl.stage_ms() if hasattr(wl, "stage_ms") else None,
@@ -1032,7 +1091,16 @@ def main():
         "launched_by": os.environ.get("WMIX_BENCH_LAUNCHED_BY", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"),
     }
     if hasattr(wl, "parity_check"):
-        out["parity_checked"] = (parity_early or wl.parity_check()) if rank == 0 else None
+        if dist is not None:
+            # every rank replays its own sampled streams through the oracle (ranks > 0 received the far-end only through the
+            # broadcast); rank 0 prints all of them
+            mine = wl.parity_check()
+            every = [None] * world
+            dist.all_gather_object(every, mine)
+            out["parity_checked"] = every[0]
+            out["parity_checked_ranks"] = every
+        else:
+            out["parity_checked"] = (parity_early or wl.parity_check()) if rank == 0 else None
     if rank == 0:
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = wl.cpu_baseline(args.cpu_seconds)

@@ -1,0 +1,173 @@
+/* host_chain.c -- a C host for the record chain on one or more MI355X: plain C99, the library's C ABI and the HIP
+ * runtime API, nothing else.
+ *
+ * What the reference does in one thread for one sound card -- the heartbeat of wmix_shmem_write_circle,
+ * src/wmix.c:613-709: ns_process -> aec_process2 -> agc_process -> vad_process on the captured packet, in place -- done for
+ * n_streams streams: one worker thread per GPU (SURVEY 8b "Threading"), streams sharded by contiguous ranges, state resident
+ * on its GPU for the whole run, and per 10 ms tick each worker receives the SHARED far-end packet with a hipMemcpyAsync
+ * (the single exchange of the path; a host that produces the far-end on a GPU uses one ncclBroadcast instead),
+ * uploads its shard's captured packets, makes ONE library call (wmx_chain_process) and downloads the result.
+ *
+ *   host_chain far.i16 near.i16 out.i16 n_streams n_ticks [n_workers] [freq]
+ *
+ * far.i16  int16 [n_ticks][pkt]             the shared far-end          (pkt = freq / 100 samples, mono)
+ * near.i16 int16 [n_streams][n_ticks][pkt]  captured audio, stream-major
+ * out.i16  same shape as near.i16           what the chain leaves in the daemon's buffer
+ * n_workers defaults to wmx_device_count(); worker w runs on device w % device_count, so a 1-GPU box can still drive
+ * several shards (tests/test_host_chain_gpu.py does, and compares out.i16 with the oracle).
+ *
+ * Build (what __graft_entry__.build() runs):
+ *   gcc -std=c99 -O2 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude examples/host_chain.c -o examples/host_chain \
+ *       -Lwmix_amd -lwmix_amd -L/opt/rocm/lib -lamdhip64 -lpthread -Wl,-rpath,'$ORIGIN/../wmix_amd' -Wl,-rpath,/opt/rocm/lib
+ */
+#define _POSIX_C_SOURCE 200809L
+#include <hip/hip_runtime_api.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include "wmix_amd.h"
+
+typedef struct {
+    int worker, dev, lo, n;      /* this shard: streams [lo, lo + n) on HIP device dev */
+    int n_ticks, pkt, freq;
+    const int16_t *far_host;     /* [n_ticks][pkt], shared */
+    const int16_t *near_host;    /* [n_streams][n_ticks][pkt] */
+    int16_t *out_host;
+    pthread_barrier_t *tick;
+    int rc;
+    double busy_ms;
+} Shard;
+
+#define HIP_OK(x)                                                                             \
+    do {                                                                                      \
+        hipError_t e_ = (x);                                                                  \
+        if (e_ != hipSuccess) {                                                               \
+            fprintf(stderr, "worker %d: %s -> %s\n", s->worker, #x, hipGetErrorString(e_));   \
+            s->rc = 1;                                                                        \
+            goto done;                                                                        \
+        }                                                                                     \
+    } while (0)
+#define WMX_OK(x)                                                                             \
+    do {                                                                                      \
+        int r_ = (x);                                                                         \
+        if (r_ != 0) {                                                                        \
+            fprintf(stderr, "worker %d: %s -> %d (%s)\n", s->worker, #x, r_, wmx_last_error()); \
+            s->rc = 1;                                                                        \
+            goto done;                                                                        \
+        }                                                                                     \
+    } while (0)
+
+static double now_ms(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+}
+
+static void *gpu_worker(void *arg) {
+    Shard *s = (Shard *)arg;
+    hipStream_t st = NULL;
+    wmx_chain *chain = NULL;
+    int16_t *d_near = NULL, *d_far = NULL;
+    const size_t row = (size_t)s->pkt * sizeof(int16_t);          /* one packet */
+    const size_t pitch = (size_t)s->n_ticks * row;                /* host rows are n_ticks packets apart */
+    int created = 0;
+    if (hipSetDevice(s->dev) == hipSuccess && hipStreamCreate(&st) == hipSuccess &&
+        wmx_chain_create(&chain, s->n, 1, s->freq, 10, 5, WMX_CHAIN_NS | WMX_CHAIN_AEC | WMX_CHAIN_AGC | WMX_CHAIN_VAD, 1) == 0 &&
+        hipMalloc((void **)&d_near, (size_t)s->n * row) == hipSuccess && hipMalloc((void **)&d_far, row) == hipSuccess)
+        created = 1;
+    else
+        fprintf(stderr, "worker %d: set-up failed (%s)\n", s->worker, wmx_last_error());
+    /* the handle remembers its device: from here on nothing depends on the thread's current device */
+    for (int t = 0; t < s->n_ticks; t++) {
+        pthread_barrier_wait(s->tick); /* the 10 ms heartbeat: every worker starts tick t together */
+        if (!created || s->rc) continue; /* keep the barrier count even after a failure */
+        const double t0 = now_ms();
+        HIP_OK(hipMemcpyAsync(d_far, s->far_host + (size_t)t * s->pkt, row, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpy2DAsync(d_near, row, s->near_host + ((size_t)s->lo * s->n_ticks + t) * s->pkt, pitch, row, (size_t)s->n,
+                                hipMemcpyHostToDevice, st));
+        WMX_OK(wmx_chain_process(chain, d_far, s->pkt, d_near, d_near, 1, s->pkt, (long)s->pkt * s->n, NULL, NULL, NULL, st));
+        HIP_OK(hipMemcpy2DAsync(s->out_host + ((size_t)s->lo * s->n_ticks + t) * s->pkt, pitch, d_near, row, row, (size_t)s->n,
+                                hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        s->busy_ms += now_ms() - t0;
+    done:;
+    }
+    if (!created) s->rc = 1;
+    if (chain) wmx_chain_destroy(chain);
+    if (d_near) (void)hipFree(d_near);
+    if (d_far) (void)hipFree(d_far);
+    if (st) (void)hipStreamDestroy(st);
+    return NULL;
+}
+
+static void *read_file(const char *path, size_t bytes) {
+    FILE *f = fopen(path, "rb");
+    void *p = malloc(bytes ? bytes : 1);
+    if (!f || !p || fread(p, 1, bytes, f) != bytes) {
+        fprintf(stderr, "host_chain: cannot read %zu bytes from %s\n", bytes, path);
+        exit(2);
+    }
+    fclose(f);
+    return p;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 6) {
+        fprintf(stderr, "usage: %s far.i16 near.i16 out.i16 n_streams n_ticks [n_workers] [freq]\n", argv[0]);
+        return 2;
+    }
+    const int n_streams = atoi(argv[4]), n_ticks = atoi(argv[5]);
+    const int n_dev = wmx_device_count();
+    if (n_dev < 1) {
+        fprintf(stderr, "host_chain: no HIP device (%s)\n", wmx_last_error());
+        return 3;
+    }
+    int n_workers = argc > 6 ? atoi(argv[6]) : n_dev;
+    const int freq = argc > 7 ? atoi(argv[7]) : 16000;
+    const int pkt = freq / 100;
+    if (n_workers < 1 || n_workers > n_streams || n_ticks < 1) return 2;
+    int16_t *far = read_file(argv[1], (size_t)n_ticks * pkt * 2);
+    int16_t *near = read_file(argv[2], (size_t)n_streams * n_ticks * pkt * 2);
+    int16_t *out = calloc((size_t)n_streams * n_ticks * pkt, 2);
+    Shard *sh = calloc((size_t)n_workers, sizeof(Shard));
+    pthread_t *th = calloc((size_t)n_workers, sizeof(pthread_t));
+    pthread_barrier_t tick;
+    pthread_barrier_init(&tick, NULL, (unsigned)n_workers);
+    /* contiguous stream ranges, the remainder spread over the first workers (wmix_amd/shard.py: stream_range) */
+    const int base = n_streams / n_workers, rem = n_streams % n_workers;
+    const double t0 = now_ms();
+    for (int w = 0; w < n_workers; w++) {
+        Shard *s = &sh[w];
+        s->worker = w;
+        s->dev = w % n_dev;
+        s->lo = w * base + (w < rem ? w : rem);
+        s->n = base + (w < rem ? 1 : 0);
+        s->n_ticks = n_ticks;
+        s->pkt = pkt;
+        s->freq = freq;
+        s->far_host = far;
+        s->near_host = near;
+        s->out_host = out;
+        s->tick = &tick;
+        pthread_create(&th[w], NULL, gpu_worker, s);
+    }
+    int rc = 0;
+    for (int w = 0; w < n_workers; w++) {
+        pthread_join(th[w], NULL);
+        rc |= sh[w].rc;
+    }
+    const double wall = now_ms() - t0;
+    if (rc == 0) {
+        FILE *f = fopen(argv[3], "wb");
+        if (!f || fwrite(out, 2, (size_t)n_streams * n_ticks * pkt, f) != (size_t)n_streams * n_ticks * pkt) rc = 4;
+        if (f) fclose(f);
+    }
+    printf("{\"workers\": %d, \"devices\": %d, \"streams\": %d, \"ticks\": %d, \"wall_ms\": %.3f, \"busy_ms_per_tick\": [", n_workers, n_dev,
+           n_streams, n_ticks, wall);
+    for (int w = 0; w < n_workers; w++) printf("%s%.4f", w ? ", " : "", sh[w].busy_ms / n_ticks);
+    printf("], \"rc\": %d}\n", rc);
+    return rc;
+}

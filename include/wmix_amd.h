@@ -43,6 +43,19 @@ int wmx_handle_device(const void *handle);
 /* library/ABI version: major*10000 + minor*100 + patch */
 int wmx_version(void);
 
+/* ------------------------------------------------------------------ per-stream lifetime inside a batch
+ * The reference creates each handle lazily in the record heartbeat and releases it when its switch drops or recording
+ * idles (src/wmix.c:565-600, 617-618, 635-636, 683-684, 702-703, 783-813; *_init / *_release in src/webrtc.c:40-82,
+ * 153-164, 217-274, 485-505, 560-602, 646-661, 694-753, 841-860): the streams of a batch join, leave and restart on their
+ * own.  Every stateful module therefore has
+ *   wmx_<m>_reset_streams(h, idx, n, stream)  <m>_release + <m>_init for the n streams listed in the HOST array idx (a
+ *                                             refill kernel ordered on `stream` like the process calls around it);
+ *   wmx_<m>_set_active(h, mask, stream)       mask: HOST array of n_streams bytes; 0 = the stream is not called -- state
+ *                                             and PCM rows untouched, like a handle nobody calls; NULL = all active.  The
+ *                                             mask stays in force until the next set_active.
+ * The AEC / AECM, whose control plane is shared by the streams that were started together, add COHORTS, see there.
+ * Bad index -> WMX_EINVAL, nothing reset. */
+
 /* ------------------------------------------------------------------ G.711
  * Replaces g711{a,u}_encode / g711{a,u}_decode (src/g711codec.h:30-34,
  * src/g711codec.c:82-216) for device-resident buffers.  law: 0 = A-law, 1 = mu-law.
@@ -82,6 +95,8 @@ int wmx_ns_process(wmx_ns *h, const int16_t *d_in, int16_t *d_out, int n_packets
  * 3 x 1000 histogram counters to host memory (either pointer may be NULL). */
 int wmx_ns_state_words(const wmx_ns *h);
 int wmx_ns_export_state(const wmx_ns *h, int stream_index, float *host_words, unsigned short *host_hist);
+int wmx_ns_reset_streams(wmx_ns *h, const int32_t *idx, int n, void *stream);
+int wmx_ns_set_active(wmx_ns *h, const uint8_t *host_mask, void *stream);
 
 /* ------------------------------------------------------------------ NSX (fixed-point noise suppressor)
  * Batched form of the SAME three wrapper functions when the reference is built with its MAKE_WEBRTC_NSX switch
@@ -97,6 +112,8 @@ int wmx_nsx_packet_samples(const wmx_nsx *h);
 int wmx_nsx_state_bytes(const wmx_nsx *h); /* per-stream state block in HBM (the 3 x 1000 int16 histograms come on top) */
 int wmx_nsx_process(wmx_nsx *h, const int16_t *d_in, int16_t *d_out, int n_packets, long stream_stride,
                     long packet_stride, void *stream);
+int wmx_nsx_reset_streams(wmx_nsx *h, const int32_t *idx, int n, void *stream);
+int wmx_nsx_set_active(wmx_nsx *h, const uint8_t *host_mask, void *stream);
 
 /* ------------------------------------------------------------------ VAD (voice-activity gate)
  * Batched form of vad_init / vad_process / vad_release (src/webrtc.h:32-36, src/webrtc.c:40-164):
@@ -114,6 +131,8 @@ int wmx_vad_destroy(wmx_vad *h);
 int wmx_vad_packet_samples(const wmx_vad *h); /* int16 elements per packet = freq/1000*intervalMs*chn */
 int wmx_vad_process(wmx_vad *h, int16_t *d_pcm, int packets_per_call, int n_calls, long stream_stride,
                     long call_stride, void *stream);
+int wmx_vad_reset_streams(wmx_vad *h, const int32_t *idx, int n, void *stream);
+int wmx_vad_set_active(wmx_vad *h, const uint8_t *host_mask, void *stream);
 
 /* ------------------------------------------------------------------ AGC (legacy fixed-point, adaptive digital)
  * Batched form of agc_init / agc_process / agc_addition / agc_release (src/webrtc.h:55-60,
@@ -129,6 +148,8 @@ int wmx_agc_packet_samples(const wmx_agc *h);
 int wmx_agc_gain_table(const wmx_agc *h, int32_t *host_table32); /* the 32 Q16 gains in use (tests) */
 int wmx_agc_process(wmx_agc *h, const int16_t *d_in, int16_t *d_out, int n_packets, long stream_stride,
                     long packet_stride, void *stream);
+int wmx_agc_reset_streams(wmx_agc *h, const int32_t *idx, int n, void *stream); /* the gain table is the batch's */
+int wmx_agc_set_active(wmx_agc *h, const uint8_t *host_mask, void *stream);
 
 /* ------------------------------------------------------------------ AEC (float echo canceller)
  * Batched form of aec_init / aec_setFrameFar / aec_process / aec_process2 / aec_release
@@ -164,6 +185,64 @@ int wmx_aec_run_groups(wmx_aec *h, int mode, const int16_t *d_far, long far_pack
                        int delay_ms, void *stream);
 int wmx_aec_state_words(const wmx_aec *h);
 int wmx_aec_export_state(const wmx_aec *h, int stream_index, float *host_words);
+/* Cohorts.  Everything in the AEC that decides WHERE data goes (ProcessNormal's start-up machine and delay filter, the ring
+ * positions, the block counters, W:echo_cancellation.c:599-872, aec_core.c:1719-1850) depends on when the handle was
+ * created and on the delays it was called with, never on the audio -- and so does the blocking of the far-end (64-sample
+ * blocks counted from the handle's first packet).  Streams that were started at the same packet and report the same delay
+ * form a COHORT: one control plane on the host, one far-end history on the device.  A far-end group of
+ * wmx_aec_create_groups IS a cohort (stream_far may be NULL there: every stream starts in cohort 0).  A stream joins by
+ *     wmx_aec_reset_cohort(h, c, stream)               -- once per cohort and join time: aec_init of the shared part
+ *     wmx_aec_reset_streams(h, idx, n, c, stream)      -- aec_release + aec_init of the streams, now members of c (c = -1:
+ *                                                         membership unchanged, e.g. one cohort and every stream restarted)
+ * and leaves through the active mask.  wmx_aec_run_cohorts is wmx_aec_run_groups with a reported delay PER COHORT
+ * (aec_process2's delayms is per handle, src/webrtc.c:410), an optional on/off byte per cohort (0: not called, control plane
+ * and far history stand still) and an optional per-cohort return code (what aec_process2 would have returned to its
+ * members; a rejected cohort runs nothing after the offending packet, the others carry on).  All arrays are HOST arrays of
+ * wmx_aec_cohorts(h) entries.  Returns 0, WMX_E*, or the first non-zero cohort code. */
+int wmx_aec_cohorts(const wmx_aec *h);
+int wmx_aec_reset_cohort(wmx_aec *h, int cohort, void *stream);
+int wmx_aec_reset_streams(wmx_aec *h, const int32_t *idx, int n, int cohort, void *stream);
+int wmx_aec_set_active(wmx_aec *h, const uint8_t *host_mask, void *stream);
+int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_packet_stride, long far_group_stride,
+                        const int16_t *d_near, int16_t *d_out, int n_packets, long stream_stride, long packet_stride,
+                        const int32_t *delay_ms, const uint8_t *cohort_on, int32_t *cohort_rc, void *stream);
+/* In-stream timing of the two AEC kernels (bench.py's roofline entry): with timing on, every near-end launch is bracketed
+ * by HIP events recorded on the launch stream -- before the far kernel, between the two, after the near kernel.
+ * wmx_aec_timing waits for the last one, returns the number of launches and the summed durations (ms) since the previous
+ * call and starts over. */
+int wmx_aec_set_timing(wmx_aec *h, int on);
+int wmx_aec_timing(wmx_aec *h, int *n_launches, double *far_ms, double *near_ms);
+
+/* ------------------------------------------------------------------ the record heartbeat: NS -> AEC -> AGC -> VAD in one call
+ * wmix_shmem_write_circle (src/wmix.c:613-709) runs, per WMIX_INTERVAL_MS of captured audio and on one buffer in place,
+ * ns_process -> aec_process2(far, near = out = buffer, delayms) -> agc_process -> vad_process, each behind its
+ * webrtcEnable[] switch.  wmx_chain is that heartbeat for a batch: `stages` = the switches, one wmx_chain_process per tick
+ * launches the enabled stages back to back on `stream` (no host synchronisation, nothing copied).
+ * n10 = 10 ms packets per stream in the tick (the daemon's 20 ms tick is 2); packet p of stream s lies at
+ * s*stream_stride + p*packet_stride in d_in / d_out (int16 elements; d_out == d_in is the daemon's case), the shared
+ * far-end's 10 ms packet p at d_far + p*far_packet_stride.  vad_process is ONE call per tick, as in the heartbeat.  Stages
+ * whose own packet is 20 ms (AEC at 8 kHz / VAD, when interval_ms % 20 == 0) need the tick contiguous (packet_stride == one
+ * 10 ms packet).  delay_ms / cohort_on / cohort_rc: HOST arrays of n_cohorts entries as in wmx_aec_run_cohorts (NULL: delay 0 as
+ * the daemon passes it, every cohort on, no codes wanted).  Returns 0, WMX_E*, or -1 when a cohort's delay was rejected.
+ * The lifetime calls forward to every stage; the stage handles themselves are reachable for everything else. */
+#define WMX_CHAIN_NS 1u
+#define WMX_CHAIN_AEC 2u
+#define WMX_CHAIN_AGC 4u
+#define WMX_CHAIN_VAD 8u
+typedef struct wmx_chain wmx_chain;
+int wmx_chain_create(wmx_chain **out, int n_streams, int chn, int freq, int interval_ms, int agc_value, unsigned stages,
+                     int n_cohorts);
+int wmx_chain_destroy(wmx_chain *h);
+int wmx_chain_process(wmx_chain *h, const int16_t *d_far, long far_packet_stride, const int16_t *d_in, int16_t *d_out, int n10,
+                      long stream_stride, long packet_stride, const int32_t *delay_ms, const uint8_t *cohort_on,
+                      int32_t *cohort_rc, void *stream);
+int wmx_chain_reset_streams(wmx_chain *h, const int32_t *idx, int n, int cohort, void *stream);
+int wmx_chain_reset_cohort(wmx_chain *h, int cohort, void *stream);
+int wmx_chain_set_active(wmx_chain *h, const uint8_t *host_mask, void *stream);
+wmx_ns *wmx_chain_ns(wmx_chain *h);
+wmx_aec *wmx_chain_aec(wmx_chain *h);
+wmx_agc *wmx_chain_agc(wmx_chain *h);
+wmx_vad *wmx_chain_vad(wmx_chain *h);
 
 /* ------------------------------------------------------------------ AECM (fixed-point echo canceller)
  * Batched form of the SAME five wrapper functions when the reference is built with its AECM switch (`#undef
@@ -180,6 +259,17 @@ int wmx_aecm_packet_samples(const wmx_aecm *h);
 int wmx_aecm_state_bytes(const wmx_aecm *h);
 int wmx_aecm_run(wmx_aecm *h, int mode, const int16_t *d_far, long far_packet_stride, const int16_t *d_near,
                  int16_t *d_out, int n_packets, long stream_stride, long packet_stride, int delay_ms, void *stream);
+/* Cohorts, as for the float AEC (see wmx_aec_run_cohorts): n_cohorts control planes + far-end histories per batch; every
+ * stream starts in cohort 0.  far_group_stride: int16 elements between the far-end packets of consecutive cohorts (0: every
+ * cohort hears the same far-end). */
+int wmx_aecm_create_cohorts(wmx_aecm **out, int n_streams, int chn, int freq, int interval_ms, int n_cohorts);
+int wmx_aecm_cohorts(const wmx_aecm *h);
+int wmx_aecm_reset_cohort(wmx_aecm *h, int cohort, void *stream);
+int wmx_aecm_reset_streams(wmx_aecm *h, const int32_t *idx, int n, int cohort, void *stream);
+int wmx_aecm_set_active(wmx_aecm *h, const uint8_t *host_mask, void *stream);
+int wmx_aecm_run_cohorts(wmx_aecm *h, int mode, const int16_t *d_far, long far_packet_stride, long far_group_stride,
+                         const int16_t *d_near, int16_t *d_out, int n_packets, long stream_stride, long packet_stride,
+                         const int32_t *delay_ms, const uint8_t *cohort_on, int32_t *cohort_rc, void *stream);
 
 /* ------------------------------------------------------------------ resample + mix
  * Batched forms of wmix_pcm_zoom (src/wmix.c:139-222) and of wmix_load_data + the play thread's drain

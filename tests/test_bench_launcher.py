@@ -45,3 +45,14 @@ def test_torchrun_launch_still_works():
     assert r.returncode == 0, r.stderr
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["launched_by"] == "torchrun"
+
+
+def test_a_dead_rank_ends_the_launch_with_its_code():
+    """Round-2 ADVICE: a rank that dies must not leave the parent waiting for the survivors' collective timeout."""
+    import time
+    t0 = time.monotonic()
+    r = _run(["--gpus", "2", "--workload", "stub_cpu", "--steps", "5", "--warmup", "2", "--prime", "3", "--no-cpu"],
+             {"WMIX_STUB_FAIL_RANK": "1"}, timeout=120)
+    assert r.returncode == 7, (r.returncode, r.stderr)
+    assert "ranks failed" in r.stderr and "(1, 7)" in r.stderr
+    assert time.monotonic() - t0 < 90

@@ -1,0 +1,40 @@
+"""The C host of the record chain (examples/host_chain.c, built by __graft_entry__.build() with plain gcc): one worker
+thread per shard, contiguous stream ranges, the shared far-end handed to every shard per tick, ONE wmx_chain_process call
+per tick -- the reference's heartbeat (src/wmix.c:613-709) for a batch, with no Python between the host and the library.
+Its output file is compared with the oracle's per-handle chain."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle import loader as L
+from test_aec_gpu import check_float_path
+from wmix_amd import synth
+
+EXE = os.path.join(ROOT, "examples", "host_chain")
+
+
+def test_host_chain_is_built():
+    assert os.path.exists(EXE), "examples/host_chain missing: run __graft_entry__.build()"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workers", [1, 3])
+def test_host_chain_shards_vs_oracle(tmp_path, oracle_port, workers):
+    S, T, freq, pkt = 40, 260, 16000, 160
+    far = synth.far_end(9700, T, pkt)
+    near = synth.near_end(9701, S, T, pkt, far=far).reshape(S, T * pkt)
+    far.astype("<i2").tofile(tmp_path / "far.i16")
+    near.astype("<i2").tofile(tmp_path / "near.i16")
+    # a child process of its own: the test process makes no GPU call on its behalf
+    r = subprocess.run([EXE, str(tmp_path / "far.i16"), str(tmp_path / "near.i16"), str(tmp_path / "out.i16"), str(S), str(T), str(workers)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["workers"] == workers and info["rc"] == 0 and len(info["busy_ms_per_tick"]) == workers
+    got = np.fromfile(tmp_path / "out.i16", dtype="<i2").reshape(S, T * pkt)
+    want = np.stack([L.run_chain(oracle_port, 1, freq, 5, 15, far, near[s], pkt, prefix="orc") for s in range(S)])
+    check_float_path(got, want, max_fraction=1e-4)

@@ -1,0 +1,193 @@
+"""GPU parity of the per-stream lifetime calls (include/wmix_amd.h "per-stream lifetime inside a batch").
+
+The reference creates every handle lazily in the record heartbeat, releases it when its switch drops or recording idles
+and creates a new one later (src/wmix.c:565-600, 617-618, 635-636, 683-684, 702-703; src/webrtc.c:217-274, 560-602), and
+aec_process2 takes the reported delay per handle per call (src/webrtc.c:410).  Here the streams of ONE batch join at
+different packets, restart, go idle and report different delays; each is compared with a per-handle oracle run that starts
+at the stream's own time (*_init ... *_release): bit-exact for the integer stages and the float NS, <= 1 LSB for the AEC.
+"""
+import numpy as np
+import pytest
+
+from oracle import loader as L
+from test_aec_gpu import check_float_path
+from wmix_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+# stream -> list of (start packet, end packet, cohort): the handle lives over [start, end), one entry per *_init
+T = 520
+LIVES = {
+    0: [(0, T, 0)],                    # there from the first packet
+    1: [(0, 400, 0), (400, T, 3)],     # restarts at packet 400 (release + init): a cohort of its own from then on
+    2: [(0, 300, 0)],                  # goes idle at 300 (released, never called again)
+    3: [(37, T, 1)],                   # joins at 37
+    4: [(37, T, 1)],
+    5: [(200, T, 2)],                  # joins at 200
+    6: [(200, 450, 2)],                # joins at 200, leaves at 450
+    7: [],                             # never created: its rows must not be touched
+    8: [(0, T, 0)],
+}
+EVENTS = sorted({0, T} | {t for lives in LIVES.values() for a, b, _ in lives for t in (a, b)})
+N_COHORTS = 4
+COHORT_START = {0: 0, 1: 37, 2: 200, 3: 400}
+DELAYS = [0, 20, 0, 40]  # reported sound-card delay per cohort (ms)
+
+
+def _inputs(freq, seed):
+    pkt = freq // 100
+    S = len(LIVES)
+    far = synth.far_end(seed, T, pkt)
+    near = synth.near_end(seed + 99, S, T, pkt, far=far).reshape(S, T, pkt)
+    return pkt, S, far.reshape(T, pkt), near
+
+
+def _drive(batch, run, S):
+    """Walk the event list: at each event time restart the cohorts that begin there, reset the streams that are created
+    there, update the active mask, then run the packets up to the next event."""
+    for t0, t1 in zip(EVENTS[:-1], EVENTS[1:]):
+        for c, tc in COHORT_START.items():
+            if tc == t0 and hasattr(batch, "reset_cohort") and batch._mod in ("aec", "aecm", "chain"):
+                batch.reset_cohort(c)
+        for c in range(N_COHORTS):
+            born = [s for s, lives in LIVES.items() for a, b, cc in lives if a == t0 and cc == c]
+            if born:
+                if batch._mod in ("aec", "aecm", "chain"):
+                    batch.reset_streams(born, cohort=c)
+                else:
+                    batch.reset_streams(born)
+        active = np.array([any(a <= t0 < b for a, b, _ in LIVES[s]) for s in range(S)])
+        batch.set_active(active)
+        on = np.array([COHORT_START[c] <= t0 and any(a <= t0 < b and cc == c for lives in LIVES.values() for a, b, cc in lives)
+                       for c in range(N_COHORTS)], dtype=np.uint8)
+        run(t0, t1, on)
+
+
+def _expected(S, near, per_handle):
+    """per_handle(stream, start, end, cohort) -> the oracle's output for a handle created at `start`; rows outside every life
+    keep the input (nobody called the handle)."""
+    want = near.copy()
+    for s in range(S):
+        for a, b, c in LIVES[s]:
+            want[s, a:b] = per_handle(s, a, b, c).reshape(b - a, -1)
+    return want
+
+
+@pytest.mark.parametrize("freq", [16000, 8000])
+def test_aec_cohorts_join_reset_idle_vs_per_handle_oracle(cuda, oracle_port, freq):
+    import torch
+    from wmix_amd.aec import AecBatch
+    pkt, S, far, near = _inputs(freq, 9100 + freq // 8000)
+    ab = AecBatch(S, 1, freq, 10, n_cohorts=N_COHORTS)
+    d = torch.from_numpy(near.copy()).to(cuda)
+    dfar = torch.from_numpy(far).to(cuda)
+
+    def run(t0, t1, on):
+        for f in range(t0, t1, 23):
+            e = min(t1, f + 23)
+            rc, codes = ab.run_cohorts(dfar[f:e], d[:, f:e], DELAYS, cohort_on=on)
+            assert rc == 0 and not codes.any()
+    _drive(ab, run, S)
+    got = d.cpu().numpy()
+    ab.close()
+    want = _expected(S, near, lambda s, a, b, c: L.run_aec(oracle_port, 1, freq, 10, far[a:b].reshape(-1), near[s, a:b].reshape(-1), pkt,
+                                                            DELAYS[c], prefix="orc"))
+    assert np.array_equal(got[7], near[7])            # never created: untouched
+    assert np.array_equal(got[2, 300:], near[2, 300:])  # idle: untouched
+    check_float_path(got, want, max_fraction=1e-4)
+
+
+def test_chain_lifetime_vs_per_handle_oracle(cuda, oracle_port):
+    """The whole heartbeat through wmx_chain_process (one C call per tick): ns / aec / agc / vad handles of a stream are
+    created together when it joins (src/wmix.c:617-703) and released together when it idles."""
+    import torch
+    from wmix_amd.chain import ChainBatch
+    freq = 16000
+    pkt, S, far, near = _inputs(freq, 9200)
+    cb = ChainBatch(S, 1, freq, 10, 5, n_cohorts=N_COHORTS)
+    d = torch.from_numpy(near.copy()).to(cuda)
+    dfar = torch.from_numpy(far).to(cuda)
+    zero = [0] * N_COHORTS
+
+    def run(t0, t1, on):
+        for f in range(t0, t1):  # one 10 ms tick per call, like bench.py
+            rc, codes, _ = cb.process(dfar[f:f + 1], d[:, f:f + 1], delays=zero, cohort_on=on)
+            assert rc == 0 and not codes.any()
+    _drive(cb, run, S)
+    got = d.cpu().numpy()
+    cb.close()
+    want = _expected(S, near, lambda s, a, b, c: L.run_chain(oracle_port, 1, freq, 5, 15, far[a:b].reshape(-1), near[s, a:b].reshape(-1), pkt,
+                                                              prefix="orc"))
+    assert np.array_equal(got[7], near[7])
+    check_float_path(got, want, max_fraction=1e-4)
+
+
+def test_fixed_point_modules_lifetime_bit_exact(cuda, oracle_port):
+    """NSX and AECM (the reference's fixed-point builds of the same wrappers) with the same join / restart / idle schedule:
+    integer paths, so every sample must equal the per-handle oracle."""
+    import torch
+    from wmix_amd.aecm import AecmBatch
+    from wmix_amd.nsx import NsxBatch
+    freq = 16000
+    pkt, S, far, near = _inputs(freq, 9300)
+    dfar = torch.from_numpy(far).to(cuda)
+    # --- AECM, cohorts with their own reported delays
+    am = AecmBatch(S, 1, freq, 10, n_cohorts=N_COHORTS)
+    d = torch.from_numpy(near.copy()).to(cuda)
+
+    def run_aecm(t0, t1, on):
+        for f in range(t0, t1, 17):
+            e = min(t1, f + 17)
+            rc, codes = am.run_cohorts(dfar[f:e], d[:, f:e], DELAYS, cohort_on=on)
+            assert rc == 0 and not codes.any()
+    _drive(am, run_aecm, S)
+    got = d.cpu().numpy()
+    am.close()
+    want = _expected(S, near, lambda s, a, b, c: L.run_aecm(oracle_port, 1, freq, 10, far[a:b].reshape(-1), near[s, a:b].reshape(-1), pkt,
+                                                             DELAYS[c], prefix="orc"))
+    assert np.array_equal(got, want)
+    # --- NSX
+    nb = NsxBatch(S, 1, freq)
+    d = torch.from_numpy(near.copy()).to(cuda)
+
+    def run_nsx(t0, t1, on):
+        nb.process(d[:, t0:t1])
+    _drive(nb, run_nsx, S)
+    got = d.cpu().numpy()
+    nb.close()
+    want = _expected(S, near, lambda s, a, b, c: L.run_nsx(oracle_port, 1, freq, near[s, a:b].reshape(-1), pkt, prefix="orc"))
+    assert np.array_equal(got, want)
+
+
+def test_single_stage_lifetime_bit_exact(cuda, oracle_port):
+    """NS, AGC and VAD on their own batch handles (the chain test goes through wmx_chain_*): reset + active mask."""
+    import torch
+    from wmix_amd.agc import AgcBatch
+    from wmix_amd.ns import NsBatch
+    from wmix_amd.vad import VadBatch
+    freq = 16000
+    pkt, S, far, near = _inputs(freq, 9400)
+    cases = [
+        (NsBatch(S, 1, freq), lambda b, x: b.process(x), lambda s, a, e: L.run_ns(oracle_port, 1, freq, near[s, a:e].reshape(-1), pkt, prefix="orc")),
+        (AgcBatch(S, 1, freq, 5), lambda b, x: b.process(x),
+         lambda s, a, e: L.run_agc(oracle_port, 1, freq, 5, near[s, a:e].reshape(-1), pkt, prefix="orc")),
+        (VadBatch(S, 1, freq, 10), lambda b, x: b.process(x),
+         lambda s, a, e: L.run_vad(oracle_port, 1, freq, 10, near[s, a:e].reshape(-1), pkt, prefix="orc")),
+    ]
+    for batch, proc, orc in cases:
+        d = torch.from_numpy(near.copy()).to(cuda)
+        _drive(batch, lambda t0, t1, on: proc(batch, d[:, t0:t1]), S)
+        got = d.cpu().numpy()
+        batch.close()
+        want = _expected(S, near, lambda s, a, b, c: orc(s, a, b))
+        assert np.array_equal(got, want), type(batch).__name__
+
+
+def test_bad_reset_list_is_rejected(cuda):
+    from wmix_amd._lib import WmxError
+    from wmix_amd.ns import NsBatch
+    nb = NsBatch(4, 1, 16000)
+    with pytest.raises(WmxError):
+        nb.reset_streams([0, 4])
+    nb.reset_streams([])
+    nb.close()

@@ -1,0 +1,36 @@
+"""N > 1 ranks with the REAL kernels: two fresh rank processes of bench.py on one GPU box, the
+rendezvous and the far-end broadcast over gloo (WMIX_BENCH_ONE_GPU_GLOO=1: every rank on cuda:0; on an 8-GPU node the same
+code runs with backend nccl = RCCL, one rank per GPU -- only the backend string differs).  Each rank shards its own streams,
+rank 0 alone owns the far-end, and every rank replays its sampled streams through the oracle: rank 1's AEC output can only be
+right if the broadcast delivered every packet."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_ranks_real_kernels_far_end_through_the_broadcast():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(WMIX_BENCH_ONE_GPU_GLOO="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # children of their own: this process makes no GPU call for them
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "chain", "--streams", "512",
+                        "--steps", "6", "--warmup", "2", "--prime", "60", "--spinup", "4", "--no-cpu"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dist_backend"] == "gloo" and d["launched_by"] == "bench.py"
+    assert len(d["per_rank_ms_per_step"]) == 2 and all(x > 0 for x in d["per_rank_ms_per_step"])
+    ranks = d["parity_checked_ranks"]
+    assert len(ranks) == 2
+    for p in ranks:
+        assert p["max_lsb"] <= 1 and p["packets_compared"] > 0 and p["steps_replayed"] >= 60 + 2 + 4 + 6
+    # whole-job aggregate over both ranks
+    assert d["value"] > 0 and d["config"]["streams_per_gpu"] == 512

@@ -128,6 +128,45 @@ def _declare(L):
     L.wmx_aec_create_groups.argtypes = [C.POINTER(vp), i, i, i, i, i, vp]
     L.wmx_aec_run_groups.restype = i
     L.wmx_aec_run_groups.argtypes = [vp, i, vp, C.c_long, C.c_long, vp, vp, i, C.c_long, C.c_long, i, vp]
+    # per-stream lifetime (include/wmix_amd.h "per-stream lifetime inside a batch")
+    for m in ("ns", "nsx", "agc", "vad"):
+        f = getattr(L, "wmx_%s_reset_streams" % m)
+        f.restype = i
+        f.argtypes = [vp, vp, i, vp]
+    for m in ("aec", "aecm", "chain"):
+        f = getattr(L, "wmx_%s_reset_streams" % m)
+        f.restype = i
+        f.argtypes = [vp, vp, i, i, vp]
+        f = getattr(L, "wmx_%s_reset_cohort" % m)
+        f.restype = i
+        f.argtypes = [vp, i, vp]
+    for m in ("ns", "nsx", "agc", "vad", "aec", "aecm", "chain"):
+        f = getattr(L, "wmx_%s_set_active" % m)
+        f.restype = i
+        f.argtypes = [vp, vp, vp]
+    for m in ("aec", "aecm"):
+        f = getattr(L, "wmx_%s_cohorts" % m)
+        f.restype = i
+        f.argtypes = [vp]
+        f = getattr(L, "wmx_%s_run_cohorts" % m)
+        f.restype = i
+        f.argtypes = [vp, i, vp, C.c_long, C.c_long, vp, vp, i, C.c_long, C.c_long, vp, vp, vp, vp]
+    L.wmx_aecm_create_cohorts.restype = i
+    L.wmx_aecm_create_cohorts.argtypes = [C.POINTER(vp), i, i, i, i, i]
+    L.wmx_aec_set_timing.restype = i
+    L.wmx_aec_set_timing.argtypes = [vp, i]
+    L.wmx_aec_timing.restype = i
+    L.wmx_aec_timing.argtypes = [vp, C.POINTER(i), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.wmx_chain_create.restype = i
+    L.wmx_chain_create.argtypes = [C.POINTER(vp), i, i, i, i, i, C.c_uint, i]
+    L.wmx_chain_destroy.restype = i
+    L.wmx_chain_destroy.argtypes = [vp]
+    L.wmx_chain_process.restype = i
+    L.wmx_chain_process.argtypes = [vp, vp, C.c_long, vp, vp, i, C.c_long, C.c_long, vp, vp, vp, vp]
+    for m in ("ns", "aec", "agc", "vad"):
+        f = getattr(L, "wmx_chain_%s" % m)
+        f.restype = vp
+        f.argtypes = [vp]
     u32 = C.c_uint32
     L.wmx_pcm_zoom.restype = i
     L.wmx_pcm_zoom.argtypes = [i, i, vp, u32, i, i, vp, u32, C.c_long, C.c_long, i, C.POINTER(u32), vp]

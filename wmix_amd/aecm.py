@@ -5,13 +5,17 @@ import ctypes as C
 
 import torch
 
+from .lifetime import Lifetime
 from ._lib import check, lib
 
 
-class AecmBatch:
-    def __init__(self, n_streams, chn, freq, interval_ms=10):
+class AecmBatch(Lifetime):
+    _mod = "aecm"
+
+    def __init__(self, n_streams, chn, freq, interval_ms=10, n_cohorts=1):
         self._h = C.c_void_p()
-        rc = lib().wmx_aecm_create(C.byref(self._h), n_streams, chn, freq, interval_ms)
+        self.n_cohorts = int(n_cohorts)
+        rc = lib().wmx_aecm_create_cohorts(C.byref(self._h), n_streams, chn, freq, interval_ms, self.n_cohorts)
         if rc != 0:
             self._h = None
             check(rc, "wmx_aecm_create")
@@ -28,6 +32,23 @@ class AecmBatch:
         if rc not in (0, -1):
             check(rc, "wmx_aecm_run")
         return rc
+
+    def run_cohorts(self, far, near, delays, cohort_on=None, out=None, mode=3):
+        """As AecBatch.run_cohorts: one reported delay (and optional on/off byte) per cohort; returns (rc, per-cohort codes)."""
+        import numpy as np
+        assert far.is_cuda and far.dtype == torch.int16 and far.dim() == 2 and far.shape[1] == self.pkt and far.stride(1) == 1
+        assert near.is_cuda and near.dtype == torch.int16 and near.dim() == 3 and near.stride(2) == 1 and near.shape[0] == self.n_streams
+        out = near if out is None else out
+        d = np.ascontiguousarray(delays, dtype=np.int32)
+        assert d.shape == (self.n_cohorts,)
+        on = None if cohort_on is None else np.ascontiguousarray(cohort_on, dtype=np.uint8)
+        codes = np.zeros(self.n_cohorts, np.int32)
+        rc = lib().wmx_aecm_run_cohorts(self._h, mode, far.data_ptr(), far.stride(0), 0, near.data_ptr(), out.data_ptr(), near.shape[1],
+                                        near.stride(0), near.stride(1), d.ctypes.data, None if on is None else on.ctypes.data,
+                                        codes.ctypes.data, torch.cuda.current_stream().cuda_stream)
+        if rc not in (0, -1):
+            check(rc, "wmx_aecm_run_cohorts")
+        return rc, codes
 
     def process2(self, far, near, out=None, delay_ms=0):
         """aec_process2: far int16 CUDA [n_packets, pkt] (shared), near [n_streams, n_packets, pkt]."""

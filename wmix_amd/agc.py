@@ -5,10 +5,13 @@ import ctypes as C
 import numpy as np
 import torch
 
+from .lifetime import Lifetime
 from ._lib import check, lib
 
 
-class AgcBatch:
+class AgcBatch(Lifetime):
+    _mod = "agc"
+
     def __init__(self, n_streams, chn, freq, value, interval_ms=10):
         self._h = C.c_void_p()
         rc = lib().wmx_agc_create(C.byref(self._h), n_streams, chn, freq, interval_ms, value)

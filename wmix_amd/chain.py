@@ -1,0 +1,96 @@
+"""Host-side mirror of the daemon's record heartbeat (src/wmix.c:613-709) for a batch of streams: ns_process ->
+aec_process2 -> agc_process -> vad_process on one buffer, ONE C call per tick (wmx_chain_process, wmix_amd/csrc/chain.hip)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .lifetime import Lifetime
+from ._lib import check, lib
+
+NS, AEC, AGC, VAD = 1, 2, 4, 8
+
+
+class ChainBatch(Lifetime):
+    _mod = "chain"
+
+    def __init__(self, n_streams, chn, freq, interval_ms=10, agc_value=5, stages=NS | AEC | AGC | VAD, n_cohorts=1):
+        self._h = C.c_void_p()
+        rc = lib().wmx_chain_create(C.byref(self._h), n_streams, chn, freq, interval_ms, agc_value, stages, n_cohorts)
+        if rc != 0:
+            self._h = None
+            check(rc, "wmx_chain_create")
+        self.n_streams, self.chn, self.freq, self.stages, self.n_cohorts = n_streams, chn, freq, stages, n_cohorts
+        self.pkt = freq // 100 * chn  # int16 elements of a 10 ms packet
+
+    def _process(self, far, pcm, out, n10, stream_stride, packet_stride, delays, cohort_on):
+        assert pcm.is_cuda and pcm.dtype == torch.int16 and pcm.stride(-1) == 1
+        out = pcm if out is None else out
+        assert out.stride() == pcm.stride()
+        fp, fs = None, 0
+        if far is not None:
+            assert far.is_cuda and far.dtype == torch.int16 and far.dim() == 2 and far.shape == (n10, self.pkt) and far.stride(1) == 1
+            fp, fs = far.data_ptr(), far.stride(0)
+        d = None if delays is None else np.ascontiguousarray(delays, dtype=np.int32)
+        on = None if cohort_on is None else np.ascontiguousarray(cohort_on, dtype=np.uint8)
+        codes = np.zeros(self.n_cohorts, np.int32)
+        rc = lib().wmx_chain_process(self._h, fp, fs, pcm.data_ptr(), out.data_ptr(), n10, stream_stride, packet_stride,
+                                     None if d is None else d.ctypes.data, None if on is None else on.ctypes.data, codes.ctypes.data,
+                                     torch.cuda.current_stream().cuda_stream)
+        if rc not in (0, -1):
+            check(rc, "wmx_chain_process")
+        return rc, codes, out
+
+    def process(self, far, pcm, out=None, delays=None, cohort_on=None):
+        """One tick: far int16 CUDA [n10, pkt] (the shared far-end), pcm [n_streams, n10, pkt]; in place unless `out`."""
+        assert pcm.dim() == 3 and pcm.shape[0] == self.n_streams and pcm.shape[2] == self.pkt
+        return self._process(far, pcm, out, pcm.shape[1], pcm.stride(0), pcm.stride(1), delays, cohort_on)
+
+    def process_packet_major(self, far, pcm, out=None, delays=None, cohort_on=None):
+        """pcm [n10, n_streams, pkt]: one 10 ms step of all streams contiguous."""
+        assert pcm.dim() == 3 and pcm.shape[1] == self.n_streams and pcm.shape[2] == self.pkt
+        return self._process(far, pcm, out, pcm.shape[0], pcm.stride(1), pcm.stride(0), delays, cohort_on)
+
+    def aec_handle(self):
+        return lib().wmx_chain_aec(self._h)
+
+    def set_aec_timing(self, on):
+        """HIP events around the AEC's two kernels inside the library, on the launch stream (wmx_aec_set_timing)."""
+        check(lib().wmx_aec_set_timing(self.aec_handle(), 1 if on else 0), "wmx_aec_set_timing")
+
+    def aec_timing(self):
+        """(launches, far-kernel ms, near-kernel ms) summed since the last call; waits for the last launch."""
+        n, f, r = C.c_int(0), C.c_double(0), C.c_double(0)
+        check(lib().wmx_aec_timing(self.aec_handle(), C.byref(n), C.byref(f), C.byref(r)), "wmx_aec_timing")
+        return n.value, f.value, r.value
+
+    def stage_calls_packet_major(self, far, pcm, out):
+        """The launches wmx_chain_process makes for a tick of 10 ms packets, one callable per stage, for callers that want an
+        event between the stages (bench.py's per-stage breakdown; interval_ms = 10 only).  Same handles, same state."""
+        L, st = lib(), torch.cuda.current_stream().cuda_stream
+        n10, ss, ps = pcm.shape[0], pcm.stride(1), pcm.stride(0)
+        calls, src = [], pcm
+        if self.stages & NS:
+            calls.append(("ns", lambda s=src: check(L.wmx_ns_process(L.wmx_chain_ns(self._h), s.data_ptr(), out.data_ptr(), n10, ss, ps, st))))
+            src = out
+        if self.stages & AEC:
+            calls.append(("aec", lambda s=src: check(L.wmx_aec_run(self.aec_handle(), 3, far.data_ptr(), far.stride(0), s.data_ptr(),
+                                                                   out.data_ptr(), n10, ss, ps, 0, st))))
+            src = out
+        if self.stages & AGC:
+            calls.append(("agc", lambda s=src: check(L.wmx_agc_process(L.wmx_chain_agc(self._h), s.data_ptr(), out.data_ptr(), n10, ss, ps, st))))
+            src = out
+        if self.stages & VAD:
+            calls.append(("vad", lambda: check(L.wmx_vad_process(L.wmx_chain_vad(self._h), out.data_ptr(), n10, 1, ss, self.pkt, st))))
+        return calls
+
+    def close(self):
+        if self._h:
+            lib().wmx_chain_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -118,6 +118,8 @@ __device__ __forceinline__ void unpack_bin(const float *a, int b, float &re, flo
 
 // ================================================================== far-end kernel
 // grid = number of far-end groups: workgroup g (one wave) serves far-end g, whose packets start at far_pcm + g * far_group_stride
+// and whose plans are plans[g * kAecMaxPktPerLaunch ...] (a group is also a control COHORT: the streams that were started at
+// the same packet with the same reported delays share the plan a handle of the reference would have computed for itself)
 // plan_by_value: a one-packet launch hands its plan over as a kernel argument; this kernel, which runs in front of the near
 // kernel in the same stream, stores it into plans[0] for both -- no host-to-device blit between the previous kernel of the
 // stream and this one (4.7 us per step of the chain).  Every far-end group stores the same bytes.
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const flo
     }
     const AecFarBufs F = far_group(F_all, (int)blockIdx.x);
     if (far_pcm) far_pcm += (size_t)blockIdx.x * far_group_stride;
+    plans += (size_t)blockIdx.x * kAecMaxPktPerLaunch;  // every far-end group (control cohort) has its own plans
     {
         // one wave, one latency chain: every request of a group goes out before the first result is used
         float *dst = reinterpret_cast<float *>(&K);
@@ -928,20 +931,22 @@ __global__ __attribute__((amdgpu_waves_per_eu(WMX_AEC_WAVES, WMX_AEC_WAVES))) __
                                                                           const AecPlan *__restrict__ plans, int n_packets,
                                                                           const int16_t *near_pcm, int16_t *out_pcm, int n_streams,
                                                                           long stream_stride, long packet_stride, int chn, int pkg,
-                                                                          const int *__restrict__ stream_far) {
+                                                                          const int *__restrict__ stream_far, const uint8_t *__restrict__ active) {
     __shared__ AecConsts K;
     __shared__ AecWaveLds Wv[kAecWavesPerBlock];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: state pointers become scalar bases
     const int sidx = blockIdx.x * kAecWavesPerBlock + wave;  // one stream per wave
-    const bool live = sidx < n_streams;
+    const bool live = stream_active(active, sidx, n_streams);  // no stream, or one that is switched off: nothing touched
     // Everything this wave needs from memory is requested up front -- its first near-end packet, the 24 filter rows, the
     // LDS part of the state, the constants -- and waited for ONCE, at the workgroup barrier; issued phase by phase, each
     // group costs its own HBM round trip.  (A wave without a stream reads stream 0 and leaves after the barrier.)
-    const int sl = live ? sidx : 0;
+    const int sl = sidx < n_streams ? sidx : 0;
     // the far-end this stream is cancelled against (one per batch unless the handle was created with far-end groups):
     // wave-uniform, so the group's buffers are scalar bases like the single far-end's
-    const AecFarBufs F = far_group(F_all, stream_far ? __builtin_amdgcn_readfirstlane(stream_far[sl]) : 0);
+    const int grp = stream_far ? __builtin_amdgcn_readfirstlane(stream_far[sl]) : 0;
+    const AecFarBufs F = far_group(F_all, grp);
+    plans += (size_t)grp * kAecMaxPktPerLaunch;
     float *gst = state + (size_t)sl * AS_WORDS;
     // the constants first (L2 hits): their copy into LDS then waits for them alone, not for the HBM loads behind them
     constexpr int kConstIt = (kAecConstWords + 64 * kAecWavesPerBlock - 1) / (64 * kAecWavesPerBlock);
@@ -1095,6 +1100,11 @@ __global__ void aec_fill_state(float *state, const float *tmpl, int words, int n
         state[i] = tmpl[i % words];
 }
 
+__global__ void aec_set_group(int *stream_far, const int32_t *idx, int n_idx, int group) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_idx) stream_far[idx[j]] = group;
+}
+
 }  // namespace
 }  // namespace wmx
 
@@ -1102,13 +1112,14 @@ __global__ void aec_fill_state(float *state, const float *tmpl, int words, int n
 struct wmx_aec {
     int device;  // the HIP device the state lives on (current device at create); every entry point switches to it
     int n_streams, chn, freq, pkg;
-    wmx::AecCtl ctl;
+    std::vector<wmx::AecCtl> ctl;  // one control plane per far-end group / cohort (n_far of them)
     float *d_state;
+    float *d_tmpl;   // the state aec_init gives a stream (reset_streams refills from it)
     float *d_consts;
     float *d_far;  // one allocation carved into AecFarBufs
     wmx::AecFarBufs far;
     static constexpr int kPlanBufs = 4;
-    wmx::AecPlan *d_plans;   // kPlanBufs x kAecMaxPktPerLaunch plans, used round robin
+    wmx::AecPlan *d_plans;   // kPlanBufs x n_far x kAecMaxPktPerLaunch plans, slots used round robin
     wmx::AecPlan *h_plans;   // pinned mirror: the asynchronous copy reads it in place, so each slot has its own
     hipEvent_t plan_free[kPlanBufs];  // recorded behind the kernels that read slot i; waited for before slot i is rewritten
     bool plan_used[kPlanBufs];
@@ -1116,6 +1127,11 @@ struct wmx_aec {
     int n_far;               // far-end groups (1 = one shared far-end)
     int *d_stream_far;       // [n_streams] group of each stream, or nullptr when n_far == 1
     int16_t *d_zero_far;  // a silent far-end packet for near-only calls that need no far data
+    wmx::StreamLife life;
+    // in-stream timing of the two kernels (wmx_aec_set_timing): event triples [before far | between | after near]
+    bool timing;
+    std::vector<hipEvent_t> tev;
+    size_t tev_used;
 };
 
 extern "C" {
@@ -1129,6 +1145,9 @@ int wmx_aec_destroy(wmx_aec *h) {
     if (h->d_plans) (void)hipFree(h->d_plans);
     if (h->h_plans) (void)hipHostFree(h->h_plans);
     if (h->d_stream_far) (void)hipFree(h->d_stream_far);
+    if (h->d_tmpl) (void)hipFree(h->d_tmpl);
+    h->life.release();
+    for (hipEvent_t ev : h->tev) (void)hipEventDestroy(ev);
     for (int i = 0; i < wmx_aec::kPlanBufs; i++)
         if (h->plan_free[i]) (void)hipEventDestroy(h->plan_free[i]);
     delete h;
@@ -1143,11 +1162,12 @@ int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int i
     using namespace wmx;
     if (!out) return WMX_EINVAL;
     *out = nullptr;
-    if (n_far < 1 || (n_far > 1 && !stream_far)) {
-        set_error("wmx_aec_create_groups: n_far=%d needs a stream -> far-end map", n_far);
+    if (n_far < 1) {
+        set_error("wmx_aec_create_groups: n_far=%d", n_far);
         return WMX_EINVAL;
     }
-    if (n_far > 1)
+    // stream_far == NULL with n_far > 1: every stream starts in group / cohort 0 and is moved by wmx_aec_reset_streams
+    if (n_far > 1 && stream_far)
         for (int i = 0; i < n_streams; i++)
             if (stream_far[i] < 0 || stream_far[i] >= n_far) {
                 set_error("wmx_aec_create_groups: stream %d maps to far-end %d of %d", i, stream_far[i], n_far);
@@ -1167,8 +1187,11 @@ int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int i
     h->chn = chn;
     h->freq = freq;
     h->pkg = freq / 1000 * ((freq <= 8000 && interval_ms % 20 == 0) ? 20 : 10);  // src/webrtc.c:239-248
-    h->ctl.init(freq);
-    h->d_state = h->d_consts = h->d_far = nullptr;
+    h->ctl.resize((size_t)n_far);
+    for (wmx::AecCtl &c : h->ctl) c.init(freq);
+    h->d_state = h->d_consts = h->d_far = h->d_tmpl = nullptr;
+    h->timing = false;
+    h->tev_used = 0;
     h->d_plans = nullptr;
     h->h_plans = nullptr;
     h->d_stream_far = nullptr;
@@ -1199,26 +1222,29 @@ int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int i
     st[AS_OVERDRIVE] = 2.f;
     st[AS_OVERDRIVESM] = 2.f;
     const size_t far_words = (size_t)kAecPreLen + 2 * (size_t)kAecFarBlocks * 130 + 2 * (size_t)kAecHist * 130 + (size_t)kAecHist * BP + BP;
-    float *d_tmpl = nullptr;
     hipError_t e;
 #define AEC_TRY(x)                                         \
     if ((e = (x)) != hipSuccess) {                         \
         int rc = hip_fail(e, #x, __FILE__, __LINE__);      \
         wmx_aec_destroy(h);                                \
-        if (d_tmpl) (void)hipFree(d_tmpl);                 \
         return rc;                                         \
     }
     AEC_TRY(hipMalloc(&h->d_state, (size_t)AS_WORDS * n_streams * sizeof(float)));
     AEC_TRY(hipMalloc(&h->d_consts, sizeof(K) + sizeof(PowTables)));  // [AecConsts | PowTables]; only the first part is copied to LDS
     AEC_TRY(hipMalloc(&h->d_far, far_words * n_far * sizeof(float)));
-    AEC_TRY(hipMalloc(&h->d_plans, wmx_aec::kPlanBufs * kAecMaxPktPerLaunch * sizeof(AecPlan)));
-    AEC_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->h_plans), wmx_aec::kPlanBufs * kAecMaxPktPerLaunch * sizeof(AecPlan), hipHostMallocDefault));
+    AEC_TRY(hipMalloc(&h->d_plans, (size_t)wmx_aec::kPlanBufs * n_far * kAecMaxPktPerLaunch * sizeof(AecPlan)));
+    AEC_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->h_plans), (size_t)wmx_aec::kPlanBufs * n_far * kAecMaxPktPerLaunch * sizeof(AecPlan),
+                          hipHostMallocDefault));
     for (int i = 0; i < wmx_aec::kPlanBufs; i++) AEC_TRY(hipEventCreateWithFlags(&h->plan_free[i], hipEventDisableTiming));
     if (n_far > 1) {
         AEC_TRY(hipMalloc(&h->d_stream_far, sizeof(int) * n_streams));
-        AEC_TRY(hipMemcpy(h->d_stream_far, stream_far, sizeof(int) * n_streams, hipMemcpyHostToDevice));
+        if (stream_far) {
+            AEC_TRY(hipMemcpy(h->d_stream_far, stream_far, sizeof(int) * n_streams, hipMemcpyHostToDevice));
+        } else {
+            AEC_TRY(hipMemset(h->d_stream_far, 0, sizeof(int) * n_streams));
+        }
     }
-    AEC_TRY(hipMalloc(&d_tmpl, AS_WORDS * sizeof(float)));
+    AEC_TRY(hipMalloc(&h->d_tmpl, AS_WORDS * sizeof(float)));
     AEC_TRY(hipMemcpy(h->d_consts, &K, sizeof(K), hipMemcpyHostToDevice));
     {
         static_assert(sizeof(AecConsts) % 16 == 0, "PowTables behind AecConsts must stay 16-byte aligned");
@@ -1226,13 +1252,11 @@ int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int i
         pow_tables(&pt);
         AEC_TRY(hipMemcpy(reinterpret_cast<char *>(h->d_consts) + sizeof(K), &pt, sizeof(pt), hipMemcpyHostToDevice));
     }
-    AEC_TRY(hipMemcpy(d_tmpl, st.data(), AS_WORDS * sizeof(float), hipMemcpyHostToDevice));
+    AEC_TRY(hipMemcpy(h->d_tmpl, st.data(), AS_WORDS * sizeof(float), hipMemcpyHostToDevice));
     AEC_TRY(hipMemset(h->d_far, 0, far_words * n_far * sizeof(float)));
-    hipLaunchKernelGGL(aec_fill_state, dim3(1024), dim3(256), 0, nullptr, h->d_state, d_tmpl, (int)AS_WORDS, n_streams);
+    hipLaunchKernelGGL(aec_fill_state, dim3(1024), dim3(256), 0, nullptr, h->d_state, h->d_tmpl, (int)AS_WORDS, n_streams);
     AEC_TRY(hipGetLastError());
     AEC_TRY(hipDeviceSynchronize());
-    (void)hipFree(d_tmpl);
-    d_tmpl = nullptr;
 #undef AEC_TRY
     float *p = h->d_far;
     h->far.pre = p;
@@ -1274,12 +1298,34 @@ int wmx_aec_run(wmx_aec *h, int mode, const int16_t *d_far, long far_packet_stri
 
 int wmx_aec_run_groups(wmx_aec *h, int mode, const int16_t *d_far, long far_packet_stride, long far_group_stride, const int16_t *d_near,
                        int16_t *d_out, int n_packets, long stream_stride, long packet_stride, int delay_ms, void *stream) {
+    if (!h) {
+        wmx::set_error("wmx_aec_run: bad argument");
+        return WMX_EINVAL;
+    }
+    // every far-end group in lockstep: same reported delay, all switched on
+    std::vector<int32_t> delays((size_t)h->n_far, delay_ms);
+    return wmx_aec_run_cohorts(h, mode, d_far, far_packet_stride, far_group_stride, d_near, d_out, n_packets, stream_stride, packet_stride,
+                               delays.data(), nullptr, nullptr, stream);
+}
+
+// The general form.  A far-end group is also a control COHORT: its streams were started together (aec_init at the same
+// packet) and are called with the same reported delay, so the one control plane the reference runs per handle
+// (ProcessNormal's start-up machine, the ring indices, the block counters) is the same for all of them and runs once, on the
+// host.  delay_ms[g]: the delay cohort g reports in this call; cohort_on[g] == 0 (optional): cohort g is not called at all --
+// its control plane, far-end buffers and streams stay as they are; cohort_rc[g] (optional) receives what aec_process2 would
+// have returned to the members of cohort g.  Return value: 0, a WMX_E* error, or the first non-zero cohort_rc.
+int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_packet_stride, long far_group_stride, const int16_t *d_near,
+                        int16_t *d_out, int n_packets, long stream_stride, long packet_stride, const int32_t *delay_ms,
+                        const uint8_t *cohort_on, int32_t *cohort_rc, void *stream) {
     WMX_ON_DEVICE(h);
     using namespace wmx;
-    if (!h || n_packets < 0 || (mode & 3) == 0) {
+    if (!h || n_packets < 0 || (mode & 3) == 0 || !delay_ms) {
         set_error("wmx_aec_run: bad argument");
         return WMX_EINVAL;
     }
+    const int G = h->n_far;
+    if (cohort_rc)
+        for (int g = 0; g < G; g++) cohort_rc[g] = 0;
     if (n_packets == 0) return 0;  // frameNum == 0: nothing to do, whatever the pointers are
     if (((mode & 1) && !d_far) || ((mode & 2) && (!d_near || !d_out))) {
         set_error("wmx_aec_run: null buffer");
@@ -1296,8 +1342,10 @@ int wmx_aec_run_groups(wmx_aec *h, int mode, const int16_t *d_far, long far_pack
     }
     hipStream_t s = as_stream(stream);
     const float gpow1np = 0.1f * 12;  // gPow[1] * num_partitions (aec_core.c:1212), evaluated in float like the reference
-    int rc_ref = 0;
-    for (int done = 0; done < n_packets && rc_ref == 0;) {
+    std::vector<int> rc_g((size_t)G, 0);   // a cohort whose call was rejected runs nothing after the offending packet
+    int rc_first = 0, running = 0;
+    for (int g = 0; g < G; g++) running += (!cohort_on || cohort_on[g]) ? 1 : 0;
+    for (int done = 0; done < n_packets && running > 0;) {
         int chunk = n_packets - done;
         if (chunk > kAecMaxPktPerLaunch) chunk = kAecMaxPktPerLaunch;
         // the next plan slot: its pinned host half and its device half are rewritten only after the kernels that read the
@@ -1305,54 +1353,152 @@ int wmx_aec_run_groups(wmx_aec *h, int mode, const int16_t *d_far, long far_pack
         const int sel = h->plan_sel;
         h->plan_sel = (sel + 1) % wmx_aec::kPlanBufs;
         if (h->plan_used[sel]) WMX_HIP(hipEventSynchronize(h->plan_free[sel]));
-        AecPlan *hp = h->h_plans + (size_t)sel * kAecMaxPktPerLaunch, *dp = h->d_plans + (size_t)sel * kAecMaxPktPerLaunch;
-        int built = 0;
-        for (; built < chunk; built++) {
-            AecPlan &pl = hp[built];
-            memset(&pl, 0, offsetof(AecPlan, blk));
-            if (mode & 1) {
-                const int r = h->ctl.buffer_farend(h->pkg, &pl);
-                if (r != 0) {
-                    rc_ref = r;
-                    break;
+        const size_t slot = (size_t)sel * G * kAecMaxPktPerLaunch;
+        AecPlan *hp = h->h_plans + slot, *dp = h->d_plans + slot;
+        int any = 0;
+        for (int g = 0; g < G; g++) {
+            AecPlan *pg = hp + (size_t)g * kAecMaxPktPerLaunch;
+            const bool on = (!cohort_on || cohort_on[g]) && rc_g[g] == 0;
+            for (int k = 0; k < chunk; k++) {
+                AecPlan &pl = pg[k];
+                memset(&pl, 0, offsetof(AecPlan, blk));
+                if (!on || rc_g[g] != 0) continue;  // has_far = has_near = 0: both kernels skip the packet for this cohort
+                any = 1;
+                if (mode & 1) {
+                    const int r = h->ctl[g].buffer_farend(h->pkg, &pl);
+                    if (r != 0) {
+                        pl.has_far = 0;
+                        rc_g[g] = r;
+                        continue;
+                    }
+                }
+                if (mode & 2) {
+                    const int r = h->ctl[g].process(h->pkg, delay_ms[g], &pl);
+                    if (r != 0) {  // src/webrtc.c:463-468: the wrapper stops here; nothing of this packet is written
+                        pl.has_near = 0;
+                        rc_g[g] = r;
+                    }
                 }
             }
-            if (mode & 2) {
-                const int r = h->ctl.process(h->pkg, delay_ms, &pl);
-                if (r != 0) {  // src/webrtc.c:463-468: the wrapper stops here; nothing of this packet is written
-                    pl.has_near = 0;
-                    rc_ref = r;
-                    built++;
-                    break;
-                }
+            if (on && rc_g[g] != 0) {
+                running--;
+                if (rc_first == 0) rc_first = rc_g[g];
             }
         }
-        if (built > 0) {
-            const int by_value = built == 1;
-            if (!by_value) WMX_HIP(hipMemcpyAsync(dp, hp, built * sizeof(AecPlan), hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(aec_far_kernel, dim3((unsigned)h->n_far), dim3(64), 0, s, h->far, h->d_consts, dp, built,
+        if (any) {
+            const int by_value = (chunk == 1 && G == 1) ? 1 : 0;
+            if (!by_value) WMX_HIP(hipMemcpyAsync(dp, hp, (size_t)G * kAecMaxPktPerLaunch * sizeof(AecPlan), hipMemcpyHostToDevice, s));
+            hipEvent_t *tv = nullptr;
+            if (h->timing && (mode & 2)) {
+                if (h->tev_used + 3 > h->tev.size())
+                    for (int k = 0; k < 3; k++) {
+                        hipEvent_t ev;
+                        WMX_HIP(hipEventCreate(&ev));
+                        h->tev.push_back(ev);
+                    }
+                tv = &h->tev[h->tev_used];
+                h->tev_used += 3;
+                WMX_HIP(hipEventRecord(tv[0], s));
+            }
+            hipLaunchKernelGGL(aec_far_kernel, dim3((unsigned)G), dim3(64), 0, s, h->far, h->d_consts, dp, chunk,
                                d_far ? d_far + (size_t)done * far_packet_stride : nullptr, far_packet_stride, far_group_stride, h->chn, gpow1np,
                                by_value, hp[0]);
             WMX_LAUNCH_CHECK();
+            if (tv) WMX_HIP(hipEventRecord(tv[1], s));
             if (mode & 2) {
                 const int16_t *nin = d_near + (size_t)done * packet_stride;
                 int16_t *nout = d_out + (size_t)done * packet_stride;
                 const unsigned grid = (unsigned)((h->n_streams + kAecWavesPerBlock - 1) / kAecWavesPerBlock);
                 const dim3 blk(64 * kAecWavesPerBlock);
                 if (h->freq == 8000)
-                    hipLaunchKernelGGL((aec_near_kernel<1>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, built, nin,
-                                       nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg, h->d_stream_far);
+                    hipLaunchKernelGGL((aec_near_kernel<1>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, chunk, nin,
+                                       nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg, h->d_stream_far, h->life.d_active);
                 else
-                    hipLaunchKernelGGL((aec_near_kernel<2>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, built, nin,
-                                       nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg, h->d_stream_far);
+                    hipLaunchKernelGGL((aec_near_kernel<2>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, chunk, nin,
+                                       nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg, h->d_stream_far, h->life.d_active);
                 WMX_LAUNCH_CHECK();
+                if (tv) WMX_HIP(hipEventRecord(tv[2], s));
             }
             WMX_HIP(hipEventRecord(h->plan_free[sel], s));
             h->plan_used[sel] = true;
         }
         done += chunk;
     }
-    return rc_ref;
+    if (cohort_rc)
+        for (int g = 0; g < G; g++) cohort_rc[g] = rc_g[g];
+    return rc_first;
+}
+
+// aec_release + aec_init for the listed streams (src/webrtc.c:217-274, 485-505): InitAec state.  cohort >= 0 also moves them
+// to that far-end group / control cohort (needs a handle created with wmx_aec_create_groups); -1 leaves the membership.
+// A stream's new cohort must have been restarted (wmx_aec_reset_cohort) at the same point of the packet sequence, or the
+// stream inherits ring positions of a control plane that started earlier -- which is what no handle of the reference has.
+int wmx_aec_reset_streams(wmx_aec *h, const int32_t *idx, int n, int cohort, void *stream) {
+    WMX_ON_DEVICE(h);
+    using namespace wmx;
+    if (!h || n < 0 || (n > 0 && !idx) || cohort < -1 || cohort >= h->n_far) return WMX_EINVAL;
+    if (cohort >= 0 && h->n_far > 1 && !h->d_stream_far) return WMX_ESTATE;
+    if (n == 0) return 0;
+    hipStream_t s = as_stream(stream);
+    const int32_t *d_idx = nullptr;
+    const int rc = h->life.upload(idx, n, h->n_streams, s, &d_idx);
+    if (rc != 0) return rc;
+    const unsigned grid = (unsigned)(n < 4096 ? n : 4096);
+    hipLaunchKernelGGL((fill_rows_idx<float>), dim3(grid), dim3(256), 0, s, h->d_state, (const float *)h->d_tmpl, (int)AS_WORDS, d_idx, n);
+    if (cohort >= 0 && h->d_stream_far)
+        hipLaunchKernelGGL(aec_set_group, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->d_stream_far, d_idx, n, cohort);
+    WMX_LAUNCH_CHECK();
+    return h->life.done(s);
+}
+
+// aec_init for a whole cohort's SHARED part: the control plane starts over (start-up phase, empty far-end buffer, ring
+// positions, comfort-noise seed) and the far-end history of the group is cleared.  The member streams are reset with
+// wmx_aec_reset_streams(..., cohort, ...).
+int wmx_aec_reset_cohort(wmx_aec *h, int cohort, void *stream) {
+    WMX_ON_DEVICE(h);
+    using namespace wmx;
+    if (!h || cohort < 0 || cohort >= h->n_far) return WMX_EINVAL;
+    h->ctl[(size_t)cohort].init(h->freq);
+    WMX_HIP(hipMemsetAsync(h->d_far + (size_t)cohort * h->far.group_words, 0, h->far.group_words * sizeof(float), as_stream(stream)));
+    return 0;
+}
+
+int wmx_aec_set_active(wmx_aec *h, const uint8_t *host_mask, void *stream) {
+    WMX_ON_DEVICE(h);
+    if (!h) return WMX_EINVAL;
+    return h->life.set_active(h->n_streams, host_mask, wmx::as_stream(stream));
+}
+
+int wmx_aec_cohorts(const wmx_aec *h) { return h ? h->n_far : WMX_EINVAL; }
+
+// In-stream timing of the AEC's two kernels: with timing on, every near-end launch is bracketed by HIP events recorded on
+// the launch stream (before the far kernel, between the two, after the near kernel).  wmx_aec_timing waits for the last
+// one, returns the number of launches and the summed durations since the previous call, and starts over.
+int wmx_aec_set_timing(wmx_aec *h, int on) {
+    WMX_ON_DEVICE(h);
+    if (!h) return WMX_EINVAL;
+    h->timing = on != 0;
+    return 0;
+}
+
+int wmx_aec_timing(wmx_aec *h, int *n_launches, double *far_ms, double *near_ms) {
+    WMX_ON_DEVICE(h);
+    if (!h) return WMX_EINVAL;
+    double f = 0, nr = 0;
+    const size_t n = h->tev_used / 3;
+    for (size_t i = 0; i < n; i++) {
+        float a = 0.f, b = 0.f;
+        WMX_HIP(hipEventSynchronize(h->tev[3 * i + 2]));
+        WMX_HIP(hipEventElapsedTime(&a, h->tev[3 * i], h->tev[3 * i + 1]));
+        WMX_HIP(hipEventElapsedTime(&b, h->tev[3 * i + 1], h->tev[3 * i + 2]));
+        f += a;
+        nr += b;
+    }
+    h->tev_used = 0;
+    if (n_launches) *n_launches = (int)n;
+    if (far_ms) *far_ms = f;
+    if (near_ms) *near_ms = nr;
+    return 0;
 }
 
 }  // extern "C"

@@ -53,7 +53,16 @@ struct AecmFarBufs {
     uint16_t *hist;     // [kAecmHist][kAecmBP]     far spectra by absolute block number
     int32_t *hist_q;    // [kAecmHist]              their Q-domains
     uint32_t *hist_bin; // [kAecmHist]              binary far spectra
+    size_t group_bytes; // bytes between the buffers of consecutive cohorts (all eight live in one slab per cohort)
 };
+#ifdef __HIPCC__
+// the buffers of cohort g (wave-uniform g: pointer arithmetic on scalars)
+__device__ __forceinline__ AecmFarBufs far_cohort(const AecmFarBufs &F, int g) {
+    const size_t o = (size_t)g * F.group_bytes;
+    auto sh = [o](auto *p) { return reinterpret_cast<decltype(p)>(reinterpret_cast<char *>(p) + o); };
+    return AecmFarBufs{sh(F.ring), sh(F.old), sh(F.frame), sh(F.x_prev), sh(F.mean_far), sh(F.hist), sh(F.hist_q), sh(F.hist_bin), F.group_bytes};
+}
+#endif
 
 // ---------------------------------------------------------------- per-stream state block (int32 words)
 enum AecmLayout : int {
@@ -184,12 +193,16 @@ __device__ uint32_t binary_spectrum(const uint16_t *mag, int32_t *mean, int q, i
 // ---------------------------------------------------------------- far-end kernel: one wave per batch
 // plan_by_value: a one-packet launch hands its plan over as a kernel argument; this kernel, which runs in front of the near
 // kernel in the same stream, stores it into plans[0] for both (no host-to-device copy of the plan in front of the launch).
-__global__ __launch_bounds__(64) void aecm_far_kernel(AecmFarBufs F, const AecmConsts *__restrict__ consts, AecmPlan *plans, int n_plans,
-                                                     const int16_t *far, long far_stride, int chn, int plan_by_value,
+// grid = number of cohorts: workgroup g (one wave) serves cohort g with plans[g * kAecmMaxPktPerLaunch ...] and the far-end
+// packets at far + g * far_group_stride (0: every cohort hears the same far-end, blocked from its own start)
+__global__ __launch_bounds__(64) void aecm_far_kernel(AecmFarBufs F_all, const AecmConsts *__restrict__ consts, AecmPlan *plans, int n_plans,
+                                                     const int16_t *far, long far_stride, long far_group_stride, int chn, int plan_by_value,
                                                      const AecmPlan plan_value) {
     __shared__ AecmConsts K;
     __shared__ AecmWave W;
     const int lane = threadIdx.x;
+    const AecmFarBufs F = far_cohort(F_all, (int)blockIdx.x);
+    if (far) far += (size_t)blockIdx.x * far_group_stride;
     if (plan_by_value) {
         const int *src = reinterpret_cast<const int *>(&plan_value);
         int *dst = reinterpret_cast<int *>(plans);
@@ -197,6 +210,7 @@ __global__ __launch_bounds__(64) void aecm_far_kernel(AecmFarBufs F, const AecmC
         __threadfence();
         wave_sync();
     }
+    plans += (size_t)blockIdx.x * kAecmMaxPktPerLaunch;
     {
         const int4 *src = reinterpret_cast<const int4 *>(consts);
         int4 *dst = reinterpret_cast<int4 *>(&K);
@@ -717,11 +731,12 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
 #ifndef WMX_AECM_WPE
 #define WMX_AECM_WPE 7  // 0.63 / 0.53 / 0.48 / 0.445 ms at 3 / 4 / 5 / 6 waves per SIMD when first measured; 22.6 KB of LDS per workgroup allow 7
 #endif
-__global__ __launch_bounds__(64 * kAecmWavesPerBlock) __attribute__((amdgpu_waves_per_eu(WMX_AECM_WPE, WMX_AECM_WPE))) void aecm_near_kernel(int32_t *__restrict__ state, AecmFarBufs F,
+__global__ __launch_bounds__(64 * kAecmWavesPerBlock) __attribute__((amdgpu_waves_per_eu(WMX_AECM_WPE, WMX_AECM_WPE))) void aecm_near_kernel(int32_t *__restrict__ state, AecmFarBufs F_all,
                                                                             const AecmConsts *__restrict__ consts,
                                                                             const AecmPlan *__restrict__ plans, int n_plans, const int16_t *near,
                                                                             int16_t *out, int n_streams, long stream_stride, long packet_stride,
-                                                                            int chn, int pkg, int mult) {
+                                                                            int chn, int pkg, int mult, const int *__restrict__ stream_cohort,
+                                                                            const uint8_t *__restrict__ active) {
     __shared__ AecmConsts K;
     __shared__ AecmWave WS[kAecmWavesPerBlock];
     {
@@ -732,7 +747,7 @@ __global__ __launch_bounds__(64 * kAecmWavesPerBlock) __attribute__((amdgpu_wave
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const long s = (long)blockIdx.x * kAecmWavesPerBlock + wave;
     AecmWave &W = WS[wave];
-    const bool live = s < n_streams;
+    const bool live = stream_active(active, (int)s, n_streams);  // no stream, or one that is switched off: nothing touched
     int32_t *st = state + (live ? s : 0) * (long)A_WORDS;
     if (live) {
         const int4 *src = reinterpret_cast<const int4 *>(st);
@@ -741,6 +756,10 @@ __global__ __launch_bounds__(64 * kAecmWavesPerBlock) __attribute__((amdgpu_wave
     }
     __syncthreads();
     if (!live) return;
+    // the cohort this stream belongs to (wave-uniform): its far-end history and its plans
+    const int grp = stream_cohort ? __builtin_amdgcn_readfirstlane(stream_cohort[s]) : 0;
+    const AecmFarBufs F = far_cohort(F_all, grp);
+    plans += (size_t)grp * kAecmMaxPktPerLaunch;
     const LdsScal sc{&W.st[A_SCAL]};
     int16_t *near_ring = reinterpret_cast<int16_t *>(&W.st[A_NEAR_RING]), *out_ring = reinterpret_cast<int16_t *>(&W.st[A_OUT_RING]);
     int16_t *d_prev = reinterpret_cast<int16_t *>(&W.st[A_D_PREV]);
@@ -807,6 +826,11 @@ __global__ __launch_bounds__(64 * kAecmWavesPerBlock) __attribute__((amdgpu_wave
     }
 }
 
+__global__ void aecm_set_cohort(int *stream_cohort, const int32_t *idx, int n_idx, int cohort) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_idx) stream_cohort[idx[j]] = cohort;
+}
+
 __global__ void aecm_fill_state(int32_t *state, const int32_t *tmpl, int words, int n_streams) {
     const size_t total = (size_t)words * n_streams;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
@@ -820,8 +844,12 @@ __global__ void aecm_fill_state(int32_t *state, const int32_t *tmpl, int words, 
 struct wmx_aecm {
     int device;  // the HIP device the state lives on (current device at create); every entry point switches to it
     int n_streams, chn, freq, pkg;
-    wmx::AecmCtl ctl;
+    int n_cohorts;
+    std::vector<wmx::AecmCtl> ctl;  // one control plane per cohort
     int32_t *d_state;
+    int32_t *d_tmpl;        // the state aec_init gives a stream (reset_streams refills from it)
+    int *d_stream_cohort;   // [n_streams] cohort of each stream, or nullptr with one cohort
+    wmx::StreamLife life;
     wmx::AecmConsts *d_consts;
     void *d_far;  // one allocation carved into AecmFarBufs
     wmx::AecmFarBufs far;
@@ -841,6 +869,9 @@ int wmx_aecm_destroy(wmx_aecm *h) {
     if (h->d_consts) (void)hipFree(h->d_consts);
     if (h->d_far) (void)hipFree(h->d_far);
     if (h->d_plans[0]) (void)hipFree(h->d_plans[0]);
+    if (h->d_tmpl) (void)hipFree(h->d_tmpl);
+    if (h->d_stream_cohort) (void)hipFree(h->d_stream_cohort);
+    h->life.release();
     for (int i = 0; i < 2; i++)
         if (h->plan_free[i]) (void)hipEventDestroy(h->plan_free[i]);
     delete h;
@@ -848,9 +879,17 @@ int wmx_aecm_destroy(wmx_aecm *h) {
 }
 
 int wmx_aecm_create(wmx_aecm **out, int n_streams, int chn, int freq, int interval_ms) {
+    return wmx_aecm_create_cohorts(out, n_streams, chn, freq, interval_ms, 1);
+}
+
+int wmx_aecm_create_cohorts(wmx_aecm **out, int n_streams, int chn, int freq, int interval_ms, int n_cohorts) {
     using namespace wmx;
     if (!out) return WMX_EINVAL;
     *out = nullptr;
+    if (n_cohorts < 1) {
+        set_error("wmx_aecm_create_cohorts: n_cohorts=%d", n_cohorts);
+        return WMX_EINVAL;
+    }
     // aec_init (src/webrtc.c:220-221) + WebRtcAecm_Init (echo_control_mobile.c:186-190)
     if ((freq != 8000 && freq != 16000) || chn < 1 || n_streams < 1) {
         set_error("wmx_aecm_create: unsupported n_streams=%d chn=%d freq=%d", n_streams, chn, freq);
@@ -865,7 +904,11 @@ int wmx_aecm_create(wmx_aecm **out, int n_streams, int chn, int freq, int interv
     h->chn = chn;
     h->freq = freq;
     h->pkg = freq / 1000 * ((freq <= 8000 && interval_ms % 20 == 0) ? 20 : 10);  // src/webrtc.c:239-248
-    h->ctl.init(freq);
+    h->n_cohorts = n_cohorts;
+    h->ctl.resize((size_t)n_cohorts);
+    for (AecmCtl &c : h->ctl) c.init(freq);
+    h->d_tmpl = nullptr;
+    h->d_stream_cohort = nullptr;
     h->d_state = nullptr;
     h->d_consts = nullptr;
     h->d_far = nullptr;
@@ -873,7 +916,7 @@ int wmx_aecm_create(wmx_aecm **out, int n_streams, int chn, int freq, int interv
     h->plan_free[0] = h->plan_free[1] = nullptr;
     h->plan_used[0] = h->plan_used[1] = false;
     h->plan_sel = 0;
-    h->h_plans.resize(kAecmMaxPktPerLaunch);
+    h->h_plans.resize((size_t)n_cohorts * kAecmMaxPktPerLaunch);
 
     AecmConsts *K = new AecmConsts();
     memset(K, 0, sizeof(*K));
@@ -924,34 +967,36 @@ int wmx_aecm_create(wmx_aecm **out, int n_streams, int chn, int freq, int interv
         sc[M_LAST_PROB] = 32 << 9;
         sc[M_LAST_DELAY] = -2;
     }
-    const size_t far_bytes = sizeof(int16_t) * (kAecmFarRing + 2 * kAecmFrame + kAecmFrameRing + 64 + 8) + sizeof(int32_t) * (36 + kAecmHist) +
-                             sizeof(uint16_t) * (size_t)kAecmHist * kAecmBP + sizeof(uint32_t) * kAecmHist + 64;
-    int32_t *d_tmpl = nullptr;
+    const size_t far_raw = sizeof(int16_t) * (kAecmFarRing + 2 * kAecmFrame + kAecmFrameRing + 64 + 8) + sizeof(int32_t) * (36 + kAecmHist) +
+                           sizeof(uint16_t) * (size_t)kAecmHist * kAecmBP + sizeof(uint32_t) * kAecmHist + 64;
+    const size_t far_bytes = (far_raw + 255) / 256 * 256;  // per cohort
     hipError_t e;
 #define AECM_TRY(x)                                         \
     if ((e = (x)) != hipSuccess) {                          \
         const int rc = hip_fail(e, #x, __FILE__, __LINE__); \
         wmx_aecm_destroy(h);                                \
-        if (d_tmpl) (void)hipFree(d_tmpl);                  \
         delete K;                                           \
         return rc;                                          \
     }
     AECM_TRY(hipMalloc(&h->d_state, (size_t)A_WORDS * n_streams * sizeof(int32_t)));
     AECM_TRY(hipMalloc(&h->d_consts, sizeof(AecmConsts)));
-    AECM_TRY(hipMalloc(&h->d_far, far_bytes));
-    AECM_TRY(hipMalloc(&h->d_plans[0], 2 * kAecmMaxPktPerLaunch * sizeof(AecmPlan)));
-    h->d_plans[1] = h->d_plans[0] + kAecmMaxPktPerLaunch;
+    AECM_TRY(hipMalloc(&h->d_far, far_bytes * n_cohorts));
+    AECM_TRY(hipMalloc(&h->d_plans[0], 2 * (size_t)n_cohorts * kAecmMaxPktPerLaunch * sizeof(AecmPlan)));
+    h->d_plans[1] = h->d_plans[0] + (size_t)n_cohorts * kAecmMaxPktPerLaunch;
+    if (n_cohorts > 1) {
+        AECM_TRY(hipMalloc(&h->d_stream_cohort, sizeof(int) * n_streams));
+        AECM_TRY(hipMemset(h->d_stream_cohort, 0, sizeof(int) * n_streams));
+    }
     AECM_TRY(hipEventCreateWithFlags(&h->plan_free[0], hipEventDisableTiming));
     AECM_TRY(hipEventCreateWithFlags(&h->plan_free[1], hipEventDisableTiming));
-    AECM_TRY(hipMalloc(&d_tmpl, A_WORDS * sizeof(int32_t)));
+    AECM_TRY(hipMalloc(&h->d_tmpl, A_WORDS * sizeof(int32_t)));
     AECM_TRY(hipMemcpy(h->d_consts, K, sizeof(AecmConsts), hipMemcpyHostToDevice));
-    AECM_TRY(hipMemcpy(d_tmpl, st.data(), A_WORDS * sizeof(int32_t), hipMemcpyHostToDevice));
-    AECM_TRY(hipMemset(h->d_far, 0, far_bytes));
-    hipLaunchKernelGGL(aecm_fill_state, dim3(1024), dim3(256), 0, nullptr, h->d_state, d_tmpl, (int)A_WORDS, n_streams);
+    AECM_TRY(hipMemcpy(h->d_tmpl, st.data(), A_WORDS * sizeof(int32_t), hipMemcpyHostToDevice));
+    AECM_TRY(hipMemset(h->d_far, 0, far_bytes * n_cohorts));
+    hipLaunchKernelGGL(aecm_fill_state, dim3(1024), dim3(256), 0, nullptr, h->d_state, h->d_tmpl, (int)A_WORDS, n_streams);
     AECM_TRY(hipGetLastError());
     AECM_TRY(hipDeviceSynchronize());
 #undef AECM_TRY
-    (void)hipFree(d_tmpl);
     delete K;
     {  // carve the far-end allocation (32-bit arrays first: alignment)
         char *p = static_cast<char *>(h->d_far);
@@ -970,6 +1015,7 @@ int wmx_aecm_create(wmx_aecm **out, int n_streams, int chn, int freq, int interv
         h->far.frame = reinterpret_cast<int16_t *>(p);
         p += sizeof(int16_t) * kAecmFrameRing;
         h->far.x_prev = reinterpret_cast<int16_t *>(p);
+        h->far.group_bytes = far_bytes;
     }
     *out = h;
     return 0;
@@ -981,12 +1027,28 @@ int wmx_aecm_state_bytes(const wmx_aecm *h) { return h ? (int)wmx::A_WORDS * 4 :
 // Same contract as wmx_aec_run: mode bit 1 = aec_setFrameFar, bit 2 = aec_process, 3 = aec_process2.
 int wmx_aecm_run(wmx_aecm *h, int mode, const int16_t *d_far, long far_packet_stride, const int16_t *d_near, int16_t *d_out, int n_packets,
                  long stream_stride, long packet_stride, int delay_ms, void *stream) {
+    if (!h) {
+        wmx::set_error("wmx_aecm_run: bad argument");
+        return WMX_EINVAL;
+    }
+    std::vector<int32_t> delays((size_t)h->n_cohorts, delay_ms);
+    return wmx_aecm_run_cohorts(h, mode, d_far, far_packet_stride, 0, d_near, d_out, n_packets, stream_stride, packet_stride, delays.data(),
+                                nullptr, nullptr, stream);
+}
+
+// Same contract as wmx_aec_run_cohorts (include/wmix_amd.h): one reported delay, one on/off byte and one return code per cohort.
+int wmx_aecm_run_cohorts(wmx_aecm *h, int mode, const int16_t *d_far, long far_packet_stride, long far_group_stride, const int16_t *d_near,
+                         int16_t *d_out, int n_packets, long stream_stride, long packet_stride, const int32_t *delay_ms,
+                         const uint8_t *cohort_on, int32_t *cohort_rc, void *stream) {
     WMX_ON_DEVICE(h);
     using namespace wmx;
-    if (!h || n_packets < 0 || (mode & 3) == 0) {
+    if (!h || n_packets < 0 || (mode & 3) == 0 || !delay_ms) {
         set_error("wmx_aecm_run: bad argument");
         return WMX_EINVAL;
     }
+    const int G = h->n_cohorts;
+    if (cohort_rc)
+        for (int g = 0; g < G; g++) cohort_rc[g] = 0;
     if (n_packets == 0) return 0;
     if (((mode & 1) && !d_far) || ((mode & 2) && (!d_near || !d_out))) {
         set_error("wmx_aecm_run: null buffer");
@@ -1002,51 +1064,63 @@ int wmx_aecm_run(wmx_aecm *h, int mode, const int16_t *d_far, long far_packet_st
         return WMX_EINVAL;
     }
     hipStream_t s = as_stream(stream);
-    int rc_ref = 0;
-    for (int done = 0; done < n_packets && rc_ref == 0;) {
+    std::vector<int> rc_g((size_t)G, 0);
+    int rc_first = 0, running = 0;
+    for (int g = 0; g < G; g++) running += (!cohort_on || cohort_on[g]) ? 1 : 0;
+    for (int done = 0; done < n_packets && running > 0;) {
         int chunk = n_packets - done;
         if (chunk > kAecmMaxPktPerLaunch) chunk = kAecmMaxPktPerLaunch;
-        int built = 0;
-        for (; built < chunk; built++) {
-            AecmPlan &pl = h->h_plans[built];
-            memset(&pl, 0, sizeof(pl));
-            if (mode & 1) {
-                const int r = h->ctl.buffer_farend(h->pkg, &pl);
-                if (r != 0) {
-                    rc_ref = r;
-                    break;
+        int any = 0;
+        for (int g = 0; g < G; g++) {
+            AecmPlan *pg = h->h_plans.data() + (size_t)g * kAecmMaxPktPerLaunch;
+            const bool on = (!cohort_on || cohort_on[g]) && rc_g[g] == 0;
+            for (int k = 0; k < chunk; k++) {
+                AecmPlan &pl = pg[k];
+                memset(&pl, 0, sizeof(pl));
+                if (!on || rc_g[g] != 0) continue;  // has_far = has_near = 0: both kernels skip the packet for this cohort
+                any = 1;
+                if (mode & 1) {
+                    const int r = h->ctl[g].buffer_farend(h->pkg, &pl);
+                    if (r != 0) {
+                        pl.has_far = 0;
+                        rc_g[g] = r;
+                        continue;
+                    }
+                }
+                if (mode & 2) {
+                    const int r = h->ctl[g].process(h->pkg, delay_ms[g], &pl);
+                    if (r != 0) {
+                        // WebRtcAecm_Process has PROCESSED the packet with the delay clamped (state advances) and returns -1; the
+                        // wmix wrapper then returns without copying its output (src/webrtc.c:382-387).  Same here: the kernel
+                        // runs the packet but leaves the caller's buffer alone; later packets are not touched.
+                        pl.discard_out = 1;
+                        rc_g[g] = r;
+                    }
                 }
             }
-            if (mode & 2) {
-                const int r = h->ctl.process(h->pkg, delay_ms, &pl);
-                if (r != 0) {
-                    // WebRtcAecm_Process has PROCESSED the packet with the delay clamped (state advances) and returns -1; the
-                    // wmix wrapper then returns without copying its output (src/webrtc.c:382-387).  Same here: the kernel
-                    // runs the packet but leaves the caller's buffer alone; later packets are not touched.
-                    pl.discard_out = 1;
-                    rc_ref = r;
-                    built++;
-                    break;
-                }
+            if (on && rc_g[g] != 0) {
+                running--;
+                if (rc_first == 0) rc_first = rc_g[g];
             }
         }
-        if (built > 0) {
+        if (any) {
             const int sel = h->plan_sel;
             AecmPlan *dp = h->d_plans[sel];
             h->plan_sel ^= 1;
             // The device buffer alternates and is rewritten only after the kernels that read it last have finished (they
             // may run on any user stream); the copy itself is blocking, so the pageable host vector can be reused at once.
             if (h->plan_used[sel]) WMX_HIP(hipEventSynchronize(h->plan_free[sel]));
-            const int by_value = built == 1;
-            if (!by_value) WMX_HIP(hipMemcpy(dp, h->h_plans.data(), built * sizeof(AecmPlan), hipMemcpyHostToDevice));
-            hipLaunchKernelGGL(aecm_far_kernel, dim3(1), dim3(64), 0, s, h->far, h->d_consts, dp, built,
-                               d_far ? d_far + (size_t)done * far_packet_stride : nullptr, far_packet_stride, h->chn, by_value, h->h_plans[0]);
+            const int by_value = (chunk == 1 && G == 1) ? 1 : 0;
+            if (!by_value) WMX_HIP(hipMemcpy(dp, h->h_plans.data(), (size_t)G * kAecmMaxPktPerLaunch * sizeof(AecmPlan), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(aecm_far_kernel, dim3((unsigned)G), dim3(64), 0, s, h->far, h->d_consts, dp, chunk,
+                               d_far ? d_far + (size_t)done * far_packet_stride : nullptr, far_packet_stride, far_group_stride, h->chn, by_value,
+                               h->h_plans[0]);
             WMX_LAUNCH_CHECK();
             if (mode & 2) {
                 const unsigned grid = (unsigned)((h->n_streams + kAecmWavesPerBlock - 1) / kAecmWavesPerBlock);
-                hipLaunchKernelGGL(aecm_near_kernel, dim3(grid), dim3(64 * kAecmWavesPerBlock), 0, s, h->d_state, h->far, h->d_consts, dp, built,
+                hipLaunchKernelGGL(aecm_near_kernel, dim3(grid), dim3(64 * kAecmWavesPerBlock), 0, s, h->d_state, h->far, h->d_consts, dp, chunk,
                                    d_near + (size_t)done * packet_stride, d_out + (size_t)done * packet_stride, h->n_streams, stream_stride,
-                                   packet_stride, h->chn, h->pkg, h->freq / 8000);
+                                   packet_stride, h->chn, h->pkg, h->freq / 8000, h->d_stream_cohort, h->life.d_active);
                 WMX_LAUNCH_CHECK();
             }
             WMX_HIP(hipEventRecord(h->plan_free[sel], s));
@@ -1054,7 +1128,45 @@ int wmx_aecm_run(wmx_aecm *h, int mode, const int16_t *d_far, long far_packet_st
         }
         done += chunk;
     }
-    return rc_ref;
+    if (cohort_rc)
+        for (int g = 0; g < G; g++) cohort_rc[g] = rc_g[g];
+    return rc_first;
+}
+
+int wmx_aecm_cohorts(const wmx_aecm *h) { return h ? h->n_cohorts : WMX_EINVAL; }
+
+// aec_init for a cohort's shared part in the AECM build: control plane, far-end ring, farendOld, far spectrum history
+int wmx_aecm_reset_cohort(wmx_aecm *h, int cohort, void *stream) {
+    WMX_ON_DEVICE(h);
+    using namespace wmx;
+    if (!h || cohort < 0 || cohort >= h->n_cohorts) return WMX_EINVAL;
+    h->ctl[(size_t)cohort].init(h->freq);
+    WMX_HIP(hipMemsetAsync(static_cast<char *>(h->d_far) + (size_t)cohort * h->far.group_bytes, 0, h->far.group_bytes, as_stream(stream)));
+    return 0;
+}
+
+// aec_release + aec_init for the listed streams in the AECM build; cohort >= 0 also makes them members of that cohort
+int wmx_aecm_reset_streams(wmx_aecm *h, const int32_t *idx, int n, int cohort, void *stream) {
+    WMX_ON_DEVICE(h);
+    using namespace wmx;
+    if (!h || n < 0 || (n > 0 && !idx) || cohort < -1 || cohort >= h->n_cohorts) return WMX_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = as_stream(stream);
+    const int32_t *d_idx = nullptr;
+    const int rc = h->life.upload(idx, n, h->n_streams, s, &d_idx);
+    if (rc != 0) return rc;
+    hipLaunchKernelGGL((fill_rows_idx<int32_t>), dim3((unsigned)(n < 4096 ? n : 4096)), dim3(256), 0, s, h->d_state, (const int32_t *)h->d_tmpl,
+                       (int)A_WORDS, d_idx, n);
+    if (cohort >= 0 && h->d_stream_cohort)
+        hipLaunchKernelGGL(aecm_set_cohort, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->d_stream_cohort, d_idx, n, cohort);
+    WMX_LAUNCH_CHECK();
+    return h->life.done(s);
+}
+
+int wmx_aecm_set_active(wmx_aecm *h, const uint8_t *host_mask, void *stream) {
+    WMX_ON_DEVICE(h);
+    if (!h) return WMX_EINVAL;
+    return h->life.set_active(h->n_streams, host_mask, wmx::as_stream(stream));
 }
 
 }  // extern "C"

@@ -314,12 +314,12 @@ __device__ void agc_packet(const AgcRef &S, const int32_t *__restrict__ gain_tab
 template <int L, int CHN>
 __global__ __launch_bounds__(64) void agc_kernel(int16_t *s16, int32_t *s32, const int32_t *gain_table_g, const int16_t *in,
                                                  int16_t *out, int n_streams, int n_packets, long stream_stride,
-                                                 long packet_stride, int chn_rt) {
+                                                 long packet_stride, int chn_rt, const uint8_t *__restrict__ active) {
     __shared__ int32_t gain_table[32];
     if (threadIdx.x < 32) gain_table[threadIdx.x] = gain_table_g[threadIdx.x];
     __syncthreads();
     const int stream = blockIdx.x * 64 + threadIdx.x;
-    if (stream >= n_streams) return;
+    if (!stream_active(active, stream, n_streams)) return;
     if constexpr (CHN == 0) {
         const AgcRef S{s16 + stream, s32 + stream, (size_t)n_streams};
         for (int p = 0; p < n_packets; p++) {
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(64) void agc_kernel(int16_t *s16, int32_t *s32, con
 template <int L, int CHN>
 __global__ __launch_bounds__(256) void agc_pipe_kernel(int16_t *s16, int32_t *s32, const int32_t *gain_table_g, const int16_t *in,
                                                        int16_t *out, int n_streams, int n_packets, long stream_stride,
-                                                       long packet_stride) {
+                                                       long packet_stride, const uint8_t *__restrict__ active) {
     constexpr int L2 = (L == 8) ? 3 : 4, VPS = L * CHN / 8;  // uint4 per sub-frame
     __shared__ int32_t gain_table[32];
     __shared__ int16_t xdet[80 * 64];  // the detector's 80 input samples of every stream, [sample][lane]
@@ -368,8 +368,9 @@ __global__ __launch_bounds__(256) void agc_pipe_kernel(int16_t *s16, int32_t *s3
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int stream_raw = (int)blockIdx.x * 64 + lane;
-    const bool live = stream_raw < n_streams;
-    const int stream = live ? stream_raw : n_streams - 1;  // a lane without a stream recomputes the last one and stores nothing
+    // a lane without a stream recomputes the last one, a lane whose stream is switched off its own, and neither stores anything
+    const bool live = stream_active(active, stream_raw, n_streams);
+    const int stream = stream_raw < n_streams ? stream_raw : n_streams - 1;
     const int k0 = wave == 0 ? 0 : (wave == 1 ? 4 : 7), nk = wave == 0 ? 4 : (wave == 3 ? 0 : 3);  // this wave's sub-frames
     int16_t r16[A16_WORDS];
     int32_t r32[A32_WORDS];
@@ -496,9 +497,12 @@ __global__ __launch_bounds__(256) void agc_pipe_kernel(int16_t *s16, int32_t *s3
     }
 }
 
-__global__ void agc_fill_state(int16_t *s16, int32_t *s32, int n_streams) {
+// idx == nullptr: every stream; else the n_idx listed ones (wmx_agc_reset_streams)
+__global__ void agc_fill_state(int16_t *s16, int32_t *s32, int n_streams, const int32_t *idx, int n_idx) {
     // WebRtcAgc_InitDigital digital_agc.c:259-282 + WebRtcAgc_InitVad :606-631
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n_streams; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t count = idx ? (size_t)n_idx : (size_t)n_streams;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = idx ? (size_t)idx[j] : j;
         for (int f = 0; f < A32_WORDS; f++) s32[(size_t)f * n_streams + i] = 0;
         for (int f = 0; f < A16_WORDS; f++) s16[(size_t)f * n_streams + i] = 0;
         s32[(size_t)A32_CAP_SLOW * n_streams + i] = 134217728;
@@ -640,6 +644,7 @@ struct wmx_agc {
     int32_t *d_s32;
     int32_t *d_table;
     int32_t table[32];
+    wmx::StreamLife life;
 };
 
 extern "C" {
@@ -650,8 +655,29 @@ int wmx_agc_destroy(wmx_agc *h) {
     if (h->d_s16) (void)hipFree(h->d_s16);
     if (h->d_s32) (void)hipFree(h->d_s32);
     if (h->d_table) (void)hipFree(h->d_table);
+    h->life.release();
     delete h;
     return 0;
+}
+
+// agc_release + agc_init for the listed streams (src/webrtc.c:694-753, 841-860); the gain table is the batch's
+int wmx_agc_reset_streams(wmx_agc *h, const int32_t *idx, int n, void *stream) {
+    WMX_ON_DEVICE(h);
+    if (!h || n < 0 || (n > 0 && !idx)) return WMX_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = wmx::as_stream(stream);
+    const int32_t *d_idx = nullptr;
+    const int rc = h->life.upload(idx, n, h->n_streams, s, &d_idx);
+    if (rc != 0) return rc;
+    hipLaunchKernelGGL(wmx::agc_fill_state, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->d_s16, h->d_s32, h->n_streams, d_idx, n);
+    WMX_LAUNCH_CHECK();
+    return h->life.done(s);
+}
+
+int wmx_agc_set_active(wmx_agc *h, const uint8_t *host_mask, void *stream) {
+    WMX_ON_DEVICE(h);
+    if (!h) return WMX_EINVAL;
+    return h->life.set_active(h->n_streams, host_mask, wmx::as_stream(stream));
 }
 
 // agc_addition (src/webrtc.c:824-839): WebRtcAgc_set_config with a new compression gain -> new table.
@@ -699,7 +725,7 @@ int wmx_agc_create(wmx_agc **out, int n_streams, int chn, int freq, int interval
     AGC_TRY(hipMalloc(&h->d_s16, (size_t)A16_WORDS * n_streams * sizeof(int16_t)));
     AGC_TRY(hipMalloc(&h->d_s32, (size_t)A32_WORDS * n_streams * sizeof(int32_t)));
     AGC_TRY(hipMalloc(&h->d_table, 32 * sizeof(int32_t)));
-    hipLaunchKernelGGL(agc_fill_state, dim3(512), dim3(256), 0, nullptr, h->d_s16, h->d_s32, n_streams);
+    hipLaunchKernelGGL(agc_fill_state, dim3(512), dim3(256), 0, nullptr, h->d_s16, h->d_s32, n_streams, (const int32_t *)nullptr, 0);
     AGC_TRY(hipGetLastError());
     AGC_TRY(hipDeviceSynchronize());
 #undef AGC_TRY
@@ -747,7 +773,7 @@ int wmx_agc_process(wmx_agc *h, const int16_t *d_in, int16_t *d_out, int n_packe
     if (pipe) {
 #define AGC_PIPE(LL, CC)                                                                                                          \
     hipLaunchKernelGGL((agc_pipe_kernel<LL, CC>), grid, dim3(256), 0, s, h->d_s16, h->d_s32, h->d_table, d_in, d_out, h->n_streams, \
-                       n_packets, stream_stride, packet_stride)
+                       n_packets, stream_stride, packet_stride, h->life.d_active)
         if (h->freq == 8000) {
             if (h->chn == 1)
                 AGC_PIPE(8, 1);
@@ -765,7 +791,7 @@ int wmx_agc_process(wmx_agc *h, const int16_t *d_in, int16_t *d_out, int n_packe
     }
 #define AGC_LAUNCH(LL, CC)                                                                                                   \
     hipLaunchKernelGGL((agc_kernel<LL, CC>), grid, block, 0, s, h->d_s16, h->d_s32, h->d_table, d_in, d_out, h->n_streams, n_packets, \
-                       stream_stride, packet_stride, h->chn)
+                       stream_stride, packet_stride, h->chn, h->life.d_active)
     if (h->freq == 8000) {
         if (h->chn == 1)
             AGC_LAUNCH(8, 1);

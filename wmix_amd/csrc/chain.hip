@@ -1,0 +1,180 @@
+// chain.hip -- the daemon's record heartbeat as ONE C call per tick (host code only: it sequences launches).
+//
+// wmix_shmem_write_circle (src/wmix.c:613-709) runs, per WMIX_INTERVAL_MS of captured audio and on one buffer in place,
+//     ns_process -> aec_process2(far = playPkgBuff_get(...), near = out = buffer, delayms) -> agc_process -> vad_process
+// each behind its webrtcEnable[] switch, creating the handle on first use and releasing it when the switch drops or
+// recording idles (src/wmix.c:565-600, 617-618, 635-636, 683-684, 702-703).  wmx_chain is that heartbeat for a batch of
+// streams: the four batched handles, one wmx_chain_process per tick launching their kernels back to back on the caller's
+// HIP stream (no host synchronisation, nothing copied), and the per-stream lifetime calls forwarded to every stage.
+// A C host (examples/host_chain.c) needs nothing else of the library for the chain.
+#include <vector>
+#include "wmx_internal.h"
+
+struct wmx_chain {
+    int device;  // first member of every handle (wmx_handle_device)
+    int n_streams, chn, freq, interval_ms;
+    unsigned stages;
+    wmx_ns *ns;
+    wmx_aec *aec;
+    wmx_agc *agc;
+    wmx_vad *vad;
+    int pkg10;                       // int16 elements of one 10 ms packet of one stream (freq / 100 * chn)
+    int aec_pkg, agc_pkg, vad_pkg;   // the stages' own packets, in int16 elements
+    int n_cohorts;
+};
+
+extern "C" {
+
+int wmx_chain_destroy(wmx_chain *h) {
+    WMX_ON_DEVICE(h);
+    if (!h) return 0;
+    if (h->ns) wmx_ns_destroy(h->ns);
+    if (h->aec) wmx_aec_destroy(h->aec);
+    if (h->agc) wmx_agc_destroy(h->agc);
+    if (h->vad) wmx_vad_destroy(h->vad);
+    delete h;
+    return 0;
+}
+
+int wmx_chain_create(wmx_chain **out, int n_streams, int chn, int freq, int interval_ms, int agc_value, unsigned stages, int n_cohorts) {
+    if (!out) return WMX_EINVAL;
+    *out = nullptr;
+    if ((stages & 15u) == 0 || (stages & ~15u) != 0 || n_cohorts < 1) {
+        wmx::set_error("wmx_chain_create: stages=0x%x n_cohorts=%d", stages, n_cohorts);
+        return WMX_EINVAL;
+    }
+    wmx_chain *h = new wmx_chain();
+    if ((h->device = wmx::current_device()) < 0) {
+        delete h;
+        return WMX_ENODEV;
+    }
+    h->n_streams = n_streams;
+    h->chn = chn;
+    h->freq = freq;
+    h->interval_ms = interval_ms;
+    h->stages = stages;
+    h->n_cohorts = n_cohorts;
+    h->pkg10 = freq / 100 * chn;
+    int rc = 0;
+    // the same *_init calls, in the heartbeat's order; an unsupported format fails the way the reference's *_init returns NULL
+    if (rc == 0 && (stages & WMX_CHAIN_NS)) rc = wmx_ns_create(&h->ns, n_streams, chn, freq);
+    if (rc == 0 && (stages & WMX_CHAIN_AEC)) rc = wmx_aec_create_groups(&h->aec, n_streams, chn, freq, interval_ms, n_cohorts, nullptr);
+    if (rc == 0 && (stages & WMX_CHAIN_AGC)) rc = wmx_agc_create(&h->agc, n_streams, chn, freq, interval_ms, agc_value);
+    if (rc == 0 && (stages & WMX_CHAIN_VAD)) rc = wmx_vad_create(&h->vad, n_streams, chn, freq, interval_ms);
+    if (rc != 0) {
+        wmx_chain_destroy(h);
+        return rc;
+    }
+    h->aec_pkg = h->aec ? wmx_aec_packet_samples(h->aec) : h->pkg10;
+    h->agc_pkg = h->agc ? wmx_agc_packet_samples(h->agc) : h->pkg10;
+    h->vad_pkg = h->vad ? wmx_vad_packet_samples(h->vad) : h->pkg10;
+    *out = h;
+    return 0;
+}
+
+wmx_ns *wmx_chain_ns(wmx_chain *h) { return h ? h->ns : nullptr; }
+wmx_aec *wmx_chain_aec(wmx_chain *h) { return h ? h->aec : nullptr; }
+wmx_agc *wmx_chain_agc(wmx_chain *h) { return h ? h->agc : nullptr; }
+wmx_vad *wmx_chain_vad(wmx_chain *h) { return h ? h->vad : nullptr; }
+
+// One heartbeat.  n10: 10 ms packets per stream in this tick (the daemon's WMIX_FRAME_NUM is 2 of them); packet p of stream s
+// at d_in / d_out + s * stream_stride + p * packet_stride.  The first enabled stage reads d_in and writes d_out, the others
+// work on d_out in place (d_out == d_in is the daemon's case).  A stage whose own packet is longer than 10 ms (AEC at 8 kHz
+// with a 20 ms interval, VAD with a 20 ms interval) needs the tick's packets contiguous (packet_stride == one packet);
+// vad_process is ONE call per tick over the whole buffer, as in the heartbeat (so it analyses the tick's first packet only,
+// SURVEY section 0 quirk 1).  delay_ms: one reported delay per cohort (NULL: 0, what the daemon passes).
+int wmx_chain_process(wmx_chain *h, const int16_t *d_far, long far_packet_stride, const int16_t *d_in, int16_t *d_out, int n10,
+                      long stream_stride, long packet_stride, const int32_t *delay_ms, const uint8_t *cohort_on, int32_t *cohort_rc,
+                      void *stream) {
+    WMX_ON_DEVICE(h);
+    if (!h || n10 < 0) {
+        wmx::set_error("wmx_chain_process: bad argument");
+        return WMX_EINVAL;
+    }
+    if (n10 == 0) return 0;
+    if (!d_in || !d_out || ((h->stages & WMX_CHAIN_AEC) && !d_far)) {
+        wmx::set_error("wmx_chain_process: null buffer");
+        return WMX_EINVAL;
+    }
+    const long total = (long)n10 * h->pkg10;  // int16 elements of the tick per stream
+    const bool contiguous = packet_stride == h->pkg10;
+    auto fits = [&](int pkg) { return total % pkg == 0 && (pkg <= h->pkg10 || contiguous); };
+    if ((h->aec && !fits(h->aec_pkg)) || (h->vad && !fits(h->vad_pkg)) || (h->aec && h->aec_pkg > h->pkg10 && far_packet_stride != h->pkg10)) {
+        wmx::set_error("wmx_chain_process: %d x 10 ms with packet stride %ld does not hold whole %d / %d-sample packets", n10, packet_stride,
+                       h->aec_pkg, h->vad_pkg);
+        return WMX_EINVAL;
+    }
+    const int16_t *src = d_in;
+    int rc = 0, rc_aec = 0;
+    if (h->ns) {
+        if ((rc = wmx_ns_process(h->ns, src, d_out, n10, stream_stride, packet_stride, stream)) != 0) return rc;
+        src = d_out;
+    }
+    if (h->aec) {
+        const int per = h->aec_pkg / h->pkg10;  // 10 ms packets per AEC packet (1 or 2)
+        std::vector<int32_t> zero;
+        if (!delay_ms) {
+            zero.assign((size_t)h->n_cohorts, 0);
+            delay_ms = zero.data();
+        }
+        rc_aec = wmx_aec_run_cohorts(h->aec, 3, d_far, far_packet_stride * per, 0, src, d_out, n10 / per, stream_stride, packet_stride * per,
+                                     delay_ms, cohort_on, cohort_rc, stream);
+        if (rc_aec != 0 && rc_aec != -1) return rc_aec;  // -1: a cohort's delay was rejected (its code is in cohort_rc); the others ran
+        src = d_out;
+    }
+    if (h->agc) {
+        if (h->agc_pkg == h->pkg10) {
+            if ((rc = wmx_agc_process(h->agc, src, d_out, n10, stream_stride, packet_stride, stream)) != 0) return rc;
+        } else if (contiguous) {  // 5 ms packets at 32 kHz, the tick in one piece
+            if ((rc = wmx_agc_process(h->agc, src, d_out, (int)(total / h->agc_pkg), stream_stride, h->agc_pkg, stream)) != 0) return rc;
+        } else {  // 5 ms packets inside 10 ms packets that lie apart: one call per 10 ms packet
+            const int per = h->pkg10 / h->agc_pkg;
+            for (int p = 0; p < n10; p++)
+                if ((rc = wmx_agc_process(h->agc, src + (size_t)p * packet_stride, d_out + (size_t)p * packet_stride, per, stream_stride,
+                                          h->agc_pkg, stream)) != 0)
+                    return rc;
+        }
+        src = d_out;
+    }
+    if (h->vad) {
+        if (src != d_out) {
+            wmx::set_error("wmx_chain_process: a VAD-only chain works in place (d_in == d_out)");
+            return WMX_EINVAL;
+        }
+        // one call over the tick's packets; only its first packet is touched, wherever the others lie
+        if ((rc = wmx_vad_process(h->vad, d_out, (int)(total / h->vad_pkg), 1, stream_stride, h->vad_pkg, stream)) != 0) return rc;
+    }
+    return rc_aec;
+}
+
+// *_release + *_init of every stage for the listed streams; cohort >= 0 makes them members of that AEC cohort (which the
+// caller restarts once per join time with wmx_chain_reset_cohort)
+int wmx_chain_reset_streams(wmx_chain *h, const int32_t *idx, int n, int cohort, void *stream) {
+    WMX_ON_DEVICE(h);
+    if (!h) return WMX_EINVAL;
+    int rc = 0;
+    if (rc == 0 && h->ns) rc = wmx_ns_reset_streams(h->ns, idx, n, stream);
+    if (rc == 0 && h->aec) rc = wmx_aec_reset_streams(h->aec, idx, n, cohort, stream);
+    if (rc == 0 && h->agc) rc = wmx_agc_reset_streams(h->agc, idx, n, stream);
+    if (rc == 0 && h->vad) rc = wmx_vad_reset_streams(h->vad, idx, n, stream);
+    return rc;
+}
+
+int wmx_chain_reset_cohort(wmx_chain *h, int cohort, void *stream) {
+    WMX_ON_DEVICE(h);
+    if (!h) return WMX_EINVAL;
+    return h->aec ? wmx_aec_reset_cohort(h->aec, cohort, stream) : 0;
+}
+
+int wmx_chain_set_active(wmx_chain *h, const uint8_t *host_mask, void *stream) {
+    WMX_ON_DEVICE(h);
+    if (!h) return WMX_EINVAL;
+    int rc = 0;
+    if (rc == 0 && h->ns) rc = wmx_ns_set_active(h->ns, host_mask, stream);
+    if (rc == 0 && h->aec) rc = wmx_aec_set_active(h->aec, host_mask, stream);
+    if (rc == 0 && h->agc) rc = wmx_agc_set_active(h->agc, host_mask, stream);
+    if (rc == 0 && h->vad) rc = wmx_vad_set_active(h->vad, host_mask, stream);
+    return rc;
+}
+
+}  // extern "C"

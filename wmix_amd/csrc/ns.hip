@@ -846,7 +846,7 @@ template <int L, bool ORDERED, int CHN>
 __global__ __launch_bounds__(64 * kNsWavesPerBlock) __attribute__((amdgpu_waves_per_eu(NsOcc<L, ORDERED>::kWaves, NsOcc<L, ORDERED>::kWaves))) void ns_kernel(float *__restrict__ state, unsigned short *__restrict__ hists,
                                                                       const float *__restrict__ consts, const int16_t *in, int16_t *out,
                                                                       int n_streams, int n_packets, long stream_stride,
-                                                                      long packet_stride, int pkg) {
+                                                                      long packet_stride, int pkg, const uint8_t *__restrict__ active) {
     using Y = NsLayout<L>;
     __shared__ NsConstLds<L> K;
     __shared__ NsWaveLds<L> Wv[kNsWavesPerBlock];
@@ -871,7 +871,7 @@ __global__ __launch_bounds__(64 * kNsWavesPerBlock) __attribute__((amdgpu_waves_
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: state pointers become scalar bases
     const int sidx = blockIdx.x * kNsWavesPerBlock + wave;  // one stream per wave; no block-level barrier below
-    if (sidx >= n_streams) return;
+    if (!stream_active(active, sidx, n_streams)) return;  // no stream, or one that is switched off: state and PCM rows untouched
     float *st = state + (size_t)sidx * Y::WORDS;
     unsigned short *hist = hists + (size_t)sidx * 3 * kHistBins;
     {
@@ -913,7 +913,9 @@ struct wmx_ns {
     float *d_state;
     unsigned short *d_hist;
     float *d_consts;
+    float *d_tmpl;  // the state ns_init gives a stream (reset_streams refills from it)
     size_t words;
+    wmx::StreamLife life;
 };
 
 namespace {
@@ -1011,27 +1013,23 @@ int wmx_ns_create(wmx_ns **out, int n_streams, int chn, int freq) {
     else
         build_ns_template<256>(st, consts);
     h->words = st.size();
-    float *d_tmpl = nullptr;
     hipError_t e;
 #define NS_TRY(x)                                                  \
     if ((e = (x)) != hipSuccess) {                                 \
         int rc = wmx::hip_fail(e, #x, __FILE__, __LINE__);         \
         wmx_ns_destroy(h);                                         \
-        if (d_tmpl) (void)hipFree(d_tmpl);                         \
         return rc;                                                 \
     }
     NS_TRY(hipMalloc(&h->d_state, h->words * sizeof(float) * (size_t)n_streams));
     NS_TRY(hipMalloc(&h->d_hist, (size_t)n_streams * 3 * 1000 * sizeof(unsigned short)));
     NS_TRY(hipMalloc(&h->d_consts, consts.size() * sizeof(float)));
-    NS_TRY(hipMalloc(&d_tmpl, st.size() * sizeof(float)));
+    NS_TRY(hipMalloc(&h->d_tmpl, st.size() * sizeof(float)));
     NS_TRY(hipMemcpy(h->d_consts, consts.data(), consts.size() * sizeof(float), hipMemcpyHostToDevice));
-    NS_TRY(hipMemcpy(d_tmpl, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
+    NS_TRY(hipMemcpy(h->d_tmpl, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
     NS_TRY(hipMemset(h->d_hist, 0, (size_t)n_streams * 3 * 1000 * sizeof(unsigned short)));
-    hipLaunchKernelGGL(ns_fill_state, dim3(1024), dim3(256), 0, nullptr, h->d_state, d_tmpl, (int)h->words, n_streams);
+    hipLaunchKernelGGL(ns_fill_state, dim3(1024), dim3(256), 0, nullptr, h->d_state, h->d_tmpl, (int)h->words, n_streams);
     NS_TRY(hipGetLastError());
     NS_TRY(hipDeviceSynchronize());
-    (void)hipFree(d_tmpl);
-    d_tmpl = nullptr;
 #undef NS_TRY
     *out = h;
     return 0;
@@ -1043,8 +1041,32 @@ int wmx_ns_destroy(wmx_ns *h) {
     if (h->d_state) (void)hipFree(h->d_state);
     if (h->d_hist) (void)hipFree(h->d_hist);
     if (h->d_consts) (void)hipFree(h->d_consts);
+    if (h->d_tmpl) (void)hipFree(h->d_tmpl);
+    h->life.release();
     delete h;
     return 0;
+}
+
+// ns_release + ns_init for the listed streams (src/webrtc.c:560-602, 646-661): WebRtcNs_InitCore state, empty histograms
+int wmx_ns_reset_streams(wmx_ns *h, const int32_t *idx, int n, void *stream) {
+    WMX_ON_DEVICE(h);
+    if (!h || n < 0 || (n > 0 && !idx)) return WMX_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = wmx::as_stream(stream);
+    const int32_t *d_idx = nullptr;
+    const int rc = h->life.upload(idx, n, h->n_streams, s, &d_idx);
+    if (rc != 0) return rc;
+    const unsigned grid = (unsigned)(n < 4096 ? n : 4096);
+    hipLaunchKernelGGL((wmx::fill_rows_idx<float>), dim3(grid), dim3(256), 0, s, h->d_state, (const float *)h->d_tmpl, (int)h->words, d_idx, n);
+    hipLaunchKernelGGL((wmx::fill_rows_idx<unsigned short>), dim3(grid), dim3(256), 0, s, h->d_hist, (const unsigned short *)nullptr, 3000, d_idx, n);
+    WMX_LAUNCH_CHECK();
+    return h->life.done(s);
+}
+
+int wmx_ns_set_active(wmx_ns *h, const uint8_t *host_mask, void *stream) {
+    WMX_ON_DEVICE(h);
+    if (!h) return WMX_EINVAL;
+    return h->life.set_active(h->n_streams, host_mask, wmx::as_stream(stream));
 }
 
 int wmx_ns_set_ordered(wmx_ns *h, int ordered) {
@@ -1090,7 +1112,7 @@ int wmx_ns_process(wmx_ns *h, const int16_t *d_in, int16_t *d_out, int n_packets
     hipStream_t s = wmx::as_stream(stream);
 #define NS_LAUNCH(LL, ORD, CC)                                                                                              \
     hipLaunchKernelGGL((wmx::ns_kernel<LL, ORD, CC>), dim3(grid), dim3(64 * wmx::kNsWavesPerBlock), 0, s, h->d_state, h->d_hist, \
-                       h->d_consts, d_in, d_out, h->n_streams, n_packets, stream_stride, packet_stride, h->pkg)
+                       h->d_consts, d_in, d_out, h->n_streams, n_packets, stream_stride, packet_stride, h->pkg, h->life.d_active)
 #define NS_LAUNCH_ORD(LL, CC) \
     do {                      \
         if (h->ordered)       \

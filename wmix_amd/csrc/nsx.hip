@@ -992,7 +992,7 @@ template <int ANA, int CHN>
 __global__ __launch_bounds__((64 * NsxShape<ANA, CHN>::WPB)) __attribute__((amdgpu_waves_per_eu(NsxShape<ANA, CHN>::WPE, NsxShape<ANA, CHN>::WPE))) void nsx_kernel(int32_t *__restrict__ state, int16_t *__restrict__ hist,
                                                                      const NsxConsts *__restrict__ consts, const int16_t *in, int16_t *out,
                                                                      int n_streams, int n_packets, long stream_stride, long packet_stride,
-                                                                     int pkg, int overdrive, int denoise_bound) {
+                                                                     int pkg, int overdrive, int denoise_bound, const uint8_t *__restrict__ active) {
     using Y = NsxLayout<ANA>;
     constexpr int WORDS = CHN == 2 ? Y::WORDS_2CH : Y::WORDS_MONO, BLOCK = ANA == 256 ? 160 : 80, WPB = NsxShape<ANA, CHN>::WPB;
     __shared__ NsxConsts K;
@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__((64 * NsxShape<ANA, CHN>::WPB)) __attribute__((amdg
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const long s = (long)blockIdx.x * WPB + wave;
     NsxWave<ANA, CHN> &W = WS[wave];
-    const bool live = s < n_streams;
+    const bool live = stream_active(active, (int)s, n_streams);  // no stream, or one that is switched off: nothing touched
     int32_t *st = state + (live ? s : 0) * (long)WORDS;
     if (live) {
         const int4 *src = reinterpret_cast<const int4 *>(st);
@@ -1072,6 +1072,8 @@ struct wmx_nsx {
     int32_t *d_state;
     int16_t *d_hist;
     wmx::NsxConsts *d_consts;
+    int32_t *d_tmpl;  // the state ns_init gives a stream (reset_streams refills from it)
+    wmx::StreamLife life;
 };
 
 extern "C" {
@@ -1082,8 +1084,32 @@ int wmx_nsx_destroy(wmx_nsx *h) {
     if (h->d_state) (void)hipFree(h->d_state);
     if (h->d_hist) (void)hipFree(h->d_hist);
     if (h->d_consts) (void)hipFree(h->d_consts);
+    if (h->d_tmpl) (void)hipFree(h->d_tmpl);
+    h->life.release();
     delete h;
     return 0;
+}
+
+// ns_release + ns_init for the listed streams in the reference's MAKE_WEBRTC_NSX build (src/webrtc.c:512-521, 560-602)
+int wmx_nsx_reset_streams(wmx_nsx *h, const int32_t *idx, int n, void *stream) {
+    WMX_ON_DEVICE(h);
+    if (!h || n < 0 || (n > 0 && !idx)) return WMX_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = wmx::as_stream(stream);
+    const int32_t *d_idx = nullptr;
+    const int rc = h->life.upload(idx, n, h->n_streams, s, &d_idx);
+    if (rc != 0) return rc;
+    const unsigned grid = (unsigned)(n < 4096 ? n : 4096);
+    hipLaunchKernelGGL((wmx::fill_rows_idx<int32_t>), dim3(grid), dim3(256), 0, s, h->d_state, (const int32_t *)h->d_tmpl, h->words, d_idx, n);
+    hipLaunchKernelGGL((wmx::fill_rows_idx<int16_t>), dim3(grid), dim3(256), 0, s, h->d_hist, (const int16_t *)nullptr, 3 * wmx::kNsxHist, d_idx, n);
+    WMX_LAUNCH_CHECK();
+    return h->life.done(s);
+}
+
+int wmx_nsx_set_active(wmx_nsx *h, const uint8_t *host_mask, void *stream) {
+    WMX_ON_DEVICE(h);
+    if (!h) return WMX_EINVAL;
+    return h->life.set_active(h->n_streams, host_mask, wmx::as_stream(stream));
 }
 
 int wmx_nsx_create(wmx_nsx **out, int n_streams, int chn, int freq) {
@@ -1110,6 +1136,7 @@ int wmx_nsx_create(wmx_nsx **out, int n_streams, int chn, int freq) {
     h->d_state = nullptr;
     h->d_hist = nullptr;
     h->d_consts = nullptr;
+    h->d_tmpl = nullptr;
     std::vector<int32_t> st;
     if (h->ana == 128)
         nsx_template<128>(st, chn);
@@ -1133,28 +1160,25 @@ int wmx_nsx_create(wmx_nsx **out, int n_streams, int chn, int freq) {
     K->sum_log_index_5 = fx_nsx_sum_log_index[5], K->sum_log_index_65 = fx_nsx_sum_log_index[65];
     K->sum_sq_log_index_5 = fx_nsx_sum_sq_log_index[5], K->sum_sq_log_index_65 = fx_nsx_sum_sq_log_index[65];
     K->determinant_5 = fx_nsx_determinant[5];
-    int32_t *d_tmpl = nullptr;
     hipError_t e;
 #define NSX_TRY(x)                                        \
     if ((e = (x)) != hipSuccess) {                        \
         const int rc = hip_fail(e, #x, __FILE__, __LINE__); \
         wmx_nsx_destroy(h);                               \
-        if (d_tmpl) (void)hipFree(d_tmpl);                \
         delete K;                                         \
         return rc;                                        \
     }
     NSX_TRY(hipMalloc(&h->d_state, (size_t)h->words * n_streams * sizeof(int32_t)));
     NSX_TRY(hipMalloc(&h->d_hist, (size_t)3 * kNsxHist * n_streams * sizeof(int16_t)));
     NSX_TRY(hipMalloc(&h->d_consts, sizeof(NsxConsts)));
-    NSX_TRY(hipMalloc(&d_tmpl, st.size() * sizeof(int32_t)));
+    NSX_TRY(hipMalloc(&h->d_tmpl, st.size() * sizeof(int32_t)));
     NSX_TRY(hipMemcpy(h->d_consts, K, sizeof(NsxConsts), hipMemcpyHostToDevice));
-    NSX_TRY(hipMemcpy(d_tmpl, st.data(), st.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    NSX_TRY(hipMemcpy(h->d_tmpl, st.data(), st.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     NSX_TRY(hipMemset(h->d_hist, 0, (size_t)3 * kNsxHist * n_streams * sizeof(int16_t)));
-    hipLaunchKernelGGL(nsx_fill_state, dim3(1024), dim3(256), 0, nullptr, h->d_state, d_tmpl, h->words, n_streams);
+    hipLaunchKernelGGL(nsx_fill_state, dim3(1024), dim3(256), 0, nullptr, h->d_state, h->d_tmpl, h->words, n_streams);
     NSX_TRY(hipGetLastError());
     NSX_TRY(hipDeviceSynchronize());
 #undef NSX_TRY
-    (void)hipFree(d_tmpl);
     delete K;
     *out = h;
     return 0;
@@ -1175,11 +1199,17 @@ int wmx_nsx_process(wmx_nsx *h, const int16_t *d_in, int16_t *d_out, int n_packe
         set_error("wmx_nsx_process: null buffer");
         return WMX_EINVAL;
     }
+    const long per_pkt = (long)h->pkg * h->chn;
+    if (packet_stride < per_pkt || (h->n_streams > 1 && stream_stride < per_pkt)) {
+        // a packet must not overlap its neighbours (the kernel would write across rows)
+        set_error("wmx_nsx_process: strides (%ld, %ld) smaller than a packet (%ld samples)", stream_stride, packet_stride, per_pkt);
+        return WMX_EINVAL;
+    }
     hipStream_t s = as_stream(stream);
 #define NSX_LAUNCH(A, C)                                                                                                    \
     hipLaunchKernelGGL((nsx_kernel<A, C>), dim3((unsigned)((h->n_streams + NsxShape<A, C>::WPB - 1) / NsxShape<A, C>::WPB)),  \
                        dim3(64 * NsxShape<A, C>::WPB), 0, s, h->d_state, h->d_hist, h->d_consts, d_in, d_out, h->n_streams, \
-                       n_packets, stream_stride, packet_stride, h->pkg, h->overdrive, h->denoise_bound)
+                       n_packets, stream_stride, packet_stride, h->pkg, h->overdrive, h->denoise_bound, h->life.d_active)
     if (h->ana == 128) {
         if (h->chn == 1)
             NSX_LAUNCH(128, 1);

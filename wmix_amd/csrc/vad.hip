@@ -818,7 +818,7 @@ __device__ __forceinline__ void vad_pipe_channels(const VadRef &S, int16_t *s16,
 // RATIO = 1 (8 kHz) or 2 (16 kHz), one mono 10 ms packet per call, 16-byte aligned rows (what wmx_vad_process checks)
 template <int RATIO>
 __global__ __launch_bounds__(256) void vad_pipe_kernel(int16_t *s16, int32_t *s32, int16_t *pcm, int n_streams, int packets_per_call,
-                                                       int n_calls, long stream_stride, long call_stride) {
+                                                       int n_calls, long stream_stride, long call_stride, const uint8_t *__restrict__ active) {
     constexpr int NB = 80, PKG = NB * RATIO, NV = PKG / 8;
     __shared__ __attribute__((aligned(16))) int16_t lds[64 * (NB / 2 + NB / 2 + NB / 4 + NB / 4)];
     __shared__ int16_t minlds[64 * kVadMinFields];
@@ -827,8 +827,9 @@ __global__ __launch_bounds__(256) void vad_pipe_kernel(int16_t *s16, int32_t *s3
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int stream_raw = (int)blockIdx.x * 64 + lane;
-    const bool live = stream_raw < n_streams;
-    const int stream = live ? stream_raw : n_streams - 1;  // a lane without a stream recomputes the last one and stores nothing
+    // a lane without a stream recomputes the last one, a lane whose stream is switched off its own, and neither stores anything
+    const bool live = stream_active(active, stream_raw, n_streams);
+    const int stream = stream_raw < n_streams ? stream_raw : n_streams - 1;
     int16_t r16[kVadRegFields];
     int32_t r32[V32_WORDS];
     const VadRef S{r16, r32, minlds + lane};
@@ -947,12 +948,12 @@ __global__ __launch_bounds__(256) void vad_pipe_kernel(int16_t *s16, int32_t *s3
 
 template <int NB, int RATIO>
 __global__ __launch_bounds__(64) void vad_kernel(int16_t *s16, int32_t *s32, int16_t *pcm, int n_streams, int packets_per_call,
-                                                 int n_calls, long stream_stride, long call_stride, int chn) {
+                                                 int n_calls, long stream_stride, long call_stride, int chn, const uint8_t *__restrict__ active) {
     __shared__ int16_t lds[64 * (NB / 2 + NB / 2 + NB / 4 + NB / 4)];
     __shared__ int16_t minlds[64 * kVadMinFields];
     const int lane = threadIdx.x;
     const int stream = blockIdx.x * 64 + lane;
-    if (stream >= n_streams) return;  // lanes are independent: no barriers anywhere in this kernel
+    if (!stream_active(active, stream, n_streams)) return;  // lanes are independent: no barriers anywhere in this kernel
     int16_t r16[kVadRegFields];
     int32_t r32[V32_WORDS];
     const VadRef S{r16, r32, minlds + lane};
@@ -1080,6 +1081,14 @@ __global__ void vad_fill_state(int16_t *s16, int32_t *s32, const int16_t *t16, i
     const size_t total32 = (size_t)V32_WORDS * n_streams;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total32; i += (size_t)gridDim.x * blockDim.x) s32[i] = 0;
 }
+// vad_release + vad_init for the listed streams
+__global__ void vad_fill_idx(int16_t *s16, int32_t *s32, const int16_t *t16, int n_streams, const int32_t *idx, int n_idx) {
+    for (int j = blockIdx.x; j < n_idx; j += gridDim.x) {
+        const size_t i = (size_t)idx[j];
+        for (int f = threadIdx.x; f < V16_WORDS; f += blockDim.x) s16[(size_t)f * n_streams + i] = t16[f];
+        for (int f = threadIdx.x; f < V32_WORDS; f += blockDim.x) s32[(size_t)f * n_streams + i] = 0;
+    }
+}
 
 }  // namespace
 }  // namespace wmx
@@ -1089,6 +1098,8 @@ struct wmx_vad {
     int n_streams, chn, freq, interval_ms, pkg;
     int16_t *d_s16;
     int32_t *d_s32;
+    int16_t *d_tmpl;  // the 16-bit fields vad_init gives a stream (the 32-bit ones start at zero)
+    wmx::StreamLife life;
 };
 
 extern "C" {
@@ -1098,8 +1109,31 @@ int wmx_vad_destroy(wmx_vad *h) {
     if (!h) return 0;
     if (h->d_s16) (void)hipFree(h->d_s16);
     if (h->d_s32) (void)hipFree(h->d_s32);
+    if (h->d_tmpl) (void)hipFree(h->d_tmpl);
+    h->life.release();
     delete h;
     return 0;
+}
+
+// vad_release + vad_init for the listed streams (src/webrtc.c:40-82, 153-164): WebRtcVad_InitCore state, reduce = 4
+int wmx_vad_reset_streams(wmx_vad *h, const int32_t *idx, int n, void *stream) {
+    WMX_ON_DEVICE(h);
+    if (!h || n < 0 || (n > 0 && !idx)) return WMX_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = wmx::as_stream(stream);
+    const int32_t *d_idx = nullptr;
+    const int rc = h->life.upload(idx, n, h->n_streams, s, &d_idx);
+    if (rc != 0) return rc;
+    hipLaunchKernelGGL(wmx::vad_fill_idx, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(64), 0, s, h->d_s16, h->d_s32, (const int16_t *)h->d_tmpl,
+                       h->n_streams, d_idx, n);
+    WMX_LAUNCH_CHECK();
+    return h->life.done(s);
+}
+
+int wmx_vad_set_active(wmx_vad *h, const uint8_t *host_mask, void *stream) {
+    WMX_ON_DEVICE(h);
+    if (!h) return WMX_EINVAL;
+    return h->life.set_active(h->n_streams, host_mask, wmx::as_stream(stream));
 }
 
 int wmx_vad_create(wmx_vad **out, int n_streams, int chn, int freq, int interval_ms) {
@@ -1136,24 +1170,20 @@ int wmx_vad_create(wmx_vad **out, int n_streams, int chn, int freq, int interval
     for (int i = 0; i < 96; i++) t[V16_LOW + i] = 10000;
     for (int i = 0; i < 6; i++) t[V16_MEAN_VALUE + i] = 1600;
     t[V16_REDUCE] = 4;
-    int16_t *d_t = nullptr;
     hipError_t e;
 #define VAD_TRY(x)                                         \
     if ((e = (x)) != hipSuccess) {                         \
         int rc = hip_fail(e, #x, __FILE__, __LINE__);      \
         wmx_vad_destroy(h);                                \
-        if (d_t) (void)hipFree(d_t);                       \
         return rc;                                         \
     }
     VAD_TRY(hipMalloc(&h->d_s16, (size_t)V16_WORDS * n_streams * sizeof(int16_t)));
     VAD_TRY(hipMalloc(&h->d_s32, (size_t)V32_WORDS * n_streams * sizeof(int32_t)));
-    VAD_TRY(hipMalloc(&d_t, V16_WORDS * sizeof(int16_t)));
-    VAD_TRY(hipMemcpy(d_t, t.data(), V16_WORDS * sizeof(int16_t), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(vad_fill_state, dim3(512), dim3(256), 0, nullptr, h->d_s16, h->d_s32, d_t, n_streams);
+    VAD_TRY(hipMalloc(&h->d_tmpl, V16_WORDS * sizeof(int16_t)));
+    VAD_TRY(hipMemcpy(h->d_tmpl, t.data(), V16_WORDS * sizeof(int16_t), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(vad_fill_state, dim3(512), dim3(256), 0, nullptr, h->d_s16, h->d_s32, h->d_tmpl, n_streams);
     VAD_TRY(hipGetLastError());
     VAD_TRY(hipDeviceSynchronize());
-    (void)hipFree(d_t);
-    d_t = nullptr;
 #undef VAD_TRY
     *out = h;
     return 0;
@@ -1174,9 +1204,11 @@ int wmx_vad_process(wmx_vad *h, int16_t *d_pcm, int packets_per_call, int n_call
         set_error("wmx_vad_process: null buffer");
         return WMX_EINVAL;
     }
-    const long per_call = (long)packets_per_call * h->pkg * h->chn;
-    if (call_stride < per_call || (h->n_streams > 1 && stream_stride < per_call)) {
-        set_error("wmx_vad_process: strides (%ld, %ld) smaller than a call (%ld samples)", stream_stride, call_stride, per_call);
+    // Only the FIRST packet of a call is ever read or written (the wrapper never advances its pointer),
+    // so that packet is what must not overlap a neighbour -- a call's later packets may lie anywhere (packet-major batches).
+    const long per_pkt = (long)h->pkg * h->chn;
+    if (call_stride < per_pkt || (h->n_streams > 1 && stream_stride < per_pkt)) {
+        set_error("wmx_vad_process: strides (%ld, %ld) smaller than a packet (%ld samples)", stream_stride, call_stride, per_pkt);
         return WMX_EINVAL;
     }
     const dim3 grid((h->n_streams + 63) / 64), block(64);
@@ -1192,16 +1224,16 @@ int wmx_vad_process(wmx_vad *h, int16_t *d_pcm, int packets_per_call, int n_call
     if (pipe) {
         if (h->freq == 8000)
             hipLaunchKernelGGL((vad_pipe_kernel<1>), grid, dim3(256), 0, s, h->d_s16, h->d_s32, d_pcm, h->n_streams, packets_per_call, n_calls,
-                               stream_stride, call_stride);
+                               stream_stride, call_stride, h->life.d_active);
         else
             hipLaunchKernelGGL((vad_pipe_kernel<2>), grid, dim3(256), 0, s, h->d_s16, h->d_s32, d_pcm, h->n_streams, packets_per_call, n_calls,
-                               stream_stride, call_stride);
+                               stream_stride, call_stride, h->life.d_active);
         WMX_LAUNCH_CHECK();
         return 0;
     }
 #define VAD_LAUNCH(NB, R)                                                                                                 \
     hipLaunchKernelGGL((vad_kernel<NB, R>), grid, block, 0, s, h->d_s16, h->d_s32, d_pcm, h->n_streams, packets_per_call, \
-                       n_calls, stream_stride, call_stride, h->chn)
+                       n_calls, stream_stride, call_stride, h->chn, h->life.d_active)
     if (nb == 80 && ratio == 1)
         VAD_LAUNCH(80, 1);
     else if (nb == 80 && ratio == 2)

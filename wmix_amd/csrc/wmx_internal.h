@@ -105,6 +105,75 @@ struct SchedCache {
     }
 };
 
+// Per-stream lifetime inside a batch.  The reference creates every handle lazily, releases it when its flag drops or recording
+// idles and creates a new one later (src/wmix.c:565-600, 617-618, 635-636, 683-684, 702-703, 783-813): streams of a batch join,
+// leave and restart on their own.  Two device-side facilities serve that without a new batch:
+//   * an ACTIVE mask [n_streams] (1 = the stream is processed; 0 = its state, and its PCM rows, are left alone, like a handle
+//     nobody calls); nullptr = every stream is active;
+//   * RESET of a list of streams to the state *_init gives (release + init), by a refill kernel of the module.
+// The index list of a reset is staged in a device buffer that is rewritten only after the kernel that read it last has
+// finished (an event, like the AEC plan slots).
+struct StreamLife {
+    uint8_t *d_active = nullptr;
+    int32_t *d_idx = nullptr;
+    size_t idx_cap = 0;
+    hipEvent_t idx_free = nullptr;
+    bool idx_used = false;
+    StreamLife() = default;
+    StreamLife(const StreamLife &) = delete;
+    StreamLife &operator=(const StreamLife &) = delete;
+    // host_mask: n_streams bytes, or nullptr for "all active" (the mask is dropped)
+    int set_active(int n_streams, const uint8_t *host_mask, hipStream_t s) {
+        if (!host_mask) {
+            if (d_active) {
+                WMX_HIP_RC(hipStreamSynchronize(s));  // kernels in flight still read it
+                (void)hipFree(d_active);
+                d_active = nullptr;
+            }
+            return 0;
+        }
+        if (!d_active) WMX_HIP_RC(hipMalloc(reinterpret_cast<void **>(&d_active), (size_t)n_streams));
+        WMX_HIP_RC(hipMemcpyAsync(d_active, host_mask, (size_t)n_streams, hipMemcpyHostToDevice, s));
+        return 0;
+    }
+    // validates and uploads a reset list; *d_out = device copy, valid for kernels launched on `s` before done(s)
+    int upload(const int32_t *idx, int n, int n_streams, hipStream_t s, const int32_t **d_out) {
+        for (int i = 0; i < n; i++)
+            if (idx[i] < 0 || idx[i] >= n_streams) {
+                set_error("reset_streams: index %d of the list is stream %d of %d", i, idx[i], n_streams);
+                return WMX_EINVAL;
+            }
+        if (idx_used) WMX_HIP_RC(hipEventSynchronize(idx_free));
+        if ((size_t)n > idx_cap) {
+            if (d_idx) (void)hipFree(d_idx);
+            d_idx = nullptr;
+            idx_cap = 0;
+            const size_t cap = (size_t)n < 256 ? 256 : (size_t)n;
+            WMX_HIP_RC(hipMalloc(reinterpret_cast<void **>(&d_idx), cap * sizeof(int32_t)));
+            idx_cap = cap;
+        }
+        if (!idx_free) WMX_HIP_RC(hipEventCreateWithFlags(&idx_free, hipEventDisableTiming));
+        WMX_HIP_RC(hipMemcpyAsync(d_idx, idx, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        *d_out = d_idx;
+        return 0;
+    }
+    int done(hipStream_t s) {
+        WMX_HIP_RC(hipEventRecord(idx_free, s));
+        idx_used = true;
+        return 0;
+    }
+    void release() {
+        if (d_active) (void)hipFree(d_active);
+        if (d_idx) (void)hipFree(d_idx);
+        if (idx_free) (void)hipEventDestroy(idx_free);
+        d_active = nullptr;
+        d_idx = nullptr;
+        idx_free = nullptr;
+        idx_cap = 0;
+        idx_used = false;
+    }
+};
+
 // wmix_pcm_zoom's cursor walk (src/wmix.c:139-222) as a gather list: out int16 i <- in int16 idx[i]; identical formats
 // give the identity (the reference's memcpy branch).  Defined in mix.hip.
 void zoom_gather_list(int inChn, int inFreq, uint32_t inLen, int outChn, int outFreq, std::vector<int32_t> &idx);
@@ -119,6 +188,19 @@ void zoom_gather_list(int inChn, int inFreq, uint32_t inLen, int outChn, int out
 // touch_done() at the end of the kernel.
 __device__ __forceinline__ void touch_line(const void *p, int &sink) {
     asm volatile("global_load_ubyte %0, %1, off" : "+v"(sink) : "v"(p) : "memory");
+}
+// refill of block-layout state ([stream][words]) for a list of streams: one workgroup per listed stream
+template <class T>
+__global__ void fill_rows_idx(T *state, const T *tmpl, int words, const int32_t *idx, int n_idx) {
+    for (int j = blockIdx.x; j < n_idx; j += gridDim.x) {
+        T *dst = state + (size_t)idx[j] * words;
+        for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = tmpl ? tmpl[i] : T(0);
+    }
+}
+// a stream takes part in a launch when it exists and the batch's active mask (if any) has it switched on; wave-uniform
+// callers get a scalar byte load
+__device__ __forceinline__ bool stream_active(const uint8_t *active, int sidx, int n_streams) {
+    return sidx < n_streams && (!active || active[sidx] != 0);
 }
 __device__ __forceinline__ void touch_done(int &sink) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory"); }
 #endif

@@ -1,0 +1,40 @@
+"""Per-stream lifetime inside a batch (include/wmix_amd.h): what the daemon does per handle -- create lazily, release when
+the switch drops or recording idles, create again later (src/wmix.c:565-600, 617-618) -- for the streams of a batch."""
+import numpy as np
+import torch
+
+from ._lib import check, lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Lifetime:
+    """Mixed into the batch classes; `_mod` names the C module (ns, nsx, agc, vad, aec, aecm, chain)."""
+    _mod = None
+
+    def reset_streams(self, idx, cohort=None):
+        """<m>_release + <m>_init for the listed streams, ordered on the current HIP stream.  AEC / AECM / chain: `cohort`
+        makes them members of that control cohort (None: membership unchanged)."""
+        a = np.ascontiguousarray(idx, dtype=np.int32)
+        f = getattr(lib(), "wmx_%s_reset_streams" % self._mod)
+        if self._mod in ("aec", "aecm", "chain"):
+            rc = f(self._h, a.ctypes.data, a.size, -1 if cohort is None else int(cohort), _stream())
+        else:
+            assert cohort is None
+            rc = f(self._h, a.ctypes.data, a.size, _stream())
+        check(rc, "wmx_%s_reset_streams" % self._mod)
+
+    def reset_cohort(self, cohort):
+        check(getattr(lib(), "wmx_%s_reset_cohort" % self._mod)(self._h, int(cohort), _stream()), "reset_cohort")
+
+    def set_active(self, mask):
+        """mask: n_streams booleans (False = the stream is not called: state and PCM rows untouched) or None = all."""
+        if mask is None:
+            rc = getattr(lib(), "wmx_%s_set_active" % self._mod)(self._h, None, _stream())
+        else:
+            m = np.ascontiguousarray(mask, dtype=np.uint8)
+            assert m.shape == (self.n_streams,)
+            rc = getattr(lib(), "wmx_%s_set_active" % self._mod)(self._h, m.ctypes.data, _stream())
+        check(rc, "wmx_%s_set_active" % self._mod)

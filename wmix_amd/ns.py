@@ -9,10 +9,13 @@ import ctypes as C
 import numpy as np
 import torch
 
+from .lifetime import Lifetime
 from ._lib import check, lib
 
 
-class NsBatch:
+class NsBatch(Lifetime):
+    _mod = "ns"
+
     def __init__(self, n_streams, chn, freq, ordered=True):
         self._h = C.c_void_p()
         L = lib()

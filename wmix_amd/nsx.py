@@ -4,10 +4,13 @@ import ctypes as C
 
 import torch
 
+from .lifetime import Lifetime
 from ._lib import check, lib
 
 
-class NsxBatch:
+class NsxBatch(Lifetime):
+    _mod = "nsx"
+
     def __init__(self, n_streams, chn, freq):
         self._h = C.c_void_p()
         L = lib()

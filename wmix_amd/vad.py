@@ -4,10 +4,13 @@ import ctypes as C
 
 import torch
 
+from .lifetime import Lifetime
 from ._lib import check, lib
 
 
-class VadBatch:
+class VadBatch(Lifetime):
+    _mod = "vad"
+
     def __init__(self, n_streams, chn, freq, interval_ms=10):
         self._h = C.c_void_p()
         rc = lib().wmx_vad_create(C.byref(self._h), n_streams, chn, freq, interval_ms)
