@@ -61,11 +61,16 @@ def _fn(lib, name, restype, argtypes):
 
 
 def port():
-    """Our C restatement (built on demand: plain gcc, a few seconds)."""
+    """Our C restatement (built on demand: plain gcc, a few seconds).  WMIX_ORACLE_SAN=1: the AddressSanitizer +
+    UndefinedBehaviorSanitizer build of the same sources (oracle/Makefile `san`; needs the ASan runtime preloaded)."""
     global _port
     if _port is None:
-        build_port()
-        _port = C.CDLL(PORT_SO)
+        if os.environ.get("WMIX_ORACLE_SAN") == "1":
+            subprocess.check_call(["make", "-s", "-C", HERE, "san"])
+            _port = C.CDLL(os.path.join(HERE, "build", "liboracle_san.so"))
+        else:
+            build_port()
+            _port = C.CDLL(PORT_SO)
     return _port
 
 
