@@ -47,7 +47,7 @@ static void downsample_by2(const int16_t *in, int len, int16_t *out, int32_t *st
 {
     static const uint16_t ap1[3] = {3284, 24441, 49528}, ap2[3] = {12199, 37471, 60255};
     for (int i = len >> 1; i > 0; i--) {
-        int32_t in32 = (int32_t)(*in++) << 10, diff, t1, t2;
+        int32_t in32 = wshl((int32_t)(*in++), 10), diff, t1, t2;
         diff = wsub(in32, st[1]);
         t1 = spl_scalediff32(ap2[0], diff, st[0]);
         st[0] = in32;
@@ -57,7 +57,7 @@ static void downsample_by2(const int16_t *in, int len, int16_t *out, int32_t *st
         diff = wsub(t2, st[3]);
         st[3] = spl_scalediff32(ap2[2], diff, st[2]);
         st[2] = t2;
-        in32 = (int32_t)(*in++) << 10;
+        in32 = wshl((int32_t)(*in++), 10);
         diff = wsub(in32, st[5]);
         t1 = spl_scalediff32(ap1[0], diff, st[4]);
         st[4] = in32;
@@ -160,7 +160,7 @@ static int16_t vad_process(orc_agc_vad *v, const int16_t *in, int n)
     v->hp_state = hp;
     /* the hand-written count-leading-zeros of digital_agc.c:685-708 (nrg == 0 gives 31) */
     int16_t zeros = nrg == 0 ? 31 : (int16_t)__builtin_clz((uint32_t)nrg);
-    int16_t dB = (int16_t)((15 - zeros) << 11);
+    int16_t dB = (int16_t)((15 - zeros) * 2048);
     if (v->counter < 250) v->counter++;
     t32 = v->mean_short * 15 + dB;
     v->mean_short = (int16_t)(t32 >> 4);
@@ -222,6 +222,7 @@ int orc_agc_gain_table(int32_t *table, int16_t comp_gain_db, int16_t target_dbfs
         inLevel = ((int32_t)diffGain << 14) - inLevel;
         uint32_t absIn = (uint32_t)(inLevel >= 0 ? inLevel : -inLevel);
         uint16_t intPart = (uint16_t)(absIn >> 14), fracPart = (uint16_t)(absIn & 0x3FFF);
+        if (intPart + 1 >= 128) return -1; /* the reference reads past kGenFuncTable for gains 187..190 dB: refused */
         uint16_t tU16 = (uint16_t)(gen[intPart + 1] - gen[intPart]);
         uint32_t u1 = (uint32_t)tU16 * fracPart, u2;
         u1 += (uint32_t)gen[intPart] << 14;
@@ -253,14 +254,14 @@ int orc_agc_gain_table(int32_t *table, int16_t comp_gain_db, int16_t target_dbfs
             zeros = orc_norm_w32(den) + 8;
         numFIX = wshl(numFIX, zeros);
         int32_t d = shift_w32(den, zeros - 8);
-        if (numFIX < 0)
-            numFIX -= d / 2;
+        if (numFIX < 0) /* the reference lets this wrap (digital_agc.c:196-200) */
+            numFIX = wsub(numFIX, d / 2);
         else
-            numFIX += d / 2;
+            numFIX = wadd(numFIX, d / 2);
         int32_t y32 = numFIX / d;
         if (limiter && (i < limiterIdx)) {
             t32 = (int32_t)(int16_t)(i - 1) * kLog10_2;
-            t32 -= limiterLvl << 14;
+            t32 -= limiterLvl * 16384;
             y32 = orc_div_w32_w16(t32 + 10, 20);
         }
         if (y32 > 39000) {

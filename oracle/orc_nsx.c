@@ -284,7 +284,7 @@ static void noise_estimation(orc_nsx_core *s, const uint16_t *magn, uint32_t *no
 static void parametric_noise(const orc_nsx_core *s, int16_t exp_avg, int32_t num_avg, int bin, uint32_t *est, uint32_t *est_avg)
 {
     int32_t t = num_avg - ((exp_avg * fx_nsx_log_index[bin]) >> 15);
-    t += (s->min_norm - s->stages) << 11;
+    t += (s->min_norm - s->stages) * 2048;
     if (t > 0) {
         const int16_t ip = (int16_t)(t >> 11), fp = (int16_t)(t & 0x7ff);
         int32_t b = (fp >> 10) ? 2048 - (((2048 - fp) * 1244) >> 10) : (fp * 804) >> 10;
@@ -346,7 +346,8 @@ static void spectral_difference(orc_nsx_core *s, const uint16_t *magn)
         const int32_t r = dp >> n_shifts;
         var_pause += (uint32_t)wmul(r, r);
     }
-    s->cur_avg_energy += s->magn_energy >> (2 * s->norm_data + s->stages - 1);
+    /* the count reaches 35 for near-silent input: undefined in C; the reference's x86 shift takes it modulo 32 */
+    s->cur_avg_energy += s->magn_energy >> ((2 * s->norm_data + s->stages - 1) & 31);
     uint32_t diff = var_magn;
     if (var_pause && cov) {
         uint32_t c = (uint32_t)(cov >= 0 ? cov : -cov);
@@ -354,7 +355,7 @@ static void spectral_difference(orc_nsx_core *s, const uint16_t *magn)
         c = norm > 0 ? c << norm : c >> -norm;
         const uint32_t c2 = c * c;
         n_shifts += norm;
-        n_shifts <<= 1;
+        n_shifts *= 2;
         if (n_shifts < 0) {
             var_pause >>= -n_shifts;
             n_shifts = 0;
@@ -786,7 +787,7 @@ void orc_nsx_core_process(orc_nsx_core *s, const int16_t *const *in, int num_ban
         q_noise = (int16_t)qd;
     }
     if (s->block_index < 200) {
-        s->time_avg_energy_tmp += s->magn_energy >> (2 * s->norm_data + s->stages - 1);
+        s->time_avg_energy_tmp += s->magn_energy >> ((2 * s->norm_data + s->stages - 1) & 31); /* as above */
         s->time_avg_energy = div_u32_u16(s->time_avg_energy_tmp, (uint16_t)(s->block_index + 1));
     }
 
@@ -808,7 +809,7 @@ void orc_nsx_core_process(orc_nsx_core *s, const int16_t *const *in, int num_ban
         }
         const uint32_t near_est = (uint32_t)(s->prev_magn[i] * s->filt[i]);
         uint32_t a = near_est << 3;
-        const uint32_t b = s->prev_noise[i] >> n_shifts;
+        const uint32_t b = s->prev_noise[i] >> (n_shifts & 31); /* negative counts happen; x86 takes them modulo 32 */
         if (b > 0) {
             a /= b;
             a = sat_max < a ? sat_max : a;

@@ -80,7 +80,7 @@ static void allpass(const int16_t *in, int n, int16_t coef, int16_t *state, int1
         int32_t t32 = wrap_add(s32, coef * in[0]);
         int16_t t16 = (int16_t)(t32 >> 16);
         *out++ = t16;
-        s32 = (int32_t)in[0] << 14;
+        s32 = wrap_shl((int32_t)in[0], 14);
         s32 = wrap_sub(s32, coef * t16);
         s32 = wrap_shl(s32, 1);
         in += 2;
@@ -180,7 +180,7 @@ int32_t orc_vad_gauss(int16_t input, int16_t mean, int16_t std, int16_t *delta)
     int16_t inv_std = (int16_t)orc_div_w32_w16(t32, std);
     int16_t t16 = (int16_t)(inv_std >> 2);
     int16_t inv_std2 = (int16_t)((t16 * t16) >> 2);
-    t16 = (int16_t)(input << 3);
+    t16 = (int16_t)(input * 8);
     t16 = (int16_t)(t16 - mean);
     *delta = (int16_t)((inv_std2 * t16) >> 10);
     t32 = (*delta * t16) >> 9;
@@ -284,7 +284,7 @@ static int16_t gmm(orc_vad_core *s, int16_t *feat, int16_t total_power, int fram
             if (h1t == 0) sh1 = 31;
             int16_t llr = (int16_t)(sh0 - sh1);
             sum_llr += (int32_t)(llr * kSpecW[c]);
-            if ((llr << 2) > loc[idx]) vadflag = 1;
+            if ((llr * 4) > loc[idx]) vadflag = 1;
             int16_t h0 = (int16_t)(h0t >> 12);
             if (h0 > 0) {
                 int32_t t = wrap_shl((int32_t)(np[0] & 0xFFFFF000), 2);
@@ -351,7 +351,7 @@ static int16_t gmm(orc_vad_core *s, int16_t *feat, int16_t total_power, int fram
                     int32_t a = (dN[g] * t16) >> 3;
                     a -= 4096;
                     t16 = (int16_t)((ngpr[g] + 2) >> 2);
-                    int32_t b = t16 * a;
+                    int32_t b = (int32_t)((uint32_t)(int32_t)t16 * (uint32_t)a); /* wraps in the reference (vad_core.c:395) */
                     a = b >> 14;
                     if (a > 0) {
                         t16 = (int16_t)orc_div_w32_w16(a, nsk);

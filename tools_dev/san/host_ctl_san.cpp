@@ -1,0 +1,146 @@
+// host_ctl_san.cpp -- everything of libwmix_amd.so that decides on the HOST where data goes, compiled without HIP under
+// AddressSanitizer + UndefinedBehaviorSanitizer (-fno-sanitize-recover: a finding aborts) and driven over its argument
+// ranges, with the invariants the kernels rely on asserted on every plan:
+//   aec_ctl.h        AecCtl:  start-up machine, delay filter, ring indices, block counters (echo_cancellation.c:599-872)
+//   aecm_ctl.h       AecmCtl: the same for the AECM (echo_control_mobile.c:233-720, aecm_core.c:569-664)
+//   agc_gain_table.h the gain-table recipe (digital_agc.c:61-257) for every compression gain, limiter on and off
+//   mix_sched.h      zoom / load schedules and the len_of_* walks for every rate and channel pair the daemon can meet
+// VERDICT r02 item 6 / SURVEY section 5.  Run by tools_dev/sanitize_cpu.sh and tests/test_sanitizers.py.
+#include <cstdio>
+#include <cstdlib>
+#include "aec_ctl.h"
+#include "aecm_ctl.h"
+#include "agc_gain_table.h"
+#include "mix_sched.h"
+
+#define CHECK(c)                                                              \
+    do {                                                                      \
+        if (!(c)) {                                                           \
+            std::fprintf(stderr, "%s:%d: CHECK failed: %s\n", __FILE__, __LINE__, #c); \
+            std::abort();                                                     \
+        }                                                                     \
+    } while (0)
+
+using namespace wmx;
+
+static uint32_t rng_state = 12345;
+static uint32_t rnd() { return rng_state = rng_state * 1664525u + 1013904223u; }
+
+static long drive_aec(int freq, int pkg, int mode_delay) {
+    AecCtl c;
+    c.init(freq);
+    long blocks = 0;
+    for (int p = 0; p < 6000; p++) {
+        AecPlan pl;
+        std::memset(&pl, 0, sizeof(pl));
+        // delays: constant 0 (the daemon), constant 120, a random walk, and now and then one the reference rejects
+        int d = mode_delay == 0 ? 0 : (mode_delay == 1 ? 120 : (int)(rnd() % 400));
+        if (mode_delay == 3 && p % 97 == 13) d = (p & 1) ? 900 : -5;
+        if (mode_delay == 3 && (rnd() % 7) == 0) continue;  // a far-end packet that never comes / a call that is skipped
+        CHECK(c.buffer_farend(pkg, &pl) == 0);
+        CHECK(pl.n_part >= 0 && pl.n_part <= 4 && pl.pre_wr >= 0 && pl.pre_wr < kAecPreLen && pl.far_n == pkg);
+        for (int q = 0; q < pl.n_part; q++)
+            CHECK(pl.part[q].pre_rd >= 0 && pl.part[q].pre_rd < kAecPreLen && pl.part[q].far_slot >= 0 && pl.part[q].far_slot < kAecFarBlocks);
+        const int r = c.process(pkg, d, &pl);
+        CHECK(r == 0 || r == -1);
+        CHECK((d < 0 || d > 500) == (r == -1));
+        if (pl.passthrough) continue;
+        CHECK(pl.n_sub == pkg / kAecFrame && pl.n_blk >= 0 && pl.n_blk <= 4);
+        int nb = 0;
+        for (int s = 0; s < pl.n_sub; s++) {
+            const AecSubPlan &sp = pl.sub[s];
+            CHECK(sp.near_wr >= 0 && sp.near_wr < kAecRing && sp.out_rd >= 0 && sp.out_rd < kAecRing && sp.first_blk == nb);
+            nb += sp.n_blocks;
+        }
+        CHECK(nb == pl.n_blk);
+        for (int k = 0; k < pl.n_blk; k++) {
+            const AecBlkPlan &b = pl.blk[k];
+            CHECK(b.near_rd >= 0 && b.near_rd < kAecRing && b.out_wr >= 0 && b.out_wr < kAecRing);
+            CHECK(b.far_slot >= 0 && b.far_slot < kAecFarBlocks && b.hist_n == blocks + k);
+            for (int i = 0; i < 64; i++) CHECK(b.ucos[i] >= -1.f && b.ucos[i] <= 1.f && b.usin[i] >= -1.f && b.usin[i] <= 1.f);
+        }
+        blocks += pl.n_blk;
+    }
+    return blocks;
+}
+
+static long drive_aecm(int freq, int pkg, int mode_delay) {
+    AecmCtl c;
+    c.init(freq);
+    long blocks = 0;
+    for (int p = 0; p < 6000; p++) {
+        AecmPlan pl;
+        std::memset(&pl, 0, sizeof(pl));
+        int d = mode_delay == 0 ? 0 : (mode_delay == 1 ? 120 : (int)(rnd() % 400));
+        if (mode_delay == 3 && p % 97 == 13) d = (p & 1) ? 900 : -5;
+        if (mode_delay == 3 && (rnd() % 7) == 0) continue;
+        CHECK(c.buffer_farend(pkg, &pl) == 0);
+        CHECK(pl.far_w >= 0 && pl.far_w < kAecmFarRing && pl.far_n >= 0 && pl.far_n <= pkg);
+        const int r = c.process(pkg, d, &pl);
+        CHECK((d < 0 || d > 500) == (r == -1));
+        if (pl.passthrough) continue;
+        CHECK(pl.n_frames == pkg / kAecmFrame);
+        for (int f = 0; f < pl.n_frames; f++) {
+            const AecmFramePlan &fp = pl.fr[f];
+            CHECK(fp.far_src >= -1 && fp.far_src < kAecmFarRing && (fp.old_slot == 0 || fp.old_slot == 1));
+            CHECK(fp.ring_w >= 0 && fp.ring_w < kAecmFrameRing && fp.out_r >= 0 && fp.out_r < kAecmFrameRing && fp.n_blocks >= 0 && fp.n_blocks <= 2);
+            for (int b = 0; b < fp.n_blocks; b++) {
+                CHECK(fp.blk_r[b] >= 0 && fp.blk_r[b] < kAecmFrameRing && fp.blk_out_w[b] >= 0 && fp.blk_out_w[b] < kAecmFrameRing);
+                CHECK(fp.blk_t[b] == blocks++);
+            }
+        }
+    }
+    return blocks;
+}
+
+int main() {
+    long total = 0;
+    for (int freq : {8000, 16000})
+        for (int ms : {10, 20}) {
+            if (freq == 16000 && ms == 20) continue;  // 20 ms packets exist at 8 kHz only (src/webrtc.c:239-248)
+            for (int md = 0; md < 4; md++) total += drive_aec(freq, freq / 1000 * ms, md) + drive_aecm(freq, freq / 1000 * ms, md);
+        }
+    CHECK(total > 100000);
+    // ---- AGC gain table: every compression gain an uint8 agc_addition() can pass, limiter off (wmix) and on
+    int ok = 0;
+    for (int comp = 0; comp < 256; comp++)
+        for (int lim = 0; lim < 2; lim++) {
+            int32_t t[32];
+            const int16_t c16 = (int16_t)comp;
+            if (host_gain_table(t, c16, 0, lim != 0, analog_target_for(c16)) == 0) {
+                ok++;
+                for (int i = 1; i < 32; i++) CHECK(t[i] >= 0);
+            }
+        }
+    CHECK(ok > 100);
+    // ---- mixer schedules: every format pair of the daemon's rates x {1, 2} channels, ragged lengths
+    const int rates[] = {8000, 11025, 16000, 22050, 32000, 44100, 48000};
+    size_t entries = 0;
+    for (int fi : rates)
+        for (int fo : rates)
+            for (int ci = 1; ci <= 2; ci++)
+                for (int co = 1; co <= 2; co++)
+                    for (uint32_t len : {0u, 2u, 6u, 320u, 1282u, 3528u, 7680u}) {
+                        std::vector<int32_t> idx;
+                        zoom_schedule((uint8_t)ci, (uint16_t)fi, len, (uint8_t)co, (uint16_t)fo, idx);
+                        for (int32_t v : idx) CHECK(v >= 0 && (uint32_t)v * 2u < len + 2u * (uint32_t)ci);
+                        const uint32_t lo = len_walk((uint8_t)ci, (uint16_t)fi, (uint8_t)co, (uint16_t)fo, len / 2, true, false);
+                        const uint32_t li = len_walk((uint8_t)ci, (uint16_t)fi, (uint8_t)co, (uint16_t)fo, len / 2, false, true);
+                        (void)lo;
+                        (void)li;
+                        std::vector<LoadEntry> sch;
+                        if (load_schedule(co, fo, len, (uint16_t)fi, (uint8_t)ci, 16, sch))
+                            for (const LoadEntry &e : sch) {
+                                CHECK(e.src >= 0 && (uint32_t)e.src * 2u <= len + 4u * (uint32_t)ci);
+                                CHECK(e.k >= -1 && e.k < 64 && e.n2 >= 0 && e.n2 <= 64);
+                            }
+                        entries += idx.size() + sch.size();
+                        sch.clear();
+                        load_schedule(co, fo, len, (uint16_t)fi, (uint8_t)ci, 8, sch);  // the reference's empty 8-bit branch
+                        CHECK(sch.empty() || (fi == fo && ci == co));
+                    }
+    CHECK(entries > 100000);
+    std::printf("host control planes: %ld AEC/AECM blocks planned, %d gain tables, %zu schedule entries -- clean under ASan + UBSan\n", total,
+                ok, entries);
+    return 0;
+}

@@ -524,7 +524,7 @@ __device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsSca
             q_noise = (int16_t)qd;
         }
         if (block_index < 200) {
-            sc[X_TIME_AVG_E_TMP] = (int32_t)((uint32_t)sc[X_TIME_AVG_E_TMP] + (magn_energy >> (2 * norm_data + STAGES - 1)));
+            sc[X_TIME_AVG_E_TMP] = (int32_t)((uint32_t)sc[X_TIME_AVG_E_TMP] + (magn_energy >> ((2 * norm_data + STAGES - 1) & 31)));
             sc[X_TIME_AVG_E] = (int32_t)div_u32_u16((uint32_t)sc[X_TIME_AVG_E_TMP], (uint16_t)(block_index + 1));
         }
 
@@ -546,7 +546,7 @@ __device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsSca
                     }
                 }
                 uint32_t a = (uint32_t)(pmagn[b] * filt[b]) << 3;
-                const uint32_t c = pnoise[b] >> n_shifts;
+                const uint32_t c = pnoise[b] >> (n_shifts & 31);  // the count can be negative or > 31: the reference's x86 shift takes it modulo 32, and so does v_lshrrev
                 if (c > 0) {
                     a /= c;
                     a = sat_max < a ? sat_max : a;
@@ -589,7 +589,7 @@ __device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsSca
             const uint32_t var_magn = wave_sum(v_m);
             uint32_t var_pause = wave_sum(v_p);
             const int32_t cov = (int32_t)wave_sum(cv);
-            sc[X_CUR_AVG_E] = (int32_t)((uint32_t)sc[X_CUR_AVG_E] + (magn_energy >> (2 * norm_data + STAGES - 1)));
+            sc[X_CUR_AVG_E] = (int32_t)((uint32_t)sc[X_CUR_AVG_E] + (magn_energy >> ((2 * norm_data + STAGES - 1) & 31)));
             uint32_t diff = var_magn;
             if (var_pause && cov) {
                 uint32_t c = (uint32_t)(cov >= 0 ? cov : -cov);

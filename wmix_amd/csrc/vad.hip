@@ -353,7 +353,7 @@ __device__ int16_t gmm_probability(const VadRef &S, const int16_t *feat, int16_t
                     int32_t a = (dN[g] * t16) >> 3;
                     a -= 4096;
                     t16 = (int16_t)((ngpr[g] + 2) >> 2);
-                    const int32_t b = t16 * a;
+                    const int32_t b = wmul(t16, a);  // wraps in the reference (vad_core.c:395)
                     a = b >> 14;
                     if (a > 0) {
                         t16 = (int16_t)div_w32_w16(a, nsk);
@@ -646,7 +646,7 @@ __device__ __forceinline__ void gmm_update_channel(const VadRef &S, int16_t feat
             int32_t a = (R.dN[k] * t16) >> 3;
             a -= 4096;
             t16 = (int16_t)((R.ngpr[k] + 2) >> 2);
-            const int32_t b = t16 * a;
+            const int32_t b = wmul(t16, a);  // wraps in the reference (vad_core.c:395)
             a = b >> 14;
             if (a > 0) {
                 t16 = (int16_t)div_w32_w16(a, nsk);
