@@ -11,7 +11,6 @@
 
 #include <stdbool.h>
 #include <stdint.h>
-#include <sys/types.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -74,7 +73,8 @@ typedef struct {
     uint32_t thread_sys, thread_record, thread_play;
     bool playRun, recordRun;
     int shmemRun;
-    key_t msg_key;
+    int msg_key; /* key_t in the reference (src/wmixConf.h:196): int on every Linux ABI; spelled int so that the header stands on
+                  * its own under strict -std=c99, where <sys/types.h> hides key_t */
     int msg_fd;
     uint8_t reduceMode;
 } WMix_Struct_Head;

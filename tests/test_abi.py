@@ -27,3 +27,14 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu(wmx):
     # reference null check: -1 only when in, out and len are all null/0 (src/g711codec.c:230)
     assert wmx.PCM2G711a(None, None, 0, 0) == -1
     assert wmx.G711u2PCM(None, None, 0, 0) == -1
+
+
+def test_headers_stand_alone_under_strict_c99(tmp_path):
+    """include/*.h must compile on their own with -std=c99 -pedantic (no _DEFAULT_SOURCE needed)."""
+    import os
+    import subprocess
+    for h in ("wmix_compat.h", "wmix_amd.h"):
+        src = tmp_path / ("t_" + h.replace(".h", ".c"))
+        src.write_text('#include "%s"\nint main(void) { return 0; }\n' % h)
+        subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I" + _lib.INCLUDE_DIR, "-c", str(src), "-o",
+                               str(tmp_path / "t.o")])

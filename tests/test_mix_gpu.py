@@ -224,3 +224,54 @@ def test_load_rejects_more_than_one_ring(cuda):
     with pytest.raises(WmxError):
         mb.load(d, 17000, 8000, 1)
     mb.close()
+
+
+def test_variable_chunk_sizes_walk_through_the_schedule_cache(cuda, wmx, oracle_port):
+    """Round-2 ADVICE: callers with variable chunk sizes (file tails, RTP) used to hit a device-wide synchronisation and a
+    mass eviction every 64 formats.  150 different lengths through wmx_pcm_zoom, twice (the second pass meets evicted
+    entries again), every result equal to the oracle's wmix_pcm_zoom."""
+    import torch
+    o = _bind(oracle_port)
+    rng = np.random.default_rng(77)
+    x = rng.integers(-30000, 30000, 2 * 4096, dtype=np.int16)
+    d = torch.from_numpy(x).to(cuda)
+    out = torch.zeros(8192, dtype=torch.int16, device=cuda)
+    for rep in range(2):
+        for k in range(150):
+            in_len = 2 * (2 * (100 + 7 * k))  # bytes of 2-channel 32 kHz input
+            need = C.c_uint32(0)
+            out.fill_(123)
+            rc = wmx.wmx_pcm_zoom(2, 32000, d.data_ptr(), in_len, 1, 8000, out.data_ptr(), 16384, 0, 0, 1, C.byref(need), None)
+            assert rc == 0
+            want = orc_zoom(o, 2, 32000, x[: in_len // 2], 1, 8000)
+            got = out[: need.value // 2].cpu().numpy()
+            assert need.value == want.size * 2 and np.array_equal(got, want), (rep, k)
+
+
+def test_legacy_adapters_on_short_lived_task_threads(wmx):
+    """The daemon starts a thread per play / record task (src/wmixTask.c) and those threads call wmix_pcm_zoom /
+    wmix_load_data; their staging buffers and device ring are thread-local and must go back when the thread ends
+    (round-2 ADVICE: they were leaked).  200 threads, each converting once: free device memory afterwards is what it was."""
+    import threading
+    import torch
+    x = (np.arange(640) * 37 % 2000 - 1000).astype(np.int16)
+
+    def task(res, i):
+        out = np.zeros(640, np.int16)
+        n = wmx.wmix_pcm_zoom(2, 32000, x.ctypes.data_as(C.c_void_p), 1280, 1, 8000, out.ctypes.data_as(C.c_void_p))
+        res[i] = (n, out[:80].copy())
+
+    res = {}
+    t = threading.Thread(target=task, args=(res, -1))
+    t.start()
+    t.join()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for i in range(200):
+        t = threading.Thread(target=task, args=(res, i))
+        t.start()
+        t.join()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert all(res[i][0] == 160 and np.array_equal(res[i][1], res[-1][1]) for i in range(200))
+    assert free0 - free1 < 8 << 20, "device memory shrank by %d bytes over 200 task threads" % (free0 - free1)

@@ -87,13 +87,25 @@ __global__ __launch_bounds__(256) void drain_kernel(int16_t *__restrict__ rings,
     }
 }
 
+// A growable device buffer owned by its (usually thread_local) object: freed when the owner dies -- a finished task
+// thread of the daemon gives its staging buffers back -- except while the process is exiting (runtime_exiting()).
 struct DevVec {
     void *p = nullptr;
     size_t cap = 0;
-    bool leak = false;  // thread_local instances skip hipFree at thread / process end (the runtime may be gone)
+    int device = -1;
     DevVec() = default;
-    explicit DevVec(bool leak_at_exit) : leak(leak_at_exit) {}
+    DevVec(const DevVec &) = delete;
+    DevVec &operator=(const DevVec &) = delete;
     int ensure(size_t bytes) {
+        int dev = -1;
+        WMX_HIP(hipGetDevice(&dev));
+        if (dev != device && p) {  // the thread moved to another device: the old buffer is of no use there
+            DeviceScope on(device);
+            (void)hipFree(p);
+            p = nullptr;
+            cap = 0;
+        }
+        device = dev;
         if (bytes <= cap) return 0;
         if (p) (void)hipFree(p);
         p = nullptr;
@@ -103,7 +115,10 @@ struct DevVec {
         return 0;
     }
     ~DevVec() {
-        if (p && !leak) (void)hipFree(p);
+        if (p && !runtime_exiting()) {
+            DeviceScope on(device);
+            (void)hipFree(p);
+        }
     }
 };
 
@@ -167,10 +182,10 @@ int wmx_pcm_zoom(int inChn, int inFreq, const int16_t *d_in, uint32_t inLen, int
     }
     // the gather list depends on the format only: built and uploaded once per format and thread
     static thread_local std::vector<int32_t> idx;
-    static thread_local SchedCache cache(true);
+    static thread_local SchedCache cache;
     const uint64_t k0 = ((uint64_t)inChn << 56) | ((uint64_t)outChn << 48) | ((uint64_t)(uint32_t)inFreq << 24) | (uint32_t)outFreq;
     const uint64_t k1 = ((uint64_t)(uint32_t)current_device() << 32) | inLen;
-    const SchedCache::Entry *ent = cache.find(k0, k1);
+    SchedCache::Entry *ent = cache.find(k0, k1);
     if (!ent) {
         zoom_schedule((uint8_t)inChn, (uint16_t)inFreq, inLen, (uint8_t)outChn, (uint16_t)outFreq, idx);
         const int rc = cache.add(k0, k1, idx.data(), idx.size() * sizeof(int32_t), idx.size(), &ent);
@@ -186,13 +201,13 @@ int wmx_pcm_zoom(int inChn, int inFreq, const int16_t *d_in, uint32_t inLen, int
     hipLaunchKernelGGL(zoom_kernel, dim3(grid), dim3(256), 0, s, d_in, d_out, (const int32_t *)ent->p, (uint32_t)ent->n, in_stride,
                        out_stride, n_streams);
     WMX_LAUNCH_CHECK();
-    return 0;
+    return cache.used(ent, s);
 }
 
 // legacy host form, src/wmix.h:122-127
 uint32_t wmix_pcm_zoom(uint8_t inChn, uint16_t inFreq, uint8_t *in, uint32_t inLen, uint8_t outChn, uint16_t outFreq, uint8_t *out) {
     using namespace wmx;
-    static thread_local DevVec a(true), b(true);
+    static thread_local DevVec a, b;
     if (inLen == 0 || !in || !out || !inFreq || !outFreq || !inChn || !outChn) return 0;
     const uint32_t need = wmix_len_of_out(inChn, inFreq, inLen, outChn, outFreq);  // what the reference's callers size `out` by
     uint32_t n = 0;
@@ -279,7 +294,7 @@ int wmx_mix_load(wmx_mix *m, const int16_t *d_src, uint32_t srcU8Len, int freq, 
         if (head_off >= m->ring_bytes) head_off = 0;
     }
     const uint64_t k0 = ((uint64_t)srcU8Len << 32) | (uint32_t)freq, k1 = ((uint64_t)(uint8_t)channels << 8) | (uint8_t)sample;
-    const SchedCache::Entry *ent = m->sched.find(k0, k1);
+    SchedCache::Entry *ent = m->sched.find(k0, k1);
     if (!ent) {
         if (!load_schedule(m->chn, m->freq, srcU8Len, (uint16_t)freq, (uint8_t)channels, (uint8_t)sample, m->sch)) {
             set_error("wmx_mix_load: rate ratio needs more than 64 fill samples (the reference overruns repairBuff here)");
@@ -302,6 +317,8 @@ int wmx_mix_load(wmx_mix *m, const int16_t *d_src, uint32_t srcU8Len, int freq, 
         hipLaunchKernelGGL(load_kernel, dim3(grid), dim3(256), 0, s, m->d_rings, m->ring_bytes / 2, d_src, (const LoadEntry *)ent->p,
                            n_out, head_off / 2, n_src, group_stride, source_stride, rdce, m->n_groups);
         WMX_LAUNCH_CHECK();
+        const int rcu = m->sched.used(ent, s);
+        if (rcu) return rcu;
     }
     // cursor bookkeeping, src/wmix.c:1942-1956
     uint32_t tickAdd = n_out * 2, new_head = head_off + tickAdd;
@@ -355,8 +372,16 @@ WMix_Point wmix_load_data(WMix_Struct_Head *wmix, WMix_Point src, uint32_t srcU8
         }
     }
     const uint32_t size = (uint32_t)(wmix->end.U8 - wmix->start.U8);
-    static thread_local wmx_mix *m = nullptr;
-    static thread_local DevVec d_src(true);
+    // this thread's device ring: destroyed with the thread (a finished task thread of the daemon gives it back)
+    struct MixOwner {
+        wmx_mix *m = nullptr;
+        ~MixOwner() {
+            if (m && !runtime_exiting()) wmx_mix_destroy(m);
+        }
+    };
+    static thread_local MixOwner owner;
+    static thread_local DevVec d_src;
+    wmx_mix *&m = owner.m;
     if (!m || m->chn != ring_chn || m->freq != ring_freq) {
         if (m) wmx_mix_destroy(m);
         m = nullptr;

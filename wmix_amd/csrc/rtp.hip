@@ -125,7 +125,7 @@ int wmx_rtp_egress(wmx_rtp *h, int in_chn, int in_freq, const int16_t *d_pcm, ui
         return WMX_EINVAL;
     }
     const uint64_t k0 = ((uint64_t)in_chn << 56) | ((uint64_t)out_chn << 48) | ((uint64_t)(uint32_t)in_freq << 24) | (uint32_t)out_freq;
-    const SchedCache::Entry *ent = h->sched.find(k0, in_bytes);
+    SchedCache::Entry *ent = h->sched.find(k0, in_bytes);
     if (!ent) {
         zoom_gather_list(in_chn, in_freq, in_bytes, out_chn, out_freq, h->idx);
         const int rc = h->sched.add(k0, in_bytes, h->idx.data(), h->idx.size() * sizeof(int32_t), h->idx.size(), &ent);
@@ -147,7 +147,7 @@ int wmx_rtp_egress(wmx_rtp *h, int in_chn, int in_freq, const int16_t *d_pcm, ui
         hipLaunchKernelGGL((rtp_egress_kernel<WMX_LAW_U>), grid, block, 0, as_stream(stream), d_pcm, pcm_stride, d_idx, n_codes,
                            n_codes / out_chn, h->d_seq, h->d_ts, d_packets, packet_stride, h->n_streams, pt);
     WMX_LAUNCH_CHECK();
-    return 0;
+    return h->sched.used(ent, as_stream(stream));
 }
 
 int wmx_rtp_ingest(int n_streams, const uint8_t *d_packets, long packet_stride, int16_t *d_pcm, long pcm_stride, uint32_t *d_pcm_bytes,

@@ -1,9 +1,18 @@
 // wmx_core.hip -- error plumbing and device queries for libwmix_amd.so.
+#include <atomic>
+#include <cstdlib>
 #include "wmx_internal.h"
 
 namespace wmx {
 
 static thread_local char g_err[512] = "";
+
+// see runtime_exiting() in wmx_internal.h
+static std::atomic<bool> g_exiting{false};
+static void mark_exiting() { g_exiting.store(true); }
+static const int g_exit_hook = (atexit(mark_exiting), 0);  // registered at load time: behind the HIP runtime's handlers, so it runs first
+__attribute__((destructor)) static void on_unload() { g_exiting.store(true); }
+bool runtime_exiting() { return g_exiting.load(); }
 
 void set_error(const char *fmt, ...) {
     va_list ap;

@@ -54,34 +54,65 @@ inline unsigned stream_grid(size_t work_items, unsigned block) {
     return (unsigned)(need < cap ? need : cap);
 }
 
-// Device-resident schedules (gather lists, load schedules) the host builds per format.  An entry, once uploaded, is
-// never overwritten or freed while other work may run: a kernel of an earlier call that still reads it on another
-// stream stays valid (round-1 ADVICE: the scratch buffers used to be rewritten by the next call).  Formats are few --
-// a daemon has a handful -- so entries simply accumulate; past kMax the cache drains the device before it frees them.
-// The upload is a blocking copy, once per format.
+// True once the process has begun to exit (an atexit handler registered when the library is loaded, i.e. after the HIP
+// runtime's own handlers, so it runs before them; also the library's destructor).  Thread-local owners of device memory
+// free it normally when their thread ends and leave it alone only then: the HIP runtime may already be gone, and a
+// finished task thread of the daemon (src/wmixTask.c starts one per play / record task) must not leak its buffers
+// (round-2 ADVICE).
+bool runtime_exiting();
+
+// Device-resident schedules (gather lists, load schedules) the host builds per format.  An entry, once uploaded, is never
+// overwritten while other work may read it (round-1 ADVICE: the scratch buffers used to be rewritten by the next call).
+// A cache holds at most kMax entries; a new format beyond that evicts the least recently used ONE, after waiting for the
+// event recorded behind the last kernel that read it (round-2 ADVICE: no device-wide synchronisation, no mass eviction),
+// on the device the entry lives on (a thread-local cache may hold entries of several devices).  The upload is a blocking
+// copy, once per format.
 struct SchedCache {
     struct Entry {
         uint64_t k0, k1;
         void *p;
         size_t n;  // elements
+        int device;
+        uint64_t last_use;
+        hipEvent_t ev;  // recorded by used(); nullptr until the first kernel has read the entry
     };
     static constexpr size_t kMax = 64;
-    std::vector<Entry> e;
-    bool leak;  // thread_local instances: the HIP runtime may be gone when the thread or process ends
-    explicit SchedCache(bool leak_at_exit = false) : leak(leak_at_exit) {}
+    // a list, not a vector: callers keep Entry pointers across add()
+    std::vector<Entry *> e;
+    uint64_t tick = 0;
+    SchedCache() = default;
     SchedCache(const SchedCache &) = delete;
     SchedCache &operator=(const SchedCache &) = delete;
-    const Entry *find(uint64_t k0, uint64_t k1) const {
-        for (const Entry &x : e)
-            if (x.k0 == k0 && x.k1 == k1) return &x;
+    Entry *find(uint64_t k0, uint64_t k1) {
+        for (Entry *x : e)
+            if (x->k0 == k0 && x->k1 == k1) {
+                x->last_use = ++tick;
+                return x;
+            }
         return nullptr;
     }
-    // returns 0 and *out on success, a WMX error otherwise
-    int add(uint64_t k0, uint64_t k1, const void *host, size_t bytes, size_t n, const Entry **out) {
-        if (e.size() >= kMax) {
-            WMX_HIP_RC(hipDeviceSynchronize());
-            clear();
+    static void drop(Entry *x) {
+        if (!runtime_exiting()) {
+            DeviceScope on(x->device);
+            if (x->ev) {
+                (void)hipEventSynchronize(x->ev);
+                (void)hipEventDestroy(x->ev);
+            }
+            if (x->p) (void)hipFree(x->p);
         }
+        delete x;
+    }
+    // returns 0 and *out on success, a WMX error otherwise
+    int add(uint64_t k0, uint64_t k1, const void *host, size_t bytes, size_t n, Entry **out) {
+        if (e.size() >= kMax) {
+            size_t lru = 0;
+            for (size_t i = 1; i < e.size(); i++)
+                if (e[i]->last_use < e[lru]->last_use) lru = i;
+            drop(e[lru]);
+            e.erase(e.begin() + (long)lru);
+        }
+        int dev = -1;
+        WMX_HIP_RC(hipGetDevice(&dev));
         void *p = nullptr;
         if (bytes) {
             WMX_HIP_RC(hipMalloc(&p, bytes));
@@ -91,18 +122,22 @@ struct SchedCache {
                 return hip_fail(er, "hipMemcpy(schedule)", __FILE__, __LINE__);
             }
         }
-        e.push_back(Entry{k0, k1, p, n});
-        *out = &e.back();
+        Entry *x = new Entry{k0, k1, p, n, dev, ++tick, nullptr};
+        e.push_back(x);
+        *out = x;
+        return 0;
+    }
+    // call after launching the kernel that reads `x` on stream `s`
+    int used(Entry *x, hipStream_t s) {
+        if (!x->ev) WMX_HIP_RC(hipEventCreateWithFlags(&x->ev, hipEventDisableTiming));
+        WMX_HIP_RC(hipEventRecord(x->ev, s));
         return 0;
     }
     void clear() {
-        for (Entry &x : e)
-            if (x.p) (void)hipFree(x.p);
+        for (Entry *x : e) drop(x);
         e.clear();
     }
-    ~SchedCache() {
-        if (!leak) clear();
-    }
+    ~SchedCache() { clear(); }
 };
 
 // Per-stream lifetime inside a batch.  The reference creates every handle lazily, releases it when its flag drops or recording
