@@ -136,3 +136,53 @@ def test_config4_ns_agc_resample_mix_vs_oracle(cuda, oracle_port):
             assert np.array_equal(out[g], ring[1600:1680]), (k, g)
             assert (h, tk) == (int(meta[-1][1]), int(meta[-1][0]))
     mb.close()
+
+
+def test_config4_full_size_32768_sources(cuda, oracle_port):
+    """BASELINE configs[4] at its real size: 32 768 two-channel 32 kHz sources through
+    ns_kernel<256, true, 2> and the two-channel AGC pipeline, then the 8-way resample-and-mix into 4 096 rings of 1 x 8 kHz
+    with the play thread's 10 ms drain -- packet-major like bench.py.  64 distinct sources replicated over the batch: equal
+    input must give equal output wherever a source sits; spot sources and spot mix groups agree with the oracle."""
+    from wmix_amd.agc import AgcBatch
+    from wmix_amd.mix import MixBatch
+    from wmix_amd.ns import NsBatch
+    _bind(oracle_port)
+    S, N, n, per, U = 32768, 8, 12, 640, 64
+    rng = np.random.default_rng(404)
+    t = np.arange(n * 320)
+    uniq = np.zeros((U, n * 320, 2), np.int16)
+    for s in range(U):
+        tone = 14000 * np.sin(2 * np.pi * (150 + 31 * s) * t / 32000) * (((t // 1600) + s) % 4 > 0)
+        uniq[s, :, 0] = np.clip(tone + rng.integers(-2500, 2500, t.size), -32768, 32767)
+        uniq[s, :, 1] = uniq[s, :, 0] // 3
+    uniq = uniq.reshape(U, n, per)
+    uniq[5] = 0  # a silent source inside every group
+    inp = torch.from_numpy(uniq).to(cuda)[torch.arange(S, device=cuda) % U].transpose(0, 1).contiguous()  # [n, S, per]
+    flat = torch.zeros(S * per + 2, dtype=torch.int16, device=cuda)  # + the mixer's look-ahead frame
+    work = flat[: S * per].view(1, S, per)
+    src = torch.as_strided(flat, (S // N, N, per + 2), (N * per, per, 1))
+    ns, agc, mb = NsBatch(S, 2, 32000), AgcBatch(S, 2, 32000, 5), MixBatch(S // N, 1, 8000)
+    pcm, mixes = [], []
+    for k in range(n):
+        ns.process_packet_major(inp[k:k + 1], work)
+        agc.process(work[0].view(S, 2, 320))
+        pcm.append(work[0, :U].cpu().numpy())
+        assert torch.equal(work.view(S // U, U, per), work[0, :U].unsqueeze(0).expand(S // U, U, per)), k
+        mb.set(0, 0, 1)
+        mb.load(src, per * 2, 32000, 2)
+        mb.set(3200, 0, 1)
+        out = mb.drain(160)
+        mixes.append(out[: U // N].cpu().numpy())
+        # groups repeat with period U / N = 8 (group g holds sources 8g .. 8g + 7 of the replicated set)
+        assert torch.equal(out.view(S // U, U // N, -1), out[: U // N].unsqueeze(0).expand(S // U, U // N, out.shape[-1])), k
+    pcm = np.stack(pcm, 1)  # [U, n, per]
+    for s in (0, 5, 17, 63):
+        want = loader.run_chain(oracle_port, 2, 32000, 5, 1 | 4, np.zeros(n * per, np.int16), uniq[s].reshape(-1), 320, prefix="orc")
+        assert np.array_equal(pcm[s].reshape(-1), want), s
+    for k in (0, 5, n - 1):
+        for g in (0, 3, 7):
+            fl = np.concatenate([pcm[g * N + i, k] for i in range(N)] + [np.zeros(2, np.int16)])
+            ring, _ = orc_load(oracle_port, 1, 8000, 32000, 2, 1, 1, N, per * 2, 0, fl)
+            assert np.array_equal(mixes[k][g], ring[1600:1680]), (k, g)
+    for b in (ns, agc, mb):
+        b.close()

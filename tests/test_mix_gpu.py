@@ -231,7 +231,8 @@ def test_variable_chunk_sizes_walk_through_the_schedule_cache(cuda, wmx, oracle_
     mass eviction every 64 formats.  150 different lengths through wmx_pcm_zoom, twice (the second pass meets evicted
     entries again), every result equal to the oracle's wmix_pcm_zoom."""
     import torch
-    o = _bind(oracle_port)
+    _bind(oracle_port)
+    o = oracle_port
     rng = np.random.default_rng(77)
     x = rng.integers(-30000, 30000, 2 * 4096, dtype=np.int16)
     d = torch.from_numpy(x).to(cuda)

@@ -464,9 +464,12 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
             if (bp.flags & kAecFlagNoiseMin) AEC_ST(AS_DMIN + b) = r.dmin;
             if (bp.flags & kAecFlagNoiseInit) AEC_ST(AS_DINIT + b) = r.dinit;
         };
-        const Pw a = power(lane, dfr, dfi), c = power(kAecPart, df64, 0.f);
+        const Pw a = power(lane, dfr, dfi);
         put(lane, a);
+#if !defined(WMX_AEC_EXP) || WMX_AEC_EXP < 1
+        const Pw c = power(kAecPart, df64, 0.f);
         if (lane == 0) put(kAecPart, c);
+#endif
     }
     // ---- ScaleErrorSignal (aec_core.c:172-194); ef stays in registers (bin = lane; lane 0 also bin 64), and so
     //      does the windowed error spectrum
@@ -494,7 +497,11 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
         // dependency chains in one instruction stream instead of a second, serial pass under `if (lane == 0)`
         const float xp64 = uniform_ld(F.xpow_seq + (n % kAecHist) * BP + kAecPart);
         scale_err(xpow_lane, efr, efi);
+#if !defined(WMX_AEC_EXP) || WMX_AEC_EXP < 1
         scale_err(xp64, ef64r, ef64i);
+#else
+        ef64r *= xp64;
+#endif
     }
     wave_sync();  // rows 2, 3 are read; the filter update overwrites the work rows
     AEC_RELANE();
@@ -688,14 +695,20 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
             AEC_ST(AS_SXD_RE + b) = r.sxd_r;
             AEC_ST(AS_SXD_IM + b) = r.sxd_i;
         };
-        const Psd a = psd(lane), c = psd(kAecPart);
+        const Psd a = psd(lane);
         put(lane, a);
+#if !defined(WMX_AEC_EXP) || WMX_AEC_EXP < 1
+        const Psd c = psd(kAecPart);
         if (lane == 0) put(kAecPart, c);
+#endif
     }
     wave_sync();
     AEC_PROF(5);
     // the two ordered sums advance side by side: lane 0 adds sd[0..64], lane 1 adds se[0..64] (index order each)
     float sdSum, seSum;
+#if defined(WMX_AEC_EXP) && WMX_AEC_EXP >= 2
+    sdSum = AEC_ST(AS_SD), seSum = AEC_ST(AS_SE + 1);
+#else
     {
         const float *mine = &AEC_ST(lane == 1 ? AS_SE : AS_SD);
         float acc = 0.f;
@@ -715,6 +728,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
         sdSum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 0));
         seSum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 1));
     }
+#endif
     const int diverge = ((Si[AS_DIVERGE] ? 1.05f : 1.0f) * seSum > sdSum) ? 1 : 0;
     const bool reset_filter = seSum > (19.95f * sdSum);
     wave_sync();
@@ -739,7 +753,11 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
         };
         float a0, a1, c0, c1;
         coh(lane, a0, a1);
+#if !defined(WMX_AEC_EXP) || WMX_AEC_EXP < 1
         coh(kAecPart, c0, c1);
+#else
+        c0 = a0, c1 = a1;
+#endif
         if (diverge) {  // divergeState: the error spectrum is replaced by the near spectrum (aec_core.c:959-962)
             ew[lane] = dw[lane];
             ew[66 + lane] = dw[66 + lane];
@@ -758,6 +776,9 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
     wave_sync();
     // the two band averages as parallel lane chains (lane 0: cohxd, lane 1: cohde), index order each
     float hNlXdAvg, hNlDeAvg;
+#if defined(WMX_AEC_EXP) && WMX_AEC_EXP >= 2
+    hNlXdAvg = t1[5] * prefSize, hNlDeAvg = t0[5] * prefSize;
+#else
     {
         const float *mine = lane == 1 ? t0 : t1;
         float acc = 0.f;
@@ -766,6 +787,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
         hNlXdAvg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 0));
         hNlDeAvg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 1));
     }
+#endif
     hNlXdAvg /= prefSize;
     hNlXdAvg = 1 - hNlXdAvg;
     hNlDeAvg /= prefSize;
@@ -810,7 +832,11 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
         t2[b] = mode == 0 ? cde : (mode == 1 ? cxd : (cde < cxd ? cde : cxd));  // hNl
     }
     wave_sync();
+#if defined(WMX_AEC_EXP) && WMX_AEC_EXP >= 2
+    if (mode == 3) {
+#else
     if (mode == 2) {
+#endif
         // qsort(hNlPref) + the two order statistics (aec_core.c:1017-1022): rank by counting
         constexpr int i75 = (int)(0.75f * (prefSize - 1)), i50 = (int)(0.5f * (prefSize - 1));
         if (lane < prefSize) {
@@ -869,7 +895,11 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
     const int noise_off = (bp.flags & kAecFlagNoiseInit) ? AS_DINIT : AS_DMIN;
     v2f out_spec = v2f{0.f, 0.f};
     float out_nyq = 0.f;
+#if defined(WMX_AEC_EXP) && WMX_AEC_EXP >= 1
+    for (int b = lane; b < kAecPart; b += 64) {
+#else
     for (int b = lane; b < kAecPart1; b += 64) {
+#endif
         float h = t2[b];
         const float wc = K.weight[b];
         if (h > hNlFb) h = wc * hNlFb + (1 - wc) * h;

@@ -202,7 +202,11 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
     // Per-bin state this frame will need, requested from HBM right behind the time-domain buffers (loads return in order) and consumed
     // several phases later (window, energy sum, FFT, spectrum loop and the ordered sums run in between): the loops below
     // never wait on HBM latency.  (A zero-energy frame does not use them; it is the rare case.)
+#if defined(WMX_NS_EXP) && WMX_NS_EXP == 1  // timing-only experiment (WRONG results): the per-bin loops without their lone Nyquist pass
+    constexpr int NI = M / 64;
+#else
     constexpr int NI = (M + 63) / 64;  // bins per lane: 3 (M = 129) or 2 (M = 65), the last one lane 0 only
+#endif
     float pf_quant[NI], pf_dens[NI][3], pf_lq[NI][3], pf_pause[NI];
 #pragma unroll
     for (int k = 0; k < NI; k++) {
