@@ -56,6 +56,14 @@ int wmx_version(void);
  * The AEC / AECM, whose control plane is shared by the streams that were started together, add COHORTS, see there.
  * Bad index -> WMX_EINVAL, nothing reset. */
 
+/* Stream migration between batches / GPUs (a stream that outlives its batch, or that moves to another device for balance):
+ *   wmx_<m>_stream_state_bytes(h)            size of one stream's state blob for this handle's format
+ *   wmx_<m>_export_stream(h, i, blob)        the complete state of stream i into HOST memory (blocking: the device is drained)
+ *   wmx_<m>_import_stream(h, i, blob[, c])   the reverse, into any handle of the same module and format (WMX_ESTATE otherwise);
+ *                                            for the AEC / AECM `c` >= 0 also makes the stream a member of cohort c
+ *   wmx_{aec,aecm}_cohort_state_bytes / _export_cohort / _import_cohort   the shared part: control plane + far-end history
+ * A stream imported together with its cohort continues bit for bit as if it had never moved (tests/test_lifetime_gpu.py). */
+
 /* ------------------------------------------------------------------ G.711
  * Replaces g711{a,u}_encode / g711{a,u}_decode (src/g711codec.h:30-34,
  * src/g711codec.c:82-216) for device-resident buffers.  law: 0 = A-law, 1 = mu-law.
@@ -97,6 +105,9 @@ int wmx_ns_state_words(const wmx_ns *h);
 int wmx_ns_export_state(const wmx_ns *h, int stream_index, float *host_words, unsigned short *host_hist);
 int wmx_ns_reset_streams(wmx_ns *h, const int32_t *idx, int n, void *stream);
 int wmx_ns_set_active(wmx_ns *h, const uint8_t *host_mask, void *stream);
+int wmx_ns_stream_state_bytes(const wmx_ns *h);
+int wmx_ns_export_stream(wmx_ns *h, int stream_index, void *host_blob);
+int wmx_ns_import_stream(wmx_ns *h, int stream_index, const void *host_blob);
 
 /* ------------------------------------------------------------------ NSX (fixed-point noise suppressor)
  * Batched form of the SAME three wrapper functions when the reference is built with its MAKE_WEBRTC_NSX switch
@@ -114,6 +125,9 @@ int wmx_nsx_process(wmx_nsx *h, const int16_t *d_in, int16_t *d_out, int n_packe
                     long packet_stride, void *stream);
 int wmx_nsx_reset_streams(wmx_nsx *h, const int32_t *idx, int n, void *stream);
 int wmx_nsx_set_active(wmx_nsx *h, const uint8_t *host_mask, void *stream);
+int wmx_nsx_stream_state_bytes(const wmx_nsx *h);
+int wmx_nsx_export_stream(wmx_nsx *h, int stream_index, void *host_blob);
+int wmx_nsx_import_stream(wmx_nsx *h, int stream_index, const void *host_blob);
 
 /* ------------------------------------------------------------------ VAD (voice-activity gate)
  * Batched form of vad_init / vad_process / vad_release (src/webrtc.h:32-36, src/webrtc.c:40-164):
@@ -133,6 +147,9 @@ int wmx_vad_process(wmx_vad *h, int16_t *d_pcm, int packets_per_call, int n_call
                     long call_stride, void *stream);
 int wmx_vad_reset_streams(wmx_vad *h, const int32_t *idx, int n, void *stream);
 int wmx_vad_set_active(wmx_vad *h, const uint8_t *host_mask, void *stream);
+int wmx_vad_stream_state_bytes(const wmx_vad *h);
+int wmx_vad_export_stream(wmx_vad *h, int stream_index, void *host_blob);
+int wmx_vad_import_stream(wmx_vad *h, int stream_index, const void *host_blob);
 
 /* ------------------------------------------------------------------ AGC (legacy fixed-point, adaptive digital)
  * Batched form of agc_init / agc_process / agc_addition / agc_release (src/webrtc.h:55-60,
@@ -150,6 +167,9 @@ int wmx_agc_process(wmx_agc *h, const int16_t *d_in, int16_t *d_out, int n_packe
                     long packet_stride, void *stream);
 int wmx_agc_reset_streams(wmx_agc *h, const int32_t *idx, int n, void *stream); /* the gain table is the batch's */
 int wmx_agc_set_active(wmx_agc *h, const uint8_t *host_mask, void *stream);
+int wmx_agc_stream_state_bytes(const wmx_agc *h);
+int wmx_agc_export_stream(wmx_agc *h, int stream_index, void *host_blob);
+int wmx_agc_import_stream(wmx_agc *h, int stream_index, const void *host_blob);
 
 /* ------------------------------------------------------------------ AEC (float echo canceller)
  * Batched form of aec_init / aec_setFrameFar / aec_process / aec_process2 / aec_release
@@ -203,6 +223,12 @@ int wmx_aec_cohorts(const wmx_aec *h);
 int wmx_aec_reset_cohort(wmx_aec *h, int cohort, void *stream);
 int wmx_aec_reset_streams(wmx_aec *h, const int32_t *idx, int n, int cohort, void *stream);
 int wmx_aec_set_active(wmx_aec *h, const uint8_t *host_mask, void *stream);
+int wmx_aec_stream_state_bytes(const wmx_aec *h);
+int wmx_aec_export_stream(wmx_aec *h, int stream_index, void *host_blob);
+int wmx_aec_import_stream(wmx_aec *h, int stream_index, const void *host_blob, int cohort);
+int wmx_aec_cohort_state_bytes(const wmx_aec *h);
+int wmx_aec_export_cohort(wmx_aec *h, int cohort, void *host_blob);
+int wmx_aec_import_cohort(wmx_aec *h, int cohort, const void *host_blob);
 int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_packet_stride, long far_group_stride,
                         const int16_t *d_near, int16_t *d_out, int n_packets, long stream_stride, long packet_stride,
                         const int32_t *delay_ms, const uint8_t *cohort_on, int32_t *cohort_rc, void *stream);
@@ -239,6 +265,9 @@ int wmx_chain_process(wmx_chain *h, const int16_t *d_far, long far_packet_stride
 int wmx_chain_reset_streams(wmx_chain *h, const int32_t *idx, int n, int cohort, void *stream);
 int wmx_chain_reset_cohort(wmx_chain *h, int cohort, void *stream);
 int wmx_chain_set_active(wmx_chain *h, const uint8_t *host_mask, void *stream);
+int wmx_chain_stream_state_bytes(const wmx_chain *h);
+int wmx_chain_export_stream(wmx_chain *h, int stream_index, void *host_blob);
+int wmx_chain_import_stream(wmx_chain *h, int stream_index, const void *host_blob, int cohort);
 wmx_ns *wmx_chain_ns(wmx_chain *h);
 wmx_aec *wmx_chain_aec(wmx_chain *h);
 wmx_agc *wmx_chain_agc(wmx_chain *h);
@@ -267,6 +296,12 @@ int wmx_aecm_cohorts(const wmx_aecm *h);
 int wmx_aecm_reset_cohort(wmx_aecm *h, int cohort, void *stream);
 int wmx_aecm_reset_streams(wmx_aecm *h, const int32_t *idx, int n, int cohort, void *stream);
 int wmx_aecm_set_active(wmx_aecm *h, const uint8_t *host_mask, void *stream);
+int wmx_aecm_stream_state_bytes(const wmx_aecm *h);
+int wmx_aecm_export_stream(wmx_aecm *h, int stream_index, void *host_blob);
+int wmx_aecm_import_stream(wmx_aecm *h, int stream_index, const void *host_blob, int cohort);
+int wmx_aecm_cohort_state_bytes(const wmx_aecm *h);
+int wmx_aecm_export_cohort(wmx_aecm *h, int cohort, void *host_blob);
+int wmx_aecm_import_cohort(wmx_aecm *h, int cohort, const void *host_blob);
 int wmx_aecm_run_cohorts(wmx_aecm *h, int mode, const int16_t *d_far, long far_packet_stride, long far_group_stride,
                          const int16_t *d_near, int16_t *d_out, int n_packets, long stream_stride, long packet_stride,
                          const int32_t *delay_ms, const uint8_t *cohort_on, int32_t *cohort_rc, void *stream);

@@ -151,6 +151,27 @@ def _declare(L):
         f = getattr(L, "wmx_%s_run_cohorts" % m)
         f.restype = i
         f.argtypes = [vp, i, vp, C.c_long, C.c_long, vp, vp, i, C.c_long, C.c_long, vp, vp, vp, vp]
+    # stream / cohort migration
+    for m in ("ns", "nsx", "agc", "vad", "aec", "aecm", "chain"):
+        f = getattr(L, "wmx_%s_stream_state_bytes" % m)
+        f.restype = i
+        f.argtypes = [vp]
+        f = getattr(L, "wmx_%s_export_stream" % m)
+        f.restype = i
+        f.argtypes = [vp, i, vp]
+        f = getattr(L, "wmx_%s_import_stream" % m)
+        f.restype = i
+        f.argtypes = [vp, i, vp] + ([i] if m in ("aec", "aecm", "chain") else [])
+    for m in ("aec", "aecm"):
+        f = getattr(L, "wmx_%s_cohort_state_bytes" % m)
+        f.restype = i
+        f.argtypes = [vp]
+        f = getattr(L, "wmx_%s_export_cohort" % m)
+        f.restype = i
+        f.argtypes = [vp, i, vp]
+        f = getattr(L, "wmx_%s_import_cohort" % m)
+        f.restype = i
+        f.argtypes = [vp, i, vp]
     L.wmx_aecm_create_cohorts.restype = i
     L.wmx_aecm_create_cohorts.argtypes = [C.POINTER(vp), i, i, i, i, i]
     L.wmx_aec_set_timing.restype = i

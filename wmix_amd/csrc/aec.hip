@@ -1158,10 +1158,16 @@ struct wmx_aec {
     int *d_stream_far;       // [n_streams] group of each stream, or nullptr when n_far == 1
     int16_t *d_zero_far;  // a silent far-end packet for near-only calls that need no far data
     wmx::StreamLife life;
-    // in-stream timing of the two kernels (wmx_aec_set_timing): event triples [before far | between | after near]
+    // in-stream timing of the two kernels (wmx_aec_set_timing): event quadruples [far start | far end | near start | near end]
     bool timing;
     std::vector<hipEvent_t> tev;
     size_t tev_used;
+    // The far kernel is one wave per cohort and needs nothing but the far-end packet: a caller that has other work for the
+    // GPU in front of the near kernel (wmx_chain_process: the noise suppressor) lets it run BESIDE that work on this side
+    // stream instead of alone in front of the near kernel (wmx::aec_fork_far).
+    hipStream_t side;
+    hipEvent_t ev_fork, ev_join;
+    bool fork_pending;
 };
 
 extern "C" {
@@ -1178,6 +1184,9 @@ int wmx_aec_destroy(wmx_aec *h) {
     if (h->d_tmpl) (void)hipFree(h->d_tmpl);
     h->life.release();
     for (hipEvent_t ev : h->tev) (void)hipEventDestroy(ev);
+    if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (int i = 0; i < wmx_aec::kPlanBufs; i++)
         if (h->plan_free[i]) (void)hipEventDestroy(h->plan_free[i]);
     delete h;
@@ -1222,6 +1231,9 @@ int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int i
     h->d_state = h->d_consts = h->d_far = h->d_tmpl = nullptr;
     h->timing = false;
     h->tev_used = 0;
+    h->side = nullptr;
+    h->ev_fork = h->ev_join = nullptr;
+    h->fork_pending = false;
     h->d_plans = nullptr;
     h->h_plans = nullptr;
     h->d_stream_far = nullptr;
@@ -1417,24 +1429,34 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
         }
         if (any) {
             const int by_value = (chunk == 1 && G == 1) ? 1 : 0;
-            if (!by_value) WMX_HIP(hipMemcpyAsync(dp, hp, (size_t)G * kAecMaxPktPerLaunch * sizeof(AecPlan), hipMemcpyHostToDevice, s));
+            // the far kernel (and the plans it reads) on the side stream when the caller forked it (first chunk of the call only)
+            const bool forked = h->fork_pending && done == 0 && (mode & 2);
+            h->fork_pending = false;
+            hipStream_t fs = forked ? h->side : s;
+            if (forked) WMX_HIP(hipStreamWaitEvent(fs, h->ev_fork, 0));
+            if (!by_value) WMX_HIP(hipMemcpyAsync(dp, hp, (size_t)G * kAecMaxPktPerLaunch * sizeof(AecPlan), hipMemcpyHostToDevice, fs));
             hipEvent_t *tv = nullptr;
             if (h->timing && (mode & 2)) {
-                if (h->tev_used + 3 > h->tev.size())
-                    for (int k = 0; k < 3; k++) {
+                if (h->tev_used + 4 > h->tev.size())
+                    for (int k = 0; k < 4; k++) {
                         hipEvent_t ev;
                         WMX_HIP(hipEventCreate(&ev));
                         h->tev.push_back(ev);
                     }
                 tv = &h->tev[h->tev_used];
-                h->tev_used += 3;
-                WMX_HIP(hipEventRecord(tv[0], s));
+                h->tev_used += 4;
+                WMX_HIP(hipEventRecord(tv[0], fs));
             }
-            hipLaunchKernelGGL(aec_far_kernel, dim3((unsigned)G), dim3(64), 0, s, h->far, h->d_consts, dp, chunk,
+            hipLaunchKernelGGL(aec_far_kernel, dim3((unsigned)G), dim3(64), 0, fs, h->far, h->d_consts, dp, chunk,
                                d_far ? d_far + (size_t)done * far_packet_stride : nullptr, far_packet_stride, far_group_stride, h->chn, gpow1np,
                                by_value, hp[0]);
             WMX_LAUNCH_CHECK();
-            if (tv) WMX_HIP(hipEventRecord(tv[1], s));
+            if (tv) WMX_HIP(hipEventRecord(tv[1], fs));
+            if (forked) {
+                WMX_HIP(hipEventRecord(h->ev_join, fs));
+                WMX_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
+            }
+            if (tv) WMX_HIP(hipEventRecord(tv[2], s));
             if (mode & 2) {
                 const int16_t *nin = d_near + (size_t)done * packet_stride;
                 int16_t *nout = d_out + (size_t)done * packet_stride;
@@ -1447,7 +1469,7 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
                     hipLaunchKernelGGL((aec_near_kernel<2>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, chunk, nin,
                                        nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg, h->d_stream_far, h->life.d_active);
                 WMX_LAUNCH_CHECK();
-                if (tv) WMX_HIP(hipEventRecord(tv[2], s));
+                if (tv) WMX_HIP(hipEventRecord(tv[3], s));
             }
             WMX_HIP(hipEventRecord(h->plan_free[sel], s));
             h->plan_used[sel] = true;
@@ -1499,7 +1521,87 @@ int wmx_aec_set_active(wmx_aec *h, const uint8_t *host_mask, void *stream) {
     return h->life.set_active(h->n_streams, host_mask, wmx::as_stream(stream));
 }
 
+// stream migration: [header | AS_WORDS state words].  The stream's COHORT (control plane + far-end history) travels on its
+// own: [header | AecCtl | the group's far-end buffers]; a destination cohort that received it continues exactly where the
+// source cohort stands, so a stream imported into it behaves as if it had never moved.
+int wmx_aec_stream_state_bytes(const wmx_aec *h) { return h ? (int)(sizeof(wmx::BlobHeader) + wmx::AS_WORDS * 4) : WMX_EINVAL; }
+int wmx_aec_cohort_state_bytes(const wmx_aec *h) {
+    return h ? (int)(sizeof(wmx::BlobHeader) + sizeof(wmx::AecCtl) + h->far.group_words * 4) : WMX_EINVAL;
+}
+
+int wmx_aec_export_stream(wmx_aec *h, int stream_index, void *host_blob) {
+    WMX_ON_DEVICE(h);
+    using namespace wmx;
+    if (!h || !host_blob || stream_index < 0 || stream_index >= h->n_streams) return WMX_EINVAL;
+    WMX_HIP(hipDeviceSynchronize());
+    char *p = static_cast<char *>(host_blob);
+    blob_begin(p, blob_tag("AEC "), (uint32_t)h->freq, AS_WORDS * 4);
+    WMX_HIP(hipMemcpy(p + sizeof(BlobHeader), h->d_state + (size_t)stream_index * AS_WORDS, AS_WORDS * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int wmx_aec_import_stream(wmx_aec *h, int stream_index, const void *host_blob, int cohort) {
+    WMX_ON_DEVICE(h);
+    using namespace wmx;
+    if (!h || !host_blob || stream_index < 0 || stream_index >= h->n_streams || cohort < -1 || cohort >= h->n_far) return WMX_EINVAL;
+    const int rc = blob_check(host_blob, blob_tag("AEC "), (uint32_t)h->freq, AS_WORDS * 4);
+    if (rc) return rc;
+    WMX_HIP(hipDeviceSynchronize());
+    WMX_HIP(hipMemcpy(h->d_state + (size_t)stream_index * AS_WORDS, static_cast<const char *>(host_blob) + sizeof(BlobHeader), AS_WORDS * 4,
+                      hipMemcpyHostToDevice));
+    if (cohort >= 0 && h->d_stream_far) WMX_HIP(hipMemcpy(h->d_stream_far + stream_index, &cohort, sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int wmx_aec_export_cohort(wmx_aec *h, int cohort, void *host_blob) {
+    WMX_ON_DEVICE(h);
+    using namespace wmx;
+    if (!h || !host_blob || cohort < 0 || cohort >= h->n_far) return WMX_EINVAL;
+    WMX_HIP(hipDeviceSynchronize());
+    char *p = static_cast<char *>(host_blob);
+    const size_t fb = h->far.group_words * 4;
+    blob_begin(p, blob_tag("AECc"), (uint32_t)h->freq, (uint32_t)(sizeof(AecCtl) + fb));
+    p += sizeof(BlobHeader);
+    memcpy(p, &h->ctl[(size_t)cohort], sizeof(AecCtl));
+    WMX_HIP(hipMemcpy(p + sizeof(AecCtl), h->d_far + (size_t)cohort * h->far.group_words, fb, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int wmx_aec_import_cohort(wmx_aec *h, int cohort, const void *host_blob) {
+    WMX_ON_DEVICE(h);
+    using namespace wmx;
+    if (!h || !host_blob || cohort < 0 || cohort >= h->n_far) return WMX_EINVAL;
+    const size_t fb = h->far.group_words * 4;
+    const int rc = blob_check(host_blob, blob_tag("AECc"), (uint32_t)h->freq, (uint32_t)(sizeof(AecCtl) + fb));
+    if (rc) return rc;
+    WMX_HIP(hipDeviceSynchronize());
+    const char *p = static_cast<const char *>(host_blob) + sizeof(BlobHeader);
+    memcpy(&h->ctl[(size_t)cohort], p, sizeof(AecCtl));
+    WMX_HIP(hipMemcpy(h->d_far + (size_t)cohort * h->far.group_words, p + sizeof(AecCtl), fb, hipMemcpyHostToDevice));
+    return 0;
+}
+
 int wmx_aec_cohorts(const wmx_aec *h) { return h ? h->n_far : WMX_EINVAL; }
+
+}  // extern "C"
+
+// Library-internal (wmx_internal.h): from this point of `stream` on, the far-end packets of the NEXT wmx_aec_run_* call on
+// this handle are in place; its far kernel may start here, on the handle's side stream, beside whatever the caller launches
+// on `stream` between now and that call.  The near kernel still runs on `stream`, behind the far kernel.
+int wmx::aec_fork_far(wmx_aec *h, hipStream_t s) {
+    WMX_ON_DEVICE(h);
+    if (!h) return WMX_EINVAL;
+    if (!h->side) {
+        WMX_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        WMX_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        WMX_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
+    WMX_HIP(hipEventRecord(h->ev_fork, s));
+    h->fork_pending = true;
+    return 0;
+}
+
+extern "C" {
 
 // In-stream timing of the AEC's two kernels: with timing on, every near-end launch is bracketed by HIP events recorded on
 // the launch stream (before the far kernel, between the two, after the near kernel).  wmx_aec_timing waits for the last
@@ -1515,12 +1617,12 @@ int wmx_aec_timing(wmx_aec *h, int *n_launches, double *far_ms, double *near_ms)
     WMX_ON_DEVICE(h);
     if (!h) return WMX_EINVAL;
     double f = 0, nr = 0;
-    const size_t n = h->tev_used / 3;
+    const size_t n = h->tev_used / 4;
     for (size_t i = 0; i < n; i++) {
         float a = 0.f, b = 0.f;
-        WMX_HIP(hipEventSynchronize(h->tev[3 * i + 2]));
-        WMX_HIP(hipEventElapsedTime(&a, h->tev[3 * i], h->tev[3 * i + 1]));
-        WMX_HIP(hipEventElapsedTime(&b, h->tev[3 * i + 1], h->tev[3 * i + 2]));
+        WMX_HIP(hipEventSynchronize(h->tev[4 * i + 3]));
+        WMX_HIP(hipEventElapsedTime(&a, h->tev[4 * i], h->tev[4 * i + 1]));
+        WMX_HIP(hipEventElapsedTime(&b, h->tev[4 * i + 2], h->tev[4 * i + 3]));
         f += a;
         nr += b;
     }

@@ -1133,6 +1133,64 @@ int wmx_aecm_run_cohorts(wmx_aecm *h, int mode, const int16_t *d_far, long far_p
     return rc_first;
 }
 
+// stream / cohort migration, as for the float AEC
+int wmx_aecm_stream_state_bytes(const wmx_aecm *h) { return h ? (int)(sizeof(wmx::BlobHeader) + wmx::A_WORDS * 4) : WMX_EINVAL; }
+int wmx_aecm_cohort_state_bytes(const wmx_aecm *h) {
+    return h ? (int)(sizeof(wmx::BlobHeader) + sizeof(wmx::AecmCtl) + h->far.group_bytes) : WMX_EINVAL;
+}
+
+int wmx_aecm_export_stream(wmx_aecm *h, int stream_index, void *host_blob) {
+    WMX_ON_DEVICE(h);
+    using namespace wmx;
+    if (!h || !host_blob || stream_index < 0 || stream_index >= h->n_streams) return WMX_EINVAL;
+    WMX_HIP(hipDeviceSynchronize());
+    char *p = static_cast<char *>(host_blob);
+    blob_begin(p, blob_tag("AECM"), (uint32_t)h->freq, A_WORDS * 4);
+    WMX_HIP(hipMemcpy(p + sizeof(BlobHeader), h->d_state + (size_t)stream_index * A_WORDS, A_WORDS * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int wmx_aecm_import_stream(wmx_aecm *h, int stream_index, const void *host_blob, int cohort) {
+    WMX_ON_DEVICE(h);
+    using namespace wmx;
+    if (!h || !host_blob || stream_index < 0 || stream_index >= h->n_streams || cohort < -1 || cohort >= h->n_cohorts) return WMX_EINVAL;
+    const int rc = blob_check(host_blob, blob_tag("AECM"), (uint32_t)h->freq, A_WORDS * 4);
+    if (rc) return rc;
+    WMX_HIP(hipDeviceSynchronize());
+    WMX_HIP(hipMemcpy(h->d_state + (size_t)stream_index * A_WORDS, static_cast<const char *>(host_blob) + sizeof(BlobHeader), A_WORDS * 4,
+                      hipMemcpyHostToDevice));
+    if (cohort >= 0 && h->d_stream_cohort) WMX_HIP(hipMemcpy(h->d_stream_cohort + stream_index, &cohort, sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int wmx_aecm_export_cohort(wmx_aecm *h, int cohort, void *host_blob) {
+    WMX_ON_DEVICE(h);
+    using namespace wmx;
+    if (!h || !host_blob || cohort < 0 || cohort >= h->n_cohorts) return WMX_EINVAL;
+    WMX_HIP(hipDeviceSynchronize());
+    char *p = static_cast<char *>(host_blob);
+    blob_begin(p, blob_tag("AEMc"), (uint32_t)h->freq, (uint32_t)(sizeof(AecmCtl) + h->far.group_bytes));
+    p += sizeof(BlobHeader);
+    memcpy(p, &h->ctl[(size_t)cohort], sizeof(AecmCtl));
+    WMX_HIP(hipMemcpy(p + sizeof(AecmCtl), static_cast<char *>(h->d_far) + (size_t)cohort * h->far.group_bytes, h->far.group_bytes,
+                      hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int wmx_aecm_import_cohort(wmx_aecm *h, int cohort, const void *host_blob) {
+    WMX_ON_DEVICE(h);
+    using namespace wmx;
+    if (!h || !host_blob || cohort < 0 || cohort >= h->n_cohorts) return WMX_EINVAL;
+    const int rc = blob_check(host_blob, blob_tag("AEMc"), (uint32_t)h->freq, (uint32_t)(sizeof(AecmCtl) + h->far.group_bytes));
+    if (rc) return rc;
+    WMX_HIP(hipDeviceSynchronize());
+    const char *p = static_cast<const char *>(host_blob) + sizeof(BlobHeader);
+    memcpy(&h->ctl[(size_t)cohort], p, sizeof(AecmCtl));
+    WMX_HIP(hipMemcpy(static_cast<char *>(h->d_far) + (size_t)cohort * h->far.group_bytes, p + sizeof(AecmCtl), h->far.group_bytes,
+                      hipMemcpyHostToDevice));
+    return 0;
+}
+
 int wmx_aecm_cohorts(const wmx_aecm *h) { return h ? h->n_cohorts : WMX_EINVAL; }
 
 // aec_init for a cohort's shared part in the AECM build: control plane, far-end ring, farendOld, far spectrum history

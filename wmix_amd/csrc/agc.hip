@@ -620,6 +620,35 @@ int wmx_agc_create(wmx_agc **out, int n_streams, int chn, int freq, int interval
     return 0;
 }
 
+// stream migration: [header | 13 int32 fields | 8 int16 fields]; the gain table belongs to the batch, not to the stream
+int wmx_agc_stream_state_bytes(const wmx_agc *h) { return h ? (int)(sizeof(wmx::BlobHeader) + wmx::A32_WORDS * 4 + wmx::A16_WORDS * 2) : WMX_EINVAL; }
+
+int wmx_agc_export_stream(wmx_agc *h, int stream_index, void *host_blob) {
+    WMX_ON_DEVICE(h);
+    using namespace wmx;
+    if (!h || !host_blob || stream_index < 0 || stream_index >= h->n_streams) return WMX_EINVAL;
+    WMX_HIP(hipDeviceSynchronize());
+    char *p = static_cast<char *>(host_blob);
+    blob_begin(p, blob_tag("AGC "), (uint32_t)h->freq, A32_WORDS * 4 + A16_WORDS * 2);
+    p += sizeof(BlobHeader);
+    WMX_HIP(column_to_host(reinterpret_cast<int32_t *>(p), h->d_s32, A32_WORDS, h->n_streams, stream_index));
+    WMX_HIP(column_to_host(reinterpret_cast<int16_t *>(p + A32_WORDS * 4), h->d_s16, A16_WORDS, h->n_streams, stream_index));
+    return 0;
+}
+
+int wmx_agc_import_stream(wmx_agc *h, int stream_index, const void *host_blob) {
+    WMX_ON_DEVICE(h);
+    using namespace wmx;
+    if (!h || !host_blob || stream_index < 0 || stream_index >= h->n_streams) return WMX_EINVAL;
+    const int rc = blob_check(host_blob, blob_tag("AGC "), (uint32_t)h->freq, A32_WORDS * 4 + A16_WORDS * 2);
+    if (rc) return rc;
+    WMX_HIP(hipDeviceSynchronize());
+    const char *p = static_cast<const char *>(host_blob) + sizeof(BlobHeader);
+    WMX_HIP(column_from_host(h->d_s32, reinterpret_cast<const int32_t *>(p), A32_WORDS, h->n_streams, stream_index));
+    WMX_HIP(column_from_host(h->d_s16, reinterpret_cast<const int16_t *>(p + A32_WORDS * 4), A16_WORDS, h->n_streams, stream_index));
+    return 0;
+}
+
 int wmx_agc_packet_samples(const wmx_agc *h) { return h ? h->pkg * h->chn : WMX_EINVAL; }
 
 int wmx_agc_gain_table(const wmx_agc *h, int32_t *host_table32) {

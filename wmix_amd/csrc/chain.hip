@@ -7,6 +7,7 @@
 // streams: the four batched handles, one wmx_chain_process per tick launching their kernels back to back on the caller's
 // HIP stream (no host synchronisation, nothing copied), and the per-stream lifetime calls forwarded to every stage.
 // A C host (examples/host_chain.c) needs nothing else of the library for the chain.
+#include <cstdlib>
 #include <vector>
 #include "wmx_internal.h"
 
@@ -106,6 +107,9 @@ int wmx_chain_process(wmx_chain *h, const int16_t *d_far, long far_packet_stride
     }
     const int16_t *src = d_in;
     int rc = 0, rc_aec = 0;
+    // the AEC's far kernel (one wave per cohort, 10-20 us with the GPU otherwise idle) needs only the far-end packet: it runs
+    // on the AEC handle's side stream beside the noise suppressor instead of between it and the near kernel
+    if (h->ns && h->aec && !getenv("WMIX_AMD_CHAIN_NO_FORK") && (rc = wmx::aec_fork_far(h->aec, wmx::as_stream(stream))) != 0) return rc;
     if (h->ns) {
         if ((rc = wmx_ns_process(h->ns, src, d_out, n10, stream_stride, packet_stride, stream)) != 0) return rc;
         src = d_out;
@@ -164,6 +168,38 @@ int wmx_chain_reset_cohort(wmx_chain *h, int cohort, void *stream) {
     WMX_ON_DEVICE(h);
     if (!h) return WMX_EINVAL;
     return h->aec ? wmx_aec_reset_cohort(h->aec, cohort, stream) : 0;
+}
+
+// A stream's state in every stage, concatenated in the heartbeat's order (each part is the stage's own blob); the AEC cohort
+// travels separately through wmx_aec_export_cohort / wmx_aec_import_cohort on wmx_chain_aec(h).
+int wmx_chain_stream_state_bytes(const wmx_chain *h) {
+    if (!h) return WMX_EINVAL;
+    return (h->ns ? wmx_ns_stream_state_bytes(h->ns) : 0) + (h->aec ? wmx_aec_stream_state_bytes(h->aec) : 0) +
+           (h->agc ? wmx_agc_stream_state_bytes(h->agc) : 0) + (h->vad ? wmx_vad_stream_state_bytes(h->vad) : 0);
+}
+
+int wmx_chain_export_stream(wmx_chain *h, int stream_index, void *host_blob) {
+    WMX_ON_DEVICE(h);
+    if (!h || !host_blob) return WMX_EINVAL;
+    char *p = static_cast<char *>(host_blob);
+    int rc = 0;
+    if (rc == 0 && h->ns) rc = wmx_ns_export_stream(h->ns, stream_index, p), p += wmx_ns_stream_state_bytes(h->ns);
+    if (rc == 0 && h->aec) rc = wmx_aec_export_stream(h->aec, stream_index, p), p += wmx_aec_stream_state_bytes(h->aec);
+    if (rc == 0 && h->agc) rc = wmx_agc_export_stream(h->agc, stream_index, p), p += wmx_agc_stream_state_bytes(h->agc);
+    if (rc == 0 && h->vad) rc = wmx_vad_export_stream(h->vad, stream_index, p), p += wmx_vad_stream_state_bytes(h->vad);
+    return rc;
+}
+
+int wmx_chain_import_stream(wmx_chain *h, int stream_index, const void *host_blob, int cohort) {
+    WMX_ON_DEVICE(h);
+    if (!h || !host_blob) return WMX_EINVAL;
+    const char *p = static_cast<const char *>(host_blob);
+    int rc = 0;
+    if (rc == 0 && h->ns) rc = wmx_ns_import_stream(h->ns, stream_index, p), p += wmx_ns_stream_state_bytes(h->ns);
+    if (rc == 0 && h->aec) rc = wmx_aec_import_stream(h->aec, stream_index, p, cohort), p += wmx_aec_stream_state_bytes(h->aec);
+    if (rc == 0 && h->agc) rc = wmx_agc_import_stream(h->agc, stream_index, p), p += wmx_agc_stream_state_bytes(h->agc);
+    if (rc == 0 && h->vad) rc = wmx_vad_import_stream(h->vad, stream_index, p), p += wmx_vad_stream_state_bytes(h->vad);
+    return rc;
 }
 
 int wmx_chain_set_active(wmx_chain *h, const uint8_t *host_mask, void *stream) {

@@ -1073,6 +1073,33 @@ int wmx_ns_set_active(wmx_ns *h, const uint8_t *host_mask, void *stream) {
     return h->life.set_active(h->n_streams, host_mask, wmx::as_stream(stream));
 }
 
+// stream migration: [header | state words | 3 x 1000 histogram counters]
+int wmx_ns_stream_state_bytes(const wmx_ns *h) { return h ? (int)(sizeof(wmx::BlobHeader) + h->words * 4 + 3000 * 2) : WMX_EINVAL; }
+
+int wmx_ns_export_stream(wmx_ns *h, int stream_index, void *host_blob) {
+    WMX_ON_DEVICE(h);
+    if (!h || !host_blob || stream_index < 0 || stream_index >= h->n_streams) return WMX_EINVAL;
+    WMX_HIP(hipDeviceSynchronize());
+    char *p = static_cast<char *>(host_blob);
+    wmx::blob_begin(p, wmx::blob_tag("NS  "), (uint32_t)h->L, (uint32_t)(h->words * 4 + 6000));
+    p += sizeof(wmx::BlobHeader);
+    WMX_HIP(hipMemcpy(p, h->d_state + (size_t)stream_index * h->words, h->words * 4, hipMemcpyDeviceToHost));
+    WMX_HIP(hipMemcpy(p + h->words * 4, h->d_hist + (size_t)stream_index * 3000, 6000, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int wmx_ns_import_stream(wmx_ns *h, int stream_index, const void *host_blob) {
+    WMX_ON_DEVICE(h);
+    if (!h || !host_blob || stream_index < 0 || stream_index >= h->n_streams) return WMX_EINVAL;
+    const int rc = wmx::blob_check(host_blob, wmx::blob_tag("NS  "), (uint32_t)h->L, (uint32_t)(h->words * 4 + 6000));
+    if (rc) return rc;
+    WMX_HIP(hipDeviceSynchronize());
+    const char *p = static_cast<const char *>(host_blob) + sizeof(wmx::BlobHeader);
+    WMX_HIP(hipMemcpy(h->d_state + (size_t)stream_index * h->words, p, h->words * 4, hipMemcpyHostToDevice));
+    WMX_HIP(hipMemcpy(h->d_hist + (size_t)stream_index * 3000, p + h->words * 4, 6000, hipMemcpyHostToDevice));
+    return 0;
+}
+
 int wmx_ns_set_ordered(wmx_ns *h, int ordered) {
     WMX_ON_DEVICE(h);
     if (!h) return WMX_EINVAL;

@@ -209,6 +209,45 @@ struct StreamLife {
     }
 };
 
+// Stream migration (wmx_<m>_export_stream / _import_stream): a stream's complete state as a self-describing host blob --
+// a header that names the module and its layout, then the bytes.  Blocking calls (a control-plane operation): the device is
+// drained first, so the blob is the state after every call made so far.
+struct BlobHeader {
+    uint32_t magic;    // 'WMXS'
+    uint32_t module;   // four characters
+    uint32_t layout;   // module-defined: sizes that must agree between exporter and importer (e.g. words per stream, rate)
+    uint32_t bytes;    // payload bytes behind the header
+};
+constexpr uint32_t kBlobMagic = 0x53584d57u;
+inline uint32_t blob_tag(const char (&t)[5]) { return (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24); }
+inline void blob_begin(void *blob, uint32_t module, uint32_t layout, uint32_t bytes) {
+    BlobHeader hd{kBlobMagic, module, layout, bytes};
+    memcpy(blob, &hd, sizeof(hd));
+}
+// 0, or WMX_ESTATE when the blob was made by another module / layout
+inline int blob_check(const void *blob, uint32_t module, uint32_t layout, uint32_t bytes) {
+    BlobHeader hd;
+    memcpy(&hd, blob, sizeof(hd));
+    if (hd.magic != kBlobMagic || hd.module != module || hd.layout != layout || hd.bytes != bytes) {
+        set_error("import: the blob is not a state of this module / format (module %08x layout %u bytes %u, expected %08x %u %u)", hd.module,
+                  hd.layout, hd.bytes, module, layout, bytes);
+        return WMX_ESTATE;
+    }
+    return 0;
+}
+// field-major device arrays ([field][n_streams]): one stream's column to / from a packed host array
+template <class T>
+inline hipError_t column_to_host(T *host, const T *dev, int fields, int n_streams, int stream) {
+    return hipMemcpy2D(host, sizeof(T), dev + stream, (size_t)n_streams * sizeof(T), sizeof(T), (size_t)fields, hipMemcpyDeviceToHost);
+}
+template <class T>
+inline hipError_t column_from_host(T *dev, const T *host, int fields, int n_streams, int stream) {
+    return hipMemcpy2D(dev + stream, (size_t)n_streams * sizeof(T), host, sizeof(T), sizeof(T), (size_t)fields, hipMemcpyHostToDevice);
+}
+
+// chain.hip -> aec.hip: let the far kernel of the next wmx_aec_run_* call start at this point of `stream` (see aec.hip)
+int aec_fork_far(wmx_aec *h, hipStream_t stream);
+
 // wmix_pcm_zoom's cursor walk (src/wmix.c:139-222) as a gather list: out int16 i <- in int16 idx[i]; identical formats
 // give the identity (the reference's memcpy branch).  Defined in mix.hip.
 void zoom_gather_list(int inChn, int inFreq, uint32_t inLen, int outChn, int outFreq, std::vector<int32_t> &idx);

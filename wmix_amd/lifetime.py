@@ -38,3 +38,38 @@ class Lifetime:
             assert m.shape == (self.n_streams,)
             rc = getattr(lib(), "wmx_%s_set_active" % self._mod)(self._h, m.ctypes.data, _stream())
         check(rc, "wmx_%s_set_active" % self._mod)
+
+    # ---- migration between batches / GPUs: a stream's complete state as a host blob (blocking calls)
+    def export_stream(self, stream_index):
+        n = getattr(lib(), "wmx_%s_stream_state_bytes" % self._mod)(self._h)
+        blob = np.zeros(n, np.uint8)
+        check(getattr(lib(), "wmx_%s_export_stream" % self._mod)(self._h, int(stream_index), blob.ctypes.data), "export_stream")
+        return blob
+
+    def import_stream(self, stream_index, blob, cohort=None):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        f = getattr(lib(), "wmx_%s_import_stream" % self._mod)
+        if self._mod in ("aec", "aecm", "chain"):
+            rc = f(self._h, int(stream_index), blob.ctypes.data, -1 if cohort is None else int(cohort))
+        else:
+            assert cohort is None
+            rc = f(self._h, int(stream_index), blob.ctypes.data)
+        check(rc, "wmx_%s_import_stream" % self._mod)
+
+    def _cohort_owner(self):
+        """(module name, handle) that owns the cohorts: the AEC inside a chain, else this handle"""
+        if self._mod == "chain":
+            return "aec", lib().wmx_chain_aec(self._h)
+        return self._mod, self._h
+
+    def export_cohort(self, cohort):
+        m, h = self._cohort_owner()
+        n = getattr(lib(), "wmx_%s_cohort_state_bytes" % m)(h)
+        blob = np.zeros(n, np.uint8)
+        check(getattr(lib(), "wmx_%s_export_cohort" % m)(h, int(cohort), blob.ctypes.data), "export_cohort")
+        return blob
+
+    def import_cohort(self, cohort, blob):
+        m, h = self._cohort_owner()
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        check(getattr(lib(), "wmx_%s_import_cohort" % m)(h, int(cohort), blob.ctypes.data), "import_cohort")
