@@ -1138,10 +1138,20 @@ def _pmc_traffic(kernel, n_frames, tag="chain"):
 
 
 def _pmc_issue(kernel, n_frames, tag, launch_ms):
-    """Vector-ALU issue floor of `kernel` from the committed SQ_INSTS_VALU count (profiles/rNN/<tag>_sq_pmc.json, same
-    command and stream count): a wave64 VALU instruction occupies its SIMD for 4 cycles, the chip has 256 CUs x 4 SIMDs at
-    2.4 GHz (MI355X_MICROARCH.md), so floor = insts x 4 / (1024 x 2.4e9).  `frac` = floor / the launch time measured in
-    this run: how close the kernel is to issuing a vector instruction on every SIMD every cycle.  None without a profile."""
+    """Vector-issue accounting of `kernel` (the per-stream DSP kernels are bound by instruction issue, not by HBM).
+
+    Inputs, all committed under profiles/rNN/ and made on the GPU box by profiles/tools/profile_workload.sh:
+      <tag>_sq_pmc.json       SQ_INSTS_VALU per launch (dynamic count, rocprofv3 PMC pass of this very command)
+      issue_costs.json        SIMD time per wave64 instruction of each class at W resident waves per SIMD, every CU busy
+                              (tools_dev/ubench/issue_cost.hip) -- round 2 priced every instruction at a constant 4 cycles,
+                              which misquoted the guide
+      <tag>_issue_model.json  the kernel's ISA class histogram priced with that table at its occupancy
+                              (tools_dev/issue_model.py)
+    Two figures:
+      lower_bound  every vector instruction at the CHEAPEST measured price of any class at the kernel's occupancy: no
+                   launch can issue its instructions faster, whatever their mix -- frac = bound / measured launch <= 1;
+      mix_estimate the same count at the histogram's mean price: what issue alone is expected to take.  The histogram is static
+                   (start-up and rare-update code included), so this one is an estimate, not a bound."""
     import glob
     here = os.path.dirname(os.path.abspath(__file__))
     for path in sorted(glob.glob(os.path.join(here, "profiles", "r*", tag + "_sq_pmc.json")), reverse=True):
@@ -1153,9 +1163,18 @@ def _pmc_issue(kernel, n_frames, tag, launch_ms):
             base = kernel.split("<")[0]
             hit = [v for k, v in d.items() if k.split("<")[0] == base]
             insts = hit[0]["mean"]["SQ_INSTS_VALU"]
-            floor_ms = insts * 4 / (1024 * 2.4e9) * 1e3
-            return {"valu_insts_per_frame": round(insts / n_frames, 1), "floor_ms": round(floor_ms, 5),
-                    "frac": round(floor_ms / launch_ms, 4), "source": os.path.relpath(path, here)}
+            out = {"valu_insts_per_frame": round(insts / n_frames, 1), "source": os.path.relpath(path, here)}
+            mpath = path.replace("_sq_pmc.json", "_issue_model.json")
+            if os.path.exists(mpath):
+                m = json.load(open(mpath))
+                n_simd = 1024.0  # 256 CUs x 4 SIMDs
+                lb = insts * m["cheapest_valu"]["ns"] / n_simd * 1e-6
+                est = insts * m["mean_ns_per_valu"] / n_simd * 1e-6
+                out.update({"waves_per_simd": m["waves_per_simd"], "cheapest_ns_per_valu": m["cheapest_valu"]["ns"],
+                            "mean_ns_per_valu": m["mean_ns_per_valu"], "lower_bound_ms": round(lb, 5),
+                            "lower_bound_frac": round(lb / launch_ms, 4), "mix_estimate_ms": round(est, 5),
+                            "mix_estimate_frac": round(est / launch_ms, 4), "model": os.path.relpath(mpath, here)})
+            return out
         except Exception:
             continue
     return None

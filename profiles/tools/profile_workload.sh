@@ -7,7 +7,7 @@
 # counts; LDS bank conflicts + occupancy.  Summaries land in gpurun_out/<round>/ -- copy the ones to be judged into
 # profiles/<round>/.
 set -u
-ROUND=${1:-r02}; WL=${2:-chain}; NFR=${3:-65536}; shift 3 || true
+ROUND=${1:-r03}; WL=${2:-chain}; NFR=${3:-65536}; shift 3 || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$ROUND/$WL
 mkdir -p "$OUT"

@@ -133,8 +133,15 @@ def model(costs, stem, pattern, waves):
     col = ws.index(waves) if waves in ws else min(range(len(ws)), key=lambda i: abs(ws[i] - waves))
     hist = collections.Counter()
     other = collections.Counter()
+    prev_vop2_select = False
     for m in ins:
         c = classify(m)
+        if c is not None:
+            # a VOP2 select directly behind another one in the vector stream has its own (much higher) measured price
+            vop2_select = m in ("v_cndmask_b32_e32", "v_cndmask_b32_dpp", "v_cndmask_b32_sdwa")
+            if vop2_select and prev_vop2_select:
+                c = "v_cndmask_b32_vop2_behind_vop2"
+            prev_vop2_select = vop2_select
         if c is None:
             other["salu" if m.startswith("s_") else ("lds" if m.startswith("ds_") else ("vmem" if m.startswith(("global", "buffer", "flat", "scratch")) else "other"))] += 1
         else:
@@ -148,9 +155,12 @@ def model(costs, stem, pattern, waves):
         ns += k / n * e["ns"][col]
         cyc += k / n * e["cycles"][col]
     plain = costs["classes"]["v_add_f32"]
+    valu = {c: e for c, e in costs["classes"].items() if c.startswith("v_")}
+    cheapest = min(valu, key=lambda c: valu[c]["ns"][col])
     return {"kernel": name, "object": stem + ".o", "waves_per_simd": ws[col], "static_valu_instructions": n,
             "static_other_instructions": dict(other), "mean_ns_per_valu": round(ns, 4), "mean_cycles_per_valu": round(cyc, 3),
             "plain_v_add_f32": {"ns": plain["ns"][col], "cycles": plain["cycles"][col]},
+            "cheapest_valu": {"class": cheapest, "ns": valu[cheapest]["ns"][col]},
             "classes": classes, "costs_from": costs.get("device", "?")}
 
 

@@ -15,16 +15,15 @@
 #include <vector>
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-#define R8(body) body body body body body body body body
 enum Cls {
-    V_ADD_F32, V_MUL_F32, V_FMA_F32, V_MOV_B32, V_CNDMASK, V_CMP_F32, V_ADD_U32, V_LSHL_ADD, V_MUL_LO_U32, V_MAD_U32_U24, V_MUL_U32_U24,
+    V_ADD_F32, V_MUL_F32, V_FMA_F32, V_MOV_B32, V_CNDMASK, V_CNDMASK_PAIR, V_CMP_F32, V_ADD_U32, V_LSHL_ADD, V_MUL_LO_U32, V_MAD_U32_U24, V_MUL_U32_U24,
     V_PK_ADD_F32, V_PK_MUL_F32, V_PK_FMA_F32, V_MOV_DPP, V_ADD_DPP, V_PERMLANE16_SWAP, V_PERMLANE32_SWAP, V_READLANE, V_READFIRSTLANE,
     V_RCP_F32, V_SQRT_F32, V_RSQ_F32, V_EXP_F32, V_LOG_F32, V_ADD_F64, V_MUL_F64, V_FMA_F64, V_RCP_F64, V_CVT_F32_I32, V_CVT_F64_F32,
     V_DIV_SCALE_F32, V_DIV_FMAS_F32, V_DIV_FIXUP_F32, V_LDEXP_F32, V_MAX_F32, V_BFE_I32, V_AND_B32, V_LSHLREV_B64, S_NOP0, S_MOV_B32,
     S_ADD_U32, DS_READ_B32, DS_READ_B64, DS_READ_B128, DS_WRITE_B32, DS_WRITE_B64, DS_BPERMUTE, N_CLS
 };
 static const char *kName[N_CLS] = {
-    "v_add_f32", "v_mul_f32", "v_fma_f32", "v_mov_b32", "v_cndmask_b32", "v_cmp_f32", "v_add_u32", "v_lshl_add_u32", "v_mul_lo_u32",
+    "v_add_f32", "v_mul_f32", "v_fma_f32", "v_mov_b32", "v_cndmask_b32", "v_cndmask_b32_vop2_behind_vop2", "v_cmp_f32", "v_add_u32", "v_lshl_add_u32", "v_mul_lo_u32",
     "v_mad_u32_u24", "v_mul_u32_u24", "v_pk_add_f32", "v_pk_mul_f32", "v_pk_fma_f32", "v_mov_b32_dpp", "v_add_f32_dpp", "v_permlane16_swap",
     "v_permlane32_swap", "v_readlane_b32", "v_readfirstlane_b32", "v_rcp_f32", "v_sqrt_f32", "v_rsq_f32", "v_exp_f32", "v_log_f32",
     "v_add_f64", "v_mul_f64", "v_fma_f64", "v_rcp_f64", "v_cvt_f32_i32", "v_cvt_f64_f32", "v_div_scale_f32", "v_div_fmas_f32",
@@ -38,7 +37,7 @@ __global__ void k(float *out, unsigned long long *stamp, int iters) {
     float a0 = threadIdx.x + 1.5f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     v2f p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7};
     double d0 = a0, d1 = a1, d2 = a2, d3 = a3;
-    const float c = out[0] + 1.0000001f;
+    const float c = out[0] + 1.0000001f, c2 = out[0] + 2.f;
     const v2f cc = {c, c};
     const double dc = c;
     int s0 = 0, s1 = 0;
@@ -47,7 +46,6 @@ __global__ void k(float *out, unsigned long long *stamp, int iters) {
     v4f q = {a0, a1, a2, a3};
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int i = 0; i < iters; i++) {
-#define OP8(txt) asm volatile(txt "\n" txt##_1 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c))
         if constexpr (C == V_ADD_F32)
             asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
@@ -61,8 +59,14 @@ __global__ void k(float *out, unsigned long long *stamp, int iters) {
             asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %4\n v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %0"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
         else if constexpr (C == V_CNDMASK)
-            asm volatile("v_cndmask_b32 %0, %1, %2, vcc\n v_cndmask_b32 %1, %2, %3, vcc\n v_cndmask_b32 %2, %3, %4, vcc\n v_cndmask_b32 %3, %4, %5, vcc\n v_cndmask_b32 %4, %5, %6, vcc\n v_cndmask_b32 %5, %6, %7, vcc\n v_cndmask_b32 %6, %7, %0, vcc\n v_cndmask_b32 %7, %0, %1, vcc"
-                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "vcc");
+            // a select as the kernels mostly have it: the VOP3 encoding, or a VOP2 one behind some other vector instruction (same price)
+            asm volatile("v_cndmask_b32_e64 %0, %8, %9, vcc\n v_cndmask_b32_e64 %1, %8, %9, vcc\n v_cndmask_b32_e64 %2, %8, %9, vcc\n v_cndmask_b32_e64 %3, %8, %9, vcc\n v_cndmask_b32_e64 %4, %8, %9, vcc\n v_cndmask_b32_e64 %5, %8, %9, vcc\n v_cndmask_b32_e64 %6, %8, %9, vcc\n v_cndmask_b32_e64 %7, %8, %9, vcc"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(c2) : "vcc");
+        else if constexpr (C == V_CNDMASK_PAIR)
+            // a VOP2 select (implicit vcc) directly behind another VOP2 select: ~20 cycles of SIMD time whatever the occupancy
+            // (tools_dev/ubench/cnd_test.hip has the variants: a scalar instruction in between does not help, a vector one does)
+            asm volatile("v_cndmask_b32 %0, %8, %9, vcc\n v_cndmask_b32 %1, %8, %9, vcc\n v_cndmask_b32 %2, %8, %9, vcc\n v_cndmask_b32 %3, %8, %9, vcc\n v_cndmask_b32 %4, %8, %9, vcc\n v_cndmask_b32 %5, %8, %9, vcc\n v_cndmask_b32 %6, %8, %9, vcc\n v_cndmask_b32 %7, %8, %9, vcc"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(c2) : "vcc");
         else if constexpr (C == V_CMP_F32)
             asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %2\n v_cmp_lt_f32 vcc, %2, %3\n v_cmp_lt_f32 vcc, %3, %4\n v_cmp_lt_f32 vcc, %4, %5\n v_cmp_lt_f32 vcc, %5, %6\n v_cmp_lt_f32 vcc, %6, %7\n v_cmp_lt_f32 vcc, %7, %0"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "vcc");
@@ -198,16 +202,17 @@ struct Res {
 
 template <int C>
 Res run(int waves_per_simd) {
-    // occupancy is pinned through dynamic LDS: one workgroup of 4 x W waves per CU (W <= 4) or two of 16 waves (W = 8)
+    // occupancy is pinned through dynamic LDS, in the shape the library's kernels have: four-wave workgroups (one wave per SIMD),
+    // W of them per CU (a CU deals a workgroup's waves to its SIMDs starting at the same one: 10-wave workgroups would load them 3/3/2/2)
     float *out;
     unsigned long long *stamp;
-    (void)hipMalloc(&out, 4 * (1 + 512 * 1024));
+    (void)hipMalloc(&out, 4 * (1 + 2048 * 1024));
     (void)hipMalloc(&stamp, 16);
     (void)hipMemset(out, 0, 4);
     const int iters = 20000;
-    const int per_cu = waves_per_simd > 4 ? 2 : 1;
-    const int threads = 256 * waves_per_simd / per_cu;
-    const size_t lds = per_cu == 2 ? 64 * 1024 : 96 * 1024;
+    const int per_cu = waves_per_simd;
+    const int threads = 256;
+    const size_t lds = ((160 * 1024) / per_cu) & ~(size_t)255;
     (void)hipFuncSetAttribute((const void *)k<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
