@@ -686,7 +686,9 @@ class ChainWorkload:
         worst, n, n_off = 0, 0, 0
         for col, s in enumerate(self.sample):
             near = np.concatenate([self.base[s % 256, (k * P + p) % self.K] for k in range(T) for p in range(P)])
-            want = loader.run_chain(port, 1, self.freq, 5, stages, far, near, self.pkt, prefix="orc").reshape(T, P, self.pkt)
+            # one oracle call per step of P packets, like wmx_chain_process: ns / aec / agc loop over the packets of a call, vad_process
+            # analyses and attenuates the call's FIRST packet only -- the daemon's own 20 ms call is P = 2
+            want = loader.run_chain(port, 1, self.freq, 5, stages, far, near, self.pkt * P, prefix="orc").reshape(T, P, self.pkt)
             for k, got in self.rec:
                 d = np.abs(got[:, col].cpu().numpy().astype(np.int32) - want[k].astype(np.int32))
                 worst, n, n_off = max(worst, int(d.max())), n + P, n_off + int((d > 0).sum())
