@@ -306,6 +306,24 @@ __device__ __forceinline__ float uniform_ld(const float *p) {
     return *reinterpret_cast<const float __attribute__((address_space(4))) *>(reinterpret_cast<size_t>(p));
 }
 
+// A wave-uniform row of the far-end history: the row's address is formed on the scalar unit and stays an SGPR pair (the empty
+// asm keeps the compiler from folding the row offset into a per-lane 64-bit address: one v_lshl_add_u64 per row otherwise), so
+// `row[lane]` is a global load in its SGPR-base + 32-bit-VGPR-offset form.
+// (The asm also strips the pointer of its address space -- loads through it would become FLAT instructions, which count
+// against the LDS counter as well and have no SGPR-base form -- so the row is handed on as an explicit global pointer.)
+typedef const float __attribute__((address_space(1))) *GlobalRow;
+__device__ __forceinline__ GlobalRow uniform_row(const float *base, int row, int row_words) {
+    const float *p = base + (size_t)row * row_words;
+    asm volatile("" : "+s"(p));
+    return (GlobalRow)p;
+}
+
+// element `word` + lane of such a row: the lane's byte offset is a 32-bit unsigned VGPR value added to the SGPR row pointer,
+// which is exactly the operand pair of global_load ... v_off, s[row] offset:imm
+__device__ __forceinline__ float row_ld(GlobalRow row, unsigned lane_bytes, int word) {
+    return *(GlobalRow)((const char __attribute__((address_space(1))) *)(row + word) + lane_bytes);
+}
+
 // out of line for the same reason as libm_dev.h's pow_d: inlined, its fp64 temporaries push the block over 128 VGPRs
 __device__ __noinline__ static float aec_powf(float x, float y, const PowTables *__restrict__ t) { return fast_pow(x, y, t); }
 
@@ -321,6 +339,9 @@ __device__ __forceinline__ int opaque_lane(int x) {
 #ifndef WMX_AEC_HOIST  // experiment switch: let the compiler keep lane-derived addresses in VGPRs (needs a lower occupancy)
     asm volatile("" : "+v"(x));
 #endif
+    // the asm hides the value's range with its origin; restated, a lane index used as an array offset is a zero-extended 32-bit
+    // offset and global loads of wave-uniform rows take the SGPR-base + VGPR-offset form instead of a 64-bit address per row
+    __builtin_assume(x >= 0 && x < 64);
     return x;
 }
 
@@ -362,7 +383,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
 
     // ---- near block (aec_core.c:1177-1195).  d = [prev | cur]; its plain transform feeds the near power, its
     //      windowed transform the coherence estimates of the NLP (aec_core.c:934-949): both now, side by side.
-    const float xpow_lane = F.xpow_seq[(n % kAecHist) * BP + lane];  // far power of this block (ScaleErrorSignal), requested early
+    const float xpow_lane = row_ld(uniform_row(F.xpow_seq, n % kAecHist, BP), 4u * (unsigned)lane, 0);  // far power of this block (ScaleErrorSignal), requested early
     W.cur[lane] = AEC_ST(AS_NEAR_RING + ring_at(bp.near_rd, lane));
     wave_sync();
     AEC_PROF(0);
@@ -374,9 +395,9 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
         float xr[12], xi[12];
 #pragma unroll
         for (int p = 0; p < 12; p++) {
-            const float *X = F.hist + (size_t)((n - p + kAecHist) % kAecHist) * 130;
-            xr[p] = X[lane];
-            xi[p] = X[kAecPart1 + lane];
+            const GlobalRow X = uniform_row(F.hist, (n - p + kAecHist) % kAecHist, 130);
+            xr[p] = row_ld(X, 4u * (unsigned)lane, 0);
+            xi[p] = row_ld(X, 4u * (unsigned)lane, kAecPart1);
         }
         float yr = 0.f, yi = 0.f, y64 = 0.f;
 #pragma unroll
@@ -517,9 +538,9 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
     for (int pass = 0; pass < 2; pass++) {
         const int base = 8 * pass, cnt = pass == 0 ? 8 : 4;
         if (pass == 1) {
-            const float *Xw = F.hist_w + (size_t)((n - delayIdx0 + kAecHist) % kAecHist) * 130;
-            xwr_pre = Xw[lane];
-            xwi_pre = Xw[kAecPart1 + lane];
+            const GlobalRow Xw = uniform_row(F.hist_w, (n - delayIdx0 + kAecHist) % kAecHist, 130);
+            xwr_pre = row_ld(Xw, 4u * (unsigned)lane, 0);
+            xwi_pre = row_ld(Xw, 4u * (unsigned)lane, kAecPart1);
         }
         float nyq_r = 0.f, nyq_i = 0.f;  // Nyquist bin of the far block of partition base + lane (lanes < cnt)
         if (lane < cnt) {
@@ -532,9 +553,9 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 if (q >= cnt) continue;
-                const float *X = F.hist + (size_t)((n - (base + q) + kAecHist) % kAecHist) * 130;
-                xr[q] = X[lane];
-                xi[q] = -X[kAecPart1 + lane];
+                const GlobalRow X = uniform_row(F.hist, (n - (base + q) + kAecHist) % kAecHist, 130);
+                xr[q] = row_ld(X, 4u * (unsigned)lane, 0);
+                xi[q] = -row_ld(X, 4u * (unsigned)lane, kAecPart1);
             }
 #pragma unroll
             for (int q = 0; q < 8; q++) {
@@ -1094,16 +1115,19 @@ __global__ __attribute__((amdgpu_waves_per_eu(WMX_AEC_WAVES, WMX_AEC_WAVES))) __
     AEC_PROF(11);  // includes the blocks; subtract 0..9
     // ---- state out (addresses recomputed: keeping the ones of the load alive across the packet loop costs 17 VGPRs)
     asm volatile("" : "+s"(gst));
+    // (the asm strips the address space with the value: restated, or the 26 stores below are FLAT stores)
+    float __attribute__((address_space(1))) *gout = (float __attribute__((address_space(1))) *)gst;
     const int ln = opaque_lane(lane);  // same for the lane-derived offsets (otherwise kept alive, or spilled, across the loop)
 #pragma unroll
     for (int p = 0; p < 12; p++) {
-        gst[AS_W_RE + p * BP + ln] = taps.re[p];
-        gst[AS_W_IM + p * BP + ln] = taps.im[p];
+        gout[AS_W_RE + p * BP + ln] = taps.re[p];
+        gout[AS_W_IM + p * BP + ln] = taps.im[p];
     }
-    if (ln < 12) gst[AS_W_RE + ln * BP + kAecPart] = W.wn[ln];
+    if (ln < 12) gout[AS_W_RE + ln * BP + kAecPart] = W.wn[ln];
     {
-        float4 *g4 = reinterpret_cast<float4 *>(gst + AS_LDS0);
-        const float4 *s4 = reinterpret_cast<const float4 *>(W.st);
+        typedef float v4f __attribute__((ext_vector_type(4)));  // a native vector: HIP's float4 class assigns through generic pointers only
+        v4f __attribute__((address_space(1))) *g4 = (v4f __attribute__((address_space(1))) *)(gout + AS_LDS0);
+        const v4f *s4 = reinterpret_cast<const v4f *>(W.st);
         for (int i = ln; i < AS_LDS_WORDS / 4; i += 64) g4[i] = s4[i];
     }
     AEC_PROF(12);
