@@ -263,6 +263,32 @@ void zoom_gather_list(int inChn, int inFreq, uint32_t inLen, int outChn, int out
 __device__ __forceinline__ void touch_line(const void *p, int &sink) {
     asm volatile("global_load_ubyte %0, %1, off" : "+v"(sink) : "v"(p) : "memory");
 }
+// ---- wave-uniform rows in HBM: SGPR row pointer + 32-bit lane offset
+// A wave-per-stream kernel reads and writes its stream's state as `st[ARRAY + bin]` with a wave-uniform `st`.  Left to itself
+// the compiler folds everything into one 64-bit per-lane address per access (v_lshl_add_u64, plus a v_add_co / v_addc_co pair
+// when the array lies beyond the 4 KB immediate range) -- vector instructions in kernels that are bound by vector issue.
+// global_row() forms the array's address on the scalar unit and keeps it an SGPR pair (the empty asm stops the folding; it
+// also strips the address space, which is restated -- accesses through a laundered generic pointer become FLAT instructions);
+// row_ld / row_st add the lane's 32-bit byte offset: global_load / global_store in their `v_off, s[row]` form.
+typedef float __attribute__((address_space(1))) *GlobalF;
+typedef const float __attribute__((address_space(1))) *GlobalCF;
+__device__ __forceinline__ GlobalF global_row(float *uniform_base, int word) {
+    float *p = uniform_base + word;
+    asm("" : "+s"(p));
+    return (GlobalF)p;
+}
+__device__ __forceinline__ GlobalCF global_row(const float *uniform_base, int word) {
+    const float *p = uniform_base + word;
+    asm("" : "+s"(p));
+    return (GlobalCF)p;
+}
+__device__ __forceinline__ float row_ld(GlobalCF row, unsigned idx) {
+    return *(GlobalCF)((const char __attribute__((address_space(1))) *)row + 4u * idx);
+}
+__device__ __forceinline__ void row_st(GlobalF row, unsigned idx, float v) {
+    *(GlobalF)((char __attribute__((address_space(1))) *)row + 4u * idx) = v;
+}
+
 // refill of block-layout state ([stream][words]) for a list of streams: one workgroup per listed stream
 template <class T>
 __global__ void fill_rows_idx(T *state, const T *tmpl, int words, const int32_t *idx, int n_idx) {
