@@ -295,8 +295,9 @@ struct alignas(16) AecWaveLds {
 #define AEC_ST(x) W.st[(x) - AS_LDS0]
 
 // The adaptive filter: lane k holds bin k of all 12 partitions (wfBuf, aec_core_internal.h:78)
+// as (re, im) pairs: the complex products and the tap update are packed fp32 operations on them
 struct AecTaps {
-    float re[12], im[12];
+    v2f t[12];
 };
 
 // wave-uniform read of far-end data (the address must be the same in every lane): through the constant address space it
@@ -399,19 +400,20 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
             xr[p] = row_ld(X, 4u * (unsigned)lane, 0);
             xi[p] = row_ld(X, 4u * (unsigned)lane, kAecPart1);
         }
-        float yr = 0.f, yi = 0.f, y64 = 0.f;
+        float y64 = 0.f;
+        v2f y2 = v2f{0.f, 0.f};
 #pragma unroll
         for (int p = 0; p < 12; p++) {
             const float *X = F.hist + (size_t)((n - p + kAecHist) % kAecHist) * 130;
-            yr += xr[p] * taps.re[p] - xi[p] * taps.im[p];
-            yi += xr[p] * taps.im[p] + xi[p] * taps.re[p];
+            // (yr, yi) += (xr*wr - xi*wi, xr*wi + xi*wr): cmul_w is those four products and two sums, as three packed instructions
+            y2 = y2 + cmul_w(xr[p], xi[p], taps.t[p]);
             const float nr = uniform_ld(X + kAecPart), ni = uniform_ld(X + kAecPart1 + kAecPart);  // ni == 0, wfBuf[1][.][64] == 0
             y64 += nr * W.wn[p] - ni * 0.f;                                                    // used by lane 0 only
         }
         // ---- error e = d - y (aec_core.c:1286-1297): y = second half of the inverse transform of the packed spectrum
         //      (lane 0 carries (bin 0, bin 64)), one point per lane in registers: lanes 32..63 end up with y[2(l-32)], +1
         AEC_PROF(1);
-        v2f pt = rdft128_inv_point_lanes(v2f{yr, lane == 0 ? y64 : yi}, &K.tab, lane);
+        v2f pt = rdft128_inv_point_lanes(v2f{y2.x, lane == 0 ? y64 : y2.y}, &K.tab, lane);
         pt = fft64_lanes<true>(pt, &K.tab, lane);
         if (lane >= 32) {
             const int i = 2 * (lane - 32);
@@ -560,7 +562,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 if (q >= cnt) continue;
-                st_pt(W.fa[q], lane, v2f{xr[q] * efr - xi[q] * efi, xr[q] * efi + xi[q] * efr});
+                st_pt(W.fa[q], lane, cmul_w(xr[q], xi[q], v2f{efr, efi}));  // (xr*efr - xi*efi, xr*efi + xi*efr)
             }
         }
         wave_sync();
@@ -619,8 +621,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
             for (int q = 0; q < 8; q++) {
                 if (q >= cnt) continue;
                 const v2f d = rdft128_fwd_bin_u(W.fa[q], cf, lane);
-                taps.re[base + q] += d.x;
-                taps.im[base + q] += d.y;  // lane 0 adds 0 (wfBuf[1][pos] is never touched, aec_core.c:262-268)
+                taps.t[base + q] = taps.t[base + q] + d;  // lane 0's imaginary half adds 0 (wfBuf[1][pos] is never touched, aec_core.c:262-268)
             }
             if (lane < cnt) W.wn[base + lane] += fa_row(W, lane)[0] - fa_row(W, lane)[1];  // wfBuf[0][pos + 64] += fft[1]: bin 64 = a[0] - a[1]
         }
@@ -639,7 +640,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
 #pragma unroll
         for (int p = 0; p < 12; p++) {
             float *dst = W.fa[p >> 1] + (p & 1) * 66;
-            dst[lane] = taps.re[p] * taps.re[p] + taps.im[p] * taps.im[p];
+            dst[lane] = taps.t[p].x * taps.t[p].x + taps.t[p].y * taps.t[p].y;
             if (lane == 0) dst[64] = W.wn[p] * W.wn[p] + 0.f * 0.f;
         }
         wave_sync();
@@ -757,8 +758,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
     if (reset_filter) {  // memset(wfBuf, 0)
 #pragma unroll
         for (int p = 0; p < 12; p++) {
-            taps.re[p] = 0.f;
-            taps.im[p] = 0.f;
+            taps.t[p] = v2f{0.f, 0.f};
             if (lane == 0) W.wn[p] = 0.f;
         }
     }
@@ -1026,8 +1026,8 @@ __global__ __attribute__((amdgpu_waves_per_eu(WMX_AEC_WAVES, WMX_AEC_WAVES))) __
     AecTaps taps;
 #pragma unroll
     for (int p = 0; p < 12; p++) {
-        taps.re[p] = gst[AS_W_RE + p * BP + lane];
-        taps.im[p] = gst[AS_W_IM + p * BP + lane];
+        taps.t[p].x = gst[AS_W_RE + p * BP + lane];
+        taps.t[p].y = gst[AS_W_IM + p * BP + lane];
     }
     const float wn0 = gst[AS_W_RE + (lane < 12 ? lane : 0) * BP + kAecPart];
     constexpr int kChunks = (AS_LDS_WORDS / 4 + 63) / 64;
@@ -1120,8 +1120,8 @@ __global__ __attribute__((amdgpu_waves_per_eu(WMX_AEC_WAVES, WMX_AEC_WAVES))) __
     const int ln = opaque_lane(lane);  // same for the lane-derived offsets (otherwise kept alive, or spilled, across the loop)
 #pragma unroll
     for (int p = 0; p < 12; p++) {
-        gout[AS_W_RE + p * BP + ln] = taps.re[p];
-        gout[AS_W_IM + p * BP + ln] = taps.im[p];
+        gout[AS_W_RE + p * BP + ln] = taps.t[p].x;
+        gout[AS_W_IM + p * BP + ln] = taps.t[p].y;
     }
     if (ln < 12) gout[AS_W_RE + ln * BP + kAecPart] = W.wn[ln];
     {
