@@ -82,7 +82,9 @@ struct AecFarBufs {
     float *pre;      // [kAecPreLen] time-domain pre-buffer ring
     float *ring;     // [kAecFarBlocks][130] plain spectra  (re[65] | im[65])
     float *ring_w;   // [kAecFarBlocks][130] windowed spectra
-    float *hist;     // [kAecHist][130] consumed plain spectra
+    float *hist;     // [2 * kAecHist][130] consumed plain spectra, every one twice (rows r and r + kAecHist): the blocks n, n - 1, ...
+                     //   are the rows R, R - 1, ... below R = n % kAecHist + kAecHist without a wrap, see hist_ld()
+    float *nyq;      // [2 * kAecHist][2]   bin 64 (re, im) of those rows, side by side for the scalar loads
     float *hist_w;   // [kAecHist][130] consumed windowed spectra
     float *xpow_seq; // [kAecHist][BP]  xPow after each consumed block
     float *xpow;     // [BP] running xPow
@@ -91,7 +93,7 @@ struct AecFarBufs {
 // the buffers of far-end group g (wave-uniform g: pointer arithmetic on scalars)
 __device__ __forceinline__ AecFarBufs far_group(const AecFarBufs &F, int g) {
     const size_t o = (size_t)g * F.group_words;
-    return AecFarBufs{F.pre + o, F.ring + o, F.ring_w + o, F.hist + o, F.hist_w + o, F.xpow_seq + o, F.xpow + o, F.group_words};
+    return AecFarBufs{F.pre + o, F.ring + o, F.ring_w + o, F.hist + o, F.nyq + o, F.hist_w + o, F.xpow_seq + o, F.xpow + o, F.group_words};
 }
 
 struct AecConsts {  // copied to LDS by both kernels
@@ -240,9 +242,11 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const flo
                     const int i = lane + 64 * j;
                     if (i < 130) {
                         F.hist[hs * 130 + i] = sp[k][j];
+                        F.hist[(hs + kAecHist) * 130 + i] = sp[k][j];
                         F.hist_w[hs * 130 + i] = spw[k][j];
                     }
                 }
+                if (lane < 4) F.nyq[2 * (hs + (lane >> 1) * kAecHist) + (lane & 1)] = (lane & 1) ? xi64[k] : xr64[k];
                 {
                     const float xr = sp[k][0], xi = xi_b[k];
                     const float far_spectrum = (xr * xr) + (xi * xi);
@@ -325,6 +329,27 @@ __device__ __forceinline__ float row_ld(GlobalRow row, unsigned lane_bytes, int 
     return *(GlobalRow)((const char __attribute__((address_space(1))) *)(row + word) + lane_bytes);
 }
 
+// The far-end history rows of one block.  R = n % kAecHist + kAecHist is the row of the block consumed now and R - p the row
+// consumed p blocks earlier -- the history holds every row twice, kAecHist apart, so the rows of the 12 partitions never wrap.
+// The lane's byte offset into row R (less kHistMid) is ONE vector register per block and every (partition, word) of the
+// history an immediate of the load: global_load_dword v, v_off, s[hist] offset:imm.  No address instruction per row, on
+// either unit: formed on the scalar unit a row cost 12 scalar instructions (index modulo the ring, times the row size, a 64-bit
+// add), and a scalar instruction occupies a compute unit's one scalar ALU for about as long as two vector instructions
+// occupy a SIMD (tools_dev/ubench/issue_spread.hip).
+constexpr int kHistRowBytes = 130 * 4, kHistMid = 2860;  // |kHistMid - 520 p + 4 word| < 4096 for p < 12, word < 130
+struct HistRows {
+    GlobalRow base;
+    unsigned voff;
+};
+__device__ __forceinline__ unsigned hist_row_now(int n) { return ((unsigned)n & (unsigned)(kAecHist - 1)) + (unsigned)kAecHist; }
+__device__ __forceinline__ HistRows hist_rows(const float *hist, int n, int lane) {
+    return HistRows{uniform_row(hist, 0, 0), hist_row_now(n) * (unsigned)kHistRowBytes - (unsigned)kHistMid + 4u * (unsigned)lane};
+}
+__device__ __forceinline__ float hist_ld(const HistRows &H, int p, int word) {  // p, word: compile-time at every call site
+    const long imm = kHistMid - kHistRowBytes * p + 4 * word;
+    return *(GlobalRow)((const char __attribute__((address_space(1))) *)H.base + (size_t)H.voff + imm);
+}
+
 // out of line for the same reason as libm_dev.h's pow_d: inlined, its fp64 temporaries push the block over 128 VGPRs
 __device__ __noinline__ static float aec_powf(float x, float y, const PowTables *__restrict__ t) { return fast_pow(x, y, t); }
 
@@ -384,7 +409,8 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
 
     // ---- near block (aec_core.c:1177-1195).  d = [prev | cur]; its plain transform feeds the near power, its
     //      windowed transform the coherence estimates of the NLP (aec_core.c:934-949): both now, side by side.
-    const float xpow_lane = row_ld(uniform_row(F.xpow_seq, n % kAecHist, BP), 4u * (unsigned)lane, 0);  // far power of this block (ScaleErrorSignal), requested early
+    const unsigned xpow_row = ((unsigned)n & (unsigned)(kAecHist - 1)) * (unsigned)BP;  // words
+    const float xpow_lane = row_ld(uniform_row(F.xpow_seq, 0, 0), 4u * (xpow_row + (unsigned)lane), 0);  // far power of this block (ScaleErrorSignal), requested early
     W.cur[lane] = AEC_ST(AS_NEAR_RING + ring_at(bp.near_rd, lane));
     wave_sync();
     AEC_PROF(0);
@@ -394,20 +420,20 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
         // all 24 far-spectrum values of this lane requested at once (one memory round trip, not one per few partitions);
         // the Nyquist column is wave-uniform and comes through the scalar path
         float xr[12], xi[12];
+        const HistRows H = hist_rows(F.hist, n, lane);
 #pragma unroll
         for (int p = 0; p < 12; p++) {
-            const GlobalRow X = uniform_row(F.hist, (n - p + kAecHist) % kAecHist, 130);
-            xr[p] = row_ld(X, 4u * (unsigned)lane, 0);
-            xi[p] = row_ld(X, 4u * (unsigned)lane, kAecPart1);
+            xr[p] = hist_ld(H, p, 0);
+            xi[p] = hist_ld(H, p, kAecPart1);
         }
+        const float *NQ = F.nyq + 2 * (hist_row_now(n) - 11);  // (re, im) of bin 64 of the rows R - 11 .. R, 24 consecutive words
         float y64 = 0.f;
         v2f y2 = v2f{0.f, 0.f};
 #pragma unroll
         for (int p = 0; p < 12; p++) {
-            const float *X = F.hist + (size_t)((n - p + kAecHist) % kAecHist) * 130;
             // (yr, yi) += (xr*wr - xi*wi, xr*wi + xi*wr): cmul_w is those four products and two sums, as three packed instructions
             y2 = y2 + cmul_w(xr[p], xi[p], taps.t[p]);
-            const float nr = uniform_ld(X + kAecPart), ni = uniform_ld(X + kAecPart1 + kAecPart);  // ni == 0, wfBuf[1][.][64] == 0
+            const float nr = uniform_ld(NQ + 2 * (11 - p)), ni = uniform_ld(NQ + 2 * (11 - p) + 1);  // ni == 0, wfBuf[1][.][64] == 0
             y64 += nr * W.wn[p] - ni * 0.f;                                                    // used by lane 0 only
         }
         // ---- error e = d - y (aec_core.c:1286-1297): y = second half of the inverse transform of the packed spectrum
@@ -518,7 +544,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
         };
         // bin 64 (read by every lane from the same LDS words) is scaled by every lane alongside its own bin: two independent
         // dependency chains in one instruction stream instead of a second, serial pass under `if (lane == 0)`
-        const float xp64 = uniform_ld(F.xpow_seq + (n % kAecHist) * BP + kAecPart);
+        const float xp64 = uniform_ld(F.xpow_seq + xpow_row + kAecPart);
         scale_err(xpow_lane, efr, efi);
 #if !defined(WMX_AEC_EXP) || WMX_AEC_EXP < 1
         scale_err(xp64, ef64r, ef64i);
@@ -540,24 +566,29 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
     for (int pass = 0; pass < 2; pass++) {
         const int base = 8 * pass, cnt = pass == 0 ? 8 : 4;
         if (pass == 1) {
-            const GlobalRow Xw = uniform_row(F.hist_w, (n - delayIdx0 + kAecHist) % kAecHist, 130);
-            xwr_pre = row_ld(Xw, 4u * (unsigned)lane, 0);
-            xwi_pre = row_ld(Xw, 4u * (unsigned)lane, kAecPart1);
+            const unsigned xw_row = ((unsigned)(n - delayIdx0) & (unsigned)(kAecHist - 1)) * 130u;  // words
+            const GlobalRow Xw = uniform_row(F.hist_w, 0, 0);
+            xwr_pre = row_ld(Xw, 4u * (xw_row + (unsigned)lane), 0);
+            xwi_pre = row_ld(Xw, 4u * (xw_row + (unsigned)lane), kAecPart1);
         }
-        float nyq_r = 0.f, nyq_i = 0.f;  // Nyquist bin of the far block of partition base + lane (lanes < cnt)
-        if (lane < cnt) {
-            const float *X = F.hist + (size_t)((n - (base + lane) + kAecHist) % kAecHist) * 130;
-            nyq_r = X[kAecPart];
-            nyq_i = -X[kAecPart1 + kAecPart];
+        // Nyquist bin of the far block of partition base + lane, used by the lanes < cnt (the others read a valid row too: no
+        // predicated region around the load)
+        float nyq_r, nyq_i;
+        {
+            const unsigned l = (unsigned)lane < 11u ? (unsigned)lane : 11u;
+            const v2f v = *reinterpret_cast<const v2f __attribute__((address_space(1))) *>(
+                (const char __attribute__((address_space(1))) *)uniform_row(F.nyq, 0, 0) + 8u * (hist_row_now(n) - (unsigned)base - l));
+            nyq_r = v.x;
+            nyq_i = -v.y;
         }
         {
             float xr[8], xi[8];
+            const HistRows H = hist_rows(F.hist, n, lane);
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 if (q >= cnt) continue;
-                const GlobalRow X = uniform_row(F.hist, (n - (base + q) + kAecHist) % kAecHist, 130);
-                xr[q] = row_ld(X, 4u * (unsigned)lane, 0);
-                xi[q] = -row_ld(X, 4u * (unsigned)lane, kAecPart1);
+                xr[q] = hist_ld(H, base + q, 0);
+                xi[q] = -hist_ld(H, base + q, kAecPart1);
             }
 #pragma unroll
             for (int q = 0; q < 8; q++) {
@@ -664,7 +695,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
     AEC_PROF(4);
     // xfw = windowed far spectrum consumed delayIdx blocks ago; the windowed near / error spectra come back from registers
     {
-        const float *Xw = F.hist_w + (size_t)((n - delayIdx + kAecHist) % kAecHist) * 130;
+        const float *Xw = F.hist_w + (size_t)(((unsigned)(n - delayIdx) & (unsigned)(kAecHist - 1)) * 130u);
         if (delayIdx != delayIdx0) {  // wave-uniform, rare
             xwr_pre = Xw[lane];
             xwi_pre = Xw[kAecPart1 + lane];
@@ -1287,7 +1318,8 @@ int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int i
     st[AS_HNLXDAVGMIN] = 1.f;
     st[AS_OVERDRIVE] = 2.f;
     st[AS_OVERDRIVESM] = 2.f;
-    const size_t far_words = (size_t)kAecPreLen + 2 * (size_t)kAecFarBlocks * 130 + 2 * (size_t)kAecHist * 130 + (size_t)kAecHist * BP + BP;
+    const size_t far_words = (size_t)kAecPreLen + 2 * (size_t)kAecFarBlocks * 130 + 3 * (size_t)kAecHist * 130 + 4 * (size_t)kAecHist +
+                             (size_t)kAecHist * BP + BP;
     hipError_t e;
 #define AEC_TRY(x)                                         \
     if ((e = (x)) != hipSuccess) {                         \
@@ -1332,7 +1364,9 @@ int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int i
     h->far.ring_w = p;
     p += (size_t)kAecFarBlocks * 130;
     h->far.hist = p;
-    p += (size_t)kAecHist * 130;
+    p += 2 * (size_t)kAecHist * 130;
+    h->far.nyq = p;
+    p += 4 * (size_t)kAecHist;
     h->far.hist_w = p;
     p += (size_t)kAecHist * 130;
     h->far.xpow_seq = p;

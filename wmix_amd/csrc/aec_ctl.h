@@ -186,7 +186,8 @@ struct AecCtl {
         AecBlkPlan &b = pl->blk[pl->n_blk++];
         near_fr.read(kAecPart, &b.near_rd);
         far_buf.read(1, &b.far_slot);
-        b.hist_n = hist_n++;
+        b.hist_n = hist_n;
+        hist_n = (hist_n + 1) & 0x3fffffff;  // only differences modulo kAecHist matter; stays non-negative for ever
         b.flags = 0;
         if (noise_ctr > 50) b.flags |= kAecFlagNoiseMin;
         if (noise_ctr < 500 * mult) {

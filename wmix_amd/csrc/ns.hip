@@ -78,8 +78,8 @@ __device__ unsigned long long g_ns_prof[16];
 #define NS_PROF(i)                                                         \
     do {                                                                   \
         const long long t_now = clock64();                                 \
-        if (lane == 0) W.prof[i] += (unsigned long long)(t_now - t_prev);  \
-        t_prev = clock64();                                                \
+        if (lane == 0) W.prof[i] += (unsigned long long)(t_now - prof_t0); \
+        prof_t0 = clock64();                                               \
     } while (0)
 #else
 #define NS_PROF(i)
@@ -163,7 +163,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
 #define NS_RELANE() asm volatile("" : "+v"(lane))
     NS_RELANE();
 #ifdef WMX_NS_PROF
-    long long t_prev = clock64();
+    long long prof_t0 = clock64();
 #endif
     constexpr int M = Y::M, B = Y::B, NT = L / 64, NC = L / 2;
     int *sti = reinterpret_cast<int *>(st);
