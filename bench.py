@@ -1143,17 +1143,22 @@ def _pmc_issue(kernel, n_frames, tag, launch_ms):
     """Vector-issue accounting of `kernel` (the per-stream DSP kernels are bound by instruction issue, not by HBM).
 
     Inputs, all committed under profiles/rNN/ and made on the GPU box by profiles/tools/profile_workload.sh:
-      <tag>_sq_pmc.json       SQ_INSTS_VALU per launch (dynamic count, rocprofv3 PMC pass of this very command)
-      issue_costs.json        SIMD time per wave64 instruction of each class at W resident waves per SIMD, every CU busy
-                              (tools_dev/ubench/issue_cost.hip) -- round 2 priced every instruction at a constant 4 cycles,
-                              which misquoted the guide
+      <tag>_sq_pmc.json       SQ_INSTS_VALU / SQ_INSTS_SALU per launch (dynamic counts, rocprofv3 PMC pass of this very command)
+      issue_costs.json        SIMD time per wave64 instruction of each class at W resident waves per SIMD, every CU busy, from
+                              waves that each run for a fixed time (tools_dev/ubench/issue_cost.hip, second version: the
+                              first divided a grid's wall time by its instructions and priced the arbiter's unfairness in)
       <tag>_issue_model.json  the kernel's ISA class histogram priced with that table at its occupancy
                               (tools_dev/issue_model.py)
-    Two figures:
-      lower_bound  every vector instruction at the CHEAPEST measured price of any class at the kernel's occupancy: no
-                   launch can issue its instructions faster, whatever their mix -- frac = bound / measured launch <= 1;
-      mix_estimate the same count at the histogram's mean price: what issue alone is expected to take.  The histogram is static
-                   (start-up and rare-update code included), so this one is an estimate, not a bound."""
+    Figures:
+      lower_bound   every vector instruction at the CHEAPEST measured price of any class at the kernel's occupancy: no
+                    launch can issue its instructions faster, whatever their mix -- frac = bound / measured launch <= 1;
+      mix_estimate  the same count at the histogram's mean price: the time the SIMDs' vector ALUs are busy.  The histogram is
+                    static (start-up and rare-update code included), so this one is an estimate, not a bound;
+      scalar_ceiling the dynamic scalar-instruction count at the price of a pure scalar stream (s_nop / s_waitcnt at theirs):
+                    what the scalar side would take ALONE; beside vector work most of it overlaps (the table's mix classes).
+    What is left of the launch after mix_estimate is time in which no wave of a SIMD had a vector instruction ready: one wave
+    issues an instruction of any kind every ~5 cycles at best, dependent ones wait for their operands, and these kernels
+    hold only 4-5 waves per SIMD (registers, LDS)."""
     import glob
     here = os.path.dirname(os.path.abspath(__file__))
     for path in sorted(glob.glob(os.path.join(here, "profiles", "r*", tag + "_sq_pmc.json")), reverse=True):
@@ -1172,10 +1177,18 @@ def _pmc_issue(kernel, n_frames, tag, launch_ms):
                 n_simd = 1024.0  # 256 CUs x 4 SIMDs
                 lb = insts * m["cheapest_valu"]["ns"] / n_simd * 1e-6
                 est = insts * m["mean_ns_per_valu"] / n_simd * 1e-6
-                out.update({"waves_per_simd": m["waves_per_simd"], "cheapest_ns_per_valu": m["cheapest_valu"]["ns"],
+                out.update({"waves_per_simd": m["waves_per_simd"], "priced_at_waves_per_simd": m.get("priced_at_waves_per_simd", m["waves_per_simd"]),
+                            "cheapest_ns_per_valu": m["cheapest_valu"]["ns"],
                             "mean_ns_per_valu": m["mean_ns_per_valu"], "lower_bound_ms": round(lb, 5),
                             "lower_bound_frac": round(lb / launch_ms, 4), "mix_estimate_ms": round(est, 5),
                             "mix_estimate_frac": round(est / launch_ms, 4), "model": os.path.relpath(mpath, here)})
+                sc, salu = m.get("scalar"), hit[0]["mean"].get("SQ_INSTS_SALU")
+                if sc and salu:
+                    # SQ_INSTS_SALU counts s_nop / s_waitcnt too: split the dynamic count like the static one
+                    idle = sc["static_nop_waitcnt"] / max(1, sc["static_nop_waitcnt"] + sc["static_alu_branch_smem"])
+                    t = salu * (idle * sc["ns_nop"] + (1 - idle) * sc["ns_alu"]) / n_simd * 1e-6
+                    out.update({"salu_insts_per_frame": round(salu / n_frames, 1), "scalar_ceiling_ms": round(t, 5),
+                                "scalar_ceiling_frac": round(t / launch_ms, 4)})
             return out
         except Exception:
             continue

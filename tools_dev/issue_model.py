@@ -130,7 +130,12 @@ def disassemble(stem, pattern):
 def model(costs, stem, pattern, waves):
     name, ins = disassemble(stem, pattern)
     ws = costs["waves_per_simd"]
-    col = ws.index(waves) if waves in ws else min(range(len(ws)), key=lambda i: abs(ws[i] - waves))
+    # a column is usable when the micro-benchmark really had that many waves per SIMD running together (its own check:
+    # resident_waves_per_simd); above four its occupancy pinning does not always hold.  Prices fall with occupancy, so the
+    # nearest usable column at or below the kernel's occupancy never flatters the kernel.
+    res = costs["classes"]["v_add_f32"].get("resident_waves_per_simd")
+    ok = [i for i in range(len(ws)) if ws[i] <= waves and (res is None or res[i] >= 0.95 * ws[i])]
+    col = max(ok, key=lambda i: ws[i]) if ok else 0
     hist = collections.Counter()
     other = collections.Counter()
     prev_vop2_select = False
@@ -154,14 +159,21 @@ def model(costs, stem, pattern, waves):
         classes[c] = {"static_count": k, "fraction": round(k / n, 4), "ns": e["ns"][col], "cycles": e["cycles"][col]}
         ns += k / n * e["ns"][col]
         cyc += k / n * e["cycles"][col]
+    # the scalar side: ALU instructions at the price of a pure scalar stream (one scalar ALU serves the CU's four SIMDs), s_nop /
+    # s_waitcnt at the price of s_nop; beside vector work they cost less (the mix classes of the table), so this is a ceiling
+    salu = [m for m in ins if m.startswith("s_")]
+    n_idle = sum(1 for m in salu if m in ("s_nop", "s_waitcnt"))
+    n_alu = len(salu) - n_idle
+    scalar = {"static_alu_branch_smem": n_alu, "static_nop_waitcnt": n_idle, "ns_alu": costs["classes"]["s_add_u32"]["ns"][col],
+              "ns_nop": costs["classes"]["s_nop"]["ns"][col]}
     plain = costs["classes"]["v_add_f32"]
     valu = {c: e for c, e in costs["classes"].items() if c.startswith("v_")}
     cheapest = min(valu, key=lambda c: valu[c]["ns"][col])
-    return {"kernel": name, "object": stem + ".o", "waves_per_simd": ws[col], "static_valu_instructions": n,
+    return {"kernel": name, "object": stem + ".o", "waves_per_simd": waves, "priced_at_waves_per_simd": ws[col], "static_valu_instructions": n,
             "static_other_instructions": dict(other), "mean_ns_per_valu": round(ns, 4), "mean_cycles_per_valu": round(cyc, 3),
             "plain_v_add_f32": {"ns": plain["ns"][col], "cycles": plain["cycles"][col]},
             "cheapest_valu": {"class": cheapest, "ns": valu[cheapest]["ns"][col]},
-            "classes": classes, "costs_from": costs.get("device", "?")}
+            "scalar": scalar, "classes": classes, "costs_from": costs.get("device", "?"), "costs_method": costs.get("method", "wall clock, v1")}
 
 
 if __name__ == "__main__":

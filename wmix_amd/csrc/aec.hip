@@ -345,6 +345,9 @@ __device__ __forceinline__ unsigned hist_row_now(int n) { return ((unsigned)n & 
 __device__ __forceinline__ HistRows hist_rows(const float *hist, int n, int lane) {
     return HistRows{uniform_row(hist, 0, 0), hist_row_now(n) * (unsigned)kHistRowBytes - (unsigned)kHistMid + 4u * (unsigned)lane};
 }
+// every outstanding vector-memory load of this wave has landed (s_waitcnt vmcnt(0); gfx9 encoding: vmcnt [3:0] + [15:14], expcnt [6:4],
+// lgkmcnt [11:8])
+__device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_waitcnt(0x0f70); }
 __device__ __forceinline__ float hist_ld(const HistRows &H, int p, int word) {  // p, word: compile-time at every call site
     const long imm = kHistMid - kHistRowBytes * p + 4 * word;
     return *(GlobalRow)((const char __attribute__((address_space(1))) *)H.base + (size_t)H.voff + imm);
@@ -426,6 +429,7 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
             xr[p] = hist_ld(H, p, 0);
             xi[p] = hist_ld(H, p, kAecPart1);
         }
+        wait_vm();  // ONE wait for the batch: left to the compiler every load gets its own s_waitcnt vmcnt(23), (22), ... in front of its use
         const float *NQ = F.nyq + 2 * (hist_row_now(n) - 11);  // (re, im) of bin 64 of the rows R - 11 .. R, 24 consecutive words
         float y64 = 0.f;
         v2f y2 = v2f{0.f, 0.f};
@@ -492,19 +496,15 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
             const float ns = re * re + im * im;
             r.dpow = 0.9f * AEC_ST(AS_DPOW + b) + 0.1f * ns;
             r.dmin = AEC_ST(AS_DMIN + b);
-            if (bp.flags & kAecFlagNoiseMin) {
-                if (r.dpow < r.dmin)
-                    r.dmin = (r.dpow + 0.1f * (r.dmin - r.dpow)) * 1.0002f;
-                else
-                    r.dmin *= 1.0002f;
+            if (bp.flags & kAecFlagNoiseMin) {  // both arms evaluated, one selected: a lane-dependent branch is three scalar instructions
+                const float down = (r.dpow + 0.1f * (r.dmin - r.dpow)) * 1.0002f, up = r.dmin * 1.0002f;
+                r.dmin = r.dpow < r.dmin ? down : up;
             }
             r.dinit = 0.f;
             if (bp.flags & kAecFlagNoiseInit) {
                 r.dinit = AEC_ST(AS_DINIT + b);
-                if (r.dmin > r.dinit)
-                    r.dinit = 0.999f * r.dinit + 0.001f * r.dmin;
-                else
-                    r.dinit = r.dmin;
+                const float track = 0.999f * r.dinit + 0.001f * r.dmin;
+                r.dinit = r.dmin > r.dinit ? track : r.dmin;
             }
             return r;
         };
@@ -588,8 +588,12 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
             for (int q = 0; q < 8; q++) {
                 if (q >= cnt) continue;
                 xr[q] = hist_ld(H, base + q, 0);
-                xi[q] = -hist_ld(H, base + q, kAecPart1);
+                xi[q] = hist_ld(H, base + q, kAecPart1);
             }
+            wait_vm();
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                if (q < cnt) xi[q] = -xi[q];
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 if (q >= cnt) continue;

@@ -17,6 +17,7 @@
 // the inverse passes, rftfsub after the forward ones) is folded into the gather of the consumer:
 // rdft128_inv_point_m() and rdft128_fwd_bin_u() evaluate one point / one bin from the packed LDS row.
 #pragma once
+#include <cstddef>
 #include "fft_ooura.h"
 
 namespace wmx {
@@ -302,7 +303,13 @@ __device__ __forceinline__ v2f bfly4_lane(int j, int b, const FftTables *T, v2f 
     // fft_ooura.h), block 1 with its outputs 1 and 3 rotated first
     const float ms = (b == 1 && (j & 1)) ? (j == 1 ? 1.f : -1.f) : 0.f;
     t = t + v2f{-ms, ms} * swap(t);
-    const float *wp = j == 1 ? T->W1[b] : (j == 2 ? T->W2[b] : (j == 3 ? T->W3[b] : T->W1[0]));
+    // W1, W2, W3 lie behind one another (FftTables): entry (j - 1) * 32 + b of the three as one array, entry 0 (= W1[0]) for
+    // j == 0 -- an index computation; as a select among four pointers it compiles to nested predicated regions, a dozen scalar
+    // instructions per butterfly
+    static_assert(offsetof(FftTables, W2) == offsetof(FftTables, W1) + 32 * 2 * sizeof(float) &&
+                      offsetof(FftTables, W3) == offsetof(FftTables, W1) + 64 * 2 * sizeof(float),
+                  "W1 | W2 | W3 contiguous");
+    const float *wp = &T->W1[0][0] + 2 * (j == 0 ? 0 : (j - 1) * 32 + b);
     return cmul_w(wp[0], wp[1], t);
 }
 
