@@ -28,7 +28,6 @@ LIVES = {
     7: [],                             # never created: its rows must not be touched
     8: [(0, T, 0)],
 }
-EVENTS = sorted({0, T} | {t for lives in LIVES.values() for a, b, _ in lives for t in (a, b)})
 N_COHORTS = 4
 COHORT_START = {0: 0, 1: 37, 2: 200, 3: 400}
 DELAYS = [0, 20, 0, 40]  # reported sound-card delay per cohort (ms)
@@ -42,35 +41,61 @@ def _inputs(freq, seed):
     return pkt, S, far.reshape(T, pkt), near
 
 
-def _drive(batch, run, S):
+def _drive(batch, run, S, lives=None, cohort_start=None, n_cohorts=None):
     """Walk the event list: at each event time restart the cohorts that begin there, reset the streams that are created
     there, update the active mask, then run the packets up to the next event."""
-    for t0, t1 in zip(EVENTS[:-1], EVENTS[1:]):
-        for c, tc in COHORT_START.items():
+    lives = LIVES if lives is None else lives
+    cohort_start = COHORT_START if cohort_start is None else cohort_start
+    n_cohorts = N_COHORTS if n_cohorts is None else n_cohorts
+    events = sorted({0, T} | {t for lv in lives.values() for a, b, _ in lv for t in (a, b)})
+    for t0, t1 in zip(events[:-1], events[1:]):
+        for c, tc in cohort_start.items():
             if tc == t0 and hasattr(batch, "reset_cohort") and batch._mod in ("aec", "aecm", "chain"):
                 batch.reset_cohort(c)
-        for c in range(N_COHORTS):
-            born = [s for s, lives in LIVES.items() for a, b, cc in lives if a == t0 and cc == c]
+        for c in range(n_cohorts):
+            born = [s for s, lv in lives.items() for a, b, cc in lv if a == t0 and cc == c]
             if born:
                 if batch._mod in ("aec", "aecm", "chain"):
                     batch.reset_streams(born, cohort=c)
                 else:
                     batch.reset_streams(born)
-        active = np.array([any(a <= t0 < b for a, b, _ in LIVES[s]) for s in range(S)])
+        active = np.array([any(a <= t0 < b for a, b, _ in lives[s]) for s in range(S)])
         batch.set_active(active)
-        on = np.array([COHORT_START[c] <= t0 and any(a <= t0 < b and cc == c for lives in LIVES.values() for a, b, cc in lives)
-                       for c in range(N_COHORTS)], dtype=np.uint8)
+        on = np.array([cohort_start[c] <= t0 and any(a <= t0 < b and cc == c for lv in lives.values() for a, b, cc in lv)
+                       for c in range(n_cohorts)], dtype=np.uint8)
         run(t0, t1, on)
 
 
-def _expected(S, near, per_handle):
+def _expected(S, near, per_handle, lives=None):
     """per_handle(stream, start, end, cohort) -> the oracle's output for a handle created at `start`; rows outside every life
     keep the input (nobody called the handle)."""
+    lives = LIVES if lives is None else lives
     want = near.copy()
     for s in range(S):
-        for a, b, c in LIVES[s]:
+        for a, b, c in lives[s]:
             want[s, a:b] = per_handle(s, a, b, c).reshape(b - a, -1)
     return want
+
+
+def _random_schedule(seed, S, n_cohorts):
+    """A seeded schedule in the shape of LIVES: every cohort starts at its own packet with one to three streams created there
+    (streams that join together share a control plane, src/webrtc.c:217-274); a stream leaves when it likes, some come back
+    later in a later cohort; one stream is never created."""
+    rng = np.random.default_rng(seed)
+    starts = sorted(int(x) for x in rng.choice(np.arange(1, T - 60), n_cohorts - 1, replace=False))
+    cohort_start = {0: 0, **{c + 1: t for c, t in enumerate(starts)}}
+    lives = {s: [] for s in range(S)}
+    free_at = {s: 0 for s in range(S - 1)}  # stream S - 1 is never created
+    for c in range(n_cohorts):
+        t0 = cohort_start[c]
+        cand = [s for s, f in free_at.items() if f <= t0]
+        rng.shuffle(cand)
+        for s in cand[: int(rng.integers(1, 4))]:
+            end = T if rng.random() < 0.5 else int(rng.integers(t0 + 1, T + 1))
+            lives[s].append((t0, end, c))
+            free_at[s] = end
+    delays = [int(x) for x in rng.choice([0, 10, 20, 40], n_cohorts)]
+    return lives, cohort_start, delays
 
 
 @pytest.mark.parametrize("freq", [16000, 8000])
@@ -119,6 +144,69 @@ def test_chain_lifetime_vs_per_handle_oracle(cuda, oracle_port):
     want = _expected(S, near, lambda s, a, b, c: L.run_chain(oracle_port, 1, freq, 5, 15, far[a:b].reshape(-1), near[s, a:b].reshape(-1), pkt,
                                                               prefix="orc"))
     assert np.array_equal(got[7], near[7])
+    check_float_path(got, want, max_fraction=1e-4)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_aec_random_schedules_vs_per_handle_oracle(cuda, oracle_port, seed):
+    """Seeded random schedules: six cohorts with their own start packet and reported delay, streams leaving and coming back,
+    launches of 1..29 packets -- each handle against its own oracle run."""
+    import torch
+    from wmix_amd.aec import AecBatch
+    freq, S, nc = (16000, 8000)[seed & 1], 10, 6
+    pkt = freq // 100
+    far = synth.far_end(9300 + seed, T, pkt).reshape(T, pkt)
+    near = synth.near_end(9400 + seed, S, T, pkt, far=far.reshape(-1)).reshape(S, T, pkt)
+    lives, cohort_start, delays = _random_schedule(seed, S, nc)
+    ab = AecBatch(S, 1, freq, 10, n_cohorts=nc)
+    d = torch.from_numpy(near.copy()).to(cuda)
+    dfar = torch.from_numpy(far).to(cuda)
+    rng = np.random.default_rng(seed + 77)
+
+    def run(t0, t1, on):
+        f = t0
+        while f < t1:
+            e = min(t1, f + int(rng.integers(1, 30)))
+            rc, codes = ab.run_cohorts(dfar[f:e], d[:, f:e], delays, cohort_on=on)
+            assert rc == 0 and not codes.any()
+            f = e
+    _drive(ab, run, S, lives, cohort_start, nc)
+    got = d.cpu().numpy()
+    ab.close()
+    want = _expected(S, near, lambda s, a, b, c: L.run_aec(oracle_port, 1, freq, 10, far[a:b].reshape(-1), near[s, a:b].reshape(-1), pkt,
+                                                            delays[c], prefix="orc"), lives)
+    assert np.array_equal(got[S - 1], near[S - 1])  # never created: untouched
+    for s in range(S):
+        dead = np.ones(T, bool)
+        for a, b, _ in lives[s]:
+            dead[a:b] = False
+        assert np.array_equal(got[s, dead], near[s, dead]), s  # outside its lives a stream's buffer is not touched
+    check_float_path(got, want, max_fraction=1e-4)
+
+
+def test_chain_random_schedule_vs_per_handle_oracle(cuda, oracle_port):
+    import torch
+    from wmix_amd.chain import ChainBatch
+    freq, S, nc, seed = 16000, 10, 6, 5
+    pkt = freq // 100
+    far = synth.far_end(9500, T, pkt).reshape(T, pkt)
+    near = synth.near_end(9501, S, T, pkt, far=far.reshape(-1)).reshape(S, T, pkt)
+    lives, cohort_start, _ = _random_schedule(seed, S, nc)
+    cb = ChainBatch(S, 1, freq, 10, 5, n_cohorts=nc)
+    d = torch.from_numpy(near.copy()).to(cuda)
+    dfar = torch.from_numpy(far).to(cuda)
+    zero = [0] * nc
+
+    def run(t0, t1, on):
+        for f in range(t0, t1):
+            rc, codes, _ = cb.process(dfar[f:f + 1], d[:, f:f + 1], delays=zero, cohort_on=on)
+            assert rc == 0 and not codes.any()
+    _drive(cb, run, S, lives, cohort_start, nc)
+    got = d.cpu().numpy()
+    cb.close()
+    want = _expected(S, near, lambda s, a, b, c: L.run_chain(oracle_port, 1, freq, 5, 15, far[a:b].reshape(-1), near[s, a:b].reshape(-1), pkt,
+                                                              prefix="orc"), lives)
+    assert np.array_equal(got[S - 1], near[S - 1])
     check_float_path(got, want, max_fraction=1e-4)
 
 
