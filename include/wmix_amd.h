@@ -384,6 +384,11 @@ int wmx_debug_fft(int kind, int n_batch, void *d_data, int32_t *d_aux, void *str
 /* Developer / test hook: the NS kernels' table-driven log (kind 0, x >= 1) and exp (kind 1) evaluated on the host from
  * the same source (wmix_amd/csrc/libm_dev.h), for sweeping against libm without a GPU. */
 int wmx_debug_ns_libm(int kind, const float *x, float *y, size_t n);
+/* Developer / test hook: the NS kernels' division for ordinary operands (wmix_amd/csrc/libm_dev.h div_ordinary: the
+ * compiler's own fp32 division sequence without its rescaling and special-case instructions) beside `a / b`, on the device
+ * (device pointers) and compiled for the host. */
+int wmx_debug_div(const float *d_a, const float *d_b, float *d_q_ordinary, float *d_q_ieee, size_t n, void *stream);
+int wmx_debug_div_host(const float *a, const float *b, float *q, size_t n);
 /* Same for the AEC kernel's table-driven powf: y[i] = x[i] ^ e[i]. */
 int wmx_debug_pow(const float *x, const float *e, float *y, size_t n);
 

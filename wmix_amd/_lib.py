@@ -213,6 +213,10 @@ def _declare(L):
     L.wmx_debug_pow.argtypes = [vp, vp, vp, C.c_size_t]
     L.wmx_debug_ns_libm.restype = i
     L.wmx_debug_ns_libm.argtypes = [i, vp, vp, C.c_size_t]
+    L.wmx_debug_div.restype = i
+    L.wmx_debug_div.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
+    L.wmx_debug_div_host.restype = i
+    L.wmx_debug_div_host.argtypes = [vp, vp, vp, C.c_size_t]
     L.wmx_pkgfifo_create.restype = i
     L.wmx_pkgfifo_create.argtypes = [C.POINTER(vp), i, i, i, i, i]
     L.wmx_pkgfifo_destroy.restype = i

@@ -50,6 +50,32 @@ __host__ __device__ __forceinline__ double fma_c(double p, double r, double c) {
 #endif
 }
 
+// a / b, correctly rounded, for ORDINARY operands: a finite, b normal, neither beyond 2^+-96, exponents less than 96 apart, a
+// quotient that is a normal number (or a == 0).  What the compiler emits for `a / b` is this same sequence -- reciprocal
+// estimate, one Newton step on it, quotient, two residual corrections (W:llvm AMDGPU LowerFDIV32; Markstein's theorem makes
+// the last one exact) -- wrapped in two v_div_scale_f32 in front and v_div_fmas_f32 / v_div_fixup_f32 behind, which rescale
+// operands outside that box and patch zeros, infinities and NaNs: for operands inside it they pass their inputs through and
+// the result is fma(f4, f1, f3) below, bit for bit.  43.6 cycles of SIMD time become 31.2 (profiles/r03/issue_costs.json).
+// Callers state their operand ranges; tests/test_div_ordinary.py sweeps 10^8 pairs on the host and on the GPU.
+__host__ __device__ __forceinline__ float div_ordinary(float a, float b) {
+#if defined(WMX_DIV_IEEE)  // developer switch (make EXTRA=-DWMX_DIV_IEEE): the compiler's full sequence, for A/B timing
+    return a / b;
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r0 = __builtin_amdgcn_rcpf(b);
+#else
+    const float r0 = 1.0f / b;  // any estimate within an ulp ends in the same quotient
+#endif
+    const float nb = -b;
+    const float f0 = __builtin_fmaf(nb, r0, 1.0f);
+    const float f1 = __builtin_fmaf(f0, r0, r0);
+    const float m = a * f1;
+    const float f2 = __builtin_fmaf(nb, m, a);
+    const float f3 = __builtin_fmaf(f2, f1, m);
+    const float f4 = __builtin_fmaf(nb, f3, a);
+    return __builtin_fmaf(f4, f1, f3);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Table-driven log / exp for the NS's per-bin calls.  The reference computes float(log((double)x)) and
 // float(exp((double)x)) with glibc (error < 1 ulp of double).  Any double result within ~1 ulp of the true value rounds

@@ -356,16 +356,17 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
                 float dens = pf_dens[k][q];
                 lq = pf_lq[k][q];
                 float delta;
+                // div_ordinary (libm_dev.h): 1 < dens <= 50, 1 <= c1 <= 201, 0.2 <= numerators <= 10 050
                 if (dens > 1.0f)
-                    delta = 40.f * 1.f / dens;
+                    delta = div_ordinary(40.f * 1.f, dens);
                 else
                     delta = 40.f;
                 if (lm > lq)
-                    lq += 0.25f * delta / c1;
+                    lq += div_ordinary(0.25f * delta, c1);
                 else
-                    lq -= (1.f - 0.25f) * delta / c1;
+                    lq -= div_ordinary((1.f - 0.25f) * delta, c1);
                 if (fabsf(lm - lq) < 0.01f) {
-                    dens = (cf * dens + 1.f / (2.f * 0.01f)) / c1;
+                    dens = div_ordinary(cf * dens + 1.f / (2.f * 0.01f), c1);
                     if (ok) st[Y::DENSITY + q * Y::MP + b] = dens;
                 }
                 if (ok) st[Y::LQUANTILE + q * Y::MP + b] = lq;
@@ -446,9 +447,11 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             const int b = ok ? b0 : M - 1;
             const float mg = W.magn[b], nz = W.noise[b];
             const float np = pf_nprev[k];
-            const float pe = pf_mprev[k] / (np + 0.0001f) * pf_smooth[k];
+            // div_ordinary: magnitudes are 0 (a stream's first frame) or in [1, 2^24] (|X| + 1 of 256 int16 samples), noise
+            // estimates positive and below 2^27, so the denominators lie in [1e-4, 2^27]
+            const float pe = div_ordinary(pf_mprev[k], np + 0.0001f) * pf_smooth[k];
             float sq = 0.f;
-            if (mg > nz) sq = mg / (nz + 0.0001f) - 1.f;
+            if (mg > nz) sq = div_ordinary(mg, nz + 0.0001f) - 1.f;
             const float dm = mg - avg_magn, dp = W.pause[b] - avg_pause;
             t_prev[k] = pe;
             t_snrq[k] = sq;
@@ -634,7 +637,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             const int b = ok ? b0 : M - 1;
             const float sp = W.snrp[b];
             const float t1 = 1.f + 2.f * sp;
-            const float t2 = 2.f * sp / (t1 + 0.0001f);
+            const float t2 = div_ordinary(2.f * sp, t1 + 0.0001f);  // 0 <= sp < 2^38 (a magnitude over a denominator >= 1e-4), t1 >= 1
             const float bessel = (t_snrq[k] + 1.f) * t2;
             float v = pf_lrt[k];
             v += 0.5f * (bessel - fast_log_ge1(t1, K.lm) - v);
@@ -716,9 +719,9 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
                 if (ok) st[Y::INIT_MAGN + b] = init_est;
             }
             float cur = 0.f;
-            if (mg > nz) cur = mg / (nz + 0.0001f) - 1.f;
+            if (mg > nz) cur = div_ordinary(mg, nz + 0.0001f) - 1.f;
             const float snr = 0.98f * t_prev[k] + (1.f - 0.98f) * cur;
-            float f = snr / (overdrive + snr);
+            float f = div_ordinary(snr, overdrive + snr);  // 0 <= snr < 2^38, overdrive >= 1
             if (f < denoise_bound) f = denoise_bound;
             if (f > 1.f) f = 1.f;
             if (startup) {
@@ -1169,6 +1172,32 @@ int wmx_ns_process(wmx_ns *h, const int16_t *d_in, int16_t *d_out, int n_packets
 }
 
 }  // extern "C"
+
+// Developer / test hook: div_ordinary (libm_dev.h) beside the compiler's a / b on the device, element by element.
+namespace wmx {
+namespace {
+__global__ void div_debug_kernel(const float *a, const float *b, float *q_ordinary, float *q_ieee, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        q_ordinary[i] = div_ordinary(a[i], b[i]);
+        q_ieee[i] = a[i] / b[i];
+    }
+}
+}  // namespace
+}  // namespace wmx
+extern "C" int wmx_debug_div(const float *d_a, const float *d_b, float *d_q_ordinary, float *d_q_ieee, size_t n, void *stream) {
+    if (!d_a || !d_b || !d_q_ordinary || !d_q_ieee) return WMX_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(wmx::div_debug_kernel, dim3(4096), dim3(256), 0, wmx::as_stream(stream), d_a, d_b, d_q_ordinary, d_q_ieee, n);
+    WMX_LAUNCH_CHECK();
+    return 0;
+}
+// the same function compiled for the host (reciprocal estimate = the rounded 1 / b, moved by `seed_ulps` ulps: the device's
+// v_rcp_f32 is good to one ulp, and the quotient must not depend on which estimate it was)
+extern "C" int wmx_debug_div_host(const float *a, const float *b, float *q, size_t n) {
+    if (!a || !b || !q) return WMX_EINVAL;
+    for (size_t i = 0; i < n; i++) q[i] = wmx::div_ordinary(a[i], b[i]);
+    return 0;
+}
 
 // Host-side evaluation of the NS's table-driven log / exp (libm_dev.h) -- the same source the kernels compile, run on
 // the CPU so that the `-m "not gpu"` tests can sweep millions of arguments against glibc.  kind 0: log (x >= 1), 1: exp, 2: tanh.
