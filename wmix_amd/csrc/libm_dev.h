@@ -50,8 +50,9 @@ __host__ __device__ __forceinline__ double fma_c(double p, double r, double c) {
 #endif
 }
 
-// a / b, correctly rounded, for ORDINARY operands: a finite, b normal, neither beyond 2^+-96, exponents less than 96 apart, a
-// quotient that is a normal number (or a == 0).  What the compiler emits for `a / b` is this same sequence -- reciprocal
+// a / b, correctly rounded, for ORDINARY operands: a == 0 or 2^-96 <= |a| <= 2^96, the same box for b, exponents less than
+// 96 apart, a quotient that is a normal number.  (A numerator below 2^-100 is NOT ordinary: the residuals f2, f4 underflow and
+// one quotient in four comes out an ulp off -- measured; that is what v_div_scale_f32 is there for.)  What the compiler emits for `a / b` is this same sequence -- reciprocal
 // estimate, one Newton step on it, quotient, two residual corrections (W:llvm AMDGPU LowerFDIV32; Markstein's theorem makes
 // the last one exact) -- wrapped in two v_div_scale_f32 in front and v_div_fmas_f32 / v_div_fixup_f32 behind, which rescale
 // operands outside that box and patch zeros, infinities and NaNs: for operands inside it they pass their inputs through and
