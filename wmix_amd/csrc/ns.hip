@@ -166,14 +166,31 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
     long long prof_t0 = clock64();
 #endif
     constexpr int M = Y::M, B = Y::B, NT = L / 64, NC = L / 2;
-    int *sti = reinterpret_cast<int *>(st);
+    // the stream's state block: ONE scalar base for the launch, every access `base + (4 * lane + constant)` in the SGPR-base +
+    // 32-bit-VGPR-offset form of global_load / global_store (wmx_internal.h: global_row, row_ld, row_st) -- as `st[i]` with a
+    // 64-bit `st` the compiler builds a per-lane 64-bit address for every array (v_lshl_add_u64, v_add_co / v_addc_co pairs)
+    struct StF {
+        GlobalF g;
+        unsigned i;
+        __device__ __forceinline__ operator float() const { return row_ld(g, i); }
+        __device__ __forceinline__ void operator=(float v) const { row_st(g, i, v); }
+    };
+    struct StI {
+        GlobalF g;
+        unsigned i;
+        __device__ __forceinline__ operator int() const { return __float_as_int(row_ld(g, i)); }
+        __device__ __forceinline__ void operator=(int v) const { row_st(g, i, __int_as_float(v)); }
+    };
+    const GlobalF st_row = global_row(st, 0);
+#define ST(idx) (StF{st_row, (unsigned)(idx)})
+#define STI(idx) (StI{st_row, (unsigned)(idx)})
     float *tdst = W.r0;  // L floats spanning r0..r1
 
     // ---- load the packet (channel 0 = low band, channel 1 = "high band") and slide the analysis
     //      buffer (UpdateBuffer, ns_core.c:855-873).  All loads before the stores.
     // the stream's 24 scalar state words in one coalesced load; read back lane by lane (every field is read at most
     // once per frame, before it is written)
-    const float scv = lane < 24 ? st[Y::SCALARS + lane] : 0.f;
+    const float scv = lane < 24 ? ST(Y::SCALARS + lane) : 0.f;
 #define SCF(f) lane_value(scv, Y::f - Y::SCALARS)
 #define SCI(f) __float_as_int(lane_value(scv, Y::f - Y::SCALARS))
     float buf[NT], hb[NT], synt[NT];
@@ -188,13 +205,13 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         const bool is_old = all_old || (!all_new && i < KEEP);
         float o = 0.f, oh = 0.f;
         int16_t n = 0, nh = 0;
-        if (!all_new) o = st[Y::IN_BUF + (is_old ? i + B : 0)];
+        if (!all_new) o = ST(Y::IN_BUF + (is_old ? i + B : 0));
         if (!all_old) n = in[(is_old ? 0 : i - KEEP) * chn];
         buf[k] = is_old ? o : (float)n;
-        synt[k] = st[Y::SYNT_BUF + i];
+        synt[k] = ST(Y::SYNT_BUF + i);
         hb[k] = 0.f;
         if (chn == 2) {
-            if (!all_new) oh = st[Y::HB_BUF + (is_old ? i + B : 0)];
+            if (!all_new) oh = ST(Y::HB_BUF + (is_old ? i + B : 0));
             if (!all_old) nh = in[(is_old ? 0 : i - KEEP) * chn + 1];
             hb[k] = is_old ? oh : (float)nh;
         }
@@ -213,20 +230,20 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         // unconditional loads: lanes past the last bin fetch bin M - 1 again (same value in every lane of that group), so
         // nothing below needs a lane test around its arithmetic
         const int b = lane + 64 * k < M ? lane + 64 * k : M - 1;
-        pf_pause[k] = st[Y::MAGN_AVG_PAUSE + b];
-        pf_quant[k] = st[Y::QUANTILE + b];
+        pf_pause[k] = ST(Y::MAGN_AVG_PAUSE + b);
+        pf_quant[k] = ST(Y::QUANTILE + b);
 #pragma unroll
         for (int q = 0; q < 3; q++) {
-            pf_dens[k][q] = st[Y::DENSITY + q * Y::MP + b];
-            pf_lq[k][q] = st[Y::LQUANTILE + q * Y::MP + b];
+            pf_dens[k][q] = ST(Y::DENSITY + q * Y::MP + b);
+            pf_lq[k][q] = ST(Y::LQUANTILE + q * Y::MP + b);
         }
     }
     wave_sync();  // other lanes' stores below overwrite what this lane just loaded: keep the compiler from interleaving them
 #pragma unroll
     for (int k = 0; k < NT; k++) {
         const int i = lane + 64 * k;
-        st[Y::IN_BUF + i] = buf[k];
-        if (chn == 2) st[Y::HB_BUF + i] = hb[k];
+        ST(Y::IN_BUF + i) = buf[k];
+        if (chn == 2) ST(Y::HB_BUF + i) = hb[k];
     }
     // window + energy (ns_core.c:1071-1072 / 1241-1242)
 #pragma unroll
@@ -248,7 +265,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
     if (!zero_frame) {
         // ===================================================== Analyze (ns_core.c:1085-1180)
         const int block_ind = SCI(S_BLOCK_IND) + 1;
-        sti[Y::S_BLOCK_IND] = block_ind;
+        STI(Y::S_BLOCK_IND) = block_ind;
         const int update_flag = SCI(S_UPDATE_FLAG);
         const bool startup = block_ind < kStartupShort;
         const float overdrive = 1.1f, denoise_bound = 0.125f;  // policy 2, ns_core.c:1030-1033
@@ -329,7 +346,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         // ---- NoiseEstimation (ns_core.c:217-285)
         int updates = SCI(S_UPDATES);
         if (updates < kStartupLong) updates++;
-        sti[Y::S_UPDATES] = updates;
+        STI(Y::S_UPDATES) = updates;
         const int cnt0 = SCI(S_COUNTER + 0), cnt1 = SCI(S_COUNTER + 1), cnt2 = SCI(S_COUNTER + 2);
         // second prefetch wave: what ComputeSnr and SpeechNoiseProb read (consumed after the quantile update and the
         // next ordered sums)
@@ -337,10 +354,10 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
 #pragma unroll
         for (int k = 0; k < NI; k++) {
             const int b = lane + 64 * k < M ? lane + 64 * k : M - 1;
-            pf_nprev[k] = st[Y::NOISE_PREV + b];
-            pf_mprev[k] = st[Y::MAGN_PREV + b];
-            pf_smooth[k] = st[Y::SMOOTH + b];
-            pf_lrt[k] = st[Y::LOG_LRT + b];
+            pf_nprev[k] = ST(Y::NOISE_PREV + b);
+            pf_mprev[k] = ST(Y::MAGN_PREV + b);
+            pf_smooth[k] = ST(Y::SMOOTH + b);
+            pf_lrt[k] = ST(Y::LOG_LRT + b);
         }
 #pragma unroll
         for (int k = 0; k < NI; k++) {
@@ -367,27 +384,27 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
                     lq -= div_ordinary((1.f - 0.25f) * delta, c1);
                 if (fabsf(lm - lq) < 0.01f) {
                     dens = div_ordinary(cf * dens + 1.f / (2.f * 0.01f), c1);
-                    if (ok) st[Y::DENSITY + q * Y::MP + b] = dens;
+                    if (ok) ST(Y::DENSITY + q * Y::MP + b) = dens;
                 }
-                if (ok) st[Y::LQUANTILE + q * Y::MP + b] = lq;
+                if (ok) ST(Y::LQUANTILE + q * Y::MP + b) = lq;
                 if (cnt >= kStartupLong && updates >= kStartupLong) quant = fast_exp(lq, K.lm);
             }
             if (updates < kStartupLong) quant = fast_exp(lq, K.lm);  // lq of the last estimator
             if (ok) {
-                st[Y::QUANTILE + b] = quant;
+                ST(Y::QUANTILE + b) = quant;
                 W.noise[b] = quant;
             }
         }
-        sti[Y::S_COUNTER + 0] = cnt0 >= kStartupLong ? 1 : cnt0 + 1;
-        sti[Y::S_COUNTER + 1] = cnt1 >= kStartupLong ? 1 : cnt1 + 1;
-        sti[Y::S_COUNTER + 2] = cnt2 >= kStartupLong ? 1 : cnt2 + 1;
+        STI(Y::S_COUNTER + 0) = cnt0 >= kStartupLong ? 1 : cnt0 + 1;
+        STI(Y::S_COUNTER + 1) = cnt1 >= kStartupLong ? 1 : cnt1 + 1;
+        STI(Y::S_COUNTER + 2) = cnt2 >= kStartupLong ? 1 : cnt2 + 1;
 
         NS_RELANE();
         NS_PROF(4);
         // ---- start-up white/pink parametric noise model (ns_core.c:1108-1160); parametricNoise kept in r1
         if (startup) {
             const float white = SCF(S_WHITE) + sum_magn / ((float)M) * overdrive;
-            st[Y::S_WHITE] = white;
+            ST(Y::S_WHITE) = white;
             const float sum_log_i = K.logi[Y::MP - 2], sum_log_i_sq = K.logi[Y::MP - 1];
             float t1 = sum_log_i_sq * ((float)(M - kStartBand));
             t1 -= (sum_log_i * sum_log_i);
@@ -395,14 +412,14 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             float t3 = t2 / t1;
             if (t3 < 0.f) t3 = 0.f;
             const float pink_num = SCF(S_PINK_NUM) + t3;
-            st[Y::S_PINK_NUM] = pink_num;
+            ST(Y::S_PINK_NUM) = pink_num;
             t2 = (sum_log_i * sum_log_magn);
             t2 -= ((float)(M - kStartBand)) * sum_log_i_log_magn;
             t3 = t2 / t1;
             if (t3 < 0.f) t3 = 0.f;
             if (t3 > 1.f) t3 = 1.f;
             const float pink_exp = SCF(S_PINK_EXP) + t3;
-            st[Y::S_PINK_EXP] = pink_exp;
+            ST(Y::S_PINK_EXP) = pink_exp;
             float pnum = 0.0f, pexp = 0.0f;
             if (pink_exp > 0.f) {
                 pnum = exp_d(pink_num / (float)(block_ind + 1));
@@ -511,7 +528,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
                     if ((feat_flat < kHistBins * 0.05f) && (feat_flat >= 0.0f)) bump(kHistBins + (int)(feat_flat / 0.05f));
                     if ((feat_diff < kHistBins * 0.1f) && (feat_diff >= 0.0f)) bump(2 * kHistBins + (int)(feat_diff / 0.1f));
                 }
-                sti[Y::S_COUNTDOWN] = countdown;
+                STI(Y::S_COUNTDOWN) = countdown;
             } else {
                 // The three histograms are walked in bin order (the float sums are order-sensitive), but only their
                 // NON-ZERO bins: an empty bin adds +0 to every sum and can never be a peak (h > max needs h > 0), and 500
@@ -607,26 +624,26 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
                 w_diff = ((float)use_diff) / fsum;
                 wave_sync();
                 for (int i = lane; i < 3 * kHistBins; i += 64) hist[i] = 0;
-                sti[Y::S_COUNTDOWN] = kUpdateWindow;
+                STI(Y::S_COUNTDOWN) = kUpdateWindow;
                 if (update_flag == 1) {
-                    sti[Y::S_UPDATE_FLAG] = 0;
+                    STI(Y::S_UPDATE_FLAG) = 0;
                 } else {
                     feat_acc = feat_acc / ((float)kUpdateWindow);
                     feat_norm = 0.5f * (feat_acc + feat_norm);
                     feat_acc = 0.f;
                 }
-                st[Y::S_THR_LRT] = thr_lrt;
-                st[Y::S_THR_FLAT] = thr_flat;
-                st[Y::S_THR_DIFF] = thr_diff;
-                st[Y::S_W_LRT] = w_lrt;
-                st[Y::S_W_FLAT] = w_flat;
-                st[Y::S_W_DIFF] = w_diff;
+                ST(Y::S_THR_LRT) = thr_lrt;
+                ST(Y::S_THR_FLAT) = thr_flat;
+                ST(Y::S_THR_DIFF) = thr_diff;
+                ST(Y::S_W_LRT) = w_lrt;
+                ST(Y::S_W_FLAT) = w_flat;
+                ST(Y::S_W_DIFF) = w_diff;
             }
         }
-        st[Y::S_FEAT_FLAT] = feat_flat;
-        st[Y::S_FEAT_DIFF] = feat_diff;
-        st[Y::S_FEAT_NORM] = feat_norm;
-        st[Y::S_FEAT_ACC] = feat_acc;
+        ST(Y::S_FEAT_FLAT) = feat_flat;
+        ST(Y::S_FEAT_DIFF) = feat_diff;
+        ST(Y::S_FEAT_NORM) = feat_norm;
+        ST(Y::S_FEAT_ACC) = feat_acc;
 
         NS_RELANE();
         // ---- SpeechNoiseProb (ns_core.c:642-749)
@@ -642,7 +659,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             float v = pf_lrt[k];
             v += 0.5f * (bessel - fast_log_ge1(t1, K.lm) - v);
             if (!ok) continue;
-            st[Y::LOG_LRT + b] = v;
+            ST(Y::LOG_LRT + b) = v;
             W.r0[b] = v;
         }
         wave_sync();
@@ -650,7 +667,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         float ksum = sum_range<ORDERED>(W.r0, 0, M, lane);
         ksum = ksum / (float)(M);
         feat_lrt = ksum;
-        st[Y::S_FEAT_LRT] = feat_lrt;
+        ST(Y::S_FEAT_LRT) = feat_lrt;
         float prior = SCF(S_PRIOR);
         {
             float width = 4.0f;
@@ -671,7 +688,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             prior += 0.1f * (ind - prior);
             if (prior > 1.f) prior = 1.f;
             if (prior < 0.01f) prior = 0.01f;
-            st[Y::S_PRIOR] = prior;
+            ST(Y::S_PRIOR) = prior;
         }
         const float gain_prior = (1.f - prior) / (prior + 0.0001f);
 #pragma unroll
@@ -703,7 +720,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             if (ps < 0.2f) {
                 float pz = W.pause[b];
                 pz += 0.05f * (mg - pz);
-                if (ok) st[Y::MAGN_AVG_PAUSE + b] = pz;
+                if (ok) ST(Y::MAGN_AVG_PAUSE + b) = pz;
             }
             float nz;
             if (gamma == gamma_old) {
@@ -715,8 +732,8 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             // ---- Process
             float init_est = 0.f;
             if (startup) {
-                init_est = st[Y::INIT_MAGN + b] + mg;
-                if (ok) st[Y::INIT_MAGN + b] = init_est;
+                init_est = ST(Y::INIT_MAGN + b) + mg;
+                if (ok) ST(Y::INIT_MAGN + b) = init_est;
             }
             float cur = 0.f;
             if (mg > nz) cur = div_ordinary(mg, nz + 0.0001f) - 1.f;
@@ -736,9 +753,9 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             }
             const float re = t_re[k] * f, im = t_im[k] * f;
             if (!ok) continue;
-            st[Y::SMOOTH + b] = f;
-            st[Y::MAGN_PREV + b] = mg;
-            st[Y::NOISE_PREV + b] = nz;
+            ST(Y::SMOOTH + b) = f;
+            ST(Y::MAGN_PREV + b) = mg;
+            ST(Y::NOISE_PREV + b) = nz;
             W.snrp[b] = f;  // the filter, for the high-band gain
             if (b == 0)
                 W.fa[0] = re;
@@ -811,7 +828,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
 #pragma unroll
     for (int k = 0; k < NT; k++) {
         const int i = lane + 64 * k;
-        if (i >= B) st[Y::SYNT_BUF + i - B] = synt[k];
+        if (i >= B) ST(Y::SYNT_BUF + i - B) = synt[k];
         tdst[i] = sat16f(synt[k]);
         // HB output: the OLDEST block of the (already slid) high-band buffer, times the gain (zero-energy frames pass
         // it through unscaled, ns_core.c:1255-1265)
@@ -820,7 +837,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
 #pragma unroll
     for (int k = 0; k < NT; k++) {
         const int i = lane + 64 * k;
-        if (i >= L - B) st[Y::SYNT_BUF + i] = 0.f;
+        if (i >= L - B) ST(Y::SYNT_BUF + i) = 0.f;
     }
     wave_sync();
     // interleave + (int16_t) cast (src/webrtc.c:640-642).  Samples beyond the core's block length (32 kHz: 160..319)
