@@ -16,6 +16,10 @@
  * n_workers defaults to wmx_device_count(); worker w runs on device w % device_count, so a 1-GPU box can still drive
  * several shards (tests/test_host_chain_gpu.py does, and compares out.i16 with the oracle).
  *
+ * Built with -DWMX_EXAMPLE_RCCL (examples/host_chain_rccl, links librccl) the far-end travels the way north_star puts it:
+ * worker 0 alone uploads the packet, and ONE ncclBroadcast per tick (every worker calls it on its own communicator and stream)
+ * delivers it from GPU 0 to the others over xGMI.  That needs one device per worker (RCCL does not put two ranks on one GPU).
+ *
  * Build (what __graft_entry__.build() runs):
  *   gcc -std=c99 -O2 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude examples/host_chain.c -o examples/host_chain \
  *       -Lwmix_amd -lwmix_amd -L/opt/rocm/lib -lamdhip64 -lpthread -Wl,-rpath,'$ORIGIN/../wmix_amd' -Wl,-rpath,/opt/rocm/lib
@@ -29,6 +33,9 @@
 #include <string.h>
 #include <time.h>
 #include "wmix_amd.h"
+#ifdef WMX_EXAMPLE_RCCL
+#include <rccl/rccl.h>
+#endif
 
 typedef struct {
     int worker, dev, lo, n;      /* this shard: streams [lo, lo + n) on HIP device dev */
@@ -39,6 +46,9 @@ typedef struct {
     pthread_barrier_t *tick;
     int rc;
     double busy_ms;
+#ifdef WMX_EXAMPLE_RCCL
+    ncclComm_t comm;             /* this worker's rank in the far-end broadcast group (rank == worker, root 0) */
+#endif
 } Shard;
 
 #define HIP_OK(x)                                                                             \
@@ -85,7 +95,20 @@ static void *gpu_worker(void *arg) {
         pthread_barrier_wait(s->tick); /* the 10 ms heartbeat: every worker starts tick t together */
         if (!created || s->rc) continue; /* keep the barrier count even after a failure */
         const double t0 = now_ms();
+#ifdef WMX_EXAMPLE_RCCL
+        /* the far-end reaches GPU 0 from the host and every other GPU from GPU 0 (the path's one exchange) */
+        if (s->worker == 0) HIP_OK(hipMemcpyAsync(d_far, s->far_host + (size_t)t * s->pkt, row, hipMemcpyHostToDevice, st));
+        {
+            ncclResult_t nr = ncclBroadcast(d_far, d_far, row, ncclInt8, 0, s->comm, st);
+            if (nr != ncclSuccess) {
+                fprintf(stderr, "worker %d: ncclBroadcast -> %s\n", s->worker, ncclGetErrorString(nr));
+                s->rc = 1;
+                goto done;
+            }
+        }
+#else
         HIP_OK(hipMemcpyAsync(d_far, s->far_host + (size_t)t * s->pkt, row, hipMemcpyHostToDevice, st));
+#endif
         HIP_OK(hipMemcpy2DAsync(d_near, row, s->near_host + ((size_t)s->lo * s->n_ticks + t) * s->pkt, pitch, row, (size_t)s->n,
                                 hipMemcpyHostToDevice, st));
         WMX_OK(wmx_chain_process(chain, d_far, s->pkt, d_near, d_near, 1, s->pkt, (long)s->pkt * s->n, NULL, NULL, NULL, st));
@@ -129,6 +152,23 @@ int main(int argc, char **argv) {
     const int freq = argc > 7 ? atoi(argv[7]) : 16000;
     const int pkt = freq / 100;
     if (n_workers < 1 || n_workers > n_streams || n_ticks < 1) return 2;
+#ifdef WMX_EXAMPLE_RCCL
+    if (n_workers > n_dev) {
+        fprintf(stderr, "host_chain_rccl: %d workers need %d devices, %d present\n", n_workers, n_workers, n_dev);
+        return 2;
+    }
+    ncclComm_t *comms = calloc((size_t)n_workers, sizeof(ncclComm_t));
+    {
+        int *devs = calloc((size_t)n_workers, sizeof(int));
+        for (int w = 0; w < n_workers; w++) devs[w] = w;
+        ncclResult_t nr = ncclCommInitAll(comms, n_workers, devs);
+        free(devs);
+        if (nr != ncclSuccess) {
+            fprintf(stderr, "host_chain_rccl: ncclCommInitAll -> %s\n", ncclGetErrorString(nr));
+            return 3;
+        }
+    }
+#endif
     int16_t *far = read_file(argv[1], (size_t)n_ticks * pkt * 2);
     int16_t *near = read_file(argv[2], (size_t)n_streams * n_ticks * pkt * 2);
     int16_t *out = calloc((size_t)n_streams * n_ticks * pkt, 2);
@@ -152,6 +192,9 @@ int main(int argc, char **argv) {
         s->near_host = near;
         s->out_host = out;
         s->tick = &tick;
+#ifdef WMX_EXAMPLE_RCCL
+        s->comm = comms[w];
+#endif
         pthread_create(&th[w], NULL, gpu_worker, s);
     }
     int rc = 0;
@@ -160,12 +203,21 @@ int main(int argc, char **argv) {
         rc |= sh[w].rc;
     }
     const double wall = now_ms() - t0;
+#ifdef WMX_EXAMPLE_RCCL
+    for (int w = 0; w < n_workers; w++) (void)ncclCommDestroy(comms[w]);
+    free(comms);
+#endif
     if (rc == 0) {
         FILE *f = fopen(argv[3], "wb");
         if (!f || fwrite(out, 2, (size_t)n_streams * n_ticks * pkt, f) != (size_t)n_streams * n_ticks * pkt) rc = 4;
         if (f) fclose(f);
     }
-    printf("{\"workers\": %d, \"devices\": %d, \"streams\": %d, \"ticks\": %d, \"wall_ms\": %.3f, \"busy_ms_per_tick\": [", n_workers, n_dev,
+#ifdef WMX_EXAMPLE_RCCL
+    printf("{\"far_end\": \"ncclBroadcast from GPU 0\", ");
+#else
+    printf("{\"far_end\": \"hipMemcpyAsync per worker\", ");
+#endif
+    printf("\"workers\": %d, \"devices\": %d, \"streams\": %d, \"ticks\": %d, \"wall_ms\": %.3f, \"busy_ms_per_tick\": [", n_workers, n_dev,
            n_streams, n_ticks, wall);
     for (int w = 0; w < n_workers; w++) printf("%s%.4f", w ? ", " : "", sh[w].busy_ms / n_ticks);
     printf("], \"rc\": %d}\n", rc);

@@ -15,10 +15,12 @@ from test_aec_gpu import check_float_path
 from wmix_amd import synth
 
 EXE = os.path.join(ROOT, "examples", "host_chain")
+EXE_RCCL = os.path.join(ROOT, "examples", "host_chain_rccl")
 
 
 def test_host_chain_is_built():
     assert os.path.exists(EXE), "examples/host_chain missing: run __graft_entry__.build()"
+    assert os.path.exists(EXE_RCCL), "examples/host_chain_rccl missing: run __graft_entry__.build()"
 
 
 @pytest.mark.gpu
@@ -35,6 +37,26 @@ def test_host_chain_shards_vs_oracle(tmp_path, oracle_port, workers):
     assert r.returncode == 0, r.stderr
     info = json.loads(r.stdout.strip().splitlines()[-1])
     assert info["workers"] == workers and info["rc"] == 0 and len(info["busy_ms_per_tick"]) == workers
+    got = np.fromfile(tmp_path / "out.i16", dtype="<i2").reshape(S, T * pkt)
+    want = np.stack([L.run_chain(oracle_port, 1, freq, 5, 15, far, near[s], pkt, prefix="orc") for s in range(S)])
+    check_float_path(got, want, max_fraction=1e-4)
+
+
+@pytest.mark.gpu
+def test_host_chain_far_end_through_rccl(tmp_path, oracle_port):
+    """The RCCL build: one worker per device, the far-end uploaded to GPU 0 only and broadcast from there every tick
+    (ncclBroadcast on each worker's communicator and stream).  Runs on however many devices the box has (one here: the
+    broadcast group has a single rank, the code path is the same)."""
+    S, T, freq, pkt = 24, 120, 16000, 160
+    far = synth.far_end(9710, T, pkt)
+    near = synth.near_end(9711, S, T, pkt, far=far).reshape(S, T * pkt)
+    far.astype("<i2").tofile(tmp_path / "far.i16")
+    near.astype("<i2").tofile(tmp_path / "near.i16")
+    r = subprocess.run([EXE_RCCL, str(tmp_path / "far.i16"), str(tmp_path / "near.i16"), str(tmp_path / "out.i16"), str(S), str(T)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["rc"] == 0 and info["far_end"].startswith("ncclBroadcast") and info["workers"] == info["devices"]
     got = np.fromfile(tmp_path / "out.i16", dtype="<i2").reshape(S, T * pkt)
     want = np.stack([L.run_chain(oracle_port, 1, freq, 5, 15, far, near[s], pkt, prefix="orc") for s in range(S)])
     check_float_path(got, want, max_fraction=1e-4)
