@@ -334,8 +334,8 @@ __device__ __forceinline__ float row_ld(GlobalRow row, unsigned lane_bytes, int 
 // The lane's byte offset into row R (less kHistMid) is ONE vector register per block and every (partition, word) of the
 // history an immediate of the load: global_load_dword v, v_off, s[hist] offset:imm.  No address instruction per row, on
 // either unit: formed on the scalar unit a row cost 12 scalar instructions (index modulo the ring, times the row size, a 64-bit
-// add), and a scalar instruction occupies a compute unit's one scalar ALU for about as long as two vector instructions
-// occupy a SIMD (tools_dev/ubench/issue_spread.hip).
+// add) in one dependent chain -- 48 rows per block -- and a wave issues one instruction of any kind per ~5 cycles at best,
+// with four waves per SIMD to cover for it (0.749 -> 0.724 ms).
 constexpr int kHistRowBytes = 130 * 4, kHistMid = 2860;  // |kHistMid - 520 p + 4 word| < 4096 for p < 12, word < 130
 struct HistRows {
     GlobalRow base;
