@@ -102,6 +102,9 @@ struct AecConsts {  // copied to LDS by both kernels
 };
 constexpr int kAecConstWords = sizeof(AecConsts) / 4;
 
+// WEBRTC_SPL_SAT as the reference spells it: a NaN fails both comparisons and passes through (and the conversion to int16 behind
+// it makes it 0, on x86 as on gfx950).  NaNs do reach this in the reference's own runs (the AEC's first blocks), so the one-instruction
+// median v_med3_f32(v, -32768, 32767), which answers a NaN with -32768, is not a substitute -- tried, aec_golden caught it.
 __device__ __forceinline__ float sat16f(float v) { return v > 32767.f ? 32767.f : (v < -32768.f ? -32768.f : v); }
 
 // spectrum of a packed rdft array: bin b of a[] (StoreAsComplex / TimeToFrequency layout rules)
