@@ -24,6 +24,7 @@
 static int16_t sat16(int32_t v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : (int16_t)v); }
 static int32_t wmul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
 static int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+static int32_t wneg(int32_t a) { return (int32_t)(0u - (uint32_t)a); } /* -a; INT32_MIN stays INT32_MIN, as on the reference's CPU */
 static int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
 static int32_t wshl(int32_t a, int s) { return (int32_t)((uint32_t)a << s); }
 static int32_t shift_w32(int32_t x, int c) { return c >= 0 ? wshl(x, c) : (x >> (-c)); }
@@ -80,7 +81,7 @@ static int32_t sqrt_local(int32_t in)
     B = wadd(B, 0x40000000);
     B = wadd(B, 0x40000000);
     x2 = wmul(wmul(x_half, x_half), 2);
-    A = -x2;
+    A = wneg(x2);
     B = wadd(B, A >> 1);
     A >>= 16;
     A = wmul(wmul(A, A), 2);
@@ -109,7 +110,7 @@ int32_t orc_spl_sqrt(int32_t value)
         A = 0x7FFFFFFF;
     int16_t x_norm = (int16_t)(A >> 16), nshift = (int16_t)(sh / 2), t16;
     A = wshl((int32_t)x_norm, 16);
-    A = A >= 0 ? A : -A;
+    A = A >= 0 ? A : wneg(A);
     A = sqrt_local(A);
     if (2 * nshift == sh) {
         t16 = (int16_t)(A >> 16);
@@ -154,7 +155,7 @@ static int16_t vad_process(orc_agc_vad *v, const int16_t *in, int n)
             int32_t out = buf2[k] + hp;
             t32 = 600 * out;
             hp = (int16_t)((t32 >> 10) - buf2[k]);
-            nrg = wadd(nrg, (out * out) >> 6);
+            nrg = wadd(nrg, wmul(out, out) >> 6); /* wraps for |out| > 46 340 (full-scale input), digital_agc.c:633 */
         }
     }
     v->hp_state = hp;

@@ -89,3 +89,35 @@ def test_handles_know_their_device(cuda, wmx):
     assert wmx.wmx_handle_device(ns._h) == torch.cuda.current_device()
     assert wmx.wmx_handle_device(None) == -10001
     ns.close()
+
+
+def _edge_signals(freq, n):
+    """Per-stream (far, near) pairs the synthetic recipe never produces: activity that falls into digital silence (the AEC's
+    smoothed spectra and the NS's noise estimate decay geometrically -- into float denormals -- for the rest of the run),
+    full-scale square waves (every sample clips), a DC offset, and silence from the first sample on."""
+    pkt = freq // 100
+    rng = np.random.default_rng(77)
+    t = np.arange(n * pkt)
+    noise = lambda a: rng.integers(-a, a + 1, n * pkt).astype(np.int16)
+    far = noise(8000)
+    far[60 * pkt:] = 0                                   # far-end falls silent after 0.6 s
+    near = np.zeros((5, n * pkt), np.int16)
+    near[0] = (far.astype(np.int32) // 2 + noise(200)).astype(np.int16)
+    near[0, 60 * pkt:] = 0                               # ... and so does the microphone: exact zeros to the end
+    near[1] = np.where((t // 40) % 2 == 0, 32767, -32768).astype(np.int16)   # full-scale square wave
+    near[2] = (12000 + noise(50)).astype(np.int16)       # DC offset
+    near[3] = 0                                          # never anything
+    near[4] = noise(30000)                               # loud noise, no echo in it
+    return far, near
+
+
+@pytest.mark.parametrize("freq", [16000, 8000])
+def test_silence_clipping_dc_vs_oracle(cuda, oracle_port, freq):
+    """3 000 packets (30 s): long enough for 0.9^n / 0.93^n recursions to run through the denormal range into zero.  The float path
+    must follow the reference there too (x86 keeps denormals; so does gfx950 in the mode the library's kernels are built for)."""
+    from test_aec_gpu import check_float_path, gpu_chain
+    n, pkt = 3000, freq // 100
+    far, near = _edge_signals(freq, n)
+    got = gpu_chain(cuda, 1, freq, 15, far, near)
+    want = np.stack([L.run_chain(oracle_port, 1, freq, 5, 15, far, near[s], pkt, prefix="orc") for s in range(near.shape[0])])
+    check_float_path(got, want, max_fraction=1e-4)

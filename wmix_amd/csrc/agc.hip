@@ -272,7 +272,7 @@ __device__ void agc_packet(const AgcRef &S, const int32_t *__restrict__ gain_tab
                 const int32_t o = b2[j] + hp;
                 const int32_t t = 600 * o;
                 hp = (int16_t)((t >> 10) - b2[j]);
-                nrg = wadd(nrg, (o * o) >> 6);
+                nrg = wadd(nrg, wmul(o, o) >> 6);  // |o| reaches 65 534: the square wraps in the reference (digital_agc.c:633), negative included
             }
         }
 #pragma unroll
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void agc_pipe_kernel(int16_t *s16, int32_t *s3
                     const int32_t o = b2 + hp;
                     const int32_t t = 600 * o;
                     hp = (int16_t)((t >> 10) - b2);
-                    nrg = wadd(nrg, (o * o) >> 6);
+                    nrg = wadd(nrg, wmul(o, o) >> 6);  // |o| reaches 65 534: the square wraps in the reference (digital_agc.c:633), negative included
                 }
             }
 #pragma unroll

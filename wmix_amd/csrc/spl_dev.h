@@ -13,6 +13,9 @@ namespace wmx {
 __device__ __forceinline__ int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
 __device__ __forceinline__ int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
 __device__ __forceinline__ int32_t wmul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
+// -a with INT32_MIN staying INT32_MIN (what the reference's `-x` does on the hardware it runs on; as `-a` it is undefined, and the
+// compiler may use that)
+__device__ __forceinline__ int32_t wneg(int32_t a) { return (int32_t)(0u - (uint32_t)a); }
 __device__ __forceinline__ int32_t wshl(int32_t a, int s) { return (int32_t)((uint32_t)a << s); }
 __device__ __forceinline__ int32_t shift_w32(int32_t x, int c) { return c >= 0 ? wshl(x, c) : (x >> (-c)); }
 __device__ __forceinline__ int16_t sat_w16(int32_t v) { return (int16_t)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v)); }
@@ -46,7 +49,7 @@ __device__ inline int32_t spl_sqrt_local(int32_t in) {
     B = wadd(B, 0x40000000);
     B = wadd(B, 0x40000000);
     x2 = wmul(wmul(x_half, x_half), 2);
-    A = -x2;
+    A = wneg(x2);  // x_half == -32768: x2 wraps to INT32_MIN and stays there
     B = wadd(B, A >> 1);
     A >>= 16;
     A = wmul(wmul(A, A), 2);
@@ -73,7 +76,7 @@ __device__ inline int32_t spl_sqrt(int32_t value) {
         A = 0x7FFFFFFF;
     const int16_t x_norm = (int16_t)(A >> 16), nshift = (int16_t)(sh / 2);
     A = wshl((int32_t)x_norm, 16);
-    A = A >= 0 ? A : -A;
+    A = A >= 0 ? A : wneg(A);
     A = spl_sqrt_local(A);
     if (2 * nshift == sh) {
         const int16_t t16 = (int16_t)(A >> 16);
