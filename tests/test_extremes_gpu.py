@@ -78,3 +78,61 @@ def test_aec_on_extreme_signals(cuda, oracle_port, freq, far_kind):
     got = gpu_aec(cuda, 1, freq, 10, 0, far, x.copy())
     want = np.stack([L.run_aec(oracle_port, 1, freq, 10, far, s, pkt, prefix="orc") for s in x])
     check_float_path(got, want, max_fraction=1e-4)
+
+
+def _stereo(x):
+    """two-channel versions of the extreme signals: every ordered pair (left = signal i, right = signal j) for a few i, j --
+    opposite full-scale signs in the two channels is what the wrappers' (L + R) / 2 averaging must round like the reference"""
+    pairs = [(0, 1), (1, 0), (2, 3), (3, 4), (4, 3), (5, 6), (6, 2), (3, 3)]
+    out = np.empty((len(pairs), x.shape[1] * 2), np.int16)
+    for r, (i, j) in enumerate(pairs):
+        out[r, 0::2] = x[i]
+        out[r, 1::2] = x[j]
+    return ["%d|%d" % p for p in pairs], out
+
+
+@pytest.mark.parametrize("freq", [8000, 16000, 32000])
+def test_two_channel_agc_vad_ns_on_extreme_signals(cuda, oracle_port, freq):
+    from test_ns_gpu import run_gpu as gpu_ns
+    from test_vadagc_gpu import gpu_agc, gpu_vad
+    pkt, _, x = extreme_signals(freq, 400)
+    names, s2 = _stereo(x)
+    # the oracle runners take FRAMES (samples per channel) per call
+    _same(gpu_agc(cuda, 2, freq, 5, s2.copy()), np.stack([L.run_agc(oracle_port, 2, freq, 5, s, pkt, prefix="orc") for s in s2]), names, "agc 2ch %d" % freq)
+    _same(gpu_vad(cuda, 2, freq, 10, 1, s2.copy()), np.stack([L.run_vad(oracle_port, 2, freq, 10, s, pkt, prefix="orc") for s in s2]), names, "vad 2ch %d" % freq)
+    _same(gpu_ns(cuda, 2, freq, s2.copy()), np.stack([L.run_ns(oracle_port, 2, freq, s, pkt, prefix="orc") for s in s2]), names, "ns 2ch %d" % freq)
+
+
+@pytest.mark.parametrize("value", [0, 1, 30, 90])
+def test_agc_gain_settings_on_extreme_signals(cuda, oracle_port, value):
+    """agc_init's compression gain at its ends (src/webrtc.c:726-760 passes it straight to WebRtcAgc_set_config)"""
+    from test_vadagc_gpu import gpu_agc
+    pkt, names, x = extreme_signals(16000, 400)
+    _same(gpu_agc(cuda, 1, 16000, value, x.copy()), np.stack([L.run_agc(oracle_port, 1, 16000, value, s, pkt, prefix="orc") for s in x]), names, "agc gain %d" % value)
+
+
+@pytest.mark.parametrize("freq,ims,k", [(8000, 20, 1), (16000, 30, 1), (16000, 10, 3), (32000, 20, 2)])
+def test_vad_intervals_on_extreme_signals(cuda, oracle_port, freq, ims, k):
+    from test_vadagc_gpu import gpu_vad, vad_pkg
+    pkt = vad_pkg(freq, ims)  # the wrapper's own packet: 20 ms when the interval allows it and the rate is at most 16 kHz, else 10 ms
+    _, names, x = extreme_signals(freq, 480)
+    x = x[:, : (x.shape[1] // (pkt * k)) * pkt * k]
+    _same(gpu_vad(cuda, 1, freq, ims, k, x.copy()), np.stack([L.run_vad(oracle_port, 1, freq, ims, s, k * pkt, prefix="orc") for s in x]), names,
+          "vad %d Hz %d ms x%d" % (freq, ims, k))
+
+
+@pytest.mark.parametrize("freq,ims,delay", [(8000, 20, 0), (16000, 10, 120), (16000, 20, 500), (8000, 10, 40)])
+def test_aec_aecm_intervals_and_delays_on_extreme_signals(cuda, oracle_port, freq, ims, delay):
+    from test_aec_gpu import check_float_path, gpu_aec
+    from test_aecm_gpu import run_gpu as gpu_aecm
+    pkt = freq // 1000 * ims
+    _, names, x = extreme_signals(freq, 300 * ims // 10)
+    x = x[:, : (x.shape[1] // pkt) * pkt]
+    far = x[names.index("loud")]
+    got = gpu_aec(cuda, 1, freq, ims, delay, far, x.copy())
+    want = np.stack([L.run_aec(oracle_port, 1, freq, ims, far, s, pkt, delay_ms=delay, prefix="orc") for s in x])
+    check_float_path(got, want, max_fraction=1e-4)
+    got, rc = gpu_aecm(cuda, 1, freq, ims, far, x.copy(), delay=delay)
+    assert rc == 0
+    _same(got, np.stack([L.run_aecm(oracle_port, 1, freq, ims, far, s, pkt, delay_ms=delay, prefix="orc") for s in x]), names,
+          "aecm %d Hz %d ms delay %d" % (freq, ims, delay))
