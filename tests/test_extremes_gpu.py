@@ -136,3 +136,38 @@ def test_aec_aecm_intervals_and_delays_on_extreme_signals(cuda, oracle_port, fre
     assert rc == 0
     _same(got, np.stack([L.run_aecm(oracle_port, 1, freq, ims, far, s, pkt, delay_ms=delay, prefix="orc") for s in x]), names,
           "aecm %d Hz %d ms delay %d" % (freq, ims, delay))
+
+
+@pytest.mark.parametrize("kind", ["min", "max", "alternating", "full_range"])
+def test_mixer_on_extreme_sources(cuda, oracle_port, kind):
+    """wmix_load_data / wmix_pcm_zoom with sources at the ends of int16: the N-way sum saturates at every sample, the
+    averaging of channel pairs and the volume reduction see their largest operands (src/wmix.c:49-222, 113-127)."""
+    from test_mix_gpu import gpu_load
+    from test_mix_oracle import _bind, orc_load, orc_zoom
+    import torch
+    from wmix_amd import mix
+    _bind(oracle_port)
+    rng = np.random.default_rng(31)
+
+    def make(n):
+        if kind == "min":
+            return np.full(n, -32768, np.int16)
+        if kind == "max":
+            return np.full(n, 32767, np.int16)
+        if kind == "alternating":
+            return np.where(np.arange(n) % 2 == 0, 32767, -32768).astype(np.int16)
+        return rng.integers(-32768, 32768, n).astype(np.int16)
+
+    for (ring_chn, ring_freq, freq, chn, rmode, rarg, nsrc, sbytes, start) in (
+            (1, 8000, 32000, 2, 1, 1, 8, 1280, 0), (1, 8000, 8000, 1, 2, 2, 8, 320, 64), (2, 16000, 16000, 2, 1, 3, 6, 1280, 0),
+            (1, 8000, 44100, 2, 3, 1, 5, 1764, 32), (1, 8000, 11025, 1, 1, 1, 7, 440, 0)):
+        src = make(nsrc * sbytes // 2 + 8)
+        want, meta = orc_load(oracle_port, ring_chn, ring_freq, freq, chn, rmode, rarg, nsrc, sbytes, start, src)
+        rings, h, t = gpu_load(cuda, ring_chn, ring_freq, freq, chn, rmode, rarg, nsrc, sbytes, start, src)
+        assert np.array_equal(rings[0], want), (kind, ring_chn, ring_freq, freq, chn, rmode, rarg)
+        assert (t, h) == tuple(meta[-1])
+    for (ic, ifr, oc, ofr, n) in ((1, 8000, 2, 16000, 640), (2, 32000, 1, 8000, 2560), (2, 44100, 2, 8000, 3528), (1, 16000, 1, 48000, 640),
+                                  (2, 8000, 2, 8000, 640)):
+        x = make(n // 2)
+        got = mix.pcm_zoom(ic, ifr, torch.from_numpy(x[None, :]).to(cuda), oc, ofr).cpu().numpy()[0]
+        assert np.array_equal(got, orc_zoom(oracle_port, ic, ifr, x, oc, ofr)), (kind, ic, ifr, oc, ofr)
