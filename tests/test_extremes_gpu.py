@@ -171,3 +171,28 @@ def test_mixer_on_extreme_sources(cuda, oracle_port, kind):
         x = make(n // 2)
         got = mix.pcm_zoom(ic, ifr, torch.from_numpy(x[None, :]).to(cuda), oc, ofr).cpu().numpy()[0]
         assert np.array_equal(got, orc_zoom(oracle_port, ic, ifr, x, oc, ofr)), (kind, ic, ifr, oc, ofr)
+
+
+@pytest.mark.parametrize("kind", range(4))
+@pytest.mark.parametrize("what", ["huge", "tiny", "spike", "zeros"])
+def test_mfft_on_extreme_values(cuda, oracle_port, kind, what):
+    """math/fft.c on values at the ends of float: 1e18 (the amplitude's re*re + im*im stays finite in double, as in the
+    reference), float denormals, one full-scale spike in zeros, all zeros (atan2(0, 0))."""
+    import torch
+    from test_mfft_gpu import check_outputs
+    from wmix_amd import mfft
+    n = 256
+    rng = np.random.default_rng(9)
+    re, im = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    if what == "huge":
+        re, im = re * np.float32(1e18), im * np.float32(1e18)
+    elif what == "tiny":
+        re, im = re * np.float32(1e-41), im * np.float32(1e-41)
+    elif what == "spike":
+        re[:], im[:] = 0, 0
+        re[17] = 32767
+    else:
+        re[:], im[:] = 0, 0
+    got = mfft.transform(kind, torch.from_numpy(re[None]).to(cuda), torch.from_numpy(im[None]).to(cuda))
+    want = L.mfft(oracle_port, kind, re, im, n, prefix="orc")
+    check_outputs(got, lambda k: want[k], (kind, what))

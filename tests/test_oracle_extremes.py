@@ -37,3 +37,17 @@ def test_port_equals_reference_on_extreme_signals(oracle_port, oracle_ref, freq)
                 a, b = fn(oracle_port, *args, prefix="orc"), fn(oracle_ref, *args, prefix="ref")
                 assert np.abs(a.astype(np.int32) - b.astype(np.int32)).max() <= (0 if fn in (L.run_nsx, L.run_aecm) else 1), \
                     "%s %s %d" % (fn.__name__, name, freq)
+
+
+@pytest.mark.parametrize("kind", range(4))
+def test_mfft_port_equals_reference_on_extreme_values(oracle_port, oracle_ref, kind):
+    n = 256
+    rng = np.random.default_rng(9)
+    base_re, base_im = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    spike = np.zeros(n, np.float32)
+    spike[17] = 32767
+    for re, im in ((base_re * np.float32(1e18), base_im * np.float32(1e18)), (base_re * np.float32(1e-41), base_im * np.float32(1e-41)),
+                   (spike, np.zeros(n, np.float32)), (np.zeros(n, np.float32), np.zeros(n, np.float32))):
+        a, b = L.mfft(oracle_port, kind, re, im, n, prefix="orc"), L.mfft(oracle_ref, kind, re, im, n, prefix="ref")
+        for k in a:
+            assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), (kind, k)
