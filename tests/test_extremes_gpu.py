@@ -196,3 +196,44 @@ def test_mfft_on_extreme_values(cuda, oracle_port, kind, what):
     got = mfft.transform(kind, torch.from_numpy(re[None]).to(cuda), torch.from_numpy(im[None]).to(cuda))
     want = L.mfft(oracle_port, kind, re, im, n, prefix="orc")
     check_outputs(got, lambda k: want[k], (kind, what))
+
+
+@pytest.mark.parametrize("freq", [8000, 16000])
+def test_echo_cancellers_on_perfect_echoes(cuda, oracle_port, freq):
+    """near == far, bit for bit (coherence exactly 1: the NLP's `1 - cohxd` lands on 0 or just below it, and powf of a negative
+    gain is a NaN the reference then converts to 0), near == -far, a pure delay, an exact half, and far-end only (near = 0)."""
+    from test_aec_gpu import check_float_path, gpu_aec
+    from test_aecm_gpu import run_gpu as gpu_aecm
+    pkt, n = freq // 100, 900
+    rng = np.random.default_rng(21)
+    far = rng.integers(-20000, 20001, n * pkt).astype(np.int16)
+    near = np.stack([far, -far, np.roll(far, 3), far // 2, np.zeros_like(far), np.roll(far, 40) // 4 + rng.integers(-3, 4, far.size).astype(np.int16)])
+    got = gpu_aec(cuda, 1, freq, 10, 0, far, near.copy())
+    want = np.stack([L.run_aec(oracle_port, 1, freq, 10, far, s, pkt, prefix="orc") for s in near])
+    check_float_path(got, want, max_fraction=1e-4)
+    got, rc = gpu_aecm(cuda, 1, freq, 10, far, near.copy())
+    assert rc == 0
+    want = np.stack([L.run_aecm(oracle_port, 1, freq, 10, far, s, pkt, prefix="orc") for s in near])
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("freq", [8000, 16000, 32000])
+def test_noise_suppressors_on_tones_and_trains(cuda, oracle_port, freq):
+    """a sine exactly on an FFT bin, one between two bins, a sweep, a click train at the block rate, white noise switched on and off:
+    spectral flatness, the LRT features and the quantile noise estimate at their ends"""
+    from test_ns_gpu import run_gpu as gpu_ns
+    pkt, n = freq // 100, 600
+    t = np.arange(n * pkt)
+    fs = min(freq, 16000)
+    rng = np.random.default_rng(4)
+    x = np.stack([
+        np.round(12000 * np.sin(2 * np.pi * t * (16 * fs / 256) / freq)),
+        np.round(12000 * np.sin(2 * np.pi * t * (16.5 * fs / 256) / freq)),
+        np.round(9000 * np.sin(2 * np.pi * (100 + t * 3000.0 / t.size) * t / freq)),
+        (t % (pkt if freq <= 16000 else pkt // 2) == 0) * 30000.0,
+        np.where((t // (pkt * 30)) % 2 == 0, rng.integers(-8000, 8001, t.size), 0),
+    ]).astype(np.int16)
+    _same(gpu_ns(cuda, 1, freq, x.copy()), np.stack([L.run_ns(oracle_port, 1, freq, s, pkt, prefix="orc") for s in x]), list("abcde"), "ns %d" % freq)
+    if freq < 32000:
+        from test_nsx_gpu import run_gpu as gpu_nsx
+        _same(gpu_nsx(cuda, 1, freq, x.copy()), np.stack([L.run_nsx(oracle_port, 1, freq, s, pkt, prefix="orc") for s in x]), list("abcde"), "nsx %d" % freq)

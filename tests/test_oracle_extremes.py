@@ -51,3 +51,21 @@ def test_mfft_port_equals_reference_on_extreme_values(oracle_port, oracle_ref, k
         a, b = L.mfft(oracle_port, kind, re, im, n, prefix="orc"), L.mfft(oracle_ref, kind, re, im, n, prefix="ref")
         for k in a:
             assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), (kind, k)
+
+
+@pytest.mark.parametrize("freq", [8000, 16000])
+def test_port_equals_reference_on_perfect_echoes_and_tones(oracle_port, oracle_ref, freq):
+    pkt, n = freq // 100, 500
+    rng = np.random.default_rng(21)
+    far = rng.integers(-20000, 20001, n * pkt).astype(np.int16)
+    t = np.arange(n * pkt)
+    for near in (far, -far, np.roll(far, 3), far // 2, np.zeros_like(far)):
+        a, b = L.run_aec(oracle_port, 1, freq, 10, far, near, pkt, prefix="orc"), L.run_aec(oracle_ref, 1, freq, 10, far, near, pkt, prefix="ref")
+        assert np.abs(a.astype(np.int32) - b.astype(np.int32)).max() <= 1
+        a, b = L.run_aecm(oracle_port, 1, freq, 10, far, near, pkt, prefix="orc"), L.run_aecm(oracle_ref, 1, freq, 10, far, near, pkt, prefix="ref")
+        assert np.array_equal(a, b)
+    for x in (np.round(12000 * np.sin(2 * np.pi * t * (16 * freq / 256) / freq)), np.round(12000 * np.sin(2 * np.pi * t * (16.5 * freq / 256) / freq)),
+              (t % pkt == 0) * 30000.0):
+        x = x.astype(np.int16)
+        assert np.array_equal(L.run_ns(oracle_port, 1, freq, x, pkt, prefix="orc"), L.run_ns(oracle_ref, 1, freq, x, pkt, prefix="ref"))
+        assert np.array_equal(L.run_nsx(oracle_port, 1, freq, x, pkt, prefix="orc"), L.run_nsx(oracle_ref, 1, freq, x, pkt, prefix="ref"))
