@@ -247,6 +247,46 @@ def test_fixed_point_modules_lifetime_bit_exact(cuda, oracle_port):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("seed", [11, 12])
+def test_fixed_point_random_schedules_bit_exact(cuda, oracle_port, seed):
+    """AECM and NSX under seeded random schedules (six cohorts, own delays, leaving and returning streams, launches of
+    1..29 packets), loud input on half of the streams so that the fixed-point code runs near its ends: every sample equal."""
+    import torch
+    from wmix_amd.aecm import AecmBatch
+    from wmix_amd.nsx import NsxBatch
+    freq, S, nc = (16000, 8000)[seed & 1], 10, 6
+    pkt = freq // 100
+    far = synth.far_end(9600 + seed, T, pkt).reshape(T, pkt)
+    near = synth.near_end(9700 + seed, S, T, pkt, far=far.reshape(-1)).reshape(S, T, pkt)
+    rng = np.random.default_rng(seed)
+    near[::2] = rng.integers(-32768, 32768, near[::2].shape).astype(np.int16)
+    lives, cohort_start, delays = _random_schedule(seed, S, nc)
+    dfar = torch.from_numpy(far).to(cuda)
+    am = AecmBatch(S, 1, freq, 10, n_cohorts=nc)
+    d = torch.from_numpy(near.copy()).to(cuda)
+
+    def run_aecm(t0, t1, on):
+        f = t0
+        while f < t1:
+            e = min(t1, f + int(rng.integers(1, 30)))
+            rc, codes = am.run_cohorts(dfar[f:e], d[:, f:e], delays, cohort_on=on)
+            assert rc == 0 and not codes.any()
+            f = e
+    _drive(am, run_aecm, S, lives, cohort_start, nc)
+    got = d.cpu().numpy()
+    am.close()
+    want = _expected(S, near, lambda s, a, b, c: L.run_aecm(oracle_port, 1, freq, 10, far[a:b].reshape(-1), near[s, a:b].reshape(-1), pkt,
+                                                             delays[c], prefix="orc"), lives)
+    assert np.array_equal(got, want)
+    nb = NsxBatch(S, 1, freq)
+    d = torch.from_numpy(near.copy()).to(cuda)
+    _drive(nb, lambda t0, t1, on: nb.process(d[:, t0:t1]), S, lives, cohort_start, nc)
+    got = d.cpu().numpy()
+    nb.close()
+    want = _expected(S, near, lambda s, a, b, c: L.run_nsx(oracle_port, 1, freq, near[s, a:b].reshape(-1), pkt, prefix="orc"), lives)
+    assert np.array_equal(got, want)
+
+
 def test_single_stage_lifetime_bit_exact(cuda, oracle_port):
     """NS, AGC and VAD on their own batch handles (the chain test goes through wmx_chain_*): reset + active mask."""
     import torch
