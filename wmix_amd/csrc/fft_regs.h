@@ -31,10 +31,10 @@ namespace wmx {
 //     gl bit 2 = lane bit 4: v_permlane16_swap_b32 (odd rows of one register <-> even rows of the other)
 //     gl bit 3 = lane bit 5: v_permlane32_swap_b32 (upper half of one register <-> lower half of the other)
 // -- the two swaps are exactly the exchange a transpose step needs, one instruction for both registers, in place.
-// Measured (tools_dev/ubench/pk_rate.hip, ns of SIMD time per wave64 instruction at 4 waves/SIMD): v_mov_b32 1.35,
-// v_mov_b32_dpp 2.0, v_permlane16_swap / v_permlane32_swap 3.6, v_cndmask_b32 2.0 (behind its v_cmp; a run of them on a VCC
-// written long before: 9.8), ds_bpermute 10.  Per register pair an exchange costs 5.4 (copy + two DPP moves) or 3.6 (swap); the contiguous-row
-// mapping used before needed a quad_perm fetch + select per register for lane bits 0 / 1 (8.4 per pair).
+// Measured (tools_dev/ubench/issue_cost.hip, cycles of SIMD time per wave64 instruction at 4 waves/SIMD, profiles/r03/issue_costs.json):
+// v_mov_b32 2.0, v_mov_b32_dpp 4.0, v_permlane16_swap / v_permlane32_swap 7.6, v_cndmask_b32 4.0 behind its v_cmp (4.0), ds_bpermute 24 of
+// the LDS pipe.  Per register pair an exchange costs 10 (copy + two DPP moves) or 7.6 (swap); the contiguous-row mapping used before
+// needed a quad_perm fetch + select per register for lane bits 0 / 1 (16 per pair).
 __device__ __forceinline__ int fft_group(int lane) { return lane & 3; }
 __device__ __forceinline__ int fft_index(int lane) { return lane >> 2; }
 template <int CTRL, int BANK_MASK = 0xf>
