@@ -69,6 +69,64 @@ __global__ void rtp_ingest_kernel(const uint8_t *__restrict__ packets, long pack
     }
 }
 
+// ---- the same two kernels for the layouts the hosts use: packets and PCM rows on 4 / 8-byte boundaries.  One lane takes FOUR
+// codes (one 32-bit word of payload, one 8-byte store of samples; or four gathered samples, one 32-bit store of codes), and
+// the lanes are dealt over (stream, word) pairs instead of one workgroup per stream: 65 536 streams were 65 536 workgroups of
+// 64 / 256 lanes moving one byte each (115 us for the ingest, 40 for the egress); now 1.3 M lanes of four codes.
+constexpr int kRtpWords = kRtpG711Payload / 4;
+__global__ __launch_bounds__(256) void rtp_ingest_wide_kernel(const uint8_t *__restrict__ packets, long packet_stride, int16_t *pcm,
+                                                               long pcm_stride, uint32_t *pcm_bytes, uint16_t *seq_raw, int n_streams) {
+    const size_t total = (size_t)n_streams * kRtpWords;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int stream = (int)(t / kRtpWords), c = (int)(t - (size_t)stream * kRtpWords);
+        const uint8_t *pkt = packets + (size_t)stream * packet_stride;
+        const uint32_t h0 = *reinterpret_cast<const uint32_t *>(pkt);  // bytes 0..3 of the header: flags, pt, seq as stored
+        const int pt = (h0 >> 8) & 0x7F;
+        const bool g711 = pt == 8 || pt == 0;  // src/rtp.c:88-95 (AAC-tagged packets: not G.711, size 0 here)
+        if (g711) {
+            const uint32_t w = *reinterpret_cast<const uint32_t *>(pkt + kRtpHeader + 4 * c);
+            uint2 o;  // G711a2PCM whatever the pt
+            o.x = ((uint32_t)dec_alaw(w & 0xFF) & 0xFFFFu) | ((uint32_t)dec_alaw((w >> 8) & 0xFF) << 16);
+            o.y = ((uint32_t)dec_alaw((w >> 16) & 0xFF) & 0xFFFFu) | ((uint32_t)dec_alaw(w >> 24) << 16);
+            *reinterpret_cast<uint2 *>(pcm + (size_t)stream * pcm_stride + 4 * c) = o;
+        }
+        if (c == 0) {
+            if (pcm_bytes) pcm_bytes[stream] = g711 ? (uint32_t)kRtpG711Payload * 2 : 0u;
+            if (seq_raw) seq_raw[stream] = (uint16_t)(h0 >> 16);  // pkt[2] | pkt[3] << 8, as stored: rtp_recv does not ntohs
+        }
+    }
+}
+
+template <int LAW>
+__global__ __launch_bounds__(256) void rtp_egress_wide_kernel(const int16_t *__restrict__ pcm, long pcm_stride, const int32_t *__restrict__ idx,
+                                                               int n_codes, int codes_per_ts, uint32_t *seq, uint32_t *ts, uint8_t *packets,
+                                                               long packet_stride, int n_streams, int pt) {
+    const int words = n_codes >> 2;  // n_codes is a multiple of 4 here
+    const size_t total = (size_t)n_streams * words;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int stream = (int)(t / words), j = (int)(t - (size_t)stream * words);
+        const int16_t *src = pcm + (size_t)stream * pcm_stride;
+        uint8_t *pkt = packets + (size_t)stream * packet_stride;
+        const int4 ix = *reinterpret_cast<const int4 *>(idx + 4 * j);
+        auto enc = [](int v) -> uint32_t { return LAW == WMX_LAW_A ? enc_alaw(v) : enc_ulaw(v); };
+        *reinterpret_cast<uint32_t *>(pkt + kRtpHeader + 4 * j) =
+            (enc(src[ix.x]) & 0xFF) | ((enc(src[ix.y]) & 0xFF) << 8) | ((enc(src[ix.z]) & 0xFF) << 16) | (enc(src[ix.w]) << 24);
+        if (j == 0) {
+            const uint32_t tt = ts[stream] + (uint32_t)codes_per_ts;  // timestamp += ret / chn, before the send
+            const uint32_t sq = seq[stream] & 0xFFFFu;
+            uint32_t *hd = reinterpret_cast<uint32_t *>(pkt);
+            // v = 2, p = x = 0, cc = 0 | m = 1, pt | seq, timestamp big endian on the wire | ssrc = 0 (src/wmixTask.c:1058)
+            hd[0] = (2u << 6) | ((0x80u | (uint32_t)pt) << 8) | ((sq >> 8) << 16) | ((sq & 0xFFu) << 24);
+            hd[1] = (tt >> 24) | (((tt >> 16) & 0xFFu) << 8) | (((tt >> 8) & 0xFFu) << 16) | ((tt & 0xFFu) << 24);
+            hd[2] = 0;
+            ts[stream] = tt;
+            seq[stream] = (sq + 1) & 0xFFFFu;  // rtpHeader.seq++ after the send (uint16 wrap)
+        }
+    }
+}
+
+inline bool aligned_to(const void *p, long stride_bytes, int a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0 && stride_bytes % a == 0; }
+
 }  // namespace
 }  // namespace wmx
 
@@ -140,7 +198,15 @@ int wmx_rtp_egress(wmx_rtp *h, int in_chn, int in_freq, const int16_t *d_pcm, ui
     if (packet_bytes) *packet_bytes = (uint32_t)(kRtpHeader + n_codes);
     const dim3 block(256), grid((unsigned)((n_codes + 255) / 256 > 0 ? (n_codes + 255) / 256 : 1), (unsigned)h->n_streams);
     const int pt = h->law == WMX_LAW_A ? 8 : 0;  // RTP_PAYLOAD_TYPE_PCMA / PCMU, src/rtp.h:21-24
-    if (h->law == WMX_LAW_A)
+    if (n_codes >= 4 && n_codes % 4 == 0 && aligned_to(d_packets, packet_stride, 4)) {  // four codes per lane (the gather list is 16-byte aligned)
+        const unsigned wgrid = wmx::stream_grid((size_t)h->n_streams * (n_codes / 4), 256);
+        if (h->law == WMX_LAW_A)
+            hipLaunchKernelGGL((rtp_egress_wide_kernel<WMX_LAW_A>), dim3(wgrid), block, 0, as_stream(stream), d_pcm, pcm_stride, d_idx, n_codes,
+                               n_codes / out_chn, h->d_seq, h->d_ts, d_packets, packet_stride, h->n_streams, pt);
+        else
+            hipLaunchKernelGGL((rtp_egress_wide_kernel<WMX_LAW_U>), dim3(wgrid), block, 0, as_stream(stream), d_pcm, pcm_stride, d_idx, n_codes,
+                               n_codes / out_chn, h->d_seq, h->d_ts, d_packets, packet_stride, h->n_streams, pt);
+    } else if (h->law == WMX_LAW_A)
         hipLaunchKernelGGL((rtp_egress_kernel<WMX_LAW_A>), grid, block, 0, as_stream(stream), d_pcm, pcm_stride, d_idx, n_codes,
                            n_codes / out_chn, h->d_seq, h->d_ts, d_packets, packet_stride, h->n_streams, pt);
     else
@@ -157,8 +223,12 @@ int wmx_rtp_ingest(int n_streams, const uint8_t *d_packets, long packet_stride, 
         return WMX_EINVAL;
     }
     if (n_streams == 0) return 0;
-    hipLaunchKernelGGL(rtp_ingest_kernel, dim3((unsigned)n_streams), dim3(64), 0, as_stream(stream), d_packets, packet_stride, d_pcm,
-                       pcm_stride, d_pcm_bytes, d_seq_raw, n_streams);
+    if (aligned_to(d_packets, packet_stride, 4) && aligned_to(d_pcm, pcm_stride * 2, 8))
+        hipLaunchKernelGGL(rtp_ingest_wide_kernel, dim3(wmx::stream_grid((size_t)n_streams * kRtpWords, 256)), dim3(256), 0, as_stream(stream),
+                           d_packets, packet_stride, d_pcm, pcm_stride, d_pcm_bytes, d_seq_raw, n_streams);
+    else
+        hipLaunchKernelGGL(rtp_ingest_kernel, dim3((unsigned)n_streams), dim3(64), 0, as_stream(stream), d_packets, packet_stride, d_pcm,
+                           pcm_stride, d_pcm_bytes, d_seq_raw, n_streams);
     WMX_LAUNCH_CHECK();
     return 0;
 }
