@@ -80,3 +80,32 @@ def test_rejects_bad_arguments(wmx):
     assert wmx.wmx_rtp_create(C.byref(h), 0, 0) == -10001
     assert wmx.wmx_rtp_create(C.byref(h), 4, 5) == -10001
     assert wmx.wmx_rtp_ingest(1, None, 172, None, 160, None, None, None) == -10001
+
+
+def test_unaligned_layouts_take_the_byte_kernels_and_agree(cuda):
+    """wmx_rtp_ingest / wmx_rtp_egress use four-codes-per-lane kernels when packets and PCM rows sit on 4 / 8-byte boundaries and
+    the byte-wise ones otherwise: odd packet strides, a packet base one byte off, PCM rows two bytes off must give the same
+    datagrams and samples."""
+    import ctypes as C
+    from wmix_amd._lib import check, lib
+    S = 300
+    x = torch.randint(-32768, 32767, (S, 160), dtype=torch.int16, device=cuda)
+    want = {}
+    for name, stride, off in (("aligned", 172, 0), ("odd stride", 175, 0), ("base off by one", 176, 1)):
+        snd = rtp.RtpSenders(S, "a")
+        buf = torch.zeros(S * stride + 8, dtype=torch.uint8, device=cuda)
+        packets = torch.as_strided(buf, (S, stride), (stride, 1), off)
+        for _ in range(2):
+            out = snd.egress(x, 1, 8000, 1, 8000, packets=packets)
+        want.setdefault("packets", out.clone())
+        assert torch.equal(out, want["packets"]), name
+        for pcm_off in (0, 1):  # PCM rows on an 8-byte boundary, and one sample off it
+            pbuf = torch.zeros(S * 164 + 4, dtype=torch.int16, device=cuda)
+            pcm = torch.as_strided(pbuf, (S, 160), (164, 1), pcm_off)
+            nbytes = torch.zeros(S, dtype=torch.int32, device=cuda)
+            seq = torch.zeros(S, dtype=torch.int16, device=cuda)
+            check(lib().wmx_rtp_ingest(S, packets.data_ptr(), packets.stride(0), pcm.data_ptr(), pcm.stride(0), nbytes.data_ptr(), seq.data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream), "wmx_rtp_ingest")
+            want.setdefault("pcm", pcm.clone())
+            assert torch.equal(pcm, want["pcm"]) and bool((nbytes == 320).all()) and bool((seq.view(torch.uint8).view(S, 2)[:, 1] == 1).all()), (name, pcm_off)
+        snd.close()
