@@ -12,10 +12,7 @@ compute of step k.  All arithmetic is in the HIP kernels; this file only sequenc
 import torch
 
 from . import rtp
-from .aec import AecBatch
-from .agc import AgcBatch
-from .ns import NsBatch
-from .vad import VadBatch
+from .chain import ChainBatch
 
 DATAGRAM = 172  # 12-byte RTP header + 160 G.711 codes (20 ms at 8 kHz), src/rtp.h:33, src/rtp.c:86-95
 FREQ, PKT = 8000, 80
@@ -24,10 +21,9 @@ FREQ, PKT = 8000, 80
 class RtpChain:
     def __init__(self, n_streams, dev, agc_value=5):
         self.n, self.dev = n_streams, dev
-        self.ns = NsBatch(n_streams, 1, FREQ)
-        self.aec = AecBatch(n_streams, 1, FREQ, 10)
-        self.agc = AgcBatch(n_streams, 1, FREQ, agc_value)
-        self.vad = VadBatch(n_streams, 1, FREQ, 10)
+        # the four stages behind one C call per tick (wmx_chain_process: the AEC's far kernel beside the noise suppressor, the VAD one
+        # call over the tick's two packets, as in the heartbeat)
+        self.chain = ChainBatch(n_streams, 1, FREQ, 10, agc_value)
         self.snd = rtp.RtpSenders(n_streams, "a")
         self.pcm = torch.zeros((n_streams, 2 * PKT), dtype=torch.int16, device=dev)
         self.nbytes = torch.zeros(n_streams, dtype=torch.int32, device=dev)
@@ -39,16 +35,12 @@ class RtpChain:
         st = torch.cuda.current_stream().cuda_stream
         check(lib().wmx_rtp_ingest(self.n, packets_in.data_ptr(), packets_in.stride(0), self.pcm.data_ptr(), self.pcm.stride(0),
                                    self.nbytes.data_ptr(), self.seq.data_ptr(), st), "wmx_rtp_ingest")
-        v = self.pcm.view(self.n, 2, PKT)
-        self.ns.process(v)
-        rc, _ = self.aec.process2(far, v)
+        rc, _, _ = self.chain.process(far, self.pcm.view(self.n, 2, PKT))
         assert rc == 0
-        self.agc.process(v)
-        self.vad.process(self.pcm.view(self.n, 1, 2 * PKT), packets_per_call=2)
         return self.snd.egress(self.pcm, 1, FREQ, 1, FREQ, packets=packets_out)
 
     def close(self):
-        for b in (self.ns, self.aec, self.agc, self.vad, self.snd):
+        for b in (self.chain, self.snd):
             b.close()
 
 
