@@ -855,6 +855,8 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
 #undef NS_RELANE
 #undef SCF
 #undef SCI
+#undef ST
+#undef STI
 }
 
 // Register budget = the occupancy the LDS allows: 16 kHz / 32 kHz streams (28.8 KB per workgroup) five workgroups per CU, 8 kHz
