@@ -237,3 +237,29 @@ def test_noise_suppressors_on_tones_and_trains(cuda, oracle_port, freq):
     if freq < 32000:
         from test_nsx_gpu import run_gpu as gpu_nsx
         _same(gpu_nsx(cuda, 1, freq, x.copy()), np.stack([L.run_nsx(oracle_port, 1, freq, s, pkt, prefix="orc") for s in x]), list("abcde"), "nsx %d" % freq)
+
+
+@pytest.mark.parametrize("freq", [16000, 8000])
+def test_every_stage_subset_of_the_chain_on_extreme_signals(cuda, oracle_port, freq):
+    """wmx_chain_process with each of the 15 stage masks (the daemon switches NS / AEC / AGC / VAD on and off independently,
+    src/wmix.c:617-703) on the extreme signals, one C call per tick, against the oracle chain with the same mask."""
+    import torch
+    from test_aec_gpu import check_float_path
+    from wmix_amd.chain import ChainBatch
+    pkt, names, x = extreme_signals(freq, 260)
+    far = x[names.index("loud")]
+    n = far.size // pkt
+    dfar = torch.from_numpy(far.reshape(n, pkt).copy()).to(cuda)
+    for stages in range(1, 16):
+        cb = ChainBatch(x.shape[0], 1, freq, 10, 5, stages)
+        d = torch.from_numpy(x.reshape(x.shape[0], n, pkt).copy()).to(cuda)
+        for f in range(n):
+            rc, _, _ = cb.process(dfar[f:f + 1] if stages & 2 else None, d[:, f:f + 1])
+            assert rc == 0
+        got = d.cpu().numpy().reshape(x.shape[0], -1)
+        cb.close()
+        want = np.stack([L.run_chain(oracle_port, 1, freq, 5, stages, far, s, pkt, prefix="orc") for s in x])
+        if stages & 3:  # a float stage in the path
+            check_float_path(got, want, max_fraction=1e-4)
+        else:
+            assert np.array_equal(got, want), stages
