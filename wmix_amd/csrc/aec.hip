@@ -434,13 +434,20 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
         }
         wait_vm();  // ONE wait for the batch: left to the compiler every load gets its own s_waitcnt vmcnt(23), (22), ... in front of its use
         const float *NQ = F.nyq + 2 * (hist_row_now(n) - 11);  // (re, im) of bin 64 of the rows R - 11 .. R, 24 consecutive words
+        // ... as three scalar loads of eight words (as 24 single words they were 24 scalar-memory instructions)
+        typedef float v8f __attribute__((ext_vector_type(8)));
+        typedef const v8f __attribute__((address_space(4), aligned(8))) *ConstV8;
+        const ConstV8 NQ8 = reinterpret_cast<ConstV8>(reinterpret_cast<size_t>(NQ));
+        v8f nq[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) nq[j] = NQ8[j];
         float y64 = 0.f;
         v2f y2 = v2f{0.f, 0.f};
 #pragma unroll
         for (int p = 0; p < 12; p++) {
             // (yr, yi) += (xr*wr - xi*wi, xr*wi + xi*wr): cmul_w is those four products and two sums, as three packed instructions
             y2 = y2 + cmul_w(xr[p], xi[p], taps.t[p]);
-            const float nr = uniform_ld(NQ + 2 * (11 - p)), ni = uniform_ld(NQ + 2 * (11 - p) + 1);  // ni == 0, wfBuf[1][.][64] == 0
+            const float nr = nq[(2 * (11 - p)) >> 3][(2 * (11 - p)) & 7], ni = nq[(2 * (11 - p) + 1) >> 3][(2 * (11 - p) + 1) & 7];  // ni == 0, wfBuf[1][.][64] == 0
             y64 += nr * W.wn[p] - ni * 0.f;                                                    // used by lane 0 only
         }
         // ---- error e = d - y (aec_core.c:1286-1297): y = second half of the inverse transform of the packed spectrum
