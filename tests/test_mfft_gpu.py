@@ -132,3 +132,64 @@ def test_reference_host_signatures(wmx, oracle_port):
         wmx.fft_stream(p(ch), 64, p(pool), 512, p(af), None)
     want_pool, want_af, _ = loader.mfft_stream(oracle_port, chunks, 512, prefix="orc")
     assert same_bits(pool, want_pool) and same_bits(af, want_af[-1])
+
+
+# ---------------------------------------------------------------- the register-resident kernel (complex sizes 256 .. 1024)
+REGS_CASES = [(kind, n) for kind in range(4) for n in ((256, 512, 1024) if kind in (0, 2) else (512, 1024, 2048))]
+
+
+@pytest.mark.parametrize("kind,n", REGS_CASES)
+def test_more_transforms_than_waves_vs_oracle(cuda, oracle_port, kind, n):
+    """mfft_regs_kernel's waves loop over their share of the batch (a grid of at most 256 x 6 workgroups of 4 waves): 6 500
+    transforms make every wave take a second one and leave a ragged tail; rows spread over the batch (the first, the last,
+    the first of the second round) against the oracle, every output the kind has."""
+    batch = 6500
+    rng = np.random.default_rng(900 + 10 * kind + n)
+    re = (rng.standard_normal((batch, n)) * 2000).astype(np.float32)
+    im = (rng.standard_normal((batch, n)) * 2000).astype(np.float32)
+    got = mfft.transform(kind, torch.from_numpy(re).to(cuda), torch.from_numpy(im).to(cuda))
+    got = {k: v.cpu().numpy() for k, v in got.items()}
+    rows = sorted({0, 1, 3, 4, 255, 3071, 3072, 5119, 5120, 6143, 6144, 6145, batch - 2, batch - 1})
+    for b in rows:
+        want = loader.mfft(oracle_port, kind, re[b], im[b], n, prefix="orc")
+        for k, w in want.items():
+            assert (phase_close if k == "p" else same_bits)(got[k][b], w), (kind, n, b, k)
+
+
+@pytest.mark.parametrize("kind,n", [(1, 1024), (3, 512), (1, 2048)])
+def test_real_input_that_is_not_8_byte_aligned(cuda, oracle_port, kind, n):
+    """FFTR / IFFTR read sample pairs with 8-byte loads when the array allows it; an array that starts on an odd float goes
+    through the LDS kernel: same bits."""
+    batch = 5
+    rng = np.random.default_rng(n + kind)
+    flat = torch.from_numpy((rng.standard_normal(batch * n + 1) * 500).astype(np.float32)).to(cuda)
+    x = flat[1:].view(batch, n)
+    assert x.data_ptr() % 8 == 4 and x.is_contiguous()
+    got = mfft.transform(kind, x, None, want="ri")
+    aligned = mfft.transform(kind, x.clone(), None, want="ri")
+    for k in "ri":
+        assert torch.equal(got[k].view(torch.int32), aligned[k].view(torch.int32)), (kind, n, k)
+    want = loader.mfft(oracle_port, kind, x[batch - 1].cpu().numpy(), None, n, prefix="orc")
+    assert same_bits(got["r"][batch - 1].cpu().numpy(), want["r"]) and same_bits(got["i"][batch - 1].cpu().numpy(), want["i"])
+
+
+@pytest.mark.parametrize("st_len,in_len", [(256, 100), (512, 256), (1024, 160), (1024, 512), (1024, 1)])
+def test_many_streams_vs_oracle(cuda, oracle_port, st_len, in_len):
+    """fft_stream on 5 300 pools at once (more than the grid's waves), four pushes; pools and curves of a few streams against
+    the oracle's fft_stream, all streams of equal input equal."""
+    n_streams, pushes = 5300, 4
+    rng = np.random.default_rng(st_len + in_len)
+    base = (rng.standard_normal((8, pushes, in_len)) * 1000).astype(np.float32)
+    sig = np.ascontiguousarray(base[np.arange(n_streams) % 8])  # [stream, push, in_len]
+    st = mfft.FftStreams(n_streams, st_len, cuda)
+    for c in range(pushes):
+        af, pf = st.push(torch.from_numpy(np.ascontiguousarray(sig[:, c])).to(cuda))
+    pool, af, pf = st.pool.cpu().numpy(), af.cpu().numpy(), pf.cpu().numpy()
+    for s in range(8):
+        want_pool, want_af, want_pf = loader.mfft_stream(oracle_port, base[s], st_len, prefix="orc")
+        for row in (s, s + 8 * 640, n_streams - 1 - (n_streams - 1 - s) % 8):
+            assert same_bits(pool[row], want_pool), (s, row)
+            assert same_bits(af[row], want_af[-1]), (s, row)
+            assert phase_close(pf[row], want_pf[-1]), (s, row)
+    assert np.array_equal(pool.view(np.uint32)[8:], pool.view(np.uint32)[:-8])
+    assert np.array_equal(af.view(np.uint32)[8:], af.view(np.uint32)[:-8])

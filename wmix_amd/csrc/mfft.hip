@@ -50,6 +50,35 @@ int twiddles_for(unsigned n, const double2 **out) {
     return 0;
 }
 
+// The same values stage by stage: entry (2^b - 1) + j is the twiddle of butterfly j of stage b + 1 (what dit_passes reads
+// as tw[j << (m - 1 - b)]), so the lanes of a wave read consecutive entries (mfft_regs_kernel).  double2[nc], nc - 1 used.
+std::map<unsigned, double2 *> g_tw_staged;
+
+int staged_twiddles_for(unsigned nc, const double2 **out) {
+    std::lock_guard<std::mutex> lock(g_tw_mutex);
+    auto it = g_tw_staged.find(nc);
+    if (it != g_tw_staged.end()) {
+        *out = it->second;
+        return 0;
+    }
+    unsigned m = 0;
+    while ((1u << (m + 1)) <= nc) m++;
+    std::vector<double2> t(nc);
+    t[nc - 1] = double2{0.0, 0.0};
+    for (unsigned b = 0; b < m; b++)
+        for (unsigned j = 0; j < (1u << b); j++) {
+            const int pi = (int)(j << (m - 1 - b));
+            t[(1u << b) - 1 + j].x = cos(2.0 * kMfftPi * pi / nc);  // the expression of twiddles_for
+            t[(1u << b) - 1 + j].y = sin(2.0 * kMfftPi * pi / nc);
+        }
+    double2 *d = nullptr;
+    WMX_HIP(hipMalloc(&d, nc * sizeof(double2)));
+    WMX_HIP(hipMemcpy(d, t.data(), nc * sizeof(double2), hipMemcpyHostToDevice));
+    g_tw_staged[nc] = d;
+    *out = d;
+    return 0;
+}
+
 // ---------------------------------------------------------------- device
 // one radix-2 DIT butterfly of the reference (math/fft.c:106-113 / 281-292): t = w * x[q] in double, rounded once;
 // x[q] = x[r] - t, x[r] = x[r] + t (the inverse halves both)
@@ -224,6 +253,237 @@ __global__ void mfft_kernel(int n_batch, unsigned n, unsigned m, const double2 *
     }
 }
 
+// ---------------------------------------------------------------- the register-resident kernel (64 <= points / 64 lanes)
+// For 256 / 512 / 1024 complex points (FFT / IFFT / fft_stream of those sizes, FFTR / IFFTR of twice as many samples) a wave
+// keeps its transform in registers, P = nc / 64 points per lane, and runs the log2(nc) stages in passes of log2(P) stages
+// whose butterflies pair registers of one lane; between two passes the points change places through the wave's LDS buffer
+// (one float2 write and one read per point, padded by one element per P so that both sides are spread over the banks).
+// The same butterflies with the same operands as dit_passes -- the order of independent butterflies is all that differs.
+//   * the bit-reversed load needs no LDS: register k of lane L takes sample (rev(k) << 6) | rev6(L), so one load instruction
+//     of the wave covers one contiguous 64-point run of the input, lanes permuted inside it;
+//   * pass 0's twiddles are the same for every lane (scalar loads, kept in SGPRs across the transforms of a wave), later
+//     passes read the stage-by-stage table in LDS at consecutive entries;
+//   * a wave works through transforms idx, idx + waves of the grid, ...: the table is staged once per workgroup.
+// Point index of register k in a pass whose register bits are [S, S + LP):
+//   r = (lane >> S) << (S + LP) | k << S | lane & (2^S - 1).
+template <int LP>
+__device__ constexpr unsigned rev_small(unsigned k) {
+    unsigned r = 0;
+    for (int b = 0; b < LP; b++) r |= ((k >> b) & 1u) << (LP - 1 - b);
+    return r;
+}
+
+template <int MC>
+struct RegFft {
+    static constexpr int NC = 1 << MC, LP = MC - 6, P = 1 << LP, NPASS = (MC + LP - 1) / LP;
+    static constexpr int kBufElems = NC + (NC >> LP);  // float2 elements of a wave's exchange buffer
+    static constexpr int shift_of(int q) { return (q + 1) * LP <= MC ? q * LP : MC - LP; }
+    __device__ static __forceinline__ unsigned pad(unsigned r) { return r + (r >> LP); }
+    template <int S>
+    __device__ static __forceinline__ unsigned point(int k, unsigned lane) {
+        return ((lane >> S) << (S + LP)) | ((unsigned)k << S) | (lane & ((1u << S) - 1u));
+    }
+
+    template <bool INV, int Q>
+    __device__ static __forceinline__ void pass(float (&vr)[P], float (&vi)[P], float2 *buf, const double2 *tw_lds,
+                                                const double2 *__restrict__ tw_glb, unsigned lane) {
+        if constexpr (Q < NPASS) {
+            constexpr int S = shift_of(Q);
+            if constexpr (Q > 0) {
+                constexpr int S0 = shift_of(Q - 1);
+#pragma unroll
+                for (int k = 0; k < P; k++) buf[pad(point<S0>(k, lane))] = make_float2(vr[k], vi[k]);
+                wave_sync();
+#pragma unroll
+                for (int k = 0; k < P; k++) {
+                    const float2 t = buf[pad(point<S>(k, lane))];
+                    vr[k] = t.x, vi[k] = t.y;
+                }
+                wave_sync();
+            }
+            constexpr int B0 = Q * LP, B1 = (Q + 1) * LP <= MC ? (Q + 1) * LP : MC;  // stages B0 + 1 .. B1 pair index bit b
+            const unsigned low = lane & ((1u << S) - 1u);
+#pragma unroll
+            for (int b = B0; b < B1; b++) {
+                const int kb = b - S;  // the register bit of this stage
+#pragma unroll
+                for (int c = 0; c < (1 << kb); c++) {
+                    // butterfly j = low b bits of r = low | c << S
+                    const double2 w = S == 0 ? tw_glb[(1 << b) - 1 + c] : tw_lds[(1u << b) - 1u + low + ((unsigned)c << S)];
+#pragma unroll
+                    for (int hi = 0; hi < (P >> (kb + 1)); hi++) {
+                        const int k0 = (hi << (kb + 1)) | c, k1 = k0 | (1 << kb);
+                        dit_bfly<INV>(vr[k0], vi[k0], vr[k1], vi[k1], w);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);  // a stage's twiddles are fetched for that stage
+            }
+            pass<INV, Q + 1>(vr, vi, buf, tw_lds, tw_glb, lane);
+        }
+    }
+};
+
+constexpr unsigned kRegsWavesPerBlock = 4;
+
+template <int KIND, bool STREAM, int MC>
+__global__ __launch_bounds__(64 * kRegsWavesPerBlock, MC <= 8 ? 6 : (MC == 9 ? 5 : 3)) void mfft_regs_kernel(int n_batch, const double2 *__restrict__ tw_staged,
+                                                                           const double2 *__restrict__ tw_n, const float *in_re,
+                                                                           const float *in_im, float *out_re, float *out_im, float *out_af,
+                                                                           float *out_pf, unsigned in_len) {
+    using R = RegFft<MC>;
+    constexpr bool REAL = (KIND == 1 || KIND == 3), INV = (KIND >= 2);
+    constexpr int NC = R::NC, P = R::P, LP = R::LP;
+    constexpr unsigned N = REAL ? 2u * NC : (unsigned)NC;
+    extern __shared__ double2 lds_tw[];  // [NC] stage-by-stage twiddles, then one exchange buffer per wave
+    for (unsigned i = threadIdx.x; i < (unsigned)NC; i += blockDim.x) lds_tw[i] = tw_staged[i];
+    __syncthreads();  // the only block-level barrier
+    const unsigned lane0 = threadIdx.x & 63u;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float2 *buf = reinterpret_cast<float2 *>(lds_tw + NC) + (size_t)wave * R::kBufElems;
+    const int stride = gridDim.x * kRegsWavesPerBlock;
+
+    for (int idx = blockIdx.x * kRegsWavesPerBlock + wave; idx < n_batch; idx += stride) {
+        // Every address of the body is a function of the lane alone; hoisted out of this loop they would be a hundred
+        // live registers (and were: scratch spills).  The lane index is made opaque per iteration so they are formed
+        // where they are used.
+        unsigned lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const unsigned rl = __brev(lane) >> 26;  // the lane's place inside a 64-point run of the input
+        const size_t base = (size_t)idx * N;
+        float *o_re = out_re ? out_re + base : nullptr, *o_im = out_im ? out_im + base : nullptr;
+        float *o_af = out_af ? out_af + base : nullptr, *o_pf = out_pf ? out_pf + base : nullptr;
+        float vr[P], vi[P];
+
+        if constexpr (STREAM) {
+            // fft_stream (math/fft.c:413-424), as in mfft_kernel: the pool's new head is stored back, every read of the
+            // old pool is complete before the first store
+            float *pool = out_re + base;
+            const float *fresh = in_re + (size_t)idx * in_len;
+#pragma unroll
+            for (int k = 0; k < P; k++) {
+                const unsigned i = (rev_small<LP>(k) << 6) | rl;
+                vr[k] = i < in_len ? pool[i + in_len] : (i < 2 * in_len ? fresh[i - in_len] : pool[i]);
+                vi[k] = 0.f;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < P; k++) {
+                const unsigned i = (rev_small<LP>(k) << 6) | rl;
+                if (i < 2 * in_len) pool[i] = vr[k];
+            }
+            o_re = nullptr;  // the pool is not a spectrum output
+        } else if constexpr (!REAL) {
+#pragma unroll
+            for (int k = 0; k < P; k++) {
+                const unsigned i = (rev_small<LP>(k) << 6) | rl;
+                vr[k] = in_re ? in_re[base + i] : 0.f;
+                vi[k] = in_im ? in_im[base + i] : 0.f;
+            }
+        } else {
+            // y[i] = in[2i] + j in[2i+1] (8-byte loads: the host checks the alignment)
+            const float2 *src = reinterpret_cast<const float2 *>(in_re + base);
+#pragma unroll
+            for (int k = 0; k < P; k++) {
+                const unsigned i = (rev_small<LP>(k) << 6) | rl;
+                const float2 t = in_re ? src[i] : make_float2(0.f, 0.f);
+                vr[k] = t.x, vi[k] = t.y;
+            }
+        }
+
+        R::template pass<INV, 0>(vr, vi, buf, lds_tw, tw_staged, lane);
+        // now register k of lane L holds point k * 64 + L
+
+        // The phase curve (double atan2, math/fft.c:149-152) is the one output that is expensive per point and rarely asked
+        // for: it runs as a rolled loop over the buffer behind everything else, so the transform's registers are not
+        // priced for sixteen inlined copies of it.
+        float *const phase = INV ? nullptr : o_pf;
+        if constexpr (!REAL) {
+#pragma unroll
+            for (int k = 0; k < P; k++) emit(k * 64u + lane, vr[k], vi[k], N, o_re, o_im, INV ? nullptr : o_af, nullptr);
+            if (phase) {
+                wave_sync();
+#pragma unroll
+                for (int k = 0; k < P; k++) buf[k * 64u + lane] = make_float2(vr[k], vi[k]);
+                wave_sync();
+#pragma nounroll
+                for (int k = 0; k < P; k++) {
+                    const float2 t = buf[k * 64u + lane];
+                    phase[k * 64u + lane] = (float)atan2((double)t.y, (double)t.x);
+                }
+                wave_sync();
+            }
+        } else {
+            // the partner NC - j of every point through the buffer (unpadded: both sides run along the banks)
+            wave_sync();
+#pragma unroll
+            for (int k = 0; k < P; k++) buf[k * 64u + lane] = make_float2(vr[k], vi[k]);
+            wave_sync();
+            constexpr unsigned h = NC;
+            float mr = 0.f, mi = 0.f;  // point h, made by lane 0 beside point 0
+#pragma unroll
+            for (int k = 0; k < P; k++) {
+                const unsigned j = k * 64u + lane;
+                const float2 z = buf[(h - j) & (h - 1u)];
+                float x1r, x1i, x2r, x2i;
+                if (j == 0) {
+                    x1r = vr[k];
+                    x1i = vi[k];
+                    x2r = vi[k];
+                    x2i = -vr[k];
+                } else {
+                    x1r = (vr[k] + z.x) / 2;
+                    x1i = (vi[k] - z.y) / 2;
+                    x2r = (vi[k] + z.y) / 2;
+                    x2i = (z.x - vr[k]) / 2;
+                }
+                const double2 w = tw_n[j];
+                float xr, xi;
+                if constexpr (!INV) {
+                    const float tr = (float)((double)x2r * w.x + (double)x2i * w.y);
+                    const float ti = (float)((double)x2i * w.x - (double)x2r * w.y);
+                    xr = x1r + tr;
+                    xi = x1i + ti;
+                } else {
+                    const float tr = (float)((double)x2r * w.x - (double)x2i * w.y);
+                    const float ti = (float)((double)x2i * w.x + (double)x2r * w.y);
+                    xr = (x1r + tr) / 2;
+                    xi = (x1i + ti) / 2;
+                }
+                emit(j, xr, xi, N, o_re, o_im, INV ? nullptr : o_af, nullptr);
+                if (j == 0) {
+                    mr = x1r - x2r, mi = x1i - x2i;
+                    if constexpr (INV) {
+                        mr = mr / 2;
+                        mi = mi / 2;
+                    }
+                    emit(h, mr, mi, N, o_re, o_im, INV ? nullptr : o_af, nullptr);
+                } else {
+                    emit(N - j, xr, -xi, N, o_re, o_im, INV ? nullptr : o_af, nullptr);
+                }
+                vr[k] = xr, vi[k] = xi;
+                __builtin_amdgcn_sched_barrier(0);  // one point's table entry and partner in flight at a time, not all P
+            }
+            wave_sync();  // every partner is read: the buffer is free
+            if (phase) {
+#pragma unroll
+                for (int k = 0; k < P; k++) buf[k * 64u + lane] = make_float2(vr[k], vi[k]);
+                wave_sync();
+#pragma nounroll
+                for (int k = 0; k < P; k++) {
+                    const unsigned j = k * 64u + lane;
+                    const float2 t = buf[j];
+                    phase[j] = (float)atan2((double)t.y, (double)t.x);
+                    if (j == 0)
+                        phase[h] = (float)atan2((double)mi, (double)mr);
+                    else
+                        phase[N - j] = (float)atan2((double)-t.y, (double)t.x);
+                }
+                wave_sync();
+            }
+        }
+    }
+}
+
 int check_size(unsigned n, unsigned *m) {
     if (n < 2 || n > kMfftMaxN || (n & (n - 1))) {
         set_error("math/fft: N = %u (must be a power of two in [2, %u])", n, kMfftMaxN);
@@ -236,6 +496,26 @@ int check_size(unsigned n, unsigned *m) {
 }
 
 unsigned waves_per_block(unsigned n) { return n <= 1024 ? 4u : (n <= 2048 ? 2u : 1u); }
+
+// mfft_regs_kernel: complex sizes 2^8 .. 2^10; a grid of as many workgroups as the device holds at once (256 CUs, 160 KB of
+// LDS each), every wave loops over its share of the batch
+bool regs_path(unsigned mc) { return mc >= 8 && mc <= 10; }
+struct RegsLaunch {
+    dim3 grid, block;
+    size_t lds;
+};
+RegsLaunch regs_launch(unsigned mc, int n_batch) {
+    const size_t nc = (size_t)1 << mc, buf = nc + (nc >> (mc - 6));
+    RegsLaunch L;
+    L.lds = nc * sizeof(double2) + kRegsWavesPerBlock * buf * sizeof(float2);
+    size_t resident = (160u * 1024u) / L.lds;
+    const size_t by_registers = mc <= 8 ? 6 : (mc == 9 ? 5 : 3);  // the kernels' waves per SIMD (__launch_bounds__)
+    if (resident > by_registers) resident = by_registers;
+    const size_t cap = 256u * resident, need = ((size_t)n_batch + kRegsWavesPerBlock - 1) / kRegsWavesPerBlock;
+    L.grid = dim3((unsigned)(need < cap ? need : cap));
+    L.block = dim3(64 * kRegsWavesPerBlock);
+    return L;
+}
 
 }  // namespace
 }  // namespace wmx
@@ -259,10 +539,34 @@ extern "C" int wmx_mfft(int kind, int n_batch, unsigned n, const float *d_in_re,
     } else {
         tw_inner = tw_n;
     }
+    hipStream_t s = as_stream(stream);
+    const unsigned mc = real ? m - 1 : m;
+    if (regs_path(mc) && (!real || (reinterpret_cast<uintptr_t>(d_in_re) & 7) == 0)) {
+        const double2 *tw_staged = nullptr;
+        if (int rc = staged_twiddles_for(1u << mc, &tw_staged)) return rc;
+        const RegsLaunch L = regs_launch(mc, n_batch);
+#define WMX_MFFT_REGS(K, MC) \
+    hipLaunchKernelGGL((mfft_regs_kernel<K, false, MC>), L.grid, L.block, L.lds, s, n_batch, tw_staged, tw_n, d_in_re, d_in_im, d_out_re, d_out_im, d_out_af, d_out_pf, 0u)
+#define WMX_MFFT_REGS_K(K) \
+    switch (mc) { \
+        case 8: WMX_MFFT_REGS(K, 8); break; \
+        case 9: WMX_MFFT_REGS(K, 9); break; \
+        default: WMX_MFFT_REGS(K, 10); break; \
+    }
+        switch (kind) {
+            case 0: WMX_MFFT_REGS_K(0); break;
+            case 1: WMX_MFFT_REGS_K(1); break;
+            case 2: WMX_MFFT_REGS_K(2); break;
+            default: WMX_MFFT_REGS_K(3); break;
+        }
+#undef WMX_MFFT_REGS_K
+#undef WMX_MFFT_REGS
+        WMX_LAUNCH_CHECK();
+        return 0;
+    }
     const unsigned wpb = waves_per_block(n);
     const dim3 grid((unsigned)((n_batch + wpb - 1) / wpb)), block(64 * wpb);
     const size_t lds = (size_t)wpb * 2 * n * sizeof(float) + (size_t)((real ? n / 4 : n / 2) ? (real ? n / 4 : n / 2) : 1) * sizeof(double2);
-    hipStream_t s = as_stream(stream);
 #define WMX_MFFT_LAUNCH(K) \
     hipLaunchKernelGGL((mfft_kernel<K, false>), grid, block, lds, s, n_batch, n, m, tw_inner, tw_n, d_in_re, d_in_im, d_out_re, d_out_im, d_out_af, d_out_pf, 0u)
     switch (kind) {
@@ -289,6 +593,21 @@ extern "C" int wmx_mfft_stream(int n_streams, const float *d_in, unsigned in_len
     if (n_streams == 0) return 0;
     const double2 *tw = nullptr;
     if (int rc = twiddles_for(st_len, &tw)) return rc;
+    if (regs_path(m)) {
+        const double2 *tw_staged = nullptr;
+        if (int rc = staged_twiddles_for(st_len, &tw_staged)) return rc;
+        const RegsLaunch L = regs_launch(m, n_streams);
+#define WMX_MFFT_REGS(MC) \
+    hipLaunchKernelGGL((mfft_regs_kernel<0, true, MC>), L.grid, L.block, L.lds, as_stream(stream), n_streams, tw_staged, tw, d_in, (const float *)nullptr, d_pool, (float *)nullptr, d_out_af, d_out_pf, in_len)
+        switch (m) {
+            case 8: WMX_MFFT_REGS(8); break;
+            case 9: WMX_MFFT_REGS(9); break;
+            default: WMX_MFFT_REGS(10); break;
+        }
+#undef WMX_MFFT_REGS
+        WMX_LAUNCH_CHECK();
+        return 0;
+    }
     const unsigned wpb = waves_per_block(st_len);
     const dim3 grid((unsigned)((n_streams + wpb - 1) / wpb)), block(64 * wpb);
     const size_t lds = (size_t)wpb * (2 * st_len + 2 * in_len) * sizeof(float) + (size_t)(st_len / 2) * sizeof(double2);
