@@ -324,9 +324,14 @@ struct RegFft {
 };
 
 constexpr unsigned kRegsWavesPerBlock = 4;
+// waves per SIMD the kernel is compiled for (its register budget): the real kinds hold P table entries on top of the P points
+constexpr int regs_waves_per_simd(int kind, int mc) {
+    const bool real = kind == 1 || kind == 3;
+    return mc <= 8 ? (real ? 5 : 6) : (mc == 9 ? (real ? 4 : 5) : (real ? 2 : 3));
+}
 
 template <int KIND, bool STREAM, int MC>
-__global__ __launch_bounds__(64 * kRegsWavesPerBlock, MC <= 8 ? 6 : (MC == 9 ? 5 : 3)) void mfft_regs_kernel(int n_batch, const double2 *__restrict__ tw_staged,
+__global__ __launch_bounds__(64 * kRegsWavesPerBlock, regs_waves_per_simd(KIND, MC)) void mfft_regs_kernel(int n_batch, const double2 *__restrict__ tw_staged,
                                                                            const double2 *__restrict__ tw_n, const float *in_re,
                                                                            const float *in_im, float *out_re, float *out_im, float *out_af,
                                                                            float *out_pf, unsigned in_len) {
@@ -341,7 +346,6 @@ __global__ __launch_bounds__(64 * kRegsWavesPerBlock, MC <= 8 ? 6 : (MC == 9 ? 5
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float2 *buf = reinterpret_cast<float2 *>(lds_tw + NC) + (size_t)wave * R::kBufElems;
     const int stride = gridDim.x * kRegsWavesPerBlock;
-
     for (int idx = blockIdx.x * kRegsWavesPerBlock + wave; idx < n_batch; idx += stride) {
         // Every address of the body is a function of the lane alone; hoisted out of this loop they would be a hundred
         // live registers (and were: scratch spills).  The lane index is made opaque per iteration so they are formed
@@ -374,19 +378,26 @@ __global__ __launch_bounds__(64 * kRegsWavesPerBlock, MC <= 8 ? 6 : (MC == 9 ? 5
             o_re = nullptr;  // the pool is not a spectrum output
         } else if constexpr (!REAL) {
 #pragma unroll
-            for (int k = 0; k < P; k++) {
-                const unsigned i = (rev_small<LP>(k) << 6) | rl;
-                vr[k] = in_re ? in_re[base + i] : 0.f;
-                vi[k] = in_im ? in_im[base + i] : 0.f;
+            for (int k = 0; k < P; k++) vr[k] = 0.f, vi[k] = 0.f;
+            if (in_re) {
+#pragma unroll
+                for (int k = 0; k < P; k++) vr[k] = in_re[base + ((rev_small<LP>(k) << 6) | rl)];
+            }
+            if (in_im) {
+#pragma unroll
+                for (int k = 0; k < P; k++) vi[k] = in_im[base + ((rev_small<LP>(k) << 6) | rl)];
             }
         } else {
             // y[i] = in[2i] + j in[2i+1] (8-byte loads: the host checks the alignment)
             const float2 *src = reinterpret_cast<const float2 *>(in_re + base);
 #pragma unroll
-            for (int k = 0; k < P; k++) {
-                const unsigned i = (rev_small<LP>(k) << 6) | rl;
-                const float2 t = in_re ? src[i] : make_float2(0.f, 0.f);
-                vr[k] = t.x, vi[k] = t.y;
+            for (int k = 0; k < P; k++) vr[k] = 0.f, vi[k] = 0.f;
+            if (in_re) {
+#pragma unroll
+                for (int k = 0; k < P; k++) {
+                    const float2 t = src[(rev_small<LP>(k) << 6) | rl];
+                    vr[k] = t.x, vi[k] = t.y;
+                }
             }
         }
 
@@ -396,10 +407,22 @@ __global__ __launch_bounds__(64 * kRegsWavesPerBlock, MC <= 8 ? 6 : (MC == 9 ? 5
         // The phase curve (double atan2, math/fft.c:149-152) is the one output that is expensive per point and rarely asked
         // for: it runs as a rolled loop over the buffer behind everything else, so the transform's registers are not
         // priced for sixteen inlined copies of it.
-        float *const phase = INV ? nullptr : o_pf;
+        float *const phase = INV ? nullptr : o_pf, *const ampl = INV ? nullptr : o_af;
+        constexpr float kAmpScale = 1.0f / (float)(N / 2);  // emit(): sqrtf(r*r + i*i) * 2^-k
         if constexpr (!REAL) {
+            // one uniform branch per output array, its P stores together
+            if (o_re) {
 #pragma unroll
-            for (int k = 0; k < P; k++) emit(k * 64u + lane, vr[k], vi[k], N, o_re, o_im, INV ? nullptr : o_af, nullptr);
+                for (int k = 0; k < P; k++) o_re[k * 64u + lane] = vr[k];
+            }
+            if (o_im) {
+#pragma unroll
+                for (int k = 0; k < P; k++) o_im[k * 64u + lane] = vi[k];
+            }
+            if (ampl) {
+#pragma unroll
+                for (int k = 0; k < P; k++) ampl[k * 64u + lane] = sqrtf(vr[k] * vr[k] + vi[k] * vi[k]) * kAmpScale;
+            }
             if (phase) {
                 wave_sync();
 #pragma unroll
@@ -413,7 +436,10 @@ __global__ __launch_bounds__(64 * kRegsWavesPerBlock, MC <= 8 ? 6 : (MC == 9 ? 5
                 wave_sync();
             }
         } else {
-            // the partner NC - j of every point through the buffer (unpadded: both sides run along the banks)
+            // the partner NC - j of every point through the buffer (unpadded: both sides run along the banks); entry j of
+            // the size-N table for the last stage: a lane's loads go out four at a time (one at a time the stage was P
+            // round trips to the L2 long, all P at once cost the registers of a wave)
+            double2 wn[4];
             wave_sync();
 #pragma unroll
             for (int k = 0; k < P; k++) buf[k * 64u + lane] = make_float2(vr[k], vi[k]);
@@ -422,21 +448,21 @@ __global__ __launch_bounds__(64 * kRegsWavesPerBlock, MC <= 8 ? 6 : (MC == 9 ? 5
             float mr = 0.f, mi = 0.f;  // point h, made by lane 0 beside point 0
 #pragma unroll
             for (int k = 0; k < P; k++) {
+                if (k % 4 == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) wn[q] = tw_n[(k + q) * 64u + lane];
+                }
                 const unsigned j = k * 64u + lane;
                 const float2 z = buf[(h - j) & (h - 1u)];
-                float x1r, x1i, x2r, x2i;
-                if (j == 0) {
-                    x1r = vr[k];
-                    x1i = vi[k];
-                    x2r = vi[k];
-                    x2i = -vr[k];
-                } else {
-                    x1r = (vr[k] + z.x) / 2;
-                    x1i = (vi[k] - z.y) / 2;
-                    x2r = (vi[k] + z.y) / 2;
-                    x2i = (z.x - vr[k]) / 2;
+                float x1r = (vr[k] + z.x) / 2, x1i = (vi[k] - z.y) / 2, x2r = (vi[k] + z.y) / 2, x2i = (z.x - vr[k]) / 2;
+                if (k == 0) {  // j = 0 is lane 0's first point: no partner (math/fft.c:189-194)
+                    x1r = j == 0 ? vr[k] : x1r;
+                    x1i = j == 0 ? vi[k] : x1i;
+                    x2r = j == 0 ? vi[k] : x2r;
+                    x2i = j == 0 ? -vr[k] : x2i;
                 }
-                const double2 w = tw_n[j];
+                const double2 w = wn[k % 4];
                 float xr, xi;
                 if constexpr (!INV) {
                     const float tr = (float)((double)x2r * w.x + (double)x2i * w.y);
@@ -449,21 +475,47 @@ __global__ __launch_bounds__(64 * kRegsWavesPerBlock, MC <= 8 ? 6 : (MC == 9 ? 5
                     xr = (x1r + tr) / 2;
                     xi = (x1i + ti) / 2;
                 }
-                emit(j, xr, xi, N, o_re, o_im, INV ? nullptr : o_af, nullptr);
-                if (j == 0) {
+                if (k == 0) {  // lane 0's j = 0 (other lanes' values are not stored)
                     mr = x1r - x2r, mi = x1i - x2i;
                     if constexpr (INV) {
                         mr = mr / 2;
                         mi = mi / 2;
                     }
-                    emit(h, mr, mi, N, o_re, o_im, INV ? nullptr : o_af, nullptr);
-                } else {
-                    emit(N - j, xr, -xi, N, o_re, o_im, INV ? nullptr : o_af, nullptr);
                 }
                 vr[k] = xr, vi[k] = xi;
-                __builtin_amdgcn_sched_barrier(0);  // one point's table entry and partner in flight at a time, not all P
             }
             wave_sync();  // every partner is read: the buffer is free
+            // outputs j and N - j (h beside j = 0), one uniform branch per array
+            if (o_re) {
+#pragma unroll
+                for (int k = 0; k < P; k++) {
+                    const unsigned j = k * 64u + lane;
+                    o_re[j] = vr[k];
+                    o_re[k == 0 && j == 0 ? h : N - j] = k == 0 && j == 0 ? mr : vr[k];
+                }
+            }
+            if (o_im) {
+#pragma unroll
+                for (int k = 0; k < P; k++) {
+                    const unsigned j = k * 64u + lane;
+                    o_im[j] = vi[k];
+                    o_im[k == 0 && j == 0 ? h : N - j] = k == 0 && j == 0 ? mi : -vi[k];
+                }
+            }
+            if (ampl) {
+#pragma unroll
+                for (int k = 0; k < P; k++) {
+                    const unsigned j = k * 64u + lane;
+                    const float a = sqrtf(vr[k] * vr[k] + vi[k] * vi[k]) * kAmpScale;  // (-xi)^2 == xi^2: point N - j has it too
+                    ampl[j] = a;
+                    if (k == 0) {
+                        const float ah = sqrtf(mr * mr + mi * mi) * kAmpScale;
+                        ampl[j == 0 ? h : N - j] = j == 0 ? ah : a;
+                    } else {
+                        ampl[N - j] = a;
+                    }
+                }
+            }
             if (phase) {
 #pragma unroll
                 for (int k = 0; k < P; k++) buf[k * 64u + lane] = make_float2(vr[k], vi[k]);
@@ -504,12 +556,12 @@ struct RegsLaunch {
     dim3 grid, block;
     size_t lds;
 };
-RegsLaunch regs_launch(unsigned mc, int n_batch) {
+RegsLaunch regs_launch(int kind, unsigned mc, int n_batch) {
     const size_t nc = (size_t)1 << mc, buf = nc + (nc >> (mc - 6));
     RegsLaunch L;
     L.lds = nc * sizeof(double2) + kRegsWavesPerBlock * buf * sizeof(float2);
     size_t resident = (160u * 1024u) / L.lds;
-    const size_t by_registers = mc <= 8 ? 6 : (mc == 9 ? 5 : 3);  // the kernels' waves per SIMD (__launch_bounds__)
+    const size_t by_registers = (size_t)regs_waves_per_simd(kind, (int)mc);
     if (resident > by_registers) resident = by_registers;
     const size_t cap = 256u * resident, need = ((size_t)n_batch + kRegsWavesPerBlock - 1) / kRegsWavesPerBlock;
     L.grid = dim3((unsigned)(need < cap ? need : cap));
@@ -544,7 +596,7 @@ extern "C" int wmx_mfft(int kind, int n_batch, unsigned n, const float *d_in_re,
     if (regs_path(mc) && (!real || (reinterpret_cast<uintptr_t>(d_in_re) & 7) == 0)) {
         const double2 *tw_staged = nullptr;
         if (int rc = staged_twiddles_for(1u << mc, &tw_staged)) return rc;
-        const RegsLaunch L = regs_launch(mc, n_batch);
+        const RegsLaunch L = regs_launch(kind, mc, n_batch);
 #define WMX_MFFT_REGS(K, MC) \
     hipLaunchKernelGGL((mfft_regs_kernel<K, false, MC>), L.grid, L.block, L.lds, s, n_batch, tw_staged, tw_n, d_in_re, d_in_im, d_out_re, d_out_im, d_out_af, d_out_pf, 0u)
 #define WMX_MFFT_REGS_K(K) \
@@ -596,7 +648,7 @@ extern "C" int wmx_mfft_stream(int n_streams, const float *d_in, unsigned in_len
     if (regs_path(m)) {
         const double2 *tw_staged = nullptr;
         if (int rc = staged_twiddles_for(st_len, &tw_staged)) return rc;
-        const RegsLaunch L = regs_launch(m, n_streams);
+        const RegsLaunch L = regs_launch(0, m, n_streams);
 #define WMX_MFFT_REGS(MC) \
     hipLaunchKernelGGL((mfft_regs_kernel<0, true, MC>), L.grid, L.block, L.lds, as_stream(stream), n_streams, tw_staged, tw, d_in, (const float *)nullptr, d_pool, (float *)nullptr, d_out_af, d_out_pf, in_len)
         switch (m) {
