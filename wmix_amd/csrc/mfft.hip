@@ -102,6 +102,23 @@ __device__ __forceinline__ void dit_bfly(float &ar, float &ai, float &xr, float 
     }
 }
 
+// the same butterfly on (re, im) register pairs
+template <bool INVERSE>
+__device__ __forceinline__ void dit_bfly2(v2f &a, v2f &x, double2 w) {
+    v2f t;
+    if constexpr (!INVERSE) {
+        t.x = (float)((double)x.x * w.x + (double)x.y * w.y);
+        t.y = (float)((double)x.y * w.x - (double)x.x * w.y);
+        x = a - t;
+        a = a + t;
+    } else {
+        t.x = (float)((double)x.x * w.x - (double)x.y * w.y);
+        t.y = (float)((double)x.y * w.x + (double)x.x * w.y);
+        x = (a - t) / 2;
+        a = (a + t) / 2;
+    }
+}
+
 // log2(n) radix-2 DIT passes on n complex points in LDS (math/fft.c:81-118 / 256-296).  Two consecutive stages are
 // evaluated on four points held in registers (the same butterflies in the same order, one LDS round trip instead of
 // two); an odd last stage runs alone.  `tw` is the size-n twiddle table in LDS.
@@ -285,20 +302,17 @@ struct RegFft {
     }
 
     template <bool INV, int Q>
-    __device__ static __forceinline__ void pass(float (&vr)[P], float (&vi)[P], float2 *buf, const double2 *tw_lds,
+    __device__ static __forceinline__ void pass(v2f (&v)[P], v2f *buf, const double2 *tw_lds,
                                                 const double2 *__restrict__ tw_glb, unsigned lane) {
         if constexpr (Q < NPASS) {
             constexpr int S = shift_of(Q);
             if constexpr (Q > 0) {
                 constexpr int S0 = shift_of(Q - 1);
 #pragma unroll
-                for (int k = 0; k < P; k++) buf[pad(point<S0>(k, lane))] = make_float2(vr[k], vi[k]);
+                for (int k = 0; k < P; k++) buf[pad(point<S0>(k, lane))] = v[k];
                 wave_sync();
 #pragma unroll
-                for (int k = 0; k < P; k++) {
-                    const float2 t = buf[pad(point<S>(k, lane))];
-                    vr[k] = t.x, vi[k] = t.y;
-                }
+                for (int k = 0; k < P; k++) v[k] = buf[pad(point<S>(k, lane))];
                 wave_sync();
             }
             constexpr int B0 = Q * LP, B1 = (Q + 1) * LP <= MC ? (Q + 1) * LP : MC;  // stages B0 + 1 .. B1 pair index bit b
@@ -313,22 +327,20 @@ struct RegFft {
 #pragma unroll
                     for (int hi = 0; hi < (P >> (kb + 1)); hi++) {
                         const int k0 = (hi << (kb + 1)) | c, k1 = k0 | (1 << kb);
-                        dit_bfly<INV>(vr[k0], vi[k0], vr[k1], vi[k1], w);
+                        dit_bfly2<INV>(v[k0], v[k1], w);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);  // a stage's twiddles are fetched for that stage
             }
-            pass<INV, Q + 1>(vr, vi, buf, tw_lds, tw_glb, lane);
+            pass<INV, Q + 1>(v, buf, tw_lds, tw_glb, lane);
         }
     }
 };
 
 constexpr unsigned kRegsWavesPerBlock = 4;
-// waves per SIMD the kernel is compiled for (its register budget): the real kinds hold P table entries on top of the P points
-constexpr int regs_waves_per_simd(int kind, int mc) {
-    const bool real = kind == 1 || kind == 3;
-    return mc <= 8 ? (real ? 5 : 6) : (mc == 9 ? (real ? 4 : 5) : (real ? 2 : 3));
-}
+
+// waves per SIMD the kernel is compiled for (its register budget; the LDS of a CU holds 6 / 6 / 3 workgroups)
+constexpr int regs_waves_per_simd(int kind, int mc) { return mc <= 8 ? (kind == 1 ? 5 : 6) : (mc == 9 ? (kind == 1 ? 4 : 5) : 3); }
 
 template <int KIND, bool STREAM, int MC>
 __global__ __launch_bounds__(64 * kRegsWavesPerBlock, regs_waves_per_simd(KIND, MC)) void mfft_regs_kernel(int n_batch, const double2 *__restrict__ tw_staged,
@@ -344,7 +356,7 @@ __global__ __launch_bounds__(64 * kRegsWavesPerBlock, regs_waves_per_simd(KIND, 
     __syncthreads();  // the only block-level barrier
     const unsigned lane0 = threadIdx.x & 63u;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float2 *buf = reinterpret_cast<float2 *>(lds_tw + NC) + (size_t)wave * R::kBufElems;
+    v2f *buf = reinterpret_cast<v2f *>(lds_tw + NC) + (size_t)wave * R::kBufElems;
     const int stride = gridDim.x * kRegsWavesPerBlock;
     for (int idx = blockIdx.x * kRegsWavesPerBlock + wave; idx < n_batch; idx += stride) {
         // Every address of the body is a function of the lane alone; hoisted out of this loop they would be a hundred
@@ -356,7 +368,7 @@ __global__ __launch_bounds__(64 * kRegsWavesPerBlock, regs_waves_per_simd(KIND, 
         const size_t base = (size_t)idx * N;
         float *o_re = out_re ? out_re + base : nullptr, *o_im = out_im ? out_im + base : nullptr;
         float *o_af = out_af ? out_af + base : nullptr, *o_pf = out_pf ? out_pf + base : nullptr;
-        float vr[P], vi[P];
+        v2f v[P];
 
         if constexpr (STREAM) {
             // fft_stream (math/fft.c:413-424), as in mfft_kernel: the pool's new head is stored back, every read of the
@@ -366,42 +378,39 @@ __global__ __launch_bounds__(64 * kRegsWavesPerBlock, regs_waves_per_simd(KIND, 
 #pragma unroll
             for (int k = 0; k < P; k++) {
                 const unsigned i = (rev_small<LP>(k) << 6) | rl;
-                vr[k] = i < in_len ? pool[i + in_len] : (i < 2 * in_len ? fresh[i - in_len] : pool[i]);
-                vi[k] = 0.f;
+                v[k].x = i < in_len ? pool[i + in_len] : (i < 2 * in_len ? fresh[i - in_len] : pool[i]);
+                v[k].y = 0.f;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int k = 0; k < P; k++) {
                 const unsigned i = (rev_small<LP>(k) << 6) | rl;
-                if (i < 2 * in_len) pool[i] = vr[k];
+                if (i < 2 * in_len) pool[i] = v[k].x;
             }
             o_re = nullptr;  // the pool is not a spectrum output
         } else if constexpr (!REAL) {
 #pragma unroll
-            for (int k = 0; k < P; k++) vr[k] = 0.f, vi[k] = 0.f;
+            for (int k = 0; k < P; k++) v[k] = v2f{0.f, 0.f};
             if (in_re) {
 #pragma unroll
-                for (int k = 0; k < P; k++) vr[k] = in_re[base + ((rev_small<LP>(k) << 6) | rl)];
+                for (int k = 0; k < P; k++) v[k].x = in_re[base + ((rev_small<LP>(k) << 6) | rl)];
             }
             if (in_im) {
 #pragma unroll
-                for (int k = 0; k < P; k++) vi[k] = in_im[base + ((rev_small<LP>(k) << 6) | rl)];
+                for (int k = 0; k < P; k++) v[k].y = in_im[base + ((rev_small<LP>(k) << 6) | rl)];
             }
         } else {
             // y[i] = in[2i] + j in[2i+1] (8-byte loads: the host checks the alignment)
-            const float2 *src = reinterpret_cast<const float2 *>(in_re + base);
+            const v2f *src = reinterpret_cast<const v2f *>(in_re + base);
 #pragma unroll
-            for (int k = 0; k < P; k++) vr[k] = 0.f, vi[k] = 0.f;
+            for (int k = 0; k < P; k++) v[k] = v2f{0.f, 0.f};
             if (in_re) {
 #pragma unroll
-                for (int k = 0; k < P; k++) {
-                    const float2 t = src[(rev_small<LP>(k) << 6) | rl];
-                    vr[k] = t.x, vi[k] = t.y;
-                }
+                for (int k = 0; k < P; k++) v[k] = src[(rev_small<LP>(k) << 6) | rl];
             }
         }
 
-        R::template pass<INV, 0>(vr, vi, buf, lds_tw, tw_staged, lane);
+        R::template pass<INV, 0>(v, buf, lds_tw, tw_staged, lane);
         // now register k of lane L holds point k * 64 + L
 
         // The phase curve (double atan2, math/fft.c:149-152) is the one output that is expensive per point and rarely asked
@@ -413,100 +422,105 @@ __global__ __launch_bounds__(64 * kRegsWavesPerBlock, regs_waves_per_simd(KIND, 
             // one uniform branch per output array, its P stores together
             if (o_re) {
 #pragma unroll
-                for (int k = 0; k < P; k++) o_re[k * 64u + lane] = vr[k];
+                for (int k = 0; k < P; k++) o_re[k * 64u + lane] = v[k].x;
             }
             if (o_im) {
 #pragma unroll
-                for (int k = 0; k < P; k++) o_im[k * 64u + lane] = vi[k];
+                for (int k = 0; k < P; k++) o_im[k * 64u + lane] = v[k].y;
             }
             if (ampl) {
 #pragma unroll
-                for (int k = 0; k < P; k++) ampl[k * 64u + lane] = sqrtf(vr[k] * vr[k] + vi[k] * vi[k]) * kAmpScale;
+                for (int k = 0; k < P; k++) ampl[k * 64u + lane] = sqrtf(v[k].x * v[k].x + v[k].y * v[k].y) * kAmpScale;
             }
             if (phase) {
                 wave_sync();
 #pragma unroll
-                for (int k = 0; k < P; k++) buf[k * 64u + lane] = make_float2(vr[k], vi[k]);
+                for (int k = 0; k < P; k++) buf[k * 64u + lane] = v[k];
                 wave_sync();
 #pragma nounroll
                 for (int k = 0; k < P; k++) {
-                    const float2 t = buf[k * 64u + lane];
+                    const v2f t = buf[k * 64u + lane];
                     phase[k * 64u + lane] = (float)atan2((double)t.y, (double)t.x);
                 }
                 wave_sync();
             }
         } else {
-            // the partner NC - j of every point through the buffer (unpadded: both sides run along the banks); entry j of
-            // the size-N table for the last stage: a lane's loads go out four at a time (one at a time the stage was P
-            // round trips to the L2 long, all P at once cost the registers of a wave)
-            double2 wn[4];
+            // The split into the spectra of the even / odd samples and the last stage (math/fft.c:182-232 / 345-392).  Points
+            // j and NC - j are each other's partners, so one lane takes both and writes both results back in place: a rolled
+            // loop of P / 2 steps over the buffer (unpadded: both sides run along the banks) with nothing but arithmetic and
+            // the two table entries of the next step in flight.  Unrolled on the registers this stage was the larger half of
+            // the kernel's code and twice the registers of everything else; with the stores inside the loop every step
+            // waited for them (one counter for loads and stores).  Lane 0's first step has j = 0, which has no partner, and
+            // takes the self-partnered point NC / 2 beside it.
+            const double2 *const twl = tw_n + lane;
+            double2 wa = twl[0], wb = twl[lane == 0 ? NC / 2 : NC - 2 * lane];  // entries j and NC - j of step 0
             wave_sync();
 #pragma unroll
-            for (int k = 0; k < P; k++) buf[k * 64u + lane] = make_float2(vr[k], vi[k]);
+            for (int k = 0; k < P; k++) buf[k * 64u + lane] = v[k];
             wave_sync();
             constexpr unsigned h = NC;
-            float mr = 0.f, mi = 0.f;  // point h, made by lane 0 beside point 0
-#pragma unroll
-            for (int k = 0; k < P; k++) {
-                if (k % 4 == 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int q = 0; q < 4; q++) wn[q] = tw_n[(k + q) * 64u + lane];
-                }
-                const unsigned j = k * 64u + lane;
-                const float2 z = buf[(h - j) & (h - 1u)];
-                float x1r = (vr[k] + z.x) / 2, x1i = (vi[k] - z.y) / 2, x2r = (vi[k] + z.y) / 2, x2i = (z.x - vr[k]) / 2;
-                if (k == 0) {  // j = 0 is lane 0's first point: no partner (math/fft.c:189-194)
-                    x1r = j == 0 ? vr[k] : x1r;
-                    x1i = j == 0 ? vi[k] : x1i;
-                    x2r = j == 0 ? vi[k] : x2r;
-                    x2i = j == 0 ? -vr[k] : x2i;
-                }
-                const double2 w = wn[k % 4];
-                float xr, xi;
-                if constexpr (!INV) {
-                    const float tr = (float)((double)x2r * w.x + (double)x2i * w.y);
-                    const float ti = (float)((double)x2i * w.x - (double)x2r * w.y);
-                    xr = x1r + tr;
-                    xi = x1i + ti;
-                } else {
-                    const float tr = (float)((double)x2r * w.x - (double)x2i * w.y);
-                    const float ti = (float)((double)x2i * w.x + (double)x2r * w.y);
-                    xr = (x1r + tr) / 2;
-                    xi = (x1i + ti) / 2;
-                }
-                if (k == 0) {  // lane 0's j = 0 (other lanes' values are not stored)
-                    mr = x1r - x2r, mi = x1i - x2i;
-                    if constexpr (INV) {
-                        mr = mr / 2;
-                        mi = mi / 2;
-                    }
-                }
-                vr[k] = xr, vi[k] = xi;
+            // point h belongs to j = 0: x1 - x2 of (re[0], im[0]) (every lane computes it, lane 0 stores it)
+            const v2f y0 = buf[0];
+            float mr = y0.x - y0.y, mi = y0.y - (-y0.x);
+            if constexpr (INV) {
+                mr = mr / 2;
+                mi = mi / 2;
             }
-            wave_sync();  // every partner is read: the buffer is free
+            wave_sync();
+#pragma unroll
+            for (int t = 0; t < P / 2; t++) {
+                const unsigned j = t * 64u + lane;
+                const bool first = j == 0;
+                const unsigned jb = first ? h / 2 : h - j;
+                const unsigned jn = j + (t + 1 < P / 2 ? 64u : 0u);  // the next step's entries (the last step's again)
+                const double2 wa_next = tw_n[jn], wb_next = tw_n[h - jn];
+                const v2f y = buf[j], z = buf[jb];
+                // point j (partner z; none for j = 0) and point jb (partner y; itself for NC / 2)
+                const v2f pa = first ? y : z, pb = first ? z : y;
+                float a1r = (y.x + pa.x) / 2, a1i = (y.y - pa.y) / 2, a2r = (y.y + pa.y) / 2, a2i = (pa.x - y.x) / 2;
+                if (first) a1r = y.x, a1i = y.y, a2r = y.y, a2i = -y.x;  // math/fft.c:189-194
+                const float b1r = (z.x + pb.x) / 2, b1i = (z.y - pb.y) / 2, b2r = (z.y + pb.y) / 2, b2i = (pb.x - z.x) / 2;
+                v2f xa, xb;
+                if constexpr (!INV) {
+                    xa.x = a1r + (float)((double)a2r * wa.x + (double)a2i * wa.y);
+                    xa.y = a1i + (float)((double)a2i * wa.x - (double)a2r * wa.y);
+                    xb.x = b1r + (float)((double)b2r * wb.x + (double)b2i * wb.y);
+                    xb.y = b1i + (float)((double)b2i * wb.x - (double)b2r * wb.y);
+                } else {
+                    xa.x = (a1r + (float)((double)a2r * wa.x - (double)a2i * wa.y)) / 2;
+                    xa.y = (a1i + (float)((double)a2i * wa.x + (double)a2r * wa.y)) / 2;
+                    xb.x = (b1r + (float)((double)b2r * wb.x - (double)b2i * wb.y)) / 2;
+                    xb.y = (b1i + (float)((double)b2i * wb.x + (double)b2r * wb.y)) / 2;
+                }
+                buf[j] = xa;
+                buf[jb] = xb;
+                wa = wa_next, wb = wb_next;
+            }
+            wave_sync();
+#pragma unroll
+            for (int k = 0; k < P; k++) v[k] = buf[k * 64u + lane];
             // outputs j and N - j (h beside j = 0), one uniform branch per array
             if (o_re) {
 #pragma unroll
                 for (int k = 0; k < P; k++) {
                     const unsigned j = k * 64u + lane;
-                    o_re[j] = vr[k];
-                    o_re[k == 0 && j == 0 ? h : N - j] = k == 0 && j == 0 ? mr : vr[k];
+                    o_re[j] = v[k].x;
+                    o_re[k == 0 && j == 0 ? h : N - j] = k == 0 && j == 0 ? mr : v[k].x;
                 }
             }
             if (o_im) {
 #pragma unroll
                 for (int k = 0; k < P; k++) {
                     const unsigned j = k * 64u + lane;
-                    o_im[j] = vi[k];
-                    o_im[k == 0 && j == 0 ? h : N - j] = k == 0 && j == 0 ? mi : -vi[k];
+                    o_im[j] = v[k].y;
+                    o_im[k == 0 && j == 0 ? h : N - j] = k == 0 && j == 0 ? mi : -v[k].y;
                 }
             }
             if (ampl) {
 #pragma unroll
                 for (int k = 0; k < P; k++) {
                     const unsigned j = k * 64u + lane;
-                    const float a = sqrtf(vr[k] * vr[k] + vi[k] * vi[k]) * kAmpScale;  // (-xi)^2 == xi^2: point N - j has it too
+                    const float a = sqrtf(v[k].x * v[k].x + v[k].y * v[k].y) * kAmpScale;  // (-xi)^2 == xi^2: point N - j has it too
                     ampl[j] = a;
                     if (k == 0) {
                         const float ah = sqrtf(mr * mr + mi * mi) * kAmpScale;
@@ -517,21 +531,18 @@ __global__ __launch_bounds__(64 * kRegsWavesPerBlock, regs_waves_per_simd(KIND, 
                 }
             }
             if (phase) {
-#pragma unroll
-                for (int k = 0; k < P; k++) buf[k * 64u + lane] = make_float2(vr[k], vi[k]);
-                wave_sync();
 #pragma nounroll
                 for (int k = 0; k < P; k++) {
                     const unsigned j = k * 64u + lane;
-                    const float2 t = buf[j];
+                    const v2f t = buf[j];
                     phase[j] = (float)atan2((double)t.y, (double)t.x);
                     if (j == 0)
                         phase[h] = (float)atan2((double)mi, (double)mr);
                     else
                         phase[N - j] = (float)atan2((double)-t.y, (double)t.x);
                 }
-                wave_sync();
             }
+            wave_sync();  // the buffer is free for the next transform
         }
     }
 }
