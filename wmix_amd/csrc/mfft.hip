@@ -340,7 +340,7 @@ struct RegFft {
 constexpr unsigned kRegsWavesPerBlock = 4;
 
 // waves per SIMD the kernel is compiled for (its register budget; the LDS of a CU holds 6 / 6 / 3 workgroups)
-constexpr int regs_waves_per_simd(int kind, int mc) { return mc <= 8 ? (kind == 1 ? 5 : 6) : (mc == 9 ? (kind == 1 ? 4 : 5) : 3); }
+constexpr int regs_waves_per_simd(int kind, int mc) { return mc <= 8 ? (kind == 1 ? 5 : 6) : (mc == 9 ? (kind == 1 ? 4 : 5) : (kind == 1 ? 2 : 3)); }
 
 template <int KIND, bool STREAM, int MC>
 __global__ __launch_bounds__(64 * kRegsWavesPerBlock, regs_waves_per_simd(KIND, MC)) void mfft_regs_kernel(int n_batch, const double2 *__restrict__ tw_staged,
@@ -358,7 +358,35 @@ __global__ __launch_bounds__(64 * kRegsWavesPerBlock, regs_waves_per_simd(KIND, 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     v2f *buf = reinterpret_cast<v2f *>(lds_tw + NC) + (size_t)wave * R::kBufElems;
     const int stride = gridDim.x * kRegsWavesPerBlock;
-    for (int idx = blockIdx.x * kRegsWavesPerBlock + wave; idx < n_batch; idx += stride) {
+    // The input of the wave's next transform is fetched while it works on the current one (not fft_stream's, whose load
+    // also stores).  load_input: register k of lane L takes sample (rev(k) << 6) | rev6(L).
+    auto load_input = [&](int idx, unsigned rl, v2f(&dst)[P]) {
+        const size_t base = (size_t)idx * N;
+#pragma unroll
+        for (int k = 0; k < P; k++) dst[k] = v2f{0.f, 0.f};
+        if constexpr (!REAL) {
+            if (in_re) {
+#pragma unroll
+                for (int k = 0; k < P; k++) dst[k].x = in_re[base + ((rev_small<LP>(k) << 6) | rl)];
+            }
+            if (in_im) {
+#pragma unroll
+                for (int k = 0; k < P; k++) dst[k].y = in_im[base + ((rev_small<LP>(k) << 6) | rl)];
+            }
+        } else if (in_re) {
+            // y[i] = in[2i] + j in[2i+1] (8-byte loads: the host checks the alignment)
+            const v2f *src = reinterpret_cast<const v2f *>(in_re + base);
+#pragma unroll
+            for (int k = 0; k < P; k++) dst[k] = src[(rev_small<LP>(k) << 6) | rl];
+        }
+    };
+    const int idx0 = blockIdx.x * kRegsWavesPerBlock + wave;
+    v2f nxt[P];
+    if constexpr (!STREAM) {
+        if (idx0 < n_batch) load_input(idx0, __brev(lane0) >> 26, nxt);
+    }
+
+    for (int idx = idx0; idx < n_batch; idx += stride) {
         // Every address of the body is a function of the lane alone; hoisted out of this loop they would be a hundred
         // live registers (and were: scratch spills).  The lane index is made opaque per iteration so they are formed
         // where they are used.
@@ -388,26 +416,10 @@ __global__ __launch_bounds__(64 * kRegsWavesPerBlock, regs_waves_per_simd(KIND, 
                 if (i < 2 * in_len) pool[i] = v[k].x;
             }
             o_re = nullptr;  // the pool is not a spectrum output
-        } else if constexpr (!REAL) {
-#pragma unroll
-            for (int k = 0; k < P; k++) v[k] = v2f{0.f, 0.f};
-            if (in_re) {
-#pragma unroll
-                for (int k = 0; k < P; k++) v[k].x = in_re[base + ((rev_small<LP>(k) << 6) | rl)];
-            }
-            if (in_im) {
-#pragma unroll
-                for (int k = 0; k < P; k++) v[k].y = in_im[base + ((rev_small<LP>(k) << 6) | rl)];
-            }
         } else {
-            // y[i] = in[2i] + j in[2i+1] (8-byte loads: the host checks the alignment)
-            const v2f *src = reinterpret_cast<const v2f *>(in_re + base);
 #pragma unroll
-            for (int k = 0; k < P; k++) v[k] = v2f{0.f, 0.f};
-            if (in_re) {
-#pragma unroll
-                for (int k = 0; k < P; k++) v[k] = src[(rev_small<LP>(k) << 6) | rl];
-            }
+            for (int k = 0; k < P; k++) v[k] = nxt[k];
+            if (idx + stride < n_batch) load_input(idx + stride, rl, nxt);
         }
 
         R::template pass<INV, 0>(v, buf, lds_tw, tw_staged, lane);
@@ -419,6 +431,13 @@ __global__ __launch_bounds__(64 * kRegsWavesPerBlock, regs_waves_per_simd(KIND, 
         float *const phase = INV ? nullptr : o_pf, *const ampl = INV ? nullptr : o_af;
         constexpr float kAmpScale = 1.0f / (float)(N / 2);  // emit(): sqrtf(r*r + i*i) * 2^-k
         if constexpr (!REAL) {
+            // Loads and stores share one in-order counter and the branches below hide their number from the compiler: the
+            // wait for the prefetched input would land behind this transform's stores.  A use in front of them puts it here,
+            // where the loads are long done.
+            if constexpr (!STREAM) {
+#pragma unroll
+                for (int k = 0; k < P; k++) asm volatile("" : "+v"(nxt[k]));
+            }
             // one uniform branch per output array, its P stores together
             if (o_re) {
 #pragma unroll
@@ -499,6 +518,8 @@ __global__ __launch_bounds__(64 * kRegsWavesPerBlock, regs_waves_per_simd(KIND, 
             wave_sync();
 #pragma unroll
             for (int k = 0; k < P; k++) v[k] = buf[k * 64u + lane];
+#pragma unroll
+            for (int k = 0; k < P; k++) asm volatile("" : "+v"(nxt[k]));  // the wait for the next input: here, not behind the stores
             // outputs j and N - j (h beside j = 0), one uniform branch per array
             if (o_re) {
 #pragma unroll
