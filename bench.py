@@ -526,7 +526,7 @@ class MfftWorkload:
     pmc_tag = "mfft"
     dtype = "f32 data, f64 twiddles"
     bytes_per_frame = 8192.0
-    dominant_kernel = "mfft_kernel<1, false>"
+    dominant_kernel = "mfft_regs_kernel<1, false, 9>"
     dominant_bytes_per_frame = 8192.0
     N = 1024
 
