@@ -964,7 +964,11 @@ def main():
     cls, default_streams = WORKLOADS[args.workload]
     on_gpu = getattr(cls, "needs_gpu", True)
     backend = None
-    if world > 1:
+    # WMIX_BENCH_FORCE_DIST=1 (developer check, tests/test_multirank_gpu.py): take the N > 1 code path -- process group,
+    # far-end broadcast, gathers, barriers -- with the ranks the launcher started, even if that is one.  On a 1-GPU box this
+    # is the only way to put backend nccl (= RCCL) itself under those calls: two ranks cannot share a device under RCCL.
+    force_dist = os.environ.get("WMIX_BENCH_FORCE_DIST") == "1" and "WORLD_SIZE" in os.environ
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -983,7 +987,7 @@ def main():
         dist = None
         if on_gpu:
             torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0) if on_gpu else torch.device("cpu")
+    dev = torch.device("cuda", local_rank if dist is not None else 0) if on_gpu else torch.device("cpu")
 
     if on_gpu:
         from wmix_amd import _lib

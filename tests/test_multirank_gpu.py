@@ -34,3 +34,23 @@ def test_two_ranks_real_kernels_far_end_through_the_broadcast():
         assert p["max_lsb"] <= 1 and p["packets_compared"] > 0 and p["steps_replayed"] >= 60 + 2 + 4 + 6
     # whole-job aggregate over both ranks
     assert d["value"] > 0 and d["config"]["streams_per_gpu"] == 512
+
+
+def test_rccl_itself_under_the_multi_rank_code_path():
+    """backend nccl = RCCL under the same calls (process group on the rank's device, the far-end broadcast as bytes, the
+    gathers, the barriers): the driver's launch line with one rank and WMIX_BENCH_FORCE_DIST=1 -- two ranks cannot share a
+    device under RCCL, so on a 1-GPU box a group of one is what can be run.  The chain is still checked against the oracle."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(WMIX_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "chain", "--streams", "512",
+                        "--steps", "6", "--warmup", "2", "--prime", "60", "--spinup", "4", "--no-cpu"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["dist_backend"] == "nccl" and d["rccl_ranks"] == 1 and d["launched_by"] == "torchrun"
+    assert "RCCL broadcast" in d["config"]["far_end"]
+    assert len(d["parity_checked_ranks"]) == 1 and d["parity_checked_ranks"][0]["max_lsb"] <= 1
+    assert d["parity_checked_ranks"][0]["packets_compared"] > 0

@@ -14,7 +14,7 @@ def broadcast_far(far, dist, src=0, async_op=False):
     async_op=True returns the collective's work handle (or None when there is nothing to exchange): the caller launches
     the stages that do not need the far-end (NS) and calls .wait() before the AEC, so the 320-byte broadcast hides
     behind the noise suppressor."""
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized():  # a group of one rank still makes the call (bench.py's WMIX_BENCH_FORCE_DIST)
         # neither RCCL nor gloo has an int16 type: broadcast the same bytes as uint8 (a view, no copy)
         import torch
         work = dist.broadcast(far.view(torch.uint8), src=src, async_op=async_op)
