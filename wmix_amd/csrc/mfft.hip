@@ -340,7 +340,10 @@ struct RegFft {
 constexpr unsigned kRegsWavesPerBlock = 4;
 
 // waves per SIMD the kernel is compiled for (its register budget; the LDS of a CU holds 6 / 6 / 3 workgroups)
-constexpr int regs_waves_per_simd(int kind, int mc) { return mc <= 8 ? (kind == 1 ? 5 : 6) : (mc == 9 ? (kind == 1 ? 4 : 5) : (kind == 1 ? 2 : 3)); }
+#ifndef WMX_MFFT_W9
+#define WMX_MFFT_W9 4
+#endif
+constexpr int regs_waves_per_simd(int kind, int mc) { return mc <= 8 ? (kind == 1 ? 5 : 6) : (mc == 9 ? (kind == 1 ? WMX_MFFT_W9 : 5) : (kind == 1 ? 2 : 3)); }
 
 template <int KIND, bool STREAM, int MC>
 __global__ __launch_bounds__(64 * kRegsWavesPerBlock, regs_waves_per_simd(KIND, MC)) void mfft_regs_kernel(int n_batch, const double2 *__restrict__ tw_staged,
