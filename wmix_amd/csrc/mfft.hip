@@ -13,6 +13,7 @@
 #include <cmath>
 #include <map>
 #include <mutex>
+#include <utility>
 #include <vector>
 #include "wmx_internal.h"
 #include "fft_ooura.h"  // wave_sync
@@ -26,11 +27,17 @@ constexpr unsigned kMfftMaxN = 4096;
 
 // ---------------------------------------------------------------- host: twiddle tables, cached per size
 std::mutex g_tw_mutex;
-std::map<unsigned, double2 *> g_tw;  // size n -> device double2[n/2] = (cos, sin)(2.0 * PI * p / n)
+// (current device, size n) -> device double2[n/2] = (cos, sin)(2.0 * PI * p / n).  The entry points take raw device
+// pointers and run on the caller's current device (one worker thread per GPU in a C host): a table
+// made on one device must not be handed to a launch on another.
+typedef std::pair<int, unsigned> TwKey;
+std::map<TwKey, double2 *> g_tw;
 
 int twiddles_for(unsigned n, const double2 **out) {
+    int dev = 0;
+    WMX_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_tw_mutex);
-    auto it = g_tw.find(n);
+    auto it = g_tw.find(TwKey(dev, n));
     if (it != g_tw.end()) {
         *out = it->second;
         return 0;
@@ -45,18 +52,20 @@ int twiddles_for(unsigned n, const double2 **out) {
     double2 *d = nullptr;
     WMX_HIP(hipMalloc(&d, h * sizeof(double2)));
     WMX_HIP(hipMemcpy(d, t.data(), h * sizeof(double2), hipMemcpyHostToDevice));
-    g_tw[n] = d;
+    g_tw[TwKey(dev, n)] = d;
     *out = d;
     return 0;
 }
 
 // The same values stage by stage: entry (2^b - 1) + j is the twiddle of butterfly j of stage b + 1 (what dit_passes reads
 // as tw[j << (m - 1 - b)]), so the lanes of a wave read consecutive entries (mfft_regs_kernel).  double2[nc], nc - 1 used.
-std::map<unsigned, double2 *> g_tw_staged;
+std::map<TwKey, double2 *> g_tw_staged;
 
 int staged_twiddles_for(unsigned nc, const double2 **out) {
+    int dev = 0;
+    WMX_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_tw_mutex);
-    auto it = g_tw_staged.find(nc);
+    auto it = g_tw_staged.find(TwKey(dev, nc));
     if (it != g_tw_staged.end()) {
         *out = it->second;
         return 0;
@@ -74,7 +83,7 @@ int staged_twiddles_for(unsigned nc, const double2 **out) {
     double2 *d = nullptr;
     WMX_HIP(hipMalloc(&d, nc * sizeof(double2)));
     WMX_HIP(hipMemcpy(d, t.data(), nc * sizeof(double2), hipMemcpyHostToDevice));
-    g_tw_staged[nc] = d;
+    g_tw_staged[TwKey(dev, nc)] = d;
     *out = d;
     return 0;
 }
