@@ -134,22 +134,23 @@ def test_reference_host_signatures(wmx, oracle_port):
     assert same_bits(pool, want_pool) and same_bits(af, want_af[-1])
 
 
-# ---------------------------------------------------------------- the register-resident kernel (complex sizes 256 .. 1024)
-REGS_CASES = [(kind, n) for kind in range(4) for n in ((256, 512, 1024) if kind in (0, 2) else (512, 1024, 2048))]
+# ---------------------------------------------------------------- the register-resident kernel (complex sizes 32 .. 4096)
+REGS_CASES = [(kind, n) for kind in range(4) for n in ((32, 64, 128, 256, 512, 1024, 2048, 4096) if kind in (0, 2) else (64, 128, 256, 512, 1024, 2048, 4096))]
 
 
 @pytest.mark.parametrize("kind,n", REGS_CASES)
 def test_more_transforms_than_waves_vs_oracle(cuda, oracle_port, kind, n):
-    """mfft_regs_kernel's waves loop over their share of the batch (a grid of at most 256 x 6 workgroups of 4 waves): 6 500
-    transforms make every wave take a second one and leave a ragged tail; rows spread over the batch (the first, the last,
-    the first of the second round) against the oracle, every output the kind has."""
-    batch = 6500
+    """mfft_regs_kernel's workgroups loop over their share of the batch (a grid of at most 256 x 6 workgroups of 32 ... 1
+    transforms): enough transforms that every workgroup takes a second group, with a ragged last group; rows spread over the
+    batch (the first, the last, the first of the second round) against the oracle, every output the kind has."""
+    nc = n if kind in (0, 2) else n // 2
+    batch = {32: 6144 * 16 + 70, 64: 6144 * 8 + 37, 128: 6144 * 4 + 21}.get(nc, 6500)
     rng = np.random.default_rng(900 + 10 * kind + n)
     re = (rng.standard_normal((batch, n)) * 2000).astype(np.float32)
     im = (rng.standard_normal((batch, n)) * 2000).astype(np.float32)
     got = mfft.transform(kind, torch.from_numpy(re).to(cuda), torch.from_numpy(im).to(cuda))
     got = {k: v.cpu().numpy() for k, v in got.items()}
-    rows = sorted({0, 1, 3, 4, 255, 3071, 3072, 5119, 5120, 6143, 6144, 6145, batch - 2, batch - 1})
+    rows = sorted({0, 1, 3, 4, 31, 32, 255, 1535, 1536, 3071, 3072, 5119, 5120, 6143, 6144, 6145, batch - 40, batch - 33, batch - 2, batch - 1})
     for b in rows:
         want = loader.mfft(oracle_port, kind, re[b], im[b], n, prefix="orc")
         for k, w in want.items():
@@ -173,11 +174,11 @@ def test_real_input_that_is_not_8_byte_aligned(cuda, oracle_port, kind, n):
     assert same_bits(got["r"][batch - 1].cpu().numpy(), want["r"]) and same_bits(got["i"][batch - 1].cpu().numpy(), want["i"])
 
 
-@pytest.mark.parametrize("st_len,in_len", [(256, 100), (512, 256), (1024, 160), (1024, 512), (1024, 1)])
+@pytest.mark.parametrize("st_len,in_len", [(32, 16), (64, 20), (128, 64), (256, 100), (512, 256), (1024, 160), (1024, 512), (1024, 1), (2048, 700), (4096, 2048)])
 def test_many_streams_vs_oracle(cuda, oracle_port, st_len, in_len):
-    """fft_stream on 5 300 pools at once (more than the grid's waves), four pushes; pools and curves of a few streams against
+    """fft_stream on 5 300 (49 189 of the short ones) pools at once, four pushes; pools and curves of a few streams against
     the oracle's fft_stream, all streams of equal input equal."""
-    n_streams, pushes = 5300, 4
+    n_streams, pushes = (49189 if st_len <= 128 else 5300), 4  # more pools than one round of the grid takes
     rng = np.random.default_rng(st_len + in_len)
     base = (rng.standard_normal((8, pushes, in_len)) * 1000).astype(np.float32)
     sig = np.ascontiguousarray(base[np.arange(n_streams) % 8])  # [stream, push, in_len]

@@ -279,17 +279,20 @@ __global__ void mfft_kernel(int n_batch, unsigned n, unsigned m, const double2 *
     }
 }
 
-// ---------------------------------------------------------------- the register-resident kernel (64 <= points / 64 lanes)
-// For 256 / 512 / 1024 complex points (FFT / IFFT / fft_stream of those sizes, FFTR / IFFTR of twice as many samples) a wave
-// keeps its transform in registers, P = nc / 64 points per lane, and runs the log2(nc) stages in passes of log2(P) stages
-// whose butterflies pair registers of one lane; between two passes the points change places through the wave's LDS buffer
-// (one float2 write and one read per point, padded by one element per P so that both sides are spread over the banks).
-// The same butterflies with the same operands as dit_passes -- the order of independent butterflies is all that differs.
-//   * the bit-reversed load needs no LDS: register k of lane L takes sample (rev(k) << 6) | rev6(L), so one load instruction
-//     of the wave covers one contiguous 64-point run of the input, lanes permuted inside it;
-//   * pass 0's twiddles are the same for every lane (scalar loads, kept in SGPRs across the transforms of a wave), later
-//     passes read the stage-by-stage table in LDS at consecutive entries;
-//   * a wave works through transforms idx, idx + waves of the grid, ...: the table is staged once per workgroup.
+// ---------------------------------------------------------------- the register-resident kernel (32 .. 4096 complex points)
+// A transform stays in registers, P = 2^LP points per lane as (re, im) pairs, on T = 2^LB lanes: 4 / 8 / 16 lanes for 32 / 64 /
+// 128 points (16 / 8 / 4 transforms per wave), one wave for 256 / 512 / 1024, two / four waves for 2048 / 4096.  The log2(nc) stages
+// run in passes of LP stages whose butterflies pair registers of one lane; between two passes the points change places through
+// the transform's LDS buffer (one float2 write and one read per point, padded by one element per P so that both sides are
+// spread over the banks; wave-scope fences up to one wave per transform, workgroup barriers above).  The same butterflies with
+// the same operands as dit_passes -- the order of independent butterflies is all that differs.
+//   * the bit-reversed load needs no LDS: register k of lane L takes sample (rev(k) << LB) | rev(L), so one load instruction
+//     covers contiguous T-point runs of the input, lanes permuted inside them;
+//   * pass 0's twiddles are the same for every lane (scalar loads, kept in SGPRs across the transforms of a wave); later
+//     passes read the stage-by-stage table at consecutive entries -- from LDS up to 1024 points, from global memory (L2)
+//     above, where the table is as large as the LDS a transform's buffer leaves;
+//   * a workgroup works through transforms g, g + grid, ...: the table is staged once per workgroup, and the next input is
+//     fetched while the current transform is computed.
 // Point index of register k in a pass whose register bits are [S, S + LP):
 //   r = (lane >> S) << (S + LP) | k << S | lane & (2^S - 1).
 template <int LP>
@@ -299,15 +302,26 @@ __device__ constexpr unsigned rev_small(unsigned k) {
     return r;
 }
 
+constexpr int regs_lane_bits(int mc) { return mc <= 7 ? mc - 3 : (mc <= 10 ? 6 : mc - 4); }  // LB: P = 8, 8, 4, 8, 16, 16, 16
+
 template <int MC>
 struct RegFft {
-    static constexpr int NC = 1 << MC, LP = MC - 6, P = 1 << LP, NPASS = (MC + LP - 1) / LP;
-    static constexpr int kBufElems = NC + (NC >> LP);  // float2 elements of a wave's exchange buffer
+    static constexpr int NC = 1 << MC, LB = regs_lane_bits(MC), T = 1 << LB, LP = MC - LB, P = 1 << LP, NPASS = (MC + LP - 1) / LP;
+    static constexpr int TPB = 256 >> LB;               // transforms per 256-thread workgroup
+    static constexpr bool TW_IN_LDS = MC <= 10;         // later passes' twiddles: LDS copy of the staged table, or the table itself
+    static constexpr int kBufElems = NC + (NC >> LP);   // float2 elements of a transform's exchange buffer
     static constexpr int shift_of(int q) { return (q + 1) * LP <= MC ? q * LP : MC - LP; }
     __device__ static __forceinline__ unsigned pad(unsigned r) { return r + (r >> LP); }
     template <int S>
     __device__ static __forceinline__ unsigned point(int k, unsigned lane) {
         return ((lane >> S) << (S + LP)) | ((unsigned)k << S) | (lane & ((1u << S) - 1u));
+    }
+    // the lanes of one transform have exchanged data through LDS
+    __device__ static __forceinline__ void group_sync() {
+        if constexpr (LB <= 6)
+            wave_sync();
+        else
+            __syncthreads();
     }
 
     template <bool INV, int Q>
@@ -319,10 +333,10 @@ struct RegFft {
                 constexpr int S0 = shift_of(Q - 1);
 #pragma unroll
                 for (int k = 0; k < P; k++) buf[pad(point<S0>(k, lane))] = v[k];
-                wave_sync();
+                group_sync();
 #pragma unroll
                 for (int k = 0; k < P; k++) v[k] = buf[pad(point<S>(k, lane))];
-                wave_sync();
+                group_sync();
             }
             constexpr int B0 = Q * LP, B1 = (Q + 1) * LP <= MC ? (Q + 1) * LP : MC;  // stages B0 + 1 .. B1 pair index bit b
             const unsigned low = lane & ((1u << S) - 1u);
@@ -332,7 +346,8 @@ struct RegFft {
 #pragma unroll
                 for (int c = 0; c < (1 << kb); c++) {
                     // butterfly j = low b bits of r = low | c << S
-                    const double2 w = S == 0 ? tw_glb[(1 << b) - 1 + c] : tw_lds[(1u << b) - 1u + low + ((unsigned)c << S)];
+                    const double2 w = S == 0 ? tw_glb[(1 << b) - 1 + c]
+                                             : (TW_IN_LDS ? tw_lds : tw_glb)[(1u << b) - 1u + low + ((unsigned)c << S)];
 #pragma unroll
                     for (int hi = 0; hi < (P >> (kb + 1)); hi++) {
                         const int k0 = (hi << (kb + 1)) | c, k1 = k0 | (1 << kb);
@@ -346,32 +361,37 @@ struct RegFft {
     }
 };
 
-constexpr unsigned kRegsWavesPerBlock = 4;
-
-// waves per SIMD the kernel is compiled for (its register budget; the LDS of a CU holds 6 / 6 / 3 workgroups)
+// waves per SIMD the kernel is compiled for (its register budget), by points per lane; the real forward kind needs more
 #ifndef WMX_MFFT_W9
 #define WMX_MFFT_W9 4
 #endif
-constexpr int regs_waves_per_simd(int kind, int mc) { return mc <= 8 ? (kind == 1 ? 5 : 6) : (mc == 9 ? (kind == 1 ? WMX_MFFT_W9 : 5) : (kind == 1 ? 2 : 3)); }
+constexpr int regs_waves_per_simd(int kind, int mc) {
+    const int lp = mc - regs_lane_bits(mc);
+    if (mc <= 7) return 4;  // several transforms per wave: per-lane base addresses on top of the P = 8 points
+    return lp <= 2 ? (kind == 1 ? 5 : 6) : (lp == 3 ? (kind == 1 ? WMX_MFFT_W9 : 5) : (kind == 1 ? 2 : 3));
+}
 
 template <int KIND, bool STREAM, int MC>
-__global__ __launch_bounds__(64 * kRegsWavesPerBlock, regs_waves_per_simd(KIND, MC)) void mfft_regs_kernel(int n_batch, const double2 *__restrict__ tw_staged,
-                                                                           const double2 *__restrict__ tw_n, const float *in_re,
-                                                                           const float *in_im, float *out_re, float *out_im, float *out_af,
-                                                                           float *out_pf, unsigned in_len) {
+__global__ __launch_bounds__(256, regs_waves_per_simd(KIND, MC)) void mfft_regs_kernel(int n_batch, const double2 *__restrict__ tw_staged,
+                                                                                     const double2 *__restrict__ tw_n, const float *in_re,
+                                                                                     const float *in_im, float *out_re, float *out_im,
+                                                                                     float *out_af, float *out_pf, unsigned in_len) {
     using R = RegFft<MC>;
     constexpr bool REAL = (KIND == 1 || KIND == 3), INV = (KIND >= 2);
-    constexpr int NC = R::NC, P = R::P, LP = R::LP;
-    constexpr unsigned N = REAL ? 2u * NC : (unsigned)NC;
-    extern __shared__ double2 lds_tw[];  // [NC] stage-by-stage twiddles, then one exchange buffer per wave
-    for (unsigned i = threadIdx.x; i < (unsigned)NC; i += blockDim.x) lds_tw[i] = tw_staged[i];
-    __syncthreads();  // the only block-level barrier
-    const unsigned lane0 = threadIdx.x & 63u;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    v2f *buf = reinterpret_cast<v2f *>(lds_tw + NC) + (size_t)wave * R::kBufElems;
-    const int stride = gridDim.x * kRegsWavesPerBlock;
-    // The input of the wave's next transform is fetched while it works on the current one (not fft_stream's, whose load
-    // also stores).  load_input: register k of lane L takes sample (rev(k) << 6) | rev6(L).
+    constexpr int NC = R::NC, P = R::P, LP = R::LP, LB = R::LB, TPB = R::TPB;
+    constexpr unsigned N = REAL ? 2u * NC : (unsigned)NC, T = R::T;
+    extern __shared__ double2 lds_tw[];  // [NC] stage-by-stage twiddles (up to 1024 points), then one exchange buffer per transform
+    constexpr int NTW = R::TW_IN_LDS ? NC : 0;
+    if constexpr (R::TW_IN_LDS) {
+        for (unsigned i = threadIdx.x; i < (unsigned)NC; i += blockDim.x) lds_tw[i] = tw_staged[i];
+        __syncthreads();
+    }
+    const unsigned lane0 = threadIdx.x & (T - 1u);  // the lane's index inside its transform
+    // the transform inside the workgroup: wave-uniform from one wave per transform up (addresses stay on the scalar unit)
+    const int sub = LB >= 6 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> LB)) : (int)(threadIdx.x >> LB);
+    v2f *buf = reinterpret_cast<v2f *>(lds_tw + NTW) + (size_t)sub * R::kBufElems;
+    // The input of the next transform is fetched while the current one is computed (not fft_stream's, whose load also
+    // stores).  load_input: register k of lane L takes sample (rev(k) << LB) | rev(L).
     auto load_input = [&](int idx, unsigned rl, v2f(&dst)[P]) {
         const size_t base = (size_t)idx * N;
 #pragma unroll
@@ -379,35 +399,41 @@ __global__ __launch_bounds__(64 * kRegsWavesPerBlock, regs_waves_per_simd(KIND, 
         if constexpr (!REAL) {
             if (in_re) {
 #pragma unroll
-                for (int k = 0; k < P; k++) dst[k].x = in_re[base + ((rev_small<LP>(k) << 6) | rl)];
+                for (int k = 0; k < P; k++) dst[k].x = in_re[base + ((rev_small<LP>(k) << LB) | rl)];
             }
             if (in_im) {
 #pragma unroll
-                for (int k = 0; k < P; k++) dst[k].y = in_im[base + ((rev_small<LP>(k) << 6) | rl)];
+                for (int k = 0; k < P; k++) dst[k].y = in_im[base + ((rev_small<LP>(k) << LB) | rl)];
             }
         } else if (in_re) {
             // y[i] = in[2i] + j in[2i+1] (8-byte loads: the host checks the alignment)
             const v2f *src = reinterpret_cast<const v2f *>(in_re + base);
 #pragma unroll
-            for (int k = 0; k < P; k++) dst[k] = src[(rev_small<LP>(k) << 6) | rl];
+            for (int k = 0; k < P; k++) dst[k] = src[(rev_small<LP>(k) << LB) | rl];
         }
     };
-    const int idx0 = blockIdx.x * kRegsWavesPerBlock + wave;
+    // A lane whose transform lies beyond the batch (the ragged end of the last group) computes the last transform again and
+    // stores nothing: the loop and its barriers stay uniform over the workgroup.
+    const int last = n_batch - 1;
     v2f nxt[P];
     if constexpr (!STREAM) {
-        if (idx0 < n_batch) load_input(idx0, __brev(lane0) >> 26, nxt);
+        const int idx0 = (int)blockIdx.x * TPB + sub;
+        load_input(idx0 < n_batch ? idx0 : last, __brev(lane0) >> (32 - LB), nxt);
     }
 
-    for (int idx = idx0; idx < n_batch; idx += stride) {
+    for (int g = blockIdx.x; g * TPB < n_batch; g += gridDim.x) {
         // Every address of the body is a function of the lane alone; hoisted out of this loop they would be a hundred
         // live registers (and were: scratch spills).  The lane index is made opaque per iteration so they are formed
         // where they are used.
         unsigned lane = lane0;
         asm volatile("" : "+v"(lane));
-        const unsigned rl = __brev(lane) >> 26;  // the lane's place inside a 64-point run of the input
+        const unsigned rl = __brev(lane) >> (32 - LB);  // the lane's place inside a T-point run of the input
+        const int idx_raw = g * TPB + sub;
+        const bool valid = idx_raw < n_batch;
+        const int idx = valid ? idx_raw : last;
         const size_t base = (size_t)idx * N;
-        float *o_re = out_re ? out_re + base : nullptr, *o_im = out_im ? out_im + base : nullptr;
-        float *o_af = out_af ? out_af + base : nullptr, *o_pf = out_pf ? out_pf + base : nullptr;
+        float *o_re = out_re && valid ? out_re + base : nullptr, *o_im = out_im && valid ? out_im + base : nullptr;
+        float *o_af = out_af && valid ? out_af + base : nullptr, *o_pf = out_pf && valid ? out_pf + base : nullptr;
         v2f v[P];
 
         if constexpr (STREAM) {
@@ -417,30 +443,33 @@ __global__ __launch_bounds__(64 * kRegsWavesPerBlock, regs_waves_per_simd(KIND, 
             const float *fresh = in_re + (size_t)idx * in_len;
 #pragma unroll
             for (int k = 0; k < P; k++) {
-                const unsigned i = (rev_small<LP>(k) << 6) | rl;
+                const unsigned i = (rev_small<LP>(k) << LB) | rl;
                 v[k].x = i < in_len ? pool[i + in_len] : (i < 2 * in_len ? fresh[i - in_len] : pool[i]);
                 v[k].y = 0.f;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (LB > 6) __syncthreads();  // the other waves of the transform have read the old pool too
 #pragma unroll
             for (int k = 0; k < P; k++) {
-                const unsigned i = (rev_small<LP>(k) << 6) | rl;
-                if (i < 2 * in_len) pool[i] = v[k].x;
+                const unsigned i = (rev_small<LP>(k) << LB) | rl;
+                if (valid && i < 2 * in_len) pool[i] = v[k].x;
             }
             o_re = nullptr;  // the pool is not a spectrum output
         } else {
 #pragma unroll
             for (int k = 0; k < P; k++) v[k] = nxt[k];
-            if (idx + stride < n_batch) load_input(idx + stride, rl, nxt);
+            const int idx_n = (g + (int)gridDim.x) * TPB + sub;
+            if ((g + (int)gridDim.x) * TPB < n_batch) load_input(idx_n < n_batch ? idx_n : last, rl, nxt);
         }
 
         R::template pass<INV, 0>(v, buf, lds_tw, tw_staged, lane);
-        // now register k of lane L holds point k * 64 + L
+        // now register k of lane L holds point k * T + L
 
         // The phase curve (double atan2, math/fft.c:149-152) is the one output that is expensive per point and rarely asked
         // for: it runs as a rolled loop over the buffer behind everything else, so the transform's registers are not
-        // priced for sixteen inlined copies of it.
+        // priced for 2 P inlined copies of it.  (The branches on the output arrays test the kernel arguments: uniform.)
         float *const phase = INV ? nullptr : o_pf, *const ampl = INV ? nullptr : o_af;
+        const bool want_phase = !INV && out_pf, want_ampl = !INV && out_af, want_re = out_re && !STREAM, want_im = out_im != nullptr;
         constexpr float kAmpScale = 1.0f / (float)(N / 2);  // emit(): sqrtf(r*r + i*i) * 2^-k
         if constexpr (!REAL) {
             // Loads and stores share one in-order counter and the branches below hide their number from the compiler: the
@@ -451,44 +480,50 @@ __global__ __launch_bounds__(64 * kRegsWavesPerBlock, regs_waves_per_simd(KIND, 
                 for (int k = 0; k < P; k++) asm volatile("" : "+v"(nxt[k]));
             }
             // one uniform branch per output array, its P stores together
-            if (o_re) {
+            if (want_re) {
 #pragma unroll
-                for (int k = 0; k < P; k++) o_re[k * 64u + lane] = v[k].x;
+                for (int k = 0; k < P; k++)
+                    if (valid) o_re[k * T + lane] = v[k].x;
             }
-            if (o_im) {
+            if (want_im) {
 #pragma unroll
-                for (int k = 0; k < P; k++) o_im[k * 64u + lane] = v[k].y;
+                for (int k = 0; k < P; k++)
+                    if (valid) o_im[k * T + lane] = v[k].y;
             }
-            if (ampl) {
+            if (want_ampl) {
 #pragma unroll
-                for (int k = 0; k < P; k++) ampl[k * 64u + lane] = sqrtf(v[k].x * v[k].x + v[k].y * v[k].y) * kAmpScale;
+                for (int k = 0; k < P; k++) {
+                    const float a = sqrtf(v[k].x * v[k].x + v[k].y * v[k].y) * kAmpScale;
+                    if (valid) ampl[k * T + lane] = a;
+                }
             }
-            if (phase) {
-                wave_sync();
+            if (want_phase) {
+                R::group_sync();
 #pragma unroll
-                for (int k = 0; k < P; k++) buf[k * 64u + lane] = v[k];
-                wave_sync();
+                for (int k = 0; k < P; k++) buf[k * T + lane] = v[k];
+                R::group_sync();
 #pragma nounroll
                 for (int k = 0; k < P; k++) {
-                    const v2f t = buf[k * 64u + lane];
-                    phase[k * 64u + lane] = (float)atan2((double)t.y, (double)t.x);
+                    const v2f t = buf[k * T + lane];
+                    const float ph = (float)atan2((double)t.y, (double)t.x);
+                    if (valid) phase[k * T + lane] = ph;
                 }
-                wave_sync();
+                R::group_sync();
             }
         } else {
             // The split into the spectra of the even / odd samples and the last stage (math/fft.c:182-232 / 345-392).  Points
-            // j and NC - j are each other's partners, so one lane takes both and writes both results back in place: a rolled
-            // loop of P / 2 steps over the buffer (unpadded: both sides run along the banks) with nothing but arithmetic and
-            // the two table entries of the next step in flight.  Unrolled on the registers this stage was the larger half of
-            // the kernel's code and twice the registers of everything else; with the stores inside the loop every step
-            // waited for them (one counter for loads and stores).  Lane 0's first step has j = 0, which has no partner, and
-            // takes the self-partnered point NC / 2 beside it.
+            // j and NC - j are each other's partners, so one lane takes both and writes both results back in place: P / 2
+            // steps over the buffer (unpadded: both sides run along the banks) with nothing but arithmetic and the two table
+            // entries of the next step in flight.  Unrolled on the registers with the stores inside, this stage was the larger
+            // half of the kernel's code and twice the registers of everything else, and every step waited for the stores
+            // (one counter for loads and stores).  Lane 0's first step has j = 0, which has no partner, and takes the
+            // self-partnered point NC / 2 beside it.
             const double2 *const twl = tw_n + lane;
             double2 wa = twl[0], wb = twl[lane == 0 ? NC / 2 : NC - 2 * lane];  // entries j and NC - j of step 0
-            wave_sync();
+            R::group_sync();
 #pragma unroll
-            for (int k = 0; k < P; k++) buf[k * 64u + lane] = v[k];
-            wave_sync();
+            for (int k = 0; k < P; k++) buf[k * T + lane] = v[k];
+            R::group_sync();
             constexpr unsigned h = NC;
             // point h belongs to j = 0: x1 - x2 of (re[0], im[0]) (every lane computes it, lane 0 stores it)
             const v2f y0 = buf[0];
@@ -497,14 +532,14 @@ __global__ __launch_bounds__(64 * kRegsWavesPerBlock, regs_waves_per_simd(KIND, 
                 mr = mr / 2;
                 mi = mi / 2;
             }
-            wave_sync();
+            R::group_sync();
 #pragma unroll
             for (int t = 0; t < P / 2; t++) {
-                const unsigned j = t * 64u + lane;
+                const unsigned j = t * T + lane;
                 const bool first = j == 0;
                 const unsigned jb = first ? h / 2 : h - j;
-                const unsigned jn = j + (t + 1 < P / 2 ? 64u : 0u);  // the next step's entries (the last step's again)
-                const double2 wa_next = tw_n[jn], wb_next = tw_n[h - jn];
+                const unsigned jn = j + (t + 1 < P / 2 ? T : 0u);  // the next step's entries (the last step's again)
+                const double2 wa_next = tw_n[jn], wb_next = tw_n[jn == 0 ? h / 2 : h - jn];
                 const v2f y = buf[j], z = buf[jb];
                 // point j (partner z; none for j = 0) and point jb (partner y; itself for NC / 2)
                 const v2f pa = first ? y : z, pb = first ? z : y;
@@ -527,55 +562,62 @@ __global__ __launch_bounds__(64 * kRegsWavesPerBlock, regs_waves_per_simd(KIND, 
                 buf[jb] = xb;
                 wa = wa_next, wb = wb_next;
             }
-            wave_sync();
+            R::group_sync();
 #pragma unroll
-            for (int k = 0; k < P; k++) v[k] = buf[k * 64u + lane];
+            for (int k = 0; k < P; k++) v[k] = buf[k * T + lane];
 #pragma unroll
             for (int k = 0; k < P; k++) asm volatile("" : "+v"(nxt[k]));  // the wait for the next input: here, not behind the stores
             // outputs j and N - j (h beside j = 0), one uniform branch per array
-            if (o_re) {
+            if (want_re) {
 #pragma unroll
                 for (int k = 0; k < P; k++) {
-                    const unsigned j = k * 64u + lane;
-                    o_re[j] = v[k].x;
-                    o_re[k == 0 && j == 0 ? h : N - j] = k == 0 && j == 0 ? mr : v[k].x;
-                }
-            }
-            if (o_im) {
-#pragma unroll
-                for (int k = 0; k < P; k++) {
-                    const unsigned j = k * 64u + lane;
-                    o_im[j] = v[k].y;
-                    o_im[k == 0 && j == 0 ? h : N - j] = k == 0 && j == 0 ? mi : -v[k].y;
-                }
-            }
-            if (ampl) {
-#pragma unroll
-                for (int k = 0; k < P; k++) {
-                    const unsigned j = k * 64u + lane;
-                    const float a = sqrtf(v[k].x * v[k].x + v[k].y * v[k].y) * kAmpScale;  // (-xi)^2 == xi^2: point N - j has it too
-                    ampl[j] = a;
-                    if (k == 0) {
-                        const float ah = sqrtf(mr * mr + mi * mi) * kAmpScale;
-                        ampl[j == 0 ? h : N - j] = j == 0 ? ah : a;
-                    } else {
-                        ampl[N - j] = a;
+                    const unsigned j = k * T + lane;
+                    if (valid) {
+                        o_re[j] = v[k].x;
+                        o_re[k == 0 && j == 0 ? h : N - j] = k == 0 && j == 0 ? mr : v[k].x;
                     }
                 }
             }
-            if (phase) {
-#pragma nounroll
+            if (want_im) {
+#pragma unroll
                 for (int k = 0; k < P; k++) {
-                    const unsigned j = k * 64u + lane;
-                    const v2f t = buf[j];
-                    phase[j] = (float)atan2((double)t.y, (double)t.x);
-                    if (j == 0)
-                        phase[h] = (float)atan2((double)mi, (double)mr);
-                    else
-                        phase[N - j] = (float)atan2((double)-t.y, (double)t.x);
+                    const unsigned j = k * T + lane;
+                    if (valid) {
+                        o_im[j] = v[k].y;
+                        o_im[k == 0 && j == 0 ? h : N - j] = k == 0 && j == 0 ? mi : -v[k].y;
+                    }
                 }
             }
-            wave_sync();  // the buffer is free for the next transform
+            if (want_ampl) {
+#pragma unroll
+                for (int k = 0; k < P; k++) {
+                    const unsigned j = k * T + lane;
+                    const float a = sqrtf(v[k].x * v[k].x + v[k].y * v[k].y) * kAmpScale;  // (-xi)^2 == xi^2: point N - j has it too
+                    float a2 = a;
+                    if (k == 0) {
+                        const float ah = sqrtf(mr * mr + mi * mi) * kAmpScale;
+                        a2 = j == 0 ? ah : a;
+                    }
+                    if (valid) {
+                        ampl[j] = a;
+                        ampl[k == 0 && j == 0 ? h : N - j] = a2;
+                    }
+                }
+            }
+            if (want_phase) {
+#pragma nounroll
+                for (int k = 0; k < P; k++) {
+                    const unsigned j = k * T + lane;
+                    const v2f t = buf[j];
+                    const float p1 = (float)atan2((double)t.y, (double)t.x);
+                    const float p2 = j == 0 ? (float)atan2((double)mi, (double)mr) : (float)atan2((double)-t.y, (double)t.x);
+                    if (valid) {
+                        phase[j] = p1;
+                        phase[j == 0 ? h : N - j] = p2;
+                    }
+                }
+            }
+            R::group_sync();  // the buffer is free for the next transform
         }
     }
 }
@@ -593,23 +635,25 @@ int check_size(unsigned n, unsigned *m) {
 
 unsigned waves_per_block(unsigned n) { return n <= 1024 ? 4u : (n <= 2048 ? 2u : 1u); }
 
-// mfft_regs_kernel: complex sizes 2^8 .. 2^10; a grid of as many workgroups as the device holds at once (256 CUs, 160 KB of
-// LDS each), every wave loops over its share of the batch
-bool regs_path(unsigned mc) { return mc >= 8 && mc <= 10; }
+// mfft_regs_kernel: complex sizes 2^5 .. 2^12 (every kind from 64 samples up); a grid of as many workgroups as the device holds at once (256 CUs, 160 KB of
+// LDS each), every workgroup loops over its share of the batch
+bool regs_path(unsigned mc) { return mc >= 5 && mc <= 12; }
 struct RegsLaunch {
     dim3 grid, block;
     size_t lds;
 };
 RegsLaunch regs_launch(int kind, unsigned mc, int n_batch) {
-    const size_t nc = (size_t)1 << mc, buf = nc + (nc >> (mc - 6));
+    const int lb = regs_lane_bits((int)mc), lp = (int)mc - lb;
+    const size_t nc = (size_t)1 << mc, buf = nc + (nc >> lp), tpb = (size_t)256 >> lb;
     RegsLaunch L;
-    L.lds = nc * sizeof(double2) + kRegsWavesPerBlock * buf * sizeof(float2);
+    L.lds = (mc <= 10 ? nc * sizeof(double2) : 0) + tpb * buf * sizeof(float2);
     size_t resident = (160u * 1024u) / L.lds;
     const size_t by_registers = (size_t)regs_waves_per_simd(kind, (int)mc);
     if (resident > by_registers) resident = by_registers;
-    const size_t cap = 256u * resident, need = ((size_t)n_batch + kRegsWavesPerBlock - 1) / kRegsWavesPerBlock;
+    if (resident < 1) resident = 1;
+    const size_t cap = 256u * resident, need = ((size_t)n_batch + tpb - 1) / tpb;
     L.grid = dim3((unsigned)(need < cap ? need : cap));
-    L.block = dim3(64 * kRegsWavesPerBlock);
+    L.block = dim3(256);
     return L;
 }
 
@@ -645,9 +689,14 @@ extern "C" int wmx_mfft(int kind, int n_batch, unsigned n, const float *d_in_re,
     hipLaunchKernelGGL((mfft_regs_kernel<K, false, MC>), L.grid, L.block, L.lds, s, n_batch, tw_staged, tw_n, d_in_re, d_in_im, d_out_re, d_out_im, d_out_af, d_out_pf, 0u)
 #define WMX_MFFT_REGS_K(K) \
     switch (mc) { \
+        case 5: WMX_MFFT_REGS(K, 5); break; \
+        case 6: WMX_MFFT_REGS(K, 6); break; \
+        case 7: WMX_MFFT_REGS(K, 7); break; \
         case 8: WMX_MFFT_REGS(K, 8); break; \
         case 9: WMX_MFFT_REGS(K, 9); break; \
-        default: WMX_MFFT_REGS(K, 10); break; \
+        case 10: WMX_MFFT_REGS(K, 10); break; \
+        case 11: WMX_MFFT_REGS(K, 11); break; \
+        default: WMX_MFFT_REGS(K, 12); break; \
     }
         switch (kind) {
             case 0: WMX_MFFT_REGS_K(0); break;
@@ -696,9 +745,14 @@ extern "C" int wmx_mfft_stream(int n_streams, const float *d_in, unsigned in_len
 #define WMX_MFFT_REGS(MC) \
     hipLaunchKernelGGL((mfft_regs_kernel<0, true, MC>), L.grid, L.block, L.lds, as_stream(stream), n_streams, tw_staged, tw, d_in, (const float *)nullptr, d_pool, (float *)nullptr, d_out_af, d_out_pf, in_len)
         switch (m) {
+            case 5: WMX_MFFT_REGS(5); break;
+            case 6: WMX_MFFT_REGS(6); break;
+            case 7: WMX_MFFT_REGS(7); break;
             case 8: WMX_MFFT_REGS(8); break;
             case 9: WMX_MFFT_REGS(9); break;
-            default: WMX_MFFT_REGS(10); break;
+            case 10: WMX_MFFT_REGS(10); break;
+            case 11: WMX_MFFT_REGS(11); break;
+            default: WMX_MFFT_REGS(12); break;
         }
 #undef WMX_MFFT_REGS
         WMX_LAUNCH_CHECK();
