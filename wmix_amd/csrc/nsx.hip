@@ -202,10 +202,28 @@ __device__ void two_peaks(const int16_t *hist, int lane, uint32_t &pos1, int &w1
 // ---------------------------------------------------------------- one 10 ms block of one stream (ProcessCore)
 // in0 / out0: low band (channel 0), in1 / out1: the "high band" (channel 1 of a 2-channel stream);
 // element stride CHN.  sc[]: the stream's scalars in its LDS state block, read wave-uniformly where used (LdsScal, spl_fx.h).
+#ifdef WMX_NSX_PROF  // developer build only (make EXTRA=-DWMX_NSX_PROF): cycles per phase of nsx_block, summed over waves
+// (one slot per SIMD-sized group of waves and phase, plain stores: atomics on sixteen shared words queued every wave's next
+// load behind everybody's counters -- the phase with the first global load read 70 %)
+__device__ unsigned long long g_nsx_prof[1024 * 16];
+#define NSX_PROF(i)                                                                              \
+    do {                                                                                         \
+        const long long t_now = clock64();                                                       \
+        prof_acc[i] += (unsigned long long)(t_now - prof_t0);                                    \
+        prof_t0 = clock64();                                                                     \
+    } while (0)
+#else
+#define NSX_PROF(i)
+#endif
+
 template <int ANA, int CHN>
 __device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsScal sc, int16_t *hist, const int16_t *in, int16_t *out,
                           int lane, int overdrive, int denoise_bound) {
     using Y = NsxLayout<ANA>;
+#ifdef WMX_NSX_PROF
+    unsigned long long prof_acc[16] = {0};
+    long long prof_t0 = clock64();
+#endif
     constexpr int BINS = Y::BINS, H = ANA / 2, BLOCK = ANA == 256 ? 160 : 80, KEEP = ANA - BLOCK, STAGES = ANA == 256 ? 8 : 7;
     constexpr int32_t kMaxLrt = ANA == 256 ? 0x0080000 : 0x0040000, kMinLrt = ANA == 256 ? 104858 : 52429;
     int16_t *ana = reinterpret_cast<int16_t *>(&W.st[Y::ANA_BUF]), *syn = reinterpret_cast<int16_t *>(&W.st[Y::SYN_BUF]);
@@ -250,6 +268,7 @@ __device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsSca
         }
         wave_sync();
     }
+    NSX_PROF(11);
     for (int i = lane; i < ANA; i += 64) td[i] = (int16_t)mul_rsft_round(K.window[i], ana[i], 14);
     wave_sync();
     int scale_energy_in;
@@ -263,6 +282,7 @@ __device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsSca
     if (mxabs > 32767) mxabs = 32767;
     const int norm_data = norm_w16((int16_t)mxabs);
     const bool zero_input = mxabs == 0;
+    NSX_PROF(12);
 
     if (!zero_input) {
         const int net_norm = STAGES - norm_data;
@@ -283,7 +303,8 @@ __device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsSca
         if constexpr (STAGES == 7)
             spl_cfft128<false>(W.cx, K.tw, lane);
         else
-            spl_cfft<STAGES, false>(W.cx, K.tw, lane);
+            spl_cfft256<false>(W.cx, K.tw, lane);
+        NSX_PROF(13);
         // spectrum, magnitudes, sums (:1231-1264 / :1266-1328)
         const bool startup = sc[X_BLOCK_INDEX] < 50;  // the previous block's index: it is advanced below
         uint32_t e_sum = 0, m_sum = 0;
@@ -361,6 +382,7 @@ __device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsSca
         }
         wave_sync();
 
+        NSX_PROF(0);
         // ---- ProcessCore, :1590 onwards
         sc[X_BLOCK_INDEX]++;
         const int block_index = sc[X_BLOCK_INDEX];
@@ -402,6 +424,7 @@ __device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsSca
             sc[X_FEAT_FLAT] = (int32_t)feat;
         }
 
+        NSX_PROF(1);
         // NoiseEstimationC, :334-453
         int16_t q_noise;
         {
@@ -476,6 +499,7 @@ __device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsSca
             q_noise = (int16_t)sc[X_QNOISE];
         }
 
+        NSX_PROF(2);
         // start-up blend with the white / pink parametric model, :1596-1709
         if (block_index < 50) {
             const int qd = (int)q_noise < sc[X_MIN_NORM] - STAGES ? (int)q_noise : sc[X_MIN_NORM] - STAGES;
@@ -528,6 +552,7 @@ __device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsSca
             sc[X_TIME_AVG_E] = (int32_t)div_u32_u16((uint32_t)sc[X_TIME_AVG_E_TMP], (uint16_t)(block_index + 1));
         }
 
+        NSX_PROF(3);
         // step 1: decision-directed prior / post SNR, :1722-1782
         const uint32_t sat_max = 1048575;
         {
@@ -560,6 +585,7 @@ __device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsSca
             }
         }
 
+        NSX_PROF(4);
         // ComputeSpectralDifference, :1091-1181
         {
             int32_t s_p = 0, mx = 0, mn = pause[0];
@@ -618,6 +644,7 @@ __device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsSca
             sc[X_FEAT_DIFF] = (int32_t)fd;
         }
 
+        NSX_PROF(5);
         // FeatureParameterExtraction, :821-1017
         sc[X_CNT_THR]++;
         const bool flag = sc[X_CNT_THR] == 512;
@@ -712,6 +739,7 @@ __device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsSca
             sc[X_CUR_AVG_E] = 0;
         }
 
+        NSX_PROF(6);
         // SpeechNoiseProb, nsx_core_c.c:26-260
         {
             uint32_t ls = 0;
@@ -795,6 +823,7 @@ __device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsSca
         }
         wave_sync();
 
+        NSX_PROF(7);
         // noise update, :1840-1945 (gamma of a bin is set by the speech probability of the bin before it)
         int norm_max;
         {
@@ -845,6 +874,7 @@ __device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsSca
         }
         q_noise = (int16_t)(sc[X_PREV_QNOISE] + norm_max - 5);
 
+        NSX_PROF(8);
         // step 3: Wiener gain from the updated noise, :1947-2013; previous-frame arrays, :2015-2029
         {
             const int n_shifts = sc[X_PREV_QNOISE] + 11 - q_magn;
@@ -889,6 +919,7 @@ __device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsSca
         sc[X_PREV_QMAGN] = q_magn;
         wave_sync();
 
+        NSX_PROF(9);
         // ---- DataSynthesis, :1421-1499: PrepareSpectrumC :456-474, inverse transform, DenormalizeC :477-488
         int32_t t_spec[NP];
         FOR_BINS(r, b) t_spec[r] = W.cx[b];
@@ -907,7 +938,8 @@ __device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsSca
         if constexpr (STAGES == 7)
             out_scale = spl_cfft128<true>(W.cx, K.tw, lane);
         else
-            out_scale = spl_cfft<STAGES, true>(W.cx, K.tw, lane);
+            out_scale = spl_cfft256<true>(W.cx, K.tw, lane);
+        NSX_PROF(14);
         {
             int16_t tv[ANA / 64];
 #pragma unroll
@@ -985,7 +1017,33 @@ __device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsSca
         for (int i = lane; i < BLOCK; i += 64) out[(long)i * CHN + 1] = zero_input ? hb[i] : (int16_t)((g * hb[i]) >> 14);
     }
     wave_sync();
+    NSX_PROF(10);
+#ifdef WMX_NSX_PROF
+    if (lane < 16) {  // racy read-modify-write among the waves that share a slot: good enough for a profile
+        unsigned long long v = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) v = lane == i ? prof_acc[i] : v;
+        g_nsx_prof[(blockIdx.x & 1023) * 16 + lane] += v;
+    }
+#endif
 }
+
+#ifdef WMX_NSX_PROF
+extern "C" int wmx_debug_nsx_prof(unsigned long long *out16, int reset) {
+    (void)hipDeviceSynchronize();
+    static unsigned long long all[1024 * 16];
+    (void)hipMemcpyFromSymbol(all, HIP_SYMBOL(g_nsx_prof), sizeof(all));
+    for (int i = 0; i < 16; i++) {
+        out16[i] = 0;
+        for (int g = 0; g < 1024; g++) out16[i] += all[g * 16 + i];
+    }
+    if (reset) {
+        static const unsigned long long z[1024 * 16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_nsx_prof), z, sizeof(z));
+    }
+    return 0;
+}
+#endif
 
 // One wave per stream, NsxShape::WPB streams per workgroup, all packets of the launch with the state in LDS.
 template <int ANA, int CHN>

@@ -291,6 +291,79 @@ __device__ int spl_cfft128(int32_t *cx, const SplTwiddles &T, int lane) {
     return scale;
 }
 
+// ---------------------------------------------------------------- the 256-point transform without LDS between stages
+// Four points per lane, x[k] = point (index bits) with two of the eight index bits in the register number k and six in the
+// lane number.  A stage whose bit is a register bit pairs two registers of one lane: stages 2 t and 2 t + 1 run on register
+// bits 0 and 1, then both register bits change places with lane bits 2 t and 2 t + 1 (spl_xchg on the register pairs that
+// differ in the bit: the same 2 x 2 transposes as above, four per round, three rounds).  Entry: lane L holds points
+// 4 L .. 4 L + 3 of the bit-reversed input (one 16-byte read); exit: register k of lane L is point L + 64 k.  The arithmetic
+// is that of spl_cfft, operation for operation; the in-LDS version spent a third of the NSX kernel's wave time in its sixteen
+// LDS round trips per frame (tools_dev/nsx_prof.py).
+template <bool INVERSE>
+__device__ int spl_cfft256(int32_t *cx, const SplTwiddles &T, int lane) {
+    int scale = 0;
+    int32_t x[4];
+    {
+        const int4 q = *reinterpret_cast<const int4 *>(cx + 4 * lane);
+        x[0] = q.x, x[1] = q.y, x[2] = q.z, x[3] = q.w;
+    }
+    uint32_t mag = 0;
+    if (INVERSE) mag = pk_max_u16(pk_max_u16(pk_abs16(x[0]), pk_abs16(x[1])), pk_max_u16(pk_abs16(x[2]), pk_abs16(x[3])));
+    // low: the index bits below the stage's bit that live in the lane number (the first 2 t lane bits); the register bit below
+    // the stage's bit joins them in the odd stages
+    auto stage = [&](auto S_) {
+        constexpr int s = decltype(S_)::value, rb = s & 1;  // rb: the register bit this stage pairs
+        int shift = INVERSE ? 0 : 1;
+        int32_t round2 = INVERSE ? 8192 : 16384;
+        if (INVERSE) {
+            uint32_t m16 = (mag & 0xffffu) > (mag >> 16) ? (mag & 0xffffu) : (mag >> 16);
+            int32_t mx = wave_max((int32_t)m16);
+            if (mx > 32767) mx = 32767;
+            if (mx > 13573) shift++, scale++, round2 <<= 1;
+            if (mx > 27146) shift++, scale++, round2 <<= 1;
+            mag = 0;
+        }
+        const int low = lane & ((1 << (s - rb)) - 1);
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            // butterfly c: registers (u, v) = (c, c + 1) for register bit 0 [c = 0, 2], (c, c + 2) for register bit 1 [c = 0, 1]
+            const int ku = rb == 0 ? 2 * c : c, kv = rb == 0 ? 2 * c + 1 : c + 2;
+            const int m = rb == 0 ? low : (low | (c << (s >= 1 ? s - 1 : 0)));  // index bits below s: lane part, plus register bit 0 in odd stages
+            const int q = m << (7 - s);
+            const int32_t fa = T.a[SplTwiddles::slot(q)], fb = T.b[SplTwiddles::slot(q)];
+            const int32_t wa = INVERSE ? (int32_t)__builtin_amdgcn_alignbit((uint32_t)fb, (uint32_t)fb, 16) : fa;
+            const int32_t wb = INVERSE ? (int32_t)__builtin_amdgcn_alignbit((uint32_t)fa, (uint32_t)fa, 16) : fb;
+            const int32_t u = x[ku], v = x[kv];
+            const int32_t tr = dot2_i16(v, wa, 1) >> 1, ti = dot2_i16(v, wb, 1) >> 1;
+            const int32_t qr = (int32_t)((uint32_t)u << 16) >> 2, qi = (int32_t)((uint32_t)u & 0xffff0000u) >> 2;  // re << 14, im << 14
+            const int sh = shift + 14;
+            x[kv] = (int32_t)__builtin_amdgcn_perm((uint32_t)((qi - ti + round2) >> sh), (uint32_t)((qr - tr + round2) >> sh), 0x05040100u);
+            x[ku] = (int32_t)__builtin_amdgcn_perm((uint32_t)((qi + ti + round2) >> sh), (uint32_t)((qr + tr + round2) >> sh), 0x05040100u);
+        }
+        if (INVERSE && s < 7) mag = pk_max_u16(pk_max_u16(pk_abs16(x[0]), pk_abs16(x[1])), pk_max_u16(pk_abs16(x[2]), pk_abs16(x[3])));
+        if constexpr (rb == 1 && s < 7) {
+            // register bit 0 <-> lane bit s - 1, register bit 1 <-> lane bit s
+            spl_xchg<s - 1>(x[0], x[1], lane);
+            spl_xchg<s - 1>(x[2], x[3], lane);
+            spl_xchg<s>(x[0], x[2], lane);
+            spl_xchg<s>(x[1], x[3], lane);
+        }
+    };
+    stage(std::integral_constant<int, 0>{});
+    stage(std::integral_constant<int, 1>{});
+    stage(std::integral_constant<int, 2>{});
+    stage(std::integral_constant<int, 3>{});
+    stage(std::integral_constant<int, 4>{});
+    stage(std::integral_constant<int, 5>{});
+    stage(std::integral_constant<int, 6>{});
+    stage(std::integral_constant<int, 7>{});
+    wave_sync();  // every lane's read of the input precedes the stores below (also in the compiler's eyes)
+#pragma unroll
+    for (int k = 0; k < 4; k++) cx[lane + 64 * k] = x[k];
+    wave_sync();
+    return scale;
+}
+
 template <int STAGES>
 __device__ __forceinline__ int bitrev(int i) { return (int)(__brev((unsigned)i) >> (32 - STAGES)); }
 
