@@ -278,8 +278,38 @@ __global__ __launch_bounds__(64) void aecm_far_kernel(AecmFarBufs F_all, const A
 // ---------------------------------------------------------------- one 64-sample block of one stream (ProcessBlock)
 // t_prev / t_new: sample `lane` of the previous and of the new near-end block on entry; on return t_prev is the new block's
 // sample (dBufNoisy slides) and t_new the block's output sample.
+#ifdef WMX_AECM_PROF  // developer build only (make EXTRA=-DWMX_AECM_PROF): cycles per phase of aecm_block, summed over waves
+__device__ unsigned long long g_aecm_prof[1024 * 16];
+#define AECM_PROF(i)                                          \
+    do {                                                      \
+        const long long t_now = clock64();                    \
+        prof_acc[i] += (unsigned long long)(t_now - prof_t0); \
+        prof_t0 = clock64();                                  \
+    } while (0)
+extern "C" int wmx_debug_aecm_prof(unsigned long long *out16, int reset) {
+    (void)hipDeviceSynchronize();
+    static unsigned long long all[1024 * 16];
+    (void)hipMemcpyFromSymbol(all, HIP_SYMBOL(g_aecm_prof), sizeof(all));
+    for (int i = 0; i < 16; i++) {
+        out16[i] = 0;
+        for (int g = 0; g < 1024; g++) out16[i] += all[g * 16 + i];
+    }
+    if (reset) {
+        static const unsigned long long z[1024 * 16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_aecm_prof), z, sizeof(z));
+    }
+    return 0;
+}
+#else
+#define AECM_PROF(i)
+#endif
+
 __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &F, const LdsScal sc, int t, int mult, int lane,
                            int16_t &t_prev, int16_t &t_new) {
+#ifdef WMX_AECM_PROF
+    unsigned long long prof_acc[16] = {0};
+    long long prof_t0 = clock64();
+#endif
     int16_t *ch_stored = reinterpret_cast<int16_t *>(&W.st[A_CH_STORED]), *ch_adapt16 = reinterpret_cast<int16_t *>(&W.st[A_CH_ADAPT16]);
     int16_t *near_filt = reinterpret_cast<int16_t *>(&W.st[A_NEAR_FILT]);
     int16_t *noise_lo = reinterpret_cast<int16_t *>(&W.st[A_NOISE_LO]), *noise_hi = reinterpret_cast<int16_t *>(&W.st[A_NOISE_HI]);
@@ -296,6 +326,7 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
     const int dfa_q_old = sc[M_DFA_Q];
     sc[M_DFA_Q] = zeros_d;
 
+    AECM_PROF(0);
     // delay estimate: BinarySpectrumFix + WebRtc_ProcessBinarySpectrum (robust validation off)
     int delay;
     {
@@ -338,12 +369,14 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
         delay = sc[M_LAST_DELAY];
         if (delay < 0) delay = 0;  // -2: no estimate yet (aecm_core_c.c:397-400); -1 cannot reach here
     }
+    AECM_PROF(1);
     // aligned far spectrum (WebRtcAecm_AlignedFarend): the block `delay` blocks ago
     const int slot = (t - delay) & (kAecmHist - 1);
     const int zeros_x = F.hist_q[slot];
     for (int b = lane; b < 65; b += 64) W.xfa[b] = F.hist[slot * kAecmBP + b];
     wave_sync();
 
+    AECM_PROF(2);
     // ---- CalcEnergies, aecm_core.c:730-851
     const int head = (sc[M_LOG_HEAD] - 1) & 63;  // the three log histories shift by one: move the ring head instead
     sc[M_LOG_HEAD] = head;
@@ -409,6 +442,7 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
     }
     wave_sync();
 
+    AECM_PROF(3);
     // ---- CalcStepSize, aecm_core.c:858-891
     int16_t mu = 1;
     if (!sc[M_CUR_VAD]) {
@@ -424,6 +458,7 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
     }
     sc[M_TOT_COUNT] = (int32_t)((uint32_t)sc[M_TOT_COUNT] + 1);
 
+    AECM_PROF(4);
     // ---- UpdateChannel, aecm_core.c:902-1109
     if (mu) {
         for (int b = lane; b < 65; b += 64) {
@@ -523,6 +558,7 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
         }
     }
 
+    AECM_PROF(5);
     // ---- CalcSuppressionGain, aecm_core.c:1118-1185
     int16_t sup_gain;
     {
@@ -549,6 +585,7 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
     }
     wave_sync();
 
+    AECM_PROF(6);
     // ---- Wiener filter coefficients, aecm_core_c.c:434-545
     int pos_count = 0;
     for (int b = lane; b < 65; b += 64) {
@@ -634,6 +671,7 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
         W.dfw[b] = pack16((int16_t)((lo16(x) * h + 8192) >> 14), (int16_t)((hi16(x) * h + 8192) >> 14));
     }
 
+    AECM_PROF(7);
     // ---- ComfortNoise, aecm_core_c.c:641-771 (cngMode is AecmTrue, echo_control_mobile.c:223)
     {
         const int16_t shift = (int16_t)(15 - zeros_d);
@@ -704,6 +742,7 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
     }
     wave_sync();
 
+    AECM_PROF(8);
     // ---- InverseFFTAndWindow, aecm_core_c.c:98-169
     for (int b = lane; b < 65; b += 64) {
         const int32_t e = W.dfw[b];
@@ -725,6 +764,15 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
         t_new = o;       // the block's output, picked up by the caller
     }
     wave_sync();
+    AECM_PROF(9);
+#ifdef WMX_AECM_PROF
+    if (lane < 16) {  // racy read-modify-write among the waves that share a slot: good enough for a profile
+        unsigned long long v = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) v = lane == i ? prof_acc[i] : v;
+        g_aecm_prof[(blockIdx.x & 1023) * 16 + lane] += v;
+    }
+#endif
 }
 
 // One wave per stream, kAecmWavesPerBlock streams per workgroup.

@@ -48,6 +48,8 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
     return (r0 + r1) + (r2 + r3);
 }
+// true in every lane if the predicate holds in any lane (all 64 lanes on)
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 __device__ __forceinline__ int32_t wave_max(int32_t v) {
     WMX_ROW_REDUCE(v, WMX_OP_MAX);
     const int32_t r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
@@ -181,11 +183,12 @@ __device__ int spl_cfft(int32_t *cx, const SplTwiddles &T, int lane) {
         int shift = INVERSE ? 0 : 1;
         int32_t round2 = INVERSE ? 8192 : 16384;
         if (INVERSE) {
-            uint32_t m16 = (mag & 0xffffu) > (mag >> 16) ? (mag & 0xffffu) : (mag >> 16);
-            int32_t mx = wave_max((int32_t)m16);
-            if (mx > 32767) mx = 32767;
-            if (mx > 13573) shift++, scale++, round2 <<= 1;
-            if (mx > 27146) shift++, scale++, round2 <<= 1;
+            // the two thresholds on the largest |value| of the array (complex_fft.c:170-186; its cap at 32767 lies above both):
+            // "any lane above" is two compares into lane masks -- the wave-wide maximum itself (a dependent chain of four DPP
+            // steps, four v_readlane and scalar maxima, once per stage) is never needed
+            const uint32_t m16 = (mag & 0xffffu) > (mag >> 16) ? (mag & 0xffffu) : (mag >> 16);
+            if (wave_any(m16 > 13573u)) shift++, scale++, round2 <<= 1;
+            if (wave_any(m16 > 27146u)) shift++, scale++, round2 <<= 1;
             mag = 0;
         }
 #pragma unroll
@@ -259,11 +262,12 @@ __device__ int spl_cfft128(int32_t *cx, const SplTwiddles &T, int lane) {
         int shift = INVERSE ? 0 : 1;
         int32_t round2 = INVERSE ? 8192 : 16384;
         if (INVERSE) {
-            uint32_t m16 = (mag & 0xffffu) > (mag >> 16) ? (mag & 0xffffu) : (mag >> 16);
-            int32_t mx = wave_max((int32_t)m16);
-            if (mx > 32767) mx = 32767;
-            if (mx > 13573) shift++, scale++, round2 <<= 1;
-            if (mx > 27146) shift++, scale++, round2 <<= 1;
+            // the two thresholds on the largest |value| of the array (complex_fft.c:170-186; its cap at 32767 lies above both):
+            // "any lane above" is two compares into lane masks -- the wave-wide maximum itself (a dependent chain of four DPP
+            // steps, four v_readlane and scalar maxima, once per stage) is never needed
+            const uint32_t m16 = (mag & 0xffffu) > (mag >> 16) ? (mag & 0xffffu) : (mag >> 16);
+            if (wave_any(m16 > 13573u)) shift++, scale++, round2 <<= 1;
+            if (wave_any(m16 > 27146u)) shift++, scale++, round2 <<= 1;
         }
         const int q = (lane & (l - 1)) << (7 - s);
         const int32_t fa = T.a[SplTwiddles::slot(q)], fb = T.b[SplTwiddles::slot(q)];
@@ -316,11 +320,12 @@ __device__ int spl_cfft256(int32_t *cx, const SplTwiddles &T, int lane) {
         int shift = INVERSE ? 0 : 1;
         int32_t round2 = INVERSE ? 8192 : 16384;
         if (INVERSE) {
-            uint32_t m16 = (mag & 0xffffu) > (mag >> 16) ? (mag & 0xffffu) : (mag >> 16);
-            int32_t mx = wave_max((int32_t)m16);
-            if (mx > 32767) mx = 32767;
-            if (mx > 13573) shift++, scale++, round2 <<= 1;
-            if (mx > 27146) shift++, scale++, round2 <<= 1;
+            // the two thresholds on the largest |value| of the array (complex_fft.c:170-186; its cap at 32767 lies above both):
+            // "any lane above" is two compares into lane masks -- the wave-wide maximum itself (a dependent chain of four DPP
+            // steps, four v_readlane and scalar maxima, once per stage) is never needed
+            const uint32_t m16 = (mag & 0xffffu) > (mag >> 16) ? (mag & 0xffffu) : (mag >> 16);
+            if (wave_any(m16 > 13573u)) shift++, scale++, round2 <<= 1;
+            if (wave_any(m16 > 27146u)) shift++, scale++, round2 <<= 1;
             mag = 0;
         }
         const int low = lane & ((1 << (s - rb)) - 1);
