@@ -10,11 +10,11 @@ lib=_lib.lib(); f=lib.wmx_debug_aec_prof; f.argtypes=[ctypes.c_void_p,ctypes.c_i
 ab=AecBatch(S,1,16000,10); nf=24
 far=synth.far_end(5,nf,160); near=synth.near_end(50,64,nf,160,far=far)
 dfar=torch.from_numpy(far.reshape(nf,160).copy()).to(dev)
-dn=torch.from_numpy(near.reshape(64,nf,160).copy()).to(dev).repeat(S//64,1,1).contiguous()
+dn=torch.from_numpy(np.ascontiguousarray(near.reshape(64,nf,160).transpose(1,0,2))).to(dev).repeat(1,S//64,1).contiguous()  # [packet][stream][160], as bench.py lays a batch out
 buf=(ctypes.c_ulonglong*16)()
 for k in range(nf):
     if k==16: f(buf,1)
-    ab.process2(dfar[k:k+1],dn[:,k:k+1]); 
+    ab.process2_packet_major(dfar[k:k+1],dn[k:k+1])
 f(buf,0); v=np.array(buf[:16],dtype=np.float64)
 names=['near ring+d,dw fft','dpow+filterfar','y ifft+e,ew fft','scale+adapt','partdelay','xfw+psd','sd/se sums','coh+hNl+scalars','overdrive+cn','ifft+ola','state in','(all pkts)','state out','scale_err','pack','24 ffts']
 tot=v[10]+v[12]+v[11]
