@@ -357,7 +357,7 @@ __global__ __launch_bounds__(64) void agc_kernel(int16_t *s16, int32_t *s32, con
 // stream as agc_kernel, which stays for more than two channels and unaligned rows.  CHN = 2: the interleaved pair is averaged
 // on the way in and the result written to both channels (src/webrtc.c:789-815), like agc_packet's load / store.
 template <int L, int CHN>
-__global__ __launch_bounds__(256) void agc_pipe_kernel(int16_t *s16, int32_t *s32, const int32_t *gain_table_g, const int16_t *in,
+__global__ __launch_bounds__(256, CHN == 1 ? 4 : 2) void agc_pipe_kernel(int16_t *s16, int32_t *s32, const int32_t *gain_table_g, const int16_t *in,
                                                        int16_t *out, int n_streams, int n_packets, long stream_stride,
                                                        long packet_stride, const uint8_t *__restrict__ active) {
     constexpr int L2 = (L == 8) ? 3 : 4, VPS = L * CHN / 8;  // uint4 per sub-frame
@@ -402,30 +402,33 @@ __global__ __launch_bounds__(256) void agc_pipe_kernel(int16_t *s16, int32_t *s3
         //      registers at a time (the next one requested while this one is reduced); pass 2 fetches them again from L2 --
         //      held across the barriers, the samples cost the registers that decide how many workgroups share a CU.
         if (nk) {
-            uint4 cur[VPS], nxt[VPS];
+            // all of the wave's sub-frames requested at once: with one in flight per wave (the next one requested while this
+            // one is reduced) a launch of 512 workgroups -- configs[4]'s 32 768 streams -- had too few bytes under way to
+            // reach the memory's rate
+            uint4 raw[4][VPS];
 #pragma unroll
-            for (int j = 0; j < VPS; j++) cur[j] = in4[k0 * VPS + j];
-#pragma unroll 1
-            for (int kk = 0; kk < nk; kk++) {
-                const int kn = kk + 1 < nk ? kk + 1 : kk;
+            for (int kk = 0; kk < 4; kk++)
+                if (kk < nk) {
 #pragma unroll
-                for (int j = 0; j < VPS; j++) nxt[j] = in4[(k0 + kn) * VPS + j];
-                int32_t mx = 0;
-#pragma unroll
-                for (int n = 0; n < L; n++) {
-                    const int32_t x = sample(cur, n);
-                    const int32_t e = x * x;
-                    if (e > mx) mx = e;
-                }
-                xenv[(k0 + kk) * 64 + lane] = mx;
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const int16_t d = L == 16 ? (int16_t)(((int32_t)sample(cur, 2 * j) + (int32_t)sample(cur, 2 * j + 1)) >> 1) : sample(cur, j);
-                    xdet[((k0 + kk) * 8 + j) * 64 + lane] = d;
+                    for (int j = 0; j < VPS; j++) raw[kk][j] = in4[(k0 + kk) * VPS + j];
                 }
 #pragma unroll
-                for (int j = 0; j < VPS; j++) cur[j] = nxt[j];
-            }
+            for (int kk = 0; kk < 4; kk++)
+                if (kk < nk) {
+                    int32_t mx = 0;
+#pragma unroll
+                    for (int n = 0; n < L; n++) {
+                        const int32_t x = sample(raw[kk], n);
+                        const int32_t e = x * x;
+                        if (e > mx) mx = e;
+                    }
+                    xenv[(k0 + kk) * 64 + lane] = mx;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int16_t d = L == 16 ? (int16_t)(((int32_t)sample(raw[kk], 2 * j) + (int32_t)sample(raw[kk], 2 * j + 1)) >> 1) : sample(raw[kk], j);
+                        xdet[((k0 + kk) * 8 + j) * 64 + lane] = d;
+                    }
+                }
         }
         __syncthreads();  // 1: peaks and detector input of the whole packet are in LDS
         if (wave == 3) {
@@ -457,36 +460,37 @@ __global__ __launch_bounds__(256) void agc_pipe_kernel(int16_t *s16, int32_t *s3
         __syncthreads();  // 2: the packet's gains are in LDS
         // ---- pass 2, this wave's share
         if (nk) {
-            uint4 cur[VPS], nxt[VPS];
+            uint4 raw[4][VPS];  // every load before the first store (in == out)
 #pragma unroll
-            for (int j = 0; j < VPS; j++) cur[j] = in4[k0 * VPS + j];
-#pragma unroll 1
-            for (int kk = 0; kk < nk; kk++) {
-                const int k = k0 + kk, kn = kk + 1 < nk ? kk + 1 : kk;
+            for (int kk = 0; kk < 4; kk++)
+                if (kk < nk) {
 #pragma unroll
-                for (int j = 0; j < VPS; j++) nxt[j] = in4[(k0 + kn) * VPS + j];  // before this sub-frame's stores (in == out)
-                const int32_t ga = xgain[k * 64 + lane], gb = xgain[(k + 1) * 64 + lane];
-                const int32_t delta = wshl(wsub(gb, ga), 4 - L2);
-                int32_t gain32 = wshl(ga, 4);
-                unsigned yw[L * CHN / 2];
-#pragma unroll
-                for (int n = 0; n < L; n++) {
-                    const int16_t y = agc_apply(sample(cur, n), gain32, k == 0);
-                    gain32 = wadd(gain32, delta);
-                    if (CHN == 2)
-                        yw[n] = (unsigned)(uint16_t)y | ((unsigned)(uint16_t)y << 16);
-                    else if (n & 1)
-                        yw[n >> 1] |= (unsigned)(uint16_t)y << 16;
-                    else
-                        yw[n >> 1] = (unsigned)(uint16_t)y;
-                }
-                if (live) {
-#pragma unroll
-                    for (int j = 0; j < VPS; j++) out4[k * VPS + j] = make_uint4(yw[4 * j], yw[4 * j + 1], yw[4 * j + 2], yw[4 * j + 3]);
+                    for (int j = 0; j < VPS; j++) raw[kk][j] = in4[(k0 + kk) * VPS + j];
                 }
 #pragma unroll
-                for (int j = 0; j < VPS; j++) cur[j] = nxt[j];
-            }
+            for (int kk = 0; kk < 4; kk++)
+                if (kk < nk) {
+                    const int k = k0 + kk;
+                    const int32_t ga = xgain[k * 64 + lane], gb = xgain[(k + 1) * 64 + lane];
+                    const int32_t delta = wshl(wsub(gb, ga), 4 - L2);
+                    int32_t gain32 = wshl(ga, 4);
+                    unsigned yw[L * CHN / 2];
+#pragma unroll
+                    for (int n = 0; n < L; n++) {
+                        const int16_t y = agc_apply(sample(raw[kk], n), gain32, k == 0);
+                        gain32 = wadd(gain32, delta);
+                        if (CHN == 2)
+                            yw[n] = (unsigned)(uint16_t)y | ((unsigned)(uint16_t)y << 16);
+                        else if (n & 1)
+                            yw[n >> 1] |= (unsigned)(uint16_t)y << 16;
+                        else
+                            yw[n >> 1] = (unsigned)(uint16_t)y;
+                    }
+                    if (live) {
+#pragma unroll
+                        for (int j = 0; j < VPS; j++) out4[k * VPS + j] = make_uint4(yw[4 * j], yw[4 * j + 1], yw[4 * j + 2], yw[4 * j + 3]);
+                    }
+                }
         }
         __syncthreads();  // 3: LDS may be overwritten by the next packet
     }
