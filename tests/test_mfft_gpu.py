@@ -102,9 +102,10 @@ def test_rejects_bad_sizes(wmx):
     assert wmx.wmx_mfft_stream(1, None, 16, None, 64, None, None, None) == -10001
 
 
-def test_reference_host_signatures(wmx, oracle_port):
-    """The legacy math/fft.h functions over host arrays (batch of one)."""
-    n = 256
+@pytest.mark.parametrize("n", [16, 64, 256, 4096])
+def test_reference_host_signatures(wmx, oracle_port, n):
+    """The legacy math/fft.h functions over host arrays (batch of one): the LDS kernel (16), several transforms per wave with
+    one of them real (64), one wave (256), four waves (4096)."""
     re, im = mfft_input(n, 99)
     f4 = lambda: np.zeros(n, np.float32)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
@@ -125,12 +126,13 @@ def test_reference_host_signatures(wmx, oracle_port):
     # fft_stream
     wmx.fft_stream.restype = None
     wmx.fft_stream.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p]
-    pool, af = np.zeros(512, np.float32), np.zeros(512, np.float32)
+    st_len = n if n >= 128 else 512
+    pool, af = np.zeros(st_len, np.float32), np.zeros(st_len, np.float32)
     chunks = mfft_input(64 * 5, 5)[0].reshape(5, 64)
     for ch in chunks:
         ch = np.ascontiguousarray(ch)
-        wmx.fft_stream(p(ch), 64, p(pool), 512, p(af), None)
-    want_pool, want_af, _ = loader.mfft_stream(oracle_port, chunks, 512, prefix="orc")
+        wmx.fft_stream(p(ch), 64, p(pool), st_len, p(af), None)
+    want_pool, want_af, _ = loader.mfft_stream(oracle_port, chunks, st_len, prefix="orc")
     assert same_bits(pool, want_pool) and same_bits(af, want_af[-1])
 
 
