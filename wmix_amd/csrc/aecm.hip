@@ -319,6 +319,14 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
     int32_t *mean_near = &W.st[A_MEAN_NEAR], *mean_bits = &W.st[A_MEAN_BITS];
     int16_t *out_buf = reinterpret_cast<int16_t *>(&W.st[A_OUT_BUF]);
 
+    // the far-end's binary spectra of the last kAecmMaxDelay blocks (global memory, L2): requested here, used by the delay
+    // estimator behind the near spectrum's transform instead of being waited for there
+    uint32_t far_bin[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int i = lane + 64 * r;
+        far_bin[r] = F.hist_bin[(t - (i < kAecmMaxDelay ? i : 0)) & (kAecmHist - 1)];  // binary_far_history[i] = the spectrum of i blocks ago
+    }
     if (sc[M_STARTUP] < 2) sc[M_STARTUP] = ((uint32_t)sc[M_TOT_COUNT] >= 512) + ((uint32_t)sc[M_TOT_COUNT] >= 1024);
     // near spectrum of [previous block | new block]
     uint32_t dfa_sum;
@@ -339,7 +347,7 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
         for (int r = 0; r < 2; r++) {
             const int i = lane + 64 * r;
             if (i < kAecmMaxDelay) {
-                const uint32_t fb = F.hist_bin[(t - i) & (kAecmHist - 1)];  // binary_far_history[i] = the spectrum of i blocks ago
+                const uint32_t fb = far_bin[r];
                 const int fbc = __popc(fb);
                 int32_t m = mean_bits[i];
                 if (fbc > 0) mean_estimator(__popc(near_bin ^ fb) << 9, 13 - ((3 * fbc) >> 4), m);
