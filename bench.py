@@ -578,7 +578,7 @@ class ChainWorkload:
     freq, pkt = 16000, 160
     with_agc_vad = True
 
-    def __init__(self, dev, n_streams, rank, dist=None, packets=1):
+    def __init__(self, dev, n_streams, rank, dist=None, packets=1, interval_ms=10, cohorts=1, cohort_layout="arrival"):
         from wmix_amd import synth
         from wmix_amd.chain import AEC, AGC, NS, VAD, ChainBatch
         global broadcast_far
@@ -606,9 +606,20 @@ class ChainWorkload:
         # itself hands the AEC a far-end that is 400 ms old, src/wmix.c:651-657: it is known long before it is needed)
         self.far = [torch.zeros(self.P, self.pkt, dtype=torch.int16, device=dev) for _ in range(2)]
         self.far_work = [None, None]
-        self.work = torch.empty_like(self.inp[0:self.P])
+        # interval_ms = 20 is the daemon's own cadence (WMIX_INTERVAL_MS, src/wmixConf.h:112: what it hands aec_init / agc_init /
+        # vad_init, src/wmix.c:636, 684, 703): VAD packets of 20 ms, AEC packets of 20 ms at 8 kHz.  Such a packet must lie in
+        # one piece, so the batch is tick-major then -- [tick][stream][P packets] -- instead of packet-major.
+        self.interval_ms = interval_ms
+        self.tick_major = interval_ms == 20
+        if self.tick_major:
+            assert self.P % 2 == 0, "--interval-ms 20 needs an even --packets-per-step (20 ms packets)"
+            K, S, P = self.K, n_streams, self.P
+            self.inp = self.inp.view(K // P, P, S, self.pkt).permute(0, 2, 1, 3).contiguous()  # [K / P, S, P, pkt]
+            self.work = torch.empty_like(self.inp[0])
+        else:
+            self.work = torch.empty_like(self.inp[0:self.P])
         # the four stages behind ONE C call per step (wmx_chain_process, the heartbeat of src/wmix.c:613-709)
-        self.chain = ChainBatch(n_streams, 1, self.freq, 10, 5,  # volumeAgc default 5, src/wmix.c:1596
+        self.chain = ChainBatch(n_streams, 1, self.freq, interval_ms, 5,  # volumeAgc default 5, src/wmix.c:1596
                                 (NS | AEC | AGC | VAD) if self.with_agc_vad else (NS | AEC))
         self.rank = rank
         self.t = _StageTimer("aec")
@@ -616,6 +627,38 @@ class ChainWorkload:
         self.near_ms, self.far_ms, self.aec_launches = 0.0, 0.0, 0
         self.sample = [int(i) for i in np.linspace(0, n_streams - 1, 16)]
         self.rec = []
+        # --cohorts N: the streams are N groups of handles created at N distinct ticks (the reference makes a handle inside the
+        # heartbeat on first use, src/wmix.c:617-618, 635-636): group j joins at step j -- wmx_chain_add_cohort (aec_init of the
+        # shared part: a control plane and a far-end history of its own from that tick on), *_init of its members in every stage,
+        # and the active mask grows.  "arrival": a group's streams are neighbours (slots handed out in arrival order);
+        # "interleaved": stream s belongs to group s % N (slots scattered by churn: the streams of a workgroup hear different
+        # cohorts' far-end histories).
+        self.n_cohorts, self.cohort_layout = int(cohorts), cohort_layout
+        assert 1 <= self.n_cohorts <= n_streams
+        if self.n_cohorts > 1:
+            sidx = np.arange(n_streams)
+            self.join_of = (sidx % self.n_cohorts) if cohort_layout == "interleaved" else (sidx * self.n_cohorts // n_streams)
+            self.members = [np.flatnonzero(self.join_of == j).astype(np.int32) for j in range(self.n_cohorts)]
+            self.active = np.zeros(n_streams, np.uint8)
+            self.host_ctl_s = 0.0
+        else:
+            self.join_of = np.zeros(n_streams, np.int64)
+
+    def min_prime(self):
+        """untimed steps needed before every stream has joined and is past the start-up phases"""
+        return self.n_cohorts - 1
+
+    def _join(self, j):
+        """group j's handles are created in front of step j"""
+        if j == 0:
+            c = 0  # the cohort the chain was created with
+            self.chain.reset_cohort(0)
+        else:
+            c = self.chain.add_cohort()
+        assert c == j
+        self.chain.reset_streams(self.members[j], cohort=c)
+        self.active[self.members[j]] = 1
+        self.chain.set_active(None if j == self.n_cohorts - 1 else self.active)
 
     def _far_for(self, step_index):
         """The far-end packets of a step.  One GPU: read where they lie.  Several: rank 0's packets arrive through the
@@ -644,9 +687,13 @@ class ChainWorkload:
         """Inside the timed region the library itself records HIP events around the AEC's kernels, on the launch stream
         (wmx_aec_set_timing): the dominant kernel's own duration, far kernel excluded."""
         self.chain.set_aec_timing(on)
-        if not on:
+        if on:
+            self.chain.aec_host_ctl()  # start over
+        else:
             n, f, r = self.chain.aec_timing()
             self.aec_launches, self.far_ms, self.near_ms = self.aec_launches + n, self.far_ms + f, self.near_ms + r
+            nl, sec = self.chain.aec_host_ctl()
+            self.host_ctl_us = sec / nl * 1e6 if nl else None
 
     def step(self, timed):
         P = self.P
@@ -654,15 +701,26 @@ class ChainWorkload:
         step_index = self.k
         self.k += 1
         far = self._far_for(step_index)
-        if timed == "all":
+        if step_index < self.n_cohorts and self.n_cohorts > 1:
+            self._join(step_index)
+        if self.tick_major:
+            src = self.inp[k // P]
+            if timed == "all":
+                for name, fn in self.chain.stage_calls_stream_major(far, src, self.work):
+                    self.t.run(name, timed, fn)
+            else:
+                rc, _, _ = self.chain.process(far, src, out=self.work)
+                assert rc == 0
+        elif timed == "all":
             for name, fn in self.chain.stage_calls_packet_major(far, self.inp[k:k + P], self.work):
                 self.t.run(name, timed, fn)
         else:
             rc, _, _ = self.chain.process_packet_major(far, self.inp[k:k + P], out=self.work)
             assert rc == 0
         if timed is not True:
-            # outside the timed region: keep what the sampled streams produced, for parity_check()
-            self.rec.append((step_index, self.work[:, self.sample].clone()))
+            # outside the timed region: keep what the sampled streams produced ([P, 16, pkt]), for parity_check()
+            got = self.work[self.sample].transpose(0, 1) if self.tick_major else self.work[:, self.sample]
+            self.rec.append((step_index, got.clone()))
 
     def dominant_ms(self):
         return self.near_ms / self.aec_launches if self.aec_launches else None
@@ -681,22 +739,32 @@ class ChainWorkload:
         from oracle import loader
         port = loader.port()
         T, P = self.k, self.P
-        far = np.concatenate([self.far_host[(k * P + p) % self.K] for k in range(T) for p in range(P)])
         stages = 15 if self.with_agc_vad else 3
         worst, n, n_off = 0, 0, 0
         for col, s in enumerate(self.sample):
-            near = np.concatenate([self.base[s % 256, (k * P + p) % self.K] for k in range(T) for p in range(P)])
+            t0 = int(self.join_of[s])  # the step in front of which this stream's handles were created (0 without --cohorts)
+            far = np.concatenate([self.far_host[(k * P + p) % self.K] for k in range(t0, T) for p in range(P)])
+            near = np.concatenate([self.base[s % 256, (k * P + p) % self.K] for k in range(t0, T) for p in range(P)])
             # one oracle call per step of P packets, like wmx_chain_process: ns / aec / agc loop over the packets of a call, vad_process
             # analyses and attenuates the call's FIRST packet only -- the daemon's own 20 ms call is P = 2
-            want = loader.run_chain(port, 1, self.freq, 5, stages, far, near, self.pkt * P, prefix="orc").reshape(T, P, self.pkt)
+            want = loader.run_chain(port, 1, self.freq, 5, stages, far, near, self.pkt * P, prefix="orc",
+                                    interval_ms=self.interval_ms).reshape(T - t0, P, self.pkt)
             for k, got in self.rec:
-                d = np.abs(got[:, col].cpu().numpy().astype(np.int32) - want[k].astype(np.int32))
+                if k < t0:
+                    continue
+                d = np.abs(got[:, col].cpu().numpy().astype(np.int32) - want[k - t0].astype(np.int32))
                 worst, n, n_off = max(worst, int(d.max())), n + P, n_off + int((d > 0).sum())
         return {"streams": len(self.sample), "packets_compared": n, "max_lsb": worst, "samples_off_by_one": n_off,
-                "oracle": "oracle/orc_*.c chain (port)", "steps_replayed": T}
+                "oracle": "oracle/orc_*.c chain (port), one run per sampled stream started at the stream's own join step",
+                "steps_replayed": T}
 
     def config(self):
         return {"workload": self.name, "streams_per_gpu": self.n_streams, "packets_per_stream_per_step": self.P,
+                "interval_ms": self.interval_ms,
+                "cohorts": self.n_cohorts,
+                "aec_host_control_plane_us_per_launch": getattr(self, "host_ctl_us", None),
+                "cohort_layout": (self.cohort_layout if self.n_cohorts > 1 else None),
+                "layout": "tick-major [tick][stream][P x 10 ms]" if self.tick_major else "packet-major [packet][stream]",
                 "frame": "%d x int16 (10 ms @ %d kHz mono)" % (self.pkt, self.freq // 1000),
                 "input": "SURVEY 8d recipe: far = LCG noise A=8000; near = far delayed 40 / 2 + noise A=200 + 3000 sin(0.01 t) gated "
                          "every 100 frames; 256 distinct streams x %d packets, tiled" % self.K,
@@ -945,6 +1013,16 @@ def main():
     ap.add_argument("--packets-per-step", type=int, default=1, choices=[1, 2, 4, 8],
                     help="chain workload: 10 ms packets per stream per step / launch (default 1; the daemon itself hands the "
                          "chain 20 ms = 2 packets per call at 16 kHz, src/wmix.c:613-709)")
+    ap.add_argument("--interval-ms", type=int, default=10, choices=[10, 20],
+                    help="chain workloads: the interval the handles are created with (aec_init / agc_init / vad_init).  20 is the "
+                         "daemon's own WMIX_INTERVAL_MS (src/wmixConf.h:112): 20 ms VAD packets, 20 ms AEC packets at 8 kHz; needs an "
+                         "even --packets-per-step (the daemon's heartbeat is 2)")
+    ap.add_argument("--cohorts", type=int, default=1,
+                    help="chain workloads: the streams are N groups of handles created at N distinct ticks (group j joins in front of "
+                         "step j: a control plane and a far-end history of its own, wmx_chain_add_cohort); the priming grows to N + "
+                         "--prime steps")
+    ap.add_argument("--cohort-layout", default="arrival", choices=["arrival", "interleaved"],
+                    help="which streams join together: neighbours (slots handed out in arrival order) or stream s in group s %% N")
     ap.add_argument("--spinup", type=int, default=64,
                     help="untimed steps queued directly in front of the timed ones, with no synchronisation in between: the timed "
                          "region starts on a busy device at its working clock (a 20-step region then reads like a 1000-step one)")
@@ -993,7 +1071,9 @@ def main():
         from wmix_amd import _lib
         _lib.lib()  # no fallback: raises when the HIP library is missing
 
-    if issubclass(cls, (ChainWorkload, StubCpuWorkload, AecmWorkload)):
+    if issubclass(cls, ChainWorkload):
+        wl = cls(dev, args.streams or default_streams, rank, dist, args.packets_per_step, args.interval_ms, args.cohorts, args.cohort_layout)
+    elif issubclass(cls, (StubCpuWorkload, AecmWorkload)):
         wl = cls(dev, args.streams or default_streams, rank, dist, args.packets_per_step)
     else:
         wl = cls(dev, args.streams or default_streams, rank)
@@ -1006,7 +1086,8 @@ def main():
         if on_gpu:
             torch.cuda.synchronize()
 
-    for _ in range(args.prime + args.warmup):
+    n_prime = args.prime + (wl.min_prime() if hasattr(wl, "min_prime") else 0)
+    for _ in range(n_prime + args.warmup):
         wl.step(False)
     sync_all()
     # The launch loop is Python: a generation-2 pass of its garbage collector stops the host for ~36 ms (seen at a fixed
@@ -1086,7 +1167,7 @@ def main():
                      "queued in front; barrier + synchronize on both sides of spin-up + region" % args.spinup) if on_gpu else "host clock",
         "host_wall_ms_per_step": host_elapsed / args.steps * 1e3,
         "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
-        "config": dict(wl.config(), primed_steps=args.prime), "roofline": roofline,
+        "config": dict(wl.config(), primed_steps=n_prime), "roofline": roofline,
         "stage_ms": wl.stage_ms() if hasattr(wl, "stage_ms") else None,
         "stage_ms_source": "mean over up to 16 extra steps after the timed region, outliers beyond 5x the median dropped (inside the timed region only the dominant kernel carries events)",
         "whole_step_hbm_frac": round(value / world * wl.bytes_per_frame / 1e9 / HBM_PEAK_GBS, 5),

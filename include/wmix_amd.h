@@ -221,6 +221,15 @@ int wmx_aec_export_state(const wmx_aec *h, int stream_index, float *host_words);
  * wmx_aec_cohorts(h) entries.  Returns 0, WMX_E*, or the first non-zero cohort code. */
 int wmx_aec_cohorts(const wmx_aec *h);
 int wmx_aec_reset_cohort(wmx_aec *h, int cohort, void *stream);
+/* Cohorts come and go with the handles they stand for (the reference makes a handle inside the heartbeat on first use and
+ * releases it when its switch drops or recording idles, src/wmix.c:565-600, 635-636): wmx_aec_add_cohort starts a NEW one --
+ * aec_init of the shared part at this point of the packet sequence; a retired id when there is one, else the next, with the
+ * device buffers growing by doubling -- and returns its id in *cohort; wmx_aec_retire_cohort says that every member was
+ * released: the cohort is never called again and its id may be handed out again.  wmx_aec_cohorts(h) = ids in use, retired
+ * ones included = the length of the per-cohort arrays.  Per launch only packets x cohorts plans of 224 bytes cross PCIe (a
+ * block's 64 comfort-noise phases travel as the generator's 4-byte state; the far kernel expands them). */
+int wmx_aec_add_cohort(wmx_aec *h, int *cohort, void *stream);
+int wmx_aec_retire_cohort(wmx_aec *h, int cohort);
 int wmx_aec_reset_streams(wmx_aec *h, const int32_t *idx, int n, int cohort, void *stream);
 int wmx_aec_set_active(wmx_aec *h, const uint8_t *host_mask, void *stream);
 int wmx_aec_stream_state_bytes(const wmx_aec *h);
@@ -238,6 +247,9 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
  * call and starts over. */
 int wmx_aec_set_timing(wmx_aec *h, int on);
 int wmx_aec_timing(wmx_aec *h, int *n_launches, double *far_ms, double *near_ms);
+/* Host side of the same launches: their number and the seconds the per-cohort control planes (index arithmetic, W:
+ * echo_cancellation.c:599-872 per cohort and packet) took on the caller's thread since the previous call. */
+int wmx_aec_host_ctl(wmx_aec *h, long *n_launches, double *seconds);
 
 /* ------------------------------------------------------------------ the record heartbeat: NS -> AEC -> AGC -> VAD in one call
  * wmix_shmem_write_circle (src/wmix.c:613-709) runs, per WMIX_INTERVAL_MS of captured audio and on one buffer in place,
@@ -264,6 +276,10 @@ int wmx_chain_process(wmx_chain *h, const int16_t *d_far, long far_packet_stride
                       int32_t *cohort_rc, void *stream);
 int wmx_chain_reset_streams(wmx_chain *h, const int32_t *idx, int n, int cohort, void *stream);
 int wmx_chain_reset_cohort(wmx_chain *h, int cohort, void *stream);
+/* wmx_aec_add_cohort / wmx_aec_retire_cohort / wmx_aec_cohorts of the chain's AEC (a chain without one has a single cohort) */
+int wmx_chain_add_cohort(wmx_chain *h, int *cohort, void *stream);
+int wmx_chain_retire_cohort(wmx_chain *h, int cohort);
+int wmx_chain_cohorts(const wmx_chain *h);
 int wmx_chain_set_active(wmx_chain *h, const uint8_t *host_mask, void *stream);
 int wmx_chain_stream_state_bytes(const wmx_chain *h);
 int wmx_chain_export_stream(wmx_chain *h, int stream_index, void *host_blob);

@@ -172,14 +172,16 @@ def run_aecm(lib, chn, freq, interval_ms, far, near, frames_per_call, delay_ms=0
     return out
 
 
-def run_chain(lib, chn, freq, agc_value, stages, far, near, frames_per_call, prefix="ref"):
-    """stages bitmask: 1 NS, 2 AEC, 4 AGC, 8 VAD (daemon order, src/wmix.c:613-709)."""
+def run_chain(lib, chn, freq, agc_value, stages, far, near, frames_per_call, prefix="ref", interval_ms=10):
+    """stages bitmask: 1 NS, 2 AEC, 4 AGC, 8 VAD (daemon order, src/wmix.c:613-709); interval_ms: what aec_init / agc_init /
+    vad_init are given (the daemon: WMIX_INTERVAL_MS = 20, src/wmixConf.h:112)."""
     far = np.ascontiguousarray(far, dtype=np.int16)
     near = np.ascontiguousarray(near, dtype=np.int16)
     out = np.empty_like(near)
     n_calls = near.size // (frames_per_call * chn)
-    fn = _fn(lib, prefix + "_run_chain", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint, _i16p, _i16p, _i16p, C.c_int, C.c_int])
-    rc = fn(chn, freq, agc_value, stages, far, near, out, frames_per_call, n_calls)
+    fn = _fn(lib, prefix + "_run_chain_iv", C.c_int,
+             [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, _i16p, _i16p, _i16p, C.c_int, C.c_int])
+    rc = fn(chn, freq, interval_ms, agc_value, stages, far, near, out, frames_per_call, n_calls)
     assert rc == 0, rc
     return out
 

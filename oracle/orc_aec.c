@@ -662,3 +662,31 @@ int orc_run_aec(int chn, int freq, int interval_ms, const int16_t *far, const in
     return rc;
 }
 
+
+/* State probe (SURVEY 8c "state probes for debugging"): the decisions of NonLinearProcessing and the scalars they are
+ * taken on (aec_core.c:911-1141), so that two runs can be compared decision by decision.
+ * ints: stNearState, echoState, divergeState, delayIdx, hNlNewMin, hNlMinCtr, noise_ctr, system_delay
+ * floats: hNlFbMin, hNlFbLocalMin, hNlXdAvgMin, overDrive, overDriveSm, sum(sd), sum(se) */
+void orc_aec_probe(const orc_aec *a, int32_t *ints8, float *floats7)
+{
+    ints8[0] = a->stNearState;
+    ints8[1] = a->echoState;
+    ints8[2] = a->divergeState;
+    ints8[3] = a->delayIdx;
+    ints8[4] = a->hNlNewMin;
+    ints8[5] = a->hNlMinCtr;
+    ints8[6] = a->noise_ctr;
+    ints8[7] = a->system_delay;
+    floats7[0] = a->hNlFbMin;
+    floats7[1] = a->hNlFbLocalMin;
+    floats7[2] = a->hNlXdAvgMin;
+    floats7[3] = a->overDrive;
+    floats7[4] = a->overDriveSm;
+    float sd = 0.f, se = 0.f;
+    for (int i = 0; i < 65; i++) {
+        sd += a->sd[i];
+        se += a->se[i];
+    }
+    floats7[5] = sd;
+    floats7[6] = se;
+}

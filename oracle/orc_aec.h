@@ -42,6 +42,7 @@ int orc_aec_process(orc_aec *a, const float *nearend, float *out, int n, int ms_
 orc_aec *orc_aec_init(int chn, int freq, int interval_ms);
 int orc_aec_process2(orc_aec *a, const int16_t *far, const int16_t *nearp, int16_t *out, int frame_num, int delay_ms);
 void orc_aec_release(orc_aec *a);
+void orc_aec_probe(const orc_aec *a, int32_t *ints8, float *floats7);
 int orc_run_aec(int chn, int freq, int interval_ms, const int16_t *far, const int16_t *nearp, int16_t *out, int frames_per_call,
                 int n_calls, int delay_ms);
 #endif

@@ -8,13 +8,14 @@
 #include "orc_ns.h"
 #include "orc_vad.h"
 
-int orc_run_chain(int chn, int freq, int agc_value, unsigned stages, const int16_t *far, const int16_t *nearp, int16_t *out,
-                  int frames_per_call, int n_calls)
+/* interval_ms: what the daemon hands aec_init / agc_init / vad_init (WMIX_INTERVAL_MS = 20, src/wmixConf.h:112, src/wmix.c:636,684,703) */
+int orc_run_chain_iv(int chn, int freq, int interval_ms, int agc_value, unsigned stages, const int16_t *far, const int16_t *nearp,
+                     int16_t *out, int frames_per_call, int n_calls)
 {
     orc_ns *ns = (stages & 1) ? orc_ns_init(chn, freq) : NULL;
-    orc_aec *aec = (stages & 2) ? orc_aec_init(chn, freq, 10) : NULL;
-    orc_agc *agc = (stages & 4) ? orc_agc_init(chn, freq, 10, agc_value) : NULL;
-    orc_vad *vad = (stages & 8) ? orc_vad_init(chn, freq, 10) : NULL;
+    orc_aec *aec = (stages & 2) ? orc_aec_init(chn, freq, interval_ms) : NULL;
+    orc_agc *agc = (stages & 4) ? orc_agc_init(chn, freq, interval_ms, agc_value) : NULL;
+    orc_vad *vad = (stages & 8) ? orc_vad_init(chn, freq, interval_ms) : NULL;
     size_t step = (size_t)frames_per_call * chn;
     int rc = 0;
     memcpy(out, nearp, step * n_calls * sizeof(int16_t));
@@ -30,4 +31,10 @@ int orc_run_chain(int chn, int freq, int agc_value, unsigned stages, const int16
     if (agc) orc_agc_release(agc);
     if (vad) orc_vad_release(vad);
     return rc;
+}
+
+int orc_run_chain(int chn, int freq, int agc_value, unsigned stages, const int16_t *far, const int16_t *nearp, int16_t *out,
+                  int frames_per_call, int n_calls)
+{
+    return orc_run_chain_iv(chn, freq, 10, agc_value, stages, far, nearp, out, frames_per_call, n_calls);
 }

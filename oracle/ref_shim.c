@@ -121,13 +121,13 @@ int ref_run_aecm(int chn, int freq, int interval_ms, const int16_t *far, const i
 }
 
 /* The daemon's record chain (src/wmix.c:613-709): NS -> AEC -> AGC -> VAD, all in place. */
-int ref_run_chain(int chn, int freq, int agc_value, unsigned stages, const int16_t *far, const int16_t *near,
-                  int16_t *out, int frames_per_call, int n_calls)
+int ref_run_chain_iv(int chn, int freq, int interval_ms, int agc_value, unsigned stages, const int16_t *far, const int16_t *near,
+                     int16_t *out, int frames_per_call, int n_calls)
 {
     void *ns = (stages & 1) ? ns_init(chn, freq, &g_dbg) : NULL;
-    void *aec = (stages & 2) ? aec_init(chn, freq, 10, &g_dbg) : NULL;
-    void *agc = (stages & 4) ? agc_init(chn, freq, 10, agc_value, &g_dbg) : NULL;
-    void *vad = (stages & 8) ? vad_init(chn, freq, 10, &g_dbg) : NULL;
+    void *aec = (stages & 2) ? aec_init(chn, freq, interval_ms, &g_dbg) : NULL;
+    void *agc = (stages & 4) ? agc_init(chn, freq, interval_ms, agc_value, &g_dbg) : NULL;
+    void *vad = (stages & 8) ? vad_init(chn, freq, interval_ms, &g_dbg) : NULL;
     size_t step = (size_t)frames_per_call * chn;
     int rc = 0;
     memcpy(out, near, step * n_calls * sizeof(int16_t));
@@ -143,4 +143,10 @@ int ref_run_chain(int chn, int freq, int agc_value, unsigned stages, const int16
     if (agc) agc_release(agc);
     if (vad) vad_release(vad);
     return rc;
+}
+
+int ref_run_chain(int chn, int freq, int agc_value, unsigned stages, const int16_t *far, const int16_t *near,
+                  int16_t *out, int frames_per_call, int n_calls)
+{
+    return ref_run_chain_iv(chn, freq, 10, agc_value, stages, far, near, out, frames_per_call, n_calls);
 }

@@ -77,3 +77,17 @@ def test_chain_against_real_reference_long(oracle_port, oracle_ref):
     a = L.run_chain(oracle_ref, 1, 16000, 5, 15, far, near, 160)
     b = L.run_chain(oracle_port, 1, 16000, 5, 15, far, near, 160, prefix="orc")
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("chn,freq", [(1, 16000), (1, 8000), (2, 16000), (2, 8000)])
+def test_chain_at_the_daemons_interval_against_real_reference(oracle_port, oracle_ref, chn, freq):
+    """The daemon hands WMIX_INTERVAL_MS = 20 to aec_init / agc_init / vad_init (src/wmixConf.h:112, src/wmix.c:636,684,703)
+    and calls the chain with 20 ms per heartbeat: VAD packets of 20 ms, AEC packets of 20 ms at 8 kHz."""
+    n_calls, per_call = 700, freq // 50  # frames per 20 ms heartbeat
+    far, near = aec_input(chn, freq, 20 if freq == 8000 else 10, n_calls * (2 if freq == 16000 else 1), seed=5200 + chn + freq // 8000)
+    a = L.run_chain(oracle_ref, chn, freq, 5, 15, far, near, per_call, interval_ms=20)
+    b = L.run_chain(oracle_port, chn, freq, 5, 15, far, near, per_call, prefix="orc", interval_ms=20)
+    assert a.size == n_calls * per_call * chn and np.array_equal(a, b)
+    # and the cadence matters: 10 ms handles fed the same audio give another result (the VAD packet differs)
+    c = L.run_chain(oracle_port, chn, freq, 5, 15, far, near, per_call, prefix="orc", interval_ms=10)
+    assert not np.array_equal(b, c)

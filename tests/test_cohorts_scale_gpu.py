@@ -1,0 +1,155 @@
+"""Cohorts at the scale north_star talks about: 65 536 streams whose handles are created at more than a thousand distinct,
+random ticks -- the reference makes every handle inside the heartbeat on first use and releases it when its switch drops or
+recording idles (src/wmix.c:565-600, 617-618, 635-636, 683-684, 702-703), each with its own control plane and far-end history
+(src/webrtc.c:217-274, 410-483; W:modules/audio_processing/aec/echo_cancellation.c:599-747).  Here a batch starts with one
+cohort and gains one per join tick (wmx_chain_add_cohort); early cohorts are retired when their members leave and their ids
+come back for later joins.  Sampled streams are compared with a per-handle oracle run started at the stream's own tick
+(round-3 VERDICT: the cohort machinery had been tested with 4 - 6 cohorts only)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import loader as L
+from test_aec_gpu import check_float_path
+from wmix_amd import synth
+from wmix_amd.chain import ChainBatch
+
+pytestmark = pytest.mark.gpu
+
+
+def _schedule(seed, S, T, n_join_ticks, n_leavers, t_leave, n_rejoin_ticks):
+    """join[s] = the tick in front of which stream s is created; `leavers` are released in front of tick t_leave (whole
+    cohorts: the earliest ones) and created again later, at one of n_rejoin_ticks ticks, in cohorts that reuse the retired ids."""
+    rng = np.random.default_rng(seed)
+    ticks = np.sort(rng.choice(np.arange(1, T - 320), n_join_ticks - 1, replace=False))
+    ticks = np.concatenate([[0], ticks])
+    join = ticks[rng.integers(0, n_join_ticks, S)]
+    join[rng.integers(0, S)] = 0
+    for t in ticks:  # every join tick has at least one stream
+        if not (join == t).any():
+            join[rng.integers(0, S)] = t
+    early = ticks[ticks < t_leave][:n_leavers]
+    leaving = np.isin(join, early)
+    rejoin_ticks = np.sort(rng.choice(np.arange(t_leave + 5, T - 320), n_rejoin_ticks, replace=False))
+    rejoin = np.where(leaving, rejoin_ticks[rng.integers(0, n_rejoin_ticks, S)], -1)
+    return join, leaving, early, rejoin
+
+
+def test_65536_streams_joining_at_more_than_1000_random_ticks(cuda, oracle_port):
+    S, T, K, U, freq = 65536, 1500, 200, 64, 16000
+    pkt = freq // 100
+    join, leaving, early, rejoin = _schedule(4242, S, T, n_join_ticks=1050, n_leavers=40, t_leave=500, n_rejoin_ticks=30)
+    assert len(np.unique(join)) >= 1000
+    far = synth.far_end(7100, K, pkt).reshape(K, pkt)
+    base = synth.near_end(7101, U, K, pkt, far=far.reshape(-1)).reshape(U, K, pkt)
+    inp = torch.from_numpy(np.ascontiguousarray(base.transpose(1, 0, 2))).to(cuda)[:, torch.arange(S, device=cuda) % U]  # [K, S, pkt]
+    dfar = torch.from_numpy(far.copy()).to(cuda)
+    work = torch.empty_like(inp[0:1])
+
+    # the streams checked against the oracle: first and last joiners, leavers that come back, and a random handful
+    rng = np.random.default_rng(99)
+    pick = {int(np.flatnonzero(join == 0)[0]), int(np.argmax(join)), int(np.flatnonzero(join == np.unique(join)[1])[0])}
+    pick |= {int(x) for x in rng.choice(np.flatnonzero(leaving), 5, replace=False)}
+    pick |= {int(x) for x in rng.choice(S, 14, replace=False)}
+    pick = sorted(pick)
+    dpick = torch.tensor(pick, device=cuda)
+    rec = torch.empty(T, len(pick), pkt, dtype=torch.int16, device=cuda)
+
+    cb = ChainBatch(S, 1, freq, 10, 5, n_cohorts=1)
+    active = np.zeros(S, np.uint8)
+    cohort_of_tick, reused, max_cohorts = {}, 0, 0
+    events = sorted(set(join.tolist()) | {int(t) for t in np.unique(rejoin[rejoin >= 0])} | {500})
+    by_tick = {t: np.flatnonzero(join == t).astype(np.int32) for t in np.unique(join)}
+    re_by_tick = {int(t): np.flatnonzero(rejoin == t).astype(np.int32) for t in np.unique(rejoin[rejoin >= 0])}
+    retired = []
+    for t in range(T):
+        if t in events:
+            if t == 500:  # the early cohorts' handles are released: members idle, cohorts retired
+                active[leaving] = 0
+                for te in early:
+                    cb.retire_cohort(cohort_of_tick[int(te)])
+                    retired.append(cohort_of_tick[int(te)])
+            for members in (by_tick.get(t), re_by_tick.get(t)):
+                if members is None or members.size == 0:
+                    continue
+                if t == 0:
+                    c = 0
+                    cb.reset_cohort(0)
+                else:
+                    c = cb.add_cohort()
+                if members is by_tick.get(t):
+                    cohort_of_tick[t] = c
+                reused += c in retired
+                cb.reset_streams(members, cohort=c)
+                active[members] = 1
+            cb.set_active(active)
+            max_cohorts = max(max_cohorts, cb.n_cohorts)
+        rc, codes, _ = cb.process_packet_major(dfar[t % K:t % K + 1], inp[t % K:t % K + 1], out=work)
+        assert rc == 0 and not codes.any()
+        rec[t] = work[0, dpick]
+    n_host, sec = cb.aec_host_ctl()
+    cb.close()
+    got = rec.cpu().numpy()
+    # retired ids came back: the batch never held more cohorts than join ticks, and re-joins reused ids
+    assert reused >= len(retired) and max_cohorts <= 1050, (reused, max_cohorts)
+    assert n_host == T and sec / T < 2e-3, "host control planes: %.1f us per tick" % (sec / T * 1e6)
+
+    far_seq = np.concatenate([far[t % K] for t in range(T)])
+    for col, s in enumerate(pick):
+        lives = [(int(join[s]), 500 if leaving[s] else T)]
+        if leaving[s]:
+            lives.append((int(rejoin[s]), T))
+        for a, b in lives:
+            near = np.concatenate([base[s % U, t % K] for t in range(a, b)])
+            want = L.run_chain(oracle_port, 1, freq, 5, 15, far_seq[a * pkt:b * pkt], near, pkt, prefix="orc").reshape(b - a, pkt)
+            check_float_path(got[a:b, col], want, max_fraction=1e-4)
+
+
+def test_cohort_ids_grow_and_come_back(cuda, oracle_port):
+    """wmx_aec_add_cohort past the capacity the batch was created with (device buffers double, running cohorts carry on
+    undisturbed), wmx_aec_retire_cohort, and the retired id handed out again with a fresh control plane."""
+    from wmix_amd.aec import AecBatch
+    S, T, freq, pkt = 12, 360, 16000, 160
+    far = synth.far_end(7300, T, pkt).reshape(T, pkt)
+    near = synth.near_end(7301, S, T, pkt, far=far.reshape(-1)).reshape(S, T, pkt)
+    ab = AecBatch(S, 1, freq, 10, n_cohorts=1)
+    d = torch.from_numpy(near.copy()).to(cuda)
+    dfar = torch.from_numpy(far.copy()).to(cuda)
+    # stream s joins at tick 20 s (cohort s); streams 3 and 4 leave at 230; stream 3's slot joins again at 280 in the retired id
+    active = np.zeros(S, np.uint8)
+    cohort = {}
+    life = {s: [(20 * s, T)] for s in range(S)}
+    life[3] = [(60, 230), (280, T)]
+    life[4] = [(80, 230)]
+    for t in range(T):
+        for s in range(S):
+            if t == 20 * s:
+                cohort[s] = 0 if s == 0 else ab.add_cohort()
+                if s == 0:
+                    ab.reset_cohort(0)
+                assert cohort[s] == s
+                ab.reset_streams([s], cohort=cohort[s])
+                active[s] = 1
+        if t == 230:
+            active[[3, 4]] = 0
+            ab.retire_cohort(cohort[3])
+            ab.retire_cohort(cohort[4])
+        if t == 280:
+            c = ab.add_cohort()
+            assert c == 3  # the lowest retired id
+            ab.reset_streams([3], cohort=c)
+            active[3] = 1
+        ab.set_active(active)
+        rc, codes = ab.run_cohorts(dfar[t:t + 1], d[:, t:t + 1], [0] * ab.n_far)
+        assert rc == 0 and not codes.any()
+    assert ab.n_far == S
+    got = d.cpu().numpy()
+    ab.close()
+    for s in range(S):
+        for a, b in life[s]:
+            want = L.run_aec(oracle_port, 1, freq, 10, far[a:b].reshape(-1), near[s, a:b].reshape(-1), pkt, 0, prefix="orc").reshape(b - a, pkt)
+            check_float_path(got[s, a:b], want, max_fraction=1e-4)
+        lived = np.zeros(T, bool)
+        for a, b in life[s]:
+            lived[a:b] = True
+        assert np.array_equal(got[s, ~lived], near[s, ~lived])  # nobody called the handle: rows untouched

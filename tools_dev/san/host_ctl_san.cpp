@@ -30,6 +30,7 @@ static long drive_aec(int freq, int pkg, int mode_delay) {
     AecCtl c;
     c.init(freq);
     long blocks = 0;
+    uint32_t lcg_expect = 777u;  // aec->seed, aec_core.c:1681
     for (int p = 0; p < 6000; p++) {
         AecPlan pl;
         std::memset(&pl, 0, sizeof(pl));
@@ -57,7 +58,10 @@ static long drive_aec(int freq, int pkg, int mode_delay) {
             const AecBlkPlan &b = pl.blk[k];
             CHECK(b.near_rd >= 0 && b.near_rd < kAecRing && b.out_wr >= 0 && b.out_wr < kAecRing);
             CHECK(b.far_slot >= 0 && b.far_slot < kAecFarBlocks && b.hist_n == blocks + k);
-            for (int i = 0; i < 64; i++) CHECK(b.ucos[i] >= -1.f && b.ucos[i] <= 1.f && b.usin[i] >= -1.f && b.usin[i] <= 1.f);
+            // the block carries the generator's state in front of its 64 draws: the reference's own recurrence, draw by draw
+            // (randomization_functions.c:87-112), must land on the next block's state -- which the control plane reaches in one jump
+            CHECK(b.seed == lcg_expect && b.seed <= 0x7FFFFFFFu);
+            for (int i = 0; i < 64; i++) lcg_expect = (lcg_expect * 69069u + 1u) & 0x7FFFFFFFu;
         }
         blocks += pl.n_blk;
     }
@@ -101,6 +105,26 @@ int main() {
             for (int md = 0; md < 4; md++) total += drive_aec(freq, freq / 1000 * ms, md) + drive_aecm(freq, freq / 1000 * ms, md);
         }
     CHECK(total > 100000);
+    {
+        // the comfort-noise phase table against the reference's per-draw expressions (aec_core.c:482-489) on generator states
+        std::vector<AecNoiseEntry> tab((size_t)kAecNoiseTab);
+        aec_noise_table(tab.data());
+        uint32_t seed = 777u;
+        for (int i = 0; i < 200000; i++) {
+            seed = (seed * 69069u + 1u) & 0x7FFFFFFFu;
+            const float r = ((float)(int16_t)(seed >> 16)) / 32768;
+            const float tmp = 6.28318530717959f * r;
+            CHECK((seed >> 16) < (uint32_t)kAecNoiseTab);
+            CHECK(tab[seed >> 16].c == cosf(tmp) && tab[seed >> 16].s == sinf(tmp));
+        }
+        // lane i of the far kernel reaches draw i + 1 in one step
+        for (int k = 1; k <= 64; k++) {
+            uint32_t a, c, s = 12345u, want = 12345u;
+            aec_lcg_jump(k, &a, &c);
+            for (int i = 0; i < k; i++) want = (want * 69069u + 1u) & 0x7FFFFFFFu;
+            CHECK(((s * a + c) & 0x7FFFFFFFu) == want);
+        }
+    }
     // ---- AGC gain table: every compression gain an uint8 agc_addition() can pass, limiter off (wmix) and on
     int ok = 0;
     for (int comp = 0; comp < 256; comp++)

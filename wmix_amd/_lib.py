@@ -4,7 +4,8 @@ import os
 import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libwmix_amd.so")
+# WMIX_AMD_LIB: another build of the same library (developer A/B runs of an experiment variant, tools_dev/); never a fallback
+LIB_PATH = os.path.abspath(os.environ["WMIX_AMD_LIB"]) if os.environ.get("WMIX_AMD_LIB") else os.path.join(HERE, "libwmix_amd.so")
 INCLUDE_DIR = os.path.join(os.path.dirname(HERE), "include")
 
 _lib = None
@@ -172,12 +173,24 @@ def _declare(L):
         f = getattr(L, "wmx_%s_import_cohort" % m)
         f.restype = i
         f.argtypes = [vp, i, vp]
+    for name in ("wmx_aec_add_cohort", "wmx_chain_add_cohort"):
+        f = getattr(L, name)
+        f.restype = i
+        f.argtypes = [vp, C.POINTER(i), vp]
+    for name in ("wmx_aec_retire_cohort", "wmx_chain_retire_cohort"):
+        f = getattr(L, name)
+        f.restype = i
+        f.argtypes = [vp, i]
+    L.wmx_chain_cohorts.restype = i
+    L.wmx_chain_cohorts.argtypes = [vp]
     L.wmx_aecm_create_cohorts.restype = i
     L.wmx_aecm_create_cohorts.argtypes = [C.POINTER(vp), i, i, i, i, i]
     L.wmx_aec_set_timing.restype = i
     L.wmx_aec_set_timing.argtypes = [vp, i]
     L.wmx_aec_timing.restype = i
     L.wmx_aec_timing.argtypes = [vp, C.POINTER(i), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.wmx_aec_host_ctl.restype = i
+    L.wmx_aec_host_ctl.argtypes = [vp, C.POINTER(C.c_long), C.POINTER(C.c_double)]
     L.wmx_chain_create.restype = i
     L.wmx_chain_create.argtypes = [C.POINTER(vp), i, i, i, i, i, C.c_uint, i]
     L.wmx_chain_destroy.restype = i

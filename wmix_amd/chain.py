@@ -64,24 +64,43 @@ class ChainBatch(Lifetime):
         check(lib().wmx_aec_timing(self.aec_handle(), C.byref(n), C.byref(f), C.byref(r)), "wmx_aec_timing")
         return n.value, f.value, r.value
 
+    def aec_host_ctl(self):
+        """(launches, seconds) the AEC's host control planes took on this thread since the last call (wmx_aec_host_ctl)."""
+        n, sec = C.c_long(0), C.c_double(0)
+        check(lib().wmx_aec_host_ctl(self.aec_handle(), C.byref(n), C.byref(sec)), "wmx_aec_host_ctl")
+        return n.value, sec.value
+
     def stage_calls_packet_major(self, far, pcm, out):
-        """The launches wmx_chain_process makes for a tick of 10 ms packets, one callable per stage, for callers that want an
-        event between the stages (bench.py's per-stage breakdown; interval_ms = 10 only).  Same handles, same state."""
+        """pcm / out [n10, n_streams, pkt] (see stage_calls)."""
+        return self.stage_calls(far, pcm, out, pcm.shape[0], pcm.stride(1), pcm.stride(0))
+
+    def stage_calls_stream_major(self, far, pcm, out):
+        """pcm / out [n_streams, n10, pkt]: a stream's tick in one piece (what 20 ms VAD / 8 kHz AEC packets need)."""
+        return self.stage_calls(far, pcm, out, pcm.shape[1], pcm.stride(0), pcm.stride(1))
+
+    def stage_calls(self, far, pcm, out, n10, ss, ps):
+        """The launches wmx_chain_process makes for a tick, one callable per stage, for callers that want an event between
+        the stages (bench.py's per-stage breakdown).  Same handles, same state, same packet arithmetic as chain.hip."""
         L, st = lib(), torch.cuda.current_stream().cuda_stream
-        n10, ss, ps = pcm.shape[0], pcm.stride(1), pcm.stride(0)
+        total = n10 * self.pkt
         calls, src = [], pcm
         if self.stages & NS:
             calls.append(("ns", lambda s=src: check(L.wmx_ns_process(L.wmx_chain_ns(self._h), s.data_ptr(), out.data_ptr(), n10, ss, ps, st))))
             src = out
         if self.stages & AEC:
-            calls.append(("aec", lambda s=src: check(L.wmx_aec_run(self.aec_handle(), 3, far.data_ptr(), far.stride(0), s.data_ptr(),
-                                                                   out.data_ptr(), n10, ss, ps, 0, st))))
+            per = L.wmx_aec_packet_samples(self.aec_handle()) // self.pkt  # 10 ms packets per AEC packet (2 at 8 kHz, interval 20)
+            calls.append(("aec", lambda s=src: check(L.wmx_aec_run(self.aec_handle(), 3, far.data_ptr(), far.stride(0) * per, s.data_ptr(),
+                                                                   out.data_ptr(), n10 // per, ss, ps * per, 0, st))))
             src = out
         if self.stages & AGC:
+            agc_pkg = L.wmx_agc_packet_samples(L.wmx_chain_agc(self._h))
+            assert agc_pkg == self.pkt, "5 ms AGC packets (32 kHz): use wmx_chain_process"
             calls.append(("agc", lambda s=src: check(L.wmx_agc_process(L.wmx_chain_agc(self._h), s.data_ptr(), out.data_ptr(), n10, ss, ps, st))))
             src = out
         if self.stages & VAD:
-            calls.append(("vad", lambda: check(L.wmx_vad_process(L.wmx_chain_vad(self._h), out.data_ptr(), n10, 1, ss, self.pkt, st))))
+            vad_pkg = L.wmx_vad_packet_samples(L.wmx_chain_vad(self._h))
+            calls.append(("vad", lambda: check(L.wmx_vad_process(L.wmx_chain_vad(self._h), out.data_ptr(), total // vad_pkg, 1, ss,
+                                                                 total if self.chn > 1 else vad_pkg, st))))
         return calls
 
     def close(self):

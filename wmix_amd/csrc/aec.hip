@@ -30,6 +30,7 @@
 // Float expressions, their order and the ordered sums follow the reference exactly (-ffp-contract=off); powf is the
 // table-driven double-precision evaluation of libm_dev.h, the rare log the library routine; cosf/sinf of the comfort
 // noise come from the host's libm through the plan.
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <vector>
@@ -101,6 +102,15 @@ struct AecConsts {  // copied to LDS by both kernels
     float hanning[BP], weight[BP], overdrive[BP];
 };
 constexpr int kAecConstWords = sizeof(AecConsts) / 4;
+// what the near kernel keeps in LDS of it: the transform tables and the window.  The two NLP curves (one read per bin and block
+// each) stay in global memory behind them (L1 / L2 hits): their 544 bytes per workgroup are what the conflict-free work-row
+// stride needs (AecWaveLds::fa)
+struct AecConstsNear {
+    FftTables tab;
+    float hanning[BP];
+};
+static_assert(offsetof(AecConsts, weight) == sizeof(AecConstsNear), "AecConstsNear is a prefix of AecConsts");
+constexpr int kAecConstNearWords = sizeof(AecConstsNear) / 4;
 
 // WEBRTC_SPL_SAT as the reference spells it: a NaN fails both comparisons and passes through (and the conversion to int16 behind
 // it makes it 0, on x86 as on gfx950).  NaNs do reach this in the reference's own runs (the AEC's first blocks), so the one-instruction
@@ -128,9 +138,15 @@ __device__ __forceinline__ void unpack_bin(const float *a, int b, float &re, flo
 // plan_by_value: a one-packet launch hands its plan over as a kernel argument; this kernel, which runs in front of the near
 // kernel in the same stream, stores it into plans[0] for both -- no host-to-device blit between the previous kernel of the
 // stream and this one (4.7 us per step of the chain).  Every far-end group stores the same bytes.
+// Plans lie [packet][cohort] (n_cohorts apart per packet: a launch uploads exactly packets x cohorts of them), and so do the
+// comfort-noise rows this kernel makes for the near kernel: noise[(packet * n_cohorts + cohort) * kAecNoiseRow + block * 128 + ...]
+// = the 64 cosines, then the 64 sines, of the block's phases (aec_core.c:482-489), looked up in the host-made table.
+constexpr int kAecNoiseRow = 4 * 2 * kAecPart;  // floats per (packet, cohort): up to 4 blocks x (64 cos | 64 sin)
 __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const float *__restrict__ consts_g, AecPlan *plans,
-                                                     int n_packets, const int16_t *far_pcm, long far_packet_stride, long far_group_stride,
-                                                     int chn, float gpow1np, int plan_by_value, const AecPlan plan_value) {
+                                                     int n_packets, int n_cohorts, const int16_t *far_pcm, long far_packet_stride,
+                                                     long far_group_stride, int chn, float gpow1np,
+                                                     const AecNoiseEntry *__restrict__ noise_tab, float *__restrict__ noise,
+                                                     int plan_by_value, const AecPlan plan_value) {
     __shared__ AecConsts K;
     __shared__ float fa[2][132];
     const int lane = threadIdx.x;
@@ -150,7 +166,14 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const flo
     }
     const AecFarBufs F = far_group(F_all, (int)blockIdx.x);
     if (far_pcm) far_pcm += (size_t)blockIdx.x * far_group_stride;
-    plans += (size_t)blockIdx.x * kAecMaxPktPerLaunch;  // every far-end group (control cohort) has its own plans
+    plans += blockIdx.x;  // every far-end group (control cohort) has its own plans: [packet][cohort]
+    noise += (size_t)blockIdx.x * kAecNoiseRow;
+    // lane i draws the (i + 1)-th number of a block: seed_i = seed * 69069^(i+1) + (1 + 69069 + ... + 69069^i), masked to 31 bits
+    uint32_t jump_a = 1u, jump_c = 0u;
+    for (int i = 0; i <= lane; i++) {
+        jump_c = jump_c * 69069u + 1u;
+        jump_a = jump_a * 69069u;
+    }
     {
         // one wave, one latency chain: every request of a group goes out before the first result is used
         float *dst = reinterpret_cast<float *>(&K);
@@ -164,7 +187,24 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const flo
     }
     wave_sync();
     for (int p = 0; p < n_packets; p++) {
-        const AecPlan &pl = plans[p];
+        const AecPlan &pl = plans[(size_t)p * n_cohorts];
+        if (pl.has_near && !pl.passthrough) {
+            // ComfortNoise's random phases (aec_core.c:476-489) for every block of the packet: WebRtcSpl_RandUArray's draws by
+            // jump-ahead, cosf / sinf of the reference's float expression by table (32 768 possible arguments, host libm)
+            float *row = noise + (size_t)p * n_cohorts * kAecNoiseRow;
+            AecNoiseEntry e[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t sd = (pl.blk[k < pl.n_blk ? k : 0].seed * jump_a + jump_c) & 0x7FFFFFFFu;
+                e[k] = noise_tab[sd >> 16];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (k >= pl.n_blk) break;
+                row[k * 2 * kAecPart + lane] = e[k].c;
+                row[k * 2 * kAecPart + kAecPart + lane] = e[k].s;
+            }
+        }
         if (pl.has_far) {
             // WebRtc_WriteBuffer(far_pre_buf, farend): channel 0 of the far-end packet (src/webrtc.c:430)
             const int16_t *src = far_pcm + (size_t)p * far_packet_stride;
@@ -286,12 +326,15 @@ __device__ unsigned long long g_aec_prof[16];
 #endif
 constexpr int AS_LDS0 = AS_DPOW;               // state words kept in LDS: everything after the filter taps
 constexpr int AS_LDS_WORDS = AS_WORDS - AS_DPOW;
-constexpr int FAS = 132;                        // floats per FFT work row (128 + pad)
+#ifndef WMX_AEC_FAS
+#define WMX_AEC_FAS 138
+#endif
+constexpr int FAS = WMX_AEC_FAS;                // floats per FFT work row (128 + pad)
 
 struct alignas(16) AecWaveLds {
     float st[AS_LDS_WORDS];  // per-bin PSDs, time-domain tails, rings, scalars (indexed AS_x - AS_LDS0)
-    float wn[32];            // [0..11] wfBuf[0][p][64], the Nyquist column of the filter (the other 64 bins live in
-                             // registers); [16..27] partition energies of PartitionDelay
+    float wn[24];            // [0..11] wfBuf[0][p][64], the Nyquist column of the filter (the other 64 bins live in
+                             // registers); [12..23] partition energies of PartitionDelay
     float fa[8][FAS];        // work rows: spectra handed to / from the register FFTs; rows 1..7 double as NLP scratch
     float cur[64], enew[64];
     int16_t park[kAecFrame];  // second sub-frame of the launch's first packet, prefetched (the first one parks in fa[])
@@ -391,8 +434,8 @@ __device__ __forceinline__ void aec_fft_fwd(float *row, const FftTables *T, int 
 }
 
 template <int MULT>  // 1: 8 kHz, 2: 16 kHz
-__device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *__restrict__ powtab, AecWaveLds &W, AecTaps &taps,
-                                          const AecFarBufs &F, const AecBlkPlan &bp, const int lane_in) {
+__device__ __forceinline__ void aec_block(const AecConstsNear &K, const float *__restrict__ curves_g, const PowTables *__restrict__ powtab, AecWaveLds &W, AecTaps &taps,
+                                          const AecFarBufs &F, const AecBlkPlan &bp, const float *__restrict__ nz, const int lane_in) {
     // The lane-derived LDS addresses (gather points, twiddle and window slots) are loop invariant; left alone the
     // compiler hoists ~100 of them out of the packet loop and pins them in VGPRs for the whole kernel.  Recomputing
     // them per block costs a few VALU ops and frees the registers.
@@ -693,14 +736,14 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
             const float *src = W.fa[lane >> 1] + (lane & 1) * 66;
             float en = 0.f;
             for (int j = 0; j < kAecPart1; j++) en += src[j];
-            W.wn[16 + lane] = en;
+            W.wn[12 + lane] = en;
         }
         wave_sync();
         float best = 0.f;
         delayIdx = 0;
         for (int p = 0; p < 12; p++)
-            if (W.wn[16 + p] > best) {
-                best = W.wn[16 + p];
+            if (W.wn[12 + p] > best) {
+                best = W.wn[12 + p];
                 delayIdx = p;
             }
         wave_sync();
@@ -967,16 +1010,16 @@ __device__ __forceinline__ void aec_block(const AecConsts &K, const PowTables *_
     for (int b = lane; b < kAecPart1; b += 64) {
 #endif
         float h = t2[b];
-        const float wc = K.weight[b];
+        const float wc = curves_g[b];  // weightCurve, overDriveCurve: AecConsts::weight / ::overdrive in global memory
         if (h > hNlFb) h = wc * hNlFb + (1 - wc) * h;
-        h = aec_powf(h, overDriveSm * K.overdrive[b], powtab);  // powf (aec_core.c:278) -> libm_dev.h fast_pow
+        h = aec_powf(h, overDriveSm * curves_g[BP + b], powtab);  // powf (aec_core.c:278) -> libm_dev.h fast_pow
         float er = ew[b] * h, ei = ew[66 + b] * h;
         ei *= -1;
         float ur = 0.f, ui = 0.f;
         if (b >= 1) {
             const float noise = sqrtf(AEC_ST(noise_off + b));
-            ur = noise * bp.ucos[b - 1];
-            ui = -noise * bp.usin[b - 1];
+            ur = noise * nz[b - 1];               // cosf / sinf of the block's 64 random phases, made by the far kernel
+            ui = -noise * nz[kAecPart + b - 1];
             if (b == kAecPart) ui = 0.f;
         }
         const float v = 1 - h * h;
@@ -1024,11 +1067,12 @@ template <int MULT>
 #endif
 __global__ __attribute__((amdgpu_waves_per_eu(WMX_AEC_WAVES, WMX_AEC_WAVES))) __launch_bounds__(64 * kAecWavesPerBlock) void aec_near_kernel(float *__restrict__ state, AecFarBufs F_all,
                                                                           const float *__restrict__ consts_g,
-                                                                          const AecPlan *__restrict__ plans, int n_packets,
+                                                                          const AecPlan *__restrict__ plans, int n_packets, int n_cohorts,
+                                                                          const float *__restrict__ noise,
                                                                           const int16_t *near_pcm, int16_t *out_pcm, int n_streams,
                                                                           long stream_stride, long packet_stride, int chn, int pkg,
                                                                           const int *__restrict__ stream_far, const uint8_t *__restrict__ active) {
-    __shared__ AecConsts K;
+    __shared__ AecConstsNear K;
     __shared__ AecWaveLds Wv[kAecWavesPerBlock];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: state pointers become scalar bases
@@ -1042,15 +1086,16 @@ __global__ __attribute__((amdgpu_waves_per_eu(WMX_AEC_WAVES, WMX_AEC_WAVES))) __
     // wave-uniform, so the group's buffers are scalar bases like the single far-end's
     const int grp = stream_far ? __builtin_amdgcn_readfirstlane(stream_far[sl]) : 0;
     const AecFarBufs F = far_group(F_all, grp);
-    plans += (size_t)grp * kAecMaxPktPerLaunch;
+    plans += grp;  // [packet][cohort]
+    noise += (size_t)grp * kAecNoiseRow;
     float *gst = state + (size_t)sl * AS_WORDS;
     // the constants first (L2 hits): their copy into LDS then waits for them alone, not for the HBM loads behind them
-    constexpr int kConstIt = (kAecConstWords + 64 * kAecWavesPerBlock - 1) / (64 * kAecWavesPerBlock);
+    constexpr int kConstIt = (kAecConstNearWords + 64 * kAecWavesPerBlock - 1) / (64 * kAecWavesPerBlock);
     float kc[kConstIt];
 #pragma unroll
     for (int k = 0; k < kConstIt; k++) {
         const int i = threadIdx.x + 64 * kAecWavesPerBlock * k;
-        kc[k] = consts_g[i < kAecConstWords ? i : 0];
+        kc[k] = consts_g[i < kAecConstNearWords ? i : 0];
     }
     int16_t pcm0[2][2];
     {
@@ -1090,7 +1135,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(WMX_AEC_WAVES, WMX_AEC_WAVES))) __
 #pragma unroll
     for (int k = 0; k < kConstIt; k++) {
         const int i = threadIdx.x + 64 * kAecWavesPerBlock * k;
-        if (i < kAecConstWords) reinterpret_cast<float *>(&K)[i] = kc[k];
+        if (i < kAecConstNearWords) reinterpret_cast<float *>(&K)[i] = kc[k];
     }
     // the only block-level barrier: LDS writes drained, then s_barrier -- spelled out because __syncthreads() would also
     // wait for every outstanding global load (the state requests above) in all eight waves
@@ -1124,8 +1169,9 @@ __global__ __attribute__((amdgpu_waves_per_eu(WMX_AEC_WAVES, WMX_AEC_WAVES))) __
     wave_sync();
     AEC_PROF(10);
     for (int p = 0; p < n_packets; p++) {
-        const AecPlan &pl = plans[p];
+        const AecPlan &pl = plans[(size_t)p * n_cohorts];
         if (!pl.has_near) continue;
+        const float *nz = noise + (size_t)p * n_cohorts * kAecNoiseRow;
         const size_t off = (size_t)sidx * stream_stride + (size_t)p * packet_stride;
         const int16_t *in = near_pcm + off;
         int16_t *out = out_pcm + off;
@@ -1148,7 +1194,9 @@ __global__ __attribute__((amdgpu_waves_per_eu(WMX_AEC_WAVES, WMX_AEC_WAVES))) __
                 AEC_ST(AS_NEAR_RING + ring_at(sp.near_wr, i)) = v;
             }
             wave_sync();
-            for (int k = 0; k < sp.n_blocks; k++) aec_block<MULT>(K, powtab, W, taps, F, pl.blk[sp.first_blk + k], lane);
+            for (int k = 0; k < sp.n_blocks; k++)
+                aec_block<MULT>(K, consts_g + kAecConstNearWords, powtab, W, taps, F, pl.blk[sp.first_blk + k],
+                                nz + (sp.first_blk + k) * 2 * kAecPart, lane);
             for (int i = opaque_lane(lane); i < kAecFrame; i += 64) {
                 const int16_t v = (int16_t)AEC_ST(AS_OUT_RING + ring_at(sp.out_rd, i));
                 for (int c = 0; c < chn; c++) out[(s * kAecFrame + i) * chn + c] = v;
@@ -1223,8 +1271,13 @@ struct wmx_aec {
     hipEvent_t plan_free[kPlanBufs];  // recorded behind the kernels that read slot i; waited for before slot i is rewritten
     bool plan_used[kPlanBufs];
     int plan_sel;
-    int n_far;               // far-end groups (1 = one shared far-end)
-    int *d_stream_far;       // [n_streams] group of each stream, or nullptr when n_far == 1
+    int n_far;               // far-end groups / control cohorts in use, retired ones included (1 = one shared far-end): ids 0 .. n_far - 1
+    int cap_far;             // cohorts the device buffers (far slabs, plan slots, noise rows) are allocated for; grows by doubling
+    std::vector<uint8_t> live;  // [n_far] 0: retired by wmx_aec_retire_cohort (never called, its id is handed out again)
+    int *d_stream_far;       // [n_streams] group of each stream, or nullptr while there has only ever been one
+    wmx::AecNoiseEntry *d_noise_tab;  // cosf / sinf of the comfort noise's 32 768 possible phases (host libm, aec_ctl.h)
+    float *d_noise;          // [noise_pkts][cap_far][kAecNoiseRow]: what the far kernel makes of the plans' seeds for the near kernel
+    int noise_pkts;
     int16_t *d_zero_far;  // a silent far-end packet for near-only calls that need no far data
     wmx::StreamLife life;
     // in-stream timing of the two kernels (wmx_aec_set_timing): event quadruples [far start | far end | near start | near end]
@@ -1237,6 +1290,13 @@ struct wmx_aec {
     hipStream_t side;
     hipEvent_t ev_fork, ev_join;
     bool fork_pending;
+    // per-call scratch kept with the handle (no allocation on the heartbeat's path)
+    std::vector<int> rc_g;           // [n_far] what the wrapper would have returned to the members of each cohort
+    std::vector<int32_t> same_delay; // [n_far] the one reported delay of wmx_aec_run / _run_groups, spread over the cohorts
+    // host time spent in the control planes (the per-cohort, per-packet AecCtl loop of wmx_aec_run_cohorts), summed; wmx_aec_host_ctl
+    double ctl_seconds;
+    long ctl_calls;
+    static constexpr size_t kMaxTimingEvents = 4 * 4096;  // timing left on and never polled: the oldest quadruples are reused
 };
 
 extern "C" {
@@ -1250,6 +1310,8 @@ int wmx_aec_destroy(wmx_aec *h) {
     if (h->d_plans) (void)hipFree(h->d_plans);
     if (h->h_plans) (void)hipHostFree(h->h_plans);
     if (h->d_stream_far) (void)hipFree(h->d_stream_far);
+    if (h->d_noise_tab) (void)hipFree(h->d_noise_tab);
+    if (h->d_noise) (void)hipFree(h->d_noise);
     if (h->d_tmpl) (void)hipFree(h->d_tmpl);
     h->life.release();
     for (hipEvent_t ev : h->tev) (void)hipEventDestroy(ev);
@@ -1264,6 +1326,88 @@ int wmx_aec_destroy(wmx_aec *h) {
 
 int wmx_aec_create(wmx_aec **out, int n_streams, int chn, int freq, int interval_ms) {
     return wmx_aec_create_groups(out, n_streams, chn, freq, interval_ms, 1, nullptr);
+}
+
+// floats of one cohort's far-end slab (AecFarBufs carved out of it)
+static size_t aec_far_words() {
+    using namespace wmx;
+    return (size_t)kAecPreLen + 2 * (size_t)kAecFarBlocks * 130 + 3 * (size_t)kAecHist * 130 + 4 * (size_t)kAecHist + (size_t)kAecHist * BP + BP;
+}
+
+static void aec_carve_far(wmx_aec *h) {
+    using namespace wmx;
+    float *p = h->d_far;
+    h->far.pre = p;
+    p += kAecPreLen;
+    h->far.ring = p;
+    p += (size_t)kAecFarBlocks * 130;
+    h->far.ring_w = p;
+    p += (size_t)kAecFarBlocks * 130;
+    h->far.hist = p;
+    p += 2 * (size_t)kAecHist * 130;
+    h->far.nyq = p;
+    p += 4 * (size_t)kAecHist;
+    h->far.hist_w = p;
+    p += (size_t)kAecHist * 130;
+    h->far.xpow_seq = p;
+    p += (size_t)kAecHist * BP;
+    h->far.xpow = p;
+    h->far.group_words = aec_far_words();
+}
+
+// Device buffers for `cap` cohorts and launches of up to `pkts` packets: the far-end slabs (existing ones are carried over),
+// the plan slots and the noise rows.  Growing is a control-plane operation (the device is drained); it doubles, so a batch that
+// gains cohorts one join at a time reallocates a logarithmic number of times.
+static int aec_reserve(wmx_aec *h, int cap, int pkts) {
+    using namespace wmx;
+    if (cap <= h->cap_far && pkts <= h->noise_pkts) return 0;
+    WMX_HIP_RC(hipDeviceSynchronize());  // plans, noise rows and far slabs may be in use by launches in flight
+    const size_t fw = aec_far_words();
+    if (cap > h->cap_far) {
+        int ncap = h->cap_far > 0 ? h->cap_far : 1;
+        while (ncap < cap) ncap *= 2;
+        float *nf = nullptr;
+        WMX_HIP_RC(hipMalloc(&nf, fw * (size_t)ncap * sizeof(float)));
+        if (h->d_far) {
+            hipError_t e = hipMemcpy(nf, h->d_far, fw * (size_t)h->cap_far * sizeof(float), hipMemcpyDeviceToDevice);
+            if (e == hipSuccess) e = hipMemset(nf + fw * (size_t)h->cap_far, 0, fw * (size_t)(ncap - h->cap_far) * sizeof(float));
+            if (e != hipSuccess) {
+                (void)hipFree(nf);
+                return hip_fail(e, "far-end slabs", __FILE__, __LINE__);
+            }
+            (void)hipFree(h->d_far);
+        } else {
+            hipError_t e = hipMemset(nf, 0, fw * (size_t)ncap * sizeof(float));
+            if (e != hipSuccess) {
+                (void)hipFree(nf);
+                return hip_fail(e, "far-end slabs", __FILE__, __LINE__);
+            }
+        }
+        h->d_far = nf;
+        aec_carve_far(h);
+        // plan slots: kPlanBufs x [kAecMaxPktPerLaunch][ncap] (a launch uses the first packets x n_far of its slot)
+        const size_t plan_bytes = (size_t)wmx_aec::kPlanBufs * ncap * kAecMaxPktPerLaunch * sizeof(AecPlan);
+        if (h->d_plans) (void)hipFree(h->d_plans);
+        if (h->h_plans) (void)hipHostFree(h->h_plans);
+        h->d_plans = nullptr;
+        h->h_plans = nullptr;
+        WMX_HIP_RC(hipMalloc(&h->d_plans, plan_bytes));
+        WMX_HIP_RC(hipHostMalloc(reinterpret_cast<void **>(&h->h_plans), plan_bytes, hipHostMallocDefault));
+        for (int i = 0; i < wmx_aec::kPlanBufs; i++) h->plan_used[i] = false;  // drained above
+        h->cap_far = ncap;
+        if (h->d_noise) (void)hipFree(h->d_noise);
+        h->d_noise = nullptr;
+        if (pkts < h->noise_pkts) pkts = h->noise_pkts;
+        h->noise_pkts = 0;
+    }
+    if (pkts > h->noise_pkts || !h->d_noise) {
+        if (pkts < 2) pkts = 2;
+        if (h->d_noise) (void)hipFree(h->d_noise);
+        h->d_noise = nullptr;
+        WMX_HIP_RC(hipMalloc(&h->d_noise, (size_t)pkts * h->cap_far * kAecNoiseRow * sizeof(float)));
+        h->noise_pkts = pkts;
+    }
+    return 0;
 }
 
 int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int interval_ms, int n_far, const int32_t *stream_far) {
@@ -1297,8 +1441,11 @@ int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int i
     h->pkg = freq / 1000 * ((freq <= 8000 && interval_ms % 20 == 0) ? 20 : 10);  // src/webrtc.c:239-248
     h->ctl.resize((size_t)n_far);
     for (wmx::AecCtl &c : h->ctl) c.init(freq);
+    h->live.assign((size_t)n_far, 1);
     h->d_state = h->d_consts = h->d_far = h->d_tmpl = nullptr;
     h->timing = false;
+    h->ctl_seconds = 0.0;
+    h->ctl_calls = 0;
     h->tev_used = 0;
     h->side = nullptr;
     h->ev_fork = h->ev_join = nullptr;
@@ -1306,7 +1453,11 @@ int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int i
     h->d_plans = nullptr;
     h->h_plans = nullptr;
     h->d_stream_far = nullptr;
+    h->d_noise_tab = nullptr;
+    h->d_noise = nullptr;
+    h->noise_pkts = 0;
     h->n_far = n_far;
+    h->cap_far = 0;
     h->plan_sel = 0;
     for (int i = 0; i < wmx_aec::kPlanBufs; i++) h->plan_free[i] = nullptr, h->plan_used[i] = false;
     h->d_zero_far = nullptr;
@@ -1332,8 +1483,6 @@ int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int i
     st[AS_HNLXDAVGMIN] = 1.f;
     st[AS_OVERDRIVE] = 2.f;
     st[AS_OVERDRIVESM] = 2.f;
-    const size_t far_words = (size_t)kAecPreLen + 2 * (size_t)kAecFarBlocks * 130 + 3 * (size_t)kAecHist * 130 + 4 * (size_t)kAecHist +
-                             (size_t)kAecHist * BP + BP;
     hipError_t e;
 #define AEC_TRY(x)                                         \
     if ((e = (x)) != hipSuccess) {                         \
@@ -1343,11 +1492,14 @@ int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int i
     }
     AEC_TRY(hipMalloc(&h->d_state, (size_t)AS_WORDS * n_streams * sizeof(float)));
     AEC_TRY(hipMalloc(&h->d_consts, sizeof(K) + sizeof(PowTables)));  // [AecConsts | PowTables]; only the first part is copied to LDS
-    AEC_TRY(hipMalloc(&h->d_far, far_words * n_far * sizeof(float)));
-    AEC_TRY(hipMalloc(&h->d_plans, (size_t)wmx_aec::kPlanBufs * n_far * kAecMaxPktPerLaunch * sizeof(AecPlan)));
-    AEC_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->h_plans), (size_t)wmx_aec::kPlanBufs * n_far * kAecMaxPktPerLaunch * sizeof(AecPlan),
-                          hipHostMallocDefault));
     for (int i = 0; i < wmx_aec::kPlanBufs; i++) AEC_TRY(hipEventCreateWithFlags(&h->plan_free[i], hipEventDisableTiming));
+    {
+        const int rc = aec_reserve(h, n_far, 2);
+        if (rc != 0) {
+            wmx_aec_destroy(h);
+            return rc;
+        }
+    }
     if (n_far > 1) {
         AEC_TRY(hipMalloc(&h->d_stream_far, sizeof(int) * n_streams));
         if (stream_far) {
@@ -1364,30 +1516,61 @@ int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int i
         pow_tables(&pt);
         AEC_TRY(hipMemcpy(reinterpret_cast<char *>(h->d_consts) + sizeof(K), &pt, sizeof(pt), hipMemcpyHostToDevice));
     }
+    {
+        // the comfort noise's phase table: made once per process with the host libm, one copy per handle on its device
+        static const std::vector<AecNoiseEntry> tab = [] {
+            std::vector<AecNoiseEntry> t((size_t)kAecNoiseTab);
+            aec_noise_table(t.data());
+            return t;
+        }();
+        AEC_TRY(hipMalloc(&h->d_noise_tab, sizeof(AecNoiseEntry) * kAecNoiseTab));
+        AEC_TRY(hipMemcpy(h->d_noise_tab, tab.data(), sizeof(AecNoiseEntry) * kAecNoiseTab, hipMemcpyHostToDevice));
+    }
     AEC_TRY(hipMemcpy(h->d_tmpl, st.data(), AS_WORDS * sizeof(float), hipMemcpyHostToDevice));
-    AEC_TRY(hipMemset(h->d_far, 0, far_words * n_far * sizeof(float)));
     hipLaunchKernelGGL(aec_fill_state, dim3(1024), dim3(256), 0, nullptr, h->d_state, h->d_tmpl, (int)AS_WORDS, n_streams);
     AEC_TRY(hipGetLastError());
     AEC_TRY(hipDeviceSynchronize());
 #undef AEC_TRY
-    float *p = h->d_far;
-    h->far.pre = p;
-    p += kAecPreLen;
-    h->far.ring = p;
-    p += (size_t)kAecFarBlocks * 130;
-    h->far.ring_w = p;
-    p += (size_t)kAecFarBlocks * 130;
-    h->far.hist = p;
-    p += 2 * (size_t)kAecHist * 130;
-    h->far.nyq = p;
-    p += 4 * (size_t)kAecHist;
-    h->far.hist_w = p;
-    p += (size_t)kAecHist * 130;
-    h->far.xpow_seq = p;
-    p += (size_t)kAecHist * BP;
-    h->far.xpow = p;
-    h->far.group_words = far_words;
     *out = h;
+    return 0;
+}
+
+// A new control cohort (a join time of its own: aec_init of the shared part, src/webrtc.c:217-274): a retired id when there is
+// one, else the next; its control plane and far-end history start over.  *cohort receives the id; members join it with
+// wmx_aec_reset_streams(h, idx, n, id, stream).  The per-cohort arrays of wmx_aec_run_cohorts have wmx_aec_cohorts(h) entries
+// from now on.
+int wmx_aec_add_cohort(wmx_aec *h, int *cohort, void *stream) {
+    WMX_ON_DEVICE(h);
+    using namespace wmx;
+    if (!h || !cohort) return WMX_EINVAL;
+    int id = -1;
+    for (int g = 0; g < h->n_far; g++)
+        if (!h->live[(size_t)g]) {
+            id = g;
+            break;
+        }
+    if (id < 0) {
+        id = h->n_far;
+        const int rc = aec_reserve(h, id + 1, h->noise_pkts);
+        if (rc != 0) return rc;
+        h->ctl.resize((size_t)id + 1);
+        h->live.push_back(1);
+        h->n_far = id + 1;
+    }
+    if (h->n_far > 1 && !h->d_stream_far) {  // so far every stream was in cohort 0 by construction
+        WMX_HIP_RC(hipMalloc(&h->d_stream_far, sizeof(int) * h->n_streams));
+        WMX_HIP_RC(hipMemsetAsync(h->d_stream_far, 0, sizeof(int) * h->n_streams, as_stream(stream)));
+    }
+    h->live[(size_t)id] = 1;
+    *cohort = id;
+    return wmx_aec_reset_cohort(h, id, stream);
+}
+
+// The cohort's handles were released (aec_release of every member): it is never called again and its id may be handed out by
+// a later wmx_aec_add_cohort.  Streams still mapped to it must be inactive or be moved before the next call.
+int wmx_aec_retire_cohort(wmx_aec *h, int cohort) {
+    if (!h || cohort < 0 || cohort >= h->n_far) return WMX_EINVAL;
+    h->live[(size_t)cohort] = 0;
     return 0;
 }
 
@@ -1417,9 +1600,9 @@ int wmx_aec_run_groups(wmx_aec *h, int mode, const int16_t *d_far, long far_pack
         return WMX_EINVAL;
     }
     // every far-end group in lockstep: same reported delay, all switched on
-    std::vector<int32_t> delays((size_t)h->n_far, delay_ms);
+    h->same_delay.assign((size_t)h->n_far, delay_ms);
     return wmx_aec_run_cohorts(h, mode, d_far, far_packet_stride, far_group_stride, d_near, d_out, n_packets, stream_stride, packet_stride,
-                               delays.data(), nullptr, nullptr, stream);
+                               h->same_delay.data(), nullptr, nullptr, stream);
 }
 
 // The general form.  A far-end group is also a control COHORT: its streams were started together (aec_init at the same
@@ -1433,6 +1616,11 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
                         const uint8_t *cohort_on, int32_t *cohort_rc, void *stream) {
     WMX_ON_DEVICE(h);
     using namespace wmx;
+    // a fork point (wmx::aec_fork_far) belongs to THIS call, whichever way it ends: taken over here, used by the first chunk that
+    // launches, and gone on every other path (argument errors, every cohort switched off) -- a later call must not start its
+    // far kernel on the side stream behind a stale event (round-3 ADVICE)
+    const bool fork_here = h && h->fork_pending;
+    if (h) h->fork_pending = false;
     if (!h || n_packets < 0 || (mode & 3) == 0 || !delay_ms) {
         set_error("wmx_aec_run: bad argument");
         return WMX_EINVAL;
@@ -1456,9 +1644,17 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
     }
     hipStream_t s = as_stream(stream);
     const float gpow1np = 0.1f * 12;  // gPow[1] * num_partitions (aec_core.c:1212), evaluated in float like the reference
-    std::vector<int> rc_g((size_t)G, 0);   // a cohort whose call was rejected runs nothing after the offending packet
+    std::vector<int> &rc_g = h->rc_g;  // a cohort whose call was rejected runs nothing after the offending packet
+    rc_g.assign((size_t)G, 0);
     int rc_first = 0, running = 0;
-    for (int g = 0; g < G; g++) running += (!cohort_on || cohort_on[g]) ? 1 : 0;
+    for (int g = 0; g < G; g++) running += (h->live[(size_t)g] && (!cohort_on || cohort_on[g])) ? 1 : 0;
+    {
+        const int need = n_packets < kAecMaxPktPerLaunch ? n_packets : kAecMaxPktPerLaunch;
+        if (need > h->noise_pkts) {
+            const int rc = aec_reserve(h, h->cap_far, need);
+            if (rc != 0) return rc;
+        }
+    }
     for (int done = 0; done < n_packets && running > 0;) {
         int chunk = n_packets - done;
         if (chunk > kAecMaxPktPerLaunch) chunk = kAecMaxPktPerLaunch;
@@ -1467,14 +1663,14 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
         const int sel = h->plan_sel;
         h->plan_sel = (sel + 1) % wmx_aec::kPlanBufs;
         if (h->plan_used[sel]) WMX_HIP(hipEventSynchronize(h->plan_free[sel]));
-        const size_t slot = (size_t)sel * G * kAecMaxPktPerLaunch;
-        AecPlan *hp = h->h_plans + slot, *dp = h->d_plans + slot;
+        const size_t slot = (size_t)sel * h->cap_far * kAecMaxPktPerLaunch;
+        AecPlan *hp = h->h_plans + slot, *dp = h->d_plans + slot;  // [packet][cohort], G apart: chunk x G plans are uploaded
         int any = 0;
+        const auto t_ctl = std::chrono::steady_clock::now();
         for (int g = 0; g < G; g++) {
-            AecPlan *pg = hp + (size_t)g * kAecMaxPktPerLaunch;
-            const bool on = (!cohort_on || cohort_on[g]) && rc_g[g] == 0;
+            const bool on = h->live[(size_t)g] && (!cohort_on || cohort_on[g]) && rc_g[g] == 0;
             for (int k = 0; k < chunk; k++) {
-                AecPlan &pl = pg[k];
+                AecPlan &pl = hp[(size_t)k * G + g];
                 memset(&pl, 0, offsetof(AecPlan, blk));
                 if (!on || rc_g[g] != 0) continue;  // has_far = has_near = 0: both kernels skip the packet for this cohort
                 any = 1;
@@ -1499,16 +1695,18 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
                 if (rc_first == 0) rc_first = rc_g[g];
             }
         }
+        h->ctl_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_ctl).count();
+        h->ctl_calls++;
         if (any) {
             const int by_value = (chunk == 1 && G == 1) ? 1 : 0;
             // the far kernel (and the plans it reads) on the side stream when the caller forked it (first chunk of the call only)
-            const bool forked = h->fork_pending && done == 0 && (mode & 2);
-            h->fork_pending = false;
+            const bool forked = fork_here && done == 0 && (mode & 2);
             hipStream_t fs = forked ? h->side : s;
             if (forked) WMX_HIP(hipStreamWaitEvent(fs, h->ev_fork, 0));
-            if (!by_value) WMX_HIP(hipMemcpyAsync(dp, hp, (size_t)G * kAecMaxPktPerLaunch * sizeof(AecPlan), hipMemcpyHostToDevice, fs));
+            if (!by_value) WMX_HIP(hipMemcpyAsync(dp, hp, (size_t)G * chunk * sizeof(AecPlan), hipMemcpyHostToDevice, fs));
             hipEvent_t *tv = nullptr;
             if (h->timing && (mode & 2)) {
+                if (h->tev_used + 4 > wmx_aec::kMaxTimingEvents) h->tev_used = 0;  // nobody polls: start over on the oldest events
                 if (h->tev_used + 4 > h->tev.size())
                     for (int k = 0; k < 4; k++) {
                         hipEvent_t ev;
@@ -1519,9 +1717,9 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
                 h->tev_used += 4;
                 WMX_HIP(hipEventRecord(tv[0], fs));
             }
-            hipLaunchKernelGGL(aec_far_kernel, dim3((unsigned)G), dim3(64), 0, fs, h->far, h->d_consts, dp, chunk,
+            hipLaunchKernelGGL(aec_far_kernel, dim3((unsigned)G), dim3(64), 0, fs, h->far, h->d_consts, dp, chunk, G,
                                d_far ? d_far + (size_t)done * far_packet_stride : nullptr, far_packet_stride, far_group_stride, h->chn, gpow1np,
-                               by_value, hp[0]);
+                               h->d_noise_tab, h->d_noise, by_value, hp[0]);
             WMX_LAUNCH_CHECK();
             if (tv) WMX_HIP(hipEventRecord(tv[1], fs));
             if (forked) {
@@ -1535,10 +1733,10 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
                 const unsigned grid = (unsigned)((h->n_streams + kAecWavesPerBlock - 1) / kAecWavesPerBlock);
                 const dim3 blk(64 * kAecWavesPerBlock);
                 if (h->freq == 8000)
-                    hipLaunchKernelGGL((aec_near_kernel<1>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, chunk, nin,
+                    hipLaunchKernelGGL((aec_near_kernel<1>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, chunk, G, h->d_noise, nin,
                                        nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg, h->d_stream_far, h->life.d_active);
                 else
-                    hipLaunchKernelGGL((aec_near_kernel<2>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, chunk, nin,
+                    hipLaunchKernelGGL((aec_near_kernel<2>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, chunk, G, h->d_noise, nin,
                                        nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg, h->d_stream_far, h->life.d_active);
                 WMX_LAUNCH_CHECK();
                 if (tv) WMX_HIP(hipEventRecord(tv[3], s));
@@ -1673,6 +1871,10 @@ int wmx::aec_fork_far(wmx_aec *h, hipStream_t s) {
     return 0;
 }
 
+void wmx::aec_cancel_fork(wmx_aec *h) {
+    if (h) h->fork_pending = false;
+}
+
 extern "C" {
 
 // In-stream timing of the AEC's two kernels: with timing on, every near-end launch is bracketed by HIP events recorded on
@@ -1682,6 +1884,17 @@ int wmx_aec_set_timing(wmx_aec *h, int on) {
     WMX_ON_DEVICE(h);
     if (!h) return WMX_EINVAL;
     h->timing = on != 0;
+    return 0;
+}
+
+// Host time of the control planes since the previous call: launches (chunks of at most 16 packets) and the seconds their
+// per-cohort, per-packet AecCtl loops took on the caller's thread (index arithmetic only; it runs ahead of the GPU).
+int wmx_aec_host_ctl(wmx_aec *h, long *n_launches, double *seconds) {
+    if (!h) return WMX_EINVAL;
+    if (n_launches) *n_launches = h->ctl_calls;
+    if (seconds) *seconds = h->ctl_seconds;
+    h->ctl_calls = 0;
+    h->ctl_seconds = 0.0;
     return 0;
 }
 

@@ -31,9 +31,40 @@ struct AecBlkPlan {
     int hist_n;    // sequence number of the consumed far block (history slot = hist_n % kAecHist)
     int far_slot;  // far ring slot consumed (plain and windowed rings move together)
     int flags;
-    int pad[3];
-    float ucos[64], usin[64];  // cosf / sinf of the 64 comfort-noise phases (aec_core.c:482-489), host libm
+    uint32_t seed;  // state of the comfort-noise generator in front of this block's 64 draws (WebRtcSpl_RandUArray,
+                    // randomization_functions.c:94-112: seed = (seed * 69069 + 1) & 0x7FFFFFFF per draw); the far kernel expands
+                    // it into the block's 64 (cos, sin) pairs through AecNoiseTable -- 32 bytes per block cross PCIe, not 544
+    int pad[2];
 };
+static_assert(sizeof(AecBlkPlan) == 32, "AecBlkPlan layout");
+
+// The comfort-noise phases (aec_core.c:476-489): u = (int16)(seed >> 16) / 32768 -> cosf / sinf of 2 pi u.  The generator's state
+// has 31 bits, so seed >> 16 takes 32 768 values: the table holds the host libm's cosf / sinf for every one of them, evaluated
+// with the reference's own float expressions -- the values a handle of the reference computes per block, looked up instead.
+constexpr int kAecNoiseTab = 32768;
+struct AecNoiseEntry {
+    float c, s;
+};
+inline void aec_noise_table(AecNoiseEntry *t) {
+    const float pi2 = 6.28318530717959f;
+    for (int i = 0; i < kAecNoiseTab; i++) {
+        const float r = ((float)(int16_t)i) / 32768;
+        const float tmp = pi2 * r;
+        t[i].c = cosf(tmp);
+        t[i].s = sinf(tmp);
+    }
+}
+// k draws in one step: seed_k = (seed * a_k + c_k) mod 2^31 with a_k = 69069^k, c_k = 1 + 69069 + ... + 69069^(k-1)
+// (arithmetic mod 2^32, masked: the low 31 bits of a product depend on the low 31 bits of its factors only)
+inline void aec_lcg_jump(int k, uint32_t *a_k, uint32_t *c_k) {
+    uint32_t a = 1u, c = 0u;
+    for (int i = 0; i < k; i++) {
+        c = c * 69069u + 1u;
+        a = a * 69069u;
+    }
+    *a_k = a;
+    *c_k = c;
+}
 struct AecSubPlan {
     int near_wr;   // near ring position where the 80 new samples go
     int n_blocks;  // blocks processed in this 80-sample sub-frame
@@ -197,15 +228,14 @@ struct AecCtl {
         delay_est_ctr++;
         if (delay_est_ctr == 10 * mult) delay_est_ctr = 0;
         if (delay_est_ctr == 0) b.flags |= kAecFlagDelayEst;
-        // ComfortNoise: 64 uniform numbers -> phases (aec_core.c:476-489), WebRtcSpl_RandUArray
-        const float pi2 = 6.28318530717959f;
-        for (int i = 0; i < kAecPart; i++) {
-            seed = (seed * 69069u + 1u) & 0x7FFFFFFFu;
-            const float r = ((float)(int16_t)(seed >> 16)) / 32768;
-            const float tmp = pi2 * r;
-            b.ucos[i] = cosf(tmp);
-            b.usin[i] = sinf(tmp);
-        }
+        // ComfortNoise draws 64 uniform numbers per block (aec_core.c:476-489, WebRtcSpl_RandUArray): the block gets the
+        // generator's state, the control plane jumps over the 64 draws
+        b.seed = seed;
+        static const struct Jump64 {
+            uint32_t a, c;
+            Jump64() { aec_lcg_jump(kAecPart, &a, &c); }
+        } J;
+        seed = (seed * J.a + J.c) & 0x7FFFFFFFu;
         out_fr.write(kAecPart, &b.out_wr);
     }
 

@@ -22,6 +22,8 @@ struct wmx_chain {
     int pkg10;                       // int16 elements of one 10 ms packet of one stream (freq / 100 * chn)
     int aec_pkg, agc_pkg, vad_pkg;   // the stages' own packets, in int16 elements
     int n_cohorts;
+    bool no_fork;                    // WMIX_AMD_CHAIN_NO_FORK, read once at create (developer A/B switch)
+    std::vector<int32_t> zero_delays;  // what the daemon reports (delayms = 0), one per cohort, for callers that pass NULL
 };
 
 extern "C" {
@@ -56,6 +58,8 @@ int wmx_chain_create(wmx_chain **out, int n_streams, int chn, int freq, int inte
     h->stages = stages;
     h->n_cohorts = n_cohorts;
     h->pkg10 = freq / 100 * chn;
+    h->no_fork = getenv("WMIX_AMD_CHAIN_NO_FORK") != nullptr;
+    h->zero_delays.assign((size_t)n_cohorts, 0);
     int rc = 0;
     // the same *_init calls, in the heartbeat's order; an unsupported format fails the way the reference's *_init returns NULL
     if (rc == 0 && (stages & WMX_CHAIN_NS)) rc = wmx_ns_create(&h->ns, n_streams, chn, freq);
@@ -105,22 +109,29 @@ int wmx_chain_process(wmx_chain *h, const int16_t *d_far, long far_packet_stride
                        h->aec_pkg, h->vad_pkg);
         return WMX_EINVAL;
     }
+    // vad_process averages interleaved channels over the WHOLE call in place and expands them again at the end
+    // (src/webrtc.c:104-116, 145-150): with several VAD packets per tick the tick must lie in one piece per stream, or the
+    // downmix would rewrite the neighbouring streams' rows (round-3 ADVICE).  Checked before anything is launched.
+    if (h->vad && h->chn > 1 && total / h->vad_pkg > 1 && !(contiguous && (h->n_streams == 1 || stream_stride >= total))) {
+        wmx::set_error("wmx_chain_process: the VAD of a %d-channel chain needs the tick's %d packets contiguous per stream "
+                       "(packet stride %ld, stream stride %ld)", h->chn, n10, packet_stride, stream_stride);
+        return WMX_EINVAL;
+    }
     const int16_t *src = d_in;
     int rc = 0, rc_aec = 0;
     // the AEC's far kernel (one wave per cohort, 10-20 us with the GPU otherwise idle) needs only the far-end packet: it runs
     // on the AEC handle's side stream beside the noise suppressor instead of between it and the near kernel
-    if (h->ns && h->aec && !getenv("WMIX_AMD_CHAIN_NO_FORK") && (rc = wmx::aec_fork_far(h->aec, wmx::as_stream(stream))) != 0) return rc;
+    if (h->ns && h->aec && !h->no_fork && (rc = wmx::aec_fork_far(h->aec, wmx::as_stream(stream))) != 0) return rc;
     if (h->ns) {
-        if ((rc = wmx_ns_process(h->ns, src, d_out, n10, stream_stride, packet_stride, stream)) != 0) return rc;
+        if ((rc = wmx_ns_process(h->ns, src, d_out, n10, stream_stride, packet_stride, stream)) != 0) {
+            if (h->aec) wmx::aec_cancel_fork(h->aec);  // no AEC call follows: the next one must not start behind a stale fork point
+            return rc;
+        }
         src = d_out;
     }
     if (h->aec) {
         const int per = h->aec_pkg / h->pkg10;  // 10 ms packets per AEC packet (1 or 2)
-        std::vector<int32_t> zero;
-        if (!delay_ms) {
-            zero.assign((size_t)h->n_cohorts, 0);
-            delay_ms = zero.data();
-        }
+        if (!delay_ms) delay_ms = h->zero_delays.data();
         rc_aec = wmx_aec_run_cohorts(h->aec, 3, d_far, far_packet_stride * per, 0, src, d_out, n10 / per, stream_stride, packet_stride * per,
                                      delay_ms, cohort_on, cohort_rc, stream);
         if (rc_aec != 0 && rc_aec != -1) return rc_aec;  // -1: a cohort's delay was rejected (its code is in cohort_rc); the others ran
@@ -145,8 +156,10 @@ int wmx_chain_process(wmx_chain *h, const int16_t *d_far, long far_packet_stride
             wmx::set_error("wmx_chain_process: a VAD-only chain works in place (d_in == d_out)");
             return WMX_EINVAL;
         }
-        // one call over the tick's packets; only its first packet is touched, wherever the others lie
-        if ((rc = wmx_vad_process(h->vad, d_out, (int)(total / h->vad_pkg), 1, stream_stride, h->vad_pkg, stream)) != 0) return rc;
+        // one call over the tick's packets.  Mono: only its first packet is touched, wherever the others lie.  Interleaved
+        // channels: the whole tick, in one piece per stream (checked at the top)
+        const int vad_calls = (int)(total / h->vad_pkg);
+        if ((rc = wmx_vad_process(h->vad, d_out, vad_calls, 1, stream_stride, h->chn > 1 ? total : h->vad_pkg, stream)) != 0) return rc;
     }
     return rc_aec;
 }
@@ -169,6 +182,27 @@ int wmx_chain_reset_cohort(wmx_chain *h, int cohort, void *stream) {
     if (!h) return WMX_EINVAL;
     return h->aec ? wmx_aec_reset_cohort(h->aec, cohort, stream) : 0;
 }
+
+int wmx_chain_add_cohort(wmx_chain *h, int *cohort, void *stream) {
+    WMX_ON_DEVICE(h);
+    if (!h || !cohort) return WMX_EINVAL;
+    if (!h->aec) {
+        *cohort = 0;
+        return 0;
+    }
+    const int rc = wmx_aec_add_cohort(h->aec, cohort, stream);
+    if (rc != 0) return rc;
+    h->n_cohorts = wmx_aec_cohorts(h->aec);
+    h->zero_delays.assign((size_t)h->n_cohorts, 0);
+    return 0;
+}
+
+int wmx_chain_retire_cohort(wmx_chain *h, int cohort) {
+    if (!h) return WMX_EINVAL;
+    return h->aec ? wmx_aec_retire_cohort(h->aec, cohort) : 0;
+}
+
+int wmx_chain_cohorts(const wmx_chain *h) { return h ? h->n_cohorts : WMX_EINVAL; }
 
 // A stream's state in every stage, concatenated in the heartbeat's order (each part is the stage's own blob); the AEC cohort
 // travels separately through wmx_aec_export_cohort / wmx_aec_import_cohort on wmx_chain_aec(h).

@@ -687,9 +687,9 @@ __device__ __forceinline__ void gmm_update_channel(const VadRef &S, int16_t feat
 // Decimation + first band split of vad_features for the pipeline's filter-bank wave, with the packet passing through the
 // registers eight output samples at a time (the next block's 2 / 4 uint4 are requested while the current one is filtered)
 // instead of 10 / 20 uint4 held at once: the kernel's register count decides how many workgroups share a CU.
-template <int RATIO>
+template <int RATIO, int NB>
 __device__ __forceinline__ void vad_front_blocked(const VadRef &S, const uint4 *frame4, LaneBuf hp120, LaneBuf lp120) {
-    constexpr int NB = 80, IT = 8, VPB = IT * 2 * RATIO / 8, NBLK = NB / 2 / IT;
+    constexpr int IT = 8, VPB = IT * 2 * RATIO / 8, NBLK = NB / 2 / IT;
     static_assert(RATIO == 1 || RATIO == 2, "8 or 16 kHz");
     int32_t d0 = 0, d1 = 0;
     if (RATIO == 2) {
@@ -735,7 +735,8 @@ enum : int { X_FEAT = 0, X_TOTAL = 6, X_LLR = 7, X_FLAG = 13, X_FIELDS = 19 };
 
 // one pair of GMM channels (C0, C0 + 1) of the workgroup's 64 streams: state in, per packet probabilities -> barrier ->
 // decision + update, state out
-template <int C0>
+// GLOB: the mode-3 total threshold of the packet length (vad_core.c:88-91: 1100 for 10 ms frames, 1050 for 20 ms)
+template <int C0, int GLOB>
 __device__ __forceinline__ void vad_pipe_channels(const VadRef &S, int16_t *s16, int32_t *s32, int32_t *xch, int16_t *minlds, int lane,
                                                   int stream, bool live, int n_streams, int n_calls) {
     const int16_t *g16 = s16 + stream;
@@ -784,7 +785,7 @@ __device__ __forceinline__ void vad_pipe_channels(const VadRef &S, int16_t *s16,
                 sum_llr += xch[(X_LLR + c) * 64 + lane];
                 vadflag |= xch[(X_FLAG + c) * 64 + lane];
             }
-            vadflag |= (sum_llr >= 1100);
+            vadflag |= (sum_llr >= GLOB);
             const int32_t frame_counter = S.w(V32_FRAME_COUNTER);
             gmm_update_channel<C0>(S, f0, vadflag, frame_counter, R0);
             gmm_update_channel<C0 + 1>(S, f1, vadflag, frame_counter, R1);
@@ -815,11 +816,14 @@ __device__ __forceinline__ void vad_pipe_channels(const VadRef &S, int16_t *s16,
     }
 }
 
-// RATIO = 1 (8 kHz) or 2 (16 kHz), one mono 10 ms packet per call, 16-byte aligned rows (what wmx_vad_process checks)
-template <int RATIO>
+// RATIO = 1 (8 kHz) or 2 (16 kHz); NB = 80: mono 10 ms packets, 160: mono 20 ms packets (what vad_init makes of the daemon's
+// WMIX_INTERVAL_MS = 20, src/webrtc.c:57-66, src/wmixConf.h:112); 16-byte aligned rows (what wmx_vad_process checks)
+template <int RATIO, int NB>
 __global__ __launch_bounds__(256) void vad_pipe_kernel(int16_t *s16, int32_t *s32, int16_t *pcm, int n_streams, int packets_per_call,
                                                        int n_calls, long stream_stride, long call_stride, const uint8_t *__restrict__ active) {
-    constexpr int NB = 80, PKG = NB * RATIO, NV = PKG / 8;
+    constexpr int PKG = NB * RATIO, NV = PKG / 8;
+    // mode-3 thresholds and hangover lengths of the frame length (vad_core.c:88-91; gmm_probability above)
+    constexpr int GLOB = NB == 80 ? 1100 : 1050, OH1 = NB == 80 ? 6 : 3, OH2 = NB == 80 ? 9 : 5;
     __shared__ __attribute__((aligned(16))) int16_t lds[64 * (NB / 2 + NB / 2 + NB / 4 + NB / 4)];
     __shared__ int16_t minlds[64 * kVadMinFields];
     int32_t *xch = reinterpret_cast<int32_t *>(lds);
@@ -834,15 +838,15 @@ __global__ __launch_bounds__(256) void vad_pipe_kernel(int16_t *s16, int32_t *s3
     int32_t r32[V32_WORDS];
     const VadRef S{r16, r32, minlds + lane};
     if (wave == 0) {
-        vad_pipe_channels<0>(S, s16, s32, xch, minlds, lane, stream, live, n_streams, n_calls * packets_per_call);
+        vad_pipe_channels<0, GLOB>(S, s16, s32, xch, minlds, lane, stream, live, n_streams, n_calls * packets_per_call);
         return;
     }
     if (wave == 1) {
-        vad_pipe_channels<2>(S, s16, s32, xch, minlds, lane, stream, live, n_streams, n_calls * packets_per_call);
+        vad_pipe_channels<2, GLOB>(S, s16, s32, xch, minlds, lane, stream, live, n_streams, n_calls * packets_per_call);
         return;
     }
     if (wave == 2) {
-        vad_pipe_channels<4>(S, s16, s32, xch, minlds, lane, stream, live, n_streams, n_calls * packets_per_call);
+        vad_pipe_channels<4, GLOB>(S, s16, s32, xch, minlds, lane, stream, live, n_streams, n_calls * packets_per_call);
         return;
     }
     // ---- wave 3: filter bank, hangover, attenuation
@@ -866,7 +870,7 @@ __global__ __launch_bounds__(256) void vad_pipe_kernel(int16_t *s16, int32_t *s3
         const int call = pass / packets_per_call, it = pass - call * packets_per_call;
         uint4 *frame4 = reinterpret_cast<uint4 *>(pcm + (size_t)stream * stream_stride + (size_t)call * call_stride);
         int16_t feat[6], total;
-        vad_front_blocked<RATIO>(S, frame4, hp120, lp120);
+        vad_front_blocked<RATIO, NB>(S, frame4, hp120, lp120);
         vad_features_rest<NB>(S, hp120, lp120, hp60, lp60, feat, total);
         // the band buffers are read for the last time above and xch lives in the same bytes: keep the compiler from moving
         // the stores below in front of those reads (the hardware executes a wave's LDS instructions in order)
@@ -886,9 +890,9 @@ __global__ __launch_bounds__(256) void vad_pipe_kernel(int16_t *s16, int32_t *s3
                 sum_llr += xch[(X_LLR + c) * 64 + lane];
                 vadflag |= xch[(X_FLAG + c) * 64 + lane];
             }
-            vadflag |= (sum_llr >= 1100);
+            vadflag |= (sum_llr >= GLOB);
         }
-        // hangover smoothing (vad_core.c:443-468), mode-3 values of the 10 ms frame length
+        // hangover smoothing (vad_core.c:443-468), mode-3 values of the frame length
         int16_t over_hang = S.h(V16_OVER_HANG), num_speech = S.h(V16_NUM_SPEECH);
         if (!vadflag) {
             if (over_hang > 0) {
@@ -900,9 +904,9 @@ __global__ __launch_bounds__(256) void vad_pipe_kernel(int16_t *s16, int32_t *s3
             num_speech++;
             if (num_speech > 6) {
                 num_speech = 6;
-                over_hang = 9;
+                over_hang = OH2;
             } else {
-                over_hang = 6;
+                over_hang = OH1;
             }
         }
         S.h(V16_OVER_HANG) = over_hang;
@@ -921,11 +925,17 @@ __global__ __launch_bounds__(256) void vad_pipe_kernel(int16_t *s16, int32_t *s3
         if (live && it == 0) {
             // the packet is fetched a second time (L2) rather than held in 80 registers across the two barriers: the
             // kernel's register count decides how many workgroups share a CU
-            uint4 again[NV];
+            constexpr int NVC = NV < 20 ? NV : 20;  // at most 20 uint4 (80 registers) in flight: a 20 ms packet at 16 kHz goes in two halves
+            static_assert(NV % NVC == 0, "whole chunks");
+#pragma unroll 1
+            for (int j0 = 0; j0 < NV; j0 += NVC) {
+                uint4 again[NVC];
 #pragma unroll
-            for (int j = 0; j < NV; j++) again[j] = frame4[j];
+                for (int j = 0; j < NVC; j++) again[j] = frame4[j0 + j];
 #pragma unroll
-            for (int j = 0; j < NV; j++) frame4[j] = make_uint4(att(again[j].x), att(again[j].y), att(again[j].z), att(again[j].w));
+                for (int j = 0; j < NVC; j++)
+                    frame4[j0 + j] = make_uint4(att(again[j].x), att(again[j].y), att(again[j].z), att(again[j].w));
+            }
             if (packets_per_call > 1) __threadfence();  // the next analysis of this call reads what was just stored
         }
         __syncthreads();  // 3
@@ -1099,6 +1109,7 @@ struct wmx_vad {
     int16_t *d_s16;
     int32_t *d_s32;
     int16_t *d_tmpl;  // the 16-bit fields vad_init gives a stream (the 32-bit ones start at zero)
+    bool one_lane;    // WMIX_AMD_VAD_ONE_LANE (developer A/B switch), read once at create
     wmx::StreamLife life;
 };
 
@@ -1154,6 +1165,7 @@ int wmx_vad_create(wmx_vad **out, int n_streams, int chn, int freq, int interval
     h->chn = chn;
     h->freq = freq;
     h->interval_ms = (freq <= 16000 && interval_ms % 20 == 0) ? 20 : 10;  // src/webrtc.c:57-66
+    h->one_lane = getenv("WMIX_AMD_VAD_ONE_LANE") != nullptr;
     h->pkg = freq / 1000 * h->interval_ms;
     // WebRtcVad_InitCore vad_core.c:482-531 (start values vad_core.c:46-57) + reduce = 4 (src/webrtc.c:68)
     static const int16_t nm[12] = {6738, 4892, 7065, 6715, 6771, 3369, 7646, 3863, 7820, 7266, 5020, 4362};
@@ -1235,28 +1247,38 @@ int wmx_vad_process(wmx_vad *h, int16_t *d_pcm, int packets_per_call, int n_call
     }
     // Only the FIRST packet of a call is ever read or written (the wrapper never advances its pointer),
     // so that packet is what must not overlap a neighbour -- a call's later packets may lie anywhere (packet-major batches).
+    // That holds for ONE channel.  With interleaved channels the wrapper first averages the channels of the WHOLE call in place
+    // and expands them again at the end (src/webrtc.c:104-116, 145-150): packets_per_call * pkg * chn contiguous int16 from the
+    // stream's first packet are read and rewritten, so all of them must belong to the stream (round-3 ADVICE).
     const long per_pkt = (long)h->pkg * h->chn;
-    if (call_stride < per_pkt || (h->n_streams > 1 && stream_stride < per_pkt)) {
-        set_error("wmx_vad_process: strides (%ld, %ld) smaller than a packet (%ld samples)", stream_stride, call_stride, per_pkt);
+    const long touched = h->chn > 1 ? per_pkt * packets_per_call : per_pkt;
+    if (call_stride < touched || (h->n_streams > 1 && stream_stride < touched)) {
+        set_error("wmx_vad_process: strides (%ld, %ld) smaller than what a call touches (%ld samples: %d channel(s), %d packet(s) per call)",
+                  stream_stride, call_stride, touched, h->chn, packets_per_call);
         return WMX_EINVAL;
     }
     const dim3 grid((h->n_streams + 63) / 64), block(64);
     hipStream_t s = as_stream(stream);
     const int nb = h->pkg / (h->freq / 8000);  // packet length at 8 kHz: 80 or 160
     const int ratio = h->freq / 8000;
-    // mono 10 ms packets at 8 / 16 kHz with 16-byte aligned rows -- the batched chain's case, one or several packets per call --
-    // go through the four-wave pipeline; every other shape (20 ms packets, 32 kHz, interleaved channels, odd alignment)
-    // through the one-lane-per-stream kernel
-    const bool pipe = h->chn == 1 && h->pkg == 80 * (h->freq / 8000) && h->freq <= 16000 &&
-                      (stream_stride % 8) == 0 && (call_stride % 8) == 0 && (reinterpret_cast<size_t>(d_pcm) % 16) == 0 &&
-                      !getenv("WMIX_AMD_VAD_ONE_LANE");
+    // mono 10 ms and 20 ms packets at 8 / 16 kHz with 16-byte aligned rows -- the batched chain's cases (10 ms handles, and the
+    // daemon's own 20 ms ones), one or several packets per call -- go through the four-wave pipeline; every other shape
+    // (32 kHz, interleaved channels, odd alignment) through the one-lane-per-stream kernel
+    const bool pipe = h->chn == 1 && (nb == 80 || nb == 160) && h->freq <= 16000 &&
+                      (stream_stride % 8) == 0 && (call_stride % 8) == 0 && (reinterpret_cast<size_t>(d_pcm) % 16) == 0 && !h->one_lane;
     if (pipe) {
-        if (h->freq == 8000)
-            hipLaunchKernelGGL((vad_pipe_kernel<1>), grid, dim3(256), 0, s, h->d_s16, h->d_s32, d_pcm, h->n_streams, packets_per_call, n_calls,
-                               stream_stride, call_stride, h->life.d_active);
+#define VAD_PIPE(R, NB)                                                                                                          \
+    hipLaunchKernelGGL((vad_pipe_kernel<R, NB>), grid, dim3(256), 0, s, h->d_s16, h->d_s32, d_pcm, h->n_streams, packets_per_call, \
+                       n_calls, stream_stride, call_stride, h->life.d_active)
+        if (ratio == 1 && nb == 80)
+            VAD_PIPE(1, 80);
+        else if (ratio == 2 && nb == 80)
+            VAD_PIPE(2, 80);
+        else if (ratio == 1)
+            VAD_PIPE(1, 160);
         else
-            hipLaunchKernelGGL((vad_pipe_kernel<2>), grid, dim3(256), 0, s, h->d_s16, h->d_s32, d_pcm, h->n_streams, packets_per_call, n_calls,
-                               stream_stride, call_stride, h->life.d_active);
+            VAD_PIPE(2, 160);
+#undef VAD_PIPE
         WMX_LAUNCH_CHECK();
         return 0;
     }

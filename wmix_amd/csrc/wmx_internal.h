@@ -161,7 +161,10 @@ struct StreamLife {
     int set_active(int n_streams, const uint8_t *host_mask, hipStream_t s) {
         if (!host_mask) {
             if (d_active) {
-                WMX_HIP_RC(hipStreamSynchronize(s));  // kernels in flight still read it
+                // kernels in flight still read it, on `s` or on any other stream the caller ran this handle on: the whole
+                // device is drained before the mask goes (a control-plane call, rare)
+                (void)s;
+                WMX_HIP_RC(hipDeviceSynchronize());
                 (void)hipFree(d_active);
                 d_active = nullptr;
             }
@@ -247,6 +250,8 @@ inline hipError_t column_from_host(T *dev, const T *host, int fields, int n_stre
 
 // chain.hip -> aec.hip: let the far kernel of the next wmx_aec_run_* call start at this point of `stream` (see aec.hip)
 int aec_fork_far(wmx_aec *h, hipStream_t stream);
+// the caller returns without the AEC call the fork was made for: the next wmx_aec_run_* starts on its own stream again
+void aec_cancel_fork(wmx_aec *h);
 
 // wmix_pcm_zoom's cursor walk (src/wmix.c:139-222) as a gather list: out int16 i <- in int16 idx[i]; identical formats
 // give the identity (the reference's memcpy branch).  Defined in mix.hip.

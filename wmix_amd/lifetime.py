@@ -29,6 +29,23 @@ class Lifetime:
     def reset_cohort(self, cohort):
         check(getattr(lib(), "wmx_%s_reset_cohort" % self._mod)(self._h, int(cohort), _stream()), "reset_cohort")
 
+    def add_cohort(self):
+        """A new control cohort (AEC / chain): aec_init of the shared part now; returns its id (a retired one when there is
+        one).  The per-cohort sequences of run_cohorts / process have n_cohorts entries afterwards."""
+        import ctypes as C
+        c = C.c_int(-1)
+        check(getattr(lib(), "wmx_%s_add_cohort" % self._mod)(self._h, C.byref(c), _stream()), "add_cohort")
+        n = getattr(lib(), "wmx_%s_cohorts" % self._mod)(self._h)
+        if self._mod == "aec":
+            self.n_far = n
+        else:
+            self.n_cohorts = n
+        return c.value
+
+    def retire_cohort(self, cohort):
+        """Every member of the cohort was released: it is never called again, its id may be handed out again."""
+        check(getattr(lib(), "wmx_%s_retire_cohort" % self._mod)(self._h, int(cohort)), "retire_cohort")
+
     def set_active(self, mask):
         """mask: n_streams booleans (False = the stream is not called: state and PCM rows untouched) or None = all."""
         if mask is None:
