@@ -911,15 +911,19 @@ class StubCpuWorkload:
     dominant_bytes_per_frame = 640.0
     needs_gpu = False
 
-    def __init__(self, dev, n_streams, rank, dist=None, packets=1):
+    def __init__(self, dev, n_streams, rank, dist=None, packets=1, stream_offset=0):
         from wmix_amd.shard import broadcast_far
+        if os.environ.get("WMIX_STUB_CHATTER") == "1" and rank > 0:  # tests: what ranks > 0 print is kept by the launcher
+            print("stub rank %d says hello" % rank, flush=True)
         if os.environ.get("WMIX_STUB_FAIL_RANK") == str(rank):  # tests: one rank dies after the rendezvous
             sys.exit(7)
         self._bcast = broadcast_far
         self.n_frames = n_streams
         self.dist, self.rank = dist, rank
+        self.lo = stream_offset  # global id of this rank's first stream (--total-streams: contiguous ranges, remainder on the first ranks)
         self.far = torch.zeros(160, dtype=torch.int16)
         self.acc = torch.zeros(n_streams, 160, dtype=torch.int32)
+        self.gid = (torch.arange(n_streams, dtype=torch.int32) + self.lo) % 5  # what a stream adds depends on its GLOBAL id
         self.k = 0
 
     def step(self, timed):
@@ -927,13 +931,21 @@ class StubCpuWorkload:
         if self.rank == 0:
             self.far.fill_(self.k)
         self._bcast(self.far, self.dist, src=0)
-        self.acc += self.far.to(torch.int32)[None, :]
+        self.acc += self.far.to(torch.int32)[None, :] + self.gid[:, None]
 
     def dominant_ms(self):
         return None
 
     def config(self):
-        return {"workload": self.name, "streams_per_gpu": self.n_frames, "far_sum": int(self.acc[0, 0].item())}
+        return {"workload": self.name, "streams_per_gpu": self.n_frames,
+                "far_sum": int((self.acc[0, 0] - self.k * self.gid[0]).item()) if self.n_frames else None}
+
+    def parity_check(self):
+        """every stream of this rank heard every far-end packet and knows its own global id (the `oracle` is arithmetic)"""
+        want = self.k * (self.k + 1) // 2 + self.k * self.gid.to(torch.int64)
+        ok = bool((self.acc.to(torch.int64) == want[:, None]).all().item())
+        return {"streams": self.n_frames, "range": [self.lo, self.lo + self.n_frames], "packets_compared": self.k * self.n_frames,
+                "max_lsb": 0 if ok else 1 << 15, "steps_replayed": self.k}
 
     def cpu_baseline(self, budget_s):
         return None
@@ -956,13 +968,24 @@ def _launch_ranks(n, argv):
     and relay rank 0's JSON line.  The parent has imported torch but made no HIP call (importing torch does not
     initialise the GPU), and it starts children -- it never replaces itself with another program."""
     import subprocess
+    import tempfile
+    import threading
     port = _free_port()
-    procs = []
+    procs, spill = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", WMIX_BENCH_LAUNCHED_BY="bench.py")
+        # ranks > 0 print nothing on success; what they do print (a traceback's first half, a library's chatter) is kept in a
+        # temporary file and shown when the launch fails
+        f = None if r == 0 else tempfile.TemporaryFile()
+        spill.append(f)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+                                      stdout=subprocess.PIPE if r == 0 else f))
+    # rank 0's line is read WHILE the ranks run: a line longer than the pipe's buffer (the per-rank parity records of 8 ranks)
+    # would otherwise block rank 0 in write() until the time limit (round-3 ADVICE)
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     # Poll every rank: when one dies (bad device index, library missing on that rank) the others would sit in the rendezvous
     # or in a barrier until the collective's own timeout -- end them, and say which rank failed with what code.
     limit = float(os.environ.get("WMIX_BENCH_LAUNCH_TIMEOUT_S", "3000"))
@@ -989,10 +1012,17 @@ def _launch_ranks(n, argv):
             except subprocess.TimeoutExpired:
                 p.kill()
                 p.wait()
-    out0 = procs[0].stdout.read() if procs[0].stdout else b""
+    reader.join(timeout=30)
+    out0 = b"".join(chunks)
     sys.stdout.write(out0.decode(errors="replace"))
     sys.stdout.flush()
     if failed:
+        for r, f in enumerate(spill):
+            if f is not None:
+                f.seek(0)
+                txt = f.read().decode(errors="replace").strip()
+                if txt:
+                    sys.stderr.write("---- stdout of rank %d ----\n%s\n" % (r, txt[-4000:]))
         sys.stderr.write("bench.py: ranks failed (rank, exit code): %s; the other ranks were stopped\n" % failed)
         bad_codes = [rc for _, rc in failed if isinstance(rc, int)]
         return bad_codes[0] if bad_codes and 0 < bad_codes[0] < 256 else 1
@@ -1006,6 +1036,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=0, help="streams (frames per step) per GPU; 0 = workload default")
+    ap.add_argument("--total-streams", type=int, default=0,
+                    help="shard THIS many streams over the ranks instead of --streams per GPU: contiguous ranges, the remainder on the "
+                         "first ranks (wmix_amd.shard.stream_range); the line then says scaling: strong")
     ap.add_argument("--prime", type=int, default=256,
                     help="untimed steps run before the warm-up so that every stream is past the reference's start-up phases "
                          "(NS: 200 blocks of noise-model start-up, ns_core.c:1103-1160; AEC: pass-through until the far-end "
@@ -1071,12 +1104,32 @@ def main():
         from wmix_amd import _lib
         _lib.lib()  # no fallback: raises when the HIP library is missing
 
+    n_mine, lo = args.streams or default_streams, 0
+    if args.total_streams:
+        from wmix_amd.shard import stream_range
+        lo, hi = stream_range(args.total_streams, rank, world)
+        n_mine = hi - lo
+        if n_mine < 1:
+            sys.stderr.write("bench.py: --total-streams %d leaves rank %d of %d without a stream\n" % (args.total_streams, rank, world))
+            sys.exit(2)
+    # one rank per GPU: the rank's device IS its LOCAL_RANK, and the collective library sees every rank (checked, not assumed:
+    # the first run on a real 8-GPU node must not silently put two ranks on one device)
+    rank_device = None
+    if on_gpu:
+        rank_device = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(),
+                       "name": torch.cuda.get_device_name(torch.cuda.current_device()),
+                       "uuid": str(getattr(torch.cuda.get_device_properties(torch.cuda.current_device()), "uuid", ""))}
+        if dist is not None and backend == "nccl":
+            assert torch.cuda.current_device() == local_rank, "rank %d: current device %d, LOCAL_RANK %d" % (rank, torch.cuda.current_device(), local_rank)
+            assert dist.get_world_size() == world, "RCCL sees %d ranks, the launcher started %d" % (dist.get_world_size(), world)
     if issubclass(cls, ChainWorkload):
-        wl = cls(dev, args.streams or default_streams, rank, dist, args.packets_per_step, args.interval_ms, args.cohorts, args.cohort_layout)
-    elif issubclass(cls, (StubCpuWorkload, AecmWorkload)):
-        wl = cls(dev, args.streams or default_streams, rank, dist, args.packets_per_step)
+        wl = cls(dev, n_mine, rank, dist, args.packets_per_step, args.interval_ms, args.cohorts, args.cohort_layout)
+    elif issubclass(cls, StubCpuWorkload):
+        wl = cls(dev, n_mine, rank, dist, args.packets_per_step, lo)
+    elif issubclass(cls, AecmWorkload):
+        wl = cls(dev, n_mine, rank, dist, args.packets_per_step)
     else:
-        wl = cls(dev, args.streams or default_streams, rank)
+        wl = cls(dev, n_mine, rank)
 
     def sync_all():
         if on_gpu:
@@ -1121,13 +1174,21 @@ def main():
     if hasattr(wl, "timed_region"):
         wl.timed_region(False)
     per_rank_ms = [elapsed / args.steps * 1e3]
+    per_rank_frames = [wl.n_frames]
+    rank_devices = [rank_device]
     if dist is not None:
         # max over ranks is the job's time; every rank's own figure rides along for the record
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, float(wl.n_frames)], dtype=torch.float64, device=dev)
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)
-        per_rank_ms = [float(x.item()) / args.steps * 1e3 for x in every]
-        elapsed = max(float(x.item()) for x in every)
+        per_rank_ms = [float(x[0].item()) / args.steps * 1e3 for x in every]
+        per_rank_frames = [int(x[1].item()) for x in every]
+        elapsed = max(float(x[0].item()) for x in every)
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, rank_device)
+        if backend == "nccl" and world > 1 and os.environ.get("WMIX_BENCH_ONE_GPU_GLOO") != "1":
+            devs = [d["device"] for d in rank_devices]
+            assert len(set(devs)) == world, "ranks share a device: %s" % rank_devices
 
     # per-stage breakdown: a few extra steps with every launch bracketed by events, outside the timed region
     for _ in range(min(args.steps, 16)):
@@ -1139,7 +1200,7 @@ def main():
         wl.measure_pcie(min(args.steps, 100))
     else:
         parity_early = None
-    frames_total = wl.n_frames * args.steps * world
+    frames_total = sum(per_rank_frames) * args.steps  # every rank's own share (equal without --total-streams)
     value = frames_total / elapsed
     dom_ms = wl.dominant_ms()
     roofline = None
@@ -1166,12 +1227,15 @@ def main():
         "timed_by": ("HIP events recorded in the launch stream around the K timed steps (max over ranks), %d untimed spin-up steps "
                      "queued in front; barrier + synchronize on both sides of spin-up + region" % args.spinup) if on_gpu else "host clock",
         "host_wall_ms_per_step": host_elapsed / args.steps * 1e3,
-        "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
+        "scaling": "strong" if args.total_streams else "weak", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
         "config": dict(wl.config(), primed_steps=n_prime), "roofline": roofline,
         "stage_ms": wl.stage_ms() if hasattr(wl, "stage_ms") else None,
         "stage_ms_source": "mean over up to 16 extra steps after the timed region, outliers beyond 5x the median dropped (inside the timed region only the dominant kernel carries events)",
         "whole_step_hbm_frac": round(value / world * wl.bytes_per_frame / 1e9 / HBM_PEAK_GBS, 5),
+        "total_streams": args.total_streams or None,
         "per_rank_ms_per_step": [round(x, 5) for x in per_rank_ms],
+        "per_rank_frames_per_step": per_rank_frames,
+        "rank_devices": rank_devices if on_gpu else None,
         # the size the collective library itself reports (backend nccl = RCCL on ROCm); None on one rank
         "rccl_ranks": (dist.get_world_size() if dist is not None and backend == "nccl" else None),
         "dist_backend": backend,

@@ -8,13 +8,14 @@
  * (the single exchange of the path; a host that produces the far-end on a GPU uses one ncclBroadcast instead),
  * uploads its shard's captured packets, makes ONE library call (wmx_chain_process) and downloads the result.
  *
- *   host_chain far.i16 near.i16 out.i16 n_streams n_ticks [n_workers] [freq]
+ *   host_chain far.i16 near.i16 out.i16 n_streams n_ticks [n_workers] [freq] [--devices k]
  *
  * far.i16  int16 [n_ticks][pkt]             the shared far-end          (pkt = freq / 100 samples, mono)
  * near.i16 int16 [n_streams][n_ticks][pkt]  captured audio, stream-major
  * out.i16  same shape as near.i16           what the chain leaves in the daemon's buffer
- * n_workers defaults to wmx_device_count(); worker w runs on device w % device_count, so a 1-GPU box can still drive
- * several shards (tests/test_host_chain_gpu.py does, and compares out.i16 with the oracle).
+ * n_workers defaults to the device count; worker w runs on device w % device_count, so a 1-GPU box can still drive
+ * several shards (tests/test_host_chain_gpu.py does, and compares out.i16 with the oracle).  --devices k: use the first k
+ * devices of the node (default: all of them), so that one binary covers 1 ... 8 GPUs.
  *
  * Built with -DWMX_EXAMPLE_RCCL (examples/host_chain_rccl, links librccl) the far-end travels the way north_star puts it:
  * worker 0 alone uploads the packet, and ONE ncclBroadcast per tick (every worker calls it on its own communicator and stream)
@@ -44,6 +45,8 @@ typedef struct {
     const int16_t *near_host;    /* [n_streams][n_ticks][pkt] */
     int16_t *out_host;
     pthread_barrier_t *tick;
+    volatile int *any_failed;    /* set by a worker that failed: from the next collective on, nobody calls it (a worker that
+                                  * skipped its ncclBroadcast would leave the others waiting in theirs for ever) */
     int rc;
     double busy_ms;
 #ifdef WMX_EXAMPLE_RCCL
@@ -93,11 +96,28 @@ static void *gpu_worker(void *arg) {
     /* the handle remembers its device: from here on nothing depends on the thread's current device */
     for (int t = 0; t < s->n_ticks; t++) {
         pthread_barrier_wait(s->tick); /* the 10 ms heartbeat: every worker starts tick t together */
+#ifdef WMX_EXAMPLE_RCCL
+        if (!created || s->rc) { /* keep the barrier count even after a failure, and tell the others before their collective */
+            *s->any_failed = 1;
+            pthread_barrier_wait(s->tick);
+            continue;
+        }
+#else
         if (!created || s->rc) continue; /* keep the barrier count even after a failure */
+#endif
         const double t0 = now_ms();
 #ifdef WMX_EXAMPLE_RCCL
         /* the far-end reaches GPU 0 from the host and every other GPU from GPU 0 (the path's one exchange) */
-        if (s->worker == 0) HIP_OK(hipMemcpyAsync(d_far, s->far_host + (size_t)t * s->pkt, row, hipMemcpyHostToDevice, st));
+        if (s->worker == 0 && hipMemcpyAsync(d_far, s->far_host + (size_t)t * s->pkt, row, hipMemcpyHostToDevice, st) != hipSuccess) {
+            fprintf(stderr, "worker 0: far-end upload failed\n");
+            s->rc = 1;
+        }
+        if (s->rc) *s->any_failed = 1;
+        pthread_barrier_wait(s->tick); /* everybody knows by now whether everybody will call the collective */
+        if (*s->any_failed) {
+            s->rc = 1;
+            goto done;
+        }
         {
             ncclResult_t nr = ncclBroadcast(d_far, d_far, row, ncclInt8, 0, s->comm, st);
             if (nr != ncclSuccess) {
@@ -138,16 +158,29 @@ static void *read_file(const char *path, size_t bytes) {
 }
 
 int main(int argc, char **argv) {
+    int want_dev = 0;
+    for (int i = 1; i + 1 < argc; i++) /* --devices k, wherever it stands: taken out of the positional arguments */
+        if (strcmp(argv[i], "--devices") == 0) {
+            want_dev = atoi(argv[i + 1]);
+            for (int j = i; j + 2 < argc; j++) argv[j] = argv[j + 2];
+            argc -= 2;
+            break;
+        }
     if (argc < 6) {
-        fprintf(stderr, "usage: %s far.i16 near.i16 out.i16 n_streams n_ticks [n_workers] [freq]\n", argv[0]);
+        fprintf(stderr, "usage: %s far.i16 near.i16 out.i16 n_streams n_ticks [n_workers] [freq] [--devices k]\n", argv[0]);
         return 2;
     }
     const int n_streams = atoi(argv[4]), n_ticks = atoi(argv[5]);
-    const int n_dev = wmx_device_count();
+    int n_dev = wmx_device_count();
     if (n_dev < 1) {
         fprintf(stderr, "host_chain: no HIP device (%s)\n", wmx_last_error());
         return 3;
     }
+    if (want_dev > n_dev || want_dev < 0) {
+        fprintf(stderr, "host_chain: --devices %d, %d present\n", want_dev, n_dev);
+        return 2;
+    }
+    if (want_dev > 0) n_dev = want_dev;
     int n_workers = argc > 6 ? atoi(argv[6]) : n_dev;
     const int freq = argc > 7 ? atoi(argv[7]) : 16000;
     const int pkt = freq / 100;
@@ -175,6 +208,7 @@ int main(int argc, char **argv) {
     Shard *sh = calloc((size_t)n_workers, sizeof(Shard));
     pthread_t *th = calloc((size_t)n_workers, sizeof(pthread_t));
     pthread_barrier_t tick;
+    static volatile int any_failed = 0;
     pthread_barrier_init(&tick, NULL, (unsigned)n_workers);
     /* contiguous stream ranges, the remainder spread over the first workers (wmix_amd/shard.py: stream_range) */
     const int base = n_streams / n_workers, rem = n_streams % n_workers;
@@ -192,6 +226,7 @@ int main(int argc, char **argv) {
         s->near_host = near;
         s->out_host = out;
         s->tick = &tick;
+        s->any_failed = &any_failed;
 #ifdef WMX_EXAMPLE_RCCL
         s->comm = comms[w];
 #endif

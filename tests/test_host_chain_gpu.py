@@ -52,11 +52,15 @@ def test_host_chain_far_end_through_rccl(tmp_path, oracle_port):
     near = synth.near_end(9711, S, T, pkt, far=far).reshape(S, T * pkt)
     far.astype("<i2").tofile(tmp_path / "far.i16")
     near.astype("<i2").tofile(tmp_path / "near.i16")
-    r = subprocess.run([EXE_RCCL, str(tmp_path / "far.i16"), str(tmp_path / "near.i16"), str(tmp_path / "out.i16"), str(S), str(T)],
+    # --devices k: the first k devices of the node (one binary for 1 ... 8 GPUs); more than the box has is refused
+    r = subprocess.run([EXE_RCCL, str(tmp_path / "far.i16"), str(tmp_path / "near.i16"), str(tmp_path / "out.i16"), str(S), str(T), "--devices", "99"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 2 and "--devices 99" in r.stderr
+    r = subprocess.run([EXE_RCCL, "--devices", "1", str(tmp_path / "far.i16"), str(tmp_path / "near.i16"), str(tmp_path / "out.i16"), str(S), str(T)],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     info = json.loads(r.stdout.strip().splitlines()[-1])
-    assert info["rc"] == 0 and info["far_end"].startswith("ncclBroadcast") and info["workers"] == info["devices"]
+    assert info["rc"] == 0 and info["far_end"].startswith("ncclBroadcast") and info["workers"] == info["devices"] == 1
     got = np.fromfile(tmp_path / "out.i16", dtype="<i2").reshape(S, T * pkt)
     want = np.stack([L.run_chain(oracle_port, 1, freq, 5, 15, far, near[s], pkt, prefix="orc") for s in range(S)])
     check_float_path(got, want, max_fraction=1e-4)

@@ -54,3 +54,24 @@ def test_rccl_itself_under_the_multi_rank_code_path():
     assert "RCCL broadcast" in d["config"]["far_end"]
     assert len(d["parity_checked_ranks"]) == 1 and d["parity_checked_ranks"][0]["max_lsb"] <= 1
     assert d["parity_checked_ranks"][0]["packets_compared"] > 0
+
+
+def test_one_rank_under_the_launcher_measures_what_the_direct_line_measures():
+    """The driver's SCALE run starts N = 1 through torch.distributed.run like every other N; its line must be the direct
+    `python bench.py` line (same timed region, same steady state), or the scaling curve's first point is off (round-3 VERDICT).
+    Also: the rank's device is its LOCAL_RANK and is reported."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--gpus", "1", "--workload", "chain", "--steps", "40", "--warmup", "5", "--no-cpu"]
+    a = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, env=env, capture_output=True, text=True, timeout=900)
+    assert a.returncode == 0, a.stderr[-3000:]
+    b = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29619", os.path.join(ROOT, "bench.py")] + common, env=env, capture_output=True, text=True, timeout=900)
+    assert b.returncode == 0, b.stderr[-3000:]
+    da = json.loads([l for l in a.stdout.splitlines() if l.startswith("{")][0])
+    db = json.loads([l for l in b.stdout.splitlines() if l.startswith("{")][0])
+    assert da["launched_by"] == "direct" and db["launched_by"] == "torchrun" and da["n_gpus"] == db["n_gpus"] == 1
+    assert abs(da["ms_per_step"] - db["ms_per_step"]) / da["ms_per_step"] < 0.03, (da["ms_per_step"], db["ms_per_step"])
+    assert da["parity_checked"]["max_lsb"] <= 1 and db["parity_checked"]["max_lsb"] <= 1
+    for d in (da, db):
+        assert d["rank_devices"][0]["device"] == d["rank_devices"][0]["local_rank"] == 0 and d["rank_devices"][0]["name"]

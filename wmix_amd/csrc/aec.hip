@@ -32,6 +32,7 @@
 // noise come from the host's libm through the plan.
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstddef>
 #include <vector>
 #include "wmx_internal.h"
@@ -320,6 +321,11 @@ __device__ unsigned long long g_aec_prof[16];
         t_prev = clock64();                                                      \
     } while (0)
 #define AEC_PROF_START long long t_prev = clock64()
+#elif defined(WMX_AEC_EXP_BARRIERS)
+// timing-only experiment (round-4): what the hand-offs of a helper-wave design would cost -- a workgroup barrier at
+// every phase boundary of a block (ten per block), valid only while the four streams of a workgroup run the same plan
+#define AEC_PROF(i) __builtin_amdgcn_s_barrier()
+#define AEC_PROF_START
 #else
 #define AEC_PROF(i)
 #define AEC_PROF_START
@@ -1071,17 +1077,29 @@ __global__ __attribute__((amdgpu_waves_per_eu(WMX_AEC_WAVES, WMX_AEC_WAVES))) __
                                                                           const float *__restrict__ noise,
                                                                           const int16_t *near_pcm, int16_t *out_pcm, int n_streams,
                                                                           long stream_stride, long packet_stride, int chn, int pkg,
-                                                                          const int *__restrict__ stream_far, const uint8_t *__restrict__ active) {
+                                                                          const int *__restrict__ stream_far, const uint8_t *__restrict__ active,
+                                                                          const int *__restrict__ order) {
     __shared__ AecConstsNear K;
     __shared__ AecWaveLds Wv[kAecWavesPerBlock];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: state pointers become scalar bases
-    const int sidx = blockIdx.x * kAecWavesPerBlock + wave;  // one stream per wave
-    const bool live = stream_active(active, sidx, n_streams);  // no stream, or one that is switched off: nothing touched
+    // One stream per wave.  With several cohorts in the batch the streams are taken in COHORT order, and so that a cohort's
+    // streams meet in one L2: workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one), so workgroup i
+    // takes chunk (i % 8) * (grid / 8) + i / 8 of the cohort-sorted list -- every XCD works through one contiguous eighth of the
+    // cohorts, and the far-end history rows a block reads (48 rows of its cohort, the same for all members) are hits of that
+    // XCD's 4 MB L2 instead of 4 096 cohorts' rows competing for each of them (order == nullptr: one cohort, stream = slot).
+    int sidx;
+    if (order) {
+        const unsigned i = blockIdx.x, per = gridDim.x >> 3;
+        sidx = __builtin_amdgcn_readfirstlane(order[((i & 7u) * per + (i >> 3)) * kAecWavesPerBlock + wave]);  // -1: no stream
+    } else {
+        sidx = blockIdx.x * kAecWavesPerBlock + wave;
+    }
+    const bool live = sidx >= 0 && stream_active(active, sidx, n_streams);  // no stream, or one that is switched off: nothing touched
     // Everything this wave needs from memory is requested up front -- its first near-end packet, the 24 filter rows, the
     // LDS part of the state, the constants -- and waited for ONCE, at the workgroup barrier; issued phase by phase, each
     // group costs its own HBM round trip.  (A wave without a stream reads stream 0 and leaves after the barrier.)
-    const int sl = sidx < n_streams ? sidx : 0;
+    const int sl = (sidx >= 0 && sidx < n_streams) ? sidx : 0;
     // the far-end this stream is cancelled against (one per batch unless the handle was created with far-end groups):
     // wave-uniform, so the group's buffers are scalar bases like the single far-end's
     const int grp = stream_far ? __builtin_amdgcn_readfirstlane(stream_far[sl]) : 0;
@@ -1275,6 +1293,14 @@ struct wmx_aec {
     int cap_far;             // cohorts the device buffers (far slabs, plan slots, noise rows) are allocated for; grows by doubling
     std::vector<uint8_t> live;  // [n_far] 0: retired by wmx_aec_retire_cohort (never called, its id is handed out again)
     int *d_stream_far;       // [n_streams] group of each stream, or nullptr while there has only ever been one
+    // cohort-sorted, XCD-aware stream order of the near kernel (see aec_near_kernel); rebuilt on the host when memberships changed
+    std::vector<int32_t> h_cohort_of;  // [n_streams] host mirror of d_stream_far
+    std::vector<int32_t> h_order;
+    int32_t *d_order;         // [order_wgs * 4] stream of every (chunk, wave), -1 = none; nullptr while one cohort
+    unsigned order_wgs;       // workgroups of an ordered launch: a multiple of 8
+    bool order_dirty;
+    int order_age;            // launches since the order was rebuilt: under churn it is rebuilt every kOrderEvery launches at most
+    static constexpr int kOrderEvery = 16;
     wmx::AecNoiseEntry *d_noise_tab;  // cosf / sinf of the comfort noise's 32 768 possible phases (host libm, aec_ctl.h)
     float *d_noise;          // [noise_pkts][cap_far][kAecNoiseRow]: what the far kernel makes of the plans' seeds for the near kernel
     int noise_pkts;
@@ -1290,6 +1316,7 @@ struct wmx_aec {
     hipStream_t side;
     hipEvent_t ev_fork, ev_join;
     bool fork_pending;
+    bool no_order;  // WMIX_AMD_AEC_NO_ORDER (developer A/B switch, read at create): streams in slot order whatever their cohorts
     // per-call scratch kept with the handle (no allocation on the heartbeat's path)
     std::vector<int> rc_g;           // [n_far] what the wrapper would have returned to the members of each cohort
     std::vector<int32_t> same_delay; // [n_far] the one reported delay of wmx_aec_run / _run_groups, spread over the cohorts
@@ -1310,6 +1337,7 @@ int wmx_aec_destroy(wmx_aec *h) {
     if (h->d_plans) (void)hipFree(h->d_plans);
     if (h->h_plans) (void)hipHostFree(h->h_plans);
     if (h->d_stream_far) (void)hipFree(h->d_stream_far);
+    if (h->d_order) (void)hipFree(h->d_order);
     if (h->d_noise_tab) (void)hipFree(h->d_noise_tab);
     if (h->d_noise) (void)hipFree(h->d_noise);
     if (h->d_tmpl) (void)hipFree(h->d_tmpl);
@@ -1326,6 +1354,34 @@ int wmx_aec_destroy(wmx_aec *h) {
 
 int wmx_aec_create(wmx_aec **out, int n_streams, int chn, int freq, int interval_ms) {
     return wmx_aec_create_groups(out, n_streams, chn, freq, interval_ms, 1, nullptr);
+}
+
+// The near kernel's stream order: streams sorted by cohort (stable), cut into chunks of one workgroup (4 streams); the kernel maps
+// its workgroup index to a chunk so that every XCD gets a contiguous eighth of the chunks.  Any permutation is CORRECT (a wave
+// finds its stream's cohort in d_stream_far); the order only decides which far-end rows meet in which L2.
+static int aec_rebuild_order(wmx_aec *h, hipStream_t s) {
+    using namespace wmx;
+    const int S = h->n_streams, G = h->n_far;
+    const unsigned wgs = (unsigned)((S + kAecWavesPerBlock - 1) / kAecWavesPerBlock), wgs8 = (wgs + 7u) / 8u * 8u;
+    std::vector<int32_t> start((size_t)G + 1, 0);
+    for (int i = 0; i < S; i++) start[(size_t)h->h_cohort_of[(size_t)i] + 1]++;
+    for (int g = 0; g < G; g++) start[(size_t)g + 1] += start[(size_t)g];
+    h->h_order.assign((size_t)wgs8 * kAecWavesPerBlock, -1);
+    for (int i = 0; i < S; i++) h->h_order[(size_t)start[(size_t)h->h_cohort_of[(size_t)i]]++] = i;
+    if (!h->d_order || h->order_wgs != wgs8) {
+        if (h->d_order) {
+            WMX_HIP_RC(hipDeviceSynchronize());
+            (void)hipFree(h->d_order);
+            h->d_order = nullptr;
+        }
+        WMX_HIP_RC(hipMalloc(reinterpret_cast<void **>(&h->d_order), h->h_order.size() * sizeof(int32_t)));
+        h->order_wgs = wgs8;
+    }
+    // in stream order behind the launches that read the previous order (pageable source: the runtime stages it before returning)
+    WMX_HIP_RC(hipMemcpyAsync(h->d_order, h->h_order.data(), h->h_order.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    h->order_dirty = false;
+    h->order_age = 0;
+    return 0;
 }
 
 // floats of one cohort's far-end slab (AecFarBufs carved out of it)
@@ -1450,12 +1506,20 @@ int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int i
     h->side = nullptr;
     h->ev_fork = h->ev_join = nullptr;
     h->fork_pending = false;
+    h->no_order = getenv("WMIX_AMD_AEC_NO_ORDER") != nullptr;
     h->d_plans = nullptr;
     h->h_plans = nullptr;
     h->d_stream_far = nullptr;
     h->d_noise_tab = nullptr;
     h->d_noise = nullptr;
     h->noise_pkts = 0;
+    h->d_order = nullptr;
+    h->order_wgs = 0;
+    h->order_dirty = n_far > 1;
+    h->order_age = wmx_aec::kOrderEvery;
+    h->h_cohort_of.assign((size_t)n_streams, 0);
+    if (n_far > 1 && stream_far)
+        for (int i = 0; i < n_streams; i++) h->h_cohort_of[(size_t)i] = stream_far[i];
     h->n_far = n_far;
     h->cap_far = 0;
     h->plan_sel = 0;
@@ -1730,14 +1794,21 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
             if (mode & 2) {
                 const int16_t *nin = d_near + (size_t)done * packet_stride;
                 int16_t *nout = d_out + (size_t)done * packet_stride;
-                const unsigned grid = (unsigned)((h->n_streams + kAecWavesPerBlock - 1) / kAecWavesPerBlock);
+                const bool ordered = h->d_stream_far != nullptr && !h->no_order;
+                if (ordered && (h->d_order == nullptr || (h->order_dirty && h->order_age >= wmx_aec::kOrderEvery))) {
+                    const int rc = aec_rebuild_order(h, s);
+                    if (rc != 0) return rc;
+                }
+                h->order_age++;
+                const int32_t *order = ordered ? h->d_order : nullptr;
+                const unsigned grid = ordered ? h->order_wgs : (unsigned)((h->n_streams + kAecWavesPerBlock - 1) / kAecWavesPerBlock);
                 const dim3 blk(64 * kAecWavesPerBlock);
                 if (h->freq == 8000)
                     hipLaunchKernelGGL((aec_near_kernel<1>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, chunk, G, h->d_noise, nin,
-                                       nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg, h->d_stream_far, h->life.d_active);
+                                       nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg, h->d_stream_far, h->life.d_active, order);
                 else
                     hipLaunchKernelGGL((aec_near_kernel<2>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, chunk, G, h->d_noise, nin,
-                                       nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg, h->d_stream_far, h->life.d_active);
+                                       nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg, h->d_stream_far, h->life.d_active, order);
                 WMX_LAUNCH_CHECK();
                 if (tv) WMX_HIP(hipEventRecord(tv[3], s));
             }
@@ -1767,8 +1838,11 @@ int wmx_aec_reset_streams(wmx_aec *h, const int32_t *idx, int n, int cohort, voi
     if (rc != 0) return rc;
     const unsigned grid = (unsigned)(n < 4096 ? n : 4096);
     hipLaunchKernelGGL((fill_rows_idx<float>), dim3(grid), dim3(256), 0, s, h->d_state, (const float *)h->d_tmpl, (int)AS_WORDS, d_idx, n);
-    if (cohort >= 0 && h->d_stream_far)
+    if (cohort >= 0 && h->d_stream_far) {
         hipLaunchKernelGGL(aec_set_group, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->d_stream_far, d_idx, n, cohort);
+        for (int i = 0; i < n; i++) h->h_cohort_of[(size_t)idx[i]] = cohort;
+        h->order_dirty = true;
+    }
     WMX_LAUNCH_CHECK();
     return h->life.done(s);
 }
@@ -1819,7 +1893,11 @@ int wmx_aec_import_stream(wmx_aec *h, int stream_index, const void *host_blob, i
     WMX_HIP(hipDeviceSynchronize());
     WMX_HIP(hipMemcpy(h->d_state + (size_t)stream_index * AS_WORDS, static_cast<const char *>(host_blob) + sizeof(BlobHeader), AS_WORDS * 4,
                       hipMemcpyHostToDevice));
-    if (cohort >= 0 && h->d_stream_far) WMX_HIP(hipMemcpy(h->d_stream_far + stream_index, &cohort, sizeof(int), hipMemcpyHostToDevice));
+    if (cohort >= 0 && h->d_stream_far) {
+        WMX_HIP(hipMemcpy(h->d_stream_far + stream_index, &cohort, sizeof(int), hipMemcpyHostToDevice));
+        h->h_cohort_of[(size_t)stream_index] = cohort;
+        h->order_dirty = true;
+    }
     return 0;
 }
 
