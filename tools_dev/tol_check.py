@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main(n_pick=64):
+def main(n_pick=64, stages=15):
     import torch
     from oracle import loader as L
     from test_aec_gpu import gpu_chain
@@ -24,14 +24,14 @@ def main(n_pick=64):
         S, n = 256, 3000
         far = synth.far_end(8001, n, pkt)
         near = synth.near_end(8100, S, n, pkt, far=far)
-        got = gpu_chain(cuda, 1, freq, 15, far, near, pkts_per_launch=50)
+        got = gpu_chain(cuda, 1, freq, stages, far, near, pkts_per_launch=50)
         pick = np.random.default_rng(8).choice(S, n_pick, replace=False)
         port = L.port()
-        want = np.stack([L.run_chain(port, 1, freq, 5, 15, far, near[s], pkt, prefix="orc") for s in pick])
+        want = np.stack([L.run_chain(port, 1, freq, 5, stages, far, near[s], pkt, prefix="orc") for s in pick])
         d = np.abs(got[pick].astype(np.int32) - want.astype(np.int32)).reshape(n_pick, n, pkt)
         early, late = d[:, :56], d[:, 56:]
         bad = np.argwhere(late.max(2) > 1)
-        print(json.dumps({"lib": os.environ.get("WMIX_AMD_LIB", "default"), "freq": freq, "streams": n_pick, "packets": n,
+        print(json.dumps({"lib": os.environ.get("WMIX_AMD_LIB", "default"), "freq": freq, "stages": stages, "streams": n_pick, "packets": n,
                           "max_lsb_packets_0_55": int(early.max()), "max_lsb_packets_56_on": int(late.max()),
                           "samples_off_from_56_on": int((late > 0).sum()), "samples_total_from_56_on": int(late.size),
                           "stream_packets_beyond_1_lsb_from_56_on": len(bad),

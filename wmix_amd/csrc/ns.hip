@@ -538,18 +538,42 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
                 // samples leave most of the 1000 bins empty.  64 bins per coalesced load, occupied ones found by ballot.
                 // (a macro, not a lambda: with the accumulators captured by reference through two lambda levels the
                 // compiler kept them in scratch memory)
-#define NS_WALK(which, ...)                                                                  \
-    for (int base = 0; base < kHistBins; base += 64) {                                       \
-        const int ii = base + lane;                                                          \
-        const int hv = ii < kHistBins ? (int)hist[(which) * kHistBins + ii] : 0;             \
-        unsigned long long m = __builtin_amdgcn_ballot_w64(hv != 0);                         \
-        while (m) {                                                                          \
-            const int j = __builtin_ctzll(m);                                                \
-            m &= m - 1;                                                                      \
-            const int i = base + j, h = __builtin_amdgcn_readlane(hv, j);                    \
-            __VA_ARGS__                                                                      \
-        }                                                                                    \
+                // A histogram reaches the wave in ONE round trip: its 500 dwords as eight coalesced loads per lane, issued together,
+                // then staged through the (dead at this point) FFT work array 2 L bins at a time and walked from LDS.
+                // Walking it with one dependent 64-bin load per step cost 48 serial HBM round trips per update: ~150 us for the
+                // one stream in 500 that updates in a given frame -- invisible while every stream of a batch has the same age
+                // (one slow launch in 500), but with streams of all ages (handles created at different ticks, the normal case
+                // for many handles) some wave of EVERY launch is in its update, and the launch lasts as long as its slowest wave:
+                // ns_kernel 0.30 -> 0.45 ms at 65 536 streams joined over 256 ticks (tools_dev/ns_age_exp.py, round 4).
+#define NS_WALK(which, ...)                                                                                        \
+    {                                                                                                              \
+        constexpr int CH_ = 2 * L, QPC_ = L / 64, NCH_ = 8 / QPC_; /* bins staged at a time (the work array holds L floats) */ \
+        const unsigned *hsrc_ = reinterpret_cast<const unsigned *>(hist + (which) * kHistBins);                    \
+        unsigned c_[8];                                                                                            \
+        _Pragma("unroll") for (int q = 0; q < 8; q++) {                                                            \
+            const int d_ = 64 * q + lane;                                                                          \
+            const unsigned v_ = hsrc_[d_ < kHistBins / 2 ? d_ : 0];                                                \
+            c_[q] = d_ < kHistBins / 2 ? v_ : 0u; /* bins past 999 are staged as zeros */                          \
+        }                                                                                                          \
+        _Pragma("unroll") for (int part_ = 0; part_ < NCH_; part_++) {                                             \
+            unsigned *stage_ = reinterpret_cast<unsigned *>(W.fa);                                                 \
+            _Pragma("unroll") for (int q = 0; q < QPC_; q++) stage_[64 * q + lane] = c_[QPC_ * part_ + q];         \
+            wave_sync();                                                                                           \
+            const unsigned short *h16_ = reinterpret_cast<const unsigned short *>(W.fa);                           \
+            _Pragma("unroll 1") for (int base = CH_ * part_; base < CH_ * part_ + CH_ && base < kHistBins; base += 64) { \
+                const int hv = (int)h16_[base - CH_ * part_ + lane];                                               \
+                unsigned long long m = __builtin_amdgcn_ballot_w64(hv != 0);                                       \
+                while (m) {                                                                                        \
+                    const int j = __builtin_ctzll(m);                                                              \
+                    m &= m - 1;                                                                                    \
+                    const int i = base + j, h = __builtin_amdgcn_readlane(hv, j);                                  \
+                    __VA_ARGS__                                                                                    \
+                }                                                                                                  \
+            }                                                                                                      \
+            wave_sync();                                                                                           \
+        }                                                                                                          \
     }
+                static_assert(L == 128 || L == 256, "the staging above is sized for these");
                 float avg = 0.0f, avg_compl = 0.0f, avg_sq = 0.0f;
                 int num = 0;
                 NS_WALK(0, {
