@@ -161,10 +161,29 @@ __device__ __forceinline__ uint32_t hist_word(const int16_t *hist, int w) {
     // from the previous window's scan when one launch spans more than 512 blocks)
     return __hip_atomic_load(reinterpret_cast<const uint32_t *>(hist) + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// the 500 words of one histogram, eight per lane (word lane + 64 q), requested TOGETHER: the scan is one L2 round trip, not eight
+// dependent ones -- it decides how long the slowest wave of a launch lives when the streams of a batch have different ages and
+// some wave of every launch is in its 512-block update (tools_dev/ns_age_exp.py nsx: 0.38 -> 0.48 ms per launch before)
+// (in two batches of four: eight values at once cost the kernels their register budget -- scratch spills)
+constexpr int kNsxHistBatch = 4, kNsxHistBatches = ((kNsxHist / 2 + 63) / 64 + kNsxHistBatch - 1) / kNsxHistBatch;
+__device__ __forceinline__ void hist_fetch(const int16_t *hist, int lane, int batch, uint32_t (&pr)[kNsxHistBatch]) {
+#pragma unroll
+    for (int q = 0; q < kNsxHistBatch; q++) {
+        const int w = lane + 64 * (kNsxHistBatch * batch + q);
+        const uint32_t v = hist_word(hist, w < kNsxHist / 2 ? w : 0);
+        pr[q] = w < kNsxHist / 2 ? v : 0u;  // past the end: empty bins (they add nothing and are never peaks)
+    }
+}
 __device__ void two_peaks(const int16_t *hist, int lane, uint32_t &pos1, int &w1) {
     uint32_t k1 = 0, k2 = 0;  // key = count << 16 | (0xFFFF - index); 0 = no peak (counts of 0 never become peaks)
-    for (int w = lane; w < kNsxHist / 2; w += 64) {
-        const uint32_t pair = hist_word(hist, w);
+#pragma unroll 1
+    for (int batch = 0; batch < kNsxHistBatches; batch++) {
+    uint32_t pr[kNsxHistBatch];
+    hist_fetch(hist, lane, batch, pr);
+#pragma unroll
+    for (int q = 0; q < kNsxHistBatch; q++) {
+        const int w = lane + 64 * (kNsxHistBatch * batch + q);
+        const uint32_t pair = pr[q];
 #pragma unroll
         for (int hlf = 0; hlf < 2; hlf++) {
             const int c = (int16_t)(hlf ? pair >> 16 : pair & 0xffff), i = 2 * w + hlf;
@@ -176,6 +195,7 @@ __device__ void two_peaks(const int16_t *hist, int lane, uint32_t &pos1, int &w1
                 k2 = key;
             }
         }
+    }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -666,12 +686,22 @@ __device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsSca
                 }
             }
         } else {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");  // the window's increments have landed
+            // The window's increments have landed: they are this wave's own (lanes 0..2, L2 atomics), nobody else touches the
+            // stream's histograms, and a wave's memory operations on one address are performed in order -- waiting for its
+            // outstanding ones is all it takes.  (An agent-scope acq_rel fence stood here: an L2 write-back per update, 2 ms
+            // when every stream of a 65 536-stream batch updated in the same launch.)
+            __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
             const int16_t *h_lrt = hist, *h_flat = hist + kNsxHist, *h_diff = hist + 2 * kNsxHist;
             int use_diff = 1;
             uint32_t a0 = 0, a1 = 0, a2 = 0, cn = 0;
-            for (int w = lane; w < kNsxHist / 2; w += 64) {
-                const uint32_t pair = hist_word(h_lrt, w);
+#pragma unroll 1
+            for (int batch = 0; batch < kNsxHistBatches; batch++) {
+            uint32_t pr[kNsxHistBatch];
+            hist_fetch(h_lrt, lane, batch, pr);
+#pragma unroll
+            for (int q = 0; q < kNsxHistBatch; q++) {
+                const int w = lane + 64 * (kNsxHistBatch * batch + q);
+                const uint32_t pair = pr[q];
 #pragma unroll
                 for (int hlf = 0; hlf < 2; hlf++) {
                     const int i = 2 * w + hlf;
@@ -684,6 +714,7 @@ __device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsSca
                     a1 += (uint32_t)t;
                     a2 += (uint32_t)wmul(t, j);
                 }
+            }
             }
             const int32_t avg = (int32_t)wave_sum(a0), avg_all = (int32_t)wave_sum(a1), avg_sq = (int32_t)wave_sum(a2);
             const int16_t count = (int16_t)wave_sum(cn);
