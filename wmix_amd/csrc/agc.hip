@@ -530,6 +530,7 @@ struct wmx_agc {
     int32_t *d_s32;
     int32_t *d_table;
     int32_t table[32];
+    bool one_lane;  // WMIX_AMD_AGC_ONE_LANE (developer A/B switch), read once at create
     wmx::StreamLife life;
 };
 
@@ -598,6 +599,7 @@ int wmx_agc_create(wmx_agc **out, int n_streams, int chn, int freq, int interval
         return WMX_ENODEV;
     }
     h->n_streams = n_streams;
+    h->one_lane = getenv("WMIX_AMD_AGC_ONE_LANE") != nullptr;
     h->chn = chn;
     h->freq = freq;
     h->pkg = freq / 1000 * (freq <= 16000 ? 10 : 5);  // 5 ms packets at 32 kHz, src/webrtc.c:724-728
@@ -684,7 +686,7 @@ int wmx_agc_process(wmx_agc *h, const int16_t *d_in, int16_t *d_out, int n_packe
     hipStream_t s = as_stream(stream);
     // one- and two-channel packets with 16-byte aligned rows -- the batched chains' cases -- go through the four-wave pipeline
     const bool pipe = h->chn <= 2 && (stream_stride % 8) == 0 && (packet_stride % 8) == 0 && (reinterpret_cast<size_t>(d_in) % 16) == 0 &&
-                      (reinterpret_cast<size_t>(d_out) % 16) == 0 && !getenv("WMIX_AMD_AGC_ONE_LANE");
+                      (reinterpret_cast<size_t>(d_out) % 16) == 0 && !h->one_lane;
     if (pipe) {
 #define AGC_PIPE(LL, CC)                                                                                                          \
     hipLaunchKernelGGL((agc_pipe_kernel<LL, CC>), grid, dim3(256), 0, s, h->d_s16, h->d_s32, h->d_table, d_in, d_out, h->n_streams, \
