@@ -894,7 +894,21 @@ class NsAec8kWorkload(ChainWorkload):
     with_agc_vad = False
 
 
-WORKLOADS = {"g711": (G711Workload, 1 << 20), "ns": (NsWorkload, 4096), "nsx": (NsxWorkload, 65536), "aecm": (AecmWorkload, 65536), "rtp_chain": (RtpChainWorkload, 65536), "chain": (ChainWorkload, 65536),
+class Chain8kWorkload(ChainWorkload):
+    """The format every platform of the reference ships with (PLAT_CHN 1, PLAT_FREQ 8000: platform/{alsa,hi3516,t31}/plat.h): the
+    whole record chain NS -> AEC -> AGC -> VAD at 8 kHz mono.  With --interval-ms 20 --packets-per-step 2 it is the daemon's own
+    heartbeat (20 ms AEC and VAD packets, src/webrtc.c:57-66, 239-248).  Algorithmic bytes per stream-frame = 320 PCM +
+    2 x (6 000 + 11 700 + 668 + 736) = 38 528 B (SURVEY 8d figures); the AEC near-end kernel: 160 + 160 + 2 x 11 700 = 23 720 B."""
+    name = "chain_ns_aec_agc_vad_8k_mono"
+    pmc_tag = "chain_8k"
+    bytes_per_frame = 38528.0
+    dominant_kernel = "aec_near_kernel<1>"
+    dominant_bytes_per_frame = 23720.0
+    freq, pkt = 8000, 80
+    with_agc_vad = True
+
+
+WORKLOADS = {"chain_8k": (Chain8kWorkload, 131072), "g711": (G711Workload, 1 << 20), "ns": (NsWorkload, 4096), "nsx": (NsxWorkload, 65536), "aecm": (AecmWorkload, 65536), "rtp_chain": (RtpChainWorkload, 65536), "chain": (ChainWorkload, 65536),
              "mfft": (MfftWorkload, 65536), "ns_aec_8k": (NsAec8kWorkload, 131072),
              "ns_agc_mix_32k": (NsAgcMix32kWorkload, 32768)}
 DEFAULT_WORKLOAD = "chain"
