@@ -210,8 +210,10 @@ __device__ __forceinline__ void bfly4_v(int b, const FftTables *T, v2f v[4]) {
     const float w3r = T->W3[b][0], w3i = T->W3[b][1];
     v2f t1 = add_i(x1, x3);  // (x1r - x3i, x1i + x3r)
     v2f t3 = sub_i(x1, x3);  // (x1r + x3i, x1i - x3r)
-    t1 = t1 + v2f{-m, m} * swap(t1);
-    t3 = t3 + v2f{m, -m} * swap(t3);
+    // m is 0 or 1: the product is exact, so the fused form rounds once to the value the product + sum pair rounds to (a zero
+    // result takes the same sign either way) -- one v_pk_fma_f32 instead of v_pk_mul_f32 + v_pk_add_f32
+    t1 = __builtin_elementwise_fma(v2f{-m, m}, swap(t1), t1);
+    t3 = __builtin_elementwise_fma(v2f{m, -m}, swap(t3), t3);
     v[2] = cmul_w(w2r, w2i, x0 - x2);
     v[1] = cmul_w(w1r, w1i, t1);
     v[3] = cmul_w(w3r, w3i, t3);

@@ -129,7 +129,8 @@ __device__ __forceinline__ void bfly4_x2(int b, const FftTables *T, Cx2 v[4]) {
     tr = x1r - x3i;
     ti = x1i + x3r;
     {
-        const v2f a = tr - m * ti, c = ti + m * tr;
+        // m is 0 or 1 (exact product): fused, one rounding, the value of the product + sum pair (see bfly4_v)
+        const v2f a = __builtin_elementwise_fma(-m, ti, tr), c = __builtin_elementwise_fma(m, tr, ti);
         tr = a;
         ti = c;
     }
@@ -138,7 +139,7 @@ __device__ __forceinline__ void bfly4_x2(int b, const FftTables *T, Cx2 v[4]) {
     tr = x1r + x3i;
     ti = x1i - x3r;
     {
-        const v2f a = tr + m * ti, c = ti - m * tr;
+        const v2f a = __builtin_elementwise_fma(m, ti, tr), c = __builtin_elementwise_fma(-m, tr, ti);
         tr = a;
         ti = c;
     }
@@ -302,7 +303,7 @@ __device__ __forceinline__ v2f bfly4_lane(int j, int b, const FftTables *T, v2f 
     // twiddle of output j in block b: W_0 = 1; blocks 0 and 1 come out of the table like any other (bfly4_v,
     // fft_ooura.h), block 1 with its outputs 1 and 3 rotated first
     const float ms = (b == 1 && (j & 1)) ? (j == 1 ? 1.f : -1.f) : 0.f;
-    t = t + v2f{-ms, ms} * swap(t);
+    t = __builtin_elementwise_fma(v2f{-ms, ms}, swap(t), t);  // ms is 0 or +-1: exact product, one rounding (see bfly4_v)
     // W1, W2, W3 lie behind one another (FftTables): entry (j - 1) * 32 + b of the three as one array, entry 0 (= W1[0]) for
     // j == 0 -- an index computation; as a select among four pointers it compiles to nested predicated regions, a dozen scalar
     // instructions per butterfly
