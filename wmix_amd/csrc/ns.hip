@@ -538,23 +538,29 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
                 // samples leave most of the 1000 bins empty.  64 bins per coalesced load, occupied ones found by ballot.
                 // (a macro, not a lambda: with the accumulators captured by reference through two lambda levels the
                 // compiler kept them in scratch memory)
-                // A histogram reaches the wave in ONE round trip: its 500 dwords as eight coalesced loads per lane, issued together,
+                // The histograms reach the wave in ONE round trip: 500 dwords each as eight coalesced loads per lane, issued together,
                 // then staged through the (dead at this point) FFT work array 2 L bins at a time and walked from LDS.
                 // Walking it with one dependent 64-bin load per step cost 48 serial HBM round trips per update: ~150 us for the
                 // one stream in 500 that updates in a given frame -- invisible while every stream of a batch has the same age
                 // (one slow launch in 500), but with streams of all ages (handles created at different ticks, the normal case
                 // for many handles) some wave of EVERY launch is in its update, and the launch lasts as long as its slowest wave:
                 // ns_kernel 0.30 -> 0.45 ms at 65 536 streams joined over 256 ticks (tools_dev/ns_age_exp.py, round 4).
+                // all three histograms are requested up front (24 registers for the length of the update): one round trip in all
+                unsigned hc_[3][8];
+#pragma unroll
+                for (int w_ = 0; w_ < 3; w_++) {
+                    const unsigned *hsrc_ = reinterpret_cast<const unsigned *>(hist + w_ * kHistBins);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const int d_ = 64 * q + lane;
+                        const unsigned v_ = hsrc_[d_ < kHistBins / 2 ? d_ : 0];
+                        hc_[w_][q] = d_ < kHistBins / 2 ? v_ : 0u;  // bins past 999 are staged as zeros
+                    }
+                }
 #define NS_WALK(which, ...)                                                                                        \
     {                                                                                                              \
         constexpr int CH_ = 2 * L, QPC_ = L / 64, NCH_ = 8 / QPC_; /* bins staged at a time (the work array holds L floats) */ \
-        const unsigned *hsrc_ = reinterpret_cast<const unsigned *>(hist + (which) * kHistBins);                    \
-        unsigned c_[8];                                                                                            \
-        _Pragma("unroll") for (int q = 0; q < 8; q++) {                                                            \
-            const int d_ = 64 * q + lane;                                                                          \
-            const unsigned v_ = hsrc_[d_ < kHistBins / 2 ? d_ : 0];                                                \
-            c_[q] = d_ < kHistBins / 2 ? v_ : 0u; /* bins past 999 are staged as zeros */                          \
-        }                                                                                                          \
+        const unsigned(&c_)[8] = hc_[which];                                                                       \
         _Pragma("unroll") for (int part_ = 0; part_ < NCH_; part_++) {                                             \
             unsigned *stage_ = reinterpret_cast<unsigned *>(W.fa);                                                 \
             _Pragma("unroll") for (int q = 0; q < QPC_; q++) stage_[64 * q + lane] = c_[QPC_ * part_ + q];         \
