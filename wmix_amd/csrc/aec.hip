@@ -1295,7 +1295,8 @@ struct wmx_aec {
     int *d_stream_far;       // [n_streams] group of each stream, or nullptr while there has only ever been one
     // cohort-sorted, XCD-aware stream order of the near kernel (see aec_near_kernel); rebuilt on the host when memberships changed
     std::vector<int32_t> h_cohort_of;  // [n_streams] host mirror of d_stream_far
-    std::vector<int32_t> h_order;
+    std::vector<int32_t> h_order[2];  // alternating: the source of the previous upload is not rewritten while that copy may still be reading it
+    int h_order_sel;
     int32_t *d_order;         // [order_wgs * 4] stream of every (chunk, wave), -1 = none; nullptr while one cohort
     unsigned order_wgs;       // workgroups of an ordered launch: a multiple of 8
     bool order_dirty;
@@ -1366,19 +1367,21 @@ static int aec_rebuild_order(wmx_aec *h, hipStream_t s) {
     std::vector<int32_t> start((size_t)G + 1, 0);
     for (int i = 0; i < S; i++) start[(size_t)h->h_cohort_of[(size_t)i] + 1]++;
     for (int g = 0; g < G; g++) start[(size_t)g + 1] += start[(size_t)g];
-    h->h_order.assign((size_t)wgs8 * kAecWavesPerBlock, -1);
-    for (int i = 0; i < S; i++) h->h_order[(size_t)start[(size_t)h->h_cohort_of[(size_t)i]]++] = i;
+    std::vector<int32_t> &ord = h->h_order[h->h_order_sel];
+    h->h_order_sel ^= 1;
+    ord.assign((size_t)wgs8 * kAecWavesPerBlock, -1);
+    for (int i = 0; i < S; i++) ord[(size_t)start[(size_t)h->h_cohort_of[(size_t)i]]++] = i;
     if (!h->d_order || h->order_wgs != wgs8) {
         if (h->d_order) {
             WMX_HIP_RC(hipDeviceSynchronize());
             (void)hipFree(h->d_order);
             h->d_order = nullptr;
         }
-        WMX_HIP_RC(hipMalloc(reinterpret_cast<void **>(&h->d_order), h->h_order.size() * sizeof(int32_t)));
+        WMX_HIP_RC(hipMalloc(reinterpret_cast<void **>(&h->d_order), ord.size() * sizeof(int32_t)));
         h->order_wgs = wgs8;
     }
     // in stream order behind the launches that read the previous order (pageable source: the runtime stages it before returning)
-    WMX_HIP_RC(hipMemcpyAsync(h->d_order, h->h_order.data(), h->h_order.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    WMX_HIP_RC(hipMemcpyAsync(h->d_order, ord.data(), ord.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
     h->order_dirty = false;
     h->order_age = 0;
     return 0;
@@ -1516,6 +1519,7 @@ int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int i
     h->d_order = nullptr;
     h->order_wgs = 0;
     h->order_dirty = n_far > 1;
+    h->h_order_sel = 0;
     h->order_age = wmx_aec::kOrderEvery;
     h->h_cohort_of.assign((size_t)n_streams, 0);
     if (n_far > 1 && stream_far)
