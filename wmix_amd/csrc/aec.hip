@@ -1422,49 +1422,50 @@ static int aec_reserve(wmx_aec *h, int cap, int pkts) {
     if (cap <= h->cap_far && pkts <= h->noise_pkts) return 0;
     WMX_HIP_RC(hipDeviceSynchronize());  // plans, noise rows and far slabs may be in use by launches in flight
     const size_t fw = aec_far_words();
+    int ncap = h->cap_far;
     if (cap > h->cap_far) {
-        int ncap = h->cap_far > 0 ? h->cap_far : 1;
+        ncap = h->cap_far > 0 ? h->cap_far : 1;
         while (ncap < cap) ncap *= 2;
-        float *nf = nullptr;
-        WMX_HIP_RC(hipMalloc(&nf, fw * (size_t)ncap * sizeof(float)));
-        if (h->d_far) {
-            hipError_t e = hipMemcpy(nf, h->d_far, fw * (size_t)h->cap_far * sizeof(float), hipMemcpyDeviceToDevice);
-            if (e == hipSuccess) e = hipMemset(nf + fw * (size_t)h->cap_far, 0, fw * (size_t)(ncap - h->cap_far) * sizeof(float));
-            if (e != hipSuccess) {
-                (void)hipFree(nf);
-                return hip_fail(e, "far-end slabs", __FILE__, __LINE__);
-            }
-            (void)hipFree(h->d_far);
-        } else {
-            hipError_t e = hipMemset(nf, 0, fw * (size_t)ncap * sizeof(float));
-            if (e != hipSuccess) {
-                (void)hipFree(nf);
-                return hip_fail(e, "far-end slabs", __FILE__, __LINE__);
-            }
-        }
-        h->d_far = nf;
-        aec_carve_far(h);
-        // plan slots: kPlanBufs x [kAecMaxPktPerLaunch][ncap] (a launch uses the first packets x n_far of its slot)
-        const size_t plan_bytes = (size_t)wmx_aec::kPlanBufs * ncap * kAecMaxPktPerLaunch * sizeof(AecPlan);
+    }
+    int npkts = pkts > h->noise_pkts ? pkts : h->noise_pkts;
+    if (npkts < 2) npkts = 2;
+    // everything new is allocated BEFORE anything old is let go: a failure leaves the handle as it was
+    float *nf = nullptr, *nn = nullptr;
+    AecPlan *nd = nullptr, *nh = nullptr;
+    const size_t plan_bytes = (size_t)wmx_aec::kPlanBufs * ncap * kAecMaxPktPerLaunch * sizeof(AecPlan);
+    hipError_t e = hipSuccess;
+    if (ncap > h->cap_far) {
+        e = hipMalloc(&nf, fw * (size_t)ncap * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(&nd, plan_bytes);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&nh), plan_bytes, hipHostMallocDefault);
+        if (e == hipSuccess && h->d_far) e = hipMemcpy(nf, h->d_far, fw * (size_t)h->cap_far * sizeof(float), hipMemcpyDeviceToDevice);
+        if (e == hipSuccess)
+            e = hipMemset(nf + fw * (size_t)h->cap_far, 0, fw * (size_t)(ncap - h->cap_far) * sizeof(float));
+    }
+    if (e == hipSuccess && (ncap > h->cap_far || npkts > h->noise_pkts || !h->d_noise))
+        e = hipMalloc(&nn, (size_t)npkts * ncap * kAecNoiseRow * sizeof(float));
+    if (e != hipSuccess) {
+        if (nf) (void)hipFree(nf);
+        if (nd) (void)hipFree(nd);
+        if (nh) (void)hipHostFree(nh);
+        if (nn) (void)hipFree(nn);
+        return hip_fail(e, "growing the cohort buffers", __FILE__, __LINE__);
+    }
+    if (nf) {
+        if (h->d_far) (void)hipFree(h->d_far);
         if (h->d_plans) (void)hipFree(h->d_plans);
         if (h->h_plans) (void)hipHostFree(h->h_plans);
-        h->d_plans = nullptr;
-        h->h_plans = nullptr;
-        WMX_HIP_RC(hipMalloc(&h->d_plans, plan_bytes));
-        WMX_HIP_RC(hipHostMalloc(reinterpret_cast<void **>(&h->h_plans), plan_bytes, hipHostMallocDefault));
+        h->d_far = nf;
+        h->d_plans = nd;  // plan slots: kPlanBufs x [kAecMaxPktPerLaunch][ncap] (a launch uses the first packets x n_far of its slot)
+        h->h_plans = nh;
         for (int i = 0; i < wmx_aec::kPlanBufs; i++) h->plan_used[i] = false;  // drained above
         h->cap_far = ncap;
-        if (h->d_noise) (void)hipFree(h->d_noise);
-        h->d_noise = nullptr;
-        if (pkts < h->noise_pkts) pkts = h->noise_pkts;
-        h->noise_pkts = 0;
+        aec_carve_far(h);
     }
-    if (pkts > h->noise_pkts || !h->d_noise) {
-        if (pkts < 2) pkts = 2;
+    if (nn) {
         if (h->d_noise) (void)hipFree(h->d_noise);
-        h->d_noise = nullptr;
-        WMX_HIP_RC(hipMalloc(&h->d_noise, (size_t)pkts * h->cap_far * kAecNoiseRow * sizeof(float)));
-        h->noise_pkts = pkts;
+        h->d_noise = nn;
+        h->noise_pkts = npkts;
     }
     return 0;
 }
