@@ -577,6 +577,8 @@ class ChainWorkload:
     dominant_bytes_per_frame = 24040.0
     freq, pkt = 16000, 160
     with_agc_vad = True
+    extra_stages = 0      # WMX_CHAIN_NSX | WMX_CHAIN_AECM for the fixed-point chain
+    timer_dominant = "aec"
 
     def __init__(self, dev, n_streams, rank, dist=None, packets=1, interval_ms=10, cohorts=1, cohort_layout="arrival"):
         from wmix_amd import synth
@@ -620,9 +622,9 @@ class ChainWorkload:
             self.work = torch.empty_like(self.inp[0:self.P])
         # the four stages behind ONE C call per step (wmx_chain_process, the heartbeat of src/wmix.c:613-709)
         self.chain = ChainBatch(n_streams, 1, self.freq, interval_ms, 5,  # volumeAgc default 5, src/wmix.c:1596
-                                (NS | AEC | AGC | VAD) if self.with_agc_vad else (NS | AEC))
+                                ((NS | AEC | AGC | VAD) if self.with_agc_vad else (NS | AEC)) | self.extra_stages)
         self.rank = rank
-        self.t = _StageTimer("aec")
+        self.t = _StageTimer(self.timer_dominant)
         self.k = 0
         self.near_ms, self.far_ms, self.aec_launches = 0.0, 0.0, 0
         self.sample = [int(i) for i in np.linspace(0, n_streams - 1, 16)]
@@ -686,6 +688,8 @@ class ChainWorkload:
     def timed_region(self, on):
         """Inside the timed region the library itself records HIP events around the AEC's kernels, on the launch stream
         (wmx_aec_set_timing): the dominant kernel's own duration, far kernel excluded."""
+        if self.extra_stages & 32:  # AECM: no float AEC handle to time; the dominant kernel comes from the stage breakdown
+            return
         self.chain.set_aec_timing(on)
         if on:
             self.chain.aec_host_ctl()  # start over
@@ -723,6 +727,8 @@ class ChainWorkload:
             self.rec.append((step_index, got.clone()))
 
     def dominant_ms(self):
+        if self.extra_stages:
+            return self.t.mean_ms(self.timer_dominant)
         return self.near_ms / self.aec_launches if self.aec_launches else None
 
     def stage_ms(self):
@@ -747,8 +753,7 @@ class ChainWorkload:
             near = np.concatenate([self.base[s % 256, (k * P + p) % self.K] for k in range(t0, T) for p in range(P)])
             # one oracle call per step of P packets, like wmx_chain_process: ns / aec / agc loop over the packets of a call, vad_process
             # analyses and attenuates the call's FIRST packet only -- the daemon's own 20 ms call is P = 2
-            want = loader.run_chain(port, 1, self.freq, 5, stages, far, near, self.pkt * P, prefix="orc",
-                                    interval_ms=self.interval_ms).reshape(T - t0, P, self.pkt)
+            want = self._oracle_chain(loader, port, stages, far, near).reshape(T - t0, P, self.pkt)
             for k, got in self.rec:
                 if k < t0:
                     continue
@@ -757,6 +762,9 @@ class ChainWorkload:
         return {"streams": len(self.sample), "packets_compared": n, "max_lsb": worst, "samples_off_by_one": n_off,
                 "oracle": "oracle/orc_*.c chain (port), one run per sampled stream started at the stream's own join step",
                 "steps_replayed": T}
+
+    def _oracle_chain(self, loader, port, stages, far, near):
+        return loader.run_chain(port, 1, self.freq, 5, stages, far, near, self.pkt * self.P, prefix="orc", interval_ms=self.interval_ms)
 
     def config(self):
         return {"workload": self.name, "streams_per_gpu": self.n_streams, "packets_per_stream_per_step": self.P,
@@ -894,6 +902,43 @@ class NsAec8kWorkload(ChainWorkload):
     with_agc_vad = False
 
 
+class ChainFxWorkload(ChainWorkload):
+    """The record chain of the reference's fixed-point builds (MAKE_WEBRTC_NSX, src/webrtc.c:512-521, and the AECM switch,
+    src/webrtc.c:168-191): NSX -> AECM -> AGC -> VAD, 16 kHz mono, one wmx_chain_process call per step.  Integer end to end: the
+    parity replay must be bit-exact.  Algorithmic bytes per stream-frame = 640 PCM + 2 x (5 516 + 3 900 + 668 + 736) = 22 280 B
+    (DESIGN 7e / 7f state figures); dominant kernel nsx_kernel: 320 + 320 + 2 x 5 516 = 11 672 B."""
+    name = "chain_nsx_aecm_agc_vad_16k_mono"
+    pmc_tag = "chain_fx"
+    dtype = "int16 / int32"
+    bytes_per_frame = 22280.0
+    dominant_kernel = "nsx_kernel<256, 1>"
+    dominant_bytes_per_frame = 11672.0
+    extra_stages = 16 | 32
+    timer_dominant = "ns"
+
+    def _oracle_chain(self, loader, port, stages, far, near):
+        per = self.pkt * self.P
+        x = loader.run_nsx(port, 1, self.freq, near, per, prefix="orc")
+        x = loader.run_aecm(port, 1, self.freq, self.interval_ms, far, x, per, 0, prefix="orc")
+        x = loader.run_agc(port, 1, self.freq, 5, x, per, prefix="orc")
+        return loader.run_vad(port, 1, self.freq, self.interval_ms, x, per, prefix="orc")
+
+    def cpu_baseline(self, budget_s):
+        from oracle import loader
+        port = loader.port()
+        n = 2000
+        far = np.tile(self.far_host.reshape(-1), n // self.K + 1)[: n * self.pkt]
+        near = np.tile(np.ascontiguousarray(self.base[0].reshape(-1)), n // self.K + 1)[: n * self.pkt]
+        P, self.P = self.P, 1
+        try:
+            reps, v1, nc, vn = _cpu_rates(lambda: self._oracle_chain(loader, port, 15, far, near), n, budget_s)
+        finally:
+            self.P = P
+        return {"value": v1, "unit": "frames/s", "cores": 1, "kind": "port", "all_cores_value": vn, "all_cores": nc, "cpu_model": _cpu_model(),
+                "sample": "%d x %d packets of one 16 kHz stream through the oracle's NSX, AECM, AGC and VAD (oracle/orc_*.c, -O2), 1 thread; "
+                          "then one stream per thread on all %d cores" % (reps, n, nc)}
+
+
 class Chain8kWorkload(ChainWorkload):
     """The format every platform of the reference ships with (PLAT_CHN 1, PLAT_FREQ 8000: platform/{alsa,hi3516,t31}/plat.h): the
     whole record chain NS -> AEC -> AGC -> VAD at 8 kHz mono.  With --interval-ms 20 --packets-per-step 2 it is the daemon's own
@@ -908,7 +953,7 @@ class Chain8kWorkload(ChainWorkload):
     with_agc_vad = True
 
 
-WORKLOADS = {"chain_8k": (Chain8kWorkload, 131072), "g711": (G711Workload, 1 << 20), "ns": (NsWorkload, 4096), "nsx": (NsxWorkload, 65536), "aecm": (AecmWorkload, 65536), "rtp_chain": (RtpChainWorkload, 65536), "chain": (ChainWorkload, 65536),
+WORKLOADS = {"chain_8k": (Chain8kWorkload, 131072), "chain_fx": (ChainFxWorkload, 65536), "g711": (G711Workload, 1 << 20), "ns": (NsWorkload, 4096), "nsx": (NsxWorkload, 65536), "aecm": (AecmWorkload, 65536), "rtp_chain": (RtpChainWorkload, 65536), "chain": (ChainWorkload, 65536),
              "mfft": (MfftWorkload, 65536), "ns_aec_8k": (NsAec8kWorkload, 131072),
              "ns_agc_mix_32k": (NsAgcMix32kWorkload, 32768)}
 DEFAULT_WORKLOAD = "chain"

@@ -267,6 +267,13 @@ int wmx_aec_host_ctl(wmx_aec *h, long *n_launches, double *seconds);
 #define WMX_CHAIN_AEC 2u
 #define WMX_CHAIN_AGC 4u
 #define WMX_CHAIN_VAD 8u
+/* The reference's two build-time alternates of the same stages (src/webrtc.c:512-521: -DMAKE_WEBRTC_NSX puts WebRtcNsx_* behind
+ * ns_*; :168-191: `#undef MAKE_WEBRTC_AEC` puts WebRtcAecm_* behind aec_*), as stage bits of the one library: with WMX_CHAIN_NSX the
+ * NS stage (WMX_CHAIN_NS must be set too) is the fixed-point suppressor, with WMX_CHAIN_AECM the AEC stage is the fixed-point
+ * canceller.  A chain of NSX + AECM + AGC + VAD is integer end to end: bit-exact against the reference.  The AECM's cohorts are
+ * fixed at create (wmx_chain_add_cohort answers WMX_ESTATE). */
+#define WMX_CHAIN_NSX 16u
+#define WMX_CHAIN_AECM 32u
 typedef struct wmx_chain wmx_chain;
 int wmx_chain_create(wmx_chain **out, int n_streams, int chn, int freq, int interval_ms, int agc_value, unsigned stages,
                      int n_cohorts);
@@ -321,6 +328,9 @@ int wmx_aecm_import_cohort(wmx_aecm *h, int cohort, const void *host_blob);
 int wmx_aecm_run_cohorts(wmx_aecm *h, int mode, const int16_t *d_far, long far_packet_stride, long far_group_stride,
                          const int16_t *d_near, int16_t *d_out, int n_packets, long stream_stride, long packet_stride,
                          const int32_t *delay_ms, const uint8_t *cohort_on, int32_t *cohort_rc, void *stream);
+/* the fixed-point stage handles of a chain made with WMX_CHAIN_NSX / WMX_CHAIN_AECM (NULL otherwise) */
+wmx_nsx *wmx_chain_nsx(wmx_chain *h);
+wmx_aecm *wmx_chain_aecm(wmx_chain *h);
 
 /* ------------------------------------------------------------------ resample + mix
  * Batched forms of wmix_pcm_zoom (src/wmix.c:139-222) and of wmix_load_data + the play thread's drain

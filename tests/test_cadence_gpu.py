@@ -141,3 +141,30 @@ def test_legacy_adapter_heartbeat_latency_is_measured_and_bounded(cuda):
     assert r["parity_max_lsb_vs_oracle"] <= 1
     assert r["adapters_us_per_heartbeat"]["median"] < 2000.0, r   # 10 % of the heartbeat's 20 ms
     assert r["adapters_us_per_heartbeat"]["p99"] < 10000.0, r
+
+
+@pytest.mark.parametrize("freq,interval_ms,n10", [(16000, 10, 1), (16000, 20, 2), (8000, 20, 2), (8000, 10, 1)])
+def test_fixed_point_chain_is_bit_exact(cuda, oracle_port, freq, interval_ms, n10):
+    """The heartbeat of the reference's OTHER builds -- MAKE_WEBRTC_NSX (src/webrtc.c:512-521) and the AECM switch
+    (src/webrtc.c:168-191): WebRtcNsx_* and WebRtcAecm_* behind the same ns_* / aec_* calls -- as ONE wmx_chain_process call per
+    tick (WMX_CHAIN_NSX | WMX_CHAIN_AECM).  Every stage is integer: the chain is bit-exact.  The oracle side composes the stages
+    over the whole signal (a stage's output for a call depends on its input up to that call only)."""
+    from wmix_amd.chain import AEC, AECM, AGC, NS, NSX, VAD
+    S, T = 20, 240
+    far, near = _inputs(1200 + freq // 8000 + interval_ms, S, n10 * T, 1, freq)
+    cb = ChainBatch(S, 1, freq, interval_ms=interval_ms, stages=NS | AEC | AGC | VAD | NSX | AECM)
+    got = _run_ticks(cuda, cb, far, near, n10)
+    cb.close()
+    per_call = freq // 100 * n10
+    for s in range(0, S, 3):
+        x = L.run_nsx(oracle_port, 1, freq, near[s], per_call, prefix="orc")
+        x = L.run_aecm(oracle_port, 1, freq, interval_ms, far, x, per_call, 0, prefix="orc")
+        x = L.run_agc(oracle_port, 1, freq, 5, x, per_call, prefix="orc")
+        x = L.run_vad(oracle_port, 1, freq, interval_ms, x, per_call, prefix="orc")
+        assert np.array_equal(got[s], x), "stream %d: %d samples differ" % (s, int((got[s] != x).sum()))
+
+
+def test_fixed_point_stage_bits_need_their_stage(cuda):
+    from wmix_amd.chain import AGC, NSX, VAD
+    with pytest.raises(WmxError):
+        ChainBatch(4, 1, 16000, stages=AGC | VAD | NSX)  # WMX_CHAIN_NSX without WMX_CHAIN_NS

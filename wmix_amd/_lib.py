@@ -197,7 +197,7 @@ def _declare(L):
     L.wmx_chain_destroy.argtypes = [vp]
     L.wmx_chain_process.restype = i
     L.wmx_chain_process.argtypes = [vp, vp, C.c_long, vp, vp, i, C.c_long, C.c_long, vp, vp, vp, vp]
-    for m in ("ns", "aec", "agc", "vad"):
+    for m in ("ns", "aec", "agc", "vad", "nsx", "aecm"):
         f = getattr(L, "wmx_chain_%s" % m)
         f.restype = vp
         f.argtypes = [vp]

@@ -9,6 +9,7 @@ from .lifetime import Lifetime
 from ._lib import check, lib
 
 NS, AEC, AGC, VAD = 1, 2, 4, 8
+NSX, AECM = 16, 32  # the NS / AEC stage is the reference's fixed-point build of it (WebRtcNsx_* / WebRtcAecm_*)
 
 
 class ChainBatch(Lifetime):
@@ -84,10 +85,19 @@ class ChainBatch(Lifetime):
         L, st = lib(), torch.cuda.current_stream().cuda_stream
         total = n10 * self.pkt
         calls, src = [], pcm
-        if self.stages & NS:
+        if self.stages & NSX:
+            calls.append(("ns", lambda s=src: check(L.wmx_nsx_process(L.wmx_chain_nsx(self._h), s.data_ptr(), out.data_ptr(), n10, ss, ps, st))))
+            src = out
+        elif self.stages & NS:
             calls.append(("ns", lambda s=src: check(L.wmx_ns_process(L.wmx_chain_ns(self._h), s.data_ptr(), out.data_ptr(), n10, ss, ps, st))))
             src = out
-        if self.stages & AEC:
+        if self.stages & AECM:
+            hm = L.wmx_chain_aecm(self._h)
+            per = L.wmx_aecm_packet_samples(hm) // self.pkt
+            calls.append(("aec", lambda s=src: check(L.wmx_aecm_run(hm, 3, far.data_ptr(), far.stride(0) * per, s.data_ptr(), out.data_ptr(),
+                                                                    n10 // per, ss, ps * per, 0, st))))
+            src = out
+        elif self.stages & AEC:
             per = L.wmx_aec_packet_samples(self.aec_handle()) // self.pkt  # 10 ms packets per AEC packet (2 at 8 kHz, interval 20)
             calls.append(("aec", lambda s=src: check(L.wmx_aec_run(self.aec_handle(), 3, far.data_ptr(), far.stride(0) * per, s.data_ptr(),
                                                                    out.data_ptr(), n10 // per, ss, ps * per, 0, st))))

@@ -15,8 +15,10 @@ struct wmx_chain {
     int device;  // first member of every handle (wmx_handle_device)
     int n_streams, chn, freq, interval_ms;
     unsigned stages;
-    wmx_ns *ns;
-    wmx_aec *aec;
+    wmx_ns *ns;      // the float noise suppressor ...
+    wmx_nsx *nsx;    // ... or the reference's MAKE_WEBRTC_NSX build of the same stage (WMX_CHAIN_NSX): at most one is set
+    wmx_aec *aec;    // the float echo canceller ...
+    wmx_aecm *aecm;  // ... or its AECM build (WMX_CHAIN_AECM)
     wmx_agc *agc;
     wmx_vad *vad;
     int pkg10;                       // int16 elements of one 10 ms packet of one stream (freq / 100 * chn)
@@ -32,7 +34,9 @@ int wmx_chain_destroy(wmx_chain *h) {
     WMX_ON_DEVICE(h);
     if (!h) return 0;
     if (h->ns) wmx_ns_destroy(h->ns);
+    if (h->nsx) wmx_nsx_destroy(h->nsx);
     if (h->aec) wmx_aec_destroy(h->aec);
+    if (h->aecm) wmx_aecm_destroy(h->aecm);
     if (h->agc) wmx_agc_destroy(h->agc);
     if (h->vad) wmx_vad_destroy(h->vad);
     delete h;
@@ -42,7 +46,8 @@ int wmx_chain_destroy(wmx_chain *h) {
 int wmx_chain_create(wmx_chain **out, int n_streams, int chn, int freq, int interval_ms, int agc_value, unsigned stages, int n_cohorts) {
     if (!out) return WMX_EINVAL;
     *out = nullptr;
-    if ((stages & 15u) == 0 || (stages & ~15u) != 0 || n_cohorts < 1) {
+    if ((stages & 15u) == 0 || (stages & ~63u) != 0 || n_cohorts < 1 || ((stages & WMX_CHAIN_NSX) && !(stages & WMX_CHAIN_NS)) ||
+        ((stages & WMX_CHAIN_AECM) && !(stages & WMX_CHAIN_AEC))) {
         wmx::set_error("wmx_chain_create: stages=0x%x n_cohorts=%d", stages, n_cohorts);
         return WMX_EINVAL;
     }
@@ -62,15 +67,19 @@ int wmx_chain_create(wmx_chain **out, int n_streams, int chn, int freq, int inte
     h->zero_delays.assign((size_t)n_cohorts, 0);
     int rc = 0;
     // the same *_init calls, in the heartbeat's order; an unsupported format fails the way the reference's *_init returns NULL
-    if (rc == 0 && (stages & WMX_CHAIN_NS)) rc = wmx_ns_create(&h->ns, n_streams, chn, freq);
-    if (rc == 0 && (stages & WMX_CHAIN_AEC)) rc = wmx_aec_create_groups(&h->aec, n_streams, chn, freq, interval_ms, n_cohorts, nullptr);
+    // (the reference picks WebRtcNsx_* / WebRtcAecm_* by build switches, src/webrtc.c:512-521, 168-191: here two stage bits)
+    if (rc == 0 && (stages & WMX_CHAIN_NS))
+        rc = (stages & WMX_CHAIN_NSX) ? wmx_nsx_create(&h->nsx, n_streams, chn, freq) : wmx_ns_create(&h->ns, n_streams, chn, freq);
+    if (rc == 0 && (stages & WMX_CHAIN_AEC))
+        rc = (stages & WMX_CHAIN_AECM) ? wmx_aecm_create_cohorts(&h->aecm, n_streams, chn, freq, interval_ms, n_cohorts)
+                                       : wmx_aec_create_groups(&h->aec, n_streams, chn, freq, interval_ms, n_cohorts, nullptr);
     if (rc == 0 && (stages & WMX_CHAIN_AGC)) rc = wmx_agc_create(&h->agc, n_streams, chn, freq, interval_ms, agc_value);
     if (rc == 0 && (stages & WMX_CHAIN_VAD)) rc = wmx_vad_create(&h->vad, n_streams, chn, freq, interval_ms);
     if (rc != 0) {
         wmx_chain_destroy(h);
         return rc;
     }
-    h->aec_pkg = h->aec ? wmx_aec_packet_samples(h->aec) : h->pkg10;
+    h->aec_pkg = h->aec ? wmx_aec_packet_samples(h->aec) : (h->aecm ? wmx_aecm_packet_samples(h->aecm) : h->pkg10);
     h->agc_pkg = h->agc ? wmx_agc_packet_samples(h->agc) : h->pkg10;
     h->vad_pkg = h->vad ? wmx_vad_packet_samples(h->vad) : h->pkg10;
     *out = h;
@@ -79,6 +88,8 @@ int wmx_chain_create(wmx_chain **out, int n_streams, int chn, int freq, int inte
 
 wmx_ns *wmx_chain_ns(wmx_chain *h) { return h ? h->ns : nullptr; }
 wmx_aec *wmx_chain_aec(wmx_chain *h) { return h ? h->aec : nullptr; }
+wmx_nsx *wmx_chain_nsx(wmx_chain *h) { return h ? h->nsx : nullptr; }
+wmx_aecm *wmx_chain_aecm(wmx_chain *h) { return h ? h->aecm : nullptr; }
 wmx_agc *wmx_chain_agc(wmx_chain *h) { return h ? h->agc : nullptr; }
 wmx_vad *wmx_chain_vad(wmx_chain *h) { return h ? h->vad : nullptr; }
 
@@ -104,7 +115,8 @@ int wmx_chain_process(wmx_chain *h, const int16_t *d_far, long far_packet_stride
     const long total = (long)n10 * h->pkg10;  // int16 elements of the tick per stream
     const bool contiguous = packet_stride == h->pkg10;
     auto fits = [&](int pkg) { return total % pkg == 0 && (pkg <= h->pkg10 || contiguous); };
-    if ((h->aec && !fits(h->aec_pkg)) || (h->vad && !fits(h->vad_pkg)) || (h->aec && h->aec_pkg > h->pkg10 && far_packet_stride != h->pkg10)) {
+    const bool any_aec = h->aec || h->aecm;
+    if ((any_aec && !fits(h->aec_pkg)) || (h->vad && !fits(h->vad_pkg)) || (any_aec && h->aec_pkg > h->pkg10 && far_packet_stride != h->pkg10)) {
         wmx::set_error("wmx_chain_process: %d x 10 ms with packet stride %ld does not hold whole %d / %d-sample packets", n10, packet_stride,
                        h->aec_pkg, h->vad_pkg);
         return WMX_EINVAL;
@@ -129,12 +141,24 @@ int wmx_chain_process(wmx_chain *h, const int16_t *d_far, long far_packet_stride
         }
         src = d_out;
     }
+    if (h->nsx) {
+        if ((rc = wmx_nsx_process(h->nsx, src, d_out, n10, stream_stride, packet_stride, stream)) != 0) return rc;
+        src = d_out;
+    }
     if (h->aec) {
         const int per = h->aec_pkg / h->pkg10;  // 10 ms packets per AEC packet (1 or 2)
         if (!delay_ms) delay_ms = h->zero_delays.data();
         rc_aec = wmx_aec_run_cohorts(h->aec, 3, d_far, far_packet_stride * per, 0, src, d_out, n10 / per, stream_stride, packet_stride * per,
                                      delay_ms, cohort_on, cohort_rc, stream);
         if (rc_aec != 0 && rc_aec != -1) return rc_aec;  // -1: a cohort's delay was rejected (its code is in cohort_rc); the others ran
+        src = d_out;
+    }
+    if (h->aecm) {
+        const int per = h->aec_pkg / h->pkg10;
+        if (!delay_ms) delay_ms = h->zero_delays.data();
+        rc_aec = wmx_aecm_run_cohorts(h->aecm, 3, d_far, far_packet_stride * per, 0, src, d_out, n10 / per, stream_stride, packet_stride * per,
+                                      delay_ms, cohort_on, cohort_rc, stream);
+        if (rc_aec != 0 && rc_aec != -1) return rc_aec;
         src = d_out;
     }
     if (h->agc) {
@@ -171,7 +195,9 @@ int wmx_chain_reset_streams(wmx_chain *h, const int32_t *idx, int n, int cohort,
     if (!h) return WMX_EINVAL;
     int rc = 0;
     if (rc == 0 && h->ns) rc = wmx_ns_reset_streams(h->ns, idx, n, stream);
+    if (rc == 0 && h->nsx) rc = wmx_nsx_reset_streams(h->nsx, idx, n, stream);
     if (rc == 0 && h->aec) rc = wmx_aec_reset_streams(h->aec, idx, n, cohort, stream);
+    if (rc == 0 && h->aecm) rc = wmx_aecm_reset_streams(h->aecm, idx, n, cohort, stream);
     if (rc == 0 && h->agc) rc = wmx_agc_reset_streams(h->agc, idx, n, stream);
     if (rc == 0 && h->vad) rc = wmx_vad_reset_streams(h->vad, idx, n, stream);
     return rc;
@@ -180,12 +206,16 @@ int wmx_chain_reset_streams(wmx_chain *h, const int32_t *idx, int n, int cohort,
 int wmx_chain_reset_cohort(wmx_chain *h, int cohort, void *stream) {
     WMX_ON_DEVICE(h);
     if (!h) return WMX_EINVAL;
-    return h->aec ? wmx_aec_reset_cohort(h->aec, cohort, stream) : 0;
+    return h->aec ? wmx_aec_reset_cohort(h->aec, cohort, stream) : (h->aecm ? wmx_aecm_reset_cohort(h->aecm, cohort, stream) : 0);
 }
 
 int wmx_chain_add_cohort(wmx_chain *h, int *cohort, void *stream) {
     WMX_ON_DEVICE(h);
     if (!h || !cohort) return WMX_EINVAL;
+    if (h->aecm) {  // the AECM's cohorts are fixed at create (wmx_aecm_create_cohorts)
+        wmx::set_error("wmx_chain_add_cohort: not available with WMX_CHAIN_AECM (create the chain with the cohorts it needs)");
+        return WMX_ESTATE;
+    }
     if (!h->aec) {
         *cohort = 0;
         return 0;
@@ -208,7 +238,8 @@ int wmx_chain_cohorts(const wmx_chain *h) { return h ? h->n_cohorts : WMX_EINVAL
 // travels separately through wmx_aec_export_cohort / wmx_aec_import_cohort on wmx_chain_aec(h).
 int wmx_chain_stream_state_bytes(const wmx_chain *h) {
     if (!h) return WMX_EINVAL;
-    return (h->ns ? wmx_ns_stream_state_bytes(h->ns) : 0) + (h->aec ? wmx_aec_stream_state_bytes(h->aec) : 0) +
+    return (h->ns ? wmx_ns_stream_state_bytes(h->ns) : 0) + (h->nsx ? wmx_nsx_stream_state_bytes(h->nsx) : 0) +
+           (h->aec ? wmx_aec_stream_state_bytes(h->aec) : 0) + (h->aecm ? wmx_aecm_stream_state_bytes(h->aecm) : 0) +
            (h->agc ? wmx_agc_stream_state_bytes(h->agc) : 0) + (h->vad ? wmx_vad_stream_state_bytes(h->vad) : 0);
 }
 
@@ -218,7 +249,9 @@ int wmx_chain_export_stream(wmx_chain *h, int stream_index, void *host_blob) {
     char *p = static_cast<char *>(host_blob);
     int rc = 0;
     if (rc == 0 && h->ns) rc = wmx_ns_export_stream(h->ns, stream_index, p), p += wmx_ns_stream_state_bytes(h->ns);
+    if (rc == 0 && h->nsx) rc = wmx_nsx_export_stream(h->nsx, stream_index, p), p += wmx_nsx_stream_state_bytes(h->nsx);
     if (rc == 0 && h->aec) rc = wmx_aec_export_stream(h->aec, stream_index, p), p += wmx_aec_stream_state_bytes(h->aec);
+    if (rc == 0 && h->aecm) rc = wmx_aecm_export_stream(h->aecm, stream_index, p), p += wmx_aecm_stream_state_bytes(h->aecm);
     if (rc == 0 && h->agc) rc = wmx_agc_export_stream(h->agc, stream_index, p), p += wmx_agc_stream_state_bytes(h->agc);
     if (rc == 0 && h->vad) rc = wmx_vad_export_stream(h->vad, stream_index, p), p += wmx_vad_stream_state_bytes(h->vad);
     return rc;
@@ -230,7 +263,9 @@ int wmx_chain_import_stream(wmx_chain *h, int stream_index, const void *host_blo
     const char *p = static_cast<const char *>(host_blob);
     int rc = 0;
     if (rc == 0 && h->ns) rc = wmx_ns_import_stream(h->ns, stream_index, p), p += wmx_ns_stream_state_bytes(h->ns);
+    if (rc == 0 && h->nsx) rc = wmx_nsx_import_stream(h->nsx, stream_index, p), p += wmx_nsx_stream_state_bytes(h->nsx);
     if (rc == 0 && h->aec) rc = wmx_aec_import_stream(h->aec, stream_index, p, cohort), p += wmx_aec_stream_state_bytes(h->aec);
+    if (rc == 0 && h->aecm) rc = wmx_aecm_import_stream(h->aecm, stream_index, p, cohort), p += wmx_aecm_stream_state_bytes(h->aecm);
     if (rc == 0 && h->agc) rc = wmx_agc_import_stream(h->agc, stream_index, p), p += wmx_agc_stream_state_bytes(h->agc);
     if (rc == 0 && h->vad) rc = wmx_vad_import_stream(h->vad, stream_index, p), p += wmx_vad_stream_state_bytes(h->vad);
     return rc;
@@ -241,7 +276,9 @@ int wmx_chain_set_active(wmx_chain *h, const uint8_t *host_mask, void *stream) {
     if (!h) return WMX_EINVAL;
     int rc = 0;
     if (rc == 0 && h->ns) rc = wmx_ns_set_active(h->ns, host_mask, stream);
+    if (rc == 0 && h->nsx) rc = wmx_nsx_set_active(h->nsx, host_mask, stream);
     if (rc == 0 && h->aec) rc = wmx_aec_set_active(h->aec, host_mask, stream);
+    if (rc == 0 && h->aecm) rc = wmx_aecm_set_active(h->aecm, host_mask, stream);
     if (rc == 0 && h->agc) rc = wmx_agc_set_active(h->agc, host_mask, stream);
     if (rc == 0 && h->vad) rc = wmx_vad_set_active(h->vad, host_mask, stream);
     return rc;
