@@ -270,8 +270,7 @@ int wmx_aec_host_ctl(wmx_aec *h, long *n_launches, double *seconds);
 /* The reference's two build-time alternates of the same stages (src/webrtc.c:512-521: -DMAKE_WEBRTC_NSX puts WebRtcNsx_* behind
  * ns_*; :168-191: `#undef MAKE_WEBRTC_AEC` puts WebRtcAecm_* behind aec_*), as stage bits of the one library: with WMX_CHAIN_NSX the
  * NS stage (WMX_CHAIN_NS must be set too) is the fixed-point suppressor, with WMX_CHAIN_AECM the AEC stage is the fixed-point
- * canceller.  A chain of NSX + AECM + AGC + VAD is integer end to end: bit-exact against the reference.  The AECM's cohorts are
- * fixed at create (wmx_chain_add_cohort answers WMX_ESTATE). */
+ * canceller.  A chain of NSX + AECM + AGC + VAD is integer end to end: bit-exact against the reference. */
 #define WMX_CHAIN_NSX 16u
 #define WMX_CHAIN_AECM 32u
 typedef struct wmx_chain wmx_chain;
@@ -317,6 +316,8 @@ int wmx_aecm_run(wmx_aecm *h, int mode, const int16_t *d_far, long far_packet_st
 int wmx_aecm_create_cohorts(wmx_aecm **out, int n_streams, int chn, int freq, int interval_ms, int n_cohorts);
 int wmx_aecm_cohorts(const wmx_aecm *h);
 int wmx_aecm_reset_cohort(wmx_aecm *h, int cohort, void *stream);
+int wmx_aecm_add_cohort(wmx_aecm *h, int *cohort, void *stream); /* as wmx_aec_add_cohort / wmx_aec_retire_cohort */
+int wmx_aecm_retire_cohort(wmx_aecm *h, int cohort);
 int wmx_aecm_reset_streams(wmx_aecm *h, const int32_t *idx, int n, int cohort, void *stream);
 int wmx_aecm_set_active(wmx_aecm *h, const uint8_t *host_mask, void *stream);
 int wmx_aecm_stream_state_bytes(const wmx_aecm *h);

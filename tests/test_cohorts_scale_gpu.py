@@ -105,14 +105,16 @@ def test_65536_streams_joining_at_more_than_1000_random_ticks(cuda, oracle_port)
             check_float_path(got[a:b, col], want, max_fraction=1e-4)
 
 
-def test_cohort_ids_grow_and_come_back(cuda, oracle_port):
-    """wmx_aec_add_cohort past the capacity the batch was created with (device buffers double, running cohorts carry on
-    undisturbed), wmx_aec_retire_cohort, and the retired id handed out again with a fresh control plane."""
+@pytest.mark.parametrize("mod", ["aec", "aecm"])
+def test_cohort_ids_grow_and_come_back(cuda, oracle_port, mod):
+    """wmx_aec_add_cohort / wmx_aecm_add_cohort past the capacity the batch was created with (device buffers double, running
+    cohorts carry on undisturbed), _retire_cohort, and the retired id handed out again with a fresh control plane."""
     from wmix_amd.aec import AecBatch
+    from wmix_amd.aecm import AecmBatch
     S, T, freq, pkt = 12, 360, 16000, 160
     far = synth.far_end(7300, T, pkt).reshape(T, pkt)
     near = synth.near_end(7301, S, T, pkt, far=far.reshape(-1)).reshape(S, T, pkt)
-    ab = AecBatch(S, 1, freq, 10, n_cohorts=1)
+    ab = AecBatch(S, 1, freq, 10, n_cohorts=1) if mod == "aec" else AecmBatch(S, 1, freq, 10, n_cohorts=1)
     d = torch.from_numpy(near.copy()).to(cuda)
     dfar = torch.from_numpy(far.copy()).to(cuda)
     # stream s joins at tick 20 s (cohort s); streams 3 and 4 leave at 230; stream 3's slot joins again at 280 in the retired id
@@ -140,15 +142,19 @@ def test_cohort_ids_grow_and_come_back(cuda, oracle_port):
             ab.reset_streams([3], cohort=c)
             active[3] = 1
         ab.set_active(active)
-        rc, codes = ab.run_cohorts(dfar[t:t + 1], d[:, t:t + 1], [0] * ab.n_far)
+        rc, codes = ab.run_cohorts(dfar[t:t + 1], d[:, t:t + 1], [0] * ab.n_cohorts)
         assert rc == 0 and not codes.any()
-    assert ab.n_far == S
+    assert ab.n_cohorts == S
     got = d.cpu().numpy()
     ab.close()
     for s in range(S):
         for a, b in life[s]:
-            want = L.run_aec(oracle_port, 1, freq, 10, far[a:b].reshape(-1), near[s, a:b].reshape(-1), pkt, 0, prefix="orc").reshape(b - a, pkt)
-            check_float_path(got[s, a:b], want, max_fraction=1e-4)
+            if mod == "aec":
+                want = L.run_aec(oracle_port, 1, freq, 10, far[a:b].reshape(-1), near[s, a:b].reshape(-1), pkt, 0, prefix="orc").reshape(b - a, pkt)
+                check_float_path(got[s, a:b], want, max_fraction=1e-4)
+            else:
+                want = L.run_aecm(oracle_port, 1, freq, 10, far[a:b].reshape(-1), near[s, a:b].reshape(-1), pkt, 0, prefix="orc").reshape(b - a, pkt)
+                assert np.array_equal(got[s, a:b], want)
         lived = np.zeros(T, bool)
         for a, b in life[s]:
             lived[a:b] = True

@@ -173,11 +173,11 @@ def _declare(L):
         f = getattr(L, "wmx_%s_import_cohort" % m)
         f.restype = i
         f.argtypes = [vp, i, vp]
-    for name in ("wmx_aec_add_cohort", "wmx_chain_add_cohort"):
+    for name in ("wmx_aec_add_cohort", "wmx_aecm_add_cohort", "wmx_chain_add_cohort"):
         f = getattr(L, name)
         f.restype = i
         f.argtypes = [vp, C.POINTER(i), vp]
-    for name in ("wmx_aec_retire_cohort", "wmx_chain_retire_cohort"):
+    for name in ("wmx_aec_retire_cohort", "wmx_aecm_retire_cohort", "wmx_chain_retire_cohort"):
         f = getattr(L, name)
         f.restype = i
         f.argtypes = [vp, i]

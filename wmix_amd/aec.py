@@ -33,6 +33,7 @@ class AecBatch(Lifetime):
             self._h = None
             check(rc, "wmx_aec_create")
         self.n_streams, self.chn, self.freq = n_streams, chn, freq
+        self.n_cohorts = self.n_far
         self.pkt = lib().wmx_aec_packet_samples(self._h)
 
     def _run(self, mode, far, near, out, n_packets, stream_stride, packet_stride, delay_ms):

@@ -193,11 +193,11 @@ __device__ uint32_t binary_spectrum(const uint16_t *mag, int32_t *mean, int q, i
 // ---------------------------------------------------------------- far-end kernel: one wave per batch
 // plan_by_value: a one-packet launch hands its plan over as a kernel argument; this kernel, which runs in front of the near
 // kernel in the same stream, stores it into plans[0] for both (no host-to-device copy of the plan in front of the launch).
-// grid = number of cohorts: workgroup g (one wave) serves cohort g with plans[g * kAecmMaxPktPerLaunch ...] and the far-end
+// grid = number of cohorts: workgroup g (one wave) serves cohort g with plans[packet * n_cohorts + g] and the far-end
 // packets at far + g * far_group_stride (0: every cohort hears the same far-end, blocked from its own start)
 __global__ __launch_bounds__(64) void aecm_far_kernel(AecmFarBufs F_all, const AecmConsts *__restrict__ consts, AecmPlan *plans, int n_plans,
-                                                     const int16_t *far, long far_stride, long far_group_stride, int chn, int plan_by_value,
-                                                     const AecmPlan plan_value) {
+                                                     int n_cohorts, const int16_t *far, long far_stride, long far_group_stride, int chn,
+                                                     int plan_by_value, const AecmPlan plan_value) {
     __shared__ AecmConsts K;
     __shared__ AecmWave W;
     const int lane = threadIdx.x;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64) void aecm_far_kernel(AecmFarBufs F_all, const A
         __threadfence();
         wave_sync();
     }
-    plans += (size_t)blockIdx.x * kAecmMaxPktPerLaunch;
+    plans += blockIdx.x;  // [packet][cohort]: a launch uploads exactly packets x cohorts plans
     {
         const int4 *src = reinterpret_cast<const int4 *>(consts);
         int4 *dst = reinterpret_cast<int4 *>(&K);
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64) void aecm_far_kernel(AecmFarBufs F_all, const A
     if (lane < 32) mean[lane] = F.mean_far[lane];
     wave_sync();
     for (int p = 0; p < n_plans; p++) {
-        const AecmPlan &pl = plans[p];
+        const AecmPlan &pl = plans[(size_t)p * n_cohorts];
         if (pl.has_far) {
             const int16_t *src = far + (long)p * far_stride;
             for (int i = lane; i < pl.far_n; i += 64) {
@@ -789,7 +789,7 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
 #endif
 __global__ __launch_bounds__(64 * kAecmWavesPerBlock) __attribute__((amdgpu_waves_per_eu(WMX_AECM_WPE, WMX_AECM_WPE))) void aecm_near_kernel(int32_t *__restrict__ state, AecmFarBufs F_all,
                                                                             const AecmConsts *__restrict__ consts,
-                                                                            const AecmPlan *__restrict__ plans, int n_plans, const int16_t *near,
+                                                                            const AecmPlan *__restrict__ plans, int n_plans, int n_cohorts, const int16_t *near,
                                                                             int16_t *out, int n_streams, long stream_stride, long packet_stride,
                                                                             int chn, int pkg, int mult, const int *__restrict__ stream_cohort,
                                                                             const uint8_t *__restrict__ active) {
@@ -815,12 +815,12 @@ __global__ __launch_bounds__(64 * kAecmWavesPerBlock) __attribute__((amdgpu_wave
     // the cohort this stream belongs to (wave-uniform): its far-end history and its plans
     const int grp = stream_cohort ? __builtin_amdgcn_readfirstlane(stream_cohort[s]) : 0;
     const AecmFarBufs F = far_cohort(F_all, grp);
-    plans += (size_t)grp * kAecmMaxPktPerLaunch;
+    plans += grp;
     const LdsScal sc{&W.st[A_SCAL]};
     int16_t *near_ring = reinterpret_cast<int16_t *>(&W.st[A_NEAR_RING]), *out_ring = reinterpret_cast<int16_t *>(&W.st[A_OUT_RING]);
     int16_t *d_prev = reinterpret_cast<int16_t *>(&W.st[A_D_PREV]);
     for (int p = 0; p < n_plans; p++) {
-        const AecmPlan &pl = plans[p];
+        const AecmPlan &pl = plans[(size_t)p * n_cohorts];
         if (!pl.has_near) continue;
         const int16_t *ip = near + s * stream_stride + (long)p * packet_stride;
         int16_t *op = out + s * stream_stride + (long)p * packet_stride;
@@ -910,10 +910,15 @@ struct wmx_aecm {
     void *d_far;  // one allocation carved into AecmFarBufs
     wmx::AecmFarBufs far;
     wmx::AecmPlan *d_plans[2];  // double-buffered: a chunk's plans stay untouched while its kernels may still run
-    hipEvent_t plan_free[2];    // recorded behind the kernels that read d_plans[i]; waited for before it is rewritten
+    wmx::AecmPlan *h_plans[2];  // pinned mirrors: the asynchronous copy reads them in place
+    hipEvent_t plan_free[2];    // recorded behind the kernels that read d_plans[i]; waited for before it (and its mirror) is rewritten
     bool plan_used[2];
     int plan_sel;
-    std::vector<wmx::AecmPlan> h_plans;
+    int cap_cohorts;            // cohorts the far slabs and plan slots are allocated for; grows by doubling (wmx_aecm_add_cohort)
+    size_t far_bytes;           // bytes of one cohort's far-end slab
+    std::vector<uint8_t> live;  // [n_cohorts] 0: retired, never called, the id is handed out again
+    std::vector<int> rc_g;             // per-call scratch kept with the handle
+    std::vector<int32_t> same_delay;
 };
 
 extern "C" {
@@ -925,12 +930,70 @@ int wmx_aecm_destroy(wmx_aecm *h) {
     if (h->d_consts) (void)hipFree(h->d_consts);
     if (h->d_far) (void)hipFree(h->d_far);
     if (h->d_plans[0]) (void)hipFree(h->d_plans[0]);
+    if (h->h_plans[0]) (void)hipHostFree(h->h_plans[0]);
     if (h->d_tmpl) (void)hipFree(h->d_tmpl);
     if (h->d_stream_cohort) (void)hipFree(h->d_stream_cohort);
     h->life.release();
     for (int i = 0; i < 2; i++)
         if (h->plan_free[i]) (void)hipEventDestroy(h->plan_free[i]);
     delete h;
+    return 0;
+}
+
+static void aecm_carve_far(wmx_aecm *h) {  // the far-end allocation (32-bit arrays first: alignment); one slab per cohort
+    using namespace wmx;
+    char *p = static_cast<char *>(h->d_far);
+    h->far.mean_far = reinterpret_cast<int32_t *>(p);
+    p += sizeof(int32_t) * 36;
+    h->far.hist_q = reinterpret_cast<int32_t *>(p);
+    p += sizeof(int32_t) * kAecmHist;
+    h->far.hist_bin = reinterpret_cast<uint32_t *>(p);
+    p += sizeof(uint32_t) * kAecmHist;
+    h->far.hist = reinterpret_cast<uint16_t *>(p);
+    p += sizeof(uint16_t) * (size_t)kAecmHist * kAecmBP;
+    h->far.ring = reinterpret_cast<int16_t *>(p);
+    p += sizeof(int16_t) * kAecmFarRing;
+    h->far.old = reinterpret_cast<int16_t *>(p);
+    p += sizeof(int16_t) * 2 * kAecmFrame;
+    h->far.frame = reinterpret_cast<int16_t *>(p);
+    p += sizeof(int16_t) * kAecmFrameRing;
+    h->far.x_prev = reinterpret_cast<int16_t *>(p);
+    h->far.group_bytes = h->far_bytes;
+}
+
+// far slabs and plan slots for `cap` cohorts (existing slabs carried over); everything new is allocated before anything old is let go
+static int aecm_reserve(wmx_aecm *h, int cap) {
+    using namespace wmx;
+    if (cap <= h->cap_cohorts) return 0;
+    WMX_HIP_RC(hipDeviceSynchronize());
+    int ncap = h->cap_cohorts > 0 ? h->cap_cohorts : 1;
+    while (ncap < cap) ncap *= 2;
+    void *nf = nullptr;
+    AecmPlan *nd = nullptr, *nh = nullptr;
+    const size_t plan_bytes = 2 * (size_t)ncap * kAecmMaxPktPerLaunch * sizeof(AecmPlan);
+    hipError_t e = hipMalloc(&nf, h->far_bytes * (size_t)ncap);
+    if (e == hipSuccess) e = hipMalloc(&nd, plan_bytes);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&nh), plan_bytes, hipHostMallocDefault);
+    if (e == hipSuccess && h->d_far) e = hipMemcpy(nf, h->d_far, h->far_bytes * (size_t)h->cap_cohorts, hipMemcpyDeviceToDevice);
+    if (e == hipSuccess)
+        e = hipMemset(static_cast<char *>(nf) + h->far_bytes * (size_t)h->cap_cohorts, 0, h->far_bytes * (size_t)(ncap - h->cap_cohorts));
+    if (e != hipSuccess) {
+        if (nf) (void)hipFree(nf);
+        if (nd) (void)hipFree(nd);
+        if (nh) (void)hipHostFree(nh);
+        return hip_fail(e, "growing the cohort buffers", __FILE__, __LINE__);
+    }
+    if (h->d_far) (void)hipFree(h->d_far);
+    if (h->d_plans[0]) (void)hipFree(h->d_plans[0]);
+    if (h->h_plans[0]) (void)hipHostFree(h->h_plans[0]);
+    h->d_far = nf;
+    h->d_plans[0] = nd;
+    h->d_plans[1] = nd + (size_t)ncap * kAecmMaxPktPerLaunch;
+    h->h_plans[0] = nh;
+    h->h_plans[1] = nh + (size_t)ncap * kAecmMaxPktPerLaunch;
+    h->plan_used[0] = h->plan_used[1] = false;  // drained above
+    h->cap_cohorts = ncap;
+    aecm_carve_far(h);
     return 0;
 }
 
@@ -969,10 +1032,12 @@ int wmx_aecm_create_cohorts(wmx_aecm **out, int n_streams, int chn, int freq, in
     h->d_consts = nullptr;
     h->d_far = nullptr;
     h->d_plans[0] = h->d_plans[1] = nullptr;
+    h->h_plans[0] = h->h_plans[1] = nullptr;
     h->plan_free[0] = h->plan_free[1] = nullptr;
     h->plan_used[0] = h->plan_used[1] = false;
     h->plan_sel = 0;
-    h->h_plans.resize((size_t)n_cohorts * kAecmMaxPktPerLaunch);
+    h->cap_cohorts = 0;
+    h->live.assign((size_t)n_cohorts, 1);
 
     AecmConsts *K = new AecmConsts();
     memset(K, 0, sizeof(*K));
@@ -1025,7 +1090,7 @@ int wmx_aecm_create_cohorts(wmx_aecm **out, int n_streams, int chn, int freq, in
     }
     const size_t far_raw = sizeof(int16_t) * (kAecmFarRing + 2 * kAecmFrame + kAecmFrameRing + 64 + 8) + sizeof(int32_t) * (36 + kAecmHist) +
                            sizeof(uint16_t) * (size_t)kAecmHist * kAecmBP + sizeof(uint32_t) * kAecmHist + 64;
-    const size_t far_bytes = (far_raw + 255) / 256 * 256;  // per cohort
+    h->far_bytes = (far_raw + 255) / 256 * 256;  // per cohort
     hipError_t e;
 #define AECM_TRY(x)                                         \
     if ((e = (x)) != hipSuccess) {                          \
@@ -1036,9 +1101,14 @@ int wmx_aecm_create_cohorts(wmx_aecm **out, int n_streams, int chn, int freq, in
     }
     AECM_TRY(hipMalloc(&h->d_state, (size_t)A_WORDS * n_streams * sizeof(int32_t)));
     AECM_TRY(hipMalloc(&h->d_consts, sizeof(AecmConsts)));
-    AECM_TRY(hipMalloc(&h->d_far, far_bytes * n_cohorts));
-    AECM_TRY(hipMalloc(&h->d_plans[0], 2 * (size_t)n_cohorts * kAecmMaxPktPerLaunch * sizeof(AecmPlan)));
-    h->d_plans[1] = h->d_plans[0] + (size_t)n_cohorts * kAecmMaxPktPerLaunch;
+    {
+        const int rc = aecm_reserve(h, n_cohorts);
+        if (rc != 0) {
+            wmx_aecm_destroy(h);
+            delete K;
+            return rc;
+        }
+    }
     if (n_cohorts > 1) {
         AECM_TRY(hipMalloc(&h->d_stream_cohort, sizeof(int) * n_streams));
         AECM_TRY(hipMemset(h->d_stream_cohort, 0, sizeof(int) * n_streams));
@@ -1048,31 +1118,11 @@ int wmx_aecm_create_cohorts(wmx_aecm **out, int n_streams, int chn, int freq, in
     AECM_TRY(hipMalloc(&h->d_tmpl, A_WORDS * sizeof(int32_t)));
     AECM_TRY(hipMemcpy(h->d_consts, K, sizeof(AecmConsts), hipMemcpyHostToDevice));
     AECM_TRY(hipMemcpy(h->d_tmpl, st.data(), A_WORDS * sizeof(int32_t), hipMemcpyHostToDevice));
-    AECM_TRY(hipMemset(h->d_far, 0, far_bytes * n_cohorts));
     hipLaunchKernelGGL(aecm_fill_state, dim3(1024), dim3(256), 0, nullptr, h->d_state, h->d_tmpl, (int)A_WORDS, n_streams);
     AECM_TRY(hipGetLastError());
     AECM_TRY(hipDeviceSynchronize());
 #undef AECM_TRY
     delete K;
-    {  // carve the far-end allocation (32-bit arrays first: alignment)
-        char *p = static_cast<char *>(h->d_far);
-        h->far.mean_far = reinterpret_cast<int32_t *>(p);
-        p += sizeof(int32_t) * 36;
-        h->far.hist_q = reinterpret_cast<int32_t *>(p);
-        p += sizeof(int32_t) * kAecmHist;
-        h->far.hist_bin = reinterpret_cast<uint32_t *>(p);
-        p += sizeof(uint32_t) * kAecmHist;
-        h->far.hist = reinterpret_cast<uint16_t *>(p);
-        p += sizeof(uint16_t) * (size_t)kAecmHist * kAecmBP;
-        h->far.ring = reinterpret_cast<int16_t *>(p);
-        p += sizeof(int16_t) * kAecmFarRing;
-        h->far.old = reinterpret_cast<int16_t *>(p);
-        p += sizeof(int16_t) * 2 * kAecmFrame;
-        h->far.frame = reinterpret_cast<int16_t *>(p);
-        p += sizeof(int16_t) * kAecmFrameRing;
-        h->far.x_prev = reinterpret_cast<int16_t *>(p);
-        h->far.group_bytes = far_bytes;
-    }
     *out = h;
     return 0;
 }
@@ -1087,9 +1137,9 @@ int wmx_aecm_run(wmx_aecm *h, int mode, const int16_t *d_far, long far_packet_st
         wmx::set_error("wmx_aecm_run: bad argument");
         return WMX_EINVAL;
     }
-    std::vector<int32_t> delays((size_t)h->n_cohorts, delay_ms);
-    return wmx_aecm_run_cohorts(h, mode, d_far, far_packet_stride, 0, d_near, d_out, n_packets, stream_stride, packet_stride, delays.data(),
-                                nullptr, nullptr, stream);
+    h->same_delay.assign((size_t)h->n_cohorts, delay_ms);
+    return wmx_aecm_run_cohorts(h, mode, d_far, far_packet_stride, 0, d_near, d_out, n_packets, stream_stride, packet_stride,
+                                h->same_delay.data(), nullptr, nullptr, stream);
 }
 
 // Same contract as wmx_aec_run_cohorts (include/wmix_amd.h): one reported delay, one on/off byte and one return code per cohort.
@@ -1120,18 +1170,24 @@ int wmx_aecm_run_cohorts(wmx_aecm *h, int mode, const int16_t *d_far, long far_p
         return WMX_EINVAL;
     }
     hipStream_t s = as_stream(stream);
-    std::vector<int> rc_g((size_t)G, 0);
+    std::vector<int> &rc_g = h->rc_g;
+    rc_g.assign((size_t)G, 0);
     int rc_first = 0, running = 0;
-    for (int g = 0; g < G; g++) running += (!cohort_on || cohort_on[g]) ? 1 : 0;
+    for (int g = 0; g < G; g++) running += (h->live[(size_t)g] && (!cohort_on || cohort_on[g])) ? 1 : 0;
     for (int done = 0; done < n_packets && running > 0;) {
         int chunk = n_packets - done;
         if (chunk > kAecmMaxPktPerLaunch) chunk = kAecmMaxPktPerLaunch;
+        // the next plan slot: its pinned host half and its device half are rewritten only after the kernels that read the device
+        // half last have finished, whatever stream they ran on
+        const int sel = h->plan_sel;
+        h->plan_sel ^= 1;
+        if (h->plan_used[sel]) WMX_HIP(hipEventSynchronize(h->plan_free[sel]));
+        AecmPlan *hp = h->h_plans[sel], *dp = h->d_plans[sel];  // [packet][cohort], G apart: chunk x G plans are uploaded
         int any = 0;
         for (int g = 0; g < G; g++) {
-            AecmPlan *pg = h->h_plans.data() + (size_t)g * kAecmMaxPktPerLaunch;
-            const bool on = (!cohort_on || cohort_on[g]) && rc_g[g] == 0;
+            const bool on = h->live[(size_t)g] && (!cohort_on || cohort_on[g]) && rc_g[g] == 0;
             for (int k = 0; k < chunk; k++) {
-                AecmPlan &pl = pg[k];
+                AecmPlan &pl = hp[(size_t)k * G + g];
                 memset(&pl, 0, sizeof(pl));
                 if (!on || rc_g[g] != 0) continue;  // has_far = has_near = 0: both kernels skip the packet for this cohort
                 any = 1;
@@ -1160,21 +1216,15 @@ int wmx_aecm_run_cohorts(wmx_aecm *h, int mode, const int16_t *d_far, long far_p
             }
         }
         if (any) {
-            const int sel = h->plan_sel;
-            AecmPlan *dp = h->d_plans[sel];
-            h->plan_sel ^= 1;
-            // The device buffer alternates and is rewritten only after the kernels that read it last have finished (they
-            // may run on any user stream); the copy itself is blocking, so the pageable host vector can be reused at once.
-            if (h->plan_used[sel]) WMX_HIP(hipEventSynchronize(h->plan_free[sel]));
             const int by_value = (chunk == 1 && G == 1) ? 1 : 0;
-            if (!by_value) WMX_HIP(hipMemcpy(dp, h->h_plans.data(), (size_t)G * kAecmMaxPktPerLaunch * sizeof(AecmPlan), hipMemcpyHostToDevice));
-            hipLaunchKernelGGL(aecm_far_kernel, dim3((unsigned)G), dim3(64), 0, s, h->far, h->d_consts, dp, chunk,
+            if (!by_value) WMX_HIP(hipMemcpyAsync(dp, hp, (size_t)G * chunk * sizeof(AecmPlan), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(aecm_far_kernel, dim3((unsigned)G), dim3(64), 0, s, h->far, h->d_consts, dp, chunk, G,
                                d_far ? d_far + (size_t)done * far_packet_stride : nullptr, far_packet_stride, far_group_stride, h->chn, by_value,
-                               h->h_plans[0]);
+                               hp[0]);
             WMX_LAUNCH_CHECK();
             if (mode & 2) {
                 const unsigned grid = (unsigned)((h->n_streams + kAecmWavesPerBlock - 1) / kAecmWavesPerBlock);
-                hipLaunchKernelGGL(aecm_near_kernel, dim3(grid), dim3(64 * kAecmWavesPerBlock), 0, s, h->d_state, h->far, h->d_consts, dp, chunk,
+                hipLaunchKernelGGL(aecm_near_kernel, dim3(grid), dim3(64 * kAecmWavesPerBlock), 0, s, h->d_state, h->far, h->d_consts, dp, chunk, G,
                                    d_near + (size_t)done * packet_stride, d_out + (size_t)done * packet_stride, h->n_streams, stream_stride,
                                    packet_stride, h->chn, h->pkg, h->freq / 8000, h->d_stream_cohort, h->life.d_active);
                 WMX_LAUNCH_CHECK();
@@ -1256,6 +1306,40 @@ int wmx_aecm_reset_cohort(wmx_aecm *h, int cohort, void *stream) {
     if (!h || cohort < 0 || cohort >= h->n_cohorts) return WMX_EINVAL;
     h->ctl[(size_t)cohort].init(h->freq);
     WMX_HIP(hipMemsetAsync(static_cast<char *>(h->d_far) + (size_t)cohort * h->far.group_bytes, 0, h->far.group_bytes, as_stream(stream)));
+    return 0;
+}
+
+// A new cohort (a join time of its own), as wmx_aec_add_cohort: a retired id when there is one, else the next, buffers doubling
+int wmx_aecm_add_cohort(wmx_aecm *h, int *cohort, void *stream) {
+    WMX_ON_DEVICE(h);
+    using namespace wmx;
+    if (!h || !cohort) return WMX_EINVAL;
+    int id = -1;
+    for (int g = 0; g < h->n_cohorts; g++)
+        if (!h->live[(size_t)g]) {
+            id = g;
+            break;
+        }
+    if (id < 0) {
+        id = h->n_cohorts;
+        const int rc = aecm_reserve(h, id + 1);
+        if (rc != 0) return rc;
+        h->ctl.resize((size_t)id + 1);
+        h->live.push_back(1);
+        h->n_cohorts = id + 1;
+    }
+    if (h->n_cohorts > 1 && !h->d_stream_cohort) {  // so far every stream was in cohort 0 by construction
+        WMX_HIP(hipMalloc(&h->d_stream_cohort, sizeof(int) * h->n_streams));
+        WMX_HIP(hipMemsetAsync(h->d_stream_cohort, 0, sizeof(int) * h->n_streams, as_stream(stream)));
+    }
+    h->live[(size_t)id] = 1;
+    *cohort = id;
+    return wmx_aecm_reset_cohort(h, id, stream);
+}
+
+int wmx_aecm_retire_cohort(wmx_aecm *h, int cohort) {
+    if (!h || cohort < 0 || cohort >= h->n_cohorts) return WMX_EINVAL;
+    h->live[(size_t)cohort] = 0;
     return 0;
 }
 

@@ -212,24 +212,20 @@ int wmx_chain_reset_cohort(wmx_chain *h, int cohort, void *stream) {
 int wmx_chain_add_cohort(wmx_chain *h, int *cohort, void *stream) {
     WMX_ON_DEVICE(h);
     if (!h || !cohort) return WMX_EINVAL;
-    if (h->aecm) {  // the AECM's cohorts are fixed at create (wmx_aecm_create_cohorts)
-        wmx::set_error("wmx_chain_add_cohort: not available with WMX_CHAIN_AECM (create the chain with the cohorts it needs)");
-        return WMX_ESTATE;
-    }
-    if (!h->aec) {
+    if (!h->aec && !h->aecm) {
         *cohort = 0;
         return 0;
     }
-    const int rc = wmx_aec_add_cohort(h->aec, cohort, stream);
+    const int rc = h->aec ? wmx_aec_add_cohort(h->aec, cohort, stream) : wmx_aecm_add_cohort(h->aecm, cohort, stream);
     if (rc != 0) return rc;
-    h->n_cohorts = wmx_aec_cohorts(h->aec);
+    h->n_cohorts = h->aec ? wmx_aec_cohorts(h->aec) : wmx_aecm_cohorts(h->aecm);
     h->zero_delays.assign((size_t)h->n_cohorts, 0);
     return 0;
 }
 
 int wmx_chain_retire_cohort(wmx_chain *h, int cohort) {
     if (!h) return WMX_EINVAL;
-    return h->aec ? wmx_aec_retire_cohort(h->aec, cohort) : 0;
+    return h->aec ? wmx_aec_retire_cohort(h->aec, cohort) : (h->aecm ? wmx_aecm_retire_cohort(h->aecm, cohort) : 0);
 }
 
 int wmx_chain_cohorts(const wmx_chain *h) { return h ? h->n_cohorts : WMX_EINVAL; }

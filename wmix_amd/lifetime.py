@@ -38,8 +38,7 @@ class Lifetime:
         n = getattr(lib(), "wmx_%s_cohorts" % self._mod)(self._h)
         if self._mod == "aec":
             self.n_far = n
-        else:
-            self.n_cohorts = n
+        self.n_cohorts = n
         return c.value
 
     def retire_cohort(self, cohort):
