@@ -21,6 +21,7 @@ chain_8k|aec|aec_near_kernel<1>|4
 ns|ns|ns_kernel<256, true, 1>|5
 ns_agc_mix_32k|ns|ns_kernel<256, true, 2>|5
 nsx|nsx|nsx_kernel<256, 1>|5
+chain_fx|nsx|nsx_kernel<256, 1>|5
 aecm|aecm|aecm_near_kernel|7
 g711|g711|g711_encode_kernel<1>|8
 mfft|mfft|mfft_regs_kernel<1, false, 9>|4
