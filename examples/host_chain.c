@@ -8,14 +8,16 @@
  * (the single exchange of the path; a host that produces the far-end on a GPU uses one ncclBroadcast instead),
  * uploads its shard's captured packets, makes ONE library call (wmx_chain_process) and downloads the result.
  *
- *   host_chain far.i16 near.i16 out.i16 n_streams n_ticks [n_workers] [freq] [--devices k]
+ *   host_chain far.i16 near.i16 out.i16 n_streams n_ticks [n_workers] [freq] [--devices k] [--interval-ms 20]
  *
  * far.i16  int16 [n_ticks][pkt]             the shared far-end          (pkt = freq / 100 samples, mono)
  * near.i16 int16 [n_streams][n_ticks][pkt]  captured audio, stream-major
  * out.i16  same shape as near.i16           what the chain leaves in the daemon's buffer
  * n_workers defaults to the device count; worker w runs on device w % device_count, so a 1-GPU box can still drive
  * several shards (tests/test_host_chain_gpu.py does, and compares out.i16 with the oracle).  --devices k: use the first k
- * devices of the node (default: all of them), so that one binary covers 1 ... 8 GPUs.
+ * devices of the node (default: all of them), so that one binary covers 1 ... 8 GPUs.  --interval-ms 20: the daemon's own cadence --
+ * handles made with WMIX_INTERVAL_MS = 20 (src/wmixConf.h:112) and a heartbeat of 20 ms = two 10 ms packets per tick (n_ticks then
+ * counts 20 ms heartbeats and every array holds 2 pkt samples per tick).
  *
  * Built with -DWMX_EXAMPLE_RCCL (examples/host_chain_rccl, links librccl) the far-end travels the way north_star puts it:
  * worker 0 alone uploads the packet, and ONE ncclBroadcast per tick (every worker calls it on its own communicator and stream)
@@ -40,7 +42,8 @@
 
 typedef struct {
     int worker, dev, lo, n;      /* this shard: streams [lo, lo + n) on HIP device dev */
-    int n_ticks, pkt, freq;
+    int n_ticks, pkt, freq;      /* pkt: int16 samples of one TICK of one stream (n10 packets of 10 ms) */
+    int interval_ms, n10;
     const int16_t *far_host;     /* [n_ticks][pkt], shared */
     const int16_t *near_host;    /* [n_streams][n_ticks][pkt] */
     int16_t *out_host;
@@ -88,7 +91,7 @@ static void *gpu_worker(void *arg) {
     const size_t pitch = (size_t)s->n_ticks * row;                /* host rows are n_ticks packets apart */
     int created = 0;
     if (hipSetDevice(s->dev) == hipSuccess && hipStreamCreate(&st) == hipSuccess &&
-        wmx_chain_create(&chain, s->n, 1, s->freq, 10, 5, WMX_CHAIN_NS | WMX_CHAIN_AEC | WMX_CHAIN_AGC | WMX_CHAIN_VAD, 1) == 0 &&
+        wmx_chain_create(&chain, s->n, 1, s->freq, s->interval_ms, 5, WMX_CHAIN_NS | WMX_CHAIN_AEC | WMX_CHAIN_AGC | WMX_CHAIN_VAD, 1) == 0 &&
         hipMalloc((void **)&d_near, (size_t)s->n * row) == hipSuccess && hipMalloc((void **)&d_far, row) == hipSuccess)
         created = 1;
     else
@@ -131,7 +134,8 @@ static void *gpu_worker(void *arg) {
 #endif
         HIP_OK(hipMemcpy2DAsync(d_near, row, s->near_host + ((size_t)s->lo * s->n_ticks + t) * s->pkt, pitch, row, (size_t)s->n,
                                 hipMemcpyHostToDevice, st));
-        WMX_OK(wmx_chain_process(chain, d_far, s->pkt, d_near, d_near, 1, s->pkt, (long)s->pkt * s->n, NULL, NULL, NULL, st));
+        /* a stream's tick in one piece: n10 packets of pkt / n10 samples, streams pkt apart */
+        WMX_OK(wmx_chain_process(chain, d_far, s->pkt / s->n10, d_near, d_near, s->n10, s->pkt, s->pkt / s->n10, NULL, NULL, NULL, st));
         HIP_OK(hipMemcpy2DAsync(s->out_host + ((size_t)s->lo * s->n_ticks + t) * s->pkt, pitch, d_near, row, row, (size_t)s->n,
                                 hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
@@ -158,16 +162,24 @@ static void *read_file(const char *path, size_t bytes) {
 }
 
 int main(int argc, char **argv) {
-    int want_dev = 0;
-    for (int i = 1; i + 1 < argc; i++) /* --devices k, wherever it stands: taken out of the positional arguments */
-        if (strcmp(argv[i], "--devices") == 0) {
-            want_dev = atoi(argv[i + 1]);
+    int want_dev = 0, interval_ms = 10;
+    for (int i = 1; i + 1 < argc;) /* --devices k / --interval-ms m, wherever they stand: taken out of the positional arguments */
+        if (strcmp(argv[i], "--devices") == 0 || strcmp(argv[i], "--interval-ms") == 0) {
+            if (argv[i][2] == 'd')
+                want_dev = atoi(argv[i + 1]);
+            else
+                interval_ms = atoi(argv[i + 1]);
             for (int j = i; j + 2 < argc; j++) argv[j] = argv[j + 2];
             argc -= 2;
-            break;
+        } else {
+            i++;
         }
+    if (interval_ms != 10 && interval_ms != 20) {
+        fprintf(stderr, "host_chain: --interval-ms 10 or 20\n");
+        return 2;
+    }
     if (argc < 6) {
-        fprintf(stderr, "usage: %s far.i16 near.i16 out.i16 n_streams n_ticks [n_workers] [freq] [--devices k]\n", argv[0]);
+        fprintf(stderr, "usage: %s far.i16 near.i16 out.i16 n_streams n_ticks [n_workers] [freq] [--devices k] [--interval-ms 20]\n", argv[0]);
         return 2;
     }
     const int n_streams = atoi(argv[4]), n_ticks = atoi(argv[5]);
@@ -183,7 +195,7 @@ int main(int argc, char **argv) {
     if (want_dev > 0) n_dev = want_dev;
     int n_workers = argc > 6 ? atoi(argv[6]) : n_dev;
     const int freq = argc > 7 ? atoi(argv[7]) : 16000;
-    const int pkt = freq / 100;
+    const int n10 = interval_ms / 10, pkt = freq / 100 * n10; /* samples of one tick of one stream */
     if (n_workers < 1 || n_workers > n_streams || n_ticks < 1) return 2;
 #ifdef WMX_EXAMPLE_RCCL
     if (n_workers > n_dev) {
@@ -222,6 +234,8 @@ int main(int argc, char **argv) {
         s->n_ticks = n_ticks;
         s->pkt = pkt;
         s->freq = freq;
+        s->interval_ms = interval_ms;
+        s->n10 = n10;
         s->far_host = far;
         s->near_host = near;
         s->out_host = out;

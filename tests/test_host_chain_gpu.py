@@ -64,3 +64,20 @@ def test_host_chain_far_end_through_rccl(tmp_path, oracle_port):
     got = np.fromfile(tmp_path / "out.i16", dtype="<i2").reshape(S, T * pkt)
     want = np.stack([L.run_chain(oracle_port, 1, freq, 5, 15, far, near[s], pkt, prefix="orc") for s in range(S)])
     check_float_path(got, want, max_fraction=1e-4)
+
+
+@pytest.mark.gpu
+def test_host_chain_at_the_daemons_cadence(tmp_path, oracle_port):
+    """--interval-ms 20: handles made with WMIX_INTERVAL_MS = 20 and 20 ms per heartbeat (src/wmixConf.h:112, src/wmix.c:613-709),
+    two shards."""
+    S, T, freq, pkt = 16, 150, 16000, 320  # T heartbeats of 20 ms
+    far = synth.far_end(9720, 2 * T, 160)
+    near = synth.near_end(9721, S, 2 * T, 160, far=far).reshape(S, T * pkt)
+    far.astype("<i2").tofile(tmp_path / "far.i16")
+    near.astype("<i2").tofile(tmp_path / "near.i16")
+    r = subprocess.run([EXE, str(tmp_path / "far.i16"), str(tmp_path / "near.i16"), str(tmp_path / "out.i16"), str(S), str(T), "2", str(freq),
+                        "--interval-ms", "20"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(tmp_path / "out.i16", dtype="<i2").reshape(S, T * pkt)
+    want = np.stack([L.run_chain(oracle_port, 1, freq, 5, 15, far, near[s], pkt, prefix="orc", interval_ms=20) for s in range(S)])
+    check_float_path(got, want, max_fraction=1e-4)
