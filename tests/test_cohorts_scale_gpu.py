@@ -159,3 +159,20 @@ def test_cohort_ids_grow_and_come_back(cuda, oracle_port, mod):
         for a, b in life[s]:
             lived[a:b] = True
         assert np.array_equal(got[s, ~lived], near[s, ~lived])  # nobody called the handle: rows untouched
+
+
+@pytest.mark.parametrize("extra", [[], ["--fx"], ["--freq", "8000"]])
+def test_churn_soak(extra):
+    """tools_dev/churn_soak.py, short: cohorts joining, leaving (retired ids handed out again) and reporting delays of 0 / 10 / 20 / 40 ms
+    for 900 ticks while the buffers grow; every life of 48 watched slots against a per-handle oracle run (float chain <= 1 LSB, the
+    fixed-point chain bit-exact).  A child process of its own."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools_dev", "churn_soak.py"), "--streams", "2048", "--ticks", "900", "--seed", "7"] + extra,
+                       cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["lives_checked"] >= 20 and d["max_lsb"] <= (0 if "--fx" in extra else 1) and d["max_cohort_ids"] >= 10

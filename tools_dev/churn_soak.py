@@ -1,0 +1,129 @@
+"""developer soak: a batch under continuous churn -- cohorts join (wmx_chain_add_cohort), leave (members idle, cohort retired, id handed
+out again) and report their own delays for thousands of ticks, while the buffers grow -- and every sampled life is compared with a
+per-handle oracle run started at its own tick.  The whole chain (or `--fx`: the fixed-point one, bit-exact).
+
+    python tools_dev/churn_soak.py [--streams 4096] [--ticks 2500] [--freq 16000] [--fx] [--seed 1]
+"""
+import argparse
+import json
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from oracle import loader as L  # noqa: E402
+from wmix_amd import synth  # noqa: E402
+from wmix_amd.chain import AEC, AECM, AGC, NS, NSX, VAD, ChainBatch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--streams", type=int, default=4096)
+    ap.add_argument("--ticks", type=int, default=2500)
+    ap.add_argument("--freq", type=int, default=16000)
+    ap.add_argument("--fx", action="store_true")
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    S, T, freq, K, U = a.streams, a.ticks, a.freq, 200, 64
+    pkt = freq // 100
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(a.seed)
+    far = synth.far_end(5000 + a.seed, K, pkt).reshape(K, pkt)
+    base = synth.near_end(5001 + a.seed, U, K, pkt, far=far.reshape(-1)).reshape(U, K, pkt)
+    inp = torch.from_numpy(np.ascontiguousarray(base.transpose(1, 0, 2))).to(dev)[:, torch.arange(S, device=dev) % U]
+    dfar = torch.from_numpy(far.copy()).to(dev)
+    work = torch.empty_like(inp[0:1])
+    stages = NS | AEC | AGC | VAD | ((NSX | AECM) if a.fx else 0)
+    cb = ChainBatch(S, 1, freq, 10, 5, stages=stages, n_cohorts=1)
+    active = np.zeros(S, np.uint8)
+    free = list(rng.permutation(S))
+    cohorts = {}      # id -> dict(members, delay, born)
+    lives = []        # (stream, start, end, delay)
+    open_life = {}    # stream -> (start, delay)
+    watch = set(int(x) for x in rng.choice(S, 48, replace=False))
+    dwatch = torch.tensor(sorted(watch), device=dev)
+    col = {s: i for i, s in enumerate(sorted(watch))}
+    rec = torch.empty(T, len(watch), pkt, dtype=torch.int16, device=dev)
+    first = True
+    t_wall = time.time()
+    max_cohorts = 0
+    for t in range(T):
+        changed = False
+        # leave: a random cohort's handles are released
+        if cohorts and rng.random() < 0.04:
+            c = int(rng.choice(list(cohorts)))
+            info = cohorts.pop(c)
+            active[info["members"]] = 0
+            for s in info["members"]:
+                st, dl = open_life.pop(int(s))
+                lives.append((int(s), st, t, dl))
+                free.append(int(s))
+            cb.retire_cohort(c)
+            changed = True
+        # join: a new cohort with its own delay
+        if free and (first or rng.random() < 0.08):
+            n = int(min(len(free), rng.integers(1, max(2, S // 40))))
+            members = np.array([free.pop() for _ in range(n)], np.int32)
+            if first:
+                c = 0
+                cb.reset_cohort(0)
+                first = False
+            else:
+                c = cb.add_cohort()
+            dl = int(rng.choice([0, 0, 10, 20, 40]))
+            cohorts[c] = {"members": members, "delay": dl, "born": t}
+            cb.reset_streams(members, cohort=c)
+            active[members] = 1
+            for s in members:
+                open_life[int(s)] = (t, dl)
+            changed = True
+        if changed:
+            cb.set_active(active)
+        G = cb.n_cohorts
+        max_cohorts = max(max_cohorts, G)
+        delays = np.zeros(G, np.int32)
+        on = np.zeros(G, np.uint8)
+        for c, info in cohorts.items():
+            delays[c] = info["delay"]
+            on[c] = 1
+        rc, codes, _ = cb.process_packet_major(dfar[t % K:t % K + 1], inp[t % K:t % K + 1], out=work, delays=delays, cohort_on=on)
+        assert rc == 0 and not codes.any(), (t, rc, codes)
+        rec[t] = work[0, dwatch]
+    for s, (st, dl) in open_life.items():
+        lives.append((s, st, T, dl))
+    n_host, sec = cb.aec_host_ctl() if not a.fx else (0, 0.0)
+    cb.close()
+    got = rec.cpu().numpy()
+    port = L.port()
+    far_seq = np.concatenate([far[t % K] for t in range(T)])
+    worst, n_lives, n_pk = 0, 0, 0
+    for s, st, en, dl in lives:
+        if s not in watch or en - st < 2:
+            continue
+        near = np.concatenate([base[s % U, t % K] for t in range(st, en)])
+        f = far_seq[st * pkt:en * pkt]
+        if a.fx:
+            x = L.run_nsx(port, 1, freq, near, pkt, prefix="orc")
+            x = L.run_aecm(port, 1, freq, 10, f, x, pkt, dl, prefix="orc")
+            x = L.run_agc(port, 1, freq, 5, x, pkt, prefix="orc")
+            want = L.run_vad(port, 1, freq, 10, x, pkt, prefix="orc")
+        else:
+            x = L.run_ns(port, 1, freq, near, pkt, prefix="orc")
+            x = L.run_aec(port, 1, freq, 10, f, x, pkt, dl, prefix="orc")
+            x = L.run_agc(port, 1, freq, 5, x, pkt, prefix="orc")
+            want = L.run_vad(port, 1, freq, 10, x, pkt, prefix="orc")
+        d = np.abs(got[st:en, col[s]].reshape(-1).astype(np.int32) - want.astype(np.int32))
+        worst = max(worst, int(d.max()))
+        n_lives += 1
+        n_pk += en - st
+    print(json.dumps({"streams": S, "ticks": T, "freq": freq, "fixed_point": a.fx, "lives_total": len(lives), "lives_checked": n_lives,
+                      "packets_checked": n_pk, "max_lsb": worst, "max_cohort_ids": max_cohorts, "cohorts_alive_at_end": len(cohorts),
+                      "wall_s": round(time.time() - t_wall, 1),
+                      "host_ctl_us_per_tick": (sec / n_host * 1e6 if n_host else None)}))
+    assert worst <= (0 if a.fx else 1)
+
+
+if __name__ == "__main__":
+    main()
