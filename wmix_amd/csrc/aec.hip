@@ -1804,7 +1804,7 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
                     const int rc = aec_rebuild_order(h, s);
                     if (rc != 0) return rc;
                 }
-                h->order_age++;
+                if (h->order_age < wmx_aec::kOrderEvery) h->order_age++;  // saturates: a service runs for months
                 const int32_t *order = ordered ? h->d_order : nullptr;
                 const unsigned grid = ordered ? h->order_wgs : (unsigned)((h->n_streams + kAecWavesPerBlock - 1) / kAecWavesPerBlock);
                 const dim3 blk(64 * kAecWavesPerBlock);
