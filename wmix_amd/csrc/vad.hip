@@ -819,12 +819,16 @@ __device__ __forceinline__ void vad_pipe_channels(const VadRef &S, int16_t *s16,
 // RATIO = 1 (8 kHz) or 2 (16 kHz); NB = 80: mono 10 ms packets, 160: mono 20 ms packets (what vad_init makes of the daemon's
 // WMIX_INTERVAL_MS = 20, src/webrtc.c:57-66, src/wmixConf.h:112); 16-byte aligned rows (what wmx_vad_process checks)
 template <int RATIO, int NB>
-__global__ __launch_bounds__(256) void vad_pipe_kernel(int16_t *s16, int32_t *s32, int16_t *pcm, int n_streams, int packets_per_call,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 80 ? 4 : (RATIO == 1 ? 3 : 2), NB == 80 ? 4 : (RATIO == 1 ? 3 : 2)))) void vad_pipe_kernel(int16_t *s16, int32_t *s32, int16_t *pcm, int n_streams, int packets_per_call,
                                                        int n_calls, long stream_stride, long call_stride, const uint8_t *__restrict__ active) {
     constexpr int PKG = NB * RATIO, NV = PKG / 8;
     // mode-3 thresholds and hangover lengths of the frame length (vad_core.c:88-91; gmm_probability above)
     constexpr int GLOB = NB == 80 ? 1100 : 1050, OH1 = NB == 80 ? 6 : 3, OH2 = NB == 80 ? 9 : 5;
-    __shared__ __attribute__((aligned(16))) int16_t lds[64 * (NB / 2 + NB / 2 + NB / 4 + NB / 4)];
+    // band buffers of the filter-bank wave: hp120 | lp120 | lp60, with hp60 IN PLACE over hp120 -- a split writes output i from inputs
+    // 2 i and 2 i + 1, so its high-pass half can take the place of its own input, and by the time the later splits write into
+    // these regions what they held has been turned into its log-energy (vad_features_rest's order).  1.25 NB instead of 1.5 NB
+    // samples per stream: the 20 ms kernel fits three workgroups per CU instead of two (50.2 KB with the order statistics).
+    __shared__ __attribute__((aligned(16))) int16_t lds[64 * (NB / 2 + NB / 2 + NB / 4)];
     __shared__ int16_t minlds[64 * kVadMinFields];
     int32_t *xch = reinterpret_cast<int32_t *>(lds);
     static_assert(X_FIELDS * 64 * 4 <= (int)sizeof(lds), "exchange area must fit in the band buffers");
@@ -863,7 +867,7 @@ __global__ __launch_bounds__(256) void vad_pipe_kernel(int16_t *s16, int32_t *s3
     S.h(V16_NUM_SPEECH) = g16[(size_t)V16_NUM_SPEECH * n_streams];
 #pragma unroll
     for (int i = 0; i < 4; i++) S.w(V32_DS + i) = s32[(size_t)(V32_DS + i) * n_streams + stream];
-    const LaneBuf hp120{lds + lane}, lp120{lds + lane + 64 * (NB / 2)}, hp60{lds + lane + 64 * NB}, lp60{lds + lane + 64 * (NB + NB / 4)};
+    const LaneBuf hp120{lds + lane}, lp120{lds + lane + 64 * (NB / 2)}, hp60{lds + lane}, lp60{lds + lane + 64 * NB};
     // A call of several packets analyses its FIRST packet once per packet (the wrapper never advances its pointer)
     // and attenuates that packet after the first analysis only: the later analyses see the attenuated samples.
     for (int pass = 0; pass < n_calls * packets_per_call; pass++) {
