@@ -362,9 +362,13 @@ __global__ __launch_bounds__(256, CHN == 1 ? 4 : 2) void agc_pipe_kernel(int16_t
                                                        long packet_stride, const uint8_t *__restrict__ active) {
     constexpr int L2 = (L == 8) ? 3 : 4, VPS = L * CHN / 8;  // uint4 per sub-frame
     __shared__ int32_t gain_table[32];
-    __shared__ int16_t xdet[80 * 64];  // the detector's 80 input samples of every stream, [sample][lane]
-    __shared__ int32_t xenv[10 * 64];  // per-millisecond peak energies
-    __shared__ int32_t xgain[11 * 64];
+    // Exchange areas, TWICE: the packets of a launch are pipelined -- while wave 3 runs packet p's serial part on one set, waves 0..2
+    // apply packet p - 1's gains from the other gain area and put packet p + 1's peaks and detector input into the other input
+    // set.  One workgroup barrier per packet instead of three, and a packet behind the first costs max(serial part, pass 2 + pass 1)
+    // instead of their sum (round 4: the daemon's own heartbeat is two packets per call, configs[4]'s 10 ms are two 5 ms packets).
+    __shared__ int16_t xdet[2][80 * 64];  // the detector's 80 input samples of every stream, [sample][lane]
+    __shared__ int32_t xenv[2][10 * 64];  // per-millisecond peak energies
+    __shared__ int32_t xgain[2][11 * 64];
     if (threadIdx.x < 32) gain_table[threadIdx.x] = gain_table_g[threadIdx.x];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -382,118 +386,129 @@ __global__ __launch_bounds__(256, CHN == 1 ? 4 : 2) void agc_pipe_kernel(int16_t
 #pragma unroll
         for (int f = 0; f < A16_WORDS; f++) r16[f] = s16[(size_t)f * n_streams + stream];
     }
-    for (int p = 0; p < n_packets; p++) {
+    auto sample = [](const uint4 (&raw)[VPS], int i) -> int16_t {  // mono sample i of a sub-frame (compile-time i)
+        if constexpr (CHN == 1) {
+            const uint4 v = raw[i >> 3];
+            const unsigned w = ((i >> 1) & 3) == 0 ? v.x : (((i >> 1) & 3) == 1 ? v.y : (((i >> 1) & 3) == 2 ? v.z : v.w));
+            return (int16_t)((i & 1) ? (w >> 16) : (w & 0xffffu));
+        } else {  // frame i = one word: left | right << 16
+            const uint4 v = raw[i >> 2];
+            const unsigned w = (i & 3) == 0 ? v.x : ((i & 3) == 1 ? v.y : ((i & 3) == 2 ? v.z : v.w));
+            const int32_t acc = (int32_t)(int16_t)(w & 0xffffu) + (int32_t)(int16_t)(w >> 16);
+            return (int16_t)(acc / 2);
+        }
+    };
+    // ---- pass 1 of packet p (waves 0..2, this wave's share): peak energy per sub-frame, the detector's input samples -> set p & 1.
+    //      All of the wave's sub-frames are requested at once; pass 2 fetches them again from L2 -- held across the barriers, the
+    //      samples cost the registers that decide how many workgroups share a CU.
+    auto pass1 = [&](int p) {
+        const uint4 *in4 = reinterpret_cast<const uint4 *>(in + (size_t)stream * stream_stride + (size_t)p * packet_stride);
+        int16_t *det = xdet[p & 1];
+        int32_t *env = xenv[p & 1];
+        uint4 raw[4][VPS];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+            if (kk < nk) {
+#pragma unroll
+                for (int j = 0; j < VPS; j++) raw[kk][j] = in4[(k0 + kk) * VPS + j];
+            }
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+            if (kk < nk) {
+                int32_t mx = 0;
+#pragma unroll
+                for (int n = 0; n < L; n++) {
+                    const int32_t x = sample(raw[kk], n);
+                    const int32_t e = x * x;
+                    if (e > mx) mx = e;
+                }
+                env[(k0 + kk) * 64 + lane] = mx;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int16_t d = L == 16 ? (int16_t)(((int32_t)sample(raw[kk], 2 * j) + (int32_t)sample(raw[kk], 2 * j + 1)) >> 1) : sample(raw[kk], j);
+                    det[((k0 + kk) * 8 + j) * 64 + lane] = d;
+                }
+            }
+    };
+    // ---- the serial part of packet p (wave 3): the detector's decimator, ProcessVad's statistics, the envelope followers, gain curve,
+    //      gate and limiter -> the eleven gains of set p & 1
+    auto serial = [&](int p) {
+        const int16_t *det = xdet[p & 1];
+        int32_t env[10], gains[11], nrg = 0;
+        int32_t ds[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) ds[i] = S.w(A32_DOWN + i);
+        int16_t hp = S.h(A16_HP);
+#pragma unroll 2
+        for (int k = 0; k < 10; k++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int16_t b2 = down2_step(det[(k * 8 + 2 * j) * 64 + lane], det[(k * 8 + 2 * j + 1) * 64 + lane], ds);
+                const int32_t o = b2 + hp;
+                const int32_t t = 600 * o;
+                hp = (int16_t)((t >> 10) - b2);
+                nrg = wadd(nrg, wmul(o, o) >> 6);  // |o| reaches 65 534: the square wraps in the reference (digital_agc.c:633), negative included
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) S.w(A32_DOWN + i) = ds[i];
+        S.h(A16_HP) = hp;
+#pragma unroll
+        for (int k = 0; k < 10; k++) env[k] = xenv[p & 1][k * 64 + lane];
+        agc_decide(S, gain_table, nrg, env, gains);
+#pragma unroll
+        for (int k = 0; k < 11; k++) xgain[p & 1][k * 64 + lane] = gains[k];
+    };
+    // ---- pass 2 of packet p (waves 0..2, this wave's share): the ramped gain applied, samples stored
+    auto pass2 = [&](int p) {
         const size_t off = (size_t)stream * stream_stride + (size_t)p * packet_stride;
         const uint4 *in4 = reinterpret_cast<const uint4 *>(in + off);
         uint4 *out4 = reinterpret_cast<uint4 *>(out + off);
-        auto sample = [](const uint4 (&raw)[VPS], int i) -> int16_t {  // mono sample i of a sub-frame (compile-time i)
-            if constexpr (CHN == 1) {
-                const uint4 v = raw[i >> 3];
-                const unsigned w = ((i >> 1) & 3) == 0 ? v.x : (((i >> 1) & 3) == 1 ? v.y : (((i >> 1) & 3) == 2 ? v.z : v.w));
-                return (int16_t)((i & 1) ? (w >> 16) : (w & 0xffffu));
-            } else {  // frame i = one word: left | right << 16
-                const uint4 v = raw[i >> 2];
-                const unsigned w = (i & 3) == 0 ? v.x : ((i & 3) == 1 ? v.y : ((i & 3) == 2 ? v.z : v.w));
-                const int32_t acc = (int32_t)(int16_t)(w & 0xffffu) + (int32_t)(int16_t)(w >> 16);
-                return (int16_t)(acc / 2);
+        const int32_t *gn = xgain[p & 1];
+        uint4 raw[4][VPS];  // every load before the first store (in == out)
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+            if (kk < nk) {
+#pragma unroll
+                for (int j = 0; j < VPS; j++) raw[kk][j] = in4[(k0 + kk) * VPS + j];
             }
-        };
-        // ---- pass 1, this wave's share: peak energy per sub-frame, the detector's input samples.  One sub-frame in
-        //      registers at a time (the next one requested while this one is reduced); pass 2 fetches them again from L2 --
-        //      held across the barriers, the samples cost the registers that decide how many workgroups share a CU.
-        if (nk) {
-            // all of the wave's sub-frames requested at once: with one in flight per wave (the next one requested while this
-            // one is reduced) a launch of 512 workgroups -- configs[4]'s 32 768 streams -- had too few bytes under way to
-            // reach the memory's rate
-            uint4 raw[4][VPS];
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++)
-                if (kk < nk) {
+        for (int kk = 0; kk < 4; kk++)
+            if (kk < nk) {
+                const int k = k0 + kk;
+                const int32_t ga = gn[k * 64 + lane], gb = gn[(k + 1) * 64 + lane];
+                const int32_t delta = wshl(wsub(gb, ga), 4 - L2);
+                int32_t gain32 = wshl(ga, 4);
+                unsigned yw[L * CHN / 2];
 #pragma unroll
-                    for (int j = 0; j < VPS; j++) raw[kk][j] = in4[(k0 + kk) * VPS + j];
+                for (int n = 0; n < L; n++) {
+                    const int16_t y = agc_apply(sample(raw[kk], n), gain32, k == 0);
+                    gain32 = wadd(gain32, delta);
+                    if (CHN == 2)
+                        yw[n] = (unsigned)(uint16_t)y | ((unsigned)(uint16_t)y << 16);
+                    else if (n & 1)
+                        yw[n >> 1] |= (unsigned)(uint16_t)y << 16;
+                    else
+                        yw[n >> 1] = (unsigned)(uint16_t)y;
                 }
+                if (live) {
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++)
-                if (kk < nk) {
-                    int32_t mx = 0;
-#pragma unroll
-                    for (int n = 0; n < L; n++) {
-                        const int32_t x = sample(raw[kk], n);
-                        const int32_t e = x * x;
-                        if (e > mx) mx = e;
-                    }
-                    xenv[(k0 + kk) * 64 + lane] = mx;
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const int16_t d = L == 16 ? (int16_t)(((int32_t)sample(raw[kk], 2 * j) + (int32_t)sample(raw[kk], 2 * j + 1)) >> 1) : sample(raw[kk], j);
-                        xdet[((k0 + kk) * 8 + j) * 64 + lane] = d;
-                    }
+                    for (int j = 0; j < VPS; j++) out4[k * VPS + j] = make_uint4(yw[4 * j], yw[4 * j + 1], yw[4 * j + 2], yw[4 * j + 3]);
                 }
-        }
-        __syncthreads();  // 1: peaks and detector input of the whole packet are in LDS
+            }
+    };
+    if (nk) pass1(0);
+    __syncthreads();  // packet 0's peaks and detector input are in LDS (and the gain table)
+    for (int p = 0; p < n_packets; p++) {
         if (wave == 3) {
-            int32_t env[10], gains[11], nrg = 0;
-            int32_t ds[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) ds[i] = S.w(A32_DOWN + i);
-            int16_t hp = S.h(A16_HP);
-#pragma unroll 2
-            for (int k = 0; k < 10; k++) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int16_t b2 = down2_step(xdet[(k * 8 + 2 * j) * 64 + lane], xdet[(k * 8 + 2 * j + 1) * 64 + lane], ds);
-                    const int32_t o = b2 + hp;
-                    const int32_t t = 600 * o;
-                    hp = (int16_t)((t >> 10) - b2);
-                    nrg = wadd(nrg, wmul(o, o) >> 6);  // |o| reaches 65 534: the square wraps in the reference (digital_agc.c:633), negative included
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 8; i++) S.w(A32_DOWN + i) = ds[i];
-            S.h(A16_HP) = hp;
-#pragma unroll
-            for (int k = 0; k < 10; k++) env[k] = xenv[k * 64 + lane];
-            agc_decide(S, gain_table, nrg, env, gains);
-#pragma unroll
-            for (int k = 0; k < 11; k++) xgain[k * 64 + lane] = gains[k];
+            serial(p);
+        } else {
+            if (p > 0) pass2(p - 1);             // its gains were published before the previous barrier
+            if (p + 1 < n_packets) pass1(p + 1);  // into the set the serial wave is not reading
         }
-        __syncthreads();  // 2: the packet's gains are in LDS
-        // ---- pass 2, this wave's share
-        if (nk) {
-            uint4 raw[4][VPS];  // every load before the first store (in == out)
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++)
-                if (kk < nk) {
-#pragma unroll
-                    for (int j = 0; j < VPS; j++) raw[kk][j] = in4[(k0 + kk) * VPS + j];
-                }
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++)
-                if (kk < nk) {
-                    const int k = k0 + kk;
-                    const int32_t ga = xgain[k * 64 + lane], gb = xgain[(k + 1) * 64 + lane];
-                    const int32_t delta = wshl(wsub(gb, ga), 4 - L2);
-                    int32_t gain32 = wshl(ga, 4);
-                    unsigned yw[L * CHN / 2];
-#pragma unroll
-                    for (int n = 0; n < L; n++) {
-                        const int16_t y = agc_apply(sample(raw[kk], n), gain32, k == 0);
-                        gain32 = wadd(gain32, delta);
-                        if (CHN == 2)
-                            yw[n] = (unsigned)(uint16_t)y | ((unsigned)(uint16_t)y << 16);
-                        else if (n & 1)
-                            yw[n >> 1] |= (unsigned)(uint16_t)y << 16;
-                        else
-                            yw[n >> 1] = (unsigned)(uint16_t)y;
-                    }
-                    if (live) {
-#pragma unroll
-                        for (int j = 0; j < VPS; j++) out4[k * VPS + j] = make_uint4(yw[4 * j], yw[4 * j + 1], yw[4 * j + 2], yw[4 * j + 3]);
-                    }
-                }
-        }
-        __syncthreads();  // 3: LDS may be overwritten by the next packet
+        __syncthreads();  // packet p's gains and packet p + 1's inputs are in LDS; set p & 1 of the inputs may be rewritten
     }
+    if (nk) pass2(n_packets - 1);
     if (wave == 3 && live) {
 #pragma unroll
         for (int f = 0; f < A32_WORDS; f++) s32[(size_t)f * n_streams + stream] = r32[f];
