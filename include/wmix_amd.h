@@ -230,6 +230,23 @@ int wmx_aec_reset_cohort(wmx_aec *h, int cohort, void *stream);
  * block's 64 comfort-noise phases travel as the generator's 4-byte state; the far kernel expands them). */
 int wmx_aec_add_cohort(wmx_aec *h, int *cohort, void *stream);
 int wmx_aec_retire_cohort(wmx_aec *h, int cohort);
+/* Coalescing.  Handles of the reference that were created at different times but are called with the same delay end up with
+ * control planes that differ only in WHERE their rings stand (W: echo_cancellation.c:599-872 and aec_core.c:1719-1850 are index
+ * arithmetic on fill levels): from then on they compute the same far-end spectra, far power and plans, once per handle.  This
+ * call merges such cohorts: (1) it completes the merges whose check -- launched by an earlier call -- came back equal: the far-end
+ * slabs of the two cohorts were compared on the device, word for word under the rotation between their ring positions (that
+ * includes the running far power, an IIR from each handle's own start); the members of `from` then get their re-blocking rings
+ * rotated to the positions of `into`, its id, and `from` is retired; every stream keeps the state of the comfort-noise generator
+ * it would have as its own handle (the near kernel draws per stream from the first merge on).  The pairs are reported in
+ * merged_from[] / merged_into[] (*n_merged of them, at most cap) so that the caller can redirect its own tables; the id range
+ * wmx_aec_cohorts(h) shrinks behind the last live cohort.  (2) it proposes up to max_pairs (<= 32) new pairs -- equal fill
+ * levels, delays and counters, start-up over, lowest id leads -- and launches their comparison behind the work already in
+ * `stream`.  Nothing waits for the device: a pair proposed by one call is merged by a later one.  A pair is dropped when its two
+ * cohorts are not called identically in between (delay, cohort_on, private far-end packets).  max_pairs = 0: only (1).
+ * Merged streams are bound to one reported delay from then on, like the members of any cohort. */
+/* cohorts of the id range that are not retired (what a launch really computes far-end spectra and plans for) */
+int wmx_aec_live_cohorts(const wmx_aec *h);
+int wmx_aec_coalesce(wmx_aec *h, int max_pairs, int32_t *merged_from, int32_t *merged_into, int cap, int *n_merged, void *stream);
 int wmx_aec_reset_streams(wmx_aec *h, const int32_t *idx, int n, int cohort, void *stream);
 int wmx_aec_set_active(wmx_aec *h, const uint8_t *host_mask, void *stream);
 int wmx_aec_stream_state_bytes(const wmx_aec *h);
@@ -285,6 +302,8 @@ int wmx_chain_reset_cohort(wmx_chain *h, int cohort, void *stream);
 /* wmx_aec_add_cohort / wmx_aec_retire_cohort / wmx_aec_cohorts of the chain's AEC (a chain without one has a single cohort) */
 int wmx_chain_add_cohort(wmx_chain *h, int *cohort, void *stream);
 int wmx_chain_retire_cohort(wmx_chain *h, int cohort);
+/* wmx_aec_coalesce of the chain's float AEC (a chain with the fixed-point AECM, or without an AEC stage, merges nothing) */
+int wmx_chain_coalesce(wmx_chain *h, int max_pairs, int32_t *merged_from, int32_t *merged_into, int cap, int *n_merged, void *stream);
 int wmx_chain_cohorts(const wmx_chain *h);
 int wmx_chain_set_active(wmx_chain *h, const uint8_t *host_mask, void *stream);
 int wmx_chain_stream_state_bytes(const wmx_chain *h);

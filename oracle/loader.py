@@ -159,6 +159,21 @@ def run_aec(lib, chn, freq, interval_ms, far, near, frames_per_call, delay_ms=0,
     return out
 
 
+def run_aec_delays(lib, chn, freq, interval_ms, far, near, frames_per_call, delays, prefix="ref"):
+    """aec_process2 per call with the reported delay of that call (delays: one per call)."""
+    far = np.ascontiguousarray(far, dtype=np.int16)
+    near = np.ascontiguousarray(near, dtype=np.int16)
+    out = np.empty_like(near)
+    n_calls = near.size // (frames_per_call * chn)
+    d = np.ascontiguousarray(delays, dtype=np.int32)
+    assert d.shape == (n_calls,)
+    fn = _fn(lib, prefix + "_run_aec_delays", C.c_int,
+             [C.c_int, C.c_int, C.c_int, _i16p, _i16p, _i16p, C.c_int, C.c_int, np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")])
+    rc = fn(chn, freq, interval_ms, far, near, out, frames_per_call, n_calls, d)
+    assert rc == 0, rc
+    return out
+
+
 def run_aecm(lib, chn, freq, interval_ms, far, near, frames_per_call, delay_ms=0, split=0, prefix="ref", expect_rc=0):
     """The wrapper built with the reference's AECM switch (src/webrtc.c:168-191): fixed-point echo canceller.
     split=1 drives aec_setFrameFar + aec_process instead of aec_process2."""

@@ -662,6 +662,20 @@ int orc_run_aec(int chn, int freq, int interval_ms, const int16_t *far, const in
     return rc;
 }
 
+/* the same with the delay the caller reports changing from call to call (aec_process2's delayms, src/webrtc.c:410-483) */
+int orc_run_aec_delays(int chn, int freq, int interval_ms, const int16_t *far, const int16_t *nearp, int16_t *out, int frames_per_call,
+                       int n_calls, const int32_t *delay_ms)
+{
+    orc_aec *a = orc_aec_init(chn, freq, interval_ms);
+    if (!a) return -100;
+    size_t step = (size_t)frames_per_call * chn;
+    int rc = 0;
+    for (int i = 0; i < n_calls && rc == 0; i++)
+        rc = orc_aec_process2(a, far + i * step, nearp + i * step, out + i * step, frames_per_call, delay_ms[i]);
+    orc_aec_release(a);
+    return rc;
+}
+
 
 /* State probe (SURVEY 8c "state probes for debugging"): the decisions of NonLinearProcessing and the scalars they are
  * taken on (aec_core.c:911-1141), so that two runs can be compared decision by decision.

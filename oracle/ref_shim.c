@@ -93,6 +93,19 @@ int ref_run_aec(int chn, int freq, int interval_ms, const int16_t *far, const in
     return rc;
 }
 
+int ref_run_aec_delays(int chn, int freq, int interval_ms, const int16_t *far, const int16_t *near, int16_t *out,
+                       int frames_per_call, int n_calls, const int32_t *delay_ms)
+{
+    void *h = aec_init(chn, freq, interval_ms, &g_dbg);
+    if (!h) return -100;
+    size_t step = (size_t)frames_per_call * chn;
+    int rc = 0;
+    for (int i = 0; i < n_calls && rc == 0; i++)
+        rc = aec_process2(h, (int16_t *)far + i * step, (int16_t *)near + i * step, out + i * step, frames_per_call, delay_ms[i]);
+    aec_release(h);
+    return rc;
+}
+
 /* the same wrapper built with the reference's AECM switch (oracle/Makefile, oracle/aecm_switch/): WebRtcAecm_* */
 void *aecm_aec_init(int chn, int freq, int intervalMs, bool *debug);
 int aecm_aec_setFrameFar(void *fp, int16_t *frameFar, int frameNum);

@@ -97,6 +97,57 @@ static long drive_aecm(int freq, int pkg, int mode_delay) {
     return blocks;
 }
 
+
+// wmx_aec_coalesce's host half: two control planes started `lag` packets apart and called with the same delays.  Once their keys
+// (aec_co_key) are equal, every later plan of the younger one must be the older one's plan under the rotations of aec_co_pair --
+// for thousands of packets, with the delay changing on the way (both see the same change).  Returns the packet at which the keys
+// first met, or -1 if they never did.
+static int drive_pair(int freq, int pkg, int lag, int delay0) {
+    AecCtl a, b;
+    a.init(freq);
+    b.init(freq);
+    int met = -1;
+    AecPairCheck pc{};
+    for (int p = 0; p < 5200; p++) {
+        const int d = p < 3600 ? delay0 : delay0 + 60;  // a step in the reported delay: EstBufDelay moves both planes alike
+        AecPlan pa, pb;
+        std::memset(&pa, 0, sizeof(pa));
+        std::memset(&pb, 0, sizeof(pb));
+        CHECK(a.buffer_farend(pkg, &pa) == 0);
+        CHECK(a.process(pkg, d, &pa) == 0);
+        if (p < lag) continue;
+        CHECK(b.buffer_farend(pkg, &pb) == 0);
+        CHECK(b.process(pkg, d, &pb) == 0);
+        if (met >= 0) {
+            CHECK(pa.has_far == pb.has_far && pa.far_n == pb.far_n && pa.n_part == pb.n_part && pa.has_near == pb.has_near);
+            CHECK(pa.passthrough == pb.passthrough && pa.n_sub == pb.n_sub && pa.n_blk == pb.n_blk);
+            CHECK(pb.pre_wr == (pa.pre_wr + pc.d_pre) % kAecPreLen);
+            for (int q = 0; q < pa.n_part; q++) {
+                CHECK(pb.part[q].pre_rd == (pa.part[q].pre_rd + pc.d_pre) % kAecPreLen);
+                CHECK(pb.part[q].far_slot == (pa.part[q].far_slot + pc.d_far) % kAecFarBlocks);
+            }
+            for (int q = 0; q < pa.n_sub; q++) {
+                CHECK(pa.sub[q].near_wr == (pb.sub[q].near_wr + pc.d_near) % kAecRing && pa.sub[q].out_rd == (pb.sub[q].out_rd + pc.d_out) % kAecRing);
+                CHECK(pa.sub[q].n_blocks == pb.sub[q].n_blocks && pa.sub[q].first_blk == pb.sub[q].first_blk);
+            }
+            for (int q = 0; q < pa.n_blk; q++) {
+                CHECK(pa.blk[q].near_rd == (pb.blk[q].near_rd + pc.d_near) % kAecRing && pa.blk[q].out_wr == (pb.blk[q].out_wr + pc.d_out) % kAecRing);
+                CHECK(pb.blk[q].far_slot == (pa.blk[q].far_slot + pc.d_far) % kAecFarBlocks);
+                CHECK(((pb.blk[q].hist_n - pa.blk[q].hist_n - pc.d_hist) & (kAecHist - 1)) == 0 && pa.blk[q].flags == pb.blk[q].flags);
+            }
+            AecCoKey ka, kb;
+            CHECK(aec_co_key(a, &ka) && aec_co_key(b, &kb) && ka == kb);  // and the keys stay equal
+        } else {
+            AecCoKey ka, kb;
+            if (aec_co_key(a, &ka) && aec_co_key(b, &kb) && ka == kb) {
+                met = p;
+                aec_co_pair(a, b, 0, 1, &pc);
+            }
+        }
+    }
+    return met;
+}
+
 int main() {
     long total = 0;
     for (int freq : {8000, 16000})
@@ -125,6 +176,19 @@ int main() {
             CHECK(((s * a + c) & 0x7FFFFFFFu) == want);
         }
     }
+    // ---- coalescing: planes 8 k packets apart meet (the 10-block delay-estimate counter and the 80 / 160-in-64 re-blocking repeat
+    //      every 8 packets) -- as soon as the younger one's noise-floor start-up is over -- and planes an odd number of packets apart
+    //      (different block phase) or a non-multiple of 8 apart never do
+    for (int freq : {8000, 16000})
+        for (int d0 : {0, 40, 120}) {
+            const int pkg = freq / 100, settle = 500 * (freq / 8000) * 64 / pkg + 80;
+            for (int lag : {8, 16, 104, 800}) {
+                const int met = drive_pair(freq, pkg, lag, d0);
+                CHECK(met >= 0 && met < lag + settle + 200);
+            }
+            for (int lag : {1, 3, 4, 12, 37}) CHECK(drive_pair(freq, pkg, lag, d0) < 0);
+        }
+    CHECK(drive_pair(8000, 160, 8, 0) >= 0);  // 20 ms packets at 8 kHz (the daemon's cadence)
     // ---- AGC gain table: every compression gain an uint8 agc_addition() can pass, limiter off (wmix) and on
     int ok = 0;
     for (int comp = 0; comp < 256; comp++)

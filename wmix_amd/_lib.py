@@ -183,6 +183,12 @@ def _declare(L):
         f.argtypes = [vp, i]
     L.wmx_chain_cohorts.restype = i
     L.wmx_chain_cohorts.argtypes = [vp]
+    L.wmx_aec_live_cohorts.restype = i
+    L.wmx_aec_live_cohorts.argtypes = [vp]
+    for name in ("wmx_aec_coalesce", "wmx_chain_coalesce"):
+        f = getattr(L, name)
+        f.restype = i
+        f.argtypes = [vp, i, vp, vp, i, C.POINTER(i), vp]
     L.wmx_aecm_create_cohorts.restype = i
     L.wmx_aecm_create_cohorts.argtypes = [C.POINTER(vp), i, i, i, i, i]
     L.wmx_aec_set_timing.restype = i

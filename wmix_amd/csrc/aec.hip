@@ -33,7 +33,9 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <cstddef>
+#include <unordered_map>
 #include <vector>
 #include "wmx_internal.h"
 #include "aec_ctl.h"
@@ -75,6 +77,9 @@ enum : int {
     AS_STNEAR = AS_SCAL + 8,
     AS_ECHOSTATE = AS_SCAL + 9,
     AS_DIVERGE = AS_SCAL + 10,
+    AS_SEED = AS_SCAL + 11,      // comfort-noise generator (WebRtcSpl_RandUArray's seed) of the stream -- maintained only once cohorts of
+                                 //   different ages have been merged (wmx_aec_coalesce, OWN_NOISE kernels); until then the generator's
+                                 //   state is the cohort's (AecCtl::seed: every member has processed the same number of blocks)
     AS_WORDS = AS_SCAL + 16,
 };
 static_assert(AS_WORDS % 4 == 0, "state block must be a whole number of 16-byte chunks");
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const flo
     wave_sync();
     for (int p = 0; p < n_packets; p++) {
         const AecPlan &pl = plans[(size_t)p * n_cohorts];
-        if (pl.has_near && !pl.passthrough) {
+        if (noise && pl.has_near && !pl.passthrough) {  // (noise == nullptr: the streams draw their own, OWN_NOISE near kernels)
             // ComfortNoise's random phases (aec_core.c:476-489) for every block of the packet: WebRtcSpl_RandUArray's draws by
             // jump-ahead, cosf / sinf of the reference's float expression by table (32 768 possible arguments, host libm)
             float *row = noise + (size_t)p * n_cohorts * kAecNoiseRow;
@@ -439,9 +444,10 @@ __device__ __forceinline__ void aec_fft_fwd(float *row, const FftTables *T, int 
     for (int m = 0; m < 4; m++) *reinterpret_cast<float2 *>(row + 2 * (gl + 16 * m)) = make_float2(v[m].r, v[m].i);
 }
 
-template <int MULT>  // 1: 8 kHz, 2: 16 kHz
+template <int MULT, bool OWN_NOISE>  // MULT 1: 8 kHz, 2: 16 kHz; OWN_NOISE: the comfort noise's phases from the stream's own generator
 __device__ __forceinline__ void aec_block(const AecConstsNear &K, const float *__restrict__ curves_g, const PowTables *__restrict__ powtab, AecWaveLds &W, AecTaps &taps,
-                                          const AecFarBufs &F, const AecBlkPlan &bp, const float *__restrict__ nz, const int lane_in) {
+                                          const AecFarBufs &F, const AecBlkPlan &bp, const float *__restrict__ nz, const AecNoiseEntry *__restrict__ noise_tab,
+                                          const int lane_in) {
     // The lane-derived LDS addresses (gather points, twiddle and window slots) are loop invariant; left alone the
     // compiler hoists ~100 of them out of the packet loop and pins them in VGPRs for the whole kernel.  Recomputing
     // them per block costs a few VALU ops and frees the registers.
@@ -820,6 +826,12 @@ __device__ __forceinline__ void aec_block(const AecConstsNear &K, const float *_
     }
     wave_sync();
     AEC_PROF(5);
+    // OWN_NOISE -- ComfortNoise's random phases (aec_core.c:476-489): the block's 64 draws of WebRtcSpl_RandUArray (randomization_
+    // functions.c:94-112, seed = (seed * 69069 + 1) & 0x7FFFFFFF per draw) by jump-ahead from the STREAM's generator state.  Lane
+    // l >= 1 takes draw l (the phase of bin l), lane 0 draw 64 (the phase of bin 64, and the state the next block starts from): the
+    // table behind the phases holds (69069^k, 1 + 69069 + ... + 69069^(k-1)) mod 2^32 for that k.  Requested here, used two phases on.
+    uint2 lcg = make_uint2(0u, 0u);
+    if constexpr (OWN_NOISE) lcg = reinterpret_cast<const uint2 *>(noise_tab + kAecNoiseTab)[lane];
     // the two ordered sums advance side by side: lane 0 adds sd[0..64], lane 1 adds se[0..64] (index order each)
     float sdSum, seSum;
 #if defined(WMX_AEC_EXP) && WMX_AEC_EXP >= 2
@@ -858,6 +870,13 @@ __device__ __forceinline__ void aec_block(const AecConstsNear &K, const float *_
     }
     AEC_PROF(6);
     AEC_RELANE();
+    AecNoiseEntry nze = AecNoiseEntry{0.f, 0.f};
+    if constexpr (OWN_NOISE) {
+        // cosf / sinf of the reference's float expression for the draw: 32 768 possible arguments, the host libm's values by table
+        const uint32_t drawn = ((uint32_t)Si[AS_SEED] * lcg.x + lcg.y) & 0x7FFFFFFFu;
+        nze = noise_tab[drawn >> 16];
+        if (lane == 0) Si[AS_SEED] = (int)drawn;
+    }
     // coherences (aec_core.c:440-449), bin `lane` and bin 64 side by side
     {
         auto coh = [&](int b, float &cde, float &cxd) {
@@ -1024,8 +1043,13 @@ __device__ __forceinline__ void aec_block(const AecConstsNear &K, const float *_
         float ur = 0.f, ui = 0.f;
         if (b >= 1) {
             const float noise = sqrtf(AEC_ST(noise_off + b));
-            ur = noise * nz[b - 1];               // cosf / sinf of the block's 64 random phases, made by the far kernel
-            ui = -noise * nz[kAecPart + b - 1];
+            if constexpr (OWN_NOISE) {
+                ur = noise * nze.c;  // bin b's phase is draw b: this lane's (b == lane, or lane 0's 64th draw for bin 64)
+                ui = -noise * nze.s;
+            } else {
+                ur = noise * nz[b - 1];  // cosf / sinf of the block's 64 random phases, made by the far kernel
+                ui = -noise * nz[kAecPart + b - 1];
+            }
             if (b == kAecPart) ui = 0.f;
         }
         const float v = 1 - h * h;
@@ -1067,14 +1091,14 @@ __device__ __forceinline__ void aec_block(const AecConstsNear &K, const float *_
 #undef AEC_RELANE
 }
 
-template <int MULT>
+template <int MULT, bool OWN_NOISE>
 #ifndef WMX_AEC_WAVES
 #define WMX_AEC_WAVES 4
 #endif
 __global__ __attribute__((amdgpu_waves_per_eu(WMX_AEC_WAVES, WMX_AEC_WAVES))) __launch_bounds__(64 * kAecWavesPerBlock) void aec_near_kernel(float *__restrict__ state, AecFarBufs F_all,
                                                                           const float *__restrict__ consts_g,
                                                                           const AecPlan *__restrict__ plans, int n_packets, int n_cohorts,
-                                                                          const float *__restrict__ noise,
+                                                                          const float *__restrict__ noise, const AecNoiseEntry *__restrict__ noise_tab,
                                                                           const int16_t *near_pcm, int16_t *out_pcm, int n_streams,
                                                                           long stream_stride, long packet_stride, int chn, int pkg,
                                                                           const int *__restrict__ stream_far, const uint8_t *__restrict__ active,
@@ -1213,8 +1237,8 @@ __global__ __attribute__((amdgpu_waves_per_eu(WMX_AEC_WAVES, WMX_AEC_WAVES))) __
             }
             wave_sync();
             for (int k = 0; k < sp.n_blocks; k++)
-                aec_block<MULT>(K, consts_g + kAecConstNearWords, powtab, W, taps, F, pl.blk[sp.first_blk + k],
-                                nz + (sp.first_blk + k) * 2 * kAecPart, lane);
+                aec_block<MULT, OWN_NOISE>(K, consts_g + kAecConstNearWords, powtab, W, taps, F, pl.blk[sp.first_blk + k],
+                                           nz + (sp.first_blk + k) * 2 * kAecPart, noise_tab, lane);
             for (int i = opaque_lane(lane); i < kAecFrame; i += 64) {
                 const int16_t v = (int16_t)AEC_ST(AS_OUT_RING + ring_at(sp.out_rd, i));
                 for (int c = 0; c < chn; c++) out[(s * kAecFrame + i) * chn + c] = v;
@@ -1270,6 +1294,80 @@ __global__ void aec_set_group(int *stream_far, const int32_t *idx, int n_idx, in
     if (j < n_idx) stream_far[idx[j]] = group;
 }
 
+
+// ---------------------------------------------------------------- coalescing control cohorts (wmx_aec_coalesce)
+// Two cohorts whose control planes have converged -- same fill levels, delays and counters, only the ring POSITIONS differ -- hold the
+// same far-end data in their slabs, rotated by the difference of their positions: this kernel says whether they really do, word for
+// word (the running far power is an IIR from each cohort's own start: it is equal once the difference has been rounded away, and
+// only the bits can say when).  One workgroup per pair; flags[pair] = 1 when every buffer of `b` equals its rotation of `a`.
+constexpr int kAecCoMax = 32;  // pairs per comparison launch / merges per call
+struct AecPairChecks {
+    AecPairCheck p[kAecCoMax];
+};
+__global__ __launch_bounds__(256) void aec_cohort_equal(AecFarBufs F_all, AecPairChecks pairs, int *flags) {
+    const AecPairCheck pc = pairs.p[blockIdx.x];
+    const AecFarBufs A = far_group(F_all, pc.a), B = far_group(F_all, pc.b);
+    unsigned diff = 0;
+    auto rows = [&](const float *a, const float *b, int n_rows, int row_len, int d_row) {
+        const unsigned *ua = reinterpret_cast<const unsigned *>(a), *ub = reinterpret_cast<const unsigned *>(b);
+        for (int i = threadIdx.x; i < n_rows * row_len; i += 256) {
+            const int r = i / row_len, c = i - r * row_len;
+            int rb = r + d_row;
+            rb -= rb >= n_rows ? n_rows : 0;
+            diff |= ua[i] ^ ub[rb * row_len + c];
+        }
+    };
+    rows(A.pre, B.pre, kAecPreLen, 1, pc.d_pre);
+    rows(A.ring, B.ring, kAecFarBlocks, 130, pc.d_far);
+    rows(A.ring_w, B.ring_w, kAecFarBlocks, 130, pc.d_far);
+    rows(A.hist, B.hist, kAecHist, 130, pc.d_hist);  // every consumed spectrum is stored twice, kAecHist rows apart
+    rows(A.hist + (size_t)kAecHist * 130, B.hist + (size_t)kAecHist * 130, kAecHist, 130, pc.d_hist);
+    rows(A.nyq, B.nyq, kAecHist, 2, pc.d_hist);
+    rows(A.nyq + 2 * kAecHist, B.nyq + 2 * kAecHist, kAecHist, 2, pc.d_hist);
+    rows(A.hist_w, B.hist_w, kAecHist, 130, pc.d_hist);
+    rows(A.xpow_seq, B.xpow_seq, kAecHist, BP, pc.d_hist);
+    rows(A.xpow, B.xpow, 1, BP, 0);
+    const int any = __syncthreads_or(diff != 0);
+    if (threadIdx.x == 0) flags[blockIdx.x] = any ? 0 : 1;
+}
+// The merge itself: one wave per stream; members of a `from` cohort get their two re-blocking rings rotated to the positions of the
+// cohort they join (the plans they will be run with are its plans) and its id.  Streams of other cohorts are not touched.
+__global__ __launch_bounds__(256) void aec_merge_streams(float *state, int *stream_far, int n_streams, AecPairChecks pairs, int n_pairs) {
+    const int s = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= n_streams) return;
+    const int c = stream_far[s];
+    int k = -1;
+    for (int i = 0; i < n_pairs; i++)
+        if (pairs.p[i].b == c) k = i;
+    if (k < 0) return;
+    float *st = state + (size_t)s * AS_WORDS;
+    const int d[2] = {pairs.p[k].d_near, pairs.p[k].d_out};
+    const int base[2] = {AS_NEAR_RING, AS_OUT_RING};
+    float v[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) v[r][j] = lane + 64 * j < kAecRing ? st[base[r] + lane + 64 * j] : 0.f;
+    __builtin_amdgcn_s_waitcnt(0);  // every load of the wave before its first store: the rotation is in place
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int i = lane + 64 * j;
+            if (i < kAecRing) st[base[r] + (i + d[r]) % kAecRing] = v[r][j];
+        }
+    if (lane == 0) stream_far[s] = pairs.p[k].a;
+}
+__global__ void aec_clamp_group(int *stream_far, int n_streams, int n_far) {
+    const int s = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (s < n_streams && stream_far[s] >= n_far) stream_far[s] = 0;
+}
+// OWN_NOISE starts: every stream gets the generator state of the cohort it has shared it with so far
+__global__ void aec_seed_streams(float *state, const int *stream_far, const uint32_t *cohort_seed, int n_streams) {
+    const int s = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (s < n_streams) reinterpret_cast<uint32_t *>(state + (size_t)s * AS_WORDS)[AS_SEED] = cohort_seed[stream_far ? stream_far[s] : 0];
+}
 }  // namespace
 }  // namespace wmx
 
@@ -1303,7 +1401,20 @@ struct wmx_aec {
     int order_age;            // launches since the order was rebuilt: under churn it is rebuilt every kOrderEvery launches at most
     static constexpr int kOrderEvery = 16;
     wmx::AecNoiseEntry *d_noise_tab;  // cosf / sinf of the comfort noise's 32 768 possible phases (host libm, aec_ctl.h)
+                                      // + 64 x (a, c): the generator's jump-ahead constants of the OWN_NOISE near kernel's lanes (aec_lcg_jump)
     float *d_noise;          // [noise_pkts][cap_far][kAecNoiseRow]: what the far kernel makes of the plans' seeds for the near kernel
+    bool own_noise;          // cohorts of different ages have been merged (wmx_aec_coalesce): every stream draws from its own generator state
+    // wmx_aec_coalesce: the pairs whose device comparison is in flight (`b` < 0: dropped, the two were not called identically since)
+    wmx::AecPairChecks co_pairs;
+    int co_n;
+    bool co_inflight;
+    int *d_co_flags, *h_co_flags;  // [kAecCoMax] device result and its pinned copy
+    uint32_t *d_co_seeds;          // [cap] cohort generator states for aec_seed_streams (allocated when OWN_NOISE starts)
+    hipEvent_t co_done;
+    long co_calls;                 // wmx_aec_coalesce calls so far
+    std::vector<long> co_retry_at; // [n_far] a cohort whose comparison failed is not proposed again before this call
+    long last_far_group_stride;    // of the latest run: cohorts that hear private far-end packets are never candidates
+    long co_merged_total;
     int noise_pkts;
     int16_t *d_zero_far;  // a silent far-end packet for near-only calls that need no far data
     wmx::StreamLife life;
@@ -1341,6 +1452,10 @@ int wmx_aec_destroy(wmx_aec *h) {
     if (h->d_order) (void)hipFree(h->d_order);
     if (h->d_noise_tab) (void)hipFree(h->d_noise_tab);
     if (h->d_noise) (void)hipFree(h->d_noise);
+    if (h->d_co_flags) (void)hipFree(h->d_co_flags);
+    if (h->h_co_flags) (void)hipHostFree(h->h_co_flags);
+    if (h->d_co_seeds) (void)hipFree(h->d_co_seeds);
+    if (h->co_done) (void)hipEventDestroy(h->co_done);
     if (h->d_tmpl) (void)hipFree(h->d_tmpl);
     h->life.release();
     for (hipEvent_t ev : h->tev) (void)hipEventDestroy(ev);
@@ -1352,6 +1467,11 @@ int wmx_aec_destroy(wmx_aec *h) {
     delete h;
     return 0;
 }
+
+}  // extern "C"
+static void aec_co_drop(wmx_aec *h, int cohort);
+static int aec_enter_own_noise(wmx_aec *h, hipStream_t s);
+extern "C" {
 
 int wmx_aec_create(wmx_aec **out, int n_streams, int chn, int freq, int interval_ms) {
     return wmx_aec_create_groups(out, n_streams, chn, freq, interval_ms, 1, nullptr);
@@ -1516,6 +1636,16 @@ int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int i
     h->d_stream_far = nullptr;
     h->d_noise_tab = nullptr;
     h->d_noise = nullptr;
+    h->own_noise = false;
+    h->co_n = 0;
+    h->co_inflight = false;
+    h->d_co_flags = h->h_co_flags = nullptr;
+    h->d_co_seeds = nullptr;
+    h->co_done = nullptr;
+    h->co_calls = 0;
+    h->co_retry_at.assign((size_t)n_far, 0);
+    h->last_far_group_stride = 0;
+    h->co_merged_total = 0;
     h->noise_pkts = 0;
     h->d_order = nullptr;
     h->order_wgs = 0;
@@ -1552,6 +1682,10 @@ int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int i
     st[AS_HNLXDAVGMIN] = 1.f;
     st[AS_OVERDRIVE] = 2.f;
     st[AS_OVERDRIVESM] = 2.f;
+    {
+        const uint32_t seed0 = AecCtl().seed;  // aec->seed = 777, aec_core.c:1670
+        memcpy(&st[AS_SEED], &seed0, sizeof(seed0));
+    }
     hipError_t e;
 #define AEC_TRY(x)                                         \
     if ((e = (x)) != hipSuccess) {                         \
@@ -1592,8 +1726,12 @@ int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int i
             aec_noise_table(t.data());
             return t;
         }();
-        AEC_TRY(hipMalloc(&h->d_noise_tab, sizeof(AecNoiseEntry) * kAecNoiseTab));
+        // behind it, the generator's jump-ahead constants: lane l of the near kernel takes draw l of a block, lane 0 the 64th
+        uint32_t jump[2 * 64];
+        for (int l = 0; l < 64; l++) aec_lcg_jump(l ? l : kAecPart, &jump[2 * l], &jump[2 * l + 1]);
+        AEC_TRY(hipMalloc(&h->d_noise_tab, sizeof(AecNoiseEntry) * kAecNoiseTab + sizeof(jump)));
         AEC_TRY(hipMemcpy(h->d_noise_tab, tab.data(), sizeof(AecNoiseEntry) * kAecNoiseTab, hipMemcpyHostToDevice));
+        AEC_TRY(hipMemcpy(h->d_noise_tab + kAecNoiseTab, jump, sizeof(jump), hipMemcpyHostToDevice));
     }
     AEC_TRY(hipMemcpy(h->d_tmpl, st.data(), AS_WORDS * sizeof(float), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(aec_fill_state, dim3(1024), dim3(256), 0, nullptr, h->d_state, h->d_tmpl, (int)AS_WORDS, n_streams);
@@ -1624,6 +1762,7 @@ int wmx_aec_add_cohort(wmx_aec *h, int *cohort, void *stream) {
         if (rc != 0) return rc;
         h->ctl.resize((size_t)id + 1);
         h->live.push_back(1);
+        h->co_retry_at.push_back(0);
         h->n_far = id + 1;
     }
     if (h->n_far > 1 && !h->d_stream_far) {  // so far every stream was in cohort 0 by construction
@@ -1640,6 +1779,143 @@ int wmx_aec_add_cohort(wmx_aec *h, int *cohort, void *stream) {
 int wmx_aec_retire_cohort(wmx_aec *h, int cohort) {
     if (!h || cohort < 0 || cohort >= h->n_far) return WMX_EINVAL;
     h->live[(size_t)cohort] = 0;
+    aec_co_drop(h, cohort);
+    return 0;
+}
+
+}  // extern "C"
+// ---------------------------------------------------------------- coalescing
+// From here on every stream draws its comfort noise from its own generator state (OWN_NOISE near kernels): today's state is the
+// one of the cohort it has shared it with so far.
+static int aec_enter_own_noise(wmx_aec *h, hipStream_t s) {
+    using namespace wmx;
+    if (h->own_noise) return 0;
+    if (!h->d_co_seeds) WMX_HIP_RC(hipMalloc(&h->d_co_seeds, sizeof(uint32_t) * (size_t)h->n_far));
+    std::vector<uint32_t> seeds((size_t)h->n_far);
+    for (int g = 0; g < h->n_far; g++) seeds[(size_t)g] = h->ctl[(size_t)g].seed;
+    WMX_HIP_RC(hipMemcpy(h->d_co_seeds, seeds.data(), sizeof(uint32_t) * seeds.size(), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(aec_seed_streams, dim3((unsigned)((h->n_streams + 255) / 256)), dim3(256), 0, s, h->d_state, h->d_stream_far, h->d_co_seeds,
+                       h->n_streams);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "aec_seed_streams", __FILE__, __LINE__);
+    h->own_noise = true;
+    return 0;
+}
+// a cohort that is restarted, retired or overwritten is no candidate of a comparison in flight
+static void aec_co_drop(wmx_aec *h, int cohort) {
+    for (int i = 0; i < h->co_n; i++)
+        if (h->co_pairs.p[i].a == cohort || h->co_pairs.p[i].b == cohort) h->co_pairs.p[i].b = -1;
+}
+extern "C" {
+
+// Merge control cohorts whose planes have converged (include/wmix_amd.h).  Each call first completes the merges whose device
+// comparison -- requested by an earlier call -- came back equal, then proposes up to max_pairs new pairs and launches their
+// comparison behind the work already in `stream`.  Nothing here waits for the device.
+int wmx_aec_coalesce(wmx_aec *h, int max_pairs, int32_t *merged_from, int32_t *merged_into, int cap, int *n_merged, void *stream) {
+    WMX_ON_DEVICE(h);
+    using namespace wmx;
+    if (n_merged) *n_merged = 0;
+    if (!h || max_pairs < 0 || cap < 0 || (cap > 0 && (!merged_from || !merged_into))) return WMX_EINVAL;
+    hipStream_t s = as_stream(stream);
+    h->co_calls++;
+    if (h->n_far < 2 || !h->d_stream_far) return 0;
+    if (!h->d_co_flags) {
+        WMX_HIP(hipMalloc(&h->d_co_flags, sizeof(int) * kAecCoMax));
+        WMX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->h_co_flags), sizeof(int) * kAecCoMax, hipHostMallocDefault));
+        WMX_HIP(hipEventCreateWithFlags(&h->co_done, hipEventDisableTiming));
+    }
+    int merged = 0;
+    if (h->co_inflight) {
+        const hipError_t q = hipEventQuery(h->co_done);
+        if (q == hipErrorNotReady) return 0;  // the comparison has not run yet: nothing new is proposed on top of it
+        if (q != hipSuccess) return hip_fail(q, "hipEventQuery(co_done)", __FILE__, __LINE__);
+        h->co_inflight = false;
+        AecPairChecks go;
+        int n_go = 0;
+        for (int i = 0; i < h->co_n; i++) {
+            AecPairCheck pc = h->co_pairs.p[i];
+            if (pc.b < 0) continue;  // dropped by a call in between
+            AecCoKey ka, kb;
+            const bool ok = h->h_co_flags[i] == 1 && h->live[(size_t)pc.a] && h->live[(size_t)pc.b] &&
+                            aec_co_key(h->ctl[(size_t)pc.a], &ka) && aec_co_key(h->ctl[(size_t)pc.b], &kb) && ka == kb;
+            if (!ok) {
+                h->co_retry_at[(size_t)pc.b] = h->co_calls + 64;
+                continue;
+            }
+            if (merged >= cap) continue;  // no room to report it: proposed again by a later call
+            aec_co_pair(h->ctl[(size_t)pc.a], h->ctl[(size_t)pc.b], pc.a, pc.b, &pc);  // the positions of NOW (same differences, by the keys)
+            go.p[n_go++] = pc;
+            merged_from[merged] = pc.b;
+            merged_into[merged] = pc.a;
+            merged++;
+        }
+        h->co_n = 0;
+        if (n_go > 0) {
+            {
+                const int rc = aec_enter_own_noise(h, s);
+                if (rc != 0) return rc;
+            }
+            hipLaunchKernelGGL(aec_merge_streams, dim3((unsigned)((h->n_streams + 3) / 4)), dim3(256), 0, s, h->d_state, h->d_stream_far,
+                               h->n_streams, go, n_go);
+            WMX_LAUNCH_CHECK();
+            std::vector<int32_t> to((size_t)h->n_far, -1);
+            for (int i = 0; i < n_go; i++) {
+                to[(size_t)go.p[i].b] = go.p[i].a;
+                h->live[(size_t)go.p[i].b] = 0;  // retired: its id may be handed out again (wmx_aec_add_cohort)
+            }
+            for (int32_t &c : h->h_cohort_of)
+                if (to[(size_t)c] >= 0) c = to[(size_t)c];
+            // the id range ends behind the last live cohort again (plans, far kernel waves and the caller's per-cohort arrays are
+            // sized by it: wmx_aec_cohorts); switched-off streams that still carry an id beyond it are parked on cohort 0
+            int nf = h->n_far;
+            while (nf > 1 && !h->live[(size_t)nf - 1]) nf--;
+            if (nf < h->n_far) {
+                hipLaunchKernelGGL(aec_clamp_group, dim3((unsigned)((h->n_streams + 255) / 256)), dim3(256), 0, s, h->d_stream_far, h->n_streams, nf);
+                WMX_LAUNCH_CHECK();
+                for (int32_t &c : h->h_cohort_of)
+                    if (c >= nf) c = 0;
+                h->n_far = nf;
+                h->ctl.resize((size_t)nf);
+                h->live.resize((size_t)nf);
+                h->co_retry_at.resize((size_t)nf);
+            }
+            h->order_dirty = true;
+            h->order_age = wmx_aec::kOrderEvery;  // the next launch sorts the streams by their new cohorts
+            h->co_merged_total += n_go;
+        }
+    }
+    if (n_merged) *n_merged = merged;
+    if (max_pairs == 0 || h->last_far_group_stride != 0) return 0;
+    if (max_pairs > kAecCoMax) max_pairs = kAecCoMax;
+    // candidates: the first live cohort with a key leads, every later one with the same key may join it
+    // (the lowest ids survive, so that the id range can shrink behind them); keys meet through a hash of their words
+    std::unordered_multimap<uint64_t, int> leads;
+    leads.reserve((size_t)h->n_far);
+    int n = 0;
+    for (int g = 0; g < h->n_far && n < max_pairs; g++) {
+        if (!h->live[(size_t)g]) continue;
+        AecCoKey k, kl;
+        if (!aec_co_key(h->ctl[(size_t)g], &k)) continue;
+        uint64_t hash = 1469598103934665603ull;
+        for (int v : k.v) hash = (hash ^ (uint32_t)v) * 1099511628211ull;
+        int lead = -1;
+        const auto range = leads.equal_range(hash);
+        for (auto it = range.first; it != range.second && lead < 0; ++it)
+            if (aec_co_key(h->ctl[(size_t)it->second], &kl) && kl == k) lead = it->second;
+        if (lead < 0) {
+            leads.emplace(hash, g);
+            continue;
+        }
+        if (h->co_retry_at[(size_t)g] > h->co_calls) continue;
+        aec_co_pair(h->ctl[(size_t)lead], h->ctl[(size_t)g], lead, g, &h->co_pairs.p[n++]);
+    }
+    h->co_n = n;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(aec_cohort_equal, dim3((unsigned)n), dim3(256), 0, s, h->far, h->co_pairs, h->d_co_flags);
+    WMX_LAUNCH_CHECK();
+    WMX_HIP(hipMemcpyAsync(h->h_co_flags, h->d_co_flags, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s));
+    WMX_HIP(hipEventRecord(h->co_done, s));
+    h->co_inflight = true;
     return 0;
 }
 
@@ -1717,6 +1993,14 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
     rc_g.assign((size_t)G, 0);
     int rc_first = 0, running = 0;
     for (int g = 0; g < G; g++) running += (h->live[(size_t)g] && (!cohort_on || cohort_on[g])) ? 1 : 0;
+    h->last_far_group_stride = (mode & 1) ? far_group_stride : h->last_far_group_stride;
+    // pairs whose comparison is in flight (wmx_aec_coalesce) stay candidates only while the two cohorts are called identically
+    for (int i = 0; i < h->co_n; i++) {
+        AecPairCheck &pc = h->co_pairs.p[i];
+        if (pc.b < 0) continue;
+        const bool on_a = !cohort_on || cohort_on[pc.a], on_b = !cohort_on || cohort_on[pc.b];
+        if (on_a != on_b || (on_a && delay_ms[pc.a] != delay_ms[pc.b]) || ((mode & 1) && far_group_stride != 0)) pc.b = -1;
+    }
     {
         const int need = n_packets < kAecMaxPktPerLaunch ? n_packets : kAecMaxPktPerLaunch;
         if (need > h->noise_pkts) {
@@ -1788,7 +2072,7 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
             }
             hipLaunchKernelGGL(aec_far_kernel, dim3((unsigned)G), dim3(64), 0, fs, h->far, h->d_consts, dp, chunk, G,
                                d_far ? d_far + (size_t)done * far_packet_stride : nullptr, far_packet_stride, far_group_stride, h->chn, gpow1np,
-                               h->d_noise_tab, h->d_noise, by_value, hp[0]);
+                               h->d_noise_tab, h->own_noise ? nullptr : h->d_noise, by_value, hp[0]);
             WMX_LAUNCH_CHECK();
             if (tv) WMX_HIP(hipEventRecord(tv[1], fs));
             if (forked) {
@@ -1808,12 +2092,22 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
                 const int32_t *order = ordered ? h->d_order : nullptr;
                 const unsigned grid = ordered ? h->order_wgs : (unsigned)((h->n_streams + kAecWavesPerBlock - 1) / kAecWavesPerBlock);
                 const dim3 blk(64 * kAecWavesPerBlock);
-                if (h->freq == 8000)
-                    hipLaunchKernelGGL((aec_near_kernel<1>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, chunk, G, h->d_noise, nin,
-                                       nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg, h->d_stream_far, h->life.d_active, order);
-                else
-                    hipLaunchKernelGGL((aec_near_kernel<2>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, chunk, G, h->d_noise, nin,
-                                       nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg, h->d_stream_far, h->life.d_active, order);
+#define AEC_NEAR_LAUNCH(M, OWN)                                                                                                               \
+    hipLaunchKernelGGL((aec_near_kernel<M, OWN>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, chunk, G, h->d_noise,       \
+                       h->d_noise_tab, nin, nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg, h->d_stream_far, h->life.d_active, \
+                       order)
+                if (h->freq == 8000) {
+                    if (h->own_noise)
+                        AEC_NEAR_LAUNCH(1, true);
+                    else
+                        AEC_NEAR_LAUNCH(1, false);
+                } else {
+                    if (h->own_noise)
+                        AEC_NEAR_LAUNCH(2, true);
+                    else
+                        AEC_NEAR_LAUNCH(2, false);
+                }
+#undef AEC_NEAR_LAUNCH
                 WMX_LAUNCH_CHECK();
                 if (tv) WMX_HIP(hipEventRecord(tv[3], s));
             }
@@ -1860,6 +2154,7 @@ int wmx_aec_reset_cohort(wmx_aec *h, int cohort, void *stream) {
     using namespace wmx;
     if (!h || cohort < 0 || cohort >= h->n_far) return WMX_EINVAL;
     h->ctl[(size_t)cohort].init(h->freq);
+    aec_co_drop(h, cohort);
     WMX_HIP(hipMemsetAsync(h->d_far + (size_t)cohort * h->far.group_words, 0, h->far.group_words * sizeof(float), as_stream(stream)));
     return 0;
 }
@@ -1886,6 +2181,8 @@ int wmx_aec_export_stream(wmx_aec *h, int stream_index, void *host_blob) {
     char *p = static_cast<char *>(host_blob);
     blob_begin(p, blob_tag("AEC "), (uint32_t)h->freq, AS_WORDS * 4);
     WMX_HIP(hipMemcpy(p + sizeof(BlobHeader), h->d_state + (size_t)stream_index * AS_WORDS, AS_WORDS * 4, hipMemcpyDeviceToHost));
+    // the blob always carries the stream's comfort-noise generator: while the cohorts are pure it is the cohort's
+    if (!h->own_noise) memcpy(p + sizeof(BlobHeader) + 4 * AS_SEED, &h->ctl[(size_t)h->h_cohort_of[(size_t)stream_index]].seed, 4);
     return 0;
 }
 
@@ -1896,6 +2193,18 @@ int wmx_aec_import_stream(wmx_aec *h, int stream_index, const void *host_blob, i
     const int rc = blob_check(host_blob, blob_tag("AEC "), (uint32_t)h->freq, AS_WORDS * 4);
     if (rc) return rc;
     WMX_HIP(hipDeviceSynchronize());
+    if (!h->own_noise) {
+        // a stream whose generator is not where its new cohort's is (it comes out of a merged cohort, or its cohort's control plane
+        // has not been imported yet): the handle's streams keep their own from here on
+        uint32_t seed;
+        memcpy(&seed, static_cast<const char *>(host_blob) + sizeof(BlobHeader) + 4 * AS_SEED, 4);
+        const int c = cohort >= 0 ? cohort : h->h_cohort_of[(size_t)stream_index];
+        if (seed != h->ctl[(size_t)c].seed) {
+            const int rc2 = aec_enter_own_noise(h, nullptr);
+            if (rc2 != 0) return rc2;
+            WMX_HIP(hipDeviceSynchronize());
+        }
+    }
     WMX_HIP(hipMemcpy(h->d_state + (size_t)stream_index * AS_WORDS, static_cast<const char *>(host_blob) + sizeof(BlobHeader), AS_WORDS * 4,
                       hipMemcpyHostToDevice));
     if (cohort >= 0 && h->d_stream_far) {
@@ -1930,11 +2239,18 @@ int wmx_aec_import_cohort(wmx_aec *h, int cohort, const void *host_blob) {
     WMX_HIP(hipDeviceSynchronize());
     const char *p = static_cast<const char *>(host_blob) + sizeof(BlobHeader);
     memcpy(&h->ctl[(size_t)cohort], p, sizeof(AecCtl));
+    aec_co_drop(h, cohort);
     WMX_HIP(hipMemcpy(h->d_far + (size_t)cohort * h->far.group_words, p + sizeof(AecCtl), fb, hipMemcpyHostToDevice));
     return 0;
 }
 
 int wmx_aec_cohorts(const wmx_aec *h) { return h ? h->n_far : WMX_EINVAL; }
+int wmx_aec_live_cohorts(const wmx_aec *h) {
+    if (!h) return WMX_EINVAL;
+    int n = 0;
+    for (uint8_t l : h->live) n += l ? 1 : 0;
+    return n;
+}
 
 }  // extern "C"
 

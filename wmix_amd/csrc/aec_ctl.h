@@ -320,4 +320,49 @@ struct AecCtl {
     }
 };
 
+// ---- coalescing (wmx_aec_coalesce): when do two control planes make the same plans from here on?
+// What decides a control plane's future, positions taken out: two planes with equal keys make the same plans up to a rotation of
+// their rings, as long as they are called with the same delays.  (The start-up fields of AecCtl are dead once startup_phase is 0;
+// the comfort-noise generator belongs to the streams once cohorts have been merged; hist_n and the ring positions are what the
+// rotation absorbs.)  tools_dev/san/host_ctl_san.cpp drives pairs of planes for thousands of packets behind an equal key.
+struct AecCoKey {
+    int v[13];
+    bool operator==(const AecCoKey &o) const {
+        for (int i = 0; i < 13; i++)
+            if (v[i] != o.v[i]) return false;
+        return true;
+    }
+};
+inline bool aec_co_key(const AecCtl &c, AecCoKey *k) {
+    if (c.startup_phase) return false;
+    const int v[13] = {c.near_fr.avail_read(), c.out_fr.avail_read(), c.far_buf.avail_read(), c.far_pre.avail_read(), c.system_delay,
+                       c.core_known_delay, c.noise_ctr, c.delay_est_ctr, c.knownDelay, c.timeForDelayChange, (int)c.msInSndCardBuf,
+                       (int)c.filtDelay, (int)c.lastDelayDiff};
+    for (int i = 0; i < 13; i++) k->v[i] = v[i];
+    return true;
+}
+// the rotations between cohort a (`into`) and cohort b (`from`)
+struct AecPairCheck {
+    int a, b;
+    int d_pre;       // b's far_pre positions = a's + d_pre   (mod kAecPreLen)
+    int d_far;       // b's far ring slots    = a's + d_far   (mod kAecFarBlocks)
+    int d_hist;      // b's history rows      = a's + d_hist  (mod kAecHist)
+    int d_near, d_out;  // a's near / out ring positions = b's + d (mod kAecRing): the rotation a merge applies to b's member streams
+    int pad;
+};
+inline int aec_mod(int x, int m) {
+    x %= m;
+    return x < 0 ? x + m : x;
+}
+inline void aec_co_pair(const AecCtl &a, const AecCtl &b, int ia, int ib, AecPairCheck *pc) {
+    pc->a = ia;
+    pc->b = ib;
+    pc->d_pre = aec_mod(b.far_pre.rd - a.far_pre.rd, kAecPreLen);
+    pc->d_far = aec_mod(b.far_buf.rd - a.far_buf.rd, kAecFarBlocks);
+    pc->d_hist = aec_mod(b.hist_n - a.hist_n, kAecHist);
+    pc->d_near = aec_mod(a.near_fr.rd - b.near_fr.rd, kAecRing);
+    pc->d_out = aec_mod(a.out_fr.rd - b.out_fr.rd, kAecRing);
+    pc->pad = 0;
+}
+
 }  // namespace wmx

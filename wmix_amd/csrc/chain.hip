@@ -228,6 +228,20 @@ int wmx_chain_retire_cohort(wmx_chain *h, int cohort) {
     return h->aec ? wmx_aec_retire_cohort(h->aec, cohort) : (h->aecm ? wmx_aecm_retire_cohort(h->aecm, cohort) : 0);
 }
 
+int wmx_chain_coalesce(wmx_chain *h, int max_pairs, int32_t *merged_from, int32_t *merged_into, int cap, int *n_merged, void *stream) {
+    WMX_ON_DEVICE(h);
+    if (n_merged) *n_merged = 0;
+    if (!h) return WMX_EINVAL;
+    if (!h->aec) return 0;
+    const int rc = wmx_aec_coalesce(h->aec, max_pairs, merged_from, merged_into, cap, n_merged, stream);
+    const int n = wmx_aec_cohorts(h->aec);
+    if (n != h->n_cohorts) {
+        h->n_cohorts = n;
+        h->zero_delays.assign((size_t)n, 0);
+    }
+    return rc;
+}
+
 int wmx_chain_cohorts(const wmx_chain *h) { return h ? h->n_cohorts : WMX_EINVAL; }
 
 // A stream's state in every stage, concatenated in the heartbeat's order (each part is the stage's own blob); the AEC cohort

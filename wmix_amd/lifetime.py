@@ -45,6 +45,28 @@ class Lifetime:
         """Every member of the cohort was released: it is never called again, its id may be handed out again."""
         check(getattr(lib(), "wmx_%s_retire_cohort" % self._mod)(self._h, int(cohort)), "retire_cohort")
 
+    def coalesce(self, max_pairs=32):
+        """wmx_aec_coalesce / wmx_chain_coalesce: completes the merges whose device check came back equal and proposes up to
+        max_pairs new ones.  Returns [(from, into), ...] of the cohorts merged by THIS call; n_cohorts is up to date afterwards."""
+        import ctypes as C
+        assert self._mod in ("aec", "chain")
+        fr = np.zeros(32, np.int32)
+        to = np.zeros(32, np.int32)
+        n = C.c_int(0)
+        check(getattr(lib(), "wmx_%s_coalesce" % self._mod)(self._h, int(max_pairs), fr.ctypes.data, to.ctypes.data, 32, C.byref(n), _stream()),
+              "coalesce")
+        k = getattr(lib(), "wmx_%s_cohorts" % self._mod)(self._h)
+        if self._mod == "aec":
+            self.n_far = k
+        self.n_cohorts = k
+        return [(int(fr[j]), int(to[j])) for j in range(n.value)]
+
+    def live_cohorts(self):
+        """Cohorts that are not retired (wmx_aec_live_cohorts of the handle's float AEC)."""
+        assert self._mod in ("aec", "chain")
+        h = self._h if self._mod == "aec" else lib().wmx_chain_aec(self._h)
+        return lib().wmx_aec_live_cohorts(h)
+
     def set_active(self, mask):
         """mask: n_streams booleans (False = the stream is not called: state and PCM rows untouched) or None = all."""
         if mask is None:
