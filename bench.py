@@ -580,7 +580,7 @@ class ChainWorkload:
     extra_stages = 0      # WMX_CHAIN_NSX | WMX_CHAIN_AECM for the fixed-point chain
     timer_dominant = "aec"
 
-    def __init__(self, dev, n_streams, rank, dist=None, packets=1, interval_ms=10, cohorts=1, cohort_layout="arrival"):
+    def __init__(self, dev, n_streams, rank, dist=None, packets=1, interval_ms=10, cohorts=1, cohort_layout="arrival", coalesce=False):
         from wmix_amd import synth
         from wmix_amd.chain import AEC, AGC, NS, VAD, ChainBatch
         global broadcast_far
@@ -636,6 +636,10 @@ class ChainWorkload:
         # "interleaved": stream s belongs to group s % N (slots scattered by churn: the streams of a workgroup hear different
         # cohorts' far-end histories).
         self.n_cohorts, self.cohort_layout = int(cohorts), cohort_layout
+        # --coalesce: wmx_chain_coalesce behind every step -- cohorts whose control planes have converged (same delay, noise-floor
+        # start-up over, same phase of the 8-packet block pattern) are merged after a word-for-word comparison of their far-end
+        # slabs on the device; the priming grows by the 1 000 blocks of that start-up and the merge rounds (32 pairs per call)
+        self.coalesce, self.merged = bool(coalesce) and int(cohorts) > 1, 0
         assert 1 <= self.n_cohorts <= n_streams
         if self.n_cohorts > 1:
             sidx = np.arange(n_streams)
@@ -648,7 +652,8 @@ class ChainWorkload:
 
     def min_prime(self):
         """untimed steps needed before every stream has joined and is past the start-up phases"""
-        return self.n_cohorts - 1
+        settle = (1000 * 64 // (self.pkt * self.P) + 120 + self.n_cohorts // 8) if self.coalesce else 0
+        return self.n_cohorts - 1 + settle
 
     def _join(self, j):
         """group j's handles are created in front of step j"""
@@ -657,7 +662,7 @@ class ChainWorkload:
             self.chain.reset_cohort(0)
         else:
             c = self.chain.add_cohort()
-        assert c == j
+        assert c == j or self.coalesce
         self.chain.reset_streams(self.members[j], cohort=c)
         self.active[self.members[j]] = 1
         self.chain.set_active(None if j == self.n_cohorts - 1 else self.active)
@@ -707,6 +712,8 @@ class ChainWorkload:
         far = self._far_for(step_index)
         if step_index < self.n_cohorts and self.n_cohorts > 1:
             self._join(step_index)
+        if self.coalesce and step_index > 0:
+            self.merged += len(self.chain.coalesce(32))
         if self.tick_major:
             src = self.inp[k // P]
             if timed == "all":
@@ -770,6 +777,8 @@ class ChainWorkload:
         return {"workload": self.name, "streams_per_gpu": self.n_streams, "packets_per_stream_per_step": self.P,
                 "interval_ms": self.interval_ms,
                 "cohorts": self.n_cohorts,
+                "coalesce": ({"cohorts_merged": self.merged, "cohorts_live": self.chain.live_cohorts(), "cohort_ids": self.chain.n_cohorts}
+                             if self.coalesce else None),
                 "aec_host_control_plane_us_per_launch": getattr(self, "host_ctl_us", None),
                 "cohort_layout": (self.cohort_layout if self.n_cohorts > 1 else None),
                 "layout": "tick-major [tick][stream][P x 10 ms]" if self.tick_major else "packet-major [packet][stream]",
@@ -1113,6 +1122,9 @@ def main():
                     help="chain workloads: the streams are N groups of handles created at N distinct ticks (group j joins in front of "
                          "step j: a control plane and a far-end history of its own, wmx_chain_add_cohort); the priming grows to N + "
                          "--prime steps")
+    ap.add_argument("--coalesce", action="store_true",
+                    help="with --cohorts: wmx_chain_coalesce behind every step (cohorts whose control planes have converged are merged; "
+                         "the priming grows until they have)")
     ap.add_argument("--cohort-layout", default="arrival", choices=["arrival", "interleaved"],
                     help="which streams join together: neighbours (slots handed out in arrival order) or stream s in group s %% N")
     ap.add_argument("--spinup", type=int, default=64,
@@ -1182,7 +1194,7 @@ def main():
             assert torch.cuda.current_device() == local_rank, "rank %d: current device %d, LOCAL_RANK %d" % (rank, torch.cuda.current_device(), local_rank)
             assert dist.get_world_size() == world, "RCCL sees %d ranks, the launcher started %d" % (dist.get_world_size(), world)
     if issubclass(cls, ChainWorkload):
-        wl = cls(dev, n_mine, rank, dist, args.packets_per_step, args.interval_ms, args.cohorts, args.cohort_layout)
+        wl = cls(dev, n_mine, rank, dist, args.packets_per_step, args.interval_ms, args.cohorts, args.cohort_layout, args.coalesce)
     elif issubclass(cls, StubCpuWorkload):
         wl = cls(dev, n_mine, rank, dist, args.packets_per_step, lo)
     elif issubclass(cls, AecmWorkload):

@@ -142,8 +142,8 @@ def test_only_cohorts_that_report_the_same_delay_fold(cuda, oracle_port):
 
 
 def test_a_stream_of_a_folded_cohort_migrates_with_its_own_generator(cuda, oracle_port):
-    """Export / import after a fold: the blob carries the stream's comfort-noise generator, and a fresh batch whose cohort's
-    generator stands elsewhere lets its streams keep their own from the import on."""
+    """Export / import after a fold: the blob carries the stream's block count -- the state of its comfort-noise generator -- and the
+    batch it moves to makes its noise table reach the oldest stream it was given."""
     S, T, freq, pkt = 8, 1500, 16000, 160
     far = synth.far_end(8300, T, pkt).reshape(T, pkt)
     near = synth.near_end(8301, S, T, pkt, far=far.reshape(-1)).reshape(S, T, pkt)

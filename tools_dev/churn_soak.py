@@ -2,7 +2,10 @@
 out again) and report their own delays for thousands of ticks, while the buffers grow -- and every sampled life is compared with a
 per-handle oracle run started at its own tick.  The whole chain (or `--fx`: the fixed-point one, bit-exact).
 
-    python tools_dev/churn_soak.py [--streams 4096] [--ticks 2500] [--freq 16000] [--fx] [--seed 1]
+    python tools_dev/churn_soak.py [--streams 4096] [--ticks 2500] [--freq 16000] [--fx] [--seed 1] [--coalesce]
+
+--coalesce: wmx_chain_coalesce behind every tick (float chain): cohorts with the same reported delay fold into one another while others
+join, leave and are retired around them; the soak's own cohort table follows the (from, into) pairs the call returns.
 """
 import argparse
 import json
@@ -25,6 +28,7 @@ def main():
     ap.add_argument("--freq", type=int, default=16000)
     ap.add_argument("--fx", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--coalesce", action="store_true")
     a = ap.parse_args()
     S, T, freq, K, U = a.streams, a.ticks, a.freq, 200, 64
     pkt = freq // 100
@@ -48,7 +52,7 @@ def main():
     rec = torch.empty(T, len(watch), pkt, dtype=torch.int16, device=dev)
     first = True
     t_wall = time.time()
-    max_cohorts = 0
+    max_cohorts = n_folds = peak_live = 0
     for t in range(T):
         changed = False
         # leave: a random cohort's handles are released
@@ -91,6 +95,13 @@ def main():
         rc, codes, _ = cb.process_packet_major(dfar[t % K:t % K + 1], inp[t % K:t % K + 1], out=work, delays=delays, cohort_on=on)
         assert rc == 0 and not codes.any(), (t, rc, codes)
         rec[t] = work[0, dwatch]
+        if a.coalesce:
+            for fr, to in cb.coalesce(32):
+                assert cohorts[fr]["delay"] == cohorts[to]["delay"], (t, fr, to)
+                gone = cohorts.pop(fr)
+                cohorts[to]["members"] = np.concatenate([cohorts[to]["members"], gone["members"]])
+                n_folds += 1
+            peak_live = max(peak_live, cb.live_cohorts())
     for s, (st, dl) in open_life.items():
         lives.append((s, st, T, dl))
     n_host, sec = cb.aec_host_ctl() if not a.fx else (0, 0.0)
@@ -120,6 +131,7 @@ def main():
         n_pk += en - st
     print(json.dumps({"streams": S, "ticks": T, "freq": freq, "fixed_point": a.fx, "lives_total": len(lives), "lives_checked": n_lives,
                       "packets_checked": n_pk, "max_lsb": worst, "max_cohort_ids": max_cohorts, "cohorts_alive_at_end": len(cohorts),
+                      "coalesce": a.coalesce, "folds": n_folds, "peak_live_cohorts": peak_live,
                       "wall_s": round(time.time() - t_wall, 1),
                       "host_ctl_us_per_tick": (sec / n_host * 1e6 if n_host else None)}))
     assert worst <= (0 if a.fx else 1)

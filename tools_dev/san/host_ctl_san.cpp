@@ -30,7 +30,6 @@ static long drive_aec(int freq, int pkg, int mode_delay) {
     AecCtl c;
     c.init(freq);
     long blocks = 0;
-    uint32_t lcg_expect = 777u;  // aec->seed, aec_core.c:1681
     for (int p = 0; p < 6000; p++) {
         AecPlan pl;
         std::memset(&pl, 0, sizeof(pl));
@@ -58,12 +57,9 @@ static long drive_aec(int freq, int pkg, int mode_delay) {
             const AecBlkPlan &b = pl.blk[k];
             CHECK(b.near_rd >= 0 && b.near_rd < kAecRing && b.out_wr >= 0 && b.out_wr < kAecRing);
             CHECK(b.far_slot >= 0 && b.far_slot < kAecFarBlocks && b.hist_n == blocks + k);
-            // the block carries the generator's state in front of its 64 draws: the reference's own recurrence, draw by draw
-            // (randomization_functions.c:87-112), must land on the next block's state -- which the control plane reaches in one jump
-            CHECK(b.seed == lcg_expect && b.seed <= 0x7FFFFFFFu);
-            for (int i = 0; i < 64; i++) lcg_expect = (lcg_expect * 69069u + 1u) & 0x7FFFFFFFu;
         }
         blocks += pl.n_blk;
+        CHECK(c.blocks == (uint32_t)blocks);
     }
     return blocks;
 }
@@ -168,7 +164,29 @@ int main() {
             CHECK((seed >> 16) < (uint32_t)kAecNoiseTab);
             CHECK(tab[seed >> 16].c == cosf(tmp) && tab[seed >> 16].s == sinf(tmp));
         }
-        // lane i of the far kernel reaches draw i + 1 in one step
+        // AecNoiseRows: the state in front of row r -- 777 advanced by 64 r draws, composed from the 2^k-draw steps -- against the
+        // reference's recurrence draw by draw, over the first 3 000 rows and at rows far out (sequentially from a jumped start)
+        {
+            uint32_t pow2[32][2];
+            aec_lcg_pow2(pow2);
+            uint32_t x = 777u;
+            for (uint32_t r = 0; r < 3000; r++) {
+                CHECK(aec_row_seed(r, pow2) == x);
+                for (int i = 0; i < 64; i++) x = (x * 69069u + 1u) & 0x7FFFFFFFu;
+            }
+            for (uint32_t r : {1u << 20, (1u << 25) - 5u, 12345678u}) {
+                uint32_t y = aec_row_seed(r, pow2);
+                for (uint32_t q = r; q < r + 4; q++) {
+                    CHECK(aec_row_seed(q & ((1u << 25) - 1), pow2) == y);  // the table's period: row 2^25 is row 0 again
+                    for (int i = 0; i < 64; i++) y = (y * 69069u + 1u) & 0x7FFFFFFFu;
+                }
+            }
+            uint32_t z = 777u;  // and the full period really is 2^31 draws: 2^k-draw steps of the one-draw map
+            z = z * pow2[30][0] + pow2[30][1];
+            z = z * pow2[30][0] + pow2[30][1];
+            CHECK((z & 0x7FFFFFFFu) == 777u);
+        }
+        // lane i of aec_noise_rows reaches draw i + 1 of a row in one step
         for (int k = 1; k <= 64; k++) {
             uint32_t a, c, s = 12345u, want = 12345u;
             aec_lcg_jump(k, &a, &c);

@@ -183,12 +183,13 @@ def _declare(L):
         f.argtypes = [vp, i]
     L.wmx_chain_cohorts.restype = i
     L.wmx_chain_cohorts.argtypes = [vp]
-    L.wmx_aec_live_cohorts.restype = i
-    L.wmx_aec_live_cohorts.argtypes = [vp]
-    for name in ("wmx_aec_coalesce", "wmx_chain_coalesce"):
-        f = getattr(L, name)
-        f.restype = i
-        f.argtypes = [vp, i, vp, vp, i, C.POINTER(i), vp]
+    if hasattr(L, "wmx_aec_coalesce"):  # (a WMIX_AMD_LIB variant built from an older tree, for A/B runs, may not have them)
+        L.wmx_aec_live_cohorts.restype = i
+        L.wmx_aec_live_cohorts.argtypes = [vp]
+        for name in ("wmx_aec_coalesce", "wmx_chain_coalesce"):
+            f = getattr(L, name)
+            f.restype = i
+            f.argtypes = [vp, i, vp, vp, i, C.POINTER(i), vp]
     L.wmx_aecm_create_cohorts.restype = i
     L.wmx_aecm_create_cohorts.argtypes = [C.POINTER(vp), i, i, i, i, i]
     L.wmx_aec_set_timing.restype = i

@@ -30,6 +30,7 @@
 // Float expressions, their order and the ordered sums follow the reference exactly (-ffp-contract=off); powf is the
 // table-driven double-precision evaluation of libm_dev.h, the rare log the library routine; cosf/sinf of the comfort
 // noise come from the host's libm through the plan.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -77,9 +78,9 @@ enum : int {
     AS_STNEAR = AS_SCAL + 8,
     AS_ECHOSTATE = AS_SCAL + 9,
     AS_DIVERGE = AS_SCAL + 10,
-    AS_SEED = AS_SCAL + 11,      // comfort-noise generator (WebRtcSpl_RandUArray's seed) of the stream -- maintained only once cohorts of
-                                 //   different ages have been merged (wmx_aec_coalesce, OWN_NOISE kernels); until then the generator's
-                                 //   state is the cohort's (AecCtl::seed: every member has processed the same number of blocks)
+    AS_NBLK = AS_SCAL + 11,      // blocks this stream has processed since aec_init (uint32): every handle's comfort-noise generator
+                                 //   starts from the same state (aec->seed = 777, aec_core.c:1670) and draws 64 numbers per block, so
+                                 //   the block count IS the generator's state -- and the row of AecNoiseRows the block's phases lie in
     AS_WORDS = AS_SCAL + 16,
 };
 static_assert(AS_WORDS % 4 == 0, "state block must be a whole number of 16-byte chunks");
@@ -144,15 +145,11 @@ __device__ __forceinline__ void unpack_bin(const float *a, int b, float &re, flo
 // plan_by_value: a one-packet launch hands its plan over as a kernel argument; this kernel, which runs in front of the near
 // kernel in the same stream, stores it into plans[0] for both -- no host-to-device blit between the previous kernel of the
 // stream and this one (4.7 us per step of the chain).  Every far-end group stores the same bytes.
-// Plans lie [packet][cohort] (n_cohorts apart per packet: a launch uploads exactly packets x cohorts of them), and so do the
-// comfort-noise rows this kernel makes for the near kernel: noise[(packet * n_cohorts + cohort) * kAecNoiseRow + block * 128 + ...]
-// = the 64 cosines, then the 64 sines, of the block's phases (aec_core.c:482-489), looked up in the host-made table.
-constexpr int kAecNoiseRow = 4 * 2 * kAecPart;  // floats per (packet, cohort): up to 4 blocks x (64 cos | 64 sin)
+// Plans lie [packet][cohort] (n_cohorts apart per packet: a launch uploads exactly packets x cohorts of them).
 __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const float *__restrict__ consts_g, AecPlan *plans,
                                                      int n_packets, int n_cohorts, const int16_t *far_pcm, long far_packet_stride,
-                                                     long far_group_stride, int chn, float gpow1np,
-                                                     const AecNoiseEntry *__restrict__ noise_tab, float *__restrict__ noise,
-                                                     int plan_by_value, const AecPlan plan_value) {
+                                                     long far_group_stride, int chn, float gpow1np, int plan_by_value,
+                                                     const AecPlan plan_value) {
     __shared__ AecConsts K;
     __shared__ float fa[2][132];
     const int lane = threadIdx.x;
@@ -173,13 +170,6 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const flo
     const AecFarBufs F = far_group(F_all, (int)blockIdx.x);
     if (far_pcm) far_pcm += (size_t)blockIdx.x * far_group_stride;
     plans += blockIdx.x;  // every far-end group (control cohort) has its own plans: [packet][cohort]
-    noise += (size_t)blockIdx.x * kAecNoiseRow;
-    // lane i draws the (i + 1)-th number of a block: seed_i = seed * 69069^(i+1) + (1 + 69069 + ... + 69069^i), masked to 31 bits
-    uint32_t jump_a = 1u, jump_c = 0u;
-    for (int i = 0; i <= lane; i++) {
-        jump_c = jump_c * 69069u + 1u;
-        jump_a = jump_a * 69069u;
-    }
     {
         // one wave, one latency chain: every request of a group goes out before the first result is used
         float *dst = reinterpret_cast<float *>(&K);
@@ -194,23 +184,6 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const flo
     wave_sync();
     for (int p = 0; p < n_packets; p++) {
         const AecPlan &pl = plans[(size_t)p * n_cohorts];
-        if (noise && pl.has_near && !pl.passthrough) {  // (noise == nullptr: the streams draw their own, OWN_NOISE near kernels)
-            // ComfortNoise's random phases (aec_core.c:476-489) for every block of the packet: WebRtcSpl_RandUArray's draws by
-            // jump-ahead, cosf / sinf of the reference's float expression by table (32 768 possible arguments, host libm)
-            float *row = noise + (size_t)p * n_cohorts * kAecNoiseRow;
-            AecNoiseEntry e[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t sd = (pl.blk[k < pl.n_blk ? k : 0].seed * jump_a + jump_c) & 0x7FFFFFFFu;
-                e[k] = noise_tab[sd >> 16];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (k >= pl.n_blk) break;
-                row[k * 2 * kAecPart + lane] = e[k].c;
-                row[k * 2 * kAecPart + kAecPart + lane] = e[k].s;
-            }
-        }
         if (pl.has_far) {
             // WebRtc_WriteBuffer(far_pre_buf, farend): channel 0 of the far-end packet (src/webrtc.c:430)
             const int16_t *src = far_pcm + (size_t)p * far_packet_stride;
@@ -444,10 +417,9 @@ __device__ __forceinline__ void aec_fft_fwd(float *row, const FftTables *T, int 
     for (int m = 0; m < 4; m++) *reinterpret_cast<float2 *>(row + 2 * (gl + 16 * m)) = make_float2(v[m].r, v[m].i);
 }
 
-template <int MULT, bool OWN_NOISE>  // MULT 1: 8 kHz, 2: 16 kHz; OWN_NOISE: the comfort noise's phases from the stream's own generator
+template <int MULT>  // 1: 8 kHz, 2: 16 kHz
 __device__ __forceinline__ void aec_block(const AecConstsNear &K, const float *__restrict__ curves_g, const PowTables *__restrict__ powtab, AecWaveLds &W, AecTaps &taps,
-                                          const AecFarBufs &F, const AecBlkPlan &bp, const float *__restrict__ nz, const AecNoiseEntry *__restrict__ noise_tab,
-                                          const int lane_in) {
+                                          const AecFarBufs &F, const AecBlkPlan &bp, const float *__restrict__ noise_rows, const int lane_in) {
     // The lane-derived LDS addresses (gather points, twiddle and window slots) are loop invariant; left alone the
     // compiler hoists ~100 of them out of the packet loop and pins them in VGPRs for the whole kernel.  Recomputing
     // them per block costs a few VALU ops and frees the registers.
@@ -826,12 +798,6 @@ __device__ __forceinline__ void aec_block(const AecConstsNear &K, const float *_
     }
     wave_sync();
     AEC_PROF(5);
-    // OWN_NOISE -- ComfortNoise's random phases (aec_core.c:476-489): the block's 64 draws of WebRtcSpl_RandUArray (randomization_
-    // functions.c:94-112, seed = (seed * 69069 + 1) & 0x7FFFFFFF per draw) by jump-ahead from the STREAM's generator state.  Lane
-    // l >= 1 takes draw l (the phase of bin l), lane 0 draw 64 (the phase of bin 64, and the state the next block starts from): the
-    // table behind the phases holds (69069^k, 1 + 69069 + ... + 69069^(k-1)) mod 2^32 for that k.  Requested here, used two phases on.
-    uint2 lcg = make_uint2(0u, 0u);
-    if constexpr (OWN_NOISE) lcg = reinterpret_cast<const uint2 *>(noise_tab + kAecNoiseTab)[lane];
     // the two ordered sums advance side by side: lane 0 adds sd[0..64], lane 1 adds se[0..64] (index order each)
     float sdSum, seSum;
 #if defined(WMX_AEC_EXP) && WMX_AEC_EXP >= 2
@@ -870,13 +836,14 @@ __device__ __forceinline__ void aec_block(const AecConstsNear &K, const float *_
     }
     AEC_PROF(6);
     AEC_RELANE();
-    AecNoiseEntry nze = AecNoiseEntry{0.f, 0.f};
-    if constexpr (OWN_NOISE) {
-        // cosf / sinf of the reference's float expression for the draw: 32 768 possible arguments, the host libm's values by table
-        const uint32_t drawn = ((uint32_t)Si[AS_SEED] * lcg.x + lcg.y) & 0x7FFFFFFFu;
-        nze = noise_tab[drawn >> 16];
-        if (lane == 0) Si[AS_SEED] = (int)drawn;
-    }
+    // ComfortNoise's random phases (aec_core.c:476-489): cosf / sinf of the block's 64 draws of WebRtcSpl_RandUArray lie in row
+    // `blocks processed so far` of the noise table (AecNoiseRows; the generator's period is 2^31 draws = 2^25 rows).  Bin b's phase
+    // is draw b - 1: lane l >= 1 takes entry l - 1, lane 0 entry 63 (bin 64's).  Requested here, used two phases on; streams of one
+    // age read one row (L2 hits), streams of merged cohorts their own.
+    const unsigned nblk = (unsigned)__builtin_amdgcn_readfirstlane(Si[AS_NBLK]);
+    const float *nz = noise_rows + (size_t)(nblk & (unsigned)(kAecNoisePeriodRows - 1)) * (2 * kAecPart);
+    const float nz_c = nz[(lane + 63) & 63], nz_s = nz[kAecPart + ((lane + 63) & 63)];
+    if (lane == 0) Si[AS_NBLK] = (int)(nblk + 1u);
     // coherences (aec_core.c:440-449), bin `lane` and bin 64 side by side
     {
         auto coh = [&](int b, float &cde, float &cxd) {
@@ -1043,13 +1010,8 @@ __device__ __forceinline__ void aec_block(const AecConstsNear &K, const float *_
         float ur = 0.f, ui = 0.f;
         if (b >= 1) {
             const float noise = sqrtf(AEC_ST(noise_off + b));
-            if constexpr (OWN_NOISE) {
-                ur = noise * nze.c;  // bin b's phase is draw b: this lane's (b == lane, or lane 0's 64th draw for bin 64)
-                ui = -noise * nze.s;
-            } else {
-                ur = noise * nz[b - 1];  // cosf / sinf of the block's 64 random phases, made by the far kernel
-                ui = -noise * nz[kAecPart + b - 1];
-            }
+            ur = noise * nz_c;  // this lane's entry: bin b == lane, or lane 0's entry 63 for bin 64
+            ui = -noise * nz_s;
             if (b == kAecPart) ui = 0.f;
         }
         const float v = 1 - h * h;
@@ -1091,14 +1053,14 @@ __device__ __forceinline__ void aec_block(const AecConstsNear &K, const float *_
 #undef AEC_RELANE
 }
 
-template <int MULT, bool OWN_NOISE>
+template <int MULT>
 #ifndef WMX_AEC_WAVES
 #define WMX_AEC_WAVES 4
 #endif
 __global__ __attribute__((amdgpu_waves_per_eu(WMX_AEC_WAVES, WMX_AEC_WAVES))) __launch_bounds__(64 * kAecWavesPerBlock) void aec_near_kernel(float *__restrict__ state, AecFarBufs F_all,
                                                                           const float *__restrict__ consts_g,
                                                                           const AecPlan *__restrict__ plans, int n_packets, int n_cohorts,
-                                                                          const float *__restrict__ noise, const AecNoiseEntry *__restrict__ noise_tab,
+                                                                          const float *__restrict__ noise_rows,
                                                                           const int16_t *near_pcm, int16_t *out_pcm, int n_streams,
                                                                           long stream_stride, long packet_stride, int chn, int pkg,
                                                                           const int *__restrict__ stream_far, const uint8_t *__restrict__ active,
@@ -1107,11 +1069,11 @@ __global__ __attribute__((amdgpu_waves_per_eu(WMX_AEC_WAVES, WMX_AEC_WAVES))) __
     __shared__ AecWaveLds Wv[kAecWavesPerBlock];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: state pointers become scalar bases
-    // One stream per wave.  With several cohorts in the batch the streams are taken in COHORT order, and so that a cohort's
-    // streams meet in one L2: workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one), so workgroup i
-    // takes chunk (i % 8) * (grid / 8) + i / 8 of the cohort-sorted list -- every XCD works through one contiguous eighth of the
-    // cohorts, and the far-end history rows a block reads (48 rows of its cohort, the same for all members) are hits of that
-    // XCD's 4 MB L2 instead of 4 096 cohorts' rows competing for each of them (order == nullptr: one cohort, stream = slot).
+    // One stream per wave.  With several cohorts in the batch the streams are taken from the host's order list: workgroups are dealt
+    // round-robin over the 8 XCDs (blocks b and b + 8 share one), so workgroup i takes slot (i % 8) * (grid / 8) + i / 8 -- XCD x
+    // works through the x-th eighth of the list in sequence.  aec_rebuild_order lays the cohort-sorted chunks out in it so that a small
+    // cohort's streams meet in one L2 (its 48 far-end history rows per block are fetched once, not by 4 096 cohorts' rows competing
+    // in every L2) and a large cohort is spread evenly (order == nullptr: one cohort, stream = slot).
     int sidx;
     if (order) {
         const unsigned i = blockIdx.x, per = gridDim.x >> 3;
@@ -1129,7 +1091,6 @@ __global__ __attribute__((amdgpu_waves_per_eu(WMX_AEC_WAVES, WMX_AEC_WAVES))) __
     const int grp = stream_far ? __builtin_amdgcn_readfirstlane(stream_far[sl]) : 0;
     const AecFarBufs F = far_group(F_all, grp);
     plans += grp;  // [packet][cohort]
-    noise += (size_t)grp * kAecNoiseRow;
     float *gst = state + (size_t)sl * AS_WORDS;
     // the constants first (L2 hits): their copy into LDS then waits for them alone, not for the HBM loads behind them
     constexpr int kConstIt = (kAecConstNearWords + 64 * kAecWavesPerBlock - 1) / (64 * kAecWavesPerBlock);
@@ -1213,7 +1174,6 @@ __global__ __attribute__((amdgpu_waves_per_eu(WMX_AEC_WAVES, WMX_AEC_WAVES))) __
     for (int p = 0; p < n_packets; p++) {
         const AecPlan &pl = plans[(size_t)p * n_cohorts];
         if (!pl.has_near) continue;
-        const float *nz = noise + (size_t)p * n_cohorts * kAecNoiseRow;
         const size_t off = (size_t)sidx * stream_stride + (size_t)p * packet_stride;
         const int16_t *in = near_pcm + off;
         int16_t *out = out_pcm + off;
@@ -1237,8 +1197,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(WMX_AEC_WAVES, WMX_AEC_WAVES))) __
             }
             wave_sync();
             for (int k = 0; k < sp.n_blocks; k++)
-                aec_block<MULT, OWN_NOISE>(K, consts_g + kAecConstNearWords, powtab, W, taps, F, pl.blk[sp.first_blk + k],
-                                           nz + (sp.first_blk + k) * 2 * kAecPart, noise_tab, lane);
+                aec_block<MULT>(K, consts_g + kAecConstNearWords, powtab, W, taps, F, pl.blk[sp.first_blk + k], noise_rows, lane);
             for (int i = opaque_lane(lane); i < kAecFrame; i += 64) {
                 const int16_t v = (int16_t)AEC_ST(AS_OUT_RING + ring_at(sp.out_rd, i));
                 for (int c = 0; c < chn; c++) out[(s * kAecFrame + i) * chn + c] = v;
@@ -1363,10 +1322,20 @@ __global__ void aec_clamp_group(int *stream_far, int n_streams, int n_far) {
     const int s = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (s < n_streams && stream_far[s] >= n_far) stream_far[s] = 0;
 }
-// OWN_NOISE starts: every stream gets the generator state of the cohort it has shared it with so far
-__global__ void aec_seed_streams(float *state, const int *stream_far, const uint32_t *cohort_seed, int n_streams) {
-    const int s = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (s < n_streams) reinterpret_cast<uint32_t *>(state + (size_t)s * AS_WORDS)[AS_SEED] = cohort_seed[stream_far ? stream_far[s] : 0];
+// AecNoiseRows: row r = the 64 cosines, then the 64 sines, of the phases ComfortNoise draws in the r-th block of a handle's life
+// (aec_core.c:476-489).  One wave per row: the generator's state in front of the row by jump-ahead over 64 r draws (composition of
+// the precomputed 2^k-draw steps), lane i's draw i + 1 from there, cosf / sinf of the reference's float expression by table.
+__global__ __launch_bounds__(64) void aec_noise_rows(float *rows, const AecNoiseEntry *__restrict__ tab, unsigned first_row, int n_rows) {
+    const unsigned r = first_row + blockIdx.x;
+    if ((int)blockIdx.x >= n_rows) return;
+    const uint2 *jump = reinterpret_cast<const uint2 *>(tab + kAecNoiseTab);  // [64] lane jumps, then [32] 2^k-draw steps
+    const uint32_t seed = aec_row_seed(r, reinterpret_cast<const uint32_t(*)[2]>(jump + 64));
+    const uint2 j = jump[threadIdx.x];
+    const uint32_t sd = (seed * j.x + j.y) & 0x7FFFFFFFu;
+    const AecNoiseEntry e = tab[sd >> 16];
+    float *row = rows + (size_t)r * (2 * kAecPart);
+    row[threadIdx.x] = e.c;
+    row[kAecPart + threadIdx.x] = e.s;
 }
 }  // namespace
 }  // namespace wmx
@@ -1388,7 +1357,7 @@ struct wmx_aec {
     bool plan_used[kPlanBufs];
     int plan_sel;
     int n_far;               // far-end groups / control cohorts in use, retired ones included (1 = one shared far-end): ids 0 .. n_far - 1
-    int cap_far;             // cohorts the device buffers (far slabs, plan slots, noise rows) are allocated for; grows by doubling
+    int cap_far;             // cohorts the device buffers (far slabs, plan slots) are allocated for; grows by doubling
     std::vector<uint8_t> live;  // [n_far] 0: retired by wmx_aec_retire_cohort (never called, its id is handed out again)
     int *d_stream_far;       // [n_streams] group of each stream, or nullptr while there has only ever been one
     // cohort-sorted, XCD-aware stream order of the near kernel (see aec_near_kernel); rebuilt on the host when memberships changed
@@ -1401,21 +1370,20 @@ struct wmx_aec {
     int order_age;            // launches since the order was rebuilt: under churn it is rebuilt every kOrderEvery launches at most
     static constexpr int kOrderEvery = 16;
     wmx::AecNoiseEntry *d_noise_tab;  // cosf / sinf of the comfort noise's 32 768 possible phases (host libm, aec_ctl.h)
-                                      // + 64 x (a, c): the generator's jump-ahead constants of the OWN_NOISE near kernel's lanes (aec_lcg_jump)
-    float *d_noise;          // [noise_pkts][cap_far][kAecNoiseRow]: what the far kernel makes of the plans' seeds for the near kernel
-    bool own_noise;          // cohorts of different ages have been merged (wmx_aec_coalesce): every stream draws from its own generator state
+                                      // + 64 x (a, c): draw i + 1 from a row's first state, + 32 x (a, c): 2^k draws in one step
+    float *d_noise_rows;     // AecNoiseRows [rows_cap][128]: rows 0 .. rows_valid - 1 are made; grown ahead of the oldest stream's block count
+    uint32_t rows_valid, rows_cap;
+    std::vector<float *> old_rows;  // tables outgrown while launches may still have been reading them: freed with the handle
     // wmx_aec_coalesce: the pairs whose device comparison is in flight (`b` < 0: dropped, the two were not called identically since)
     wmx::AecPairChecks co_pairs;
     int co_n;
     bool co_inflight;
     int *d_co_flags, *h_co_flags;  // [kAecCoMax] device result and its pinned copy
-    uint32_t *d_co_seeds;          // [cap] cohort generator states for aec_seed_streams (allocated when OWN_NOISE starts)
     hipEvent_t co_done;
     long co_calls;                 // wmx_aec_coalesce calls so far
     std::vector<long> co_retry_at; // [n_far] a cohort whose comparison failed is not proposed again before this call
     long last_far_group_stride;    // of the latest run: cohorts that hear private far-end packets are never candidates
     long co_merged_total;
-    int noise_pkts;
     int16_t *d_zero_far;  // a silent far-end packet for near-only calls that need no far data
     wmx::StreamLife life;
     // in-stream timing of the two kernels (wmx_aec_set_timing): event quadruples [far start | far end | near start | near end]
@@ -1451,10 +1419,10 @@ int wmx_aec_destroy(wmx_aec *h) {
     if (h->d_stream_far) (void)hipFree(h->d_stream_far);
     if (h->d_order) (void)hipFree(h->d_order);
     if (h->d_noise_tab) (void)hipFree(h->d_noise_tab);
-    if (h->d_noise) (void)hipFree(h->d_noise);
+    if (h->d_noise_rows) (void)hipFree(h->d_noise_rows);
+    for (float *p : h->old_rows) (void)hipFree(p);
     if (h->d_co_flags) (void)hipFree(h->d_co_flags);
     if (h->h_co_flags) (void)hipHostFree(h->h_co_flags);
-    if (h->d_co_seeds) (void)hipFree(h->d_co_seeds);
     if (h->co_done) (void)hipEventDestroy(h->co_done);
     if (h->d_tmpl) (void)hipFree(h->d_tmpl);
     h->life.release();
@@ -1470,27 +1438,47 @@ int wmx_aec_destroy(wmx_aec *h) {
 
 }  // extern "C"
 static void aec_co_drop(wmx_aec *h, int cohort);
-static int aec_enter_own_noise(wmx_aec *h, hipStream_t s);
 extern "C" {
 
 int wmx_aec_create(wmx_aec **out, int n_streams, int chn, int freq, int interval_ms) {
     return wmx_aec_create_groups(out, n_streams, chn, freq, interval_ms, 1, nullptr);
 }
 
-// The near kernel's stream order: streams sorted by cohort (stable), cut into chunks of one workgroup (4 streams); the kernel maps
-// its workgroup index to a chunk so that every XCD gets a contiguous eighth of the chunks.  Any permutation is CORRECT (a wave
-// finds its stream's cohort in d_stream_far); the order only decides which far-end rows meet in which L2.
+// The near kernel's stream order: streams sorted by (re-blocking phase, cohort), cut into chunks of one workgroup (4 streams).  The kernel gives
+// XCD x the slots [x W/8, (x + 1) W/8) of the list in sequence; the list is laid out so that the sorted chunks are DEALT to the XCDs in
+// runs of kOrderRun: a small cohort's chunks stay in one XCD, next to each other in time (its far-end rows are fetched into one L2,
+// once); a large cohort -- what wmx_aec_coalesce leaves -- is spread evenly over all eight, and all eight walk through the sorted list
+// side by side.  Evenly matters: a packet is 2.5 blocks at 16 kHz, so a cohort runs 2 or 3 blocks in a launch depending on the phase
+// of its re-blocking ring, and eight cohorts of four phases each laid out one per XCD made every launch as long as a 3-block one
+// (0.82 ms instead of 0.70, measured).  Any permutation is CORRECT (a wave finds its stream's cohort in d_stream_far).
 static int aec_rebuild_order(wmx_aec *h, hipStream_t s) {
     using namespace wmx;
     const int S = h->n_streams, G = h->n_far;
-    const unsigned wgs = (unsigned)((S + kAecWavesPerBlock - 1) / kAecWavesPerBlock), wgs8 = (wgs + 7u) / 8u * 8u;
+    constexpr unsigned kOrderRun = 16;  // chunks dealt to one XCD at a time
+    const unsigned wgs = (unsigned)((S + kAecWavesPerBlock - 1) / kAecWavesPerBlock), wgs8 = (wgs + 8u * kOrderRun - 1u) / (8u * kOrderRun) * (8u * kOrderRun);
+    // sort key: (phase of the cohort's re-blocking ring, cohort id).  The phase decides how many blocks a packet is for the cohort
+    // (the fill level behind a packet: 0 / 32 at 16 kHz, 0 / 16 / 32 / 48 at 8 kHz) and never changes in a handle's life; cohorts of
+    // one phase form one long segment of the list, which the dealing below spreads evenly -- whatever the pattern of the join ticks
+    // (cohorts created at consecutive ticks alternate phases: dealt by id alone, 256 cohorts of 256 streams put one phase on XCDs
+    // 0 - 3 and the other on 4 - 7)
+    std::vector<int32_t> rank((size_t)G), by((size_t)G);
+    for (int g = 0; g < G; g++) by[(size_t)g] = g;
+    std::stable_sort(by.begin(), by.end(), [&](int32_t a, int32_t b) {
+        return h->ctl[(size_t)a].near_fr.avail_read() < h->ctl[(size_t)b].near_fr.avail_read();
+    });
+    for (int r = 0; r < G; r++) rank[(size_t)by[(size_t)r]] = r;
     std::vector<int32_t> start((size_t)G + 1, 0);
-    for (int i = 0; i < S; i++) start[(size_t)h->h_cohort_of[(size_t)i] + 1]++;
+    for (int i = 0; i < S; i++) start[(size_t)rank[(size_t)h->h_cohort_of[(size_t)i]] + 1]++;
     for (int g = 0; g < G; g++) start[(size_t)g + 1] += start[(size_t)g];
     std::vector<int32_t> &ord = h->h_order[h->h_order_sel];
     h->h_order_sel ^= 1;
     ord.assign((size_t)wgs8 * kAecWavesPerBlock, -1);
-    for (int i = 0; i < S; i++) ord[(size_t)start[(size_t)h->h_cohort_of[(size_t)i]]++] = i;
+    for (int i = 0; i < S; i++) {
+        const unsigned q = (unsigned)start[(size_t)rank[(size_t)h->h_cohort_of[(size_t)i]]]++;  // position in the sorted list
+        const unsigned j = q / kAecWavesPerBlock, w = q % kAecWavesPerBlock;      // sorted chunk, wave
+        const unsigned x = (j / kOrderRun) & 7u, k = j / (8u * kOrderRun) * kOrderRun + j % kOrderRun;
+        ord[((size_t)x * (wgs8 / 8u) + k) * kAecWavesPerBlock + w] = i;
+    }
     if (!h->d_order || h->order_wgs != wgs8) {
         if (h->d_order) {
             WMX_HIP_RC(hipDeviceSynchronize());
@@ -1535,22 +1523,20 @@ static void aec_carve_far(wmx_aec *h) {
 }
 
 // Device buffers for `cap` cohorts and launches of up to `pkts` packets: the far-end slabs (existing ones are carried over),
-// the plan slots and the noise rows.  Growing is a control-plane operation (the device is drained); it doubles, so a batch that
+// and the plan slots.  Growing is a control-plane operation (the device is drained); it doubles, so a batch that
 // gains cohorts one join at a time reallocates a logarithmic number of times.
-static int aec_reserve(wmx_aec *h, int cap, int pkts) {
+static int aec_reserve(wmx_aec *h, int cap) {
     using namespace wmx;
-    if (cap <= h->cap_far && pkts <= h->noise_pkts) return 0;
-    WMX_HIP_RC(hipDeviceSynchronize());  // plans, noise rows and far slabs may be in use by launches in flight
+    if (cap <= h->cap_far) return 0;
+    WMX_HIP_RC(hipDeviceSynchronize());  // plans and far slabs may be in use by launches in flight
     const size_t fw = aec_far_words();
     int ncap = h->cap_far;
     if (cap > h->cap_far) {
         ncap = h->cap_far > 0 ? h->cap_far : 1;
         while (ncap < cap) ncap *= 2;
     }
-    int npkts = pkts > h->noise_pkts ? pkts : h->noise_pkts;
-    if (npkts < 2) npkts = 2;
     // everything new is allocated BEFORE anything old is let go: a failure leaves the handle as it was
-    float *nf = nullptr, *nn = nullptr;
+    float *nf = nullptr;
     AecPlan *nd = nullptr, *nh = nullptr;
     const size_t plan_bytes = (size_t)wmx_aec::kPlanBufs * ncap * kAecMaxPktPerLaunch * sizeof(AecPlan);
     hipError_t e = hipSuccess;
@@ -1562,13 +1548,10 @@ static int aec_reserve(wmx_aec *h, int cap, int pkts) {
         if (e == hipSuccess)
             e = hipMemset(nf + fw * (size_t)h->cap_far, 0, fw * (size_t)(ncap - h->cap_far) * sizeof(float));
     }
-    if (e == hipSuccess && (ncap > h->cap_far || npkts > h->noise_pkts || !h->d_noise))
-        e = hipMalloc(&nn, (size_t)npkts * ncap * kAecNoiseRow * sizeof(float));
     if (e != hipSuccess) {
         if (nf) (void)hipFree(nf);
         if (nd) (void)hipFree(nd);
         if (nh) (void)hipHostFree(nh);
-        if (nn) (void)hipFree(nn);
         return hip_fail(e, "growing the cohort buffers", __FILE__, __LINE__);
     }
     if (nf) {
@@ -1581,11 +1564,6 @@ static int aec_reserve(wmx_aec *h, int cap, int pkts) {
         for (int i = 0; i < wmx_aec::kPlanBufs; i++) h->plan_used[i] = false;  // drained above
         h->cap_far = ncap;
         aec_carve_far(h);
-    }
-    if (nn) {
-        if (h->d_noise) (void)hipFree(h->d_noise);
-        h->d_noise = nn;
-        h->noise_pkts = npkts;
     }
     return 0;
 }
@@ -1635,18 +1613,16 @@ int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int i
     h->h_plans = nullptr;
     h->d_stream_far = nullptr;
     h->d_noise_tab = nullptr;
-    h->d_noise = nullptr;
-    h->own_noise = false;
+    h->d_noise_rows = nullptr;
+    h->rows_valid = h->rows_cap = 0;
     h->co_n = 0;
     h->co_inflight = false;
     h->d_co_flags = h->h_co_flags = nullptr;
-    h->d_co_seeds = nullptr;
     h->co_done = nullptr;
     h->co_calls = 0;
     h->co_retry_at.assign((size_t)n_far, 0);
     h->last_far_group_stride = 0;
     h->co_merged_total = 0;
-    h->noise_pkts = 0;
     h->d_order = nullptr;
     h->order_wgs = 0;
     h->order_dirty = n_far > 1;
@@ -1682,10 +1658,6 @@ int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int i
     st[AS_HNLXDAVGMIN] = 1.f;
     st[AS_OVERDRIVE] = 2.f;
     st[AS_OVERDRIVESM] = 2.f;
-    {
-        const uint32_t seed0 = AecCtl().seed;  // aec->seed = 777, aec_core.c:1670
-        memcpy(&st[AS_SEED], &seed0, sizeof(seed0));
-    }
     hipError_t e;
 #define AEC_TRY(x)                                         \
     if ((e = (x)) != hipSuccess) {                         \
@@ -1697,7 +1669,7 @@ int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int i
     AEC_TRY(hipMalloc(&h->d_consts, sizeof(K) + sizeof(PowTables)));  // [AecConsts | PowTables]; only the first part is copied to LDS
     for (int i = 0; i < wmx_aec::kPlanBufs; i++) AEC_TRY(hipEventCreateWithFlags(&h->plan_free[i], hipEventDisableTiming));
     {
-        const int rc = aec_reserve(h, n_far, 2);
+        const int rc = aec_reserve(h, n_far);
         if (rc != 0) {
             wmx_aec_destroy(h);
             return rc;
@@ -1726,9 +1698,11 @@ int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int i
             aec_noise_table(t.data());
             return t;
         }();
-        // behind it, the generator's jump-ahead constants: lane l of the near kernel takes draw l of a block, lane 0 the 64th
-        uint32_t jump[2 * 64];
-        for (int l = 0; l < 64; l++) aec_lcg_jump(l ? l : kAecPart, &jump[2 * l], &jump[2 * l + 1]);
+        // behind it, the generator's jump-ahead constants for aec_noise_rows: lane i's draw i + 1 from the state in front of a row,
+        // and the 2^k-draw steps that state is composed from
+        uint32_t jump[2 * 64 + 2 * 32];
+        for (int l = 0; l < 64; l++) aec_lcg_jump(l + 1, &jump[2 * l], &jump[2 * l + 1]);
+        aec_lcg_pow2(reinterpret_cast<uint32_t(*)[2]>(jump + 128));
         AEC_TRY(hipMalloc(&h->d_noise_tab, sizeof(AecNoiseEntry) * kAecNoiseTab + sizeof(jump)));
         AEC_TRY(hipMemcpy(h->d_noise_tab, tab.data(), sizeof(AecNoiseEntry) * kAecNoiseTab, hipMemcpyHostToDevice));
         AEC_TRY(hipMemcpy(h->d_noise_tab + kAecNoiseTab, jump, sizeof(jump), hipMemcpyHostToDevice));
@@ -1758,7 +1732,7 @@ int wmx_aec_add_cohort(wmx_aec *h, int *cohort, void *stream) {
         }
     if (id < 0) {
         id = h->n_far;
-        const int rc = aec_reserve(h, id + 1, h->noise_pkts);
+        const int rc = aec_reserve(h, id + 1);
         if (rc != 0) return rc;
         h->ctl.resize((size_t)id + 1);
         h->live.push_back(1);
@@ -1784,23 +1758,39 @@ int wmx_aec_retire_cohort(wmx_aec *h, int cohort) {
 }
 
 }  // extern "C"
-// ---------------------------------------------------------------- coalescing
-// From here on every stream draws its comfort noise from its own generator state (OWN_NOISE near kernels): today's state is the
-// one of the cohort it has shared it with so far.
-static int aec_enter_own_noise(wmx_aec *h, hipStream_t s) {
+// ---------------------------------------------------------------- the comfort-noise rows
+// Rows 0 .. `oldest` + a launch's worth are made before the near kernel can read them (in `s`, in front of it).  The table grows
+// by doubling up to the generator's period (2^25 rows = 16 GiB after 37 hours of one handle at 16 kHz; a batch of short-lived
+// handles never gets there); an outgrown table stays allocated until the handle goes, launches in flight may be reading it.
+static int aec_noise_reserve(wmx_aec *h, uint32_t oldest, hipStream_t s) {
     using namespace wmx;
-    if (h->own_noise) return 0;
-    if (!h->d_co_seeds) WMX_HIP_RC(hipMalloc(&h->d_co_seeds, sizeof(uint32_t) * (size_t)h->n_far));
-    std::vector<uint32_t> seeds((size_t)h->n_far);
-    for (int g = 0; g < h->n_far; g++) seeds[(size_t)g] = h->ctl[(size_t)g].seed;
-    WMX_HIP_RC(hipMemcpy(h->d_co_seeds, seeds.data(), sizeof(uint32_t) * seeds.size(), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(aec_seed_streams, dim3((unsigned)((h->n_streams + 255) / 256)), dim3(256), 0, s, h->d_state, h->d_stream_far, h->d_co_seeds,
-                       h->n_streams);
+    uint64_t need = (uint64_t)oldest + 4 * kAecMaxPktPerLaunch + 1;  // block counts the launch can reach (<= 4 blocks per packet)
+    if (need > (uint64_t)kAecNoisePeriodRows) need = kAecNoisePeriodRows;
+    if (need <= h->rows_valid) return 0;
+    uint64_t want = (need + 1023) / 1024 * 1024 + 1024;  // ahead of the need: one generator launch per few hundred heartbeats
+    if (want > (uint64_t)kAecNoisePeriodRows) want = kAecNoisePeriodRows;
+    if (want > h->rows_cap) {
+        uint64_t cap = h->rows_cap ? h->rows_cap : 4096;
+        while (cap < want) cap *= 2;
+        if (cap > (uint64_t)kAecNoisePeriodRows) cap = kAecNoisePeriodRows;
+        float *nr = nullptr;
+        WMX_HIP_RC(hipMalloc(&nr, (size_t)cap * 2 * kAecPart * sizeof(float)));
+        if (h->d_noise_rows) {
+            WMX_HIP_RC(hipMemcpyAsync(nr, h->d_noise_rows, (size_t)h->rows_valid * 2 * kAecPart * sizeof(float), hipMemcpyDeviceToDevice, s));
+            h->old_rows.push_back(h->d_noise_rows);
+        }
+        h->d_noise_rows = nr;
+        h->rows_cap = (uint32_t)cap;
+    }
+    const uint32_t n = (uint32_t)want - h->rows_valid;
+    hipLaunchKernelGGL(aec_noise_rows, dim3(n), dim3(64), 0, s, h->d_noise_rows, h->d_noise_tab, h->rows_valid, (int)n);
     const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "aec_seed_streams", __FILE__, __LINE__);
-    h->own_noise = true;
+    if (e != hipSuccess) return hip_fail(e, "aec_noise_rows", __FILE__, __LINE__);
+    h->rows_valid = (uint32_t)want;
     return 0;
 }
+
+// ---------------------------------------------------------------- coalescing
 // a cohort that is restarted, retired or overwritten is no candidate of a comparison in flight
 static void aec_co_drop(wmx_aec *h, int cohort) {
     for (int i = 0; i < h->co_n; i++)
@@ -1851,16 +1841,13 @@ int wmx_aec_coalesce(wmx_aec *h, int max_pairs, int32_t *merged_from, int32_t *m
         }
         h->co_n = 0;
         if (n_go > 0) {
-            {
-                const int rc = aec_enter_own_noise(h, s);
-                if (rc != 0) return rc;
-            }
             hipLaunchKernelGGL(aec_merge_streams, dim3((unsigned)((h->n_streams + 3) / 4)), dim3(256), 0, s, h->d_state, h->d_stream_far,
                                h->n_streams, go, n_go);
             WMX_LAUNCH_CHECK();
             std::vector<int32_t> to((size_t)h->n_far, -1);
             for (int i = 0; i < n_go; i++) {
                 to[(size_t)go.p[i].b] = go.p[i].a;
+                if (h->ctl[(size_t)go.p[i].b].blocks > h->ctl[(size_t)go.p[i].a].blocks) h->ctl[(size_t)go.p[i].a].blocks = h->ctl[(size_t)go.p[i].b].blocks;
                 h->live[(size_t)go.p[i].b] = 0;  // retired: its id may be handed out again (wmx_aec_add_cohort)
             }
             for (int32_t &c : h->h_cohort_of)
@@ -2001,13 +1988,6 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
         const bool on_a = !cohort_on || cohort_on[pc.a], on_b = !cohort_on || cohort_on[pc.b];
         if (on_a != on_b || (on_a && delay_ms[pc.a] != delay_ms[pc.b]) || ((mode & 1) && far_group_stride != 0)) pc.b = -1;
     }
-    {
-        const int need = n_packets < kAecMaxPktPerLaunch ? n_packets : kAecMaxPktPerLaunch;
-        if (need > h->noise_pkts) {
-            const int rc = aec_reserve(h, h->cap_far, need);
-            if (rc != 0) return rc;
-        }
-    }
     for (int done = 0; done < n_packets && running > 0;) {
         int chunk = n_packets - done;
         if (chunk > kAecMaxPktPerLaunch) chunk = kAecMaxPktPerLaunch;
@@ -2050,6 +2030,14 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
         }
         h->ctl_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_ctl).count();
         h->ctl_calls++;
+        if (any && (mode & 2)) {
+            // the comfort-noise rows of every block this launch can reach: one past the oldest live cohort's block count
+            uint32_t oldest = 0;
+            for (int g = 0; g < G; g++)
+                if (h->live[(size_t)g] && h->ctl[(size_t)g].blocks > oldest) oldest = h->ctl[(size_t)g].blocks;
+            const int rc = aec_noise_reserve(h, oldest, s);
+            if (rc != 0) return rc;
+        }
         if (any) {
             const int by_value = (chunk == 1 && G == 1) ? 1 : 0;
             // the far kernel (and the plans it reads) on the side stream when the caller forked it (first chunk of the call only)
@@ -2072,7 +2060,7 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
             }
             hipLaunchKernelGGL(aec_far_kernel, dim3((unsigned)G), dim3(64), 0, fs, h->far, h->d_consts, dp, chunk, G,
                                d_far ? d_far + (size_t)done * far_packet_stride : nullptr, far_packet_stride, far_group_stride, h->chn, gpow1np,
-                               h->d_noise_tab, h->own_noise ? nullptr : h->d_noise, by_value, hp[0]);
+                               by_value, hp[0]);
             WMX_LAUNCH_CHECK();
             if (tv) WMX_HIP(hipEventRecord(tv[1], fs));
             if (forked) {
@@ -2092,22 +2080,12 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
                 const int32_t *order = ordered ? h->d_order : nullptr;
                 const unsigned grid = ordered ? h->order_wgs : (unsigned)((h->n_streams + kAecWavesPerBlock - 1) / kAecWavesPerBlock);
                 const dim3 blk(64 * kAecWavesPerBlock);
-#define AEC_NEAR_LAUNCH(M, OWN)                                                                                                               \
-    hipLaunchKernelGGL((aec_near_kernel<M, OWN>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, chunk, G, h->d_noise,       \
-                       h->d_noise_tab, nin, nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg, h->d_stream_far, h->life.d_active, \
-                       order)
-                if (h->freq == 8000) {
-                    if (h->own_noise)
-                        AEC_NEAR_LAUNCH(1, true);
-                    else
-                        AEC_NEAR_LAUNCH(1, false);
-                } else {
-                    if (h->own_noise)
-                        AEC_NEAR_LAUNCH(2, true);
-                    else
-                        AEC_NEAR_LAUNCH(2, false);
-                }
-#undef AEC_NEAR_LAUNCH
+                if (h->freq == 8000)
+                    hipLaunchKernelGGL((aec_near_kernel<1>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, chunk, G, h->d_noise_rows, nin,
+                                       nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg, h->d_stream_far, h->life.d_active, order);
+                else
+                    hipLaunchKernelGGL((aec_near_kernel<2>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, chunk, G, h->d_noise_rows, nin,
+                                       nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg, h->d_stream_far, h->life.d_active, order);
                 WMX_LAUNCH_CHECK();
                 if (tv) WMX_HIP(hipEventRecord(tv[3], s));
             }
@@ -2181,8 +2159,6 @@ int wmx_aec_export_stream(wmx_aec *h, int stream_index, void *host_blob) {
     char *p = static_cast<char *>(host_blob);
     blob_begin(p, blob_tag("AEC "), (uint32_t)h->freq, AS_WORDS * 4);
     WMX_HIP(hipMemcpy(p + sizeof(BlobHeader), h->d_state + (size_t)stream_index * AS_WORDS, AS_WORDS * 4, hipMemcpyDeviceToHost));
-    // the blob always carries the stream's comfort-noise generator: while the cohorts are pure it is the cohort's
-    if (!h->own_noise) memcpy(p + sizeof(BlobHeader) + 4 * AS_SEED, &h->ctl[(size_t)h->h_cohort_of[(size_t)stream_index]].seed, 4);
     return 0;
 }
 
@@ -2193,17 +2169,12 @@ int wmx_aec_import_stream(wmx_aec *h, int stream_index, const void *host_blob, i
     const int rc = blob_check(host_blob, blob_tag("AEC "), (uint32_t)h->freq, AS_WORDS * 4);
     if (rc) return rc;
     WMX_HIP(hipDeviceSynchronize());
-    if (!h->own_noise) {
-        // a stream whose generator is not where its new cohort's is (it comes out of a merged cohort, or its cohort's control plane
-        // has not been imported yet): the handle's streams keep their own from here on
-        uint32_t seed;
-        memcpy(&seed, static_cast<const char *>(host_blob) + sizeof(BlobHeader) + 4 * AS_SEED, 4);
-        const int c = cohort >= 0 ? cohort : h->h_cohort_of[(size_t)stream_index];
-        if (seed != h->ctl[(size_t)c].seed) {
-            const int rc2 = aec_enter_own_noise(h, nullptr);
-            if (rc2 != 0) return rc2;
-            WMX_HIP(hipDeviceSynchronize());
-        }
+    {
+        // the stream brings its block count (its comfort-noise generator's state): its new cohort is at least that old
+        uint32_t nblk;
+        memcpy(&nblk, static_cast<const char *>(host_blob) + sizeof(BlobHeader) + 4 * AS_NBLK, 4);
+        AecCtl &c = h->ctl[(size_t)(cohort >= 0 ? cohort : h->h_cohort_of[(size_t)stream_index])];
+        if (nblk > c.blocks) c.blocks = nblk;
     }
     WMX_HIP(hipMemcpy(h->d_state + (size_t)stream_index * AS_WORDS, static_cast<const char *>(host_blob) + sizeof(BlobHeader), AS_WORDS * 4,
                       hipMemcpyHostToDevice));

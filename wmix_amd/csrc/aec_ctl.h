@@ -31,10 +31,7 @@ struct AecBlkPlan {
     int hist_n;    // sequence number of the consumed far block (history slot = hist_n % kAecHist)
     int far_slot;  // far ring slot consumed (plain and windowed rings move together)
     int flags;
-    uint32_t seed;  // state of the comfort-noise generator in front of this block's 64 draws (WebRtcSpl_RandUArray,
-                    // randomization_functions.c:94-112: seed = (seed * 69069 + 1) & 0x7FFFFFFF per draw); the far kernel expands
-                    // it into the block's 64 (cos, sin) pairs through AecNoiseTable -- 32 bytes per block cross PCIe, not 544
-    int pad[2];
+    int pad[3];
 };
 static_assert(sizeof(AecBlkPlan) == 32, "AecBlkPlan layout");
 
@@ -53,6 +50,35 @@ inline void aec_noise_table(AecNoiseEntry *t) {
         t[i].c = cosf(tmp);
         t[i].s = sinf(tmp);
     }
+}
+// AecNoiseRows.  Every handle's generator starts from the same state (aec->seed = 777, aec_core.c:1670) and ComfortNoise draws 64
+// numbers per block, unconditionally (aec_core.c:476-480): the phases of a handle's r-th block are the same for every handle that
+// ever lives.  They are kept as a table -- row r = 64 cosines | 64 sines -- that the near kernel indexes with the STREAM's block
+// count, so streams of different ages can share a control cohort.  The generator's period is 2^31 draws: 2^25 rows, then the table
+// repeats.  (4 bytes of state per stream instead of a cohort-wide seed; 512 bytes of table per block of the oldest stream's life.)
+constexpr int kAecNoisePeriodRows = 1 << 25;
+#ifdef __HIPCC__
+#define WMX_HD __host__ __device__
+#else
+#define WMX_HD
+#endif
+// t[k] = (a, c) of 2^k draws in one step, k = 0 .. 30 (t[31] unused)
+inline void aec_lcg_pow2(uint32_t (*t)[2]) {
+    uint32_t a = 69069u, c = 1u;
+    for (int k = 0; k < 32; k++) {
+        t[k][0] = a;
+        t[k][1] = c;
+        c = a * c + c;  // x -> a (a x + c) + c
+        a = a * a;
+    }
+}
+// the generator's state in front of row r (r < 2^25): 777 advanced by 64 r draws
+WMX_HD inline uint32_t aec_row_seed(uint32_t r, const uint32_t (*pow2)[2]) {
+    uint32_t x = 777u;
+    const uint32_t k = r << 6;
+    for (int j = 6; j < 31; j++)
+        if ((k >> j) & 1u) x = x * pow2[j][0] + pow2[j][1];
+    return x & 0x7FFFFFFFu;
 }
 // k draws in one step: seed_k = (seed * a_k + c_k) mod 2^31 with a_k = 69069^k, c_k = 1 + 69069 + ... + 69069^(k-1)
 // (arithmetic mod 2^32, masked: the low 31 bits of a product depend on the low 31 bits of its factors only)
@@ -140,7 +166,8 @@ struct AecCtl {
     RingIdx near_fr, out_fr, far_buf, far_pre;
     int system_delay = 0, core_known_delay = 0;
     int noise_ctr = 0, delay_est_ctr = 0;
-    uint32_t seed = 777;
+    uint32_t blocks = 0;  // blocks planned since init -- after a merge (wmx_aec_coalesce) or an import, of the OLDEST member: the comfort-
+                          // noise table must reach that far (AecNoiseRows)
     int hist_n = 0;
     // Aec wrapper (echo_cancellation_internal.h:17-65)
     int bufSizeStart = 0, knownDelay = 0, sum = 0, timeForDelayChange = 0, startup_phase = 1, checkBuffSize = 1;
@@ -228,14 +255,7 @@ struct AecCtl {
         delay_est_ctr++;
         if (delay_est_ctr == 10 * mult) delay_est_ctr = 0;
         if (delay_est_ctr == 0) b.flags |= kAecFlagDelayEst;
-        // ComfortNoise draws 64 uniform numbers per block (aec_core.c:476-489, WebRtcSpl_RandUArray): the block gets the
-        // generator's state, the control plane jumps over the 64 draws
-        b.seed = seed;
-        static const struct Jump64 {
-            uint32_t a, c;
-            Jump64() { aec_lcg_jump(kAecPart, &a, &c); }
-        } J;
-        seed = (seed * J.a + J.c) & 0x7FFFFFFFu;
+        blocks++;  // (the stream's own count, AS_NBLK in aec.hip, selects the block's comfort-noise row)
         out_fr.write(kAecPart, &b.out_wr);
     }
 
