@@ -226,8 +226,8 @@ int wmx_aec_reset_cohort(wmx_aec *h, int cohort, void *stream);
  * aec_init of the shared part at this point of the packet sequence; a retired id when there is one, else the next, with the
  * device buffers growing by doubling -- and returns its id in *cohort; wmx_aec_retire_cohort says that every member was
  * released: the cohort is never called again and its id may be handed out again.  wmx_aec_cohorts(h) = ids in use, retired
- * ones included = the length of the per-cohort arrays.  Per launch only packets x cohorts plans of 224 bytes cross PCIe (a
- * block's 64 comfort-noise phases travel as the generator's 4-byte state; the far kernel expands them). */
+ * ones included = the length of the per-cohort arrays.  Per launch only packets x cohorts plans of 224 bytes cross PCIe (the
+ * comfort noise's phases are not in them: they lie in a device table indexed by the stream's own block count). */
 int wmx_aec_add_cohort(wmx_aec *h, int *cohort, void *stream);
 int wmx_aec_retire_cohort(wmx_aec *h, int cohort);
 /* Coalescing.  Handles of the reference that were created at different times but are called with the same delay end up with
@@ -236,8 +236,8 @@ int wmx_aec_retire_cohort(wmx_aec *h, int cohort);
  * call merges such cohorts: (1) it completes the merges whose check -- launched by an earlier call -- came back equal: the far-end
  * slabs of the two cohorts were compared on the device, word for word under the rotation between their ring positions (that
  * includes the running far power, an IIR from each handle's own start); the members of `from` then get their re-blocking rings
- * rotated to the positions of `into`, its id, and `from` is retired; every stream keeps the state of the comfort-noise generator
- * it would have as its own handle (the near kernel draws per stream from the first merge on).  The pairs are reported in
+ * rotated to the positions of `into`, its id, and `from` is retired; every stream keeps the comfort-noise generator it would have
+ * as its own handle (its state is the stream's block count, part of the stream's state).  The pairs are reported in
  * merged_from[] / merged_into[] (*n_merged of them, at most cap) so that the caller can redirect its own tables; the id range
  * wmx_aec_cohorts(h) shrinks behind the last live cohort.  (2) it proposes up to max_pairs (<= 32) new pairs -- equal fill
  * levels, delays and counters, start-up over, lowest id leads -- and launches their comparison behind the work already in

@@ -91,3 +91,23 @@ def test_chain_at_the_daemons_interval_against_real_reference(oracle_port, oracl
     # and the cadence matters: 10 ms handles fed the same audio give another result (the VAD packet differs)
     c = L.run_chain(oracle_port, chn, freq, 5, 15, far, near, per_call, prefix="orc", interval_ms=10)
     assert not np.array_equal(b, c)
+
+
+@pytest.mark.parametrize("freq,ims", [(16000, 10), (8000, 20)])
+def test_reported_delay_that_changes_from_call_to_call_against_real_reference(oracle_port, oracle_ref, freq, ims):
+    """aec_process2's delayms is a per-call argument (src/webrtc.c:410-483): EstBufDelay filters it, knownDelay follows with its
+    hysteresis and the far-end read pointer moves (W: echo_cancellation.c:821-872, aec_core.c:1753-1760).  A wandering delay, steps
+    across the hysteresis, and the clamp at 0: the port against the rebuilt reference, call by call."""
+    pkg = aec_pkg(freq, ims)
+    n = 1800
+    far, near = aec_input(1, freq, ims, n, seed=5300 + freq // 8000)
+    t = np.arange(n)
+    delays = (20 + 15 * np.sin(t / 37.0) + (t % 7)).astype(np.int32)
+    delays[600:900] = 260   # a step far beyond the 224-sample threshold ...
+    delays[900:1200] = 0    # ... and back below 96
+    delays[1500:] = 480
+    a = L.run_aec_delays(oracle_ref, 1, freq, ims, far, near, pkg, delays)
+    b = L.run_aec_delays(oracle_port, 1, freq, ims, far, near, pkg, delays, prefix="orc")
+    assert np.array_equal(a, b)
+    c = L.run_aec(oracle_port, 1, freq, ims, far, near, pkg, 20, prefix="orc")
+    assert not np.array_equal(b, c)
