@@ -176,3 +176,18 @@ def test_churn_soak(extra):
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["lives_checked"] >= 20 and d["max_lsb"] <= (0 if "--fx" in extra else 1) and d["max_cohort_ids"] >= 10
+
+
+def test_churn_soak_with_coalescing():
+    """The same soak with wmx_chain_coalesce behind every tick, long enough for cohorts to get past their noise-floor start-up: joins,
+    leaves, retired ids and folds interleave; the soak's own cohort table follows the (from, into) pairs the call returns."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools_dev", "churn_soak.py"), "--streams", "2048", "--ticks", "2600", "--seed", "9", "--coalesce"],
+                       cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["lives_checked"] >= 20 and d["max_lsb"] <= 1 and d["folds"] >= 10, d
