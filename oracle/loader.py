@@ -159,6 +159,31 @@ def run_aec(lib, chn, freq, interval_ms, far, near, frames_per_call, delay_ms=0,
     return out
 
 
+def run_aec_seeded(lib, chn, freq, interval_ms, far, near, frames_per_call, delay_ms, seed):
+    """orc_run_aec for a handle whose comfort-noise generator stands at `seed` (port only)."""
+    far = np.ascontiguousarray(far, dtype=np.int16)
+    near = np.ascontiguousarray(near, dtype=np.int16)
+    out = np.empty_like(near)
+    n_calls = near.size // (frames_per_call * chn)
+    fn = _fn(lib, "orc_run_aec_seeded", C.c_int, [C.c_int, C.c_int, C.c_int, _i16p, _i16p, _i16p, C.c_int, C.c_int, C.c_int, C.c_uint32])
+    rc = fn(chn, freq, interval_ms, far, near, out, frames_per_call, n_calls, delay_ms, int(seed))
+    assert rc == 0, rc
+    return out
+
+
+def lcg_after_blocks(n_blocks):
+    """The AEC's comfort-noise generator (seed 777, x -> 69069 x + 1 mod 2^31, 64 draws per block) after n_blocks blocks."""
+    a, c, k, x = 69069, 1, 64 * int(n_blocks), 777
+    m = (1 << 32) - 1
+    while k:
+        if k & 1:
+            x = (a * x + c) & m
+        c = (a * c + c) & m
+        a = (a * a) & m
+        k >>= 1
+    return x & 0x7FFFFFFF
+
+
 def run_aec_delays(lib, chn, freq, interval_ms, far, near, frames_per_call, delays, prefix="ref"):
     """aec_process2 per call with the reported delay of that call (delays: one per call)."""
     far = np.ascontiguousarray(far, dtype=np.int16)

@@ -662,6 +662,23 @@ int orc_run_aec(int chn, int freq, int interval_ms, const int16_t *far, const in
     return rc;
 }
 
+/* the same for a handle whose comfort-noise generator stands at `seed` when the run starts (aec->seed, aec_core.c:1670, is 777 for a
+ * new handle and moves by 64 draws per block): what a handle that has already lived for many blocks draws from here on.  Test
+ * infrastructure for the kernels' noise table far from its start; nothing else of the handle's state is aged. */
+int orc_run_aec_seeded(int chn, int freq, int interval_ms, const int16_t *far, const int16_t *nearp, int16_t *out, int frames_per_call,
+                       int n_calls, int delay_ms, uint32_t seed)
+{
+    orc_aec *a = orc_aec_init(chn, freq, interval_ms);
+    if (!a) return -100;
+    a->seed = seed & 0x7FFFFFFFu;
+    size_t step = (size_t)frames_per_call * chn;
+    int rc = 0;
+    for (int i = 0; i < n_calls && rc == 0; i++)
+        rc = orc_aec_process2(a, far + i * step, nearp + i * step, out + i * step, frames_per_call, delay_ms);
+    orc_aec_release(a);
+    return rc;
+}
+
 /* the same with the delay the caller reports changing from call to call (aec_process2's delayms, src/webrtc.c:410-483) */
 int orc_run_aec_delays(int chn, int freq, int interval_ms, const int16_t *far, const int16_t *nearp, int16_t *out, int frames_per_call,
                        int n_calls, const int32_t *delay_ms)

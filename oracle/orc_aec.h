@@ -45,6 +45,8 @@ void orc_aec_release(orc_aec *a);
 void orc_aec_probe(const orc_aec *a, int32_t *ints8, float *floats7);
 int orc_run_aec(int chn, int freq, int interval_ms, const int16_t *far, const int16_t *nearp, int16_t *out, int frames_per_call,
                 int n_calls, int delay_ms);
+int orc_run_aec_seeded(int chn, int freq, int interval_ms, const int16_t *far, const int16_t *nearp, int16_t *out, int frames_per_call,
+                       int n_calls, int delay_ms, uint32_t seed);
 int orc_run_aec_delays(int chn, int freq, int interval_ms, const int16_t *far, const int16_t *nearp, int16_t *out, int frames_per_call,
                        int n_calls, const int32_t *delay_ms);
 #endif

@@ -182,3 +182,36 @@ def test_a_stream_of_a_folded_cohort_migrates_with_its_own_generator(cuda, oracl
         for s in (2 * k, 2 * k + 1):
             want = L.run_aec(oracle_port, 1, freq, 10, far[t0:].reshape(-1), near[s, t0:].reshape(-1), pkt, 0, prefix="orc")
             check_float_path(out[s, t0:].reshape(-1), want, max_fraction=1e-4)
+
+
+def test_a_stream_that_has_lived_for_hours_draws_from_far_out_in_the_noise_table(cuda, oracle_port):
+    """The comfort noise follows the stream's block count (AS_NBLK): a state imported with a count of 3.1 million blocks (3.4 hours at
+    16 kHz) makes the batch grow its table to that row, and the stream draws what a handle of the reference draws whose generator
+    stands there (oracle: the same run with aec->seed set to 777 advanced by 64 draws per block)."""
+    from wmix_amd._lib import lib
+    S, T, freq, pkt, R = 4, 300, 16000, 160, 3_100_003
+    far = synth.far_end(8400, T, pkt).reshape(T, pkt)
+    near = synth.near_end(8401, S, T, pkt, far=far.reshape(-1)).reshape(S, T, pkt)
+    d = torch.from_numpy(near.copy()).to(cuda)
+    dfar = torch.from_numpy(far.copy()).to(cuda)
+    ab = AecBatch(S, 1, freq, 10)
+    words = lib().wmx_aec_state_words(ab._h)
+    blob = ab.export_stream(2)
+    hdr = blob.size - 4 * words
+    w = blob[hdr:].view(np.uint32)
+    assert w[words - 5] == 0  # AS_NBLK = AS_SCAL + 11 of 16 scalar words at the end of the block: a new handle has processed nothing
+    w[words - 5] = R
+    ab.import_stream(2, blob)
+    rc, _ = ab.process2(dfar, d, delay_ms=0)
+    assert rc == 0
+    out = d.cpu().numpy()
+    ab.close()
+    for s in range(S):
+        if s == 2:
+            want = L.run_aec_seeded(oracle_port, 1, freq, 10, far.reshape(-1), near[s].reshape(-1), pkt, 0, L.lcg_after_blocks(R))
+        else:
+            want = L.run_aec(oracle_port, 1, freq, 10, far.reshape(-1), near[s].reshape(-1), pkt, 0, prefix="orc")
+        check_float_path(out[s].reshape(-1), want, max_fraction=1e-4)
+    # and the generator's position is audible in the output: the same stream as a NEW handle gives other samples
+    fresh = L.run_aec(oracle_port, 1, freq, 10, far.reshape(-1), near[2].reshape(-1), pkt, 0, prefix="orc")
+    assert int((fresh.astype(np.int32) != out[2].reshape(-1)).sum()) > 100

@@ -1761,7 +1761,7 @@ int wmx_aec_retire_cohort(wmx_aec *h, int cohort) {
 // ---------------------------------------------------------------- the comfort-noise rows
 // Rows 0 .. `oldest` + a launch's worth are made before the near kernel can read them (in `s`, in front of it).  The table grows
 // by doubling up to the generator's period (2^25 rows = 16 GiB after 37 hours of one handle at 16 kHz; a batch of short-lived
-// handles never gets there); an outgrown table stays allocated until the handle goes, launches in flight may be reading it.
+// handles never gets there); an outgrown table stays allocated until the next doubling, launches in flight may be reading it.
 static int aec_noise_reserve(wmx_aec *h, uint32_t oldest, hipStream_t s) {
     using namespace wmx;
     uint64_t need = (uint64_t)oldest + 4 * kAecMaxPktPerLaunch + 1;  // block counts the launch can reach (<= 4 blocks per packet)
@@ -1777,6 +1777,9 @@ static int aec_noise_reserve(wmx_aec *h, uint32_t oldest, hipStream_t s) {
         WMX_HIP_RC(hipMalloc(&nr, (size_t)cap * 2 * kAecPart * sizeof(float)));
         if (h->d_noise_rows) {
             WMX_HIP_RC(hipMemcpyAsync(nr, h->d_noise_rows, (size_t)h->rows_valid * 2 * kAecPart * sizeof(float), hipMemcpyDeviceToDevice, s));
+            // the table outgrown LAST time has had a whole doubling's worth of heartbeats to be done with (hipFree waits anyway)
+            for (float *p : h->old_rows) (void)hipFree(p);
+            h->old_rows.clear();
             h->old_rows.push_back(h->d_noise_rows);
         }
         h->d_noise_rows = nr;
