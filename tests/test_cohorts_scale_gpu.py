@@ -35,7 +35,10 @@ def _schedule(seed, S, T, n_join_ticks, n_leavers, t_leave, n_rejoin_ticks):
     return join, leaving, early, rejoin
 
 
-def test_65536_streams_joining_at_more_than_1000_random_ticks(cuda, oracle_port):
+@pytest.mark.parametrize("coalesce", [False, True])
+def test_65536_streams_joining_at_more_than_1000_random_ticks(cuda, oracle_port, coalesce):
+    """coalesce: wmx_chain_coalesce behind every tick as well -- cohorts fold into one another while others are still being created,
+    retired and their ids reused; the host's table (which join ticks live under which cohort id) follows the pairs the call returns."""
     S, T, K, U, freq = 65536, 1500, 200, 64, 16000
     pkt = freq // 100
     join, leaving, early, rejoin = _schedule(4242, S, T, n_join_ticks=1050, n_leavers=40, t_leave=500, n_rejoin_ticks=30)
@@ -58,6 +61,7 @@ def test_65536_streams_joining_at_more_than_1000_random_ticks(cuda, oracle_port)
     cb = ChainBatch(S, 1, freq, 10, 5, n_cohorts=1)
     active = np.zeros(S, np.uint8)
     cohort_of_tick, reused, max_cohorts = {}, 0, 0
+    ticks_of_id, folds, live_end = {}, 0, None  # cohort id -> the join ticks whose handles it stands for
     events = sorted(set(join.tolist()) | {int(t) for t in np.unique(rejoin[rejoin >= 0])} | {500})
     by_tick = {t: np.flatnonzero(join == t).astype(np.int32) for t in np.unique(join)}
     re_by_tick = {int(t): np.flatnonzero(rejoin == t).astype(np.int32) for t in np.unique(rejoin[rejoin >= 0])}
@@ -67,8 +71,12 @@ def test_65536_streams_joining_at_more_than_1000_random_ticks(cuda, oracle_port)
             if t == 500:  # the early cohorts' handles are released: members idle, cohorts retired
                 active[leaving] = 0
                 for te in early:
-                    cb.retire_cohort(cohort_of_tick[int(te)])
-                    retired.append(cohort_of_tick[int(te)])
+                    c = cohort_of_tick[int(te)]
+                    ticks_of_id[c].discard(int(te))
+                    if not ticks_of_id[c]:  # (a cohort that other join ticks have folded into lives on)
+                        del ticks_of_id[c]
+                        cb.retire_cohort(c)
+                        retired.append(c)
             for members in (by_tick.get(t), re_by_tick.get(t)):
                 if members is None or members.size == 0:
                     continue
@@ -79,6 +87,7 @@ def test_65536_streams_joining_at_more_than_1000_random_ticks(cuda, oracle_port)
                     c = cb.add_cohort()
                 if members is by_tick.get(t):
                     cohort_of_tick[t] = c
+                ticks_of_id.setdefault(c, set()).add(t if members is by_tick.get(t) else -t)
                 reused += c in retired
                 cb.reset_streams(members, cohort=c)
                 active[members] = 1
@@ -87,11 +96,21 @@ def test_65536_streams_joining_at_more_than_1000_random_ticks(cuda, oracle_port)
         rc, codes, _ = cb.process_packet_major(dfar[t % K:t % K + 1], inp[t % K:t % K + 1], out=work)
         assert rc == 0 and not codes.any()
         rec[t] = work[0, dpick]
+        if coalesce:
+            for fr, to in cb.coalesce(32):
+                ticks_of_id[to] |= ticks_of_id.pop(fr)
+                for tt, c in cohort_of_tick.items():
+                    if c == fr:
+                        cohort_of_tick[tt] = to
+                folds += 1
     n_host, sec = cb.aec_host_ctl()
+    live_end = cb.live_cohorts()
     cb.close()
+    if coalesce:  # most of the 1 050 + 30 control planes have folded by the end (the last joiners are still in their start-up)
+        assert folds >= 600 and live_end <= 480, (folds, live_end)
     got = rec.cpu().numpy()
     # retired ids came back: the batch never held more cohorts than join ticks, and re-joins reused ids
-    assert reused >= len(retired) and max_cohorts <= 1050, (reused, max_cohorts)
+    assert (coalesce or reused >= len(retired)) and max_cohorts <= 1050, (reused, max_cohorts)
     assert n_host == T and sec / T < 2e-3, "host control planes: %.1f us per tick" % (sec / T * 1e6)
 
     far_seq = np.concatenate([far[t % K] for t in range(T)])
