@@ -652,7 +652,10 @@ class ChainWorkload:
 
     def min_prime(self):
         """untimed steps needed before every stream has joined and is past the start-up phases"""
-        settle = (1000 * 64 // (self.pkt * self.P) + 120 + self.n_cohorts // 8) if self.coalesce else 0
+        # blocks until a young cohort can fold: the float AEC's noise-floor start-up (1 000 blocks); the AECM's binary far spectrum
+        # thresholds meeting the older cohort's bit for bit (~1 500 blocks)
+        blocks = 1800 if getattr(self, "extra_stages", 0) & 32 else 1000
+        settle = (blocks * 64 // (self.pkt * self.P) + 120 + self.n_cohorts // 8) if self.coalesce else 0
         return self.n_cohorts - 1 + settle
 
     def _join(self, j):

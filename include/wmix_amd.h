@@ -302,7 +302,7 @@ int wmx_chain_reset_cohort(wmx_chain *h, int cohort, void *stream);
 /* wmx_aec_add_cohort / wmx_aec_retire_cohort / wmx_aec_cohorts of the chain's AEC (a chain without one has a single cohort) */
 int wmx_chain_add_cohort(wmx_chain *h, int *cohort, void *stream);
 int wmx_chain_retire_cohort(wmx_chain *h, int cohort);
-/* wmx_aec_coalesce of the chain's float AEC (a chain with the fixed-point AECM, or without an AEC stage, merges nothing) */
+/* wmx_aec_coalesce / wmx_aecm_coalesce of the chain's echo canceller (a chain without one merges nothing) */
 int wmx_chain_coalesce(wmx_chain *h, int max_pairs, int32_t *merged_from, int32_t *merged_into, int cap, int *n_merged, void *stream);
 int wmx_chain_cohorts(const wmx_chain *h);
 int wmx_chain_set_active(wmx_chain *h, const uint8_t *host_mask, void *stream);
@@ -337,6 +337,19 @@ int wmx_aecm_cohorts(const wmx_aecm *h);
 int wmx_aecm_reset_cohort(wmx_aecm *h, int cohort, void *stream);
 int wmx_aecm_add_cohort(wmx_aecm *h, int *cohort, void *stream); /* as wmx_aec_add_cohort / wmx_aec_retire_cohort */
 int wmx_aecm_retire_cohort(wmx_aecm *h, int cohort);
+/* as wmx_aec_coalesce / wmx_aec_live_cohorts: cohorts whose control planes have converged (the AECM's has no periodic counters: one
+ * cohort per reported delay and phase of the 80-in-64 re-blocking remains) are merged after their far-end slabs -- far ring, frame
+ * ring, the 256-block history of far spectra, Q-domains and binary spectra, the binary spectrum's running thresholds -- compared
+ * equal on the device; the members' near and out frame rings are rotated; the comfort-noise generator was per stream already */
+int wmx_aecm_coalesce(wmx_aecm *h, int max_pairs, int32_t *merged_from, int32_t *merged_into, int cap, int *n_merged, void *stream);
+int wmx_aecm_live_cohorts(const wmx_aecm *h);
+/* Why two cohorts do (not) fold: the words of the control plane that decide its future, positions taken out -- cohorts are proposed
+ * for a merge when these are equal.  AEC (13): fill levels of the near / out / far-spectrum / far-sample rings, system delay, known
+ * delay of the core, noise-floor counter, delay-estimate counter, knownDelay, timeForDelayChange, msInSndCardBuf, filtDelay,
+ * lastDelayDiff.  AECM (8): fill levels of the far / frame / out rings, knownDelay, timeForDelayChange, msInSndCardBuf, filtDelay,
+ * lastDelayDiff.  Returns 0, 1 (the cohort is retired or still in its start-up phase: no key), or WMX_E*. */
+int wmx_aec_cohort_key(const wmx_aec *h, int cohort, int32_t *key13);
+int wmx_aecm_cohort_key(const wmx_aecm *h, int cohort, int32_t *key8);
 int wmx_aecm_reset_streams(wmx_aecm *h, const int32_t *idx, int n, int cohort, void *stream);
 int wmx_aecm_set_active(wmx_aecm *h, const uint8_t *host_mask, void *stream);
 int wmx_aecm_stream_state_bytes(const wmx_aecm *h);

@@ -215,3 +215,50 @@ def test_a_stream_that_has_lived_for_hours_draws_from_far_out_in_the_noise_table
     # and the generator's position is audible in the output: the same stream as a NEW handle gives other samples
     fresh = L.run_aec(oracle_port, 1, freq, 10, far.reshape(-1), near[2].reshape(-1), pkt, 0, prefix="orc")
     assert int((fresh.astype(np.int32) != out[2].reshape(-1)).sum()) > 100
+
+
+@pytest.mark.parametrize("freq,S,T", [(16000, 2048, 1200), (8000, 1024, 2200)])
+def test_aecm_cohorts_fold_too_bit_exact(cuda, oracle_port, freq, S, T):
+    """wmx_aecm_coalesce: the fixed-point canceller's control plane has no periodic counters, so cohorts fold as soon as the younger
+    one's far-end slab equals the older one's -- the 256-block history is the quick part, the binary far spectrum's running thresholds
+    (integer IIRs with a shift of 6) take some 1 400 blocks to meet bit for bit: one cohort per phase of the 80-in-64 re-blocking
+    remains (two at 16 kHz, four at 8 kHz).  Integer arithmetic: every sampled stream equals its own handle of the reference bit for bit."""
+    from wmix_amd.aecm import AecmBatch
+    pkt = freq // 100
+    far = synth.far_end(8500 + freq // 1000, T, pkt).reshape(T, pkt)
+    U = 32
+    base = synth.near_end(8501, U, T, pkt, far=far.reshape(-1)).reshape(U, T, pkt)
+    d = torch.from_numpy(np.ascontiguousarray(base.transpose(1, 0, 2))).to(cuda)[:, torch.arange(S, device=cuda) % U].contiguous()  # [T, S, pkt]
+    dfar = torch.from_numpy(far.copy()).to(cuda)
+    rng = np.random.default_rng(6)
+    n_ticks = 60
+    ticks = np.concatenate([[0], np.sort(rng.choice(np.arange(1, 250), n_ticks - 1, replace=False))])
+    join = ticks[rng.integers(0, n_ticks, S)]
+    for i, t in enumerate(ticks):
+        join[i] = t
+    by_tick = {int(t): np.flatnonzero(join == t).astype(np.int32) for t in ticks}
+    pick = sorted({0, int(np.argmax(join))} | {int(x) for x in rng.choice(S, 14, replace=False)})
+    ab = AecmBatch(S, 1, freq, 10, n_cohorts=1)
+    active = np.zeros(S, np.uint8)
+    folds, peak = 0, 0
+    for t in range(T):
+        if t in by_tick:
+            c = 0 if t == 0 else ab.add_cohort()
+            if t == 0:
+                ab.reset_cohort(0)
+            ab.reset_streams(by_tick[t], cohort=c)
+            active[by_tick[t]] = 1
+            ab.set_active(active)
+        peak = max(peak, ab.live_cohorts())
+        rc, codes = ab.run_cohorts(dfar[t:t + 1], d[t:t + 1].transpose(0, 1), np.zeros(ab.n_cohorts, np.int32))
+        assert rc == 0 and not codes.any()
+        folds += len(ab.coalesce(32))
+    live, ids = ab.live_cohorts(), ab.n_cohorts
+    ab.close()
+    classes = 2 if freq == 16000 else 4
+    assert peak >= 20 and live <= classes and ids <= 16 and folds >= n_ticks - classes, (peak, live, ids, folds)
+    out = d.cpu().numpy()
+    for s in pick:
+        a = int(join[s])
+        want = L.run_aecm(oracle_port, 1, freq, 10, far[a:].reshape(-1), base[s % U, a:].reshape(-1), pkt, 0, prefix="orc")
+        assert np.array_equal(out[a:, s].reshape(-1), want), s

@@ -186,7 +186,13 @@ def _declare(L):
     if hasattr(L, "wmx_aec_coalesce"):  # (a WMIX_AMD_LIB variant built from an older tree, for A/B runs, may not have them)
         L.wmx_aec_live_cohorts.restype = i
         L.wmx_aec_live_cohorts.argtypes = [vp]
-        for name in ("wmx_aec_coalesce", "wmx_chain_coalesce"):
+        L.wmx_aecm_live_cohorts.restype = i
+        L.wmx_aecm_live_cohorts.argtypes = [vp]
+        for name in ("wmx_aec_cohort_key", "wmx_aecm_cohort_key"):
+            f = getattr(L, name)
+            f.restype = i
+            f.argtypes = [vp, i, vp]
+        for name in ("wmx_aec_coalesce", "wmx_aecm_coalesce", "wmx_chain_coalesce"):
             f = getattr(L, name)
             f.restype = i
             f.argtypes = [vp, i, vp, vp, i, C.POINTER(i), vp]

@@ -2219,6 +2219,13 @@ int wmx_aec_import_cohort(wmx_aec *h, int cohort, const void *host_blob) {
 }
 
 int wmx_aec_cohorts(const wmx_aec *h) { return h ? h->n_far : WMX_EINVAL; }
+int wmx_aec_cohort_key(const wmx_aec *h, int cohort, int32_t *key13) {
+    if (!h || !key13 || cohort < 0 || cohort >= h->n_far) return WMX_EINVAL;
+    wmx::AecCoKey k;
+    if (!h->live[(size_t)cohort] || !wmx::aec_co_key(h->ctl[(size_t)cohort], &k)) return 1;  // retired, or still in its start-up
+    for (int i = 0; i < 13; i++) key13[i] = k.v[i];
+    return 0;
+}
 int wmx_aec_live_cohorts(const wmx_aec *h) {
     if (!h) return WMX_EINVAL;
     int n = 0;

@@ -21,6 +21,7 @@
 // One reference quirk is pinned to its well-defined reading: at 8 kHz with 20 ms packets the second 10 ms frame of a
 // packet replays farendOld[1], which WebRtcAecm_Init leaves uninitialised (it clears 160 bytes, not 160 samples,
 // echo_control_mobile.c:211); here it starts as zeros, what a fresh heap gives (tests/golden/make_aecm_golden.py).
+#include <unordered_map>
 #include <vector>
 #include "wmx_internal.h"
 #include "spl_fx.h"
@@ -893,6 +894,70 @@ __global__ void aecm_fill_state(int32_t *state, const int32_t *tmpl, int words, 
         state[i] = tmpl[i % words];
 }
 
+
+// ---------------------------------------------------------------- coalescing control cohorts (wmx_aecm_coalesce; aec.hip has the long story)
+constexpr int kAecmCoMax = 32;
+struct AecmPairChecks {
+    AecmPairCheck p[kAecmCoMax];
+};
+// flags[pair] = 1 when every far-end buffer of cohort b equals its rotation of cohort a's, bit for bit (the running thresholds of the
+// binary far spectrum are integer IIRs from each cohort's own start: equal when they are, not before)
+__global__ __launch_bounds__(256) void aecm_cohort_equal(AecmFarBufs F_all, AecmPairChecks pairs, int *flags) {
+    const AecmPairCheck pc = pairs.p[blockIdx.x];
+    const AecmFarBufs A = far_cohort(F_all, pc.a), B = far_cohort(F_all, pc.b);
+    unsigned diff = 0;
+    auto rows = [&](auto *a, auto *b, int n_rows, int row_len, int d_row) {
+        for (int i = threadIdx.x; i < n_rows * row_len; i += 256) {
+            const int r = i / row_len, c = i - r * row_len;
+            int rb = r + d_row;
+            rb -= rb >= n_rows ? n_rows : 0;
+            diff |= (unsigned)(a[i] ^ b[rb * row_len + c]);
+        }
+    };
+    rows(A.ring, B.ring, kAecmFarRing, 1, pc.d_ring);
+    rows(A.frame, B.frame, kAecmFrameRing, 1, pc.d_frame);
+    rows(A.old, B.old, 2 * kAecmFrame, 1, 0);
+    rows(A.x_prev, B.x_prev, kAecmPart, 1, 0);
+    rows(A.mean_far, B.mean_far, 33, 1, 0);
+    rows(A.hist, B.hist, kAecmHist, kAecmBP, pc.d_hist);
+    rows(A.hist_q, B.hist_q, kAecmHist, 1, pc.d_hist);
+    rows(A.hist_bin, B.hist_bin, kAecmHist, 1, pc.d_hist);
+    const int any = __syncthreads_or(diff != 0);
+    if (threadIdx.x == 0) flags[blockIdx.x] = any ? 0 : 1;
+}
+// one wave per stream: members of a `from` cohort get their near and out frame rings rotated to the positions of the cohort they join
+__global__ __launch_bounds__(256) void aecm_merge_streams(int32_t *state, int *stream_cohort, int n_streams, AecmPairChecks pairs, int n_pairs) {
+    const int s = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= n_streams) return;
+    const int c = stream_cohort[s];
+    int k = -1;
+    for (int i = 0; i < n_pairs; i++)
+        if (pairs.p[i].b == c) k = i;
+    if (k < 0) return;
+    int16_t *st = reinterpret_cast<int16_t *>(state + (size_t)s * A_WORDS);
+    // position p of b's ring is position p - d of a's: contents move by ring - d
+    const int d[2] = {kAecmFrameRing - pairs.p[k].d_frame, kAecmFrameRing - pairs.p[k].d_out};
+    const int base[2] = {2 * A_NEAR_RING, 2 * A_OUT_RING};  // int16 offsets
+    int16_t v[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) v[r][j] = lane + 64 * j < kAecmFrameRing ? st[base[r] + lane + 64 * j] : (int16_t)0;
+    __builtin_amdgcn_s_waitcnt(0);  // every load of the wave before its first store: the rotation is in place
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int i = lane + 64 * j;
+            if (i < kAecmFrameRing) st[base[r] + (i + d[r]) % kAecmFrameRing] = v[r][j];
+        }
+    if (lane == 0) stream_cohort[s] = pairs.p[k].a;
+}
+__global__ void aecm_clamp_cohort(int *stream_cohort, int n_streams, int n_cohorts) {
+    const int s = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (s < n_streams && stream_cohort[s] >= n_cohorts) stream_cohort[s] = 0;
+}
 }  // namespace
 }  // namespace wmx
 
@@ -919,7 +984,20 @@ struct wmx_aecm {
     std::vector<uint8_t> live;  // [n_cohorts] 0: retired, never called, the id is handed out again
     std::vector<int> rc_g;             // per-call scratch kept with the handle
     std::vector<int32_t> same_delay;
+    // wmx_aecm_coalesce: the pairs whose device comparison is in flight (`b` < 0: dropped)
+    wmx::AecmPairChecks co_pairs;
+    int co_n;
+    bool co_inflight;
+    int *d_co_flags, *h_co_flags;
+    hipEvent_t co_done;
+    long co_calls;
+    std::vector<long> co_retry_at;
+    long last_far_group_stride;
 };
+static void aecm_co_drop(wmx_aecm *h, int cohort) {
+    for (int i = 0; i < h->co_n; i++)
+        if (h->co_pairs.p[i].a == cohort || h->co_pairs.p[i].b == cohort) h->co_pairs.p[i].b = -1;
+}
 
 extern "C" {
 
@@ -933,6 +1011,9 @@ int wmx_aecm_destroy(wmx_aecm *h) {
     if (h->h_plans[0]) (void)hipHostFree(h->h_plans[0]);
     if (h->d_tmpl) (void)hipFree(h->d_tmpl);
     if (h->d_stream_cohort) (void)hipFree(h->d_stream_cohort);
+    if (h->d_co_flags) (void)hipFree(h->d_co_flags);
+    if (h->h_co_flags) (void)hipHostFree(h->h_co_flags);
+    if (h->co_done) (void)hipEventDestroy(h->co_done);
     h->life.release();
     for (int i = 0; i < 2; i++)
         if (h->plan_free[i]) (void)hipEventDestroy(h->plan_free[i]);
@@ -1028,6 +1109,13 @@ int wmx_aecm_create_cohorts(wmx_aecm **out, int n_streams, int chn, int freq, in
     for (AecmCtl &c : h->ctl) c.init(freq);
     h->d_tmpl = nullptr;
     h->d_stream_cohort = nullptr;
+    h->co_n = 0;
+    h->co_inflight = false;
+    h->d_co_flags = h->h_co_flags = nullptr;
+    h->co_done = nullptr;
+    h->co_calls = 0;
+    h->co_retry_at.assign((size_t)n_cohorts, 0);
+    h->last_far_group_stride = 0;
     h->d_state = nullptr;
     h->d_consts = nullptr;
     h->d_far = nullptr;
@@ -1174,6 +1262,14 @@ int wmx_aecm_run_cohorts(wmx_aecm *h, int mode, const int16_t *d_far, long far_p
     rc_g.assign((size_t)G, 0);
     int rc_first = 0, running = 0;
     for (int g = 0; g < G; g++) running += (h->live[(size_t)g] && (!cohort_on || cohort_on[g])) ? 1 : 0;
+    h->last_far_group_stride = (mode & 1) ? far_group_stride : h->last_far_group_stride;
+    // pairs whose comparison is in flight (wmx_aecm_coalesce) stay candidates only while the two cohorts are called identically
+    for (int i = 0; i < h->co_n; i++) {
+        AecmPairCheck &pc = h->co_pairs.p[i];
+        if (pc.b < 0) continue;
+        const bool on_a = !cohort_on || cohort_on[pc.a], on_b = !cohort_on || cohort_on[pc.b];
+        if (on_a != on_b || (on_a && delay_ms[pc.a] != delay_ms[pc.b]) || ((mode & 1) && far_group_stride != 0)) pc.b = -1;
+    }
     for (int done = 0; done < n_packets && running > 0;) {
         int chunk = n_packets - done;
         if (chunk > kAecmMaxPktPerLaunch) chunk = kAecmMaxPktPerLaunch;
@@ -1292,12 +1388,118 @@ int wmx_aecm_import_cohort(wmx_aecm *h, int cohort, const void *host_blob) {
     WMX_HIP(hipDeviceSynchronize());
     const char *p = static_cast<const char *>(host_blob) + sizeof(BlobHeader);
     memcpy(&h->ctl[(size_t)cohort], p, sizeof(AecmCtl));
+    aecm_co_drop(h, cohort);
     WMX_HIP(hipMemcpy(static_cast<char *>(h->d_far) + (size_t)cohort * h->far.group_bytes, p + sizeof(AecmCtl), h->far.group_bytes,
                       hipMemcpyHostToDevice));
     return 0;
 }
 
 int wmx_aecm_cohorts(const wmx_aecm *h) { return h ? h->n_cohorts : WMX_EINVAL; }
+int wmx_aecm_cohort_key(const wmx_aecm *h, int cohort, int32_t *key8) {
+    if (!h || !key8 || cohort < 0 || cohort >= h->n_cohorts) return WMX_EINVAL;
+    wmx::AecmCoKey k;
+    if (!h->live[(size_t)cohort] || !wmx::aecm_co_key(h->ctl[(size_t)cohort], &k)) return 1;  // retired, or still in its start-up
+    for (int i = 0; i < 8; i++) key8[i] = k.v[i];
+    return 0;
+}
+int wmx_aecm_live_cohorts(const wmx_aecm *h) {
+    if (!h) return WMX_EINVAL;
+    int n = 0;
+    for (uint8_t l : h->live) n += l ? 1 : 0;
+    return n;
+}
+
+// wmx_aec_coalesce for the fixed-point canceller (include/wmix_amd.h): completes the merges whose device comparison came back equal,
+// then proposes up to max_pairs new pairs and launches their comparison behind the work already in `stream`.
+int wmx_aecm_coalesce(wmx_aecm *h, int max_pairs, int32_t *merged_from, int32_t *merged_into, int cap, int *n_merged, void *stream) {
+    WMX_ON_DEVICE(h);
+    using namespace wmx;
+    if (n_merged) *n_merged = 0;
+    if (!h || max_pairs < 0 || cap < 0 || (cap > 0 && (!merged_from || !merged_into))) return WMX_EINVAL;
+    hipStream_t s = as_stream(stream);
+    h->co_calls++;
+    if (h->n_cohorts < 2 || !h->d_stream_cohort) return 0;
+    if (!h->d_co_flags) {
+        WMX_HIP(hipMalloc(&h->d_co_flags, sizeof(int) * kAecmCoMax));
+        WMX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->h_co_flags), sizeof(int) * kAecmCoMax, hipHostMallocDefault));
+        WMX_HIP(hipEventCreateWithFlags(&h->co_done, hipEventDisableTiming));
+    }
+    int merged = 0;
+    if (h->co_inflight) {
+        const hipError_t q = hipEventQuery(h->co_done);
+        if (q == hipErrorNotReady) return 0;
+        if (q != hipSuccess) return hip_fail(q, "hipEventQuery(co_done)", __FILE__, __LINE__);
+        h->co_inflight = false;
+        AecmPairChecks go;
+        int n_go = 0;
+        for (int i = 0; i < h->co_n; i++) {
+            AecmPairCheck pc = h->co_pairs.p[i];
+            if (pc.b < 0) continue;
+            AecmCoKey ka, kb;
+            const bool ok = h->h_co_flags[i] == 1 && h->live[(size_t)pc.a] && h->live[(size_t)pc.b] &&
+                            aecm_co_key(h->ctl[(size_t)pc.a], &ka) && aecm_co_key(h->ctl[(size_t)pc.b], &kb) && ka == kb;
+            if (!ok) {
+                h->co_retry_at[(size_t)pc.b] = h->co_calls + 64;
+                continue;
+            }
+            if (merged >= cap) continue;
+            aecm_co_pair(h->ctl[(size_t)pc.a], h->ctl[(size_t)pc.b], pc.a, pc.b, &pc);
+            go.p[n_go++] = pc;
+            merged_from[merged] = pc.b;
+            merged_into[merged] = pc.a;
+            merged++;
+        }
+        h->co_n = 0;
+        if (n_go > 0) {
+            hipLaunchKernelGGL(aecm_merge_streams, dim3((unsigned)((h->n_streams + 3) / 4)), dim3(256), 0, s, h->d_state, h->d_stream_cohort,
+                               h->n_streams, go, n_go);
+            WMX_LAUNCH_CHECK();
+            for (int i = 0; i < n_go; i++) h->live[(size_t)go.p[i].b] = 0;
+            int nc = h->n_cohorts;
+            while (nc > 1 && !h->live[(size_t)nc - 1]) nc--;
+            if (nc < h->n_cohorts) {
+                hipLaunchKernelGGL(aecm_clamp_cohort, dim3((unsigned)((h->n_streams + 255) / 256)), dim3(256), 0, s, h->d_stream_cohort, h->n_streams, nc);
+                WMX_LAUNCH_CHECK();
+                h->n_cohorts = nc;
+                h->ctl.resize((size_t)nc);
+                h->live.resize((size_t)nc);
+                h->co_retry_at.resize((size_t)nc);
+            }
+        }
+    }
+    if (n_merged) *n_merged = merged;
+    if (max_pairs == 0 || h->last_far_group_stride != 0) return 0;
+    if (max_pairs > kAecmCoMax) max_pairs = kAecmCoMax;
+    std::unordered_multimap<uint64_t, int> leads;
+    leads.reserve((size_t)h->n_cohorts);
+    int n = 0;
+    for (int g = 0; g < h->n_cohorts && n < max_pairs; g++) {
+        if (!h->live[(size_t)g]) continue;
+        AecmCoKey k, kl;
+        if (!aecm_co_key(h->ctl[(size_t)g], &k)) continue;
+        uint64_t hash = 1469598103934665603ull;
+        for (int v : k.v) hash = (hash ^ (uint32_t)v) * 1099511628211ull;
+        int lead = -1;
+        const auto range = leads.equal_range(hash);
+        for (auto it = range.first; it != range.second && lead < 0; ++it)
+            if (aecm_co_key(h->ctl[(size_t)it->second], &kl) && kl == k) lead = it->second;
+        if (lead < 0) {
+            leads.emplace(hash, g);
+            continue;
+        }
+        if (h->co_retry_at[(size_t)g] > h->co_calls) continue;
+        aecm_co_pair(h->ctl[(size_t)lead], h->ctl[(size_t)g], lead, g, &h->co_pairs.p[n++]);
+    }
+    h->co_n = n;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(aecm_cohort_equal, dim3((unsigned)n), dim3(256), 0, s, h->far, h->co_pairs, h->d_co_flags);
+    WMX_LAUNCH_CHECK();
+    WMX_HIP(hipMemcpyAsync(h->h_co_flags, h->d_co_flags, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s));
+    WMX_HIP(hipEventRecord(h->co_done, s));
+    h->co_inflight = true;
+    return 0;
+}
+
 
 // aec_init for a cohort's shared part in the AECM build: control plane, far-end ring, farendOld, far spectrum history
 int wmx_aecm_reset_cohort(wmx_aecm *h, int cohort, void *stream) {
@@ -1305,6 +1507,7 @@ int wmx_aecm_reset_cohort(wmx_aecm *h, int cohort, void *stream) {
     using namespace wmx;
     if (!h || cohort < 0 || cohort >= h->n_cohorts) return WMX_EINVAL;
     h->ctl[(size_t)cohort].init(h->freq);
+    aecm_co_drop(h, cohort);
     WMX_HIP(hipMemsetAsync(static_cast<char *>(h->d_far) + (size_t)cohort * h->far.group_bytes, 0, h->far.group_bytes, as_stream(stream)));
     return 0;
 }
@@ -1326,6 +1529,7 @@ int wmx_aecm_add_cohort(wmx_aecm *h, int *cohort, void *stream) {
         if (rc != 0) return rc;
         h->ctl.resize((size_t)id + 1);
         h->live.push_back(1);
+        h->co_retry_at.push_back(0);
         h->n_cohorts = id + 1;
     }
     if (h->n_cohorts > 1 && !h->d_stream_cohort) {  // so far every stream was in cohort 0 by construction
@@ -1340,6 +1544,7 @@ int wmx_aecm_add_cohort(wmx_aecm *h, int *cohort, void *stream) {
 int wmx_aecm_retire_cohort(wmx_aecm *h, int cohort) {
     if (!h || cohort < 0 || cohort >= h->n_cohorts) return WMX_EINVAL;
     h->live[(size_t)cohort] = 0;
+    aecm_co_drop(h, cohort);
     return 0;
 }
 

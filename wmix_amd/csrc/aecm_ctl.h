@@ -177,4 +177,40 @@ struct AecmCtl {
     }
 };
 
+// ---- coalescing (wmx_aecm_coalesce), as for the float AEC (aec_ctl.h): what decides a control plane's future, positions taken out.
+// The AECM's plane has no periodic counters: two planes past their start-up with the same fill levels and delay filter make the same
+// plans up to a rotation of their rings and of the far-end history's block numbers.
+struct AecmCoKey {
+    int v[8];
+    bool operator==(const AecmCoKey &o) const {
+        for (int i = 0; i < 8; i++)
+            if (v[i] != o.v[i]) return false;
+        return true;
+    }
+};
+inline bool aecm_co_key(const AecmCtl &c, AecmCoKey *k) {
+    if (c.ec_startup) return false;
+    const int v[8] = {c.farend.avail_read(), c.frame_ring.avail_read(), c.out_ring.avail_read(), c.known_delay, c.time_for_delay_change,
+                      (int)c.ms_in_snd, (int)c.filt_delay, (int)c.last_delay_diff};
+    for (int i = 0; i < 8; i++) k->v[i] = v[i];
+    return true;
+}
+struct AecmPairCheck {
+    int a, b;       // cohorts: `b` (from) would join `a` (into)
+    int d_ring;     // b's far ring positions    = a's + d_ring   (mod kAecmFarRing)
+    int d_frame;    // b's frame ring positions  = a's + d_frame  (mod kAecmFrameRing); a's = b's + (ring - d_frame): the members' near rings
+    int d_out;      // b's out ring positions    = a's + d_out    (mod kAecmFrameRing)
+    int d_hist;     // b's history slots         = a's + d_hist   (mod kAecmHist)
+    int pad[2];
+};
+inline void aecm_co_pair(const AecmCtl &a, const AecmCtl &b, int ia, int ib, AecmPairCheck *pc) {
+    pc->a = ia;
+    pc->b = ib;
+    pc->d_ring = aec_mod(b.farend.rd - a.farend.rd, kAecmFarRing);
+    pc->d_frame = aec_mod(b.frame_ring.rd - a.frame_ring.rd, kAecmFrameRing);
+    pc->d_out = aec_mod(b.out_ring.rd - a.out_ring.rd, kAecmFrameRing);
+    pc->d_hist = aec_mod(b.block_t - a.block_t, kAecmHist);
+    pc->pad[0] = pc->pad[1] = 0;
+}
+
 }  // namespace wmx

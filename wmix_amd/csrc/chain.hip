@@ -232,9 +232,10 @@ int wmx_chain_coalesce(wmx_chain *h, int max_pairs, int32_t *merged_from, int32_
     WMX_ON_DEVICE(h);
     if (n_merged) *n_merged = 0;
     if (!h) return WMX_EINVAL;
-    if (!h->aec) return 0;
-    const int rc = wmx_aec_coalesce(h->aec, max_pairs, merged_from, merged_into, cap, n_merged, stream);
-    const int n = wmx_aec_cohorts(h->aec);
+    if (!h->aec && !h->aecm) return 0;
+    const int rc = h->aec ? wmx_aec_coalesce(h->aec, max_pairs, merged_from, merged_into, cap, n_merged, stream)
+                          : wmx_aecm_coalesce(h->aecm, max_pairs, merged_from, merged_into, cap, n_merged, stream);
+    const int n = h->aec ? wmx_aec_cohorts(h->aec) : wmx_aecm_cohorts(h->aecm);
     if (n != h->n_cohorts) {
         h->n_cohorts = n;
         h->zero_delays.assign((size_t)n, 0);

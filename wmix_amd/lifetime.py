@@ -49,7 +49,7 @@ class Lifetime:
         """wmx_aec_coalesce / wmx_chain_coalesce: completes the merges whose device check came back equal and proposes up to
         max_pairs new ones.  Returns [(from, into), ...] of the cohorts merged by THIS call; n_cohorts is up to date afterwards."""
         import ctypes as C
-        assert self._mod in ("aec", "chain")
+        assert self._mod in ("aec", "aecm", "chain")
         fr = np.zeros(32, np.int32)
         to = np.zeros(32, np.int32)
         n = C.c_int(0)
@@ -61,10 +61,25 @@ class Lifetime:
         self.n_cohorts = k
         return [(int(fr[j]), int(to[j])) for j in range(n.value)]
 
+    def cohort_key(self, cohort):
+        """The words of the cohort's control plane that decide whether it can fold into another (wmx_aec_cohort_key /
+        wmx_aecm_cohort_key), or None while it has none (retired, start-up)."""
+        assert self._mod in ("aec", "aecm")
+        k = np.zeros(13 if self._mod == "aec" else 8, np.int32)
+        rc = getattr(lib(), "wmx_%s_cohort_key" % self._mod)(self._h, int(cohort), k.ctypes.data)
+        if rc == 1:
+            return None
+        check(rc, "cohort_key")
+        return k
+
     def live_cohorts(self):
         """Cohorts that are not retired (wmx_aec_live_cohorts of the handle's float AEC)."""
+        if self._mod == "aecm":
+            return lib().wmx_aecm_live_cohorts(self._h)
         assert self._mod in ("aec", "chain")
         h = self._h if self._mod == "aec" else lib().wmx_chain_aec(self._h)
+        if not h:  # a chain whose echo canceller is the fixed-point one
+            return lib().wmx_aecm_live_cohorts(lib().wmx_chain_aecm(self._h))
         return lib().wmx_aec_live_cohorts(h)
 
     def set_active(self, mask):
