@@ -144,6 +144,51 @@ static int drive_pair(int freq, int pkg, int lag, int delay0) {
     return met;
 }
 
+// the same for the AECM's plane (wmx_aecm_coalesce): no periodic counters, so planes meet as soon as both are past their start-up with
+// the same phase of the 80-in-64 re-blocking (4 frames: 2 packets at 16 kHz, 4 at 8 kHz)
+static int drive_pair_aecm(int freq, int pkg, int lag, int delay0) {
+    AecmCtl a, b;
+    a.init(freq);
+    b.init(freq);
+    int met = -1;
+    AecmPairCheck pc{};
+    for (int p = 0; p < 4000; p++) {
+        const int d = p < 2500 ? delay0 : delay0 + 60;
+        AecmPlan pa, pb;
+        std::memset(&pa, 0, sizeof(pa));
+        std::memset(&pb, 0, sizeof(pb));
+        CHECK(a.buffer_farend(pkg, &pa) == 0);
+        CHECK(a.process(pkg, d, &pa) == 0);
+        if (p < lag) continue;
+        CHECK(b.buffer_farend(pkg, &pb) == 0);
+        CHECK(b.process(pkg, d, &pb) == 0);
+        if (met >= 0) {
+            CHECK(pa.has_far == pb.has_far && pa.far_n == pb.far_n && pa.has_near == pb.has_near && pa.passthrough == pb.passthrough);
+            CHECK(pa.n_frames == pb.n_frames && pa.discard_out == pb.discard_out);
+            CHECK(pb.far_w == (pa.far_w + pc.d_ring) % kAecmFarRing);
+            for (int f = 0; f < pa.n_frames && !pa.passthrough; f++) {
+                const AecmFramePlan &fa = pa.fr[f], &fb = pb.fr[f];
+                CHECK((fa.far_src < 0) == (fb.far_src < 0) && fa.old_slot == fb.old_slot && fa.n_blocks == fb.n_blocks);
+                if (fa.far_src >= 0) CHECK(fb.far_src == (fa.far_src + pc.d_ring) % kAecmFarRing);
+                CHECK(fb.ring_w == (fa.ring_w + pc.d_frame) % kAecmFrameRing && fb.out_r == (fa.out_r + pc.d_out) % kAecmFrameRing);
+                for (int q = 0; q < fa.n_blocks; q++) {
+                    CHECK(fb.blk_r[q] == (fa.blk_r[q] + pc.d_frame) % kAecmFrameRing && fb.blk_out_w[q] == (fa.blk_out_w[q] + pc.d_out) % kAecmFrameRing);
+                    CHECK(((fb.blk_t[q] - fa.blk_t[q] - pc.d_hist) & (kAecmHist - 1)) == 0);
+                }
+            }
+            AecmCoKey ka, kb;
+            CHECK(aecm_co_key(a, &ka) && aecm_co_key(b, &kb) && ka == kb);
+        } else {
+            AecmCoKey ka, kb;
+            if (aecm_co_key(a, &ka) && aecm_co_key(b, &kb) && ka == kb) {
+                met = p;
+                aecm_co_pair(a, b, 0, 1, &pc);
+            }
+        }
+    }
+    return met;
+}
+
 int main() {
     long total = 0;
     for (int freq : {8000, 16000})
@@ -207,6 +252,12 @@ int main() {
             for (int lag : {1, 3, 4, 12, 37}) CHECK(drive_pair(freq, pkg, lag, d0) < 0);
         }
     CHECK(drive_pair(8000, 160, 8, 0) >= 0);  // 20 ms packets at 8 kHz (the daemon's cadence)
+    for (int freq : {8000, 16000})
+        for (int d0 : {0, 40, 120}) {
+            const int pkg = freq / 100, period = freq == 16000 ? 2 : 4;
+            for (int lag : {period, 3 * period, 100, 800}) CHECK(drive_pair_aecm(freq, pkg, lag, d0) >= 0);
+            for (int lag : {1, period + 1, 37}) CHECK(drive_pair_aecm(freq, pkg, lag, d0) < 0);
+        }
     // ---- AGC gain table: every compression gain an uint8 agc_addition() can pass, limiter off (wmix) and on
     int ok = 0;
     for (int comp = 0; comp < 256; comp++)
