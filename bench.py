@@ -636,9 +636,9 @@ class ChainWorkload:
         # "interleaved": stream s belongs to group s % N (slots scattered by churn: the streams of a workgroup hear different
         # cohorts' far-end histories).
         self.n_cohorts, self.cohort_layout = int(cohorts), cohort_layout
-        # --coalesce: wmx_chain_coalesce behind every step -- cohorts whose control planes have converged (same delay, noise-floor
-        # start-up over, same phase of the 8-packet block pattern) are merged after a word-for-word comparison of their far-end
-        # slabs on the device; the priming grows by the 1 000 blocks of that start-up and the merge rounds (32 pairs per call)
+        # --coalesce: wmx_chain_coalesce behind every step -- cohorts whose control planes have converged (same delay, start-up over,
+        # same phase of the re-blocking) are merged after a word-for-word comparison of their far-end slabs on the device; the
+        # priming grows by the blocks that takes and the merge rounds (32 pairs per call)
         self.coalesce, self.merged = bool(coalesce) and int(cohorts) > 1, 0
         assert 1 <= self.n_cohorts <= n_streams
         if self.n_cohorts > 1:
@@ -652,9 +652,9 @@ class ChainWorkload:
 
     def min_prime(self):
         """untimed steps needed before every stream has joined and is past the start-up phases"""
-        # blocks until a young cohort can fold: the float AEC's noise-floor start-up (1 000 blocks); the AECM's binary far spectrum
-        # thresholds meeting the older cohort's bit for bit (~1 500 blocks)
-        blocks = 1800 if getattr(self, "extra_stages", 0) & 32 else 1000
+        # blocks until a young cohort can fold: the float AEC's far-end rings filled and its far power rounded onto the older cohort's
+        # (250 blocks and a margin); the AECM's binary far spectrum thresholds meeting the older cohort's bit for bit (~1 500 blocks)
+        blocks = 1800 if getattr(self, "extra_stages", 0) & 32 else 500
         settle = (blocks * 64 // (self.pkt * self.P) + 120 + self.n_cohorts // 8) if self.coalesce else 0
         return self.n_cohorts - 1 + settle
 

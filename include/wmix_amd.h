@@ -240,7 +240,7 @@ int wmx_aec_retire_cohort(wmx_aec *h, int cohort);
  * as its own handle (its state is the stream's block count, part of the stream's state).  The pairs are reported in
  * merged_from[] / merged_into[] (*n_merged of them, at most cap) so that the caller can redirect its own tables; the id range
  * wmx_aec_cohorts(h) shrinks behind the last live cohort.  (2) it proposes up to max_pairs (<= 32) new pairs -- equal fill
- * levels, delays and counters, start-up over, lowest id leads -- and launches their comparison behind the work already in
+ * levels and delay filter, start-up over, lowest id leads -- and launches their comparison behind the work already in
  * `stream`.  Nothing waits for the device: a pair proposed by one call is merged by a later one.  A pair is dropped when its two
  * cohorts are not called identically in between (delay, cohort_on, private far-end packets).  max_pairs = 0: only (1).
  * Merged streams are bound to one reported delay from then on, like the members of any cohort. */
@@ -344,11 +344,11 @@ int wmx_aecm_retire_cohort(wmx_aecm *h, int cohort);
 int wmx_aecm_coalesce(wmx_aecm *h, int max_pairs, int32_t *merged_from, int32_t *merged_into, int cap, int *n_merged, void *stream);
 int wmx_aecm_live_cohorts(const wmx_aecm *h);
 /* Why two cohorts do (not) fold: the words of the control plane that decide its future, positions taken out -- cohorts are proposed
- * for a merge when these are equal.  AEC (13): fill levels of the near / out / far-spectrum / far-sample rings, system delay, known
- * delay of the core, noise-floor counter, delay-estimate counter, knownDelay, timeForDelayChange, msInSndCardBuf, filtDelay,
- * lastDelayDiff.  AECM (8): fill levels of the far / frame / out rings, knownDelay, timeForDelayChange, msInSndCardBuf, filtDelay,
+ * for a merge when these are equal.  AEC (11): fill levels of the near / out / far-spectrum / far-sample rings, system delay, known
+ * delay of the core, knownDelay, timeForDelayChange, msInSndCardBuf, filtDelay, lastDelayDiff (the core's two block counters, noise
+ * floor and delay estimate, count with the stream).  AECM (8): fill levels of the far / frame / out rings, knownDelay, timeForDelayChange, msInSndCardBuf, filtDelay,
  * lastDelayDiff.  Returns 0, 1 (the cohort is retired or still in its start-up phase: no key), or WMX_E*. */
-int wmx_aec_cohort_key(const wmx_aec *h, int cohort, int32_t *key13);
+int wmx_aec_cohort_key(const wmx_aec *h, int cohort, int32_t *key11);
 int wmx_aecm_cohort_key(const wmx_aecm *h, int cohort, int32_t *key8);
 int wmx_aecm_reset_streams(wmx_aecm *h, const int32_t *idx, int n, int cohort, void *stream);
 int wmx_aecm_set_active(wmx_aecm *h, const uint8_t *host_mask, void *stream);

@@ -129,7 +129,7 @@ static int drive_pair(int freq, int pkg, int lag, int delay0) {
             for (int q = 0; q < pa.n_blk; q++) {
                 CHECK(pa.blk[q].near_rd == (pb.blk[q].near_rd + pc.d_near) % kAecRing && pa.blk[q].out_wr == (pb.blk[q].out_wr + pc.d_out) % kAecRing);
                 CHECK(pb.blk[q].far_slot == (pa.blk[q].far_slot + pc.d_far) % kAecFarBlocks);
-                CHECK(((pb.blk[q].hist_n - pa.blk[q].hist_n - pc.d_hist) & (kAecHist - 1)) == 0 && pa.blk[q].flags == pb.blk[q].flags);
+                CHECK(((pb.blk[q].hist_n - pa.blk[q].hist_n - pc.d_hist) & (kAecHist - 1)) == 0);
             }
             AecCoKey ka, kb;
             CHECK(aec_co_key(a, &ka) && aec_co_key(b, &kb) && ka == kb);  // and the keys stay equal
@@ -239,19 +239,19 @@ int main() {
             CHECK(((s * a + c) & 0x7FFFFFFFu) == want);
         }
     }
-    // ---- coalescing: planes 8 k packets apart meet (the 10-block delay-estimate counter and the 80 / 160-in-64 re-blocking repeat
-    //      every 8 packets) -- as soon as the younger one's noise-floor start-up is over -- and planes an odd number of packets apart
-    //      (different block phase) or a non-multiple of 8 apart never do
+    // ---- coalescing: planes meet as soon as the younger one's start-up is over when they are a multiple of the re-blocking period
+    //      apart (160-in-64: 2 packets; 80-in-64: 4 packets) -- the core's two block counters count with the stream, not with the plane
+    //      -- and never when they are not (another block phase)
     for (int freq : {8000, 16000})
         for (int d0 : {0, 40, 120}) {
-            const int pkg = freq / 100, settle = 500 * (freq / 8000) * 64 / pkg + 80;
-            for (int lag : {8, 16, 104, 800}) {
+            const int pkg = freq / 100, period = freq == 16000 ? 2 : 4;
+            for (int lag : {period, 3 * period, 104, 800}) {
                 const int met = drive_pair(freq, pkg, lag, d0);
-                CHECK(met >= 0 && met < lag + settle + 200);
+                CHECK(met >= 0 && met < lag + 400);
             }
-            for (int lag : {1, 3, 4, 12, 37}) CHECK(drive_pair(freq, pkg, lag, d0) < 0);
+            for (int lag : {1, period + 1, 37}) CHECK(drive_pair(freq, pkg, lag, d0) < 0);
         }
-    CHECK(drive_pair(8000, 160, 8, 0) >= 0);  // 20 ms packets at 8 kHz (the daemon's cadence)
+    CHECK(drive_pair(8000, 160, 2, 0) >= 0 && drive_pair(8000, 160, 3, 0) < 0);  // 20 ms packets at 8 kHz (the daemon's cadence)
     for (int freq : {8000, 16000})
         for (int d0 : {0, 40, 120}) {
             const int pkg = freq / 100, period = freq == 16000 ? 2 : 4;

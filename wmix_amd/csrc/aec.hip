@@ -78,6 +78,10 @@ enum : int {
     AS_STNEAR = AS_SCAL + 8,
     AS_ECHOSTATE = AS_SCAL + 9,
     AS_DIVERGE = AS_SCAL + 10,
+    AS_NOISECTR = AS_SCAL + 12,  // noiseEstCtr (aec_core.c:1216-1243): counts a handle's first 500 * mult blocks
+    AS_DELAYCTR = AS_SCAL + 13,  // delayEstCtr (aec_core.c:1020-1025): PartitionDelay every 10 * mult blocks of the handle
+                                 //   -- both with the stream, not with its control cohort, so that cohorts can fold (wmx_aec_coalesce)
+                                 //   as soon as their rings agree, whatever their members' ages
     AS_NBLK = AS_SCAL + 11,      // blocks this stream has processed since aec_init (uint32): every handle's comfort-noise generator
                                  //   starts from the same state (aec->seed = 777, aec_core.c:1670) and draws 64 numbers per block, so
                                  //   the block count IS the generator's state -- and the row of AecNoiseRows the block's phases lie in
@@ -428,6 +432,24 @@ __device__ __forceinline__ void aec_block(const AecConstsNear &K, const float *_
     const float mu = MULT == 1 ? 0.6f : 0.5f, err_thr = MULT == 1 ? 2e-6f : 1.5e-6f;  // aec_core.c:1530-1538
     const float scale = 2.0f / 128;
     const int n = bp.hist_n;
+    // the handle's two block counters: the first 500 * mult blocks initialise the noise floor, every (10 * mult)-th block re-estimates
+    // the dominant filter partition -- wave-uniform, kept in the stream's scalars
+    int blk_flags;
+    {
+        int nctr = __builtin_amdgcn_readfirstlane(Si[AS_NOISECTR]), dctr = __builtin_amdgcn_readfirstlane(Si[AS_DELAYCTR]);
+        blk_flags = nctr > 50 ? kAecFlagNoiseMin : 0;
+        if (nctr < 500 * MULT) {
+            nctr++;
+            blk_flags |= kAecFlagNoiseInit;
+        }
+        dctr++;
+        if (dctr == 10 * MULT) dctr = 0;
+        if (dctr == 0) blk_flags |= kAecFlagDelayEst;
+        if (lane == 0) {
+            Si[AS_NOISECTR] = nctr;
+            Si[AS_DELAYCTR] = dctr;
+        }
+    }
     int g = fft_group(lane), gl = fft_index(lane);
 #define AEC_RELANE()              \
     do {                          \
@@ -533,12 +555,12 @@ __device__ __forceinline__ void aec_block(const AecConstsNear &K, const float *_
             const float ns = re * re + im * im;
             r.dpow = 0.9f * AEC_ST(AS_DPOW + b) + 0.1f * ns;
             r.dmin = AEC_ST(AS_DMIN + b);
-            if (bp.flags & kAecFlagNoiseMin) {  // both arms evaluated, one selected: a lane-dependent branch is three scalar instructions
+            if (blk_flags & kAecFlagNoiseMin) {  // both arms evaluated, one selected: a lane-dependent branch is three scalar instructions
                 const float down = (r.dpow + 0.1f * (r.dmin - r.dpow)) * 1.0002f, up = r.dmin * 1.0002f;
                 r.dmin = r.dpow < r.dmin ? down : up;
             }
             r.dinit = 0.f;
-            if (bp.flags & kAecFlagNoiseInit) {
+            if (blk_flags & kAecFlagNoiseInit) {
                 r.dinit = AEC_ST(AS_DINIT + b);
                 const float track = 0.999f * r.dinit + 0.001f * r.dmin;
                 r.dinit = r.dmin > r.dinit ? track : r.dmin;
@@ -547,8 +569,8 @@ __device__ __forceinline__ void aec_block(const AecConstsNear &K, const float *_
         };
         auto put = [&](int b, const Pw &r) {
             AEC_ST(AS_DPOW + b) = r.dpow;
-            if (bp.flags & kAecFlagNoiseMin) AEC_ST(AS_DMIN + b) = r.dmin;
-            if (bp.flags & kAecFlagNoiseInit) AEC_ST(AS_DINIT + b) = r.dinit;
+            if (blk_flags & kAecFlagNoiseMin) AEC_ST(AS_DMIN + b) = r.dmin;
+            if (blk_flags & kAecFlagNoiseInit) AEC_ST(AS_DINIT + b) = r.dinit;
         };
         const Pw a = power(lane, dfr, dfi);
         put(lane, a);
@@ -707,7 +729,7 @@ __device__ __forceinline__ void aec_block(const AecConstsNear &K, const float *_
     const float gc0 = MULT == 1 ? 0.9f : 0.93f, gc1 = MULT == 1 ? 0.1f : 0.07f;  // kNormalSmoothingCoefficients
     // PartitionDelay (aec_core.c:295-319) every 10*mult blocks: per-partition ordered energy sums
     int delayIdx = delayIdx0;
-    if (bp.flags & kAecFlagDelayEst) {
+    if (blk_flags & kAecFlagDelayEst) {
         // two partitions per work row: [0..64] and [66..130]
 #pragma unroll
         for (int p = 0; p < 12; p++) {
@@ -993,7 +1015,7 @@ __device__ __forceinline__ void aec_block(const AecConstsNear &K, const float *_
     AEC_PROF(7);
     AEC_RELANE();
     // OverdriveAndSuppress (aec_core.c:272-293) + ComfortNoise (:462-547) + packing for the inverse transform
-    const int noise_off = (bp.flags & kAecFlagNoiseInit) ? AS_DINIT : AS_DMIN;
+    const int noise_off = (blk_flags & kAecFlagNoiseInit) ? AS_DINIT : AS_DMIN;
     v2f out_spec = v2f{0.f, 0.f};
     float out_nyq = 0.f;
 #if defined(WMX_AEC_EXP) && WMX_AEC_EXP >= 1
@@ -2219,11 +2241,11 @@ int wmx_aec_import_cohort(wmx_aec *h, int cohort, const void *host_blob) {
 }
 
 int wmx_aec_cohorts(const wmx_aec *h) { return h ? h->n_far : WMX_EINVAL; }
-int wmx_aec_cohort_key(const wmx_aec *h, int cohort, int32_t *key13) {
-    if (!h || !key13 || cohort < 0 || cohort >= h->n_far) return WMX_EINVAL;
+int wmx_aec_cohort_key(const wmx_aec *h, int cohort, int32_t *key11) {
+    if (!h || !key11 || cohort < 0 || cohort >= h->n_far) return WMX_EINVAL;
     wmx::AecCoKey k;
     if (!h->live[(size_t)cohort] || !wmx::aec_co_key(h->ctl[(size_t)cohort], &k)) return 1;  // retired, or still in its start-up
-    for (int i = 0; i < 13; i++) key13[i] = k.v[i];
+    for (int i = 0; i < 11; i++) key11[i] = k.v[i];
     return 0;
 }
 int wmx_aec_live_cohorts(const wmx_aec *h) {

@@ -165,7 +165,6 @@ struct AecCtl {
     int fs = 0, mult = 1, rate_factor = 1;
     RingIdx near_fr, out_fr, far_buf, far_pre;
     int system_delay = 0, core_known_delay = 0;
-    int noise_ctr = 0, delay_est_ctr = 0;
     uint32_t blocks = 0;  // blocks planned since init -- after a merge (wmx_aec_coalesce) or an import, of the OLDEST member: the comfort-
                           // noise table must reach that far (AecNoiseRows)
     int hist_n = 0;
@@ -246,15 +245,7 @@ struct AecCtl {
         far_buf.read(1, &b.far_slot);
         b.hist_n = hist_n;
         hist_n = (hist_n + 1) & 0x3fffffff;  // only differences modulo kAecHist matter; stays non-negative for ever
-        b.flags = 0;
-        if (noise_ctr > 50) b.flags |= kAecFlagNoiseMin;
-        if (noise_ctr < 500 * mult) {
-            noise_ctr++;
-            b.flags |= kAecFlagNoiseInit;
-        }
-        delay_est_ctr++;
-        if (delay_est_ctr == 10 * mult) delay_est_ctr = 0;
-        if (delay_est_ctr == 0) b.flags |= kAecFlagDelayEst;
+        b.flags = 0;  // (noiseEstCtr and delayEstCtr count the STREAM's blocks: aec.hip AS_NOISECTR / AS_DELAYCTR)
         blocks++;  // (the stream's own count, AS_NBLK in aec.hip, selects the block's comfort-noise row)
         out_fr.write(kAecPart, &b.out_wr);
     }
@@ -346,19 +337,18 @@ struct AecCtl {
 // the comfort-noise generator belongs to the streams once cohorts have been merged; hist_n and the ring positions are what the
 // rotation absorbs.)  tools_dev/san/host_ctl_san.cpp drives pairs of planes for thousands of packets behind an equal key.
 struct AecCoKey {
-    int v[13];
+    int v[11];
     bool operator==(const AecCoKey &o) const {
-        for (int i = 0; i < 13; i++)
+        for (int i = 0; i < 11; i++)
             if (v[i] != o.v[i]) return false;
         return true;
     }
 };
 inline bool aec_co_key(const AecCtl &c, AecCoKey *k) {
     if (c.startup_phase) return false;
-    const int v[13] = {c.near_fr.avail_read(), c.out_fr.avail_read(), c.far_buf.avail_read(), c.far_pre.avail_read(), c.system_delay,
-                       c.core_known_delay, c.noise_ctr, c.delay_est_ctr, c.knownDelay, c.timeForDelayChange, (int)c.msInSndCardBuf,
-                       (int)c.filtDelay, (int)c.lastDelayDiff};
-    for (int i = 0; i < 13; i++) k->v[i] = v[i];
+    const int v[11] = {c.near_fr.avail_read(), c.out_fr.avail_read(), c.far_buf.avail_read(), c.far_pre.avail_read(), c.system_delay,
+                       c.core_known_delay, c.knownDelay, c.timeForDelayChange, (int)c.msInSndCardBuf, (int)c.filtDelay, (int)c.lastDelayDiff};
+    for (int i = 0; i < 11; i++) k->v[i] = v[i];
     return true;
 }
 // the rotations between cohort a (`into`) and cohort b (`from`)

@@ -65,7 +65,7 @@ class Lifetime:
         """The words of the cohort's control plane that decide whether it can fold into another (wmx_aec_cohort_key /
         wmx_aecm_cohort_key), or None while it has none (retired, start-up)."""
         assert self._mod in ("aec", "aecm")
-        k = np.zeros(13 if self._mod == "aec" else 8, np.int32)
+        k = np.zeros(11 if self._mod == "aec" else 8, np.int32)
         rc = getattr(lib(), "wmx_%s_cohort_key" % self._mod)(self._h, int(cohort), k.ctypes.data)
         if rc == 1:
             return None
