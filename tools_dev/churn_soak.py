@@ -110,6 +110,7 @@ def main():
     port = L.port()
     far_seq = np.concatenate([far[t % K] for t in range(T)])
     worst, n_lives, n_pk = 0, 0, 0
+    hist, big = np.zeros(4, np.int64), []
     for s, st, en, dl in lives:
         if s not in watch or en - st < 2:
             continue
@@ -127,14 +128,19 @@ def main():
             want = L.run_vad(port, 1, freq, 10, x, pkt, prefix="orc")
         d = np.abs(got[st:en, col[s]].reshape(-1).astype(np.int32) - want.astype(np.int32))
         worst = max(worst, int(d.max()))
+        hist += np.bincount(np.minimum(d, 3), minlength=4)
+        for i in np.flatnonzero(d >= 2)[:4]:
+            big.append({"stream": int(s), "life": [int(st), int(en)], "delay": int(dl), "packet_of_life": int(i // pkt), "sample": int(i % pkt),
+                        "got": int(got[st:en, col[s]].reshape(-1)[i]), "want": int(want[i])})
         n_lives += 1
         n_pk += en - st
     print(json.dumps({"streams": S, "ticks": T, "freq": freq, "fixed_point": a.fx, "lives_total": len(lives), "lives_checked": n_lives,
-                      "packets_checked": n_pk, "max_lsb": worst, "max_cohort_ids": max_cohorts, "cohorts_alive_at_end": len(cohorts),
+                      "packets_checked": n_pk, "max_lsb": worst, "abs_diff_histogram_0_1_2_3plus": hist.tolist(), "samples_off_by_2_or_more": big[:12], "max_cohort_ids": max_cohorts, "cohorts_alive_at_end": len(cohorts),
                       "coalesce": a.coalesce, "folds": n_folds, "peak_live_cohorts": peak_live,
                       "wall_s": round(time.time() - t_wall, 1),
                       "host_ctl_us_per_tick": (sec / n_host * 1e6 if n_host else None)}))
-    assert worst <= (0 if a.fx else 1)
+    # the float chain: the AEC's rare 1-LSB samples (libm's powf / cosf / sinf) can come out of the AGC behind it as 2 (gain up to x 1.78)
+    assert worst <= (0 if a.fx else 2) and hist[2:].sum() <= max(1, hist.sum() // 10_000_000), hist
 
 
 if __name__ == "__main__":
