@@ -1005,6 +1005,10 @@ struct wmx_aecm {
     long co_calls;
     std::vector<long> co_retry_at;
     long last_far_group_stride;
+    // the far kernel on a side stream beside whatever the caller launches in front of the near kernel (wmx::aecm_fork_far; aec.hip)
+    hipStream_t side;
+    hipEvent_t ev_fork, ev_join;
+    bool fork_pending;
 };
 static void aecm_co_drop(wmx_aecm *h, int cohort) {
     for (int i = 0; i < h->co_n; i++)
@@ -1026,6 +1030,9 @@ int wmx_aecm_destroy(wmx_aecm *h) {
     if (h->d_co_flags) (void)hipFree(h->d_co_flags);
     if (h->h_co_flags) (void)hipHostFree(h->h_co_flags);
     if (h->co_done) (void)hipEventDestroy(h->co_done);
+    if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     h->life.release();
     for (int i = 0; i < 2; i++)
         if (h->plan_free[i]) (void)hipEventDestroy(h->plan_free[i]);
@@ -1128,6 +1135,9 @@ int wmx_aecm_create_cohorts(wmx_aecm **out, int n_streams, int chn, int freq, in
     h->co_calls = 0;
     h->co_retry_at.assign((size_t)n_cohorts, 0);
     h->last_far_group_stride = 0;
+    h->side = nullptr;
+    h->ev_fork = h->ev_join = nullptr;
+    h->fork_pending = false;
     h->d_state = nullptr;
     h->d_consts = nullptr;
     h->d_far = nullptr;
@@ -1248,6 +1258,9 @@ int wmx_aecm_run_cohorts(wmx_aecm *h, int mode, const int16_t *d_far, long far_p
                          const uint8_t *cohort_on, int32_t *cohort_rc, void *stream) {
     WMX_ON_DEVICE(h);
     using namespace wmx;
+    // a fork point belongs to THIS call, whichever way it ends (as in wmx_aec_run_cohorts)
+    const bool fork_here = h && h->fork_pending;
+    if (h) h->fork_pending = false;
     if (!h || n_packets < 0 || (mode & 3) == 0 || !delay_ms) {
         set_error("wmx_aecm_run: bad argument");
         return WMX_EINVAL;
@@ -1325,10 +1338,18 @@ int wmx_aecm_run_cohorts(wmx_aecm *h, int mode, const int16_t *d_far, long far_p
         }
         if (any) {
             const int by_value = (chunk == 1 && G == 1) ? 1 : 0;
-            hipLaunchKernelGGL(aecm_far_kernel, dim3((unsigned)G), dim3(64), 0, s, h->far, h->d_consts, dp, chunk, G,
+            // the far kernel on the side stream when the caller forked it (first chunk of the call only)
+            const bool forked = fork_here && done == 0 && (mode & 2);
+            hipStream_t fs = forked ? h->side : s;
+            if (forked) WMX_HIP(hipStreamWaitEvent(fs, h->ev_fork, 0));
+            hipLaunchKernelGGL(aecm_far_kernel, dim3((unsigned)G), dim3(64), 0, fs, h->far, h->d_consts, dp, chunk, G,
                                d_far ? d_far + (size_t)done * far_packet_stride : nullptr, far_packet_stride, far_group_stride, h->chn, by_value,
                                hp[0], by_value ? nullptr : hp);
             WMX_LAUNCH_CHECK();
+            if (forked) {
+                WMX_HIP(hipEventRecord(h->ev_join, fs));
+                WMX_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
+            }
             if (mode & 2) {
                 const unsigned grid = (unsigned)((h->n_streams + kAecmWavesPerBlock - 1) / kAecmWavesPerBlock);
                 hipLaunchKernelGGL(aecm_near_kernel, dim3(grid), dim3(64 * kAecmWavesPerBlock), 0, s, h->d_state, h->far, h->d_consts, dp, chunk, G,
@@ -1345,6 +1366,27 @@ int wmx_aecm_run_cohorts(wmx_aecm *h, int mode, const int16_t *d_far, long far_p
         for (int g = 0; g < G; g++) cohort_rc[g] = rc_g[g];
     return rc_first;
 }
+
+}  // extern "C"
+// Library-internal (wmx_internal.h): from this point of `stream` on, the far-end packets of the NEXT wmx_aecm_run_* call on this
+// handle are in place; its far kernel may start here, on the handle's side stream, beside whatever the caller launches on `stream`
+// between now and that call (wmx_chain_process: the NSX).  The near kernel still runs on `stream`, behind the far kernel.
+int wmx::aecm_fork_far(wmx_aecm *h, hipStream_t s) {
+    WMX_ON_DEVICE(h);
+    if (!h) return WMX_EINVAL;
+    if (!h->side) {
+        WMX_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        WMX_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        WMX_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
+    WMX_HIP(hipEventRecord(h->ev_fork, s));
+    h->fork_pending = true;
+    return 0;
+}
+void wmx::aecm_cancel_fork(wmx_aecm *h) {
+    if (h) h->fork_pending = false;
+}
+extern "C" {
 
 // stream / cohort migration, as for the float AEC
 int wmx_aecm_stream_state_bytes(const wmx_aecm *h) { return h ? (int)(sizeof(wmx::BlobHeader) + wmx::A_WORDS * 4) : WMX_EINVAL; }

@@ -252,6 +252,9 @@ inline hipError_t column_from_host(T *dev, const T *host, int fields, int n_stre
 int aec_fork_far(wmx_aec *h, hipStream_t stream);
 // the caller returns without the AEC call the fork was made for: the next wmx_aec_run_* starts on its own stream again
 void aec_cancel_fork(wmx_aec *h);
+// the same for the fixed-point canceller's far kernel (beside the NSX)
+int aecm_fork_far(wmx_aecm *h, hipStream_t stream);
+void aecm_cancel_fork(wmx_aecm *h);
 
 // wmix_pcm_zoom's cursor walk (src/wmix.c:139-222) as a gather list: out int16 i <- in int16 idx[i]; identical formats
 // give the identity (the reference's memcpy branch).  Defined in mix.hip.
