@@ -266,3 +266,46 @@ def test_aecm_cohorts_fold_too_bit_exact(cuda, oracle_port, freq, S, T):
         a = int(join[s])
         want = L.run_aecm(oracle_port, 1, freq, 10, far[a:].reshape(-1), base[s % U, a:].reshape(-1), pkt, 0, prefix="orc")
         assert np.array_equal(out[a:, s].reshape(-1), want), s
+
+
+def test_coalesce_argument_edges(cuda):
+    """Bad arguments are refused; a batch with one cohort, or a call without room to report a merge, merges nothing; cohort_key says
+    why a cohort is (not) a candidate."""
+    import ctypes as C
+    from wmix_amd._lib import lib
+    S, freq, pkt = 8, 16000, 160
+    ab = AecBatch(S, 1, freq, 10, n_cohorts=1)
+    n = C.c_int(7)
+    fr, to = np.zeros(4, np.int32), np.zeros(4, np.int32)
+    L_ = lib()
+    assert L_.wmx_aec_coalesce(None, 1, fr.ctypes.data, to.ctypes.data, 4, C.byref(n), None) != 0
+    assert L_.wmx_aec_coalesce(ab._h, -1, fr.ctypes.data, to.ctypes.data, 4, C.byref(n), None) != 0
+    assert L_.wmx_aec_coalesce(ab._h, 4, None, None, 4, C.byref(n), None) != 0
+    assert L_.wmx_aec_coalesce(ab._h, 4, fr.ctypes.data, to.ctypes.data, 4, C.byref(n), None) == 0 and n.value == 0  # one cohort
+    assert ab.cohort_key(0) is None  # still in its start-up phase
+    far = synth.far_end(8600, 700, pkt).reshape(700, pkt)
+    near = synth.near_end(8601, S, 700, pkt, far=far.reshape(-1)).reshape(S, 700, pkt)
+    d = torch.from_numpy(np.ascontiguousarray(near.transpose(1, 0, 2))).to(cuda)
+    dfar = torch.from_numpy(far.copy()).to(cuda)
+    ab.reset_cohort(0)
+    active = np.zeros(S, np.uint8)
+    for t in range(700):
+        if t in (0, 2):
+            c = 0 if t == 0 else ab.add_cohort()
+            m = np.arange(0, 4, dtype=np.int32) if t == 0 else np.arange(4, 8, dtype=np.int32)
+            ab.reset_streams(m, cohort=c)
+            active[m] = 1
+            ab.set_active(active)
+        rc, _ = ab.run_cohorts(dfar[t:t + 1], d[t:t + 1].transpose(0, 1), np.zeros(ab.n_cohorts, np.int32))
+        assert rc == 0
+        # no room to report: the pair is proposed and checked again and again, and never merged
+        assert L_.wmx_aec_coalesce(ab._h, 4, None, None, 0, C.byref(n), torch.cuda.current_stream().cuda_stream) == 0 and n.value == 0
+    assert ab.live_cohorts() == 2
+    k0, k1 = ab.cohort_key(0), ab.cohort_key(1)
+    assert k0 is not None and np.array_equal(k0, k1)  # two packets apart: the same phase of the re-blocking
+    merged = []
+    for _ in range(4):
+        merged += ab.coalesce(4)
+        torch.cuda.synchronize()
+    assert merged == [(1, 0)] and ab.live_cohorts() == 1 and ab.n_cohorts == 1
+    ab.close()
