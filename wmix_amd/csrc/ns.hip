@@ -381,10 +381,9 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
                     delta = div_ordinary(40.f * 1.f, dens);
                 else
                     delta = 40.f;
-                if (lm > lq)
-                    lq += div_ordinary(0.25f * delta, c1);
-                else
-                    lq -= div_ordinary((1.f - 0.25f) * delta, c1);
+                // lq += 0.25 delta / c1  or  lq -= 0.75 delta / c1 (ns_core.c:247-253) as ONE division: a quotient changes sign with its
+                // numerator and nothing else, and x - y is x + (-y): same bits, one correction sequence instead of two
+                lq += div_ordinary(lm > lq ? 0.25f * delta : -((1.f - 0.25f) * delta), c1);
                 if (fabsf(lm - lq) < 0.01f) {
                     dens = div_ordinary(cf * dens + 1.f / (2.f * 0.01f), c1);
                     if (ok) ST(Y::DENSITY + q * Y::MP + b) = dens;
