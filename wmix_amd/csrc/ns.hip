@@ -211,7 +211,9 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         if (!all_new) o = ST(Y::IN_BUF + (is_old ? i + B : 0));
         if (!all_old) n = in[(is_old ? 0 : i - KEEP) * chn];
         buf[k] = is_old ? o : (float)n;
-        synt[k] = ST(Y::SYNT_BUF + i);
+        // syntBuf: its first KEEP samples carry the overlap, the rest is the zeros UpdateBuffer shifted in (ns_core.c:855-873): known, not
+        // stored, not read -- 1 280 bytes per frame less traffic together with the store below
+        synt[k] = (64 * k < KEEP && i < KEEP) ? ST(Y::SYNT_BUF + (i < KEEP ? i : 0)) : 0.f;
         hb[k] = 0.f;
         if (chn == 2) {
             if (!all_new) oh = ST(Y::HB_BUF + (is_old ? i + B : 0));
@@ -244,9 +246,14 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
     wave_sync();  // other lanes' stores below overwrite what this lane just loaded: keep the compiler from interleaving them
 #pragma unroll
     for (int k = 0; k < NT; k++) {
+        // only what the NEXT frame reads back: its KEEP old samples are this buffer's last KEEP (positions >= B); the first B stay
+        // whatever they were -- 640 bytes per frame that the kernel, which runs at three quarters of the device-copy rate, need not write
         const int i = lane + 64 * k;
-        ST(Y::IN_BUF + i) = buf[k];
-        if (chn == 2) ST(Y::HB_BUF + i) = hb[k];
+        if (64 * k + 63 < B) continue;  // a compile-time fact per group
+        if (i >= B) {
+            ST(Y::IN_BUF + i) = buf[k];
+            if (chn == 2) ST(Y::HB_BUF + i) = hb[k];
+        }
     }
     // window + energy (ns_core.c:1071-1072 / 1241-1242)
 #pragma unroll
@@ -393,7 +400,9 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             }
             if (updates < kStartupLong) quant = fast_exp(lq, K.lm);  // lq of the last estimator
             if (ok) {
-                ST(Y::QUANTILE + b) = quant;
+                // the noise quantile changes in a stream's first 200 frames and then when one of the three staggered counters comes
+                // round (3 frames in 200): the other frames need not store what they loaded
+                if (updates < kStartupLong || cnt0 >= kStartupLong || cnt1 >= kStartupLong || cnt2 >= kStartupLong) ST(Y::QUANTILE + b) = quant;
                 W.noise[b] = quant;
             }
         }
@@ -865,11 +874,6 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         // HB output: the OLDEST block of the (already slid) high-band buffer, times the gain (zero-energy frames pass
         // it through unscaled, ns_core.c:1255-1265)
         if (chn == 2) W.fa[i] = zero_frame ? sat16f(hb[k]) : sat16f(hb_gain * hb[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < NT; k++) {
-        const int i = lane + 64 * k;
-        if (i >= L - B) ST(Y::SYNT_BUF + i) = 0.f;
     }
     wave_sync();
     // interleave + (int16_t) cast (src/webrtc.c:640-642).  Samples beyond the core's block length (32 kHz: 160..319)
