@@ -926,7 +926,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 80 ? 
             const int lo = (int)(int16_t)(w & 0xffffu) >> reduce, hi = (int)(int16_t)(w >> 16) >> reduce;
             return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16);
         };
-        if (live && it == 0) {
+        if (live && it == 0 && reduce != 0) {  // (>> 0 leaves the packet as it is, and vad_process works in place: nothing to fetch or store)
             // the packet is fetched a second time (L2) rather than held in 80 registers across the two barriers: the
             // kernel's register count decides how many workgroups share a CU
             constexpr int NVC = NV < 20 ? NV : 20;  // at most 20 uint4 (80 registers) in flight: a 20 ms packet at 16 kHz goes in two halves
