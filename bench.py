@@ -70,6 +70,20 @@ class G711Workload:
     def config(self):
         return {"workload": self.name, "frames_per_step_per_gpu": self.n_frames, "frame": "80 x int16 (10 ms @ 8 kHz mono)"}
 
+    def parity_check(self):
+        """EVERY code and EVERY decoded sample of the last step against oracle/orc_g711.c (stateless: each step writes the same
+        buffers from the same input), both laws of the round trip timed; bit-exact is the bar."""
+        from oracle import loader
+        port = loader.port()
+        pcm = np.ascontiguousarray(self.pcm.cpu().numpy())
+        want_code, want_back = np.zeros(pcm.size, np.uint8), np.zeros(pcm.size, np.int16)
+        assert port.orc_PCM2G711u(C.c_void_p(pcm.ctypes.data), C.c_void_p(want_code.ctypes.data), pcm.size * 2, 0) == pcm.size
+        assert port.orc_G711u2PCM(C.c_void_p(want_code.ctypes.data), C.c_void_p(want_back.ctypes.data), pcm.size, 0) == pcm.size * 2
+        bad_c = int((self.code.cpu().numpy() != want_code).sum())
+        bad_p = int((self.back.cpu().numpy() != want_back).sum())
+        return {"frames": self.n_frames, "samples_compared": 2 * int(pcm.size), "codes_differing": bad_c, "decoded_differing": bad_p,
+                "max_lsb": 0 if bad_c + bad_p == 0 else 1 << 15, "oracle": "oracle/orc_g711.c (port), every sample of the step"}
+
     def cpu_baseline(self, budget_s):
         from oracle import loader
         port = loader.port()
@@ -145,20 +159,41 @@ class NsWorkload:
         from wmix_amd import synth
         from wmix_amd.ns import NsBatch
         self.n_frames = n_streams
-        self.K = 8
+        # one full gate period of the SURVEY 8d recipe (noise + a tone gated every 100 frames), 256 distinct streams, tiled
+        self.K = 200
         base = synth.ns_input(2000 + 7919 * rank, 256, self.K, self.pkt).reshape(256, self.K, self.pkt)
-        reps = (n_streams + 255) // 256
-        x = np.tile(base, (reps, 1, 1))[:n_streams].transpose(1, 0, 2)  # [K, S, pkt] packet-major
-        self.inp = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        self.base = base
+        b = torch.from_numpy(np.ascontiguousarray(base.transpose(1, 0, 2))).to(dev)  # [K, 256, pkt]
+        self.inp = b[:, torch.arange(n_streams, device=dev) % 256]                     # [K, S, pkt] packet-major
         self.work = torch.empty_like(self.inp[0:1])
         self.ns = NsBatch(n_streams, 1, self.freq, ordered=True)
         self.t = _StageTimer("ns")
         self.k = 0
+        self.sample = [int(i) for i in np.linspace(0, n_streams - 1, 16)]
+        self.rec = []
 
     def step(self, timed):
         k = self.k % self.K
-        self.k += 1
         self.t.run("ns", timed, lambda: self.ns.process_packet_major(self.inp[k:k + 1], self.work))
+        if timed is not True:  # outside the timed region: keep what the sampled streams produced, for parity_check()
+            self.rec.append((self.k, self.work[0, self.sample].clone()))
+        self.k += 1
+
+    def parity_check(self):
+        """Replays 16 sampled streams through the oracle's NS for exactly the packets this run fed and compares every packet
+        recorded outside the timed region (those behind it depend on every timed step through the noise model).  Float path:
+        +-1 LSB is the bar; the ordered mode is observed bit-exact."""
+        from oracle import loader
+        port = loader.port()
+        worst, n, n_off = 0, 0, 0
+        for col, s in enumerate(self.sample):
+            x = np.concatenate([self.base[s % 256, k % self.K] for k in range(self.k)])
+            want = loader.run_ns(port, 1, self.freq, x, self.pkt, prefix="orc").reshape(self.k, self.pkt)
+            for k, got in self.rec:
+                d = np.abs(got[col].cpu().numpy().astype(np.int32) - want[k].astype(np.int32))
+                worst, n, n_off = max(worst, int(d.max())), n + 1, n_off + int((d > 0).sum())
+        return {"streams": len(self.sample), "packets_compared": n, "max_lsb": worst, "samples_off_by_one": n_off,
+                "oracle": "oracle/orc_ns.c (port)", "steps_replayed": self.k}
 
     def dominant_ms(self):
         return self.t.dominant_ms()
@@ -168,13 +203,15 @@ class NsWorkload:
 
     def config(self):
         return {"workload": self.name, "streams_per_gpu": self.n_frames, "frame": "160 x int16 (10 ms @ 16 kHz mono)",
-                "sum_order": "reference (bit-exact mode)"}
+                "sum_order": "reference (bit-exact mode)",
+                "input": "noise A=3000 + 3000 sin(0.01 t) gated every 100 frames (SURVEY 8d recipe), 256 distinct streams x %d "
+                         "packets, tiled" % self.K}
 
     def cpu_baseline(self, budget_s):
         from oracle import loader
         port = loader.port()
         n = 3000
-        x = np.ascontiguousarray(self.inp[:, 0].cpu().numpy().reshape(-1))
+        x = np.ascontiguousarray(self.base[0].reshape(-1))
         x = np.tile(x, n // self.K + 1)[: n * self.pkt]
         reps, v1, nc, vn = _cpu_rates(lambda: loader.run_ns(port, 1, self.freq, x, self.pkt, prefix="orc"), n, budget_s)
         return {"value": v1, "unit": "frames/s", "cores": 1, "kind": "port", "all_cores_value": vn, "all_cores": nc, "cpu_model": _cpu_model(),
@@ -539,7 +576,25 @@ class MfftWorkload:
         self.t = _StageTimer("fftr")
 
     def step(self, timed):
-        self.t.run("fftr", timed, lambda: self.mfft.transform(1, self.x, None, want="a"))
+        self.out = self.t.run("fftr", timed, lambda: self.mfft.transform(1, self.x, None, want="a"))
+
+    def parity_check(self):
+        """64 sampled transforms of the last step against oracle/orc_mfft.c, the amplitude curve bit for bit (the transform is
+        stateless: every step computes the same curves from the same input)."""
+        from oracle import loader
+        port = loader.port()
+        rows = [int(i) for i in np.linspace(0, self.n_frames - 1, 64)]
+        got = self.out["a"][rows].cpu().numpy()
+        x = self.x[rows].cpu().numpy()
+        bad, worst = 0, 0.0
+        for i in range(len(rows)):
+            want = loader.mfft(port, 1, x[i], None, self.N, prefix="orc", want="a")["a"]
+            neq = got[i].view(np.uint32) != want.view(np.uint32)
+            bad += int(neq.sum())
+            if neq.any():
+                worst = max(worst, float(np.abs(got[i] - want).max()))
+        return {"transforms": len(rows), "values_compared": len(rows) * self.N, "values_differing": bad, "max_abs_diff": worst,
+                "max_lsb": 0 if bad == 0 else 1, "oracle": "oracle/orc_mfft.c (port), float32 bit patterns"}
 
     def dominant_ms(self):
         return self.t.dominant_ms()
@@ -855,7 +910,8 @@ class NsAgcMix32kWorkload:
             tone = 6000 * np.sin(2 * np.pi * (150 + 31 * s) * t / 32000)
             base[s, :, 0] = np.clip(tone + rng.integers(-2000, 2000, t.size), -32768, 32767)
             base[s, :, 1] = base[s, :, 0] // 3
-        x = np.tile(base.reshape(64, self.K, per), (S // 64 + 1, 1, 1))[:S].transpose(1, 0, 2)
+        self.base = base.reshape(64, self.K, per)
+        x = np.tile(self.base, (S // 64 + 1, 1, 1))[:S].transpose(1, 0, 2)
         self.inp = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
         self.flat = torch.zeros(S * per + 2, dtype=torch.int16, device=dev)  # + the mixer's 2-sample look-ahead
         self.work = self.flat[: S * per].view(1, S, per)
@@ -864,9 +920,14 @@ class NsAgcMix32kWorkload:
         self.mix = MixBatch(S // self.N, 1, 8000)
         self.t = _StageTimer("ns")
         self.k = 0
+        # parity: 4 mix groups (their 32 sources) watched outside the timed region
+        self.groups = sorted({int(g) for g in np.linspace(0, S // self.N - 1, 4)})
+        self.watch = [g * self.N + i for g in self.groups for i in range(self.N)]
+        self.rec = []
 
     def step(self, timed):
         k = self.k % self.K
+        step_index = self.k
         self.k += 1
         S = self.n_frames
         self.t.run("ns", timed, lambda: self.ns.process_packet_major(self.inp[k:k + 1], self.work))
@@ -877,13 +938,42 @@ class NsAgcMix32kWorkload:
             self.mix.load(self.src, 1280, 32000, 2)
             self.mix.set(3200, 0, 1)
             return self.mix.drain(160)
-        self.t.run("mix", timed, mix)
+        out = self.t.run("mix", timed, mix)
+        if timed is not True:
+            self.rec.append((step_index, self.work[0, self.watch].clone(), out[self.groups].clone()))
 
     def dominant_ms(self):
         return self.t.dominant_ms()
 
     def stage_ms(self):
         return {k: self.t.mean_ms(k) for k in ("ns", "agc", "mix")}
+
+    def parity_check(self):
+        """The 32 sources of 4 sampled mix groups replayed through the oracle's NS + AGC (2 x 32 kHz, R channel = high band,
+        5 ms AGC packets) for exactly the packets fed; every packet recorded outside the timed region is compared, and so is the
+        group's drained 10 ms of the 8 kHz ring against oracle/orc_mix.c fed with the ORACLE's source packets in call order
+        (saturating accumulate).  NS float path: +-1 LSB is the bar (bit-exact observed); AGC and mix are integer."""
+        from oracle import loader
+        port = loader.port()
+        per, N = 640, self.N
+        want = {}
+        z = np.zeros(self.k * per, np.int16)
+        for s in self.watch:
+            x = np.concatenate([self.base[s % 64, k % self.K] for k in range(self.k)])
+            want[s] = loader.run_chain(port, 2, 32000, 5, 1 | 4, z, x, 320, prefix="orc").reshape(self.k, per)
+        worst, worst_mix, n, n_mix = 0, 0, 0, 0
+        for k, pcm, drained in self.rec:
+            pcm, drained = pcm.cpu().numpy(), drained.cpu().numpy()
+            for col, s in enumerate(self.watch):
+                worst, n = max(worst, int(np.abs(pcm[col].astype(np.int32) - want[s][k].astype(np.int32)).max())), n + 1
+            for gi, g in enumerate(self.groups):
+                flat = np.concatenate([want[g * N + i][k] for i in range(N)] + [np.zeros(2, np.int16)])
+                ring, _ = loader.mix_load(port, 1, 8000, 32000, 2, 1, 1, N, per * 2, 0, flat)
+                worst_mix = max(worst_mix, int(np.abs(drained[gi].astype(np.int32) - ring[1600:1680].astype(np.int32)).max()))
+                n_mix += 1
+        return {"sources": len(self.watch), "packets_compared": n, "max_lsb": max(worst, worst_mix), "max_lsb_ns_agc": worst,
+                "mix_groups": len(self.groups), "drains_compared": n_mix, "max_lsb_mix": worst_mix,
+                "oracle": "oracle/orc_ns.c + orc_agc.c per source, orc_mix.c per group (port)", "steps_replayed": self.k}
 
     def config(self):
         return {"workload": self.name, "sources_per_gpu": self.n_frames, "mix_groups": self.n_frames // self.N,
@@ -1100,6 +1190,99 @@ def _launch_ranks(n, argv):
     return 0
 
 
+# BASELINE.json configs[0], [1], [3], [4] as (workload, streams per GPU): the default line (configs[2]) carries a short run of each
+SIDE_CONFIGS = [("configs[0]", "g711"), ("configs[1]", "ns"), ("configs[3]", "ns_aec_8k"), ("configs[4]", "ns_agc_mix_32k")]
+
+
+def _make_workload(cls, dev, n_mine, rank, dist, args, lo=0):
+    if issubclass(cls, ChainWorkload):
+        return cls(dev, n_mine, rank, dist, args.packets_per_step, args.interval_ms, args.cohorts, args.cohort_layout, args.coalesce)
+    if issubclass(cls, StubCpuWorkload):
+        return cls(dev, n_mine, rank, dist, args.packets_per_step, lo)
+    if issubclass(cls, AecmWorkload):
+        return cls(dev, n_mine, rank, dist, args.packets_per_step)
+    return cls(dev, n_mine, rank)
+
+
+def _side_config(label, name, args, dev):
+    """One of the other BASELINE configs, measured like the headline (same --steps / --warmup / --prime / --spinup, HIP events
+    around the timed steps, the dominant kernel bracketed by its own events) and proven in the same run: parity_check replays
+    sampled streams through the oracle for exactly the packets fed.  One GPU, no CPU baseline (the workload's own line has it)."""
+    import copy
+    cls, n = WORKLOADS[name]
+    a = copy.copy(args)
+    a.packets_per_step, a.interval_ms, a.cohorts, a.cohort_layout, a.coalesce = 1, 10, 1, "arrival", False
+    t_start = time.perf_counter()
+    wl = _make_workload(cls, dev, n, 0, None, a)
+
+    def sync():
+        torch.cuda.synchronize()
+    n_prime, elapsed, _ = _measure(wl, a, True, sync)
+    for _ in range(min(a.steps, 16)):
+        wl.step("all")
+    sync()
+    dom_ms = wl.dominant_ms()
+    frac = None
+    if dom_ms:
+        frac = wl.dominant_bytes_per_frame * wl.n_frames / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    parity = wl.parity_check()
+    entry = {"config": label, "workload": wl.name, "streams": n, "value": wl.n_frames * a.steps / elapsed, "unit": "frames/s",
+             "ms_per_step": elapsed / a.steps * 1e3, "steps": a.steps, "warmup": a.warmup, "primed_steps": n_prime, "dtype": wl.dtype,
+             "roofline": {"kernel": wl.dominant_kernel, "frac": round(frac, 5) if frac else None,
+                          "avg_launch_ms": round(dom_ms, 5) if dom_ms else None,
+                          "algorithmic_bytes_per_launch": wl.dominant_bytes_per_frame * wl.n_frames},
+             "whole_step_hbm_frac": round(wl.n_frames * a.steps / elapsed * wl.bytes_per_frame / 1e9 / HBM_PEAK_GBS, 5),
+             "parity_checked": parity, "wall_s": None}
+    for attr in ("chain", "ns", "agc", "mix", "nsx", "aecm"):  # the batch handles give their HBM back before the next config
+        h = getattr(wl, attr, None)
+        if h is not None and hasattr(h, "close"):
+            h.close()
+    del wl
+    torch.cuda.empty_cache()
+    entry["wall_s"] = round(time.perf_counter() - t_start, 2)
+    return entry
+
+
+def _measure(wl, args, on_gpu, sync_all):
+    """Priming, warm-up, spin-up and the K timed steps of one workload on this rank.  Returns (primed steps, seconds of the
+    timed region on the device, seconds on the host's clock)."""
+    n_prime = args.prime + (wl.min_prime() if hasattr(wl, "min_prime") else 0)
+    for _ in range(n_prime + args.warmup):
+        wl.step(False)
+    sync_all()
+    # The launch loop is Python: a generation-2 pass of its garbage collector stops the host for ~36 ms (seen at a fixed
+    # step of the loop, tools_dev/chain_steps.py) while the GPU runs dry -- 3 % of a 1 000-step region, none of it the
+    # measured work.  Collect now, keep the collector off for the timed steps.
+    import gc
+    gc.collect()
+    gc.disable()
+    # The barrier + synchronize above (and the one below) bracket the region as the contract asks, but they also leave the
+    # device empty and clocked down: a short region started cold measures the ramp, not the path (round 2: 20 steps read 13 %
+    # slower than 1 000).  So `--spinup` untimed steps are queued first, WITHOUT a synchronisation behind them, and the K timed
+    # steps are bracketed by two HIP events recorded in the launch stream: ms_per_step is the device time between them --
+    # exactly K steps, on a device that is already busy.  The host's wall clock over the same K steps is reported beside it.
+    on_events = on_gpu
+    for _ in range(args.spinup if on_gpu else 0):
+        wl.step(False)
+    if hasattr(wl, "timed_region"):
+        wl.timed_region(True)
+    if on_events:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step(True)
+    if on_events:
+        ev1.record()
+    sync_all()
+    host_elapsed = time.perf_counter() - t0
+    gc.enable()
+    elapsed = ev0.elapsed_time(ev1) * 1e-3 if on_events else host_elapsed
+    if hasattr(wl, "timed_region"):
+        wl.timed_region(False)
+    return n_prime, elapsed, host_elapsed
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1135,6 +1318,9 @@ def main():
                          "region starts on a busy device at its working clock (a 20-step region then reads like a 1000-step one)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="default workload on one GPU: leave out the `configs` block (short runs of BASELINE configs[0], [1], [3], [4], "
+                         "each with its own in-run parity proof)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -1196,14 +1382,7 @@ def main():
         if dist is not None and backend == "nccl":
             assert torch.cuda.current_device() == local_rank, "rank %d: current device %d, LOCAL_RANK %d" % (rank, torch.cuda.current_device(), local_rank)
             assert dist.get_world_size() == world, "RCCL sees %d ranks, the launcher started %d" % (dist.get_world_size(), world)
-    if issubclass(cls, ChainWorkload):
-        wl = cls(dev, n_mine, rank, dist, args.packets_per_step, args.interval_ms, args.cohorts, args.cohort_layout, args.coalesce)
-    elif issubclass(cls, StubCpuWorkload):
-        wl = cls(dev, n_mine, rank, dist, args.packets_per_step, lo)
-    elif issubclass(cls, AecmWorkload):
-        wl = cls(dev, n_mine, rank, dist, args.packets_per_step)
-    else:
-        wl = cls(dev, n_mine, rank)
+    wl = _make_workload(cls, dev, n_mine, rank, dist, args, lo)
 
     def sync_all():
         if on_gpu:
@@ -1213,40 +1392,7 @@ def main():
         if on_gpu:
             torch.cuda.synchronize()
 
-    n_prime = args.prime + (wl.min_prime() if hasattr(wl, "min_prime") else 0)
-    for _ in range(n_prime + args.warmup):
-        wl.step(False)
-    sync_all()
-    # The launch loop is Python: a generation-2 pass of its garbage collector stops the host for ~36 ms (seen at a fixed
-    # step of the loop, tools_dev/chain_steps.py) while the GPU runs dry -- 3 % of a 1 000-step region, none of it the
-    # measured work.  Collect now, keep the collector off for the timed steps.
-    import gc
-    gc.collect()
-    gc.disable()
-    # The barrier + synchronize above (and the one below) bracket the region as the contract asks, but they also leave the
-    # device empty and clocked down: a short region started cold measures the ramp, not the path (round 2: 20 steps read 13 %
-    # slower than 1 000).  So `--spinup` untimed steps are queued first, WITHOUT a synchronisation behind them, and the K timed
-    # steps are bracketed by two HIP events recorded in the launch stream: ms_per_step is the device time between them --
-    # exactly K steps, on a device that is already busy.  The host's wall clock over the same K steps is reported beside it.
-    on_events = on_gpu
-    for _ in range(args.spinup if on_gpu else 0):
-        wl.step(False)
-    if hasattr(wl, "timed_region"):
-        wl.timed_region(True)
-    if on_events:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wl.step(True)
-    if on_events:
-        ev1.record()
-    sync_all()
-    host_elapsed = time.perf_counter() - t0
-    gc.enable()
-    elapsed = ev0.elapsed_time(ev1) * 1e-3 if on_events else host_elapsed
-    if hasattr(wl, "timed_region"):
-        wl.timed_region(False)
+    n_prime, elapsed, host_elapsed = _measure(wl, args, on_gpu, sync_all)
     per_rank_ms = [elapsed / args.steps * 1e3]
     per_rank_frames = [wl.n_frames]
     rank_devices = [rank_device]
@@ -1331,6 +1477,20 @@ def main():
             out["cpu_baseline"] = wl.cpu_baseline(args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
+        plain = (args.packets_per_step, args.interval_ms, args.cohorts, args.coalesce, args.streams, args.total_streams) == (1, 10, 1, False, 0, 0)
+        if world == 1 and dist is None and on_gpu and args.workload == DEFAULT_WORKLOAD and plain and not args.no_configs:
+            # the other four BASELINE configs on the same line, each measured and proven in this very run; the headline's
+            # handles are released first (the 8 kHz config alone holds 131 072 streams of state)
+            wl.chain.close()
+            del wl
+            torch.cuda.empty_cache()
+            out["configs"] = [_side_config(label, name, args, dev) for label, name in SIDE_CONFIGS]
+            # the same entries, cut down to what fits any truncation of the line, inside `config`
+            out["config"]["configs"] = [{"config": e["config"], "workload": e["workload"], "streams": e["streams"],
+                                         "value": round(e["value"], 1), "ms_per_step": round(e["ms_per_step"], 5),
+                                         "kernel": e["roofline"]["kernel"], "frac": e["roofline"]["frac"],
+                                         "avg_launch_ms": e["roofline"]["avg_launch_ms"],
+                                         "parity_max_lsb": e["parity_checked"].get("max_lsb")} for e in out["configs"]]
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:

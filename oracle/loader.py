@@ -292,6 +292,43 @@ def mfft_stream(lib, chunks, st_len, prefix="ref"):
     return stream, afs, pfs
 
 
+# ---------------------------------------------------------------- resample + mix (restatement, in-process)
+class MixRing(C.Structure):  # orc_mix_ring (oracle/orc_mix.h)
+    _fields_ = [("chn", C.c_int), ("freq", C.c_int), ("size", C.c_uint32), ("buff", C.c_void_p), ("head_off", C.c_uint32),
+                ("tick", C.c_uint32), ("reduce_mode", C.c_uint8), ("play_correct", C.c_uint32)]
+
+
+def mix_bind(p):
+    for n in ("orc_len_of_out", "orc_len_of_in", "orc_pcm_zoom", "orc_load_data"):
+        getattr(p, n).restype = C.c_uint32
+
+
+def mix_zoom(p, ic, ifr, x, oc, ofr):
+    """orc_pcm_zoom of one int16 buffer: the bytes wmix_pcm_zoom would write, as int16."""
+    mix_bind(p)
+    out = np.zeros(x.size * 16 + 64, np.int16)
+    m = p.orc_pcm_zoom(ic, ifr, x.ctypes.data_as(C.c_void_p), x.size * 2, oc, ofr, out.ctypes.data_as(C.c_void_p))
+    return out[: m // 2].copy()
+
+
+def mix_load(p, ring_chn, ring_freq, freq, chn, rmode, rarg, nsrc, sbytes, start, src):
+    """nsrc wmix_load_data calls in order (source i at src + i * sbytes bytes, each with a fresh head) into one fresh ring whose
+    head stands at byte `start`.  Returns (the ring as int16, [(tick, head) after each call])."""
+    mix_bind(p)
+    size = ring_chn * 2 * ring_freq
+    store = np.zeros(size + 64, np.uint8)
+    r = MixRing()
+    p.orc_mix_ring_init(C.byref(r), store.ctypes.data_as(C.c_void_p), ring_chn, ring_freq)
+    r.head_off, r.reduce_mode = start, rmode
+    meta = []
+    for i in range(nsrc):
+        tick = C.c_uint32(0)
+        h = p.orc_load_data(C.byref(r), C.c_void_p(src.ctypes.data + i * sbytes), sbytes, freq, chn, 16, C.c_uint32(0xFFFFFFFF), rarg,
+                            C.byref(tick))
+        meta.append((tick.value, h))
+    return store[:size].view(np.int16).copy(), np.array(meta, np.uint32)
+
+
 # ---------------------------------------------------------------- reference mixer (executable)
 def ref_mix(*args, stdin=b""):
     return subprocess.run([REF_MIX] + [str(a) for a in args], input=stdin, stdout=subprocess.PIPE, check=True).stdout

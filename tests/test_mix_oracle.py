@@ -16,35 +16,7 @@ from make_mix_golden import LOAD_CASES, ZOOM_CASES, load_input, zoom_input  # no
 G = np.load(os.path.join(GOLDEN, "mix_golden.npz"))
 
 
-class Ring(C.Structure):  # orc_mix_ring
-    _fields_ = [("chn", C.c_int), ("freq", C.c_int), ("size", C.c_uint32), ("buff", C.c_void_p), ("head_off", C.c_uint32),
-                ("tick", C.c_uint32), ("reduce_mode", C.c_uint8), ("play_correct", C.c_uint32)]
-
-
-def _bind(p):
-    for n in ("orc_len_of_out", "orc_len_of_in", "orc_pcm_zoom", "orc_load_data"):
-        getattr(p, n).restype = C.c_uint32
-
-
-def orc_zoom(p, ic, ifr, x, oc, ofr):
-    out = np.zeros(x.size * 16 + 64, np.int16)
-    m = p.orc_pcm_zoom(ic, ifr, x.ctypes.data_as(C.c_void_p), x.size * 2, oc, ofr, out.ctypes.data_as(C.c_void_p))
-    return out[: m // 2].copy()
-
-
-def orc_load(p, ring_chn, ring_freq, freq, chn, rmode, rarg, nsrc, sbytes, start, src):
-    size = ring_chn * 2 * ring_freq
-    store = np.zeros(size + 64, np.uint8)
-    r = Ring()
-    p.orc_mix_ring_init(C.byref(r), store.ctypes.data_as(C.c_void_p), ring_chn, ring_freq)
-    r.head_off, r.reduce_mode = start, rmode
-    meta = []
-    for i in range(nsrc):
-        tick = C.c_uint32(0)
-        h = p.orc_load_data(C.byref(r), C.c_void_p(src.ctypes.data + i * sbytes), sbytes, freq, chn, 16, C.c_uint32(0xFFFFFFFF), rarg,
-                            C.byref(tick))
-        meta.append((tick.value, h))
-    return store[:size].view(np.int16).copy(), np.array(meta, np.uint32)
+Ring, _bind, orc_zoom, orc_load = L.MixRing, L.mix_bind, L.mix_zoom, L.mix_load  # the helpers live beside the other oracle drivers
 
 
 @pytest.mark.parametrize("i", range(len(ZOOM_CASES)))
