@@ -156,16 +156,28 @@ int wmx_vad_import_stream(wmx_vad *h, int stream_index, const void *host_blob);
  * src/webrtc.c:694-860): target 0 dBFS, compression gain `value` dB, limiter off.  Channels are
  * averaged to mono, processed as one band and duplicated back.  Packet = 10 ms (5 ms at 32 kHz,
  * SURVEY.md section 0 quirk 4).  `value` outside the reference's gain-table range makes create/set_gain
- * fail with WMX_EINVAL (agc_init returns NULL there).  Integer path: bit-exact. */
+ * fail with WMX_EINVAL (agc_init returns NULL there).  Integer path: bit-exact.
+ *
+ * The compression gain is PER STREAM, as it is per handle in the reference (agc_init's `value`, agc_addition(fp, value);
+ * the daemon: src/wmix.c:684, 1068-1070): wmx_agc_create / wmx_agc_set_gain give every stream of the batch one value;
+ * wmx_agc_set_gain_streams is agc_addition for the listed streams (state untouched, new gain curve from the next packet on),
+ * wmx_agc_reset_streams_gain is agc_release + agc_init(.., value, ..) for them; wmx_agc_reset_streams re-creates a stream
+ * with the gain it has.  One 32-entry table per distinct value in use; a batch whose streams all share one value runs
+ * the same kernels as before.  The value travels with wmx_agc_export_stream / _import_stream. */
 typedef struct wmx_agc wmx_agc;
 int wmx_agc_create(wmx_agc **out, int n_streams, int chn, int freq, int interval_ms, int value);
 int wmx_agc_destroy(wmx_agc *h);
-int wmx_agc_set_gain(wmx_agc *h, int value); /* agc_addition for every stream of the batch */
+int wmx_agc_set_gain(wmx_agc *h, int value); /* agc_addition for every stream of the batch (blocking) */
+/* idx: HOST array of n stream indices; ordered on `stream` like the process calls around it.  A value the reference's
+ * WebRtcAgc_set_config refuses -> WMX_EINVAL, nothing changed. */
+int wmx_agc_set_gain_streams(wmx_agc *h, const int32_t *idx, int n, int value, void *stream);
+int wmx_agc_reset_streams_gain(wmx_agc *h, const int32_t *idx, int n, int value, void *stream);
+int wmx_agc_stream_gain(const wmx_agc *h, int stream_index); /* the compression gain stream i runs with */
 int wmx_agc_packet_samples(const wmx_agc *h);
-int wmx_agc_gain_table(const wmx_agc *h, int32_t *host_table32); /* the 32 Q16 gains in use (tests) */
+int wmx_agc_gain_table(const wmx_agc *h, int32_t *host_table32); /* the 32 Q16 gains of the batch's own value (tests) */
 int wmx_agc_process(wmx_agc *h, const int16_t *d_in, int16_t *d_out, int n_packets, long stream_stride,
                     long packet_stride, void *stream);
-int wmx_agc_reset_streams(wmx_agc *h, const int32_t *idx, int n, void *stream); /* the gain table is the batch's */
+int wmx_agc_reset_streams(wmx_agc *h, const int32_t *idx, int n, void *stream); /* each stream keeps its gain */
 int wmx_agc_set_active(wmx_agc *h, const uint8_t *host_mask, void *stream);
 int wmx_agc_stream_state_bytes(const wmx_agc *h);
 int wmx_agc_export_stream(wmx_agc *h, int stream_index, void *host_blob);
@@ -299,6 +311,11 @@ int wmx_chain_process(wmx_chain *h, const int16_t *d_far, long far_packet_stride
                       int32_t *cohort_rc, void *stream);
 int wmx_chain_reset_streams(wmx_chain *h, const int32_t *idx, int n, int cohort, void *stream);
 int wmx_chain_reset_cohort(wmx_chain *h, int cohort, void *stream);
+/* wmx_chain_reset_streams with agc_init's own `value` for the new handles (the daemon creates the AGC with the volumeAgc of
+ * that moment, src/wmix.c:684), and agc_addition for the listed streams of a running chain (src/wmix.c:1068-1070); a chain
+ * without an AGC stage ignores the value */
+int wmx_chain_reset_streams_gain(wmx_chain *h, const int32_t *idx, int n, int cohort, int agc_value, void *stream);
+int wmx_chain_set_agc_gain_streams(wmx_chain *h, const int32_t *idx, int n, int agc_value, void *stream);
 /* wmx_aec_add_cohort / wmx_aec_retire_cohort / wmx_aec_cohorts of the chain's AEC (a chain without one has a single cohort) */
 int wmx_chain_add_cohort(wmx_chain *h, int *cohort, void *stream);
 int wmx_chain_retire_cohort(wmx_chain *h, int cohort);

@@ -138,6 +138,39 @@ def run_agc(lib, chn, freq, value, pcm, frames_per_call, prefix="ref"):
     return out
 
 
+def run_agc_handle(lib, chn, freq, value, pcm, frames_per_call, additions=None, prefix="ref"):
+    """One AGC HANDLE driven call by call: agc_init(chn, freq, 10, value), then agc_process per call of frames_per_call frames,
+    with agc_addition(fp, v) in FRONT of call c for every (c, v) of `additions` (src/webrtc.c:694-753, 767-839).  prefix "ref":
+    the real wrapper functions of oracle/_ref/libwmixref.so; "orc": the restatement's handle API."""
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    out = np.empty_like(pcm)
+    per = frames_per_call * chn
+    n_calls = pcm.size // per
+    add = dict(additions or {})
+    vp = C.c_void_p
+    if prefix == "orc":
+        init = _fn(lib, "orc_agc_init", vp, [C.c_int, C.c_int, C.c_int, C.c_int])
+        run = _fn(lib, "orc_agc_run", C.c_int, [vp, vp, vp, C.c_int])
+        addf = _fn(lib, "orc_agc_addition", None, [vp, C.c_uint8])
+        rel = _fn(lib, "orc_agc_release", None, [vp])
+        h = init(chn, freq, 10, value)
+    else:
+        init = _fn(lib, "agc_init", vp, [C.c_int, C.c_int, C.c_int, C.c_int, vp])
+        run = _fn(lib, "agc_process", C.c_int, [vp, vp, vp, C.c_int])
+        addf = _fn(lib, "agc_addition", None, [vp, C.c_uint8])
+        rel = _fn(lib, "agc_release", None, [vp])
+        h = init(chn, freq, 10, value, None)
+    assert h, "agc_init returned NULL"
+    try:
+        for c in range(n_calls):
+            if c in add:
+                addf(h, int(add[c]))
+            assert run(h, pcm[c * per:].ctypes.data, out[c * per:].ctypes.data, frames_per_call) == 0
+    finally:
+        rel(h)
+    return out
+
+
 def run_vad(lib, chn, freq, interval_ms, pcm, frames_per_call, prefix="ref"):
     pcm = np.ascontiguousarray(pcm, dtype=np.int16)
     out = np.empty_like(pcm)

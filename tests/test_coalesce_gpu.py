@@ -188,10 +188,12 @@ def test_a_stream_of_a_folded_cohort_migrates_with_its_own_generator(cuda, oracl
             check_float_path(out[s, t0:].reshape(-1), want, max_fraction=1e-4)
 
 
-def test_a_stream_that_has_lived_for_hours_draws_from_far_out_in_the_noise_table(cuda, oracle_port):
-    """The comfort noise follows the stream's block count (AS_NBLK): a state imported with a count of 3.1 million blocks (3.4 hours at
-    16 kHz) makes the batch grow its table to that row, and the stream draws what a handle of the reference draws whose generator
-    stands there (oracle: the same run with aec->seed set to 777 advanced by 64 draws per block)."""
+def test_a_stream_that_has_lived_for_hours_keeps_its_own_noise_generator(cuda, oracle_port):
+    """The comfort-noise generator is part of the STREAM's state (AS_NSEED), as it is of the handle in the reference: a state imported
+    with a generator that stands 3.1 million blocks into its life (3.4 hours at 16 kHz) draws what a handle of the reference draws
+    whose generator stands there (oracle: the same run with aec->seed set to 777 advanced by 64 draws per block), while its
+    neighbours in the batch -- same cohort, same control plane -- draw from their own.  Nothing in the batch grows with a
+    stream's age (round-4 ADVICE: the table of rows that did is gone)."""
     from wmix_amd._lib import lib
     S, T, freq, pkt, R = 4, 300, 16000, 160, 3_100_003
     far = synth.far_end(8400, T, pkt).reshape(T, pkt)
@@ -203,8 +205,8 @@ def test_a_stream_that_has_lived_for_hours_draws_from_far_out_in_the_noise_table
     blob = ab.export_stream(2)
     hdr = blob.size - 4 * words
     w = blob[hdr:].view(np.uint32)
-    assert w[words - 5] == 0  # AS_NBLK = AS_SCAL + 11 of 16 scalar words at the end of the block: a new handle has processed nothing
-    w[words - 5] = R
+    assert w[words - 5] == 777  # AS_NSEED = AS_SCAL + 11 of 16 scalar words at the end of the block: aec->seed of a new handle
+    w[words - 5] = L.lcg_after_blocks(R)
     ab.import_stream(2, blob)
     rc, _ = ab.process2(dfar, d, delay_ms=0)
     assert rc == 0

@@ -147,6 +147,39 @@ def test_chain_lifetime_vs_per_handle_oracle(cuda, oracle_port):
     check_float_path(got, want, max_fraction=1e-4)
 
 
+def test_chain_agc_gain_per_stream(cuda, oracle_port):
+    """The daemon creates a record chain's AGC with the volumeAgc of that moment (agc_init(.., wmix->volumeAgc, ..), src/wmix.c:684)
+    and turns a running one with agc_addition (src/wmix.c:1068-1070): per handle.  In one chain batch the streams start with three
+    gains (wmx_chain_reset_streams_gain), a third of them is turned in mid-life (wmx_chain_set_agc_gain_streams), and every stream
+    equals the oracle chain of ITS gain history; the streams nobody touched equal the plain batch value."""
+    import torch
+    from wmix_amd.chain import ChainBatch
+    freq, S, n = 16000, 70, 300
+    pkt = freq // 100
+    far = synth.far_end(9400, n, pkt)
+    near = synth.near_end(9401, S, n, pkt, far=far).reshape(S, n, pkt)
+    sid = np.arange(S)
+    start = np.where(sid % 3 == 0, 5, np.where(sid % 3 == 1, 18, 33))
+    cb = ChainBatch(S, 1, freq, 10, 5)
+    cb.reset_streams_gain(sid[sid % 3 == 1], 18, cohort=0)
+    cb.reset_streams_gain(sid[sid % 3 == 2], 33, cohort=0)
+    turned = sid[sid % 4 == 1]
+    d = torch.from_numpy(near.transpose(1, 0, 2).copy()).to(cuda)  # [n, S, pkt]
+    dfar = torch.from_numpy(far.reshape(n, pkt).copy()).to(cuda)
+    for f in range(n):
+        if f == 150:
+            cb.set_agc_gain_streams(turned, 9)
+        rc, _, _ = cb.process_packet_major(dfar[f:f + 1], d[f:f + 1])
+        assert rc == 0
+    got = d.cpu().numpy().transpose(1, 0, 2).reshape(S, -1)
+    cb.close()
+    for s in range(0, S, 3):  # a sample of the streams through the oracle: NS -> AEC once, then the AGC handle with its history, then VAD
+        x = L.run_chain(oracle_port, 1, freq, 5, 3, far, near[s].reshape(-1), pkt, prefix="orc")
+        x = L.run_agc_handle(oracle_port, 1, freq, int(start[s]), x, pkt, {150: 9} if s in turned else None, prefix="orc")
+        want = L.run_vad(oracle_port, 1, freq, 10, x, pkt, prefix="orc")
+        check_float_path(got[s], want)
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_aec_random_schedules_vs_per_handle_oracle(cuda, oracle_port, seed):
     """Seeded random schedules: six cohorts with their own start packet and reported delay, streams leaving and coming back,

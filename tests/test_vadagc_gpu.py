@@ -102,6 +102,78 @@ def test_agc_many_streams_vs_oracle(cuda, oracle_port, chn, freq, value):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("chn,freq,packet_major", [(1, 16000, True), (1, 8000, False), (2, 32000, False), (2, 16000, True), (3, 16000, False)])
+def test_agc_gain_per_stream(cuda, oracle_port, chn, freq, packet_major):
+    """The compression gain is per handle in the reference (agc_init's value, agc_addition(fp, value): src/webrtc.c:694-753,
+    824-839; src/wmix.c:684, 1068-1070): streams of ONE batch run with three different gains from the start, two groups get an
+    agc_addition in mid-life (one of them twice, one back to the batch's own value), some are re-created with a gain of their
+    own -- and every stream equals its own per-handle oracle run, bit for bit."""
+    import torch
+    from wmix_amd.agc import AgcBatch
+    from wmix_amd._lib import WmxError
+    S, n, step = 150, 360, 40  # 150: a partially filled third wave
+    pkt = agc_pkg(freq)
+    x = np.stack([agc_input(chn, freq, n_calls=n, seed=1300 + 7 * s) for s in range(S)])
+    x[3] = 0
+    sid = np.arange(S)
+    v0 = np.where(sid % 3 == 0, 5, np.where(sid % 3 == 1, 20, 40))  # three gains from the first packet on
+    ab = AgcBatch(S, chn, freq, 5)
+    ab.reset_streams_gain(sid[sid % 3 == 1], 20)  # before the first packet: agc_init(.., 20, ..)
+    ab.reset_streams_gain(sid[sid % 3 == 2], 40)
+    ga, gb, gc = sid[sid % 5 == 1], sid[sid % 7 == 2], sid[sid % 11 == 4]
+    events = {120: [("add", ga, 30)], 200: [("add", gb, 0), ("add", ga, 5)], 280: [("reinit", gc, 12)]}
+    per = pkt * chn
+    if packet_major:
+        d = torch.from_numpy(np.ascontiguousarray(x.reshape(S, n, per).transpose(1, 0, 2))).to(cuda)
+    else:
+        d = torch.from_numpy(np.ascontiguousarray(x.reshape(S, n, per))).to(cuda)
+    for c in range(0, n, step):
+        for kind, who, v in events.get(c, []):
+            (ab.set_gain_streams if kind == "add" else ab.reset_streams_gain)(who, v)
+        if c == 200:
+            with pytest.raises(WmxError):
+                ab.set_gain_streams(ga, 200)  # WebRtcAgc_set_config refuses: agc_addition prints and nothing changes
+        (ab.process_packet_major(d[c:c + step]) if packet_major else ab.process(d[:, c:c + step]))
+    got = (d.cpu().numpy().transpose(1, 0, 2) if packet_major else d.cpu().numpy()).reshape(S, -1)
+    assert ab.stream_gain(int(ga[0])) == 5 and ab.stream_gain(int(gc[0])) == 12
+    for s in range(S):
+        adds, cuts = {}, [0]
+        for c, evs in sorted(events.items()):
+            for kind, who, v in evs:
+                if s in who:
+                    if kind == "add":
+                        adds[c] = v
+                    else:
+                        cuts.append(c)
+        # a re-created handle starts over at its cut with its own gain
+        lo = cuts[-1]
+        val = int(v0[s]) if lo == 0 else 12
+        adds = {c - lo: v for c, v in adds.items() if c >= lo}
+        want = L.run_agc_handle(oracle_port, chn, freq, val, x[s, lo * per:], pkt, adds, prefix="orc")
+        assert np.array_equal(got[s, lo * per:], want), (s, val, adds)
+        if lo:  # what the old handle produced until it was released
+            old = {c: v for c, v in ((c, v) for c, evs in events.items() for kind, who, v in evs if kind == "add" and s in who) if c < lo}
+            want0 = L.run_agc_handle(oracle_port, chn, freq, int(v0[s]), x[s, : lo * per], pkt, old, prefix="orc")
+            assert np.array_equal(got[s, : lo * per], want0), (s, "before the re-creation")
+    # export / import carries the gain: a stream moved into a fresh batch continues bit for bit
+    mover = int(gc[0])  # runs with 12 dB: a value the other batch has no table for yet
+    blob = ab.export_stream(mover)
+    other = AgcBatch(4, chn, freq, 9)
+    other.import_stream(2, blob)
+    assert other.stream_gain(2) == 12 and other.stream_gain(0) == 9
+    tail = agc_input(chn, freq, n_calls=50, seed=77).reshape(1, 50, per)
+    a = torch.from_numpy(np.repeat(tail, S, 0)).to(cuda)
+    b = torch.from_numpy(np.repeat(tail, 4, 0)).to(cuda)
+    ab.process(a)
+    other.process(b)
+    assert torch.equal(a[mover], b[2]) and not torch.equal(a[mover], b[1])
+    # one value for the whole batch again: back on the single-table kernels, same results as a batch that never had another
+    ab.set_gain(9)
+    assert all(ab.stream_gain(s) == 9 for s in (0, 1, 2, int(gc[0])))
+    other.close()
+    ab.close()
+
+
 def test_agc_addition_changes_the_table_like_the_reference(cuda, oracle_port):
     from wmix_amd.agc import AgcBatch
     from wmix_amd._lib import WmxError

@@ -154,3 +154,24 @@ def test_against_real_reference_long(oracle_port, oracle_ref):
         x = agc_input(chn, freq, n_calls=3000, seed=78)
         assert np.array_equal(L.run_agc(oracle_ref, chn, freq, value, x, agc_pkg(freq)),
                               L.run_agc(oracle_port, chn, freq, value, x, agc_pkg(freq), prefix="orc"))
+
+
+def test_agc_addition_in_mid_life_against_real_reference(oracle_port, oracle_ref):
+    """agc_addition on a RUNNING handle (src/webrtc.c:824-839; the daemon: src/wmix.c:1068-1070): the state stays, the gain table
+    changes from the next packet on.  The restatement's handle API against the real wrapper functions, call by call.  (A value
+    WebRtcAgc_set_config refuses, e.g. 200, cannot be put to the real library: built as shipped, without -DNDEBUG, it dies in
+    digital_agc.c:111 `assert(0)`; the restatement returns the error and keeps the old table, see the next test.)"""
+    for chn, freq, v0, adds in ((1, 16000, 5, {100: 30, 400: 0, 1000: 9}), (2, 32000, 40, {7: 3, 8: 60}),
+                                (1, 8000, 0, {0: 20, 1500: 90})):
+        x = agc_input(chn, freq, n_calls=2000, seed=81)
+        a = L.run_agc_handle(oracle_ref, chn, freq, v0, x, agc_pkg(freq), adds)
+        b = L.run_agc_handle(oracle_port, chn, freq, v0, x, agc_pkg(freq), adds, prefix="orc")
+        assert np.array_equal(a, b)
+        assert not np.array_equal(a, L.run_agc(oracle_port, chn, freq, v0, x, agc_pkg(freq), prefix="orc"))  # the additions did something
+
+
+def test_agc_addition_of_a_refused_value_keeps_the_old_table(oracle_port):
+    x = agc_input(1, 16000, n_calls=600, seed=82)
+    a = L.run_agc_handle(oracle_port, 1, 16000, 5, x, 160, {100: 30, 300: 200}, prefix="orc")
+    b = L.run_agc_handle(oracle_port, 1, 16000, 5, x, 160, {100: 30}, prefix="orc")
+    assert np.array_equal(a, b)

@@ -209,29 +209,25 @@ int main() {
             CHECK((seed >> 16) < (uint32_t)kAecNoiseTab);
             CHECK(tab[seed >> 16].c == cosf(tmp) && tab[seed >> 16].s == sinf(tmp));
         }
-        // AecNoiseRows: the state in front of row r -- 777 advanced by 64 r draws, composed from the 2^k-draw steps -- against the
-        // reference's recurrence draw by draw, over the first 3 000 rows and at rows far out (sequentially from a jumped start)
+        // the near kernel's generator: lane l's draw l (lane 0: draw 64) from the state in front of a block in ONE multiply-add, and the
+        // state moved on by the 64-draw step -- against the reference's recurrence draw by draw, over 3 000 blocks from 777 and from
+        // states far out
         {
-            uint32_t pow2[32][2];
-            aec_lcg_pow2(pow2);
-            uint32_t x = 777u;
-            for (uint32_t r = 0; r < 3000; r++) {
-                CHECK(aec_row_seed(r, pow2) == x);
-                for (int i = 0; i < 64; i++) x = (x * 69069u + 1u) & 0x7FFFFFFFu;
-            }
-            for (uint32_t r : {1u << 20, (1u << 25) - 5u, 12345678u}) {
-                uint32_t y = aec_row_seed(r, pow2);
-                for (uint32_t q = r; q < r + 4; q++) {
-                    CHECK(aec_row_seed(q & ((1u << 25) - 1), pow2) == y);  // the table's period: row 2^25 is row 0 again
-                    for (int i = 0; i < 64; i++) y = (y * 69069u + 1u) & 0x7FFFFFFFu;
+            uint32_t a[65], c[65];
+            for (int k = 1; k <= 64; k++) aec_lcg_jump(k, &a[k], &c[k]);
+            for (uint32_t start : {777u, 0x7FFFFFFFu, 0u, 123456789u}) {
+                uint32_t state = start, x = start;
+                for (int blk = 0; blk < 3000; blk++) {
+                    for (int k = 1; k <= 64; k++) {
+                        x = (x * 69069u + 1u) & 0x7FFFFFFFu;
+                        CHECK(((state * a[k] + c[k]) & 0x7FFFFFFFu) == x);
+                    }
+                    state = (state * a[64] + c[64]) & 0x7FFFFFFFu;
+                    CHECK(state == x);
                 }
             }
-            uint32_t z = 777u;  // and the full period really is 2^31 draws: 2^k-draw steps of the one-draw map
-            z = z * pow2[30][0] + pow2[30][1];
-            z = z * pow2[30][0] + pow2[30][1];
-            CHECK((z & 0x7FFFFFFFu) == 777u);
         }
-        // lane i of aec_noise_rows reaches draw i + 1 of a row in one step
+        // k draws in one step, any start
         for (int k = 1; k <= 64; k++) {
             uint32_t a, c, s = 12345u, want = 12345u;
             aec_lcg_jump(k, &a, &c);

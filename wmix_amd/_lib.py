@@ -107,6 +107,16 @@ def _declare(L):
     L.wmx_agc_destroy.argtypes = [vp]
     L.wmx_agc_set_gain.restype = i
     L.wmx_agc_set_gain.argtypes = [vp, i]
+    L.wmx_agc_set_gain_streams.restype = i
+    L.wmx_agc_set_gain_streams.argtypes = [vp, vp, i, i, vp]
+    L.wmx_agc_reset_streams_gain.restype = i
+    L.wmx_agc_reset_streams_gain.argtypes = [vp, vp, i, i, vp]
+    L.wmx_agc_stream_gain.restype = i
+    L.wmx_agc_stream_gain.argtypes = [vp, i]
+    L.wmx_chain_reset_streams_gain.restype = i
+    L.wmx_chain_reset_streams_gain.argtypes = [vp, vp, i, i, i, vp]
+    L.wmx_chain_set_agc_gain_streams.restype = i
+    L.wmx_chain_set_agc_gain_streams.argtypes = [vp, vp, i, i, vp]
     L.wmx_agc_packet_samples.restype = i
     L.wmx_agc_packet_samples.argtypes = [vp]
     L.wmx_agc_gain_table.restype = i

@@ -24,6 +24,24 @@ class AgcBatch(Lifetime):
     def set_gain(self, value):
         check(lib().wmx_agc_set_gain(self._h, value), "wmx_agc_set_gain")
 
+    def set_gain_streams(self, idx, value):
+        """agc_addition(fp, value) for the listed streams (src/webrtc.c:824-839), ordered on the current HIP stream."""
+        a = np.ascontiguousarray(idx, dtype=np.int32)
+        check(lib().wmx_agc_set_gain_streams(self._h, a.ctypes.data, a.size, int(value), torch.cuda.current_stream().cuda_stream),
+              "wmx_agc_set_gain_streams")
+
+    def reset_streams_gain(self, idx, value):
+        """agc_release + agc_init(chn, freq, intervalMs, value) for the listed streams."""
+        a = np.ascontiguousarray(idx, dtype=np.int32)
+        check(lib().wmx_agc_reset_streams_gain(self._h, a.ctypes.data, a.size, int(value), torch.cuda.current_stream().cuda_stream),
+              "wmx_agc_reset_streams_gain")
+
+    def stream_gain(self, stream_index):
+        v = lib().wmx_agc_stream_gain(self._h, int(stream_index))
+        if v < -10000:
+            check(v, "wmx_agc_stream_gain")
+        return v
+
     def gain_table(self):
         t = np.zeros(32, np.int32)
         check(lib().wmx_agc_gain_table(self._h, t.ctypes.data), "wmx_agc_gain_table")

@@ -71,6 +71,18 @@ class ChainBatch(Lifetime):
         check(lib().wmx_aec_host_ctl(self.aec_handle(), C.byref(n), C.byref(sec)), "wmx_aec_host_ctl")
         return n.value, sec.value
 
+    def reset_streams_gain(self, idx, agc_value, cohort=None):
+        """wmx_chain_reset_streams with agc_init's own `value` for the new handles (src/wmix.c:684)."""
+        a = np.ascontiguousarray(idx, dtype=np.int32)
+        check(lib().wmx_chain_reset_streams_gain(self._h, a.ctypes.data, a.size, -1 if cohort is None else int(cohort), int(agc_value),
+                                                 torch.cuda.current_stream().cuda_stream), "wmx_chain_reset_streams_gain")
+
+    def set_agc_gain_streams(self, idx, agc_value):
+        """agc_addition(fp, value) for the listed streams of the running chain (src/wmix.c:1068-1070)."""
+        a = np.ascontiguousarray(idx, dtype=np.int32)
+        check(lib().wmx_chain_set_agc_gain_streams(self._h, a.ctypes.data, a.size, int(agc_value), torch.cuda.current_stream().cuda_stream),
+              "wmx_chain_set_agc_gain_streams")
+
     def stage_calls_packet_major(self, far, pcm, out):
         """pcm / out [n10, n_streams, pkt] (see stage_calls)."""
         return self.stage_calls(far, pcm, out, pcm.shape[0], pcm.stride(1), pcm.stride(0))

@@ -82,9 +82,8 @@ enum : int {
     AS_DELAYCTR = AS_SCAL + 13,  // delayEstCtr (aec_core.c:1020-1025): PartitionDelay every 10 * mult blocks of the handle
                                  //   -- both with the stream, not with its control cohort, so that cohorts can fold (wmx_aec_coalesce)
                                  //   as soon as their rings agree, whatever their members' ages
-    AS_NBLK = AS_SCAL + 11,      // blocks this stream has processed since aec_init (uint32): every handle's comfort-noise generator
-                                 //   starts from the same state (aec->seed = 777, aec_core.c:1670) and draws 64 numbers per block, so
-                                 //   the block count IS the generator's state -- and the row of AecNoiseRows the block's phases lie in
+    AS_NSEED = AS_SCAL + 11,     // the state of this stream's comfort-noise generator in front of its next block (uint32; aec->seed,
+                                 //   aec_core.c:1670: 777 at aec_init, 64 draws of WebRtcSpl_RandUArray per block, :476-480)
     AS_WORDS = AS_SCAL + 16,
 };
 static_assert(AS_WORDS % 4 == 0, "state block must be a whole number of 16-byte chunks");
@@ -423,7 +422,7 @@ __device__ __forceinline__ void aec_fft_fwd(float *row, const FftTables *T, int 
 
 template <int MULT>  // 1: 8 kHz, 2: 16 kHz
 __device__ __forceinline__ void aec_block(const AecConstsNear &K, const float *__restrict__ curves_g, const PowTables *__restrict__ powtab, AecWaveLds &W, AecTaps &taps,
-                                          const AecFarBufs &F, const AecBlkPlan &bp, const float *__restrict__ noise_rows, const int lane_in) {
+                                          const AecFarBufs &F, const AecBlkPlan &bp, const AecNoiseEntry *__restrict__ noise_tab, const int lane_in) {
     // The lane-derived LDS addresses (gather points, twiddle and window slots) are loop invariant; left alone the
     // compiler hoists ~100 of them out of the packet loop and pins them in VGPRs for the whole kernel.  Recomputing
     // them per block costs a few VALU ops and frees the registers.
@@ -858,14 +857,19 @@ __device__ __forceinline__ void aec_block(const AecConstsNear &K, const float *_
     }
     AEC_PROF(6);
     AEC_RELANE();
-    // ComfortNoise's random phases (aec_core.c:476-489): cosf / sinf of the block's 64 draws of WebRtcSpl_RandUArray lie in row
-    // `blocks processed so far` of the noise table (AecNoiseRows; the generator's period is 2^31 draws = 2^25 rows).  Bin b's phase
-    // is draw b - 1: lane l >= 1 takes entry l - 1, lane 0 entry 63 (bin 64's).  Requested here, used two phases on; streams of one
-    // age read one row (L2 hits), streams of merged cohorts their own.
-    const unsigned nblk = (unsigned)__builtin_amdgcn_readfirstlane(Si[AS_NBLK]);
-    const float *nz = noise_rows + (size_t)(nblk & (unsigned)(kAecNoisePeriodRows - 1)) * (2 * kAecPart);
-    const float nz_c = nz[(lane + 63) & 63], nz_s = nz[kAecPart + ((lane + 63) & 63)];
-    if (lane == 0) Si[AS_NBLK] = (int)(nblk + 1u);
+    // ComfortNoise's random phases (aec_core.c:476-489).  WebRtcSpl_RandUArray draws 64 numbers per block, seed -> seed * 69069 + 1 mod
+    // 2^31 each; bin b's phase comes from draw b: lane l >= 1 takes draw l, lane 0 draw 64 (bin 64's) -- k draws are one multiply-add
+    // with precomputed (a_k, c_k), so every lane reaches its draw from the stream's state in one step, and the state moves on by the
+    // 64-draw step on the scalar unit.  u = (int16)(draw >> 16) / 32768 takes 32 768 values: cosf / sinf of 2 pi u are looked up in the
+    // table of the host libm's values (AecNoiseEntry; one 8-byte gather per lane and block, requested here, used two phases on).
+    // The generator is the stream's own (4 bytes of its state), as it is the handle's in the reference: streams of any age share a
+    // control cohort, and nothing grows with a stream's life.
+    const uint32_t nseed = (uint32_t)__builtin_amdgcn_readfirstlane(Si[AS_NSEED]);
+    const uint2 *jump = reinterpret_cast<const uint2 *>(noise_tab + kAecNoiseTab);  // [k - 1] = (a_k, c_k), k = 1 .. 64
+    const uint2 jl = jump[(lane + 63) & 63], j64 = jump[63];
+    const AecNoiseEntry nz = noise_tab[((nseed * jl.x + jl.y) & 0x7FFFFFFFu) >> 16];
+    const float nz_c = nz.c, nz_s = nz.s;
+    if (lane == 0) Si[AS_NSEED] = (int)((nseed * j64.x + j64.y) & 0x7FFFFFFFu);
     // coherences (aec_core.c:440-449), bin `lane` and bin 64 side by side
     {
         auto coh = [&](int b, float &cde, float &cxd) {
@@ -1082,7 +1086,7 @@ template <int MULT>
 __global__ __attribute__((amdgpu_waves_per_eu(WMX_AEC_WAVES, WMX_AEC_WAVES))) __launch_bounds__(64 * kAecWavesPerBlock) void aec_near_kernel(float *__restrict__ state, AecFarBufs F_all,
                                                                           const float *__restrict__ consts_g,
                                                                           const AecPlan *__restrict__ plans, int n_packets, int n_cohorts,
-                                                                          const float *__restrict__ noise_rows,
+                                                                          const AecNoiseEntry *__restrict__ noise_tab,
                                                                           const int16_t *near_pcm, int16_t *out_pcm, int n_streams,
                                                                           long stream_stride, long packet_stride, int chn, int pkg,
                                                                           const int *__restrict__ stream_far, const uint8_t *__restrict__ active,
@@ -1219,7 +1223,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(WMX_AEC_WAVES, WMX_AEC_WAVES))) __
             }
             wave_sync();
             for (int k = 0; k < sp.n_blocks; k++)
-                aec_block<MULT>(K, consts_g + kAecConstNearWords, powtab, W, taps, F, pl.blk[sp.first_blk + k], noise_rows, lane);
+                aec_block<MULT>(K, consts_g + kAecConstNearWords, powtab, W, taps, F, pl.blk[sp.first_blk + k], noise_tab, lane);
             for (int i = opaque_lane(lane); i < kAecFrame; i += 64) {
                 const int16_t v = (int16_t)AEC_ST(AS_OUT_RING + ring_at(sp.out_rd, i));
                 for (int c = 0; c < chn; c++) out[(s * kAecFrame + i) * chn + c] = v;
@@ -1344,21 +1348,6 @@ __global__ void aec_clamp_group(int *stream_far, int n_streams, int n_far) {
     const int s = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (s < n_streams && stream_far[s] >= n_far) stream_far[s] = 0;
 }
-// AecNoiseRows: row r = the 64 cosines, then the 64 sines, of the phases ComfortNoise draws in the r-th block of a handle's life
-// (aec_core.c:476-489).  One wave per row: the generator's state in front of the row by jump-ahead over 64 r draws (composition of
-// the precomputed 2^k-draw steps), lane i's draw i + 1 from there, cosf / sinf of the reference's float expression by table.
-__global__ __launch_bounds__(64) void aec_noise_rows(float *rows, const AecNoiseEntry *__restrict__ tab, unsigned first_row, int n_rows) {
-    const unsigned r = first_row + blockIdx.x;
-    if ((int)blockIdx.x >= n_rows) return;
-    const uint2 *jump = reinterpret_cast<const uint2 *>(tab + kAecNoiseTab);  // [64] lane jumps, then [32] 2^k-draw steps
-    const uint32_t seed = aec_row_seed(r, reinterpret_cast<const uint32_t(*)[2]>(jump + 64));
-    const uint2 j = jump[threadIdx.x];
-    const uint32_t sd = (seed * j.x + j.y) & 0x7FFFFFFFu;
-    const AecNoiseEntry e = tab[sd >> 16];
-    float *row = rows + (size_t)r * (2 * kAecPart);
-    row[threadIdx.x] = e.c;
-    row[kAecPart + threadIdx.x] = e.s;
-}
 }  // namespace
 }  // namespace wmx
 
@@ -1392,10 +1381,7 @@ struct wmx_aec {
     int order_age;            // launches since the order was rebuilt: under churn it is rebuilt every kOrderEvery launches at most
     static constexpr int kOrderEvery = 16;
     wmx::AecNoiseEntry *d_noise_tab;  // cosf / sinf of the comfort noise's 32 768 possible phases (host libm, aec_ctl.h)
-                                      // + 64 x (a, c): draw i + 1 from a row's first state, + 32 x (a, c): 2^k draws in one step
-    float *d_noise_rows;     // AecNoiseRows [rows_cap][128]: rows 0 .. rows_valid - 1 are made; grown ahead of the oldest stream's block count
-    uint32_t rows_valid, rows_cap;
-    std::vector<float *> old_rows;  // tables outgrown while launches may still have been reading them: freed with the handle
+                                      // + 64 x (a_k, c_k): k = 1 .. 64 draws of the generator in one step
     // wmx_aec_coalesce: the pairs whose device comparison is in flight (`b` < 0: dropped, the two were not called identically since)
     wmx::AecPairChecks co_pairs;
     int co_n;
@@ -1441,8 +1427,6 @@ int wmx_aec_destroy(wmx_aec *h) {
     if (h->d_stream_far) (void)hipFree(h->d_stream_far);
     if (h->d_order) (void)hipFree(h->d_order);
     if (h->d_noise_tab) (void)hipFree(h->d_noise_tab);
-    if (h->d_noise_rows) (void)hipFree(h->d_noise_rows);
-    for (float *p : h->old_rows) (void)hipFree(p);
     if (h->d_co_flags) (void)hipFree(h->d_co_flags);
     if (h->h_co_flags) (void)hipHostFree(h->h_co_flags);
     if (h->co_done) (void)hipEventDestroy(h->co_done);
@@ -1635,8 +1619,6 @@ int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int i
     h->h_plans = nullptr;
     h->d_stream_far = nullptr;
     h->d_noise_tab = nullptr;
-    h->d_noise_rows = nullptr;
-    h->rows_valid = h->rows_cap = 0;
     h->co_n = 0;
     h->co_inflight = false;
     h->d_co_flags = h->h_co_flags = nullptr;
@@ -1680,6 +1662,10 @@ int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int i
     st[AS_HNLXDAVGMIN] = 1.f;
     st[AS_OVERDRIVE] = 2.f;
     st[AS_OVERDRIVESM] = 2.f;
+    {
+        const uint32_t seed0 = 777u;  // aec->seed, aec_core.c:1670
+        memcpy(&st[AS_NSEED], &seed0, 4);
+    }
     hipError_t e;
 #define AEC_TRY(x)                                         \
     if ((e = (x)) != hipSuccess) {                         \
@@ -1720,11 +1706,9 @@ int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int i
             aec_noise_table(t.data());
             return t;
         }();
-        // behind it, the generator's jump-ahead constants for aec_noise_rows: lane i's draw i + 1 from the state in front of a row,
-        // and the 2^k-draw steps that state is composed from
-        uint32_t jump[2 * 64 + 2 * 32];
+        // behind it, the generator's k-draw steps, k = 1 .. 64: lane l's draw from the state in front of a block, and the 64-draw step
+        uint32_t jump[2 * 64];
         for (int l = 0; l < 64; l++) aec_lcg_jump(l + 1, &jump[2 * l], &jump[2 * l + 1]);
-        aec_lcg_pow2(reinterpret_cast<uint32_t(*)[2]>(jump + 128));
         AEC_TRY(hipMalloc(&h->d_noise_tab, sizeof(AecNoiseEntry) * kAecNoiseTab + sizeof(jump)));
         AEC_TRY(hipMemcpy(h->d_noise_tab, tab.data(), sizeof(AecNoiseEntry) * kAecNoiseTab, hipMemcpyHostToDevice));
         AEC_TRY(hipMemcpy(h->d_noise_tab + kAecNoiseTab, jump, sizeof(jump), hipMemcpyHostToDevice));
@@ -1780,41 +1764,6 @@ int wmx_aec_retire_cohort(wmx_aec *h, int cohort) {
 }
 
 }  // extern "C"
-// ---------------------------------------------------------------- the comfort-noise rows
-// Rows 0 .. `oldest` + a launch's worth are made before the near kernel can read them (in `s`, in front of it).  The table grows
-// by doubling up to the generator's period (2^25 rows = 16 GiB after 37 hours of one handle at 16 kHz; a batch of short-lived
-// handles never gets there); an outgrown table stays allocated until the next doubling, launches in flight may be reading it.
-static int aec_noise_reserve(wmx_aec *h, uint32_t oldest, hipStream_t s) {
-    using namespace wmx;
-    uint64_t need = (uint64_t)oldest + 4 * kAecMaxPktPerLaunch + 1;  // block counts the launch can reach (<= 4 blocks per packet)
-    if (need > (uint64_t)kAecNoisePeriodRows) need = kAecNoisePeriodRows;
-    if (need <= h->rows_valid) return 0;
-    uint64_t want = (need + 1023) / 1024 * 1024 + 1024;  // ahead of the need: one generator launch per few hundred heartbeats
-    if (want > (uint64_t)kAecNoisePeriodRows) want = kAecNoisePeriodRows;
-    if (want > h->rows_cap) {
-        uint64_t cap = h->rows_cap ? h->rows_cap : 4096;
-        while (cap < want) cap *= 2;
-        if (cap > (uint64_t)kAecNoisePeriodRows) cap = kAecNoisePeriodRows;
-        float *nr = nullptr;
-        WMX_HIP_RC(hipMalloc(&nr, (size_t)cap * 2 * kAecPart * sizeof(float)));
-        if (h->d_noise_rows) {
-            WMX_HIP_RC(hipMemcpyAsync(nr, h->d_noise_rows, (size_t)h->rows_valid * 2 * kAecPart * sizeof(float), hipMemcpyDeviceToDevice, s));
-            // the table outgrown LAST time has had a whole doubling's worth of heartbeats to be done with (hipFree waits anyway)
-            for (float *p : h->old_rows) (void)hipFree(p);
-            h->old_rows.clear();
-            h->old_rows.push_back(h->d_noise_rows);
-        }
-        h->d_noise_rows = nr;
-        h->rows_cap = (uint32_t)cap;
-    }
-    const uint32_t n = (uint32_t)want - h->rows_valid;
-    hipLaunchKernelGGL(aec_noise_rows, dim3(n), dim3(64), 0, s, h->d_noise_rows, h->d_noise_tab, h->rows_valid, (int)n);
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "aec_noise_rows", __FILE__, __LINE__);
-    h->rows_valid = (uint32_t)want;
-    return 0;
-}
-
 // ---------------------------------------------------------------- coalescing
 // a cohort that is restarted, retired or overwritten is no candidate of a comparison in flight
 static void aec_co_drop(wmx_aec *h, int cohort) {
@@ -1872,7 +1821,6 @@ int wmx_aec_coalesce(wmx_aec *h, int max_pairs, int32_t *merged_from, int32_t *m
             std::vector<int32_t> to((size_t)h->n_far, -1);
             for (int i = 0; i < n_go; i++) {
                 to[(size_t)go.p[i].b] = go.p[i].a;
-                if (h->ctl[(size_t)go.p[i].b].blocks > h->ctl[(size_t)go.p[i].a].blocks) h->ctl[(size_t)go.p[i].a].blocks = h->ctl[(size_t)go.p[i].b].blocks;
                 h->live[(size_t)go.p[i].b] = 0;  // retired: its id may be handed out again (wmx_aec_add_cohort)
             }
             for (int32_t &c : h->h_cohort_of)
@@ -2013,6 +1961,14 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
         const bool on_a = !cohort_on || cohort_on[pc.a], on_b = !cohort_on || cohort_on[pc.b];
         if (on_a != on_b || (on_a && delay_ms[pc.a] != delay_ms[pc.b]) || ((mode & 1) && far_group_stride != 0)) pc.b = -1;
     }
+    // Everything that can fail for lack of memory happens HERE, before a control plane has moved: a call that returns an error has
+    // advanced neither the host's planes nor the device's far-end history (round-4 ADVICE: the stream order used to be rebuilt --
+    // an allocation and an upload -- between the far and the near kernel of a chunk whose planes had already been advanced).
+    const bool ordered = (mode & 2) && h->d_stream_far != nullptr && !h->no_order;
+    if (ordered && running > 0 && (h->d_order == nullptr || (h->order_dirty && h->order_age >= wmx_aec::kOrderEvery))) {
+        const int rc = aec_rebuild_order(h, s);
+        if (rc != 0) return rc;
+    }
     for (int done = 0; done < n_packets && running > 0;) {
         int chunk = n_packets - done;
         if (chunk > kAecMaxPktPerLaunch) chunk = kAecMaxPktPerLaunch;
@@ -2055,14 +2011,6 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
         }
         h->ctl_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_ctl).count();
         h->ctl_calls++;
-        if (any && (mode & 2)) {
-            // the comfort-noise rows of every block this launch can reach: one past the oldest live cohort's block count
-            uint32_t oldest = 0;
-            for (int g = 0; g < G; g++)
-                if (h->live[(size_t)g] && h->ctl[(size_t)g].blocks > oldest) oldest = h->ctl[(size_t)g].blocks;
-            const int rc = aec_noise_reserve(h, oldest, s);
-            if (rc != 0) return rc;
-        }
         if (any) {
             const int by_value = (chunk == 1 && G == 1) ? 1 : 0;
             // the far kernel (and the plans it reads) on the side stream when the caller forked it (first chunk of the call only)
@@ -2096,20 +2044,15 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
             if (mode & 2) {
                 const int16_t *nin = d_near + (size_t)done * packet_stride;
                 int16_t *nout = d_out + (size_t)done * packet_stride;
-                const bool ordered = h->d_stream_far != nullptr && !h->no_order;
-                if (ordered && (h->d_order == nullptr || (h->order_dirty && h->order_age >= wmx_aec::kOrderEvery))) {
-                    const int rc = aec_rebuild_order(h, s);
-                    if (rc != 0) return rc;
-                }
                 if (h->order_age < wmx_aec::kOrderEvery) h->order_age++;  // saturates: a service runs for months
                 const int32_t *order = ordered ? h->d_order : nullptr;
                 const unsigned grid = ordered ? h->order_wgs : (unsigned)((h->n_streams + kAecWavesPerBlock - 1) / kAecWavesPerBlock);
                 const dim3 blk(64 * kAecWavesPerBlock);
                 if (h->freq == 8000)
-                    hipLaunchKernelGGL((aec_near_kernel<1>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, chunk, G, h->d_noise_rows, nin,
+                    hipLaunchKernelGGL((aec_near_kernel<1>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, chunk, G, h->d_noise_tab, nin,
                                        nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg, h->d_stream_far, h->life.d_active, order);
                 else
-                    hipLaunchKernelGGL((aec_near_kernel<2>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, chunk, G, h->d_noise_rows, nin,
+                    hipLaunchKernelGGL((aec_near_kernel<2>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, chunk, G, h->d_noise_tab, nin,
                                        nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg, h->d_stream_far, h->life.d_active, order);
                 WMX_LAUNCH_CHECK();
                 if (tv) WMX_HIP(hipEventRecord(tv[3], s));
@@ -2194,13 +2137,6 @@ int wmx_aec_import_stream(wmx_aec *h, int stream_index, const void *host_blob, i
     const int rc = blob_check(host_blob, blob_tag("AEC "), (uint32_t)h->freq, AS_WORDS * 4);
     if (rc) return rc;
     WMX_HIP(hipDeviceSynchronize());
-    {
-        // the stream brings its block count (its comfort-noise generator's state): its new cohort is at least that old
-        uint32_t nblk;
-        memcpy(&nblk, static_cast<const char *>(host_blob) + sizeof(BlobHeader) + 4 * AS_NBLK, 4);
-        AecCtl &c = h->ctl[(size_t)(cohort >= 0 ? cohort : h->h_cohort_of[(size_t)stream_index])];
-        if (nblk > c.blocks) c.blocks = nblk;
-    }
     WMX_HIP(hipMemcpy(h->d_state + (size_t)stream_index * AS_WORDS, static_cast<const char *>(host_blob) + sizeof(BlobHeader), AS_WORDS * 4,
                       hipMemcpyHostToDevice));
     if (cohort >= 0 && h->d_stream_far) {

@@ -51,35 +51,9 @@ inline void aec_noise_table(AecNoiseEntry *t) {
         t[i].s = sinf(tmp);
     }
 }
-// AecNoiseRows.  Every handle's generator starts from the same state (aec->seed = 777, aec_core.c:1670) and ComfortNoise draws 64
-// numbers per block, unconditionally (aec_core.c:476-480): the phases of a handle's r-th block are the same for every handle that
-// ever lives.  They are kept as a table -- row r = 64 cosines | 64 sines -- that the near kernel indexes with the STREAM's block
-// count, so streams of different ages can share a control cohort.  The generator's period is 2^31 draws: 2^25 rows, then the table
-// repeats.  (4 bytes of state per stream instead of a cohort-wide seed; 512 bytes of table per block of the oldest stream's life.)
-constexpr int kAecNoisePeriodRows = 1 << 25;
-#ifdef __HIPCC__
-#define WMX_HD __host__ __device__
-#else
-#define WMX_HD
-#endif
-// t[k] = (a, c) of 2^k draws in one step, k = 0 .. 30 (t[31] unused)
-inline void aec_lcg_pow2(uint32_t (*t)[2]) {
-    uint32_t a = 69069u, c = 1u;
-    for (int k = 0; k < 32; k++) {
-        t[k][0] = a;
-        t[k][1] = c;
-        c = a * c + c;  // x -> a (a x + c) + c
-        a = a * a;
-    }
-}
-// the generator's state in front of row r (r < 2^25): 777 advanced by 64 r draws
-WMX_HD inline uint32_t aec_row_seed(uint32_t r, const uint32_t (*pow2)[2]) {
-    uint32_t x = 777u;
-    const uint32_t k = r << 6;
-    for (int j = 6; j < 31; j++)
-        if ((k >> j) & 1u) x = x * pow2[j][0] + pow2[j][1];
-    return x & 0x7FFFFFFFu;
-}
+// Every handle's generator starts from the same state (aec->seed = 777, aec_core.c:1670) and ComfortNoise draws 64 numbers per
+// block, unconditionally (aec_core.c:476-480).  The generator's state is part of the STREAM's state (AS_NSEED in aec.hip): the near
+// kernel reaches lane l's draw with one multiply-add (aec_lcg_jump) and moves the state on by the 64-draw step.
 // k draws in one step: seed_k = (seed * a_k + c_k) mod 2^31 with a_k = 69069^k, c_k = 1 + 69069 + ... + 69069^(k-1)
 // (arithmetic mod 2^32, masked: the low 31 bits of a product depend on the low 31 bits of its factors only)
 inline void aec_lcg_jump(int k, uint32_t *a_k, uint32_t *c_k) {
@@ -165,8 +139,7 @@ struct AecCtl {
     int fs = 0, mult = 1, rate_factor = 1;
     RingIdx near_fr, out_fr, far_buf, far_pre;
     int system_delay = 0, core_known_delay = 0;
-    uint32_t blocks = 0;  // blocks planned since init -- after a merge (wmx_aec_coalesce) or an import, of the OLDEST member: the comfort-
-                          // noise table must reach that far (AecNoiseRows)
+    uint32_t blocks = 0;  // blocks planned since init (a counter for the sanitizer driver; nothing on the device depends on it)
     int hist_n = 0;
     // Aec wrapper (echo_cancellation_internal.h:17-65)
     int bufSizeStart = 0, knownDelay = 0, sum = 0, timeForDelayChange = 0, startup_phase = 1, checkBuffSize = 1;
@@ -246,7 +219,7 @@ struct AecCtl {
         b.hist_n = hist_n;
         hist_n = (hist_n + 1) & 0x3fffffff;  // only differences modulo kAecHist matter; stays non-negative for ever
         b.flags = 0;  // (noiseEstCtr and delayEstCtr count the STREAM's blocks: aec.hip AS_NOISECTR / AS_DELAYCTR)
-        blocks++;  // (the stream's own count, AS_NBLK in aec.hip, selects the block's comfort-noise row)
+        blocks++;
         out_fr.write(kAecPart, &b.out_wr);
     }
 

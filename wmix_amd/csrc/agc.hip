@@ -8,7 +8,9 @@
 // WebRtcSpl_Sqrt spl_sqrt.c).  Everything is a per-stream integer recurrence (ten 1 ms
 // envelope steps, a 4 kHz level detector, a per-sample gain ramp), so 64 streams share a
 // wavefront, state is field-major ([field][stream], one coalesced line per access) and the
-// 32-entry gain table -- identical for every stream of a batch -- sits in LDS.  The channel count is
+// 32-entry gain table sits in LDS: ONE table while every stream of the batch has the same compression gain (the common case,
+// kernels with PS = false), else the table of each of the workgroup's 64 streams, [entry][lane] (PS = true: the compression
+// gain is per handle in the reference, agc_init's `value` / agc_addition, src/webrtc.c:694-753, 824-839).  The channel count is
 // a template parameter (1, 2; 0 = any, at run time): with a run-time `for (c < chn)` around every
 // sample access the compiler could not batch the packet's loads and the kernel ran 3x longer.
 // Bit-exact.
@@ -19,6 +21,7 @@
 // the host by WebRtcAgc_CalculateGainTable's integer recipe (digital_agc.c:61-257).
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 #include "wmx_internal.h"
 #include "agc_gain_table.h"
@@ -83,9 +86,31 @@ __device__ __forceinline__ int16_t down2_step(int16_t a, int16_t b, int32_t *st)
     return sat_w16(wadd(wadd(st[3], st[7]), 1024) >> 11);
 }
 
+// The gain table as the kernels see it: one table shared by the workgroup, or one per lane ([entry][lane]: conflict-free whatever
+// entries the lanes ask for)
+struct GainShared {
+    const int32_t *t;
+    __device__ __forceinline__ int32_t operator()(int e) const { return t[e]; }
+};
+struct GainPerLane {
+    const int32_t *t;  // already offset by the lane
+    __device__ __forceinline__ int32_t operator()(int e) const { return t[e * 64]; }
+};
+// stages the tables of a workgroup's 64 streams: entry e of lane l at [e * 64 + l]
+__device__ __forceinline__ void stage_lane_tables(int32_t *lds, const int32_t *__restrict__ tables_g, const uint16_t *__restrict__ stream_table,
+                                                  int n_streams) {
+    for (int i = threadIdx.x; i < 32 * 64; i += blockDim.x) {
+        const int e = i >> 6, l = i & 63;
+        int sidx = (int)blockIdx.x * 64 + l;
+        if (sidx >= n_streams) sidx = n_streams - 1;
+        lds[i] = tables_g[(int)stream_table[sidx] * 32 + e];
+    }
+}
+
 // Everything between the two passes over a packet: ProcessVad's statistics from the level detector's energy, the envelope
 // followers over the ten per-millisecond peaks, the gain curve, the gate and the overflow limiter -> gains[0..10]
-__device__ __forceinline__ void agc_decide(const AgcRef &S, const int32_t *__restrict__ gain_table, int32_t nrg, const int32_t (&env)[10],
+template <class GT>
+__device__ __forceinline__ void agc_decide(const AgcRef &S, const GT gain_table, int32_t nrg, const int32_t (&env)[10],
                                            int32_t (&gains)[11]) {
     // ---- ProcessVad statistics (digital_agc.c:685-770)
     int16_t std_long, std_short, logratio;
@@ -155,8 +180,8 @@ __device__ __forceinline__ void agc_decide(const AgcRef &S, const int32_t *__res
         if (cur == 0) zeros = 31;
         int32_t t32 = wshl(cur, zeros) & 0x7FFFFFFF;
         frac = (int16_t)(t32 >> 19);
-        t32 = wmul(wsub(gain_table[(zeros - 1) & 31], gain_table[zeros & 31]), frac);
-        gains[k + 1] = wadd(gain_table[zeros & 31], t32 >> 12);
+        t32 = wmul(wsub(gain_table((zeros - 1) & 31), gain_table(zeros & 31)), frac);
+        gains[k + 1] = wadd(gain_table(zeros & 31), t32 >> 12);
     }
     S.w(A32_CAP_FAST) = cap_fast;
     S.w(A32_CAP_SLOW) = cap_slow;
@@ -177,7 +202,7 @@ __device__ __forceinline__ void agc_decide(const AgcRef &S, const int32_t *__res
         gate = (int16_t)((gate + t32) >> 3);
         S.h(A16_GATE_PREV) = gate;
     }
-    const int32_t g0 = gain_table[0];
+    const int32_t g0 = gain_table(0);
     if (gate > 0) {
         const int16_t gain_adj = gate < 2500 ? (int16_t)((2500 - gate) >> 5) : (int16_t)0;
 #pragma unroll
@@ -227,8 +252,8 @@ __device__ __forceinline__ int16_t agc_apply(int16_t x, int32_t gain32, bool fir
 
 // One packet (10*L mono samples) of one stream.  in/out point at the packet's first frame;
 // `chn` interleaved channels are averaged on input and duplicated on output (src/webrtc.c:789-815).
-template <int L, int CHN>  // L samples per millisecond sub-frame: 8 (8 kHz) or 16 (16 / 32 kHz); CHN interleaved channels
-__device__ void agc_packet(const AgcRef &S, const int32_t *__restrict__ gain_table, const int16_t *in, int16_t *out, int chn_rt) {
+template <int L, int CHN, class GT>  // L samples per millisecond sub-frame: 8 (8 kHz) or 16 (16 / 32 kHz); CHN interleaved channels
+__device__ void agc_packet(const AgcRef &S, const GT gain_table, const int16_t *in, int16_t *out, int chn_rt) {
     const int chn = CHN ? CHN : chn_rt;  // CHN = 1, 2: compile-time (the daemon's cases); 0: any count, at run time
     constexpr int L2 = (L == 8) ? 3 : 4;
     auto load = [&](int i) -> int16_t {
@@ -312,20 +337,25 @@ __device__ void agc_packet(const AgcRef &S, const int32_t *__restrict__ gain_tab
     }
 }
 
-template <int L, int CHN>
-__global__ __launch_bounds__(64) void agc_kernel(int16_t *s16, int32_t *s32, const int32_t *gain_table_g, const int16_t *in,
-                                                 int16_t *out, int n_streams, int n_packets, long stream_stride,
+template <int L, int CHN, bool PS>
+__global__ __launch_bounds__(64) void agc_kernel(int16_t *s16, int32_t *s32, const int32_t *gain_table_g, const uint16_t *__restrict__ stream_table,
+                                                 const int16_t *in, int16_t *out, int n_streams, int n_packets, long stream_stride,
                                                  long packet_stride, int chn_rt, const uint8_t *__restrict__ active) {
-    __shared__ int32_t gain_table[32];
-    if (threadIdx.x < 32) gain_table[threadIdx.x] = gain_table_g[threadIdx.x];
+    __shared__ int32_t gain_lds[PS ? 32 * 64 : 32];
+    if constexpr (PS)
+        stage_lane_tables(gain_lds, gain_table_g, stream_table, n_streams);
+    else if (threadIdx.x < 32)
+        gain_lds[threadIdx.x] = gain_table_g[threadIdx.x];
     __syncthreads();
+    using GT = typename std::conditional<PS, GainPerLane, GainShared>::type;
+    const GT gain_table{PS ? gain_lds + threadIdx.x : gain_lds};
     const int stream = blockIdx.x * 64 + threadIdx.x;
     if (!stream_active(active, stream, n_streams)) return;
     if constexpr (CHN == 0) {
         const AgcRef S{s16 + stream, s32 + stream, (size_t)n_streams};
         for (int p = 0; p < n_packets; p++) {
             const size_t off = (size_t)stream * stream_stride + (size_t)p * packet_stride;
-            agc_packet<L, CHN>(S, gain_table, in + off, out + off, chn_rt);
+            agc_packet<L, CHN, GT>(S, gain_table, in + off, out + off, chn_rt);
         }
     } else {
         int16_t r16[A16_WORDS];
@@ -337,7 +367,7 @@ __global__ __launch_bounds__(64) void agc_kernel(int16_t *s16, int32_t *s32, con
         const AgcRef S{r16, r32, 1};
         for (int p = 0; p < n_packets; p++) {
             const size_t off = (size_t)stream * stream_stride + (size_t)p * packet_stride;
-            agc_packet<L, CHN>(S, gain_table, in + off, out + off, chn_rt);
+            agc_packet<L, CHN, GT>(S, gain_table, in + off, out + off, chn_rt);
         }
 #pragma unroll
         for (int f = 0; f < A32_WORDS; f++) s32[(size_t)f * n_streams + stream] = r32[f];
@@ -356,12 +386,13 @@ __global__ __launch_bounds__(64) void agc_kernel(int16_t *s16, int32_t *s32, con
 // gains; waves 0..2 then apply the gain ramp to the samples they still hold and store them.  Same integer operations per
 // stream as agc_kernel, which stays for more than two channels and unaligned rows.  CHN = 2: the interleaved pair is averaged
 // on the way in and the result written to both channels (src/webrtc.c:789-815), like agc_packet's load / store.
-template <int L, int CHN>
-__global__ __launch_bounds__(256, CHN == 1 ? 4 : 2) void agc_pipe_kernel(int16_t *s16, int32_t *s32, const int32_t *gain_table_g, const int16_t *in,
+template <int L, int CHN, bool PS>
+__global__ __launch_bounds__(256, CHN == 1 ? 4 : 2) void agc_pipe_kernel(int16_t *s16, int32_t *s32, const int32_t *gain_table_g,
+                                                       const uint16_t *__restrict__ stream_table, const int16_t *in,
                                                        int16_t *out, int n_streams, int n_packets, long stream_stride,
                                                        long packet_stride, const uint8_t *__restrict__ active) {
     constexpr int L2 = (L == 8) ? 3 : 4, VPS = L * CHN / 8;  // uint4 per sub-frame
-    __shared__ int32_t gain_table[32];
+    __shared__ int32_t gain_lds[PS ? 32 * 64 : 32];
     // Exchange areas, TWICE: the packets of a launch are pipelined -- while wave 3 runs packet p's serial part on one set, waves 0..2
     // apply packet p - 1's gains from the other gain area and put packet p + 1's peaks and detector input into the other input
     // set.  One workgroup barrier per packet instead of three, and a packet behind the first costs max(serial part, pass 2 + pass 1)
@@ -369,8 +400,13 @@ __global__ __launch_bounds__(256, CHN == 1 ? 4 : 2) void agc_pipe_kernel(int16_t
     __shared__ int16_t xdet[2][80 * 64];  // the detector's 80 input samples of every stream, [sample][lane]
     __shared__ int32_t xenv[2][10 * 64];  // per-millisecond peak energies
     __shared__ int32_t xgain[2][11 * 64];
-    if (threadIdx.x < 32) gain_table[threadIdx.x] = gain_table_g[threadIdx.x];
+    if constexpr (PS)
+        stage_lane_tables(gain_lds, gain_table_g, stream_table, n_streams);
+    else if (threadIdx.x < 32)
+        gain_lds[threadIdx.x] = gain_table_g[threadIdx.x];
     const int lane = threadIdx.x & 63;
+    using GT = typename std::conditional<PS, GainPerLane, GainShared>::type;
+    const GT gain_table{PS ? gain_lds + lane : gain_lds};
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int stream_raw = (int)blockIdx.x * 64 + lane;
     // a lane without a stream recomputes the last one, a lane whose stream is switched off its own, and neither stores anything
@@ -535,6 +571,13 @@ __global__ void agc_fill_state(int16_t *s16, int32_t *s32, int n_streams, const 
     }
 }
 
+// stream_table[idx[j]] = t for the listed streams (idx == nullptr: every stream)
+__global__ void agc_set_table(uint16_t *stream_table, int n_streams, const int32_t *idx, int n_idx, uint16_t t) {
+    const size_t count = idx ? (size_t)n_idx : (size_t)n_streams;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (size_t)gridDim.x * blockDim.x)
+        stream_table[idx ? (size_t)idx[j] : j] = t;
+}
+
 }  // namespace
 }  // namespace wmx
 
@@ -543,11 +586,63 @@ struct wmx_agc {
     int n_streams, chn, freq, pkg;
     int16_t *d_s16;
     int32_t *d_s32;
-    int32_t *d_table;
-    int32_t table[32];
+    // The compression gain is per handle in the reference (agc_init's `value`, agc_addition): one 32-entry table per DISTINCT value
+    // in use, tables[0] being the batch's own (wmx_agc_create / wmx_agc_set_gain).  While every stream points at table 0 --
+    // n_off_batch == 0 -- the launches are the PS = false kernels and never look at the map.
+    static constexpr int kMaxTables = 256;  // valid gains are 0 .. 186 dB (host_gain_table): never reached
+    int32_t *d_table;                       // [kMaxTables][32]
+    uint16_t *d_stream_table;               // [n_streams] -> table index
+    std::vector<uint16_t> stream_table;     // the host's copy (export / import, counting)
+    std::vector<int> table_value;           // compression gain of table i
+    std::vector<int32_t> tables;            // [n][32] host copies
+    int n_off_batch;                        // streams whose table is not table 0
     bool one_lane;  // WMIX_AMD_AGC_ONE_LANE (developer A/B switch), read once at create
     wmx::StreamLife life;
 };
+
+namespace wmx {
+namespace {
+// index of the table for `value`, made (and uploaded, ordered on `s`) when new; < 0: WMX error (the reference's set_config fails)
+int agc_table_for(wmx_agc *h, int value, hipStream_t s, const char *who) {
+    for (size_t i = 1; i < h->table_value.size(); i++)
+        if (h->table_value[i] == value) return (int)i;
+    if (!h->table_value.empty() && h->table_value[0] == value) return 0;
+    int32_t t[32];
+    const int16_t comp = (int16_t)value;
+    if (host_gain_table(t, comp, 0, false, analog_target_for(comp)) != 0) {
+        set_error("%s: compression gain %d dB is outside the gain-table range", who, value);
+        return WMX_EINVAL;
+    }
+    if ((int)h->table_value.size() >= wmx_agc::kMaxTables) {
+        set_error("%s: more than %d distinct compression gains in one batch", who, wmx_agc::kMaxTables);
+        return WMX_EINVAL;
+    }
+    const size_t i = h->table_value.size();
+    h->table_value.push_back(value);
+    h->tables.insert(h->tables.end(), t, t + 32);
+    // the source is the vector's storage, which a later push_back may move: a blocking copy (a new gain value is a rare event)
+    (void)s;
+    hipError_t e = hipMemcpy(h->d_table + i * 32, t, sizeof(t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        h->table_value.pop_back();
+        h->tables.resize(i * 32);
+        return hip_fail(e, "hipMemcpy(gain table)", __FILE__, __LINE__);
+    }
+    return (int)i;
+}
+// the listed streams (already uploaded: d_idx) now use table t: host copy, count, device map (a scatter kernel ordered on `s`)
+int agc_point_streams(wmx_agc *h, const int32_t *idx, const int32_t *d_idx, int n, int t, hipStream_t s) {
+    for (int j = 0; j < n; j++) {
+        uint16_t &cur = h->stream_table[(size_t)idx[j]];
+        h->n_off_batch += (t != 0) - (cur != 0);
+        cur = (uint16_t)t;
+    }
+    hipLaunchKernelGGL(agc_set_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->d_stream_table, h->n_streams, d_idx, n, (uint16_t)t);
+    WMX_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace
+}  // namespace wmx
 
 extern "C" {
 
@@ -557,23 +652,54 @@ int wmx_agc_destroy(wmx_agc *h) {
     if (h->d_s16) (void)hipFree(h->d_s16);
     if (h->d_s32) (void)hipFree(h->d_s32);
     if (h->d_table) (void)hipFree(h->d_table);
+    if (h->d_stream_table) (void)hipFree(h->d_stream_table);
     h->life.release();
     delete h;
     return 0;
 }
 
-// agc_release + agc_init for the listed streams (src/webrtc.c:694-753, 841-860); the gain table is the batch's
-int wmx_agc_reset_streams(wmx_agc *h, const int32_t *idx, int n, void *stream) {
+// agc_release + agc_init for the listed streams (src/webrtc.c:694-753, 841-860).  wmx_agc_reset_streams: agc_init with the gain
+// each stream has; wmx_agc_reset_streams_gain: agc_init(..., value, ...) -- the new handles' own compression gain.
+static int agc_reset(wmx_agc *h, const int32_t *idx, int n, const int *value, void *stream) {
     WMX_ON_DEVICE(h);
     if (!h || n < 0 || (n > 0 && !idx)) return WMX_EINVAL;
     if (n == 0) return 0;
     hipStream_t s = wmx::as_stream(stream);
     const int32_t *d_idx = nullptr;
-    const int rc = h->life.upload(idx, n, h->n_streams, s, &d_idx);
+    int rc = h->life.upload(idx, n, h->n_streams, s, &d_idx);  // validates the list
     if (rc != 0) return rc;
+    if (value) {
+        const int t = wmx::agc_table_for(h, *value, s, "wmx_agc_reset_streams_gain");  // agc_init returns NULL: nothing is reset
+        if (t < 0) return t;
+        if ((rc = wmx::agc_point_streams(h, idx, d_idx, n, t, s)) != 0) return rc;
+    }
     hipLaunchKernelGGL(wmx::agc_fill_state, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->d_s16, h->d_s32, h->n_streams, d_idx, n);
     WMX_LAUNCH_CHECK();
     return h->life.done(s);
+}
+int wmx_agc_reset_streams(wmx_agc *h, const int32_t *idx, int n, void *stream) { return agc_reset(h, idx, n, nullptr, stream); }
+int wmx_agc_reset_streams_gain(wmx_agc *h, const int32_t *idx, int n, int value, void *stream) { return agc_reset(h, idx, n, &value, stream); }
+
+// agc_addition for the listed streams (src/webrtc.c:824-839: WebRtcAgc_set_config on a running handle -- the state stays, the
+// table changes).  A value the reference's set_config refuses leaves every stream as it was (agc_addition prints and carries on).
+int wmx_agc_set_gain_streams(wmx_agc *h, const int32_t *idx, int n, int value, void *stream) {
+    WMX_ON_DEVICE(h);
+    if (!h || n < 0 || (n > 0 && !idx)) return WMX_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = wmx::as_stream(stream);
+    const int32_t *d_idx = nullptr;
+    int rc = h->life.upload(idx, n, h->n_streams, s, &d_idx);  // validates the list
+    if (rc != 0) return rc;
+    const int t = wmx::agc_table_for(h, value, s, "wmx_agc_set_gain_streams");
+    if (t < 0) return t;
+    if ((rc = wmx::agc_point_streams(h, idx, d_idx, n, t, s)) != 0) return rc;
+    return h->life.done(s);
+}
+
+// the compression gain stream i runs with
+int wmx_agc_stream_gain(const wmx_agc *h, int stream_index) {
+    if (!h || stream_index < 0 || stream_index >= h->n_streams) return WMX_EINVAL;
+    return h->table_value[h->stream_table[(size_t)stream_index]];
 }
 
 int wmx_agc_set_active(wmx_agc *h, const uint8_t *host_mask, void *stream) {
@@ -582,8 +708,9 @@ int wmx_agc_set_active(wmx_agc *h, const uint8_t *host_mask, void *stream) {
     return h->life.set_active(h->n_streams, host_mask, wmx::as_stream(stream));
 }
 
-// agc_addition (src/webrtc.c:824-839): WebRtcAgc_set_config with a new compression gain -> new table.
-// Returns WMX_EINVAL and keeps the old table when the reference's set_config would fail.
+// agc_addition for EVERY stream of the batch (src/webrtc.c:824-839): WebRtcAgc_set_config with a new compression gain -> the batch
+// is back on one table (table 0) and on the kernels that know no other.  Returns WMX_EINVAL and changes nothing when the
+// reference's set_config would fail.  Blocking (the device is drained: launches in flight still read the old tables).
 int wmx_agc_set_gain(wmx_agc *h, int value) {
     WMX_ON_DEVICE(h);
     using namespace wmx;
@@ -594,8 +721,13 @@ int wmx_agc_set_gain(wmx_agc *h, int value) {
         set_error("wmx_agc_set_gain: compression gain %d dB is outside the gain-table range", value);
         return WMX_EINVAL;
     }
-    memcpy(h->table, t, sizeof(t));
+    WMX_HIP(hipDeviceSynchronize());
     WMX_HIP(hipMemcpy(h->d_table, t, sizeof(t), hipMemcpyHostToDevice));
+    if (h->n_off_batch) WMX_HIP(hipMemset(h->d_stream_table, 0, (size_t)h->n_streams * sizeof(uint16_t)));
+    h->table_value.assign(1, value);
+    h->tables.assign(t, t + 32);
+    std::fill(h->stream_table.begin(), h->stream_table.end(), (uint16_t)0);
+    h->n_off_batch = 0;
     return 0;
 }
 
@@ -627,7 +759,11 @@ int wmx_agc_create(wmx_agc **out, int n_streams, int chn, int freq, int interval
     }
     AGC_TRY(hipMalloc(&h->d_s16, (size_t)A16_WORDS * n_streams * sizeof(int16_t)));
     AGC_TRY(hipMalloc(&h->d_s32, (size_t)A32_WORDS * n_streams * sizeof(int32_t)));
-    AGC_TRY(hipMalloc(&h->d_table, 32 * sizeof(int32_t)));
+    AGC_TRY(hipMalloc(&h->d_table, (size_t)wmx_agc::kMaxTables * 32 * sizeof(int32_t)));
+    AGC_TRY(hipMalloc(&h->d_stream_table, (size_t)n_streams * sizeof(uint16_t)));
+    AGC_TRY(hipMemset(h->d_stream_table, 0, (size_t)n_streams * sizeof(uint16_t)));
+    h->stream_table.assign((size_t)n_streams, (uint16_t)0);
+    h->n_off_batch = 0;
     hipLaunchKernelGGL(agc_fill_state, dim3(512), dim3(256), 0, nullptr, h->d_s16, h->d_s32, n_streams, (const int32_t *)nullptr, 0);
     AGC_TRY(hipGetLastError());
     AGC_TRY(hipDeviceSynchronize());
@@ -641,8 +777,9 @@ int wmx_agc_create(wmx_agc **out, int n_streams, int chn, int freq, int interval
     return 0;
 }
 
-// stream migration: [header | 13 int32 fields | 8 int16 fields]; the gain table belongs to the batch, not to the stream
-int wmx_agc_stream_state_bytes(const wmx_agc *h) { return h ? (int)(sizeof(wmx::BlobHeader) + wmx::A32_WORDS * 4 + wmx::A16_WORDS * 2) : WMX_EINVAL; }
+// stream migration: [header | 13 int32 fields | 8 int16 fields | int32 compression gain] -- the gain is the handle's own
+// (WebRtcAgc_set_config's value lives in the reference's handle), so it travels with the stream
+int wmx_agc_stream_state_bytes(const wmx_agc *h) { return h ? (int)(sizeof(wmx::BlobHeader) + wmx::A32_WORDS * 4 + wmx::A16_WORDS * 2 + 4) : WMX_EINVAL; }
 
 int wmx_agc_export_stream(wmx_agc *h, int stream_index, void *host_blob) {
     WMX_ON_DEVICE(h);
@@ -650,10 +787,12 @@ int wmx_agc_export_stream(wmx_agc *h, int stream_index, void *host_blob) {
     if (!h || !host_blob || stream_index < 0 || stream_index >= h->n_streams) return WMX_EINVAL;
     WMX_HIP(hipDeviceSynchronize());
     char *p = static_cast<char *>(host_blob);
-    blob_begin(p, blob_tag("AGC "), (uint32_t)h->freq, A32_WORDS * 4 + A16_WORDS * 2);
+    blob_begin(p, blob_tag("AGC "), (uint32_t)h->freq, A32_WORDS * 4 + A16_WORDS * 2 + 4);
     p += sizeof(BlobHeader);
     WMX_HIP(column_to_host(reinterpret_cast<int32_t *>(p), h->d_s32, A32_WORDS, h->n_streams, stream_index));
     WMX_HIP(column_to_host(reinterpret_cast<int16_t *>(p + A32_WORDS * 4), h->d_s16, A16_WORDS, h->n_streams, stream_index));
+    const int32_t value = h->table_value[h->stream_table[(size_t)stream_index]];
+    memcpy(p + A32_WORDS * 4 + A16_WORDS * 2, &value, 4);
     return 0;
 }
 
@@ -661,12 +800,20 @@ int wmx_agc_import_stream(wmx_agc *h, int stream_index, const void *host_blob) {
     WMX_ON_DEVICE(h);
     using namespace wmx;
     if (!h || !host_blob || stream_index < 0 || stream_index >= h->n_streams) return WMX_EINVAL;
-    const int rc = blob_check(host_blob, blob_tag("AGC "), (uint32_t)h->freq, A32_WORDS * 4 + A16_WORDS * 2);
+    const int rc = blob_check(host_blob, blob_tag("AGC "), (uint32_t)h->freq, A32_WORDS * 4 + A16_WORDS * 2 + 4);
     if (rc) return rc;
     WMX_HIP(hipDeviceSynchronize());
     const char *p = static_cast<const char *>(host_blob) + sizeof(BlobHeader);
+    int32_t value;
+    memcpy(&value, p + A32_WORDS * 4 + A16_WORDS * 2, 4);
+    const int t = agc_table_for(h, value, nullptr, "wmx_agc_import_stream");
+    if (t < 0) return t;
     WMX_HIP(column_from_host(h->d_s32, reinterpret_cast<const int32_t *>(p), A32_WORDS, h->n_streams, stream_index));
     WMX_HIP(column_from_host(h->d_s16, reinterpret_cast<const int16_t *>(p + A32_WORDS * 4), A16_WORDS, h->n_streams, stream_index));
+    uint16_t &cur = h->stream_table[(size_t)stream_index];
+    h->n_off_batch += (t != 0) - (cur != 0);
+    cur = (uint16_t)t;
+    WMX_HIP(hipMemcpy(h->d_stream_table + stream_index, &cur, sizeof(uint16_t), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -675,7 +822,7 @@ int wmx_agc_packet_samples(const wmx_agc *h) { return h ? h->pkg * h->chn : WMX_
 int wmx_agc_gain_table(const wmx_agc *h, int32_t *host_table32) {
     WMX_ON_DEVICE(h);
     if (!h || !host_table32) return WMX_EINVAL;
-    memcpy(host_table32, h->table, sizeof(h->table));
+    memcpy(host_table32, h->tables.data(), 32 * sizeof(int32_t));  // table 0: the batch's own
     return 0;
 }
 
@@ -702,10 +849,18 @@ int wmx_agc_process(wmx_agc *h, const int16_t *d_in, int16_t *d_out, int n_packe
     // one- and two-channel packets with 16-byte aligned rows -- the batched chains' cases -- go through the four-wave pipeline
     const bool pipe = h->chn <= 2 && (stream_stride % 8) == 0 && (packet_stride % 8) == 0 && (reinterpret_cast<size_t>(d_in) % 16) == 0 &&
                       (reinterpret_cast<size_t>(d_out) % 16) == 0 && !h->one_lane;
+    const bool ps = h->n_off_batch != 0;  // some stream has a compression gain of its own: per-lane tables
     if (pipe) {
-#define AGC_PIPE(LL, CC)                                                                                                          \
-    hipLaunchKernelGGL((agc_pipe_kernel<LL, CC>), grid, dim3(256), 0, s, h->d_s16, h->d_s32, h->d_table, d_in, d_out, h->n_streams, \
-                       n_packets, stream_stride, packet_stride, h->life.d_active)
+#define AGC_PIPE(LL, CC)                                                                                                             \
+    do {                                                                                                                             \
+        if (ps)                                                                                                                      \
+            hipLaunchKernelGGL((agc_pipe_kernel<LL, CC, true>), grid, dim3(256), 0, s, h->d_s16, h->d_s32, h->d_table, h->d_stream_table, \
+                               d_in, d_out, h->n_streams, n_packets, stream_stride, packet_stride, h->life.d_active);                \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((agc_pipe_kernel<LL, CC, false>), grid, dim3(256), 0, s, h->d_s16, h->d_s32, h->d_table,              \
+                               (const uint16_t *)nullptr, d_in, d_out, h->n_streams, n_packets, stream_stride, packet_stride,        \
+                               h->life.d_active);                                                                                    \
+    } while (0)
         if (h->freq == 8000) {
             if (h->chn == 1)
                 AGC_PIPE(8, 1);
@@ -721,9 +876,16 @@ int wmx_agc_process(wmx_agc *h, const int16_t *d_in, int16_t *d_out, int n_packe
         WMX_LAUNCH_CHECK();
         return 0;
     }
-#define AGC_LAUNCH(LL, CC)                                                                                                   \
-    hipLaunchKernelGGL((agc_kernel<LL, CC>), grid, block, 0, s, h->d_s16, h->d_s32, h->d_table, d_in, d_out, h->n_streams, n_packets, \
-                       stream_stride, packet_stride, h->chn, h->life.d_active)
+#define AGC_LAUNCH(LL, CC)                                                                                                          \
+    do {                                                                                                                            \
+        if (ps)                                                                                                                     \
+            hipLaunchKernelGGL((agc_kernel<LL, CC, true>), grid, block, 0, s, h->d_s16, h->d_s32, h->d_table, h->d_stream_table, d_in, \
+                               d_out, h->n_streams, n_packets, stream_stride, packet_stride, h->chn, h->life.d_active);             \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((agc_kernel<LL, CC, false>), grid, block, 0, s, h->d_s16, h->d_s32, h->d_table,                      \
+                               (const uint16_t *)nullptr, d_in, d_out, h->n_streams, n_packets, stream_stride, packet_stride,       \
+                               h->chn, h->life.d_active);                                                                           \
+    } while (0)
     if (h->freq == 8000) {
         if (h->chn == 1)
             AGC_LAUNCH(8, 1);

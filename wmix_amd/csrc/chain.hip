@@ -156,7 +156,12 @@ int wmx_chain_process(wmx_chain *h, const int16_t *d_far, long far_packet_stride
     }
     if (h->aec) {
         const int per = h->aec_pkg / h->pkg10;  // 10 ms packets per AEC packet (1 or 2)
-        if (!delay_ms) delay_ms = h->zero_delays.data();
+        if (!delay_ms) {
+            // sized by the canceller's own count: a cohort added on the inner handle (wmx_chain_aec + wmx_aec_add_cohort) is covered too
+            const size_t nc = (size_t)wmx_aec_cohorts(h->aec);
+            if (h->zero_delays.size() < nc) h->zero_delays.resize(nc, 0);
+            delay_ms = h->zero_delays.data();
+        }
         rc_aec = wmx_aec_run_cohorts(h->aec, 3, d_far, far_packet_stride * per, 0, src, d_out, n10 / per, stream_stride, packet_stride * per,
                                      delay_ms, cohort_on, cohort_rc, stream);
         if (rc_aec != 0 && rc_aec != -1) return rc_aec;  // -1: a cohort's delay was rejected (its code is in cohort_rc); the others ran
@@ -164,7 +169,11 @@ int wmx_chain_process(wmx_chain *h, const int16_t *d_far, long far_packet_stride
     }
     if (h->aecm) {
         const int per = h->aec_pkg / h->pkg10;
-        if (!delay_ms) delay_ms = h->zero_delays.data();
+        if (!delay_ms) {
+            const size_t nc = (size_t)wmx_aecm_cohorts(h->aecm);
+            if (h->zero_delays.size() < nc) h->zero_delays.resize(nc, 0);
+            delay_ms = h->zero_delays.data();
+        }
         rc_aec = wmx_aecm_run_cohorts(h->aecm, 3, d_far, far_packet_stride * per, 0, src, d_out, n10 / per, stream_stride, packet_stride * per,
                                       delay_ms, cohort_on, cohort_rc, stream);
         if (rc_aec != 0 && rc_aec != -1) return rc_aec;
@@ -210,6 +219,26 @@ int wmx_chain_reset_streams(wmx_chain *h, const int32_t *idx, int n, int cohort,
     if (rc == 0 && h->agc) rc = wmx_agc_reset_streams(h->agc, idx, n, stream);
     if (rc == 0 && h->vad) rc = wmx_vad_reset_streams(h->vad, idx, n, stream);
     return rc;
+}
+
+int wmx_chain_reset_streams_gain(wmx_chain *h, const int32_t *idx, int n, int cohort, int agc_value, void *stream) {
+    WMX_ON_DEVICE(h);
+    if (!h) return WMX_EINVAL;
+    int rc = 0;
+    // the one stage that can refuse (agc_init returns NULL for a gain outside the table's range) goes first: nothing is reset then
+    if (rc == 0 && h->agc) rc = wmx_agc_reset_streams_gain(h->agc, idx, n, agc_value, stream);
+    if (rc == 0 && h->ns) rc = wmx_ns_reset_streams(h->ns, idx, n, stream);
+    if (rc == 0 && h->nsx) rc = wmx_nsx_reset_streams(h->nsx, idx, n, stream);
+    if (rc == 0 && h->aec) rc = wmx_aec_reset_streams(h->aec, idx, n, cohort, stream);
+    if (rc == 0 && h->aecm) rc = wmx_aecm_reset_streams(h->aecm, idx, n, cohort, stream);
+    if (rc == 0 && h->vad) rc = wmx_vad_reset_streams(h->vad, idx, n, stream);
+    return rc;
+}
+
+int wmx_chain_set_agc_gain_streams(wmx_chain *h, const int32_t *idx, int n, int agc_value, void *stream) {
+    WMX_ON_DEVICE(h);
+    if (!h) return WMX_EINVAL;
+    return h->agc ? wmx_agc_set_gain_streams(h->agc, idx, n, agc_value, stream) : 0;
 }
 
 int wmx_chain_reset_cohort(wmx_chain *h, int cohort, void *stream) {

@@ -690,7 +690,15 @@ __device__ void nsx_block(NsxWave<ANA, CHN> &W, const NsxConsts &K, const LdsSca
             // stream's histograms, and a wave's memory operations on one address are performed in order -- waiting for its
             // outstanding ones is all it takes.  (An agent-scope acq_rel fence stood here: an L2 write-back per update, 2 ms
             // when every stream of a 65 536-stream batch updated in the same launch.)
+            // The immediate is the gfx9 encoding of vmcnt(0) (bits 3:0 and 15:14; expcnt and lgkmcnt left at their maxima), and on
+            // gfx9 returning atomics and stores both count in vmcnt.  gfx10+ counts stores in vscnt and lays the fields out
+            // differently: this line must not be compiled for anything but gfx9 (round-4 ADVICE).
+#if !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__) && defined(__HIP_DEVICE_COMPILE__)
+#error "nsx.hip: s_waitcnt immediate 0x0f70 is the gfx9 encoding of vmcnt(0)"
+#endif
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // compiler-level ordering edge: nothing moves across the wait
             __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const int16_t *h_lrt = hist, *h_flat = hist + kNsxHist, *h_diff = hist + 2 * kNsxHist;
             int use_diff = 1;
             uint32_t a0 = 0, a1 = 0, a2 = 0, cn = 0;
