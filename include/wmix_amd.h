@@ -305,6 +305,14 @@ int wmx_aec_host_ctl(wmx_aec *h, long *n_launches, double *seconds);
 typedef struct wmx_chain wmx_chain;
 int wmx_chain_create(wmx_chain **out, int n_streams, int chn, int freq, int interval_ms, int agc_value, unsigned stages,
                      int n_cohorts);
+/* stream_cohort: HOST array of n_streams entries (NULL: every stream in cohort 0) -- the cohort (control plane + far-end) each stream
+ * belongs to from the start; wmx_chain_process_groups hands every cohort its OWN far-end: cohort c's 10 ms packet p at
+ * d_far + c * far_group_stride + p * far_packet_stride (aec_process2's far-end is per handle, src/webrtc.c:410) */
+int wmx_chain_create_groups(wmx_chain **out, int n_streams, int chn, int freq, int interval_ms, int agc_value, unsigned stages,
+                            int n_cohorts, const int32_t *stream_cohort);
+int wmx_chain_process_groups(wmx_chain *h, const int16_t *d_far, long far_packet_stride, long far_group_stride, const int16_t *d_in,
+                             int16_t *d_out, int n10, long stream_stride, long packet_stride, const int32_t *delay_ms,
+                             const uint8_t *cohort_on, int32_t *cohort_rc, void *stream);
 int wmx_chain_destroy(wmx_chain *h);
 int wmx_chain_process(wmx_chain *h, const int16_t *d_far, long far_packet_stride, const int16_t *d_in, int16_t *d_out, int n10,
                       long stream_stride, long packet_stride, const int32_t *delay_ms, const uint8_t *cohort_on,
@@ -452,6 +460,40 @@ int wmx_pkgfifo_create(wmx_pkgfifo **out, int n_streams, int n_slots, int pkg_by
 int wmx_pkgfifo_destroy(wmx_pkgfifo *h);
 int wmx_pkgfifo_add(wmx_pkgfifo *h, const uint8_t *d_pkgs, long stride, void *stream);
 int wmx_pkgfifo_get(wmx_pkgfifo *h, uint8_t *d_out, long stride, int delayms, void *stream);
+
+/* ------------------------------------------------------------------ the daemon's tick: play package + record heartbeat
+ * With WMIX_RECORD_PLAY_SYNC (src/wmixConf.h:144) the play thread does, per package of WMIX_INTERVAL_MS: drain the ring head
+ * (src/wmix.c:1347-1366) -> playPkgBuff_add (:1419, :480-491) -> wmix_ao_write -> wmix_shmem_write_circle (:1439): ns_process ->
+ * aec_process2(playPkgBuff_get(AEC_INTERVALMS), ..) -> agc_process -> vad_process on the captured package (:613-709) ->
+ * wmix_pcm_zoom to 1 x 8000 (:730); the task threads feed the ring with wmix_load_data.  wmx_tick is n_groups such daemons side by
+ * side: one ring, one FIFO row and one far-end per mix group, rec_per_group record streams per group (rows g * R .. g * R + R - 1)
+ * whose echo canceller hears THAT group's playback, aec_delay_ms (= AEC_INTERVALMS, platform/alsa/plat.h:52: 400) late.  One mix
+ * group = one control cohort with a far-end of its own.  chn / freq: the ring's and the capture's format (WMIX_CHN / WMIX_FREQ);
+ * stages: WMX_CHAIN_* bits of the heartbeat.
+ *   wmx_tick_load: this tick's wmix_load_data calls (= wmx_mix_load on the tick's mixer; same arguments and cursor rule).
+ *   wmx_tick_play: the play side of one package.  d_play (may be NULL): n_groups rows, play_stride int16 apart <- what goes to the
+ *                  sound card; the far-end package of every group (playPkgBuff_get) is left in wmx_tick_far(h): [n_groups][package]
+ *                  int16 on the device.
+ *   wmx_tick_record: the record side (the heartbeat).  d_rec: n_groups * rec_per_group rows of one package, rec_stride apart:
+ *                  captured audio in, the chain's output out (in place, like the daemon's buffSrc).  d_rec_1x8000 (may be NULL):
+ *                  rows of out_capacity bytes, out_stride int16 apart <- wmix_pcm_zoom(.., 1, 8000); *out_len = bytes per row.
+ *   wmx_tick_run:  both, for audio captured beforehand (the daemon reads the capture between the two, src/wmix.c:609). */
+typedef struct wmx_tick wmx_tick;
+int wmx_tick_create(wmx_tick **out, int n_groups, int rec_per_group, int chn, int freq, int interval_ms, int aec_delay_ms, int agc_value,
+                    unsigned stages);
+int wmx_tick_destroy(wmx_tick *h);
+int wmx_tick_package_samples(const wmx_tick *h); /* int16 elements of one package of one stream = WMIX_PKG_SIZE / 2 */
+int wmx_tick_load(wmx_tick *h, const int16_t *d_src, uint32_t srcU8Len, int freq, int channels, int sample, int n_src, long group_stride,
+                  long source_stride, int reduce, uint32_t *head, uint32_t *tick, void *stream);
+int wmx_tick_play(wmx_tick *h, int16_t *d_play, long play_stride, void *stream);
+const int16_t *wmx_tick_far(const wmx_tick *h);
+int wmx_tick_record(wmx_tick *h, int16_t *d_rec, long rec_stride, int16_t *d_rec_1x8000, long out_stride, uint32_t out_capacity,
+                    uint32_t *out_len, void *stream);
+int wmx_tick_run(wmx_tick *h, int16_t *d_play, long play_stride, int16_t *d_rec, long rec_stride, int16_t *d_rec_1x8000, long out_stride,
+                 uint32_t out_capacity, uint32_t *out_len, void *stream);
+wmx_mix *wmx_tick_mix(wmx_tick *h);
+wmx_chain *wmx_tick_chain(wmx_tick *h);
+wmx_pkgfifo *wmx_tick_fifo(wmx_tick *h);
 
 /* Developer / test hook: the cross-lane FFT executors of the kernels, stand-alone, one transform per wavefront, in place
  * (wmix_amd/csrc/fft_debug.hip lists the kinds: Ooura rdft 128 / 256 through the LDS executor, aec_rdft_128 through the LDS,

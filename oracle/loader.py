@@ -362,6 +362,80 @@ def mix_load(p, ring_chn, ring_freq, freq, chn, rmode, rarg, nsrc, sbytes, start
     return store[:size].view(np.int16).copy(), np.array(meta, np.uint32)
 
 
+# ---------------------------------------------------------------- the daemon's tick, composed (SURVEY 8f-2 closed: FIFO -> AEC)
+TICK_ECHO_DELAY = 40  # samples the room delays the played far-end by on its way into the microphone (the harness' input model)
+
+
+def tick_room(local, far, prev_far):
+    """near = sat(local + (far-end delayed by TICK_ECHO_DELAY samples) >> 1): what a microphone next to the loudspeaker picks up.
+    local [.., N] int16 (the room without the loudspeaker), far / prev_far [N]: this tick's and the previous tick's far-end package."""
+    line = np.concatenate([prev_far, far]).astype(np.int32)
+    n = far.size
+    echo = line[n - TICK_ECHO_DELAY: 2 * n - TICK_ECHO_DELAY] >> 1
+    return np.clip(local.astype(np.int32) + echo, -32768, 32767).astype(np.int16)
+
+
+class _PkgFifo(C.Structure):  # orc_pkgfifo (oracle/orc_pkgfifo.c)
+    _fields_ = [("slots", C.c_void_p), ("n_slots", C.c_int), ("pkg_bytes", C.c_int), ("interval_ms", C.c_int), ("frame_bytes", C.c_int),
+                ("count", C.c_int)]
+
+
+def tick_port(lib, sources, local, src_freq, src_chn, stages=15, agc_value=5, aec_delay_ms=400):
+    """ONE daemon (1 x 8000 Hz ring, 20 ms packages) over T ticks with the restatement, in the play thread's order (src/wmix.c:
+    1347-1440 with wmix_shmem_write_circle inside): the task threads' orc_load_data calls (sources int16 [T, n_src, samples of
+    20 ms]; every source keeps its cursor), the drain of one package, orc_pkgfifo add / get(aec_delay_ms) = the far-end, the room
+    (tick_room), and per record stream (local int16 [T, n_rec, 160]) NS -> AEC(far) -> AGC -> VAD (`stages` bits 1 2 4 8) and the
+    zoom to 1 x 8000.  Returns dict(play [T,160], far [T,160], near [T,n_rec,160], out [T,n_rec,160], zoom [T,n_rec,160])."""
+    mix_bind(lib)
+    T, n_src, per = sources.shape
+    n_rec, N = local.shape[1], 160
+    size = 16000
+    store = np.zeros(size + 64, np.uint8)
+    ring = store[:size].view(np.int16)
+    r = MixRing()
+    lib.orc_mix_ring_init(C.byref(r), store.ctypes.data_as(C.c_void_p), 1, 8000)
+    r.reduce_mode = 1
+    n_slots = aec_delay_ms // 20 + 2
+    fstore = np.zeros(n_slots * 2 * N, np.uint8)
+    f = _PkgFifo()
+    lib.orc_pkgfifo_init(C.byref(f), fstore.ctypes.data_as(C.c_void_p), n_slots, 2 * N, 20, 2)
+    heads, ticks = [0xFFFFFFFF] * n_src, [C.c_uint32(0) for _ in range(n_src)]
+    pad = np.zeros(per + 8, np.int16)
+    play, far = np.zeros((T, N), np.int16), np.zeros((T, N), np.int16)
+    for t in range(T):
+        for i in range(n_src):
+            pad[:per] = sources[t, i]
+            heads[i] = lib.orc_load_data(C.byref(r), pad.ctypes.data_as(C.c_void_p), per * 2, src_freq, src_chn, 16, C.c_uint32(heads[i]), 1,
+                                         C.byref(ticks[i]))
+        pos = (r.head_off // 2 + np.arange(N)) % (size // 2)  # the play thread's package: copy out, zero, head and tick move on
+        play[t] = ring[pos]
+        ring[pos] = 0
+        r.head_off = (r.head_off + 2 * N) % size
+        r.tick += 2 * N
+        lib.orc_pkgfifo_add(C.byref(f), play[t].ctypes.data_as(C.c_void_p))
+        assert lib.orc_pkgfifo_get(C.byref(f), far[t].ctypes.data_as(C.c_void_p), aec_delay_ms) == 0
+    zero = np.zeros(N, np.int16)
+    near = np.stack([tick_room(local[t], far[t], far[t - 1] if t else zero) for t in range(T)])  # [T, n_rec, N]
+    out = np.zeros_like(near)
+    for k in range(n_rec):
+        out[:, k] = run_chain(lib, 1, 8000, agc_value, stages, far.reshape(-1), near[:, k].reshape(-1), N, prefix="orc",
+                              interval_ms=20).reshape(T, N)
+    zoom = np.stack([np.stack([mix_zoom(lib, 1, 8000, out[t, k], 1, 8000) for k in range(n_rec)]) for t in range(T)])
+    return {"play": play, "far": far, "near": near, "out": out, "zoom": zoom}
+
+
+def tick_ref(sources, local, src_freq, src_chn, stages=15, agc_value=5):
+    """The same tick composed from the REAL functions (oracle/_ref/ref_mix_driver tick: wmix_load_data, playPkgBuff_add / _get,
+    ns_process / aec_process2 / agc_process / vad_process, wmix_pcm_zoom as compiled from /root/reference).  Same arguments and
+    result as tick_port (no `near`)."""
+    T, n_src, per = sources.shape
+    n_rec, N = local.shape[1], 160
+    blob = b"".join(np.ascontiguousarray(sources[t]).tobytes() + np.ascontiguousarray(local[t]).tobytes() for t in range(T))
+    raw = np.frombuffer(ref_mix("tick", n_src, src_freq, src_chn, n_rec, T, stages, agc_value, stdin=blob), np.int16)
+    raw = raw.reshape(T, 2 + 2 * n_rec, N)
+    return {"play": raw[:, 0], "far": raw[:, 1], "out": raw[:, 2::2], "zoom": raw[:, 3::2]}
+
+
 # ---------------------------------------------------------------- reference mixer (executable)
 def ref_mix(*args, stdin=b""):
     return subprocess.run([REF_MIX] + [str(a) for a in args], input=stdin, stdout=subprocess.PIPE, check=True).stdout

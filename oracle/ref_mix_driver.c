@@ -24,6 +24,17 @@
  *   ref_mix_driver pkgfifo delayms <ops.bin >out.bin
  *        stdin = a sequence of WMIX_PKG_SIZE-byte packets; each is pushed with playPkgBuff_add and followed by a
  *        playPkgBuff_get(buff, delayms) (src/wmix.c:487-526); the WMIX_PKG_SIZE bytes of every get are written out.
+ *   ref_mix_driver tick nSrc srcFreq srcChn nRec nTicks stages agcValue <in.bin >out.bin
+ *        ONE daemon's tick composed from the reference's own functions, in the order the play thread runs them with
+ *        WMIX_RECORD_PLAY_SYNC (src/wmix.c:1347-1440 with wmix_shmem_write_circle inside, :528-780).  Per tick, stdin holds nSrc
+ *        sources of one WMIX_INTERVAL_MS each in (srcFreq, srcChn) and then nRec captured packages ("local": what the microphone
+ *        would pick up WITHOUT the loudspeaker).  The task threads' wmix_load_data calls (every source keeps its head / tick like a
+ *        task thread does), the play thread's drain of one package (its loop body restated here: copy a sample out, zero it, head
+ *        and tick move on, wrap -- :1347-1366), playPkgBuff_add, playPkgBuff_get(AEC_INTERVALMS) = the far-end, the room (near =
+ *        sat(local + far delayed by 40 samples >> 1): the harness' own input model), then per record handle set ns_process ->
+ *        aec_process2(far, near, near, .., 0) -> agc_process -> vad_process (:613-709, `stages` bits 1 2 4 8 = the webrtcEnable
+ *        switches) and wmix_pcm_zoom to 1 x 8000 (:730).  Written per tick: played package, far-end package, then per record handle set
+ *        its chain output and the zoomed copy (2 * 8000 * WMIX_INTERVAL_MS / 1000 bytes).
  *   ref_mix_driver rtprecv <packets.bin >pcm.bin
  *        every [uint32 len][bytes] record is sent to a socket opened with rtp_socket(bind) and taken through
  *        rtp_recv + G711a2PCM (src/wmixTask.c:1278-1282); writes [uint32 pcm_bytes][pcm][uint16 header seq as stored].
@@ -34,6 +45,7 @@
 #include "wmix.h"
 #include "rtp.h"
 #include "g711codec.h"
+#include "webrtc.h"
 #include <arpa/inet.h>
 #include <sys/socket.h>
 #include <unistd.h>
@@ -141,6 +153,90 @@ int main(int argc, char **argv)
             fwrite(&pcm, 4, 1, stdout);
             fwrite(buff, 1, pcm > sizeof(buff) ? sizeof(buff) : pcm, stdout);
             fwrite(&seq, 2, 1, stdout);
+        }
+        return 0;
+    }
+    if (!strcmp(argv[1], "tick") && argc == 9) {
+        extern void playPkgBuff_add(uint8_t *pkgBuff);
+        extern uint8_t *playPkgBuff_get(uint8_t *buff, int delayms);
+        extern int ref_pin_generic_c(void); /* oracle/ref_shim.c in libwmixref.so: the generic-C AEC kernels */
+        const int nsrc = atoi(argv[2]), sfreq = atoi(argv[3]), schn = atoi(argv[4]), nrec = atoi(argv[5]), nticks = atoi(argv[6]);
+        const unsigned stages = (unsigned)atoi(argv[7]);
+        const int agc_value = atoi(argv[8]);
+        const uint32_t sbytes = (uint32_t)(sfreq / 1000 * WMIX_INTERVAL_MS * schn * 2);
+        const int N = WMIX_FRAME_NUM * WMIX_CHN; /* int16 per package */
+        if (ref_pin_generic_c() != 1) return 7;
+        size_t n;
+        unsigned char *in = slurp(&n);
+        const size_t per_tick = (size_t)nsrc * sbytes + (size_t)nrec * WMIX_PKG_SIZE;
+        if (n < per_tick * nticks) return 3;
+        WMix_Struct *w = calloc(1, sizeof(WMix_Struct));
+        w->buff = calloc(WMIX_BUFF_SIZE + 64, 1);
+        w->start.U8 = w->head.U8 = w->tail.U8 = w->buff;
+        w->end.U8 = w->buff + WMIX_BUFF_SIZE;
+        w->run = true;
+        w->reduceMode = 1;
+        WMix_Point *heads = calloc(nsrc, sizeof(WMix_Point));
+        uint32_t *ticks = calloc(nsrc, sizeof(uint32_t));
+        void **ns = calloc(nrec, sizeof(void *)), **aec = calloc(nrec, sizeof(void *)), **agc = calloc(nrec, sizeof(void *)),
+             **vad = calloc(nrec, sizeof(void *));
+        for (int r = 0; r < nrec; r++) {
+            if (stages & 1) ns[r] = ns_init(WMIX_CHN, WMIX_FREQ, NULL);
+            if (stages & 2) aec[r] = aec_init(WMIX_CHN, WMIX_FREQ, WMIX_INTERVAL_MS, NULL);
+            if (stages & 4) agc[r] = agc_init(WMIX_CHN, WMIX_FREQ, WMIX_INTERVAL_MS, agc_value, NULL);
+            if (stages & 8) vad[r] = vad_init(WMIX_CHN, WMIX_FREQ, WMIX_INTERVAL_MS, NULL);
+            if (((stages & 1) && !ns[r]) || ((stages & 2) && !aec[r]) || ((stages & 4) && !agc[r]) || ((stages & 8) && !vad[r])) return 8;
+        }
+        unsigned char *srcpad = calloc(sbytes + 64, 1); /* the up-sampling fill reads one frame past the source (src/wmix.c:1857) */
+        int16_t *farline = calloc((size_t)(nticks + 1) * N, sizeof(int16_t)); /* package t at (t + 1) * N: one package of silence in front */
+        uint8_t playBuff[WMIX_PKG_SIZE], farBuff[WMIX_PKG_SIZE], buffSrc[WMIX_PKG_SIZE];
+        uint8_t buffDist[2 * 8000 * WMIX_INTERVAL_MS / 1000 + 64];
+        const int echo_delay = 40;
+        for (int t = 0; t < nticks; t++) {
+            const unsigned char *p = in + (size_t)t * per_tick;
+            for (int i = 0; i < nsrc; i++) { /* the task threads */
+                memcpy(srcpad, p + (size_t)i * sbytes, sbytes);
+                WMix_Point s = {.U8 = srcpad};
+                heads[i] = wmix_load_data(w, s, sbytes, sfreq, schn, 16, heads[i], 1, &ticks[i]);
+            }
+            /* the play thread: one package */
+            if (w->head.U8 >= w->end.U8) w->head.U8 = w->start.U8;
+            WMix_Point dist = {.U8 = playBuff};
+            for (uint32_t count = 0; count < WMIX_PKG_SIZE;) {
+#if (WMIX_CHN == 1)
+                *dist.U16++ = *w->head.U16;
+                *w->head.U16++ = 0;
+                w->tick += 2;
+                count += 2;
+#else
+                *dist.U32++ = *w->head.U32;
+                *w->head.U32++ = 0;
+                w->tick += 4;
+                count += 4;
+#endif
+                if (w->head.U8 >= w->end.U8) w->head.U8 = w->start.U8;
+            }
+            playPkgBuff_add(playBuff);
+            fwrite(playBuff, 1, WMIX_PKG_SIZE, stdout);
+            playPkgBuff_get(farBuff, AEC_INTERVALMS);
+            fwrite(farBuff, 1, WMIX_PKG_SIZE, stdout);
+            memcpy(farline + (size_t)(t + 1) * N, farBuff, WMIX_PKG_SIZE);
+            for (int r = 0; r < nrec; r++) { /* the record heartbeat of handle set r */
+                const int16_t *local = (const int16_t *)(p + (size_t)nsrc * sbytes + (size_t)r * WMIX_PKG_SIZE);
+                int16_t *near = (int16_t *)buffSrc;
+                for (int i = 0; i < N; i++) {
+                    int v = local[i] + (farline[(size_t)(t + 1) * N + i - echo_delay] >> 1);
+                    near[i] = (int16_t)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v));
+                }
+                if (ns[r]) ns_process(ns[r], near, near, WMIX_FRAME_NUM);
+                if (aec[r] && aec_process2(aec[r], (int16_t *)farBuff, near, near, WMIX_FRAME_NUM, 0) != 0) return 9;
+                if (agc[r] && agc_process(agc[r], near, near, WMIX_FRAME_NUM) != 0) return 10;
+                if (vad[r]) vad_process(vad[r], near, WMIX_FRAME_NUM);
+                fwrite(buffSrc, 1, WMIX_PKG_SIZE, stdout);
+                memset(buffDist, 0, sizeof(buffDist));
+                wmix_pcm_zoom(WMIX_CHN, WMIX_FREQ, buffSrc, WMIX_PKG_SIZE, 1, 8000, buffDist);
+                fwrite(buffDist, 1, 2 * 8000 * WMIX_INTERVAL_MS / 1000, stdout);
+            }
         }
         return 0;
     }

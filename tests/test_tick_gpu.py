@@ -1,0 +1,108 @@
+"""GPU parity of wmx_tick (wmix_amd/csrc/tick.hip): the daemon's tick end to end for several mixers side by side -- the task
+threads' wmix_load_data into each group's ring, the play thread's package, playPkgBuff_add / playPkgBuff_get(AEC_INTERVALMS), the
+record heartbeat NS -> AEC(far = THAT group's delayed playback) -> AGC -> VAD per record stream and the zoom to 1 x 8000
+(src/wmix.c:1347-1440 with wmix_shmem_write_circle, :528-780, inside; round-4 VERDICT "next" 3: the delay FIFO feeding the AEC).
+Every group is compared with ONE daemon composed from the restatement (oracle.loader.tick_port) and, where oracle/_ref travelled,
+from the real functions (ref_mix_driver tick): played package, far-end package bit for bit; the chain's output and its 1 x 8000
+copy within 1 LSB (float NS / AEC), and bit for bit when the chain is the fixed-point one."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import loader as L
+from test_aec_gpu import check_float_path
+from test_tick_oracle import tick_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def room(local, far, prev_far):
+    """oracle.loader.tick_room on the device: local [S, N], far / prev_far [G, N] with S = G * R record streams"""
+    G, N = far.shape
+    R = local.shape[0] // G
+    line = torch.cat([prev_far, far], 1).to(torch.int32)
+    echo = (line[:, N - L.TICK_ECHO_DELAY: 2 * N - L.TICK_ECHO_DELAY] >> 1).repeat_interleave(R, 0)
+    return torch.clamp(local.to(torch.int32) + echo, -32768, 32767).to(torch.int16)
+
+
+def gpu_tick(cuda, src, local, src_freq, src_chn, stages, agc_value=5):
+    """src [G, T, n_src, per], local [G, T, R, 160] -> dict of numpy arrays shaped like tick_port's, per group"""
+    from wmix_amd.tick import TickBatch
+    G, T, n_src, per = src.shape
+    R = local.shape[2]
+    tb = TickBatch(G, R, stages=stages, agc_value=agc_value)
+    assert tb.pkg == 160
+    dsrc = torch.zeros((T, G, n_src, per + 2 * src_chn), dtype=torch.int16, device=cuda)  # + the up-sampling fill's look-ahead frame
+    dsrc[..., :per] = torch.from_numpy(np.ascontiguousarray(src.transpose(1, 0, 2, 3))).to(cuda)
+    dloc = torch.from_numpy(np.ascontiguousarray(local.transpose(1, 0, 2, 3)).reshape(T, G * R, 160)).to(cuda)
+    play = torch.zeros((T, G, 160), dtype=torch.int16, device=cuda)
+    far = torch.zeros((T, G, 160), dtype=torch.int16, device=cuda)
+    out = torch.zeros((T, G * R, 160), dtype=torch.int16, device=cuda)
+    zoom = torch.zeros((T, G * R, 160), dtype=torch.int16, device=cuda)
+    prev = torch.zeros((G, 160), dtype=torch.int16, device=cuda)
+    for t in range(T):
+        tb.load(dsrc[t], per * 2, src_freq, src_chn)
+        f = tb.play(play[t])
+        far[t].copy_(f)
+        out[t].copy_(room(dloc[t], f, prev))
+        prev = far[t]
+        assert tb.record(out[t], zoom[t]) == 320
+    tb.close()
+    sh = lambda x: x.cpu().numpy().reshape(T, G, -1, 160).transpose(1, 0, 2, 3)  # noqa: E731
+    return {"play": play.cpu().numpy().transpose(1, 0, 2), "far": far.cpu().numpy().transpose(1, 0, 2), "out": sh(out), "zoom": sh(zoom)}
+
+
+@pytest.mark.parametrize("src_freq,src_chn,n_src,R,stages,T", [
+    (32000, 2, 8, 2, 15, 170),       # configs[4]'s sources, 8 per group, two record streams per group, the whole heartbeat
+    (8000, 1, 3, 1, 15, 120),        # the shipped format on both sides
+    (16000, 1, 2, 1, 15 | 16 | 32, 140),  # the fixed-point chain (NSX + AECM): integer end to end
+])
+def test_tick_vs_one_daemon_per_group(cuda, oracle_port, src_freq, src_chn, n_src, R, stages, T):
+    G = 5
+    per_group = [tick_inputs(100 + 13 * g, T, n_src, R, src_freq, src_chn, loud=(12000 if g == 3 else 7000)) for g in range(G)]
+    src = np.stack([p[0] for p in per_group])     # [G, T, n_src, per]
+    local = np.stack([p[1] for p in per_group])   # [G, T, R, 160]
+    local[1, :, 0] = 0  # a record stream in a silent room: it hears the loudspeaker only
+    src[2] = 0          # a group nobody plays into: far-end silence, the cancellers pass the talkers through
+    got = gpu_tick(cuda, src, local, src_freq, src_chn, stages)
+    fx = bool(stages & 48)
+    for g in range(G):
+        if fx:  # NSX -> AECM -> AGC -> VAD through the restatement's own whole-run drivers, on the far / near of tick_port
+            base = L.tick_port(oracle_port, src[g], local[g], src_freq, src_chn, stages=0)
+            want = dict(base)
+            o = np.zeros_like(base["near"])
+            for k in range(R):
+                x = L.run_nsx(oracle_port, 1, 8000, base["near"][:, k].reshape(-1), 160, prefix="orc")
+                x = L.run_aecm(oracle_port, 1, 8000, 20, base["far"].reshape(-1), x, 160, 0, prefix="orc")
+                x = L.run_agc(oracle_port, 1, 8000, 5, x, 160, prefix="orc")
+                o[:, k] = L.run_vad(oracle_port, 1, 8000, 20, x, 160, prefix="orc").reshape(T, 160)
+            want["out"] = want["zoom"] = o
+        else:
+            want = L.tick_port(oracle_port, src[g], local[g], src_freq, src_chn, stages=stages)
+        assert np.array_equal(got["play"][g], want["play"]), ("play", g)
+        assert np.array_equal(got["far"][g], want["far"]), ("far", g)
+        if fx:
+            assert np.array_equal(got["out"][g], want["out"]), ("out", g)
+        else:
+            check_float_path(got["out"][g].reshape(-1), want["out"].reshape(-1))
+        assert np.array_equal(got["zoom"][g], got["out"][g])  # 1 x 8000 -> 1 x 8000: wmix_pcm_zoom copies
+        if L.have_ref_mix() and not fx and g in (0, 3):
+            real = L.tick_ref(src[g], local[g], src_freq, src_chn, stages=stages)
+            assert np.array_equal(got["play"][g], real["play"]) and np.array_equal(got["far"][g], real["far"])
+            check_float_path(got["out"][g].reshape(-1), real["out"].reshape(-1))
+    assert not got["play"][2].any() and got["play"][0].any()
+
+
+def test_tick_groups_do_not_hear_each_other(cuda, oracle_port):
+    """Group g's cancellers get group g's playback and nothing else: swapping what another group plays changes nothing here."""
+    G, T, n_src, R = 3, 110, 2, 1
+    per_group = [tick_inputs(300 + g, T, n_src, R, 8000, 1) for g in range(G)]
+    src = np.stack([p[0] for p in per_group])
+    local = np.stack([p[1] for p in per_group])
+    a = gpu_tick(cuda, src, local, 8000, 1, 15)
+    src2 = src.copy()
+    src2[1] = src[1][::-1]
+    b = gpu_tick(cuda, src2, local, 8000, 1, 15)
+    for g in (0, 2):
+        assert np.array_equal(a["out"][g], b["out"][g]) and np.array_equal(a["far"][g], b["far"][g])
+    assert not np.array_equal(a["out"][1], b["out"][1])

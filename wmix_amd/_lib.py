@@ -107,6 +107,27 @@ def _declare(L):
     L.wmx_agc_destroy.argtypes = [vp]
     L.wmx_agc_set_gain.restype = i
     L.wmx_agc_set_gain.argtypes = [vp, i]
+    L.wmx_chain_create_groups.restype = i
+    L.wmx_chain_create_groups.argtypes = [C.POINTER(vp), i, i, i, i, i, C.c_uint, i, vp]
+    L.wmx_chain_process_groups.restype = i
+    L.wmx_chain_process_groups.argtypes = [vp, vp, C.c_long, C.c_long, vp, vp, i, C.c_long, C.c_long, vp, vp, vp, vp]
+    L.wmx_tick_create.restype = i
+    L.wmx_tick_create.argtypes = [C.POINTER(vp), i, i, i, i, i, i, i, C.c_uint]
+    L.wmx_tick_destroy.restype = i
+    L.wmx_tick_destroy.argtypes = [vp]
+    L.wmx_tick_package_samples.restype = i
+    L.wmx_tick_package_samples.argtypes = [vp]
+    L.wmx_tick_load.restype = i
+    L.wmx_tick_load.argtypes = [vp, vp, C.c_uint32, i, i, i, i, C.c_long, C.c_long, i, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), vp]
+    L.wmx_tick_run.restype = i
+    L.wmx_tick_run.argtypes = [vp, vp, C.c_long, vp, C.c_long, vp, C.c_long, C.c_uint32, C.POINTER(C.c_uint32), vp]
+    L.wmx_tick_play.restype = i
+    L.wmx_tick_play.argtypes = [vp, vp, C.c_long, vp]
+    L.wmx_tick_record.restype = i
+    L.wmx_tick_record.argtypes = [vp, vp, C.c_long, vp, C.c_long, C.c_uint32, C.POINTER(C.c_uint32), vp]
+    for name in ("wmx_tick_mix", "wmx_tick_chain", "wmx_tick_fifo", "wmx_tick_far"):
+        getattr(L, name).restype = vp
+        getattr(L, name).argtypes = [vp]
     L.wmx_agc_set_gain_streams.restype = i
     L.wmx_agc_set_gain_streams.argtypes = [vp, vp, i, i, vp]
     L.wmx_agc_reset_streams_gain.restype = i

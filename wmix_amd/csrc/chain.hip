@@ -44,6 +44,13 @@ int wmx_chain_destroy(wmx_chain *h) {
 }
 
 int wmx_chain_create(wmx_chain **out, int n_streams, int chn, int freq, int interval_ms, int agc_value, unsigned stages, int n_cohorts) {
+    return wmx_chain_create_groups(out, n_streams, chn, freq, interval_ms, agc_value, stages, n_cohorts, nullptr);
+}
+
+// stream_cohort (HOST array of n_streams entries, or NULL = every stream in cohort 0): the cohort -- control plane and far-end --
+// each stream belongs to from the start, e.g. the mix group whose playback a record stream hears (wmx_tick)
+int wmx_chain_create_groups(wmx_chain **out, int n_streams, int chn, int freq, int interval_ms, int agc_value, unsigned stages, int n_cohorts,
+                            const int32_t *stream_cohort) {
     if (!out) return WMX_EINVAL;
     *out = nullptr;
     if ((stages & 15u) == 0 || (stages & ~63u) != 0 || n_cohorts < 1 || ((stages & WMX_CHAIN_NSX) && !(stages & WMX_CHAIN_NS)) ||
@@ -72,7 +79,22 @@ int wmx_chain_create(wmx_chain **out, int n_streams, int chn, int freq, int inte
         rc = (stages & WMX_CHAIN_NSX) ? wmx_nsx_create(&h->nsx, n_streams, chn, freq) : wmx_ns_create(&h->ns, n_streams, chn, freq);
     if (rc == 0 && (stages & WMX_CHAIN_AEC))
         rc = (stages & WMX_CHAIN_AECM) ? wmx_aecm_create_cohorts(&h->aecm, n_streams, chn, freq, interval_ms, n_cohorts)
-                                       : wmx_aec_create_groups(&h->aec, n_streams, chn, freq, interval_ms, n_cohorts, nullptr);
+                                       : wmx_aec_create_groups(&h->aec, n_streams, chn, freq, interval_ms, n_cohorts, stream_cohort);
+    if (rc == 0 && h->aecm && stream_cohort && n_cohorts > 1) {
+        // the fixed-point canceller takes memberships through its reset call: one call per cohort that has members (create time only)
+        std::vector<std::vector<int32_t>> members((size_t)n_cohorts);
+        for (int s = 0; s < n_streams && rc == 0; s++) {
+            if (stream_cohort[s] < 0 || stream_cohort[s] >= n_cohorts) {
+                wmx::set_error("wmx_chain_create_groups: stream %d in cohort %d of %d", s, stream_cohort[s], n_cohorts);
+                rc = WMX_EINVAL;
+            } else {
+                members[(size_t)stream_cohort[s]].push_back(s);
+            }
+        }
+        for (int c = 1; c < n_cohorts && rc == 0; c++)
+            if (!members[(size_t)c].empty()) rc = wmx_aecm_reset_streams(h->aecm, members[(size_t)c].data(), (int)members[(size_t)c].size(), c, nullptr);
+        if (rc == 0 && hipDeviceSynchronize() != hipSuccess) rc = WMX_ENODEV;
+    }
     if (rc == 0 && (stages & WMX_CHAIN_AGC)) rc = wmx_agc_create(&h->agc, n_streams, chn, freq, interval_ms, agc_value);
     if (rc == 0 && (stages & WMX_CHAIN_VAD)) rc = wmx_vad_create(&h->vad, n_streams, chn, freq, interval_ms);
     if (rc != 0) {
@@ -102,6 +124,16 @@ wmx_vad *wmx_chain_vad(wmx_chain *h) { return h ? h->vad : nullptr; }
 int wmx_chain_process(wmx_chain *h, const int16_t *d_far, long far_packet_stride, const int16_t *d_in, int16_t *d_out, int n10,
                       long stream_stride, long packet_stride, const int32_t *delay_ms, const uint8_t *cohort_on, int32_t *cohort_rc,
                       void *stream) {
+    return wmx_chain_process_groups(h, d_far, far_packet_stride, 0, d_in, d_out, n10, stream_stride, packet_stride, delay_ms, cohort_on, cohort_rc,
+                                    stream);
+}
+
+// The same with a far-end PER COHORT: cohort c's 10 ms packet p at d_far + c * far_group_stride + p * far_packet_stride
+// (far_group_stride 0: one far-end for all, wmx_chain_process).  aec_process2 takes the far-end per handle (src/webrtc.c:410); in the
+// daemon it is playPkgBuff_get() of that daemon's own playback (src/wmix.c:651-657).
+int wmx_chain_process_groups(wmx_chain *h, const int16_t *d_far, long far_packet_stride, long far_group_stride, const int16_t *d_in,
+                             int16_t *d_out, int n10, long stream_stride, long packet_stride, const int32_t *delay_ms, const uint8_t *cohort_on,
+                             int32_t *cohort_rc, void *stream) {
     WMX_ON_DEVICE(h);
     if (!h || n10 < 0) {
         wmx::set_error("wmx_chain_process: bad argument");
@@ -162,7 +194,7 @@ int wmx_chain_process(wmx_chain *h, const int16_t *d_far, long far_packet_stride
             if (h->zero_delays.size() < nc) h->zero_delays.resize(nc, 0);
             delay_ms = h->zero_delays.data();
         }
-        rc_aec = wmx_aec_run_cohorts(h->aec, 3, d_far, far_packet_stride * per, 0, src, d_out, n10 / per, stream_stride, packet_stride * per,
+        rc_aec = wmx_aec_run_cohorts(h->aec, 3, d_far, far_packet_stride * per, far_group_stride, src, d_out, n10 / per, stream_stride, packet_stride * per,
                                      delay_ms, cohort_on, cohort_rc, stream);
         if (rc_aec != 0 && rc_aec != -1) return rc_aec;  // -1: a cohort's delay was rejected (its code is in cohort_rc); the others ran
         src = d_out;
@@ -174,7 +206,7 @@ int wmx_chain_process(wmx_chain *h, const int16_t *d_far, long far_packet_stride
             if (h->zero_delays.size() < nc) h->zero_delays.resize(nc, 0);
             delay_ms = h->zero_delays.data();
         }
-        rc_aec = wmx_aecm_run_cohorts(h->aecm, 3, d_far, far_packet_stride * per, 0, src, d_out, n10 / per, stream_stride, packet_stride * per,
+        rc_aec = wmx_aecm_run_cohorts(h->aecm, 3, d_far, far_packet_stride * per, far_group_stride, src, d_out, n10 / per, stream_stride, packet_stride * per,
                                       delay_ms, cohort_on, cohort_rc, stream);
         if (rc_aec != 0 && rc_aec != -1) return rc_aec;
         src = d_out;

@@ -1,0 +1,160 @@
+// tick.hip -- the daemon's 20 ms tick, play side and record side together, as ONE C call for many mixers (host code only: it
+// sequences launches of mix.hip, pkgfifo.hip, chain.hip).
+//
+// With WMIX_RECORD_PLAY_SYNC (src/wmixConf.h:144, the shipped configuration) the play thread does, per package of
+// WMIX_INTERVAL_MS (src/wmix.c:1347-1440):
+//     drain WMIX_PKG_SIZE bytes at the ring head (copy out, zero, head and tick advance)          :1347-1366
+//     playPkgBuff_add(playBuff)                                                                    :1419   (:480-491)
+//     wmix_ao_write(playBuff)                                                                      :1421   -> d_play, the caller's
+//     wmix_shmem_write_circle():                                                                   :1439   (:528-780)
+//         buffSrc = wmix_ai_read()                                                                 :609    <- d_rec, the caller's
+//         ns_process -> aec_process2(playPkgBuff_get(AEC_INTERVALMS), buffSrc, buffSrc, .., 0) -> agc_process -> vad_process
+//                                                                                                  :613-709
+//         wmix_pcm_zoom(WMIX_CHN, WMIX_FREQ, buffSrc, .., 1, 8000, buffDist)                       :730    -> d_rec_1x8000
+// while the task threads put their sources into the ring with wmix_load_data (src/wmixTask.c:85, 973, 1311, 1484, 1704, 1927).
+//
+// A wmx_tick is G such daemons side by side: G rings (one mix group each), one FIFO slot row per group, and R record streams per
+// group whose echo canceller hears THAT group's delayed playback -- one mix group = one far-end = one control cohort, so nothing
+// folds (round-4 VERDICT "next" 3).  The record streams of group g are the rows g * R .. g * R + R - 1.
+#include <vector>
+#include "wmx_internal.h"
+
+struct wmx_tick {
+    int device;  // first member of every handle (wmx_handle_device)
+    int n_groups, rec_per_group, chn, freq, interval_ms, aec_delay_ms;
+    int pkg;          // int16 elements of one package of one stream: freq / 1000 * interval_ms * chn  (WMIX_PKG_SIZE / 2)
+    wmx_mix *mix;
+    wmx_pkgfifo *fifo;
+    wmx_chain *chain;
+    int16_t *d_play;  // [n_groups][pkg] when the caller does not want the playback
+    int16_t *d_far;   // [n_groups][pkg] playPkgBuff_get()'s packet of every group
+};
+
+extern "C" {
+
+int wmx_tick_destroy(wmx_tick *h) {
+    WMX_ON_DEVICE(h);
+    if (!h) return 0;
+    if (h->mix) wmx_mix_destroy(h->mix);
+    if (h->fifo) wmx_pkgfifo_destroy(h->fifo);
+    if (h->chain) wmx_chain_destroy(h->chain);
+    if (h->d_play) (void)hipFree(h->d_play);
+    if (h->d_far) (void)hipFree(h->d_far);
+    delete h;
+    return 0;
+}
+
+int wmx_tick_create(wmx_tick **out, int n_groups, int rec_per_group, int chn, int freq, int interval_ms, int aec_delay_ms, int agc_value,
+                    unsigned stages) {
+    if (!out) return WMX_EINVAL;
+    *out = nullptr;
+    if (n_groups < 1 || rec_per_group < 1 || interval_ms < 10 || interval_ms % 10 || aec_delay_ms < 0 || aec_delay_ms % interval_ms) {
+        // (a delay that is not a whole number of packages makes the reference's FIFO read a byte range that straddles two slots,
+        // src/wmix.c:511-523; wmx_pkgfifo does that too, but no platform of the reference asks for it)
+        wmx::set_error("wmx_tick_create: n_groups=%d rec_per_group=%d interval_ms=%d aec_delay_ms=%d", n_groups, rec_per_group, interval_ms,
+                       aec_delay_ms);
+        return WMX_EINVAL;
+    }
+    wmx_tick *h = new wmx_tick();
+    if ((h->device = wmx::current_device()) < 0) {
+        delete h;
+        return WMX_ENODEV;
+    }
+    h->n_groups = n_groups;
+    h->rec_per_group = rec_per_group;
+    h->chn = chn;
+    h->freq = freq;
+    h->interval_ms = interval_ms;
+    h->aec_delay_ms = aec_delay_ms;
+    h->pkg = freq / 1000 * interval_ms * chn;
+    int rc = wmx_mix_create(&h->mix, n_groups, chn, freq);
+    // AEC_FIFO_PKG_NUM = AEC_INTERVALMS / WMIX_INTERVAL_MS + 2 slots of WMIX_PKG_SIZE bytes, src/wmixConf.h:141
+    if (rc == 0) rc = wmx_pkgfifo_create(&h->fifo, n_groups, aec_delay_ms / interval_ms + 2, h->pkg * 2, interval_ms, chn * 2);
+    if (rc == 0) {
+        std::vector<int32_t> cohort((size_t)n_groups * rec_per_group);
+        for (size_t s = 0; s < cohort.size(); s++) cohort[s] = (int32_t)(s / (size_t)rec_per_group);
+        // one cohort per group only where a canceller needs it: without one the chain has no far-end at all
+        const int nc = (stages & WMX_CHAIN_AEC) ? n_groups : 1;
+        rc = wmx_chain_create_groups(&h->chain, n_groups * rec_per_group, chn, freq, interval_ms, agc_value, stages, nc,
+                                     nc > 1 ? cohort.data() : nullptr);
+    }
+    if (rc == 0) {
+        hipError_t e = hipMalloc(&h->d_play, (size_t)n_groups * h->pkg * sizeof(int16_t));
+        if (e == hipSuccess) e = hipMalloc(&h->d_far, (size_t)n_groups * h->pkg * sizeof(int16_t));
+        if (e != hipSuccess) rc = wmx::hip_fail(e, "hipMalloc(tick buffers)", __FILE__, __LINE__);
+    }
+    if (rc != 0) {
+        wmx_tick_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+wmx_mix *wmx_tick_mix(wmx_tick *h) { return h ? h->mix : nullptr; }
+wmx_chain *wmx_tick_chain(wmx_tick *h) { return h ? h->chain : nullptr; }
+wmx_pkgfifo *wmx_tick_fifo(wmx_tick *h) { return h ? h->fifo : nullptr; }
+int wmx_tick_package_samples(const wmx_tick *h) { return h ? h->pkg : WMX_EINVAL; }
+
+// the task threads' wmix_load_data calls of this tick: wmx_mix_load on the tick's mixer (same arguments, same cursor rule)
+int wmx_tick_load(wmx_tick *h, const int16_t *d_src, uint32_t srcU8Len, int freq, int channels, int sample, int n_src, long group_stride,
+                  long source_stride, int reduce, uint32_t *head, uint32_t *tick, void *stream) {
+    if (!h) return WMX_EINVAL;
+    return wmx_mix_load(h->mix, d_src, srcU8Len, freq, channels, sample, n_src, group_stride, source_stride, reduce, head, tick, stream);
+}
+
+// The play side of one package (src/wmix.c:1347-1421): drain -> playPkgBuff_add -> what goes to the sound card (d_play, may be NULL:
+// n_groups rows, play_stride int16 apart) -- and playPkgBuff_get(AEC_INTERVALMS) into the tick's far-end rows, which the record side
+// of the same package will hand the echo cancellers (the daemon fetches it inside the heartbeat, :651; the FIFO does not move in
+// between, so fetching it here is the same packet).
+int wmx_tick_play(wmx_tick *h, int16_t *d_play, long play_stride, void *stream) {
+    WMX_ON_DEVICE(h);
+    if (!h || (d_play && play_stride < h->pkg)) {
+        wmx::set_error("wmx_tick_play: bad argument");
+        return WMX_EINVAL;
+    }
+    int16_t *play = d_play ? d_play : h->d_play;
+    const long pstride = d_play ? play_stride : (long)h->pkg;
+    const uint32_t pkg_bytes = (uint32_t)h->pkg * 2;
+    int rc = wmx_mix_drain(h->mix, play, pkg_bytes, pstride, stream);
+    if (rc == 0) rc = wmx_pkgfifo_add(h->fifo, reinterpret_cast<const uint8_t *>(play), pstride * 2, stream);
+    if (rc == 0) rc = wmx_pkgfifo_get(h->fifo, reinterpret_cast<uint8_t *>(h->d_far), (long)pkg_bytes, h->aec_delay_ms, stream);
+    return rc;
+}
+
+// the far-end package of every group as wmx_tick_play left it: [n_groups][package] int16 on the device (a harness that models the
+// room -- loudspeaker into microphone -- reads it between the two halves of a tick)
+const int16_t *wmx_tick_far(const wmx_tick *h) { return h ? h->d_far : nullptr; }
+
+// The record side of the package = wmix_shmem_write_circle (src/wmix.c:528-780) for every record stream.  d_rec: n_groups *
+// rec_per_group rows of one package each, rec_stride apart: the captured audio in, the chain's output out (in place, like buffSrc).
+// d_rec_1x8000 (may be NULL): rows of out_capacity bytes, out_stride int16 apart, receive wmix_pcm_zoom(.., 1, 8000); *out_len the
+// bytes written per row.
+int wmx_tick_record(wmx_tick *h, int16_t *d_rec, long rec_stride, int16_t *d_rec_1x8000, long out_stride, uint32_t out_capacity,
+                    uint32_t *out_len, void *stream) {
+    WMX_ON_DEVICE(h);
+    if (!h || !d_rec || rec_stride < h->pkg) {
+        wmx::set_error("wmx_tick_record: bad argument");
+        return WMX_EINVAL;
+    }
+    const int pkg10 = h->freq / 100 * h->chn;
+    int rc = wmx_chain_process_groups(h->chain, h->d_far, pkg10, h->pkg, d_rec, d_rec, h->interval_ms / 10, rec_stride, pkg10, nullptr, nullptr,
+                                      nullptr, stream);
+    if (rc != 0) return rc;
+    if (d_rec_1x8000) {
+        uint32_t got = 0;
+        rc = wmx_pcm_zoom(h->chn, h->freq, d_rec, (uint32_t)h->pkg * 2, 1, 8000, d_rec_1x8000, out_capacity, rec_stride, out_stride,
+                          h->n_groups * h->rec_per_group, &got, stream);
+        if (out_len) *out_len = got;
+    }
+    return rc;
+}
+
+// One whole package: the play side, then the record side on audio that was captured beforehand.
+int wmx_tick_run(wmx_tick *h, int16_t *d_play, long play_stride, int16_t *d_rec, long rec_stride, int16_t *d_rec_1x8000, long out_stride,
+                 uint32_t out_capacity, uint32_t *out_len, void *stream) {
+    const int rc = wmx_tick_play(h, d_play, play_stride, stream);
+    return rc ? rc : wmx_tick_record(h, d_rec, rec_stride, d_rec_1x8000, out_stride, out_capacity, out_len, stream);
+}
+
+}  // extern "C"
