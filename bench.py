@@ -991,6 +991,143 @@ class NsAgcMix32kWorkload:
                           "cores" % (reps, n, nc)}
 
 
+class ConferenceWorkload:
+    """The daemon's tick end to end, 4 096 daemons side by side (round-4 VERDICT "next" 3; BASELINE configs[4]'s shape on the play
+    side, the shipped platform's format on the record side): per 20 ms tick and mix group eight 2-channel 32 kHz sources ->
+    wmix_load_data into the group's 1 x 8000 ring -> the play thread's package -> playPkgBuff_add -> playPkgBuff_get(400 ms) = the
+    far-end of THAT group's eight record streams -> NS -> AEC -> AGC -> VAD (20 ms AEC and VAD packets) -> wmix_pcm_zoom to 1 x 8000
+    (src/wmix.c:1347-1440 with :528-780 inside; one C call per half: wmx_tick_play / wmx_tick_record).  One mix group = one control
+    cohort with a far-end of its own: nothing folds, 4 096 far-end histories are live.  A step = one tick; `value` counts the RECORD
+    side's 10 ms stream-frames (2 per stream and tick); the play side's 32 768 source packages per tick ride along.
+    Algorithmic bytes per record stream-frame: 320 PCM + 2 x (6 000 + 11 700 + 668 + 736) state (SURVEY 8d, 8 kHz) + the group's far-end
+    spectra, which its R = 8 streams share: 2 x (6 240 + 6 240) / 8 (SURVEY 8d "non-shared far adds xfBuf + xfwBuf") = 41 648 B, plus
+    per source-frame 1 280 B of PCM in and the ring's 160 x (1 + 1/8) B = 1 460 B: 43 108 B.  Dominant kernel aec_near_kernel<1>:
+    160 + 160 + 2 x 11 700 + 24 960 / 8 = 26 840 B."""
+    name = "conference_mix8_32k_to_8k_chain"
+    pmc_tag = "conference"
+    dtype = "int16 (mix, FIFO, AGC, VAD), f32 (NS, AEC)"
+    bytes_per_frame = 43108.0
+    dominant_kernel = "aec_near_kernel<1>"
+    dominant_bytes_per_frame = 26840.0
+    N, R = 8, 8  # sources and record streams per mix group
+
+    def __init__(self, dev, n_streams, rank):
+        from wmix_amd import synth
+        from wmix_amd.tick import TickBatch
+        S = self.S = n_streams
+        assert S % self.R == 0
+        G = self.G = S // self.R
+        self.n_frames = 2 * S  # 10 ms record stream-frames per tick
+        self.K, U = 50, 16     # 50 ticks (1 s) of 16 distinct groups, tiled over the batch
+        self.U = U
+        per = 1280
+        groups = [synth.conference_inputs(7000 + 7919 * rank + 13 * u, self.K, self.N, self.R, 32000, 2, loud=9000) for u in range(U)]
+        self.src_host = np.stack([g[0] for g in groups])    # [U, K, N, per]
+        self.loc_host = np.stack([g[1] for g in groups])    # [U, K, R, 160]
+        gi = torch.arange(G, device=dev) % U
+        s_pad = torch.zeros((self.K, U, self.N, per + 2), dtype=torch.int16, device=dev)  # + the mixer's look-ahead frame
+        s_pad[..., :per] = torch.from_numpy(np.ascontiguousarray(self.src_host.transpose(1, 0, 2, 3))).to(dev)
+        self.src = s_pad[:, gi].contiguous()                                               # [K, G, N, per + 2]
+        loc = torch.from_numpy(np.ascontiguousarray(self.loc_host.transpose(1, 0, 2, 3))).to(dev)  # [K, U, R, 160]
+        self.loc = loc[:, gi].reshape(self.K, S, 160).contiguous()
+        self.tb = TickBatch(G, self.R)  # 1 x 8000, 20 ms, AEC_INTERVALMS 400, volumeAgc 5, the whole heartbeat
+        self.rec = torch.zeros((S, 160), dtype=torch.int16, device=dev)
+        self.zoom = torch.zeros((S, 160), dtype=torch.int16, device=dev)
+        self.play = torch.zeros((G, 160), dtype=torch.int16, device=dev)
+        self.prev_far = torch.zeros((G, 160), dtype=torch.int16, device=dev)
+        self.t = _StageTimer("none")  # the dominant kernel is timed by the library's own events (wmx_aec_set_timing)
+        self.k = 0
+        self.near_ms, self.far_ms, self.aec_launches = 0.0, 0.0, 0
+        self.groups = sorted({int(g) for g in np.linspace(0, G - 1, 4)})
+        self.rows = [g * self.R + r for g in self.groups for r in range(self.R)]
+        self.rec_log = []
+
+    def _room(self, local, far):
+        """near = sat(local + (the group's far-end delayed by 40 samples) >> 1): the loudspeaker in the microphone (the harness' input
+        model, oracle.loader.tick_room on the device; it needs this tick's far-end, so it runs between the tick's two halves)"""
+        N = 160
+        line = torch.cat([self.prev_far, far], 1).to(torch.int32)
+        echo = (line[:, N - 40: 2 * N - 40] >> 1).repeat_interleave(self.R, 0)
+        torch.clamp(local.to(torch.int32) + echo, -32768, 32767, out=echo)
+        self.rec.copy_(echo)
+        self.prev_far.copy_(far)
+
+    def timed_region(self, on):
+        L = self.tb
+        from wmix_amd._lib import check, lib
+        import ctypes as C_
+        aec = lib().wmx_chain_aec(L.chain_handle())
+        check(lib().wmx_aec_set_timing(aec, 1 if on else 0), "wmx_aec_set_timing")
+        if not on:
+            n, f, r = C_.c_int(0), C_.c_double(0), C_.c_double(0)
+            check(lib().wmx_aec_timing(aec, C_.byref(n), C_.byref(f), C_.byref(r)), "wmx_aec_timing")
+            self.aec_launches, self.far_ms, self.near_ms = self.aec_launches + n.value, self.far_ms + f.value, self.near_ms + r.value
+
+    def step(self, timed):
+        k = self.k % self.K
+        step_index = self.k
+        self.k += 1
+        self.t.run("load (8 sources per group)", timed, lambda: self.tb.load(self.src[k], 2560, 32000, 2))
+        far = self.t.run("play (drain, fifo add / get)", timed, lambda: self.tb.play(self.play))
+        self.t.run("room (harness)", timed, lambda: self._room(self.loc[k], far))
+        self.t.run("record", timed, lambda: self.tb.record(self.rec, self.zoom))
+        if timed is not True:
+            self.rec_log.append((step_index, self.play[self.groups].clone(), far[self.groups].clone(), self.zoom[self.rows].clone()))
+
+    def dominant_ms(self):
+        return self.near_ms / self.aec_launches if self.aec_launches else None
+
+    def stage_ms(self):
+        d = {k: self.t.mean_ms(k) for k in ("load (8 sources per group)", "play (drain, fifo add / get)", "room (harness)", "record")}
+        if self.aec_launches:
+            d["aec_far_kernel (timed region)"] = self.far_ms / self.aec_launches
+            d["aec_near_kernel (timed region)"] = self.near_ms / self.aec_launches
+        return d
+
+    def config(self):
+        return {"workload": self.name, "record_streams_per_gpu": self.S, "sources_per_gpu": self.G * self.N, "mix_groups": self.G,
+                "far_ends": self.G, "cohorts": self.G, "tick_ms": 20,
+                "frame": "record: 160 x int16 (20 ms @ 8 kHz mono) per stream and tick; sources: 1 280 x int16 (20 ms @ 32 kHz, 2 channels)",
+                "far_end": "per mix group: that group's own playback out of the 400 ms FIFO, never shared between groups",
+                "input": "16 distinct groups x 50 ticks (tone per source gated every 200 ms, talkers one second on / off), tiled; the "
+                         "microphone signal = local + the group's far-end delayed 40 samples / 2, computed on the device between the "
+                         "tick's two halves (in the timed step, not library code)"}
+
+    def parity_check(self):
+        """4 sampled mix groups as 4 daemons through the restatement (oracle.loader.tick_port: orc_load_data per source and tick, the
+        package drain, orc_pkgfifo, the room, the oracle chain per record stream, orc_pcm_zoom) for exactly the ticks fed; every tick
+        recorded outside the timed region is compared: played package and far-end bit for bit, the record streams' 1 x 8000 output
+        within 1 LSB."""
+        from oracle import loader
+        port = loader.port()
+        T = self.k
+        worst_i, worst, n, n_off = 0, 0, 0, 0
+        for gi, g in enumerate(self.groups):
+            u = g % self.U
+            ticks = [t % self.K for t in range(T)]
+            want = loader.tick_port(port, self.src_host[u][ticks], self.loc_host[u][ticks], 32000, 2)
+            for t, play, far, zoom in self.rec_log:
+                worst_i = max(worst_i, int(np.abs(play[gi].cpu().numpy().astype(np.int32) - want["play"][t]).max()),
+                              int(np.abs(far[gi].cpu().numpy().astype(np.int32) - want["far"][t]).max()))
+                d = np.abs(zoom[gi * self.R:(gi + 1) * self.R].cpu().numpy().astype(np.int32) - want["zoom"][t].astype(np.int32))
+                worst, n, n_off = max(worst, int(d.max())), n + 2 * self.R, n_off + int((d > 0).sum())
+        return {"mix_groups": len(self.groups), "record_streams": len(self.rows), "packets_compared": n, "max_lsb": max(worst, worst_i),
+                "max_lsb_play_and_far_end": worst_i, "max_lsb_record": worst, "samples_off_by_one": n_off,
+                "oracle": "oracle.loader.tick_port: one daemon per sampled group (orc_mix, orc_pkgfifo, orc_* chain, orc_pcm_zoom)",
+                "steps_replayed": T}
+
+    def cpu_baseline(self, budget_s):
+        from oracle import loader
+        port = loader.port()
+        n = 100
+        ticks = [t % self.K for t in range(n)]
+        src, loc = self.src_host[0][ticks], self.loc_host[0][ticks]
+        reps, v1, nc, vn = _cpu_rates(lambda: loader.tick_port(port, src, loc, 32000, 2), 2 * self.R * n, budget_s)
+        return {"value": v1, "unit": "frames/s", "cores": 1, "kind": "port", "all_cores_value": vn, "all_cores": nc, "cpu_model": _cpu_model(),
+                "sample": "%d x %d ticks of one daemon (8 sources, 8 record streams) through oracle.loader.tick_port (oracle/orc_*.c, -O2; "
+                          "the per-tick mixer calls go through python), 1 thread; then one daemon per thread on all %d cores" % (reps, n, nc)}
+
+
 class NsAec8kWorkload(ChainWorkload):
     """BASELINE.json configs[3]: NS -> AEC, 8 kHz mono, shared far-end, 131 072 streams per GPU (the 1 M streams of the
     config over 8 GPUs).  Algorithmic bytes per stream-frame = 320 PCM + 2 x (6 000 + 11 700) = 35 720 B; the
@@ -1057,7 +1194,7 @@ class Chain8kWorkload(ChainWorkload):
 
 WORKLOADS = {"chain_8k": (Chain8kWorkload, 131072), "chain_fx": (ChainFxWorkload, 65536), "g711": (G711Workload, 1 << 20), "ns": (NsWorkload, 4096), "nsx": (NsxWorkload, 65536), "aecm": (AecmWorkload, 65536), "rtp_chain": (RtpChainWorkload, 65536), "chain": (ChainWorkload, 65536),
              "mfft": (MfftWorkload, 65536), "ns_aec_8k": (NsAec8kWorkload, 131072),
-             "ns_agc_mix_32k": (NsAgcMix32kWorkload, 32768)}
+             "ns_agc_mix_32k": (NsAgcMix32kWorkload, 32768), "conference": (ConferenceWorkload, 32768)}
 DEFAULT_WORKLOAD = "chain"
 
 

@@ -13,21 +13,8 @@ pytestmark = pytest.mark.skipif(not L.have_ref_mix(), reason="oracle/_ref/ref_mi
 
 def tick_inputs(seed, T, n_src, n_rec, src_freq, src_chn, loud=8000):
     """sources int16 [T, n_src, 20 ms of (src_freq, src_chn)], local microphone signal int16 [T, n_rec, 160]"""
-    rng = np.random.default_rng(seed)
-    fr = src_freq // 1000 * 20
-    t = np.arange(T * fr)
-    src = np.zeros((T, n_src, fr * src_chn), np.int16)
-    for i in range(n_src):
-        tone = loud * np.sin(2 * np.pi * (200 + 61 * i) * t / src_freq) * (((t // (fr * 10)) + i) % 3 > 0)  # on / off every 200 ms
-        x = np.clip(tone + rng.integers(-1500, 1500, t.size), -32768, 32767).astype(np.int16)
-        cols = [x] + [x // 3] * (src_chn - 1)
-        src[:, i] = np.stack(cols, 1).reshape(T, fr * src_chn)
-    tt = np.arange(T * 160)
-    local = np.zeros((T, n_rec, 160), np.int16)
-    for k in range(n_rec):
-        speech = 3000 * np.sin(0.01 * (1 + 0.1 * k) * tt) * ((tt // 16000 + k) % 2)  # a talker, one second on, one off
-        local[:, k] = (speech + rng.integers(-200, 200, tt.size)).astype(np.int16).reshape(T, 160)
-    return src, local
+    from wmix_amd import synth
+    return synth.conference_inputs(seed, T, n_src, n_rec, src_freq, src_chn, loud=loud)
 
 
 @pytest.mark.parametrize("src_freq,src_chn,n_src,n_rec,stages,T", [

@@ -59,3 +59,26 @@ def near_end(seed0, n_streams, n_frames, pkt, far=None, delay=40, noise_amp=200,
 def ns_input(seed0, n_streams, n_frames, pkt, noise_amp=3000):
     """NS-only config: noise A=3000 + gated tone. int16 [n_streams, n_frames*pkt]."""
     return near_end(seed0, n_streams, n_frames, pkt, far=None, noise_amp=noise_amp, tone=True)
+
+
+def conference_inputs(seed, n_ticks, n_src, n_rec, src_freq, src_chn, loud=8000, tick_ms=20):
+    """One mixer's inputs for the daemon's tick (wmix_amd.tick / oracle.loader.tick_port): sources int16 [n_ticks, n_src, tick_ms
+    of (src_freq, src_chn) interleaved] -- a tone per source, on and off every 200 ms, in noise, the right channel a third of the
+    left -- and the microphones' LOCAL signal int16 [n_ticks, n_rec, 8000 / 1000 * tick_ms]: a talker one second on, one off, in
+    noise A = 200 (what the microphone picks up without the loudspeaker; the room adds the echo)."""
+    rng = np.random.default_rng(seed)
+    fr = src_freq // 1000 * tick_ms
+    t = np.arange(n_ticks * fr)
+    src = np.zeros((n_ticks, n_src, fr * src_chn), np.int16)
+    for i in range(n_src):
+        tone = loud * np.sin(2 * np.pi * (200 + 61 * i) * t / src_freq) * (((t // (fr * 10)) + i) % 3 > 0)
+        x = np.clip(tone + rng.integers(-1500, 1500, t.size), -32768, 32767).astype(np.int16)
+        cols = [x] + [x // 3] * (src_chn - 1)
+        src[:, i] = np.stack(cols, 1).reshape(n_ticks, fr * src_chn)
+    n = 8 * tick_ms
+    tt = np.arange(n_ticks * n)
+    local = np.zeros((n_ticks, n_rec, n), np.int16)
+    for k in range(n_rec):
+        speech = 3000 * np.sin(0.01 * (1 + 0.1 * k) * tt) * ((tt // 16000 + k) % 2)
+        local[:, k] = (speech + rng.integers(-200, 200, tt.size)).astype(np.int16).reshape(n_ticks, n)
+    return src, local
