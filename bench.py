@@ -635,7 +635,8 @@ class ChainWorkload:
     extra_stages = 0      # WMX_CHAIN_NSX | WMX_CHAIN_AECM for the fixed-point chain
     timer_dominant = "aec"
 
-    def __init__(self, dev, n_streams, rank, dist=None, packets=1, interval_ms=10, cohorts=1, cohort_layout="arrival", coalesce=False):
+    def __init__(self, dev, n_streams, rank, dist=None, packets=1, interval_ms=10, cohorts=1, cohort_layout="arrival", coalesce=False,
+                 far_ends=1):
         from wmix_amd import synth
         from wmix_amd.chain import AEC, AGC, NS, VAD, ChainBatch
         global broadcast_far
@@ -649,12 +650,34 @@ class ChainWorkload:
         # tone-on, tone-off and both transitions, so the data-dependent branches (VAD decisions, NS feature updates, AEC
         # near-state) are not frozen on one 80 ms loop as in round 1.
         self.K = 200
-        far = synth.far_end(3000, self.K, self.pkt)  # the same far-end on every rank (rank 0's copy is broadcast)
-        base = synth.near_end(3001 + 7919 * rank, 256, self.K, self.pkt, far=far).reshape(256, self.K, self.pkt)
+        # --far-ends N: N DISTINCT far-end signals, stream s cancelled against far-end s * N // S (neighbours share one: a mix group,
+        # a call) -- aec_process2 takes the far-end per handle (src/webrtc.c:410-483), and every mix group / call of a telephony
+        # server is its own.  All N are created together (one tick, one delay): their control planes run in lockstep but their
+        # far-end histories differ, so they never fold.  16 distinct far signals x 16 near-end streams each, tiled.
+        self.far_ends = int(far_ends)
+        assert 1 <= self.far_ends <= n_streams and (self.far_ends == 1 or (cohorts == 1 and dist is None)), \
+            "--far-ends: one rank, no --cohorts (every far-end is a cohort of its own, created at step 0)"
+        if self.far_ends > 1:
+            FU = 16
+            fars = np.stack([synth.far_end(3000 + 101 * u, self.K, self.pkt) for u in range(FU)])  # [FU, K * pkt]
+            base = np.concatenate([synth.near_end(3001 + 7919 * rank + 997 * u, 16, self.K, self.pkt, far=fars[u]) for u in range(FU)])
+            base = base.reshape(256, self.K, self.pkt)  # pattern u * 16 + v: near-end v of far signal u
+            self.far_pat = fars.reshape(FU, self.K, self.pkt)
+            sidx = np.arange(n_streams)
+            self.far_of = sidx * self.far_ends // n_streams            # the far-end of stream s
+            self.pat_of = (self.far_of % FU) * 16 + sidx % 16           # its near-end pattern
+            far = fars[0]
+        else:
+            far = synth.far_end(3000, self.K, self.pkt)  # the same far-end on every rank (rank 0's copy is broadcast)
+            base = synth.near_end(3001 + 7919 * rank, 256, self.K, self.pkt, far=far).reshape(256, self.K, self.pkt)
+            self.pat_of = np.arange(n_streams) % 256
         self.base, self.far_host = base, far.reshape(self.K, self.pkt)
         b = torch.from_numpy(np.ascontiguousarray(base.transpose(1, 0, 2))).to(dev)  # [K, 256, pkt]
-        self.inp = b[:, torch.arange(n_streams, device=dev) % 256]                     # [K, S, pkt] packet-major
+        self.inp = b[:, torch.from_numpy(self.pat_of).to(dev)]                         # [K, S, pkt] packet-major
         self.far_src = torch.from_numpy(far.reshape(self.K, self.pkt).copy()).to(dev)
+        if self.far_ends > 1:  # [K, N, pkt]: far-end j hears far signal j % 16
+            fp = torch.from_numpy(np.ascontiguousarray(self.far_pat.transpose(1, 0, 2))).to(dev)
+            self.far_src = fp[:, torch.arange(self.far_ends, device=dev) % 16].contiguous()
         if dist is not None and rank != 0:
             self.far_src.zero_()  # only rank 0 has the far-end; the others hear it through the broadcast alone
         self.P = packets  # 10 ms packets per stream per step (1 = one packet per launch; 2 = the daemon's own 20 ms calls)
@@ -677,7 +700,8 @@ class ChainWorkload:
             self.work = torch.empty_like(self.inp[0:self.P])
         # the four stages behind ONE C call per step (wmx_chain_process, the heartbeat of src/wmix.c:613-709)
         self.chain = ChainBatch(n_streams, 1, self.freq, interval_ms, 5,  # volumeAgc default 5, src/wmix.c:1596
-                                ((NS | AEC | AGC | VAD) if self.with_agc_vad else (NS | AEC)) | self.extra_stages)
+                                ((NS | AEC | AGC | VAD) if self.with_agc_vad else (NS | AEC)) | self.extra_stages,
+                                n_cohorts=self.far_ends, stream_cohort=(self.far_of if self.far_ends > 1 else None))
         self.rank = rank
         self.t = _StageTimer(self.timer_dominant)
         self.k = 0
@@ -731,7 +755,7 @@ class ChainWorkload:
         P = self.P
         k = (step_index * P) % self.K
         if self.dist is None:
-            return self.far_src[k:k + P]
+            return self.far_src[k:k + P]  # [P, pkt], or [P, N, pkt] with --far-ends N
         b = step_index & 1
         if self.far_work[b] is None:  # first step: nothing was requested ahead
             self._request_far(step_index)
@@ -774,13 +798,13 @@ class ChainWorkload:
             self.merged += len(self.chain.coalesce(32))
         if self.tick_major:
             src = self.inp[k // P]
-            if timed == "all":
+            if timed == "all" and self.far_ends == 1:
                 for name, fn in self.chain.stage_calls_stream_major(far, src, self.work):
                     self.t.run(name, timed, fn)
             else:
                 rc, _, _ = self.chain.process(far, src, out=self.work)
                 assert rc == 0
-        elif timed == "all":
+        elif timed == "all" and self.far_ends == 1:
             for name, fn in self.chain.stage_calls_packet_major(far, self.inp[k:k + P], self.work):
                 self.t.run(name, timed, fn)
         else:
@@ -814,8 +838,9 @@ class ChainWorkload:
         worst, n, n_off = 0, 0, 0
         for col, s in enumerate(self.sample):
             t0 = int(self.join_of[s])  # the step in front of which this stream's handles were created (0 without --cohorts)
-            far = np.concatenate([self.far_host[(k * P + p) % self.K] for k in range(t0, T) for p in range(P)])
-            near = np.concatenate([self.base[s % 256, (k * P + p) % self.K] for k in range(t0, T) for p in range(P)])
+            far_host = self.far_pat[self.far_of[s] % 16] if self.far_ends > 1 else self.far_host  # the far-end THIS stream hears
+            far = np.concatenate([far_host[(k * P + p) % self.K] for k in range(t0, T) for p in range(P)])
+            near = np.concatenate([self.base[self.pat_of[s], (k * P + p) % self.K] for k in range(t0, T) for p in range(P)])
             # one oracle call per step of P packets, like wmx_chain_process: ns / aec / agc loop over the packets of a call, vad_process
             # analyses and attenuates the call's FIRST packet only -- the daemon's own 20 ms call is P = 2
             want = self._oracle_chain(loader, port, stages, far, near).reshape(T - t0, P, self.pkt)
@@ -835,6 +860,7 @@ class ChainWorkload:
         return {"workload": self.name, "streams_per_gpu": self.n_streams, "packets_per_stream_per_step": self.P,
                 "interval_ms": self.interval_ms,
                 "cohorts": self.n_cohorts,
+                "far_ends": self.far_ends,
                 "coalesce": ({"cohorts_merged": self.merged, "cohorts_live": self.chain.live_cohorts(), "cohort_ids": self.chain.n_cohorts}
                              if self.coalesce else None),
                 "aec_host_control_plane_us_per_launch": getattr(self, "host_ctl_us", None),
@@ -844,7 +870,9 @@ class ChainWorkload:
                 "input": "SURVEY 8d recipe: far = LCG noise A=8000; near = far delayed 40 / 2 + noise A=200 + 3000 sin(0.01 t) gated "
                          "every 100 frames; 256 distinct streams x %d packets, tiled" % self.K,
                 "far_end": ("shared, RCCL broadcast from rank 0 each step (the packet of step k + 1 travels while step k computes)"
-                            if self.dist is not None else "shared, resident in HBM (one GPU: nothing to broadcast)"),
+                            if self.dist is not None else
+                            ("%d distinct far-ends, stream s hears far-end s * N // S; resident in HBM" % self.far_ends if self.far_ends > 1
+                             else "shared, resident in HBM (one GPU: nothing to broadcast)")),
                 "sum_order": "reference (bit-exact NS mode)",
                 "host_calls_per_step": "one: wmx_chain_process (NS, AEC far + near, AGC, VAD launched back to back by the C library)",
                 "aec_launch": "far kernel + near kernel; roofline = the near kernel alone, timed by HIP events the library records "
@@ -1333,7 +1361,8 @@ SIDE_CONFIGS = [("configs[0]", "g711"), ("configs[1]", "ns"), ("configs[3]", "ns
 
 def _make_workload(cls, dev, n_mine, rank, dist, args, lo=0):
     if issubclass(cls, ChainWorkload):
-        return cls(dev, n_mine, rank, dist, args.packets_per_step, args.interval_ms, args.cohorts, args.cohort_layout, args.coalesce)
+        return cls(dev, n_mine, rank, dist, args.packets_per_step, args.interval_ms, args.cohorts, args.cohort_layout, args.coalesce,
+                   getattr(args, "far_ends", 1))
     if issubclass(cls, StubCpuWorkload):
         return cls(dev, n_mine, rank, dist, args.packets_per_step, lo)
     if issubclass(cls, AecmWorkload):
@@ -1348,7 +1377,7 @@ def _side_config(label, name, args, dev):
     import copy
     cls, n = WORKLOADS[name]
     a = copy.copy(args)
-    a.packets_per_step, a.interval_ms, a.cohorts, a.cohort_layout, a.coalesce = 1, 10, 1, "arrival", False
+    a.packets_per_step, a.interval_ms, a.cohorts, a.cohort_layout, a.coalesce, a.far_ends = 1, 10, 1, "arrival", False, 1
     t_start = time.perf_counter()
     wl = _make_workload(cls, dev, n, 0, None, a)
 
@@ -1445,6 +1474,10 @@ def main():
                     help="chain workloads: the streams are N groups of handles created at N distinct ticks (group j joins in front of "
                          "step j: a control plane and a far-end history of its own, wmx_chain_add_cohort); the priming grows to N + "
                          "--prime steps")
+    ap.add_argument("--far-ends", type=int, default=1,
+                    help="chain workloads: N DISTINCT far-end signals per GPU, stream s cancelled against far-end s * N // S (every mix "
+                         "group / call its own far-end: aec_process2's far-end is per handle); the roofline entry then counts the far-end "
+                         "spectra each group of S / N streams shares")
     ap.add_argument("--coalesce", action="store_true",
                     help="with --cohorts: wmx_chain_coalesce behind every step (cohorts whose control planes have converged are merged; "
                          "the priming grows until they have)")
@@ -1563,12 +1596,17 @@ def main():
     roofline = None
     traffic, traffic_src = _pmc_traffic(wl.dominant_kernel, wl.n_frames, getattr(wl, "pmc_tag", "chain"))
     if dom_ms:
-        achieved = wl.dominant_bytes_per_frame * wl.n_frames / (dom_ms * 1e-3) / 1e9
+        dom_bytes = wl.dominant_bytes_per_frame
+        if getattr(wl, "far_ends", 1) > 1:
+            # "non-shared far adds xfBuf 6 240 + xfwBuf 6 240" to a handle's live state (read + written once per frame): the
+            # S / N streams of a far-end share that history
+            dom_bytes += 2.0 * (6240 + 6240) * wl.far_ends / wl.n_streams
+        achieved = dom_bytes * wl.n_frames / (dom_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": wl.dominant_kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "traffic_source": traffic_src,
                     "avg_launch_ms": round(dom_ms, 5),
-                    "algorithmic_bytes_per_launch": wl.dominant_bytes_per_frame * wl.n_frames,
+                    "algorithmic_bytes_per_launch": dom_bytes * wl.n_frames,
                     # what actually bounds the per-stream DSP kernels: vector-ALU issue (see _pmc_issue)
                     "valu_issue": _pmc_issue(wl.dominant_kernel, wl.n_frames, getattr(wl, "pmc_tag", "chain"), dom_ms)}
     if roofline is None and getattr(wl, "name", "") == "rtp_chain_8k_pcma":
@@ -1614,7 +1652,7 @@ def main():
             out["cpu_baseline"] = wl.cpu_baseline(args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
-        plain = (args.packets_per_step, args.interval_ms, args.cohorts, args.coalesce, args.streams, args.total_streams) == (1, 10, 1, False, 0, 0)
+        plain = (args.packets_per_step, args.interval_ms, args.cohorts, args.coalesce, args.streams, args.total_streams, args.far_ends) == (1, 10, 1, False, 0, 0, 1)
         if world == 1 and dist is None and on_gpu and args.workload == DEFAULT_WORKLOAD and plain and not args.no_configs:
             # the other four BASELINE configs on the same line, each measured and proven in this very run; the headline's
             # handles are released first (the 8 kHz config alone holds 131 072 streams of state)

@@ -15,9 +15,16 @@ NSX, AECM = 16, 32  # the NS / AEC stage is the reference's fixed-point build of
 class ChainBatch(Lifetime):
     _mod = "chain"
 
-    def __init__(self, n_streams, chn, freq, interval_ms=10, agc_value=5, stages=NS | AEC | AGC | VAD, n_cohorts=1):
+    def __init__(self, n_streams, chn, freq, interval_ms=10, agc_value=5, stages=NS | AEC | AGC | VAD, n_cohorts=1, stream_cohort=None):
+        """stream_cohort: optional int array [n_streams], the cohort (control plane + far-end) each stream belongs to from the start;
+        `far` may then carry one far-end per cohort: [n10, n_cohorts, pkt] (wmx_chain_process_groups)."""
         self._h = C.c_void_p()
-        rc = lib().wmx_chain_create(C.byref(self._h), n_streams, chn, freq, interval_ms, agc_value, stages, n_cohorts)
+        m = None
+        if stream_cohort is not None:
+            m = np.ascontiguousarray(stream_cohort, dtype=np.int32)
+            assert m.shape == (n_streams,) and m.min() >= 0 and m.max() < n_cohorts
+        rc = lib().wmx_chain_create_groups(C.byref(self._h), n_streams, chn, freq, interval_ms, agc_value, stages, n_cohorts,
+                                           None if m is None else m.ctypes.data)
         if rc != 0:
             self._h = None
             check(rc, "wmx_chain_create")
@@ -28,16 +35,19 @@ class ChainBatch(Lifetime):
         assert pcm.is_cuda and pcm.dtype == torch.int16 and pcm.stride(-1) == 1
         out = pcm if out is None else out
         assert out.stride() == pcm.stride()
-        fp, fs = None, 0
-        if far is not None:
+        fp, fs, gs = None, 0, 0
+        if far is not None and far.dim() == 3:  # one far-end per cohort: [n10, n_cohorts, pkt]
+            assert far.is_cuda and far.dtype == torch.int16 and far.shape == (n10, self.n_cohorts, self.pkt) and far.stride(2) == 1
+            fp, fs, gs = far.data_ptr(), far.stride(0), far.stride(1)
+        elif far is not None:
             assert far.is_cuda and far.dtype == torch.int16 and far.dim() == 2 and far.shape == (n10, self.pkt) and far.stride(1) == 1
             fp, fs = far.data_ptr(), far.stride(0)
         d = None if delays is None else np.ascontiguousarray(delays, dtype=np.int32)
         on = None if cohort_on is None else np.ascontiguousarray(cohort_on, dtype=np.uint8)
         codes = np.zeros(self.n_cohorts, np.int32)
-        rc = lib().wmx_chain_process(self._h, fp, fs, pcm.data_ptr(), out.data_ptr(), n10, stream_stride, packet_stride,
-                                     None if d is None else d.ctypes.data, None if on is None else on.ctypes.data, codes.ctypes.data,
-                                     torch.cuda.current_stream().cuda_stream)
+        rc = lib().wmx_chain_process_groups(self._h, fp, fs, gs, pcm.data_ptr(), out.data_ptr(), n10, stream_stride, packet_stride,
+                                            None if d is None else d.ctypes.data, None if on is None else on.ctypes.data, codes.ctypes.data,
+                                            torch.cuda.current_stream().cuda_stream)
         if rc not in (0, -1):
             check(rc, "wmx_chain_process")
         return rc, codes, out

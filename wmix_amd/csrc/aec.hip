@@ -150,7 +150,8 @@ __device__ __forceinline__ void unpack_bin(const float *a, int b, float &re, flo
 // stream and this one (4.7 us per step of the chain).  Every far-end group stores the same bytes.
 // Plans lie [packet][cohort] (n_cohorts apart per packet: a launch uploads exactly packets x cohorts of them).
 __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const float *__restrict__ consts_g, AecPlan *plans,
-                                                     int n_packets, int n_cohorts, const int16_t *far_pcm, long far_packet_stride,
+                                                     int n_packets, int n_classes, const int32_t *__restrict__ plan_of,
+                                                     const int16_t *far_pcm, long far_packet_stride,
                                                      long far_group_stride, int chn, float gpow1np, int plan_by_value,
                                                      const AecPlan plan_value) {
     __shared__ AecConsts K;
@@ -172,7 +173,9 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const flo
     }
     const AecFarBufs F = far_group(F_all, (int)blockIdx.x);
     if (far_pcm) far_pcm += (size_t)blockIdx.x * far_group_stride;
-    plans += blockIdx.x;  // every far-end group (control cohort) has its own plans: [packet][cohort]
+    // [packet][class]: cohorts whose control planes run in lockstep (same start, same calls) share one plan -- the indices are
+    // positions inside the cohort's OWN far-end slab, equal for all of them (wmx_aec_run_cohorts)
+    plans += plan_of ? plan_of[blockIdx.x] : (int)blockIdx.x;
     {
         // one wave, one latency chain: every request of a group goes out before the first result is used
         float *dst = reinterpret_cast<float *>(&K);
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const flo
     }
     wave_sync();
     for (int p = 0; p < n_packets; p++) {
-        const AecPlan &pl = plans[(size_t)p * n_cohorts];
+        const AecPlan &pl = plans[(size_t)p * n_classes];
         if (pl.has_far) {
             // WebRtc_WriteBuffer(far_pre_buf, farend): channel 0 of the far-end packet (src/webrtc.c:430)
             const int16_t *src = far_pcm + (size_t)p * far_packet_stride;
@@ -1085,7 +1088,8 @@ template <int MULT>
 #endif
 __global__ __attribute__((amdgpu_waves_per_eu(WMX_AEC_WAVES, WMX_AEC_WAVES))) __launch_bounds__(64 * kAecWavesPerBlock) void aec_near_kernel(float *__restrict__ state, AecFarBufs F_all,
                                                                           const float *__restrict__ consts_g,
-                                                                          const AecPlan *__restrict__ plans, int n_packets, int n_cohorts,
+                                                                          const AecPlan *__restrict__ plans, int n_packets, int n_classes,
+                                                                          const int32_t *__restrict__ plan_of,
                                                                           const AecNoiseEntry *__restrict__ noise_tab,
                                                                           const int16_t *near_pcm, int16_t *out_pcm, int n_streams,
                                                                           long stream_stride, long packet_stride, int chn, int pkg,
@@ -1116,7 +1120,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(WMX_AEC_WAVES, WMX_AEC_WAVES))) __
     // wave-uniform, so the group's buffers are scalar bases like the single far-end's
     const int grp = stream_far ? __builtin_amdgcn_readfirstlane(stream_far[sl]) : 0;
     const AecFarBufs F = far_group(F_all, grp);
-    plans += grp;  // [packet][cohort]
+    plans += plan_of ? __builtin_amdgcn_readfirstlane(plan_of[grp]) : grp;  // [packet][class]
     float *gst = state + (size_t)sl * AS_WORDS;
     // the constants first (L2 hits): their copy into LDS then waits for them alone, not for the HBM loads behind them
     constexpr int kConstIt = (kAecConstNearWords + 64 * kAecWavesPerBlock - 1) / (64 * kAecWavesPerBlock);
@@ -1198,7 +1202,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(WMX_AEC_WAVES, WMX_AEC_WAVES))) __
     wave_sync();
     AEC_PROF(10);
     for (int p = 0; p < n_packets; p++) {
-        const AecPlan &pl = plans[(size_t)p * n_cohorts];
+        const AecPlan &pl = plans[(size_t)p * n_classes];
         if (!pl.has_near) continue;
         const size_t off = (size_t)sidx * stream_stride + (size_t)p * packet_stride;
         const int16_t *in = near_pcm + off;
@@ -1355,7 +1359,21 @@ __global__ void aec_clamp_group(int *stream_far, int n_streams, int n_far) {
 struct wmx_aec {
     int device;  // the HIP device the state lives on (current device at create); every entry point switches to it
     int n_streams, chn, freq, pkg;
-    std::vector<wmx::AecCtl> ctl;  // one control plane per far-end group / cohort (n_far of them)
+    std::vector<wmx::AecCtl> ctl;  // one control plane per far-end group / cohort (n_far of them) -- of which only the LEADERS' are kept
+                                   // up to date, see `lead`
+    // Control-plane classes.  A control plane is index arithmetic on the call pattern (when the handle was made, packet sizes,
+    // reported delays), never on audio: cohorts that were started at the same point and are called alike have EQUAL planes for ever
+    // -- every mix group of a conference server started together, every call set up in the same tick -- although their far-ends
+    // (and so their far-end histories on the device) differ and they can never be merged.  Such cohorts form a class: lead[g] is
+    // the cohort whose AecCtl stands for g's (lead[g] == g: g leads); a launch runs ONE control plane and uploads ONE plan per class
+    // and packet, and the kernels find a cohort's plan through d_plan_of.  ctl[g] of a follower is stale; aec_ctl() reads through,
+    // aec_ctl_own() makes a cohort the owner of an up-to-date copy before anything treats it differently from its class.
+    std::vector<int32_t> lead;         // [n_far]
+    std::vector<int32_t> cls_leader;   // [n_cls] the leaders, compact
+    std::vector<int32_t> h_plan_of[2]; // [n_far] class index of every cohort; alternating sources of the asynchronous upload
+    int h_plan_of_sel;
+    int32_t *d_plan_of;                // [cap_far]
+    bool cls_dirty;                    // lead[] changed: cls_leader / plan_of are rebuilt (and uploaded) by the next launch
     float *d_state;
     float *d_tmpl;   // the state aec_init gives a stream (reset_streams refills from it)
     float *d_consts;
@@ -1425,6 +1443,7 @@ int wmx_aec_destroy(wmx_aec *h) {
     if (h->d_plans) (void)hipFree(h->d_plans);
     if (h->h_plans) (void)hipHostFree(h->h_plans);
     if (h->d_stream_far) (void)hipFree(h->d_stream_far);
+    if (h->d_plan_of) (void)hipFree(h->d_plan_of);
     if (h->d_order) (void)hipFree(h->d_order);
     if (h->d_noise_tab) (void)hipFree(h->d_noise_tab);
     if (h->d_co_flags) (void)hipFree(h->d_co_flags);
@@ -1457,6 +1476,62 @@ int wmx_aec_create(wmx_aec **out, int n_streams, int chn, int freq, int interval
 // side by side.  Evenly matters: a packet is 2.5 blocks at 16 kHz, so a cohort runs 2 or 3 blocks in a launch depending on the phase
 // of its re-blocking ring, and eight cohorts of four phases each laid out one per XCD made every launch as long as a 3-block one
 // (0.82 ms instead of 0.70, measured).  Any permutation is CORRECT (a wave finds its stream's cohort in d_stream_far).
+// ---- control-plane classes (see wmx_aec::lead)
+static inline wmx::AecCtl &aec_ctl(wmx_aec *h, int g) { return h->ctl[(size_t)h->lead[(size_t)g]]; }
+static inline const wmx::AecCtl &aec_ctl(const wmx_aec *h, int g) { return h->ctl[(size_t)h->lead[(size_t)g]]; }
+// cohort g leaves its class with an up-to-date plane of its own (a leader hands the class over to its first follower)
+static void aec_ctl_own(wmx_aec *h, int g) {
+    const int l = h->lead[(size_t)g];
+    if (l != g) {
+        h->ctl[(size_t)g] = h->ctl[(size_t)l];
+        h->lead[(size_t)g] = g;
+        h->cls_dirty = true;
+        return;
+    }
+    int heir = -1;
+    for (int x = 0; x < h->n_far; x++)
+        if (x != g && h->lead[(size_t)x] == g) {
+            if (heir < 0) {
+                heir = x;
+                h->ctl[(size_t)x] = h->ctl[(size_t)g];
+            }
+            h->lead[(size_t)x] = heir;
+            h->cls_dirty = true;
+        }
+}
+// cohort g (a leader of itself alone, its plane just rewritten: aec_init, an import) joins a class whose plane is equal, if one of
+// the first few hundred leaders has it -- planes made at the same point of the packet sequence (a bounded search: a miss costs
+// a control plane of its own, nothing else)
+static void aec_ctl_join(wmx_aec *h, int g) {
+    int seen = 0;
+    for (int x = 0; x < h->n_far && seen < 256; x++) {
+        if (x == g || h->lead[(size_t)x] != x || !h->live[(size_t)x]) continue;
+        seen++;
+        if (h->ctl[(size_t)x].same_as(h->ctl[(size_t)g])) {
+            h->lead[(size_t)g] = x;
+            h->cls_dirty = true;
+            return;
+        }
+    }
+}
+// cls_leader / plan_of from lead[], and plan_of onto the device in `s` (alternating host sources, like the stream order)
+static int aec_rebuild_classes(wmx_aec *h, hipStream_t s) {
+    const int G = h->n_far;
+    h->h_plan_of_sel ^= 1;
+    std::vector<int32_t> &po = h->h_plan_of[h->h_plan_of_sel];
+    po.assign((size_t)G, 0);
+    h->cls_leader.clear();
+    for (int g = 0; g < G; g++)
+        if (h->lead[(size_t)g] == g) {
+            po[(size_t)g] = (int32_t)h->cls_leader.size();
+            h->cls_leader.push_back(g);
+        }
+    for (int g = 0; g < G; g++) po[(size_t)g] = po[(size_t)h->lead[(size_t)g]];
+    if (G > 1) WMX_HIP_RC(hipMemcpyAsync(h->d_plan_of, po.data(), sizeof(int32_t) * (size_t)G, hipMemcpyHostToDevice, s));
+    h->cls_dirty = false;
+    return 0;
+}
+
 static int aec_rebuild_order(wmx_aec *h, hipStream_t s) {
     using namespace wmx;
     const int S = h->n_streams, G = h->n_far;
@@ -1470,7 +1545,7 @@ static int aec_rebuild_order(wmx_aec *h, hipStream_t s) {
     std::vector<int32_t> rank((size_t)G), by((size_t)G);
     for (int g = 0; g < G; g++) by[(size_t)g] = g;
     std::stable_sort(by.begin(), by.end(), [&](int32_t a, int32_t b) {
-        return h->ctl[(size_t)a].near_fr.avail_read() < h->ctl[(size_t)b].near_fr.avail_read();
+        return aec_ctl(h, a).near_fr.avail_read() < aec_ctl(h, b).near_fr.avail_read();
     });
     for (int r = 0; r < G; r++) rank[(size_t)by[(size_t)r]] = r;
     std::vector<int32_t> start((size_t)G + 1, 0);
@@ -1544,12 +1619,14 @@ static int aec_reserve(wmx_aec *h, int cap) {
     // everything new is allocated BEFORE anything old is let go: a failure leaves the handle as it was
     float *nf = nullptr;
     AecPlan *nd = nullptr, *nh = nullptr;
+    int32_t *npo = nullptr;
     const size_t plan_bytes = (size_t)wmx_aec::kPlanBufs * ncap * kAecMaxPktPerLaunch * sizeof(AecPlan);
     hipError_t e = hipSuccess;
     if (ncap > h->cap_far) {
         e = hipMalloc(&nf, fw * (size_t)ncap * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(&nd, plan_bytes);
         if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&nh), plan_bytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc(&npo, sizeof(int32_t) * (size_t)ncap);
         if (e == hipSuccess && h->d_far) e = hipMemcpy(nf, h->d_far, fw * (size_t)h->cap_far * sizeof(float), hipMemcpyDeviceToDevice);
         if (e == hipSuccess)
             e = hipMemset(nf + fw * (size_t)h->cap_far, 0, fw * (size_t)(ncap - h->cap_far) * sizeof(float));
@@ -1558,12 +1635,16 @@ static int aec_reserve(wmx_aec *h, int cap) {
         if (nf) (void)hipFree(nf);
         if (nd) (void)hipFree(nd);
         if (nh) (void)hipHostFree(nh);
+        if (npo) (void)hipFree(npo);
         return hip_fail(e, "growing the cohort buffers", __FILE__, __LINE__);
     }
     if (nf) {
         if (h->d_far) (void)hipFree(h->d_far);
         if (h->d_plans) (void)hipFree(h->d_plans);
         if (h->h_plans) (void)hipHostFree(h->h_plans);
+        if (h->d_plan_of) (void)hipFree(h->d_plan_of);
+        h->d_plan_of = npo;
+        h->cls_dirty = true;  // the new array holds nothing yet
         h->d_far = nf;
         h->d_plans = nd;  // plan slots: kPlanBufs x [kAecMaxPktPerLaunch][ncap] (a launch uses the first packets x n_far of its slot)
         h->h_plans = nh;
@@ -1605,6 +1686,10 @@ int wmx_aec_create_groups(wmx_aec **out, int n_streams, int chn, int freq, int i
     h->pkg = freq / 1000 * ((freq <= 8000 && interval_ms % 20 == 0) ? 20 : 10);  // src/webrtc.c:239-248
     h->ctl.resize((size_t)n_far);
     for (wmx::AecCtl &c : h->ctl) c.init(freq);
+    h->lead.assign((size_t)n_far, 0);  // made together, equal planes: one class led by cohort 0 until something tells them apart
+    h->h_plan_of_sel = 0;
+    h->d_plan_of = nullptr;
+    h->cls_dirty = true;
     h->live.assign((size_t)n_far, 1);
     h->d_state = h->d_consts = h->d_far = h->d_tmpl = nullptr;
     h->timing = false;
@@ -1741,6 +1826,8 @@ int wmx_aec_add_cohort(wmx_aec *h, int *cohort, void *stream) {
         const int rc = aec_reserve(h, id + 1);
         if (rc != 0) return rc;
         h->ctl.resize((size_t)id + 1);
+        h->lead.push_back(id);
+        h->cls_dirty = true;
         h->live.push_back(1);
         h->co_retry_at.push_back(0);
         h->n_far = id + 1;
@@ -1758,6 +1845,7 @@ int wmx_aec_add_cohort(wmx_aec *h, int *cohort, void *stream) {
 // a later wmx_aec_add_cohort.  Streams still mapped to it must be inactive or be moved before the next call.
 int wmx_aec_retire_cohort(wmx_aec *h, int cohort) {
     if (!h || cohort < 0 || cohort >= h->n_far) return WMX_EINVAL;
+    aec_ctl_own(h, cohort);  // a retired cohort leads nobody
     h->live[(size_t)cohort] = 0;
     aec_co_drop(h, cohort);
     return 0;
@@ -1801,13 +1889,13 @@ int wmx_aec_coalesce(wmx_aec *h, int max_pairs, int32_t *merged_from, int32_t *m
             if (pc.b < 0) continue;  // dropped by a call in between
             AecCoKey ka, kb;
             const bool ok = h->h_co_flags[i] == 1 && h->live[(size_t)pc.a] && h->live[(size_t)pc.b] &&
-                            aec_co_key(h->ctl[(size_t)pc.a], &ka) && aec_co_key(h->ctl[(size_t)pc.b], &kb) && ka == kb;
+                            aec_co_key(aec_ctl(h, pc.a), &ka) && aec_co_key(aec_ctl(h, pc.b), &kb) && ka == kb;
             if (!ok) {
                 h->co_retry_at[(size_t)pc.b] = h->co_calls + 64;
                 continue;
             }
             if (merged >= cap) continue;  // no room to report it: proposed again by a later call
-            aec_co_pair(h->ctl[(size_t)pc.a], h->ctl[(size_t)pc.b], pc.a, pc.b, &pc);  // the positions of NOW (same differences, by the keys)
+            aec_co_pair(aec_ctl(h, pc.a), aec_ctl(h, pc.b), pc.a, pc.b, &pc);  // the positions of NOW (same differences, by the keys)
             go.p[n_go++] = pc;
             merged_from[merged] = pc.b;
             merged_into[merged] = pc.a;
@@ -1821,6 +1909,7 @@ int wmx_aec_coalesce(wmx_aec *h, int max_pairs, int32_t *merged_from, int32_t *m
             std::vector<int32_t> to((size_t)h->n_far, -1);
             for (int i = 0; i < n_go; i++) {
                 to[(size_t)go.p[i].b] = go.p[i].a;
+                aec_ctl_own(h, go.p[i].b);  // a retired cohort leads nobody
                 h->live[(size_t)go.p[i].b] = 0;  // retired: its id may be handed out again (wmx_aec_add_cohort)
             }
             for (int32_t &c : h->h_cohort_of)
@@ -1836,6 +1925,8 @@ int wmx_aec_coalesce(wmx_aec *h, int max_pairs, int32_t *merged_from, int32_t *m
                     if (c >= nf) c = 0;
                 h->n_far = nf;
                 h->ctl.resize((size_t)nf);
+                h->lead.resize((size_t)nf);
+                h->cls_dirty = true;
                 h->live.resize((size_t)nf);
                 h->co_retry_at.resize((size_t)nf);
             }
@@ -1855,19 +1946,19 @@ int wmx_aec_coalesce(wmx_aec *h, int max_pairs, int32_t *merged_from, int32_t *m
     for (int g = 0; g < h->n_far && n < max_pairs; g++) {
         if (!h->live[(size_t)g]) continue;
         AecCoKey k, kl;
-        if (!aec_co_key(h->ctl[(size_t)g], &k)) continue;
+        if (!aec_co_key(aec_ctl(h, g), &k)) continue;
         uint64_t hash = 1469598103934665603ull;
         for (int v : k.v) hash = (hash ^ (uint32_t)v) * 1099511628211ull;
         int lead = -1;
         const auto range = leads.equal_range(hash);
         for (auto it = range.first; it != range.second && lead < 0; ++it)
-            if (aec_co_key(h->ctl[(size_t)it->second], &kl) && kl == k) lead = it->second;
+            if (aec_co_key(aec_ctl(h, it->second), &kl) && kl == k) lead = it->second;
         if (lead < 0) {
             leads.emplace(hash, g);
             continue;
         }
         if (h->co_retry_at[(size_t)g] > h->co_calls) continue;
-        aec_co_pair(h->ctl[(size_t)lead], h->ctl[(size_t)g], lead, g, &h->co_pairs.p[n++]);
+        aec_co_pair(aec_ctl(h, lead), aec_ctl(h, g), lead, g, &h->co_pairs.p[n++]);
     }
     h->co_n = n;
     if (n == 0) return 0;
@@ -1969,6 +2060,30 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
         const int rc = aec_rebuild_order(h, s);
         if (rc != 0) return rc;
     }
+    // Control-plane classes: a follower that is called differently from its leader in THIS call (switched on / off alone, another
+    // reported delay) takes a plane of its own first.  (wmx_aec_run / _run_groups hand every cohort the same delay and no switches.)
+    if (G > 1 && (cohort_on || delay_ms != h->same_delay.data()))
+        for (int g = 0; g < G; g++) {
+            const int l = h->lead[(size_t)g];
+            if (l == g || !h->live[(size_t)g]) continue;
+            const bool on_g = !cohort_on || cohort_on[g], on_l = !cohort_on || cohort_on[l];
+            if (on_g != on_l || (on_g && delay_ms[g] != delay_ms[l])) aec_ctl_own(h, g);
+        }
+    bool classes_moved = false;
+    if (h->cls_dirty) {
+        // uploaded in `s`, behind every launch that still reads the old classes; a far kernel forked onto the side stream would not
+        // wait for it (its fork point lies in front of this call): this one launch keeps the far kernel in line
+        const int rc = aec_rebuild_classes(h, s);
+        if (rc != 0) return rc;
+        classes_moved = true;
+    }
+    const int C = (int)h->cls_leader.size();
+    const int32_t *plan_of = G > 1 ? h->d_plan_of : nullptr;
+    running = 0;
+    for (int c = 0; c < C; c++) {
+        const int g = h->cls_leader[(size_t)c];
+        running += (h->live[(size_t)g] && (!cohort_on || cohort_on[g])) ? 1 : 0;
+    }
     for (int done = 0; done < n_packets && running > 0;) {
         int chunk = n_packets - done;
         if (chunk > kAecMaxPktPerLaunch) chunk = kAecMaxPktPerLaunch;
@@ -1978,18 +2093,19 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
         h->plan_sel = (sel + 1) % wmx_aec::kPlanBufs;
         if (h->plan_used[sel]) WMX_HIP(hipEventSynchronize(h->plan_free[sel]));
         const size_t slot = (size_t)sel * h->cap_far * kAecMaxPktPerLaunch;
-        AecPlan *hp = h->h_plans + slot, *dp = h->d_plans + slot;  // [packet][cohort], G apart: chunk x G plans are uploaded
+        AecPlan *hp = h->h_plans + slot, *dp = h->d_plans + slot;  // [packet][class], C apart: chunk x C plans are uploaded
         int any = 0;
         const auto t_ctl = std::chrono::steady_clock::now();
-        for (int g = 0; g < G; g++) {
+        for (int c = 0; c < C; c++) {
+            const int g = h->cls_leader[(size_t)c];  // the class's one control plane
             const bool on = h->live[(size_t)g] && (!cohort_on || cohort_on[g]) && rc_g[g] == 0;
             for (int k = 0; k < chunk; k++) {
-                AecPlan &pl = hp[(size_t)k * G + g];
+                AecPlan &pl = hp[(size_t)k * C + c];
                 memset(&pl, 0, offsetof(AecPlan, blk));
-                if (!on || rc_g[g] != 0) continue;  // has_far = has_near = 0: both kernels skip the packet for this cohort
+                if (!on || rc_g[g] != 0) continue;  // has_far = has_near = 0: both kernels skip the packet for this class's cohorts
                 any = 1;
                 if (mode & 1) {
-                    const int r = h->ctl[g].buffer_farend(h->pkg, &pl);
+                    const int r = h->ctl[(size_t)g].buffer_farend(h->pkg, &pl);
                     if (r != 0) {
                         pl.has_far = 0;
                         rc_g[g] = r;
@@ -1997,7 +2113,7 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
                     }
                 }
                 if (mode & 2) {
-                    const int r = h->ctl[g].process(h->pkg, delay_ms[g], &pl);
+                    const int r = h->ctl[(size_t)g].process(h->pkg, delay_ms[g], &pl);
                     if (r != 0) {  // src/webrtc.c:463-468: the wrapper stops here; nothing of this packet is written
                         pl.has_near = 0;
                         rc_g[g] = r;
@@ -2012,12 +2128,13 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
         h->ctl_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_ctl).count();
         h->ctl_calls++;
         if (any) {
-            const int by_value = (chunk == 1 && G == 1) ? 1 : 0;
+            // (with many cohorts in one class every far wave would store the same plan into the same line: those read the upload)
+            const int by_value = (chunk == 1 && C == 1 && G == 1) ? 1 : 0;
             // the far kernel (and the plans it reads) on the side stream when the caller forked it (first chunk of the call only)
-            const bool forked = fork_here && done == 0 && (mode & 2);
+            const bool forked = fork_here && done == 0 && (mode & 2) && !classes_moved;
             hipStream_t fs = forked ? h->side : s;
             if (forked) WMX_HIP(hipStreamWaitEvent(fs, h->ev_fork, 0));
-            if (!by_value) WMX_HIP(hipMemcpyAsync(dp, hp, (size_t)G * chunk * sizeof(AecPlan), hipMemcpyHostToDevice, fs));
+            if (!by_value) WMX_HIP(hipMemcpyAsync(dp, hp, (size_t)C * chunk * sizeof(AecPlan), hipMemcpyHostToDevice, fs));
             hipEvent_t *tv = nullptr;
             if (h->timing && (mode & 2)) {
                 if (h->tev_used + 4 > wmx_aec::kMaxTimingEvents) h->tev_used = 0;  // nobody polls: start over on the oldest events
@@ -2031,7 +2148,7 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
                 h->tev_used += 4;
                 WMX_HIP(hipEventRecord(tv[0], fs));
             }
-            hipLaunchKernelGGL(aec_far_kernel, dim3((unsigned)G), dim3(64), 0, fs, h->far, h->d_consts, dp, chunk, G,
+            hipLaunchKernelGGL(aec_far_kernel, dim3((unsigned)G), dim3(64), 0, fs, h->far, h->d_consts, dp, chunk, C, plan_of,
                                d_far ? d_far + (size_t)done * far_packet_stride : nullptr, far_packet_stride, far_group_stride, h->chn, gpow1np,
                                by_value, hp[0]);
             WMX_LAUNCH_CHECK();
@@ -2049,11 +2166,13 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
                 const unsigned grid = ordered ? h->order_wgs : (unsigned)((h->n_streams + kAecWavesPerBlock - 1) / kAecWavesPerBlock);
                 const dim3 blk(64 * kAecWavesPerBlock);
                 if (h->freq == 8000)
-                    hipLaunchKernelGGL((aec_near_kernel<1>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, chunk, G, h->d_noise_tab, nin,
-                                       nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg, h->d_stream_far, h->life.d_active, order);
+                    hipLaunchKernelGGL((aec_near_kernel<1>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, chunk, C, plan_of,
+                                       h->d_noise_tab, nin, nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg, h->d_stream_far,
+                                       h->life.d_active, order);
                 else
-                    hipLaunchKernelGGL((aec_near_kernel<2>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, chunk, G, h->d_noise_tab, nin,
-                                       nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg, h->d_stream_far, h->life.d_active, order);
+                    hipLaunchKernelGGL((aec_near_kernel<2>), dim3(grid), blk, 0, s, h->d_state, h->far, h->d_consts, dp, chunk, C, plan_of,
+                                       h->d_noise_tab, nin, nout, h->n_streams, stream_stride, packet_stride, h->chn, h->pkg, h->d_stream_far,
+                                       h->life.d_active, order);
                 WMX_LAUNCH_CHECK();
                 if (tv) WMX_HIP(hipEventRecord(tv[3], s));
             }
@@ -2063,7 +2182,7 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
         done += chunk;
     }
     if (cohort_rc)
-        for (int g = 0; g < G; g++) cohort_rc[g] = rc_g[g];
+        for (int g = 0; g < G; g++) cohort_rc[g] = (h->live[(size_t)g] && (!cohort_on || cohort_on[g])) ? rc_g[(size_t)h->lead[(size_t)g]] : 0;
     return rc_first;
 }
 
@@ -2099,7 +2218,9 @@ int wmx_aec_reset_cohort(wmx_aec *h, int cohort, void *stream) {
     WMX_ON_DEVICE(h);
     using namespace wmx;
     if (!h || cohort < 0 || cohort >= h->n_far) return WMX_EINVAL;
+    aec_ctl_own(h, cohort);
     h->ctl[(size_t)cohort].init(h->freq);
+    aec_ctl_join(h, cohort);  // cohorts restarted at the same point of the packet sequence run one control plane
     aec_co_drop(h, cohort);
     WMX_HIP(hipMemsetAsync(h->d_far + (size_t)cohort * h->far.group_words, 0, h->far.group_words * sizeof(float), as_stream(stream)));
     return 0;
@@ -2156,7 +2277,7 @@ int wmx_aec_export_cohort(wmx_aec *h, int cohort, void *host_blob) {
     const size_t fb = h->far.group_words * 4;
     blob_begin(p, blob_tag("AECc"), (uint32_t)h->freq, (uint32_t)(sizeof(AecCtl) + fb));
     p += sizeof(BlobHeader);
-    memcpy(p, &h->ctl[(size_t)cohort], sizeof(AecCtl));
+    memcpy(p, &aec_ctl(h, cohort), sizeof(AecCtl));
     WMX_HIP(hipMemcpy(p + sizeof(AecCtl), h->d_far + (size_t)cohort * h->far.group_words, fb, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -2170,7 +2291,9 @@ int wmx_aec_import_cohort(wmx_aec *h, int cohort, const void *host_blob) {
     if (rc) return rc;
     WMX_HIP(hipDeviceSynchronize());
     const char *p = static_cast<const char *>(host_blob) + sizeof(BlobHeader);
+    aec_ctl_own(h, cohort);
     memcpy(&h->ctl[(size_t)cohort], p, sizeof(AecCtl));
+    aec_ctl_join(h, cohort);
     aec_co_drop(h, cohort);
     WMX_HIP(hipMemcpy(h->d_far + (size_t)cohort * h->far.group_words, p + sizeof(AecCtl), fb, hipMemcpyHostToDevice));
     return 0;
@@ -2180,7 +2303,7 @@ int wmx_aec_cohorts(const wmx_aec *h) { return h ? h->n_far : WMX_EINVAL; }
 int wmx_aec_cohort_key(const wmx_aec *h, int cohort, int32_t *key11) {
     if (!h || !key11 || cohort < 0 || cohort >= h->n_far) return WMX_EINVAL;
     wmx::AecCoKey k;
-    if (!h->live[(size_t)cohort] || !wmx::aec_co_key(h->ctl[(size_t)cohort], &k)) return 1;  // retired, or still in its start-up
+    if (!h->live[(size_t)cohort] || !wmx::aec_co_key(aec_ctl(h, cohort), &k)) return 1;  // retired, or still in its start-up
     for (int i = 0; i < 11; i++) key11[i] = k.v[i];
     return 0;
 }

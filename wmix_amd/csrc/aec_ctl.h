@@ -94,6 +94,7 @@ struct RingIdx {
         rd = wr = 0;
         diff_wrap = 0;
     }
+    bool same_as(const RingIdx &o) const { return count == o.count && rd == o.rd && wr == o.wr && diff_wrap == o.diff_wrap; }
     int avail_read() const { return diff_wrap ? count - rd + wr : wr - rd; }
     int avail_write() const { return count - avail_read(); }
     int move_read(int n) {
@@ -144,6 +145,18 @@ struct AecCtl {
     // Aec wrapper (echo_cancellation_internal.h:17-65)
     int bufSizeStart = 0, knownDelay = 0, sum = 0, timeForDelayChange = 0, startup_phase = 1, checkBuffSize = 1;
     short counter = 0, firstVal = 0, checkBufSizeCtr = 0, msInSndCardBuf = 0, filtDelay = -1, lastDelayDiff = 0;
+
+    // Every word that decides the plane's future equal: two such planes called alike (same packets, same reported delay) stay equal
+    // for ever and hand out the same plans -- control planes are index arithmetic on the call pattern, never on audio.  (`blocks`
+    // is a counter nothing reads.)
+    bool same_as(const AecCtl &o) const {
+        return fs == o.fs && mult == o.mult && rate_factor == o.rate_factor && near_fr.same_as(o.near_fr) && out_fr.same_as(o.out_fr) &&
+               far_buf.same_as(o.far_buf) && far_pre.same_as(o.far_pre) && system_delay == o.system_delay &&
+               core_known_delay == o.core_known_delay && hist_n == o.hist_n && bufSizeStart == o.bufSizeStart && knownDelay == o.knownDelay &&
+               sum == o.sum && timeForDelayChange == o.timeForDelayChange && startup_phase == o.startup_phase &&
+               checkBuffSize == o.checkBuffSize && counter == o.counter && firstVal == o.firstVal && checkBufSizeCtr == o.checkBufSizeCtr &&
+               msInSndCardBuf == o.msInSndCardBuf && filtDelay == o.filtDelay && lastDelayDiff == o.lastDelayDiff;
+    }
 
     void init(int freq) {  // WebRtcAec_Init echo_cancellation.c:179-275 + InitAec aec_core.c:1527-1688
         *this = AecCtl();
