@@ -448,6 +448,35 @@ int wmx_rtp_ingest(int n_streams, const uint8_t *d_packets, long packet_stride, 
                    uint32_t *d_pcm_bytes, uint16_t *d_seq_raw, void *stream);
 int wmx_rtp_export(wmx_rtp *h, int stream_index, uint16_t *seq, uint32_t *timestamp);
 
+/* ------------------------------------------------------------------ the packet edge as a pipeline
+ * What wmix_thread_rtp_recv_pcma, the record heartbeat and wmix_thread_rtp_send_pcma do for one stream per 20 ms
+ * (src/wmixTask.c:1278-1316, src/wmix.c:613-709, src/wmixTask.c:1124-1143), for n_streams per step with only the 172-byte
+ * RTP/PCMA datagrams (src/rtp.h:51-78) crossing PCIe: datagram -> wmx_rtp_ingest -> wmx_chain_process (two 10 ms packets, 8 kHz
+ * mono) -> wmx_rtp_egress -> datagram.  A wmx_pipe owns `slots` (1 .. 16) sets of PINNED host rows for the datagrams in and out,
+ * their device twins, a copy-in and a copy-out HIP stream and the events between them, all made once:
+ *   wmx_pipe_in / _out / _far(h, slot)  the slot's host rows: n_streams x 172 bytes in, the same out, 160 far-end samples
+ *   wmx_pipe_submit(h, d_far, &slot, stream)  queues H2D -> ingest, chain, egress on `stream` -> D2H for the NEXT slot (round robin)
+ *                  and returns at once; it blocks only when that slot is still in flight from `slots` steps ago.  d_far: the
+ *                  shared far-end's two 10 ms packets on the device, or NULL = the slot's own wmx_pipe_far samples
+ *   wmx_pipe_wait(h, slot)  blocks until that slot's datagrams are in its out rows (slot < 0: every slot)
+ *   wmx_pipe_step_resident  the three launches alone, on datagrams that are on the device already (rows in_stride / out_stride
+ *                  bytes apart)
+ * With three slots the H2D of step k + 1 and the D2H of step k - 1 overlap the compute of step k. */
+typedef struct wmx_pipe wmx_pipe;
+int wmx_pipe_create(wmx_pipe **out, int n_streams, int slots, int law, int agc_value, unsigned stages);
+int wmx_pipe_destroy(wmx_pipe *h);
+int wmx_pipe_slots(const wmx_pipe *h);
+int wmx_pipe_datagram_bytes(const wmx_pipe *h);
+uint8_t *wmx_pipe_in(wmx_pipe *h, int slot);
+const uint8_t *wmx_pipe_out(wmx_pipe *h, int slot);
+int16_t *wmx_pipe_far(wmx_pipe *h, int slot);
+int wmx_pipe_submit(wmx_pipe *h, const int16_t *d_far, int *slot, void *stream);
+int wmx_pipe_wait(wmx_pipe *h, int slot);
+int wmx_pipe_step_resident(wmx_pipe *h, const uint8_t *d_in, long in_stride, const int16_t *d_far, uint8_t *d_out, long out_stride,
+                           void *stream);
+wmx_chain *wmx_pipe_chain(wmx_pipe *h);
+wmx_rtp *wmx_pipe_senders(wmx_pipe *h);
+
 /* ------------------------------------------------------------------ AEC far-end delay FIFO
  * Batched form of playPkgBuff_add/get and recordPkgBuff_add/get (src/wmix.c:432-526): n_slots packets
  * (AEC_FIFO_PKG_NUM = AEC_INTERVALMS / WMIX_INTERVAL_MS + 2, src/wmixConf.h:141) of pkg_bytes per stream, resident on

@@ -16,11 +16,13 @@ from wmix_amd import synth
 
 EXE = os.path.join(ROOT, "examples", "host_chain")
 EXE_RCCL = os.path.join(ROOT, "examples", "host_chain_rccl")
+EXE_RTP = os.path.join(ROOT, "examples", "host_rtp_pipe")
 
 
 def test_host_chain_is_built():
     assert os.path.exists(EXE), "examples/host_chain missing: run __graft_entry__.build()"
     assert os.path.exists(EXE_RCCL), "examples/host_chain_rccl missing: run __graft_entry__.build()"
+    assert os.path.exists(EXE_RTP), "examples/host_rtp_pipe missing: run __graft_entry__.build()"
 
 
 @pytest.mark.gpu
@@ -81,3 +83,28 @@ def test_host_chain_at_the_daemons_cadence(tmp_path, oracle_port):
     got = np.fromfile(tmp_path / "out.i16", dtype="<i2").reshape(S, T * pkt)
     want = np.stack([L.run_chain(oracle_port, 1, freq, 5, 15, far, near[s], pkt, prefix="orc", interval_ms=20) for s in range(S)])
     check_float_path(got, want, max_fraction=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("slots", [1, 3])
+def test_host_rtp_pipe_vs_oracle(tmp_path, oracle_port, slots):
+    """The packet edge driven from C (examples/host_rtp_pipe.c over wmx_pipe_submit / wmx_pipe_wait: pinned slots, copy streams and
+    events inside the library; src/wmixTask.c:1278-1316, src/wmix.c:613-709, src/wmixTask.c:1124-1143): the datagrams it writes
+    equal the oracle composition orc_rtp_ingest -> oracle chain -> orc_rtp_egress -- headers identical, payload within one A-law
+    step where the float stages differ by their 1 LSB (observed: identical)."""
+    from test_pipeline_gpu import make_datagrams
+    S, n = 29, 140
+    far, pk = make_datagrams(oracle_port, S, n, seed=9900)  # far [n * 160], pk [S, n, 172]
+    far.astype("<i2").tofile(tmp_path / "far.i16")
+    np.ascontiguousarray(pk.transpose(1, 0, 2)).tofile(tmp_path / "in.rtp")  # step-major
+    r = subprocess.run([EXE_RTP, str(tmp_path / "far.i16"), str(tmp_path / "in.rtp"), str(tmp_path / "out.rtp"), str(S), str(n), str(slots)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["rc"] == 0 and info["slots"] == slots
+    got = np.fromfile(tmp_path / "out.rtp", dtype=np.uint8).reshape(n, S, 172).transpose(1, 0, 2)
+    for s in (0, 11, 28):
+        want = L.run_rtp_chain(oracle_port, far, pk[s])
+        assert np.array_equal(got[s][:, :12], want[:, :12])
+        diff = got[s][:, 12:].astype(np.int16) - want[:, 12:].astype(np.int16)
+        assert np.abs(diff).max() <= 1 and (diff != 0).mean() < 1e-4

@@ -57,13 +57,19 @@ def test_rtp_chain_vs_oracle_resident_and_streaming(cuda, oracle_port):
         slot = k % pipe.SLOTS
         if len(pending) == pipe.SLOTS:  # the slot is about to be reused: collect its result first
             kk, ss = pending.pop(0)
-            pipe.ev_out[ss].synchronize()
-            got2[:, kk] = pipe.h_out[ss].numpy()
-        pipe.h_in[slot].copy_(torch.from_numpy(pk[:, k]))
-        pending.append((k, pipe.submit(dfar[k])))
+            pipe.wait(ss)
+            got2[:, kk] = pipe.h_out[ss]
+        pipe.h_in[slot][:] = pk[:, k]
+        if k % 2:  # the far-end from host memory too, every other step (wmx_pipe_far), else from the device
+            pipe.h_far[slot][:] = far.reshape(n, 2, 80)[k]
+            got_slot = pipe.submit(None)
+        else:
+            got_slot = pipe.submit(dfar[k])
+        assert got_slot == slot
+        pending.append((k, got_slot))
     pipe.drain()
     for kk, ss in pending:
-        got2[:, kk] = pipe.h_out[ss].numpy()
+        got2[:, kk] = pipe.h_out[ss]
     ch2.close()
     assert np.array_equal(got, got2)
     for s in (0, 1, 17, 36):

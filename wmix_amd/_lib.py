@@ -111,6 +111,26 @@ def _declare(L):
     L.wmx_chain_create_groups.argtypes = [C.POINTER(vp), i, i, i, i, i, C.c_uint, i, vp]
     L.wmx_chain_process_groups.restype = i
     L.wmx_chain_process_groups.argtypes = [vp, vp, C.c_long, C.c_long, vp, vp, i, C.c_long, C.c_long, vp, vp, vp, vp]
+    L.wmx_pipe_create.restype = i
+    L.wmx_pipe_create.argtypes = [C.POINTER(vp), i, i, i, i, C.c_uint]
+    L.wmx_pipe_destroy.restype = i
+    L.wmx_pipe_destroy.argtypes = [vp]
+    L.wmx_pipe_slots.restype = i
+    L.wmx_pipe_slots.argtypes = [vp]
+    L.wmx_pipe_datagram_bytes.restype = i
+    L.wmx_pipe_datagram_bytes.argtypes = [vp]
+    for name in ("wmx_pipe_in", "wmx_pipe_out", "wmx_pipe_far"):
+        getattr(L, name).restype = vp
+        getattr(L, name).argtypes = [vp, i]
+    for name in ("wmx_pipe_chain", "wmx_pipe_senders"):
+        getattr(L, name).restype = vp
+        getattr(L, name).argtypes = [vp]
+    L.wmx_pipe_submit.restype = i
+    L.wmx_pipe_submit.argtypes = [vp, vp, C.POINTER(i), vp]
+    L.wmx_pipe_wait.restype = i
+    L.wmx_pipe_wait.argtypes = [vp, i]
+    L.wmx_pipe_step_resident.restype = i
+    L.wmx_pipe_step_resident.argtypes = [vp, vp, C.c_long, vp, vp, C.c_long, vp]
     L.wmx_tick_create.restype = i
     L.wmx_tick_create.argtypes = [C.POINTER(vp), i, i, i, i, i, i, i, C.c_uint]
     L.wmx_tick_destroy.restype = i

@@ -1,0 +1,238 @@
+// pipe.hip -- the packet edge end to end as a C pipeline (host code only: it sequences copies and launches).
+//
+// What wmix_thread_rtp_recv_pcma / the record heartbeat / wmix_thread_rtp_send_pcma do for ONE stream per 20 ms
+// (src/wmixTask.c:1278-1316: rtp_recv -> G711a2PCM; src/wmix.c:613-709: ns -> aec -> agc -> vad; src/wmixTask.c:1124-1143:
+// wmix_pcm_zoom -> PCM2G711a -> timestamp / seq -> rtp_send), for n streams per step with only the 172-byte datagrams crossing PCIe:
+//
+//     host datagrams --H2D--> wmx_rtp_ingest -> wmx_chain_process (two 10 ms packets, 8 kHz mono, in place) -> wmx_rtp_egress --D2H--> host
+//
+// A wmx_pipe owns `slots` sets of buffers -- pinned host memory for the datagrams in and out (hipHostMalloc: the copies run on the
+// DMA engines, no staging) and their device twins -- a copy-in and a copy-out HIP stream and one event triple per slot, all made
+// once.  wmx_pipe_submit(slot k) queues   H2D on the copy-in stream -> (event) -> ingest, chain, egress on the caller's stream ->
+// (event) -> D2H on the copy-out stream -> (event)   and returns at once: while step k computes, the datagrams of step k + 1 arrive
+// and those of step k - 1 leave.  wmx_pipe_wait(slot) blocks until that slot's datagrams are in host memory.  The host thread makes
+// five runtime calls per step and waits only when it takes a slot that is still in flight.
+#include <vector>
+#include "wmx_internal.h"
+
+namespace {
+constexpr int kDatagram = 172;  // 12-byte RTP header + 160 G.711 codes (20 ms at 8 kHz), src/rtp.h:33, src/rtp.c:86-95
+constexpr int kFreq = 8000, kPkt10 = 80;
+}  // namespace
+
+struct wmx_pipe {
+    int device;  // first member of every handle (wmx_handle_device)
+    int n_streams, slots;
+    wmx_chain *chain;
+    wmx_rtp *snd;
+    int16_t *d_pcm;        // [n][160] the 20 ms of every stream between ingest and egress
+    uint32_t *d_nbytes;    // [n] what rtp_recv + G711a2PCM delivered (320 or 0)
+    uint16_t *d_seq;       // [n] header sequence numbers as the reference leaves them
+    struct Slot {
+        uint8_t *h_in, *h_out;   // pinned [n][172]
+        int16_t *h_far;          // pinned [160]: the shared far-end of these 20 ms, for hosts that have it in host memory
+        uint8_t *d_in, *d_out;   // [n][172]
+        int16_t *d_far;          // [160]
+        hipEvent_t ev_in, ev_done, ev_gate, ev_out;
+        bool in_flight;
+    };
+    std::vector<Slot> slot;
+    hipStream_t s_in, s_out;
+    int next;
+    int pending;  // the slot whose D2H is not queued yet (see wmx_pipe_submit), or -1
+};
+
+extern "C" {
+
+int wmx_pipe_destroy(wmx_pipe *h) {
+    WMX_ON_DEVICE(h);
+    if (!h) return 0;
+    (void)hipDeviceSynchronize();
+    for (wmx_pipe::Slot &s : h->slot) {
+        if (s.h_in) (void)hipHostFree(s.h_in);
+        if (s.h_out) (void)hipHostFree(s.h_out);
+        if (s.h_far) (void)hipHostFree(s.h_far);
+        if (s.d_in) (void)hipFree(s.d_in);
+        if (s.d_out) (void)hipFree(s.d_out);
+        if (s.d_far) (void)hipFree(s.d_far);
+        if (s.ev_in) (void)hipEventDestroy(s.ev_in);
+        if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+        if (s.ev_gate) (void)hipEventDestroy(s.ev_gate);
+        if (s.ev_out) (void)hipEventDestroy(s.ev_out);
+    }
+    if (h->s_in) (void)hipStreamDestroy(h->s_in);
+    if (h->s_out) (void)hipStreamDestroy(h->s_out);
+    if (h->d_pcm) (void)hipFree(h->d_pcm);
+    if (h->d_nbytes) (void)hipFree(h->d_nbytes);
+    if (h->d_seq) (void)hipFree(h->d_seq);
+    if (h->chain) wmx_chain_destroy(h->chain);
+    if (h->snd) wmx_rtp_destroy(h->snd);
+    delete h;
+    return 0;
+}
+
+// law: WMX_LAW_A (payload type 8, the reference's wmix_thread_rtp_*_pcma) or WMX_LAW_U; stages: WMX_CHAIN_* bits of the heartbeat
+int wmx_pipe_create(wmx_pipe **out, int n_streams, int slots, int law, int agc_value, unsigned stages) {
+    if (!out) return WMX_EINVAL;
+    *out = nullptr;
+    if (n_streams < 1 || slots < 1 || slots > 16 || law != WMX_LAW_A) {
+        // (the ingest side decodes A-law as wmix_thread_rtp_recv_pcma does, src/wmixTask.c:1282; a mu-law receiver does not exist in the
+        // reference)
+        wmx::set_error("wmx_pipe_create: n_streams=%d slots=%d law=%d", n_streams, slots, law);
+        return WMX_EINVAL;
+    }
+    wmx_pipe *h = new wmx_pipe();
+    if ((h->device = wmx::current_device()) < 0) {
+        delete h;
+        return WMX_ENODEV;
+    }
+    h->n_streams = n_streams;
+    h->slots = slots;
+    h->next = 0;
+    h->pending = -1;
+    h->slot.assign((size_t)slots, wmx_pipe::Slot{});
+    int rc = wmx_chain_create(&h->chain, n_streams, 1, kFreq, 10, agc_value, stages, 1);
+    if (rc == 0) rc = wmx_rtp_create(&h->snd, n_streams, law);
+    hipError_t e = hipSuccess;
+    const size_t bytes = (size_t)n_streams * kDatagram;
+    if (rc == 0) {
+        e = hipMalloc(&h->d_pcm, (size_t)n_streams * 2 * kPkt10 * sizeof(int16_t));
+        if (e == hipSuccess) e = hipMalloc(&h->d_nbytes, (size_t)n_streams * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&h->d_seq, (size_t)n_streams * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking);
+        for (wmx_pipe::Slot &s : h->slot) {
+            if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.h_in), bytes, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.h_out), bytes, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.h_far), 2 * kPkt10 * sizeof(int16_t), hipHostMallocDefault);
+            if (e == hipSuccess) e = hipMalloc(&s.d_in, bytes);
+            if (e == hipSuccess) e = hipMalloc(&s.d_out, bytes);
+            if (e == hipSuccess) e = hipMalloc(&s.d_far, 2 * kPkt10 * sizeof(int16_t));
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_gate, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming);
+            if (e == hipSuccess) memset(s.h_far, 0, 2 * kPkt10 * sizeof(int16_t));
+        }
+        if (e != hipSuccess) rc = wmx::hip_fail(e, "wmx_pipe_create: buffers / streams / events", __FILE__, __LINE__);
+    }
+    if (rc != 0) {
+        wmx_pipe_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+int wmx_pipe_slots(const wmx_pipe *h) { return h ? h->slots : WMX_EINVAL; }
+int wmx_pipe_datagram_bytes(const wmx_pipe *h) { return h ? kDatagram : WMX_EINVAL; }
+// the pinned host rows of a slot: n_streams datagrams of 172 bytes in / out, and the 160 far-end samples of the slot's 20 ms
+uint8_t *wmx_pipe_in(wmx_pipe *h, int slot) { return (h && slot >= 0 && slot < h->slots) ? h->slot[(size_t)slot].h_in : nullptr; }
+const uint8_t *wmx_pipe_out(wmx_pipe *h, int slot) { return (h && slot >= 0 && slot < h->slots) ? h->slot[(size_t)slot].h_out : nullptr; }
+int16_t *wmx_pipe_far(wmx_pipe *h, int slot) { return (h && slot >= 0 && slot < h->slots) ? h->slot[(size_t)slot].h_far : nullptr; }
+wmx_chain *wmx_pipe_chain(wmx_pipe *h) { return h ? h->chain : nullptr; }
+wmx_rtp *wmx_pipe_senders(wmx_pipe *h) { return h ? h->snd : nullptr; }
+
+static int pipe_ingest(wmx_pipe *h, const uint8_t *d_in, long in_stride, void *stream) {
+    return wmx_rtp_ingest(h->n_streams, d_in, in_stride, h->d_pcm, 2 * kPkt10, h->d_nbytes, h->d_seq, stream);
+}
+static int pipe_chain_egress(wmx_pipe *h, const int16_t *d_far, uint8_t *d_out, long out_stride, void *stream) {
+    int rc = wmx_chain_process(h->chain, d_far, kPkt10, h->d_pcm, h->d_pcm, 2, 2 * kPkt10, kPkt10, nullptr, nullptr, nullptr, stream);
+    if (rc != 0) return rc;
+    uint32_t bytes = 0;
+    rc = wmx_rtp_egress(h->snd, 1, kFreq, h->d_pcm, 2 * kPkt10 * 2, 2 * kPkt10, 1, kFreq, d_out, out_stride, &bytes, stream);
+    if (rc == 0 && bytes != (uint32_t)kDatagram) {
+        wmx::set_error("wmx_pipe: egress made %u-byte datagrams", bytes);
+        return WMX_ESTATE;
+    }
+    return rc;
+}
+
+// One step on datagrams that are ALREADY on the device: ingest -> chain -> egress, three launches' worth of calls on `stream`.
+// d_in / d_out: n_streams rows of 172 bytes, in_stride / out_stride bytes apart; d_far: the shared far-end's two 10 ms packets.
+int wmx_pipe_step_resident(wmx_pipe *h, const uint8_t *d_in, long in_stride, const int16_t *d_far, uint8_t *d_out, long out_stride,
+                           void *stream) {
+    WMX_ON_DEVICE(h);
+    if (!h || !d_in || !d_out || !d_far || in_stride < kDatagram || out_stride < kDatagram) {
+        wmx::set_error("wmx_pipe_step_resident: bad argument");
+        return WMX_EINVAL;
+    }
+    const int rc = pipe_ingest(h, d_in, in_stride, stream);
+    return rc ? rc : pipe_chain_egress(h, d_far, d_out, out_stride, stream);
+}
+
+// the D2H of the pending slot, behind `gate` (an event of the compute stream)
+static int pipe_flush(wmx_pipe *h, hipEvent_t gate) {
+    if (h->pending < 0) return 0;
+    wmx_pipe::Slot &p = h->slot[(size_t)h->pending];
+    h->pending = -1;
+    WMX_HIP(hipStreamWaitEvent(h->s_out, gate, 0));
+    WMX_HIP(hipMemcpyAsync(p.h_out, p.d_out, (size_t)h->n_streams * kDatagram, hipMemcpyDeviceToHost, h->s_out));
+    WMX_HIP(hipEventRecord(p.ev_out, h->s_out));
+    return 0;
+}
+
+// Queue the next slot: its h_in rows (and, when d_far is NULL, its h_far samples) must hold this step's input.  *slot receives the
+// slot index; its h_out rows are valid after wmx_pipe_wait(h, *slot).  Blocks only if that slot is still in flight from `slots`
+// steps ago.  d_far != NULL: the far-end is on the device already (its two 10 ms packets, contiguous).
+//
+// WHERE the download of a step is queued matters: the runtime copies device-to-host with a blit kernel (11 MB of posted writes over
+// PCIe, ~210 us), and a memory-bound kernel beside it starves -- the next step's ingest kernel, 15 us alone, took the blit's whole
+// 210 us when the download was queued right behind the egress (rocprofv3 kernel trace, profiles/r05).  So the download of step k is
+// queued by submit(k + 1), gated on an event BEHIND step k + 1's ingest kernel: it runs beside the noise suppressor and the echo
+// canceller, which are bound by arithmetic.  The last step's download is queued by wmx_pipe_wait.
+int wmx_pipe_submit(wmx_pipe *h, const int16_t *d_far, int *slot, void *stream) {
+    WMX_ON_DEVICE(h);
+    if (!h) return WMX_EINVAL;
+    const int k = h->next;
+    h->next = (k + 1) % h->slots;
+    wmx_pipe::Slot &s = h->slot[(size_t)k];
+    hipStream_t main = wmx::as_stream(stream);
+    if (s.in_flight) {
+        if (h->pending == k) {  // one slot only: its download cannot wait for the next ingest
+            const int rc = pipe_flush(h, s.ev_done);
+            if (rc != 0) return rc;
+        }
+        WMX_HIP(hipEventSynchronize(s.ev_out));  // the slot's previous result has left the device: its buffers are free
+        s.in_flight = false;
+    }
+    const size_t bytes = (size_t)h->n_streams * kDatagram;
+    WMX_HIP(hipMemcpyAsync(s.d_in, s.h_in, bytes, hipMemcpyHostToDevice, h->s_in));
+    if (!d_far) WMX_HIP(hipMemcpyAsync(s.d_far, s.h_far, 2 * kPkt10 * sizeof(int16_t), hipMemcpyHostToDevice, h->s_in));
+    WMX_HIP(hipEventRecord(s.ev_in, h->s_in));
+    WMX_HIP(hipStreamWaitEvent(main, s.ev_in, 0));
+    int rc = pipe_ingest(h, s.d_in, kDatagram, stream);
+    if (rc != 0) return rc;
+    if (h->pending >= 0) {
+        WMX_HIP(hipEventRecord(s.ev_gate, main));
+        if ((rc = pipe_flush(h, s.ev_gate)) != 0) return rc;
+    }
+    rc = pipe_chain_egress(h, d_far ? d_far : s.d_far, s.d_out, kDatagram, stream);
+    if (rc != 0) return rc;
+    WMX_HIP(hipEventRecord(s.ev_done, main));
+    h->pending = k;
+    s.in_flight = true;
+    if (slot) *slot = k;
+    return 0;
+}
+
+// Blocks until the slot's datagrams are in its h_out rows (returns at once for a slot that is not in flight); slot < 0: every slot.
+int wmx_pipe_wait(wmx_pipe *h, int slot) {
+    WMX_ON_DEVICE(h);
+    if (!h || slot >= h->slots) return WMX_EINVAL;
+    if (h->pending >= 0 && (slot < 0 || slot == h->pending)) {
+        const int rc = pipe_flush(h, h->slot[(size_t)h->pending].ev_done);
+        if (rc != 0) return rc;
+    }
+    for (int k = 0; k < h->slots; k++) {
+        if (slot >= 0 && k != slot) continue;
+        wmx_pipe::Slot &s = h->slot[(size_t)k];
+        if (s.in_flight) {
+            WMX_HIP(hipEventSynchronize(s.ev_out));
+            s.in_flight = false;
+        }
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -5,85 +5,78 @@ src/wmixTask.c:1124-1143), for a batch of streams with only the 172-byte datagra
     RTP/PCMA datagram -> header + A-law decode (rtp.hip) -> NS -> AEC -> AGC -> VAD (two 10 ms packets each, 8 kHz mono,
     in place) -> zoom 1x8000 -> A-law encode -> RTP header with the stream's running seq / timestamp (rtp.hip)
 
-`step()` works on datagrams already resident in HBM.  `StreamingPipe` adds the host side of a server: pinned host buffers,
-a copy-in and a copy-out HIP stream, three slots in flight, so the H2D of step k+1 and the D2H of step k-1 overlap the
-compute of step k.  All arithmetic is in the HIP kernels; this file only sequences launches.
+This file is a ctypes mirror: the sequencing -- pinned slots, the copy-in and copy-out HIP streams, the events, the three launches
+per step -- lives in the library (wmix_amd/csrc/pipe.hip, wmx_pipe_*), where a C host finds it too (examples/host_chain.c --rtp).
+`RtpChain.step()` works on datagrams already resident in HBM; `StreamingPipe` drives the slots: H2D of step k + 1 and D2H of
+step k - 1 overlap the compute of step k.
 """
+import ctypes as C
+
+import numpy as np
 import torch
 
-from . import rtp
-from .chain import ChainBatch
+from ._lib import check, lib
+from .chain import AEC, AGC, NS, VAD
 
 DATAGRAM = 172  # 12-byte RTP header + 160 G.711 codes (20 ms at 8 kHz), src/rtp.h:33, src/rtp.c:86-95
 FREQ, PKT = 8000, 80
 
 
 class RtpChain:
-    def __init__(self, n_streams, dev, agc_value=5):
+    def __init__(self, n_streams, dev, agc_value=5, slots=3):
         self.n, self.dev = n_streams, dev
-        # the four stages behind one C call per tick (wmx_chain_process: the AEC's far kernel beside the noise suppressor, the VAD one
-        # call over the tick's two packets, as in the heartbeat)
-        self.chain = ChainBatch(n_streams, 1, FREQ, 10, agc_value)
-        self.snd = rtp.RtpSenders(n_streams, "a")
-        self.pcm = torch.zeros((n_streams, 2 * PKT), dtype=torch.int16, device=dev)
-        self.nbytes = torch.zeros(n_streams, dtype=torch.int32, device=dev)
-        self.seq = torch.zeros(n_streams, dtype=torch.int16, device=dev)
+        self._h = C.c_void_p()
+        check(lib().wmx_pipe_create(C.byref(self._h), n_streams, slots, 0, agc_value, NS | AEC | AGC | VAD), "wmx_pipe_create")
+        self.slots = slots
 
     def step(self, packets_in, far, packets_out):
         """packets_in / packets_out: uint8 CUDA [n_streams, 172]; far: int16 CUDA [2, 80], the shared far-end of these 20 ms."""
-        from ._lib import check, lib
-        st = torch.cuda.current_stream().cuda_stream
-        check(lib().wmx_rtp_ingest(self.n, packets_in.data_ptr(), packets_in.stride(0), self.pcm.data_ptr(), self.pcm.stride(0),
-                                   self.nbytes.data_ptr(), self.seq.data_ptr(), st), "wmx_rtp_ingest")
-        rc, _, _ = self.chain.process(far, self.pcm.view(self.n, 2, PKT))
-        assert rc == 0
-        return self.snd.egress(self.pcm, 1, FREQ, 1, FREQ, packets=packets_out)
+        assert packets_in.is_cuda and packets_out.is_cuda and packets_in.stride(1) == 1 and packets_out.stride(1) == 1
+        assert far.is_cuda and far.dtype == torch.int16 and far.is_contiguous() and far.numel() == 2 * PKT
+        check(lib().wmx_pipe_step_resident(self._h, packets_in.data_ptr(), packets_in.stride(0), far.data_ptr(), packets_out.data_ptr(),
+                                           packets_out.stride(0), torch.cuda.current_stream().cuda_stream), "wmx_pipe_step_resident")
+        return packets_out
 
     def close(self):
-        for b in (self.chain, self.snd):
-            b.close()
+        if self._h:
+            lib().wmx_pipe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _host_rows(ptr, shape, dtype):
+    """numpy view of a pinned host buffer the library owns"""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    buf = (C.c_uint8 * n).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
 
 class StreamingPipe:
-    """Host-resident datagrams in, host-resident datagrams out, copies overlapped with compute (3 slots in flight)."""
-    SLOTS = 3
+    """Host-resident datagrams in, host-resident datagrams out, copies overlapped with compute (wmx_pipe_submit / _wait)."""
 
     def __init__(self, chain):
         self.c = chain
-        n, dev = chain.n, chain.dev
-        self.h_in = [torch.empty((n, DATAGRAM), dtype=torch.uint8).pin_memory() for _ in range(self.SLOTS)]
-        self.h_out = [torch.empty((n, DATAGRAM), dtype=torch.uint8).pin_memory() for _ in range(self.SLOTS)]
-        self.d_in = [torch.empty((n, DATAGRAM), dtype=torch.uint8, device=dev) for _ in range(self.SLOTS)]
-        self.d_out = [torch.empty((n, DATAGRAM), dtype=torch.uint8, device=dev) for _ in range(self.SLOTS)]
-        self.s_in, self.s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-        self.ev_in = [torch.cuda.Event() for _ in range(self.SLOTS)]
-        self.ev_done = [torch.cuda.Event() for _ in range(self.SLOTS)]
-        self.ev_out = [None] * self.SLOTS
-        self.k = 0
+        self.SLOTS = chain.slots
+        L = lib()
+        self.h_in = [_host_rows(L.wmx_pipe_in(chain._h, s), (chain.n, DATAGRAM), np.uint8) for s in range(self.SLOTS)]
+        self.h_out = [_host_rows(L.wmx_pipe_out(chain._h, s), (chain.n, DATAGRAM), np.uint8) for s in range(self.SLOTS)]
+        self.h_far = [_host_rows(L.wmx_pipe_far(chain._h, s), (2, PKT), np.int16) for s in range(self.SLOTS)]
 
-    def submit(self, far):
-        """Process the datagrams the caller has placed in h_in[slot] (slot = k % SLOTS); the result lands in h_out[slot]
-        once ev_out[slot] has fired.  Returns the slot."""
-        s = self.k % self.SLOTS
-        self.k += 1
-        main = torch.cuda.current_stream()
-        if self.ev_out[s] is not None:
-            self.ev_out[s].synchronize()  # the slot's previous result has left the device: its buffers are free
-        with torch.cuda.stream(self.s_in):
-            self.d_in[s].copy_(self.h_in[s], non_blocking=True)
-            self.ev_in[s].record(self.s_in)
-        main.wait_event(self.ev_in[s])
-        self.c.step(self.d_in[s], far, self.d_out[s])
-        self.ev_done[s].record(main)
-        with torch.cuda.stream(self.s_out):
-            self.s_out.wait_event(self.ev_done[s])
-            self.h_out[s].copy_(self.d_out[s], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self.s_out)
-            self.ev_out[s] = ev
-        return s
+    def submit(self, far=None):
+        """Process the datagrams the caller has placed in h_in[slot] (slots are taken round robin); far: int16 CUDA [2, 80], or
+        None = the samples in h_far[slot].  Returns the slot; its h_out rows are valid after wait(slot)."""
+        slot = C.c_int(-1)
+        check(lib().wmx_pipe_submit(self.c._h, None if far is None else far.data_ptr(), C.byref(slot),
+                                    torch.cuda.current_stream().cuda_stream), "wmx_pipe_submit")
+        return slot.value
+
+    def wait(self, slot=-1):
+        check(lib().wmx_pipe_wait(self.c._h, slot), "wmx_pipe_wait")
 
     def drain(self):
-        for ev in self.ev_out:
-            if ev is not None:
-                ev.synchronize()
+        self.wait(-1)
