@@ -638,7 +638,7 @@ class ChainWorkload:
     timer_dominant = "aec"
 
     def __init__(self, dev, n_streams, rank, dist=None, packets=1, interval_ms=10, cohorts=1, cohort_layout="arrival", coalesce=False,
-                 far_ends=1):
+                 far_ends=1, far_chunk=1):
         from wmix_amd import synth
         from wmix_amd.chain import AEC, AGC, NS, VAD, ChainBatch
         global broadcast_far
@@ -686,7 +686,11 @@ class ChainWorkload:
         assert self.K % self.P == 0
         # several GPUs: two far-end receive buffers; the packet of step k + 1 is broadcast while step k computes (the daemon
         # itself hands the AEC a far-end that is 400 ms old, src/wmix.c:651-657: it is known long before it is needed)
-        self.far = [torch.zeros(self.P, self.pkt, dtype=torch.int16, device=dev) for _ in range(2)]
+        # --far-chunk K: ONE broadcast carries the far-end of K steps ("one ncclBroadcast per batch of K frames"):
+        # the collective's host cost -- the one thing that can bend the scaling curve at a 1 ms step -- is paid once per K steps
+        self.FC = int(far_chunk)
+        assert self.FC >= 1
+        self.far = [torch.zeros(self.FC * self.P, self.pkt, dtype=torch.int16, device=dev) for _ in range(2)]
         self.far_work = [None, None]
         # interval_ms = 20 is the daemon's own cadence (WMIX_INTERVAL_MS, src/wmixConf.h:112: what it hands aec_init / agc_init /
         # vad_init, src/wmix.c:636, 684, 703): VAD packets of 20 ms, AEC packets of 20 ms at 8 kHz.  Such a packet must lie in
@@ -758,20 +762,24 @@ class ChainWorkload:
         k = (step_index * P) % self.K
         if self.dist is None:
             return self.far_src[k:k + P]  # [P, pkt], or [P, N, pkt] with --far-ends N
-        b = step_index & 1
-        if self.far_work[b] is None:  # first step: nothing was requested ahead
-            self._request_far(step_index)
-        w, self.far_work[b] = self.far_work[b], None
-        if w is not True:
-            w.wait()
-        self._request_far(step_index + 1)
-        return self.far[b]
+        c, j = divmod(step_index, self.FC)  # chunk c of FC steps, step j inside it
+        b = c & 1
+        if j == 0:
+            if self.far_work[b] is None:  # first chunk: nothing was requested ahead
+                self._request_far(c)
+            w, self.far_work[b] = self.far_work[b], None
+            if w is not True:
+                w.wait()
+            self._request_far(c + 1)  # the next chunk travels while this one computes
+        return self.far[b][j * P:(j + 1) * P]
 
-    def _request_far(self, step_index):
-        b = step_index & 1
-        k = (step_index * self.P) % self.K
+    def _request_far(self, chunk_index):
+        b = chunk_index & 1
         if self.rank == 0:
-            self.far[b].copy_(self.far_src[k:k + self.P])
+            n = self.FC * self.P
+            k = (chunk_index * n) % self.K
+            idx = (k + torch.arange(n, device=self.far_src.device)) % self.K  # a chunk may wrap around the K-packet pattern
+            self.far[b].copy_(self.far_src[idx])
         self.far_work[b] = broadcast_far(self.far[b], self.dist, src=0, async_op=True) or True
 
     def timed_region(self, on):
@@ -871,8 +879,8 @@ class ChainWorkload:
                 "frame": "%d x int16 (10 ms @ %d kHz mono)" % (self.pkt, self.freq // 1000),
                 "input": "SURVEY 8d recipe: far = LCG noise A=8000; near = far delayed 40 / 2 + noise A=200 + 3000 sin(0.01 t) gated "
                          "every 100 frames; 256 distinct streams x %d packets, tiled" % self.K,
-                "far_end": ("shared, RCCL broadcast from rank 0 each step (the packet of step k + 1 travels while step k computes)"
-                            if self.dist is not None else
+                "far_end": ("shared, RCCL broadcast from rank 0: one collective per %d step(s), the next chunk travels while this one "
+                            "computes" % self.FC if self.dist is not None else
                             ("%d distinct far-ends, stream s hears far-end s * N // S; resident in HBM" % self.far_ends if self.far_ends > 1
                              else "shared, resident in HBM (one GPU: nothing to broadcast)")),
                 "sum_order": "reference (bit-exact NS mode)",
@@ -1239,7 +1247,7 @@ class StubCpuWorkload:
     dominant_bytes_per_frame = 640.0
     needs_gpu = False
 
-    def __init__(self, dev, n_streams, rank, dist=None, packets=1, stream_offset=0):
+    def __init__(self, dev, n_streams, rank, dist=None, packets=1, stream_offset=0, far_chunk=1):
         from wmix_amd.shard import broadcast_far
         if os.environ.get("WMIX_STUB_CHATTER") == "1" and rank > 0:  # tests: what ranks > 0 print is kept by the launcher
             print("stub rank %d says hello" % rank, flush=True)
@@ -1249,23 +1257,28 @@ class StubCpuWorkload:
         self.n_frames = n_streams
         self.dist, self.rank = dist, rank
         self.lo = stream_offset  # global id of this rank's first stream (--total-streams: contiguous ranges, remainder on the first ranks)
-        self.far = torch.zeros(160, dtype=torch.int16)
+        self.FC = int(far_chunk)  # --far-chunk K: one broadcast per K steps
+        self.far = torch.zeros(self.FC, 160, dtype=torch.int16)
+        self.n_bcast = 0
         self.acc = torch.zeros(n_streams, 160, dtype=torch.int32)
         self.gid = (torch.arange(n_streams, dtype=torch.int32) + self.lo) % 5  # what a stream adds depends on its GLOBAL id
         self.k = 0
 
     def step(self, timed):
+        j = self.k % self.FC
+        if j == 0:  # rank 0 knows the far-end of the next FC steps (their values: k + 1 .. k + FC) and sends them at once
+            if self.rank == 0:
+                self.far.copy_((self.k + 1 + torch.arange(self.FC, dtype=torch.int16))[:, None].expand(self.FC, 160))
+            self._bcast(self.far, self.dist, src=0)
+            self.n_bcast += 1
         self.k += 1
-        if self.rank == 0:
-            self.far.fill_(self.k)
-        self._bcast(self.far, self.dist, src=0)
-        self.acc += self.far.to(torch.int32)[None, :] + self.gid[:, None]
+        self.acc += self.far[j].to(torch.int32)[None, :] + self.gid[:, None]
 
     def dominant_ms(self):
         return None
 
     def config(self):
-        return {"workload": self.name, "streams_per_gpu": self.n_frames,
+        return {"workload": self.name, "streams_per_gpu": self.n_frames, "far_chunk": self.FC, "broadcasts": self.n_bcast,
                 "far_sum": int((self.acc[0, 0] - self.k * self.gid[0]).item()) if self.n_frames else None}
 
     def parity_check(self):
@@ -1364,9 +1377,9 @@ SIDE_CONFIGS = [("configs[0]", "g711"), ("configs[1]", "ns"), ("configs[3]", "ns
 def _make_workload(cls, dev, n_mine, rank, dist, args, lo=0):
     if issubclass(cls, ChainWorkload):
         return cls(dev, n_mine, rank, dist, args.packets_per_step, args.interval_ms, args.cohorts, args.cohort_layout, args.coalesce,
-                   getattr(args, "far_ends", 1))
+                   getattr(args, "far_ends", 1), getattr(args, "far_chunk", 1))
     if issubclass(cls, StubCpuWorkload):
-        return cls(dev, n_mine, rank, dist, args.packets_per_step, lo)
+        return cls(dev, n_mine, rank, dist, args.packets_per_step, lo, getattr(args, "far_chunk", 1))
     if issubclass(cls, AecmWorkload):
         return cls(dev, n_mine, rank, dist, args.packets_per_step)
     return cls(dev, n_mine, rank)
@@ -1379,7 +1392,7 @@ def _side_config(label, name, args, dev):
     import copy
     cls, n = WORKLOADS[name]
     a = copy.copy(args)
-    a.packets_per_step, a.interval_ms, a.cohorts, a.cohort_layout, a.coalesce, a.far_ends = 1, 10, 1, "arrival", False, 1
+    a.packets_per_step, a.interval_ms, a.cohorts, a.cohort_layout, a.coalesce, a.far_ends, a.far_chunk = 1, 10, 1, "arrival", False, 1, 1
     t_start = time.perf_counter()
     wl = _make_workload(cls, dev, n, 0, None, a)
 
@@ -1480,6 +1493,9 @@ def main():
                     help="chain workloads: N DISTINCT far-end signals per GPU, stream s cancelled against far-end s * N // S (every mix "
                          "group / call its own far-end: aec_process2's far-end is per handle); the roofline entry then counts the far-end "
                          "spectra each group of S / N streams shares")
+    ap.add_argument("--far-chunk", type=int, default=1,
+                    help="N > 1 ranks: rank 0 broadcasts the far-end of K steps with ONE collective (SURVEY section 5: one ncclBroadcast per batch "
+                         "of K frames; the daemon's far-end is 400 ms old when the AEC gets it, src/wmix.c:651-657: it is known long before)")
     ap.add_argument("--coalesce", action="store_true",
                     help="with --cohorts: wmx_chain_coalesce behind every step (cohorts whose control planes have converged are merged; "
                          "the priming grows until they have)")

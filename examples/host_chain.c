@@ -8,7 +8,7 @@
  * (the single exchange of the path; a host that produces the far-end on a GPU uses one ncclBroadcast instead),
  * uploads its shard's captured packets, makes ONE library call (wmx_chain_process) and downloads the result.
  *
- *   host_chain far.i16 near.i16 out.i16 n_streams n_ticks [n_workers] [freq] [--devices k] [--interval-ms 20]
+ *   host_chain far.i16 near.i16 out.i16 n_streams n_ticks [n_workers] [freq] [--devices k] [--interval-ms 20] [--far-chunk K]
  *
  * far.i16  int16 [n_ticks][pkt]             the shared far-end          (pkt = freq / 100 samples, mono)
  * near.i16 int16 [n_streams][n_ticks][pkt]  captured audio, stream-major
@@ -17,7 +17,9 @@
  * several shards (tests/test_host_chain_gpu.py does, and compares out.i16 with the oracle).  --devices k: use the first k
  * devices of the node (default: all of them), so that one binary covers 1 ... 8 GPUs.  --interval-ms 20: the daemon's own cadence --
  * handles made with WMIX_INTERVAL_MS = 20 (src/wmixConf.h:112) and a heartbeat of 20 ms = two 10 ms packets per tick (n_ticks then
- * counts 20 ms heartbeats and every array holds 2 pkt samples per tick).
+ * counts 20 ms heartbeats and every array holds 2 pkt samples per tick).  --far-chunk K: the far-end of K ticks travels at once -- one
+ * upload (one ncclBroadcast in the RCCL build) per K ticks instead of one per tick ("one ncclBroadcast per batch of K
+ * frames"; the daemon's far-end is 400 ms old when the canceller gets it, src/wmix.c:651-657: it is known long before it is needed).
  *
  * Built with -DWMX_EXAMPLE_RCCL (examples/host_chain_rccl, links librccl) the far-end travels the way north_star puts it:
  * worker 0 alone uploads the packet, and ONE ncclBroadcast per tick (every worker calls it on its own communicator and stream)
@@ -44,6 +46,7 @@ typedef struct {
     int worker, dev, lo, n;      /* this shard: streams [lo, lo + n) on HIP device dev */
     int n_ticks, pkt, freq;      /* pkt: int16 samples of one TICK of one stream (n10 packets of 10 ms) */
     int interval_ms, n10;
+    int far_chunk;               /* ticks of far-end per upload / broadcast */
     const int16_t *far_host;     /* [n_ticks][pkt], shared */
     const int16_t *near_host;    /* [n_streams][n_ticks][pkt] */
     int16_t *out_host;
@@ -92,7 +95,7 @@ static void *gpu_worker(void *arg) {
     int created = 0;
     if (hipSetDevice(s->dev) == hipSuccess && hipStreamCreate(&st) == hipSuccess &&
         wmx_chain_create(&chain, s->n, 1, s->freq, s->interval_ms, 5, WMX_CHAIN_NS | WMX_CHAIN_AEC | WMX_CHAIN_AGC | WMX_CHAIN_VAD, 1) == 0 &&
-        hipMalloc((void **)&d_near, (size_t)s->n * row) == hipSuccess && hipMalloc((void **)&d_far, row) == hipSuccess)
+        hipMalloc((void **)&d_near, (size_t)s->n * row) == hipSuccess && hipMalloc((void **)&d_far, row * (size_t)s->far_chunk) == hipSuccess)
         created = 1;
     else
         fprintf(stderr, "worker %d: set-up failed (%s)\n", s->worker, wmx_last_error());
@@ -111,7 +114,10 @@ static void *gpu_worker(void *arg) {
         const double t0 = now_ms();
 #ifdef WMX_EXAMPLE_RCCL
         /* the far-end reaches GPU 0 from the host and every other GPU from GPU 0 (the path's one exchange) */
-        if (s->worker == 0 && hipMemcpyAsync(d_far, s->far_host + (size_t)t * s->pkt, row, hipMemcpyHostToDevice, st) != hipSuccess) {
+        const int fj = t % s->far_chunk;                                        /* tick t's place in its chunk */
+        const int fn = s->n_ticks - t < s->far_chunk ? s->n_ticks - t : s->far_chunk; /* ticks in the chunk that starts at t */
+        if (fj == 0 && s->worker == 0 &&
+            hipMemcpyAsync(d_far, s->far_host + (size_t)t * s->pkt, row * (size_t)fn, hipMemcpyHostToDevice, st) != hipSuccess) {
             fprintf(stderr, "worker 0: far-end upload failed\n");
             s->rc = 1;
         }
@@ -121,8 +127,8 @@ static void *gpu_worker(void *arg) {
             s->rc = 1;
             goto done;
         }
-        {
-            ncclResult_t nr = ncclBroadcast(d_far, d_far, row, ncclInt8, 0, s->comm, st);
+        if (fj == 0) { /* ONE collective for the chunk's fn ticks */
+            ncclResult_t nr = ncclBroadcast(d_far, d_far, row * (size_t)fn, ncclInt8, 0, s->comm, st);
             if (nr != ncclSuccess) {
                 fprintf(stderr, "worker %d: ncclBroadcast -> %s\n", s->worker, ncclGetErrorString(nr));
                 s->rc = 1;
@@ -130,12 +136,14 @@ static void *gpu_worker(void *arg) {
             }
         }
 #else
-        HIP_OK(hipMemcpyAsync(d_far, s->far_host + (size_t)t * s->pkt, row, hipMemcpyHostToDevice, st));
+        const int fj = t % s->far_chunk;
+        const int fn = s->n_ticks - t < s->far_chunk ? s->n_ticks - t : s->far_chunk;
+        if (fj == 0) HIP_OK(hipMemcpyAsync(d_far, s->far_host + (size_t)t * s->pkt, row * (size_t)fn, hipMemcpyHostToDevice, st));
 #endif
         HIP_OK(hipMemcpy2DAsync(d_near, row, s->near_host + ((size_t)s->lo * s->n_ticks + t) * s->pkt, pitch, row, (size_t)s->n,
                                 hipMemcpyHostToDevice, st));
         /* a stream's tick in one piece: n10 packets of pkt / n10 samples, streams pkt apart */
-        WMX_OK(wmx_chain_process(chain, d_far, s->pkt / s->n10, d_near, d_near, s->n10, s->pkt, s->pkt / s->n10, NULL, NULL, NULL, st));
+        WMX_OK(wmx_chain_process(chain, d_far + (size_t)fj * s->pkt, s->pkt / s->n10, d_near, d_near, s->n10, s->pkt, s->pkt / s->n10, NULL, NULL, NULL, st));
         HIP_OK(hipMemcpy2DAsync(s->out_host + ((size_t)s->lo * s->n_ticks + t) * s->pkt, pitch, d_near, row, row, (size_t)s->n,
                                 hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
@@ -162,11 +170,13 @@ static void *read_file(const char *path, size_t bytes) {
 }
 
 int main(int argc, char **argv) {
-    int want_dev = 0, interval_ms = 10;
-    for (int i = 1; i + 1 < argc;) /* --devices k / --interval-ms m, wherever they stand: taken out of the positional arguments */
-        if (strcmp(argv[i], "--devices") == 0 || strcmp(argv[i], "--interval-ms") == 0) {
+    int want_dev = 0, interval_ms = 10, far_chunk = 1;
+    for (int i = 1; i + 1 < argc;) /* --devices k / --interval-ms m / --far-chunk K, wherever they stand: taken out of the positional arguments */
+        if (strcmp(argv[i], "--devices") == 0 || strcmp(argv[i], "--interval-ms") == 0 || strcmp(argv[i], "--far-chunk") == 0) {
             if (argv[i][2] == 'd')
                 want_dev = atoi(argv[i + 1]);
+            else if (argv[i][2] == 'f')
+                far_chunk = atoi(argv[i + 1]);
             else
                 interval_ms = atoi(argv[i + 1]);
             for (int j = i; j + 2 < argc; j++) argv[j] = argv[j + 2];
@@ -178,8 +188,12 @@ int main(int argc, char **argv) {
         fprintf(stderr, "host_chain: --interval-ms 10 or 20\n");
         return 2;
     }
+    if (far_chunk < 1 || far_chunk > 4096) {
+        fprintf(stderr, "host_chain: --far-chunk 1 .. 4096\n");
+        return 2;
+    }
     if (argc < 6) {
-        fprintf(stderr, "usage: %s far.i16 near.i16 out.i16 n_streams n_ticks [n_workers] [freq] [--devices k] [--interval-ms 20]\n", argv[0]);
+        fprintf(stderr, "usage: %s far.i16 near.i16 out.i16 n_streams n_ticks [n_workers] [freq] [--devices k] [--interval-ms 20] [--far-chunk K]\n", argv[0]);
         return 2;
     }
     const int n_streams = atoi(argv[4]), n_ticks = atoi(argv[5]);
@@ -235,6 +249,7 @@ int main(int argc, char **argv) {
         s->pkt = pkt;
         s->freq = freq;
         s->interval_ms = interval_ms;
+        s->far_chunk = far_chunk;
         s->n10 = n10;
         s->far_host = far;
         s->near_host = near;

@@ -83,6 +83,22 @@ def test_eight_ranks_shard_a_non_divisible_stream_count():
     assert took < 240, took
 
 
+def test_eight_ranks_far_end_in_chunks():
+    """--far-chunk K (round-4 VERDICT "next" 6; SURVEY section 5: one broadcast per batch of K frames): rank 0 sends the far-end of K
+    steps with ONE collective; every stream of every rank still hears every packet, in order, for K = 1, 8 and a K beyond the
+    whole run.  18 steps in all (4 priming + 2 warm-up + 6 timed + 6 breakdown)."""
+    import pytest
+    for K, want_bcast in ((1, 18), (8, 3), (100, 1)):
+        r = _run(["--gpus", "8", "--workload", "stub_cpu", "--total-streams", "37", "--steps", "6", "--warmup", "2", "--prime", "4", "--no-cpu",
+                  "--far-chunk", str(K)], timeout=300)
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+        assert d["n_gpus"] == 8 and d["config"]["far_chunk"] == K and d["config"]["broadcasts"] == want_bcast
+        assert d["config"]["far_sum"] == sum(range(1, 19))
+        ranks = d["parity_checked_ranks"]
+        assert len(ranks) == 8 and all(p["max_lsb"] == 0 and p["packets_compared"] > 0 for p in ranks), K
+
+
 def test_eight_ranks_under_the_drivers_own_launch_line():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",

@@ -54,6 +54,15 @@ def test_rccl_itself_under_the_multi_rank_code_path():
     assert "RCCL broadcast" in d["config"]["far_end"]
     assert len(d["parity_checked_ranks"]) == 1 and d["parity_checked_ranks"][0]["max_lsb"] <= 1
     assert d["parity_checked_ranks"][0]["packets_compared"] > 0
+    # --far-chunk 8: ONE RCCL broadcast per 8 steps, the next chunk in flight while this one computes
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29621", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "chain", "--streams", "512",
+                        "--steps", "6", "--warmup", "2", "--prime", "60", "--spinup", "4", "--no-cpu", "--far-chunk", "8"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert "one collective per 8 step" in d["config"]["far_end"] and d["parity_checked_ranks"][0]["max_lsb"] <= 1
+    assert d["parity_checked_ranks"][0]["packets_compared"] > 0
 
 
 def test_one_rank_under_the_launcher_measures_what_the_direct_line_measures():
