@@ -1653,6 +1653,8 @@ def main():
         "rccl_ranks": (dist.get_world_size() if dist is not None and backend == "nccl" else None),
         "dist_backend": backend,
         "launched_by": os.environ.get("WMIX_BENCH_LAUNCHED_BY", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"),
+        # which build of the library measured this ("default" = the product; anything else is a developer variant, loaded on purpose)
+        "build": (_lib.build_info() if on_gpu else None),
     }
     if hasattr(wl, "parity_check"):
         if dist is not None:

@@ -42,6 +42,10 @@ int wmx_device_count(void);
 int wmx_handle_device(const void *handle);
 /* library/ABI version: major*10000 + minor*100 + patch */
 int wmx_version(void);
+/* "default" for the product build; else the developer flags the library was built with (prefixed "TIMING-ONLY (wrong results): "
+ * when one of them is a timing experiment's switch).  The Python mirror, build(), smoke() and bench.py refuse anything but "default"
+ * unless WMIX_AMD_ALLOW_VARIANT_BUILD=1. */
+const char *wmx_build_info(void);
 
 /* ------------------------------------------------------------------ per-stream lifetime inside a batch
  * The reference creates each handle lazily in the record heartbeat and releases it when its switch drops or recording

@@ -23,9 +23,21 @@ def lib():
             raise WmxError(
                 "libwmix_amd.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C wmix_amd/csrc` (there is no CPU fallback)")
-        _lib = C.CDLL(LIB_PATH)
-        _declare(_lib)
+        L = C.CDLL(LIB_PATH)
+        L.wmx_build_info.restype = C.c_char_p
+        L.wmx_build_info.argtypes = []
+        info = L.wmx_build_info().decode(errors="replace")
+        if info != "default" and os.environ.get("WMIX_AMD_ALLOW_VARIANT_BUILD") != "1":
+            raise WmxError("%s is not the product build: wmx_build_info() = %r (a developer variant; set WMIX_AMD_ALLOW_VARIANT_BUILD=1 to "
+                           "load it on purpose)" % (LIB_PATH, info))
+        _declare(L)
+        _lib = L
     return _lib
+
+
+def build_info():
+    """wmx_build_info() of the loaded library: "default", or the developer flags of a variant build."""
+    return lib().wmx_build_info().decode(errors="replace")
 
 
 def check(rc, what=""):
@@ -55,6 +67,8 @@ def _declare(L):
     L.wmx_last_error.argtypes = []
     L.wmx_device_count.restype = i
     L.wmx_version.restype = i
+    L.wmx_build_info.restype = C.c_char_p
+    L.wmx_build_info.argtypes = []
     for name in ("wmx_g711_encode", "wmx_g711_decode"):
         f = getattr(L, name)
         f.restype = i

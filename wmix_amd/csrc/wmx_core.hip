@@ -53,7 +53,17 @@ int wmx_device_count(void) {
     return n;
 }
 
-int wmx_version(void) { return 200; }
+int wmx_version(void) { return 300; }
+
+// "default" for the product build; otherwise the developer flags it was made with (the Makefile's EXTRA), prefixed "TIMING-ONLY
+// (wrong results): " when one of them is a timing experiment's switch.  See build_flags.h.
+const char *wmx_build_info(void) {
+#ifdef WMX_TIMING_ONLY_BUILD
+    return "TIMING-ONLY (wrong results): " WMX_BUILD_EXTRA;
+#else
+    return WMX_BUILD_EXTRA[0] ? WMX_BUILD_EXTRA : "default";
+#endif
+}
 
 // `int device` is the first member of every wmx_* handle struct
 int wmx_handle_device(const void *handle) { return handle ? *static_cast<const int *>(handle) : WMX_EINVAL; }

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <vector>
 #include "../../include/wmix_amd.h"
+#include "build_flags.h"
 
 #define WMX_HIP_RC(expr)                                                      \
     do {                                                                      \
