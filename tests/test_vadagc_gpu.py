@@ -263,6 +263,27 @@ def test_pipeline_kernels_equal_the_one_lane_kernels(cuda, monkeypatch, freq, S,
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("chn,freq,ims", [(2, 16000, 10), (2, 8000, 10), (2, 32000, 10), (1, 32000, 10), (2, 16000, 20), (2, 8000, 20)])
+def test_vad_pipeline_for_every_shape_vad_init_accepts(cuda, oracle_port, monkeypatch, chn, freq, ims):
+    """vad_init takes any channel count and 8 / 16 / 32 kHz (src/webrtc.c:40-82); vad_process averages the channels in place,
+    analyses and attenuates the mean and writes it back to every channel (:104-150); 32 kHz goes through two chained decimators
+    (W: vad_core.c:623-644).  The four-wave pipeline now takes interleaved two-channel packets and 32 kHz: against the one-lane
+    kernel on partly filled waves, and against the oracle's per-handle run."""
+    S, n_calls = 130, 260
+    x = np.stack([vad_input(chn, freq, ims, 1, n_calls=n_calls, seed=1500 + 7 * s) for s in range(S)])
+    x[3] = 0
+    x[4] = (np.arange(x.shape[1]) % 251 * 131).astype(np.int16)
+    res = {}
+    for one_lane in ("1", "0"):
+        monkeypatch.setenv("WMIX_AMD_VAD_ONE_LANE", one_lane)
+        res[one_lane] = gpu_vad(cuda, chn, freq, ims, 1, x, calls_per_launch=64, packet_major=True)
+    assert np.array_equal(res["1"], res["0"])
+    for s in (0, 3, 4, 63, 64, 129):
+        assert np.array_equal(res["0"][s], L.run_vad(oracle_port, chn, freq, ims, x[s], vad_pkg(freq, ims), prefix="orc")), s
+    # the gate moved: some packets came back attenuated, some not
+    assert not np.array_equal(res["0"][0], x[0])
+
+
 @pytest.mark.parametrize("freq", [8000, 32000])
 def test_two_channel_agc_pipeline_equals_the_one_lane_kernel(cuda, monkeypatch, freq):
     """Interleaved stereo through the AGC pipeline (pair averaged on the way in, result written to both channels)."""

@@ -746,7 +746,10 @@ int wmx_agc_create(wmx_agc **out, int n_streams, int chn, int freq, int interval
         return WMX_ENODEV;
     }
     h->n_streams = n_streams;
-    h->one_lane = getenv("WMIX_AMD_AGC_ONE_LANE") != nullptr;
+    {
+        const char *e = getenv("WMIX_AMD_AGC_ONE_LANE");  // unset, empty or "0": the pipelines
+        h->one_lane = e && e[0] && e[0] != '0';
+    }
     h->chn = chn;
     h->freq = freq;
     h->pkg = freq / 1000 * (freq <= 16000 ? 10 : 5);  // 5 ms packets at 32 kHz, src/webrtc.c:724-728

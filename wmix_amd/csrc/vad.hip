@@ -684,17 +684,44 @@ __device__ __forceinline__ void gmm_update_channel(const VadRef &S, int16_t feat
     }
 }
 
+// mono sample i of a packet that lies in registers as uint4's: CHN = 1 sample i itself (RegSrc); CHN = 2 the interleaved frame i
+// = one 32-bit word (left | right << 16) averaged the way vad_process's in-place down-mix does it (src/webrtc.c:104-116:
+// (L + R) / 2 in int32, truncated towards zero)
+template <int CHN>
+struct FrameSrc {
+    const uint4 *raw;
+    __device__ __forceinline__ int16_t operator()(int i) const {
+        if constexpr (CHN == 1) {
+            const uint4 v = raw[i >> 3];
+            const unsigned w = ((i >> 1) & 3) == 0 ? v.x : (((i >> 1) & 3) == 1 ? v.y : (((i >> 1) & 3) == 2 ? v.z : v.w));
+            return (int16_t)((i & 1) ? (w >> 16) : (w & 0xffffu));
+        } else {
+            const uint4 v = raw[i >> 2];
+            const unsigned w = (i & 3) == 0 ? v.x : ((i & 3) == 1 ? v.y : ((i & 3) == 2 ? v.z : v.w));
+            const int32_t acc = (int32_t)(int16_t)(w & 0xffffu) + (int32_t)(int16_t)(w >> 16);
+            return (int16_t)(acc / 2);
+        }
+    }
+};
+
 // Decimation + first band split of vad_features for the pipeline's filter-bank wave, with the packet passing through the
-// registers eight output samples at a time (the next block's 2 / 4 uint4 are requested while the current one is filtered)
-// instead of 10 / 20 uint4 held at once: the kernel's register count decides how many workgroups share a CU.
-template <int RATIO, int NB>
+// registers a few output samples at a time (the next block's uint4's are requested while the current one is filtered) instead
+// of the whole packet held at once: the kernel's register count decides how many workgroups share a CU.  RATIO = 1, 2, 4: 8, 16,
+// 32 kHz (one or two chained 2:1 decimators in front of the 8 kHz core, vad_core.c:623-674); CHN = 1, 2 interleaved channels.
+template <int RATIO, int NB, int CHN>
 __device__ __forceinline__ void vad_front_blocked(const VadRef &S, const uint4 *frame4, LaneBuf hp120, LaneBuf lp120) {
-    constexpr int IT = 8, VPB = IT * 2 * RATIO / 8, NBLK = NB / 2 / IT;
-    static_assert(RATIO == 1 || RATIO == 2, "8 or 16 kHz");
-    int32_t d0 = 0, d1 = 0;
-    if (RATIO == 2) {
+    static_assert(RATIO == 1 || RATIO == 2 || RATIO == 4, "8, 16 or 32 kHz");
+    // IT pairs of 8 kHz samples per block = 2 IT RATIO CHN int16 of input: at most four uint4 per block in flight twice
+    constexpr int IT = RATIO * CHN <= 2 ? 8 : 16 / (RATIO * CHN), VPB = IT * 2 * RATIO * CHN / 8, NBLK = NB / 2 / IT;
+    static_assert(VPB >= 1 && VPB <= 4 && NBLK * IT * 2 == NB, "block geometry");
+    int32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+    if (RATIO >= 2) {
         d0 = S.w(V32_DS + 0);
         d1 = S.w(V32_DS + 1);
+    }
+    if (RATIO == 4) {
+        d2 = S.w(V32_DS + 2);
+        d3 = S.w(V32_DS + 3);
     }
     int32_t su = wshl(S.h(V16_UPPER + 0), 16), sl = wshl(S.h(V16_LOWER + 0), 16);
     uint4 cur[VPB], nxt[VPB];
@@ -705,14 +732,22 @@ __device__ __forceinline__ void vad_front_blocked(const VadRef &S, const uint4 *
         const int nb = blk + 1 < NBLK ? blk + 1 : blk;  // the last block re-requests itself (no branch around the loads)
 #pragma unroll
         for (int j = 0; j < VPB; j++) nxt[j] = frame4[nb * VPB + j];
-        const RegSrc<VPB> p{cur};
+        const FrameSrc<CHN> p{cur};
 #pragma unroll
         for (int it = 0; it < IT; it++) {
             int16_t s8[2];
 #pragma unroll
             for (int e = 0; e < 2; e++) {
                 const int q = (2 * it + e) * RATIO;
-                s8[e] = RATIO == 1 ? p(q) : ds2_step(p(q), p(q + 1), d0, d1);
+                if (RATIO == 1) {
+                    s8[e] = p(q);
+                } else if (RATIO == 2) {
+                    s8[e] = ds2_step(p(q), p(q + 1), d0, d1);
+                } else {
+                    const int16_t w0 = ds2_step(p(q), p(q + 1), d2, d3);
+                    const int16_t w1 = ds2_step(p(q + 2), p(q + 3), d2, d3);
+                    s8[e] = ds2_step(w0, w1, d0, d1);
+                }
             }
             const int16_t h = allpass_step(s8[0], 20972, su);
             const int16_t l = allpass_step(s8[1], 5571, sl);
@@ -724,9 +759,13 @@ __device__ __forceinline__ void vad_front_blocked(const VadRef &S, const uint4 *
     }
     S.h(V16_UPPER + 0) = (int16_t)(su >> 16);
     S.h(V16_LOWER + 0) = (int16_t)(sl >> 16);
-    if (RATIO == 2) {
+    if (RATIO >= 2) {
         S.w(V32_DS + 0) = d0;
         S.w(V32_DS + 1) = d1;
+    }
+    if (RATIO == 4) {
+        S.w(V32_DS + 2) = d2;
+        S.w(V32_DS + 3) = d3;
     }
 }
 
@@ -816,12 +855,15 @@ __device__ __forceinline__ void vad_pipe_channels(const VadRef &S, int16_t *s16,
     }
 }
 
-// RATIO = 1 (8 kHz) or 2 (16 kHz); NB = 80: mono 10 ms packets, 160: mono 20 ms packets (what vad_init makes of the daemon's
-// WMIX_INTERVAL_MS = 20, src/webrtc.c:57-66, src/wmixConf.h:112); 16-byte aligned rows (what wmx_vad_process checks)
-template <int RATIO, int NB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 80 ? 4 : (RATIO == 1 ? 3 : 2), NB == 80 ? 4 : (RATIO == 1 ? 3 : 2)))) void vad_pipe_kernel(int16_t *s16, int32_t *s32, int16_t *pcm, int n_streams, int packets_per_call,
+// RATIO = 1 (8 kHz), 2 (16 kHz) or 4 (32 kHz); NB = 80: 10 ms packets, 160: 20 ms packets (what vad_init makes of the daemon's
+// WMIX_INTERVAL_MS = 20 up to 16 kHz, src/webrtc.c:57-66, src/wmixConf.h:112); CHN = 1, or 2 interleaved channels -- every shape
+// vad_init accepts for the platforms' formats (src/webrtc.c:40-82).  With CHN = 2 the call is vad_process's down-mix / analyse /
+// attenuate / re-expand on ONE packet per call (src/webrtc.c:104-150): the analysed samples are (L + R) / 2 and BOTH channels of
+// the packet come back as the attenuated mean.  16-byte aligned rows (what wmx_vad_process checks).
+template <int RATIO, int NB, int CHN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 80 ? 4 : 3, NB == 80 ? 4 : 3))) void vad_pipe_kernel(int16_t *s16, int32_t *s32, int16_t *pcm, int n_streams, int packets_per_call,
                                                        int n_calls, long stream_stride, long call_stride, const uint8_t *__restrict__ active) {
-    constexpr int PKG = NB * RATIO, NV = PKG / 8;
+    constexpr int PKG = NB * RATIO, NV = PKG * CHN / 8;
     // mode-3 thresholds and hangover lengths of the frame length (vad_core.c:88-91; gmm_probability above)
     constexpr int GLOB = NB == 80 ? 1100 : 1050, OH1 = NB == 80 ? 6 : 3, OH2 = NB == 80 ? 9 : 5;
     // band buffers of the filter-bank wave: hp120 | lp120 | lp60, with hp60 IN PLACE over hp120 -- a split writes output i from inputs
@@ -874,7 +916,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 80 ? 
         const int call = pass / packets_per_call, it = pass - call * packets_per_call;
         uint4 *frame4 = reinterpret_cast<uint4 *>(pcm + (size_t)stream * stream_stride + (size_t)call * call_stride);
         int16_t feat[6], total;
-        vad_front_blocked<RATIO, NB>(S, frame4, hp120, lp120);
+        vad_front_blocked<RATIO, NB, CHN>(S, frame4, hp120, lp120);
         vad_features_rest<NB>(S, hp120, lp120, hp60, lp60, feat, total);
         // the band buffers are read for the last time above and xch lives in the same bytes: keep the compiler from moving
         // the stores below in front of those reads (the hardware executes a wave's LDS instructions in order)
@@ -926,11 +968,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 80 ? 
             const int lo = (int)(int16_t)(w & 0xffffu) >> reduce, hi = (int)(int16_t)(w >> 16) >> reduce;
             return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16);
         };
-        if (live && it == 0 && reduce != 0) {  // (>> 0 leaves the packet as it is, and vad_process works in place: nothing to fetch or store)
-            // the packet is fetched a second time (L2) rather than held in 80 registers across the two barriers: the
-            // kernel's register count decides how many workgroups share a CU
-            constexpr int NVC = NV < 20 ? NV : 20;  // at most 20 uint4 (80 registers) in flight: a 20 ms packet at 16 kHz goes in two halves
+        // mono: >> 0 leaves the packet as it is, and vad_process works in place: nothing to fetch or store.  Two channels: the packet
+        // always comes back as the mean on both channels (src/webrtc.c:145-150), attenuated or not.
+        if (live && it == 0 && (CHN == 2 || reduce != 0)) {
+            // the packet is fetched a second time (L2) rather than held in registers across the two barriers: the kernel's
+            // register count decides how many workgroups share a CU
+            constexpr int NVC = NV <= 20 ? NV : 5;  // a packet of up to 20 uint4 in one piece (80 registers, nothing else is live here); longer ones five at a time
             static_assert(NV % NVC == 0, "whole chunks");
+            auto dup = [&](unsigned w) {  // (L + R) / 2 >> reduce on both channels
+                const int m = ((int)(int16_t)(w & 0xffffu) + (int)(int16_t)(w >> 16)) / 2;
+                const unsigned v = (unsigned)((int)(int16_t)m >> reduce) & 0xffffu;
+                return v | (v << 16);
+            };
 #pragma unroll 1
             for (int j0 = 0; j0 < NV; j0 += NVC) {
                 uint4 again[NVC];
@@ -938,7 +987,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 80 ? 
                 for (int j = 0; j < NVC; j++) again[j] = frame4[j0 + j];
 #pragma unroll
                 for (int j = 0; j < NVC; j++)
-                    frame4[j0 + j] = make_uint4(att(again[j].x), att(again[j].y), att(again[j].z), att(again[j].w));
+                    frame4[j0 + j] = CHN == 2 ? make_uint4(dup(again[j].x), dup(again[j].y), dup(again[j].z), dup(again[j].w))
+                                              : make_uint4(att(again[j].x), att(again[j].y), att(again[j].z), att(again[j].w));
             }
             if (packets_per_call > 1) __threadfence();  // the next analysis of this call reads what was just stored
         }
@@ -1169,7 +1219,10 @@ int wmx_vad_create(wmx_vad **out, int n_streams, int chn, int freq, int interval
     h->chn = chn;
     h->freq = freq;
     h->interval_ms = (freq <= 16000 && interval_ms % 20 == 0) ? 20 : 10;  // src/webrtc.c:57-66
-    h->one_lane = getenv("WMIX_AMD_VAD_ONE_LANE") != nullptr;
+    {
+        const char *e = getenv("WMIX_AMD_VAD_ONE_LANE");  // unset, empty or "0": the pipelines
+        h->one_lane = e && e[0] && e[0] != '0';
+    }
     h->pkg = freq / 1000 * h->interval_ms;
     // WebRtcVad_InitCore vad_core.c:482-531 (start values vad_core.c:46-57) + reduce = 4 (src/webrtc.c:68)
     static const int16_t nm[12] = {6738, 4892, 7065, 6715, 6771, 3369, 7646, 3863, 7820, 7266, 5020, 4362};
@@ -1265,23 +1318,34 @@ int wmx_vad_process(wmx_vad *h, int16_t *d_pcm, int packets_per_call, int n_call
     hipStream_t s = as_stream(stream);
     const int nb = h->pkg / (h->freq / 8000);  // packet length at 8 kHz: 80 or 160
     const int ratio = h->freq / 8000;
-    // mono 10 ms and 20 ms packets at 8 / 16 kHz with 16-byte aligned rows -- the batched chain's cases (10 ms handles, and the
-    // daemon's own 20 ms ones), one or several packets per call -- go through the four-wave pipeline; every other shape
-    // (32 kHz, interleaved channels, odd alignment) through the one-lane-per-stream kernel
-    const bool pipe = h->chn == 1 && (nb == 80 || nb == 160) && h->freq <= 16000 &&
+    // one- and two-channel 10 ms and 20 ms packets at 8 / 16 / 32 kHz with 16-byte aligned rows -- every shape vad_init accepts for
+    // the batched chains and the daemon's own cadence -- go through the four-wave pipeline (two channels: one packet per call, which is
+    // what the heartbeat makes; several packets of interleaved channels per call keep the one-lane kernel's whole-call down-mix);
+    // more than two channels and odd alignment through the one-lane-per-stream kernel
+    const bool pipe = (h->chn == 1 || (h->chn == 2 && packets_per_call == 1)) && (nb == 80 || (nb == 160 && ratio <= 2)) &&
                       (stream_stride % 8) == 0 && (call_stride % 8) == 0 && (reinterpret_cast<size_t>(d_pcm) % 16) == 0 && !h->one_lane;
     if (pipe) {
-#define VAD_PIPE(R, NB)                                                                                                          \
-    hipLaunchKernelGGL((vad_pipe_kernel<R, NB>), grid, dim3(256), 0, s, h->d_s16, h->d_s32, d_pcm, h->n_streams, packets_per_call, \
+#define VAD_PIPE(R, NB, CH)                                                                                                          \
+    hipLaunchKernelGGL((vad_pipe_kernel<R, NB, CH>), grid, dim3(256), 0, s, h->d_s16, h->d_s32, d_pcm, h->n_streams, packets_per_call, \
                        n_calls, stream_stride, call_stride, h->life.d_active)
+#define VAD_PIPE_CH(R, NB)     \
+    do {                       \
+        if (h->chn == 1)       \
+            VAD_PIPE(R, NB, 1); \
+        else                   \
+            VAD_PIPE(R, NB, 2); \
+    } while (0)
         if (ratio == 1 && nb == 80)
-            VAD_PIPE(1, 80);
+            VAD_PIPE_CH(1, 80);
         else if (ratio == 2 && nb == 80)
-            VAD_PIPE(2, 80);
+            VAD_PIPE_CH(2, 80);
+        else if (ratio == 4)
+            VAD_PIPE_CH(4, 80);
         else if (ratio == 1)
-            VAD_PIPE(1, 160);
+            VAD_PIPE_CH(1, 160);
         else
-            VAD_PIPE(2, 160);
+            VAD_PIPE_CH(2, 160);
+#undef VAD_PIPE_CH
 #undef VAD_PIPE
         WMX_LAUNCH_CHECK();
         return 0;
