@@ -13,7 +13,7 @@ OUT=$R/gpurun_out/$ROUND/$WL
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 STEPS=40
-CMD="python3 $R/bench.py --no-cpu --workload $WL --steps $STEPS --warmup 8 $*"
+CMD="python3 $R/bench.py --no-cpu --no-configs --workload $WL --steps $STEPS --warmup 8 $*"
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o p --output-format csv -- $CMD > "$OUT/bench_under_stats.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o p --output-format csv -- $CMD > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -o p --output-format csv -- $CMD > /dev/null 2>&1
@@ -23,6 +23,9 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS
   -d "$OUT/pmc_sq_insts" -o p --output-format csv -- $CMD > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES \
   -d "$OUT/pmc_sq_lds" -o p --output-format csv -- $CMD > /dev/null 2>&1
+# lane utilisation of the vector ALU (round-4 VERDICT "next" 9): thread-cycles against instruction-cycles x 64 lanes
+rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU \
+  -d "$OUT/pmc_sq_lanes" -o p --output-format csv -- $CMD > /dev/null 2>&1
 cd "$R"
 python3 profiles/tools/summarise.py "$OUT" "$NFR" $STEPS "$WL"
 # the raw traces are tens of MB per workload and gpurun brings back at most 64 MiB: keep the summaries only

@@ -40,7 +40,7 @@ tail = int(sys.argv[5]) if len(sys.argv) > 5 else min(steps, 16)
 if tag == "rtp_chain" and len(sys.argv) <= 5:
     # bench.py's rtp_chain workload runs its PCIe-streaming measurement (min(steps, 100) more steps, H2D / D2H copies beside the
     # kernels) behind the breakdown steps: those launches are not the timed region either
-    tail += min(steps, 100)
+    tail += min(steps, 300) + 4  # (four warm-up submits in front of the streamed steps)
 
 
 def timed(v):
@@ -99,6 +99,9 @@ for k, c in sq.items():
                                              if n.startswith(("SQ_WAIT", "SQ_ACTIVE")) and n != "SQ_WAVE_CYCLES"}}
     if m.get("SQ_LDS_IDX_ACTIVE"):
         sq_out[k]["lds_bank_conflict_fraction_of_lds_active"] = round(m.get("SQ_LDS_BANK_CONFLICT", 0) / m["SQ_LDS_IDX_ACTIVE"], 3)
+    if m.get("SQ_THREAD_CYCLES_VALU") and m.get("SQ_ACTIVE_INST_VALU"):
+        # lanes doing work per vector-ALU instruction-cycle: 1.0 = every issued vector instruction had all 64 lanes enabled
+        sq_out[k]["valu_lane_utilisation"] = round(m["SQ_THREAD_CYCLES_VALU"] / (m["SQ_ACTIVE_INST_VALU"] * 64.0), 4)
     if m.get("SQ_BUSY_CYCLES") and m.get("SQ_WAVE_CYCLES"):
         # mean resident waves per SIMD while the kernel ran: wave-cycles / (busy cycles x SIMDs seen by the counter)
         sq_out[k]["wave_cycles_per_busy_cycle"] = round(m["SQ_WAVE_CYCLES"] / m["SQ_BUSY_CYCLES"], 2)

@@ -1,4 +1,4 @@
-"""Evidence for DESIGN.md section 5d (round-3 VERDICT item 1c): what fused multiply-adds do to the float AEC.
+"""Evidence for DESIGN_HISTORY.md section 5d (round-3 VERDICT item 1c): what fused multiply-adds do to the float AEC.
 
 Not a test (pytest does not collect it).  north_star allows +-1 LSB for the float path and SURVEY section 0 item 8 measured
 `-mfma -ffp-contract=fast` at <= 1 LSB on ONE stream over 3 000 frames.  On the GPU the near kernel built with contraction is
@@ -71,7 +71,7 @@ def main(n_streams=64, n=3000, freq=16000):
                 first_big = p
             if p < 56:
                 max_early = max(max_early, m)
-                # the reference's first blocks produce NaNs (powf of a slightly negative suppression gain), which
+                # the reference's first blocks produce NaNs (powf of a slightly negative suppression gain, DESIGN_HISTORY section 2), which
                 # the int16 conversion turns into 0: a sample that is 0 in one build and far from 0 in the other is that
                 nan_like += int((((oa == 0) != (ob == 0)) & (d > 1)).sum())
             else:

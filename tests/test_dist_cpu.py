@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the N > 1 path of bench.py / DESIGN.md section 6 -- contiguous stream sharding plus
+"""CPU, world_size 2 over gloo: the N > 1 path of bench.py / DESIGN_HISTORY.md section 6 -- contiguous stream sharding plus
 one broadcast of the shared far-end packet per step -- gives every stream exactly the output of the unsharded
 run.  The per-stream compute here is the oracle chain (no GPU in this container); on the GPU box the same
 plumbing drives the HIP kernels."""

@@ -1,4 +1,4 @@
-"""Bank model behind DESIGN.md section 5d (a): LDS cycles of the access families of aec_near_kernel's work rows that conflict.
+"""Bank model behind DESIGN_HISTORY.md section 5d (a): LDS cycles of the access families of aec_near_kernel's work rows that conflict.
 
 A 16-lane group (lanes with the same lane % 4: g = lane & 3, gl = lane >> 2) owns one transform in row g (or 4 + g) of the wave's
 eight work rows; a row holds 64 complex points (two floats each).  Per 64-sample block the kernel issues, on those rows,

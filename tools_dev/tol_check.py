@@ -1,7 +1,7 @@
 """developer check of a TOLERANCE build of the float AEC (WMIX_AMD_LIB=<variant>): the 3 000-frame parity gate's streams
 (tests/test_aec_gpu.py::test_chain_parity_gate_3000_frames) through the whole chain on the GPU against the oracle chain; prints the
 largest difference inside the first 56 packets (the start-up pass-through and the blocks behind it, where the REFERENCE itself emits
-NaN-derived zeros) and from packet 56 on, per rate.  Run on the GPU box: python tools_dev/tol_check.py [n_streams]"""
+NaN-derived zeros, DESIGN_HISTORY section 2) and from packet 56 on, per rate.  Run on the GPU box: python tools_dev/tol_check.py [n_streams]"""
 import json
 import os
 import sys

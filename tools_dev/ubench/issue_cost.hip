@@ -1,6 +1,6 @@
 // issue_cost.hip -- what one wave64 instruction of each CLASS costs its SIMD on gfx950, measured.
 //
-// The per-stream DSP kernels of this library are bound by vector-instruction issue, not by HBM.  Round 2
+// The per-stream DSP kernels of this library are bound by vector-instruction issue, not by HBM (DESIGN_HISTORY.md section 5).  Round 2
 // priced every VALU instruction at 4 cycles and called the product a floor; the guide (MI355X_MICROARCH.md, "Per-instruction
 // cycle constants") says a wave64 v_fma_f32 occupies a SIMD-32 for 2 cycles when another wave can issue beside it and 4 when a
 // wave is alone, and that packed / DPP / transcendental / fp64 forms cost more.  This program measures those prices in the

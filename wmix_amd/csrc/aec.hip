@@ -24,7 +24,7 @@
 //                    The transforms run in registers (fft_regs.h): the 24 constraint FFTs of the filter update as
 //                    16-lane groups (partitions 0-7 as packed pairs, then 8-11), the two single inverse transforms
 //                    of a block with one point per lane, the two forward pairs in two 16-lane groups.
-//                    A wave spends more of its life waiting for data than issuing, so every
+//                    A wave spends more of its life waiting for data than issuing (DESIGN_HISTORY.md section 5), so every
 //                    global request of a phase goes out in one batch, a phase early where registers allow, and
 //                    wave-uniform far-end data takes the scalar path.
 // Float expressions, their order and the ordered sums follow the reference exactly (-ffp-contract=off); powf is the
@@ -306,7 +306,7 @@ __device__ unsigned long long g_aec_prof[16];
     } while (0)
 #define AEC_PROF_START long long t_prev = clock64()
 #elif defined(WMX_AEC_EXP_BARRIERS)
-// timing-only experiment (round-4): what the hand-offs of a helper-wave design would cost -- a workgroup barrier at
+// timing-only experiment (round-4, DESIGN_HISTORY section 5d): what the hand-offs of a helper-wave design would cost -- a workgroup barrier at
 // every phase boundary of a block (ten per block), valid only while the four streams of a workgroup run the same plan
 #define AEC_PROF(i) __builtin_amdgcn_s_barrier()
 #define AEC_PROF_START
@@ -371,7 +371,7 @@ __device__ __forceinline__ float row_ld(GlobalRow row, unsigned lane_bytes, int 
 // history an immediate of the load: global_load_dword v, v_off, s[hist] offset:imm.  No address instruction per row, on
 // either unit: formed on the scalar unit a row cost 12 scalar instructions (index modulo the ring, times the row size, a 64-bit
 // add) in one dependent chain -- 48 rows per block -- and a wave issues one instruction of any kind per ~5 cycles at best,
-// with four waves per SIMD to cover for it (0.749 -> 0.724 ms).
+// with four waves per SIMD to cover for it (DESIGN_HISTORY.md section 5c; 0.749 -> 0.724 ms).
 constexpr int kHistRowBytes = 130 * 4, kHistMid = 2860;  // |kHistMid - 520 p + 4 word| < 4096 for p < 12, word < 130
 struct HistRows {
     GlobalRow base;

@@ -378,7 +378,7 @@ __global__ __launch_bounds__(64) void agc_kernel(int16_t *s16, int32_t *s32, con
 
 // ================================================================== the mono packet as a four-wave pipeline
 // agc_kernel runs a stream in one lane from end to end: 65 536 streams are 1 024 waves, one per SIMD, and the launch lasts as
-// long as one wave's chain of ~3 900 instructions issued one every ~5 cycles at best (a wave alone on its SIMD).  Here a workgroup still owns 64 streams
+// long as one wave's chain of ~3 900 instructions issued one every ~5 cycles at best (a wave alone on its SIMD, DESIGN_HISTORY.md section 5c).  Here a workgroup still owns 64 streams
 // (lane = stream), but as four waves: waves 0..2 share the packet's ten 1 ms sub-frames ({0..3}, {4..6}, {7..9}), load them
 // once (two 16-byte loads per sub-frame at 16 kHz), take their peak energies and hand the level detector's input (pair
 // averages at 16 kHz) over through LDS; wave 3, which holds no samples, runs the serial part -- the detector's decimator,
