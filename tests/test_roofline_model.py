@@ -22,7 +22,7 @@ def _bench():
 def test_issue_accounting_from_committed_profiles(tag, kernel, n_frames):
     b = _bench()
     r = b._pmc_issue(kernel, n_frames, tag, 1.0)
-    assert r is not None and r["source"].startswith("profiles/r0")
+    assert r is not None and r["source"].startswith("profiles/r")
     rnd = r["source"].split("/")[1]  # the newest round that profiled this workload at this size
     line = json.load(open(os.path.join(ROOT, "profiles", rnd, tag + "_bench_line_under_rocprof.json")))
     launch_ms = line["roofline"]["avg_launch_ms"]
