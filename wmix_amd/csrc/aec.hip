@@ -176,81 +176,76 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const flo
     // [packet][class]: cohorts whose control planes run in lockstep (same start, same calls) share one plan -- the indices are
     // positions inside the cohort's OWN far-end slab, equal for all of them (wmx_aec_run_cohorts)
     plans += plan_of ? plan_of[blockIdx.x] : (int)blockIdx.x;
+    // One wave, one latency chain: the kernel is as long as its dependent round trips to memory (it used to make about a hundred:
+    // 45 us for ONE far-end, 0.15 ms for the 4 096 of a conference server's tick).  So: (1) the tables, the time-domain pre-buffer
+    // ring (448 floats) and the running far power are requested together at entry and live in LDS / registers for the launch -- the
+    // windows of a packet's partitions are cut out of the LDS copy, the ring in memory is only written; (2) the spectra of the far
+    // blocks a packet CONSUMES are requested at the top of the packet, before the transforms of the blocks it PRODUCES -- they are
+    // old slots of the 250-slot ring as a rule (the canceller runs behind the far-end by the system delay); when a consumed slot
+    // is one this packet writes, the copy kept in LDS replaces what was fetched.
+    __shared__ float lpre[kAecPreLen];
+    __shared__ float spec[4][2][132];  // ring rows (re[65] | im[65]) of this packet's partitions: plain, windowed
+    float xp0, xp1;
     {
-        // one wave, one latency chain: every request of a group goes out before the first result is used
         float *dst = reinterpret_cast<float *>(&K);
-        constexpr int NIT = (kAecConstWords + 63) / 64;
-        float c[NIT];
+        constexpr int NIT = (kAecConstWords + 63) / 64, NP = kAecPreLen / 64;
+        static_assert(kAecPreLen % 64 == 0, "whole rows of the pre-buffer per lane");
+        float c[NIT], pr[NP];
 #pragma unroll
         for (int k = 0; k < NIT; k++) c[k] = consts_g[lane + 64 * k < kAecConstWords ? lane + 64 * k : 0];
 #pragma unroll
+        for (int k = 0; k < NP; k++) pr[k] = F.pre[lane + 64 * k];
+        xp0 = F.xpow[lane];
+        xp1 = F.xpow[lane == 0 ? kAecPart : 0];
+#pragma unroll
         for (int k = 0; k < NIT; k++)
             if (lane + 64 * k < kAecConstWords) dst[lane + 64 * k] = c[k];
+#pragma unroll
+        for (int k = 0; k < NP; k++) lpre[lane + 64 * k] = pr[k];
     }
     wave_sync();
+    bool xpow_dirty = false;
+    // (3) the packet's plan is fetched ONCE, 56 words by 56 lanes, into LDS: read field by field from memory every access was a
+    // vector load with a full wait behind it -- most of the kernel's round trips
+    __shared__ int lplan[sizeof(AecPlan) / 4];
     for (int p = 0; p < n_packets; p++) {
-        const AecPlan &pl = plans[(size_t)p * n_classes];
-        if (pl.has_far) {
-            // WebRtc_WriteBuffer(far_pre_buf, farend): channel 0 of the far-end packet (src/webrtc.c:430)
-            const int16_t *src = far_pcm + (size_t)p * far_packet_stride;
-            {
-                // at most 160 samples (20 ms at 8 kHz): three per lane, fetched together (clamped index, guarded store)
-                int16_t s3[3];
-#pragma unroll
-                for (int j = 0; j < 3; j++) s3[j] = src[(lane + 64 * j < pl.far_n ? lane + 64 * j : 0) * chn];
-#pragma unroll
-                for (int j = 0; j < 3; j++)
-                    if (lane + 64 * j < pl.far_n) F.pre[(pl.pre_wr + lane + 64 * j) % kAecPreLen] = (float)s3[j];
-            }
+        {
+            const int *src = reinterpret_cast<const int *>(&plans[(size_t)p * n_classes]);
+            constexpr int NW = (int)(sizeof(AecPlan) / 4);
+            static_assert(NW <= 64, "one word of the plan per lane");
+            wave_sync();  // the previous packet's reads of lplan are done
+            if (lane < NW) lplan[lane] = src[lane];
             wave_sync();
-            // the [prev64 | new64] windows of all partitions of this packet (at most 4), requested together
-            float win[4][2];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                if (q >= pl.n_part) break;
-#pragma unroll
-                for (int h = 0; h < 2; h++) win[q][h] = F.pre[(pl.part[q].pre_rd + lane + 64 * h) % kAecPreLen];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                if (q >= pl.n_part) break;
-                // BufferFarendPartition (aec_core.c:1690-1707): plain and windowed transform of [prev64 | new64]
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const int i = lane + 64 * h;
-                    const float v = win[q][h];
-                    fa[0][i] = v;
-                    fa[1][i] = v * (h == 0 ? K.hanning[lane] : K.hanning[kAecPart - lane]);
-                }
-                wave_sync();
-                rdft_forward<64>(fa[0], &K.tab, lane);
-                rdft_forward<64>(fa[1], &K.tab, lane);
-                float *dst = F.ring + (size_t)pl.part[q].far_slot * 130;
-                float *dstw = F.ring_w + (size_t)pl.part[q].far_slot * 130;
-                for (int b = lane; b < kAecPart1; b += 64) {
-                    float re, im;
-                    unpack_bin(fa[0], b, re, im);
-                    dst[b] = re;
-                    dst[kAecPart1 + b] = im;
-                    unpack_bin(fa[1], b, re, im);
-                    dstw[b] = re;
-                    dstw[kAecPart1 + b] = im;
-                }
-                wave_sync();
-            }
         }
-        if (pl.has_near && !pl.passthrough) {
-            // far blocks consumed by the ProcessBlock calls of this packet: history entries + xPow
-            // (aec_core.c:1209-1216).  The spectra of all blocks (at most 4) are requested together; xPow is a
-            // recurrence over the blocks and stays in registers between them.
-            float sp[4][3], spw[4][3];  // row elements lane, lane + 64, lane + 128 (the last for lanes 0, 1): the copy
-            float xi_b[4], xr64[4], xi64[4];  // imaginary part of bin `lane`; bin 64 (every lane reads the same two words)
-            float xp0 = F.xpow[lane], xp1 = F.xpow[lane == 0 ? kAecPart : 0];
+        // ... and its fields become scalars again (an LDS read is per lane as far as the compiler knows): uniform branches, SGPR bases
+        const AecPlan &lp = *reinterpret_cast<const AecPlan *>(lplan);
+        auto rf = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+        struct {
+            int has_far, far_n, pre_wr, n_part, n_blk;
+            int pre_rd[4], pslot[4], bslot[4], hist_n[4];
+        } pl;
+        pl.has_far = rf(lp.has_far);
+        pl.far_n = rf(lp.far_n);
+        pl.pre_wr = rf(lp.pre_wr);
+        pl.n_part = rf(lp.n_part);
+        pl.n_blk = rf(lp.n_blk);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            pl.pre_rd[q] = rf(lp.part[q].pre_rd);
+            pl.pslot[q] = rf(lp.part[q].far_slot);
+            pl.bslot[q] = rf(lp.blk[q].far_slot);
+            pl.hist_n[q] = rf(lp.blk[q].hist_n);
+        }
+        const bool consume = rf(lp.has_near) && !rf(lp.passthrough);
+        // far blocks consumed by the ProcessBlock calls of this packet (at most 4), requested first
+        float sp[4][3], spw[4][3];  // row elements lane, lane + 64, lane + 128 (the last for lanes 0, 1): the copy
+        float xi_b[4], xr64[4], xi64[4];  // imaginary part of bin `lane`; bin 64 (every lane reads the same two words)
+        if (consume) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (k >= pl.n_blk) break;
-                const float *src = F.ring + (size_t)pl.blk[k].far_slot * 130;
-                const float *srcw = F.ring_w + (size_t)pl.blk[k].far_slot * 130;
+                const float *src = F.ring + (size_t)pl.bslot[k] * 130;
+                const float *srcw = F.ring_w + (size_t)pl.bslot[k] * 130;
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
                     const int i = lane + 64 * j < 130 ? lane + 64 * j : 0;
@@ -261,10 +256,79 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const flo
                 xr64[k] = src[kAecPart];
                 xi64[k] = src[kAecPart1 + kAecPart];
             }
+        }
+        if (pl.has_far) {
+            // WebRtc_WriteBuffer(far_pre_buf, farend): channel 0 of the far-end packet (src/webrtc.c:430) -- into the LDS copy of the
+            // ring and into the ring itself (for the launches to come)
+            const int16_t *src = far_pcm + (size_t)p * far_packet_stride;
+            {
+                // at most 160 samples (20 ms at 8 kHz): three per lane, fetched together (clamped index, guarded store)
+                int16_t s3[3];
+#pragma unroll
+                for (int j = 0; j < 3; j++) s3[j] = src[(lane + 64 * j < pl.far_n ? lane + 64 * j : 0) * chn];
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                    if (lane + 64 * j < pl.far_n) {
+                        const int at = (pl.pre_wr + lane + 64 * j) % kAecPreLen;
+                        lpre[at] = (float)s3[j];
+                        F.pre[at] = (float)s3[j];
+                    }
+            }
+            wave_sync();
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (q >= pl.n_part) break;
+                // BufferFarendPartition (aec_core.c:1690-1707): plain and windowed transform of [prev64 | new64]
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int i = lane + 64 * h;
+                    const float v = lpre[(pl.pre_rd[q] + i) % kAecPreLen];
+                    fa[0][i] = v;
+                    fa[1][i] = v * (h == 0 ? K.hanning[lane] : K.hanning[kAecPart - lane]);
+                }
+                wave_sync();
+                rdft_forward<64>(fa[0], &K.tab, lane);
+                rdft_forward<64>(fa[1], &K.tab, lane);
+                float *dst = F.ring + (size_t)pl.pslot[q] * 130;
+                float *dstw = F.ring_w + (size_t)pl.pslot[q] * 130;
+                for (int b = lane; b < kAecPart1; b += 64) {
+                    float re, im;
+                    unpack_bin(fa[0], b, re, im);
+                    dst[b] = re;
+                    dst[kAecPart1 + b] = im;
+                    spec[q][0][b] = re;
+                    spec[q][0][kAecPart1 + b] = im;
+                    unpack_bin(fa[1], b, re, im);
+                    dstw[b] = re;
+                    dstw[kAecPart1 + b] = im;
+                    spec[q][1][b] = re;
+                    spec[q][1][kAecPart1 + b] = im;
+                }
+                wave_sync();
+            }
+        }
+        if (consume) {
+            // history entries + xPow (aec_core.c:1209-1216); xPow is a recurrence over the blocks and stays in registers
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (k >= pl.n_blk) break;
-                const int hs = pl.blk[k].hist_n % kAecHist;
+                if (pl.has_far) {  // a block produced by this very packet: what was fetched above is older than the slot's new content
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        if (q >= pl.n_part) break;
+                        if (pl.pslot[q] != pl.bslot[k]) continue;
+#pragma unroll
+                        for (int j = 0; j < 3; j++) {
+                            const int i = lane + 64 * j < 130 ? lane + 64 * j : 0;
+                            sp[k][j] = spec[q][0][i];
+                            spw[k][j] = spec[q][1][i];
+                        }
+                        xi_b[k] = spec[q][0][kAecPart1 + lane];
+                        xr64[k] = spec[q][0][kAecPart];
+                        xi64[k] = spec[q][0][kAecPart1 + kAecPart];
+                    }
+                }
+                const int hs = pl.hist_n[k] % kAecHist;
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
                     const int i = lane + 64 * j;
@@ -286,11 +350,14 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const flo
                     xp1 = 0.9f * xp1 + gpow1np * far_spectrum;  // every lane, same value
                     if (lane == 0) F.xpow_seq[hs * BP + kAecPart] = xp1;
                 }
+                xpow_dirty = true;
             }
-            F.xpow[lane] = xp0;
-            if (lane == 0) F.xpow[kAecPart] = xp1;
             wave_sync();
         }
+    }
+    if (xpow_dirty) {
+        F.xpow[lane] = xp0;
+        if (lane == 0) F.xpow[kAecPart] = xp1;
     }
 }
 
