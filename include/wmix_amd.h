@@ -515,6 +515,9 @@ typedef struct wmx_tick wmx_tick;
 int wmx_tick_create(wmx_tick **out, int n_groups, int rec_per_group, int chn, int freq, int interval_ms, int aec_delay_ms, int agc_value,
                     unsigned stages);
 int wmx_tick_destroy(wmx_tick *h);
+/* webrtcEnable[WR_NS_PA] (src/wmix.c:1370-1386): on = 1 puts ns_process over the played package, in front of playPkgBuff_add (ns_init of
+ * one suppressor per group now); on = 0 releases it */
+int wmx_tick_play_ns(wmx_tick *h, int on);
 int wmx_tick_package_samples(const wmx_tick *h); /* int16 elements of one package of one stream = WMIX_PKG_SIZE / 2 */
 int wmx_tick_load(wmx_tick *h, const int16_t *d_src, uint32_t srcU8Len, int freq, int channels, int sample, int n_src, long group_stride,
                   long source_stride, int reduce, uint32_t *head, uint32_t *tick, void *stream);

@@ -402,6 +402,11 @@ def tick_port(lib, sources, local, src_freq, src_chn, stages=15, agc_value=5, ae
     heads, ticks = [0xFFFFFFFF] * n_src, [C.c_uint32(0) for _ in range(n_src)]
     pad = np.zeros(per + 8, np.int16)
     play, far = np.zeros((T, N), np.int16), np.zeros((T, N), np.int16)
+    ns_pa = None
+    if stages & 16:  # webrtcEnable[WR_NS_PA]: ONE suppressor handle over the played packages, call by call (the FIFO sees its output)
+        ns_pa = _fn(lib, "orc_ns_init", C.c_void_p, [C.c_int, C.c_int])(1, 8000)
+        ns_run = _fn(lib, "orc_ns_run", None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int])
+        assert ns_pa
     for t in range(T):
         for i in range(n_src):
             pad[:per] = sources[t, i]
@@ -412,13 +417,17 @@ def tick_port(lib, sources, local, src_freq, src_chn, stages=15, agc_value=5, ae
         ring[pos] = 0
         r.head_off = (r.head_off + 2 * N) % size
         r.tick += 2 * N
+        if ns_pa:
+            ns_run(ns_pa, play[t].ctypes.data, play[t].ctypes.data, N)
         lib.orc_pkgfifo_add(C.byref(f), play[t].ctypes.data_as(C.c_void_p))
         assert lib.orc_pkgfifo_get(C.byref(f), far[t].ctypes.data_as(C.c_void_p), aec_delay_ms) == 0
+    if ns_pa:
+        _fn(lib, "orc_ns_release", None, [C.c_void_p])(ns_pa)
     zero = np.zeros(N, np.int16)
     near = np.stack([tick_room(local[t], far[t], far[t - 1] if t else zero) for t in range(T)])  # [T, n_rec, N]
     out = np.zeros_like(near)
     for k in range(n_rec):
-        out[:, k] = run_chain(lib, 1, 8000, agc_value, stages, far.reshape(-1), near[:, k].reshape(-1), N, prefix="orc",
+        out[:, k] = run_chain(lib, 1, 8000, agc_value, stages & 15, far.reshape(-1), near[:, k].reshape(-1), N, prefix="orc",
                               interval_ms=20).reshape(T, N)
     zoom = np.stack([np.stack([mix_zoom(lib, 1, 8000, out[t, k], 1, 8000) for k in range(n_rec)]) for t in range(T)])
     return {"play": play, "far": far, "near": near, "out": out, "zoom": zoom}

@@ -33,7 +33,7 @@
  *        and tick move on, wrap -- :1347-1366), playPkgBuff_add, playPkgBuff_get(AEC_INTERVALMS) = the far-end, the room (near =
  *        sat(local + far delayed by 40 samples >> 1): the harness' own input model), then per record handle set ns_process ->
  *        aec_process2(far, near, near, .., 0) -> agc_process -> vad_process (:613-709, `stages` bits 1 2 4 8 = the webrtcEnable
- *        switches) and wmix_pcm_zoom to 1 x 8000 (:730).  Written per tick: played package, far-end package, then per record handle set
+ *        switches; bit 16 = WR_NS_PA: ns_process over the played package in front of playPkgBuff_add, :1370-1386) and wmix_pcm_zoom to 1 x 8000 (:730).  Written per tick: played package, far-end package, then per record handle set
  *        its chain output and the zoomed copy (2 * 8000 * WMIX_INTERVAL_MS / 1000 bytes).
  *   ref_mix_driver rtprecv <packets.bin >pcm.bin
  *        every [uint32 len][bytes] record is sent to a socket opened with rtp_socket(bind) and taken through
@@ -178,6 +178,8 @@ int main(int argc, char **argv)
         w->reduceMode = 1;
         WMix_Point *heads = calloc(nsrc, sizeof(WMix_Point));
         uint32_t *ticks = calloc(nsrc, sizeof(uint32_t));
+        void *ns_pa = (stages & 16) ? ns_init(WMIX_CHN, WMIX_FREQ, NULL) : NULL; /* webrtcEnable[WR_NS_PA], src/wmix.c:1370-1386 */
+        if ((stages & 16) && !ns_pa) return 8;
         void **ns = calloc(nrec, sizeof(void *)), **aec = calloc(nrec, sizeof(void *)), **agc = calloc(nrec, sizeof(void *)),
              **vad = calloc(nrec, sizeof(void *));
         for (int r = 0; r < nrec; r++) {
@@ -216,6 +218,7 @@ int main(int argc, char **argv)
 #endif
                 if (w->head.U8 >= w->end.U8) w->head.U8 = w->start.U8;
             }
+            if (ns_pa) ns_process(ns_pa, (int16_t *)playBuff, (int16_t *)playBuff, WMIX_FRAME_NUM);
             playPkgBuff_add(playBuff);
             fwrite(playBuff, 1, WMIX_PKG_SIZE, stdout);
             playPkgBuff_get(farBuff, AEC_INTERVALMS);

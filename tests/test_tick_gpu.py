@@ -30,8 +30,10 @@ def gpu_tick(cuda, src, local, src_freq, src_chn, stages, agc_value=5):
     from wmix_amd.tick import TickBatch
     G, T, n_src, per = src.shape
     R = local.shape[2]
-    tb = TickBatch(G, R, stages=stages, agc_value=agc_value)
+    tb = TickBatch(G, R, stages=stages & ~64, agc_value=agc_value)
     assert tb.pkg == 160
+    if stages & 64:  # (bit 64 in these tests: webrtcEnable[WR_NS_PA], the playback's own noise suppressor)
+        tb.play_ns(True)
     dsrc = torch.zeros((T, G, n_src, per + 2 * src_chn), dtype=torch.int16, device=cuda)  # + the up-sampling fill's look-ahead frame
     dsrc[..., :per] = torch.from_numpy(np.ascontiguousarray(src.transpose(1, 0, 2, 3))).to(cuda)
     dloc = torch.from_numpy(np.ascontiguousarray(local.transpose(1, 0, 2, 3)).reshape(T, G * R, 160)).to(cuda)
@@ -56,6 +58,7 @@ def gpu_tick(cuda, src, local, src_freq, src_chn, stages, agc_value=5):
     (32000, 2, 8, 2, 15, 170),       # configs[4]'s sources, 8 per group, two record streams per group, the whole heartbeat
     (8000, 1, 3, 1, 15, 120),        # the shipped format on both sides
     (16000, 1, 2, 1, 15 | 16 | 32, 140),  # the fixed-point chain (NSX + AECM): integer end to end
+    (32000, 2, 4, 1, 15 | 64, 130),      # WR_NS_PA on: ns_process over the played package in front of playPkgBuff_add
 ])
 def test_tick_vs_one_daemon_per_group(cuda, oracle_port, src_freq, src_chn, n_src, R, stages, T):
     G = 5
@@ -66,6 +69,7 @@ def test_tick_vs_one_daemon_per_group(cuda, oracle_port, src_freq, src_chn, n_sr
     src[2] = 0          # a group nobody plays into: far-end silence, the cancellers pass the talkers through
     got = gpu_tick(cuda, src, local, src_freq, src_chn, stages)
     fx = bool(stages & 48)
+    orc_stages = (stages & 15) | (16 if stages & 64 else 0)  # the oracle compositions spell WR_NS_PA as bit 16
     for g in range(G):
         if fx:  # NSX -> AECM -> AGC -> VAD through the restatement's own whole-run drivers, on the far / near of tick_port
             base = L.tick_port(oracle_port, src[g], local[g], src_freq, src_chn, stages=0)
@@ -78,17 +82,22 @@ def test_tick_vs_one_daemon_per_group(cuda, oracle_port, src_freq, src_chn, n_sr
                 o[:, k] = L.run_vad(oracle_port, 1, 8000, 20, x, 160, prefix="orc").reshape(T, 160)
             want["out"] = want["zoom"] = o
         else:
-            want = L.tick_port(oracle_port, src[g], local[g], src_freq, src_chn, stages=stages)
-        assert np.array_equal(got["play"][g], want["play"]), ("play", g)
-        assert np.array_equal(got["far"][g], want["far"]), ("far", g)
+            want = L.tick_port(oracle_port, src[g], local[g], src_freq, src_chn, stages=orc_stages)
+        if stages & 64:  # the played package is a float NS output now
+            check_float_path(got["play"][g].reshape(-1), want["play"].reshape(-1))
+            check_float_path(got["far"][g].reshape(-1), want["far"].reshape(-1))
+        else:
+            assert np.array_equal(got["play"][g], want["play"]), ("play", g)
+            assert np.array_equal(got["far"][g], want["far"]), ("far", g)
         if fx:
             assert np.array_equal(got["out"][g], want["out"]), ("out", g)
         else:
             check_float_path(got["out"][g].reshape(-1), want["out"].reshape(-1))
         assert np.array_equal(got["zoom"][g], got["out"][g])  # 1 x 8000 -> 1 x 8000: wmix_pcm_zoom copies
         if L.have_ref_mix() and not fx and g in (0, 3):
-            real = L.tick_ref(src[g], local[g], src_freq, src_chn, stages=stages)
-            assert np.array_equal(got["play"][g], real["play"]) and np.array_equal(got["far"][g], real["far"])
+            real = L.tick_ref(src[g], local[g], src_freq, src_chn, stages=orc_stages)
+            check_float_path(got["play"][g].reshape(-1), real["play"].reshape(-1))
+            check_float_path(got["far"][g].reshape(-1), real["far"].reshape(-1))
             check_float_path(got["out"][g].reshape(-1), real["out"].reshape(-1))
     assert not got["play"][2].any() and got["play"][0].any()
 

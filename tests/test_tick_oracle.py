@@ -23,6 +23,7 @@ def tick_inputs(seed, T, n_src, n_rec, src_freq, src_chn, loud=8000):
     (16000, 1, 2, 1, 15, 100),
     (44100, 2, 2, 1, 2, 80),     # a rate that does not divide: AEC alone
     (8000, 1, 8, 1, 1 | 2, 100),  # eight loud sources: the saturating accumulate is order dependent
+    (16000, 2, 3, 2, 15 | 16, 130),  # WR_NS_PA: the playback goes through ns_process in front of the FIFO (src/wmix.c:1370-1386)
 ])
 def test_port_tick_equals_the_real_functions(oracle_port, src_freq, src_chn, n_src, n_rec, stages, T):
     src, local = tick_inputs(7 + n_src, T, n_src, n_rec, src_freq, src_chn, loud=14000 if n_src == 8 else 8000)
@@ -37,5 +38,8 @@ def test_port_tick_equals_the_real_functions(oracle_port, src_freq, src_chn, n_s
         assert any(np.array_equal(a["far"][t], a["play"][u]) for u in range(max(0, t - 22), t + 1)) or not a["far"][t].any(), t
     # ... the playback starts VIEW_PLAY_CORRECT = 200 ms after the first load, and the canceller had something to cancel
     assert not a["play"][:10].any() and a["play"][10:].any()
+    if stages & 16:  # the suppressor changed what was played (and so what the cancellers heard)
+        plain = L.tick_port(oracle_port, src, local, src_freq, src_chn, stages=stages & 15)
+        assert not np.array_equal(plain["play"], a["play"]) and not np.array_equal(plain["out"], a["out"])
     if stages & 2:
         assert np.abs(a["out"][60:].astype(np.int32)).mean() < np.abs(a["near"][60:].astype(np.int32)).mean()

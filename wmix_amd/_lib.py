@@ -149,6 +149,8 @@ def _declare(L):
     L.wmx_tick_create.argtypes = [C.POINTER(vp), i, i, i, i, i, i, i, C.c_uint]
     L.wmx_tick_destroy.restype = i
     L.wmx_tick_destroy.argtypes = [vp]
+    L.wmx_tick_play_ns.restype = i
+    L.wmx_tick_play_ns.argtypes = [vp, i]
     L.wmx_tick_package_samples.restype = i
     L.wmx_tick_package_samples.argtypes = [vp]
     L.wmx_tick_load.restype = i

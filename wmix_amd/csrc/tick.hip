@@ -26,6 +26,7 @@ struct wmx_tick {
     wmx_mix *mix;
     wmx_pkgfifo *fifo;
     wmx_chain *chain;
+    wmx_ns *play_ns;  // WR_NS_PA: the playback's own noise suppressor (src/wmix.c:1370-1386), one stream per group; NULL = switched off
     int16_t *d_play;  // [n_groups][pkg] when the caller does not want the playback
     int16_t *d_far;   // [n_groups][pkg] playPkgBuff_get()'s packet of every group
 };
@@ -38,6 +39,7 @@ int wmx_tick_destroy(wmx_tick *h) {
     if (h->mix) wmx_mix_destroy(h->mix);
     if (h->fifo) wmx_pkgfifo_destroy(h->fifo);
     if (h->chain) wmx_chain_destroy(h->chain);
+    if (h->play_ns) wmx_ns_destroy(h->play_ns);
     if (h->d_play) (void)hipFree(h->d_play);
     if (h->d_far) (void)hipFree(h->d_far);
     delete h;
@@ -91,6 +93,24 @@ int wmx_tick_create(wmx_tick **out, int n_groups, int rec_per_group, int chn, in
     return 0;
 }
 
+// webrtcEnable[WR_NS_PA] (src/wmix.c:1370-1386): the played package goes through ns_process on its way out -- BEFORE playPkgBuff_add,
+// so the echo cancellers hear the suppressed playback too.  on = 1: ns_init of one suppressor per group (the switch coming on);
+// on = 0: ns_release.
+int wmx_tick_play_ns(wmx_tick *h, int on) {
+    WMX_ON_DEVICE(h);
+    if (!h) return WMX_EINVAL;
+    if (!on) {
+        if (h->play_ns) {
+            WMX_HIP(hipDeviceSynchronize());
+            wmx_ns_destroy(h->play_ns);
+            h->play_ns = nullptr;
+        }
+        return 0;
+    }
+    if (h->play_ns) return 0;
+    return wmx_ns_create(&h->play_ns, h->n_groups, h->chn, h->freq);
+}
+
 wmx_mix *wmx_tick_mix(wmx_tick *h) { return h ? h->mix : nullptr; }
 wmx_chain *wmx_tick_chain(wmx_tick *h) { return h ? h->chain : nullptr; }
 wmx_pkgfifo *wmx_tick_fifo(wmx_tick *h) { return h ? h->fifo : nullptr; }
@@ -117,6 +137,10 @@ int wmx_tick_play(wmx_tick *h, int16_t *d_play, long play_stride, void *stream) 
     const long pstride = d_play ? play_stride : (long)h->pkg;
     const uint32_t pkg_bytes = (uint32_t)h->pkg * 2;
     int rc = wmx_mix_drain(h->mix, play, pkg_bytes, pstride, stream);
+    if (rc == 0 && h->play_ns) {
+        const int pkg10 = h->freq / 100 * h->chn;
+        rc = wmx_ns_process(h->play_ns, play, play, h->interval_ms / 10, pstride, pkg10, stream);
+    }
     if (rc == 0) rc = wmx_pkgfifo_add(h->fifo, reinterpret_cast<const uint8_t *>(play), pstride * 2, stream);
     if (rc == 0) rc = wmx_pkgfifo_get(h->fifo, reinterpret_cast<uint8_t *>(h->d_far), (long)pkg_bytes, h->aec_delay_ms, stream);
     return rc;

@@ -34,6 +34,10 @@ class TickBatch:
                                   C.byref(h), C.byref(t), torch.cuda.current_stream().cuda_stream), "wmx_tick_load")
         self.head, self.tick = h.value, t.value
 
+    def play_ns(self, on=True):
+        """webrtcEnable[WR_NS_PA]: ns_process over the played package in front of playPkgBuff_add (src/wmix.c:1370-1386)."""
+        check(lib().wmx_tick_play_ns(self._h, 1 if on else 0), "wmx_tick_play_ns")
+
     def play(self, play=None):
         """The play side of one package; returns the groups' far-end packages (a VIEW of the handle's own [n_groups, pkg] rows:
         valid until the next play)."""
