@@ -189,6 +189,131 @@ static int drive_pair_aecm(int freq, int pkg, int lag, int delay0) {
     return met;
 }
 
+
+// ---- control-plane classes against a model that keeps one plane per cohort (aec.hip runs ONE plane per class and hands every member
+//      its plan): random histories -- cohorts added, retired, restarted, imported over, switched off for a while, reporting delays of
+//      their own for a while -- and after every launch the plan a member gets through its class must be the plan its own plane makes.
+struct ClsHost {
+    std::vector<AecCtl> ctl;
+    std::vector<int32_t> lead;
+    std::vector<uint8_t> live;
+    int n_far = 0;
+    bool cls_dirty = false;
+};
+static void drive_classes(int freq, int pkg, uint32_t seed, int n_start, int ticks) {
+    rng_state = seed;
+    ClsHost h;
+    std::vector<AecCtl> model;  // the reference's way: every cohort (handle) its own plane
+    auto add = [&](bool fresh_class) {
+        int id = -1;
+        for (int g = 0; g < h.n_far; g++)
+            if (!h.live[(size_t)g]) {
+                id = g;
+                break;
+            }
+        if (id < 0) {
+            id = h.n_far++;
+            h.ctl.emplace_back();
+            h.lead.push_back(id);
+            h.live.push_back(1);
+            model.emplace_back();
+        }
+        h.live[(size_t)id] = 1;
+        aec_ctl_own(&h, id);  // wmx_aec_reset_cohort
+        h.ctl[(size_t)id].init(freq);
+        if (!fresh_class) aec_ctl_join(&h, id);
+        model[(size_t)id].init(freq);
+        return id;
+    };
+    // wmx_aec_create_groups: made together, one class
+    h.n_far = n_start;
+    h.ctl.resize((size_t)n_start);
+    model.resize((size_t)n_start);
+    for (int g = 0; g < n_start; g++) {
+        h.ctl[(size_t)g].init(freq);
+        model[(size_t)g].init(freq);
+    }
+    h.lead.assign((size_t)n_start, 0);
+    h.live.assign((size_t)n_start, 1);
+    std::vector<int32_t> delay, leaders, plan_of;
+    std::vector<uint8_t> on;
+    std::vector<int> odd_until((size_t)n_start, 0), off_until((size_t)n_start, 0);
+    long shared = 0, launches = 0;
+    for (int t = 0; t < ticks; t++) {
+        // churn between launches
+        const uint32_t r = rnd() % 400;  // something happens every fifth tick or so: classes have time to exist
+        if (r < 4 && h.n_far < 48) {
+            add(false);
+            odd_until.resize((size_t)h.n_far, 0);
+            off_until.resize((size_t)h.n_far, 0);
+        } else if (r < 7) {  // retire one
+            const int g = (int)(rnd() % (uint32_t)h.n_far);
+            if (h.live[(size_t)g] && g != 0) {
+                aec_ctl_own(&h, g);
+                h.live[(size_t)g] = 0;
+            }
+        } else if (r < 10) {  // restart one (aec_release + aec_init of every member)
+            const int g = (int)(rnd() % (uint32_t)h.n_far);
+            if (h.live[(size_t)g]) {
+                aec_ctl_own(&h, g);
+                h.ctl[(size_t)g].init(freq);
+                aec_ctl_join(&h, g);
+                model[(size_t)g].init(freq);
+            }
+        } else if (r < 12) {  // import a cohort's plane over another (wmx_aec_import_cohort)
+            const int a = (int)(rnd() % (uint32_t)h.n_far), b = (int)(rnd() % (uint32_t)h.n_far);
+            if (a != b && h.live[(size_t)a] && h.live[(size_t)b]) {
+                const AecCtl blob = aec_ctl(&h, a);
+                aec_ctl_own(&h, b);
+                h.ctl[(size_t)b] = blob;
+                aec_ctl_join(&h, b);
+                model[(size_t)b] = model[(size_t)a];
+            }
+        } else if (r < 16) {
+            odd_until[rnd() % (uint32_t)h.n_far] = t + 1 + (int)(rnd() % 40);  // reports a delay of its own for a while
+        } else if (r < 19) {
+            off_until[rnd() % (uint32_t)h.n_far] = t + 1 + (int)(rnd() % 30);  // not called for a while
+        }
+        delay.assign((size_t)h.n_far, 0);
+        on.assign((size_t)h.n_far, 1);
+        for (int g = 0; g < h.n_far; g++) {
+            if (odd_until[(size_t)g] > t) delay[(size_t)g] = 40 + 20 * (g % 3);
+            if (off_until[(size_t)g] > t) on[(size_t)g] = 0;
+        }
+        // the launch, as wmx_aec_run_cohorts does it
+        aec_classes_split(&h, delay.data(), on.data());
+        aec_classes_list(&h, leaders, plan_of);
+        h.cls_dirty = false;
+        std::vector<AecPlan> plans(leaders.size());
+        for (size_t c = 0; c < leaders.size(); c++) {
+            const int g = leaders[c];
+            std::memset(&plans[c], 0, sizeof(AecPlan));
+            if (!h.live[(size_t)g] || !on[(size_t)g]) continue;
+            CHECK(h.ctl[(size_t)g].buffer_farend(pkg, &plans[c]) == 0);
+            CHECK(h.ctl[(size_t)g].process(pkg, delay[(size_t)g], &plans[c]) == 0);
+        }
+        for (int g = 0; g < h.n_far; g++) {
+            CHECK(h.lead[(size_t)g] >= 0 && h.lead[(size_t)g] < h.n_far && h.lead[(size_t)h.lead[(size_t)g]] == h.lead[(size_t)g]);  // leaders lead themselves
+            if (!h.live[(size_t)g]) {
+                CHECK(h.lead[(size_t)g] == g);  // a retired cohort leads nobody and follows nobody
+                continue;
+            }
+            CHECK(h.live[(size_t)h.lead[(size_t)g]]);
+            AecPlan want;
+            std::memset(&want, 0, sizeof(want));
+            if (on[(size_t)g]) {
+                CHECK(model[(size_t)g].buffer_farend(pkg, &want) == 0);
+                CHECK(model[(size_t)g].process(pkg, delay[(size_t)g], &want) == 0);
+            }
+            CHECK(std::memcmp(&want, &plans[(size_t)plan_of[(size_t)g]], sizeof(AecPlan)) == 0);
+            CHECK(aec_ctl(&h, g).same_as(model[(size_t)g]));
+            shared += h.lead[(size_t)g] != g;
+        }
+        launches++;
+    }
+    CHECK(shared > launches / 4);  // the histories do leave cohorts in shared classes (0.7 - 1 follower per launch on average here)
+}
+
 int main() {
     long total = 0;
     for (int freq : {8000, 16000})
@@ -234,6 +359,11 @@ int main() {
             for (int i = 0; i < k; i++) want = (want * 69069u + 1u) & 0x7FFFFFFFu;
             CHECK(((s * a + c) & 0x7FFFFFFFu) == want);
         }
+    }
+    for (uint32_t seed : {1u, 7u, 99u}) {
+        drive_classes(16000, 160, seed, 12, 3000);
+        drive_classes(8000, 80, seed + 1000, 5, 2500);
+        drive_classes(8000, 160, seed + 2000, 30, 1500);
     }
     // ---- coalescing: planes meet as soon as the younger one's start-up is over when they are a multiple of the re-blocking period
     //      apart (160-in-64: 2 packets; 80-in-64: 4 packets) -- the core's two block counters count with the stream, not with the plane

@@ -1543,57 +1543,17 @@ int wmx_aec_create(wmx_aec **out, int n_streams, int chn, int freq, int interval
 // side by side.  Evenly matters: a packet is 2.5 blocks at 16 kHz, so a cohort runs 2 or 3 blocks in a launch depending on the phase
 // of its re-blocking ring, and eight cohorts of four phases each laid out one per XCD made every launch as long as a 3-block one
 // (0.82 ms instead of 0.70, measured).  Any permutation is CORRECT (a wave finds its stream's cohort in d_stream_far).
-// ---- control-plane classes (see wmx_aec::lead)
-static inline wmx::AecCtl &aec_ctl(wmx_aec *h, int g) { return h->ctl[(size_t)h->lead[(size_t)g]]; }
-static inline const wmx::AecCtl &aec_ctl(const wmx_aec *h, int g) { return h->ctl[(size_t)h->lead[(size_t)g]]; }
-// cohort g leaves its class with an up-to-date plane of its own (a leader hands the class over to its first follower)
-static void aec_ctl_own(wmx_aec *h, int g) {
-    const int l = h->lead[(size_t)g];
-    if (l != g) {
-        h->ctl[(size_t)g] = h->ctl[(size_t)l];
-        h->lead[(size_t)g] = g;
-        h->cls_dirty = true;
-        return;
-    }
-    int heir = -1;
-    for (int x = 0; x < h->n_far; x++)
-        if (x != g && h->lead[(size_t)x] == g) {
-            if (heir < 0) {
-                heir = x;
-                h->ctl[(size_t)x] = h->ctl[(size_t)g];
-            }
-            h->lead[(size_t)x] = heir;
-            h->cls_dirty = true;
-        }
-}
-// cohort g (a leader of itself alone, its plane just rewritten: aec_init, an import) joins a class whose plane is equal, if one of
-// the first few hundred leaders has it -- planes made at the same point of the packet sequence (a bounded search: a miss costs
-// a control plane of its own, nothing else)
-static void aec_ctl_join(wmx_aec *h, int g) {
-    int seen = 0;
-    for (int x = 0; x < h->n_far && seen < 256; x++) {
-        if (x == g || h->lead[(size_t)x] != x || !h->live[(size_t)x]) continue;
-        seen++;
-        if (h->ctl[(size_t)x].same_as(h->ctl[(size_t)g])) {
-            h->lead[(size_t)g] = x;
-            h->cls_dirty = true;
-            return;
-        }
-    }
-}
+// ---- control-plane classes (see wmx_aec::lead): aec_ctl / aec_ctl_own / aec_ctl_join / aec_classes_split / aec_classes_list live in
+// aec_ctl.h, free of HIP, so that the sanitizer driver can run them against a per-cohort model
+using wmx::aec_ctl;
+using wmx::aec_ctl_own;
+using wmx::aec_ctl_join;
 // cls_leader / plan_of from lead[], and plan_of onto the device in `s` (alternating host sources, like the stream order)
 static int aec_rebuild_classes(wmx_aec *h, hipStream_t s) {
     const int G = h->n_far;
     h->h_plan_of_sel ^= 1;
     std::vector<int32_t> &po = h->h_plan_of[h->h_plan_of_sel];
-    po.assign((size_t)G, 0);
-    h->cls_leader.clear();
-    for (int g = 0; g < G; g++)
-        if (h->lead[(size_t)g] == g) {
-            po[(size_t)g] = (int32_t)h->cls_leader.size();
-            h->cls_leader.push_back(g);
-        }
-    for (int g = 0; g < G; g++) po[(size_t)g] = po[(size_t)h->lead[(size_t)g]];
+    wmx::aec_classes_list(h, h->cls_leader, po);
     if (G > 1) WMX_HIP_RC(hipMemcpyAsync(h->d_plan_of, po.data(), sizeof(int32_t) * (size_t)G, hipMemcpyHostToDevice, s));
     h->cls_dirty = false;
     return 0;
@@ -2129,13 +2089,7 @@ int wmx_aec_run_cohorts(wmx_aec *h, int mode, const int16_t *d_far, long far_pac
     }
     // Control-plane classes: a follower that is called differently from its leader in THIS call (switched on / off alone, another
     // reported delay) takes a plane of its own first.  (wmx_aec_run / _run_groups hand every cohort the same delay and no switches.)
-    if (G > 1 && (cohort_on || delay_ms != h->same_delay.data()))
-        for (int g = 0; g < G; g++) {
-            const int l = h->lead[(size_t)g];
-            if (l == g || !h->live[(size_t)g]) continue;
-            const bool on_g = !cohort_on || cohort_on[g], on_l = !cohort_on || cohort_on[l];
-            if (on_g != on_l || (on_g && delay_ms[g] != delay_ms[l])) aec_ctl_own(h, g);
-        }
+    if (G > 1 && (cohort_on || delay_ms != h->same_delay.data())) wmx::aec_classes_split(h, delay_ms, cohort_on);
     bool classes_moved = false;
     if (h->cls_dirty) {
         // uploaded in `s`, behind every launch that still reads the old classes; a far kernel forked onto the side stream would not

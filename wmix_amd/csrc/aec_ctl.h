@@ -12,6 +12,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <vector>
 #include <cstring>
 
 namespace wmx {
@@ -359,6 +360,78 @@ inline void aec_co_pair(const AecCtl &a, const AecCtl &b, int ia, int ib, AecPai
     pc->d_near = aec_mod(a.near_fr.rd - b.near_fr.rd, kAecRing);
     pc->d_out = aec_mod(a.out_fr.rd - b.out_fr.rd, kAecRing);
     pc->pad = 0;
+}
+
+// ---------------------------------------------------------------- control-plane classes (host bookkeeping, no HIP)
+// A control plane is index arithmetic on the call pattern, never on audio: cohorts that were started at the same point and are
+// called alike have EQUAL planes for ever, although their far-ends differ.  H is anything with
+//     std::vector<AecCtl> ctl;  std::vector<int32_t> lead;  std::vector<uint8_t> live;  int n_far;  bool cls_dirty;
+// (wmx_aec in aec.hip; a plain struct in tools_dev/san/host_ctl_san.cpp, where these run under ASan / UBSan against a model that
+// keeps one plane per cohort).  lead[g] = the cohort whose plane stands for g's; ctl[g] of a follower is stale.
+template <class H>
+inline AecCtl &aec_ctl(H *h, int g) { return h->ctl[(size_t)h->lead[(size_t)g]]; }
+template <class H>
+inline const AecCtl &aec_ctl(const H *h, int g) { return h->ctl[(size_t)h->lead[(size_t)g]]; }
+// cohort g leaves its class with an up-to-date plane of its own (a leader hands the class over to its first follower)
+template <class H>
+inline void aec_ctl_own(H *h, int g) {
+    const int l = h->lead[(size_t)g];
+    if (l != g) {
+        h->ctl[(size_t)g] = h->ctl[(size_t)l];
+        h->lead[(size_t)g] = g;
+        h->cls_dirty = true;
+        return;
+    }
+    int heir = -1;
+    for (int x = 0; x < h->n_far; x++)
+        if (x != g && h->lead[(size_t)x] == g) {
+            if (heir < 0) {
+                heir = x;
+                h->ctl[(size_t)x] = h->ctl[(size_t)g];
+            }
+            h->lead[(size_t)x] = heir;
+            h->cls_dirty = true;
+        }
+}
+// cohort g (a leader of itself alone, its plane just rewritten: aec_init, an import) joins a class whose plane is equal, if one of
+// the first few hundred leaders has it -- planes made at the same point of the packet sequence (a bounded search: a miss costs
+// a control plane of its own, nothing else)
+template <class H>
+inline void aec_ctl_join(H *h, int g) {
+    int seen = 0;
+    for (int x = 0; x < h->n_far && seen < 256; x++) {
+        if (x == g || h->lead[(size_t)x] != x || !h->live[(size_t)x]) continue;
+        seen++;
+        if (h->ctl[(size_t)x].same_as(h->ctl[(size_t)g])) {
+            h->lead[(size_t)g] = x;
+            h->cls_dirty = true;
+            return;
+        }
+    }
+}
+// in front of a launch: a follower that is called differently from its leader in THIS call (switched on / off alone, another
+// reported delay) takes a plane of its own first.  cohort_on may be null (all on).
+template <class H>
+inline void aec_classes_split(H *h, const int32_t *delay_ms, const uint8_t *cohort_on) {
+    for (int g = 0; g < h->n_far; g++) {
+        const int l = h->lead[(size_t)g];
+        if (l == g || !h->live[(size_t)g]) continue;
+        const bool on_g = !cohort_on || cohort_on[g], on_l = !cohort_on || cohort_on[l];
+        if (on_g != on_l || (on_g && delay_ms[g] != delay_ms[l])) aec_ctl_own(h, g);
+    }
+}
+// the leaders, compact, and every cohort's class index
+template <class H>
+inline void aec_classes_list(const H *h, std::vector<int32_t> &leaders, std::vector<int32_t> &plan_of) {
+    const int G = h->n_far;
+    plan_of.assign((size_t)G, 0);
+    leaders.clear();
+    for (int g = 0; g < G; g++)
+        if (h->lead[(size_t)g] == g) {
+            plan_of[(size_t)g] = (int32_t)leaders.size();
+            leaders.push_back(g);
+        }
+    for (int g = 0; g < G; g++) plan_of[(size_t)g] = plan_of[(size_t)h->lead[(size_t)g]];
 }
 
 }  // namespace wmx
