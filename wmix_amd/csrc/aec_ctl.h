@@ -365,13 +365,12 @@ inline void aec_co_pair(const AecCtl &a, const AecCtl &b, int ia, int ib, AecPai
 // ---------------------------------------------------------------- control-plane classes (host bookkeeping, no HIP)
 // A control plane is index arithmetic on the call pattern, never on audio: cohorts that were started at the same point and are
 // called alike have EQUAL planes for ever, although their far-ends differ.  H is anything with
-//     std::vector<AecCtl> ctl;  std::vector<int32_t> lead;  std::vector<uint8_t> live;  int n_far;  bool cls_dirty;
+//     std::vector<Ctl> ctl;  std::vector<int32_t> lead;  std::vector<uint8_t> live;  bool cls_dirty;     (Ctl: AecCtl or AecmCtl --
+//     anything with same_as(); lead.size() is the number of cohort ids in use)
 // (wmx_aec in aec.hip; a plain struct in tools_dev/san/host_ctl_san.cpp, where these run under ASan / UBSan against a model that
 // keeps one plane per cohort).  lead[g] = the cohort whose plane stands for g's; ctl[g] of a follower is stale.
 template <class H>
-inline AecCtl &aec_ctl(H *h, int g) { return h->ctl[(size_t)h->lead[(size_t)g]]; }
-template <class H>
-inline const AecCtl &aec_ctl(const H *h, int g) { return h->ctl[(size_t)h->lead[(size_t)g]]; }
+inline auto aec_ctl(H *h, int g) -> decltype((h->ctl[0])) { return h->ctl[(size_t)h->lead[(size_t)g]]; }
 // cohort g leaves its class with an up-to-date plane of its own (a leader hands the class over to its first follower)
 template <class H>
 inline void aec_ctl_own(H *h, int g) {
@@ -383,7 +382,7 @@ inline void aec_ctl_own(H *h, int g) {
         return;
     }
     int heir = -1;
-    for (int x = 0; x < h->n_far; x++)
+    for (int x = 0; x < (int)h->lead.size(); x++)
         if (x != g && h->lead[(size_t)x] == g) {
             if (heir < 0) {
                 heir = x;
@@ -399,7 +398,7 @@ inline void aec_ctl_own(H *h, int g) {
 template <class H>
 inline void aec_ctl_join(H *h, int g) {
     int seen = 0;
-    for (int x = 0; x < h->n_far && seen < 256; x++) {
+    for (int x = 0; x < (int)h->lead.size() && seen < 256; x++) {
         if (x == g || h->lead[(size_t)x] != x || !h->live[(size_t)x]) continue;
         seen++;
         if (h->ctl[(size_t)x].same_as(h->ctl[(size_t)g])) {
@@ -413,7 +412,7 @@ inline void aec_ctl_join(H *h, int g) {
 // reported delay) takes a plane of its own first.  cohort_on may be null (all on).
 template <class H>
 inline void aec_classes_split(H *h, const int32_t *delay_ms, const uint8_t *cohort_on) {
-    for (int g = 0; g < h->n_far; g++) {
+    for (int g = 0; g < (int)h->lead.size(); g++) {
         const int l = h->lead[(size_t)g];
         if (l == g || !h->live[(size_t)g]) continue;
         const bool on_g = !cohort_on || cohort_on[g], on_l = !cohort_on || cohort_on[l];
@@ -423,7 +422,7 @@ inline void aec_classes_split(H *h, const int32_t *delay_ms, const uint8_t *coho
 // the leaders, compact, and every cohort's class index
 template <class H>
 inline void aec_classes_list(const H *h, std::vector<int32_t> &leaders, std::vector<int32_t> &plan_of) {
-    const int G = h->n_far;
+    const int G = (int)h->lead.size();
     plan_of.assign((size_t)G, 0);
     leaders.clear();
     for (int g = 0; g < G; g++)

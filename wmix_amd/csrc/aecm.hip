@@ -196,14 +196,23 @@ __device__ uint32_t binary_spectrum(const uint16_t *mag, int32_t *mean, int q, i
 // kernel in the same stream, stores it into plans[0] for both (no host-to-device copy of the plan in front of the launch).
 // grid = number of cohorts: workgroup g (one wave) serves cohort g with plans[packet * n_cohorts + g] and the far-end
 // packets at far + g * far_group_stride (0: every cohort hears the same far-end, blocked from its own start)
+// What one lane of this wave has stored to global memory, the other lanes of the SAME wave read next (a workgroup here is one wave):
+// a workgroup-scope fence -- the stores have left the wave (s_waitcnt vmcnt(0)); loads of the same compute unit see them, its L1 is
+// write-through -- instead of the agent-scope __threadfence() that stood here: with thousands of far-end waves (one per cohort) in
+// flight, five cache write-backs per packet and cohort made this kernel 0.45 ms for 4 096 far-ends, 14 x the single one.
+__device__ __forceinline__ void wave_handoff_global() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
 __global__ __launch_bounds__(64) void aecm_far_kernel(AecmFarBufs F_all, const AecmConsts *__restrict__ consts, AecmPlan *plans, int n_plans,
-                                                     int n_cohorts, const int16_t *far, long far_stride, long far_group_stride, int chn,
-                                                     int plan_by_value, const AecmPlan plan_value, const AecmPlan *__restrict__ host_plans) {
+                                                     int n_classes, const int32_t *__restrict__ plan_of, const int16_t *far, long far_stride,
+                                                     long far_group_stride, int chn, int plan_by_value, const AecmPlan plan_value,
+                                                     const AecmPlan *__restrict__ host_plans) {
     __shared__ AecmConsts K;
     __shared__ AecmWave W;
     const int lane = threadIdx.x;
     const AecmFarBufs F = far_cohort(F_all, (int)blockIdx.x);
     if (far) far += (size_t)blockIdx.x * far_group_stride;
+    // [packet][class]: cohorts whose control planes run in lockstep share one plan (control-plane classes, aec_ctl.h; wmx_aecm_run_cohorts)
+    const int cls = plan_of ? plan_of[blockIdx.x] : (int)blockIdx.x;
     if (plan_by_value) {
         const int *src = reinterpret_cast<const int *>(&plan_value);
         int *dst = reinterpret_cast<int *>(plans);
@@ -216,14 +225,14 @@ __global__ __launch_bounds__(64) void aecm_far_kernel(AecmFarBufs F_all, const A
         // kernel of the stream and this one (13 us per step with two cohorts, 45 with 256: the launch queue drains around a blit)
         constexpr int NW = (int)(sizeof(AecmPlan) / 4);
         for (int p = 0; p < n_plans; p++) {
-            const int *src = reinterpret_cast<const int *>(host_plans + (size_t)p * n_cohorts + blockIdx.x);
-            int *dst = reinterpret_cast<int *>(plans + (size_t)p * n_cohorts + blockIdx.x);
+            const int *src = reinterpret_cast<const int *>(host_plans + (size_t)p * n_classes + cls);  // (every cohort its own class here)
+            int *dst = reinterpret_cast<int *>(plans + (size_t)p * n_classes + cls);
             for (int i = lane; i < NW; i += 64) dst[i] = __builtin_nontemporal_load(src + i);
         }
         __threadfence();
         wave_sync();
     }
-    plans += blockIdx.x;  // [packet][cohort]: a launch uploads exactly packets x cohorts plans
+    plans += cls;  // [packet][class]: a launch uploads exactly packets x classes plans
     {
         const int4 *src = reinterpret_cast<const int4 *>(consts);
         int4 *dst = reinterpret_cast<int4 *>(&K);
@@ -235,7 +244,7 @@ __global__ __launch_bounds__(64) void aecm_far_kernel(AecmFarBufs F_all, const A
     if (lane < 32) mean[lane] = F.mean_far[lane];
     wave_sync();
     for (int p = 0; p < n_plans; p++) {
-        const AecmPlan &pl = plans[(size_t)p * n_cohorts];
+        const AecmPlan &pl = plans[(size_t)p * n_classes];
         if (pl.has_far) {
             const int16_t *src = far + (long)p * far_stride;
             for (int i = lane; i < pl.far_n; i += 64) {
@@ -243,7 +252,7 @@ __global__ __launch_bounds__(64) void aecm_far_kernel(AecmFarBufs F_all, const A
                 pos -= pos >= kAecmFarRing ? kAecmFarRing : 0;
                 F.ring[pos] = src[(long)i * chn];  // left channel only, src/webrtc.c:303-309
             }
-            __threadfence();
+            wave_handoff_global();
             wave_sync();
         }
         if (!pl.has_near || pl.passthrough) continue;
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(64) void aecm_far_kernel(AecmFarBufs F_all, const A
                 w -= w >= kAecmFrameRing ? kAecmFrameRing : 0;
                 F.frame[w] = v;
             }
-            __threadfence();
+            wave_handoff_global();
             wave_sync();
             for (int b = 0; b < fp.n_blocks; b++) {
                 int r = fp.blk_r[b] + lane;
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(64) void aecm_far_kernel(AecmFarBufs F_all, const A
                     F.hist_bin[slot] = bin;
                 }
                 F.x_prev[lane] = nw;
-                __threadfence();
+                wave_handoff_global();
                 wave_sync();
             }
         }
@@ -802,7 +811,7 @@ __device__ void aecm_block(AecmWave &W, const AecmConsts &K, const AecmFarBufs &
 #endif
 __global__ __launch_bounds__(64 * kAecmWavesPerBlock) __attribute__((amdgpu_waves_per_eu(WMX_AECM_WPE, WMX_AECM_WPE))) void aecm_near_kernel(int32_t *__restrict__ state, AecmFarBufs F_all,
                                                                             const AecmConsts *__restrict__ consts,
-                                                                            const AecmPlan *__restrict__ plans, int n_plans, int n_cohorts, const int16_t *near,
+                                                                            const AecmPlan *__restrict__ plans, int n_plans, int n_classes, const int32_t *__restrict__ plan_of, const int16_t *near,
                                                                             int16_t *out, int n_streams, long stream_stride, long packet_stride,
                                                                             int chn, int pkg, int mult, const int *__restrict__ stream_cohort,
                                                                             const uint8_t *__restrict__ active) {
@@ -828,12 +837,12 @@ __global__ __launch_bounds__(64 * kAecmWavesPerBlock) __attribute__((amdgpu_wave
     // the cohort this stream belongs to (wave-uniform): its far-end history and its plans
     const int grp = stream_cohort ? __builtin_amdgcn_readfirstlane(stream_cohort[s]) : 0;
     const AecmFarBufs F = far_cohort(F_all, grp);
-    plans += grp;
+    plans += plan_of ? __builtin_amdgcn_readfirstlane(plan_of[grp]) : grp;  // [packet][class]
     const LdsScal sc{&W.st[A_SCAL]};
     int16_t *near_ring = reinterpret_cast<int16_t *>(&W.st[A_NEAR_RING]), *out_ring = reinterpret_cast<int16_t *>(&W.st[A_OUT_RING]);
     int16_t *d_prev = reinterpret_cast<int16_t *>(&W.st[A_D_PREV]);
     for (int p = 0; p < n_plans; p++) {
-        const AecmPlan &pl = plans[(size_t)p * n_cohorts];
+        const AecmPlan &pl = plans[(size_t)p * n_classes];
         if (!pl.has_near) continue;
         const int16_t *ip = near + s * stream_stride + (long)p * packet_stride;
         int16_t *op = out + s * stream_stride + (long)p * packet_stride;
@@ -978,7 +987,15 @@ struct wmx_aecm {
     int device;  // the HIP device the state lives on (current device at create); every entry point switches to it
     int n_streams, chn, freq, pkg;
     int n_cohorts;
-    std::vector<wmx::AecmCtl> ctl;  // one control plane per cohort
+    std::vector<wmx::AecmCtl> ctl;  // one control plane per cohort -- kept up to date for the LEADERS of the control-plane classes only
+    // control-plane classes, as in aec.hip (wmx_aec::lead; the bookkeeping is aec_ctl.h's, shared): cohorts started together and
+    // called alike run ONE plane and get ONE plan per packet, however many far-ends they hear
+    std::vector<int32_t> lead;         // [n_cohorts]
+    std::vector<int32_t> cls_leader;   // [n_cls]
+    std::vector<int32_t> h_plan_of[2]; // alternating sources of the asynchronous upload
+    int h_plan_of_sel;
+    int32_t *d_plan_of;                // [cap_cohorts]
+    bool cls_dirty;
     int32_t *d_state;
     int32_t *d_tmpl;        // the state aec_init gives a stream (reset_streams refills from it)
     int *d_stream_cohort;   // [n_streams] cohort of each stream, or nullptr with one cohort
@@ -1023,6 +1040,7 @@ int wmx_aecm_destroy(wmx_aecm *h) {
     if (h->d_state) (void)hipFree(h->d_state);
     if (h->d_consts) (void)hipFree(h->d_consts);
     if (h->d_far) (void)hipFree(h->d_far);
+    if (h->d_plan_of) (void)hipFree(h->d_plan_of);
     if (h->d_plans[0]) (void)hipFree(h->d_plans[0]);
     if (h->h_plans[0]) (void)hipHostFree(h->h_plans[0]);
     if (h->d_tmpl) (void)hipFree(h->d_tmpl);
@@ -1070,8 +1088,10 @@ static int aecm_reserve(wmx_aecm *h, int cap) {
     while (ncap < cap) ncap *= 2;
     void *nf = nullptr;
     AecmPlan *nd = nullptr, *nh = nullptr;
+    int32_t *npo = nullptr;
     const size_t plan_bytes = 2 * (size_t)ncap * kAecmMaxPktPerLaunch * sizeof(AecmPlan);
     hipError_t e = hipMalloc(&nf, h->far_bytes * (size_t)ncap);
+    if (e == hipSuccess) e = hipMalloc(&npo, sizeof(int32_t) * (size_t)ncap);
     if (e == hipSuccess) e = hipMalloc(&nd, plan_bytes);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&nh), plan_bytes, hipHostMallocDefault);
     if (e == hipSuccess && h->d_far) e = hipMemcpy(nf, h->d_far, h->far_bytes * (size_t)h->cap_cohorts, hipMemcpyDeviceToDevice);
@@ -1081,9 +1101,13 @@ static int aecm_reserve(wmx_aecm *h, int cap) {
         if (nf) (void)hipFree(nf);
         if (nd) (void)hipFree(nd);
         if (nh) (void)hipHostFree(nh);
+        if (npo) (void)hipFree(npo);
         return hip_fail(e, "growing the cohort buffers", __FILE__, __LINE__);
     }
     if (h->d_far) (void)hipFree(h->d_far);
+    if (h->d_plan_of) (void)hipFree(h->d_plan_of);
+    h->d_plan_of = npo;
+    h->cls_dirty = true;  // the new array holds nothing yet
     if (h->d_plans[0]) (void)hipFree(h->d_plans[0]);
     if (h->h_plans[0]) (void)hipHostFree(h->h_plans[0]);
     h->d_far = nf;
@@ -1126,6 +1150,10 @@ int wmx_aecm_create_cohorts(wmx_aecm **out, int n_streams, int chn, int freq, in
     h->n_cohorts = n_cohorts;
     h->ctl.resize((size_t)n_cohorts);
     for (AecmCtl &c : h->ctl) c.init(freq);
+    h->lead.assign((size_t)n_cohorts, 0);  // made together, equal planes: one class led by cohort 0 until something tells them apart
+    h->h_plan_of_sel = 0;
+    h->d_plan_of = nullptr;
+    h->cls_dirty = true;
     h->d_tmpl = nullptr;
     h->d_stream_cohort = nullptr;
     h->co_n = 0;
@@ -1258,6 +1286,7 @@ int wmx_aecm_run_cohorts(wmx_aecm *h, int mode, const int16_t *d_far, long far_p
                          const uint8_t *cohort_on, int32_t *cohort_rc, void *stream) {
     WMX_ON_DEVICE(h);
     using namespace wmx;
+    using wmx::aec_ctl;
     // a fork point belongs to THIS call, whichever way it ends (as in wmx_aec_run_cohorts)
     const bool fork_here = h && h->fork_pending;
     if (h) h->fork_pending = false;
@@ -1295,6 +1324,27 @@ int wmx_aecm_run_cohorts(wmx_aecm *h, int mode, const int16_t *d_far, long far_p
         const bool on_a = !cohort_on || cohort_on[pc.a], on_b = !cohort_on || cohort_on[pc.b];
         if (on_a != on_b || (on_a && delay_ms[pc.a] != delay_ms[pc.b]) || ((mode & 1) && far_group_stride != 0)) pc.b = -1;
     }
+    // control-plane classes (aec.hip / aec_ctl.h): a follower that is called differently from its leader in THIS call takes a plane of
+    // its own first; then one plane and one plan per class and packet
+    if (G > 1 && (cohort_on || delay_ms != h->same_delay.data())) wmx::aec_classes_split(h, delay_ms, cohort_on);
+    bool classes_moved = false;
+    if (h->cls_dirty) {
+        // uploaded in `s`, behind every launch that still reads the old classes; a far kernel forked onto the side stream would not
+        // wait for it: this one launch keeps the far kernel in line
+        h->h_plan_of_sel ^= 1;
+        std::vector<int32_t> &po = h->h_plan_of[h->h_plan_of_sel];
+        wmx::aec_classes_list(h, h->cls_leader, po);
+        if (G > 1) WMX_HIP(hipMemcpyAsync(h->d_plan_of, po.data(), sizeof(int32_t) * (size_t)G, hipMemcpyHostToDevice, s));
+        h->cls_dirty = false;
+        classes_moved = true;
+    }
+    const int C = (int)h->cls_leader.size();
+    const int32_t *plan_of = G > 1 ? h->d_plan_of : nullptr;
+    running = 0;
+    for (int c = 0; c < C; c++) {
+        const int g = h->cls_leader[(size_t)c];
+        running += (h->live[(size_t)g] && (!cohort_on || cohort_on[g])) ? 1 : 0;
+    }
     for (int done = 0; done < n_packets && running > 0;) {
         int chunk = n_packets - done;
         if (chunk > kAecmMaxPktPerLaunch) chunk = kAecmMaxPktPerLaunch;
@@ -1303,17 +1353,18 @@ int wmx_aecm_run_cohorts(wmx_aecm *h, int mode, const int16_t *d_far, long far_p
         const int sel = h->plan_sel;
         h->plan_sel ^= 1;
         if (h->plan_used[sel]) WMX_HIP(hipEventSynchronize(h->plan_free[sel]));
-        AecmPlan *hp = h->h_plans[sel], *dp = h->d_plans[sel];  // [packet][cohort], G apart: chunk x G plans are uploaded
+        AecmPlan *hp = h->h_plans[sel], *dp = h->d_plans[sel];  // [packet][class], C apart: chunk x C plans
         int any = 0;
-        for (int g = 0; g < G; g++) {
+        for (int c = 0; c < C; c++) {
+            const int g = h->cls_leader[(size_t)c];  // the class's one control plane
             const bool on = h->live[(size_t)g] && (!cohort_on || cohort_on[g]) && rc_g[g] == 0;
             for (int k = 0; k < chunk; k++) {
-                AecmPlan &pl = hp[(size_t)k * G + g];
+                AecmPlan &pl = hp[(size_t)k * C + c];
                 memset(&pl, 0, sizeof(pl));
-                if (!on || rc_g[g] != 0) continue;  // has_far = has_near = 0: both kernels skip the packet for this cohort
+                if (!on || rc_g[g] != 0) continue;  // has_far = has_near = 0: both kernels skip the packet for this class's cohorts
                 any = 1;
                 if (mode & 1) {
-                    const int r = h->ctl[g].buffer_farend(h->pkg, &pl);
+                    const int r = h->ctl[(size_t)g].buffer_farend(h->pkg, &pl);
                     if (r != 0) {
                         pl.has_far = 0;
                         rc_g[g] = r;
@@ -1321,7 +1372,7 @@ int wmx_aecm_run_cohorts(wmx_aecm *h, int mode, const int16_t *d_far, long far_p
                     }
                 }
                 if (mode & 2) {
-                    const int r = h->ctl[g].process(h->pkg, delay_ms[g], &pl);
+                    const int r = h->ctl[(size_t)g].process(h->pkg, delay_ms[g], &pl);
                     if (r != 0) {
                         // WebRtcAecm_Process has PROCESSED the packet with the delay clamped (state advances) and returns -1; the
                         // wmix wrapper then returns without copying its output (src/webrtc.c:382-387).  Same here: the kernel
@@ -1337,14 +1388,18 @@ int wmx_aecm_run_cohorts(wmx_aecm *h, int mode, const int16_t *d_far, long far_p
             }
         }
         if (any) {
-            const int by_value = (chunk == 1 && G == 1) ? 1 : 0;
+            const int by_value = (chunk == 1 && C == 1 && G == 1) ? 1 : 0;
             // the far kernel on the side stream when the caller forked it (first chunk of the call only)
-            const bool forked = fork_here && done == 0 && (mode & 2);
+            const bool forked = fork_here && done == 0 && (mode & 2) && !classes_moved;
             hipStream_t fs = forked ? h->side : s;
             if (forked) WMX_HIP(hipStreamWaitEvent(fs, h->ev_fork, 0));
-            hipLaunchKernelGGL(aecm_far_kernel, dim3((unsigned)G), dim3(64), 0, fs, h->far, h->d_consts, dp, chunk, G,
+            // every cohort its own class: each far wave fetches ITS plans from the pinned host slot (no copy-engine operation in front of
+            // the launch); classes shared by several cohorts: one small upload, and every member reads the class's plan on the device
+            const bool from_host = !by_value && C == G;
+            if (!by_value && !from_host) WMX_HIP(hipMemcpyAsync(dp, hp, (size_t)C * chunk * sizeof(AecmPlan), hipMemcpyHostToDevice, fs));
+            hipLaunchKernelGGL(aecm_far_kernel, dim3((unsigned)G), dim3(64), 0, fs, h->far, h->d_consts, dp, chunk, C, plan_of,
                                d_far ? d_far + (size_t)done * far_packet_stride : nullptr, far_packet_stride, far_group_stride, h->chn, by_value,
-                               hp[0], by_value ? nullptr : hp);
+                               hp[0], from_host ? hp : nullptr);
             WMX_LAUNCH_CHECK();
             if (forked) {
                 WMX_HIP(hipEventRecord(h->ev_join, fs));
@@ -1352,9 +1407,9 @@ int wmx_aecm_run_cohorts(wmx_aecm *h, int mode, const int16_t *d_far, long far_p
             }
             if (mode & 2) {
                 const unsigned grid = (unsigned)((h->n_streams + kAecmWavesPerBlock - 1) / kAecmWavesPerBlock);
-                hipLaunchKernelGGL(aecm_near_kernel, dim3(grid), dim3(64 * kAecmWavesPerBlock), 0, s, h->d_state, h->far, h->d_consts, dp, chunk, G,
-                                   d_near + (size_t)done * packet_stride, d_out + (size_t)done * packet_stride, h->n_streams, stream_stride,
-                                   packet_stride, h->chn, h->pkg, h->freq / 8000, h->d_stream_cohort, h->life.d_active);
+                hipLaunchKernelGGL(aecm_near_kernel, dim3(grid), dim3(64 * kAecmWavesPerBlock), 0, s, h->d_state, h->far, h->d_consts, dp, chunk, C,
+                                   plan_of, d_near + (size_t)done * packet_stride, d_out + (size_t)done * packet_stride, h->n_streams,
+                                   stream_stride, packet_stride, h->chn, h->pkg, h->freq / 8000, h->d_stream_cohort, h->life.d_active);
                 WMX_LAUNCH_CHECK();
             }
             WMX_HIP(hipEventRecord(h->plan_free[sel], s));
@@ -1363,7 +1418,7 @@ int wmx_aecm_run_cohorts(wmx_aecm *h, int mode, const int16_t *d_far, long far_p
         done += chunk;
     }
     if (cohort_rc)
-        for (int g = 0; g < G; g++) cohort_rc[g] = rc_g[g];
+        for (int g = 0; g < G; g++) cohort_rc[g] = (h->live[(size_t)g] && (!cohort_on || cohort_on[g])) ? rc_g[(size_t)h->lead[(size_t)g]] : 0;
     return rc_first;
 }
 
@@ -1426,7 +1481,7 @@ int wmx_aecm_export_cohort(wmx_aecm *h, int cohort, void *host_blob) {
     char *p = static_cast<char *>(host_blob);
     blob_begin(p, blob_tag("AEMc"), (uint32_t)h->freq, (uint32_t)(sizeof(AecmCtl) + h->far.group_bytes));
     p += sizeof(BlobHeader);
-    memcpy(p, &h->ctl[(size_t)cohort], sizeof(AecmCtl));
+    memcpy(p, &wmx::aec_ctl(h, cohort), sizeof(AecmCtl));
     WMX_HIP(hipMemcpy(p + sizeof(AecmCtl), static_cast<char *>(h->d_far) + (size_t)cohort * h->far.group_bytes, h->far.group_bytes,
                       hipMemcpyDeviceToHost));
     return 0;
@@ -1440,7 +1495,9 @@ int wmx_aecm_import_cohort(wmx_aecm *h, int cohort, const void *host_blob) {
     if (rc) return rc;
     WMX_HIP(hipDeviceSynchronize());
     const char *p = static_cast<const char *>(host_blob) + sizeof(BlobHeader);
+    wmx::aec_ctl_own(h, cohort);
     memcpy(&h->ctl[(size_t)cohort], p, sizeof(AecmCtl));
+    wmx::aec_ctl_join(h, cohort);
     aecm_co_drop(h, cohort);
     WMX_HIP(hipMemcpy(static_cast<char *>(h->d_far) + (size_t)cohort * h->far.group_bytes, p + sizeof(AecmCtl), h->far.group_bytes,
                       hipMemcpyHostToDevice));
@@ -1451,7 +1508,7 @@ int wmx_aecm_cohorts(const wmx_aecm *h) { return h ? h->n_cohorts : WMX_EINVAL; 
 int wmx_aecm_cohort_key(const wmx_aecm *h, int cohort, int32_t *key8) {
     if (!h || !key8 || cohort < 0 || cohort >= h->n_cohorts) return WMX_EINVAL;
     wmx::AecmCoKey k;
-    if (!h->live[(size_t)cohort] || !wmx::aecm_co_key(h->ctl[(size_t)cohort], &k)) return 1;  // retired, or still in its start-up
+    if (!h->live[(size_t)cohort] || !wmx::aecm_co_key(wmx::aec_ctl(h, cohort), &k)) return 1;  // retired, or still in its start-up
     for (int i = 0; i < 8; i++) key8[i] = k.v[i];
     return 0;
 }
@@ -1490,13 +1547,13 @@ int wmx_aecm_coalesce(wmx_aecm *h, int max_pairs, int32_t *merged_from, int32_t 
             if (pc.b < 0) continue;
             AecmCoKey ka, kb;
             const bool ok = h->h_co_flags[i] == 1 && h->live[(size_t)pc.a] && h->live[(size_t)pc.b] &&
-                            aecm_co_key(h->ctl[(size_t)pc.a], &ka) && aecm_co_key(h->ctl[(size_t)pc.b], &kb) && ka == kb;
+                            aecm_co_key(aec_ctl(h, pc.a), &ka) && aecm_co_key(aec_ctl(h, pc.b), &kb) && ka == kb;
             if (!ok) {
                 h->co_retry_at[(size_t)pc.b] = h->co_calls + 64;
                 continue;
             }
             if (merged >= cap) continue;
-            aecm_co_pair(h->ctl[(size_t)pc.a], h->ctl[(size_t)pc.b], pc.a, pc.b, &pc);
+            aecm_co_pair(aec_ctl(h, pc.a), aec_ctl(h, pc.b), pc.a, pc.b, &pc);
             go.p[n_go++] = pc;
             merged_from[merged] = pc.b;
             merged_into[merged] = pc.a;
@@ -1507,7 +1564,10 @@ int wmx_aecm_coalesce(wmx_aecm *h, int max_pairs, int32_t *merged_from, int32_t 
             hipLaunchKernelGGL(aecm_merge_streams, dim3((unsigned)((h->n_streams + 3) / 4)), dim3(256), 0, s, h->d_state, h->d_stream_cohort,
                                h->n_streams, go, n_go);
             WMX_LAUNCH_CHECK();
-            for (int i = 0; i < n_go; i++) h->live[(size_t)go.p[i].b] = 0;
+            for (int i = 0; i < n_go; i++) {
+                wmx::aec_ctl_own(h, go.p[i].b);  // a retired cohort leads nobody
+                h->live[(size_t)go.p[i].b] = 0;
+            }
             int nc = h->n_cohorts;
             while (nc > 1 && !h->live[(size_t)nc - 1]) nc--;
             if (nc < h->n_cohorts) {
@@ -1515,6 +1575,8 @@ int wmx_aecm_coalesce(wmx_aecm *h, int max_pairs, int32_t *merged_from, int32_t 
                 WMX_LAUNCH_CHECK();
                 h->n_cohorts = nc;
                 h->ctl.resize((size_t)nc);
+                h->lead.resize((size_t)nc);
+                h->cls_dirty = true;
                 h->live.resize((size_t)nc);
                 h->co_retry_at.resize((size_t)nc);
             }
@@ -1529,19 +1591,19 @@ int wmx_aecm_coalesce(wmx_aecm *h, int max_pairs, int32_t *merged_from, int32_t 
     for (int g = 0; g < h->n_cohorts && n < max_pairs; g++) {
         if (!h->live[(size_t)g]) continue;
         AecmCoKey k, kl;
-        if (!aecm_co_key(h->ctl[(size_t)g], &k)) continue;
+        if (!aecm_co_key(aec_ctl(h, g), &k)) continue;
         uint64_t hash = 1469598103934665603ull;
         for (int v : k.v) hash = (hash ^ (uint32_t)v) * 1099511628211ull;
         int lead = -1;
         const auto range = leads.equal_range(hash);
         for (auto it = range.first; it != range.second && lead < 0; ++it)
-            if (aecm_co_key(h->ctl[(size_t)it->second], &kl) && kl == k) lead = it->second;
+            if (aecm_co_key(aec_ctl(h, it->second), &kl) && kl == k) lead = it->second;
         if (lead < 0) {
             leads.emplace(hash, g);
             continue;
         }
         if (h->co_retry_at[(size_t)g] > h->co_calls) continue;
-        aecm_co_pair(h->ctl[(size_t)lead], h->ctl[(size_t)g], lead, g, &h->co_pairs.p[n++]);
+        aecm_co_pair(aec_ctl(h, lead), aec_ctl(h, g), lead, g, &h->co_pairs.p[n++]);
     }
     h->co_n = n;
     if (n == 0) return 0;
@@ -1559,7 +1621,9 @@ int wmx_aecm_reset_cohort(wmx_aecm *h, int cohort, void *stream) {
     WMX_ON_DEVICE(h);
     using namespace wmx;
     if (!h || cohort < 0 || cohort >= h->n_cohorts) return WMX_EINVAL;
+    wmx::aec_ctl_own(h, cohort);
     h->ctl[(size_t)cohort].init(h->freq);
+    wmx::aec_ctl_join(h, cohort);  // cohorts restarted at the same point of the packet sequence run one control plane
     aecm_co_drop(h, cohort);
     WMX_HIP(hipMemsetAsync(static_cast<char *>(h->d_far) + (size_t)cohort * h->far.group_bytes, 0, h->far.group_bytes, as_stream(stream)));
     return 0;
@@ -1581,6 +1645,8 @@ int wmx_aecm_add_cohort(wmx_aecm *h, int *cohort, void *stream) {
         const int rc = aecm_reserve(h, id + 1);
         if (rc != 0) return rc;
         h->ctl.resize((size_t)id + 1);
+        h->lead.push_back(id);
+        h->cls_dirty = true;
         h->live.push_back(1);
         h->co_retry_at.push_back(0);
         h->n_cohorts = id + 1;
@@ -1596,6 +1662,7 @@ int wmx_aecm_add_cohort(wmx_aecm *h, int *cohort, void *stream) {
 
 int wmx_aecm_retire_cohort(wmx_aecm *h, int cohort) {
     if (!h || cohort < 0 || cohort >= h->n_cohorts) return WMX_EINVAL;
+    wmx::aec_ctl_own(h, cohort);  // a retired cohort leads nobody
     h->live[(size_t)cohort] = 0;
     aecm_co_drop(h, cohort);
     return 0;

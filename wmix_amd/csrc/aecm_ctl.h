@@ -46,6 +46,15 @@ struct AecmCtl {
     short buf_size_start = 0, counter = 0, sum = 0, first_val = 0, check_buf_size_ctr = 0, ms_in_snd = 0, filt_delay = 0, last_delay_diff = 0;
     int block_t = 0;
 
+    // every word that decides the plane's future equal (see AecCtl::same_as): such planes, called alike, stay equal for ever
+    bool same_as(const AecmCtl &o) const {
+        return fs == o.fs && mult == o.mult && farend.same_as(o.farend) && frame_ring.same_as(o.frame_ring) && out_ring.same_as(o.out_ring) &&
+               known_delay == o.known_delay && time_for_delay_change == o.time_for_delay_change && ec_startup == o.ec_startup &&
+               check_buff_size == o.check_buff_size && buf_size_start == o.buf_size_start && counter == o.counter && sum == o.sum &&
+               first_val == o.first_val && check_buf_size_ctr == o.check_buf_size_ctr && ms_in_snd == o.ms_in_snd &&
+               filt_delay == o.filt_delay && last_delay_diff == o.last_delay_diff && block_t == o.block_t;
+    }
+
     void init(int freq) {  // WebRtcAecm_Init echo_control_mobile.c:177-231, WebRtcAecm_InitCore aecm_core.c:401-546
         *this = AecmCtl();
         fs = freq;

@@ -990,7 +990,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 80 ? 
                     frame4[j0 + j] = CHN == 2 ? make_uint4(dup(again[j].x), dup(again[j].y), dup(again[j].z), dup(again[j].w))
                                               : make_uint4(att(again[j].x), att(again[j].y), att(again[j].z), att(again[j].w));
             }
-            if (packets_per_call > 1) __threadfence();  // the next analysis of this call reads what was just stored
+            // the next analysis of this call reads what this very lane has just stored: the stores must have left the wave, nothing more
+            // (a workgroup-scope fence; the agent-scope __threadfence() that stood here is a cache write-back per packet and workgroup)
+            if (packets_per_call > 1) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         }
         __syncthreads();  // 3
     }
