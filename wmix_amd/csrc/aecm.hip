@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64) void aecm_far_kernel(AecmFarBufs F_all, const A
         const int *src = reinterpret_cast<const int *>(&plan_value);
         int *dst = reinterpret_cast<int *>(plans);
         for (int i = lane; i < (int)(sizeof(AecmPlan) / 4); i += 64) dst[i] = src[i];
-        __threadfence();
+        wave_handoff_global();  // (the near kernel sees the stored plans through the kernel boundary)
         wave_sync();
     } else if (host_plans) {
         // several cohorts or packets: every cohort's wave fetches ITS plans from the pinned host slot (device-visible host memory,
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64) void aecm_far_kernel(AecmFarBufs F_all, const A
             int *dst = reinterpret_cast<int *>(plans + (size_t)p * n_classes + cls);
             for (int i = lane; i < NW; i += 64) dst[i] = __builtin_nontemporal_load(src + i);
         }
-        __threadfence();
+        wave_handoff_global();  // (the near kernel sees the stored plans through the kernel boundary)
         wave_sync();
     }
     plans += cls;  // [packet][class]: a launch uploads exactly packets x classes plans
