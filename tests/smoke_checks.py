@@ -61,6 +61,40 @@ def _mfft(dev, np, torch):
             assert np.array_equal(got[k][b].cpu().numpy().view(np.uint32), w.view(np.uint32)), "math/fft FFTR %s mismatch" % k
 
 
+def _tick(dev, np, torch):
+    """The daemon's tick for 2 mixers x 3 sources x 1 record stream, 60 ticks: mix -> drain -> delay FIFO -> far-end of the group's
+    record chain -> zoom, against one oracle daemon per group (played package and far-end bit for bit, record stream <= 1 LSB)."""
+    from oracle import loader
+    from wmix_amd import synth
+    from wmix_amd.tick import TickBatch
+    port = loader.port()
+    G, T, N = 2, 60, 160
+    ins = [synth.conference_inputs(40 + g, T, 3, 1, 8000, 1) for g in range(G)]
+    tb = TickBatch(G, 1)
+    prev = torch.zeros((G, N), dtype=torch.int16, device=dev)
+    got = {"play": [], "far": [], "out": []}
+    for t in range(T):
+        src = torch.zeros((G, 3, N + 1), dtype=torch.int16, device=dev)
+        src[:, :, :N] = torch.from_numpy(np.stack([ins[g][0][t] for g in range(G)])).to(dev)
+        tb.load(src, 2 * N, 8000, 1)
+        play = torch.zeros((G, N), dtype=torch.int16, device=dev)
+        far = tb.play(play).clone()
+        line = torch.cat([prev, far], 1).to(torch.int32)
+        local = torch.from_numpy(np.stack([ins[g][1][t, 0] for g in range(G)])).to(dev).to(torch.int32)
+        rec = torch.clamp(local + (line[:, N - loader.TICK_ECHO_DELAY: 2 * N - loader.TICK_ECHO_DELAY] >> 1), -32768, 32767).to(torch.int16)
+        tb.record(rec)
+        prev = far
+        for k, v in (("play", play), ("far", far), ("out", rec)):
+            got[k].append(v.cpu().numpy())
+    tb.close()
+    for g in range(G):
+        want = loader.tick_port(port, ins[g][0], ins[g][1], 8000, 1)
+        assert np.array_equal(np.stack([x[g] for x in got["play"]]), want["play"]), "tick: played package differs"
+        assert np.array_equal(np.stack([x[g] for x in got["far"]]), want["far"]), "tick: far-end out of the delay FIFO differs"
+        d = np.abs(np.stack([x[g] for x in got["out"]]).astype(np.int32) - want["out"][:, 0].astype(np.int32))
+        assert d.max() <= 1, "tick: record stream differs from the oracle daemon by %d LSB" % d.max()
+
+
 _run_g711 = run
 
 
@@ -68,3 +102,4 @@ def run(dev, np, torch):  # noqa: F811
     _run_g711(dev, np, torch)
     _chain(dev, np, torch)
     _mfft(dev, np, torch)
+    _tick(dev, np, torch)

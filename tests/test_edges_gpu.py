@@ -121,3 +121,45 @@ def test_silence_clipping_dc_vs_oracle(cuda, oracle_port, freq):
     got = gpu_chain(cuda, 1, freq, 15, far, near)
     want = np.stack([L.run_chain(oracle_port, 1, freq, 5, 15, far, near[s], pkt, prefix="orc") for s in range(near.shape[0])])
     check_float_path(got, want, max_fraction=1e-4)
+
+
+def test_round5_entry_points_refuse_bad_arguments(cuda):
+    """wmx_tick_*, wmx_pipe_*, the per-stream AGC gain and the per-cohort far-end of the chain: bad arguments come back as WMX_E*
+    with nothing launched, like the reference's *_init returning NULL."""
+    import ctypes as C
+    import torch
+    from wmix_amd._lib import WmxError, lib
+    from wmix_amd.agc import AgcBatch
+    from wmix_amd.chain import ChainBatch
+    from wmix_amd.pipeline import RtpChain, StreamingPipe
+    from wmix_amd.tick import TickBatch
+    W = lib()
+    h = C.c_void_p()
+    assert W.wmx_tick_create(C.byref(h), 0, 1, 1, 8000, 20, 400, 5, 15) < 0              # no groups
+    assert W.wmx_tick_create(C.byref(h), 2, 1, 1, 8000, 20, 410, 5, 15) < 0              # a delay that is not whole packages
+    assert W.wmx_tick_create(C.byref(h), 2, 1, 1, 44100, 20, 400, 5, 15) < 0             # ns_init / aec_init return NULL at 44.1 kHz
+    assert W.wmx_tick_create(C.byref(h), 2, 1, 1, 32000, 20, 400, 5, 15) < 0             # aec_init: freq > 16000
+    assert W.wmx_pipe_create(C.byref(h), 4, 0, 0, 5, 15) < 0 and W.wmx_pipe_create(C.byref(h), 4, 3, 1, 5, 15) < 0  # slots, law
+    tb = TickBatch(2, 2)
+    rec = torch.zeros((4, 160), dtype=torch.int16, device=cuda)
+    assert W.wmx_tick_record(tb._h, rec.data_ptr(), 100, None, 0, 0, None, None) < 0    # rows shorter than a package
+    assert W.wmx_tick_play(tb._h, rec.data_ptr(), 100, None) < 0
+    tb.close()
+    ab = AgcBatch(8, 1, 16000, 5)
+    with pytest.raises(WmxError):
+        ab.set_gain_streams([0, 8], 9)      # stream 8 of 8
+    with pytest.raises(WmxError):
+        ab.reset_streams_gain([1], 250)     # agc_init returns NULL for this gain: nothing is reset
+    assert ab.stream_gain(1) == 5 and ab.stream_gain(0) == 5
+    ab.set_gain_streams([], 9)
+    ab.close()
+    with pytest.raises(WmxError):
+        ChainBatch(4, 1, 16000, 10, 5, n_cohorts=2, stream_cohort=[0, 1, 2, 0])  # cohort 2 of 2
+    pc = RtpChain(3, cuda, slots=2)
+    pipe = StreamingPipe(pc)
+    pipe.wait(-1)                           # nothing in flight: returns at once
+    assert W.wmx_pipe_wait(pc._h, 2) < 0    # slot 2 of 2
+    d = torch.zeros((3, 172), dtype=torch.uint8, device=cuda)
+    far = torch.zeros((2, 80), dtype=torch.int16, device=cuda)
+    assert W.wmx_pipe_step_resident(pc._h, d.data_ptr(), 100, far.data_ptr(), d.data_ptr(), 172, None) < 0  # rows shorter than a datagram
+    pc.close()

@@ -22,7 +22,7 @@ class ChainBatch(Lifetime):
         m = None
         if stream_cohort is not None:
             m = np.ascontiguousarray(stream_cohort, dtype=np.int32)
-            assert m.shape == (n_streams,) and m.min() >= 0 and m.max() < n_cohorts
+            assert m.shape == (n_streams,)  # (the range is the library's to refuse: WMX_EINVAL)
         rc = lib().wmx_chain_create_groups(C.byref(self._h), n_streams, chn, freq, interval_ms, agc_value, stages, n_cohorts,
                                            None if m is None else m.ctypes.data)
         if rc != 0:
