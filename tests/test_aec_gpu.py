@@ -21,17 +21,15 @@ pytestmark = pytest.mark.gpu
 G = np.load(os.path.join(GOLDEN, "aec_golden.npz"))
 
 
-def check_float_path(got, want, max_fraction=2e-5):
-    """max |d| <= 1 LSB, RMS <= 1e-3 of full scale (BASELINE.json), and -- because the kernels keep the reference's
-    operation order -- at most a 2e-5 fraction of samples may differ at all.  The only known source of a
-    difference is powf()/cosf()/sinf(): the reference calls the host's libm, whose float results are not always
-    correctly rounded and depend on the CPU's ifunc variant; the kernel rounds a double-precision pow() instead
-    (measured on MI355X vs glibc 2.35: 9 of 2.0e7 samples, isolated single samples, never fed back into state)."""
+def check_float_path(got, want, max_fraction=None):
+    """Bit for bit (round 5).  Through round 4 this allowed 1 LSB in a 2e-5 fraction of samples: the kernels kept the reference's
+    operation order but rounded a double-precision pow() where the reference calls the host's powf, which is not correctly rounded
+    (measured then: 4 - 9 isolated samples of 2e7).  The product now evaluates glibc's powf algorithm itself
+    (wmix_amd/csrc/libm_dev.h, tests/test_libm_tables.py::test_pow_sweep), and the float path is held to the same bar as the
+    integer ones.  `max_fraction` is what callers used to pass; it no longer loosens anything."""
     d = got.astype(np.int32) - want.astype(np.int32)
-    assert np.abs(d).max() <= 1, "max |d| = %d LSB" % np.abs(d).max()
-    assert np.sqrt((d.astype(np.float64) ** 2).mean()) / 32768.0 <= 1e-3
     n_diff = int((d != 0).sum())
-    assert n_diff <= max(1, int(max_fraction * d.size)), "%d of %d samples differ" % (n_diff, d.size)
+    assert n_diff == 0, "%d of %d samples differ, max |d| = %d LSB" % (n_diff, d.size, np.abs(d).max())
 
 
 def gpu_aec(cuda, chn, freq, ims, delay, far, near_streams, pkts_per_launch=23, packet_major=False):

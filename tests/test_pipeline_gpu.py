@@ -78,5 +78,5 @@ def test_rtp_chain_vs_oracle_resident_and_streaming(cuda, oracle_port):
         # payload: the float stages may differ from the CPU by 1 LSB on a few samples (AEC powf); a 1-LSB PCM
         # difference moves an A-law code by at most one step.  Observed: identical.
         diff = got[s][:, 12:].astype(np.int16) - want[:, 12:].astype(np.int16)
-        assert np.abs(diff).max() <= 1 and (diff != 0).mean() < 1e-4
+        assert not diff.any()
     assert got[0][5, 3] == 5 and got[0][5, 1] == 0x88

@@ -203,70 +203,118 @@ __host__ __device__ __forceinline__ float fast_tanh(float xf, const NsLibmTables
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// powf for the AEC's OverdriveAndSuppress (aec_core.c:278: hNl[i] = powf(hNl[i], overDriveSm * curve[i])), same
-// scheme: x^y = exp(y * log x) with log and exp as above but kept in double end to end (no intermediate rounding), for
-// 0 < x < inf.  The log is the general-argument version: mantissas above sqrt(2) are folded down (c/2 with e + 1) so
-// that arguments next to 1 -- no suppression, the common case -- see no cancellation between e*ln2 and log c.
-// Error ~ y * 2^-53 * |log x| relative, i.e. the result rounds to glibc's float except within ~2^-48 of a rounding
-// boundary; glibc's powf itself is not correctly rounded, and the parity criterion for the AEC is <= 1 LSB.
+// powf for the AEC's OverdriveAndSuppress (aec_core.c:278: hNl[i] = powf(hNl[i], overDriveSm * curve[i])) -- glibc's own
+// algorithm, bit for bit (round 5).  Rounds 1-4 evaluated x^y = exp(y log x) in double end to end: nearly correctly rounded, which
+// glibc's powf is NOT, so 0.09 % of arguments came out one float ulp apart and a handful of samples per 10^8 one LSB (behind the AGC
+// two) off the reference.  glibc 2.28+ computes powf as exp2(y * log2 x) in double: log2 by a 16-entry (1/c, log2 c) table and a
+// degree-4 polynomial in r = z/c - 1, exp2 by a 32-entry 2^(i/32) table and a degree-3 polynomial, one rounding to float at the end
+// (sysdeps/ieee754/flt-32/e_powf.c, from Arm's optimized routines; on x86-64 the ifunc picks the build with fused multiply-adds on
+// any CPU that has them -- the reference's hosts here do).  The restatement below follows it operation for operation, every a * b + c
+// of that build a fused multiply-add; the 16 + 5 + 3 constants are the published ones (each log2 c re-derives from its 1/c; the
+// exp2 table is 2^(i/32) with i << 47 taken off the bits), and tests/test_libm_tables.py sweeps it against the host's powf:
+// 6 M arguments of the AEC's domain and the special cases, bit for bit.
 struct PowTables {
-    double2 logtab[128];  // (RN(1/c), RN(log c)) for c < sqrt 2, (RN(1/c), RN(log(c/2))) above; c = 1 + i/128
-    double exptab[64];    // 2^(j/64)
+    double invc[16], logc[16];  // log2: c near the centre of [0x1.66p-1 * 2^(i/16) ...), invc = RN(1/c), logc = RN(log2 c)
+    double A[5];                // log2(1 + r) / r - polynomial, degree 4
+    unsigned long long E[32];   // bits(2^(i/32)) - (i << 47)
+    double C[3];                // 2^r - 1 polynomial, degree 3
 };
-constexpr int kPowFold = 53;  // first i with 1 + i/128 > sqrt(2)
 
 inline void pow_tables(PowTables *t) {
-    for (int i = 0; i < 128; i++) {
-        const double c = 1.0 + i / 128.0;
-        t->logtab[i].x = 1.0 / c;
-        t->logtab[i].y = i < kPowFold ? log(c) : log(c / 2.0);
-    }
-    for (int j = 0; j < 64; j++) t->exptab[j] = exp2(j / 64.0);
+    static const double invc[16] = {0x1.661ec79f8f3bep+0, 0x1.571ed4aaf883dp+0, 0x1.49539f0f010bp+0,  0x1.3c995b0b80385p+0,
+                                    0x1.30d190c8864a5p+0, 0x1.25e227b0b8eap+0,  0x1.1bb4a4a1a343fp+0, 0x1.12358f08ae5bap+0,
+                                    0x1.0953f419900a7p+0, 0x1p+0,               0x1.e608cfd9a47acp-1, 0x1.ca4b31f026aap-1,
+                                    0x1.b2036576afce6p-1, 0x1.9c2d163a1aa2dp-1, 0x1.886e6037841edp-1, 0x1.767dcf5534862p-1};
+    static const double logc[16] = {-0x1.efec65b963019p-2, -0x1.b0b6832d4fca4p-2, -0x1.7418b0a1fb77bp-2, -0x1.39de91a6dcf7bp-2,
+                                    -0x1.01d9bf3f2b631p-2, -0x1.97c1d1b3b7afp-3,  -0x1.2f9e393af3c9fp-3, -0x1.960cbbf788d5cp-4,
+                                    -0x1.a6f9db6475fcep-5, 0x0p+0,                0x1.338ca9f24f53dp-4,  0x1.476a9543891bap-3,
+                                    0x1.e840b4ac4e4d2p-3,  0x1.40645f0c6651cp-2,  0x1.88e9c2c1b9ff8p-2,  0x1.ce0a44eb17bccp-2};
+    static const unsigned long long E[32] = {
+        0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull,
+        0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull,
+        0x3feedea64c123422ull, 0x3feece086061892dull, 0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull,
+        0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+        0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull, 0x3feee89f995ad3adull,
+        0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+        0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+    for (int i = 0; i < 16; i++) t->invc[i] = invc[i], t->logc[i] = logc[i];
+    t->A[0] = 0x1.27616c9496e0bp-2, t->A[1] = -0x1.71969a075c67ap-2, t->A[2] = 0x1.ec70a6ca7baddp-2, t->A[3] = -0x1.7154748bef6c8p-1,
+    t->A[4] = 0x1.71547652ab82bp0;
+    for (int i = 0; i < 32; i++) t->E[i] = E[i];
+    t->C[0] = 0x1.c6af84b912394p-5, t->C[1] = 0x1.ebfce50fac4f3p-3, t->C[2] = 0x1.62e42ff0c52d6p-1;
 }
 
 __host__ __device__ __forceinline__ float fast_pow(float x, float y, const PowTables *__restrict__ M) {
-    unsigned u;
-    __builtin_memcpy(&u, &x, 4);
-    if (!(u >= 0x00800000u && u < 0x7F800000u)) return (float)pow((double)x, (double)y);  // zero, denormal, negative, inf, NaN
-    const int idx = (u >> 16) & 0x7F;
-    const int e = (int)(u >> 23) - 127 + (idx >= kPowFold ? 1 : 0);
-    const unsigned mu = (u & 0x007FFFFFu) | 0x3F800000u;
-    float mf;
-    __builtin_memcpy(&mf, &mu, 4);
-    const double2 t = M->logtab[idx];
-    const double r = fma((double)mf, t.x, -1.0);
-    double p = -1.0 / 9.0 * r + 1.0 / 8.0;
-    p = fma_c(p, r, -1.0 / 7.0);
-    p = fma_c(p, r, 1.0 / 6.0);
-    p = fma_c(p, r, -1.0 / 5.0);
-    p = fma_c(p, r, 1.0 / 4.0);
-    p = fma_c(p, r, -1.0 / 3.0);
-    p = fma(p, r, 1.0 / 2.0);
-    p = fma(-p, r, 1.0);
-    p = p * r;
-    const double ed = (double)e;
-    constexpr double kLn2Hi = 0x1.62e42fefa38p-1, kLn2Lo = 0x1.ef35793c7673p-45;
-    const double lg = fma(ed, kLn2Hi, t.y) + fma(ed, kLn2Lo, p);
-    const double z = (double)y * lg;
-    if (!(z > -700.0 && z < 700.0)) return (float)exp(z);
-    constexpr double kInv = 0x1.71547652b82fep+6, kHi = 0x1.62e42fefa0000p-7, kLo = 0x1.cf79abc9e3b3ap-46;
-    const double kd = rint(z * kInv);
-    const int k = (int)kd;
-    double rr = fma(-kd, kHi, z);
-    rr = fma(-kd, kLo, rr);
-    double q = fma_c(rr, 1.0 / 720.0, 1.0 / 120.0);
-    q = fma_c(q, rr, 1.0 / 24.0);
-    q = fma_c(q, rr, 1.0 / 6.0);
-    q = fma(q, rr, 0.5);
-    q = fma(q, rr, 1.0);
-    q = q * rr;
-    const double tt = M->exptab[k & 63];
-    const double yv = fma(tt, q, tt);
-    long long bits;
-    __builtin_memcpy(&bits, &yv, 8);
-    bits += (long long)(k >> 6) << 52;
-    double out;
-    __builtin_memcpy(&out, &bits, 8);
+    unsigned ix, iy;
+    __builtin_memcpy(&ix, &x, 4);
+    __builtin_memcpy(&iy, &y, 4);
+    unsigned long long sign_bias = 0;
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u || 2u * iy - 1u >= 2u * 0x7f800000u - 1u) {
+        // x zero, subnormal, negative, inf or NaN; y zero, inf or NaN.  What glibc decides by RULE (zeros, infinities, NaNs) the double
+        // pow decides the same way; negative finite x and subnormal x continue into the arithmetic like there (e_powf.c:150-190)
+        if (2u * iy - 1u >= 2u * 0x7f800000u - 1u || 2u * ix - 1u >= 2u * 0x7f800000u - 1u) return (float)pow((double)x, (double)y);
+        if (ix > 0x7f800000u) {  // x < 0: NaN unless y is an integer; an odd one flips the sign
+            const int e = (int)(iy >> 23 & 0xff);
+            int yint;
+            if (e < 0x7f)
+                yint = 0;
+            else if (e > 0x7f + 23)
+                yint = 2;
+            else if (iy & ((1u << (0x7f + 23 - e)) - 1u))
+                yint = 0;
+            else
+                yint = (iy & (1u << (0x7f + 23 - e))) ? 1 : 2;
+            if (yint == 0) return (float)pow((double)x, (double)y);  // invalid: NaN
+            if (yint == 1) sign_bias = 1ull << 16;
+            ix &= 0x7fffffffu;
+        }
+        if (ix < 0x00800000u) {  // subnormal x: normalise
+            const float xs = x * 0x1p23f;
+            __builtin_memcpy(&ix, &xs, 4);
+            ix &= 0x7fffffffu;
+            ix -= 23u << 23;
+        }
+    }
+    // log2_inline
+    const unsigned tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> (23 - 4)) % 16u);
+    const unsigned top = tmp & 0xff800000u, iz = ix - top;
+    const int k = (int)top >> 23;  // arithmetic shift
+    float zf;
+    __builtin_memcpy(&zf, &iz, 4);
+    const double z = (double)zf;
+    const double r = fma(z, M->invc[i], -1.0);
+    const double y0 = M->logc[i] + (double)k;
+    const double r2 = r * r;
+    double yy = fma(M->A[0], r, M->A[1]);
+    const double p = fma(M->A[2], r, M->A[3]);
+    const double r4 = r2 * r2;
+    double q = fma(M->A[4], r, y0);
+    q = fma(p, r2, q);
+    yy = fma(yy, r4, q);
+    const double ylogx = (double)y * yy;
+    unsigned long long yb;
+    __builtin_memcpy(&yb, &ylogx, 8);
+    if ((yb >> 47 & 0xffffull) >= (0x405f800000000000ull >> 47)) {  // |y log2 x| >= 126
+        if (ylogx > 0x1.fffffffd1d571p+6) return sign_bias ? -__builtin_huge_valf() : __builtin_huge_valf();
+        if (ylogx <= -150.0) return sign_bias ? -0.0f : 0.0f;
+    }
+    // exp2_inline
+    constexpr double kShift = 0x1.8p+52 / 32;
+    double kd = ylogx + kShift;
+    unsigned long long ki;
+    __builtin_memcpy(&ki, &kd, 8);
+    kd -= kShift;
+    const double rr = ylogx - kd;
+    unsigned long long t = M->E[ki % 32];
+    t += (ki + sign_bias) << (52 - 5);
+    double sc;
+    __builtin_memcpy(&sc, &t, 8);
+    const double zz = fma(M->C[0], rr, M->C[1]);
+    const double rr2 = rr * rr;
+    double out = fma(M->C[2], rr, 1.0);
+    out = fma(zz, rr2, out);
+    out = out * sc;
     return (float)out;
 }
 
