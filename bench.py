@@ -182,7 +182,7 @@ class NsWorkload:
     def parity_check(self):
         """Replays 16 sampled streams through the oracle's NS for exactly the packets this run fed and compares every packet
         recorded outside the timed region (those behind it depend on every timed step through the noise model).  Float path:
-        +-1 LSB is the bar; the ordered mode is observed bit-exact."""
+        bit-exact (ordered mode)."""
         from oracle import loader
         port = loader.port()
         worst, n, n_off = 0, 0, 0
@@ -840,7 +840,8 @@ class ChainWorkload:
     def parity_check(self):
         """Replays 16 sampled streams through the oracle chain for exactly the packets this run fed (priming, warm-up,
         timed and breakdown steps) and compares every packet recorded outside the timed region; the packets behind the
-        timed region depend on every timed step through the filter / model state.  +-1 LSB is the float path's bar."""
+        timed region depend on every timed step through the filter / model state.  The float path is bit-exact since round 5
+        (glibc's powf algorithm on the device); max_lsb is reported, the tests require 0."""
         from oracle import loader
         port = loader.port()
         T, P = self.k, self.P
@@ -990,7 +991,7 @@ class NsAgcMix32kWorkload:
         """The 32 sources of 4 sampled mix groups replayed through the oracle's NS + AGC (2 x 32 kHz, R channel = high band,
         5 ms AGC packets) for exactly the packets fed; every packet recorded outside the timed region is compared, and so is the
         group's drained 10 ms of the 8 kHz ring against oracle/orc_mix.c fed with the ORACLE's source packets in call order
-        (saturating accumulate).  NS float path: +-1 LSB is the bar (bit-exact observed); AGC and mix are integer."""
+        (saturating accumulate).  NS float path: bit-exact; AGC and mix are integer."""
         from oracle import loader
         port = loader.port()
         per, N = 640, self.N
@@ -1137,8 +1138,7 @@ class ConferenceWorkload:
     def parity_check(self):
         """4 sampled mix groups as 4 daemons through the restatement (oracle.loader.tick_port: orc_load_data per source and tick, the
         package drain, orc_pkgfifo, the room, the oracle chain per record stream, orc_pcm_zoom) for exactly the ticks fed; every tick
-        recorded outside the timed region is compared: played package and far-end bit for bit, the record streams' 1 x 8000 output
-        within 1 LSB."""
+        recorded outside the timed region is compared bit for bit: played package, far-end and the record streams' 1 x 8000 output."""
         from oracle import loader
         port = loader.port()
         T = self.k

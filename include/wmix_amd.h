@@ -202,8 +202,8 @@ int wmx_agc_import_stream(wmx_agc *h, int stream_index, const void *host_blob);
  * d_out may alias d_near.  delay_ms is the reported sound-card delay (the daemon passes 0).
  * Returns 0, a WMX_E* error, or -1 where the reference wrapper would return non-zero (delay outside
  * [0,500]: the offending packet is left unwritten and nothing after it runs).
- * Float path: same operation order as the reference; tests require max |d| <= 1 LSB, and
- * observe bit-exactness. */
+ * Float path: same operation order as the reference and the same powf (glibc's algorithm, restated
+ * in csrc/libm_dev.h); tests require bit-exactness. */
 typedef struct wmx_aec wmx_aec;
 int wmx_aec_create(wmx_aec **out, int n_streams, int chn, int freq, int interval_ms);
 int wmx_aec_destroy(wmx_aec *h);

@@ -45,7 +45,7 @@ def _chain(dev, np, torch):
         vad.process(blk)
     got = d.cpu().numpy().reshape(S, -1)
     diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
-    assert diff.max() <= 1, "chain differs from the oracle by %d LSB" % diff.max()
+    assert diff.max() == 0, "chain differs from the oracle by %d LSB" % diff.max()
 
 
 def _mfft(dev, np, torch):
@@ -63,7 +63,7 @@ def _mfft(dev, np, torch):
 
 def _tick(dev, np, torch):
     """The daemon's tick for 2 mixers x 3 sources x 1 record stream, 60 ticks: mix -> drain -> delay FIFO -> far-end of the group's
-    record chain -> zoom, against one oracle daemon per group (played package and far-end bit for bit, record stream <= 1 LSB)."""
+    record chain -> zoom, against one oracle daemon per group (played package and far-end bit for bit, record stream too)."""
     from oracle import loader
     from wmix_amd import synth
     from wmix_amd.tick import TickBatch
@@ -92,7 +92,7 @@ def _tick(dev, np, torch):
         assert np.array_equal(np.stack([x[g] for x in got["play"]]), want["play"]), "tick: played package differs"
         assert np.array_equal(np.stack([x[g] for x in got["far"]]), want["far"]), "tick: far-end out of the delay FIFO differs"
         d = np.abs(np.stack([x[g] for x in got["out"]]).astype(np.int32) - want["out"][:, 0].astype(np.int32))
-        assert d.max() <= 1, "tick: record stream differs from the oracle daemon by %d LSB" % d.max()
+        assert d.max() == 0, "tick: record stream differs from the oracle daemon by %d LSB" % d.max()
 
 
 _run_g711 = run

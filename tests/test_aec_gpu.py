@@ -1,8 +1,8 @@
 """GPU parity: wmix_amd/csrc/aec.hip (+ the whole NS->AEC->AGC->VAD chain through the batched
 C ABI) vs the reference goldens and vs the oracle on many streams sharing one far-end.
 Tolerance stated by BASELINE.json for the float AEC / chain path: max |d| <= 1 LSB and RMS <= 1e-3
-of full scale; the kernels keep the reference's operation order, so we additionally require that
-(almost) every sample is bit-identical -- see check_float_path."""
+of full scale; the kernels keep the reference's operation order and (round 5) the reference's powf, so
+the tests require every sample bit-identical -- see check_float_path."""
 import ctypes as C
 import os
 import sys

@@ -4,7 +4,7 @@ The reference creates every handle lazily in the record heartbeat, releases it w
 and creates a new one later (src/wmix.c:565-600, 617-618, 635-636, 683-684, 702-703; src/webrtc.c:217-274, 560-602), and
 aec_process2 takes the reported delay per handle per call (src/webrtc.c:410).  Here the streams of ONE batch join at
 different packets, restart, go idle and report different delays; each is compared with a per-handle oracle run that starts
-at the stream's own time (*_init ... *_release): bit-exact for the integer stages and the float NS, <= 1 LSB for the AEC.
+at the stream's own time (*_init ... *_release): bit-exact, the float stages too.
 """
 import numpy as np
 import pytest

@@ -27,8 +27,8 @@
 //                    A wave spends more of its life waiting for data than issuing (DESIGN_HISTORY.md section 5), so every
 //                    global request of a phase goes out in one batch, a phase early where registers allow, and
 //                    wave-uniform far-end data takes the scalar path.
-// Float expressions, their order and the ordered sums follow the reference exactly (-ffp-contract=off); powf is the
-// table-driven double-precision evaluation of libm_dev.h, the rare log the library routine; cosf/sinf of the comfort
+// Float expressions, their order and the ordered sums follow the reference exactly (-ffp-contract=off); powf is glibc's
+// own algorithm restated in libm_dev.h (bit for bit the host's), the rare log the library routine; cosf/sinf of the comfort
 // noise come from the host's libm through the plan.
 #include <algorithm>
 #include <chrono>
