@@ -406,6 +406,11 @@ typedef struct wmx_mix wmx_mix;
 int wmx_mix_create(wmx_mix **out, int n_groups, int ring_chn, int ring_freq);
 int wmx_mix_destroy(wmx_mix *m);
 int wmx_mix_set(wmx_mix *m, uint32_t head_off, uint32_t tick, int reduce_mode); /* wmix->head/tick/reduceMode */
+/* VIEW_PLAY_CORRECT = PLAT_PLAY_CORRECT (src/wmixPlat.h:20; src/wmix.c:1668-1669): bytes in front of the play head where a source
+ * without a cursor starts.  Compile-time in the reference, per platform directory: platform/alsa/plat.h:21 chn*freq*16/8/5 (200 ms;
+ * what wmx_mix_create sets), platform/hi3516/plat.h:16 and platform/t31/plat.h:16 0.  A whole number of frames inside the ring, else
+ * WMX_EINVAL.  (The legacy wmix_load_data of wmix_compat.h reads WMIX_AMD_PLAY_CORRECT=<bytes> from the environment.) */
+int wmx_mix_set_play_correct(wmx_mix *m, uint32_t bytes);
 int wmx_mix_ring_bytes(const wmx_mix *m);
 int wmx_mix_load(wmx_mix *m, const int16_t *d_src, uint32_t srcU8Len, int freq, int channels, int sample, int n_src,
                  long group_stride, long source_stride, int reduce, uint32_t *head, uint32_t *tick, void *stream);
@@ -518,6 +523,10 @@ int wmx_tick_destroy(wmx_tick *h);
 /* webrtcEnable[WR_NS_PA] (src/wmix.c:1370-1386): on = 1 puts ns_process over the played package, in front of playPkgBuff_add (ns_init of
  * one suppressor per group now); on = 0 releases it */
 int wmx_tick_play_ns(wmx_tick *h, int on);
+/* the daemon of another platform directory: PLAT_AEC_INTERVALMS (alsa 400, hi3516 700, t31 0; plat.h:14/19) is wmx_tick_create's
+ * aec_delay_ms -- the FIFO gets AEC_FIFO_PKG_NUM = aec_delay_ms / interval_ms + 2 slots (src/wmixConf.h:141) -- and PLAT_PLAY_CORRECT is
+ * set here (wmx_mix_set_play_correct on the tick's rings; default platform/alsa's) */
+int wmx_tick_set_play_correct(wmx_tick *h, uint32_t bytes);
 int wmx_tick_package_samples(const wmx_tick *h); /* int16 elements of one package of one stream = WMIX_PKG_SIZE / 2 */
 int wmx_tick_load(wmx_tick *h, const int16_t *d_src, uint32_t srcU8Len, int freq, int channels, int sample, int n_src, long group_stride,
                   long source_stride, int reduce, uint32_t *head, uint32_t *tick, void *stream);

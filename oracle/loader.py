@@ -34,7 +34,10 @@ def have_ref():
     return os.path.exists(REF_SO)
 
 
-def have_ref_mix():
+def have_ref_mix(platform="alsa"):
+    if platform != "alsa":
+        exe = ref_mix_exe(platform)
+        return os.path.exists(exe) and os.access(exe, os.X_OK)
     return os.path.exists(REF_MIX) and os.access(REF_MIX, os.X_OK)
 
 
@@ -344,15 +347,18 @@ def mix_zoom(p, ic, ifr, x, oc, ofr):
     return out[: m // 2].copy()
 
 
-def mix_load(p, ring_chn, ring_freq, freq, chn, rmode, rarg, nsrc, sbytes, start, src):
+def mix_load(p, ring_chn, ring_freq, freq, chn, rmode, rarg, nsrc, sbytes, start, src, play_correct=None):
     """nsrc wmix_load_data calls in order (source i at src + i * sbytes bytes, each with a fresh head) into one fresh ring whose
-    head stands at byte `start`.  Returns (the ring as int16, [(tick, head) after each call])."""
+    head stands at byte `start`.  play_correct: VIEW_PLAY_CORRECT of the platform build in bytes (None = platform/alsa's formula,
+    which orc_mix_ring_init applies).  Returns (the ring as int16, [(tick, head) after each call])."""
     mix_bind(p)
     size = ring_chn * 2 * ring_freq
     store = np.zeros(size + 64, np.uint8)
     r = MixRing()
     p.orc_mix_ring_init(C.byref(r), store.ctypes.data_as(C.c_void_p), ring_chn, ring_freq)
     r.head_off, r.reduce_mode = start, rmode
+    if play_correct is not None:
+        r.play_correct = play_correct
     meta = []
     for i in range(nsrc):
         tick = C.c_uint32(0)
@@ -380,12 +386,13 @@ class _PkgFifo(C.Structure):  # orc_pkgfifo (oracle/orc_pkgfifo.c)
                 ("count", C.c_int)]
 
 
-def tick_port(lib, sources, local, src_freq, src_chn, stages=15, agc_value=5, aec_delay_ms=400):
+def tick_port(lib, sources, local, src_freq, src_chn, stages=15, agc_value=5, aec_delay_ms=400, play_correct=None):
     """ONE daemon (1 x 8000 Hz ring, 20 ms packages) over T ticks with the restatement, in the play thread's order (src/wmix.c:
     1347-1440 with wmix_shmem_write_circle inside): the task threads' orc_load_data calls (sources int16 [T, n_src, samples of
     20 ms]; every source keeps its cursor), the drain of one package, orc_pkgfifo add / get(aec_delay_ms) = the far-end, the room
     (tick_room), and per record stream (local int16 [T, n_rec, 160]) NS -> AEC(far) -> AGC -> VAD (`stages` bits 1 2 4 8) and the
-    zoom to 1 x 8000.  Returns dict(play [T,160], far [T,160], near [T,n_rec,160], out [T,n_rec,160], zoom [T,n_rec,160])."""
+    zoom to 1 x 8000.  aec_delay_ms / play_correct: the platform build's AEC_INTERVALMS / VIEW_PLAY_CORRECT (PLATFORMS; defaults =
+    platform/alsa).  Returns dict(play [T,160], far [T,160], near [T,n_rec,160], out [T,n_rec,160], zoom [T,n_rec,160])."""
     mix_bind(lib)
     T, n_src, per = sources.shape
     n_rec, N = local.shape[1], 160
@@ -395,6 +402,8 @@ def tick_port(lib, sources, local, src_freq, src_chn, stages=15, agc_value=5, ae
     r = MixRing()
     lib.orc_mix_ring_init(C.byref(r), store.ctypes.data_as(C.c_void_p), 1, 8000)
     r.reduce_mode = 1
+    if play_correct is not None:
+        r.play_correct = play_correct
     n_slots = aec_delay_ms // 20 + 2
     fstore = np.zeros(n_slots * 2 * N, np.uint8)
     f = _PkgFifo()
@@ -433,21 +442,32 @@ def tick_port(lib, sources, local, src_freq, src_chn, stages=15, agc_value=5, ae
     return {"play": play, "far": far, "near": near, "out": out, "zoom": zoom}
 
 
-def tick_ref(sources, local, src_freq, src_chn, stages=15, agc_value=5):
+def tick_ref(sources, local, src_freq, src_chn, stages=15, agc_value=5, platform="alsa"):
     """The same tick composed from the REAL functions (oracle/_ref/ref_mix_driver tick: wmix_load_data, playPkgBuff_add / _get,
     ns_process / aec_process2 / agc_process / vad_process, wmix_pcm_zoom as compiled from /root/reference).  Same arguments and
-    result as tick_port (no `near`)."""
+    result as tick_port (no `near`).  platform: which of the reference's platform builds (AEC_INTERVALMS and VIEW_PLAY_CORRECT are
+    compile-time there)."""
     T, n_src, per = sources.shape
     n_rec, N = local.shape[1], 160
     blob = b"".join(np.ascontiguousarray(sources[t]).tobytes() + np.ascontiguousarray(local[t]).tobytes() for t in range(T))
-    raw = np.frombuffer(ref_mix("tick", n_src, src_freq, src_chn, n_rec, T, stages, agc_value, stdin=blob), np.int16)
+    raw = np.frombuffer(ref_mix("tick", n_src, src_freq, src_chn, n_rec, T, stages, agc_value, stdin=blob, platform=platform), np.int16)
     raw = raw.reshape(T, 2 + 2 * n_rec, N)
     return {"play": raw[:, 0], "far": raw[:, 1], "out": raw[:, 2::2], "zoom": raw[:, 3::2]}
 
 
 # ---------------------------------------------------------------- reference mixer (executable)
-def ref_mix(*args, stdin=b""):
-    return subprocess.run([REF_MIX] + [str(a) for a in args], input=stdin, stdout=subprocess.PIPE, check=True).stdout
+# the reference's three platform builds (platform/<name>/plat.h:10-21): (PLAT_AEC_INTERVALMS, PLAT_PLAY_CORRECT in bytes).  The ring
+# is 1 x 8000 Hz in all of them; oracle/Makefile builds src/wmix.c and the driver once per header.
+PLATFORMS = {"alsa": (400, 3200), "hi3516": (700, 0), "t31": (0, 0)}
+
+
+def ref_mix_exe(platform="alsa"):
+    assert platform in PLATFORMS, platform
+    return REF_MIX if platform == "alsa" else REF_MIX + "_" + platform
+
+
+def ref_mix(*args, stdin=b"", platform="alsa"):
+    return subprocess.run([ref_mix_exe(platform)] + [str(a) for a in args], input=stdin, stdout=subprocess.PIPE, check=True).stdout
 
 
 # ---------------------------------------------------------------- hashing for golden files

@@ -17,11 +17,13 @@ pytestmark = pytest.mark.gpu
 G = np.load(os.path.join(GOLDEN, "mix_golden.npz"))
 
 
-def gpu_load(cuda, ring_chn, ring_freq, freq, chn, rmode, rarg, nsrc, sbytes, start, src, n_groups=1):
+def gpu_load(cuda, ring_chn, ring_freq, freq, chn, rmode, rarg, nsrc, sbytes, start, src, n_groups=1, play_correct=None):
     import torch
     from wmix_amd.mix import MixBatch
     mb = MixBatch(n_groups, ring_chn, ring_freq)
     mb.set(start, 0, rmode)
+    if play_correct is not None:
+        mb.set_play_correct(play_correct)
     per = sbytes // 2
     # sources back to back like the reference driver: source s starts at s*per, look-ahead reads the next one
     d = torch.from_numpy(np.ascontiguousarray(np.tile(src[None, :], (n_groups, 1)))).to(cuda)
@@ -69,19 +71,79 @@ def test_other_ring_formats_vs_oracle(cuda, oracle_port, ring_chn, ring_freq):
         assert np.array_equal(rings[0], want) and (t, h) == tuple(meta[-1])
 
 
+class Point(C.Union):
+    _fields_ = [("U8", C.c_void_p)]
+
+
+class Head(C.Structure):  # WMix_Struct_Head (include/wmix_compat.h)
+    _fields_ = [("objAo", C.c_void_p), ("objAi", C.c_void_p), ("buff", C.c_void_p), ("start", Point), ("end", Point), ("head", Point),
+                ("tail", Point), ("run", C.c_bool), ("loopWord", C.c_uint8), ("loopWordRecord", C.c_uint8), ("loopWordFifo", C.c_uint8),
+                ("loopWordRtp", C.c_uint8), ("tick", C.c_uint32), ("thread_sys", C.c_uint32), ("thread_record", C.c_uint32),
+                ("thread_play", C.c_uint32), ("playRun", C.c_bool), ("recordRun", C.c_bool), ("shmemRun", C.c_int), ("msg_key", C.c_int),
+                ("msg_fd", C.c_int), ("reduceMode", C.c_uint8)]
+
+
+def legacy_load(wmx, freq, chn, rmode, rarg, nsrc, sbytes, start, src):
+    """nsrc calls of the legacy wmix_load_data (NULL head each) into a fresh 1 x 8000 host ring -> (ring, [(tick, head)])"""
+    wmx.wmix_load_data.restype = Point
+    wmx.wmix_load_data.argtypes = [C.POINTER(Head), Point, C.c_uint32, C.c_uint16, C.c_uint8, C.c_uint8, Point, C.c_uint8, C.POINTER(C.c_uint32)]
+    ring = np.zeros(16000 // 2 + 8, np.int16)
+    w = Head()
+    w.start.U8 = ring.ctypes.data
+    w.end.U8 = ring.ctypes.data + 16000
+    w.head.U8 = ring.ctypes.data + start
+    w.run, w.reduceMode, w.tick = True, rmode, 0
+    meta = []
+    for s in range(nsrc):
+        tick = C.c_uint32(0)
+        sp, hp = Point(), Point()
+        sp.U8 = src.ctypes.data + s * sbytes
+        hp.U8 = None
+        r = wmx.wmix_load_data(C.byref(w), sp, sbytes, freq, chn, 16, hp, rarg, C.byref(tick))
+        meta.append((tick.value, r.U8 - ring.ctypes.data if r.U8 else None))
+    return ring[:8000].copy(), meta
+
+
+@pytest.mark.parametrize("platform", ["hi3516", "t31"])
+def test_play_correct_of_the_other_platform_builds(cuda, oracle_port, platform):
+    """PLAT_PLAY_CORRECT = 0 (platform/hi3516/plat.h:16, platform/t31/plat.h:16): a source without a cursor starts AT the play head
+    (src/wmix.c:1668-1669).  wmx_mix_set_play_correct against the restatement and -- where oracle/_ref travelled -- against
+    src/wmix.c compiled with that platform's header; then the legacy wmix_load_data with WMIX_AMD_PLAY_CORRECT=0 in a process of its
+    own (the adapter reads its environment once)."""
+    import subprocess
+    from conftest import ROOT
+    from oracle import loader as L
+    _bind(oracle_port)
+    correct = L.PLATFORMS[platform][1]
+    rng = np.random.default_rng(99)
+    for (freq, chn, rmode, rarg, nsrc, sbytes, start) in ((32000, 2, 1, 1, 3, 1280, 0), (8000, 1, 2, 1, 2, 320, 64), (11025, 2, 1, 1, 2, 884, 15872),
+                                                          (44100, 1, 4, 1, 3, 1764, 8000)):
+        src = rng.integers(-20000, 20000, size=nsrc * sbytes // 2 + 8, dtype=np.int16)
+        want, meta = L.mix_load(oracle_port, 1, 8000, freq, chn, rmode, rarg, nsrc, sbytes, start, src, play_correct=correct)
+        rings, h, t = gpu_load(cuda, 1, 8000, freq, chn, rmode, rarg, nsrc, sbytes, start, src, play_correct=correct)
+        assert np.array_equal(rings[0], want) and (t, h) == tuple(meta[-1])
+        if L.have_ref_mix(platform):
+            b = L.ref_mix("load", freq, chn, rmode, rarg, nsrc, sbytes, start, stdin=src.tobytes(), platform=platform)
+            assert np.array_equal(rings[0], np.frombuffer(b[:16000], dtype=np.int16))
+    code = ("import sys, numpy as np; sys.path[:0] = [%r, %r]; from wmix_amd import _lib; from test_mix_gpu import legacy_load;"
+            "src = np.random.default_rng(5).integers(-20000, 20000, size=2000, dtype=np.int16);"
+            "ring, meta = legacy_load(_lib.lib(), 32000, 2, 1, 1, 3, 1280, 600, src); np.save(sys.argv[1], ring); print(meta)")
+    env = dict(os.environ, WMIX_AMD_PLAY_CORRECT=str(correct))
+    out = os.path.join(os.environ.get("TMPDIR", "/tmp"), "legacy_ring_%s_%d.npy" % (platform, os.getpid()))
+    r = subprocess.run([sys.executable, "-c", code % (ROOT, os.path.join(ROOT, "tests")), out], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    src = np.random.default_rng(5).integers(-20000, 20000, size=2000, dtype=np.int16)
+    want, meta = L.mix_load(oracle_port, 1, 8000, 32000, 2, 1, 1, 3, 1280, 600, src, play_correct=correct)
+    assert np.array_equal(np.load(out), want) and r.stdout.strip().splitlines()[-1] == str([(int(a), int(b)) for a, b in meta])
+    os.remove(out)
+    bad = subprocess.run([sys.executable, "-c", code % (ROOT, os.path.join(ROOT, "tests")), out], env=dict(env, WMIX_AMD_PLAY_CORRECT="16001"),
+                         capture_output=True, text=True, timeout=300)  # not inside the ring: every call refuses, the ring stays empty
+    assert bad.returncode == 0 and "WMIX_AMD_PLAY_CORRECT=16001" in bad.stderr and not np.load(out).any()
+    os.remove(out)
+
+
 def test_legacy_wmix_load_data_signature(wmx):
     """WMix_Point wmix_load_data(WMix_Struct*, ...) over a host ring (src/wmix.h:40-49), default 1 x 8000 ring."""
-
-    class Point(C.Union):
-        _fields_ = [("U8", C.c_void_p)]
-
-    class Head(C.Structure):  # WMix_Struct_Head (include/wmix_compat.h)
-        _fields_ = [("objAo", C.c_void_p), ("objAi", C.c_void_p), ("buff", C.c_void_p), ("start", Point), ("end", Point), ("head", Point),
-                    ("tail", Point), ("run", C.c_bool), ("loopWord", C.c_uint8), ("loopWordRecord", C.c_uint8), ("loopWordFifo", C.c_uint8),
-                    ("loopWordRtp", C.c_uint8), ("tick", C.c_uint32), ("thread_sys", C.c_uint32), ("thread_record", C.c_uint32),
-                    ("thread_play", C.c_uint32), ("playRun", C.c_bool), ("recordRun", C.c_bool), ("shmemRun", C.c_int), ("msg_key", C.c_int),
-                    ("msg_fd", C.c_int), ("reduceMode", C.c_uint8)]
-
     wmx.wmix_load_data.restype = Point
     wmx.wmix_load_data.argtypes = [C.POINTER(Head), Point, C.c_uint32, C.c_uint16, C.c_uint8, C.c_uint8, Point, C.c_uint8, C.POINTER(C.c_uint32)]
     i = 2

@@ -76,3 +76,25 @@ def test_against_real_reference_fresh_inputs(oracle_port):
             ring, meta = orc_load(oracle_port, 1, 8000, freq, chn, rmode, rarg, nsrc, sbytes, start, src)
             assert np.array_equal(ring, np.frombuffer(b[:16000], dtype=np.int16))
             assert np.array_equal(meta, np.frombuffer(b[16000:], dtype=np.uint32).reshape(nsrc, 2))
+
+
+@pytest.mark.parametrize("platform", ["hi3516", "t31"])
+def test_against_the_other_platform_builds(oracle_port, platform):
+    """The reference's hi3516 and t31 builds (platform/<name>/plat.h:10-16) place a fresh source AT the play head:
+    PLAT_PLAY_CORRECT is 0 there, 3200 bytes in platform/alsa (src/wmix.c:1668-1669).  src/wmix.c compiled against each header
+    (oracle/Makefile) vs the restatement with that constant."""
+    if not L.have_ref_mix(platform):
+        pytest.skip("oracle/_ref/ref_mix_driver_%s not present" % platform)
+    _bind(oracle_port)
+    aec_ms, correct = L.PLATFORMS[platform]
+    assert L.ref_mix("consts", platform=platform).split() == [b"1", b"8000", b"16000", str(correct).encode()]
+    rng = np.random.default_rng(4321)
+    for (freq, chn) in ((8000, 1), (32000, 2), (44100, 1), (12000, 1)):
+        for (rmode, rarg, nsrc, sbytes, start) in ((1, 1, 5, 1000, 0), (4, 1, 3, 2000, 15000), (2, 2, 2, 400, 15998)):
+            src = rng.integers(-25000, 25000, size=nsrc * sbytes // 2 + 8, dtype=np.int16)
+            b = L.ref_mix("load", freq, chn, rmode, rarg, nsrc, sbytes, start, stdin=src.tobytes(), platform=platform)
+            ring, meta = L.mix_load(oracle_port, 1, 8000, freq, chn, rmode, rarg, nsrc, sbytes, start, src, play_correct=correct)
+            assert np.array_equal(ring, np.frombuffer(b[:16000], dtype=np.int16))
+            assert np.array_equal(meta, np.frombuffer(b[16000:], dtype=np.uint32).reshape(nsrc, 2))
+            other, _ = L.mix_load(oracle_port, 1, 8000, freq, chn, rmode, rarg, nsrc, sbytes, start, src)  # platform/alsa's 3200
+            assert not np.array_equal(other, ring)

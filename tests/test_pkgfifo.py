@@ -15,10 +15,10 @@ class Fifo(C.Structure):
                 ("count", C.c_int)]
 
 
-def orc_run(port, pkts, delay):
-    store = np.zeros(SLOTS * PKG, np.uint8)
+def orc_run(port, pkts, delay, slots=SLOTS):
+    store = np.zeros(slots * PKG, np.uint8)
     f = Fifo()
-    port.orc_pkgfifo_init(C.byref(f), store.ctypes.data_as(C.c_void_p), SLOTS, PKG, 20, 2)
+    port.orc_pkgfifo_init(C.byref(f), store.ctypes.data_as(C.c_void_p), slots, PKG, 20, 2)
     out, rcs = [], []
     for p in pkts:
         port.orc_pkgfifo_add(C.byref(f), np.ascontiguousarray(p).ctypes.data_as(C.c_void_p))
@@ -39,6 +39,28 @@ def test_oracle_against_real_reference(oracle_port, delay):
     want = np.frombuffer(loader.ref_mix("pkgfifo", delay, stdin=pk.tobytes()), np.uint8).reshape(-1, PKG)
     got, rcs = orc_run(oracle_port, pk, delay)
     assert not any(rcs) and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("platform", ["hi3516", "t31"])
+def test_oracle_against_the_other_platform_builds(oracle_port, platform):
+    """AEC_FIFO_PKG_NUM = AEC_INTERVALMS / WMIX_INTERVAL_MS + 2 (src/wmixConf.h:141) is 37 slots in the hi3516 build (700 ms) and 2
+    in the t31 build (0 ms).  The real playPkgBuff_add / _get of each build against the
+    restatement with that many slots: the build's own delay, and delays on both sides of what the FIFO can hold."""
+    if not loader.have_ref_mix(platform):
+        pytest.skip("oracle/_ref/ref_mix_driver_%s not present" % platform)
+    aec_ms = loader.PLATFORMS[platform][0]
+    slots = aec_ms // 20 + 2
+    for delay in sorted({aec_ms, 0, 20, 40, max(aec_ms - 20, 0), aec_ms + 20, aec_ms + 40, 1000}):
+        pk = packets(100, delay + 1)
+        want = np.frombuffer(loader.ref_mix("pkgfifo", delay, stdin=pk.tobytes(), platform=platform), np.uint8).reshape(-1, PKG)
+        got, rcs = orc_run(oracle_port, pk, delay, slots=slots)
+        assert not any(rcs) and np.array_equal(got, want), delay
+    if aec_ms == 0:
+        # what the t31 daemon's canceller is given (src/wmix.c:494-510 with delayms 0: pkgCount = count - count = 0, always slot 0,
+        # which playPkgBuff_add refreshes every SECOND tick): the package just played on even ticks, the one before it on odd ticks
+        pk = packets(10, 3)
+        got, _ = orc_run(oracle_port, pk, 0, slots=slots)
+        assert np.array_equal(got, pk[np.arange(10) & ~1])
 
 
 @pytest.mark.skipif(not loader.have_ref_mix(), reason="real reference not built here")

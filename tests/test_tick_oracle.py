@@ -43,3 +43,23 @@ def test_port_tick_equals_the_real_functions(oracle_port, src_freq, src_chn, n_s
         assert not np.array_equal(plain["play"], a["play"]) and not np.array_equal(plain["out"], a["out"])
     if stages & 2:
         assert np.abs(a["out"][60:].astype(np.int32)).mean() < np.abs(a["near"][60:].astype(np.int32)).mean()
+
+
+@pytest.mark.parametrize("platform", ["hi3516", "t31"])
+@pytest.mark.parametrize("src_freq,src_chn,n_src,n_rec,stages,T", [(32000, 2, 3, 2, 15, 150), (8000, 1, 2, 1, 15 | 16, 110)])
+def test_port_tick_equals_the_other_platform_builds(oracle_port, platform, src_freq, src_chn, n_src, n_rec, stages, T):
+    """The hi3516 and t31 daemons (platform/<name>/plat.h:10-16): far-end 700 ms / 0 ms behind the playback, 37 / 2 FIFO slots, and a
+    fresh source lands AT the play head (PLAT_PLAY_CORRECT 0).  The whole tick of each build against the restatement."""
+    if not L.have_ref_mix(platform):
+        pytest.skip("oracle/_ref/ref_mix_driver_%s not present" % platform)
+    aec_ms, correct = L.PLATFORMS[platform]
+    src, local = tick_inputs(31 + n_src, T, n_src, n_rec, src_freq, src_chn)
+    a = L.tick_port(oracle_port, src, local, src_freq, src_chn, stages=stages, aec_delay_ms=aec_ms, play_correct=correct)
+    b = L.tick_ref(src, local, src_freq, src_chn, stages=stages, platform=platform)
+    for k in ("play", "far", "out", "zoom"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["play"][0].any()  # no 200 ms of lead: the first package already plays
+    if aec_ms == 0:  # slot 0 of 2, refreshed every second tick (tests/test_pkgfifo.py): this tick's package, or the previous one
+        assert np.array_equal(a["far"], a["play"][np.arange(T) & ~1])
+    alsa = L.tick_port(oracle_port, src, local, src_freq, src_chn, stages=stages)
+    assert not np.array_equal(alsa["out"], a["out"])

@@ -151,6 +151,8 @@ def _declare(L):
     L.wmx_tick_destroy.argtypes = [vp]
     L.wmx_tick_play_ns.restype = i
     L.wmx_tick_play_ns.argtypes = [vp, i]
+    L.wmx_tick_set_play_correct.restype = i
+    L.wmx_tick_set_play_correct.argtypes = [vp, C.c_uint32]
     L.wmx_tick_package_samples.restype = i
     L.wmx_tick_package_samples.argtypes = [vp]
     L.wmx_tick_load.restype = i
@@ -324,6 +326,8 @@ def _declare(L):
     L.wmx_mix_destroy.argtypes = [vp]
     L.wmx_mix_set.restype = i
     L.wmx_mix_set.argtypes = [vp, u32, u32, i]
+    L.wmx_mix_set_play_correct.restype = i
+    L.wmx_mix_set_play_correct.argtypes = [vp, u32]
     L.wmx_mix_ring_bytes.restype = i
     L.wmx_mix_ring_bytes.argtypes = [vp]
     L.wmx_mix_load.restype = i

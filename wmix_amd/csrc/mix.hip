@@ -270,6 +270,18 @@ int wmx_mix_set(wmx_mix *m, uint32_t head_off, uint32_t tick, int reduce_mode) {
     return 0;
 }
 
+// VIEW_PLAY_CORRECT (src/wmixPlat.h:20, src/wmix.c:1668-1669): how far in front of the play head a source without a cursor of its
+// own starts.  A compile-time constant of the reference's platform directory: 200 ms of ring in platform/alsa (the default of
+// wmx_mix_create), 0 in platform/hi3516 and platform/t31 (plat.h:16).
+int wmx_mix_set_play_correct(wmx_mix *m, uint32_t bytes) {
+    if (!m || bytes >= m->ring_bytes || bytes % (uint32_t)(m->chn * 2)) {
+        wmx::set_error("wmx_mix_set_play_correct: %u bytes is not a whole frame inside the ring", bytes);
+        return WMX_EINVAL;
+    }
+    m->play_correct = bytes;
+    return 0;
+}
+
 int wmx_mix_ring_bytes(const wmx_mix *m) { return m ? (int)m->ring_bytes : WMX_EINVAL; }
 
 // wmix_load_data for every group: n_src sources per group (source s of group g at d_src + g*group_stride +
@@ -354,14 +366,22 @@ int wmx_mix_drain(wmx_mix *m, int16_t *d_out, uint32_t bytes, long out_stride, v
 
 // legacy host form, src/wmix.h:40-49.  The ring format is the reference's compile-time WMIX_CHN x WMIX_FREQ; the
 // default platform is 1 x 8000 (platform/alsa/plat.h:48-50).  A differently configured daemon sets
-// WMIX_AMD_RING="chn,freq" in the environment.
+// WMIX_AMD_RING="chn,freq" in the environment, and one built for platform/hi3516 or platform/t31 WMIX_AMD_PLAY_CORRECT=0
+// (PLAT_PLAY_CORRECT in bytes, plat.h:16; unset = platform/alsa's 200 ms).
 WMix_Point wmix_load_data(WMix_Struct_Head *wmix, WMix_Point src, uint32_t srcU8Len, uint16_t freq, uint8_t channels, uint8_t sample,
                           WMix_Point head, uint8_t reduce, uint32_t *tick) {
     using namespace wmx;
     WMix_Point pHead = head;
     if (!wmix || !wmix->run || !src.U8 || srcU8Len < 1) return pHead;  // src/wmix.c:1663-1664
     static int ring_chn = 0, ring_freq = 0;
+    static long play_correct = -1;  // -1: the default of wmx_mix_create
     if (!ring_chn) {
+        const char *pc = getenv("WMIX_AMD_PLAY_CORRECT");
+        char *endp = nullptr;
+        if (pc && pc[0]) {
+            const long v = strtol(pc, &endp, 10);
+            if (endp && !*endp && v >= 0) play_correct = v;
+        }
         ring_chn = 1;
         ring_freq = 8000;
         const char *env = getenv("WMIX_AMD_RING");
@@ -386,6 +406,12 @@ WMix_Point wmix_load_data(WMix_Struct_Head *wmix, WMix_Point src, uint32_t srcU8
         if (m) wmx_mix_destroy(m);
         m = nullptr;
         if (wmx_mix_create(&m, 1, ring_chn, ring_freq) != 0) return pHead;
+        if (play_correct >= 0 && wmx_mix_set_play_correct(m, (uint32_t)play_correct) != 0) {
+            fprintf(stderr, "wmix_amd: WMIX_AMD_PLAY_CORRECT=%ld: %s\n", play_correct, wmx_last_error());
+            wmx_mix_destroy(m);
+            m = nullptr;
+            return pHead;
+        }
     }
     if (size != m->ring_bytes) {
         set_error("wmix_load_data: ring of %u bytes does not match WMIX_AMD_RING=%d,%d", size, ring_chn, ring_freq);

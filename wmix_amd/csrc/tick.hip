@@ -93,6 +93,9 @@ int wmx_tick_create(wmx_tick **out, int n_groups, int rec_per_group, int chn, in
     return 0;
 }
 
+// The platform build's PLAT_PLAY_CORRECT (wmx_mix_set_play_correct); its PLAT_AEC_INTERVALMS is wmx_tick_create's aec_delay_ms.
+int wmx_tick_set_play_correct(wmx_tick *h, uint32_t bytes) { return h ? wmx_mix_set_play_correct(h->mix, bytes) : WMX_EINVAL; }
+
 // webrtcEnable[WR_NS_PA] (src/wmix.c:1370-1386): the played package goes through ns_process on its way out -- BEFORE playPkgBuff_add,
 // so the echo cancellers hear the suppressed playback too.  on = 1: ns_init of one suppressor per group (the switch coming on);
 // on = 0: ns_release.

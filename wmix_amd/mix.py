@@ -41,6 +41,10 @@ class MixBatch:
         self.n_groups = n_groups
         self.ring_bytes = lib().wmx_mix_ring_bytes(self._h)
 
+    def set_play_correct(self, n_bytes):
+        """VIEW_PLAY_CORRECT of the reference's platform build (platform/<name>/plat.h): alsa 200 ms of ring (the default), hi3516 / t31 0"""
+        check(lib().wmx_mix_set_play_correct(self._h, n_bytes), "wmx_mix_set_play_correct")
+
     def set(self, head_off=0, tick=0, reduce_mode=1):
         check(lib().wmx_mix_set(self._h, head_off, tick, reduce_mode), "wmx_mix_set")
 

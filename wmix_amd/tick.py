@@ -12,9 +12,20 @@ NULL_HEAD = 0xFFFFFFFF
 
 
 class TickBatch:
+    # the reference's platform directories (platform/<name>/plat.h): (PLAT_AEC_INTERVALMS, PLAT_PLAY_CORRECT in bytes of a 1 x 8000 ring)
+    PLATFORMS = {"alsa": (400, 3200), "hi3516": (700, 0), "t31": (0, 0)}
+
+    @classmethod
+    def for_platform(cls, platform, n_groups, rec_per_group=1, agc_value=5, stages=NS | AEC | AGC | VAD):
+        """the daemon as built from platform/<platform>: 1 x 8000 Hz, 20 ms, that header's echo delay and play-head lead"""
+        aec_ms, correct = cls.PLATFORMS[platform]
+        tb = cls(n_groups, rec_per_group, 1, 8000, 20, aec_ms, agc_value, stages)
+        check(lib().wmx_tick_set_play_correct(tb._h, correct), "wmx_tick_set_play_correct")
+        return tb
+
     def __init__(self, n_groups, rec_per_group=1, chn=1, freq=8000, interval_ms=20, aec_delay_ms=400, agc_value=5,
                  stages=NS | AEC | AGC | VAD):
-        """defaults = the shipped platform: 1 x 8000 Hz, WMIX_INTERVAL_MS 20, AEC_INTERVALMS 400, volumeAgc 5"""
+        """defaults = the shipped platform (platform/alsa): 1 x 8000 Hz, WMIX_INTERVAL_MS 20, AEC_INTERVALMS 400, volumeAgc 5"""
         self._h = C.c_void_p()
         rc = lib().wmx_tick_create(C.byref(self._h), n_groups, rec_per_group, chn, freq, interval_ms, aec_delay_ms, agc_value, stages)
         if rc != 0:
