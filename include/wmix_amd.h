@@ -523,6 +523,10 @@ int wmx_tick_destroy(wmx_tick *h);
 /* webrtcEnable[WR_NS_PA] (src/wmix.c:1370-1386): on = 1 puts ns_process over the played package, in front of playPkgBuff_add (ns_init of
  * one suppressor per group now); on = 0 releases it */
 int wmx_tick_play_ns(wmx_tick *h, int on);
+/* wmix->rwTest (src/wmix.c:714-732), the self send-receive test: while on, wmx_tick_record loads the chain's output of each group's
+ * first record stream back into the group's play ring (wmix_load_data with the heartbeat's own cursor, reduce 1) before the zoom;
+ * switching it off forgets the cursor (:728-732) */
+int wmx_tick_rw_test(wmx_tick *h, int on);
 /* the daemon of another platform directory: PLAT_AEC_INTERVALMS (alsa 400, hi3516 700, t31 0; plat.h:14/19) is wmx_tick_create's
  * aec_delay_ms -- the FIFO gets AEC_FIFO_PKG_NUM = aec_delay_ms / interval_ms + 2 slots (src/wmixConf.h:141) -- and PLAT_PLAY_CORRECT is
  * set here (wmx_mix_set_play_correct on the tick's rings; default platform/alsa's) */

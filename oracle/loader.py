@@ -390,8 +390,10 @@ def tick_port(lib, sources, local, src_freq, src_chn, stages=15, agc_value=5, ae
     """ONE daemon (1 x 8000 Hz ring, 20 ms packages) over T ticks with the restatement, in the play thread's order (src/wmix.c:
     1347-1440 with wmix_shmem_write_circle inside): the task threads' orc_load_data calls (sources int16 [T, n_src, samples of
     20 ms]; every source keeps its cursor), the drain of one package, orc_pkgfifo add / get(aec_delay_ms) = the far-end, the room
-    (tick_room), and per record stream (local int16 [T, n_rec, 160]) NS -> AEC(far) -> AGC -> VAD (`stages` bits 1 2 4 8) and the
-    zoom to 1 x 8000.  aec_delay_ms / play_correct: the platform build's AEC_INTERVALMS / VIEW_PLAY_CORRECT (PLATFORMS; defaults =
+    (tick_room), and per record stream (local int16 [T, n_rec, 160]) NS -> AEC(far) -> AGC -> VAD (`stages` bits 1 2 4 8; bit 16 =
+    WR_NS_PA over the playback; bit 32 = wmix->rwTest: record stream 0's output goes back into the play ring through orc_load_data
+    with a cursor of its own, src/wmix.c:714-732 -- a feedback loop through loudspeaker, room and cancellers) and the zoom to
+    1 x 8000.  aec_delay_ms / play_correct: the platform build's AEC_INTERVALMS / VIEW_PLAY_CORRECT (PLATFORMS; defaults =
     platform/alsa).  Returns dict(play [T,160], far [T,160], near [T,n_rec,160], out [T,n_rec,160], zoom [T,n_rec,160])."""
     mix_bind(lib)
     T, n_src, per = sources.shape
@@ -416,6 +418,12 @@ def tick_port(lib, sources, local, src_freq, src_chn, stages=15, agc_value=5, ae
         ns_pa = _fn(lib, "orc_ns_init", C.c_void_p, [C.c_int, C.c_int])(1, 8000)
         ns_run = _fn(lib, "orc_ns_run", None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int])
         assert ns_pa
+    zero = np.zeros(N, np.int16)
+    near, out = np.zeros((T, n_rec, N), np.int16), np.zeros((T, n_rec, N), np.int16)
+    c_open = _fn(lib, "orc_chain_open", C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint])
+    c_step = _fn(lib, "orc_chain_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int])
+    chains = [c_open(1, 8000, 20, agc_value, stages & 15) for _ in range(n_rec)]
+    rw_head, rw_tick, rw_pad = 0xFFFFFFFF, C.c_uint32(0), np.zeros(N + 8, np.int16)
     for t in range(T):
         for i in range(n_src):
             pad[:per] = sources[t, i]
@@ -430,14 +438,17 @@ def tick_port(lib, sources, local, src_freq, src_chn, stages=15, agc_value=5, ae
             ns_run(ns_pa, play[t].ctypes.data, play[t].ctypes.data, N)
         lib.orc_pkgfifo_add(C.byref(f), play[t].ctypes.data_as(C.c_void_p))
         assert lib.orc_pkgfifo_get(C.byref(f), far[t].ctypes.data_as(C.c_void_p), aec_delay_ms) == 0
+        near[t] = tick_room(local[t], far[t], far[t - 1] if t else zero)
+        out[t] = near[t]
+        for k in range(n_rec):  # the record heartbeat of handle set k, in place
+            assert c_step(chains[k], far[t].ctypes.data, out[t, k].ctypes.data, N) == 0
+        if stages & 32:
+            rw_pad[:N] = out[t, 0]
+            rw_head = lib.orc_load_data(C.byref(r), rw_pad.ctypes.data_as(C.c_void_p), 2 * N, 8000, 1, 16, C.c_uint32(rw_head), 1, C.byref(rw_tick))
     if ns_pa:
         _fn(lib, "orc_ns_release", None, [C.c_void_p])(ns_pa)
-    zero = np.zeros(N, np.int16)
-    near = np.stack([tick_room(local[t], far[t], far[t - 1] if t else zero) for t in range(T)])  # [T, n_rec, N]
-    out = np.zeros_like(near)
-    for k in range(n_rec):
-        out[:, k] = run_chain(lib, 1, 8000, agc_value, stages & 15, far.reshape(-1), near[:, k].reshape(-1), N, prefix="orc",
-                              interval_ms=20).reshape(T, N)
+    for c in chains:
+        _fn(lib, "orc_chain_close", None, [C.c_void_p])(c)
     zoom = np.stack([np.stack([mix_zoom(lib, 1, 8000, out[t, k], 1, 8000) for k in range(n_rec)]) for t in range(T)])
     return {"play": play, "far": far, "near": near, "out": out, "zoom": zoom}
 

@@ -38,3 +38,45 @@ int orc_run_chain(int chn, int freq, int agc_value, unsigned stages, const int16
 {
     return orc_run_chain_iv(chn, freq, 10, agc_value, stages, far, nearp, out, frames_per_call, n_calls);
 }
+
+/* the same heartbeat as a handle set that lives across calls (what the daemon keeps in wmix->webrtcPoint[], src/wmix.c:613-709):
+ * one call = one package through the enabled stages, in place */
+typedef struct {
+    orc_ns *ns;
+    orc_aec *aec;
+    orc_agc *agc;
+    orc_vad *vad;
+    int chn;
+} orc_chain;
+
+orc_chain *orc_chain_open(int chn, int freq, int interval_ms, int agc_value, unsigned stages)
+{
+    orc_chain *c = (orc_chain *)calloc(1, sizeof(*c));
+    if (!c) return NULL;
+    c->chn = chn;
+    c->ns = (stages & 1) ? orc_ns_init(chn, freq) : NULL;
+    c->aec = (stages & 2) ? orc_aec_init(chn, freq, interval_ms) : NULL;
+    c->agc = (stages & 4) ? orc_agc_init(chn, freq, interval_ms, agc_value) : NULL;
+    c->vad = (stages & 8) ? orc_vad_init(chn, freq, interval_ms) : NULL;
+    return c;
+}
+
+int orc_chain_step(orc_chain *c, const int16_t *far, int16_t *pcm, int frames)
+{
+    int rc = 0;
+    if (c->ns) orc_ns_run(c->ns, pcm, pcm, frames);
+    if (c->aec) rc = orc_aec_process2(c->aec, far, pcm, pcm, frames, 0);
+    if (c->agc && rc == 0) rc = orc_agc_run(c->agc, pcm, pcm, frames);
+    if (c->vad && rc == 0) orc_vad_run(c->vad, pcm, frames);
+    return rc;
+}
+
+void orc_chain_close(orc_chain *c)
+{
+    if (!c) return;
+    if (c->ns) orc_ns_release(c->ns);
+    if (c->aec) orc_aec_release(c->aec);
+    if (c->agc) orc_agc_release(c->agc);
+    if (c->vad) orc_vad_release(c->vad);
+    free(c);
+}

@@ -33,7 +33,8 @@
  *        and tick move on, wrap -- :1347-1366), playPkgBuff_add, playPkgBuff_get(AEC_INTERVALMS) = the far-end, the room (near =
  *        sat(local + far delayed by 40 samples >> 1): the harness' own input model), then per record handle set ns_process ->
  *        aec_process2(far, near, near, .., 0) -> agc_process -> vad_process (:613-709, `stages` bits 1 2 4 8 = the webrtcEnable
- *        switches; bit 16 = WR_NS_PA: ns_process over the played package in front of playPkgBuff_add, :1370-1386) and wmix_pcm_zoom to 1 x 8000 (:730).  Written per tick: played package, far-end package, then per record handle set
+ *        switches; bit 16 = WR_NS_PA: ns_process over the played package in front of playPkgBuff_add, :1370-1386; bit 32 = wmix->rwTest:
+ *        record handle set 0's output goes back into the play ring through wmix_load_data with a cursor of its own, :714-732) and wmix_pcm_zoom to 1 x 8000 (:730).  Written per tick: played package, far-end package, then per record handle set
  *        its chain output and the zoomed copy (2 * 8000 * WMIX_INTERVAL_MS / 1000 bytes).
  *   ref_mix_driver rtprecv <packets.bin >pcm.bin
  *        every [uint32 len][bytes] record is sent to a socket opened with rtp_socket(bind) and taken through
@@ -194,6 +195,8 @@ int main(int argc, char **argv)
         uint8_t playBuff[WMIX_PKG_SIZE], farBuff[WMIX_PKG_SIZE], buffSrc[WMIX_PKG_SIZE];
         uint8_t buffDist[2 * 8000 * WMIX_INTERVAL_MS / 1000 + 64];
         const int echo_delay = 40;
+        WMix_Point rwTestSrc = {.U8 = 0}, rwTestHead = {.U8 = 0}; /* wmix->rwTest, src/wmix.c:531-532, 714-732 */
+        uint32_t rwTick = 0;
         for (int t = 0; t < nticks; t++) {
             const unsigned char *p = in + (size_t)t * per_tick;
             for (int i = 0; i < nsrc; i++) { /* the task threads */
@@ -235,6 +238,10 @@ int main(int argc, char **argv)
                 if (aec[r] && aec_process2(aec[r], (int16_t *)farBuff, near, near, WMIX_FRAME_NUM, 0) != 0) return 9;
                 if (agc[r] && agc_process(agc[r], near, near, WMIX_FRAME_NUM) != 0) return 10;
                 if (vad[r]) vad_process(vad[r], near, WMIX_FRAME_NUM);
+                if ((stages & 32) && r == 0) { /* the self send-receive test: what was recorded goes back into the play ring */
+                    rwTestSrc.U8 = buffSrc;
+                    rwTestHead = wmix_load_data(w, rwTestSrc, WMIX_PKG_SIZE, WMIX_FREQ, WMIX_CHN, WMIX_SAMPLE, rwTestHead, 1, &rwTick);
+                }
                 fwrite(buffSrc, 1, WMIX_PKG_SIZE, stdout);
                 memset(buffDist, 0, sizeof(buffDist));
                 wmix_pcm_zoom(WMIX_CHN, WMIX_FREQ, buffSrc, WMIX_PKG_SIZE, 1, 8000, buffDist);

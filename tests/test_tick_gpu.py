@@ -25,7 +25,7 @@ def room(local, far, prev_far):
     return torch.clamp(local.to(torch.int32) + echo, -32768, 32767).to(torch.int16)
 
 
-def gpu_tick(cuda, src, local, src_freq, src_chn, stages, agc_value=5, platform="alsa"):
+def gpu_tick(cuda, src, local, src_freq, src_chn, stages, agc_value=5, platform="alsa", rw_test=None):
     """src [G, T, n_src, per], local [G, T, R, 160] -> dict of numpy arrays shaped like tick_port's, per group"""
     from wmix_amd.tick import TickBatch
     G, T, n_src, per = src.shape
@@ -43,6 +43,8 @@ def gpu_tick(cuda, src, local, src_freq, src_chn, stages, agc_value=5, platform=
     zoom = torch.zeros((T, G * R, 160), dtype=torch.int16, device=cuda)
     prev = torch.zeros((G, 160), dtype=torch.int16, device=cuda)
     for t in range(T):
+        if rw_test is not None:
+            tb.rw_test(rw_test[0] <= t < rw_test[1])  # wmix->rwTest on for ticks [a, b)
         tb.load(dsrc[t], per * 2, src_freq, src_chn)
         f = tb.play(play[t])
         far[t].copy_(f)
@@ -139,3 +141,32 @@ def test_tick_of_the_other_platform_builds(cuda, oracle_port, platform):
     assert got["play"][0][0].any()  # no 200 ms of lead in these builds
     alsa = gpu_tick(cuda, src[:1], local[:1], src_freq, src_chn, 15)
     assert not alsa["play"][0][0].any() and not np.array_equal(alsa["out"][0], got["out"][0])
+
+
+@pytest.mark.parametrize("platform", ["alsa", "t31"])
+def test_tick_with_the_self_send_receive_test(cuda, oracle_port, platform):
+    """wmix->rwTest (src/wmix.c:714-732) on the device: wmx_tick_rw_test makes wmx_tick_record load the first record stream of every
+    group back into that group's ring.  Against one daemon per group (restatement; the real functions where oracle/_ref
+    travelled), and: switching it off and on again forgets the cursor like the reference does."""
+    aec_ms, correct = L.PLATFORMS[platform]
+    G, T, n_src, R = 3, 140, 2, 2
+    per_group = [tick_inputs(800 + g, T, n_src, R, 16000, 1) for g in range(G)]
+    src = np.stack([p[0] for p in per_group])
+    local = np.stack([p[1] for p in per_group])
+    src[:, 40:] = 0
+    got = gpu_tick(cuda, src, local, 16000, 1, 15, platform=platform, rw_test=(0, T))
+    for g in range(G):
+        want = L.tick_port(oracle_port, src[g], local[g], 16000, 1, stages=15 | 32, aec_delay_ms=aec_ms, play_correct=correct)
+        for k in ("play", "far", "out"):
+            assert np.array_equal(got[k][g], want[k]), (k, g)
+        if L.have_ref_mix(platform) and g == 1:
+            real = L.tick_ref(src[g], local[g], 16000, 1, stages=15 | 32, platform=platform)
+            for k in ("play", "far", "out", "zoom"):
+                assert np.array_equal(got[k][g], real[k]), (k, "real")
+    assert got["play"][0][60:].any()
+    # on for ticks [0, 50), off, on again from 90: the second run starts from a fresh cursor (head + VIEW_PLAY_CORRECT), so the
+    # loudspeaker is silent from where the first run's last package ended until the second run's first package comes up
+    two = gpu_tick(cuda, src[:1], local[:1], 16000, 1, 15, platform=platform, rw_test=(0, 50))
+    lead = 1 + correct // 320
+    assert two["play"][0][49 + lead].any() and not two["play"][0][50 + lead:].any()
+    assert np.array_equal(two["play"][0][:50 + lead], got["play"][0][:50 + lead])

@@ -63,3 +63,24 @@ def test_port_tick_equals_the_other_platform_builds(oracle_port, platform, src_f
         assert np.array_equal(a["far"], a["play"][np.arange(T) & ~1])
     alsa = L.tick_port(oracle_port, src, local, src_freq, src_chn, stages=stages)
     assert not np.array_equal(alsa["out"], a["out"])
+
+
+@pytest.mark.parametrize("platform", ["alsa", "t31"])
+def test_port_tick_with_the_self_send_receive_test(oracle_port, platform):
+    """wmix->rwTest (src/wmix.c:714-732): the heartbeat loads what it recorded back into the play ring with a cursor of its own --
+    a loop through loudspeaker, FIFO, room and cancellers.  Stage bit 32 of both compositions; two record handle sets, of which the
+    first feeds the ring (the daemon has one)."""
+    if not L.have_ref_mix(platform):
+        pytest.skip("oracle/_ref/ref_mix_driver_%s not present" % platform)
+    aec_ms, correct = L.PLATFORMS[platform]
+    T, n_src, n_rec = 140, 2, 2
+    src, local = tick_inputs(77, T, n_src, n_rec, 16000, 1)
+    src[40:] = 0  # the task threads fall silent: from then on the loudspeaker plays the recording alone
+    a = L.tick_port(oracle_port, src, local, 16000, 1, stages=15 | 32, aec_delay_ms=aec_ms, play_correct=correct)
+    b = L.tick_ref(src, local, 16000, 1, stages=15 | 32, platform=platform)
+    for k in ("play", "far", "out", "zoom"):
+        assert np.array_equal(a[k], b[k]), k
+    plain = L.tick_port(oracle_port, src, local, 16000, 1, stages=15, aec_delay_ms=aec_ms, play_correct=correct)
+    assert not plain["play"][60:].any() and a["play"][60:].any()
+    # the heartbeat runs behind the drain of its tick: what it loads is played one package + VIEW_PLAY_CORRECT later
+    assert np.array_equal(a["play"][50 + 1 + correct // 320], a["out"][50, 0])

@@ -151,6 +151,8 @@ def _declare(L):
     L.wmx_tick_destroy.argtypes = [vp]
     L.wmx_tick_play_ns.restype = i
     L.wmx_tick_play_ns.argtypes = [vp, i]
+    L.wmx_tick_rw_test.restype = i
+    L.wmx_tick_rw_test.argtypes = [vp, i]
     L.wmx_tick_set_play_correct.restype = i
     L.wmx_tick_set_play_correct.argtypes = [vp, C.c_uint32]
     L.wmx_tick_package_samples.restype = i

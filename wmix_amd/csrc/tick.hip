@@ -29,6 +29,8 @@ struct wmx_tick {
     wmx_ns *play_ns;  // WR_NS_PA: the playback's own noise suppressor (src/wmix.c:1370-1386), one stream per group; NULL = switched off
     int16_t *d_play;  // [n_groups][pkg] when the caller does not want the playback
     int16_t *d_far;   // [n_groups][pkg] playPkgBuff_get()'s packet of every group
+    bool rw_test = false;                    // wmix->rwTest (src/wmix.c:714-732)
+    uint32_t rw_head = UINT32_MAX, rw_tick = 0;  // rwTestHead / tick, the heartbeat's static cursor (:531-532)
 };
 
 extern "C" {
@@ -95,6 +97,17 @@ int wmx_tick_create(wmx_tick **out, int n_groups, int rec_per_group, int chn, in
 
 // The platform build's PLAT_PLAY_CORRECT (wmx_mix_set_play_correct); its PLAT_AEC_INTERVALMS is wmx_tick_create's aec_delay_ms.
 int wmx_tick_set_play_correct(wmx_tick *h, uint32_t bytes) { return h ? wmx_mix_set_play_correct(h->mix, bytes) : WMX_EINVAL; }
+
+// wmix->rwTest, the daemon's self send-receive test (src/wmix.c:714-732): while on, every heartbeat loads what it recorded -- the
+// chain's output of the group's FIRST record stream, the daemon has one -- back into the group's play ring through wmix_load_data
+// with a cursor of its own (reduce 1), so it is played VIEW_PLAY_CORRECT later, reaches the FIFO and comes back as far-end.  Off: the
+// cursor is forgotten (rwTestHead = 0, tick = 0, :728-732).
+int wmx_tick_rw_test(wmx_tick *h, int on) {
+    if (!h) return WMX_EINVAL;
+    h->rw_test = on != 0;
+    if (!on) h->rw_head = UINT32_MAX, h->rw_tick = 0;
+    return 0;
+}
 
 // webrtcEnable[WR_NS_PA] (src/wmix.c:1370-1386): the played package goes through ns_process on its way out -- BEFORE playPkgBuff_add,
 // so the echo cancellers hear the suppressed playback too.  on = 1: ns_init of one suppressor per group (the switch coming on);
@@ -168,6 +181,11 @@ int wmx_tick_record(wmx_tick *h, int16_t *d_rec, long rec_stride, int16_t *d_rec
     int rc = wmx_chain_process_groups(h->chain, h->d_far, pkg10, h->pkg, d_rec, d_rec, h->interval_ms / 10, rec_stride, pkg10, nullptr, nullptr,
                                       nullptr, stream);
     if (rc != 0) return rc;
+    if (h->rw_test) {  // :716-726: buffSrc, `ret` bytes, WMIX_FREQ x WMIX_CHN x WMIX_SAMPLE, rwTestHead, reduce 1, &tick
+        rc = wmx_mix_load(h->mix, d_rec, (uint32_t)h->pkg * 2, h->freq, h->chn, 16, 1, (long)h->rec_per_group * rec_stride, 0, 1, &h->rw_head,
+                          &h->rw_tick, stream);
+        if (rc != 0) return rc;
+    }
     if (d_rec_1x8000) {
         uint32_t got = 0;
         rc = wmx_pcm_zoom(h->chn, h->freq, d_rec, (uint32_t)h->pkg * 2, 1, 8000, d_rec_1x8000, out_capacity, rec_stride, out_stride,

@@ -49,6 +49,10 @@ class TickBatch:
         """webrtcEnable[WR_NS_PA]: ns_process over the played package in front of playPkgBuff_add (src/wmix.c:1370-1386)."""
         check(lib().wmx_tick_play_ns(self._h, 1 if on else 0), "wmx_tick_play_ns")
 
+    def rw_test(self, on=True):
+        """wmix->rwTest: the heartbeat loads what it recorded back into the play ring (src/wmix.c:714-732)."""
+        check(lib().wmx_tick_rw_test(self._h, 1 if on else 0), "wmx_tick_rw_test")
+
     def play(self, play=None):
         """The play side of one package; returns the groups' far-end packages (a VIEW of the handle's own [n_groups, pkg] rows:
         valid until the next play)."""
