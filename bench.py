@@ -867,8 +867,46 @@ class ChainWorkload:
     def _oracle_chain(self, loader, port, stages, far, near):
         return loader.run_chain(port, 1, self.freq, 5, stages, far, near, self.pkt * self.P, prefix="orc", interval_ms=self.interval_ms)
 
+    def measure_pcie(self, steps):
+        """The heartbeat's own boundary is a package in HOST memory (buffSrc, src/wmix.c:609-709).  The same workload through
+        wmx_pipe_create_pcm / wmx_pipe_submit / wmx_pipe_wait: pinned rows in and out, H2D of step k + 1 and D2H of step k - 1 beside the
+        compute of step k, a chain of its own (primed like the resident one).  Reported as `pcie_inclusive`; never `value`."""
+        if (self.dist is not None or self.far_ends > 1 or self.n_cohorts > 1 or self.P != 1 or self.tick_major or self.extra_stages
+                or os.environ.get("WMIX_BENCH_NO_PCIE") == "1"):
+            return None
+        from wmix_amd.chain import AEC, AGC, NS, VAD
+        from wmix_amd.pipeline import PcmChain, StreamingPipe
+        ch = PcmChain(self.n_streams, self.inp.device, 1, self.freq, 10, 5, (NS | AEC | AGC | VAD) if self.with_agc_vad else (NS | AEC), slots=3)
+        pipe = StreamingPipe(ch)
+        host = self.inp[: pipe.SLOTS].cpu().numpy()  # three consecutive packets of every stream; the slots are fed these again and again
+        for sl in range(pipe.SLOTS):
+            pipe.h_in[sl][:] = host[sl]
+        far = self.far_src.view(self.K, 1, self.pkt)
+        k = 0
+        for _ in range(300):  # past the canceller's start-up
+            pipe.submit(far[k % self.K])
+            k += 1
+        pipe.drain()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pipe.submit(far[k % self.K])
+            k += 1
+        pipe.drain()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        row = self.pkt * 2
+        self.pcie = {"value": self.n_frames * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+                     "bytes_over_pcie_per_step": 2 * row * self.n_streams, "GB_per_s_each_way": row * self.n_streams * steps / dt / 1e9,
+                     "note": "wmx_pipe_create_pcm + wmx_pipe_submit / wmx_pipe_wait: pinned host rows of one 10 ms package per stream, 3 slots "
+                             "in flight, copy-in / copy-out streams beside the compute stream; a second chain of the same shape, primed 300 "
+                             "steps; its output is covered by tests/test_pipeline_gpu.py, not by parity_checked"}
+        ch.close()
+        return self.pcie
+
     def config(self):
         return {"workload": self.name, "streams_per_gpu": self.n_streams, "packets_per_stream_per_step": self.P,
+                "pcie_inclusive": getattr(self, "pcie", None),
                 "interval_ms": self.interval_ms,
                 "cohorts": self.n_cohorts,
                 "far_ends": self.far_ends,

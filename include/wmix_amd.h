@@ -473,6 +473,12 @@ int wmx_rtp_export(wmx_rtp *h, int stream_index, uint16_t *seq, uint32_t *timest
  * With three slots the H2D of step k + 1 and the D2H of step k - 1 overlap the compute of step k. */
 typedef struct wmx_pipe wmx_pipe;
 int wmx_pipe_create(wmx_pipe **out, int n_streams, int slots, int law, int agc_value, unsigned stages);
+/* The same pipeline for a host that holds PCM: the heartbeat's own boundary is a package in host memory, worked on in place
+ * (buffSrc: wmix_ai_read, src/wmix.c:609-612; ns / aec_process2 / agc / vad on it, :613-709).  A row is one package of one stream --
+ * chn x freq x interval_ms, wmx_pipe_datagram_bytes() = WMIX_PKG_SIZE bytes -- the slot's far-end one package of the same format;
+ * there is no ingest / egress, the chain (made with chn, freq, interval_ms, agc_value, stages) runs in place on the uploaded rows.
+ * wmx_pipe_step_resident on such a pipe wants in_stride == out_stride. */
+int wmx_pipe_create_pcm(wmx_pipe **out, int n_streams, int slots, int chn, int freq, int interval_ms, int agc_value, unsigned stages);
 int wmx_pipe_destroy(wmx_pipe *h);
 int wmx_pipe_slots(const wmx_pipe *h);
 int wmx_pipe_datagram_bytes(const wmx_pipe *h);

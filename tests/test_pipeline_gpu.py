@@ -80,3 +80,57 @@ def test_rtp_chain_vs_oracle_resident_and_streaming(cuda, oracle_port):
         diff = got[s][:, 12:].astype(np.int16) - want[:, 12:].astype(np.int16)
         assert not diff.any()
     assert got[0][5, 3] == 5 and got[0][5, 1] == 0x88
+
+
+@pytest.mark.parametrize("chn,freq,interval_ms,stages,slots", [(1, 16000, 10, 15, 3), (1, 8000, 20, 15, 2), (2, 32000, 10, 1 | 4 | 8, 1)])
+def test_pcm_pipe_vs_oracle_resident_and_streaming(cuda, oracle_port, chn, freq, interval_ms, stages, slots):
+    """wmx_pipe_create_pcm: the heartbeat's own boundary -- a package in HOST memory worked on in place (buffSrc, src/wmix.c:609-709) --
+    for a batch: pinned rows in, pinned rows out, copies overlapped by the library.  Resident and streaming forms against per-handle
+    oracle runs (the daemon's cadence: what aec_init / agc_init / vad_init are given is interval_ms), and the far-end from the slot's
+    own host samples as well as from the device."""
+    from wmix_amd.pipeline import PcmChain, StreamingPipe
+    from wmix_amd._lib import WmxError
+    S, n = 23, 130
+    pkt10, ppc = freq // 100 * chn, interval_ms // 10
+    far1 = synth.far_end(8900 + freq, n * ppc, freq // 100)           # mono signal ...
+    near1 = synth.near_end(8901 + freq, S, n * ppc, freq // 100, far=far1).reshape(S, -1)
+    far = np.repeat(far1, chn)                                        # ... interleaved to chn channels (the AEC takes channel 0)
+    near = np.repeat(near1, chn, axis=1)
+    if chn == 2:
+        near[:, 1::2] = near[:, 1::2] // 2                            # a right channel of its own
+    want = np.stack([L.run_chain(oracle_port, chn, freq, 5, stages, far, near[s], freq // 100 * ppc, prefix="orc", interval_ms=interval_ms)
+                     for s in range(S)])
+    rows = near.reshape(S, n, pkt10 * ppc).transpose(1, 0, 2)         # [n, S, package]
+    dfar = torch.from_numpy(far.reshape(n, ppc, pkt10).copy()).to(cuda)
+    ch = PcmChain(S, cuda, chn, freq, interval_ms, 5, stages, slots=slots)
+    d = torch.from_numpy(np.ascontiguousarray(rows)).to(cuda)
+    for k in range(n):
+        ch.step(d[k], dfar[k])
+    got = d.cpu().numpy().transpose(1, 0, 2).reshape(S, -1)
+    ch.close()
+    assert np.array_equal(got, want)
+    ch2 = PcmChain(S, cuda, chn, freq, interval_ms, 5, stages, slots=slots)
+    pipe = StreamingPipe(ch2)
+    got2 = np.zeros((n, S, pkt10 * ppc), np.int16)
+    pending = []
+    for k in range(n):
+        slot = k % pipe.SLOTS
+        if len(pending) == pipe.SLOTS:
+            kk, ss = pending.pop(0)
+            pipe.wait(ss)
+            got2[kk] = pipe.h_out[ss]
+        pipe.h_in[slot][:] = rows[k]
+        if k % 2:
+            pipe.h_far[slot][:] = far.reshape(n, ppc, pkt10)[k]
+            assert pipe.submit(None) == slot
+        else:
+            assert pipe.submit(dfar[k]) == slot
+        pending.append((k, slot))
+    for kk, ss in pending:
+        pipe.wait(ss)
+        got2[kk] = pipe.h_out[ss]
+    ch2.close()
+    assert np.array_equal(got2.transpose(1, 0, 2).reshape(S, -1), want)
+    for bad in ((3, 16000, 10), (1, 16050, 10), (1, 16000, 15), (1, 48000, 10)):  # the last: a rate the AEC / NS refuse (freq > 32000)
+        with pytest.raises(WmxError):
+            PcmChain(4, cuda, bad[0], bad[1], bad[2], 5, 15)

@@ -127,6 +127,8 @@ def _declare(L):
     L.wmx_chain_process_groups.argtypes = [vp, vp, C.c_long, C.c_long, vp, vp, i, C.c_long, C.c_long, vp, vp, vp, vp]
     L.wmx_pipe_create.restype = i
     L.wmx_pipe_create.argtypes = [C.POINTER(vp), i, i, i, i, C.c_uint]
+    L.wmx_pipe_create_pcm.restype = i
+    L.wmx_pipe_create_pcm.argtypes = [C.POINTER(vp), i, i, i, i, i, i, C.c_uint]
     L.wmx_pipe_destroy.restype = i
     L.wmx_pipe_destroy.argtypes = [vp]
     L.wmx_pipe_slots.restype = i

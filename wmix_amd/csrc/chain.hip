@@ -26,7 +26,17 @@ struct wmx_chain {
     int n_cohorts;
     bool no_fork;                    // WMIX_AMD_CHAIN_NO_FORK, read once at create (developer A/B switch)
     std::vector<int32_t> zero_delays;  // what the daemon reports (delayms = 0), one per cohort, for callers that pass NULL
+    hipEvent_t gate_after_ns = nullptr;  // recorded behind the noise suppressor's launch by the next process call (wmx::chain_gate_after_ns)
 };
+
+namespace wmx {
+// For the packet pipeline (pipe.hip): an event the NEXT wmx_chain_process call records on its stream between the noise suppressor and
+// the echo canceller, once.  The suppressor moves 24 KB of state per stream at 70 % of the HBM peak; the canceller's near kernel is
+// bound by arithmetic -- a device-to-host copy (a blit kernel of posted PCIe writes) belongs beside the latter.
+void chain_gate_after_ns(wmx_chain *h, hipEvent_t ev) {
+    if (h) h->gate_after_ns = ev;
+}
+}  // namespace wmx
 
 extern "C" {
 
@@ -185,6 +195,11 @@ int wmx_chain_process_groups(wmx_chain *h, const int16_t *d_far, long far_packet
             return rc;
         }
         src = d_out;
+    }
+    if (h->gate_after_ns) {
+        const hipEvent_t ev = h->gate_after_ns;
+        h->gate_after_ns = nullptr;
+        WMX_HIP(hipEventRecord(ev, wmx::as_stream(stream)));
     }
     if (h->aec) {
         const int per = h->aec_pkg / h->pkg10;  // 10 ms packets per AEC packet (1 or 2)

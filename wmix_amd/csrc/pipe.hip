@@ -12,6 +12,10 @@
 // (event) -> D2H on the copy-out stream -> (event)   and returns at once: while step k computes, the datagrams of step k + 1 arrive
 // and those of step k - 1 leave.  wmx_pipe_wait(slot) blocks until that slot's datagrams are in host memory.  The host thread makes
 // five runtime calls per step and waits only when it takes a slot that is still in flight.
+//
+// wmx_pipe_create_pcm makes the same pipeline for a host that holds PCM -- the heartbeat's own boundary: buffSrc is host memory
+// (wmix_ai_read, src/wmix.c:609-612) and the chain works on it in place (:613-709).  A row is then one WMIX_PKG_SIZE package of one
+// stream (chn x freq x interval_ms), there is no ingest / egress, and the chain runs in place on the uploaded rows.
 #include <vector>
 #include "wmx_internal.h"
 
@@ -23,6 +27,10 @@ constexpr int kFreq = 8000, kPkt10 = 80;
 struct wmx_pipe {
     int device;  // first member of every handle (wmx_handle_device)
     int n_streams, slots;
+    bool pcm;          // rows are PCM packages (wmx_pipe_create_pcm), not RTP datagrams
+    int row_bytes;     // bytes of one stream's row in a slot: 172, or WMIX_PKG_SIZE
+    int far_samples;   // int16 elements of the far-end of one step
+    int pkt10, ppc;    // int16 elements of one 10 ms packet, packets per step
     wmx_chain *chain;
     wmx_rtp *snd;
     int16_t *d_pcm;        // [n][160] the 20 ms of every stream between ingest and egress
@@ -53,7 +61,7 @@ int wmx_pipe_destroy(wmx_pipe *h) {
         if (s.h_out) (void)hipHostFree(s.h_out);
         if (s.h_far) (void)hipHostFree(s.h_far);
         if (s.d_in) (void)hipFree(s.d_in);
-        if (s.d_out) (void)hipFree(s.d_out);
+        if (s.d_out && s.d_out != s.d_in) (void)hipFree(s.d_out);
         if (s.d_far) (void)hipFree(s.d_far);
         if (s.ev_in) (void)hipEventDestroy(s.ev_in);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
@@ -71,16 +79,8 @@ int wmx_pipe_destroy(wmx_pipe *h) {
     return 0;
 }
 
-// law: WMX_LAW_A (payload type 8, the reference's wmix_thread_rtp_*_pcma) or WMX_LAW_U; stages: WMX_CHAIN_* bits of the heartbeat
-int wmx_pipe_create(wmx_pipe **out, int n_streams, int slots, int law, int agc_value, unsigned stages) {
-    if (!out) return WMX_EINVAL;
-    *out = nullptr;
-    if (n_streams < 1 || slots < 1 || slots > 16 || law != WMX_LAW_A) {
-        // (the ingest side decodes A-law as wmix_thread_rtp_recv_pcma does, src/wmixTask.c:1282; a mu-law receiver does not exist in the
-        // reference)
-        wmx::set_error("wmx_pipe_create: n_streams=%d slots=%d law=%d", n_streams, slots, law);
-        return WMX_EINVAL;
-    }
+static int pipe_make(wmx_pipe **out, int n_streams, int slots, bool pcm, int law, int chn, int freq, int interval_ms, int agc_value,
+                     unsigned stages) {
     wmx_pipe *h = new wmx_pipe();
     if ((h->device = wmx::current_device()) < 0) {
         delete h;
@@ -88,31 +88,40 @@ int wmx_pipe_create(wmx_pipe **out, int n_streams, int slots, int law, int agc_v
     }
     h->n_streams = n_streams;
     h->slots = slots;
+    h->pcm = pcm;
+    h->pkt10 = freq / 100 * chn;
+    h->ppc = interval_ms / 10;
+    h->row_bytes = pcm ? h->pkt10 * h->ppc * 2 : kDatagram;
+    h->far_samples = h->pkt10 * h->ppc;
     h->next = 0;
     h->pending = -1;
     h->slot.assign((size_t)slots, wmx_pipe::Slot{});
-    int rc = wmx_chain_create(&h->chain, n_streams, 1, kFreq, 10, agc_value, stages, 1);
-    if (rc == 0) rc = wmx_rtp_create(&h->snd, n_streams, law);
+    // the RTP edge hands the heartbeat 10 ms packets (two per datagram); a PCM host hands it whole packages like the daemon does
+    int rc = wmx_chain_create(&h->chain, n_streams, chn, freq, pcm ? interval_ms : 10, agc_value, stages, 1);
+    if (rc == 0 && !pcm) rc = wmx_rtp_create(&h->snd, n_streams, law);
     hipError_t e = hipSuccess;
-    const size_t bytes = (size_t)n_streams * kDatagram;
+    const size_t bytes = (size_t)n_streams * (size_t)h->row_bytes, far_bytes = (size_t)h->far_samples * sizeof(int16_t);
     if (rc == 0) {
-        e = hipMalloc(&h->d_pcm, (size_t)n_streams * 2 * kPkt10 * sizeof(int16_t));
-        if (e == hipSuccess) e = hipMalloc(&h->d_nbytes, (size_t)n_streams * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc(&h->d_seq, (size_t)n_streams * sizeof(uint16_t));
+        if (!pcm) {
+            e = hipMalloc(&h->d_pcm, (size_t)n_streams * 2 * kPkt10 * sizeof(int16_t));
+            if (e == hipSuccess) e = hipMalloc(&h->d_nbytes, (size_t)n_streams * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMalloc(&h->d_seq, (size_t)n_streams * sizeof(uint16_t));
+        }
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking);
         for (wmx_pipe::Slot &s : h->slot) {
             if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.h_in), bytes, hipHostMallocDefault);
             if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.h_out), bytes, hipHostMallocDefault);
-            if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.h_far), 2 * kPkt10 * sizeof(int16_t), hipHostMallocDefault);
+            if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.h_far), far_bytes, hipHostMallocDefault);
             if (e == hipSuccess) e = hipMalloc(&s.d_in, bytes);
-            if (e == hipSuccess) e = hipMalloc(&s.d_out, bytes);
-            if (e == hipSuccess) e = hipMalloc(&s.d_far, 2 * kPkt10 * sizeof(int16_t));
+            if (e == hipSuccess && !pcm) e = hipMalloc(&s.d_out, bytes);
+            if (pcm) s.d_out = s.d_in;  // the heartbeat works in place
+            if (e == hipSuccess) e = hipMalloc(&s.d_far, far_bytes);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_gate, hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming);
-            if (e == hipSuccess) memset(s.h_far, 0, 2 * kPkt10 * sizeof(int16_t));
+            if (e == hipSuccess) memset(s.h_far, 0, far_bytes);
         }
         if (e != hipSuccess) rc = wmx::hip_fail(e, "wmx_pipe_create: buffers / streams / events", __FILE__, __LINE__);
     }
@@ -124,9 +133,36 @@ int wmx_pipe_create(wmx_pipe **out, int n_streams, int slots, int law, int agc_v
     return 0;
 }
 
+// law: WMX_LAW_A (payload type 8, the reference's wmix_thread_rtp_*_pcma) or WMX_LAW_U; stages: WMX_CHAIN_* bits of the heartbeat
+int wmx_pipe_create(wmx_pipe **out, int n_streams, int slots, int law, int agc_value, unsigned stages) {
+    if (!out) return WMX_EINVAL;
+    *out = nullptr;
+    if (n_streams < 1 || slots < 1 || slots > 16 || law != WMX_LAW_A) {
+        // (the ingest side decodes A-law as wmix_thread_rtp_recv_pcma does, src/wmixTask.c:1282; a mu-law receiver does not exist in the
+        // reference)
+        wmx::set_error("wmx_pipe_create: n_streams=%d slots=%d law=%d", n_streams, slots, law);
+        return WMX_EINVAL;
+    }
+    return pipe_make(out, n_streams, slots, false, law, 1, kFreq, 20, agc_value, stages);
+}
+
+// The heartbeat over PCM in host memory (src/wmix.c:609-709): a row = one package of chn x freq x interval_ms (WMIX_PKG_SIZE bytes),
+// processed in place by the chain made with (chn, freq, interval_ms, agc_value, stages); the step's far-end is one package of the
+// same format.  Whatever the chain refuses (a rate the enabled stages do not take, ...) is refused here with its error.
+int wmx_pipe_create_pcm(wmx_pipe **out, int n_streams, int slots, int chn, int freq, int interval_ms, int agc_value, unsigned stages) {
+    if (!out) return WMX_EINVAL;
+    *out = nullptr;
+    if (n_streams < 1 || slots < 1 || slots > 16 || (chn != 1 && chn != 2) || freq < 8000 || freq % 100 || interval_ms < 10 || interval_ms % 10 ||
+        interval_ms > 100) {
+        wmx::set_error("wmx_pipe_create_pcm: n_streams=%d slots=%d chn=%d freq=%d interval_ms=%d", n_streams, slots, chn, freq, interval_ms);
+        return WMX_EINVAL;
+    }
+    return pipe_make(out, n_streams, slots, true, 0, chn, freq, interval_ms, agc_value, stages);
+}
+
 int wmx_pipe_slots(const wmx_pipe *h) { return h ? h->slots : WMX_EINVAL; }
-int wmx_pipe_datagram_bytes(const wmx_pipe *h) { return h ? kDatagram : WMX_EINVAL; }
-// the pinned host rows of a slot: n_streams datagrams of 172 bytes in / out, and the 160 far-end samples of the slot's 20 ms
+int wmx_pipe_datagram_bytes(const wmx_pipe *h) { return h ? h->row_bytes : WMX_EINVAL; }  // 172, or the package bytes of a PCM pipe
+// the pinned host rows of a slot: n_streams rows of wmx_pipe_datagram_bytes in / out, and the far-end samples of the slot's step
 uint8_t *wmx_pipe_in(wmx_pipe *h, int slot) { return (h && slot >= 0 && slot < h->slots) ? h->slot[(size_t)slot].h_in : nullptr; }
 const uint8_t *wmx_pipe_out(wmx_pipe *h, int slot) { return (h && slot >= 0 && slot < h->slots) ? h->slot[(size_t)slot].h_out : nullptr; }
 int16_t *wmx_pipe_far(wmx_pipe *h, int slot) { return (h && slot >= 0 && slot < h->slots) ? h->slot[(size_t)slot].h_far : nullptr; }
@@ -134,9 +170,14 @@ wmx_chain *wmx_pipe_chain(wmx_pipe *h) { return h ? h->chain : nullptr; }
 wmx_rtp *wmx_pipe_senders(wmx_pipe *h) { return h ? h->snd : nullptr; }
 
 static int pipe_ingest(wmx_pipe *h, const uint8_t *d_in, long in_stride, void *stream) {
+    if (h->pcm) return 0;
     return wmx_rtp_ingest(h->n_streams, d_in, in_stride, h->d_pcm, 2 * kPkt10, h->d_nbytes, h->d_seq, stream);
 }
-static int pipe_chain_egress(wmx_pipe *h, const int16_t *d_far, uint8_t *d_out, long out_stride, void *stream) {
+static int pipe_chain_egress(wmx_pipe *h, const int16_t *d_far, const uint8_t *d_in, long in_stride, uint8_t *d_out, long out_stride,
+                             void *stream) {
+    if (h->pcm)  // rows are packages: ppc packets of pkt10 samples, stream rows in_stride / out_stride BYTES apart
+        return wmx_chain_process(h->chain, d_far, h->pkt10, reinterpret_cast<const int16_t *>(d_in), reinterpret_cast<int16_t *>(d_out), h->ppc,
+                                 out_stride / 2, h->pkt10, nullptr, nullptr, nullptr, stream);
     int rc = wmx_chain_process(h->chain, d_far, kPkt10, h->d_pcm, h->d_pcm, 2, 2 * kPkt10, kPkt10, nullptr, nullptr, nullptr, stream);
     if (rc != 0) return rc;
     uint32_t bytes = 0;
@@ -153,12 +194,12 @@ static int pipe_chain_egress(wmx_pipe *h, const int16_t *d_far, uint8_t *d_out, 
 int wmx_pipe_step_resident(wmx_pipe *h, const uint8_t *d_in, long in_stride, const int16_t *d_far, uint8_t *d_out, long out_stride,
                            void *stream) {
     WMX_ON_DEVICE(h);
-    if (!h || !d_in || !d_out || !d_far || in_stride < kDatagram || out_stride < kDatagram) {
+    if (!h || !d_in || !d_out || !d_far || in_stride < h->row_bytes || out_stride < h->row_bytes || (h->pcm && (in_stride != out_stride || in_stride % 2))) {
         wmx::set_error("wmx_pipe_step_resident: bad argument");
         return WMX_EINVAL;
     }
     const int rc = pipe_ingest(h, d_in, in_stride, stream);
-    return rc ? rc : pipe_chain_egress(h, d_far, d_out, out_stride, stream);
+    return rc ? rc : pipe_chain_egress(h, d_far, d_in, in_stride, d_out, out_stride, stream);
 }
 
 // the D2H of the pending slot, behind `gate` (an event of the compute stream)
@@ -167,7 +208,7 @@ static int pipe_flush(wmx_pipe *h, hipEvent_t gate) {
     wmx_pipe::Slot &p = h->slot[(size_t)h->pending];
     h->pending = -1;
     WMX_HIP(hipStreamWaitEvent(h->s_out, gate, 0));
-    WMX_HIP(hipMemcpyAsync(p.h_out, p.d_out, (size_t)h->n_streams * kDatagram, hipMemcpyDeviceToHost, h->s_out));
+    WMX_HIP(hipMemcpyAsync(p.h_out, p.d_out, (size_t)h->n_streams * (size_t)h->row_bytes, hipMemcpyDeviceToHost, h->s_out));
     WMX_HIP(hipEventRecord(p.ev_out, h->s_out));
     return 0;
 }
@@ -176,11 +217,12 @@ static int pipe_flush(wmx_pipe *h, hipEvent_t gate) {
 // slot index; its h_out rows are valid after wmx_pipe_wait(h, *slot).  Blocks only if that slot is still in flight from `slots`
 // steps ago.  d_far != NULL: the far-end is on the device already (its two 10 ms packets, contiguous).
 //
-// WHERE the download of a step is queued matters: the runtime copies device-to-host with a blit kernel (11 MB of posted writes over
-// PCIe, ~210 us), and a memory-bound kernel beside it starves -- the next step's ingest kernel, 15 us alone, took the blit's whole
-// 210 us when the download was queued right behind the egress (rocprofv3 kernel trace, profiles/r05).  So the download of step k is
-// queued by submit(k + 1), gated on an event BEHIND step k + 1's ingest kernel: it runs beside the noise suppressor and the echo
-// canceller, which are bound by arithmetic.  The last step's download is queued by wmx_pipe_wait.
+// WHERE the download of a step is queued matters: the runtime copies device-to-host with a blit kernel (11 - 21 MB of posted writes
+// over PCIe, 0.2 - 0.4 ms), and a memory-bound kernel beside it starves -- the next step's ingest kernel, 15 us alone, took the blit's
+// whole 210 us when the download was queued right behind the egress (rocprofv3 kernel trace, profiles/r05), and the noise suppressor
+// (24 KB of state per stream at 70 % of the HBM peak) is the next most sensitive.  So the download of step k is queued by
+// submit(k + 1), gated on an event the chain records BEHIND step k + 1's noise suppressor: it runs beside the echo canceller, which
+// is bound by arithmetic.  The last step's download is queued by wmx_pipe_wait.
 int wmx_pipe_submit(wmx_pipe *h, const int16_t *d_far, int *slot, void *stream) {
     WMX_ON_DEVICE(h);
     if (!h) return WMX_EINVAL;
@@ -196,19 +238,21 @@ int wmx_pipe_submit(wmx_pipe *h, const int16_t *d_far, int *slot, void *stream) 
         WMX_HIP(hipEventSynchronize(s.ev_out));  // the slot's previous result has left the device: its buffers are free
         s.in_flight = false;
     }
-    const size_t bytes = (size_t)h->n_streams * kDatagram;
+    const size_t bytes = (size_t)h->n_streams * (size_t)h->row_bytes;
     WMX_HIP(hipMemcpyAsync(s.d_in, s.h_in, bytes, hipMemcpyHostToDevice, h->s_in));
-    if (!d_far) WMX_HIP(hipMemcpyAsync(s.d_far, s.h_far, 2 * kPkt10 * sizeof(int16_t), hipMemcpyHostToDevice, h->s_in));
+    if (!d_far) WMX_HIP(hipMemcpyAsync(s.d_far, s.h_far, (size_t)h->far_samples * sizeof(int16_t), hipMemcpyHostToDevice, h->s_in));
     WMX_HIP(hipEventRecord(s.ev_in, h->s_in));
     WMX_HIP(hipStreamWaitEvent(main, s.ev_in, 0));
-    int rc = pipe_ingest(h, s.d_in, kDatagram, stream);
+    int rc = pipe_ingest(h, s.d_in, h->row_bytes, stream);
     if (rc != 0) return rc;
-    if (h->pending >= 0) {
-        WMX_HIP(hipEventRecord(s.ev_gate, main));
-        if ((rc = pipe_flush(h, s.ev_gate)) != 0) return rc;
+    const bool gated = h->pending >= 0;
+    if (gated) wmx::chain_gate_after_ns(h->chain, s.ev_gate);  // recorded by the chain call below, behind its noise suppressor
+    rc = pipe_chain_egress(h, d_far ? d_far : s.d_far, s.d_in, h->row_bytes, s.d_out, h->row_bytes, stream);
+    if (rc != 0) {
+        wmx::chain_gate_after_ns(h->chain, nullptr);
+        return rc;
     }
-    rc = pipe_chain_egress(h, d_far ? d_far : s.d_far, s.d_out, kDatagram, stream);
-    if (rc != 0) return rc;
+    if (gated && (rc = pipe_flush(h, s.ev_gate)) != 0) return rc;  // the wait is queued after the record was: the event is this step's
     WMX_HIP(hipEventRecord(s.ev_done, main));
     h->pending = k;
     s.in_flight = true;

@@ -28,6 +28,7 @@ class RtpChain:
         self._h = C.c_void_p()
         check(lib().wmx_pipe_create(C.byref(self._h), n_streams, slots, 0, agc_value, NS | AEC | AGC | VAD), "wmx_pipe_create")
         self.slots = slots
+        self.row_shape, self.row_dtype, self.far_shape = (n_streams, DATAGRAM), np.uint8, (2, PKT)
 
     def step(self, packets_in, far, packets_out):
         """packets_in / packets_out: uint8 CUDA [n_streams, 172]; far: int16 CUDA [2, 80], the shared far-end of these 20 ms."""
@@ -49,6 +50,27 @@ class RtpChain:
             pass
 
 
+class PcmChain(RtpChain):
+    """wmx_pipe_create_pcm: the heartbeat over PCM packages in host memory (src/wmix.c:609-709); rows int16 [n_streams, package],
+    far-end int16 [packets, 10 ms packet]."""
+
+    def __init__(self, n_streams, dev, chn=1, freq=16000, interval_ms=10, agc_value=5, stages=NS | AEC | AGC | VAD, slots=3):
+        self.n, self.dev = n_streams, dev
+        self._h = C.c_void_p()
+        check(lib().wmx_pipe_create_pcm(C.byref(self._h), n_streams, slots, chn, freq, interval_ms, agc_value, stages), "wmx_pipe_create_pcm")
+        self.slots = slots
+        self.pkt10, self.ppc = freq // 100 * chn, interval_ms // 10
+        assert lib().wmx_pipe_datagram_bytes(self._h) == self.pkt10 * self.ppc * 2
+        self.row_shape, self.row_dtype, self.far_shape = (n_streams, self.pkt10 * self.ppc), np.int16, (self.ppc, self.pkt10)
+
+    def step(self, pcm, far):
+        """in place on packages already resident in HBM: pcm int16 CUDA [n_streams, package], far int16 CUDA [packets, 10 ms packet]"""
+        assert pcm.is_cuda and pcm.dtype == torch.int16 and pcm.stride(1) == 1 and far.is_cuda and far.is_contiguous()
+        check(lib().wmx_pipe_step_resident(self._h, pcm.data_ptr(), pcm.stride(0) * 2, far.data_ptr(), pcm.data_ptr(), pcm.stride(0) * 2,
+                                           torch.cuda.current_stream().cuda_stream), "wmx_pipe_step_resident")
+        return pcm
+
+
 def _host_rows(ptr, shape, dtype):
     """numpy view of a pinned host buffer the library owns"""
     n = int(np.prod(shape)) * np.dtype(dtype).itemsize
@@ -63,9 +85,9 @@ class StreamingPipe:
         self.c = chain
         self.SLOTS = chain.slots
         L = lib()
-        self.h_in = [_host_rows(L.wmx_pipe_in(chain._h, s), (chain.n, DATAGRAM), np.uint8) for s in range(self.SLOTS)]
-        self.h_out = [_host_rows(L.wmx_pipe_out(chain._h, s), (chain.n, DATAGRAM), np.uint8) for s in range(self.SLOTS)]
-        self.h_far = [_host_rows(L.wmx_pipe_far(chain._h, s), (2, PKT), np.int16) for s in range(self.SLOTS)]
+        self.h_in = [_host_rows(L.wmx_pipe_in(chain._h, s), chain.row_shape, chain.row_dtype) for s in range(self.SLOTS)]
+        self.h_out = [_host_rows(L.wmx_pipe_out(chain._h, s), chain.row_shape, chain.row_dtype) for s in range(self.SLOTS)]
+        self.h_far = [_host_rows(L.wmx_pipe_far(chain._h, s), chain.far_shape, np.int16) for s in range(self.SLOTS)]
 
     def submit(self, far=None):
         """Process the datagrams the caller has placed in h_in[slot] (slots are taken round robin); far: int16 CUDA [2, 80], or
