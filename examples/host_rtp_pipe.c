@@ -15,6 +15,12 @@
  * out.rtp  same shape                      what the senders put on the wire
  * Prints one JSON line with the wall time per step.
  *
+ *   host_rtp_pipe far.i16 in.pcm out.pcm n_streams n_steps slots --pcm chn freq interval_ms
+ *
+ * the same loop over wmx_pipe_create_pcm: the heartbeat's own boundary, a package of chn x freq x interval_ms per stream in host
+ * memory, worked on in place (src/wmix.c:609-709).  in.pcm / out.pcm: int16 [n_steps][n_streams][package], far.i16: int16
+ * [n_steps][package] (a far-end package of the same format per step).  Row sizes come from the library (wmx_pipe_datagram_bytes).
+ *
  * Build (what __graft_entry__.build() runs):
  *   gcc -std=c99 -O2 -Iinclude examples/host_rtp_pipe.c -o examples/host_rtp_pipe -Lwmix_amd -lwmix_amd -Wl,-rpath,'$ORIGIN/../wmix_amd'
  */
@@ -50,15 +56,20 @@ int main(int argc, char **argv) {
     }
     const int n = atoi(argv[4]), steps = atoi(argv[5]), slots = argc > 6 ? atoi(argv[6]) : 3;
     if (n < 1 || steps < 1) return 2;
-    const size_t row = 172, step_bytes = (size_t)n * row;
-    int16_t *far = read_file(argv[1], (size_t)steps * 160 * 2);
-    uint8_t *in = read_file(argv[2], (size_t)steps * step_bytes);
-    uint8_t *out = calloc((size_t)steps, step_bytes);
+    const int pcm = argc == 11 && !strcmp(argv[7], "--pcm");
+    const unsigned stages = WMX_CHAIN_NS | WMX_CHAIN_AEC | WMX_CHAIN_AGC | WMX_CHAIN_VAD;
     wmx_pipe *p = NULL;
-    if (wmx_pipe_create(&p, n, slots, WMX_LAW_A, 5, WMX_CHAIN_NS | WMX_CHAIN_AEC | WMX_CHAIN_AGC | WMX_CHAIN_VAD) != 0) {
-        fprintf(stderr, "host_rtp_pipe: wmx_pipe_create: %s\n", wmx_last_error());
+    const int rcc = pcm ? wmx_pipe_create_pcm(&p, n, slots, atoi(argv[8]), atoi(argv[9]), atoi(argv[10]), 5, stages)
+                        : wmx_pipe_create(&p, n, slots, WMX_LAW_A, 5, stages);
+    if (rcc != 0) {
+        fprintf(stderr, "host_rtp_pipe: wmx_pipe_create%s: %s\n", pcm ? "_pcm" : "", wmx_last_error());
         return 3;
     }
+    const size_t row = (size_t)wmx_pipe_datagram_bytes(p), step_bytes = (size_t)n * row;
+    const size_t far_n = pcm ? row / 2 : 160; /* int16 elements of the far-end of one step */
+    int16_t *far = read_file(argv[1], (size_t)steps * far_n * 2);
+    uint8_t *in = read_file(argv[2], (size_t)steps * step_bytes);
+    uint8_t *out = calloc((size_t)steps, step_bytes);
     int rc = 0;
     const double t0 = now_ms();
     for (int k = 0; k < steps + slots && rc == 0; k++) {
@@ -71,7 +82,7 @@ int main(int argc, char **argv) {
             const int slot = k % slots;
             int got = -1;
             memcpy(wmx_pipe_in(p, slot), in + (size_t)k * step_bytes, step_bytes);
-            memcpy(wmx_pipe_far(p, slot), far + (size_t)k * 160, 160 * 2);
+            memcpy(wmx_pipe_far(p, slot), far + (size_t)k * far_n, far_n * 2);
             rc = wmx_pipe_submit(p, NULL, &got, NULL);
             if (rc == 0 && got != slot) rc = -1;
         }
@@ -84,7 +95,7 @@ int main(int argc, char **argv) {
         if (!f || fwrite(out, 1, (size_t)steps * step_bytes, f) != (size_t)steps * step_bytes) rc = 4;
         if (f) fclose(f);
     }
-    printf("{\"streams\": %d, \"steps\": %d, \"slots\": %d, \"wall_ms\": %.3f, \"ms_per_step\": %.4f, \"rc\": %d}\n", n, steps, slots, wall,
-           wall / steps, rc);
+    printf("{\"streams\": %d, \"steps\": %d, \"slots\": %d, \"row_bytes\": %zu, \"wall_ms\": %.3f, \"ms_per_step\": %.4f, \"rc\": %d}\n", n, steps,
+           slots, row, wall, wall / steps, rc);
     return rc ? 1 : 0;
 }

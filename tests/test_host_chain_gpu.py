@@ -136,3 +136,25 @@ def test_host_rtp_pipe_vs_oracle(tmp_path, oracle_port, slots):
         assert np.array_equal(got[s][:, :12], want[:, :12])
         diff = got[s][:, 12:].astype(np.int16) - want[:, 12:].astype(np.int16)
         assert not diff.any()
+
+
+@pytest.mark.gpu
+def test_host_pcm_pipe_vs_oracle(tmp_path, oracle_port):
+    """The same C host over wmx_pipe_create_pcm (--pcm chn freq interval_ms): the heartbeat's own boundary, packages in host memory
+    worked on in place (src/wmix.c:609-709) -- here the daemon's cadence, 20 ms packages of 1 x 16000 -- against per-handle oracle
+    runs, bit for bit."""
+    S, n, freq, interval = 21, 120, 16000, 20
+    pkg = freq // 1000 * interval
+    far = synth.far_end(9950, 2 * n, 160)
+    near = synth.near_end(9951, S, 2 * n, 160, far=far).reshape(S, n, pkg)
+    far.astype("<i2").tofile(tmp_path / "far.i16")
+    np.ascontiguousarray(near.transpose(1, 0, 2)).astype("<i2").tofile(tmp_path / "in.pcm")  # step-major
+    r = subprocess.run([EXE_RTP, str(tmp_path / "far.i16"), str(tmp_path / "in.pcm"), str(tmp_path / "out.pcm"), str(S), str(n), "3",
+                        "--pcm", "1", str(freq), str(interval)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["rc"] == 0 and info["row_bytes"] == pkg * 2
+    got = np.fromfile(tmp_path / "out.pcm", dtype="<i2").reshape(n, S, pkg).transpose(1, 0, 2).reshape(S, -1)
+    for s in (0, 7, 20):
+        want = L.run_chain(oracle_port, 1, freq, 5, 15, far, near[s].reshape(-1), pkg, prefix="orc", interval_ms=interval)
+        assert np.array_equal(got[s], want)
