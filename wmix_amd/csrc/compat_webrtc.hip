@@ -8,28 +8,48 @@
 // caller's `bool *debug` and print only when it is set; in == out aliasing is fine; frameNum is
 // in frames (chn samples each) and must be a multiple of the packet size.
 #include <cstdlib>
+#include <cstring>
 #include "wmx_internal.h"
 #include "../../include/wmix_compat.h"
 
 namespace {
 
+// The handle's staging buffer: PINNED HOST memory mapped into the device's address space.  A legacy call moves a few hundred bytes;
+// two runtime copies around the launch cost more than the work (round 5: ~ 45 us per call, of which the kernel ~ 8).  The kernels
+// read the packet straight out of this buffer and write the result back into it over PCIe -- two plain memcpy calls on the host,
+// one launch, one synchronisation.
 struct DevBuf {
-    int16_t *p = nullptr;
+    int16_t *p = nullptr;  // the device's view (what the wmx_* entry points get)
+    int16_t *host = nullptr;
     size_t cap = 0;  // int16 elements
     bool ensure(size_t n) {
         if (n <= cap) return true;
-        if (p) (void)hipFree(p);
-        p = nullptr;
+        if (host) (void)hipHostFree(host);
+        host = p = nullptr;
         cap = 0;
-        if (hipMalloc(&p, n * sizeof(int16_t)) != hipSuccess) {
+        void *hp = nullptr, *dp = nullptr;
+        if (hipHostMalloc(&hp, n * sizeof(int16_t), hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
             (void)hipGetLastError();
+            if (hp) (void)hipHostFree(hp);
             return false;
         }
+        host = static_cast<int16_t *>(hp);
+        p = static_cast<int16_t *>(dp);
         cap = n;
         return true;
     }
+    bool in(const int16_t *src, size_t n_elems) {
+        memcpy(host, src, n_elems * sizeof(int16_t));
+        return true;
+    }
+    // the launches of this call have finished and their writes are in host memory
+    bool out(int16_t *dst, size_t n_elems) {
+        if (hipStreamSynchronize(nullptr) != hipSuccess) return false;
+        memcpy(dst, host, n_elems * sizeof(int16_t));
+        return true;
+    }
     ~DevBuf() {
-        if (p) (void)hipFree(p);
+        if (host && !wmx::runtime_exiting()) (void)hipHostFree(host);
     }
 };
 
@@ -68,10 +88,10 @@ int aec_run_host(AecHandleCompat *h, int mode, int16_t *far, int16_t *nearp, int
     const int per_pkt = h->pkg * h->chn, total = frameNum * h->chn;
     const int n_packets = (total + per_pkt - 1) / per_pkt;
     if (n_packets <= 0) return 0;
-    const size_t n = (size_t)n_packets * per_pkt, bytes = (size_t)total * sizeof(int16_t);
+    const size_t n = (size_t)n_packets * per_pkt;
     bool ok = true;
-    if (mode & 1) ok = ok && h->far.ensure(n) && hipMemcpy(h->far.p, far, bytes, hipMemcpyHostToDevice) == hipSuccess;
-    if (mode & 2) ok = ok && h->near.ensure(n) && hipMemcpy(h->near.p, nearp, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    if (mode & 1) ok = ok && h->far.ensure(n) && h->far.in(far, (size_t)total);
+    if (mode & 2) ok = ok && h->near.ensure(n) && h->near.in(nearp, (size_t)total);
     int rc = -1;
     if (ok) {
         rc = h->batchm ? wmx_aecm_run(h->batchm, mode, (mode & 1) ? h->far.p : nullptr, per_pkt, (mode & 2) ? h->near.p : nullptr,
@@ -80,7 +100,11 @@ int aec_run_host(AecHandleCompat *h, int mode, int16_t *far, int16_t *nearp, int
                                      (mode & 2) ? h->near.p : nullptr, n_packets, 0, per_pkt, delayms, nullptr);
         if (rc == 0 || rc == -1) {
             // rc == -1: the reference returned mid-buffer; packets before the offending one were written
-            if ((mode & 2) && hipMemcpy(out, h->near.p, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = -1;
+            if (mode & 2) {
+                if (!h->near.out(out, (size_t)total)) rc = -1;
+            } else if (hipStreamSynchronize(nullptr) != hipSuccess) {  // aec_setFrameFar: the far buffer is reused by the next call
+                rc = -1;
+            }
         }
     }
     if (rc != 0) {
@@ -170,9 +194,9 @@ void vad_process(void *fp, int16_t *frame, int frameNum) {
     if (packets <= 0) return;
     const size_t n = (size_t)packets * h->pkg * h->chn, given = (size_t)frameNum * h->chn;
     bool ok = h->buf.ensure(n);
-    ok = ok && hipMemcpy(h->buf.p, frame, given * sizeof(int16_t), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && h->buf.in(frame, given);
     ok = ok && wmx_vad_process(h->batch, h->buf.p, packets, 1, 0, (long)n, nullptr) == 0;
-    ok = ok && hipMemcpy(frame, h->buf.p, given * sizeof(int16_t), hipMemcpyDeviceToHost) == hipSuccess;
+    ok = ok && h->buf.out(frame, given);
     if (!ok) {
         (void)hipGetLastError();
         fprintf(stderr, "wmix_amd: vad_process failed on the GPU: %s\n", wmx_last_error());
@@ -215,9 +239,9 @@ int agc_process(void *fp, int16_t *frame, int16_t *frameOut, int frameNum) {
     if (n_packets <= 0) return 0;
     const size_t n = (size_t)n_packets * per_pkt;
     bool ok = h->buf.ensure(n);
-    ok = ok && hipMemcpy(h->buf.p, frame, (size_t)total * sizeof(int16_t), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && h->buf.in(frame, (size_t)total);
     ok = ok && wmx_agc_process(h->batch, h->buf.p, h->buf.p, n_packets, 0, per_pkt, nullptr) == 0;
-    ok = ok && hipMemcpy(frameOut, h->buf.p, (size_t)total * sizeof(int16_t), hipMemcpyDeviceToHost) == hipSuccess;
+    ok = ok && h->buf.out(frameOut, (size_t)total);
     if (!ok) {
         (void)hipGetLastError();
         if (h->debug && *h->debug) printf("WebRtcAgc_Process failed !!, ret %d \r\n", -1);
@@ -276,10 +300,10 @@ void ns_process(void *fp, int16_t *frame, int16_t *frameOut, int frameNum) {
     if (n_packets <= 0) return;
     const size_t n = (size_t)n_packets * per_pkt;
     bool ok = h->buf.ensure(n);
-    ok = ok && hipMemcpy(h->buf.p, frame, (size_t)total * sizeof(int16_t), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && h->buf.in(frame, (size_t)total);
     ok = ok && (h->batchx ? wmx_nsx_process(h->batchx, h->buf.p, h->buf.p, n_packets, 0, per_pkt, nullptr)
                           : wmx_ns_process(h->batch, h->buf.p, h->buf.p, n_packets, 0, per_pkt, nullptr)) == 0;
-    ok = ok && hipMemcpy(frameOut, h->buf.p, (size_t)total * sizeof(int16_t), hipMemcpyDeviceToHost) == hipSuccess;
+    ok = ok && h->buf.out(frameOut, (size_t)total);
     if (!ok) {
         (void)hipGetLastError();
         fprintf(stderr, "wmix_amd: ns_process failed on the GPU: %s\n", wmx_last_error());
