@@ -75,6 +75,53 @@ def heartbeat_latency(freq=8000, chn=1, n_beats=600, warm=100, check=True):
     return out
 
 
+def packet_edge_latency(n_calls=600, warm=100):
+    """The task threads' per-packet legacy calls on host pointers: PCM2G711a / G711a2PCM of one RTP payload (160 samples,
+    src/wmixTask.c:1139, 1282), wmix_pcm_zoom of one 20 ms package (src/wmix.c:730).  Microseconds per call (mean, p99)."""
+    from wmix_amd import _lib
+    W = _lib.lib()
+    rng = np.random.default_rng(3)
+    pcm = rng.integers(-20000, 20000, 160, dtype=np.int16)
+    codes = np.zeros(160, np.uint8)
+    back = np.zeros(160, np.int16)
+    big = rng.integers(-20000, 20000, 1280, dtype=np.int16)  # 20 ms of 2 x 16000
+    small = np.zeros(1280, np.int16)
+    for f in (W.PCM2G711a, W.G711a2PCM):
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        f.restype = C.c_int
+    W.wmix_pcm_zoom.argtypes = [C.c_uint8, C.c_uint16, C.c_void_p, C.c_uint32, C.c_uint8, C.c_uint16, C.c_void_p]
+    W.wmix_pcm_zoom.restype = C.c_uint32
+    calls = {"PCM2G711a_160": lambda: W.PCM2G711a(pcm.ctypes.data, codes.ctypes.data, 320, 0),
+             "G711a2PCM_160": lambda: W.G711a2PCM(codes.ctypes.data, back.ctypes.data, 160, 0),
+             "wmix_pcm_zoom_2x16000_to_1x8000_20ms": lambda: W.wmix_pcm_zoom(2, 16000, big.ctypes.data, 2560, 1, 8000, small.ctypes.data)}
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_mix_gpu import Head, Point  # the WMix_Struct head as ctypes (tests/test_mix_gpu.py)
+    W.wmix_load_data.restype = Point
+    W.wmix_load_data.argtypes = [C.POINTER(Head), Point, C.c_uint32, C.c_uint16, C.c_uint8, C.c_uint8, Point, C.c_uint8, C.POINTER(C.c_uint32)]
+    ring = np.zeros(8008, np.int16)
+    w = Head()
+    w.start.U8, w.end.U8, w.head.U8 = ring.ctypes.data, ring.ctypes.data + 16000, ring.ctypes.data
+    w.run, w.reduceMode, w.tick = True, 1, 0
+    cur = {"head": None, "tick": C.c_uint32(0)}
+
+    def load():  # one task thread's 20 ms chunk of 2 x 16000 into the 1 x 8000 ring, its cursor carried along
+        sp, hp = Point(), Point()
+        sp.U8, hp.U8 = big.ctypes.data, cur["head"]
+        cur["head"] = W.wmix_load_data(C.byref(w), sp, 2560, 16000, 2, 16, hp, 1, C.byref(cur["tick"])).U8
+
+    calls["wmix_load_data_2x16000_20ms"] = load
+    out = {}
+    for name, fn in calls.items():
+        t = np.zeros(n_calls)
+        for k in range(n_calls):
+            t0 = time.perf_counter()
+            fn()
+            t[k] = time.perf_counter() - t0
+        out[name] = {"mean_us": float(t[warm:].mean() * 1e6), "p99_us": float(np.percentile(t[warm:], 99) * 1e6)}
+    return {"packet_edge_legacy_calls": out}
+
+
 if __name__ == "__main__":
     for freq, chn in ((8000, 1), (16000, 1), (16000, 2)):
         print(json.dumps(heartbeat_latency(freq, chn)))
+    print(json.dumps(packet_edge_latency()))

@@ -6,6 +6,7 @@
 // null/0 (src/g711codec.c:230 uses &&); otherwise the element count (encode) or
 // byte count (decode) is returned.  A HIP failure returns -1 and sets
 // wmx_last_error().
+#include <cstring>
 #include "wmx_internal.h"
 #include "../../include/wmix_compat.h"
 
@@ -27,9 +28,41 @@ struct Scratch {
 };
 thread_local Scratch g_a, g_b;
 
+// The daemon converts one RTP payload per call (160 - 320 samples, src/wmixTask.c:285, 1139, 1282): two runtime copies around the
+// launch cost several times the work.  Up to kMappedMax elements the caller's data goes through a pinned host buffer that is mapped
+// into the device: memcpy in, ONE launch whose kernel reads and writes it over PCIe, one synchronisation, memcpy out.
+constexpr size_t kMappedMax = 16384;
+struct Mapped {
+    uint8_t *host = nullptr, *dev = nullptr;  // 3 bytes per element: the int16 side at [0, 2 * kMappedMax), the codes behind it
+    int ensure() {
+        if (host) return 0;
+        void *hp = nullptr, *dp = nullptr;
+        WMX_HIP(hipHostMalloc(&hp, 3 * kMappedMax, hipHostMallocMapped));
+        if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipHostFree(hp);
+            return -1;
+        }
+        host = static_cast<uint8_t *>(hp);
+        dev = static_cast<uint8_t *>(dp);
+        return 0;
+    }
+    ~Mapped() {
+        if (host && !wmx::runtime_exiting()) (void)hipHostFree(host);
+    }
+};
+thread_local Mapped g_m;
+
 int host_encode(int law, unsigned char *out, const short *in, int len) {
     if (len <= 0) return 0;
     size_t n = (size_t)len;
+    if (n <= kMappedMax && g_m.ensure() == 0) {
+        memcpy(g_m.host, in, n * 2);
+        if (wmx_g711_encode(law, (const int16_t *)g_m.dev, g_m.dev + 2 * kMappedMax, n, nullptr)) return -1;
+        if (hipStreamSynchronize(nullptr) != hipSuccess) return -1;
+        memcpy(out, g_m.host + 2 * kMappedMax, n);
+        return len;
+    }
     if (g_a.ensure(n * 2) || g_b.ensure(n)) return -1;
     if (hipMemcpy(g_a.p, in, n * 2, hipMemcpyHostToDevice) != hipSuccess) return -1;
     if (wmx_g711_encode(law, (const int16_t *)g_a.p, (uint8_t *)g_b.p, n, nullptr)) return -1;
@@ -40,6 +73,13 @@ int host_encode(int law, unsigned char *out, const short *in, int len) {
 int host_decode(int law, short *out, const unsigned char *in, int bytes) {
     if (bytes <= 0) return 0;
     size_t n = (size_t)bytes;
+    if (n <= kMappedMax && g_m.ensure() == 0) {
+        memcpy(g_m.host + 2 * kMappedMax, in, n);
+        if (wmx_g711_decode(law, g_m.dev + 2 * kMappedMax, (int16_t *)g_m.dev, n, nullptr)) return -1;
+        if (hipStreamSynchronize(nullptr) != hipSuccess) return -1;
+        memcpy(out, g_m.host, n * 2);
+        return bytes * 2;
+    }
     if (g_a.ensure(n) || g_b.ensure(n * 2)) return -1;
     if (hipMemcpy(g_a.p, in, n, hipMemcpyHostToDevice) != hipSuccess) return -1;
     if (wmx_g711_decode(law, (const uint8_t *)g_a.p, (int16_t *)g_b.p, n, nullptr)) return -1;

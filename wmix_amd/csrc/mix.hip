@@ -13,6 +13,7 @@
 // order-dependent saturation (src/wmix.c:1617-1636) is reproduced without atomics.  Bit-exact.
 #include <cstddef>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include "wmx_internal.h"
 #include "../../include/wmix_compat.h"
@@ -122,6 +123,39 @@ struct DevVec {
     }
 };
 
+// Pinned HOST memory mapped into the device, for the legacy adapters' small buffers: two runtime copies around a launch cost several
+// times the work of a few hundred samples (wmix_pcm_zoom of one package: 43 us with copies).  The kernel reads and writes the mapped
+// buffer over PCIe instead: memcpy in, one launch, one synchronisation, memcpy out.
+struct MapVec {
+    uint8_t *host = nullptr, *dev = nullptr;
+    size_t cap = 0;
+    MapVec() = default;
+    MapVec(const MapVec &) = delete;
+    MapVec &operator=(const MapVec &) = delete;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (host) (void)hipHostFree(host);
+        host = dev = nullptr;
+        cap = 0;
+        void *hp = nullptr, *dp = nullptr;
+        WMX_HIP(hipHostMalloc(&hp, bytes < 4096 ? 4096 : bytes, hipHostMallocMapped));
+        if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipHostFree(hp);
+            set_error("hipHostGetDevicePointer failed");
+            return WMX_ENODEV;
+        }
+        host = static_cast<uint8_t *>(hp);
+        dev = static_cast<uint8_t *>(dp);
+        cap = bytes < 4096 ? 4096 : bytes;
+        return 0;
+    }
+    ~MapVec() {
+        if (host && !runtime_exiting()) (void)hipHostFree(host);
+    }
+};
+constexpr size_t kMappedMaxBytes = 64 * 1024;  // above this the DMA engines win: the copy path
+
 }  // namespace
 
 void zoom_gather_list(int inChn, int inFreq, uint32_t inLen, int outChn, int outFreq, std::vector<int32_t> &idx) {
@@ -140,6 +174,7 @@ struct wmx_mix {
     uint32_t ring_bytes, head_off, tick, play_correct;
     uint8_t reduce_mode;
     int16_t *d_rings;
+    uint8_t *h_rings = nullptr;  // set when the rings are pinned host memory mapped into the device (the legacy adapter's one ring)
     wmx::SchedCache sched;  // load schedules per source format, never rewritten (see SchedCache)
     std::vector<wmx::LoadEntry> sch;
 };
@@ -208,9 +243,18 @@ int wmx_pcm_zoom(int inChn, int inFreq, const int16_t *d_in, uint32_t inLen, int
 uint32_t wmix_pcm_zoom(uint8_t inChn, uint16_t inFreq, uint8_t *in, uint32_t inLen, uint8_t outChn, uint16_t outFreq, uint8_t *out) {
     using namespace wmx;
     static thread_local DevVec a, b;
+    static thread_local MapVec ma, mb;
     if (inLen == 0 || !in || !out || !inFreq || !outFreq || !inChn || !outChn) return 0;
     const uint32_t need = wmix_len_of_out(inChn, inFreq, inLen, outChn, outFreq);  // what the reference's callers size `out` by
     uint32_t n = 0;
+    if ((size_t)inLen + need <= kMappedMaxBytes && ma.ensure(inLen + 16) == 0 && mb.ensure((size_t)need + 16) == 0) {
+        memcpy(ma.host, in, inLen);
+        if (wmx_pcm_zoom(inChn, inFreq, (const int16_t *)ma.dev, inLen, outChn, outFreq, (int16_t *)mb.dev, need + 16, 0, 0, 1, &n, nullptr) != 0)
+            return 0;
+        if (hipStreamSynchronize(nullptr) != hipSuccess) return 0;
+        if (n) memcpy(out, mb.host, n);
+        return n;
+    }
     if (a.ensure(inLen + 16) || b.ensure((size_t)need + 16)) return 0;
     if (hipMemcpy(a.p, in, inLen, hipMemcpyHostToDevice) != hipSuccess) return 0;
     if (wmx_pcm_zoom(inChn, inFreq, (const int16_t *)a.p, inLen, outChn, outFreq, (int16_t *)b.p, need + 16, 0, 0, 1, &n, nullptr) != 0)
@@ -222,7 +266,10 @@ uint32_t wmix_pcm_zoom(uint8_t inChn, uint16_t inFreq, uint8_t *in, uint32_t inL
 int wmx_mix_destroy(wmx_mix *m) {
     WMX_ON_DEVICE(m);
     if (!m) return 0;
-    if (m->d_rings) (void)hipFree(m->d_rings);
+    if (m->h_rings)
+        (void)hipHostFree(m->h_rings);
+    else if (m->d_rings)
+        (void)hipFree(m->d_rings);
     delete m;
     return 0;
 }
@@ -406,6 +453,18 @@ WMix_Point wmix_load_data(WMix_Struct_Head *wmix, WMix_Point src, uint32_t srcU8
         if (m) wmx_mix_destroy(m);
         m = nullptr;
         if (wmx_mix_create(&m, 1, ring_chn, ring_freq) != 0) return pHead;
+        {  // this ring only ever holds the span of one call: pinned host memory the kernel works on over PCIe (see MapVec)
+            void *hp = nullptr, *dp = nullptr;
+            if (hipHostMalloc(&hp, m->ring_bytes, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+                (void)hipFree(m->d_rings);
+                memset(hp, 0, m->ring_bytes);
+                m->h_rings = static_cast<uint8_t *>(hp);
+                m->d_rings = static_cast<int16_t *>(dp);
+            } else {
+                (void)hipGetLastError();
+                if (hp) (void)hipHostFree(hp);
+            }
+        }
         if (play_correct >= 0 && wmx_mix_set_play_correct(m, (uint32_t)play_correct) != 0) {
             fprintf(stderr, "wmix_amd: WMIX_AMD_PLAY_CORRECT=%ld: %s\n", play_correct, wmx_last_error());
             wmx_mix_destroy(m);
@@ -444,6 +503,24 @@ WMix_Point wmix_load_data(WMix_Struct_Head *wmix, WMix_Point src, uint32_t srcU8
     const bool reads_ahead = sample == 16 && (channels == 1 || channels == 2) && (int)freq < m->freq;
     const size_t src_bytes = (size_t)srcU8Len + (reads_ahead ? 2 * channels : 0);
     uint8_t *ring = (uint8_t *)m->d_rings;
+    static thread_local MapVec m_src;
+    if (m->h_rings && src_bytes <= kMappedMaxBytes && m_src.ensure(src_bytes + 8) == 0) {
+        memcpy(m_src.host, src.U8, src_bytes);
+        if (first) memcpy(m->h_rings + span_off, wmix->start.U8 + span_off, first);
+        if (second) memcpy(m->h_rings, wmix->start.U8, second);
+        bool okm = wmx_mix_load(m, (const int16_t *)m_src.dev, srcU8Len, freq, channels, sample, 1, 0, 0, reduce, &h, &t, nullptr) == 0;
+        okm = okm && hipStreamSynchronize(nullptr) == hipSuccess;
+        if (!okm) {
+            (void)hipGetLastError();
+            fprintf(stderr, "wmix_amd: wmix_load_data failed on the GPU: %s\n", wmx_last_error());
+            return pHead;
+        }
+        if (first) memcpy(wmix->start.U8 + span_off, m->h_rings + span_off, first);
+        if (second) memcpy(wmix->start.U8, m->h_rings, second);
+        *tick = t;
+        pHead.U8 = wmix->start.U8 + h;
+        return pHead;
+    }
     bool ok = d_src.ensure(src_bytes + 8) == 0;
     ok = ok && hipMemcpy(d_src.p, src.U8, src_bytes, hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && (!first || hipMemcpy(ring + span_off, wmix->start.U8 + span_off, first, hipMemcpyHostToDevice) == hipSuccess);
