@@ -110,6 +110,11 @@ def packet_edge_latency(n_calls=600, warm=100):
         cur["head"] = W.wmix_load_data(C.byref(w), sp, 2560, 16000, 2, 16, hp, 1, C.byref(cur["tick"])).U8
 
     calls["wmix_load_data_2x16000_20ms"] = load
+    x = rng.standard_normal(1024).astype(np.float32)
+    o = [np.zeros(1024, np.float32) for _ in range(4)]
+    W.FFTR.argtypes = [C.c_void_p] * 6 + [C.c_uint]
+    W.FFTR.restype = None
+    calls["FFTR_1024"] = lambda: W.FFTR(x.ctypes.data, None, o[0].ctypes.data, o[1].ctypes.data, o[2].ctypes.data, o[3].ctypes.data, 1024)
     out = {}
     for name, fn in calls.items():
         t = np.zeros(n_calls)

@@ -15,6 +15,7 @@
 #include <mutex>
 #include <utility>
 #include <vector>
+#include <cstring>
 #include "wmx_internal.h"
 #include "fft_ooura.h"  // wave_sync
 #include "../../include/wmix_compat.h"
@@ -770,11 +771,30 @@ extern "C" int wmx_mfft_stream(int n_streams, const float *d_in, unsigned in_len
 // ------------------------------------------------------------------ legacy signatures (math/fft.h:19-51): one transform,
 // host arrays, NULLs as in the reference
 namespace {
+constexpr size_t kLegacyMappedMax = 1u << 20;  // bytes of staging up to which a legacy call goes through a mapped pinned buffer
+
 int legacy(int kind, float *in_re, float *in_im, float *out_re, float *out_im, float *out_af, float *out_pf, unsigned n) {
     unsigned m;
     if (check_size(n, &m)) return -1;
     float *d = nullptr;
     const size_t bytes = (size_t)n * sizeof(float);
+    // One transform of a few KB (the daemon's spectrum display: N = 1024, src/wmix.c:1124-1137): a device allocation and six copies
+    // around the launch cost many times the work.  Pinned host memory mapped into the device instead, owned by the calling thread:
+    // memcpy in, one launch, one synchronisation, memcpy out.
+    static thread_local MapVec mv;
+    if (6 * bytes <= kLegacyMappedMax && mv.ensure(6 * bytes) == 0) {
+        float *hst = reinterpret_cast<float *>(mv.host), *dv = reinterpret_cast<float *>(mv.dev);
+        if (in_re) memcpy(hst, in_re, bytes);
+        if (in_im) memcpy(hst + n, in_im, bytes);
+        if (wmx_mfft(kind, 1, n, in_re ? dv : nullptr, in_im ? dv + n : nullptr, out_re ? dv + 2 * n : nullptr, out_im ? dv + 3 * n : nullptr,
+                     out_af ? dv + 4 * n : nullptr, out_pf ? dv + 5 * n : nullptr, nullptr) != 0 ||
+            hipStreamSynchronize(nullptr) != hipSuccess)
+            return -1;
+        float *outs[4] = {out_re, out_im, out_af, out_pf};
+        for (int k = 0; k < 4; k++)
+            if (outs[k]) memcpy(outs[k], hst + (size_t)(2 + k) * n, bytes);
+        return 0;
+    }
     if (hipMalloc(&d, 6 * bytes) != hipSuccess) return -1;
     float *d_ir = in_re ? d : nullptr, *d_ii = in_im ? d + n : nullptr;
     float *d_or = out_re ? d + 2 * n : nullptr, *d_oi = out_im ? d + 3 * n : nullptr;
@@ -809,6 +829,20 @@ extern "C" void fft_stream(float in[], unsigned int inLen, float stream[], unsig
     if (!in || !stream || inLen == 0 || 2 * inLen > stLen || check_size(stLen, &m)) return;
     float *d = nullptr;
     const size_t sb = (size_t)stLen * sizeof(float), ib = (size_t)inLen * sizeof(float);
+    static thread_local MapVec mv;
+    if (3 * sb + ib <= kLegacyMappedMax && mv.ensure(3 * sb + ib) == 0) {
+        float *hst = reinterpret_cast<float *>(mv.host), *dv = reinterpret_cast<float *>(mv.dev);
+        memcpy(hst, stream, sb);
+        memcpy(hst + 3 * (size_t)stLen, in, ib);
+        if (wmx_mfft_stream(1, dv + 3 * (size_t)stLen, inLen, dv, stLen, outAF ? dv + stLen : nullptr, outPF ? dv + 2 * (size_t)stLen : nullptr,
+                            nullptr) != 0 ||
+            hipStreamSynchronize(nullptr) != hipSuccess)
+            return;
+        memcpy(stream, hst, sb);
+        if (outAF) memcpy(outAF, hst + stLen, sb);
+        if (outPF) memcpy(outPF, hst + 2 * (size_t)stLen, sb);
+        return;
+    }
     if (hipMalloc(&d, 3 * sb + ib) != hipSuccess) return;
     float *d_pool = d, *d_af = d + stLen, *d_pf = d + 2 * stLen, *d_in = d + 3 * stLen;
     bool ok = hipMemcpy(d_pool, stream, sb, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d_in, in, ib, hipMemcpyHostToDevice) == hipSuccess;

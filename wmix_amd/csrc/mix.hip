@@ -123,37 +123,6 @@ struct DevVec {
     }
 };
 
-// Pinned HOST memory mapped into the device, for the legacy adapters' small buffers: two runtime copies around a launch cost several
-// times the work of a few hundred samples (wmix_pcm_zoom of one package: 43 us with copies).  The kernel reads and writes the mapped
-// buffer over PCIe instead: memcpy in, one launch, one synchronisation, memcpy out.
-struct MapVec {
-    uint8_t *host = nullptr, *dev = nullptr;
-    size_t cap = 0;
-    MapVec() = default;
-    MapVec(const MapVec &) = delete;
-    MapVec &operator=(const MapVec &) = delete;
-    int ensure(size_t bytes) {
-        if (bytes <= cap) return 0;
-        if (host) (void)hipHostFree(host);
-        host = dev = nullptr;
-        cap = 0;
-        void *hp = nullptr, *dp = nullptr;
-        WMX_HIP(hipHostMalloc(&hp, bytes < 4096 ? 4096 : bytes, hipHostMallocMapped));
-        if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
-            (void)hipGetLastError();
-            (void)hipHostFree(hp);
-            set_error("hipHostGetDevicePointer failed");
-            return WMX_ENODEV;
-        }
-        host = static_cast<uint8_t *>(hp);
-        dev = static_cast<uint8_t *>(dp);
-        cap = bytes < 4096 ? 4096 : bytes;
-        return 0;
-    }
-    ~MapVec() {
-        if (host && !runtime_exiting()) (void)hipHostFree(host);
-    }
-};
 constexpr size_t kMappedMaxBytes = 64 * 1024;  // above this the DMA engines win: the copy path
 
 }  // namespace

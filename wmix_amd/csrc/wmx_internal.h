@@ -249,6 +249,39 @@ inline hipError_t column_from_host(T *dev, const T *host, int fields, int n_stre
     return hipMemcpy2D(dev + stream, (size_t)n_streams * sizeof(T), host, sizeof(T), sizeof(T), (size_t)fields, hipMemcpyHostToDevice);
 }
 
+// Pinned HOST memory mapped into the device, for the legacy adapters' small buffers: two runtime copies around a launch cost several
+// times the work of a few hundred samples (wmix_pcm_zoom of one package: 43 us with copies).  The kernel reads and writes the mapped
+// buffer over PCIe instead: memcpy in, one launch, one synchronisation, memcpy out.
+struct MapVec {
+    uint8_t *host = nullptr, *dev = nullptr;
+    size_t cap = 0;
+    MapVec() = default;
+    MapVec(const MapVec &) = delete;
+    MapVec &operator=(const MapVec &) = delete;
+    inline int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (host) (void)hipHostFree(host);
+        host = dev = nullptr;
+        cap = 0;
+        void *hp = nullptr, *dp = nullptr;
+        const hipError_t e = hipHostMalloc(&hp, bytes < 4096 ? 4096 : bytes, hipHostMallocMapped);
+        if (e != hipSuccess) return hip_fail(e, "hipHostMalloc(mapped)", __FILE__, __LINE__);
+        if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipHostFree(hp);
+            set_error("hipHostGetDevicePointer failed");
+            return WMX_ENODEV;
+        }
+        host = static_cast<uint8_t *>(hp);
+        dev = static_cast<uint8_t *>(dp);
+        cap = bytes < 4096 ? 4096 : bytes;
+        return 0;
+    }
+    ~MapVec() {
+        if (host && !runtime_exiting()) (void)hipHostFree(host);
+    }
+};
+
 // chain.hip -> aec.hip: let the far kernel of the next wmx_aec_run_* call start at this point of `stream` (see aec.hip)
 int aec_fork_far(wmx_aec *h, hipStream_t stream);
 // the caller returns without the AEC call the fork was made for: the next wmx_aec_run_* starts on its own stream again
