@@ -564,6 +564,8 @@ int wmx_debug_div(const float *d_a, const float *d_b, float *d_q_ordinary, float
 int wmx_debug_div_host(const float *a, const float *b, float *q, size_t n);
 /* Same for the AEC kernel's table-driven powf: y[i] = x[i] ^ e[i]. */
 int wmx_debug_pow(const float *x, const float *e, float *y, size_t n);
+/* ... and evaluated on the device (device pointers; synchronises `stream`) */
+int wmx_debug_pow_device(const float *d_x, const float *d_e, float *d_y, size_t n, void *stream);
 
 #ifdef __cplusplus
 }

@@ -64,12 +64,9 @@ def test_tanh_sweep(wmx, oracle_port):
     assert np.array_equal(got.view(np.uint32)[~nan], want.view(np.uint32)[~nan])
 
 
-def test_pow_sweep(wmx, oracle_port):
-    """The AEC's hNl ^ (overDriveSm * curve): base in (0, 1], exponent in [1, 30].  Since round 5 the product evaluates glibc's own
-    powf algorithm (exp2(y log2 x) in double, 16- and 32-entry tables, fused multiply-adds; wmix_amd/csrc/libm_dev.h): it must equal
-    the host's powf -- which is NOT correctly rounded -- bit for bit, over the AEC's domain, over general positive arguments, and in
-    the cases powf decides by rule (zeros, infinities, NaNs, negative bases with integer and non-integer exponents, subnormals,
-    overflow and underflow).  The rounded double pow, which rounds 1-4 matched instead, differs from it in ~0.1 % of arguments."""
+def _pow_arguments():
+    """6 M arguments of the AEC's domain (base in (0, 1], exponent in [1, 30]), 3 M general positive ones, and the cases powf decides
+    by rule: zeros, infinities, NaNs, negative bases with integer and non-integer exponents, subnormals, overflow and underflow."""
     rng = np.random.default_rng(13)
     n = 6_000_000
     sx = np.array([1.0, 0.5, 1e-30, 1e-45, 0.0, 2.0, np.inf, np.nan, -0.5, -0.5, -0.5, -0.5, -2.0, -2.0, -0.0, -0.0, 0.0, 1e-40, 3e-39, 1e30, 1e-30,
@@ -78,6 +75,16 @@ def test_pow_sweep(wmx, oracle_port):
                    -5.0, np.inf, 3.0, 2.0, -1.0, -np.inf, 127.99, 128.0, -149.0, -150.0, np.inf, 1e10, np.nan, 0.0, 16777217.0, 0.0])
     x = np.concatenate([rng.random(n // 2), 1 - rng.random(n // 2) * 1e-2, np.exp(rng.random(n // 2) * 40 - 20), sx]).astype(np.float32)
     e = np.concatenate([1 + rng.random(n) * 29, rng.random(n // 2) * 16 - 8, se]).astype(np.float32)
+    return x, e
+
+
+def test_pow_sweep(wmx, oracle_port):
+    """The AEC's hNl ^ (overDriveSm * curve): base in (0, 1], exponent in [1, 30].  Since round 5 the product evaluates glibc's own
+    powf algorithm (exp2(y log2 x) in double, 16- and 32-entry tables, fused multiply-adds; wmix_amd/csrc/libm_dev.h): it must equal
+    the host's powf -- which is NOT correctly rounded -- bit for bit, over the AEC's domain, over general positive arguments, and in
+    the cases powf decides by rule (zeros, infinities, NaNs, negative bases with integer and non-integer exponents, subnormals,
+    overflow and underflow).  The rounded double pow, which rounds 1-4 matched instead, differs from it in ~0.1 % of arguments."""
+    x, e = _pow_arguments()
     got = np.zeros_like(x)
     assert wmx.wmx_debug_pow(x.ctypes.data, e.ctypes.data, got.ctypes.data, x.size) == 0
     p = lambda a: a.ctypes.data_as(C.c_void_p)
@@ -91,6 +98,26 @@ def test_pow_sweep(wmx, oracle_port):
     # and the sweep is not vacuous: the correctly rounded power is a different function on these arguments
     d = got.view(np.int32)[ok].astype(np.int64) - dbl.view(np.int32)[ok].astype(np.int64)
     assert np.abs(d).max() == 1 and 1e-4 < (d != 0).mean() < 2e-3
+
+
+@pytest.mark.gpu
+def test_pow_sweep_on_the_device(wmx, cuda, oracle_port):
+    """The same 9 M arguments through the kernel's own aec_powf on the GPU (wmx_debug_pow_device): the vector ALU's fused multiply-adds,
+    conversions, subnormals and the double pow behind the rule cases give the host's powf bit for bit."""
+    import torch
+    x, e = _pow_arguments()
+    dx, de = torch.from_numpy(x).to(cuda), torch.from_numpy(e).to(cuda)
+    dy = torch.empty_like(dx)
+    rc = wmx.wmx_debug_pow_device(dx.data_ptr(), de.data_ptr(), dy.data_ptr(), x.size, None)
+    assert rc == 0, (rc, wmx.wmx_last_error())
+    got = dy.cpu().numpy()
+    flt = np.zeros_like(x)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    with np.errstate(all="ignore"):
+        oracle_port.orc_libm_powf(p(x), p(e), p(flt), C.c_size_t(x.size))
+    ok = ~np.isnan(flt)
+    assert np.array_equal(np.isnan(got), ~ok)
+    assert np.array_equal(got.view(np.uint32)[ok], flt.view(np.uint32)[ok])
 
 
 def test_rejects_bad_arguments(wmx):

@@ -23,6 +23,15 @@ def lib():
             raise WmxError(
                 "libwmix_amd.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C wmix_amd/csrc` (there is no CPU fallback)")
+        # One HIP runtime per process: PyTorch-ROCm brings its own copy of libamdhip64 and loads it by path.  Loaded AFTER torch, this
+        # library's `libamdhip64.so.N` dependency binds to that copy (same SONAME) and both sides share devices, streams and pointers;
+        # loaded BEFORE torch, /opt/rocm's copy comes in as a second runtime, and the one that initialises second finds no device
+        # ("no ROCm-capable device is detected").  The mirrors here always work next to torch (device memory, streams), so torch goes
+        # first.  A C host has no torch and none of this (examples/*.c).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.wmx_build_info.restype = C.c_char_p
         L.wmx_build_info.argtypes = []
@@ -312,6 +321,8 @@ def _declare(L):
     L.wmx_debug_pow.argtypes = [vp, vp, vp, C.c_size_t]
     L.wmx_debug_ns_libm.restype = i
     L.wmx_debug_ns_libm.argtypes = [i, vp, vp, C.c_size_t]
+    L.wmx_debug_pow_device.restype = i
+    L.wmx_debug_pow_device.argtypes = [vp, vp, vp, C.c_size_t, vp]
     L.wmx_debug_div.restype = i
     L.wmx_debug_div.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
     L.wmx_debug_div_host.restype = i

@@ -2402,6 +2402,36 @@ int wmx_aec_timing(wmx_aec *h, int *n_launches, double *far_ms, double *near_ms)
 
 }  // extern "C"
 
+// The same on the DEVICE (device pointers), through the kernel's own out-of-line aec_powf: what the vector ALU's fused
+// multiply-adds, conversions and subnormals make of the routine, swept against the host's powf by tests/test_libm_gpu.py.
+namespace wmx {
+namespace {
+__global__ void dbg_pow_kernel(const float *__restrict__ x, const float *__restrict__ e, float *__restrict__ y, size_t n,
+                               const PowTables *__restrict__ tab) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = aec_powf(x[i], e[i], tab);
+}
+}  // namespace
+}  // namespace wmx
+
+extern "C" int wmx_debug_pow_device(const float *d_x, const float *d_e, float *d_y, size_t n, void *stream) {
+    using namespace wmx;
+    if (!d_x || !d_e || !d_y) return WMX_EINVAL;
+    if (n == 0) return 0;
+    if (current_device() < 0) return WMX_ENODEV;
+    PowTables pt;
+    pow_tables(&pt);
+    PowTables *d_tab = nullptr;
+    WMX_HIP(hipMalloc(reinterpret_cast<void **>(&d_tab), sizeof(pt)));
+    hipError_t e = hipMemcpy(d_tab, &pt, sizeof(pt), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(dbg_pow_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, as_stream(stream), d_x, d_e, d_y, n, d_tab);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(as_stream(stream));
+    (void)hipFree(d_tab);
+    return e == hipSuccess ? 0 : hip_fail(e, "wmx_debug_pow_device", __FILE__, __LINE__);
+}
+
 // Host-side evaluation of the AEC's table-driven powf (libm_dev.h), same source as the kernel, for CPU sweeps against
 // glibc's powf (tests/test_libm_tables.py).
 extern "C" int wmx_debug_pow(const float *x, const float *e, float *y, size_t n) {
