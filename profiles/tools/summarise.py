@@ -41,6 +41,17 @@ if tag == "rtp_chain" and len(sys.argv) <= 5:
     # bench.py's rtp_chain workload runs its PCIe-streaming measurement (min(steps, 100) more steps, H2D / D2H copies beside the
     # kernels) behind the breakdown steps: those launches are not the timed region either
     tail += min(steps, 300) + 4  # (four warm-up submits in front of the streamed steps)
+elif len(sys.argv) <= 5:
+    # the chain workloads' own streaming measurement (ChainWorkload.measure_pcie: a second chain, 300 priming steps + the streamed
+    # ones, copies beside the kernels): when the profiled command ran it, its line says so
+    try:
+        import json as _json
+        _line = [l for l in open(out + "/bench_under_stats.log") if l.startswith("{")][-1]
+        _p = _json.loads(_line)["config"].get("pcie_inclusive")
+        if _p:
+            tail += 300 + int(_p.get("steps", min(steps, 300)))
+    except (OSError, IndexError, KeyError, ValueError):
+        pass
 
 
 def timed(v):

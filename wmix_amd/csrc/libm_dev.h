@@ -214,7 +214,7 @@ __host__ __device__ __forceinline__ float fast_tanh(float xf, const NsLibmTables
 // exp2 table is 2^(i/32) with i << 47 taken off the bits), and tests/test_libm_tables.py sweeps it against the host's powf:
 // 6 M arguments of the AEC's domain and the special cases, bit for bit.
 struct PowTables {
-    double invc[16], logc[16];  // log2: c near the centre of [0x1.66p-1 * 2^(i/16) ...), invc = RN(1/c), logc = RN(log2 c)
+    double2 lt[16];             // log2: c near the centre of [0x1.66p-1 * 2^(i/16) ...), .x = invc = RN(1/c), .y = logc = RN(log2 c)
     double A[5];                // log2(1 + r) / r - polynomial, degree 4
     unsigned long long E[32];   // bits(2^(i/32)) - (i << 47)
     double C[3];                // 2^r - 1 polynomial, degree 3
@@ -237,7 +237,7 @@ inline void pow_tables(PowTables *t) {
         0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull, 0x3feee89f995ad3adull,
         0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
         0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
-    for (int i = 0; i < 16; i++) t->invc[i] = invc[i], t->logc[i] = logc[i];
+    for (int i = 0; i < 16; i++) t->lt[i].x = invc[i], t->lt[i].y = logc[i];
     t->A[0] = 0x1.27616c9496e0bp-2, t->A[1] = -0x1.71969a075c67ap-2, t->A[2] = 0x1.ec70a6ca7baddp-2, t->A[3] = -0x1.7154748bef6c8p-1,
     t->A[4] = 0x1.71547652ab82bp0;
     for (int i = 0; i < 32; i++) t->E[i] = E[i];
@@ -277,14 +277,15 @@ __host__ __device__ __forceinline__ float fast_pow(float x, float y, const PowTa
     }
     // log2_inline
     const unsigned tmp = ix - 0x3f330000u;
-    const int i = (int)((tmp >> (23 - 4)) % 16u);
+    const unsigned i = (tmp >> (23 - 4)) & 15u;
     const unsigned top = tmp & 0xff800000u, iz = ix - top;
     const int k = (int)top >> 23;  // arithmetic shift
     float zf;
     __builtin_memcpy(&zf, &iz, 4);
     const double z = (double)zf;
-    const double r = fma(z, M->invc[i], -1.0);
-    const double y0 = M->logc[i] + (double)k;
+    const double2 ic = M->lt[i];  // one 16-byte load
+    const double r = fma(z, ic.x, -1.0);
+    const double y0 = ic.y + (double)k;
     const double r2 = r * r;
     double yy = fma(M->A[0], r, M->A[1]);
     const double p = fma(M->A[2], r, M->A[3]);
@@ -295,7 +296,7 @@ __host__ __device__ __forceinline__ float fast_pow(float x, float y, const PowTa
     const double ylogx = (double)y * yy;
     unsigned long long yb;
     __builtin_memcpy(&yb, &ylogx, 8);
-    if ((yb >> 47 & 0xffffull) >= (0x405f800000000000ull >> 47)) {  // |y log2 x| >= 126
+    if (((unsigned)(yb >> 32) >> 15 & 0xffffu) >= (0x405f8000u >> 15)) {  // |y log2 x| >= 126 (bits 47 .. 62 of the double, as glibc tests them)
         if (ylogx > 0x1.fffffffd1d571p+6) return sign_bias ? -__builtin_huge_valf() : __builtin_huge_valf();
         if (ylogx <= -150.0) return sign_bias ? -0.0f : 0.0f;
     }
@@ -306,8 +307,9 @@ __host__ __device__ __forceinline__ float fast_pow(float x, float y, const PowTa
     __builtin_memcpy(&ki, &kd, 8);
     kd -= kShift;
     const double rr = ylogx - kd;
-    unsigned long long t = M->E[ki % 32];
-    t += (ki + sign_bias) << (52 - 5);
+    // t = E[ki % 32] + ((ki + sign_bias) << 47): only the low 17 bits of the sum reach the double, all of them in its high word
+    unsigned long long t = M->E[(unsigned)ki & 31u];
+    t += (unsigned long long)(((unsigned)ki + (unsigned)sign_bias) << 15) << 32;
     double sc;
     __builtin_memcpy(&sc, &t, 8);
     const double zz = fma(M->C[0], rr, M->C[1]);
