@@ -6,7 +6,7 @@ src/wmixTask.c:1124-1143), for a batch of streams with only the 172-byte datagra
     in place) -> zoom 1x8000 -> A-law encode -> RTP header with the stream's running seq / timestamp (rtp.hip)
 
 This file is a ctypes mirror: the sequencing -- pinned slots, the copy-in and copy-out HIP streams, the events, the three launches
-per step -- lives in the library (wmix_amd/csrc/pipe.hip, wmx_pipe_*), where a C host finds it too (examples/host_chain.c --rtp).
+per step -- lives in the library (wmix_amd/csrc/pipe.hip, wmx_pipe_*), where a C host finds it too (examples/host_rtp_pipe.c; its --pcm mode drives wmx_pipe_create_pcm).
 `RtpChain.step()` works on datagrams already resident in HBM; `StreamingPipe` drives the slots: H2D of step k + 1 and D2H of
 step k - 1 overlap the compute of step k.
 """
