@@ -1644,7 +1644,8 @@ def main():
         wl.step("all")
     sync_all()
 
-    if hasattr(wl, "measure_pcie") and rank == 0:
+    if hasattr(wl, "measure_pcie") and rank == 0 and (dist is None or not isinstance(wl, ChainWorkload)):
+        # (several ranks: the chain workloads stream nothing, and every rank replays its own streams further down)
         parity_early = wl.parity_check()  # before the streaming steps advance the state past what was recorded
         wl.measure_pcie(min(args.steps, 300))
     else:
