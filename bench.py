@@ -1412,7 +1412,12 @@ def _launch_ranks(n, argv):
 
 
 # BASELINE.json configs[0], [1], [3], [4] as (workload, streams per GPU): the default line (configs[2]) carries a short run of each
-SIDE_CONFIGS = [("configs[0]", "g711"), ("configs[1]", "ns"), ("configs[3]", "ns_aec_8k"), ("configs[4]", "ns_agc_mix_32k")]
+# (label, workload[, overrides]): the other BASELINE configs, and the headline workload once more in the shape the reference itself
+# calls the wrappers with -- handles made with WMIX_INTERVAL_MS = 20, one 20 ms heartbeat (two 10 ms packets) per call
+# (src/wmixConf.h:112, src/wmix.c:613-709) -- next to the headline's one packet per launch
+SIDE_CONFIGS = [("configs[0]", "g711"), ("configs[1]", "ns"), ("configs[3]", "ns_aec_8k"), ("configs[4]", "ns_agc_mix_32k"),
+                ("configs[2] at the daemon's cadence: 20 ms handles, one 20 ms heartbeat per launch", "chain",
+                 {"packets_per_step": 2, "interval_ms": 20})]
 
 
 def _make_workload(cls, dev, n_mine, rank, dist, args, lo=0):
@@ -1426,7 +1431,7 @@ def _make_workload(cls, dev, n_mine, rank, dist, args, lo=0):
     return cls(dev, n_mine, rank)
 
 
-def _side_config(label, name, args, dev):
+def _side_config(label, name, args, dev, overrides=None):
     """One of the other BASELINE configs, measured like the headline (same --steps / --warmup / --prime / --spinup, HIP events
     around the timed steps, the dominant kernel bracketed by its own events) and proven in the same run: parity_check replays
     sampled streams through the oracle for exactly the packets fed.  One GPU, no CPU baseline (the workload's own line has it)."""
@@ -1434,6 +1439,8 @@ def _side_config(label, name, args, dev):
     cls, n = WORKLOADS[name]
     a = copy.copy(args)
     a.packets_per_step, a.interval_ms, a.cohorts, a.cohort_layout, a.coalesce, a.far_ends, a.far_chunk = 1, 10, 1, "arrival", False, 1, 1
+    for k, v in (overrides or {}).items():
+        setattr(a, k, v)
     t_start = time.perf_counter()
     wl = _make_workload(cls, dev, n, 0, None, a)
 
@@ -1449,7 +1456,7 @@ def _side_config(label, name, args, dev):
         frac = wl.dominant_bytes_per_frame * wl.n_frames / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     parity = wl.parity_check()
     entry = {"config": label, "workload": wl.name, "streams": n, "value": wl.n_frames * a.steps / elapsed, "unit": "frames/s",
-             "ms_per_step": elapsed / a.steps * 1e3, "steps": a.steps, "warmup": a.warmup, "primed_steps": n_prime, "dtype": wl.dtype,
+             "ms_per_step": elapsed / a.steps * 1e3, "frames_per_step": wl.n_frames, "steps": a.steps, "warmup": a.warmup, "primed_steps": n_prime, "dtype": wl.dtype,
              "roofline": {"kernel": wl.dominant_kernel, "frac": round(frac, 5) if frac else None,
                           "avg_launch_ms": round(dom_ms, 5) if dom_ms else None,
                           "algorithmic_bytes_per_launch": wl.dominant_bytes_per_frame * wl.n_frames},
@@ -1721,7 +1728,7 @@ def main():
             wl.chain.close()
             del wl
             torch.cuda.empty_cache()
-            out["configs"] = [_side_config(label, name, args, dev) for label, name in SIDE_CONFIGS]
+            out["configs"] = [_side_config(c[0], c[1], args, dev, c[2] if len(c) > 2 else None) for c in SIDE_CONFIGS]
             # the same entries, cut down to what fits any truncation of the line, inside `config`
             out["config"]["configs"] = [{"config": e["config"], "workload": e["workload"], "streams": e["streams"],
                                          "value": round(e["value"], 1), "ms_per_step": round(e["ms_per_step"], 5),
