@@ -163,3 +163,23 @@ def test_round5_entry_points_refuse_bad_arguments(cuda):
     far = torch.zeros((2, 80), dtype=torch.int16, device=cuda)
     assert W.wmx_pipe_step_resident(pc._h, d.data_ptr(), 100, far.data_ptr(), d.data_ptr(), 172, None) < 0  # rows shorter than a datagram
     pc.close()
+    # later in round 5: the platform constants, rwTest, the PCM pipeline, the device-side pow sweep
+    from wmix_amd.mix import MixBatch
+    from wmix_amd.pipeline import PcmChain
+    mb = MixBatch(2, 1, 8000)
+    for bad in (16000, 3201, 1 << 20):      # not inside the ring / not a whole frame
+        with pytest.raises(WmxError):
+            mb.set_play_correct(bad)
+    mb.set_play_correct(0)
+    mb.close()
+    assert W.wmx_mix_set_play_correct(None, 0) < 0 and W.wmx_tick_set_play_correct(None, 0) < 0 and W.wmx_tick_rw_test(None, 1) < 0
+    with pytest.raises(KeyError):
+        TickBatch.for_platform("qnx", 2)
+    pcm = PcmChain(3, cuda, 1, 16000, 10, 5, 15, slots=1)
+    x = torch.zeros((3, 200), dtype=torch.int16, device=cuda)
+    farp = torch.zeros((1, 160), dtype=torch.int16, device=cuda)
+    assert W.wmx_pipe_step_resident(pcm._h, x.data_ptr(), 400, farp.data_ptr(), x.data_ptr(), 320, None) < 0   # in place: one stride
+    assert W.wmx_pipe_step_resident(pcm._h, x.data_ptr(), 300, farp.data_ptr(), x.data_ptr(), 300, None) < 0   # rows shorter than a package
+    assert W.wmx_pipe_datagram_bytes(pcm._h) == 320
+    pcm.close()
+    assert W.wmx_debug_pow_device(None, None, None, 4, None) < 0 and W.wmx_debug_pow_device(x.data_ptr(), x.data_ptr(), x.data_ptr(), 0, None) == 0
