@@ -17,12 +17,14 @@ from wmix_amd import synth
 EXE = os.path.join(ROOT, "examples", "host_chain")
 EXE_RCCL = os.path.join(ROOT, "examples", "host_chain_rccl")
 EXE_RTP = os.path.join(ROOT, "examples", "host_rtp_pipe")
+EXE_TICK = os.path.join(ROOT, "examples", "host_tick")
 
 
 def test_host_chain_is_built():
     assert os.path.exists(EXE), "examples/host_chain missing: run __graft_entry__.build()"
     assert os.path.exists(EXE_RCCL), "examples/host_chain_rccl missing: run __graft_entry__.build()"
     assert os.path.exists(EXE_RTP), "examples/host_rtp_pipe missing: run __graft_entry__.build()"
+    assert os.path.exists(EXE_TICK), "examples/host_tick missing: run __graft_entry__.build()"
 
 
 @pytest.mark.gpu
@@ -158,3 +160,35 @@ def test_host_pcm_pipe_vs_oracle(tmp_path, oracle_port):
     for s in (0, 7, 20):
         want = L.run_chain(oracle_port, 1, freq, 5, 15, far, near[s].reshape(-1), pkg, prefix="orc", interval_ms=interval)
         assert np.array_equal(got[s], want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("platform,rwtest", [("alsa", False), ("t31", True), ("hi3516", False)])
+def test_host_tick_vs_one_daemon_per_group(tmp_path, oracle_port, platform, rwtest):
+    """examples/host_tick.c: the daemon's whole tick for several mixers from plain C (wmx_tick_load / _play / _far / _record; the room
+    on the host) -- played package, far-end and record streams against one oracle daemon per group, for the reference's platform
+    builds and with its self send-receive test on."""
+    from test_tick_oracle import tick_inputs
+    G, n_src, R, T, sfreq, schn = 3, 2, 2, 120, 16000, 2
+    aec_ms, correct = L.PLATFORMS[platform]
+    per_group = [tick_inputs(640 + g, T, n_src, R, sfreq, schn) for g in range(G)]
+    src = np.stack([p[0] for p in per_group])     # [G, T, n_src, per]
+    local = np.stack([p[1] for p in per_group])   # [G, T, R, 160]
+    if rwtest:
+        src[:, 40:] = 0
+    np.ascontiguousarray(src.transpose(1, 0, 2, 3)).astype("<i2").tofile(tmp_path / "src.i16")
+    np.ascontiguousarray(local.transpose(1, 0, 2, 3)).astype("<i2").tofile(tmp_path / "local.i16")
+    cmd = [EXE_TICK, str(tmp_path / "src.i16"), str(tmp_path / "local.i16"), str(tmp_path / "out.i16"), str(G), str(n_src), str(R), str(T),
+           str(sfreq), str(schn), "--platform", platform] + (["--rwtest"] if rwtest else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["rc"] == 0 and info["platform"] == platform and info["aec_delay_ms"] == aec_ms
+    got = np.fromfile(tmp_path / "out.i16", dtype="<i2").reshape(T, 2 * G + G * R, 160)
+    for g in range(G):
+        want = L.tick_port(oracle_port, src[g], local[g], sfreq, schn, stages=15 | (32 if rwtest else 0), aec_delay_ms=aec_ms,
+                           play_correct=correct)
+        assert np.array_equal(got[:, g], want["play"]) and np.array_equal(got[:, G + g], want["far"])
+        assert np.array_equal(got[:, 2 * G + g * R: 2 * G + (g + 1) * R], want["out"])
+    bad = subprocess.run(cmd[:10] + ["--platform", "qnx"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 2 and "qnx" in bad.stderr
