@@ -342,7 +342,9 @@ def mix_bind(p):
 def mix_zoom(p, ic, ifr, x, oc, ofr):
     """orc_pcm_zoom of one int16 buffer: the bytes wmix_pcm_zoom would write, as int16."""
     mix_bind(p)
-    out = np.zeros(x.size * 16 + 64, np.int16)
+    # room for what the walk can write: one output frame per input frame or ofr / ifr of them, whichever is more (x.size * 16 was
+    # too little for 1 x 5000 -> 2 x 48000: tools_dev/fuzz_mix.py found the heap corruption in THIS helper)
+    out = np.zeros((int(np.ceil(x.size / ic * max(ofr / ifr, 1.0))) + 8) * oc + 64, np.int16)
     m = p.orc_pcm_zoom(ic, ifr, x.ctypes.data_as(C.c_void_p), x.size * 2, oc, ofr, out.ctypes.data_as(C.c_void_p))
     return out[: m // 2].copy()
 

@@ -261,7 +261,7 @@ int main(int argc, char **argv)
     if (!strcmp(argv[1], "zoom") && argc == 6) {
         size_t n;
         unsigned char *in = slurp(&n);
-        unsigned char *out = calloc(n * 8 + 64, 1);
+        unsigned char *out = calloc(n * 48 + 64, 1); /* 1 x 5000 -> 2 x 48000 writes 19.2 bytes per input byte */
         uint32_t m = wmix_pcm_zoom(atoi(argv[2]), atoi(argv[3]), in, (uint32_t)n, atoi(argv[4]), atoi(argv[5]), out);
         fwrite(out, 1, m, stdout);
         return 0;

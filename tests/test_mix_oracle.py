@@ -98,3 +98,28 @@ def test_against_the_other_platform_builds(oracle_port, platform):
             assert np.array_equal(meta, np.frombuffer(b[16000:], dtype=np.uint32).reshape(nsrc, 2))
             other, _ = L.mix_load(oracle_port, 1, 8000, freq, chn, rmode, rarg, nsrc, sbytes, start, src)  # platform/alsa's 3200
             assert not np.array_equal(other, ring)
+
+
+def test_random_formats_against_the_real_reference(oracle_port):
+    """Seeded random campaign, restatement vs the REAL wmix_pcm_zoom / wmix_load_data (ref_mix_driver): odd rate pairs, both channel
+    counts, lengths, reduce modes, several sources, play heads anywhere in the ring (the wrap included).  tools_dev/fuzz_mix.py draws
+    the same kind of cases for the device against the restatement."""
+    if not L.have_ref_mix():
+        pytest.skip("oracle/_ref/ref_mix_driver not present")
+    _bind(oracle_port)
+    rng = np.random.default_rng(int(os.environ.get("WMIX_FUZZ_SEED", "77")))
+    rates = [5000, 8000, 11025, 12000, 16000, 22050, 24000, 32000, 44100, 48000]
+    for _ in range(int(os.environ.get("WMIX_FUZZ_CASES", "150"))):
+        ic, oc, ifr, ofr = int(rng.integers(1, 3)), int(rng.integers(1, 3)), int(rng.choice(rates)), int(rng.choice(rates))
+        x = rng.integers(-32768, 32768, size=int(rng.integers(1, 600)) * ic, dtype=np.int16)
+        want = np.frombuffer(L.ref_mix("zoom", ic, ifr, oc, ofr, stdin=x.tobytes()), dtype=np.int16)
+        assert np.array_equal(orc_zoom(oracle_port, ic, ifr, x, oc, ofr), want), (ic, ifr, oc, ofr, x.size)
+        chn, freq = int(rng.integers(1, 3)), int(rng.choice(rates))
+        rmode, rarg, nsrc = int(rng.choice([1, 1, 2, 4])), int(rng.choice([1, 1, 2, 4])), int(rng.integers(1, 6))
+        sbytes = int(rng.integers(1, 400)) * chn * 2
+        start = int(rng.choice([0, 15998, int(rng.integers(0, 8000)) * 2]))
+        src = rng.integers(-30000, 30000, size=nsrc * sbytes // 2 + 8, dtype=np.int16)
+        b = L.ref_mix("load", freq, chn, rmode, rarg, nsrc, sbytes, start, stdin=src.tobytes())
+        ring, meta = orc_load(oracle_port, 1, 8000, freq, chn, rmode, rarg, nsrc, sbytes, start, src)
+        assert np.array_equal(ring, np.frombuffer(b[:16000], dtype=np.int16)), (freq, chn, rmode, rarg, nsrc, sbytes, start)
+        assert np.array_equal(meta, np.frombuffer(b[16000:], dtype=np.uint32).reshape(nsrc, 2))
