@@ -109,3 +109,27 @@ def test_unaligned_layouts_take_the_byte_kernels_and_agree(cuda):
             want.setdefault("pcm", pcm.clone())
             assert torch.equal(pcm, want["pcm"]) and bool((nbytes == 320).all()) and bool((seq.view(torch.uint8).view(S, 2)[:, 1] == 1).all()), (name, pcm_off)
         snd.close()
+
+
+def test_ingest_of_arbitrary_datagrams_vs_oracle(cuda, oracle_port):
+    """20 000 datagrams of random bytes -- every payload type, marker, version, CSRC count, whatever -- and 20 000 with a G.711
+    payload type and random rest: what rtp_recv + G711a2PCM leave (bytes delivered, header bytes 2..3, PCM) equals the restatement,
+    which is pinned on the real functions (tests/test_rtp_oracle.py)."""
+    rng = np.random.default_rng(424242)
+    pk = rng.integers(0, 256, size=(40000, 172), dtype=np.uint8)
+    pk[20000:, 1] = (pk[20000:, 1] & 0x80) | rng.choice([0, 8], size=20000).astype(np.uint8)
+    pcm, nbytes, seq = rtp.ingest(torch.from_numpy(pk).to(cuda))
+    pcm, nbytes, seq = pcm.cpu().numpy(), nbytes.cpu().numpy(), seq.cpu().numpy().view(np.uint16)
+    ing = oracle_port.orc_rtp_ingest
+    ing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    ing.restype = C.c_int
+    want = np.zeros(160, np.int16)
+    sq = C.c_uint16(0)
+    decoded = 0
+    for k in range(len(pk)):
+        n = ing(pk[k].ctypes.data, want.ctypes.data, C.byref(sq))
+        assert (n, sq.value) == (int(nbytes[k]), int(seq[k])), k
+        if n:
+            decoded += 1
+            assert np.array_equal(pcm[k], want), k
+    assert 20000 <= decoded < 21000  # the random half hits payload type 0 or 8 once in 64
