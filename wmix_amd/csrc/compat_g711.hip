@@ -37,7 +37,7 @@ struct Mapped {
     int ensure() {
         if (host) return 0;
         void *hp = nullptr, *dp = nullptr;
-        WMX_HIP(hipHostMalloc(&hp, 3 * kMappedMax, hipHostMallocMapped));
+        WMX_HIP(hipHostMalloc(&hp, 3 * kMappedMax, hipHostMallocMapped | hipHostMallocPortable));
         if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
             (void)hipGetLastError();
             (void)hipHostFree(hp);

@@ -28,7 +28,7 @@ struct DevBuf {
         host = p = nullptr;
         cap = 0;
         void *hp = nullptr, *dp = nullptr;
-        if (hipHostMalloc(&hp, n * sizeof(int16_t), hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+        if (hipHostMalloc(&hp, n * sizeof(int16_t), hipHostMallocMapped | hipHostMallocPortable) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
             (void)hipGetLastError();
             if (hp) (void)hipHostFree(hp);
             return false;

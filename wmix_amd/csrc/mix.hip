@@ -424,7 +424,7 @@ WMix_Point wmix_load_data(WMix_Struct_Head *wmix, WMix_Point src, uint32_t srcU8
         if (wmx_mix_create(&m, 1, ring_chn, ring_freq) != 0) return pHead;
         {  // this ring only ever holds the span of one call: pinned host memory the kernel works on over PCIe (see MapVec)
             void *hp = nullptr, *dp = nullptr;
-            if (hipHostMalloc(&hp, m->ring_bytes, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+            if (hipHostMalloc(&hp, m->ring_bytes, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
                 (void)hipFree(m->d_rings);
                 memset(hp, 0, m->ring_bytes);
                 m->h_rings = static_cast<uint8_t *>(hp);

@@ -264,7 +264,7 @@ struct MapVec {
         host = dev = nullptr;
         cap = 0;
         void *hp = nullptr, *dp = nullptr;
-        const hipError_t e = hipHostMalloc(&hp, bytes < 4096 ? 4096 : bytes, hipHostMallocMapped);
+        const hipError_t e = hipHostMalloc(&hp, bytes < 4096 ? 4096 : bytes, hipHostMallocMapped | hipHostMallocPortable);
         if (e != hipSuccess) return hip_fail(e, "hipHostMalloc(mapped)", __FILE__, __LINE__);
         if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
             (void)hipGetLastError();
