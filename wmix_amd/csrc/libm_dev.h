@@ -206,7 +206,8 @@ __host__ __device__ __forceinline__ float fast_tanh(float xf, const NsLibmTables
 // powf for the AEC's OverdriveAndSuppress (aec_core.c:278: hNl[i] = powf(hNl[i], overDriveSm * curve[i])) -- glibc's own
 // algorithm, bit for bit (round 5).  Rounds 1-4 evaluated x^y = exp(y log x) in double end to end: nearly correctly rounded, which
 // glibc's powf is NOT, so 0.09 % of arguments came out one float ulp apart and a handful of samples per 10^8 one LSB (behind the AGC
-// two) off the reference.  glibc 2.28+ computes powf as exp2(y * log2 x) in double: log2 by a 16-entry (1/c, log2 c) table and a
+// two) off the reference.  The reference links the host's libm -- here glibc 2.35 (Ubuntu 2.35-0ubuntu3.11), not part of
+// /root/reference.  glibc 2.28+ computes powf as exp2(y * log2 x) in double: log2 by a 16-entry (1/c, log2 c) table and a
 // degree-4 polynomial in r = z/c - 1, exp2 by a 32-entry 2^(i/32) table and a degree-3 polynomial, one rounding to float at the end
 // (sysdeps/ieee754/flt-32/e_powf.c, from Arm's optimized routines; on x86-64 the ifunc picks the build with fused multiply-adds on
 // any CPU that has them -- the reference's hosts here do).  The restatement below follows it operation for operation, every a * b + c
