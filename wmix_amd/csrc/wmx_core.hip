@@ -53,7 +53,7 @@ int wmx_device_count(void) {
     return n;
 }
 
-int wmx_version(void) { return 300; }
+int wmx_version(void) { return 310; }  // 310: platform setters, rwTest, the PCM pipeline (round 5, second half)
 
 // "default" for the product build; otherwise the developer flags it was made with (the Makefile's EXTRA), prefixed "TIMING-ONLY
 // (wrong results): " when one of them is a timing experiment's switch.  See build_flags.h.
