@@ -523,7 +523,7 @@ class RtpChainWorkload:
         pipe.drain()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        self.pcie = {"value": self.n_frames * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3,
+        self.pcie = {"value": self.n_frames * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "priming_steps": 4,
                      "bytes_over_pcie_per_step": 2 * 172 * self.S, "GB_per_s_each_way": 172 * self.S * steps / dt / 1e9,
                      "note": "wmx_pipe_submit / wmx_pipe_wait (the library's own C pipeline): pinned host rows, 3 slots in flight, copy-in / "
                              "copy-out streams beside the compute stream; the streaming steps fed the pinned slots' datagrams again, so "
@@ -896,7 +896,7 @@ class ChainWorkload:
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         row = self.pkt * 2
-        self.pcie = {"value": self.n_frames * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+        self.pcie = {"value": self.n_frames * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "priming_steps": 300,
                      "bytes_over_pcie_per_step": 2 * row * self.n_streams, "GB_per_s_each_way": row * self.n_streams * steps / dt / 1e9,
                      "note": "wmx_pipe_create_pcm + wmx_pipe_submit / wmx_pipe_wait: pinned host rows of one 10 ms package per stream, 3 slots "
                              "in flight, copy-in / copy-out streams beside the compute stream; a second chain of the same shape, primed 300 "
@@ -1654,7 +1654,8 @@ def main():
     if hasattr(wl, "measure_pcie") and rank == 0 and (dist is None or not isinstance(wl, ChainWorkload)):
         # (several ranks: the chain workloads stream nothing, and every rank replays its own streams further down)
         parity_early = wl.parity_check()  # before the streaming steps advance the state past what was recorded
-        wl.measure_pcie(min(args.steps, 300))
+        # at least 200 streamed steps whatever --steps says: the pipeline's fill and drain (three slots) are not part of its rate
+        wl.measure_pcie(max(min(args.steps, 300), 200))
     else:
         parity_early = None
     frames_total = sum(per_rank_frames) * args.steps  # every rank's own share (equal without --total-streams)

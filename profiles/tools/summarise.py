@@ -37,19 +37,16 @@ if stats:
 # must agree with.
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 tail = int(sys.argv[5]) if len(sys.argv) > 5 else min(steps, 16)
-if tag == "rtp_chain" and len(sys.argv) <= 5:
-    # bench.py's rtp_chain workload runs its PCIe-streaming measurement (min(steps, 100) more steps, H2D / D2H copies beside the
-    # kernels) behind the breakdown steps: those launches are not the timed region either
-    tail += min(steps, 300) + 4  # (four warm-up submits in front of the streamed steps)
-elif len(sys.argv) <= 5:
-    # the chain workloads' own streaming measurement (ChainWorkload.measure_pcie: a second chain, 300 priming steps + the streamed
-    # ones, copies beside the kernels): when the profiled command ran it, its line says so
+if len(sys.argv) <= 5:
+    # bench.py's chain and rtp_chain workloads run a PCIe-streaming measurement behind the breakdown steps (priming + streamed steps,
+    # H2D / D2H copies beside the kernels; the chain workloads on a second chain): those launches are not the timed region either.
+    # The profiled command's own line says how many there were.
     try:
         import json as _json
         _line = [l for l in open(out + "/bench_under_stats.log") if l.startswith("{")][-1]
         _p = _json.loads(_line)["config"].get("pcie_inclusive")
         if _p:
-            tail += 300 + int(_p.get("steps", min(steps, 300)))
+            tail += int(_p["priming_steps"]) + int(_p["steps"])
     except (OSError, IndexError, KeyError, ValueError):
         pass
 
