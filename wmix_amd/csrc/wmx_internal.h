@@ -9,9 +9,23 @@
 #include "../../include/wmix_amd.h"
 #include "build_flags.h"
 
+// Fault injection (developer variant only: -DWMX_FAULT_INJECTION, recorded by wmx_build_info and refused by the Python mirror like every
+// variant build).  Every runtime call that goes through WMX_HIP / WMX_HIP_RC first passes a countdown; when it reaches zero the call is
+// NOT made and reports hipErrorUnknown instead -- "call n of this entry point failed" -- so that tests can walk a fault through every
+// fallible step of an entry point (tests/test_pipe_faults_gpu.py).  Armed by wmx_debug_fail_nth_hip_call(n) or, for the first arming,
+// WMIX_AMD_FAIL_NTH_HIP_CALL=n in the environment; wmx_debug_hip_calls() = calls counted since the last arming.
+#ifdef WMX_FAULT_INJECTION
+namespace wmx {
+hipError_t fault_point();
+}
+#define WMX_FAULT_OR(expr) (wmx::fault_point() != hipSuccess ? hipErrorUnknown : (expr))
+#else
+#define WMX_FAULT_OR(expr) (expr)
+#endif
+
 #define WMX_HIP_RC(expr)                                                      \
     do {                                                                      \
-        hipError_t _e = (expr);                                               \
+        hipError_t _e = WMX_FAULT_OR(expr);                                   \
         if (_e != hipSuccess) return wmx::hip_fail(_e, #expr, __FILE__, __LINE__); \
     } while (0)
 
@@ -353,7 +367,7 @@ __device__ __forceinline__ void touch_done(int &sink) { asm volatile("s_waitcnt 
 
 #define WMX_HIP(expr)                                                         \
     do {                                                                      \
-        hipError_t _e = (expr);                                               \
+        hipError_t _e = WMX_FAULT_OR(expr);                                   \
         if (_e != hipSuccess) return wmx::hip_fail(_e, #expr, __FILE__, __LINE__); \
     } while (0)
 

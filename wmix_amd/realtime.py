@@ -1,0 +1,177 @@
+"""The paced heartbeat over S concurrent streams in host memory: a ctypes mirror of wmx_rt_* (wmix_amd/csrc/rt.hip) and the paced
+loop around it.
+
+The reference's record thread is a paced loop -- one package of WMIX_INTERVAL_MS = 20 ms per tick (src/wmixConf.h:112), the tick's work
+and a sleep adding up to WMIX_INTERVAL_MS * 1000 - 2000 us (src/wmix.c:536-538, 820; the play thread :1468-1474): a tick has to be done
+2 ms before the next package is due.  `RtBatch` is that tick for S streams (sub-batches of a wmx_pipe each, uploads and downloads beside
+the compute); `paced_loop` releases one tick per period on an absolute schedule and reports, per tick, the time from the SCHEDULED
+release to the moment the last row is back in host memory -- a tick that starts late because its predecessor overran carries that
+backlog in its own latency.  examples/host_paced.c is the same loop in C.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+import torch
+
+from ._lib import check, lib
+from .chain import AEC, AGC, NS, VAD
+from .pipeline import DATAGRAM, PKT, _host_rows
+
+
+class RtBatch:
+    """wmx_rt_create_pcm (kind "pcm": rows are int16 packages of chn x freq x interval_ms) or wmx_rt_create_rtp (kind "rtp": rows are
+    172-byte RTP/PCMA datagrams, 8 kHz mono, 20 ms)."""
+
+    def __init__(self, n_streams, dev, sub_batch=65536, slots=2, kind="pcm", chn=1, freq=16000, interval_ms=20, agc_value=5,
+                 stages=NS | AEC | AGC | VAD):
+        self.n, self.dev, self.kind, self.slots = int(n_streams), dev, kind, slots
+        self._h = C.c_void_p()
+        L = lib()
+        if kind == "pcm":
+            check(L.wmx_rt_create_pcm(C.byref(self._h), self.n, sub_batch, slots, chn, freq, interval_ms, agc_value, stages), "wmx_rt_create_pcm")
+            self.pkt10, self.ppc = freq // 100 * chn, interval_ms // 10
+            self.row, self.row_dtype, self.far_shape = self.pkt10 * self.ppc, np.int16, (self.ppc, self.pkt10)
+            self.row_bytes = self.row * 2
+        else:
+            check(L.wmx_rt_create_rtp(C.byref(self._h), self.n, sub_batch, slots, 0, agc_value, stages), "wmx_rt_create_rtp")
+            self.pkt10, self.ppc = PKT, 2
+            self.row, self.row_dtype, self.far_shape, self.row_bytes = DATAGRAM, np.uint8, (2, PKT), DATAGRAM
+        self.B = L.wmx_rt_batches(self._h)
+        self.batch_n = [L.wmx_rt_batch_streams(self._h, b) for b in range(self.B)]
+        self.lo = np.concatenate([[0], np.cumsum(self.batch_n)]).astype(np.int64)
+        self.pipes = [L.wmx_rt_pipe(self._h, b) for b in range(self.B)]
+        # numpy views of the library's pinned rows: h_in[b][slot] is [batch_n[b], row]
+        self.h_in = [[_host_rows(L.wmx_pipe_in(p, s), (n, self.row), self.row_dtype) for s in range(slots)] for p, n in zip(self.pipes, self.batch_n)]
+        self.h_out = [[_host_rows(L.wmx_pipe_out(p, s), (n, self.row), self.row_dtype) for s in range(slots)] for p, n in zip(self.pipes, self.batch_n)]
+        self.h_far = [_host_rows(L.wmx_rt_far(self._h, s), self.far_shape, np.int16) for s in range(slots)]
+
+    def locate(self, stream):
+        """(sub-batch, row) of a stream"""
+        b = int(np.searchsorted(self.lo, stream, side="right") - 1)
+        return b, int(stream - self.lo[b])
+
+    def fill(self, slot, rows):
+        """rows: [S, row] host array -> the slot's pinned input rows of every sub-batch"""
+        for b in range(self.B):
+            self.h_in[b][slot][:] = rows[self.lo[b]:self.lo[b + 1]]
+
+    def gather(self, slot, streams=None):
+        if streams is None:
+            return np.concatenate([self.h_out[b][slot] for b in range(self.B)])
+        return np.stack([self.h_out[b][slot][r] for b, r in map(self.locate, streams)])
+
+    def _far(self, far):
+        if far is None:
+            return None
+        assert far.is_cuda and far.dtype == torch.int16 and far.is_contiguous() and far.numel() == self.ppc * self.pkt10
+        return far.data_ptr()
+
+    def submit(self, far=None):
+        slot = C.c_int(-1)
+        check(lib().wmx_rt_submit(self._h, self._far(far), C.byref(slot), torch.cuda.current_stream().cuda_stream), "wmx_rt_submit")
+        return slot.value
+
+    def wait(self):
+        check(lib().wmx_rt_wait(self._h), "wmx_rt_wait")
+
+    def tick(self, far=None):
+        """one tick: every sub-batch up, through the chain and down again; returns (the slot) when the last row is in host memory"""
+        slot = C.c_int(-1)
+        check(lib().wmx_rt_tick(self._h, self._far(far), C.byref(slot), torch.cuda.current_stream().cuda_stream), "wmx_rt_tick")
+        return slot.value
+
+    def step_resident(self, rows, far, out=None):
+        """the tick's launches alone, rows [S, row] on the device (PCM: in place; RTP: datagrams into `out`)"""
+        assert rows.is_cuda and rows.stride(1) == 1 and rows.shape[0] == self.n
+        es = rows.element_size()
+        o = rows if out is None else out
+        check(lib().wmx_rt_step_resident(self._h, rows.data_ptr(), rows.stride(0) * es, self._far(far), o.data_ptr(), o.stride(0) * o.element_size(),
+                                         torch.cuda.current_stream().cuda_stream), "wmx_rt_step_resident")
+
+    def failed_steps(self):
+        return sum(lib().wmx_pipe_failed_steps(p) for p in self.pipes)
+
+    def close(self):
+        if self._h:
+            lib().wmx_rt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GpuClock:
+    """The shader clock the driver reports for THIS process's device, from sysfs (pp_dpm_sclk marks the current level with '*'; an idle
+    device shows the sleep level "S: 94Mhz"); None where it cannot be read.  The box's sysfs lists every GPU of the host: the device is
+    found by its PCI address.  Read off the critical path: just before a tick is released."""
+
+    def __init__(self, index=0):
+        self.path = None
+        try:
+            p = torch.cuda.get_device_properties(index)
+            bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+            cand = ["/sys/bus/pci/devices/%s/pp_dpm_sclk" % bdf]
+        except Exception:
+            cand = []
+        for c in cand:
+            try:
+                open(c).read()
+                self.path = c
+                break
+            except OSError:
+                continue
+
+    def mhz(self):
+        if not self.path:
+            return None
+        try:
+            for line in open(self.path).read().splitlines():
+                if line.rstrip().endswith("*"):
+                    return int(line.split(":")[1].strip().rstrip("*").strip().lower().replace("mhz", ""))
+        except (OSError, ValueError, IndexError):
+            return None
+        return None
+
+
+def paced_loop(tick_fn, tick_ms, n_ticks, clock=None, clock_every=16, spin_us=300, after=None):
+    """Release tick k at t0 + k * tick_ms (absolute schedule): sleep until shortly before, spin the rest, call tick_fn(k), which returns
+    when the tick's last row is in host memory.  Returns (latency_ms[k] = completion - scheduled release, lag_ms[k] = actual start -
+    scheduled release, sclk MHz samples taken just before a release)."""
+    period = tick_ms * 1e-3
+    lat, lag, clk = np.empty(n_ticks), np.empty(n_ticks), []
+    now = time.perf_counter
+    t0 = now() + period
+    for k in range(n_ticks):
+        due = t0 + k * period
+        d = due - now() - spin_us * 1e-6
+        if d > 0:
+            time.sleep(d)
+        if clock is not None and k % clock_every == 0 and now() < due:
+            clk.append(clock.mhz())
+        while now() < due:
+            pass
+        start = now()
+        tick_fn(k)
+        end = now()
+        lag[k], lat[k] = (start - due) * 1e3, (end - due) * 1e3
+        if after is not None:
+            after(k)  # behind the clock: whatever the host does with the rows is not part of the tick
+    return lat, lag, [c for c in clk if c is not None]
+
+
+def latency_summary(lat_ms, lag_ms, tick_ms, clk=None):
+    """p50 / p99 / p99.9 / max and the misses against the reference's own budget: tick_ms - 2 ms (src/wmix.c:538)."""
+    budget = tick_ms - 2.0
+    q = np.percentile(lat_ms, [50, 99, 99.9])
+    out = {"ticks": int(lat_ms.size), "tick_ms": tick_ms, "budget_ms": budget, "p50_ms": round(float(q[0]), 4), "p99_ms": round(float(q[1]), 4),
+           "p99_9_ms": round(float(q[2]), 4), "max_ms": round(float(lat_ms.max()), 4), "misses": int((lat_ms > budget).sum()),
+           "overruns_of_the_period": int((lat_ms > tick_ms).sum()),
+           "release_lag_p50_ms": round(float(np.percentile(lag_ms, 50)), 4), "release_lag_max_ms": round(float(lag_ms.max()), 4),
+           "worst_tick": int(lat_ms.argmax())}
+    if clk:
+        out["sclk_mhz_before_release"] = {"min": int(min(clk)), "median": int(np.median(clk)), "max": int(max(clk)), "samples": len(clk)}
+    return out
