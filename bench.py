@@ -1378,77 +1378,122 @@ def paced_replay(kind, far, rows, pattern_row, n_ticks, interval_ms=20):
     return loader.run_rtp_chain(port, far_seq, np.ascontiguousarray(rows[t, pattern_row]))
 
 
-def run_paced(dev, kind, S, tick_ms, ticks, sub=32768, slots=4, prime=150, resident=False, keep=24, interval_ms=None, parity=True):
-    """One paced run: S concurrent streams, a tick released every tick_ms on an absolute schedule, every tick through wmx_rt_tick (H2D,
-    NS -> AEC -> AGC -> VAD, D2H; sub-batches overlapped) or, resident, through wmx_rt_step_resident + a synchronisation.  Latency =
-    scheduled release -> last row in host memory (resident: -> the device idle).  The budget is the reference's own: tick_ms - 2 ms
-    (src/wmix.c:536-538, 820).  16 sampled streams are replayed through the oracle for every tick of the run, start-up included, and
-    compared on the last `keep` ticks (whose state has been through all of them)."""
+def run_paced(dev, kind, S, tick_ms, ticks, sub=32768, slots=4, prime=150, resident=False, keep=24, interval_ms=None, parity=True, compute_streams=1,
+              phases=1):
+    """One paced run: S concurrent streams, every stream's package due every tick_ms.  phases = 1: all S at the same instant, one tick
+    through wmx_rt_tick (H2D, NS -> AEC -> AGC -> VAD, D2H; sub-batches overlapped) or, resident, wmx_rt_step_resident + a
+    synchronisation.  phases = P > 1: P groups of S / P streams released tick_ms / P apart (wmx_rt_submit at the release, completion
+    seen by polling), each with the whole period as its own.  Latency = scheduled release -> last row of the group in host memory
+    (resident: -> its launches done).  The budget is the reference's own: tick_ms - 2 ms (src/wmix.c:536-538, 820).  16 sampled streams
+    are replayed through the oracle for every tick of the run, start-up included, and compared on the last `keep` ticks."""
     import gc
-    from wmix_amd.realtime import GpuClock, RtBatch, latency_summary, paced_loop
+    from wmix_amd.realtime import GpuClock, RtBatch, latency_summary, paced_groups, paced_loop
     form, freq = PACED_KINDS[kind]
     interval_ms = interval_ms or int(tick_ms)
     assert form == "pcm" or interval_ms == 20, "the RTP edge is 20 ms datagrams"
     t_start = time.perf_counter()
     far, rows = paced_pattern(kind, slots, interval_ms)
     n_pattern = rows.shape[1]
-    rt = RtBatch(S, dev, sub_batch=sub, slots=slots, kind=form, chn=1, freq=freq, interval_ms=interval_ms)
+    P = int(phases)
+    bounds = [S * g // P for g in range(P + 1)]  # group g = streams [bounds[g], bounds[g + 1])
+    rts = [RtBatch(bounds[g + 1] - bounds[g], dev, sub_batch=sub, slots=slots, kind=form, chn=1, freq=freq, interval_ms=interval_ms,
+                   compute_streams=compute_streams) for g in range(P)]
+    rt0 = rts[0]
     pat_of = np.arange(S) % n_pattern
     sample = sorted(set(int(i) for i in np.linspace(0, S - 1, 16)))
+    sample_of = [[s - bounds[g] for s in sample if bounds[g] <= s < bounds[g + 1]] for g in range(P)]
+    col_of = [[c for c, s in enumerate(sample) if bounds[g] <= s < bounds[g + 1]] for g in range(P)]
     if resident:
-        idx = torch.from_numpy(pat_of).to(dev)
-        src = [torch.from_numpy(rows[j]).to(dev)[idx].contiguous() for j in range(slots)]  # [S, row] per slot
-        work = torch.empty_like(src[0])
-        out = torch.empty_like(src[0]) if form == "rtp" else None
-        dfar = torch.from_numpy(far.reshape(slots, rt.ppc, rt.pkt10).copy()).to(dev)
-        work.copy_(src[0])
+        dfar = torch.from_numpy(far.reshape(slots, rt0.ppc, rt0.pkt10).copy()).to(dev)
+        src, work, outb, evs = [], [], [], []
+        for g in range(P):
+            idx = torch.from_numpy(pat_of[bounds[g]:bounds[g + 1]]).to(dev)
+            src.append([torch.from_numpy(rows[j]).to(dev)[idx].contiguous() for j in range(slots)])  # [n_g, row] per slot
+            work.append(src[g][0].clone())
+            outb.append(torch.empty_like(work[g]) if form == "rtp" else None)
+            evs.append(torch.cuda.Event())
     else:
-        for j in range(slots):
-            rt.h_far[j][:] = far[j].reshape(rt.far_shape)
-            rt.fill(j, rows[j][pat_of])
-    kept = np.zeros((keep, len(sample), rt.row), rt.row_dtype)
-    state = {"t": 0}
+        for g, rt in enumerate(rts):
+            for j in range(slots):
+                rt.h_far[j][:] = far[j].reshape(rt.far_shape)
+                rt.fill(j, rows[j][pat_of[bounds[g]:bounds[g + 1]]])
+    kept = np.zeros((keep, len(sample), rt0.row), rt0.row_dtype)
+    t_of = [0] * P      # ticks group g has been through
+    gpu_ms = []
 
-    def one(k_paced):
-        t = state["t"]
-        j = t % slots
+    def submit(g):
+        j = t_of[g] % slots
         if resident:
-            rt.step_resident(work, dfar[j], out)
-            torch.cuda.synchronize()
+            rts[g].step_resident(work[g], dfar[j], outb[g])
+            evs[g].record()
         else:
-            assert rt.tick(None) == j
-        state["t"] = t + 1
+            assert rts[g].submit(None) == j
+        t_of[g] += 1
 
-    def after(k_paced):
-        """behind the clock: keep the sampled rows of the last ticks; resident: put the next tick's input where the chain works in place"""
-        j = (state["t"] - 1) % slots
-        if k_paced is not None and k_paced >= ticks - keep:
-            if resident:
-                res = (out if form == "rtp" else work)[sample].cpu().numpy()
-            else:
-                res = rt.gather(j, sample)
-            kept[k_paced - (ticks - keep)] = res
+    def poll(g):
+        return evs[g].query() if resident else rts[g].poll()
+
+    def wait(g):
         if resident:
-            work.copy_(src[state["t"] % slots])
-            torch.cuda.synchronize()
+            evs[g].synchronize()
+        else:
+            rts[g].wait()
+
+    def after(k_paced, g):
+        """behind the clock: keep the sampled rows of the last ticks; resident: put the next tick's input where the chain works in place"""
+        j = (t_of[g] - 1) % slots
+        if k_paced is not None and k_paced // P >= ticks - keep and sample_of[g]:
+            if resident:
+                res = (outb[g] if form == "rtp" else work[g])[sample_of[g]].cpu().numpy()
+            else:
+                res = rts[g].gather(j, sample_of[g])
+            kept[k_paced // P - (ticks - keep), col_of[g]] = res
+        if resident:
+            work[g].copy_(src[g][t_of[g] % slots])
+
+    def one(k_paced):  # phases = 1: the blocking tick
+        if resident and k_paced is not None and k_paced % 8 == 0:  # every eighth tick between two events: the device's own time for it
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            submit(0)
+            e1.record()
+            e1.synchronize()
+            gpu_ms.append(e0.elapsed_time(e1))
+        else:
+            submit(0)
+            wait(0)
 
     for _ in range(prime):  # past the start-up phases of every stage, back to back
-        one(None)
-        after(None)
+        for g in range(P):
+            submit(g)
+            wait(g)
+            after(None, g)
+    torch.cuda.synchronize()
     gc.collect()
     gc.disable()
     try:
-        lat, lag, clk = paced_loop(one, tick_ms, ticks, GpuClock(), after=after)
+        if P == 1:
+            lat, lag, clk = paced_loop(one, tick_ms, ticks, GpuClock(), after=lambda k: (after(k, 0), torch.cuda.current_stream().synchronize()))
+        else:
+            lat, lag, clk = paced_groups(submit, poll, wait, P, tick_ms, ticks, GpuClock(), after=after)
     finally:
         gc.enable()
-    failed = rt.failed_steps()
-    rt.close()
+    torch.cuda.synchronize()
+    failed = sum(rt.failed_steps() for rt in rts)
+    n_sub = sum(rt.B for rt in rts)
+    for rt in rts:
+        rt.close()
     out_d = latency_summary(lat, lag, tick_ms, clk)
-    out_d.update({"kind": kind, "streams": S, "sub_batch": sub, "sub_batches": rt.B, "slots": slots, "primed_ticks": prime, "interval_ms": interval_ms,
-                  "path": "resident in HBM (wmx_rt_step_resident + synchronize)" if resident else
-                          "pinned host rows: H2D -> chain -> D2H per sub-batch, overlapped (wmx_rt_tick)",
-                  "bytes_over_pcie_per_tick": 0 if resident else 2 * rt.row_bytes * S,
+    out_d.update({"kind": kind, "streams": S, "phases": P, "release": ("all %d streams at the same instant" % S) if P == 1 else
+                  ("%d groups of %d streams, %.3g ms apart" % (P, S // P, tick_ms / P)),
+                  "sub_batch": sub, "sub_batches": n_sub, "slots": slots, "primed_ticks": prime, "interval_ms": interval_ms,
+                  "compute_streams": compute_streams,
+                  "path": "resident in HBM (wmx_rt_step_resident)" if resident else
+                          "pinned host rows: H2D -> chain -> D2H per sub-batch, overlapped (wmx_rt_submit / _poll / _wait)",
+                  "bytes_over_pcie_per_tick": 0 if resident else 2 * rt0.row_bytes * S,
                   "stream_frames_per_s_sustained": S * (interval_ms // 10) / (tick_ms * 1e-3), "failed_steps": failed})
+    if gpu_ms:
+        out_d["device_ms_between_events_p50"] = round(float(np.median(gpu_ms)), 4)
     if parity:
         T = prime + ticks
         worst, n_off = 0, 0
@@ -1465,7 +1510,8 @@ def run_paced(dev, kind, S, tick_ms, ticks, sub=32768, slots=4, prime=150, resid
 def paced_main(args, dev):
     """bench.py --paced: one run, or (--paced-search S1,S2,...) the largest S without a miss."""
     from wmix_amd import _lib
-    common = dict(sub=args.sub_batch, slots=args.slots, prime=args.paced_prime, resident=args.resident, interval_ms=args.paced_interval_ms or None)
+    common = dict(sub=args.sub_batch, slots=args.slots, prime=args.paced_prime, resident=args.resident, interval_ms=args.paced_interval_ms or None,
+                  compute_streams=args.compute_streams, phases=args.phases)
     if args.paced_search:
         runs, s_max = [], None
         for S in sorted(int(x) for x in args.paced_search.split(",")):
@@ -1719,6 +1765,10 @@ def main():
     ap.add_argument("--paced-interval-ms", type=int, default=0, help="--paced: the package a tick carries (default: the tick itself)")
     ap.add_argument("--sub-batch", type=int, default=32768, help="--paced: streams per sub-batch (one wmx_pipe each; uploads and downloads of "
                                                                 "neighbouring sub-batches run beside the compute)")
+    ap.add_argument("--compute-streams", type=int, default=1, help="--paced: wmx_rt_set_compute_streams (sub-batch b on stream b %% n)")
+    ap.add_argument("--phases", type=int, default=1,
+                    help="--paced: release the streams in P groups tick / P apart instead of all at the same instant (every group still has "
+                         "the whole tick as its period and tick - 2 ms as its budget)")
     ap.add_argument("--slots", type=int, default=4, help="--paced: sets of pinned rows (tick t works on slot t %% slots)")
     ap.add_argument("--paced-prime", type=int, default=150, help="--paced: unpaced ticks in front (past every stage's start-up)")
     ap.add_argument("--resident", action="store_true", help="--paced: rows resident in HBM, no PCIe inside the tick")

@@ -16,7 +16,12 @@
  * `keep` ticks and written to --dump for the parity check (tests/test_paced_host_gpu.py replays them through the oracle).
  *
  *   host_paced --streams S [--sub 32768] [--slots 4] [--tick-ms 20] [--ticks 1500] [--prime 150] [--kind pcm|rtp] [--freq 16000]
- *              [--interval-ms 20] [--pattern file --n-pattern 256] [--dump file --keep 32 --sample a,b,c] [--lat file]
+ *              [--interval-ms 20] [--phases 1] [--pattern file --n-pattern 256] [--dump file --keep 32 --sample a,b,c] [--lat file]
+ *
+ * --phases P > 1: the streams of a server do not all deliver their package at the same instant.  P groups of S / P streams (one
+ * wmx_rt each), group g released at t0 + (k * P + g) * tick_ms / P with the whole tick as its period and tick_ms - 2 ms as its budget:
+ * wmx_rt_submit at the release, wmx_rt_poll between releases (a completion is seen within microseconds).  The device then works in P
+ * short bursts per period and never idles long enough for its power management to clock it down (profiles/r06/README_paced.md).
  *
  * pattern file: int16 far [slots][far_samples], then rows [slots][n_pattern][row_bytes] (row_bytes from the library).
  * dump file:    rows [keep][n_sample][row_bytes] of the last `keep` ticks.     lat file: double latency_ms[ticks].
@@ -68,6 +73,8 @@ static const char *arg_of(int argc, char **argv, const char *name, const char *d
     return dflt;
 }
 
+#define MAX_PHASES 16
+
 int main(int argc, char **argv) {
     const long S = atol(arg_of(argc, argv, "--streams", "0"));
     const int sub = atoi(arg_of(argc, argv, "--sub", "32768")), slots = atoi(arg_of(argc, argv, "--slots", "4"));
@@ -75,27 +82,34 @@ int main(int argc, char **argv) {
     const int ticks = atoi(arg_of(argc, argv, "--ticks", "1500")), prime = atoi(arg_of(argc, argv, "--prime", "150"));
     const char *kind = arg_of(argc, argv, "--kind", "pcm");
     const int freq = atoi(arg_of(argc, argv, "--freq", "16000")), interval_ms = atoi(arg_of(argc, argv, "--interval-ms", "20"));
+    const int P = atoi(arg_of(argc, argv, "--phases", "1"));
     const char *pattern = arg_of(argc, argv, "--pattern", NULL), *dump = arg_of(argc, argv, "--dump", NULL), *latf = arg_of(argc, argv, "--lat", NULL);
     const int n_pattern = atoi(arg_of(argc, argv, "--n-pattern", "256"));
     int keep = atoi(arg_of(argc, argv, "--keep", "32"));
     const char *sample_s = arg_of(argc, argv, "--sample", "0");
-    if (S < 1 || ticks < 1 || tick_ms <= 2.0 || slots < 1 || n_pattern < 1) {
-        fprintf(stderr, "usage: %s --streams S [--sub N] [--slots N] [--tick-ms T] [--ticks N] [--prime N] [--kind pcm|rtp] ...\n", argv[0]);
+    if (S < 1 || ticks < 1 || tick_ms <= 2.0 || slots < 1 || n_pattern < 1 || P < 1 || P > MAX_PHASES || S < P) {
+        fprintf(stderr, "usage: %s --streams S [--sub N] [--slots N] [--tick-ms T] [--ticks N] [--prime N] [--kind pcm|rtp] [--phases P] ...\n", argv[0]);
         return 2;
     }
     if (keep > ticks) keep = ticks;
     const unsigned stages = WMX_CHAIN_NS | WMX_CHAIN_AEC | WMX_CHAIN_AGC | WMX_CHAIN_VAD;
     const int rtp = !strcmp(kind, "rtp");
-    wmx_rt *rt = NULL;
-    int rc = rtp ? wmx_rt_create_rtp(&rt, S, sub, slots, WMX_LAW_A, 5, stages) : wmx_rt_create_pcm(&rt, S, sub, slots, 1, freq, interval_ms, 5, stages);
+    wmx_rt *rt[MAX_PHASES] = {0};
+    long lo_of[MAX_PHASES + 1];
+    int rc = 0, n_sub = 0;
+    for (int g = 0; g <= P; g++) lo_of[g] = S * g / P; /* group g = streams [lo_of[g], lo_of[g + 1]) */
+    for (int g = 0; g < P && rc == 0; g++) {
+        const long n = lo_of[g + 1] - lo_of[g];
+        rc = rtp ? wmx_rt_create_rtp(&rt[g], n, sub, slots, WMX_LAW_A, 5, stages) : wmx_rt_create_pcm(&rt[g], n, sub, slots, 1, freq, interval_ms, 5, stages);
+        if (rc == 0) n_sub += wmx_rt_batches(rt[g]);
+    }
     if (rc != 0) {
         fprintf(stderr, "host_paced: wmx_rt_create: %s\n", wmx_last_error());
         return 3;
     }
-    const int B = wmx_rt_batches(rt);
-    const size_t row = (size_t)wmx_pipe_datagram_bytes(wmx_rt_pipe(rt, 0));
+    const size_t row = (size_t)wmx_pipe_datagram_bytes(wmx_rt_pipe(rt[0], 0));
     const size_t far_n = rtp ? 160 : row / 2;
-    /* the slots' rows: the pattern, tiled */
+    /* the slots' rows: the pattern, tiled (stream s of the whole server gets pattern row s % n_pattern) */
     if (pattern) {
         FILE *f = fopen(pattern, "rb");
         const size_t far_bytes = (size_t)slots * far_n * 2, rows_bytes = (size_t)slots * (size_t)n_pattern * row;
@@ -105,16 +119,17 @@ int main(int argc, char **argv) {
             return 2;
         }
         fclose(f);
-        for (int k = 0; k < slots; k++) {
-            memcpy(wmx_rt_far(rt, k), buf + (size_t)k * far_n * 2, far_n * 2);
-            long s = 0;
-            for (int b = 0; b < B; b++) {
-                uint8_t *dst = wmx_pipe_in(wmx_rt_pipe(rt, b), k);
-                const int nb = wmx_rt_batch_streams(rt, b);
-                for (int r = 0; r < nb; r++, s++)
-                    memcpy(dst + (size_t)r * row, buf + far_bytes + ((size_t)k * (size_t)n_pattern + (size_t)(s % n_pattern)) * row, row);
+        for (int g = 0; g < P; g++)
+            for (int k = 0; k < slots; k++) {
+                memcpy(wmx_rt_far(rt[g], k), buf + (size_t)k * far_n * 2, far_n * 2);
+                long s = lo_of[g];
+                for (int b = 0; b < wmx_rt_batches(rt[g]); b++) {
+                    uint8_t *dst = wmx_pipe_in(wmx_rt_pipe(rt[g], b), k);
+                    const int nb = wmx_rt_batch_streams(rt[g], b);
+                    for (int r = 0; r < nb; r++, s++)
+                        memcpy(dst + (size_t)r * row, buf + far_bytes + ((size_t)k * (size_t)n_pattern + (size_t)(s % n_pattern)) * row, row);
+                }
             }
-        }
         free(buf);
     }
     /* the sample streams whose rows are kept */
@@ -129,37 +144,87 @@ int main(int argc, char **argv) {
         free(tmp);
     }
     uint8_t *kept = dump ? calloc((size_t)keep * (size_t)n_sample, row) : NULL;
-    double *lat = malloc(sizeof(double) * (size_t)ticks), *lag = malloc(sizeof(double) * (size_t)ticks);
-    /* past the start-up phases of every stage, back to back (tick t of the whole run works on slot t % slots) */
-    for (int k = 0; k < prime && rc == 0; k++) rc = wmx_rt_tick(rt, NULL, NULL, NULL);
-    const int64_t period = (int64_t)(tick_ms * 1e6);
+    const int total = ticks * P; /* group-ticks */
+    double *lat = malloc(sizeof(double) * (size_t)total), *lag = malloc(sizeof(double) * (size_t)total);
+    /* past the start-up phases of every stage, back to back (tick t of a group's life works on slot t % slots) */
+    for (int k = 0; k < prime && rc == 0; k++)
+        for (int g = 0; g < P && rc == 0; g++) rc = wmx_rt_tick(rt[g], NULL, NULL, NULL);
+    const int64_t period = (int64_t)(tick_ms * 1e6), step = period / P;
     const int64_t t0 = now_ns() + period;
-    int misses = 0, overruns = 0;
-    const double budget = tick_ms - 2.0;
-    for (int k = 0; k < ticks && rc == 0; k++) {
-        const int64_t due = t0 + (int64_t)k * period;
-        sleep_until(due, 200000);
-        const int64_t start = now_ns();
-        int slot = -1;
-        rc = wmx_rt_tick(rt, NULL, &slot, NULL);
-        const int64_t end = now_ns();
-        lag[k] = (double)(start - due) * 1e-6;
-        lat[k] = (double)(end - due) * 1e-6;
-        misses += lat[k] > budget;
-        overruns += lat[k] > tick_ms;
-        if (kept && k >= ticks - keep) { /* behind the clock: the copy of a few rows is not part of the tick */
-            for (int j = 0; j < n_sample; j++) {
-                long s = sample[j];
-                int b = 0;
-                while (s >= wmx_rt_batch_streams(rt, b)) s -= wmx_rt_batch_streams(rt, b++);
-                memcpy(kept + ((size_t)(k - (ticks - keep)) * (size_t)n_sample + (size_t)j) * row, wmx_pipe_out(wmx_rt_pipe(rt, b), slot) + (size_t)s * row, row);
+    int flying_j[MAX_PHASES], flying_slot[MAX_PHASES];
+    int64_t flying_due[MAX_PHASES];
+    for (int g = 0; g < P; g++) flying_j[g] = -1;
+    /* a group whose rows are back: its latency, and (behind the clock) the sampled rows of the last ticks */
+#define REAP(g)                                                                                                                          \
+    do {                                                                                                                                 \
+        const int j_ = flying_j[g], k_ = j_ / P;                                                                                         \
+        lat[j_] = (double)(now_ns() - flying_due[g]) * 1e-6;                                                                             \
+        flying_j[g] = -1;                                                                                                                \
+        if (kept && k_ >= ticks - keep)                                                                                                  \
+            for (int i_ = 0; i_ < n_sample; i_++) {                                                                                      \
+                long s_ = sample[i_] - lo_of[g];                                                                                         \
+                if (sample[i_] < lo_of[g] || sample[i_] >= lo_of[g + 1]) continue;                                                       \
+                int b_ = 0;                                                                                                              \
+                while (s_ >= wmx_rt_batch_streams(rt[g], b_)) s_ -= wmx_rt_batch_streams(rt[g], b_++);                                   \
+                memcpy(kept + ((size_t)(k_ - (ticks - keep)) * (size_t)n_sample + (size_t)i_) * row,                                     \
+                       wmx_pipe_out(wmx_rt_pipe(rt[g], b_), flying_slot[g]) + (size_t)s_ * row, row);                                    \
+            }                                                                                                                            \
+    } while (0)
+    int64_t next_note = t0 + 30000000000LL;
+    for (int j = 0; j < total && rc == 0; j++) {
+        const int64_t due = t0 + (int64_t)j * step;
+        const int g = j % P;
+        if (due >= next_note) { /* a long run says it is alive twice a minute (behind a completed tick, in front of the sleep) */
+            fprintf(stderr, "host_paced: tick %d of %d\n", j / P, ticks);
+            next_note += 30000000000LL;
+        }
+        if (P == 1) {
+            sleep_until(due, 200000);
+        } else {
+            for (;;) { /* until the release: see the groups in flight come back */
+                int any = 0;
+                for (int q = 0; q < P; q++)
+                    if (flying_j[q] >= 0) {
+                        const int d = wmx_rt_poll(rt[q]);
+                        if (d < 0) rc = d;
+                        if (d == 1) REAP(q);
+                        else any = 1;
+                    }
+                if (now_ns() >= due || rc != 0) break;
+                if (!any) {
+                    sleep_until(due, 200000);
+                    break;
+                }
+            }
+            if (flying_j[g] >= 0 && rc == 0) { /* its previous tick is not back yet: the release waits for it (and the wait counts) */
+                rc = wmx_rt_wait(rt[g]);
+                REAP(g);
             }
         }
+        if (rc != 0) break;
+        const int64_t start = now_ns();
+        lag[j] = (double)(start - due) * 1e-6;
+        flying_due[g] = due;
+        flying_j[g] = j;
+        if (P == 1) {
+            rc = wmx_rt_tick(rt[g], NULL, &flying_slot[g], NULL);
+            REAP(g);
+        } else {
+            rc = wmx_rt_submit(rt[g], NULL, &flying_slot[g], NULL);
+        }
     }
+    for (int g = 0; g < P; g++)
+        if (flying_j[g] >= 0) {
+            const int rw = wmx_rt_wait(rt[g]);
+            if (rc == 0) rc = rw;
+            REAP(g);
+        }
     if (rc != 0) fprintf(stderr, "host_paced: failed (rc %d): %s\n", rc, wmx_last_error());
     long failed = 0;
-    for (int b = 0; b < B; b++) failed += wmx_pipe_failed_steps(wmx_rt_pipe(rt, b));
-    wmx_rt_destroy(rt);
+    for (int g = 0; g < P; g++) {
+        for (int b = 0; b < wmx_rt_batches(rt[g]); b++) failed += wmx_pipe_failed_steps(wmx_rt_pipe(rt[g], b));
+        wmx_rt_destroy(rt[g]);
+    }
     if (rc == 0 && dump) {
         FILE *f = fopen(dump, "wb");
         if (!f || fwrite(kept, row, (size_t)keep * (size_t)n_sample, f) != (size_t)keep * (size_t)n_sample) rc = 4;
@@ -167,23 +232,26 @@ int main(int argc, char **argv) {
     }
     if (rc == 0 && latf) {
         FILE *f = fopen(latf, "wb");
-        if (!f || fwrite(lat, sizeof(double), (size_t)ticks, f) != (size_t)ticks) rc = 4;
+        if (!f || fwrite(lat, sizeof(double), (size_t)total, f) != (size_t)total) rc = 4;
         if (f) fclose(f);
     }
-    int worst = 0;
+    int worst = 0, misses = 0, overruns = 0;
     double lag_max = 0;
-    for (int k = 0; k < ticks; k++) {
+    const double budget = tick_ms - 2.0;
+    for (int k = 0; k < total; k++) {
         if (lat[k] > lat[worst]) worst = k;
         if (lag[k] > lag_max) lag_max = lag[k];
+        misses += lat[k] > budget;
+        overruns += lat[k] > tick_ms;
     }
     const double worst_ms = lat[worst];
-    qsort(lat, (size_t)ticks, sizeof(double), cmp_double);
-    qsort(lag, (size_t)ticks, sizeof(double), cmp_double);
-    printf("{\"host\": \"examples/host_paced.c\", \"kind\": \"%s\", \"streams\": %ld, \"sub_batch\": %d, \"sub_batches\": %d, \"slots\": %d, \"row_bytes\": %zu, "
-           "\"tick_ms\": %.3f, \"budget_ms\": %.3f, \"ticks\": %d, \"primed_ticks\": %d, \"p50_ms\": %.4f, \"p99_ms\": %.4f, \"p99_9_ms\": %.4f, \"max_ms\": %.4f, "
-           "\"misses\": %d, \"overruns_of_the_period\": %d, \"release_lag_p50_ms\": %.4f, \"release_lag_max_ms\": %.4f, \"worst_tick\": %d, "
-           "\"failed_steps\": %ld, \"kept_ticks\": %d, \"rc\": %d}\n",
-           kind, S, sub, B, slots, row, tick_ms, budget, ticks, prime, quantile(lat, ticks, 0.5), quantile(lat, ticks, 0.99), quantile(lat, ticks, 0.999),
-           worst_ms, misses, overruns, quantile(lag, ticks, 0.5), lag_max, worst, failed, dump ? keep : 0, rc);
+    qsort(lat, (size_t)total, sizeof(double), cmp_double);
+    qsort(lag, (size_t)total, sizeof(double), cmp_double);
+    printf("{\"host\": \"examples/host_paced.c\", \"kind\": \"%s\", \"streams\": %ld, \"phases\": %d, \"sub_batch\": %d, \"sub_batches\": %d, \"slots\": %d, "
+           "\"row_bytes\": %zu, \"tick_ms\": %.3f, \"budget_ms\": %.3f, \"ticks\": %d, \"group_ticks\": %d, \"primed_ticks\": %d, \"p50_ms\": %.4f, \"p99_ms\": %.4f, "
+           "\"p99_9_ms\": %.4f, \"max_ms\": %.4f, \"misses\": %d, \"overruns_of_the_period\": %d, \"release_lag_p50_ms\": %.4f, \"release_lag_max_ms\": %.4f, "
+           "\"worst_tick\": %d, \"failed_steps\": %ld, \"kept_ticks\": %d, \"rc\": %d}\n",
+           kind, S, P, sub, n_sub, slots, row, tick_ms, budget, ticks, total, prime, quantile(lat, total, 0.5), quantile(lat, total, 0.99),
+           quantile(lat, total, 0.999), worst_ms, misses, overruns, quantile(lag, total, 0.5), lag_max, worst / P, failed, dump ? keep : 0, rc);
     return rc ? 1 : 0;
 }

@@ -499,6 +499,8 @@ int16_t *wmx_pipe_far(wmx_pipe *h, int slot);
 int wmx_pipe_submit(wmx_pipe *h, const int16_t *d_far, int *slot, void *stream);
 int wmx_pipe_wait(wmx_pipe *h, int slot);
 long wmx_pipe_failed_steps(const wmx_pipe *h);
+/* non-blocking wmx_pipe_wait: 1 = the rows of `slot` (< 0: of every slot) are in host memory, 0 = still on their way */
+int wmx_pipe_poll(wmx_pipe *h, int slot);
 int wmx_pipe_step_resident(wmx_pipe *h, const uint8_t *d_in, long in_stride, const int16_t *d_far, uint8_t *d_out, long out_stride,
                            void *stream);
 wmx_chain *wmx_pipe_chain(wmx_pipe *h);
@@ -518,7 +520,7 @@ wmx_rtp *wmx_pipe_senders(wmx_pipe *h);
  *   wmx_rt_batches, wmx_rt_batch_streams(b), wmx_rt_pipe(b)   the sub-batches; rows of tick slot k: wmx_pipe_in / _out(wmx_rt_pipe(h, b), k)
  *   wmx_rt_far(h, slot)        the tick's shared far-end in host memory (uploaded once per tick when d_far is NULL)
  *   wmx_rt_submit              queues one tick (the next slot, round robin) and returns; *slot = its slot
- *   wmx_rt_wait                blocks until every row of every queued tick is in host memory
+ *   wmx_rt_wait                blocks until every row of every queued tick is in host memory (wmx_rt_poll: the same without blocking)
  *   wmx_rt_tick                both: returns when the last row of the tick is in host memory -- the latency a paced host sees
  *   wmx_rt_step_resident       the tick's launches alone on rows already in HBM (row of stream s at d_rows + s * stride bytes, in place
  *                              for PCM; d_out rows for RTP)
@@ -528,12 +530,16 @@ typedef struct wmx_rt wmx_rt;
 int wmx_rt_create_pcm(wmx_rt **out, long n_streams, int sub_batch, int slots, int chn, int freq, int interval_ms, int agc_value, unsigned stages);
 int wmx_rt_create_rtp(wmx_rt **out, long n_streams, int sub_batch, int slots, int law, int agc_value, unsigned stages);
 int wmx_rt_destroy(wmx_rt *h);
+/* sub-batch b on the library's own compute stream b % n (n = 1: all on the caller's stream, one behind the other; n >= 2: forked
+ * from the caller's stream per tick and joined to it again, so that the tail of one sub-batch's kernels overlaps the head of the next) */
+int wmx_rt_set_compute_streams(wmx_rt *h, int n);
 int wmx_rt_batches(const wmx_rt *h);
 int wmx_rt_batch_streams(const wmx_rt *h, int batch);
 wmx_pipe *wmx_rt_pipe(wmx_rt *h, int batch);
 int16_t *wmx_rt_far(wmx_rt *h, int slot);
 int wmx_rt_submit(wmx_rt *h, const int16_t *d_far, int *slot, void *stream);
 int wmx_rt_wait(wmx_rt *h);
+int wmx_rt_poll(wmx_rt *h); /* non-blocking wmx_rt_wait: 1 = every row of every queued tick is in host memory, 0 = not yet */
 int wmx_rt_tick(wmx_rt *h, const int16_t *d_far, int *slot, void *stream);
 int wmx_rt_step_resident(wmx_rt *h, uint8_t *d_rows, long stride, const int16_t *d_far, uint8_t *d_out, long out_stride, void *stream);
 

@@ -17,8 +17,9 @@ pytestmark = pytest.mark.gpu
 HOST = os.path.join(ROOT, "examples", "host_paced")
 
 
-@pytest.mark.parametrize("kind,tick_ms,freq,interval_ms", [("pcm16k", 20, 16000, 20), ("pcm16k", 10, 16000, 10), ("rtp8k", 20, 8000, 20)])
-def test_host_paced_meets_the_budget_and_the_oracle(cuda, tmp_path, kind, tick_ms, freq, interval_ms):
+@pytest.mark.parametrize("kind,tick_ms,freq,interval_ms,phases", [("pcm16k", 20, 16000, 20, 1), ("pcm16k", 10, 16000, 10, 1), ("rtp8k", 20, 8000, 20, 1),
+                                                                  ("pcm16k", 20, 16000, 20, 3), ("rtp8k", 20, 8000, 20, 4)])
+def test_host_paced_meets_the_budget_and_the_oracle(cuda, tmp_path, kind, tick_ms, freq, interval_ms, phases):
     import bench
     assert os.path.exists(HOST), "examples/host_paced is built by __graft_entry__.build()"
     S, sub, slots, ticks, prime, keep, n_pat = 3000, 1024, 4, 120, 90, 16, 64
@@ -31,14 +32,14 @@ def test_host_paced_meets_the_budget_and_the_oracle(cuda, tmp_path, kind, tick_m
     dump, lat = tmp_path / "dump.bin", tmp_path / "lat.f64"
     cmd = [HOST, "--streams", str(S), "--sub", str(sub), "--slots", str(slots), "--tick-ms", str(tick_ms), "--ticks", str(ticks), "--prime", str(prime),
            "--kind", "rtp" if kind == "rtp8k" else "pcm", "--freq", str(freq), "--interval-ms", str(interval_ms), "--pattern", str(pat), "--n-pattern",
-           str(n_pat), "--dump", str(dump), "--keep", str(keep), "--sample", ",".join(map(str, sample)), "--lat", str(lat)]
+           str(n_pat), "--dump", str(dump), "--keep", str(keep), "--sample", ",".join(map(str, sample)), "--lat", str(lat), "--phases", str(phases)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     d = json.loads(r.stdout.strip().splitlines()[-1])
-    assert d["ticks"] == ticks and d["sub_batches"] == 3 and d["failed_steps"] == 0 and d["rc"] == 0
+    assert d["ticks"] == ticks and d["group_ticks"] == ticks * phases and d["sub_batches"] == (3 if phases <= 3 else 4) and d["failed_steps"] == 0 and d["rc"] == 0
     assert d["budget_ms"] == tick_ms - 2 and d["misses"] <= 1, d  # (one late wake-up of a shared test box is not the library's)
     lat_ms = np.fromfile(lat, np.float64)
-    assert lat_ms.size == ticks and abs(np.percentile(lat_ms, 50) - d["p50_ms"]) < 1e-3
+    assert lat_ms.size == ticks * phases and abs(np.percentile(lat_ms, 50) - d["p50_ms"]) < 1e-3
     got = np.fromfile(dump, rows.dtype).reshape(keep, len(sample), rows.shape[2])
     T = prime + ticks
     for col, s in enumerate(sample):
@@ -61,3 +62,10 @@ def test_bench_paced_line(cuda):
     assert r.returncode == 0, r.stderr[-2000:]
     rt = json.loads(r.stdout.strip().splitlines()[-1])["realtime"]
     assert rt["parity_checked"]["max_lsb"] == 0 and rt["bytes_over_pcie_per_tick"] == 0 and rt["misses"] <= 1, rt
+    # staggered release: four groups 5 ms apart, from host memory and resident
+    for extra in ([], ["--resident"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--paced", "--phases", "4", "--streams", "6000", "--sub-batch", "1000", "--ticks", "60",
+                            "--paced-prime", "70"] + extra, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        rt = json.loads(r.stdout.strip().splitlines()[-1])["realtime"]
+        assert rt["phases"] == 4 and rt["ticks"] == 240 and rt["sub_batches"] == 8 and rt["parity_checked"]["max_lsb"] == 0 and rt["misses"] <= 1, rt

@@ -45,7 +45,7 @@ def test_rt_pcm_every_stream_vs_its_own_oracle_handle(cuda, oracle_port, chn, fr
     rt.close()
     assert np.array_equal(got.transpose(1, 0, 2).reshape(S, -1), want)
     # pipelined: ticks queued `slots` deep before anybody waits (the bench's streaming form); resident: the same launches on rows in HBM
-    rt2 = RtBatch(S, cuda, sub_batch=sub, slots=slots, kind="pcm", chn=chn, freq=freq, interval_ms=interval_ms, stages=stages)
+    rt2 = RtBatch(S, cuda, sub_batch=sub, slots=slots, kind="pcm", chn=chn, freq=freq, interval_ms=interval_ms, stages=stages, compute_streams=2)
     got2 = np.zeros_like(rows)
     k = 0
     while k < n:
@@ -59,7 +59,7 @@ def test_rt_pcm_every_stream_vs_its_own_oracle_handle(cuda, oracle_port, chn, fr
         k += m
     rt2.close()
     assert np.array_equal(got2, got)
-    rt3 = RtBatch(S, cuda, sub_batch=sub, slots=1, kind="pcm", chn=chn, freq=freq, interval_ms=interval_ms, stages=stages)
+    rt3 = RtBatch(S, cuda, sub_batch=sub, slots=1, kind="pcm", chn=chn, freq=freq, interval_ms=interval_ms, stages=stages, compute_streams=3)
     d = torch.from_numpy(rows).to(cuda)
     for k in range(n):
         rt3.step_resident(d[k], dfar[k])

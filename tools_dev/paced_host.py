@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""paced_host.py -- drive examples/host_paced (the paced heartbeat in C) on the GPU box and prove its rows.
+
+    python tools_dev/paced_host.py --streams 393216,425984 --ticks 1500 [--phases 4] [--kind pcm16k|rtp8k] [--tick-ms 20] [--sub 32768]
+                                   [--stop-at-miss] [--out profiles/r06/paced_x.jsonl]
+
+Per stream count: writes the pattern file (bench.paced_pattern: `slots` ticks of 256 distinct streams), runs host_paced, replays 12
+sampled streams through the oracle for every tick of the run (start-up included) and compares the rows host_paced kept for the last
+ticks.  One JSON line per run (host_paced's own line + parity + the latency file's histogram)."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--streams", required=True)
+    ap.add_argument("--ticks", type=int, default=1500)
+    ap.add_argument("--prime", type=int, default=150)
+    ap.add_argument("--phases", type=int, default=1)
+    ap.add_argument("--kind", default="pcm16k")
+    ap.add_argument("--tick-ms", type=float, default=20.0)
+    ap.add_argument("--interval-ms", type=int, default=0)
+    ap.add_argument("--sub", type=int, default=32768)
+    ap.add_argument("--slots", type=int, default=4)
+    ap.add_argument("--keep", type=int, default=24)
+    ap.add_argument("--stop-at-miss", action="store_true")
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    import bench
+    form, freq = bench.PACED_KINDS[a.kind]
+    interval_ms = a.interval_ms or int(a.tick_ms)
+    n_pat = 256
+    far, rows = bench.paced_pattern(a.kind, a.slots, interval_ms, n_pattern=n_pat)
+    tmp = tempfile.mkdtemp(prefix="paced_")
+    pat = os.path.join(tmp, "pattern.bin")
+    with open(pat, "wb") as f:
+        f.write(np.ascontiguousarray(far).tobytes())
+        f.write(np.ascontiguousarray(rows).tobytes())
+    host = os.path.join(ROOT, "examples", "host_paced")
+    for S in [int(x) for x in a.streams.split(",")]:
+        sample = sorted(set(int(i) for i in np.linspace(0, S - 1, 12)))
+        dump, lat = os.path.join(tmp, "dump.bin"), os.path.join(tmp, "lat.f64")
+        cmd = [host, "--streams", str(S), "--sub", str(a.sub), "--slots", str(a.slots), "--tick-ms", str(a.tick_ms), "--ticks", str(a.ticks), "--prime",
+               str(a.prime), "--kind", form, "--freq", str(freq), "--interval-ms", str(interval_ms), "--phases", str(a.phases), "--pattern", pat,
+               "--n-pattern", str(n_pat), "--dump", dump, "--keep", str(a.keep), "--sample", ",".join(map(str, sample)), "--lat", lat]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)  # stderr passes through: a long run reports twice a minute
+        if r.returncode != 0:
+            sys.exit(1)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        got = np.fromfile(dump, rows.dtype).reshape(a.keep, len(sample), rows.shape[2])
+        T = a.prime + a.ticks
+        worst = 0
+        for col, s in enumerate(sample):
+            want = bench.paced_replay(a.kind, far, rows, s % n_pat, T, interval_ms)[T - a.keep:]
+            worst = max(worst, int(np.abs(got[:, col].astype(np.int32) - want.astype(np.int32)).max()))
+        lat_ms = np.fromfile(lat, np.float64)
+        edges = [0, 2, 4, 6, 8, 10, 12, 14, 15, 16, 17, 18, 19, 20, 25, 50, 1e9]
+        d["latency_histogram_ms"] = {("%g-%g" % (edges[i], edges[i + 1])) if edges[i + 1] < 1e9 else (">%g" % edges[i]): int(c)
+                                     for i, c in enumerate(np.histogram(lat_ms, edges)[0]) if c}
+        d["parity_checked"] = {"streams": len(sample), "ticks_compared": a.keep, "ticks_replayed": T, "max_lsb": worst,
+                               "oracle": "oracle/orc_*.c chain (port): every tick of the run replayed per sampled stream"}
+        d["stream_frames_per_s_sustained"] = S * (interval_ms // 10) / (a.tick_ms * 1e-3)
+        line = json.dumps(d)
+        print(line)
+        sys.stdout.flush()
+        if a.out:
+            with open(a.out, "a") as f:
+                f.write(line + "\n")
+        if a.stop_at_miss and d["misses"] > 0:
+            break
+
+
+if __name__ == "__main__":
+    main()

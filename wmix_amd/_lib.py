@@ -173,6 +173,12 @@ def _declare(L):
     L.wmx_rt_create_rtp.argtypes = [C.POINTER(vp), C.c_long, i, i, i, i, C.c_uint]
     L.wmx_rt_destroy.restype = i
     L.wmx_rt_destroy.argtypes = [vp]
+    L.wmx_rt_set_compute_streams.restype = i
+    L.wmx_rt_set_compute_streams.argtypes = [vp, i]
+    L.wmx_rt_poll.restype = i
+    L.wmx_rt_poll.argtypes = [vp]
+    L.wmx_pipe_poll.restype = i
+    L.wmx_pipe_poll.argtypes = [vp, i]
     L.wmx_rt_batches.restype = i
     L.wmx_rt_batches.argtypes = [vp]
     L.wmx_rt_batch_streams.restype = i

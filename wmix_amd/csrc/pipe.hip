@@ -319,4 +319,31 @@ int wmx_pipe_wait(wmx_pipe *h, int slot) {
     return 0;
 }
 
+// Non-blocking wmx_pipe_wait: queues the download still owed for `slot` (< 0: any) and returns 1 when the rows of the slot (every
+// slot) are in host memory, 0 when they are still on their way.
+int wmx_pipe_poll(wmx_pipe *h, int slot) {
+    WMX_ON_DEVICE(h);
+    if (!h || slot >= h->slots) return WMX_EINVAL;
+    if (h->pending >= 0 && (slot < 0 || slot == h->pending)) {
+        const int rc = pipe_flush(h, h->slot[(size_t)h->pending].ev_done);
+        if (rc != 0) return rc;
+    }
+    int done = 1;
+    for (int k = 0; k < h->slots; k++) {
+        if (slot >= 0 && k != slot) continue;
+        wmx_pipe::Slot &s = h->slot[(size_t)k];
+        if (!s.in_flight) continue;
+        const hipError_t q = hipEventQuery(s.ev_out);
+        if (q == hipSuccess) {
+            s.in_flight = false;
+        } else if (q == hipErrorNotReady) {
+            (void)hipGetLastError();
+            done = 0;
+        } else {
+            return wmx::hip_fail(q, "hipEventQuery(ev_out)", __FILE__, __LINE__);
+        }
+    }
+    return done;
+}
+
 }  // extern "C"

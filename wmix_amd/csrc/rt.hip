@@ -17,6 +17,12 @@ struct wmx_rt {
     std::vector<wmx_pipe *> pipe;
     hipStream_t s_in, s_out;
     int next;  // the slot of the next tick (every sub-batch rotates in lockstep, also past a failed one)
+    // compute streams of the library's own (wmx_rt_set_compute_streams): sub-batch b runs on cs[b % n_cs], forked from the caller's
+    // stream at the start of the tick and joined to it at the end
+    static constexpr int kMaxCs = 4;
+    int n_cs;
+    hipStream_t cs[kMaxCs];
+    hipEvent_t ev_fork, ev_join[kMaxCs];
 };
 
 extern "C" {
@@ -28,7 +34,33 @@ int wmx_rt_destroy(wmx_rt *h) {
         if (p) wmx_pipe_destroy(p);
     if (h->s_in) (void)hipStreamDestroy(h->s_in);
     if (h->s_out) (void)hipStreamDestroy(h->s_out);
+    for (int i = 0; i < wmx_rt::kMaxCs; i++) {
+        if (h->cs[i]) (void)hipStreamDestroy(h->cs[i]);
+        if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     delete h;
+    return 0;
+}
+
+// Sub-batch b of a tick runs on compute stream b % n: with n = 1 (the default) that is the caller's stream and the sub-batches run
+// strictly one behind the other -- every kernel boundary drains the device (the last waves of a launch run alone) before the next
+// launch ramps up; with n >= 2 the library's own streams take turns, forked from the caller's stream when the tick starts and joined
+// to it when it ends, and the tail of one sub-batch's kernel overlaps the head of the next one's.
+int wmx_rt_set_compute_streams(wmx_rt *h, int n) {
+    WMX_ON_DEVICE(h);
+    if (!h || n < 1 || n > wmx_rt::kMaxCs) {
+        wmx::set_error("wmx_rt_set_compute_streams: n=%d (1 .. %d)", n, wmx_rt::kMaxCs);
+        return WMX_EINVAL;
+    }
+    if (n > 1) {
+        if (!h->ev_fork) WMX_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        for (int i = 0; i < n; i++) {
+            if (!h->cs[i]) WMX_HIP(hipStreamCreateWithFlags(&h->cs[i], hipStreamNonBlocking));
+            if (!h->ev_join[i]) WMX_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+        }
+    }
+    h->n_cs = n;
     return 0;
 }
 
@@ -50,6 +82,7 @@ static int rt_make(wmx_rt **out, long n_streams, int sub_batch, int slots, bool 
     h->slots = slots;
     h->pcm = pcm;
     h->next = 0;
+    h->n_cs = 1;
     hipError_t e = hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking);
     int rc = e == hipSuccess ? 0 : wmx::hip_fail(e, "wmx_rt_create: copy streams", __FILE__, __LINE__);
@@ -93,27 +126,56 @@ int wmx_rt_batch_streams(const wmx_rt *h, int b) { return (h && b >= 0 && b < (i
 wmx_pipe *wmx_rt_pipe(wmx_rt *h, int b) { return (h && b >= 0 && b < (int)h->pipe.size()) ? h->pipe[(size_t)b] : nullptr; }
 int16_t *wmx_rt_far(wmx_rt *h, int slot) { return h ? wmx_pipe_far(h->pipe[0], slot) : nullptr; }
 
+// the tick's launches: sub-batch b on `main`, or on the library's stream b % n_cs between a fork from and a join to `main`
+static int rt_launches(wmx_rt *h, hipStream_t main, int (*one)(wmx_rt *, size_t, void *, void *), void *ctx) {
+    const bool own = h->n_cs > 1 && h->pipe.size() > 1;
+    if (own) {
+        WMX_HIP(hipEventRecord(h->ev_fork, main));
+        for (int i = 0; i < h->n_cs; i++) WMX_HIP(hipStreamWaitEvent(h->cs[i], h->ev_fork, 0));
+    }
+    int first = 0;
+    for (size_t b = 0; b < h->pipe.size(); b++) {
+        const int rc = one(h, b, own ? (void *)h->cs[b % (size_t)h->n_cs] : (void *)main, ctx);
+        if (rc != 0 && first == 0) first = rc;
+    }
+    if (own)
+        for (int i = 0; i < h->n_cs; i++) {
+            WMX_HIP(hipEventRecord(h->ev_join[i], h->cs[i]));
+            WMX_HIP(hipStreamWaitEvent(main, h->ev_join[i], 0));
+        }
+    return first;
+}
+
+struct SubmitCtx {
+    const int16_t *d_far;
+    wmx_pipe *prev;
+    int k;
+    bool lost;
+};
+static int submit_one(wmx_rt *h, size_t b, void *stream, void *vctx) {
+    SubmitCtx *c = static_cast<SubmitCtx *>(vctx);
+    if (c->lost) return 0;
+    wmx_pipe *p = h->pipe[b];
+    p->next = c->k;
+    // sub-batch 0 uploads the tick's far-end (unless it is on the device already), the others use its copy
+    const int rc = wmx::pipe_submit(p, c->d_far, nullptr, stream, c->prev ? c->prev : p, (c->d_far || b == 0) ? nullptr : h->pipe[0]);
+    if (rc != 0) {
+        if (b == 0 && !c->d_far) c->lost = true;  // nobody has the far-end: the tick is lost as a whole
+        return rc;  // this sub-batch has lost its step; `prev` keeps its pending download for the next one that runs
+    }
+    c->prev = p;
+    return 0;
+}
+
 int wmx_rt_submit(wmx_rt *h, const int16_t *d_far, int *slot, void *stream) {
     WMX_ON_DEVICE(h);
     if (!h) return WMX_EINVAL;
     const int k = h->next;
     h->next = (k + 1) % h->slots;  // a tick takes its slot whatever becomes of its sub-batches
-    int first = 0;
-    wmx_pipe *prev = nullptr;
-    for (size_t b = 0; b < h->pipe.size(); b++) {
-        wmx_pipe *p = h->pipe[b];
-        p->next = k;
-        // sub-batch 0 uploads the tick's far-end (unless it is on the device already), the others use its copy
-        const int rc = wmx::pipe_submit(p, d_far, nullptr, stream, prev ? prev : p, (d_far || b == 0) ? nullptr : h->pipe[0]);
-        if (rc != 0) {
-            if (first == 0) first = rc;
-            if (b == 0 && !d_far) break;  // nobody has the far-end: the tick is lost as a whole
-            continue;  // this sub-batch has lost its step; `prev` keeps its pending download for the next one that runs
-        }
-        prev = p;
-    }
+    SubmitCtx c{d_far, nullptr, k, false};
+    const int rc = rt_launches(h, wmx::as_stream(stream), submit_one, &c);
     if (slot) *slot = k;
-    return first;
+    return rc;
 }
 
 int wmx_rt_wait(wmx_rt *h) {
@@ -134,10 +196,40 @@ int wmx_rt_wait(wmx_rt *h) {
     return first;
 }
 
+// Non-blocking wmx_rt_wait: queues every download still owed and returns 1 when every row of every queued tick is in host memory, 0
+// when something is still on its way (a host that releases groups of streams at staggered phases polls the older groups while it
+// waits for the next release, examples/host_paced.c --phases).
+int wmx_rt_poll(wmx_rt *h) {
+    WMX_ON_DEVICE(h);
+    if (!h) return WMX_EINVAL;
+    int done = 1;
+    for (wmx_pipe *p : h->pipe) {
+        const int rc = wmx_pipe_poll(p, -1);
+        if (rc < 0) return rc;
+        done &= rc;
+    }
+    return done;
+}
+
 int wmx_rt_tick(wmx_rt *h, const int16_t *d_far, int *slot, void *stream) {
     const int rc = wmx_rt_submit(h, d_far, slot, stream);
     const int rw = wmx_rt_wait(h);
     return rc ? rc : rw;
+}
+
+struct ResidentCtx {
+    uint8_t *d_rows, *d_out;
+    long stride, out_stride;
+    const int16_t *d_far;
+    long lo;
+};
+static int resident_one(wmx_rt *h, size_t b, void *stream, void *vctx) {
+    ResidentCtx *c = static_cast<ResidentCtx *>(vctx);
+    wmx_pipe *p = h->pipe[b];
+    uint8_t *in = c->d_rows + (size_t)c->lo * (size_t)c->stride;
+    uint8_t *o = h->pcm ? in : c->d_out + (size_t)c->lo * (size_t)c->out_stride;
+    c->lo += p->n_streams;
+    return wmx_pipe_step_resident(p, in, c->stride, c->d_far, o, h->pcm ? c->stride : c->out_stride, stream);
 }
 
 int wmx_rt_step_resident(wmx_rt *h, uint8_t *d_rows, long stride, const int16_t *d_far, uint8_t *d_out, long out_stride, void *stream) {
@@ -146,15 +238,8 @@ int wmx_rt_step_resident(wmx_rt *h, uint8_t *d_rows, long stride, const int16_t 
         wmx::set_error("wmx_rt_step_resident: bad argument");
         return WMX_EINVAL;
     }
-    long lo = 0;
-    for (wmx_pipe *p : h->pipe) {
-        uint8_t *in = d_rows + (size_t)lo * (size_t)stride;
-        uint8_t *o = h->pcm ? in : d_out + (size_t)lo * (size_t)out_stride;
-        const int rc = wmx_pipe_step_resident(p, in, stride, d_far, o, h->pcm ? stride : out_stride, stream);
-        if (rc != 0) return rc;
-        lo += p->n_streams;
-    }
-    return 0;
+    ResidentCtx c{d_rows, d_out, stride, out_stride, d_far, 0};
+    return rt_launches(h, wmx::as_stream(stream), resident_one, &c);
 }
 
 }  // extern "C"

@@ -24,7 +24,7 @@ class RtBatch:
     172-byte RTP/PCMA datagrams, 8 kHz mono, 20 ms)."""
 
     def __init__(self, n_streams, dev, sub_batch=65536, slots=2, kind="pcm", chn=1, freq=16000, interval_ms=20, agc_value=5,
-                 stages=NS | AEC | AGC | VAD):
+                 stages=NS | AEC | AGC | VAD, compute_streams=1):
         self.n, self.dev, self.kind, self.slots = int(n_streams), dev, kind, slots
         self._h = C.c_void_p()
         L = lib()
@@ -37,6 +37,7 @@ class RtBatch:
             check(L.wmx_rt_create_rtp(C.byref(self._h), self.n, sub_batch, slots, 0, agc_value, stages), "wmx_rt_create_rtp")
             self.pkt10, self.ppc = PKT, 2
             self.row, self.row_dtype, self.far_shape, self.row_bytes = DATAGRAM, np.uint8, (2, PKT), DATAGRAM
+        check(L.wmx_rt_set_compute_streams(self._h, compute_streams), "wmx_rt_set_compute_streams")
         self.B = L.wmx_rt_batches(self._h)
         self.batch_n = [L.wmx_rt_batch_streams(self._h, b) for b in range(self.B)]
         self.lo = np.concatenate([[0], np.cumsum(self.batch_n)]).astype(np.int64)
@@ -74,6 +75,13 @@ class RtBatch:
 
     def wait(self):
         check(lib().wmx_rt_wait(self._h), "wmx_rt_wait")
+
+    def poll(self):
+        """non-blocking wait(): True when every row of every queued tick is in host memory"""
+        rc = lib().wmx_rt_poll(self._h)
+        if rc < 0:
+            check(rc, "wmx_rt_poll")
+        return rc == 1
 
     def tick(self, far=None):
         """one tick: every sub-batch up, through the chain and down again; returns (the slot) when the last row is in host memory"""
@@ -136,22 +144,44 @@ class GpuClock:
             return None
         return None
 
+    # The read goes through the driver to the SMU and can take milliseconds: never on the releasing thread.  start() samples every
+    # `period_s` on a thread of its own (file I/O releases the GIL); stop() returns the samples.
+    def start(self, period_s=0.25):
+        import threading
+        self._samples, self._stop = [], threading.Event()
+
+        def run():
+            while not self._stop.wait(period_s):
+                v = self.mhz()
+                if v is not None:
+                    self._samples.append(v)
+        self._thread = threading.Thread(target=run, daemon=True)
+        if self.path:
+            self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        if self._thread.is_alive():
+            self._thread.join(timeout=2.0)
+        return list(self._samples)
+
 
 def paced_loop(tick_fn, tick_ms, n_ticks, clock=None, clock_every=16, spin_us=300, after=None):
     """Release tick k at t0 + k * tick_ms (absolute schedule): sleep until shortly before, spin the rest, call tick_fn(k), which returns
     when the tick's last row is in host memory.  Returns (latency_ms[k] = completion - scheduled release, lag_ms[k] = actual start -
-    scheduled release, sclk MHz samples taken just before a release)."""
+    scheduled release, sclk MHz samples taken every 250 ms by a thread of their own)."""
     period = tick_ms * 1e-3
-    lat, lag, clk = np.empty(n_ticks), np.empty(n_ticks), []
+    lat, lag = np.empty(n_ticks), np.empty(n_ticks)
     now = time.perf_counter
+    if clock is not None:
+        clock.start()
     t0 = now() + period
     for k in range(n_ticks):
         due = t0 + k * period
         d = due - now() - spin_us * 1e-6
         if d > 0:
             time.sleep(d)
-        if clock is not None and k % clock_every == 0 and now() < due:
-            clk.append(clock.mhz())
         while now() < due:
             pass
         start = now()
@@ -160,7 +190,52 @@ def paced_loop(tick_fn, tick_ms, n_ticks, clock=None, clock_every=16, spin_us=30
         lag[k], lat[k] = (start - due) * 1e3, (end - due) * 1e3
         if after is not None:
             after(k)  # behind the clock: whatever the host does with the rows is not part of the tick
-    return lat, lag, [c for c in clk if c is not None]
+    return lat, lag, (clock.stop() if clock is not None else [])
+
+
+def paced_groups(submit, poll, wait, n_groups, tick_ms, n_ticks, clock=None, after=None):
+    """Staggered release: group g (of n_groups groups of streams, each with the whole tick as its period) is released at
+    t0 + (k * n_groups + g) * tick_ms / n_groups -- the streams of a server do not all deliver their package at the same instant, and a
+    device that works in n_groups short bursts per period never idles long enough for its power management to clock it down
+    (profiles/r06/README_paced.md).  submit(g) queues the group's tick and returns; poll(g) is the non-blocking completion check;
+    wait(g) blocks.  Between releases the loop polls the groups in flight, so a completion is seen within microseconds of the last
+    row's arrival.  Returns (latency_ms, lag_ms, clock samples) over all n_ticks * n_groups group-ticks, in release order."""
+    P, sub = n_groups, tick_ms * 1e-3 / n_groups
+    total = n_ticks * P
+    lat, lag = np.empty(total), np.empty(total)
+    now = time.perf_counter
+    flying = {}  # group -> (index, due)
+    if clock is not None:
+        clock.start()
+
+    def reap(block_group=None):
+        for g in list(flying):
+            if g == block_group:
+                wait(g)
+            elif not poll(g):
+                continue
+            j, due = flying.pop(g)
+            lat[j] = (now() - due) * 1e3
+            if after is not None:
+                after(j, g)
+
+    t0 = now() + tick_ms * 1e-3
+    for j in range(total):
+        due, g = t0 + j * sub, j % P
+        while now() < due:
+            if flying:
+                reap()
+            elif due - now() > 4e-4:
+                time.sleep(due - now() - 3e-4)
+        if g in flying:  # its previous tick is not back yet: the release waits for it (and the wait counts)
+            reap(block_group=g)
+        start = now()
+        submit(g)
+        flying[g] = (j, due)
+        lag[j] = (start - due) * 1e3
+    while flying:
+        reap(block_group=next(iter(flying)))
+    return lat, lag, (clock.stop() if clock is not None else [])
 
 
 def latency_summary(lat_ms, lag_ms, tick_ms, clk=None):
@@ -171,7 +246,9 @@ def latency_summary(lat_ms, lag_ms, tick_ms, clk=None):
            "p99_9_ms": round(float(q[2]), 4), "max_ms": round(float(lat_ms.max()), 4), "misses": int((lat_ms > budget).sum()),
            "overruns_of_the_period": int((lat_ms > tick_ms).sum()),
            "release_lag_p50_ms": round(float(np.percentile(lag_ms, 50)), 4), "release_lag_max_ms": round(float(lag_ms.max()), 4),
+           # the tick's own duration (actual start -> done), whatever backlog it started with
+           "service_p50_ms": round(float(np.percentile(lat_ms - lag_ms, 50)), 4), "service_max_ms": round(float((lat_ms - lag_ms).max()), 4),
            "worst_tick": int(lat_ms.argmax())}
     if clk:
-        out["sclk_mhz_before_release"] = {"min": int(min(clk)), "median": int(np.median(clk)), "max": int(max(clk)), "samples": len(clk)}
+        out["sclk_mhz_sampled"] = {"min": int(min(clk)), "median": int(np.median(clk)), "max": int(max(clk)), "samples": len(clk)}
     return out
