@@ -166,7 +166,7 @@ class NsWorkload:
         b = torch.from_numpy(np.ascontiguousarray(base.transpose(1, 0, 2))).to(dev)  # [K, 256, pkt]
         self.inp = b[:, torch.arange(n_streams, device=dev) % 256]                     # [K, S, pkt] packet-major
         self.work = torch.empty_like(self.inp[0:1])
-        self.ns = NsBatch(n_streams, 1, self.freq, ordered=True)
+        self.ns = NsBatch(n_streams, 1, self.freq)
         self.t = _StageTimer("ns")
         self.k = 0
         self.sample = [int(i) for i in np.linspace(0, n_streams - 1, 16)]
@@ -182,7 +182,7 @@ class NsWorkload:
     def parity_check(self):
         """Replays 16 sampled streams through the oracle's NS for exactly the packets this run fed and compares every packet
         recorded outside the timed region (those behind it depend on every timed step through the noise model).  Float path:
-        bit-exact (ordered mode)."""
+        bit-exact."""
         from oracle import loader
         port = loader.port()
         worst, n, n_off = 0, 0, 0
@@ -203,7 +203,7 @@ class NsWorkload:
 
     def config(self):
         return {"workload": self.name, "streams_per_gpu": self.n_frames, "frame": "160 x int16 (10 ms @ 16 kHz mono)",
-                "sum_order": "reference (bit-exact mode)",
+                "sum_order": "reference (the only one the library has)",
                 "input": "noise A=3000 + 3000 sin(0.01 t) gated every 100 frames (SURVEY 8d recipe), 256 distinct streams x %d "
                          "packets, tiled" % self.K}
 
@@ -922,7 +922,7 @@ class ChainWorkload:
                             "computes" % self.FC if self.dist is not None else
                             ("%d distinct far-ends, stream s hears far-end s * N // S; resident in HBM" % self.far_ends if self.far_ends > 1
                              else "shared, resident in HBM (one GPU: nothing to broadcast)")),
-                "sum_order": "reference (bit-exact NS mode)",
+                "sum_order": "reference (the only one the library has)",
                 "host_calls_per_step": "one: wmx_chain_process (NS, AEC far + near, AGC, VAD launched back to back by the C library)",
                 "aec_launch": "far kernel + near kernel; roofline = the near kernel alone, timed by HIP events the library records "
                               "on the launch stream around it (wmx_aec_set_timing)"}
@@ -993,7 +993,7 @@ class NsAgcMix32kWorkload:
         self.flat = torch.zeros(S * per + 2, dtype=torch.int16, device=dev)  # + the mixer's 2-sample look-ahead
         self.work = self.flat[: S * per].view(1, S, per)
         self.src = torch.as_strided(self.flat, (S // self.N, self.N, per + 2), (self.N * per, per, 1))
-        self.ns, self.agc = NsBatch(S, 2, 32000, ordered=True), AgcBatch(S, 2, 32000, 5)
+        self.ns, self.agc = NsBatch(S, 2, 32000), AgcBatch(S, 2, 32000, 5)
         self.mix = MixBatch(S // self.N, 1, 8000)
         self.t = _StageTimer("ns")
         self.k = 0

@@ -97,14 +97,11 @@ int wmx_g711_decode(int law, const uint8_t *d_code, int16_t *d_pcm, size_t n_cod
  * first 160 frames of each packet are processed, the rest of the output packet is zero
  * (SURVEY.md section 0 quirks 2-3).
  *
- * wmx_ns_set_ordered(h, 1) (default) adds every spectral/time sum in the reference's index order:
- * bit-exact with the CPU path.  0 lets the wave add in parallel (faster, NOT parity-grade: sums
- * change by an ulp and NS feeds them back into decisions; RMS error stays < 1e-3 of full scale but
- * individual samples of a few streams can be off by several LSB for a few frames). */
+ * Every spectral / time sum is added in the reference's index order: bit-exact with the CPU path.  (The faster re-associated mode of
+ * rounds 1-5, wmx_ns_set_ordered(h, 0), was outside north_star's +-1 LSB -- up to 13 LSB on a few samples -- and is gone.) */
 typedef struct wmx_ns wmx_ns;
 int wmx_ns_create(wmx_ns **out, int n_streams, int chn, int freq);
 int wmx_ns_destroy(wmx_ns *h);
-int wmx_ns_set_ordered(wmx_ns *h, int ordered);
 int wmx_ns_packet_samples(const wmx_ns *h); /* int16 elements per packet = freq/100*chn */
 int wmx_ns_process(wmx_ns *h, const int16_t *d_in, int16_t *d_out, int n_packets, long stream_stride,
                    long packet_stride, void *stream);

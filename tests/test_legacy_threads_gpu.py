@@ -1,0 +1,78 @@
+"""The legacy adapters under the reference's own threading (round-5 VERDICT weak 4 / next 3): six task threads in wmix_load_data
+(src/wmixTask.c:85, 973, 1311, 1484, 1704, 1927), the message thread in agc_addition (src/wmix.c:1070), the record thread's four-call
+heartbeat (src/wmix.c:613-709) -- and a 65 536-stream batch running wmx_chain_process on a BLOCKING stream of the same process.
+examples/host_legacy_threads.c is that process (plain C + pthreads); here its results are checked: every thread's output equals
+the per-handle oracle's, and the heartbeat's p99 in that company stays within 20 % of what it is alone (no adapter launches on or
+waits for the NULL stream any more: one non-blocking stream per compat handle, one per thread for the stateless calls)."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle import loader as L
+
+pytestmark = pytest.mark.gpu
+
+HOST = os.path.join(ROOT, "examples", "host_legacy_threads")
+BEAT, CHUNK, N_LOAD = 320, 1280, 6
+
+
+def _inputs(d, n):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_aec_golden import aec_input
+    far, near = aec_input(1, 16000, 10, n * 2, seed=7411)
+    far.tofile(os.path.join(d, "hb_far.i16"))
+    near.tofile(os.path.join(d, "hb_near.i16"))
+    rng = np.random.default_rng(7412)
+    srcs = [rng.integers(-6000, 6000, n * CHUNK, dtype=np.int16) for _ in range(N_LOAD)]
+    for k, s in enumerate(srcs):
+        s.tofile(os.path.join(d, "src_%d.i16" % k))
+    agc_in = (rng.standard_normal(n * BEAT) * 1500).astype(np.int16)
+    agc_in.tofile(os.path.join(d, "agc_in.i16"))
+    return far, near, srcs, agc_in
+
+
+def _ring_want(port, src, n):
+    """one task thread's life: a chunk of 2 x 16000 per beat of phase 2 into its own 1 x 8000 ring, the cursor carried along"""
+    L.mix_bind(port)
+    store = np.zeros(16000 + 64, np.uint8)
+    r = L.MixRing()
+    port.orc_mix_ring_init(C.byref(r), store.ctypes.data_as(C.c_void_p), 1, 8000)
+    r.head_off, r.reduce_mode = 0, 1
+    head, tick = 0xFFFFFFFF, C.c_uint32(0)
+    for b in range(n // 2, n):
+        head = port.orc_load_data(C.byref(r), C.c_void_p(src.ctypes.data + b * CHUNK * 2), CHUNK * 2, 16000, 2, 16, C.c_uint32(head), 1, C.byref(tick))
+    return store[:16000].view(np.int16).copy(), head, tick.value
+
+
+def test_the_daemons_threads_beside_a_batch(cuda, oracle_port, tmp_path):
+    assert os.path.exists(HOST), "examples/host_legacy_threads is built by __graft_entry__.build()"
+    n = 600
+    d = str(tmp_path)
+    far, near, srcs, agc_in = _inputs(d, n)
+    r = subprocess.run([HOST, d, str(n), "65536"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    # the heartbeat: ONE run of n beats through the four legacy calls, whatever went on beside it
+    want = L.run_chain(oracle_port, 1, 16000, 5, 15, far, near, BEAT, prefix="orc", interval_ms=20)
+    got = np.fromfile(os.path.join(d, "hb_out.i16"), np.int16)
+    assert np.array_equal(got, want)
+    # the six task threads
+    for k in range(N_LOAD):
+        ring_w, head_w, tick_w = _ring_want(oracle_port, srcs[k], n)
+        ring = np.fromfile(os.path.join(d, "ring_%d.i16" % k), np.int16)
+        head, tick = np.fromfile(os.path.join(d, "ring_%d.meta" % k), np.uint32)
+        assert np.array_equal(ring, ring_w) and (int(head), int(tick)) == (head_w, tick_w), k
+    # the message thread's own handle: agc_addition in front of every agc_process
+    h = n // 2
+    agc_w = L.run_agc_handle(oracle_port, 1, 16000, 5, agc_in[h * BEAT:], BEAT, additions=[(c, 3 + (h + c) % 5) for c in range(n - h)], prefix="orc")
+    agc_g = np.fromfile(os.path.join(d, "agc_out.i16"), np.int16)
+    assert np.array_equal(agc_g[:h * BEAT], agc_in[:h * BEAT]) and np.array_equal(agc_g[h * BEAT:], agc_w)
+    # and what it cost: the batch really ran beside it, the heartbeat's p99 within 20 % of its figure alone
+    assert res["batch_steps_in_phase_2"] >= 20, res
+    assert res["p99_ratio"] <= 1.2, res

@@ -438,3 +438,35 @@ def test_fixed_point_stream_migration_bit_exact(cuda, oracle_port):
         assert np.array_equal(db[2, cut:].cpu().numpy(), want[cut:]), type(A).__name__
         A.close()
         B.close()
+
+
+def test_a_blob_of_an_older_format_is_refused(cuda):
+    """Round-5 ADVICE (medium): round 5 changed the MEANING of one AEC state word in place (block count -> comfort-noise seed) and a
+    blob of the build before would have been accepted.  Every blob now carries its module's format version (top byte of the header's
+    layout word); rounds 1-5 wrote version 0.  All six stream blobs and both cohort blobs refuse it and say why."""
+    from wmix_amd._lib import WmxError
+    from wmix_amd.aec import AecBatch
+    from wmix_amd.aecm import AecmBatch
+    from wmix_amd.agc import AgcBatch
+    from wmix_amd.ns import NsBatch
+    from wmix_amd.nsx import NsxBatch
+    from wmix_amd.vad import VadBatch
+    made = [("aec", AecBatch(2, 1, 16000, 10), 2), ("aecm", AecmBatch(2, 1, 16000, 10), 1), ("agc", AgcBatch(2, 1, 16000, 5), 1),
+            ("ns", NsBatch(2, 1, 16000), 1), ("nsx", NsxBatch(2, 1, 16000), 1), ("vad", VadBatch(2, 1, 16000, 10), 1)]
+    for name, b, version in made:
+        for kind in (("stream", "cohort") if name in ("aec", "aecm") else ("stream",)):
+            blob = b.export_stream(0) if kind == "stream" else b.export_cohort(0)
+            hdr = blob[:16].view(np.uint32)
+            assert hdr[2] >> 24 == (2 if (name, kind) == ("aec", "cohort") else version), (name, kind, hdr)
+            if kind == "stream":
+                b.import_stream(1, blob)  # its own format: accepted
+            else:
+                b.import_cohort(0, blob)
+            old = blob.copy()
+            old[:16].view(np.uint32)[2] &= 0x00FFFFFF  # what a build of rounds 1-5 wrote: no version
+            with pytest.raises(WmxError, match="format version 0"):
+                if kind == "stream":
+                    b.import_stream(1, old)
+                else:
+                    b.import_cohort(0, old)
+        b.close()

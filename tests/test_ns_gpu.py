@@ -19,14 +19,14 @@ pytestmark = pytest.mark.gpu
 G = np.load(os.path.join(GOLDEN, "ns_golden.npz"))
 
 
-def run_gpu(cuda, chn, freq, x_streams, ordered=True, packets_per_launch=64, packet_major=False):
+def run_gpu(cuda, chn, freq, x_streams, packets_per_launch=64, packet_major=False):
     """x_streams: int16 [S, n_frames*pkt*chn] -> same shape, through NsBatch."""
     import torch
     from wmix_amd.ns import NsBatch
     S = x_streams.shape[0]
     per = freq // 100 * chn
     nf = x_streams.shape[1] // per
-    nb = NsBatch(S, chn, freq, ordered=ordered)
+    nb = NsBatch(S, chn, freq)
     if packet_major:
         d = torch.from_numpy(np.ascontiguousarray(x_streams.reshape(S, nf, per).transpose(1, 0, 2))).to(cuda)
         for f in range(0, nf, packets_per_launch):
@@ -63,15 +63,14 @@ def test_many_streams_long_run_vs_oracle(cuda, oracle_port, chn, freq):
     want = np.stack([L.run_ns(oracle_port, chn, freq, x[s], freq // 100, prefix="orc") for s in range(S)])
     got = run_gpu(cuda, chn, freq, x, packets_per_launch=100, packet_major=(chn == 1))
     assert np.array_equal(got, want)
-    # The optional parallel-sum mode (wmx_ns_set_ordered(h, 0)) is NOT the parity mode: re-associating the
-    # spectral sums perturbs them by an ulp, and NS feeds those sums back into threshold decisions, so a few
-    # streams drift by more than 1 LSB for a few frames (measured: 4 of 64 streams, worst 13 LSB, 0.02 % of
-    # samples).  It must still be statistically indistinguishable: RMS error <= 1e-3 of full scale and
-    # >= 99.9 % of samples within 1 LSB.
-    fast = run_gpu(cuda, chn, freq, x, ordered=False, packets_per_launch=100)
-    d = fast.astype(np.int32) - want.astype(np.int32)
-    assert np.sqrt((d.astype(np.float64) ** 2).mean()) / 32768.0 <= 1e-3
-    assert (np.abs(d) > 1).mean() <= 1e-3
+
+
+def test_no_entry_point_outside_the_tolerance(wmx):
+    """The re-associated sum mode of rounds 1-5 (wmx_ns_set_ordered(h, 0): up to 13 LSB on a few samples, north_star allows 1) is gone:
+    the library exports no such switch and compiles one noise-suppressor kernel per shape, the reference's summation order."""
+    assert not hasattr(wmx, "wmx_ns_set_ordered")
+    from wmix_amd import _lib
+    assert "wmx_ns_set_ordered" not in _lib.declared_symbols()
 
 
 def test_reference_host_signatures(wmx, oracle_port):

@@ -1,0 +1,167 @@
+"""wmx_pipe_submit / wmx_pipe_wait fail clean (round-5 VERDICT weak 6 / next 4).  A variant of the library built with
+-DWMX_FAULT_INJECTION (tools_dev/build/lib_faults.so, made by __graft_entry__.build(); refused by the Python mirror like every variant
+unless asked for) lets a test make "HIP call n of this entry point" fail.  For every n from 1 to the last call of a submit:
+
+  * the submit returns an error, the rotation / slots in flight / pending download are what they were (the download still owed for the
+    step before arrives and is right);
+  * a fault BEFORE the first launch has advanced nothing: failed_steps stays, the same rows are submitted again;
+  * a fault AFTER it has lost the step (failed_steps counts it): the host restores the streams from the blobs it took at its last
+    checkpoint (wmx_chain_export_stream / _export_cohort) and submits again;
+  * either way the next three submits deliver exactly what an undisturbed run delivers.
+
+The child process below does the work (it must load the variant library; this process has the product)."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+VARIANT = os.path.join(ROOT, "tools_dev", "build", "lib_faults.so")
+
+
+def _child(kind):
+    import torch
+    from wmix_amd import _lib, synth
+    from wmix_amd.lifetime import Lifetime
+    from wmix_amd.pipeline import PcmChain, RtpChain, StreamingPipe
+    L = _lib.lib()
+    assert "WMX_FAULT_INJECTION" in _lib.build_info()
+    L.wmx_debug_fail_nth_hip_call.argtypes = [C.c_long]
+    L.wmx_debug_hip_calls.restype = C.c_long
+    dev = torch.device("cuda:0")
+    S, n = 24, 400
+
+    class Borrowed(Lifetime):  # the pipe's own chain, for the checkpoint blobs
+        _mod = "chain"
+
+        def __init__(self, h):
+            self._h, self.n_streams = h, S
+
+    if kind == "pcm":
+        far = synth.far_end(9700, n, 160)
+        near = synth.near_end(9701, S, n, 160, far=far).reshape(S, n, 160).transpose(1, 0, 2)
+        make = lambda: PcmChain(S, dev, 1, 16000, 10, 5, 15, slots=3)  # noqa: E731
+        far_rows = far.reshape(n, 1, 160)
+    else:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle import loader
+        from test_pipeline_gpu import make_datagrams
+        far, pk = make_datagrams(loader.port(), S, n, seed=9710)
+        near = pk.transpose(1, 0, 2)
+        make = lambda: RtpChain(S, dev)  # noqa: E731
+        far_rows = far.reshape(n, 2, 80)
+
+    def run(pipe, k):
+        slot = k % pipe.SLOTS
+        pipe.h_in[slot][:] = near[k]
+        pipe.h_far[slot][:] = far_rows[k]
+        s = C.c_int(-1)
+        rc = L.wmx_pipe_submit(pipe.c._h, None, C.byref(s), None)
+        return rc, s.value
+
+    # the undisturbed run
+    u = make()
+    pu = StreamingPipe(u)
+    want = np.zeros((n,) + pu.h_out[0].shape, pu.h_out[0].dtype)
+    for k in range(n):
+        rc, slot = run(pu, k)
+        assert rc == 0
+        pu.wait(slot)
+        want[k] = pu.h_out[slot]
+    u.close()
+
+    f = make()
+    pf = StreamingPipe(f)
+    chain = Borrowed(L.wmx_pipe_chain(f._h))
+    got = {}
+    k = 0
+    for _ in range(6):  # past the first rotation: every submit from here on makes the same runtime calls
+        rc, slot = run(pf, k)
+        assert rc == 0
+        k += 1
+    pf.wait(-1)
+    report = {"kind": kind, "faults": 0, "before_first_launch": 0, "lost_steps": 0, "wait_faults": 0}
+    i = 1
+    while True:
+        assert k + 4 < n, "ran out of steps at fault %d" % i
+        # step k - 1 stays owed (submitted, its download not queued yet) while step k fails
+        rc, slot_prev = run(pf, k)
+        assert rc == 0
+        k_prev, k = k, k + 1
+        snap = None
+        if kind == "pcm":  # the host's checkpoint: every stream and the cohort
+            snap = ([chain.export_stream(s) for s in range(S)], chain.export_cohort(0))
+        lost0 = L.wmx_pipe_failed_steps(f._h)
+        L.wmx_debug_fail_nth_hip_call(i)
+        rc, _ = run(pf, k)
+        calls = L.wmx_debug_hip_calls()
+        L.wmx_debug_fail_nth_hip_call(0)
+        if rc == 0:  # the fault lies behind the last call of a submit: every call has had its turn
+            assert calls < i
+            pf.wait(-1)
+            break
+        assert rc <= -11000, (i, rc)  # a HIP error's code, far from the reference's -1
+        report["faults"] += 1
+        lost = L.wmx_pipe_failed_steps(f._h) - lost0
+        assert lost in (0, 1)
+        if lost == 0:
+            report["before_first_launch"] += 1
+        else:
+            report["lost_steps"] += 1
+            if kind != "pcm":
+                # the RTP senders' sequence numbers have no import call: this form is walked through the faults in front of the first launch only
+                break
+            chain.import_cohort(0, snap[1])
+            for s in range(S):
+                chain.import_stream(s, snap[0][s], cohort=0)
+        # the same step again, then two more; the step that was owed when the fault came is delivered by the next submit / wait
+        for kk in (k, k + 1, k + 2):
+            rc, slot = run(pf, kk)
+            assert rc == 0, (i, kk, L.wmx_last_error())
+            if kk == k:
+                pf.wait(slot_prev)
+                assert np.array_equal(pf.h_out[slot_prev], want[k_prev]), ("the step owed at fault %d" % i)
+            pf.wait(slot)
+            assert np.array_equal(pf.h_out[slot], want[kk]), ("step %d after fault %d" % (kk, i))
+        k += 3
+        i += 1
+    # wmx_pipe_wait: a failing wait changes nothing either
+    for j in (1, 2, 3, 4):
+        rc, slot = run(pf, k)
+        assert rc == 0
+        L.wmx_debug_fail_nth_hip_call(j)
+        rw = L.wmx_pipe_wait(f._h, slot)
+        L.wmx_debug_fail_nth_hip_call(0)
+        report["wait_faults"] += rw != 0
+        pf.wait(slot)
+        assert np.array_equal(pf.h_out[slot], want[k]), ("wait fault", j)
+        k += 1
+    f.close()
+    print(json.dumps(report))
+
+
+@pytest.mark.parametrize("kind", ["pcm", "rtp"])
+def test_every_fallible_call_of_a_submit(cuda, kind):
+    assert os.path.exists(VARIANT), "tools_dev/build/lib_faults.so is built by __graft_entry__.build() (tools_dev/variant.sh build faults -DWMX_FAULT_INJECTION)"
+    env = dict(os.environ, WMIX_AMD_LIB=VARIANT, WMIX_AMD_ALLOW_VARIANT_BUILD="1", PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), kind], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["before_first_launch"] >= 3 and rep["wait_faults"] >= 2, rep
+    if kind == "pcm":
+        assert rep["lost_steps"] >= 10 and rep["faults"] == rep["before_first_launch"] + rep["lost_steps"], rep
+
+
+def test_the_product_build_has_no_fault_hooks(wmx):
+    assert not hasattr(wmx, "wmx_debug_fail_nth_hip_call") and not hasattr(wmx, "wmx_debug_hip_calls")
+
+
+if __name__ == "__main__":
+    _child(sys.argv[1])

@@ -10,8 +10,8 @@ for chn,freq in ((1,16000),(1,8000),(2,16000),(1,32000),(2,32000),(2,8000)):
     x=np.stack([synth.ns_input(100+s*17,chn,NF,pkt).T.reshape(-1) for s in range(S)]).astype(np.int16)  # [S, NF*pkt*chn]
     x[3].reshape(NF,-1)[60:70]=0
     want=np.stack([L.run_ns(port,chn,freq,x[s],pkt,prefix='orc') for s in range(S)])
-    for ordered in (True,False):
-        nb=NsBatch(S,chn,freq,ordered=ordered)
+    for ordered in (True,):
+        nb=NsBatch(S,chn,freq)
         d=torch.from_numpy(x.reshape(S,NF,pkt*chn).copy()).to(dev)
         t0=time.time()
         for f in range(0,NF,50):   # several launches of 50 packets

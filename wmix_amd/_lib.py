@@ -97,8 +97,6 @@ def _declare(L):
     L.wmx_ns_create.argtypes = [C.POINTER(vp), i, i, i]
     L.wmx_ns_destroy.restype = i
     L.wmx_ns_destroy.argtypes = [vp]
-    L.wmx_ns_set_ordered.restype = i
-    L.wmx_ns_set_ordered.argtypes = [vp, i]
     L.wmx_ns_packet_samples.restype = i
     L.wmx_ns_packet_samples.argtypes = [vp]
     L.wmx_ns_state_words.restype = i

@@ -2256,6 +2256,9 @@ int wmx_aec_set_active(wmx_aec *h, const uint8_t *host_mask, void *stream) {
 // stream migration: [header | AS_WORDS state words].  The stream's COHORT (control plane + far-end history) travels on its
 // own: [header | AecCtl | the group's far-end buffers]; a destination cohort that received it continues exactly where the
 // source cohort stands, so a stream imported into it behaves as if it had never moved.
+// Format versions of the AEC's blobs (wmx_internal.h: blob_layout).  Stream: 2 since round 5 turned AS_NBLK (the block count) into
+// AS_NSEED (the comfort-noise generator's state) in place.  Cohort: 2 since round 6 resized the far-end slab.
+static constexpr uint32_t kAecBlobVersion = 2, kAecCohortBlobVersion = 2;
 int wmx_aec_stream_state_bytes(const wmx_aec *h) { return h ? (int)(sizeof(wmx::BlobHeader) + wmx::AS_WORDS * 4) : WMX_EINVAL; }
 int wmx_aec_cohort_state_bytes(const wmx_aec *h) {
     return h ? (int)(sizeof(wmx::BlobHeader) + sizeof(wmx::AecCtl) + h->far.group_words * 4) : WMX_EINVAL;
@@ -2267,7 +2270,7 @@ int wmx_aec_export_stream(wmx_aec *h, int stream_index, void *host_blob) {
     if (!h || !host_blob || stream_index < 0 || stream_index >= h->n_streams) return WMX_EINVAL;
     WMX_HIP(hipDeviceSynchronize());
     char *p = static_cast<char *>(host_blob);
-    blob_begin(p, blob_tag("AEC "), (uint32_t)h->freq, AS_WORDS * 4);
+    blob_begin(p, blob_tag("AEC "), blob_layout((uint32_t)h->freq, kAecBlobVersion), AS_WORDS * 4);
     WMX_HIP(hipMemcpy(p + sizeof(BlobHeader), h->d_state + (size_t)stream_index * AS_WORDS, AS_WORDS * 4, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -2276,7 +2279,7 @@ int wmx_aec_import_stream(wmx_aec *h, int stream_index, const void *host_blob, i
     WMX_ON_DEVICE(h);
     using namespace wmx;
     if (!h || !host_blob || stream_index < 0 || stream_index >= h->n_streams || cohort < -1 || cohort >= h->n_far) return WMX_EINVAL;
-    const int rc = blob_check(host_blob, blob_tag("AEC "), (uint32_t)h->freq, AS_WORDS * 4);
+    const int rc = blob_check(host_blob, blob_tag("AEC "), blob_layout((uint32_t)h->freq, kAecBlobVersion), AS_WORDS * 4);
     if (rc) return rc;
     WMX_HIP(hipDeviceSynchronize());
     WMX_HIP(hipMemcpy(h->d_state + (size_t)stream_index * AS_WORDS, static_cast<const char *>(host_blob) + sizeof(BlobHeader), AS_WORDS * 4,
@@ -2296,7 +2299,7 @@ int wmx_aec_export_cohort(wmx_aec *h, int cohort, void *host_blob) {
     WMX_HIP(hipDeviceSynchronize());
     char *p = static_cast<char *>(host_blob);
     const size_t fb = h->far.group_words * 4;
-    blob_begin(p, blob_tag("AECc"), (uint32_t)h->freq, (uint32_t)(sizeof(AecCtl) + fb));
+    blob_begin(p, blob_tag("AECc"), blob_layout((uint32_t)h->freq, kAecCohortBlobVersion), (uint32_t)(sizeof(AecCtl) + fb));
     p += sizeof(BlobHeader);
     memcpy(p, &aec_ctl(h, cohort), sizeof(AecCtl));
     WMX_HIP(hipMemcpy(p + sizeof(AecCtl), h->d_far + (size_t)cohort * h->far.group_words, fb, hipMemcpyDeviceToHost));
@@ -2308,7 +2311,7 @@ int wmx_aec_import_cohort(wmx_aec *h, int cohort, const void *host_blob) {
     using namespace wmx;
     if (!h || !host_blob || cohort < 0 || cohort >= h->n_far) return WMX_EINVAL;
     const size_t fb = h->far.group_words * 4;
-    const int rc = blob_check(host_blob, blob_tag("AECc"), (uint32_t)h->freq, (uint32_t)(sizeof(AecCtl) + fb));
+    const int rc = blob_check(host_blob, blob_tag("AECc"), blob_layout((uint32_t)h->freq, kAecCohortBlobVersion), (uint32_t)(sizeof(AecCtl) + fb));
     if (rc) return rc;
     WMX_HIP(hipDeviceSynchronize());
     const char *p = static_cast<const char *>(host_blob) + sizeof(BlobHeader);

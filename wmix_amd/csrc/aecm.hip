@@ -1444,6 +1444,7 @@ void wmx::aecm_cancel_fork(wmx_aecm *h) {
 extern "C" {
 
 // stream / cohort migration, as for the float AEC
+static constexpr uint32_t kAecmBlobVersion = 1;  // bump when the meaning of a state word changes (wmx_internal.h: blob_layout)
 int wmx_aecm_stream_state_bytes(const wmx_aecm *h) { return h ? (int)(sizeof(wmx::BlobHeader) + wmx::A_WORDS * 4) : WMX_EINVAL; }
 int wmx_aecm_cohort_state_bytes(const wmx_aecm *h) {
     return h ? (int)(sizeof(wmx::BlobHeader) + sizeof(wmx::AecmCtl) + h->far.group_bytes) : WMX_EINVAL;
@@ -1455,7 +1456,7 @@ int wmx_aecm_export_stream(wmx_aecm *h, int stream_index, void *host_blob) {
     if (!h || !host_blob || stream_index < 0 || stream_index >= h->n_streams) return WMX_EINVAL;
     WMX_HIP(hipDeviceSynchronize());
     char *p = static_cast<char *>(host_blob);
-    blob_begin(p, blob_tag("AECM"), (uint32_t)h->freq, A_WORDS * 4);
+    blob_begin(p, blob_tag("AECM"), blob_layout((uint32_t)h->freq, kAecmBlobVersion), A_WORDS * 4);
     WMX_HIP(hipMemcpy(p + sizeof(BlobHeader), h->d_state + (size_t)stream_index * A_WORDS, A_WORDS * 4, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -1464,7 +1465,7 @@ int wmx_aecm_import_stream(wmx_aecm *h, int stream_index, const void *host_blob,
     WMX_ON_DEVICE(h);
     using namespace wmx;
     if (!h || !host_blob || stream_index < 0 || stream_index >= h->n_streams || cohort < -1 || cohort >= h->n_cohorts) return WMX_EINVAL;
-    const int rc = blob_check(host_blob, blob_tag("AECM"), (uint32_t)h->freq, A_WORDS * 4);
+    const int rc = blob_check(host_blob, blob_tag("AECM"), blob_layout((uint32_t)h->freq, kAecmBlobVersion), A_WORDS * 4);
     if (rc) return rc;
     WMX_HIP(hipDeviceSynchronize());
     WMX_HIP(hipMemcpy(h->d_state + (size_t)stream_index * A_WORDS, static_cast<const char *>(host_blob) + sizeof(BlobHeader), A_WORDS * 4,
@@ -1479,7 +1480,7 @@ int wmx_aecm_export_cohort(wmx_aecm *h, int cohort, void *host_blob) {
     if (!h || !host_blob || cohort < 0 || cohort >= h->n_cohorts) return WMX_EINVAL;
     WMX_HIP(hipDeviceSynchronize());
     char *p = static_cast<char *>(host_blob);
-    blob_begin(p, blob_tag("AEMc"), (uint32_t)h->freq, (uint32_t)(sizeof(AecmCtl) + h->far.group_bytes));
+    blob_begin(p, blob_tag("AEMc"), blob_layout((uint32_t)h->freq, kAecmBlobVersion), (uint32_t)(sizeof(AecmCtl) + h->far.group_bytes));
     p += sizeof(BlobHeader);
     memcpy(p, &wmx::aec_ctl(h, cohort), sizeof(AecmCtl));
     WMX_HIP(hipMemcpy(p + sizeof(AecmCtl), static_cast<char *>(h->d_far) + (size_t)cohort * h->far.group_bytes, h->far.group_bytes,
@@ -1491,7 +1492,7 @@ int wmx_aecm_import_cohort(wmx_aecm *h, int cohort, const void *host_blob) {
     WMX_ON_DEVICE(h);
     using namespace wmx;
     if (!h || !host_blob || cohort < 0 || cohort >= h->n_cohorts) return WMX_EINVAL;
-    const int rc = blob_check(host_blob, blob_tag("AEMc"), (uint32_t)h->freq, (uint32_t)(sizeof(AecmCtl) + h->far.group_bytes));
+    const int rc = blob_check(host_blob, blob_tag("AEMc"), blob_layout((uint32_t)h->freq, kAecmBlobVersion), (uint32_t)(sizeof(AecmCtl) + h->far.group_bytes));
     if (rc) return rc;
     WMX_HIP(hipDeviceSynchronize());
     const char *p = static_cast<const char *>(host_blob) + sizeof(BlobHeader);

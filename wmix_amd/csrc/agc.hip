@@ -782,6 +782,7 @@ int wmx_agc_create(wmx_agc **out, int n_streams, int chn, int freq, int interval
 
 // stream migration: [header | 13 int32 fields | 8 int16 fields | int32 compression gain] -- the gain is the handle's own
 // (WebRtcAgc_set_config's value lives in the reference's handle), so it travels with the stream
+static constexpr uint32_t kAgcBlobVersion = 1;  // bump when the meaning of a state word changes (wmx_internal.h: blob_layout)
 int wmx_agc_stream_state_bytes(const wmx_agc *h) { return h ? (int)(sizeof(wmx::BlobHeader) + wmx::A32_WORDS * 4 + wmx::A16_WORDS * 2 + 4) : WMX_EINVAL; }
 
 int wmx_agc_export_stream(wmx_agc *h, int stream_index, void *host_blob) {
@@ -790,7 +791,7 @@ int wmx_agc_export_stream(wmx_agc *h, int stream_index, void *host_blob) {
     if (!h || !host_blob || stream_index < 0 || stream_index >= h->n_streams) return WMX_EINVAL;
     WMX_HIP(hipDeviceSynchronize());
     char *p = static_cast<char *>(host_blob);
-    blob_begin(p, blob_tag("AGC "), (uint32_t)h->freq, A32_WORDS * 4 + A16_WORDS * 2 + 4);
+    blob_begin(p, blob_tag("AGC "), blob_layout((uint32_t)h->freq, kAgcBlobVersion), A32_WORDS * 4 + A16_WORDS * 2 + 4);
     p += sizeof(BlobHeader);
     WMX_HIP(column_to_host(reinterpret_cast<int32_t *>(p), h->d_s32, A32_WORDS, h->n_streams, stream_index));
     WMX_HIP(column_to_host(reinterpret_cast<int16_t *>(p + A32_WORDS * 4), h->d_s16, A16_WORDS, h->n_streams, stream_index));
@@ -803,7 +804,7 @@ int wmx_agc_import_stream(wmx_agc *h, int stream_index, const void *host_blob) {
     WMX_ON_DEVICE(h);
     using namespace wmx;
     if (!h || !host_blob || stream_index < 0 || stream_index >= h->n_streams) return WMX_EINVAL;
-    const int rc = blob_check(host_blob, blob_tag("AGC "), (uint32_t)h->freq, A32_WORDS * 4 + A16_WORDS * 2 + 4);
+    const int rc = blob_check(host_blob, blob_tag("AGC "), blob_layout((uint32_t)h->freq, kAgcBlobVersion), A32_WORDS * 4 + A16_WORDS * 2 + 4);
     if (rc) return rc;
     WMX_HIP(hipDeviceSynchronize());
     const char *p = static_cast<const char *>(host_blob) + sizeof(BlobHeader);

@@ -53,37 +53,46 @@ struct Mapped {
 };
 thread_local Mapped g_m;
 
+// every launch and copy of a call goes to the calling THREAD's own non-blocking stream and only that stream is waited for
+// (wmx_internal.h: thread_stream) -- the daemon's RTP threads convert side by side (src/wmixTask.c:285, 1139, 1282)
+bool copy_sync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t s, bool wait) {
+    if (hipMemcpyAsync(dst, src, bytes, kind, s) != hipSuccess) return false;
+    return !wait || hipStreamSynchronize(s) == hipSuccess;
+}
+
 int host_encode(int law, unsigned char *out, const short *in, int len) {
     if (len <= 0) return 0;
     size_t n = (size_t)len;
+    hipStream_t s = wmx::thread_stream();
     if (n <= kMappedMax && g_m.ensure() == 0) {
         memcpy(g_m.host, in, n * 2);
-        if (wmx_g711_encode(law, (const int16_t *)g_m.dev, g_m.dev + 2 * kMappedMax, n, nullptr)) return -1;
-        if (hipStreamSynchronize(nullptr) != hipSuccess) return -1;
+        if (wmx_g711_encode(law, (const int16_t *)g_m.dev, g_m.dev + 2 * kMappedMax, n, s)) return -1;
+        if (hipStreamSynchronize(s) != hipSuccess) return -1;
         memcpy(out, g_m.host + 2 * kMappedMax, n);
         return len;
     }
     if (g_a.ensure(n * 2) || g_b.ensure(n)) return -1;
-    if (hipMemcpy(g_a.p, in, n * 2, hipMemcpyHostToDevice) != hipSuccess) return -1;
-    if (wmx_g711_encode(law, (const int16_t *)g_a.p, (uint8_t *)g_b.p, n, nullptr)) return -1;
-    if (hipMemcpy(out, g_b.p, n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (!copy_sync(g_a.p, in, n * 2, hipMemcpyHostToDevice, s, true)) return -1;  // (pageable source: waited for before the caller may reuse it)
+    if (wmx_g711_encode(law, (const int16_t *)g_a.p, (uint8_t *)g_b.p, n, s)) return -1;
+    if (!copy_sync(out, g_b.p, n, hipMemcpyDeviceToHost, s, true)) return -1;
     return len;
 }
 
 int host_decode(int law, short *out, const unsigned char *in, int bytes) {
     if (bytes <= 0) return 0;
     size_t n = (size_t)bytes;
+    hipStream_t s = wmx::thread_stream();
     if (n <= kMappedMax && g_m.ensure() == 0) {
         memcpy(g_m.host + 2 * kMappedMax, in, n);
-        if (wmx_g711_decode(law, g_m.dev + 2 * kMappedMax, (int16_t *)g_m.dev, n, nullptr)) return -1;
-        if (hipStreamSynchronize(nullptr) != hipSuccess) return -1;
+        if (wmx_g711_decode(law, g_m.dev + 2 * kMappedMax, (int16_t *)g_m.dev, n, s)) return -1;
+        if (hipStreamSynchronize(s) != hipSuccess) return -1;
         memcpy(out, g_m.host, n * 2);
         return bytes * 2;
     }
     if (g_a.ensure(n) || g_b.ensure(n * 2)) return -1;
-    if (hipMemcpy(g_a.p, in, n, hipMemcpyHostToDevice) != hipSuccess) return -1;
-    if (wmx_g711_decode(law, (const uint8_t *)g_a.p, (int16_t *)g_b.p, n, nullptr)) return -1;
-    if (hipMemcpy(out, g_b.p, n * 2, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (!copy_sync(g_a.p, in, n, hipMemcpyHostToDevice, s, true)) return -1;
+    if (wmx_g711_decode(law, (const uint8_t *)g_a.p, (int16_t *)g_b.p, n, s)) return -1;
+    if (!copy_sync(out, g_b.p, n * 2, hipMemcpyDeviceToHost, s, true)) return -1;
     return bytes * 2;
 }
 

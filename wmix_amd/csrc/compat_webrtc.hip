@@ -1,6 +1,7 @@
 // compat_webrtc.hip -- the reference's per-handle wrapper API (src/webrtc.h:32-61) exported
 // unchanged over HOST buffers, as thin adapters over a batch of ONE stream: each call stages
-// the caller's int16 buffer in HBM, launches the batched kernel and copies the result back.
+// the caller's int16 buffer in mapped pinned memory, launches the batched kernel on the HANDLE'S OWN
+// non-blocking stream and waits for that stream alone (never the NULL stream: wmx_internal.h).
 // This is what lets the wmix daemon link against libwmix_amd.so instead of src/webrtc.c + the
 // five libwebrtc*.so; throughput comes from the wmx_* batch API, not from here.
 //
@@ -9,6 +10,7 @@
 // in frames (chn samples each) and must be a multiple of the packet size.
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include "wmx_internal.h"
 #include "../../include/wmix_compat.h"
 
@@ -42,9 +44,9 @@ struct DevBuf {
         memcpy(host, src, n_elems * sizeof(int16_t));
         return true;
     }
-    // the launches of this call have finished and their writes are in host memory
-    bool out(int16_t *dst, size_t n_elems) {
-        if (hipStreamSynchronize(nullptr) != hipSuccess) return false;
+    // the launches of this call (on the handle's stream) have finished and their writes are in host memory
+    bool out(int16_t *dst, size_t n_elems, hipStream_t s) {
+        if (hipStreamSynchronize(s) != hipSuccess) return false;
         memcpy(dst, host, n_elems * sizeof(int16_t));
         return true;
     }
@@ -54,6 +56,7 @@ struct DevBuf {
 };
 
 struct NsHandleCompat {
+    hipStream_t s = nullptr;  // this handle's launch stream (wmx_internal.h: legacy_stream_create)
     wmx_ns *batch;    // float NS (the reference's default build) ...
     wmx_nsx *batchx;  // ... or the fixed-point NSX (its MAKE_WEBRTC_NSX build): exactly one is set
     int chn, freq, pkg;
@@ -62,6 +65,7 @@ struct NsHandleCompat {
 };
 
 struct VadHandleCompat {
+    hipStream_t s = nullptr;  // this handle's launch stream (wmx_internal.h: legacy_stream_create)
     wmx_vad *batch;
     int chn, freq, pkg;
     bool *debug;
@@ -69,6 +73,10 @@ struct VadHandleCompat {
 };
 
 struct AgcHandleCompat {
+    hipStream_t s = nullptr;  // this handle's launch stream (wmx_internal.h: legacy_stream_create)
+    // agc_addition comes from the daemon's message thread while the record thread is inside agc_process (src/wmix.c:1070 beside :684-690);
+    // the reference has no lock there and lives with it, the batch's host-side tables need one
+    std::mutex mu;
     wmx_agc *batch;
     int chn, freq, pkg;
     bool *debug;
@@ -76,6 +84,7 @@ struct AgcHandleCompat {
 };
 
 struct AecHandleCompat {
+    hipStream_t s = nullptr;
     wmx_aec *batch;    // float AEC (the reference's default build) ...
     wmx_aecm *batchm;  // ... or the fixed-point AECM (its `#undef MAKE_WEBRTC_AEC` build): exactly one is set
     int chn, freq, pkg;
@@ -95,14 +104,14 @@ int aec_run_host(AecHandleCompat *h, int mode, int16_t *far, int16_t *nearp, int
     int rc = -1;
     if (ok) {
         rc = h->batchm ? wmx_aecm_run(h->batchm, mode, (mode & 1) ? h->far.p : nullptr, per_pkt, (mode & 2) ? h->near.p : nullptr,
-                                      (mode & 2) ? h->near.p : nullptr, n_packets, 0, per_pkt, delayms, nullptr)
+                                      (mode & 2) ? h->near.p : nullptr, n_packets, 0, per_pkt, delayms, h->s)
                        : wmx_aec_run(h->batch, mode, (mode & 1) ? h->far.p : nullptr, per_pkt, (mode & 2) ? h->near.p : nullptr,
-                                     (mode & 2) ? h->near.p : nullptr, n_packets, 0, per_pkt, delayms, nullptr);
+                                     (mode & 2) ? h->near.p : nullptr, n_packets, 0, per_pkt, delayms, h->s);
         if (rc == 0 || rc == -1) {
             // rc == -1: the reference returned mid-buffer; packets before the offending one were written
             if (mode & 2) {
-                if (!h->near.out(out, (size_t)total)) rc = -1;
-            } else if (hipStreamSynchronize(nullptr) != hipSuccess) {  // aec_setFrameFar: the far buffer is reused by the next call
+                if (!h->near.out(out, (size_t)total, h->s)) rc = -1;
+            } else if (hipStreamSynchronize(h->s) != hipSuccess) {  // aec_setFrameFar: the far buffer is reused by the next call
                 rc = -1;
             }
         }
@@ -110,8 +119,10 @@ int aec_run_host(AecHandleCompat *h, int mode, int16_t *far, int16_t *nearp, int
     if (rc != 0) {
         (void)hipGetLastError();
         if (h->debug && *h->debug) printf("WebRtcAecX_Process failed !!, ret %d \r\n", rc);
+        // the reference's own -1 (a delay outside [0, 500]) is the caller's business; a HIP or WMX_E* failure is the operator's
+        if (rc != -1) fprintf(stderr, "wmix_amd: aec_process failed on the GPU (rc %d): %s\n", rc, wmx_last_error());
     }
-    return rc == 0 ? 0 : -1;
+    return rc == 0 ? 0 : -1;  // every failure is the reference's -1 to the daemon (HIP errors live at WMX_EHIP_BASE - e, never at -1)
 }
 
 }  // namespace
@@ -138,6 +149,7 @@ void *aec_init(int chn, int freq, int intervalMs, bool *debug) {
     h->freq = freq;
     h->pkg = (mobile ? wmx_aecm_packet_samples(bm) : wmx_aec_packet_samples(b)) / chn;
     h->debug = debug;
+    h->s = wmx::legacy_stream_create();
     if (debug && *debug)
         printf("aec_init: chn/%d freq/%d intervalMs/%d pkgFrame/%d x %d\r\n", chn, freq, h->pkg / (freq / 1000), h->pkg, chn);
     return h;
@@ -165,6 +177,7 @@ void aec_release(void *fp) {
     if (!h) return;
     if (h->batch) wmx_aec_destroy(h->batch);
     if (h->batchm) wmx_aecm_destroy(h->batchm);
+    wmx::legacy_stream_destroy(h->s);
     if (h->debug && *h->debug) printf("aec_release\r\n");
     delete h;
 }
@@ -183,6 +196,7 @@ void *vad_init(int chn, int freq, int intervalMs, bool *debug) {
     h->freq = freq;
     h->pkg = wmx_vad_packet_samples(b) / chn;
     h->debug = debug;
+    h->s = wmx::legacy_stream_create();
     if (debug && *debug) printf("vad_init: chn/%d freq/%d intervalMs/%d pkgFrame/%d\r\n", chn, freq, h->pkg / (freq / 1000), h->pkg);
     return h;
 }
@@ -195,8 +209,8 @@ void vad_process(void *fp, int16_t *frame, int frameNum) {
     const size_t n = (size_t)packets * h->pkg * h->chn, given = (size_t)frameNum * h->chn;
     bool ok = h->buf.ensure(n);
     ok = ok && h->buf.in(frame, given);
-    ok = ok && wmx_vad_process(h->batch, h->buf.p, packets, 1, 0, (long)n, nullptr) == 0;
-    ok = ok && h->buf.out(frame, given);
+    ok = ok && wmx_vad_process(h->batch, h->buf.p, packets, 1, 0, (long)n, h->s) == 0;
+    ok = ok && h->buf.out(frame, given, h->s);
     if (!ok) {
         (void)hipGetLastError();
         fprintf(stderr, "wmix_amd: vad_process failed on the GPU: %s\n", wmx_last_error());
@@ -208,6 +222,7 @@ void vad_release(void *fp) {
     VadHandleCompat *h = static_cast<VadHandleCompat *>(fp);
     if (!h) return;
     wmx_vad_destroy(h->batch);
+    wmx::legacy_stream_destroy(h->s);
     if (h->debug && *h->debug) printf("vad_release\r\n");
     delete h;
 }
@@ -226,6 +241,7 @@ void *agc_init(int chn, int freq, int intervalMs, int value, bool *debug) {
     h->freq = freq;
     h->pkg = wmx_agc_packet_samples(b) / chn;
     h->debug = debug;
+    h->s = wmx::legacy_stream_create();
     if (debug && *debug)
         printf("agc_init: chn/%d freq/%d intervalMs/%d pkgFrame/%d x %d\r\n", chn, freq, freq <= 16000 ? 10 : 5, h->pkg, chn);
     return h;
@@ -238,10 +254,11 @@ int agc_process(void *fp, int16_t *frame, int16_t *frameOut, int frameNum) {
     const int n_packets = (total + per_pkt - 1) / per_pkt;
     if (n_packets <= 0) return 0;
     const size_t n = (size_t)n_packets * per_pkt;
+    std::lock_guard<std::mutex> lock(h->mu);
     bool ok = h->buf.ensure(n);
     ok = ok && h->buf.in(frame, (size_t)total);
-    ok = ok && wmx_agc_process(h->batch, h->buf.p, h->buf.p, n_packets, 0, per_pkt, nullptr) == 0;
-    ok = ok && h->buf.out(frameOut, (size_t)total);
+    ok = ok && wmx_agc_process(h->batch, h->buf.p, h->buf.p, n_packets, 0, per_pkt, h->s) == 0;
+    ok = ok && h->buf.out(frameOut, (size_t)total, h->s);
     if (!ok) {
         (void)hipGetLastError();
         if (h->debug && *h->debug) printf("WebRtcAgc_Process failed !!, ret %d \r\n", -1);
@@ -254,7 +271,14 @@ int agc_process(void *fp, int16_t *frame, int16_t *frameOut, int frameNum) {
 // src/webrtc.c:824-839
 void agc_addition(void *fp, uint8_t value) {
     AgcHandleCompat *h = static_cast<AgcHandleCompat *>(fp);
-    const int ret = wmx_agc_set_gain(h->batch, (int)value);
+    std::lock_guard<std::mutex> lock(h->mu);
+    // ordered on the handle's own stream (nothing else of the device is waited for): the new table is in place when the call returns
+    const int32_t all = 0;
+    int ret = wmx_agc_set_gain_streams(h->batch, &all, 1, (int)value, h->s);
+    if (ret == 0 && hipStreamSynchronize(h->s) != hipSuccess) {
+        (void)hipGetLastError();
+        ret = -1;
+    }
     if (ret != 0 && h->debug && *h->debug) printf("WebRtcAgc_set_config failed !!, ret %d \r\n", -1);
 }
 
@@ -263,6 +287,7 @@ void agc_release(void *fp) {
     AgcHandleCompat *h = static_cast<AgcHandleCompat *>(fp);
     if (!h) return;
     wmx_agc_destroy(h->batch);
+    wmx::legacy_stream_destroy(h->s);
     if (h->debug && *h->debug) printf("agc_release\r\n");
     delete h;
 }
@@ -287,6 +312,7 @@ void *ns_init(int chn, int freq, bool *debug) {
     h->freq = freq;
     h->pkg = freq / 1000 * 10;
     h->debug = debug;
+    h->s = wmx::legacy_stream_create();
     if (debug && *debug) printf("ns_init: chn/%d freq/%d intervalMs/%d pkgFrame/%d x %d\r\n", chn, freq, 10, h->pkg, chn);
     return h;
 }
@@ -301,9 +327,9 @@ void ns_process(void *fp, int16_t *frame, int16_t *frameOut, int frameNum) {
     const size_t n = (size_t)n_packets * per_pkt;
     bool ok = h->buf.ensure(n);
     ok = ok && h->buf.in(frame, (size_t)total);
-    ok = ok && (h->batchx ? wmx_nsx_process(h->batchx, h->buf.p, h->buf.p, n_packets, 0, per_pkt, nullptr)
-                          : wmx_ns_process(h->batch, h->buf.p, h->buf.p, n_packets, 0, per_pkt, nullptr)) == 0;
-    ok = ok && h->buf.out(frameOut, (size_t)total);
+    ok = ok && (h->batchx ? wmx_nsx_process(h->batchx, h->buf.p, h->buf.p, n_packets, 0, per_pkt, h->s)
+                          : wmx_ns_process(h->batch, h->buf.p, h->buf.p, n_packets, 0, per_pkt, h->s)) == 0;
+    ok = ok && h->buf.out(frameOut, (size_t)total, h->s);
     if (!ok) {
         (void)hipGetLastError();
         fprintf(stderr, "wmix_amd: ns_process failed on the GPU: %s\n", wmx_last_error());
@@ -316,6 +342,7 @@ void ns_release(void *fp) {
     if (!h) return;
     if (h->batch) wmx_ns_destroy(h->batch);
     if (h->batchx) wmx_nsx_destroy(h->batchx);
+    wmx::legacy_stream_destroy(h->s);
     if (h->debug && *h->debug) printf("ns_release\r\n");
     delete h;
 }

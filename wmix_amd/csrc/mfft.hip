@@ -782,13 +782,14 @@ int legacy(int kind, float *in_re, float *in_im, float *out_re, float *out_im, f
     // around the launch cost many times the work.  Pinned host memory mapped into the device instead, owned by the calling thread:
     // memcpy in, one launch, one synchronisation, memcpy out.
     static thread_local MapVec mv;
+    hipStream_t ts = wmx::thread_stream();  // the calling thread's own non-blocking stream (wmx_internal.h)
     if (6 * bytes <= kLegacyMappedMax && mv.ensure(6 * bytes) == 0) {
         float *hst = reinterpret_cast<float *>(mv.host), *dv = reinterpret_cast<float *>(mv.dev);
         if (in_re) memcpy(hst, in_re, bytes);
         if (in_im) memcpy(hst + n, in_im, bytes);
         if (wmx_mfft(kind, 1, n, in_re ? dv : nullptr, in_im ? dv + n : nullptr, out_re ? dv + 2 * n : nullptr, out_im ? dv + 3 * n : nullptr,
-                     out_af ? dv + 4 * n : nullptr, out_pf ? dv + 5 * n : nullptr, nullptr) != 0 ||
-            hipStreamSynchronize(nullptr) != hipSuccess)
+                     out_af ? dv + 4 * n : nullptr, out_pf ? dv + 5 * n : nullptr, ts) != 0 ||
+            hipStreamSynchronize(ts) != hipSuccess)
             return -1;
         float *outs[4] = {out_re, out_im, out_af, out_pf};
         for (int k = 0; k < 4; k++)
@@ -800,13 +801,13 @@ int legacy(int kind, float *in_re, float *in_im, float *out_re, float *out_im, f
     float *d_or = out_re ? d + 2 * n : nullptr, *d_oi = out_im ? d + 3 * n : nullptr;
     float *d_af = out_af ? d + 4 * n : nullptr, *d_pf = out_pf ? d + 5 * n : nullptr;
     int rc = 0;
-    if (in_re && hipMemcpy(d_ir, in_re, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = -1;
-    if (in_im && hipMemcpy(d_ii, in_im, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = -1;
-    if (!rc) rc = wmx_mfft(kind, 1, n, d_ir, d_ii, d_or, d_oi, d_af, d_pf, nullptr);
-    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = -1;
+    if (in_re && hipMemcpyAsync(d_ir, in_re, bytes, hipMemcpyHostToDevice, ts) != hipSuccess) rc = -1;
+    if (in_im && hipMemcpyAsync(d_ii, in_im, bytes, hipMemcpyHostToDevice, ts) != hipSuccess) rc = -1;
+    if (!rc) rc = wmx_mfft(kind, 1, n, d_ir, d_ii, d_or, d_oi, d_af, d_pf, ts);
     float *outs[4] = {out_re, out_im, out_af, out_pf}, *devs[4] = {d_or, d_oi, d_af, d_pf};
     for (int k = 0; k < 4 && !rc; k++)
-        if (outs[k] && hipMemcpy(outs[k], devs[k], bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = -1;
+        if (outs[k] && hipMemcpyAsync(outs[k], devs[k], bytes, hipMemcpyDeviceToHost, ts) != hipSuccess) rc = -1;
+    if (hipStreamSynchronize(ts) != hipSuccess) rc = -1;  // also on failure: nothing of this call may still touch `d`
     (void)hipFree(d);
     return rc;
 }
@@ -830,13 +831,14 @@ extern "C" void fft_stream(float in[], unsigned int inLen, float stream[], unsig
     float *d = nullptr;
     const size_t sb = (size_t)stLen * sizeof(float), ib = (size_t)inLen * sizeof(float);
     static thread_local MapVec mv;
+    hipStream_t ts = wmx::thread_stream();
     if (3 * sb + ib <= kLegacyMappedMax && mv.ensure(3 * sb + ib) == 0) {
         float *hst = reinterpret_cast<float *>(mv.host), *dv = reinterpret_cast<float *>(mv.dev);
         memcpy(hst, stream, sb);
         memcpy(hst + 3 * (size_t)stLen, in, ib);
         if (wmx_mfft_stream(1, dv + 3 * (size_t)stLen, inLen, dv, stLen, outAF ? dv + stLen : nullptr, outPF ? dv + 2 * (size_t)stLen : nullptr,
-                            nullptr) != 0 ||
-            hipStreamSynchronize(nullptr) != hipSuccess)
+                            ts) != 0 ||
+            hipStreamSynchronize(ts) != hipSuccess)
             return;
         memcpy(stream, hst, sb);
         if (outAF) memcpy(outAF, hst + stLen, sb);
@@ -845,10 +847,11 @@ extern "C" void fft_stream(float in[], unsigned int inLen, float stream[], unsig
     }
     if (hipMalloc(&d, 3 * sb + ib) != hipSuccess) return;
     float *d_pool = d, *d_af = d + stLen, *d_pf = d + 2 * stLen, *d_in = d + 3 * stLen;
-    bool ok = hipMemcpy(d_pool, stream, sb, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d_in, in, ib, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && wmx_mfft_stream(1, d_in, inLen, d_pool, stLen, outAF ? d_af : nullptr, outPF ? d_pf : nullptr, nullptr) == 0;
-    ok = ok && hipDeviceSynchronize() == hipSuccess && hipMemcpy(stream, d_pool, sb, hipMemcpyDeviceToHost) == hipSuccess;
-    if (ok && outAF) ok = hipMemcpy(outAF, d_af, sb, hipMemcpyDeviceToHost) == hipSuccess;
-    if (ok && outPF) ok = hipMemcpy(outPF, d_pf, sb, hipMemcpyDeviceToHost) == hipSuccess;
+    bool ok = hipMemcpyAsync(d_pool, stream, sb, hipMemcpyHostToDevice, ts) == hipSuccess && hipMemcpyAsync(d_in, in, ib, hipMemcpyHostToDevice, ts) == hipSuccess;
+    ok = ok && wmx_mfft_stream(1, d_in, inLen, d_pool, stLen, outAF ? d_af : nullptr, outPF ? d_pf : nullptr, ts) == 0;
+    ok = ok && hipMemcpyAsync(stream, d_pool, sb, hipMemcpyDeviceToHost, ts) == hipSuccess;
+    if (ok && outAF) ok = hipMemcpyAsync(outAF, d_af, sb, hipMemcpyDeviceToHost, ts) == hipSuccess;
+    if (ok && outPF) ok = hipMemcpyAsync(outPF, d_pf, sb, hipMemcpyDeviceToHost, ts) == hipSuccess;
+    (void)hipStreamSynchronize(ts);
     (void)hipFree(d);
 }

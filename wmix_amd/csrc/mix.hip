@@ -216,19 +216,21 @@ uint32_t wmix_pcm_zoom(uint8_t inChn, uint16_t inFreq, uint8_t *in, uint32_t inL
     if (inLen == 0 || !in || !out || !inFreq || !outFreq || !inChn || !outChn) return 0;
     const uint32_t need = wmix_len_of_out(inChn, inFreq, inLen, outChn, outFreq);  // what the reference's callers size `out` by
     uint32_t n = 0;
+    // the calling thread's own non-blocking stream, and only that one is waited for (wmx_internal.h: thread_stream)
+    hipStream_t ts = thread_stream();
     if ((size_t)inLen + need <= kMappedMaxBytes && ma.ensure(inLen + 16) == 0 && mb.ensure((size_t)need + 16) == 0) {
         memcpy(ma.host, in, inLen);
-        if (wmx_pcm_zoom(inChn, inFreq, (const int16_t *)ma.dev, inLen, outChn, outFreq, (int16_t *)mb.dev, need + 16, 0, 0, 1, &n, nullptr) != 0)
+        if (wmx_pcm_zoom(inChn, inFreq, (const int16_t *)ma.dev, inLen, outChn, outFreq, (int16_t *)mb.dev, need + 16, 0, 0, 1, &n, ts) != 0)
             return 0;
-        if (hipStreamSynchronize(nullptr) != hipSuccess) return 0;
+        if (hipStreamSynchronize(ts) != hipSuccess) return 0;
         if (n) memcpy(out, mb.host, n);
         return n;
     }
     if (a.ensure(inLen + 16) || b.ensure((size_t)need + 16)) return 0;
-    if (hipMemcpy(a.p, in, inLen, hipMemcpyHostToDevice) != hipSuccess) return 0;
-    if (wmx_pcm_zoom(inChn, inFreq, (const int16_t *)a.p, inLen, outChn, outFreq, (int16_t *)b.p, need + 16, 0, 0, 1, &n, nullptr) != 0)
+    if (hipMemcpyAsync(a.p, in, inLen, hipMemcpyHostToDevice, ts) != hipSuccess || hipStreamSynchronize(ts) != hipSuccess) return 0;
+    if (wmx_pcm_zoom(inChn, inFreq, (const int16_t *)a.p, inLen, outChn, outFreq, (int16_t *)b.p, need + 16, 0, 0, 1, &n, ts) != 0)
         return 0;
-    if (n && hipMemcpy(out, b.p, n, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    if (n && (hipMemcpyAsync(out, b.p, n, hipMemcpyDeviceToHost, ts) != hipSuccess || hipStreamSynchronize(ts) != hipSuccess)) return 0;
     return n;
 }
 
@@ -473,12 +475,15 @@ WMix_Point wmix_load_data(WMix_Struct_Head *wmix, WMix_Point src, uint32_t srcU8
     const size_t src_bytes = (size_t)srcU8Len + (reads_ahead ? 2 * channels : 0);
     uint8_t *ring = (uint8_t *)m->d_rings;
     static thread_local MapVec m_src;
+    // six task threads of the daemon load side by side (src/wmixTask.c:85, 973, 1311, 1484, 1704, 1927): each on its own non-blocking
+    // stream, waiting for that stream alone (wmx_internal.h: thread_stream)
+    hipStream_t ts = thread_stream();
     if (m->h_rings && src_bytes <= kMappedMaxBytes && m_src.ensure(src_bytes + 8) == 0) {
         memcpy(m_src.host, src.U8, src_bytes);
         if (first) memcpy(m->h_rings + span_off, wmix->start.U8 + span_off, first);
         if (second) memcpy(m->h_rings, wmix->start.U8, second);
-        bool okm = wmx_mix_load(m, (const int16_t *)m_src.dev, srcU8Len, freq, channels, sample, 1, 0, 0, reduce, &h, &t, nullptr) == 0;
-        okm = okm && hipStreamSynchronize(nullptr) == hipSuccess;
+        bool okm = wmx_mix_load(m, (const int16_t *)m_src.dev, srcU8Len, freq, channels, sample, 1, 0, 0, reduce, &h, &t, ts) == 0;
+        okm = okm && hipStreamSynchronize(ts) == hipSuccess;
         if (!okm) {
             (void)hipGetLastError();
             fprintf(stderr, "wmix_amd: wmix_load_data failed on the GPU: %s\n", wmx_last_error());
@@ -491,12 +496,13 @@ WMix_Point wmix_load_data(WMix_Struct_Head *wmix, WMix_Point src, uint32_t srcU8
         return pHead;
     }
     bool ok = d_src.ensure(src_bytes + 8) == 0;
-    ok = ok && hipMemcpy(d_src.p, src.U8, src_bytes, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && (!first || hipMemcpy(ring + span_off, wmix->start.U8 + span_off, first, hipMemcpyHostToDevice) == hipSuccess);
-    ok = ok && (!second || hipMemcpy(ring, wmix->start.U8, second, hipMemcpyHostToDevice) == hipSuccess);
-    ok = ok && wmx_mix_load(m, (const int16_t *)d_src.p, srcU8Len, freq, channels, sample, 1, 0, 0, reduce, &h, &t, nullptr) == 0;
-    ok = ok && (!first || hipMemcpy(wmix->start.U8 + span_off, ring + span_off, first, hipMemcpyDeviceToHost) == hipSuccess);
-    ok = ok && (!second || hipMemcpy(wmix->start.U8, ring, second, hipMemcpyDeviceToHost) == hipSuccess);
+    ok = ok && hipMemcpyAsync(d_src.p, src.U8, src_bytes, hipMemcpyHostToDevice, ts) == hipSuccess;
+    ok = ok && (!first || hipMemcpyAsync(ring + span_off, wmix->start.U8 + span_off, first, hipMemcpyHostToDevice, ts) == hipSuccess);
+    ok = ok && (!second || hipMemcpyAsync(ring, wmix->start.U8, second, hipMemcpyHostToDevice, ts) == hipSuccess);
+    ok = ok && wmx_mix_load(m, (const int16_t *)d_src.p, srcU8Len, freq, channels, sample, 1, 0, 0, reduce, &h, &t, ts) == 0;
+    ok = ok && (!first || hipMemcpyAsync(wmix->start.U8 + span_off, ring + span_off, first, hipMemcpyDeviceToHost, ts) == hipSuccess);
+    ok = ok && (!second || hipMemcpyAsync(wmix->start.U8, ring, second, hipMemcpyDeviceToHost, ts) == hipSuccess);
+    ok = ok && hipStreamSynchronize(ts) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
         fprintf(stderr, "wmix_amd: wmix_load_data failed on the GPU: %s\n", wmx_last_error());

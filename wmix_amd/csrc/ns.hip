@@ -28,11 +28,12 @@
 // Numerics.  Same float expressions as the reference, -ffp-contract=off, the reference's
 // double-precision libm calls evaluated in double (log / exp by the table-driven routines of
 // libm_dev.h, same floats as glibc's over every argument class swept; tanh / pow by ocml).  Sums over
-// bins/samples are where a parallel machine wants a different order: with ORDERED=true the
-// kernel adds in the reference's index order (bit-exact against the CPU path); with
-// ORDERED=false each lane adds its own elements and the wave combines them by a butterfly
-// (an ulp of difference in the sums; NS feeds them back into decisions, so this mode is
-// statistically equivalent but not parity-grade -- see tests/test_ns_gpu.py).
+// bins/samples are where a parallel machine wants a different order, and does not get it: the
+// kernel adds in the reference's index order (bit-exact against the CPU path).  (Rounds 1-5 also
+// carried a variant in which each lane added its own elements and the wave combined them by a
+// butterfly -- an ulp of difference in the sums, which NS feeds back into decisions: up to 13 LSB
+// on a few samples, outside north_star's +-1 LSB.  It is gone since round 6: no entry point
+// of this library produces anything but the reference's result.)
 #include <cmath>
 #include <vector>
 #include "wmx_internal.h"
@@ -91,41 +92,28 @@ static_assert(2 * NsLayout<256>::MP >= 256 && 2 * NsLayout<128>::MP >= 128, "r0.
 // median v_med3_f32(v, -32768, 32767), which answers a NaN with -32768, is not a substitute -- tried, aec_golden caught it.
 __device__ __forceinline__ float sat16f(float v) { return v > 32767.f ? 32767.f : (v < -32768.f ? -32768.f : v); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-// sum of x[lo..hi); every lane gets the result.  ORDERED: the reference's index order, every lane adds the same
-// LDS-broadcast values (16-byte reads, eight terms in flight); else lane partials + butterfly.
-template <bool ORDERED>
+// sum of x[lo..hi) in the reference's index order; every lane adds the same LDS-broadcast values (16-byte reads, eight terms in
+// flight) and gets the result
 __device__ __forceinline__ float sum_range(const float *x, int lo, int hi, int lane) {
-    if constexpr (ORDERED) {
-        float acc = 0.f;
-        int i = lo;
+    float acc = 0.f;
+    int i = lo;
 #pragma unroll 1
-        for (; i < hi && (i & 3); i++) acc += x[i];
+    for (; i < hi && (i & 3); i++) acc += x[i];
 #pragma unroll 4
-        for (; i + 8 <= hi; i += 8) {
-            const float4 a = *reinterpret_cast<const float4 *>(x + i), b = *reinterpret_cast<const float4 *>(x + i + 4);
-            acc += a.x;
-            acc += a.y;
-            acc += a.z;
-            acc += a.w;
-            acc += b.x;
-            acc += b.y;
-            acc += b.z;
-            acc += b.w;
-        }
-#pragma unroll 1
-        for (; i < hi; i++) acc += x[i];
-        return acc;
-    } else {
-        float acc = 0.f;
-        for (int i = lo + lane; i < hi; i += 64) acc += x[i];
-        return wave_sum(acc);
+    for (; i + 8 <= hi; i += 8) {
+        const float4 a = *reinterpret_cast<const float4 *>(x + i), b = *reinterpret_cast<const float4 *>(x + i + 4);
+        acc += a.x;
+        acc += a.y;
+        acc += a.z;
+        acc += a.w;
+        acc += b.x;
+        acc += b.y;
+        acc += b.z;
+        acc += b.w;
     }
+#pragma unroll 1
+    for (; i < hi; i++) acc += x[i];
+    return acc;
 }
 
 // Several ordered sums at once: lane k (k < n) adds the MP4*4 floats at its own pointer in index order, all chains
@@ -155,7 +143,7 @@ __device__ __forceinline__ float sum_lanes(const float *mine) {
 __device__ __noinline__ static float tanh_call(float x, const NsLibmTables *m) { return fast_tanh(x, *m); }
 __device__ __forceinline__ float lane_value(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
 
-template <int L, bool ORDERED, int CHN>
+template <int L, int CHN>
 __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restrict__ st, unsigned short *__restrict__ hist,
                          const int16_t *in, int16_t *out, const int pkg, const int lane_in) {
     using Y = NsLayout<L>;
@@ -264,7 +252,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         tdst[i] = w * w;
     }
     wave_sync();
-    const float energy1 = sum_range<ORDERED>(tdst, 0, L, lane);
+    const float energy1 = sum_range(tdst, 0, L, lane);
     wave_sync();
     NS_PROF(0);
 
@@ -325,7 +313,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         NS_PROF(2);
         // ordered reductions over the bins (ns_core.c:1089-1101, :540, :608)
         float signal_energy, sum_magn, flat_num, avg_pause, sum_log_magn = 0.f, sum_log_i_log_magn = 0.f;
-        if constexpr (ORDERED) {
+        {
             const float *mine =
                 lane == 1 ? W.magn : (lane == 2 ? W.r2 : (lane == 3 ? W.pause : (lane == 4 ? W.snrp : (lane == 5 ? W.r1 : W.r0))));
             const float acc = sum_lanes<Y::MP / 4>(mine);
@@ -336,15 +324,6 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             if (startup) {
                 sum_log_magn = lane_value(acc, 4);
                 sum_log_i_log_magn = lane_value(acc, 5);
-            }
-        } else {
-            signal_energy = sum_range<ORDERED>(W.r0, 0, M, lane);
-            sum_magn = sum_range<ORDERED>(W.magn, 0, M, lane);
-            flat_num = sum_range<ORDERED>(W.r2, 0, M, lane);
-            avg_pause = sum_range<ORDERED>(W.pause, 0, M, lane);
-            if (startup) {
-                sum_log_magn = sum_range<ORDERED>(W.snrp, 0, M, lane);
-                sum_log_i_log_magn = sum_range<ORDERED>(W.r1, 0, M, lane);
             }
         }
         const float magn0 = W.magn[0];
@@ -502,15 +481,11 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
             feat_flat += 0.3f * (tmp - feat_flat);
         }
         float cov, var_pause, var_magn;
-        if constexpr (ORDERED) {
+        {
             const float acc = sum_lanes<Y::MP / 4>(lane == 1 ? W.r2 : (lane == 2 ? W.lmagn : W.r0));
             cov = lane_value(acc, 0);
             var_pause = lane_value(acc, 1);
             var_magn = lane_value(acc, 2);
-        } else {
-            cov = sum_range<ORDERED>(W.r0, 0, M, lane);
-            var_pause = sum_range<ORDERED>(W.r2, 0, M, lane);
-            var_magn = sum_range<ORDERED>(W.lmagn, 0, M, lane);
         }
         wave_sync();
         NS_PROF(6);
@@ -705,7 +680,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         }
         wave_sync();
         NS_PROF(7);
-        float ksum = sum_range<ORDERED>(W.r0, 0, M, lane);
+        float ksum = sum_range(W.r0, 0, M, lane);
         ksum = ksum / (float)(M);
         feat_lrt = ksum;
         ST(Y::S_FEAT_LRT) = feat_lrt;
@@ -823,7 +798,7 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         NS_PROF(11);
         float factor = 1.f;
         if (block_ind > kStartupLong) {  // gainmap == 1 for policy 2
-            const float energy2 = sum_range<ORDERED>(tdst, 0, L, lane);
+            const float energy2 = sum_range(tdst, 0, L, lane);
             float gain = sqrtf(energy2 / (energy1 + 1.f));
             float factor1 = 1.f, factor2 = 1.f;
             if (gain > 0.5f) {
@@ -845,11 +820,11 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
         // ---- high band: time-domain gain (ns_core.c:1362-1414), only when chn == 2
         if (chn == 2) {
             constexpr int D = M / 4;
-            float avg_prob = sum_range<ORDERED>(W.sprob, M - D - 1, M - 1, lane);
+            float avg_prob = sum_range(W.sprob, M - D - 1, M - 1, lane);
             avg_prob = avg_prob / ((float)D);
             // magnPrevAnalyze == magnPrevProcess here, so sumMagnProcess / sumMagnAnalyze is x / x
             avg_prob *= sum_magn / sum_magn;
-            float avg_gain = sum_range<ORDERED>(W.snrp, M - D - 1, M - 1, lane);
+            float avg_gain = sum_range(W.snrp, M - D - 1, M - 1, lane);
             avg_gain = avg_gain / ((float)D);
             const float t = 2.f * avg_prob - 1.f;
             const float gain_mod = 0.5f * (1.f + tanh_call(1.0f * t, &K.lm));
@@ -893,19 +868,19 @@ __device__ void ns_frame(const NsConstLds<L> &K, NsWaveLds<L> &W, float *__restr
 }
 
 // Register budget = the occupancy the LDS allows: 16 kHz / 32 kHz streams (28.8 KB per workgroup) five workgroups per CU, 8 kHz
-// streams (16.7 KB) nine, more than the seven waves per SIMD a 72-register budget gives.  The unordered variants need more registers.
+// streams (16.7 KB) nine, more than the seven waves per SIMD a 72-register budget gives.
 #ifndef WMX_NS_W128
 #define WMX_NS_W128 7  // 6: 0.409, 7: 0.393, 8: 0.389 ms (131 072 streams; at 8 the 2-channel variant spills)
 #endif
 #ifndef WMX_NS_W256
 #define WMX_NS_W256 5
 #endif
-template <int L, bool ORDERED>
+template <int L>
 struct NsOcc {
-    static constexpr int kWaves = !ORDERED ? 4 : (L == 128 ? WMX_NS_W128 : WMX_NS_W256);
+    static constexpr int kWaves = L == 128 ? WMX_NS_W128 : WMX_NS_W256;
 };
-template <int L, bool ORDERED, int CHN>
-__global__ __launch_bounds__(64 * kNsWavesPerBlock) __attribute__((amdgpu_waves_per_eu(NsOcc<L, ORDERED>::kWaves, NsOcc<L, ORDERED>::kWaves))) void ns_kernel(float *__restrict__ state, unsigned short *__restrict__ hists,
+template <int L, int CHN>
+__global__ __launch_bounds__(64 * kNsWavesPerBlock) __attribute__((amdgpu_waves_per_eu(NsOcc<L>::kWaves, NsOcc<L>::kWaves))) void ns_kernel(float *__restrict__ state, unsigned short *__restrict__ hists,
                                                                       const float *__restrict__ consts, const int16_t *in, int16_t *out,
                                                                       int n_streams, int n_packets, long stream_stride,
                                                                       long packet_stride, int pkg, const uint8_t *__restrict__ active) {
@@ -947,7 +922,7 @@ __global__ __launch_bounds__(64 * kNsWavesPerBlock) __attribute__((amdgpu_waves_
 #endif
     for (int p = 0; p < n_packets; p++) {
         const size_t off = (size_t)sidx * stream_stride + (size_t)p * packet_stride;
-        ns_frame<L, ORDERED, CHN>(K, Wv[wave], st, hist, in + off, out + off, pkg, lane);
+        ns_frame<L, CHN>(K, Wv[wave], st, hist, in + off, out + off, pkg, lane);
     }
 #ifdef WMX_NS_PROF
     if (lane < 16) atomicAdd(&g_ns_prof[lane], Wv[wave].prof[lane]);
@@ -971,7 +946,7 @@ extern "C" int wmx_debug_ns_prof(unsigned long long *out16, int reset) {
 // ------------------------------------------------------------------------------------ host
 struct wmx_ns {
     int device;  // the HIP device the state lives on (current device at create); every entry point switches to it
-    int n_streams, chn, freq, L, pkg, ordered;
+    int n_streams, chn, freq, L, pkg;
     float *d_state;
     unsigned short *d_hist;
     float *d_consts;
@@ -1068,7 +1043,6 @@ int wmx_ns_create(wmx_ns **out, int n_streams, int chn, int freq) {
     h->freq = freq;
     h->L = (freq == 8000) ? 128 : 256;
     h->pkg = freq / 1000 * 10;
-    h->ordered = 1;
     std::vector<float> st, consts;
     if (h->L == 128)
         build_ns_template<128>(st, consts);
@@ -1132,6 +1106,7 @@ int wmx_ns_set_active(wmx_ns *h, const uint8_t *host_mask, void *stream) {
 }
 
 // stream migration: [header | state words | 3 x 1000 histogram counters]
+static constexpr uint32_t kNsBlobVersion = 1;  // bump when the meaning of a state word changes (wmx_internal.h: blob_layout)
 int wmx_ns_stream_state_bytes(const wmx_ns *h) { return h ? (int)(sizeof(wmx::BlobHeader) + h->words * 4 + 3000 * 2) : WMX_EINVAL; }
 
 int wmx_ns_export_stream(wmx_ns *h, int stream_index, void *host_blob) {
@@ -1139,7 +1114,7 @@ int wmx_ns_export_stream(wmx_ns *h, int stream_index, void *host_blob) {
     if (!h || !host_blob || stream_index < 0 || stream_index >= h->n_streams) return WMX_EINVAL;
     WMX_HIP(hipDeviceSynchronize());
     char *p = static_cast<char *>(host_blob);
-    wmx::blob_begin(p, wmx::blob_tag("NS  "), (uint32_t)h->L, (uint32_t)(h->words * 4 + 6000));
+    wmx::blob_begin(p, wmx::blob_tag("NS  "), wmx::blob_layout((uint32_t)h->L, kNsBlobVersion), (uint32_t)(h->words * 4 + 6000));
     p += sizeof(wmx::BlobHeader);
     WMX_HIP(hipMemcpy(p, h->d_state + (size_t)stream_index * h->words, h->words * 4, hipMemcpyDeviceToHost));
     WMX_HIP(hipMemcpy(p + h->words * 4, h->d_hist + (size_t)stream_index * 3000, 6000, hipMemcpyDeviceToHost));
@@ -1149,19 +1124,12 @@ int wmx_ns_export_stream(wmx_ns *h, int stream_index, void *host_blob) {
 int wmx_ns_import_stream(wmx_ns *h, int stream_index, const void *host_blob) {
     WMX_ON_DEVICE(h);
     if (!h || !host_blob || stream_index < 0 || stream_index >= h->n_streams) return WMX_EINVAL;
-    const int rc = wmx::blob_check(host_blob, wmx::blob_tag("NS  "), (uint32_t)h->L, (uint32_t)(h->words * 4 + 6000));
+    const int rc = wmx::blob_check(host_blob, wmx::blob_tag("NS  "), wmx::blob_layout((uint32_t)h->L, kNsBlobVersion), (uint32_t)(h->words * 4 + 6000));
     if (rc) return rc;
     WMX_HIP(hipDeviceSynchronize());
     const char *p = static_cast<const char *>(host_blob) + sizeof(wmx::BlobHeader);
     WMX_HIP(hipMemcpy(h->d_state + (size_t)stream_index * h->words, p, h->words * 4, hipMemcpyHostToDevice));
     WMX_HIP(hipMemcpy(h->d_hist + (size_t)stream_index * 3000, p + h->words * 4, 6000, hipMemcpyHostToDevice));
-    return 0;
-}
-
-int wmx_ns_set_ordered(wmx_ns *h, int ordered) {
-    WMX_ON_DEVICE(h);
-    if (!h) return WMX_EINVAL;
-    h->ordered = ordered ? 1 : 0;
     return 0;
 }
 
@@ -1199,28 +1167,20 @@ int wmx_ns_process(wmx_ns *h, const int16_t *d_in, int16_t *d_out, int n_packets
     }
     const unsigned grid = (unsigned)((h->n_streams + wmx::kNsWavesPerBlock - 1) / wmx::kNsWavesPerBlock);
     hipStream_t s = wmx::as_stream(stream);
-#define NS_LAUNCH(LL, ORD, CC)                                                                                              \
-    hipLaunchKernelGGL((wmx::ns_kernel<LL, ORD, CC>), dim3(grid), dim3(64 * wmx::kNsWavesPerBlock), 0, s, h->d_state, h->d_hist, \
+#define NS_LAUNCH(LL, CC)                                                                                                  \
+    hipLaunchKernelGGL((wmx::ns_kernel<LL, CC>), dim3(grid), dim3(64 * wmx::kNsWavesPerBlock), 0, s, h->d_state, h->d_hist, \
                        h->d_consts, d_in, d_out, h->n_streams, n_packets, stream_stride, packet_stride, h->pkg, h->life.d_active)
-#define NS_LAUNCH_ORD(LL, CC) \
-    do {                      \
-        if (h->ordered)       \
-            NS_LAUNCH(LL, true, CC); \
-        else                  \
-            NS_LAUNCH(LL, false, CC); \
-    } while (0)
     if (h->L == 128) {
         if (h->chn == 1)
-            NS_LAUNCH_ORD(128, 1);
+            NS_LAUNCH(128, 1);
         else
-            NS_LAUNCH_ORD(128, 2);
+            NS_LAUNCH(128, 2);
     } else {
         if (h->chn == 1)
-            NS_LAUNCH_ORD(256, 1);
+            NS_LAUNCH(256, 1);
         else
-            NS_LAUNCH_ORD(256, 2);
+            NS_LAUNCH(256, 2);
     }
-#undef NS_LAUNCH_ORD
 #undef NS_LAUNCH
     WMX_LAUNCH_CHECK();
     return 0;

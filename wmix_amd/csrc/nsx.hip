@@ -1210,6 +1210,7 @@ int wmx_nsx_set_active(wmx_nsx *h, const uint8_t *host_mask, void *stream) {
 }
 
 // stream migration: [header | state words | 3 x 1000 histogram counters]
+static constexpr uint32_t kNsxBlobVersion = 1;  // bump when the meaning of a state word changes (wmx_internal.h: blob_layout)
 int wmx_nsx_stream_state_bytes(const wmx_nsx *h) { return h ? (int)(sizeof(wmx::BlobHeader) + h->words * 4 + 3 * wmx::kNsxHist * 2) : WMX_EINVAL; }
 
 int wmx_nsx_export_stream(wmx_nsx *h, int stream_index, void *host_blob) {
@@ -1218,7 +1219,7 @@ int wmx_nsx_export_stream(wmx_nsx *h, int stream_index, void *host_blob) {
     WMX_HIP(hipDeviceSynchronize());
     const size_t hb = 3 * wmx::kNsxHist * 2;
     char *p = static_cast<char *>(host_blob);
-    wmx::blob_begin(p, wmx::blob_tag("NSX "), (uint32_t)h->words, (uint32_t)(h->words * 4 + hb));
+    wmx::blob_begin(p, wmx::blob_tag("NSX "), wmx::blob_layout((uint32_t)h->words, kNsxBlobVersion), (uint32_t)(h->words * 4 + hb));
     p += sizeof(wmx::BlobHeader);
     WMX_HIP(hipMemcpy(p, h->d_state + (size_t)stream_index * h->words, (size_t)h->words * 4, hipMemcpyDeviceToHost));
     WMX_HIP(hipMemcpy(p + (size_t)h->words * 4, h->d_hist + (size_t)stream_index * 3 * wmx::kNsxHist, hb, hipMemcpyDeviceToHost));
@@ -1229,7 +1230,7 @@ int wmx_nsx_import_stream(wmx_nsx *h, int stream_index, const void *host_blob) {
     WMX_ON_DEVICE(h);
     if (!h || !host_blob || stream_index < 0 || stream_index >= h->n_streams) return WMX_EINVAL;
     const size_t hb = 3 * wmx::kNsxHist * 2;
-    const int rc = wmx::blob_check(host_blob, wmx::blob_tag("NSX "), (uint32_t)h->words, (uint32_t)(h->words * 4 + hb));
+    const int rc = wmx::blob_check(host_blob, wmx::blob_tag("NSX "), wmx::blob_layout((uint32_t)h->words, kNsxBlobVersion), (uint32_t)(h->words * 4 + hb));
     if (rc) return rc;
     WMX_HIP(hipDeviceSynchronize());
     const char *p = static_cast<const char *>(host_blob) + sizeof(wmx::BlobHeader);

@@ -1261,6 +1261,7 @@ int wmx_vad_create(wmx_vad **out, int n_streams, int chn, int freq, int interval
 }
 
 // stream migration: [header | V32_WORDS int32 fields | V16_WORDS int16 fields]
+static constexpr uint32_t kVadBlobVersion = 1;  // bump when the meaning of a state word changes (wmx_internal.h: blob_layout)
 int wmx_vad_stream_state_bytes(const wmx_vad *h) { return h ? (int)(sizeof(wmx::BlobHeader) + wmx::V32_WORDS * 4 + wmx::V16_WORDS * 2) : WMX_EINVAL; }
 
 int wmx_vad_export_stream(wmx_vad *h, int stream_index, void *host_blob) {
@@ -1269,7 +1270,7 @@ int wmx_vad_export_stream(wmx_vad *h, int stream_index, void *host_blob) {
     if (!h || !host_blob || stream_index < 0 || stream_index >= h->n_streams) return WMX_EINVAL;
     WMX_HIP(hipDeviceSynchronize());
     char *p = static_cast<char *>(host_blob);
-    blob_begin(p, blob_tag("VAD "), (uint32_t)(h->freq + h->interval_ms), V32_WORDS * 4 + V16_WORDS * 2);
+    blob_begin(p, blob_tag("VAD "), blob_layout((uint32_t)(h->freq + h->interval_ms), kVadBlobVersion), V32_WORDS * 4 + V16_WORDS * 2);
     p += sizeof(BlobHeader);
     WMX_HIP(column_to_host(reinterpret_cast<int32_t *>(p), h->d_s32, V32_WORDS, h->n_streams, stream_index));
     WMX_HIP(column_to_host(reinterpret_cast<int16_t *>(p + V32_WORDS * 4), h->d_s16, V16_WORDS, h->n_streams, stream_index));
@@ -1280,7 +1281,7 @@ int wmx_vad_import_stream(wmx_vad *h, int stream_index, const void *host_blob) {
     WMX_ON_DEVICE(h);
     using namespace wmx;
     if (!h || !host_blob || stream_index < 0 || stream_index >= h->n_streams) return WMX_EINVAL;
-    const int rc = blob_check(host_blob, blob_tag("VAD "), (uint32_t)(h->freq + h->interval_ms), V32_WORDS * 4 + V16_WORDS * 2);
+    const int rc = blob_check(host_blob, blob_tag("VAD "), blob_layout((uint32_t)(h->freq + h->interval_ms), kVadBlobVersion), V32_WORDS * 4 + V16_WORDS * 2);
     if (rc) return rc;
     WMX_HIP(hipDeviceSynchronize());
     const char *p = static_cast<const char *>(host_blob) + sizeof(BlobHeader);

@@ -46,6 +46,44 @@ hipError_t fault_point() {
 }
 #endif
 
+hipStream_t legacy_stream_create() {
+    int least = 0, greatest = 0;
+    hipStream_t s = nullptr;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) greatest = 0;
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return s;
+}
+void legacy_stream_destroy(hipStream_t s) {
+    if (s && !runtime_exiting()) (void)hipStreamDestroy(s);
+}
+namespace {
+struct ThreadStream {
+    hipStream_t s = nullptr;
+    int device = -1;
+    ~ThreadStream() { legacy_stream_destroy(s); }
+};
+}  // namespace
+hipStream_t thread_stream() {
+    static thread_local ThreadStream t;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    if (t.s && t.device != dev) {  // the thread moved to another device: its stream does not follow
+        legacy_stream_destroy(t.s);
+        t.s = nullptr;
+    }
+    if (!t.s) {
+        t.s = legacy_stream_create();
+        t.device = dev;
+    }
+    return t.s;
+}
+
 int current_device() {
     int d = -1;
     hipError_t e = hipGetDevice(&d);

@@ -237,6 +237,12 @@ struct BlobHeader {
     uint32_t bytes;    // payload bytes behind the header
 };
 constexpr uint32_t kBlobMagic = 0x53584d57u;
+// The FORMAT VERSION of a module's blob rides in the top byte of `layout` (rates and word counts stay far below 2^24).  A module bumps
+// its version whenever the MEANING of a state word changes, even if tag, layout and size do not: round 5 turned the AEC's block count
+// (AS_NBLK) into the comfort-noise generator's state (AS_NSEED) in place, and a blob exported by the build before would have been
+// accepted and replayed with the old block count as the seed (round-5 ADVICE, medium).  Blobs of rounds 1-5 carry version 0 and are
+// refused with WMX_ESTATE.
+inline uint32_t blob_layout(uint32_t layout, uint32_t version) { return (layout & 0x00ffffffu) | (version << 24); }
 inline uint32_t blob_tag(const char (&t)[5]) { return (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24); }
 inline void blob_begin(void *blob, uint32_t module, uint32_t layout, uint32_t bytes) {
     BlobHeader hd{kBlobMagic, module, layout, bytes};
@@ -247,8 +253,12 @@ inline int blob_check(const void *blob, uint32_t module, uint32_t layout, uint32
     BlobHeader hd;
     memcpy(&hd, blob, sizeof(hd));
     if (hd.magic != kBlobMagic || hd.module != module || hd.layout != layout || hd.bytes != bytes) {
-        set_error("import: the blob is not a state of this module / format (module %08x layout %u bytes %u, expected %08x %u %u)", hd.module,
-                  hd.layout, hd.bytes, module, layout, bytes);
+        if (hd.magic == kBlobMagic && hd.module == module && (hd.layout >> 24) != (layout >> 24))
+            set_error("import: the blob is format version %u of this module, this library reads version %u (the meaning of a state word "
+                      "changed in between: re-export from a stream of this build)", hd.layout >> 24, layout >> 24);
+        else
+            set_error("import: the blob is not a state of this module / format (module %08x layout %u bytes %u, expected %08x %u %u)", hd.module,
+                      hd.layout & 0x00ffffffu, hd.bytes, module, layout & 0x00ffffffu, bytes);
         return WMX_ESTATE;
     }
     return 0;
@@ -295,6 +305,18 @@ struct MapVec {
         if (host && !runtime_exiting()) (void)hipHostFree(host);
     }
 };
+
+// The legacy adapters' launch streams (round-5 VERDICT weak 4).  The reference calls its per-handle functions from many threads at once --
+// wmix_load_data from six task threads, agc_addition from the message thread, the four-call heartbeat from the record thread (SURVEY 8b
+// "Threading"; src/wmixTask.c:85, 973, 1311, 1484, 1704, 1927; src/wmix.c:1070) -- and rounds 1-5 put every one of those launches on the
+// legacy NULL stream and waited with hipStreamSynchronize(NULL): each caller waited for all the others' launches, and a batch running
+// on a blocking stream of the same process stalled them all (and was stalled by them).  Now: one NON-BLOCKING stream per compat handle
+// (legacy_stream_create; the handle's calls are ordered among themselves whatever thread makes them) and one per THREAD for the
+// stateless adapters (thread_stream: G.711, wmix_pcm_zoom, wmix_load_data, math/fft.c), at the device's highest priority -- a legacy call
+// is a few hundred samples somebody waits for.  nullptr (the NULL stream, the old behaviour) only if the runtime refuses a stream.
+hipStream_t legacy_stream_create();
+void legacy_stream_destroy(hipStream_t s);
+hipStream_t thread_stream();
 
 // chain.hip -> aec.hip: let the far kernel of the next wmx_aec_run_* call start at this point of `stream` (see aec.hip)
 int aec_fork_far(wmx_aec *h, hipStream_t stream);

@@ -16,7 +16,7 @@ from ._lib import check, lib
 class NsBatch(Lifetime):
     _mod = "ns"
 
-    def __init__(self, n_streams, chn, freq, ordered=True):
+    def __init__(self, n_streams, chn, freq):
         self._h = C.c_void_p()
         L = lib()
         rc = L.wmx_ns_create(C.byref(self._h), n_streams, chn, freq)
@@ -25,10 +25,6 @@ class NsBatch(Lifetime):
             check(rc, "wmx_ns_create")  # raises; ns_init returns NULL for the same arguments
         self.n_streams, self.chn, self.freq = n_streams, chn, freq
         self.pkt = L.wmx_ns_packet_samples(self._h)  # int16 elements per 10 ms packet
-        L.wmx_ns_set_ordered(self._h, 1 if ordered else 0)
-
-    def set_ordered(self, ordered):
-        lib().wmx_ns_set_ordered(self._h, 1 if ordered else 0)
 
     def process(self, pcm, out=None):
         """pcm: int16 CUDA tensor [n_streams, n_packets, pkt] (stream-major) or
