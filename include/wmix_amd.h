@@ -320,6 +320,13 @@ int wmx_chain_process_groups(wmx_chain *h, const int16_t *d_far, long far_packet
                              int16_t *d_out, int n10, long stream_stride, long packet_stride, const int32_t *delay_ms,
                              const uint8_t *cohort_on, int32_t *cohort_rc, void *stream);
 int wmx_chain_destroy(wmx_chain *h);
+/* webrtcEnable[] at run time (the daemon's message thread sets the switches, src/wmix.c:1010-1050): a stage whose bit drops is released
+ * (src/wmix.c:783-813), one whose bit comes on is made anew -- fresh state for every stream, the cohorts the chain was created with,
+ * agc_value as agc_init's value (< 0: the chain's own) -- stages that stay on keep their state.  stages = 0 is a heartbeat with every
+ * switch off (the package passes through; such a chain works in place).  wmx_chain_create takes stages = 0 too.  A control-plane call:
+ * the device is drained when a stage goes. */
+int wmx_chain_set_stages(wmx_chain *h, unsigned stages, int agc_value);
+unsigned wmx_chain_stages(const wmx_chain *h);
 int wmx_chain_process(wmx_chain *h, const int16_t *d_far, long far_packet_stride, const int16_t *d_in, int16_t *d_out, int n10,
                       long stream_stride, long packet_stride, const int32_t *delay_ms, const uint8_t *cohort_on,
                       int32_t *cohort_rc, void *stream);
@@ -574,6 +581,10 @@ typedef struct wmx_tick wmx_tick;
 int wmx_tick_create(wmx_tick **out, int n_groups, int rec_per_group, int chn, int freq, int interval_ms, int aec_delay_ms, int agc_value,
                     unsigned stages);
 int wmx_tick_destroy(wmx_tick *h);
+/* the heartbeat's switches at run time (wmx_chain_set_stages on the tick's chain): the reference SHIPS with NS = 1, AGC = 1, VAD = 0,
+ * AEC = 0 (src/wmix.c:1580-1584) and its message thread turns them (:1010-1050); a canceller that comes on hears one far-end per mix
+ * group; 0 = a pure mix / FIFO / zoom tick */
+int wmx_tick_set_stages(wmx_tick *h, unsigned stages, int agc_value);
 /* webrtcEnable[WR_NS_PA] (src/wmix.c:1370-1386): on = 1 puts ns_process over the played package, in front of playPkgBuff_add (ns_init of
  * one suppressor per group now); on = 0 releases it */
 int wmx_tick_play_ns(wmx_tick *h, int on);

@@ -26,10 +26,16 @@ def check_float_path(got, want, max_fraction=None):
     operation order but rounded a double-precision pow() where the reference calls the host's powf, which is not correctly rounded
     (measured then: 4 - 9 isolated samples of 2e7).  The product now evaluates glibc's powf algorithm itself
     (wmix_amd/csrc/libm_dev.h, tests/test_libm_tables.py::test_pow_sweep), and the float path is held to the same bar as the
-    integer ones.  `max_fraction` is what callers used to pass; it no longer loosens anything."""
+    integer ones.  `max_fraction` is what callers used to pass; it no longer loosens anything -- except on a host whose own powf is
+    another function than the one the device restates (conftest.host_powf_is_the_products: the parity claim is tied to the reference's
+    libm, not to the test host's), where the bar is the old one: <= 1 LSB on a 2e-5 fraction of samples."""
+    from conftest import host_powf_is_the_products
     d = got.astype(np.int32) - want.astype(np.int32)
     n_diff = int((d != 0).sum())
-    assert n_diff == 0, "%d of %d samples differ, max |d| = %d LSB" % (n_diff, d.size, np.abs(d).max())
+    if host_powf_is_the_products():
+        assert n_diff == 0, "%d of %d samples differ, max |d| = %d LSB" % (n_diff, d.size, np.abs(d).max())
+    else:
+        assert np.abs(d).max() <= 1 and n_diff <= max(4, 2e-5 * d.size), "%d of %d samples differ, max |d| = %d LSB" % (n_diff, d.size, np.abs(d).max())
 
 
 def gpu_aec(cuda, chn, freq, ims, delay, far, near_streams, pkts_per_launch=23, packet_major=False):

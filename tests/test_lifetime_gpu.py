@@ -470,3 +470,88 @@ def test_a_blob_of_an_older_format_is_refused(cuda):
                 else:
                     b.import_cohort(0, old)
         b.close()
+
+
+def test_the_heartbeats_switches_at_run_time(cuda, oracle_port):
+    """webrtcEnable[] (round-5 ADVICE): the reference ships with NS = 1, AGC = 1, VAD = 0, AEC = 0 (src/wmix.c:1580-1584) and its
+    message thread turns the switches while the heartbeat runs (:1010-1050) -- a stage that goes is released (:783-813), one that
+    comes on is made inside the next heartbeat (:617-618, 635-636, 683-684, 702-703).  wmx_chain_set_stages / wmx_tick_set_stages:
+    the daemon's default, then everything on, then the AGC alone, then nothing, then everything again -- every stage's stretch
+    of life against a handle of the oracle made at the tick the switch came on."""
+    import torch
+    from wmix_amd.chain import AEC, AGC, NS, VAD, ChainBatch
+    freq, pkt, S = 16000, 160, 5
+    plan = [(NS | AGC, 60), (NS | AEC | AGC | VAD, 90), (AGC, 40), (0, 20), (NS | AEC | AGC | VAD, 80)]
+    T = sum(n for _, n in plan)
+    far = synth.far_end(9900, T, pkt).reshape(T, pkt)
+    near = synth.near_end(9901, S, T, pkt, far=far.reshape(-1)).reshape(S, T, pkt)
+    ch = ChainBatch(S, 1, freq, 10, 5, stages=plan[0][0])
+    d = torch.from_numpy(near.copy()).to(cuda)
+    dfar = torch.from_numpy(far).to(cuda)
+    t = 0
+    for stages, n in plan:
+        if t:
+            ch.set_stages(stages, agc_value=7 if stages == AGC else -1)  # (an AGC that stays on keeps its state AND its gain)
+            assert lib_stages(ch) == stages
+        for _ in range(n):
+            rc, _, _ = ch.process(dfar[t:t + 1], d[:, t:t + 1])
+            assert rc == 0
+            t += 1
+    got = d.cpu().numpy()
+    ch.close()
+    # the oracle, stage by stage: a handle lives over the consecutive segments in which its switch is on
+    bounds = np.cumsum([0] + [n for _, n in plan])
+
+    def lives(bit):
+        out, start = [], None
+        for i, (st, _) in enumerate(plan):
+            if st & bit and start is None:
+                start = bounds[i]
+            if not (st & bit) and start is not None:
+                out.append((start, bounds[i]))
+                start = None
+        if start is not None:
+            out.append((start, bounds[-1]))
+        return out
+    for s in range(S):
+        y = near[s].copy()  # [T, pkt]
+        for a, b in lives(NS):
+            y[a:b] = L.run_ns(oracle_port, 1, freq, y[a:b].reshape(-1), pkt, prefix="orc").reshape(-1, pkt)
+        for a, b in lives(AEC):
+            y[a:b] = L.run_aec(oracle_port, 1, freq, 10, far[a:b].reshape(-1), y[a:b].reshape(-1), pkt, prefix="orc").reshape(-1, pkt)
+        for i, (a, b) in enumerate(lives(AGC)):  # the second AGC is made with the volumeAgc handed over while the first was alive: 7
+            y[a:b] = L.run_agc(oracle_port, 1, freq, 5 if i == 0 else 7, y[a:b].reshape(-1), pkt, prefix="orc").reshape(-1, pkt)
+        for a, b in lives(VAD):
+            y[a:b] = L.run_vad(oracle_port, 1, freq, 10, y[a:b].reshape(-1), pkt, prefix="orc").reshape(-1, pkt)
+        assert np.array_equal(got[s], y), (s, int(np.argmax((got[s] != y).any(axis=1))))
+
+
+def lib_stages(ch):
+    from wmix_amd._lib import lib
+    return lib().wmx_chain_stages(ch._h)
+
+
+def test_tick_switches(cuda):
+    """the same through the daemon's tick, and the tick without any stage (mix / FIFO / zoom only)"""
+    import torch
+    from wmix_amd._lib import lib
+    from wmix_amd.chain import AEC, AGC, NS, VAD
+    from wmix_amd.tick import TickBatch
+    assert TickBatch.SHIPPED_STAGES == NS | AGC
+    tb = TickBatch(3, 2, stages=TickBatch.SHIPPED_STAGES)
+    ch = lib().wmx_tick_chain(tb._h)
+    assert lib().wmx_chain_stages(ch) == NS | AGC and lib().wmx_chain_cohorts(ch) == 1
+    tb.set_stages(NS | AEC | AGC | VAD, agc_value=9)
+    assert lib().wmx_chain_stages(ch) == 15 and lib().wmx_chain_cohorts(ch) == 3  # the canceller hears one far-end per mix group
+    rec = torch.zeros(6, tb.pkg, dtype=torch.int16, device=cuda)
+    tb.play()
+    tb.record(rec)
+    tb.set_stages(0)
+    assert lib().wmx_chain_stages(ch) == 0
+    rec[:] = 1234
+    tb.play()
+    tb.record(rec)
+    assert bool((rec == 1234).all())  # every switch off: the package passes through
+    tb.close()
+    tb0 = TickBatch(2, 1, stages=0)  # a tick may be MADE without stages too
+    tb0.close()

@@ -20,6 +20,71 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+class DeviceWatch:
+    """The device's shader clock, power and temperature every 2 s while host_paced runs (sysfs of this process's GPU; whatever cannot
+    be read is left out): a long paced run is also a statement about what the power management does to a device at 80 - 98 % duty."""
+
+    def __init__(self):
+        import glob
+        import threading
+        import torch
+        self.rows, self._stop = [], threading.Event()
+        try:
+            p = torch.cuda.get_device_properties(0)
+            base = "/sys/bus/pci/devices/%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        except Exception:
+            base = None
+        self.sclk = base and os.path.join(base, "pp_dpm_sclk")
+        hw = glob.glob(os.path.join(base, "hwmon", "hwmon*")) if base else []
+        self.power = hw and os.path.join(hw[0], "power1_average")
+        self.temp = hw and os.path.join(hw[0], "temp1_input")
+        self.t0 = None
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def _read(path):
+        try:
+            return open(path).read()
+        except (OSError, TypeError):
+            return None
+
+    def _run(self):
+        import time
+        self.t0 = time.time()
+        while not self._stop.wait(2.0):
+            row = [round(time.time() - self.t0, 1), None, None, None]
+            txt = self._read(self.sclk)
+            if txt:
+                for line in txt.splitlines():
+                    if line.rstrip().endswith("*"):
+                        try:
+                            row[1] = int(line.split(":")[1].strip().rstrip("*").strip().lower().replace("mhz", ""))
+                        except ValueError:
+                            pass
+            v = self._read(self.power)
+            row[2] = round(int(v) / 1e6, 1) if v and v.strip().isdigit() else None
+            v = self._read(self.temp)
+            row[3] = round(int(v) / 1e3, 1) if v and v.strip().isdigit() else None
+            self.rows.append(row)
+
+    def start(self):
+        self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        self._thread.join(timeout=5)
+        out = {}
+        for i, name in ((1, "sclk_mhz"), (2, "power_w"), (3, "temp_c")):
+            v = [r[i] for r in self.rows if r[i] is not None]
+            if v:
+                out[name] = {"min": min(v), "median": float(np.median(v)), "max": max(v), "first_minute_median": float(np.median(v[:30])),
+                             "last_minute_median": float(np.median(v[-30:]))}
+        step = max(1, len(self.rows) // 60)
+        out["series_t_sclk_power_temp"] = self.rows[::step]
+        return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", required=True)
@@ -52,7 +117,9 @@ def main():
         cmd = [host, "--streams", str(S), "--sub", str(a.sub), "--slots", str(a.slots), "--tick-ms", str(a.tick_ms), "--ticks", str(a.ticks), "--prime",
                str(a.prime), "--kind", form, "--freq", str(freq), "--interval-ms", str(interval_ms), "--phases", str(a.phases), "--pattern", pat,
                "--n-pattern", str(n_pat), "--dump", dump, "--keep", str(a.keep), "--sample", ",".join(map(str, sample)), "--lat", lat]
+        watch = DeviceWatch().start()
         r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)  # stderr passes through: a long run reports twice a minute
+        device = watch.stop()
         if r.returncode != 0:
             sys.exit(1)
         d = json.loads(r.stdout.strip().splitlines()[-1])
@@ -68,6 +135,7 @@ def main():
                                      for i, c in enumerate(np.histogram(lat_ms, edges)[0]) if c}
         d["parity_checked"] = {"streams": len(sample), "ticks_compared": a.keep, "ticks_replayed": T, "max_lsb": worst,
                                "oracle": "oracle/orc_*.c chain (port): every tick of the run replayed per sampled stream"}
+        d["device"] = device
         d["stream_frames_per_s_sustained"] = S * (interval_ms // 10) / (a.tick_ms * 1e-3)
         line = json.dumps(d)
         print(line)

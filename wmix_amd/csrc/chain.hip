@@ -26,6 +26,9 @@ struct wmx_chain {
     int n_cohorts;
     bool no_fork;                    // WMIX_AMD_CHAIN_NO_FORK, read once at create (developer A/B switch)
     std::vector<int32_t> zero_delays;  // what the daemon reports (delayms = 0), one per cohort, for callers that pass NULL
+    // what a stage that is switched on later is made with (wmx_chain_set_stages): the arguments of wmx_chain_create_groups
+    int agc_value, n_cohorts_made;
+    std::vector<int32_t> stream_cohort_made;
     hipEvent_t gate_after_ns = nullptr;  // recorded behind the noise suppressor's launch by the next process call (wmx::chain_gate_after_ns)
 };
 
@@ -35,6 +38,16 @@ namespace wmx {
 // bound by arithmetic -- a device-to-host copy (a blit kernel of posted PCIe writes) belongs beside the latter.
 void chain_gate_after_ns(wmx_chain *h, hipEvent_t ev) {
     if (h) h->gate_after_ns = ev;
+}
+// For the daemon's tick (tick.hip): the cohorts an echo canceller is made with when wmx_chain_set_stages switches one on LATER -- a
+// tick made without a canceller has a chain of one cohort, but its groups' far-ends are there from the start.
+void chain_cohorts_when_made(wmx_chain *h, int n_cohorts, const int32_t *stream_cohort) {
+    if (!h) return;
+    h->n_cohorts_made = n_cohorts;
+    if (stream_cohort)
+        h->stream_cohort_made.assign(stream_cohort, stream_cohort + h->n_streams);
+    else
+        h->stream_cohort_made.clear();
 }
 }  // namespace wmx
 
@@ -53,6 +66,85 @@ int wmx_chain_destroy(wmx_chain *h) {
     return 0;
 }
 
+}  // extern "C"
+
+// Makes the stage handles that `stages` asks for and the chain does not have, in the heartbeat's order -- the same *_init calls; an
+// unsupported format fails the way the reference's *_init returns NULL (the reference picks WebRtcNsx_* / WebRtcAecm_* by build
+// switches, src/webrtc.c:512-521, 168-191: here two stage bits).  A handle that exists is left alone.
+static int chain_make_stages(wmx_chain *h, unsigned stages) {
+    const int n_streams = h->n_streams, chn = h->chn, freq = h->freq, interval_ms = h->interval_ms, n_cohorts = h->n_cohorts_made;
+    const int32_t *stream_cohort = h->stream_cohort_made.empty() ? nullptr : h->stream_cohort_made.data();
+    int rc = 0;
+    if (rc == 0 && (stages & WMX_CHAIN_NS) && !h->ns && !h->nsx)
+        rc = (stages & WMX_CHAIN_NSX) ? wmx_nsx_create(&h->nsx, n_streams, chn, freq) : wmx_ns_create(&h->ns, n_streams, chn, freq);
+    if (rc == 0 && (stages & WMX_CHAIN_AEC) && !h->aec && !h->aecm) {
+        rc = (stages & WMX_CHAIN_AECM) ? wmx_aecm_create_cohorts(&h->aecm, n_streams, chn, freq, interval_ms, n_cohorts)
+                                       : wmx_aec_create_groups(&h->aec, n_streams, chn, freq, interval_ms, n_cohorts, stream_cohort);
+        if (rc == 0 && h->aecm && stream_cohort && n_cohorts > 1) {
+            // the fixed-point canceller takes memberships through its reset call: one call per cohort that has members
+            std::vector<std::vector<int32_t>> members((size_t)n_cohorts);
+            for (int s = 0; s < n_streams && rc == 0; s++) {
+                if (stream_cohort[s] < 0 || stream_cohort[s] >= n_cohorts) {
+                    wmx::set_error("wmx_chain_create_groups: stream %d in cohort %d of %d", s, stream_cohort[s], n_cohorts);
+                    rc = WMX_EINVAL;
+                } else {
+                    members[(size_t)stream_cohort[s]].push_back(s);
+                }
+            }
+            for (int c = 1; c < n_cohorts && rc == 0; c++)
+                if (!members[(size_t)c].empty())
+                    rc = wmx_aecm_reset_streams(h->aecm, members[(size_t)c].data(), (int)members[(size_t)c].size(), c, nullptr);
+            if (rc == 0 && hipDeviceSynchronize() != hipSuccess) rc = WMX_ENODEV;
+        }
+        if (rc == 0) {
+            h->n_cohorts = n_cohorts;
+            h->zero_delays.assign((size_t)n_cohorts, 0);
+        }
+    }
+    if (rc == 0 && (stages & WMX_CHAIN_AGC) && !h->agc) rc = wmx_agc_create(&h->agc, n_streams, chn, freq, interval_ms, h->agc_value);
+    if (rc == 0 && (stages & WMX_CHAIN_VAD) && !h->vad) rc = wmx_vad_create(&h->vad, n_streams, chn, freq, interval_ms);
+    if (rc != 0) return rc;
+    h->stages = stages;
+    h->aec_pkg = h->aec ? wmx_aec_packet_samples(h->aec) : (h->aecm ? wmx_aecm_packet_samples(h->aecm) : h->pkg10);
+    h->agc_pkg = h->agc ? wmx_agc_packet_samples(h->agc) : h->pkg10;
+    h->vad_pkg = h->vad ? wmx_vad_packet_samples(h->vad) : h->pkg10;
+    return 0;
+}
+
+extern "C" {
+
+// The heartbeat's switches at run time (webrtcEnable[], set by the daemon's message thread, src/wmix.c:1010-1050): a stage whose
+// switch drops is RELEASED (src/wmix.c:783-813: *_release, the pointer zeroed) and one that comes on is made anew inside the next
+// heartbeat (:617-618, 635-636, 683-684, 702-703: *_init on first use) -- fresh state for every stream, the cohorts the chain was
+// created with, agc_value as agc_init's value (the daemon passes the volumeAgc of that moment, :684; < 0: the value the chain was
+// made with).  Stages that stay on keep their state.  A control-plane call: the device is drained when a stage goes.
+int wmx_chain_set_stages(wmx_chain *h, unsigned stages, int agc_value) {
+    WMX_ON_DEVICE(h);
+    if (!h || (stages & ~63u) != 0 || ((stages & WMX_CHAIN_NSX) && !(stages & WMX_CHAIN_NS)) || ((stages & WMX_CHAIN_AECM) && !(stages & WMX_CHAIN_AEC))) {
+        wmx::set_error("wmx_chain_set_stages: stages=0x%x", stages);
+        return WMX_EINVAL;
+    }
+    if (agc_value >= 0) h->agc_value = agc_value;
+    // what goes: a stage switched off, or kept on in its OTHER build (float <-> fixed point)
+    const bool ns_goes = h->ns && (!(stages & WMX_CHAIN_NS) || (stages & WMX_CHAIN_NSX));
+    const bool nsx_goes = h->nsx && (!(stages & WMX_CHAIN_NS) || !(stages & WMX_CHAIN_NSX));
+    const bool aec_goes = h->aec && (!(stages & WMX_CHAIN_AEC) || (stages & WMX_CHAIN_AECM));
+    const bool aecm_goes = h->aecm && (!(stages & WMX_CHAIN_AEC) || !(stages & WMX_CHAIN_AECM));
+    if (ns_goes) wmx_ns_destroy(h->ns), h->ns = nullptr;
+    if (nsx_goes) wmx_nsx_destroy(h->nsx), h->nsx = nullptr;
+    if (aec_goes) wmx_aec_destroy(h->aec), h->aec = nullptr;
+    if (aecm_goes) wmx_aecm_destroy(h->aecm), h->aecm = nullptr;
+    if (h->agc && !(stages & WMX_CHAIN_AGC)) wmx_agc_destroy(h->agc), h->agc = nullptr;
+    if (h->vad && !(stages & WMX_CHAIN_VAD)) wmx_vad_destroy(h->vad), h->vad = nullptr;
+    if (!h->aec && !h->aecm) {  // without a canceller a chain has one cohort
+        h->n_cohorts = 1;
+        h->zero_delays.assign(1, 0);
+    }
+    h->gate_after_ns = nullptr;
+    return chain_make_stages(h, stages);
+}
+unsigned wmx_chain_stages(const wmx_chain *h) { return h ? h->stages : 0u; }
+
 int wmx_chain_create(wmx_chain **out, int n_streams, int chn, int freq, int interval_ms, int agc_value, unsigned stages, int n_cohorts) {
     return wmx_chain_create_groups(out, n_streams, chn, freq, interval_ms, agc_value, stages, n_cohorts, nullptr);
 }
@@ -63,7 +155,8 @@ int wmx_chain_create_groups(wmx_chain **out, int n_streams, int chn, int freq, i
                             const int32_t *stream_cohort) {
     if (!out) return WMX_EINVAL;
     *out = nullptr;
-    if ((stages & 15u) == 0 || (stages & ~63u) != 0 || n_cohorts < 1 || ((stages & WMX_CHAIN_NSX) && !(stages & WMX_CHAIN_NS)) ||
+    // (no stage at all is a heartbeat with every webrtcEnable[] switch off: the package passes through untouched, src/wmix.c:613-709)
+    if ((stages & ~63u) != 0 || n_cohorts < 1 || ((stages & WMX_CHAIN_NSX) && !(stages & WMX_CHAIN_NS)) ||
         ((stages & WMX_CHAIN_AECM) && !(stages & WMX_CHAIN_AEC))) {
         wmx::set_error("wmx_chain_create: stages=0x%x n_cohorts=%d", stages, n_cohorts);
         return WMX_EINVAL;
@@ -82,38 +175,14 @@ int wmx_chain_create_groups(wmx_chain **out, int n_streams, int chn, int freq, i
     h->pkg10 = freq / 100 * chn;
     h->no_fork = getenv("WMIX_AMD_CHAIN_NO_FORK") != nullptr;
     h->zero_delays.assign((size_t)n_cohorts, 0);
-    int rc = 0;
-    // the same *_init calls, in the heartbeat's order; an unsupported format fails the way the reference's *_init returns NULL
-    // (the reference picks WebRtcNsx_* / WebRtcAecm_* by build switches, src/webrtc.c:512-521, 168-191: here two stage bits)
-    if (rc == 0 && (stages & WMX_CHAIN_NS))
-        rc = (stages & WMX_CHAIN_NSX) ? wmx_nsx_create(&h->nsx, n_streams, chn, freq) : wmx_ns_create(&h->ns, n_streams, chn, freq);
-    if (rc == 0 && (stages & WMX_CHAIN_AEC))
-        rc = (stages & WMX_CHAIN_AECM) ? wmx_aecm_create_cohorts(&h->aecm, n_streams, chn, freq, interval_ms, n_cohorts)
-                                       : wmx_aec_create_groups(&h->aec, n_streams, chn, freq, interval_ms, n_cohorts, stream_cohort);
-    if (rc == 0 && h->aecm && stream_cohort && n_cohorts > 1) {
-        // the fixed-point canceller takes memberships through its reset call: one call per cohort that has members (create time only)
-        std::vector<std::vector<int32_t>> members((size_t)n_cohorts);
-        for (int s = 0; s < n_streams && rc == 0; s++) {
-            if (stream_cohort[s] < 0 || stream_cohort[s] >= n_cohorts) {
-                wmx::set_error("wmx_chain_create_groups: stream %d in cohort %d of %d", s, stream_cohort[s], n_cohorts);
-                rc = WMX_EINVAL;
-            } else {
-                members[(size_t)stream_cohort[s]].push_back(s);
-            }
-        }
-        for (int c = 1; c < n_cohorts && rc == 0; c++)
-            if (!members[(size_t)c].empty()) rc = wmx_aecm_reset_streams(h->aecm, members[(size_t)c].data(), (int)members[(size_t)c].size(), c, nullptr);
-        if (rc == 0 && hipDeviceSynchronize() != hipSuccess) rc = WMX_ENODEV;
-    }
-    if (rc == 0 && (stages & WMX_CHAIN_AGC)) rc = wmx_agc_create(&h->agc, n_streams, chn, freq, interval_ms, agc_value);
-    if (rc == 0 && (stages & WMX_CHAIN_VAD)) rc = wmx_vad_create(&h->vad, n_streams, chn, freq, interval_ms);
+    h->agc_value = agc_value;
+    h->n_cohorts_made = n_cohorts;
+    if (stream_cohort) h->stream_cohort_made.assign(stream_cohort, stream_cohort + n_streams);
+    const int rc = chain_make_stages(h, stages);
     if (rc != 0) {
         wmx_chain_destroy(h);
         return rc;
     }
-    h->aec_pkg = h->aec ? wmx_aec_packet_samples(h->aec) : (h->aecm ? wmx_aecm_packet_samples(h->aecm) : h->pkg10);
-    h->agc_pkg = h->agc ? wmx_agc_packet_samples(h->agc) : h->pkg10;
-    h->vad_pkg = h->vad ? wmx_vad_packet_samples(h->vad) : h->pkg10;
     *out = h;
     return 0;
 }
@@ -152,6 +221,11 @@ int wmx_chain_process_groups(wmx_chain *h, const int16_t *d_far, long far_packet
     if (n10 == 0) return 0;
     if (!d_in || !d_out || ((h->stages & WMX_CHAIN_AEC) && !d_far)) {
         wmx::set_error("wmx_chain_process: null buffer");
+        return WMX_EINVAL;
+    }
+    if ((h->stages & 15u) == 0) {  // every switch off: the heartbeat leaves the package as it is (src/wmix.c:613-709)
+        if (d_in == d_out) return 0;
+        wmx::set_error("wmx_chain_process: a chain with every stage off works in place (d_in == d_out)");
         return WMX_EINVAL;
     }
     const long total = (long)n10 * h->pkg10;  // int16 elements of the tick per stream

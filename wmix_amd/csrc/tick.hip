@@ -81,6 +81,8 @@ int wmx_tick_create(wmx_tick **out, int n_groups, int rec_per_group, int chn, in
         const int nc = (stages & WMX_CHAIN_AEC) ? n_groups : 1;
         rc = wmx_chain_create_groups(&h->chain, n_groups * rec_per_group, chn, freq, interval_ms, agc_value, stages, nc,
                                      nc > 1 ? cohort.data() : nullptr);
+        // a canceller that is switched on later (wmx_tick_set_stages) still hears one far-end per group
+        if (rc == 0) wmx::chain_cohorts_when_made(h->chain, n_groups, n_groups > 1 ? cohort.data() : nullptr);
     }
     if (rc == 0) {
         hipError_t e = hipMalloc(&h->d_play, (size_t)n_groups * h->pkg * sizeof(int16_t));
@@ -94,6 +96,13 @@ int wmx_tick_create(wmx_tick **out, int n_groups, int rec_per_group, int chn, in
     *out = h;
     return 0;
 }
+
+// The heartbeat's switches at run time: webrtcEnable[WR_VAD / WR_AEC / WR_NS / WR_AGC], which the daemon's message thread sets
+// (src/wmix.c:1010-1050) -- and which the reference SHIPS as NS = 1, AGC = 1, VAD = 0, AEC = 0 (src/wmix.c:1580-1584).  A stage whose
+// switch drops is released, one that comes on gets fresh handles in the next heartbeat (wmx_chain_set_stages); 0 = a pure
+// mix / FIFO / zoom tick.  agc_value: agc_init's value for an AGC that comes on (the daemon: wmix->volumeAgc of that moment; < 0 keeps
+// the tick's).  A control-plane call (the device is drained when a stage goes).
+int wmx_tick_set_stages(wmx_tick *h, unsigned stages, int agc_value) { return h ? wmx_chain_set_stages(h->chain, stages, agc_value) : WMX_EINVAL; }
 
 // The platform build's PLAT_PLAY_CORRECT (wmx_mix_set_play_correct); its PLAT_AEC_INTERVALMS is wmx_tick_create's aec_delay_ms.
 int wmx_tick_set_play_correct(wmx_tick *h, uint32_t bytes) { return h ? wmx_mix_set_play_correct(h->mix, bytes) : WMX_EINVAL; }

@@ -327,6 +327,8 @@ int aecm_fork_far(wmx_aecm *h, hipStream_t stream);
 void aecm_cancel_fork(wmx_aecm *h);
 // pipe.hip -> chain.hip: an event the next wmx_chain_process call records between the noise suppressor and the echo canceller
 void chain_gate_after_ns(wmx_chain *h, hipEvent_t ev);
+// tick.hip -> chain.hip: the cohorts a canceller switched on later (wmx_chain_set_stages) is made with
+void chain_cohorts_when_made(wmx_chain *h, int n_cohorts, const int32_t *stream_cohort);
 
 // wmix_pcm_zoom's cursor walk (src/wmix.c:139-222) as a gather list: out int16 i <- in int16 idx[i]; identical formats
 // give the identity (the reference's memcpy branch).  Defined in mix.hip.

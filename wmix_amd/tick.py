@@ -23,9 +23,15 @@ class TickBatch:
         check(lib().wmx_tick_set_play_correct(tb._h, correct), "wmx_tick_set_play_correct")
         return tb
 
+    # what the reference SHIPS switched on (src/wmix.c:1580-1584: webrtcEnable[WR_NS] = 1, [WR_AGC] = 1, [WR_VAD] = 0, [WR_AEC] = 0);
+    # the message thread turns the others on at run time (:1010-1050) -> set_stages
+    SHIPPED_STAGES = NS | AGC
+
     def __init__(self, n_groups, rec_per_group=1, chn=1, freq=8000, interval_ms=20, aec_delay_ms=400, agc_value=5,
                  stages=NS | AEC | AGC | VAD):
-        """defaults = the shipped platform (platform/alsa): 1 x 8000 Hz, WMIX_INTERVAL_MS 20, AEC_INTERVALMS 400, volumeAgc 5"""
+        """format defaults = the shipped platform (platform/alsa): 1 x 8000 Hz, WMIX_INTERVAL_MS 20, AEC_INTERVALMS 400, volumeAgc 5.
+        `stages` defaults to ALL FOUR switches on (the heartbeat at full length, what the tests and the bench exercise) -- NOT the
+        daemon's start-up state, which is SHIPPED_STAGES; stages = 0 is a pure mix / FIFO / zoom tick."""
         self._h = C.c_void_p()
         rc = lib().wmx_tick_create(C.byref(self._h), n_groups, rec_per_group, chn, freq, interval_ms, aec_delay_ms, agc_value, stages)
         if rc != 0:
@@ -44,6 +50,11 @@ class TickBatch:
         check(lib().wmx_tick_load(self._h, src.data_ptr(), src_bytes, freq, channels, sample, src.shape[1], src.stride(0), src.stride(1), reduce,
                                   C.byref(h), C.byref(t), torch.cuda.current_stream().cuda_stream), "wmx_tick_load")
         self.head, self.tick = h.value, t.value
+
+    def set_stages(self, stages, agc_value=-1):
+        """webrtcEnable[] at run time (src/wmix.c:1010-1050): a stage that goes is released, one that comes on starts with fresh handles
+        (an AGC with agc_value = the daemon's volumeAgc of that moment; < 0: the tick's own)."""
+        check(lib().wmx_tick_set_stages(self._h, int(stages), int(agc_value)), "wmx_tick_set_stages")
 
     def play_ns(self, on=True):
         """webrtcEnable[WR_NS_PA]: ns_process over the played package in front of playPkgBuff_add (src/wmix.c:1370-1386)."""
