@@ -106,6 +106,7 @@ def _child(kind):
         if rc == 0:  # the fault lies behind the last call of a submit: every call has had its turn
             assert calls < i
             pf.wait(-1)
+            k += 1  # (that submit was step k, and it went through)
             break
         assert rc <= -11000, (i, rc)  # a HIP error's code, far from the reference's -1
         report["faults"] += 1

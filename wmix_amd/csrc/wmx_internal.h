@@ -314,6 +314,12 @@ struct MapVec {
 // (legacy_stream_create; the handle's calls are ordered among themselves whatever thread makes them) and one per THREAD for the
 // stateless adapters (thread_stream: G.711, wmix_pcm_zoom, wmix_load_data, math/fft.c), at the device's highest priority -- a legacy call
 // is a few hundred samples somebody waits for.  nullptr (the NULL stream, the old behaviour) only if the runtime refuses a stream.
+// Measured (examples/host_legacy_threads.c, profiles/r06/legacy_threads.jsonl): the heartbeat beside the six loaders and the
+// agc_addition thread costs what it costs alone (p99 ratio 1.0).  Beside a BATCH that saturates the device it still waits -- not for a
+// stream, for the hardware: a launch from another queue is served when the batch's running kernel has issued its workgroups, so the
+// wait grows with the batch's launch size (p50 per heartbeat of four calls: 0.21 ms alone, 0.28 ms beside 1 024-stream launches, 0.63
+// beside 16 384, 1.2 beside 65 536).  Stream priority does not change that, and compute units reserved with a CU mask made it worse
+// (tried, round 6).  A gateway that serves legacy callers and a batch on one device keeps its launches small (wmx_rt's sub-batches).
 hipStream_t legacy_stream_create();
 void legacy_stream_destroy(hipStream_t s);
 hipStream_t thread_stream();
