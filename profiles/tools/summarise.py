@@ -7,11 +7,17 @@ doubled; WRITE_SIZE is exact.  `bytes_per_dispatch_corrected` applies that.
 """
 import collections
 import csv
+import os
 import glob
 import json
 import re
 import sys
 
+if len(sys.argv) > 1 and sys.argv[1] == "--markdown":  # DESIGN.md's tables from a committed profiles/rNN: profiles/tools/tables.py
+    sys.argv = [os.path.join(os.path.dirname(os.path.abspath(__file__)), "tables.py")] + sys.argv[2:]
+    import runpy
+    runpy.run_path(sys.argv[0], run_name="__main__")
+    sys.exit(0)
 out = sys.argv[1]
 tag = sys.argv[4] if len(sys.argv) > 4 else "chain"
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The non-shared far-end regime (round-4 VERDICT "next" 4): the chain at 65 536 streams with N distinct far-ends, N = 1 .. 65 536.
-# Run on the GPU box from the repository root; one JSON line per N under gpurun_out/r05/.
-O=gpurun_out/r05
+# Run on the GPU box from the repository root; one JSON line per N under gpurun_out/r06/.
+O=gpurun_out/r06
 mkdir -p $O
 TAG=${1:-a}
 for n in 1 256 4096 65536; do

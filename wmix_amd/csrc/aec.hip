@@ -145,6 +145,19 @@ __device__ __forceinline__ void unpack_bin(const float *a, int b, float &re, flo
     }
 }
 
+// One 128-point real transform per 16-lane group, data in registers (fft_regs.h).  `src(p)` supplies complex
+// point p of the time-domain input; the result of the complex passes goes to `row` (natural order), where
+// rdft128_fwd_bin() finishes the real split for whoever reads a bin.
+template <class Src>
+__device__ __forceinline__ void aec_fft_fwd(float *row, const FftTables *T, int gl, Src src) {
+    Cx v[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) v[m] = src(fft64_src_point(gl, m));
+    fft64_regs<false>(v, T, gl);
+#pragma unroll
+    for (int m = 0; m < 4; m++) *reinterpret_cast<float2 *>(row + 2 * (gl + 16 * m)) = make_float2(v[m].r, v[m].i);
+}
+
 // ================================================================== far-end kernel
 // grid = number of far-end groups: workgroup g (one wave) serves far-end g, whose packets start at far_pcm + g * far_group_stride
 // and whose plans are plans[g * kAecMaxPktPerLaunch ...] (a group is also a control COHORT: the streams that were started at
@@ -159,7 +172,12 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const flo
                                                      long far_group_stride, int chn, float gpow1np, int plan_by_value,
                                                      const AecPlan plan_value) {
     __shared__ AecConsts K;
-    __shared__ float fa[2][132];
+    // four transforms at a time, one per 16-lane group, in registers (fft_regs.h, the near kernel's executor): the plain and the windowed
+    // spectrum of TWO consumed blocks.  tin[g]: the 128 time-domain samples of transform g; fa[g]: the result of its complex passes,
+    // from which every lane takes one bin (rdft128_fwd_bin_u).  (Until round 6: one transform at a time through the LDS executor,
+    // seven passes with a barrier each -- the far kernel was 0.21 ms of a 1.35 ms step with 65 536 far-ends, most of it these.)
+    __shared__ float tin[4][128];
+    __shared__ float fa[4][132];
     const int lane = threadIdx.x;
     if (plan_by_value) {
         const int *src = reinterpret_cast<const int *>(&plan_value);
@@ -286,17 +304,15 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const flo
         }
         if (consume) {
             // history entries + xPow (aec_core.c:1209-1216); xPow is a recurrence over the blocks and stays in registers
+            const int gl = fft_index(lane), grp = fft_group(lane);
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (k >= pl.n_blk) break;
-                float sp[3], spw[3];  // row elements lane, lane + 64, lane + 128 (the last for lanes 0, 1) of the plain / windowed spectrum
-                float xi_b, xr64, xi64;  // imaginary part of bin `lane`; bin 64 (every lane the same two words)
-                if (pl.unwritten[k]) {
-                    // a slot nobody has written yet (the read pointer was moved back into the ring's zeroed storage,
-                    // WebRtc_InitBuffer + aec_core.c:1709-1717): the reference reads the zeros of its memset, not a transform of zeros
-                    sp[0] = sp[1] = sp[2] = spw[0] = spw[1] = spw[2] = 0.f;
-                    xi_b = xr64 = xi64 = 0.f;
-                } else {
+            for (int k0 = 0; k0 < 4; k0 += 2) {
+                if (k0 >= pl.n_blk) break;
+                // TimeToFrequency(.., window = 0 / 1), aec_core.c:1690-1707, 792-819: rows 2 j / 2 j + 1 = the plain / windowed input of block k0 + j
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int k = k0 + j;
+                    if (k >= pl.n_blk || pl.unwritten[k]) continue;
                     float t0 = (float)(short)(tw[k] & 0xffffu), t1 = (float)(short)(tw[k] >> 16);
                     if (pl.has_far) {  // a block produced by this very packet: what was fetched above is older than the slot's new content
 #pragma unroll
@@ -307,62 +323,70 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const flo
                             t1 = tpart[q][2 * lane + 1];
                         }
                     }
-                    // TimeToFrequency(.., window = 0 / 1), aec_core.c:1690-1707, 792-819: the plain and the windowed transform of the 128 samples
-                    {
-                        const int i0 = 2 * lane, i1 = 2 * lane + 1;
-                        fa[0][i0] = t0;
-                        fa[0][i1] = t1;
-                        fa[1][i0] = t0 * (i0 < kAecPart ? K.hanning[i0] : K.hanning[2 * kAecPart - i0]);
-                        fa[1][i1] = t1 * (i1 < kAecPart ? K.hanning[i1] : K.hanning[2 * kAecPart - i1]);
-                    }
-                    wave_sync();
-                    rdft_forward<64>(fa[0], &K.tab, lane);
-                    rdft_forward<64>(fa[1], &K.tab, lane);
-                    wave_sync();
+                    const int i0 = 2 * lane, i1 = 2 * lane + 1;
+                    tin[2 * j][i0] = t0;
+                    tin[2 * j][i1] = t1;
+                    tin[2 * j + 1][i0] = t0 * (i0 < kAecPart ? K.hanning[i0] : K.hanning[2 * kAecPart - i0]);
+                    tin[2 * j + 1][i1] = t1 * (i1 < kAecPart ? K.hanning[i1] : K.hanning[2 * kAecPart - i1]);
+                }
+                wave_sync();
+#ifndef WMX_AEC_EXP_NOFARFFT  // (timing experiment: what the far kernel costs without its transforms)
+                // group `grp` transforms row `grp` (a row without a live block behind it is transformed too -- the exchanges between the
+                // lanes of a group want every lane there -- and nobody reads the result)
+                aec_fft_fwd(fa[grp], &K.tab, gl, [&](int p) {
+                    const v2f c = ld_pt(tin[grp], p);
+                    return Cx{c.x, c.y};
+                });
+#endif
+                wave_sync();
+                const SplitLane cf = rdft128_fwd_coef(&K.tab, lane);
 #pragma unroll
-                    for (int j = 0; j < 3; j++) {
-                        const int i = lane + 64 * j < 130 ? lane + 64 * j : 0;  // row element i: re of bin i, or im of bin i - 65
-                        float re, im;
-                        unpack_bin(fa[0], i < kAecPart1 ? i : i - kAecPart1, re, im);
-                        sp[j] = i < kAecPart1 ? re : im;
-                        unpack_bin(fa[1], i < kAecPart1 ? i : i - kAecPart1, re, im);
-                        spw[j] = i < kAecPart1 ? re : im;
+                for (int j = 0; j < 2; j++) {
+                    const int k = k0 + j;
+                    if (k >= pl.n_blk) continue;
+                    // bin `lane` of the plain and of the windowed spectrum; bin 64 (real) for everybody
+                    v2f P = v2f{0.f, 0.f}, Wd = v2f{0.f, 0.f};
+                    float xr64 = 0.f, w64 = 0.f;
+                    const float xi64 = 0.f;
+                    if (!pl.unwritten[k]) {
+                        // (an unwritten slot -- the read pointer was moved back into the ring's zeroed storage, WebRtc_InitBuffer +
+                        // aec_core.c:1709-1717 -- reads as the zeros of the reference's memset, not as a transform of zeros)
+                        P = rdft128_fwd_bin_u(fa[2 * j], cf, lane);
+                        Wd = rdft128_fwd_bin_u(fa[2 * j + 1], cf, lane);
+                        if (lane == 0) P.y = 0.f, Wd.y = 0.f;  // bin 0 is real: +0, as StoreAsComplex / TimeToFrequency write it
+                        xr64 = fa[2 * j][0] - fa[2 * j][1];
+                        w64 = fa[2 * j + 1][0] - fa[2 * j + 1][1];
+                    }
+                    const int hs = pl.hist_n[k] % kAecHist;
+                    // rows are re[65] | im[65]
+                    F.hist[hs * 130 + lane] = P.x;
+                    F.hist[hs * 130 + kAecPart1 + lane] = P.y;
+                    F.hist[(hs + kAecHist) * 130 + lane] = P.x;
+                    F.hist[(hs + kAecHist) * 130 + kAecPart1 + lane] = P.y;
+                    F.hist_w[hs * 130 + lane] = Wd.x;
+                    F.hist_w[hs * 130 + kAecPart1 + lane] = Wd.y;
+                    if (lane < 2) {  // bin 64: lane 0 the real part, lane 1 the (zero) imaginary part
+                        const int at = lane == 0 ? kAecPart : kAecPart1 + kAecPart;
+                        F.hist[hs * 130 + at] = lane == 0 ? xr64 : xi64;
+                        F.hist[(hs + kAecHist) * 130 + at] = lane == 0 ? xr64 : xi64;
+                        F.hist_w[hs * 130 + at] = lane == 0 ? w64 : 0.f;
+                    }
+                    if (lane < 4) F.nyq[2 * (hs + (lane >> 1) * kAecHist) + (lane & 1)] = (lane & 1) ? xi64 : xr64;
+                    {
+                        const float xr = P.x, xi = P.y;
+                        const float far_spectrum = (xr * xr) + (xi * xi);
+                        xp0 = 0.9f * xp0 + gpow1np * far_spectrum;
+                        F.xpow_seq[hs * BP + lane] = xp0;
                     }
                     {
-                        float re, im;
-                        unpack_bin(fa[0], lane, re, im);
-                        xi_b = im;
-                        unpack_bin(fa[0], kAecPart, re, im);
-                        xr64 = re;
-                        xi64 = im;
+                        const float far_spectrum = (xr64 * xr64) + (xi64 * xi64);
+                        xp1 = 0.9f * xp1 + gpow1np * far_spectrum;  // every lane, same value
+                        if (lane == 0) F.xpow_seq[hs * BP + kAecPart] = xp1;
                     }
-                    wave_sync();  // fa[] is free for the next block
+                    xpow_dirty = true;
                 }
-                const int hs = pl.hist_n[k] % kAecHist;
-#pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    const int i = lane + 64 * j;
-                    if (i < 130) {
-                        F.hist[hs * 130 + i] = sp[j];
-                        F.hist[(hs + kAecHist) * 130 + i] = sp[j];
-                        F.hist_w[hs * 130 + i] = spw[j];
-                    }
-                }
-                if (lane < 4) F.nyq[2 * (hs + (lane >> 1) * kAecHist) + (lane & 1)] = (lane & 1) ? xi64 : xr64;
-                {
-                    const float xr = sp[0], xi = xi_b;
-                    const float far_spectrum = (xr * xr) + (xi * xi);
-                    xp0 = 0.9f * xp0 + gpow1np * far_spectrum;
-                    F.xpow_seq[hs * BP + lane] = xp0;
-                }
-                {
-                    const float far_spectrum = (xr64 * xr64) + (xi64 * xi64);
-                    xp1 = 0.9f * xp1 + gpow1np * far_spectrum;  // every lane, same value
-                    if (lane == 0) F.xpow_seq[hs * BP + kAecPart] = xp1;
-                }
-                xpow_dirty = true;
+                wave_sync();  // tin[] / fa[] are free for the next pair
             }
-            wave_sync();
         }
     }
     if (xpow_dirty) {
@@ -485,19 +509,6 @@ __device__ __forceinline__ int opaque_lane(int x) {
     // offset and global loads of wave-uniform rows take the SGPR-base + VGPR-offset form instead of a 64-bit address per row
     __builtin_assume(x >= 0 && x < 64);
     return x;
-}
-
-// One 128-point real transform per 16-lane group, data in registers (fft_regs.h).  `src(p)` supplies complex
-// point p of the time-domain input; the result of the complex passes goes to `row` (natural order), where
-// rdft128_fwd_bin() finishes the real split for whoever reads a bin.
-template <class Src>
-__device__ __forceinline__ void aec_fft_fwd(float *row, const FftTables *T, int gl, Src src) {
-    Cx v[4];
-#pragma unroll
-    for (int m = 0; m < 4; m++) v[m] = src(fft64_src_point(gl, m));
-    fft64_regs<false>(v, T, gl);
-#pragma unroll
-    for (int m = 0; m < 4; m++) *reinterpret_cast<float2 *>(row + 2 * (gl + 16 * m)) = make_float2(v[m].r, v[m].i);
 }
 
 template <int MULT>  // 1: 8 kHz, 2: 16 kHz

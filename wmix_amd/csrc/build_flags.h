@@ -8,7 +8,7 @@
 //    WMIX_AMD_ALLOW_VARIANT_BUILD=1, and bench.py prints it on its line.
 #pragma once
 
-#if (defined(WMX_AEC_EXP) || defined(WMX_AEC_EXP_BARRIERS) || defined(WMX_NS_EXP)) && !defined(WMX_TIMING_ONLY_BUILD)
+#if (defined(WMX_AEC_EXP) || defined(WMX_AEC_EXP_BARRIERS) || defined(WMX_NS_EXP) || defined(WMX_AEC_EXP_NOFARFFT)) && !defined(WMX_TIMING_ONLY_BUILD)
 #error "WMX_AEC_EXP / WMX_AEC_EXP_BARRIERS / WMX_NS_EXP give WRONG results (timing experiments): add -DWMX_TIMING_ONLY_BUILD to say so"
 #endif
 
