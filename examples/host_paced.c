@@ -24,7 +24,7 @@
  * short bursts per period and never idles long enough for its power management to clock it down (profiles/r06/README_paced.md).
  *
  * pattern file: int16 far [slots][far_samples], then rows [slots][n_pattern][row_bytes] (row_bytes from the library).
- * dump file:    rows [keep][n_sample][row_bytes] of the last `keep` ticks.     lat file: double latency_ms[ticks].
+ * dump file:    rows [keep][n_sample][row_bytes] of the last `keep` ticks.     lat / lag file (--lag): double latency_ms / release_lag_ms [ticks * phases].
  *
  * Build (what __graft_entry__.build() runs):
  *   gcc -std=c99 -O2 -Iinclude examples/host_paced.c -o examples/host_paced -Lwmix_amd -lwmix_amd -Wl,-rpath,'$ORIGIN/../wmix_amd' -lm
@@ -83,7 +83,7 @@ int main(int argc, char **argv) {
     const char *kind = arg_of(argc, argv, "--kind", "pcm");
     const int freq = atoi(arg_of(argc, argv, "--freq", "16000")), interval_ms = atoi(arg_of(argc, argv, "--interval-ms", "20"));
     const int P = atoi(arg_of(argc, argv, "--phases", "1"));
-    const char *pattern = arg_of(argc, argv, "--pattern", NULL), *dump = arg_of(argc, argv, "--dump", NULL), *latf = arg_of(argc, argv, "--lat", NULL);
+    const char *pattern = arg_of(argc, argv, "--pattern", NULL), *dump = arg_of(argc, argv, "--dump", NULL), *latf = arg_of(argc, argv, "--lat", NULL), *lagf = arg_of(argc, argv, "--lag", NULL);
     const int n_pattern = atoi(arg_of(argc, argv, "--n-pattern", "256"));
     int keep = atoi(arg_of(argc, argv, "--keep", "32"));
     const char *sample_s = arg_of(argc, argv, "--sample", "0");
@@ -233,6 +233,11 @@ int main(int argc, char **argv) {
     if (rc == 0 && latf) {
         FILE *f = fopen(latf, "wb");
         if (!f || fwrite(lat, sizeof(double), (size_t)total, f) != (size_t)total) rc = 4;
+        if (f) fclose(f);
+    }
+    if (rc == 0 && lagf) { /* release lag per group-tick: how late the host thread was (its own oversleep, or a predecessor that overran) */
+        FILE *f = fopen(lagf, "wb");
+        if (!f || fwrite(lag, sizeof(double), (size_t)total, f) != (size_t)total) rc = 4;
         if (f) fclose(f);
     }
     int worst = 0, misses = 0, overruns = 0;

@@ -113,10 +113,10 @@ def main():
     host = os.path.join(ROOT, "examples", "host_paced")
     for S in [int(x) for x in a.streams.split(",")]:
         sample = sorted(set(int(i) for i in np.linspace(0, S - 1, 12)))
-        dump, lat = os.path.join(tmp, "dump.bin"), os.path.join(tmp, "lat.f64")
+        dump, lat, lag = os.path.join(tmp, "dump.bin"), os.path.join(tmp, "lat.f64"), os.path.join(tmp, "lag.f64")
         cmd = [host, "--streams", str(S), "--sub", str(a.sub), "--slots", str(a.slots), "--tick-ms", str(a.tick_ms), "--ticks", str(a.ticks), "--prime",
                str(a.prime), "--kind", form, "--freq", str(freq), "--interval-ms", str(interval_ms), "--phases", str(a.phases), "--pattern", pat,
-               "--n-pattern", str(n_pat), "--dump", dump, "--keep", str(a.keep), "--sample", ",".join(map(str, sample)), "--lat", lat]
+               "--n-pattern", str(n_pat), "--dump", dump, "--keep", str(a.keep), "--sample", ",".join(map(str, sample)), "--lat", lat, "--lag", lag]
         watch = DeviceWatch().start()
         r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)  # stderr passes through: a long run reports twice a minute
         device = watch.stop()
@@ -129,7 +129,17 @@ def main():
         for col, s in enumerate(sample):
             want = bench.paced_replay(a.kind, far, rows, s % n_pat, T, interval_ms)[T - a.keep:]
             worst = max(worst, int(np.abs(got[:, col].astype(np.int32) - want.astype(np.int32)).max()))
-        lat_ms = np.fromfile(lat, np.float64)
+        lat_ms, lag_ms = np.fromfile(lat, np.float64), np.fromfile(lag, np.float64)
+        # whose hiccup was it?  a slow group-tick (> median + 1.5 ms) started late (the host: its thread overslept, or a predecessor overran)
+        # or ran long (the device / the link) -- or both
+        svc = lat_ms - lag_ms
+        slow = lat_ms > np.median(lat_ms) + 1.5
+        d["slow_group_ticks"] = {"count": int(slow.sum()), "released_late_by_more_than_1ms": int((slow & (lag_ms > 1.0)).sum()),
+                                 "ran_long_by_more_than_1ms": int((slow & (svc > np.median(svc) + 1.0)).sum()),
+                                 "service_p50_ms": round(float(np.median(svc)), 4), "service_max_ms": round(float(svc.max()), 4),
+                                 "release_lag_over_1ms": int((lag_ms > 1.0).sum())}
+        if a.out:  # the series themselves beside the line (float32, group-tick order)
+            np.stack([lat_ms, lag_ms]).astype(np.float32).tofile(a.out + ".S%d.lat_lag.f32" % S)
         edges = [0, 2, 4, 6, 8, 10, 12, 14, 15, 16, 17, 18, 19, 20, 25, 50, 1e9]
         d["latency_histogram_ms"] = {("%g-%g" % (edges[i], edges[i + 1])) if edges[i + 1] < 1e9 else (">%g" % edges[i]): int(c)
                                      for i, c in enumerate(np.histogram(lat_ms, edges)[0]) if c}
