@@ -16,7 +16,7 @@
  * `keep` ticks and written to --dump for the parity check (tests/test_paced_host_gpu.py replays them through the oracle).
  *
  *   host_paced --streams S [--sub 32768] [--slots 4] [--tick-ms 20] [--ticks 1500] [--prime 150] [--kind pcm|rtp] [--freq 16000]
- *              [--interval-ms 20] [--phases 1] [--pattern file --n-pattern 256] [--dump file --keep 32 --sample a,b,c] [--lat file]
+ *              [--interval-ms 20] [--phases 1] [--spin 0] [--pattern file --n-pattern 256] [--dump file --keep 32 --sample a,b,c] [--lat file]
  *
  * --phases P > 1: the streams of a server do not all deliver their package at the same instant.  P groups of S / P streams (one
  * wmx_rt each), group g released at t0 + (k * P + g) * tick_ms / P with the whole tick as its period and tick_ms - 2 ms as its budget:
@@ -87,6 +87,8 @@ int main(int argc, char **argv) {
     const int n_pattern = atoi(arg_of(argc, argv, "--n-pattern", "256"));
     int keep = atoi(arg_of(argc, argv, "--keep", "32"));
     const char *sample_s = arg_of(argc, argv, "--sample", "0");
+    /* --spin 1: never sleep between ticks, spin on the clock (a core burnt for the sake of never being woken up late) */
+    const int64_t spin_ns = atoi(arg_of(argc, argv, "--spin", "0")) ? (int64_t)1 << 60 : 200000;
     if (S < 1 || ticks < 1 || tick_ms <= 2.0 || slots < 1 || n_pattern < 1 || P < 1 || P > MAX_PHASES || S < P) {
         fprintf(stderr, "usage: %s --streams S [--sub N] [--slots N] [--tick-ms T] [--ticks N] [--prime N] [--kind pcm|rtp] [--phases P] ...\n", argv[0]);
         return 2;
@@ -179,7 +181,7 @@ int main(int argc, char **argv) {
             next_note += 30000000000LL;
         }
         if (P == 1) {
-            sleep_until(due, 200000);
+            sleep_until(due, spin_ns);
         } else {
             for (;;) { /* until the release: see the groups in flight come back */
                 int any = 0;
@@ -192,7 +194,7 @@ int main(int argc, char **argv) {
                     }
                 if (now_ns() >= due || rc != 0) break;
                 if (!any) {
-                    sleep_until(due, 200000);
+                    sleep_until(due, spin_ns);
                     break;
                 }
             }

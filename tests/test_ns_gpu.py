@@ -1,7 +1,7 @@
 """GPU parity: wmix_amd/csrc/ns.hip through the C ABI vs the oracle and the golden vectors.
-ordered mode (the default, and the mode bench.py measures): bit-exact, which is stricter than the
-+-1 LSB / 1e-3 RMS BASELINE.json's north_star asks for the float NS path.  The optional parallel-sum
-mode is checked statistically only (see test_many_streams_long_run_vs_oracle)."""
+Bit-exact (the reference's summation order), which is stricter than the +-1 LSB / 1e-3 RMS BASELINE.json's
+north_star asks for the float NS path.  (The optional re-associated sum mode of rounds 1-5 was outside that
+tolerance and is gone: test_no_entry_point_outside_the_tolerance.)"""
 import ctypes as C
 import os
 import sys

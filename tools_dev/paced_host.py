@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--slots", type=int, default=4)
     ap.add_argument("--keep", type=int, default=24)
     ap.add_argument("--stop-at-miss", action="store_true")
+    ap.add_argument("--spin", type=int, default=0, help="1: host_paced never sleeps between ticks (spins on the clock)")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     import bench
@@ -116,7 +117,7 @@ def main():
         dump, lat, lag = os.path.join(tmp, "dump.bin"), os.path.join(tmp, "lat.f64"), os.path.join(tmp, "lag.f64")
         cmd = [host, "--streams", str(S), "--sub", str(a.sub), "--slots", str(a.slots), "--tick-ms", str(a.tick_ms), "--ticks", str(a.ticks), "--prime",
                str(a.prime), "--kind", form, "--freq", str(freq), "--interval-ms", str(interval_ms), "--phases", str(a.phases), "--pattern", pat,
-               "--n-pattern", str(n_pat), "--dump", dump, "--keep", str(a.keep), "--sample", ",".join(map(str, sample)), "--lat", lat, "--lag", lag]
+               "--n-pattern", str(n_pat), "--dump", dump, "--keep", str(a.keep), "--sample", ",".join(map(str, sample)), "--lat", lat, "--lag", lag, "--spin", str(a.spin)]
         watch = DeviceWatch().start()
         r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)  # stderr passes through: a long run reports twice a minute
         device = watch.stop()
@@ -146,6 +147,7 @@ def main():
         d["parity_checked"] = {"streams": len(sample), "ticks_compared": a.keep, "ticks_replayed": T, "max_lsb": worst,
                                "oracle": "oracle/orc_*.c chain (port): every tick of the run replayed per sampled stream"}
         d["device"] = device
+        d["spin_between_ticks"] = bool(a.spin)
         d["stream_frames_per_s_sustained"] = S * (interval_ms // 10) / (a.tick_ms * 1e-3)
         line = json.dumps(d)
         print(line)
