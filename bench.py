@@ -154,7 +154,7 @@ class NsWorkload:
     pmc_tag = "ns"
     dtype = "f32"
     bytes_per_frame = 25040.0
-    dominant_kernel = "ns_kernel<256, true, 1>"
+    dominant_kernel = "ns_kernel<256, 1>"
     dominant_bytes_per_frame = 25040.0
     freq, pkt = 16000, 160
 
@@ -982,7 +982,7 @@ class NsAgcMix32kWorkload:
     pmc_tag = "ns_agc_mix_32k"
     dtype = "f32 (NS), int16/int32 (AGC, mix)"
     bytes_per_frame = 32550.0
-    dominant_kernel = "ns_kernel<256, true, 2>"
+    dominant_kernel = "ns_kernel<256, 2>"
     dominant_bytes_per_frame = 31056.0
     N = 8  # sources per mix group
 

@@ -18,8 +18,8 @@ done <<'LIST'
 chain|aec|aec_near_kernel<2>|4
 ns_aec_8k|aec|aec_near_kernel<1>|4
 chain_8k|aec|aec_near_kernel<1>|4
-ns|ns|ns_kernel<256, true, 1>|5
-ns_agc_mix_32k|ns|ns_kernel<256, true, 2>|5
+ns|ns|ns_kernel<256, 1>|5
+ns_agc_mix_32k|ns|ns_kernel<256, 2>|5
 nsx|nsx|nsx_kernel<256, 1>|5
 chain_fx|nsx|nsx_kernel<256, 1>|5
 aecm|aecm|aecm_near_kernel|7

