@@ -171,12 +171,15 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const flo
                                                      const int16_t *far_pcm, long far_packet_stride,
                                                      long far_group_stride, int chn, float gpow1np, int plan_by_value,
                                                      const AecPlan plan_value) {
-    __shared__ AecConsts K;
+    // (the transform tables and the window: the two NLP curves behind them in AecConsts are the near kernel's)
+    __shared__ AecConstsNear K;
     // four transforms at a time, one per 16-lane group, in registers (fft_regs.h, the near kernel's executor): the plain and the windowed
-    // spectrum of TWO consumed blocks.  tin[g]: the 128 time-domain samples of transform g; fa[g]: the result of its complex passes,
-    // from which every lane takes one bin (rdft128_fwd_bin_u).  (Until round 6: one transform at a time through the LDS executor,
-    // seven passes with a barrier each -- the far kernel was 0.21 ms of a 1.35 ms step with 65 536 far-ends, most of it these.)
-    __shared__ float tin[4][128];
+    // spectrum of TWO consumed blocks.  fa[g]: the 128 time-domain samples of transform g, then -- in place -- the result of its complex
+    // passes, from which every lane takes one bin (rdft128_fwd_bin_u).  (Until round 6: one transform at a time through the LDS executor,
+    // seven passes with a barrier each.)
+    // This kernel is one dependent chain of memory round trips per wave; with one far-end per stream (65 536 waves) its time is that
+    // chain times waves / resident waves.  5.4 KB of LDS per wave (10 KB before: separate input rows, a copy of the packet's
+    // partitions, the near kernel's curves) let the registers, not the LDS, set the residency: 28 waves per CU instead of 16.
     __shared__ float fa[4][132];
     const int lane = threadIdx.x;
     if (plan_by_value) {
@@ -206,22 +209,21 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const flo
     // old slots of the 250-slot ring as a rule (the canceller runs behind the far-end by the system delay); when a consumed slot
     // is one this packet writes, the copy kept in LDS replaces what was fetched.
     __shared__ float lpre[kAecPreLen];
-    __shared__ float tpart[4][128];  // this packet's partitions [prev64 | new64], as stored into their ring slots
     float xp0, xp1;
     {
         float *dst = reinterpret_cast<float *>(&K);
-        constexpr int NIT = (kAecConstWords + 63) / 64, NP = kAecPreLen / 64;
+        constexpr int NIT = (kAecConstNearWords + 63) / 64, NP = kAecPreLen / 64;
         static_assert(kAecPreLen % 64 == 0, "whole rows of the pre-buffer per lane");
         float c[NIT], pr[NP];
 #pragma unroll
-        for (int k = 0; k < NIT; k++) c[k] = consts_g[lane + 64 * k < kAecConstWords ? lane + 64 * k : 0];
+        for (int k = 0; k < NIT; k++) c[k] = consts_g[lane + 64 * k < kAecConstNearWords ? lane + 64 * k : 0];
 #pragma unroll
         for (int k = 0; k < NP; k++) pr[k] = F.pre[lane + 64 * k];
         xp0 = F.xpow[lane];
         xp1 = F.xpow[lane == 0 ? kAecPart : 0];
 #pragma unroll
         for (int k = 0; k < NIT; k++)
-            if (lane + 64 * k < kAecConstWords) dst[lane + 64 * k] = c[k];
+            if (lane + 64 * k < kAecConstNearWords) dst[lane + 64 * k] = c[k];
 #pragma unroll
         for (int k = 0; k < NP; k++) lpre[lane + 64 * k] = pr[k];
     }
@@ -294,9 +296,9 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const flo
                 // BufferFarendPartition (aec_core.c:1690-1707) stores the partition's plain and windowed spectrum; here its 128
                 // samples [prev64 | new64] go into the slot (they are int16 values: the conversion back is exact) and the two
                 // transforms wait until the block is consumed
+                // (the LDS copy of the pre-buffer keeps them for the blocks this very packet consumes: nothing overwrites that window
+                // before the next packet's samples arrive)
                 const float a = lpre[(pl.pre_rd[q] + 2 * lane) % kAecPreLen], b = lpre[(pl.pre_rd[q] + 2 * lane + 1) % kAecPreLen];
-                tpart[q][2 * lane] = a;
-                tpart[q][2 * lane + 1] = b;
                 reinterpret_cast<unsigned *>(F.tring)[(size_t)pl.pslot[q] * 64 + lane] =
                     (unsigned)(unsigned short)(short)a | ((unsigned)(unsigned short)(short)b << 16);
             }
@@ -319,22 +321,23 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const flo
                         for (int q = 0; q < 4; q++) {
                             if (q >= pl.n_part) break;
                             if (pl.pslot[q] != pl.bslot[k]) continue;
-                            t0 = tpart[q][2 * lane];
-                            t1 = tpart[q][2 * lane + 1];
+                            t0 = lpre[(pl.pre_rd[q] + 2 * lane) % kAecPreLen];
+                            t1 = lpre[(pl.pre_rd[q] + 2 * lane + 1) % kAecPreLen];
                         }
                     }
                     const int i0 = 2 * lane, i1 = 2 * lane + 1;
-                    tin[2 * j][i0] = t0;
-                    tin[2 * j][i1] = t1;
-                    tin[2 * j + 1][i0] = t0 * (i0 < kAecPart ? K.hanning[i0] : K.hanning[2 * kAecPart - i0]);
-                    tin[2 * j + 1][i1] = t1 * (i1 < kAecPart ? K.hanning[i1] : K.hanning[2 * kAecPart - i1]);
+                    fa[2 * j][i0] = t0;
+                    fa[2 * j][i1] = t1;
+                    fa[2 * j + 1][i0] = t0 * (i0 < kAecPart ? K.hanning[i0] : K.hanning[2 * kAecPart - i0]);
+                    fa[2 * j + 1][i1] = t1 * (i1 < kAecPart ? K.hanning[i1] : K.hanning[2 * kAecPart - i1]);
                 }
                 wave_sync();
 #ifndef WMX_AEC_EXP_NOFARFFT  // (timing experiment: what the far kernel costs without its transforms)
                 // group `grp` transforms row `grp` (a row without a live block behind it is transformed too -- the exchanges between the
-                // lanes of a group want every lane there -- and nobody reads the result)
+                // lanes of a group want every lane there -- and nobody reads the result).  In place: every lane has read its four input
+                // points before any lane stores a result (one wave, one instruction stream, LDS operations in order)
                 aec_fft_fwd(fa[grp], &K.tab, gl, [&](int p) {
-                    const v2f c = ld_pt(tin[grp], p);
+                    const v2f c = ld_pt(fa[grp], p);
                     return Cx{c.x, c.y};
                 });
 #endif
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(64) void aec_far_kernel(AecFarBufs F_all, const flo
                     }
                     xpow_dirty = true;
                 }
-                wave_sync();  // tin[] / fa[] are free for the next pair
+                wave_sync();  // fa[] is free for the next pair
             }
         }
     }
