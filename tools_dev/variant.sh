@@ -19,7 +19,7 @@ case $cmd in
   build)
     name=${1:?name}; flags=${2-}
     mkdir -p $B/obj_$name
-    make -s -j 8 -C $R/wmix_amd/csrc OUT=$B/lib_$name.so OBJDIR=$B/obj_$name EXTRA="$flags"
+    make -s -j 4 -C $R/wmix_amd/csrc OUT=$B/lib_$name.so OBJDIR=$B/obj_$name EXTRA="$flags"
     echo "built $B/lib_$name.so: $(WMIX_AMD_ALLOW_VARIANT_BUILD=1 WMIX_AMD_LIB=$B/lib_$name.so python -c 'from wmix_amd import _lib; print(_lib.build_info())')"
     ;;
   ab)
