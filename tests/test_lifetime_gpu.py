@@ -555,3 +555,35 @@ def test_tick_switches(cuda):
     tb.close()
     tb0 = TickBatch(2, 1, stages=0)  # a tick may be MADE without stages too
     tb0.close()
+
+
+def test_switches_between_the_float_and_the_fixed_point_builds(cuda, oracle_port):
+    """wmx_chain_set_stages also moves a stage between its two builds (the reference: MAKE_WEBRTC_NSX, src/webrtc.c:512-521; the AECM
+    switch, :168-191): the one that goes is released, the other starts fresh; the AGC in the middle keeps its state throughout."""
+    import torch
+    from wmix_amd.chain import AEC, AECM, AGC, NS, NSX, ChainBatch
+    freq, pkt, S = 16000, 160, 3
+    plan = [(NS | NSX | AGC, 40), (NS | AGC, 50), (NS | NSX | AEC | AECM | AGC, 60)]
+    T = sum(n for _, n in plan)
+    far = synth.far_end(9950, T, pkt).reshape(T, pkt)
+    near = synth.near_end(9951, S, T, pkt, far=far.reshape(-1)).reshape(S, T, pkt)
+    ch = ChainBatch(S, 1, freq, 10, 5, stages=plan[0][0])
+    d, dfar = torch.from_numpy(near.copy()).to(cuda), torch.from_numpy(far).to(cuda)
+    t = 0
+    for i, (stages, n) in enumerate(plan):
+        if i:
+            ch.set_stages(stages)
+        for _ in range(n):
+            rc, _, _ = ch.process(dfar[t:t + 1], d[:, t:t + 1])
+            assert rc == 0
+            t += 1
+    got = d.cpu().numpy()
+    ch.close()
+    for s in range(S):
+        y = near[s].copy()
+        y[0:40] = L.run_nsx(oracle_port, 1, freq, y[0:40].reshape(-1), pkt, prefix="orc").reshape(-1, pkt)
+        y[40:90] = L.run_ns(oracle_port, 1, freq, y[40:90].reshape(-1), pkt, prefix="orc").reshape(-1, pkt)
+        y[90:150] = L.run_nsx(oracle_port, 1, freq, y[90:150].reshape(-1), pkt, prefix="orc").reshape(-1, pkt)
+        y[90:150] = L.run_aecm(oracle_port, 1, freq, 10, far[90:150].reshape(-1), y[90:150].reshape(-1), pkt, prefix="orc").reshape(-1, pkt)
+        y[:] = L.run_agc(oracle_port, 1, freq, 5, y.reshape(-1), pkt, prefix="orc").reshape(-1, pkt)
+        assert np.array_equal(got[s], y), (s, int(np.argmax((got[s] != y).any(axis=1))))
