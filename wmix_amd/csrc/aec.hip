@@ -1237,6 +1237,9 @@ __global__ __attribute__((amdgpu_waves_per_eu(WMX_AEC_WAVES, WMX_AEC_WAVES))) __
             }
     }
     // filter taps straight into registers (256-byte rows), the rest as one contiguous block, later parked in LDS
+    // (tried in round 6: the state -- read once, written once per launch -- as NON-TEMPORAL accesses, so that it would not push the
+    // far-end history rows, which are re-read, out of the L2 when every stream has its own far-end: no change at either end,
+    // profiles/r06/sweeps/ab_nt_state.txt)
     AecTaps taps;
 #pragma unroll
     for (int p = 0; p < 12; p++) {
