@@ -16,7 +16,7 @@
  * `keep` ticks and written to --dump for the parity check (tests/test_paced_host_gpu.py replays them through the oracle).
  *
  *   host_paced --streams S [--sub 32768] [--slots 4] [--tick-ms 20] [--ticks 1500] [--prime 150] [--kind pcm|rtp] [--freq 16000]
- *              [--interval-ms 20] [--phases 1] [--spin 0] [--pattern file --n-pattern 256] [--dump file --keep 32 --sample a,b,c] [--lat file]
+ *              [--interval-ms 20] [--phases 1] [--spin 0] [--rt-prio 0] [--pattern file --n-pattern 256] [--dump file --keep 32 --sample a,b,c] [--lat file]
  *
  * --phases P > 1: the streams of a server do not all deliver their package at the same instant.  P groups of S / P streams (one
  * wmx_rt each), group g released at t0 + (k * P + g) * tick_ms / P with the whole tick as its period and tick_ms - 2 ms as its budget:
@@ -31,10 +31,12 @@
  */
 #define _POSIX_C_SOURCE 200809L
 #include <math.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <time.h>
 #include "wmix_amd.h"
 
@@ -94,6 +96,18 @@ int main(int argc, char **argv) {
         return 2;
     }
     if (keep > ticks) keep = ticks;
+    /* --rt-prio N: what a real-time host does about late wake-ups -- SCHED_FIFO at priority N and its pages locked.  Needs
+     * CAP_SYS_NICE / an rtprio limit; where the box refuses, the run goes on in the ordinary class and the line says so */
+    const int rt_prio = atoi(arg_of(argc, argv, "--rt-prio", "0"));
+    int rt_granted = 0;
+    if (rt_prio > 0) {
+        struct sched_param sp;
+        memset(&sp, 0, sizeof(sp));
+        sp.sched_priority = rt_prio;
+        rt_granted = sched_setscheduler(0, SCHED_FIFO, &sp) == 0;
+        if (rt_granted) (void)mlockall(MCL_CURRENT | MCL_FUTURE);
+        else perror("host_paced: sched_setscheduler(SCHED_FIFO)");
+    }
     const unsigned stages = WMX_CHAIN_NS | WMX_CHAIN_AEC | WMX_CHAIN_AGC | WMX_CHAIN_VAD;
     const int rtp = !strcmp(kind, "rtp");
     wmx_rt *rt[MAX_PHASES] = {0};
@@ -257,8 +271,9 @@ int main(int argc, char **argv) {
     printf("{\"host\": \"examples/host_paced.c\", \"kind\": \"%s\", \"streams\": %ld, \"phases\": %d, \"sub_batch\": %d, \"sub_batches\": %d, \"slots\": %d, "
            "\"row_bytes\": %zu, \"tick_ms\": %.3f, \"budget_ms\": %.3f, \"ticks\": %d, \"group_ticks\": %d, \"primed_ticks\": %d, \"p50_ms\": %.4f, \"p99_ms\": %.4f, "
            "\"p99_9_ms\": %.4f, \"max_ms\": %.4f, \"misses\": %d, \"overruns_of_the_period\": %d, \"release_lag_p50_ms\": %.4f, \"release_lag_max_ms\": %.4f, "
-           "\"worst_tick\": %d, \"failed_steps\": %ld, \"kept_ticks\": %d, \"rc\": %d}\n",
+           "\"worst_tick\": %d, \"failed_steps\": %ld, \"kept_ticks\": %d, \"sched_fifo\": %s, \"rc\": %d}\n",
            kind, S, P, sub, n_sub, slots, row, tick_ms, budget, ticks, total, prime, quantile(lat, total, 0.5), quantile(lat, total, 0.99),
-           quantile(lat, total, 0.999), worst_ms, misses, overruns, quantile(lag, total, 0.5), lag_max, worst / P, failed, dump ? keep : 0, rc);
+           quantile(lat, total, 0.999), worst_ms, misses, overruns, quantile(lag, total, 0.5), lag_max, worst / P, failed, dump ? keep : 0,
+           rt_prio > 0 ? (rt_granted ? "true" : "\"refused\"") : "false", rc);
     return rc ? 1 : 0;
 }
