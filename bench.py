@@ -1353,7 +1353,7 @@ WORKLOADS["stub_cpu"] = (StubCpuWorkload, 4)
 PACED_KINDS = {"pcm16k": ("pcm", 16000), "pcm8k": ("pcm", 8000), "rtp8k": ("rtp", 8000)}
 
 
-def paced_pattern(kind, slots, interval_ms=20, n_pattern=256, seed=7000):
+def paced_pattern(kind, slots, interval_ms=20, n_pattern=256, seed=7000, n_far=1):
     """The rows a paced run works on: `slots` consecutive ticks of n_pattern distinct streams (SURVEY 8d recipe: near = echo of the shared
     far-end + noise + gated tone), which the slots hold for the whole run -- tick t works on pattern slot t % slots.  Returns
     (far int16 [slots, far_samples], rows [slots, n_pattern, row]): int16 packages for "pcm", uint8 RTP/PCMA datagrams for "rtp"
@@ -1361,6 +1361,12 @@ def paced_pattern(kind, slots, interval_ms=20, n_pattern=256, seed=7000):
     from wmix_amd import synth
     form, freq = PACED_KINDS[kind]
     pkt, ppc = freq // 100, (interval_ms // 10 if form == "pcm" else 2)
+    if n_far > 1:  # a far-end per stream ("calls"): n_far distinct far signals, near row r is the echo of far signal r % n_far
+        assert form == "pcm" and n_pattern % n_far == 0
+        fars = np.stack([synth.far_end(seed + 101 * u, slots * ppc, pkt) for u in range(n_far)])
+        near = np.stack([synth.near_end(seed + 1 + 7919 * r, 1, slots * ppc, pkt, far=fars[r % n_far])[0] for r in range(n_pattern)])
+        pcm = np.ascontiguousarray(near.reshape(n_pattern, slots, ppc * pkt).transpose(1, 0, 2))
+        return np.ascontiguousarray(fars.reshape(n_far, slots, ppc * pkt).transpose(1, 0, 2)), pcm  # far [slots, n_far, package]
     far = synth.far_end(seed, slots * ppc, pkt)
     near = synth.near_end(seed + 1, n_pattern, slots * ppc, pkt, far=far).reshape(n_pattern, slots, ppc * pkt)
     pcm = np.ascontiguousarray(near.transpose(1, 0, 2))  # [slots, n_pattern, package]
@@ -1383,7 +1389,7 @@ def paced_replay(kind, far, rows, pattern_row, n_ticks, interval_ms=20):
     form, freq = PACED_KINDS[kind]
     slots = rows.shape[0]
     t = np.arange(n_ticks) % slots
-    far_seq = np.ascontiguousarray(far[t]).reshape(-1)
+    far_seq = np.ascontiguousarray(far[t] if far.ndim == 2 else far[t, pattern_row % far.shape[1]]).reshape(-1)
     if form == "pcm":
         near = np.ascontiguousarray(rows[t, pattern_row]).reshape(-1)
         pkg = freq // 100 * (interval_ms // 10)

@@ -16,14 +16,14 @@
  * `keep` ticks and written to --dump for the parity check (tests/test_paced_host_gpu.py replays them through the oracle).
  *
  *   host_paced --streams S [--sub 32768] [--slots 4] [--tick-ms 20] [--ticks 1500] [--prime 150] [--kind pcm|rtp] [--freq 16000]
- *              [--interval-ms 20] [--phases 1] [--spin 0] [--rt-prio 0] [--pattern file --n-pattern 256] [--dump file --keep 32 --sample a,b,c] [--lat file]
+ *              [--interval-ms 20] [--phases 1] [--calls 0 [--n-far 16]] [--spin 0] [--rt-prio 0] [--pattern file --n-pattern 256] [--dump file --keep 32 --sample a,b,c] [--lat file]
  *
  * --phases P > 1: the streams of a server do not all deliver their package at the same instant.  P groups of S / P streams (one
  * wmx_rt each), group g released at t0 + (k * P + g) * tick_ms / P with the whole tick as its period and tick_ms - 2 ms as its budget:
  * wmx_rt_submit at the release, wmx_rt_poll between releases (a completion is seen within microseconds).  The device then works in P
  * short bursts per period and never idles long enough for its power management to clock it down (profiles/r06/README_paced.md).
  *
- * pattern file: int16 far [slots][far_samples], then rows [slots][n_pattern][row_bytes] (row_bytes from the library).
+ * pattern file: int16 far [slots][n_far][far_samples] (n_far = 1 without --calls), then rows [slots][n_pattern][row_bytes] (row_bytes from the library).
  * dump file:    rows [keep][n_sample][row_bytes] of the last `keep` ticks.     lat / lag file (--lag): double latency_ms / release_lag_ms [ticks * phases].
  *
  * Build (what __graft_entry__.build() runs):
@@ -85,13 +85,16 @@ int main(int argc, char **argv) {
     const char *kind = arg_of(argc, argv, "--kind", "pcm");
     const int freq = atoi(arg_of(argc, argv, "--freq", "16000")), interval_ms = atoi(arg_of(argc, argv, "--interval-ms", "20"));
     const int P = atoi(arg_of(argc, argv, "--phases", "1"));
+    /* --calls 1: every stream hears a far-end of its own (wmx_rt_create_pcm_calls: aec_process2's far-end is per handle); the pattern
+     * file then carries n_far far-end signals per slot and stream s hears number (s % n_pattern) % n_far */
+    const int calls = atoi(arg_of(argc, argv, "--calls", "0")), n_far = calls ? atoi(arg_of(argc, argv, "--n-far", "16")) : 1;
     const char *pattern = arg_of(argc, argv, "--pattern", NULL), *dump = arg_of(argc, argv, "--dump", NULL), *latf = arg_of(argc, argv, "--lat", NULL), *lagf = arg_of(argc, argv, "--lag", NULL);
     const int n_pattern = atoi(arg_of(argc, argv, "--n-pattern", "256"));
     int keep = atoi(arg_of(argc, argv, "--keep", "32"));
     const char *sample_s = arg_of(argc, argv, "--sample", "0");
     /* --spin 1: never sleep between ticks, spin on the clock (a core burnt for the sake of never being woken up late) */
     const int64_t spin_ns = atoi(arg_of(argc, argv, "--spin", "0")) ? (int64_t)1 << 60 : 200000;
-    if (S < 1 || ticks < 1 || tick_ms <= 2.0 || slots < 1 || n_pattern < 1 || P < 1 || P > MAX_PHASES || S < P) {
+    if (S < 1 || ticks < 1 || tick_ms <= 2.0 || slots < 1 || n_pattern < 1 || P < 1 || P > MAX_PHASES || S < P || n_far < 1) {
         fprintf(stderr, "usage: %s --streams S [--sub N] [--slots N] [--tick-ms T] [--ticks N] [--prime N] [--kind pcm|rtp] [--phases P] ...\n", argv[0]);
         return 2;
     }
@@ -116,7 +119,9 @@ int main(int argc, char **argv) {
     for (int g = 0; g <= P; g++) lo_of[g] = S * g / P; /* group g = streams [lo_of[g], lo_of[g + 1]) */
     for (int g = 0; g < P && rc == 0; g++) {
         const long n = lo_of[g + 1] - lo_of[g];
-        rc = rtp ? wmx_rt_create_rtp(&rt[g], n, sub, slots, WMX_LAW_A, 5, stages) : wmx_rt_create_pcm(&rt[g], n, sub, slots, 1, freq, interval_ms, 5, stages);
+        rc = rtp ? wmx_rt_create_rtp(&rt[g], n, sub, slots, WMX_LAW_A, 5, stages)
+                 : (calls ? wmx_rt_create_pcm_calls(&rt[g], n, sub, slots, 1, freq, interval_ms, 5, stages)
+                          : wmx_rt_create_pcm(&rt[g], n, sub, slots, 1, freq, interval_ms, 5, stages));
         if (rc == 0) n_sub += wmx_rt_batches(rt[g]);
     }
     if (rc != 0) {
@@ -128,7 +133,7 @@ int main(int argc, char **argv) {
     /* the slots' rows: the pattern, tiled (stream s of the whole server gets pattern row s % n_pattern) */
     if (pattern) {
         FILE *f = fopen(pattern, "rb");
-        const size_t far_bytes = (size_t)slots * far_n * 2, rows_bytes = (size_t)slots * (size_t)n_pattern * row;
+        const size_t far_bytes = (size_t)slots * (size_t)n_far * far_n * 2, rows_bytes = (size_t)slots * (size_t)n_pattern * row;
         uint8_t *buf = malloc(far_bytes + rows_bytes);
         if (!f || !buf || fread(buf, 1, far_bytes + rows_bytes, f) != far_bytes + rows_bytes) {
             fprintf(stderr, "host_paced: cannot read %zu bytes of %s\n", far_bytes + rows_bytes, pattern);
@@ -137,13 +142,17 @@ int main(int argc, char **argv) {
         fclose(f);
         for (int g = 0; g < P; g++)
             for (int k = 0; k < slots; k++) {
-                memcpy(wmx_rt_far(rt[g], k), buf + (size_t)k * far_n * 2, far_n * 2);
+                if (!calls) memcpy(wmx_rt_far(rt[g], k), buf + (size_t)k * far_n * 2, far_n * 2);
                 long s = lo_of[g];
                 for (int b = 0; b < wmx_rt_batches(rt[g]); b++) {
                     uint8_t *dst = wmx_pipe_in(wmx_rt_pipe(rt[g], b), k);
+                    uint8_t *fdst = (uint8_t *)wmx_pipe_far(wmx_rt_pipe(rt[g], b), k);
                     const int nb = wmx_rt_batch_streams(rt[g], b);
-                    for (int r = 0; r < nb; r++, s++)
+                    for (int r = 0; r < nb; r++, s++) {
                         memcpy(dst + (size_t)r * row, buf + far_bytes + ((size_t)k * (size_t)n_pattern + (size_t)(s % n_pattern)) * row, row);
+                        if (calls)
+                            memcpy(fdst + (size_t)r * far_n * 2, buf + ((size_t)k * (size_t)n_far + (size_t)((s % n_pattern) % n_far)) * far_n * 2, far_n * 2);
+                    }
                 }
             }
         free(buf);
@@ -268,11 +277,11 @@ int main(int argc, char **argv) {
     const double worst_ms = lat[worst];
     qsort(lat, (size_t)total, sizeof(double), cmp_double);
     qsort(lag, (size_t)total, sizeof(double), cmp_double);
-    printf("{\"host\": \"examples/host_paced.c\", \"kind\": \"%s\", \"streams\": %ld, \"phases\": %d, \"sub_batch\": %d, \"sub_batches\": %d, \"slots\": %d, "
+    printf("{\"host\": \"examples/host_paced.c\", \"kind\": \"%s\", \"far_end_per_stream\": %s, \"streams\": %ld, \"phases\": %d, \"sub_batch\": %d, \"sub_batches\": %d, \"slots\": %d, "
            "\"row_bytes\": %zu, \"tick_ms\": %.3f, \"budget_ms\": %.3f, \"ticks\": %d, \"group_ticks\": %d, \"primed_ticks\": %d, \"p50_ms\": %.4f, \"p99_ms\": %.4f, "
            "\"p99_9_ms\": %.4f, \"max_ms\": %.4f, \"misses\": %d, \"overruns_of_the_period\": %d, \"release_lag_p50_ms\": %.4f, \"release_lag_max_ms\": %.4f, "
            "\"worst_tick\": %d, \"failed_steps\": %ld, \"kept_ticks\": %d, \"sched_fifo\": %s, \"rc\": %d}\n",
-           kind, S, P, sub, n_sub, slots, row, tick_ms, budget, ticks, total, prime, quantile(lat, total, 0.5), quantile(lat, total, 0.99),
+           kind, calls ? "true" : "false", S, P, sub, n_sub, slots, row, tick_ms, budget, ticks, total, prime, quantile(lat, total, 0.5), quantile(lat, total, 0.99),
            quantile(lat, total, 0.999), worst_ms, misses, overruns, quantile(lag, total, 0.5), lag_max, worst / P, failed, dump ? keep : 0,
            rt_prio > 0 ? (rt_granted ? "true" : "\"refused\"") : "false", rc);
     return rc ? 1 : 0;

@@ -488,6 +488,11 @@ int wmx_pipe_create(wmx_pipe **out, int n_streams, int slots, int law, int agc_v
  * there is no ingest / egress, the chain (made with chn, freq, interval_ms, agc_value, stages) runs in place on the uploaded rows.
  * wmx_pipe_step_resident on such a pipe wants in_stride == out_stride. */
 int wmx_pipe_create_pcm(wmx_pipe **out, int n_streams, int slots, int chn, int freq, int interval_ms, int agc_value, unsigned stages);
+/* The same for CALLS: every stream hears a far-end of its own, as every handle of the reference does (aec_process2(fp, far, near, ..),
+ * src/webrtc.c:410-483; the far-end of a call is the other party).  wmx_pipe_far(h, slot) then is n_streams rows of one package each
+ * (stream-major like the near rows), and so is d_far of wmx_pipe_submit / wmx_pipe_step_resident.  Every stream is a control cohort
+ * with a far-end history of its own (122 KB of device memory); the float canceller must be among the stages. */
+int wmx_pipe_create_pcm_calls(wmx_pipe **out, int n_streams, int slots, int chn, int freq, int interval_ms, int agc_value, unsigned stages);
 int wmx_pipe_destroy(wmx_pipe *h);
 int wmx_pipe_slots(const wmx_pipe *h);
 int wmx_pipe_datagram_bytes(const wmx_pipe *h);
@@ -538,6 +543,9 @@ wmx_rtp *wmx_pipe_senders(wmx_pipe *h);
 typedef struct wmx_rt wmx_rt;
 int wmx_rt_create_pcm(wmx_rt **out, long n_streams, int sub_batch, int slots, int chn, int freq, int interval_ms, int agc_value, unsigned stages);
 int wmx_rt_create_rtp(wmx_rt **out, long n_streams, int sub_batch, int slots, int law, int agc_value, unsigned stages);
+/* calls: every stream its own far-end (wmx_pipe_create_pcm_calls); the far rows of sub-batch b are wmx_pipe_far(wmx_rt_pipe(h, b), slot),
+ * a d_far on the device holds all n_streams rows (wmx_rt_far is sub-batch 0's) */
+int wmx_rt_create_pcm_calls(wmx_rt **out, long n_streams, int sub_batch, int slots, int chn, int freq, int interval_ms, int agc_value, unsigned stages);
 int wmx_rt_destroy(wmx_rt *h);
 /* sub-batch b on the library's own compute stream b % n (n = 1, the default: all on the caller's stream, one behind the other; n >= 2:
  * forked from the caller's stream per tick and joined to it again, so that the tail of one sub-batch's kernels overlaps the head of the

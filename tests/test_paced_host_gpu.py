@@ -17,13 +17,14 @@ pytestmark = pytest.mark.gpu
 HOST = os.path.join(ROOT, "examples", "host_paced")
 
 
-@pytest.mark.parametrize("kind,tick_ms,freq,interval_ms,phases", [("pcm16k", 20, 16000, 20, 1), ("pcm16k", 10, 16000, 10, 1), ("rtp8k", 20, 8000, 20, 1),
-                                                                  ("pcm16k", 20, 16000, 20, 3), ("rtp8k", 20, 8000, 20, 4)])
-def test_host_paced_meets_the_budget_and_the_oracle(cuda, tmp_path, kind, tick_ms, freq, interval_ms, phases):
+@pytest.mark.parametrize("kind,tick_ms,freq,interval_ms,phases,calls", [("pcm16k", 20, 16000, 20, 1, 0), ("pcm16k", 10, 16000, 10, 1, 0), ("rtp8k", 20, 8000, 20, 1, 0),
+                                                                        ("pcm16k", 20, 16000, 20, 3, 0), ("rtp8k", 20, 8000, 20, 4, 0),
+                                                                        ("pcm16k", 20, 16000, 20, 2, 1)])  # calls: a far-end per stream
+def test_host_paced_meets_the_budget_and_the_oracle(cuda, tmp_path, kind, tick_ms, freq, interval_ms, phases, calls):
     import bench
     assert os.path.exists(HOST), "examples/host_paced is built by __graft_entry__.build()"
     S, sub, slots, ticks, prime, keep, n_pat = 3000, 1024, 4, 120, 90, 16, 64
-    far, rows = bench.paced_pattern(kind, slots, interval_ms, n_pattern=n_pat)
+    far, rows = bench.paced_pattern(kind, slots, interval_ms, n_pattern=n_pat, n_far=16 if calls else 1)
     pat = tmp_path / "pattern.bin"
     with open(pat, "wb") as f:
         f.write(np.ascontiguousarray(far).tobytes())
@@ -32,11 +33,11 @@ def test_host_paced_meets_the_budget_and_the_oracle(cuda, tmp_path, kind, tick_m
     dump, lat = tmp_path / "dump.bin", tmp_path / "lat.f64"
     cmd = [HOST, "--streams", str(S), "--sub", str(sub), "--slots", str(slots), "--tick-ms", str(tick_ms), "--ticks", str(ticks), "--prime", str(prime),
            "--kind", "rtp" if kind == "rtp8k" else "pcm", "--freq", str(freq), "--interval-ms", str(interval_ms), "--pattern", str(pat), "--n-pattern",
-           str(n_pat), "--dump", str(dump), "--keep", str(keep), "--sample", ",".join(map(str, sample)), "--lat", str(lat), "--phases", str(phases)]
+           str(n_pat), "--dump", str(dump), "--keep", str(keep), "--sample", ",".join(map(str, sample)), "--lat", str(lat), "--phases", str(phases), "--calls", str(calls), "--n-far", "16"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     d = json.loads(r.stdout.strip().splitlines()[-1])
-    assert d["ticks"] == ticks and d["group_ticks"] == ticks * phases and d["sub_batches"] == (3 if phases <= 3 else 4) and d["failed_steps"] == 0 and d["rc"] == 0
+    assert d["ticks"] == ticks and d["group_ticks"] == ticks * phases and d["sub_batches"] == {1: 3, 2: 4, 3: 3, 4: 4}[phases] and d["failed_steps"] == 0 and d["far_end_per_stream"] == bool(calls) and d["rc"] == 0
     assert d["budget_ms"] == tick_ms - 2 and d["misses"] <= 3, d  # (a late wake-up or two of a shared test box are not the library's: DESIGN.md 5a)
     lat_ms = np.fromfile(lat, np.float64)
     assert lat_ms.size == ticks * phases and abs(np.percentile(lat_ms, 50) - d["p50_ms"]) < 1e-3

@@ -150,8 +150,9 @@ def _child(kind):
 
 @pytest.mark.parametrize("kind", ["pcm", "rtp"])
 def test_every_fallible_call_of_a_submit(cuda, kind):
-    if not os.path.exists(VARIANT):  # __graft_entry__.build() makes it; a tree that was not built that way gets it here (a minute of hipcc)
-        subprocess.run([os.path.join(ROOT, "tools_dev", "variant.sh"), "build", "faults", "-DWMX_FAULT_INJECTION"], timeout=1500, capture_output=True)
+    # __graft_entry__.build() makes it; `make` brings it up to date when a source has changed since (nothing to do otherwise, a minute of
+    # hipcc if the tree was not built that way at all)
+    subprocess.run([os.path.join(ROOT, "tools_dev", "variant.sh"), "build", "faults", "-DWMX_FAULT_INJECTION"], timeout=1500, capture_output=True)
     assert os.path.exists(VARIANT), "tools_dev/build/lib_faults.so is built by __graft_entry__.build() (tools_dev/variant.sh build faults -DWMX_FAULT_INJECTION)"
     env = dict(os.environ, WMIX_AMD_LIB=VARIANT, WMIX_AMD_ALLOW_VARIANT_BUILD="1", PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, "tests"))
     r = subprocess.run([sys.executable, os.path.abspath(__file__), kind], capture_output=True, text=True, timeout=900, env=env)

@@ -131,3 +131,38 @@ def test_paced_loop_small(cuda, oracle_port):
     for col, st in enumerate(sample):
         assert np.array_equal(got[:, col].reshape(-1), want[st % 8])
     assert s["ticks"] == n and s["misses"] <= 3, s  # (a late wake-up or two of a shared test box are not the library's: DESIGN.md 5a)
+
+
+@pytest.mark.parametrize("freq,interval_ms,sub,slots", [(16000, 20, 5, 2), (8000, 20, 16, 1), (16000, 10, 3, 3)])
+def test_rt_calls_every_stream_its_own_far_end(cuda, oracle_port, freq, interval_ms, sub, slots):
+    """wmx_rt_create_pcm_calls: every stream hears a far-end of its own, like every handle of the reference (aec_process2(fp, far, near, ..),
+    src/webrtc.c:410-483) -- far rows beside the near rows, from host memory (uploaded per sub-batch) and from the device, streamed and
+    resident: every stream against an oracle handle fed ITS far-end."""
+    from wmix_amd.realtime import RtBatch
+    S, n = 13, 80
+    pkt10, ppc = freq // 100, interval_ms // 10
+    fars = np.stack([synth.far_end(9600 + 7 * s, n * ppc, pkt10) for s in range(S)])                          # [S, n * package]
+    near = np.stack([synth.near_end(9700 + s, 1, n * ppc, pkt10, far=fars[s])[0] for s in range(S)])
+    want = np.stack([L.run_chain(oracle_port, 1, freq, 5, 15, fars[s], near[s], pkt10 * ppc, prefix="orc", interval_ms=interval_ms) for s in range(S)])
+    rows = np.ascontiguousarray(near.reshape(S, n, pkt10 * ppc).transpose(1, 0, 2))                         # [n, S, package]
+    frows = np.ascontiguousarray(fars.reshape(S, n, pkt10 * ppc).transpose(1, 0, 2))
+    dfar = torch.from_numpy(frows).to(cuda)
+    rt = RtBatch(S, cuda, sub_batch=sub, slots=slots, kind="pcm", chn=1, freq=freq, interval_ms=interval_ms, far_rows=True)
+    got = np.zeros_like(rows)
+    for k in range(n):
+        slot = k % slots
+        rt.fill(slot, rows[k])
+        if k % 2:
+            rt.fill_far(slot, frows[k])
+            assert rt.tick(None) == slot
+        else:
+            assert rt.tick(dfar[k]) == slot
+        got[k] = rt.gather(slot)
+    rt.close()
+    assert np.array_equal(got.transpose(1, 0, 2).reshape(S, -1), want)
+    rt2 = RtBatch(S, cuda, sub_batch=sub, slots=1, kind="pcm", chn=1, freq=freq, interval_ms=interval_ms, far_rows=True)
+    d = torch.from_numpy(rows).to(cuda)
+    for k in range(n):
+        rt2.step_resident(d[k], dfar[k])
+    rt2.close()
+    assert np.array_equal(d.cpu().numpy(), got)

@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--slots", type=int, default=4)
     ap.add_argument("--keep", type=int, default=24)
     ap.add_argument("--stop-at-miss", action="store_true")
+    ap.add_argument("--calls", type=int, default=0, help="1: every stream hears a far-end of its own (wmx_rt_create_pcm_calls), 16 distinct far signals")
     ap.add_argument("--rt-prio", type=int, default=0, help="host_paced asks for SCHED_FIFO at this priority (and mlockall); the line says whether it got it")
     ap.add_argument("--spin", type=int, default=0, help="1: host_paced never sleeps between ticks (spins on the clock)")
     ap.add_argument("--out", default="")
@@ -106,7 +107,7 @@ def main():
     form, freq = bench.PACED_KINDS[a.kind]
     interval_ms = a.interval_ms or int(a.tick_ms)
     n_pat = 256
-    far, rows = bench.paced_pattern(a.kind, a.slots, interval_ms, n_pattern=n_pat)
+    far, rows = bench.paced_pattern(a.kind, a.slots, interval_ms, n_pattern=n_pat, n_far=16 if a.calls else 1)
     tmp = tempfile.mkdtemp(prefix="paced_")
     pat = os.path.join(tmp, "pattern.bin")
     with open(pat, "wb") as f:
@@ -118,7 +119,7 @@ def main():
         dump, lat, lag = os.path.join(tmp, "dump.bin"), os.path.join(tmp, "lat.f64"), os.path.join(tmp, "lag.f64")
         cmd = [host, "--streams", str(S), "--sub", str(a.sub), "--slots", str(a.slots), "--tick-ms", str(a.tick_ms), "--ticks", str(a.ticks), "--prime",
                str(a.prime), "--kind", form, "--freq", str(freq), "--interval-ms", str(interval_ms), "--phases", str(a.phases), "--pattern", pat,
-               "--n-pattern", str(n_pat), "--dump", dump, "--keep", str(a.keep), "--sample", ",".join(map(str, sample)), "--lat", lat, "--lag", lag, "--spin", str(a.spin), "--rt-prio", str(a.rt_prio)]
+               "--n-pattern", str(n_pat), "--dump", dump, "--keep", str(a.keep), "--sample", ",".join(map(str, sample)), "--lat", lat, "--lag", lag, "--spin", str(a.spin), "--rt-prio", str(a.rt_prio), "--calls", str(a.calls), "--n-far", "16"]
         watch = DeviceWatch().start()
         r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)  # stderr passes through: a long run reports twice a minute
         device = watch.stop()

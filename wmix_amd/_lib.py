@@ -147,6 +147,10 @@ def _declare(L):
     L.wmx_pipe_create.argtypes = [C.POINTER(vp), i, i, i, i, C.c_uint]
     L.wmx_pipe_create_pcm.restype = i
     L.wmx_pipe_create_pcm.argtypes = [C.POINTER(vp), i, i, i, i, i, i, C.c_uint]
+    L.wmx_pipe_create_pcm_calls.restype = i
+    L.wmx_pipe_create_pcm_calls.argtypes = [C.POINTER(vp), i, i, i, i, i, i, C.c_uint]
+    L.wmx_rt_create_pcm_calls.restype = i
+    L.wmx_rt_create_pcm_calls.argtypes = [C.POINTER(vp), C.c_long, i, i, i, i, i, i, C.c_uint]
     L.wmx_pipe_destroy.restype = i
     L.wmx_pipe_destroy.argtypes = [vp]
     L.wmx_pipe_slots.restype = i

@@ -59,7 +59,7 @@ int wmx_pipe_destroy(wmx_pipe *h) {
 }  // extern "C"
 
 int wmx::pipe_make(wmx_pipe **out, int n_streams, int slots, bool pcm, int law, int chn, int freq, int interval_ms, int agc_value,
-                   unsigned stages, hipStream_t shared_in, hipStream_t shared_out) {
+                   unsigned stages, hipStream_t shared_in, hipStream_t shared_out, bool far_rows) {
     wmx_pipe *h = new wmx_pipe();
     if ((h->device = wmx::current_device()) < 0) {
         delete h;
@@ -68,6 +68,7 @@ int wmx::pipe_make(wmx_pipe **out, int n_streams, int slots, bool pcm, int law, 
     h->n_streams = n_streams;
     h->slots = slots;
     h->pcm = pcm;
+    h->far_rows = far_rows && pcm;
     h->pkt10 = freq / 100 * chn;
     h->ppc = interval_ms / 10;
     h->row_bytes = pcm ? h->pkt10 * h->ppc * 2 : kDatagram;
@@ -80,10 +81,20 @@ int wmx::pipe_make(wmx_pipe **out, int n_streams, int slots, bool pcm, int law, 
     h->s_out = shared_out;
     h->slot.assign((size_t)slots, wmx_pipe::Slot{});
     // the RTP edge hands the heartbeat 10 ms packets (two per datagram); a PCM host hands it whole packages like the daemon does
-    int rc = wmx_chain_create(&h->chain, n_streams, chn, freq, pcm ? interval_ms : 10, agc_value, stages, 1);
+    int rc;
+    if (h->far_rows) {
+        // aec_process2(fp, far, near, ..) takes the far-end per handle (src/webrtc.c:410-483): every stream a control cohort and a far-end
+        // history of its own (122 KB each); cohorts made together share one host control plane (aec_ctl.h classes)
+        std::vector<int32_t> own((size_t)n_streams);
+        for (int i = 0; i < n_streams; i++) own[(size_t)i] = i;
+        rc = wmx_chain_create_groups(&h->chain, n_streams, chn, freq, interval_ms, agc_value, stages, n_streams, own.data());
+    } else {
+        rc = wmx_chain_create(&h->chain, n_streams, chn, freq, pcm ? interval_ms : 10, agc_value, stages, 1);
+    }
     if (rc == 0 && !pcm) rc = wmx_rtp_create(&h->snd, n_streams, law);
     hipError_t e = hipSuccess;
-    const size_t bytes = (size_t)n_streams * (size_t)h->row_bytes, far_bytes = (size_t)h->far_samples * sizeof(int16_t);
+    const size_t bytes = (size_t)n_streams * (size_t)h->row_bytes;
+    const size_t far_bytes = (size_t)h->far_samples * sizeof(int16_t) * (h->far_rows ? (size_t)n_streams : 1);
     if (rc == 0) {
         if (!pcm) {
             e = hipMalloc(&h->d_pcm, (size_t)n_streams * 2 * kPkt10 * sizeof(int16_t));
@@ -147,6 +158,21 @@ int wmx_pipe_create_pcm(wmx_pipe **out, int n_streams, int slots, int chn, int f
     return wmx::pipe_make(out, n_streams, slots, true, 0, chn, freq, interval_ms, agc_value, stages, nullptr, nullptr);
 }
 
+// The same for CALLS: every stream hears a far-end of its own, as every handle of the reference does (aec_process2(fp, far, near, ..),
+// src/webrtc.c:410-483; in a telephony server the far-end of a call is the other party).  wmx_pipe_far(h, slot) then is n_streams rows of
+// one package each (stream-major like the near rows), d_far of wmx_pipe_submit / _step_resident likewise.
+int wmx_pipe_create_pcm_calls(wmx_pipe **out, int n_streams, int slots, int chn, int freq, int interval_ms, int agc_value, unsigned stages) {
+    if (!out) return WMX_EINVAL;
+    *out = nullptr;
+    if (n_streams < 1 || slots < 1 || slots > 16 || (chn != 1 && chn != 2) || freq < 8000 || freq % 100 || interval_ms < 10 || interval_ms % 10 ||
+        interval_ms > 100 || !(stages & WMX_CHAIN_AEC) || (stages & WMX_CHAIN_AECM)) {
+        wmx::set_error("wmx_pipe_create_pcm_calls: n_streams=%d slots=%d chn=%d freq=%d interval_ms=%d stages=0x%x (the float canceller must be on)", n_streams,
+                       slots, chn, freq, interval_ms, stages);
+        return WMX_EINVAL;
+    }
+    return wmx::pipe_make(out, n_streams, slots, true, 0, chn, freq, interval_ms, agc_value, stages, nullptr, nullptr, true);
+}
+
 int wmx_pipe_slots(const wmx_pipe *h) { return h ? h->slots : WMX_EINVAL; }
 int wmx_pipe_datagram_bytes(const wmx_pipe *h) { return h ? h->row_bytes : WMX_EINVAL; }  // 172, or the package bytes of a PCM pipe
 long wmx_pipe_failed_steps(const wmx_pipe *h) { return h ? h->failed_steps : WMX_EINVAL; }
@@ -163,6 +189,9 @@ static int pipe_ingest(wmx_pipe *h, const uint8_t *d_in, long in_stride, void *s
 }
 static int pipe_chain_egress(wmx_pipe *h, const int16_t *d_far, const uint8_t *d_in, long in_stride, uint8_t *d_out, long out_stride,
                              void *stream) {
+    if (h->pcm && h->far_rows)  // far rows like near rows: stream s hears the package at d_far + s * far_samples
+        return wmx_chain_process_groups(h->chain, d_far, h->pkt10, h->far_samples, reinterpret_cast<const int16_t *>(d_in),
+                                        reinterpret_cast<int16_t *>(d_out), h->ppc, out_stride / 2, h->pkt10, nullptr, nullptr, nullptr, stream);
     if (h->pcm)  // rows are packages: ppc packets of pkt10 samples, stream rows in_stride / out_stride BYTES apart
         return wmx_chain_process(h->chain, d_far, h->pkt10, reinterpret_cast<const int16_t *>(d_in), reinterpret_cast<int16_t *>(d_out), h->ppc,
                                  out_stride / 2, h->pkt10, nullptr, nullptr, nullptr, stream);
@@ -240,7 +269,9 @@ int wmx::pipe_submit(wmx_pipe *h, const int16_t *d_far, int *slot, void *stream,
     const int16_t *far = d_far ? d_far : (far_of ? far_of->slot[(size_t)k % far_of->slot.size()].d_far : s.d_far);
     auto uploads = [&]() -> int {
         WMX_HIP(hipMemcpyAsync(s.d_in, s.h_in, bytes, hipMemcpyHostToDevice, h->s_in));
-        if (!d_far && !far_of) WMX_HIP(hipMemcpyAsync(s.d_far, s.h_far, (size_t)h->far_samples * sizeof(int16_t), hipMemcpyHostToDevice, h->s_in));
+        if (!d_far && !far_of)
+            WMX_HIP(hipMemcpyAsync(s.d_far, s.h_far, (size_t)h->far_samples * sizeof(int16_t) * (h->far_rows ? (size_t)h->n_streams : 1),
+                                   hipMemcpyHostToDevice, h->s_in));
         WMX_HIP(hipEventRecord(s.ev_in, h->s_in));
         WMX_HIP(hipStreamWaitEvent(main, s.ev_in, 0));
         return 0;

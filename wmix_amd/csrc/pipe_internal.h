@@ -12,6 +12,7 @@ struct wmx_pipe {
     int device;  // first member of every handle (wmx_handle_device)
     int n_streams, slots;
     bool pcm;          // rows are PCM packages (wmx_pipe_create_pcm), not RTP datagrams
+    bool far_rows;     // every stream hears a far-end of its own (wmx_pipe_create_pcm_calls): far rows like near rows, one cohort per stream
     int row_bytes;     // bytes of one stream's row in a slot: 172, or WMIX_PKG_SIZE
     int far_samples;   // int16 elements of the far-end of one step
     int pkt10, ppc;    // int16 elements of one 10 ms packet, packets per step
@@ -39,7 +40,7 @@ struct wmx_pipe {
 namespace wmx {
 // rt.hip -> pipe.hip.  pipe_make with `s_in` / `s_out` given makes a sub-batch of a wmx_rt on the rt's copy streams.
 int pipe_make(wmx_pipe **out, int n_streams, int slots, bool pcm, int law, int chn, int freq, int interval_ms, int agc_value, unsigned stages,
-              hipStream_t s_in, hipStream_t s_out);
+              hipStream_t s_in, hipStream_t s_out, bool far_rows = false);
 // wmx_pipe_submit with two extras for a tick made of several sub-batches: `flush_for` (may be NULL) = the pipe whose pending download
 // this submit queues behind ITS noise suppressor (the previous sub-batch of the same tick; h's own pending one otherwise);
 // `d_far_shared` as d_far, but when `upload_far` is false and d_far is NULL nothing is uploaded and far_of's slot copy is used

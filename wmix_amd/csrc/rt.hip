@@ -13,7 +13,7 @@ struct wmx_rt {
     int device;  // first member of every handle (wmx_handle_device)
     long n_streams;
     int sub, slots;
-    bool pcm;
+    bool pcm, far_rows;
     std::vector<wmx_pipe *> pipe;
     hipStream_t s_in, s_out;
     int next;  // the slot of the next tick (every sub-batch rotates in lockstep, also past a failed one)
@@ -67,7 +67,7 @@ int wmx_rt_set_compute_streams(wmx_rt *h, int n) {
 }
 
 static int rt_make(wmx_rt **out, long n_streams, int sub_batch, int slots, bool pcm, int law, int chn, int freq, int interval_ms, int agc_value,
-                   unsigned stages) {
+                   unsigned stages, bool far_rows = false) {
     if (!out) return WMX_EINVAL;
     *out = nullptr;
     if (n_streams < 1 || sub_batch < 1 || slots < 1 || slots > 16 || (n_streams + sub_batch - 1) / sub_batch > 4096) {
@@ -83,6 +83,7 @@ static int rt_make(wmx_rt **out, long n_streams, int sub_batch, int slots, bool 
     h->sub = sub_batch;
     h->slots = slots;
     h->pcm = pcm;
+    h->far_rows = far_rows;
     h->next = 0;
     h->n_cs = 1;
     hipError_t e = hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking);
@@ -91,7 +92,7 @@ static int rt_make(wmx_rt **out, long n_streams, int sub_batch, int slots, bool 
     for (long lo = 0; rc == 0 && lo < n_streams; lo += sub_batch) {
         const int n = (int)(n_streams - lo < sub_batch ? n_streams - lo : sub_batch);
         wmx_pipe *p = nullptr;
-        rc = wmx::pipe_make(&p, n, slots, pcm, law, chn, freq, interval_ms, agc_value, stages, h->s_in, h->s_out);
+        rc = wmx::pipe_make(&p, n, slots, pcm, law, chn, freq, interval_ms, agc_value, stages, h->s_in, h->s_out, far_rows);
         if (rc == 0) h->pipe.push_back(p);
     }
     if (rc != 0) {
@@ -112,6 +113,17 @@ int wmx_rt_create_pcm(wmx_rt **out, long n_streams, int sub_batch, int slots, in
         return WMX_EINVAL;
     }
     return rt_make(out, n_streams, sub_batch, slots, true, 0, chn, freq, interval_ms, agc_value, stages);
+}
+
+// calls: every stream its own far-end (wmx_pipe_create_pcm_calls); the far rows of sub-batch b: wmx_pipe_far(wmx_rt_pipe(h, b), slot)
+int wmx_rt_create_pcm_calls(wmx_rt **out, long n_streams, int sub_batch, int slots, int chn, int freq, int interval_ms, int agc_value, unsigned stages) {
+    if ((chn != 1 && chn != 2) || freq < 8000 || freq % 100 || interval_ms < 10 || interval_ms % 10 || interval_ms > 100 || !(stages & WMX_CHAIN_AEC) ||
+        (stages & WMX_CHAIN_AECM)) {
+        if (out) *out = nullptr;
+        wmx::set_error("wmx_rt_create_pcm_calls: chn=%d freq=%d interval_ms=%d stages=0x%x (the float canceller must be on)", chn, freq, interval_ms, stages);
+        return WMX_EINVAL;
+    }
+    return rt_make(out, n_streams, sub_batch, slots, true, 0, chn, freq, interval_ms, agc_value, stages, true);
 }
 
 int wmx_rt_create_rtp(wmx_rt **out, long n_streams, int sub_batch, int slots, int law, int agc_value, unsigned stages) {
@@ -153,16 +165,21 @@ struct SubmitCtx {
     wmx_pipe *prev;
     int k;
     bool lost;
+    long lo;  // first stream of the sub-batch at hand
 };
 static int submit_one(wmx_rt *h, size_t b, void *stream, void *vctx) {
     SubmitCtx *c = static_cast<SubmitCtx *>(vctx);
     if (c->lost) return 0;
     wmx_pipe *p = h->pipe[b];
     p->next = c->k;
-    // sub-batch 0 uploads the tick's far-end (unless it is on the device already), the others use its copy
-    const int rc = wmx::pipe_submit(p, c->d_far, nullptr, stream, c->prev ? c->prev : p, (c->d_far || b == 0) ? nullptr : h->pipe[0]);
+    // sub-batch 0 uploads the tick's far-end (unless it is on the device already), the others use its copy; with a far-end per stream
+    // every sub-batch has (and uploads) its own far rows, or finds them at its streams' offset of d_far
+    const int16_t *far_b = c->d_far;
+    if (h->far_rows && far_b) far_b += (size_t)c->lo * (size_t)p->far_samples;
+    c->lo += p->n_streams;
+    const int rc = wmx::pipe_submit(p, far_b, nullptr, stream, c->prev ? c->prev : p, (c->d_far || b == 0 || h->far_rows) ? nullptr : h->pipe[0]);
     if (rc != 0) {
-        if (b == 0 && !c->d_far) c->lost = true;  // nobody has the far-end: the tick is lost as a whole
+        if (b == 0 && !c->d_far && !h->far_rows) c->lost = true;  // nobody has the far-end: the tick is lost as a whole
         return rc;  // this sub-batch has lost its step; `prev` keeps its pending download for the next one that runs
     }
     c->prev = p;
@@ -174,7 +191,7 @@ int wmx_rt_submit(wmx_rt *h, const int16_t *d_far, int *slot, void *stream) {
     if (!h) return WMX_EINVAL;
     const int k = h->next;
     h->next = (k + 1) % h->slots;  // a tick takes its slot whatever becomes of its sub-batches
-    SubmitCtx c{d_far, nullptr, k, false};
+    SubmitCtx c{d_far, nullptr, k, false, 0};
     const int rc = rt_launches(h, wmx::as_stream(stream), submit_one, &c);
     if (slot) *slot = k;
     return rc;
@@ -230,8 +247,9 @@ static int resident_one(wmx_rt *h, size_t b, void *stream, void *vctx) {
     wmx_pipe *p = h->pipe[b];
     uint8_t *in = c->d_rows + (size_t)c->lo * (size_t)c->stride;
     uint8_t *o = h->pcm ? in : c->d_out + (size_t)c->lo * (size_t)c->out_stride;
+    const int16_t *far_b = h->far_rows ? c->d_far + (size_t)c->lo * (size_t)p->far_samples : c->d_far;
     c->lo += p->n_streams;
-    return wmx_pipe_step_resident(p, in, c->stride, c->d_far, o, h->pcm ? c->stride : c->out_stride, stream);
+    return wmx_pipe_step_resident(p, in, c->stride, far_b, o, h->pcm ? c->stride : c->out_stride, stream);
 }
 
 int wmx_rt_step_resident(wmx_rt *h, uint8_t *d_rows, long stride, const int16_t *d_far, uint8_t *d_out, long out_stride, void *stream) {

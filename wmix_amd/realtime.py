@@ -24,12 +24,17 @@ class RtBatch:
     172-byte RTP/PCMA datagrams, 8 kHz mono, 20 ms)."""
 
     def __init__(self, n_streams, dev, sub_batch=65536, slots=2, kind="pcm", chn=1, freq=16000, interval_ms=20, agc_value=5,
-                 stages=NS | AEC | AGC | VAD, compute_streams=1):
-        self.n, self.dev, self.kind, self.slots = int(n_streams), dev, kind, slots
+                 stages=NS | AEC | AGC | VAD, compute_streams=1, far_rows=False):
+        """far_rows: every stream hears a far-end of its own (wmx_rt_create_pcm_calls: aec_process2's far-end is per handle) -- the far-end
+        then comes in rows like the near-end: h_far_rows[b][slot] is [batch_n[b], package], a device far is [S, package]."""
+        self.n, self.dev, self.kind, self.slots, self.far_rows = int(n_streams), dev, kind, slots, bool(far_rows)
         self._h = C.c_void_p()
         L = lib()
         if kind == "pcm":
-            check(L.wmx_rt_create_pcm(C.byref(self._h), self.n, sub_batch, slots, chn, freq, interval_ms, agc_value, stages), "wmx_rt_create_pcm")
+            if far_rows:
+                check(L.wmx_rt_create_pcm_calls(C.byref(self._h), self.n, sub_batch, slots, chn, freq, interval_ms, agc_value, stages), "wmx_rt_create_pcm_calls")
+            else:
+                check(L.wmx_rt_create_pcm(C.byref(self._h), self.n, sub_batch, slots, chn, freq, interval_ms, agc_value, stages), "wmx_rt_create_pcm")
             self.pkt10, self.ppc = freq // 100 * chn, interval_ms // 10
             self.row, self.row_dtype, self.far_shape = self.pkt10 * self.ppc, np.int16, (self.ppc, self.pkt10)
             self.row_bytes = self.row * 2
@@ -45,7 +50,9 @@ class RtBatch:
         # numpy views of the library's pinned rows: h_in[b][slot] is [batch_n[b], row]
         self.h_in = [[_host_rows(L.wmx_pipe_in(p, s), (n, self.row), self.row_dtype) for s in range(slots)] for p, n in zip(self.pipes, self.batch_n)]
         self.h_out = [[_host_rows(L.wmx_pipe_out(p, s), (n, self.row), self.row_dtype) for s in range(slots)] for p, n in zip(self.pipes, self.batch_n)]
-        self.h_far = [_host_rows(L.wmx_rt_far(self._h, s), self.far_shape, np.int16) for s in range(slots)]
+        self.h_far = [_host_rows(L.wmx_rt_far(self._h, s), self.far_shape, np.int16) for s in range(slots)] if not far_rows else None
+        self.h_far_rows = ([[_host_rows(L.wmx_pipe_far(p, s), (n, self.row), np.int16) for s in range(slots)] for p, n in zip(self.pipes, self.batch_n)]
+                           if far_rows else None)
 
     def locate(self, stream):
         """(sub-batch, row) of a stream"""
@@ -57,6 +64,11 @@ class RtBatch:
         for b in range(self.B):
             self.h_in[b][slot][:] = rows[self.lo[b]:self.lo[b + 1]]
 
+    def fill_far(self, slot, rows):
+        """far_rows: [S, package] host array -> the slot's pinned far rows of every sub-batch"""
+        for b in range(self.B):
+            self.h_far_rows[b][slot][:] = rows[self.lo[b]:self.lo[b + 1]]
+
     def gather(self, slot, streams=None):
         if streams is None:
             return np.concatenate([self.h_out[b][slot] for b in range(self.B)])
@@ -65,7 +77,8 @@ class RtBatch:
     def _far(self, far):
         if far is None:
             return None
-        assert far.is_cuda and far.dtype == torch.int16 and far.is_contiguous() and far.numel() == self.ppc * self.pkt10
+        assert far.is_cuda and far.dtype == torch.int16 and far.is_contiguous()
+        assert far.numel() == self.ppc * self.pkt10 * (self.n if self.far_rows else 1)
         return far.data_ptr()
 
     def submit(self, far=None):
