@@ -1398,7 +1398,7 @@ def paced_replay(kind, far, rows, pattern_row, n_ticks, interval_ms=20):
 
 
 def run_paced(dev, kind, S, tick_ms, ticks, sub=32768, slots=4, prime=150, resident=False, keep=24, interval_ms=None, parity=True, compute_streams=1,
-              phases=1):
+              phases=1, calls=False):
     """One paced run: S concurrent streams, every stream's package due every tick_ms.  phases = 1: all S at the same instant, one tick
     through wmx_rt_tick (H2D, NS -> AEC -> AGC -> VAD, D2H; sub-batches overlapped) or, resident, wmx_rt_step_resident + a
     synchronisation.  phases = P > 1: P groups of S / P streams released tick_ms / P apart (wmx_rt_submit at the release, completion
@@ -1411,22 +1411,25 @@ def run_paced(dev, kind, S, tick_ms, ticks, sub=32768, slots=4, prime=150, resid
     interval_ms = interval_ms or int(tick_ms)
     assert form == "pcm" or interval_ms == 20, "the RTP edge is 20 ms datagrams"
     t_start = time.perf_counter()
-    far, rows = paced_pattern(kind, slots, interval_ms)
+    # calls: every stream hears a far-end of its own (wmx_rt_create_pcm_calls; aec_process2's far-end is per handle): 16 distinct far signals
+    far, rows = paced_pattern(kind, slots, interval_ms, n_far=16 if calls else 1)
     n_pattern = rows.shape[1]
     P = int(phases)
     bounds = [S * g // P for g in range(P + 1)]  # group g = streams [bounds[g], bounds[g + 1])
     rts = [RtBatch(bounds[g + 1] - bounds[g], dev, sub_batch=sub, slots=slots, kind=form, chn=1, freq=freq, interval_ms=interval_ms,
-                   compute_streams=compute_streams) for g in range(P)]
+                   compute_streams=compute_streams, far_rows=calls) for g in range(P)]
     rt0 = rts[0]
     pat_of = np.arange(S) % n_pattern
     sample = sorted(set(int(i) for i in np.linspace(0, S - 1, 16)))
     sample_of = [[s - bounds[g] for s in sample if bounds[g] <= s < bounds[g + 1]] for g in range(P)]
     col_of = [[c for c, s in enumerate(sample) if bounds[g] <= s < bounds[g + 1]] for g in range(P)]
     if resident:
-        dfar = torch.from_numpy(far.reshape(slots, rt0.ppc, rt0.pkt10).copy()).to(dev)
-        src, work, outb, evs = [], [], [], []
+        dfar = None if calls else torch.from_numpy(far.reshape(slots, rt0.ppc, rt0.pkt10).copy()).to(dev)
+        src, work, outb, evs, dfar_g = [], [], [], [], []
         for g in range(P):
             idx = torch.from_numpy(pat_of[bounds[g]:bounds[g + 1]]).to(dev)
+            if calls:  # [slots][n_g, package]: stream s hears far signal (s % n_pattern) % 16
+                dfar_g.append([torch.from_numpy(far[j]).to(dev)[idx % far.shape[1]].contiguous() for j in range(slots)])
             src.append([torch.from_numpy(rows[j]).to(dev)[idx].contiguous() for j in range(slots)])  # [n_g, row] per slot
             work.append(src[g][0].clone())
             outb.append(torch.empty_like(work[g]) if form == "rtp" else None)
@@ -1434,7 +1437,10 @@ def run_paced(dev, kind, S, tick_ms, ticks, sub=32768, slots=4, prime=150, resid
     else:
         for g, rt in enumerate(rts):
             for j in range(slots):
-                rt.h_far[j][:] = far[j].reshape(rt.far_shape)
+                if calls:
+                    rt.fill_far(j, far[j][pat_of[bounds[g]:bounds[g + 1]] % far.shape[1]])
+                else:
+                    rt.h_far[j][:] = far[j].reshape(rt.far_shape)
                 rt.fill(j, rows[j][pat_of[bounds[g]:bounds[g + 1]]])
     kept = np.zeros((keep, len(sample), rt0.row), rt0.row_dtype)
     t_of = [0] * P      # ticks group g has been through
@@ -1443,7 +1449,7 @@ def run_paced(dev, kind, S, tick_ms, ticks, sub=32768, slots=4, prime=150, resid
     def submit(g):
         j = t_of[g] % slots
         if resident:
-            rts[g].step_resident(work[g], dfar[j], outb[g])
+            rts[g].step_resident(work[g], dfar_g[g][j] if calls else dfar[j], outb[g])
             evs[g].record()
         else:
             assert rts[g].submit(None) == j
@@ -1503,7 +1509,7 @@ def run_paced(dev, kind, S, tick_ms, ticks, sub=32768, slots=4, prime=150, resid
     for rt in rts:
         rt.close()
     out_d = latency_summary(lat, lag, tick_ms, clk)
-    out_d.update({"kind": kind, "streams": S, "phases": P, "release": ("all %d streams at the same instant" % S) if P == 1 else
+    out_d.update({"kind": kind, "streams": S, "far_end_per_stream": bool(calls), "phases": P, "release": ("all %d streams at the same instant" % S) if P == 1 else
                   ("%d groups of %d streams, %.3g ms apart" % (P, S // P, tick_ms / P)),
                   "sub_batch": sub, "sub_batches": n_sub, "slots": slots, "primed_ticks": prime, "interval_ms": interval_ms,
                   "compute_streams": compute_streams,
@@ -1530,7 +1536,7 @@ def paced_main(args, dev):
     """bench.py --paced: one run, or (--paced-search S1,S2,...) the largest S without a miss."""
     from wmix_amd import _lib
     common = dict(sub=args.sub_batch, slots=args.slots, prime=args.paced_prime, resident=args.resident, interval_ms=args.paced_interval_ms or None,
-                  compute_streams=args.compute_streams, phases=args.phases)
+                  compute_streams=args.compute_streams, phases=args.phases, calls=args.calls)
     if args.paced_search:
         runs, s_max = [], None
         for S in sorted(int(x) for x in args.paced_search.split(",")):
@@ -1785,6 +1791,9 @@ def main():
     ap.add_argument("--sub-batch", type=int, default=32768, help="--paced: streams per sub-batch (one wmx_pipe each; uploads and downloads of "
                                                                 "neighbouring sub-batches run beside the compute)")
     ap.add_argument("--compute-streams", type=int, default=1, help="--paced: wmx_rt_set_compute_streams (sub-batch b on stream b %% n)")
+    ap.add_argument("--calls", action="store_true",
+                    help="--paced: every stream hears a far-end of its own (wmx_rt_create_pcm_calls: aec_process2's far-end is per handle; the "
+                         "far-end of a call is the other party) -- far rows beside the near rows, 122 KB of far-end history per stream")
     ap.add_argument("--phases", type=int, default=1,
                     help="--paced: release the streams in P groups tick / P apart instead of all at the same instant (every group still has "
                          "the whole tick as its period and tick - 2 ms as its budget)")

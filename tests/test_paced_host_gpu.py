@@ -63,8 +63,8 @@ def test_bench_paced_line(cuda):
     assert r.returncode == 0, r.stderr[-2000:]
     rt = json.loads(r.stdout.strip().splitlines()[-1])["realtime"]
     assert rt["parity_checked"]["max_lsb"] == 0 and rt["bytes_over_pcie_per_tick"] == 0 and rt["misses"] <= 3, rt
-    # staggered release: four groups 5 ms apart, from host memory and resident
-    for extra in ([], ["--resident"]):
+    # staggered release: four groups 5 ms apart, from host memory and resident; and with a far-end per stream
+    for extra in ([], ["--resident"], ["--calls"], ["--calls", "--resident"]):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--paced", "--phases", "4", "--streams", "6000", "--sub-batch", "1000", "--ticks", "60",
                             "--paced-prime", "70"] + extra, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
