@@ -43,7 +43,9 @@
 
 static const char *g_dir;
 static int g_beats;
-static volatile int g_go = 0, g_stop = 0;
+static int g_go = 0, g_stop = 0; /* read and written with the __atomic builtins (GO / STOP below) */
+#define GO() __atomic_load_n(&g_go, __ATOMIC_ACQUIRE)
+#define STOP() __atomic_load_n(&g_stop, __ATOMIC_ACQUIRE)
 
 static double now_us(void) {
     struct timespec t;
@@ -105,7 +107,7 @@ static void *loader(void *vp) {
     w.reduceMode = 1;
     WMix_Point head = {.U8 = NULL};
     uint32_t tick = 0;
-    while (!g_go) {
+    while (!GO()) {
     }
     for (int b = g_beats / 2; b < g_beats; b++) { /* phase 2 only */
         WMix_Point sp = {.S16 = src + (size_t)b * CHUNK};
@@ -129,7 +131,7 @@ static void *turner(void *unused) {
     int16_t *x = read_file("agc_in.i16", (size_t)g_beats * BEAT * 2);
     void *agc = agc_init(1, 16000, 20, 5, NULL);
     if (!agc) exit(3);
-    while (!g_go) {
+    while (!GO()) {
     }
     for (int b = g_beats / 2; b < g_beats; b++) {
         agc_addition(agc, (uint8_t)(3 + b % 5));
@@ -143,7 +145,7 @@ static void *turner(void *unused) {
 }
 
 /* ---- the batch: wmx_chain_process back to back on a BLOCKING stream of the same process */
-static long g_batch_steps = 0;
+static long g_batch_steps = 0; /* written by the batch thread, read after it was joined */
 static int g_batch_streams;
 static void *batch(void *unused) {
     (void)unused;
@@ -158,9 +160,9 @@ static void *batch(void *unused) {
         fprintf(stderr, "host_legacy_threads: batch setup: %s\n", wmx_last_error());
         exit(3);
     }
-    while (!g_go) {
+    while (!GO()) {
     }
-    while (!g_stop) { /* a few steps queued ahead, like any streaming host */
+    while (!STOP()) { /* a few steps queued ahead, like any streaming host */
         for (int i = 0; i < 4; i++)
             if (wmx_chain_process(ch, d_far, 160, d_pcm, d_pcm, 2, BEAT, 160, NULL, NULL, NULL, s) != 0) {
                 fprintf(stderr, "host_legacy_threads: batch step: %s\n", wmx_last_error());
@@ -206,7 +208,7 @@ int main(int argc, char **argv) {
         if (b == g_beats / 2) {
             struct timespec nap = {1, 0}; /* the company's handles and device buffers are made by now */
             nanosleep(&nap, NULL);
-            g_go = 1;
+            __atomic_store_n(&g_go, 1, __ATOMIC_RELEASE);
             nap.tv_sec = 0, nap.tv_nsec = 50000000; /* ... and at work */
             nanosleep(&nap, NULL);
         }
@@ -220,7 +222,7 @@ int main(int argc, char **argv) {
         struct timespec gap = {0, 300000}; /* the daemon's heartbeat is paced; a third of a millisecond keeps the test short */
         nanosleep(&gap, NULL);
     }
-    g_stop = 1;
+    __atomic_store_n(&g_stop, 1, __ATOMIC_RELEASE);
     for (int k = 0; k < N_LOAD; k++) pthread_join(tl[k], NULL);
     pthread_join(tt, NULL);
     pthread_join(tb, NULL);
