@@ -26,7 +26,97 @@ pytestmark = pytest.mark.gpu
 VARIANT = os.path.join(ROOT, "tools_dev", "build", "lib_faults.so")
 
 
+def _child_rt():
+    """the paced tick (wmx_rt_submit over three sub-batches) under the same faults: a failed tick takes its slot, loses the steps of the
+    sub-batches it had reached, leaves every pipe's bookkeeping consistent -- and after the host has restored the streams from its
+    checkpoint, the following ticks are those of an undisturbed run"""
+    import torch
+    from wmix_amd import _lib, synth
+    from wmix_amd.lifetime import Lifetime
+    from wmix_amd.realtime import RtBatch
+    L = _lib.lib()
+    assert "WMX_FAULT_INJECTION" in _lib.build_info()
+    L.wmx_debug_fail_nth_hip_call.argtypes = [C.c_long]
+    L.wmx_debug_hip_calls.restype = C.c_long
+    dev = torch.device("cuda:0")
+    S, n, slots = 24, 300, 3
+    far = synth.far_end(9720, n, 160).reshape(n, 1, 160)
+    near = synth.near_end(9721, S, n, 160, far=far.reshape(-1)).reshape(S, n, 160).transpose(1, 0, 2)
+    make = lambda: RtBatch(S, dev, sub_batch=10, slots=slots, kind="pcm", chn=1, freq=16000, interval_ms=10)  # noqa: E731
+
+    class Borrowed(Lifetime):
+        _mod = "chain"
+
+        def __init__(self, h, n_streams):
+            self._h, self.n_streams = h, n_streams
+
+    u = make()
+    want = np.zeros((n, S, 160), np.int16)
+    for k in range(n):
+        u.fill(k % slots, near[k])
+        u.h_far[k % slots][:] = far[k]
+        assert u.tick(None) == k % slots
+        want[k] = u.gather(k % slots)
+    u.close()
+
+    f = make()
+    chains = [Borrowed(L.wmx_pipe_chain(p), nb) for p, nb in zip(f.pipes, f.batch_n)]
+    nxt = [0]
+
+    def tick(k, arm=0):
+        slot = nxt[0]
+        nxt[0] = (slot + 1) % slots  # a tick takes its slot whatever becomes of it
+        f.fill(slot, near[k])
+        f.h_far[slot][:] = far[k]
+        got = C.c_int(-1)
+        if arm:
+            L.wmx_debug_fail_nth_hip_call(arm)
+        rc = L.wmx_rt_submit(f._h, None, C.byref(got), None)
+        calls = L.wmx_debug_hip_calls()
+        L.wmx_debug_fail_nth_hip_call(0)
+        if got.value == -1:  # the call failed in front of everything (its device scope): not even the slot was taken
+            assert rc != 0
+            nxt[0] = slot
+        else:
+            assert got.value == slot
+        rw = L.wmx_rt_wait(f._h)
+        return rc, rw, slot, calls
+    k = 0
+    for _ in range(2 * slots):
+        rc, rw, slot, _ = tick(k)
+        assert rc == 0 and rw == 0 and np.array_equal(f.gather(slot), want[k])
+        k += 1
+    report = {"kind": "rt", "faults": 0, "lost_steps": 0}
+    i = 1
+    while True:
+        assert k + 3 < n
+        snap = [([c.export_stream(s) for s in range(c.n_streams)], c.export_cohort(0)) for c in chains]
+        lost0 = f.failed_steps()
+        rc, rw, slot, calls = tick(k, arm=i)
+        if rc == 0:
+            assert calls < i and np.array_equal(f.gather(slot), want[k])
+            k += 1
+            break
+        assert rc <= -11000 and rw == 0, (i, rc, rw)
+        report["faults"] += 1
+        report["lost_steps"] += f.failed_steps() - lost0
+        for c, (streams, cohort) in zip(chains, snap):  # the checkpoint: whatever each sub-batch had reached is undone
+            c.import_cohort(0, cohort)
+            for s in range(c.n_streams):
+                c.import_stream(s, streams[s], cohort=0)
+        for kk in (k, k + 1, k + 2):
+            rc, rw, slot, _ = tick(kk)
+            assert rc == 0 and rw == 0, (i, kk, L.wmx_last_error())
+            assert np.array_equal(f.gather(slot), want[kk]), ("tick %d after fault %d" % (kk, i))
+        k += 3
+        i += 3 if i > 12 else 1  # every call of the first sub-batch's uploads and launches, then every third
+    f.close()
+    print(json.dumps(report))
+
+
 def _child(kind):
+    if kind == "rt":
+        return _child_rt()
     import torch
     from wmix_amd import _lib, synth
     from wmix_amd.lifetime import Lifetime
@@ -148,7 +238,7 @@ def _child(kind):
     print(json.dumps(report))
 
 
-@pytest.mark.parametrize("kind", ["pcm", "rtp"])
+@pytest.mark.parametrize("kind", ["pcm", "rtp", "rt"])
 def test_every_fallible_call_of_a_submit(cuda, kind):
     # __graft_entry__.build() makes it; `make` brings it up to date when a source has changed since (nothing to do otherwise, a minute of
     # hipcc if the tree was not built that way at all)
@@ -158,6 +248,9 @@ def test_every_fallible_call_of_a_submit(cuda, kind):
     r = subprocess.run([sys.executable, os.path.abspath(__file__), kind], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     rep = json.loads(r.stdout.strip().splitlines()[-1])
+    if kind == "rt":
+        assert rep["faults"] >= 20 and rep["lost_steps"] >= 10, rep
+        return
     assert rep["before_first_launch"] >= 3 and rep["wait_faults"] >= 2, rep
     if kind == "pcm":
         assert rep["lost_steps"] >= 10 and rep["faults"] == rep["before_first_launch"] + rep["lost_steps"], rep
